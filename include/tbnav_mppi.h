@@ -1,0 +1,141 @@
+/* tbnav_mppi.h — C-ABI of the MI355X MPPI rollout path.
+ *
+ * Drop-in boundary for controller::MPPI (reference controller/include/controller/mppi.hpp:119-185,
+ * controller/src/controller/mppi.cpp:28-184).  Plain pointers and sizes only; the handle owns all
+ * device memory; one handle per controller object; not thread-safe (the reference is not either:
+ * it draws from a process-global RNG, rigid2d/src/rigid2d/utilities.cpp:12-24).
+ *
+ * State vector order is (x, y, theta) as in mppi.cpp:75-76 — NOT rigid2d::Pose's (theta, x, y).
+ *
+ * Device data layout (all fp64):
+ *   duL, duR : [T][K]  time-major, rollout index fastest (lanes = rollouts, coalesced)
+ *              — the transpose of the reference's column-major duL/duR(T,K), mppi.hpp:182-183
+ *   J        : [T][K]  cost-to-go, same layout                           (mppi.hpp:181)
+ *   u        : [2][T]  warm-start controls, resident on the device       (mppi.hpp:180)
+ *   records  : [T][R][TBNAV_MPPI_REC]  per-time-step soft-min partial sums (see below)
+ *
+ * Sharded soft-min (one shard = one GPU, or one K-slice inside a GPU).  For time step i and shard
+ * g over its rollouts k:
+ *   m = min_k J(i,k);  e_k = exp(((J(i,k) - m) * -1.0) / lambda)
+ *   rec = { m, A=sum e_k, B=sum e_k*duL(i,k), C=sum e_k*duR(i,k), D=sum duL(i,k), E=sum duR(i,k),
+ *           n=count, 0 }
+ * Combining R records reproduces mppi.cpp:112-126 including its "+1e-8" weight floor:
+ *   M = min m_r;  s_r = exp(((m_r - M) * -1.0) / lambda)
+ *   W  = sum s_r*A_r + 1e-8 * sum n_r
+ *   uL(i) += (sum s_r*B_r + 1e-8 * sum D_r) / W     (then clamp to +-max_wheel_vel, mppi.cpp:124-125)
+ */
+#ifndef TBNAV_MPPI_H
+#define TBNAV_MPPI_H
+
+#include <stdint.h>
+#include "tbnav_status.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TBNAV_MPPI_REC 8 /* doubles per partial record: m, A, B, C, D, E, n, pad */
+
+/* Constructor arguments of controller::CartModel (mppi.hpp:33), controller::LossFunc
+ * (mppi.hpp:63-65) and controller::MPPI (mppi.hpp:133-141), flattened. */
+typedef struct tbnav_mppi_params {
+  double wheel_radius;   /* CartModel::wheel_radius                      */
+  double wheel_base;     /* CartModel::wheel_base                        */
+  double lambda;         /* temperature                                  */
+  double max_wheel_vel;  /* clamp on the updated controls                */
+  double ul_var;         /* sampling variance, left wheel                */
+  double ur_var;         /* sampling variance, right wheel               */
+  double horizon;        /* seconds; steps = (int)(horizon / dt), mppi.cpp:47 */
+  double dt;             /* RK4 step                                     */
+  double Q[3];           /* diag state cost (x, y, theta)                */
+  double R[2];           /* diag control cost (uL, uR)                   */
+  double P1[3];          /* diag terminal cost                           */
+  int32_t rollouts;      /* K handled by THIS handle (a shard's slice when sharded) */
+  int32_t device;        /* HIP device ordinal, -1 = current device      */
+} tbnav_mppi_params;
+
+typedef struct tbnav_mppi tbnav_mppi; /* opaque */
+
+/* ---- lifetime -------------------------------------------------------------------------------- */
+
+/* MPPI::MPPI + initController (mppi.cpp:28-51,157-170): u = 0, uinit = 0, xd = 0, J/duL/duR = 0. */
+int tbnav_mppi_create(const tbnav_mppi_params* params, tbnav_mppi** out);
+void tbnav_mppi_destroy(tbnav_mppi* h);
+
+int tbnav_mppi_steps(const tbnav_mppi* h);    /* T = (int)(horizon / dt)   */
+int tbnav_mppi_rollouts(const tbnav_mppi* h); /* K of this handle           */
+
+/* ---- controller state ------------------------------------------------------------------------ */
+
+/* MPPI::setInitialControls (mppi.cpp:54-61): uinit = (uL,uR) and every column of u = uinit. */
+int tbnav_mppi_set_initial_controls(tbnav_mppi* h, double uL, double uR);
+/* MPPI::setWaypoint (mppi.cpp:64-69): xd = (x, y, theta). */
+int tbnav_mppi_set_waypoint(tbnav_mppi* h, double x, double y, double theta);
+/* Read / overwrite the warm-start control matrix u, host buffer of 2*T doubles laid out [2][T]. */
+int tbnav_mppi_get_controls(tbnav_mppi* h, double* u_host);
+int tbnav_mppi_set_controls(tbnav_mppi* h, const double* u_host);
+
+/* ---- one control tick: MPPI::newControls (mppi.cpp:72-140) ---------------------------------- */
+
+/* Noise supplied by the caller on the HOST in the reference's draw order
+ * (mppi.cpp:81-89,173-184): noise[(k*T + i)*2 + c], c=0 left, c=1 right, already scaled by
+ * sqrt(var).  Uploads, transposes on the device, runs the tick, returns u(:,0) before the shift. */
+int tbnav_mppi_new_controls(tbnav_mppi* h, const double x0[3], const double* noise_host,
+                            double u_out[2]);
+
+/* Noise already resident in HBM in the device layout (duL[T][K], duR[T][K]).  `stream` is a
+ * hipStream_t (NULL = default stream).  Synchronous: waits for the tick and returns u(:,0). */
+int tbnav_mppi_new_controls_dev(tbnav_mppi* h, const double x0[3], const double* d_duL,
+                                const double* d_duR, void* stream, double u_out[2]);
+
+/* Same tick, enqueue only (no host wait).  u(:,0) of the most recent tick is fetched with
+ * tbnav_mppi_last_controls, which synchronises `stream`. */
+int tbnav_mppi_enqueue_dev(tbnav_mppi* h, const double x0[3], const double* d_duL,
+                           const double* d_duR, void* stream);
+int tbnav_mppi_last_controls(tbnav_mppi* h, void* stream, double u_out[2]);
+
+/* Noise drawn ON the device (production mode; replaces MPPI::pertubations, mppi.cpp:173-184):
+ * Philox4x32-10 keyed by `seed`, counter = tick*K*T + k*T + i, one Box-Muller pair per (k,i) gives
+ * (duL, duR) scaled by sqrt(ul_var), sqrt(ur_var).  Fills the handle's own duL/duR buffers, which
+ * tbnav_mppi_*_dev accept when d_duL == d_duR == NULL. */
+int tbnav_mppi_sample_noise(tbnav_mppi* h, uint64_t seed, uint64_t tick, void* stream);
+/* Copy the handle's own noise buffers to the host ([T][K] each) — for statistical tests. */
+int tbnav_mppi_get_noise(tbnav_mppi* h, double* duL_host, double* duR_host);
+
+/* ---- sharded tick (multi-GPU: rollouts split across ranks; mppi.cpp:81-126 split in two) ----- */
+
+/* Number of K-slices this handle cuts its own rollouts into (records per time step it emits). */
+int tbnav_mppi_records_per_step(const tbnav_mppi* h);
+
+/* Rollouts + per-time-step partial records of THIS shard.  d_records_out is a device buffer of
+ * T * records_per_step * TBNAV_MPPI_REC doubles laid out [T][S][REC].  Enqueue only. */
+int tbnav_mppi_shard_partials(tbnav_mppi* h, const double x0[3], const double* d_duL,
+                              const double* d_duR, void* stream, double* d_records_out);
+
+/* Combine `n_shards` record sets (device buffer [n_shards][T][S][REC], e.g. the output of one
+ * all-gather), update u, clamp, emit u(:,0), shift.  Every rank runs this on the same input and so
+ * holds the same u afterwards.  Enqueue only; fetch with tbnav_mppi_last_controls. */
+int tbnav_mppi_shard_combine(tbnav_mppi* h, const double* d_records_all, int32_t n_shards,
+                             void* stream);
+
+/* ---- parity / debug hooks --------------------------------------------------------------------- */
+
+/* Cost-to-go J of the last tick BEFORE the per-step min subtraction, host buffer [T][K]
+ * (reference J(i,k) after cumSumCost, mppi.cpp:109). */
+int tbnav_mppi_get_cost_to_go(tbnav_mppi* h, double* J_host);
+
+/* ---- measurement hook -------------------------------------------------------------------------- */
+
+/* One tick with a hipEvent pair around each kernel, recorded on `stream` (the stream the kernels
+ * run on); waits, then returns the three durations in milliseconds:
+ *   ms[0] mppi_rollout_cost, ms[1] mppi_partials, ms[2] mppi_combine.
+ * Same launches and same state update as tbnav_mppi_enqueue_dev; bench.py averages it over the
+ * timed number of steps to price the dominant kernel against the HBM roofline. */
+#define TBNAV_MPPI_NKERNELS 3
+int tbnav_mppi_profile_tick(tbnav_mppi* h, const double x0[3], const double* d_duL,
+                            const double* d_duR, void* stream, float ms[TBNAV_MPPI_NKERNELS]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TBNAV_MPPI_H */

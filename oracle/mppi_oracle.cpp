@@ -1,0 +1,261 @@
+// mppi_oracle.cpp — CPU restatement of the reference MPPI tick.  TEST INFRASTRUCTURE ONLY.
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the
+// product path (ros-turtlebot-navigation_amd/) never links, imports or calls it.
+//
+// PARITY UNPINNED: controller/src/controller/{mppi,rk4}.cpp need Eigen 3.3, which this image does
+// not have, so the reference itself cannot be compiled here, and the reference ships no test, golden
+// vector or fixture for this path.  This file follows the reference line by
+// line, in IEEE double, with the evaluation order Eigen's expression templates produce for these
+// (tiny, coefficient-wise) expressions; the hand-checkable known answers of SURVEY.md's appendix
+// are asserted in tests/test_oracle_mppi.py.
+//
+// All paths below are relative to /root/reference/.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <random>
+#include <vector>
+
+namespace {
+
+struct Params {
+  double wheel_radius, wheel_base, lambda, max_wheel_vel, ul_var, ur_var, horizon, dt;
+  double Q[3], R[2], P1[3];
+  int32_t rollouts;
+  int32_t device;  // unused by the oracle; keeps the struct layout equal to tbnav_mppi_params
+};
+
+// controller/include/controller/mppi.hpp:41-48  CartModel::kinematicCart
+inline void kinematic_cart(const Params& p, const double x[3], const double u[2], double xdot[3]) {
+  xdot[0] = (p.wheel_radius / 2.0) * (u[0] + u[1]) * std::cos(x[2]);
+  xdot[1] = (p.wheel_radius / 2.0) * (u[0] + u[1]) * std::sin(x[2]);
+  xdot[2] = (p.wheel_radius / p.wheel_base) * (u[1] - u[0]);
+}
+
+// controller/src/controller/rk4.cpp:95-115  RK4::integrate(x_t, u_t)
+inline void rk4_integrate(const Params& p, double x[3], const double u[2]) {
+  const double step = p.dt;
+  double k1[3], k2[3], k3[3], k4[3], arg[3];
+  kinematic_cart(p, x, u, k1);
+  for (int c = 0; c < 3; ++c) arg[c] = x[c] + step * (0.5 * k1[c]);  // rk4.cpp:105
+  kinematic_cart(p, arg, u, k2);
+  for (int c = 0; c < 3; ++c) arg[c] = x[c] + step * (0.5 * k2[c]);  // rk4.cpp:108
+  kinematic_cart(p, arg, u, k3);
+  for (int c = 0; c < 3; ++c) arg[c] = x[c] + step * k3[c];          // rk4.cpp:111
+  kinematic_cart(p, arg, u, k4);
+  for (int c = 0; c < 3; ++c)                                        // rk4.cpp:114
+    x[c] = x[c] + (step / 6.0) * (((k1[c] + 2.0 * k2[c]) + 2.0 * k3[c]) + k4[c]);
+}
+
+// mppi.hpp:87-93  LossFunc::loss — (e^T Q e)(0) + (u^T R u)(0) with diagonal Q, R.  Eigen forms the
+// row vector e^T*Q first (its off-diagonal terms are exact zeros) and then the dot with e.
+inline double loss(const Params& p, const double x[3], const double xd[3], const double u[2]) {
+  const double e0 = x[0] - xd[0], e1 = x[1] - xd[1], e2 = x[2] - xd[2];
+  const double state = ((e0 * p.Q[0]) * e0 + (e1 * p.Q[1]) * e1) + (e2 * p.Q[2]) * e2;
+  const double ctrl = (u[0] * p.R[0]) * u[0] + (u[1] * p.R[1]) * u[1];
+  return state + ctrl;
+}
+
+// mppi.hpp:100-105  LossFunc::terminalLoss
+inline double terminal_loss(const Params& p, const double x[3], const double xd[3]) {
+  const double e0 = x[0] - xd[0], e1 = x[1] - xd[1], e2 = x[2] - xd[2];
+  return ((e0 * p.P1[0]) * e0 + (e1 * p.P1[1]) * e1) + (e2 * p.P1[2]) * e2;
+}
+
+// Sum in the order Eigen 3.3's linear-vectorised redux uses for a contiguous VectorXd with SSE2
+// packets (2 doubles, 2-way unrolled): four interleaved partial sums combined as
+// (s0+s2)+(s1+s3), then the scalar tail.  (Best effort: cannot be checked against Eigen here; the
+// difference from a sequential sum is O(1e-16) relative and far inside every tolerance we assert.)
+inline double eigen_like_sum(const double* v, int n) {
+  if (n < 4) {
+    double s = 0.0;
+    if (n >= 2) { s = v[0] + v[1]; for (int i = 2; i < n; ++i) s += v[i]; }
+    else if (n == 1) s = v[0];
+    return s;
+  }
+  double s0 = v[0], s1 = v[1], s2 = v[2], s3 = v[3];
+  const int n4 = (n / 4) * 4;
+  for (int i = 4; i < n4; i += 4) { s0 += v[i]; s1 += v[i + 1]; s2 += v[i + 2]; s3 += v[i + 3]; }
+  double a = s0 + s2, b = s1 + s3;
+  int i = n4;
+  if (n - n4 >= 2) { a += v[i]; b += v[i + 1]; i += 2; }
+  double s = a + b;
+  for (; i < n; ++i) s += v[i];
+  return s;
+}
+
+inline int steps_of(const Params& p) { return static_cast<int>(p.horizon / p.dt); }  // mppi.cpp:47
+
+}  // namespace
+
+extern "C" {
+
+// rigid2d/src/rigid2d/utilities.cpp:20-24 (and bmapping particle_filter.cpp:25-34): a FRESH
+// std::normal_distribution per draw on one std::mt19937_64, so the polar method's cached second
+// variate is thrown away every time.
+void orc_normal_stream(uint64_t seed, int64_t n, double mu, double sigma, double* out) {
+  std::mt19937_64 gen(seed);
+  for (int64_t i = 0; i < n; ++i) {
+    std::normal_distribution<double> dis(mu, sigma);
+    out[i] = dis(gen);
+  }
+}
+
+int orc_mppi_steps(const Params* p) { return steps_of(*p); }
+
+void orc_rk4_step(const Params* p, double x[3], const double u[2]) { rk4_integrate(*p, x, u); }
+double orc_loss(const Params* p, const double x[3], const double xd[3], const double u[2]) {
+  return loss(*p, x, xd, u);
+}
+double orc_terminal_loss(const Params* p, const double x[3], const double xd[3]) {
+  return terminal_loss(*p, x, xd);
+}
+
+// mppi.cpp:115-125 for ONE time step: J row (K values, already cost-to-go), perturbation rows.
+// Returns the weights in w_out (nullable) and the two weighted sums.
+void orc_softmin_step(double lambda, int K, const double* Jrow, const double* dul, const double* dur,
+                      double* w_out, double* sum_l, double* sum_r) {
+  std::vector<double> w(K);
+  double mn = Jrow[0];
+  for (int k = 1; k < K; ++k) mn = std::min(mn, Jrow[k]);              // minCoeff, mppi.cpp:115
+  for (int k = 0; k < K; ++k) w[k] = std::exp(((Jrow[k] - mn) * -1.0) / lambda) + 1e-8;  // :117
+  const double inv = 1.0 / eigen_like_sum(w.data(), K);                 // :118
+  for (int k = 0; k < K; ++k) w[k] = w[k] * inv;
+  double sl = 0.0, sr = 0.0;                                            // :120-121 (strided row: scalar dot)
+  for (int k = 0; k < K; ++k) { sl += w[k] * dul[k]; sr += w[k] * dur[k]; }
+  if (w_out) std::memcpy(w_out, w.data(), sizeof(double) * K);
+  *sum_l = sl;
+  *sum_r = sr;
+}
+
+// MPPI::newControls, mppi.cpp:72-140.
+//   u        [2][T]  in: warm start; out: after update, clamp and shift
+//   noise    [K][T][2] reference draw order (mppi.cpp:81-89,173-184), already scaled by sqrt(var)
+//   loss_out [T][K] (nullable)   loss_mat
+//   J_out    [T][K] (nullable)   cost-to-go after cumSumCost, BEFORE the per-step min subtraction
+//   u_upd    [2][T] (nullable)   u after update+clamp, BEFORE the shift
+void orc_mppi_new_controls(const Params* pp, double* u, const double uinit[2], const double xd[3],
+                           const double x0[3], const double* noise, double* loss_out, double* J_out,
+                           double* u_upd, double out[2]) {
+  const Params& p = *pp;
+  const int T = steps_of(p), K = p.rollouts;
+  std::vector<double> loss_mat((size_t)T * K, 0.0), J((size_t)T * K), dul((size_t)T * K),
+      dur((size_t)T * K);
+
+  for (int k = 0; k < K; ++k) {                                         // mppi.cpp:81
+    double x[3] = {x0[0], x0[1], x0[2]};                                // :75-76 (x, y, theta)
+    for (int i = 0; i < T; ++i) {
+      const double pl = noise[((size_t)k * T + i) * 2 + 0];
+      const double pr = noise[((size_t)k * T + i) * 2 + 1];
+      dul[(size_t)i * K + k] = pl;                                      // :88-89
+      dur[(size_t)i * K + k] = pr;
+      const double up[2] = {u[i] + pl, u[T + i] + pr};                  // :93 (no clamp)
+      rk4_integrate(p, x, up);                                          // :96 -> rk4.cpp:61-66
+      loss_mat[(size_t)i * K + k] = loss(p, x, xd, up);                 // :99-102
+      if (i == T - 1) loss_mat[(size_t)i * K + k] = terminal_loss(p, x, xd);  // :105 overwrites
+    }
+  }
+
+  // cumSumCost, mppi.cpp:15-25
+  for (int k = 0; k < K; ++k) J[(size_t)(T - 1) * K + k] = loss_mat[(size_t)(T - 1) * K + k];
+  for (int i = T - 2; i >= 0; --i)
+    for (int k = 0; k < K; ++k)
+      J[(size_t)i * K + k] = loss_mat[(size_t)i * K + k] + J[(size_t)(i + 1) * K + k];
+  if (loss_out) std::memcpy(loss_out, loss_mat.data(), sizeof(double) * T * K);
+  if (J_out) std::memcpy(J_out, J.data(), sizeof(double) * T * K);
+
+  for (int i = 0; i < T; ++i) {                                         // :112-126
+    double sl, sr;
+    orc_softmin_step(p.lambda, K, &J[(size_t)i * K], &dul[(size_t)i * K], &dur[(size_t)i * K],
+                     nullptr, &sl, &sr);
+    u[i] += sl;
+    u[T + i] += sr;
+    u[i] = std::clamp(u[i], -p.max_wheel_vel, p.max_wheel_vel);
+    u[T + i] = std::clamp(u[T + i], -p.max_wheel_vel, p.max_wheel_vel);
+  }
+  if (u_upd) std::memcpy(u_upd, u, sizeof(double) * 2 * T);
+
+  out[0] = u[0];                                                        // :129-131
+  out[1] = u[T];
+  for (int i = 0; i + 1 < T; ++i) { u[i] = u[i + 1]; u[T + i] = u[T + i + 1]; }  // :134
+  u[T - 1] = uinit[0];                                                  // :136-137
+  u[2 * T - 1] = uinit[1];
+}
+
+// ---- sharded formulation (include/tbnav_mppi.h header comment) — used by the world_size-2 gloo
+// test to prove that "partials -> all-gather -> combine" equals the unsharded tick. ----
+
+// Rollouts of one shard; writes J [T][K] and the records [T][8] (one record per time step).
+void orc_mppi_shard_partials(const Params* pp, const double* u, const double xd[3],
+                             const double x0[3], const double* noise, double* J_out,
+                             double* records) {
+  const Params& p = *pp;
+  const int T = steps_of(p), K = p.rollouts;
+  std::vector<double> lossv(T), J((size_t)T * K), dul((size_t)T * K), dur((size_t)T * K);
+  for (int k = 0; k < K; ++k) {
+    double x[3] = {x0[0], x0[1], x0[2]};
+    for (int i = 0; i < T; ++i) {
+      const double pl = noise[((size_t)k * T + i) * 2 + 0];
+      const double pr = noise[((size_t)k * T + i) * 2 + 1];
+      dul[(size_t)i * K + k] = pl;
+      dur[(size_t)i * K + k] = pr;
+      const double up[2] = {u[i] + pl, u[T + i] + pr};
+      rk4_integrate(p, x, up);
+      lossv[i] = (i == T - 1) ? terminal_loss(p, x, xd) : loss(p, x, xd, up);
+    }
+    double acc = lossv[T - 1];
+    J[(size_t)(T - 1) * K + k] = acc;
+    for (int i = T - 2; i >= 0; --i) { acc = lossv[i] + acc; J[(size_t)i * K + k] = acc; }
+  }
+  for (int i = 0; i < T; ++i) {
+    const double* Jr = &J[(size_t)i * K];
+    double m = Jr[0];
+    for (int k = 1; k < K; ++k) m = std::min(m, Jr[k]);
+    double A = 0, B = 0, C = 0, D = 0, E = 0;
+    for (int k = 0; k < K; ++k) {
+      const double e = std::exp(((Jr[k] - m) * -1.0) / p.lambda);
+      A += e;
+      B += e * dul[(size_t)i * K + k];
+      C += e * dur[(size_t)i * K + k];
+      D += dul[(size_t)i * K + k];
+      E += dur[(size_t)i * K + k];
+    }
+    double* r = records + (size_t)i * 8;
+    r[0] = m; r[1] = A; r[2] = B; r[3] = C; r[4] = D; r[5] = E; r[6] = (double)K; r[7] = 0.0;
+  }
+  if (J_out) std::memcpy(J_out, J.data(), sizeof(double) * T * K);
+}
+
+// records_all [n_rec][T][8]; updates u exactly as mppi.cpp:112-137 would on the union of shards.
+void orc_mppi_combine(const Params* pp, double* u, const double uinit[2], const double* records_all,
+                      int n_rec, double out[2]) {
+  const Params& p = *pp;
+  const int T = steps_of(p);
+  for (int i = 0; i < T; ++i) {
+    double M = std::numeric_limits<double>::infinity();
+    for (int r = 0; r < n_rec; ++r) M = std::min(M, records_all[((size_t)r * T + i) * 8 + 0]);
+    double W = 0, NL = 0, NR = 0, SD = 0, SE = 0, SN = 0;
+    for (int r = 0; r < n_rec; ++r) {
+      const double* rec = records_all + ((size_t)r * T + i) * 8;
+      if (rec[6] == 0.0) continue;
+      const double s = std::exp(((rec[0] - M) * -1.0) / p.lambda);
+      W += s * rec[1]; NL += s * rec[2]; NR += s * rec[3];
+      SD += rec[4]; SE += rec[5]; SN += rec[6];
+    }
+    W += 1e-8 * SN;
+    u[i] += (NL + 1e-8 * SD) / W;
+    u[T + i] += (NR + 1e-8 * SE) / W;
+    u[i] = std::clamp(u[i], -p.max_wheel_vel, p.max_wheel_vel);
+    u[T + i] = std::clamp(u[T + i], -p.max_wheel_vel, p.max_wheel_vel);
+  }
+  out[0] = u[0];
+  out[1] = u[T];
+  for (int i = 0; i + 1 < T; ++i) { u[i] = u[i + 1]; u[T + i] = u[T + i + 1]; }
+  u[T - 1] = uinit[0];
+  u[2 * T - 1] = uinit[1];
+}
+
+}  // extern "C"

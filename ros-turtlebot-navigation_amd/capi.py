@@ -1,0 +1,105 @@
+"""ctypes binding of the C-ABI declared in include/tbnav_*.h (libtbnav_hip.so).
+
+This is plumbing for tests, smoke() and bench.py: it loads the in-tree shared library and exposes
+the entry points with typed signatures.  There is NO fallback: if the library is missing or a call
+fails, it raises.  Nothing here imports or calls oracle/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtbnav_hip.so")
+INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
+
+TBNAV_MPPI_REC = 8
+
+# tbnav_status.h
+OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OUT_OF_WORLD, ERR_ETA_ZERO, ERR_PDF_VARIANCE, \
+    ERR_BRESENHAM, ERR_UNSUPPORTED = range(9)
+
+
+class TbnavError(RuntimeError):
+    def __init__(self, status: int, where: str, detail: str = ""):
+        self.status = status
+        super().__init__(f"{where}: status {status}" + (f" ({detail})" if detail else ""))
+
+
+class MppiParams(C.Structure):
+    """tbnav_mppi_params (include/tbnav_mppi.h)."""
+    _fields_ = [
+        ("wheel_radius", C.c_double), ("wheel_base", C.c_double), ("lam", C.c_double),
+        ("max_wheel_vel", C.c_double), ("ul_var", C.c_double), ("ur_var", C.c_double),
+        ("horizon", C.c_double), ("dt", C.c_double),
+        ("Q", C.c_double * 3), ("R", C.c_double * 2), ("P1", C.c_double * 3),
+        ("rollouts", C.c_int32), ("device", C.c_int32),
+    ]
+
+
+_lib = None
+
+
+def declared_symbols() -> list[str]:
+    """Every function name declared in include/tbnav_*.h (used by the symbol-export test)."""
+    names: list[str] = []
+    for fn in sorted(os.listdir(INCLUDE_DIR)):
+        if not (fn.startswith("tbnav_") and fn.endswith(".h")):
+            continue
+        text = open(os.path.join(INCLUDE_DIR, fn)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names += re.findall(r"\b(tbnav_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(names))
+
+
+def lib() -> C.CDLL:
+    """Load libtbnav_hip.so (once).  Raises if it has not been built — never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(the HIP path has no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    dp, vp, i32, u64, dbl = C.POINTER(C.c_double), C.c_void_p, C.c_int32, C.c_uint64, C.c_double
+    sig = {
+        "tbnav_status_string": (C.c_char_p, [C.c_int]),
+        "tbnav_last_hip_error": (C.c_char_p, []),
+        "tbnav_device_count": (C.c_int, []),
+        # MPPI
+        "tbnav_mppi_create": (C.c_int, [C.POINTER(MppiParams), C.POINTER(vp)]),
+        "tbnav_mppi_destroy": (None, [vp]),
+        "tbnav_mppi_steps": (C.c_int, [vp]),
+        "tbnav_mppi_rollouts": (C.c_int, [vp]),
+        "tbnav_mppi_records_per_step": (C.c_int, [vp]),
+        "tbnav_mppi_set_initial_controls": (C.c_int, [vp, dbl, dbl]),
+        "tbnav_mppi_set_waypoint": (C.c_int, [vp, dbl, dbl, dbl]),
+        "tbnav_mppi_get_controls": (C.c_int, [vp, vp]),
+        "tbnav_mppi_set_controls": (C.c_int, [vp, vp]),
+        "tbnav_mppi_new_controls": (C.c_int, [vp, dp, vp, dp]),
+        "tbnav_mppi_new_controls_dev": (C.c_int, [vp, dp, vp, vp, vp, dp]),
+        "tbnav_mppi_enqueue_dev": (C.c_int, [vp, dp, vp, vp, vp]),
+        "tbnav_mppi_last_controls": (C.c_int, [vp, vp, dp]),
+        "tbnav_mppi_sample_noise": (C.c_int, [vp, u64, u64, vp]),
+        "tbnav_mppi_get_noise": (C.c_int, [vp, vp, vp]),
+        "tbnav_mppi_shard_partials": (C.c_int, [vp, dp, vp, vp, vp, vp]),
+        "tbnav_mppi_shard_combine": (C.c_int, [vp, vp, i32, vp]),
+        "tbnav_mppi_get_cost_to_go": (C.c_int, [vp, vp]),
+        "tbnav_mppi_profile_tick": (C.c_int, [vp, dp, vp, vp, vp, C.POINTER(C.c_float)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(status: int, where: str) -> None:
+    if status != OK:
+        L = lib()
+        detail = L.tbnav_status_string(status).decode()
+        hip = L.tbnav_last_hip_error().decode()
+        raise TbnavError(status, where, detail + (": " + hip if hip else ""))

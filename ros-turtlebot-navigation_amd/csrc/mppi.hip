@@ -1,0 +1,573 @@
+// mppi.hip — MI355X (gfx950) implementation of controller::MPPI::newControls behind the C-ABI of
+// include/tbnav_mppi.h.  Reference: controller/src/controller/mppi.cpp:72-140, rk4.cpp:49-115,
+// controller/include/controller/mppi.hpp:41-105 (paths relative to the reference tree).
+//
+// Kernels (all fp64; this file is compiled with -ffp-contract=off so the op order below is the
+// reference's, and the only numerical difference from the CPU path is libm vs ocml sin/cos/exp):
+//   mppi_rollout_cost   one lane per rollout: T RK4 steps, per-step LQR loss staged in LDS,
+//                       in-lane suffix sum -> J[T][K]                    (mppi.cpp:81-109)
+//   mppi_partials       grid (K-slices, T): per-time-step min / soft-min partial sums over one
+//                       K-slice -> records[T][S][8]                       (mppi.cpp:115-121)
+//   mppi_combine        one workgroup: merge records of all slices/shards, update + clamp u,
+//                       emit u(:,0), shift                                (mppi.cpp:118-137)
+//   mppi_unpack_noise   reference draw order [K][T][2] -> duL/duR [T][K]
+//   mppi_sample_noise   Philox4x32-10 + Box-Muller, production replacement of mppi.cpp:173-184
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <new>
+
+#include "common.hpp"
+#include "tbnav_mppi.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kSliceThreads = 256;
+constexpr int kSliceItems = 8;
+constexpr int kSlice = kSliceThreads * kSliceItems;  // rollouts per K-slice record
+constexpr int kMaxLdsBytes = 160 * 1024;
+
+struct RolloutArgs {
+  double half_r;    // wheel_radius / 2.0            (mppi.hpp:45)
+  double r_over_b;  // wheel_radius / wheel_base     (mppi.hpp:47)
+  double h;         // step                          (rk4.cpp:105)
+  double h6;        // step / 6.0                    (rk4.cpp:114)
+  double x0[3];
+  double xd[3];
+  double Q[3], R[2], P1[3];
+  int T, K;
+};
+
+// One RK4 step of the kinematic cart with zero-order-hold control (rk4.cpp:95-115).  k2 and k3 see
+// the same heading because k1.theta == k2.theta (theta-dot does not depend on the state), so three
+// sincos evaluations cover the four stages; every product/sum keeps the reference's association.
+__device__ __forceinline__ void rk4_step(const RolloutArgs& a, double& x, double& y, double& th,
+                                         double ul, double ur) {
+  const double v = a.half_r * (ul + ur);
+  const double w = a.r_over_b * (ur - ul);
+  double s1, c1, s2, c2, s4, c4;
+  sincos(th, &s1, &c1);
+  const double th2 = th + a.h * (0.5 * w);
+  sincos(th2, &s2, &c2);
+  const double th4 = th + a.h * w;
+  sincos(th4, &s4, &c4);
+  const double k1x = v * c1, k1y = v * s1;
+  const double k2x = v * c2, k2y = v * s2;
+  const double k4x = v * c4, k4y = v * s4;
+  x = x + a.h6 * (((k1x + 2.0 * k2x) + 2.0 * k2x) + k4x);
+  y = y + a.h6 * (((k1y + 2.0 * k2y) + 2.0 * k2y) + k4y);
+  th = th + a.h6 * (((w + 2.0 * w) + 2.0 * w) + w);
+}
+
+__device__ __forceinline__ double lqr_loss(const RolloutArgs& a, double x, double y, double th,
+                                           double ul, double ur) {
+  const double e0 = x - a.xd[0], e1 = y - a.xd[1], e2 = th - a.xd[2];
+  const double state = ((e0 * a.Q[0]) * e0 + (e1 * a.Q[1]) * e1) + (e2 * a.Q[2]) * e2;
+  const double ctrl = (ul * a.R[0]) * ul + (ur * a.R[1]) * ur;
+  return state + ctrl;
+}
+__device__ __forceinline__ double terminal_loss(const RolloutArgs& a, double x, double y, double th) {
+  const double e0 = x - a.xd[0], e1 = y - a.xd[1], e2 = th - a.xd[2];
+  return ((e0 * a.P1[0]) * e0 + (e1 * a.P1[1]) * e1) + (e2 * a.P1[2]) * e2;
+}
+
+// LDS_STAGE: per-step losses live in LDS ([T][64] doubles, one column per lane, conflict-free 8-B
+// accesses) so J is written to HBM exactly once; otherwise J itself is the scratch (T too long).
+template <bool LDS_STAGE>
+__global__ __launch_bounds__(kWave) void mppi_rollout_cost(RolloutArgs a,
+                                                           const double* __restrict__ duL,
+                                                           const double* __restrict__ duR,
+                                                           const double* __restrict__ u,
+                                                           double* __restrict__ J) {
+  extern __shared__ __attribute__((aligned(16))) double lds_loss[];
+  const int lane = threadIdx.x;
+  const int k = blockIdx.x * kWave + lane;
+  if (k >= a.K) return;
+  const int T = a.T, K = a.K;
+  double x = a.x0[0], y = a.x0[1], th = a.x0[2];
+  for (int i = 0; i < T; ++i) {
+    const double ul = u[i] + duL[(size_t)i * K + k];      // mppi.cpp:93 — rollout controls unclamped
+    const double ur = u[T + i] + duR[(size_t)i * K + k];
+    rk4_step(a, x, y, th, ul, ur);
+    const double l = (i == T - 1) ? terminal_loss(a, x, y, th)  // mppi.cpp:105 overwrites, not adds
+                                  : lqr_loss(a, x, y, th, ul, ur);
+    if (LDS_STAGE) lds_loss[i * kWave + lane] = l;
+    else J[(size_t)i * K + k] = l;
+  }
+  // cumSumCost (mppi.cpp:15-25): J(i) = loss(i) + J(i+1), from the end.
+  double acc = LDS_STAGE ? lds_loss[(T - 1) * kWave + lane] : J[(size_t)(T - 1) * K + k];
+  J[(size_t)(T - 1) * K + k] = acc;
+  for (int i = T - 2; i >= 0; --i) {
+    const double l = LDS_STAGE ? lds_loss[i * kWave + lane] : J[(size_t)i * K + k];
+    acc = l + acc;
+    J[(size_t)i * K + k] = acc;
+  }
+}
+
+__device__ __forceinline__ double block_min(double v, double* scratch) {
+  v = tbnav::wave_min(v);
+  const int wid = threadIdx.x / kWave;
+  if ((threadIdx.x & (kWave - 1)) == 0) scratch[wid] = v;
+  __syncthreads();
+  double r = scratch[0];
+  for (int w = 1; w < kSliceThreads / kWave; ++w) r = fmin(r, scratch[w]);
+  __syncthreads();
+  return r;
+}
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+  v = tbnav::wave_sum(v);
+  const int wid = threadIdx.x / kWave;
+  if ((threadIdx.x & (kWave - 1)) == 0) scratch[wid] = v;
+  __syncthreads();
+  double r = scratch[0];
+  for (int w = 1; w < kSliceThreads / kWave; ++w) r += scratch[w];
+  __syncthreads();
+  return r;
+}
+
+// grid = (S, T).  Block (s, i) reduces time step i over rollouts [s*kSlice, (s+1)*kSlice).
+__global__ __launch_bounds__(kSliceThreads) void mppi_partials(int T, int K, int S, double lambda,
+                                                               const double* __restrict__ J,
+                                                               const double* __restrict__ duL,
+                                                               const double* __restrict__ duR,
+                                                               double* __restrict__ records) {
+  __shared__ double scratch[kSliceThreads / kWave];
+  const int s = blockIdx.x, i = blockIdx.y;
+  const int base = s * kSlice;
+  const double inf = __builtin_huge_val();
+  double j[kSliceItems], l[kSliceItems], r[kSliceItems];
+  double mn = inf;
+  int cnt = 0;
+#pragma unroll
+  for (int it = 0; it < kSliceItems; ++it) {
+    const int k = base + it * kSliceThreads + threadIdx.x;  // coalesced across lanes
+    const bool ok = k < K;
+    j[it] = ok ? J[(size_t)i * K + k] : inf;
+    l[it] = ok ? duL[(size_t)i * K + k] : 0.0;
+    r[it] = ok ? duR[(size_t)i * K + k] : 0.0;
+    mn = fmin(mn, j[it]);
+    cnt += ok ? 1 : 0;
+  }
+  mn = block_min(mn, scratch);
+  double A = 0, B = 0, C = 0, D = 0, E = 0;
+#pragma unroll
+  for (int it = 0; it < kSliceItems; ++it) {
+    // exp(-(J - min)/lambda) with the reference's association: (J - min) * -1.0 / lambda (mppi.cpp:117)
+    const double e = (j[it] == inf) ? 0.0 : exp(((j[it] - mn) * -1.0) / lambda);
+    A += e;
+    B += e * l[it];
+    C += e * r[it];
+    D += l[it];
+    E += r[it];
+  }
+  A = block_sum(A, scratch);
+  B = block_sum(B, scratch);
+  C = block_sum(C, scratch);
+  D = block_sum(D, scratch);
+  E = block_sum(E, scratch);
+  const double n = block_sum((double)cnt, scratch);
+  if (threadIdx.x == 0) {
+    double* rec = records + ((size_t)i * S + s) * TBNAV_MPPI_REC;
+    rec[0] = mn; rec[1] = A; rec[2] = B; rec[3] = C; rec[4] = D; rec[5] = E; rec[6] = n; rec[7] = 0.0;
+  }
+}
+
+// One workgroup.  records: [G][T][S][8].  Thread i (strided) merges the G*S records of time step i,
+// updates u(:,i) (mppi.cpp:118-125), then the block emits u(:,0) and shifts (mppi.cpp:129-137).
+__global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, double lambda, double umax,
+                                                    double uinit_l, double uinit_r,
+                                                    const double* __restrict__ records,
+                                                    double* __restrict__ u, double* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) double unew[];  // [2][T]
+  for (int i = threadIdx.x; i < T; i += blockDim.x) {
+    double M = __builtin_huge_val();
+    for (int g = 0; g < G; ++g)
+      for (int s = 0; s < S; ++s) {
+        const double* rec = records + (((size_t)g * T + i) * S + s) * TBNAV_MPPI_REC;
+        if (rec[6] > 0.0) M = fmin(M, rec[0]);
+      }
+    double W = 0, NL = 0, NR = 0, SD = 0, SE = 0, SN = 0;
+    for (int g = 0; g < G; ++g)
+      for (int s = 0; s < S; ++s) {
+        const double* rec = records + (((size_t)g * T + i) * S + s) * TBNAV_MPPI_REC;
+        if (rec[6] > 0.0) {
+          const double sc = exp(((rec[0] - M) * -1.0) / lambda);
+          W += sc * rec[1];
+          NL += sc * rec[2];
+          NR += sc * rec[3];
+          SD += rec[4];
+          SE += rec[5];
+          SN += rec[6];
+        }
+      }
+    W += 1e-8 * SN;  // the reference adds 1e-8 to every weight before normalising (mppi.cpp:117)
+    double ul = u[i] + (NL + 1e-8 * SD) / W;
+    double ur = u[T + i] + (NR + 1e-8 * SE) / W;
+    ul = fmin(fmax(ul, -umax), umax);  // std::clamp(u, -max, max), mppi.cpp:124-125
+    ur = fmin(fmax(ur, -umax), umax);
+    unew[i] = ul;
+    unew[T + i] = ur;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { out[0] = unew[0]; out[1] = unew[T]; }
+  for (int i = threadIdx.x; i < T; i += blockDim.x) {
+    u[i] = (i + 1 < T) ? unew[i + 1] : uinit_l;
+    u[T + i] = (i + 1 < T) ? unew[T + i + 1] : uinit_r;
+  }
+}
+
+// raw[(k*T + i)*2 + c]  ->  duL[i*K + k], duR[i*K + k]
+__global__ void mppi_unpack_noise(int T, int K, const double* __restrict__ raw,
+                                  double* __restrict__ duL, double* __restrict__ duR) {
+  const size_t n = (size_t)T * K;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(idx / T), i = (int)(idx % T);
+    const double2 v = reinterpret_cast<const double2*>(raw)[idx];
+    duL[(size_t)i * K + k] = v.x;
+    duR[(size_t)i * K + k] = v.y;
+  }
+}
+
+// ---- Philox4x32-10 (Salmon et al., SC'11) ------------------------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+  const uint32_t n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+  const uint32_t n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ void philox4x32_10(uint64_t ctr, uint64_t key, uint32_t (&out)[4]) {
+  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+  uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+
+__global__ void mppi_sample_noise(int T, int K, uint64_t seed, uint64_t tick, double sig_l,
+                                  double sig_r, double* __restrict__ duL, double* __restrict__ duR) {
+  const size_t n = (size_t)T * K;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int i = (int)(idx / K), k = (int)(idx % K);  // k fastest: coalesced stores
+    uint32_t r[4];
+    philox4x32_10(tick * n + (uint64_t)k * T + i, seed, r);
+    const uint64_t a = ((uint64_t)r[0] << 32) | r[1];
+    const uint64_t b = ((uint64_t)r[2] << 32) | r[3];
+    const double u1 = ((double)(a >> 11) + 0.5) * 0x1.0p-53;  // (0,1)
+    const double u2 = ((double)(b >> 11) + 0.5) * 0x1.0p-53;
+    const double rad = sqrt(-2.0 * log(u1));
+    double sn, cs;
+    sincospi(2.0 * u2, &sn, &cs);
+    duL[idx] = sig_l * (rad * cs);
+    duR[idx] = sig_r * (rad * sn);
+  }
+}
+
+}  // namespace
+
+// =================================================================================================
+// Handle + C-ABI
+// =================================================================================================
+struct tbnav_mppi {
+  tbnav_mppi_params p;
+  int T = 0, K = 0, S = 0, device = 0;
+  double xd[3] = {0, 0, 0};
+  double uinit[2] = {0, 0};
+  double* d_u = nullptr;        // [2][T]
+  double* d_J = nullptr;        // [T][K]
+  double* d_duL = nullptr;      // [T][K] own noise buffers (host-noise upload / device RNG)
+  double* d_duR = nullptr;
+  double* d_raw = nullptr;      // [K][T][2] staging for host-order noise (lazy)
+  double* d_records = nullptr;  // [T][S][8]
+  double* d_out = nullptr;      // [2]
+  double* h_out = nullptr;      // pinned [2]
+  bool lds_stage = true;
+};
+
+namespace {
+
+int launch_rollout(tbnav_mppi* h, const double x0[3], const double* d_duL, const double* d_duR,
+                   hipStream_t st) {
+  RolloutArgs a;
+  a.half_r = h->p.wheel_radius / 2.0;
+  a.r_over_b = h->p.wheel_radius / h->p.wheel_base;
+  a.h = h->p.dt;
+  a.h6 = h->p.dt / 6.0;
+  for (int c = 0; c < 3; ++c) { a.x0[c] = x0[c]; a.xd[c] = h->xd[c]; a.Q[c] = h->p.Q[c]; a.P1[c] = h->p.P1[c]; }
+  a.R[0] = h->p.R[0]; a.R[1] = h->p.R[1];
+  a.T = h->T; a.K = h->K;
+  const dim3 grid((h->K + kWave - 1) / kWave), block(kWave);
+  if (h->lds_stage) {
+    const size_t lds = (size_t)h->T * kWave * sizeof(double);
+    hipLaunchKernelGGL(mppi_rollout_cost<true>, grid, block, lds, st, a, d_duL, d_duR, h->d_u, h->d_J);
+  } else {
+    hipLaunchKernelGGL(mppi_rollout_cost<false>, grid, block, 0, st, a, d_duL, d_duR, h->d_u, h->d_J);
+  }
+  TBNAV_HIP(hipGetLastError());
+  return TBNAV_OK;
+}
+
+int launch_partials(tbnav_mppi* h, const double* d_duL, const double* d_duR, double* d_records,
+                    hipStream_t st) {
+  const dim3 grid(h->S, h->T), block(kSliceThreads);
+  hipLaunchKernelGGL(mppi_partials, grid, block, 0, st, h->T, h->K, h->S, h->p.lambda, h->d_J, d_duL,
+                     d_duR, d_records);
+  TBNAV_HIP(hipGetLastError());
+  return TBNAV_OK;
+}
+
+int launch_combine(tbnav_mppi* h, const double* d_records, int G, hipStream_t st) {
+  const size_t lds = (size_t)2 * h->T * sizeof(double);
+  hipLaunchKernelGGL(mppi_combine, dim3(1), dim3(256), lds, st, h->T, G, h->S, h->p.lambda,
+                     h->p.max_wheel_vel, h->uinit[0], h->uinit[1], d_records, h->d_u, h->d_out);
+  TBNAV_HIP(hipGetLastError());
+  return TBNAV_OK;
+}
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(dev) == hipSuccess) ok = true;
+  }
+  ~DeviceGuard() { if (ok && prev >= 0) (void)hipSetDevice(prev); }
+};
+
+bool pick_noise(tbnav_mppi* h, const double*& d_duL, const double*& d_duR) {
+  if (!d_duL && !d_duR) { d_duL = h->d_duL; d_duR = h->d_duR; return true; }
+  return d_duL && d_duR;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tbnav_mppi_create(const tbnav_mppi_params* params, tbnav_mppi** out) {
+  if (!params || !out) return TBNAV_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (params->rollouts <= 0 || !(params->dt > 0.0) || !(params->horizon > 0.0) ||
+      !(params->lambda > 0.0) || !(params->wheel_base != 0.0))
+    return TBNAV_ERR_INVALID_ARG;
+  const int T = static_cast<int>(params->horizon / params->dt);  // mppi.cpp:47
+  if (T <= 0) return TBNAV_ERR_INVALID_ARG;
+  int ndev = 0;
+  {
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+      return tbnav::hip_fail(e == hipSuccess ? hipErrorNoDevice : e, "hipGetDeviceCount", __FILE__, __LINE__);
+  }
+  int dev = params->device;
+  if (dev < 0) TBNAV_HIP(hipGetDevice(&dev));
+  if (dev >= ndev) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(dev);
+  if (!guard.ok) return TBNAV_ERR_NO_DEVICE;
+
+  tbnav_mppi* h = new (std::nothrow) tbnav_mppi();
+  if (!h) return TBNAV_ERR_INVALID_ARG;
+  h->p = *params;
+  h->T = T;
+  h->K = params->rollouts;
+  h->S = (h->K + kSlice - 1) / kSlice;
+  h->device = dev;
+  h->lds_stage = (size_t)T * kWave * sizeof(double) <= (size_t)kMaxLdsBytes;
+  const size_t tk = (size_t)T * h->K;
+  hipError_t e = hipSuccess;
+  auto alloc = [&](double** p, size_t n) { if (e == hipSuccess) e = hipMalloc((void**)p, n * sizeof(double)); };
+  alloc(&h->d_u, 2 * (size_t)T);
+  alloc(&h->d_J, tk);
+  alloc(&h->d_duL, tk);
+  alloc(&h->d_duR, tk);
+  alloc(&h->d_records, (size_t)T * h->S * TBNAV_MPPI_REC);
+  alloc(&h->d_out, 2);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_out, 2 * sizeof(double), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipMemset(h->d_u, 0, 2 * (size_t)T * sizeof(double));
+  if (e == hipSuccess) e = hipMemset(h->d_J, 0, tk * sizeof(double));
+  if (e == hipSuccess) e = hipMemset(h->d_duL, 0, tk * sizeof(double));
+  if (e == hipSuccess) e = hipMemset(h->d_duR, 0, tk * sizeof(double));
+  if (e == hipSuccess) e = hipMemset(h->d_out, 0, 2 * sizeof(double));
+  if (e == hipSuccess && h->lds_stage) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mppi_rollout_cost<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)T * kWave * sizeof(double)));
+  }
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {
+    const int rc = tbnav::hip_fail(e, "tbnav_mppi_create allocation", __FILE__, __LINE__);
+    tbnav_mppi_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return TBNAV_OK;
+}
+
+void tbnav_mppi_destroy(tbnav_mppi* h) {
+  if (!h) return;
+  DeviceGuard guard(h->device);
+  (void)hipFree(h->d_u); (void)hipFree(h->d_J); (void)hipFree(h->d_duL); (void)hipFree(h->d_duR);
+  (void)hipFree(h->d_raw); (void)hipFree(h->d_records); (void)hipFree(h->d_out);
+  if (h->h_out) (void)hipHostFree(h->h_out);
+  delete h;
+}
+
+int tbnav_mppi_steps(const tbnav_mppi* h) { return h ? h->T : -1; }
+int tbnav_mppi_rollouts(const tbnav_mppi* h) { return h ? h->K : -1; }
+int tbnav_mppi_records_per_step(const tbnav_mppi* h) { return h ? h->S : -1; }
+
+int tbnav_mppi_set_initial_controls(tbnav_mppi* h, double uL, double uR) {
+  if (!h) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  h->uinit[0] = uL; h->uinit[1] = uR;
+  double* tmp = new (std::nothrow) double[2 * (size_t)h->T];
+  if (!tmp) return TBNAV_ERR_INVALID_ARG;
+  for (int i = 0; i < h->T; ++i) { tmp[i] = uL; tmp[h->T + i] = uR; }
+  hipError_t e = hipMemcpy(h->d_u, tmp, 2 * (size_t)h->T * sizeof(double), hipMemcpyHostToDevice);
+  delete[] tmp;
+  TBNAV_HIP(e);
+  return TBNAV_OK;
+}
+
+int tbnav_mppi_set_waypoint(tbnav_mppi* h, double x, double y, double theta) {
+  if (!h) return TBNAV_ERR_INVALID_ARG;
+  h->xd[0] = x; h->xd[1] = y; h->xd[2] = theta;
+  return TBNAV_OK;
+}
+
+int tbnav_mppi_get_controls(tbnav_mppi* h, double* u_host) {
+  if (!h || !u_host) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  TBNAV_HIP(hipDeviceSynchronize());
+  TBNAV_HIP(hipMemcpy(u_host, h->d_u, 2 * (size_t)h->T * sizeof(double), hipMemcpyDeviceToHost));
+  return TBNAV_OK;
+}
+
+int tbnav_mppi_set_controls(tbnav_mppi* h, const double* u_host) {
+  if (!h || !u_host) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  TBNAV_HIP(hipDeviceSynchronize());
+  TBNAV_HIP(hipMemcpy(h->d_u, u_host, 2 * (size_t)h->T * sizeof(double), hipMemcpyHostToDevice));
+  return TBNAV_OK;
+}
+
+int tbnav_mppi_shard_partials(tbnav_mppi* h, const double x0[3], const double* d_duL,
+                              const double* d_duR, void* stream, double* d_records_out) {
+  if (!h || !x0 || !d_records_out || !pick_noise(h, d_duL, d_duR)) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int rc = launch_rollout(h, x0, d_duL, d_duR, st);
+  if (rc != TBNAV_OK) return rc;
+  return launch_partials(h, d_duL, d_duR, d_records_out, st);
+}
+
+int tbnav_mppi_shard_combine(tbnav_mppi* h, const double* d_records_all, int32_t n_shards, void* stream) {
+  if (!h || !d_records_all || n_shards <= 0) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  return launch_combine(h, d_records_all, n_shards, static_cast<hipStream_t>(stream));
+}
+
+int tbnav_mppi_enqueue_dev(tbnav_mppi* h, const double x0[3], const double* d_duL,
+                           const double* d_duR, void* stream) {
+  if (!h || !x0 || !pick_noise(h, d_duL, d_duR)) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int rc = launch_rollout(h, x0, d_duL, d_duR, st);
+  if (rc != TBNAV_OK) return rc;
+  rc = launch_partials(h, d_duL, d_duR, h->d_records, st);
+  if (rc != TBNAV_OK) return rc;
+  return launch_combine(h, h->d_records, 1, st);
+}
+
+int tbnav_mppi_profile_tick(tbnav_mppi* h, const double x0[3], const double* d_duL,
+                            const double* d_duR, void* stream, float ms[TBNAV_MPPI_NKERNELS]) {
+  if (!h || !x0 || !ms || !pick_noise(h, d_duL, d_duR)) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipEvent_t ev[TBNAV_MPPI_NKERNELS + 1];
+  for (auto& e : ev) TBNAV_HIP(hipEventCreate(&e));
+  int rc = TBNAV_OK;
+  TBNAV_HIP(hipEventRecord(ev[0], st));
+  rc = launch_rollout(h, x0, d_duL, d_duR, st);
+  if (rc == TBNAV_OK) { TBNAV_HIP(hipEventRecord(ev[1], st)); rc = launch_partials(h, d_duL, d_duR, h->d_records, st); }
+  if (rc == TBNAV_OK) { TBNAV_HIP(hipEventRecord(ev[2], st)); rc = launch_combine(h, h->d_records, 1, st); }
+  if (rc == TBNAV_OK) {
+    TBNAV_HIP(hipEventRecord(ev[3], st));
+    TBNAV_HIP(hipEventSynchronize(ev[3]));
+    for (int i = 0; i < TBNAV_MPPI_NKERNELS; ++i) TBNAV_HIP(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  return rc;
+}
+
+int tbnav_mppi_last_controls(tbnav_mppi* h, void* stream, double u_out[2]) {
+  if (!h || !u_out) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  TBNAV_HIP(hipMemcpyAsync(h->h_out, h->d_out, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+  TBNAV_HIP(hipStreamSynchronize(st));
+  u_out[0] = h->h_out[0];
+  u_out[1] = h->h_out[1];
+  return TBNAV_OK;
+}
+
+int tbnav_mppi_new_controls_dev(tbnav_mppi* h, const double x0[3], const double* d_duL,
+                                const double* d_duR, void* stream, double u_out[2]) {
+  if (!u_out) return TBNAV_ERR_INVALID_ARG;
+  int rc = tbnav_mppi_enqueue_dev(h, x0, d_duL, d_duR, stream);
+  if (rc != TBNAV_OK) return rc;
+  return tbnav_mppi_last_controls(h, stream, u_out);
+}
+
+int tbnav_mppi_new_controls(tbnav_mppi* h, const double x0[3], const double* noise_host,
+                            double u_out[2]) {
+  if (!h || !x0 || !noise_host || !u_out) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  const size_t n = (size_t)h->T * h->K;
+  if (!h->d_raw) TBNAV_HIP(hipMalloc((void**)&h->d_raw, 2 * n * sizeof(double)));
+  TBNAV_HIP(hipMemcpyAsync(h->d_raw, noise_host, 2 * n * sizeof(double), hipMemcpyHostToDevice, nullptr));
+  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(mppi_unpack_noise, dim3(blocks), dim3(256), 0, nullptr, h->T, h->K, h->d_raw,
+                     h->d_duL, h->d_duR);
+  TBNAV_HIP(hipGetLastError());
+  return tbnav_mppi_new_controls_dev(h, x0, nullptr, nullptr, nullptr, u_out);
+}
+
+int tbnav_mppi_sample_noise(tbnav_mppi* h, uint64_t seed, uint64_t tick, void* stream) {
+  if (!h) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  const size_t n = (size_t)h->T * h->K;
+  const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+  hipLaunchKernelGGL(mppi_sample_noise, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     h->T, h->K, seed, tick, std::sqrt(h->p.ul_var), std::sqrt(h->p.ur_var), h->d_duL,
+                     h->d_duR);
+  TBNAV_HIP(hipGetLastError());
+  return TBNAV_OK;
+}
+
+int tbnav_mppi_get_noise(tbnav_mppi* h, double* duL_host, double* duR_host) {
+  if (!h || !duL_host || !duR_host) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  const size_t n = (size_t)h->T * h->K;
+  TBNAV_HIP(hipDeviceSynchronize());
+  TBNAV_HIP(hipMemcpy(duL_host, h->d_duL, n * sizeof(double), hipMemcpyDeviceToHost));
+  TBNAV_HIP(hipMemcpy(duR_host, h->d_duR, n * sizeof(double), hipMemcpyDeviceToHost));
+  return TBNAV_OK;
+}
+
+int tbnav_mppi_get_cost_to_go(tbnav_mppi* h, double* J_host) {
+  if (!h || !J_host) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  TBNAV_HIP(hipDeviceSynchronize());
+  TBNAV_HIP(hipMemcpy(J_host, h->d_J, (size_t)h->T * h->K * sizeof(double), hipMemcpyDeviceToHost));
+  return TBNAV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,143 @@
+"""Python mirror of controller::MPPI over the C-ABI (tests / smoke / bench plumbing).
+
+Same names and argument meaning as the reference's class surface
+(controller/include/controller/mppi.hpp:31-185): CartModel, LossFunc, MPPI with
+setInitialControls / setWaypoint / newControls.  The shipped host surface for ROS nodes is the C++
+shim in host/; this module exists so the parity tests read like the reference's own call sites
+(nuturtle_robot/src/mppi_waypoints_node.cpp:186-199,216,257,265).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import capi
+
+
+@dataclass
+class CartModel:  # mppi.hpp:31-52
+    wheel_radius: float
+    wheel_base: float
+
+
+@dataclass
+class LossFunc:  # mppi.hpp:56-110 (diagonals only, like the reference's ctor)
+    Q: list = field(default_factory=lambda: [0.0, 0.0, 0.0])
+    R: list = field(default_factory=lambda: [0.0, 0.0])
+    P1: list = field(default_factory=lambda: [0.0, 0.0, 0.0])
+
+    def __post_init__(self):
+        # std::vector::at throws std::out_of_range on short vectors (mppi.hpp:68-79)
+        if len(self.Q) < 3 or len(self.R) < 2 or len(self.P1) < 3:
+            raise IndexError("LossFunc: Q, P1 need 3 entries and R needs 2")
+
+
+def _dptr(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class MPPI:
+    """controller::MPPI (mppi.hpp:119-185) on one MI355X."""
+
+    def __init__(self, cart_model: CartModel, loss_func: LossFunc, lam: float, max_wheel_vel: float,
+                 ul_var: float, ur_var: float, horizon: float, dt: float, rollouts: int,
+                 device: int = -1):
+        p = capi.MppiParams()
+        p.wheel_radius, p.wheel_base = cart_model.wheel_radius, cart_model.wheel_base
+        p.lam, p.max_wheel_vel, p.ul_var, p.ur_var = lam, max_wheel_vel, ul_var, ur_var
+        p.horizon, p.dt = horizon, dt
+        p.Q[:] = loss_func.Q[:3]
+        p.R[:] = loss_func.R[:2]
+        p.P1[:] = loss_func.P1[:3]
+        p.rollouts, p.device = rollouts, device
+        self.params = p
+        self._L = capi.lib()
+        self._h = C.c_void_p()
+        capi.check(self._L.tbnav_mppi_create(C.byref(p), C.byref(self._h)), "tbnav_mppi_create")
+        self.steps = self._L.tbnav_mppi_steps(self._h)
+        self.rollouts = self._L.tbnav_mppi_rollouts(self._h)
+        self.records_per_step = self._L.tbnav_mppi_records_per_step(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.tbnav_mppi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    # ---- reference surface ----
+    def setInitialControls(self, uL: float, uR: float):
+        capi.check(self._L.tbnav_mppi_set_initial_controls(self._h, uL, uR), "set_initial_controls")
+
+    def setWaypoint(self, x: float, y: float, theta: float):
+        capi.check(self._L.tbnav_mppi_set_waypoint(self._h, x, y, theta), "set_waypoint")
+
+    def newControls(self, x: float, y: float, theta: float, noise: np.ndarray):
+        """noise: host array [K][T][2] in the reference's draw order.  Returns (ul, ur)."""
+        noise = np.ascontiguousarray(noise, dtype=np.float64)
+        assert noise.size == self.rollouts * self.steps * 2
+        x0 = (C.c_double * 3)(x, y, theta)
+        out = (C.c_double * 2)()
+        capi.check(self._L.tbnav_mppi_new_controls(self._h, x0, noise.ctypes.data, out), "new_controls")
+        return out[0], out[1]
+
+    # ---- device-resident variants ----
+    def newControlsDev(self, x0, d_duL: int, d_duR: int, stream: int = 0):
+        x0c = (C.c_double * 3)(*x0)
+        out = (C.c_double * 2)()
+        capi.check(self._L.tbnav_mppi_new_controls_dev(self._h, x0c, d_duL or None, d_duR or None,
+                                                       stream or None, out), "new_controls_dev")
+        return out[0], out[1]
+
+    def enqueueDev(self, x0, d_duL: int, d_duR: int, stream: int = 0):
+        x0c = (C.c_double * 3)(*x0)
+        capi.check(self._L.tbnav_mppi_enqueue_dev(self._h, x0c, d_duL or None, d_duR or None,
+                                                  stream or None), "enqueue_dev")
+
+    def profileTick(self, x0, d_duL: int, d_duR: int, stream: int = 0):
+        """(ms_rollout_cost, ms_partials, ms_combine) of one tick, HIP events on `stream`."""
+        x0c = (C.c_double * 3)(*x0)
+        ms = (C.c_float * 3)()
+        capi.check(self._L.tbnav_mppi_profile_tick(self._h, x0c, d_duL or None, d_duR or None,
+                                                   stream or None, ms), "profile_tick")
+        return ms[0], ms[1], ms[2]
+
+    def lastControls(self, stream: int = 0):
+        out = (C.c_double * 2)()
+        capi.check(self._L.tbnav_mppi_last_controls(self._h, stream or None, out), "last_controls")
+        return out[0], out[1]
+
+    def sampleNoise(self, seed: int, tick: int, stream: int = 0):
+        capi.check(self._L.tbnav_mppi_sample_noise(self._h, seed, tick, stream or None), "sample_noise")
+
+    def getNoise(self):
+        a = np.empty((self.steps, self.rollouts)); b = np.empty_like(a)
+        capi.check(self._L.tbnav_mppi_get_noise(self._h, a.ctypes.data, b.ctypes.data), "get_noise")
+        return a, b
+
+    def shardPartials(self, x0, d_duL: int, d_duR: int, d_records: int, stream: int = 0):
+        x0c = (C.c_double * 3)(*x0)
+        capi.check(self._L.tbnav_mppi_shard_partials(self._h, x0c, d_duL or None, d_duR or None,
+                                                     stream or None, d_records), "shard_partials")
+
+    def shardCombine(self, d_records_all: int, n_shards: int, stream: int = 0):
+        capi.check(self._L.tbnav_mppi_shard_combine(self._h, d_records_all, n_shards, stream or None),
+                   "shard_combine")
+
+    # ---- state / debug ----
+    def getControls(self) -> np.ndarray:
+        u = np.empty((2, self.steps))
+        capi.check(self._L.tbnav_mppi_get_controls(self._h, u.ctypes.data), "get_controls")
+        return u
+
+    def setControls(self, u: np.ndarray):
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        assert u.shape == (2, self.steps)
+        capi.check(self._L.tbnav_mppi_set_controls(self._h, u.ctypes.data), "set_controls")
+
+    def costToGo(self) -> np.ndarray:
+        J = np.empty((self.steps, self.rollouts))
+        capi.check(self._L.tbnav_mppi_get_cost_to_go(self._h, J.ctypes.data), "get_cost_to_go")
+        return J

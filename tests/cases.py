@@ -1,0 +1,28 @@
+"""Shared parameter sets (values from the reference's shipped configs)."""
+import numpy as np
+
+# controller/config/mppi_params.yaml, nuturtle_description/config/diff_params.yaml:6,8,20
+MPPI_BASE = dict(wheel_radius=0.033, wheel_base=0.16, lam=0.01, max_wheel_vel=6.35495, ul_var=0.9,
+                 ur_var=0.9, horizon=0.25, dt=0.01, Q=[1e4, 1e4, 1.0], R=[0.1, 0.1],
+                 P1=[1e3, 1e3, 1e3], rollouts=64)
+# nuturtle_robot/config/real_waypoints.yaml:3-7
+WAYPOINTS = [(0.0, 0.0, 0.0), (1.0, 0.0, 1.5707), (1.0, 1.0, 2.3562), (0.5, 2.0, -2.3562), (0.0, 1.0, -1.5707)]
+
+
+def mppi_cfg(K, horizon, **kw):
+    d = dict(MPPI_BASE)
+    d.update(rollouts=K, horizon=horizon)
+    d.update(kw)
+    return d
+
+
+def make_mppi(pkg, d, device=-1):
+    from rtn_amd.mppi import MPPI, CartModel, LossFunc
+    return MPPI(CartModel(d["wheel_radius"], d["wheel_base"]), LossFunc(d["Q"], d["R"], d["P1"]),
+                d["lam"], d["max_wheel_vel"], d["ul_var"], d["ur_var"], d["horizon"], d["dt"],
+                d["rollouts"], device)
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)))

