@@ -1,0 +1,39 @@
+#!/usr/bin/env python
+"""Summarise a rocprofv3 (ROCm 7.2, rocpd sqlite output) kernel trace into a small markdown table.
+
+usage: python profiles/summarize_rocpd.py <results.db> [--match substr] > profiles/<name>.md
+
+Groups dispatches by (kernel name, grid, workgroup) so that one bench run that launches the same
+kernel on two workload sizes (K=1024/T=50 and K=65536/T=100) is reported per size; durations in µs.
+"""
+import re
+import sqlite3
+import sys
+
+
+def short(name: str) -> str:
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    return name.split("(")[0][:70]
+
+
+def main():
+    db = sys.argv[1]
+    match = sys.argv[sys.argv.index("--match") + 1] if "--match" in sys.argv else ""
+    c = sqlite3.connect(db)
+    rows = c.execute(
+        "select name, grid_x, grid_y, grid_z, workgroup_x, count(*), avg(duration), min(duration), max(duration), "
+        "sum(duration), max(vgpr_count), max(sgpr_count), max(lds_size), max(scratch_size) from kernels "
+        "group by name, grid_x, grid_y, grid_z, workgroup_x order by sum(duration) desc").fetchall()
+    total = sum(r[9] for r in rows) or 1
+    print("| kernel | grid (threads) | wg | calls | avg µs | min µs | max µs | total ms | % | vgpr | sgpr | lds B | scratch |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+    for r in rows:
+        if match and match not in r[0]:
+            continue
+        print(f"| {short(r[0])} | {r[1]}x{r[2]}x{r[3]} | {r[4]} | {r[5]} | {r[6]/1e3:.3f} | {r[7]/1e3:.3f} | {r[8]/1e3:.3f} | "
+              f"{r[9]/1e6:.3f} | {100*r[9]/total:.1f} | {r[10]} | {r[11]} | {r[12]} | {r[13]} |")
+
+
+if __name__ == "__main__":
+    main()

@@ -58,6 +58,14 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch bundles its own HIP runtime (torch/lib/libamdhip64.so) and must be the first to load
+    # one: if /opt/rocm's copy (our DT_NEEDED) is mapped first, torch later maps a second runtime
+    # and sees "No HIP GPUs".  With torch first, our NEEDED resolves to the already-loaded SONAME
+    # and the process has ONE runtime, so torch streams/pointers are valid in our kernels.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise FileNotFoundError(
             f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
