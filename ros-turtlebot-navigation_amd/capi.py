@@ -38,6 +38,31 @@ class MppiParams(C.Structure):
     ]
 
 
+class RbpfParams(C.Structure):
+    """tbnav_rbpf_params (include/tbnav_rbpf.h)."""
+    _fields_ = [
+        ("num_particles", C.c_int32), ("num_samples_mode", C.c_int32),
+        ("srr", C.c_double), ("srt", C.c_double), ("str_", C.c_double), ("stt", C.c_double),
+        ("motion_noise", C.c_double * 3), ("sample_range", C.c_double * 3),
+        ("scan_likelihood_min", C.c_double), ("scan_likelihood_max", C.c_double),
+        ("pose_likelihood_min", C.c_double), ("pose_likelihood_max", C.c_double),
+        ("beam_min", C.c_float), ("beam_max", C.c_float), ("beam_delta", C.c_float),
+        ("range_min", C.c_float), ("range_max", C.c_float), ("device", C.c_int32),
+        ("z_hit", C.c_double), ("z_short", C.c_double), ("z_max", C.c_double), ("z_rand", C.c_double),
+        ("sigma_hit", C.c_double),
+        ("Trs", C.c_double * 3),
+        ("resolution", C.c_double), ("xmin", C.c_double), ("xmax", C.c_double), ("ymin", C.c_double),
+        ("ymax", C.c_double),
+        ("pose0", C.c_double * 3),
+    ]
+
+
+class RbpfStats(C.Structure):
+    """tbnav_rbpf_stats."""
+    _fields_ = [("sum_w", C.c_double), ("sq_sum", C.c_double), ("neff", C.c_int32), ("resampled", C.c_int32),
+                ("status", C.c_int32), ("n_valid_beams", C.c_int32)]
+
+
 _lib = None
 
 
@@ -96,6 +121,27 @@ def lib() -> C.CDLL:
         "tbnav_mppi_shard_combine": (C.c_int, [vp, vp, i32, vp]),
         "tbnav_mppi_get_cost_to_go": (C.c_int, [vp, vp]),
         "tbnav_mppi_profile_tick": (C.c_int, [vp, dp, vp, vp, vp, C.POINTER(C.c_float)]),
+        # RBPF
+        "tbnav_rbpf_create": (C.c_int, [C.POINTER(RbpfParams), C.POINTER(vp)]),
+        "tbnav_rbpf_destroy": (None, [vp]),
+        "tbnav_rbpf_grid_size": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32)]),
+        "tbnav_rbpf_num_normals": (C.c_int64, [vp, i32]),
+        "tbnav_rbpf_slam": (C.c_int, [vp, vp, i32, dp, dp, dp, i32, dp, vp, C.POINTER(RbpfStats)]),
+        "tbnav_rbpf_slam_local": (C.c_int, [vp, vp, i32, dp, dp, dp, i32, dp, vp, C.POINTER(RbpfStats)]),
+        "tbnav_rbpf_resample_global": (C.c_int, [vp, C.c_int64, dbl, vp, vp, C.POINTER(RbpfStats)]),
+        "tbnav_rbpf_gather_local": (C.c_int, [vp, vp]),
+        "tbnav_rbpf_best_state": (C.c_int, [vp, dp, C.POINTER(i32)]),
+        "tbnav_rbpf_best_map": (C.c_int, [vp, vp]),
+        "tbnav_rbpf_get_particles": (C.c_int, [vp, vp, vp, vp]),
+        "tbnav_rbpf_set_particles": (C.c_int, [vp, vp, vp, vp]),
+        "tbnav_rbpf_get_log_odds": (C.c_int, [vp, i32, vp]),
+        "tbnav_rbpf_set_log_odds": (C.c_int, [vp, i32, vp]),
+        "tbnav_rbpf_get_occ_dist": (C.c_int, [vp, i32, vp]),
+        "tbnav_rbpf_set_occ_dist": (C.c_int, [vp, i32, vp]),
+        "tbnav_rbpf_get_dist_code": (C.c_int, [vp, i32, vp]),
+        "tbnav_rbpf_get_occupied_count": (C.c_int, [vp, vp]),
+        "tbnav_rbpf_get_trace": (C.c_int, [vp] + [vp] * 9),
+        "tbnav_rbpf_last_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

@@ -1,0 +1,1080 @@
+// rbpf.hip — MI355X (gfx950) implementation of bmapping::ParticleFilter::SLAM behind the C-ABI of
+// include/tbnav_rbpf.h.  Reference (paths relative to the reference tree):
+//   bmapping/src/bmapping/particle_filter.cpp:141-251 (SLAM), :295-322, :383-437, :442-500, :504-599
+//   bmapping/src/bmapping/grid_mapper.cpp:69-182 (likelihood field, integrateScan), :549-898
+//   bmapping/src/bmapping/sensor_model.cpp:43-112 (laserEndPoints)
+//
+// Kernels (fp64 / integer; compiled with -ffp-contract=off):
+//   rbpf_propose      one workgroup per particle: sample k poses round the ICP mode, score each
+//                     (scan likelihood over all valid beams x pose likelihood), Gaussian proposal,
+//                     3x3 Cholesky, new pose, weight *= eta         (particle_filter.cpp:158-231)
+//   rbpf_raycast      one wave per particle: beams IN ORDER, cells of one ray in parallel (closed-form
+//                     Bresenham), log-odds += l_free / l_occ        (grid_mapper.cpp:140-178)
+//   rbpf_occupancy    wave per map row: cells with prob >= 0.9 (log-odds cut-off) -> bitmap + count
+//   rbpf_edt          exact squared Euclidean distance transform per particle (row pass by bit
+//                     scans, column pass by integer lower envelope in LDS) -> u16 code
+//                     (replaces the whole-map priority-queue brushfire, grid_mapper.cpp:333-435)
+//   rbpf_normalize    sequential-order normalise / Neff / low-variance selection
+//                                                                  (particle_filter.cpp:442-500)
+//   rbpf_gather       copy parents into the alternate buffers after a resample (:495 deep copies)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "common.hpp"
+#include "tbnav_rbpf.h"
+
+namespace {
+
+constexpr double kPI = 3.14159265358979323846;  // rigid2d.hpp:13
+constexpr int kWave = 64;
+constexpr int kProposeThreads = 256;
+constexpr uint16_t kCodeUnreached = 0xFFFF;
+constexpr int kMaxLds = 160 * 1024;
+
+// ---- small math shared by host and device ----------------------------------------------------------
+__host__ __device__ inline bool almost_equal(double a, double b, double eps = 1.0e-12) { return fabs(a - b) < eps; }
+__host__ __device__ inline double normalize_angle_PI(double rad) {  // rigid2d.hpp:52-64
+  const double q = floor((rad + kPI) / (2.0 * kPI));
+  rad = (rad + kPI) - q * 2.0 * kPI;
+  if (rad < 0) rad += 2.0 * kPI;
+  return (rad - kPI);
+}
+
+struct GridC {
+  double xmin, xmax, ymin, ymax, res;
+  int xsize, ysize, words;  // words = ceil(ysize / 64) u64 per bitmap row
+  double max_occ_dist;
+};
+
+struct ScanC {  // everything constant during one SLAM call
+  GridC g;
+  int N, k, Bv, icp_ok;
+  double Trs[3];                 // theta, x, y
+  double z_hit, var_hit, sqrt_inv_hit, rand_term;  // mixture: z_hit * N(z;0,var) + z_rand/z_max
+  double Ld[3], Lm[3];           // sqrt of sample_range / motion_noise diagonals (LLT of a diagonal)
+  double scan_min, scan_max, pose_min, pose_max;
+  double a1, a2, a3, a4;
+  double rot1, trans, rot2;      // odometry deltas, particle-independent (particle_filter.cpp:393-403)
+  double Ticp[3];
+  double u[3];                   // w, vx, vy
+  double d_free, d_occ, cut_occ; // log-odds increments and the host-derived occupied cut-off
+  int stride_normals;            // 3k+3 or 3
+};
+
+// world -> cell, grid_mapper.cpp:810-887.  false = outside the world (the reference throws).
+__device__ __forceinline__ bool world2cell(const GridC& g, double x, double y, int& ci, int& cj) {
+  if (!(x >= g.xmin && x <= g.xmax)) return false;
+  if (!(y >= g.ymin && y <= g.ymax)) return false;
+  double fi = floor((x - g.xmin) / g.res);
+  if (fi == g.xsize) fi -= 1.0;
+  double fj = floor((y - g.ymin) / g.res);
+  if (fj == g.ysize) fj -= 1.0;
+  ci = (int)fi;
+  cj = (int)fj;
+  return true;
+}
+
+__device__ __forceinline__ double code_to_dist(const GridC& g, uint16_t code) {
+  return code == kCodeUnreached ? g.max_occ_dist : sqrt((double)code) * g.res;
+}
+
+// grid_mapper.cpp:18-28 with the variance check hoisted (err set by the caller)
+__device__ __forceinline__ double pdf_normal(double a, double b) {
+  const double sqrt_inv = 1.0 / sqrt(2.0 * kPI * b);
+  const double var = -0.5 * (a * a) / b;
+  return sqrt_inv * exp(var);
+}
+
+__device__ __forceinline__ double wave_prod(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v *= __shfl_xor(v, off, 64);
+  return v;
+}
+
+// GridMapper::likelihoodFieldModel for ONE pose, evaluated by one wave (lanes stride the valid beams).
+// beams[b] = (r*cos a_b, r*sin a_b) in the sensor frame, built on the host exactly as
+// sensor_model.cpp:73-108 does.  Returns the product in every lane; *oob is set if a beam leaves
+// the world (the reference throws from world2RowMajor).
+__device__ __forceinline__ double wave_scan_likelihood(const ScanC& c, const double2* __restrict__ beams,
+                                                       const uint16_t* __restrict__ code, int n_occ,
+                                                       double th, double x, double y, int lane, int* oob) {
+  if (n_occ == 0) return 1.0;  // grid_mapper.cpp:94-98
+  // Tms = T(pose) * Trs  (rigid2d.cpp:214-224)
+  double s0, c0;
+  sincos(th, &s0, &c0);
+  const double X = c0 * c.Trs[1] - s0 * c.Trs[2] + x;
+  const double Y = s0 * c.Trs[1] + c0 * c.Trs[2] + y;
+  double st, ct;
+  sincos(th + c.Trs[0], &st, &ct);
+  double p = 1.0;
+  for (int b = lane; b < c.Bv; b += kWave) {
+    const double2 pt = beams[b];
+    const double ex = ct * pt.x - st * pt.y + X;
+    const double ey = st * pt.x + ct * pt.y + Y;
+    int ci, cj;
+    if (!world2cell(c.g, ex, ey, ci, cj)) { *oob = 1; continue; }
+    const double z = code_to_dist(c.g, code[(size_t)ci * c.g.xsize + cj]);
+    double pz = 0.0;
+    pz += c.z_hit * (c.sqrt_inv_hit * exp(-0.5 * (z * z) / c.var_hit));
+    pz += c.rand_term;
+    p *= pz;
+  }
+  return wave_prod(p);
+}
+
+// particle_filter.cpp:383-437 (odometry part precomputed on the host: rot1, trans, rot2)
+__device__ __forceinline__ double pose_likelihood_odom(const ScanC& c, const double* cur, const double* prev, int* var_err) {
+  const double rot1_hat = atan2(cur[2] - prev[2], cur[1] - prev[1]) - prev[0];
+  const double dx = cur[1] - prev[1], dy = cur[2] - prev[2];
+  const double trans_hat = sqrt(dx * dx + dy * dy);
+  const double rot2_hat = normalize_angle_PI(normalize_angle_PI(cur[0]) - normalize_angle_PI(prev[0]) - rot1_hat);
+  const double temp1 = c.a1 * rot1_hat * rot1_hat + c.a2 * trans_hat * trans_hat;
+  const double temp2 = c.a3 * trans_hat * trans_hat + c.a4 * rot1_hat * rot1_hat + c.a4 * rot2_hat * rot2_hat;
+  const double temp3 = c.a1 * rot2_hat * rot2_hat + c.a2 * trans_hat * trans_hat;
+  if (almost_equal(temp1, 0.0) || almost_equal(temp2, 0.0) || almost_equal(temp3, 0.0)) { *var_err = 1; return 0.0; }
+  const double p1 = pdf_normal(normalize_angle_PI(normalize_angle_PI(c.rot1) - normalize_angle_PI(rot1_hat)), temp1);
+  const double p2 = pdf_normal(c.trans - trans_hat, temp2);
+  const double p3 = pdf_normal(normalize_angle_PI(normalize_angle_PI(c.rot2) - normalize_angle_PI(rot2_hat)), temp3);
+  return p1 * p2 * p3;
+}
+
+// Eigen 3.3 unblocked lower LLT of a 3x3 (stops at a non-positive pivot, like llt_inplace)
+__device__ inline void llt3(const double A[3][3], double L[3][3]) {
+  double M[3][3];
+  for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) M[r][q] = A[r][q];
+  for (int kk = 0; kk < 3; ++kk) {
+    double x = M[kk][kk];
+    if (kk > 0) { double sq = 0.0; for (int q = 0; q < kk; ++q) sq += M[kk][q] * M[kk][q]; x -= sq; }
+    if (x <= 0.0) break;
+    x = sqrt(x);
+    M[kk][kk] = x;
+    for (int r = kk + 1; r < 3; ++r) {
+      if (kk > 0) { double dot = 0.0; for (int q = 0; q < kk; ++q) dot += M[r][q] * M[kk][q]; M[r][kk] -= dot; }
+      M[r][kk] /= x;
+    }
+  }
+  for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) L[r][q] = (q <= r) ? M[r][q] : 0.0;
+}
+
+struct Trace {
+  double *sampled, *p_scan, *p_pose, *mu, *sigma, *eta, *new_pose, *weight_raw;
+};
+
+// err[0] = out of world, err[1] = eta zero, err[2] = pdf variance zero, err[3] = bresenham
+__global__ __launch_bounds__(kProposeThreads) void rbpf_propose(ScanC c, const double2* __restrict__ beams,
+                                                                const uint16_t* __restrict__ codes,
+                                                                const int* __restrict__ n_occ,
+                                                                const double* __restrict__ normals,
+                                                                double* __restrict__ pose, double* __restrict__ prev_pose,
+                                                                double* __restrict__ weight, Trace tr, int* __restrict__ err) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int p = blockIdx.x;
+  const int k = c.k;
+  double* smp = lds;               // [k][3]
+  double* pscan = lds + 3 * k;     // [k]
+  double* ppose = lds + 4 * k;     // [k]
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
+  const uint16_t* code = codes + (size_t)p * c.g.xsize * c.g.ysize;
+  const double* z = normals + (size_t)p * c.stride_normals;
+  const int nocc = n_occ[p];
+  int oob = 0;
+
+  if (!c.icp_ok) {
+    // ICP failed: odometry motion model sample + scan likelihood (particle_filter.cpp:161-176, :295-322)
+    if (wid == 0) {
+      double th = pose[p * 3 + 0], x = pose[p * 3 + 1], y = pose[p * 3 + 2];
+      const double w0 = c.Lm[0] * z[0], w1 = c.Lm[1] * z[1], w2 = c.Lm[2] * z[2];
+      const double uw = c.u[0], uvx = c.u[1];
+      double nth, nx, ny;
+      if (almost_equal(uw, 0.0)) {
+        nth = normalize_angle_PI(th + w0);
+        nx = x + (uvx * cos(nth) + w1);
+        ny = y + (uvx * sin(nth) + w2);
+      } else {
+        nth = normalize_angle_PI(th + uw + w0);
+        nx = x + ((-uvx / uw) * sin(nth) + (uvx / uw) * sin(nth + uw) + w1);
+        ny = y + ((uvx / uw) * cos(nth) - (uvx / uw) * cos(nth + uw) + w2);
+      }
+      const double sl = wave_scan_likelihood(c, beams, code, nocc, nth, nx, ny, lane, &oob);
+      if (lane == 0) {
+        prev_pose[p * 3 + 0] = th; prev_pose[p * 3 + 1] = x; prev_pose[p * 3 + 2] = y;
+        pose[p * 3 + 0] = nth; pose[p * 3 + 1] = nx; pose[p * 3 + 2] = ny;
+        const double w = weight[p] * sl;
+        weight[p] = w;
+        tr.p_scan[(size_t)p * k] = sl;
+        tr.weight_raw[p] = w;
+        tr.new_pose[p * 3 + 0] = nth; tr.new_pose[p * 3 + 1] = nx; tr.new_pose[p * 3 + 2] = ny;
+      }
+      if (oob) atomicOr(&err[0], 1);
+    }
+    return;
+  }
+
+  // ---- sample k poses round T(pose) * T_icp (particle_filter.cpp:181-188, :504-519) and score the
+  //      odometry likelihood of each (:542), one thread per sample
+  const double th0 = pose[p * 3 + 0], x0 = pose[p * 3 + 1], y0 = pose[p * 3 + 2];
+  double s0, c0;
+  sincos(th0, &s0, &c0);
+  const double mu0[3] = {th0 + c.Ticp[0], c0 * c.Ticp[1] - s0 * c.Ticp[2] + x0, s0 * c.Ticp[1] + c0 * c.Ticp[2] + y0};
+  const double pv[3] = {prev_pose[p * 3 + 0], prev_pose[p * 3 + 1], prev_pose[p * 3 + 2]};
+  int var_err = 0;
+  for (int j = tid; j < k; j += kProposeThreads) {
+    double s[3];
+    for (int q = 0; q < 3; ++q) s[q] = mu0[q] + c.Ld[q] * z[3 * j + q];
+    s[0] = normalize_angle_PI(s[0]);
+    smp[3 * j + 0] = s[0]; smp[3 * j + 1] = s[1]; smp[3 * j + 2] = s[2];
+    ppose[j] = pose_likelihood_odom(c, s, pv, &var_err);
+  }
+  if (var_err) atomicOr(&err[2], 1);
+  __syncthreads();
+
+  // ---- scan likelihood of every sample (:541): one wave per sample, lanes over beams
+  for (int j = wid; j < k; j += kProposeThreads / kWave) {
+    const double sl = wave_scan_likelihood(c, beams, code, nocc, smp[3 * j + 0], smp[3 * j + 1], smp[3 * j + 2], lane, &oob);
+    if (lane == 0) pscan[j] = sl;
+  }
+  if (oob) atomicOr(&err[0], 1);
+  __syncthreads();
+
+  // ---- Gaussian proposal in the reference's sequential order (:522-599), new pose (:214-231)
+  if (tid == 0) {
+    double mu[3] = {0.0, 0.0, 0.0}, sigma[3][3] = {{0.0}}, eta = 0.0;
+    for (int j = 0; j < k; ++j) {
+      const double ps = fmin(fmax(pscan[j], c.scan_min), c.scan_max);  // std::clamp
+      const double pp = fmin(fmax(ppose[j], c.pose_min), c.pose_max);
+      const double pj = ps * pp;
+      tr.p_scan[(size_t)p * k + j] = pscan[j];
+      tr.p_pose[(size_t)p * k + j] = ppose[j];
+      tr.sampled[((size_t)p * k + j) * 3 + 0] = smp[3 * j + 0];
+      tr.sampled[((size_t)p * k + j) * 3 + 1] = smp[3 * j + 1];
+      tr.sampled[((size_t)p * k + j) * 3 + 2] = smp[3 * j + 2];
+      pscan[j] = pj;  // likelihoods.at(i)
+      for (int q = 0; q < 3; ++q) mu[q] += smp[3 * j + q] * pj;
+      eta += pj;
+    }
+    if (almost_equal(eta, 0.0)) { atomicOr(&err[1], 1); return; }
+    for (int q = 0; q < 3; ++q) mu[q] /= eta;
+    mu[0] = normalize_angle_PI(mu[0]);
+    for (int j = 0; j < k; ++j) {
+      const double d[3] = {smp[3 * j + 0] - mu[0], smp[3 * j + 1] - mu[1], smp[3 * j + 2] - mu[2]};
+      for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) sigma[r][q] += (d[r] * d[q]) * pscan[j];
+    }
+    for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) sigma[r][q] /= eta;
+    double L[3][3];
+    llt3(sigma, L);
+    const double* zz = z + 3 * k;
+    double np[3];
+    for (int r = 0; r < 3; ++r) np[r] = mu[r] + ((L[r][0] * zz[0] + L[r][1] * zz[1]) + L[r][2] * zz[2]);
+    prev_pose[p * 3 + 0] = th0; prev_pose[p * 3 + 1] = x0; prev_pose[p * 3 + 2] = y0;
+    for (int q = 0; q < 3; ++q) { pose[p * 3 + q] = np[q]; tr.new_pose[p * 3 + q] = np[q]; tr.mu[p * 3 + q] = mu[q]; }
+    for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) tr.sigma[p * 9 + r * 3 + q] = sigma[r][q];
+    tr.eta[p] = eta;
+    const double w = weight[p] * eta;
+    weight[p] = w;
+    tr.weight_raw[p] = w;
+  }
+}
+
+// ---- raycast ---------------------------------------------------------------------------------------
+// n-th free cell of the ray robot(x0,y0) -> endpoint(x1,y1), grid_mapper.cpp:549-807, in closed form:
+// Bresenham's error recurrence D > 0 <=> c_t < (2*dmin*t - dmaj)/(2*dmaj) gives the minor-axis offset
+// after t major steps  c_t = max(0, ceil((2*dmin*t - dmaj) / (2*dmaj)))  (checked against the
+// reference's loops for every octant in tests).  Reversed octants start from the endpoint side.
+struct Ray {
+  int kind, count;   // 0 vertical, 1 horizontal, 2 low, 3 high, 4 diagonal
+  int x0, y0, xa, ya, dmaj, dmin, sgn, sx, sy;
+};
+__device__ __forceinline__ Ray make_ray(int x0, int y0, int x1, int y1) {
+  Ray r;
+  r.x0 = x0; r.y0 = y0; r.xa = x0; r.ya = y0; r.dmaj = 0; r.dmin = 0; r.sgn = 1; r.sx = 1; r.sy = 1;
+  const int dx = x1 - x0, dy = y1 - y0;
+  const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
+  if (dx == 0) { r.kind = 0; r.count = ady; r.sy = dy < 0 ? -1 : 1; }
+  else if (dy == 0) { r.kind = 1; r.count = adx; r.sx = dx < 0 ? -1 : 1; }
+  else if (ady < adx) {
+    r.kind = 2; r.count = adx;
+    int xb, yb;
+    if (x0 > x1) { r.xa = x1; r.ya = y1; xb = x0; yb = y0; } else { xb = x1; yb = y1; }
+    r.dmaj = xb - r.xa;
+    const int d = yb - r.ya;
+    r.sgn = d < 0 ? -1 : 1;
+    r.dmin = d < 0 ? -d : d;
+  } else if (ady > adx) {
+    r.kind = 3; r.count = ady;
+    int xb, yb;
+    if (y0 > y1) { r.xa = x1; r.ya = y1; xb = x0; yb = y0; } else { xb = x1; yb = y1; }
+    r.dmaj = yb - r.ya;
+    const int d = xb - r.xa;
+    r.sgn = d < 0 ? -1 : 1;
+    r.dmin = d < 0 ? -d : d;
+  } else { r.kind = 4; r.count = adx; r.sx = dx < 0 ? -1 : 1; r.sy = dy < 0 ? -1 : 1; }
+  return r;
+}
+__device__ __forceinline__ void ray_cell(const Ray& r, int n, int& cx, int& cy) {
+  switch (r.kind) {
+    case 0: cx = r.x0; cy = r.y0 + r.sy * n; break;
+    case 1: cx = r.x0 + r.sx * n; cy = r.y0; break;
+    case 4: cx = r.x0 + r.sx * n; cy = r.y0 + r.sy * n; break;
+    default: {
+      if (n == 0) { cx = r.x0; cy = r.y0; break; }
+      const int a = 2 * r.dmin * n - r.dmaj;
+      const int ct = a > 0 ? (a + 2 * r.dmaj - 1) / (2 * r.dmaj) : 0;
+      if (r.kind == 2) { cx = r.xa + n; cy = r.ya + r.sgn * ct; }
+      else { cx = r.xa + r.sgn * ct; cy = r.ya + n; }
+    }
+  }
+}
+
+// One wave per particle.  Beams are applied IN ORDER (the per-cell floating-point add order is the
+// reference's); the cells of one ray are distinct, so the lanes of the wave update them in parallel
+// without atomics.  Endpoints are staged in LDS first.
+__global__ __launch_bounds__(kWave) void rbpf_raycast(ScanC c, const double2* __restrict__ beams,
+                                                     const double* __restrict__ pose, double* __restrict__ log_odds,
+                                                     int* __restrict__ err) {
+  extern __shared__ __attribute__((aligned(16))) int lds_i[];
+  int* ex = lds_i;         // [Bv]
+  int* ey = lds_i + c.Bv;  // [Bv]
+  __shared__ int bad;
+  const int p = blockIdx.x, lane = threadIdx.x;
+  double* lo = log_odds + (size_t)p * c.g.xsize * c.g.ysize;
+  const double th = pose[p * 3 + 0], x = pose[p * 3 + 1], y = pose[p * 3 + 2];
+  if (lane == 0) bad = 0;
+  __syncthreads();
+  double s0, c0;
+  sincos(th, &s0, &c0);
+  const double X = c0 * c.Trs[1] - s0 * c.Trs[2] + x;
+  const double Y = s0 * c.Trs[1] + c0 * c.Trs[2] + y;
+  double st, ct;
+  sincos(th + c.Trs[0], &st, &ct);
+  for (int b = lane; b < c.Bv; b += kWave) {
+    const double2 pt = beams[b];
+    int ci = 0, cj = 0;
+    if (!world2cell(c.g, ct * pt.x - st * pt.y + X, st * pt.x + ct * pt.y + Y, ci, cj)) bad = 1;
+    ex[b] = ci; ey[b] = cj;
+  }
+  int rx = 0, ry = 0;
+  if (!world2cell(c.g, x, y, rx, ry)) bad = 1;  // freeGridIndex: world2Grid of the ROBOT pose (:558)
+  __syncthreads();
+  if (bad) { if (lane == 0) atomicOr(&err[0], 1); return; }
+  const int xs = c.g.xsize;
+  for (int b = 0; b < c.Bv; ++b) {
+    const int x1 = ex[b], y1 = ey[b];
+    const Ray r = make_ray(rx, ry, x1, y1);
+    for (int n = lane; n < r.count; n += kWave) {
+      int cx, cy;
+      ray_cell(r, n, cx, cy);
+      const size_t idx = (size_t)cx * xs + cy;
+      lo[idx] = lo[idx] + c.d_free;
+    }
+    __syncthreads();  // free-cell adds of this beam land before the endpoint / next beam touch the cells
+    if (lane == 0) {
+      const size_t idx = (size_t)x1 * xs + y1;
+      lo[idx] = lo[idx] + c.d_occ;
+    }
+    __syncthreads();
+  }
+}
+
+// ---- occupancy bitmap ------------------------------------------------------------------------------
+// grid (rows/4, N), 256 threads: one wave per map row; lanes read the row coalesced.
+__global__ __launch_bounds__(256) void rbpf_occupancy(GridC g, double cut_occ, const double* __restrict__ log_odds,
+                                                      unsigned long long* __restrict__ bitmap, int* __restrict__ n_occ) {
+  const int p = blockIdx.y;
+  const int row = blockIdx.x * 4 + threadIdx.x / kWave;
+  const int lane = threadIdx.x & (kWave - 1);
+  if (row >= g.xsize) return;
+  const double* lo = log_odds + ((size_t)p * g.xsize + row) * g.ysize;
+  unsigned long long* bm = bitmap + ((size_t)p * g.xsize + row) * g.words;
+  int cnt = 0;
+  for (int w = 0; w < g.words; ++w) {
+    const int j = w * 64 + lane;
+    const bool occ = (j < g.ysize) && (lo[j] >= cut_occ);
+    const unsigned long long m = __ballot(occ);
+    if (lane == 0) bm[w] = m;
+    cnt += __popcll(m);
+  }
+  if (lane == 0 && cnt) atomicAdd(&n_occ[p], cnt);
+}
+
+// ---- exact distance transform ------------------------------------------------------------------------
+// distance (cells) from column j to the nearest set bit of a bitmap row, capped at `cap` (255 = none)
+__device__ __forceinline__ int row_nearest(const unsigned long long* row, int words, int j, int cap) {
+  const int w = j >> 6, b = j & 63;
+  int best = 1 << 20;
+  // at or left of j
+  unsigned long long m = row[w] & (b == 63 ? ~0ull : ((1ull << (b + 1)) - 1ull));
+  int ww = w;
+  while (true) {
+    if (m) { best = j - (ww * 64 + 63 - __clzll((long long)m)); break; }
+    if (--ww < 0 || (j - (ww * 64 + 63)) > cap) break;
+    m = row[ww];
+  }
+  // right of j
+  m = row[w] & ~(b == 63 ? ~0ull : ((1ull << (b + 1)) - 1ull));
+  ww = w;
+  while (true) {
+    if (m) { const int d = (ww * 64 + (__ffsll((long long)m) - 1)) - j; best = d < best ? d : best; break; }
+    if (++ww >= words || (ww * 64 - j) > cap) break;
+    m = row[ww];
+  }
+  return best <= cap ? best : 255;
+}
+
+__device__ __forceinline__ int floor_div(int num, int den) {  // den > 0
+  int q = num / den;
+  if ((num % den != 0) && (num < 0)) --q;
+  return q;
+}
+
+// grid (column tiles, N), C threads (one per column of the tile; C = 64 or 32).  LDS: the particle's
+// bitmap rows, f[xsize][C] u8 (row-pass distance, 255 = none), v[xsize][C] u16 and z[xsize][C] i16
+// (lower-envelope stack).  Integer arithmetic only: d2 = min_i' (i-i')^2 + f(i',j)^2 exactly.
+template <int C>
+__global__ __launch_bounds__(C) void rbpf_edt(GridC g, int radius, const unsigned long long* __restrict__ bitmap,
+                                              uint16_t* __restrict__ codes) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int xs = g.xsize, words = g.words;
+  unsigned long long* rows = reinterpret_cast<unsigned long long*>(lds_raw);            // [xs][words]
+  uint16_t* v = reinterpret_cast<uint16_t*>(lds_raw + (size_t)xs * words * 8);          // [xs][C]
+  int16_t* z = reinterpret_cast<int16_t*>(lds_raw + (size_t)xs * words * 8 + (size_t)xs * C * 2);  // [xs][C]
+  uint8_t* f = lds_raw + (size_t)xs * words * 8 + (size_t)xs * C * 4;                   // [xs][C]
+  const int p = blockIdx.y, lane = threadIdx.x;
+  const int j = blockIdx.x * C + lane;
+  const unsigned long long* bm = bitmap + (size_t)p * xs * words;
+  for (int t = lane; t < xs * words; t += C) rows[t] = bm[t];
+  __syncthreads();
+  if (j >= g.ysize) return;
+  // row pass
+  for (int i = 0; i < xs; ++i) f[i * C + lane] = (uint8_t)row_nearest(rows + (size_t)i * words, words, j, radius);
+  // lower envelope of the parabolas (i - q)^2 + f(q)^2 over rows q with f(q) finite
+  int top = -1;
+  for (int q = 0; q < xs; ++q) {
+    const int fq = f[q * C + lane];
+    if (fq == 255) continue;
+    const int hq = fq * fq + q * q;
+    int s = -32768;
+    while (top >= 0) {
+      const int vq = v[top * C + lane];
+      const int fv = f[vq * C + lane];
+      s = floor_div(hq - (fv * fv + vq * vq), 2 * (q - vq));
+      if (s <= z[top * C + lane]) --top; else break;
+    }
+    ++top;
+    v[top * C + lane] = (uint16_t)q;
+    if (top == 0) s = -32768;
+    z[top * C + lane] = (int16_t)(s < -32768 ? -32768 : (s > 32767 ? 32767 : s));
+  }
+  uint16_t* out = codes + (size_t)p * xs * g.ysize;
+  if (top < 0) return;  // nothing within reach of this column: every cell keeps its previous value
+  const int r2 = radius * radius;
+  int kk = 0;
+  for (int i = 0; i < xs; ++i) {
+    while (kk < top && z[(kk + 1) * C + lane] < i) ++kk;
+    const int vq = v[kk * C + lane];
+    const int fv = f[vq * C + lane];
+    const int d2 = (i - vq) * (i - vq) + fv * fv;
+    // farther than cell_radius_: the reference never writes such a cell (grid_mapper.cpp:310-313)
+    if (d2 <= r2) out[(size_t)i * g.ysize + j] = (uint16_t)d2;
+  }
+}
+
+// ---- normalise / Neff / low-variance selection (sequential order = the reference's) ---------------
+struct NormOut { double sum_w, sq_sum; int neff, resampled; };
+__global__ void rbpf_normalize(int N, double z, double* __restrict__ weight, int* __restrict__ parent, NormOut* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double sum = 0.0;
+  for (int i = 0; i < N; ++i) sum += weight[i];
+  double sq = 0.0;
+  for (int i = 0; i < N; ++i) { const double w = weight[i] / sum; weight[i] = w; sq += w * w; }
+  const int neff = (int)(1.0 / sq);
+  const int res = (neff < (N / 2)) ? 1 : 0;
+  out->sum_w = sum; out->sq_sum = sq; out->neff = neff; out->resampled = res;
+  if (!res) { for (int m = 0; m < N; ++m) parent[m] = m; return; }
+  const double r = z / (double)N;
+  double cacc = weight[0];
+  int i = 0;
+  for (int m = 0; m < N; ++m) {
+    const double U = r + (double)(m * (1.0 / (N - 1)));
+    while (U > cacc) {
+      i++;
+      if (i > N - 1) { i = N - 1; break; }
+      cacc += weight[i];
+    }
+    parent[m] = i;
+  }
+}
+
+// grid (chunks, N): slot m <- parent[m] for maps and state (particle_filter.cpp:495 deep copy)
+__global__ __launch_bounds__(256) void rbpf_gather(int N, size_t G, int words_total, const int* __restrict__ parent,
+                                                   const double* __restrict__ lo_src, double* __restrict__ lo_dst,
+                                                   const uint16_t* __restrict__ cd_src, uint16_t* __restrict__ cd_dst,
+                                                   const int* __restrict__ nocc_src, int* __restrict__ nocc_dst) {
+  const int m = blockIdx.y;
+  const int src = parent[m];
+  if (src < 0) return;
+  const double2* a = reinterpret_cast<const double2*>(lo_src + (size_t)src * G);
+  double2* b = reinterpret_cast<double2*>(lo_dst + (size_t)m * G);
+  const size_t n2 = G / 2;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n2; t += (size_t)gridDim.x * blockDim.x) b[t] = a[t];
+  const uint2* ca = reinterpret_cast<const uint2*>(cd_src + (size_t)src * G);
+  uint2* cb = reinterpret_cast<uint2*>(cd_dst + (size_t)m * G);
+  const size_t n4 = G / 4;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += (size_t)gridDim.x * blockDim.x) cb[t] = ca[t];
+  if (blockIdx.x == 0 && threadIdx.x == 0) nocc_dst[m] = nocc_src[src];  // pose/weight are gathered by the host side
+  (void)N; (void)words_total;
+}
+
+}  // namespace
+
+// =================================================================================================
+// Handle + C-ABI
+// =================================================================================================
+struct tbnav_rbpf {
+  tbnav_rbpf_params p;
+  int device = 0, N = 0, k = 0, xsize = 0, ysize = 0, words = 0, radius = 0, edt_cols = 64;
+  size_t G = 0;
+  double l_prior = 0, l_occ = 0, l_free = 0, cut_occ = 0, max_occ_dist = 10.0;
+  // particle state: [N][7] = pose(3), prev_pose(3), weight — double-buffered with the maps
+  double* d_state[2] = {nullptr, nullptr};
+  double* d_log_odds[2] = {nullptr, nullptr};
+  uint16_t* d_code[2] = {nullptr, nullptr};
+  int* d_nocc[2] = {nullptr, nullptr};
+  int cur = 0;
+  unsigned long long* d_bitmap = nullptr;
+  double2* d_beams = nullptr;  // capacity max_beams
+  int max_beams = 0;
+  double* d_normals = nullptr;
+  size_t normals_cap = 0;
+  int* d_parent = nullptr;
+  int* d_err = nullptr;
+  NormOut* d_norm = nullptr;
+  double* d_trace = nullptr;   // sampled, p_scan, p_pose, mu, sigma, eta, new_pose, weight_raw
+  Trace tr{};
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[TBNAV_RBPF_NKERNELS + 2] = {};  // 0..5 bracket kernels 0..4; 6,7 bracket the gather
+  float last_ms[TBNAV_RBPF_NKERNELS] = {0};
+  std::vector<int> h_parent;
+};
+
+namespace {
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(dev) == hipSuccess) ok = true; }
+  ~DeviceGuard() { if (ok && prev >= 0) (void)hipSetDevice(prev); }
+};
+
+// state layout helpers: the kernels take pose / prev_pose / weight pointers with [N][3] / [N] strides,
+// so the 7-double record is split into three arrays inside one allocation.
+struct StatePtrs { double *pose, *prev, *weight; };
+StatePtrs state_ptrs(double* base, int N) { return {base, base + (size_t)3 * N, base + (size_t)6 * N}; }
+
+double logodds_to_prob(double l) { return 1 - (1 / (1 + std::exp(l))); }  // grid_mapper.hpp:27-30 (glibc on the host)
+
+// smallest l with prob(l) >= p_occ, found by bisection on the host (prob is monotone in l)
+double find_occ_cut(double l_occ_nominal, double p_occ) {
+  double lo = l_occ_nominal - 1.0, hi = l_occ_nominal + 1.0;  // prob(lo) < p_occ <= prob(hi)
+  for (int it = 0; it < 200; ++it) {
+    const double mid = 0.5 * (lo + hi);
+    if (mid == lo || mid == hi) break;
+    if (logodds_to_prob(mid) >= p_occ) hi = mid; else lo = mid;
+  }
+  return hi;
+}
+
+size_t edt_lds_bytes(int xs, int words, int C) { return (size_t)xs * words * 8 + (size_t)xs * C * 5; }
+
+int build_scan_consts(tbnav_rbpf* h, ScanC& c, const float* scan, int n_beams, const double u[3],
+                      const double cur_odom[3], const double prev_odom[3], int icp_ok, const double T_icp[3],
+                      std::vector<double2>& beams) {
+  const tbnav_rbpf_params& P = h->p;
+  c.g = GridC{P.xmin, P.xmax, P.ymin, P.ymax, P.resolution, h->xsize, h->ysize, h->words, h->max_occ_dist};
+  c.N = h->N; c.k = h->k; c.icp_ok = icp_ok ? 1 : 0;
+  for (int q = 0; q < 3; ++q) { c.Trs[q] = P.Trs[q]; c.Ld[q] = std::sqrt(P.sample_range[q]); c.Lm[q] = std::sqrt(P.motion_noise[q]);
+                                c.Ticp[q] = T_icp[q]; c.u[q] = u[q]; }
+  c.z_hit = P.z_hit;
+  c.var_hit = P.sigma_hit * P.sigma_hit;                       // grid_mapper.cpp:77
+  if (almost_equal(c.var_hit, 0.0)) return TBNAV_ERR_PDF_VARIANCE;
+  c.sqrt_inv_hit = 1.0 / std::sqrt(2.0 * kPI * c.var_hit);    // pdfNormal, grid_mapper.cpp:25
+  c.rand_term = P.z_rand / P.z_max;                            // grid_mapper.cpp:121
+  c.scan_min = P.scan_likelihood_min; c.scan_max = P.scan_likelihood_max;
+  c.pose_min = P.pose_likelihood_min; c.pose_max = P.pose_likelihood_max;
+  c.a1 = P.srr; c.a2 = P.srt; c.a3 = P.str_; c.a4 = P.stt;
+  // odometry deltas (particle_filter.cpp:393-403), identical for every particle and sample
+  c.rot1 = std::atan2(cur_odom[2] - prev_odom[2], cur_odom[1] - prev_odom[1]) - prev_odom[0];
+  const double dxo = cur_odom[1] - prev_odom[1], dyo = cur_odom[2] - prev_odom[2];
+  c.trans = std::sqrt(dxo * dxo + dyo * dyo);
+  c.rot2 = normalize_angle_PI(normalize_angle_PI(cur_odom[0]) - normalize_angle_PI(prev_odom[0]) - c.rot1);
+  c.d_free = h->l_free - h->l_prior;
+  c.d_occ = h->l_occ - h->l_prior;
+  c.cut_occ = h->cut_occ;
+  c.stride_normals = icp_ok ? 3 * h->k + 3 : 3;
+  // valid beams in the sensor frame, sensor_model.cpp:73-108 (float limits, double angle accumulation)
+  beams.clear();
+  double beam_angle = P.beam_min;
+  for (int i = 0; i < n_beams; ++i) {
+    const double range = scan[i];
+    if (range >= P.range_min && range < P.range_max) beams.push_back(double2{range * std::cos(beam_angle), range * std::sin(beam_angle)});
+    beam_angle += P.beam_delta;
+    if (P.beam_max < 0.0 && beam_angle <= P.beam_max) beam_angle = P.beam_min;
+    else if (P.beam_max >= 0.0 && beam_angle >= P.beam_max) beam_angle = P.beam_min;
+  }
+  c.Bv = (int)beams.size();
+  return TBNAV_OK;
+}
+
+int status_from_err(const int err[4]) {
+  if (err[0]) return TBNAV_ERR_OUT_OF_WORLD;
+  if (err[2]) return TBNAV_ERR_PDF_VARIANCE;
+  if (err[1]) return TBNAV_ERR_ETA_ZERO;
+  if (err[3]) return TBNAV_ERR_BRESENHAM;
+  return TBNAV_OK;
+}
+
+int run_distance_field(tbnav_rbpf* h, const GridC& g, hipEvent_t e_mid) {
+  hipStream_t st = h->stream;
+  TBNAV_HIP(hipMemsetAsync(h->d_nocc[h->cur], 0, sizeof(int) * h->N, st));
+  hipLaunchKernelGGL(rbpf_occupancy, dim3((h->xsize + 3) / 4, h->N), dim3(256), 0, st, g, h->cut_occ,
+                     h->d_log_odds[h->cur], h->d_bitmap, h->d_nocc[h->cur]);
+  TBNAV_HIP(hipGetLastError());
+  if (e_mid) TBNAV_HIP(hipEventRecord(e_mid, st));
+  const int C = h->edt_cols;
+  const size_t lds = edt_lds_bytes(h->xsize, h->words, C);
+  const dim3 grid((h->ysize + C - 1) / C, h->N);
+  if (C == 64) hipLaunchKernelGGL(rbpf_edt<64>, grid, dim3(64), lds, st, g, h->radius, h->d_bitmap, h->d_code[h->cur]);
+  else hipLaunchKernelGGL(rbpf_edt<32>, grid, dim3(32), lds, st, g, h->radius, h->d_bitmap, h->d_code[h->cur]);
+  TBNAV_HIP(hipGetLastError());
+  return TBNAV_OK;
+}
+
+int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], const double cur_odom[3],
+              const double prev_odom[3], int icp_ok, const double T_icp[3], const double* normals,
+              tbnav_rbpf_stats* out, bool local_only) {
+  if (!h || !scan || n_beams <= 0 || !u || !cur_odom || !prev_odom || !T_icp || !normals || !out) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  hipStream_t st = h->stream;
+  ScanC c;
+  std::vector<double2> beams;
+  int rc = build_scan_consts(h, c, scan, n_beams, u, cur_odom, prev_odom, icp_ok, T_icp, beams);
+  std::memset(out, 0, sizeof *out);
+  if (rc != TBNAV_OK) { out->status = rc; return rc; }
+  out->n_valid_beams = c.Bv;
+  if (n_beams > h->max_beams) {
+    (void)hipFree(h->d_beams);
+    h->d_beams = nullptr;
+    TBNAV_HIP(hipMalloc((void**)&h->d_beams, sizeof(double2) * n_beams));
+    h->max_beams = n_beams;
+  }
+  const size_t n_norm = (size_t)h->N * c.stride_normals + 1;
+  if (n_norm > h->normals_cap) {
+    (void)hipFree(h->d_normals);
+    h->d_normals = nullptr;
+    TBNAV_HIP(hipMalloc((void**)&h->d_normals, sizeof(double) * n_norm));
+    h->normals_cap = n_norm;
+  }
+  if (c.Bv) TBNAV_HIP(hipMemcpyAsync(h->d_beams, beams.data(), sizeof(double2) * c.Bv, hipMemcpyHostToDevice, st));
+  TBNAV_HIP(hipMemcpyAsync(h->d_normals, normals, sizeof(double) * n_norm, hipMemcpyHostToDevice, st));
+  TBNAV_HIP(hipMemsetAsync(h->d_err, 0, sizeof(int) * 4, st));
+  StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
+
+  TBNAV_HIP(hipEventRecord(h->ev[0], st));
+  hipLaunchKernelGGL(rbpf_propose, dim3(h->N), dim3(kProposeThreads), sizeof(double) * 5 * h->k, st, c, h->d_beams,
+                     h->d_code[h->cur], h->d_nocc[h->cur], h->d_normals, sp.pose, sp.prev, sp.weight, h->tr, h->d_err);
+  TBNAV_HIP(hipGetLastError());
+  TBNAV_HIP(hipEventRecord(h->ev[1], st));
+  hipLaunchKernelGGL(rbpf_raycast, dim3(h->N), dim3(kWave), sizeof(int) * 2 * (c.Bv > 0 ? c.Bv : 1), st, c, h->d_beams,
+                     sp.pose, h->d_log_odds[h->cur], h->d_err);
+  TBNAV_HIP(hipGetLastError());
+  TBNAV_HIP(hipEventRecord(h->ev[2], st));
+  rc = run_distance_field(h, c.g, h->ev[3]);
+  if (rc != TBNAV_OK) return rc;
+  TBNAV_HIP(hipEventRecord(h->ev[4], st));
+  if (!local_only) {
+    const double z = normals[(size_t)h->N * c.stride_normals];
+    hipLaunchKernelGGL(rbpf_normalize, dim3(1), dim3(64), 0, st, h->N, z, sp.weight, h->d_parent, h->d_norm);
+    TBNAV_HIP(hipGetLastError());
+  }
+  TBNAV_HIP(hipEventRecord(h->ev[5], st));
+  int err[4];
+  NormOut no{};
+  TBNAV_HIP(hipMemcpyAsync(err, h->d_err, sizeof err, hipMemcpyDeviceToHost, st));
+  if (!local_only) TBNAV_HIP(hipMemcpyAsync(&no, h->d_norm, sizeof no, hipMemcpyDeviceToHost, st));
+  TBNAV_HIP(hipStreamSynchronize(st));
+  out->status = status_from_err(err);
+  out->sum_w = no.sum_w; out->sq_sum = no.sq_sum; out->neff = no.neff; out->resampled = no.resampled;
+  bool gathered = false;
+  if (!local_only && no.resampled && out->status == TBNAV_OK) {
+    const int nxt = 1 - h->cur;
+    TBNAV_HIP(hipEventRecord(h->ev[6], st));
+    hipLaunchKernelGGL(rbpf_gather, dim3(16, h->N), dim3(256), 0, st, h->N, h->G, 0, h->d_parent, h->d_log_odds[h->cur],
+                       h->d_log_odds[nxt], h->d_code[h->cur], h->d_code[nxt], h->d_nocc[h->cur], h->d_nocc[nxt]);
+    TBNAV_HIP(hipGetLastError());
+    TBNAV_HIP(hipEventRecord(h->ev[7], st));
+    gathered = true;
+  }
+  TBNAV_HIP(hipStreamSynchronize(st));
+  for (int i = 0; i < TBNAV_RBPF_NKERNELS - 1; ++i) TBNAV_HIP(hipEventElapsedTime(&h->last_ms[i], h->ev[i], h->ev[i + 1]));
+  h->last_ms[5] = 0.f;
+  if (gathered) TBNAV_HIP(hipEventElapsedTime(&h->last_ms[5], h->ev[6], h->ev[7]));
+  if (gathered) {
+    // particle state is tiny: gather it on the host side of the boundary (pose, prev_pose, weight)
+    const int N = h->N, nxt = 1 - h->cur;
+    std::vector<double> s((size_t)7 * N), d((size_t)7 * N);
+    h->h_parent.resize(N);
+    TBNAV_HIP(hipMemcpy(s.data(), h->d_state[h->cur], sizeof(double) * 7 * N, hipMemcpyDeviceToHost));
+    TBNAV_HIP(hipMemcpy(h->h_parent.data(), h->d_parent, sizeof(int) * N, hipMemcpyDeviceToHost));
+    for (int m = 0; m < N; ++m) {
+      const int src = h->h_parent[m];
+      for (int q = 0; q < 3; ++q) { d[(size_t)m * 3 + q] = s[(size_t)src * 3 + q]; d[(size_t)3 * N + m * 3 + q] = s[(size_t)3 * N + src * 3 + q]; }
+      d[(size_t)6 * N + m] = s[(size_t)6 * N + src];  // weights are NOT reset (particle_filter.cpp:495)
+    }
+    TBNAV_HIP(hipMemcpy(h->d_state[nxt], d.data(), sizeof(double) * 7 * N, hipMemcpyHostToDevice));
+    h->cur = nxt;
+  }
+  return out->status;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) {
+  if (!P || !out) return TBNAV_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (P->num_particles <= 0 || P->num_samples_mode <= 0 || !(P->resolution > 0.0) || !(P->xmax > P->xmin) || !(P->ymax > P->ymin))
+    return TBNAV_ERR_INVALID_ARG;
+  const int xsize = (int)static_cast<unsigned int>(std::ceil((P->xmax - P->xmin) / P->resolution));  // mapSize, grid_mapper.cpp:31-34
+  const int ysize = (int)static_cast<unsigned int>(std::ceil((P->ymax - P->ymin) / P->resolution));
+  if (xsize != ysize) return TBNAV_ERR_UNSUPPORTED;  // the reference indexes both axes with xsize_ (grid_mapper.cpp:195-197,896)
+  if (xsize < 4 || xsize > 32000 || (xsize & 1)) return TBNAV_ERR_UNSUPPORTED;  // vectorised map copies need G % 4 == 0
+  if (P->num_particles > 65535) return TBNAV_ERR_UNSUPPORTED;                  // particle index rides in gridDim.y
+  const int radius = (int)static_cast<unsigned int>(std::ceil((10.0 - 0.0) / P->resolution));         // cell_radius_, grid_mapper.cpp:50
+  if (radius > 254) return TBNAV_ERR_UNSUPPORTED;  // row-pass distances are stored as u8 (and radius^2 must fit the u16 code)
+  const int words = (ysize + 63) / 64;
+  int C = 64;
+  if (edt_lds_bytes(xsize, words, C) > (size_t)kMaxLds) C = 32;
+  if (edt_lds_bytes(xsize, words, C) > (size_t)kMaxLds) return TBNAV_ERR_UNSUPPORTED;
+  int ndev = 0;
+  {
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+      return tbnav::hip_fail(e == hipSuccess ? hipErrorNoDevice : e, "hipGetDeviceCount", __FILE__, __LINE__);
+  }
+  int dev = P->device;
+  if (dev < 0) TBNAV_HIP(hipGetDevice(&dev));
+  if (dev >= ndev) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(dev);
+  if (!guard.ok) return TBNAV_ERR_NO_DEVICE;
+
+  tbnav_rbpf* h = new (std::nothrow) tbnav_rbpf();
+  if (!h) return TBNAV_ERR_INVALID_ARG;
+  h->p = *P; h->device = dev; h->N = P->num_particles; h->k = P->num_samples_mode;
+  h->xsize = xsize; h->ysize = ysize; h->words = words; h->radius = radius; h->edt_cols = C;
+  h->G = (size_t)xsize * ysize;
+  // log-odds constants with the host libm, exactly as the reference's ctor (grid_mapper.cpp:42-47)
+  h->l_prior = std::log(0.5 / (1 - 0.5));
+  h->l_occ = std::log(0.90 / (1 - 0.90));
+  h->l_free = std::log(0.35 / (1 - 0.35));
+  h->cut_occ = find_occ_cut(h->l_occ, 0.90);
+  const int N = h->N;
+  hipError_t e = hipSuccess;
+  auto A = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
+  for (int b = 0; b < 2; ++b) {
+    A((void**)&h->d_state[b], sizeof(double) * 7 * N);
+    A((void**)&h->d_log_odds[b], sizeof(double) * h->G * N);
+    A((void**)&h->d_code[b], sizeof(uint16_t) * h->G * N);
+    A((void**)&h->d_nocc[b], sizeof(int) * N);
+  }
+  A((void**)&h->d_bitmap, sizeof(unsigned long long) * (size_t)N * xsize * words);
+  A((void**)&h->d_parent, sizeof(int) * N);
+  A((void**)&h->d_err, sizeof(int) * 4);
+  A((void**)&h->d_norm, sizeof(NormOut));
+  const size_t kk = (size_t)h->k;
+  const size_t trace_doubles = (size_t)N * (kk * 3 + kk + kk + 3 + 9 + 1 + 3 + 1);
+  A((void**)&h->d_trace, sizeof(double) * trace_doubles);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  for (auto& ev : h->ev) if (e == hipSuccess) e = hipEventCreate(&ev);
+  if (e == hipSuccess) {
+    double* t = h->d_trace;
+    h->tr.sampled = t; t += (size_t)N * kk * 3;
+    h->tr.p_scan = t; t += (size_t)N * kk;
+    h->tr.p_pose = t; t += (size_t)N * kk;
+    h->tr.mu = t; t += (size_t)N * 3;
+    h->tr.sigma = t; t += (size_t)N * 9;
+    h->tr.eta = t; t += (size_t)N;
+    h->tr.new_pose = t; t += (size_t)N * 3;
+    h->tr.weight_raw = t;
+    e = hipMemset(h->d_trace, 0, sizeof(double) * trace_doubles);
+  }
+  if (e == hipSuccess) {  // initParticleSet, particle_filter.cpp:125-138
+    std::vector<double> s((size_t)7 * N);
+    for (int i = 0; i < N; ++i) {
+      for (int q = 0; q < 3; ++q) { s[(size_t)i * 3 + q] = P->pose0[q]; s[(size_t)3 * N + i * 3 + q] = P->pose0[q]; }
+      s[(size_t)6 * N + i] = 1.0 / N;
+    }
+    e = hipMemcpy(h->d_state[0], s.data(), sizeof(double) * 7 * N, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(h->d_log_odds[0], 0, sizeof(double) * h->G * N);  // log_odds_prior_ = log(1) = 0
+    if (e == hipSuccess) e = hipMemset(h->d_code[0], 0xFF, sizeof(uint16_t) * h->G * N);  // occ_dist = max_occ_dist_
+    if (e == hipSuccess) e = hipMemset(h->d_nocc[0], 0, sizeof(int) * N);
+  }
+  if (e == hipSuccess) {
+    const int lds = (int)edt_lds_bytes(xsize, words, C);
+    e = (C == 64) ? hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_edt<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)
+                  : hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_edt<32>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  }
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {
+    const int rc = tbnav::hip_fail(e, "tbnav_rbpf_create allocation", __FILE__, __LINE__);
+    tbnav_rbpf_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return TBNAV_OK;
+}
+
+void tbnav_rbpf_destroy(tbnav_rbpf* h) {
+  if (!h) return;
+  DeviceGuard guard(h->device);
+  for (int b = 0; b < 2; ++b) { (void)hipFree(h->d_state[b]); (void)hipFree(h->d_log_odds[b]); (void)hipFree(h->d_code[b]); (void)hipFree(h->d_nocc[b]); }
+  (void)hipFree(h->d_bitmap); (void)hipFree(h->d_beams); (void)hipFree(h->d_normals); (void)hipFree(h->d_parent);
+  (void)hipFree(h->d_err); (void)hipFree(h->d_norm); (void)hipFree(h->d_trace);
+  for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int tbnav_rbpf_grid_size(const tbnav_rbpf* h, int32_t* xsize, int32_t* ysize) {
+  if (!h || !xsize || !ysize) return TBNAV_ERR_INVALID_ARG;
+  *xsize = h->xsize; *ysize = h->ysize;
+  return TBNAV_OK;
+}
+
+int64_t tbnav_rbpf_num_normals(const tbnav_rbpf* h, int32_t icp_ok) {
+  if (!h) return -1;
+  return (int64_t)h->N * (icp_ok ? 3 * h->k + 3 : 3) + 1;
+}
+
+int tbnav_rbpf_slam(tbnav_rbpf* h, const float* scan, int32_t n_beams, const double u[3], const double cur_odom[3],
+                    const double prev_odom[3], int32_t icp_ok, const double T_icp[3], const double* normals,
+                    tbnav_rbpf_stats* out) {
+  return slam_impl(h, scan, n_beams, u, cur_odom, prev_odom, icp_ok, T_icp, normals, out, false);
+}
+
+int tbnav_rbpf_slam_local(tbnav_rbpf* h, const float* scan, int32_t n_beams, const double u[3], const double cur_odom[3],
+                          const double prev_odom[3], int32_t icp_ok, const double T_icp[3], const double* normals,
+                          tbnav_rbpf_stats* out) {
+  return slam_impl(h, scan, n_beams, u, cur_odom, prev_odom, icp_ok, T_icp, normals, out, true);
+}
+
+// Host-side, sequential, bit-faithful: O(n_global) double adds — the exchange step of the sharded
+// filter; every rank runs it on the same all-gathered weights.
+int tbnav_rbpf_resample_global(const double* w, int64_t n, double z, int32_t* parents, double* wn, tbnav_rbpf_stats* out) {
+  if (!w || n <= 0 || !parents || !wn || !out) return TBNAV_ERR_INVALID_ARG;
+  std::memset(out, 0, sizeof *out);
+  double sum = 0.0;
+  for (int64_t i = 0; i < n; ++i) sum += w[i];
+  double sq = 0.0;
+  for (int64_t i = 0; i < n; ++i) { wn[i] = w[i] / sum; sq += wn[i] * wn[i]; }
+  out->sum_w = sum; out->sq_sum = sq;
+  out->neff = static_cast<int>(1.0 / sq);
+  const int N = (int)n;
+  out->resampled = (out->neff < (N / 2)) ? 1 : 0;
+  if (!out->resampled) { for (int m = 0; m < N; ++m) parents[m] = m; return TBNAV_OK; }
+  const double r = z / static_cast<double>(N);
+  double c = wn[0];
+  int i = 0;
+  for (int m = 0; m < N; ++m) {
+    const double U = r + static_cast<double>(m * (1.0 / (N - 1)));
+    while (U > c) {
+      i++;
+      if (i > N - 1) { i = N - 1; break; }
+      c += wn[i];
+    }
+    parents[m] = i;
+  }
+  return TBNAV_OK;
+}
+
+int tbnav_rbpf_gather_local(tbnav_rbpf* h, const int32_t* local_parent) {
+  if (!h || !local_parent) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  const int N = h->N, nxt = 1 - h->cur;
+  hipStream_t st = h->stream;
+  TBNAV_HIP(hipMemcpyAsync(h->d_parent, local_parent, sizeof(int) * N, hipMemcpyHostToDevice, st));
+  // slots with parent -1 keep their own content: copy self
+  std::vector<int> par(local_parent, local_parent + N);
+  for (int m = 0; m < N; ++m) if (par[m] < 0) par[m] = m;
+  TBNAV_HIP(hipMemcpyAsync(h->d_parent, par.data(), sizeof(int) * N, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(rbpf_gather, dim3(16, N), dim3(256), 0, st, N, h->G, 0, h->d_parent, h->d_log_odds[h->cur],
+                     h->d_log_odds[nxt], h->d_code[h->cur], h->d_code[nxt], h->d_nocc[h->cur], h->d_nocc[nxt]);
+  TBNAV_HIP(hipGetLastError());
+  TBNAV_HIP(hipStreamSynchronize(st));
+  std::vector<double> s((size_t)7 * N), d((size_t)7 * N);
+  TBNAV_HIP(hipMemcpy(s.data(), h->d_state[h->cur], sizeof(double) * 7 * N, hipMemcpyDeviceToHost));
+  for (int m = 0; m < N; ++m) {
+    const int src = par[m];
+    for (int q = 0; q < 3; ++q) { d[(size_t)m * 3 + q] = s[(size_t)src * 3 + q]; d[(size_t)3 * N + m * 3 + q] = s[(size_t)3 * N + src * 3 + q]; }
+    d[(size_t)6 * N + m] = s[(size_t)6 * N + src];
+  }
+  TBNAV_HIP(hipMemcpy(h->d_state[nxt], d.data(), sizeof(double) * 7 * N, hipMemcpyHostToDevice));
+  h->cur = nxt;
+  return TBNAV_OK;
+}
+
+int tbnav_rbpf_get_particles(tbnav_rbpf* h, double* pose, double* prev_pose, double* weight) {
+  if (!h) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  const int N = h->N;
+  StatePtrs sp = state_ptrs(h->d_state[h->cur], N);
+  TBNAV_HIP(hipStreamSynchronize(h->stream));
+  if (pose) TBNAV_HIP(hipMemcpy(pose, sp.pose, sizeof(double) * 3 * N, hipMemcpyDeviceToHost));
+  if (prev_pose) TBNAV_HIP(hipMemcpy(prev_pose, sp.prev, sizeof(double) * 3 * N, hipMemcpyDeviceToHost));
+  if (weight) TBNAV_HIP(hipMemcpy(weight, sp.weight, sizeof(double) * N, hipMemcpyDeviceToHost));
+  return TBNAV_OK;
+}
+
+int tbnav_rbpf_set_particles(tbnav_rbpf* h, const double* pose, const double* prev_pose, const double* weight) {
+  if (!h) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  const int N = h->N;
+  StatePtrs sp = state_ptrs(h->d_state[h->cur], N);
+  TBNAV_HIP(hipStreamSynchronize(h->stream));
+  if (pose) TBNAV_HIP(hipMemcpy(sp.pose, pose, sizeof(double) * 3 * N, hipMemcpyHostToDevice));
+  if (prev_pose) TBNAV_HIP(hipMemcpy(sp.prev, prev_pose, sizeof(double) * 3 * N, hipMemcpyHostToDevice));
+  if (weight) TBNAV_HIP(hipMemcpy(sp.weight, weight, sizeof(double) * N, hipMemcpyHostToDevice));
+  return TBNAV_OK;
+}
+
+int tbnav_rbpf_get_log_odds(tbnav_rbpf* h, int32_t particle, double* out) {
+  if (!h || !out || particle < 0 || particle >= h->N) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  TBNAV_HIP(hipStreamSynchronize(h->stream));
+  TBNAV_HIP(hipMemcpy(out, h->d_log_odds[h->cur] + (size_t)particle * h->G, sizeof(double) * h->G, hipMemcpyDeviceToHost));
+  return TBNAV_OK;
+}
+
+int tbnav_rbpf_set_log_odds(tbnav_rbpf* h, int32_t particle, const double* in) {
+  if (!h || !in || particle < 0 || particle >= h->N) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  TBNAV_HIP(hipStreamSynchronize(h->stream));
+  TBNAV_HIP(hipMemcpy(h->d_log_odds[h->cur] + (size_t)particle * h->G, in, sizeof(double) * h->G, hipMemcpyHostToDevice));
+  // refresh the occupied count (likelihoodFieldModel's "map has no obstacles" test, grid_mapper.cpp:94)
+  int cnt = 0;
+  for (size_t c = 0; c < h->G; ++c) cnt += (in[c] >= h->cut_occ) ? 1 : 0;
+  TBNAV_HIP(hipMemcpy(h->d_nocc[h->cur] + particle, &cnt, sizeof(int), hipMemcpyHostToDevice));
+  return TBNAV_OK;
+}
+
+int tbnav_rbpf_get_dist_code(tbnav_rbpf* h, int32_t particle, uint16_t* out) {
+  if (!h || !out || particle < 0 || particle >= h->N) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  TBNAV_HIP(hipStreamSynchronize(h->stream));
+  TBNAV_HIP(hipMemcpy(out, h->d_code[h->cur] + (size_t)particle * h->G, sizeof(uint16_t) * h->G, hipMemcpyDeviceToHost));
+  return TBNAV_OK;
+}
+
+int tbnav_rbpf_get_occ_dist(tbnav_rbpf* h, int32_t particle, double* out) {
+  if (!h || !out || particle < 0 || particle >= h->N) return TBNAV_ERR_INVALID_ARG;
+  std::vector<uint16_t> code(h->G);
+  int rc = tbnav_rbpf_get_dist_code(h, particle, code.data());
+  if (rc != TBNAV_OK) return rc;
+  for (size_t c = 0; c < h->G; ++c)
+    out[c] = code[c] == kCodeUnreached ? h->max_occ_dist : std::sqrt((double)code[c]) * h->p.resolution;
+  return TBNAV_OK;
+}
+
+int tbnav_rbpf_set_occ_dist(tbnav_rbpf* h, int32_t particle, const double* in) {
+  if (!h || !in || particle < 0 || particle >= h->N) return TBNAV_ERR_INVALID_ARG;
+  std::vector<uint16_t> code(h->G);
+  const double res = h->p.resolution;
+  for (size_t c = 0; c < h->G; ++c) {
+    const double v = in[c];
+    const double cells = v / res;
+    const long d2 = std::lround(cells * cells);
+    if (d2 >= 0 && d2 < 65535 && std::sqrt((double)d2) * res == v) { code[c] = (uint16_t)d2; continue; }
+    if (v == h->max_occ_dist) { code[c] = kCodeUnreached; continue; }
+    return TBNAV_ERR_INVALID_ARG;
+  }
+  DeviceGuard guard(h->device);
+  TBNAV_HIP(hipStreamSynchronize(h->stream));
+  TBNAV_HIP(hipMemcpy(h->d_code[h->cur] + (size_t)particle * h->G, code.data(), sizeof(uint16_t) * h->G, hipMemcpyHostToDevice));
+  return TBNAV_OK;
+}
+
+int tbnav_rbpf_get_occupied_count(tbnav_rbpf* h, int32_t* counts) {
+  if (!h || !counts) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  TBNAV_HIP(hipStreamSynchronize(h->stream));
+  TBNAV_HIP(hipMemcpy(counts, h->d_nocc[h->cur], sizeof(int) * h->N, hipMemcpyDeviceToHost));
+  return TBNAV_OK;
+}
+
+int tbnav_rbpf_get_trace(tbnav_rbpf* h, double* sampled, double* p_scan, double* p_pose, double* mu, double* sigma,
+                         double* eta, double* new_pose, double* weight_raw, int32_t* resample_parent) {
+  if (!h) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  const size_t N = h->N, k = h->k;
+  TBNAV_HIP(hipStreamSynchronize(h->stream));
+  auto get = [&](double* dst, const double* src, size_t n) -> hipError_t {
+    return dst ? hipMemcpy(dst, src, sizeof(double) * n, hipMemcpyDeviceToHost) : hipSuccess;
+  };
+  TBNAV_HIP(get(sampled, h->tr.sampled, N * k * 3));
+  TBNAV_HIP(get(p_scan, h->tr.p_scan, N * k));
+  TBNAV_HIP(get(p_pose, h->tr.p_pose, N * k));
+  TBNAV_HIP(get(mu, h->tr.mu, N * 3));
+  TBNAV_HIP(get(sigma, h->tr.sigma, N * 9));
+  TBNAV_HIP(get(eta, h->tr.eta, N));
+  TBNAV_HIP(get(new_pose, h->tr.new_pose, N * 3));
+  TBNAV_HIP(get(weight_raw, h->tr.weight_raw, N));
+  if (resample_parent) TBNAV_HIP(hipMemcpy(resample_parent, h->d_parent, sizeof(int) * N, hipMemcpyDeviceToHost));
+  return TBNAV_OK;
+}
+
+int tbnav_rbpf_best_state(tbnav_rbpf* h, double pose[3], int32_t* best_index) {
+  if (!h || !pose) return TBNAV_ERR_INVALID_ARG;
+  const int N = h->N;
+  std::vector<double> ps((size_t)3 * N), w(N);
+  int rc = tbnav_rbpf_get_particles(h, ps.data(), nullptr, w.data());
+  if (rc != TBNAV_OK) return rc;
+  double best = 0.0;
+  int idx = 0;
+  for (int i = 0; i < N; ++i) if (w[i] > best) { best = w[i]; idx = i; }  // particle_filter.cpp:260-267
+  for (int q = 0; q < 3; ++q) pose[q] = ps[(size_t)idx * 3 + q];
+  if (best_index) *best_index = idx;
+  return TBNAV_OK;
+}
+
+int tbnav_rbpf_best_map(tbnav_rbpf* h, int8_t* map) {
+  if (!h || !map) return TBNAV_ERR_INVALID_ARG;
+  double pose[3];
+  int idx = 0;
+  int rc = tbnav_rbpf_best_state(h, pose, &idx);
+  if (rc != TBNAV_OK) return rc;
+  std::vector<double> lo(h->G);
+  rc = tbnav_rbpf_get_log_odds(h, idx, lo.data());
+  if (rc != TBNAV_OK) return rc;
+  const int xs = h->xsize;
+  for (size_t i = 0; i < h->G; ++i) {  // GridMapper::gridMap, grid_mapper.cpp:185-226, after updateCellState :438-477
+    const size_t row = i / xs, col = i % xs, idxT = col * xs + row;
+    const double prob = logodds_to_prob(lo[i]);
+    if (prob == 0.5) map[idxT] = -1;
+    else if (prob >= 0.90) map[idxT] = 100;
+    else if (prob <= 0.35) map[idxT] = 0;
+    else map[idxT] = (int8_t)(prob * 100);
+  }
+  return TBNAV_OK;
+}
+
+int tbnav_rbpf_last_kernel_ms(tbnav_rbpf* h, float ms[TBNAV_RBPF_NKERNELS]) {
+  if (!h || !ms) return TBNAV_ERR_INVALID_ARG;
+  for (int i = 0; i < TBNAV_RBPF_NKERNELS; ++i) ms[i] = h->last_ms[i];
+  return TBNAV_OK;
+}
+
+}  // extern "C"

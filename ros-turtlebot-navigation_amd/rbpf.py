@@ -1,0 +1,160 @@
+"""Python mirror of bmapping::ParticleFilter over the C-ABI (tests / smoke / bench plumbing).
+
+Same method names and argument meaning as the reference's class surface
+(bmapping/include/bmapping/particle_filter.hpp:88-146): SLAM(scan, u, cur_odom, prev_odom),
+getRobotState(), newMap().  ICP runs on the host before SLAM exactly where particle_filter.cpp:153
+calls it, so its result (icp_ok, T_icp) is passed in, as are the standard-normal draws.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+def default_params(N=40, k=50, map_min=-2.0, map_max=2.0, beam_delta_deg=1.0, pose0=(0.0, 0.0, 0.0), device=-1,
+                   **kw) -> "capi.RbpfParams":
+    """The shipped configuration: bmapping/launch/slam.launch:19-42, config/LDS_01_lidar.yaml
+    (degrees converted like turtle_mapping_node.cpp:300-302, then narrowed to float like
+    LaserProperties, sensor_model.hpp:23-27)."""
+    p = capi.RbpfParams()
+    p.num_particles, p.num_samples_mode = N, k
+    p.srr, p.srt, p.str_, p.stt = 0.1, 0.2, 0.1, 0.2
+    p.motion_noise[:] = [1e-10, 1e-10, 1e-10]
+    p.sample_range[:] = [1e-10, 1e-8, 1e-8]
+    p.scan_likelihood_min, p.scan_likelihood_max = 1.0, 20.0
+    p.pose_likelihood_min, p.pose_likelihood_max = 1.0, 10.0
+    d2r = np.pi / 180.0
+    p.beam_min, p.beam_max, p.beam_delta = 0.0, float(np.float32(360.0 * d2r)), float(np.float32(beam_delta_deg * d2r))
+    p.range_min, p.range_max = 0.12, 3.5
+    p.z_hit, p.z_short, p.z_max, p.z_rand, p.sigma_hit = 0.95, 0.0, 0.04, 0.01, 0.5
+    p.Trs[:] = [0.0, 0.0, 0.0]
+    p.resolution, p.xmin, p.xmax, p.ymin, p.ymax = 0.05, map_min, map_max, map_min, map_max
+    p.pose0[:] = list(pose0)
+    p.device = device
+    for key, v in kw.items():
+        if isinstance(v, (list, tuple, np.ndarray)):
+            getattr(p, key)[:] = list(v)
+        else:
+            setattr(p, key, v)
+    return p
+
+
+def _d3(v):
+    return (C.c_double * 3)(*[float(x) for x in v])
+
+
+class ParticleFilter:
+    """bmapping::ParticleFilter on one MI355X."""
+
+    def __init__(self, params: "capi.RbpfParams"):
+        self._L = capi.lib()
+        self.params = params
+        self._h = C.c_void_p()
+        capi.check(self._L.tbnav_rbpf_create(C.byref(params), C.byref(self._h)), "tbnav_rbpf_create")
+        xs, ys = C.c_int32(), C.c_int32()
+        capi.check(self._L.tbnav_rbpf_grid_size(self._h, C.byref(xs), C.byref(ys)), "grid_size")
+        self.xsize, self.ysize = xs.value, ys.value
+        self.G = self.xsize * self.ysize
+        self.N, self.k = params.num_particles, params.num_samples_mode
+        self.last_stats = None
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.tbnav_rbpf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def numNormals(self, icp_ok=True) -> int:
+        return int(self._L.tbnav_rbpf_num_normals(self._h, 1 if icp_ok else 0))
+
+    # ---- reference surface ----
+    def SLAM(self, scan, u, cur_odom, prev_odom, icp_ok, T_icp, normals, local_only=False, check=True):
+        """u = (w, vx, vy); odometry and T_icp as (theta, x, y).  Returns the stats struct; raises
+        TbnavError with the reference's exception text when the reference would have thrown."""
+        scan = np.ascontiguousarray(scan, dtype=np.float32)
+        normals = np.ascontiguousarray(normals, dtype=np.float64)
+        assert normals.size >= self.numNormals(icp_ok)
+        st = capi.RbpfStats()
+        fn = self._L.tbnav_rbpf_slam_local if local_only else self._L.tbnav_rbpf_slam
+        rc = fn(self._h, scan.ctypes.data, scan.size, _d3(u), _d3(cur_odom), _d3(prev_odom), 1 if icp_ok else 0,
+                _d3(T_icp), normals.ctypes.data, C.byref(st))
+        self.last_stats = st
+        if check:
+            capi.check(rc, "tbnav_rbpf_slam")
+        return st
+
+    def getRobotState(self):
+        pose = (C.c_double * 3)(); idx = C.c_int32()
+        capi.check(self._L.tbnav_rbpf_best_state(self._h, pose, C.byref(idx)), "best_state")
+        return (pose[0], pose[1], pose[2]), idx.value
+
+    def newMap(self) -> np.ndarray:
+        m = np.empty(self.G, dtype=np.int8)
+        capi.check(self._L.tbnav_rbpf_best_map(self._h, m.ctypes.data), "best_map")
+        return m
+
+    # ---- state access ----
+    def particles(self):
+        pose = np.empty((self.N, 3)); prev = np.empty((self.N, 3)); w = np.empty(self.N)
+        capi.check(self._L.tbnav_rbpf_get_particles(self._h, pose.ctypes.data, prev.ctypes.data, w.ctypes.data), "get_particles")
+        return pose, prev, w
+
+    def setParticles(self, pose=None, prev=None, w=None):
+        a = [None if v is None else np.ascontiguousarray(v, dtype=np.float64) for v in (pose, prev, w)]
+        capi.check(self._L.tbnav_rbpf_set_particles(self._h, *[None if v is None else v.ctypes.data for v in a]), "set_particles")
+
+    def logOdds(self, p) -> np.ndarray:
+        out = np.empty(self.G)
+        capi.check(self._L.tbnav_rbpf_get_log_odds(self._h, p, out.ctypes.data), "get_log_odds")
+        return out
+
+    def setLogOdds(self, p, lo):
+        lo = np.ascontiguousarray(lo, dtype=np.float64)
+        capi.check(self._L.tbnav_rbpf_set_log_odds(self._h, p, lo.ctypes.data), "set_log_odds")
+
+    def occDist(self, p) -> np.ndarray:
+        out = np.empty(self.G)
+        capi.check(self._L.tbnav_rbpf_get_occ_dist(self._h, p, out.ctypes.data), "get_occ_dist")
+        return out
+
+    def setOccDist(self, p, od):
+        od = np.ascontiguousarray(od, dtype=np.float64)
+        capi.check(self._L.tbnav_rbpf_set_occ_dist(self._h, p, od.ctypes.data), "set_occ_dist")
+
+    def distCode(self, p) -> np.ndarray:
+        out = np.empty(self.G, dtype=np.uint16)
+        capi.check(self._L.tbnav_rbpf_get_dist_code(self._h, p, out.ctypes.data), "get_dist_code")
+        return out
+
+    def occupiedCount(self) -> np.ndarray:
+        out = np.empty(self.N, dtype=np.int32)
+        capi.check(self._L.tbnav_rbpf_get_occupied_count(self._h, out.ctypes.data), "get_occupied_count")
+        return out
+
+    def trace(self) -> dict:
+        N, k = self.N, self.k
+        t = dict(sampled=np.empty((N, k, 3)), p_scan=np.empty((N, k)), p_pose=np.empty((N, k)), mu=np.empty((N, 3)),
+                 sigma=np.empty((N, 3, 3)), eta=np.empty(N), new_pose=np.empty((N, 3)), weight_raw=np.empty(N),
+                 resample_idx=np.empty(N, dtype=np.int32))
+        capi.check(self._L.tbnav_rbpf_get_trace(self._h, *[a.ctypes.data for a in t.values()]), "get_trace")
+        return t
+
+    def kernelMs(self):
+        ms = (C.c_float * 6)()
+        capi.check(self._L.tbnav_rbpf_last_kernel_ms(self._h, ms), "last_kernel_ms")
+        return dict(zip(("propose", "raycast", "occupancy", "edt", "normalize", "gather"), [float(x) for x in ms]))
+
+
+def resample_global(weights_all: np.ndarray, z: float):
+    """normalizeWeights + effectiveParticles + lowVarianceResampling on the global weight vector
+    (host, sequential order).  Returns (parents, normalised weights, stats)."""
+    w = np.ascontiguousarray(weights_all, dtype=np.float64)
+    parents = np.empty(w.size, dtype=np.int32); wn = np.empty(w.size)
+    st = capi.RbpfStats()
+    capi.check(capi.lib().tbnav_rbpf_resample_global(w.ctypes.data, w.size, float(z), parents.ctypes.data,
+                                                     wn.ctypes.data, C.byref(st)), "resample_global")
+    return parents, wn, st
