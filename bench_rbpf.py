@@ -1,0 +1,115 @@
+"""RBPF leg of bench.py: BASELINE configs[2] — 1000 particles, 360-beam synthetic scan, 400x400 @ 0.05 m,
+k = 50 samples round the mode (shipped slam.launch), ICP-ok branch, 20-scan trajectory of SURVEY.md 8-d.
+
+particle-updates/s = N * SLAM calls / wall time of the synchronous tbnav_rbpf_slam calls.  The call
+takes the scan and the standard-normal draws as HOST buffers (that is the reference's boundary), so
+the wall figure includes their H2D copy (1.2 MB/scan) and one stream sync; `device_ms_per_scan` is
+the sum of the kernels' HIP-event durations alone.
+
+roofline: the distance-field kernel pair is the dominant cost; algorithmic bytes per particle-update
+are SURVEY.md 8-d's  k*Bv*8 + (C_free+Bv)*16 + G_reach*16.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+HBM_PEAK_GBS = 8000.0
+
+
+def _world():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import rbpf_cases as rc
+    return rc
+
+
+def _room_scan(pose, rng, walls, n_beams=360, sigma=0.01):
+    th, x, y = pose
+    ang = th + np.deg2rad(1.0) * np.arange(n_beams)
+    c, s = np.cos(ang), np.sin(ang)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tx = np.where(c > 0, (walls[1] - x) / c, np.where(c < 0, (walls[0] - x) / c, np.inf))
+        ty = np.where(s > 0, (walls[3] - y) / s, np.where(s < 0, (walls[2] - y) / s, np.inf))
+    return (np.minimum(tx, ty) + rng.normal(0.0, sigma, n_beams)).astype(np.float32)
+
+
+def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
+    from rtn_amd.rbpf import ParticleFilter, default_params
+    rc = _world()
+    pf = ParticleFilter(default_params(N=N, k=k, map_min=-10.0, map_max=10.0, device=device.index or 0))
+    steps, poses = rc.trajectory(n_scans, inc=(0.07, 0.10, 0.05))
+    rng = np.random.default_rng(7)
+    scans = [_room_scan(poses[s], rng, rc.ROOM_SURVEY) for s in range(n_scans)]
+    nn = pf.numNormals(True)
+    normals = [np.random.default_rng(100 + s).standard_normal(nn) for s in range(n_scans)]
+    kms = {}
+    free_cells = 0
+    t_total = 0.0
+    n_timed = 0
+    resamples = 0
+    for s, (prev, cur, t_icp, u) in enumerate(steps):
+        t0 = time.perf_counter()
+        st = pf.SLAM(scans[s], u, cur, prev, True, t_icp, normals[s])
+        dt = time.perf_counter() - t0
+        if s >= 2:  # first two scans: empty maps / first-touch
+            t_total += dt; n_timed += 1
+            for key, v in pf.kernelMs().items():
+                kms[key] = kms.get(key, 0.0) + v
+        resamples += st.resampled
+    kms = {key: v / n_timed for key, v in kms.items()}
+    ms_scan = t_total / n_timed * 1e3
+    dev_ms = sum(kms.values())
+    G = pf.G
+    Bv = int(st.n_valid_beams)
+    c_free = 30 * Bv  # ~30 free cells per ray in this room
+    alg_per_update = k * Bv * 8 + (c_free + Bv) * 16 + G * 16
+    alg_edt = G * 16  # distance-field refresh: 8 B seed/occupancy read + 8 B distance write per reachable cell
+    edt_ms = kms["occupancy"] + kms["edt"]
+    out = {
+        "metric": "RBPF particle-updates/s", "value": round(N / (ms_scan * 1e-3), 1), "unit": "particle-updates/s",
+        "config": {"workload": f"RBPF SLAM N={N}, k={k}, {Bv} valid beams, {pf.xsize}x{pf.ysize} @0.05 m, ICP-ok branch "
+                               "(BASELINE configs[2])", "scans_timed": n_timed, "resamples": resamples,
+                   "inputs": "scan + normals handed over as host buffers (H2D inside the timed call)"},
+        "ms_per_scan": round(ms_scan, 4), "device_ms_per_scan": round(dev_ms, 4),
+        "device_only_updates_per_s": round(N / (dev_ms * 1e-3), 1),
+        "kernel_ms": {key: round(v, 4) for key, v in kms.items()},
+        "dtype": "f64+u16",
+        "roofline": {"bound": "hbm", "kernel": "rbpf_occupancy+rbpf_edt (distance field)",
+                     "achieved": round(alg_edt * N / (edt_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(alg_edt * N / (edt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
+                     "algorithmic_bytes_per_launch": alg_edt * N,
+                     "whole_update": {"algorithmic_bytes_per_particle_update": alg_per_update,
+                                      "achieved": round(alg_per_update * N / (dev_ms * 1e-3) / 1e9, 3),
+                                      "frac": round(alg_per_update * N / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)}},
+    }
+    pf.close()
+    if with_cpu:
+        out["cpu_baseline"] = cpu_baseline(k, scans, steps)
+    return out
+
+
+def cpu_baseline(k, scans, steps, n_particles=16, n_scans=6):
+    """oracle port (restated GridMapper + ParticleFilter, bit-exact vs the reference's GridMapper), 1 core,
+    same world / parameters, a BOUNDED sample: 16 particles x 6 scans."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_api as orc
+    pf = orc.PfAPI(orc.pf_params(N=n_particles, k=k, map_min=-10.0, map_max=10.0))
+    nn = pf.normals_per_scan(True)
+    t_total, n = 0.0, 0
+    for s in range(n_scans):
+        prev, cur, t_icp, u = steps[s]
+        nz = np.random.default_rng(100 + s).standard_normal(nn)
+        t0 = time.perf_counter()
+        pf.slam(scans[s], u, cur, prev, True, t_icp, nz, trace=False)
+        dt = time.perf_counter() - t0
+        if s >= 1:
+            t_total += dt; n += 1
+    pf.close()
+    return {"value": round(n_particles * n / t_total, 2), "unit": "particle-updates/s", "cores": 1, "kind": "port",
+            "sample": f"{n_particles} particles x {n} scans, k={k}, 360 beams, 400x400 (oracle/rbpf_oracle.cpp incl. the "
+                      "reference's priority-queue brushfire, g++ -O2, 1 thread)",
+            "ms_per_particle_update": round(t_total / (n_particles * n) * 1e3, 3)}

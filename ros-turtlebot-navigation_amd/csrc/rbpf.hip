@@ -383,7 +383,8 @@ __global__ __launch_bounds__(kWave) void rbpf_raycast(ScanC c, const double2* __
 // ---- occupancy bitmap ------------------------------------------------------------------------------
 // grid (rows/4, N), 256 threads: one wave per map row; lanes read the row coalesced.
 __global__ __launch_bounds__(256) void rbpf_occupancy(GridC g, double cut_occ, const double* __restrict__ log_odds,
-                                                      unsigned long long* __restrict__ bitmap, int* __restrict__ n_occ) {
+                                                      unsigned long long* __restrict__ bitmap, uint16_t* __restrict__ row_count,
+                                                      int* __restrict__ n_occ) {
   const int p = blockIdx.y;
   const int row = blockIdx.x * 4 + threadIdx.x / kWave;
   const int lane = threadIdx.x & (kWave - 1);
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(256) void rbpf_occupancy(GridC g, double cut_occ, c
     if (lane == 0) bm[w] = m;
     cnt += __popcll(m);
   }
-  if (lane == 0 && cnt) atomicAdd(&n_occ[p], cnt);
+  if (lane == 0) { row_count[(size_t)p * g.xsize + row] = (uint16_t)cnt; if (cnt) atomicAdd(&n_occ[p], cnt); }
 }
 
 // ---- exact distance transform ------------------------------------------------------------------------
@@ -436,8 +437,9 @@ __device__ __forceinline__ int floor_div(int num, int den) {  // den > 0
 // (lower-envelope stack).  Integer arithmetic only: d2 = min_i' (i-i')^2 + f(i',j)^2 exactly.
 template <int C>
 __global__ __launch_bounds__(C) void rbpf_edt(GridC g, int radius, const unsigned long long* __restrict__ bitmap,
-                                              uint16_t* __restrict__ codes) {
+                                              uint16_t* __restrict__ codes, const int* __restrict__ tier, int my_tier) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  if (tier[blockIdx.y] != my_tier) return;  // this particle was handled by a compact-row kernel
   const int xs = g.xsize, words = g.words;
   unsigned long long* rows = reinterpret_cast<unsigned long long*>(lds_raw);            // [xs][words]
   uint16_t* v = reinterpret_cast<uint16_t*>(lds_raw + (size_t)xs * words * 8);          // [xs][C]
@@ -482,6 +484,115 @@ __global__ __launch_bounds__(C) void rbpf_edt(GridC g, int radius, const unsigne
     if (d2 <= r2) out[(size_t)i * g.ysize + j] = (uint16_t)d2;
   }
 }
+
+// Fast path of the distance transform.  Only map rows that hold at least one occupied cell can
+// contribute a parabola to a column's lower envelope, and in a room-sized world that is ~100 of the
+// 400 rows: the envelope stack is sized by SMAX compacted rows instead of xsize, which cuts LDS per
+// wave from 150 KB to <= 40 KB (4 waves per CU instead of 1), the row pass only visits those rows, and
+// the stack top is kept in registers.  grid (column tiles, N), 64 threads.  A particle with more than
+// SMAX non-empty rows raises its tier and is left to the next kernel (SMAX doubled, finally the
+// general kernel above).  LDS: rowlist u16[SMAX] | vz u32[SMAX][64] (row | (z+32768)<<16) | f u8[SMAX][64].
+// packed envelope entry (maps up to 2047 rows): row v in bits 0-10, row distance f in bits 11-18, z+1 in bits 19-31
+constexpr int kZMax = 8190;
+constexpr int kEdtCompactMaxRows = 2047;  // packed entry: 11 bits of row index
+__device__ __forceinline__ uint32_t pack(int v, int f, int z) { return (uint32_t)v | ((uint32_t)f << 11) | ((uint32_t)(z + 1) << 19); }
+__device__ __forceinline__ void unpack(uint32_t e, int& v, int& f, int& z) { v = (int)(e & 0x7FFu); f = (int)((e >> 11) & 0xFFu); z = (int)(e >> 19) - 1; }
+__device__ __forceinline__ int unpack_z(uint32_t e) { return (int)(e >> 19) - 1; }
+template <int SMAX>
+__global__ __launch_bounds__(kWave) void rbpf_edt_compact(GridC g, int radius, const unsigned long long* __restrict__ bitmap,
+                                                          const uint16_t* __restrict__ row_count,
+                                                          uint16_t* __restrict__ codes, int* __restrict__ tier, int my_tier) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int p = blockIdx.y, lane = threadIdx.x;
+  if (tier[p] != my_tier) return;
+  uint32_t* ent = reinterpret_cast<uint32_t*>(lds_raw);                                  // [SMAX][64] packed stack entries
+  unsigned long long* roww = reinterpret_cast<unsigned long long*>(lds_raw + (size_t)SMAX * kWave * 4);  // [SMAX] tile word of the row
+  uint16_t* rowlist = reinterpret_cast<uint16_t*>(lds_raw + (size_t)SMAX * kWave * 4 + (size_t)SMAX * 8);  // [SMAX]
+  uint16_t* rowdl = rowlist + SMAX;   // [SMAX] distance from the tile's first column to the nearest occupied cell left of the tile
+  uint16_t* rowdr = rowdl + SMAX;     // [SMAX] distance from the tile's last column to the nearest one right of it
+  const int xs = g.xsize, words = g.words;
+  const int tw = blockIdx.x;          // the tile is exactly bitmap word `tw` of every row
+  const int j = tw * kWave + lane;
+  const unsigned long long* bm = bitmap + (size_t)p * xs * words;
+  const uint16_t* rc = row_count + (size_t)p * xs;
+  // compact list of non-empty rows (ascending)
+  int S = 0;
+  for (int base = 0; base < xs; base += kWave) {
+    const int row = base + lane;
+    const bool ne = (row < xs) && (rc[row] != 0);
+    const unsigned long long m = __ballot(ne);
+    if (ne) {
+      const int pos = S + __popcll(m & ((1ull << lane) - 1ull));
+      if (pos < SMAX) rowlist[pos] = (uint16_t)row;
+    }
+    S += __popcll(m);
+  }
+  if (S == 0) return;  // empty map: nothing to write
+  if (S > SMAX || xs > kEdtCompactMaxRows) { if (lane == 0 && tw == 0) tier[p] = my_tier + 1; return; }
+  __syncthreads();
+  // per (row, tile): the tile's own word and the distances to the nearest set bits outside the tile
+  for (int s = lane; s < S; s += kWave) {
+    const unsigned long long* r = bm + (size_t)rowlist[s] * words;
+    roww[s] = r[tw];
+    int dl = 0xFFFF, dr = 0xFFFF;
+    for (int w = tw - 1; w >= 0 && (tw - w - 1) * 64 < radius; --w) {
+      const unsigned long long m = r[w];
+      if (m) { dl = tw * 64 - (w * 64 + 63 - __clzll((long long)m)); break; }
+    }
+    for (int w = tw + 1; w < words && (w - tw - 1) * 64 < radius; ++w) {
+      const unsigned long long m = r[w];
+      if (m) { dr = (w * 64 + (__ffsll((long long)m) - 1)) - (tw * 64 + 63); break; }
+    }
+    rowdl[s] = (uint16_t)dl; rowdr[s] = (uint16_t)dr;
+  }
+  __syncthreads();
+  if (j >= g.ysize) return;
+  const unsigned long long le_mask = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);  // bits <= lane
+  const unsigned long long ge_mask = ~((1ull << lane) - 1ull);                        // bits >= lane
+  // lower envelope over the non-empty rows; top-of-stack (v_t, f_t, z_t) lives in registers
+  int top = -1, v_t = 0, f_t = 0, z_t = -1;
+  for (int s = 0; s < S; ++s) {
+    const int q = rowlist[s];
+    const unsigned long long word = roww[s];
+    int fq = min(lane + (int)rowdl[s], (63 - lane) + (int)rowdr[s]);
+    const unsigned long long ml = word & le_mask, mr = word & ge_mask;
+    if (ml) fq = min(fq, lane - (63 - __clzll((long long)ml)));
+    if (mr) fq = min(fq, (__ffsll((long long)mr) - 1) - lane);
+    if (fq > radius) continue;
+    const int hq = fq * fq + q * q;
+    int sd = -1;
+    while (top >= 0) {
+      sd = floor_div(hq - (f_t * f_t + v_t * v_t), 2 * (q - v_t));
+      if (sd > z_t) break;
+      --top;
+      if (top >= 0) unpack(ent[top * kWave + lane], v_t, f_t, z_t);
+    }
+    ++top;
+    // z only ever meets row indices 0..xs-1: clamping it to [-1, kZMax] changes no decision that matters
+    if (top == 0) sd = -1;
+    sd = sd < -1 ? -1 : (sd > kZMax ? kZMax : sd);
+    v_t = q; f_t = fq; z_t = sd;
+    ent[top * kWave + lane] = pack(q, fq, sd);
+  }
+  if (top < 0) return;  // nothing within reach of this column: every cell keeps its previous value
+  uint16_t* out = codes + (size_t)p * xs * g.ysize + j;
+  const int r2 = radius * radius;
+  int kk = 0, vq, fv, zz;
+  unpack(ent[lane], vq, fv, zz);
+  int z_next = (top >= 1) ? unpack_z(ent[kWave + lane]) : 0x7fffffff;
+  for (int i = 0; i < xs; ++i) {
+    while (z_next < i) {
+      ++kk;
+      unpack(ent[kk * kWave + lane], vq, fv, zz);
+      z_next = (kk < top) ? unpack_z(ent[(kk + 1) * kWave + lane]) : 0x7fffffff;
+    }
+    const int d2 = (i - vq) * (i - vq) + fv * fv;
+    if (d2 <= r2) out[(size_t)i * g.ysize] = (uint16_t)d2;
+  }
+}
+constexpr size_t edt_compact_lds(int smax) { return (size_t)smax * kWave * 4 + (size_t)smax * (8 + 6) + 16; }
+constexpr int kEdtRowsA = 144;  // 38.9 KB -> 4 waves per CU
+constexpr int kEdtRowsB = 288;  // 77.8 KB -> 2 waves per CU
 
 // ---- normalise / Neff / low-variance selection (sequential order = the reference's) ---------------
 struct NormOut { double sum_w, sq_sum; int neff, resampled; };
@@ -546,11 +657,13 @@ struct tbnav_rbpf {
   int* d_nocc[2] = {nullptr, nullptr};
   int cur = 0;
   unsigned long long* d_bitmap = nullptr;
+  uint16_t* d_rowcount = nullptr;  // [N][xsize] occupied cells per map row
   double2* d_beams = nullptr;  // capacity max_beams
   int max_beams = 0;
   double* d_normals = nullptr;
   size_t normals_cap = 0;
   int* d_parent = nullptr;
+  int* d_tier = nullptr;       // [N] which distance-field kernel handles the particle this scan
   int* d_err = nullptr;
   NormOut* d_norm = nullptr;
   double* d_trace = nullptr;   // sampled, p_scan, p_pose, mu, sigma, eta, new_pose, weight_raw
@@ -641,14 +754,23 @@ int run_distance_field(tbnav_rbpf* h, const GridC& g, hipEvent_t e_mid) {
   hipStream_t st = h->stream;
   TBNAV_HIP(hipMemsetAsync(h->d_nocc[h->cur], 0, sizeof(int) * h->N, st));
   hipLaunchKernelGGL(rbpf_occupancy, dim3((h->xsize + 3) / 4, h->N), dim3(256), 0, st, g, h->cut_occ,
-                     h->d_log_odds[h->cur], h->d_bitmap, h->d_nocc[h->cur]);
+                     h->d_log_odds[h->cur], h->d_bitmap, h->d_rowcount, h->d_nocc[h->cur]);
   TBNAV_HIP(hipGetLastError());
   if (e_mid) TBNAV_HIP(hipEventRecord(e_mid, st));
+  // tier 0: <= kEdtRowsA non-empty rows, tier 1: <= kEdtRowsB, tier 2: the general kernel (decided on the device)
+  TBNAV_HIP(hipMemsetAsync(h->d_tier, 0, sizeof(int) * h->N, st));
+  const dim3 gridc((h->ysize + kWave - 1) / kWave, h->N);
+  hipLaunchKernelGGL(rbpf_edt_compact<kEdtRowsA>, gridc, dim3(kWave), edt_compact_lds(kEdtRowsA), st, g, h->radius,
+                     h->d_bitmap, h->d_rowcount, h->d_code[h->cur], h->d_tier, 0);
+  TBNAV_HIP(hipGetLastError());
+  hipLaunchKernelGGL(rbpf_edt_compact<kEdtRowsB>, gridc, dim3(kWave), edt_compact_lds(kEdtRowsB), st, g, h->radius,
+                     h->d_bitmap, h->d_rowcount, h->d_code[h->cur], h->d_tier, 1);
+  TBNAV_HIP(hipGetLastError());
   const int C = h->edt_cols;
   const size_t lds = edt_lds_bytes(h->xsize, h->words, C);
   const dim3 grid((h->ysize + C - 1) / C, h->N);
-  if (C == 64) hipLaunchKernelGGL(rbpf_edt<64>, grid, dim3(64), lds, st, g, h->radius, h->d_bitmap, h->d_code[h->cur]);
-  else hipLaunchKernelGGL(rbpf_edt<32>, grid, dim3(32), lds, st, g, h->radius, h->d_bitmap, h->d_code[h->cur]);
+  if (C == 64) hipLaunchKernelGGL(rbpf_edt<64>, grid, dim3(64), lds, st, g, h->radius, h->d_bitmap, h->d_code[h->cur], h->d_tier, 2);
+  else hipLaunchKernelGGL(rbpf_edt<32>, grid, dim3(32), lds, st, g, h->radius, h->d_bitmap, h->d_code[h->cur], h->d_tier, 2);
   TBNAV_HIP(hipGetLastError());
   return TBNAV_OK;
 }
@@ -793,6 +915,8 @@ int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) {
   }
   A((void**)&h->d_bitmap, sizeof(unsigned long long) * (size_t)N * xsize * words);
   A((void**)&h->d_parent, sizeof(int) * N);
+  A((void**)&h->d_rowcount, sizeof(uint16_t) * (size_t)N * xsize);
+  A((void**)&h->d_tier, sizeof(int) * N);
   A((void**)&h->d_err, sizeof(int) * 4);
   A((void**)&h->d_norm, sizeof(NormOut));
   const size_t kk = (size_t)h->k;
@@ -828,6 +952,10 @@ int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) {
     e = (C == 64) ? hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_edt<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)
                   : hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_edt<32>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_edt_compact<kEdtRowsA>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)edt_compact_lds(kEdtRowsA));
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_edt_compact<kEdtRowsB>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)edt_compact_lds(kEdtRowsB));
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) {
     const int rc = tbnav::hip_fail(e, "tbnav_rbpf_create allocation", __FILE__, __LINE__);
@@ -842,7 +970,7 @@ void tbnav_rbpf_destroy(tbnav_rbpf* h) {
   if (!h) return;
   DeviceGuard guard(h->device);
   for (int b = 0; b < 2; ++b) { (void)hipFree(h->d_state[b]); (void)hipFree(h->d_log_odds[b]); (void)hipFree(h->d_code[b]); (void)hipFree(h->d_nocc[b]); }
-  (void)hipFree(h->d_bitmap); (void)hipFree(h->d_beams); (void)hipFree(h->d_normals); (void)hipFree(h->d_parent);
+  (void)hipFree(h->d_bitmap); (void)hipFree(h->d_beams); (void)hipFree(h->d_normals); (void)hipFree(h->d_parent); (void)hipFree(h->d_tier); (void)hipFree(h->d_rowcount);
   (void)hipFree(h->d_err); (void)hipFree(h->d_norm); (void)hipFree(h->d_trace);
   for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
   if (h->stream) (void)hipStreamDestroy(h->stream);

@@ -250,3 +250,34 @@ def test_cfg3_full_size_properties(gpu_pkg):
     prev, cur, t_icp, u = steps[-1]
     pf_d.SLAM(empty, u, cur + 0.01, cur, True, t_icp, normals)
     assert np.array_equal(pf_d.distCode(0), codes)
+
+
+@pytest.mark.parametrize("rows_used,expect", [(140, "compact-144"), (280, "compact-288"), (400, "general")])
+def test_distance_field_tiers_random_occupancy(gpu_pkg, rows_used, expect):
+    """The distance transform picks its kernel per particle from the number of non-empty map rows
+    (<= 144, <= 288, any).  Random occupancy patterns exercise each tier, ragged column tiles
+    (400 = 6*64 + 16) and the radius cut-off; codes must equal the brute-force exact EDT."""
+    N, k = 2, 3
+    pf_d = _dev(gpu_pkg, N=N, k=k, map_min=-10.0, map_max=10.0)
+    xs = pf_d.xsize
+    rng = np.random.default_rng(rows_used)
+    l_occ = np.log(0.9 / (1 - 0.9))
+    occs = []
+    for p in range(N):
+        occ = np.zeros((xs, xs), dtype=np.uint8)
+        rows = rng.choice(xs, size=rows_used, replace=False)
+        for r in rows:
+            occ[r, rng.choice(xs, size=int(rng.integers(1, 4)), replace=False)] = 1
+        if p == 1 and rows_used == 140:
+            occ[:] = 0; occ[5, 7] = 1   # single obstacle in a corner: most of the map is beyond the 200-cell radius
+        pf_d.setLogOdds(p, occ.reshape(-1) * l_occ)
+        occs.append(occ)
+    prev_codes = [pf_d.distCode(p).reshape(xs, xs) for p in range(N)]
+    empty = np.full(360, 9.0, dtype=np.float32)
+    normals = orc.normal_stream(1, pf_d.numNormals(True), 0.0, 1.0)
+    st = pf_d.SLAM(empty, (0.05, 0.1, 0), (0.05, 0.1, 0.02), (0, 0, 0), True, (0.05, 0.1, 0.02), normals)
+    assert st.status == 0
+    assert pf_d.occupiedCount().tolist() == [int(o.sum()) for o in occs]
+    for p in range(N):
+        want = orc.exact_edt_codes(occs[p], 200, prev_codes[p])
+        assert np.array_equal(pf_d.distCode(p).reshape(xs, xs), want), expect
