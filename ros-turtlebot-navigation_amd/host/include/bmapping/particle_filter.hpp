@@ -1,0 +1,61 @@
+// bmapping/particle_filter.hpp — bmapping::ParticleFilter with the reference's class surface
+// (reference bmapping/include/bmapping/particle_filter.hpp:88-233): the 19-argument constructor,
+// SLAM(scan, u, cur_odom, prev_odom), getRobotState(), newMap(map).  bmapping/src/turtle_mapping_node.cpp
+// (:404-410, :474, :479, :494) compiles unchanged against it.  All particle state lives on the GPU
+// behind include/tbnav_rbpf.h.
+#ifndef TBNAV_BMAPPING_PARTICLE_FILTER_HPP
+#define TBNAV_BMAPPING_PARTICLE_FILTER_HPP
+
+#include <cstdint>
+#include <random>
+#include <vector>
+
+#include "bmapping/cloud_alignment.hpp"
+#include "bmapping/grid_mapper.hpp"
+#include "bmapping/sensor_model.hpp"
+#include "rigid2d/diff_drive.hpp"
+#include "rigid2d/rigid2d.hpp"
+
+struct tbnav_rbpf;  // C-ABI handle
+
+namespace bmapping {
+
+using rigid2d::Pose;
+using rigid2d::Transform2D;
+using rigid2d::Twist2D;
+
+/// the filter's own process-global engine (particle_filter.cpp:17-22); reseed with getTwister().seed(s)
+std::mt19937_64& getTwister();
+
+class ParticleFilter {
+ public:
+  ParticleFilter(int num_particles, int k, double srr, double srt, double str, double stt, double motion_noise_theta,
+                 double motion_noise_x, double motion_noise_y, double sample_range_theta, double sample_range_x,
+                 double sample_range_y, double scan_likelihood_min, double scan_likelihood_max,
+                 double pose_likelihood_min, double pose_likelihood_max, ScanAlignment& scan_matcher,
+                 const Transform2D& pose, const GridMapper& mapper);
+  ~ParticleFilter();
+  ParticleFilter(const ParticleFilter&) = delete;
+  ParticleFilter& operator=(const ParticleFilter&) = delete;
+
+  /// One scan update.  Prints "Neff: <n>" and, when it resamples, "Resampling", like the reference.
+  /// Throws std::invalid_argument with the reference's messages ("eta is 0", "... NOT in the bounds of
+  /// the world", "Variance in pdfNormal is 0").
+  void SLAM(const std::vector<float>& scan, const Twist2D& u, const Pose& cur_odom, const Pose& prev_odom);
+  Transform2D getRobotState();
+  void newMap(std::vector<int8_t>& map);
+
+  // ---- additions (not in the reference) ----
+  int effectiveParticles() const { return last_neff_; }
+  bool resampledLastScan() const { return last_resampled_; }
+
+ private:
+  tbnav_rbpf* h_ = nullptr;
+  ScanAlignment scan_matcher_;  // copied, as the reference does (particle_filter.hpp:222)
+  int num_particles_ = 0, k_ = 0, last_neff_ = 0;
+  bool last_resampled_ = false;
+  std::vector<double> normals_;
+};
+
+}  // namespace bmapping
+#endif

@@ -1,0 +1,76 @@
+// mppi_shim.cpp — controller::MPPI over the C-ABI.  Status codes become the exceptions a caller of
+// the reference would have seen (std::invalid_argument / std::runtime_error); there is no CPU path.
+#include <cmath>
+#include <stdexcept>
+#include <string>
+
+#include "controller/mppi.hpp"
+#include "rigid2d/utilities.hpp"
+#include "tbnav_mppi.h"
+
+namespace controller {
+namespace {
+void check(int rc, const char* where) {
+  if (rc == TBNAV_OK) return;
+  std::string msg = std::string(where) + ": " + tbnav_status_string(rc);
+  const char* hip = tbnav_last_hip_error();
+  if (hip && *hip) msg += std::string(" [") + hip + "]";
+  if (rc == TBNAV_ERR_INVALID_ARG) throw std::invalid_argument(msg);
+  throw std::runtime_error(msg);
+}
+}  // namespace
+
+MPPI::MPPI(const CartModel& cart, const LossFunc& loss, double lambda, double max_wheel_vel, double ul_var, double ur_var,
+           double horizon, double dt, int rollouts) {
+  tbnav_mppi_params p{};
+  p.wheel_radius = cart.wheel_radius; p.wheel_base = cart.wheel_base;
+  p.lambda = lambda; p.max_wheel_vel = max_wheel_vel; p.ul_var = ul_var; p.ur_var = ur_var;
+  p.horizon = horizon; p.dt = dt;
+  for (int i = 0; i < 3; ++i) { p.Q[i] = loss.Q[i]; p.P1[i] = loss.P1[i]; }
+  p.R[0] = loss.R[0]; p.R[1] = loss.R[1];
+  p.rollouts = rollouts; p.device = -1;
+  check(tbnav_mppi_create(&p, &h_), "controller::MPPI");
+  steps_ = tbnav_mppi_steps(h_);
+  rollouts_ = rollouts;
+  ul_sig_ = std::sqrt(ul_var);  // mppi.cpp:176-177: the sampler takes a standard deviation
+  ur_sig_ = std::sqrt(ur_var);
+}
+
+MPPI::~MPPI() { tbnav_mppi_destroy(h_); }
+MPPI::MPPI(MPPI&& o) noexcept
+    : h_(o.h_), steps_(o.steps_), rollouts_(o.rollouts_), ul_sig_(o.ul_sig_), ur_sig_(o.ur_sig_), device_noise_(o.device_noise_),
+      seed_(o.seed_), tick_(o.tick_), noise_(std::move(o.noise_)) { o.h_ = nullptr; }
+
+void MPPI::setInitialControls(double uL, double uR) { check(tbnav_mppi_set_initial_controls(h_, uL, uR), "setInitialControls"); }
+void MPPI::setWaypoint(const Pose& w) { check(tbnav_mppi_set_waypoint(h_, w.x, w.y, w.theta), "setWaypoint"); }
+void MPPI::useDeviceNoise(std::uint64_t seed) { device_noise_ = true; seed_ = seed; tick_ = 0; }
+
+WheelVelocities MPPI::newControls(const Pose& ps) {
+  const double x0[3] = {ps.x, ps.y, ps.theta};  // mppi.cpp:75-76: state order (x, y, theta)
+  double out[2] = {0.0, 0.0};
+  if (device_noise_) {
+    check(tbnav_mppi_sample_noise(h_, seed_, tick_++, nullptr), "sample_noise");
+    check(tbnav_mppi_new_controls_dev(h_, x0, nullptr, nullptr, nullptr, out), "newControls");
+  } else {
+    noise_.resize((size_t)2 * steps_ * rollouts_);
+    size_t n = 0;
+    for (int k = 0; k < rollouts_; ++k)        // rollout-major, left then right per step (mppi.cpp:81-89,179-183)
+      for (int i = 0; i < steps_; ++i) {
+        noise_[n++] = rigid2d::sampleNormalDistribution(0.0, ul_sig_);
+        noise_[n++] = rigid2d::sampleNormalDistribution(0.0, ur_sig_);
+      }
+    check(tbnav_mppi_new_controls(h_, x0, noise_.data(), out), "newControls");
+  }
+  WheelVelocities w;
+  w.ul = out[0];
+  w.ur = out[1];
+  return w;
+}
+
+std::vector<double> MPPI::controls() const {
+  std::vector<double> u((size_t)2 * steps_);
+  check(tbnav_mppi_get_controls(h_, u.data()), "controls");
+  return u;
+}
+
+}  // namespace controller

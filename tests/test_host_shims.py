@@ -1,0 +1,169 @@
+"""The C++ class shims (ros-turtlebot-navigation_amd/host/, libtbnav_host.so): the rigid2d layer is
+bit-exact against the oracle (itself pinned to the reference build); the controller::MPPI and
+bmapping::ParticleFilter surfaces are driven exactly the way the ROS nodes call them."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_api as orc
+import rbpf_cases as rc
+from cases import MPPI_BASE, WAYPOINTS
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST_LIB = os.path.join(ROOT, "ros-turtlebot-navigation_amd", "lib", "libtbnav_host.so")
+
+
+@pytest.fixture(scope="module")
+def host(pkg):
+    pkg.capi.lib()  # loads torch's HIP runtime first, then libtbnav_hip.so
+    L = C.CDLL(HOST_LIB)
+    L.hst_normalize_angle_PI.restype = C.c_double
+    L.hst_normalize_angle_PI.argtypes = [C.c_double]
+    L.hst_dd_create.restype = C.c_void_p
+    L.hst_dd_create.argtypes = [C.c_void_p, C.c_double, C.c_double]
+    L.hst_dd_update_odometry.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_void_p]
+    L.hst_last_error.restype = C.c_char_p
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _arr(v):
+    return np.array(v, dtype=np.float64)
+
+
+def test_rigid2d_shim_bit_exact_vs_oracle(host):
+    r = orc.RigidAPI("orc")
+    rng = np.random.default_rng(4)
+    for x in np.concatenate([rng.uniform(-40, 40, 500), [0.0, np.pi, -np.pi]]):
+        assert host.hst_normalize_angle_PI(x) == r.normalize_angle_PI(x)
+    for _ in range(200):
+        a, b, v, tw = rng.uniform(-3, 3, 3), rng.uniform(-3, 3, 3), rng.uniform(-4, 4, 2), rng.uniform(-2, 2, 3)
+        out = np.empty(5)
+        host.hst_transform_compose(_p(a), _p(b), _p(out)); assert np.array_equal(out[:3], r.compose(a, b)[:3])
+        host.hst_transform_inv(_p(a), _p(out)); assert np.array_equal(out[:3], r.inv(a)[:3])
+        host.hst_transform_integrate_twist(_p(a), _p(tw), _p(out)); assert np.array_equal(out[:3], r.integrate_twist(a, tw)[:3])
+        o2 = np.empty(2); host.hst_transform_apply(_p(a), _p(v), _p(o2)); assert np.array_equal(o2, r.apply(a, v))
+    buf = C.create_string_buffer(128)
+    host.hst_transform_print(_p(_arr([np.pi / 2, 3.0, 5.0])), buf, 128)
+    assert buf.value.decode() == "theta (degrees): 90 x: 3 y: 5\n"   # operator<<, rigid2d.cpp:307-311
+
+
+def test_diff_drive_shim_bit_exact_vs_oracle(host):
+    r = orc.RigidAPI("orc")
+    rng = np.random.default_rng(6)
+    pose = _arr([0.1, -0.2, 0.3])
+    dh = C.c_void_p(host.hst_dd_create(_p(pose), 0.16, 0.033)); do = r.dd_create(pose, 0.16, 0.033)
+    enc = np.zeros(2); st = np.empty(7); out2 = np.empty(2)
+    for step in range(300):
+        if step % 2:
+            tw = _arr([rng.uniform(-1, 1), rng.uniform(-0.3, 0.3), 0.0])
+            assert host.hst_dd_feedforward(dh, _p(tw)) == r.dd_feedforward(do, tw) == 0
+        else:
+            enc = enc + rng.uniform(-0.5, 0.7, 2)
+            host.hst_dd_update_odometry(dh, enc[0], enc[1], _p(out2))
+            assert np.array_equal(out2, r.dd_update_odometry(do, *enc))
+        host.hst_dd_state(dh, _p(st))
+        assert np.array_equal(st, r.dd_state(do))
+    assert host.hst_dd_twist_to_wheels(dh, _p(_arr([0, 1, 0.5])), _p(out2)) == 1
+    assert host.hst_last_error() == b"Twist cannot have y velocity component"   # diff_drive.cpp:72
+    host.hst_dd_destroy(dh); r.dd_destroy(do)
+
+
+def test_host_twister_draws_like_the_reference_sampler(host):
+    a = np.empty(1000)
+    host.hst_twister_stream(C.c_uint64(42), C.c_int64(1000), C.c_double(0.0), C.c_double(np.sqrt(0.9)), _p(a))
+    assert np.array_equal(a, orc.normal_stream(42, 1000, 0.0, np.sqrt(0.9)))
+
+
+def _mppi_params(d):
+    return _arr([d["wheel_radius"], d["wheel_base"], d["lam"], d["max_wheel_vel"], d["ul_var"], d["ur_var"], d["horizon"],
+                 d["dt"]] + d["Q"] + d["R"] + d["P1"])
+
+
+@pytest.mark.gpu
+def test_mppi_class_surface_matches_oracle_with_seeded_twister(host, gpu_pkg):
+    """controller::MPPI::newControls draws its own noise from rigid2d::getTwister(): with the twister
+    seeded, three ticks equal three oracle ticks fed the same stream (control vector <= 1e-9)."""
+    d = dict(MPPI_BASE, rollouts=64)
+    T, K, n_ticks = 25, 64, 3
+    out = np.empty(2 * n_ticks); u_dev = np.empty((2, T))
+    got_T = host.hst_mppi_tick(_p(_mppi_params(d)), K, C.c_uint64(7), _p(_arr(WAYPOINTS[1])), _p(_arr([0.0, 0.0, 0.0])),
+                               n_ticks, _p(out), _p(u_dev))
+    assert got_T == T, host.hst_last_error()
+    stream = orc.normal_stream(7, n_ticks * K * T * 2, 0.0, np.sqrt(0.9)).reshape(n_ticks, K, T, 2)
+    u = np.zeros((2, T))
+    for t in range(n_ticks):
+        ref = orc.mppi_new_controls(d, u, (0, 0), WAYPOINTS[1], (0, 0, 0), stream[t])
+        u = ref["u"]
+        assert np.allclose(out[2 * t:2 * t + 2], ref["out"], rtol=1e-9, atol=1e-12)
+    assert np.allclose(u_dev, u, rtol=1e-9, atol=1e-12)
+
+
+def _closed_loop(host, d, K, max_ticks, seed=3):
+    wp = _arr(WAYPOINTS).copy()
+    traj = np.zeros((max_ticks, 5)); reached = C.c_int()
+    ticks = host.hst_mppi_closed_loop(_p(_mppi_params(d)), K, C.c_uint64(seed), _p(wp), 5, C.c_double(0.05), C.c_double(60.0),
+                                      max_ticks, _p(traj), C.byref(reached))
+    assert ticks > 0, host.hst_last_error()
+    return traj[:ticks], reached.value
+
+
+@pytest.mark.gpu
+def test_cfg1_closed_loop_plumbing(host, gpu_pkg):
+    """BASELINE configs[0] (K=64, T=25, diff-drive kinematics, 5-waypoint path): the whole chain
+    newControls -> DiffDrive::wheelsToTwist -> plant feedforward(twist/60) -> pose -> waypoint switch
+    (mppi_waypoints_node.cpp:226-305, fake_diff_encoders_node.cpp:105-113) runs and drives toward the
+    goal.  With a 0.25 s horizon this controller only creeps up to a waypoint (measured: it needs
+    > 40 000 ticks for the second one), so the plumbing check is progress, not lap completion."""
+    d = dict(MPPI_BASE, rollouts=64)
+    traj, reached = _closed_loop(host, d, 64, 3000)
+    dist = np.hypot(traj[:, 0] - WAYPOINTS[1][0], traj[:, 1] - WAYPOINTS[1][1])
+    print(f"\n[cfg1 closed loop] ticks {len(traj)}, waypoints reached {reached}, distance to waypoint 1: {dist[0]:.3f} -> {dist[-1]:.3f} m")
+    assert dist[-1] < 0.15 and dist[-1] < 0.2 * dist[0]
+    assert np.all(np.abs(traj[:, 3:]) <= d["max_wheel_vel"] + 1e-12)
+
+
+@pytest.mark.gpu
+def test_cfg2_closed_loop_completes_the_pentagon(host, gpu_pkg):
+    """K=1024, T=50 (BASELINE configs[1]) through the class surface: one full lap of the five waypoints
+    of nuturtle_robot/config/real_waypoints.yaml (measured on MI355X: ~2000 ticks at 60 Hz)."""
+    d = dict(MPPI_BASE, rollouts=1024, horizon=0.5)
+    traj, reached = _closed_loop(host, d, 1024, 6000)
+    print(f"\n[cfg2 closed loop] ticks {len(traj)}, waypoints reached {reached}")
+    assert reached == 5
+
+
+@pytest.mark.gpu
+def test_particle_filter_class_surface_end_to_end(host, gpu_pkg):
+    """bmapping::ParticleFilter driven like turtle_mapping_node.cpp:459-494 (SLAM, getRobotState,
+    newMap).  No distance-field injection here, so the comparison with the oracle filter is an
+    integration check: best pose within 1 mm, exported maps agree on >= 99 % of cells."""
+    N, k, n_scans = 40, 50, 5
+    steps, poses = rc.trajectory(n_scans, inc=(0.04, 0.03, 0.02))
+    rng = np.random.default_rng(3)
+    scans = np.stack([orc.room_scan(poses[s], walls=rc.ROOM_SMALL, rng=rng) for s in range(n_scans)])
+    odom = np.stack([steps[0][0]] + [st[1] for st in steps])
+    out_pose = np.empty((n_scans, 3)); out_neff = np.empty(n_scans, dtype=np.int32); m = np.empty(80 * 80, dtype=np.int8)
+    xs = host.hst_pf_run(N, k, C.c_double(2.0), C.c_uint64(11), _p(scans), 360, n_scans, _p(odom), _p(out_pose), _p(out_neff), _p(m))
+    assert xs == 80, host.hst_last_error()
+    # the same run through the oracle filter: same twister stream, same ICP convention
+    pf = orc.PfAPI(orc.pf_params(N=N, k=k, pose0=tuple(odom[0])))
+    stream = orc.normal_stream(11, n_scans * (N * (3 * k + 3) + 1), 0.0, 1.0)
+    off = 0
+    for s in range(n_scans):
+        prev, cur = odom[s], odom[s + 1]
+        t_icp = (0.0, 0.0, 0.0) if s == 0 else rc.compose(rc.inverse(prev), cur)  # first call: identity (cloud_alignment.cpp:43-50)
+        nz = stream[off:off + N * (3 * k + 3) + 1]
+        tr = pf.slam(scans[s], (0, 0, 0), cur, prev, True, t_icp, nz)
+        off += tr["normals_used"]
+        assert tr["rc"] == 0
+        po, _, _ = pf.particles()
+        assert np.allclose(out_pose[s], po[pf.best()], atol=1e-3)
+    agree = np.mean(m == pf.grid(pf.best()).grid_map())
+    print(f"\n[pf class surface] Neff {out_neff.tolist()}, exported map agreement {agree*100:.2f} %")
+    assert agree >= 0.99
