@@ -1,0 +1,197 @@
+"""Worker entry points for the world_size-2 tests (spawned processes; gloo over 127.0.0.1)."""
+import os
+import sys
+import traceback
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def _init(rank, world, port):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    return dist
+
+
+def run_spawn(fn, world, *args):
+    """Spawn `world` processes running fn(rank, world, port, result_dict, *args); returns {rank: result}."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    res = mgr.dict()
+    procs = [ctx.Process(target=_guard, args=(fn, r, world, port, res) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+    out = dict(res)
+    errs = [v for k, v in out.items() if isinstance(k, str) and k.startswith("err")]
+    assert not errs, "\n".join(errs)
+    assert all(r in out for r in range(world)), f"missing ranks: {sorted(k for k in out)}"
+    return out
+
+
+def _guard(fn, rank, world, port, res, *args):
+    try:
+        dist = _init(rank, world, port)
+        res[rank] = fn(rank, world, *args)
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        res[f"err{rank}"] = f"rank {rank}:\n{traceback.format_exc()}"
+
+
+# ---- MPPI: oracle compute per rank, real exchange -------------------------------------------------
+class OracleMppiBackend:
+    """Per-rank compute by the oracle (CPU): same partial-record contract as the HIP handle."""
+
+    def __init__(self, cfg_local, cfg_global, xd, uinit):
+        import oracle_api as orc
+        self.orc, self.cl, self.cg, self.xd, self.uinit = orc, cfg_local, cfg_global, xd, uinit
+        self.T = orc.mppi_steps(cfg_local)
+        self.u = np.zeros((2, self.T))
+        self.out = None
+
+    def partials(self, x0, noise):
+        import torch
+        _, rec = self.orc.mppi_shard_partials(self.cl, self.u, self.xd, x0, noise)
+        return torch.from_numpy(rec.reshape(self.T, 1, 8).copy())
+
+    def combine(self, records_all, n_shards):
+        rec = records_all.numpy().reshape(n_shards, self.T, 8)
+        self.u, self.out = self.orc.mppi_combine(self.cg, self.u, self.uinit, rec)
+
+    def result(self):
+        return self.out
+
+
+def mppi_worker(rank, world, K_global, horizon, n_ticks, seed):
+    import __graft_entry__ as g
+    g.load_package()
+    import oracle_api as orc
+    from cases import WAYPOINTS, mppi_cfg
+    from rtn_amd.sharded import ShardedMPPI
+    Kl = K_global // world
+    cg, cl = mppi_cfg(K_global, horizon), mppi_cfg(Kl, horizon)
+    T = orc.mppi_steps(cg)
+    sm = ShardedMPPI(OracleMppiBackend(cl, cg, WAYPOINTS[1], (0.0, 0.0)))
+    outs = []
+    for t in range(n_ticks):
+        noise = orc.normal_stream(seed + t, K_global * T * 2, 0.0, np.sqrt(0.9)).reshape(K_global, T, 2)
+        sm.tick((0.0, 0.0, 0.0), noise[rank * Kl:(rank + 1) * Kl])
+        outs.append(sm.result())
+    return dict(outs=outs, u=sm.b.u)
+
+
+# ---- RBPF: fake per-rank compute, real exchange + the product's resample_global -------------------
+class FakeRbpfBackend:
+    """Stands in for the HIP handle: deterministic per-particle 'update', a small vector as the map."""
+
+    def __init__(self, rank, n_local, map_len=32):
+        self.n_local, self.rank = n_local, rank
+        gid = np.arange(rank * n_local, (rank + 1) * n_local)
+        self.state = np.stack([gid + 0.25, gid * 2.0, gid * 3.0, gid + 0.5, gid * 5.0, gid * 7.0, np.zeros(n_local)], 1)
+        self.maps = gid[:, None] * 1000.0 + np.arange(map_len)[None, :]
+        self.dist_maps = -self.maps
+
+    def slam_local(self, scan, u, cur, prev, icp_ok, T_icp, normals_local):
+        self.state[:, 6] = np.abs(normals_local[:self.n_local]) ** 4 + 1e-3  # raw weights from this rank's draws
+        return None
+
+    def weights(self):
+        return self.state[:, 6].copy()
+
+    def set_weights(self, w):
+        self.state[:, 6] = w
+
+    def export_particle(self, slot):
+        return dict(state=self.state[slot].copy(), log_odds=self.maps[slot].copy(), dist=self.dist_maps[slot].copy())
+
+    def import_particle(self, slot, blob):
+        self.state[slot], self.maps[slot], self.dist_maps[slot] = blob["state"], blob["log_odds"], blob["dist"]
+
+    def gather_local(self, local_parent):
+        src = np.where(local_parent < 0, np.arange(self.n_local), local_parent)
+        self.state, self.maps, self.dist_maps = self.state[src].copy(), self.maps[src].copy(), self.dist_maps[src].copy()
+
+
+def rbpf_worker(rank, world, n_local, seed):
+    import __graft_entry__ as g
+    g.load_package()
+    from rtn_amd.rbpf import resample_global
+    from rtn_amd.sharded import ShardedRBPF
+    N = n_local * world
+    b = FakeRbpfBackend(rank, n_local)
+    sr = ShardedRBPF(b, resample_global)
+    rng = np.random.default_rng(seed)
+    normals = rng.standard_normal(N * 1 + 1)
+    st, _, parents = sr.tick(None, None, None, None, True, None, normals, 1)
+    return dict(state=b.state, maps=b.maps, dist=b.dist_maps, parents=parents, neff=st.neff, resampled=st.resampled)
+
+
+# ---- HIP compute per rank (two processes sharing ONE GPU, gloo exchange) -----------------------------
+def mppi_hip_worker(rank, world, K_global, horizon, n_ticks, seed):
+    import torch
+    import __graft_entry__ as g
+    g.load_package()
+    import oracle_api as orc
+    from cases import WAYPOINTS, make_mppi, mppi_cfg
+    from rtn_amd.sharded import HipShardBackend, ShardedMPPI
+    Kl = K_global // world
+    T = orc.mppi_steps(mppi_cfg(K_global, horizon))
+    m = make_mppi(None, mppi_cfg(Kl, horizon), 0)
+    m.setWaypoint(*WAYPOINTS[1])
+    dev = torch.device("cuda", 0)
+    sm = ShardedMPPI(HipShardBackend(m, dev))
+    outs = []
+    for t in range(n_ticks):
+        noise = orc.normal_stream(seed + t, K_global * T * 2, 0.0, np.sqrt(0.9)).reshape(K_global, T, 2)
+        nz = torch.from_numpy(noise[rank * Kl:(rank + 1) * Kl]).to(dev)
+        a, b = nz[:, :, 0].t().contiguous(), nz[:, :, 1].t().contiguous()
+        sm.tick((0.0, 0.0, 0.0), (a.data_ptr(), b.data_ptr()))
+        outs.append(sm.result())
+    return dict(outs=outs, u=m.getControls())
+
+
+def rbpf_scenario(n_scans=3):
+    import oracle_api as orc
+    import rbpf_cases as rc
+    steps, poses = rc.trajectory(n_scans, inc=(0.03, 0.02, 0.02))
+    rng = np.random.default_rng(5)
+    scans = [orc.room_scan(poses[s], walls=rc.ROOM_SMALL, rng=rng) for s in range(n_scans)]
+    return steps, scans
+
+
+def rbpf_hip_worker(rank, world, n_local, k, skew_scan):
+    import __graft_entry__ as g
+    g.load_package()
+    import oracle_api as orc
+    from rtn_amd.rbpf import ParticleFilter, default_params, resample_global
+    from rtn_amd.sharded import HipRbpfShardBackend, ShardedRBPF
+    N = n_local * world
+    pf = ParticleFilter(default_params(N=n_local, k=k))
+    sr = ShardedRBPF(HipRbpfShardBackend(pf), resample_global)
+    steps, scans = rbpf_scenario()
+    stride = 3 * k + 3
+    hist = []
+    for s, (prev, cur, t_icp, u) in enumerate(steps):
+        normals = orc.normal_stream(50 + s, N * stride + 1, 0.0, 1.0)
+        if s == skew_scan:
+            w = np.full(N, 0.01); w[3] = 0.6; w[N - 2] = 0.25; w /= w.sum()
+            pf.setParticles(w=w[rank * n_local:(rank + 1) * n_local])
+        st, _, parents = sr.tick(scans[s], u, cur, prev, True, t_icp, normals, stride)
+        hist.append((st.neff, st.resampled, parents.tolist()))
+    pose, prev_pose, w = pf.particles()
+    return dict(pose=pose, prev=prev_pose, w=w, hist=hist, lo=[pf.logOdds(p) for p in range(n_local)],
+                codes=[pf.distCode(p) for p in range(n_local)])

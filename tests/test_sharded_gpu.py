@@ -1,0 +1,64 @@
+"""The sharded drivers with the HIP backends: two ranks (two processes) sharing ONE MI355X, gloo for
+the exchange (RCCL needs one GPU per rank; the 8-GPU run is the driver's).  The sharded result must
+equal the unsharded HIP run — bit-exact for the RBPF (same kernels per particle, same sequential
+normalise/selection), within fp64 reassociation for the MPPI soft-min."""
+import numpy as np
+import pytest
+
+import oracle_api as orc
+from cases import WAYPOINTS, make_mppi, mppi_cfg
+from dist_workers import mppi_hip_worker, rbpf_hip_worker, rbpf_scenario, run_spawn
+
+pytestmark = pytest.mark.gpu
+
+
+def test_mppi_two_ranks_one_gpu(gpu_pkg):
+    K, horizon, n_ticks, seed = 4096, 0.5, 3, 9
+    res = run_spawn(mppi_hip_worker, 2, K, horizon, n_ticks, seed)
+    d = mppi_cfg(K, horizon)
+    T = orc.mppi_steps(d)
+    m = make_mppi(gpu_pkg, d)
+    m.setWaypoint(*WAYPOINTS[1])
+    u = np.zeros((2, T))
+    for t in range(n_ticks):
+        noise = orc.normal_stream(seed + t, K * T * 2, 0.0, np.sqrt(0.9)).reshape(K, T, 2)
+        got = m.newControls(0.0, 0.0, 0.0, noise)
+        ref = orc.mppi_new_controls(d, u, (0, 0), WAYPOINTS[1], (0, 0, 0), noise)
+        u = ref["u"]
+        for r in (0, 1):
+            assert np.allclose(res[r]["outs"][t], got, rtol=1e-10, atol=1e-13)
+            assert np.allclose(res[r]["outs"][t], ref["out"], rtol=1e-9, atol=1e-12)
+    assert np.array_equal(res[0]["u"], res[1]["u"])
+    assert np.allclose(res[0]["u"], m.getControls(), rtol=1e-10, atol=1e-13)
+
+
+def test_rbpf_two_ranks_one_gpu_equals_unsharded_bit_exact(gpu_pkg):
+    from rtn_amd.rbpf import ParticleFilter, default_params
+    n_local, k, skew_scan = 6, 8, 1
+    N = 2 * n_local
+    res = run_spawn(rbpf_hip_worker, 2, n_local, k, skew_scan)
+    pf = ParticleFilter(default_params(N=N, k=k))
+    steps, scans = rbpf_scenario()
+    stride = 3 * k + 3
+    resampled_any = False
+    for s, (prev, cur, t_icp, u) in enumerate(steps):
+        normals = orc.normal_stream(50 + s, N * stride + 1, 0.0, 1.0)
+        if s == skew_scan:
+            w = np.full(N, 0.01); w[3] = 0.6; w[N - 2] = 0.25; w /= w.sum()
+            pf.setParticles(w=w)
+        st = pf.SLAM(scans[s], u, cur, prev, True, t_icp, normals)
+        for r in (0, 1):
+            neff, resampled, parents = res[r]["hist"][s]
+            assert (neff, resampled) == (st.neff, st.resampled)
+            if st.resampled:
+                assert parents == pf.trace()["resample_idx"].tolist()
+        resampled_any |= bool(st.resampled)
+    assert resampled_any
+    pose, prev_pose, w = pf.particles()
+    for r in (0, 1):
+        sl = slice(r * n_local, (r + 1) * n_local)
+        assert np.array_equal(res[r]["pose"], pose[sl]) and np.array_equal(res[r]["prev"], prev_pose[sl])
+        assert np.array_equal(res[r]["w"], w[sl])
+        for p in range(n_local):
+            assert np.array_equal(res[r]["lo"][p], pf.logOdds(r * n_local + p))
+            assert np.array_equal(res[r]["codes"][p], pf.distCode(r * n_local + p))
