@@ -124,6 +124,10 @@ int tbnav_mppi_shard_combine(tbnav_mppi* h, const double* d_records_all, int32_t
  * (reference J(i,k) after cumSumCost, mppi.cpp:109). */
 int tbnav_mppi_get_cost_to_go(tbnav_mppi* h, double* J_host);
 
+/* The rollout kernel's own sin/cos (Cody-Waite reduction + fdlibm kernel polynomials; ocml's sincos
+ * beyond |x| = 1e5) evaluated on n host values — lets the tests bound its error against libm. */
+int tbnav_mppi_debug_sincos(const double* x_host, int32_t n, double* sin_host, double* cos_host);
+
 /* ---- measurement hook -------------------------------------------------------------------------- */
 
 /* One tick with a hipEvent pair around each kernel, recorded on `stream` (the stream the kernels

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -41,25 +42,122 @@ struct RolloutArgs {
   int T, K;
 };
 
-// One RK4 step of the kinematic cart with zero-order-hold control (rk4.cpp:95-115).  k2 and k3 see
-// the same heading because k1.theta == k2.theta (theta-dot does not depend on the state), so three
-// sincos evaluations cover the four stages; every product/sum keeps the reference's association.
-__device__ __forceinline__ void rk4_step(const RolloutArgs& a, double& x, double& y, double& th,
-                                         double ul, double ur) {
-  const double v = a.half_r * (ul + ur);
-  const double w = a.r_over_b * (ur - ul);
-  double s1, c1, s2, c2, s4, c4;
-  sincos(th, &s1, &c1);
-  const double th2 = th + a.h * (0.5 * w);
-  sincos(th2, &s2, &c2);
-  const double th4 = th + a.h * w;
-  sincos(th4, &s4, &c4);
-  const double k1x = v * c1, k1y = v * s1;
-  const double k2x = v * c2, k2y = v * s2;
-  const double k4x = v * c4, k4y = v * s4;
-  x = x + a.h6 * (((k1x + 2.0 * k2x) + 2.0 * k2x) + k4x);
-  y = y + a.h6 * (((k1y + 2.0 * k2y) + 2.0 * k2y) + k4y);
-  th = th + a.h6 * (((w + 2.0 * w) + 2.0 * w) + w);
+// One RK4 step of the kinematic cart with zero-order-hold control (rk4.cpp:95-115).  theta-dot does
+// not depend on the state, so k1.theta == k2.theta == k3.theta == k4.theta == w and the four stages
+// see the headings th, th+d, th+d, th+2d with d = h*(0.5*w).  Every product/sum keeps the
+// reference's association.
+//
+// TRIG = 3: three sincos calls per step (th, th+d, th+2d), exactly the reference's evaluations.
+// TRIG = 1: ONE sincos per step (th, refreshed every step so nothing accumulates) and the other two
+//           headings by angle addition with sin/cos of the small angle d (|d| <= 2^-5: degree-11/10
+//           Taylor polynomials, truncation < 1e-24; larger |d|: a full sincos of d).  The rotated
+//           values are within ~2 ulp of libm's, i.e. the same size as the libm-vs-ocml difference the
+//           parity tolerance already absorbs; J stays within 1e-12 of the oracle (tests).
+// ---- device trig for the rollout -------------------------------------------------------------------
+// ocml's sincos carries a Payne-Hanek path and (under this file's flags) ~130 fp64 instructions; a
+// rollout heading is a few radians.  fast_sincos: Cody-Waite reduction by pi/2 held as three doubles
+// (exact-product FMAs, good to ~1e-16 absolute for |x| <= 1e5) + the fdlibm kernel polynomials on
+// [-pi/4, pi/4] (< 1 ulp).  Larger |x| or non-finite input takes the out-of-line ocml call.
+__device__ __noinline__ void slow_sincos(double x, double* s, double* c) { sincos(x, s, c); }
+
+__device__ __forceinline__ void fast_sincos(double x, double& s, double& c) {
+  if (!(fabs(x) <= 1.0e5)) { slow_sincos(x, &s, &c); return; }
+  const double kf = rint(x * 0.6366197723675814);
+  double r = fma(-kf, 0x1.921fb54442d18p+0, x);
+  r = fma(-kf, 0x1.1a62633145c07p-54, r);
+  r = fma(-kf, -0x1.f1976b7ed8fbcp-110, r);
+  const double z = r * r;
+  // sin kernel
+  double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = fma(z, ps, 2.75573137070700676789e-06);
+  ps = fma(z, ps, -1.98412698298579493134e-04);
+  ps = fma(z, ps, 8.33333333332248946124e-03);
+  const double sr = fma(z * r, fma(z, ps, -1.66666666666666324348e-01), r);
+  // cos kernel
+  double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = fma(z, pc, -2.75573143513906633035e-07);
+  pc = fma(z, pc, 2.48015872894767294178e-05);
+  pc = fma(z, pc, -1.38888888888741095749e-03);
+  pc = fma(z, pc, 4.16666666666666019037e-02);
+  const double hz = 0.5 * z, wq = 1.0 - hz;
+  const double cr = wq + (((1.0 - wq) - hz) + z * (z * pc));
+  const int n = (int)kf & 3;
+  const double sa = (n & 1) ? cr : sr, ca = (n & 1) ? sr : cr;
+  s = (n & 2) ? -sa : sa;
+  c = ((n + 1) & 2) ? -ca : ca;
+}
+
+__device__ __forceinline__ void small_sincos(double d, double& sd, double& cd) {
+  if (fabs(d) <= 0.03125) {
+    const double d2 = d * d;
+    // sin d = d (1 - d2/6 (1 - d2/20 (1 - d2/42 (1 - d2/72 (1 - d2/110)))))
+    double ps = 1.0 - d2 * (1.0 / 110.0);
+    ps = 1.0 - d2 * (1.0 / 72.0) * ps;
+    ps = 1.0 - d2 * (1.0 / 42.0) * ps;
+    ps = 1.0 - d2 * (1.0 / 20.0) * ps;
+    ps = 1.0 - d2 * (1.0 / 6.0) * ps;
+    sd = d * ps;
+    // cos d = 1 - d2/2 (1 - d2/12 (1 - d2/30 (1 - d2/56 (1 - d2/90))))
+    double pc = 1.0 - d2 * (1.0 / 90.0);
+    pc = 1.0 - d2 * (1.0 / 56.0) * pc;
+    pc = 1.0 - d2 * (1.0 / 30.0) * pc;
+    pc = 1.0 - d2 * (1.0 / 12.0) * pc;
+    cd = 1.0 - d2 * 0.5 * pc;
+  } else {
+    fast_sincos(d, sd, cd);
+  }
+}
+
+// G consecutive RK4 steps.  The heading recurrence th_{i+1} = th_i + (h/6)*(6 w_i) is a cheap serial
+// chain, so the G headings are formed first and the G expensive trig evaluations that depend on them
+// are INDEPENDENT: with one wave per SIMD (K = 65536 gives exactly that) the in-order issue would
+// otherwise sit on each sincos's dependent chain; this way G chains are in flight at once.  x and y
+// are then accumulated in step order with the reference's association, and the per-step losses formed.
+template <int TRIG, int G>
+__device__ __forceinline__ void rk4_steps(const RolloutArgs& a, double& x, double& y, double& th,
+                                          const double (&ul)[G], const double (&ur)[G], double (&thq)[G],
+                                          double (&xq)[G], double (&yq)[G]) {
+  double v[G], w[G], hth[G];
+#pragma unroll
+  for (int q = 0; q < G; ++q) {
+    v[q] = a.half_r * (ul[q] + ur[q]);
+    w[q] = a.r_over_b * (ur[q] - ul[q]);
+  }
+  double t = th;
+#pragma unroll
+  for (int q = 0; q < G; ++q) {
+    hth[q] = t;                                              // heading at the START of step q
+    t = t + a.h6 * (((w[q] + 2.0 * w[q]) + 2.0 * w[q]) + w[q]);
+    thq[q] = t;                                              // heading AFTER step q (what the loss sees)
+  }
+  th = t;
+  double s1[G], c1[G], s2[G], c2[G], s4[G], c4[G];
+#pragma unroll
+  for (int q = 0; q < G; ++q) {
+    fast_sincos(hth[q], s1[q], c1[q]);
+    if (TRIG == 3) {
+      fast_sincos(hth[q] + a.h * (0.5 * w[q]), s2[q], c2[q]);
+      fast_sincos(hth[q] + a.h * w[q], s4[q], c4[q]);
+    } else {
+      double sd, cd;
+      small_sincos(a.h * (0.5 * w[q]), sd, cd);
+      c2[q] = c1[q] * cd - s1[q] * sd;
+      s2[q] = s1[q] * cd + c1[q] * sd;
+      const double s2d = 2.0 * sd * cd, c2d = 1.0 - 2.0 * sd * sd;  // double angle: one rotation from (c1, s1)
+      c4[q] = c1[q] * c2d - s1[q] * s2d;
+      s4[q] = s1[q] * c2d + c1[q] * s2d;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < G; ++q) {
+    const double k1x = v[q] * c1[q], k1y = v[q] * s1[q];
+    const double k2x = v[q] * c2[q], k2y = v[q] * s2[q];
+    const double k4x = v[q] * c4[q], k4y = v[q] * s4[q];
+    x = x + a.h6 * (((k1x + 2.0 * k2x) + 2.0 * k2x) + k4x);
+    y = y + a.h6 * (((k1y + 2.0 * k2y) + 2.0 * k2y) + k4y);
+    xq[q] = x;
+    yq[q] = y;
+  }
 }
 
 __device__ __forceinline__ double lqr_loss(const RolloutArgs& a, double x, double y, double th,
@@ -75,8 +173,36 @@ __device__ __forceinline__ double terminal_loss(const RolloutArgs& a, double x, 
 }
 
 // LDS_STAGE: per-step losses live in LDS ([T][64] doubles, one column per lane, conflict-free 8-B
-// accesses) so J is written to HBM exactly once; otherwise J itself is the scratch (T too long).
-template <bool LDS_STAGE>
+// accesses) so J is written to HBM exactly once; otherwise J itself is the scratch (forward pass
+// writes the loss, the backward pass re-reads it last-written-first, i.e. out of L2) and no LDS limits
+// residency — chosen at create time from the grid size (see tbnav_mppi_create).
+// The noise of group g+1 (G steps x 2 arrays x 512 B per wave) is requested before group g is
+// integrated, so the loads fly under a group's worth of trig instead of stalling each step.
+constexpr int kGroup = 4;
+template <bool LDS_STAGE, int TRIG, int G>
+__device__ __forceinline__ void rollout_group(const RolloutArgs& a, int i0, int lane, int k, double& x, double& y,
+                                              double& th, const double (&dl)[G], const double (&dr)[G],
+                                              const double* __restrict__ u, double* __restrict__ lds_loss,
+                                              double* __restrict__ J) {
+  const int T = a.T, K = a.K;
+  double ul[G], ur[G], thq[G], xq[G], yq[G];
+#pragma unroll
+  for (int q = 0; q < G; ++q) {
+    ul[q] = u[i0 + q] + dl[q];        // mppi.cpp:93 — rollout controls are not clamped
+    ur[q] = u[T + i0 + q] + dr[q];
+  }
+  rk4_steps<TRIG, G>(a, x, y, th, ul, ur, thq, xq, yq);
+#pragma unroll
+  for (int q = 0; q < G; ++q) {
+    const int i = i0 + q;
+    const double l = (i == T - 1) ? terminal_loss(a, xq[q], yq[q], thq[q])  // mppi.cpp:105 overwrites, not adds
+                                  : lqr_loss(a, xq[q], yq[q], thq[q], ul[q], ur[q]);
+    if (LDS_STAGE) lds_loss[i * kWave + lane] = l;
+    else J[(size_t)i * K + k] = l;
+  }
+}
+
+template <bool LDS_STAGE, int TRIG>
 __global__ __launch_bounds__(kWave) void mppi_rollout_cost(RolloutArgs a,
                                                            const double* __restrict__ duL,
                                                            const double* __restrict__ duR,
@@ -88,21 +214,48 @@ __global__ __launch_bounds__(kWave) void mppi_rollout_cost(RolloutArgs a,
   if (k >= a.K) return;
   const int T = a.T, K = a.K;
   double x = a.x0[0], y = a.x0[1], th = a.x0[2];
-  for (int i = 0; i < T; ++i) {
-    const double ul = u[i] + duL[(size_t)i * K + k];      // mppi.cpp:93 — rollout controls unclamped
-    const double ur = u[T + i] + duR[(size_t)i * K + k];
-    rk4_step(a, x, y, th, ul, ur);
-    const double l = (i == T - 1) ? terminal_loss(a, x, y, th)  // mppi.cpp:105 overwrites, not adds
-                                  : lqr_loss(a, x, y, th, ul, ur);
-    if (LDS_STAGE) lds_loss[i * kWave + lane] = l;
-    else J[(size_t)i * K + k] = l;
+  const int n_full = T / kGroup;
+  double nl[kGroup], nr[kGroup];
+  if (n_full > 0) {
+#pragma unroll
+    for (int q = 0; q < kGroup; ++q) { nl[q] = duL[(size_t)q * K + k]; nr[q] = duR[(size_t)q * K + k]; }
   }
-  // cumSumCost (mppi.cpp:15-25): J(i) = loss(i) + J(i+1), from the end.
-  double acc = LDS_STAGE ? lds_loss[(T - 1) * kWave + lane] : J[(size_t)(T - 1) * K + k];
-  J[(size_t)(T - 1) * K + k] = acc;
-  for (int i = T - 2; i >= 0; --i) {
+  for (int g = 0; g < n_full; ++g) {
+    double dl[kGroup], dr[kGroup];
+#pragma unroll
+    for (int q = 0; q < kGroup; ++q) { dl[q] = nl[q]; dr[q] = nr[q]; }
+    if (g + 1 < n_full) {
+#pragma unroll
+      for (int q = 0; q < kGroup; ++q) {
+        const size_t off = (size_t)((g + 1) * kGroup + q) * K + k;
+        nl[q] = duL[off];
+        nr[q] = duR[off];
+      }
+    }
+    rollout_group<LDS_STAGE, TRIG, kGroup>(a, g * kGroup, lane, k, x, y, th, dl, dr, u, lds_loss, J);
+  }
+  for (int i = n_full * kGroup; i < T; ++i) {  // ragged tail, one step at a time
+    const double dl[1] = {duL[(size_t)i * K + k]}, dr[1] = {duR[(size_t)i * K + k]};
+    rollout_group<LDS_STAGE, TRIG, 1>(a, i, lane, k, x, y, th, dl, dr, u, lds_loss, J);
+  }
+  // cumSumCost (mppi.cpp:15-25): J(i) = loss(i) + J(i+1), from the end.  The staged losses are fetched
+  // eight at a time (independent loads in flight together), then added in order.
+  double acc = 0.0;
+  int i = T - 1;
+  constexpr int kB = 8;
+  for (; i >= kB - 1; i -= kB) {
+    double l[kB];
+#pragma unroll
+    for (int q = 0; q < kB; ++q) l[q] = LDS_STAGE ? lds_loss[(i - q) * kWave + lane] : J[(size_t)(i - q) * K + k];
+#pragma unroll
+    for (int q = 0; q < kB; ++q) {
+      acc = (i - q == T - 1) ? l[q] : l[q] + acc;
+      J[(size_t)(i - q) * K + k] = acc;
+    }
+  }
+  for (; i >= 0; --i) {
     const double l = LDS_STAGE ? lds_loss[i * kWave + lane] : J[(size_t)i * K + k];
-    acc = l + acc;
+    acc = (i == T - 1) ? l : l + acc;
     J[(size_t)i * K + k] = acc;
   }
 }
@@ -220,6 +373,12 @@ __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, double 
 }
 
 // raw[(k*T + i)*2 + c]  ->  duL[i*K + k], duR[i*K + k]
+__global__ void mppi_debug_sincos(int n, const double* __restrict__ x, double* __restrict__ sn, double* __restrict__ cs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { double a, b; fast_sincos(x[i], a, b); sn[i] = a; cs[i] = b; }
+}
+
+// raw[(k*T + i)*2 + c]  ->  duL[i*K + k], duR[i*K + k]
 __global__ void mppi_unpack_noise(int T, int K, const double* __restrict__ raw,
                                   double* __restrict__ duL, double* __restrict__ duR) {
   const size_t n = (size_t)T * K;
@@ -293,6 +452,7 @@ struct tbnav_mppi {
   double* d_out = nullptr;      // [2]
   double* h_out = nullptr;      // pinned [2]
   bool lds_stage = true;
+  int trig = 1;               // sincos evaluations per RK4 step (1 = angle addition, 3 = the reference's three)
 };
 
 namespace {
@@ -308,12 +468,11 @@ int launch_rollout(tbnav_mppi* h, const double x0[3], const double* d_duL, const
   a.R[0] = h->p.R[0]; a.R[1] = h->p.R[1];
   a.T = h->T; a.K = h->K;
   const dim3 grid((h->K + kWave - 1) / kWave), block(kWave);
-  if (h->lds_stage) {
-    const size_t lds = (size_t)h->T * kWave * sizeof(double);
-    hipLaunchKernelGGL(mppi_rollout_cost<true>, grid, block, lds, st, a, d_duL, d_duR, h->d_u, h->d_J);
-  } else {
-    hipLaunchKernelGGL(mppi_rollout_cost<false>, grid, block, 0, st, a, d_duL, d_duR, h->d_u, h->d_J);
-  }
+  const size_t lds = (size_t)h->T * kWave * sizeof(double);
+  if (h->lds_stage && h->trig == 1) hipLaunchKernelGGL((mppi_rollout_cost<true, 1>), grid, block, lds, st, a, d_duL, d_duR, h->d_u, h->d_J);
+  else if (h->lds_stage) hipLaunchKernelGGL((mppi_rollout_cost<true, 3>), grid, block, lds, st, a, d_duL, d_duR, h->d_u, h->d_J);
+  else if (h->trig == 1) hipLaunchKernelGGL((mppi_rollout_cost<false, 1>), grid, block, 0, st, a, d_duL, d_duR, h->d_u, h->d_J);
+  else hipLaunchKernelGGL((mppi_rollout_cost<false, 3>), grid, block, 0, st, a, d_duL, d_duR, h->d_u, h->d_J);
   TBNAV_HIP(hipGetLastError());
   return TBNAV_OK;
 }
@@ -380,7 +539,21 @@ int tbnav_mppi_create(const tbnav_mppi_params* params, tbnav_mppi** out) {
   h->K = params->rollouts;
   h->S = (h->K + kSlice - 1) / kSlice;
   h->device = dev;
-  h->lds_stage = (size_t)T * kWave * sizeof(double) <= (size_t)kMaxLdsBytes;
+  {
+    // LDS staging writes J once, but T*512 B of LDS per one-wave block caps residency at
+    // floor(160 KB / that) blocks per CU; if the grid does not fit in one resident round the tail
+    // round costs more than the extra L2 traffic of staging the losses in J itself.
+    const size_t lds_bytes = (size_t)T * kWave * sizeof(double);
+    hipDeviceProp_t prop;
+    int cus = 256;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    const long blocks = (params->rollouts + kWave - 1) / kWave;
+    const long per_cu = lds_bytes ? (long)(kMaxLdsBytes / lds_bytes) : 0;
+    h->lds_stage = lds_bytes <= (size_t)kMaxLdsBytes && blocks <= per_cu * cus;
+  }
+  // development switches (A/B measurements; not part of the contract)
+  if (const char* e = std::getenv("TBNAV_MPPI_TRIG")) h->trig = (std::atoi(e) == 3) ? 3 : 1;
+  if (const char* e = std::getenv("TBNAV_MPPI_NO_LDS")) if (std::atoi(e) == 1) h->lds_stage = false;
   const size_t tk = (size_t)T * h->K;
   hipError_t e = hipSuccess;
   auto alloc = [&](double** p, size_t n) { if (e == hipSuccess) e = hipMalloc((void**)p, n * sizeof(double)); };
@@ -397,8 +570,11 @@ int tbnav_mppi_create(const tbnav_mppi_params* params, tbnav_mppi** out) {
   if (e == hipSuccess) e = hipMemset(h->d_duR, 0, tk * sizeof(double));
   if (e == hipSuccess) e = hipMemset(h->d_out, 0, 2 * sizeof(double));
   if (e == hipSuccess && h->lds_stage) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mppi_rollout_cost<true>),
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mppi_rollout_cost<true, 1>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)T * kWave * sizeof(double)));
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mppi_rollout_cost<true, 3>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)T * kWave * sizeof(double)));
   }
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) {
@@ -559,6 +735,21 @@ int tbnav_mppi_get_noise(tbnav_mppi* h, double* duL_host, double* duR_host) {
   TBNAV_HIP(hipDeviceSynchronize());
   TBNAV_HIP(hipMemcpy(duL_host, h->d_duL, n * sizeof(double), hipMemcpyDeviceToHost));
   TBNAV_HIP(hipMemcpy(duR_host, h->d_duR, n * sizeof(double), hipMemcpyDeviceToHost));
+  return TBNAV_OK;
+}
+
+int tbnav_mppi_debug_sincos(const double* x_host, int32_t n, double* sin_host, double* cos_host) {
+  if (!x_host || !sin_host || !cos_host || n <= 0) return TBNAV_ERR_INVALID_ARG;
+  double *dx = nullptr, *ds = nullptr, *dc = nullptr;
+  TBNAV_HIP(hipMalloc((void**)&dx, sizeof(double) * n));
+  TBNAV_HIP(hipMalloc((void**)&ds, sizeof(double) * n));
+  TBNAV_HIP(hipMalloc((void**)&dc, sizeof(double) * n));
+  hipError_t e = hipMemcpy(dx, x_host, sizeof(double) * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess) { hipLaunchKernelGGL(mppi_debug_sincos, dim3((n + 255) / 256), dim3(256), 0, nullptr, n, dx, ds, dc); e = hipGetLastError(); }
+  if (e == hipSuccess) e = hipMemcpy(sin_host, ds, sizeof(double) * n, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(cos_host, dc, sizeof(double) * n, hipMemcpyDeviceToHost);
+  (void)hipFree(dx); (void)hipFree(ds); (void)hipFree(dc);
+  TBNAV_HIP(e);
   return TBNAV_OK;
 }
 

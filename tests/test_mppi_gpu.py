@@ -219,3 +219,21 @@ def test_null_arguments_are_rejected(gpu_pkg):
     x0 = (C.c_double * 3)(0, 0, 0)
     dummy = C.c_void_p(8)
     assert L.tbnav_mppi_new_controls_dev(m._h, x0, dummy, None, None, out) == gpu_pkg.capi.ERR_INVALID_ARG
+
+
+def test_device_sincos_accuracy(gpu_pkg):
+    """The rollout kernel's own sin/cos against libm (numpy): <= 2 ulp-of-1 absolute over the range
+    rollout headings live in, the quadrant boundaries, tiny arguments, and the large-|x| fallback."""
+    L = gpu_pkg.capi.lib()
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-40, 40, 200000), rng.uniform(-1e5, 1e5, 50000), rng.uniform(-1e-3, 1e-3, 1000),
+                        np.arange(-64, 65) * (np.pi / 4), np.arange(-64, 65) * (np.pi / 2) + 1e-9,
+                        [0.0, -0.0, 1e-300, 1e5, -1e5, 1.0e5 + 1.0, 3e7, -2.5e12, 1e22]])
+    s = np.empty_like(x); c = np.empty_like(x)
+    gpu_pkg.capi.check(L.tbnav_mppi_debug_sincos(x.ctypes.data, x.size, s.ctypes.data, c.ctypes.data), "debug_sincos")
+    es, ec = np.abs(s - np.sin(x)), np.abs(c - np.cos(x))
+    print(f"\n[device sincos] max abs err sin {es.max():.3e} cos {ec.max():.3e}")
+    big = np.abs(x) > 1e5
+    print("   worst small-range:", es[~big].max(), ec[~big].max(), "worst x:", x[np.argmax(es)], x[np.argmax(ec)])
+    assert es.max() <= 2.5e-16 and ec.max() <= 2.5e-16
+    assert np.allclose(s * s + c * c, 1.0, atol=5e-16)

@@ -1,0 +1,10 @@
+#!/bin/bash
+# Dev A/B: rollout-kernel variants (sincos per step, LDS vs global loss staging).
+for trig in 3 1; do for nolds in 0 1; do
+  echo "== TRIG=$trig NO_LDS=$nolds"
+  TBNAV_MPPI_TRIG=$trig TBNAV_MPPI_NO_LDS=$nolds timeout 200 python bench.py --steps 300 --warmup 30 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline())
+print(' small: %.1f Mroll/s tick %.1f us kernels %s' % (d['value']/1e6, d['ms_per_step']*1e3, d['roofline']['kernel_ms']))
+l=d['roofline_large']; print(' large: %.1f Mroll/s tick %.1f us frac(tick) %.3f kernels %s' % (l['rollouts_per_s']/1e6, l['whole_tick']['ms']*1e3, l['whole_tick']['frac'], l['kernel_ms']))"
+done; done
