@@ -40,6 +40,7 @@ struct RolloutArgs {
   double xd[3];
   double Q[3], R[2], P1[3];
   int T, K;
+  int lds_from;     // steps i >= lds_from stage their loss in LDS (row i - lds_from); earlier ones in J itself
 };
 
 // One RK4 step of the kinematic cart with zero-order-hold control (rk4.cpp:95-115).  theta-dot does
@@ -54,14 +55,14 @@ struct RolloutArgs {
 //           values are within ~2 ulp of libm's, i.e. the same size as the libm-vs-ocml difference the
 //           parity tolerance already absorbs; J stays within 1e-12 of the oracle (tests).
 // ---- device trig for the rollout -------------------------------------------------------------------
-// ocml's sincos carries a Payne-Hanek path and (under this file's flags) ~130 fp64 instructions; a
-// rollout heading is a few radians.  fast_sincos: Cody-Waite reduction by pi/2 held as three doubles
-// (exact-product FMAs, good to ~1e-16 absolute for |x| <= 1e5) + the fdlibm kernel polynomials on
-// [-pi/4, pi/4] (< 1 ulp).  Larger |x| or non-finite input takes the out-of-line ocml call.
-__device__ __noinline__ void slow_sincos(double x, double* s, double* c) { sincos(x, s, c); }
-
+// ocml's sincos carries a Payne-Hanek path behind a branch and ~130 fp64 instructions; a rollout
+// heading is a few radians.  fast_sincos: Cody-Waite reduction by pi/2 held as three doubles, each
+// step one FMA (exact product, single rounding), then the fdlibm kernel polynomials on [-pi/4, pi/4].
+// Measured against libm: <= 1.1e-16 absolute for |x| <= 1e5 (tests); the reduction itself stays good to
+// ~1e-16 * (|x| * 2^-40 + 1), i.e. it degrades gracefully beyond 1e12 rad instead of branching to a
+// library call (a call inside the unrolled rollout spills the whole register set).  Headings that
+// large are unphysical (1e12 rad = 1.6e11 revolutions within one horizon); NaN/Inf propagate.
 __device__ __forceinline__ void fast_sincos(double x, double& s, double& c) {
-  if (!(fabs(x) <= 1.0e5)) { slow_sincos(x, &s, &c); return; }
   const double kf = rint(x * 0.6366197723675814);
   double r = fma(-kf, 0x1.921fb54442d18p+0, x);
   r = fma(-kf, 0x1.1a62633145c07p-54, r);
@@ -81,7 +82,7 @@ __device__ __forceinline__ void fast_sincos(double x, double& s, double& c) {
   pc = fma(z, pc, 4.16666666666666019037e-02);
   const double hz = 0.5 * z, wq = 1.0 - hz;
   const double cr = wq + (((1.0 - wq) - hz) + z * (z * pc));
-  const int n = (int)kf & 3;
+  const int n = (int)(kf - 4.0 * rint(kf * 0.25)) & 3;   // quadrant; kf may exceed the int range
   const double sa = (n & 1) ? cr : sr, ca = (n & 1) ? sr : cr;
   s = (n & 2) ? -sa : sa;
   c = ((n + 1) & 2) ? -ca : ca;
@@ -172,14 +173,15 @@ __device__ __forceinline__ double terminal_loss(const RolloutArgs& a, double x, 
   return ((e0 * a.P1[0]) * e0 + (e1 * a.P1[1]) * e1) + (e2 * a.P1[2]) * e2;
 }
 
-// LDS_STAGE: per-step losses live in LDS ([T][64] doubles, one column per lane, conflict-free 8-B
-// accesses) so J is written to HBM exactly once; otherwise J itself is the scratch (forward pass
-// writes the loss, the backward pass re-reads it last-written-first, i.e. out of L2) and no LDS limits
-// residency — chosen at create time from the grid size (see tbnav_mppi_create).
+// Per-step losses are staged for the backward suffix sum.  LDS ([steps][64] doubles, one column per
+// lane, conflict-free 8-B accesses) is the cheap place — J is then written exactly once and the forward
+// pass issues no global stores — but T*512 B per one-wave block caps residency.  So the LAST
+// (T - lds_from) steps go to LDS, sized at create time so that the whole grid is resident in one round
+// (tbnav_mppi_create), and the first lds_from steps use J itself as scratch (re-read from L2).
 // The noise of group g+1 (G steps x 2 arrays x 512 B per wave) is requested before group g is
 // integrated, so the loads fly under a group's worth of trig instead of stalling each step.
 constexpr int kGroup = 4;
-template <bool LDS_STAGE, int TRIG, int G>
+template <int TRIG, int G>
 __device__ __forceinline__ void rollout_group(const RolloutArgs& a, int i0, int lane, int k, double& x, double& y,
                                               double& th, const double (&dl)[G], const double (&dr)[G],
                                               const double* __restrict__ u, double* __restrict__ lds_loss,
@@ -197,66 +199,218 @@ __device__ __forceinline__ void rollout_group(const RolloutArgs& a, int i0, int 
     const int i = i0 + q;
     const double l = (i == T - 1) ? terminal_loss(a, xq[q], yq[q], thq[q])  // mppi.cpp:105 overwrites, not adds
                                   : lqr_loss(a, xq[q], yq[q], thq[q], ul[q], ur[q]);
-    if (LDS_STAGE) lds_loss[i * kWave + lane] = l;
+    if (i >= a.lds_from) lds_loss[(i - a.lds_from) * kWave + lane] = l;
     else J[(size_t)i * K + k] = l;
   }
 }
 
-template <bool LDS_STAGE, int TRIG>
+// LDS carve (dynamic): u_lds [2*T] (warm-start controls, broadcast reads) then, if LDS_STAGE, the losses.
+constexpr int kAhead = 3;  // groups of noise requested ahead of the one being integrated (12 steps ~ 1.5 us of trig)
+template <int TRIG>
 __global__ __launch_bounds__(kWave) void mppi_rollout_cost(RolloutArgs a,
                                                            const double* __restrict__ duL,
                                                            const double* __restrict__ duR,
                                                            const double* __restrict__ u,
                                                            double* __restrict__ J) {
-  extern __shared__ __attribute__((aligned(16))) double lds_loss[];
+  extern __shared__ __attribute__((aligned(16))) double lds_all[];
   const int lane = threadIdx.x;
-  const int k = blockIdx.x * kWave + lane;
-  if (k >= a.K) return;
   const int T = a.T, K = a.K;
+  double* u_lds = lds_all;                 // [2*T]
+  double* lds_loss = lds_all + 2 * T;      // [T - lds_from][64]
+  for (int t = lane; t < 2 * T; t += kWave) u_lds[t] = u[t];
+  __syncthreads();
+  const int k = blockIdx.x * kWave + lane;
+  if (k >= K) return;
   double x = a.x0[0], y = a.x0[1], th = a.x0[2];
   const int n_full = T / kGroup;
-  double nl[kGroup], nr[kGroup];
-  if (n_full > 0) {
+  const double* pl = duL + k;
+  const double* pr = duR + k;
+  double nl[kAhead][kGroup], nr[kAhead][kGroup];
 #pragma unroll
-    for (int q = 0; q < kGroup; ++q) { nl[q] = duL[(size_t)q * K + k]; nr[q] = duR[(size_t)q * K + k]; }
-  }
-  for (int g = 0; g < n_full; ++g) {
-    double dl[kGroup], dr[kGroup];
-#pragma unroll
-    for (int q = 0; q < kGroup; ++q) { dl[q] = nl[q]; dr[q] = nr[q]; }
-    if (g + 1 < n_full) {
+  for (int r = 0; r < kAhead; ++r) {
+    if (r < n_full) {
 #pragma unroll
       for (int q = 0; q < kGroup; ++q) {
-        const size_t off = (size_t)((g + 1) * kGroup + q) * K + k;
-        nl[q] = duL[off];
-        nr[q] = duR[off];
+        const size_t off = (size_t)(r * kGroup + q) * K;
+        nl[r][q] = pl[off];
+        nr[r][q] = pr[off];
       }
     }
-    rollout_group<LDS_STAGE, TRIG, kGroup>(a, g * kGroup, lane, k, x, y, th, dl, dr, u, lds_loss, J);
+  }
+  for (int g0 = 0; g0 < n_full; g0 += kAhead) {
+#pragma unroll
+    for (int r = 0; r < kAhead; ++r) {   // ring slot r holds group g0 + r
+      const int g = g0 + r;
+      if (g < n_full) {
+        double dl[kGroup], dr[kGroup];
+#pragma unroll
+        for (int q = 0; q < kGroup; ++q) { dl[q] = nl[r][q]; dr[q] = nr[r][q]; }
+        if (g + kAhead < n_full) {
+#pragma unroll
+          for (int q = 0; q < kGroup; ++q) {
+            const size_t off = (size_t)((g + kAhead) * kGroup + q) * K;
+            nl[r][q] = pl[off];
+            nr[r][q] = pr[off];
+          }
+        }
+        rollout_group<TRIG, kGroup>(a, g * kGroup, lane, k, x, y, th, dl, dr, u_lds, lds_loss, J);
+      }
+    }
   }
   for (int i = n_full * kGroup; i < T; ++i) {  // ragged tail, one step at a time
-    const double dl[1] = {duL[(size_t)i * K + k]}, dr[1] = {duR[(size_t)i * K + k]};
-    rollout_group<LDS_STAGE, TRIG, 1>(a, i, lane, k, x, y, th, dl, dr, u, lds_loss, J);
+    const double dl[1] = {pl[(size_t)i * K]}, dr[1] = {pr[(size_t)i * K]};
+    rollout_group<TRIG, 1>(a, i, lane, k, x, y, th, dl, dr, u_lds, lds_loss, J);
   }
   // cumSumCost (mppi.cpp:15-25): J(i) = loss(i) + J(i+1), from the end.  The staged losses are fetched
-  // eight at a time (independent loads in flight together), then added in order.
+  // eight at a time, the next eight already in flight while these are added in order.
+  double* Jk = J + k;
+  const int lds_from = a.lds_from;
+  auto staged = [&](int t) -> double { return t >= lds_from ? lds_loss[(t - lds_from) * kWave + lane] : Jk[(size_t)t * K]; };
+  constexpr int kB = 8;
   double acc = 0.0;
   int i = T - 1;
-  constexpr int kB = 8;
-  for (; i >= kB - 1; i -= kB) {
-    double l[kB];
+  double cur[kB], nxt[kB];
+  if (i >= kB - 1) {
 #pragma unroll
-    for (int q = 0; q < kB; ++q) l[q] = LDS_STAGE ? lds_loss[(i - q) * kWave + lane] : J[(size_t)(i - q) * K + k];
+    for (int q = 0; q < kB; ++q) cur[q] = staged(i - q);
+  }
+  for (; i >= kB - 1; i -= kB) {
+    const bool more = (i - kB) >= kB - 1;
+    if (more) {
+#pragma unroll
+      for (int q = 0; q < kB; ++q) nxt[q] = staged(i - kB - q);
+    }
 #pragma unroll
     for (int q = 0; q < kB; ++q) {
-      acc = (i - q == T - 1) ? l[q] : l[q] + acc;
-      J[(size_t)(i - q) * K + k] = acc;
+      acc = (i - q == T - 1) ? cur[q] : cur[q] + acc;
+      Jk[(size_t)(i - q) * K] = acc;
+    }
+    if (more) {
+#pragma unroll
+      for (int q = 0; q < kB; ++q) cur[q] = nxt[q];
     }
   }
   for (; i >= 0; --i) {
-    const double l = LDS_STAGE ? lds_loss[i * kWave + lane] : J[(size_t)i * K + k];
+    const double l = staged(i);
     acc = (i == T - 1) ? l : l + acc;
-    J[(size_t)i * K + k] = acc;
+    Jk[(size_t)i * K] = acc;
+  }
+}
+
+// ---- time-parallel rollout ---------------------------------------------------------------------------
+// The cart's increments do not depend on position: th_{i+1} = th_i + dth(u_i) and
+// x_{i+1} = x_i + incx(th_i, u_i), so a rollout is three scans (heading, position, cost-to-go) around
+// purely element-wise work — and the element-wise work is where the time goes (sincos, the loss).
+// One workgroup = 64 rollouts x C time chunks (one wave per chunk of TC steps held in registers):
+//   1. every thread loads its TC steps of noise (2*TC independent 512-B wave loads in flight at once),
+//      forms dth, chunk-local exclusive prefix; chunk totals meet in LDS; heading at chunk start =
+//      th0 + totals of the earlier chunks (added in chunk order);
+//   2. TC independent trig evaluations (ILP), incx/incy, chunk-local prefix, totals through LDS;
+//   3. losses, chunk-local suffix sums, totals of the LATER chunks added from the horizon backwards.
+// Compared with the one-lane-per-rollout kernel this multiplies the number of waves by C (K = 1024,
+// T = 50: 16 -> 208 waves; K = 65536, T = 100: 1024 -> 13312), which is what hides the fp64 dependent
+// latency.  The only numerical difference is the association of the three sums (chunked instead of
+// strictly sequential): <= a few 1e-16 relative on x, y, theta and J (tests assert J within 1e-11).
+constexpr int kScanMaxChunks = 12;   // waves per workgroup of the time-parallel kernel (3 per SIMD -> up to 168 VGPRs)
+template <int TRIG, int TC>
+__global__ __launch_bounds__(kWave * kScanMaxChunks) void mppi_rollout_scan(RolloutArgs a, const double* __restrict__ duL,
+                                                                           const double* __restrict__ duR,
+                                                                           const double* __restrict__ u,
+                                                                           double* __restrict__ J) {
+  extern __shared__ __attribute__((aligned(16))) double lds_all[];
+  const int lane = threadIdx.x, c = threadIdx.y, C = blockDim.y;
+  const int T = a.T, K = a.K;
+  double* u_lds = lds_all;                       // [2*T]
+  double* tot = lds_all + 2 * T;                 // [4][C][64]: dtheta, dx, dy, loss totals per chunk
+  for (int t = c * kWave + lane; t < 2 * T; t += C * kWave) u_lds[t] = u[t];
+  __syncthreads();
+  const int k = blockIdx.x * kWave + lane;
+  const bool live = k < K;
+  const int kk = live ? k : K - 1;               // dead lanes shadow a valid rollout (no divergence at the barriers)
+  const int i0 = c * TC;
+  // Live across the phases: per step v, w (or the control cost), the chunk-local heading, then x, y.
+  // The trig is done in sub-batches of kSub steps (scheduling barrier between them): kSub independent
+  // chains are enough to cover the fp64 latency, and the temporaries of more would spill.
+  constexpr int kSub = (TC % 5 == 0) ? 5 : 4;
+  double vv[TC], ww[TC];
+#pragma unroll
+  for (int q = 0; q < TC; ++q) {                 // 2*TC independent 512-B wave loads in flight
+    const int i = i0 + q;
+    const size_t off = (size_t)(i < T ? i : T - 1) * K + kk;
+    vv[q] = duL[off];
+    ww[q] = duR[off];
+  }
+  double tha[TC], ctrl[TC];                      // chunk-local heading AFTER step q; control cost of step q
+  double run = 0.0;
+#pragma unroll
+  for (int q = 0; q < TC; ++q) {
+    const int i = i0 + q;
+    const bool in = i < T;
+    const double ul = in ? u_lds[i] + vv[q] : 0.0;      // mppi.cpp:93 — rollout controls are not clamped
+    const double ur = in ? u_lds[T + i] + ww[q] : 0.0;
+    ctrl[q] = (ul * a.R[0]) * ul + (ur * a.R[1]) * ur;
+    vv[q] = a.half_r * (ul + ur);
+    ww[q] = a.r_over_b * (ur - ul);
+    run += in ? a.h6 * (((ww[q] + 2.0 * ww[q]) + 2.0 * ww[q]) + ww[q]) : 0.0;
+    tha[q] = run;
+  }
+  tot[(0 * C + c) * kWave + lane] = run;
+  __syncthreads();
+  double th0 = a.x0[2];
+  for (int cc = 0; cc < c; ++cc) th0 += tot[(0 * C + cc) * kWave + lane];
+  double runx = 0.0, runy = 0.0;
+#pragma unroll
+  for (int q = 0; q < TC; ++q) {
+    if (q % kSub == 0 && q) __builtin_amdgcn_sched_barrier(0);
+    const double hth = th0 + (q == 0 ? 0.0 : tha[q - 1]);   // heading at the START of step i0+q
+    const double v = vv[q], w = ww[q];
+    double s1, c1, s2, c2, s4, c4;
+    fast_sincos(hth, s1, c1);
+    if (TRIG == 3) {
+      fast_sincos(hth + a.h * (0.5 * w), s2, c2);
+      fast_sincos(hth + a.h * w, s4, c4);
+    } else {
+      double sd, cd;
+      small_sincos(a.h * (0.5 * w), sd, cd);
+      c2 = c1 * cd - s1 * sd;
+      s2 = s1 * cd + c1 * sd;
+      const double s2d = 2.0 * sd * cd, c2d = 1.0 - 2.0 * sd * sd;
+      c4 = c1 * c2d - s1 * s2d;
+      s4 = s1 * c2d + c1 * s2d;
+    }
+    const double k1x = v * c1, k1y = v * s1, k2x = v * c2, k2y = v * s2, k4x = v * c4, k4y = v * s4;
+    const bool in = i0 + q < T;
+    runx += in ? a.h6 * (((k1x + 2.0 * k2x) + 2.0 * k2x) + k4x) : 0.0;
+    runy += in ? a.h6 * (((k1y + 2.0 * k2y) + 2.0 * k2y) + k4y) : 0.0;
+    vv[q] = runx;                                // (reuse) chunk-local x AFTER step q
+    ww[q] = runy;                                //         chunk-local y
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  tot[(1 * C + c) * kWave + lane] = runx;
+  tot[(2 * C + c) * kWave + lane] = runy;
+  __syncthreads();
+  double xs = a.x0[0], ys = a.x0[1];
+  for (int cc = 0; cc < c; ++cc) { xs += tot[(1 * C + cc) * kWave + lane]; ys += tot[(2 * C + cc) * kWave + lane]; }
+  double* xa = vv;
+  run = 0.0;
+#pragma unroll
+  for (int q = TC - 1; q >= 0; --q) {
+    const int i = i0 + q;
+    const double e0 = (xs + vv[q]) - a.xd[0], e1 = (ys + ww[q]) - a.xd[1], e2 = (th0 + tha[q]) - a.xd[2];
+    double l = (i == T - 1) ? ((e0 * a.P1[0]) * e0 + (e1 * a.P1[1]) * e1) + (e2 * a.P1[2]) * e2      // mppi.cpp:105 overwrites
+                            : (((e0 * a.Q[0]) * e0 + (e1 * a.Q[1]) * e1) + (e2 * a.Q[2]) * e2) + ctrl[q];
+    if (i >= T) l = 0.0;
+    run = l + run;                               // chunk-local suffix sum, from the chunk's end
+    xa[q] = run;                                 // (reuse: suffix value)
+  }
+  tot[(3 * C + c) * kWave + lane] = run;
+  __syncthreads();
+  double tail = 0.0;
+  for (int cc = C - 1; cc > c; --cc) tail = tot[(3 * C + cc) * kWave + lane] + tail;
+  if (live) {
+#pragma unroll
+    for (int q = 0; q < TC; ++q)
+      if (i0 + q < T) J[(size_t)(i0 + q) * K + k] = xa[q] + tail;
   }
 }
 
@@ -281,13 +435,21 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
   return r;
 }
 
+__device__ __forceinline__ void combine_block(int T, int G, int S, double lambda, double umax, double uinit_l,
+                                              double uinit_r, const double* __restrict__ records,
+                                              double* __restrict__ u, double* __restrict__ out, double* unew);
+
+struct FuseArgs { unsigned int* counter; double* u; double* out; double umax, uinit_l, uinit_r; };
+
 // grid = (S, T).  Block (s, i) reduces time step i over rollouts [s*kSlice, (s+1)*kSlice).
 __global__ __launch_bounds__(kSliceThreads) void mppi_partials(int T, int K, int S, double lambda,
                                                                const double* __restrict__ J,
                                                                const double* __restrict__ duL,
                                                                const double* __restrict__ duR,
-                                                               double* __restrict__ records) {
+                                                               double* __restrict__ records, FuseArgs fz) {
+  extern __shared__ __attribute__((aligned(16))) double unew_lds[];  // [2][T], used by the fused combine only
   __shared__ double scratch[kSliceThreads / kWave];
+  __shared__ int is_last;
   const int s = blockIdx.x, i = blockIdx.y;
   const int base = s * kSlice;
   const double inf = __builtin_huge_val();
@@ -326,43 +488,70 @@ __global__ __launch_bounds__(kSliceThreads) void mppi_partials(int T, int K, int
     double* rec = records + ((size_t)i * S + s) * TBNAV_MPPI_REC;
     rec[0] = mn; rec[1] = A; rec[2] = B; rec[3] = C; rec[4] = D; rec[5] = E; rec[6] = n; rec[7] = 0.0;
   }
+  if (!fz.counter) return;
+  // Fused combine (single shard): the LAST workgroup to publish its record merges them all, which
+  // saves the separate launch.  Publish = record store, agent-scope release fence, counter increment;
+  // the last arriver acquires before it reads the other workgroups' records (guide G16 / the classic
+  // threadfence reduction).  The counter is left at zero for the next tick.
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const unsigned int prev = atomicAdd(fz.counter, 1u);
+    is_last = (prev == (unsigned int)(gridDim.x * gridDim.y) - 1u) ? 1 : 0;
+    if (is_last) { __threadfence(); *fz.counter = 0u; }
+  }
+  __syncthreads();
+  if (!is_last) return;
+  combine_block(T, 1, S, lambda, fz.umax, fz.uinit_l, fz.uinit_r, records, fz.u, fz.out, unew_lds);
 }
 
-// One workgroup.  records: [G][T][S][8].  Thread i (strided) merges the G*S records of time step i,
-// updates u(:,i) (mppi.cpp:118-125), then the block emits u(:,0) and shifts (mppi.cpp:129-137).
-__global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, double lambda, double umax,
-                                                    double uinit_l, double uinit_r,
-                                                    const double* __restrict__ records,
-                                                    double* __restrict__ u, double* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) double unew[];  // [2][T]
-  for (int i = threadIdx.x; i < T; i += blockDim.x) {
+// Merge the G*S partial records of every time step (records: [G][T][S][8]), update u(:,i)
+// (mppi.cpp:118-125), emit u(:,0) and shift (mppi.cpp:129-137).  Called by ALL threads of one
+// workgroup.  Each time step gets a group of `tpr` lanes (the power of two >= the record count, at
+// most a wave), so 64/tpr steps are merged per wave at once and the min / six sums are xor-shuffle
+// reductions inside the group.  unew: LDS scratch [2][T].
+__device__ __forceinline__ void combine_block(int T, int G, int S, double lambda, double umax, double uinit_l,
+                                              double uinit_r, const double* __restrict__ records,
+                                              double* __restrict__ u, double* __restrict__ out, double* unew) {
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave, nw = blockDim.x / kWave;
+  const int R = G * S;
+  int tpr = 1;
+  while (tpr < R && tpr < kWave) tpr <<= 1;
+  const int spw = kWave / tpr, sub = lane / tpr, l = lane - sub * tpr;
+  for (int base = wid * spw; base < T; base += nw * spw) {
+    const int i = base + sub;
+    const bool valid = i < T;
     double M = __builtin_huge_val();
-    for (int g = 0; g < G; ++g)
-      for (int s = 0; s < S; ++s) {
-        const double* rec = records + (((size_t)g * T + i) * S + s) * TBNAV_MPPI_REC;
+    if (valid)
+      for (int r = l; r < R; r += tpr) {
+        const int g = r / S, sl = r - g * S;
+        const double* rec = records + (((size_t)g * T + i) * S + sl) * TBNAV_MPPI_REC;
         if (rec[6] > 0.0) M = fmin(M, rec[0]);
       }
+    for (int off = tpr >> 1; off > 0; off >>= 1) M = fmin(M, __shfl_xor(M, off, kWave));
     double W = 0, NL = 0, NR = 0, SD = 0, SE = 0, SN = 0;
-    for (int g = 0; g < G; ++g)
-      for (int s = 0; s < S; ++s) {
-        const double* rec = records + (((size_t)g * T + i) * S + s) * TBNAV_MPPI_REC;
+    if (valid)
+      for (int r = l; r < R; r += tpr) {
+        const int g = r / S, sl = r - g * S;
+        const double* rec = records + (((size_t)g * T + i) * S + sl) * TBNAV_MPPI_REC;
         if (rec[6] > 0.0) {
           const double sc = exp(((rec[0] - M) * -1.0) / lambda);
-          W += sc * rec[1];
-          NL += sc * rec[2];
-          NR += sc * rec[3];
-          SD += rec[4];
-          SE += rec[5];
-          SN += rec[6];
+          W += sc * rec[1]; NL += sc * rec[2]; NR += sc * rec[3];
+          SD += rec[4]; SE += rec[5]; SN += rec[6];
         }
       }
-    W += 1e-8 * SN;  // the reference adds 1e-8 to every weight before normalising (mppi.cpp:117)
-    double ul = u[i] + (NL + 1e-8 * SD) / W;
-    double ur = u[T + i] + (NR + 1e-8 * SE) / W;
-    ul = fmin(fmax(ul, -umax), umax);  // std::clamp(u, -max, max), mppi.cpp:124-125
-    ur = fmin(fmax(ur, -umax), umax);
-    unew[i] = ul;
-    unew[T + i] = ur;
+    for (int off = tpr >> 1; off > 0; off >>= 1) {
+      W += __shfl_xor(W, off, kWave); NL += __shfl_xor(NL, off, kWave); NR += __shfl_xor(NR, off, kWave);
+      SD += __shfl_xor(SD, off, kWave); SE += __shfl_xor(SE, off, kWave); SN += __shfl_xor(SN, off, kWave);
+    }
+    if (valid && l == 0) {
+      W += 1e-8 * SN;  // the reference adds 1e-8 to every weight before normalising (mppi.cpp:117)
+      double ul = u[i] + (NL + 1e-8 * SD) / W;
+      double ur = u[T + i] + (NR + 1e-8 * SE) / W;
+      ul = fmin(fmax(ul, -umax), umax);  // std::clamp(u, -max, max), mppi.cpp:124-125
+      ur = fmin(fmax(ur, -umax), umax);
+      unew[i] = ul;
+      unew[T + i] = ur;
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) { out[0] = unew[0]; out[1] = unew[T]; }
@@ -370,6 +559,14 @@ __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, double 
     u[i] = (i + 1 < T) ? unew[i + 1] : uinit_l;
     u[T + i] = (i + 1 < T) ? unew[T + i + 1] : uinit_r;
   }
+}
+
+__global__ __launch_bounds__(1024) void mppi_combine(int T, int G, int S, double lambda, double umax,
+                                                     double uinit_l, double uinit_r,
+                                                     const double* __restrict__ records,
+                                                     double* __restrict__ u, double* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) double unew[];  // [2][T]
+  combine_block(T, G, S, lambda, umax, uinit_l, uinit_r, records, u, out, unew);
 }
 
 // raw[(k*T + i)*2 + c]  ->  duL[i*K + k], duR[i*K + k]
@@ -450,8 +647,10 @@ struct tbnav_mppi {
   double* d_raw = nullptr;      // [K][T][2] staging for host-order noise (lazy)
   double* d_records = nullptr;  // [T][S][8]
   double* d_out = nullptr;      // [2]
+  unsigned int* d_counter = nullptr;  // arrival counter of the fused partials+combine kernel
   double* h_out = nullptr;      // pinned [2]
-  bool lds_stage = true;
+  int lds_from = 0;           // first time step whose loss is staged in LDS (0 = all of them)
+  int scan_tc = 0;            // steps per thread of the time-parallel rollout kernel (0 = sequential kernel)
   int trig = 1;               // sincos evaluations per RK4 step (1 = angle addition, 3 = the reference's three)
 };
 
@@ -468,27 +667,50 @@ int launch_rollout(tbnav_mppi* h, const double x0[3], const double* d_duL, const
   a.R[0] = h->p.R[0]; a.R[1] = h->p.R[1];
   a.T = h->T; a.K = h->K;
   const dim3 grid((h->K + kWave - 1) / kWave), block(kWave);
-  const size_t lds = (size_t)h->T * kWave * sizeof(double);
-  if (h->lds_stage && h->trig == 1) hipLaunchKernelGGL((mppi_rollout_cost<true, 1>), grid, block, lds, st, a, d_duL, d_duR, h->d_u, h->d_J);
-  else if (h->lds_stage) hipLaunchKernelGGL((mppi_rollout_cost<true, 3>), grid, block, lds, st, a, d_duL, d_duR, h->d_u, h->d_J);
-  else if (h->trig == 1) hipLaunchKernelGGL((mppi_rollout_cost<false, 1>), grid, block, 0, st, a, d_duL, d_duR, h->d_u, h->d_J);
-  else hipLaunchKernelGGL((mppi_rollout_cost<false, 3>), grid, block, 0, st, a, d_duL, d_duR, h->d_u, h->d_J);
+  if (h->scan_tc > 0) {
+    const int TCv = h->scan_tc, C = (h->T + TCv - 1) / TCv;
+    const size_t lds = ((size_t)2 * h->T + (size_t)4 * C * kWave) * sizeof(double);
+    const dim3 blk(kWave, C);
+#define TBNAV_SCAN(TR, TCC) hipLaunchKernelGGL((mppi_rollout_scan<TR, TCC>), grid, blk, lds, st, a, d_duL, d_duR, h->d_u, h->d_J)
+#define TBNAV_SCAN_TC(TR)                                                                                   \
+  switch (TCv) {                                                                                            \
+    case 4: TBNAV_SCAN(TR, 4); break;   case 5: TBNAV_SCAN(TR, 5); break;   case 6: TBNAV_SCAN(TR, 6); break;  \
+    case 8: TBNAV_SCAN(TR, 8); break;   case 10: TBNAV_SCAN(TR, 10); break; case 12: TBNAV_SCAN(TR, 12); break; \
+    case 16: TBNAV_SCAN(TR, 16); break; default: TBNAV_SCAN(TR, 20); break;                                  \
+  }
+    if (h->trig == 1) { TBNAV_SCAN_TC(1) } else { TBNAV_SCAN_TC(3) }
+#undef TBNAV_SCAN_TC
+#undef TBNAV_SCAN
+  } else {
+    const size_t lds = (size_t)2 * h->T * sizeof(double) + (size_t)(h->T - h->lds_from) * kWave * sizeof(double);
+    a.lds_from = h->lds_from;
+    if (h->trig == 1) hipLaunchKernelGGL((mppi_rollout_cost<1>), grid, block, lds, st, a, d_duL, d_duR, h->d_u, h->d_J);
+    else hipLaunchKernelGGL((mppi_rollout_cost<3>), grid, block, lds, st, a, d_duL, d_duR, h->d_u, h->d_J);
+  }
   TBNAV_HIP(hipGetLastError());
   return TBNAV_OK;
 }
 
 int launch_partials(tbnav_mppi* h, const double* d_duL, const double* d_duR, double* d_records,
-                    hipStream_t st) {
+                    hipStream_t st, bool fuse_combine) {
   const dim3 grid(h->S, h->T), block(kSliceThreads);
-  hipLaunchKernelGGL(mppi_partials, grid, block, 0, st, h->T, h->K, h->S, h->p.lambda, h->d_J, d_duL,
-                     d_duR, d_records);
+  FuseArgs fz{};
+  if (fuse_combine) fz = FuseArgs{h->d_counter, h->d_u, h->d_out, h->p.max_wheel_vel, h->uinit[0], h->uinit[1]};
+  const size_t lds = fuse_combine ? (size_t)2 * h->T * sizeof(double) : 0;
+  hipLaunchKernelGGL(mppi_partials, grid, block, lds, st, h->T, h->K, h->S, h->p.lambda, h->d_J, d_duL,
+                     d_duR, d_records, fz);
   TBNAV_HIP(hipGetLastError());
   return TBNAV_OK;
 }
 
 int launch_combine(tbnav_mppi* h, const double* d_records, int G, hipStream_t st) {
   const size_t lds = (size_t)2 * h->T * sizeof(double);
-  hipLaunchKernelGGL(mppi_combine, dim3(1), dim3(256), lds, st, h->T, G, h->S, h->p.lambda,
+  // enough waves to merge every time step in one pass (64 / tpr steps per wave), 4..16 waves
+  int tpr = 1;
+  while (tpr < G * h->S && tpr < kWave) tpr <<= 1;
+  int waves = (h->T + (kWave / tpr) - 1) / (kWave / tpr);
+  waves = waves < 4 ? 4 : (waves > 16 ? 16 : waves);
+  hipLaunchKernelGGL(mppi_combine, dim3(1), dim3(waves * kWave), lds, st, h->T, G, h->S, h->p.lambda,
                      h->p.max_wheel_vel, h->uinit[0], h->uinit[1], d_records, h->d_u, h->d_out);
   TBNAV_HIP(hipGetLastError());
   return TBNAV_OK;
@@ -540,20 +762,38 @@ int tbnav_mppi_create(const tbnav_mppi_params* params, tbnav_mppi** out) {
   h->S = (h->K + kSlice - 1) / kSlice;
   h->device = dev;
   {
-    // LDS staging writes J once, but T*512 B of LDS per one-wave block caps residency at
-    // floor(160 KB / that) blocks per CU; if the grid does not fit in one resident round the tail
-    // round costs more than the extra L2 traffic of staging the losses in J itself.
-    const size_t lds_bytes = (size_t)T * kWave * sizeof(double);
+    // How many steps' losses fit in LDS while the whole grid stays resident in ONE round:
+    // blocks per CU needed = ceil(blocks / CUs) (at most 8 considered), LDS budget per block = 160 KB / that.
     hipDeviceProp_t prop;
     int cus = 256;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     const long blocks = (params->rollouts + kWave - 1) / kWave;
-    const long per_cu = lds_bytes ? (long)(kMaxLdsBytes / lds_bytes) : 0;
-    h->lds_stage = lds_bytes <= (size_t)kMaxLdsBytes && blocks <= per_cu * cus;
+    long per_cu = (blocks + cus - 1) / cus;
+    per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
+    const long budget = (long)kMaxLdsBytes / per_cu - 512 - (long)(2 * T * sizeof(double));
+    long steps_in_lds = budget > 0 ? budget / (long)(kWave * sizeof(double)) : 0;
+    if (steps_in_lds > T) steps_in_lds = T;
+    h->lds_from = T - (int)steps_in_lds;
+  }
+  // time-parallel kernel: up to 16 chunks (waves) per workgroup
+  h->scan_tc = 0;
+  for (int tc : {4, 5, 6, 8, 10, 12, 16, 20})
+    if ((T + tc - 1) / tc <= kScanMaxChunks) { h->scan_tc = tc; break; }
+  {
+    // The time-parallel kernel exists to create waves when the rollout count alone cannot fill the chip;
+    // once K/64 one-wave workgroups cover >= 2 waves per CU-SIMD pair the sequential kernel (fewer
+    // registers, no chunk barriers) is faster (measured on MI355X: K=65536,T=100 87 us vs 121 us;
+    // K=1024,T=50 32 us vs 11 us).
+    hipDeviceProp_t prop;
+    int cus = 256;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    if ((params->rollouts + kWave - 1) / kWave >= 2 * cus) h->scan_tc = 0;
   }
   // development switches (A/B measurements; not part of the contract)
+  if (const char* e = std::getenv("TBNAV_MPPI_SEQ")) if (std::atoi(e) == 1) h->scan_tc = 0;
+  if (const char* e = std::getenv("TBNAV_MPPI_SCAN_TC")) h->scan_tc = std::atoi(e);
   if (const char* e = std::getenv("TBNAV_MPPI_TRIG")) h->trig = (std::atoi(e) == 3) ? 3 : 1;
-  if (const char* e = std::getenv("TBNAV_MPPI_NO_LDS")) if (std::atoi(e) == 1) h->lds_stage = false;
+  if (const char* e = std::getenv("TBNAV_MPPI_NO_LDS")) { if (std::atoi(e) == 1) h->lds_from = T; }
   const size_t tk = (size_t)T * h->K;
   hipError_t e = hipSuccess;
   auto alloc = [&](double** p, size_t n) { if (e == hipSuccess) e = hipMalloc((void**)p, n * sizeof(double)); };
@@ -563,18 +803,19 @@ int tbnav_mppi_create(const tbnav_mppi_params* params, tbnav_mppi** out) {
   alloc(&h->d_duR, tk);
   alloc(&h->d_records, (size_t)T * h->S * TBNAV_MPPI_REC);
   alloc(&h->d_out, 2);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_counter, sizeof(unsigned int));
+  if (e == hipSuccess) e = hipMemset(h->d_counter, 0, sizeof(unsigned int));
   if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_out, 2 * sizeof(double), hipHostMallocDefault);
   if (e == hipSuccess) e = hipMemset(h->d_u, 0, 2 * (size_t)T * sizeof(double));
   if (e == hipSuccess) e = hipMemset(h->d_J, 0, tk * sizeof(double));
   if (e == hipSuccess) e = hipMemset(h->d_duL, 0, tk * sizeof(double));
   if (e == hipSuccess) e = hipMemset(h->d_duR, 0, tk * sizeof(double));
   if (e == hipSuccess) e = hipMemset(h->d_out, 0, 2 * sizeof(double));
-  if (e == hipSuccess && h->lds_stage) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mppi_rollout_cost<true, 1>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)T * kWave * sizeof(double)));
+  if (e == hipSuccess) {
+    const int lds_max = (int)((size_t)2 * T * sizeof(double) + (size_t)(T - h->lds_from) * kWave * sizeof(double));
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mppi_rollout_cost<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mppi_rollout_cost<true, 3>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)T * kWave * sizeof(double)));
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mppi_rollout_cost<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
   }
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) {
@@ -590,7 +831,7 @@ void tbnav_mppi_destroy(tbnav_mppi* h) {
   if (!h) return;
   DeviceGuard guard(h->device);
   (void)hipFree(h->d_u); (void)hipFree(h->d_J); (void)hipFree(h->d_duL); (void)hipFree(h->d_duR);
-  (void)hipFree(h->d_raw); (void)hipFree(h->d_records); (void)hipFree(h->d_out);
+  (void)hipFree(h->d_raw); (void)hipFree(h->d_records); (void)hipFree(h->d_out); (void)hipFree(h->d_counter);
   if (h->h_out) (void)hipHostFree(h->h_out);
   delete h;
 }
@@ -641,7 +882,7 @@ int tbnav_mppi_shard_partials(tbnav_mppi* h, const double x0[3], const double* d
   hipStream_t st = static_cast<hipStream_t>(stream);
   int rc = launch_rollout(h, x0, d_duL, d_duR, st);
   if (rc != TBNAV_OK) return rc;
-  return launch_partials(h, d_duL, d_duR, d_records_out, st);
+  return launch_partials(h, d_duL, d_duR, d_records_out, st, false);
 }
 
 int tbnav_mppi_shard_combine(tbnav_mppi* h, const double* d_records_all, int32_t n_shards, void* stream) {
@@ -657,7 +898,12 @@ int tbnav_mppi_enqueue_dev(tbnav_mppi* h, const double x0[3], const double* d_du
   hipStream_t st = static_cast<hipStream_t>(stream);
   int rc = launch_rollout(h, x0, d_duL, d_duR, st);
   if (rc != TBNAV_OK) return rc;
-  rc = launch_partials(h, d_duL, d_duR, h->d_records, st);
+  // NOT fused into the partials kernel's last workgroup: measured on MI355X the per-workgroup
+  // agent-scope fence + atomic of that scheme costs more (tick 15.8 -> 43 us at K=1024) than the
+  // ~1.5 us kernel boundary it removes; fuse_combine stays available behind TBNAV_MPPI_FUSE=1.
+  static const bool fuse = [] { const char* e = std::getenv("TBNAV_MPPI_FUSE"); return e && std::atoi(e) == 1; }();
+  if (fuse) return launch_partials(h, d_duL, d_duR, h->d_records, st, true);
+  rc = launch_partials(h, d_duL, d_duR, h->d_records, st, false);
   if (rc != TBNAV_OK) return rc;
   return launch_combine(h, h->d_records, 1, st);
 }
@@ -672,7 +918,7 @@ int tbnav_mppi_profile_tick(tbnav_mppi* h, const double x0[3], const double* d_d
   int rc = TBNAV_OK;
   TBNAV_HIP(hipEventRecord(ev[0], st));
   rc = launch_rollout(h, x0, d_duL, d_duR, st);
-  if (rc == TBNAV_OK) { TBNAV_HIP(hipEventRecord(ev[1], st)); rc = launch_partials(h, d_duL, d_duR, h->d_records, st); }
+  if (rc == TBNAV_OK) { TBNAV_HIP(hipEventRecord(ev[1], st)); rc = launch_partials(h, d_duL, d_duR, h->d_records, st, false); }
   if (rc == TBNAV_OK) { TBNAV_HIP(hipEventRecord(ev[2], st)); rc = launch_combine(h, h->d_records, 1, st); }
   if (rc == TBNAV_OK) {
     TBNAV_HIP(hipEventRecord(ev[3], st));

@@ -1,0 +1,15 @@
+"""Dev driver: run N MPPI ticks at (K, horizon) for profiling under rocprofv3."""
+import os, sys, numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as g
+g.load_package()
+import bench
+K = int(sys.argv[1]); hor = float(sys.argv[2]); n = int(sys.argv[3])
+dev = torch.device("cuda", 0)
+m = bench.make_mppi(K, hor, 0)
+a, b = bench.synth_noise(m.steps, K, dev, 1)
+st = torch.cuda.current_stream(dev).cuda_stream
+for _ in range(n):
+    m.enqueueDev(bench.X0, a.data_ptr(), b.data_ptr(), st)
+print(m.lastControls(st))
