@@ -333,15 +333,37 @@ __device__ __forceinline__ void ray_cell(const Ray& r, int n, int& cx, int& cy) 
 // One wave per particle.  Beams are applied IN ORDER (the per-cell floating-point add order is the
 // reference's); the cells of one ray are distinct, so the lanes of the wave update them in parallel
 // without atomics.  Endpoints are staged in LDS first.
+// The occupancy bitmap / per-row counts / occupied count of the particle are kept up to date here: a
+// log-odds add that crosses the occupied cut-off toggles the cell's bit (rare: a few hundred cells per
+// scan), so no pass over the whole map is needed to find the distance transform's seeds.
+__device__ __forceinline__ void add_log_odds(double* __restrict__ lo, size_t idx, double d, double cut, int cx, int cy,
+                                             int words, unsigned long long* __restrict__ bm, int* __restrict__ rowcount,
+                                             int* __restrict__ nocc) {
+  const double old = lo[idx];
+  const double nw = old + d;
+  lo[idx] = nw;
+  const bool was = old >= cut, now = nw >= cut;
+  if (was != now) {
+    atomicXor(&bm[(size_t)cx * words + (cy >> 6)], 1ull << (cy & 63));
+    const int delta = now ? 1 : -1;
+    atomicAdd(&rowcount[cx], delta);
+    atomicAdd(nocc, delta);
+  }
+}
+
 __global__ __launch_bounds__(kWave) void rbpf_raycast(ScanC c, const double2* __restrict__ beams,
                                                      const double* __restrict__ pose, double* __restrict__ log_odds,
-                                                     int* __restrict__ err) {
+                                                     unsigned long long* __restrict__ bitmap, int* __restrict__ row_count,
+                                                     int* __restrict__ n_occ, int* __restrict__ err) {
   extern __shared__ __attribute__((aligned(16))) int lds_i[];
   int* ex = lds_i;         // [Bv]
   int* ey = lds_i + c.Bv;  // [Bv]
   __shared__ int bad;
   const int p = blockIdx.x, lane = threadIdx.x;
   double* lo = log_odds + (size_t)p * c.g.xsize * c.g.ysize;
+  unsigned long long* bm = bitmap + (size_t)p * c.g.xsize * c.g.words;
+  int* rc = row_count + (size_t)p * c.g.xsize;
+  int* nocc = n_occ + p;
   const double th = pose[p * 3 + 0], x = pose[p * 3 + 1], y = pose[p * 3 + 2];
   if (lane == 0) bad = 0;
   __syncthreads();
@@ -368,24 +390,20 @@ __global__ __launch_bounds__(kWave) void rbpf_raycast(ScanC c, const double2* __
     for (int n = lane; n < r.count; n += kWave) {
       int cx, cy;
       ray_cell(r, n, cx, cy);
-      const size_t idx = (size_t)cx * xs + cy;
-      lo[idx] = lo[idx] + c.d_free;
+      add_log_odds(lo, (size_t)cx * xs + cy, c.d_free, c.cut_occ, cx, cy, c.g.words, bm, rc, nocc);
     }
     __syncthreads();  // free-cell adds of this beam land before the endpoint / next beam touch the cells
-    if (lane == 0) {
-      const size_t idx = (size_t)x1 * xs + y1;
-      lo[idx] = lo[idx] + c.d_occ;
-    }
+    if (lane == 0) add_log_odds(lo, (size_t)x1 * xs + y1, c.d_occ, c.cut_occ, x1, y1, c.g.words, bm, rc, nocc);
     __syncthreads();
   }
 }
 
 // ---- occupancy bitmap ------------------------------------------------------------------------------
 // grid (rows/4, N), 256 threads: one wave per map row; lanes read the row coalesced.
-__global__ __launch_bounds__(256) void rbpf_occupancy(GridC g, double cut_occ, const double* __restrict__ log_odds,
-                                                      unsigned long long* __restrict__ bitmap, uint16_t* __restrict__ row_count,
+__global__ __launch_bounds__(256) void rbpf_occupancy(GridC g, double cut_occ, int p0, const double* __restrict__ log_odds,
+                                                      unsigned long long* __restrict__ bitmap, int* __restrict__ row_count,
                                                       int* __restrict__ n_occ) {
-  const int p = blockIdx.y;
+  const int p = p0 + blockIdx.y;
   const int row = blockIdx.x * 4 + threadIdx.x / kWave;
   const int lane = threadIdx.x & (kWave - 1);
   if (row >= g.xsize) return;
@@ -399,7 +417,7 @@ __global__ __launch_bounds__(256) void rbpf_occupancy(GridC g, double cut_occ, c
     if (lane == 0) bm[w] = m;
     cnt += __popcll(m);
   }
-  if (lane == 0) { row_count[(size_t)p * g.xsize + row] = (uint16_t)cnt; if (cnt) atomicAdd(&n_occ[p], cnt); }
+  if (lane == 0) { row_count[(size_t)p * g.xsize + row] = cnt; if (cnt) atomicAdd(&n_occ[p], cnt); }
 }
 
 // ---- exact distance transform ------------------------------------------------------------------------
@@ -500,7 +518,7 @@ __device__ __forceinline__ void unpack(uint32_t e, int& v, int& f, int& z) { v =
 __device__ __forceinline__ int unpack_z(uint32_t e) { return (int)(e >> 19) - 1; }
 template <int SMAX>
 __global__ __launch_bounds__(kWave) void rbpf_edt_compact(GridC g, int radius, const unsigned long long* __restrict__ bitmap,
-                                                          const uint16_t* __restrict__ row_count,
+                                                          const int* __restrict__ row_count,
                                                           uint16_t* __restrict__ codes, int* __restrict__ tier, int my_tier) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int p = blockIdx.y, lane = threadIdx.x;
@@ -514,7 +532,7 @@ __global__ __launch_bounds__(kWave) void rbpf_edt_compact(GridC g, int radius, c
   const int tw = blockIdx.x;          // the tile is exactly bitmap word `tw` of every row
   const int j = tw * kWave + lane;
   const unsigned long long* bm = bitmap + (size_t)p * xs * words;
-  const uint16_t* rc = row_count + (size_t)p * xs;
+  const int* rc = row_count + (size_t)p * xs;
   // compact list of non-empty rows (ascending)
   int S = 0;
   for (int base = 0; base < xs; base += kWave) {
@@ -596,7 +614,61 @@ constexpr int kEdtRowsB = 288;  // 77.8 KB -> 2 waves per CU
 
 // ---- normalise / Neff / low-variance selection (sequential order = the reference's) ---------------
 struct NormOut { double sum_w, sq_sum; int neff, resampled; };
-__global__ void rbpf_normalize(int N, double z, double* __restrict__ weight, int* __restrict__ parent, NormOut* __restrict__ out) {
+// One workgroup.  The three reductions that decide integers (sum, sum of squares -> Neff, the comb's
+// running sum c) are done by ONE lane in index order — the reference's association — over an LDS copy of
+// the weights (the only serial part: 3N dependent fp64 adds).  Everything else is parallel: the
+// divisions, and the selection itself — with the sequential prefix c[] in hand, slot m's parent is the
+// first i with U_m <= c[i] (the reference's while-loop, particle_filter.cpp:485-493, advances to exactly
+// that i because U_m and c[] are both non-decreasing), found by binary search, clamped to N-1.
+// buf: dynamic LDS, 2*N doubles (w then c).  N <= kNormMaxLds, else the global-memory variant below.
+constexpr int kNormMaxLds = 9000;
+__global__ __launch_bounds__(256) void rbpf_normalize(int N, double z, double* __restrict__ weight, int* __restrict__ parent,
+                                                      NormOut* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) double buf[];
+  double* w = buf;
+  double* cs = buf + N;
+  __shared__ double s_sum;
+  __shared__ int s_res;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) w[i] = weight[i];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sum = 0.0;
+    for (int i = 0; i < N; ++i) sum += w[i];
+    s_sum = sum;
+  }
+  __syncthreads();
+  const double sum = s_sum;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) { const double v = w[i] / sum; w[i] = v; weight[i] = v; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sq = 0.0;
+    for (int i = 0; i < N; ++i) sq += w[i] * w[i];
+    const int neff = (int)(1.0 / sq);
+    const int res = (neff < (N / 2)) ? 1 : 0;
+    out->sum_w = sum; out->sq_sum = sq; out->neff = neff; out->resampled = res;
+    s_res = res;
+    if (res) {
+      double c = w[0];
+      cs[0] = c;
+      for (int i = 1; i < N; ++i) { c += w[i]; cs[i] = c; }  // c += weight(i), particle_filter.cpp:492
+    }
+  }
+  __syncthreads();
+  if (!s_res) { for (int m = threadIdx.x; m < N; m += blockDim.x) parent[m] = m; return; }
+  const double r = z / (double)N;
+  for (int m = threadIdx.x; m < N; m += blockDim.x) {
+    const double U = r + (double)(m * (1.0 / (N - 1)));
+    int lo = 0, hi = N - 1;  // first index with U <= cs[i]; N-1 if none (the reference clamps there)
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (U > cs[mid]) lo = mid + 1; else hi = mid;
+    }
+    parent[m] = lo;
+  }
+}
+
+// Same contract, weights read from global memory (N too large for LDS): fully sequential.
+__global__ void rbpf_normalize_seq(int N, double z, double* __restrict__ weight, int* __restrict__ parent, NormOut* __restrict__ out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double sum = 0.0;
   for (int i = 0; i < N; ++i) sum += weight[i];
@@ -624,6 +696,8 @@ __global__ void rbpf_normalize(int N, double z, double* __restrict__ weight, int
 __global__ __launch_bounds__(256) void rbpf_gather(int N, size_t G, int words_total, const int* __restrict__ parent,
                                                    const double* __restrict__ lo_src, double* __restrict__ lo_dst,
                                                    const uint16_t* __restrict__ cd_src, uint16_t* __restrict__ cd_dst,
+                                                   const unsigned long long* __restrict__ bm_src, unsigned long long* __restrict__ bm_dst,
+                                                   const int* __restrict__ rc_src, int* __restrict__ rc_dst, int xsize,
                                                    const int* __restrict__ nocc_src, int* __restrict__ nocc_dst) {
   const int m = blockIdx.y;
   const int src = parent[m];
@@ -636,8 +710,13 @@ __global__ __launch_bounds__(256) void rbpf_gather(int N, size_t G, int words_to
   uint2* cb = reinterpret_cast<uint2*>(cd_dst + (size_t)m * G);
   const size_t n4 = G / 4;
   for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += (size_t)gridDim.x * blockDim.x) cb[t] = ca[t];
+  const size_t nb = (size_t)words_total;  // bitmap words per particle
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < nb; t += (size_t)gridDim.x * blockDim.x)
+    bm_dst[(size_t)m * nb + t] = bm_src[(size_t)src * nb + t];
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < (size_t)xsize; t += (size_t)gridDim.x * blockDim.x)
+    rc_dst[(size_t)m * xsize + t] = rc_src[(size_t)src * xsize + t];
   if (blockIdx.x == 0 && threadIdx.x == 0) nocc_dst[m] = nocc_src[src];  // pose/weight are gathered by the host side
-  (void)N; (void)words_total;
+  (void)N;
 }
 
 }  // namespace
@@ -656,8 +735,8 @@ struct tbnav_rbpf {
   uint16_t* d_code[2] = {nullptr, nullptr};
   int* d_nocc[2] = {nullptr, nullptr};
   int cur = 0;
-  unsigned long long* d_bitmap = nullptr;
-  uint16_t* d_rowcount = nullptr;  // [N][xsize] occupied cells per map row
+  unsigned long long* d_bitmap[2] = {nullptr, nullptr};  // [N][xsize][words], kept current by the raycast kernel
+  int* d_rowcount[2] = {nullptr, nullptr};               // [N][xsize] occupied cells per map row
   double2* d_beams = nullptr;  // capacity max_beams
   int max_beams = 0;
   double* d_normals = nullptr;
@@ -752,25 +831,21 @@ int status_from_err(const int err[4]) {
 
 int run_distance_field(tbnav_rbpf* h, const GridC& g, hipEvent_t e_mid) {
   hipStream_t st = h->stream;
-  TBNAV_HIP(hipMemsetAsync(h->d_nocc[h->cur], 0, sizeof(int) * h->N, st));
-  hipLaunchKernelGGL(rbpf_occupancy, dim3((h->xsize + 3) / 4, h->N), dim3(256), 0, st, g, h->cut_occ,
-                     h->d_log_odds[h->cur], h->d_bitmap, h->d_rowcount, h->d_nocc[h->cur]);
-  TBNAV_HIP(hipGetLastError());
-  if (e_mid) TBNAV_HIP(hipEventRecord(e_mid, st));
+  if (e_mid) TBNAV_HIP(hipEventRecord(e_mid, st));  // (the occupancy pass is gone: the raycast kernel keeps the bitmap current)
   // tier 0: <= kEdtRowsA non-empty rows, tier 1: <= kEdtRowsB, tier 2: the general kernel (decided on the device)
   TBNAV_HIP(hipMemsetAsync(h->d_tier, 0, sizeof(int) * h->N, st));
   const dim3 gridc((h->ysize + kWave - 1) / kWave, h->N);
   hipLaunchKernelGGL(rbpf_edt_compact<kEdtRowsA>, gridc, dim3(kWave), edt_compact_lds(kEdtRowsA), st, g, h->radius,
-                     h->d_bitmap, h->d_rowcount, h->d_code[h->cur], h->d_tier, 0);
+                     h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_code[h->cur], h->d_tier, 0);
   TBNAV_HIP(hipGetLastError());
   hipLaunchKernelGGL(rbpf_edt_compact<kEdtRowsB>, gridc, dim3(kWave), edt_compact_lds(kEdtRowsB), st, g, h->radius,
-                     h->d_bitmap, h->d_rowcount, h->d_code[h->cur], h->d_tier, 1);
+                     h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_code[h->cur], h->d_tier, 1);
   TBNAV_HIP(hipGetLastError());
   const int C = h->edt_cols;
   const size_t lds = edt_lds_bytes(h->xsize, h->words, C);
   const dim3 grid((h->ysize + C - 1) / C, h->N);
-  if (C == 64) hipLaunchKernelGGL(rbpf_edt<64>, grid, dim3(64), lds, st, g, h->radius, h->d_bitmap, h->d_code[h->cur], h->d_tier, 2);
-  else hipLaunchKernelGGL(rbpf_edt<32>, grid, dim3(32), lds, st, g, h->radius, h->d_bitmap, h->d_code[h->cur], h->d_tier, 2);
+  if (C == 64) hipLaunchKernelGGL(rbpf_edt<64>, grid, dim3(64), lds, st, g, h->radius, h->d_bitmap[h->cur], h->d_code[h->cur], h->d_tier, 2);
+  else hipLaunchKernelGGL(rbpf_edt<32>, grid, dim3(32), lds, st, g, h->radius, h->d_bitmap[h->cur], h->d_code[h->cur], h->d_tier, 2);
   TBNAV_HIP(hipGetLastError());
   return TBNAV_OK;
 }
@@ -811,7 +886,7 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
   TBNAV_HIP(hipGetLastError());
   TBNAV_HIP(hipEventRecord(h->ev[1], st));
   hipLaunchKernelGGL(rbpf_raycast, dim3(h->N), dim3(kWave), sizeof(int) * 2 * (c.Bv > 0 ? c.Bv : 1), st, c, h->d_beams,
-                     sp.pose, h->d_log_odds[h->cur], h->d_err);
+                     sp.pose, h->d_log_odds[h->cur], h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_nocc[h->cur], h->d_err);
   TBNAV_HIP(hipGetLastError());
   TBNAV_HIP(hipEventRecord(h->ev[2], st));
   rc = run_distance_field(h, c.g, h->ev[3]);
@@ -819,7 +894,10 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
   TBNAV_HIP(hipEventRecord(h->ev[4], st));
   if (!local_only) {
     const double z = normals[(size_t)h->N * c.stride_normals];
-    hipLaunchKernelGGL(rbpf_normalize, dim3(1), dim3(64), 0, st, h->N, z, sp.weight, h->d_parent, h->d_norm);
+    if (h->N <= kNormMaxLds)
+      hipLaunchKernelGGL(rbpf_normalize, dim3(1), dim3(256), sizeof(double) * 2 * h->N, st, h->N, z, sp.weight, h->d_parent, h->d_norm);
+    else
+      hipLaunchKernelGGL(rbpf_normalize_seq, dim3(1), dim3(64), 0, st, h->N, z, sp.weight, h->d_parent, h->d_norm);
     TBNAV_HIP(hipGetLastError());
   }
   TBNAV_HIP(hipEventRecord(h->ev[5], st));
@@ -834,8 +912,9 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
   if (!local_only && no.resampled && out->status == TBNAV_OK) {
     const int nxt = 1 - h->cur;
     TBNAV_HIP(hipEventRecord(h->ev[6], st));
-    hipLaunchKernelGGL(rbpf_gather, dim3(16, h->N), dim3(256), 0, st, h->N, h->G, 0, h->d_parent, h->d_log_odds[h->cur],
-                       h->d_log_odds[nxt], h->d_code[h->cur], h->d_code[nxt], h->d_nocc[h->cur], h->d_nocc[nxt]);
+    hipLaunchKernelGGL(rbpf_gather, dim3(16, h->N), dim3(256), 0, st, h->N, h->G, h->xsize * h->words, h->d_parent, h->d_log_odds[h->cur],
+                       h->d_log_odds[nxt], h->d_code[h->cur], h->d_code[nxt], h->d_bitmap[h->cur], h->d_bitmap[nxt],
+                       h->d_rowcount[h->cur], h->d_rowcount[nxt], h->xsize, h->d_nocc[h->cur], h->d_nocc[nxt]);
     TBNAV_HIP(hipGetLastError());
     TBNAV_HIP(hipEventRecord(h->ev[7], st));
     gathered = true;
@@ -912,10 +991,10 @@ int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) {
     A((void**)&h->d_log_odds[b], sizeof(double) * h->G * N);
     A((void**)&h->d_code[b], sizeof(uint16_t) * h->G * N);
     A((void**)&h->d_nocc[b], sizeof(int) * N);
+    A((void**)&h->d_bitmap[b], sizeof(unsigned long long) * (size_t)N * xsize * words);
+    A((void**)&h->d_rowcount[b], sizeof(int) * (size_t)N * xsize);
   }
-  A((void**)&h->d_bitmap, sizeof(unsigned long long) * (size_t)N * xsize * words);
   A((void**)&h->d_parent, sizeof(int) * N);
-  A((void**)&h->d_rowcount, sizeof(uint16_t) * (size_t)N * xsize);
   A((void**)&h->d_tier, sizeof(int) * N);
   A((void**)&h->d_err, sizeof(int) * 4);
   A((void**)&h->d_norm, sizeof(NormOut));
@@ -946,6 +1025,8 @@ int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) {
     if (e == hipSuccess) e = hipMemset(h->d_log_odds[0], 0, sizeof(double) * h->G * N);  // log_odds_prior_ = log(1) = 0
     if (e == hipSuccess) e = hipMemset(h->d_code[0], 0xFF, sizeof(uint16_t) * h->G * N);  // occ_dist = max_occ_dist_
     if (e == hipSuccess) e = hipMemset(h->d_nocc[0], 0, sizeof(int) * N);
+    if (e == hipSuccess) e = hipMemset(h->d_bitmap[0], 0, sizeof(unsigned long long) * (size_t)N * xsize * words);
+    if (e == hipSuccess) e = hipMemset(h->d_rowcount[0], 0, sizeof(int) * (size_t)N * xsize);
   }
   if (e == hipSuccess) {
     const int lds = (int)edt_lds_bytes(xsize, words, C);
@@ -956,6 +1037,8 @@ int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) {
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)edt_compact_lds(kEdtRowsA));
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_edt_compact<kEdtRowsB>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)edt_compact_lds(kEdtRowsB));
+  if (e == hipSuccess && N <= kNormMaxLds)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_normalize), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 2 * N));
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) {
     const int rc = tbnav::hip_fail(e, "tbnav_rbpf_create allocation", __FILE__, __LINE__);
@@ -969,8 +1052,8 @@ int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) {
 void tbnav_rbpf_destroy(tbnav_rbpf* h) {
   if (!h) return;
   DeviceGuard guard(h->device);
-  for (int b = 0; b < 2; ++b) { (void)hipFree(h->d_state[b]); (void)hipFree(h->d_log_odds[b]); (void)hipFree(h->d_code[b]); (void)hipFree(h->d_nocc[b]); }
-  (void)hipFree(h->d_bitmap); (void)hipFree(h->d_beams); (void)hipFree(h->d_normals); (void)hipFree(h->d_parent); (void)hipFree(h->d_tier); (void)hipFree(h->d_rowcount);
+  for (int b = 0; b < 2; ++b) { (void)hipFree(h->d_state[b]); (void)hipFree(h->d_log_odds[b]); (void)hipFree(h->d_code[b]); (void)hipFree(h->d_nocc[b]); (void)hipFree(h->d_bitmap[b]); (void)hipFree(h->d_rowcount[b]); }
+  (void)hipFree(h->d_beams); (void)hipFree(h->d_normals); (void)hipFree(h->d_parent); (void)hipFree(h->d_tier);
   (void)hipFree(h->d_err); (void)hipFree(h->d_norm); (void)hipFree(h->d_trace);
   for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1039,8 +1122,9 @@ int tbnav_rbpf_gather_local(tbnav_rbpf* h, const int32_t* local_parent) {
   std::vector<int> par(local_parent, local_parent + N);
   for (int m = 0; m < N; ++m) if (par[m] < 0) par[m] = m;
   TBNAV_HIP(hipMemcpyAsync(h->d_parent, par.data(), sizeof(int) * N, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(rbpf_gather, dim3(16, N), dim3(256), 0, st, N, h->G, 0, h->d_parent, h->d_log_odds[h->cur],
-                     h->d_log_odds[nxt], h->d_code[h->cur], h->d_code[nxt], h->d_nocc[h->cur], h->d_nocc[nxt]);
+  hipLaunchKernelGGL(rbpf_gather, dim3(16, N), dim3(256), 0, st, N, h->G, h->xsize * h->words, h->d_parent, h->d_log_odds[h->cur],
+                     h->d_log_odds[nxt], h->d_code[h->cur], h->d_code[nxt], h->d_bitmap[h->cur], h->d_bitmap[nxt],
+                       h->d_rowcount[h->cur], h->d_rowcount[nxt], h->xsize, h->d_nocc[h->cur], h->d_nocc[nxt]);
   TBNAV_HIP(hipGetLastError());
   TBNAV_HIP(hipStreamSynchronize(st));
   std::vector<double> s((size_t)7 * N), d((size_t)7 * N);
@@ -1092,10 +1176,13 @@ int tbnav_rbpf_set_log_odds(tbnav_rbpf* h, int32_t particle, const double* in) {
   DeviceGuard guard(h->device);
   TBNAV_HIP(hipStreamSynchronize(h->stream));
   TBNAV_HIP(hipMemcpy(h->d_log_odds[h->cur] + (size_t)particle * h->G, in, sizeof(double) * h->G, hipMemcpyHostToDevice));
-  // refresh the occupied count (likelihoodFieldModel's "map has no obstacles" test, grid_mapper.cpp:94)
-  int cnt = 0;
-  for (size_t c = 0; c < h->G; ++c) cnt += (in[c] >= h->cut_occ) ? 1 : 0;
-  TBNAV_HIP(hipMemcpy(h->d_nocc[h->cur] + particle, &cnt, sizeof(int), hipMemcpyHostToDevice));
+  // rebuild this particle's occupancy bitmap / row counts / occupied count from the new log-odds
+  TBNAV_HIP(hipMemsetAsync(h->d_nocc[h->cur] + particle, 0, sizeof(int), h->stream));
+  const GridC g{h->p.xmin, h->p.xmax, h->p.ymin, h->p.ymax, h->p.resolution, h->xsize, h->ysize, h->words, h->max_occ_dist};
+  hipLaunchKernelGGL(rbpf_occupancy, dim3((h->xsize + 3) / 4, 1), dim3(256), 0, h->stream, g, h->cut_occ, particle,
+                     h->d_log_odds[h->cur], h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_nocc[h->cur]);
+  TBNAV_HIP(hipGetLastError());
+  TBNAV_HIP(hipStreamSynchronize(h->stream));
   return TBNAV_OK;
 }
 
