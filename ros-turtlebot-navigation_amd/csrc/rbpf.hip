@@ -449,6 +449,16 @@ __device__ __forceinline__ int floor_div(int num, int den) {  // den > 0
   if ((num % den != 0) && (num < 0)) --q;
   return q;
 }
+// Exact floor(num/den) for |num| < 2^24 and 0 < den < 2^13 (the envelope's operands: |num| <= 255^2 +
+// 2047^2, den <= 2*2047): both convert to float exactly, the float quotient is within 1 of the true
+// one, and one integer remainder check fixes it — ~10 instructions instead of the ~40 of an int division.
+__device__ __forceinline__ int floor_div_small(int num, int den) {
+  int q = (int)floorf(__fdividef((float)num, (float)den));
+  int r = num - q * den;
+  if (r < 0) { --q; r += den; }
+  if (r >= den) ++q;
+  return q;
+}
 
 // grid (column tiles, N), C threads (one per column of the tile; C = 64 or 32).  LDS: the particle's
 // bitmap rows, f[xsize][C] u8 (row-pass distance, 255 = none), v[xsize][C] u16 and z[xsize][C] i16
@@ -567,27 +577,35 @@ __global__ __launch_bounds__(kWave) void rbpf_edt_compact(GridC g, int radius, c
   if (j >= g.ysize) return;
   const unsigned long long le_mask = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);  // bits <= lane
   const unsigned long long ge_mask = ~((1ull << lane) - 1ull);                        // bits >= lane
-  // lower envelope over the non-empty rows; top-of-stack (v_t, f_t, z_t) lives in registers
+  // lower envelope over the non-empty rows; top-of-stack (v_t, f_t, z_t) lives in registers, and the
+  // (wave-uniform) row record of the NEXT iteration is fetched from LDS before this one is processed
   int top = -1, v_t = 0, f_t = 0, z_t = -1;
+  int nq = rowlist[0];
+  unsigned long long nword = roww[0];
+  int ndl = rowdl[0], ndr = rowdr[0];
   for (int s = 0; s < S; ++s) {
-    const int q = rowlist[s];
-    const unsigned long long word = roww[s];
-    int fq = min(lane + (int)rowdl[s], (63 - lane) + (int)rowdr[s]);
+    const int q = nq;
+    const unsigned long long word = nword;
+    const int dl = ndl, dr = ndr;
+    if (s + 1 < S) { nq = rowlist[s + 1]; nword = roww[s + 1]; ndl = rowdl[s + 1]; ndr = rowdr[s + 1]; }
+    int fq = min(lane + dl, (63 - lane) + dr);
     const unsigned long long ml = word & le_mask, mr = word & ge_mask;
     if (ml) fq = min(fq, lane - (63 - __clzll((long long)ml)));
     if (mr) fq = min(fq, (__ffsll((long long)mr) - 1) - lane);
     if (fq > radius) continue;
     const int hq = fq * fq + q * q;
-    int sd = -1;
+    // pop while the newcomer's intersection with the top is at or left of the top's own start:
+    // floor(num/den) <= z  <=>  num < (z+1)*den  (den > 0) — no division needed to decide
     while (top >= 0) {
-      sd = floor_div(hq - (f_t * f_t + v_t * v_t), 2 * (q - v_t));
-      if (sd > z_t) break;
+      const int num = hq - (f_t * f_t + v_t * v_t), den = 2 * (q - v_t);
+      if (num >= (z_t + 1) * den) break;
       --top;
       if (top >= 0) unpack(ent[top * kWave + lane], v_t, f_t, z_t);
     }
+    int sd = -1;
+    if (top >= 0) sd = floor_div_small(hq - (f_t * f_t + v_t * v_t), 2 * (q - v_t));
     ++top;
     // z only ever meets row indices 0..xs-1: clamping it to [-1, kZMax] changes no decision that matters
-    if (top == 0) sd = -1;
     sd = sd < -1 ? -1 : (sd > kZMax ? kZMax : sd);
     v_t = q; f_t = fq; z_t = sd;
     ent[top * kWave + lane] = pack(q, fq, sd);
@@ -595,14 +613,15 @@ __global__ __launch_bounds__(kWave) void rbpf_edt_compact(GridC g, int radius, c
   if (top < 0) return;  // nothing within reach of this column: every cell keeps its previous value
   uint16_t* out = codes + (size_t)p * xs * g.ysize + j;
   const int r2 = radius * radius;
-  int kk = 0, vq, fv, zz;
+  // walk the envelope; the NEXT entry is already in registers when the walk reaches its start row
+  int kk = 0, vq, fv, zz, vn = 0, fn = 0, zn = 0x7fffffff;
   unpack(ent[lane], vq, fv, zz);
-  int z_next = (top >= 1) ? unpack_z(ent[kWave + lane]) : 0x7fffffff;
+  if (top >= 1) unpack(ent[kWave + lane], vn, fn, zn);
   for (int i = 0; i < xs; ++i) {
-    while (z_next < i) {
+    while (zn < i) {
       ++kk;
-      unpack(ent[kk * kWave + lane], vq, fv, zz);
-      z_next = (kk < top) ? unpack_z(ent[(kk + 1) * kWave + lane]) : 0x7fffffff;
+      vq = vn; fv = fn;
+      if (kk < top) unpack(ent[(kk + 1) * kWave + lane], vn, fn, zn); else zn = 0x7fffffff;
     }
     const int d2 = (i - vq) * (i - vq) + fv * fv;
     if (d2 <= r2) out[(size_t)i * g.ysize] = (uint16_t)d2;

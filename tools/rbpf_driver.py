@@ -1,0 +1,17 @@
+"""Dev driver: a few cfg3 RBPF scans for profiling under rocprofv3."""
+import os, sys, numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import __graft_entry__ as g
+g.load_package()
+import bench_rbpf, rbpf_cases as rc
+from rtn_amd.rbpf import ParticleFilter, default_params
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+n_scans = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+pf = ParticleFilter(default_params(N=N, k=50, map_min=-10.0, map_max=10.0))
+steps, poses = rc.trajectory(n_scans, inc=(0.07, 0.10, 0.05))
+rng = np.random.default_rng(7)
+for s, (prev, cur, t_icp, u) in enumerate(steps):
+    scan = bench_rbpf._room_scan(poses[s], rng, rc.ROOM_SURVEY)
+    st = pf.SLAM(scan, u, cur, prev, True, t_icp, np.random.default_rng(100 + s).standard_normal(pf.numNormals(True)))
+print(st.neff, pf.kernelMs())
