@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -398,6 +399,149 @@ __global__ __launch_bounds__(kWave) void rbpf_raycast(ScanC c, const double2* __
   }
 }
 
+// Is map cell (cx, cy) one of the FREE cells of ray r (i.e. some n in [0, count) has ray_cell(r, n) == it)?
+__device__ __forceinline__ bool on_ray(const Ray& r, int cx, int cy) {
+  switch (r.kind) {
+    case 0: { const int n = (cy - r.y0) * r.sy; return cx == r.x0 && n >= 0 && n < r.count; }
+    case 1: { const int n = (cx - r.x0) * r.sx; return cy == r.y0 && n >= 0 && n < r.count; }
+    case 4: { const int n = (cx - r.x0) * r.sx; return n >= 0 && n < r.count && cy == r.y0 + r.sy * n; }
+    default: {
+      if (cx == r.x0 && cy == r.y0) return r.count > 0;
+      const int n = (r.kind == 2) ? cx - r.xa : cy - r.ya;      // steps along the major axis
+      if (n < 1 || n > r.dmaj - 1) return false;
+      const int t = ((r.kind == 2) ? cy - r.ya : cx - r.xa) * r.sgn;  // offset along the minor axis
+      // ray_cell gives offset c = max(0, ceil(a / (2*dmaj))) with a = 2*dmin*n - dmaj; test t == c without dividing
+      const int a = 2 * r.dmin * n - r.dmaj, d2 = 2 * r.dmaj;
+      return (a <= 0) ? (t == 0) : (t >= 1 && d2 * (t - 1) < a && a <= d2 * t);
+    }
+  }
+}
+
+// Tile version of the raycast (the default): no per-beam barrier.
+//  1. every (beam, step) pair bumps a 16-bit counter of its cell in an LDS tile covering the scan's
+//     bounding box (<= (2*range_max/res + 3)^2 cells) — order-free, LDS atomics;
+//  2. cells that are some beam's END POINT (<= Bv of them; they are the only cells that see both kinds
+//     of update in one scan, and there the floating-point add order matters) are replayed by one lane
+//     each: beams 0..Bv-1 in order, "+= l_free" if the cell is on the beam's free ray, "+= l_occ" if
+//     it is the beam's end point — exactly the reference's sequence for that cell;
+//  3. every other touched cell gets its count of "+= l_free" (same addend each time, so the order among
+//     them is immaterial) — bit-identical to the beam-ordered loop, checked against it and the oracle.
+// LDS: ex[Bv], ey[Bv] (int) | tile u32[(cap+1)/2] (two 16-bit counters per word; bit 15 = end-point flag).
+__global__ __launch_bounds__(512) void rbpf_raycast_tile(ScanC c, const double2* __restrict__ beams,
+                                                         const double* __restrict__ pose, double* __restrict__ log_odds,
+                                                         unsigned long long* __restrict__ bitmap, int* __restrict__ row_count,
+                                                         int* __restrict__ n_occ, int* __restrict__ err, int tile_cap) {
+  extern __shared__ __attribute__((aligned(16))) int lds_i[];
+  int* ex = lds_i;
+  int* ey = lds_i + c.Bv;
+  unsigned int* tile = reinterpret_cast<unsigned int*>(lds_i + 2 * c.Bv);
+  __shared__ int bad, bx0, bx1, by0, by1;
+  const int p = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave, nw = blockDim.x / kWave;
+  double* lo = log_odds + (size_t)p * c.g.xsize * c.g.ysize;
+  unsigned long long* bm = bitmap + (size_t)p * c.g.xsize * c.g.words;
+  int* rc = row_count + (size_t)p * c.g.xsize;
+  int* nocc = n_occ + p;
+  const double th = pose[p * 3 + 0], x = pose[p * 3 + 1], y = pose[p * 3 + 2];
+  int rx = 0, ry = 0;
+  const bool robot_ok = world2cell(c.g, x, y, rx, ry);  // freeGridIndex: world2Grid of the ROBOT pose (:558)
+  if (tid == 0) { bad = robot_ok ? 0 : 1; bx0 = bx1 = rx; by0 = by1 = ry; }
+  __syncthreads();
+  double s0, c0;
+  sincos(th, &s0, &c0);
+  const double X = c0 * c.Trs[1] - s0 * c.Trs[2] + x;
+  const double Y = s0 * c.Trs[1] + c0 * c.Trs[2] + y;
+  double st, ct;
+  sincos(th + c.Trs[0], &st, &ct);
+  for (int b = tid; b < c.Bv; b += blockDim.x) {
+    const double2 pt = beams[b];
+    int ci = rx, cj = ry;
+    if (!world2cell(c.g, ct * pt.x - st * pt.y + X, st * pt.x + ct * pt.y + Y, ci, cj)) { bad = 1; ci = rx; cj = ry; }
+    ex[b] = ci; ey[b] = cj;
+    atomicMin(&bx0, ci); atomicMax(&bx1, ci); atomicMin(&by0, cj); atomicMax(&by1, cj);
+  }
+  __syncthreads();
+  if (bad) { if (tid == 0) atomicOr(&err[0], 1); return; }
+  const int minx = bx0, miny = by0, bw = by1 - by0 + 1, bh = bx1 - bx0 + 1, ncell = bw * bh;
+  if (ncell > tile_cap) { if (tid == 0) atomicOr(&err[3], 2); return; }  // cannot happen for beams within range_max
+  for (int t = tid; t < (ncell + 1) / 2; t += blockDim.x) tile[t] = 0u;
+  __syncthreads();
+  const int xs = c.g.xsize;
+  // 1. counters
+  for (int b = wid; b < c.Bv; b += nw) {
+    const Ray r = make_ray(rx, ry, ex[b], ey[b]);
+    for (int n = lane; n < r.count; n += kWave) {
+      int cx, cy;
+      ray_cell(r, n, cx, cy);
+      const int t = (cx - minx) * bw + (cy - miny);
+      atomicAdd(&tile[t >> 1], (t & 1) ? 0x10000u : 1u);
+    }
+  }
+  for (int b = tid; b < c.Bv; b += blockDim.x) {
+    const int t = (ex[b] - minx) * bw + (ey[b] - miny);
+    atomicOr(&tile[t >> 1], (t & 1) ? 0x80000000u : 0x8000u);
+  }
+  __syncthreads();
+  // 2. end-point cells, replayed in beam order by the lane of the FIRST beam that ends there
+  for (int b = tid; b < c.Bv; b += blockDim.x) {
+    const int cx = ex[b], cy = ey[b];
+    bool first = true;
+    for (int q = 0; q < b; ++q) if (ex[q] == cx && ey[q] == cy) { first = false; break; }
+    if (!first) continue;
+    const size_t idx = (size_t)cx * xs + cy;
+    const double v0 = lo[idx];
+    double v = v0;
+    for (int q = 0; q < c.Bv; ++q) {
+      const int qx = ex[q], qy = ey[q];
+      if (qx == cx && qy == cy) { v += c.d_occ; continue; }  // the end point is never one of its own ray's free cells
+      // cheap reject: a ray only visits cells inside the box spanned by the robot cell and its end point
+      if ((cx < rx && cx < qx) || (cx > rx && cx > qx) || (cy < ry && cy < qy) || (cy > ry && cy > qy)) continue;
+      if (on_ray(make_ray(rx, ry, qx, qy), cx, cy)) v += c.d_free;
+    }
+    lo[idx] = v;
+    const bool was = v0 >= c.cut_occ, now = v >= c.cut_occ;
+    if (was != now) {
+      atomicXor(&bm[(size_t)cx * c.g.words + (cy >> 6)], 1ull << (cy & 63));
+      atomicAdd(&rc[cx], now ? 1 : -1);
+      atomicAdd(nocc, now ? 1 : -1);
+    }
+  }
+  // 3. every other touched cell: its count of free adds.  Four cells per thread per trip so that the four
+  //    (independent) log-odds loads are in flight together instead of one exposed L2 round trip per cell.
+  for (int t0 = tid * 4; t0 < ncell; t0 += blockDim.x * 4) {
+    int cn[4];
+    size_t idx[4];
+    double v0[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int t = t0 + q;
+      cn[q] = 0;
+      idx[q] = 0;
+      if (t < ncell) {
+        const unsigned int word = tile[t >> 1];
+        const unsigned int hlf = (t & 1) ? (word >> 16) : (word & 0xFFFFu);
+        if (!(hlf & 0x8000u)) cn[q] = (int)(hlf & 0x7FFFu);
+        idx[q] = (size_t)(minx + t / bw) * xs + (miny + t % bw);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v0[q] = cn[q] ? lo[idx[q]] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (!cn[q]) continue;
+      double v = v0[q];
+      for (int a = 0; a < cn[q]; ++a) v += c.d_free;
+      lo[idx[q]] = v;
+      const bool was = v0[q] >= c.cut_occ, now = v >= c.cut_occ;
+      if (was != now) {
+        const int t = t0 + q, cx = minx + t / bw, cy = miny + t % bw;
+        atomicXor(&bm[(size_t)cx * c.g.words + (cy >> 6)], 1ull << (cy & 63));
+        atomicAdd(&rc[cx], now ? 1 : -1);
+        atomicAdd(nocc, now ? 1 : -1);
+      }
+    }
+  }
+}
+
 // ---- occupancy bitmap ------------------------------------------------------------------------------
 // grid (rows/4, N), 256 threads: one wave per map row; lanes read the row coalesced.
 __global__ __launch_bounds__(256) void rbpf_occupancy(GridC g, double cut_occ, int p0, const double* __restrict__ log_odds,
@@ -761,6 +905,7 @@ struct tbnav_rbpf {
   double* d_normals = nullptr;
   size_t normals_cap = 0;
   int* d_parent = nullptr;
+  int tile_cap = 0;            // cells of the raycast LDS tile (0 = use the beam-ordered kernel)
   int* d_tier = nullptr;       // [N] which distance-field kernel handles the particle this scan
   int* d_err = nullptr;
   NormOut* d_norm = nullptr;
@@ -904,8 +1049,16 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
                      h->d_code[h->cur], h->d_nocc[h->cur], h->d_normals, sp.pose, sp.prev, sp.weight, h->tr, h->d_err);
   TBNAV_HIP(hipGetLastError());
   TBNAV_HIP(hipEventRecord(h->ev[1], st));
-  hipLaunchKernelGGL(rbpf_raycast, dim3(h->N), dim3(kWave), sizeof(int) * 2 * (c.Bv > 0 ? c.Bv : 1), st, c, h->d_beams,
-                     sp.pose, h->d_log_odds[h->cur], h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_nocc[h->cur], h->d_err);
+  {
+    const int bvn = c.Bv > 0 ? c.Bv : 1;
+    const size_t tile_lds = sizeof(int) * 2 * bvn + sizeof(unsigned int) * ((size_t)(h->tile_cap + 1) / 2);
+    if (h->tile_cap > 0 && c.Bv < 32768 && tile_lds <= 64 * 1024)
+      hipLaunchKernelGGL(rbpf_raycast_tile, dim3(h->N), dim3(512), tile_lds, st, c, h->d_beams, sp.pose, h->d_log_odds[h->cur],
+                         h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_nocc[h->cur], h->d_err, h->tile_cap);
+    else
+      hipLaunchKernelGGL(rbpf_raycast, dim3(h->N), dim3(kWave), sizeof(int) * 2 * bvn, st, c, h->d_beams, sp.pose,
+                         h->d_log_odds[h->cur], h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_nocc[h->cur], h->d_err);
+  }
   TBNAV_HIP(hipGetLastError());
   TBNAV_HIP(hipEventRecord(h->ev[2], st));
   rc = run_distance_field(h, c.g, h->ev[3]);
@@ -997,6 +1150,13 @@ int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) {
   h->p = *P; h->device = dev; h->N = P->num_particles; h->k = P->num_samples_mode;
   h->xsize = xsize; h->ysize = ysize; h->words = words; h->radius = radius; h->edt_cols = C;
   h->G = (size_t)xsize * ysize;
+  {
+    // every beam shorter than range_max ends within this many cells of the robot cell (+2 for the laser offset / rounding)
+    const double reach = (double)P->range_max + std::sqrt(P->Trs[1] * P->Trs[1] + P->Trs[2] * P->Trs[2]);
+    const long side = 2 * ((long)std::ceil(reach / P->resolution) + 2) + 1;
+    h->tile_cap = (side * side <= 30000) ? (int)(side * side) : 0;
+    if (const char* e = std::getenv("TBNAV_RBPF_RAYCAST_ORDERED")) if (std::atoi(e) == 1) h->tile_cap = 0;
+  }
   // log-odds constants with the host libm, exactly as the reference's ctor (grid_mapper.cpp:42-47)
   h->l_prior = std::log(0.5 / (1 - 0.5));
   h->l_occ = std::log(0.90 / (1 - 0.90));
