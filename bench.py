@@ -78,16 +78,32 @@ def kernel_profile(m, a, b, stream, n):
     return acc / n
 
 
-def roofline_obj(K, T, ms_kernels, ms_tick):
+def pmc_traffic(workload_key, kernel_prefix):
+    """HBM bytes per launch of a kernel from the committed PMC passes (profiles/r01_traffic_pmc.json:
+    separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 read correction calibrated on a known byte count)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")) as f:
+            wl = json.load(f)["workloads"][workload_key]
+        for name, v in wl.items():
+            if name.startswith(kernel_prefix):
+                return v["hbm_bytes"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
+def roofline_obj(K, T, ms_kernels, ms_tick, kernel_name, traffic_key=None):
     alg = BYTES_ROLLOUT_KERNEL * K * T
     achieved = alg / (ms_kernels[0] * 1e-3) / 1e9
     tick_gbs = BYTES_PER_ROLLOUT_STEP * K * T / (ms_tick * 1e-3) / 1e9
     return {
-        "bound": "hbm", "kernel": "mppi_rollout_cost", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+        "bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+        "traffic": pmc_traffic(traffic_key, kernel_name.split("<")[0]) if traffic_key else None,
+        "traffic_source": "profiles/r01_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" if traffic_key else None,
         "algorithmic_bytes_per_launch": alg,
-        "kernel_ms": {"mppi_rollout_cost": round(float(ms_kernels[0]), 6), "mppi_partials": round(float(ms_kernels[1]), 6),
-                      "mppi_combine": round(float(ms_kernels[2]), 6)},
+        "kernel_ms": {"rollout": round(float(ms_kernels[0]), 6), "partials": round(float(ms_kernels[1]), 6),
+                      "combine": round(float(ms_kernels[2]), 6)},
         "whole_tick": {"algorithmic_bytes": BYTES_PER_ROLLOUT_STEP * K * T, "ms": round(ms_tick, 6),
                        "achieved": round(tick_gbs, 3), "frac": round(tick_gbs / HBM_PEAK_GBS, 6)},
     }
@@ -186,7 +202,7 @@ def main():
                        "parallelism": f"rollout-shard x{world}" + (", 1 all-gather of soft-min records/tick" if world > 1 else "")},
             "rollout_steps_per_s": round(value * T, 1),
             "sync_tick_ms": round(sync_ms, 6),
-            "roofline": roofline_obj(K, T, ms_k, ms_step),
+            "roofline": roofline_obj(K, T, ms_k, ms_step, m.rollout_kernel, "mppi_K1024_T50" if (K, T) == (1024, 50) else None),
         }
         if world == 1 and not args.no_large:
             KL, HL = 65536, 1.0  # BASELINE configs[3] per-call size, on one GPU
@@ -195,7 +211,7 @@ def main():
             tl = lambda: ml.enqueueDev(X0, al.data_ptr(), bl.data_ptr(), stream)  # noqa: E731
             el_l = time_ticks(tl, sync, 50, 10, lambda: None)
             ms_l = kernel_profile(ml, al, bl, stream, 50)
-            rl = roofline_obj(KL, ml.steps, ms_l, el_l / 50 * 1e3)
+            rl = roofline_obj(KL, ml.steps, ms_l, el_l / 50 * 1e3, ml.rollout_kernel, "mppi_K65536_T100")
             rl["workload"] = f"MPPI newControls K={KL}, T={ml.steps} on 1 GPU"
             rl["rollouts_per_s"] = round(KL * 50 / el_l, 1)
             line["roofline_large"] = rl

@@ -69,6 +69,15 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
     alg_per_update = k * Bv * 8 + (c_free + Bv) * 16 + G * 16
     alg_edt = G * 16  # distance-field refresh: 8 B seed/occupancy read + 8 B distance write per reachable cell
     edt_ms = kms["occupancy"] + kms["edt"]
+    traffic = None
+    try:
+        import json
+        with open(os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")) as f:
+            wl = json.load(f)["workloads"]["rbpf_N1000_k50_400x400"]
+        if N == 1000:
+            traffic = sum(v["hbm_bytes"] for name, v in wl.items() if name.startswith("rbpf_edt"))
+    except (OSError, KeyError, ValueError):
+        pass
     out = {
         "metric": "RBPF particle-updates/s", "value": round(N / (ms_scan * 1e-3), 1), "unit": "particle-updates/s",
         "config": {"workload": f"RBPF SLAM N={N}, k={k}, {Bv} valid beams, {pf.xsize}x{pf.ysize} @0.05 m, ICP-ok branch "
@@ -78,9 +87,10 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
         "device_only_updates_per_s": round(N / (dev_ms * 1e-3), 1),
         "kernel_ms": {key: round(v, 4) for key, v in kms.items()},
         "dtype": "f64+u16",
-        "roofline": {"bound": "hbm", "kernel": "rbpf_occupancy+rbpf_edt (distance field)",
+        "roofline": {"bound": "hbm", "kernel": "rbpf_edt_compact (distance field)",
                      "achieved": round(alg_edt * N / (edt_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(alg_edt * N / (edt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
+                     "frac": round(alg_edt * N / (edt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": traffic,
+                     "traffic_source": "profiles/r01_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
                      "algorithmic_bytes_per_launch": alg_edt * N,
                      "whole_update": {"algorithmic_bytes_per_particle_update": alg_per_update,
                                       "achieved": round(alg_per_update * N / (dev_ms * 1e-3) / 1e9, 3),
