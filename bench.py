@@ -145,11 +145,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # dev switch: exercise the multi-rank path on a ONE-GPU box (all ranks on cuda:0, gloo exchange);
+    # the real run is one rank per GPU over RCCL.
+    one_gpu_test = os.environ.get("TBNAV_BENCH_ONE_GPU_GLOO") == "1"
+    if one_gpu_test:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if one_gpu_test:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     graft.load_package()
@@ -177,7 +185,7 @@ def main():
     sync = lambda: torch.cuda.synchronize(device)  # noqa: E731
     el = time_ticks(tick, sync, args.steps, args.warmup, barrier)
     if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=device)
+        t = torch.tensor([el], dtype=torch.float64, device="cpu" if one_gpu_test else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     out_controls = m.lastControls(stream)

@@ -67,14 +67,22 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
     Bv = int(st.n_valid_beams)
     c_free = 30 * Bv  # ~30 free cells per ray in this room
     alg_per_update = k * Bv * 8 + (c_free + Bv) * 16 + G * 16
-    alg_edt = G * 16  # distance-field refresh: 8 B seed/occupancy read + 8 B distance write per reachable cell
+    # distance-field refresh: 8 B seed/occupancy read + 8 B distance write per refreshed cell.  The device
+    # refreshes a window round each particle (every lookup of the scan provably falls inside it; the whole
+    # field is produced on demand), so the dominant kernel is priced on the cells it refreshes, while
+    # `whole_update` keeps SURVEY.md 8-d's reference-data-flow figure (whole reachable map).
+    move = max(float(np.hypot(steps[-1][2][1], steps[-1][2][2])), abs(float(steps[-1][3][1])))
+    half_cells = int(np.ceil((3.5 + move + 8.0 * np.sqrt(1e-8)) / 0.05)) + 3
+    win_cells = min(2 * half_cells + 1, pf.xsize) ** 2
+    full_edt = os.environ.get("TBNAV_RBPF_FULL_EDT") == "1"
+    alg_edt = (G if full_edt else win_cells) * 16
     edt_ms = kms["occupancy"] + kms["edt"]
     traffic = None
     try:
         import json
         with open(os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")) as f:
             wl = json.load(f)["workloads"]["rbpf_N1000_k50_400x400"]
-        if N == 1000:
+        if N == 1000 and not full_edt:
             traffic = sum(v["hbm_bytes"] for name, v in wl.items() if name.startswith("rbpf_edt"))
     except (OSError, KeyError, ValueError):
         pass
@@ -87,7 +95,7 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
         "device_only_updates_per_s": round(N / (dev_ms * 1e-3), 1),
         "kernel_ms": {key: round(v, 4) for key, v in kms.items()},
         "dtype": "f64+u16",
-        "roofline": {"bound": "hbm", "kernel": "rbpf_edt_compact (distance field)",
+        "roofline": {"bound": "hbm", "kernel": "rbpf_edt_compact (distance field" + ("" if full_edt else f", {int(np.sqrt(win_cells))}^2-cell window per particle") + ")",
                      "achieved": round(alg_edt * N / (edt_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(alg_edt * N / (edt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": traffic,
                      "traffic_source": "profiles/r01_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",

@@ -311,9 +311,9 @@ __global__ __launch_bounds__(kWave) void mppi_rollout_cost(RolloutArgs a,
 // T = 50: 16 -> 208 waves; K = 65536, T = 100: 1024 -> 13312), which is what hides the fp64 dependent
 // latency.  The only numerical difference is the association of the three sums (chunked instead of
 // strictly sequential): <= a few 1e-16 relative on x, y, theta and J (tests assert J within 1e-11).
-constexpr int kScanMaxChunks = 12;   // waves per workgroup of the time-parallel kernel (3 per SIMD -> up to 168 VGPRs)
-template <int TRIG, int TC>
-__global__ __launch_bounds__(kWave * kScanMaxChunks) void mppi_rollout_scan(RolloutArgs a, const double* __restrict__ duL,
+// MAXW = most waves (time chunks) per workgroup: 12 -> 3 waves per SIMD, up to 168 VGPRs; 16 -> 4 per SIMD, 128.
+template <int TRIG, int TC, int MAXW>
+__global__ __launch_bounds__(kWave * MAXW) void mppi_rollout_scan(RolloutArgs a, const double* __restrict__ duL,
                                                                            const double* __restrict__ duR,
                                                                            const double* __restrict__ u,
                                                                            double* __restrict__ J) {
@@ -671,12 +671,15 @@ int launch_rollout(tbnav_mppi* h, const double x0[3], const double* d_duL, const
     const int TCv = h->scan_tc, C = (h->T + TCv - 1) / TCv;
     const size_t lds = ((size_t)2 * h->T + (size_t)4 * C * kWave) * sizeof(double);
     const dim3 blk(kWave, C);
-#define TBNAV_SCAN(TR, TCC) hipLaunchKernelGGL((mppi_rollout_scan<TR, TCC>), grid, blk, lds, st, a, d_duL, d_duR, h->d_u, h->d_J)
-#define TBNAV_SCAN_TC(TR)                                                                                   \
-  switch (TCv) {                                                                                            \
-    case 4: TBNAV_SCAN(TR, 4); break;   case 5: TBNAV_SCAN(TR, 5); break;   case 6: TBNAV_SCAN(TR, 6); break;  \
-    case 8: TBNAV_SCAN(TR, 8); break;   case 10: TBNAV_SCAN(TR, 10); break; case 12: TBNAV_SCAN(TR, 12); break; \
-    case 16: TBNAV_SCAN(TR, 16); break; default: TBNAV_SCAN(TR, 20); break;                                  \
+#define TBNAV_SCAN(TR, TCC, MW) hipLaunchKernelGGL((mppi_rollout_scan<TR, TCC, MW>), grid, blk, lds, st, a, d_duL, d_duR, h->d_u, h->d_J)
+#define TBNAV_SCAN_TC(TR)                                                                                          \
+  switch (TCv) {                                                                                                   \
+    case 4: if (C > 12) TBNAV_SCAN(TR, 4, 16); else TBNAV_SCAN(TR, 4, 12); break;                                  \
+    case 5: TBNAV_SCAN(TR, 5, 12); break;   case 6: TBNAV_SCAN(TR, 6, 12); break;                                  \
+    case 7: TBNAV_SCAN(TR, 7, 16); break;                                                                          \
+    case 8: if (C > 12) TBNAV_SCAN(TR, 8, 16); else TBNAV_SCAN(TR, 8, 12); break;                                  \
+    case 10: TBNAV_SCAN(TR, 10, 12); break; case 12: TBNAV_SCAN(TR, 12, 12); break;                                \
+    case 16: TBNAV_SCAN(TR, 16, 12); break; default: TBNAV_SCAN(TR, 20, 12); break;                                \
   }
     if (h->trig == 1) { TBNAV_SCAN_TC(1) } else { TBNAV_SCAN_TC(3) }
 #undef TBNAV_SCAN_TC
@@ -778,7 +781,7 @@ int tbnav_mppi_create(const tbnav_mppi_params* params, tbnav_mppi** out) {
   // time-parallel kernel: up to 16 chunks (waves) per workgroup
   h->scan_tc = 0;
   for (int tc : {4, 5, 6, 8, 10, 12, 16, 20})
-    if ((T + tc - 1) / tc <= kScanMaxChunks) { h->scan_tc = tc; break; }
+    if ((T + tc - 1) / tc <= 12) { h->scan_tc = tc; break; }
   {
     // The time-parallel kernel exists to create waves when the rollout count alone cannot fill the chip;
     // once K/64 one-wave workgroups cover >= 2 waves per CU-SIMD pair the sequential kernel (fewer
@@ -791,7 +794,10 @@ int tbnav_mppi_create(const tbnav_mppi_params* params, tbnav_mppi** out) {
   }
   // development switches (A/B measurements; not part of the contract)
   if (const char* e = std::getenv("TBNAV_MPPI_SEQ")) if (std::atoi(e) == 1) h->scan_tc = 0;
-  if (const char* e = std::getenv("TBNAV_MPPI_SCAN_TC")) h->scan_tc = std::atoi(e);
+  if (const char* e = std::getenv("TBNAV_MPPI_SCAN_TC")) {  // 4/7/8 may use up to 16 chunks, the others 12
+    const int tc = std::atoi(e), cmax = (tc == 4 || tc == 7 || tc == 8) ? 16 : 12;
+    if (tc > 0 && (T + tc - 1) / tc <= cmax) h->scan_tc = tc;
+  }
   if (const char* e = std::getenv("TBNAV_MPPI_TRIG")) h->trig = (std::atoi(e) == 3) ? 3 : 1;
   if (const char* e = std::getenv("TBNAV_MPPI_NO_LDS")) { if (std::atoi(e) == 1) h->lds_from = T; }
   const size_t tk = (size_t)T * h->K;

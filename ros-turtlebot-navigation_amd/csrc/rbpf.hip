@@ -102,7 +102,7 @@ __device__ __forceinline__ double wave_prod(double v) {
 // sensor_model.cpp:73-108 does.  Returns the product in every lane; *oob is set if a beam leaves
 // the world (the reference throws from world2RowMajor).
 __device__ __forceinline__ double wave_scan_likelihood(const ScanC& c, const double2* __restrict__ beams,
-                                                       const uint16_t* __restrict__ code, int n_occ,
+                                                       const uint16_t* __restrict__ code, int n_occ, const int4 win,
                                                        double th, double x, double y, int lane, int* oob) {
   if (n_occ == 0) return 1.0;  // grid_mapper.cpp:94-98
   // Tms = T(pose) * Trs  (rigid2d.cpp:214-224)
@@ -118,7 +118,10 @@ __device__ __forceinline__ double wave_scan_likelihood(const ScanC& c, const dou
     const double ex = ct * pt.x - st * pt.y + X;
     const double ey = st * pt.x + ct * pt.y + Y;
     int ci, cj;
-    if (!world2cell(c.g, ex, ey, ci, cj)) { *oob = 1; continue; }
+    if (!world2cell(c.g, ex, ey, ci, cj)) { *oob |= 1; continue; }
+    // the distance field is only guaranteed fresh inside this particle's window (DESIGN.md "windowed refresh");
+    // the window is sized so that this cannot fail — if it ever does, the call reports it instead of reading stale data
+    if (ci < win.x || ci > win.y || cj < win.z || cj > win.w) { *oob |= 2; continue; }
     const double z = code_to_dist(c.g, code[(size_t)ci * c.g.xsize + cj]);
     double pz = 0.0;
     pz += c.z_hit * (c.sqrt_inv_hit * exp(-0.5 * (z * z) / c.var_hit));
@@ -169,7 +172,7 @@ struct Trace {
 // err[0] = out of world, err[1] = eta zero, err[2] = pdf variance zero, err[3] = bresenham
 __global__ __launch_bounds__(kProposeThreads) void rbpf_propose(ScanC c, const double2* __restrict__ beams,
                                                                 const uint16_t* __restrict__ codes,
-                                                                const int* __restrict__ n_occ,
+                                                                const int* __restrict__ n_occ, const int4* __restrict__ win,
                                                                 const double* __restrict__ normals,
                                                                 double* __restrict__ pose, double* __restrict__ prev_pose,
                                                                 double* __restrict__ weight, Trace tr, int* __restrict__ err) {
@@ -183,6 +186,7 @@ __global__ __launch_bounds__(kProposeThreads) void rbpf_propose(ScanC c, const d
   const uint16_t* code = codes + (size_t)p * c.g.xsize * c.g.ysize;
   const double* z = normals + (size_t)p * c.stride_normals;
   const int nocc = n_occ[p];
+  const int4 wn = win[p];
   int oob = 0;
 
   if (!c.icp_ok) {
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(kProposeThreads) void rbpf_propose(ScanC c, const d
         nx = x + ((-uvx / uw) * sin(nth) + (uvx / uw) * sin(nth + uw) + w1);
         ny = y + ((uvx / uw) * cos(nth) - (uvx / uw) * cos(nth + uw) + w2);
       }
-      const double sl = wave_scan_likelihood(c, beams, code, nocc, nth, nx, ny, lane, &oob);
+      const double sl = wave_scan_likelihood(c, beams, code, nocc, wn, nth, nx, ny, lane, &oob);
       if (lane == 0) {
         prev_pose[p * 3 + 0] = th; prev_pose[p * 3 + 1] = x; prev_pose[p * 3 + 2] = y;
         pose[p * 3 + 0] = nth; pose[p * 3 + 1] = nx; pose[p * 3 + 2] = ny;
@@ -211,7 +215,8 @@ __global__ __launch_bounds__(kProposeThreads) void rbpf_propose(ScanC c, const d
         tr.weight_raw[p] = w;
         tr.new_pose[p * 3 + 0] = nth; tr.new_pose[p * 3 + 1] = nx; tr.new_pose[p * 3 + 2] = ny;
       }
-      if (oob) atomicOr(&err[0], 1);
+      if (oob & 1) atomicOr(&err[0], 1);
+      if (oob & 2) atomicOr(&err[3], 4);
     }
     return;
   }
@@ -236,10 +241,11 @@ __global__ __launch_bounds__(kProposeThreads) void rbpf_propose(ScanC c, const d
 
   // ---- scan likelihood of every sample (:541): one wave per sample, lanes over beams
   for (int j = wid; j < k; j += kProposeThreads / kWave) {
-    const double sl = wave_scan_likelihood(c, beams, code, nocc, smp[3 * j + 0], smp[3 * j + 1], smp[3 * j + 2], lane, &oob);
+    const double sl = wave_scan_likelihood(c, beams, code, nocc, wn, smp[3 * j + 0], smp[3 * j + 1], smp[3 * j + 2], lane, &oob);
     if (lane == 0) pscan[j] = sl;
   }
-  if (oob) atomicOr(&err[0], 1);
+  if (oob & 1) atomicOr(&err[0], 1);
+  if (oob & 2) atomicOr(&err[3], 4);
   __syncthreads();
 
   // ---- Gaussian proposal in the reference's sequential order (:522-599), new pose (:214-231)
@@ -565,6 +571,34 @@ __global__ __launch_bounds__(256) void rbpf_occupancy(GridC g, double cut_occ, i
 }
 
 // ---- exact distance transform ------------------------------------------------------------------------
+// ---- windowed refresh --------------------------------------------------------------------------------
+// The distance field is recomputed from the occupancy bitmap from scratch (it has no state of its own apart
+// from "cells out of reach keep their value"), and the only reader between two scans is the next scan's
+// likelihood: beam end points within range_max of poses near the particle's predicted pose.  So the refresh
+// runs at the START of the next SLAM call, for a window round the particle that provably contains every
+// lookup of that call (checked in the likelihood: a miss is reported, never read stale); the whole field of a
+// particle is produced on demand (tbnav_rbpf_get_occ_dist / get_dist_code, particle export).
+// state[p]: 0 = bitmap changed since the last transform, 1 = window fresh, 2 = whole field fresh (or injected).
+__global__ void rbpf_window(GridC g, int N, int half_cells, const double* __restrict__ pose, int* __restrict__ state,
+                            int* __restrict__ skip, int4* __restrict__ win) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= N) return;
+  const int stt = state[p];
+  skip[p] = (stt == 2) ? 1 : 0;
+  int4 w = make_int4(0, g.xsize - 1, 0, g.ysize - 1);
+  if (stt != 2) {
+    int ci, cj;
+    if (world2cell(g, pose[p * 3 + 1], pose[p * 3 + 2], ci, cj)) {
+      w.x = max(0, ci - half_cells); w.y = min(g.xsize - 1, ci + half_cells);
+      w.z = max(0, cj - half_cells); w.w = min(g.ysize - 1, cj + half_cells);
+    }
+    state[p] = 1;
+  }
+  win[p] = w;
+}
+
+struct EdtJob { const int4* win; const int* skip; int p0; };
+
 // distance (cells) from column j to the nearest set bit of a bitmap row, capped at `cap` (255 = none)
 __device__ __forceinline__ int row_nearest(const unsigned long long* row, int words, int j, int cap) {
   const int w = j >> 6, b = j & 63;
@@ -609,16 +643,20 @@ __device__ __forceinline__ int floor_div_small(int num, int den) {
 // (lower-envelope stack).  Integer arithmetic only: d2 = min_i' (i-i')^2 + f(i',j)^2 exactly.
 template <int C>
 __global__ __launch_bounds__(C) void rbpf_edt(GridC g, int radius, const unsigned long long* __restrict__ bitmap,
-                                              uint16_t* __restrict__ codes, const int* __restrict__ tier, int my_tier) {
+                                              uint16_t* __restrict__ codes, const int* __restrict__ tier, int my_tier, EdtJob job) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  if (tier[blockIdx.y] != my_tier) return;  // this particle was handled by a compact-row kernel
+  const int p = job.p0 + blockIdx.y;
+  if (job.skip[p] || tier[p] != my_tier) return;  // fresh already / handled by a compact-row kernel
+  const int4 wn = job.win[p];
+  const int tile = wn.z / C + blockIdx.x;
+  if (tile * C > wn.w) return;
   const int xs = g.xsize, words = g.words;
   unsigned long long* rows = reinterpret_cast<unsigned long long*>(lds_raw);            // [xs][words]
   uint16_t* v = reinterpret_cast<uint16_t*>(lds_raw + (size_t)xs * words * 8);          // [xs][C]
   int16_t* z = reinterpret_cast<int16_t*>(lds_raw + (size_t)xs * words * 8 + (size_t)xs * C * 2);  // [xs][C]
   uint8_t* f = lds_raw + (size_t)xs * words * 8 + (size_t)xs * C * 4;                   // [xs][C]
-  const int p = blockIdx.y, lane = threadIdx.x;
-  const int j = blockIdx.x * C + lane;
+  const int lane = threadIdx.x;
+  const int j = tile * C + lane;
   const unsigned long long* bm = bitmap + (size_t)p * xs * words;
   for (int t = lane; t < xs * words; t += C) rows[t] = bm[t];
   __syncthreads();
@@ -647,7 +685,7 @@ __global__ __launch_bounds__(C) void rbpf_edt(GridC g, int radius, const unsigne
   if (top < 0) return;  // nothing within reach of this column: every cell keeps its previous value
   const int r2 = radius * radius;
   int kk = 0;
-  for (int i = 0; i < xs; ++i) {
+  for (int i = wn.x; i <= wn.y; ++i) {
     while (kk < top && z[(kk + 1) * C + lane] < i) ++kk;
     const int vq = v[kk * C + lane];
     const int fv = f[vq * C + lane];
@@ -673,17 +711,19 @@ __device__ __forceinline__ int unpack_z(uint32_t e) { return (int)(e >> 19) - 1;
 template <int SMAX>
 __global__ __launch_bounds__(kWave) void rbpf_edt_compact(GridC g, int radius, const unsigned long long* __restrict__ bitmap,
                                                           const int* __restrict__ row_count,
-                                                          uint16_t* __restrict__ codes, int* __restrict__ tier, int my_tier) {
+                                                          uint16_t* __restrict__ codes, int* __restrict__ tier, int my_tier, EdtJob job) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const int p = blockIdx.y, lane = threadIdx.x;
-  if (tier[p] != my_tier) return;
+  const int p = job.p0 + blockIdx.y, lane = threadIdx.x;
+  if (job.skip[p] || tier[p] != my_tier) return;
+  const int4 wn = job.win[p];
+  const int tw = (wn.z >> 6) + blockIdx.x;          // the tile is exactly bitmap word `tw` of every row
+  if (tw > (wn.w >> 6)) return;
   uint32_t* ent = reinterpret_cast<uint32_t*>(lds_raw);                                  // [SMAX][64] packed stack entries
   unsigned long long* roww = reinterpret_cast<unsigned long long*>(lds_raw + (size_t)SMAX * kWave * 4);  // [SMAX] tile word of the row
   uint16_t* rowlist = reinterpret_cast<uint16_t*>(lds_raw + (size_t)SMAX * kWave * 4 + (size_t)SMAX * 8);  // [SMAX]
   uint16_t* rowdl = rowlist + SMAX;   // [SMAX] distance from the tile's first column to the nearest occupied cell left of the tile
   uint16_t* rowdr = rowdl + SMAX;     // [SMAX] distance from the tile's last column to the nearest one right of it
   const int xs = g.xsize, words = g.words;
-  const int tw = blockIdx.x;          // the tile is exactly bitmap word `tw` of every row
   const int j = tw * kWave + lane;
   const unsigned long long* bm = bitmap + (size_t)p * xs * words;
   const int* rc = row_count + (size_t)p * xs;
@@ -700,7 +740,7 @@ __global__ __launch_bounds__(kWave) void rbpf_edt_compact(GridC g, int radius, c
     S += __popcll(m);
   }
   if (S == 0) return;  // empty map: nothing to write
-  if (S > SMAX || xs > kEdtCompactMaxRows) { if (lane == 0 && tw == 0) tier[p] = my_tier + 1; return; }
+  if (S > SMAX || xs > kEdtCompactMaxRows) { if (lane == 0 && blockIdx.x == 0) tier[p] = my_tier + 1; return; }
   __syncthreads();
   // per (row, tile): the tile's own word and the distances to the nearest set bits outside the tile
   for (int s = lane; s < S; s += kWave) {
@@ -761,7 +801,7 @@ __global__ __launch_bounds__(kWave) void rbpf_edt_compact(GridC g, int radius, c
   int kk = 0, vq, fv, zz, vn = 0, fn = 0, zn = 0x7fffffff;
   unpack(ent[lane], vq, fv, zz);
   if (top >= 1) unpack(ent[kWave + lane], vn, fn, zn);
-  for (int i = 0; i < xs; ++i) {
+  for (int i = wn.x; i <= wn.y; ++i) {
     while (zn < i) {
       ++kk;
       vq = vn; fv = fn;
@@ -906,6 +946,10 @@ struct tbnav_rbpf {
   size_t normals_cap = 0;
   int* d_parent = nullptr;
   int tile_cap = 0;            // cells of the raycast LDS tile (0 = use the beam-ordered kernel)
+  bool full_edt = false;       // TBNAV_RBPF_FULL_EDT=1: whole-map distance transform after every map update
+  int* d_fstate = nullptr;     // [N] distance-field state: 0 stale, 1 window fresh, 2 whole field fresh / injected
+  int* d_skip = nullptr;       // [N] scratch: 1 = no refresh needed this call
+  int4* d_win = nullptr;       // [N] refreshed window (i0, i1, j0, j1), inclusive
   int* d_tier = nullptr;       // [N] which distance-field kernel handles the particle this scan
   int* d_err = nullptr;
   NormOut* d_norm = nullptr;
@@ -989,28 +1033,53 @@ int status_from_err(const int err[4]) {
   if (err[0]) return TBNAV_ERR_OUT_OF_WORLD;
   if (err[2]) return TBNAV_ERR_PDF_VARIANCE;
   if (err[1]) return TBNAV_ERR_ETA_ZERO;
+  if (err[3] & 4) return TBNAV_ERR_UNSUPPORTED;  // a likelihood lookup left the particle's refreshed window (cannot happen: see rbpf_window)
   if (err[3]) return TBNAV_ERR_BRESENHAM;
   return TBNAV_OK;
 }
 
-int run_distance_field(tbnav_rbpf* h, const GridC& g, hipEvent_t e_mid) {
+// The three tiers of the exact distance transform for particles [p0, p0 + count): windowed (tiles_x = the
+// tiles a window can span) or whole-map (tiles_x = every tile; the caller has set win/skip accordingly).
+int run_distance_field(tbnav_rbpf* h, const GridC& g, int p0, int count, int tiles64) {
   hipStream_t st = h->stream;
-  if (e_mid) TBNAV_HIP(hipEventRecord(e_mid, st));  // (the occupancy pass is gone: the raycast kernel keeps the bitmap current)
   // tier 0: <= kEdtRowsA non-empty rows, tier 1: <= kEdtRowsB, tier 2: the general kernel (decided on the device)
-  TBNAV_HIP(hipMemsetAsync(h->d_tier, 0, sizeof(int) * h->N, st));
-  const dim3 gridc((h->ysize + kWave - 1) / kWave, h->N);
+  TBNAV_HIP(hipMemsetAsync(h->d_tier + p0, 0, sizeof(int) * count, st));
+  const EdtJob job{h->d_win, h->d_skip, p0};
+  const dim3 gridc(tiles64, count);
   hipLaunchKernelGGL(rbpf_edt_compact<kEdtRowsA>, gridc, dim3(kWave), edt_compact_lds(kEdtRowsA), st, g, h->radius,
-                     h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_code[h->cur], h->d_tier, 0);
+                     h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_code[h->cur], h->d_tier, 0, job);
   TBNAV_HIP(hipGetLastError());
   hipLaunchKernelGGL(rbpf_edt_compact<kEdtRowsB>, gridc, dim3(kWave), edt_compact_lds(kEdtRowsB), st, g, h->radius,
-                     h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_code[h->cur], h->d_tier, 1);
+                     h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_code[h->cur], h->d_tier, 1, job);
   TBNAV_HIP(hipGetLastError());
   const int C = h->edt_cols;
   const size_t lds = edt_lds_bytes(h->xsize, h->words, C);
-  const dim3 grid((h->ysize + C - 1) / C, h->N);
-  if (C == 64) hipLaunchKernelGGL(rbpf_edt<64>, grid, dim3(64), lds, st, g, h->radius, h->d_bitmap[h->cur], h->d_code[h->cur], h->d_tier, 2);
-  else hipLaunchKernelGGL(rbpf_edt<32>, grid, dim3(32), lds, st, g, h->radius, h->d_bitmap[h->cur], h->d_code[h->cur], h->d_tier, 2);
+  const dim3 grid(tiles64 * (kWave / C), count);
+  if (C == 64) hipLaunchKernelGGL(rbpf_edt<64>, grid, dim3(64), lds, st, g, h->radius, h->d_bitmap[h->cur], h->d_code[h->cur], h->d_tier, 2, job);
+  else hipLaunchKernelGGL(rbpf_edt<32>, grid, dim3(32), lds, st, g, h->radius, h->d_bitmap[h->cur], h->d_code[h->cur], h->d_tier, 2, job);
   TBNAV_HIP(hipGetLastError());
+  return TBNAV_OK;
+}
+
+GridC grid_of(const tbnav_rbpf* h) {
+  return GridC{h->p.xmin, h->p.xmax, h->p.ymin, h->p.ymax, h->p.resolution, h->xsize, h->ysize, h->words, h->max_occ_dist};
+}
+
+// Whole-field refresh of ONE particle, on demand (state 2 afterwards).
+int ensure_full_field(tbnav_rbpf* h, int particle) {
+  hipStream_t st = h->stream;
+  int stt = 0;
+  TBNAV_HIP(hipStreamSynchronize(st));
+  TBNAV_HIP(hipMemcpy(&stt, h->d_fstate + particle, sizeof(int), hipMemcpyDeviceToHost));
+  if (stt == 2) return TBNAV_OK;
+  const int4 full = make_int4(0, h->xsize - 1, 0, h->ysize - 1);
+  const int zero = 0, two = 2;
+  TBNAV_HIP(hipMemcpy(h->d_win + particle, &full, sizeof full, hipMemcpyHostToDevice));
+  TBNAV_HIP(hipMemcpy(h->d_skip + particle, &zero, sizeof zero, hipMemcpyHostToDevice));
+  int rc = run_distance_field(h, grid_of(h), particle, 1, (h->ysize + kWave - 1) / kWave);
+  if (rc != TBNAV_OK) return rc;
+  TBNAV_HIP(hipStreamSynchronize(st));
+  TBNAV_HIP(hipMemcpy(h->d_fstate + particle, &two, sizeof two, hipMemcpyHostToDevice));
   return TBNAV_OK;
 }
 
@@ -1044,11 +1113,32 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
   TBNAV_HIP(hipMemsetAsync(h->d_err, 0, sizeof(int) * 4, st));
   StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
 
+  // ---- distance-field refresh for this call's lookups (windowed), then the particle update
   TBNAV_HIP(hipEventRecord(h->ev[0], st));
-  hipLaunchKernelGGL(rbpf_propose, dim3(h->N), dim3(kProposeThreads), sizeof(double) * 5 * h->k, st, c, h->d_beams,
-                     h->d_code[h->cur], h->d_nocc[h->cur], h->d_normals, sp.pose, sp.prev, sp.weight, h->tr, h->d_err);
-  TBNAV_HIP(hipGetLastError());
+  {
+    // every lookup of this call lies within `half` metres of the particle's CURRENT position: the sampled poses
+    // sit at T(pose)*T_icp (or the motion-model pose) +- the sampling noise, the laser at |Trs| from them, and
+    // a valid beam ends less than range_max from the laser
+    double sig = 0.0;
+    for (int q = 1; q < 3; ++q) sig = std::max(sig, std::max(h->p.sample_range[q], h->p.motion_noise[q]));
+    const double move = std::max(std::hypot(T_icp[1], T_icp[2]), std::fabs(u[1]));
+    const double half = (double)h->p.range_max + std::hypot(h->p.Trs[1], h->p.Trs[2]) + move + 8.0 * std::sqrt(sig);
+    int half_cells = (int)std::ceil(half / h->p.resolution) + 3;
+    if (h->full_edt || half_cells > h->xsize) half_cells = h->xsize;  // whole map
+    hipLaunchKernelGGL(rbpf_window, dim3((h->N + 255) / 256), dim3(256), 0, st, c.g, h->N, half_cells, sp.pose, h->d_fstate,
+                       h->d_skip, h->d_win);
+    TBNAV_HIP(hipGetLastError());
+    if (!h->full_edt) {
+      const int tiles = std::min((2 * half_cells + 1 + kWave - 1) / kWave + 1, (h->ysize + kWave - 1) / kWave);
+      rc = run_distance_field(h, c.g, 0, h->N, tiles);
+      if (rc != TBNAV_OK) return rc;
+    }
+  }
   TBNAV_HIP(hipEventRecord(h->ev[1], st));
+  hipLaunchKernelGGL(rbpf_propose, dim3(h->N), dim3(kProposeThreads), sizeof(double) * 5 * h->k, st, c, h->d_beams,
+                     h->d_code[h->cur], h->d_nocc[h->cur], h->d_win, h->d_normals, sp.pose, sp.prev, sp.weight, h->tr, h->d_err);
+  TBNAV_HIP(hipGetLastError());
+  TBNAV_HIP(hipEventRecord(h->ev[2], st));
   {
     const int bvn = c.Bv > 0 ? c.Bv : 1;
     const size_t tile_lds = sizeof(int) * 2 * bvn + sizeof(unsigned int) * ((size_t)(h->tile_cap + 1) / 2);
@@ -1060,9 +1150,15 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
                          h->d_log_odds[h->cur], h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_nocc[h->cur], h->d_err);
   }
   TBNAV_HIP(hipGetLastError());
-  TBNAV_HIP(hipEventRecord(h->ev[2], st));
-  rc = run_distance_field(h, c.g, h->ev[3]);
-  if (rc != TBNAV_OK) return rc;
+  TBNAV_HIP(hipEventRecord(h->ev[3], st));
+  if (h->full_edt) {
+    // legacy placement (TBNAV_RBPF_FULL_EDT=1): whole field of every particle right after the map update,
+    // where the reference runs its brushfire (grid_mapper.cpp:181)
+    TBNAV_HIP(hipMemsetAsync(h->d_skip, 0, sizeof(int) * h->N, st));
+    rc = run_distance_field(h, c.g, 0, h->N, (h->ysize + kWave - 1) / kWave);
+    if (rc != TBNAV_OK) return rc;
+    TBNAV_HIP(hipMemsetAsync(h->d_fstate, 0, sizeof(int) * h->N, st));  // overwritten with 2 below
+  }
   TBNAV_HIP(hipEventRecord(h->ev[4], st));
   if (!local_only) {
     const double z = normals[(size_t)h->N * c.stride_normals];
@@ -1092,7 +1188,22 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
     gathered = true;
   }
   TBNAV_HIP(hipStreamSynchronize(st));
-  for (int i = 0; i < TBNAV_RBPF_NKERNELS - 1; ++i) TBNAV_HIP(hipEventElapsedTime(&h->last_ms[i], h->ev[i], h->ev[i + 1]));
+  {
+    // the map changed: every field is stale until the next refresh (whole-map mode: fresh everywhere)
+    std::vector<int> stt(h->N, h->full_edt ? 2 : 0);
+    TBNAV_HIP(hipMemcpy(h->d_fstate, stt.data(), sizeof(int) * h->N, hipMemcpyHostToDevice));
+  }
+  float e01, e12, e23, e34, e45;
+  TBNAV_HIP(hipEventElapsedTime(&e01, h->ev[0], h->ev[1]));
+  TBNAV_HIP(hipEventElapsedTime(&e12, h->ev[1], h->ev[2]));
+  TBNAV_HIP(hipEventElapsedTime(&e23, h->ev[2], h->ev[3]));
+  TBNAV_HIP(hipEventElapsedTime(&e34, h->ev[3], h->ev[4]));
+  TBNAV_HIP(hipEventElapsedTime(&e45, h->ev[4], h->ev[5]));
+  h->last_ms[0] = e12;        // propose
+  h->last_ms[1] = e23;        // raycast
+  h->last_ms[2] = 0.f;        // (occupancy pass: folded into the raycast)
+  h->last_ms[3] = e01 + e34;  // distance field (windowed refresh before the update, or whole-map after it)
+  h->last_ms[4] = e45;        // normalise / select
   h->last_ms[5] = 0.f;
   if (gathered) TBNAV_HIP(hipEventElapsedTime(&h->last_ms[5], h->ev[6], h->ev[7]));
   if (gathered) {
@@ -1156,6 +1267,7 @@ int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) {
     const long side = 2 * ((long)std::ceil(reach / P->resolution) + 2) + 1;
     h->tile_cap = (side * side <= 30000) ? (int)(side * side) : 0;
     if (const char* e = std::getenv("TBNAV_RBPF_RAYCAST_ORDERED")) if (std::atoi(e) == 1) h->tile_cap = 0;
+    if (const char* e = std::getenv("TBNAV_RBPF_FULL_EDT")) h->full_edt = std::atoi(e) == 1;
   }
   // log-odds constants with the host libm, exactly as the reference's ctor (grid_mapper.cpp:42-47)
   h->l_prior = std::log(0.5 / (1 - 0.5));
@@ -1174,6 +1286,9 @@ int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) {
     A((void**)&h->d_rowcount[b], sizeof(int) * (size_t)N * xsize);
   }
   A((void**)&h->d_parent, sizeof(int) * N);
+  A((void**)&h->d_fstate, sizeof(int) * N);
+  A((void**)&h->d_skip, sizeof(int) * N);
+  A((void**)&h->d_win, sizeof(int4) * N);
   A((void**)&h->d_tier, sizeof(int) * N);
   A((void**)&h->d_err, sizeof(int) * 4);
   A((void**)&h->d_norm, sizeof(NormOut));
@@ -1204,6 +1319,15 @@ int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) {
     if (e == hipSuccess) e = hipMemset(h->d_log_odds[0], 0, sizeof(double) * h->G * N);  // log_odds_prior_ = log(1) = 0
     if (e == hipSuccess) e = hipMemset(h->d_code[0], 0xFF, sizeof(uint16_t) * h->G * N);  // occ_dist = max_occ_dist_
     if (e == hipSuccess) e = hipMemset(h->d_nocc[0], 0, sizeof(int) * N);
+    if (e == hipSuccess) e = hipMemset(h->d_skip, 0, sizeof(int) * N);
+    if (e == hipSuccess) {  // empty maps: the initial field (everything unreached) IS the whole, fresh field
+      std::vector<int> two(N, 2);
+      e = hipMemcpy(h->d_fstate, two.data(), sizeof(int) * N, hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess) {
+      std::vector<int4> w(N, make_int4(0, xsize - 1, 0, ysize - 1));
+      e = hipMemcpy(h->d_win, w.data(), sizeof(int4) * N, hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipMemset(h->d_bitmap[0], 0, sizeof(unsigned long long) * (size_t)N * xsize * words);
     if (e == hipSuccess) e = hipMemset(h->d_rowcount[0], 0, sizeof(int) * (size_t)N * xsize);
   }
@@ -1232,7 +1356,7 @@ void tbnav_rbpf_destroy(tbnav_rbpf* h) {
   if (!h) return;
   DeviceGuard guard(h->device);
   for (int b = 0; b < 2; ++b) { (void)hipFree(h->d_state[b]); (void)hipFree(h->d_log_odds[b]); (void)hipFree(h->d_code[b]); (void)hipFree(h->d_nocc[b]); (void)hipFree(h->d_bitmap[b]); (void)hipFree(h->d_rowcount[b]); }
-  (void)hipFree(h->d_beams); (void)hipFree(h->d_normals); (void)hipFree(h->d_parent); (void)hipFree(h->d_tier);
+  (void)hipFree(h->d_beams); (void)hipFree(h->d_normals); (void)hipFree(h->d_parent); (void)hipFree(h->d_tier); (void)hipFree(h->d_fstate); (void)hipFree(h->d_skip); (void)hipFree(h->d_win);
   (void)hipFree(h->d_err); (void)hipFree(h->d_norm); (void)hipFree(h->d_trace);
   for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1362,12 +1486,15 @@ int tbnav_rbpf_set_log_odds(tbnav_rbpf* h, int32_t particle, const double* in) {
                      h->d_log_odds[h->cur], h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_nocc[h->cur]);
   TBNAV_HIP(hipGetLastError());
   TBNAV_HIP(hipStreamSynchronize(h->stream));
+  const int zero = 0;  // the distance field no longer matches the map
+  TBNAV_HIP(hipMemcpy(h->d_fstate + particle, &zero, sizeof zero, hipMemcpyHostToDevice));
   return TBNAV_OK;
 }
 
 int tbnav_rbpf_get_dist_code(tbnav_rbpf* h, int32_t particle, uint16_t* out) {
   if (!h || !out || particle < 0 || particle >= h->N) return TBNAV_ERR_INVALID_ARG;
   DeviceGuard guard(h->device);
+  { const int rc = ensure_full_field(h, particle); if (rc != TBNAV_OK) return rc; }  // whole field on demand
   TBNAV_HIP(hipStreamSynchronize(h->stream));
   TBNAV_HIP(hipMemcpy(out, h->d_code[h->cur] + (size_t)particle * h->G, sizeof(uint16_t) * h->G, hipMemcpyDeviceToHost));
   return TBNAV_OK;
@@ -1398,6 +1525,8 @@ int tbnav_rbpf_set_occ_dist(tbnav_rbpf* h, int32_t particle, const double* in) {
   DeviceGuard guard(h->device);
   TBNAV_HIP(hipStreamSynchronize(h->stream));
   TBNAV_HIP(hipMemcpy(h->d_code[h->cur] + (size_t)particle * h->G, code.data(), sizeof(uint16_t) * h->G, hipMemcpyHostToDevice));
+  const int two = 2;  // an injected field is authoritative: the next call does not refresh it
+  TBNAV_HIP(hipMemcpy(h->d_fstate + particle, &two, sizeof two, hipMemcpyHostToDevice));
   return TBNAV_OK;
 }
 
