@@ -2,6 +2,8 @@
 // ctypes: the rigid2d layer is compared bit-exactly with the reference build, and the two class
 // surfaces (controller::MPPI, bmapping::ParticleFilter) are exercised end to end on the GPU exactly
 // the way the ROS nodes call them.  Same argument conventions as oracle/ref_harness.cpp.
+#include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <sstream>
@@ -90,8 +92,14 @@ void hst_twister_stream(uint64_t seed, int64_t n, double mu, double sigma, doubl
 // Closed loop of nuturtle_robot/src/mppi_waypoints_node.cpp:226-305 without ROS: newControls ->
 // DiffDrive::wheelsToTwist -> plant DiffDrive::feedforward(twist / rate) -> pose -> waypoint switch at
 // goal_thresh.  traj_out: [n_ticks][5] = (x, y, theta, ul, ur).  Returns ticks run or -1.
+// odometry_mode 0: the controller sees the plant's pose directly.
+// odometry_mode 1: the full chain of the demo: the plant's wheel encoders, wrapped to
+//   [-pi, pi) as fake_diff_encoders publishes them (fake_diff_encoders_node.cpp:100-144), feed a second DiffDrive
+//   through updateOdometry (odometry_node.cpp:169-253); the controller sees THAT pose.
 int hst_mppi_closed_loop(const double* params, int rollouts, uint64_t seed, const double* waypoints /*[n][3] x,y,theta*/,
-                         int n_wpts, double goal_thresh, double rate, int max_ticks, double* traj_out, int* wpts_reached) {
+                         int n_wpts, double goal_thresh, double rate, int max_ticks, double* traj_out, int* wpts_reached,
+                         int odometry_mode, double* max_odom_dev) {
+  double dev = 0.0;
   try {
     controller::CartModel cart(params[0], params[1]);
     controller::LossFunc loss({params[8], params[9], params[10]}, {params[11], params[12]}, {params[13], params[14], params[15]});
@@ -99,13 +107,14 @@ int hst_mppi_closed_loop(const double* params, int rollouts, uint64_t seed, cons
     rigid2d::getTwister().seed(seed);
     rigid2d::Pose start; start.x = waypoints[0]; start.y = waypoints[1]; start.theta = waypoints[2];
     rigid2d::DiffDrive plant(start, params[1], params[0]);
+    rigid2d::DiffDrive odometer(start, params[1], params[0]);
     const rigid2d::DiffDrive model(start, params[1], params[0]);
     mppi.setInitialControls(0.0, 0.0);
     int target = 1 % n_wpts, reached = 0, tick = 0;
     auto set_wpt = [&](int i) { rigid2d::Pose w; w.x = waypoints[3 * i]; w.y = waypoints[3 * i + 1]; w.theta = waypoints[3 * i + 2]; mppi.setWaypoint(w); };
     set_wpt(target);
     for (; tick < max_ticks; ++tick) {
-      const rigid2d::Pose ps = plant.pose();
+      const rigid2d::Pose ps = odometry_mode ? odometer.pose() : plant.pose();
       if (rigid2d::euclideanDistance(ps.x, ps.y, waypoints[3 * target], waypoints[3 * target + 1]) < goal_thresh) {
         ++reached;
         target = (target + 1) % n_wpts;
@@ -116,11 +125,19 @@ int hst_mppi_closed_loop(const double* params, int rollouts, uint64_t seed, cons
       Twist2D cmd = model.wheelsToTwist(u);
       cmd.w /= rate; cmd.vx /= rate; cmd.vy = 0.0;
       plant.feedforward(cmd);
+      if (odometry_mode) {
+        const rigid2d::WheelEncoders enc = plant.getEncoders();  // already wrapped by feedforward (diff_drive.cpp:166-167)
+        odometer.updateOdometry(enc.left, enc.right);
+        const rigid2d::Pose po = odometer.pose(), pp = plant.pose();
+        dev = std::max(dev, std::max(std::fabs(po.x - pp.x), std::max(std::fabs(po.y - pp.y),
+                                     std::fabs(rigid2d::normalize_angle_PI(po.theta - pp.theta)))));
+      }
       const rigid2d::Pose np = plant.pose();
       double* row = traj_out + (size_t)tick * 5;
       row[0] = np.x; row[1] = np.y; row[2] = np.theta; row[3] = u.ul; row[4] = u.ur;
     }
     *wpts_reached = reached;
+    if (max_odom_dev) *max_odom_dev = dev;
     return tick;
   } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }

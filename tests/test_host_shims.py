@@ -104,12 +104,13 @@ def test_mppi_class_surface_matches_oracle_with_seeded_twister(host, gpu_pkg):
     assert np.allclose(u_dev, u, rtol=1e-9, atol=1e-12)
 
 
-def _closed_loop(host, d, K, max_ticks, seed=3):
+def _closed_loop(host, d, K, max_ticks, seed=3, odometry_mode=0):
     wp = _arr(WAYPOINTS).copy()
-    traj = np.zeros((max_ticks, 5)); reached = C.c_int()
+    traj = np.zeros((max_ticks, 5)); reached = C.c_int(); dev = C.c_double()
     ticks = host.hst_mppi_closed_loop(_p(_mppi_params(d)), K, C.c_uint64(seed), _p(wp), 5, C.c_double(0.05), C.c_double(60.0),
-                                      max_ticks, _p(traj), C.byref(reached))
+                                      max_ticks, _p(traj), C.byref(reached), C.c_int(odometry_mode), C.byref(dev))
     assert ticks > 0, host.hst_last_error()
+    _closed_loop.last_dev = dev.value
     return traj[:ticks], reached.value
 
 
@@ -136,6 +137,21 @@ def test_cfg2_closed_loop_completes_the_pentagon(host, gpu_pkg):
     traj, reached = _closed_loop(host, d, 1024, 6000)
     print(f"\n[cfg2 closed loop] ticks {len(traj)}, waypoints reached {reached}")
     assert reached == 5
+
+
+@pytest.mark.gpu
+def test_closed_loop_through_wrapped_encoders_and_odometry(host, gpu_pkg):
+    """MPPI -> wheelsToTwist -> plant feedforward(twist/60) -> encoders wrapped to [-pi, pi)
+    -> updateOdometry -> pose -> MPPI, on the HIP path, over a full lap (thousands of ticks, many encoder
+    wraps).  The odometry pose the controller steers by must stay on the plant's true pose."""
+    d = dict(MPPI_BASE, rollouts=1024, horizon=0.5)
+    traj, reached = _closed_loop(host, d, 1024, 6000, odometry_mode=1)
+    print(f"\n[closed loop via encoders] ticks {len(traj)}, waypoints reached {reached}")
+    assert reached == 5
+    # the odometry the controller steers by (integrated from WRAPPED encoder angles) stays on the plant's pose
+    print(f"   max |odometry pose - plant pose| over the lap: {_closed_loop.last_dev:.3e}")
+    assert _closed_loop.last_dev < 1e-9
+    assert np.all(np.abs(traj[:, 3:]) <= d["max_wheel_vel"] + 1e-12)
 
 
 @pytest.mark.gpu
