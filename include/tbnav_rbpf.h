@@ -78,10 +78,17 @@ int tbnav_rbpf_grid_size(const tbnav_rbpf* h, int32_t* xsize, int32_t* ysize);
 /* Standard normals one SLAM call consumes, in draw order: N*(3k+3) (ICP ok) or N*3 (ICP failed),
  * plus 1 for the resampling offset (particle_filter.cpp:474), which is read only if resampling fires. */
 int64_t tbnav_rbpf_num_normals(const tbnav_rbpf* h, int32_t icp_ok);
+/* Seed of the device noise source (resets its scan counter).  Default seed 0x5EED. */
+int tbnav_rbpf_set_seed(tbnav_rbpf* h, uint64_t seed);
+/* The first n standard normals the LAST SLAM call consumed (host- or device-drawn) — for statistical tests. */
+int tbnav_rbpf_get_normals(tbnav_rbpf* h, double* out, int64_t n);
 
 /* ---- one scan: ParticleFilter::SLAM (particle_filter.cpp:141-251) --------------------------- */
 /* scan: n_beams ranges (float, as sensor_msgs/LaserScan); u = body twist (w, vx, vy);
  * cur/prev_odom = (theta, x, y); (icp_ok, T_icp) = what ScanAlignment::pclICPWrapper returned.
+ * normals: tbnav_rbpf_num_normals() standard normals in the reference's draw order (parity mode), or NULL:
+ * they are then drawn ON the device (Philox4x32-10 + Box-Muller keyed by tbnav_rbpf_set_seed and the
+ * scan count) — the production mode, no host RNG and no 1.2 MB/scan upload.
  * Synchronous.  Returns out->status (also when the reference would have thrown). */
 int tbnav_rbpf_slam(tbnav_rbpf* h, const float* scan, int32_t n_beams, const double u[3],
                     const double cur_odom[3], const double prev_odom[3], int32_t icp_ok,

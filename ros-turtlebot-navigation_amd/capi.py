@@ -128,6 +128,8 @@ def lib() -> C.CDLL:
         "tbnav_rbpf_destroy": (None, [vp]),
         "tbnav_rbpf_grid_size": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32)]),
         "tbnav_rbpf_num_normals": (C.c_int64, [vp, i32]),
+        "tbnav_rbpf_set_seed": (C.c_int, [vp, u64]),
+        "tbnav_rbpf_get_normals": (C.c_int, [vp, vp, C.c_int64]),
         "tbnav_rbpf_slam": (C.c_int, [vp, vp, i32, dp, dp, dp, i32, dp, vp, C.POINTER(RbpfStats)]),
         "tbnav_rbpf_slam_local": (C.c_int, [vp, vp, i32, dp, dp, dp, i32, dp, vp, C.POINTER(RbpfStats)]),
         "tbnav_rbpf_resample_global": (C.c_int, [vp, C.c_int64, dbl, vp, vp, C.POINTER(RbpfStats)]),

@@ -165,6 +165,38 @@ __device__ inline void llt3(const double A[3][3], double L[3][3]) {
   for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) L[r][q] = (q <= r) ? M[r][q] : 0.0;
 }
 
+// ---- production noise source: standard normals drawn on the device (normals == NULL) --------------------
+// Philox4x32-10 keyed by the handle's seed, counter = scan_index * 2^40 + pair index; each counter value
+// yields one Box-Muller pair.  Replaces the host's mt19937_64 draws (particle_filter.cpp:25-34) when
+// reproducibility against the CPU path is not needed; same layout as the host stream.
+__device__ __forceinline__ void philox4x32_10(unsigned long long ctr, unsigned long long key, unsigned int (&out)[4]) {
+  unsigned int c0 = (unsigned int)ctr, c1 = (unsigned int)(ctr >> 32), c2 = 0u, c3 = 0u;
+  unsigned int k0 = (unsigned int)key, k1 = (unsigned int)(key >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned int)p1;
+    const unsigned int n2 = (unsigned int)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned int)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__global__ void rbpf_sample_normals(size_t n, unsigned long long seed, unsigned long long scan, double* __restrict__ out) {
+  const size_t pairs = (n + 1) / 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned int r[4];
+    philox4x32_10((scan << 40) + i, seed, r);
+    const unsigned long long a = ((unsigned long long)r[0] << 32) | r[1], b = ((unsigned long long)r[2] << 32) | r[3];
+    const double u1 = ((double)(a >> 11) + 0.5) * 0x1.0p-53, u2 = ((double)(b >> 11) + 0.5) * 0x1.0p-53;
+    const double rad = sqrt(-2.0 * log(u1));
+    double sn, cs;
+    sincospi(2.0 * u2, &sn, &cs);
+    out[2 * i] = rad * cs;
+    if (2 * i + 1 < n) out[2 * i + 1] = rad * sn;
+  }
+}
+
 struct Trace {
   double *sampled, *p_scan, *p_pose, *mu, *sigma, *eta, *new_pose, *weight_raw;
 };
@@ -825,8 +857,9 @@ struct NormOut { double sum_w, sq_sum; int neff, resampled; };
 // that i because U_m and c[] are both non-decreasing), found by binary search, clamped to N-1.
 // buf: dynamic LDS, 2*N doubles (w then c).  N <= kNormMaxLds, else the global-memory variant below.
 constexpr int kNormMaxLds = 9000;
-__global__ __launch_bounds__(256) void rbpf_normalize(int N, double z, double* __restrict__ weight, int* __restrict__ parent,
+__global__ __launch_bounds__(256) void rbpf_normalize(int N, const double* __restrict__ zp, double* __restrict__ weight, int* __restrict__ parent,
                                                       NormOut* __restrict__ out) {
+  const double z = *zp;  // the one standard normal of lowVarianceResampling (particle_filter.cpp:474)
   extern __shared__ __attribute__((aligned(16))) double buf[];
   double* w = buf;
   double* cs = buf + N;
@@ -871,8 +904,9 @@ __global__ __launch_bounds__(256) void rbpf_normalize(int N, double z, double* _
 }
 
 // Same contract, weights read from global memory (N too large for LDS): fully sequential.
-__global__ void rbpf_normalize_seq(int N, double z, double* __restrict__ weight, int* __restrict__ parent, NormOut* __restrict__ out) {
+__global__ void rbpf_normalize_seq(int N, const double* __restrict__ zp, double* __restrict__ weight, int* __restrict__ parent, NormOut* __restrict__ out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double z = *zp;
   double sum = 0.0;
   for (int i = 0; i < N; ++i) sum += weight[i];
   double sq = 0.0;
@@ -946,6 +980,7 @@ struct tbnav_rbpf {
   size_t normals_cap = 0;
   int* d_parent = nullptr;
   int tile_cap = 0;            // cells of the raycast LDS tile (0 = use the beam-ordered kernel)
+  uint64_t seed = 0x5EEDull, scan_index = 0;  // device noise source (normals == NULL)
   bool full_edt = false;       // TBNAV_RBPF_FULL_EDT=1: whole-map distance transform after every map update
   int* d_fstate = nullptr;     // [N] distance-field state: 0 stale, 1 window fresh, 2 whole field fresh / injected
   int* d_skip = nullptr;       // [N] scratch: 1 = no refresh needed this call
@@ -1086,7 +1121,7 @@ int ensure_full_field(tbnav_rbpf* h, int particle) {
 int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], const double cur_odom[3],
               const double prev_odom[3], int icp_ok, const double T_icp[3], const double* normals,
               tbnav_rbpf_stats* out, bool local_only) {
-  if (!h || !scan || n_beams <= 0 || !u || !cur_odom || !prev_odom || !T_icp || !normals || !out) return TBNAV_ERR_INVALID_ARG;
+  if (!h || !scan || n_beams <= 0 || !u || !cur_odom || !prev_odom || !T_icp || !out) return TBNAV_ERR_INVALID_ARG;
   DeviceGuard guard(h->device);
   hipStream_t st = h->stream;
   ScanC c;
@@ -1109,7 +1144,15 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
     h->normals_cap = n_norm;
   }
   if (c.Bv) TBNAV_HIP(hipMemcpyAsync(h->d_beams, beams.data(), sizeof(double2) * c.Bv, hipMemcpyHostToDevice, st));
-  TBNAV_HIP(hipMemcpyAsync(h->d_normals, normals, sizeof(double) * n_norm, hipMemcpyHostToDevice, st));
+  if (normals) {
+    TBNAV_HIP(hipMemcpyAsync(h->d_normals, normals, sizeof(double) * n_norm, hipMemcpyHostToDevice, st));
+  } else {
+    const int blocks = (int)std::min<size_t>((n_norm / 2 + 255) / 256, 4096);
+    hipLaunchKernelGGL(rbpf_sample_normals, dim3(blocks), dim3(256), 0, st, n_norm, (unsigned long long)h->seed,
+                       (unsigned long long)h->scan_index, h->d_normals);
+    TBNAV_HIP(hipGetLastError());
+  }
+  ++h->scan_index;
   TBNAV_HIP(hipMemsetAsync(h->d_err, 0, sizeof(int) * 4, st));
   StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
 
@@ -1161,7 +1204,7 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
   }
   TBNAV_HIP(hipEventRecord(h->ev[4], st));
   if (!local_only) {
-    const double z = normals[(size_t)h->N * c.stride_normals];
+    const double* z = h->d_normals + (size_t)h->N * c.stride_normals;
     if (h->N <= kNormMaxLds)
       hipLaunchKernelGGL(rbpf_normalize, dim3(1), dim3(256), sizeof(double) * 2 * h->N, st, h->N, z, sp.weight, h->d_parent, h->d_norm);
     else
@@ -1366,6 +1409,21 @@ void tbnav_rbpf_destroy(tbnav_rbpf* h) {
 int tbnav_rbpf_grid_size(const tbnav_rbpf* h, int32_t* xsize, int32_t* ysize) {
   if (!h || !xsize || !ysize) return TBNAV_ERR_INVALID_ARG;
   *xsize = h->xsize; *ysize = h->ysize;
+  return TBNAV_OK;
+}
+
+int tbnav_rbpf_set_seed(tbnav_rbpf* h, uint64_t seed) {
+  if (!h) return TBNAV_ERR_INVALID_ARG;
+  h->seed = seed;
+  h->scan_index = 0;
+  return TBNAV_OK;
+}
+
+int tbnav_rbpf_get_normals(tbnav_rbpf* h, double* out, int64_t n) {
+  if (!h || !out || n <= 0 || (size_t)n > h->normals_cap) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  TBNAV_HIP(hipStreamSynchronize(h->stream));
+  TBNAV_HIP(hipMemcpy(out, h->d_normals, sizeof(double) * n, hipMemcpyDeviceToHost));
   return TBNAV_OK;
 }
 

@@ -46,6 +46,7 @@ class ParticleFilter {
   void newMap(std::vector<int8_t>& map);
 
   // ---- additions (not in the reference) ----
+  void useDeviceNoise(std::uint64_t seed);  ///< draw the standard normals on the GPU instead of from getTwister()
   int effectiveParticles() const { return last_neff_; }
   bool resampledLastScan() const { return last_resampled_; }
 
@@ -53,7 +54,7 @@ class ParticleFilter {
   tbnav_rbpf* h_ = nullptr;
   ScanAlignment scan_matcher_;  // copied, as the reference does (particle_filter.hpp:222)
   int num_particles_ = 0, k_ = 0, last_neff_ = 0;
-  bool last_resampled_ = false;
+  bool last_resampled_ = false, device_noise_ = false;
   std::vector<double> normals_;
 };
 

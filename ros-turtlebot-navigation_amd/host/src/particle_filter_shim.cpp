@@ -64,6 +64,11 @@ ParticleFilter::ParticleFilter(int num_particles, int k, double srr, double srt,
 
 ParticleFilter::~ParticleFilter() { tbnav_rbpf_destroy(h_); }
 
+void ParticleFilter::useDeviceNoise(std::uint64_t seed) {
+  device_noise_ = true;
+  check(tbnav_rbpf_set_seed(h_, seed), "useDeviceNoise");
+}
+
 void ParticleFilter::SLAM(const std::vector<float>& scan, const Twist2D& u, const Pose& cur_odom, const Pose& prev_odom) {
   // icpInitGuess (particle_filter.cpp:602-612): the raw world-frame odometry delta
   const double dth = rigid2d::normalize_angle_PI(rigid2d::normalize_angle_PI(cur_odom.theta) - rigid2d::normalize_angle_PI(prev_odom.theta));
@@ -76,14 +81,15 @@ void ParticleFilter::SLAM(const std::vector<float>& scan, const Twist2D& u, cons
   // engine: per particle 3k (sampleMode) + 3 (new pose), or 3 (motion model); the resampling offset
   // is drawn only if resampling fires, so the engine is rewound when it does not.
   const int64_t n = tbnav_rbpf_num_normals(h_, ok ? 1 : 0);
-  normals_.resize((size_t)n);
   std::mt19937_64& gen = getTwister();
-  for (int64_t i = 0; i + 1 < n; ++i) {
-    std::normal_distribution<double> dis(0, 1);
-    normals_[(size_t)i] = dis(gen);
-  }
-  const std::mt19937_64 before_resample_draw = gen;
-  {
+  std::mt19937_64 before_resample_draw = gen;
+  if (!device_noise_) {
+    normals_.resize((size_t)n);
+    for (int64_t i = 0; i + 1 < n; ++i) {
+      std::normal_distribution<double> dis(0, 1);
+      normals_[(size_t)i] = dis(gen);
+    }
+    before_resample_draw = gen;
     std::normal_distribution<double> dis(0, 1);
     normals_[(size_t)n - 1] = dis(gen);
   }
@@ -92,7 +98,7 @@ void ParticleFilter::SLAM(const std::vector<float>& scan, const Twist2D& u, cons
   const double prev[3] = {prev_odom.theta, prev_odom.x, prev_odom.y};
   const double ticp[3] = {t.theta, t.x, t.y};
   tbnav_rbpf_stats st{};
-  const int rc = tbnav_rbpf_slam(h_, scan.data(), (int32_t)scan.size(), uu, cur, prev, ok ? 1 : 0, ticp, normals_.data(), &st);
+  const int rc = tbnav_rbpf_slam(h_, scan.data(), (int32_t)scan.size(), uu, cur, prev, ok ? 1 : 0, ticp, device_noise_ ? nullptr : normals_.data(), &st);
   if (rc != TBNAV_OK || !st.resampled) gen = before_resample_draw;
   check(rc, "ParticleFilter::SLAM");
   last_neff_ = st.neff;

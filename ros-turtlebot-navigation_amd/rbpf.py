@@ -76,16 +76,25 @@ class ParticleFilter:
         """u = (w, vx, vy); odometry and T_icp as (theta, x, y).  Returns the stats struct; raises
         TbnavError with the reference's exception text when the reference would have thrown."""
         scan = np.ascontiguousarray(scan, dtype=np.float32)
-        normals = np.ascontiguousarray(normals, dtype=np.float64)
-        assert normals.size >= self.numNormals(icp_ok)
+        if normals is not None:
+            normals = np.ascontiguousarray(normals, dtype=np.float64)
+            assert normals.size >= self.numNormals(icp_ok)
         st = capi.RbpfStats()
         fn = self._L.tbnav_rbpf_slam_local if local_only else self._L.tbnav_rbpf_slam
         rc = fn(self._h, scan.ctypes.data, scan.size, _d3(u), _d3(cur_odom), _d3(prev_odom), 1 if icp_ok else 0,
-                _d3(T_icp), normals.ctypes.data, C.byref(st))
+                _d3(T_icp), normals.ctypes.data if normals is not None else None, C.byref(st))
         self.last_stats = st
         if check:
             capi.check(rc, "tbnav_rbpf_slam")
         return st
+
+    def setSeed(self, seed: int):
+        capi.check(self._L.tbnav_rbpf_set_seed(self._h, seed), "set_seed")
+
+    def lastNormals(self, n: int) -> np.ndarray:
+        out = np.empty(n)
+        capi.check(self._L.tbnav_rbpf_get_normals(self._h, out.ctypes.data, n), "get_normals")
+        return out
 
     def getRobotState(self):
         pose = (C.c_double * 3)(); idx = C.c_int32()

@@ -281,3 +281,41 @@ def test_distance_field_tiers_random_occupancy(gpu_pkg, rows_used, expect):
     for p in range(N):
         want = orc.exact_edt_codes(occs[p], 200, prev_codes[p])
         assert np.array_equal(pf_d.distCode(p).reshape(xs, xs), want), expect
+
+
+def test_device_noise_source_statistics_and_filter_health(gpu_pkg):
+    """normals == NULL: the standard normals are drawn on the device (Philox + Box-Muller).  Moments of
+    the stream, determinism in (seed, scan count), and the filter it drives stays healthy: poses track the
+    trajectory like the host-noise run, weights normalised, maps populated."""
+    N, k = 256, 50
+    pf = _dev(gpu_pkg, N=N, k=k)
+    pf.setSeed(99)
+    steps, poses = rc.trajectory(4, inc=(0.04, 0.03, 0.02))
+    rng = np.random.default_rng(3)
+    scans = [orc.room_scan(poses[s], walls=rc.ROOM_SMALL, rng=rng) for s in range(4)]
+    streams = []
+    for s, (prev, cur, t_icp, u) in enumerate(steps):
+        st = pf.SLAM(scans[s], u, cur, prev, True, t_icp, None)
+        assert st.status == 0
+        streams.append(pf.lastNormals(pf.numNormals(True)))
+    z = np.concatenate(streams)
+    n = z.size
+    assert abs(z.mean()) < 5 / np.sqrt(n) and abs(z.var() - 1.0) < 0.02
+    assert abs(np.mean(z ** 3)) < 0.05 and abs(np.mean(z ** 4) - 3.0) < 0.1
+    assert abs(np.corrcoef(z[0::2], z[1::2])[0, 1]) < 0.01       # the two Box-Muller outputs are uncorrelated
+    assert not np.array_equal(streams[0], streams[1])
+    pose, _, w = pf.particles()
+    assert abs(w.sum() - 1.0) < 1e-12
+    # same inputs through the oracle filter with host normals: the two particle clouds coincide (the sampling
+    # spread is 1e-4 m, so "coincide" = means within 1 mm, spread within 1 mm)
+    pf_o = orc.PfAPI(orc.pf_params(N=64, k=k))
+    for s, (prev, cur, t_icp, u) in enumerate(steps):
+        pf_o.slam(scans[s], u, cur, prev, True, t_icp, orc.normal_stream(7 + s, pf_o.normals_per_scan(True), 0.0, 1.0), trace=False)
+    po, _, _ = pf_o.particles()
+    assert np.allclose(pose.mean(0), po.mean(0), atol=1e-3) and np.all(pose.std(0) < 1e-3)
+    assert pf.occupiedCount().min() > 100
+    # same seed -> same stream
+    pf2 = _dev(gpu_pkg, N=N, k=k); pf2.setSeed(99)
+    prev, cur, t_icp, u = steps[0]
+    pf2.SLAM(scans[0], u, cur, prev, True, t_icp, None)
+    assert np.array_equal(pf2.lastNormals(pf2.numNormals(True)), streams[0])
