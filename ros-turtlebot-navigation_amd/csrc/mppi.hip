@@ -89,23 +89,28 @@ __device__ __forceinline__ void fast_sincos(double x, double& s, double& c) {
 }
 
 __device__ __forceinline__ void small_sincos(double d, double& sd, double& cd) {
-  if (fabs(d) <= 0.03125) {
-    const double d2 = d * d;
-    // sin d = d (1 - d2/6 (1 - d2/20 (1 - d2/42 (1 - d2/72 (1 - d2/110)))))
-    double ps = 1.0 - d2 * (1.0 / 110.0);
-    ps = 1.0 - d2 * (1.0 / 72.0) * ps;
-    ps = 1.0 - d2 * (1.0 / 42.0) * ps;
-    ps = 1.0 - d2 * (1.0 / 20.0) * ps;
-    ps = 1.0 - d2 * (1.0 / 6.0) * ps;
-    sd = d * ps;
-    // cos d = 1 - d2/2 (1 - d2/12 (1 - d2/30 (1 - d2/56 (1 - d2/90))))
-    double pc = 1.0 - d2 * (1.0 / 90.0);
-    pc = 1.0 - d2 * (1.0 / 56.0) * pc;
-    pc = 1.0 - d2 * (1.0 / 30.0) * pc;
-    pc = 1.0 - d2 * (1.0 / 12.0) * pc;
-    cd = 1.0 - d2 * 0.5 * pc;
-  } else {
-    fast_sincos(d, sd, cd);
+  // straight-line Taylor pair (valid to < 1e-24 for |d| <= 2^-5); the full evaluation is entered only if SOME
+  // lane of the wave needs it (wave-uniform branch: no divergence, and never taken for physical wheel speeds)
+  const double d2 = d * d;
+  // sin d = d (1 - d2/6 (1 - d2/20 (1 - d2/42 (1 - d2/72 (1 - d2/110)))))
+  double ps = 1.0 - d2 * (1.0 / 110.0);
+  ps = 1.0 - d2 * (1.0 / 72.0) * ps;
+  ps = 1.0 - d2 * (1.0 / 42.0) * ps;
+  ps = 1.0 - d2 * (1.0 / 20.0) * ps;
+  ps = 1.0 - d2 * (1.0 / 6.0) * ps;
+  sd = d * ps;
+  // cos d = 1 - d2/2 (1 - d2/12 (1 - d2/30 (1 - d2/56 (1 - d2/90))))
+  double pc = 1.0 - d2 * (1.0 / 90.0);
+  pc = 1.0 - d2 * (1.0 / 56.0) * pc;
+  pc = 1.0 - d2 * (1.0 / 30.0) * pc;
+  pc = 1.0 - d2 * (1.0 / 12.0) * pc;
+  cd = 1.0 - d2 * 0.5 * pc;
+  const bool big = !(fabs(d) <= 0.03125);
+  if (__any(big)) {
+    double sf, cf;
+    fast_sincos(d, sf, cf);
+    sd = big ? sf : sd;
+    cd = big ? cf : cd;
   }
 }
 
@@ -181,7 +186,7 @@ __device__ __forceinline__ double terminal_loss(const RolloutArgs& a, double x, 
 // The noise of group g+1 (G steps x 2 arrays x 512 B per wave) is requested before group g is
 // integrated, so the loads fly under a group's worth of trig instead of stalling each step.
 constexpr int kGroup = 4;
-template <int TRIG, int G>
+template <int TRIG, int G, bool TO_LDS>
 __device__ __forceinline__ void rollout_group(const RolloutArgs& a, int i0, int lane, int k, double& x, double& y,
                                               double& th, const double (&dl)[G], const double (&dr)[G],
                                               const double* __restrict__ u, double* __restrict__ lds_loss,
@@ -199,7 +204,7 @@ __device__ __forceinline__ void rollout_group(const RolloutArgs& a, int i0, int 
     const int i = i0 + q;
     const double l = (i == T - 1) ? terminal_loss(a, xq[q], yq[q], thq[q])  // mppi.cpp:105 overwrites, not adds
                                   : lqr_loss(a, xq[q], yq[q], thq[q], ul[q], ur[q]);
-    if (i >= a.lds_from) lds_loss[(i - a.lds_from) * kWave + lane] = l;
+    if (TO_LDS) lds_loss[(i - a.lds_from) * kWave + lane] = l;
     else J[(size_t)i * K + k] = l;
   }
 }
@@ -253,13 +258,15 @@ __global__ __launch_bounds__(kWave) void mppi_rollout_cost(RolloutArgs a,
             nr[r][q] = pr[off];
           }
         }
-        rollout_group<TRIG, kGroup>(a, g * kGroup, lane, k, x, y, th, dl, dr, u_lds, lds_loss, J);
+        if (g * kGroup >= a.lds_from) rollout_group<TRIG, kGroup, true>(a, g * kGroup, lane, k, x, y, th, dl, dr, u_lds, lds_loss, J);
+        else rollout_group<TRIG, kGroup, false>(a, g * kGroup, lane, k, x, y, th, dl, dr, u_lds, lds_loss, J);
       }
     }
   }
   for (int i = n_full * kGroup; i < T; ++i) {  // ragged tail, one step at a time
     const double dl[1] = {pl[(size_t)i * K]}, dr[1] = {pr[(size_t)i * K]};
-    rollout_group<TRIG, 1>(a, i, lane, k, x, y, th, dl, dr, u_lds, lds_loss, J);
+    if (i >= a.lds_from) rollout_group<TRIG, 1, true>(a, i, lane, k, x, y, th, dl, dr, u_lds, lds_loss, J);
+    else rollout_group<TRIG, 1, false>(a, i, lane, k, x, y, th, dl, dr, u_lds, lds_loss, J);
   }
   // cumSumCost (mppi.cpp:15-25): J(i) = loss(i) + J(i+1), from the end.  The staged losses are fetched
   // eight at a time, the next eight already in flight while these are added in order.
@@ -777,6 +784,8 @@ int tbnav_mppi_create(const tbnav_mppi_params* params, tbnav_mppi** out) {
     long steps_in_lds = budget > 0 ? budget / (long)(kWave * sizeof(double)) : 0;
     if (steps_in_lds > T) steps_in_lds = T;
     h->lds_from = T - (int)steps_in_lds;
+    h->lds_from = ((h->lds_from + 3) / 4) * 4;  // whole groups of 4 steps switch staging together
+    if (h->lds_from > T) h->lds_from = T;
   }
   // time-parallel kernel: up to 16 chunks (waves) per workgroup
   h->scan_tc = 0;
