@@ -98,8 +98,9 @@ int tbnav_rbpf_slam(tbnav_rbpf* h, const float* scan, int32_t n_beams, const dou
  * (strict >, first wins, starting from 0.0).  best_index is optional. */
 int tbnav_rbpf_best_state(tbnav_rbpf* h, double pose[3], int32_t* best_index);
 /* ParticleFilter::newMap -> GridMapper::gridMap (particle_filter.cpp:277-291, grid_mapper.cpp:
- * 185-226): int8 {-1, 0, 100, prob*100}, transposed, of the arg-max-weight particle; prob is
- * evaluated on the host with glibc from the device log-odds.  map holds G entries. */
+ * 185-226): int8 {-1, 0, 100, (int8)(prob*100)}, transposed, of the arg-max-weight particle.  Computed on the
+ * device: the log-odds at which the exported value changes were found on the host with glibc at create time,
+ * so the result is the reference's bit for bit and only G bytes cross PCIe.  map holds G entries. */
 int tbnav_rbpf_best_map(tbnav_rbpf* h, int8_t* map);
 
 /* ---- multi-GPU building blocks (particles sharded across ranks) ------------------------------- */

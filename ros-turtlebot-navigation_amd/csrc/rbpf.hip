@@ -956,6 +956,65 @@ __global__ __launch_bounds__(256) void rbpf_gather(int N, size_t G, int words_to
   (void)N;
 }
 
+// ---- getRobotState / newMap on the device ------------------------------------------
+// arg-max weight with the reference's tie rule (strict '>', first wins, starting from 0.0:
+// particle_filter.cpp:260-267): the smallest index among the maxima, 0 if no weight is positive.
+__global__ __launch_bounds__(256) void rbpf_argmax(int N, const double* __restrict__ weight, const double* __restrict__ pose,
+                                                   int* __restrict__ best_idx, double* __restrict__ best_pose) {
+  __shared__ double sv[256];
+  __shared__ int si[256];
+  double bv = 0.0;
+  int bi = 0x7fffffff;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) {
+    const double w = weight[i];
+    if (w > bv) { bv = w; bi = i; }  // strided scan keeps the lowest index per thread for equal values
+  }
+  sv[threadIdx.x] = bv; si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      const double ov = sv[threadIdx.x + off];
+      const int oi = si[threadIdx.x + off];
+      if (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x])) { sv[threadIdx.x] = ov; si[threadIdx.x] = oi; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int idx = (sv[0] > 0.0 && si[0] != 0x7fffffff) ? si[0] : 0;
+    *best_idx = idx;
+    best_pose[0] = pose[idx * 3 + 0]; best_pose[1] = pose[idx * 3 + 1]; best_pose[2] = pose[idx * 3 + 2];
+  }
+}
+
+// GridMapper::gridMap (grid_mapper.cpp:185-226) of the best particle: int8 {-1, 0, 100, (int8)(prob*100)},
+// transposed.  prob is never evaluated here: the host found, with glibc, the log-odds at which the exported
+// value changes (ExportCuts), so the device output is the reference's bit for bit.
+struct ExportCuts {
+  double occ_cut;     // smallest l exported as 100 (prob >= 0.90)
+  double free_cut;    // largest l exported as 0    (prob <= 0.35)
+  double half_lo, half_hi;  // [lo, hi]: prob == 0.5 exactly -> -1 (unknown)
+  double step[64];    // step[m] = smallest l exported as >= 36 + m   (values 35..89 in between)
+  int n_steps;
+};
+__global__ __launch_bounds__(256) void rbpf_export_map(int xs, size_t G, ExportCuts cuts, const int* __restrict__ best_idx,
+                                                       const double* __restrict__ log_odds, int8_t* __restrict__ out) {
+  const double* lo = log_odds + (size_t)(*best_idx) * G;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < G; i += (size_t)gridDim.x * blockDim.x) {
+    const double l = lo[i];
+    int v;
+    if (l >= cuts.half_lo && l <= cuts.half_hi) v = -1;
+    else if (l >= cuts.occ_cut) v = 100;
+    else if (l <= cuts.free_cut) v = 0;
+    else {
+      int a = 0, b = cuts.n_steps;  // number of steps <= l
+      while (a < b) { const int m = (a + b) >> 1; if (cuts.step[m] <= l) a = m + 1; else b = m; }
+      v = 35 + a;
+    }
+    const size_t row = i / xs, col = i % xs;
+    out[col * xs + row] = (int8_t)v;
+  }
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -979,6 +1038,10 @@ struct tbnav_rbpf {
   double* d_normals = nullptr;
   size_t normals_cap = 0;
   int* d_parent = nullptr;
+  ExportCuts cuts{};           // host-derived (glibc) log-odds break points of the int8 map export
+  int* d_best = nullptr;       // arg-max particle index
+  double* d_best_pose = nullptr;
+  int8_t* d_export = nullptr;  // [G]
   int tile_cap = 0;            // cells of the raycast LDS tile (0 = use the beam-ordered kernel)
   uint64_t seed = 0x5EEDull, scan_index = 0;  // device noise source (normals == NULL)
   bool full_edt = false;       // TBNAV_RBPF_FULL_EDT=1: whole-map distance transform after every map update
@@ -1021,6 +1084,38 @@ double find_occ_cut(double l_occ_nominal, double p_occ) {
     if (logodds_to_prob(mid) >= p_occ) hi = mid; else lo = mid;
   }
   return hi;
+}
+
+// Break points of the exported map value as a function of the log-odds, found with the HOST libm by bisection
+// (the exported value is monotone in l apart from the prob == 0.5 plateau, which maps to -1).
+int export_value_host(double l) {  // GridMapper::gridMap after updateCellState, evaluated as the reference does
+  const double prob = logodds_to_prob(l);
+  if (prob == 0.5) return -1;
+  if (prob >= 0.90) return 100;
+  if (prob <= 0.35) return 0;
+  return (int)(int8_t)(prob * 100);
+}
+double bisect_first(double lo, double hi, bool (*pred)(double, int), int arg) {  // pred(lo) false, pred(hi) true, monotone
+  for (int it = 0; it < 300; ++it) {
+    const double mid = 0.5 * (lo + hi);
+    if (mid == lo || mid == hi) break;
+    if (pred(mid, arg)) hi = mid; else lo = mid;
+  }
+  return hi;
+}
+ExportCuts derive_export_cuts(double cut_occ) {
+  ExportCuts c{};
+  c.occ_cut = cut_occ;
+  // largest l with prob <= 0.35: the predecessor of the first l with prob > 0.35
+  const double first_above = bisect_first(-3.0, 0.0, [](double l, int) { return logodds_to_prob(l) > 0.35; }, 0);
+  c.free_cut = std::nextafter(first_above, -1.0e9);
+  c.half_lo = bisect_first(-1.0, 1.0, [](double l, int) { return logodds_to_prob(l) >= 0.5; }, 0);
+  const double first_gt = bisect_first(-1.0, 1.0, [](double l, int) { return logodds_to_prob(l) > 0.5; }, 0);
+  c.half_hi = std::nextafter(first_gt, -1.0e9);
+  c.n_steps = 0;
+  for (int k = 36; k <= 89; ++k)  // smallest l (outside the 0.5 plateau) whose exported value is >= k
+    c.step[c.n_steps++] = bisect_first(c.free_cut, cut_occ, [](double l, int kk) { const int v = export_value_host(l); return v == 100 || (v >= kk); }, k);
+  return c;
 }
 
 size_t edt_lds_bytes(int xs, int words, int C) { return (size_t)xs * words * 8 + (size_t)xs * C * 5; }
@@ -1317,6 +1412,7 @@ int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) {
   h->l_occ = std::log(0.90 / (1 - 0.90));
   h->l_free = std::log(0.35 / (1 - 0.35));
   h->cut_occ = find_occ_cut(h->l_occ, 0.90);
+  h->cuts = derive_export_cuts(h->cut_occ);
   const int N = h->N;
   hipError_t e = hipSuccess;
   auto A = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
@@ -1329,6 +1425,9 @@ int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) {
     A((void**)&h->d_rowcount[b], sizeof(int) * (size_t)N * xsize);
   }
   A((void**)&h->d_parent, sizeof(int) * N);
+  A((void**)&h->d_best, sizeof(int));
+  A((void**)&h->d_best_pose, sizeof(double) * 3);
+  A((void**)&h->d_export, h->G);
   A((void**)&h->d_fstate, sizeof(int) * N);
   A((void**)&h->d_skip, sizeof(int) * N);
   A((void**)&h->d_win, sizeof(int4) * N);
@@ -1399,7 +1498,7 @@ void tbnav_rbpf_destroy(tbnav_rbpf* h) {
   if (!h) return;
   DeviceGuard guard(h->device);
   for (int b = 0; b < 2; ++b) { (void)hipFree(h->d_state[b]); (void)hipFree(h->d_log_odds[b]); (void)hipFree(h->d_code[b]); (void)hipFree(h->d_nocc[b]); (void)hipFree(h->d_bitmap[b]); (void)hipFree(h->d_rowcount[b]); }
-  (void)hipFree(h->d_beams); (void)hipFree(h->d_normals); (void)hipFree(h->d_parent); (void)hipFree(h->d_tier); (void)hipFree(h->d_fstate); (void)hipFree(h->d_skip); (void)hipFree(h->d_win);
+  (void)hipFree(h->d_beams); (void)hipFree(h->d_normals); (void)hipFree(h->d_parent); (void)hipFree(h->d_best); (void)hipFree(h->d_best_pose); (void)hipFree(h->d_export); (void)hipFree(h->d_tier); (void)hipFree(h->d_fstate); (void)hipFree(h->d_skip); (void)hipFree(h->d_win);
   (void)hipFree(h->d_err); (void)hipFree(h->d_norm); (void)hipFree(h->d_trace);
   for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1619,36 +1718,32 @@ int tbnav_rbpf_get_trace(tbnav_rbpf* h, double* sampled, double* p_scan, double*
 
 int tbnav_rbpf_best_state(tbnav_rbpf* h, double pose[3], int32_t* best_index) {
   if (!h || !pose) return TBNAV_ERR_INVALID_ARG;
-  const int N = h->N;
-  std::vector<double> ps((size_t)3 * N), w(N);
-  int rc = tbnav_rbpf_get_particles(h, ps.data(), nullptr, w.data());
-  if (rc != TBNAV_OK) return rc;
-  double best = 0.0;
+  DeviceGuard guard(h->device);
+  hipStream_t st = h->stream;
+  StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
+  hipLaunchKernelGGL(rbpf_argmax, dim3(1), dim3(256), 0, st, h->N, sp.weight, sp.pose, h->d_best, h->d_best_pose);
+  TBNAV_HIP(hipGetLastError());
   int idx = 0;
-  for (int i = 0; i < N; ++i) if (w[i] > best) { best = w[i]; idx = i; }  // particle_filter.cpp:260-267
-  for (int q = 0; q < 3; ++q) pose[q] = ps[(size_t)idx * 3 + q];
+  TBNAV_HIP(hipMemcpyAsync(pose, h->d_best_pose, sizeof(double) * 3, hipMemcpyDeviceToHost, st));
+  TBNAV_HIP(hipMemcpyAsync(&idx, h->d_best, sizeof(int), hipMemcpyDeviceToHost, st));
+  TBNAV_HIP(hipStreamSynchronize(st));
   if (best_index) *best_index = idx;
   return TBNAV_OK;
 }
 
 int tbnav_rbpf_best_map(tbnav_rbpf* h, int8_t* map) {
   if (!h || !map) return TBNAV_ERR_INVALID_ARG;
-  double pose[3];
-  int idx = 0;
-  int rc = tbnav_rbpf_best_state(h, pose, &idx);
-  if (rc != TBNAV_OK) return rc;
-  std::vector<double> lo(h->G);
-  rc = tbnav_rbpf_get_log_odds(h, idx, lo.data());
-  if (rc != TBNAV_OK) return rc;
-  const int xs = h->xsize;
-  for (size_t i = 0; i < h->G; ++i) {  // GridMapper::gridMap, grid_mapper.cpp:185-226, after updateCellState :438-477
-    const size_t row = i / xs, col = i % xs, idxT = col * xs + row;
-    const double prob = logodds_to_prob(lo[i]);
-    if (prob == 0.5) map[idxT] = -1;
-    else if (prob >= 0.90) map[idxT] = 100;
-    else if (prob <= 0.35) map[idxT] = 0;
-    else map[idxT] = (int8_t)(prob * 100);
-  }
+  DeviceGuard guard(h->device);
+  hipStream_t st = h->stream;
+  StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
+  hipLaunchKernelGGL(rbpf_argmax, dim3(1), dim3(256), 0, st, h->N, sp.weight, sp.pose, h->d_best, h->d_best_pose);
+  TBNAV_HIP(hipGetLastError());
+  const int blocks = (int)std::min<size_t>((h->G + 255) / 256, 2048);
+  hipLaunchKernelGGL(rbpf_export_map, dim3(blocks), dim3(256), 0, st, h->xsize, h->G, h->cuts, h->d_best, h->d_log_odds[h->cur],
+                     h->d_export);
+  TBNAV_HIP(hipGetLastError());
+  TBNAV_HIP(hipMemcpyAsync(map, h->d_export, h->G, hipMemcpyDeviceToHost, st));
+  TBNAV_HIP(hipStreamSynchronize(st));
   return TBNAV_OK;
 }
 

@@ -319,3 +319,47 @@ def test_device_noise_source_statistics_and_filter_health(gpu_pkg):
     prev, cur, t_icp, u = steps[0]
     pf2.SLAM(scans[0], u, cur, prev, True, t_icp, None)
     assert np.array_equal(pf2.lastNormals(pf2.numNormals(True)), streams[0])
+
+
+def test_device_map_export_matches_glibc_evaluation(gpu_pkg):
+    """newMap on the device: int8 {-1, 0, 100, (int8)(prob*100)}, transposed
+    (grid_mapper.cpp:185-226).  The device never evaluates prob; it uses log-odds break points found with glibc
+    at create time.  Checked on every log-odds value reachable with up to 8 hits per cell in any order, the
+    knife edges (one occupied hit = exactly 0.9, one free hit = exactly 0.35, untouched = exactly 0.5) and
+    their neighbours in the last bit; the expected value is computed with the oracle's glibc logOdds2Prob."""
+    r = orc.RigidAPI("orc")
+    l_occ, l_free = r.prob_to_log_odds(0.90), r.prob_to_log_odds(0.35)
+    vals = {0.0}
+    frontier = {0.0}
+    for _ in range(8):                       # every add ORDER gives its own rounding: enumerate sequences
+        frontier = {v + d for v in frontier for d in (l_occ, l_free)}
+        vals |= frontier
+    edge = [l_occ, l_free, 0.0, l_occ + l_free]
+    for e in edge:
+        for _ in range(3):
+            vals |= {np.nextafter(e, 9.0), np.nextafter(e, -9.0)}
+            e = np.nextafter(e, 9.0)
+    vals |= {1e-17, -1e-17, 2.3e-16, -2.3e-16, 1e-15, -1e-15, 5.0, -5.0, 40.0, -40.0}
+    vals = np.array(sorted(vals))
+    pf = _dev(gpu_pkg, N=3, k=3)             # 80 x 80 = 6400 cells
+    assert vals.size <= pf.G
+    lo = np.zeros(pf.G); lo[:vals.size] = vals
+    pf.setLogOdds(1, lo)
+    pf.setParticles(w=np.array([0.2, 0.5, 0.3]))   # particle 1 is the arg-max
+    (pose, idx) = pf.getRobotState()
+    assert idx == 1
+    got = pf.newMap().reshape(pf.xsize, pf.xsize).T.reshape(-1)   # undo the transpose
+    def expect(l):
+        p = r.log_odds_to_prob(l)
+        if p == 0.5: return -1
+        if p >= 0.90: return 100
+        if p <= 0.35: return 0
+        return int(np.int8(int(p * 100)))
+    want = np.array([expect(l) for l in lo[:vals.size]])
+    bad = np.flatnonzero(got[:vals.size] != want)
+    assert bad.size == 0, (vals[bad][:5], got[bad][:5], want[bad][:5])
+    assert np.all(got[vals.size:] == -1)
+    assert set(np.unique(want)) >= {-1, 0, 100, 82}   # occ then free -> 0.829 -> 82
+    # arg-max tie rule: strict '>', first wins; all-zero weights -> index 0
+    pf.setParticles(w=np.array([0.4, 0.4, 0.2])); assert pf.getRobotState()[1] == 0
+    pf.setParticles(w=np.array([0.0, 0.0, 0.0])); assert pf.getRobotState()[1] == 0
