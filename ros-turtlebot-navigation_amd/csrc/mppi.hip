@@ -19,6 +19,7 @@
 #include <cstring>
 #include <limits>
 #include <new>
+#include <vector>
 
 #include "common.hpp"
 #include "tbnav_mppi.h"
@@ -30,6 +31,19 @@ constexpr int kSliceThreads = 256;
 constexpr int kSliceItems = 8;
 constexpr int kSlice = kSliceThreads * kSliceItems;  // rollouts per K-slice record
 constexpr int kMaxLdsBytes = 160 * 1024;
+
+// The warm-start controls as the kernels see them.  A tick leaves its updated, UNSHIFTED controls in `p`;
+// the shift of mppi.cpp:134-137 (u(:,i) <- u(:,i+1), last <- uinit) is applied on read by the next tick
+// (`shift` = 1), so no single workgroup has to own the whole vector and the combine can use many.
+struct USrc {
+  const double* p;   // [2][T]
+  int shift;
+  double init_l, init_r;
+  __device__ __forceinline__ double get(int row, int i, int T) const {
+    if (!shift) return p[row * T + i];
+    return (i + 1 < T) ? p[row * T + i + 1] : (row ? init_r : init_l);
+  }
+};
 
 struct RolloutArgs {
   double half_r;    // wheel_radius / 2.0            (mppi.hpp:45)
@@ -49,7 +63,10 @@ struct RolloutArgs {
 // reference's association.
 //
 // TRIG = 3: three sincos calls per step (th, th+d, th+2d), exactly the reference's evaluations.
-// TRIG = 1: ONE sincos per step (th, refreshed every step so nothing accumulates) and the other two
+// TRIG = 2: ONE sincos per step (th, refreshed every step) and the other two by angle addition.
+// TRIG = 1 (default): as 2, and the step's own heading is carried over from the previous step's stage-4
+//           rotation, with a fresh sincos every 4th step (<= 3 chained rotations, ~5e-16 absolute).
+// TRIG 1/2: ONE sincos per step (th, refreshed every step so nothing accumulates) and the other two
 //           headings by angle addition with sin/cos of the small angle d (|d| <= 2^-5: degree-11/10
 //           Taylor polynomials, truncation < 1e-24; larger |d|: a full sincos of d).  The rotated
 //           values are within ~2 ulp of libm's, i.e. the same size as the libm-vs-ocml difference the
@@ -89,19 +106,16 @@ __device__ __forceinline__ void fast_sincos(double x, double& s, double& c) {
 }
 
 __device__ __forceinline__ void small_sincos(double d, double& sd, double& cd) {
-  // straight-line Taylor pair (valid to < 1e-24 for |d| <= 2^-5); the full evaluation is entered only if SOME
+  // straight-line Taylor pair (truncation < 3e-19 relative for |d| <= 2^-5); the full evaluation is entered only if SOME
   // lane of the wave needs it (wave-uniform branch: no divergence, and never taken for physical wheel speeds)
   const double d2 = d * d;
-  // sin d = d (1 - d2/6 (1 - d2/20 (1 - d2/42 (1 - d2/72 (1 - d2/110)))))
-  double ps = 1.0 - d2 * (1.0 / 110.0);
-  ps = 1.0 - d2 * (1.0 / 72.0) * ps;
-  ps = 1.0 - d2 * (1.0 / 42.0) * ps;
+  // sin d = d (1 - d2/6 (1 - d2/20 (1 - d2/42)))          next term d^9/9!  <= 3e-19 relative at |d| = 2^-5
+  double ps = 1.0 - d2 * (1.0 / 42.0);
   ps = 1.0 - d2 * (1.0 / 20.0) * ps;
   ps = 1.0 - d2 * (1.0 / 6.0) * ps;
   sd = d * ps;
-  // cos d = 1 - d2/2 (1 - d2/12 (1 - d2/30 (1 - d2/56 (1 - d2/90))))
-  double pc = 1.0 - d2 * (1.0 / 90.0);
-  pc = 1.0 - d2 * (1.0 / 56.0) * pc;
+  // cos d = 1 - d2/2 (1 - d2/12 (1 - d2/30 (1 - d2/56)))  next term d^10/10! <= 3e-22
+  double pc = 1.0 - d2 * (1.0 / 56.0);
   pc = 1.0 - d2 * (1.0 / 30.0) * pc;
   pc = 1.0 - d2 * (1.0 / 12.0) * pc;
   cd = 1.0 - d2 * 0.5 * pc;
@@ -140,7 +154,11 @@ __device__ __forceinline__ void rk4_steps(const RolloutArgs& a, double& x, doubl
   double s1[G], c1[G], s2[G], c2[G], s4[G], c4[G];
 #pragma unroll
   for (int q = 0; q < G; ++q) {
-    fast_sincos(hth[q], s1[q], c1[q]);
+    // TRIG == 1: only the group's first step evaluates sincos; the heading at the start of step q is the
+    // stage-4 heading of step q-1 (th + h*w vs th + (h/6)*6w: the same angle up to one rounding), so its
+    // sin/cos are carried over — three chained rotations at most before the next fresh evaluation.
+    if (TRIG == 1 && q > 0) { s1[q] = s4[q - 1]; c1[q] = c4[q - 1]; }
+    else fast_sincos(hth[q], s1[q], c1[q]);
     if (TRIG == 3) {
       fast_sincos(hth[q] + a.h * (0.5 * w[q]), s2[q], c2[q]);
       fast_sincos(hth[q] + a.h * w[q], s4[q], c4[q]);
@@ -215,14 +233,14 @@ template <int TRIG>
 __global__ __launch_bounds__(kWave) void mppi_rollout_cost(RolloutArgs a,
                                                            const double* __restrict__ duL,
                                                            const double* __restrict__ duR,
-                                                           const double* __restrict__ u,
+                                                           USrc u,
                                                            double* __restrict__ J) {
   extern __shared__ __attribute__((aligned(16))) double lds_all[];
   const int lane = threadIdx.x;
   const int T = a.T, K = a.K;
   double* u_lds = lds_all;                 // [2*T]
   double* lds_loss = lds_all + 2 * T;      // [T - lds_from][64]
-  for (int t = lane; t < 2 * T; t += kWave) u_lds[t] = u[t];
+  for (int t = lane; t < 2 * T; t += kWave) u_lds[t] = u.get(t >= T, t >= T ? t - T : t, T);
   __syncthreads();
   const int k = blockIdx.x * kWave + lane;
   if (k >= K) return;
@@ -322,14 +340,14 @@ __global__ __launch_bounds__(kWave) void mppi_rollout_cost(RolloutArgs a,
 template <int TRIG, int TC, int MAXW>
 __global__ __launch_bounds__(kWave * MAXW) void mppi_rollout_scan(RolloutArgs a, const double* __restrict__ duL,
                                                                            const double* __restrict__ duR,
-                                                                           const double* __restrict__ u,
+                                                                           USrc u,
                                                                            double* __restrict__ J) {
   extern __shared__ __attribute__((aligned(16))) double lds_all[];
   const int lane = threadIdx.x, c = threadIdx.y, C = blockDim.y;
   const int T = a.T, K = a.K;
   double* u_lds = lds_all;                       // [2*T]
   double* tot = lds_all + 2 * T;                 // [4][C][64]: dtheta, dx, dy, loss totals per chunk
-  for (int t = c * kWave + lane; t < 2 * T; t += C * kWave) u_lds[t] = u[t];
+  for (int t = c * kWave + lane; t < 2 * T; t += C * kWave) u_lds[t] = u.get(t >= T, t >= T ? t - T : t, T);
   __syncthreads();
   const int k = blockIdx.x * kWave + lane;
   const bool live = k < K;
@@ -366,13 +384,15 @@ __global__ __launch_bounds__(kWave * MAXW) void mppi_rollout_scan(RolloutArgs a,
   double th0 = a.x0[2];
   for (int cc = 0; cc < c; ++cc) th0 += tot[(0 * C + cc) * kWave + lane];
   double runx = 0.0, runy = 0.0;
+  double s4 = 0.0, c4 = 1.0;
 #pragma unroll
   for (int q = 0; q < TC; ++q) {
     if (q % kSub == 0 && q) __builtin_amdgcn_sched_barrier(0);
     const double hth = th0 + (q == 0 ? 0.0 : tha[q - 1]);   // heading at the START of step i0+q
     const double v = vv[q], w = ww[q];
-    double s1, c1, s2, c2, s4, c4;
-    fast_sincos(hth, s1, c1);
+    double s1, c1, s2, c2;
+    if (TRIG == 1 && (q & 3) != 0) { s1 = s4; c1 = c4; }   // carried from the previous step's stage 4 (refresh every 4th step)
+    else fast_sincos(hth, s1, c1);
     if (TRIG == 3) {
       fast_sincos(hth + a.h * (0.5 * w), s2, c2);
       fast_sincos(hth + a.h * w, s4, c4);
@@ -442,21 +462,13 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
   return r;
 }
 
-__device__ __forceinline__ void combine_block(int T, int G, int S, double lambda, double umax, double uinit_l,
-                                              double uinit_r, const double* __restrict__ records,
-                                              double* __restrict__ u, double* __restrict__ out, double* unew);
-
-struct FuseArgs { unsigned int* counter; double* u; double* out; double umax, uinit_l, uinit_r; };
-
 // grid = (S, T).  Block (s, i) reduces time step i over rollouts [s*kSlice, (s+1)*kSlice).
 __global__ __launch_bounds__(kSliceThreads) void mppi_partials(int T, int K, int S, double lambda,
                                                                const double* __restrict__ J,
                                                                const double* __restrict__ duL,
                                                                const double* __restrict__ duR,
-                                                               double* __restrict__ records, FuseArgs fz) {
-  extern __shared__ __attribute__((aligned(16))) double unew_lds[];  // [2][T], used by the fused combine only
+                                                               double* __restrict__ records) {
   __shared__ double scratch[kSliceThreads / kWave];
-  __shared__ int is_last;
   const int s = blockIdx.x, i = blockIdx.y;
   const int base = s * kSlice;
   const double inf = __builtin_huge_val();
@@ -495,85 +507,56 @@ __global__ __launch_bounds__(kSliceThreads) void mppi_partials(int T, int K, int
     double* rec = records + ((size_t)i * S + s) * TBNAV_MPPI_REC;
     rec[0] = mn; rec[1] = A; rec[2] = B; rec[3] = C; rec[4] = D; rec[5] = E; rec[6] = n; rec[7] = 0.0;
   }
-  if (!fz.counter) return;
-  // Fused combine (single shard): the LAST workgroup to publish its record merges them all, which
-  // saves the separate launch.  Publish = record store, agent-scope release fence, counter increment;
-  // the last arriver acquires before it reads the other workgroups' records (guide G16 / the classic
-  // threadfence reduction).  The counter is left at zero for the next tick.
-  if (threadIdx.x == 0) {
-    __threadfence();
-    const unsigned int prev = atomicAdd(fz.counter, 1u);
-    is_last = (prev == (unsigned int)(gridDim.x * gridDim.y) - 1u) ? 1 : 0;
-    if (is_last) { __threadfence(); *fz.counter = 0u; }
-  }
-  __syncthreads();
-  if (!is_last) return;
-  combine_block(T, 1, S, lambda, fz.umax, fz.uinit_l, fz.uinit_r, records, fz.u, fz.out, unew_lds);
 }
 
-// Merge the G*S partial records of every time step (records: [G][T][S][8]), update u(:,i)
-// (mppi.cpp:118-125), emit u(:,0) and shift (mppi.cpp:129-137).  Called by ALL threads of one
-// workgroup.  Each time step gets a group of `tpr` lanes (the power of two >= the record count, at
-// most a wave), so 64/tpr steps are merged per wave at once and the min / six sums are xor-shuffle
-// reductions inside the group.  unew: LDS scratch [2][T].
-__device__ __forceinline__ void combine_block(int T, int G, int S, double lambda, double umax, double uinit_l,
-                                              double uinit_r, const double* __restrict__ records,
-                                              double* __restrict__ u, double* __restrict__ out, double* unew) {
+// Merge the G*S partial records of every time step (records: [G][T][S][8]) and update u(:,i)
+// (mppi.cpp:118-125).  Each time step gets a group of `tpr` lanes (the power of two >= the record count, at
+// most a wave): 64/tpr steps per wave, xor-shuffle reductions inside the group.  Any number of workgroups:
+// the updated controls are written UNSHIFTED to u_out and the shift is applied on read by the next tick
+// (USrc), u(:,0) goes to `out` (mppi.cpp:129-131).
+__global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, double lambda, double umax, USrc u,
+                                                    const double* __restrict__ records, double* __restrict__ u_out,
+                                                    double* __restrict__ out) {
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave, nw = blockDim.x / kWave;
   const int R = G * S;
   int tpr = 1;
   while (tpr < R && tpr < kWave) tpr <<= 1;
   const int spw = kWave / tpr, sub = lane / tpr, l = lane - sub * tpr;
-  for (int base = wid * spw; base < T; base += nw * spw) {
-    const int i = base + sub;
-    const bool valid = i < T;
-    double M = __builtin_huge_val();
-    if (valid)
-      for (int r = l; r < R; r += tpr) {
-        const int g = r / S, sl = r - g * S;
-        const double* rec = records + (((size_t)g * T + i) * S + sl) * TBNAV_MPPI_REC;
-        if (rec[6] > 0.0) M = fmin(M, rec[0]);
-      }
-    for (int off = tpr >> 1; off > 0; off >>= 1) M = fmin(M, __shfl_xor(M, off, kWave));
-    double W = 0, NL = 0, NR = 0, SD = 0, SE = 0, SN = 0;
-    if (valid)
-      for (int r = l; r < R; r += tpr) {
-        const int g = r / S, sl = r - g * S;
-        const double* rec = records + (((size_t)g * T + i) * S + sl) * TBNAV_MPPI_REC;
-        if (rec[6] > 0.0) {
-          const double sc = exp(((rec[0] - M) * -1.0) / lambda);
-          W += sc * rec[1]; NL += sc * rec[2]; NR += sc * rec[3];
-          SD += rec[4]; SE += rec[5]; SN += rec[6];
-        }
-      }
-    for (int off = tpr >> 1; off > 0; off >>= 1) {
-      W += __shfl_xor(W, off, kWave); NL += __shfl_xor(NL, off, kWave); NR += __shfl_xor(NR, off, kWave);
-      SD += __shfl_xor(SD, off, kWave); SE += __shfl_xor(SE, off, kWave); SN += __shfl_xor(SN, off, kWave);
+  const int i = (blockIdx.x * nw + wid) * spw + sub;
+  const bool valid = i < T;
+  double M = __builtin_huge_val();
+  if (valid)
+    for (int r = l; r < R; r += tpr) {
+      const int g = r / S, sl = r - g * S;
+      const double* rec = records + (((size_t)g * T + i) * S + sl) * TBNAV_MPPI_REC;
+      if (rec[6] > 0.0) M = fmin(M, rec[0]);
     }
-    if (valid && l == 0) {
-      W += 1e-8 * SN;  // the reference adds 1e-8 to every weight before normalising (mppi.cpp:117)
-      double ul = u[i] + (NL + 1e-8 * SD) / W;
-      double ur = u[T + i] + (NR + 1e-8 * SE) / W;
-      ul = fmin(fmax(ul, -umax), umax);  // std::clamp(u, -max, max), mppi.cpp:124-125
-      ur = fmin(fmax(ur, -umax), umax);
-      unew[i] = ul;
-      unew[T + i] = ur;
+  for (int off = tpr >> 1; off > 0; off >>= 1) M = fmin(M, __shfl_xor(M, off, kWave));
+  double W = 0, NL = 0, NR = 0, SD = 0, SE = 0, SN = 0;
+  if (valid)
+    for (int r = l; r < R; r += tpr) {
+      const int g = r / S, sl = r - g * S;
+      const double* rec = records + (((size_t)g * T + i) * S + sl) * TBNAV_MPPI_REC;
+      if (rec[6] > 0.0) {
+        const double sc = exp(((rec[0] - M) * -1.0) / lambda);
+        W += sc * rec[1]; NL += sc * rec[2]; NR += sc * rec[3];
+        SD += rec[4]; SE += rec[5]; SN += rec[6];
+      }
     }
+  for (int off = tpr >> 1; off > 0; off >>= 1) {
+    W += __shfl_xor(W, off, kWave); NL += __shfl_xor(NL, off, kWave); NR += __shfl_xor(NR, off, kWave);
+    SD += __shfl_xor(SD, off, kWave); SE += __shfl_xor(SE, off, kWave); SN += __shfl_xor(SN, off, kWave);
   }
-  __syncthreads();
-  if (threadIdx.x == 0) { out[0] = unew[0]; out[1] = unew[T]; }
-  for (int i = threadIdx.x; i < T; i += blockDim.x) {
-    u[i] = (i + 1 < T) ? unew[i + 1] : uinit_l;
-    u[T + i] = (i + 1 < T) ? unew[T + i + 1] : uinit_r;
+  if (valid && l == 0) {
+    W += 1e-8 * SN;  // the reference adds 1e-8 to every weight before normalising (mppi.cpp:117)
+    double ul = u.get(0, i, T) + (NL + 1e-8 * SD) / W;
+    double ur = u.get(1, i, T) + (NR + 1e-8 * SE) / W;
+    ul = fmin(fmax(ul, -umax), umax);  // std::clamp(u, -max, max), mppi.cpp:124-125
+    ur = fmin(fmax(ur, -umax), umax);
+    u_out[i] = ul;
+    u_out[T + i] = ur;
+    if (i == 0) { out[0] = ul; out[1] = ur; }
   }
-}
-
-__global__ __launch_bounds__(1024) void mppi_combine(int T, int G, int S, double lambda, double umax,
-                                                     double uinit_l, double uinit_r,
-                                                     const double* __restrict__ records,
-                                                     double* __restrict__ u, double* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) double unew[];  // [2][T]
-  combine_block(T, G, S, lambda, umax, uinit_l, uinit_r, records, u, out, unew);
 }
 
 // raw[(k*T + i)*2 + c]  ->  duL[i*K + k], duR[i*K + k]
@@ -647,14 +630,15 @@ struct tbnav_mppi {
   int T = 0, K = 0, S = 0, device = 0;
   double xd[3] = {0, 0, 0};
   double uinit[2] = {0, 0};
-  double* d_u = nullptr;        // [2][T]
+  double* d_u[2] = {nullptr, nullptr};  // [2][T] each; d_u[ucur] holds the controls, d_u[1-ucur] receives the next update
+  int ucur = 0;
+  bool pending_shift = false;   // d_u[ucur] is an updated, not yet shifted vector (the shift is applied on read)
   double* d_J = nullptr;        // [T][K]
   double* d_duL = nullptr;      // [T][K] own noise buffers (host-noise upload / device RNG)
   double* d_duR = nullptr;
   double* d_raw = nullptr;      // [K][T][2] staging for host-order noise (lazy)
   double* d_records = nullptr;  // [T][S][8]
   double* d_out = nullptr;      // [2]
-  unsigned int* d_counter = nullptr;  // arrival counter of the fused partials+combine kernel
   double* h_out = nullptr;      // pinned [2]
   int lds_from = 0;           // first time step whose loss is staged in LDS (0 = all of them)
   int scan_tc = 0;            // steps per thread of the time-parallel rollout kernel (0 = sequential kernel)
@@ -674,11 +658,12 @@ int launch_rollout(tbnav_mppi* h, const double x0[3], const double* d_duL, const
   a.R[0] = h->p.R[0]; a.R[1] = h->p.R[1];
   a.T = h->T; a.K = h->K;
   const dim3 grid((h->K + kWave - 1) / kWave), block(kWave);
+  const USrc usrc{h->d_u[h->ucur], h->pending_shift ? 1 : 0, h->uinit[0], h->uinit[1]};
   if (h->scan_tc > 0) {
     const int TCv = h->scan_tc, C = (h->T + TCv - 1) / TCv;
     const size_t lds = ((size_t)2 * h->T + (size_t)4 * C * kWave) * sizeof(double);
     const dim3 blk(kWave, C);
-#define TBNAV_SCAN(TR, TCC, MW) hipLaunchKernelGGL((mppi_rollout_scan<TR, TCC, MW>), grid, blk, lds, st, a, d_duL, d_duR, h->d_u, h->d_J)
+#define TBNAV_SCAN(TR, TCC, MW) hipLaunchKernelGGL((mppi_rollout_scan<TR, TCC, MW>), grid, blk, lds, st, a, d_duL, d_duR, usrc, h->d_J)
 #define TBNAV_SCAN_TC(TR)                                                                                          \
   switch (TCv) {                                                                                                   \
     case 4: if (C > 12) TBNAV_SCAN(TR, 4, 16); else TBNAV_SCAN(TR, 4, 12); break;                                  \
@@ -688,41 +673,55 @@ int launch_rollout(tbnav_mppi* h, const double x0[3], const double* d_duL, const
     case 10: TBNAV_SCAN(TR, 10, 12); break; case 12: TBNAV_SCAN(TR, 12, 12); break;                                \
     case 16: TBNAV_SCAN(TR, 16, 12); break; default: TBNAV_SCAN(TR, 20, 12); break;                                \
   }
-    if (h->trig == 1) { TBNAV_SCAN_TC(1) } else { TBNAV_SCAN_TC(3) }
+    if (h->trig == 1) { TBNAV_SCAN_TC(1) } else if (h->trig == 2) { TBNAV_SCAN_TC(2) } else { TBNAV_SCAN_TC(3) }
 #undef TBNAV_SCAN_TC
 #undef TBNAV_SCAN
   } else {
     const size_t lds = (size_t)2 * h->T * sizeof(double) + (size_t)(h->T - h->lds_from) * kWave * sizeof(double);
     a.lds_from = h->lds_from;
-    if (h->trig == 1) hipLaunchKernelGGL((mppi_rollout_cost<1>), grid, block, lds, st, a, d_duL, d_duR, h->d_u, h->d_J);
-    else hipLaunchKernelGGL((mppi_rollout_cost<3>), grid, block, lds, st, a, d_duL, d_duR, h->d_u, h->d_J);
+    if (h->trig == 1) hipLaunchKernelGGL((mppi_rollout_cost<1>), grid, block, lds, st, a, d_duL, d_duR, usrc, h->d_J);
+    else if (h->trig == 2) hipLaunchKernelGGL((mppi_rollout_cost<2>), grid, block, lds, st, a, d_duL, d_duR, usrc, h->d_J);
+    else hipLaunchKernelGGL((mppi_rollout_cost<3>), grid, block, lds, st, a, d_duL, d_duR, usrc, h->d_J);
   }
   TBNAV_HIP(hipGetLastError());
   return TBNAV_OK;
 }
 
-int launch_partials(tbnav_mppi* h, const double* d_duL, const double* d_duR, double* d_records,
-                    hipStream_t st, bool fuse_combine) {
+int launch_partials(tbnav_mppi* h, const double* d_duL, const double* d_duR, double* d_records, hipStream_t st) {
   const dim3 grid(h->S, h->T), block(kSliceThreads);
-  FuseArgs fz{};
-  if (fuse_combine) fz = FuseArgs{h->d_counter, h->d_u, h->d_out, h->p.max_wheel_vel, h->uinit[0], h->uinit[1]};
-  const size_t lds = fuse_combine ? (size_t)2 * h->T * sizeof(double) : 0;
-  hipLaunchKernelGGL(mppi_partials, grid, block, lds, st, h->T, h->K, h->S, h->p.lambda, h->d_J, d_duL,
-                     d_duR, d_records, fz);
+  hipLaunchKernelGGL(mppi_partials, grid, block, 0, st, h->T, h->K, h->S, h->p.lambda, h->d_J, d_duL, d_duR, d_records);
   TBNAV_HIP(hipGetLastError());
   return TBNAV_OK;
 }
 
 int launch_combine(tbnav_mppi* h, const double* d_records, int G, hipStream_t st) {
-  const size_t lds = (size_t)2 * h->T * sizeof(double);
-  // enough waves to merge every time step in one pass (64 / tpr steps per wave), 4..16 waves
   int tpr = 1;
   while (tpr < G * h->S && tpr < kWave) tpr <<= 1;
-  int waves = (h->T + (kWave / tpr) - 1) / (kWave / tpr);
-  waves = waves < 4 ? 4 : (waves > 16 ? 16 : waves);
-  hipLaunchKernelGGL(mppi_combine, dim3(1), dim3(waves * kWave), lds, st, h->T, G, h->S, h->p.lambda,
-                     h->p.max_wheel_vel, h->uinit[0], h->uinit[1], d_records, h->d_u, h->d_out);
+  const int steps_per_block = 4 * (kWave / tpr);  // 4 waves per workgroup
+  const int blocks = (h->T + steps_per_block - 1) / steps_per_block;
+  const USrc usrc{h->d_u[h->ucur], h->pending_shift ? 1 : 0, h->uinit[0], h->uinit[1]};
+  hipLaunchKernelGGL(mppi_combine, dim3(blocks), dim3(256), 0, st, h->T, G, h->S, h->p.lambda, h->p.max_wheel_vel, usrc,
+                     d_records, h->d_u[1 - h->ucur], h->d_out);
   TBNAV_HIP(hipGetLastError());
+  h->ucur = 1 - h->ucur;       // the freshly written vector is current ...
+  h->pending_shift = true;     // ... and its shift is still owed
+  return TBNAV_OK;
+}
+
+// Apply an owed shift for real (host side; only the state accessors need the materialised vector).
+int materialize_controls(tbnav_mppi* h, double* u_host /*[2][T], may be null*/) {
+  const int T = h->T;
+  std::vector<double> tmp((size_t)2 * T);
+  TBNAV_HIP(hipDeviceSynchronize());
+  TBNAV_HIP(hipMemcpy(tmp.data(), h->d_u[h->ucur], sizeof(double) * 2 * T, hipMemcpyDeviceToHost));
+  if (h->pending_shift) {
+    for (int i = 0; i + 1 < T; ++i) { tmp[i] = tmp[i + 1]; tmp[T + i] = tmp[T + i + 1]; }
+    tmp[T - 1] = h->uinit[0];
+    tmp[2 * T - 1] = h->uinit[1];
+    TBNAV_HIP(hipMemcpy(h->d_u[h->ucur], tmp.data(), sizeof(double) * 2 * T, hipMemcpyHostToDevice));
+    h->pending_shift = false;
+  }
+  if (u_host) std::memcpy(u_host, tmp.data(), sizeof(double) * 2 * T);
   return TBNAV_OK;
 }
 
@@ -807,21 +806,21 @@ int tbnav_mppi_create(const tbnav_mppi_params* params, tbnav_mppi** out) {
     const int tc = std::atoi(e), cmax = (tc == 4 || tc == 7 || tc == 8) ? 16 : 12;
     if (tc > 0 && (T + tc - 1) / tc <= cmax) h->scan_tc = tc;
   }
-  if (const char* e = std::getenv("TBNAV_MPPI_TRIG")) h->trig = (std::atoi(e) == 3) ? 3 : 1;
+  if (const char* e = std::getenv("TBNAV_MPPI_TRIG")) { const int t = std::atoi(e); h->trig = (t == 2 || t == 3) ? t : 1; }
   if (const char* e = std::getenv("TBNAV_MPPI_NO_LDS")) { if (std::atoi(e) == 1) h->lds_from = T; }
   const size_t tk = (size_t)T * h->K;
   hipError_t e = hipSuccess;
   auto alloc = [&](double** p, size_t n) { if (e == hipSuccess) e = hipMalloc((void**)p, n * sizeof(double)); };
-  alloc(&h->d_u, 2 * (size_t)T);
+  alloc(&h->d_u[0], 2 * (size_t)T);
+  alloc(&h->d_u[1], 2 * (size_t)T);
   alloc(&h->d_J, tk);
   alloc(&h->d_duL, tk);
   alloc(&h->d_duR, tk);
   alloc(&h->d_records, (size_t)T * h->S * TBNAV_MPPI_REC);
   alloc(&h->d_out, 2);
-  if (e == hipSuccess) e = hipMalloc((void**)&h->d_counter, sizeof(unsigned int));
-  if (e == hipSuccess) e = hipMemset(h->d_counter, 0, sizeof(unsigned int));
   if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_out, 2 * sizeof(double), hipHostMallocDefault);
-  if (e == hipSuccess) e = hipMemset(h->d_u, 0, 2 * (size_t)T * sizeof(double));
+  if (e == hipSuccess) e = hipMemset(h->d_u[0], 0, 2 * (size_t)T * sizeof(double));
+  if (e == hipSuccess) e = hipMemset(h->d_u[1], 0, 2 * (size_t)T * sizeof(double));
   if (e == hipSuccess) e = hipMemset(h->d_J, 0, tk * sizeof(double));
   if (e == hipSuccess) e = hipMemset(h->d_duL, 0, tk * sizeof(double));
   if (e == hipSuccess) e = hipMemset(h->d_duR, 0, tk * sizeof(double));
@@ -829,6 +828,8 @@ int tbnav_mppi_create(const tbnav_mppi_params* params, tbnav_mppi** out) {
   if (e == hipSuccess) {
     const int lds_max = (int)((size_t)2 * T * sizeof(double) + (size_t)(T - h->lds_from) * kWave * sizeof(double));
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mppi_rollout_cost<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mppi_rollout_cost<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     if (e == hipSuccess)
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mppi_rollout_cost<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
   }
@@ -845,8 +846,8 @@ int tbnav_mppi_create(const tbnav_mppi_params* params, tbnav_mppi** out) {
 void tbnav_mppi_destroy(tbnav_mppi* h) {
   if (!h) return;
   DeviceGuard guard(h->device);
-  (void)hipFree(h->d_u); (void)hipFree(h->d_J); (void)hipFree(h->d_duL); (void)hipFree(h->d_duR);
-  (void)hipFree(h->d_raw); (void)hipFree(h->d_records); (void)hipFree(h->d_out); (void)hipFree(h->d_counter);
+  (void)hipFree(h->d_u[0]); (void)hipFree(h->d_u[1]); (void)hipFree(h->d_J); (void)hipFree(h->d_duL); (void)hipFree(h->d_duR);
+  (void)hipFree(h->d_raw); (void)hipFree(h->d_records); (void)hipFree(h->d_out);
   if (h->h_out) (void)hipHostFree(h->h_out);
   delete h;
 }
@@ -863,7 +864,9 @@ int tbnav_mppi_set_initial_controls(tbnav_mppi* h, double uL, double uR) {
   double* tmp = new (std::nothrow) double[2 * (size_t)h->T];
   if (!tmp) return TBNAV_ERR_INVALID_ARG;
   for (int i = 0; i < h->T; ++i) { tmp[i] = uL; tmp[h->T + i] = uR; }
-  hipError_t e = hipMemcpy(h->d_u, tmp, 2 * (size_t)h->T * sizeof(double), hipMemcpyHostToDevice);
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(h->d_u[h->ucur], tmp, 2 * (size_t)h->T * sizeof(double), hipMemcpyHostToDevice);
+  h->pending_shift = false;
   delete[] tmp;
   TBNAV_HIP(e);
   return TBNAV_OK;
@@ -878,16 +881,15 @@ int tbnav_mppi_set_waypoint(tbnav_mppi* h, double x, double y, double theta) {
 int tbnav_mppi_get_controls(tbnav_mppi* h, double* u_host) {
   if (!h || !u_host) return TBNAV_ERR_INVALID_ARG;
   DeviceGuard guard(h->device);
-  TBNAV_HIP(hipDeviceSynchronize());
-  TBNAV_HIP(hipMemcpy(u_host, h->d_u, 2 * (size_t)h->T * sizeof(double), hipMemcpyDeviceToHost));
-  return TBNAV_OK;
+  return materialize_controls(h, u_host);
 }
 
 int tbnav_mppi_set_controls(tbnav_mppi* h, const double* u_host) {
   if (!h || !u_host) return TBNAV_ERR_INVALID_ARG;
   DeviceGuard guard(h->device);
   TBNAV_HIP(hipDeviceSynchronize());
-  TBNAV_HIP(hipMemcpy(h->d_u, u_host, 2 * (size_t)h->T * sizeof(double), hipMemcpyHostToDevice));
+  TBNAV_HIP(hipMemcpy(h->d_u[h->ucur], u_host, 2 * (size_t)h->T * sizeof(double), hipMemcpyHostToDevice));
+  h->pending_shift = false;
   return TBNAV_OK;
 }
 
@@ -898,7 +900,7 @@ int tbnav_mppi_shard_partials(tbnav_mppi* h, const double x0[3], const double* d
   hipStream_t st = static_cast<hipStream_t>(stream);
   int rc = launch_rollout(h, x0, d_duL, d_duR, st);
   if (rc != TBNAV_OK) return rc;
-  return launch_partials(h, d_duL, d_duR, d_records_out, st, false);
+  return launch_partials(h, d_duL, d_duR, d_records_out, st);
 }
 
 int tbnav_mppi_shard_combine(tbnav_mppi* h, const double* d_records_all, int32_t n_shards, void* stream) {
@@ -914,12 +916,8 @@ int tbnav_mppi_enqueue_dev(tbnav_mppi* h, const double x0[3], const double* d_du
   hipStream_t st = static_cast<hipStream_t>(stream);
   int rc = launch_rollout(h, x0, d_duL, d_duR, st);
   if (rc != TBNAV_OK) return rc;
-  // NOT fused into the partials kernel's last workgroup: measured on MI355X the per-workgroup
-  // agent-scope fence + atomic of that scheme costs more (tick 15.8 -> 43 us at K=1024) than the
-  // ~1.5 us kernel boundary it removes; fuse_combine stays available behind TBNAV_MPPI_FUSE=1.
-  static const bool fuse = [] { const char* e = std::getenv("TBNAV_MPPI_FUSE"); return e && std::atoi(e) == 1; }();
-  if (fuse) return launch_partials(h, d_duL, d_duR, h->d_records, st, true);
-  rc = launch_partials(h, d_duL, d_duR, h->d_records, st, false);
+  // (fusing the combine into the partials kernel's last workgroup was measured and rejected: DESIGN.md section 4)
+  rc = launch_partials(h, d_duL, d_duR, h->d_records, st);
   if (rc != TBNAV_OK) return rc;
   return launch_combine(h, h->d_records, 1, st);
 }
@@ -934,7 +932,7 @@ int tbnav_mppi_profile_tick(tbnav_mppi* h, const double x0[3], const double* d_d
   int rc = TBNAV_OK;
   TBNAV_HIP(hipEventRecord(ev[0], st));
   rc = launch_rollout(h, x0, d_duL, d_duR, st);
-  if (rc == TBNAV_OK) { TBNAV_HIP(hipEventRecord(ev[1], st)); rc = launch_partials(h, d_duL, d_duR, h->d_records, st, false); }
+  if (rc == TBNAV_OK) { TBNAV_HIP(hipEventRecord(ev[1], st)); rc = launch_partials(h, d_duL, d_duR, h->d_records, st); }
   if (rc == TBNAV_OK) { TBNAV_HIP(hipEventRecord(ev[2], st)); rc = launch_combine(h, h->d_records, 1, st); }
   if (rc == TBNAV_OK) {
     TBNAV_HIP(hipEventRecord(ev[3], st));
