@@ -46,6 +46,8 @@ __host__ __device__ inline double normalize_angle_PI(double rad) {  // rigid2d.h
   return (rad - kPI);
 }
 
+__device__ __forceinline__ int floor_div_small(int num, int den);  // exact floor(num/den), |num| < 2^24, 0 < den < 2^13
+
 struct GridC {
   double xmin, xmax, ymin, ymax, res;
   int xsize, ysize, words;  // words = ceil(ysize / 64) u64 per bitmap row
@@ -101,9 +103,22 @@ __device__ __forceinline__ double wave_prod(double v) {
 // beams[b] = (r*cos a_b, r*sin a_b) in the sensor frame, built on the host exactly as
 // sensor_model.cpp:73-108 does.  Returns the product in every lane; *oob is set if a beam leaves
 // the world (the reference throws from world2RowMajor).
+// Mixture term of one beam as a function of the distance code it lands on (grid_mapper.cpp:119-121).
+__device__ __forceinline__ double beam_mixture(const ScanC& c, uint16_t code) {
+  const double z = code_to_dist(c.g, code);
+  double pz = 0.0;
+  pz += c.z_hit * (c.sqrt_inv_hit * exp(-0.5 * (z * z) / c.var_hit));
+  pz += c.rand_term;
+  return pz;
+}
+
+// ctag/cpz (nullable): per-beam cache filled once per particle for the centre of its k samples — the samples
+// lie within ~1e-4 m of it, so nearly every (sample, beam) lands on the same code and takes its mixture term
+// from LDS instead of re-evaluating sqrt + exp.  Read-only here; a miss computes the term afresh.
 __device__ __forceinline__ double wave_scan_likelihood(const ScanC& c, const double2* __restrict__ beams,
                                                        const uint16_t* __restrict__ code, int n_occ, const int4 win,
-                                                       double th, double x, double y, int lane, int* oob) {
+                                                       double th, double x, double y, int lane, int* oob,
+                                                       const unsigned int* ctag = nullptr, const double* cpz = nullptr) {
   if (n_occ == 0) return 1.0;  // grid_mapper.cpp:94-98
   // Tms = T(pose) * Trs  (rigid2d.cpp:214-224)
   double s0, c0;
@@ -122,11 +137,8 @@ __device__ __forceinline__ double wave_scan_likelihood(const ScanC& c, const dou
     // the distance field is only guaranteed fresh inside this particle's window (DESIGN.md "windowed refresh");
     // the window is sized so that this cannot fail — if it ever does, the call reports it instead of reading stale data
     if (ci < win.x || ci > win.y || cj < win.z || cj > win.w) { *oob |= 2; continue; }
-    const double z = code_to_dist(c.g, code[(size_t)ci * c.g.xsize + cj]);
-    double pz = 0.0;
-    pz += c.z_hit * (c.sqrt_inv_hit * exp(-0.5 * (z * z) / c.var_hit));
-    pz += c.rand_term;
-    p *= pz;
+    const uint16_t cd = code[(size_t)ci * c.g.xsize + cj];
+    p *= (ctag && ctag[b] == (unsigned int)cd) ? cpz[b] : beam_mixture(c, cd);
   }
   return wave_prod(p);
 }
@@ -214,6 +226,8 @@ __global__ __launch_bounds__(kProposeThreads) void rbpf_propose(ScanC c, const d
   double* smp = lds;               // [k][3]
   double* pscan = lds + 3 * k;     // [k]
   double* ppose = lds + 4 * k;     // [k]
+  double* cpz = lds + 5 * k;       // [Bv] mixture term of beam b at the samples' centre
+  unsigned int* ctag = reinterpret_cast<unsigned int*>(cpz + c.Bv);  // [Bv] the code it was computed for (0xFFFFFFFF = none)
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
   const uint16_t* code = codes + (size_t)p * c.g.xsize * c.g.ysize;
   const double* z = normals + (size_t)p * c.stride_normals;
@@ -269,11 +283,32 @@ __global__ __launch_bounds__(kProposeThreads) void rbpf_propose(ScanC c, const d
     ppose[j] = pose_likelihood_odom(c, s, pv, &var_err);
   }
   if (var_err) atomicOr(&err[2], 1);
+  if (nocc) {  // per-beam cache at the centre of the samples (T(pose)*T_icp)
+    double sc, cc;
+    sincos(mu0[0], &sc, &cc);
+    const double Xc = cc * c.Trs[1] - sc * c.Trs[2] + mu0[1], Yc = sc * c.Trs[1] + cc * c.Trs[2] + mu0[2];
+    double stc, ctc;
+    sincos(mu0[0] + c.Trs[0], &stc, &ctc);
+    for (int b = tid; b < c.Bv; b += kProposeThreads) {
+      const double2 pt = beams[b];
+      int ci, cj;
+      unsigned int tag = 0xFFFFFFFFu;
+      double pz = 0.0;
+      if (world2cell(c.g, ctc * pt.x - stc * pt.y + Xc, stc * pt.x + ctc * pt.y + Yc, ci, cj) && ci >= wn.x && ci <= wn.y &&
+          cj >= wn.z && cj <= wn.w) {
+        const uint16_t cd = code[(size_t)ci * c.g.xsize + cj];
+        tag = cd;
+        pz = beam_mixture(c, cd);
+      }
+      ctag[b] = tag;
+      cpz[b] = pz;
+    }
+  }
   __syncthreads();
 
   // ---- scan likelihood of every sample (:541): one wave per sample, lanes over beams
   for (int j = wid; j < k; j += kProposeThreads / kWave) {
-    const double sl = wave_scan_likelihood(c, beams, code, nocc, wn, smp[3 * j + 0], smp[3 * j + 1], smp[3 * j + 2], lane, &oob);
+    const double sl = wave_scan_likelihood(c, beams, code, nocc, wn, smp[3 * j + 0], smp[3 * j + 1], smp[3 * j + 2], lane, &oob, ctag, cpz);
     if (lane == 0) pscan[j] = sl;
   }
   if (oob & 1) atomicOr(&err[0], 1);
@@ -362,7 +397,7 @@ __device__ __forceinline__ void ray_cell(const Ray& r, int n, int& cx, int& cy) 
     default: {
       if (n == 0) { cx = r.x0; cy = r.y0; break; }
       const int a = 2 * r.dmin * n - r.dmaj;
-      const int ct = a > 0 ? (a + 2 * r.dmaj - 1) / (2 * r.dmaj) : 0;
+      const int ct = a > 0 ? floor_div_small(a + 2 * r.dmaj - 1, 2 * r.dmaj) : 0;  // operands < 2^24
       if (r.kind == 2) { cx = r.xa + n; cy = r.ya + r.sgn * ct; }
       else { cx = r.xa + r.sgn * ct; cy = r.ya + n; }
     }
@@ -558,7 +593,8 @@ __global__ __launch_bounds__(512) void rbpf_raycast_tile(ScanC c, const double2*
         const unsigned int word = tile[t >> 1];
         const unsigned int hlf = (t & 1) ? (word >> 16) : (word & 0xFFFFu);
         if (!(hlf & 0x8000u)) cn[q] = (int)(hlf & 0x7FFFu);
-        idx[q] = (size_t)(minx + t / bw) * xs + (miny + t % bw);
+        const int tr = floor_div_small(t, bw);  // t < 2^15, bw < 2^8
+        idx[q] = (size_t)(minx + tr) * xs + (miny + (t - tr * bw));
       }
     }
 #pragma unroll
@@ -571,7 +607,7 @@ __global__ __launch_bounds__(512) void rbpf_raycast_tile(ScanC c, const double2*
       lo[idx[q]] = v;
       const bool was = v0[q] >= c.cut_occ, now = v >= c.cut_occ;
       if (was != now) {
-        const int t = t0 + q, cx = minx + t / bw, cy = miny + t % bw;
+        const int t = t0 + q, tr = floor_div_small(t, bw), cx = minx + tr, cy = miny + (t - tr * bw);
         atomicXor(&bm[(size_t)cx * c.g.words + (cy >> 6)], 1ull << (cy & 63));
         atomicAdd(&rc[cx], now ? 1 : -1);
         atomicAdd(nocc, now ? 1 : -1);
@@ -1273,7 +1309,7 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
     }
   }
   TBNAV_HIP(hipEventRecord(h->ev[1], st));
-  hipLaunchKernelGGL(rbpf_propose, dim3(h->N), dim3(kProposeThreads), sizeof(double) * 5 * h->k, st, c, h->d_beams,
+  hipLaunchKernelGGL(rbpf_propose, dim3(h->N), dim3(kProposeThreads), sizeof(double) * (5 * h->k + (c.Bv > 0 ? c.Bv : 1)) + sizeof(unsigned int) * (c.Bv > 0 ? c.Bv : 1), st, c, h->d_beams,
                      h->d_code[h->cur], h->d_nocc[h->cur], h->d_win, h->d_normals, sp.pose, sp.prev, sp.weight, h->tr, h->d_err);
   TBNAV_HIP(hipGetLastError());
   TBNAV_HIP(hipEventRecord(h->ev[2], st));
