@@ -33,7 +33,13 @@ namespace {
 
 constexpr double kPI = 3.14159265358979323846;  // rigid2d.hpp:13
 constexpr int kWave = 64;
-constexpr int kProposeThreads = 256;
+#ifndef TBNAV_PROPOSE_THREADS
+#define TBNAV_PROPOSE_THREADS 256
+#endif
+#ifndef TBNAV_PROPOSE_WAVES
+#define TBNAV_PROPOSE_WAVES 3
+#endif
+constexpr int kProposeThreads = TBNAV_PROPOSE_THREADS;
 constexpr uint16_t kCodeUnreached = 0xFFFF;
 constexpr int kMaxLds = 160 * 1024;
 
@@ -52,6 +58,7 @@ struct GridC {
   double xmin, xmax, ymin, ymax, res;
   int xsize, ysize, words;  // words = ceil(ysize / 64) u64 per bitmap row
   double max_occ_dist;
+  double inv_res;  // fl(1/res), for the guarded fast path of world2cell
 };
 
 struct ScanC {  // everything constant during one SLAM call
@@ -70,12 +77,24 @@ struct ScanC {  // everything constant during one SLAM call
 };
 
 // world -> cell, grid_mapper.cpp:810-887.  false = outside the world (the reference throws).
+// The reference's cell is floor(fl(fl(x - xmin) / res)).  An f64 division costs ~25 instructions, and this runs
+// once per (sample, beam): so the quotient is first formed with the reciprocal (q~ = fl(d * fl(1/res)), off the
+// exact quotient by < 4 ulp, i.e. < 2e-11 cells for maps up to 2^15 cells a side) and used when it is further
+// than 1e-9 from a cell border — then floor(q~) IS the reference's floor; only a point that close to a border
+// takes the division.  Bit-identical by construction (and checked against the oracle's division).
+__device__ __forceinline__ double cell_floor(double d, const GridC& g) {
+  const double q = d * g.inv_res;
+  double f = floor(q);
+  const double fr = q - f;
+  if (!(fr > 1e-9 && fr < 1.0 - 1e-9)) f = floor(d / g.res);
+  return f;
+}
 __device__ __forceinline__ bool world2cell(const GridC& g, double x, double y, int& ci, int& cj) {
   if (!(x >= g.xmin && x <= g.xmax)) return false;
   if (!(y >= g.ymin && y <= g.ymax)) return false;
-  double fi = floor((x - g.xmin) / g.res);
+  double fi = cell_floor(x - g.xmin, g);
   if (fi == g.xsize) fi -= 1.0;
-  double fj = floor((y - g.ymin) / g.res);
+  double fj = cell_floor(y - g.ymin, g);
   if (fj == g.ysize) fj -= 1.0;
   ci = (int)fi;
   cj = (int)fj;
@@ -103,6 +122,46 @@ __device__ __forceinline__ double wave_prod(double v) {
 // beams[b] = (r*cos a_b, r*sin a_b) in the sensor frame, built on the host exactly as
 // sensor_model.cpp:73-108 does.  Returns the product in every lane; *oob is set if a beam leaves
 // the world (the reference throws from world2RowMajor).
+__device__ __forceinline__ int row_nearest(const unsigned long long* row, int words, int j, int cap);
+
+// Where a lookup gets its distance code from.
+//  field  : the particle's u16 field is authoritative (injected, or whole-field fresh) -> read it
+//  window : the field was refreshed inside `win` for this call -> read it, report a lookup outside the window
+//  query  : no field refresh at all — the squared distance to the nearest occupied cell is computed from the
+//           occupancy bitmap at the looked-up cell: rows i, i+-1, i+-2, ... each contribute (dr^2 + nearest set
+//           bit in that row)^2 and the walk stops once dr^2 >= best.  A beam ends on or next to a wall, so this
+//           is a handful of rows; the result is the exact transform's value (same integer arithmetic), and a
+//           cell with no obstacle within cell_radius keeps its stored code, like the transform.
+struct DistSrc {
+  const uint16_t* code;             // [G] of the particle
+  const unsigned long long* bm;     // [xs][words]
+  const int* rowcount;              // [xs]
+  int4 win;
+  int mode;                         // 0 field, 1 window, 2 query
+};
+__device__ __forceinline__ uint16_t nearest_code_query(const GridC& g, const DistSrc& d, int radius, int ci, int cj) {
+  int best = 0x7fffffff;
+  for (int dr = 0; dr <= radius; ++dr) {
+    if (dr * dr >= best) break;
+    for (int sg = 0; sg < (dr ? 2 : 1); ++sg) {
+      const int r = sg ? ci - dr : ci + dr;
+      if (r < 0 || r >= g.xsize || d.rowcount[r] == 0) continue;
+      int cap = radius;
+      if (best != 0x7fffffff) { cap = (int)sqrtf((float)(best - dr * dr)) + 1; cap = cap < radius ? cap : radius; }
+      const int f = row_nearest(d.bm + (size_t)r * g.words, g.words, cj, cap);
+      if (f != 255) { const int cand = dr * dr + f * f; best = cand < best ? cand : best; }
+    }
+  }
+  return (best <= radius * radius) ? (uint16_t)best : d.code[(size_t)ci * g.xsize + cj];
+}
+// returns false when a windowed lookup falls outside the refreshed window
+__device__ __forceinline__ bool lookup_code(const GridC& g, const DistSrc& d, int radius, int ci, int cj, uint16_t& out) {
+  if (d.mode == 2) { out = nearest_code_query(g, d, radius, ci, cj); return true; }
+  if (d.mode == 1 && (ci < d.win.x || ci > d.win.y || cj < d.win.z || cj > d.win.w)) return false;
+  out = d.code[(size_t)ci * g.xsize + cj];
+  return true;
+}
+
 // Mixture term of one beam as a function of the distance code it lands on (grid_mapper.cpp:119-121).
 __device__ __forceinline__ double beam_mixture(const ScanC& c, uint16_t code) {
   const double z = code_to_dist(c.g, code);
@@ -112,21 +171,25 @@ __device__ __forceinline__ double beam_mixture(const ScanC& c, uint16_t code) {
   return pz;
 }
 
-// ctag/cpz (nullable): per-beam cache filled once per particle for the centre of its k samples — the samples
-// lie within ~1e-4 m of it, so nearly every (sample, beam) lands on the same code and takes its mixture term
-// from LDS instead of re-evaluating sqrt + exp.  Read-only here; a miss computes the term afresh.
-__device__ __forceinline__ double wave_scan_likelihood(const ScanC& c, const double2* __restrict__ beams,
-                                                       const uint16_t* __restrict__ code, int n_occ, const int4 win,
-                                                       double th, double x, double y, int lane, int* oob,
-                                                       const unsigned int* ctag = nullptr, const double* cpz = nullptr) {
-  if (n_occ == 0) return 1.0;  // grid_mapper.cpp:94-98
-  // Tms = T(pose) * Trs  (rigid2d.cpp:214-224)
+// ctag/ccell/cpz (nullable): per-beam cache filled once per particle for the centre of its k samples — the
+// samples lie within ~1e-4 m of it, so nearly every (sample, beam) lands on the same cell (no lookup at all) or at
+// least the same code, and takes its mixture term from LDS instead of re-evaluating sqrt + exp.  Read-only here;
+// a miss computes the term afresh.
+// Tms = T(pose) * Trs  (rigid2d.cpp:214-224) as (X, Y, sin, cos); Trs.theta == 0 (the shipped robot) needs one sincos
+__device__ __forceinline__ void sensor_transform(const ScanC& c, double th, double x, double y, double out[4]) {
   double s0, c0;
   sincos(th, &s0, &c0);
-  const double X = c0 * c.Trs[1] - s0 * c.Trs[2] + x;
-  const double Y = s0 * c.Trs[1] + c0 * c.Trs[2] + y;
-  double st, ct;
-  sincos(th + c.Trs[0], &st, &ct);
+  out[0] = c0 * c.Trs[1] - s0 * c.Trs[2] + x;
+  out[1] = s0 * c.Trs[1] + c0 * c.Trs[2] + y;
+  if (c.Trs[0] == 0.0) { out[2] = s0; out[3] = c0; }  // th + 0.0 == th: same bits
+  else sincos(th + c.Trs[0], &out[2], &out[3]);
+}
+__device__ __forceinline__ double wave_scan_likelihood_t(const ScanC& c, const double2* __restrict__ beams,
+                                                         const DistSrc& ds, int radius, int n_occ,
+                                                         double X, double Y, double st, double ct, int lane, int* oob,
+                                                         const unsigned int* ctag = nullptr, const unsigned int* ccell = nullptr,
+                                                         const double* cpz = nullptr) {
+  if (n_occ == 0) return 1.0;  // grid_mapper.cpp:94-98
   double p = 1.0;
   for (int b = lane; b < c.Bv; b += kWave) {
     const double2 pt = beams[b];
@@ -134,13 +197,22 @@ __device__ __forceinline__ double wave_scan_likelihood(const ScanC& c, const dou
     const double ey = st * pt.x + ct * pt.y + Y;
     int ci, cj;
     if (!world2cell(c.g, ex, ey, ci, cj)) { *oob |= 1; continue; }
-    // the distance field is only guaranteed fresh inside this particle's window (DESIGN.md "windowed refresh");
-    // the window is sized so that this cannot fail — if it ever does, the call reports it instead of reading stale data
-    if (ci < win.x || ci > win.y || cj < win.z || cj > win.w) { *oob |= 2; continue; }
-    const uint16_t cd = code[(size_t)ci * c.g.xsize + cj];
+    // same cell as the cached centre -> same code -> same term (the field is a function of the cell)
+    if (ccell && ccell[b] == (unsigned int)(ci * c.g.xsize + cj)) { p *= cpz[b]; continue; }
+    uint16_t cd;
+    // (window mode: the window is sized so that a miss cannot happen — if it ever does it is reported, never read stale)
+    if (!lookup_code(c.g, ds, radius, ci, cj, cd)) { *oob |= 2; continue; }
     p *= (ctag && ctag[b] == (unsigned int)cd) ? cpz[b] : beam_mixture(c, cd);
   }
   return wave_prod(p);
+}
+__device__ __forceinline__ double wave_scan_likelihood(const ScanC& c, const double2* __restrict__ beams,
+                                                       const DistSrc& ds, int radius, int n_occ,
+                                                       double th, double x, double y, int lane, int* oob) {
+  if (n_occ == 0) return 1.0;
+  double T[4];
+  sensor_transform(c, th, x, y, T);
+  return wave_scan_likelihood_t(c, beams, ds, radius, n_occ, T[0], T[1], T[2], T[3], lane, oob);
 }
 
 // particle_filter.cpp:383-437 (odometry part precomputed on the host: rot1, trans, rot2)
@@ -209,13 +281,25 @@ __global__ void rbpf_sample_normals(size_t n, unsigned long long seed, unsigned 
   }
 }
 
+#ifdef TBNAV_PHASE_PROF
+__device__ unsigned long long g_phase[8];
+__device__ unsigned long long g_phase_p[8];
+#define PHASE_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_phase[i], now_ - t_prev_); t_prev_ = now_; } } while (0)
+#define PHASE_STAMP_P(i) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_phase_p[i], now_ - t_prev_); t_prev_ = now_; } } while (0)
+#else
+#define PHASE_STAMP(i)
+#define PHASE_STAMP_P(i)
+#endif
 struct Trace {
   double *sampled, *p_scan, *p_pose, *mu, *sigma, *eta, *new_pose, *weight_raw;
 };
 
 // err[0] = out of world, err[1] = eta zero, err[2] = pdf variance zero, err[3] = bresenham
-__global__ __launch_bounds__(kProposeThreads) void rbpf_propose(ScanC c, const double2* __restrict__ beams,
+__global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c, const double2* __restrict__ beams,
                                                                 const uint16_t* __restrict__ codes,
+                                                                const unsigned long long* __restrict__ bitmap,
+                                                                const int* __restrict__ row_count, const int* __restrict__ skip,
+                                                                int df_mode, int radius,
                                                                 const int* __restrict__ n_occ, const int4* __restrict__ win,
                                                                 const double* __restrict__ normals,
                                                                 double* __restrict__ pose, double* __restrict__ prev_pose,
@@ -226,13 +310,16 @@ __global__ __launch_bounds__(kProposeThreads) void rbpf_propose(ScanC c, const d
   double* smp = lds;               // [k][3]
   double* pscan = lds + 3 * k;     // [k]
   double* ppose = lds + 4 * k;     // [k]
-  double* cpz = lds + 5 * k;       // [Bv] mixture term of beam b at the samples' centre
+  double* stf = lds + 5 * k;       // [k][4] sensor transform of sample j; later reused as wj[k] | op[k][6]
+  double* cpz = lds + 12 * k;      // [Bv] mixture term of beam b at the samples' centre
   unsigned int* ctag = reinterpret_cast<unsigned int*>(cpz + c.Bv);  // [Bv] the code it was computed for (0xFFFFFFFF = none)
+  unsigned int* ccell = ctag + c.Bv;                                 // [Bv] the cell that code was looked up at
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
   const uint16_t* code = codes + (size_t)p * c.g.xsize * c.g.ysize;
   const double* z = normals + (size_t)p * c.stride_normals;
   const int nocc = n_occ[p];
-  const int4 wn = win[p];
+  // a particle whose field is authoritative (injected / whole-field fresh) always reads it
+  const DistSrc ds{code, bitmap + (size_t)p * c.g.xsize * c.g.words, row_count + (size_t)p * c.g.xsize, win[p], skip[p] ? 0 : df_mode};
   int oob = 0;
 
   if (!c.icp_ok) {
@@ -251,7 +338,7 @@ __global__ __launch_bounds__(kProposeThreads) void rbpf_propose(ScanC c, const d
         nx = x + ((-uvx / uw) * sin(nth) + (uvx / uw) * sin(nth + uw) + w1);
         ny = y + ((uvx / uw) * cos(nth) - (uvx / uw) * cos(nth + uw) + w2);
       }
-      const double sl = wave_scan_likelihood(c, beams, code, nocc, wn, nth, nx, ny, lane, &oob);
+      const double sl = wave_scan_likelihood(c, beams, ds, radius, nocc, nth, nx, ny, lane, &oob);
       if (lane == 0) {
         prev_pose[p * 3 + 0] = th; prev_pose[p * 3 + 1] = x; prev_pose[p * 3 + 2] = y;
         pose[p * 3 + 0] = nth; pose[p * 3 + 1] = nx; pose[p * 3 + 2] = ny;
@@ -267,8 +354,11 @@ __global__ __launch_bounds__(kProposeThreads) void rbpf_propose(ScanC c, const d
     return;
   }
 
-  // ---- sample k poses round T(pose) * T_icp (particle_filter.cpp:181-188, :504-519) and score the
-  //      odometry likelihood of each (:542), one thread per sample
+  // ---- sample k poses round T(pose) * T_icp (particle_filter.cpp:181-188, :504-519), score the odometry
+  //      likelihood of each (:542) and derive its sensor transform: one thread per sample
+#ifdef TBNAV_PHASE_PROF
+  unsigned long long t_prev_ = wall_clock64();
+#endif
   const double th0 = pose[p * 3 + 0], x0 = pose[p * 3 + 1], y0 = pose[p * 3 + 2];
   double s0, c0;
   sincos(th0, &s0, &c0);
@@ -280,65 +370,100 @@ __global__ __launch_bounds__(kProposeThreads) void rbpf_propose(ScanC c, const d
     for (int q = 0; q < 3; ++q) s[q] = mu0[q] + c.Ld[q] * z[3 * j + q];
     s[0] = normalize_angle_PI(s[0]);
     smp[3 * j + 0] = s[0]; smp[3 * j + 1] = s[1]; smp[3 * j + 2] = s[2];
+    double T[4];
+    sensor_transform(c, s[0], s[1], s[2], T);
+    for (int q = 0; q < 4; ++q) stf[4 * j + q] = T[q];
     ppose[j] = pose_likelihood_odom(c, s, pv, &var_err);
   }
   if (var_err) atomicOr(&err[2], 1);
-  if (nocc) {  // per-beam cache at the centre of the samples (T(pose)*T_icp)
-    double sc, cc;
-    sincos(mu0[0], &sc, &cc);
-    const double Xc = cc * c.Trs[1] - sc * c.Trs[2] + mu0[1], Yc = sc * c.Trs[1] + cc * c.Trs[2] + mu0[2];
-    double stc, ctc;
-    sincos(mu0[0] + c.Trs[0], &stc, &ctc);
-    for (int b = tid; b < c.Bv; b += kProposeThreads) {
+#ifdef TBNAV_PHASE_PROF
+  if (tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_phase_p[5], now_ - t_prev_); }
+#endif
+  if (nocc && wid > 0) {  // per-beam cache at the centre of the samples (T(pose)*T_icp); wave 0 is busy sampling
+    double Tc[4];
+    sensor_transform(c, mu0[0], mu0[1], mu0[2], Tc);
+    for (int b = tid - kWave; b < c.Bv; b += kProposeThreads - kWave) {
       const double2 pt = beams[b];
       int ci, cj;
-      unsigned int tag = 0xFFFFFFFFu;
+      unsigned int tag = 0xFFFFFFFFu, cell = 0xFFFFFFFFu;
       double pz = 0.0;
-      if (world2cell(c.g, ctc * pt.x - stc * pt.y + Xc, stc * pt.x + ctc * pt.y + Yc, ci, cj) && ci >= wn.x && ci <= wn.y &&
-          cj >= wn.z && cj <= wn.w) {
-        const uint16_t cd = code[(size_t)ci * c.g.xsize + cj];
+      uint16_t cd;
+      if (world2cell(c.g, Tc[3] * pt.x - Tc[2] * pt.y + Tc[0], Tc[2] * pt.x + Tc[3] * pt.y + Tc[1], ci, cj) &&
+          lookup_code(c.g, ds, radius, ci, cj, cd)) {
         tag = cd;
+        cell = (unsigned int)(ci * c.g.xsize + cj);
         pz = beam_mixture(c, cd);
       }
       ctag[b] = tag;
+      ccell[b] = cell;
       cpz[b] = pz;
     }
   }
   __syncthreads();
+  PHASE_STAMP_P(0);
 
   // ---- scan likelihood of every sample (:541): one wave per sample, lanes over beams
   for (int j = wid; j < k; j += kProposeThreads / kWave) {
-    const double sl = wave_scan_likelihood(c, beams, code, nocc, wn, smp[3 * j + 0], smp[3 * j + 1], smp[3 * j + 2], lane, &oob, ctag, cpz);
+    const double sl = wave_scan_likelihood_t(c, beams, ds, radius, nocc, stf[4 * j + 0], stf[4 * j + 1], stf[4 * j + 2],
+                                             stf[4 * j + 3], lane, &oob, ctag, ccell, cpz);
     if (lane == 0) pscan[j] = sl;
   }
   if (oob & 1) atomicOr(&err[0], 1);
   if (oob & 2) atomicOr(&err[3], 4);
   __syncthreads();
 
-  // ---- Gaussian proposal in the reference's sequential order (:522-599), new pose (:214-231)
+  // ---- Gaussian proposal (:522-599), new pose (:214-231).  The sums run in the reference's sequential order on
+  //      one thread; everything that is per-sample (clamps, products, outer products, trace) is done by the
+  //      sample's own thread so that the serial part is only the chains of adds.
+  PHASE_STAMP_P(1);
+  double* wj = stf;           // [k]    likelihoods.at(j)   (the sensor transforms are dead by now)
+  double* op = stf + k;       // [k][6] (d d^T)(r,q) * w_j, upper triangle — filled after mu is known
+  __shared__ double sh_mu[3], sh_eta;
+  __shared__ int sh_stop;
+  for (int j = tid; j < k; j += kProposeThreads) {
+    const double ps = fmin(fmax(pscan[j], c.scan_min), c.scan_max);  // std::clamp
+    const double pp = fmin(fmax(ppose[j], c.pose_min), c.pose_max);
+    tr.p_scan[(size_t)p * k + j] = pscan[j];
+    tr.p_pose[(size_t)p * k + j] = ppose[j];
+    tr.sampled[((size_t)p * k + j) * 3 + 0] = smp[3 * j + 0];
+    tr.sampled[((size_t)p * k + j) * 3 + 1] = smp[3 * j + 1];
+    tr.sampled[((size_t)p * k + j) * 3 + 2] = smp[3 * j + 2];
+    wj[j] = ps * pp;
+  }
+  __syncthreads();
   if (tid == 0) {
-    double mu[3] = {0.0, 0.0, 0.0}, sigma[3][3] = {{0.0}}, eta = 0.0;
+    double mu[3] = {0.0, 0.0, 0.0}, eta = 0.0;
     for (int j = 0; j < k; ++j) {
-      const double ps = fmin(fmax(pscan[j], c.scan_min), c.scan_max);  // std::clamp
-      const double pp = fmin(fmax(ppose[j], c.pose_min), c.pose_max);
-      const double pj = ps * pp;
-      tr.p_scan[(size_t)p * k + j] = pscan[j];
-      tr.p_pose[(size_t)p * k + j] = ppose[j];
-      tr.sampled[((size_t)p * k + j) * 3 + 0] = smp[3 * j + 0];
-      tr.sampled[((size_t)p * k + j) * 3 + 1] = smp[3 * j + 1];
-      tr.sampled[((size_t)p * k + j) * 3 + 2] = smp[3 * j + 2];
-      pscan[j] = pj;  // likelihoods.at(i)
+      const double pj = wj[j];
       for (int q = 0; q < 3; ++q) mu[q] += smp[3 * j + q] * pj;
       eta += pj;
     }
-    if (almost_equal(eta, 0.0)) { atomicOr(&err[1], 1); return; }
-    for (int q = 0; q < 3; ++q) mu[q] /= eta;
-    mu[0] = normalize_angle_PI(mu[0]);
-    for (int j = 0; j < k; ++j) {
-      const double d[3] = {smp[3 * j + 0] - mu[0], smp[3 * j + 1] - mu[1], smp[3 * j + 2] - mu[2]};
-      for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) sigma[r][q] += (d[r] * d[q]) * pscan[j];
+    const int stop = almost_equal(eta, 0.0) ? 1 : 0;
+    if (stop) atomicOr(&err[1], 1);
+    else {
+      for (int q = 0; q < 3; ++q) mu[q] /= eta;
+      mu[0] = normalize_angle_PI(mu[0]);
     }
-    for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) sigma[r][q] /= eta;
+    sh_mu[0] = mu[0]; sh_mu[1] = mu[1]; sh_mu[2] = mu[2]; sh_eta = eta; sh_stop = stop;
+  }
+  __syncthreads();
+  if (sh_stop) return;
+  for (int j = tid; j < k; j += kProposeThreads) {
+    const double d[3] = {smp[3 * j + 0] - sh_mu[0], smp[3 * j + 1] - sh_mu[1], smp[3 * j + 2] - sh_mu[2]};
+    const double w = wj[j];
+    int o = 0;
+    for (int r = 0; r < 3; ++r) for (int q = r; q < 3; ++q) op[6 * j + o++] = (d[r] * d[q]) * w;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const double mu[3] = {sh_mu[0], sh_mu[1], sh_mu[2]}, eta = sh_eta;
+    double su[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < k; ++j) for (int o = 0; o < 6; ++o) su[o] += op[6 * j + o];
+    double sigma[3][3];
+    {
+      int o = 0;
+      for (int r = 0; r < 3; ++r) for (int q = r; q < 3; ++q) { sigma[r][q] = su[o] / eta; sigma[q][r] = sigma[r][q]; ++o; }
+    }
     double L[3][3];
     llt3(sigma, L);
     const double* zz = z + 3 * k;
@@ -352,6 +477,10 @@ __global__ __launch_bounds__(kProposeThreads) void rbpf_propose(ScanC c, const d
     weight[p] = w;
     tr.weight_raw[p] = w;
   }
+  PHASE_STAMP_P(2);
+#ifdef TBNAV_PHASE_PROF
+  if (tid == 0) atomicAdd(&g_phase_p[7], 1ull);
+#endif
 }
 
 // ---- raycast ---------------------------------------------------------------------------------------
@@ -491,84 +620,209 @@ __device__ __forceinline__ bool on_ray(const Ray& r, int cx, int cy) {
 }
 
 // Tile version of the raycast (the default): no per-beam barrier.
-//  1. every (beam, step) pair bumps a 16-bit counter of its cell in an LDS tile covering the scan's
-//     bounding box (<= (2*range_max/res + 3)^2 cells) — order-free, LDS atomics;
-//  2. cells that are some beam's END POINT (<= Bv of them; they are the only cells that see both kinds
-//     of update in one scan, and there the floating-point add order matters) are replayed by one lane
-//     each: beams 0..Bv-1 in order, "+= l_free" if the cell is on the beam's free ray, "+= l_occ" if
-//     it is the beam's end point — exactly the reference's sequence for that cell;
+//  F. every distinct END-POINT cell (<= Bv of them; the only cells that see both kinds of update in one scan,
+//     and there the floating-point add order matters) is flagged in an LDS tile covering the scan's bounding
+//     box (<= (2*range_max/res + 3)^2 cells) and gets a slot: a short list of (beam, kind) events;
+//  1. every (beam, step) pair looks at its cell in the tile: a plain cell bumps its 15-bit counter (order-free
+//     LDS atomic), a flagged cell records the event "beam b, free" in the cell's slot; every beam also records
+//     "beam b, occupied" in its own end point's slot;
+//  2. one LANE per end-point cell replays its slot in beam order ("+= l_free" / "+= l_occ": exactly the
+//     reference's sequence of adds for that cell).  A slot that overflowed (kEvCap events; e.g. the robot's
+//     own cell) is replayed by a whole wave instead, which tests the cell against every beam;
 //  3. every other touched cell gets its count of "+= l_free" (same addend each time, so the order among
 //     them is immaterial) — bit-identical to the beam-ordered loop, checked against it and the oracle.
-// LDS: ex[Bv], ey[Bv] (int) | tile u32[(cap+1)/2] (two 16-bit counters per word; bit 15 = end-point flag).
-__global__ __launch_bounds__(512) void rbpf_raycast_tile(ScanC c, const double2* __restrict__ beams,
-                                                         const double* __restrict__ pose, double* __restrict__ log_odds,
-                                                         unsigned long long* __restrict__ bitmap, int* __restrict__ row_count,
-                                                         int* __restrict__ n_occ, int* __restrict__ err, int tile_cap) {
+// LDS (ints): ex ey own rk rxy rdd ecnt [Bv each] | ev u16[Bv][kEvCap] | tile u32[(cap+1)/2] (two 16-bit
+// halves per word: bit 15 = end-point flag, low 15 bits = free-add count, or the slot index when flagged).
+constexpr int kEvCap = 16;
+constexpr int kTileIntsPerBeam = 7 + kEvCap / 2;
+// Packed ray for the counting pass.  Every ray is written in the form of the reference's plotLineLow / plotLineHigh
+// cases: a major axis, a start (xa, ya) at the low end of that axis, dmaj steps along it, and the minor offset
+// c_t of ray_cell.  The vertical / horizontal / diagonal cases fit the same form with dmin = 0 / 0 / dmaj
+// (a = 2*dmin*t - dmaj gives c_t = 0 and c_t = t), and the SET of free cells is the same: the robot cell plus the
+// cells strictly between the two ends (the counting pass is order-free; ordered work uses Ray/on_ray).
+//   k  = ymajor | (sgn < 0) << 1 | count << 8        xy = xa | ya << 16        dd = dmaj | dmin << 16
+__device__ __forceinline__ void pack_ray(const Ray& r, int x1, int y1, int& k, int& xy, int& dd) {
+  int ymajor = (r.kind == 3), xa = r.xa, ya = r.ya, dmaj = r.dmaj, dmin = r.dmin, sgn = r.sgn;
+  if (r.kind == 0) { ymajor = 1; xa = r.x0; ya = r.y0 < y1 ? r.y0 : y1; dmaj = r.count; dmin = 0; sgn = 1; }
+  if (r.kind == 1) { ymajor = 0; ya = r.y0; xa = r.x0 < x1 ? r.x0 : x1; dmaj = r.count; dmin = 0; sgn = 1; }
+  if (r.kind == 4) {
+    ymajor = 0; dmaj = r.count; dmin = r.count;
+    if (r.x0 < x1) { xa = r.x0; ya = r.y0; sgn = (y1 < r.y0) ? -1 : 1; } else { xa = x1; ya = y1; sgn = (r.y0 < y1) ? -1 : 1; }
+  }
+  k = ymajor | (sgn < 0 ? 2 : 0) | (r.count << 8);
+  xy = xa | (ya << 16);
+  dd = dmaj | (dmin << 16);
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off, 64); v = o < v ? o : v; }
+  return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
+  return v;
+}
+__global__ __launch_bounds__(1024, 8) void rbpf_raycast_tile(ScanC c, const double2* __restrict__ beams,
+                                                          const double* __restrict__ pose, double* __restrict__ log_odds,
+                                                          unsigned long long* __restrict__ bitmap, int* __restrict__ row_count,
+                                                          int* __restrict__ n_occ, int* __restrict__ err, int tile_cap) {
   extern __shared__ __attribute__((aligned(16))) int lds_i[];
+  const int Bv = c.Bv;
   int* ex = lds_i;
-  int* ey = lds_i + c.Bv;
-  unsigned int* tile = reinterpret_cast<unsigned int*>(lds_i + 2 * c.Bv);
-  __shared__ int bad, bx0, bx1, by0, by1;
+  int* ey = ex + Bv;
+  int* own = ey + Bv;    // [n_own] a beam ending in the slot's cell
+  int* rk = own + Bv;    // packed rays
+  int* rxy = rk + Bv;
+  int* rdd = rxy + Bv;
+  int* ecnt = rdd + Bv;  // [n_own] events recorded (may exceed kEvCap: overflow)
+  unsigned short* ev = reinterpret_cast<unsigned short*>(ecnt + Bv);  // [n_own][kEvCap]  beam | 0x8000 if occupied
+  unsigned int* tile = reinterpret_cast<unsigned int*>(lds_i + kTileIntsPerBeam * Bv);
+  __shared__ int bad, bx0, bx1, by0, by1, n_own, srx, sry;
   const int p = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave, nw = blockDim.x / kWave;
+  const int nthr = blockDim.x;
+#ifdef TBNAV_PHASE_PROF
+  unsigned long long t_prev_ = wall_clock64();
+#endif
   double* lo = log_odds + (size_t)p * c.g.xsize * c.g.ysize;
   unsigned long long* bm = bitmap + (size_t)p * c.g.xsize * c.g.words;
   int* rc = row_count + (size_t)p * c.g.xsize;
   int* nocc = n_occ + p;
-  const double th = pose[p * 3 + 0], x = pose[p * 3 + 1], y = pose[p * 3 + 2];
-  int rx = 0, ry = 0;
-  const bool robot_ok = world2cell(c.g, x, y, rx, ry);  // freeGridIndex: world2Grid of the ROBOT pose (:558)
-  if (tid == 0) { bad = robot_ok ? 0 : 1; bx0 = bx1 = rx; by0 = by1 = ry; }
+  // wave 0 derives everything that depends only on the particle's pose (two sincos, two divisions) while the
+  // other waves clear the tile: 16 waves repeating that arithmetic would cost more issue slots than the rest
+  // of the set-up together
+  __shared__ double sh_pose[4];  // X, Y, sin, cos of Tms = T(pose) * Trs
+  if (wid == 0) {
+    const double th = pose[p * 3 + 0], x = pose[p * 3 + 1], y = pose[p * 3 + 2];
+    int rx0 = 0, ry0 = 0;
+    const bool robot_ok = world2cell(c.g, x, y, rx0, ry0);  // freeGridIndex: world2Grid of the ROBOT pose (:558)
+    double s0, c0, st0, ct0;
+    sincos(th, &s0, &c0);
+    sincos(th + c.Trs[0], &st0, &ct0);
+    if (lane == 0) {
+      sh_pose[0] = c0 * c.Trs[1] - s0 * c.Trs[2] + x;
+      sh_pose[1] = s0 * c.Trs[1] + c0 * c.Trs[2] + y;
+      sh_pose[2] = st0; sh_pose[3] = ct0;
+      bad = robot_ok ? 0 : 1; bx0 = bx1 = rx0; by0 = by1 = ry0; n_own = 0; srx = rx0; sry = ry0;
+    }
+  } else {
+    for (int t = tid - kWave; t < (tile_cap + 1) / 2; t += nthr - kWave) tile[t] = 0u;
+    for (int b = tid - kWave; b < Bv; b += nthr - kWave) ecnt[b] = 0;
+  }
   __syncthreads();
-  double s0, c0;
-  sincos(th, &s0, &c0);
-  const double X = c0 * c.Trs[1] - s0 * c.Trs[2] + x;
-  const double Y = s0 * c.Trs[1] + c0 * c.Trs[2] + y;
-  double st, ct;
-  sincos(th + c.Trs[0], &st, &ct);
-  for (int b = tid; b < c.Bv; b += blockDim.x) {
-    const double2 pt = beams[b];
-    int ci = rx, cj = ry;
-    if (!world2cell(c.g, ct * pt.x - st * pt.y + X, st * pt.x + ct * pt.y + Y, ci, cj)) { bad = 1; ci = rx; cj = ry; }
-    ex[b] = ci; ey[b] = cj;
-    atomicMin(&bx0, ci); atomicMax(&bx1, ci); atomicMin(&by0, cj); atomicMax(&by1, cj);
+  const int rx = srx, ry = sry;
+  {
+    const double X = sh_pose[0], Y = sh_pose[1], st = sh_pose[2], ct = sh_pose[3];
+    for (int b0 = wid * kWave; b0 < Bv; b0 += nthr) {
+      const int b = b0 + lane;
+      int ci = rx, cj = ry;
+      if (b < Bv) {
+        const double2 pt = beams[b];
+        if (!world2cell(c.g, ct * pt.x - st * pt.y + X, st * pt.x + ct * pt.y + Y, ci, cj)) { bad = 1; ci = rx; cj = ry; }
+        ex[b] = ci; ey[b] = cj;
+        int k, xy, dd;
+        pack_ray(make_ray(rx, ry, ci, cj), ci, cj, k, xy, dd);
+        rk[b] = k; rxy[b] = xy; rdd[b] = dd;
+      }
+      const int lo_x = wave_min_i(ci), hi_x = wave_max_i(ci), lo_y = wave_min_i(cj), hi_y = wave_max_i(cj);
+      if (lane == 0) { atomicMin(&bx0, lo_x); atomicMax(&bx1, hi_x); atomicMin(&by0, lo_y); atomicMax(&by1, hi_y); }
+    }
   }
   __syncthreads();
   if (bad) { if (tid == 0) atomicOr(&err[0], 1); return; }
   const int minx = bx0, miny = by0, bw = by1 - by0 + 1, bh = bx1 - bx0 + 1, ncell = bw * bh;
   if (ncell > tile_cap) { if (tid == 0) atomicOr(&err[3], 2); return; }  // cannot happen for beams within range_max
-  for (int t = tid; t < (ncell + 1) / 2; t += blockDim.x) tile[t] = 0u;
-  __syncthreads();
   const int xs = c.g.xsize;
-  // 1. counters
-  for (int b = wid; b < c.Bv; b += nw) {
-    const Ray r = make_ray(rx, ry, ex[b], ey[b]);
-    for (int n = lane; n < r.count; n += kWave) {
-      int cx, cy;
-      ray_cell(r, n, cx, cy);
-      const int t = (cx - minx) * bw + (cy - miny);
-      atomicAdd(&tile[t >> 1], (t & 1) ? 0x10000u : 1u);
+  PHASE_STAMP(0);
+  // F. flag the end-point cells; the beam that finds the flag clear opens the cell's slot
+  for (int b = tid; b < Bv; b += nthr) {
+    const int t = (ex[b] - minx) * bw + (ey[b] - miny), sh = (t & 1) * 16;
+    if (!((atomicOr(&tile[t >> 1], 0x8000u << sh) >> sh) & 0x8000u)) {
+      const int o = atomicAdd(&n_own, 1);
+      own[o] = b;
+      atomicOr(&tile[t >> 1], (unsigned int)o << sh);
     }
   }
-  for (int b = tid; b < c.Bv; b += blockDim.x) {
-    const int t = (ex[b] - minx) * bw + (ey[b] - miny);
-    atomicOr(&tile[t >> 1], (t & 1) ? 0x80000000u : 0x8000u);
-  }
   __syncthreads();
-  // 2. end-point cells, replayed in beam order by the lane of the FIRST beam that ends there
-  for (int b = tid; b < c.Bv; b += blockDim.x) {
-    const int cx = ex[b], cy = ey[b];
-    bool first = true;
-    for (int q = 0; q < b; ++q) if (ex[q] == cx && ey[q] == cy) { first = false; break; }
-    if (!first) continue;
+  for (int b = tid; b < Bv; b += nthr) {
+    const int t = (ex[b] - minx) * bw + (ey[b] - miny);
+    const int o = (int)((tile[t >> 1] >> ((t & 1) * 16)) & 0x7FFFu);
+    const int e = atomicAdd(&ecnt[o], 1);
+    if (e < kEvCap) ev[o * kEvCap + e] = (unsigned short)(b | 0x8000);
+  }
+  PHASE_STAMP(1);
+  // 1. counters / events: one LANE per ray segment.  A lane finds its first cell in closed form (one division)
+  //    and then walks the ray with the integer error recurrence that the closed form solves:
+  //      rem_t = a_t - 2*dmaj*(c_t - 1) in (0, 2*dmaj];   rem += 2*dmin;  if (rem > 2*dmaj) { ++c; rem -= 2*dmaj; }
+  //    — a handful of integer instructions per cell instead of a division per cell.  Lanes of one wave take rays
+  //    spread round the scan (b = lane * G + ...), so that they rarely meet in the same LDS word near the robot.
+  {
+    int S = Bv > 0 ? nthr / Bv : 1;  // segments per ray: as many as give every thread at most one task
+    S = S < 1 ? 1 : (S > 4 ? 4 : S);
+    const int G = (Bv + kWave - 1) / kWave;
+    const int t_robot = (rx - minx) * bw + (ry - miny);
+    auto visit = [&](int t, int b) {
+      const int sh = (t & 1) * 16;
+      const unsigned int hlf = tile[t >> 1] >> sh;  // the flag and slot bits are final since the barrier above
+      if (hlf & 0x8000u) {
+        const int o = (int)(hlf & 0x7FFFu);
+        const int e = atomicAdd(&ecnt[o], 1);
+        if (e < kEvCap) ev[o * kEvCap + e] = (unsigned short)b;
+      } else {
+        atomicAdd(&tile[t >> 1], 1u << sh);
+      }
+    };
+    for (int task = tid; task < kWave * G * S; task += nthr) {
+      const int tb = floor_div_small(task, S), sgm = task - tb * S;
+      const int b = (tb & (kWave - 1)) * G + (tb >> 6);
+      if (b >= Bv) continue;
+      const int k = rk[b], xy = rxy[b], dd = rdd[b];
+      const int count = k >> 8, L = floor_div_small(count + S - 1, S);
+      int n = sgm * L;
+      const int n1 = (n + L < count) ? n + L : count;
+      if (n >= n1) continue;
+      const int xa = xy & 0xFFFF, ya = xy >> 16, dmaj = dd & 0xFFFF, dmin = dd >> 16;
+      const bool ymajor = k & 1, neg = k & 2;
+      const int a0 = 2 * dmin * n - dmaj;
+      const int c0 = a0 > 0 ? floor_div_small(a0 + 2 * dmaj - 1, 2 * dmaj) : 0;  // operands < 2^24
+      int rem = a0 - 2 * dmaj * (c0 - 1);
+      const int sc = neg ? -c0 : c0;
+      int t = ((ymajor ? xa + sc : xa + n) - minx) * bw + ((ymajor ? ya + n : ya + sc) - miny);
+      const int d_major = ymajor ? 1 : bw, d_minor = (ymajor ? bw : 1) * (neg ? -1 : 1);
+      const int two_dmin = 2 * dmin, two_dmaj = 2 * dmaj;
+      if (n == 0) {  // the first free cell is the robot's own cell (for a reversed ray, step 0 is the end point)
+        visit(t_robot, b);
+        rem += two_dmin; t += d_major;
+        if (rem > two_dmaj) { rem -= two_dmaj; t += d_minor; }
+        ++n;
+      }
+      for (; n < n1; ++n) {
+        visit(t, b);
+        rem += two_dmin; t += d_major;
+        if (rem > two_dmaj) { rem -= two_dmaj; t += d_minor; }
+      }
+    }
+  }
+  __syncthreads();  // every event is recorded
+  PHASE_STAMP(2);
+  // 2a. end-point cells whose slot holds every event: one lane each, events applied in beam order
+  const int n_cells = n_own;
+  for (int o = tid; o < n_cells; o += nthr) {
+    const int ne = ecnt[o];
+    if (ne > kEvCap) continue;
+    const int cx = ex[own[o]], cy = ey[own[o]];
     const size_t idx = (size_t)cx * xs + cy;
     const double v0 = lo[idx];
     double v = v0;
-    for (int q = 0; q < c.Bv; ++q) {
-      const int qx = ex[q], qy = ey[q];
-      if (qx == cx && qy == cy) { v += c.d_occ; continue; }  // the end point is never one of its own ray's free cells
-      // cheap reject: a ray only visits cells inside the box spanned by the robot cell and its end point
-      if ((cx < rx && cx < qx) || (cx > rx && cx > qx) || (cy < ry && cy < qy) || (cy > ry && cy > qy)) continue;
-      if (on_ray(make_ray(rx, ry, qx, qy), cx, cy)) v += c.d_free;
+    int last = -1;
+    for (int i = 0; i < ne; ++i) {  // selection by ascending beam (ne is a handful)
+      int best_key = 0x8000, best_ev = 0;
+      for (int j = 0; j < ne; ++j) {
+        const int e = ev[o * kEvCap + j], key = e & 0x7FFF;
+        if (key > last && key < best_key) { best_key = key; best_ev = e; }
+      }
+      v += (best_ev & 0x8000) ? c.d_occ : c.d_free;
+      last = best_key;
     }
     lo[idx] = v;
     const bool was = v0 >= c.cut_occ, now = v >= c.cut_occ;
@@ -578,42 +832,101 @@ __global__ __launch_bounds__(512) void rbpf_raycast_tile(ScanC c, const double2*
       atomicAdd(nocc, now ? 1 : -1);
     }
   }
-  // 3. every other touched cell: its count of free adds.  Four cells per thread per trip so that the four
-  //    (independent) log-odds loads are in flight together instead of one exposed L2 round trip per cell.
-  for (int t0 = tid * 4; t0 < ncell; t0 += blockDim.x * 4) {
-    int cn[4];
-    size_t idx[4];
-    double v0[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int t = t0 + q;
-      cn[q] = 0;
-      idx[q] = 0;
-      if (t < ncell) {
-        const unsigned int word = tile[t >> 1];
-        const unsigned int hlf = (t & 1) ? (word >> 16) : (word & 0xFFFFu);
-        if (!(hlf & 0x8000u)) cn[q] = (int)(hlf & 0x7FFFu);
-        const int tr = floor_div_small(t, bw);  // t < 2^15, bw < 2^8
-        idx[q] = (size_t)(minx + tr) * xs + (miny + (t - tr * bw));
+  // 2b. overflowed slots: one wave per cell.  Lanes test beams q = 64*i + lane against the cell (is it q's end
+  //     point / one of q's free cells); the two ballots are the cell's update sequence for those 64 beams,
+  //     replayed in bit (= beam) order.  Pre-filter: Bresenham cells lie within half a cell of the line
+  //     robot -> end point, so a cell whose perpendicular distance to that line exceeds ONE cell
+  //     (cross^2 > |d|^2, exact in f64) cannot be on the ray.
+  const int trips = (Bv + kWave - 1) / kWave;
+  for (int o = wid; o < n_cells; o += nw) {
+    if (ecnt[o] <= kEvCap) continue;
+    const int cx = ex[own[o]], cy = ey[own[o]];
+    const size_t idx = (size_t)cx * xs + cy;
+    const double v0 = lo[idx];
+    double v = v0;
+    const int ux = cx - rx, uy = cy - ry;
+    for (int i = 0; i < trips; ++i) {
+      const int q = i * kWave + lane;
+      bool is_end = false, hit = false;
+      if (q < Bv) {
+        const int qx = ex[q], qy = ey[q];
+        is_end = (qx == cx) && (qy == cy);  // the end point is never one of its own ray's free cells
+        const int dx = qx - rx, dy = qy - ry;
+        const double cr = (double)(ux * dy - uy * dx), l2 = (double)(dx * dx + dy * dy);
+        // a ray only visits cells inside the box spanned by the robot cell and its end point
+        const bool outside = (cx < rx && cx < qx) || (cx > rx && cx > qx) || (cy < ry && cy < qy) || (cy > ry && cy > qy);
+        if (!is_end && !outside && cr * cr <= l2) hit = on_ray(make_ray(rx, ry, qx, qy), cx, cy);
+      }
+      const unsigned long long occm = __ballot(is_end), freem = __ballot(hit);
+      unsigned long long m = occm | freem;
+      while (m) {
+        const int bit = __ffsll((long long)m) - 1;
+        v += ((occm >> bit) & 1ull) ? c.d_occ : c.d_free;
+        m &= m - 1;
       }
     }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) v0[q] = cn[q] ? lo[idx[q]] : 0.0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (!cn[q]) continue;
-      double v = v0[q];
-      for (int a = 0; a < cn[q]; ++a) v += c.d_free;
-      lo[idx[q]] = v;
-      const bool was = v0[q] >= c.cut_occ, now = v >= c.cut_occ;
+    if (lane == 0) {
+      lo[idx] = v;
+      const bool was = v0 >= c.cut_occ, now = v >= c.cut_occ;
       if (was != now) {
-        const int t = t0 + q, tr = floor_div_small(t, bw), cx = minx + tr, cy = miny + (t - tr * bw);
         atomicXor(&bm[(size_t)cx * c.g.words + (cy >> 6)], 1ull << (cy & 63));
         atomicAdd(&rc[cx], now ? 1 : -1);
         atomicAdd(nocc, now ? 1 : -1);
       }
     }
   }
+  PHASE_STAMP(3);
+  // 3. every other touched cell: its count of free adds.  Eight cells per thread per trip (lanes on consecutive
+  //    cells, the eight a whole block apart) so that the eight independent log-odds loads are in flight
+  //    together instead of one exposed HBM round trip per cell.
+  constexpr int kPer = 8;
+  const int step_r = floor_div_small(nthr, bw), step_c = nthr - step_r * bw;  // cell t + nthr in (row, col) terms
+  for (int base = 0; base < ncell; base += nthr * kPer) {
+    int cn[kPer];
+    size_t idx[kPer];
+    double v0[kPer];
+    const int t0 = base + tid;
+    int trow = floor_div_small(t0 < ncell ? t0 : 0, bw), tcol = (t0 < ncell ? t0 : 0) - trow * bw;  // t < 2^15, bw < 2^8
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+      const int t = t0 + q * nthr;
+      cn[q] = 0;
+      idx[q] = 0;
+      if (t < ncell) {
+        const unsigned int hlf = (tile[t >> 1] >> ((t & 1) * 16)) & 0xFFFFu;
+        if (!(hlf & 0x8000u)) cn[q] = (int)hlf;
+        idx[q] = (size_t)(minx + trow) * xs + (miny + tcol);
+      }
+      trow += step_r; tcol += step_c;
+      if (tcol >= bw) { tcol -= bw; ++trow; }
+    }
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) v0[q] = cn[q] ? lo[idx[q]] : 0.0;
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+      if (!cn[q]) continue;
+      double v = v0[q];
+      int a = 0;
+      for (; a + 4 <= cn[q]; a += 4) { v += c.d_free; v += c.d_free; v += c.d_free; v += c.d_free; }
+      for (; a < cn[q]; ++a) v += c.d_free;
+      lo[idx[q]] = v;
+      const bool was = v0[q] >= c.cut_occ, now = v >= c.cut_occ;
+      if (was != now) {
+        const int t = t0 + q * nthr, tr = floor_div_small(t, bw), cx = minx + tr, cy = miny + (t - tr * bw);
+        atomicXor(&bm[(size_t)cx * c.g.words + (cy >> 6)], 1ull << (cy & 63));
+        atomicAdd(&rc[cx], now ? 1 : -1);
+        atomicAdd(nocc, now ? 1 : -1);
+      }
+    }
+  }
+  PHASE_STAMP(4);
+#ifdef TBNAV_PHASE_PROF
+  if (tid == 0) {
+    int novf = 0;
+    for (int o = 0; o < n_cells; ++o) novf += ecnt[o] > kEvCap;
+    atomicAdd(&g_phase[5], (unsigned long long)novf); atomicAdd(&g_phase[6], (unsigned long long)n_cells); atomicAdd(&g_phase[7], 1ull);
+  }
+#endif
 }
 
 // ---- occupancy bitmap ------------------------------------------------------------------------------
@@ -647,7 +960,7 @@ __global__ __launch_bounds__(256) void rbpf_occupancy(GridC g, double cut_occ, i
 // lookup of that call (checked in the likelihood: a miss is reported, never read stale); the whole field of a
 // particle is produced on demand (tbnav_rbpf_get_occ_dist / get_dist_code, particle export).
 // state[p]: 0 = bitmap changed since the last transform, 1 = window fresh, 2 = whole field fresh (or injected).
-__global__ void rbpf_window(GridC g, int N, int half_cells, const double* __restrict__ pose, int* __restrict__ state,
+__global__ void rbpf_window(GridC g, int N, int half_cells, int mark_fresh, const double* __restrict__ pose, int* __restrict__ state,
                             int* __restrict__ skip, int4* __restrict__ win) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= N) return;
@@ -660,7 +973,7 @@ __global__ void rbpf_window(GridC g, int N, int half_cells, const double* __rest
       w.x = max(0, ci - half_cells); w.y = min(g.xsize - 1, ci + half_cells);
       w.z = max(0, cj - half_cells); w.w = min(g.ysize - 1, cj + half_cells);
     }
-    state[p] = 1;
+    if (mark_fresh) state[p] = 1;
   }
   win[p] = w;
 }
@@ -1079,8 +1392,10 @@ struct tbnav_rbpf {
   double* d_best_pose = nullptr;
   int8_t* d_export = nullptr;  // [G]
   int tile_cap = 0;            // cells of the raycast LDS tile (0 = use the beam-ordered kernel)
+  int raycast_threads = 1024;  // block size of the tile raycast (dev switch TBNAV_RBPF_RAYCAST_THREADS)
   uint64_t seed = 0x5EEDull, scan_index = 0;  // device noise source (normals == NULL)
-  bool full_edt = false;       // TBNAV_RBPF_FULL_EDT=1: whole-map distance transform after every map update
+  bool full_edt = false;       // distance-field mode 0 (TBNAV_RBPF_DF=full): whole-map transform after every map update
+  int df_mode = 2;             // 0 full, 1 windowed refresh before the update (TBNAV_RBPF_DF=window), 2 exact query at lookup (default)
   int* d_fstate = nullptr;     // [N] distance-field state: 0 stale, 1 window fresh, 2 whole field fresh / injected
   int* d_skip = nullptr;       // [N] scratch: 1 = no refresh needed this call
   int4* d_win = nullptr;       // [N] refreshed window (i0, i1, j0, j1), inclusive
@@ -1160,7 +1475,7 @@ int build_scan_consts(tbnav_rbpf* h, ScanC& c, const float* scan, int n_beams, c
                       const double cur_odom[3], const double prev_odom[3], int icp_ok, const double T_icp[3],
                       std::vector<double2>& beams) {
   const tbnav_rbpf_params& P = h->p;
-  c.g = GridC{P.xmin, P.xmax, P.ymin, P.ymax, P.resolution, h->xsize, h->ysize, h->words, h->max_occ_dist};
+  c.g = GridC{P.xmin, P.xmax, P.ymin, P.ymax, P.resolution, h->xsize, h->ysize, h->words, h->max_occ_dist, 1.0 / P.resolution};
   c.N = h->N; c.k = h->k; c.icp_ok = icp_ok ? 1 : 0;
   for (int q = 0; q < 3; ++q) { c.Trs[q] = P.Trs[q]; c.Ld[q] = std::sqrt(P.sample_range[q]); c.Lm[q] = std::sqrt(P.motion_noise[q]);
                                 c.Ticp[q] = T_icp[q]; c.u[q] = u[q]; }
@@ -1228,7 +1543,7 @@ int run_distance_field(tbnav_rbpf* h, const GridC& g, int p0, int count, int til
 }
 
 GridC grid_of(const tbnav_rbpf* h) {
-  return GridC{h->p.xmin, h->p.xmax, h->p.ymin, h->p.ymax, h->p.resolution, h->xsize, h->ysize, h->words, h->max_occ_dist};
+  return GridC{h->p.xmin, h->p.xmax, h->p.ymin, h->p.ymax, h->p.resolution, h->xsize, h->ysize, h->words, h->max_occ_dist, 1.0 / h->p.resolution};
 }
 
 // Whole-field refresh of ONE particle, on demand (state 2 afterwards).
@@ -1299,25 +1614,26 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
     const double half = (double)h->p.range_max + std::hypot(h->p.Trs[1], h->p.Trs[2]) + move + 8.0 * std::sqrt(sig);
     int half_cells = (int)std::ceil(half / h->p.resolution) + 3;
     if (h->full_edt || half_cells > h->xsize) half_cells = h->xsize;  // whole map
-    hipLaunchKernelGGL(rbpf_window, dim3((h->N + 255) / 256), dim3(256), 0, st, c.g, h->N, half_cells, sp.pose, h->d_fstate,
-                       h->d_skip, h->d_win);
+    hipLaunchKernelGGL(rbpf_window, dim3((h->N + 255) / 256), dim3(256), 0, st, c.g, h->N, half_cells, h->df_mode == 1 ? 1 : 0,
+                       sp.pose, h->d_fstate, h->d_skip, h->d_win);
     TBNAV_HIP(hipGetLastError());
-    if (!h->full_edt) {
+    if (h->df_mode == 1) {
       const int tiles = std::min((2 * half_cells + 1 + kWave - 1) / kWave + 1, (h->ysize + kWave - 1) / kWave);
       rc = run_distance_field(h, c.g, 0, h->N, tiles);
       if (rc != TBNAV_OK) return rc;
     }
   }
   TBNAV_HIP(hipEventRecord(h->ev[1], st));
-  hipLaunchKernelGGL(rbpf_propose, dim3(h->N), dim3(kProposeThreads), sizeof(double) * (5 * h->k + (c.Bv > 0 ? c.Bv : 1)) + sizeof(unsigned int) * (c.Bv > 0 ? c.Bv : 1), st, c, h->d_beams,
-                     h->d_code[h->cur], h->d_nocc[h->cur], h->d_win, h->d_normals, sp.pose, sp.prev, sp.weight, h->tr, h->d_err);
+  hipLaunchKernelGGL(rbpf_propose, dim3(h->N), dim3(kProposeThreads), sizeof(double) * (12 * h->k + (c.Bv > 0 ? c.Bv : 1)) + sizeof(unsigned int) * 2 * (c.Bv > 0 ? c.Bv : 1), st, c, h->d_beams,
+                     h->d_code[h->cur], h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_skip, h->df_mode, h->radius,
+                     h->d_nocc[h->cur], h->d_win, h->d_normals, sp.pose, sp.prev, sp.weight, h->tr, h->d_err);
   TBNAV_HIP(hipGetLastError());
   TBNAV_HIP(hipEventRecord(h->ev[2], st));
   {
     const int bvn = c.Bv > 0 ? c.Bv : 1;
-    const size_t tile_lds = sizeof(int) * 2 * bvn + sizeof(unsigned int) * ((size_t)(h->tile_cap + 1) / 2);
-    if (h->tile_cap > 0 && c.Bv < 32768 && tile_lds <= 64 * 1024)
-      hipLaunchKernelGGL(rbpf_raycast_tile, dim3(h->N), dim3(512), tile_lds, st, c, h->d_beams, sp.pose, h->d_log_odds[h->cur],
+    const size_t tile_lds = sizeof(int) * kTileIntsPerBeam * bvn + sizeof(unsigned int) * ((size_t)(h->tile_cap + 1) / 2);
+    if (h->tile_cap > 0 && c.Bv < 32768 && tile_lds <= (size_t)kMaxLds - 1024)
+      hipLaunchKernelGGL(rbpf_raycast_tile, dim3(h->N), dim3(h->raycast_threads), tile_lds, st, c, h->d_beams, sp.pose, h->d_log_odds[h->cur],
                          h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_nocc[h->cur], h->d_err, h->tile_cap);
     else
       hipLaunchKernelGGL(rbpf_raycast, dim3(h->N), dim3(kWave), sizeof(int) * 2 * bvn, st, c, h->d_beams, sp.pose,
@@ -1441,7 +1757,16 @@ int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) {
     const long side = 2 * ((long)std::ceil(reach / P->resolution) + 2) + 1;
     h->tile_cap = (side * side <= 30000) ? (int)(side * side) : 0;
     if (const char* e = std::getenv("TBNAV_RBPF_RAYCAST_ORDERED")) if (std::atoi(e) == 1) h->tile_cap = 0;
-    if (const char* e = std::getenv("TBNAV_RBPF_FULL_EDT")) h->full_edt = std::atoi(e) == 1;
+    if (const char* e = std::getenv("TBNAV_RBPF_RAYCAST_THREADS")) {
+      const int t = std::atoi(e);
+      if (t == 256 || t == 512 || t == 1024) h->raycast_threads = t;
+    }
+    if (const char* e = std::getenv("TBNAV_RBPF_FULL_EDT")) if (std::atoi(e) == 1) h->df_mode = 0;
+    if (const char* e = std::getenv("TBNAV_RBPF_DF")) {
+      const std::string v(e);
+      h->df_mode = (v == "full") ? 0 : (v == "window") ? 1 : 2;
+    }
+    h->full_edt = h->df_mode == 0;
   }
   // log-odds constants with the host libm, exactly as the reference's ctor (grid_mapper.cpp:42-47)
   h->l_prior = std::log(0.5 / (1 - 0.5));
@@ -1514,6 +1839,7 @@ int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) {
     e = (C == 64) ? hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_edt<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)
                   : hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_edt<32>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_tile), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_edt_compact<kEdtRowsA>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)edt_compact_lds(kEdtRowsA));
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_edt_compact<kEdtRowsB>),
@@ -1531,6 +1857,10 @@ int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) {
 }
 
 void tbnav_rbpf_destroy(tbnav_rbpf* h) {
+#ifdef TBNAV_PHASE_PROF
+  { unsigned long long ph[8]; if (hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_phase_p), sizeof(ph)) == hipSuccess && ph[7]) { std::fprintf(stderr, "[propose phases, 10ns ticks per block] sample+prefill %.1f (wave0 sampling %.1f) likelihood %.1f tail %.1f\n", (double)ph[0]/ph[7], (double)ph[5]/ph[7], (double)ph[1]/ph[7], (double)ph[2]/ph[7]); } }
+  { unsigned long long ph[8]; if (hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_phase), sizeof(ph)) == hipSuccess && ph[7]) { std::fprintf(stderr, "[raycast phases, 10ns ticks per block] setup %.1f count %.1f flag %.1f replay %.1f rest %.1f | ncell %.0f endcells %.0f\n", (double)ph[0]/ph[7], (double)ph[1]/ph[7], (double)ph[2]/ph[7], (double)ph[3]/ph[7], (double)ph[4]/ph[7], (double)ph[5]/ph[7], (double)ph[6]/ph[7]); } }
+#endif
   if (!h) return;
   DeviceGuard guard(h->device);
   for (int b = 0; b < 2; ++b) { (void)hipFree(h->d_state[b]); (void)hipFree(h->d_log_odds[b]); (void)hipFree(h->d_code[b]); (void)hipFree(h->d_nocc[b]); (void)hipFree(h->d_bitmap[b]); (void)hipFree(h->d_rowcount[b]); }
@@ -1674,7 +2004,7 @@ int tbnav_rbpf_set_log_odds(tbnav_rbpf* h, int32_t particle, const double* in) {
   TBNAV_HIP(hipMemcpy(h->d_log_odds[h->cur] + (size_t)particle * h->G, in, sizeof(double) * h->G, hipMemcpyHostToDevice));
   // rebuild this particle's occupancy bitmap / row counts / occupied count from the new log-odds
   TBNAV_HIP(hipMemsetAsync(h->d_nocc[h->cur] + particle, 0, sizeof(int), h->stream));
-  const GridC g{h->p.xmin, h->p.xmax, h->p.ymin, h->p.ymax, h->p.resolution, h->xsize, h->ysize, h->words, h->max_occ_dist};
+  const GridC g{h->p.xmin, h->p.xmax, h->p.ymin, h->p.ymax, h->p.resolution, h->xsize, h->ysize, h->words, h->max_occ_dist, 1.0 / h->p.resolution};
   hipLaunchKernelGGL(rbpf_occupancy, dim3((h->xsize + 3) / 4, 1), dim3(256), 0, h->stream, g, h->cut_occ, particle,
                      h->d_log_odds[h->cur], h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_nocc[h->cur]);
   TBNAV_HIP(hipGetLastError());

@@ -252,6 +252,38 @@ def test_cfg3_full_size_properties(gpu_pkg):
     assert np.array_equal(pf_d.distCode(0), codes)
 
 
+def test_distance_lookup_modes_are_bit_identical(gpu_pkg, monkeypatch):
+    """The scan likelihood gets its distance codes three ways: whole-map transform after every
+    update ("full", the reference's data flow), a per-particle window refreshed before the update ("window"), or
+    an exact nearest-obstacle query on the occupancy bitmap at each lookup ("query", the default — no transform in
+    the SLAM path).  All three must give the same bits everywhere: sampled-pose likelihoods, weights, poses, maps,
+    and the field that get_dist_code materialises afterwards."""
+    N, k, n_scans = 96, 20, 6
+    steps, poses = rc.trajectory(n_scans, inc=(0.07, 0.10, 0.05))
+    rng = np.random.default_rng(11)
+    scans = [orc.room_scan(poses[s], walls=rc.ROOM_SURVEY, rng=rng) for s in range(n_scans)]
+    outs = {}
+    for mode in ("full", "window", "query"):
+        monkeypatch.setenv("TBNAV_RBPF_DF", mode)
+        pf = _dev(gpu_pkg, N=N, k=k, map_min=-10.0, map_max=10.0)
+        rec = []
+        for s, (prev, cur, t_icp, u) in enumerate(steps):
+            normals = orc.normal_stream(500 + s, pf.numNormals(True), 0.0, 1.0)
+            st = pf.SLAM(scans[s], u, cur, prev, True, t_icp, normals)
+            assert st.status == 0
+            tr = pf.trace()
+            rec.append((tr["p_scan"].copy(), tr["weight_raw"].copy(), tr["new_pose"].copy(), st.neff, st.resampled))
+        pose, prevp, w = pf.particles()
+        outs[mode] = (rec, pose, w, pf.logOdds(5).copy(), pf.distCode(5).copy(), pf.distCode(N - 1).copy())
+        pf.close()
+    for mode in ("window", "query"):
+        for a, b in zip(outs["full"][0], outs[mode][0]):
+            assert all(np.array_equal(x, y) for x, y in zip(a[:3], b[:3])) and a[3:] == b[3:], mode
+        for x, y in zip(outs["full"][1:], outs[mode][1:]):
+            assert np.array_equal(x, y), mode
+    assert (outs["full"][4] != 0xFFFF).sum() > 1000      # the field really is populated
+
+
 @pytest.mark.parametrize("rows_used,expect", [(140, "compact-144"), (280, "compact-288"), (400, "general")])
 def test_distance_field_tiers_random_occupancy(gpu_pkg, rows_used, expect):
     """The distance transform picks its kernel per particle from the number of non-empty map rows
