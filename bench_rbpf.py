@@ -7,8 +7,8 @@ standard normals drawn ON the device (normals == NULL: nothing but the 1.4 KB sc
 buffer copied inside the call (PCIe-inclusive; never the headline); `device_ms_per_scan` is the sum of
 the kernels' HIP-event durations alone.
 
-roofline: the distance-field kernel pair is the dominant cost; algorithmic bytes per particle-update
-are SURVEY.md 8-d's  k*Bv*8 + (C_free+Bv)*16 + G_reach*16.
+roofline: priced on the kernel that dominates the distance-field mode that ran (see run()); algorithmic
+bytes per particle-update are SURVEY.md 8-d's  k*Bv*8 + (C_free+Bv)*16 + G_reach*16.
 """
 from __future__ import annotations
 
@@ -56,7 +56,20 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
         if s >= 2:
             t_host += time.perf_counter() - t0; n_host += 1
     pf_h.close()
-    kms = {}
+    # per-kernel durations: their own pass on their own filter, with the C-ABI's event timing switched on (the
+    # events cost device time themselves, so the headline pass below runs without them)
+    pf_k = ParticleFilter(default_params(N=N, k=k, map_min=-10.0, map_max=10.0, device=device.index or 0))
+    pf_k.setSeed(2026)
+    pf_k.setTiming(True)
+    kms, n_k = {}, 0
+    for s, (prev, cur, t_icp, u) in enumerate(steps):
+        pf_k.SLAM(scans[s], u, cur, prev, True, t_icp, None)
+        if s >= 2:
+            n_k += 1
+            for key, v in pf_k.kernelMs().items():
+                kms[key] = kms.get(key, 0.0) + v
+    pf_k.close()
+    kms = {key: v / n_k for key, v in kms.items()}
     t_total = 0.0
     n_timed = 0
     resamples = 0
@@ -67,35 +80,47 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
         dt = time.perf_counter() - t0
         if s >= 2:  # first two scans: empty maps / first-touch
             t_total += dt; n_timed += 1
-            for key, v in pf.kernelMs().items():
-                kms[key] = kms.get(key, 0.0) + v
         resamples += st.resampled
-    kms = {key: v / n_timed for key, v in kms.items()}
     ms_scan = t_total / n_timed * 1e3
     dev_ms = sum(kms.values())
     G = pf.G
     Bv = int(st.n_valid_beams)
     c_free = 30 * Bv  # ~30 free cells per ray in this room
     alg_per_update = k * Bv * 8 + (c_free + Bv) * 16 + G * 16
-    # distance-field refresh: 8 B seed/occupancy read + 8 B distance write per refreshed cell.  The device
-    # refreshes a window round each particle (every lookup of the scan provably falls inside it; the whole
-    # field is produced on demand), so the dominant kernel is priced on the cells it refreshes, while
-    # `whole_update` keeps SURVEY.md 8-d's reference-data-flow figure (whole reachable map).
+    # Distance-field modes (TBNAV_RBPF_DF): "query" (default) answers each lookup from the occupancy bitmap — no
+    # transform in the SLAM path; "window" refreshes a window per particle before the update; "full" transforms
+    # the whole map after every update (the reference's data flow).  The roofline object prices the kernel that
+    # dominates the mode that ran; `whole_update` keeps SURVEY.md 8-d's reference-data-flow bytes for the sum.
+    mode = os.environ.get("TBNAV_RBPF_DF", "query")
+    if os.environ.get("TBNAV_RBPF_FULL_EDT") == "1":
+        mode = "full"
+    if mode not in ("full", "window"):
+        mode = "query"
     move = max(float(np.hypot(steps[-1][2][1], steps[-1][2][2])), abs(float(steps[-1][3][1])))
     half_cells = int(np.ceil((3.5 + move + 8.0 * np.sqrt(1e-8)) / 0.05)) + 3
     win_cells = min(2 * half_cells + 1, pf.xsize) ** 2
-    full_edt = os.environ.get("TBNAV_RBPF_FULL_EDT") == "1"
-    alg_edt = (G if full_edt else win_cells) * 16
-    edt_ms = kms["occupancy"] + kms["edt"]
     traffic = None
-    try:
-        import json
-        with open(os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")) as f:
-            wl = json.load(f)["workloads"]["rbpf_N1000_k50_400x400"]
-        if N == 1000 and not full_edt:
-            traffic = sum(v["hbm_bytes"] for name, v in wl.items() if name.startswith("rbpf_edt"))
-    except (OSError, KeyError, ValueError):
-        pass
+    if mode == "query":
+        # dominant kernel: the raycast / log-odds update.  Algorithmic bytes: every cell a beam touches is one
+        # f64 read + one f64 write (SURVEY.md 8-d's (C_free + Bv) * 16 counts a cell once per touching beam; the
+        # kernel merges the touches of one scan, so the bytes that have to move are the DISTINCT cells).
+        dom_name = "rbpf_raycast_tile (log-odds update)"
+        dom_ms = kms["raycast"]
+        alg_dom = (c_free + Bv) * 16
+        alg_note = "(C_free + Bv) * 16 B per particle, SURVEY.md 8-d"
+    else:
+        dom_name = "rbpf_edt_compact (distance field" + ("" if mode == "full" else f", {int(np.sqrt(win_cells))}^2-cell window per particle") + ")"
+        dom_ms = kms["occupancy"] + kms["edt"]
+        alg_dom = (G if mode == "full" else win_cells) * 16
+        alg_note = "16 B per refreshed cell"
+        try:
+            import json
+            with open(os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")) as f:
+                wl = json.load(f)["workloads"]["rbpf_N1000_k50_400x400"]
+            if N == 1000 and mode == "window":
+                traffic = sum(v["hbm_bytes"] for name, v in wl.items() if name.startswith("rbpf_edt"))
+        except (OSError, KeyError, ValueError):
+            pass
     out = {
         "metric": "RBPF particle-updates/s", "value": round(N / (ms_scan * 1e-3), 1), "unit": "particle-updates/s",
         "config": {"workload": f"RBPF SLAM N={N}, k={k}, {Bv} valid beams, {pf.xsize}x{pf.ysize} @0.05 m, ICP-ok branch "
@@ -107,14 +132,17 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
         "device_only_updates_per_s": round(N / (dev_ms * 1e-3), 1),
         "kernel_ms": {key: round(v, 4) for key, v in kms.items()},
         "dtype": "f64+u16",
-        "roofline": {"bound": "hbm", "kernel": "rbpf_edt_compact (distance field" + ("" if full_edt else f", {int(np.sqrt(win_cells))}^2-cell window per particle") + ")",
-                     "achieved": round(alg_edt * N / (edt_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(alg_edt * N / (edt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": traffic,
+        "distance_field_mode": mode,
+        "roofline": {"bound": "hbm", "kernel": dom_name,
+                     "achieved": round(alg_dom * N / (dom_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(alg_dom * N / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": traffic,
                      "traffic_source": "profiles/r01_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
-                     "algorithmic_bytes_per_launch": alg_edt * N,
+                     "algorithmic_bytes_per_launch": alg_dom * N, "algorithmic_bytes_note": alg_note,
                      "whole_update": {"algorithmic_bytes_per_particle_update": alg_per_update,
                                       "achieved": round(alg_per_update * N / (dev_ms * 1e-3) / 1e9, 3),
-                                      "frac": round(alg_per_update * N / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)}},
+                                      "frac": round(alg_per_update * N / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                                      "note": "reference data flow (k*Bv*8 lookups + (C_free+Bv)*16 + G*16 transform) over the "
+                                              "device time of one scan; > 1 means traffic the reference needs is not moved at all"}},
     }
     pf.close()
     if with_cpu:

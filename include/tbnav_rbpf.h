@@ -149,6 +149,10 @@ int tbnav_rbpf_get_trace(tbnav_rbpf* h, double* sampled, double* p_scan, double*
  * [3] distance field, [4] normalise/select, [5] resample gather (0 if it did not run). */
 #define TBNAV_RBPF_NKERNELS 6
 int tbnav_rbpf_last_kernel_ms(tbnav_rbpf* h, float ms[TBNAV_RBPF_NKERNELS]);
+/* The events that feed tbnav_rbpf_last_kernel_ms cost device time themselves (a few microseconds each, which is
+ * not small next to the kernels), so they are recorded only after tbnav_rbpf_set_timing(h, 1); off by default,
+ * in which case last_kernel_ms reports zeros. */
+int tbnav_rbpf_set_timing(tbnav_rbpf* h, int32_t enable);
 
 #ifdef __cplusplus
 }

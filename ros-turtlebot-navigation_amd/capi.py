@@ -146,6 +146,7 @@ def lib() -> C.CDLL:
         "tbnav_rbpf_get_occupied_count": (C.c_int, [vp, vp]),
         "tbnav_rbpf_get_trace": (C.c_int, [vp] + [vp] * 9),
         "tbnav_rbpf_last_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
+        "tbnav_rbpf_set_timing": (C.c_int, [vp, i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

@@ -40,6 +40,8 @@ constexpr int kWave = 64;
 #define TBNAV_PROPOSE_WAVES 3
 #endif
 constexpr int kProposeThreads = TBNAV_PROPOSE_THREADS;
+constexpr int kUnCap = 16;  // unstable beams handled by the per-pair path of the proposal kernel
+static_assert(kProposeThreads >= 128 && kProposeThreads % 64 == 0, "wave 0 samples, the other waves look the beams up");
 constexpr uint16_t kCodeUnreached = 0xFFFF;
 constexpr int kMaxLds = 160 * 1024;
 
@@ -54,6 +56,15 @@ __host__ __device__ inline double normalize_angle_PI(double rad) {  // rigid2d.h
 
 __device__ __forceinline__ int floor_div_small(int num, int den);  // exact floor(num/den), |num| < 2^24, 0 < den < 2^13
 
+#ifdef TBNAV_PHASE_PROF
+__device__ unsigned long long g_phase[8];
+__device__ unsigned long long g_phase_p[8];
+#define PHASE_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_phase[i], now_ - t_prev_); t_prev_ = now_; } } while (0)
+#define PHASE_STAMP_P(i) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_phase_p[i], now_ - t_prev_); t_prev_ = now_; } } while (0)
+#else
+#define PHASE_STAMP(i)
+#define PHASE_STAMP_P(i)
+#endif
 struct GridC {
   double xmin, xmax, ymin, ymax, res;
   int xsize, ysize, words;  // words = ceil(ysize / 64) u64 per bitmap row
@@ -112,6 +123,16 @@ __device__ __forceinline__ double pdf_normal(double a, double b) {
   return sqrt_inv * exp(var);
 }
 
+__device__ __forceinline__ double wave_max_d(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
 __device__ __forceinline__ double wave_prod(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v *= __shfl_xor(v, off, 64);
@@ -138,28 +159,80 @@ struct DistSrc {
   const int* rowcount;              // [xs]
   int4 win;
   int mode;                         // 0 field, 1 window, 2 query
+  // query mode, optional: the part of the bitmap round the particle held in LDS (rows R0..R1, 64-cell word
+  // columns W0..W0+nW-1; any[r] = row r has a set bit inside those columns).  nW == 0: no tile.
+  const unsigned long long* tbm;
+  const int* tany;
+  int R0, R1, W0, nW;
 };
-__device__ __forceinline__ uint16_t nearest_code_query(const GridC& g, const DistSrc& d, int radius, int ci, int cj) {
+// Walk rows i, i+-1, i+-2, ... of an occupancy bitmap (stride `words` u64 per row, rows row_lo..row_hi present,
+// cell columns [0, words*64) relative to the bitmap) and return the least squared distance found (INT_MAX: none
+// within `radius`).  row_any(r) says whether row r can hold a set bit.
+template <class RowAny>
+__device__ __forceinline__ int nearest_d2_rows(const unsigned long long* bm, int words, int row_lo, int row_hi, int radius,
+                                               int ci, int cj, RowAny row_any) {
   int best = 0x7fffffff;
   for (int dr = 0; dr <= radius; ++dr) {
     if (dr * dr >= best) break;
+    if (ci + dr > row_hi && ci - dr < row_lo) break;
     for (int sg = 0; sg < (dr ? 2 : 1); ++sg) {
       const int r = sg ? ci - dr : ci + dr;
-      if (r < 0 || r >= g.xsize || d.rowcount[r] == 0) continue;
+      if (r < row_lo || r > row_hi || !row_any(r)) continue;
       int cap = radius;
       if (best != 0x7fffffff) { cap = (int)sqrtf((float)(best - dr * dr)) + 1; cap = cap < radius ? cap : radius; }
-      const int f = row_nearest(d.bm + (size_t)r * g.words, g.words, cj, cap);
+      const int f = row_nearest(bm + (size_t)(r - row_lo) * words, words, cj, cap);
       if (f != 255) { const int cand = dr * dr + f * f; best = cand < best ? cand : best; }
     }
   }
+  return best;
+}
+__device__ __forceinline__ uint16_t nearest_code_query(const GridC& g, const DistSrc& d, int radius, int ci, int cj) {
+  if (d.nW > 0) {
+    // LDS tile first.  Its answer is the map's answer when no cell outside the tile can be nearer: a side of the
+    // tile that is not the map's own border is (distance to that side + 1) cells away at least.
+    const int C0 = d.W0 * 64, C1 = (d.W0 + d.nW) * 64 - 1;
+    if (ci >= d.R0 && ci <= d.R1 && cj >= C0 && cj <= C1) {
+      int clear = radius + 1;  // nothing beyond the radius matters
+      if (d.R0 > 0) clear = min(clear, ci - d.R0 + 1);
+      if (d.R1 < g.xsize - 1) clear = min(clear, d.R1 - ci + 1);
+      if (C0 > 0) clear = min(clear, cj - C0 + 1);
+      if (C1 < g.ysize - 1) clear = min(clear, C1 - cj + 1);
+      {
+        // A beam ends on or next to a wall: look at the 7 rows x 64 columns round the cell first, branch-free.
+        // Anything outside that window is >= 4 cells away, so a result <= 9 (and <= clear^2) is the map's answer.
+        const int cjr = cj - C0, s0 = cjr - 32, w = s0 >> 6, sh = s0 & 63;
+        int bw = 0x7fffffff;
+#pragma unroll
+        for (int dr = -3; dr <= 3; ++dr) {
+          const int r = ci + dr;
+          if (r < d.R0 || r > d.R1) continue;
+          const unsigned long long* row = d.tbm + (size_t)(r - d.R0) * d.nW;
+          const unsigned long long lo64 = (w >= 0 && w < d.nW) ? row[w] : 0ull, hi64 = (w + 1 >= 0 && w + 1 < d.nW) ? row[w + 1] : 0ull;
+          const unsigned long long W = sh ? ((lo64 >> sh) | (hi64 << (64 - sh))) : lo64;  // bit i = column s0 + i, the cell at bit 32
+          const unsigned long long L = W & 0x1FFFFFFFFull, Rr = W >> 33;
+          int f = 1 << 12;
+          if (L) f = __clzll((long long)L) - 31;
+          if (Rr) f = min(f, __ffsll((long long)Rr));
+          bw = min(bw, dr * dr + f * f);
+        }
+        if (bw <= 9 && bw <= clear * clear) return (uint16_t)bw;
+      }
+      const int* any = d.tany;
+      const int R0 = d.R0;
+      const int best = nearest_d2_rows(d.tbm, d.nW, d.R0, d.R1, radius, ci, cj - C0, [any, R0](int r) { return any[r - R0] != 0; });
+      if (best != 0x7fffffff && best <= clear * clear && best <= radius * radius) return (uint16_t)best;
+      if (best == 0x7fffffff && clear > radius) return d.code[(size_t)ci * g.xsize + cj];
+    }
+  }
+  const int* rcnt = d.rowcount;
+  const int best = nearest_d2_rows(d.bm, g.words, 0, g.xsize - 1, radius, ci, cj, [rcnt](int r) { return rcnt[r] != 0; });
   return (best <= radius * radius) ? (uint16_t)best : d.code[(size_t)ci * g.xsize + cj];
 }
-// returns false when a windowed lookup falls outside the refreshed window
-__device__ __forceinline__ bool lookup_code(const GridC& g, const DistSrc& d, int radius, int ci, int cj, uint16_t& out) {
-  if (d.mode == 2) { out = nearest_code_query(g, d, radius, ci, cj); return true; }
-  if (d.mode == 1 && (ci < d.win.x || ci > d.win.y || cj < d.win.z || cj > d.win.w)) return false;
-  out = d.code[(size_t)ci * g.xsize + cj];
-  return true;
+// Distance code of cell (ci, cj), or -1 when a windowed lookup falls outside the refreshed window.
+__device__ __forceinline__ int lookup_code(const GridC& g, const DistSrc& d, int radius, int ci, int cj) {
+  if (d.mode == 2) return nearest_code_query(g, d, radius, ci, cj);
+  if (d.mode == 1 && (ci < d.win.x || ci > d.win.y || cj < d.win.z || cj > d.win.w)) return -1;
+  return d.code[(size_t)ci * g.xsize + cj];
 }
 
 // Mixture term of one beam as a function of the distance code it lands on (grid_mapper.cpp:119-121).
@@ -184,26 +257,30 @@ __device__ __forceinline__ void sensor_transform(const ScanC& c, double th, doub
   if (c.Trs[0] == 0.0) { out[2] = s0; out[3] = c0; }  // th + 0.0 == th: same bits
   else sincos(th + c.Trs[0], &out[2], &out[3]);
 }
+// Mixture term of one beam seen from one sensor pose (grid_mapper.cpp:100-121).  (cc, tg, pzc) is the beam's cache
+// entry — cell / code / term at the centre of the particle's samples (0xFFFFFFFF: none): the samples lie within
+// ~1e-4 m of the centre, so nearly every (sample, beam) lands on the same cell (no lookup at all) or at least the
+// same code, and takes its term from the cache instead of re-evaluating sqrt + exp.  A beam that leaves the world
+// sets *oob (the reference throws from world2RowMajor) and contributes 1.
+__device__ __forceinline__ double beam_factor(const ScanC& c, const DistSrc& ds, int radius, const double2 pt, double X, double Y,
+                                              double st, double ct, unsigned int cc, unsigned int tg, double pzc, int* oob) {
+  const double ex = ct * pt.x - st * pt.y + X;
+  const double ey = st * pt.x + ct * pt.y + Y;
+  int ci, cj;
+  if (!world2cell(c.g, ex, ey, ci, cj)) { *oob |= 1; return 1.0; }
+  if (cc == (unsigned int)(ci * c.g.xsize + cj)) return pzc;  // same cell -> same code -> same term
+  // (window mode: the window is sized so that a miss cannot happen — if it ever does it is reported, never read stale)
+  const int cd = lookup_code(c.g, ds, radius, ci, cj);
+  if (cd < 0) { *oob |= 2; return 1.0; }
+  return (tg == (unsigned int)cd) ? pzc : beam_mixture(c, (uint16_t)cd);
+}
+// GridMapper::likelihoodFieldModel for ONE pose, evaluated by one wave (lanes stride the valid beams).
 __device__ __forceinline__ double wave_scan_likelihood_t(const ScanC& c, const double2* __restrict__ beams,
                                                          const DistSrc& ds, int radius, int n_occ,
-                                                         double X, double Y, double st, double ct, int lane, int* oob,
-                                                         const unsigned int* ctag = nullptr, const unsigned int* ccell = nullptr,
-                                                         const double* cpz = nullptr) {
+                                                         double X, double Y, double st, double ct, int lane, int* oob) {
   if (n_occ == 0) return 1.0;  // grid_mapper.cpp:94-98
   double p = 1.0;
-  for (int b = lane; b < c.Bv; b += kWave) {
-    const double2 pt = beams[b];
-    const double ex = ct * pt.x - st * pt.y + X;
-    const double ey = st * pt.x + ct * pt.y + Y;
-    int ci, cj;
-    if (!world2cell(c.g, ex, ey, ci, cj)) { *oob |= 1; continue; }
-    // same cell as the cached centre -> same code -> same term (the field is a function of the cell)
-    if (ccell && ccell[b] == (unsigned int)(ci * c.g.xsize + cj)) { p *= cpz[b]; continue; }
-    uint16_t cd;
-    // (window mode: the window is sized so that a miss cannot happen — if it ever does it is reported, never read stale)
-    if (!lookup_code(c.g, ds, radius, ci, cj, cd)) { *oob |= 2; continue; }
-    p *= (ctag && ctag[b] == (unsigned int)cd) ? cpz[b] : beam_mixture(c, cd);
-  }
+  for (int b = lane; b < c.Bv; b += kWave) p *= beam_factor(c, ds, radius, beams[b], X, Y, st, ct, 0xFFFFFFFFu, 0xFFFFFFFFu, 0.0, oob);
   return wave_prod(p);
 }
 __device__ __forceinline__ double wave_scan_likelihood(const ScanC& c, const double2* __restrict__ beams,
@@ -281,15 +358,6 @@ __global__ void rbpf_sample_normals(size_t n, unsigned long long seed, unsigned 
   }
 }
 
-#ifdef TBNAV_PHASE_PROF
-__device__ unsigned long long g_phase[8];
-__device__ unsigned long long g_phase_p[8];
-#define PHASE_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_phase[i], now_ - t_prev_); t_prev_ = now_; } } while (0)
-#define PHASE_STAMP_P(i) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_phase_p[i], now_ - t_prev_); t_prev_ = now_; } } while (0)
-#else
-#define PHASE_STAMP(i)
-#define PHASE_STAMP_P(i)
-#endif
 struct Trace {
   double *sampled, *p_scan, *p_pose, *mu, *sigma, *eta, *new_pose, *weight_raw;
 };
@@ -299,7 +367,7 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
                                                                 const uint16_t* __restrict__ codes,
                                                                 const unsigned long long* __restrict__ bitmap,
                                                                 const int* __restrict__ row_count, const int* __restrict__ skip,
-                                                                int df_mode, int radius,
+                                                                int skip_eq, int df_mode, int radius, int occ_half,
                                                                 const int* __restrict__ n_occ, const int4* __restrict__ win,
                                                                 const double* __restrict__ normals,
                                                                 double* __restrict__ pose, double* __restrict__ prev_pose,
@@ -311,15 +379,23 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
   double* pscan = lds + 3 * k;     // [k]
   double* ppose = lds + 4 * k;     // [k]
   double* stf = lds + 5 * k;       // [k][4] sensor transform of sample j; later reused as wj[k] | op[k][6]
-  double* cpz = lds + 12 * k;      // [Bv] mixture term of beam b at the samples' centre
+  double* fac = lds + 12 * k;      // [k][kUnCap] per-(sample, unstable beam) terms
+  double2* lbeams = reinterpret_cast<double2*>(lds + (12 + kUnCap) * k);  // [Bv] the scan, staged: every later read is an LDS read
+  double* cpz = lds + (12 + kUnCap) * k + 2 * c.Bv;  // [Bv] mixture term of beam b at the samples' centre
   unsigned int* ctag = reinterpret_cast<unsigned int*>(cpz + c.Bv);  // [Bv] the code it was computed for (0xFFFFFFFF = none)
   unsigned int* ccell = ctag + c.Bv;                                 // [Bv] the cell that code was looked up at
+  int* unst = reinterpret_cast<int*>(ccell + c.Bv);                  // [Bv] 1 = some sample may see the beam in another cell
+  int* ulist = unst + c.Bv;                                          // [<= Bv] those beams, ascending
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
   const uint16_t* code = codes + (size_t)p * c.g.xsize * c.g.ysize;
   const double* z = normals + (size_t)p * c.stride_normals;
   const int nocc = n_occ[p];
   // a particle whose field is authoritative (injected / whole-field fresh) always reads it
-  const DistSrc ds{code, bitmap + (size_t)p * c.g.xsize * c.g.words, row_count + (size_t)p * c.g.xsize, win[p], skip[p] ? 0 : df_mode};
+  // (the tile pointers are set unconditionally — nW == 0 means "no tile" — so that the compiler can see they are LDS
+  //  addresses and use ds_read instead of flat loads in the lookups)
+  unsigned long long* const tile_bm = reinterpret_cast<unsigned long long*>(ulist + c.Bv);
+  DistSrc ds{code, bitmap + (size_t)p * c.g.xsize * c.g.words, row_count + (size_t)p * c.g.xsize, win[p], skip[p] == skip_eq ? 0 : df_mode,
+             tile_bm, reinterpret_cast<const int*>(tile_bm), 0, 0, 0, 0};
   int oob = 0;
 
   if (!c.icp_ok) {
@@ -364,49 +440,162 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
   sincos(th0, &s0, &c0);
   const double mu0[3] = {th0 + c.Ticp[0], c0 * c.Ticp[1] - s0 * c.Ticp[2] + x0, s0 * c.Ticp[1] + c0 * c.Ticp[2] + y0};
   const double pv[3] = {prev_pose[p * 3 + 0], prev_pose[p * 3 + 1], prev_pose[p * 3 + 2]};
-  int var_err = 0;
-  for (int j = tid; j < k; j += kProposeThreads) {
-    double s[3];
-    for (int q = 0; q < 3; ++q) s[q] = mu0[q] + c.Ld[q] * z[3 * j + q];
-    s[0] = normalize_angle_PI(s[0]);
-    smp[3 * j + 0] = s[0]; smp[3 * j + 1] = s[1]; smp[3 * j + 2] = s[2];
-    double T[4];
-    sensor_transform(c, s[0], s[1], s[2], T);
-    for (int q = 0; q < 4; ++q) stf[4 * j + q] = T[q];
-    ppose[j] = pose_likelihood_odom(c, s, pv, &var_err);
+  for (int b = tid; b < c.Bv; b += kProposeThreads) lbeams[b] = beams[b];  // visible after the next barrier
+  double Tc[4];  // sensor transform at the centre of the samples
+  sensor_transform(c, mu0[0], mu0[1], mu0[2], Tc);
+  if (ds.mode == 2 && occ_half > 0 && nocc) {
+    // query mode: stage the bitmap rows/columns within occ_half cells of the sensor in LDS — every lookup of this
+    // block ends within range_max of it, and its nearest obstacle is usually a few cells further at most
+    int sci, scj;
+    if (world2cell(c.g, Tc[0], Tc[1], sci, scj)) {
+      const int R0 = max(0, sci - occ_half), R1 = min(c.g.xsize - 1, sci + occ_half);
+      const int W0 = max(0, scj - occ_half) >> 6, W1 = min(c.g.ysize - 1, scj + occ_half) >> 6, nW = W1 - W0 + 1;
+      unsigned long long* tb = tile_bm;
+      int* ta = reinterpret_cast<int*>(tile_bm + (size_t)(R1 - R0 + 1) * nW);
+      for (int r = tid; r <= R1 - R0; r += kProposeThreads) {
+        unsigned long long acc = 0ull;
+        for (int w = 0; w < nW; ++w) {
+          const unsigned long long v = ds.bm[(size_t)(R0 + r) * c.g.words + W0 + w];
+          tb[r * nW + w] = v;
+          acc |= v;
+        }
+        ta[r] = acc != 0ull;
+      }
+      ds.tany = ta; ds.R0 = R0; ds.R1 = R1; ds.W0 = W0; ds.nW = nW;
+    }
+    __syncthreads();
   }
-  if (var_err) atomicOr(&err[2], 1);
+  // ---- 1. wave 0: the k sampled poses and their sensor transforms; how far any of them is from the centre
+  __shared__ double sh_spread[2], sh_pst[kProposeThreads / kWave];
+  __shared__ int sh_nun;
+  constexpr int kPW = kProposeThreads / kWave;
+  if (wid == 0) {
+    double dxy = 0.0, dth = 0.0;
+    for (int j = lane; j < k; j += kWave) {
+      double sj[3];
+      for (int q = 0; q < 3; ++q) sj[q] = mu0[q] + c.Ld[q] * z[3 * j + q];
+      dth = fmax(dth, fabs(c.Ld[0] * z[3 * j]));
+      sj[0] = normalize_angle_PI(sj[0]);
+      smp[3 * j + 0] = sj[0]; smp[3 * j + 1] = sj[1]; smp[3 * j + 2] = sj[2];
+      double T[4];
+      sensor_transform(c, sj[0], sj[1], sj[2], T);
+      for (int q = 0; q < 4; ++q) stf[4 * j + q] = T[q];
+      dxy = fmax(dxy, fmax(fabs(T[0] - Tc[0]), fabs(T[1] - Tc[1])));
+    }
+    dxy = wave_max_d(dxy); dth = wave_max_d(dth);
+    if (lane == 0) { sh_spread[0] = dxy; sh_spread[1] = dth; }
+  }
+  __syncthreads();
 #ifdef TBNAV_PHASE_PROF
   if (tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_phase_p[5], now_ - t_prev_); }
 #endif
-  if (nocc && wid > 0) {  // per-beam cache at the centre of the samples (T(pose)*T_icp); wave 0 is busy sampling
-    double Tc[4];
-    sensor_transform(c, mu0[0], mu0[1], mu0[2], Tc);
+  // ---- 2. wave 0: odometry likelihood of every sample (:542).  Other waves: one lookup per beam at the centre of
+  //      the samples, and the beam's verdict: STABLE if the centre's end point is further from every border of
+  //      its cell than any sample's end point can be from it,
+  //          |e_j - e_c|_inf <= max_j |T_j - T_c|_inf + |beam| * max_j |theta_j - theta_c|      (chord <= arc),
+  //      plus 1e-9 m for the rounding of the end points themselves.  Every sample then sees that beam in the
+  //      centre's cell, i.e. with the centre's mixture term: the k * Bv evaluations of the reference
+  //      (grid_mapper.cpp:100-121 called from particle_filter.cpp:541) collapse to Bv, and only the few beams
+  //      near a cell border are evaluated per sample (step 4).  Same cells, same terms — only the order of the
+  //      product differs from the reference's (tolerance).
+  int var_err = 0;
+  if (wid == 0) {
+    for (int j = lane; j < k; j += kWave) ppose[j] = pose_likelihood_odom(c, &smp[3 * j], pv, &var_err);
+    if (var_err) atomicOr(&err[2], 1);
+  } else if (nocc) {
+    const double dxy = sh_spread[0], dth = sh_spread[1];
+    double pst = 1.0;
     for (int b = tid - kWave; b < c.Bv; b += kProposeThreads - kWave) {
-      const double2 pt = beams[b];
+      const double2 pt = lbeams[b];
+      const double ex = Tc[3] * pt.x - Tc[2] * pt.y + Tc[0], ey = Tc[2] * pt.x + Tc[3] * pt.y + Tc[1];
       int ci, cj;
       unsigned int tag = 0xFFFFFFFFu, cell = 0xFFFFFFFFu;
       double pz = 0.0;
-      uint16_t cd;
-      if (world2cell(c.g, Tc[3] * pt.x - Tc[2] * pt.y + Tc[0], Tc[2] * pt.x + Tc[3] * pt.y + Tc[1], ci, cj) &&
-          lookup_code(c.g, ds, radius, ci, cj, cd)) {
-        tag = cd;
+      int cd = -1;
+      if (world2cell(c.g, ex, ey, ci, cj)) cd = lookup_code(c.g, ds, radius, ci, cj);
+      bool stable = false;
+      if (cd >= 0) {
+        tag = (unsigned int)cd;
         cell = (unsigned int)(ci * c.g.xsize + cj);
-        pz = beam_mixture(c, cd);
+        pz = beam_mixture(c, (uint16_t)cd);
+        const double delta = dxy + sqrt(pt.x * pt.x + pt.y * pt.y) * dth + 1e-9;
+        const double x_lo = c.g.xmin + ci * c.g.res, x_hi = c.g.xmin + (ci + 1) * c.g.res;
+        const double y_lo = c.g.ymin + cj * c.g.res, y_hi = c.g.ymin + (cj + 1) * c.g.res;
+        stable = (ex - x_lo > delta) && (x_hi - ex > delta) && (ey - y_lo > delta) && (y_hi - ey > delta);
       }
+      if (stable) pst *= pz;
+      unst[b] = stable ? 0 : 1;
       ctag[b] = tag;
       ccell[b] = cell;
       cpz[b] = pz;
     }
+    pst = wave_prod(pst);
+    if (lane == 0) sh_pst[wid] = pst;
   }
   __syncthreads();
   PHASE_STAMP_P(0);
-
-  // ---- scan likelihood of every sample (:541): one wave per sample, lanes over beams
-  for (int j = wid; j < k; j += kProposeThreads / kWave) {
-    const double sl = wave_scan_likelihood_t(c, beams, ds, radius, nocc, stf[4 * j + 0], stf[4 * j + 1], stf[4 * j + 2],
-                                             stf[4 * j + 3], lane, &oob, ctag, ccell, cpz);
-    if (lane == 0) pscan[j] = sl;
+  // ---- 3. the unstable beams, listed in beam order (so that the products below have one fixed order)
+  if (wid == 0 && nocc) {
+    int n = 0;
+    for (int b0 = 0; b0 < c.Bv; b0 += kWave) {
+      const int b = b0 + lane;
+      const bool f = b < c.Bv && unst[b];
+      const unsigned long long m = __ballot(f);
+      if (f) ulist[n + __popcll(m & ((1ull << lane) - 1ull))] = b;
+      n += __popcll(m);
+    }
+    if (lane == 0) sh_nun = n;
+#ifdef TBNAV_PHASE_PROF
+    if (lane == 0) atomicAdd(&g_phase_p[6], (unsigned long long)n);
+#endif
+  }
+  __syncthreads();
+  // ---- 4. scan likelihood of every sample: (product over the stable beams) * (its own terms of the unstable ones);
+  //      one wave per sample, lanes over the unstable beams
+  if (nocc == 0) {
+    for (int j = tid; j < k; j += kProposeThreads) pscan[j] = 1.0;  // grid_mapper.cpp:94-98
+  } else {
+    double p_stable = sh_pst[1];
+    for (int w = 2; w < kPW; ++w) p_stable *= sh_pst[w];
+    const int n_un = sh_nun;
+    if (n_un <= kUnCap) {
+      // the usual case, a handful of unstable beams: one THREAD per (sample, unstable beam), then each sample's
+      // thread multiplies its few terms in beam order
+      for (int pair = tid; pair < k * n_un; pair += kProposeThreads) {
+        const int j = floor_div_small(pair, n_un), i = pair - j * n_un;
+        const int b = ulist[i];
+        fac[j * kUnCap + i] = beam_factor(c, ds, radius, lbeams[b], stf[4 * j + 0], stf[4 * j + 1], stf[4 * j + 2], stf[4 * j + 3],
+                                          ccell[b], ctag[b], cpz[b], &oob);
+      }
+      __syncthreads();
+      for (int j = tid; j < k; j += kProposeThreads) {
+        double pr = p_stable;
+        for (int i = 0; i < n_un; ++i) pr *= fac[j * kUnCap + i];
+        pscan[j] = pr;
+      }
+    } else {
+    constexpr int kSB = 4;  // samples per wave in flight: their shuffle chains overlap
+    for (int j0 = wid; j0 < k; j0 += kPW * kSB) {
+      double pr[kSB];
+#pragma unroll
+      for (int u = 0; u < kSB; ++u) pr[u] = 1.0;
+      for (int i = lane; i < n_un; i += kWave) {
+        const int b = ulist[i];
+        const double2 pt = lbeams[b];
+        const unsigned int cc = ccell[b], tg = ctag[b];
+        const double pzc = cpz[b];
+#pragma unroll
+        for (int u = 0; u < kSB; ++u) {
+          const int j = j0 + u * kPW;
+          if (j < k) pr[u] *= beam_factor(c, ds, radius, pt, stf[4 * j + 0], stf[4 * j + 1], stf[4 * j + 2], stf[4 * j + 3], cc, tg, pzc, &oob);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kSB; ++u) pr[u] = wave_prod(pr[u]);
+#pragma unroll
+      for (int u = 0; u < kSB; ++u) if (lane == 0 && j0 + u * kPW < k) pscan[j0 + u * kPW] = p_stable * pr[u];
+    }
+    }
   }
   if (oob & 1) atomicOr(&err[0], 1);
   if (oob & 2) atomicOr(&err[3], 4);
@@ -417,7 +606,6 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
   //      sample's own thread so that the serial part is only the chains of adds.
   PHASE_STAMP_P(1);
   double* wj = stf;           // [k]    likelihoods.at(j)   (the sensor transforms are dead by now)
-  double* op = stf + k;       // [k][6] (d d^T)(r,q) * w_j, upper triangle — filled after mu is known
   __shared__ double sh_mu[3], sh_eta;
   __shared__ int sh_stop;
   for (int j = tid; j < k; j += kProposeThreads) {
@@ -431,51 +619,58 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
     wj[j] = ps * pp;
   }
   __syncthreads();
-  if (tid == 0) {
-    double mu[3] = {0.0, 0.0, 0.0}, eta = 0.0;
-    for (int j = 0; j < k; ++j) {
+  // The weighted sums (:545-585) are taken by wave 0 as lane-strided partial sums closed with a butterfly: a fixed
+  // order, not the reference's left-to-right one — the results agree to rounding (asserted at 1e-10 against the
+  // oracle), and the serial chain of 4 + 6 adds per sample leaves the block's critical path.
+  if (wid == 0) {
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int j = lane; j < k; j += kWave) {
       const double pj = wj[j];
-      for (int q = 0; q < 3; ++q) mu[q] += smp[3 * j + q] * pj;
-      eta += pj;
+      for (int q = 0; q < 3; ++q) a[q] += smp[3 * j + q] * pj;
+      a[3] += pj;
     }
-    const int stop = almost_equal(eta, 0.0) ? 1 : 0;
-    if (stop) atomicOr(&err[1], 1);
-    else {
-      for (int q = 0; q < 3; ++q) mu[q] /= eta;
-      mu[0] = normalize_angle_PI(mu[0]);
+    for (int q = 0; q < 4; ++q) a[q] = wave_sum_d(a[q]);
+    if (lane == 0) {
+      const int stop = almost_equal(a[3], 0.0) ? 1 : 0;
+      if (stop) atomicOr(&err[1], 1);
+      else {
+        for (int q = 0; q < 3; ++q) a[q] /= a[3];
+        a[0] = normalize_angle_PI(a[0]);
+      }
+      sh_mu[0] = a[0]; sh_mu[1] = a[1]; sh_mu[2] = a[2]; sh_eta = a[3]; sh_stop = stop;
     }
-    sh_mu[0] = mu[0]; sh_mu[1] = mu[1]; sh_mu[2] = mu[2]; sh_eta = eta; sh_stop = stop;
   }
   __syncthreads();
   if (sh_stop) return;
-  for (int j = tid; j < k; j += kProposeThreads) {
-    const double d[3] = {smp[3 * j + 0] - sh_mu[0], smp[3 * j + 1] - sh_mu[1], smp[3 * j + 2] - sh_mu[2]};
-    const double w = wj[j];
-    int o = 0;
-    for (int r = 0; r < 3; ++r) for (int q = r; q < 3; ++q) op[6 * j + o++] = (d[r] * d[q]) * w;
-  }
-  __syncthreads();
-  if (tid == 0) {
+  if (wid == 0) {
     const double mu[3] = {sh_mu[0], sh_mu[1], sh_mu[2]}, eta = sh_eta;
     double su[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    for (int j = 0; j < k; ++j) for (int o = 0; o < 6; ++o) su[o] += op[6 * j + o];
-    double sigma[3][3];
-    {
+    for (int j = lane; j < k; j += kWave) {
+      const double d[3] = {smp[3 * j + 0] - mu[0], smp[3 * j + 1] - mu[1], smp[3 * j + 2] - mu[2]};
+      const double w = wj[j];
       int o = 0;
-      for (int r = 0; r < 3; ++r) for (int q = r; q < 3; ++q) { sigma[r][q] = su[o] / eta; sigma[q][r] = sigma[r][q]; ++o; }
+      for (int r = 0; r < 3; ++r) for (int q = r; q < 3; ++q) su[o++] += (d[r] * d[q]) * w;
     }
-    double L[3][3];
-    llt3(sigma, L);
-    const double* zz = z + 3 * k;
-    double np[3];
-    for (int r = 0; r < 3; ++r) np[r] = mu[r] + ((L[r][0] * zz[0] + L[r][1] * zz[1]) + L[r][2] * zz[2]);
-    prev_pose[p * 3 + 0] = th0; prev_pose[p * 3 + 1] = x0; prev_pose[p * 3 + 2] = y0;
-    for (int q = 0; q < 3; ++q) { pose[p * 3 + q] = np[q]; tr.new_pose[p * 3 + q] = np[q]; tr.mu[p * 3 + q] = mu[q]; }
-    for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) tr.sigma[p * 9 + r * 3 + q] = sigma[r][q];
-    tr.eta[p] = eta;
-    const double w = weight[p] * eta;
-    weight[p] = w;
-    tr.weight_raw[p] = w;
+    for (int o = 0; o < 6; ++o) su[o] = wave_sum_d(su[o]);
+    if (lane == 0) {
+      double sigma[3][3];
+      {
+        int o = 0;
+        for (int r = 0; r < 3; ++r) for (int q = r; q < 3; ++q) { sigma[r][q] = su[o] / eta; sigma[q][r] = sigma[r][q]; ++o; }
+      }
+      double L[3][3];
+      llt3(sigma, L);
+      const double* zz = z + 3 * k;
+      double np[3];
+      for (int r = 0; r < 3; ++r) np[r] = mu[r] + ((L[r][0] * zz[0] + L[r][1] * zz[1]) + L[r][2] * zz[2]);
+      prev_pose[p * 3 + 0] = th0; prev_pose[p * 3 + 1] = x0; prev_pose[p * 3 + 2] = y0;
+      for (int q = 0; q < 3; ++q) { pose[p * 3 + q] = np[q]; tr.new_pose[p * 3 + q] = np[q]; tr.mu[p * 3 + q] = mu[q]; }
+      for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) tr.sigma[p * 9 + r * 3 + q] = sigma[r][q];
+      tr.eta[p] = eta;
+      const double w = weight[p] * eta;
+      weight[p] = w;
+      tr.weight_raw[p] = w;
+    }
   }
   PHASE_STAMP_P(2);
 #ifdef TBNAV_PHASE_PROF
@@ -1206,6 +1401,32 @@ struct NormOut { double sum_w, sq_sum; int neff, resampled; };
 // that i because U_m and c[] are both non-decreasing), found by binary search, clamped to N-1.
 // buf: dynamic LDS, 2*N doubles (w then c).  N <= kNormMaxLds, else the global-memory variant below.
 constexpr int kNormMaxLds = 9000;
+// Left-to-right sum (of squares) of an LDS array by ONE thread — the reference's order (particle_filter.cpp:
+// 446-450, 458-461), which Neff and the resampling decision depend on.  The chain of adds is inherent; the loads are
+// not part of it: the next eight values are fetched while the current eight are added.
+template <bool SQ>
+__device__ __forceinline__ double seq_sum(const double* w, int N) {
+  double acc = 0.0;
+  int i = 0;
+  if (N >= 8) {
+    double a[8], b[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a[q] = w[q];
+    for (i = 0; i + 16 <= N; i += 8) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) b[q] = w[i + 8 + q];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc += SQ ? a[q] * a[q] : a[q];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) a[q] = b[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc += SQ ? a[q] * a[q] : a[q];
+    i += 8;
+  }
+  for (; i < N; ++i) acc += SQ ? w[i] * w[i] : w[i];
+  return acc;
+}
 __global__ __launch_bounds__(256) void rbpf_normalize(int N, const double* __restrict__ zp, double* __restrict__ weight, int* __restrict__ parent,
                                                       NormOut* __restrict__ out) {
   const double z = *zp;  // the one standard normal of lowVarianceResampling (particle_filter.cpp:474)
@@ -1216,18 +1437,13 @@ __global__ __launch_bounds__(256) void rbpf_normalize(int N, const double* __res
   __shared__ int s_res;
   for (int i = threadIdx.x; i < N; i += blockDim.x) w[i] = weight[i];
   __syncthreads();
-  if (threadIdx.x == 0) {
-    double sum = 0.0;
-    for (int i = 0; i < N; ++i) sum += w[i];
-    s_sum = sum;
-  }
+  if (threadIdx.x == 0) s_sum = seq_sum<false>(w, N);
   __syncthreads();
   const double sum = s_sum;
   for (int i = threadIdx.x; i < N; i += blockDim.x) { const double v = w[i] / sum; w[i] = v; weight[i] = v; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    double sq = 0.0;
-    for (int i = 0; i < N; ++i) sq += w[i] * w[i];
+    const double sq = seq_sum<true>(w, N);
     const int neff = (int)(1.0 / sq);
     const int res = (neff < (N / 2)) ? 1 : 0;
     out->sum_w = sum; out->sq_sum = sq; out->neff = neff; out->resampled = res;
@@ -1391,6 +1607,7 @@ struct tbnav_rbpf {
   int* d_best = nullptr;       // arg-max particle index
   double* d_best_pose = nullptr;
   int8_t* d_export = nullptr;  // [G]
+  bool timing = false;         // record HIP events round the kernels (tbnav_rbpf_set_timing): each costs device time, so off by default
   int tile_cap = 0;            // cells of the raycast LDS tile (0 = use the beam-ordered kernel)
   int raycast_threads = 1024;  // block size of the tile raycast (dev switch TBNAV_RBPF_RAYCAST_THREADS)
   uint64_t seed = 0x5EEDull, scan_index = 0;  // device noise source (normals == NULL)
@@ -1402,6 +1619,11 @@ struct tbnav_rbpf {
   int* d_tier = nullptr;       // [N] which distance-field kernel handles the particle this scan
   int* d_err = nullptr;
   NormOut* d_norm = nullptr;
+  // pinned host staging: the scan going in, the error flags and the normalisation result coming out (pageable
+  // buffers make every one of those small copies a blocking, staged transfer)
+  double2* h_beams = nullptr;  // capacity max_beams
+  int* h_err = nullptr;        // [4]
+  NormOut* h_norm = nullptr;
   double* d_trace = nullptr;   // sampled, p_scan, p_pose, mu, sigma, eta, new_pose, weight_raw
   Trace tr{};
   hipStream_t stream = nullptr;
@@ -1578,8 +1800,10 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
   out->n_valid_beams = c.Bv;
   if (n_beams > h->max_beams) {
     (void)hipFree(h->d_beams);
-    h->d_beams = nullptr;
+    (void)hipHostFree(h->h_beams);
+    h->d_beams = nullptr; h->h_beams = nullptr; h->max_beams = 0;
     TBNAV_HIP(hipMalloc((void**)&h->d_beams, sizeof(double2) * n_beams));
+    TBNAV_HIP(hipHostMalloc((void**)&h->h_beams, sizeof(double2) * n_beams, hipHostMallocDefault));
     h->max_beams = n_beams;
   }
   const size_t n_norm = (size_t)h->N * c.stride_normals + 1;
@@ -1589,7 +1813,10 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
     TBNAV_HIP(hipMalloc((void**)&h->d_normals, sizeof(double) * n_norm));
     h->normals_cap = n_norm;
   }
-  if (c.Bv) TBNAV_HIP(hipMemcpyAsync(h->d_beams, beams.data(), sizeof(double2) * c.Bv, hipMemcpyHostToDevice, st));
+  if (c.Bv) {
+    std::memcpy(h->h_beams, beams.data(), sizeof(double2) * c.Bv);
+    TBNAV_HIP(hipMemcpyAsync(h->d_beams, h->h_beams, sizeof(double2) * c.Bv, hipMemcpyHostToDevice, st));
+  }
   if (normals) {
     TBNAV_HIP(hipMemcpyAsync(h->d_normals, normals, sizeof(double) * n_norm, hipMemcpyHostToDevice, st));
   } else {
@@ -1603,7 +1830,7 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
   StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
 
   // ---- distance-field refresh for this call's lookups (windowed), then the particle update
-  TBNAV_HIP(hipEventRecord(h->ev[0], st));
+  if (h->timing) TBNAV_HIP(hipEventRecord(h->ev[0], st));
   {
     // every lookup of this call lies within `half` metres of the particle's CURRENT position: the sampled poses
     // sit at T(pose)*T_icp (or the motion-model pose) +- the sampling noise, the laser at |Trs| from them, and
@@ -1614,21 +1841,39 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
     const double half = (double)h->p.range_max + std::hypot(h->p.Trs[1], h->p.Trs[2]) + move + 8.0 * std::sqrt(sig);
     int half_cells = (int)std::ceil(half / h->p.resolution) + 3;
     if (h->full_edt || half_cells > h->xsize) half_cells = h->xsize;  // whole map
-    hipLaunchKernelGGL(rbpf_window, dim3((h->N + 255) / 256), dim3(256), 0, st, c.g, h->N, half_cells, h->df_mode == 1 ? 1 : 0,
-                       sp.pose, h->d_fstate, h->d_skip, h->d_win);
-    TBNAV_HIP(hipGetLastError());
+    if (h->df_mode != 2) {  // query mode needs neither windows nor skip flags: the proposal kernel reads the field state itself
+      hipLaunchKernelGGL(rbpf_window, dim3((h->N + 255) / 256), dim3(256), 0, st, c.g, h->N, half_cells, h->df_mode == 1 ? 1 : 0,
+                         sp.pose, h->d_fstate, h->d_skip, h->d_win);
+      TBNAV_HIP(hipGetLastError());
+    }
     if (h->df_mode == 1) {
       const int tiles = std::min((2 * half_cells + 1 + kWave - 1) / kWave + 1, (h->ysize + kWave - 1) / kWave);
       rc = run_distance_field(h, c.g, 0, h->N, tiles);
       if (rc != TBNAV_OK) return rc;
     }
   }
-  TBNAV_HIP(hipEventRecord(h->ev[1], st));
-  hipLaunchKernelGGL(rbpf_propose, dim3(h->N), dim3(kProposeThreads), sizeof(double) * (12 * h->k + (c.Bv > 0 ? c.Bv : 1)) + sizeof(unsigned int) * 2 * (c.Bv > 0 ? c.Bv : 1), st, c, h->d_beams,
-                     h->d_code[h->cur], h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_skip, h->df_mode, h->radius,
+  if (h->timing) TBNAV_HIP(hipEventRecord(h->ev[1], st));
+  size_t propose_lds = sizeof(double) * ((12 + kUnCap) * h->k + 3 * (c.Bv > 0 ? c.Bv : 1)) + sizeof(unsigned int) * 4 * (c.Bv > 0 ? c.Bv : 1);
+  int occ_half = 0;
+  if (h->df_mode == 2) {
+    // LDS copy of the occupancy bitmap round each particle's sensor: reach of a lookup (range_max + sampling
+    // spread) plus a margin for the walk to the nearest obstacle; shrunk, then dropped, if it would not fit
+    double sig = 0.0;
+    for (int q = 1; q < 3; ++q) sig = std::max(sig, std::max(h->p.sample_range[q], h->p.motion_noise[q]));
+    const int reach = (int)std::ceil(((double)h->p.range_max + 8.0 * std::sqrt(sig)) / h->p.resolution) + 2;
+    for (int margin : {48, 16, 0}) {
+      const int half = reach + margin;
+      const int rows = std::min(h->xsize, 2 * half + 1), nw = std::min(h->words, (2 * half + 1 + 63) / 64 + 1);
+      const size_t bytes = (size_t)rows * nw * 8 + (size_t)rows * 4;
+      if (bytes <= 48 * 1024) { occ_half = half; propose_lds += bytes; break; }
+    }
+  }
+  hipLaunchKernelGGL(rbpf_propose, dim3(h->N), dim3(kProposeThreads), propose_lds, st, c, h->d_beams,
+                     h->d_code[h->cur], h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->df_mode == 2 ? h->d_fstate : h->d_skip,
+                     h->df_mode == 2 ? 2 : 1, h->df_mode, h->radius, occ_half,
                      h->d_nocc[h->cur], h->d_win, h->d_normals, sp.pose, sp.prev, sp.weight, h->tr, h->d_err);
   TBNAV_HIP(hipGetLastError());
-  TBNAV_HIP(hipEventRecord(h->ev[2], st));
+  if (h->timing) TBNAV_HIP(hipEventRecord(h->ev[2], st));
   {
     const int bvn = c.Bv > 0 ? c.Bv : 1;
     const size_t tile_lds = sizeof(int) * kTileIntsPerBeam * bvn + sizeof(unsigned int) * ((size_t)(h->tile_cap + 1) / 2);
@@ -1640,7 +1885,7 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
                          h->d_log_odds[h->cur], h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_nocc[h->cur], h->d_err);
   }
   TBNAV_HIP(hipGetLastError());
-  TBNAV_HIP(hipEventRecord(h->ev[3], st));
+  if (h->timing) TBNAV_HIP(hipEventRecord(h->ev[3], st));
   if (h->full_edt) {
     // legacy placement (TBNAV_RBPF_FULL_EDT=1): whole field of every particle right after the map update,
     // where the reference runs its brushfire (grid_mapper.cpp:181)
@@ -1649,7 +1894,7 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
     if (rc != TBNAV_OK) return rc;
     TBNAV_HIP(hipMemsetAsync(h->d_fstate, 0, sizeof(int) * h->N, st));  // overwritten with 2 below
   }
-  TBNAV_HIP(hipEventRecord(h->ev[4], st));
+  if (h->timing) TBNAV_HIP(hipEventRecord(h->ev[4], st));
   if (!local_only) {
     const double* z = h->d_normals + (size_t)h->N * c.stride_normals;
     if (h->N <= kNormMaxLds)
@@ -1658,44 +1903,44 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
       hipLaunchKernelGGL(rbpf_normalize_seq, dim3(1), dim3(64), 0, st, h->N, z, sp.weight, h->d_parent, h->d_norm);
     TBNAV_HIP(hipGetLastError());
   }
-  TBNAV_HIP(hipEventRecord(h->ev[5], st));
-  int err[4];
-  NormOut no{};
-  TBNAV_HIP(hipMemcpyAsync(err, h->d_err, sizeof err, hipMemcpyDeviceToHost, st));
-  if (!local_only) TBNAV_HIP(hipMemcpyAsync(&no, h->d_norm, sizeof no, hipMemcpyDeviceToHost, st));
+  if (h->timing) TBNAV_HIP(hipEventRecord(h->ev[5], st));
+  // the map changed: every field is stale until the next refresh (whole-map mode: fresh everywhere)
+  TBNAV_HIP(hipMemsetD32Async((hipDeviceptr_t)h->d_fstate, h->full_edt ? 2 : 0, h->N, st));
+  *h->h_norm = NormOut{};
+  TBNAV_HIP(hipMemcpyAsync(h->h_err, h->d_err, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
+  if (!local_only) TBNAV_HIP(hipMemcpyAsync(h->h_norm, h->d_norm, sizeof(NormOut), hipMemcpyDeviceToHost, st));
   TBNAV_HIP(hipStreamSynchronize(st));
+  const int* err = h->h_err;
+  const NormOut no = *h->h_norm;
   out->status = status_from_err(err);
   out->sum_w = no.sum_w; out->sq_sum = no.sq_sum; out->neff = no.neff; out->resampled = no.resampled;
   bool gathered = false;
   if (!local_only && no.resampled && out->status == TBNAV_OK) {
     const int nxt = 1 - h->cur;
-    TBNAV_HIP(hipEventRecord(h->ev[6], st));
+    if (h->timing) TBNAV_HIP(hipEventRecord(h->ev[6], st));
     hipLaunchKernelGGL(rbpf_gather, dim3(16, h->N), dim3(256), 0, st, h->N, h->G, h->xsize * h->words, h->d_parent, h->d_log_odds[h->cur],
                        h->d_log_odds[nxt], h->d_code[h->cur], h->d_code[nxt], h->d_bitmap[h->cur], h->d_bitmap[nxt],
                        h->d_rowcount[h->cur], h->d_rowcount[nxt], h->xsize, h->d_nocc[h->cur], h->d_nocc[nxt]);
     TBNAV_HIP(hipGetLastError());
-    TBNAV_HIP(hipEventRecord(h->ev[7], st));
+    if (h->timing) TBNAV_HIP(hipEventRecord(h->ev[7], st));
     gathered = true;
   }
-  TBNAV_HIP(hipStreamSynchronize(st));
-  {
-    // the map changed: every field is stale until the next refresh (whole-map mode: fresh everywhere)
-    std::vector<int> stt(h->N, h->full_edt ? 2 : 0);
-    TBNAV_HIP(hipMemcpy(h->d_fstate, stt.data(), sizeof(int) * h->N, hipMemcpyHostToDevice));
+  if (gathered) TBNAV_HIP(hipStreamSynchronize(st));
+  for (float& v : h->last_ms) v = 0.f;
+  if (h->timing) {
+    float e01, e12, e23, e34, e45;
+    TBNAV_HIP(hipEventElapsedTime(&e01, h->ev[0], h->ev[1]));
+    TBNAV_HIP(hipEventElapsedTime(&e12, h->ev[1], h->ev[2]));
+    TBNAV_HIP(hipEventElapsedTime(&e23, h->ev[2], h->ev[3]));
+    TBNAV_HIP(hipEventElapsedTime(&e34, h->ev[3], h->ev[4]));
+    TBNAV_HIP(hipEventElapsedTime(&e45, h->ev[4], h->ev[5]));
+    h->last_ms[0] = e12;        // propose
+    h->last_ms[1] = e23;        // raycast
+    h->last_ms[2] = 0.f;        // (occupancy pass: folded into the raycast)
+    h->last_ms[3] = e01 + e34;  // distance field (windowed refresh before the update, or whole-map after it)
+    h->last_ms[4] = e45;        // normalise / select
+    if (gathered) TBNAV_HIP(hipEventElapsedTime(&h->last_ms[5], h->ev[6], h->ev[7]));
   }
-  float e01, e12, e23, e34, e45;
-  TBNAV_HIP(hipEventElapsedTime(&e01, h->ev[0], h->ev[1]));
-  TBNAV_HIP(hipEventElapsedTime(&e12, h->ev[1], h->ev[2]));
-  TBNAV_HIP(hipEventElapsedTime(&e23, h->ev[2], h->ev[3]));
-  TBNAV_HIP(hipEventElapsedTime(&e34, h->ev[3], h->ev[4]));
-  TBNAV_HIP(hipEventElapsedTime(&e45, h->ev[4], h->ev[5]));
-  h->last_ms[0] = e12;        // propose
-  h->last_ms[1] = e23;        // raycast
-  h->last_ms[2] = 0.f;        // (occupancy pass: folded into the raycast)
-  h->last_ms[3] = e01 + e34;  // distance field (windowed refresh before the update, or whole-map after it)
-  h->last_ms[4] = e45;        // normalise / select
-  h->last_ms[5] = 0.f;
-  if (gathered) TBNAV_HIP(hipEventElapsedTime(&h->last_ms[5], h->ev[6], h->ev[7]));
   if (gathered) {
     // particle state is tiny: gather it on the host side of the boundary (pose, prev_pose, weight)
     const int N = h->N, nxt = 1 - h->cur;
@@ -1795,6 +2040,8 @@ int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) {
   A((void**)&h->d_tier, sizeof(int) * N);
   A((void**)&h->d_err, sizeof(int) * 4);
   A((void**)&h->d_norm, sizeof(NormOut));
+  if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_err, sizeof(int) * 4, hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_norm, sizeof(NormOut), hipHostMallocDefault);
   const size_t kk = (size_t)h->k;
   const size_t trace_doubles = (size_t)N * (kk * 3 + kk + kk + 3 + 9 + 1 + 3 + 1);
   A((void**)&h->d_trace, sizeof(double) * trace_doubles);
@@ -1858,7 +2105,7 @@ int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) {
 
 void tbnav_rbpf_destroy(tbnav_rbpf* h) {
 #ifdef TBNAV_PHASE_PROF
-  { unsigned long long ph[8]; if (hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_phase_p), sizeof(ph)) == hipSuccess && ph[7]) { std::fprintf(stderr, "[propose phases, 10ns ticks per block] sample+prefill %.1f (wave0 sampling %.1f) likelihood %.1f tail %.1f\n", (double)ph[0]/ph[7], (double)ph[5]/ph[7], (double)ph[1]/ph[7], (double)ph[2]/ph[7]); } }
+  { unsigned long long ph[8]; if (hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_phase_p), sizeof(ph)) == hipSuccess && ph[7]) { std::fprintf(stderr, "[propose phases, 10ns ticks per block] sample+prefill %.1f (wave0 sampling %.1f) likelihood %.1f tail %.1f | unstable beams per block %.1f | wave0 clocks per block: first beam loop %.0f first wave_prods %.0f\n", (double)ph[0]/ph[7], (double)ph[5]/ph[7], (double)ph[1]/ph[7], (double)ph[2]/ph[7], (double)ph[6]/ph[7], (double)ph[3]/ph[7], (double)ph[4]/ph[7]); } }
   { unsigned long long ph[8]; if (hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_phase), sizeof(ph)) == hipSuccess && ph[7]) { std::fprintf(stderr, "[raycast phases, 10ns ticks per block] setup %.1f count %.1f flag %.1f replay %.1f rest %.1f | ncell %.0f endcells %.0f\n", (double)ph[0]/ph[7], (double)ph[1]/ph[7], (double)ph[2]/ph[7], (double)ph[3]/ph[7], (double)ph[4]/ph[7], (double)ph[5]/ph[7], (double)ph[6]/ph[7]); } }
 #endif
   if (!h) return;
@@ -1866,6 +2113,7 @@ void tbnav_rbpf_destroy(tbnav_rbpf* h) {
   for (int b = 0; b < 2; ++b) { (void)hipFree(h->d_state[b]); (void)hipFree(h->d_log_odds[b]); (void)hipFree(h->d_code[b]); (void)hipFree(h->d_nocc[b]); (void)hipFree(h->d_bitmap[b]); (void)hipFree(h->d_rowcount[b]); }
   (void)hipFree(h->d_beams); (void)hipFree(h->d_normals); (void)hipFree(h->d_parent); (void)hipFree(h->d_best); (void)hipFree(h->d_best_pose); (void)hipFree(h->d_export); (void)hipFree(h->d_tier); (void)hipFree(h->d_fstate); (void)hipFree(h->d_skip); (void)hipFree(h->d_win);
   (void)hipFree(h->d_err); (void)hipFree(h->d_norm); (void)hipFree(h->d_trace);
+  (void)hipHostFree(h->h_beams); (void)hipHostFree(h->h_err); (void)hipHostFree(h->h_norm);
   for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -2110,6 +2358,12 @@ int tbnav_rbpf_best_map(tbnav_rbpf* h, int8_t* map) {
   TBNAV_HIP(hipGetLastError());
   TBNAV_HIP(hipMemcpyAsync(map, h->d_export, h->G, hipMemcpyDeviceToHost, st));
   TBNAV_HIP(hipStreamSynchronize(st));
+  return TBNAV_OK;
+}
+
+int tbnav_rbpf_set_timing(tbnav_rbpf* h, int32_t enable) {
+  if (!h) return TBNAV_ERR_INVALID_ARG;
+  h->timing = enable != 0;
   return TBNAV_OK;
 }
 

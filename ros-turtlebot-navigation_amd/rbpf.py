@@ -152,7 +152,12 @@ class ParticleFilter:
         capi.check(self._L.tbnav_rbpf_get_trace(self._h, *[a.ctypes.data for a in t.values()]), "get_trace")
         return t
 
+    def setTiming(self, on: bool = True):
+        """Record HIP events round the kernels of the following SLAM calls (they cost device time: off by default)."""
+        capi.check(self._L.tbnav_rbpf_set_timing(self._h, 1 if on else 0), "set_timing")
+
     def kernelMs(self):
+        """Per-kernel durations of the last SLAM call; zeros unless setTiming(True) was called before it."""
         ms = (C.c_float * 6)()
         capi.check(self._L.tbnav_rbpf_last_kernel_ms(self._h, ms), "last_kernel_ms")
         return dict(zip(("propose", "raycast", "occupancy", "edt", "normalize", "gather"), [float(x) for x in ms]))

@@ -227,6 +227,7 @@ def test_cfg3_full_size_properties(gpu_pkg):
     from rtn_amd.rbpf import resample_global
     N, k = 1000, 50
     pf_d = _dev(gpu_pkg, N=N, k=k, map_min=-10.0, map_max=10.0)
+    pf_d.setTiming(True)
     steps, poses = rc.trajectory(3, inc=(0.07, 0.10, 0.05))
     rng = np.random.default_rng(7)
     grids = {p: orc.GridAPI("orc", grid=(0.05, -10.0, 10.0, -10.0, 10.0)) for p in (0, 499, 999)}

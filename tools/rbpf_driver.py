@@ -9,6 +9,7 @@ from rtn_amd.rbpf import ParticleFilter, default_params
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 n_scans = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 pf = ParticleFilter(default_params(N=N, k=50, map_min=-10.0, map_max=10.0))
+pf.setTiming(True)
 steps, poses = rc.trajectory(n_scans, inc=(0.07, 0.10, 0.05))
 rng = np.random.default_rng(7)
 for s, (prev, cur, t_icp, u) in enumerate(steps):
