@@ -1622,8 +1622,13 @@ struct tbnav_rbpf {
   // pinned host staging: the scan going in, the error flags and the normalisation result coming out (pageable
   // buffers make every one of those small copies a blocking, staged transfer)
   double2* h_beams = nullptr;  // capacity max_beams
-  int* h_err = nullptr;        // [4]
-  NormOut* h_norm = nullptr;
+  // error flags and normalisation result live in mapped pinned host memory: the kernels write them over the
+  // fabric (a handful of bytes per scan) and the host reads them after the stream sync — no copy kernels, no memset
+  int* h_err = nullptr;        // [4] host view; d_err is the device view of the same bytes
+  NormOut* h_norm = nullptr;   // host view of d_norm
+  hipStream_t stream2 = nullptr;  // normalise/select runs here, beside the raycast (it only needs the weights)
+  hipEvent_t ev_w = nullptr, ev_n = nullptr;
+  bool fstate_dirty = true;    // some d_fstate entry may be non-zero
   double* d_trace = nullptr;   // sampled, p_scan, p_pose, mu, sigma, eta, new_pose, weight_raw
   Trace tr{};
   hipStream_t stream = nullptr;
@@ -1783,6 +1788,7 @@ int ensure_full_field(tbnav_rbpf* h, int particle) {
   if (rc != TBNAV_OK) return rc;
   TBNAV_HIP(hipStreamSynchronize(st));
   TBNAV_HIP(hipMemcpy(h->d_fstate + particle, &two, sizeof two, hipMemcpyHostToDevice));
+  h->fstate_dirty = true;
   return TBNAV_OK;
 }
 
@@ -1826,7 +1832,8 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
     TBNAV_HIP(hipGetLastError());
   }
   ++h->scan_index;
-  TBNAV_HIP(hipMemsetAsync(h->d_err, 0, sizeof(int) * 4, st));
+  for (int q = 0; q < 4; ++q) h->h_err[q] = 0;  // mapped: the previous call has synchronised, nothing is in flight
+  *h->h_norm = NormOut{};
   StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
 
   // ---- distance-field refresh for this call's lookups (windowed), then the particle update
@@ -1874,6 +1881,26 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
                      h->d_nocc[h->cur], h->d_win, h->d_normals, sp.pose, sp.prev, sp.weight, h->tr, h->d_err);
   TBNAV_HIP(hipGetLastError());
   if (h->timing) TBNAV_HIP(hipEventRecord(h->ev[2], st));
+  // normalise / select needs only the weights the proposal kernel left: it runs on the second stream, beside the
+  // raycast (one workgroup; the chain of adds it is made of would otherwise sit on the critical path).  With
+  // event timing on, everything stays on one stream so that the intervals mean what they say.
+  auto launch_normalize = [&](hipStream_t s2) -> int {
+    const double* z = h->d_normals + (size_t)h->N * c.stride_normals;
+    if (h->N <= kNormMaxLds)
+      hipLaunchKernelGGL(rbpf_normalize, dim3(1), dim3(256), sizeof(double) * 2 * h->N, s2, h->N, z, sp.weight, h->d_parent, h->d_norm);
+    else
+      hipLaunchKernelGGL(rbpf_normalize_seq, dim3(1), dim3(64), 0, s2, h->N, z, sp.weight, h->d_parent, h->d_norm);
+    TBNAV_HIP(hipGetLastError());
+    return TBNAV_OK;
+  };
+  const bool overlap = !local_only && !h->timing;
+  if (overlap) {
+    TBNAV_HIP(hipEventRecord(h->ev_w, st));
+    TBNAV_HIP(hipStreamWaitEvent(h->stream2, h->ev_w, 0));
+    rc = launch_normalize(h->stream2);
+    if (rc != TBNAV_OK) return rc;
+    TBNAV_HIP(hipEventRecord(h->ev_n, h->stream2));
+  }
   {
     const int bvn = c.Bv > 0 ? c.Bv : 1;
     const size_t tile_lds = sizeof(int) * kTileIntsPerBeam * bvn + sizeof(unsigned int) * ((size_t)(h->tile_cap + 1) / 2);
@@ -1892,23 +1919,23 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
     TBNAV_HIP(hipMemsetAsync(h->d_skip, 0, sizeof(int) * h->N, st));
     rc = run_distance_field(h, c.g, 0, h->N, (h->ysize + kWave - 1) / kWave);
     if (rc != TBNAV_OK) return rc;
-    TBNAV_HIP(hipMemsetAsync(h->d_fstate, 0, sizeof(int) * h->N, st));  // overwritten with 2 below
   }
   if (h->timing) TBNAV_HIP(hipEventRecord(h->ev[4], st));
-  if (!local_only) {
-    const double* z = h->d_normals + (size_t)h->N * c.stride_normals;
-    if (h->N <= kNormMaxLds)
-      hipLaunchKernelGGL(rbpf_normalize, dim3(1), dim3(256), sizeof(double) * 2 * h->N, st, h->N, z, sp.weight, h->d_parent, h->d_norm);
-    else
-      hipLaunchKernelGGL(rbpf_normalize_seq, dim3(1), dim3(64), 0, st, h->N, z, sp.weight, h->d_parent, h->d_norm);
-    TBNAV_HIP(hipGetLastError());
+  if (!local_only && !overlap) {
+    rc = launch_normalize(st);
+    if (rc != TBNAV_OK) return rc;
   }
   if (h->timing) TBNAV_HIP(hipEventRecord(h->ev[5], st));
-  // the map changed: every field is stale until the next refresh (whole-map mode: fresh everywhere)
-  TBNAV_HIP(hipMemsetD32Async((hipDeviceptr_t)h->d_fstate, h->full_edt ? 2 : 0, h->N, st));
-  *h->h_norm = NormOut{};
-  TBNAV_HIP(hipMemcpyAsync(h->h_err, h->d_err, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
-  if (!local_only) TBNAV_HIP(hipMemcpyAsync(h->h_norm, h->d_norm, sizeof(NormOut), hipMemcpyDeviceToHost, st));
+  // the map changed: every field is stale until the next refresh (whole-map mode: fresh everywhere).  In query mode
+  // the states are all zero already unless a field was injected or materialised since the last call.
+  if (h->full_edt) {
+    TBNAV_HIP(hipMemsetD32Async((hipDeviceptr_t)h->d_fstate, 2, h->N, st));
+    h->fstate_dirty = true;
+  } else if (h->fstate_dirty || h->df_mode != 2) {
+    TBNAV_HIP(hipMemsetD32Async((hipDeviceptr_t)h->d_fstate, 0, h->N, st));
+    h->fstate_dirty = h->df_mode != 2;
+  }
+  if (overlap) TBNAV_HIP(hipStreamWaitEvent(st, h->ev_n, 0));
   TBNAV_HIP(hipStreamSynchronize(st));
   const int* err = h->h_err;
   const NormOut no = *h->h_norm;
@@ -2038,10 +2065,13 @@ int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) {
   A((void**)&h->d_skip, sizeof(int) * N);
   A((void**)&h->d_win, sizeof(int4) * N);
   A((void**)&h->d_tier, sizeof(int) * N);
-  A((void**)&h->d_err, sizeof(int) * 4);
-  A((void**)&h->d_norm, sizeof(NormOut));
-  if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_err, sizeof(int) * 4, hipHostMallocDefault);
-  if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_norm, sizeof(NormOut), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_err, sizeof(int) * 4, hipHostMallocMapped);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_norm, sizeof(NormOut), hipHostMallocMapped);
+  if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&h->d_err, h->h_err, 0);
+  if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&h->d_norm, h->h_norm, 0);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_w, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_n, hipEventDisableTiming);
   const size_t kk = (size_t)h->k;
   const size_t trace_doubles = (size_t)N * (kk * 3 + kk + kk + 3 + 9 + 1 + 3 + 1);
   A((void**)&h->d_trace, sizeof(double) * trace_doubles);
@@ -2112,8 +2142,11 @@ void tbnav_rbpf_destroy(tbnav_rbpf* h) {
   DeviceGuard guard(h->device);
   for (int b = 0; b < 2; ++b) { (void)hipFree(h->d_state[b]); (void)hipFree(h->d_log_odds[b]); (void)hipFree(h->d_code[b]); (void)hipFree(h->d_nocc[b]); (void)hipFree(h->d_bitmap[b]); (void)hipFree(h->d_rowcount[b]); }
   (void)hipFree(h->d_beams); (void)hipFree(h->d_normals); (void)hipFree(h->d_parent); (void)hipFree(h->d_best); (void)hipFree(h->d_best_pose); (void)hipFree(h->d_export); (void)hipFree(h->d_tier); (void)hipFree(h->d_fstate); (void)hipFree(h->d_skip); (void)hipFree(h->d_win);
-  (void)hipFree(h->d_err); (void)hipFree(h->d_norm); (void)hipFree(h->d_trace);
+  (void)hipFree(h->d_trace);
   (void)hipHostFree(h->h_beams); (void)hipHostFree(h->h_err); (void)hipHostFree(h->h_norm);
+  if (h->ev_w) (void)hipEventDestroy(h->ev_w);
+  if (h->ev_n) (void)hipEventDestroy(h->ev_n);
+  if (h->stream2) (void)hipStreamDestroy(h->stream2);
   for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -2298,6 +2331,7 @@ int tbnav_rbpf_set_occ_dist(tbnav_rbpf* h, int32_t particle, const double* in) {
   TBNAV_HIP(hipMemcpy(h->d_code[h->cur] + (size_t)particle * h->G, code.data(), sizeof(uint16_t) * h->G, hipMemcpyHostToDevice));
   const int two = 2;  // an injected field is authoritative: the next call does not refresh it
   TBNAV_HIP(hipMemcpy(h->d_fstate + particle, &two, sizeof two, hipMemcpyHostToDevice));
+  h->fstate_dirty = true;
   return TBNAV_OK;
 }
 

@@ -66,10 +66,10 @@ def _compare_scan(pf_o, pf_d, tr_o, st, icp_ok):
         assert nocc[p] == len(g.occ_cells())
 
 
-def _run(gpu_pkg, N, k, map_half, walls, n_scans, icp_ok, beam_delta_deg=1.0, inc=(0.04, 0.03, 0.02), seed=3):
+def _run(gpu_pkg, N, k, map_half, walls, n_scans, icp_ok, beam_delta_deg=1.0, inc=(0.04, 0.03, 0.02), seed=3, **extra):
     n_beams = int(round(360 / beam_delta_deg))
-    pf_o = orc.PfAPI(orc.pf_params(N=N, k=k, map_min=-map_half, map_max=map_half, beam_delta_deg=beam_delta_deg))
-    pf_d = _dev(gpu_pkg, N=N, k=k, map_min=-map_half, map_max=map_half, beam_delta_deg=beam_delta_deg)
+    pf_o = orc.PfAPI(orc.pf_params(N=N, k=k, map_min=-map_half, map_max=map_half, beam_delta_deg=beam_delta_deg, **extra))
+    pf_d = _dev(gpu_pkg, N=N, k=k, map_min=-map_half, map_max=map_half, beam_delta_deg=beam_delta_deg, **extra)
     assert (pf_d.xsize, pf_d.ysize) == (pf_o.grid(0).xsize, pf_o.grid(0).ysize)
     steps, poses = rc.trajectory(n_scans, inc=inc)
     rng = np.random.default_rng(seed)
@@ -90,6 +90,21 @@ def test_shipped_config_40_particles_80x80_icp_ok(gpu_pkg):
     (pose, idx) = pf_d.getRobotState()
     assert idx == pf_o.best()
     assert np.array_equal(pf_d.newMap(), pf_o.grid(idx).grid_map())
+
+
+@pytest.mark.parametrize("spread", [1e-6, 1e-4, 4e-3])
+def test_sampling_spread_from_stable_to_all_unstable_beams(gpu_pkg, spread):
+    """The proposal kernel evaluates a beam once for all k samples when no sample can move its end point out of
+    the centre's cell, and per sample otherwise.  sample_range variances 1e-6 .. 4e-3 (sigma 1 mm .. 6 cm, against
+    5 cm cells) take it from "a few beams near cell borders" through the per-pair path to "every beam unstable"
+    (the wave-per-sample path); each must still match the oracle's k * Bv evaluation."""
+    _run(gpu_pkg, N=24, k=20, map_half=3.0, walls=rc.ROOM_SMALL, n_scans=4, icp_ok=True, sample_range=[spread * 0.1, spread, spread])
+
+
+def test_sensor_offset_and_rotation(gpu_pkg):
+    """Trs != identity (robot -> laser, rigid2d.cpp:214-224): the sensor transform takes both sincos, and the lookup
+    tile is centred on the sensor, not the robot."""
+    _run(gpu_pkg, N=24, k=20, map_half=3.0, walls=rc.ROOM_SMALL, n_scans=4, icp_ok=True, Trs=[0.3, 0.05, -0.02])
 
 
 def test_icp_failure_branch_motion_model(gpu_pkg):
