@@ -108,6 +108,14 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
         dom_ms = kms["raycast"]
         alg_dom = (c_free + Bv) * 16
         alg_note = "(C_free + Bv) * 16 B per particle, SURVEY.md 8-d"
+        try:
+            import json
+            with open(os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")) as f:
+                wl = json.load(f)["workloads"]["rbpf_N1000_k50_400x400"]
+            if N == 1000:
+                traffic = wl["rbpf_raycast_tile"]["hbm_bytes"]
+        except (OSError, KeyError, ValueError):
+            pass
     else:
         dom_name = "rbpf_edt_compact (distance field" + ("" if mode == "full" else f", {int(np.sqrt(win_cells))}^2-cell window per particle") + ")"
         dom_ms = kms["occupancy"] + kms["edt"]
