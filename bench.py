@@ -138,6 +138,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large", action="store_true")
+    ap.add_argument("--no-rbpf", action="store_true", help="skip the secondary RBPF object (development)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -226,11 +227,12 @@ def main():
             ml.close()
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(K, T, horizon)
-        try:
-            import bench_rbpf
-            line["rbpf"] = bench_rbpf.run(device, args)
-        except ImportError:
-            pass
+        if world == 1 and not args.no_rbpf:
+            try:
+                import bench_rbpf
+                line["rbpf"] = bench_rbpf.run(device, args, with_cpu=not args.no_cpu_baseline)
+            except ImportError:
+                pass
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

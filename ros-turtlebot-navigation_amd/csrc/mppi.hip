@@ -441,6 +441,139 @@ __global__ __launch_bounds__(kWave * MAXW) void mppi_rollout_scan(RolloutArgs a,
   }
 }
 
+
+// ---- fused rollout + soft-min partials for small K (lanes = TIME) ------------------------------------------
+// When K/64 one-wave workgroups cannot fill the chip (K = 1024: 16 of 256 CUs), the tick is three short kernels
+// whose execution time is all latency.  This kernel turns the rollout round: one WAVE per rollout with its lanes
+// over the time steps (TL consecutive steps per lane), so the three scans of the time-parallel formulation
+// (heading, position, cost-to-go) are wave scans — no chunk totals through LDS, no barriers between them — and a
+// workgroup is R rollouts (R waves), i.e. K/R workgroups spread over the chip (K = 1024, R = 8: 128 CUs).
+//   1. lane t of wave r loads element (t, k0 + r) of the noise: the R waves share each row's cache line(s);
+//   2. per lane: controls, dtheta -> wave scan -> heading at the start of its steps -> ONE sincos per step
+//      (+ angle addition) -> RK4 increments -> wave scans -> x, y -> loss -> wave suffix scan -> J (into LDS);
+//   3. J goes out coalesced, and — the tile being in LDS anyway — the soft-min partial record of every time step
+//      over the workgroup's R rollouts is formed here (groups of R lanes, xor-shuffles inside the group):
+//      records[T][K/R][8], the same record the partials kernel writes for a 2048-rollout slice.
+// The combine then merges K/R records per step instead of K/2048.  Numerics: the sums are wave-scan trees
+// instead of sequential chains (a few 1e-16 relative on x, y, theta, J — inside the 1e-11 J assertion).
+template <int TRIG, int R, int TL>
+__global__ __launch_bounds__(kWave * R) void mppi_rollout_fused(RolloutArgs a, const double* __restrict__ duL,
+                                                                const double* __restrict__ duR, USrc u, double lambda,
+                                                                double* __restrict__ J, double* __restrict__ records, int S) {
+  extern __shared__ __attribute__((aligned(16))) double lds_all[];
+  constexpr int RP = R + 1;  // padded tile rows: the transposed reads of a wave hit distinct banks
+  const int T = a.T, K = a.K;
+  double* nL = lds_all;           // [T][RP]
+  double* nR = nL + T * RP;       // [T][RP]
+  double* Jl = nR + T * RP;       // [T][RP]
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), r = tid / kWave, nthr = kWave * R;
+  const int k0 = blockIdx.x * R;
+  const int kk = (k0 + r < K) ? k0 + r : K - 1;  // a ragged tail shadows a valid rollout
+  {
+    // lane = time: the R waves of the workgroup read the same 64*R/8-byte rows of the noise, one element each (the
+    // row is one or two cache lines, fetched once and served to the other waves from L1); the values also go to
+    // the LDS tile for the partials below
+    double dl[TL], dr[TL], uL[TL], uR[TL];
+#pragma unroll
+    for (int q = 0; q < TL; ++q) {
+      const int i = lane * TL + q, ii = i < T ? i : T - 1;
+      dl[q] = duL[(size_t)ii * K + kk];
+      dr[q] = duR[(size_t)ii * K + kk];
+      uL[q] = u.get(0, ii, T);
+      uR[q] = u.get(1, ii, T);
+    }
+    double v[TL], w[TL], ctrl[TL], pth[TL];
+    double run = 0.0;
+#pragma unroll
+    for (int q = 0; q < TL; ++q) {
+      const int i = lane * TL + q;
+      const bool in = i < T;
+      const double ul = in ? uL[q] + dl[q] : 0.0;  // mppi.cpp:93 — rollout controls are not clamped
+      const double ur = in ? uR[q] + dr[q] : 0.0;
+      if (in) { nL[i * RP + r] = dl[q]; nR[i * RP + r] = dr[q]; }
+      ctrl[q] = (ul * a.R[0]) * ul + (ur * a.R[1]) * ur;
+      v[q] = a.half_r * (ul + ur);
+      w[q] = a.r_over_b * (ur - ul);
+      run += in ? a.h6 * (((w[q] + 2.0 * w[q]) + 2.0 * w[q]) + w[q]) : 0.0;
+      pth[q] = run;  // lane-local heading change AFTER step q
+    }
+    const double th_lane = a.x0[2] + (tbnav::wave_scan_incl(run, lane) - run);  // heading at the start of this lane's steps
+    double runx = 0.0, runy = 0.0, px[TL], py[TL];
+#pragma unroll
+    for (int q = 0; q < TL; ++q) {
+      const double hth = th_lane + (q == 0 ? 0.0 : pth[q - 1]);
+      double s1, c1, s2, c2, s4, c4;
+      fast_sincos(hth, s1, c1);
+      if (TRIG == 3) {
+        fast_sincos(hth + a.h * (0.5 * w[q]), s2, c2);
+        fast_sincos(hth + a.h * w[q], s4, c4);
+      } else {
+        double sd, cd;
+        small_sincos(a.h * (0.5 * w[q]), sd, cd);
+        c2 = c1 * cd - s1 * sd;
+        s2 = s1 * cd + c1 * sd;
+        const double s2d = 2.0 * sd * cd, c2d = 1.0 - 2.0 * sd * sd;
+        c4 = c1 * c2d - s1 * s2d;
+        s4 = s1 * c2d + c1 * s2d;
+      }
+      const double k1x = v[q] * c1, k1y = v[q] * s1, k2x = v[q] * c2, k2y = v[q] * s2, k4x = v[q] * c4, k4y = v[q] * s4;
+      const bool in = lane * TL + q < T;
+      runx += in ? a.h6 * (((k1x + 2.0 * k2x) + 2.0 * k2x) + k4x) : 0.0;
+      runy += in ? a.h6 * (((k1y + 2.0 * k2y) + 2.0 * k2y) + k4y) : 0.0;
+      px[q] = runx;
+      py[q] = runy;
+    }
+    const double x_lane = a.x0[0] + (tbnav::wave_scan_incl(runx, lane) - runx);
+    const double y_lane = a.x0[1] + (tbnav::wave_scan_incl(runy, lane) - runy);
+    double suf[TL];
+    run = 0.0;
+#pragma unroll
+    for (int q = TL - 1; q >= 0; --q) {
+      const int i = lane * TL + q;
+      const double e0 = (x_lane + px[q]) - a.xd[0], e1 = (y_lane + py[q]) - a.xd[1], e2 = (th_lane + pth[q]) - a.xd[2];
+      double l = (i == T - 1) ? ((e0 * a.P1[0]) * e0 + (e1 * a.P1[1]) * e1) + (e2 * a.P1[2]) * e2      // mppi.cpp:105 overwrites
+                              : (((e0 * a.Q[0]) * e0 + (e1 * a.Q[1]) * e1) + (e2 * a.Q[2]) * e2) + ctrl[q];
+      if (i >= T) l = 0.0;
+      run = l + run;
+      suf[q] = run;  // lane-local suffix sum from the lane's last step
+    }
+    const double tail = tbnav::wave_scan_incl_rev(run, lane) - run;  // cost of every later lane's steps
+#pragma unroll
+    for (int q = 0; q < TL; ++q) {
+      const int i = lane * TL + q;
+      if (i < T) Jl[i * RP + r] = suf[q] + tail;
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < T * R; idx += nthr) {
+    const int t = idx / R, rr = idx - t * R;
+    if (k0 + rr < K) J[(size_t)t * K + k0 + rr] = Jl[t * RP + rr];
+  }
+  // soft-min partial record of each time step over this workgroup's rollouts (mppi.cpp:115-121)
+  const double inf = __builtin_huge_val();
+  const int rr = tid % R;
+  const bool ok = k0 + rr < K;
+  for (int t = tid / R; t < T; t += nthr / R) {
+    const double j = ok ? Jl[t * RP + rr] : inf;
+    const double l = ok ? nL[t * RP + rr] : 0.0, rg = ok ? nR[t * RP + rr] : 0.0;
+    double mn = j;
+#pragma unroll
+    for (int off = R / 2; off > 0; off >>= 1) mn = fmin(mn, __shfl_xor(mn, off, kWave));
+    // exp(-(J - min)/lambda) with the reference's association: (J - min) * -1.0 / lambda (mppi.cpp:117)
+    const double e = ok ? exp(((j - mn) * -1.0) / lambda) : 0.0;
+    double A = e, B = e * l, C = e * rg, D = l, E = rg, n = ok ? 1.0 : 0.0;
+#pragma unroll
+    for (int off = R / 2; off > 0; off >>= 1) {
+      A += __shfl_xor(A, off, kWave); B += __shfl_xor(B, off, kWave); C += __shfl_xor(C, off, kWave);
+      D += __shfl_xor(D, off, kWave); E += __shfl_xor(E, off, kWave); n += __shfl_xor(n, off, kWave);
+    }
+    if (rr == 0) {
+      double* rec = records + ((size_t)t * S + blockIdx.x) * TBNAV_MPPI_REC;
+      rec[0] = mn; rec[1] = A; rec[2] = B; rec[3] = C; rec[4] = D; rec[5] = E; rec[6] = n; rec[7] = 0.0;
+    }
+  }
+}
+
 __device__ __forceinline__ double block_min(double v, double* scratch) {
   v = tbnav::wave_min(v);
   const int wid = threadIdx.x / kWave;
@@ -531,7 +664,8 @@ __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, double 
       const double* rec = records + (((size_t)g * T + i) * S + sl) * TBNAV_MPPI_REC;
       if (rec[6] > 0.0) M = fmin(M, rec[0]);
     }
-  for (int off = tpr >> 1; off > 0; off >>= 1) M = fmin(M, __shfl_xor(M, off, kWave));
+  if (tpr == kWave) M = tbnav::wave_min_dpp(M);  // a whole wave per time step: reductions on the DPP network
+  else for (int off = tpr >> 1; off > 0; off >>= 1) M = fmin(M, __shfl_xor(M, off, kWave));
   double W = 0, NL = 0, NR = 0, SD = 0, SE = 0, SN = 0;
   if (valid)
     for (int r = l; r < R; r += tpr) {
@@ -543,9 +677,14 @@ __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, double 
         SD += rec[4]; SE += rec[5]; SN += rec[6];
       }
     }
-  for (int off = tpr >> 1; off > 0; off >>= 1) {
-    W += __shfl_xor(W, off, kWave); NL += __shfl_xor(NL, off, kWave); NR += __shfl_xor(NR, off, kWave);
-    SD += __shfl_xor(SD, off, kWave); SE += __shfl_xor(SE, off, kWave); SN += __shfl_xor(SN, off, kWave);
+  if (tpr == kWave) {
+    W = tbnav::wave_sum_dpp(W); NL = tbnav::wave_sum_dpp(NL); NR = tbnav::wave_sum_dpp(NR);
+    SD = tbnav::wave_sum_dpp(SD); SE = tbnav::wave_sum_dpp(SE); SN = tbnav::wave_sum_dpp(SN);
+  } else {
+    for (int off = tpr >> 1; off > 0; off >>= 1) {
+      W += __shfl_xor(W, off, kWave); NL += __shfl_xor(NL, off, kWave); NR += __shfl_xor(NR, off, kWave);
+      SD += __shfl_xor(SD, off, kWave); SE += __shfl_xor(SE, off, kWave); SN += __shfl_xor(SN, off, kWave);
+    }
   }
   if (valid && l == 0) {
     W += 1e-8 * SN;  // the reference adds 1e-8 to every weight before normalising (mppi.cpp:117)
@@ -642,6 +781,9 @@ struct tbnav_mppi {
   double* h_out = nullptr;      // pinned [2]
   int lds_from = 0;           // first time step whose loss is staged in LDS (0 = all of them)
   int scan_tc = 0;            // steps per thread of the time-parallel rollout kernel (0 = sequential kernel)
+  int fused_r = 0;            // rollouts per workgroup of the fused rollout+partials kernel (0 = off: three kernels)
+  int fused_S = 0;            // its records per time step, ceil(K / fused_r)
+  double* d_records_f = nullptr;  // [T][fused_S][8]
   int trig = 1;               // sincos evaluations per RK4 step (1 = angle addition, 3 = the reference's three)
 };
 
@@ -687,6 +829,42 @@ int launch_rollout(tbnav_mppi* h, const double x0[3], const double* d_duL, const
   return TBNAV_OK;
 }
 
+
+RolloutArgs rollout_args(const tbnav_mppi* h, const double x0[3]) {
+  RolloutArgs a;
+  a.half_r = h->p.wheel_radius / 2.0;
+  a.r_over_b = h->p.wheel_radius / h->p.wheel_base;
+  a.h = h->p.dt;
+  a.h6 = h->p.dt / 6.0;
+  for (int c = 0; c < 3; ++c) { a.x0[c] = x0[c]; a.xd[c] = h->xd[c]; a.Q[c] = h->p.Q[c]; a.P1[c] = h->p.P1[c]; }
+  a.R[0] = h->p.R[0]; a.R[1] = h->p.R[1];
+  a.T = h->T; a.K = h->K;
+  a.lds_from = 0;
+  return a;
+}
+
+size_t fused_lds_bytes(int T, int R) { return (size_t)3 * T * (R + 1) * sizeof(double); }
+
+// rollout + partial records in one launch (small K); the caller follows with launch_combine(..., fused_S)
+int launch_fused(tbnav_mppi* h, const double x0[3], const double* d_duL, const double* d_duR, hipStream_t st) {
+  const RolloutArgs a = rollout_args(h, x0);
+  const USrc usrc{h->d_u[h->ucur], h->pending_shift ? 1 : 0, h->uinit[0], h->uinit[1]};
+  const int R = h->fused_r, TL = (h->T + kWave - 1) / kWave;
+  const dim3 grid(h->fused_S), block(kWave * R);
+  const size_t lds = fused_lds_bytes(h->T, R);
+#define TBNAV_FUSED(TR, RR, TLL) hipLaunchKernelGGL((mppi_rollout_fused<TR, RR, TLL>), grid, block, lds, st, a, d_duL, d_duR, usrc, \
+                                                    h->p.lambda, h->d_J, h->d_records_f, h->fused_S)
+#define TBNAV_FUSED_R(TR)                                                                  \
+  if (R == 8) { if (TL == 1) TBNAV_FUSED(TR, 8, 1); else TBNAV_FUSED(TR, 8, 2); }          \
+  else if (R == 4) { if (TL == 1) TBNAV_FUSED(TR, 4, 1); else TBNAV_FUSED(TR, 4, 2); }     \
+  else { if (TL == 1) TBNAV_FUSED(TR, 16, 1); else TBNAV_FUSED(TR, 16, 2); }
+  if (h->trig == 3) { TBNAV_FUSED_R(3) } else { TBNAV_FUSED_R(2) }
+#undef TBNAV_FUSED_R
+#undef TBNAV_FUSED
+  TBNAV_HIP(hipGetLastError());
+  return TBNAV_OK;
+}
+
 int launch_partials(tbnav_mppi* h, const double* d_duL, const double* d_duR, double* d_records, hipStream_t st) {
   const dim3 grid(h->S, h->T), block(kSliceThreads);
   hipLaunchKernelGGL(mppi_partials, grid, block, 0, st, h->T, h->K, h->S, h->p.lambda, h->d_J, d_duL, d_duR, d_records);
@@ -694,13 +872,14 @@ int launch_partials(tbnav_mppi* h, const double* d_duL, const double* d_duR, dou
   return TBNAV_OK;
 }
 
-int launch_combine(tbnav_mppi* h, const double* d_records, int G, hipStream_t st) {
+int launch_combine(tbnav_mppi* h, const double* d_records, int G, hipStream_t st, int S = -1) {
+  if (S < 0) S = h->S;
   int tpr = 1;
-  while (tpr < G * h->S && tpr < kWave) tpr <<= 1;
+  while (tpr < G * S && tpr < kWave) tpr <<= 1;
   const int steps_per_block = 4 * (kWave / tpr);  // 4 waves per workgroup
   const int blocks = (h->T + steps_per_block - 1) / steps_per_block;
   const USrc usrc{h->d_u[h->ucur], h->pending_shift ? 1 : 0, h->uinit[0], h->uinit[1]};
-  hipLaunchKernelGGL(mppi_combine, dim3(blocks), dim3(256), 0, st, h->T, G, h->S, h->p.lambda, h->p.max_wheel_vel, usrc,
+  hipLaunchKernelGGL(mppi_combine, dim3(blocks), dim3(256), 0, st, h->T, G, S, h->p.lambda, h->p.max_wheel_vel, usrc,
                      d_records, h->d_u[1 - h->ucur], h->d_out);
   TBNAV_HIP(hipGetLastError());
   h->ucur = 1 - h->ucur;       // the freshly written vector is current ...
@@ -806,6 +985,13 @@ int tbnav_mppi_create(const tbnav_mppi_params* params, tbnav_mppi** out) {
     const int tc = std::atoi(e), cmax = (tc == 4 || tc == 7 || tc == 8) ? 16 : 12;
     if (tc > 0 && (T + tc - 1) / tc <= cmax) h->scan_tc = tc;
   }
+  // fused rollout + partials (lanes = time): whenever the time-parallel kernel would be chosen and T fits two steps per lane
+  h->fused_r = (h->scan_tc > 0 && T <= 2 * kWave) ? 8 : 0;
+  if (const char* e = std::getenv("TBNAV_MPPI_FUSED")) {  // development switch: 0 = three kernels, 4 / 8 / 16 = rollouts per workgroup
+    const int r = std::atoi(e);
+    h->fused_r = (T <= 2 * kWave && (r == 4 || r == 8 || r == 16)) ? r : 0;
+  }
+  h->fused_S = h->fused_r ? (h->K + h->fused_r - 1) / h->fused_r : 0;
   if (const char* e = std::getenv("TBNAV_MPPI_TRIG")) { const int t = std::atoi(e); h->trig = (t == 2 || t == 3) ? t : 1; }
   if (const char* e = std::getenv("TBNAV_MPPI_NO_LDS")) { if (std::atoi(e) == 1) h->lds_from = T; }
   const size_t tk = (size_t)T * h->K;
@@ -817,6 +1003,7 @@ int tbnav_mppi_create(const tbnav_mppi_params* params, tbnav_mppi** out) {
   alloc(&h->d_duL, tk);
   alloc(&h->d_duR, tk);
   alloc(&h->d_records, (size_t)T * h->S * TBNAV_MPPI_REC);
+  if (h->fused_r) alloc(&h->d_records_f, (size_t)T * h->fused_S * TBNAV_MPPI_REC);
   alloc(&h->d_out, 2);
   if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_out, 2 * sizeof(double), hipHostMallocDefault);
   if (e == hipSuccess) e = hipMemset(h->d_u[0], 0, 2 * (size_t)T * sizeof(double));
@@ -847,7 +1034,7 @@ void tbnav_mppi_destroy(tbnav_mppi* h) {
   if (!h) return;
   DeviceGuard guard(h->device);
   (void)hipFree(h->d_u[0]); (void)hipFree(h->d_u[1]); (void)hipFree(h->d_J); (void)hipFree(h->d_duL); (void)hipFree(h->d_duR);
-  (void)hipFree(h->d_raw); (void)hipFree(h->d_records); (void)hipFree(h->d_out);
+  (void)hipFree(h->d_raw); (void)hipFree(h->d_records); (void)hipFree(h->d_records_f); (void)hipFree(h->d_out);
   if (h->h_out) (void)hipHostFree(h->h_out);
   delete h;
 }
@@ -914,6 +1101,11 @@ int tbnav_mppi_enqueue_dev(tbnav_mppi* h, const double x0[3], const double* d_du
   if (!h || !x0 || !pick_noise(h, d_duL, d_duR)) return TBNAV_ERR_INVALID_ARG;
   DeviceGuard guard(h->device);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (h->fused_r > 0) {
+    const int rcf = launch_fused(h, x0, d_duL, d_duR, st);
+    if (rcf != TBNAV_OK) return rcf;
+    return launch_combine(h, h->d_records_f, 1, st, h->fused_S);
+  }
   int rc = launch_rollout(h, x0, d_duL, d_duR, st);
   if (rc != TBNAV_OK) return rc;
   // (fusing the combine into the partials kernel's last workgroup was measured and rejected: DESIGN.md section 4)
@@ -931,9 +1123,14 @@ int tbnav_mppi_profile_tick(tbnav_mppi* h, const double x0[3], const double* d_d
   for (auto& e : ev) TBNAV_HIP(hipEventCreate(&e));
   int rc = TBNAV_OK;
   TBNAV_HIP(hipEventRecord(ev[0], st));
-  rc = launch_rollout(h, x0, d_duL, d_duR, st);
-  if (rc == TBNAV_OK) { TBNAV_HIP(hipEventRecord(ev[1], st)); rc = launch_partials(h, d_duL, d_duR, h->d_records, st); }
-  if (rc == TBNAV_OK) { TBNAV_HIP(hipEventRecord(ev[2], st)); rc = launch_combine(h, h->d_records, 1, st); }
+  if (h->fused_r > 0) {  // rollout and partials are one kernel: its time is reported under [0], [1] is the empty interval
+    rc = launch_fused(h, x0, d_duL, d_duR, st);
+    if (rc == TBNAV_OK) { TBNAV_HIP(hipEventRecord(ev[1], st)); TBNAV_HIP(hipEventRecord(ev[2], st)); rc = launch_combine(h, h->d_records_f, 1, st, h->fused_S); }
+  } else {
+    rc = launch_rollout(h, x0, d_duL, d_duR, st);
+    if (rc == TBNAV_OK) { TBNAV_HIP(hipEventRecord(ev[1], st)); rc = launch_partials(h, d_duL, d_duR, h->d_records, st); }
+    if (rc == TBNAV_OK) { TBNAV_HIP(hipEventRecord(ev[2], st)); rc = launch_combine(h, h->d_records, 1, st); }
+  }
   if (rc == TBNAV_OK) {
     TBNAV_HIP(hipEventRecord(ev[3], st));
     TBNAV_HIP(hipEventSynchronize(ev[3]));
