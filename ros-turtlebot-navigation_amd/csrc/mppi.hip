@@ -1040,7 +1040,7 @@ void tbnav_mppi_destroy(tbnav_mppi* h) {
 }
 
 int tbnav_mppi_steps(const tbnav_mppi* h) { return h ? h->T : -1; }
-int tbnav_mppi_rollout_variant(const tbnav_mppi* h) { return h ? h->scan_tc : -1; }
+int tbnav_mppi_rollout_variant(const tbnav_mppi* h) { return h ? (h->fused_r > 0 ? -h->fused_r : h->scan_tc) : 0; }
 int tbnav_mppi_rollouts(const tbnav_mppi* h) { return h ? h->K : -1; }
 int tbnav_mppi_records_per_step(const tbnav_mppi* h) { return h ? h->S : -1; }
 

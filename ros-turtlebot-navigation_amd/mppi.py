@@ -60,7 +60,8 @@ class MPPI:
         self.rollouts = self._L.tbnav_mppi_rollouts(self._h)
         self.records_per_step = self._L.tbnav_mppi_records_per_step(self._h)
         v = self._L.tbnav_mppi_rollout_variant(self._h)
-        self.rollout_kernel = "mppi_rollout_cost" if v == 0 else f"mppi_rollout_scan<{v} steps/thread>"
+        self.rollout_kernel = ("mppi_rollout_cost" if v == 0 else f"mppi_rollout_scan<{v} steps/thread>" if v > 0
+                               else f"mppi_rollout_fused<{-v} rollouts/workgroup> (rollout + partial records)")
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

@@ -68,6 +68,27 @@ def test_ragged_sizes(gpu_pkg, K, horizon):
     _check_tick(m, d, np.zeros((2, T)), (0, 0), WAYPOINTS[2], (0.5, 0.2, 1.0), _noise(K, K, T))
 
 
+@pytest.mark.parametrize("fused", ["0", "4", "8", "16"])
+@pytest.mark.parametrize("K,horizon", [(1024, 0.5), (100, 1.0), (37, 1.28), (9, 0.65)])
+def test_rollout_kernel_variants_agree_with_the_oracle(gpu_pkg, monkeypatch, fused, K, horizon):
+    """The small-K tick has two implementations: three kernels (time-parallel rollout, partials, combine;
+    TBNAV_MPPI_FUSED=0) and the fused rollout+partials kernel (one wave per rollout, lanes over time; 4 / 8 / 16
+    rollouts per workgroup).  Each must meet the oracle on its own: T = 50 (one step per lane), T = 100 and 128
+    (two steps per lane, full last lane), T = 65 (ragged last lanes), K not a multiple of the workgroup tile, and
+    three consecutive ticks so that the shift-on-read warm start is exercised in every variant."""
+    monkeypatch.setenv("TBNAV_MPPI_FUSED", fused)
+    d = mppi_cfg(K, horizon)
+    m = make_mppi(gpu_pkg, d)
+    T = orc.mppi_steps(d)
+    assert m.steps == T
+    m.setWaypoint(*WAYPOINTS[2])
+    u = np.zeros((2, T)); x0 = (0.5, 0.2, 1.0)
+    for tick in range(3):
+        ref = _check_tick(m, d, u, (0, 0), WAYPOINTS[2], x0, _noise(K + tick, K, T))
+        u = ref["u"]
+        x0 = (x0[0] + 0.002, x0[1] - 0.001, x0[2] + 0.003)
+
+
 def test_long_horizon_uses_global_scratch_path(gpu_pkg):
     """T = 400 > 320: per-step losses no longer fit LDS ([T][64] doubles), J is the scratch."""
     d = mppi_cfg(96, 4.0)
