@@ -70,6 +70,17 @@ int tbnav_mppi_rollouts(const tbnav_mppi* h); /* K of this handle           */
  * in the same launch).  The sharding entry points (tbnav_mppi_shard_partials) always use the first two. */
 int tbnav_mppi_rollout_variant(const tbnav_mppi* h);
 
+/* Rollout dynamics.  TBNAV_MPPI_DYN_RK4 (default) is the reference MPPI: CartModel + RK4 (controller/include/
+ * controller/mppi.hpp:41-48, controller/src/controller/rk4.cpp:95-115).  TBNAV_MPPI_DYN_ARC is an OPTION the
+ * reference's controller does not have: every rollout step is the plant's own update,
+ * rigid2d::DiffDrive::feedforward(wheelsToTwist(u) * dt) — exact arcs through Transform2D::integrateTwist, heading
+ * normalised to (-pi, pi] each step (rigid2d/src/rigid2d/diff_drive.cpp:79-94,153-195, rigid2d.cpp:239-303).  It
+ * changes the controller's results (model == plant, no RK4 truncation), so it has its own oracle, pinned against
+ * the reference's DiffDrive class. */
+#define TBNAV_MPPI_DYN_RK4 0
+#define TBNAV_MPPI_DYN_ARC 1
+int tbnav_mppi_set_dynamics(tbnav_mppi* h, int32_t model);
+
 /* ---- controller state ------------------------------------------------------------------------ */
 
 /* MPPI::setInitialControls (mppi.cpp:54-61): uinit = (uL,uR) and every column of u = uinit. */

@@ -91,6 +91,10 @@ inline int steps_of(const Params& p) { return static_cast<int>(p.horizon / p.dt)
 
 }  // namespace
 
+// exact-arc plant step (rbpf_oracle.cpp: the restated rigid2d::DiffDrive, itself pinned bit for bit against the
+// reference's own class by tests/test_oracle_vs_reference.py)
+extern "C" int orc_dd_arc_step(double wheel_base, double wheel_radius, double dt, double pose_xyt[3], const double wheels[2]);
+
 extern "C" {
 
 // rigid2d/src/rigid2d/utilities.cpp:20-24 (and bmapping particle_filter.cpp:25-34): a FRESH
@@ -137,9 +141,12 @@ void orc_softmin_step(double lambda, int K, const double* Jrow, const double* du
 //   loss_out [T][K] (nullable)   loss_mat
 //   J_out    [T][K] (nullable)   cost-to-go after cumSumCost, BEFORE the per-step min subtraction
 //   u_upd    [2][T] (nullable)   u after update+clamp, BEFORE the shift
-void orc_mppi_new_controls(const Params* pp, double* u, const double uinit[2], const double xd[3],
-                           const double x0[3], const double* noise, double* loss_out, double* J_out,
-                           double* u_upd, double out[2]) {
+// dyn = 0: the reference's RK4 cart (mppi.cpp:96).  dyn = 1 (an OPTION the reference's MPPI does
+// not have): each step is the plant's own update, rigid2d::DiffDrive::feedforward of wheelsToTwist(u) * dt
+// (diff_drive.cpp:79-94,153-195; rigid2d.cpp:239-303) — exact arcs, heading normalised to (-pi, pi] every step.
+void orc_mppi_new_controls_dyn(const Params* pp, double* u, const double uinit[2], const double xd[3],
+                               const double x0[3], const double* noise, double* loss_out, double* J_out,
+                               double* u_upd, double out[2], int dyn) {
   const Params& p = *pp;
   const int T = steps_of(p), K = p.rollouts;
   std::vector<double> loss_mat((size_t)T * K, 0.0), J((size_t)T * K), dul((size_t)T * K),
@@ -153,7 +160,8 @@ void orc_mppi_new_controls(const Params* pp, double* u, const double uinit[2], c
       dul[(size_t)i * K + k] = pl;                                      // :88-89
       dur[(size_t)i * K + k] = pr;
       const double up[2] = {u[i] + pl, u[T + i] + pr};                  // :93 (no clamp)
-      rk4_integrate(p, x, up);                                          // :96 -> rk4.cpp:61-66
+      if (dyn == 1) orc_dd_arc_step(p.wheel_base, p.wheel_radius, p.dt, x, up);
+      else rk4_integrate(p, x, up);                                     // :96 -> rk4.cpp:61-66
       loss_mat[(size_t)i * K + k] = loss(p, x, xd, up);                 // :99-102
       if (i == T - 1) loss_mat[(size_t)i * K + k] = terminal_loss(p, x, xd);  // :105 overwrites
     }
@@ -183,6 +191,12 @@ void orc_mppi_new_controls(const Params* pp, double* u, const double uinit[2], c
   for (int i = 0; i + 1 < T; ++i) { u[i] = u[i + 1]; u[T + i] = u[T + i + 1]; }  // :134
   u[T - 1] = uinit[0];                                                  // :136-137
   u[2 * T - 1] = uinit[1];
+}
+
+void orc_mppi_new_controls(const Params* pp, double* u, const double uinit[2], const double xd[3],
+                           const double x0[3], const double* noise, double* loss_out, double* J_out,
+                           double* u_upd, double out[2]) {
+  orc_mppi_new_controls_dyn(pp, u, uinit, xd, x0, noise, loss_out, J_out, u_upd, out, 0);
 }
 
 // ---- sharded formulation (include/tbnav_mppi.h header comment) — used by the world_size-2 gloo

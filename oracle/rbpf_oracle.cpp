@@ -689,6 +689,18 @@ int orc_dd_twist_to_wheels(void* d, const double tw[3], double out[2]) { return 
 void orc_dd_wheels_to_twist(void* d, const double w[2], double out[3]) { static_cast<orc::DiffDrive*>(d)->wheels_to_twist(w[0], w[1], out[0], out[1], out[2]); }
 void orc_dd_update_odometry(void* d, double left, double right, double out[2]) { static_cast<orc::DiffDrive*>(d)->update_odometry(left, right, out[0], out[1]); }
 int orc_dd_feedforward(void* d, const double tw[3]) { return static_cast<orc::DiffDrive*>(d)->feedforward(tw[0], tw[1], tw[2]) ? 0 : 1; }
+// One plant step as the nodes take it (mppi_waypoints_node.cpp:270-279, fake_diff_encoders_node.cpp:100-144):
+// twist = wheelsToTwist(wheels), scaled by the step, then DiffDrive::feedforward (diff_drive.cpp:79-94,153-195).
+// pose is (x, y, theta) in/out — the MPPI state order.  Returns 1 if feedforward would throw.
+int orc_dd_arc_step(double wheel_base, double wheel_radius, double dt, double pose_xyt[3], const double wheels[2]) {
+  orc::DiffDrive d;
+  d.theta = pose_xyt[2]; d.x = pose_xyt[0]; d.y = pose_xyt[1]; d.wheel_base = wheel_base; d.wheel_radius = wheel_radius;
+  double w, vx, vy;
+  d.wheels_to_twist(wheels[0], wheels[1], w, vx, vy);
+  if (!d.feedforward(w * dt, vx * dt, vy * dt)) return 1;
+  pose_xyt[0] = d.x; pose_xyt[1] = d.y; pose_xyt[2] = d.theta;
+  return 0;
+}
 void orc_dd_state(void* d, double out[7]) {
   auto* dd = static_cast<orc::DiffDrive*>(d);
   out[0] = orc::normalize_angle_PI(dd->theta); out[1] = dd->x; out[2] = dd->y;  // DiffDrive::pose(), :198-206

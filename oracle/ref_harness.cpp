@@ -90,6 +90,20 @@ int ref_dd_feedforward(void* d, const double tw[3]) {
     return 0;
   } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }
+// One plant step with the reference's own DiffDrive (same contract as orc_dd_arc_step): pose is (x, y, theta) in/out.
+int ref_dd_arc_step(double wheel_base, double wheel_radius, double dt, double pose_xyt[3], const double wheels[2]) {
+  try {
+    rigid2d::Pose p; p.theta = pose_xyt[2]; p.x = pose_xyt[0]; p.y = pose_xyt[1];
+    rigid2d::DiffDrive d(p, wheel_base, wheel_radius);
+    rigid2d::WheelVelocities v; v.ul = wheels[0]; v.ur = wheels[1];
+    Twist2D t = d.wheelsToTwist(v);
+    t.w = t.w * dt; t.vx = t.vx * dt; t.vy = t.vy * dt;
+    d.feedforward(t);
+    const auto q = d.pose();
+    pose_xyt[0] = q.x; pose_xyt[1] = q.y; pose_xyt[2] = q.theta;
+    return 0;
+  } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
 // out = (theta, x, y, enc_left, enc_right, ul, ur)
 void ref_dd_state(void* d, double out[7]) {
   auto* dd = static_cast<rigid2d::DiffDrive*>(d);

@@ -107,6 +107,7 @@ def lib() -> C.CDLL:
         "tbnav_mppi_steps": (C.c_int, [vp]),
         "tbnav_mppi_rollouts": (C.c_int, [vp]),
         "tbnav_mppi_rollout_variant": (C.c_int, [vp]),
+        "tbnav_mppi_set_dynamics": (C.c_int, [vp, i32]),
         "tbnav_mppi_records_per_step": (C.c_int, [vp]),
         "tbnav_mppi_set_initial_controls": (C.c_int, [vp, dbl, dbl]),
         "tbnav_mppi_set_waypoint": (C.c_int, [vp, dbl, dbl, dbl]),

@@ -48,6 +48,7 @@ struct USrc {
 struct RolloutArgs {
   double half_r;    // wheel_radius / 2.0            (mppi.hpp:45)
   double r_over_b;  // wheel_radius / wheel_base     (mppi.hpp:47)
+  double r_d;       // wheel_radius * (1 / wheel_base)   (diff_drive.cpp:85-88, arc dynamics only)
   double h;         // step                          (rk4.cpp:105)
   double h6;        // step / 6.0                    (rk4.cpp:114)
   double x0[3];
@@ -125,6 +126,63 @@ __device__ __forceinline__ void small_sincos(double d, double& sd, double& cd) {
     fast_sincos(d, sf, cf);
     sd = big ? sf : sd;
     cd = big ? cf : cd;
+  }
+}
+
+
+// ---- exact-arc dynamics (TRIG == 4; SURVEY.md 8-f N4 — an option, NOT the reference MPPI's RK4) ------------
+// One rollout step = the plant's own update: twist = DiffDrive::wheelsToTwist(u) * dt (diff_drive.cpp:79-94),
+// Transform2D::integrateTwist from the identity (rigid2d.cpp:239-303: the screw's rotation branch, the pure
+// translation branch for |w dt| < 1e-12, standstill), composed onto the pose as DiffDrive::feedforward does
+// (diff_drive.cpp:175-194: x += c*x' - s*y', heading normalised to (-pi, pi]).  The body-frame displacement
+// (xn, yn, thn) of a step depends only on the controls, so the rollout keeps the time-parallel shape: heading =
+// scan of thn, position = scan of the rotated displacements.
+__device__ __forceinline__ double normalize_angle_pi(double rad) {  // rigid2d.hpp:52-64
+  const double kPi = 3.14159265358979323846;
+  const double q = floor((rad + kPi) / (2.0 * kPi));
+  rad = (rad + kPi) - q * 2.0 * kPi;
+  if (rad < 0) rad += 2.0 * kPi;
+  return rad - kPi;
+}
+__device__ __forceinline__ void arc_body_step(const RolloutArgs& a, double ul, double ur, double& xn, double& yn, double& thn) {
+  const double tw = (a.r_d * (ur - ul)) * a.h;      // twist.w * dt
+  const double tv = (a.half_r * (ul + ur)) * a.h;   // twist.vx * dt   (vy == 0)
+  xn = 0.0; yn = 0.0; thn = 0.0;
+  if (!(fabs(tw) < 1.0e-12)) {
+    const double beta = fabs(tw), Sw = tw / beta, Svx = tv / beta;
+    double sb, cb;
+    fast_sincos(beta, sb, cb);
+    const double mw2 = -1.0 * (Sw * Sw);
+    xn = Svx * (beta + (beta - sb) * mw2);
+    yn = Svx * ((1.0 - cb) * Sw);
+    thn = atan2(sb * Sw, 1.0 + (1.0 - cb) * mw2);
+  } else if (!(fabs(tv) < 1.0e-12)) {
+    xn = tv;  // S.vx * beta with beta = |tv|, S.vx = +-1; no rotation
+  }
+}
+template <int G>
+__device__ __forceinline__ void arc_steps(const RolloutArgs& a, double& x, double& y, double& th,
+                                          const double (&ul)[G], const double (&ur)[G], double (&thq)[G],
+                                          double (&xq)[G], double (&yq)[G]) {
+  double xn[G], yn[G], hth[G];
+  double t = th;
+#pragma unroll
+  for (int q = 0; q < G; ++q) {
+    double thn;
+    arc_body_step(a, ul[q], ur[q], xn[q], yn[q], thn);
+    hth[q] = t;                              // heading at the START of step q (what Twb is built from)
+    t = normalize_angle_pi(t + thn);
+    thq[q] = t;
+  }
+  th = t;
+#pragma unroll
+  for (int q = 0; q < G; ++q) {
+    double s1, c1;
+    fast_sincos(hth[q], s1, c1);
+    x = (c1 * xn[q] - s1 * yn[q]) + x;
+    y = (s1 * xn[q] + c1 * yn[q]) + y;
+    xq[q] = x;
+    yq[q] = y;
   }
 }
 
@@ -216,7 +274,8 @@ __device__ __forceinline__ void rollout_group(const RolloutArgs& a, int i0, int 
     ul[q] = u[i0 + q] + dl[q];        // mppi.cpp:93 — rollout controls are not clamped
     ur[q] = u[T + i0 + q] + dr[q];
   }
-  rk4_steps<TRIG, G>(a, x, y, th, ul, ur, thq, xq, yq);
+  if constexpr (TRIG == 4) arc_steps<G>(a, x, y, th, ul, ur, thq, xq, yq);
+  else rk4_steps<TRIG, G>(a, x, y, th, ul, ur, thq, xq, yq);
 #pragma unroll
   for (int q = 0; q < G; ++q) {
     const int i = i0 + q;
@@ -492,17 +551,34 @@ __global__ __launch_bounds__(kWave * R) void mppi_rollout_fused(RolloutArgs a, c
       const double ur = in ? uR[q] + dr[q] : 0.0;
       if (in) { nL[i * RP + r] = dl[q]; nR[i * RP + r] = dr[q]; }
       ctrl[q] = (ul * a.R[0]) * ul + (ur * a.R[1]) * ur;
-      v[q] = a.half_r * (ul + ur);
-      w[q] = a.r_over_b * (ur - ul);
-      run += in ? a.h6 * (((w[q] + 2.0 * w[q]) + 2.0 * w[q]) + w[q]) : 0.0;
+      if constexpr (TRIG == 4) {  // exact arc: (v, w) hold the step's body-frame displacement (xn, yn)
+        double thn;
+        arc_body_step(a, ul, ur, v[q], w[q], thn);
+        run += in ? thn : 0.0;
+      } else {
+        v[q] = a.half_r * (ul + ur);
+        w[q] = a.r_over_b * (ur - ul);
+        run += in ? a.h6 * (((w[q] + 2.0 * w[q]) + 2.0 * w[q]) + w[q]) : 0.0;
+      }
       pth[q] = run;  // lane-local heading change AFTER step q
     }
     const double th_lane = a.x0[2] + (tbnav::wave_scan_incl(run, lane) - run);  // heading at the start of this lane's steps
     double runx = 0.0, runy = 0.0, px[TL], py[TL];
 #pragma unroll
     for (int q = 0; q < TL; ++q) {
-      const double hth = th_lane + (q == 0 ? 0.0 : pth[q - 1]);
+      double hth = th_lane + (q == 0 ? 0.0 : pth[q - 1]);
       double s1, c1, s2, c2, s4, c4;
+      if constexpr (TRIG == 4) {
+        // feedforward builds Twb from the CURRENT heading: the raw x0 for the first step, normalised afterwards
+        if (lane * TL + q > 0) hth = normalize_angle_pi(hth);
+        fast_sincos(hth, s1, c1);
+        const bool in4 = lane * TL + q < T;
+        runx += in4 ? (c1 * v[q] - s1 * w[q]) : 0.0;
+        runy += in4 ? (s1 * v[q] + c1 * w[q]) : 0.0;
+        px[q] = runx;
+        py[q] = runy;
+        continue;
+      }
       fast_sincos(hth, s1, c1);
       if (TRIG == 3) {
         fast_sincos(hth + a.h * (0.5 * w[q]), s2, c2);
@@ -530,7 +606,8 @@ __global__ __launch_bounds__(kWave * R) void mppi_rollout_fused(RolloutArgs a, c
 #pragma unroll
     for (int q = TL - 1; q >= 0; --q) {
       const int i = lane * TL + q;
-      const double e0 = (x_lane + px[q]) - a.xd[0], e1 = (y_lane + py[q]) - a.xd[1], e2 = (th_lane + pth[q]) - a.xd[2];
+      const double th_after = (TRIG == 4) ? normalize_angle_pi(th_lane + pth[q]) : th_lane + pth[q];
+      const double e0 = (x_lane + px[q]) - a.xd[0], e1 = (y_lane + py[q]) - a.xd[1], e2 = th_after - a.xd[2];
       double l = (i == T - 1) ? ((e0 * a.P1[0]) * e0 + (e1 * a.P1[1]) * e1) + (e2 * a.P1[2]) * e2      // mppi.cpp:105 overwrites
                               : (((e0 * a.Q[0]) * e0 + (e1 * a.Q[1]) * e1) + (e2 * a.Q[2]) * e2) + ctrl[q];
       if (i >= T) l = 0.0;
@@ -785,6 +862,7 @@ struct tbnav_mppi {
   int fused_S = 0;            // its records per time step, ceil(K / fused_r)
   double* d_records_f = nullptr;  // [T][fused_S][8]
   int trig = 1;               // sincos evaluations per RK4 step (1 = angle addition, 3 = the reference's three)
+  int dyn = 0;                // rollout dynamics: 0 = the reference's RK4 cart, 1 = exact arcs (tbnav_mppi_set_dynamics)
 };
 
 namespace {
@@ -794,6 +872,7 @@ int launch_rollout(tbnav_mppi* h, const double x0[3], const double* d_duL, const
   RolloutArgs a;
   a.half_r = h->p.wheel_radius / 2.0;
   a.r_over_b = h->p.wheel_radius / h->p.wheel_base;
+  a.r_d = h->p.wheel_radius * (1 / h->p.wheel_base);
   a.h = h->p.dt;
   a.h6 = h->p.dt / 6.0;
   for (int c = 0; c < 3; ++c) { a.x0[c] = x0[c]; a.xd[c] = h->xd[c]; a.Q[c] = h->p.Q[c]; a.P1[c] = h->p.P1[c]; }
@@ -801,7 +880,7 @@ int launch_rollout(tbnav_mppi* h, const double x0[3], const double* d_duL, const
   a.T = h->T; a.K = h->K;
   const dim3 grid((h->K + kWave - 1) / kWave), block(kWave);
   const USrc usrc{h->d_u[h->ucur], h->pending_shift ? 1 : 0, h->uinit[0], h->uinit[1]};
-  if (h->scan_tc > 0) {
+  if (h->scan_tc > 0 && h->dyn == 0) {  // (the arc dynamics live in the fused and the sequential kernels)
     const int TCv = h->scan_tc, C = (h->T + TCv - 1) / TCv;
     const size_t lds = ((size_t)2 * h->T + (size_t)4 * C * kWave) * sizeof(double);
     const dim3 blk(kWave, C);
@@ -821,7 +900,8 @@ int launch_rollout(tbnav_mppi* h, const double x0[3], const double* d_duL, const
   } else {
     const size_t lds = (size_t)2 * h->T * sizeof(double) + (size_t)(h->T - h->lds_from) * kWave * sizeof(double);
     a.lds_from = h->lds_from;
-    if (h->trig == 1) hipLaunchKernelGGL((mppi_rollout_cost<1>), grid, block, lds, st, a, d_duL, d_duR, usrc, h->d_J);
+    if (h->dyn == 1) hipLaunchKernelGGL((mppi_rollout_cost<4>), grid, block, lds, st, a, d_duL, d_duR, usrc, h->d_J);
+    else if (h->trig == 1) hipLaunchKernelGGL((mppi_rollout_cost<1>), grid, block, lds, st, a, d_duL, d_duR, usrc, h->d_J);
     else if (h->trig == 2) hipLaunchKernelGGL((mppi_rollout_cost<2>), grid, block, lds, st, a, d_duL, d_duR, usrc, h->d_J);
     else hipLaunchKernelGGL((mppi_rollout_cost<3>), grid, block, lds, st, a, d_duL, d_duR, usrc, h->d_J);
   }
@@ -834,6 +914,7 @@ RolloutArgs rollout_args(const tbnav_mppi* h, const double x0[3]) {
   RolloutArgs a;
   a.half_r = h->p.wheel_radius / 2.0;
   a.r_over_b = h->p.wheel_radius / h->p.wheel_base;
+  a.r_d = h->p.wheel_radius * (1 / h->p.wheel_base);
   a.h = h->p.dt;
   a.h6 = h->p.dt / 6.0;
   for (int c = 0; c < 3; ++c) { a.x0[c] = x0[c]; a.xd[c] = h->xd[c]; a.Q[c] = h->p.Q[c]; a.P1[c] = h->p.P1[c]; }
@@ -858,7 +939,7 @@ int launch_fused(tbnav_mppi* h, const double x0[3], const double* d_duL, const d
   if (R == 8) { if (TL == 1) TBNAV_FUSED(TR, 8, 1); else TBNAV_FUSED(TR, 8, 2); }          \
   else if (R == 4) { if (TL == 1) TBNAV_FUSED(TR, 4, 1); else TBNAV_FUSED(TR, 4, 2); }     \
   else { if (TL == 1) TBNAV_FUSED(TR, 16, 1); else TBNAV_FUSED(TR, 16, 2); }
-  if (h->trig == 3) { TBNAV_FUSED_R(3) } else { TBNAV_FUSED_R(2) }
+  if (h->dyn == 1) { TBNAV_FUSED_R(4) } else if (h->trig == 3) { TBNAV_FUSED_R(3) } else { TBNAV_FUSED_R(2) }
 #undef TBNAV_FUSED_R
 #undef TBNAV_FUSED
   TBNAV_HIP(hipGetLastError());
@@ -1019,6 +1100,8 @@ int tbnav_mppi_create(const tbnav_mppi_params* params, tbnav_mppi** out) {
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mppi_rollout_cost<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     if (e == hipSuccess)
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mppi_rollout_cost<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mppi_rollout_cost<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
   }
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) {
@@ -1040,6 +1123,12 @@ void tbnav_mppi_destroy(tbnav_mppi* h) {
 }
 
 int tbnav_mppi_steps(const tbnav_mppi* h) { return h ? h->T : -1; }
+int tbnav_mppi_set_dynamics(tbnav_mppi* h, int32_t model) {
+  if (!h || (model != TBNAV_MPPI_DYN_RK4 && model != TBNAV_MPPI_DYN_ARC)) return TBNAV_ERR_INVALID_ARG;
+  h->dyn = model;
+  return TBNAV_OK;
+}
+
 int tbnav_mppi_rollout_variant(const tbnav_mppi* h) { return h ? (h->fused_r > 0 ? -h->fused_r : h->scan_tc) : 0; }
 int tbnav_mppi_rollouts(const tbnav_mppi* h) { return h ? h->K : -1; }
 int tbnav_mppi_records_per_step(const tbnav_mppi* h) { return h ? h->S : -1; }

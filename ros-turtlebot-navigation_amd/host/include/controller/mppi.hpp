@@ -52,6 +52,9 @@ class MPPI {
 
   // ---- additions (not in the reference) ----
   void useDeviceNoise(std::uint64_t seed);   ///< draw the perturbations on the GPU (Philox) instead of the host twister
+  /// Not in the reference: integrate the rollouts with the plant's own step, rigid2d::DiffDrive::feedforward of
+  /// wheelsToTwist(u) * dt (exact arcs), instead of CartModel + RK4.  Off by default (tbnav_mppi_set_dynamics).
+  void useExactArcDynamics(bool on = true);
   int steps() const { return steps_; }
   int rollouts() const { return rollouts_; }
   std::vector<double> controls() const;      ///< warm-start matrix u, [2][T]

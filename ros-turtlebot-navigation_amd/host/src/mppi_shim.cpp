@@ -44,6 +44,7 @@ MPPI::MPPI(MPPI&& o) noexcept
 void MPPI::setInitialControls(double uL, double uR) { check(tbnav_mppi_set_initial_controls(h_, uL, uR), "setInitialControls"); }
 void MPPI::setWaypoint(const Pose& w) { check(tbnav_mppi_set_waypoint(h_, w.x, w.y, w.theta), "setWaypoint"); }
 void MPPI::useDeviceNoise(std::uint64_t seed) { device_noise_ = true; seed_ = seed; tick_ = 0; }
+void MPPI::useExactArcDynamics(bool on) { check(tbnav_mppi_set_dynamics(h_, on ? TBNAV_MPPI_DYN_ARC : TBNAV_MPPI_DYN_RK4), "useExactArcDynamics"); }
 
 WheelVelocities MPPI::newControls(const Pose& ps) {
   const double x0[3] = {ps.x, ps.y, ps.theta};  // mppi.cpp:75-76: state order (x, y, theta)

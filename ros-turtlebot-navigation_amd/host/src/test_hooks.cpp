@@ -96,6 +96,7 @@ void hst_twister_stream(uint64_t seed, int64_t n, double mu, double sigma, doubl
 // odometry_mode 1: the full chain of the demo: the plant's wheel encoders, wrapped to
 //   [-pi, pi) as fake_diff_encoders publishes them (fake_diff_encoders_node.cpp:100-144), feed a second DiffDrive
 //   through updateOdometry (odometry_node.cpp:169-253); the controller sees THAT pose.
+// odometry_mode bit 1 (value 2): the controller integrates its rollouts with exact arcs (useExactArcDynamics, N4).
 int hst_mppi_closed_loop(const double* params, int rollouts, uint64_t seed, const double* waypoints /*[n][3] x,y,theta*/,
                          int n_wpts, double goal_thresh, double rate, int max_ticks, double* traj_out, int* wpts_reached,
                          int odometry_mode, double* max_odom_dev) {
@@ -104,6 +105,8 @@ int hst_mppi_closed_loop(const double* params, int rollouts, uint64_t seed, cons
     controller::CartModel cart(params[0], params[1]);
     controller::LossFunc loss({params[8], params[9], params[10]}, {params[11], params[12]}, {params[13], params[14], params[15]});
     controller::MPPI mppi(cart, loss, params[2], params[3], params[4], params[5], params[6], params[7], rollouts);
+    if (odometry_mode & 2) mppi.useExactArcDynamics(true);
+    odometry_mode &= 1;
     rigid2d::getTwister().seed(seed);
     rigid2d::Pose start; start.x = waypoints[0]; start.y = waypoints[1]; start.theta = waypoints[2];
     rigid2d::DiffDrive plant(start, params[1], params[0]);

@@ -74,6 +74,11 @@ class MPPI:
     def setInitialControls(self, uL: float, uR: float):
         capi.check(self._L.tbnav_mppi_set_initial_controls(self._h, uL, uR), "set_initial_controls")
 
+    def setDynamics(self, model: str):
+        """"rk4": the reference's CartModel + RK4 (default).  "arc": every rollout step is the plant's own update,
+        DiffDrive::feedforward(wheelsToTwist(u) * dt) — exact arcs (SURVEY.md 8-f N4; an option, not the reference)."""
+        capi.check(self._L.tbnav_mppi_set_dynamics(self._h, {"rk4": 0, "arc": 1}[model]), "set_dynamics")
+
     def setWaypoint(self, x: float, y: float, theta: float):
         capi.check(self._L.tbnav_mppi_set_waypoint(self._h, x, y, theta), "set_waypoint")
 

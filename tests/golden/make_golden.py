@@ -104,6 +104,12 @@ def rigid_fixture():
         states.append(r.dd_state(d))
     out["dd_cmds"] = np.array(cmds); out["dd_states"] = np.array(states)
     r.dd_destroy(d)
+    # exact-arc plant steps (wheelsToTwist * dt -> feedforward), the dynamics of the arc-rollout option (N4)
+    arc_pose = np.concatenate([rng.uniform(-3, 3, (80, 2)), rng.uniform(-7, 7, (80, 1))], 1)
+    arc_wheels = rng.uniform(-6.35, 6.35, (80, 2))
+    arc_wheels[:4] = [[1.0, 1.0], [0.0, 0.0], [2.0, 2.0 + 1e-11], [6.3, -6.3]]
+    out["arc_pose"] = arc_pose; out["arc_wheels"] = arc_wheels
+    out["arc_out"] = np.array([r.dd_arc_step(0.16, 0.033, 0.01, p, w)[0] for p, w in zip(arc_pose, arc_wheels)])
     # knife-edge thresholds (SURVEY.md hard part 2): prob(l) for l around the occupied / free cut-offs
     l_occ, l_free = r.prob_to_log_odds(0.90), r.prob_to_log_odds(0.35)
     ls = np.array([l_occ, np.nextafter(l_occ, 0), np.nextafter(l_occ, 9), l_free, np.nextafter(l_free, 0), np.nextafter(l_free, -9),

@@ -94,9 +94,10 @@ def softmin_step(lam, Jrow, dul, dur):
     return w, sl.value, sr.value
 
 
-def mppi_new_controls(d: dict, u: np.ndarray, uinit, xd, x0, noise: np.ndarray) -> dict:
+def mppi_new_controls(d: dict, u: np.ndarray, uinit, xd, x0, noise: np.ndarray, dyn: int = 0) -> dict:
     """Runs one reference tick.  `u` ([2][T]) is NOT modified; the result dict carries
-    loss, J (before min-subtraction), u_upd (before shift), u (after shift), out (ul, ur)."""
+    loss, J (before min-subtraction), u_upd (before shift), u (after shift), out (ul, ur).
+    dyn = 1: exact-arc plant dynamics (DiffDrive::feedforward per step) instead of the RK4 cart."""
     p = mppi_params(d)
     T, K = lib().orc_mppi_steps(C.byref(p)), p.rollouts
     u2 = np.array(u, dtype=np.float64, order="C").copy()
@@ -104,8 +105,8 @@ def mppi_new_controls(d: dict, u: np.ndarray, uinit, xd, x0, noise: np.ndarray) 
     assert noise.size == K * T * 2 and u2.shape == (2, T)
     lossm = np.empty((T, K)); J = np.empty((T, K)); uupd = np.empty((2, T)); out = np.empty(2)
     ui, xdv, x0v = (np.array(v, dtype=np.float64) for v in (uinit, xd, x0))
-    lib().orc_mppi_new_controls(C.byref(p), _p(u2), _p(ui), _p(xdv), _p(x0v), _p(noise), _p(lossm), _p(J),
-                                _p(uupd), _p(out))
+    lib().orc_mppi_new_controls_dyn(C.byref(p), _p(u2), _p(ui), _p(xdv), _p(x0v), _p(noise), _p(lossm), _p(J),
+                                    _p(uupd), _p(out), int(dyn))
     return dict(loss=lossm, J=J, u_upd=uupd, u=u2, out=(out[0], out[1]))
 
 
@@ -323,6 +324,14 @@ class RigidAPI:
 
     def dd_state(self, d):
         out = np.empty(7); self._f("dd_state")(d, _p(out)); return out
+
+    def dd_arc_step(self, wheel_base, wheel_radius, dt, pose_xyt, wheels):
+        """One plant step (wheelsToTwist * dt -> feedforward); returns the new (x, y, theta) and the error flag."""
+        f = self._f("dd_arc_step")
+        f.argtypes = [C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+        pose = np.array(pose_xyt, dtype=np.float64)
+        rc = f(float(wheel_base), float(wheel_radius), float(dt), _p(pose), _p(np.array(wheels, dtype=np.float64)))
+        return pose, rc
 
 
 # ---- particle filter (restatement only: the reference's particle_filter.cpp needs Eigen) ----------

@@ -155,6 +155,17 @@ def test_closed_loop_through_wrapped_encoders_and_odometry(host, gpu_pkg):
 
 
 @pytest.mark.gpu
+def test_closed_loop_with_exact_arc_rollouts(host, gpu_pkg):
+    """SURVEY.md 8-f N4 in the loop: the controller integrates its rollouts with the plant's own arc step
+    (controller::MPPI::useExactArcDynamics) and still laps the pentagon through the wrapped-encoder odometry chain."""
+    d = dict(MPPI_BASE, rollouts=1024, horizon=0.5)
+    traj, reached = _closed_loop(host, d, 1024, 6000, odometry_mode=3)
+    assert reached == 5, f"only {reached} of 5 waypoints in {len(traj)} ticks"
+    assert _closed_loop.last_dev < 1e-9
+    print(f"   arc-dynamics lap: {len(traj)} ticks")
+
+
+@pytest.mark.gpu
 def test_particle_filter_class_surface_end_to_end(host, gpu_pkg):
     """bmapping::ParticleFilter driven like turtle_mapping_node.cpp:459-494 (SLAM, getRobotState,
     newMap).  No distance-field injection here, so the comparison with the oracle filter is an

@@ -20,8 +20,8 @@ def _noise(seed, K, T, var=0.9):
     return orc.normal_stream(seed, K * T * 2, 0.0, np.sqrt(var)).reshape(K, T, 2)
 
 
-def _check_tick(m, d, u_before, uinit, xd, x0, noise):
-    ref = orc.mppi_new_controls(d, u_before, uinit, xd, x0, noise)
+def _check_tick(m, d, u_before, uinit, xd, x0, noise, dyn=0):
+    ref = orc.mppi_new_controls(d, u_before, uinit, xd, x0, noise, dyn=dyn)
     got = m.newControls(*x0, noise)
     J = m.costToGo()
     assert rel_err(J, ref["J"]) < J_RTOL
@@ -87,6 +87,45 @@ def test_rollout_kernel_variants_agree_with_the_oracle(gpu_pkg, monkeypatch, fus
         ref = _check_tick(m, d, u, (0, 0), WAYPOINTS[2], x0, _noise(K + tick, K, T))
         u = ref["u"]
         x0 = (x0[0] + 0.002, x0[1] - 0.001, x0[2] + 0.003)
+
+
+@pytest.mark.parametrize("K,horizon,x0", [(1024, 0.5, (0.5, 0.2, 1.0)), (64, 1.0, (0.0, 0.0, 3.1)), (37, 1.28, (-1.0, 2.0, -3.0)),
+                                          (100, 4.0, (0.1, 0.1, 0.4)), (16640, 0.3, (0.3, -0.2, 2.0))])
+def test_exact_arc_dynamics_option(gpu_pkg, K, horizon, x0):
+    """SURVEY.md 8-f N4: rollouts integrated with the plant's own step (DiffDrive::feedforward of
+    wheelsToTwist(u) * dt) instead of the RK4 cart.  The oracle's step is pinned bit for bit against the reference's
+    DiffDrive class (tests/test_oracle_vs_reference.py, tests/golden/ref_rigid2d.npz); the device must meet the
+    oracle at the usual tolerances in the fused kernel (T = 50, 100, 128), the sequential kernel (T = 400 and
+    K = 16640 >= 2 waves per CU-SIMD pair) — including headings that cross the +-pi cut during the horizon — over
+    three ticks of warm start."""
+    d = mppi_cfg(K, horizon)
+    m = make_mppi(gpu_pkg, d)
+    m.setDynamics("arc")
+    T = orc.mppi_steps(d)
+    m.setWaypoint(*WAYPOINTS[2])
+    m.setInitialControls(2.0, 3.5)             # a turning warm start: the heading sweeps ~0.3 rad/s
+    u = np.zeros((2, T)); u[0] = 2.0; u[1] = 3.5
+    for tick in range(3 if K <= 1024 else 1):
+        ref = _check_tick(m, d, u, (2.0, 3.5), WAYPOINTS[2], x0, _noise(K + tick, K, T), dyn=1)
+        u = ref["u"]
+        x0 = (x0[0] + 0.002, x0[1] - 0.001, x0[2] + 0.003)
+
+
+def test_arc_and_rk4_dynamics_agree_to_truncation_order(gpu_pkg):
+    """The two dynamics describe the same cart: with zero-order-hold controls RK4's error per step is O(dt^5) in the
+    position, so the cost-to-go of the two models differs by a hair, not by a modelling error (and not by zero:
+    the option really is a different integrator)."""
+    d = mppi_cfg(256, 0.5)
+    nz = _noise(5, 256, 50)
+    Js = []
+    for model in ("rk4", "arc"):
+        m = make_mppi(gpu_pkg, d)
+        m.setDynamics(model)
+        m.setWaypoint(*WAYPOINTS[1])
+        m.newControls(0.1, 0.2, 0.3, nz)
+        Js.append(m.costToGo().copy())
+    rel = np.abs(Js[0] - Js[1]) / np.abs(Js[0])
+    assert 0 < rel.max() < 1e-6
 
 
 def test_long_horizon_uses_global_scratch_path(gpu_pkg):

@@ -73,6 +73,9 @@ def test_rigid2d_matches_reference_fixture(rg):
             r.dd_update_odometry(d, cmd[1], cmd[2])
         assert np.array_equal(r.dd_state(d), st)
     r.dd_destroy(d)
+    for p, w, want in zip(rg["arc_pose"], rg["arc_wheels"], rg["arc_out"]):   # the arc-rollout plant step (N4)
+        got, rc = r.dd_arc_step(0.16, 0.033, 0.01, p, w)
+        assert rc == 0 and np.array_equal(got, want)
     assert np.array_equal([r.log_odds_to_prob(l) for l in rg["knife_l"]], rg["knife_prob"])
     assert np.array_equal([r.pdf_normal(a, b)[0] for a, b in rg["pdf_in"]], rg["pdf_out"])
 

@@ -66,6 +66,30 @@ def test_diff_drive_sequences_bit_exact():
     a.dd_destroy(da); b.dd_destroy(db)
 
 
+def test_arc_plant_step_bit_exact():
+    """the exact-arc rollout dynamics are the plant's own step, wheelsToTwist(u) * dt ->
+    DiffDrive::feedforward.  The restated step (what the arc-dynamics MPPI oracle integrates with) must equal the
+    reference's own class bit for bit: turning both ways, straight lines (|w dt| < 1e-12: the screw's translation
+    branch), standstill, headings that wrap at +-pi, and chains of steps fed back into themselves."""
+    a, b = orc.RigidAPI("orc"), orc.RigidAPI("ref")
+    rng = np.random.default_rng(4)
+    wb, wr, dt = 0.16, 0.033, 0.01
+    cases = [((0.0, 0.0, 0.0), (1.0, 1.0)), ((0.3, -0.2, 3.14159), (6.3, -6.3)), ((1.0, 2.0, -3.1415926), (-2.0, 5.0)),
+             ((0.0, 0.0, 1.0), (0.0, 0.0)), ((0.5, 0.5, 0.7), (2.0, 2.0 + 1e-11)), ((0.5, 0.5, 0.7), (1e-13, -1e-13))]
+    cases += [(tuple(rng.uniform(-3, 3, 2)) + (rng.uniform(-7, 7),), tuple(rng.uniform(-6.35, 6.35, 2))) for _ in range(400)]
+    for pose, wheels in cases:
+        pa, ra = a.dd_arc_step(wb, wr, dt, pose, wheels)
+        pb, rb = b.dd_arc_step(wb, wr, dt, pose, wheels)
+        assert ra == rb == 0 and np.array_equal(pa, pb), (pose, wheels)
+    pa = pb = np.array([0.1, -0.4, 3.0])
+    for i in range(500):                       # a lap that crosses the +-pi cut several times
+        wheels = (4.0 + np.sin(0.05 * i), 6.0)
+        pa, _ = a.dd_arc_step(wb, wr, 0.05, pa, wheels)
+        pb, _ = b.dd_arc_step(wb, wr, 0.05, pb, wheels)
+        assert np.array_equal(pa, pb)
+    assert abs(pa[2]) <= np.pi
+
+
 @pytest.mark.parametrize("grid,delta", [((0.05, -2.0, 2.0, -2.0, 2.0), 1.0), ((0.05, -3.0, 3.0, -3.0, 3.0), 1.0),
                                         ((0.05, -10.0, 10.0, -10.0, 10.0), 1.0), ((0.1, -5.0, 5.0, -5.0, 5.0), 1.0 / 3.0)])
 def test_grid_mapper_scan_sequences_bit_exact(grid, delta):
