@@ -67,7 +67,7 @@ int tbnav_mppi_rollouts(const tbnav_mppi* h); /* K of this handle           */
 /* Which rollout kernel a tick of this handle launches: 0 = mppi_rollout_cost (one lane per rollout, sequential in
  * time), n > 0 = mppi_rollout_scan with n time steps per thread (64 rollouts x ceil(T/n) waves), n < 0 =
  * mppi_rollout_fused with -n rollouts per workgroup (one wave per rollout, lanes over time, partial records formed
- * in the same launch).  The sharding entry points (tbnav_mppi_shard_partials) always use the first two. */
+ * in the same launch; tbnav_mppi_shard_partials then folds those fine records into the K-slice records). */
 int tbnav_mppi_rollout_variant(const tbnav_mppi* h);
 
 /* Rollout dynamics.  TBNAV_MPPI_DYN_RK4 (default) is the reference MPPI: CartModel + RK4 (controller/include/

@@ -719,6 +719,39 @@ __global__ __launch_bounds__(kSliceThreads) void mppi_partials(int T, int K, int
   }
 }
 
+
+// Fold the fused kernel's fine records ([T][Sf][8], one per R rollouts) into the K-slice records the sharding
+// interface exchanges ([T][S][8], one per kSlice = 2048 rollouts): grid (S, T), one wave each.  Same algebra as the
+// combine's first half — re-base every partial sum to the common minimum — so the result equals the partials
+// kernel's record for that slice up to the association of the sums.
+__global__ __launch_bounds__(kWave) void mppi_merge_records(int T, int Sf, int per_slice, int S, double lambda,
+                                                            const double* __restrict__ fine, double* __restrict__ records) {
+  const int s = blockIdx.x, i = blockIdx.y, lane = threadIdx.x;
+  const int r0 = s * per_slice, r1 = min(Sf, r0 + per_slice);
+  const double inf = __builtin_huge_val();
+  double M = inf;
+  for (int r = r0 + lane; r < r1; r += kWave) {
+    const double* rec = fine + ((size_t)i * Sf + r) * TBNAV_MPPI_REC;
+    if (rec[6] > 0.0) M = fmin(M, rec[0]);
+  }
+  M = tbnav::wave_min_dpp(M);
+  double A = 0, B = 0, C = 0, D = 0, E = 0, n = 0;
+  for (int r = r0 + lane; r < r1; r += kWave) {
+    const double* rec = fine + ((size_t)i * Sf + r) * TBNAV_MPPI_REC;
+    if (rec[6] > 0.0) {
+      const double sc = exp(((rec[0] - M) * -1.0) / lambda);
+      A += sc * rec[1]; B += sc * rec[2]; C += sc * rec[3];
+      D += rec[4]; E += rec[5]; n += rec[6];
+    }
+  }
+  A = tbnav::wave_sum_dpp(A); B = tbnav::wave_sum_dpp(B); C = tbnav::wave_sum_dpp(C);
+  D = tbnav::wave_sum_dpp(D); E = tbnav::wave_sum_dpp(E); n = tbnav::wave_sum_dpp(n);
+  if (lane == 0) {
+    double* out = records + ((size_t)i * S + s) * TBNAV_MPPI_REC;
+    out[0] = M; out[1] = A; out[2] = B; out[3] = C; out[4] = D; out[5] = E; out[6] = n; out[7] = 0.0;
+  }
+}
+
 // Merge the G*S partial records of every time step (records: [G][T][S][8]) and update u(:,i)
 // (mppi.cpp:118-125).  Each time step gets a group of `tpr` lanes (the power of two >= the record count, at
 // most a wave): 64/tpr steps per wave, xor-shuffle reductions inside the group.  Any number of workgroups:
@@ -1174,6 +1207,16 @@ int tbnav_mppi_shard_partials(tbnav_mppi* h, const double x0[3], const double* d
   if (!h || !x0 || !d_records_out || !pick_noise(h, d_duL, d_duR)) return TBNAV_ERR_INVALID_ARG;
   DeviceGuard guard(h->device);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (h->fused_r > 0 && kSlice % h->fused_r == 0) {
+    // small K: the fused rollout+partials kernel, then its fine records folded into the K-slice records that the
+    // ranks exchange (two short launches instead of three)
+    const int rcf = launch_fused(h, x0, d_duL, d_duR, st);
+    if (rcf != TBNAV_OK) return rcf;
+    hipLaunchKernelGGL(mppi_merge_records, dim3(h->S, h->T), dim3(kWave), 0, st, h->T, h->fused_S, kSlice / h->fused_r, h->S,
+                       h->p.lambda, h->d_records_f, d_records_out);
+    TBNAV_HIP(hipGetLastError());
+    return TBNAV_OK;
+  }
   int rc = launch_rollout(h, x0, d_duL, d_duR, st);
   if (rc != TBNAV_OK) return rc;
   return launch_partials(h, d_duL, d_duR, d_records_out, st);

@@ -56,6 +56,9 @@ __host__ __device__ inline double normalize_angle_PI(double rad) {  // rigid2d.h
 
 __device__ __forceinline__ int floor_div_small(int num, int den);  // exact floor(num/den), |num| < 2^24, 0 < den < 2^13
 
+// Development build (-DTBNAV_PHASE_PROF): per-phase wall-clock stamps inside the proposal and raycast kernels, summed
+// over workgroups and printed by tbnav_rbpf_destroy.  The stamps add barriers and global atomics — the kernels
+// run measurably slower with them; the numbers are for comparing phases, not for the bench.
 #ifdef TBNAV_PHASE_PROF
 __device__ unsigned long long g_phase[8];
 __device__ unsigned long long g_phase_p[8];
@@ -1283,7 +1286,6 @@ constexpr int kZMax = 8190;
 constexpr int kEdtCompactMaxRows = 2047;  // packed entry: 11 bits of row index
 __device__ __forceinline__ uint32_t pack(int v, int f, int z) { return (uint32_t)v | ((uint32_t)f << 11) | ((uint32_t)(z + 1) << 19); }
 __device__ __forceinline__ void unpack(uint32_t e, int& v, int& f, int& z) { v = (int)(e & 0x7FFu); f = (int)((e >> 11) & 0xFFu); z = (int)(e >> 19) - 1; }
-__device__ __forceinline__ int unpack_z(uint32_t e) { return (int)(e >> 19) - 1; }
 template <int SMAX>
 __global__ __launch_bounds__(kWave) void rbpf_edt_compact(GridC g, int radius, const unsigned long long* __restrict__ bitmap,
                                                           const int* __restrict__ row_count,
@@ -2135,8 +2137,18 @@ int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) {
 
 void tbnav_rbpf_destroy(tbnav_rbpf* h) {
 #ifdef TBNAV_PHASE_PROF
-  { unsigned long long ph[8]; if (hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_phase_p), sizeof(ph)) == hipSuccess && ph[7]) { std::fprintf(stderr, "[propose phases, 10ns ticks per block] sample+prefill %.1f (wave0 sampling %.1f) likelihood %.1f tail %.1f | unstable beams per block %.1f | wave0 clocks per block: first beam loop %.0f first wave_prods %.0f\n", (double)ph[0]/ph[7], (double)ph[5]/ph[7], (double)ph[1]/ph[7], (double)ph[2]/ph[7], (double)ph[6]/ph[7], (double)ph[3]/ph[7], (double)ph[4]/ph[7]); } }
-  { unsigned long long ph[8]; if (hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_phase), sizeof(ph)) == hipSuccess && ph[7]) { std::fprintf(stderr, "[raycast phases, 10ns ticks per block] setup %.1f count %.1f flag %.1f replay %.1f rest %.1f | ncell %.0f endcells %.0f\n", (double)ph[0]/ph[7], (double)ph[1]/ph[7], (double)ph[2]/ph[7], (double)ph[3]/ph[7], (double)ph[4]/ph[7], (double)ph[5]/ph[7], (double)ph[6]/ph[7]); } }
+  {
+    unsigned long long ph[8];
+    if (hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_phase_p), sizeof(ph)) == hipSuccess && ph[7])
+      std::fprintf(stderr, "[propose phases, 10 ns ticks per workgroup] sampling %.1f | up to the per-beam lookups %.1f | per-sample products %.1f | "
+                           "Gaussian fit %.1f | unstable beams %.1f\n",
+                   (double)ph[5] / ph[7], (double)ph[0] / ph[7], (double)ph[1] / ph[7], (double)ph[2] / ph[7], (double)ph[6] / ph[7]);
+    if (hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_phase), sizeof(ph)) == hipSuccess && ph[7])
+      std::fprintf(stderr, "[raycast phases, 10 ns ticks per workgroup] set-up %.1f | flags/slots %.1f | ray walk %.1f | end-point replay %.1f | "
+                           "other cells %.1f | overflowed slots %.2f | end-point cells %.1f\n",
+                   (double)ph[0] / ph[7], (double)ph[1] / ph[7], (double)ph[2] / ph[7], (double)ph[3] / ph[7], (double)ph[4] / ph[7],
+                   (double)ph[5] / ph[7], (double)ph[6] / ph[7]);
+  }
 #endif
   if (!h) return;
   DeviceGuard guard(h->device);
