@@ -94,6 +94,17 @@ int tbnav_rbpf_slam(tbnav_rbpf* h, const float* scan, int32_t n_beams, const dou
                     const double cur_odom[3], const double prev_odom[3], int32_t icp_ok,
                     const double T_icp[3], const double* normals, tbnav_rbpf_stats* out);
 
+/* OPTION (not something the reference does): per-particle scan-to-map matching.  The reference
+ * aligns scan to scan once per call with PCL ICP (cloud_alignment.cpp:37-223) and every particle samples round
+ * T(pose) * T_icp (particle_filter.cpp:146-153,181-188).  With this on, each particle first refines that pose
+ * against its OWN map by hill climbing on the reference's scoring function (GridMapper::likelihoodFieldModel,
+ * grid_mapper.cpp:69-133): six neighbours (+-x, +-y by lstep metres, +-theta by astep radians), move to the best
+ * strictly better one, else halve the steps, `iterations` halvings; T_icp then only has to be a rough initial
+ * guess (e.g. the odometry increment), which removes the third-party matcher from the loop.  Off by default.
+ * tbnav_rbpf_get_scan_match returns the matched poses [N][3] (theta, x, y) and scores [N] of the last call. */
+int tbnav_rbpf_set_scan_matching(tbnav_rbpf* h, int32_t enable, double lstep, double astep, int32_t iterations);
+int tbnav_rbpf_get_scan_match(tbnav_rbpf* h, double* centers, double* scores);
+
 /* ParticleFilter::getRobotState (particle_filter.cpp:255-274): pose of the arg-max-weight particle
  * (strict >, first wins, starting from 0.0).  best_index is optional. */
 int tbnav_rbpf_best_state(tbnav_rbpf* h, double pose[3], int32_t* best_index);

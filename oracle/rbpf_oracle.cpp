@@ -494,6 +494,14 @@ class PF {
       } else {
         T2 T_x = make_T(particle.pose[1], particle.pose[2], particle.pose[0]);
         compose(T_x, T_icp);
+        if (sm_on) {
+          double c3[3] = {T_x.theta, T_x.x, T_x.y};
+          const double sc = scan_match(particle, scan, n, c3);
+          T_x = make_T(c3[1], c3[2], c3[0]);
+          sm_centers.resize((size_t)N * 3); sm_scores.resize(N);
+          for (int c = 0; c < 3; ++c) sm_centers[(size_t)pi * 3 + c] = c3[c];
+          sm_scores[pi] = sc;
+        }
         std::vector<double> sampled((size_t)k * 3);
         sample_mode(T_x, sampled.data(), normals + nz);  // :504-519
         nz += (size_t)3 * k;
@@ -561,6 +569,40 @@ class PF {
   PfParams P;
   std::vector<Particle> set;
   double sq_sum = 0.0;
+  // N1 option (NOT in the reference): per-particle scan-to-map refinement of the mode T(pose)*T_icp before sampling
+  bool sm_on = false;
+  double sm_lstep = 0.05, sm_astep = 0.05;
+  int sm_iters = 5, sm_max_moves = 64;
+  std::vector<double> sm_centers;  // [N][3] (theta, x, y) of the last call
+  std::vector<double> sm_scores;   // [N]
+
+  // Hill climbing on the particle's own likelihood field (the scoring function is the reference's
+  // GridMapper::likelihoodFieldModel, grid_mapper.cpp:69-133).  From the pose c0: evaluate the six neighbours
+  // +x, -x, +y, -y, +theta, -theta (world frame, steps lstep / astep); move to the best of them if it is strictly
+  // better than the current pose; otherwise halve both steps; stop after `iters` halvings (or max_moves rounds).
+  // "Better" means by a factor > 1 + 1e-9: the likelihood is piecewise constant in the pose (it only sees cells), so
+  // neighbouring poses often have the SAME factors on different beams, and a bare > would follow rounding noise.
+  static constexpr double kSmGain = 1.0 + 1e-9;
+  double scan_match(Particle& particle, const float* scan, int n, double c[3]) const {
+    double best = particle.grid.likelihood(scan, n, make_T(c[1], c[2], c[0]));
+    double lstep = sm_lstep, astep = sm_astep;
+    int refinements = 0;
+    for (int round = 0; round < sm_max_moves && refinements < sm_iters; ++round) {
+      double cand_best = best, cand[3] = {c[0], c[1], c[2]};
+      for (int m = 0; m < 6; ++m) {
+        double q[3] = {c[0], c[1], c[2]};
+        const double sgn = (m & 1) ? -1.0 : 1.0;
+        if (m < 2) q[1] = c[1] + sgn * lstep;
+        else if (m < 4) q[2] = c[2] + sgn * lstep;
+        else q[0] = normalize_angle_PI(c[0] + sgn * astep);
+        const double sc = particle.grid.likelihood(scan, n, make_T(q[1], q[2], q[0]));
+        if (sc > cand_best * kSmGain) { cand_best = sc; cand[0] = q[0]; cand[1] = q[1]; cand[2] = q[2]; }
+      }
+      if (cand_best > best) { best = cand_best; c[0] = cand[0]; c[1] = cand[1]; c[2] = cand[2]; }
+      else { lstep *= 0.5; astep *= 0.5; ++refinements; }
+    }
+    return best;
+  }
 
  private:
   // particle_filter.cpp:295-322 (+ sampleMultivariateDistribution(cov) :37-47 with a diagonal cov)
@@ -803,6 +845,16 @@ void orc_pf_set_particles(void* pf, const double* pose, const double* prev_pose,
     for (int c = 0; c < 3; ++c) { if (pose) f->set[i].pose[c] = pose[i * 3 + c]; if (prev_pose) f->set[i].prev_pose[c] = prev_pose[i * 3 + c]; }
     if (weight) f->set[i].weight = weight[i];
   }
+}
+// N1 option: switch the per-particle scan matcher on/off; centres/scores of the last call.
+void orc_pf_set_scan_matching(void* pf, int on, double lstep, double astep, int iters) {
+  auto* f = static_cast<orc::PF*>(pf);
+  f->sm_on = on != 0; f->sm_lstep = lstep; f->sm_astep = astep; f->sm_iters = iters;
+}
+void orc_pf_get_scan_match(void* pf, double* centers, double* scores) {
+  auto* f = static_cast<orc::PF*>(pf);
+  if (centers) std::memcpy(centers, f->sm_centers.data(), sizeof(double) * f->sm_centers.size());
+  if (scores) std::memcpy(scores, f->sm_scores.data(), sizeof(double) * f->sm_scores.size());
 }
 void* orc_pf_grid(void* pf, int p) { return &static_cast<orc::PF*>(pf)->set.at(p).grid; }  // borrowed orc_gm handle
 int orc_pf_best(void* pf) { return static_cast<orc::PF*>(pf)->best(); }

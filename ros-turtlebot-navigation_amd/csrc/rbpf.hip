@@ -365,6 +365,115 @@ struct Trace {
   double *sampled, *p_scan, *p_pose, *mu, *sigma, *eta, *new_pose, *weight_raw;
 };
 
+
+// ---- per-particle scan matcher (SURVEY.md 8-f N1 — an OPTION, not the reference) -----------------------------
+// The reference matches scan to scan ONCE per call with PCL ICP (cloud_alignment.cpp:37-223) and every particle
+// samples round T(pose) * T_icp (particle_filter.cpp:146-153,181-188).  With scan matching on, each particle
+// refines that pose against ITS OWN map before sampling, gmapping-style: hill climbing on the likelihood field
+// (GridMapper::likelihoodFieldModel, grid_mapper.cpp:69-133 — the reference's own scoring function).  From the
+// current pose evaluate the six neighbours +x, -x, +y, -y, +theta, -theta (world frame); move to the best of them if it
+// is better by a factor > 1 + 1e-9 (the likelihood only sees cells, so neighbouring poses often carry the same
+// factors on different beams: a bare > would follow rounding noise); otherwise halve both steps; stop after
+// `iters` halvings (or max_moves rounds).
+// Workgroup = particle, 6 waves: wave m scores neighbour m (lanes over the beams, lookups on the LDS slice of the
+// bitmap), thread 0 applies the rule.  Same rule, same order of comparisons as oracle/rbpf_oracle.cpp::scan_match.
+struct ScanMatchC { double lstep, astep; int iters, max_moves; };
+constexpr int kMatchThreads = 6 * kWave;
+__global__ __launch_bounds__(kMatchThreads) void rbpf_scanmatch(ScanC c, ScanMatchC sm, const double2* __restrict__ beams,
+                                                                const uint16_t* __restrict__ codes,
+                                                                const unsigned long long* __restrict__ bitmap,
+                                                                const int* __restrict__ row_count, const int* __restrict__ skip,
+                                                                int skip_eq, int df_mode, int radius, int occ_half,
+                                                                const int* __restrict__ n_occ, const int4* __restrict__ win,
+                                                                const double* __restrict__ pose, double* __restrict__ center,
+                                                                double* __restrict__ score, int* __restrict__ err) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int p = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
+  double2* lbeams = reinterpret_cast<double2*>(lds);                       // [Bv]
+  unsigned long long* const tile_bm = reinterpret_cast<unsigned long long*>(lbeams + c.Bv);
+  __shared__ double cur[3], best, steps[2], cand[6];
+  __shared__ int refinements, done;
+  const double th0 = pose[p * 3 + 0], x0 = pose[p * 3 + 1], y0 = pose[p * 3 + 2];
+  double s0, c0;
+  sincos(th0, &s0, &c0);
+  const double mu0[3] = {th0 + c.Ticp[0], c0 * c.Ticp[1] - s0 * c.Ticp[2] + x0, s0 * c.Ticp[1] + c0 * c.Ticp[2] + y0};
+  const int nocc = n_occ[p];
+  if (nocc == 0) {  // empty map: the likelihood is 1 everywhere (grid_mapper.cpp:94-98), nothing can improve
+    if (tid == 0) { center[p * 3 + 0] = mu0[0]; center[p * 3 + 1] = mu0[1]; center[p * 3 + 2] = mu0[2]; score[p] = 1.0; }
+    return;
+  }
+  DistSrc ds{codes + (size_t)p * c.g.xsize * c.g.ysize, bitmap + (size_t)p * c.g.xsize * c.g.words, row_count + (size_t)p * c.g.xsize,
+             win[p], skip[p] == skip_eq ? 0 : df_mode, tile_bm, reinterpret_cast<const int*>(tile_bm), 0, 0, 0, 0};
+  for (int b = tid; b < c.Bv; b += kMatchThreads) lbeams[b] = beams[b];
+  if (ds.mode == 2 && occ_half > 0) {  // the same LDS slice of the bitmap as the proposal kernel, round the first guess
+    double Tc[4];
+    sensor_transform(c, mu0[0], mu0[1], mu0[2], Tc);
+    int sci, scj;
+    if (world2cell(c.g, Tc[0], Tc[1], sci, scj)) {
+      const int R0 = max(0, sci - occ_half), R1 = min(c.g.xsize - 1, sci + occ_half);
+      const int W0 = max(0, scj - occ_half) >> 6, W1 = min(c.g.ysize - 1, scj + occ_half) >> 6, nW = W1 - W0 + 1;
+      int* ta = reinterpret_cast<int*>(tile_bm + (size_t)(R1 - R0 + 1) * nW);
+      for (int r = tid; r <= R1 - R0; r += kMatchThreads) {
+        unsigned long long acc = 0ull;
+        for (int w = 0; w < nW; ++w) {
+          const unsigned long long v = ds.bm[(size_t)(R0 + r) * c.g.words + W0 + w];
+          tile_bm[r * nW + w] = v;
+          acc |= v;
+        }
+        ta[r] = acc != 0ull;
+      }
+      ds.tany = ta; ds.R0 = R0; ds.R1 = R1; ds.W0 = W0; ds.nW = nW;
+    }
+  }
+  if (tid == 0) { cur[0] = mu0[0]; cur[1] = mu0[1]; cur[2] = mu0[2]; steps[0] = sm.lstep; steps[1] = sm.astep; refinements = 0; done = 0; }
+  __syncthreads();
+  int oob = 0;
+  auto likelihood = [&](double th, double x, double y) {
+    double T[4];
+    sensor_transform(c, th, x, y, T);
+    double pr = 1.0;
+    for (int b = lane; b < c.Bv; b += kWave) pr *= beam_factor(c, ds, radius, lbeams[b], T[0], T[1], T[2], T[3], 0xFFFFFFFFu, 0xFFFFFFFFu, 0.0, &oob);
+    return wave_prod(pr);
+  };
+  if (wid == 0) {
+    const double l0 = likelihood(cur[0], cur[1], cur[2]);
+    if (lane == 0) best = l0;
+  }
+  __syncthreads();
+  for (int round = 0; round < sm.max_moves; ++round) {
+    {
+      const double sgn = (wid & 1) ? -1.0 : 1.0;
+      double q[3] = {cur[0], cur[1], cur[2]};
+      if (wid < 2) q[1] = cur[1] + sgn * steps[0];
+      else if (wid < 4) q[2] = cur[2] + sgn * steps[0];
+      else q[0] = normalize_angle_PI(cur[0] + sgn * steps[1]);
+      const double sc = likelihood(q[0], q[1], q[2]);
+      if (lane == 0) cand[wid] = sc;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double cb = best;
+      int arg = -1;
+      for (int m = 0; m < 6; ++m) if (cand[m] > cb * (1.0 + 1e-9)) { cb = cand[m]; arg = m; }
+      if (arg >= 0) {
+        const double sgn = (arg & 1) ? -1.0 : 1.0;
+        if (arg < 2) cur[1] = cur[1] + sgn * steps[0];
+        else if (arg < 4) cur[2] = cur[2] + sgn * steps[0];
+        else cur[0] = normalize_angle_PI(cur[0] + sgn * steps[1]);
+        best = cb;
+      } else {
+        steps[0] *= 0.5; steps[1] *= 0.5;
+        if (++refinements >= sm.iters) done = 1;
+      }
+    }
+    __syncthreads();
+    if (done) break;
+  }
+  if (oob & 1) atomicOr(&err[0], 1);
+  if (oob & 2) atomicOr(&err[3], 4);
+  if (tid == 0) { center[p * 3 + 0] = cur[0]; center[p * 3 + 1] = cur[1]; center[p * 3 + 2] = cur[2]; score[p] = best; }
+}
+
 // err[0] = out of world, err[1] = eta zero, err[2] = pdf variance zero, err[3] = bresenham
 __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c, const double2* __restrict__ beams,
                                                                 const uint16_t* __restrict__ codes,
@@ -372,7 +481,7 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
                                                                 const int* __restrict__ row_count, const int* __restrict__ skip,
                                                                 int skip_eq, int df_mode, int radius, int occ_half,
                                                                 const int* __restrict__ n_occ, const int4* __restrict__ win,
-                                                                const double* __restrict__ normals,
+                                                                const double* __restrict__ normals, const double* __restrict__ center,
                                                                 double* __restrict__ pose, double* __restrict__ prev_pose,
                                                                 double* __restrict__ weight, Trace tr, int* __restrict__ err) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -441,7 +550,9 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
   const double th0 = pose[p * 3 + 0], x0 = pose[p * 3 + 1], y0 = pose[p * 3 + 2];
   double s0, c0;
   sincos(th0, &s0, &c0);
-  const double mu0[3] = {th0 + c.Ticp[0], c0 * c.Ticp[1] - s0 * c.Ticp[2] + x0, s0 * c.Ticp[1] + c0 * c.Ticp[2] + y0};
+  // the mode the samples are drawn round: T(pose) * T_icp, or the particle's own scan-matched pose (N1 option)
+  const double mu0[3] = {center ? center[p * 3 + 0] : th0 + c.Ticp[0], center ? center[p * 3 + 1] : c0 * c.Ticp[1] - s0 * c.Ticp[2] + x0,
+                         center ? center[p * 3 + 2] : s0 * c.Ticp[1] + c0 * c.Ticp[2] + y0};
   const double pv[3] = {prev_pose[p * 3 + 0], prev_pose[p * 3 + 1], prev_pose[p * 3 + 2]};
   for (int b = tid; b < c.Bv; b += kProposeThreads) lbeams[b] = beams[b];  // visible after the next barrier
   double Tc[4];  // sensor transform at the centre of the samples
@@ -1609,6 +1720,10 @@ struct tbnav_rbpf {
   int* d_best = nullptr;       // arg-max particle index
   double* d_best_pose = nullptr;
   int8_t* d_export = nullptr;  // [G]
+  bool sm_on = false;          // N1 option: per-particle scan matching before sampling (tbnav_rbpf_set_scan_matching)
+  ScanMatchC sm{0.05, 0.05, 5, 64};
+  double* d_center = nullptr;  // [N][3] matched poses of the last call
+  double* d_score = nullptr;   // [N]
   bool timing = false;         // record HIP events round the kernels (tbnav_rbpf_set_timing): each costs device time, so off by default
   int tile_cap = 0;            // cells of the raycast LDS tile (0 = use the beam-ordered kernel)
   int raycast_threads = 1024;  // block size of the tile raycast (dev switch TBNAV_RBPF_RAYCAST_THREADS)
@@ -1863,6 +1978,7 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
   }
   if (h->timing) TBNAV_HIP(hipEventRecord(h->ev[1], st));
   size_t propose_lds = sizeof(double) * ((12 + kUnCap) * h->k + 3 * (c.Bv > 0 ? c.Bv : 1)) + sizeof(unsigned int) * 4 * (c.Bv > 0 ? c.Bv : 1);
+  const size_t propose_lds_base = propose_lds;  // (what follows adds the LDS slice of the occupancy bitmap)
   int occ_half = 0;
   if (h->df_mode == 2) {
     // LDS copy of the occupancy bitmap round each particle's sensor: reach of a lookup (range_max + sampling
@@ -1877,10 +1993,21 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
       if (bytes <= 48 * 1024) { occ_half = half; propose_lds += bytes; break; }
     }
   }
+  const int* skip_arr = h->df_mode == 2 ? h->d_fstate : h->d_skip;
+  const int skip_eq = h->df_mode == 2 ? 2 : 1;
+  const double* center = nullptr;
+  if (h->sm_on && c.icp_ok) {
+    // N1 option: every particle refines T(pose) * T_icp against its own map first; the samples are drawn round that
+    const size_t sm_lds = sizeof(double2) * (c.Bv > 0 ? c.Bv : 1) + (propose_lds - propose_lds_base);
+    hipLaunchKernelGGL(rbpf_scanmatch, dim3(h->N), dim3(kMatchThreads), sm_lds, st, c, h->sm, h->d_beams, h->d_code[h->cur],
+                       h->d_bitmap[h->cur], h->d_rowcount[h->cur], skip_arr, skip_eq, h->df_mode, h->radius, occ_half,
+                       h->d_nocc[h->cur], h->d_win, sp.pose, h->d_center, h->d_score, h->d_err);
+    TBNAV_HIP(hipGetLastError());
+    center = h->d_center;
+  }
   hipLaunchKernelGGL(rbpf_propose, dim3(h->N), dim3(kProposeThreads), propose_lds, st, c, h->d_beams,
-                     h->d_code[h->cur], h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->df_mode == 2 ? h->d_fstate : h->d_skip,
-                     h->df_mode == 2 ? 2 : 1, h->df_mode, h->radius, occ_half,
-                     h->d_nocc[h->cur], h->d_win, h->d_normals, sp.pose, sp.prev, sp.weight, h->tr, h->d_err);
+                     h->d_code[h->cur], h->d_bitmap[h->cur], h->d_rowcount[h->cur], skip_arr, skip_eq, h->df_mode, h->radius, occ_half,
+                     h->d_nocc[h->cur], h->d_win, h->d_normals, center, sp.pose, sp.prev, sp.weight, h->tr, h->d_err);
   TBNAV_HIP(hipGetLastError());
   if (h->timing) TBNAV_HIP(hipEventRecord(h->ev[2], st));
   // normalise / select needs only the weights the proposal kernel left: it runs on the second stream, beside the
@@ -2064,6 +2191,8 @@ int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) {
   A((void**)&h->d_best_pose, sizeof(double) * 3);
   A((void**)&h->d_export, h->G);
   A((void**)&h->d_fstate, sizeof(int) * N);
+  A((void**)&h->d_center, sizeof(double) * 3 * N);
+  A((void**)&h->d_score, sizeof(double) * N);
   A((void**)&h->d_skip, sizeof(int) * N);
   A((void**)&h->d_win, sizeof(int4) * N);
   A((void**)&h->d_tier, sizeof(int) * N);
@@ -2153,7 +2282,7 @@ void tbnav_rbpf_destroy(tbnav_rbpf* h) {
   if (!h) return;
   DeviceGuard guard(h->device);
   for (int b = 0; b < 2; ++b) { (void)hipFree(h->d_state[b]); (void)hipFree(h->d_log_odds[b]); (void)hipFree(h->d_code[b]); (void)hipFree(h->d_nocc[b]); (void)hipFree(h->d_bitmap[b]); (void)hipFree(h->d_rowcount[b]); }
-  (void)hipFree(h->d_beams); (void)hipFree(h->d_normals); (void)hipFree(h->d_parent); (void)hipFree(h->d_best); (void)hipFree(h->d_best_pose); (void)hipFree(h->d_export); (void)hipFree(h->d_tier); (void)hipFree(h->d_fstate); (void)hipFree(h->d_skip); (void)hipFree(h->d_win);
+  (void)hipFree(h->d_beams); (void)hipFree(h->d_normals); (void)hipFree(h->d_parent); (void)hipFree(h->d_best); (void)hipFree(h->d_best_pose); (void)hipFree(h->d_export); (void)hipFree(h->d_tier); (void)hipFree(h->d_fstate); (void)hipFree(h->d_skip); (void)hipFree(h->d_win); (void)hipFree(h->d_center); (void)hipFree(h->d_score);
   (void)hipFree(h->d_trace);
   (void)hipHostFree(h->h_beams); (void)hipHostFree(h->h_err); (void)hipHostFree(h->h_norm);
   if (h->ev_w) (void)hipEventDestroy(h->ev_w);
@@ -2404,6 +2533,22 @@ int tbnav_rbpf_best_map(tbnav_rbpf* h, int8_t* map) {
   TBNAV_HIP(hipGetLastError());
   TBNAV_HIP(hipMemcpyAsync(map, h->d_export, h->G, hipMemcpyDeviceToHost, st));
   TBNAV_HIP(hipStreamSynchronize(st));
+  return TBNAV_OK;
+}
+
+int tbnav_rbpf_set_scan_matching(tbnav_rbpf* h, int32_t enable, double lstep, double astep, int32_t iterations) {
+  if (!h || (enable && (!(lstep > 0.0) || !(astep > 0.0) || iterations < 1 || iterations > 32))) return TBNAV_ERR_INVALID_ARG;
+  h->sm_on = enable != 0;
+  if (enable) { h->sm.lstep = lstep; h->sm.astep = astep; h->sm.iters = iterations; h->sm.max_moves = 64; }
+  return TBNAV_OK;
+}
+
+int tbnav_rbpf_get_scan_match(tbnav_rbpf* h, double* centers, double* scores) {
+  if (!h) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  TBNAV_HIP(hipStreamSynchronize(h->stream));
+  if (centers) TBNAV_HIP(hipMemcpy(centers, h->d_center, sizeof(double) * 3 * h->N, hipMemcpyDeviceToHost));
+  if (scores) TBNAV_HIP(hipMemcpy(scores, h->d_score, sizeof(double) * h->N, hipMemcpyDeviceToHost));
   return TBNAV_OK;
 }
 

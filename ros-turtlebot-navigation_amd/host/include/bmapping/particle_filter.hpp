@@ -47,6 +47,9 @@ class ParticleFilter {
 
   // ---- additions (not in the reference) ----
   void useDeviceNoise(std::uint64_t seed);  ///< draw the standard normals on the GPU instead of from getTwister()
+  /// Not in the reference: every particle refines T(pose) * T_icp against its own map (hill climbing on the
+  /// likelihood field) before sampling, so T_icp may be a rough guess such as the odometry increment.
+  void useScanMatching(bool on = true, double lstep = 0.05, double astep = 0.05, int iterations = 5);
   int effectiveParticles() const { return last_neff_; }
   bool resampledLastScan() const { return last_resampled_; }
 

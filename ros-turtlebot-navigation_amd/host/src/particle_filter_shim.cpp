@@ -64,6 +64,10 @@ ParticleFilter::ParticleFilter(int num_particles, int k, double srr, double srt,
 
 ParticleFilter::~ParticleFilter() { tbnav_rbpf_destroy(h_); }
 
+void ParticleFilter::useScanMatching(bool on, double lstep, double astep, int iterations) {
+  check(tbnav_rbpf_set_scan_matching(h_, on ? 1 : 0, lstep, astep, iterations), "useScanMatching");
+}
+
 void ParticleFilter::useDeviceNoise(std::uint64_t seed) {
   device_noise_ = true;
   check(tbnav_rbpf_set_seed(h_, seed), "useDeviceNoise");

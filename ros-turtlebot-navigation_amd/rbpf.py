@@ -152,6 +152,17 @@ class ParticleFilter:
         capi.check(self._L.tbnav_rbpf_get_trace(self._h, *[a.ctypes.data for a in t.values()]), "get_trace")
         return t
 
+    def setScanMatching(self, on: bool = True, lstep: float = 0.05, astep: float = 0.05, iterations: int = 5):
+        """Option, not the reference: every particle refines T(pose) * T_icp against its own map (hill climbing on
+        the likelihood field) before the samples are drawn round it."""
+        capi.check(self._L.tbnav_rbpf_set_scan_matching(self._h, 1 if on else 0, lstep, astep, iterations), "set_scan_matching")
+
+    def scanMatch(self):
+        """Matched poses [N][3] (theta, x, y) and scores [N] of the last SLAM call with scan matching on."""
+        c = np.empty((self.N, 3)); sc = np.empty(self.N)
+        capi.check(self._L.tbnav_rbpf_get_scan_match(self._h, c.ctypes.data, sc.ctypes.data), "get_scan_match")
+        return c, sc
+
     def setTiming(self, on: bool = True):
         """Record HIP events round the kernels of the following SLAM calls (they cost device time: off by default)."""
         capi.check(self._L.tbnav_rbpf_set_timing(self._h, 1 if on else 0), "set_timing")

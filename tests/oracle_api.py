@@ -419,6 +419,15 @@ class PfAPI:
         self.L.orc_pf_get_particles(self.h, _p(pose), _p(prev), _p(w))
         return pose, prev, w
 
+    def set_scan_matching(self, on, lstep=0.05, astep=0.05, iters=5):
+        """N1 option (not the reference): refine T(pose)*T_icp per particle by hill climbing before sampling."""
+        self.L.orc_pf_set_scan_matching(self.h, C.c_int(1 if on else 0), C.c_double(lstep), C.c_double(astep), C.c_int(iters))
+
+    def scan_match_result(self):
+        c = np.empty((self.N, 3)); sc = np.empty(self.N)
+        self.L.orc_pf_get_scan_match(self.h, _p(c), _p(sc))
+        return c, sc
+
     def set_particles(self, pose=None, prev=None, w=None):
         arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (pose, prev, w)]
         self.L.orc_pf_set_particles(self.h, *[None if a is None else _p(a) for a in arrs])

@@ -107,6 +107,42 @@ def test_sensor_offset_and_rotation(gpu_pkg):
     _run(gpu_pkg, N=24, k=20, map_half=3.0, walls=rc.ROOM_SMALL, n_scans=4, icp_ok=True, Trs=[0.3, 0.05, -0.02])
 
 
+def test_scan_matching_option_matches_the_oracle_and_pulls_a_bad_guess_in(gpu_pkg):
+    """SURVEY.md 8-f N1 (an option, not the reference): each particle refines T(pose) * T_icp against its own map by
+    hill climbing on GridMapper::likelihoodFieldModel before sampling.  (1) Device and oracle run the same rule on the
+    same (injected) distance fields: matched poses, scores and everything downstream agree at the usual tolerances.
+    (2) It does its job: T_icp is deliberately off by (1.5 deg, 3 cm, -2 cm) on the last scans and the matched pose
+    is closer to the true increment than the guess was."""
+    N, k, n_scans = 24, 20, 6
+    pf_o = orc.PfAPI(orc.pf_params(N=N, k=k, map_min=-3.0, map_max=3.0))
+    pf_d = _dev(gpu_pkg, N=N, k=k, map_min=-3.0, map_max=3.0)
+    steps, poses = rc.trajectory(n_scans, inc=(0.04, 0.03, 0.02))
+    rng = np.random.default_rng(5)
+    off = np.array([np.deg2rad(1.5), 0.03, -0.02])
+    for s, (prev, cur, t_icp, u) in enumerate(steps):
+        scan = orc.room_scan(poses[s], walls=rc.ROOM_SMALL, rng=rng)
+        normals = orc.normal_stream(700 + s, pf_o.normals_per_scan(True), 0.0, 1.0)
+        matching = s >= 3                       # three plain scans build the maps, then the matcher runs on bad guesses
+        pf_o.set_scan_matching(matching); pf_d.setScanMatching(matching)
+        guess = np.asarray(t_icp) + (off if matching else 0.0)
+        _inject(pf_o, pf_d)
+        pose_before = pf_o.particles()[0].copy()
+        tr_o = pf_o.slam(scan, u, cur, prev, True, guess, normals)
+        st = pf_d.SLAM(scan, u, cur, prev, True, guess, normals)
+        if matching:
+            c_o, sc_o = pf_o.scan_match_result()
+            c_d, sc_d = pf_d.scanMatch()
+            assert _close(c_d, c_o, POSE_RTOL, 1e-14) and _close(sc_d, sc_o, LIK_RTOL)
+            # the true mode is T(pose) * t_icp; the guess was `off` away from it, the match must be nearer
+            th, x, y = pose_before[:, 0], pose_before[:, 1], pose_before[:, 2]
+            true_xy = np.stack([np.cos(th) * t_icp[1] - np.sin(th) * t_icp[2] + x, np.sin(th) * t_icp[1] + np.cos(th) * t_icp[2] + y], 1)
+            guess_xy = np.stack([np.cos(th) * guess[1] - np.sin(th) * guess[2] + x, np.sin(th) * guess[1] + np.cos(th) * guess[2] + y], 1)
+            err_match = np.linalg.norm(c_d[:, 1:] - true_xy, axis=1)
+            err_guess = np.linalg.norm(guess_xy - true_xy, axis=1)
+            assert np.median(err_match) < 0.6 * np.median(err_guess), (np.median(err_match), np.median(err_guess))
+        _compare_scan(pf_o, pf_d, tr_o, st, True)
+
+
 def test_icp_failure_branch_motion_model(gpu_pkg):
     """ICP failed (particle_filter.cpp:161-176): odometry motion-model sample, weight *= scan likelihood."""
     _run(gpu_pkg, N=64, k=10, map_half=2.0, walls=rc.ROOM_SMALL, n_scans=4, icp_ok=False)

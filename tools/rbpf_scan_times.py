@@ -13,6 +13,8 @@ steps, poses = rc.trajectory(n_scans, inc=(0.07, 0.10, 0.05))
 for icp_ok in (True, False):
     pf = ParticleFilter(default_params(N=N, k=50, map_min=-10.0, map_max=10.0))
     pf.setSeed(1)
+    if "sm" in sys.argv[2:]:
+        pf.setScanMatching(True)
     rng = np.random.default_rng(7)
     ts = []
     for s, (prev, cur, t_icp, u) in enumerate(steps):
