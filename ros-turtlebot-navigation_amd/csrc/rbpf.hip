@@ -1993,6 +1993,7 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
       if (bytes <= 48 * 1024) { occ_half = half; propose_lds += bytes; break; }
     }
   }
+  if (propose_lds > (size_t)kMaxLds - 1024) return TBNAV_ERR_UNSUPPORTED;  // scan x samples too large for one workgroup's LDS
   const int* skip_arr = h->df_mode == 2 ? h->d_fstate : h->d_skip;
   const int skip_eq = h->df_mode == 2 ? 2 : 1;
   const double* center = nullptr;
@@ -2248,6 +2249,10 @@ int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) {
                   : hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_edt<32>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_tile), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 1024);
+  // the proposal / scan-match kernels carry the scan, the per-sample data and the bitmap slice: more than the 64 KB
+  // default for long scans or many samples
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_propose), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_scanmatch), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_edt_compact<kEdtRowsA>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)edt_compact_lds(kEdtRowsA));
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_edt_compact<kEdtRowsB>),

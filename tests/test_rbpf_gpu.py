@@ -153,6 +153,10 @@ def test_400x400_map_and_1080_beams(gpu_pkg):
     _run(gpu_pkg, N=6, k=12, map_half=10.0, walls=rc.ROOM_SURVEY, n_scans=3, icp_ok=True, inc=(0.07, 0.10, 0.05))
     _run(gpu_pkg, N=4, k=8, map_half=10.0, walls=rc.ROOM_SURVEY, n_scans=2, icp_ok=True, beam_delta_deg=1.0 / 3.0,
          inc=(0.07, 0.10, 0.05))
+    # 1080 beams x 120 samples: the proposal kernel's LDS (scan + per-sample data + bitmap slice) exceeds the 64 KB
+    # default dynamic limit
+    _run(gpu_pkg, N=3, k=120, map_half=10.0, walls=rc.ROOM_SURVEY, n_scans=2, icp_ok=True, beam_delta_deg=1.0 / 3.0,
+         inc=(0.07, 0.10, 0.05))
 
 
 def test_gated_beams_and_ragged_scan(gpu_pkg):
