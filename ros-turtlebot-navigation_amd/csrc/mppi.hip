@@ -767,17 +767,45 @@ __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, double 
   const int spw = kWave / tpr, sub = lane / tpr, l = lane - sub * tpr;
   const int i = (blockIdx.x * nw + wid) * spw + sub;
   const bool valid = i < T;
+  // the warm-start controls do not depend on the records: fetch them first, under the record loads
+  const double u_l = valid ? u.get(0, i, T) : 0.0, u_r = valid ? u.get(1, i, T) : 0.0;
+  // Up to two records per lane stay in registers (R <= 2 * tpr: every configuration with at most 128 records per
+  // step, i.e. every single-GPU tick); beyond that the second pass re-reads them (L1/L2 hits).
+  constexpr int kKeep = 2;
+  const bool keep = R <= kKeep * tpr;
+  double rk[kKeep][7];
+#pragma unroll
+  for (int q = 0; q < kKeep; ++q) {
+    const int r = l + q * tpr;
+    const bool have = valid && keep && r < R;
+    const int g = have ? r / S : 0, sl = have ? r - g * S : 0;
+    const double* rec = records + (((size_t)g * T + (valid ? i : 0)) * S + sl) * TBNAV_MPPI_REC;
+#pragma unroll
+    for (int f = 0; f < 7; ++f) rk[q][f] = have ? rec[f] : 0.0;  // n == 0 marks "no record"
+  }
   double M = __builtin_huge_val();
-  if (valid)
+  if (keep) {
+#pragma unroll
+    for (int q = 0; q < kKeep; ++q) if (rk[q][6] > 0.0) M = fmin(M, rk[q][0]);
+  } else if (valid) {
     for (int r = l; r < R; r += tpr) {
       const int g = r / S, sl = r - g * S;
       const double* rec = records + (((size_t)g * T + i) * S + sl) * TBNAV_MPPI_REC;
       if (rec[6] > 0.0) M = fmin(M, rec[0]);
     }
+  }
   if (tpr == kWave) M = tbnav::wave_min_dpp(M);  // a whole wave per time step: reductions on the DPP network
   else for (int off = tpr >> 1; off > 0; off >>= 1) M = fmin(M, __shfl_xor(M, off, kWave));
   double W = 0, NL = 0, NR = 0, SD = 0, SE = 0, SN = 0;
-  if (valid)
+  if (keep) {
+#pragma unroll
+    for (int q = 0; q < kKeep; ++q)
+      if (rk[q][6] > 0.0) {
+        const double sc = exp(((rk[q][0] - M) * -1.0) / lambda);
+        W += sc * rk[q][1]; NL += sc * rk[q][2]; NR += sc * rk[q][3];
+        SD += rk[q][4]; SE += rk[q][5]; SN += rk[q][6];
+      }
+  } else if (valid) {
     for (int r = l; r < R; r += tpr) {
       const int g = r / S, sl = r - g * S;
       const double* rec = records + (((size_t)g * T + i) * S + sl) * TBNAV_MPPI_REC;
@@ -787,6 +815,7 @@ __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, double 
         SD += rec[4]; SE += rec[5]; SN += rec[6];
       }
     }
+  }
   if (tpr == kWave) {
     W = tbnav::wave_sum_dpp(W); NL = tbnav::wave_sum_dpp(NL); NR = tbnav::wave_sum_dpp(NR);
     SD = tbnav::wave_sum_dpp(SD); SE = tbnav::wave_sum_dpp(SE); SN = tbnav::wave_sum_dpp(SN);
@@ -798,8 +827,8 @@ __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, double 
   }
   if (valid && l == 0) {
     W += 1e-8 * SN;  // the reference adds 1e-8 to every weight before normalising (mppi.cpp:117)
-    double ul = u.get(0, i, T) + (NL + 1e-8 * SD) / W;
-    double ur = u.get(1, i, T) + (NR + 1e-8 * SE) / W;
+    double ul = u_l + (NL + 1e-8 * SD) / W;
+    double ur = u_r + (NR + 1e-8 * SE) / W;
     ul = fmin(fmax(ul, -umax), umax);  // std::clamp(u, -max, max), mppi.cpp:124-125
     ur = fmin(fmax(ur, -umax), umax);
     u_out[i] = ul;
