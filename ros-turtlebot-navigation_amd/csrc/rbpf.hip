@@ -366,6 +366,22 @@ struct Trace {
 };
 
 
+
+// Whole field of ONE particle for maps whose column envelope does not fit a workgroup's LDS (xsize > ~640): every
+// cell asks the same exact query the likelihood uses (rows i, i+-1, ... on the global bitmap).  On-demand path only
+// (get_occ_dist / get_dist_code / export) — the SLAM path of such maps runs in query mode and never needs it.
+__global__ __launch_bounds__(256) void rbpf_field_by_query(GridC g, int radius, int particle, const unsigned long long* __restrict__ bitmap,
+                                                           const int* __restrict__ row_count, uint16_t* __restrict__ codes) {
+  const size_t G = (size_t)g.xsize * g.ysize;
+  const size_t cell = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell >= G) return;
+  const int ci = (int)(cell / g.xsize), cj = (int)(cell - (size_t)ci * g.xsize);
+  uint16_t* code = codes + (size_t)particle * G;
+  const DistSrc ds{code, bitmap + (size_t)particle * g.xsize * g.words, row_count + (size_t)particle * g.xsize, make_int4(0, 0, 0, 0), 2,
+                   nullptr, nullptr, 0, 0, 0, 0};
+  code[cell] = nearest_code_query(g, ds, radius, ci, cj);  // a cell out of reach keeps its stored code, like the transform
+}
+
 // ---- per-particle scan matcher (SURVEY.md 8-f N1 — an OPTION, not the reference) -----------------------------
 // The reference matches scan to scan ONCE per call with PCL ICP (cloud_alignment.cpp:37-223) and every particle
 // samples round T(pose) * T_icp (particle_filter.cpp:146-153,181-188).  With scan matching on, each particle
@@ -1897,8 +1913,18 @@ int ensure_full_field(tbnav_rbpf* h, int particle) {
   TBNAV_HIP(hipStreamSynchronize(st));
   TBNAV_HIP(hipMemcpy(&stt, h->d_fstate + particle, sizeof(int), hipMemcpyDeviceToHost));
   if (stt == 2) return TBNAV_OK;
-  const int4 full = make_int4(0, h->xsize - 1, 0, h->ysize - 1);
   const int zero = 0, two = 2;
+  if (h->edt_cols == 0) {
+    const GridC g = grid_of(h);
+    hipLaunchKernelGGL(rbpf_field_by_query, dim3((unsigned)((h->G + 255) / 256)), dim3(256), 0, st, g, h->radius, particle,
+                       h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_code[h->cur]);
+    TBNAV_HIP(hipGetLastError());
+    TBNAV_HIP(hipStreamSynchronize(st));
+    TBNAV_HIP(hipMemcpy(h->d_fstate + particle, &two, sizeof two, hipMemcpyHostToDevice));
+    h->fstate_dirty = true;
+    return TBNAV_OK;
+  }
+  const int4 full = make_int4(0, h->xsize - 1, 0, h->ysize - 1);
   TBNAV_HIP(hipMemcpy(h->d_win + particle, &full, sizeof full, hipMemcpyHostToDevice));
   TBNAV_HIP(hipMemcpy(h->d_skip + particle, &zero, sizeof zero, hipMemcpyHostToDevice));
   int rc = run_distance_field(h, grid_of(h), particle, 1, (h->ysize + kWave - 1) / kWave);
@@ -2135,7 +2161,9 @@ int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) {
   const int words = (ysize + 63) / 64;
   int C = 64;
   if (edt_lds_bytes(xsize, words, C) > (size_t)kMaxLds) C = 32;
-  if (edt_lds_bytes(xsize, words, C) > (size_t)kMaxLds) return TBNAV_ERR_UNSUPPORTED;
+  // larger maps (xsize > ~640, e.g. BASELINE configs[4]'s 2000 x 2000): no LDS distance transform.  The SLAM path then
+  // always answers lookups by query, and an on-demand field is produced cell by cell with the same query.
+  if (edt_lds_bytes(xsize, words, C) > (size_t)kMaxLds) C = 0;
   int ndev = 0;
   {
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -2168,6 +2196,7 @@ int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) {
       const std::string v(e);
       h->df_mode = (v == "full") ? 0 : (v == "window") ? 1 : 2;
     }
+    if (h->edt_cols == 0) h->df_mode = 2;  // no LDS transform for this map size: query mode only
     h->full_edt = h->df_mode == 0;
   }
   // log-odds constants with the host libm, exactly as the reference's ctor (grid_mapper.cpp:42-47)
@@ -2243,7 +2272,7 @@ int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) {
     if (e == hipSuccess) e = hipMemset(h->d_bitmap[0], 0, sizeof(unsigned long long) * (size_t)N * xsize * words);
     if (e == hipSuccess) e = hipMemset(h->d_rowcount[0], 0, sizeof(int) * (size_t)N * xsize);
   }
-  if (e == hipSuccess) {
+  if (e == hipSuccess && C > 0) {
     const int lds = (int)edt_lds_bytes(xsize, words, C);
     e = (C == 64) ? hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_edt<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)
                   : hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_edt<32>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -159,6 +159,35 @@ def test_400x400_map_and_1080_beams(gpu_pkg):
          inc=(0.07, 0.10, 0.05))
 
 
+def test_large_map_2000x2000_with_1080_beams(gpu_pkg):
+    """BASELINE configs[4]'s grid (2000 x 2000 @ 0.05 m) and beam count on one GPU (a handful of particles; the config's
+    100 k particles need sparse maps and 8 GPUs).  Maps this size have no LDS distance transform: lookups are by query
+    only, everything else is the same code path — and must meet the oracle like any other size."""
+    _run(gpu_pkg, N=2, k=6, map_half=50.0, walls=rc.ROOM_SURVEY, n_scans=2, icp_ok=True, beam_delta_deg=1.0 / 3.0,
+         inc=(0.07, 0.10, 0.05))
+
+
+def test_on_demand_field_of_a_large_map(gpu_pkg):
+    """704 x 704: just past what the LDS transform holds.  get_dist_code then produces the field cell by cell with the
+    lookup query; it must equal the brute-force exact EDT (radius cut-off, out-of-reach cells keep their code)."""
+    pf_d = _dev(gpu_pkg, N=2, k=3, map_min=-17.6, map_max=17.6)
+    xs = pf_d.xsize
+    assert xs == 704
+    rng = np.random.default_rng(9)
+    l_occ = np.log(0.9 / (1 - 0.9))
+    for p in range(2):
+        occ = np.zeros((xs, xs), dtype=np.uint8)
+        if p == 0:
+            for r in rng.choice(xs, size=150, replace=False):
+                occ[r, rng.choice(xs, size=int(rng.integers(1, 4)), replace=False)] = 1
+        else:
+            occ[3, 700] = 1; occ[650, 2] = 1            # two far corners: most of the map is out of reach of both
+        prev = pf_d.distCode(p).reshape(xs, xs).copy()   # all 0xFFFF
+        pf_d.setLogOdds(p, occ.reshape(-1) * l_occ)
+        want = orc.exact_edt_codes(occ, 200, prev)
+        assert np.array_equal(pf_d.distCode(p).reshape(xs, xs), want)
+
+
 def test_gated_beams_and_ragged_scan(gpu_pkg):
     """Ranges below range_min / at or above range_max are skipped but still advance the beam angle
     (sensor_model.cpp:77-108); a scan with 357 beams (not a multiple of the wave)."""
