@@ -155,6 +155,12 @@ int tbnav_mppi_debug_sincos(const double* x_host, int32_t n, double* sin_host, d
 int tbnav_mppi_profile_tick(tbnav_mppi* h, const double x0[3], const double* d_duL,
                             const double* d_duR, void* stream, float ms[TBNAV_MPPI_NKERNELS]);
 
+/* Per-kernel durations priced without the events' own cost: each kernel of the tick is launched `reps` (even, >= 2)
+ * times back to back between one event pair; ms[i] = elapsed / reps (ms[1] = 0 when rollout and partials are one
+ * kernel).  The controller state advances as if `reps` ticks had run on the same inputs. */
+int tbnav_mppi_profile_kernels(tbnav_mppi* h, const double x0[3], const double* d_duL, const double* d_duR, void* stream,
+                               int32_t reps, float ms[TBNAV_MPPI_NKERNELS]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -124,6 +124,7 @@ def lib() -> C.CDLL:
         "tbnav_mppi_get_cost_to_go": (C.c_int, [vp, vp]),
         "tbnav_mppi_debug_sincos": (C.c_int, [vp, i32, vp, vp]),
         "tbnav_mppi_profile_tick": (C.c_int, [vp, dp, vp, vp, vp, C.POINTER(C.c_float)]),
+        "tbnav_mppi_profile_kernels": (C.c_int, [vp, dp, vp, vp, vp, i32, C.POINTER(C.c_float)]),
         # RBPF
         "tbnav_rbpf_create": (C.c_int, [C.POINTER(RbpfParams), C.POINTER(vp)]),
         "tbnav_rbpf_destroy": (None, [vp]),

@@ -1301,6 +1301,41 @@ int tbnav_mppi_profile_tick(tbnav_mppi* h, const double x0[3], const double* d_d
   return rc;
 }
 
+
+// Per-kernel durations without the event overhead: every kernel of the tick is launched `reps` times back to back
+// between ONE pair of events (a single launch of a 5 us kernel between two events measures the events as much as
+// the kernel).  The controller state advances as if `reps` ticks had run on the same inputs.
+int tbnav_mppi_profile_kernels(tbnav_mppi* h, const double x0[3], const double* d_duL, const double* d_duR, void* stream,
+                               int32_t reps, float ms[TBNAV_MPPI_NKERNELS]) {
+  if (!h || !x0 || !ms || reps < 2 || (reps & 1) || !pick_noise(h, d_duL, d_duR)) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipEvent_t ev[2];
+  for (auto& e : ev) TBNAV_HIP(hipEventCreate(&e));
+  int rc = TBNAV_OK;
+  auto timed = [&](int which, auto&& launch) {
+    if (rc != TBNAV_OK) return;
+    if (hipEventRecord(ev[0], st) != hipSuccess) { rc = TBNAV_ERR_HIP; return; }
+    for (int r = 0; r < reps && rc == TBNAV_OK; ++r) rc = launch();
+    if (rc != TBNAV_OK) return;
+    float t = 0.f;
+    if (hipEventRecord(ev[1], st) != hipSuccess || hipEventSynchronize(ev[1]) != hipSuccess ||
+        hipEventElapsedTime(&t, ev[0], ev[1]) != hipSuccess) { rc = TBNAV_ERR_HIP; return; }
+    ms[which] = t / (float)reps;
+  };
+  for (int i = 0; i < TBNAV_MPPI_NKERNELS; ++i) ms[i] = 0.f;
+  if (h->fused_r > 0) {
+    timed(0, [&] { return launch_fused(h, x0, d_duL, d_duR, st); });
+    timed(2, [&] { return launch_combine(h, h->d_records_f, 1, st, h->fused_S); });
+  } else {
+    timed(0, [&] { return launch_rollout(h, x0, d_duL, d_duR, st); });
+    timed(1, [&] { return launch_partials(h, d_duL, d_duR, h->d_records, st); });
+    timed(2, [&] { return launch_combine(h, h->d_records, 1, st); });
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  return rc;
+}
+
 int tbnav_mppi_last_controls(tbnav_mppi* h, void* stream, double u_out[2]) {
   if (!h || !u_out) return TBNAV_ERR_INVALID_ARG;
   DeviceGuard guard(h->device);

@@ -112,6 +112,14 @@ class MPPI:
                                                    stream or None, ms), "profile_tick")
         return ms[0], ms[1], ms[2]
 
+    def profileKernels(self, x0, d_duL: int, d_duR: int, stream: int = 0, reps: int = 100):
+        """(ms_rollout, ms_partials, ms_combine): each kernel launched `reps` times back to back between one event pair."""
+        x0c = (C.c_double * 3)(*x0)
+        ms = (C.c_float * 3)()
+        capi.check(self._L.tbnav_mppi_profile_kernels(self._h, x0c, d_duL or None, d_duR or None, stream or None, reps, ms),
+                   "profile_kernels")
+        return ms[0], ms[1], ms[2]
+
     def lastControls(self, stream: int = 0):
         out = (C.c_double * 2)()
         capi.check(self._L.tbnav_mppi_last_controls(self._h, stream or None, out), "last_controls")
