@@ -19,6 +19,8 @@
 #include <cstring>
 #include <limits>
 #include <new>
+#include <atomic>
+#include <chrono>
 #include <vector>
 
 #include "common.hpp"
@@ -759,7 +761,7 @@ __global__ __launch_bounds__(kWave) void mppi_merge_records(int T, int Sf, int p
 // (USrc), u(:,0) goes to `out` (mppi.cpp:129-131).
 __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, double lambda, double umax, USrc u,
                                                     const double* __restrict__ records, double* __restrict__ u_out,
-                                                    double* __restrict__ out) {
+                                                    double* __restrict__ out, double* __restrict__ out_host, double seq) {
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave, nw = blockDim.x / kWave;
   const int R = G * S;
   int tpr = 1;
@@ -833,7 +835,17 @@ __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, double 
     ur = fmin(fmax(ur, -umax), umax);
     u_out[i] = ul;
     u_out[T + i] = ur;
-    if (i == 0) { out[0] = ul; out[1] = ur; }
+    if (i == 0) {
+      out[0] = ul; out[1] = ur;
+      if (out_host) {
+        // synchronous ticks: the answer also lands in mapped pinned host memory, without a copy.  The tick number goes
+        // last, behind a system-scope fence, so a host that sees it also sees the two values.  (Not done for
+        // enqueue-only ticks: the fence and the write over the fabric sit on the kernel's critical path.)
+        out_host[0] = ul; out_host[1] = ur;
+        __threadfence_system();
+        out_host[2] = seq;
+      }
+    }
   }
 }
 
@@ -916,8 +928,12 @@ struct tbnav_mppi {
   double* d_duR = nullptr;
   double* d_raw = nullptr;      // [K][T][2] staging for host-order noise (lazy)
   double* d_records = nullptr;  // [T][S][8]
-  double* d_out = nullptr;      // [2]
-  double* h_out = nullptr;      // pinned [2]
+  double* d_out = nullptr;      // [2] device copy of the last controls
+  double* d_out_host = nullptr; // device view of h_out
+  double* h_out = nullptr;      // mapped pinned [4]: ul, ur, tick number of the combine that published them
+  uint64_t seq = 0;             // combines enqueued so far
+  uint64_t published = 0;       // tick number of the last combine that was asked to publish to h_out
+  bool publish_next = false;    // set by the synchronous entry points round their enqueue
   int lds_from = 0;           // first time step whose loss is staged in LDS (0 = all of them)
   int scan_tc = 0;            // steps per thread of the time-parallel rollout kernel (0 = sequential kernel)
   int fused_r = 0;            // rollouts per workgroup of the fused rollout+partials kernel (0 = off: three kernels)
@@ -1023,8 +1039,10 @@ int launch_combine(tbnav_mppi* h, const double* d_records, int G, hipStream_t st
   const int blocks = (h->T + steps_per_block - 1) / steps_per_block;
   const USrc usrc{h->d_u[h->ucur], h->pending_shift ? 1 : 0, h->uinit[0], h->uinit[1]};
   hipLaunchKernelGGL(mppi_combine, dim3(blocks), dim3(256), 0, st, h->T, G, S, h->p.lambda, h->p.max_wheel_vel, usrc,
-                     d_records, h->d_u[1 - h->ucur], h->d_out);
+                     d_records, h->d_u[1 - h->ucur], h->d_out, h->publish_next ? h->d_out_host : nullptr, (double)(h->seq + 1));
   TBNAV_HIP(hipGetLastError());
+  ++h->seq;
+  if (h->publish_next) h->published = h->seq;
   h->ucur = 1 - h->ucur;       // the freshly written vector is current ...
   h->pending_shift = true;     // ... and its shift is still owed
   return TBNAV_OK;
@@ -1148,13 +1166,14 @@ int tbnav_mppi_create(const tbnav_mppi_params* params, tbnav_mppi** out) {
   alloc(&h->d_records, (size_t)T * h->S * TBNAV_MPPI_REC);
   if (h->fused_r) alloc(&h->d_records_f, (size_t)T * h->fused_S * TBNAV_MPPI_REC);
   alloc(&h->d_out, 2);
-  if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_out, 2 * sizeof(double), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipMemset(h->d_out, 0, 2 * sizeof(double));
+  if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_out, 4 * sizeof(double), hipHostMallocMapped);
+  if (e == hipSuccess) { for (int q = 0; q < 4; ++q) h->h_out[q] = 0.0; e = hipHostGetDevicePointer((void**)&h->d_out_host, h->h_out, 0); }
   if (e == hipSuccess) e = hipMemset(h->d_u[0], 0, 2 * (size_t)T * sizeof(double));
   if (e == hipSuccess) e = hipMemset(h->d_u[1], 0, 2 * (size_t)T * sizeof(double));
   if (e == hipSuccess) e = hipMemset(h->d_J, 0, tk * sizeof(double));
   if (e == hipSuccess) e = hipMemset(h->d_duL, 0, tk * sizeof(double));
   if (e == hipSuccess) e = hipMemset(h->d_duR, 0, tk * sizeof(double));
-  if (e == hipSuccess) e = hipMemset(h->d_out, 0, 2 * sizeof(double));
   if (e == hipSuccess) {
     const int lds_max = (int)((size_t)2 * T * sizeof(double) + (size_t)(T - h->lds_from) * kWave * sizeof(double));
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mppi_rollout_cost<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
@@ -1340,17 +1359,34 @@ int tbnav_mppi_last_controls(tbnav_mppi* h, void* stream, double u_out[2]) {
   if (!h || !u_out) return TBNAV_ERR_INVALID_ARG;
   DeviceGuard guard(h->device);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  TBNAV_HIP(hipMemcpyAsync(h->h_out, h->d_out, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
-  TBNAV_HIP(hipStreamSynchronize(st));
-  u_out[0] = h->h_out[0];
-  u_out[1] = h->h_out[1];
+  if (h->published != h->seq) {  // the last tick was enqueue-only: fetch the device copy
+    TBNAV_HIP(hipMemcpyAsync(h->h_out, h->d_out, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+    TBNAV_HIP(hipStreamSynchronize(st));
+    u_out[0] = h->h_out[0];
+    u_out[1] = h->h_out[1];
+    return TBNAV_OK;
+  }
+  // The last combine published (ul, ur, tick number) in mapped host memory.  Poll for its number for a short while (a
+  // control loop calls this right behind the enqueue: the answer is microseconds away and a stream synchronisation
+  // costs more than the tick), then fall back to waiting on the stream.
+  const double want = (double)h->seq;
+  volatile double* vo = h->h_out;
+  const auto t0 = std::chrono::steady_clock::now();
+  bool seen = vo[2] == want;
+  while (!seen && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(200)) seen = vo[2] == want;
+  if (!seen) TBNAV_HIP(hipStreamSynchronize(st));
+  std::atomic_thread_fence(std::memory_order_acquire);
+  u_out[0] = vo[0];
+  u_out[1] = vo[1];
   return TBNAV_OK;
 }
 
 int tbnav_mppi_new_controls_dev(tbnav_mppi* h, const double x0[3], const double* d_duL,
                                 const double* d_duR, void* stream, double u_out[2]) {
   if (!u_out) return TBNAV_ERR_INVALID_ARG;
+  if (h) h->publish_next = true;
   int rc = tbnav_mppi_enqueue_dev(h, x0, d_duL, d_duR, stream);
+  if (h) h->publish_next = false;
   if (rc != TBNAV_OK) return rc;
   return tbnav_mppi_last_controls(h, stream, u_out);
 }
