@@ -2,25 +2,33 @@
 // include/tbnav_mppi.h.  Reference: controller/src/controller/mppi.cpp:72-140, rk4.cpp:49-115,
 // controller/include/controller/mppi.hpp:41-105 (paths relative to the reference tree).
 //
-// Kernels (all fp64; this file is compiled with -ffp-contract=off so the op order below is the
-// reference's, and the only numerical difference from the CPU path is libm vs ocml sin/cos/exp):
-//   mppi_rollout_cost   one lane per rollout: T RK4 steps, per-step LQR loss staged in LDS,
-//                       in-lane suffix sum -> J[T][K]                    (mppi.cpp:81-109)
-//   mppi_partials       grid (K-slices, T): per-time-step min / soft-min partial sums over one
-//                       K-slice -> records[T][S][8]                       (mppi.cpp:115-121)
-//   mppi_combine        one workgroup: merge records of all slices/shards, update + clamp u,
-//                       emit u(:,0), shift                                (mppi.cpp:118-137)
+// Kernels (all fp64; compiled with -ffp-contract=fast-honor-pragmas — the contract is a tolerance, csrc/Makefile and
+// DESIGN.md section 4 say why; sin/cos are this file's own fast_sincos):
+//   mppi_rollout_fused  small K (the default for K/64 < 2 x CUs, T <= 128): one wave per rollout with its lanes over
+//                       TIME, DPP wave scans for heading / position / cost-to-go, J -> [T][K], and the soft-min partial
+//                       record of every time step over the workgroup's rollouts in the same launch (mppi.cpp:81-121)
+//   mppi_rollout_scan   128 < T <= 240: 64 rollouts x ceil(T/TC) waves, TC steps per thread in registers, chunk totals
+//                       through LDS
+//   mppi_rollout_cost   large K: one lane per rollout, T steps in groups of four independent trig chains, per-step loss
+//                       staged in LDS / J, in-lane suffix sum -> J[T][K]        (mppi.cpp:81-109)
+//   mppi_partials       grid (K-slices, T): per-time-step min / soft-min partial sums over one K-slice ->
+//                       records[T][S][8]                                        (mppi.cpp:115-121)
+//   mppi_merge_records  sharded small-K ticks: fold the fused kernel's fine records into the K-slice records
+//   mppi_combine        any number of workgroups: merge the records of all slices / shards, update + clamp u, emit
+//                       u(:,0); the shift is applied on read by the next tick   (mppi.cpp:118-137)
 //   mppi_unpack_noise   reference draw order [K][T][2] -> duL/duR [T][K]
 //   mppi_sample_noise   Philox4x32-10 + Box-Muller, production replacement of mppi.cpp:173-184
+// Rollout dynamics: the reference's CartModel + RK4 (TRIG 1..3 = how many sincos per step are evaluated afresh), or the
+// exact-arc option TRIG == 4 (DiffDrive::feedforward per step).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
-#include <new>
 #include <atomic>
 #include <chrono>
+#include <new>
 #include <vector>
 
 #include "common.hpp"

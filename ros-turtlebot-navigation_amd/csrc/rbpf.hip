@@ -4,19 +4,25 @@
 //   bmapping/src/bmapping/grid_mapper.cpp:69-182 (likelihood field, integrateScan), :549-898
 //   bmapping/src/bmapping/sensor_model.cpp:43-112 (laserEndPoints)
 //
-// Kernels (fp64 / integer; compiled with -ffp-contract=off):
-//   rbpf_propose      one workgroup per particle: sample k poses round the ICP mode, score each
-//                     (scan likelihood over all valid beams x pose likelihood), Gaussian proposal,
-//                     3x3 Cholesky, new pose, weight *= eta         (particle_filter.cpp:158-231)
-//   rbpf_raycast      one wave per particle: beams IN ORDER, cells of one ray in parallel (closed-form
-//                     Bresenham), log-odds += l_free / l_occ        (grid_mapper.cpp:140-178)
-//   rbpf_occupancy    wave per map row: cells with prob >= 0.9 (log-odds cut-off) -> bitmap + count
-//   rbpf_edt          exact squared Euclidean distance transform per particle (row pass by bit
-//                     scans, column pass by integer lower envelope in LDS) -> u16 code
-//                     (replaces the whole-map priority-queue brushfire, grid_mapper.cpp:333-435)
-//   rbpf_normalize    sequential-order normalise / Neff / low-variance selection
-//                                                                  (particle_filter.cpp:442-500)
-//   rbpf_gather       copy parents into the alternate buffers after a resample (:495 deep copies)
+// Kernels (fp64 / integer; compiled with -ffp-contract=off; DESIGN.md section 4 has the reasoning and the numbers):
+//   rbpf_sample_normals   production noise source (Philox + Box-Muller) when the caller passes no normals
+//   rbpf_propose          workgroup per particle: k sampled poses, ONE likelihood lookup per beam at their centre,
+//                         stable-beam collapse of the k x Bv evaluations, Gaussian proposal, 3x3 Cholesky, new pose,
+//                         weight *= eta; lookups by exact nearest-obstacle query on an LDS slice of the bitmap
+//                         (particle_filter.cpp:158-231, grid_mapper.cpp:69-133)
+//   rbpf_scanmatch        option (N1): per-particle hill climbing on the likelihood field before sampling
+//   rbpf_raycast_tile     workgroup per particle: LDS tile of 16-bit counters over the scan's bounding box, integer DDA
+//                         walk per ray segment, end-point cells replayed in beam order, log-odds += l_free / l_occ,
+//                         occupancy bitmap kept current                  (grid_mapper.cpp:140-178, :549-807)
+//   rbpf_raycast          fallback when the tile cannot hold the scan: one wave per particle, beams in order
+//   rbpf_normalize(_seq)  sequential-order normalise / Neff / low-variance selection (particle_filter.cpp:442-500)
+//   rbpf_gather           copy parents into the alternate buffers after a resample (:495 deep copies)
+//   rbpf_argmax, rbpf_export_map   getRobotState / newMap on the device (:255-291, grid_mapper.cpp:185-226)
+//   rbpf_occupancy        rebuild one particle's bitmap from its log-odds (after tbnav_rbpf_set_log_odds)
+//   rbpf_window, rbpf_edt_compact<R>, rbpf_edt<C>, rbpf_field_by_query
+//                         the stored u16 distance field: windowed / whole-map exact EDT (modes TBNAV_RBPF_DF=window|full,
+//                         and every on-demand field), cell-by-cell query for maps too large for the LDS transform
+//                         (replaces the whole-map priority-queue brushfire, grid_mapper.cpp:333-435)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
