@@ -49,8 +49,12 @@ def mppi_case(i):
         J = m.costToGo()
         ej = rel_err(J, ref["J"])
         assert ej < 1e-10, ("J", ej, desc)
-        assert np.allclose(got, ref["out"], rtol=1e-8, atol=1e-10), ("out", got, ref["out"], desc)
-        assert np.allclose(m.getControls(), ref["u"], rtol=1e-8, atol=1e-10), ("u", desc)
+        # the soft-min amplifies a relative error eps of J by J / lambda (J up to 1e7 here, lambda down to 0.01): the bar
+        # is the north star's 1e-5 on the control vector, asserted at 1e-6
+        assert np.allclose(got, ref["out"], rtol=1e-6, atol=1e-8), ("out", got, ref["out"], desc)
+        uu = m.getControls()
+        assert np.allclose(uu, ref["u"], rtol=1e-6, atol=1e-8), ("u", desc, "max abs diff", float(np.abs(uu - ref["u"]).max()), "J rel", ej,
+                                                                   "J max", float(np.abs(ref["J"]).max()))
         u = ref["u"]
         x0 = (x0[0] + 0.003, x0[1] - 0.002, x0[2] + 0.004)
     m.close()
@@ -92,7 +96,11 @@ def rbpf_case(i):
             for p in range(N):
                 pf_d.setOccDist(p, pf_o.grid(p).dump()["occ_dist"])
         tr_o = pf_o.slam(scan, u, cur, prev, icp_ok, t_icp, normals)
-        st = pf_d.SLAM(scan, u, cur, prev, icp_ok, t_icp, normals)
+        try:
+            st = pf_d.SLAM(scan, u, cur, prev, icp_ok, t_icp, normals)
+        except Exception as e:  # the wrapper raises on a non-zero status: the oracle must have refused the same scan
+            assert getattr(e, "status", None) == tr_o["rc"] != 0, ("status", getattr(e, "status", None), tr_o["rc"], desc)
+            break
         assert st.status == 0 and tr_o["rc"] == 0, ("status", st.status, tr_o["rc"], desc)
         tr_d = pf_d.trace()
         # log-odds are bit-exact whenever the poses that drive the raycast agree; compare through the oracle grid
