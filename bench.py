@@ -236,6 +236,16 @@ def main():
             rl["rollouts_per_s"] = round(KL * 50 / el_l, 1)
             line["roofline_large"] = rl
             ml.close()
+        if world == 1:
+            # the exact-arc dynamics option, same workload, same timing as `value`
+            ma = make_mppi(K, horizon, local_rank)
+            ma.setDynamics("arc")
+            el_a = time_ticks(lambda: ma.enqueueDev(X0, a.data_ptr(), b.data_ptr(), stream), sync, min(args.steps, 1000),
+                              min(args.warmup, 100), lambda: None)
+            n_a = min(args.steps, 1000)
+            line["options"] = {"mppi_exact_arc_dynamics": {"rollouts_per_s": round(K * n_a / el_a, 1),
+                                                           "ms_per_step": round(el_a / n_a * 1e3, 6)}}
+            ma.close()
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(K, T, horizon)
         if world == 1 and not args.no_rbpf:

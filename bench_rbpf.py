@@ -82,6 +82,17 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
             t_total += dt; n_timed += 1
         resamples += st.resampled
     ms_scan = t_total / n_timed * 1e3
+    # the per-particle scan-matching option on the same scans, its own filter
+    pf_m = ParticleFilter(default_params(N=N, k=k, map_min=-10.0, map_max=10.0, device=device.index or 0))
+    pf_m.setSeed(2026)
+    pf_m.setScanMatching(True)
+    t_sm, n_sm = 0.0, 0
+    for s, (prev, cur, t_icp, u) in enumerate(steps[:12]):
+        t0 = time.perf_counter()
+        pf_m.SLAM(scans[s], u, cur, prev, True, t_icp, None)
+        if s >= 2:
+            t_sm += time.perf_counter() - t0; n_sm += 1
+    pf_m.close()
     dev_ms = sum(kms.values())
     G = pf.G
     Bv = int(st.n_valid_beams)
@@ -140,6 +151,8 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
         "device_only_updates_per_s": round(N / (dev_ms * 1e-3), 1),
         "kernel_ms": {key: round(v, 4) for key, v in kms.items()},
         "dtype": "f64+u16",
+        "options": {"scan_matching": {"value": round(N / (t_sm / n_sm), 1), "ms_per_scan": round(t_sm / n_sm * 1e3, 4),
+                                      "note": "per-particle hill climbing on the likelihood field before sampling (not the reference)"}},
         "distance_field_mode": mode,
         "roofline": {"bound": "hbm", "kernel": dom_name,
                      "achieved": round(alg_dom * N / (dom_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
