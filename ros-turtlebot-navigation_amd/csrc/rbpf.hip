@@ -271,10 +271,9 @@ __device__ __forceinline__ void sensor_transform(const ScanC& c, double th, doub
 // ~1e-4 m of the centre, so nearly every (sample, beam) lands on the same cell (no lookup at all) or at least the
 // same code, and takes its term from the cache instead of re-evaluating sqrt + exp.  A beam that leaves the world
 // sets *oob (the reference throws from world2RowMajor) and contributes 1.
-constexpr int kMixLut = 1024;  // distance codes (squared cells) below this have their mixture term tabulated by kernels that pass `lut`
+constexpr int kMixLut = 1024;  // the scan matcher tabulates the mixture term of distance codes (squared cells) below this
 __device__ __forceinline__ double beam_factor(const ScanC& c, const DistSrc& ds, int radius, const double2 pt, double X, double Y,
-                                              double st, double ct, unsigned int cc, unsigned int tg, double pzc, int* oob,
-                                              const double* lut = nullptr) {
+                                              double st, double ct, unsigned int cc, unsigned int tg, double pzc, int* oob) {
   const double ex = ct * pt.x - st * pt.y + X;
   const double ey = st * pt.x + ct * pt.y + Y;
   int ci, cj;
@@ -283,8 +282,7 @@ __device__ __forceinline__ double beam_factor(const ScanC& c, const DistSrc& ds,
   // (window mode: the window is sized so that a miss cannot happen — if it ever does it is reported, never read stale)
   const int cd = lookup_code(c.g, ds, radius, ci, cj);
   if (cd < 0) { *oob |= 2; return 1.0; }
-  if (tg == (unsigned int)cd) return pzc;
-  return (lut && cd < kMixLut) ? lut[cd] : beam_mixture(c, (uint16_t)cd);  // the table holds beam_mixture's own values
+  return (tg == (unsigned int)cd) ? pzc : beam_mixture(c, (uint16_t)cd);
 }
 // GridMapper::likelihoodFieldModel for ONE pose, evaluated by one wave (lanes stride the valid beams).
 __device__ __forceinline__ double wave_scan_likelihood_t(const ScanC& c, const double2* __restrict__ beams,
@@ -417,7 +415,11 @@ __global__ __launch_bounds__(kMatchThreads) void rbpf_scanmatch(ScanC c, ScanMat
   double2* lbeams = reinterpret_cast<double2*>(lds);                       // [Bv]
   double* lut = reinterpret_cast<double*>(lbeams + c.Bv);                 // [kMixLut] mixture term per distance code: the
   //   matcher scores ~100 poses x Bv beams, nearly all of them a few cells from a wall (sqrt + exp each otherwise)
-  unsigned long long* const tile_bm = reinterpret_cast<unsigned long long*>(lut + kMixLut);
+  // per-beam cache of looked-up cells, shared by the six waves: [Bv][4] words, slot = parity of (ci, cj) — the four
+  // cells of any 2 x 2 neighbourhood never collide, and the matcher's poses move a beam's end point by a cell or two.
+  // One u64 per entry ((cell + 1) << 16 | code) so that concurrent writers leave a consistent entry either way.
+  unsigned long long* ccache = reinterpret_cast<unsigned long long*>(lut + kMixLut);
+  unsigned long long* const tile_bm = ccache + (size_t)4 * c.Bv;
   __shared__ double cur[3], best, steps[2], cand[6];
   __shared__ int refinements, done;
   const double th0 = pose[p * 3 + 0], x0 = pose[p * 3 + 1], y0 = pose[p * 3 + 2];
@@ -433,6 +435,7 @@ __global__ __launch_bounds__(kMatchThreads) void rbpf_scanmatch(ScanC c, ScanMat
              win[p], skip[p] == skip_eq ? 0 : df_mode, tile_bm, reinterpret_cast<const int*>(tile_bm), 0, 0, 0, 0};
   for (int b = tid; b < c.Bv; b += kMatchThreads) lbeams[b] = beams[b];
   for (int q = tid; q < kMixLut; q += kMatchThreads) lut[q] = beam_mixture(c, (uint16_t)q);
+  for (int q = tid; q < 4 * c.Bv; q += kMatchThreads) ccache[q] = 0ull;
   if (ds.mode == 2 && occ_half > 0) {  // the same LDS slice of the bitmap as the proposal kernel, round the first guess
     double Tc[4];
     sensor_transform(c, mu0[0], mu0[1], mu0[2], Tc);
@@ -460,7 +463,22 @@ __global__ __launch_bounds__(kMatchThreads) void rbpf_scanmatch(ScanC c, ScanMat
     double T[4];
     sensor_transform(c, th, x, y, T);
     double pr = 1.0;
-    for (int b = lane; b < c.Bv; b += kWave) pr *= beam_factor(c, ds, radius, lbeams[b], T[0], T[1], T[2], T[3], 0xFFFFFFFFu, 0xFFFFFFFFu, 0.0, &oob, lut);
+    for (int b = lane; b < c.Bv; b += kWave) {
+      const double2 pt = lbeams[b];
+      int ci, cj;
+      if (!world2cell(c.g, T[3] * pt.x - T[2] * pt.y + T[0], T[2] * pt.x + T[3] * pt.y + T[1], ci, cj)) { oob |= 1; continue; }
+      const unsigned long long cell1 = (unsigned long long)(ci * c.g.xsize + cj) + 1ull;
+      unsigned long long* slot = ccache + 4 * b + ((ci & 1) | ((cj & 1) << 1));
+      const unsigned long long e = *slot;
+      int cd;
+      if ((e >> 16) == cell1) cd = (int)(e & 0xFFFFull);
+      else {
+        cd = lookup_code(c.g, ds, radius, ci, cj);
+        if (cd < 0) { oob |= 2; continue; }
+        *slot = (cell1 << 16) | (unsigned long long)cd;
+      }
+      pr *= cd < kMixLut ? lut[cd] : beam_mixture(c, (uint16_t)cd);
+    }
     return wave_prod(pr);
   };
   if (wid == 0) {
@@ -2037,7 +2055,8 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
   const double* center = nullptr;
   if (h->sm_on && c.icp_ok) {
     // N1 option: every particle refines T(pose) * T_icp against its own map first; the samples are drawn round that
-    const size_t sm_lds = sizeof(double2) * (c.Bv > 0 ? c.Bv : 1) + sizeof(double) * kMixLut + (propose_lds - propose_lds_base);
+    const size_t sm_lds = sizeof(double2) * (c.Bv > 0 ? c.Bv : 1) + sizeof(double) * kMixLut + sizeof(unsigned long long) * 4 * (c.Bv > 0 ? c.Bv : 1) +
+                          (propose_lds - propose_lds_base);
     hipLaunchKernelGGL(rbpf_scanmatch, dim3(h->N), dim3(kMatchThreads), sm_lds, st, c, h->sm, h->d_beams, h->d_code[h->cur],
                        h->d_bitmap[h->cur], h->d_rowcount[h->cur], skip_arr, skip_eq, h->df_mode, h->radius, occ_half,
                        h->d_nocc[h->cur], h->d_win, sp.pose, h->d_center, h->d_score, h->d_err);
