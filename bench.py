@@ -246,6 +246,16 @@ def main():
             line["options"] = {"mppi_exact_arc_dynamics": {"rollouts_per_s": round(K * n_a / el_a, 1),
                                                            "ms_per_step": round(el_a / n_a * 1e3, 6)}}
             ma.close()
+            # production tick: fresh perturbations drawn on the device every tick (Philox, inside the fused kernel) —
+            # what a controller that does not bring its own noise pays; `value` is quoted with the inputs resident
+            tk = [0]
+
+            def prod_tick():
+                m.enqueueRng(X0, 42, tk[0], stream)
+                tk[0] += 1
+            el_p = time_ticks(prod_tick, sync, n_a, min(args.warmup, 100), lambda: None)
+            line["options"]["mppi_tick_with_device_noise"] = {"rollouts_per_s": round(K * n_a / el_p, 1),
+                                                              "ms_per_step": round(el_p / n_a * 1e3, 6)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(K, T, horizon)
         if world == 1 and not args.no_rbpf:

@@ -155,6 +155,15 @@ int tbnav_mppi_debug_sincos(const double* x_host, int32_t n, double* sin_host, d
 int tbnav_mppi_profile_tick(tbnav_mppi* h, const double x0[3], const double* d_duL,
                             const double* d_duR, void* stream, float ms[TBNAV_MPPI_NKERNELS]);
 
+/* Production tick with the perturbations drawn on the device (Philox4x32-10 + Box-Muller, the values
+ * tbnav_mppi_sample_noise(h, seed, tick) would write — MPPI::pertubations, mppi.cpp:173-184, in production mode): for
+ * the fused small-K kernel they are generated inside it and never touch HBM; other configurations sample into the
+ * handle's buffers first.  Either way the result equals tbnav_mppi_sample_noise + tbnav_mppi_new_controls_dev(NULL
+ * noise) bit for bit.  _enqueue_ is asynchronous on `stream`, _new_controls_ waits and returns (ul, ur). */
+int tbnav_mppi_enqueue_rng(tbnav_mppi* h, const double x0[3], uint64_t seed, uint64_t tick, void* stream);
+int tbnav_mppi_new_controls_rng(tbnav_mppi* h, const double x0[3], uint64_t seed, uint64_t tick, void* stream,
+                                double u_out[2]);
+
 /* Per-kernel durations priced without the events' own cost: each kernel of the tick is launched `reps` (even, >= 2)
  * times back to back between one event pair; ms[i] = elapsed / reps (ms[1] = 0 when rollout and partials are one
  * kernel).  The controller state advances as if `reps` ticks had run on the same inputs. */

@@ -118,6 +118,8 @@ def lib() -> C.CDLL:
         "tbnav_mppi_enqueue_dev": (C.c_int, [vp, dp, vp, vp, vp]),
         "tbnav_mppi_last_controls": (C.c_int, [vp, vp, dp]),
         "tbnav_mppi_sample_noise": (C.c_int, [vp, u64, u64, vp]),
+        "tbnav_mppi_enqueue_rng": (C.c_int, [vp, dp, u64, u64, vp]),
+        "tbnav_mppi_new_controls_rng": (C.c_int, [vp, dp, u64, u64, vp, dp]),
         "tbnav_mppi_get_noise": (C.c_int, [vp, vp, vp]),
         "tbnav_mppi_shard_partials": (C.c_int, [vp, dp, vp, vp, vp, vp]),
         "tbnav_mppi_shard_combine": (C.c_int, [vp, vp, i32, vp]),

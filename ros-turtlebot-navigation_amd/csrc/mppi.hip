@@ -511,6 +511,44 @@ __global__ __launch_bounds__(kWave * MAXW) void mppi_rollout_scan(RolloutArgs a,
 }
 
 
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+  const uint32_t n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+  const uint32_t n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ void philox4x32_10(uint64_t ctr, uint64_t key, uint32_t (&out)[4]) {
+  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+  uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+
+// One (duL, duR) pair of the device noise source: Philox4x32-10 keyed by the seed, counter = tick*T*K + k*T + i, then
+// Box-Muller.  mppi_sample_noise fills the [T][K] arrays with it; the fused kernel can call it in place of the loads.
+struct RngArgs { uint64_t seed, base; double sig_l, sig_r; };
+__device__ __forceinline__ void device_noise(const RngArgs& g, int T, int i, int k, double& dl, double& dr) {
+  uint32_t r[4];
+  philox4x32_10(g.base + (uint64_t)k * T + i, g.seed, r);
+  const uint64_t a = ((uint64_t)r[0] << 32) | r[1];
+  const uint64_t b = ((uint64_t)r[2] << 32) | r[3];
+  const double u1 = ((double)(a >> 11) + 0.5) * 0x1.0p-53;  // (0,1)
+  const double u2 = ((double)(b >> 11) + 0.5) * 0x1.0p-53;
+  const double rad = sqrt(-2.0 * log(u1));
+  double sn, cs;
+  sincospi(2.0 * u2, &sn, &cs);
+  dl = g.sig_l * (rad * cs);
+  dr = g.sig_r * (rad * sn);
+}
+
 // ---- fused rollout + soft-min partials for small K (lanes = TIME) ------------------------------------------
 // When K/64 one-wave workgroups cannot fill the chip (K = 1024: 16 of 256 CUs), the tick is three short kernels
 // whose execution time is all latency.  This kernel turns the rollout round: one WAVE per rollout with its lanes
@@ -525,10 +563,11 @@ __global__ __launch_bounds__(kWave * MAXW) void mppi_rollout_scan(RolloutArgs a,
 //      records[T][K/R][8], the same record the partials kernel writes for a 2048-rollout slice.
 // The combine then merges K/R records per step instead of K/2048.  Numerics: the sums are wave-scan trees
 // instead of sequential chains (a few 1e-16 relative on x, y, theta, J — inside the 1e-11 J assertion).
-template <int TRIG, int R, int TL>
+template <int TRIG, int R, int TL, bool RNG>
 __global__ __launch_bounds__(kWave * R) void mppi_rollout_fused(RolloutArgs a, const double* __restrict__ duL,
                                                                 const double* __restrict__ duR, USrc u, double lambda,
-                                                                double* __restrict__ J, double* __restrict__ records, int S) {
+                                                                double* __restrict__ J, double* __restrict__ records, int S,
+                                                                RngArgs rng) {
   extern __shared__ __attribute__((aligned(16))) double lds_all[];
   constexpr int RP = R + 1;  // padded tile rows: the transposed reads of a wave hit distinct banks
   const int T = a.T, K = a.K;
@@ -546,8 +585,8 @@ __global__ __launch_bounds__(kWave * R) void mppi_rollout_fused(RolloutArgs a, c
 #pragma unroll
     for (int q = 0; q < TL; ++q) {
       const int i = lane * TL + q, ii = i < T ? i : T - 1;
-      dl[q] = duL[(size_t)ii * K + kk];
-      dr[q] = duR[(size_t)ii * K + kk];
+      if constexpr (RNG) device_noise(rng, T, ii, kk, dl[q], dr[q]);  // production mode: the perturbations never touch HBM
+      else { dl[q] = duL[(size_t)ii * K + kk]; dr[q] = duR[(size_t)ii * K + kk]; }
       uL[q] = u.get(0, ii, T);
       uR[q] = u.get(1, ii, T);
     }
@@ -877,44 +916,14 @@ __global__ void mppi_unpack_noise(int T, int K, const double* __restrict__ raw,
 }
 
 // ---- Philox4x32-10 (Salmon et al., SC'11) ------------------------------------------------------
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
-  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
-  const uint32_t n1 = (uint32_t)p1;
-  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-  const uint32_t n3 = (uint32_t)p0;
-  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-}
-__device__ __forceinline__ void philox4x32_10(uint64_t ctr, uint64_t key, uint32_t (&out)[4]) {
-  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
-  uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    philox_round(c, k0, k1);
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
-}
-
 __global__ void mppi_sample_noise(int T, int K, uint64_t seed, uint64_t tick, double sig_l,
                                   double sig_r, double* __restrict__ duL, double* __restrict__ duR) {
   const size_t n = (size_t)T * K;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
        idx += (size_t)gridDim.x * blockDim.x) {
     const int i = (int)(idx / K), k = (int)(idx % K);  // k fastest: coalesced stores
-    uint32_t r[4];
-    philox4x32_10(tick * n + (uint64_t)k * T + i, seed, r);
-    const uint64_t a = ((uint64_t)r[0] << 32) | r[1];
-    const uint64_t b = ((uint64_t)r[2] << 32) | r[3];
-    const double u1 = ((double)(a >> 11) + 0.5) * 0x1.0p-53;  // (0,1)
-    const double u2 = ((double)(b >> 11) + 0.5) * 0x1.0p-53;
-    const double rad = sqrt(-2.0 * log(u1));
-    double sn, cs;
-    sincospi(2.0 * u2, &sn, &cs);
-    duL[idx] = sig_l * (rad * cs);
-    duR[idx] = sig_r * (rad * sn);
+    const RngArgs g{seed, tick * n, sig_l, sig_r};
+    device_noise(g, T, i, k, duL[idx], duR[idx]);
   }
 }
 
@@ -1013,19 +1022,25 @@ RolloutArgs rollout_args(const tbnav_mppi* h, const double x0[3]) {
 size_t fused_lds_bytes(int T, int R) { return (size_t)3 * T * (R + 1) * sizeof(double); }
 
 // rollout + partial records in one launch (small K); the caller follows with launch_combine(..., fused_S)
-int launch_fused(tbnav_mppi* h, const double x0[3], const double* d_duL, const double* d_duR, hipStream_t st) {
+int launch_fused(tbnav_mppi* h, const double x0[3], const double* d_duL, const double* d_duR, hipStream_t st,
+                 const RngArgs* rng = nullptr) {
   const RolloutArgs a = rollout_args(h, x0);
   const USrc usrc{h->d_u[h->ucur], h->pending_shift ? 1 : 0, h->uinit[0], h->uinit[1]};
   const int R = h->fused_r, TL = (h->T + kWave - 1) / kWave;
   const dim3 grid(h->fused_S), block(kWave * R);
   const size_t lds = fused_lds_bytes(h->T, R);
-#define TBNAV_FUSED(TR, RR, TLL) hipLaunchKernelGGL((mppi_rollout_fused<TR, RR, TLL>), grid, block, lds, st, a, d_duL, d_duR, usrc, \
-                                                    h->p.lambda, h->d_J, h->d_records_f, h->fused_S)
-#define TBNAV_FUSED_R(TR)                                                                  \
-  if (R == 8) { if (TL == 1) TBNAV_FUSED(TR, 8, 1); else TBNAV_FUSED(TR, 8, 2); }          \
-  else if (R == 4) { if (TL == 1) TBNAV_FUSED(TR, 4, 1); else TBNAV_FUSED(TR, 4, 2); }     \
-  else { if (TL == 1) TBNAV_FUSED(TR, 16, 1); else TBNAV_FUSED(TR, 16, 2); }
-  if (h->dyn == 1) { TBNAV_FUSED_R(4) } else if (h->trig == 3) { TBNAV_FUSED_R(3) } else { TBNAV_FUSED_R(2) }
+  const RngArgs g = rng ? *rng : RngArgs{0, 0, 0.0, 0.0};
+#define TBNAV_FUSED(TR, RR, TLL, RG) hipLaunchKernelGGL((mppi_rollout_fused<TR, RR, TLL, RG>), grid, block, lds, st, a, d_duL, d_duR, usrc, \
+                                                        h->p.lambda, h->d_J, h->d_records_f, h->fused_S, g)
+#define TBNAV_FUSED_R(TR)                                                                                \
+  if (R == 8) { if (TL == 1) TBNAV_FUSED(TR, 8, 1, false); else TBNAV_FUSED(TR, 8, 2, false); }          \
+  else if (R == 4) { if (TL == 1) TBNAV_FUSED(TR, 4, 1, false); else TBNAV_FUSED(TR, 4, 2, false); }     \
+  else { if (TL == 1) TBNAV_FUSED(TR, 16, 1, false); else TBNAV_FUSED(TR, 16, 2, false); }
+#define TBNAV_FUSED_RNG(TR) if (TL == 1) TBNAV_FUSED(TR, 8, 1, true); else TBNAV_FUSED(TR, 8, 2, true)
+  if (rng) {  // in-kernel noise: instantiated for the default tile (8 rollouts per workgroup) only — the caller checks
+    if (h->dyn == 1) { TBNAV_FUSED_RNG(4); } else if (h->trig == 3) { TBNAV_FUSED_RNG(3); } else { TBNAV_FUSED_RNG(2); }
+  } else if (h->dyn == 1) { TBNAV_FUSED_R(4) } else if (h->trig == 3) { TBNAV_FUSED_R(3) } else { TBNAV_FUSED_R(2) }
+#undef TBNAV_FUSED_RNG
 #undef TBNAV_FUSED_R
 #undef TBNAV_FUSED
   TBNAV_HIP(hipGetLastError());
@@ -1423,6 +1438,30 @@ int tbnav_mppi_sample_noise(tbnav_mppi* h, uint64_t seed, uint64_t tick, void* s
                      h->d_duR);
   TBNAV_HIP(hipGetLastError());
   return TBNAV_OK;
+}
+
+// Production tick: the perturbations of tick `tick` under `seed` are the ones tbnav_mppi_sample_noise would write, but
+// for the fused small-K kernel they are generated inside it and never stored (the soft-min reads them from the
+// workgroup's LDS tile).  Other configurations sample into the handle's buffers first — same values, same result.
+int tbnav_mppi_enqueue_rng(tbnav_mppi* h, const double x0[3], uint64_t seed, uint64_t tick, void* stream) {
+  if (!h || !x0) return TBNAV_ERR_INVALID_ARG;
+  if (h->fused_r != 8) {
+    const int rc = tbnav_mppi_sample_noise(h, seed, tick, stream);
+    return rc != TBNAV_OK ? rc : tbnav_mppi_enqueue_dev(h, x0, nullptr, nullptr, stream);
+  }
+  DeviceGuard guard(h->device);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const RngArgs g{seed, tick * (uint64_t)h->T * (uint64_t)h->K, std::sqrt(h->p.ul_var), std::sqrt(h->p.ur_var)};
+  const int rc = launch_fused(h, x0, h->d_duL, h->d_duR, st, &g);
+  return rc != TBNAV_OK ? rc : launch_combine(h, h->d_records_f, 1, st, h->fused_S);
+}
+
+int tbnav_mppi_new_controls_rng(tbnav_mppi* h, const double x0[3], uint64_t seed, uint64_t tick, void* stream, double u_out[2]) {
+  if (!h || !u_out) return TBNAV_ERR_INVALID_ARG;
+  h->publish_next = true;
+  const int rc = tbnav_mppi_enqueue_rng(h, x0, seed, tick, stream);
+  h->publish_next = false;
+  return rc != TBNAV_OK ? rc : tbnav_mppi_last_controls(h, stream, u_out);
 }
 
 int tbnav_mppi_get_noise(tbnav_mppi* h, double* duL_host, double* duR_host) {

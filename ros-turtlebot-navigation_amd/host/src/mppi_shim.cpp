@@ -50,8 +50,8 @@ WheelVelocities MPPI::newControls(const Pose& ps) {
   const double x0[3] = {ps.x, ps.y, ps.theta};  // mppi.cpp:75-76: state order (x, y, theta)
   double out[2] = {0.0, 0.0};
   if (device_noise_) {
-    check(tbnav_mppi_sample_noise(h_, seed_, tick_++, nullptr), "sample_noise");
-    check(tbnav_mppi_new_controls_dev(h_, x0, nullptr, nullptr, nullptr, out), "newControls");
+    // the perturbations of (seed, tick) are generated inside the rollout kernel where the configuration has the fused one
+    check(tbnav_mppi_new_controls_rng(h_, x0, seed_, tick_++, nullptr, out), "newControls");
   } else {
     noise_.resize((size_t)2 * steps_ * rollouts_);
     size_t n = 0;

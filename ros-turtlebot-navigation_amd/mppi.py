@@ -125,6 +125,16 @@ class MPPI:
         capi.check(self._L.tbnav_mppi_last_controls(self._h, stream or None, out), "last_controls")
         return out[0], out[1]
 
+    def enqueueRng(self, x0, seed: int, tick: int, stream: int = 0):
+        """Production tick: perturbations of (seed, tick) drawn on the device, inside the fused kernel where there is one."""
+        capi.check(self._L.tbnav_mppi_enqueue_rng(self._h, (C.c_double * 3)(*x0), seed, tick, stream or None), "enqueue_rng")
+
+    def newControlsRng(self, x0, seed: int, tick: int, stream: int = 0):
+        out = (C.c_double * 2)()
+        capi.check(self._L.tbnav_mppi_new_controls_rng(self._h, (C.c_double * 3)(*x0), seed, tick, stream or None, out),
+                   "new_controls_rng")
+        return out[0], out[1]
+
     def sampleNoise(self, seed: int, tick: int, stream: int = 0):
         capi.check(self._L.tbnav_mppi_sample_noise(self._h, seed, tick, stream or None), "sample_noise")
 

@@ -128,6 +128,32 @@ def test_arc_and_rk4_dynamics_agree_to_truncation_order(gpu_pkg):
     assert 0 < rel.max() < 1e-6
 
 
+@pytest.mark.parametrize("K,horizon", [(1024, 0.5), (100, 1.0), (37, 1.28), (200, 2.0)])
+def test_in_kernel_noise_equals_sampled_noise(gpu_pkg, K, horizon):
+    """Production tick (tbnav_mppi_new_controls_rng): the fused small-K kernel generates the perturbations of
+    (seed, tick) itself instead of loading them.  They must be the values tbnav_mppi_sample_noise writes, so the tick
+    equals "sample, then tick on the sampled arrays" bit for bit — and those arrays are what the oracle is fed.
+    T = 200 has no fused kernel: the entry point then samples first, same contract."""
+    d = mppi_cfg(K, horizon)
+    m_rng, m_ref = make_mppi(gpu_pkg, d), make_mppi(gpu_pkg, d)
+    T = m_rng.steps
+    for m in (m_rng, m_ref):
+        m.setWaypoint(*WAYPOINTS[1])
+    x0 = (0.1, -0.2, 0.3)
+    u = np.zeros((2, T))
+    for tick in range(3):
+        got = m_rng.newControlsRng(x0, 77, tick)
+        m_ref.sampleNoise(77, tick)
+        want = m_ref.newControlsDev(x0, 0, 0)
+        assert got == want and np.array_equal(m_rng.getControls(), m_ref.getControls())
+        a, b = m_ref.getNoise()                      # [T][K] each -> the oracle's [K][T][2]
+        ref = orc.mppi_new_controls(d, u, (0, 0), WAYPOINTS[1], x0, np.stack([a.T, b.T], axis=2))
+        assert np.allclose(got, ref["out"], rtol=U_RTOL, atol=U_ATOL)
+        assert rel_err(m_rng.costToGo(), ref["J"]) < J_RTOL
+        u = ref["u"]
+        x0 = (x0[0] + 0.002, x0[1], x0[2] + 0.001)
+
+
 def test_long_horizon_uses_global_scratch_path(gpu_pkg):
     """T = 400 > 320: per-step losses no longer fit LDS ([T][64] doubles), J is the scratch."""
     d = mppi_cfg(96, 4.0)
