@@ -20,14 +20,32 @@
  * Device data layout (per handle; N particles, G = xsize*ysize cells, cell index
  * idx = i*xsize + j with i the x-cell, grid_mapper.cpp:890-898; square maps only, as the reference):
  *   pose, prev_pose : [N][3] f64        weight : [N] f64
- *   log_odds        : [N][G] f64        (Cell::log_odds, grid_mapper.hpp:67; beam-ordered adds)
- *   dist_code       : [N][G] u16        squared distance IN CELLS to the nearest occupied cell;
- *                     occ_dist = sqrt((double)code) * resolution is bit-identical to the reference's
- *                     distances_[di][dj] * resolution_ (grid_mapper.cpp:263,318); 0xFFFF = never
- *                     reached = max_occ_dist_ 10.0 (grid_mapper.cpp:49,58)
+ *   log_odds        : f64 (Cell::log_odds, grid_mapper.hpp:67; beam-ordered adds), TILED and COPY-ON-WRITE: each
+ *                     particle holds a table of ceil(xsize/32)^2 tile ids into one pool of 32x32-cell tiles
+ *                     (8 KB each) shared by the handle's particles; id 0 = the shared all-zero tile (untouched
+ *                     area).  The reference deep-copies a whole map per resampled particle
+ *                     (particle_filter.cpp:495); here a resample copies tables and bumps reference counts, and
+ *                     the next scan clones only the tiles it writes.  100 000 particles x 2000 x 2000 cells
+ *                     (BASELINE configs[4]) would be 3.2 TB dense; tiled it is the scanned area per lineage.
  *   occupancy       : [N][xsize][ceil(ysize/64)] u64 bitmap of cells with prob >= 0.90, decided in
  *                     log-odds space against a cut-off found on the host with glibc at create time
  *                     (SURVEY.md hard part 2: prob(log 9) == 0.9 exactly with glibc)
+ *   dist_code       : [N][G] u16, allocated only when something needs a STORED field (tbnav_rbpf_set_occ_dist,
+ *                     get_occ_dist/get_dist_code, the stored-field modes of TBNAV_RBPF_OPT_DF_MODE): squared
+ *                     distance IN CELLS to the nearest occupied cell; occ_dist = sqrt((double)code) * resolution
+ *                     is bit-identical to the reference's distances_[di][dj] * resolution_
+ *                     (grid_mapper.cpp:263,318); 0xFFFF = never reached = max_occ_dist_ 10.0
+ *                     (grid_mapper.cpp:49,58)
+ *
+ * DISTANCE FIELD — what differs from the reference unless the REFERENCE mode is selected.  The reference's
+ * GridMapper::euclideanSignedDistanceField (grid_mapper.cpp:333-435) is a priority-queue brushfire whose result
+ * depends on std::unordered_set iteration order and heap tie-breaking and is not the exact Euclidean distance
+ * transform (hard part 1).  By default a likelihood lookup computes the EXACT distance to the
+ * nearest occupied cell within cell_radius_ (never larger than the reference's value, equal in most cells; a cell
+ * with no obstacle within cell_radius_ reads max_occ_dist_, where the reference keeps whatever an earlier brushfire
+ * left).  Scan likelihoods, eta and weights of a default-mode run therefore differ slightly from the reference's
+ * (measured in DESIGN.md); TBNAV_RBPF_DF_REFERENCE reproduces the reference's field bit for bit for small
+ * ensembles.
  */
 #ifndef TBNAV_RBPF_H
 #define TBNAV_RBPF_H
@@ -73,7 +91,13 @@ typedef struct tbnav_rbpf tbnav_rbpf; /* opaque */
 /* ParticleFilter::ParticleFilter + initParticleSet (particle_filter.cpp:67-138): N particles at
  * pose0 with weight 1/N, empty maps (log-odds 0, distance = max_occ_dist). */
 int tbnav_rbpf_create(const tbnav_rbpf_params* params, tbnav_rbpf** out);
+/* Same, with an explicit budget for the log-odds tile pool (bytes; 0 = the default: what every particle's map could
+ * ever need if that fits in half of the device memory free at create time, else that half).  A scan that needs a
+ * tile when none is free returns TBNAV_ERR_POOL_EXHAUSTED and leaves the maps of the particles concerned unchanged. */
+int tbnav_rbpf_create_pool(const tbnav_rbpf_params* params, uint64_t max_pool_bytes, tbnav_rbpf** out);
 void tbnav_rbpf_destroy(tbnav_rbpf* h);
+/* Tile pool occupancy: tiles the pool holds, tiles free now, bytes of log-odds per tile (any pointer may be NULL). */
+int tbnav_rbpf_pool_stats(tbnav_rbpf* h, uint64_t* capacity_tiles, uint64_t* free_tiles, uint64_t* tile_bytes);
 int tbnav_rbpf_grid_size(const tbnav_rbpf* h, int32_t* xsize, int32_t* ysize);
 /* Standard normals one SLAM call consumes, in draw order: N*(3k+3) (ICP ok) or N*3 (ICP failed),
  * plus 1 for the resampling offset (particle_filter.cpp:474), which is read only if resampling fires. */
@@ -114,23 +138,41 @@ int tbnav_rbpf_best_state(tbnav_rbpf* h, double pose[3], int32_t* best_index);
  * so the result is the reference's bit for bit and only G bytes cross PCIe.  map holds G entries. */
 int tbnav_rbpf_best_map(tbnav_rbpf* h, int8_t* map);
 
-/* ---- multi-GPU building blocks (particles sharded across ranks) ------------------------------- */
-/* SLAM without the normalise/resample tail: per-particle update only.  Weights are left
- * un-normalised; fetch them with tbnav_rbpf_get_particles, all-gather, then call
- * tbnav_rbpf_resample_global on every rank. */
+/* ---- multi-GPU building blocks (particles sharded across ranks) -------------------------------
+ * One handle per rank holds N/P particles.  Per scan: tbnav_rbpf_slam_local (no normalise/resample tail) ->
+ * tbnav_rbpf_copy_weights_dev into the rank's slice of a device buffer -> ONE all-gather of the raw weights (RCCL)
+ * -> tbnav_rbpf_resample_global_dev on every rank: the reference's sequential normalise / Neff / low-variance
+ * selection (particle_filter.cpp:442-500) over the identical global vector, so Neff and the parent list are
+ * bit-exact and the same everywhere; the local slice of the normalised weights lands in the handle.  Only when
+ * resampling fires do particles move: tbnav_rbpf_gather_local for parents that live on this rank,
+ * tbnav_rbpf_export_particle_dev / tbnav_rbpf_import_particle_dev (device buffers, sent point to point) for the
+ * others, tbnav_rbpf_set_weights_from_global_dev for the slots' weights.  Nothing passes through host memory
+ * except the parent list, which the host needs to plan the sends. */
 int tbnav_rbpf_slam_local(tbnav_rbpf* h, const float* scan, int32_t n_beams, const double u[3],
                           const double cur_odom[3], const double prev_odom[3], int32_t icp_ok,
                           const double T_icp[3], const double* normals, tbnav_rbpf_stats* out);
-/* normalizeWeights + effectiveParticles + lowVarianceResampling (particle_filter.cpp:442-500) over
- * the GLOBAL weight vector (n_global entries, identical on every rank), in the reference's
- * sequential order so Neff and the parent list are bit-exact; z = the one standard normal.
+/* This handle's weights [N] -> device buffer (synchronous on the handle's stream). */
+int tbnav_rbpf_copy_weights_dev(tbnav_rbpf* h, double* d_dst);
+/* d_weights_all: n_global raw weights on the device (identical on every rank); offset: global index of this
+ * handle's slot 0; z: the one standard normal of lowVarianceResampling (particle_filter.cpp:474).  parents_out
+ * (n_global int32, host, may be NULL) is filled only if out->resampled. */
+int tbnav_rbpf_resample_global_dev(tbnav_rbpf* h, const double* d_weights_all, int64_t n_global, int64_t offset, double z,
+                                   int32_t* parents_out, tbnav_rbpf_stats* out);
+/* After a resample: slot m takes the normalised weight of its GLOBAL parent (weights are not reset, :495). */
+int tbnav_rbpf_set_weights_from_global_dev(tbnav_rbpf* h, const int32_t* global_parent_of_slot /*[N]*/);
+/* Same selection on host buffers (n_global entries, identical on every rank), for callers without device tensors.
  * parents_out (n_global int32, host) receives the parent index of every slot (identity when no
  * resampling fires); weights_out (n_global, host) the normalised weights. */
 int tbnav_rbpf_resample_global(const double* weights_all, int64_t n_global, double z,
                                int32_t* parents_out, double* weights_out, tbnav_rbpf_stats* out);
-/* Re-populate this rank's slots from LOCAL parents (gather inside the handle); slots whose parent
- * lives on another rank are filled through get/set_particle_state below. */
+/* Re-populate this rank's slots from LOCAL parents (tables, bitmaps and state move on the device); -1 = keep. */
 int tbnav_rbpf_gather_local(tbnav_rbpf* h, const int32_t* local_parent /*[N], -1 = leave*/);
+/* A particle as one device buffer: header, state (pose, prev_pose, weight), the indices and 8 KB payloads of the
+ * tiles it does not share with the empty map, its occupancy bitmap + row counts, and its stored distance field if
+ * that is authoritative (injected).  export_size: bytes the export of `slot` needs now. */
+int tbnav_rbpf_export_size(tbnav_rbpf* h, int32_t slot, uint64_t* bytes);
+int tbnav_rbpf_export_particle_dev(tbnav_rbpf* h, int32_t slot, void* d_buf, uint64_t capacity, uint64_t* bytes);
+int tbnav_rbpf_import_particle_dev(tbnav_rbpf* h, int32_t slot, const void* d_buf, uint64_t bytes);
 
 /* ---- state access: parity hooks and particle migration --------------------------------------- */
 int tbnav_rbpf_get_particles(tbnav_rbpf* h, double* pose, double* prev_pose, double* weight);
@@ -153,6 +195,32 @@ int tbnav_rbpf_get_occupied_count(tbnav_rbpf* h, int32_t* counts /*[N]*/);
 int tbnav_rbpf_get_trace(tbnav_rbpf* h, double* sampled, double* p_scan, double* p_pose, double* mu,
                          double* sigma, double* eta, double* new_pose, double* weight_raw,
                          int32_t* resample_parent);
+
+/* ---- options (explicit setters; nothing in the library reads the environment) --------------------------------
+ * TBNAV_RBPF_OPT_DF_MODE — where a likelihood lookup gets its distance from.  Must be chosen before the first scan.
+ *   TBNAV_RBPF_DF_QUERY     (default) exact nearest-obstacle query on the occupancy bitmap at lookup time; no
+ *                           transform and no stored field in the SLAM path.
+ *   TBNAV_RBPF_DF_WINDOW    exact transform of a window round each particle, stored, before each update.
+ *   TBNAV_RBPF_DF_FULL      exact transform of every whole map after every update (the reference's data flow).
+ *                           QUERY / WINDOW / FULL give bit-identical results while every looked-up cell has an
+ *                           obstacle within cell_radius_.
+ *   TBNAV_RBPF_DF_REFERENCE the reference's own brushfire (grid_mapper.cpp:272-435), reproduced on the host per
+ *                           particle with the same libstdc++ containers fed the same occupied-set insert / erase
+ *                           sequence (the beam-ordered raycast kernel logs it) and copied on resampling the way
+ *                           particle_filter.cpp:495-499 copies particles; its result becomes the stored field the
+ *                           next scan reads.  Serial host work per particle: N <= 4096, meant for the reference's
+ *                           own launch configuration.  After tbnav_rbpf_set_log_odds the set of that particle is
+ *                           rebuilt in ascending cell order (its history is unknown).
+ * TBNAV_RBPF_OPT_RAYCAST_ORDERED 1 = always use the beam-ordered raycast kernel (development / A-B runs).
+ * TBNAV_RBPF_OPT_RAYCAST_THREADS 256 | 512 | 1024 threads per workgroup of the tile raycast (default 1024).
+ * TBNAV_RBPF_OPT_COUNT_CELLS     1 = the tile raycast counts the cells it updates (tbnav_rbpf_scan_counts). */
+enum { TBNAV_RBPF_OPT_DF_MODE = 1, TBNAV_RBPF_OPT_RAYCAST_ORDERED = 2, TBNAV_RBPF_OPT_RAYCAST_THREADS = 3, TBNAV_RBPF_OPT_COUNT_CELLS = 4 };
+enum { TBNAV_RBPF_DF_FULL = 0, TBNAV_RBPF_DF_WINDOW = 1, TBNAV_RBPF_DF_QUERY = 2, TBNAV_RBPF_DF_REFERENCE = 3 };
+int tbnav_rbpf_set_option(tbnav_rbpf* h, int32_t option, int32_t value);
+/* Since the last reset, summed over particles and scans (TBNAV_RBPF_OPT_COUNT_CELLS on): cell_updates = log-odds
+ * adds the reference performs (free cells of every ray + end points, grid_mapper.cpp:153-177), distinct_cells =
+ * cells actually read-modified-written (a cell touched by several beams of one scan counts once per scan). */
+int tbnav_rbpf_scan_counts(tbnav_rbpf* h, uint64_t* cell_updates, uint64_t* distinct_cells, int32_t reset);
 
 /* ---- measurement hook --------------------------------------------------------------------------
  * Durations (ms, HIP events on the handle's stream) of the kernels of the LAST slam call:

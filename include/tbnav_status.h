@@ -21,7 +21,8 @@ typedef enum tbnav_status {
   TBNAV_ERR_ETA_ZERO = 5,        /* "eta is 0" (particle_filter.cpp:579)                            */
   TBNAV_ERR_PDF_VARIANCE = 6,    /* "Variance in pdfNormal is 0" (grid_mapper.cpp:22)               */
   TBNAV_ERR_BRESENHAM = 7,       /* "Bresenham's Line Algorithm" (grid_mapper.cpp:701)              */
-  TBNAV_ERR_UNSUPPORTED = 8      /* configuration outside what the device path implements           */
+  TBNAV_ERR_UNSUPPORTED = 8,     /* configuration outside what the device path implements           */
+  TBNAV_ERR_POOL_EXHAUSTED = 9   /* RBPF: no free log-odds tile left in the handle's pool (tbnav_rbpf_create_pool) */
 } tbnav_status;
 
 /* Human-readable text for a status code; for OUT_OF_WORLD/ETA_ZERO/PDF_VARIANCE/BRESENHAM it is the

@@ -18,7 +18,11 @@ TBNAV_MPPI_REC = 8
 
 # tbnav_status.h
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OUT_OF_WORLD, ERR_ETA_ZERO, ERR_PDF_VARIANCE, \
-    ERR_BRESENHAM, ERR_UNSUPPORTED = range(9)
+    ERR_BRESENHAM, ERR_UNSUPPORTED, ERR_POOL_EXHAUSTED = range(10)
+
+# tbnav_rbpf.h options
+RBPF_OPT_DF_MODE, RBPF_OPT_RAYCAST_ORDERED, RBPF_OPT_RAYCAST_THREADS, RBPF_OPT_COUNT_CELLS = 1, 2, 3, 4
+RBPF_DF = {"full": 0, "window": 1, "query": 2, "reference": 3}
 
 
 class TbnavError(RuntimeError):
@@ -129,6 +133,10 @@ def lib() -> C.CDLL:
         "tbnav_mppi_profile_kernels": (C.c_int, [vp, dp, vp, vp, vp, i32, C.POINTER(C.c_float)]),
         # RBPF
         "tbnav_rbpf_create": (C.c_int, [C.POINTER(RbpfParams), C.POINTER(vp)]),
+        "tbnav_rbpf_create_pool": (C.c_int, [C.POINTER(RbpfParams), u64, C.POINTER(vp)]),
+        "tbnav_rbpf_pool_stats": (C.c_int, [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]),
+        "tbnav_rbpf_set_option": (C.c_int, [vp, i32, i32]),
+        "tbnav_rbpf_scan_counts": (C.c_int, [vp, C.POINTER(u64), C.POINTER(u64), i32]),
         "tbnav_rbpf_destroy": (None, [vp]),
         "tbnav_rbpf_grid_size": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32)]),
         "tbnav_rbpf_num_normals": (C.c_int64, [vp, i32]),
@@ -138,6 +146,12 @@ def lib() -> C.CDLL:
         "tbnav_rbpf_slam_local": (C.c_int, [vp, vp, i32, dp, dp, dp, i32, dp, vp, C.POINTER(RbpfStats)]),
         "tbnav_rbpf_resample_global": (C.c_int, [vp, C.c_int64, dbl, vp, vp, C.POINTER(RbpfStats)]),
         "tbnav_rbpf_gather_local": (C.c_int, [vp, vp]),
+        "tbnav_rbpf_copy_weights_dev": (C.c_int, [vp, vp]),
+        "tbnav_rbpf_resample_global_dev": (C.c_int, [vp, vp, C.c_int64, C.c_int64, dbl, vp, C.POINTER(RbpfStats)]),
+        "tbnav_rbpf_set_weights_from_global_dev": (C.c_int, [vp, vp]),
+        "tbnav_rbpf_export_size": (C.c_int, [vp, i32, C.POINTER(u64)]),
+        "tbnav_rbpf_export_particle_dev": (C.c_int, [vp, i32, vp, u64, C.POINTER(u64)]),
+        "tbnav_rbpf_import_particle_dev": (C.c_int, [vp, i32, vp, u64]),
         "tbnav_rbpf_best_state": (C.c_int, [vp, dp, C.POINTER(i32)]),
         "tbnav_rbpf_best_map": (C.c_int, [vp, vp]),
         "tbnav_rbpf_get_particles": (C.c_int, [vp, vp, vp, vp]),

@@ -33,6 +33,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "ref_field.hpp"
 #include "tbnav_rbpf.h"
 
 namespace {
@@ -95,6 +96,65 @@ struct ScanC {  // everything constant during one SLAM call
   double d_free, d_occ, cut_occ; // log-odds increments and the host-derived occupied cut-off
   int stride_normals;            // 3k+3 or 3
 };
+
+// ---- tiled copy-on-write log-odds maps -------------------------------------------------------------------
+// The reference gives every particle its own dense map and deep-copies it when a particle is resampled
+// (particle_filter.cpp:125-138, :495).  Here a particle's log-odds are a TABLE of kTS x kTS-cell tiles drawn from
+// one pool shared by all particles of the handle:
+//   table[p][ti * TW + tj] = id of the tile holding cells (32*ti .. 32*ti+31, 32*tj .. 32*tj+31); id 0 = the shared
+//   all-zero tile (a cell nobody has touched has log-odds 0 = log_odds_prior_, grid_mapper.cpp:42-58);
+//   ref[id] = how many table (and shed) entries name the tile.
+// A resample copies tables and bumps counts (rbpf_resample_tables / rbpf_release_tables) instead of copying maps;
+// the raycast makes a tile private on first write (tile_make_private): it takes a fresh tile from the free ring,
+// copies (or zero-fills) 8 KB, and notes the tile it left in shed[p][t].  Counts of shared tiles are NOT touched
+// while a scan runs (every sharer sees a stable count > 1 and copies); the shed notes are settled at the next
+// resample, which is also the only time tiles return to the ring.  Pops (scan) and pushes (resample) therefore
+// never run concurrently and the ring needs no ABA protection.
+constexpr int kTS = 32, kTSh = 5, kTileCells = kTS * kTS;
+struct TilePool {
+  double* lo;               // [cap][kTileCells], in-tile index = (i & 31) * 32 + (j & 31)
+  int* ref;                 // [cap]
+  unsigned int* ring;       // [cap] free tile ids
+  unsigned long long* ctr;  // [0] head: tiles popped, [1] tail: tiles pushed (free = tail - head)
+  unsigned int cap;
+};
+struct MapT {
+  unsigned int* table;  // [N][TT] of the current buffer
+  unsigned int* shed;   // [N][TT] tile this slot stopped using since the last resample (0 = none)
+  int TW, TT;           // tiles per side, tiles per map
+};
+__device__ __forceinline__ int tile_of(const MapT& M, int ci, int cj) { return (ci >> kTSh) * M.TW + (cj >> kTSh); }
+__device__ __forceinline__ int in_tile(int ci, int cj) { return ((ci & (kTS - 1)) << kTSh) | (cj & (kTS - 1)); }
+__device__ __forceinline__ unsigned int tile_pop(const TilePool& P) {  // 0 = pool exhausted
+  const unsigned long long pos = atomicAdd(P.ctr, 1ull);
+  if (pos >= P.ctr[1]) { atomicAdd(P.ctr, ~0ull); return 0u; }  // (no push can be in flight: see above)
+  return P.ring[pos % P.cap];
+}
+__device__ __forceinline__ void tile_push(const TilePool& P, unsigned int id) {
+  const unsigned long long pos = atomicAdd(P.ctr + 1, 1ull);
+  P.ring[pos % P.cap] = id;
+}
+// Make tile t of one particle private to it (called by all 64 lanes of a wave, wave-uniform arguments).
+// Returns the tile's id, 0 if the pool is exhausted.
+__device__ __forceinline__ unsigned int tile_make_private(const TilePool& P, unsigned int* __restrict__ table_p,
+                                                          unsigned int* __restrict__ shed_p, int t, int lane) {
+  const unsigned int id = table_p[t];
+  if (id != 0u && P.ref[id] == 1) return id;
+  unsigned int nid = 0u;
+  if (lane == 0) nid = tile_pop(P);
+  nid = __shfl(nid, 0, kWave);
+  if (nid == 0u) return 0u;
+  double2* dst = reinterpret_cast<double2*>(P.lo + (size_t)nid * kTileCells);
+  const double2* src = reinterpret_cast<const double2*>(P.lo + (size_t)id * kTileCells);  // id 0 = the zero tile
+#pragma unroll
+  for (int i = 0; i < kTileCells / 2 / kWave; ++i) dst[i * kWave + lane] = src[i * kWave + lane];
+  if (lane == 0) {
+    P.ref[nid] = 1;
+    table_p[t] = nid;
+    if (id != 0u) shed_p[t] = id;  // a (p, t) entry leaves a shared tile at most once between two resamples
+  }
+  return nid;
+}
 
 // world -> cell, grid_mapper.cpp:810-887.  false = outside the world (the reference throws).
 // The reference's cell is floor(fl(fl(x - xmin) / res)).  An f64 division costs ~25 instructions, and this runs
@@ -163,7 +223,7 @@ __device__ __forceinline__ int row_nearest(const unsigned long long* row, int wo
 //           is a handful of rows; the result is the exact transform's value (same integer arithmetic), and a
 //           cell with no obstacle within cell_radius keeps its stored code, like the transform.
 struct DistSrc {
-  const uint16_t* code;             // [G] of the particle
+  const uint16_t* code;             // [G] of the particle; NULL when the handle keeps no stored field (query mode only)
   const unsigned long long* bm;     // [xs][words]
   const int* rowcount;              // [xs]
   int4 win;
@@ -230,12 +290,14 @@ __device__ __forceinline__ uint16_t nearest_code_query(const GridC& g, const Dis
       const int R0 = d.R0;
       const int best = nearest_d2_rows(d.tbm, d.nW, d.R0, d.R1, radius, ci, cj - C0, [any, R0](int r) { return any[r - R0] != 0; });
       if (best != 0x7fffffff && best <= clear * clear && best <= radius * radius) return (uint16_t)best;
-      if (best == 0x7fffffff && clear > radius) return d.code[(size_t)ci * g.xsize + cj];
+      if (best == 0x7fffffff && clear > radius) return d.code ? d.code[(size_t)ci * g.xsize + cj] : kCodeUnreached;
     }
   }
   const int* rcnt = d.rowcount;
   const int best = nearest_d2_rows(d.bm, g.words, 0, g.xsize - 1, radius, ci, cj, [rcnt](int r) { return rcnt[r] != 0; });
-  return (best <= radius * radius) ? (uint16_t)best : d.code[(size_t)ci * g.xsize + cj];
+  // nothing within cell_radius_: the stored code if the handle keeps a stored field (injected / materialised), else
+  // "never reached" (the reference keeps whatever an earlier brushfire left there, grid_mapper.cpp:310-313)
+  return (best <= radius * radius) ? (uint16_t)best : (d.code ? d.code[(size_t)ci * g.xsize + cj] : kCodeUnreached);
 }
 // Distance code of cell (ci, cj), or -1 when a windowed lookup falls outside the refreshed window.
 __device__ __forceinline__ int lookup_code(const GridC& g, const DistSrc& d, int radius, int ci, int cj) {
@@ -431,7 +493,7 @@ __global__ __launch_bounds__(kMatchThreads) void rbpf_scanmatch(ScanC c, ScanMat
     if (tid == 0) { center[p * 3 + 0] = mu0[0]; center[p * 3 + 1] = mu0[1]; center[p * 3 + 2] = mu0[2]; score[p] = 1.0; }
     return;
   }
-  DistSrc ds{codes + (size_t)p * c.g.xsize * c.g.ysize, bitmap + (size_t)p * c.g.xsize * c.g.words, row_count + (size_t)p * c.g.xsize,
+  DistSrc ds{codes ? codes + (size_t)p * c.g.xsize * c.g.ysize : nullptr, bitmap + (size_t)p * c.g.xsize * c.g.words, row_count + (size_t)p * c.g.xsize,
              win[p], skip[p] == skip_eq ? 0 : df_mode, tile_bm, reinterpret_cast<const int*>(tile_bm), 0, 0, 0, 0};
   for (int b = tid; b < c.Bv; b += kMatchThreads) lbeams[b] = beams[b];
   for (int q = tid; q < kMixLut; q += kMatchThreads) lut[q] = beam_mixture(c, (uint16_t)q);
@@ -545,7 +607,7 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
   int* unst = reinterpret_cast<int*>(ccell + c.Bv);                  // [Bv] 1 = some sample may see the beam in another cell
   int* ulist = unst + c.Bv;                                          // [<= Bv] those beams, ascending
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
-  const uint16_t* code = codes + (size_t)p * c.g.xsize * c.g.ysize;
+  const uint16_t* code = codes ? codes + (size_t)p * c.g.xsize * c.g.ysize : nullptr;  // NULL: no stored field (query mode)
   const double* z = normals + (size_t)p * c.stride_normals;
   const int nocc = n_occ[p];
   // a particle whose field is authoritative (injected / whole-field fresh) always reads it
@@ -894,12 +956,12 @@ __device__ __forceinline__ void ray_cell(const Ray& r, int n, int& cx, int& cy) 
 // The occupancy bitmap / per-row counts / occupied count of the particle are kept up to date here: a
 // log-odds add that crosses the occupied cut-off toggles the cell's bit (rare: a few hundred cells per
 // scan), so no pass over the whole map is needed to find the distance transform's seeds.
-__device__ __forceinline__ void add_log_odds(double* __restrict__ lo, size_t idx, double d, double cut, int cx, int cy,
+__device__ __forceinline__ bool add_log_odds(double* __restrict__ cell, double d, double cut, int cx, int cy,
                                              int words, unsigned long long* __restrict__ bm, int* __restrict__ rowcount,
                                              int* __restrict__ nocc) {
-  const double old = lo[idx];
+  const double old = *cell;
   const double nw = old + d;
-  lo[idx] = nw;
+  *cell = nw;
   const bool was = old >= cut, now = nw >= cut;
   if (was != now) {
     atomicXor(&bm[(size_t)cx * words + (cy >> 6)], 1ull << (cy & 63));
@@ -907,23 +969,34 @@ __device__ __forceinline__ void add_log_odds(double* __restrict__ lo, size_t idx
     atomicAdd(&rowcount[cx], delta);
     atomicAdd(nocc, delta);
   }
+  return was != now;
 }
 
-__global__ __launch_bounds__(kWave) void rbpf_raycast(ScanC c, const double2* __restrict__ beams,
-                                                     const double* __restrict__ pose, double* __restrict__ log_odds,
+// Ordered log of the occupied-set changes of one scan, per particle (reference distance-field mode only): entry =
+// cell index, bit 31 set = the cell LEFT the set.  Same order as the reference's occ_cells_ insert / erase calls
+// (grid_mapper.cpp:153-177 -> updateCellState/updateCellHash :438-546): beam by beam, the ray's free cells in
+// free_index order, then the end point.  ev == NULL: no log.
+struct OccLog { int* ev; int* count; int cap; };
+
+__global__ __launch_bounds__(kWave) void rbpf_raycast(ScanC c, TilePool P, MapT M, const double2* __restrict__ beams,
+                                                     const double* __restrict__ pose,
                                                      unsigned long long* __restrict__ bitmap, int* __restrict__ row_count,
-                                                     int* __restrict__ n_occ, int* __restrict__ err) {
+                                                     int* __restrict__ n_occ, int* __restrict__ err, OccLog log) {
   extern __shared__ __attribute__((aligned(16))) int lds_i[];
   int* ex = lds_i;         // [Bv]
   int* ey = lds_i + c.Bv;  // [Bv]
+  unsigned int* tbits = reinterpret_cast<unsigned int*>(lds_i + 2 * c.Bv);  // [(TT + 31) / 32] tiles this scan writes
   __shared__ int bad;
   const int p = blockIdx.x, lane = threadIdx.x;
-  double* lo = log_odds + (size_t)p * c.g.xsize * c.g.ysize;
+  unsigned int* tab = M.table + (size_t)p * M.TT;
+  unsigned int* shed = M.shed + (size_t)p * M.TT;
   unsigned long long* bm = bitmap + (size_t)p * c.g.xsize * c.g.words;
   int* rc = row_count + (size_t)p * c.g.xsize;
   int* nocc = n_occ + p;
   const double th = pose[p * 3 + 0], x = pose[p * 3 + 1], y = pose[p * 3 + 2];
   if (lane == 0) bad = 0;
+  const int tword = (M.TT + 31) / 32;
+  for (int w = lane; w < tword; w += kWave) tbits[w] = 0u;
   __syncthreads();
   double s0, c0;
   sincos(th, &s0, &c0);
@@ -941,19 +1014,63 @@ __global__ __launch_bounds__(kWave) void rbpf_raycast(ScanC c, const double2* __
   if (!world2cell(c.g, x, y, rx, ry)) bad = 1;  // freeGridIndex: world2Grid of the ROBOT pose (:558)
   __syncthreads();
   if (bad) { if (lane == 0) atomicOr(&err[0], 1); return; }
-  const int xs = c.g.xsize;
+  // which tiles does this scan write?  (one extra walk of the rays; this kernel is the fallback / reference-mode path)
   for (int b = 0; b < c.Bv; ++b) {
     const int x1 = ex[b], y1 = ey[b];
     const Ray r = make_ray(rx, ry, x1, y1);
     for (int n = lane; n < r.count; n += kWave) {
       int cx, cy;
       ray_cell(r, n, cx, cy);
-      add_log_odds(lo, (size_t)cx * xs + cy, c.d_free, c.cut_occ, cx, cy, c.g.words, bm, rc, nocc);
+      const int t = tile_of(M, cx, cy);
+      atomicOr(&tbits[t >> 5], 1u << (t & 31));
+    }
+    if (lane == 0) { const int t = tile_of(M, x1, y1); atomicOr(&tbits[t >> 5], 1u << (t & 31)); }
+  }
+  __syncthreads();
+  for (int w = 0; w < tword; ++w) {
+    unsigned int m = tbits[w];
+    while (m) {
+      const int t = w * 32 + __ffs((int)m) - 1;
+      m &= m - 1;
+      if (tile_make_private(P, tab, shed, t, lane) == 0u) bad = 1;
+    }
+  }
+  __syncthreads();
+  if (bad) { if (lane == 0) atomicOr(&err[3], 8); return; }  // tile pool exhausted: nothing has been written
+  int n_log = 0;
+  int* ev = log.ev ? log.ev + (size_t)p * log.cap : nullptr;
+  for (int b = 0; b < c.Bv; ++b) {
+    const int x1 = ex[b], y1 = ey[b];
+    const Ray r = make_ray(rx, ry, x1, y1);
+    for (int n0 = 0; n0 < r.count; n0 += kWave) {
+      const int n = n0 + lane;
+      bool flip = false;
+      int cell = 0;
+      if (n < r.count) {
+        int cx, cy;
+        ray_cell(r, n, cx, cy);
+        cell = cx * c.g.xsize + cy;
+        flip = add_log_odds(P.lo + (size_t)tab[tile_of(M, cx, cy)] * kTileCells + in_tile(cx, cy), c.d_free, c.cut_occ, cx, cy, c.g.words, bm, rc, nocc);
+      }
+      if (ev) {  // a free add can only take a cell OUT of the occupied set
+        const unsigned long long m = __ballot(flip);
+        if (flip) { const int at = n_log + __popcll(m & ((1ull << lane) - 1ull)); if (at < log.cap) ev[at] = cell | (int)0x80000000; }
+        n_log += __popcll(m);
+      }
     }
     __syncthreads();  // free-cell adds of this beam land before the endpoint / next beam touch the cells
-    if (lane == 0) add_log_odds(lo, (size_t)x1 * xs + y1, c.d_occ, c.cut_occ, x1, y1, c.g.words, bm, rc, nocc);
+    int eflip = 0;
+    if (lane == 0) {
+      double* cellp = P.lo + (size_t)tab[tile_of(M, x1, y1)] * kTileCells + in_tile(x1, y1);
+      const double before = *cellp;
+      const bool flip = add_log_odds(cellp, c.d_occ, c.cut_occ, x1, y1, c.g.words, bm, rc, nocc);
+      if (ev && flip && n_log < log.cap) ev[n_log] = (x1 * c.g.xsize + y1) | (before >= c.cut_occ ? (int)0x80000000 : 0);
+      eflip = flip ? 1 : 0;
+    }
+    if (ev) n_log += __shfl(eflip, 0, kWave);
     __syncthreads();
   }
+  if (ev && lane == 0) log.count[p] = n_log;
 }
 
 // Is map cell (cx, cy) one of the FREE cells of ray r (i.e. some n in [0, count) has ray_cell(r, n) == it)?
@@ -990,6 +1107,7 @@ __device__ __forceinline__ bool on_ray(const Ray& r, int cx, int cy) {
 // halves per word: bit 15 = end-point flag, low 15 bits = free-add count, or the slot index when flagged).
 constexpr int kEvCap = 16;
 constexpr int kTileIntsPerBeam = 7 + kEvCap / 2;
+constexpr int kMapTilesMax = 64;  // map tiles a scan's bounding box can span: (ceil(175 / 32) + 1)^2 = 49 for tile_cap 30000
 // Packed ray for the counting pass.  Every ray is written in the form of the reference's plotLineLow / plotLineHigh
 // cases: a major axis, a start (xa, ya) at the low end of that axis, dmaj steps along it, and the minor offset
 // c_t of ray_cell.  The vertical / horizontal / diagonal cases fit the same form with dmin = 0 / 0 / dmaj
@@ -1018,10 +1136,16 @@ __device__ __forceinline__ int wave_max_i(int v) {
   for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
   return v;
 }
-__global__ __launch_bounds__(1024, 8) void rbpf_raycast_tile(ScanC c, const double2* __restrict__ beams,
-                                                          const double* __restrict__ pose, double* __restrict__ log_odds,
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__global__ __launch_bounds__(1024, 8) void rbpf_raycast_tile(ScanC c, TilePool P, MapT M, const double2* __restrict__ beams,
+                                                          const double* __restrict__ pose,
                                                           unsigned long long* __restrict__ bitmap, int* __restrict__ row_count,
-                                                          int* __restrict__ n_occ, int* __restrict__ err, int tile_cap) {
+                                                          int* __restrict__ n_occ, int* __restrict__ err, int tile_cap,
+                                                          unsigned long long* __restrict__ touched) {
   extern __shared__ __attribute__((aligned(16))) int lds_i[];
   const int Bv = c.Bv;
   int* ex = lds_i;
@@ -1034,12 +1158,13 @@ __global__ __launch_bounds__(1024, 8) void rbpf_raycast_tile(ScanC c, const doub
   unsigned short* ev = reinterpret_cast<unsigned short*>(ecnt + Bv);  // [n_own][kEvCap]  beam | 0x8000 if occupied
   unsigned int* tile = reinterpret_cast<unsigned int*>(lds_i + kTileIntsPerBeam * Bv);
   __shared__ int bad, bx0, bx1, by0, by1, n_own, srx, sry;
+  __shared__ unsigned int mt_id[kMapTilesMax];  // map tiles under the bounding box: 0 = not written by this scan, else the
+  //                                               particle's private tile id (phase C)
   const int p = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave, nw = blockDim.x / kWave;
   const int nthr = blockDim.x;
 #ifdef TBNAV_PHASE_PROF
   unsigned long long t_prev_ = wall_clock64();
 #endif
-  double* lo = log_odds + (size_t)p * c.g.xsize * c.g.ysize;
   unsigned long long* bm = bitmap + (size_t)p * c.g.xsize * c.g.words;
   int* rc = row_count + (size_t)p * c.g.xsize;
   int* nocc = n_occ + p;
@@ -1063,6 +1188,7 @@ __global__ __launch_bounds__(1024, 8) void rbpf_raycast_tile(ScanC c, const doub
   } else {
     for (int t = tid - kWave; t < (tile_cap + 1) / 2; t += nthr - kWave) tile[t] = 0u;
     for (int b = tid - kWave; b < Bv; b += nthr - kWave) ecnt[b] = 0;
+    for (int t = tid - kWave; t < kMapTilesMax; t += nthr - kWave) mt_id[t] = 0u;
   }
   __syncthreads();
   const int rx = srx, ry = sry;
@@ -1087,7 +1213,6 @@ __global__ __launch_bounds__(1024, 8) void rbpf_raycast_tile(ScanC c, const doub
   if (bad) { if (tid == 0) atomicOr(&err[0], 1); return; }
   const int minx = bx0, miny = by0, bw = by1 - by0 + 1, bh = bx1 - bx0 + 1, ncell = bw * bh;
   if (ncell > tile_cap) { if (tid == 0) atomicOr(&err[3], 2); return; }  // cannot happen for beams within range_max
-  const int xs = c.g.xsize;
   PHASE_STAMP(0);
   // F. flag the end-point cells; the beam that finds the flag clear opens the cell's slot
   for (int b = tid; b < Bv; b += nthr) {
@@ -1160,14 +1285,45 @@ __global__ __launch_bounds__(1024, 8) void rbpf_raycast_tile(ScanC c, const doub
   }
   __syncthreads();  // every event is recorded
   PHASE_STAMP(2);
+  // M. which map tiles does this scan write?  Every cell with a counter or a flag marks its tile (kTS x kTS cells of
+  //    the particle's tile table; the bounding box spans mtx x mty of them).
+  const int tx0 = minx >> kTSh, ty0 = miny >> kTSh, mty = (by1 >> kTSh) - ty0 + 1, mtn = ((bx1 >> kTSh) - tx0 + 1) * mty;
+  if (mtn > kMapTilesMax) { if (tid == 0) atomicOr(&err[3], 2); return; }  // cannot happen: tile_cap bounds the box
+  {
+    const int step_r = floor_div_small(nthr, bw), step_c = nthr - step_r * bw;
+    int trow = floor_div_small(tid < ncell ? tid : 0, bw), tcol = (tid < ncell ? tid : 0) - trow * bw;
+    for (int t = tid; t < ncell; t += nthr) {
+      if ((tile[t >> 1] >> ((t & 1) * 16)) & 0xFFFFu) mt_id[(((minx + trow) >> kTSh) - tx0) * mty + (((miny + tcol) >> kTSh) - ty0)] = 1u;
+      trow += step_r; tcol += step_c;
+      if (tcol >= bw) { tcol -= bw; ++trow; }
+    }
+  }
+  __syncthreads();
+  // C. make those tiles private to the particle (first write after a resample, or first touch of the area): one wave
+  //    per tile; a tile the particle already owns alone costs two loads
+  {
+    unsigned int* tab = M.table + (size_t)p * M.TT;
+    unsigned int* shed = M.shed + (size_t)p * M.TT;
+    for (int q = wid; q < mtn; q += nw) {
+      if (mt_id[q] == 0u) continue;
+      const int qi = floor_div_small(q, mty), qj = q - qi * mty;
+      const unsigned int id = tile_make_private(P, tab, shed, (tx0 + qi) * M.TW + (ty0 + qj), lane);
+      if (lane == 0) { mt_id[q] = id; if (id == 0u) bad = 1; }
+    }
+  }
+  __syncthreads();
+  if (bad) { if (tid == 0) atomicOr(&err[3], 8); return; }  // tile pool exhausted: nothing has been written
+  auto cell_ptr = [&](int cx, int cy) -> double* {
+    return P.lo + (size_t)mt_id[((cx >> kTSh) - tx0) * mty + ((cy >> kTSh) - ty0)] * kTileCells + in_tile(cx, cy);
+  };
   // 2a. end-point cells whose slot holds every event: one lane each, events applied in beam order
   const int n_cells = n_own;
   for (int o = tid; o < n_cells; o += nthr) {
     const int ne = ecnt[o];
     if (ne > kEvCap) continue;
     const int cx = ex[own[o]], cy = ey[own[o]];
-    const size_t idx = (size_t)cx * xs + cy;
-    const double v0 = lo[idx];
+    double* const cellp = cell_ptr(cx, cy);
+    const double v0 = *cellp;
     double v = v0;
     int last = -1;
     for (int i = 0; i < ne; ++i) {  // selection by ascending beam (ne is a handful)
@@ -1179,7 +1335,7 @@ __global__ __launch_bounds__(1024, 8) void rbpf_raycast_tile(ScanC c, const doub
       v += (best_ev & 0x8000) ? c.d_occ : c.d_free;
       last = best_key;
     }
-    lo[idx] = v;
+    *cellp = v;
     const bool was = v0 >= c.cut_occ, now = v >= c.cut_occ;
     if (was != now) {
       atomicXor(&bm[(size_t)cx * c.g.words + (cy >> 6)], 1ull << (cy & 63));
@@ -1196,8 +1352,8 @@ __global__ __launch_bounds__(1024, 8) void rbpf_raycast_tile(ScanC c, const doub
   for (int o = wid; o < n_cells; o += nw) {
     if (ecnt[o] <= kEvCap) continue;
     const int cx = ex[own[o]], cy = ey[own[o]];
-    const size_t idx = (size_t)cx * xs + cy;
-    const double v0 = lo[idx];
+    double* const cellp = cell_ptr(cx, cy);
+    const double v0 = *cellp;
     double v = v0;
     const int ux = cx - rx, uy = cy - ry;
     for (int i = 0; i < trips; ++i) {
@@ -1221,7 +1377,7 @@ __global__ __launch_bounds__(1024, 8) void rbpf_raycast_tile(ScanC c, const doub
       }
     }
     if (lane == 0) {
-      lo[idx] = v;
+      *cellp = v;
       const bool was = v0 >= c.cut_occ, now = v >= c.cut_occ;
       if (was != now) {
         atomicXor(&bm[(size_t)cx * c.g.words + (cy >> 6)], 1ull << (cy & 63));
@@ -1236,9 +1392,10 @@ __global__ __launch_bounds__(1024, 8) void rbpf_raycast_tile(ScanC c, const doub
   //    together instead of one exposed HBM round trip per cell.
   constexpr int kPer = 8;
   const int step_r = floor_div_small(nthr, bw), step_c = nthr - step_r * bw;  // cell t + nthr in (row, col) terms
+  int n_distinct = 0;
   for (int base = 0; base < ncell; base += nthr * kPer) {
     int cn[kPer];
-    size_t idx[kPer];
+    double* idx[kPer];
     double v0[kPer];
     const int t0 = base + tid;
     int trow = floor_div_small(t0 < ncell ? t0 : 0, bw), tcol = (t0 < ncell ? t0 : 0) - trow * bw;  // t < 2^15, bw < 2^8
@@ -1246,25 +1403,26 @@ __global__ __launch_bounds__(1024, 8) void rbpf_raycast_tile(ScanC c, const doub
     for (int q = 0; q < kPer; ++q) {
       const int t = t0 + q * nthr;
       cn[q] = 0;
-      idx[q] = 0;
+      idx[q] = nullptr;
       if (t < ncell) {
         const unsigned int hlf = (tile[t >> 1] >> ((t & 1) * 16)) & 0xFFFFu;
         if (!(hlf & 0x8000u)) cn[q] = (int)hlf;
-        idx[q] = (size_t)(minx + trow) * xs + (miny + tcol);
+        if (cn[q]) idx[q] = cell_ptr(minx + trow, miny + tcol);
       }
       trow += step_r; tcol += step_c;
       if (tcol >= bw) { tcol -= bw; ++trow; }
     }
 #pragma unroll
-    for (int q = 0; q < kPer; ++q) v0[q] = cn[q] ? lo[idx[q]] : 0.0;
+    for (int q = 0; q < kPer; ++q) v0[q] = cn[q] ? *idx[q] : 0.0;
 #pragma unroll
     for (int q = 0; q < kPer; ++q) {
       if (!cn[q]) continue;
+      ++n_distinct;
       double v = v0[q];
       int a = 0;
       for (; a + 4 <= cn[q]; a += 4) { v += c.d_free; v += c.d_free; v += c.d_free; v += c.d_free; }
       for (; a < cn[q]; ++a) v += c.d_free;
-      lo[idx[q]] = v;
+      *idx[q] = v;
       const bool was = v0[q] >= c.cut_occ, now = v >= c.cut_occ;
       if (was != now) {
         const int t = t0 + q * nthr, tr = floor_div_small(t, bw), cx = minx + tr, cy = miny + (t - tr * bw);
@@ -1273,6 +1431,12 @@ __global__ __launch_bounds__(1024, 8) void rbpf_raycast_tile(ScanC c, const doub
         atomicAdd(nocc, now ? 1 : -1);
       }
     }
+  }
+  if (touched) {  // measurement hook (tbnav_rbpf_scan_counts): [0] += cell updates (free adds + end points), [1] += distinct cells written
+    int n_upd = 0;
+    for (int b = tid; b < Bv; b += nthr) n_upd += (rk[b] >> 8) + 1;
+    n_upd = wave_sum_i(n_upd); n_distinct = wave_sum_i(n_distinct);
+    if (lane == 0) { atomicAdd(&touched[0], (unsigned long long)n_upd); atomicAdd(&touched[1], (unsigned long long)(n_distinct + (wid == 0 ? n_cells : 0))); }
   }
   PHASE_STAMP(4);
 #ifdef TBNAV_PHASE_PROF
@@ -1286,19 +1450,19 @@ __global__ __launch_bounds__(1024, 8) void rbpf_raycast_tile(ScanC c, const doub
 
 // ---- occupancy bitmap ------------------------------------------------------------------------------
 // grid (rows/4, N), 256 threads: one wave per map row; lanes read the row coalesced.
-__global__ __launch_bounds__(256) void rbpf_occupancy(GridC g, double cut_occ, int p0, const double* __restrict__ log_odds,
+__global__ __launch_bounds__(256) void rbpf_occupancy(GridC g, double cut_occ, int p0, TilePool P, MapT M,
                                                       unsigned long long* __restrict__ bitmap, int* __restrict__ row_count,
                                                       int* __restrict__ n_occ) {
   const int p = p0 + blockIdx.y;
   const int row = blockIdx.x * 4 + threadIdx.x / kWave;
   const int lane = threadIdx.x & (kWave - 1);
   if (row >= g.xsize) return;
-  const double* lo = log_odds + ((size_t)p * g.xsize + row) * g.ysize;
+  const unsigned int* tab = M.table + (size_t)p * M.TT;
   unsigned long long* bm = bitmap + ((size_t)p * g.xsize + row) * g.words;
   int cnt = 0;
   for (int w = 0; w < g.words; ++w) {
     const int j = w * 64 + lane;
-    const bool occ = (j < g.ysize) && (lo[j] >= cut_occ);
+    const bool occ = (j < g.ysize) && (P.lo[(size_t)tab[tile_of(M, row, j)] * kTileCells + in_tile(row, j)] >= cut_occ);
     const unsigned long long m = __ballot(occ);
     if (lane == 0) bm[w] = m;
     cnt += __popcll(m);
@@ -1558,14 +1722,14 @@ struct NormOut { double sum_w, sq_sum; int neff, resampled; };
 // divisions, and the selection itself — with the sequential prefix c[] in hand, slot m's parent is the
 // first i with U_m <= c[i] (the reference's while-loop, particle_filter.cpp:485-493, advances to exactly
 // that i because U_m and c[] are both non-decreasing), found by binary search, clamped to N-1.
-// buf: dynamic LDS, 2*N doubles (w then c).  N <= kNormMaxLds, else the global-memory variant below.
-constexpr int kNormMaxLds = 9000;
-// Left-to-right sum (of squares) of an LDS array by ONE thread — the reference's order (particle_filter.cpp:
-// 446-450, 458-461), which Neff and the resampling decision depend on.  The chain of adds is inherent; the loads are
-// not part of it: the next eight values are fetched while the current eight are added.
+// Any N: the weights pass through LDS in chunks of kNormChunk (parallel loads / divisions, the one lane carries its
+// running sums from chunk to chunk); the prefix c[] lives in LDS when one chunk holds it, else in a global scratch.
+constexpr int kNormChunk = 2048;
+// Left-to-right sum (of squares) of an LDS array by ONE thread, continuing from `acc` — the reference's order
+// (particle_filter.cpp:446-450, 458-461), which Neff and the resampling decision depend on.  The chain of adds is
+// inherent; the loads are not part of it: the next eight values are fetched while the current eight are added.
 template <bool SQ>
-__device__ __forceinline__ double seq_sum(const double* w, int N) {
-  double acc = 0.0;
+__device__ __forceinline__ double seq_sum(double acc, const double* w, int N) {
   int i = 0;
   if (N >= 8) {
     double a[8], b[8];
@@ -1586,98 +1750,196 @@ __device__ __forceinline__ double seq_sum(const double* w, int N) {
   for (; i < N; ++i) acc += SQ ? w[i] * w[i] : w[i];
   return acc;
 }
-__global__ __launch_bounds__(256) void rbpf_normalize(int N, const double* __restrict__ zp, double* __restrict__ weight, int* __restrict__ parent,
-                                                      NormOut* __restrict__ out) {
+// weight_out: where the normalised weights go ([N]; may alias weight).  cs: [N] scratch for the prefix (N > kNormChunk).
+__global__ __launch_bounds__(256) void rbpf_normalize(int N, const double* __restrict__ zp, const double* weight, double* weight_out,
+                                                      double* __restrict__ cs, int* __restrict__ parent, NormOut* __restrict__ out) {
   const double z = *zp;  // the one standard normal of lowVarianceResampling (particle_filter.cpp:474)
-  extern __shared__ __attribute__((aligned(16))) double buf[];
-  double* w = buf;
-  double* cs = buf + N;
-  __shared__ double s_sum;
+  __shared__ double w[kNormChunk], cl[kNormChunk];
+  __shared__ double s_acc;
   __shared__ int s_res;
-  for (int i = threadIdx.x; i < N; i += blockDim.x) w[i] = weight[i];
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  if (tid == 0) s_acc = 0.0;
+  for (int base = 0; base < N; base += kNormChunk) {
+    const int n = min(kNormChunk, N - base);
+    __syncthreads();
+    for (int i = tid; i < n; i += nthr) w[i] = weight[base + i];
+    __syncthreads();
+    if (tid == 0) s_acc = seq_sum<false>(s_acc, w, n);
+  }
   __syncthreads();
-  if (threadIdx.x == 0) s_sum = seq_sum<false>(w, N);
+  const double sum = s_acc;
   __syncthreads();
-  const double sum = s_sum;
-  for (int i = threadIdx.x; i < N; i += blockDim.x) { const double v = w[i] / sum; w[i] = v; weight[i] = v; }
+  if (tid == 0) s_acc = 0.0;
+  for (int base = 0; base < N; base += kNormChunk) {
+    const int n = min(kNormChunk, N - base);
+    __syncthreads();
+    for (int i = tid; i < n; i += nthr) { const double v = weight[base + i] / sum; w[i] = v; weight_out[base + i] = v; }
+    __syncthreads();
+    if (tid == 0) s_acc = seq_sum<true>(s_acc, w, n);
+  }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const double sq = seq_sum<true>(w, N);
+  if (tid == 0) {
+    const double sq = s_acc;
     const int neff = (int)(1.0 / sq);
     const int res = (neff < (N / 2)) ? 1 : 0;
     out->sum_w = sum; out->sq_sum = sq; out->neff = neff; out->resampled = res;
     s_res = res;
-    if (res) {
-      double c = w[0];
-      cs[0] = c;
-      for (int i = 1; i < N; ++i) { c += w[i]; cs[i] = c; }  // c += weight(i), particle_filter.cpp:492
-    }
+    s_acc = 0.0;
   }
   __syncthreads();
-  if (!s_res) { for (int m = threadIdx.x; m < N; m += blockDim.x) parent[m] = m; return; }
+  if (!s_res) { for (int m = tid; m < N; m += nthr) parent[m] = m; return; }
+  const bool one_chunk = N <= kNormChunk;
+  for (int base = 0; base < N; base += kNormChunk) {
+    const int n = min(kNormChunk, N - base);
+    __syncthreads();
+    if (!one_chunk) for (int i = tid; i < n; i += nthr) w[i] = weight_out[base + i];  // (one chunk: w[] still holds them)
+    __syncthreads();
+    if (tid == 0) {
+      double c = s_acc;
+      for (int i = 0; i < n; ++i) { c += w[i]; cl[i] = c; }  // c = weight(0); c += weight(i), particle_filter.cpp:478,492
+      s_acc = c;
+    }
+    __syncthreads();
+    if (!one_chunk) for (int i = tid; i < n; i += nthr) cs[base + i] = cl[i];
+  }
+  __syncthreads();
+  const double* csr = one_chunk ? cl : cs;
   const double r = z / (double)N;
-  for (int m = threadIdx.x; m < N; m += blockDim.x) {
+  for (int m = tid; m < N; m += nthr) {
     const double U = r + (double)(m * (1.0 / (N - 1)));
     int lo = 0, hi = N - 1;  // first index with U <= cs[i]; N-1 if none (the reference clamps there)
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
-      if (U > cs[mid]) lo = mid + 1; else hi = mid;
+      if (U > csr[mid]) lo = mid + 1; else hi = mid;
     }
     parent[m] = lo;
   }
 }
 
-// Same contract, weights read from global memory (N too large for LDS): fully sequential.
-__global__ void rbpf_normalize_seq(int N, const double* __restrict__ zp, double* __restrict__ weight, int* __restrict__ parent, NormOut* __restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const double z = *zp;
-  double sum = 0.0;
-  for (int i = 0; i < N; ++i) sum += weight[i];
-  double sq = 0.0;
-  for (int i = 0; i < N; ++i) { const double w = weight[i] / sum; weight[i] = w; sq += w * w; }
-  const int neff = (int)(1.0 / sq);
-  const int res = (neff < (N / 2)) ? 1 : 0;
-  out->sum_w = sum; out->sq_sum = sq; out->neff = neff; out->resampled = res;
-  if (!res) { for (int m = 0; m < N; ++m) parent[m] = m; return; }
-  const double r = z / (double)N;
-  double cacc = weight[0];
-  int i = 0;
-  for (int m = 0; m < N; ++m) {
-    const double U = r + (double)(m * (1.0 / (N - 1)));
-    while (U > cacc) {
-      i++;
-      if (i > N - 1) { i = N - 1; break; }
-      cacc += weight[i];
+// free ring = every tile but tile 0 (the shared zero tile, pinned)
+__global__ void rbpf_pool_init(TilePool P) {
+  for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i + 1 < P.cap; i += gridDim.x * blockDim.x) P.ring[i] = i + 1;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { P.ctr[0] = 0ull; P.ctr[1] = (unsigned long long)P.cap - 1ull; P.ref[0] = 1 << 30; }
+}
+
+// ---- resampling: slot m <- parent[m] (particle_filter.cpp:495 deep copies) -----------------------------------
+// Maps: the new slot takes a COPY OF ITS PARENT'S TILE TABLE and every named tile gains a reference (pass 1); then the
+// old generation's references — table entries and the shed notes of tiles left since the last resample — are
+// dropped and tiles nobody names any more go back to the free ring (pass 2, a separate launch: no count may reach
+// zero before every new reference is in).  16 KB of table per particle at 2000 x 2000 instead of a 32 MB map.
+__global__ __launch_bounds__(256) void rbpf_resample_tables(int N, int TT, const int* __restrict__ parent, const unsigned int* __restrict__ tab_old,
+                                                            unsigned int* __restrict__ tab_new, int* __restrict__ ref) {
+  const size_t n = (size_t)N * TT;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const int m = (int)(e / TT), t = (int)(e - (size_t)m * TT);
+    const unsigned int id = tab_old[(size_t)parent[m] * TT + t];
+    tab_new[e] = id;
+    if (id) atomicAdd(&ref[id], 1);
+  }
+}
+__global__ __launch_bounds__(256) void rbpf_release_tables(int N, int TT, const unsigned int* __restrict__ tab_old, unsigned int* __restrict__ shed,
+                                                           TilePool P) {
+  const size_t n = (size_t)N * TT;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const unsigned int id = tab_old[e], sh = shed[e];
+    if (id && atomicSub(&P.ref[id], 1) == 1) tile_push(P, id);
+    if (sh) { if (atomicSub(&P.ref[sh], 1) == 1) tile_push(P, sh); shed[e] = 0u; }
+  }
+}
+// Everything else a particle owns: pose / prev_pose / weight (weights are NOT reset, :495), the occupancy bitmap with
+// its row counts, the state of its stored distance field and — only where that field is authoritative (injected or
+// materialised, state 2; always in the stored-field modes) — the field itself.  grid (N, chunks).
+__global__ __launch_bounds__(256) void rbpf_gather(int N, size_t G, int words_total, int xsize, const int* __restrict__ parent,
+                                                   const double* __restrict__ st_src, double* __restrict__ st_dst,
+                                                   const unsigned long long* __restrict__ bm_src, unsigned long long* __restrict__ bm_dst,
+                                                   const int* __restrict__ rc_src, int* __restrict__ rc_dst,
+                                                   const int* __restrict__ nocc_src, int* __restrict__ nocc_dst,
+                                                   const int* __restrict__ fs_src, int* __restrict__ fs_dst,
+                                                   const uint16_t* __restrict__ cd_src, uint16_t* __restrict__ cd_dst, int copy_all_codes) {
+  const int m = blockIdx.x;
+  const int src = parent[m];
+  const size_t t0 = (size_t)blockIdx.y * blockDim.x + threadIdx.x, stride = (size_t)gridDim.y * blockDim.x;
+  const size_t nb = (size_t)words_total;  // bitmap words per particle
+  for (size_t t = t0; t < nb; t += stride) bm_dst[(size_t)m * nb + t] = bm_src[(size_t)src * nb + t];
+  for (size_t t = t0; t < (size_t)xsize; t += stride) rc_dst[(size_t)m * xsize + t] = rc_src[(size_t)src * xsize + t];
+  const int fs = fs_src[src];
+  if (cd_src && (copy_all_codes || fs == 2)) {
+    const uint2* ca = reinterpret_cast<const uint2*>(cd_src + (size_t)src * G);
+    uint2* cb = reinterpret_cast<uint2*>(cd_dst + (size_t)m * G);
+    for (size_t t = t0; t < G / 4; t += stride) cb[t] = ca[t];
+  }
+  if (t0 == 0) {
+    nocc_dst[m] = nocc_src[src];
+    fs_dst[m] = fs;
+    for (int q = 0; q < 3; ++q) {
+      st_dst[(size_t)m * 3 + q] = st_src[(size_t)src * 3 + q];
+      st_dst[(size_t)3 * N + (size_t)m * 3 + q] = st_src[(size_t)3 * N + (size_t)src * 3 + q];
     }
-    parent[m] = i;
+    st_dst[(size_t)6 * N + m] = st_src[(size_t)6 * N + src];
   }
 }
 
-// grid (chunks, N): slot m <- parent[m] for maps and state (particle_filter.cpp:495 deep copy)
-__global__ __launch_bounds__(256) void rbpf_gather(int N, size_t G, int words_total, const int* __restrict__ parent,
-                                                   const double* __restrict__ lo_src, double* __restrict__ lo_dst,
-                                                   const uint16_t* __restrict__ cd_src, uint16_t* __restrict__ cd_dst,
-                                                   const unsigned long long* __restrict__ bm_src, unsigned long long* __restrict__ bm_dst,
-                                                   const int* __restrict__ rc_src, int* __restrict__ rc_dst, int xsize,
-                                                   const int* __restrict__ nocc_src, int* __restrict__ nocc_dst) {
-  const int m = blockIdx.y;
-  const int src = parent[m];
-  if (src < 0) return;
-  const double2* a = reinterpret_cast<const double2*>(lo_src + (size_t)src * G);
-  double2* b = reinterpret_cast<double2*>(lo_dst + (size_t)m * G);
-  const size_t n2 = G / 2;
-  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n2; t += (size_t)gridDim.x * blockDim.x) b[t] = a[t];
-  const uint2* ca = reinterpret_cast<const uint2*>(cd_src + (size_t)src * G);
-  uint2* cb = reinterpret_cast<uint2*>(cd_dst + (size_t)m * G);
-  const size_t n4 = G / 4;
-  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += (size_t)gridDim.x * blockDim.x) cb[t] = ca[t];
-  const size_t nb = (size_t)words_total;  // bitmap words per particle
-  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < nb; t += (size_t)gridDim.x * blockDim.x)
-    bm_dst[(size_t)m * nb + t] = bm_src[(size_t)src * nb + t];
-  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < (size_t)xsize; t += (size_t)gridDim.x * blockDim.x)
-    rc_dst[(size_t)m * xsize + t] = rc_src[(size_t)src * xsize + t];
-  if (blockIdx.x == 0 && threadIdx.x == 0) nocc_dst[m] = nocc_src[src];  // pose/weight are gathered by the host side
-  (void)N;
+// ---- dense views of one particle's tiled log-odds (tbnav_rbpf_get/set_log_odds, parity hooks) ------------------
+__global__ __launch_bounds__(256) void rbpf_tiles_to_dense(int xs, size_t G, TilePool P, MapT M, int p, double* __restrict__ out) {
+  const unsigned int* tab = M.table + (size_t)p * M.TT;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < G; i += (size_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i / xs), cj = (int)(i - (size_t)ci * xs);
+    out[i] = P.lo[(size_t)tab[tile_of(M, ci, cj)] * kTileCells + in_tile(ci, cj)];
+  }
+}
+// grid = TT workgroups of one wave: tile t of particle p takes the values of `in`; a tile that is all zero in `in`
+// and still the shared zero tile stays shared.
+__global__ __launch_bounds__(kWave) void rbpf_dense_to_tiles(int xs, TilePool P, MapT M, int p, const double* __restrict__ in, int* __restrict__ err) {
+  const int t = blockIdx.x, lane = threadIdx.x, ti = t / M.TW, tj = t - ti * M.TW;
+  unsigned int* tab = M.table + (size_t)p * M.TT;
+  unsigned int* shed = M.shed + (size_t)p * M.TT;
+  bool nz = false;
+  for (int q = lane; q < kTileCells; q += kWave) {
+    const int ci = ti * kTS + (q >> kTSh), cj = tj * kTS + (q & (kTS - 1));
+    if (ci < xs && cj < xs && in[(size_t)ci * xs + cj] != 0.0) nz = true;
+  }
+  if (__ballot(nz) == 0ull && tab[t] == 0u) return;
+  const unsigned int id = tile_make_private(P, tab, shed, t, lane);
+  if (id == 0u) { if (lane == 0) atomicOr(&err[3], 8); return; }
+  for (int q = lane; q < kTileCells; q += kWave) {
+    const int ci = ti * kTS + (q >> kTSh), cj = tj * kTS + (q & (kTS - 1));
+    P.lo[(size_t)id * kTileCells + q] = (ci < xs && cj < xs) ? in[(size_t)ci * xs + cj] : 0.0;
+  }
+}
+// Drop every tile reference of slot p (table and shed) and leave it with the empty map: the slot is about to receive
+// an imported particle (tbnav_rbpf_import_particle_dev).
+__global__ __launch_bounds__(256) void rbpf_release_slot(TilePool P, MapT M, int p) {
+  unsigned int* tab = M.table + (size_t)p * M.TT;
+  unsigned int* shed = M.shed + (size_t)p * M.TT;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < M.TT; t += gridDim.x * blockDim.x) {
+    const unsigned int id = tab[t], sh = shed[t];
+    if (id && atomicSub(&P.ref[id], 1) == 1) tile_push(P, id);
+    if (sh && atomicSub(&P.ref[sh], 1) == 1) tile_push(P, sh);
+    tab[t] = 0u; shed[t] = 0u;
+  }
+}
+
+// ---- particle migration between handles (sharded filter): a particle travels as its state, its
+//      occupancy bitmap and ONLY the tiles it does not share with the zero tile ------------------------------------
+__global__ __launch_bounds__(256) void rbpf_pack_tiles(TilePool P, const unsigned int* __restrict__ ids, double* __restrict__ out) {
+  const double2* src = reinterpret_cast<const double2*>(P.lo + (size_t)ids[blockIdx.x] * kTileCells);
+  double2* dst = reinterpret_cast<double2*>(out + (size_t)blockIdx.x * kTileCells);
+  for (int i = threadIdx.x; i < kTileCells / 2; i += blockDim.x) dst[i] = src[i];
+}
+// one workgroup per received tile: take a free tile, name it in the (released) slot's table, fill it
+__global__ __launch_bounds__(256) void rbpf_unpack_tiles(TilePool P, MapT M, int p, const unsigned int* __restrict__ tidx,
+                                                         const double* __restrict__ in, int* __restrict__ err) {
+  __shared__ unsigned int sid;
+  if (threadIdx.x == 0) {
+    const unsigned int id = tile_pop(P);
+    if (id) { P.ref[id] = 1; M.table[(size_t)p * M.TT + tidx[blockIdx.x]] = id; } else atomicOr(&err[3], 8);
+    sid = id;
+  }
+  __syncthreads();
+  if (sid == 0u) return;
+  const double2* src = reinterpret_cast<const double2*>(in + (size_t)blockIdx.x * kTileCells);
+  double2* dst = reinterpret_cast<double2*>(P.lo + (size_t)sid * kTileCells);
+  for (int i = threadIdx.x; i < kTileCells / 2; i += blockDim.x) dst[i] = src[i];
 }
 
 // ---- getRobotState / newMap on the device ------------------------------------------
@@ -1721,10 +1983,11 @@ struct ExportCuts {
   int n_steps;
 };
 __global__ __launch_bounds__(256) void rbpf_export_map(int xs, size_t G, ExportCuts cuts, const int* __restrict__ best_idx,
-                                                       const double* __restrict__ log_odds, int8_t* __restrict__ out) {
-  const double* lo = log_odds + (size_t)(*best_idx) * G;
+                                                       TilePool P, MapT M, int8_t* __restrict__ out) {
+  const unsigned int* tab = M.table + (size_t)(*best_idx) * M.TT;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < G; i += (size_t)gridDim.x * blockDim.x) {
-    const double l = lo[i];
+    const int ci = (int)(i / xs), cj = (int)(i - (size_t)ci * xs);
+    const double l = P.lo[(size_t)tab[tile_of(M, ci, cj)] * kTileCells + in_tile(ci, cj)];
     int v;
     if (l >= cuts.half_lo && l <= cuts.half_hi) v = -1;
     else if (l >= cuts.occ_cut) v = 100;
@@ -1751,7 +2014,20 @@ struct tbnav_rbpf {
   double l_prior = 0, l_occ = 0, l_free = 0, cut_occ = 0, max_occ_dist = 10.0;
   // particle state: [N][7] = pose(3), prev_pose(3), weight — double-buffered with the maps
   double* d_state[2] = {nullptr, nullptr};
-  double* d_log_odds[2] = {nullptr, nullptr};
+  // log-odds: tiled, copy-on-write (see TilePool).  The tables are double-buffered with the rest of the particle state.
+  TilePool pool{};
+  unsigned int* d_table[2] = {nullptr, nullptr};  // [N][TT]
+  unsigned int* d_shed = nullptr;                 // [N][TT]
+  int TW = 0, TT = 0;
+  double* d_dense = nullptr;   // [G] staging of one particle's dense log-odds (get/set_log_odds), allocated on first use
+  double* d_cs = nullptr;      // [N] prefix scratch of the normalise kernel (N > kNormChunk)
+  unsigned int* d_tile_scratch = nullptr;  // [TT] tile ids of a particle being exported
+  // sharded filter: normalise / select over the all-gathered weights (tbnav_rbpf_resample_global_dev)
+  double* d_gw = nullptr; double* d_gcs = nullptr; int* d_gparent = nullptr; double* d_gz = nullptr; size_t g_cap = 0;
+  unsigned long long* d_touched = nullptr;  // [2] measurement hook: cell updates / distinct cells written (tbnav_rbpf_scan_counts)
+  bool count_touched = false;
+  // stored distance field, u16 [N][G] x 2: allocated on first need (injection, materialisation, the stored-field
+  // modes); the default query mode never touches it.  NULL until then.
   uint16_t* d_code[2] = {nullptr, nullptr};
   int* d_nocc[2] = {nullptr, nullptr};
   int cur = 0;
@@ -1777,6 +2053,15 @@ struct tbnav_rbpf {
   bool full_edt = false;       // distance-field mode 0 (TBNAV_RBPF_DF=full): whole-map transform after every map update
   int df_mode = 2;             // 0 full, 1 windowed refresh before the update (TBNAV_RBPF_DF=window), 2 exact query at lookup (default)
   int* d_fstate = nullptr;     // [N] distance-field state: 0 stale, 1 window fresh, 2 whole field fresh / injected
+  int* d_fstate_alt = nullptr; // [N] the other buffer of the resample gather
+  // reference distance-field mode (tbnav_rbpf_set_option DF_MODE = REFERENCE): host-side brushfire state + the
+  // device log of occupied-set changes it is fed from
+  bool ref_field = false;
+  tbnav::RefField* ref = nullptr;
+  int* d_log_ev = nullptr;     // [N][log_cap]
+  int* d_log_cnt = nullptr;    // [N]
+  int log_cap = 0;
+  uint64_t scans_done = 0;
   int* d_skip = nullptr;       // [N] scratch: 1 = no refresh needed this call
   int4* d_win = nullptr;       // [N] refreshed window (i0, i1, j0, j1), inclusive
   int* d_tier = nullptr;       // [N] which distance-field kernel handles the particle this scan
@@ -1813,6 +2098,20 @@ struct DeviceGuard {
 // so the 7-double record is split into three arrays inside one allocation.
 struct StatePtrs { double *pose, *prev, *weight; };
 StatePtrs state_ptrs(double* base, int N) { return {base, base + (size_t)3 * N, base + (size_t)6 * N}; }
+MapT map_of(const tbnav_rbpf* h) { return MapT{h->d_table[h->cur], h->d_shed, h->TW, h->TT}; }
+
+// The stored u16 distance field exists only once something needs it: 2 * N * G * 2 bytes (double-buffered like the
+// rest of the particle state).  Refused beyond 32 GB — BASELINE configs[4]-sized handles run in query mode only.
+int ensure_codes(tbnav_rbpf* h) {
+  if (h->d_code[0]) return TBNAV_OK;
+  const size_t bytes = sizeof(uint16_t) * h->G * (size_t)h->N;
+  if (2 * bytes > ((size_t)32 << 30) || h->N > 65535) return TBNAV_ERR_UNSUPPORTED;
+  for (int b = 0; b < 2; ++b) {
+    TBNAV_HIP(hipMalloc((void**)&h->d_code[b], bytes));
+    TBNAV_HIP(hipMemset(h->d_code[b], 0xFF, bytes));  // occ_dist = max_occ_dist_ (grid_mapper.cpp:49,58)
+  }
+  return TBNAV_OK;
+}
 
 double logodds_to_prob(double l) { return 1 - (1 / (1 + std::exp(l))); }  // grid_mapper.hpp:27-30 (glibc on the host)
 
@@ -1904,6 +2203,7 @@ int status_from_err(const int err[4]) {
   if (err[0]) return TBNAV_ERR_OUT_OF_WORLD;
   if (err[2]) return TBNAV_ERR_PDF_VARIANCE;
   if (err[1]) return TBNAV_ERR_ETA_ZERO;
+  if (err[3] & 8) return TBNAV_ERR_POOL_EXHAUSTED;  // no free log-odds tile left (the scan of that particle was not applied)
   if (err[3] & 4) return TBNAV_ERR_UNSUPPORTED;  // a likelihood lookup left the particle's refreshed window (cannot happen: see rbpf_window)
   if (err[3]) return TBNAV_ERR_BRESENHAM;
   return TBNAV_OK;
@@ -1938,6 +2238,7 @@ GridC grid_of(const tbnav_rbpf* h) {
 
 // Whole-field refresh of ONE particle, on demand (state 2 afterwards).
 int ensure_full_field(tbnav_rbpf* h, int particle) {
+  { const int rc = ensure_codes(h); if (rc != TBNAV_OK) return rc; }
   hipStream_t st = h->stream;
   int stt = 0;
   TBNAV_HIP(hipStreamSynchronize(st));
@@ -1965,12 +2266,84 @@ int ensure_full_field(tbnav_rbpf* h, int particle) {
   return TBNAV_OK;
 }
 
+// lowVarianceResampling's copies on the device: d_parent holds the parent of every slot.  Tables and counts first
+// (two launches, see rbpf_resample_tables), then bitmaps / state / field state into the alternate buffers.
+int resample_on_device(tbnav_rbpf* h) {
+  const int N = h->N, nxt = 1 - h->cur;
+  hipStream_t st = h->stream;
+  const size_t n = (size_t)N * h->TT;
+  const int blocks = (int)std::min<size_t>((n + 255) / 256, 16384);
+  hipLaunchKernelGGL(rbpf_resample_tables, dim3(blocks), dim3(256), 0, st, N, h->TT, h->d_parent, h->d_table[h->cur], h->d_table[nxt], h->pool.ref);
+  TBNAV_HIP(hipGetLastError());
+  hipLaunchKernelGGL(rbpf_release_tables, dim3(blocks), dim3(256), 0, st, N, h->TT, h->d_table[h->cur], h->d_shed, h->pool);
+  TBNAV_HIP(hipGetLastError());
+  const size_t nb = (size_t)h->xsize * h->words;
+  const size_t work = std::max(nb, h->d_code[0] ? h->G / 4 : (size_t)0);
+  const int chunks = (int)std::min<size_t>(std::max<size_t>(work / 2048, 1), 64);
+  hipLaunchKernelGGL(rbpf_gather, dim3(N, chunks), dim3(256), 0, st, N, h->G, (int)nb, h->xsize, h->d_parent, h->d_state[h->cur], h->d_state[nxt],
+                     h->d_bitmap[h->cur], h->d_bitmap[nxt], h->d_rowcount[h->cur], h->d_rowcount[nxt], h->d_nocc[h->cur], h->d_nocc[nxt],
+                     h->d_fstate, h->d_fstate_alt, h->d_code[h->cur], h->d_code[nxt], h->df_mode != 2 ? 1 : 0);
+  TBNAV_HIP(hipGetLastError());
+  std::swap(h->d_fstate, h->d_fstate_alt);
+  h->cur = nxt;
+  return TBNAV_OK;
+}
+
+// ---- reference distance-field mode (ref_field.hpp) ------------------------------------------------------------
+// Before the raycast: a log big enough for every cell update of the scan (a cell can enter and leave the occupied set
+// more than once in one scan).
+int ref_field_prepare_log(tbnav_rbpf* h, int Bv, OccLog& log) {
+  const double reach = (double)h->p.range_max + std::hypot(h->p.Trs[1], h->p.Trs[2]);
+  const long per_ray = (long)std::ceil(reach / h->p.resolution) + 4;
+  const long cap = (long)std::max(Bv, 1) * per_ray;
+  if ((size_t)cap * h->N * sizeof(int) > ((size_t)1 << 30)) return TBNAV_ERR_UNSUPPORTED;
+  if (cap > h->log_cap) {
+    (void)hipFree(h->d_log_ev); h->d_log_ev = nullptr; h->log_cap = 0;
+    TBNAV_HIP(hipMalloc((void**)&h->d_log_ev, sizeof(int) * (size_t)cap * h->N));
+    h->log_cap = (int)cap;
+  }
+  if (!h->d_log_cnt) TBNAV_HIP(hipMalloc((void**)&h->d_log_cnt, sizeof(int) * h->N));
+  TBNAV_HIP(hipMemsetAsync(h->d_log_cnt, 0, sizeof(int) * h->N, h->stream));
+  log = OccLog{h->d_log_ev, h->d_log_cnt, h->log_cap};
+  return TBNAV_OK;
+}
+// After the scan (and its resample, if one fired): replay the logged set changes, run the reference's brushfire for
+// every particle as it was BEFORE the resample (the reference integrates the scan in the particle loop and resamples
+// afterwards, particle_filter.cpp:158-249), copy like the resample did, and make the result the authoritative field.
+int ref_field_after_scan(tbnav_rbpf* h, bool resampled) {
+  const int N = h->N;
+  { const int rc = ensure_codes(h); if (rc != TBNAV_OK) return rc; }
+  TBNAV_HIP(hipStreamSynchronize(h->stream));
+  std::vector<int> cnt(N);
+  TBNAV_HIP(hipMemcpy(cnt.data(), h->d_log_cnt, sizeof(int) * N, hipMemcpyDeviceToHost));
+  std::vector<int> ev;
+  for (int p = 0; p < N; ++p) {
+    if (cnt[p] > h->log_cap) return TBNAV_ERR_UNSUPPORTED;  // cannot happen: the log holds every cell update
+    ev.resize(cnt[p]);
+    if (cnt[p]) TBNAV_HIP(hipMemcpy(ev.data(), h->d_log_ev + (size_t)p * h->log_cap, sizeof(int) * cnt[p], hipMemcpyDeviceToHost));
+    h->ref->apply(p, ev.data(), cnt[p]);
+    h->ref->brushfire(p);
+  }
+  if (resampled) {
+    h->h_parent.resize(N);
+    TBNAV_HIP(hipMemcpy(h->h_parent.data(), h->d_parent, sizeof(int) * N, hipMemcpyDeviceToHost));
+    h->ref->resample(h->h_parent.data());
+  }
+  for (int p = 0; p < N; ++p)
+    TBNAV_HIP(hipMemcpy(h->d_code[h->cur] + (size_t)p * h->G, h->ref->codes(p), sizeof(uint16_t) * h->G, hipMemcpyHostToDevice));
+  TBNAV_HIP(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(h->d_fstate), 2, N));
+  h->fstate_dirty = true;
+  return TBNAV_OK;
+}
+
 int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], const double cur_odom[3],
               const double prev_odom[3], int icp_ok, const double T_icp[3], const double* normals,
               tbnav_rbpf_stats* out, bool local_only) {
   if (!h || !scan || n_beams <= 0 || !u || !cur_odom || !prev_odom || !T_icp || !out) return TBNAV_ERR_INVALID_ARG;
+  if (h->ref_field && local_only) return TBNAV_ERR_UNSUPPORTED;  // the reference-field mode is a single-handle mode
   DeviceGuard guard(h->device);
   hipStream_t st = h->stream;
+  ++h->scans_done;
   ScanC c;
   std::vector<double2> beams;
   int rc = build_scan_consts(h, c, scan, n_beams, u, cur_odom, prev_odom, icp_ok, T_icp, beams);
@@ -2073,10 +2446,7 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
   // event timing on, everything stays on one stream so that the intervals mean what they say.
   auto launch_normalize = [&](hipStream_t s2) -> int {
     const double* z = h->d_normals + (size_t)h->N * c.stride_normals;
-    if (h->N <= kNormMaxLds)
-      hipLaunchKernelGGL(rbpf_normalize, dim3(1), dim3(256), sizeof(double) * 2 * h->N, s2, h->N, z, sp.weight, h->d_parent, h->d_norm);
-    else
-      hipLaunchKernelGGL(rbpf_normalize_seq, dim3(1), dim3(64), 0, s2, h->N, z, sp.weight, h->d_parent, h->d_norm);
+    hipLaunchKernelGGL(rbpf_normalize, dim3(1), dim3(256), 0, s2, h->N, z, sp.weight, sp.weight, h->d_cs, h->d_parent, h->d_norm);
     TBNAV_HIP(hipGetLastError());
     return TBNAV_OK;
   };
@@ -2091,12 +2461,22 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
   {
     const int bvn = c.Bv > 0 ? c.Bv : 1;
     const size_t tile_lds = sizeof(int) * kTileIntsPerBeam * bvn + sizeof(unsigned int) * ((size_t)(h->tile_cap + 1) / 2);
-    if (h->tile_cap > 0 && c.Bv < 32768 && tile_lds <= (size_t)kMaxLds - 1024)
-      hipLaunchKernelGGL(rbpf_raycast_tile, dim3(h->N), dim3(h->raycast_threads), tile_lds, st, c, h->d_beams, sp.pose, h->d_log_odds[h->cur],
-                         h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_nocc[h->cur], h->d_err, h->tile_cap);
-    else
-      hipLaunchKernelGGL(rbpf_raycast, dim3(h->N), dim3(kWave), sizeof(int) * 2 * bvn, st, c, h->d_beams, sp.pose,
-                         h->d_log_odds[h->cur], h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_nocc[h->cur], h->d_err);
+    const MapT M = map_of(h);
+    if (h->tile_cap > 0 && !h->ref_field && c.Bv < 32768 && tile_lds <= (size_t)kMaxLds - 1024)
+      hipLaunchKernelGGL(rbpf_raycast_tile, dim3(h->N), dim3(h->raycast_threads), tile_lds, st, c, h->pool, M, h->d_beams, sp.pose,
+                         h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_nocc[h->cur], h->d_err, h->tile_cap,
+                         h->count_touched ? h->d_touched : nullptr);
+    else {
+      // beam-ordered kernel: scans the LDS tile cannot hold, and the reference distance-field mode (it logs the
+      // occupied-set changes in the reference's order)
+      OccLog log{nullptr, nullptr, 0};
+      if (h->ref_field) {
+        const int rc2 = ref_field_prepare_log(h, c.Bv, log);
+        if (rc2 != TBNAV_OK) return rc2;
+      }
+      hipLaunchKernelGGL(rbpf_raycast, dim3(h->N), dim3(kWave), sizeof(int) * (2 * bvn + (h->TT + 31) / 32), st, c, h->pool, M, h->d_beams,
+                         sp.pose, h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_nocc[h->cur], h->d_err, log);
+    }
   }
   TBNAV_HIP(hipGetLastError());
   if (h->timing) TBNAV_HIP(hipEventRecord(h->ev[3], st));
@@ -2130,12 +2510,10 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
   out->sum_w = no.sum_w; out->sq_sum = no.sq_sum; out->neff = no.neff; out->resampled = no.resampled;
   bool gathered = false;
   if (!local_only && no.resampled && out->status == TBNAV_OK) {
-    const int nxt = 1 - h->cur;
+    // lowVarianceResampling's deep copies (particle_filter.cpp:495): tables, bitmaps and state move on the device
     if (h->timing) TBNAV_HIP(hipEventRecord(h->ev[6], st));
-    hipLaunchKernelGGL(rbpf_gather, dim3(16, h->N), dim3(256), 0, st, h->N, h->G, h->xsize * h->words, h->d_parent, h->d_log_odds[h->cur],
-                       h->d_log_odds[nxt], h->d_code[h->cur], h->d_code[nxt], h->d_bitmap[h->cur], h->d_bitmap[nxt],
-                       h->d_rowcount[h->cur], h->d_rowcount[nxt], h->xsize, h->d_nocc[h->cur], h->d_nocc[nxt]);
-    TBNAV_HIP(hipGetLastError());
+    rc = resample_on_device(h);
+    if (rc != TBNAV_OK) return rc;
     if (h->timing) TBNAV_HIP(hipEventRecord(h->ev[7], st));
     gathered = true;
   }
@@ -2155,20 +2533,9 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
     h->last_ms[4] = e45;        // normalise / select
     if (gathered) TBNAV_HIP(hipEventElapsedTime(&h->last_ms[5], h->ev[6], h->ev[7]));
   }
-  if (gathered) {
-    // particle state is tiny: gather it on the host side of the boundary (pose, prev_pose, weight)
-    const int N = h->N, nxt = 1 - h->cur;
-    std::vector<double> s((size_t)7 * N), d((size_t)7 * N);
-    h->h_parent.resize(N);
-    TBNAV_HIP(hipMemcpy(s.data(), h->d_state[h->cur], sizeof(double) * 7 * N, hipMemcpyDeviceToHost));
-    TBNAV_HIP(hipMemcpy(h->h_parent.data(), h->d_parent, sizeof(int) * N, hipMemcpyDeviceToHost));
-    for (int m = 0; m < N; ++m) {
-      const int src = h->h_parent[m];
-      for (int q = 0; q < 3; ++q) { d[(size_t)m * 3 + q] = s[(size_t)src * 3 + q]; d[(size_t)3 * N + m * 3 + q] = s[(size_t)3 * N + src * 3 + q]; }
-      d[(size_t)6 * N + m] = s[(size_t)6 * N + src];  // weights are NOT reset (particle_filter.cpp:495)
-    }
-    TBNAV_HIP(hipMemcpy(h->d_state[nxt], d.data(), sizeof(double) * 7 * N, hipMemcpyHostToDevice));
-    h->cur = nxt;
+  if (h->ref_field && out->status == TBNAV_OK) {
+    rc = ref_field_after_scan(h, gathered);
+    if (rc != TBNAV_OK) return rc;
   }
   return out->status;
 }
@@ -2177,7 +2544,8 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
 
 extern "C" {
 
-int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) {
+namespace {
+int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf** out) {
   if (!P || !out) return TBNAV_ERR_INVALID_ARG;
   *out = nullptr;
   if (P->num_particles <= 0 || P->num_samples_mode <= 0 || !(P->resolution > 0.0) || !(P->xmax > P->xmin) || !(P->ymax > P->ymin))
@@ -2185,8 +2553,8 @@ int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) {
   const int xsize = (int)static_cast<unsigned int>(std::ceil((P->xmax - P->xmin) / P->resolution));  // mapSize, grid_mapper.cpp:31-34
   const int ysize = (int)static_cast<unsigned int>(std::ceil((P->ymax - P->ymin) / P->resolution));
   if (xsize != ysize) return TBNAV_ERR_UNSUPPORTED;  // the reference indexes both axes with xsize_ (grid_mapper.cpp:195-197,896)
-  if (xsize < 4 || xsize > 32000 || (xsize & 1)) return TBNAV_ERR_UNSUPPORTED;  // vectorised map copies need G % 4 == 0
-  if (P->num_particles > 65535) return TBNAV_ERR_UNSUPPORTED;                  // particle index rides in gridDim.y
+  if (xsize < 4 || xsize > 32000 || (xsize & 1)) return TBNAV_ERR_UNSUPPORTED;  // vectorised code copies need G % 4 == 0
+  if (P->num_particles > (1 << 20)) return TBNAV_ERR_UNSUPPORTED;
   const int radius = (int)static_cast<unsigned int>(std::ceil((10.0 - 0.0) / P->resolution));         // cell_radius_, grid_mapper.cpp:50
   if (radius > 254) return TBNAV_ERR_UNSUPPORTED;  // row-pass distances are stored as u8 (and radius^2 must fit the u16 code)
   const int words = (ysize + 63) / 64;
@@ -2212,23 +2580,14 @@ int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) {
   h->p = *P; h->device = dev; h->N = P->num_particles; h->k = P->num_samples_mode;
   h->xsize = xsize; h->ysize = ysize; h->words = words; h->radius = radius; h->edt_cols = C;
   h->G = (size_t)xsize * ysize;
+  h->TW = (xsize + kTS - 1) / kTS; h->TT = h->TW * h->TW;
   {
     // every beam shorter than range_max ends within this many cells of the robot cell (+2 for the laser offset / rounding)
     const double reach = (double)P->range_max + std::sqrt(P->Trs[1] * P->Trs[1] + P->Trs[2] * P->Trs[2]);
     const long side = 2 * ((long)std::ceil(reach / P->resolution) + 2) + 1;
     h->tile_cap = (side * side <= 30000) ? (int)(side * side) : 0;
-    if (const char* e = std::getenv("TBNAV_RBPF_RAYCAST_ORDERED")) if (std::atoi(e) == 1) h->tile_cap = 0;
-    if (const char* e = std::getenv("TBNAV_RBPF_RAYCAST_THREADS")) {
-      const int t = std::atoi(e);
-      if (t == 256 || t == 512 || t == 1024) h->raycast_threads = t;
-    }
-    if (const char* e = std::getenv("TBNAV_RBPF_FULL_EDT")) if (std::atoi(e) == 1) h->df_mode = 0;
-    if (const char* e = std::getenv("TBNAV_RBPF_DF")) {
-      const std::string v(e);
-      h->df_mode = (v == "full") ? 0 : (v == "window") ? 1 : 2;
-    }
-    if (h->edt_cols == 0) h->df_mode = 2;  // no LDS transform for this map size: query mode only
-    h->full_edt = h->df_mode == 0;
+    h->df_mode = 2;  // exact query at lookup; the other modes are selected with tbnav_rbpf_set_option
+    h->full_edt = false;
   }
   // log-odds constants with the host libm, exactly as the reference's ctor (grid_mapper.cpp:42-47)
   h->l_prior = std::log(0.5 / (1 - 0.5));
@@ -2239,19 +2598,24 @@ int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) {
   const int N = h->N;
   hipError_t e = hipSuccess;
   auto A = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
+  const size_t table_entries = (size_t)N * h->TT;
   for (int b = 0; b < 2; ++b) {
     A((void**)&h->d_state[b], sizeof(double) * 7 * N);
-    A((void**)&h->d_log_odds[b], sizeof(double) * h->G * N);
-    A((void**)&h->d_code[b], sizeof(uint16_t) * h->G * N);
+    A((void**)&h->d_table[b], sizeof(unsigned int) * table_entries);
     A((void**)&h->d_nocc[b], sizeof(int) * N);
     A((void**)&h->d_bitmap[b], sizeof(unsigned long long) * (size_t)N * xsize * words);
     A((void**)&h->d_rowcount[b], sizeof(int) * (size_t)N * xsize);
   }
+  A((void**)&h->d_shed, sizeof(unsigned int) * table_entries);
+  A((void**)&h->d_cs, sizeof(double) * N);
+  A((void**)&h->d_tile_scratch, sizeof(unsigned int) * h->TT);
+  A((void**)&h->d_touched, sizeof(unsigned long long) * 2);
   A((void**)&h->d_parent, sizeof(int) * N);
   A((void**)&h->d_best, sizeof(int));
   A((void**)&h->d_best_pose, sizeof(double) * 3);
   A((void**)&h->d_export, h->G);
   A((void**)&h->d_fstate, sizeof(int) * N);
+  A((void**)&h->d_fstate_alt, sizeof(int) * N);
   A((void**)&h->d_center, sizeof(double) * 3 * N);
   A((void**)&h->d_score, sizeof(double) * N);
   A((void**)&h->d_skip, sizeof(int) * N);
@@ -2269,6 +2633,25 @@ int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) {
   A((void**)&h->d_trace, sizeof(double) * trace_doubles);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   for (auto& ev : h->ev) if (e == hipSuccess) e = hipEventCreate(&ev);
+  // ---- the tile pool: everything the particles' maps can ever need if that fits the budget, else the budget.
+  //      Default budget: half of the memory that is free now (several handles can live side by side).
+  if (e == hipSuccess) {
+    size_t free_b = 0, total_b = 0;
+    e = hipMemGetInfo(&free_b, &total_b);
+    const size_t per_tile = sizeof(double) * kTileCells + sizeof(int) + sizeof(unsigned int);
+    const size_t budget = max_pool_bytes ? (size_t)max_pool_bytes : free_b / 2;
+    // worst case: every table entry its own tile, plus the tiles the entries left since the last resample (still named by
+    // the shed notes until the next resample settles them), plus the zero tile
+    size_t cap = 2 * table_entries + 1;
+    if (cap * per_tile > budget) cap = budget / per_tile;
+    if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
+    if (cap < (size_t)N + 2 && e == hipSuccess) e = hipErrorOutOfMemory;  // not even one tile per particle
+    h->pool.cap = (unsigned int)cap;
+    A((void**)&h->pool.lo, sizeof(double) * kTileCells * cap);
+    A((void**)&h->pool.ref, sizeof(int) * cap);
+    A((void**)&h->pool.ring, sizeof(unsigned int) * cap);
+    A((void**)&h->pool.ctr, sizeof(unsigned long long) * 2);
+  }
   if (e == hipSuccess) {
     double* t = h->d_trace;
     h->tr.sampled = t; t += (size_t)N * kk * 3;
@@ -2288,14 +2671,22 @@ int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) {
       s[(size_t)6 * N + i] = 1.0 / N;
     }
     e = hipMemcpy(h->d_state[0], s.data(), sizeof(double) * 7 * N, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(h->d_log_odds[0], 0, sizeof(double) * h->G * N);  // log_odds_prior_ = log(1) = 0
-    if (e == hipSuccess) e = hipMemset(h->d_code[0], 0xFF, sizeof(uint16_t) * h->G * N);  // occ_dist = max_occ_dist_
+    // empty maps: every table entry names the shared zero tile (log_odds_prior_ = log(1) = 0)
+    if (e == hipSuccess) e = hipMemset(h->d_table[0], 0, sizeof(unsigned int) * table_entries);
+    if (e == hipSuccess) e = hipMemset(h->d_shed, 0, sizeof(unsigned int) * table_entries);
+    if (e == hipSuccess) e = hipMemset(h->pool.lo, 0, sizeof(double) * kTileCells);  // tile 0
+    if (e == hipSuccess) e = hipMemset(h->pool.ref, 0, sizeof(int) * h->pool.cap);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(rbpf_pool_init, dim3(1024), dim3(256), 0, h->stream, h->pool);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemset(h->d_touched, 0, sizeof(unsigned long long) * 2);
     if (e == hipSuccess) e = hipMemset(h->d_nocc[0], 0, sizeof(int) * N);
     if (e == hipSuccess) e = hipMemset(h->d_skip, 0, sizeof(int) * N);
-    if (e == hipSuccess) {  // empty maps: the initial field (everything unreached) IS the whole, fresh field
-      std::vector<int> two(N, 2);
-      e = hipMemcpy(h->d_fstate, two.data(), sizeof(int) * N, hipMemcpyHostToDevice);
-    }
+    // empty maps: the field "everything unreached" is what any lookup computes, no stored field needed (state 0)
+    if (e == hipSuccess) e = hipMemset(h->d_fstate, 0, sizeof(int) * N);
+    if (e == hipSuccess) e = hipMemset(h->d_fstate_alt, 0, sizeof(int) * N);
+    h->fstate_dirty = false;
     if (e == hipSuccess) {
       std::vector<int4> w(N, make_int4(0, xsize - 1, 0, ysize - 1));
       e = hipMemcpy(h->d_win, w.data(), sizeof(int4) * N, hipMemcpyHostToDevice);
@@ -2309,6 +2700,7 @@ int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) {
                   : hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_edt<32>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_tile), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 1024);
   // the proposal / scan-match kernels carry the scan, the per-sample data and the bitmap slice: more than the 64 KB
   // default for long scans or many samples
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_propose), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 1024);
@@ -2317,8 +2709,6 @@ int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) {
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)edt_compact_lds(kEdtRowsA));
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_edt_compact<kEdtRowsB>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)edt_compact_lds(kEdtRowsB));
-  if (e == hipSuccess && N <= kNormMaxLds)
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_normalize), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 2 * N));
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) {
     const int rc = tbnav::hip_fail(e, "tbnav_rbpf_create allocation", __FILE__, __LINE__);
@@ -2326,6 +2716,22 @@ int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) {
     return rc;
   }
   *out = h;
+  return TBNAV_OK;
+}
+}  // namespace
+
+int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) { return create_impl(P, 0, out); }
+int tbnav_rbpf_create_pool(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf** out) { return create_impl(P, max_pool_bytes, out); }
+
+int tbnav_rbpf_pool_stats(tbnav_rbpf* h, uint64_t* capacity_tiles, uint64_t* free_tiles, uint64_t* tile_bytes) {
+  if (!h) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  TBNAV_HIP(hipStreamSynchronize(h->stream));
+  unsigned long long ctr[2] = {0, 0};
+  TBNAV_HIP(hipMemcpy(ctr, h->pool.ctr, sizeof ctr, hipMemcpyDeviceToHost));
+  if (capacity_tiles) *capacity_tiles = h->pool.cap - 1;  // tile 0 is the shared zero tile
+  if (free_tiles) *free_tiles = ctr[1] - ctr[0];
+  if (tile_bytes) *tile_bytes = sizeof(double) * kTileCells;
   return TBNAV_OK;
 }
 
@@ -2346,7 +2752,11 @@ void tbnav_rbpf_destroy(tbnav_rbpf* h) {
 #endif
   if (!h) return;
   DeviceGuard guard(h->device);
-  for (int b = 0; b < 2; ++b) { (void)hipFree(h->d_state[b]); (void)hipFree(h->d_log_odds[b]); (void)hipFree(h->d_code[b]); (void)hipFree(h->d_nocc[b]); (void)hipFree(h->d_bitmap[b]); (void)hipFree(h->d_rowcount[b]); }
+  for (int b = 0; b < 2; ++b) { (void)hipFree(h->d_state[b]); (void)hipFree(h->d_table[b]); (void)hipFree(h->d_code[b]); (void)hipFree(h->d_nocc[b]); (void)hipFree(h->d_bitmap[b]); (void)hipFree(h->d_rowcount[b]); }
+  (void)hipFree(h->pool.lo); (void)hipFree(h->pool.ref); (void)hipFree(h->pool.ring); (void)hipFree(h->pool.ctr);
+  (void)hipFree(h->d_shed); (void)hipFree(h->d_dense); (void)hipFree(h->d_cs); (void)hipFree(h->d_touched); (void)hipFree(h->d_fstate_alt);
+  (void)hipFree(h->d_log_ev); (void)hipFree(h->d_log_cnt); (void)hipFree(h->d_tile_scratch);
+  (void)hipFree(h->d_gw); (void)hipFree(h->d_gcs); (void)hipFree(h->d_gparent); (void)hipFree(h->d_gz);
   (void)hipFree(h->d_beams); (void)hipFree(h->d_normals); (void)hipFree(h->d_parent); (void)hipFree(h->d_best); (void)hipFree(h->d_best_pose); (void)hipFree(h->d_export); (void)hipFree(h->d_tier); (void)hipFree(h->d_fstate); (void)hipFree(h->d_skip); (void)hipFree(h->d_win); (void)hipFree(h->d_center); (void)hipFree(h->d_score);
   (void)hipFree(h->d_trace);
   (void)hipHostFree(h->h_beams); (void)hipHostFree(h->h_err); (void)hipHostFree(h->h_norm);
@@ -2355,6 +2765,7 @@ void tbnav_rbpf_destroy(tbnav_rbpf* h) {
   if (h->stream2) (void)hipStreamDestroy(h->stream2);
   for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
   if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h->ref;
   delete h;
 }
 
@@ -2427,28 +2838,181 @@ int tbnav_rbpf_resample_global(const double* w, int64_t n, double z, int32_t* pa
 
 int tbnav_rbpf_gather_local(tbnav_rbpf* h, const int32_t* local_parent) {
   if (!h || !local_parent) return TBNAV_ERR_INVALID_ARG;
+  if (h->ref_field) return TBNAV_ERR_UNSUPPORTED;  // the reference-field mode is a single-handle mode
   DeviceGuard guard(h->device);
-  const int N = h->N, nxt = 1 - h->cur;
-  hipStream_t st = h->stream;
-  TBNAV_HIP(hipMemcpyAsync(h->d_parent, local_parent, sizeof(int) * N, hipMemcpyHostToDevice, st));
+  const int N = h->N;
   // slots with parent -1 keep their own content: copy self
   std::vector<int> par(local_parent, local_parent + N);
-  for (int m = 0; m < N; ++m) if (par[m] < 0) par[m] = m;
-  TBNAV_HIP(hipMemcpyAsync(h->d_parent, par.data(), sizeof(int) * N, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(rbpf_gather, dim3(16, N), dim3(256), 0, st, N, h->G, h->xsize * h->words, h->d_parent, h->d_log_odds[h->cur],
-                     h->d_log_odds[nxt], h->d_code[h->cur], h->d_code[nxt], h->d_bitmap[h->cur], h->d_bitmap[nxt],
-                       h->d_rowcount[h->cur], h->d_rowcount[nxt], h->xsize, h->d_nocc[h->cur], h->d_nocc[nxt]);
-  TBNAV_HIP(hipGetLastError());
-  TBNAV_HIP(hipStreamSynchronize(st));
-  std::vector<double> s((size_t)7 * N), d((size_t)7 * N);
-  TBNAV_HIP(hipMemcpy(s.data(), h->d_state[h->cur], sizeof(double) * 7 * N, hipMemcpyDeviceToHost));
-  for (int m = 0; m < N; ++m) {
-    const int src = par[m];
-    for (int q = 0; q < 3; ++q) { d[(size_t)m * 3 + q] = s[(size_t)src * 3 + q]; d[(size_t)3 * N + m * 3 + q] = s[(size_t)3 * N + src * 3 + q]; }
-    d[(size_t)6 * N + m] = s[(size_t)6 * N + src];
+  for (int m = 0; m < N; ++m) { if (par[m] < 0) par[m] = m; if (par[m] >= N) return TBNAV_ERR_INVALID_ARG; }
+  TBNAV_HIP(hipMemcpyAsync(h->d_parent, par.data(), sizeof(int) * N, hipMemcpyHostToDevice, h->stream));
+  TBNAV_HIP(hipStreamSynchronize(h->stream));  // par is a local
+  const int rc = resample_on_device(h);
+  if (rc != TBNAV_OK) return rc;
+  TBNAV_HIP(hipStreamSynchronize(h->stream));
+  return TBNAV_OK;
+}
+
+// ---- device-side exchange for the sharded filter -------------------------------------------------------------
+int tbnav_rbpf_copy_weights_dev(tbnav_rbpf* h, double* d_dst) {
+  if (!h || !d_dst) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
+  TBNAV_HIP(hipMemcpyAsync(d_dst, sp.weight, sizeof(double) * h->N, hipMemcpyDeviceToDevice, h->stream));
+  TBNAV_HIP(hipStreamSynchronize(h->stream));
+  return TBNAV_OK;
+}
+
+int tbnav_rbpf_resample_global_dev(tbnav_rbpf* h, const double* d_weights_all, int64_t n_global, int64_t offset, double z,
+                                   int32_t* parents_out, tbnav_rbpf_stats* out) {
+  if (!h || !d_weights_all || n_global <= 0 || offset < 0 || offset + h->N > n_global || !out || n_global > (1 << 24)) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  hipStream_t st = h->stream;
+  if ((size_t)n_global > h->g_cap) {
+    (void)hipFree(h->d_gw); (void)hipFree(h->d_gcs); (void)hipFree(h->d_gparent); h->d_gw = h->d_gcs = nullptr; h->d_gparent = nullptr; h->g_cap = 0;
+    TBNAV_HIP(hipMalloc((void**)&h->d_gw, sizeof(double) * n_global));
+    TBNAV_HIP(hipMalloc((void**)&h->d_gcs, sizeof(double) * n_global));
+    TBNAV_HIP(hipMalloc((void**)&h->d_gparent, sizeof(int) * n_global));
+    h->g_cap = (size_t)n_global;
   }
-  TBNAV_HIP(hipMemcpy(h->d_state[nxt], d.data(), sizeof(double) * 7 * N, hipMemcpyHostToDevice));
-  h->cur = nxt;
+  if (!h->d_gz) TBNAV_HIP(hipMalloc((void**)&h->d_gz, sizeof(double)));
+  TBNAV_HIP(hipMemcpyAsync(h->d_gz, &z, sizeof z, hipMemcpyHostToDevice, st));
+  *h->h_norm = NormOut{};
+  // the reference's sequential normalise / Neff / selection (particle_filter.cpp:442-500) over the GLOBAL vector:
+  // every rank runs the same kernel on the same values, so all ranks agree bit for bit
+  hipLaunchKernelGGL(rbpf_normalize, dim3(1), dim3(256), 0, st, (int)n_global, h->d_gz, d_weights_all, h->d_gw, h->d_gcs, h->d_gparent, h->d_norm);
+  TBNAV_HIP(hipGetLastError());
+  StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
+  TBNAV_HIP(hipMemcpyAsync(sp.weight, h->d_gw + offset, sizeof(double) * h->N, hipMemcpyDeviceToDevice, st));
+  TBNAV_HIP(hipStreamSynchronize(st));
+  const NormOut no = *h->h_norm;
+  std::memset(out, 0, sizeof *out);
+  out->sum_w = no.sum_w; out->sq_sum = no.sq_sum; out->neff = no.neff; out->resampled = no.resampled;
+  if (no.resampled && parents_out) TBNAV_HIP(hipMemcpy(parents_out, h->d_gparent, sizeof(int) * n_global, hipMemcpyDeviceToHost));
+  return TBNAV_OK;
+}
+
+int tbnav_rbpf_set_weights_from_global_dev(tbnav_rbpf* h, const int32_t* global_parent_of_slot /*[N]*/) {
+  // after a resample every slot carries its parent's normalised weight (weights are NOT reset, particle_filter.cpp:495)
+  if (!h || !global_parent_of_slot || !h->d_gw) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
+  for (int m = 0; m < h->N; ++m) {
+    if (global_parent_of_slot[m] < 0 || (size_t)global_parent_of_slot[m] >= h->g_cap) return TBNAV_ERR_INVALID_ARG;
+    TBNAV_HIP(hipMemcpyAsync(sp.weight + m, h->d_gw + global_parent_of_slot[m], sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  }
+  TBNAV_HIP(hipStreamSynchronize(h->stream));
+  return TBNAV_OK;
+}
+
+namespace {
+struct BlobHeader { uint64_t magic; uint32_t n_tiles, has_codes; int32_t nocc, fstate; uint32_t xsize, TT; };
+constexpr uint64_t kBlobMagic = 0x54424e4156504631ull;  // "TBNAVPF1"
+struct BlobLayout { size_t state, tidx, tiles, bitmap, rowcount, codes, total; };
+BlobLayout blob_layout(const tbnav_rbpf* h, uint32_t n_tiles, bool has_codes) {
+  auto up8 = [](size_t v) { return (v + 7) & ~(size_t)7; };
+  BlobLayout L{};
+  size_t o = sizeof(BlobHeader);
+  L.state = o; o += sizeof(double) * 7;
+  L.tidx = o; o = up8(o + sizeof(uint32_t) * n_tiles);
+  L.tiles = o; o += sizeof(double) * kTileCells * n_tiles;
+  L.bitmap = o; o += sizeof(unsigned long long) * (size_t)h->xsize * h->words;
+  L.rowcount = o; o = up8(o + sizeof(int) * h->xsize);
+  L.codes = o; if (has_codes) o = up8(o + sizeof(uint16_t) * h->G);
+  L.total = o;
+  return L;
+}
+int slot_tiles(tbnav_rbpf* h, int slot, std::vector<uint32_t>& tidx, std::vector<uint32_t>& ids, int& fstate) {
+  std::vector<uint32_t> row(h->TT);
+  TBNAV_HIP(hipStreamSynchronize(h->stream));
+  TBNAV_HIP(hipMemcpy(row.data(), h->d_table[h->cur] + (size_t)slot * h->TT, sizeof(uint32_t) * h->TT, hipMemcpyDeviceToHost));
+  TBNAV_HIP(hipMemcpy(&fstate, h->d_fstate + slot, sizeof(int), hipMemcpyDeviceToHost));
+  tidx.clear(); ids.clear();
+  for (int t = 0; t < h->TT; ++t) if (row[t]) { tidx.push_back((uint32_t)t); ids.push_back(row[t]); }
+  return TBNAV_OK;
+}
+}  // namespace
+
+int tbnav_rbpf_export_size(tbnav_rbpf* h, int32_t slot, uint64_t* bytes) {
+  if (!h || !bytes || slot < 0 || slot >= h->N) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  std::vector<uint32_t> tidx, ids; int fs = 0;
+  { const int rc = slot_tiles(h, slot, tidx, ids, fs); if (rc != TBNAV_OK) return rc; }
+  *bytes = blob_layout(h, (uint32_t)tidx.size(), fs == 2 && h->d_code[0]).total;
+  return TBNAV_OK;
+}
+
+int tbnav_rbpf_export_particle_dev(tbnav_rbpf* h, int32_t slot, void* d_buf, uint64_t capacity, uint64_t* bytes) {
+  if (!h || !d_buf || slot < 0 || slot >= h->N) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  hipStream_t st = h->stream;
+  std::vector<uint32_t> tidx, ids; int fs = 0;
+  { const int rc = slot_tiles(h, slot, tidx, ids, fs); if (rc != TBNAV_OK) return rc; }
+  const bool has_codes = fs == 2 && h->d_code[0];
+  const uint32_t n = (uint32_t)tidx.size();
+  const BlobLayout L = blob_layout(h, n, has_codes);
+  if (bytes) *bytes = L.total;
+  if (L.total > capacity) return TBNAV_ERR_INVALID_ARG;
+  char* b = static_cast<char*>(d_buf);
+  BlobHeader hd{kBlobMagic, n, has_codes ? 1u : 0u, 0, fs, (uint32_t)h->xsize, (uint32_t)h->TT};
+  TBNAV_HIP(hipMemcpy(&hd.nocc, h->d_nocc[h->cur] + slot, sizeof(int), hipMemcpyDeviceToHost));
+  TBNAV_HIP(hipMemcpy(b, &hd, sizeof hd, hipMemcpyHostToDevice));
+  StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
+  double* bs = reinterpret_cast<double*>(b + L.state);
+  TBNAV_HIP(hipMemcpyAsync(bs, sp.pose + (size_t)slot * 3, sizeof(double) * 3, hipMemcpyDeviceToDevice, st));
+  TBNAV_HIP(hipMemcpyAsync(bs + 3, sp.prev + (size_t)slot * 3, sizeof(double) * 3, hipMemcpyDeviceToDevice, st));
+  TBNAV_HIP(hipMemcpyAsync(bs + 6, sp.weight + slot, sizeof(double), hipMemcpyDeviceToDevice, st));
+  if (n) {
+    TBNAV_HIP(hipMemcpy(b + L.tidx, tidx.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+    TBNAV_HIP(hipMemcpy(h->d_tile_scratch, ids.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(rbpf_pack_tiles, dim3(n), dim3(256), 0, st, h->pool, h->d_tile_scratch, reinterpret_cast<double*>(b + L.tiles));
+    TBNAV_HIP(hipGetLastError());
+  }
+  const size_t nb = (size_t)h->xsize * h->words;
+  TBNAV_HIP(hipMemcpyAsync(b + L.bitmap, h->d_bitmap[h->cur] + (size_t)slot * nb, sizeof(unsigned long long) * nb, hipMemcpyDeviceToDevice, st));
+  TBNAV_HIP(hipMemcpyAsync(b + L.rowcount, h->d_rowcount[h->cur] + (size_t)slot * h->xsize, sizeof(int) * h->xsize, hipMemcpyDeviceToDevice, st));
+  if (has_codes) TBNAV_HIP(hipMemcpyAsync(b + L.codes, h->d_code[h->cur] + (size_t)slot * h->G, sizeof(uint16_t) * h->G, hipMemcpyDeviceToDevice, st));
+  TBNAV_HIP(hipStreamSynchronize(st));
+  return TBNAV_OK;
+}
+
+int tbnav_rbpf_import_particle_dev(tbnav_rbpf* h, int32_t slot, const void* d_buf, uint64_t bytes) {
+  if (!h || !d_buf || slot < 0 || slot >= h->N || bytes < sizeof(BlobHeader)) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  hipStream_t st = h->stream;
+  const char* b = static_cast<const char*>(d_buf);
+  BlobHeader hd{};
+  TBNAV_HIP(hipStreamSynchronize(st));
+  TBNAV_HIP(hipMemcpy(&hd, b, sizeof hd, hipMemcpyDeviceToHost));
+  if (hd.magic != kBlobMagic || hd.xsize != (uint32_t)h->xsize || hd.TT != (uint32_t)h->TT || hd.n_tiles > (uint32_t)h->TT) return TBNAV_ERR_INVALID_ARG;
+  const BlobLayout L = blob_layout(h, hd.n_tiles, hd.has_codes != 0);
+  if (L.total > bytes) return TBNAV_ERR_INVALID_ARG;
+  if (hd.has_codes) { const int rc = ensure_codes(h); if (rc != TBNAV_OK) return rc; }
+  const MapT M = map_of(h);
+  for (int q = 0; q < 4; ++q) h->h_err[q] = 0;
+  hipLaunchKernelGGL(rbpf_release_slot, dim3((h->TT + 255) / 256), dim3(256), 0, st, h->pool, M, slot);
+  TBNAV_HIP(hipGetLastError());
+  if (hd.n_tiles) {
+    hipLaunchKernelGGL(rbpf_unpack_tiles, dim3(hd.n_tiles), dim3(256), 0, st, h->pool, M, slot, reinterpret_cast<const unsigned int*>(b + L.tidx),
+                       reinterpret_cast<const double*>(b + L.tiles), h->d_err);
+    TBNAV_HIP(hipGetLastError());
+  }
+  StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
+  const double* bs = reinterpret_cast<const double*>(b + L.state);
+  TBNAV_HIP(hipMemcpyAsync(sp.pose + (size_t)slot * 3, bs, sizeof(double) * 3, hipMemcpyDeviceToDevice, st));
+  TBNAV_HIP(hipMemcpyAsync(sp.prev + (size_t)slot * 3, bs + 3, sizeof(double) * 3, hipMemcpyDeviceToDevice, st));
+  TBNAV_HIP(hipMemcpyAsync(sp.weight + slot, bs + 6, sizeof(double), hipMemcpyDeviceToDevice, st));
+  const size_t nb = (size_t)h->xsize * h->words;
+  TBNAV_HIP(hipMemcpyAsync(h->d_bitmap[h->cur] + (size_t)slot * nb, b + L.bitmap, sizeof(unsigned long long) * nb, hipMemcpyDeviceToDevice, st));
+  TBNAV_HIP(hipMemcpyAsync(h->d_rowcount[h->cur] + (size_t)slot * h->xsize, b + L.rowcount, sizeof(int) * h->xsize, hipMemcpyDeviceToDevice, st));
+  TBNAV_HIP(hipMemcpyAsync(h->d_nocc[h->cur] + slot, &hd.nocc, sizeof(int), hipMemcpyHostToDevice, st));
+  const int fs = hd.has_codes ? 2 : 0;
+  if (hd.has_codes) {
+    TBNAV_HIP(hipMemcpyAsync(h->d_code[h->cur] + (size_t)slot * h->G, b + L.codes, sizeof(uint16_t) * h->G, hipMemcpyDeviceToDevice, st));
+    h->fstate_dirty = true;
+  }
+  TBNAV_HIP(hipMemcpyAsync(h->d_fstate + slot, &fs, sizeof(int), hipMemcpyHostToDevice, st));
+  TBNAV_HIP(hipStreamSynchronize(st));  // hd / fs are locals
+  if (h->h_err[3] & 8) return TBNAV_ERR_POOL_EXHAUSTED;
   return TBNAV_OK;
 }
 
@@ -2479,25 +3043,39 @@ int tbnav_rbpf_set_particles(tbnav_rbpf* h, const double* pose, const double* pr
 int tbnav_rbpf_get_log_odds(tbnav_rbpf* h, int32_t particle, double* out) {
   if (!h || !out || particle < 0 || particle >= h->N) return TBNAV_ERR_INVALID_ARG;
   DeviceGuard guard(h->device);
+  if (!h->d_dense) TBNAV_HIP(hipMalloc((void**)&h->d_dense, sizeof(double) * h->G));
+  const int blocks = (int)std::min<size_t>((h->G + 255) / 256, 4096);
+  hipLaunchKernelGGL(rbpf_tiles_to_dense, dim3(blocks), dim3(256), 0, h->stream, h->xsize, h->G, h->pool, map_of(h), particle, h->d_dense);
+  TBNAV_HIP(hipGetLastError());
+  TBNAV_HIP(hipMemcpyAsync(out, h->d_dense, sizeof(double) * h->G, hipMemcpyDeviceToHost, h->stream));
   TBNAV_HIP(hipStreamSynchronize(h->stream));
-  TBNAV_HIP(hipMemcpy(out, h->d_log_odds[h->cur] + (size_t)particle * h->G, sizeof(double) * h->G, hipMemcpyDeviceToHost));
   return TBNAV_OK;
 }
 
 int tbnav_rbpf_set_log_odds(tbnav_rbpf* h, int32_t particle, const double* in) {
   if (!h || !in || particle < 0 || particle >= h->N) return TBNAV_ERR_INVALID_ARG;
   DeviceGuard guard(h->device);
+  if (!h->d_dense) TBNAV_HIP(hipMalloc((void**)&h->d_dense, sizeof(double) * h->G));
   TBNAV_HIP(hipStreamSynchronize(h->stream));
-  TBNAV_HIP(hipMemcpy(h->d_log_odds[h->cur] + (size_t)particle * h->G, in, sizeof(double) * h->G, hipMemcpyHostToDevice));
+  TBNAV_HIP(hipMemcpy(h->d_dense, in, sizeof(double) * h->G, hipMemcpyHostToDevice));
+  for (int q = 0; q < 4; ++q) h->h_err[q] = 0;
+  hipLaunchKernelGGL(rbpf_dense_to_tiles, dim3(h->TT), dim3(kWave), 0, h->stream, h->xsize, h->pool, map_of(h), particle, h->d_dense, h->d_err);
+  TBNAV_HIP(hipGetLastError());
   // rebuild this particle's occupancy bitmap / row counts / occupied count from the new log-odds
   TBNAV_HIP(hipMemsetAsync(h->d_nocc[h->cur] + particle, 0, sizeof(int), h->stream));
-  const GridC g{h->p.xmin, h->p.xmax, h->p.ymin, h->p.ymax, h->p.resolution, h->xsize, h->ysize, h->words, h->max_occ_dist, 1.0 / h->p.resolution};
-  hipLaunchKernelGGL(rbpf_occupancy, dim3((h->xsize + 3) / 4, 1), dim3(256), 0, h->stream, g, h->cut_occ, particle,
-                     h->d_log_odds[h->cur], h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_nocc[h->cur]);
+  const GridC g = grid_of(h);
+  hipLaunchKernelGGL(rbpf_occupancy, dim3((h->xsize + 3) / 4, 1), dim3(256), 0, h->stream, g, h->cut_occ, particle, h->pool, map_of(h),
+                     h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_nocc[h->cur]);
   TBNAV_HIP(hipGetLastError());
   TBNAV_HIP(hipStreamSynchronize(h->stream));
+  if (h->h_err[3] & 8) return TBNAV_ERR_POOL_EXHAUSTED;
   const int zero = 0;  // the distance field no longer matches the map
   TBNAV_HIP(hipMemcpy(h->d_fstate + particle, &zero, sizeof zero, hipMemcpyHostToDevice));
+  if (h->ref_field) {  // the occupied set's history is unknown from here on: ascending order (documented in tbnav_rbpf.h)
+    std::vector<int> cells;
+    for (size_t c = 0; c < h->G; ++c) if (in[c] >= h->cut_occ) cells.push_back((int)c);
+    h->ref->reset(particle, cells);
+  }
   return TBNAV_OK;
 }
 
@@ -2533,7 +3111,9 @@ int tbnav_rbpf_set_occ_dist(tbnav_rbpf* h, int32_t particle, const double* in) {
     return TBNAV_ERR_INVALID_ARG;
   }
   DeviceGuard guard(h->device);
+  { const int rc = ensure_codes(h); if (rc != TBNAV_OK) return rc; }
   TBNAV_HIP(hipStreamSynchronize(h->stream));
+  if (h->ref_field) h->ref->set_codes(particle, code.data());
   TBNAV_HIP(hipMemcpy(h->d_code[h->cur] + (size_t)particle * h->G, code.data(), sizeof(uint16_t) * h->G, hipMemcpyHostToDevice));
   const int two = 2;  // an injected field is authoritative: the next call does not refresh it
   TBNAV_HIP(hipMemcpy(h->d_fstate + particle, &two, sizeof two, hipMemcpyHostToDevice));
@@ -2593,7 +3173,7 @@ int tbnav_rbpf_best_map(tbnav_rbpf* h, int8_t* map) {
   hipLaunchKernelGGL(rbpf_argmax, dim3(1), dim3(256), 0, st, h->N, sp.weight, sp.pose, h->d_best, h->d_best_pose);
   TBNAV_HIP(hipGetLastError());
   const int blocks = (int)std::min<size_t>((h->G + 255) / 256, 2048);
-  hipLaunchKernelGGL(rbpf_export_map, dim3(blocks), dim3(256), 0, st, h->xsize, h->G, h->cuts, h->d_best, h->d_log_odds[h->cur],
+  hipLaunchKernelGGL(rbpf_export_map, dim3(blocks), dim3(256), 0, st, h->xsize, h->G, h->cuts, h->d_best, h->pool, map_of(h),
                      h->d_export);
   TBNAV_HIP(hipGetLastError());
   TBNAV_HIP(hipMemcpyAsync(map, h->d_export, h->G, hipMemcpyDeviceToHost, st));
@@ -2614,6 +3194,63 @@ int tbnav_rbpf_get_scan_match(tbnav_rbpf* h, double* centers, double* scores) {
   TBNAV_HIP(hipStreamSynchronize(h->stream));
   if (centers) TBNAV_HIP(hipMemcpy(centers, h->d_center, sizeof(double) * 3 * h->N, hipMemcpyDeviceToHost));
   if (scores) TBNAV_HIP(hipMemcpy(scores, h->d_score, sizeof(double) * h->N, hipMemcpyDeviceToHost));
+  return TBNAV_OK;
+}
+
+int tbnav_rbpf_set_option(tbnav_rbpf* h, int32_t option, int32_t value) {
+  if (!h) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  switch (option) {
+    case TBNAV_RBPF_OPT_DF_MODE: {
+      if (value < TBNAV_RBPF_DF_FULL || value > TBNAV_RBPF_DF_REFERENCE) return TBNAV_ERR_INVALID_ARG;
+      if (h->scans_done) return TBNAV_ERR_INVALID_ARG;  // the mode belongs to the filter's whole life
+      if (value == TBNAV_RBPF_DF_REFERENCE) {
+        if (h->N > 4096) return TBNAV_ERR_UNSUPPORTED;  // serial host brushfire per particle: small ensembles only
+        { const int rc = ensure_codes(h); if (rc != TBNAV_OK) return rc; }
+        delete h->ref;
+        h->ref = new (std::nothrow) tbnav::RefField(h->N, h->xsize, h->radius);
+        if (!h->ref) return TBNAV_ERR_INVALID_ARG;
+        h->ref_field = true; h->df_mode = 2; h->full_edt = false;
+        return TBNAV_OK;
+      }
+      if (value != TBNAV_RBPF_DF_QUERY) {
+        if (h->edt_cols == 0) return TBNAV_ERR_UNSUPPORTED;  // no LDS transform for this map size
+        { const int rc = ensure_codes(h); if (rc != TBNAV_OK) return rc; }
+        // empty maps: the stored field "everything unreached" IS the whole, fresh field
+        TBNAV_HIP(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(h->d_fstate), 2, h->N));
+        h->fstate_dirty = true;
+      }
+      h->ref_field = false; h->df_mode = value; h->full_edt = value == TBNAV_RBPF_DF_FULL;
+      return TBNAV_OK;
+    }
+    case TBNAV_RBPF_OPT_RAYCAST_ORDERED:
+      if (value) h->tile_cap = 0;
+      else {
+        const double reach = (double)h->p.range_max + std::hypot(h->p.Trs[1], h->p.Trs[2]);
+        const long side = 2 * ((long)std::ceil(reach / h->p.resolution) + 2) + 1;
+        h->tile_cap = (side * side <= 30000) ? (int)(side * side) : 0;
+      }
+      return TBNAV_OK;
+    case TBNAV_RBPF_OPT_RAYCAST_THREADS:
+      if (value != 256 && value != 512 && value != 1024) return TBNAV_ERR_INVALID_ARG;
+      h->raycast_threads = value;
+      return TBNAV_OK;
+    case TBNAV_RBPF_OPT_COUNT_CELLS:
+      h->count_touched = value != 0;
+      return TBNAV_OK;
+    default: return TBNAV_ERR_INVALID_ARG;
+  }
+}
+
+int tbnav_rbpf_scan_counts(tbnav_rbpf* h, uint64_t* cell_updates, uint64_t* distinct_cells, int32_t reset) {
+  if (!h) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  TBNAV_HIP(hipStreamSynchronize(h->stream));
+  unsigned long long v[2] = {0, 0};
+  TBNAV_HIP(hipMemcpy(v, h->d_touched, sizeof v, hipMemcpyDeviceToHost));
+  if (cell_updates) *cell_updates = v[0];
+  if (distinct_cells) *distinct_cells = v[1];
+  if (reset) TBNAV_HIP(hipMemset(h->d_touched, 0, sizeof v));
   return TBNAV_OK;
 }
 

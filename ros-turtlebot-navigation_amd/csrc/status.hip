@@ -29,6 +29,7 @@ const char* tbnav_status_string(int status) {
     case TBNAV_ERR_PDF_VARIANCE: return "Variance in pdfNormal is 0";                 // grid_mapper.cpp:22
     case TBNAV_ERR_BRESENHAM: return "Bresenham's Line Algorithm";                    // grid_mapper.cpp:701
     case TBNAV_ERR_UNSUPPORTED: return "configuration not supported by the device path";
+    case TBNAV_ERR_POOL_EXHAUSTED: return "log-odds tile pool exhausted";
     default: return "unknown status";
   }
 }

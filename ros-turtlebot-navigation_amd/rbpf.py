@@ -49,11 +49,15 @@ def _d3(v):
 class ParticleFilter:
     """bmapping::ParticleFilter on one MI355X."""
 
-    def __init__(self, params: "capi.RbpfParams"):
+    def __init__(self, params: "capi.RbpfParams", pool_bytes: int = 0, df_mode: str | None = None):
+        """pool_bytes: budget of the log-odds tile pool (0 = default policy, tbnav_rbpf.h); df_mode: one of
+        "query" (default) / "window" / "full" / "reference" (TBNAV_RBPF_OPT_DF_MODE)."""
         self._L = capi.lib()
         self.params = params
         self._h = C.c_void_p()
-        capi.check(self._L.tbnav_rbpf_create(C.byref(params), C.byref(self._h)), "tbnav_rbpf_create")
+        capi.check(self._L.tbnav_rbpf_create_pool(C.byref(params), int(pool_bytes), C.byref(self._h)), "tbnav_rbpf_create")
+        if df_mode is not None:
+            capi.check(self._L.tbnav_rbpf_set_option(self._h, capi.RBPF_OPT_DF_MODE, capi.RBPF_DF[df_mode]), "set_option(df_mode)")
         xs, ys = C.c_int32(), C.c_int32()
         capi.check(self._L.tbnav_rbpf_grid_size(self._h, C.byref(xs), C.byref(ys)), "grid_size")
         self.xsize, self.ysize = xs.value, ys.value
@@ -162,6 +166,21 @@ class ParticleFilter:
         c = np.empty((self.N, 3)); sc = np.empty(self.N)
         capi.check(self._L.tbnav_rbpf_get_scan_match(self._h, c.ctypes.data, sc.ctypes.data), "get_scan_match")
         return c, sc
+
+    def setOption(self, option: int, value: int):
+        capi.check(self._L.tbnav_rbpf_set_option(self._h, option, value), "set_option")
+
+    def poolStats(self):
+        """(tiles the pool holds, tiles free, bytes per tile)."""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        capi.check(self._L.tbnav_rbpf_pool_stats(self._h, C.byref(a), C.byref(b), C.byref(c)), "pool_stats")
+        return a.value, b.value, c.value
+
+    def scanCounts(self, reset: bool = True):
+        """(cell updates, distinct cells written) summed since the last reset; needs setOption(RBPF_OPT_COUNT_CELLS, 1)."""
+        a, b = C.c_uint64(), C.c_uint64()
+        capi.check(self._L.tbnav_rbpf_scan_counts(self._h, C.byref(a), C.byref(b), 1 if reset else 0), "scan_counts")
+        return a.value, b.value
 
     def setTiming(self, on: bool = True):
         """Record HIP events round the kernels of the following SLAM calls (they cost device time: off by default)."""

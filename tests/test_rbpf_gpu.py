@@ -21,9 +21,9 @@ POSE_RTOL = 1e-10
 LIK_RTOL = 1e-9
 
 
-def _dev(gpu_pkg, **kw):
+def _dev(gpu_pkg, df_mode=None, pool_bytes=0, **kw):
     from rtn_amd.rbpf import ParticleFilter, default_params
-    return ParticleFilter(default_params(**kw))
+    return ParticleFilter(default_params(**kw), pool_bytes=pool_bytes, df_mode=df_mode)
 
 
 def _close(a, b, rtol, atol=0.0):
@@ -337,7 +337,7 @@ def test_cfg3_full_size_properties(gpu_pkg):
     assert np.array_equal(pf_d.distCode(0), codes)
 
 
-def test_distance_lookup_modes_are_bit_identical(gpu_pkg, monkeypatch):
+def test_distance_lookup_modes_are_bit_identical(gpu_pkg):
     """The scan likelihood gets its distance codes three ways: whole-map transform after every
     update ("full", the reference's data flow), a per-particle window refreshed before the update ("window"), or
     an exact nearest-obstacle query on the occupancy bitmap at each lookup ("query", the default — no transform in
@@ -349,8 +349,7 @@ def test_distance_lookup_modes_are_bit_identical(gpu_pkg, monkeypatch):
     scans = [orc.room_scan(poses[s], walls=rc.ROOM_SURVEY, rng=rng) for s in range(n_scans)]
     outs = {}
     for mode in ("full", "window", "query"):
-        monkeypatch.setenv("TBNAV_RBPF_DF", mode)
-        pf = _dev(gpu_pkg, N=N, k=k, map_min=-10.0, map_max=10.0)
+        pf = _dev(gpu_pkg, df_mode=mode, N=N, k=k, map_min=-10.0, map_max=10.0)
         rec = []
         for s, (prev, cur, t_icp, u) in enumerate(steps):
             normals = orc.normal_stream(500 + s, pf.numNormals(True), 0.0, 1.0)

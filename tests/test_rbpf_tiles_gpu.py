@@ -1,0 +1,113 @@
+"""GPU tests of the tiled copy-on-write maps: a resample copies tile tables, the next scan
+clones only the tiles it writes, tiles nobody names return to the pool — and the log-odds stay the reference's bits
+(particle_filter.cpp:468-500 deep copies, grid_mapper.cpp:140-178 updates)."""
+import numpy as np
+import pytest
+
+import oracle_api as orc
+import rbpf_cases as rc
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(gpu_pkg, pool_bytes=0, df_mode=None, **kw):
+    from rtn_amd.rbpf import ParticleFilter, default_params
+    return ParticleFilter(default_params(**kw), pool_bytes=pool_bytes, df_mode=df_mode)
+
+
+def _oracle_map(grid, laser, scans, poses):
+    """log-odds after integrating `scans` at `poses` (theta, x, y) with the oracle's GridMapper (no brushfire)."""
+    g = orc.GridAPI("orc", grid=grid, laser=laser)
+    for sc, po in zip(scans, poses):
+        g.integrate_scan(sc, po, esdf=False)
+    lo = g.dump()["log_odds"].copy()
+    g.close()
+    return lo
+
+
+def test_resample_shares_tiles_and_the_next_scan_clones_what_it_writes(gpu_pkg):
+    N, k, n_scans = 64, 8, 5
+    pf = _dev(gpu_pkg, N=N, k=k, map_min=-10.0, map_max=10.0)
+    cap, free0, tile_bytes = pf.poolStats()
+    assert tile_bytes == 8192 and free0 == cap
+    steps, poses = rc.trajectory(n_scans, inc=(0.05, 0.04, 0.03))
+    rng = np.random.default_rng(3)
+    scans = [orc.room_scan(poses[s], walls=rc.ROOM_SURVEY, rng=rng) for s in range(n_scans)]
+    hist, used, parents = [], [], None
+    for s, (prev, cur, t_icp, u) in enumerate(steps):
+        normals = orc.normal_stream(300 + s, pf.numNormals(True), 0.0, 1.0)
+        if s == 2:  # force a resample: two heavy particles
+            w = np.full(N, 1e-3); w[5] = 0.7; w[40] = 0.2; w /= w.sum()
+            pf.setParticles(w=w)
+        st = pf.SLAM(scans[s], u, cur, prev, True, t_icp, normals)
+        assert st.status == 0
+        hist.append(pf.trace()["new_pose"].copy())  # the pose each slot integrated this scan at (before any resample)
+        used.append(cap - pf.poolStats()[1])
+        if s == 2:
+            assert st.resampled == 1
+            parents = pf.trace()["resample_idx"].copy()
+        else:
+            assert st.resampled == 0
+    # scan 0 allocates the footprint, scans over the same area reuse it
+    assert used[0] > 0 and used[1] - used[0] < 0.2 * used[0]
+    # the resample freed the tiles of the particles that died: far fewer lineages are alive
+    n_alive = len(set(parents.tolist()))
+    assert n_alive < N // 2 and used[2] <= used[1] * (n_alive + 1) / N + 8
+    # the scan after it cloned the shared tiles each slot wrote (about one footprint per slot again) ...
+    assert used[3] > used[2] and used[3] <= used[2] + 1.2 * used[0]
+    # ... and the one after that found them private already
+    assert used[4] - used[3] < 0.2 * used[0]
+    # bits: every slot's map equals the oracle's GridMapper fed the slot's lineage of poses
+    grid = (0.05, -10.0, 10.0, -10.0, 10.0)
+    for m in (0, 5, 17, 40, N - 1):
+        q = int(parents[m])
+        lineage = [hist[0][q], hist[1][q], hist[2][q], hist[3][m], hist[4][m]]
+        assert np.array_equal(pf.logOdds(m), _oracle_map(grid, None, scans, lineage)), m
+    pf.close()
+
+
+def test_pool_exhaustion_is_reported_not_silent(gpu_pkg):
+    from rtn_amd import capi
+    pf = _dev(gpu_pkg, pool_bytes=8192 * 100, N=16, k=4, map_min=-10.0, map_max=10.0)  # 16 particles x ~25 tiles each do not fit
+    steps, poses = rc.trajectory(1)
+    prev, cur, t_icp, u = steps[0]
+    scan = orc.room_scan(poses[0], walls=rc.ROOM_SURVEY, rng=np.random.default_rng(1))
+    st = pf.SLAM(scan, u, cur, prev, True, t_icp, orc.normal_stream(1, pf.numNormals(True), 0.0, 1.0), check=False)
+    assert st.status == capi.ERR_POOL_EXHAUSTED
+    pf.close()
+
+
+def test_configs4_shard_10000_particles_2000x2000_1080_beams(gpu_pkg):
+    """BASELINE configs[4] per-GPU shard at scale: 10 000 particles on a 2000 x 2000 grid (dense that would be
+    320 GB of log-odds), 1080-beam scans, three scans with a forced resample after the second; spot-checked bit for
+    bit against the oracle's GridMapper along each spot particle's lineage."""
+    N, k, n_scans, bd = 10000, 4, 3, 1.0 / 3.0
+    pf = _dev(gpu_pkg, pool_bytes=24 << 30, N=N, k=k, map_min=-50.0, map_max=50.0, beam_delta_deg=bd)
+    assert (pf.xsize, pf.ysize) == (2000, 2000)
+    steps, poses = rc.trajectory(n_scans, inc=(0.05, 0.04, 0.03))
+    rng = np.random.default_rng(8)
+    scans = [orc.room_scan(poses[s], n_beams=1080, beam_delta_deg=bd, walls=rc.ROOM_SURVEY, rng=rng) for s in range(n_scans)]
+    hist, parents = [], None
+    for s, (prev, cur, t_icp, u) in enumerate(steps):
+        normals = np.random.default_rng(40 + s).standard_normal(pf.numNormals(True))
+        if s == 1:
+            w = np.full(N, 1e-6); w[[7, 1234, 5000, 9999]] = [0.4, 0.3, 0.2, 0.1]; w /= w.sum()
+            pf.setParticles(w=w)
+        st = pf.SLAM(scans[s], u, cur, prev, True, t_icp, normals)
+        assert st.status == 0 and st.n_valid_beams > 600
+        hist.append(pf.trace()["new_pose"].copy())
+        if s == 1:
+            assert st.resampled == 1
+            parents = pf.trace()["resample_idx"].copy()
+    assert {7, 1234, 5000, 9999} <= set(parents.tolist()) and len(set(parents.tolist())) < 300  # the four heavy ones + ~1 % of the rest
+    cap, free, _ = pf.poolStats()
+    assert cap - free < 120 * N  # a few tens of tiles per particle, not 3969
+    grid = (0.05, -50.0, 50.0, -50.0, 50.0)
+    laser = orc.lds01_laser(bd)
+    for m in (0, 4321, N - 1):
+        q = int(parents[m])
+        want = _oracle_map(grid, laser, scans, [hist[0][q], hist[1][q], hist[2][m]])
+        assert np.array_equal(pf.logOdds(m), want), m
+    (pose, idx) = pf.getRobotState()
+    assert 0 <= idx < N and np.all(np.isfinite(pose))
+    pf.close()
