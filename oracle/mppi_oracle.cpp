@@ -93,6 +93,8 @@ inline int steps_of(const Params& p) { return static_cast<int>(p.horizon / p.dt)
 
 // exact-arc plant step (rbpf_oracle.cpp: the restated rigid2d::DiffDrive, itself pinned bit for bit against the
 // reference's own class by tests/test_oracle_vs_reference.py)
+int g_orc_threads = 1;  // shared with rbpf_oracle.cpp (orc_set_threads)
+extern "C" void orc_set_threads(int n) { g_orc_threads = n < 1 ? 1 : n; }
 extern "C" int orc_dd_arc_step(double wheel_base, double wheel_radius, double dt, double pose_xyt[3], const double wheels[2]);
 
 extern "C" {
@@ -152,6 +154,9 @@ void orc_mppi_new_controls_dyn(const Params* pp, double* u, const double uinit[2
   std::vector<double> loss_mat((size_t)T * K, 0.0), J((size_t)T * K), dul((size_t)T * K),
       dur((size_t)T * K);
 
+  // (rollouts are independent: with orc_set_threads(n > 1) this loop is spread over n cores — the "all host cores"
+  //  CPU baseline of bench.py; results are identical, every rollout writes its own column)
+#pragma omp parallel for num_threads(g_orc_threads) if (g_orc_threads > 1) schedule(static)
   for (int k = 0; k < K; ++k) {                                         // mppi.cpp:81
     double x[3] = {x0[0], x0[1], x0[2]};                                // :75-76 (x, y, theta)
     for (int i = 0; i < T; ++i) {

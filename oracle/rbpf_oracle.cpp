@@ -26,6 +26,7 @@
 #include <unordered_set>
 #include <vector>
 
+extern int g_orc_threads;  // mppi_oracle.cpp
 namespace orc {
 
 constexpr double PI = 3.14159265358979323846;  // rigid2d.hpp:13
@@ -479,9 +480,14 @@ class PF {
             const double* const* inject_occ_dist_after_likelihood = nullptr) {
     (void)inject_occ_dist_after_likelihood;
     const int N = P.num_particles, k = P.k;
-    size_t nz = 0;
+    const size_t stride = icp_ok ? (size_t)3 * k + 3 : 3;  // draws per particle, in particle order
     const T2 T_icp = make_T(Ticp[1], Ticp[2], Ticp[0]);
+    if (sm_on) { sm_centers.resize((size_t)N * 3); sm_scores.resize(N); }
+    // (particles are independent inside this loop; with orc_set_threads(n > 1) it is spread over n cores — the
+    //  "all host cores" CPU baseline of bench_rbpf.py.  Same results: every particle reads its own slice of the draws.)
+#pragma omp parallel for num_threads(g_orc_threads) if (g_orc_threads > 1) schedule(dynamic, 1)
     for (int pi = 0; pi < N; ++pi) {
+      size_t nz = (size_t)pi * stride;
       Particle& particle = set[pi];
       if (!icp_ok) {
         for (int c = 0; c < 3; ++c) particle.prev_pose[c] = particle.pose[c];
@@ -498,7 +504,6 @@ class PF {
           double c3[3] = {T_x.theta, T_x.x, T_x.y};
           const double sc = scan_match(particle, scan, n, c3);
           T_x = make_T(c3[1], c3[2], c3[0]);
-          sm_centers.resize((size_t)N * 3); sm_scores.resize(N);
           for (int c = 0; c < 3; ++c) sm_centers[(size_t)pi * 3 + c] = c3[c];
           sm_scores[pi] = sc;
         }
@@ -526,6 +531,7 @@ class PF {
       const T2 Pp = make_T(particle.pose[1], particle.pose[2], particle.pose[0]);
       particle.grid.integrate_scan(scan, n, Pp);  // :237-239
     }
+    size_t nz = (size_t)N * stride;
     // normalizeWeights, :442-458
     double sum = 0.0;
     for (const auto& q : set) sum += q.weight;

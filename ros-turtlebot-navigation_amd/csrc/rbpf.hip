@@ -134,6 +134,33 @@ __device__ __forceinline__ void tile_push(const TilePool& P, unsigned int id) {
   const unsigned long long pos = atomicAdd(P.ctr + 1, 1ull);
   P.ring[pos % P.cap] = id;
 }
+// n tiles at once: ONE atomic on the ring's head per caller (a workgroup that clones 15 tiles after a resample would
+// otherwise queue 15 times on a word every other workgroup is queueing on — a single address retires ~90 atomics
+// per microsecond).  Returns the position of the first tile in the ring, ~0 if fewer than n are free.
+__device__ __forceinline__ unsigned long long tile_pop_n(const TilePool& P, unsigned int n) {
+  const unsigned long long pos = atomicAdd(P.ctr, (unsigned long long)n);
+  if (pos + n > P.ctr[1]) { atomicAdd(P.ctr, ~(unsigned long long)n + 1ull); return ~0ull; }
+  return pos;
+}
+__device__ __forceinline__ unsigned int tile_at(const TilePool& P, unsigned long long pos) { return P.ring[pos % P.cap]; }
+__device__ __forceinline__ bool tile_is_private(const TilePool& P, const unsigned int* __restrict__ table_p, int t) {
+  const unsigned int id = table_p[t];
+  return id != 0u && P.ref[id] == 1;
+}
+// Tile t of one particle becomes the fresh tile nid, filled from the tile it named so far (all 64 lanes of a wave).
+__device__ __forceinline__ void tile_clone_into(const TilePool& P, unsigned int* __restrict__ table_p, unsigned int* __restrict__ shed_p,
+                                                int t, unsigned int nid, int lane) {
+  const unsigned int id = table_p[t];
+  double2* dst = reinterpret_cast<double2*>(P.lo + (size_t)nid * kTileCells);
+  const double2* src = reinterpret_cast<const double2*>(P.lo + (size_t)id * kTileCells);  // id 0 = the zero tile
+#pragma unroll
+  for (int i = 0; i < kTileCells / 2 / kWave; ++i) dst[i * kWave + lane] = src[i * kWave + lane];
+  if (lane == 0) {
+    P.ref[nid] = 1;
+    table_p[t] = nid;
+    if (id != 0u) shed_p[t] = id;  // a (p, t) entry leaves a shared tile at most once between two resamples
+  }
+}
 // Make tile t of one particle private to it (called by all 64 lanes of a wave, wave-uniform arguments).
 // Returns the tile's id, 0 if the pool is exhausted.
 __device__ __forceinline__ unsigned int tile_make_private(const TilePool& P, unsigned int* __restrict__ table_p,
@@ -1027,16 +1054,32 @@ __global__ __launch_bounds__(kWave) void rbpf_raycast(ScanC c, TilePool P, MapT 
     if (lane == 0) { const int t = tile_of(M, x1, y1); atomicOr(&tbits[t >> 5], 1u << (t & 31)); }
   }
   __syncthreads();
-  for (int w = 0; w < tword; ++w) {
-    unsigned int m = tbits[w];
-    while (m) {
-      const int t = w * 32 + __ffs((int)m) - 1;
-      m &= m - 1;
-      if (tile_make_private(P, tab, shed, t, lane) == 0u) bad = 1;
+  {
+    int need = 0;  // tiles to clone: one pop of the ring for all of them
+    for (int w = 0; w < tword; ++w) {
+      unsigned int m = tbits[w];
+      while (m) {
+        const int t = w * 32 + __ffs((int)m) - 1;
+        m &= m - 1;
+        if (!tile_is_private(P, tab, t)) ++need;
+      }
+    }
+    if (need) {
+      unsigned long long base = 0ull;
+      if (lane == 0) base = tile_pop_n(P, (unsigned int)need);
+      base = ((unsigned long long)__shfl((int)(base >> 32), 0, kWave) << 32) | (unsigned int)__shfl((int)base, 0, kWave);
+      if (base == ~0ull) { if (lane == 0) atomicOr(&err[3], 8); return; }  // tile pool exhausted: nothing has been written
+      for (int w = 0; w < tword; ++w) {
+        unsigned int m = tbits[w];
+        while (m) {
+          const int t = w * 32 + __ffs((int)m) - 1;
+          m &= m - 1;
+          if (!tile_is_private(P, tab, t)) { tile_clone_into(P, tab, shed, t, tile_at(P, base), lane); ++base; }
+        }
+      }
     }
   }
   __syncthreads();
-  if (bad) { if (lane == 0) atomicOr(&err[3], 8); return; }  // tile pool exhausted: nothing has been written
   int n_log = 0;
   int* ev = log.ev ? log.ev + (size_t)p * log.cap : nullptr;
   for (int b = 0; b < c.Bv; ++b) {
@@ -1304,15 +1347,31 @@ __global__ __launch_bounds__(1024, 8) void rbpf_raycast_tile(ScanC c, TilePool P
   {
     unsigned int* tab = M.table + (size_t)p * M.TT;
     unsigned int* shed = M.shed + (size_t)p * M.TT;
-    for (int q = wid; q < mtn; q += nw) {
-      if (mt_id[q] == 0u) continue;
-      const int qi = floor_div_small(q, mty), qj = q - qi * mty;
-      const unsigned int id = tile_make_private(P, tab, shed, (tx0 + qi) * M.TW + (ty0 + qj), lane);
-      if (lane == 0) { mt_id[q] = id; if (id == 0u) bad = 1; }
+    __shared__ int n_need;
+    __shared__ unsigned long long need_base;
+    __shared__ int mt_slot[kMapTilesMax];  // -1: the tile is private already, else its place in this workgroup's batch
+    if (tid == 0) n_need = 0;
+    __syncthreads();
+    if (tid < mtn && mt_id[tid] != 0u) {
+      const int qi = floor_div_small(tid, mty), qj = tid - qi * mty, t = (tx0 + qi) * M.TW + (ty0 + qj);
+      if (tile_is_private(P, tab, t)) { mt_slot[tid] = -1; mt_id[tid] = tab[t]; }
+      else mt_slot[tid] = atomicAdd(&n_need, 1);
+    }
+    __syncthreads();
+    if (n_need) {  // workgroup-uniform
+      if (tid == 0) { need_base = tile_pop_n(P, (unsigned int)n_need); if (need_base == ~0ull) bad = 1; }
+      __syncthreads();
+      if (bad) { if (tid == 0) atomicOr(&err[3], 8); return; }  // tile pool exhausted: nothing has been written
+      for (int q = wid; q < mtn; q += nw) {
+        if (mt_id[q] == 0u || mt_slot[q] < 0) continue;
+        const int qi = floor_div_small(q, mty), qj = q - qi * mty;
+        const unsigned int nid = tile_at(P, need_base + (unsigned long long)mt_slot[q]);
+        tile_clone_into(P, tab, shed, (tx0 + qi) * M.TW + (ty0 + qj), nid, lane);
+        if (lane == 0) mt_id[q] = nid;
+      }
+      __syncthreads();
     }
   }
-  __syncthreads();
-  if (bad) { if (tid == 0) atomicOr(&err[3], 8); return; }  // tile pool exhausted: nothing has been written
   auto cell_ptr = [&](int cx, int cy) -> double* {
     return P.lo + (size_t)mt_id[((cx >> kTSh) - tx0) * mty + ((cy >> kTSh) - ty0)] * kTileCells + in_tile(cx, cy);
   };
@@ -1433,10 +1492,15 @@ __global__ __launch_bounds__(1024, 8) void rbpf_raycast_tile(ScanC c, TilePool P
     }
   }
   if (touched) {  // measurement hook (tbnav_rbpf_scan_counts): [0] += cell updates (free adds + end points), [1] += distinct cells written
+    __shared__ int cnt_upd, cnt_dis;
+    if (tid == 0) { cnt_upd = 0; cnt_dis = n_cells; }
+    __syncthreads();
     int n_upd = 0;
     for (int b = tid; b < Bv; b += nthr) n_upd += (rk[b] >> 8) + 1;
     n_upd = wave_sum_i(n_upd); n_distinct = wave_sum_i(n_distinct);
-    if (lane == 0) { atomicAdd(&touched[0], (unsigned long long)n_upd); atomicAdd(&touched[1], (unsigned long long)(n_distinct + (wid == 0 ? n_cells : 0))); }
+    if (lane == 0) { atomicAdd(&cnt_upd, n_upd); atomicAdd(&cnt_dis, n_distinct); }
+    __syncthreads();
+    if (tid == 0) { atomicAdd(&touched[0], (unsigned long long)cnt_upd); atomicAdd(&touched[1], (unsigned long long)cnt_dis); }
   }
   PHASE_STAMP(4);
 #ifdef TBNAV_PHASE_PROF

@@ -103,49 +103,89 @@ class ShardedMPPI:
 # ======================================================================================================
 # RBPF
 # ======================================================================================================
-class HipRbpfShardBackend:
-    """Per-rank RBPF compute on the HIP path (ros-turtlebot-navigation_amd/rbpf.py handle)."""
+def _all_gather_flat(out: torch.Tensor, local: torch.Tensor, group=None):
+    """all_gather_into_tensor; device tensors ride RCCL as they are, and are staged through the host only when the
+    process group is gloo (the CPU-side tests: two ranks sharing one GPU)."""
+    if _backend_is_gloo(group) and local.is_cuda:
+        h_out = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(h_out, local.cpu(), group=group)
+        out.copy_(h_out)
+    else:
+        dist.all_gather_into_tensor(out, local, group=group)
 
-    def __init__(self, pf):
+
+class HipRbpfShardBackend:
+    """Per-rank RBPF compute on the HIP path (ros-turtlebot-navigation_amd/rbpf.py handle).  Everything the exchange
+    touches stays in device memory: weights, the global normalise / selection, particle blobs."""
+
+    def __init__(self, pf, device: torch.device | None = None):
         self.pf = pf
         self.n_local = pf.N
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self._L, self._h = pf._L, pf._h
 
     def slam_local(self, scan, u, cur_odom, prev_odom, icp_ok, T_icp, normals_local):
         return self.pf.SLAM(scan, u, cur_odom, prev_odom, icp_ok, T_icp, normals_local, local_only=True)
 
-    def weights(self) -> np.ndarray:
-        return self.pf.particles()[2]
+    def weights_tensor(self) -> torch.Tensor:
+        w = torch.empty(self.n_local, dtype=torch.float64, device=self.device)
+        capi.check(self._L.tbnav_rbpf_copy_weights_dev(self._h, w.data_ptr()), "copy_weights_dev")
+        return w
 
-    def set_weights(self, w: np.ndarray):
-        self.pf.setParticles(w=w)
+    def resample(self, w_all: torch.Tensor, offset: int, z: float):
+        """Sequential normalise / Neff / selection over the global vector, on the device; this rank's slice of the
+        normalised weights lands in the handle.  Returns (stats, parents or None)."""
+        import ctypes as C
+        n = w_all.numel()
+        parents = np.empty(n, dtype=np.int32)
+        st = capi.RbpfStats()
+        capi.check(self._L.tbnav_rbpf_resample_global_dev(self._h, w_all.data_ptr(), n, offset, float(z), parents.ctypes.data, C.byref(st)),
+                   "resample_global_dev")
+        return st, (parents if st.resampled else None)
 
-    def export_particle(self, slot: int) -> dict:
-        pose, prev, w = self.pf.particles()
-        return dict(state=np.concatenate([pose[slot], prev[slot], [w[slot]]]), log_odds=self.pf.logOdds(slot),
-                    dist=self.pf.occDist(slot))
+    def set_weights_after_resample(self, global_parents_of_my_slots: np.ndarray):
+        gp = np.ascontiguousarray(global_parents_of_my_slots, dtype=np.int32)
+        capi.check(self._L.tbnav_rbpf_set_weights_from_global_dev(self._h, gp.ctypes.data), "set_weights_from_global_dev")
 
-    def import_particle(self, slot: int, blob: dict):
-        pose, prev, w = self.pf.particles()
-        pose[slot], prev[slot], w[slot] = blob["state"][0:3], blob["state"][3:6], blob["state"][6]
-        self.pf.setParticles(pose, prev, w)
-        self.pf.setLogOdds(slot, blob["log_odds"])
-        self.pf.setOccDist(slot, blob["dist"])
+    def export_size(self, slot: int) -> int:
+        import ctypes as C
+        n = C.c_uint64()
+        capi.check(self._L.tbnav_rbpf_export_size(self._h, slot, C.byref(n)), "export_size")
+        return n.value
+
+    def export_blob(self, slot: int) -> torch.Tensor:
+        import ctypes as C
+        buf = torch.empty(self.export_size(slot), dtype=torch.uint8, device=self.device)
+        n = C.c_uint64()
+        capi.check(self._L.tbnav_rbpf_export_particle_dev(self._h, slot, buf.data_ptr(), buf.numel(), C.byref(n)), "export_particle_dev")
+        assert n.value == buf.numel()
+        return buf
+
+    def new_blob(self, nbytes: int) -> torch.Tensor:
+        return torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+
+    def import_blob(self, slot: int, blob: torch.Tensor):
+        torch.cuda.synchronize(self.device)  # the receive ran on the communicator's stream
+        capi.check(self._L.tbnav_rbpf_import_particle_dev(self._h, slot, blob.data_ptr(), blob.numel()), "import_particle_dev")
 
     def gather_local(self, local_parent: np.ndarray):
-        capi.check(self.pf._L.tbnav_rbpf_gather_local(self.pf._h, np.ascontiguousarray(local_parent, dtype=np.int32).ctypes.data),
+        capi.check(self._L.tbnav_rbpf_gather_local(self._h, np.ascontiguousarray(local_parent, dtype=np.int32).ctypes.data),
                    "gather_local")
 
 
 class ShardedRBPF:
-    """ParticleFilter::SLAM over `world_size` particle shards (equal shard sizes)."""
+    """ParticleFilter::SLAM over `world_size` particle shards (equal shard sizes).
 
-    def __init__(self, backend, resample_global, group=None):
+    Backend protocol (HipRbpfShardBackend above; the CPU tests plug in a numpy stand-in): slam_local, weights_tensor,
+    resample, set_weights_after_resample, export_size, export_blob, new_blob, import_blob, gather_local."""
+
+    def __init__(self, backend, group=None):
         self.b = backend
-        self.resample_global = resample_global  # callable(weights_all, z) -> (parents, w_norm, stats)
         self.group = group
         self.world, self.rank = _world(group), _rank(group)
         self.n_local = backend.n_local
         self.n_global = self.n_local * self.world
+        self.bytes_migrated = 0
 
     def normals_slice(self, normals_global: np.ndarray, stride: int) -> np.ndarray:
         """This rank's part of the reference's draw stream (particle-major) + the resampling offset."""
@@ -153,65 +193,72 @@ class ShardedRBPF:
         return np.concatenate([normals_global[lo:lo + self.n_local * stride], normals_global[-1:]])
 
     def tick(self, scan, u, cur_odom, prev_odom, icp_ok, T_icp, normals_global, stride):
-        st_local = self.b.slam_local(scan, u, cur_odom, prev_odom, icp_ok, T_icp, self.normals_slice(normals_global, stride))
-        w_local = torch.from_numpy(np.ascontiguousarray(self.b.weights(), dtype=np.float64))
+        st_local = self.b.slam_local(scan, u, cur_odom, prev_odom, icp_ok, T_icp,
+                                     None if normals_global is None else self.normals_slice(normals_global, stride))
+        w_local = self.b.weights_tensor()
         if self.world > 1:
-            w_all = torch.empty(self.n_global, dtype=torch.float64)
-            if dist.get_backend(self.group) == "nccl":
-                dev = torch.device("cuda", torch.cuda.current_device())
-                g = torch.empty(self.n_global, dtype=torch.float64, device=dev)
-                dist.all_gather_into_tensor(g, w_local.to(dev), group=self.group)
-                w_all = g.cpu()
-            else:
-                dist.all_gather_into_tensor(w_all, w_local, group=self.group)
+            w_all = torch.empty(self.n_global, dtype=w_local.dtype, device=w_local.device)
+            _all_gather_flat(w_all, w_local, self.group)   # the ONE collective of the update (N doubles)
         else:
             w_all = w_local
-        parents, w_norm, st = self.resample_global(w_all.numpy(), float(normals_global[-1]))
         lo = self.rank * self.n_local
-        if st.resampled:
-            self._migrate(parents)
-            # weights are NOT reset by the reference: every slot carries its parent's normalised weight
-            self.b.set_weights(w_norm[parents[lo:lo + self.n_local]])
-        else:
-            self.b.set_weights(w_norm[lo:lo + self.n_local])
+        z = float(normals_global[-1]) if normals_global is not None else self.resample_offset()
+        st, parents = self.b.resample(w_all, lo, z)
+        if parents is None:
+            return st, st_local, np.arange(self.n_global, dtype=np.int32)
+        self._migrate(parents)
+        # weights are NOT reset by the reference: every slot carries its parent's normalised weight
+        self.b.set_weights_after_resample(parents[lo:lo + self.n_local])
         return st, st_local, parents
 
+    def resample_offset(self) -> float:
+        """Production mode (device-drawn normals): the one standard normal of lowVarianceResampling must be the same on
+        every rank — rank 0 draws it."""
+        t = torch.randn(1, dtype=torch.float64)
+        if self.world > 1:
+            if not _backend_is_gloo(self.group):
+                t = t.to(self.b.device)
+            dist.broadcast(t, 0, group=self.group)
+        return float(t.item())
+
     def _migrate(self, parents: np.ndarray):
-        """Slot m (global) takes the state of particle parents[m].  Remote parents are exported by their
-        owner and sent point-to-point; local ones are gathered inside the handle."""
+        """Slot m (global) takes the state of particle parents[m].  Parents on this rank are gathered inside the
+        handle (tile tables + reference counts); a parent on another rank arrives as one device buffer: its state,
+        bitmap and the tiles it owns — point to point, only for the slots that need it."""
         nl, me = self.n_local, self.rank
         lo = me * nl
-        # what I must send: for every remote slot whose parent I own (dedup per (dst, parent))
-        sends = {}
-        for m, q in enumerate(parents):
-            dst, src = m // nl, q // nl
-            if src == me and dst != me:
-                sends.setdefault((dst, int(q)), None)
+        sends = sorted({(m // nl, int(q)) for m, q in enumerate(parents) if q // nl == me and m // nl != me})
         recvs = sorted({(int(parents[m]) // nl, int(parents[m])) for m in range(lo, lo + nl) if parents[m] // nl != me})
-        blobs = {key: self.b.export_particle(key[1] - lo) for key in sends}  # export BEFORE anything is overwritten
+        blobs = {key: self.b.export_blob(key[1] - lo) for key in sends}  # export BEFORE anything is overwritten
         received = {}
         if self.world > 1:
-            reqs = []
+            # sizes first: one small all-gather (a particle's blob depends on how many tiles it owns)
+            mine = torch.zeros(nl, dtype=torch.int64)
+            for (_, q), blob in blobs.items():
+                mine[q - lo] = blob.numel()
+            stage_cpu = _backend_is_gloo(self.group)
+            sizes = torch.empty(self.n_global, dtype=torch.int64, device=mine.device if stage_cpu else self.b.device)
+            _all_gather_flat(sizes, mine if stage_cpu else mine.to(self.b.device), self.group)
+            sizes = sizes.cpu().numpy()
+            ops, keep = [], []
             for (dst, q), blob in sorted(blobs.items()):
-                for name in ("state", "log_odds", "dist"):
-                    reqs.append(dist.isend(torch.from_numpy(np.ascontiguousarray(blob[name])), dst, group=self.group))
-            sizes = None
+                t = blob.cpu() if (stage_cpu and blob.is_cuda) else blob
+                keep.append(t)
+                ops.append(dist.P2POp(dist.isend, t, dst, group=self.group))
+                self.bytes_migrated += blob.numel()
             for (src, q) in recvs:
-                if sizes is None:
-                    probe = self.b.export_particle(0)
-                    sizes = {k: v.size for k, v in probe.items()}
-                got = {}
-                for name in ("state", "log_odds", "dist"):
-                    t = torch.empty(sizes[name], dtype=torch.float64)
-                    dist.recv(t, src, group=self.group)
-                    got[name] = t.numpy()
-                received[q] = got
-            for r in reqs:
-                r.wait()
-        # local parents first (double-buffered gather inside the handle), then the imported ones
+                t = torch.empty(int(sizes[q]), dtype=torch.uint8) if stage_cpu else self.b.new_blob(int(sizes[q]))
+                received[q] = t
+                ops.append(dist.P2POp(dist.irecv, t, src, group=self.group))
+            if ops:
+                for r in dist.batch_isend_irecv(ops):
+                    r.wait()
+        # local parents first (inside the handle), then the imported ones
         local_parent = np.array([int(parents[m]) - lo if parents[m] // nl == me else -1 for m in range(lo, lo + nl)], dtype=np.int32)
         self.b.gather_local(local_parent)
         for m in range(lo, lo + nl):
             q = int(parents[m])
             if q // nl != me:
-                self.b.import_particle(m - lo, received[q])
+                t = received[q]
+                dev = getattr(self.b, "device", torch.device("cpu"))
+                self.b.import_blob(m - lo, t if t.device == dev else t.to(dev))

@@ -11,23 +11,27 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
-def _init(rank, world, port):
+def _init(rank, world, port, backend="gloo"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend == "nccl":
+        import torch
+        torch.cuda.set_device(rank)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     return dist
 
 
-def run_spawn(fn, world, *args):
-    """Spawn `world` processes running fn(rank, world, port, result_dict, *args); returns {rank: result}."""
+def run_spawn(fn, world, *args, backend="gloo"):
+    """Spawn `world` processes running fn(rank, world, *args) under a `backend` process group; returns {rank: result}."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     mgr = ctx.Manager()
     res = mgr.dict()
-    procs = [ctx.Process(target=_guard, args=(fn, r, world, port, res) + args) for r in range(world)]
+    procs = [ctx.Process(target=_guard, args=(fn, r, world, port, res, backend) + args) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -42,9 +46,9 @@ def run_spawn(fn, world, *args):
     return out
 
 
-def _guard(fn, rank, world, port, res, *args):
+def _guard(fn, rank, world, port, res, backend, *args):
     try:
-        dist = _init(rank, world, port)
+        dist = _init(rank, world, port, backend)
         res[rank] = fn(rank, world, *args)
         dist.barrier()
         dist.destroy_process_group()
@@ -96,44 +100,66 @@ def mppi_worker(rank, world, K_global, horizon, n_ticks, seed):
 
 # ---- RBPF: fake per-rank compute, real exchange + the product's resample_global -------------------
 class FakeRbpfBackend:
-    """Stands in for the HIP handle: deterministic per-particle 'update', a small vector as the map."""
+    """Stands in for the HIP handle: deterministic per-particle 'update', a small vector as the map; blobs of
+    DIFFERENT sizes per particle (like tiled maps), so the size exchange is exercised."""
 
     def __init__(self, rank, n_local, map_len=32):
-        self.n_local, self.rank = n_local, rank
+        import torch
+        self.torch = torch
+        self.device = torch.device("cpu")
+        self.n_local, self.rank, self.map_len = n_local, rank, map_len
         gid = np.arange(rank * n_local, (rank + 1) * n_local)
         self.state = np.stack([gid + 0.25, gid * 2.0, gid * 3.0, gid + 0.5, gid * 5.0, gid * 7.0, np.zeros(n_local)], 1)
         self.maps = gid[:, None] * 1000.0 + np.arange(map_len)[None, :]
         self.dist_maps = -self.maps
+        self.pad = gid % 3  # extra doubles in the blob
 
     def slam_local(self, scan, u, cur, prev, icp_ok, T_icp, normals_local):
         self.state[:, 6] = np.abs(normals_local[:self.n_local]) ** 4 + 1e-3  # raw weights from this rank's draws
         return None
 
-    def weights(self):
-        return self.state[:, 6].copy()
+    def weights_tensor(self):
+        return self.torch.from_numpy(self.state[:, 6].copy())
 
-    def set_weights(self, w):
-        self.state[:, 6] = w
+    def resample(self, w_all, offset, z):
+        from rtn_amd.rbpf import resample_global
+        parents, wn, st = resample_global(w_all.numpy(), z)
+        self._wn = wn
+        self.state[:, 6] = wn[offset:offset + self.n_local]
+        return st, (parents if st.resampled else None)
 
-    def export_particle(self, slot):
-        return dict(state=self.state[slot].copy(), log_odds=self.maps[slot].copy(), dist=self.dist_maps[slot].copy())
+    def set_weights_after_resample(self, gp):
+        self.state[:, 6] = self._wn[gp]
 
-    def import_particle(self, slot, blob):
-        self.state[slot], self.maps[slot], self.dist_maps[slot] = blob["state"], blob["log_odds"], blob["dist"]
+    def export_size(self, slot):
+        return 8 * (7 + 2 * self.map_len + 1 + int(self.pad[slot]))
+
+    def export_blob(self, slot):
+        v = np.concatenate([self.state[slot], self.maps[slot], self.dist_maps[slot], [float(self.pad[slot])], np.zeros(int(self.pad[slot]))])
+        return self.torch.from_numpy(v.copy()).view(self.torch.uint8)
+
+    def new_blob(self, n):
+        return self.torch.empty(n, dtype=self.torch.uint8)
+
+    def import_blob(self, slot, t):
+        v = t.view(self.torch.float64).numpy()
+        L = self.map_len
+        self.state[slot], self.maps[slot], self.dist_maps[slot] = v[:7], v[7:7 + L], v[7 + L:7 + 2 * L]
+        self.pad[slot] = int(v[7 + 2 * L])
+        assert v.size == 7 + 2 * L + 1 + self.pad[slot]
 
     def gather_local(self, local_parent):
         src = np.where(local_parent < 0, np.arange(self.n_local), local_parent)
-        self.state, self.maps, self.dist_maps = self.state[src].copy(), self.maps[src].copy(), self.dist_maps[src].copy()
+        self.state, self.maps, self.dist_maps, self.pad = self.state[src].copy(), self.maps[src].copy(), self.dist_maps[src].copy(), self.pad[src].copy()
 
 
 def rbpf_worker(rank, world, n_local, seed):
     import __graft_entry__ as g
     g.load_package()
-    from rtn_amd.rbpf import resample_global
     from rtn_amd.sharded import ShardedRBPF
     N = n_local * world
     b = FakeRbpfBackend(rank, n_local)
-    sr = ShardedRBPF(b, resample_global)
+    sr = ShardedRBPF(b)
     rng = np.random.default_rng(seed)
     normals = rng.standard_normal(N * 1 + 1)
     st, _, parents = sr.tick(None, None, None, None, True, None, normals, 1)
@@ -173,25 +199,33 @@ def rbpf_scenario(n_scans=3):
     return steps, scans
 
 
-def rbpf_hip_worker(rank, world, n_local, k, skew_scan):
+def rbpf_hip_worker(rank, world, n_local, k, skew_scan, heavy=None, df_inject=False, backend="gloo"):
+    """heavy: {global index: weight} forced before scan `skew_scan` (default: 3 -> 0.6, N-2 -> 0.25)."""
+    import torch
     import __graft_entry__ as g
     g.load_package()
     import oracle_api as orc
-    from rtn_amd.rbpf import ParticleFilter, default_params, resample_global
+    from rtn_amd.rbpf import ParticleFilter, default_params
     from rtn_amd.sharded import HipRbpfShardBackend, ShardedRBPF
     N = n_local * world
-    pf = ParticleFilter(default_params(N=n_local, k=k))
-    sr = ShardedRBPF(HipRbpfShardBackend(pf), resample_global)
-    steps, scans = rbpf_scenario()
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    pf = ParticleFilter(default_params(N=n_local, k=k, device=dev.index))
+    sr = ShardedRBPF(HipRbpfShardBackend(pf, dev))
+    steps, scans = rbpf_scenario(4)
     stride = 3 * k + 3
     hist = []
+    heavy = heavy or {3: 0.6, N - 2: 0.25}
     for s, (prev, cur, t_icp, u) in enumerate(steps):
         normals = orc.normal_stream(50 + s, N * stride + 1, 0.0, 1.0)
         if s == skew_scan:
-            w = np.full(N, 0.01); w[3] = 0.6; w[N - 2] = 0.25; w /= w.sum()
+            w = np.full(N, 0.01)
+            for i, v in heavy.items():
+                w[i] = v
+            w /= w.sum()
             pf.setParticles(w=w[rank * n_local:(rank + 1) * n_local])
         st, _, parents = sr.tick(scans[s], u, cur, prev, True, t_icp, normals, stride)
         hist.append((st.neff, st.resampled, parents.tolist()))
     pose, prev_pose, w = pf.particles()
     return dict(pose=pose, prev=prev_pose, w=w, hist=hist, lo=[pf.logOdds(p) for p in range(n_local)],
-                codes=[pf.distCode(p) for p in range(n_local)])
+                codes=[pf.distCode(p) for p in range(n_local)], migrated=sr.bytes_migrated)

@@ -106,7 +106,10 @@ def test_default_mode_effect_of_the_exact_field_on_weights_is_bounded(gpu_pkg, c
           f", neff gap {neff_gap}, neff per scan {[r['neff'] for r in rows]}")
     # the first scan sees empty maps (likelihood 1 on both sides): identical
     assert rows[0]["w"] <= 1e-9
-    assert worst["p_scan"] <= 0.25 and worst["eta"] <= 0.25 and worst["w"] <= 0.5
-    assert worst["best_xy"] <= 5e-3 and worst["best_th"] <= 5e-3
-    assert neff_gap <= max(2, args["N"] // 10)
+    # measured on MI355X (round 2): shipped config 4e-14 everywhere (every looked-up cell lies within a cell or two of
+    # a wall, where the brushfire IS exact); 200 x 400^2: p_scan / eta / weights 7.5e-3, Neff equal, best pose 4e-16
+    lik_bound = 1e-6 if cfg == "shipped_40x80x80" else 0.03
+    assert worst["p_scan"] <= lik_bound and worst["eta"] <= lik_bound and worst["w"] <= lik_bound
+    assert worst["best_xy"] <= 1e-6 and worst["best_th"] <= 1e-6
+    assert neff_gap <= 1
     pf_d.close()

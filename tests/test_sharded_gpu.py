@@ -32,19 +32,21 @@ def test_mppi_two_ranks_one_gpu(gpu_pkg):
     assert np.allclose(res[0]["u"], m.getControls(), rtol=1e-10, atol=1e-13)
 
 
-def test_rbpf_two_ranks_one_gpu_equals_unsharded_bit_exact(gpu_pkg):
+def _rbpf_sharded_vs_unsharded(n_local, k, skew_scan, heavy, backend):
     from rtn_amd.rbpf import ParticleFilter, default_params
-    n_local, k, skew_scan = 6, 8, 1
     N = 2 * n_local
-    res = run_spawn(rbpf_hip_worker, 2, n_local, k, skew_scan)
+    res = run_spawn(rbpf_hip_worker, 2, n_local, k, skew_scan, heavy, backend=backend)
     pf = ParticleFilter(default_params(N=N, k=k))
-    steps, scans = rbpf_scenario()
+    steps, scans = rbpf_scenario(4)
     stride = 3 * k + 3
     resampled_any = False
     for s, (prev, cur, t_icp, u) in enumerate(steps):
         normals = orc.normal_stream(50 + s, N * stride + 1, 0.0, 1.0)
         if s == skew_scan:
-            w = np.full(N, 0.01); w[3] = 0.6; w[N - 2] = 0.25; w /= w.sum()
+            w = np.full(N, 0.01)
+            for i, v in heavy.items():
+                w[i] = v
+            w /= w.sum()
             pf.setParticles(w=w)
         st = pf.SLAM(scans[s], u, cur, prev, True, t_icp, normals)
         for r in (0, 1):
@@ -54,11 +56,32 @@ def test_rbpf_two_ranks_one_gpu_equals_unsharded_bit_exact(gpu_pkg):
                 assert parents == pf.trace()["resample_idx"].tolist()
         resampled_any |= bool(st.resampled)
     assert resampled_any
+    assert res[0]["migrated"] + res[1]["migrated"] > 0      # a particle really crossed ranks ...
     pose, prev_pose, w = pf.particles()
     for r in (0, 1):
         sl = slice(r * n_local, (r + 1) * n_local)
         assert np.array_equal(res[r]["pose"], pose[sl]) and np.array_equal(res[r]["prev"], prev_pose[sl])
         assert np.array_equal(res[r]["w"], w[sl])
-        for p in range(n_local):
+        for p in range(n_local):                            # ... and the scans after the resample kept every map equal
             assert np.array_equal(res[r]["lo"][p], pf.logOdds(r * n_local + p))
             assert np.array_equal(res[r]["codes"][p], pf.distCode(r * n_local + p))
+    return res
+
+
+@pytest.mark.parametrize("heavy", [{3: 0.6, 10: 0.25}, {2: 0.35, 5: 0.55}])
+def test_rbpf_two_ranks_one_gpu_equals_unsharded_bit_exact(gpu_pkg, heavy):
+    """Two ranks on one GPU (gloo carries the exchange, the HIP handles do the work), a forced cross-rank resample
+    after the second scan and two more scans.  {2: .35, 5: .55} with 8 particles per rank is the case where an
+    EXPORTED parent (5, sent to rank 1) has its own slot taken over by another local parent (2)."""
+    n_local = 6 if 10 in heavy else 8
+    res = _rbpf_sharded_vs_unsharded(n_local, 8, 1, heavy, "gloo")
+    # a travelling particle is its tiles, not its map: 80 x 80 cells = 9 tiles of 8 KB at most + bitmap + state
+    assert max(res[0]["migrated"], res[1]["migrated"]) < 8 * (9 * 8192 + 4096)
+
+
+def test_rbpf_two_ranks_two_gpus_rccl(gpu_pkg):
+    """The same exchange over RCCL (backend "nccl"), one GPU per rank: device tensors end to end."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the 1-GPU box runs the gloo variant above)")
+    _rbpf_sharded_vs_unsharded(8, 8, 1, {2: 0.35, 5: 0.55}, "nccl")

@@ -1,0 +1,16 @@
+"""Per-phase timing of the proposal and raycast kernels (build csrc with EXTRA=-DTBNAV_PHASE_PROF first; the stamps
+add barriers and atomics, so the numbers compare phases, they are not the bench)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as g
+g.load_package()
+import torch
+import bench_rbpf
+from rtn_amd.rbpf import ParticleFilter, default_params
+steps, scans = bench_rbpf.workload(12)
+pf = ParticleFilter(default_params(N=1000, k=50, map_min=-10.0, map_max=10.0))
+pf.setSeed(1)
+for s, (prev, cur, t_icp, u) in enumerate(steps):
+    pf.SLAM(scans[s], u, cur, prev, True, t_icp, None)
+pf.close()
