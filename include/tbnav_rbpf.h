@@ -173,6 +173,9 @@ int tbnav_rbpf_gather_local(tbnav_rbpf* h, const int32_t* local_parent /*[N], -1
 int tbnav_rbpf_export_size(tbnav_rbpf* h, int32_t slot, uint64_t* bytes);
 int tbnav_rbpf_export_particle_dev(tbnav_rbpf* h, int32_t slot, void* d_buf, uint64_t capacity, uint64_t* bytes);
 int tbnav_rbpf_import_particle_dev(tbnav_rbpf* h, int32_t slot, const void* d_buf, uint64_t bytes);
+/* Particle src_slot of `src` -> dst_slot of `dst` (same device, same grid, same distance-field mode): the deep copy
+ * behind bmapping::GridMapper's value semantics.  In the REFERENCE mode the occupied set travels with its history. */
+int tbnav_rbpf_copy_particle(tbnav_rbpf* dst, int32_t dst_slot, tbnav_rbpf* src, int32_t src_slot);
 
 /* ---- state access: parity hooks and particle migration --------------------------------------- */
 int tbnav_rbpf_get_particles(tbnav_rbpf* h, double* pose, double* prev_pose, double* weight);
@@ -195,6 +198,17 @@ int tbnav_rbpf_get_occupied_count(tbnav_rbpf* h, int32_t* counts /*[N]*/);
 int tbnav_rbpf_get_trace(tbnav_rbpf* h, double* sampled, double* p_scan, double* p_pose, double* mu,
                          double* sigma, double* eta, double* new_pose, double* weight_raw,
                          int32_t* resample_parent);
+
+/* ---- one particle's map on its own: the methods of bmapping::GridMapper (grid_mapper.hpp:128-140) ------------------
+ * The host class bmapping::GridMapper is a one-particle handle driven through these three calls (same kernels as
+ * the filter's per-particle update).  pose = (theta, x, y) of the ROBOT in the map frame.
+ *  integrate_scan : GridMapper::integrateScan (grid_mapper.cpp:140-182) — moves `particle` to `pose`, ray-casts the
+ *                   scan into its map; in the stored-field / REFERENCE modes the distance field is refreshed too.
+ *  likelihood     : GridMapper::likelihoodFieldModel (grid_mapper.cpp:69-133) of the particle's map at `pose`.
+ *  particle_map   : GridMapper::gridMap (grid_mapper.cpp:185-226) of that particle (int8, transposed, G entries). */
+int tbnav_rbpf_integrate_scan(tbnav_rbpf* h, int32_t particle, const float* scan, int32_t n_beams, const double pose[3]);
+int tbnav_rbpf_likelihood(tbnav_rbpf* h, int32_t particle, const float* scan, int32_t n_beams, const double pose[3], double* out);
+int tbnav_rbpf_particle_map(tbnav_rbpf* h, int32_t particle, int8_t* map);
 
 /* ---- options (explicit setters; nothing in the library reads the environment) --------------------------------
  * TBNAV_RBPF_OPT_DF_MODE — where a likelihood lookup gets its distance from.  Must be chosen before the first scan.

@@ -136,6 +136,9 @@ def lib() -> C.CDLL:
         "tbnav_rbpf_create_pool": (C.c_int, [C.POINTER(RbpfParams), u64, C.POINTER(vp)]),
         "tbnav_rbpf_pool_stats": (C.c_int, [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]),
         "tbnav_rbpf_set_option": (C.c_int, [vp, i32, i32]),
+        "tbnav_rbpf_integrate_scan": (C.c_int, [vp, i32, vp, i32, dp]),
+        "tbnav_rbpf_likelihood": (C.c_int, [vp, i32, vp, i32, dp, dp]),
+        "tbnav_rbpf_particle_map": (C.c_int, [vp, i32, vp]),
         "tbnav_rbpf_scan_counts": (C.c_int, [vp, C.POINTER(u64), C.POINTER(u64), i32]),
         "tbnav_rbpf_destroy": (None, [vp]),
         "tbnav_rbpf_grid_size": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32)]),
@@ -152,6 +155,7 @@ def lib() -> C.CDLL:
         "tbnav_rbpf_export_size": (C.c_int, [vp, i32, C.POINTER(u64)]),
         "tbnav_rbpf_export_particle_dev": (C.c_int, [vp, i32, vp, u64, C.POINTER(u64)]),
         "tbnav_rbpf_import_particle_dev": (C.c_int, [vp, i32, vp, u64]),
+        "tbnav_rbpf_copy_particle": (C.c_int, [vp, i32, vp, i32]),
         "tbnav_rbpf_best_state": (C.c_int, [vp, dp, C.POINTER(i32)]),
         "tbnav_rbpf_best_map": (C.c_int, [vp, vp]),
         "tbnav_rbpf_get_particles": (C.c_int, [vp, vp, vp, vp]),

@@ -95,6 +95,7 @@ struct ScanC {  // everything constant during one SLAM call
   double u[3];                   // w, vx, vy
   double d_free, d_occ, cut_occ; // log-odds increments and the host-derived occupied cut-off
   int stride_normals;            // 3k+3 or 3
+  int p0;                        // first particle of the launch (0 for a whole-filter update)
 };
 
 // ---- tiled copy-on-write log-odds maps -------------------------------------------------------------------
@@ -476,6 +477,23 @@ __global__ __launch_bounds__(256) void rbpf_field_by_query(GridC g, int radius, 
   const DistSrc ds{code, bitmap + (size_t)particle * g.xsize * g.words, row_count + (size_t)particle * g.xsize, make_int4(0, 0, 0, 0), 2,
                    nullptr, nullptr, 0, 0, 0, 0};
   code[cell] = nearest_code_query(g, ds, radius, ci, cj);  // a cell out of reach keeps its stored code, like the transform
+}
+
+// GridMapper::likelihoodFieldModel (grid_mapper.cpp:69-133) of ONE particle's map at an arbitrary pose — the host
+// class bmapping::GridMapper's method of that name (tbnav_rbpf_likelihood).  One wave; product in beam order per lane,
+// closed by the wave's butterfly.
+__global__ __launch_bounds__(kWave) void rbpf_likelihood_one(ScanC c, const double2* __restrict__ beams, const uint16_t* __restrict__ codes,
+                                                            const unsigned long long* __restrict__ bitmap, const int* __restrict__ row_count,
+                                                            const int* __restrict__ fstate, int radius, const int* __restrict__ n_occ,
+                                                            double th, double x, double y, double* __restrict__ out, int* __restrict__ err) {
+  const int p = c.p0, lane = threadIdx.x;
+  const DistSrc ds{codes ? codes + (size_t)p * c.g.xsize * c.g.ysize : nullptr, bitmap + (size_t)p * c.g.xsize * c.g.words,
+                   row_count + (size_t)p * c.g.xsize, make_int4(0, c.g.xsize - 1, 0, c.g.ysize - 1), (codes && fstate[p] == 2) ? 0 : 2,
+                   nullptr, nullptr, 0, 0, 0, 0};
+  int oob = 0;
+  const double v = wave_scan_likelihood(c, beams, ds, radius, n_occ[p], th, x, y, lane, &oob);
+  if (oob & 1) atomicOr(&err[0], 1);
+  if (lane == 0) *out = v;
 }
 
 // ---- per-particle scan matcher (SURVEY.md 8-f N1 — an OPTION, not the reference) -----------------------------
@@ -1014,7 +1032,7 @@ __global__ __launch_bounds__(kWave) void rbpf_raycast(ScanC c, TilePool P, MapT 
   int* ey = lds_i + c.Bv;  // [Bv]
   unsigned int* tbits = reinterpret_cast<unsigned int*>(lds_i + 2 * c.Bv);  // [(TT + 31) / 32] tiles this scan writes
   __shared__ int bad;
-  const int p = blockIdx.x, lane = threadIdx.x;
+  const int p = c.p0 + blockIdx.x, lane = threadIdx.x;
   unsigned int* tab = M.table + (size_t)p * M.TT;
   unsigned int* shed = M.shed + (size_t)p * M.TT;
   unsigned long long* bm = bitmap + (size_t)p * c.g.xsize * c.g.words;
@@ -1203,7 +1221,7 @@ __global__ __launch_bounds__(1024, 8) void rbpf_raycast_tile(ScanC c, TilePool P
   __shared__ int bad, bx0, bx1, by0, by1, n_own, srx, sry;
   __shared__ unsigned int mt_id[kMapTilesMax];  // map tiles under the bounding box: 0 = not written by this scan, else the
   //                                               particle's private tile id (phase C)
-  const int p = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave, nw = blockDim.x / kWave;
+  const int p = c.p0 + blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave, nw = blockDim.x / kWave;
   const int nthr = blockDim.x;
 #ifdef TBNAV_PHASE_PROF
   unsigned long long t_prev_ = wall_clock64();
@@ -2249,6 +2267,7 @@ int build_scan_consts(tbnav_rbpf* h, ScanC& c, const float* scan, int n_beams, c
   c.d_occ = h->l_occ - h->l_prior;
   c.cut_occ = h->cut_occ;
   c.stride_normals = icp_ok ? 3 * h->k + 3 : 3;
+  c.p0 = 0;
   // valid beams in the sensor frame, sensor_model.cpp:73-108 (float limits, double angle accumulation)
   beams.clear();
   double beam_angle = P.beam_min;
@@ -2374,14 +2393,15 @@ int ref_field_prepare_log(tbnav_rbpf* h, int Bv, OccLog& log) {
 // After the scan (and its resample, if one fired): replay the logged set changes, run the reference's brushfire for
 // every particle as it was BEFORE the resample (the reference integrates the scan in the particle loop and resamples
 // afterwards, particle_filter.cpp:158-249), copy like the resample did, and make the result the authoritative field.
-int ref_field_after_scan(tbnav_rbpf* h, bool resampled) {
+int ref_field_after_scan(tbnav_rbpf* h, bool resampled, int p_first = 0, int p_count = -1) {
   const int N = h->N;
+  if (p_count < 0) p_count = N;
   { const int rc = ensure_codes(h); if (rc != TBNAV_OK) return rc; }
   TBNAV_HIP(hipStreamSynchronize(h->stream));
   std::vector<int> cnt(N);
   TBNAV_HIP(hipMemcpy(cnt.data(), h->d_log_cnt, sizeof(int) * N, hipMemcpyDeviceToHost));
   std::vector<int> ev;
-  for (int p = 0; p < N; ++p) {
+  for (int p = p_first; p < p_first + p_count; ++p) {
     if (cnt[p] > h->log_cap) return TBNAV_ERR_UNSUPPORTED;  // cannot happen: the log holds every cell update
     ev.resize(cnt[p]);
     if (cnt[p]) TBNAV_HIP(hipMemcpy(ev.data(), h->d_log_ev + (size_t)p * h->log_cap, sizeof(int) * cnt[p], hipMemcpyDeviceToHost));
@@ -2393,10 +2413,54 @@ int ref_field_after_scan(tbnav_rbpf* h, bool resampled) {
     TBNAV_HIP(hipMemcpy(h->h_parent.data(), h->d_parent, sizeof(int) * N, hipMemcpyDeviceToHost));
     h->ref->resample(h->h_parent.data());
   }
-  for (int p = 0; p < N; ++p)
+  if (resampled) { p_first = 0; p_count = N; }
+  for (int p = p_first; p < p_first + p_count; ++p)
     TBNAV_HIP(hipMemcpy(h->d_code[h->cur] + (size_t)p * h->G, h->ref->codes(p), sizeof(uint16_t) * h->G, hipMemcpyHostToDevice));
-  TBNAV_HIP(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(h->d_fstate), 2, N));
+  TBNAV_HIP(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(h->d_fstate + p_first), 2, p_count));
   h->fstate_dirty = true;
+  return TBNAV_OK;
+}
+
+// GridMapper::integrateScan's map update (grid_mapper.cpp:140-178) for particles [c.p0, c.p0 + count) at their poses.
+int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count) {
+  hipStream_t st = h->stream;
+  StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
+  const int bvn = c.Bv > 0 ? c.Bv : 1;
+  const size_t tile_lds = sizeof(int) * kTileIntsPerBeam * bvn + sizeof(unsigned int) * ((size_t)(h->tile_cap + 1) / 2);
+  const MapT M = map_of(h);
+  if (h->tile_cap > 0 && !h->ref_field && c.Bv < 32768 && tile_lds <= (size_t)kMaxLds - 1024)
+    hipLaunchKernelGGL(rbpf_raycast_tile, dim3(count), dim3(h->raycast_threads), tile_lds, st, c, h->pool, M, h->d_beams, sp.pose,
+                       h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_nocc[h->cur], h->d_err, h->tile_cap,
+                       h->count_touched ? h->d_touched : nullptr);
+  else {
+    // beam-ordered kernel: scans the LDS tile cannot hold, and the reference distance-field mode (it logs the
+    // occupied-set changes in the reference's order)
+    OccLog log{nullptr, nullptr, 0};
+    if (h->ref_field) {
+      const int rc2 = ref_field_prepare_log(h, c.Bv, log);
+      if (rc2 != TBNAV_OK) return rc2;
+    }
+    hipLaunchKernelGGL(rbpf_raycast, dim3(count), dim3(kWave), sizeof(int) * (2 * bvn + (h->TT + 31) / 32), st, c, h->pool, M, h->d_beams,
+                       sp.pose, h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_nocc[h->cur], h->d_err, log);
+  }
+  TBNAV_HIP(hipGetLastError());
+  return TBNAV_OK;
+}
+
+// the scan's valid beams into d_beams (shared by slam_impl and the one-particle entry points)
+int upload_beams(tbnav_rbpf* h, const std::vector<double2>& beams, int n_beams, int Bv) {
+  if (n_beams > h->max_beams) {
+    (void)hipFree(h->d_beams);
+    (void)hipHostFree(h->h_beams);
+    h->d_beams = nullptr; h->h_beams = nullptr; h->max_beams = 0;
+    TBNAV_HIP(hipMalloc((void**)&h->d_beams, sizeof(double2) * n_beams));
+    TBNAV_HIP(hipHostMalloc((void**)&h->h_beams, sizeof(double2) * n_beams, hipHostMallocDefault));
+    h->max_beams = n_beams;
+  }
+  if (Bv) {
+    std::memcpy(h->h_beams, beams.data(), sizeof(double2) * Bv);
+    TBNAV_HIP(hipMemcpyAsync(h->d_beams, h->h_beams, sizeof(double2) * Bv, hipMemcpyHostToDevice, h->stream));
+  }
   return TBNAV_OK;
 }
 
@@ -2414,24 +2478,14 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
   std::memset(out, 0, sizeof *out);
   if (rc != TBNAV_OK) { out->status = rc; return rc; }
   out->n_valid_beams = c.Bv;
-  if (n_beams > h->max_beams) {
-    (void)hipFree(h->d_beams);
-    (void)hipHostFree(h->h_beams);
-    h->d_beams = nullptr; h->h_beams = nullptr; h->max_beams = 0;
-    TBNAV_HIP(hipMalloc((void**)&h->d_beams, sizeof(double2) * n_beams));
-    TBNAV_HIP(hipHostMalloc((void**)&h->h_beams, sizeof(double2) * n_beams, hipHostMallocDefault));
-    h->max_beams = n_beams;
-  }
+  rc = upload_beams(h, beams, n_beams, c.Bv);
+  if (rc != TBNAV_OK) return rc;
   const size_t n_norm = (size_t)h->N * c.stride_normals + 1;
   if (n_norm > h->normals_cap) {
     (void)hipFree(h->d_normals);
     h->d_normals = nullptr;
     TBNAV_HIP(hipMalloc((void**)&h->d_normals, sizeof(double) * n_norm));
     h->normals_cap = n_norm;
-  }
-  if (c.Bv) {
-    std::memcpy(h->h_beams, beams.data(), sizeof(double2) * c.Bv);
-    TBNAV_HIP(hipMemcpyAsync(h->d_beams, h->h_beams, sizeof(double2) * c.Bv, hipMemcpyHostToDevice, st));
   }
   if (normals) {
     TBNAV_HIP(hipMemcpyAsync(h->d_normals, normals, sizeof(double) * n_norm, hipMemcpyHostToDevice, st));
@@ -2522,27 +2576,8 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
     if (rc != TBNAV_OK) return rc;
     TBNAV_HIP(hipEventRecord(h->ev_n, h->stream2));
   }
-  {
-    const int bvn = c.Bv > 0 ? c.Bv : 1;
-    const size_t tile_lds = sizeof(int) * kTileIntsPerBeam * bvn + sizeof(unsigned int) * ((size_t)(h->tile_cap + 1) / 2);
-    const MapT M = map_of(h);
-    if (h->tile_cap > 0 && !h->ref_field && c.Bv < 32768 && tile_lds <= (size_t)kMaxLds - 1024)
-      hipLaunchKernelGGL(rbpf_raycast_tile, dim3(h->N), dim3(h->raycast_threads), tile_lds, st, c, h->pool, M, h->d_beams, sp.pose,
-                         h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_nocc[h->cur], h->d_err, h->tile_cap,
-                         h->count_touched ? h->d_touched : nullptr);
-    else {
-      // beam-ordered kernel: scans the LDS tile cannot hold, and the reference distance-field mode (it logs the
-      // occupied-set changes in the reference's order)
-      OccLog log{nullptr, nullptr, 0};
-      if (h->ref_field) {
-        const int rc2 = ref_field_prepare_log(h, c.Bv, log);
-        if (rc2 != TBNAV_OK) return rc2;
-      }
-      hipLaunchKernelGGL(rbpf_raycast, dim3(h->N), dim3(kWave), sizeof(int) * (2 * bvn + (h->TT + 31) / 32), st, c, h->pool, M, h->d_beams,
-                         sp.pose, h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_nocc[h->cur], h->d_err, log);
-    }
-  }
-  TBNAV_HIP(hipGetLastError());
+  rc = launch_raycast(h, c, h->N);
+  if (rc != TBNAV_OK) return rc;
   if (h->timing) TBNAV_HIP(hipEventRecord(h->ev[3], st));
   if (h->full_edt) {
     // legacy placement (TBNAV_RBPF_FULL_EDT=1): whole field of every particle right after the map update,
@@ -3080,6 +3115,22 @@ int tbnav_rbpf_import_particle_dev(tbnav_rbpf* h, int32_t slot, const void* d_bu
   return TBNAV_OK;
 }
 
+int tbnav_rbpf_copy_particle(tbnav_rbpf* dst, int32_t dst_slot, tbnav_rbpf* src, int32_t src_slot) {
+  if (!dst || !src || dst_slot < 0 || dst_slot >= dst->N || src_slot < 0 || src_slot >= src->N) return TBNAV_ERR_INVALID_ARG;
+  if (dst->xsize != src->xsize || dst->ref_field != src->ref_field || dst->device != src->device) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(src->device);
+  uint64_t bytes = 0;
+  int rc = tbnav_rbpf_export_size(src, src_slot, &bytes);
+  if (rc != TBNAV_OK) return rc;
+  void* buf = nullptr;
+  TBNAV_HIP(hipMalloc(&buf, bytes));
+  rc = tbnav_rbpf_export_particle_dev(src, src_slot, buf, bytes, nullptr);
+  if (rc == TBNAV_OK) rc = tbnav_rbpf_import_particle_dev(dst, dst_slot, buf, bytes);
+  (void)hipFree(buf);
+  if (rc == TBNAV_OK && src->ref_field) dst->ref->copy_slot(dst_slot, *src->ref, src_slot);  // the set with its history, the field with its stale cells
+  return rc;
+}
+
 int tbnav_rbpf_get_particles(tbnav_rbpf* h, double* pose, double* prev_pose, double* weight) {
   if (!h) return TBNAV_ERR_INVALID_ARG;
   DeviceGuard guard(h->device);
@@ -3258,6 +3309,69 @@ int tbnav_rbpf_get_scan_match(tbnav_rbpf* h, double* centers, double* scores) {
   TBNAV_HIP(hipStreamSynchronize(h->stream));
   if (centers) TBNAV_HIP(hipMemcpy(centers, h->d_center, sizeof(double) * 3 * h->N, hipMemcpyDeviceToHost));
   if (scores) TBNAV_HIP(hipMemcpy(scores, h->d_score, sizeof(double) * h->N, hipMemcpyDeviceToHost));
+  return TBNAV_OK;
+}
+
+// ---- one particle's GridMapper, for the host class bmapping::GridMapper (grid_mapper.hpp:128-140) ---------------
+namespace {
+int one_particle_consts(tbnav_rbpf* h, int32_t particle, const float* scan, int32_t n_beams, ScanC& c) {
+  const double zero[3] = {0.0, 0.0, 0.0};
+  std::vector<double2> beams;
+  int rc = build_scan_consts(h, c, scan, n_beams, zero, zero, zero, 1, zero, beams);
+  if (rc != TBNAV_OK) return rc;
+  c.p0 = particle;
+  return upload_beams(h, beams, n_beams, c.Bv);
+}
+}  // namespace
+
+int tbnav_rbpf_integrate_scan(tbnav_rbpf* h, int32_t particle, const float* scan, int32_t n_beams, const double pose[3]) {
+  if (!h || !scan || n_beams <= 0 || !pose || particle < 0 || particle >= h->N) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  ++h->scans_done;
+  ScanC c;
+  int rc = one_particle_consts(h, particle, scan, n_beams, c);
+  if (rc != TBNAV_OK) return rc;
+  StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
+  TBNAV_HIP(hipStreamSynchronize(h->stream));
+  TBNAV_HIP(hipMemcpy(sp.pose + (size_t)particle * 3, pose, sizeof(double) * 3, hipMemcpyHostToDevice));
+  for (int q = 0; q < 4; ++q) h->h_err[q] = 0;
+  rc = launch_raycast(h, c, 1);
+  if (rc != TBNAV_OK) return rc;
+  const int zero = 0;  // the map changed: a stored field of this particle is stale
+  TBNAV_HIP(hipMemcpyAsync(h->d_fstate + particle, &zero, sizeof zero, hipMemcpyHostToDevice, h->stream));
+  TBNAV_HIP(hipStreamSynchronize(h->stream));
+  rc = status_from_err(h->h_err);
+  if (rc != TBNAV_OK) return rc;
+  if (h->ref_field) return ref_field_after_scan(h, false, particle, 1);
+  if (h->df_mode != 2) return ensure_full_field(h, particle);  // stored-field modes: the whole field after the update
+  return TBNAV_OK;
+}
+
+int tbnav_rbpf_likelihood(tbnav_rbpf* h, int32_t particle, const float* scan, int32_t n_beams, const double pose[3], double* out) {
+  if (!h || !scan || n_beams <= 0 || !pose || !out || particle < 0 || particle >= h->N) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  ScanC c;
+  int rc = one_particle_consts(h, particle, scan, n_beams, c);
+  if (rc != TBNAV_OK) return rc;
+  for (int q = 0; q < 4; ++q) h->h_err[q] = 0;
+  hipLaunchKernelGGL(rbpf_likelihood_one, dim3(1), dim3(kWave), 0, h->stream, c, h->d_beams, h->d_code[h->cur], h->d_bitmap[h->cur],
+                     h->d_rowcount[h->cur], h->d_fstate, h->radius, h->d_nocc[h->cur], pose[0], pose[1], pose[2], h->d_score, h->d_err);
+  TBNAV_HIP(hipGetLastError());
+  TBNAV_HIP(hipMemcpyAsync(out, h->d_score, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  TBNAV_HIP(hipStreamSynchronize(h->stream));
+  return status_from_err(h->h_err);
+}
+
+int tbnav_rbpf_particle_map(tbnav_rbpf* h, int32_t particle, int8_t* map) {
+  if (!h || !map || particle < 0 || particle >= h->N) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  hipStream_t st = h->stream;
+  TBNAV_HIP(hipMemcpyAsync(h->d_best, &particle, sizeof(int), hipMemcpyHostToDevice, st));
+  const int blocks = (int)std::min<size_t>((h->G + 255) / 256, 2048);
+  hipLaunchKernelGGL(rbpf_export_map, dim3(blocks), dim3(256), 0, st, h->xsize, h->G, h->cuts, h->d_best, h->pool, map_of(h), h->d_export);
+  TBNAV_HIP(hipGetLastError());
+  TBNAV_HIP(hipMemcpyAsync(map, h->d_export, h->G, hipMemcpyDeviceToHost, st));
+  TBNAV_HIP(hipStreamSynchronize(st));
   return TBNAV_OK;
 }
 

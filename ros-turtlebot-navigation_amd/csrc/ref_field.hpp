@@ -54,6 +54,12 @@ class RefField {
     sets_[p] = std::unordered_set<int>();
     for (int c : cells_ascending) sets_[p].insert(c);
   }
+  // One particle of another filter, copied the way a GridMapper is copied (std::unordered_set's copy constructor keeps
+  // the iteration order and bucket layout, so the copy behaves like the original from here on).
+  void copy_slot(int p, const RefField& from, int q) {
+    sets_[p] = std::unordered_set<int>(from.sets_[q]);  // copy-construct (as GridMapper's copy does), then move in
+    codes_[p] = from.codes_[q];
+  }
   void set_codes(int p, const uint16_t* codes) { codes_[p].assign(codes, codes + codes_[p].size()); }
 
   // euclideanSignedDistanceField, grid_mapper.cpp:333-435

@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 
+#include "bmapping/grid_mapper.hpp"
 #include "bmapping/particle_filter.hpp"
 #include "controller/mppi.hpp"
 #include "rigid2d/diff_drive.hpp"
@@ -203,6 +204,50 @@ int hst_pf_run(int N, int k, double map_half, uint64_t seed, const float* scans,
     int xs = 0; while ((size_t)xs * xs < map.size()) ++xs;
     return xs;
   } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+
+
+// ---- bmapping::GridMapper / LaserScanner (host class over a one-particle handle) ---------------------------------
+// grid = (res, xmin, xmax, ymin, ymax); laser = 5 floats (beam_min, beam_max, beam_delta, range_min, range_max);
+// mix = (z_hit, z_short, z_max, z_rand, sigma_hit); trs / pose = (theta, x, y)
+void* hst_gm_create(const double grid[5], const float laser[5], const double mix[5], const double trs[3], int reference_field) {
+  try {
+    bmapping::LaserProperties props(laser[0], laser[1], laser[2], laser[3], laser[4], mix[0], mix[1], mix[2], mix[3], mix[4]);
+    auto* g = new bmapping::GridMapper(grid[0], grid[1], grid[2], grid[3], grid[4], props, make_T(trs));
+    if (reference_field) g->useReferenceDistanceField(true);
+    return g;
+  } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+void hst_gm_destroy(void* g) { delete static_cast<bmapping::GridMapper*>(g); }
+void* hst_gm_clone(void* g) {
+  try { return new bmapping::GridMapper(*static_cast<bmapping::GridMapper*>(g)); }
+  catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+int hst_gm_integrate_scan(void* g, const float* scan, int n, const double pose[3]) {
+  try { static_cast<bmapping::GridMapper*>(g)->integrateScan(std::vector<float>(scan, scan + n), make_T(pose)); return 0; }
+  catch (const std::invalid_argument& e) { g_err = e.what(); return 1; }
+  catch (const std::exception& e) { g_err = e.what(); return 2; }
+}
+int hst_gm_likelihood(void* g, const float* scan, int n, const double pose[3], double* out) {
+  try { *out = static_cast<const bmapping::GridMapper*>(g)->likelihoodFieldModel(std::vector<float>(scan, scan + n), make_T(pose)); return 0; }
+  catch (const std::invalid_argument& e) { g_err = e.what(); return 1; }
+  catch (const std::exception& e) { g_err = e.what(); return 2; }
+}
+int hst_gm_grid_map(void* g, int8_t* out, int cap) {
+  try {
+    std::vector<int8_t> m;
+    static_cast<const bmapping::GridMapper*>(g)->gridMap(m);
+    if ((int)m.size() > cap) return -1;
+    std::memcpy(out, m.data(), m.size());
+    return (int)m.size();
+  } catch (const std::exception& e) { g_err = e.what(); return -2; }
+}
+int hst_gm_end_points(void* g, const float* scan, int n, const double pose[3], double* xy /*[n][2]*/) {
+  std::vector<Vector2D> pts;
+  const bmapping::LaserScanner* s = static_cast<const bmapping::GridMapper*>(g);
+  s->laserEndPoints(pts, std::vector<float>(scan, scan + n), make_T(pose));
+  for (size_t i = 0; i < pts.size(); ++i) { xy[2 * i] = pts[i].x; xy[2 * i + 1] = pts[i].y; }
+  return (int)pts.size() == (int)s->numberValidMeasurements(std::vector<float>(scan, scan + n)) ? (int)pts.size() : -1;
 }
 
 }  // extern "C"

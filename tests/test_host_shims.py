@@ -194,3 +194,63 @@ def test_particle_filter_class_surface_end_to_end(host, gpu_pkg):
     agree = np.mean(m == pf.grid(pf.best()).grid_map())
     print(f"\n[pf class surface] Neff {out_neff.tolist()}, exported map agreement {agree*100:.2f} %")
     assert agree >= 0.99
+
+
+def test_node_call_sites_compile_against_these_headers():
+    """host/test/node_calls.cpp spells every call turtle_mapping_node.cpp / mppi_waypoints_node.cpp make on the hot-path
+    classes; build() compiles it (host/Makefile), so the object must be there and newer than the headers' users."""
+    obj = os.path.join(ROOT, "ros-turtlebot-navigation_amd", "lib", "obj", "node_calls.o")
+    assert os.path.exists(obj), "run __graft_entry__.build()"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("reference_field", [0, 1])
+def test_grid_mapper_class_surface_against_the_oracle(host, gpu_pkg, reference_field):
+    """bmapping::GridMapper as a class of its own (grid_mapper.hpp:128-140): integrateScan / likelihoodFieldModel /
+    gridMap / laserEndPoints / value copies, against the oracle's GridMapper (pinned to the compiled reference).
+    With useReferenceDistanceField() the likelihood is the reference's to 1e-9; by default (exact field) it is close."""
+    host.hst_gm_create.restype = C.c_void_p
+    host.hst_gm_clone.restype = C.c_void_p
+    grid = _arr([0.05, -2.0, 2.0, -2.0, 2.0]); laser = orc.lds01_laser(); trs = _arr([0.0, 0.0, 0.0])
+    g = C.c_void_p(host.hst_gm_create(_p(grid), _p(laser), _p(orc.MIX), _p(trs), reference_field))
+    assert g.value, host.hst_last_error()
+    o = orc.GridAPI("orc", grid=tuple(grid))
+    steps, poses = rc.trajectory(4, inc=(0.04, 0.03, 0.02))
+    rng = np.random.default_rng(4)
+    lik = C.c_double()
+    for s in range(4):
+        scan = orc.room_scan(poses[s], walls=rc.ROOM_SMALL, rng=rng)
+        pose = _arr(poses[s])
+        probe = _arr(poses[s] + np.array([0.01, 0.02, -0.015]))
+        assert host.hst_gm_likelihood(g, _p(scan), 360, _p(probe), C.byref(lik)) == 0, host.hst_last_error()
+        want, err = o.likelihood(scan, probe)
+        assert err == 0
+        if reference_field or s == 0:
+            assert abs(lik.value - want) <= 1e-9 * abs(want), (s, lik.value, want)
+        else:
+            assert abs(lik.value - want) <= 0.05 * abs(want), (s, lik.value, want)
+        xy = np.empty((360, 2))
+        n = host.hst_gm_end_points(g, _p(scan), 360, _p(pose), _p(xy))
+        assert n == 360 and np.array_equal(xy[:n], o.end_points(scan, pose))          # LaserScanner::laserEndPoints, bit-exact
+        assert host.hst_gm_integrate_scan(g, _p(scan), 360, _p(pose)) == 0, host.hst_last_error()
+        o.integrate_scan(scan, pose)
+        m = np.empty(80 * 80, dtype=np.int8)
+        assert host.hst_gm_grid_map(g, _p(m), m.size) == m.size
+        assert np.array_equal(m, o.grid_map())                                        # gridMap, bit-exact
+    # value semantics: a copy maps on its own
+    g2 = C.c_void_p(host.hst_gm_clone(g)); o2 = o.clone()
+    scan = orc.room_scan(poses[3], walls=rc.ROOM_SMALL, rng=rng)
+    assert host.hst_gm_integrate_scan(g2, _p(scan), 360, _p(_arr(poses[3]))) == 0
+    o2.integrate_scan(scan, poses[3])
+    m2 = np.empty(80 * 80, dtype=np.int8); m1 = np.empty(80 * 80, dtype=np.int8)
+    host.hst_gm_grid_map(g2, _p(m2), m2.size); host.hst_gm_grid_map(g, _p(m1), m1.size)
+    assert np.array_equal(m2, o2.grid_map()) and np.array_equal(m1, o.grid_map()) and not np.array_equal(m1, m2)
+    if reference_field:
+        assert host.hst_gm_likelihood(g2, _p(scan), 360, _p(_arr(poses[3])), C.byref(lik)) == 0
+        want, _ = o2.likelihood(scan, poses[3])
+        assert abs(lik.value - want) <= 1e-9 * abs(want)
+    # the reference's exception, as an exception
+    far = np.full(360, 3.0, dtype=np.float32)
+    assert host.hst_gm_integrate_scan(g, _p(far), 360, _p(_arr([0.0, 1.5, 1.5]))) == 1
+    assert b"NOT in the bounds of the world" in host.hst_last_error()
+    host.hst_gm_destroy(g); host.hst_gm_destroy(g2); o.close(); o2.close()
