@@ -254,3 +254,48 @@ def test_grid_mapper_class_surface_against_the_oracle(host, gpu_pkg, reference_f
     assert host.hst_gm_integrate_scan(g, _p(far), 360, _p(_arr([0.0, 1.5, 1.5]))) == 1
     assert b"NOT in the bounds of the world" in host.hst_last_error()
     host.hst_gm_destroy(g); host.hst_gm_destroy(g2); o.close(); o2.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("odometry_mode", [0, 1])
+def test_closed_loop_tick_sequence_equals_the_oracle_loop(host, gpu_pkg, odometry_mode):
+    """SURVEY.md 8-f N3 as PARITY, not only as a property: the first 200 ticks of the closed loop
+    (mppi_waypoints_node.cpp:226-305: waypoint switch -> newControls -> wheelsToTwist -> plant feedforward(twist / 60)
+    [-> wrapped encoders -> updateOdometry]) on the HIP path, against the same loop run with the oracle (MPPI restatement
+    + the DiffDrive restatement that is pinned bit-exact to the reference build), both consuming the same seeded
+    mt19937_64 stream.  Controls and poses tick by tick within 1e-9."""
+    d = dict(MPPI_BASE, rollouts=64)  # BASELINE configs[0]: K=64, T=25
+    K, T, n_ticks, seed, rate, goal = 64, 25, 200, 3, 60.0, 0.05
+    wp = _arr(WAYPOINTS).copy()
+    traj = np.zeros((n_ticks, 5)); reached = C.c_int(); dev = C.c_double()
+    ticks = host.hst_mppi_closed_loop(_p(_mppi_params(d)), K, C.c_uint64(seed), _p(wp), 5, C.c_double(goal), C.c_double(rate),
+                                      n_ticks, _p(traj), C.byref(reached), C.c_int(odometry_mode), C.byref(dev))
+    assert ticks == n_ticks, host.hst_last_error()
+    # ---- the oracle's loop
+    r = orc.RigidAPI("orc")
+    start = [wp[0][2], wp[0][0], wp[0][1]]  # (theta, x, y)
+    plant, odometer, model = (r.dd_create(start, d["wheel_base"], d["wheel_radius"]) for _ in range(3))
+    stream = orc.normal_stream(seed, n_ticks * K * T * 2, 0.0, np.sqrt(d["ul_var"])).reshape(n_ticks, K, T, 2)
+    u = np.zeros((2, T))
+    target, n_reached = 1, 0
+    worst_u = worst_pose = 0.0
+    for t in range(n_ticks):
+        st = r.dd_state(odometer if odometry_mode else plant)
+        th, x, y = st[0], st[1], st[2]
+        if np.sqrt((x - wp[target][0]) ** 2 + (y - wp[target][1]) ** 2) < goal:
+            n_reached += 1
+            target = (target + 1) % 5
+        ref = orc.mppi_new_controls(d, u, (0.0, 0.0), tuple(wp[target]), (x, y, th), stream[t])
+        u = ref["u"]
+        cmd = r.dd_wheels_to_twist(model, ref["out"])
+        assert r.dd_feedforward(plant, [cmd[0] / rate, cmd[1] / rate, 0.0]) == 0
+        ps = r.dd_state(plant)
+        if odometry_mode:
+            r.dd_update_odometry(odometer, ps[3], ps[4])
+        worst_u = max(worst_u, float(np.max(np.abs(traj[t, 3:5] - ref["out"]) / np.maximum(np.abs(ref["out"]), 1e-3))))
+        worst_pose = max(worst_pose, float(np.max(np.abs(traj[t, :3] - np.array([ps[1], ps[2], ps[0]])))))
+    print(f"\n[closed loop vs oracle, odometry_mode={odometry_mode}] {n_ticks} ticks: max rel. control diff {worst_u:.2e}, max pose diff {worst_pose:.2e}")
+    assert worst_u <= 1e-9 and worst_pose <= 1e-9
+    assert n_reached == reached.value
+    for dd in (plant, odometer, model):
+        r.dd_destroy(dd)
