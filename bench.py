@@ -4,18 +4,22 @@
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one MPPI control tick (controller::MPPI::newControls, mppi.cpp:72-140) over one batch
-of synthetic control noise that is already resident in HBM when the timed region starts.
-Workload at every N: BASELINE.json configs[1] per GPU — K=1024 rollouts, T=50 steps, shipped
-controller parameters — so N>1 is weak scaling (global K = N*1024) with ONE all-gather of the
-per-time-step soft-min records per tick (RCCL).  value = rollouts/s = N*K*steps / max-over-ranks
-time.  Extra objects on the same JSON line:
-  roofline        dominant kernel of the timed workload (mppi_rollout_cost) vs the HBM roofline
-  roofline_large  same kernel set on BASELINE configs[3]'s per-call size on ONE GPU (K=65536, T=100),
+A "step" is one MPPI control tick (controller::MPPI::newControls, mppi.cpp:72-140) INCLUDING its Gaussian control-noise
+sampling (mppi.cpp:173-184), which is part of the path: the perturbations of every tick are drawn on the device inside
+the rollout kernel.  Only the 2*T warm-start controls are resident when the timed region starts.
+Workload at every N: BASELINE.json configs[1] per GPU — K=1024 rollouts, T=50 steps, shipped controller parameters — so
+N>1 is weak scaling (global K = N*1024) with ONE all-gather of the per-time-step soft-min records per tick (RCCL).
+value = rollouts/s = N*K*steps / max-over-ranks time.  Extra objects on the same JSON line:
+  roofline        dominant kernel of the timed workload vs the HBM roofline (per-kernel times: HIP events on the launch stream)
+  latency_floor   what two dependent launches cost by themselves (the K=1024 tick is latency-bound, not HBM-bound)
+  roofline_large  the kernel set of BASELINE configs[3]'s per-call size on ONE GPU (K=65536, T=100, resident noise),
                   where the path actually streams from HBM (315 MB algorithmic per tick)
-  cpu_baseline    the oracle port (oracle/mppi_oracle.cpp, 1 core) on the same workload, rank 0, N=1
-  rbpf            secondary headline: RBPF particle-updates/s (BASELINE configs[2]) when built
-Only the cpu_baseline leg touches oracle/.
+  options         the same tick with resident noise; the exact-arc dynamics option
+  cpu_baseline / cpu_baseline_all_cores   the oracle port (oracle/mppi_oracle.cpp) on 1 core / all host cores (OpenMP)
+  rbpf            secondary headline: RBPF particle-updates/s (BASELINE configs[2]), bench_rbpf.py
+  N > 1 only:     strong_scaling_configs3 (K=65536 split N ways), rbpf_sharded (1000 particles per rank with
+                  cross-rank particle migration in the timed region)
+Only the cpu_baseline legs touch oracle/.
 """
 from __future__ import annotations
 
@@ -33,6 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
+PMC_FILE = "r02_traffic_pmc.json"  # rocprofv3 --pmc passes of this round's final build (tools/collect_pmc.sh)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_ROLLOUT_STEP = 48.0          # rollout pass 16 B noise + 8 B J; weighting 8 B J + 16 B noise
 BYTES_ROLLOUT_KERNEL = 24.0            # of which the rollout/cost kernel: reads duL,duR (16 B), writes J (8 B)
@@ -47,7 +52,7 @@ def make_mppi(K, horizon, device):
     from rtn_amd.mppi import MPPI, CartModel, LossFunc
     m = MPPI(CartModel(SHIPPED["wheel_radius"], SHIPPED["wheel_base"]),
              LossFunc(SHIPPED["Q"], SHIPPED["R"], SHIPPED["P1"]), SHIPPED["lam"], SHIPPED["max_wheel_vel"],
-             SHIPPED["ul_var"], SHIPPED["ur_var"], horizon, SHIPPED["dt"], K, device)
+             SHIPPED["ul_var"], SHIPPED["ur_var"], horizon, SHIPPED["dt"], K, device, keep_j=False)
     m.setWaypoint(*WAYPOINT)
     return m
 
@@ -93,7 +98,7 @@ def pmc_traffic(workload_key, kernel_prefix):
     """HBM bytes per launch of a kernel from the committed PMC passes (profiles/r01_traffic_pmc.json:
     separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 read correction calibrated on a known byte count)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")) as f:
+        with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
             wl = json.load(f)["workloads"][workload_key]
         for name, v in wl.items():
             if name.startswith(kernel_prefix):
@@ -111,7 +116,7 @@ def roofline_obj(K, T, ms_kernels, ms_tick, kernel_name, traffic_key=None):
         "bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
         "traffic": pmc_traffic(traffic_key, kernel_name.split("<")[0]) if traffic_key else None,
-        "traffic_source": "profiles/r01_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" if traffic_key else None,
+        "traffic_source": f"profiles/{PMC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" if traffic_key else None,
         "algorithmic_bytes_per_launch": alg,
         "kernel_ms": {"rollout": round(float(ms_kernels[0]), 6), "partials": round(float(ms_kernels[1]), 6),
                       "combine": round(float(ms_kernels[2]), 6)},
@@ -120,11 +125,19 @@ def roofline_obj(K, T, ms_kernels, ms_tick, kernel_name, traffic_key=None):
     }
 
 
-def cpu_baseline(K, T, horizon, budget_s=12.0):
-    """oracle port (kind 'port'), 1 core, same workload: ticks of K rollouts x T steps with state
-    carried, noise pre-drawn (sampling excluded on both sides)."""
+def cpu_baseline(K, T, horizon, budget_s=12.0, threads=1):
+    """oracle port (kind 'port'), same workload: ticks of K rollouts x T steps with state carried, noise pre-drawn
+    (sampling excluded on the CPU side).  threads > 1: the rollout loop under OpenMP."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_api as orc
+    orc.lib().orc_set_threads(int(threads))
+    try:
+        return _cpu_baseline(orc, K, T, horizon, budget_s, threads)
+    finally:
+        orc.lib().orc_set_threads(1)
+
+
+def _cpu_baseline(orc, K, T, horizon, budget_s, threads):
     d = dict(SHIPPED, horizon=horizon, rollouts=K)
     rng = np.random.default_rng(0)
     noise = rng.standard_normal((K, T, 2)) * np.sqrt(SHIPPED["ul_var"])
@@ -137,8 +150,9 @@ def cpu_baseline(K, T, horizon, budget_s=12.0):
         el = time.perf_counter() - t0
         if el > budget_s or n >= 2000:
             break
-    return {"value": round(n * K / el, 1), "unit": "rollouts/s", "cores": 1, "kind": "port",
-            "sample": f"{n} ticks of K={K}, T={T} (oracle/mppi_oracle.cpp, g++ -O2, 1 thread, noise pre-drawn)",
+    import bench_rbpf
+    return {"value": round(n * K / el, 1), "unit": "rollouts/s", "cores": int(threads), "kind": "port", "cpu": bench_rbpf._cpu_model(),
+            "sample": f"{n} ticks of K={K}, T={T} (oracle/mppi_oracle.cpp, g++ -O2, {threads} thread(s), noise pre-drawn)",
             "ms_per_tick": round(el / n * 1e3, 4)}
 
 
@@ -157,8 +171,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    # dev switch: exercise the multi-rank path on a ONE-GPU box (all ranks on cuda:0, gloo exchange);
-    # the real run is one rank per GPU over RCCL.
+    # dev switch of THIS SCRIPT (not of the library): exercise the multi-rank path on a ONE-GPU box (all ranks on
+    # cuda:0, gloo exchange); the real run is one rank per GPU over RCCL.
     one_gpu_test = os.environ.get("TBNAV_BENCH_ONE_GPU_GLOO") == "1"
     if one_gpu_test:
         local_rank = 0
@@ -166,6 +180,7 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if one_gpu_test:
             dist.init_process_group("gloo")
         else:
@@ -177,19 +192,27 @@ def main():
 
     K, horizon = 1024, 0.5  # BASELINE configs[1] per GPU
     m = make_mppi(K, horizon, local_rank)
+    m.setRngShard(rank * K, world * K)
     T = m.steps
     a, b = synth_noise(T, K, device, 1234 + rank)
     stream = torch.cuda.current_stream(device).cuda_stream
+    SEED = 42
+    tk = [0]
 
+    # THE TIMED STEP = the production tick: the Gaussian control-noise sampling is part of the path (north_star), so
+    # the perturbations of every tick are drawn on the device, inside the fused rollout kernel (Philox); nothing is
+    # resident beforehand but the 2*T warm-start controls.
     if world == 1:
         def tick():
-            m.enqueueDev(X0, a.data_ptr(), b.data_ptr(), stream)
+            m.enqueueRng(X0, SEED, tk[0], stream)
+            tk[0] += 1
         barrier = lambda: None  # noqa: E731
     else:
         sm = ShardedMPPI(HipShardBackend(m, device))
 
         def tick():
-            sm.tick(X0, (a.data_ptr(), b.data_ptr()))
+            sm.tick(X0, ("rng", SEED, tk[0]))
+            tk[0] += 1
 
         def barrier():
             dist.barrier()
@@ -203,14 +226,18 @@ def main():
     out_controls = m.lastControls(stream)
     assert all(np.isfinite(out_controls)), out_controls
 
+    extra = {}
+    if world > 1:
+        extra = multi_gpu_legs(world, rank, local_rank, device, one_gpu_test, stream, sync, barrier)
+
     if rank == 0:
         ms_step = el / args.steps * 1e3
         value = world * K * args.steps / el
         ms_k = kernel_profile(m, a, b, stream, min(args.steps, 500))
         # one synchronous tick (launch + wait + 16-byte D2H), the latency a control loop sees
         t0 = time.perf_counter()
-        for _ in range(200):
-            m.newControlsDev(X0, a.data_ptr(), b.data_ptr(), stream)
+        for i in range(200):
+            m.newControlsRng(X0, SEED, 10_000_000 + i, stream)
         sync_ms = (time.perf_counter() - t0) / 200 * 1e3
         line = {
             "metric": "MPPI rollouts/s", "value": round(value, 1), "unit": "rollouts/s", "n_gpus": world,
@@ -218,12 +245,18 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"MPPI newControls K={K} per GPU, T={T} (BASELINE configs[1]); global K={world * K}",
-                       "noise": "resident in HBM, [T][K] fp64 x2", "state_carried": True,
+                       "noise": "drawn on the device inside the timed tick (Philox4x32-10 + Box-Muller, in the rollout kernel)",
+                       "state_carried": True,
                        "parallelism": f"rollout-shard x{world}" + (", 1 all-gather of soft-min records/tick" if world > 1 else "")},
             "rollout_steps_per_s": round(value * T, 1),
             "sync_tick_ms": round(sync_ms, 6),
             "roofline": roofline_obj(K, T, ms_k, ms_step, m.rollout_kernel, "mppi_K1024_T50" if (K, T) == (1024, 50) else None),
+            # the tick is two dependent launches: what the guide prices for that alone (MI355X_MICROARCH.md, "boundary" row)
+            "latency_floor": {"dependent_launches_per_tick": 2, "boundary_us_each": [1.45, 1.9],
+                              "note": "K*T*48 B = 2.46 MB lives in L2: the tick is launch / dependent-latency bound, not HBM bound; "
+                                      "kernel_ms are back-to-back launch averages and already contain one boundary each"},
         }
+        line.update(extra)
         if world == 1 and not args.no_large:
             KL, HL = 65536, 1.0  # BASELINE configs[3] per-call size, on one GPU
             ml = make_mppi(KL, HL, local_rank)
@@ -232,42 +265,95 @@ def main():
             el_l = time_ticks(tl, sync, 50, 10, lambda: None)
             ms_l = kernel_profile(ml, al, bl, stream, 50)
             rl = roofline_obj(KL, ml.steps, ms_l, el_l / 50 * 1e3, ml.rollout_kernel, "mppi_K65536_T100")
-            rl["workload"] = f"MPPI newControls K={KL}, T={ml.steps} on 1 GPU"
+            rl["workload"] = f"MPPI newControls K={KL}, T={ml.steps} on 1 GPU, noise resident in HBM (the streaming regime)"
             rl["rollouts_per_s"] = round(KL * 50 / el_l, 1)
             line["roofline_large"] = rl
             ml.close()
         if world == 1:
-            # the exact-arc dynamics option, same workload, same timing as `value`
+            n_a = min(args.steps, 1000)
+            # the same tick with the perturbations already resident in HBM ([T][K] fp64 x2): the parity-mode data flow
+            el_r = time_ticks(lambda: m.enqueueDev(X0, a.data_ptr(), b.data_ptr(), stream), sync, n_a, min(args.warmup, 100), lambda: None)
+            line["options"] = {"mppi_tick_with_resident_noise": {"rollouts_per_s": round(K * n_a / el_r, 1),
+                                                                 "ms_per_step": round(el_r / n_a * 1e3, 6)}}
+            # the exact-arc dynamics option, production tick
             ma = make_mppi(K, horizon, local_rank)
             ma.setDynamics("arc")
-            el_a = time_ticks(lambda: ma.enqueueDev(X0, a.data_ptr(), b.data_ptr(), stream), sync, min(args.steps, 1000),
-                              min(args.warmup, 100), lambda: None)
-            n_a = min(args.steps, 1000)
-            line["options"] = {"mppi_exact_arc_dynamics": {"rollouts_per_s": round(K * n_a / el_a, 1),
-                                                           "ms_per_step": round(el_a / n_a * 1e3, 6)}}
-            ma.close()
-            # production tick: fresh perturbations drawn on the device every tick (Philox, inside the fused kernel) —
-            # what a controller that does not bring its own noise pays; `value` is quoted with the inputs resident
-            tk = [0]
+            tka = [0]
 
-            def prod_tick():
-                m.enqueueRng(X0, 42, tk[0], stream)
-                tk[0] += 1
-            el_p = time_ticks(prod_tick, sync, n_a, min(args.warmup, 100), lambda: None)
-            line["options"]["mppi_tick_with_device_noise"] = {"rollouts_per_s": round(K * n_a / el_p, 1),
-                                                              "ms_per_step": round(el_p / n_a * 1e3, 6)}
+            def arc_tick():
+                ma.enqueueRng(X0, SEED, tka[0], stream)
+                tka[0] += 1
+            el_a = time_ticks(arc_tick, sync, n_a, min(args.warmup, 100), lambda: None)
+            line["options"]["mppi_exact_arc_dynamics"] = {"rollouts_per_s": round(K * n_a / el_a, 1),
+                                                          "ms_per_step": round(el_a / n_a * 1e3, 6)}
+            ma.close()
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(K, T, horizon)
+            line["cpu_baseline"] = cpu_baseline(K, T, horizon, threads=1)
+            line["cpu_baseline_all_cores"] = cpu_baseline(K, T, horizon, threads=os.cpu_count() or 1, budget_s=8.0)
         if world == 1 and not args.no_rbpf:
-            try:
-                import bench_rbpf
-                line["rbpf"] = bench_rbpf.run(device, args, with_cpu=not args.no_cpu_baseline)
-            except ImportError:
-                pass
+            import bench_rbpf
+            line["rbpf"] = bench_rbpf.run(device, args, with_cpu=not args.no_cpu_baseline)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def multi_gpu_legs(world, rank, local_rank, device, one_gpu_test, stream, sync, barrier):
+    """Two more measurements when N > 1 (same processes, after the headline):
+      strong_scaling_configs3  BASELINE configs[3]: K = 65536, T = 100 split N ways (K/N rollouts per rank, resident
+                               noise — the streaming regime), one all-gather of records per tick;
+      rbpf_sharded             BASELINE configs[2] per rank (1000 particles each, weak): slam_local + ONE all-gather of
+                               the weights + the global normalise/selection on every rank; two of the timed scans are
+                               forced to resample, so the cross-rank particle migration (tile blobs over RCCL) is timed."""
+    from rtn_amd.sharded import HipRbpfShardBackend, HipShardBackend, ShardedMPPI, ShardedRBPF
+    out = {}
+    # ---- MPPI strong scaling
+    KL, HL = 65536, 1.0
+    ml = make_mppi(KL // world, HL, local_rank)
+    al, bl = synth_noise(ml.steps, KL // world, device, 99 + rank)
+    sml = ShardedMPPI(HipShardBackend(ml, device))
+    el = time_ticks(lambda: sml.tick(X0, (al.data_ptr(), bl.data_ptr())), sync, 50, 10, barrier)
+    t = torch.tensor([el], dtype=torch.float64, device="cpu" if one_gpu_test else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    out["strong_scaling_configs3"] = {"workload": f"MPPI K={KL} total, T={ml.steps}, K/N = {KL // world} per rank, resident noise",
+                                      "rollouts_per_s": round(KL * 50 / float(t.item()), 1), "ms_per_step": round(float(t.item()) / 50 * 1e3, 6),
+                                      "scaling": "strong"}
+    ml.close()
+    # ---- RBPF weak scaling with migration
+    import bench_rbpf
+    from rtn_amd.rbpf import ParticleFilter, default_params
+    n_local, k = 1000, 50
+    steps, scans = bench_rbpf.workload(14)
+    pf = ParticleFilter(default_params(N=n_local, k=k, map_min=-10.0, map_max=10.0, device=local_rank))
+    pf.setSeed(2026 + rank)
+    sr = ShardedRBPF(HipRbpfShardBackend(pf, device))
+    t_total, n_timed, resamples = 0.0, 0, 0
+    for s, (prev, cur, t_icp, u) in enumerate(steps):
+        if s in (6, 10):  # skew the GLOBAL weights: heavy particles on the first and the last rank
+            w = np.full(n_local, 0.2 / (n_local * world))
+            if rank == 0:
+                w[n_local // 7] += 0.5
+            if rank == world - 1:
+                w[(5 * n_local) // 7] += 0.3
+            pf.setParticles(w=w)
+        sync(); barrier(); sync()
+        t0 = time.perf_counter()
+        st, _, _ = sr.tick(scans[s], u, cur, prev, True, t_icp, None, 3 * k + 3)
+        sync(); barrier(); sync()
+        dt = time.perf_counter() - t0
+        if s >= 2:
+            t_total += dt; n_timed += 1
+        resamples += st.resampled
+    t = torch.tensor([t_total], dtype=torch.float64, device="cpu" if one_gpu_test else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    out["rbpf_sharded"] = {"workload": f"RBPF N={n_local} per rank ({n_local * world} global), k={k}, 360 beams, 400x400; weights all-gather + "
+                                       "global selection per scan, particle migration when resampling fires",
+                           "particle_updates_per_s": round(n_local * world * n_timed / float(t.item()), 1),
+                           "ms_per_scan": round(float(t.item()) / n_timed * 1e3, 4), "scans_timed": n_timed, "resamples": resamples,
+                           "bytes_migrated_rank0": sr.bytes_migrated, "scaling": "weak"}
+    pf.close()
+    return out
 
 
 if __name__ == "__main__":

@@ -70,6 +70,18 @@ int tbnav_mppi_rollouts(const tbnav_mppi* h); /* K of this handle           */
  * in the same launch; tbnav_mppi_shard_partials then folds those fine records into the K-slice records). */
 int tbnav_mppi_rollout_variant(const tbnav_mppi* h);
 
+/* Options (explicit setters; nothing in the library reads the environment).
+ *  TBNAV_MPPI_OPT_KERNEL   which rollout kernel the handle launches instead of the automatic choice: 0 = mppi_rollout_cost,
+ *                          n > 0 = mppi_rollout_scan with n steps per thread, -4 / -8 / -16 = mppi_rollout_fused with that
+ *                          many rollouts per workgroup (A/B measurements, variant parity tests).
+ *  TBNAV_MPPI_OPT_TRIG     sincos evaluations per RK4 step: 1 (default: angle addition, a fresh sincos every 4th step),
+ *                          2 (fresh every step), 3 (the reference's three evaluations).
+ *  TBNAV_MPPI_OPT_NO_LDS_STAGING  1 = mppi_rollout_cost stages every per-step loss through J (development).
+ *  TBNAV_MPPI_OPT_KEEP_J   1 = the fused kernel also stores the cost-to-go J[T][K] (410 KB at K=1024, T=50) so that
+ *                          tbnav_mppi_get_cost_to_go can return it; off by default — the update needs only the records. */
+enum { TBNAV_MPPI_OPT_KERNEL = 1, TBNAV_MPPI_OPT_TRIG = 2, TBNAV_MPPI_OPT_NO_LDS_STAGING = 3, TBNAV_MPPI_OPT_KEEP_J = 4 };
+int tbnav_mppi_set_option(tbnav_mppi* h, int32_t option, int32_t value);
+
 /* Rollout dynamics.  TBNAV_MPPI_DYN_RK4 (default) is the reference MPPI: CartModel + RK4 (controller/include/
  * controller/mppi.hpp:41-48, controller/src/controller/rk4.cpp:95-115).  TBNAV_MPPI_DYN_ARC is an OPTION the
  * reference's controller does not have: every rollout step is the plant's own update,
@@ -111,10 +123,16 @@ int tbnav_mppi_enqueue_dev(tbnav_mppi* h, const double x0[3], const double* d_du
 int tbnav_mppi_last_controls(tbnav_mppi* h, void* stream, double u_out[2]);
 
 /* Noise drawn ON the device (production mode; replaces MPPI::pertubations, mppi.cpp:173-184):
- * Philox4x32-10 keyed by `seed`, counter = tick*K*T + k*T + i, one Box-Muller pair per (k,i) gives
- * (duL, duR) scaled by sqrt(ul_var), sqrt(ur_var).  Fills the handle's own duL/duR buffers, which
+ * Philox4x32-10 keyed by `seed`, counter = tick*K*T + k*T + i (see tbnav_mppi_set_rng_shard for sharded ensembles), one
+ * Box-Muller pair per (k,i) — evaluated on the fp32 transcendental units: normals on a 2^-24 grid out to 5.9 sigma —
+ * gives (duL, duR) scaled by sqrt(ul_var), sqrt(ur_var).  Fills the handle's own duL/duR buffers, which
  * tbnav_mppi_*_dev accept when d_duL == d_duR == NULL. */
 int tbnav_mppi_sample_noise(tbnav_mppi* h, uint64_t seed, uint64_t tick, void* stream);
+/* Sharded ensembles: this handle's K rollouts are rollouts [first_rollout, first_rollout + K) of rollouts_global.  The
+ * device noise counter becomes tick*T*rollouts_global + (first_rollout + k)*T + i, so ranks that share a seed draw
+ * DISJOINT perturbations — the same ones the unsharded ensemble of rollouts_global rollouts would draw.  Without this
+ * call a handle numbers its rollouts from 0 and ranks sharing a seed would all draw the same K perturbations. */
+int tbnav_mppi_set_rng_shard(tbnav_mppi* h, uint64_t first_rollout, uint64_t rollouts_global);
 /* Copy the handle's own noise buffers to the host ([T][K] each) — for statistical tests. */
 int tbnav_mppi_get_noise(tbnav_mppi* h, double* duL_host, double* duR_host);
 
@@ -127,6 +145,11 @@ int tbnav_mppi_records_per_step(const tbnav_mppi* h);
  * T * records_per_step * TBNAV_MPPI_REC doubles laid out [T][S][REC].  Enqueue only. */
 int tbnav_mppi_shard_partials(tbnav_mppi* h, const double x0[3], const double* d_duL,
                               const double* d_duR, void* stream, double* d_records_out);
+
+/* Same with the shard's perturbations drawn on the device (production mode; call tbnav_mppi_set_rng_shard once so that
+ * the shards of one ensemble draw disjoint perturbations from one seed). */
+int tbnav_mppi_shard_partials_rng(tbnav_mppi* h, const double x0[3], uint64_t seed, uint64_t tick, void* stream,
+                                  double* d_records_out);
 
 /* Combine `n_shards` record sets (device buffer [n_shards][T][S][REC], e.g. the output of one
  * all-gather), update u, clamp, emit u(:,0), shift.  Every rank runs this on the same input and so

@@ -20,6 +20,9 @@ TBNAV_MPPI_REC = 8
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OUT_OF_WORLD, ERR_ETA_ZERO, ERR_PDF_VARIANCE, \
     ERR_BRESENHAM, ERR_UNSUPPORTED, ERR_POOL_EXHAUSTED = range(10)
 
+# tbnav_mppi.h options
+MPPI_OPT_KERNEL, MPPI_OPT_TRIG, MPPI_OPT_NO_LDS_STAGING, MPPI_OPT_KEEP_J = 1, 2, 3, 4
+
 # tbnav_rbpf.h options
 RBPF_OPT_DF_MODE, RBPF_OPT_RAYCAST_ORDERED, RBPF_OPT_RAYCAST_THREADS, RBPF_OPT_COUNT_CELLS = 1, 2, 3, 4
 RBPF_DF = {"full": 0, "window": 1, "query": 2, "reference": 3}
@@ -112,6 +115,8 @@ def lib() -> C.CDLL:
         "tbnav_mppi_rollouts": (C.c_int, [vp]),
         "tbnav_mppi_rollout_variant": (C.c_int, [vp]),
         "tbnav_mppi_set_dynamics": (C.c_int, [vp, i32]),
+        "tbnav_mppi_set_option": (C.c_int, [vp, i32, i32]),
+        "tbnav_mppi_set_rng_shard": (C.c_int, [vp, u64, u64]),
         "tbnav_mppi_records_per_step": (C.c_int, [vp]),
         "tbnav_mppi_set_initial_controls": (C.c_int, [vp, dbl, dbl]),
         "tbnav_mppi_set_waypoint": (C.c_int, [vp, dbl, dbl, dbl]),
@@ -127,6 +132,7 @@ def lib() -> C.CDLL:
         "tbnav_mppi_get_noise": (C.c_int, [vp, vp, vp]),
         "tbnav_mppi_shard_partials": (C.c_int, [vp, dp, vp, vp, vp, vp]),
         "tbnav_mppi_shard_combine": (C.c_int, [vp, vp, i32, vp]),
+        "tbnav_mppi_shard_partials_rng": (C.c_int, [vp, dp, u64, u64, vp, vp]),
         "tbnav_mppi_get_cost_to_go": (C.c_int, [vp, vp]),
         "tbnav_mppi_debug_sincos": (C.c_int, [vp, i32, vp, vp]),
         "tbnav_mppi_profile_tick": (C.c_int, [vp, dp, vp, vp, vp, C.POINTER(C.c_float)]),

@@ -534,19 +534,19 @@ __device__ __forceinline__ void philox4x32_10(uint64_t ctr, uint64_t key, uint32
 
 // One (duL, duR) pair of the device noise source: Philox4x32-10 keyed by the seed, counter = tick*T*K + k*T + i, then
 // Box-Muller.  mppi_sample_noise fills the [T][K] arrays with it; the fused kernel can call it in place of the loads.
-struct RngArgs { uint64_t seed, base; double sig_l, sig_r; };
+struct RngArgs { uint64_t seed, base; double sig_l, sig_r; };  // base = tick * T * K_global + k0 * T
 __device__ __forceinline__ void device_noise(const RngArgs& g, int T, int i, int k, double& dl, double& dr) {
   uint32_t r[4];
   philox4x32_10(g.base + (uint64_t)k * T + i, g.seed, r);
-  const uint64_t a = ((uint64_t)r[0] << 32) | r[1];
-  const uint64_t b = ((uint64_t)r[2] << 32) | r[3];
-  const double u1 = ((double)(a >> 11) + 0.5) * 0x1.0p-53;  // (0,1)
-  const double u2 = ((double)(b >> 11) + 0.5) * 0x1.0p-53;
-  const double rad = sqrt(-2.0 * log(u1));
-  double sn, cs;
-  sincospi(2.0 * u2, &sn, &cs);
-  dl = g.sig_l * (rad * cs);
-  dr = g.sig_r * (rad * sn);
+  // Box-Muller on the fp32 transcendental units (v_log_f32, v_sin_f32 / v_cos_f32 take their argument in turns):
+  // a handful of instructions instead of ~130 fp64 ones for log + sincospi + sqrt.  The perturbations are random
+  // numbers, not parity quantities: 24-bit uniforms give normals on a 2^-24 grid out to 5.9 sigma, which is all a
+  // sampling controller can use (the reference's own sampler is not reproducible run to run either, utilities.cpp:14).
+  const float u1 = ((float)(r[0] >> 8) + 0.5f) * 0x1.0p-24f;  // (0, 1)
+  const float u2 = ((float)(r[1] >> 8) + 0.5f) * 0x1.0p-24f;  // [0, 1) turns
+  const float rad = __builtin_sqrtf(-2.0f * 0.69314718056f * __builtin_amdgcn_logf(u1));  // v_log_f32 is log2
+  dl = g.sig_l * (double)(rad * __builtin_amdgcn_cosf(u2));
+  dr = g.sig_r * (double)(rad * __builtin_amdgcn_sinf(u2));
 }
 
 // ---- fused rollout + soft-min partials for small K (lanes = TIME) ------------------------------------------
@@ -566,7 +566,7 @@ __device__ __forceinline__ void device_noise(const RngArgs& g, int T, int i, int
 template <int TRIG, int R, int TL, bool RNG>
 __global__ __launch_bounds__(kWave * R) void mppi_rollout_fused(RolloutArgs a, const double* __restrict__ duL,
                                                                 const double* __restrict__ duR, USrc u, double lambda,
-                                                                double* __restrict__ J, double* __restrict__ records, int S,
+                                                                double* __restrict__ J /* NULL: not kept */, double* __restrict__ records, int S,
                                                                 RngArgs rng) {
   extern __shared__ __attribute__((aligned(16))) double lds_all[];
   constexpr int RP = R + 1;  // padded tile rows: the transposed reads of a wave hit distinct banks
@@ -671,9 +671,11 @@ __global__ __launch_bounds__(kWave * R) void mppi_rollout_fused(RolloutArgs a, c
     }
   }
   __syncthreads();
-  for (int idx = tid; idx < T * R; idx += nthr) {
-    const int t = idx / R, rr = idx - t * R;
-    if (k0 + rr < K) J[(size_t)t * K + k0 + rr] = Jl[t * RP + rr];
+  if (J) {  // parity hook only (tbnav_mppi_get_cost_to_go): the update itself needs the records, not J
+    for (int idx = tid; idx < T * R; idx += nthr) {
+      const int t = idx / R, rr = idx - t * R;
+      if (k0 + rr < K) J[(size_t)t * K + k0 + rr] = Jl[t * RP + rr];
+    }
   }
   // soft-min partial record of each time step over this workgroup's rollouts (mppi.cpp:115-121)
   const double inf = __builtin_huge_val();
@@ -916,13 +918,13 @@ __global__ void mppi_unpack_noise(int T, int K, const double* __restrict__ raw,
 }
 
 // ---- Philox4x32-10 (Salmon et al., SC'11) ------------------------------------------------------
-__global__ void mppi_sample_noise(int T, int K, uint64_t seed, uint64_t tick, double sig_l,
+__global__ void mppi_sample_noise(int T, int K, uint64_t seed, uint64_t base, double sig_l,
                                   double sig_r, double* __restrict__ duL, double* __restrict__ duR) {
   const size_t n = (size_t)T * K;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
        idx += (size_t)gridDim.x * blockDim.x) {
     const int i = (int)(idx / K), k = (int)(idx % K);  // k fastest: coalesced stores
-    const RngArgs g{seed, tick * n, sig_l, sig_r};
+    const RngArgs g{seed, base, sig_l, sig_r};
     device_noise(g, T, i, k, duL[idx], duR[idx]);
   }
 }
@@ -958,6 +960,9 @@ struct tbnav_mppi {
   double* d_records_f = nullptr;  // [T][fused_S][8]
   int trig = 1;               // sincos evaluations per RK4 step (1 = angle addition, 3 = the reference's three)
   int dyn = 0;                // rollout dynamics: 0 = the reference's RK4 cart, 1 = exact arcs (tbnav_mppi_set_dynamics)
+  bool keep_j = false;        // the fused kernel also writes J to HBM (parity hook tbnav_mppi_get_cost_to_go); other kernels always do
+  bool j_valid = false;       // d_J holds the last tick's cost-to-go
+  uint64_t k0 = 0, k_global = 0;  // device noise source: this handle's rollouts are [k0, k0 + K) of k_global (sharded ensembles)
 };
 
 namespace {
@@ -1001,6 +1006,7 @@ int launch_rollout(tbnav_mppi* h, const double x0[3], const double* d_duL, const
     else hipLaunchKernelGGL((mppi_rollout_cost<3>), grid, block, lds, st, a, d_duL, d_duR, usrc, h->d_J);
   }
   TBNAV_HIP(hipGetLastError());
+  h->j_valid = true;
   return TBNAV_OK;
 }
 
@@ -1031,7 +1037,7 @@ int launch_fused(tbnav_mppi* h, const double x0[3], const double* d_duL, const d
   const size_t lds = fused_lds_bytes(h->T, R);
   const RngArgs g = rng ? *rng : RngArgs{0, 0, 0.0, 0.0};
 #define TBNAV_FUSED(TR, RR, TLL, RG) hipLaunchKernelGGL((mppi_rollout_fused<TR, RR, TLL, RG>), grid, block, lds, st, a, d_duL, d_duR, usrc, \
-                                                        h->p.lambda, h->d_J, h->d_records_f, h->fused_S, g)
+                                                        h->p.lambda, h->keep_j ? h->d_J : nullptr, h->d_records_f, h->fused_S, g)
 #define TBNAV_FUSED_R(TR)                                                                                \
   if (R == 8) { if (TL == 1) TBNAV_FUSED(TR, 8, 1, false); else TBNAV_FUSED(TR, 8, 2, false); }          \
   else if (R == 4) { if (TL == 1) TBNAV_FUSED(TR, 4, 1, false); else TBNAV_FUSED(TR, 4, 2, false); }     \
@@ -1044,6 +1050,7 @@ int launch_fused(tbnav_mppi* h, const double x0[3], const double* d_duL, const d
 #undef TBNAV_FUSED_R
 #undef TBNAV_FUSED
   TBNAV_HIP(hipGetLastError());
+  h->j_valid = h->keep_j;
   return TBNAV_OK;
 }
 
@@ -1096,6 +1103,10 @@ struct DeviceGuard {
   }
   ~DeviceGuard() { if (ok && prev >= 0) (void)hipSetDevice(prev); }
 };
+
+// counter of rollout 0, step 0 of this handle at tick `tick`: counter(k, i) = tick*T*K_global + (k0 + k)*T + i, so the
+// shards of one ensemble draw disjoint perturbations from one seed (and the same ones as the unsharded ensemble)
+uint64_t rng_base(const tbnav_mppi* h, uint64_t tick) { return tick * (uint64_t)h->T * h->k_global + h->k0 * (uint64_t)h->T; }
 
 bool pick_noise(tbnav_mppi* h, const double*& d_duL, const double*& d_duR) {
   if (!d_duL && !d_duR) { d_duL = h->d_duL; d_duR = h->d_duR; return true; }
@@ -1163,21 +1174,11 @@ int tbnav_mppi_create(const tbnav_mppi_params* params, tbnav_mppi** out) {
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     if ((params->rollouts + kWave - 1) / kWave >= 2 * cus) h->scan_tc = 0;
   }
-  // development switches (A/B measurements; not part of the contract)
-  if (const char* e = std::getenv("TBNAV_MPPI_SEQ")) if (std::atoi(e) == 1) h->scan_tc = 0;
-  if (const char* e = std::getenv("TBNAV_MPPI_SCAN_TC")) {  // 4/7/8 may use up to 16 chunks, the others 12
-    const int tc = std::atoi(e), cmax = (tc == 4 || tc == 7 || tc == 8) ? 16 : 12;
-    if (tc > 0 && (T + tc - 1) / tc <= cmax) h->scan_tc = tc;
-  }
   // fused rollout + partials (lanes = time): whenever the time-parallel kernel would be chosen and T fits two steps per lane
+  // (other kernel choices: tbnav_mppi_set_option)
   h->fused_r = (h->scan_tc > 0 && T <= 2 * kWave) ? 8 : 0;
-  if (const char* e = std::getenv("TBNAV_MPPI_FUSED")) {  // development switch: 0 = three kernels, 4 / 8 / 16 = rollouts per workgroup
-    const int r = std::atoi(e);
-    h->fused_r = (T <= 2 * kWave && (r == 4 || r == 8 || r == 16)) ? r : 0;
-  }
   h->fused_S = h->fused_r ? (h->K + h->fused_r - 1) / h->fused_r : 0;
-  if (const char* e = std::getenv("TBNAV_MPPI_TRIG")) { const int t = std::atoi(e); h->trig = (t == 2 || t == 3) ? t : 1; }
-  if (const char* e = std::getenv("TBNAV_MPPI_NO_LDS")) { if (std::atoi(e) == 1) h->lds_from = T; }
+  h->k_global = (uint64_t)h->K;
   const size_t tk = (size_t)T * h->K;
   hipError_t e = hipSuccess;
   auto alloc = [&](double** p, size_t n) { if (e == hipSuccess) e = hipMalloc((void**)p, n * sizeof(double)); };
@@ -1230,6 +1231,51 @@ int tbnav_mppi_steps(const tbnav_mppi* h) { return h ? h->T : -1; }
 int tbnav_mppi_set_dynamics(tbnav_mppi* h, int32_t model) {
   if (!h || (model != TBNAV_MPPI_DYN_RK4 && model != TBNAV_MPPI_DYN_ARC)) return TBNAV_ERR_INVALID_ARG;
   h->dyn = model;
+  return TBNAV_OK;
+}
+
+int tbnav_mppi_set_option(tbnav_mppi* h, int32_t option, int32_t value) {
+  if (!h) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  const int T = h->T;
+  switch (option) {
+    case TBNAV_MPPI_OPT_KEEP_J: h->keep_j = value != 0; return TBNAV_OK;
+    case TBNAV_MPPI_OPT_TRIG:
+      if (value < 1 || value > 3) return TBNAV_ERR_INVALID_ARG;
+      h->trig = value;
+      return TBNAV_OK;
+    case TBNAV_MPPI_OPT_NO_LDS_STAGING:
+      if (value) h->lds_from = T;
+      return TBNAV_OK;
+    case TBNAV_MPPI_OPT_KERNEL: {
+      // 0: mppi_rollout_cost (sequential); n > 0: mppi_rollout_scan with n steps per thread; -4 / -8 / -16: fused, that many rollouts per workgroup
+      int fused = 0, tc = 0;
+      if (value < 0) {
+        fused = -value;
+        if (!(T <= 2 * kWave && (fused == 4 || fused == 8 || fused == 16))) return TBNAV_ERR_INVALID_ARG;
+      } else if (value > 0) {
+        const int cmax = (value == 4 || value == 7 || value == 8) ? 16 : 12;
+        bool known = false;
+        for (int t : {4, 5, 6, 7, 8, 10, 12, 16, 20}) known |= t == value;
+        if (!known || (T + value - 1) / value > cmax) return TBNAV_ERR_INVALID_ARG;
+        tc = value;
+      }
+      h->scan_tc = tc;
+      h->fused_r = fused;
+      h->fused_S = fused ? (h->K + fused - 1) / fused : 0;
+      (void)hipFree(h->d_records_f);
+      h->d_records_f = nullptr;
+      if (fused) TBNAV_HIP(hipMalloc((void**)&h->d_records_f, sizeof(double) * (size_t)T * h->fused_S * TBNAV_MPPI_REC));
+      return TBNAV_OK;
+    }
+    default: return TBNAV_ERR_INVALID_ARG;
+  }
+}
+
+int tbnav_mppi_set_rng_shard(tbnav_mppi* h, uint64_t first_rollout, uint64_t rollouts_global) {
+  if (!h || rollouts_global < first_rollout + (uint64_t)h->K) return TBNAV_ERR_INVALID_ARG;
+  h->k0 = first_rollout;
+  h->k_global = rollouts_global;
   return TBNAV_OK;
 }
 
@@ -1291,6 +1337,25 @@ int tbnav_mppi_shard_partials(tbnav_mppi* h, const double x0[3], const double* d
   int rc = launch_rollout(h, x0, d_duL, d_duR, st);
   if (rc != TBNAV_OK) return rc;
   return launch_partials(h, d_duL, d_duR, d_records_out, st);
+}
+
+// Same, with this shard's perturbations drawn on the device (tbnav_mppi_set_rng_shard gives the shard its place in
+// the ensemble's counter space): inside the fused kernel when that is the handle's kernel, else sampled first.
+int tbnav_mppi_shard_partials_rng(tbnav_mppi* h, const double x0[3], uint64_t seed, uint64_t tick, void* stream, double* d_records_out) {
+  if (!h || !x0 || !d_records_out) return TBNAV_ERR_INVALID_ARG;
+  if (!(h->fused_r == 8 && kSlice % h->fused_r == 0)) {
+    const int rc = tbnav_mppi_sample_noise(h, seed, tick, stream);
+    return rc != TBNAV_OK ? rc : tbnav_mppi_shard_partials(h, x0, nullptr, nullptr, stream, d_records_out);
+  }
+  DeviceGuard guard(h->device);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const RngArgs g{seed, rng_base(h, tick), std::sqrt(h->p.ul_var), std::sqrt(h->p.ur_var)};
+  const int rcf = launch_fused(h, x0, h->d_duL, h->d_duR, st, &g);
+  if (rcf != TBNAV_OK) return rcf;
+  hipLaunchKernelGGL(mppi_merge_records, dim3(h->S, h->T), dim3(kWave), 0, st, h->T, h->fused_S, kSlice / h->fused_r, h->S,
+                     h->p.lambda, h->d_records_f, d_records_out);
+  TBNAV_HIP(hipGetLastError());
+  return TBNAV_OK;
 }
 
 int tbnav_mppi_shard_combine(tbnav_mppi* h, const double* d_records_all, int32_t n_shards, void* stream) {
@@ -1434,7 +1499,7 @@ int tbnav_mppi_sample_noise(tbnav_mppi* h, uint64_t seed, uint64_t tick, void* s
   const size_t n = (size_t)h->T * h->K;
   const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
   hipLaunchKernelGGL(mppi_sample_noise, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     h->T, h->K, seed, tick, std::sqrt(h->p.ul_var), std::sqrt(h->p.ur_var), h->d_duL,
+                     h->T, h->K, seed, rng_base(h, tick), std::sqrt(h->p.ul_var), std::sqrt(h->p.ur_var), h->d_duL,
                      h->d_duR);
   TBNAV_HIP(hipGetLastError());
   return TBNAV_OK;
@@ -1451,7 +1516,7 @@ int tbnav_mppi_enqueue_rng(tbnav_mppi* h, const double x0[3], uint64_t seed, uin
   }
   DeviceGuard guard(h->device);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const RngArgs g{seed, tick * (uint64_t)h->T * (uint64_t)h->K, std::sqrt(h->p.ul_var), std::sqrt(h->p.ur_var)};
+  const RngArgs g{seed, rng_base(h, tick), std::sqrt(h->p.ul_var), std::sqrt(h->p.ur_var)};
   const int rc = launch_fused(h, x0, h->d_duL, h->d_duR, st, &g);
   return rc != TBNAV_OK ? rc : launch_combine(h, h->d_records_f, 1, st, h->fused_S);
 }
@@ -1491,6 +1556,7 @@ int tbnav_mppi_debug_sincos(const double* x_host, int32_t n, double* sin_host, d
 
 int tbnav_mppi_get_cost_to_go(tbnav_mppi* h, double* J_host) {
   if (!h || !J_host) return TBNAV_ERR_INVALID_ARG;
+  if (!h->j_valid) return TBNAV_ERR_INVALID_ARG;  // the last tick ran the fused kernel without TBNAV_MPPI_OPT_KEEP_J
   DeviceGuard guard(h->device);
   TBNAV_HIP(hipDeviceSynchronize());
   TBNAV_HIP(hipMemcpy(J_host, h->d_J, (size_t)h->T * h->K * sizeof(double), hipMemcpyDeviceToHost));

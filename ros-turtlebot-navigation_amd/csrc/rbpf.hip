@@ -96,6 +96,7 @@ struct ScanC {  // everything constant during one SLAM call
   double d_free, d_occ, cut_occ; // log-odds increments and the host-derived occupied cut-off
   int stride_normals;            // 3k+3 or 3
   int p0;                        // first particle of the launch (0 for a whole-filter update)
+  double rmax;                   // longest valid beam of this scan
 };
 
 // ---- tiled copy-on-write log-odds maps -------------------------------------------------------------------
@@ -636,7 +637,8 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
                                                                 const int* __restrict__ n_occ, const int4* __restrict__ win,
                                                                 const double* __restrict__ normals, const double* __restrict__ center,
                                                                 double* __restrict__ pose, double* __restrict__ prev_pose,
-                                                                double* __restrict__ weight, Trace tr, int* __restrict__ err) {
+                                                                double* __restrict__ weight, Trace tr, double* __restrict__ sens,
+                                                                int* __restrict__ err) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int p = blockIdx.x;
   const int k = c.k;
@@ -688,6 +690,9 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
         tr.p_scan[(size_t)p * k] = sl;
         tr.weight_raw[p] = w;
         tr.new_pose[p * 3 + 0] = nth; tr.new_pose[p * 3 + 1] = nx; tr.new_pose[p * 3 + 2] = ny;
+        double Ts[4];  // the sensor transform of the new pose, for the raycast kernel
+        sensor_transform(c, nth, nx, ny, Ts);
+        for (int q = 0; q < 4; ++q) sens[p * 4 + q] = Ts[q];
       }
       if (oob & 1) atomicOr(&err[0], 1);
       if (oob & 2) atomicOr(&err[3], 4);
@@ -908,7 +913,10 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
     }
   }
   __syncthreads();
-  if (sh_stop) return;
+  if (sh_stop) {  // eta is 0 (reported): the pose stays, and so does its sensor transform
+    if (tid == 0) { double Ts[4]; sensor_transform(c, th0, x0, y0, Ts); for (int q = 0; q < 4; ++q) sens[p * 4 + q] = Ts[q]; }
+    return;
+  }
   if (wid == 0) {
     const double mu[3] = {sh_mu[0], sh_mu[1], sh_mu[2]}, eta = sh_eta;
     double su[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -937,6 +945,9 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
       const double w = weight[p] * eta;
       weight[p] = w;
       tr.weight_raw[p] = w;
+      double Ts[4];  // the sensor transform of the new pose, for the raycast kernel (saves it two sincos on its critical path)
+      sensor_transform(c, np[0], np[1], np[2], Ts);
+      for (int q = 0; q < 4; ++q) sens[p * 4 + q] = Ts[q];
     }
   }
   PHASE_STAMP_P(2);
@@ -1167,7 +1178,7 @@ __device__ __forceinline__ bool on_ray(const Ray& r, int cx, int cy) {
 // LDS (ints): ex ey own rk rxy rdd ecnt [Bv each] | ev u16[Bv][kEvCap] | tile u32[(cap+1)/2] (two 16-bit
 // halves per word: bit 15 = end-point flag, low 15 bits = free-add count, or the slot index when flagged).
 constexpr int kEvCap = 16;
-constexpr int kTileIntsPerBeam = 7 + kEvCap / 2;
+constexpr int kTileIntsPerBeam = 3 + kEvCap / 2;
 constexpr int kMapTilesMax = 64;  // map tiles a scan's bounding box can span: (ceil(175 / 32) + 1)^2 = 49 for tile_cap 30000
 // Packed ray for the counting pass.  Every ray is written in the form of the reference's plotLineLow / plotLineHigh
 // cases: a major axis, a start (xa, ya) at the low end of that axis, dmaj steps along it, and the minor offset
@@ -1175,7 +1186,8 @@ constexpr int kMapTilesMax = 64;  // map tiles a scan's bounding box can span: (
 // (a = 2*dmin*t - dmaj gives c_t = 0 and c_t = t), and the SET of free cells is the same: the robot cell plus the
 // cells strictly between the two ends (the counting pass is order-free; ordered work uses Ray/on_ray).
 //   k  = ymajor | (sgn < 0) << 1 | count << 8        xy = xa | ya << 16        dd = dmaj | dmin << 16
-__device__ __forceinline__ void pack_ray(const Ray& r, int x1, int y1, int& k, int& xy, int& dd) {
+struct PackedRay { int k, xy, dd; };
+__device__ __forceinline__ PackedRay pack_ray(const Ray& r, int x1, int y1) {
   int ymajor = (r.kind == 3), xa = r.xa, ya = r.ya, dmaj = r.dmaj, dmin = r.dmin, sgn = r.sgn;
   if (r.kind == 0) { ymajor = 1; xa = r.x0; ya = r.y0 < y1 ? r.y0 : y1; dmaj = r.count; dmin = 0; sgn = 1; }
   if (r.kind == 1) { ymajor = 0; ya = r.y0; xa = r.x0 < x1 ? r.x0 : x1; dmaj = r.count; dmin = 0; sgn = 1; }
@@ -1183,9 +1195,7 @@ __device__ __forceinline__ void pack_ray(const Ray& r, int x1, int y1, int& k, i
     ymajor = 0; dmaj = r.count; dmin = r.count;
     if (r.x0 < x1) { xa = r.x0; ya = r.y0; sgn = (y1 < r.y0) ? -1 : 1; } else { xa = x1; ya = y1; sgn = (r.y0 < y1) ? -1 : 1; }
   }
-  k = ymajor | (sgn < 0 ? 2 : 0) | (r.count << 8);
-  xy = xa | (ya << 16);
-  dd = dmaj | (dmin << 16);
+  return PackedRay{ymajor | (sgn < 0 ? 2 : 0) | (r.count << 8), xa | (ya << 16), dmaj | (dmin << 16)};
 }
 __device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
@@ -1202,54 +1212,66 @@ __device__ __forceinline__ int wave_sum_i(int v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
-__global__ __launch_bounds__(1024, 8) void rbpf_raycast_tile(ScanC c, TilePool P, MapT M, const double2* __restrict__ beams,
-                                                          const double* __restrict__ pose,
-                                                          unsigned long long* __restrict__ bitmap, int* __restrict__ row_count,
-                                                          int* __restrict__ n_occ, int* __restrict__ err, int tile_cap,
-                                                          unsigned long long* __restrict__ touched) {
+// LDS of the tile kernel (ints): exy own ecnt [Bv each] | ev u16[Bv][kEvCap] | tile u32[(cap+1)/2].  A ray is rebuilt
+// from (robot cell, end point) where it is walked instead of being stored.
+constexpr int kBoxSideMax = 176;  // rows a scan's bounding box can have (tile_cap <= 30000 -> side <= 173)
+// Residency the register allocation is held to: 1024 threads -> 2 workgroups per CU (8 waves per SIMD, 64 VGPRs),
+// 512 -> 3 (6 per SIMD, 80 VGPRs), 256 -> 3 (LDS-bound anyway).
+template <int NT>
+__global__ __launch_bounds__(NT, NT == 1024 ? 8 : (NT == 512 ? 6 : 3)) void rbpf_raycast_tile(ScanC c, TilePool P, MapT M, const double2* __restrict__ beams,
+                                                       const double* __restrict__ pose, const double* __restrict__ sens,
+                                                       unsigned long long* __restrict__ bitmap, int* __restrict__ row_count,
+                                                       int* __restrict__ n_occ, int* __restrict__ err, int tile_cap,
+                                                       unsigned long long* __restrict__ touched) {
   extern __shared__ __attribute__((aligned(16))) int lds_i[];
   const int Bv = c.Bv;
-  int* ex = lds_i;
-  int* ey = ex + Bv;
-  int* own = ey + Bv;    // [n_own] a beam ending in the slot's cell
-  int* rk = own + Bv;    // packed rays
-  int* rxy = rk + Bv;
-  int* rdd = rxy + Bv;
-  int* ecnt = rdd + Bv;  // [n_own] events recorded (may exceed kEvCap: overflow)
+  int* exy = lds_i;      // [Bv] end-point cell, x | y << 16
+  int* own = exy + Bv;   // [n_own] a beam ending in the slot's cell
+  int* ecnt = own + Bv;  // [n_own] events recorded (may exceed kEvCap: overflow)
   unsigned short* ev = reinterpret_cast<unsigned short*>(ecnt + Bv);  // [n_own][kEvCap]  beam | 0x8000 if occupied
   unsigned int* tile = reinterpret_cast<unsigned int*>(lds_i + kTileIntsPerBeam * Bv);
-  __shared__ int bad, bx0, bx1, by0, by1, n_own, srx, sry;
+  __shared__ int bad, bx0, bx1, by0, by1, n_own, srx, sry, n_need, robot_cnt, nocc_delta;
+  __shared__ unsigned long long need_base;
   __shared__ unsigned int mt_id[kMapTilesMax];  // map tiles under the bounding box: 0 = not written by this scan, else the
   //                                               particle's private tile id (phase C)
-  const int p = c.p0 + blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave, nw = blockDim.x / kWave;
-  const int nthr = blockDim.x;
+  __shared__ int mt_ref[kMapTilesMax], mt_slot[kMapTilesMax];
+  __shared__ int rc_delta[kBoxSideMax];         // change of the occupied count of each map row under the box
+  __shared__ double sh_pose[4];                 // X, Y, sin, cos of Tms = T(pose) * Trs
+  constexpr int nthr = NT, nw = NT / kWave;
+  const int p = c.p0 + blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
 #ifdef TBNAV_PHASE_PROF
   unsigned long long t_prev_ = wall_clock64();
 #endif
   unsigned long long* bm = bitmap + (size_t)p * c.g.xsize * c.g.words;
   int* rc = row_count + (size_t)p * c.g.xsize;
-  int* nocc = n_occ + p;
-  // wave 0 derives everything that depends only on the particle's pose (two sincos, two divisions) while the
-  // other waves clear the tile: 16 waves repeating that arithmetic would cost more issue slots than the rest
-  // of the set-up together
-  __shared__ double sh_pose[4];  // X, Y, sin, cos of Tms = T(pose) * Trs
+  unsigned int* tab = M.table + (size_t)p * M.TT;
+  unsigned int* shed = M.shed + (size_t)p * M.TT;
+  // wave 0 derives everything that depends only on the particle's pose while the other waves clear the tile; the
+  // sensor transform comes from the proposal kernel when it ran for this particle (`sens`), else two sincos here
   if (wid == 0) {
-    const double th = pose[p * 3 + 0], x = pose[p * 3 + 1], y = pose[p * 3 + 2];
+    const double x = pose[p * 3 + 1], y = pose[p * 3 + 2];
     int rx0 = 0, ry0 = 0;
     const bool robot_ok = world2cell(c.g, x, y, rx0, ry0);  // freeGridIndex: world2Grid of the ROBOT pose (:558)
-    double s0, c0, st0, ct0;
-    sincos(th, &s0, &c0);
-    sincos(th + c.Trs[0], &st0, &ct0);
+    double X, Y, st0, ct0;
+    if (sens) { X = sens[p * 4 + 0]; Y = sens[p * 4 + 1]; st0 = sens[p * 4 + 2]; ct0 = sens[p * 4 + 3]; }
+    else {
+      const double th = pose[p * 3 + 0];
+      double s0, c0;
+      sincos(th, &s0, &c0);
+      if (c.Trs[0] == 0.0) { st0 = s0; ct0 = c0; } else sincos(th + c.Trs[0], &st0, &ct0);
+      X = c0 * c.Trs[1] - s0 * c.Trs[2] + x;
+      Y = s0 * c.Trs[1] + c0 * c.Trs[2] + y;
+    }
     if (lane == 0) {
-      sh_pose[0] = c0 * c.Trs[1] - s0 * c.Trs[2] + x;
-      sh_pose[1] = s0 * c.Trs[1] + c0 * c.Trs[2] + y;
-      sh_pose[2] = st0; sh_pose[3] = ct0;
+      sh_pose[0] = X; sh_pose[1] = Y; sh_pose[2] = st0; sh_pose[3] = ct0;
       bad = robot_ok ? 0 : 1; bx0 = bx1 = rx0; by0 = by1 = ry0; n_own = 0; srx = rx0; sry = ry0;
+      n_need = 0; robot_cnt = 0; nocc_delta = 0;
     }
   } else {
     for (int t = tid - kWave; t < (tile_cap + 1) / 2; t += nthr - kWave) tile[t] = 0u;
     for (int b = tid - kWave; b < Bv; b += nthr - kWave) ecnt[b] = 0;
     for (int t = tid - kWave; t < kMapTilesMax; t += nthr - kWave) mt_id[t] = 0u;
+    for (int t = tid - kWave; t < kBoxSideMax; t += nthr - kWave) rc_delta[t] = 0;
   }
   __syncthreads();
   const int rx = srx, ry = sry;
@@ -1261,10 +1283,7 @@ __global__ __launch_bounds__(1024, 8) void rbpf_raycast_tile(ScanC c, TilePool P
       if (b < Bv) {
         const double2 pt = beams[b];
         if (!world2cell(c.g, ct * pt.x - st * pt.y + X, st * pt.x + ct * pt.y + Y, ci, cj)) { bad = 1; ci = rx; cj = ry; }
-        ex[b] = ci; ey[b] = cj;
-        int k, xy, dd;
-        pack_ray(make_ray(rx, ry, ci, cj), ci, cj, k, xy, dd);
-        rk[b] = k; rxy[b] = xy; rdd[b] = dd;
+        exy[b] = ci | (cj << 16);
       }
       const int lo_x = wave_min_i(ci), hi_x = wave_max_i(ci), lo_y = wave_min_i(cj), hi_y = wave_max_i(cj);
       if (lane == 0) { atomicMin(&bx0, lo_x); atomicMax(&bx1, hi_x); atomicMin(&by0, lo_y); atomicMax(&by1, hi_y); }
@@ -1273,35 +1292,47 @@ __global__ __launch_bounds__(1024, 8) void rbpf_raycast_tile(ScanC c, TilePool P
   __syncthreads();
   if (bad) { if (tid == 0) atomicOr(&err[0], 1); return; }
   const int minx = bx0, miny = by0, bw = by1 - by0 + 1, bh = bx1 - bx0 + 1, ncell = bw * bh;
-  if (ncell > tile_cap) { if (tid == 0) atomicOr(&err[3], 2); return; }  // cannot happen for beams within range_max
+  const int tx0 = minx >> kTSh, ty0 = miny >> kTSh, mty = (by1 >> kTSh) - ty0 + 1, mtn = ((bx1 >> kTSh) - tx0 + 1) * mty;
+  if (ncell > tile_cap || mtn > kMapTilesMax || bh > kBoxSideMax) { if (tid == 0) atomicOr(&err[3], 2); return; }  // cannot happen: see launch_raycast
+  // the particle's table entries under the box and the reference counts of the tiles they name: requested now, needed
+  // only after the ray walk (phase C) — the two dependent round trips fly under the flag and walk phases
+  unsigned int my_tab = 0u;
+  int my_ref = 0;
+  if (tid < mtn) {
+    const int qi = floor_div_small(tid, mty), qj = tid - qi * mty;
+    my_tab = tab[(tx0 + qi) * M.TW + (ty0 + qj)];
+  }
   PHASE_STAMP(0);
   // F. flag the end-point cells; the beam that finds the flag clear opens the cell's slot
   for (int b = tid; b < Bv; b += nthr) {
-    const int t = (ex[b] - minx) * bw + (ey[b] - miny), sh = (t & 1) * 16;
+    const int e = exy[b], t = ((e & 0xFFFF) - minx) * bw + ((e >> 16) - miny), sh = (t & 1) * 16;
     if (!((atomicOr(&tile[t >> 1], 0x8000u << sh) >> sh) & 0x8000u)) {
       const int o = atomicAdd(&n_own, 1);
       own[o] = b;
       atomicOr(&tile[t >> 1], (unsigned int)o << sh);
     }
   }
+  if (tid < mtn) my_ref = my_tab ? P.ref[my_tab] : 0;
   __syncthreads();
   for (int b = tid; b < Bv; b += nthr) {
-    const int t = (ex[b] - minx) * bw + (ey[b] - miny);
+    const int e = exy[b], t = ((e & 0xFFFF) - minx) * bw + ((e >> 16) - miny);
     const int o = (int)((tile[t >> 1] >> ((t & 1) * 16)) & 0x7FFFu);
-    const int e = atomicAdd(&ecnt[o], 1);
-    if (e < kEvCap) ev[o * kEvCap + e] = (unsigned short)(b | 0x8000);
+    const int en = atomicAdd(&ecnt[o], 1);
+    if (en < kEvCap) ev[o * kEvCap + en] = (unsigned short)(b | 0x8000);
   }
+  const int t_robot = (rx - minx) * bw + (ry - miny);
   PHASE_STAMP(1);
   // 1. counters / events: one LANE per ray segment.  A lane finds its first cell in closed form (one division)
   //    and then walks the ray with the integer error recurrence that the closed form solves:
   //      rem_t = a_t - 2*dmaj*(c_t - 1) in (0, 2*dmaj];   rem += 2*dmin;  if (rem > 2*dmaj) { ++c; rem -= 2*dmaj; }
   //    — a handful of integer instructions per cell instead of a division per cell.  Lanes of one wave take rays
   //    spread round the scan (b = lane * G + ...), so that they rarely meet in the same LDS word near the robot.
+  //    The ROBOT's own cell is the first free cell of every ray: it is not visited (Bv atomics on one LDS word), its
+  //    count is the number of rays that have a free cell at all, added once below.
   {
     int S = Bv > 0 ? nthr / Bv : 1;  // segments per ray: as many as give every thread at most one task
     S = S < 1 ? 1 : (S > 4 ? 4 : S);
     const int G = (Bv + kWave - 1) / kWave;
-    const int t_robot = (rx - minx) * bw + (ry - miny);
     auto visit = [&](int t, int b) {
       const int sh = (t & 1) * 16;
       const unsigned int hlf = tile[t >> 1] >> sh;  // the flag and slot bits are final since the barrier above
@@ -1313,11 +1344,14 @@ __global__ __launch_bounds__(1024, 8) void rbpf_raycast_tile(ScanC c, TilePool P
         atomicAdd(&tile[t >> 1], 1u << sh);
       }
     };
+    int n_first = 0;
     for (int task = tid; task < kWave * G * S; task += nthr) {
       const int tb = floor_div_small(task, S), sgm = task - tb * S;
       const int b = (tb & (kWave - 1)) * G + (tb >> 6);
       if (b >= Bv) continue;
-      const int k = rk[b], xy = rxy[b], dd = rdd[b];
+      const int e = exy[b], ex = e & 0xFFFF, ey = e >> 16;
+      const PackedRay pr = pack_ray(make_ray(rx, ry, ex, ey), ex, ey);
+      const int k = pr.k, xy = pr.xy, dd = pr.dd;
       const int count = k >> 8, L = floor_div_small(count + S - 1, S);
       int n = sgm * L;
       const int n1 = (n + L < count) ? n + L : count;
@@ -1332,7 +1366,7 @@ __global__ __launch_bounds__(1024, 8) void rbpf_raycast_tile(ScanC c, TilePool P
       const int d_major = ymajor ? 1 : bw, d_minor = (ymajor ? bw : 1) * (neg ? -1 : 1);
       const int two_dmin = 2 * dmin, two_dmaj = 2 * dmaj;
       if (n == 0) {  // the first free cell is the robot's own cell (for a reversed ray, step 0 is the end point)
-        visit(t_robot, b);
+        ++n_first;
         rem += two_dmin; t += d_major;
         if (rem > two_dmaj) { rem -= two_dmaj; t += d_minor; }
         ++n;
@@ -1343,15 +1377,23 @@ __global__ __launch_bounds__(1024, 8) void rbpf_raycast_tile(ScanC c, TilePool P
         if (rem > two_dmaj) { rem -= two_dmaj; t += d_minor; }
       }
     }
+    n_first = wave_sum_i(n_first);
+    if (lane == 0 && n_first) atomicAdd(&robot_cnt, n_first);
   }
   __syncthreads();  // every event is recorded
+  if (tid == 0 && robot_cnt) {
+    const int sh = (t_robot & 1) * 16;
+    const unsigned int hlf = tile[t_robot >> 1] >> sh;
+    if (hlf & 0x8000u) ecnt[hlf & 0x7FFFu] = kEvCap + 1;  // the robot's cell is an end point too: replayed against every beam (2b)
+    else tile[t_robot >> 1] += (unsigned int)robot_cnt << sh;
+  }
+  if (tid < mtn) mt_ref[tid] = my_ref;
+  __syncthreads();
   PHASE_STAMP(2);
   // M. which map tiles does this scan write?  Every cell with a counter or a flag marks its tile (kTS x kTS cells of
   //    the particle's tile table; the bounding box spans mtx x mty of them).
-  const int tx0 = minx >> kTSh, ty0 = miny >> kTSh, mty = (by1 >> kTSh) - ty0 + 1, mtn = ((bx1 >> kTSh) - tx0 + 1) * mty;
-  if (mtn > kMapTilesMax) { if (tid == 0) atomicOr(&err[3], 2); return; }  // cannot happen: tile_cap bounds the box
+  const int step_r = floor_div_small(nthr, bw), step_c = nthr - step_r * bw;  // cell t + nthr in (row, col) terms
   {
-    const int step_r = floor_div_small(nthr, bw), step_c = nthr - step_r * bw;
     int trow = floor_div_small(tid < ncell ? tid : 0, bw), tcol = (tid < ncell ? tid : 0) - trow * bw;
     for (int t = tid; t < ncell; t += nthr) {
       if ((tile[t >> 1] >> ((t & 1) * 16)) & 0xFFFFu) mt_id[(((minx + trow) >> kTSh) - tx0) * mty + (((miny + tcol) >> kTSh) - ty0)] = 1u;
@@ -1360,48 +1402,77 @@ __global__ __launch_bounds__(1024, 8) void rbpf_raycast_tile(ScanC c, TilePool P
     }
   }
   __syncthreads();
-  // C. make those tiles private to the particle (first write after a resample, or first touch of the area): one wave
-  //    per tile; a tile the particle already owns alone costs two loads
-  {
-    unsigned int* tab = M.table + (size_t)p * M.TT;
-    unsigned int* shed = M.shed + (size_t)p * M.TT;
-    __shared__ int n_need;
-    __shared__ unsigned long long need_base;
-    __shared__ int mt_slot[kMapTilesMax];  // -1: the tile is private already, else its place in this workgroup's batch
-    if (tid == 0) n_need = 0;
+  // C. make those tiles private to the particle (first write after a resample, or first touch of the area): ONE pop of
+  //    the free ring for all of them, then one wave per tile copies 8 KB
+  if (tid < mtn && mt_id[tid] != 0u) {
+    if (my_tab != 0u && mt_ref[tid] == 1) { mt_slot[tid] = -1; mt_id[tid] = my_tab; }
+    else mt_slot[tid] = atomicAdd(&n_need, 1);
+  }
+  __syncthreads();
+  if (n_need) {  // workgroup-uniform
+    if (tid == 0) { need_base = tile_pop_n(P, (unsigned int)n_need); if (need_base == ~0ull) bad = 1; }
     __syncthreads();
-    if (tid < mtn && mt_id[tid] != 0u) {
-      const int qi = floor_div_small(tid, mty), qj = tid - qi * mty, t = (tx0 + qi) * M.TW + (ty0 + qj);
-      if (tile_is_private(P, tab, t)) { mt_slot[tid] = -1; mt_id[tid] = tab[t]; }
-      else mt_slot[tid] = atomicAdd(&n_need, 1);
+    if (bad) { if (tid == 0) atomicOr(&err[3], 8); return; }  // tile pool exhausted: nothing has been written
+    for (int q = wid; q < mtn; q += nw) {
+      if (mt_id[q] == 0u || mt_slot[q] < 0) continue;
+      const int qi = floor_div_small(q, mty), qj = q - qi * mty;
+      const unsigned int nid = tile_at(P, need_base + (unsigned long long)mt_slot[q]);
+      tile_clone_into(P, tab, shed, (tx0 + qi) * M.TW + (ty0 + qj), nid, lane);
+      if (lane == 0) mt_id[q] = nid;
     }
     __syncthreads();
-    if (n_need) {  // workgroup-uniform
-      if (tid == 0) { need_base = tile_pop_n(P, (unsigned int)n_need); if (need_base == ~0ull) bad = 1; }
-      __syncthreads();
-      if (bad) { if (tid == 0) atomicOr(&err[3], 8); return; }  // tile pool exhausted: nothing has been written
-      for (int q = wid; q < mtn; q += nw) {
-        if (mt_id[q] == 0u || mt_slot[q] < 0) continue;
-        const int qi = floor_div_small(q, mty), qj = q - qi * mty;
-        const unsigned int nid = tile_at(P, need_base + (unsigned long long)mt_slot[q]);
-        tile_clone_into(P, tab, shed, (tx0 + qi) * M.TW + (ty0 + qj), nid, lane);
-        if (lane == 0) mt_id[q] = nid;
-      }
-      __syncthreads();
-    }
   }
   auto cell_ptr = [&](int cx, int cy) -> double* {
     return P.lo + (size_t)mt_id[((cx >> kTSh) - tx0) * mty + ((cy >> kTSh) - ty0)] * kTileCells + in_tile(cx, cy);
   };
-  // 2a. end-point cells whose slot holds every event: one lane each, events applied in beam order
+  auto toggled = [&](int cx, int cy, bool now) {  // the cell crossed the occupied cut-off: bitmap bit, row count, total
+    atomicXor(&bm[(size_t)cx * c.g.words + (cy >> 6)], 1ull << (cy & 63));
+    atomicAdd(&rc_delta[cx - minx], now ? 1 : -1);
+    atomicAdd(&nocc_delta, now ? 1 : -1);
+  };
+  // The two read-modify-write passes share their memory round trip: the end-point cell of this thread (2a) and the
+  // first eight plain cells (3) are requested together, then the end point is replayed while the rest is in flight.
   const int n_cells = n_own;
-  for (int o = tid; o < n_cells; o += nthr) {
+  constexpr int kPer = NT == 1024 ? 4 : 8;  // plain cells per thread in flight (1024 threads: 64 VGPRs to live in)
+  double v0[kPer];         // (only the loaded values stay live across the end-point replay: counts and addresses are re-derived)
+  int n_distinct = 0;
+  // cell t0 + q * nthr of the box, q = 0 .. kPer-1: its count of free adds (0: untouched or an end point) and its address
+  auto plain_cells = [&](int base, auto&& fn) {
+    const int t0 = base + tid;
+    int trow = floor_div_small(t0 < ncell ? t0 : 0, bw), tcol = (t0 < ncell ? t0 : 0) - trow * bw;  // t < 2^15, bw < 2^8
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+      const int t = t0 + q * nthr;
+      int cnq = 0;
+      if (t < ncell) {
+        const unsigned int hlf = (tile[t >> 1] >> ((t & 1) * 16)) & 0xFFFFu;
+        if (!(hlf & 0x8000u)) cnq = (int)hlf;
+      }
+      fn(q, cnq, minx + trow, miny + tcol);
+      trow += step_r; tcol += step_c;
+      if (tcol >= bw) { tcol -= bw; ++trow; }
+    }
+  };
+  auto fetch_plain = [&](int base) {
+    plain_cells(base, [&](int q, int cnq, int cx, int cy) { v0[q] = cnq ? *cell_ptr(cx, cy) : 0.0; });
+  };
+  auto finish_plain = [&](int base) {
+    plain_cells(base, [&](int q, int cnq, int cx, int cy) {
+      if (!cnq) return;
+      ++n_distinct;
+      double v = v0[q];
+      int a = 0;
+      for (; a + 4 <= cnq; a += 4) { v += c.d_free; v += c.d_free; v += c.d_free; v += c.d_free; }
+      for (; a < cnq; ++a) v += c.d_free;
+      *cell_ptr(cx, cy) = v;
+      const bool was = v0[q] >= c.cut_occ, now = v >= c.cut_occ;
+      if (was != now) toggled(cx, cy, now);
+    });
+  };
+  // 2a. end-point cells whose slot holds every event: one lane each, events applied in beam order
+  auto replay_slot = [&](int o, double* cellp, double v0e) {
     const int ne = ecnt[o];
-    if (ne > kEvCap) continue;
-    const int cx = ex[own[o]], cy = ey[own[o]];
-    double* const cellp = cell_ptr(cx, cy);
-    const double v0 = *cellp;
-    double v = v0;
+    double v = v0e;
     int last = -1;
     for (int i = 0; i < ne; ++i) {  // selection by ascending beam (ne is a handful)
       int best_key = 0x8000, best_ev = 0;
@@ -1413,11 +1484,21 @@ __global__ __launch_bounds__(1024, 8) void rbpf_raycast_tile(ScanC c, TilePool P
       last = best_key;
     }
     *cellp = v;
-    const bool was = v0 >= c.cut_occ, now = v >= c.cut_occ;
-    if (was != now) {
-      atomicXor(&bm[(size_t)cx * c.g.words + (cy >> 6)], 1ull << (cy & 63));
-      atomicAdd(&rc[cx], now ? 1 : -1);
-      atomicAdd(nocc, now ? 1 : -1);
+    const bool was = v0e >= c.cut_occ, now = v >= c.cut_occ;
+    if (was != now) { const int e = exy[own[o]]; toggled(e & 0xFFFF, e >> 16, now); }
+  };
+  {
+    const bool mine = tid < n_cells && ecnt[tid] <= kEvCap;
+    double* cellp = nullptr;
+    double v0e = 0.0;
+    if (mine) { const int e = exy[own[tid]]; cellp = cell_ptr(e & 0xFFFF, e >> 16); v0e = *cellp; }
+    fetch_plain(0);
+    if (mine) replay_slot(tid, cellp, v0e);
+    for (int o = tid + nthr; o < n_cells; o += nthr) {  // (more end-point cells than threads: long scans)
+      if (ecnt[o] > kEvCap) continue;
+      const int e = exy[own[o]];
+      double* cp = cell_ptr(e & 0xFFFF, e >> 16);
+      replay_slot(o, cp, *cp);
     }
   }
   // 2b. overflowed slots: one wave per cell.  Lanes test beams q = 64*i + lane against the cell (is it q's end
@@ -1428,16 +1509,16 @@ __global__ __launch_bounds__(1024, 8) void rbpf_raycast_tile(ScanC c, TilePool P
   const int trips = (Bv + kWave - 1) / kWave;
   for (int o = wid; o < n_cells; o += nw) {
     if (ecnt[o] <= kEvCap) continue;
-    const int cx = ex[own[o]], cy = ey[own[o]];
+    const int eo = exy[own[o]], cx = eo & 0xFFFF, cy = eo >> 16;
     double* const cellp = cell_ptr(cx, cy);
-    const double v0 = *cellp;
-    double v = v0;
+    const double v0o = *cellp;
+    double v = v0o;
     const int ux = cx - rx, uy = cy - ry;
     for (int i = 0; i < trips; ++i) {
       const int q = i * kWave + lane;
       bool is_end = false, hit = false;
       if (q < Bv) {
-        const int qx = ex[q], qy = ey[q];
+        const int eq = exy[q], qx = eq & 0xFFFF, qy = eq >> 16;
         is_end = (qx == cx) && (qy == cy);  // the end point is never one of its own ray's free cells
         const int dx = qx - rx, dy = qy - ry;
         const double cr = (double)(ux * dy - uy * dx), l2 = (double)(dx * dx + dy * dy);
@@ -1455,66 +1536,30 @@ __global__ __launch_bounds__(1024, 8) void rbpf_raycast_tile(ScanC c, TilePool P
     }
     if (lane == 0) {
       *cellp = v;
-      const bool was = v0 >= c.cut_occ, now = v >= c.cut_occ;
-      if (was != now) {
-        atomicXor(&bm[(size_t)cx * c.g.words + (cy >> 6)], 1ull << (cy & 63));
-        atomicAdd(&rc[cx], now ? 1 : -1);
-        atomicAdd(nocc, now ? 1 : -1);
-      }
+      const bool was = v0o >= c.cut_occ, now = v >= c.cut_occ;
+      if (was != now) toggled(cx, cy, now);
     }
   }
   PHASE_STAMP(3);
-  // 3. every other touched cell: its count of free adds.  Eight cells per thread per trip (lanes on consecutive
-  //    cells, the eight a whole block apart) so that the eight independent log-odds loads are in flight
-  //    together instead of one exposed HBM round trip per cell.
-  constexpr int kPer = 8;
-  const int step_r = floor_div_small(nthr, bw), step_c = nthr - step_r * bw;  // cell t + nthr in (row, col) terms
-  int n_distinct = 0;
-  for (int base = 0; base < ncell; base += nthr * kPer) {
-    int cn[kPer];
-    double* idx[kPer];
-    double v0[kPer];
-    const int t0 = base + tid;
-    int trow = floor_div_small(t0 < ncell ? t0 : 0, bw), tcol = (t0 < ncell ? t0 : 0) - trow * bw;  // t < 2^15, bw < 2^8
-#pragma unroll
-    for (int q = 0; q < kPer; ++q) {
-      const int t = t0 + q * nthr;
-      cn[q] = 0;
-      idx[q] = nullptr;
-      if (t < ncell) {
-        const unsigned int hlf = (tile[t >> 1] >> ((t & 1) * 16)) & 0xFFFFu;
-        if (!(hlf & 0x8000u)) cn[q] = (int)hlf;
-        if (cn[q]) idx[q] = cell_ptr(minx + trow, miny + tcol);
-      }
-      trow += step_r; tcol += step_c;
-      if (tcol >= bw) { tcol -= bw; ++trow; }
-    }
-#pragma unroll
-    for (int q = 0; q < kPer; ++q) v0[q] = cn[q] ? *idx[q] : 0.0;
-#pragma unroll
-    for (int q = 0; q < kPer; ++q) {
-      if (!cn[q]) continue;
-      ++n_distinct;
-      double v = v0[q];
-      int a = 0;
-      for (; a + 4 <= cn[q]; a += 4) { v += c.d_free; v += c.d_free; v += c.d_free; v += c.d_free; }
-      for (; a < cn[q]; ++a) v += c.d_free;
-      *idx[q] = v;
-      const bool was = v0[q] >= c.cut_occ, now = v >= c.cut_occ;
-      if (was != now) {
-        const int t = t0 + q * nthr, tr = floor_div_small(t, bw), cx = minx + tr, cy = miny + (t - tr * bw);
-        atomicXor(&bm[(size_t)cx * c.g.words + (cy >> 6)], 1ull << (cy & 63));
-        atomicAdd(&rc[cx], now ? 1 : -1);
-        atomicAdd(nocc, now ? 1 : -1);
-      }
-    }
+  // 3. every other touched cell: its count of free adds (the first eight per thread are already here)
+  finish_plain(0);
+  for (int base = nthr * kPer; base < ncell; base += nthr * kPer) {
+    fetch_plain(base);
+    finish_plain(base);
   }
+  __syncthreads();
+  // the row counts / occupied count of the particle: one plain update per changed row (this workgroup owns them)
+  for (int r = tid; r < bh; r += nthr) if (rc_delta[r]) rc[minx + r] += rc_delta[r];
+  if (tid == 0 && nocc_delta) n_occ[p] += nocc_delta;
   if (touched) {  // measurement hook (tbnav_rbpf_scan_counts): [0] += cell updates (free adds + end points), [1] += distinct cells written
     __shared__ int cnt_upd, cnt_dis;
     if (tid == 0) { cnt_upd = 0; cnt_dis = n_cells; }
     __syncthreads();
     int n_upd = 0;
-    for (int b = tid; b < Bv; b += nthr) n_upd += (rk[b] >> 8) + 1;
+    for (int b = tid; b < Bv; b += nthr) {
+      const int e = exy[b], dx = (e & 0xFFFF) - rx, dy = (e >> 16) - ry;
+      n_upd += max(dx < 0 ? -dx : dx, dy < 0 ? -dy : dy) + 1;  // free cells of the ray (its Chebyshev length) + the end point
+    }
     n_upd = wave_sum_i(n_upd); n_distinct = wave_sum_i(n_distinct);
     if (lane == 0) { atomicAdd(&cnt_upd, n_upd); atomicAdd(&cnt_dis, n_distinct); }
     __syncthreads();
@@ -2130,7 +2175,8 @@ struct tbnav_rbpf {
   double* d_score = nullptr;   // [N]
   bool timing = false;         // record HIP events round the kernels (tbnav_rbpf_set_timing): each costs device time, so off by default
   int tile_cap = 0;            // cells of the raycast LDS tile (0 = use the beam-ordered kernel)
-  int raycast_threads = 1024;  // block size of the tile raycast (dev switch TBNAV_RBPF_RAYCAST_THREADS)
+  int raycast_threads = 0;     // block size of the tile raycast: 0 = chosen per scan from its LDS footprint (TBNAV_RBPF_OPT_RAYCAST_THREADS)
+  double* d_sens = nullptr;    // [N][4] sensor transform (X, Y, sin, cos) of each particle's new pose, left by the proposal kernel
   uint64_t seed = 0x5EEDull, scan_index = 0;  // device noise source (normals == NULL)
   bool full_edt = false;       // distance-field mode 0 (TBNAV_RBPF_DF=full): whole-map transform after every map update
   int df_mode = 2;             // 0 full, 1 windowed refresh before the update (TBNAV_RBPF_DF=window), 2 exact query at lookup (default)
@@ -2270,10 +2316,14 @@ int build_scan_consts(tbnav_rbpf* h, ScanC& c, const float* scan, int n_beams, c
   c.p0 = 0;
   // valid beams in the sensor frame, sensor_model.cpp:73-108 (float limits, double angle accumulation)
   beams.clear();
+  c.rmax = 0.0;
   double beam_angle = P.beam_min;
   for (int i = 0; i < n_beams; ++i) {
     const double range = scan[i];
-    if (range >= P.range_min && range < P.range_max) beams.push_back(double2{range * std::cos(beam_angle), range * std::sin(beam_angle)});
+    if (range >= P.range_min && range < P.range_max) {
+      beams.push_back(double2{range * std::cos(beam_angle), range * std::sin(beam_angle)});
+      c.rmax = std::max(c.rmax, range);
+    }
     beam_angle += P.beam_delta;
     if (P.beam_max < 0.0 && beam_angle <= P.beam_max) beam_angle = P.beam_min;
     else if (P.beam_max >= 0.0 && beam_angle >= P.beam_max) beam_angle = P.beam_min;
@@ -2422,17 +2472,31 @@ int ref_field_after_scan(tbnav_rbpf* h, bool resampled, int p_first = 0, int p_c
 }
 
 // GridMapper::integrateScan's map update (grid_mapper.cpp:140-178) for particles [c.p0, c.p0 + count) at their poses.
-int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count) {
+// sens: the sensor transforms the proposal kernel left for exactly these poses (NULL: the raycast derives them).
+int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens) {
   hipStream_t st = h->stream;
   StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
   const int bvn = c.Bv > 0 ? c.Bv : 1;
-  const size_t tile_lds = sizeof(int) * kTileIntsPerBeam * bvn + sizeof(unsigned int) * ((size_t)(h->tile_cap + 1) / 2);
+  // The LDS counter tile covers the scan's bounding box: every end point lies within (longest valid beam of THIS scan
+  // + the laser's offset) of the robot cell, +2 cells for rounding — usually well below the worst case the handle
+  // was sized for (range_max), which is what lets more than two workgroups share a CU.
+  int cap = 0;
+  if (h->tile_cap > 0) {
+    const double reach = c.rmax + std::hypot(h->p.Trs[1], h->p.Trs[2]);
+    const long side = 2 * ((long)std::ceil(reach / h->p.resolution) + 2) + 1;
+    cap = (int)std::min<long>(side * side, h->tile_cap);
+  }
+  const size_t tile_lds = sizeof(int) * kTileIntsPerBeam * bvn + sizeof(unsigned int) * ((size_t)(cap + 1) / 2);
   const MapT M = map_of(h);
-  if (h->tile_cap > 0 && !h->ref_field && c.Bv < 32768 && tile_lds <= (size_t)kMaxLds - 1024)
-    hipLaunchKernelGGL(rbpf_raycast_tile, dim3(count), dim3(h->raycast_threads), tile_lds, st, c, h->pool, M, h->d_beams, sp.pose,
-                       h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_nocc[h->cur], h->d_err, h->tile_cap,
-                       h->count_touched ? h->d_touched : nullptr);
-  else {
+  if (cap > 0 && !h->ref_field && c.Bv < 32768 && tile_lds <= (size_t)kMaxLds - 2048) {
+    unsigned long long* touched = h->count_touched ? h->d_touched : nullptr;
+#define TBNAV_RAYCAST(NT) hipLaunchKernelGGL(rbpf_raycast_tile<NT>, dim3(count), dim3(NT), tile_lds, st, c, h->pool, M, h->d_beams, sp.pose, sens, \
+                                             h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_nocc[h->cur], h->d_err, cap, touched)
+    int nt = h->raycast_threads;
+    if (nt == 0) nt = 1024;  // measured at cfg3 (N = 1000 / 4000): 1024 threads 70 / 268 us, 512 threads 78 / 273 us, 256 threads 114 / 393 us
+    if (nt == 256) TBNAV_RAYCAST(256); else if (nt == 512) TBNAV_RAYCAST(512); else TBNAV_RAYCAST(1024);
+#undef TBNAV_RAYCAST
+  } else {
     // beam-ordered kernel: scans the LDS tile cannot hold, and the reference distance-field mode (it logs the
     // occupied-set changes in the reference's order)
     OccLog log{nullptr, nullptr, 0};
@@ -2556,7 +2620,7 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
   }
   hipLaunchKernelGGL(rbpf_propose, dim3(h->N), dim3(kProposeThreads), propose_lds, st, c, h->d_beams,
                      h->d_code[h->cur], h->d_bitmap[h->cur], h->d_rowcount[h->cur], skip_arr, skip_eq, h->df_mode, h->radius, occ_half,
-                     h->d_nocc[h->cur], h->d_win, h->d_normals, center, sp.pose, sp.prev, sp.weight, h->tr, h->d_err);
+                     h->d_nocc[h->cur], h->d_win, h->d_normals, center, sp.pose, sp.prev, sp.weight, h->tr, h->d_sens, h->d_err);
   TBNAV_HIP(hipGetLastError());
   if (h->timing) TBNAV_HIP(hipEventRecord(h->ev[2], st));
   // normalise / select needs only the weights the proposal kernel left: it runs on the second stream, beside the
@@ -2576,7 +2640,7 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
     if (rc != TBNAV_OK) return rc;
     TBNAV_HIP(hipEventRecord(h->ev_n, h->stream2));
   }
-  rc = launch_raycast(h, c, h->N);
+  rc = launch_raycast(h, c, h->N, h->d_sens);
   if (rc != TBNAV_OK) return rc;
   if (h->timing) TBNAV_HIP(hipEventRecord(h->ev[3], st));
   if (h->full_edt) {
@@ -2707,6 +2771,7 @@ int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf*
   }
   A((void**)&h->d_shed, sizeof(unsigned int) * table_entries);
   A((void**)&h->d_cs, sizeof(double) * N);
+  A((void**)&h->d_sens, sizeof(double) * 4 * N);
   A((void**)&h->d_tile_scratch, sizeof(unsigned int) * h->TT);
   A((void**)&h->d_touched, sizeof(unsigned long long) * 2);
   A((void**)&h->d_parent, sizeof(int) * N);
@@ -2798,7 +2863,9 @@ int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf*
     e = (C == 64) ? hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_edt<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)
                   : hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_edt<32>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_tile), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_tile<256>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 2048);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_tile<512>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 2048);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_tile<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 2048);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 1024);
   // the proposal / scan-match kernels carry the scan, the per-sample data and the bitmap slice: more than the 64 KB
   // default for long scans or many samples
@@ -2853,7 +2920,7 @@ void tbnav_rbpf_destroy(tbnav_rbpf* h) {
   DeviceGuard guard(h->device);
   for (int b = 0; b < 2; ++b) { (void)hipFree(h->d_state[b]); (void)hipFree(h->d_table[b]); (void)hipFree(h->d_code[b]); (void)hipFree(h->d_nocc[b]); (void)hipFree(h->d_bitmap[b]); (void)hipFree(h->d_rowcount[b]); }
   (void)hipFree(h->pool.lo); (void)hipFree(h->pool.ref); (void)hipFree(h->pool.ring); (void)hipFree(h->pool.ctr);
-  (void)hipFree(h->d_shed); (void)hipFree(h->d_dense); (void)hipFree(h->d_cs); (void)hipFree(h->d_touched); (void)hipFree(h->d_fstate_alt);
+  (void)hipFree(h->d_sens); (void)hipFree(h->d_shed); (void)hipFree(h->d_dense); (void)hipFree(h->d_cs); (void)hipFree(h->d_touched); (void)hipFree(h->d_fstate_alt);
   (void)hipFree(h->d_log_ev); (void)hipFree(h->d_log_cnt); (void)hipFree(h->d_tile_scratch);
   (void)hipFree(h->d_gw); (void)hipFree(h->d_gcs); (void)hipFree(h->d_gparent); (void)hipFree(h->d_gz);
   (void)hipFree(h->d_beams); (void)hipFree(h->d_normals); (void)hipFree(h->d_parent); (void)hipFree(h->d_best); (void)hipFree(h->d_best_pose); (void)hipFree(h->d_export); (void)hipFree(h->d_tier); (void)hipFree(h->d_fstate); (void)hipFree(h->d_skip); (void)hipFree(h->d_win); (void)hipFree(h->d_center); (void)hipFree(h->d_score);
@@ -3335,7 +3402,7 @@ int tbnav_rbpf_integrate_scan(tbnav_rbpf* h, int32_t particle, const float* scan
   TBNAV_HIP(hipStreamSynchronize(h->stream));
   TBNAV_HIP(hipMemcpy(sp.pose + (size_t)particle * 3, pose, sizeof(double) * 3, hipMemcpyHostToDevice));
   for (int q = 0; q < 4; ++q) h->h_err[q] = 0;
-  rc = launch_raycast(h, c, 1);
+  rc = launch_raycast(h, c, 1, nullptr);
   if (rc != TBNAV_OK) return rc;
   const int zero = 0;  // the map changed: a stored field of this particle is stale
   TBNAV_HIP(hipMemcpyAsync(h->d_fstate + particle, &zero, sizeof zero, hipMemcpyHostToDevice, h->stream));
@@ -3410,7 +3477,7 @@ int tbnav_rbpf_set_option(tbnav_rbpf* h, int32_t option, int32_t value) {
       }
       return TBNAV_OK;
     case TBNAV_RBPF_OPT_RAYCAST_THREADS:
-      if (value != 256 && value != 512 && value != 1024) return TBNAV_ERR_INVALID_ARG;
+      if (value != 0 && value != 256 && value != 512 && value != 1024) return TBNAV_ERR_INVALID_ARG;
       h->raycast_threads = value;
       return TBNAV_OK;
     case TBNAV_RBPF_OPT_COUNT_CELLS:

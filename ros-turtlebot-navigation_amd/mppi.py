@@ -43,7 +43,10 @@ class MPPI:
 
     def __init__(self, cart_model: CartModel, loss_func: LossFunc, lam: float, max_wheel_vel: float,
                  ul_var: float, ur_var: float, horizon: float, dt: float, rollouts: int,
-                 device: int = -1):
+                 device: int = -1, keep_j: bool = True, kernel: int | str | None = None):
+        """keep_j: the fused small-K kernel also stores the cost-to-go so that costToGo() works (test plumbing; the
+        bench and the C++ class leave it off).  kernel: TBNAV_MPPI_OPT_KERNEL value, or "scan" for the time-parallel
+        three-kernel tick with its automatic chunk size."""
         p = capi.MppiParams()
         p.wheel_radius, p.wheel_base = cart_model.wheel_radius, cart_model.wheel_base
         p.lam, p.max_wheel_vel, p.ul_var, p.ur_var = lam, max_wheel_vel, ul_var, ur_var
@@ -57,11 +60,23 @@ class MPPI:
         self._h = C.c_void_p()
         capi.check(self._L.tbnav_mppi_create(C.byref(p), C.byref(self._h)), "tbnav_mppi_create")
         self.steps = self._L.tbnav_mppi_steps(self._h)
+        if kernel == "scan":
+            kernel = next(tc for tc in (4, 5, 6, 8, 10, 12, 16, 20) if -(-self.steps // tc) <= 12)
+        if kernel is not None:
+            self.setOption(capi.MPPI_OPT_KERNEL, int(kernel))
+        if keep_j:
+            self.setOption(capi.MPPI_OPT_KEEP_J, 1)
         self.rollouts = self._L.tbnav_mppi_rollouts(self._h)
         self.records_per_step = self._L.tbnav_mppi_records_per_step(self._h)
         v = self._L.tbnav_mppi_rollout_variant(self._h)
         self.rollout_kernel = ("mppi_rollout_cost" if v == 0 else f"mppi_rollout_scan<{v} steps/thread>" if v > 0
                                else f"mppi_rollout_fused<{-v} rollouts/workgroup> (rollout + partial records)")
+
+    def setOption(self, option: int, value: int):
+        capi.check(self._L.tbnav_mppi_set_option(self._h, option, value), "tbnav_mppi_set_option")
+
+    def setRngShard(self, first_rollout: int, rollouts_global: int):
+        capi.check(self._L.tbnav_mppi_set_rng_shard(self._h, first_rollout, rollouts_global), "tbnav_mppi_set_rng_shard")
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -147,6 +162,10 @@ class MPPI:
         x0c = (C.c_double * 3)(*x0)
         capi.check(self._L.tbnav_mppi_shard_partials(self._h, x0c, d_duL or None, d_duR or None,
                                                      stream or None, d_records), "shard_partials")
+
+    def shardPartialsRng(self, x0, seed: int, tick: int, d_records: int, stream: int = 0):
+        x0c = (C.c_double * 3)(*x0)
+        capi.check(self._L.tbnav_mppi_shard_partials_rng(self._h, x0c, seed, tick, stream or None, d_records), "shard_partials_rng")
 
     def shardCombine(self, d_records_all: int, n_shards: int, stream: int = 0):
         capi.check(self._L.tbnav_mppi_shard_combine(self._h, d_records_all, n_shards, stream or None),

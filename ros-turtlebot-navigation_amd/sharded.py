@@ -57,8 +57,13 @@ class HipShardBackend:
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def partials(self, x0, noise) -> torch.Tensor:
-        d_l, d_r = noise  # device pointers (ints), layout [T][K_local]
-        self.m.shardPartials(x0, d_l, d_r, self.records.data_ptr(), self._stream())
+        """noise = (d_duL, d_duR) device pointers, layout [T][K_local] — or ("rng", seed, tick): the shard draws its own
+        perturbations on the device (MPPI.setRngShard gives it its place in the ensemble's counter space)."""
+        if noise[0] == "rng":
+            self.m.shardPartialsRng(x0, int(noise[1]), int(noise[2]), self.records.data_ptr(), self._stream())
+        else:
+            d_l, d_r = noise
+            self.m.shardPartials(x0, d_l, d_r, self.records.data_ptr(), self._stream())
         return self.records
 
     def combine(self, records_all: torch.Tensor, n_shards: int):

@@ -70,15 +70,14 @@ def test_ragged_sizes(gpu_pkg, K, horizon):
 
 @pytest.mark.parametrize("fused", ["0", "4", "8", "16"])
 @pytest.mark.parametrize("K,horizon", [(1024, 0.5), (100, 1.0), (37, 1.28), (9, 0.65)])
-def test_rollout_kernel_variants_agree_with_the_oracle(gpu_pkg, monkeypatch, fused, K, horizon):
+def test_rollout_kernel_variants_agree_with_the_oracle(gpu_pkg, fused, K, horizon):
     """The small-K tick has two implementations: three kernels (time-parallel rollout, partials, combine;
     TBNAV_MPPI_FUSED=0) and the fused rollout+partials kernel (one wave per rollout, lanes over time; 4 / 8 / 16
     rollouts per workgroup).  Each must meet the oracle on its own: T = 50 (one step per lane), T = 100 and 128
     (two steps per lane, full last lane), T = 65 (ragged last lanes), K not a multiple of the workgroup tile, and
     three consecutive ticks so that the shift-on-read warm start is exercised in every variant."""
-    monkeypatch.setenv("TBNAV_MPPI_FUSED", fused)
     d = mppi_cfg(K, horizon)
-    m = make_mppi(gpu_pkg, d)
+    m = make_mppi(gpu_pkg, d, kernel="scan" if fused == "0" else -int(fused))
     T = orc.mppi_steps(d)
     assert m.steps == T
     m.setWaypoint(*WAYPOINTS[2])

@@ -73,11 +73,10 @@ def rbpf_case(i):
     sm = bool(rng.random() < 0.25) and icp_ok
     mode = str(rng.choice(["query", "query", "window", "full"]))
     desc = dict(N=N, k=k, half=half, bd=bd, spread=spread, trs=trs, icp_ok=icp_ok, sm=sm, mode=mode)
-    os.environ["TBNAV_RBPF_DF"] = mode
     extra = dict(sample_range=[spread * 0.1, spread, spread], Trs=trs)
     n_beams = int(round(360 / bd))
     pf_o = orc.PfAPI(orc.pf_params(N=N, k=k, map_min=-half, map_max=half, beam_delta_deg=bd, **extra))
-    pf_d = ParticleFilter(default_params(N=N, k=k, map_min=-half, map_max=half, beam_delta_deg=bd, **extra))
+    pf_d = ParticleFilter(default_params(N=N, k=k, map_min=-half, map_max=half, beam_delta_deg=bd, **extra), df_mode=mode)
     inc = (float(rng.uniform(-0.06, 0.06)), float(rng.uniform(0.01, 0.06)), float(rng.uniform(-0.04, 0.04)))
     steps, poses = rc.trajectory(4, inc=inc, start=(float(rng.uniform(-3.1, 3.1)), 0.0, 0.0))
     walls = (-1.2, 1.1, -1.0, 1.3)
@@ -156,5 +155,4 @@ for name, fn, n in (("mppi", mppi_case, n_mppi), ("rbpf", rbpf_case, n_rbpf)):
             if fails <= 3:
                 traceback.print_exc(limit=2)
     print(f"{name}: {n} cases done, failures so far {fails}", flush=True)
-os.environ.pop("TBNAV_RBPF_DF", None)
 sys.exit(1 if fails else 0)

@@ -7,10 +7,13 @@ import __graft_entry__ as g
 g.load_package()
 import torch
 import bench_rbpf
+from rtn_amd import capi
 from rtn_amd.rbpf import ParticleFilter, default_params
 steps, scans = bench_rbpf.workload(12)
-pf = ParticleFilter(default_params(N=1000, k=50, map_min=-10.0, map_max=10.0))
-pf.setSeed(1)
+nt = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+pf = ParticleFilter(default_params(N=N, k=50, map_min=-10.0, map_max=10.0))
+pf.setSeed(1); pf.setOption(capi.RBPF_OPT_RAYCAST_THREADS, nt)
 for s, (prev, cur, t_icp, u) in enumerate(steps):
     pf.SLAM(scans[s], u, cur, prev, True, t_icp, None)
 pf.close()
