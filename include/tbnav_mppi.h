@@ -78,8 +78,9 @@ int tbnav_mppi_rollout_variant(const tbnav_mppi* h);
  *                          2 (fresh every step), 3 (the reference's three evaluations).
  *  TBNAV_MPPI_OPT_NO_LDS_STAGING  1 = mppi_rollout_cost stages every per-step loss through J (development).
  *  TBNAV_MPPI_OPT_KEEP_J   1 = the fused kernel also stores the cost-to-go J[T][K] (410 KB at K=1024, T=50) so that
- *                          tbnav_mppi_get_cost_to_go can return it; off by default — the update needs only the records. */
-enum { TBNAV_MPPI_OPT_KERNEL = 1, TBNAV_MPPI_OPT_TRIG = 2, TBNAV_MPPI_OPT_NO_LDS_STAGING = 3, TBNAV_MPPI_OPT_KEEP_J = 4 };
+ *                          tbnav_mppi_get_cost_to_go can return it; off by default — the update needs only the records.
+ *  TBNAV_MPPI_OPT_REG_TAIL 0 = do not use mppi_rollout_cost_reg (losses of the last steps in registers) even where it applies. */
+enum { TBNAV_MPPI_OPT_KERNEL = 1, TBNAV_MPPI_OPT_TRIG = 2, TBNAV_MPPI_OPT_NO_LDS_STAGING = 3, TBNAV_MPPI_OPT_KEEP_J = 4, TBNAV_MPPI_OPT_REG_TAIL = 5 };
 int tbnav_mppi_set_option(tbnav_mppi* h, int32_t option, int32_t value);
 
 /* Rollout dynamics.  TBNAV_MPPI_DYN_RK4 (default) is the reference MPPI: CartModel + RK4 (controller/include/

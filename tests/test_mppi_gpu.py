@@ -327,3 +327,21 @@ def test_device_sincos_accuracy(gpu_pkg):
     print(f"[device sincos] |x| <= 1e12: max abs err {eb[:20000].max():.3e}; at 3e7 {eb[20000]:.1e}, -2.5e12 {eb[20001]:.1e}, 1e15 {eb[20002]:.1e}")
     assert eb[:20000].max() <= 5e-16
     assert np.allclose(sb * sb + cb * cb, 1.0, atol=1e-12)
+
+
+@pytest.mark.parametrize("K,horizon", [(32768 + 37, 1.0), (32768, 0.6), (40000, 0.12), (33000, 0.32)])
+def test_streaming_rollout_kernel_against_the_oracle(gpu_pkg, K, horizon):
+    """The large-K rollout kernel (mppi_rollout_cost_reg: K/64 >= 2 waves per CU-SIMD pair, T a multiple of 4: losses of
+    the last steps in registers, the rest in LDS, branch-free rounds of three groups) against the oracle tick: T = 100
+    (a whole number of rounds), 60, 12 (fewer groups than one round) and 32 (a partial last round), a ragged last wave,
+    two ticks of warm start."""
+    d = mppi_cfg(K, horizon)
+    m = make_mppi(gpu_pkg, d)
+    T = orc.mppi_steps(d)
+    assert m.steps == T and T % 4 == 0 and m.rollout_kernel == "mppi_rollout_cost"
+    m.setWaypoint(*WAYPOINTS[2])
+    u = np.zeros((2, T)); x0 = (0.3, -0.2, 0.7)
+    for tick in range(2):
+        ref = _check_tick(m, d, u, (0, 0), WAYPOINTS[2], x0, _noise(90 + tick, K, T))
+        u = ref["u"]
+        x0 = (x0[0] + 0.002, x0[1] - 0.001, x0[2] + 0.003)
