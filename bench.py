@@ -289,7 +289,8 @@ def main():
             ma.close()
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(K, T, horizon, threads=1)
-            line["cpu_baseline_all_cores"] = cpu_baseline(K, T, horizon, threads=os.cpu_count() or 1, budget_s=8.0)
+            import bench_rbpf
+            line["cpu_baseline_all_cores"] = cpu_baseline(K, T, horizon, threads=bench_rbpf.effective_cores(), budget_s=8.0)
         if world == 1 and not args.no_rbpf:
             import bench_rbpf
             line["rbpf"] = bench_rbpf.run(device, args, with_cpu=not args.no_cpu_baseline)

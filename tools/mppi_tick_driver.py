@@ -10,6 +10,10 @@ dev = torch.device("cuda", 0)
 m = bench.make_mppi(K, hor, 0)
 a, b = bench.synth_noise(m.steps, K, dev, 1)
 st = torch.cuda.current_stream(dev).cuda_stream
-for _ in range(n):
-    m.enqueueDev(bench.X0, a.data_ptr(), b.data_ptr(), st)
+rng = len(sys.argv) > 4 and sys.argv[4] == "rng"   # production tick: perturbations drawn inside the kernel
+for i in range(n):
+    if rng:
+        m.enqueueRng(bench.X0, 42, i, st)
+    else:
+        m.enqueueDev(bench.X0, a.data_ptr(), b.data_ptr(), st)
 print(m.lastControls(st))

@@ -10,10 +10,10 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 n_scans = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 dev_noise = len(sys.argv) > 3 and sys.argv[3] == "dev"   # standard normals drawn on the device (bench mode)
 pf = ParticleFilter(default_params(N=N, k=50, map_min=-10.0, map_max=10.0))
-pf.setTiming(True)
-steps, poses = rc.trajectory(n_scans, inc=(0.07, 0.10, 0.05))
-rng = np.random.default_rng(7)
+steps, scans = bench_rbpf.workload(n_scans)   # the bench's room: all 360 beams valid
 for s, (prev, cur, t_icp, u) in enumerate(steps):
-    scan = bench_rbpf._room_scan(poses[s], rng, rc.ROOM_SURVEY)
+    scan = scans[s]
+    if s in bench_rbpf.RESAMPLE_AT:
+        bench_rbpf._skew(pf, N)
     st = pf.SLAM(scan, u, cur, prev, True, t_icp, None if dev_noise else np.random.default_rng(100 + s).standard_normal(pf.numNormals(True)))
-print(st.neff, pf.kernelMs())
+print(st.neff)

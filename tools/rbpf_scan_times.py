@@ -25,5 +25,5 @@ for icp_ok in (True, False):
         t0 = time.perf_counter()
         st = pf.SLAM(scan, u, cur, prev, icp_ok, t_icp, None)
         ts.append((time.perf_counter() - t0) * 1e3)
-    print("icp_ok" if icp_ok else "icp_failed", os.environ.get("TBNAV_RBPF_DF", "query"), " ".join(f"{t:.3f}" for t in ts), "ms; status", st.status)
+    print("icp_ok" if icp_ok else "icp_failed", "query", " ".join(f"{t:.3f}" for t in ts), "ms; status", st.status)
     pf.close()
