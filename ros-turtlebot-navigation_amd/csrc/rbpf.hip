@@ -1177,8 +1177,6 @@ __device__ __forceinline__ bool on_ray(const Ray& r, int cx, int cy) {
 //     them is immaterial) — bit-identical to the beam-ordered loop, checked against it and the oracle.
 // LDS (ints): ex ey own rk rxy rdd ecnt [Bv each] | ev u16[Bv][kEvCap] | tile u32[(cap+1)/2] (two 16-bit
 // halves per word: bit 15 = end-point flag, low 15 bits = free-add count, or the slot index when flagged).
-constexpr int kEvCap = 16;
-constexpr int kTileIntsPerBeam = 3 + kEvCap / 2;
 constexpr int kMapTilesMax = 64;  // map tiles a scan's bounding box can span: (ceil(175 / 32) + 1)^2 = 49 for tile_cap 30000
 // Packed ray for the counting pass.  Every ray is written in the form of the reference's plotLineLow / plotLineHigh
 // cases: a major axis, a start (xa, ya) at the low end of that axis, dmaj steps along it, and the minor offset
@@ -1217,8 +1215,18 @@ __device__ __forceinline__ int wave_sum_i(int v) {
 constexpr int kBoxSideMax = 176;  // rows a scan's bounding box can have (tile_cap <= 30000 -> side <= 173)
 // Residency the register allocation is held to: 1024 threads -> 2 workgroups per CU (8 waves per SIMD, 64 VGPRs),
 // 512 -> 3 (6 per SIMD, 80 VGPRs), 256 -> 3 (LDS-bound anyway).
-template <int NT>
-__global__ __launch_bounds__(NT, NT == 1024 ? 8 : (NT == 512 ? 6 : 3)) void rbpf_raycast_tile(ScanC c, TilePool P, MapT M, const double2* __restrict__ beams,
+// FW = bits per cell of the LDS tile: 16 (flag + 15 bits of count / slot index; any scan), or 10 (flag + 9 bits, three
+// cells per word: 2/3 of the LDS — scans of at most 511 valid beams, where neither a count nor a slot index can reach
+// 512).  EC = events a slot holds before it is replayed exhaustively.  The 10-bit / 8-event form is what lets four
+// 512-thread workgroups share a CU instead of two 1024-thread ones.
+template <int FW> struct TileF {
+  static constexpr unsigned int kFlag = 1u << (FW - 1), kMask = (1u << FW) - 1u, kLow = kFlag - 1u;
+  static __device__ __forceinline__ int word(int t) { return FW == 16 ? (t >> 1) : (int)(((unsigned int)t * 43691u) >> 17); }  // t / 3, t < 2^15
+  static __device__ __forceinline__ int shift(int t) { return FW == 16 ? (t & 1) * 16 : (t - 3 * word(t)) * 10; }
+  static __host__ __device__ constexpr size_t words(size_t cap) { return FW == 16 ? (cap + 1) / 2 : (cap + 2) / 3; }
+};
+template <int NT, int FW, int EC>
+__global__ __launch_bounds__(NT, NT == 1024 ? 8 : (NT == 512 ? 8 : 3)) void rbpf_raycast_tile(ScanC c, TilePool P, MapT M, const double2* __restrict__ beams,
                                                        const double* __restrict__ pose, const double* __restrict__ sens,
                                                        unsigned long long* __restrict__ bitmap, int* __restrict__ row_count,
                                                        int* __restrict__ n_occ, int* __restrict__ err, int tile_cap,
@@ -1228,8 +1236,10 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : (NT == 512 ? 6 : 3)) void rbpf
   int* exy = lds_i;      // [Bv] end-point cell, x | y << 16
   int* own = exy + Bv;   // [n_own] a beam ending in the slot's cell
   int* ecnt = own + Bv;  // [n_own] events recorded (may exceed kEvCap: overflow)
-  unsigned short* ev = reinterpret_cast<unsigned short*>(ecnt + Bv);  // [n_own][kEvCap]  beam | 0x8000 if occupied
-  unsigned int* tile = reinterpret_cast<unsigned int*>(lds_i + kTileIntsPerBeam * Bv);
+  unsigned short* ev = reinterpret_cast<unsigned short*>(ecnt + Bv);  // [n_own][EC]  beam | 0x8000 if occupied
+  unsigned int* tile = reinterpret_cast<unsigned int*>(lds_i + (3 + EC / 2) * Bv);
+  using TF = TileF<FW>;
+  constexpr int kEvCap = EC;
   __shared__ int bad, bx0, bx1, by0, by1, n_own, srx, sry, n_need, robot_cnt, nocc_delta;
   __shared__ unsigned long long need_base;
   __shared__ unsigned int mt_id[kMapTilesMax];  // map tiles under the bounding box: 0 = not written by this scan, else the
@@ -1268,7 +1278,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : (NT == 512 ? 6 : 3)) void rbpf
       n_need = 0; robot_cnt = 0; nocc_delta = 0;
     }
   } else {
-    for (int t = tid - kWave; t < (tile_cap + 1) / 2; t += nthr - kWave) tile[t] = 0u;
+    for (int t = tid - kWave; t < (int)TF::words(tile_cap); t += nthr - kWave) tile[t] = 0u;
     for (int b = tid - kWave; b < Bv; b += nthr - kWave) ecnt[b] = 0;
     for (int t = tid - kWave; t < kMapTilesMax; t += nthr - kWave) mt_id[t] = 0u;
     for (int t = tid - kWave; t < kBoxSideMax; t += nthr - kWave) rc_delta[t] = 0;
@@ -1305,18 +1315,18 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : (NT == 512 ? 6 : 3)) void rbpf
   PHASE_STAMP(0);
   // F. flag the end-point cells; the beam that finds the flag clear opens the cell's slot
   for (int b = tid; b < Bv; b += nthr) {
-    const int e = exy[b], t = ((e & 0xFFFF) - minx) * bw + ((e >> 16) - miny), sh = (t & 1) * 16;
-    if (!((atomicOr(&tile[t >> 1], 0x8000u << sh) >> sh) & 0x8000u)) {
+    const int e = exy[b], t = ((e & 0xFFFF) - minx) * bw + ((e >> 16) - miny), sh = TF::shift(t), tw = TF::word(t);
+    if (!((atomicOr(&tile[tw], TF::kFlag << sh) >> sh) & TF::kFlag)) {
       const int o = atomicAdd(&n_own, 1);
       own[o] = b;
-      atomicOr(&tile[t >> 1], (unsigned int)o << sh);
+      atomicOr(&tile[tw], (unsigned int)o << sh);
     }
   }
   if (tid < mtn) my_ref = my_tab ? P.ref[my_tab] : 0;
   __syncthreads();
   for (int b = tid; b < Bv; b += nthr) {
     const int e = exy[b], t = ((e & 0xFFFF) - minx) * bw + ((e >> 16) - miny);
-    const int o = (int)((tile[t >> 1] >> ((t & 1) * 16)) & 0x7FFFu);
+    const int o = (int)((tile[TF::word(t)] >> TF::shift(t)) & TF::kLow);
     const int en = atomicAdd(&ecnt[o], 1);
     if (en < kEvCap) ev[o * kEvCap + en] = (unsigned short)(b | 0x8000);
   }
@@ -1334,14 +1344,14 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : (NT == 512 ? 6 : 3)) void rbpf
     S = S < 1 ? 1 : (S > 4 ? 4 : S);
     const int G = (Bv + kWave - 1) / kWave;
     auto visit = [&](int t, int b) {
-      const int sh = (t & 1) * 16;
-      const unsigned int hlf = tile[t >> 1] >> sh;  // the flag and slot bits are final since the barrier above
-      if (hlf & 0x8000u) {
-        const int o = (int)(hlf & 0x7FFFu);
+      const int sh = TF::shift(t), tw = TF::word(t);
+      const unsigned int hlf = tile[tw] >> sh;  // the flag and slot bits are final since the barrier above
+      if (hlf & TF::kFlag) {
+        const int o = (int)(hlf & TF::kLow);
         const int e = atomicAdd(&ecnt[o], 1);
         if (e < kEvCap) ev[o * kEvCap + e] = (unsigned short)b;
       } else {
-        atomicAdd(&tile[t >> 1], 1u << sh);
+        atomicAdd(&tile[tw], 1u << sh);
       }
     };
     int n_first = 0;
@@ -1382,10 +1392,10 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : (NT == 512 ? 6 : 3)) void rbpf
   }
   __syncthreads();  // every event is recorded
   if (tid == 0 && robot_cnt) {
-    const int sh = (t_robot & 1) * 16;
-    const unsigned int hlf = tile[t_robot >> 1] >> sh;
-    if (hlf & 0x8000u) ecnt[hlf & 0x7FFFu] = kEvCap + 1;  // the robot's cell is an end point too: replayed against every beam (2b)
-    else tile[t_robot >> 1] += (unsigned int)robot_cnt << sh;
+    const int sh = TF::shift(t_robot), tw = TF::word(t_robot);
+    const unsigned int hlf = tile[tw] >> sh;
+    if (hlf & TF::kFlag) ecnt[hlf & TF::kLow] = kEvCap + 1;  // the robot's cell is an end point too: replayed against every beam (2b)
+    else tile[tw] += (unsigned int)robot_cnt << sh;
   }
   if (tid < mtn) mt_ref[tid] = my_ref;
   __syncthreads();
@@ -1396,7 +1406,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : (NT == 512 ? 6 : 3)) void rbpf
   {
     int trow = floor_div_small(tid < ncell ? tid : 0, bw), tcol = (tid < ncell ? tid : 0) - trow * bw;
     for (int t = tid; t < ncell; t += nthr) {
-      if ((tile[t >> 1] >> ((t & 1) * 16)) & 0xFFFFu) mt_id[(((minx + trow) >> kTSh) - tx0) * mty + (((miny + tcol) >> kTSh) - ty0)] = 1u;
+      if ((tile[TF::word(t)] >> TF::shift(t)) & TF::kMask) mt_id[(((minx + trow) >> kTSh) - tx0) * mty + (((miny + tcol) >> kTSh) - ty0)] = 1u;
       trow += step_r; tcol += step_c;
       if (tcol >= bw) { tcol -= bw; ++trow; }
     }
@@ -1445,8 +1455,8 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : (NT == 512 ? 6 : 3)) void rbpf
       const int t = t0 + q * nthr;
       int cnq = 0;
       if (t < ncell) {
-        const unsigned int hlf = (tile[t >> 1] >> ((t & 1) * 16)) & 0xFFFFu;
-        if (!(hlf & 0x8000u)) cnq = (int)hlf;
+        const unsigned int hlf = (tile[TF::word(t)] >> TF::shift(t)) & TF::kMask;
+        if (!(hlf & TF::kFlag)) cnq = (int)hlf;
       }
       fn(q, cnq, minx + trow, miny + tcol);
       trow += step_r; tcol += step_c;
@@ -2486,15 +2496,27 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens)
     const long side = 2 * ((long)std::ceil(reach / h->p.resolution) + 2) + 1;
     cap = (int)std::min<long>(side * side, h->tile_cap);
   }
-  const size_t tile_lds = sizeof(int) * kTileIntsPerBeam * bvn + sizeof(unsigned int) * ((size_t)(cap + 1) / 2);
+  // two forms of the kernel: 16-bit tile fields / 16 events per slot / 1024 threads (any scan), and 10-bit fields /
+  // 8 events / 512 threads for scans of at most 511 valid beams when that brings a workgroup under 40 KB of LDS
+  // (four workgroups = 32 waves per CU instead of two)
+  const size_t lds16 = sizeof(int) * (3 + 16 / 2) * bvn + sizeof(unsigned int) * TileF<16>::words((size_t)cap);
+  const size_t lds10 = sizeof(int) * (3 + 8 / 2) * bvn + sizeof(unsigned int) * TileF<10>::words((size_t)cap);
   const MapT M = map_of(h);
+  int nt = h->raycast_threads;
+  const bool small_ok = c.Bv <= 511 && lds10 + 2048 <= 40 * 1024;
+  // measured at cfg3 (N = 1000 / 4000): 1024 threads x 2 per CU 69.5 / 266 us; 512 threads x 4 per CU (10-bit form, 37 KB of
+  // LDS) 81 / 355 us; 256 threads 113 / 391 us — with 32 waves resident either way, fewer and larger workgroups win
+  if (nt == 0) nt = 1024;
+  const bool small = nt == 512 && small_ok;
+  const size_t tile_lds = small ? lds10 : lds16;
   if (cap > 0 && !h->ref_field && c.Bv < 32768 && tile_lds <= (size_t)kMaxLds - 2048) {
     unsigned long long* touched = h->count_touched ? h->d_touched : nullptr;
-#define TBNAV_RAYCAST(NT) hipLaunchKernelGGL(rbpf_raycast_tile<NT>, dim3(count), dim3(NT), tile_lds, st, c, h->pool, M, h->d_beams, sp.pose, sens, \
-                                             h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_nocc[h->cur], h->d_err, cap, touched)
-    int nt = h->raycast_threads;
-    if (nt == 0) nt = 1024;  // measured at cfg3 (N = 1000 / 4000): 1024 threads 70 / 268 us, 512 threads 78 / 273 us, 256 threads 114 / 393 us
-    if (nt == 256) TBNAV_RAYCAST(256); else if (nt == 512) TBNAV_RAYCAST(512); else TBNAV_RAYCAST(1024);
+#define TBNAV_RAYCAST(NT, FW, EC) hipLaunchKernelGGL((rbpf_raycast_tile<NT, FW, EC>), dim3(count), dim3(NT), tile_lds, st, c, h->pool, M, h->d_beams, sp.pose, sens, \
+                                                     h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_nocc[h->cur], h->d_err, cap, touched)
+    if (small) TBNAV_RAYCAST(512, 10, 8);
+    else if (nt == 256) TBNAV_RAYCAST(256, 16, 16);
+    else if (nt == 512) TBNAV_RAYCAST(512, 16, 16);
+    else TBNAV_RAYCAST(1024, 16, 16);
 #undef TBNAV_RAYCAST
   } else {
     // beam-ordered kernel: scans the LDS tile cannot hold, and the reference distance-field mode (it logs the
@@ -2863,9 +2885,10 @@ int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf*
     e = (C == 64) ? hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_edt<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)
                   : hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_edt<32>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_tile<256>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 2048);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_tile<512>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 2048);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_tile<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 2048);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_tile<256, 16, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 2048);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_tile<512, 16, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 2048);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_tile<512, 10, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 2048);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_tile<1024, 16, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 2048);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 1024);
   // the proposal / scan-match kernels carry the scan, the per-sample data and the bitmap slice: more than the 64 KB
   // default for long scans or many samples

@@ -111,3 +111,29 @@ def test_configs4_shard_10000_particles_2000x2000_1080_beams(gpu_pkg):
     (pose, idx) = pf.getRobotState()
     assert 0 <= idx < N and np.all(np.isfinite(pose))
     pf.close()
+
+
+@pytest.mark.parametrize("variant", ["threads256", "threads512_10bit", "threads1024", "beam_ordered"])
+def test_raycast_kernel_variants_are_bit_exact(gpu_pkg, variant):
+    """Every form of the map update — the tile kernel with 256 / 512 (10-bit tile fields, 8-event slots) / 1024 threads,
+    and the beam-ordered kernel — must leave the oracle's GridMapper bits (the default alone is what the other tests
+    exercise).  Scans with close obstacles (many events per end-point cell: the overflow path) and a long corridor."""
+    from rtn_amd import capi
+    N, k, n_scans = 24, 6, 4
+    pf = _dev(gpu_pkg, N=N, k=k, map_min=-10.0, map_max=10.0)
+    if variant == "beam_ordered":
+        pf.setOption(capi.RBPF_OPT_RAYCAST_ORDERED, 1)
+    else:
+        pf.setOption(capi.RBPF_OPT_RAYCAST_THREADS, int(variant[7:].split("_")[0]))
+    steps, poses = rc.trajectory(n_scans, inc=(0.05, 0.04, 0.03))
+    rng = np.random.default_rng(12)
+    scans = [orc.room_scan(poses[s], walls=(-0.4, 3.2, -0.35, 0.5), rng=rng) for s in range(n_scans)]  # a wall 7 cells away
+    hist = []
+    for s, (prev, cur, t_icp, u) in enumerate(steps):
+        st = pf.SLAM(scans[s], u, cur, prev, True, t_icp, orc.normal_stream(60 + s, pf.numNormals(True), 0.0, 1.0))
+        assert st.status == 0
+        hist.append(pf.trace()["new_pose"].copy())
+    grid = (0.05, -10.0, 10.0, -10.0, 10.0)
+    for m in (0, 11, N - 1):
+        assert np.array_equal(pf.logOdds(m), _oracle_map(grid, None, scans, [h[m] for h in hist])), (variant, m)
+    pf.close()
