@@ -4,7 +4,7 @@ that EVERY one of the 360 beams returns inside [range_min, range_max) at every p
 
 particle-updates/s = N * SLAM calls / wall time of the synchronous tbnav_rbpf_slam calls with the standard normals
 drawn ON the device (normals == NULL: nothing but the 1.4 KB scan crosses PCIe).  Two of the timed scans are forced
-to RESAMPLE (skewed weights set beforehand, untimed): their table copy / reference counting, the bitmap gather and
+to RESAMPLE (skewed weights set beforehand, untimed): their table copy / reference counting, the state gather and
 the tile clones of the scan that follows are all inside the timed region (`resamples`, `scan_ms`).
 `host_normals` is the parity-mode figure (1.2 MB/scan of reference-order normals copied inside the call;
 PCIe-inclusive, never the headline); `device_ms_per_scan` is the sum of the kernels' HIP-event durations.

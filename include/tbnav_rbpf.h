@@ -27,7 +27,8 @@
  *                     (particle_filter.cpp:495); here a resample copies tables and bumps reference counts, and
  *                     the next scan clones only the tiles it writes.  100 000 particles x 2000 x 2000 cells
  *                     (BASELINE configs[4]) would be 3.2 TB dense; tiled it is the scanned area per lineage.
- *   occupancy       : [N][xsize][ceil(ysize/64)] u64 bitmap of cells with prob >= 0.90, decided in
+ *   occupancy       : one bit per cell with prob >= 0.90, 32 x u32 per tile, stored, shared and copied WITH the
+ *                     log-odds tile (+ occupied cells per tile row, [N][ceil(xsize/32)] i32); decided in
  *                     log-odds space against a cut-off found on the host with glibc at create time
  *                     (SURVEY.md hard part 2: prob(log 9) == 0.9 exactly with glibc)
  *   dist_code       : [N][G] u16, allocated only when something needs a STORED field (tbnav_rbpf_set_occ_dist,
@@ -165,10 +166,10 @@ int tbnav_rbpf_set_weights_from_global_dev(tbnav_rbpf* h, const int32_t* global_
  * resampling fires); weights_out (n_global, host) the normalised weights. */
 int tbnav_rbpf_resample_global(const double* weights_all, int64_t n_global, double z,
                                int32_t* parents_out, double* weights_out, tbnav_rbpf_stats* out);
-/* Re-populate this rank's slots from LOCAL parents (tables, bitmaps and state move on the device); -1 = keep. */
+/* Re-populate this rank's slots from LOCAL parents (tables and state move on the device); -1 = keep. */
 int tbnav_rbpf_gather_local(tbnav_rbpf* h, const int32_t* local_parent /*[N], -1 = leave*/);
 /* A particle as one device buffer: header, state (pose, prev_pose, weight), the indices and 8 KB payloads of the
- * tiles it does not share with the empty map, its occupancy bitmap + row counts, and its stored distance field if
+ * tiles (log-odds + occupancy bits) it does not share with the empty map, its tile-row counts, and its stored distance field if
  * that is authoritative (injected).  export_size: bytes the export of `slot` needs now. */
 int tbnav_rbpf_export_size(tbnav_rbpf* h, int32_t slot, uint64_t* bytes);
 int tbnav_rbpf_export_particle_dev(tbnav_rbpf* h, int32_t slot, void* d_buf, uint64_t capacity, uint64_t* bytes);

@@ -13,12 +13,12 @@
 //   rbpf_scanmatch        option (N1): per-particle hill climbing on the likelihood field before sampling
 //   rbpf_raycast_tile     workgroup per particle: LDS tile of 16-bit counters over the scan's bounding box, integer DDA
 //                         walk per ray segment, end-point cells replayed in beam order, log-odds += l_free / l_occ,
-//                         occupancy bitmap kept current                  (grid_mapper.cpp:140-178, :549-807)
+//                         the tiles' occupancy bits kept current         (grid_mapper.cpp:140-178, :549-807)
 //   rbpf_raycast          fallback when the tile cannot hold the scan: one wave per particle, beams in order
 //   rbpf_normalize(_seq)  sequential-order normalise / Neff / low-variance selection (particle_filter.cpp:442-500)
 //   rbpf_gather           copy parents into the alternate buffers after a resample (:495 deep copies)
 //   rbpf_argmax, rbpf_export_map   getRobotState / newMap on the device (:255-291, grid_mapper.cpp:185-226)
-//   rbpf_occupancy        rebuild one particle's bitmap from its log-odds (after tbnav_rbpf_set_log_odds)
+//   rbpf_densify          dense bitmap rows of a range of particles from their tiles, for the exact-transform kernels
 //   rbpf_window, rbpf_edt_compact<R>, rbpf_edt<C>, rbpf_field_by_query
 //                         the stored u16 distance field: windowed / whole-map exact EDT (modes TBNAV_RBPF_DF=window|full,
 //                         and every on-demand field), cell-by-cell query for maps too large for the LDS transform
@@ -115,6 +115,7 @@ struct ScanC {  // everything constant during one SLAM call
 constexpr int kTS = 32, kTSh = 5, kTileCells = kTS * kTS;
 struct TilePool {
   double* lo;               // [cap][kTileCells], in-tile index = (i & 31) * 32 + (j & 31)
+  unsigned int* bm;         // [cap][kTS] occupancy bits of the tile's cells (prob >= 0.90): row i & 31, bit j & 31
   int* ref;                 // [cap]
   unsigned int* ring;       // [cap] free tile ids
   unsigned long long* ctr;  // [0] head: tiles popped, [1] tail: tiles pushed (free = tail - head)
@@ -157,6 +158,7 @@ __device__ __forceinline__ void tile_clone_into(const TilePool& P, unsigned int*
   const double2* src = reinterpret_cast<const double2*>(P.lo + (size_t)id * kTileCells);  // id 0 = the zero tile
 #pragma unroll
   for (int i = 0; i < kTileCells / 2 / kWave; ++i) dst[i * kWave + lane] = src[i * kWave + lane];
+  if (lane < kTS) P.bm[(size_t)nid * kTS + lane] = P.bm[(size_t)id * kTS + lane];
   if (lane == 0) {
     P.ref[nid] = 1;
     table_p[t] = nid;
@@ -177,12 +179,32 @@ __device__ __forceinline__ unsigned int tile_make_private(const TilePool& P, uns
   const double2* src = reinterpret_cast<const double2*>(P.lo + (size_t)id * kTileCells);  // id 0 = the zero tile
 #pragma unroll
   for (int i = 0; i < kTileCells / 2 / kWave; ++i) dst[i * kWave + lane] = src[i * kWave + lane];
+  if (lane < kTS) P.bm[(size_t)nid * kTS + lane] = P.bm[(size_t)id * kTS + lane];
   if (lane == 0) {
     P.ref[nid] = 1;
     table_p[t] = nid;
     if (id != 0u) shed_p[t] = id;  // a (p, t) entry leaves a shared tile at most once between two resamples
   }
   return nid;
+}
+// One particle's occupancy bits, read through its tile table.  trow[ti] = occupied cells in tile row ti (cells
+// 32*ti .. 32*ti+31 of the x axis): lets a search skip 32 map rows at a time.
+struct OccT {
+  const unsigned int* bm;   // pool.bm
+  const unsigned int* tab;  // the particle's table
+  const int* trow;          // [TW]
+  int TW;
+  // columns 64w .. 64w+63 of map row r, as the dense bitmap's u64 word was: two tiles side by side
+  __device__ __forceinline__ unsigned long long word(int r, int w) const {
+    const unsigned int* t = tab + (r >> kTSh) * TW + 2 * w;
+    const unsigned int lo = bm[(size_t)t[0] * kTS + (r & (kTS - 1))];
+    const unsigned int hi = (2 * w + 1 < TW) ? bm[(size_t)t[1] * kTS + (r & (kTS - 1))] : 0u;
+    return (unsigned long long)lo | ((unsigned long long)hi << 32);
+  }
+  __device__ __forceinline__ bool row_any(int r) const { return trow[r >> kTSh] != 0; }
+};
+__device__ __forceinline__ OccT occ_of(const TilePool& P, const MapT& M, const int* trow_occ, int p) {
+  return OccT{P.bm, M.table + (size_t)p * M.TT, trow_occ + (size_t)p * M.TW, M.TW};
 }
 
 // world -> cell, grid_mapper.cpp:810-887.  false = outside the world (the reference throws).
@@ -241,6 +263,7 @@ __device__ __forceinline__ double wave_prod(double v) {
 // beams[b] = (r*cos a_b, r*sin a_b) in the sensor frame, built on the host exactly as
 // sensor_model.cpp:73-108 does.  Returns the product in every lane; *oob is set if a beam leaves
 // the world (the reference throws from world2RowMajor).
+template <class Word> __device__ __forceinline__ int row_nearest_f(Word word, int words, int j, int cap);
 __device__ __forceinline__ int row_nearest(const unsigned long long* row, int words, int j, int cap);
 
 // Where a lookup gets its distance code from.
@@ -253,8 +276,7 @@ __device__ __forceinline__ int row_nearest(const unsigned long long* row, int wo
 //           cell with no obstacle within cell_radius keeps its stored code, like the transform.
 struct DistSrc {
   const uint16_t* code;             // [G] of the particle; NULL when the handle keeps no stored field (query mode only)
-  const unsigned long long* bm;     // [xs][words]
-  const int* rowcount;              // [xs]
+  OccT occ;                         // the particle's occupancy bits (tiled)
   int4 win;
   int mode;                         // 0 field, 1 window, 2 query
   // query mode, optional: the part of the bitmap round the particle held in LDS (rows R0..R1, 64-cell word
@@ -266,8 +288,8 @@ struct DistSrc {
 // Walk rows i, i+-1, i+-2, ... of an occupancy bitmap (stride `words` u64 per row, rows row_lo..row_hi present,
 // cell columns [0, words*64) relative to the bitmap) and return the least squared distance found (INT_MAX: none
 // within `radius`).  row_any(r) says whether row r can hold a set bit.
-template <class RowAny>
-__device__ __forceinline__ int nearest_d2_rows(const unsigned long long* bm, int words, int row_lo, int row_hi, int radius,
+template <class RowWord, class RowAny>
+__device__ __forceinline__ int nearest_d2_rows(RowWord row_word, int words, int row_lo, int row_hi, int radius,
                                                int ci, int cj, RowAny row_any) {
   int best = 0x7fffffff;
   for (int dr = 0; dr <= radius; ++dr) {
@@ -278,7 +300,7 @@ __device__ __forceinline__ int nearest_d2_rows(const unsigned long long* bm, int
       if (r < row_lo || r > row_hi || !row_any(r)) continue;
       int cap = radius;
       if (best != 0x7fffffff) { cap = (int)sqrtf((float)(best - dr * dr)) + 1; cap = cap < radius ? cap : radius; }
-      const int f = row_nearest(bm + (size_t)(r - row_lo) * words, words, cj, cap);
+      const int f = row_nearest_f([&](int w) { return row_word(r, w); }, words, cj, cap);
       if (f != 255) { const int cand = dr * dr + f * f; best = cand < best ? cand : best; }
     }
   }
@@ -317,13 +339,17 @@ __device__ __forceinline__ uint16_t nearest_code_query(const GridC& g, const Dis
       }
       const int* any = d.tany;
       const int R0 = d.R0;
-      const int best = nearest_d2_rows(d.tbm, d.nW, d.R0, d.R1, radius, ci, cj - C0, [any, R0](int r) { return any[r - R0] != 0; });
+      const unsigned long long* tbm = d.tbm;
+      const int nW = d.nW;
+      const int best = nearest_d2_rows([tbm, nW, R0](int r, int w) { return tbm[(size_t)(r - R0) * nW + w]; }, d.nW, d.R0, d.R1, radius, ci, cj - C0,
+                                       [any, R0](int r) { return any[r - R0] != 0; });
       if (best != 0x7fffffff && best <= clear * clear && best <= radius * radius) return (uint16_t)best;
       if (best == 0x7fffffff && clear > radius) return d.code ? d.code[(size_t)ci * g.xsize + cj] : kCodeUnreached;
     }
   }
-  const int* rcnt = d.rowcount;
-  const int best = nearest_d2_rows(d.bm, g.words, 0, g.xsize - 1, radius, ci, cj, [rcnt](int r) { return rcnt[r] != 0; });
+  const OccT occ = d.occ;
+  const int best = nearest_d2_rows([&occ](int r, int w) { return occ.word(r, w); }, g.words, 0, g.xsize - 1, radius, ci, cj,
+                                   [&occ](int r) { return occ.row_any(r); });
   // nothing within cell_radius_: the stored code if the handle keeps a stored field (injected / materialised), else
   // "never reached" (the reference keeps whatever an earlier brushfire left there, grid_mapper.cpp:310-313)
   return (best <= radius * radius) ? (uint16_t)best : (d.code ? d.code[(size_t)ci * g.xsize + cj] : kCodeUnreached);
@@ -468,15 +494,14 @@ struct Trace {
 // Whole field of ONE particle for maps whose column envelope does not fit a workgroup's LDS (xsize > ~640): every
 // cell asks the same exact query the likelihood uses (rows i, i+-1, ... on the global bitmap).  On-demand path only
 // (get_occ_dist / get_dist_code / export) — the SLAM path of such maps runs in query mode and never needs it.
-__global__ __launch_bounds__(256) void rbpf_field_by_query(GridC g, int radius, int particle, const unsigned long long* __restrict__ bitmap,
-                                                           const int* __restrict__ row_count, uint16_t* __restrict__ codes) {
+__global__ __launch_bounds__(256) void rbpf_field_by_query(GridC g, int radius, int particle, TilePool P, MapT M,
+                                                           const int* __restrict__ trow_occ, uint16_t* __restrict__ codes) {
   const size_t G = (size_t)g.xsize * g.ysize;
   const size_t cell = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (cell >= G) return;
   const int ci = (int)(cell / g.xsize), cj = (int)(cell - (size_t)ci * g.xsize);
   uint16_t* code = codes + (size_t)particle * G;
-  const DistSrc ds{code, bitmap + (size_t)particle * g.xsize * g.words, row_count + (size_t)particle * g.xsize, make_int4(0, 0, 0, 0), 2,
-                   nullptr, nullptr, 0, 0, 0, 0};
+  const DistSrc ds{code, occ_of(P, M, trow_occ, particle), make_int4(0, 0, 0, 0), 2, nullptr, nullptr, 0, 0, 0, 0};
   code[cell] = nearest_code_query(g, ds, radius, ci, cj);  // a cell out of reach keeps its stored code, like the transform
 }
 
@@ -484,13 +509,12 @@ __global__ __launch_bounds__(256) void rbpf_field_by_query(GridC g, int radius, 
 // class bmapping::GridMapper's method of that name (tbnav_rbpf_likelihood).  One wave; product in beam order per lane,
 // closed by the wave's butterfly.
 __global__ __launch_bounds__(kWave) void rbpf_likelihood_one(ScanC c, const double2* __restrict__ beams, const uint16_t* __restrict__ codes,
-                                                            const unsigned long long* __restrict__ bitmap, const int* __restrict__ row_count,
+                                                            TilePool P, MapT M, const int* __restrict__ trow_occ,
                                                             const int* __restrict__ fstate, int radius, const int* __restrict__ n_occ,
                                                             double th, double x, double y, double* __restrict__ out, int* __restrict__ err) {
   const int p = c.p0, lane = threadIdx.x;
-  const DistSrc ds{codes ? codes + (size_t)p * c.g.xsize * c.g.ysize : nullptr, bitmap + (size_t)p * c.g.xsize * c.g.words,
-                   row_count + (size_t)p * c.g.xsize, make_int4(0, c.g.xsize - 1, 0, c.g.ysize - 1), (codes && fstate[p] == 2) ? 0 : 2,
-                   nullptr, nullptr, 0, 0, 0, 0};
+  const DistSrc ds{codes ? codes + (size_t)p * c.g.xsize * c.g.ysize : nullptr, occ_of(P, M, trow_occ, p),
+                   make_int4(0, c.g.xsize - 1, 0, c.g.ysize - 1), (codes && fstate[p] == 2) ? 0 : 2, nullptr, nullptr, 0, 0, 0, 0};
   int oob = 0;
   const double v = wave_scan_likelihood(c, beams, ds, radius, n_occ[p], th, x, y, lane, &oob);
   if (oob & 1) atomicOr(&err[0], 1);
@@ -512,8 +536,8 @@ struct ScanMatchC { double lstep, astep; int iters, max_moves; };
 constexpr int kMatchThreads = 6 * kWave;
 __global__ __launch_bounds__(kMatchThreads) void rbpf_scanmatch(ScanC c, ScanMatchC sm, const double2* __restrict__ beams,
                                                                 const uint16_t* __restrict__ codes,
-                                                                const unsigned long long* __restrict__ bitmap,
-                                                                const int* __restrict__ row_count, const int* __restrict__ skip,
+                                                                TilePool P, MapT M,
+                                                                const int* __restrict__ trow_occ, const int* __restrict__ skip,
                                                                 int skip_eq, int df_mode, int radius, int occ_half,
                                                                 const int* __restrict__ n_occ, const int4* __restrict__ win,
                                                                 const double* __restrict__ pose, double* __restrict__ center,
@@ -539,7 +563,7 @@ __global__ __launch_bounds__(kMatchThreads) void rbpf_scanmatch(ScanC c, ScanMat
     if (tid == 0) { center[p * 3 + 0] = mu0[0]; center[p * 3 + 1] = mu0[1]; center[p * 3 + 2] = mu0[2]; score[p] = 1.0; }
     return;
   }
-  DistSrc ds{codes ? codes + (size_t)p * c.g.xsize * c.g.ysize : nullptr, bitmap + (size_t)p * c.g.xsize * c.g.words, row_count + (size_t)p * c.g.xsize,
+  DistSrc ds{codes ? codes + (size_t)p * c.g.xsize * c.g.ysize : nullptr, occ_of(P, M, trow_occ, p),
              win[p], skip[p] == skip_eq ? 0 : df_mode, tile_bm, reinterpret_cast<const int*>(tile_bm), 0, 0, 0, 0};
   for (int b = tid; b < c.Bv; b += kMatchThreads) lbeams[b] = beams[b];
   for (int q = tid; q < kMixLut; q += kMatchThreads) lut[q] = beam_mixture(c, (uint16_t)q);
@@ -555,7 +579,7 @@ __global__ __launch_bounds__(kMatchThreads) void rbpf_scanmatch(ScanC c, ScanMat
       for (int r = tid; r <= R1 - R0; r += kMatchThreads) {
         unsigned long long acc = 0ull;
         for (int w = 0; w < nW; ++w) {
-          const unsigned long long v = ds.bm[(size_t)(R0 + r) * c.g.words + W0 + w];
+          const unsigned long long v = ds.occ.word(R0 + r, W0 + w);
           tile_bm[r * nW + w] = v;
           acc |= v;
         }
@@ -631,8 +655,8 @@ __global__ __launch_bounds__(kMatchThreads) void rbpf_scanmatch(ScanC c, ScanMat
 // err[0] = out of world, err[1] = eta zero, err[2] = pdf variance zero, err[3] = bresenham
 __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c, const double2* __restrict__ beams,
                                                                 const uint16_t* __restrict__ codes,
-                                                                const unsigned long long* __restrict__ bitmap,
-                                                                const int* __restrict__ row_count, const int* __restrict__ skip,
+                                                                TilePool P, MapT M,
+                                                                const int* __restrict__ trow_occ, const int* __restrict__ skip,
                                                                 int skip_eq, int df_mode, int radius, int occ_half,
                                                                 const int* __restrict__ n_occ, const int4* __restrict__ win,
                                                                 const double* __restrict__ normals, const double* __restrict__ center,
@@ -661,7 +685,7 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
   // (the tile pointers are set unconditionally — nW == 0 means "no tile" — so that the compiler can see they are LDS
   //  addresses and use ds_read instead of flat loads in the lookups)
   unsigned long long* const tile_bm = reinterpret_cast<unsigned long long*>(ulist + c.Bv);
-  DistSrc ds{code, bitmap + (size_t)p * c.g.xsize * c.g.words, row_count + (size_t)p * c.g.xsize, win[p], skip[p] == skip_eq ? 0 : df_mode,
+  DistSrc ds{code, occ_of(P, M, trow_occ, p), win[p], skip[p] == skip_eq ? 0 : df_mode,
              tile_bm, reinterpret_cast<const int*>(tile_bm), 0, 0, 0, 0};
   int oob = 0;
 
@@ -727,7 +751,7 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
       for (int r = tid; r <= R1 - R0; r += kProposeThreads) {
         unsigned long long acc = 0ull;
         for (int w = 0; w < nW; ++w) {
-          const unsigned long long v = ds.bm[(size_t)(R0 + r) * c.g.words + W0 + w];
+          const unsigned long long v = ds.occ.word(R0 + r, W0 + w);
           tb[r * nW + w] = v;
           acc |= v;
         }
@@ -1009,20 +1033,21 @@ __device__ __forceinline__ void ray_cell(const Ray& r, int n, int& cx, int& cy) 
 // One wave per particle.  Beams are applied IN ORDER (the per-cell floating-point add order is the
 // reference's); the cells of one ray are distinct, so the lanes of the wave update them in parallel
 // without atomics.  Endpoints are staged in LDS first.
-// The occupancy bitmap / per-row counts / occupied count of the particle are kept up to date here: a
-// log-odds add that crosses the occupied cut-off toggles the cell's bit (rare: a few hundred cells per
-// scan), so no pass over the whole map is needed to find the distance transform's seeds.
-__device__ __forceinline__ bool add_log_odds(double* __restrict__ cell, double d, double cut, int cx, int cy,
-                                             int words, unsigned long long* __restrict__ bm, int* __restrict__ rowcount,
-                                             int* __restrict__ nocc) {
+// The occupancy bits (one u32 per tile row, copy-on-write with the tile) / per-tile-row counts / occupied count of
+// the particle are kept up to date here: a log-odds add that crosses the occupied cut-off toggles the cell's bit
+// (rare: a few hundred cells per scan), so no pass over the whole map is needed to find the nearest-obstacle
+// query's rows.
+__device__ __forceinline__ bool add_log_odds(const TilePool& P, unsigned int id, double d, double cut, int cx, int cy,
+                                             int* __restrict__ trow, int* __restrict__ nocc) {
+  double* cell = P.lo + (size_t)id * kTileCells + in_tile(cx, cy);
   const double old = *cell;
   const double nw = old + d;
   *cell = nw;
   const bool was = old >= cut, now = nw >= cut;
   if (was != now) {
-    atomicXor(&bm[(size_t)cx * words + (cy >> 6)], 1ull << (cy & 63));
+    atomicXor(&P.bm[(size_t)id * kTS + (cx & (kTS - 1))], 1u << (cy & (kTS - 1)));
     const int delta = now ? 1 : -1;
-    atomicAdd(&rowcount[cx], delta);
+    atomicAdd(&trow[cx >> kTSh], delta);
     atomicAdd(nocc, delta);
   }
   return was != now;
@@ -1035,8 +1060,7 @@ __device__ __forceinline__ bool add_log_odds(double* __restrict__ cell, double d
 struct OccLog { int* ev; int* count; int cap; };
 
 __global__ __launch_bounds__(kWave) void rbpf_raycast(ScanC c, TilePool P, MapT M, const double2* __restrict__ beams,
-                                                     const double* __restrict__ pose,
-                                                     unsigned long long* __restrict__ bitmap, int* __restrict__ row_count,
+                                                     const double* __restrict__ pose, int* __restrict__ trow_occ,
                                                      int* __restrict__ n_occ, int* __restrict__ err, OccLog log) {
   extern __shared__ __attribute__((aligned(16))) int lds_i[];
   int* ex = lds_i;         // [Bv]
@@ -1046,8 +1070,7 @@ __global__ __launch_bounds__(kWave) void rbpf_raycast(ScanC c, TilePool P, MapT 
   const int p = c.p0 + blockIdx.x, lane = threadIdx.x;
   unsigned int* tab = M.table + (size_t)p * M.TT;
   unsigned int* shed = M.shed + (size_t)p * M.TT;
-  unsigned long long* bm = bitmap + (size_t)p * c.g.xsize * c.g.words;
-  int* rc = row_count + (size_t)p * c.g.xsize;
+  int* rc = trow_occ + (size_t)p * M.TW;
   int* nocc = n_occ + p;
   const double th = pose[p * 3 + 0], x = pose[p * 3 + 1], y = pose[p * 3 + 2];
   if (lane == 0) bad = 0;
@@ -1122,7 +1145,7 @@ __global__ __launch_bounds__(kWave) void rbpf_raycast(ScanC c, TilePool P, MapT 
         int cx, cy;
         ray_cell(r, n, cx, cy);
         cell = cx * c.g.xsize + cy;
-        flip = add_log_odds(P.lo + (size_t)tab[tile_of(M, cx, cy)] * kTileCells + in_tile(cx, cy), c.d_free, c.cut_occ, cx, cy, c.g.words, bm, rc, nocc);
+        flip = add_log_odds(P, tab[tile_of(M, cx, cy)], c.d_free, c.cut_occ, cx, cy, rc, nocc);
       }
       if (ev) {  // a free add can only take a cell OUT of the occupied set
         const unsigned long long m = __ballot(flip);
@@ -1133,9 +1156,9 @@ __global__ __launch_bounds__(kWave) void rbpf_raycast(ScanC c, TilePool P, MapT 
     __syncthreads();  // free-cell adds of this beam land before the endpoint / next beam touch the cells
     int eflip = 0;
     if (lane == 0) {
-      double* cellp = P.lo + (size_t)tab[tile_of(M, x1, y1)] * kTileCells + in_tile(x1, y1);
-      const double before = *cellp;
-      const bool flip = add_log_odds(cellp, c.d_occ, c.cut_occ, x1, y1, c.g.words, bm, rc, nocc);
+      const unsigned int eid = tab[tile_of(M, x1, y1)];
+      const double before = P.lo[(size_t)eid * kTileCells + in_tile(x1, y1)];
+      const bool flip = add_log_odds(P, eid, c.d_occ, c.cut_occ, x1, y1, rc, nocc);
       if (ev && flip && n_log < log.cap) ev[n_log] = (x1 * c.g.xsize + y1) | (before >= c.cut_occ ? (int)0x80000000 : 0);
       eflip = flip ? 1 : 0;
     }
@@ -1228,7 +1251,7 @@ template <int FW> struct TileF {
 template <int NT, int FW, int EC>
 __global__ __launch_bounds__(NT, NT == 1024 ? 8 : (NT == 512 ? 8 : 3)) void rbpf_raycast_tile(ScanC c, TilePool P, MapT M, const double2* __restrict__ beams,
                                                        const double* __restrict__ pose, const double* __restrict__ sens,
-                                                       unsigned long long* __restrict__ bitmap, int* __restrict__ row_count,
+                                                       int* __restrict__ trow_occ,
                                                        int* __restrict__ n_occ, int* __restrict__ err, int tile_cap,
                                                        unsigned long long* __restrict__ touched) {
   extern __shared__ __attribute__((aligned(16))) int lds_i[];
@@ -1245,15 +1268,14 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : (NT == 512 ? 8 : 3)) void rbpf
   __shared__ unsigned int mt_id[kMapTilesMax];  // map tiles under the bounding box: 0 = not written by this scan, else the
   //                                               particle's private tile id (phase C)
   __shared__ int mt_ref[kMapTilesMax], mt_slot[kMapTilesMax];
-  __shared__ int rc_delta[kBoxSideMax];         // change of the occupied count of each map row under the box
+  __shared__ int rc_delta[kBoxSideMax / kTS + 2];  // change of the occupied count of each tile row under the box
   __shared__ double sh_pose[4];                 // X, Y, sin, cos of Tms = T(pose) * Trs
   constexpr int nthr = NT, nw = NT / kWave;
   const int p = c.p0 + blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
 #ifdef TBNAV_PHASE_PROF
   unsigned long long t_prev_ = wall_clock64();
 #endif
-  unsigned long long* bm = bitmap + (size_t)p * c.g.xsize * c.g.words;
-  int* rc = row_count + (size_t)p * c.g.xsize;
+  int* rc = trow_occ + (size_t)p * M.TW;
   unsigned int* tab = M.table + (size_t)p * M.TT;
   unsigned int* shed = M.shed + (size_t)p * M.TT;
   // wave 0 derives everything that depends only on the particle's pose while the other waves clear the tile; the
@@ -1281,7 +1303,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : (NT == 512 ? 8 : 3)) void rbpf
     for (int t = tid - kWave; t < (int)TF::words(tile_cap); t += nthr - kWave) tile[t] = 0u;
     for (int b = tid - kWave; b < Bv; b += nthr - kWave) ecnt[b] = 0;
     for (int t = tid - kWave; t < kMapTilesMax; t += nthr - kWave) mt_id[t] = 0u;
-    for (int t = tid - kWave; t < kBoxSideMax; t += nthr - kWave) rc_delta[t] = 0;
+    for (int t = tid - kWave; t < kBoxSideMax / kTS + 2; t += nthr - kWave) rc_delta[t] = 0;
   }
   __syncthreads();
   const int rx = srx, ry = sry;
@@ -1435,9 +1457,9 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : (NT == 512 ? 8 : 3)) void rbpf
   auto cell_ptr = [&](int cx, int cy) -> double* {
     return P.lo + (size_t)mt_id[((cx >> kTSh) - tx0) * mty + ((cy >> kTSh) - ty0)] * kTileCells + in_tile(cx, cy);
   };
-  auto toggled = [&](int cx, int cy, bool now) {  // the cell crossed the occupied cut-off: bitmap bit, row count, total
-    atomicXor(&bm[(size_t)cx * c.g.words + (cy >> 6)], 1ull << (cy & 63));
-    atomicAdd(&rc_delta[cx - minx], now ? 1 : -1);
+  auto toggled = [&](int cx, int cy, bool now) {  // the cell crossed the occupied cut-off: its bit in the (private) tile, tile-row count, total
+    atomicXor(&P.bm[(size_t)mt_id[((cx >> kTSh) - tx0) * mty + ((cy >> kTSh) - ty0)] * kTS + (cx & (kTS - 1))], 1u << (cy & (kTS - 1)));
+    atomicAdd(&rc_delta[(cx >> kTSh) - tx0], now ? 1 : -1);
     atomicAdd(&nocc_delta, now ? 1 : -1);
   };
   // The two read-modify-write passes share their memory round trip: the end-point cell of this thread (2a) and the
@@ -1559,7 +1581,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : (NT == 512 ? 8 : 3)) void rbpf
   }
   __syncthreads();
   // the row counts / occupied count of the particle: one plain update per changed row (this workgroup owns them)
-  for (int r = tid; r < bh; r += nthr) if (rc_delta[r]) rc[minx + r] += rc_delta[r];
+  for (int r = tid; r <= (bx1 >> kTSh) - tx0; r += nthr) if (rc_delta[r]) rc[tx0 + r] += rc_delta[r];
   if (tid == 0 && nocc_delta) n_occ[p] += nocc_delta;
   if (touched) {  // measurement hook (tbnav_rbpf_scan_counts): [0] += cell updates (free adds + end points), [1] += distinct cells written
     __shared__ int cnt_upd, cnt_dis;
@@ -1585,26 +1607,26 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : (NT == 512 ? 8 : 3)) void rbpf
 #endif
 }
 
-// ---- occupancy bitmap ------------------------------------------------------------------------------
-// grid (rows/4, N), 256 threads: one wave per map row; lanes read the row coalesced.
-__global__ __launch_bounds__(256) void rbpf_occupancy(GridC g, double cut_occ, int p0, TilePool P, MapT M,
-                                                      unsigned long long* __restrict__ bitmap, int* __restrict__ row_count,
-                                                      int* __restrict__ n_occ) {
+// ---- dense view of the occupancy bits -----------------------------------------------------------------------
+// The exact-transform kernels below (stored-field modes, on-demand fields) work on dense bitmap rows and per-row
+// counts; this rebuilds them from the tiles for particles [p0, p0 + gridDim.y).  grid (rows/4, count), 256 threads:
+// one wave per map row, lane w assembles the row's u64 word w.
+__global__ __launch_bounds__(256) void rbpf_densify(GridC g, int p0, TilePool P, MapT M, const int* __restrict__ trow_occ,
+                                                    unsigned long long* __restrict__ bitmap, int* __restrict__ row_count) {
   const int p = p0 + blockIdx.y;
   const int row = blockIdx.x * 4 + threadIdx.x / kWave;
   const int lane = threadIdx.x & (kWave - 1);
   if (row >= g.xsize) return;
-  const unsigned int* tab = M.table + (size_t)p * M.TT;
+  const OccT occ = occ_of(P, M, trow_occ, p);
   unsigned long long* bm = bitmap + ((size_t)p * g.xsize + row) * g.words;
   int cnt = 0;
-  for (int w = 0; w < g.words; ++w) {
-    const int j = w * 64 + lane;
-    const bool occ = (j < g.ysize) && (P.lo[(size_t)tab[tile_of(M, row, j)] * kTileCells + in_tile(row, j)] >= cut_occ);
-    const unsigned long long m = __ballot(occ);
-    if (lane == 0) bm[w] = m;
-    cnt += __popcll(m);
+  for (int w = lane; w < g.words; w += kWave) {
+    const unsigned long long v = occ.row_any(row) ? occ.word(row, w) : 0ull;
+    bm[w] = v;
+    cnt += __popcll(v);
   }
-  if (lane == 0) { row_count[(size_t)p * g.xsize + row] = cnt; if (cnt) atomicAdd(&n_occ[p], cnt); }
+  cnt = wave_sum_i(cnt);
+  if (lane == 0) row_count[(size_t)p * g.xsize + row] = cnt;
 }
 
 // ---- exact distance transform ------------------------------------------------------------------------
@@ -1636,27 +1658,33 @@ __global__ void rbpf_window(GridC g, int N, int half_cells, int mark_fresh, cons
 
 struct EdtJob { const int4* win; const int* skip; int p0; };
 
-// distance (cells) from column j to the nearest set bit of a bitmap row, capped at `cap` (255 = none)
-__device__ __forceinline__ int row_nearest(const unsigned long long* row, int words, int j, int cap) {
+// distance (cells) from column j to the nearest set bit of a bitmap row (word(w) = its u64 word w), capped at `cap`
+// (255 = none)
+template <class Word>
+__device__ __forceinline__ int row_nearest_f(Word word, int words, int j, int cap) {
   const int w = j >> 6, b = j & 63;
   int best = 1 << 20;
+  const unsigned long long here = word(w);
   // at or left of j
-  unsigned long long m = row[w] & (b == 63 ? ~0ull : ((1ull << (b + 1)) - 1ull));
+  unsigned long long m = here & (b == 63 ? ~0ull : ((1ull << (b + 1)) - 1ull));
   int ww = w;
   while (true) {
     if (m) { best = j - (ww * 64 + 63 - __clzll((long long)m)); break; }
     if (--ww < 0 || (j - (ww * 64 + 63)) > cap) break;
-    m = row[ww];
+    m = word(ww);
   }
   // right of j
-  m = row[w] & ~(b == 63 ? ~0ull : ((1ull << (b + 1)) - 1ull));
+  m = here & ~(b == 63 ? ~0ull : ((1ull << (b + 1)) - 1ull));
   ww = w;
   while (true) {
     if (m) { const int d = (ww * 64 + (__ffsll((long long)m) - 1)) - j; best = d < best ? d : best; break; }
     if (++ww >= words || (ww * 64 - j) > cap) break;
-    m = row[ww];
+    m = word(ww);
   }
   return best <= cap ? best : 255;
+}
+__device__ __forceinline__ int row_nearest(const unsigned long long* row, int words, int j, int cap) {
+  return row_nearest_f([row](int w) { return row[w]; }, words, j, cap);
 }
 
 __device__ __forceinline__ int floor_div(int num, int den) {  // den > 0
@@ -1983,12 +2011,11 @@ __global__ __launch_bounds__(256) void rbpf_release_tables(int N, int TT, const 
     if (sh) { if (atomicSub(&P.ref[sh], 1) == 1) tile_push(P, sh); shed[e] = 0u; }
   }
 }
-// Everything else a particle owns: pose / prev_pose / weight (weights are NOT reset, :495), the occupancy bitmap with
-// its row counts, the state of its stored distance field and — only where that field is authoritative (injected or
+// Everything else a particle owns: pose / prev_pose / weight (weights are NOT reset, :495), its occupied counts (per tile
+// row and total; the occupancy BITS live in the tiles and follow the tables), the state of its stored distance field and — only where that field is authoritative (injected or
 // materialised, state 2; always in the stored-field modes) — the field itself.  grid (N, chunks).
-__global__ __launch_bounds__(256) void rbpf_gather(int N, size_t G, int words_total, int xsize, const int* __restrict__ parent,
+__global__ __launch_bounds__(256) void rbpf_gather(int N, size_t G, int TW, const int* __restrict__ parent,
                                                    const double* __restrict__ st_src, double* __restrict__ st_dst,
-                                                   const unsigned long long* __restrict__ bm_src, unsigned long long* __restrict__ bm_dst,
                                                    const int* __restrict__ rc_src, int* __restrict__ rc_dst,
                                                    const int* __restrict__ nocc_src, int* __restrict__ nocc_dst,
                                                    const int* __restrict__ fs_src, int* __restrict__ fs_dst,
@@ -1996,9 +2023,7 @@ __global__ __launch_bounds__(256) void rbpf_gather(int N, size_t G, int words_to
   const int m = blockIdx.x;
   const int src = parent[m];
   const size_t t0 = (size_t)blockIdx.y * blockDim.x + threadIdx.x, stride = (size_t)gridDim.y * blockDim.x;
-  const size_t nb = (size_t)words_total;  // bitmap words per particle
-  for (size_t t = t0; t < nb; t += stride) bm_dst[(size_t)m * nb + t] = bm_src[(size_t)src * nb + t];
-  for (size_t t = t0; t < (size_t)xsize; t += stride) rc_dst[(size_t)m * xsize + t] = rc_src[(size_t)src * xsize + t];
+  for (size_t t = t0; t < (size_t)TW; t += stride) rc_dst[(size_t)m * TW + t] = rc_src[(size_t)src * TW + t];
   const int fs = fs_src[src];
   if (cd_src && (copy_all_codes || fs == 2)) {
     const uint2* ca = reinterpret_cast<const uint2*>(cd_src + (size_t)src * G);
@@ -2024,9 +2049,11 @@ __global__ __launch_bounds__(256) void rbpf_tiles_to_dense(int xs, size_t G, Til
     out[i] = P.lo[(size_t)tab[tile_of(M, ci, cj)] * kTileCells + in_tile(ci, cj)];
   }
 }
-// grid = TT workgroups of one wave: tile t of particle p takes the values of `in`; a tile that is all zero in `in`
-// and still the shared zero tile stays shared.
-__global__ __launch_bounds__(kWave) void rbpf_dense_to_tiles(int xs, TilePool P, MapT M, int p, const double* __restrict__ in, int* __restrict__ err) {
+// grid = TT workgroups of one wave: tile t of particle p takes the values of `in` and the occupancy bits they imply
+// (the caller has zeroed the particle's occupied counts); a tile that is all zero in `in` and still the shared zero
+// tile stays shared.
+__global__ __launch_bounds__(kWave) void rbpf_dense_to_tiles(int xs, double cut_occ, TilePool P, MapT M, int p, const double* __restrict__ in,
+                                                             int* __restrict__ trow_occ, int* __restrict__ n_occ, int* __restrict__ err) {
   const int t = blockIdx.x, lane = threadIdx.x, ti = t / M.TW, tj = t - ti * M.TW;
   unsigned int* tab = M.table + (size_t)p * M.TT;
   unsigned int* shed = M.shed + (size_t)p * M.TT;
@@ -2038,10 +2065,17 @@ __global__ __launch_bounds__(kWave) void rbpf_dense_to_tiles(int xs, TilePool P,
   if (__ballot(nz) == 0ull && tab[t] == 0u) return;
   const unsigned int id = tile_make_private(P, tab, shed, t, lane);
   if (id == 0u) { if (lane == 0) atomicOr(&err[3], 8); return; }
-  for (int q = lane; q < kTileCells; q += kWave) {
+  int n_occ_tile = 0;
+  for (int q0 = 0; q0 < kTileCells; q0 += kWave) {  // two tile rows per trip: lanes 0-31 row 2i, 32-63 row 2i+1
+    const int q = q0 + lane;
     const int ci = ti * kTS + (q >> kTSh), cj = tj * kTS + (q & (kTS - 1));
-    P.lo[(size_t)id * kTileCells + q] = (ci < xs && cj < xs) ? in[(size_t)ci * xs + cj] : 0.0;
+    const double v = (ci < xs && cj < xs) ? in[(size_t)ci * xs + cj] : 0.0;
+    P.lo[(size_t)id * kTileCells + q] = v;
+    const unsigned long long m = __ballot(v >= cut_occ);
+    if (lane == 0) { P.bm[(size_t)id * kTS + (q0 >> kTSh)] = (unsigned int)m; P.bm[(size_t)id * kTS + (q0 >> kTSh) + 1] = (unsigned int)(m >> 32); }
+    n_occ_tile += __popcll(m);
   }
+  if (lane == 0 && n_occ_tile) { atomicAdd(&trow_occ[(size_t)p * M.TW + ti], n_occ_tile); atomicAdd(&n_occ[p], n_occ_tile); }
 }
 // Drop every tile reference of slot p (table and shed) and leave it with the empty map: the slot is about to receive
 // an imported particle (tbnav_rbpf_import_particle_dev).
@@ -2057,15 +2091,18 @@ __global__ __launch_bounds__(256) void rbpf_release_slot(TilePool P, MapT M, int
 }
 
 // ---- particle migration between handles (sharded filter): a particle travels as its state, its
-//      occupancy bitmap and ONLY the tiles it does not share with the zero tile ------------------------------------
-__global__ __launch_bounds__(256) void rbpf_pack_tiles(TilePool P, const unsigned int* __restrict__ ids, double* __restrict__ out) {
+//      per-tile-row counts and ONLY the tiles (log-odds + occupancy bits) it does not share with the zero tile ------------------------------------
+__global__ __launch_bounds__(256) void rbpf_pack_tiles(TilePool P, const unsigned int* __restrict__ ids, double* __restrict__ out,
+                                                       unsigned int* __restrict__ out_bm) {
   const double2* src = reinterpret_cast<const double2*>(P.lo + (size_t)ids[blockIdx.x] * kTileCells);
   double2* dst = reinterpret_cast<double2*>(out + (size_t)blockIdx.x * kTileCells);
   for (int i = threadIdx.x; i < kTileCells / 2; i += blockDim.x) dst[i] = src[i];
+  if (threadIdx.x < kTS) out_bm[(size_t)blockIdx.x * kTS + threadIdx.x] = P.bm[(size_t)ids[blockIdx.x] * kTS + threadIdx.x];
 }
 // one workgroup per received tile: take a free tile, name it in the (released) slot's table, fill it
 __global__ __launch_bounds__(256) void rbpf_unpack_tiles(TilePool P, MapT M, int p, const unsigned int* __restrict__ tidx,
-                                                         const double* __restrict__ in, int* __restrict__ err) {
+                                                         const double* __restrict__ in, const unsigned int* __restrict__ in_bm,
+                                                         int* __restrict__ err) {
   __shared__ unsigned int sid;
   if (threadIdx.x == 0) {
     const unsigned int id = tile_pop(P);
@@ -2077,6 +2114,7 @@ __global__ __launch_bounds__(256) void rbpf_unpack_tiles(TilePool P, MapT M, int
   const double2* src = reinterpret_cast<const double2*>(in + (size_t)blockIdx.x * kTileCells);
   double2* dst = reinterpret_cast<double2*>(P.lo + (size_t)sid * kTileCells);
   for (int i = threadIdx.x; i < kTileCells / 2; i += blockDim.x) dst[i] = src[i];
+  if (threadIdx.x < kTS) P.bm[(size_t)sid * kTS + threadIdx.x] = in_bm[(size_t)blockIdx.x * kTS + threadIdx.x];
 }
 
 // ---- getRobotState / newMap on the device ------------------------------------------
@@ -2168,8 +2206,9 @@ struct tbnav_rbpf {
   uint16_t* d_code[2] = {nullptr, nullptr};
   int* d_nocc[2] = {nullptr, nullptr};
   int cur = 0;
-  unsigned long long* d_bitmap[2] = {nullptr, nullptr};  // [N][xsize][words], kept current by the raycast kernel
-  int* d_rowcount[2] = {nullptr, nullptr};               // [N][xsize] occupied cells per map row
+  int* d_trow[2] = {nullptr, nullptr};                   // [N][TW] occupied cells per tile row, kept current by the raycast kernel (the bits themselves live in the tiles)
+  unsigned long long* d_bm_dense = nullptr;              // [N][xsize][words] dense rows for the exact-transform kernels, rebuilt from the tiles on demand
+  int* d_rc_dense = nullptr;                             // [N][xsize]        (allocated with the stored field)
   double2* d_beams = nullptr;  // capacity max_beams
   int max_beams = 0;
   double* d_normals = nullptr;
@@ -2248,6 +2287,8 @@ int ensure_codes(tbnav_rbpf* h) {
     TBNAV_HIP(hipMalloc((void**)&h->d_code[b], bytes));
     TBNAV_HIP(hipMemset(h->d_code[b], 0xFF, bytes));  // occ_dist = max_occ_dist_ (grid_mapper.cpp:49,58)
   }
+  TBNAV_HIP(hipMalloc((void**)&h->d_bm_dense, sizeof(unsigned long long) * (size_t)h->N * h->xsize * h->words));
+  TBNAV_HIP(hipMalloc((void**)&h->d_rc_dense, sizeof(int) * (size_t)h->N * h->xsize));
   return TBNAV_OK;
 }
 
@@ -2356,21 +2397,25 @@ int status_from_err(const int err[4]) {
 // tiles a window can span) or whole-map (tiles_x = every tile; the caller has set win/skip accordingly).
 int run_distance_field(tbnav_rbpf* h, const GridC& g, int p0, int count, int tiles64) {
   hipStream_t st = h->stream;
+  // dense bitmap rows + row counts of these particles, from their tiles
+  hipLaunchKernelGGL(rbpf_densify, dim3((h->xsize + 3) / 4, count), dim3(256), 0, st, g, p0, h->pool, map_of(h), h->d_trow[h->cur],
+                     h->d_bm_dense, h->d_rc_dense);
+  TBNAV_HIP(hipGetLastError());
   // tier 0: <= kEdtRowsA non-empty rows, tier 1: <= kEdtRowsB, tier 2: the general kernel (decided on the device)
   TBNAV_HIP(hipMemsetAsync(h->d_tier + p0, 0, sizeof(int) * count, st));
   const EdtJob job{h->d_win, h->d_skip, p0};
   const dim3 gridc(tiles64, count);
   hipLaunchKernelGGL(rbpf_edt_compact<kEdtRowsA>, gridc, dim3(kWave), edt_compact_lds(kEdtRowsA), st, g, h->radius,
-                     h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_code[h->cur], h->d_tier, 0, job);
+                     h->d_bm_dense, h->d_rc_dense, h->d_code[h->cur], h->d_tier, 0, job);
   TBNAV_HIP(hipGetLastError());
   hipLaunchKernelGGL(rbpf_edt_compact<kEdtRowsB>, gridc, dim3(kWave), edt_compact_lds(kEdtRowsB), st, g, h->radius,
-                     h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_code[h->cur], h->d_tier, 1, job);
+                     h->d_bm_dense, h->d_rc_dense, h->d_code[h->cur], h->d_tier, 1, job);
   TBNAV_HIP(hipGetLastError());
   const int C = h->edt_cols;
   const size_t lds = edt_lds_bytes(h->xsize, h->words, C);
   const dim3 grid(tiles64 * (kWave / C), count);
-  if (C == 64) hipLaunchKernelGGL(rbpf_edt<64>, grid, dim3(64), lds, st, g, h->radius, h->d_bitmap[h->cur], h->d_code[h->cur], h->d_tier, 2, job);
-  else hipLaunchKernelGGL(rbpf_edt<32>, grid, dim3(32), lds, st, g, h->radius, h->d_bitmap[h->cur], h->d_code[h->cur], h->d_tier, 2, job);
+  if (C == 64) hipLaunchKernelGGL(rbpf_edt<64>, grid, dim3(64), lds, st, g, h->radius, h->d_bm_dense, h->d_code[h->cur], h->d_tier, 2, job);
+  else hipLaunchKernelGGL(rbpf_edt<32>, grid, dim3(32), lds, st, g, h->radius, h->d_bm_dense, h->d_code[h->cur], h->d_tier, 2, job);
   TBNAV_HIP(hipGetLastError());
   return TBNAV_OK;
 }
@@ -2391,7 +2436,7 @@ int ensure_full_field(tbnav_rbpf* h, int particle) {
   if (h->edt_cols == 0) {
     const GridC g = grid_of(h);
     hipLaunchKernelGGL(rbpf_field_by_query, dim3((unsigned)((h->G + 255) / 256)), dim3(256), 0, st, g, h->radius, particle,
-                       h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_code[h->cur]);
+                       h->pool, map_of(h), h->d_trow[h->cur], h->d_code[h->cur]);
     TBNAV_HIP(hipGetLastError());
     TBNAV_HIP(hipStreamSynchronize(st));
     TBNAV_HIP(hipMemcpy(h->d_fstate + particle, &two, sizeof two, hipMemcpyHostToDevice));
@@ -2410,7 +2455,8 @@ int ensure_full_field(tbnav_rbpf* h, int particle) {
 }
 
 // lowVarianceResampling's copies on the device: d_parent holds the parent of every slot.  Tables and counts first
-// (two launches, see rbpf_resample_tables), then bitmaps / state / field state into the alternate buffers.
+// (two launches, see rbpf_resample_tables), then state / counts / field state into the alternate buffers (the
+// occupancy bits travel with the tiles: nothing of map size is copied).
 int resample_on_device(tbnav_rbpf* h) {
   const int N = h->N, nxt = 1 - h->cur;
   hipStream_t st = h->stream;
@@ -2420,11 +2466,10 @@ int resample_on_device(tbnav_rbpf* h) {
   TBNAV_HIP(hipGetLastError());
   hipLaunchKernelGGL(rbpf_release_tables, dim3(blocks), dim3(256), 0, st, N, h->TT, h->d_table[h->cur], h->d_shed, h->pool);
   TBNAV_HIP(hipGetLastError());
-  const size_t nb = (size_t)h->xsize * h->words;
-  const size_t work = std::max(nb, h->d_code[0] ? h->G / 4 : (size_t)0);
+  const size_t work = h->d_code[0] ? h->G / 4 : (size_t)0;
   const int chunks = (int)std::min<size_t>(std::max<size_t>(work / 2048, 1), 64);
-  hipLaunchKernelGGL(rbpf_gather, dim3(N, chunks), dim3(256), 0, st, N, h->G, (int)nb, h->xsize, h->d_parent, h->d_state[h->cur], h->d_state[nxt],
-                     h->d_bitmap[h->cur], h->d_bitmap[nxt], h->d_rowcount[h->cur], h->d_rowcount[nxt], h->d_nocc[h->cur], h->d_nocc[nxt],
+  hipLaunchKernelGGL(rbpf_gather, dim3(N, chunks), dim3(256), 0, st, N, h->G, h->TW, h->d_parent, h->d_state[h->cur], h->d_state[nxt],
+                     h->d_trow[h->cur], h->d_trow[nxt], h->d_nocc[h->cur], h->d_nocc[nxt],
                      h->d_fstate, h->d_fstate_alt, h->d_code[h->cur], h->d_code[nxt], h->df_mode != 2 ? 1 : 0);
   TBNAV_HIP(hipGetLastError());
   std::swap(h->d_fstate, h->d_fstate_alt);
@@ -2512,7 +2557,7 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens)
   if (cap > 0 && !h->ref_field && c.Bv < 32768 && tile_lds <= (size_t)kMaxLds - 2048) {
     unsigned long long* touched = h->count_touched ? h->d_touched : nullptr;
 #define TBNAV_RAYCAST(NT, FW, EC) hipLaunchKernelGGL((rbpf_raycast_tile<NT, FW, EC>), dim3(count), dim3(NT), tile_lds, st, c, h->pool, M, h->d_beams, sp.pose, sens, \
-                                                     h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_nocc[h->cur], h->d_err, cap, touched)
+                                                     h->d_trow[h->cur], h->d_nocc[h->cur], h->d_err, cap, touched)
     if (small) TBNAV_RAYCAST(512, 10, 8);
     else if (nt == 256) TBNAV_RAYCAST(256, 16, 16);
     else if (nt == 512) TBNAV_RAYCAST(512, 16, 16);
@@ -2527,7 +2572,7 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens)
       if (rc2 != TBNAV_OK) return rc2;
     }
     hipLaunchKernelGGL(rbpf_raycast, dim3(count), dim3(kWave), sizeof(int) * (2 * bvn + (h->TT + 31) / 32), st, c, h->pool, M, h->d_beams,
-                       sp.pose, h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_nocc[h->cur], h->d_err, log);
+                       sp.pose, h->d_trow[h->cur], h->d_nocc[h->cur], h->d_err, log);
   }
   TBNAV_HIP(hipGetLastError());
   return TBNAV_OK;
@@ -2635,13 +2680,13 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
     const size_t sm_lds = sizeof(double2) * (c.Bv > 0 ? c.Bv : 1) + sizeof(double) * kMixLut + sizeof(unsigned long long) * 4 * (c.Bv > 0 ? c.Bv : 1) +
                           (propose_lds - propose_lds_base);
     hipLaunchKernelGGL(rbpf_scanmatch, dim3(h->N), dim3(kMatchThreads), sm_lds, st, c, h->sm, h->d_beams, h->d_code[h->cur],
-                       h->d_bitmap[h->cur], h->d_rowcount[h->cur], skip_arr, skip_eq, h->df_mode, h->radius, occ_half,
+                       h->pool, map_of(h), h->d_trow[h->cur], skip_arr, skip_eq, h->df_mode, h->radius, occ_half,
                        h->d_nocc[h->cur], h->d_win, sp.pose, h->d_center, h->d_score, h->d_err);
     TBNAV_HIP(hipGetLastError());
     center = h->d_center;
   }
   hipLaunchKernelGGL(rbpf_propose, dim3(h->N), dim3(kProposeThreads), propose_lds, st, c, h->d_beams,
-                     h->d_code[h->cur], h->d_bitmap[h->cur], h->d_rowcount[h->cur], skip_arr, skip_eq, h->df_mode, h->radius, occ_half,
+                     h->d_code[h->cur], h->pool, map_of(h), h->d_trow[h->cur], skip_arr, skip_eq, h->df_mode, h->radius, occ_half,
                      h->d_nocc[h->cur], h->d_win, h->d_normals, center, sp.pose, sp.prev, sp.weight, h->tr, h->d_sens, h->d_err);
   TBNAV_HIP(hipGetLastError());
   if (h->timing) TBNAV_HIP(hipEventRecord(h->ev[2], st));
@@ -2695,7 +2740,7 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
   out->sum_w = no.sum_w; out->sq_sum = no.sq_sum; out->neff = no.neff; out->resampled = no.resampled;
   bool gathered = false;
   if (!local_only && no.resampled && out->status == TBNAV_OK) {
-    // lowVarianceResampling's deep copies (particle_filter.cpp:495): tables, bitmaps and state move on the device
+    // lowVarianceResampling's deep copies (particle_filter.cpp:495): tables and state move on the device
     if (h->timing) TBNAV_HIP(hipEventRecord(h->ev[6], st));
     rc = resample_on_device(h);
     if (rc != TBNAV_OK) return rc;
@@ -2788,8 +2833,7 @@ int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf*
     A((void**)&h->d_state[b], sizeof(double) * 7 * N);
     A((void**)&h->d_table[b], sizeof(unsigned int) * table_entries);
     A((void**)&h->d_nocc[b], sizeof(int) * N);
-    A((void**)&h->d_bitmap[b], sizeof(unsigned long long) * (size_t)N * xsize * words);
-    A((void**)&h->d_rowcount[b], sizeof(int) * (size_t)N * xsize);
+    A((void**)&h->d_trow[b], sizeof(int) * (size_t)N * h->TW);
   }
   A((void**)&h->d_shed, sizeof(unsigned int) * table_entries);
   A((void**)&h->d_cs, sizeof(double) * N);
@@ -2824,7 +2868,7 @@ int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf*
   if (e == hipSuccess) {
     size_t free_b = 0, total_b = 0;
     e = hipMemGetInfo(&free_b, &total_b);
-    const size_t per_tile = sizeof(double) * kTileCells + sizeof(int) + sizeof(unsigned int);
+    const size_t per_tile = sizeof(double) * kTileCells + sizeof(unsigned int) * kTS + sizeof(int) + sizeof(unsigned int);
     const size_t budget = max_pool_bytes ? (size_t)max_pool_bytes : free_b / 2;
     // worst case: every table entry its own tile, plus the tiles the entries left since the last resample (still named by
     // the shed notes until the next resample settles them), plus the zero tile
@@ -2834,6 +2878,7 @@ int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf*
     if (cap < (size_t)N + 2 && e == hipSuccess) e = hipErrorOutOfMemory;  // not even one tile per particle
     h->pool.cap = (unsigned int)cap;
     A((void**)&h->pool.lo, sizeof(double) * kTileCells * cap);
+    A((void**)&h->pool.bm, sizeof(unsigned int) * kTS * cap);
     A((void**)&h->pool.ref, sizeof(int) * cap);
     A((void**)&h->pool.ring, sizeof(unsigned int) * cap);
     A((void**)&h->pool.ctr, sizeof(unsigned long long) * 2);
@@ -2877,8 +2922,8 @@ int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf*
       std::vector<int4> w(N, make_int4(0, xsize - 1, 0, ysize - 1));
       e = hipMemcpy(h->d_win, w.data(), sizeof(int4) * N, hipMemcpyHostToDevice);
     }
-    if (e == hipSuccess) e = hipMemset(h->d_bitmap[0], 0, sizeof(unsigned long long) * (size_t)N * xsize * words);
-    if (e == hipSuccess) e = hipMemset(h->d_rowcount[0], 0, sizeof(int) * (size_t)N * xsize);
+    if (e == hipSuccess) e = hipMemset(h->d_trow[0], 0, sizeof(int) * (size_t)N * h->TW);
+    if (e == hipSuccess) e = hipMemset(h->pool.bm, 0, sizeof(unsigned int) * kTS);  // tile 0
   }
   if (e == hipSuccess && C > 0) {
     const int lds = (int)edt_lds_bytes(xsize, words, C);
@@ -2941,8 +2986,9 @@ void tbnav_rbpf_destroy(tbnav_rbpf* h) {
 #endif
   if (!h) return;
   DeviceGuard guard(h->device);
-  for (int b = 0; b < 2; ++b) { (void)hipFree(h->d_state[b]); (void)hipFree(h->d_table[b]); (void)hipFree(h->d_code[b]); (void)hipFree(h->d_nocc[b]); (void)hipFree(h->d_bitmap[b]); (void)hipFree(h->d_rowcount[b]); }
-  (void)hipFree(h->pool.lo); (void)hipFree(h->pool.ref); (void)hipFree(h->pool.ring); (void)hipFree(h->pool.ctr);
+  for (int b = 0; b < 2; ++b) { (void)hipFree(h->d_state[b]); (void)hipFree(h->d_table[b]); (void)hipFree(h->d_code[b]); (void)hipFree(h->d_nocc[b]); (void)hipFree(h->d_trow[b]); }
+  (void)hipFree(h->d_bm_dense); (void)hipFree(h->d_rc_dense);
+  (void)hipFree(h->pool.lo); (void)hipFree(h->pool.bm); (void)hipFree(h->pool.ref); (void)hipFree(h->pool.ring); (void)hipFree(h->pool.ctr);
   (void)hipFree(h->d_sens); (void)hipFree(h->d_shed); (void)hipFree(h->d_dense); (void)hipFree(h->d_cs); (void)hipFree(h->d_touched); (void)hipFree(h->d_fstate_alt);
   (void)hipFree(h->d_log_ev); (void)hipFree(h->d_log_cnt); (void)hipFree(h->d_tile_scratch);
   (void)hipFree(h->d_gw); (void)hipFree(h->d_gcs); (void)hipFree(h->d_gparent); (void)hipFree(h->d_gz);
@@ -3096,7 +3142,7 @@ int tbnav_rbpf_set_weights_from_global_dev(tbnav_rbpf* h, const int32_t* global_
 namespace {
 struct BlobHeader { uint64_t magic; uint32_t n_tiles, has_codes; int32_t nocc, fstate; uint32_t xsize, TT; };
 constexpr uint64_t kBlobMagic = 0x54424e4156504631ull;  // "TBNAVPF1"
-struct BlobLayout { size_t state, tidx, tiles, bitmap, rowcount, codes, total; };
+struct BlobLayout { size_t state, tidx, tiles, tile_bm, trow, codes, total; };
 BlobLayout blob_layout(const tbnav_rbpf* h, uint32_t n_tiles, bool has_codes) {
   auto up8 = [](size_t v) { return (v + 7) & ~(size_t)7; };
   BlobLayout L{};
@@ -3104,8 +3150,8 @@ BlobLayout blob_layout(const tbnav_rbpf* h, uint32_t n_tiles, bool has_codes) {
   L.state = o; o += sizeof(double) * 7;
   L.tidx = o; o = up8(o + sizeof(uint32_t) * n_tiles);
   L.tiles = o; o += sizeof(double) * kTileCells * n_tiles;
-  L.bitmap = o; o += sizeof(unsigned long long) * (size_t)h->xsize * h->words;
-  L.rowcount = o; o = up8(o + sizeof(int) * h->xsize);
+  L.tile_bm = o; o = up8(o + sizeof(unsigned int) * kTS * n_tiles);
+  L.trow = o; o = up8(o + sizeof(int) * h->TW);
   L.codes = o; if (has_codes) o = up8(o + sizeof(uint16_t) * h->G);
   L.total = o;
   return L;
@@ -3153,12 +3199,11 @@ int tbnav_rbpf_export_particle_dev(tbnav_rbpf* h, int32_t slot, void* d_buf, uin
   if (n) {
     TBNAV_HIP(hipMemcpy(b + L.tidx, tidx.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
     TBNAV_HIP(hipMemcpy(h->d_tile_scratch, ids.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(rbpf_pack_tiles, dim3(n), dim3(256), 0, st, h->pool, h->d_tile_scratch, reinterpret_cast<double*>(b + L.tiles));
+    hipLaunchKernelGGL(rbpf_pack_tiles, dim3(n), dim3(256), 0, st, h->pool, h->d_tile_scratch, reinterpret_cast<double*>(b + L.tiles),
+                       reinterpret_cast<unsigned int*>(b + L.tile_bm));
     TBNAV_HIP(hipGetLastError());
   }
-  const size_t nb = (size_t)h->xsize * h->words;
-  TBNAV_HIP(hipMemcpyAsync(b + L.bitmap, h->d_bitmap[h->cur] + (size_t)slot * nb, sizeof(unsigned long long) * nb, hipMemcpyDeviceToDevice, st));
-  TBNAV_HIP(hipMemcpyAsync(b + L.rowcount, h->d_rowcount[h->cur] + (size_t)slot * h->xsize, sizeof(int) * h->xsize, hipMemcpyDeviceToDevice, st));
+  TBNAV_HIP(hipMemcpyAsync(b + L.trow, h->d_trow[h->cur] + (size_t)slot * h->TW, sizeof(int) * h->TW, hipMemcpyDeviceToDevice, st));
   if (has_codes) TBNAV_HIP(hipMemcpyAsync(b + L.codes, h->d_code[h->cur] + (size_t)slot * h->G, sizeof(uint16_t) * h->G, hipMemcpyDeviceToDevice, st));
   TBNAV_HIP(hipStreamSynchronize(st));
   return TBNAV_OK;
@@ -3182,7 +3227,7 @@ int tbnav_rbpf_import_particle_dev(tbnav_rbpf* h, int32_t slot, const void* d_bu
   TBNAV_HIP(hipGetLastError());
   if (hd.n_tiles) {
     hipLaunchKernelGGL(rbpf_unpack_tiles, dim3(hd.n_tiles), dim3(256), 0, st, h->pool, M, slot, reinterpret_cast<const unsigned int*>(b + L.tidx),
-                       reinterpret_cast<const double*>(b + L.tiles), h->d_err);
+                       reinterpret_cast<const double*>(b + L.tiles), reinterpret_cast<const unsigned int*>(b + L.tile_bm), h->d_err);
     TBNAV_HIP(hipGetLastError());
   }
   StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
@@ -3190,9 +3235,7 @@ int tbnav_rbpf_import_particle_dev(tbnav_rbpf* h, int32_t slot, const void* d_bu
   TBNAV_HIP(hipMemcpyAsync(sp.pose + (size_t)slot * 3, bs, sizeof(double) * 3, hipMemcpyDeviceToDevice, st));
   TBNAV_HIP(hipMemcpyAsync(sp.prev + (size_t)slot * 3, bs + 3, sizeof(double) * 3, hipMemcpyDeviceToDevice, st));
   TBNAV_HIP(hipMemcpyAsync(sp.weight + slot, bs + 6, sizeof(double), hipMemcpyDeviceToDevice, st));
-  const size_t nb = (size_t)h->xsize * h->words;
-  TBNAV_HIP(hipMemcpyAsync(h->d_bitmap[h->cur] + (size_t)slot * nb, b + L.bitmap, sizeof(unsigned long long) * nb, hipMemcpyDeviceToDevice, st));
-  TBNAV_HIP(hipMemcpyAsync(h->d_rowcount[h->cur] + (size_t)slot * h->xsize, b + L.rowcount, sizeof(int) * h->xsize, hipMemcpyDeviceToDevice, st));
+  TBNAV_HIP(hipMemcpyAsync(h->d_trow[h->cur] + (size_t)slot * h->TW, b + L.trow, sizeof(int) * h->TW, hipMemcpyDeviceToDevice, st));
   TBNAV_HIP(hipMemcpyAsync(h->d_nocc[h->cur] + slot, &hd.nocc, sizeof(int), hipMemcpyHostToDevice, st));
   const int fs = hd.has_codes ? 2 : 0;
   if (hd.has_codes) {
@@ -3264,13 +3307,11 @@ int tbnav_rbpf_set_log_odds(tbnav_rbpf* h, int32_t particle, const double* in) {
   TBNAV_HIP(hipStreamSynchronize(h->stream));
   TBNAV_HIP(hipMemcpy(h->d_dense, in, sizeof(double) * h->G, hipMemcpyHostToDevice));
   for (int q = 0; q < 4; ++q) h->h_err[q] = 0;
-  hipLaunchKernelGGL(rbpf_dense_to_tiles, dim3(h->TT), dim3(kWave), 0, h->stream, h->xsize, h->pool, map_of(h), particle, h->d_dense, h->d_err);
-  TBNAV_HIP(hipGetLastError());
-  // rebuild this particle's occupancy bitmap / row counts / occupied count from the new log-odds
+  // the tiles take the new log-odds and the occupancy bits they imply; the particle's occupied counts are rebuilt
   TBNAV_HIP(hipMemsetAsync(h->d_nocc[h->cur] + particle, 0, sizeof(int), h->stream));
-  const GridC g = grid_of(h);
-  hipLaunchKernelGGL(rbpf_occupancy, dim3((h->xsize + 3) / 4, 1), dim3(256), 0, h->stream, g, h->cut_occ, particle, h->pool, map_of(h),
-                     h->d_bitmap[h->cur], h->d_rowcount[h->cur], h->d_nocc[h->cur]);
+  TBNAV_HIP(hipMemsetAsync(h->d_trow[h->cur] + (size_t)particle * h->TW, 0, sizeof(int) * h->TW, h->stream));
+  hipLaunchKernelGGL(rbpf_dense_to_tiles, dim3(h->TT), dim3(kWave), 0, h->stream, h->xsize, h->cut_occ, h->pool, map_of(h), particle, h->d_dense,
+                     h->d_trow[h->cur], h->d_nocc[h->cur], h->d_err);
   TBNAV_HIP(hipGetLastError());
   TBNAV_HIP(hipStreamSynchronize(h->stream));
   if (h->h_err[3] & 8) return TBNAV_ERR_POOL_EXHAUSTED;
@@ -3444,8 +3485,8 @@ int tbnav_rbpf_likelihood(tbnav_rbpf* h, int32_t particle, const float* scan, in
   int rc = one_particle_consts(h, particle, scan, n_beams, c);
   if (rc != TBNAV_OK) return rc;
   for (int q = 0; q < 4; ++q) h->h_err[q] = 0;
-  hipLaunchKernelGGL(rbpf_likelihood_one, dim3(1), dim3(kWave), 0, h->stream, c, h->d_beams, h->d_code[h->cur], h->d_bitmap[h->cur],
-                     h->d_rowcount[h->cur], h->d_fstate, h->radius, h->d_nocc[h->cur], pose[0], pose[1], pose[2], h->d_score, h->d_err);
+  hipLaunchKernelGGL(rbpf_likelihood_one, dim3(1), dim3(kWave), 0, h->stream, c, h->d_beams, h->d_code[h->cur], h->pool, map_of(h),
+                     h->d_trow[h->cur], h->d_fstate, h->radius, h->d_nocc[h->cur], pose[0], pose[1], pose[2], h->d_score, h->d_err);
   TBNAV_HIP(hipGetLastError());
   TBNAV_HIP(hipMemcpyAsync(out, h->d_score, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   TBNAV_HIP(hipStreamSynchronize(h->stream));

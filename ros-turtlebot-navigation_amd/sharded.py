@@ -229,7 +229,7 @@ class ShardedRBPF:
     def _migrate(self, parents: np.ndarray):
         """Slot m (global) takes the state of particle parents[m].  Parents on this rank are gathered inside the
         handle (tile tables + reference counts); a parent on another rank arrives as one device buffer: its state,
-        bitmap and the tiles it owns — point to point, only for the slots that need it."""
+        counts and the tiles it owns — point to point, only for the slots that need it."""
         nl, me = self.n_local, self.rank
         lo = me * nl
         sends = sorted({(m // nl, int(q)) for m, q in enumerate(parents) if q // nl == me and m // nl != me})

@@ -110,6 +110,11 @@ def test_configs4_shard_10000_particles_2000x2000_1080_beams(gpu_pkg):
         assert np.array_equal(pf.logOdds(m), want), m
     (pose, idx) = pf.getRobotState()
     assert 0 <= idx < N and np.all(np.isfinite(pose))
+    # a particle of this shard travels as its tiles (log-odds + occupancy bits): ~1 MB, not a 32 MB map + 512 KB bitmap
+    import ctypes as C
+    nbytes = C.c_uint64()
+    assert pf._L.tbnav_rbpf_export_size(pf._h, 4321, C.byref(nbytes)) == 0
+    assert nbytes.value < 120 * (8192 + 128) + 65536, nbytes.value
     pf.close()
 
 

@@ -75,7 +75,7 @@ def test_rbpf_two_ranks_one_gpu_equals_unsharded_bit_exact(gpu_pkg, heavy):
     EXPORTED parent (5, sent to rank 1) has its own slot taken over by another local parent (2)."""
     n_local = 6 if 10 in heavy else 8
     res = _rbpf_sharded_vs_unsharded(n_local, 8, 1, heavy, "gloo")
-    # a travelling particle is its tiles, not its map: 80 x 80 cells = 9 tiles of 8 KB at most + bitmap + state
+    # a travelling particle is its tiles, not its map: 80 x 80 cells = 9 tiles of 8 KB + 128 B at most + counts + state
     assert max(res[0]["migrated"], res[1]["migrated"]) < 8 * (9 * 8192 + 4096)
 
 
