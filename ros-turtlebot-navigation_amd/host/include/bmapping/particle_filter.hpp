@@ -3,6 +3,12 @@
 // SLAM(scan, u, cur_odom, prev_odom), getRobotState(), newMap(map).  bmapping/src/turtle_mapping_node.cpp
 // (:404-410, :474, :479, :494) compiles unchanged against it.  All particle state lives on the GPU
 // behind include/tbnav_rbpf.h.
+//
+// ONE DEVIATION to know about: by default the likelihood-field lookups use the exact nearest-obstacle distance,
+// not the reference's priority-queue brushfire (grid_mapper.cpp:333-435), whose result depends on the occupied
+// set's hash order and keeps stale cells (include/tbnav_rbpf.h, "DISTANCE FIELD"; measured effect on the weights:
+// DESIGN.md section 5).  useReferenceDistanceField() switches to a bit-for-bit reproduction of the brushfire
+// (serial host work per particle: meant for the reference's 40-particle launch configuration).
 #ifndef TBNAV_BMAPPING_PARTICLE_FILTER_HPP
 #define TBNAV_BMAPPING_PARTICLE_FILTER_HPP
 
@@ -50,6 +56,9 @@ class ParticleFilter {
   /// Not in the reference: every particle refines T(pose) * T_icp against its own map (hill climbing on the
   /// likelihood field) before sampling, so T_icp may be a rough guess such as the odometry increment.
   void useScanMatching(bool on = true, double lstep = 0.05, double astep = 0.05, int iterations = 5);
+  /// Reproduce the reference's brushfire distance field bit for bit instead of the exact one (see the header note).
+  /// Call before the first SLAM(): the brushfire's result depends on the whole history of the occupied set.
+  void useReferenceDistanceField(bool on = true);
   int effectiveParticles() const { return last_neff_; }
   bool resampledLastScan() const { return last_resampled_; }
 

@@ -68,6 +68,10 @@ void ParticleFilter::useScanMatching(bool on, double lstep, double astep, int it
   check(tbnav_rbpf_set_scan_matching(h_, on ? 1 : 0, lstep, astep, iterations), "useScanMatching");
 }
 
+void ParticleFilter::useReferenceDistanceField(bool on) {
+  check(tbnav_rbpf_set_option(h_, TBNAV_RBPF_OPT_DF_MODE, on ? TBNAV_RBPF_DF_REFERENCE : TBNAV_RBPF_DF_QUERY), "useReferenceDistanceField");
+}
+
 void ParticleFilter::useDeviceNoise(std::uint64_t seed) {
   device_noise_ = true;
   check(tbnav_rbpf_set_seed(h_, seed), "useDeviceNoise");

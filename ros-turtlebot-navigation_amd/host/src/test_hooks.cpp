@@ -171,6 +171,9 @@ int hst_mppi_tick(const double* params, int rollouts, uint64_t seed, const doubl
 // Shipped parameters (slam.launch) with N, k, map half-size given; runs n_scans of SLAM() on the given
 // scans/odometry with the filter's twister seeded; out_pose [n_scans][3] = getRobotState per scan,
 // out_neff [n_scans]; map_out = newMap() after the last scan.  Returns xsize or -1 (message in hst_last_error).
+static int g_pf_reference_field = 0;
+void hst_pf_reference_field(int on) { g_pf_reference_field = on; }  // next hst_pf_run: ParticleFilter::useReferenceDistanceField()
+
 int hst_pf_run(int N, int k, double map_half, uint64_t seed, const float* scans, int n_beams, int n_scans,
                const double* odom /*[n_scans+1][3] theta,x,y: odom[s] = prev, odom[s+1] = cur*/, double* out_pose,
                int* out_neff, int8_t* map_out) {
@@ -185,6 +188,7 @@ int hst_pf_run(int N, int k, double map_half, uint64_t seed, const float* scans,
     aligner.setMatcher([&](Transform2D& T, const Transform2D&, const std::vector<float>&, const std::vector<float>&) { T = icp_result; return true; });
     Transform2D start(Vector2D(odom[1], odom[2]), odom[0]);
     bmapping::ParticleFilter pf(N, k, 0.1, 0.2, 0.1, 0.2, 1e-10, 1e-10, 1e-10, 1e-10, 1e-8, 1e-8, 1.0, 20.0, 1.0, 10.0, aligner, start, grid);
+    if (g_pf_reference_field) pf.useReferenceDistanceField(true);
     bmapping::getTwister().seed(seed);
     for (int s = 0; s < n_scans; ++s) {
       std::vector<float> scan(scans + (size_t)s * n_beams, scans + (size_t)(s + 1) * n_beams);

@@ -166,17 +166,21 @@ def test_closed_loop_with_exact_arc_rollouts(host, gpu_pkg):
 
 
 @pytest.mark.gpu
-def test_particle_filter_class_surface_end_to_end(host, gpu_pkg):
+@pytest.mark.parametrize("reference_field", [0, 1])
+def test_particle_filter_class_surface_end_to_end(host, gpu_pkg, reference_field):
     """bmapping::ParticleFilter driven like turtle_mapping_node.cpp:459-494 (SLAM, getRobotState,
-    newMap).  No distance-field injection here, so the comparison with the oracle filter is an
-    integration check: best pose within 1 mm, exported maps agree on >= 99 % of cells."""
+    newMap).  No distance-field injection.  Default (exact field): best pose within 1 mm, exported maps agree on
+    >= 99 % of cells.  With ParticleFilter::useReferenceDistanceField() the class IS the reference filter: best pose
+    to 1e-9, Neff and the exported map identical."""
     N, k, n_scans = 40, 50, 5
+    host.hst_pf_reference_field(reference_field)
     steps, poses = rc.trajectory(n_scans, inc=(0.04, 0.03, 0.02))
     rng = np.random.default_rng(3)
     scans = np.stack([orc.room_scan(poses[s], walls=rc.ROOM_SMALL, rng=rng) for s in range(n_scans)])
     odom = np.stack([steps[0][0]] + [st[1] for st in steps])
     out_pose = np.empty((n_scans, 3)); out_neff = np.empty(n_scans, dtype=np.int32); m = np.empty(80 * 80, dtype=np.int8)
     xs = host.hst_pf_run(N, k, C.c_double(2.0), C.c_uint64(11), _p(scans), 360, n_scans, _p(odom), _p(out_pose), _p(out_neff), _p(m))
+    host.hst_pf_reference_field(0)
     assert xs == 80, host.hst_last_error()
     # the same run through the oracle filter: same twister stream, same ICP convention
     pf = orc.PfAPI(orc.pf_params(N=N, k=k, pose0=tuple(odom[0])))
@@ -190,10 +194,12 @@ def test_particle_filter_class_surface_end_to_end(host, gpu_pkg):
         off += tr["normals_used"]
         assert tr["rc"] == 0
         po, _, _ = pf.particles()
-        assert np.allclose(out_pose[s], po[pf.best()], atol=1e-3)
+        assert np.allclose(out_pose[s], po[pf.best()], atol=1e-9 if reference_field else 1e-3)
+        if reference_field:
+            assert out_neff[s] == tr["neff"]
     agree = np.mean(m == pf.grid(pf.best()).grid_map())
-    print(f"\n[pf class surface] Neff {out_neff.tolist()}, exported map agreement {agree*100:.2f} %")
-    assert agree >= 0.99
+    print(f"\n[pf class surface, reference_field={reference_field}] Neff {out_neff.tolist()}, exported map agreement {agree*100:.2f} %")
+    assert agree == 1.0 if reference_field else agree >= 0.99
 
 
 def test_node_call_sites_compile_against_these_headers():
