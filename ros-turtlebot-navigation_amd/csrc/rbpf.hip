@@ -1233,6 +1233,21 @@ __device__ __forceinline__ int wave_sum_i(int v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
+// The same reductions without LDS round trips: an inclusive scan inside each row of 16 lanes by DPP shifts, then the row
+// totals broadcast down the rows (row_bcast:15 / :31); lane 63 holds the result.  (__shfl_xor is ds_bpermute: six
+// dependent LDS-latency steps per reduction.)
+template <class Op> __device__ __forceinline__ int wave_reduce_dpp(int v, int ident, Op op) {
+  v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x111, 0xf, 0xf, false));  // row_shr:1
+  v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x112, 0xf, 0xf, false));  // row_shr:2
+  v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x114, 0xf, 0xf, false));  // row_shr:4
+  v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x118, 0xf, 0xf, false));  // row_shr:8
+  v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x142, 0xa, 0xf, false));  // row_bcast:15 into rows 1, 3
+  v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x143, 0xc, 0xf, false));  // row_bcast:31 into rows 2, 3
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_min_dpp(int v) { return wave_reduce_dpp(v, 0x7FFFFFFF, [](int a, int b) { return a < b ? a : b; }); }
+__device__ __forceinline__ int wave_max_dpp(int v) { return wave_reduce_dpp(v, (int)0x80000000, [](int a, int b) { return a > b ? a : b; }); }
+__device__ __forceinline__ int wave_sum_dpp(int v) { return wave_reduce_dpp(v, 0, [](int a, int b) { return a + b; }); }
 // LDS of the tile kernel (ints): exy own ecnt [Bv each] | ev u16[Bv][kEvCap] | tile u32[(cap+1)/2].  A ray is rebuilt
 // from (robot cell, end point) where it is walked instead of being stored.
 constexpr int kBoxSideMax = 176;  // rows a scan's bounding box can have (tile_cap <= 30000 -> side <= 173)
@@ -1608,6 +1623,512 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : (NT == 512 ? 8 : 3)) void rbpf
 }
 
 // ---- dense view of the occupancy bits -----------------------------------------------------------------------
+// The packed form of a ray straight from its two ends, selects only (what pack_ray(make_ray(..)) returns; the Ray struct's
+// case analysis turns into a private array the compiler indexes at run time).  Along the major axis the ray starts at
+// its LOW end (xa, ya) — the robot's cell or, for a reversed ray, the end point — takes dmaj steps and moves c_t =
+// max(0, ceil((2 dmin t - dmaj) / (2 dmaj))) cells sideways (negated if neg); its free cells are the robot's cell and
+// the cells strictly between the ends.
+struct RayP { int xa, ya, dmaj, dmin; bool ymajor, neg; };
+__device__ __forceinline__ RayP ray_packed(int x0, int y0, int x1, int y1) {
+  const int dx = x1 - x0, dy = y1 - y0, adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
+  RayP r;
+  r.ymajor = ady > adx;
+  const bool rev = r.ymajor ? (y0 > y1) : (x0 > x1);
+  r.xa = rev ? x1 : x0; r.ya = rev ? y1 : y0;
+  const int d = r.ymajor ? (rev ? x0 : x1) - r.xa : (rev ? y0 : y1) - r.ya;
+  r.neg = d < 0;
+  r.dmaj = r.ymajor ? ady : adx; r.dmin = r.ymajor ? adx : ady;
+  return r;
+}
+// Is (cx, cy) a free cell of the ray (x0, y0) -> (x1, y1)?  Same set as on_ray(make_ray(..)).
+__device__ __forceinline__ bool on_ray_packed(int x0, int y0, int x1, int y1, int cx, int cy) {
+  const RayP r = ray_packed(x0, y0, x1, y1);
+  if (r.dmaj == 0) return false;  // the beam ends in the robot's cell: no free cell
+  if (cx == x0 && cy == y0) return true;
+  const int n = r.ymajor ? cy - r.ya : cx - r.xa;  // steps along the major axis
+  const int tm = r.ymajor ? cx - r.xa : cy - r.ya, t = r.neg ? -tm : tm;  // offset along the minor axis, in the ray's sense
+  const int a = 2 * r.dmin * n - r.dmaj, d2 = 2 * r.dmaj;
+  const bool side = (a <= 0) ? (t == 0) : (t >= 1 && d2 * (t - 1) < a && a <= d2 * t);
+  return n >= 1 && n <= r.dmaj - 1 && side;
+}
+
+// ---- the default map update: box counters ------------------------------------------------------------------------
+// Same contract as rbpf_raycast_tile (bit-identical maps) with fewer, cheaper phases:
+//  F. the beams' end-point cells — the only cells that see both l_free and l_occ in one scan, i.e. where the floating-
+//     point add order matters — are flagged in an LDS array with one 32-bit word per cell of the scan's bounding box
+//     (bit 31; bits 16-30 = the cell's slot in the list of distinct end-point cells);
+//  1. every ray segment walks its cells with ONE returning LDS add per cell (low 16 bits = free adds) and never waits
+//     for it: the value that comes back is looked at one step later, and only if it carries the flag does the lane
+//     record "beam b, free" in that cell's slot (a few percent of the steps); every beam records "beam b, occupied" in
+//     its own end point's slot;
+//  2. one pass over the box, a group of 8 cells at a time, marks the map tiles the scan writes; they are made private to
+//     the particle (usually they already are);
+//  3. the read-modify-write: each thread requests its group (64 contiguous bytes of one map tile); meanwhile one lane
+//     per end-point cell replays its slot in beam order (an overflowed slot: a whole wave tests the cell against every
+//     beam), and the cells round the robot — hundreds of sequential adds each: every ray starts there — get a lane of
+//     their own in an otherwise idle wave; both hand their result to the group's owner through LDS.  A plain cell adds
+//     its count of l_free (same addend each time, so the order among the adds is immaterial); the group goes back as
+//     whole 16-byte stores.
+// The LDS array holds as many rows of the box as fit (tile_cap words); a box with more rows (a long-range scan seen
+// from a rotated pose) is worked through in bands of rows, every phase once per band with the rays clipped to the band.
+// LDS: tile u32[tile_cap] (rows padded to whole groups of 8 cells along y: group g = words 8g .. 8g+7) |
+// ev u16[Bv][kBoxEv] | val_e f64[Bv + 64] | exy own ecnt i32[Bv]
+#ifdef TBNAV_PHASE_PROF
+__device__ unsigned long long g_phase_w[16];
+#define PHASE_STAMP_W(i) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_phase_w[i], now_ - t_prev_); t_prev_ = now_; } } while (0)
+#else
+#define PHASE_STAMP_W(i)
+#endif
+#ifndef TBNAV_EXP
+#define TBNAV_EXP 0  // development: -DTBNAV_EXP=<mask> removes parts of the kernel to time the rest (results are then wrong)
+#endif
+constexpr int kBoxEv = 8;     // events a slot holds before it is replayed exhaustively
+constexpr int kHotSide = 7;   // the kHotSide x kHotSide cells round the robot are candidates for a lane of their own ...
+constexpr int kHotMin = 16;   // ... when they collect at least this many free adds
+__host__ __device__ constexpr size_t box_lds_bytes(size_t cap, size_t bv) { return 4 * cap + 8 * (bv + 64) + 4 * 3 * bv + 2 * kBoxEv * bv; }
+template <int NT>
+__global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, MapT M, const double2* __restrict__ beams,
+                                                          const double* __restrict__ pose, const double* __restrict__ sens,
+                                                          int* __restrict__ trow_occ, int* __restrict__ n_occ, int* __restrict__ err,
+                                                          int tile_cap, unsigned long long* __restrict__ touched) {
+  extern __shared__ __attribute__((aligned(16))) int lds_i[];
+  const int Bv = c.Bv;
+  unsigned int* tile = reinterpret_cast<unsigned int*>(lds_i);         // (tile_cap is a multiple of 8)
+  unsigned short* ev = reinterpret_cast<unsigned short*>(lds_i + tile_cap);  // [n_own][kBoxEv]  beam << 1 | occupied  (16 bytes a slot, 16-byte aligned)
+  double* val_e = reinterpret_cast<double*>(lds_i + tile_cap + 4 * Bv);      // [Bv + 64] the value replayed for an end-point cell / a hot cell
+  int* exy = lds_i + tile_cap + 4 * Bv + 2 * (Bv + 64);  // [Bv] end-point cell, x | y << 16
+  int* own = exy + Bv;                                   // [n_own] the first beam that ended in each distinct end-point cell of the band
+  int* ecnt = own + Bv;                                  // [n_own] events recorded (may exceed kBoxEv: overflow)
+  constexpr unsigned int kFlag = 0x80000000u;
+  constexpr int kEv = kBoxEv;
+  __shared__ int bad, bx0, bx1, by0, by1, n_own, srx, sry, n_need, nocc_delta, n_ovf;
+  __shared__ unsigned long long need_base;
+  __shared__ unsigned int mt_id[kMapTilesMax];  // map tiles under the box: the tile the particle's table names (once written: its private tile)
+  __shared__ int mt_touch[kMapTilesMax], mt_slot[kMapTilesMax], mt_priv[kMapTilesMax];
+  __shared__ int rc_delta[kBoxSideMax / kTS + 2];
+  __shared__ int ovf[kWave];                    // slots whose event list overflowed (more than these: found by scanning)
+  __shared__ double sh_pose[4];
+  constexpr int nthr = NT, nw = NT / kWave;
+  const int p = c.p0 + blockIdx.x, tid_k = threadIdx.x, tid = tid_k, lane = tid & (kWave - 1), wid = tid / kWave;
+#ifdef TBNAV_PHASE_PROF
+  unsigned long long t_prev_ = wall_clock64();
+#endif
+  unsigned int* tab = M.table + (size_t)p * M.TT;
+  unsigned int* shed = M.shed + (size_t)p * M.TT;
+  if (wid == 0) {
+    const double x = pose[p * 3 + 1], y = pose[p * 3 + 2];
+    int rx0 = 0, ry0 = 0;
+    const bool robot_ok = world2cell(c.g, x, y, rx0, ry0);  // freeGridIndex: world2Grid of the ROBOT pose (:558)
+    double X, Y, st0, ct0;
+    if (sens) { X = sens[p * 4 + 0]; Y = sens[p * 4 + 1]; st0 = sens[p * 4 + 2]; ct0 = sens[p * 4 + 3]; }
+    else {
+      const double th = pose[p * 3 + 0];
+      double s0, c0;
+      sincos(th, &s0, &c0);
+      if (c.Trs[0] == 0.0) { st0 = s0; ct0 = c0; } else sincos(th + c.Trs[0], &st0, &ct0);
+      X = c0 * c.Trs[1] - s0 * c.Trs[2] + x;
+      Y = s0 * c.Trs[1] + c0 * c.Trs[2] + y;
+    }
+    if (lane == 0) {
+      sh_pose[0] = X; sh_pose[1] = Y; sh_pose[2] = st0; sh_pose[3] = ct0;
+      bad = robot_ok ? 0 : 1; bx0 = bx1 = rx0; by0 = by1 = ry0; n_own = 0; srx = rx0; sry = ry0;
+      n_need = 0; nocc_delta = 0; n_ovf = 0;
+    }
+  } else {
+    uint4* t4 = reinterpret_cast<uint4*>(tile);
+    for (int t = tid - kWave; t < tile_cap / 4; t += nthr - kWave) t4[t] = uint4{0u, 0u, 0u, 0u};
+    for (int b = tid - kWave; b < Bv; b += nthr - kWave) ecnt[b] = 0;
+    for (int t = tid - kWave; t < kMapTilesMax; t += nthr - kWave) mt_touch[t] = 0;
+    for (int t = tid - kWave; t < kBoxSideMax / kTS + 2; t += nthr - kWave) rc_delta[t] = 0;
+  }
+  __syncthreads();
+  // (workgroup-uniform values read from LDS are moved to scalar registers: the kernel has 64 VGPRs to live in)
+  auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+  const int rx = uni(srx), ry = uni(sry);
+  {
+    const double X = sh_pose[0], Y = sh_pose[1], st = sh_pose[2], ct = sh_pose[3];
+    for (int b0 = wid * kWave; b0 < Bv; b0 += nthr) {
+      const int b = b0 + lane;
+      int ci = rx, cj = ry;
+      if (b < Bv) {
+        const double2 pt = beams[b];
+        if (!world2cell(c.g, ct * pt.x - st * pt.y + X, st * pt.x + ct * pt.y + Y, ci, cj)) { bad = 1; ci = rx; cj = ry; }
+        exy[b] = ci | (cj << 16);
+      }
+      const int lo_x = wave_min_dpp(ci), hi_x = wave_max_dpp(ci), lo_y = wave_min_dpp(cj), hi_y = wave_max_dpp(cj);
+      if (lane == 0) { atomicMin(&bx0, lo_x); atomicMax(&bx1, hi_x); atomicMin(&by0, lo_y); atomicMax(&by1, hi_y); }
+    }
+  }
+  __syncthreads();
+  if (bad) { if (tid == 0) atomicOr(&err[0], 1); return; }
+  const int minx = uni(bx0), maxx = uni(bx1), maxy = uni(by1);
+  const int miny = uni(by0) & ~7;                                   // the box starts on a multiple of 8 along y and
+  const int bw = ((maxy | 7) + 1) - miny, gw = bw >> 3;             // is whole groups wide: a group never straddles a map tile
+  const int bh = maxx - minx + 1;
+  const int tx0 = minx >> kTSh, ty0 = miny >> kTSh, mty = (maxy >> kTSh) - ty0 + 1, mtn = ((maxx >> kTSh) - tx0 + 1) * mty;
+  const int rows_fit = uni(floor_div_small(tile_cap, bw));          // rows of the box the LDS array holds at a time
+  if (rows_fit < 1 || mtn > kMapTilesMax || bh > kBoxSideMax) { if (tid == 0) atomicOr(&err[3], 2); return; }  // cannot happen: see launch_raycast
+  // the particle's table entries under the box, and the reference counts of the tiles they name (needed in phase C)
+  const int tq = nthr - 1 - tid;  // (the table work sits on the LAST threads: they have no ray segment to walk)
+  if (tq < mtn) {
+    const int qi = floor_div_small(tq, mty), qj = tq - qi * mty;
+    const unsigned int my_tab = tab[(tx0 + qi) * M.TW + (ty0 + qj)];
+    mt_id[tq] = my_tab;
+    mt_priv[tq] = (my_tab != 0u && P.ref[my_tab] == 1) ? 1 : 0;
+  }
+  auto map_tile = [&](int cx, int cy) { return __mul24((cx >> kTSh) - tx0, mty) + ((cy >> kTSh) - ty0); };
+  auto cell_ptr = [&](int cx, int cy) -> double* { return P.lo + (size_t)mt_id[map_tile(cx, cy)] * kTileCells + in_tile(cx, cy); };
+  auto toggled = [&](int cx, int cy, bool now) {  // the cell crossed the occupied cut-off: its bit in the (private) tile, tile-row count, total
+    atomicXor(&P.bm[(size_t)mt_id[map_tile(cx, cy)] * kTS + (cx & (kTS - 1))], 1u << (cy & (kTS - 1)));
+    atomicAdd(&rc_delta[(cx >> kTSh) - tx0], now ? 1 : -1);
+    atomicAdd(&nocc_delta, now ? 1 : -1);
+  };
+  auto record = [&](unsigned int word, int what) {  // an event for the flagged cell whose tile word this is
+    const int o = (int)((word >> 16) & 0x7FFFu);
+    const int en = atomicAdd(&ecnt[o], 1);
+    if (en < kEv) ev[o * kEv + en] = (unsigned short)what;
+  };
+  const uint4* tile4 = reinterpret_cast<const uint4*>(tile);
+  const int step_r = uni(floor_div_small(2 * nthr, bw)), step_c = 2 * nthr - step_r * bw;  // pair pi + nthr in (row, column) terms
+  int n_distinct = 0, n_ends = 0;
+  for (int x0 = minx; x0 <= maxx; x0 += rows_fit) {  // one band of rows at a time (one trip unless the box is larger than the LDS array)
+    // (per-thread values are re-derived from an opaque copy of the thread index in every trip: hoisted out of this loop they
+    //  would be spilled — the kernel has 64 VGPRs — and a spill reload between memory requests serialises them)
+    int tid = tid_k;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & (kWave - 1), wid = tid / kWave, tq = nthr - 1 - tid;
+    const int nr = (maxx - x0 + 1 < rows_fit) ? maxx - x0 + 1 : rows_fit;
+    const int band_cells = __mul24(nr, bw), ng = band_cells >> 3;
+    const bool clip = nr != bh;
+    if (x0 != minx) {  // (a further band: the LDS state of the previous one is cleared)
+      __syncthreads();
+      uint4* t4 = reinterpret_cast<uint4*>(tile);
+      for (int t = tid; t < tile_cap / 4; t += nthr) t4[t] = uint4{0u, 0u, 0u, 0u};
+      for (int b = tid; b < Bv; b += nthr) ecnt[b] = 0;
+      for (int t = tid; t < kMapTilesMax; t += nthr) mt_touch[t] = 0;
+      if (tid == 0) { n_own = 0; n_need = 0; n_ovf = 0; }
+      __syncthreads();
+    }
+    auto cell_t = [&](int e) { return __mul24((e & 0xFFFF) - x0, bw) + ((e >> 16) - miny); };
+    auto in_band = [&](int e) { return (unsigned int)((e & 0xFFFF) - x0) < (unsigned int)nr; };
+    // F. flag the end-point cells; the beam that finds the flag clear opens the cell's slot
+    for (int b = tid; b < Bv; b += nthr) {
+      const int e = exy[b];
+      if (!in_band(e)) continue;
+      const int t = cell_t(e);
+      if (!(atomicOr(&tile[t], kFlag) & kFlag)) {
+        const int o = atomicAdd(&n_own, 1);
+        own[o] = b;
+        atomicOr(&tile[t], (unsigned int)o << 16);
+      }
+    }
+    __syncthreads();
+    PHASE_STAMP_W(0);
+    // 1. events and counters
+    for (int b = tid; b < Bv; b += nthr) { const int e = exy[b]; if (in_band(e)) record(tile[cell_t(e)], (b << 1) | 1); }
+    {
+      int S = Bv > 0 ? nthr / Bv : 1;  // segments per ray: as many as give every thread at most one task
+      S = S < 1 ? 1 : (S > 4 ? 4 : S);
+      const int G = (Bv + kWave - 1) / kWave;
+      const unsigned int band_bytes = 4u * (unsigned int)band_cells;
+      int n_first = 0;
+      for (int task = tid; task < kWave * G * S; task += nthr) {
+        const int tb = floor_div_small(task, S), sgm = task - tb * S;
+        const int b = __mul24(tb & (kWave - 1), G) + (tb >> 6);  // lanes of a wave take rays spread round the scan
+        if (b >= Bv) continue;
+        const int e = exy[b];
+        const RayP pr = ray_packed(rx, ry, e & 0xFFFF, e >> 16);
+        const int count = pr.dmaj, L = floor_div_small(count + S - 1, S);
+        int n = __mul24(sgm, L);
+        const int n1 = (n + L < count) ? n + L : count;
+        if (n >= n1) continue;
+        const int two_dmin = 2 * pr.dmin, two_dmaj = 2 * pr.dmaj;
+        const int a0 = __mul24(two_dmin, n) - pr.dmaj;
+        const int c0 = a0 > 0 ? floor_div_small(a0 + two_dmaj - 1, two_dmaj) : 0;  // operands < 2^24
+        int rem = a0 - __mul24(two_dmaj, c0 - 1);
+        const int sc = pr.neg ? -c0 : c0;
+        // byte offset of the segment's first cell in the band's array, and the byte steps along / across the ray
+        int at = 4 * (__mul24((pr.ymajor ? pr.xa + sc : pr.xa + n) - x0, bw) + ((pr.ymajor ? pr.ya + n : pr.ya + sc) - miny));
+        const int d_major = 4 * (pr.ymajor ? 1 : bw);
+        const int d_both = d_major + 4 * (pr.ymajor ? bw : 1) * (pr.neg ? -1 : 1);
+        auto advance = [&]() {
+          const int r2 = rem + two_dmin;
+          const bool side = r2 > two_dmaj;
+          rem = side ? r2 - two_dmaj : r2;
+          at += side ? d_both : d_major;
+        };
+        if (n == 0) { ++n_first; advance(); ++n; }  // position 0 is the robot's cell (or, for a reversed ray, the end point): counted below
+        char* const tile_b = reinterpret_cast<char*>(tile);
+        unsigned int seen = 0u;  // what the previous step's add returned: looked at while this step's add is in flight
+        if (!clip) {
+          for (; n < n1; ++n) {
+#if !(TBNAV_EXP & 4)
+            const unsigned int got = atomicAdd(reinterpret_cast<unsigned int*>(tile_b + at), 1u);
+#else
+            const unsigned int got = 0u;
+#endif
+            advance();
+            if (seen & kFlag) record(seen, b << 1);
+            seen = got;
+          }
+        } else {
+          for (; n < n1; ++n) {  // (the cells of the ray that lie in this band of rows)
+            unsigned int got = 0u;
+            if ((unsigned int)at < band_bytes) got = atomicAdd(reinterpret_cast<unsigned int*>(tile_b + at), 1u);
+            advance();
+            if (seen & kFlag) record(seen, b << 1);
+            seen = got;
+          }
+        }
+        if (seen & kFlag) record(seen, b << 1);
+      }
+      // the robot's own cell is the first free cell of every ray that has a free cell at all
+      n_first = wave_sum_dpp(n_first);
+      if (lane == 0 && n_first && (unsigned int)(rx - x0) < (unsigned int)nr) atomicAdd(&tile[__mul24(rx - x0, bw) + (ry - miny)], (unsigned int)n_first);
+    }
+    __syncthreads();  // every event is recorded
+    PHASE_STAMP_W(1);
+    // 2. one pass over the band, a group of 8 cells (two 128-bit LDS reads) at a time: mark the map tiles the scan writes;
+    //    slots that overflowed are listed on the way
+    for (int g = tid; g < ng; g += nthr) {
+      const uint4 a = tile4[2 * g], b = tile4[2 * g + 1];
+      if (a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) {
+        const int row = floor_div_small(g, gw);
+        mt_touch[map_tile(x0 + row, miny + 8 * (g - __mul24(row, gw)))] = 1;
+      }
+    }
+    const int n_cells = uni(n_own);
+    for (int o = tid; o < n_cells; o += nthr) {
+      const int e = exy[own[o]];
+      const bool robot_cell = (e & 0xFFFF) == rx && (e >> 16) == ry;  // an end point too: no events from the walk, replayed against every beam
+      if (robot_cell) ecnt[o] = kEv + 1;
+      if (robot_cell || ecnt[o] > kEv) { const int i = atomicAdd(&n_ovf, 1); if (i < kWave) ovf[i] = o; }
+    }
+    __syncthreads();
+    PHASE_STAMP_W(2);
+    // C. make the written tiles private to the particle (first write after a resample, or first touch of the area): ONE pop
+    //    of the free ring for all of them, then one wave per tile copies 8 KB.  Usually there is nothing to do.
+    if (tq < mtn && mt_touch[tq]) {
+      if (mt_priv[tq]) mt_slot[tq] = -1;
+      else mt_slot[tq] = atomicAdd(&n_need, 1);
+    }
+    __syncthreads();
+    if (n_need) {  // workgroup-uniform
+      if (tid == 0) { need_base = tile_pop_n(P, (unsigned int)n_need); if (need_base == ~0ull) bad = 1; }
+      __syncthreads();
+      if (bad) { if (tid == 0) atomicOr(&err[3], 8); return; }  // tile pool exhausted (nothing has been written if this is the first band)
+      for (int q = wid; q < mtn; q += nw) {
+        if (!mt_touch[q] || mt_slot[q] < 0) continue;
+        const int qi = floor_div_small(q, mty), qj = q - qi * mty;
+        const unsigned int nid = tile_at(P, need_base + (unsigned long long)mt_slot[q]);
+        tile_clone_into(P, tab, shed, (tx0 + qi) * M.TW + (ty0 + qj), nid, lane);
+        if (lane == 0) { mt_id[q] = nid; mt_priv[q] = 1; }
+      }
+      __syncthreads();
+    }
+    PHASE_STAMP_W(3);
+    // 3. requests first.  The band as PAIRS of cells (16 bytes of a map tile's row, two tile words): pair tid + i * nthr for
+    //    i < 4 — consecutive lanes take consecutive pairs, so a wave's request is whole cache lines
+    const int np = band_cells >> 1;
+    const uint2* tile2 = reinterpret_cast<const uint2*>(tile);
+    constexpr int kSl = 4;
+    double2 v[kSl];
+    auto pairs = [&](int first, auto&& fn) {  // fn(i, the pair's two tile words, cx, cy of its first cell), i < kSl
+      const int pi0 = first + tid;
+      int row = floor_div_small(2 * (pi0 < np ? pi0 : 0), bw), col = 2 * (pi0 < np ? pi0 : 0) - __mul24(row, bw);  // cell index < 2^16, bw < 2^8
+#pragma unroll
+      for (int i = 0; i < kSl; ++i) {
+        const int pi = pi0 + i * nthr;
+        uint2 w = uint2{0u, 0u};
+        if (pi < np) w = tile2[pi];
+        fn(i, w, x0 + row, miny + col);
+        row += step_r; col += step_c;
+        if (col >= bw) { col -= bw; ++row; }
+      }
+    };
+#if !(TBNAV_EXP & 8)
+    pairs(0, [&](int i, uint2 w, int cx, int cy) { v[i] = (w.x | w.y) ? *reinterpret_cast<const double2*>(cell_ptr(cx, cy)) : double2{0.0, 0.0}; });
+#endif
+    auto finish_end = [&](int slot, int cx, int cy, double v0o, double vv) {
+      val_e[slot] = vv;
+      const bool was = v0o >= c.cut_occ, now = vv >= c.cut_occ;
+      if (was != now) toggled(cx, cy, now);
+    };
+#if !(TBNAV_EXP & 16)
+    // 3a. end-point cells whose slot holds every event: one lane each, the events sorted by beam in registers (a
+    //     19-comparator network on the 8 sixteen-bit entries; an empty entry sorts last) and applied in that order
+    for (int o = tid; o < n_cells; o += nthr) {
+      const int ne = ecnt[o];
+      if (ne > kEv) continue;
+      const int e = exy[own[o]], cx = e & 0xFFFF, cy = e >> 16;
+      const double v0o = *cell_ptr(cx, cy);
+      // the events in beam order without sorting: every beam that reaches the cell lies within a few beams of the slot's
+      // own beam b0, so bit (beam - b0 + 32) of a 64-bit mask per kind orders them (checked per event; a stray one sends
+      // the slot to the exhaustive path).  Beam indices are circular: the bits are walked from the one that stands for the
+      // lowest ABSOLUTE beam index.
+      const uint4 raw = *reinterpret_cast<const uint4*>(ev + o * kEv);
+      const unsigned int w4[4] = {raw.x, raw.y, raw.z, raw.w};
+      const int base = own[o] - 32;
+      unsigned long long m_free = 0ull, m_occ = 0ull;
+      bool stray = false;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const unsigned int k = (q & 1) ? (w4[q >> 1] >> 16) : (w4[q >> 1] & 0xFFFFu);
+        int d = (int)(k >> 1) - base;
+        d += d < 0 ? Bv : 0; d -= d >= Bv ? Bv : 0;  // circular distance from base, in [0, Bv)
+        const bool valid = q < ne;
+        stray |= valid && d > 63;
+        const unsigned long long bit = valid ? 1ull << (d & 63) : 0ull;
+        if (k & 1u) m_occ |= bit; else m_free |= bit;
+      }
+      // absolute beam of bit d is base + d (mod Bv): bits from d0 = (base < 0 ? -base : (base + 63 >= Bv ? Bv - base : 0)) up are
+      // the low absolute indices when the window wraps
+      int d0 = 0;
+      if (base < 0) d0 = -base; else if (base + 63 >= Bv) d0 = Bv - base;
+      d0 = d0 > 63 ? 0 : d0;
+      double vv = v0o;
+      if (!stray) {
+#pragma unroll 1
+        for (int part = 0; part < 2; ++part) {
+          const unsigned long long keep = part == 0 ? ~0ull << d0 : ~(~0ull << d0);
+          unsigned long long m = (m_free | m_occ) & keep;
+          while (m) {
+            const int bit = __ffsll((long long)m) - 1;
+            vv += ((m_occ >> bit) & 1ull) ? c.d_occ : c.d_free;
+            m &= m - 1;
+          }
+        }
+      } else {  // (never seen: an event more than 31 beams from the slot's own) selection by ascending beam from LDS
+        int last = -1;
+        for (int i = 0; i < ne; ++i) {
+          int best = 0x10000;
+          for (int j = 0; j < ne; ++j) { const int k = ev[o * kEv + j]; if (k > last && k < best) best = k; }
+          vv += (best & 1) ? c.d_occ : c.d_free;
+          last = best;
+        }
+      }
+      ++n_ends;
+      finish_end(o, cx, cy, v0o, vv);
+    }
+    // 3b. overflowed slots: one wave per cell.  Lanes test beams q = 64*i + lane against the cell (is it q's end point /
+    //     one of q's free cells); the two ballots are the cell's update sequence for those 64 beams, replayed in bit (=
+    //     beam) order.  Pre-filter: a Bresenham cell lies within one cell of the line robot -> end point.
+    {
+      const int n_over = uni(n_ovf);
+      const int trips = (Bv + kWave - 1) / kWave;
+      for (int i0 = wid; i0 < (n_over <= kWave ? n_over : n_cells); i0 += nw) {
+        const int o = n_over <= kWave ? ovf[i0] : i0;  // (more overflowed slots than the list holds: scan them all)
+        if (ecnt[o] <= kEv) continue;
+        const int eo = exy[own[o]], cx = eo & 0xFFFF, cy = eo >> 16;
+        const double v0o = *cell_ptr(cx, cy);
+        double vv = v0o;
+        const int ux = cx - rx, uy = cy - ry;
+        for (int i = 0; i < trips; ++i) {
+          const int q = i * kWave + lane;
+          bool is_end = false, hit = false;
+          if (q < Bv) {
+            const int eq = exy[q], qx = eq & 0xFFFF, qy = eq >> 16;
+            is_end = eq == eo;  // the end point is never one of its own ray's free cells
+            const int dx = qx - rx, dy = qy - ry;
+            const double cr = (double)(ux * dy - uy * dx), l2 = (double)(dx * dx + dy * dy);
+            if (!is_end && cr * cr <= l2) hit = on_ray_packed(rx, ry, qx, qy, cx, cy);
+          }
+          const unsigned long long occm = __ballot(is_end), freem = __ballot(hit);
+          unsigned long long m = occm | freem;
+          while (m) {
+            const int bit = __ffsll((long long)m) - 1;
+            vv += ((occm >> bit) & 1ull) ? c.d_occ : c.d_free;
+            m &= m - 1;
+          }
+        }
+        if (lane == 0) { ++n_ends; finish_end(o, cx, cy, v0o, vv); }
+      }
+    }
+    // 3h. the cells round the robot: every ray starts there, so they collect tens to hundreds of adds — one long dependent
+    //     chain each.  They get a lane of their own in the last wave (which has no end-point cell to replay), are then
+    //     flagged like end-point cells, and their group's owner takes the value from val_e.
+    if (wid == nw - 1 && lane < kHotSide * kHotSide) {
+      const int hi = floor_div_small(lane, kHotSide), hx = rx - kHotSide / 2 + hi, hy = ry - kHotSide / 2 + (lane - hi * kHotSide);
+      if ((unsigned int)(hx - x0) < (unsigned int)nr && hy >= miny && hy < miny + bw) {
+        const int t = __mul24(hx - x0, bw) + (hy - miny);
+        const unsigned int f = tile[t];
+        if (!(f & kFlag) && (int)(f & 0xFFFFu) >= kHotMin) {
+          const double v0o = *cell_ptr(hx, hy);
+          double vv = v0o;
+          const int cnq = (int)(f & 0xFFFFu);
+          int a = 0;
+          for (; a + 4 <= cnq; a += 4) { vv += c.d_free; vv += c.d_free; vv += c.d_free; vv += c.d_free; }
+          for (; a < cnq; ++a) vv += c.d_free;
+          tile[t] = kFlag | ((unsigned int)(Bv + lane) << 16);
+          ++n_distinct;
+          finish_end(Bv + lane, hx, hy, v0o, vv);
+        }
+      }
+    }
+#endif
+    __syncthreads();  // val_e is complete
+    PHASE_STAMP_W(4);
+    // 3c. the pairs: a plain cell adds its count, an end-point or hot cell takes the value worked out for it, an untouched one
+    //     keeps its own; the pair goes back as one 16-byte store (the tile is private to the particle and nobody else writes
+    //     these cells)
+#if !(TBNAV_EXP & 8)
+    for (int first = 0; first < np; first += kSl * nthr) {
+      if (first) pairs(first, [&](int i, uint2 w, int cx, int cy) { v[i] = (w.x | w.y) ? *reinterpret_cast<const double2*>(cell_ptr(cx, cy)) : double2{0.0, 0.0}; });
+      pairs(first, [&](int i, uint2 w, int cx, int cy) {
+        if (!(w.x | w.y)) return;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const unsigned int f = q ? w.y : w.x;
+          double& slot = q ? v[i].y : v[i].x;
+          if (f == 0u) continue;
+          if (f & kFlag) { slot = val_e[(f >> 16) & 0x7FFFu]; continue; }
+          ++n_distinct;
+          const double old = slot;
+          double nv = old;
+          int a = 0;
+#if TBNAV_EXP & 1
+          const int cnq = 1;
+#else
+          const int cnq = (int)(f & 0xFFFFu);
+#endif
+          for (; a + 4 <= cnq; a += 4) { nv += c.d_free; nv += c.d_free; nv += c.d_free; nv += c.d_free; }
+          for (; a < cnq; ++a) nv += c.d_free;
+          slot = nv;
+          const bool was = old >= c.cut_occ, now = nv >= c.cut_occ;
+          if (was != now) toggled(cx, cy + q, now);
+        }
+#if !(TBNAV_EXP & 32)
+        *reinterpret_cast<double2*>(cell_ptr(cx, cy)) = v[i];
+#endif
+      });
+    }
+#endif
+    PHASE_STAMP_W(5);
+  }
+  __syncthreads();
+  // the tile-row counts / occupied count of the particle (this workgroup owns them; nothing waits for the adds)
+  int* rc = trow_occ + (size_t)p * M.TW;
+  for (int r = tid; r <= (maxx >> kTSh) - tx0; r += nthr) if (rc_delta[r]) atomicAdd(&rc[tx0 + r], rc_delta[r]);
+  if (tid == 0 && nocc_delta) atomicAdd(&n_occ[p], nocc_delta);
+  if (touched) {  // measurement hook (tbnav_rbpf_scan_counts): [0] += cell updates (free adds + end points), [1] += distinct cells written
+    __shared__ int cnt_upd, cnt_dis;
+    if (tid == 0) { cnt_upd = 0; cnt_dis = 0; }
+    __syncthreads();
+    int n_upd = 0;
+    for (int b = tid; b < Bv; b += nthr) {
+      const int e = exy[b], dx = (e & 0xFFFF) - rx, dy = (e >> 16) - ry;
+      n_upd += max(dx < 0 ? -dx : dx, dy < 0 ? -dy : dy) + 1;  // free cells of the ray (its Chebyshev length) + the end point
+    }
+    n_upd = wave_sum_i(n_upd); n_distinct = wave_sum_i(n_distinct + n_ends);
+    if (lane == 0) { atomicAdd(&cnt_upd, n_upd); atomicAdd(&cnt_dis, n_distinct); }
+    __syncthreads();
+    if (tid == 0) { atomicAdd(&touched[0], (unsigned long long)cnt_upd); atomicAdd(&touched[1], (unsigned long long)cnt_dis); }
+  }
+#ifdef TBNAV_PHASE_PROF
+  if (tid == 0) { atomicAdd(&g_phase_w[15], 1ull); }
+#endif
+}
+
 // The exact-transform kernels below (stored-field modes, on-demand fields) work on dense bitmap rows and per-row
 // counts; this rebuilds them from the tiles for particles [p0, p0 + gridDim.y).  grid (rows/4, count), 256 threads:
 // one wave per map row, lane w assembles the row's u64 word w.
@@ -2224,7 +2745,8 @@ struct tbnav_rbpf {
   double* d_score = nullptr;   // [N]
   bool timing = false;         // record HIP events round the kernels (tbnav_rbpf_set_timing): each costs device time, so off by default
   int tile_cap = 0;            // cells of the raycast LDS tile (0 = use the beam-ordered kernel)
-  int raycast_threads = 0;     // block size of the tile raycast: 0 = chosen per scan from its LDS footprint (TBNAV_RBPF_OPT_RAYCAST_THREADS)
+  int raycast_threads = 0;     // block size of the tile raycast: 0 = 1024 (TBNAV_RBPF_OPT_RAYCAST_THREADS)
+  int raycast_form = 0;        // 0 = box counters (rbpf_raycast_box), 1 = event slots (rbpf_raycast_tile) (TBNAV_RBPF_OPT_RAYCAST_FORM)
   double* d_sens = nullptr;    // [N][4] sensor transform (X, Y, sin, cos) of each particle's new pose, left by the proposal kernel
   uint64_t seed = 0x5EEDull, scan_index = 0;  // device noise source (normals == NULL)
   bool full_edt = false;       // distance-field mode 0 (TBNAV_RBPF_DF=full): whole-map transform after every map update
@@ -2552,6 +3074,32 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens)
   // measured at cfg3 (N = 1000 / 4000): 1024 threads x 2 per CU 69.5 / 266 us; 512 threads x 4 per CU (10-bit form, 37 KB of
   // LDS) 81 / 355 us; 256 threads 113 / 391 us — with 32 waves resident either way, fewer and larger workgroups win
   if (nt == 0) nt = 1024;
+  // rbpf_raycast_box: one u32 per cell of the box, the box padded to whole groups of 8 cells along y
+  long cap_win = 0;
+  if (h->tile_cap > 0) {
+    // every end point lies within `reach` of the robot's position: at most floor(2 reach / res) + 2 rows or columns (+1 spare);
+    // along y the box is padded to whole groups of 8 wherever it starts
+    const double reach = c.rmax + std::hypot(h->p.Trs[1], h->p.Trs[2]);
+    const long side = (long)std::floor(2.0 * reach / h->p.resolution) + 3;
+    cap_win = side * ((side + 14) & ~7L);
+    // ... but no more than lets TWO workgroups share a CU's 160 KB (the kernel works a larger box through in bands of rows;
+    // at least one padded row must fit)
+    const long cap_fit = ((78L * 1024 - (long)box_lds_bytes(0, (size_t)bvn) - 1536) / 4) & ~7L;
+    if (cap_win > cap_fit) cap_win = std::max(cap_fit, (side + 14) & ~7L);
+  }
+  const size_t lds_win = box_lds_bytes((size_t)cap_win, (size_t)bvn);
+  if (cap_win > 0 && !h->ref_field && c.Bv < 32768 && h->raycast_form == 0 && nt >= 512 && lds_win <= (size_t)kMaxLds - 2048) {
+    // default: box counters (rbpf_raycast_box)
+    unsigned long long* touched = h->count_touched ? h->d_touched : nullptr;
+    if (nt == 512)
+      hipLaunchKernelGGL((rbpf_raycast_box<512>), dim3(count), dim3(512), lds_win, st, c, h->pool, M, h->d_beams, sp.pose, sens,
+                         h->d_trow[h->cur], h->d_nocc[h->cur], h->d_err, (int)cap_win, touched);
+    else
+      hipLaunchKernelGGL((rbpf_raycast_box<1024>), dim3(count), dim3(1024), lds_win, st, c, h->pool, M, h->d_beams, sp.pose, sens,
+                         h->d_trow[h->cur], h->d_nocc[h->cur], h->d_err, (int)cap_win, touched);
+    TBNAV_HIP(hipGetLastError());
+    return TBNAV_OK;
+  }
   const bool small = nt == 512 && small_ok;
   const size_t tile_lds = small ? lds10 : lds16;
   if (cap > 0 && !h->ref_field && c.Bv < 32768 && tile_lds <= (size_t)kMaxLds - 2048) {
@@ -2934,6 +3482,8 @@ int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf*
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_tile<512, 16, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 2048);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_tile<512, 10, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 2048);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_tile<1024, 16, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 2048);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_box<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 2048);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_box<512>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 2048);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 1024);
   // the proposal / scan-match kernels carry the scan, the per-sample data and the bitmap slice: more than the 64 KB
   // default for long scans or many samples
@@ -2982,6 +3532,12 @@ void tbnav_rbpf_destroy(tbnav_rbpf* h) {
                            "other cells %.1f | overflowed slots %.2f | end-point cells %.1f\n",
                    (double)ph[0] / ph[7], (double)ph[1] / ph[7], (double)ph[2] / ph[7], (double)ph[3] / ph[7], (double)ph[4] / ph[7],
                    (double)ph[5] / ph[7], (double)ph[6] / ph[7]);
+    unsigned long long pw[16];
+    if (hipMemcpyFromSymbol(pw, HIP_SYMBOL(g_phase_w), sizeof(pw)) == hipSuccess && pw[15])
+      std::fprintf(stderr, "[raycast_box phases, 10 ns ticks per workgroup] set-up + flags %.1f | events + walk %.1f | marks %.1f | "
+                           "private tiles %.1f | requests + end-point replay %.1f | groups %.1f | end-point cells %.1f\n",
+                   (double)pw[0] / pw[15], (double)pw[1] / pw[15], (double)pw[2] / pw[15], (double)pw[3] / pw[15], (double)pw[4] / pw[15],
+                   (double)pw[5] / pw[15], (double)pw[14] / pw[15]);
   }
 #endif
   if (!h) return;
@@ -3543,6 +4099,10 @@ int tbnav_rbpf_set_option(tbnav_rbpf* h, int32_t option, int32_t value) {
     case TBNAV_RBPF_OPT_RAYCAST_THREADS:
       if (value != 0 && value != 256 && value != 512 && value != 1024) return TBNAV_ERR_INVALID_ARG;
       h->raycast_threads = value;
+      return TBNAV_OK;
+    case TBNAV_RBPF_OPT_RAYCAST_FORM:
+      if (value != 0 && value != 1) return TBNAV_ERR_INVALID_ARG;
+      h->raycast_form = value;
       return TBNAV_OK;
     case TBNAV_RBPF_OPT_COUNT_CELLS:
       h->count_touched = value != 0;

@@ -118,18 +118,22 @@ def test_configs4_shard_10000_particles_2000x2000_1080_beams(gpu_pkg):
     pf.close()
 
 
-@pytest.mark.parametrize("variant", ["threads256", "threads512_10bit", "threads1024", "beam_ordered"])
+@pytest.mark.parametrize("variant", ["box512", "slots256", "slots512_10bit", "slots1024", "beam_ordered"])
 def test_raycast_kernel_variants_are_bit_exact(gpu_pkg, variant):
-    """Every form of the map update — the tile kernel with 256 / 512 (10-bit tile fields, 8-event slots) / 1024 threads,
-    and the beam-ordered kernel — must leave the oracle's GridMapper bits (the default alone is what the other tests
-    exercise).  Scans with close obstacles (many events per end-point cell: the overflow path) and a long corridor."""
+    """Every form of the map update — the box-counter kernel with 512 threads (1024 is the default: every other
+    test), the first tile kernel with 256 / 512 (10-bit tile fields, 8-event slots) / 1024 threads, and the
+    beam-ordered kernel — must leave the oracle's GridMapper bits.  Scans with close obstacles (many events per
+    end-point cell: the slot overflow path) and a long corridor."""
     from rtn_amd import capi
     N, k, n_scans = 24, 6, 4
     pf = _dev(gpu_pkg, N=N, k=k, map_min=-10.0, map_max=10.0)
     if variant == "beam_ordered":
         pf.setOption(capi.RBPF_OPT_RAYCAST_ORDERED, 1)
+    elif variant.startswith("slots"):
+        pf.setOption(capi.RBPF_OPT_RAYCAST_FORM, 1)
+        pf.setOption(capi.RBPF_OPT_RAYCAST_THREADS, int(variant[5:].split("_")[0]))
     else:
-        pf.setOption(capi.RBPF_OPT_RAYCAST_THREADS, int(variant[7:].split("_")[0]))
+        pf.setOption(capi.RBPF_OPT_RAYCAST_THREADS, int(variant[3:]))
     steps, poses = rc.trajectory(n_scans, inc=(0.05, 0.04, 0.03))
     rng = np.random.default_rng(12)
     scans = [orc.room_scan(poses[s], walls=(-0.4, 3.2, -0.35, 0.5), rng=rng) for s in range(n_scans)]  # a wall 7 cells away

@@ -1,4 +1,5 @@
-"""A/B of the tile raycast's workgroup size on the bench workload (BASELINE configs[2]): kernel time from HIP events."""
+"""A/B of the tile raycast's form (0 = box counters, 1 = the first tile kernel) and workgroup size on the bench
+workload (BASELINE configs[2]): kernel time from HIP events."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,9 +11,9 @@ from rtn_amd import capi
 from rtn_amd.rbpf import ParticleFilter, default_params
 steps, scans = bench_rbpf.workload(14)
 for N in (1000, 4000):
-    for nt in (0, 256, 512, 1024):
+    for form, nt in ((0, 0), (0, 512), (1, 1024), (1, 512), (1, 256)):
         pf = ParticleFilter(default_params(N=N, k=50, map_min=-10.0, map_max=10.0))
-        pf.setSeed(1); pf.setTiming(True); pf.setOption(capi.RBPF_OPT_RAYCAST_THREADS, nt)
+        pf.setSeed(1); pf.setTiming(True); pf.setOption(capi.RBPF_OPT_RAYCAST_FORM, form); pf.setOption(capi.RBPF_OPT_RAYCAST_THREADS, nt)
         acc, n = {}, 0
         for s, (prev, cur, t_icp, u) in enumerate(steps):
             pf.SLAM(scans[s], u, cur, prev, True, t_icp, None)
@@ -20,5 +21,5 @@ for N in (1000, 4000):
                 n += 1
                 for k_, v in pf.kernelMs().items():
                     acc[k_] = acc.get(k_, 0.0) + v
-        print(f"N={N} threads={nt}: raycast {acc['raycast'] / n * 1e3:.1f} us, propose {acc['propose'] / n * 1e3:.1f} us", flush=True)
+        print(f"N={N} form={form} threads={nt}: raycast {acc['raycast'] / n * 1e3:.1f} us, propose {acc['propose'] / n * 1e3:.1f} us", flush=True)
         pf.close()
