@@ -1675,9 +1675,17 @@ __device__ __forceinline__ bool on_ray_packed(int x0, int y0, int x1, int y1, in
 // ev u16[Bv][kBoxEv] | val_e f64[Bv + 64] | exy own ecnt i32[Bv]
 #ifdef TBNAV_PHASE_PROF
 __device__ unsigned long long g_phase_w[16];
+#endif
+#if defined(TBNAV_PHASE_PROF) && !defined(TBNAV_TRACE_ONLY)
 #define PHASE_STAMP_W(i) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_phase_w[i], now_ - t_prev_); t_prev_ = now_; } } while (0)
 #else
 #define PHASE_STAMP_W(i)
+#endif
+#ifdef TBNAV_PHASE_PROF
+__device__ unsigned long long g_trace[16][16];  // [wave][stamp] of ONE workgroup (blockIdx.x == 100): 10 ns ticks since its first stamp
+#define TRACE_W(i) do { if (blockIdx.x == 100 && (threadIdx.x & 63) == 0) g_trace[threadIdx.x >> 6][i] = wall_clock64(); } while (0)
+#else
+#define TRACE_W(i)
 #endif
 #ifndef TBNAV_EXP
 #define TBNAV_EXP 0  // development: -DTBNAV_EXP=<mask> removes parts of the kernel to time the rest (results are then wrong)
@@ -1708,6 +1716,8 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
   __shared__ int rc_delta[kBoxSideMax / kTS + 2];
   __shared__ int ovf[kWave];                    // slots whose event list overflowed (more than these: found by scanning)
   __shared__ double sh_pose[4];
+  __shared__ double robot_v0, robot_v;  // the robot's own cell: its log-odds before the scan / after the adds applied so far
+  __shared__ int robot_cnt, robot_left; // beams with a free cell (each adds l_free to the robot's cell once) / adds still to apply
   constexpr int nthr = NT, nw = NT / kWave;
   const int p = c.p0 + blockIdx.x, tid_k = threadIdx.x, tid = tid_k, lane = tid & (kWave - 1), wid = tid / kWave;
 #ifdef TBNAV_PHASE_PROF
@@ -1715,6 +1725,7 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
 #endif
   unsigned int* tab = M.table + (size_t)p * M.TT;
   unsigned int* shed = M.shed + (size_t)p * M.TT;
+  TRACE_W(0);
   if (wid == 0) {
     const double x = pose[p * 3 + 1], y = pose[p * 3 + 2];
     int rx0 = 0, ry0 = 0;
@@ -1732,7 +1743,7 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
     if (lane == 0) {
       sh_pose[0] = X; sh_pose[1] = Y; sh_pose[2] = st0; sh_pose[3] = ct0;
       bad = robot_ok ? 0 : 1; bx0 = bx1 = rx0; by0 = by1 = ry0; n_own = 0; srx = rx0; sry = ry0;
-      n_need = 0; nocc_delta = 0; n_ovf = 0;
+      n_need = 0; nocc_delta = 0; n_ovf = 0; robot_cnt = 0;
     }
   } else {
     uint4* t4 = reinterpret_cast<uint4*>(tile);
@@ -1742,9 +1753,11 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
     for (int t = tid - kWave; t < kBoxSideMax / kTS + 2; t += nthr - kWave) rc_delta[t] = 0;
   }
   __syncthreads();
+  TRACE_W(1);
   // (workgroup-uniform values read from LDS are moved to scalar registers: the kernel has 64 VGPRs to live in)
   auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
   const int rx = uni(srx), ry = uni(sry);
+  double robot_old = 0.0;
   {
     const double X = sh_pose[0], Y = sh_pose[1], st = sh_pose[2], ct = sh_pose[3];
     for (int b0 = wid * kWave; b0 < Bv; b0 += nthr) {
@@ -1756,26 +1769,53 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
         exy[b] = ci | (cj << 16);
       }
       const int lo_x = wave_min_dpp(ci), hi_x = wave_max_dpp(ci), lo_y = wave_min_dpp(cj), hi_y = wave_max_dpp(cj);
-      if (lane == 0) { atomicMin(&bx0, lo_x); atomicMax(&bx1, hi_x); atomicMin(&by0, lo_y); atomicMax(&by1, hi_y); }
+      const unsigned long long has_free = __ballot(b < Bv && (ci != rx || cj != ry));  // the ray has a free cell: its first is the robot's
+      if (lane == 0) {
+        atomicMin(&bx0, lo_x); atomicMax(&bx1, hi_x); atomicMin(&by0, lo_y); atomicMax(&by1, hi_y);
+        if (has_free) atomicAdd(&robot_cnt, __popcll(has_free));
+      }
+    }
+    // The robot's own cell takes one add per beam — hundreds of DEPENDENT adds, microseconds for one lane.  Its count is
+    // known as soon as the end points are, so lane 0 of the last wave (which walks no ray) fetches the cell now and works
+    // the chain off in pieces between the barriers that follow, out of everybody's way.
+    if (tid == nthr - kWave) {
+      const unsigned int rt = tab[(rx >> kTSh) * M.TW + (ry >> kTSh)];
+      robot_old = P.lo[(size_t)rt * kTileCells + in_tile(rx, ry)];  // (used after the barrier: nothing waits for it here)
     }
   }
   __syncthreads();
+  TRACE_W(2);
   if (bad) { if (tid == 0) atomicOr(&err[0], 1); return; }
+  auto robot_chain = [&](int most) {  // (lane 0 of the last wave) up to `most` more adds of the robot cell's chain
+    int left = robot_left;
+    if (left <= 0) return;
+    const int k = left < most ? left : most;
+    double vv = robot_v;
+    int a = 0;
+    for (; a + 4 <= k; a += 4) { vv += c.d_free; vv += c.d_free; vv += c.d_free; vv += c.d_free; }
+    for (; a < k; ++a) vv += c.d_free;
+    robot_v = vv; robot_left = left - k;
+  };
+  if (tid == nthr - kWave) { robot_v0 = robot_old; robot_v = robot_old; robot_left = robot_cnt; }
   const int minx = uni(bx0), maxx = uni(bx1), maxy = uni(by1);
-  const int miny = uni(by0) & ~7;                                   // the box starts on a multiple of 8 along y and
-  const int bw = ((maxy | 7) + 1) - miny, gw = bw >> 3;             // is whole groups wide: a group never straddles a map tile
+  const int miny = uni(by0) & ~1;                                   // the box starts on an even column and is an even number of
+  const int bw = ((maxy | 1) + 1) - miny;                           // columns wide: a PAIR of cells never straddles a row or a map tile
   const int bh = maxx - minx + 1;
   const int tx0 = minx >> kTSh, ty0 = miny >> kTSh, mty = (maxy >> kTSh) - ty0 + 1, mtn = ((maxx >> kTSh) - tx0 + 1) * mty;
   const int rows_fit = uni(floor_div_small(tile_cap, bw));          // rows of the box the LDS array holds at a time
   if (rows_fit < 1 || mtn > kMapTilesMax || bh > kBoxSideMax) { if (tid == 0) atomicOr(&err[3], 2); return; }  // cannot happen: see launch_raycast
   // the particle's table entries under the box, and the reference counts of the tiles they name (needed in phase C)
-  const int tq = nthr - 1 - tid;  // (the table work sits on the LAST threads: they have no ray segment to walk)
-  if (tq < mtn) {
+  // (the table work sits on the last threads of the LAST BUT ONE wave, which walks no ray — the last wave, which walks none
+  //  either, has the robot cell's chain to work on)
+  const int tq = nthr - kWave - 1 - tid;
+  unsigned int my_tab = 0u;
+  int my_ref = 0;
+  if (tq >= 0 && tq < mtn) {
     const int qi = floor_div_small(tq, mty), qj = tq - qi * mty;
-    const unsigned int my_tab = tab[(tx0 + qi) * M.TW + (ty0 + qj)];
-    mt_id[tq] = my_tab;
-    mt_priv[tq] = (my_tab != 0u && P.ref[my_tab] == 1) ? 1 : 0;
+    my_tab = tab[(tx0 + qi) * M.TW + (ty0 + qj)];
+    my_ref = my_tab ? P.ref[my_tab] : 0;
   }
+  if (tid == nthr - kWave) robot_chain(100);
   auto map_tile = [&](int cx, int cy) { return __mul24((cx >> kTSh) - tx0, mty) + ((cy >> kTSh) - ty0); };
   auto cell_ptr = [&](int cx, int cy) -> double* { return P.lo + (size_t)mt_id[map_tile(cx, cy)] * kTileCells + in_tile(cx, cy); };
   auto toggled = [&](int cx, int cy, bool now) {  // the cell crossed the occupied cut-off: its bit in the (private) tile, tile-row count, total
@@ -1788,7 +1828,6 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
     const int en = atomicAdd(&ecnt[o], 1);
     if (en < kEv) ev[o * kEv + en] = (unsigned short)what;
   };
-  const uint4* tile4 = reinterpret_cast<const uint4*>(tile);
   const int step_r = uni(floor_div_small(2 * nthr, bw)), step_c = 2 * nthr - step_r * bw;  // pair pi + nthr in (row, column) terms
   int n_distinct = 0, n_ends = 0;
   for (int x0 = minx; x0 <= maxx; x0 += rows_fit) {  // one band of rows at a time (one trip unless the box is larger than the LDS array)
@@ -1796,9 +1835,9 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
     //  would be spilled — the kernel has 64 VGPRs — and a spill reload between memory requests serialises them)
     int tid = tid_k;
     asm volatile("" : "+v"(tid));
-    const int lane = tid & (kWave - 1), wid = tid / kWave, tq = nthr - 1 - tid;
+    const int lane = tid & (kWave - 1), wid = tid / kWave, tq = nthr - kWave - 1 - tid;
     const int nr = (maxx - x0 + 1 < rows_fit) ? maxx - x0 + 1 : rows_fit;
-    const int band_cells = __mul24(nr, bw), ng = band_cells >> 3;
+    const int band_cells = __mul24(nr, bw);
     const bool clip = nr != bh;
     if (x0 != minx) {  // (a further band: the LDS state of the previous one is cleared)
       __syncthreads();
@@ -1816,16 +1855,29 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
       const int e = exy[b];
       if (!in_band(e)) continue;
       const int t = cell_t(e);
-      if (!(atomicOr(&tile[t], kFlag) & kFlag)) {
-        const int o = atomicAdd(&n_own, 1);
-        own[o] = b;
-        atomicOr(&tile[t], (unsigned int)o << 16);
+      const bool first = !(atomicOr(&tile[t], kFlag) & kFlag);
+      const unsigned long long fm = __ballot(first);  // (the lanes that open a slot take consecutive ones: one add per wave on the counter)
+      if (fm) {
+        const int leader = __ffsll((long long)fm) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&n_own, __popcll(fm));
+        base = __builtin_amdgcn_readlane(base, leader);
+        if (first) {
+          const int o = base + __popcll(fm & ((1ull << lane) - 1ull));
+          own[o] = b;
+          atomicOr(&tile[t], (unsigned int)o << 16);
+        }
       }
     }
+    TRACE_W(3);
     __syncthreads();
     PHASE_STAMP_W(0);
+    TRACE_W(4);
     // 1. events and counters
     for (int b = tid; b < Bv; b += nthr) { const int e = exy[b]; if (in_band(e)) record(tile[cell_t(e)], (b << 1) | 1); }
+    TRACE_W(5);
+    if (x0 == minx && tq >= 0 && tq < mtn) { mt_id[tq] = my_tab; mt_priv[tq] = (my_tab != 0u && my_ref == 1) ? 1 : 0; }
+    if (tid == nthr - kWave) robot_chain(clip ? 64 : 220);  // (the last wave walks no ray; the walk of a clipped band is shorter)
     {
       int S = Bv > 0 ? nthr / Bv : 1;  // segments per ray: as many as give every thread at most one task
       S = S < 1 ? 1 : (S > 4 ? 4 : S);
@@ -1886,49 +1938,15 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
       n_first = wave_sum_dpp(n_first);
       if (lane == 0 && n_first && (unsigned int)(rx - x0) < (unsigned int)nr) atomicAdd(&tile[__mul24(rx - x0, bw) + (ry - miny)], (unsigned int)n_first);
     }
+    TRACE_W(6);
     __syncthreads();  // every event is recorded
+    TRACE_W(7);
     PHASE_STAMP_W(1);
-    // 2. one pass over the band, a group of 8 cells (two 128-bit LDS reads) at a time: mark the map tiles the scan writes;
-    //    slots that overflowed are listed on the way
-    for (int g = tid; g < ng; g += nthr) {
-      const uint4 a = tile4[2 * g], b = tile4[2 * g + 1];
-      if (a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) {
-        const int row = floor_div_small(g, gw);
-        mt_touch[map_tile(x0 + row, miny + 8 * (g - __mul24(row, gw)))] = 1;
-      }
-    }
-    const int n_cells = uni(n_own);
-    for (int o = tid; o < n_cells; o += nthr) {
-      const int e = exy[own[o]];
-      const bool robot_cell = (e & 0xFFFF) == rx && (e >> 16) == ry;  // an end point too: no events from the walk, replayed against every beam
-      if (robot_cell) ecnt[o] = kEv + 1;
-      if (robot_cell || ecnt[o] > kEv) { const int i = atomicAdd(&n_ovf, 1); if (i < kWave) ovf[i] = o; }
-    }
-    __syncthreads();
-    PHASE_STAMP_W(2);
-    // C. make the written tiles private to the particle (first write after a resample, or first touch of the area): ONE pop
-    //    of the free ring for all of them, then one wave per tile copies 8 KB.  Usually there is nothing to do.
-    if (tq < mtn && mt_touch[tq]) {
-      if (mt_priv[tq]) mt_slot[tq] = -1;
-      else mt_slot[tq] = atomicAdd(&n_need, 1);
-    }
-    __syncthreads();
-    if (n_need) {  // workgroup-uniform
-      if (tid == 0) { need_base = tile_pop_n(P, (unsigned int)n_need); if (need_base == ~0ull) bad = 1; }
-      __syncthreads();
-      if (bad) { if (tid == 0) atomicOr(&err[3], 8); return; }  // tile pool exhausted (nothing has been written if this is the first band)
-      for (int q = wid; q < mtn; q += nw) {
-        if (!mt_touch[q] || mt_slot[q] < 0) continue;
-        const int qi = floor_div_small(q, mty), qj = q - qi * mty;
-        const unsigned int nid = tile_at(P, need_base + (unsigned long long)mt_slot[q]);
-        tile_clone_into(P, tab, shed, (tx0 + qi) * M.TW + (ty0 + qj), nid, lane);
-        if (lane == 0) { mt_id[q] = nid; mt_priv[q] = 1; }
-      }
-      __syncthreads();
-    }
-    PHASE_STAMP_W(3);
-    // 3. requests first.  The band as PAIRS of cells (16 bytes of a map tile's row, two tile words): pair tid + i * nthr for
-    //    i < 4 — consecutive lanes take consecutive pairs, so a wave's request is whole cache lines
+    // 2. requests and marks in one pass.  The band as PAIRS of cells (16 bytes of a map tile's row, two tile words): pair
+    //    tid + i * nthr for i < 4 — consecutive lanes take consecutive pairs, so a wave's request is whole cache lines.  A
+    //    counted or flagged pair marks its map tile as written and asks for its log-odds from whichever tile the particle's
+    //    table names NOW (shared, private or the zero tile hold the same values: the loads fly while the tiles are made
+    //    private).  Slots that overflowed are listed on the way.
     const int np = band_cells >> 1;
     const uint2* tile2 = reinterpret_cast<const uint2*>(tile);
     constexpr int kSl = 4;
@@ -1947,8 +1965,50 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
       }
     };
 #if !(TBNAV_EXP & 8)
-    pairs(0, [&](int i, uint2 w, int cx, int cy) { v[i] = (w.x | w.y) ? *reinterpret_cast<const double2*>(cell_ptr(cx, cy)) : double2{0.0, 0.0}; });
+    pairs(0, [&](int i, uint2 w, int cx, int cy) {
+      v[i] = double2{0.0, 0.0};
+      if (w.x | w.y) {
+        const int mt = map_tile(cx, cy);
+        mt_touch[mt] = 1;
+        v[i] = *reinterpret_cast<const double2*>(P.lo + (size_t)mt_id[mt] * kTileCells + in_tile(cx, cy));
+      }
+    });
+    for (int first = kSl * nthr; first < np; first += kSl * nthr)  // (bands of more than 8 * nthr cells: marks only, their loads follow)
+      pairs(first, [&](int, uint2 w, int cx, int cy) { if (w.x | w.y) mt_touch[map_tile(cx, cy)] = 1; });
 #endif
+    const int n_cells = uni(n_own);
+    for (int o = tid; o < n_cells; o += nthr) {
+      const int e = exy[own[o]];
+      const bool robot_cell = (e & 0xFFFF) == rx && (e >> 16) == ry;  // an end point too: no events from the walk, replayed against every beam
+      if (robot_cell) ecnt[o] = kEv + 1;
+      if (robot_cell || ecnt[o] > kEv) { const int i = atomicAdd(&n_ovf, 1); if (i < kWave) ovf[i] = o; }
+    }
+    TRACE_W(8);
+    __syncthreads();
+    PHASE_STAMP_W(2);
+    TRACE_W(9);
+    // C. make the written tiles private to the particle (first write after a resample, or first touch of the area): ONE pop
+    //    of the free ring for all of them, then one wave per tile copies 8 KB.  Usually there is nothing to do.
+    if (tq >= 0 && tq < mtn && mt_touch[tq]) {
+      if (mt_priv[tq]) mt_slot[tq] = -1;
+      else mt_slot[tq] = atomicAdd(&n_need, 1);
+    }
+    __syncthreads();
+    if (n_need) {  // workgroup-uniform
+      if (tid == 0) { need_base = tile_pop_n(P, (unsigned int)n_need); if (need_base == ~0ull) bad = 1; }
+      __syncthreads();
+      if (bad) { if (tid == 0) atomicOr(&err[3], 8); return; }  // tile pool exhausted (nothing has been written if this is the first band)
+      for (int q = wid; q < mtn; q += nw) {
+        if (!mt_touch[q] || mt_slot[q] < 0) continue;
+        const int qi = floor_div_small(q, mty), qj = q - qi * mty;
+        const unsigned int nid = tile_at(P, need_base + (unsigned long long)mt_slot[q]);
+        tile_clone_into(P, tab, shed, (tx0 + qi) * M.TW + (ty0 + qj), nid, lane);
+        if (lane == 0) { mt_id[q] = nid; mt_priv[q] = 1; }
+      }
+      __syncthreads();
+    }
+    PHASE_STAMP_W(3);
+    TRACE_W(10);
     auto finish_end = [&](int slot, int cx, int cy, double v0o, double vv) {
       val_e[slot] = vv;
       const bool was = v0o >= c.cut_occ, now = vv >= c.cut_occ;
@@ -2010,6 +2070,7 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
       ++n_ends;
       finish_end(o, cx, cy, v0o, vv);
     }
+    TRACE_W(11);
     // 3b. overflowed slots: one wave per cell.  Lanes test beams q = 64*i + lane against the cell (is it q's end point /
     //     one of q's free cells); the two ballots are the cell's update sequence for those 64 beams, replayed in bit (=
     //     beam) order.  Pre-filter: a Bresenham cell lies within one cell of the line robot -> end point.
@@ -2052,10 +2113,11 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
       if ((unsigned int)(hx - x0) < (unsigned int)nr && hy >= miny && hy < miny + bw) {
         const int t = __mul24(hx - x0, bw) + (hy - miny);
         const unsigned int f = tile[t];
-        if (!(f & kFlag) && (int)(f & 0xFFFFu) >= kHotMin) {
-          const double v0o = *cell_ptr(hx, hy);
-          double vv = v0o;
-          const int cnq = (int)(f & 0xFFFFu);
+        const bool robot_cell = hx == rx && hy == ry;  // its chain is under way: what is left of it runs here, beside the others
+        if (!(f & kFlag) && (robot_cell ? f != 0u : (int)(f & 0xFFFFu) >= kHotMin)) {
+          const double v0o = robot_cell ? robot_v0 : *cell_ptr(hx, hy);
+          double vv = robot_cell ? robot_v : v0o;
+          const int cnq = robot_cell ? robot_left : (int)(f & 0xFFFFu);
           int a = 0;
           for (; a + 4 <= cnq; a += 4) { vv += c.d_free; vv += c.d_free; vv += c.d_free; vv += c.d_free; }
           for (; a < cnq; ++a) vv += c.d_free;
@@ -2066,7 +2128,9 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
       }
     }
 #endif
+    TRACE_W(12);
     __syncthreads();  // val_e is complete
+    TRACE_W(13);
     PHASE_STAMP_W(4);
     // 3c. the pairs: a plain cell adds its count, an end-point or hot cell takes the value worked out for it, an untouched one
     //     keeps its own; the pair goes back as one 16-byte store (the tile is private to the particle and nobody else writes
@@ -2105,6 +2169,7 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
 #endif
     PHASE_STAMP_W(5);
   }
+  TRACE_W(14);
   __syncthreads();
   // the tile-row counts / occupied count of the particle (this workgroup owns them; nothing waits for the adds)
   int* rc = trow_occ + (size_t)p * M.TW;
@@ -3078,14 +3143,14 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens)
   long cap_win = 0;
   if (h->tile_cap > 0) {
     // every end point lies within `reach` of the robot's position: at most floor(2 reach / res) + 2 rows or columns (+1 spare);
-    // along y the box is padded to whole groups of 8 wherever it starts
+    // along y the box is padded to whole pairs of cells
     const double reach = c.rmax + std::hypot(h->p.Trs[1], h->p.Trs[2]);
     const long side = (long)std::floor(2.0 * reach / h->p.resolution) + 3;
-    cap_win = side * ((side + 14) & ~7L);
+    cap_win = (side * ((side + 2) & ~1L) + 7) & ~7L;
     // ... but no more than lets TWO workgroups share a CU's 160 KB (the kernel works a larger box through in bands of rows;
     // at least one padded row must fit)
     const long cap_fit = ((78L * 1024 - (long)box_lds_bytes(0, (size_t)bvn) - 1536) / 4) & ~7L;
-    if (cap_win > cap_fit) cap_win = std::max(cap_fit, (side + 14) & ~7L);
+    if (cap_win > cap_fit) cap_win = std::max(cap_fit, (side + 9) & ~7L);
   }
   const size_t lds_win = box_lds_bytes((size_t)cap_win, (size_t)bvn);
   if (cap_win > 0 && !h->ref_field && c.Bv < 32768 && h->raycast_form == 0 && nt >= 512 && lds_win <= (size_t)kMaxLds - 2048) {
@@ -3532,6 +3597,17 @@ void tbnav_rbpf_destroy(tbnav_rbpf* h) {
                            "other cells %.1f | overflowed slots %.2f | end-point cells %.1f\n",
                    (double)ph[0] / ph[7], (double)ph[1] / ph[7], (double)ph[2] / ph[7], (double)ph[3] / ph[7], (double)ph[4] / ph[7],
                    (double)ph[5] / ph[7], (double)ph[6] / ph[7]);
+    unsigned long long tr[16][16];
+    if (hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_trace), sizeof(tr)) == hipSuccess && tr[0][0]) {
+      std::fprintf(stderr, "[raycast_box trace of workgroup 100, us since its first stamp; columns: entry, pose barrier, end-point barrier, flags, flag barrier, own events, walk, walk barrier, requests, barrier, tiles private, replay, overflow+hot, barrier, stores]\n");
+      unsigned long long t0 = ~0ull;
+      for (int w = 0; w < 16; ++w) if (tr[w][0] && tr[w][0] < t0) t0 = tr[w][0];
+      for (int w = 0; w < 16; ++w) {
+        std::fprintf(stderr, "  wave %2d:", w);
+        for (int i = 0; i < 15; ++i) std::fprintf(stderr, " %5.2f", tr[w][i] ? (double)(tr[w][i] - t0) * 0.01 : -1.0);
+        std::fprintf(stderr, "\n");
+      }
+    }
     unsigned long long pw[16];
     if (hipMemcpyFromSymbol(pw, HIP_SYMBOL(g_phase_w), sizeof(pw)) == hipSuccess && pw[15])
       std::fprintf(stderr, "[raycast_box phases, 10 ns ticks per workgroup] set-up + flags %.1f | events + walk %.1f | marks %.1f | "
