@@ -151,7 +151,7 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
     # lookups read, its normals, and the per-stage outputs the C-ABI keeps (trace)
     slice_bytes = min(pf.xsize, 2 * (int(np.ceil(3.5 / 0.05)) + 2 + 48) + 1) * 4 * 8
     dev_alg_per = distinct_per * 16.0 + slice_bytes + (3 * k + 3) * 8 + (k * 5 + 17) * 8
-    traffic, traffic_src = pmc_traffic("rbpf_raycast_tile") if N == 1000 else (None, None)
+    traffic, traffic_src = pmc_traffic("rbpf_raycast_box") if N == 1000 else (None, None)
     out = {
         "metric": "RBPF particle-updates/s", "value": round(N / (ms_scan * 1e-3), 1), "unit": "particle-updates/s",
         "config": {"workload": f"RBPF SLAM N={N}, k={k}, {Bv} valid beams of 360, {pf.xsize}x{pf.ysize} @0.05 m, ICP-ok branch "
@@ -171,7 +171,7 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
         "options": {"scan_matching": {"value": round(N / (t_sm / n_sm), 1), "ms_per_scan": round(t_sm / n_sm * 1e3, 4),
                                       "note": "per-particle hill climbing on the likelihood field before sampling (not the reference)"}},
         "distance_field_mode": "query",
-        "roofline": {"bound": "hbm", "kernel": "rbpf_raycast_tile (log-odds update)",
+        "roofline": {"bound": "hbm", "kernel": "rbpf_raycast_box (log-odds update)",
                      # SURVEY.md 8-d's algorithmic bytes of this kernel's share of a particle-update: (C_free + Bv) x 16 B, one
                      # read-modify-write per (beam, cell) touch as the reference's loop performs them — with C_free + Bv COUNTED
                      # on the device for this very workload, not assumed

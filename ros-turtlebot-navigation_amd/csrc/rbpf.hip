@@ -1661,17 +1661,23 @@ __device__ __forceinline__ bool on_ray_packed(int x0, int y0, int x1, int y1, in
 //     for it: the value that comes back is looked at one step later, and only if it carries the flag does the lane
 //     record "beam b, free" in that cell's slot (a few percent of the steps); every beam records "beam b, occupied" in
 //     its own end point's slot;
-//  2. one pass over the box, a group of 8 cells at a time, marks the map tiles the scan writes; they are made private to
-//     the particle (usually they already are);
-//  3. the read-modify-write: each thread requests its group (64 contiguous bytes of one map tile); meanwhile one lane
-//     per end-point cell replays its slot in beam order (an overflowed slot: a whole wave tests the cell against every
-//     beam), and the cells round the robot — hundreds of sequential adds each: every ray starts there — get a lane of
-//     their own in an otherwise idle wave; both hand their result to the group's owner through LDS.  A plain cell adds
-//     its count of l_free (same addend each time, so the order among the adds is immaterial); the group goes back as
-//     whole 16-byte stores.
-// The LDS array holds as many rows of the box as fit (tile_cap words); a box with more rows (a long-range scan seen
-// from a rotated pose) is worked through in bands of rows, every phase once per band with the rays clipped to the band.
-// LDS: tile u32[tile_cap] (rows padded to whole groups of 8 cells along y: group g = words 8g .. 8g+7) |
+//  2. one pass over the box, a PAIR of cells (16 bytes of a map tile's row) per lane and consecutive pairs in consecutive
+//     lanes — whole cache lines per wave: a counted or flagged pair marks its map tile as written and requests its log-odds
+//     from whichever tile the particle's table names now (shared, private or the zero tile hold the same values); the
+//     written tiles are then made private to the particle (usually they already are) while the loads are in flight;
+//  3. one lane per end-point cell replays its slot in beam order — bit (beam - own beam + 32) of a 64-bit mask per kind
+//     orders the events without sorting; an overflowed slot: a whole wave tests the cell against every beam — and the
+//     cells round the robot, tens to hundreds of DEPENDENT adds each because every ray starts there, get a lane of their
+//     own in the last wave, which walks no ray (the robot's own cell, one add per beam, is started right after the end
+//     points are known and worked off in pieces between the barriers); both hand their result over through LDS;
+//  4. the pairs: a plain cell adds its count of l_free (same addend each time, so the order among the adds is
+//     immaterial), an end-point or hot cell takes the value worked out for it; the pair goes back as one 16-byte store.
+// The LDS array holds as many rows of the box as fit (tile_cap words: the host keeps a workgroup under half of the CU's
+// 160 KB so that two are resident); a box with more rows (a long-range scan seen from a rotated pose) is worked through in
+// bands of rows, every phase once per band with the rays clipped to the band.
+// What bounds it (per-wave trace): instruction issue — ~28 k wave-instructions per particle through
+// 16 waves on 4 SIMDs between 9 barriers; memory traffic is the distinct cells once each way.
+// LDS: tile u32[tile_cap] (rows padded to an even number of columns: pair i = words 2i, 2i+1) |
 // ev u16[Bv][kBoxEv] | val_e f64[Bv + 64] | exy own ecnt i32[Bv]
 #ifdef TBNAV_PHASE_PROF
 __device__ unsigned long long g_phase_w[16];
@@ -3610,8 +3616,8 @@ void tbnav_rbpf_destroy(tbnav_rbpf* h) {
     }
     unsigned long long pw[16];
     if (hipMemcpyFromSymbol(pw, HIP_SYMBOL(g_phase_w), sizeof(pw)) == hipSuccess && pw[15])
-      std::fprintf(stderr, "[raycast_box phases, 10 ns ticks per workgroup] set-up + flags %.1f | events + walk %.1f | marks %.1f | "
-                           "private tiles %.1f | requests + end-point replay %.1f | groups %.1f | end-point cells %.1f\n",
+      std::fprintf(stderr, "[raycast_box phases, 10 ns ticks per workgroup] set-up + flags %.1f | events + walk %.1f | requests + marks %.1f | "
+                           "private tiles %.1f | end-point replay + hot cells %.1f | pairs %.1f | (unused) %.1f\n",
                    (double)pw[0] / pw[15], (double)pw[1] / pw[15], (double)pw[2] / pw[15], (double)pw[3] / pw[15], (double)pw[4] / pw[15],
                    (double)pw[5] / pw[15], (double)pw[14] / pw[15]);
   }
