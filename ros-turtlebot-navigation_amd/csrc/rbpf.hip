@@ -30,6 +30,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "common.hpp"
@@ -1917,28 +1918,28 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
         };
         if (n == 0) { ++n_first; advance(); ++n; }  // position 0 is the robot's cell (or, for a reversed ray, the end point): counted below
         char* const tile_b = reinterpret_cast<char*>(tile);
-        unsigned int seen = 0u;  // what the previous step's add returned: looked at while this step's add is in flight
-        if (!clip) {
-          for (; n < n1; ++n) {
-#if !(TBNAV_EXP & 4)
-            const unsigned int got = atomicAdd(reinterpret_cast<unsigned int*>(tile_b + at), 1u);
+        // What an add returns is looked at TWO steps later, while the next two adds are in flight: three registers take turns
+        // (no register is copied at the top of the loop, which would wait for the add just issued), so the walk never waits
+        // for LDS unless it has an event to record.
+        unsigned int r0 = 0u, r1 = 0u, r2 = 0u;
+        auto look = [&](unsigned int& old) { if (old & kFlag) record(old, b << 1); old = 0u; };
+        auto step = [&](auto clipped, unsigned int& fresh, unsigned int& old) {
+#if TBNAV_EXP & 4
+          fresh = 0u;
 #else
-            const unsigned int got = 0u;
+          if (!decltype(clipped)::value || (unsigned int)at < band_bytes) fresh = atomicAdd(reinterpret_cast<unsigned int*>(tile_b + at), 1u);  // (clipped: the cells of the ray in this band of rows)
 #endif
-            advance();
-            if (seen & kFlag) record(seen, b << 1);
-            seen = got;
-          }
-        } else {
-          for (; n < n1; ++n) {  // (the cells of the ray that lie in this band of rows)
-            unsigned int got = 0u;
-            if ((unsigned int)at < band_bytes) got = atomicAdd(reinterpret_cast<unsigned int*>(tile_b + at), 1u);
-            advance();
-            if (seen & kFlag) record(seen, b << 1);
-            seen = got;
-          }
-        }
-        if (seen & kFlag) record(seen, b << 1);
+          advance();
+          look(old);
+        };
+        auto walk = [&](auto clipped) {
+          int m = n1 - n;
+          for (; m >= 3; m -= 3) { step(clipped, r0, r1); step(clipped, r1, r2); step(clipped, r2, r0); }
+          if (m >= 1) step(clipped, r0, r1);
+          if (m >= 2) step(clipped, r1, r2);
+        };
+        if (clip) walk(std::true_type{}); else walk(std::false_type{});
+        look(r0); look(r1); look(r2);
       }
       // the robot's own cell is the first free cell of every ray that has a free cell at all
       n_first = wave_sum_dpp(n_first);
@@ -2121,9 +2122,10 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
         const unsigned int f = tile[t];
         const bool robot_cell = hx == rx && hy == ry;  // its chain is under way: what is left of it runs here, beside the others
         if (!(f & kFlag) && (robot_cell ? f != 0u : (int)(f & 0xFFFFu) >= kHotMin)) {
-          const double v0o = robot_cell ? robot_v0 : *cell_ptr(hx, hy);
-          double vv = robot_cell ? robot_v : v0o;
-          const int cnq = robot_cell ? robot_left : (int)(f & 0xFFFFu);
+          double v0o, vv;
+          int cnq;
+          if (robot_cell) { v0o = robot_v0; vv = robot_v; cnq = robot_left; }
+          else { v0o = *cell_ptr(hx, hy); vv = v0o; cnq = (int)(f & 0xFFFFu); }
           int a = 0;
           for (; a + 4 <= cnq; a += 4) { vv += c.d_free; vv += c.d_free; vv += c.d_free; vv += c.d_free; }
           for (; a < cnq; ++a) vv += c.d_free;
@@ -2146,30 +2148,35 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
       if (first) pairs(first, [&](int i, uint2 w, int cx, int cy) { v[i] = (w.x | w.y) ? *reinterpret_cast<const double2*>(cell_ptr(cx, cy)) : double2{0.0, 0.0}; });
       pairs(first, [&](int i, uint2 w, int cx, int cy) {
         if (!(w.x | w.y)) return;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const unsigned int f = q ? w.y : w.x;
-          double& slot = q ? v[i].y : v[i].x;
-          if (f == 0u) continue;
-          if (f & kFlag) { slot = val_e[(f >> 16) & 0x7FFFu]; continue; }
-          ++n_distinct;
-          const double old = slot;
-          double nv = old;
-          int a = 0;
+        // both cells of the pair in ONE loop (two independent chains of adds, predicated on each cell's count): a few
+        // straight-line instructions instead of a nest of divergent branches and loops per cell
+        const bool plain0 = w.x != 0u && !(w.x & kFlag), plain1 = w.y != 0u && !(w.y & kFlag);
 #if TBNAV_EXP & 1
-          const int cnq = 1;
+        const int c0 = plain0 ? 1 : 0, c1 = plain1 ? 1 : 0;
 #else
-          const int cnq = (int)(f & 0xFFFFu);
+        const int c0 = plain0 ? (int)(w.x & 0xFFFFu) : 0, c1 = plain1 ? (int)(w.y & 0xFFFFu) : 0;
 #endif
-          for (; a + 4 <= cnq; a += 4) { nv += c.d_free; nv += c.d_free; nv += c.d_free; nv += c.d_free; }
-          for (; a < cnq; ++a) nv += c.d_free;
-          slot = nv;
-          const bool was = old >= c.cut_occ, now = nv >= c.cut_occ;
-          if (was != now) toggled(cx, cy + q, now);
+        const double o0 = v[i].x, o1 = v[i].y;
+        double n0 = o0, n1 = o1;
+        const int cm = c0 > c1 ? c0 : c1;
+        for (int a = 0; a < cm; ++a) {
+          const double t0 = n0 + c.d_free, t1 = n1 + c.d_free;
+          n0 = a < c0 ? t0 : n0;
+          n1 = a < c1 ? t1 : n1;
         }
+        if ((w.x | w.y) & kFlag) {  // an end-point or hot cell takes the value worked out for it
+          if (w.x & kFlag) n0 = val_e[(w.x >> 16) & 0x7FFFu];
+          if (w.y & kFlag) n1 = val_e[(w.y >> 16) & 0x7FFFu];
+        }
+        n_distinct += (plain0 ? 1 : 0) + (plain1 ? 1 : 0);
 #if !(TBNAV_EXP & 32)
-        *reinterpret_cast<double2*>(cell_ptr(cx, cy)) = v[i];
+        *reinterpret_cast<double2*>(cell_ptr(cx, cy)) = double2{n0, n1};
 #endif
+        const bool tog0 = plain0 && ((o0 >= c.cut_occ) != (n0 >= c.cut_occ)), tog1 = plain1 && ((o1 >= c.cut_occ) != (n1 >= c.cut_occ));
+        if (tog0 | tog1) {
+          if (tog0) toggled(cx, cy, n0 >= c.cut_occ);
+          if (tog1) toggled(cx, cy + 1, n1 >= c.cut_occ);
+        }
       });
     }
 #endif
