@@ -244,21 +244,26 @@ __device__ __forceinline__ double pdf_normal(double a, double b) {
   return sqrt_inv * exp(var);
 }
 
-__device__ __forceinline__ double wave_max_d(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
-  return v;
+// Wave-wide reductions of doubles without LDS round trips (__shfl_xor is ds_bpermute: six dependent LDS-latency steps per
+// reduction, two permutes each for a double): an inclusive scan inside each row of 16 lanes by DPP shifts, then the row
+// totals carried down the rows (row_bcast:15 / :31); lane 63 holds the result, which is handed to every lane.  A fixed
+// order of operations, the same on every call (the proposal kernel's sums and products are compared with the oracle at
+// 1e-9, not bit for bit).
+#define TBNAV_DPP_D(v, ident, ctrl, rmask)                                                                                      \
+  __hiloint2double(__builtin_amdgcn_update_dpp(__double2hiint(ident), __double2hiint(v), ctrl, rmask, 0xf, false),              \
+                   __builtin_amdgcn_update_dpp(__double2loint(ident), __double2loint(v), ctrl, rmask, 0xf, false))
+template <class Op> __device__ __forceinline__ double wave_reduce_dpp_d(double v, double ident, Op op) {
+  v = op(v, TBNAV_DPP_D(v, ident, 0x111, 0xf));  // row_shr:1
+  v = op(v, TBNAV_DPP_D(v, ident, 0x112, 0xf));  // row_shr:2
+  v = op(v, TBNAV_DPP_D(v, ident, 0x114, 0xf));  // row_shr:4
+  v = op(v, TBNAV_DPP_D(v, ident, 0x118, 0xf));  // row_shr:8
+  v = op(v, TBNAV_DPP_D(v, ident, 0x142, 0xa));  // row_bcast:15 into rows 1, 3
+  v = op(v, TBNAV_DPP_D(v, ident, 0x143, 0xc));  // row_bcast:31 into rows 2, 3
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-__device__ __forceinline__ double wave_prod(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v *= __shfl_xor(v, off, 64);
-  return v;
-}
+__device__ __forceinline__ double wave_max_d(double v) { return wave_reduce_dpp_d(v, -1.0e300, [](double a, double b) { return fmax(a, b); }); }
+__device__ __forceinline__ double wave_sum_d(double v) { return wave_reduce_dpp_d(v, 0.0, [](double a, double b) { return a + b; }); }
+__device__ __forceinline__ double wave_prod(double v) { return wave_reduce_dpp_d(v, 1.0, [](double a, double b) { return a * b; }); }
 
 // GridMapper::likelihoodFieldModel for ONE pose, evaluated by one wave (lanes stride the valid beams).
 // beams[b] = (r*cos a_b, r*sin a_b) in the sensor frame, built on the host exactly as
