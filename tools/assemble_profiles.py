@@ -1,0 +1,34 @@
+"""Builds profiles/r02_traffic_pmc.json, r02_sq_counters.json and r02_kernel_stats.md from what tools/profile_round.sh left in
+gpurun_out/ (run here after the GPU call has merged its files back)."""
+import json, os, shutil
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = lambda f: os.path.join(ROOT, "gpurun_out", f)  # noqa: E731
+P = lambda f: os.path.join(ROOT, "profiles", f)    # noqa: E731
+
+old = json.load(open(P("r02_traffic_pmc.json")))
+tags = {"mppi_K1024_T50": "mppi_small_rng", "mppi_K1024_T50_resident_noise": "mppi_small", "mppi_K65536_T100": "mppi_large",
+        "rbpf_N1000_k50_400x400": "rbpf"}
+out = {"_about": old["_about"], "commands": old["commands"] + ["python tools/assemble_profiles.py"], "workloads": {}}
+out["commands"] = sorted(set(out["commands"]), key=out["commands"].index)
+for key, tag in tags.items():
+    wl = json.load(open(G(f"pmc_summary_{tag}.json")))
+    for name, v in wl.items():
+        if name.startswith("mppi_rollout_fused"):
+            v["read_bytes"] = int(v["fetch_size_kb_raw"] * 1024)
+            v["hbm_bytes"] = v["read_bytes"] + v["write_bytes"]
+            v["note"] = "reads are 64-byte row segments (8 rollouts x 8 B per time step): FETCH_SIZE at face value, no x2"
+        if name.startswith("rbpf_raycast"):
+            v["note"] = ("average over 11 launches of which ONE is the scan after a forced resample (15 tiles x 8 KB cloned per particle: "
+                         "+123 MB written, +123 MB read in that launch); 16-byte accesses, whole cache lines per wave: the x2 read "
+                         "correction and the 1:1 write reading are uncalibrated for this pattern (MI355X_MICROARCH.md, HBM)")
+    out["workloads"][key] = wl
+json.dump(out, open(P("r02_traffic_pmc.json"), "w"), indent=1)
+
+olds = json.load(open(P("r02_sq_counters.json")))
+sq = {"_about": olds["_about"]}
+for key, tag in {"rbpf_N1000_k50_400x400": "rbpf", "mppi_K65536_T100": "mppi_large", "mppi_K1024_T50_device_noise": "mppi_small_rng"}.items():
+    sq[key] = json.load(open(G(f"sq_summary_{tag}.json")))
+json.dump(sq, open(P("r02_sq_counters.json"), "w"), indent=1)
+shutil.copy(G("r02_kernel_stats.md"), P("r02_kernel_stats.md"))
+shutil.copy(G("r02_bench_under_rocprof.json"), P("r02_bench_under_rocprof.json"))
+print("profiles/ refreshed")
