@@ -119,18 +119,37 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
     pf_k.close()
     kms = {key: v / max(n_k, 1) for key, v in kms.items()}
     kms_res = {key: v / max(n_kr, 1) for key, v in kms_res.items()}
-    # ---- headline pass
-    t_total, n_timed, resamples, scan_ms = 0.0, 0, 0, []
-    pf.setSeed(2026)
+    # ---- single-call pass: one tbnav_rbpf_slam call per scan from this (Python) harness — what round 1 and the first half
+    #      of round 2 reported; kept beside the headline to show what the harness costs
+    pf_s = mk()
+    pf_s.setSeed(2026)
+    t_single, n_single = 0.0, 0
     for s, (prev, cur, t_icp, u) in enumerate(steps):
         if s in RESAMPLE_AT:
-            _skew(pf, N)       # untimed: the filter's weights are made skewed, the timed call does the resampling
+            _skew(pf_s, N)
         t0 = time.perf_counter()
-        st = pf.SLAM(scans[s], u, cur, prev, True, t_icp, None)
+        pf_s.SLAM(scans[s], u, cur, prev, True, t_icp, None)
+        if s >= 2:
+            t_single += time.perf_counter() - t0; n_single += 1
+    pf_s.close()
+    # ---- headline pass: the logged run replayed through tbnav_rbpf_slam_batch (the same synchronous per-scan calls, made
+    #      from C), in stretches between the points where the weights are skewed (untimed) to force a resample
+    t_total, n_timed, resamples, scan_ms = 0.0, 0, 0, []
+    pf.setSeed(2026)
+    odom = np.array([steps[0][0]] + [st_[1] for st_ in steps], dtype=np.float64)
+    u_all = np.array([st_[3] for st_ in steps], dtype=np.float64)
+    ticp_all = np.array([st_[2] for st_ in steps], dtype=np.float64)
+    cuts = sorted(set([0, 2, n_scans] + [r for r in RESAMPLE_AT if r < n_scans]))
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        if lo in RESAMPLE_AT:
+            _skew(pf, N)       # untimed: the filter's weights are made skewed, the timed stretch's first call does the resampling
+        t0 = time.perf_counter()
+        sts = pf.SLAMBatch(np.stack(scans[lo:hi]), u_all[lo:hi], odom[lo:hi + 1], ticp_all[lo:hi])
         dt = time.perf_counter() - t0
-        if s >= 2:  # first two scans: empty maps / first-touch tile allocation
-            t_total += dt; n_timed += 1; scan_ms.append(round(dt * 1e3, 4))
-        resamples += st.resampled
+        if lo >= 2:  # first two scans: empty maps / first-touch tile allocation
+            t_total += dt; n_timed += hi - lo; scan_ms.append(round(dt / (hi - lo) * 1e3, 4))
+        resamples += sum(x.resampled for x in sts)
+        st = sts[-1]
     ms_scan = t_total / n_timed * 1e3
     cap, free, tile_bytes = pf.poolStats()
     Bv = int(st.n_valid_beams)
@@ -155,12 +174,14 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
     out = {
         "metric": "RBPF particle-updates/s", "value": round(N / (ms_scan * 1e-3), 1), "unit": "particle-updates/s",
         "config": {"workload": f"RBPF SLAM N={N}, k={k}, {Bv} valid beams of 360, {pf.xsize}x{pf.ysize} @0.05 m, ICP-ok branch "
-                               "(BASELINE configs[2])", "scans_timed": n_timed, "resamples": resamples,
+                               "(BASELINE configs[2])", "scans_timed": n_timed, "resamples": resamples, "entry_point": "tbnav_rbpf_slam_batch (synchronous per scan)",
                    "inputs": "standard normals drawn on the device (Philox); only the 1.4 KB scan is a host buffer",
                    "room": list(ROOM_BENCH)},
         "host_normals": {"value": round(N / (t_host / n_host), 1), "ms_per_scan": round(t_host / n_host * 1e3, 4),
                          "note": "parity mode: 1.2 MB/scan of reference-order normals copied H2D inside the call (PCIe-inclusive)"},
-        "ms_per_scan": round(ms_scan, 4), "scan_ms": scan_ms,
+        "ms_per_scan": round(ms_scan, 4), "scan_ms_by_stretch": scan_ms,
+        "single_calls_from_python": {"value": round(N / (t_single / n_single), 1), "ms_per_scan": round(t_single / n_single * 1e3, 4),
+                                     "note": "the same scans, one tbnav_rbpf_slam call each from this harness"},
         "device_ms_per_scan": round(dev_ms, 4),
         "device_only_updates_per_s": round(N / (dev_ms * 1e-3), 1),
         "kernel_ms": {key: round(v, 4) for key, v in kms.items()},

@@ -118,6 +118,13 @@ int tbnav_rbpf_get_normals(tbnav_rbpf* h, double* out, int64_t n);
 int tbnav_rbpf_slam(tbnav_rbpf* h, const float* scan, int32_t n_beams, const double u[3],
                     const double cur_odom[3], const double prev_odom[3], int32_t icp_ok,
                     const double T_icp[3], const double* normals, tbnav_rbpf_stats* out);
+/* Replay of a LOGGED run (what turtle_mapping_node.cpp:459-494 does per laser message, for n_scans messages in a row):
+ * scans [n_scans][n_beams]; u [n_scans][3]; odom [n_scans + 1][3] with odom[s] = prev, odom[s + 1] = cur of scan s;
+ * icp_ok [n_scans] or NULL (all 1); T_icp [n_scans][3]; noise drawn on the device; out [n_scans].  Exactly n_scans
+ * tbnav_rbpf_slam calls (each synchronous), without a trip through the caller's language per scan.  Stops at the
+ * first scan whose status is not TBNAV_OK and returns it. */
+int tbnav_rbpf_slam_batch(tbnav_rbpf* h, const float* scans, int32_t n_beams, int32_t n_scans, const double* u,
+                          const double* odom, const int32_t* icp_ok, const double* T_icp, tbnav_rbpf_stats* out);
 
 /* OPTION (not something the reference does): per-particle scan-to-map matching.  The reference
  * aligns scan to scan once per call with PCL ICP (cloud_alignment.cpp:37-223) and every particle samples round

@@ -2829,6 +2829,8 @@ struct tbnav_rbpf {
   bool timing = false;         // record HIP events round the kernels (tbnav_rbpf_set_timing): each costs device time, so off by default
   int tile_cap = 0;            // cells of the raycast LDS tile (0 = use the beam-ordered kernel)
   int raycast_threads = 0;     // block size of the tile raycast: 0 = 1024 (TBNAV_RBPF_OPT_RAYCAST_THREADS)
+  std::vector<double2> beam_cs;  // (cos, sin) of every beam's angle in the sensor frame, kept between scans
+  std::vector<double2> beams_tmp;
   int raycast_form = 0;        // 0 = box counters (rbpf_raycast_box), 1 = event slots (rbpf_raycast_tile) (TBNAV_RBPF_OPT_RAYCAST_FORM)
   double* d_sens = nullptr;    // [N][4] sensor transform (X, Y, sin, cos) of each particle's new pose, left by the proposal kernel
   uint64_t seed = 0x5EEDull, scan_index = 0;  // device noise source (normals == NULL)
@@ -2971,18 +2973,26 @@ int build_scan_consts(tbnav_rbpf* h, ScanC& c, const float* scan, int n_beams, c
   c.stride_normals = icp_ok ? 3 * h->k + 3 : 3;
   c.p0 = 0;
   // valid beams in the sensor frame, sensor_model.cpp:73-108 (float limits, double angle accumulation)
+  // (the angle of beam i does not depend on the scan: its cosine and sine — glibc's, in the reference's accumulation
+  //  order — are kept from one call to the next; 2 x 360 libm calls were a tenth of the host's time per scan)
+  if ((int)h->beam_cs.size() != n_beams) {
+    h->beam_cs.resize(n_beams);
+    double beam_angle = P.beam_min;
+    for (int i = 0; i < n_beams; ++i) {
+      h->beam_cs[i] = double2{std::cos(beam_angle), std::sin(beam_angle)};
+      beam_angle += P.beam_delta;
+      if (P.beam_max < 0.0 && beam_angle <= P.beam_max) beam_angle = P.beam_min;
+      else if (P.beam_max >= 0.0 && beam_angle >= P.beam_max) beam_angle = P.beam_min;
+    }
+  }
   beams.clear();
   c.rmax = 0.0;
-  double beam_angle = P.beam_min;
   for (int i = 0; i < n_beams; ++i) {
     const double range = scan[i];
     if (range >= P.range_min && range < P.range_max) {
-      beams.push_back(double2{range * std::cos(beam_angle), range * std::sin(beam_angle)});
+      beams.push_back(double2{range * h->beam_cs[i].x, range * h->beam_cs[i].y});
       c.rmax = std::max(c.rmax, range);
     }
-    beam_angle += P.beam_delta;
-    if (P.beam_max < 0.0 && beam_angle <= P.beam_max) beam_angle = P.beam_min;
-    else if (P.beam_max >= 0.0 && beam_angle >= P.beam_max) beam_angle = P.beam_min;
   }
   c.Bv = (int)beams.size();
   return TBNAV_OK;
@@ -3235,7 +3245,7 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
   hipStream_t st = h->stream;
   ++h->scans_done;
   ScanC c;
-  std::vector<double2> beams;
+  std::vector<double2>& beams = h->beams_tmp;  // (kept between calls: no allocation per scan)
   int rc = build_scan_consts(h, c, scan, n_beams, u, cur_odom, prev_odom, icp_ok, T_icp, beams);
   std::memset(out, 0, sizeof *out);
   if (rc != TBNAV_OK) { out->status = rc; return rc; }
@@ -3684,6 +3694,17 @@ int tbnav_rbpf_slam(tbnav_rbpf* h, const float* scan, int32_t n_beams, const dou
                     const double prev_odom[3], int32_t icp_ok, const double T_icp[3], const double* normals,
                     tbnav_rbpf_stats* out) {
   return slam_impl(h, scan, n_beams, u, cur_odom, prev_odom, icp_ok, T_icp, normals, out, false);
+}
+
+int tbnav_rbpf_slam_batch(tbnav_rbpf* h, const float* scans, int32_t n_beams, int32_t n_scans, const double* u, const double* odom,
+                          const int32_t* icp_ok, const double* T_icp, tbnav_rbpf_stats* out) {
+  if (!h || !scans || n_scans <= 0 || !u || !odom || !T_icp || !out) return TBNAV_ERR_INVALID_ARG;
+  for (int s = 0; s < n_scans; ++s) {
+    const int rc = slam_impl(h, scans + (size_t)s * n_beams, n_beams, u + 3 * s, odom + 3 * (s + 1), odom + 3 * s, icp_ok ? icp_ok[s] : 1,
+                             T_icp + 3 * s, nullptr, out + s, false);
+    if (rc != TBNAV_OK) return rc;
+  }
+  return TBNAV_OK;
 }
 
 int tbnav_rbpf_slam_local(tbnav_rbpf* h, const float* scan, int32_t n_beams, const double u[3], const double cur_odom[3],

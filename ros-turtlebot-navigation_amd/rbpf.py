@@ -92,6 +92,22 @@ class ParticleFilter:
             capi.check(rc, "tbnav_rbpf_slam")
         return st
 
+    def SLAMBatch(self, scans, u, odom, T_icp, icp_ok=None):
+        """Replay of a logged run (tbnav_rbpf_slam_batch): scans [n][n_beams], u [n][3], odom [n + 1][3] (odom[s] = prev,
+        odom[s + 1] = cur), T_icp [n][3]; device noise.  Returns the list of per-scan stats."""
+        scans = np.ascontiguousarray(scans, dtype=np.float32)
+        n, nb = scans.shape
+        u = np.ascontiguousarray(u, dtype=np.float64).reshape(n, 3)
+        odom = np.ascontiguousarray(odom, dtype=np.float64).reshape(n + 1, 3)
+        T_icp = np.ascontiguousarray(T_icp, dtype=np.float64).reshape(n, 3)
+        ok = None if icp_ok is None else np.ascontiguousarray(icp_ok, dtype=np.int32)
+        out = (capi.RbpfStats * n)()
+        rc = self._L.tbnav_rbpf_slam_batch(self._h, scans.ctypes.data, nb, n, u.ctypes.data, odom.ctypes.data,
+                                           None if ok is None else ok.ctypes.data, T_icp.ctypes.data, C.cast(out, C.c_void_p))
+        capi.check(rc, "tbnav_rbpf_slam_batch")
+        self.last_stats = out[n - 1]
+        return list(out)
+
     def setSeed(self, seed: int):
         capi.check(self._L.tbnav_rbpf_set_seed(self._h, seed), "set_seed")
 

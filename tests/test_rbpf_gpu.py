@@ -479,3 +479,29 @@ def test_device_map_export_matches_glibc_evaluation(gpu_pkg):
     # arg-max tie rule: strict '>', first wins; all-zero weights -> index 0
     pf.setParticles(w=np.array([0.4, 0.4, 0.2])); assert pf.getRobotState()[1] == 0
     pf.setParticles(w=np.array([0.0, 0.0, 0.0])); assert pf.getRobotState()[1] == 0
+
+
+def test_batch_replay_equals_one_call_per_scan(gpu_pkg):
+    """tbnav_rbpf_slam_batch is n tbnav_rbpf_slam calls made from C: same seed, same scans -> the same filter, bit for
+    bit (poses, weights, every map), and the same per-scan stats."""
+    N, k, n_scans = 64, 10, 6
+    steps, poses = rc.trajectory(n_scans, inc=(0.05, 0.04, 0.03))
+    rng = np.random.default_rng(21)
+    scans = np.stack([orc.room_scan(poses[s], walls=rc.ROOM_SMALL, rng=rng) for s in range(n_scans)])
+    odom = np.array([steps[0][0]] + [st[1] for st in steps], dtype=np.float64)
+    u = np.array([st[3] for st in steps], dtype=np.float64)
+    t_icp = np.array([st[2] for st in steps], dtype=np.float64)
+    a = _dev(gpu_pkg, N=N, k=k)
+    b = _dev(gpu_pkg, N=N, k=k)
+    a.setSeed(77); b.setSeed(77)
+    one = [a.SLAM(scans[s], steps[s][3], steps[s][1], steps[s][0], True, steps[s][2], None) for s in range(n_scans)]
+    many = b.SLAMBatch(scans[:2], u[:2], odom[:3], t_icp[:2]) + b.SLAMBatch(scans[2:], u[2:], odom[2:], t_icp[2:])
+    for x, y in zip(one, many):
+        assert (x.status, x.neff, x.resampled, x.n_valid_beams) == (y.status, y.neff, y.resampled, y.n_valid_beams)
+        assert x.sum_w == y.sum_w and x.sq_sum == y.sq_sum
+    pa, pb = a.particles(), b.particles()
+    for q in range(3):
+        assert np.array_equal(pa[q], pb[q])
+    for m in (0, 17, N - 1):
+        assert np.array_equal(a.logOdds(m), b.logOdds(m))
+    a.close(); b.close()
