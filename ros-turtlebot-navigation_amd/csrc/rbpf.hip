@@ -476,7 +476,11 @@ __device__ __forceinline__ void philox4x32_10(unsigned long long ctr, unsigned l
   }
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
-__global__ void rbpf_sample_normals(size_t n, unsigned long long seed, unsigned long long scan, double* __restrict__ out) {
+// (also carries the scan's beam table from pinned host memory to the device — n_copy entries, 0 = none: one launch and
+//  one dependent boundary fewer per scan than a separate copy)
+__global__ void rbpf_sample_normals(size_t n, unsigned long long seed, unsigned long long scan, double* __restrict__ out,
+                                    const double2* __restrict__ host_beams, double2* __restrict__ dev_beams, int n_copy) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_copy; i += gridDim.x * blockDim.x) dev_beams[i] = host_beams[i];
   const size_t pairs = (n + 1) / 2;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += (size_t)gridDim.x * blockDim.x) {
     unsigned int r[4];
@@ -2499,22 +2503,17 @@ constexpr int kNormChunk = 2048;
 // inherent; the loads are not part of it: the next eight values are fetched while the current eight are added.
 template <bool SQ>
 __device__ __forceinline__ double seq_sum(double acc, const double* w, int N) {
+  // 32 values per trip: sixteen 16-byte LDS reads issued together, then the 32 dependent adds and nothing else — a lone wave
+  // issues an instruction every four to five cycles, so every instruction that is not an add stretches the chain (the
+  // first version's register shuffling made it 13 ns per add)
+  const double2* w2 = reinterpret_cast<const double2*>(w);  // (w is 16-byte aligned LDS)
   int i = 0;
-  if (N >= 8) {
-    double a[8], b[8];
+  for (; i + 32 <= N; i += 32) {
+    double2 a[16];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) a[q] = w[q];
-    for (i = 0; i + 16 <= N; i += 8) {
+    for (int q = 0; q < 16; ++q) a[q] = w2[(i >> 1) + q];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) b[q] = w[i + 8 + q];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) acc += SQ ? a[q] * a[q] : a[q];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) a[q] = b[q];
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) acc += SQ ? a[q] * a[q] : a[q];
-    i += 8;
+    for (int q = 0; q < 16; ++q) { acc += SQ ? a[q].x * a[q].x : a[q].x; acc += SQ ? a[q].y * a[q].y : a[q].y; }
   }
   for (; i < N; ++i) acc += SQ ? w[i] * w[i] : w[i];
   return acc;
@@ -2523,7 +2522,7 @@ __device__ __forceinline__ double seq_sum(double acc, const double* w, int N) {
 __global__ __launch_bounds__(256) void rbpf_normalize(int N, const double* __restrict__ zp, const double* weight, double* weight_out,
                                                       double* __restrict__ cs, int* __restrict__ parent, NormOut* __restrict__ out) {
   const double z = *zp;  // the one standard normal of lowVarianceResampling (particle_filter.cpp:474)
-  __shared__ double w[kNormChunk], cl[kNormChunk];
+  __shared__ __attribute__((aligned(16))) double w[kNormChunk], cl[kNormChunk];
   __shared__ double s_acc;
   __shared__ int s_res;
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -2564,8 +2563,18 @@ __global__ __launch_bounds__(256) void rbpf_normalize(int N, const double* __res
     if (!one_chunk) for (int i = tid; i < n; i += nthr) w[i] = weight_out[base + i];  // (one chunk: w[] still holds them)
     __syncthreads();
     if (tid == 0) {
-      double c = s_acc;
-      for (int i = 0; i < n; ++i) { c += w[i]; cl[i] = c; }  // c = weight(0); c += weight(i), particle_filter.cpp:478,492
+      double c = s_acc;  // c = weight(0); c += weight(i), particle_filter.cpp:478,492
+      const double2* w2 = reinterpret_cast<const double2*>(w);
+      double2* c2 = reinterpret_cast<double2*>(cl);
+      int i = 0;
+      for (; i + 16 <= n; i += 16) {
+        double2 a[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] = w2[(i >> 1) + q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { double2 o; c += a[q].x; o.x = c; c += a[q].y; o.y = c; c2[(i >> 1) + q] = o; }
+      }
+      for (; i < n; ++i) { c += w[i]; cl[i] = c; }
       s_acc = c;
     }
     __syncthreads();
@@ -3220,7 +3229,7 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens)
 }
 
 // the scan's valid beams into d_beams (shared by slam_impl and the one-particle entry points)
-int upload_beams(tbnav_rbpf* h, const std::vector<double2>& beams, int n_beams, int Bv) {
+int upload_beams(tbnav_rbpf* h, const std::vector<double2>& beams, int n_beams, int Bv, bool stage_only = false) {
   if (n_beams > h->max_beams) {
     (void)hipFree(h->d_beams);
     (void)hipHostFree(h->h_beams);
@@ -3231,7 +3240,7 @@ int upload_beams(tbnav_rbpf* h, const std::vector<double2>& beams, int n_beams, 
   }
   if (Bv) {
     std::memcpy(h->h_beams, beams.data(), sizeof(double2) * Bv);
-    TBNAV_HIP(hipMemcpyAsync(h->d_beams, h->h_beams, sizeof(double2) * Bv, hipMemcpyHostToDevice, h->stream));
+    if (!stage_only) TBNAV_HIP(hipMemcpyAsync(h->d_beams, h->h_beams, sizeof(double2) * Bv, hipMemcpyHostToDevice, h->stream));
   }
   return TBNAV_OK;
 }
@@ -3250,7 +3259,7 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
   std::memset(out, 0, sizeof *out);
   if (rc != TBNAV_OK) { out->status = rc; return rc; }
   out->n_valid_beams = c.Bv;
-  rc = upload_beams(h, beams, n_beams, c.Bv);
+  rc = upload_beams(h, beams, n_beams, c.Bv, /*stage_only=*/normals == nullptr);  // device noise: the noise kernel carries the beams over
   if (rc != TBNAV_OK) return rc;
   const size_t n_norm = (size_t)h->N * c.stride_normals + 1;
   if (n_norm > h->normals_cap) {
@@ -3264,7 +3273,7 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
   } else {
     const int blocks = (int)std::min<size_t>((n_norm / 2 + 255) / 256, 4096);
     hipLaunchKernelGGL(rbpf_sample_normals, dim3(blocks), dim3(256), 0, st, n_norm, (unsigned long long)h->seed,
-                       (unsigned long long)h->scan_index, h->d_normals);
+                       (unsigned long long)h->scan_index, h->d_normals, (const double2*)h->h_beams, h->d_beams, c.Bv);
     TBNAV_HIP(hipGetLastError());
   }
   ++h->scan_index;
