@@ -68,10 +68,22 @@ __device__ __forceinline__ int floor_div_small(int num, int den);  // exact floo
 // over workgroups and printed by tbnav_rbpf_destroy.  The stamps add barriers and global atomics — the kernels
 // run measurably slower with them; the numbers are for comparing phases, not for the bench.
 #ifdef TBNAV_PHASE_PROF
+__device__ unsigned long long g_trace_p[4][16];  // [wave][stamp] of ONE proposal workgroup (blockIdx.x == 100)
+#define TRACE_P(i) do { if (blockIdx.x == 100 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 4) g_trace_p[threadIdx.x >> 6][i] = wall_clock64(); } while (0)
+#else
+#define TRACE_P(i)
+#endif
+#ifdef TBNAV_PHASE_PROF
 __device__ unsigned long long g_phase[8];
 __device__ unsigned long long g_phase_p[8];
 #define PHASE_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_phase[i], now_ - t_prev_); t_prev_ = now_; } } while (0)
 #define PHASE_STAMP_P(i) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_phase_p[i], now_ - t_prev_); t_prev_ = now_; } } while (0)
+#ifdef TBNAV_TRACE_ONLY
+#undef PHASE_STAMP
+#undef PHASE_STAMP_P
+#define PHASE_STAMP(i)
+#define PHASE_STAMP_P(i)
+#endif
 #else
 #define PHASE_STAMP(i)
 #define PHASE_STAMP_P(i)
@@ -740,6 +752,7 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
   unsigned long long t_prev_ = wall_clock64();
 #endif
   const double th0 = pose[p * 3 + 0], x0 = pose[p * 3 + 1], y0 = pose[p * 3 + 2];
+  TRACE_P(0);
   double s0, c0;
   sincos(th0, &s0, &c0);
   // the mode the samples are drawn round: T(pose) * T_icp, or the particle's own scan-matched pose (N1 option)
@@ -758,17 +771,48 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
       const int W0 = max(0, scj - occ_half) >> 6, W1 = min(c.g.ysize - 1, scj + occ_half) >> 6, nW = W1 - W0 + 1;
       unsigned long long* tb = tile_bm;
       int* ta = reinterpret_cast<int*>(tile_bm + (size_t)(R1 - R0 + 1) * nW);
-      for (int r = tid; r <= R1 - R0; r += kProposeThreads) {
-        unsigned long long acc = 0ull;
-        for (int w = 0; w < nW; ++w) {
-          const unsigned long long v = ds.occ.word(R0 + r, W0 + w);
-          tb[r * nW + w] = v;
-          acc |= v;
+      // Two round trips instead of a chain of dependent ones per word: the ids of the tiles under the window go to LDS
+      // first, then every row requests its (up to kStC) 32-bit pieces at once.
+      constexpr int kStC = 12, kStIds = 128;
+      __shared__ unsigned int st_ids[kStIds];
+      const int tr0 = R0 >> kTSh, tc0 = 2 * W0, ntc = min(2 * nW, ds.occ.TW - tc0), n_ids = ((R1 >> kTSh) - tr0 + 1) * ntc;
+      if (ntc <= kStC && n_ids <= kStIds) {
+        for (int q = tid; q < n_ids; q += kProposeThreads) {
+          const int qi = floor_div_small(q, ntc);
+          st_ids[q] = ds.occ.tab[(tr0 + qi) * ds.occ.TW + tc0 + (q - qi * ntc)];
         }
-        ta[r] = acc != 0ull;
+        __syncthreads();
+        for (int r = tid; r <= R1 - R0; r += kProposeThreads) {
+          const int row = R0 + r;
+          const unsigned int* ids = st_ids + ((row >> kTSh) - tr0) * ntc;
+          unsigned int v32[kStC];
+#pragma unroll
+          for (int q = 0; q < kStC; ++q) v32[q] = q < ntc ? ds.occ.bm[(size_t)ids[q] * kTS + (row & (kTS - 1))] : 0u;
+          unsigned long long acc = 0ull;
+#pragma unroll
+          for (int w = 0; w < kStC / 2; ++w) {
+            if (w < nW) {
+              const unsigned long long v = (unsigned long long)v32[2 * w] | ((unsigned long long)v32[2 * w + 1] << 32);
+              tb[r * nW + w] = v;
+              acc |= v;
+            }
+          }
+          ta[r] = acc != 0ull;
+        }
+      } else {
+        for (int r = tid; r <= R1 - R0; r += kProposeThreads) {
+          unsigned long long acc = 0ull;
+          for (int w = 0; w < nW; ++w) {
+            const unsigned long long v = ds.occ.word(R0 + r, W0 + w);
+            tb[r * nW + w] = v;
+            acc |= v;
+          }
+          ta[r] = acc != 0ull;
+        }
       }
       ds.tany = ta; ds.R0 = R0; ds.R1 = R1; ds.W0 = W0; ds.nW = nW;
     }
+    TRACE_P(1);
     __syncthreads();
   }
   // ---- 1. wave 0: the k sampled poses and their sensor transforms; how far any of them is from the centre
@@ -792,6 +836,7 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
     if (lane == 0) { sh_spread[0] = dxy; sh_spread[1] = dth; }
   }
   __syncthreads();
+  TRACE_P(2);
 #ifdef TBNAV_PHASE_PROF
   if (tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_phase_p[5], now_ - t_prev_); }
 #endif
@@ -838,8 +883,10 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
     pst = wave_prod(pst);
     if (lane == 0) sh_pst[wid] = pst;
   }
+  TRACE_P(3);
   __syncthreads();
   PHASE_STAMP_P(0);
+  TRACE_P(4);
   // ---- 3. the unstable beams, listed in beam order (so that the products below have one fixed order)
   if (wid == 0 && nocc) {
     int n = 0;
@@ -856,6 +903,7 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
 #endif
   }
   __syncthreads();
+  TRACE_P(5);
   // ---- 4. scan likelihood of every sample: (product over the stable beams) * (its own terms of the unstable ones);
   //      one wave per sample, lanes over the unstable beams
   if (nocc == 0) {
@@ -906,6 +954,7 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
   if (oob & 1) atomicOr(&err[0], 1);
   if (oob & 2) atomicOr(&err[3], 4);
   __syncthreads();
+  TRACE_P(7);
 
   // ---- Gaussian proposal (:522-599), new pose (:214-231).  The sums run in the reference's sequential order on
   //      one thread; everything that is per-sample (clamps, products, outer products, trace) is done by the
@@ -925,6 +974,7 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
     wj[j] = ps * pp;
   }
   __syncthreads();
+  TRACE_P(8);
   // The weighted sums (:545-585) are taken by wave 0 as lane-strided partial sums closed with a butterfly: a fixed
   // order, not the reference's left-to-right one — the results agree to rounding (asserted at 1e-10 against the
   // oracle), and the serial chain of 4 + 6 adds per sample leaves the block's critical path.
@@ -947,6 +997,7 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
     }
   }
   __syncthreads();
+  TRACE_P(9);
   if (sh_stop) {  // eta is 0 (reported): the pose stays, and so does its sensor transform
     if (tid == 0) { double Ts[4]; sensor_transform(c, th0, x0, y0, Ts); for (int q = 0; q < 4; ++q) sens[p * 4 + q] = Ts[q]; }
     return;
@@ -984,6 +1035,7 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
       for (int q = 0; q < 4; ++q) sens[p * 4 + q] = Ts[q];
     }
   }
+  TRACE_P(10);
   PHASE_STAMP_P(2);
 #ifdef TBNAV_PHASE_PROF
   if (tid == 0) atomicAdd(&g_phase_p[7], 1ull);
@@ -3634,6 +3686,18 @@ void tbnav_rbpf_destroy(tbnav_rbpf* h) {
                            "other cells %.1f | overflowed slots %.2f | end-point cells %.1f\n",
                    (double)ph[0] / ph[7], (double)ph[1] / ph[7], (double)ph[2] / ph[7], (double)ph[3] / ph[7], (double)ph[4] / ph[7],
                    (double)ph[5] / ph[7], (double)ph[6] / ph[7]);
+    unsigned long long tp[4][16];
+    if (hipMemcpyFromSymbol(tp, HIP_SYMBOL(g_trace_p), sizeof(tp)) == hipSuccess && tp[0][0]) {
+      std::fprintf(stderr, "[rbpf_propose trace of workgroup 100, us; columns: entry, bitmap slice staged, samples drawn (barrier), lookups done, barrier, "
+                           "unstable list (barrier), -, products (barrier), weights (barrier), mean (barrier), end]\n");
+      unsigned long long t0 = ~0ull;
+      for (int w = 0; w < 4; ++w) if (tp[w][0] && tp[w][0] < t0) t0 = tp[w][0];
+      for (int w = 0; w < 4; ++w) {
+        std::fprintf(stderr, "  wave %d:", w);
+        for (int i = 0; i < 11; ++i) std::fprintf(stderr, " %6.2f", tp[w][i] ? (double)(tp[w][i] - t0) * 0.01 : -1.0);
+        std::fprintf(stderr, "\n");
+      }
+    }
     unsigned long long tr[16][16];
     if (hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_trace), sizeof(tr)) == hipSuccess && tr[0][0]) {
       std::fprintf(stderr, "[raycast_box trace of workgroup 100, us since its first stamp; columns: entry, pose barrier, end-point barrier, flags, flag barrier, own events, walk, walk barrier, requests, barrier, tiles private, replay, overflow+hot, barrier, stores]\n");
