@@ -2354,11 +2354,15 @@ __device__ __forceinline__ int floor_div(int num, int den) {  // den > 0
 }
 // Exact floor(num/den) for |num| < 2^24 and 0 < den < 2^13 (the envelope's operands: |num| <= 255^2 +
 // 2047^2, den <= 2*2047): both convert to float exactly, the float quotient is within 1 of the true
-// one, and one integer remainder check fixes it — ~10 instructions instead of the ~40 of an int division.
+// one, and an integer remainder check fixes it — ~12 instructions instead of the ~40 of an int division.
+// (the quotient comes from v_rcp_f32 — one instruction, 1 ulp — not from a float division, which without fast-math is a
+//  twelve-instruction sequence: the estimate may then be off by two, hence two correction steps each way)
 __device__ __forceinline__ int floor_div_small(int num, int den) {
-  int q = (int)floorf(__fdividef((float)num, (float)den));
+  int q = (int)floorf((float)num * __builtin_amdgcn_rcpf((float)den));
   int r = num - q * den;
   if (r < 0) { --q; r += den; }
+  if (r < 0) { --q; r += den; }
+  if (r >= den) { ++q; r -= den; }
   if (r >= den) ++q;
   return q;
 }
