@@ -485,8 +485,13 @@ class PF {
     if (sm_on) { sm_centers.resize((size_t)N * 3); sm_scores.resize(N); }
     // (particles are independent inside this loop; with orc_set_threads(n > 1) it is spread over n cores — the
     //  "all host cores" CPU baseline of bench_rbpf.py.  Same results: every particle reads its own slice of the draws.)
+    // (an exception must not leave an OpenMP region: what the reference would have thrown — at the first particle that
+    //  throws — is caught per particle, the lowest particle index wins, and it is rethrown after the loop)
+    int thrown_code = 0, thrown_pi = N;
 #pragma omp parallel for num_threads(g_orc_threads) if (g_orc_threads > 1) schedule(dynamic, 1)
     for (int pi = 0; pi < N; ++pi) {
+      if (thrown_code && pi > thrown_pi) continue;  // the reference stops at its first throw
+      try {
       size_t nz = (size_t)pi * stride;
       Particle& particle = set[pi];
       if (!icp_ok) {
@@ -530,7 +535,12 @@ class PF {
       if (tr && tr->weight_raw) tr->weight_raw[pi] = particle.weight;
       const T2 Pp = make_T(particle.pose[1], particle.pose[2], particle.pose[0]);
       particle.grid.integrate_scan(scan, n, Pp);  // :237-239
+      } catch (const Thrown& t) {
+#pragma omp critical(orc_thrown)
+        { if (pi < thrown_pi) { thrown_pi = pi; thrown_code = t.code; } }
+      }
     }
+    if (thrown_code) throw Thrown{thrown_code};
     size_t nz = (size_t)N * stride;
     // normalizeWeights, :442-458
     double sum = 0.0;
