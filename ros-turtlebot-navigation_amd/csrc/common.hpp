@@ -87,10 +87,43 @@ __device__ __forceinline__ double wave_min_dpp(double v) {
   out = fmin(out, dpp_or_inf<0x143, 0xc, 0xf>(out));
   return lane63(out);
 }
+// The partner of a butterfly step inside groups of 2 / 4 / 8 / 16 consecutive lanes, on the DPP network: lane ^ 1 and
+// lane ^ 2 are quad permutations; once a quad's lanes agree, the mirror image within 8 (row_half_mirror) or 16
+// (row_mirror) lanes lies in the other quad / half, which is all a commutative reduction needs.
+template <int STEP>
+__device__ __forceinline__ double dpp_group_partner(double v) {
+  constexpr int ctrl = STEP == 1 ? 0xB1 : STEP == 2 ? 0x4E : STEP == 4 ? 0x141 : 0x140;  // quad_perm [1,0,3,2] / [2,3,0,1], row_half_mirror, row_mirror
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// all-lanes reduction over groups of R consecutive lanes (R = 2, 4, 8, 16), steps in the order 1, 2, 4, 8
+template <int R, class Op>
+__device__ __forceinline__ double group_reduce_dpp(double v, Op op) {
+  static_assert(R == 2 || R == 4 || R == 8 || R == 16, "groups of 2..16 lanes");
+  v = op(v, dpp_group_partner<1>(v));
+  if constexpr (R >= 4) v = op(v, dpp_group_partner<2>(v));
+  if constexpr (R >= 8) v = op(v, dpp_group_partner<4>(v));
+  if constexpr (R >= 16) v = op(v, dpp_group_partner<8>(v));
+  return v;
+}
 // inclusive suffix sum (lane i gets v_i + ... + v_63): mirror the wave, scan, mirror back
+__device__ __forceinline__ double readlane_d(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 __device__ __forceinline__ double wave_scan_incl_rev(double v, int lane) {
-  const double m = __shfl(v, 63 - lane, 64);
-  return __shfl(wave_scan_incl(m, lane), 63 - lane, 64);
+  // the mirror image of wave_scan_incl inside each row of 16 lanes (row_shl), then the totals of the later rows — read
+  // from their first lanes — are added; no LDS permute (two dependent ones before)
+  double out = v;
+  out += dpp_or_zero<0x101, 0xf, 0xf>(v);    // row_shl:1
+  out += dpp_or_zero<0x102, 0xf, 0xf>(v);    // row_shl:2
+  out += dpp_or_zero<0x103, 0xf, 0xf>(v);    // row_shl:3
+  out += dpp_or_zero<0x104, 0xf, 0x7>(out);  // row_shl:4, banks 0-2
+  out += dpp_or_zero<0x108, 0xf, 0x3>(out);  // row_shl:8, banks 0-1 -> inclusive suffix within each row of 16
+  const double t1 = readlane_d(out, 16), t2 = readlane_d(out, 32), t3 = readlane_d(out, 48);
+  const int row = lane >> 4;
+  const double later = row == 0 ? (t1 + t2) + t3 : row == 1 ? t2 + t3 : row == 2 ? t3 : 0.0;
+  return out + later;
 }
 
 }  // namespace tbnav

@@ -842,17 +842,14 @@ __global__ __launch_bounds__(kWave * R) void mppi_rollout_fused(RolloutArgs a, c
   for (int t = tid / R; t < T; t += nthr / R) {
     const double j = ok ? Jl[t * RP + rr] : inf;
     const double l = ok ? nL[t * RP + rr] : 0.0, rg = ok ? nR[t * RP + rr] : 0.0;
-    double mn = j;
-#pragma unroll
-    for (int off = R / 2; off > 0; off >>= 1) mn = fmin(mn, __shfl_xor(mn, off, kWave));
+    // (group reductions on the DPP network: R is 4, 8 or 16 consecutive lanes — no LDS round trip per butterfly step)
+    auto gmin = [](double x, double y) { return fmin(x, y); };
+    auto gsum = [](double x, double y) { return x + y; };
+    const double mn = tbnav::group_reduce_dpp<R>(j, gmin);
     // exp(-(J - min)/lambda) with the reference's association: (J - min) * -1.0 / lambda (mppi.cpp:117)
     const double e = ok ? exp(((j - mn) * -1.0) / lambda) : 0.0;
-    double A = e, B = e * l, C = e * rg, D = l, E = rg, n = ok ? 1.0 : 0.0;
-#pragma unroll
-    for (int off = R / 2; off > 0; off >>= 1) {
-      A += __shfl_xor(A, off, kWave); B += __shfl_xor(B, off, kWave); C += __shfl_xor(C, off, kWave);
-      D += __shfl_xor(D, off, kWave); E += __shfl_xor(E, off, kWave); n += __shfl_xor(n, off, kWave);
-    }
+    const double A = tbnav::group_reduce_dpp<R>(e, gsum), B = tbnav::group_reduce_dpp<R>(e * l, gsum), C = tbnav::group_reduce_dpp<R>(e * rg, gsum);
+    const double D = tbnav::group_reduce_dpp<R>(l, gsum), E = tbnav::group_reduce_dpp<R>(rg, gsum), n = tbnav::group_reduce_dpp<R>(ok ? 1.0 : 0.0, gsum);
     if (rr == 0) {
       double* rec = records + ((size_t)t * S + blockIdx.x) * TBNAV_MPPI_REC;
       rec[0] = mn; rec[1] = A; rec[2] = B; rec[3] = C; rec[4] = D; rec[5] = E; rec[6] = n; rec[7] = 0.0;
@@ -861,7 +858,7 @@ __global__ __launch_bounds__(kWave * R) void mppi_rollout_fused(RolloutArgs a, c
 }
 
 __device__ __forceinline__ double block_min(double v, double* scratch) {
-  v = tbnav::wave_min(v);
+  v = tbnav::wave_min_dpp(v);
   const int wid = threadIdx.x / kWave;
   if ((threadIdx.x & (kWave - 1)) == 0) scratch[wid] = v;
   __syncthreads();
@@ -871,7 +868,7 @@ __device__ __forceinline__ double block_min(double v, double* scratch) {
   return r;
 }
 __device__ __forceinline__ double block_sum(double v, double* scratch) {
-  v = tbnav::wave_sum(v);
+  v = tbnav::wave_sum_dpp(v);
   const int wid = threadIdx.x / kWave;
   if ((threadIdx.x & (kWave - 1)) == 0) scratch[wid] = v;
   __syncthreads();
