@@ -707,6 +707,14 @@ __device__ __forceinline__ void device_noise(const RngArgs& g, int T, int i, int
   dr = g.sig_r * (double)(rad * __builtin_amdgcn_sinf(u2));
 }
 
+#ifdef TBNAV_PHASE_PROF
+// development build: per-wave timeline (10 ns ticks) of workgroup 5 of the fused kernel and of the combine, printed by
+// tbnav_mppi_destroy
+__device__ unsigned long long g_mtrace[2][8][8];
+#define MTRACE(k, i) do { if (blockIdx.x == 5 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 8) g_mtrace[k][threadIdx.x >> 6][i] = wall_clock64(); } while (0)
+#else
+#define MTRACE(k, i)
+#endif
 // ---- fused rollout + soft-min partials for small K (lanes = TIME) ------------------------------------------
 // When K/64 one-wave workgroups cannot fill the chip (K = 1024: 16 of 256 CUs), the tick is three short kernels
 // whose execution time is all latency.  This kernel turns the rollout round: one WAVE per rollout with its lanes
@@ -735,6 +743,7 @@ __global__ __launch_bounds__(kWave * R) void mppi_rollout_fused(RolloutArgs a, c
   const int tid = threadIdx.x, lane = tid & (kWave - 1), r = tid / kWave, nthr = kWave * R;
   const int k0 = blockIdx.x * R;
   const int kk = (k0 + r < K) ? k0 + r : K - 1;  // a ragged tail shadows a valid rollout
+  MTRACE(0, 0);
   {
     // lane = time: the R waves of the workgroup read the same 64*R/8-byte rows of the noise, one element each (the
     // row is one or two cache lines, fetched once and served to the other waves from L1); the values also go to
@@ -748,6 +757,7 @@ __global__ __launch_bounds__(kWave * R) void mppi_rollout_fused(RolloutArgs a, c
       uL[q] = u.get(0, ii, T);
       uR[q] = u.get(1, ii, T);
     }
+    MTRACE(0, 1);
     double v[TL], w[TL], ctrl[TL], pth[TL];
     double run = 0.0;
 #pragma unroll
@@ -770,6 +780,7 @@ __global__ __launch_bounds__(kWave * R) void mppi_rollout_fused(RolloutArgs a, c
       pth[q] = run;  // lane-local heading change AFTER step q
     }
     const double th_lane = a.x0[2] + (tbnav::wave_scan_incl(run, lane) - run);  // heading at the start of this lane's steps
+    MTRACE(0, 2);
     double runx = 0.0, runy = 0.0, px[TL], py[TL];
 #pragma unroll
     for (int q = 0; q < TL; ++q) {
@@ -808,6 +819,7 @@ __global__ __launch_bounds__(kWave * R) void mppi_rollout_fused(RolloutArgs a, c
     }
     const double x_lane = a.x0[0] + (tbnav::wave_scan_incl(runx, lane) - runx);
     const double y_lane = a.x0[1] + (tbnav::wave_scan_incl(runy, lane) - runy);
+    MTRACE(0, 3);
     double suf[TL];
     run = 0.0;
 #pragma unroll
@@ -828,6 +840,7 @@ __global__ __launch_bounds__(kWave * R) void mppi_rollout_fused(RolloutArgs a, c
       if (i < T) Jl[i * RP + r] = suf[q] + tail;
     }
   }
+  MTRACE(0, 4);
   __syncthreads();
   if (J) {  // parity hook only (tbnav_mppi_get_cost_to_go): the update itself needs the records, not J
     for (int idx = tid; idx < T * R; idx += nthr) {
@@ -835,6 +848,7 @@ __global__ __launch_bounds__(kWave * R) void mppi_rollout_fused(RolloutArgs a, c
       if (k0 + rr < K) J[(size_t)t * K + k0 + rr] = Jl[t * RP + rr];
     }
   }
+  MTRACE(0, 5);
   // soft-min partial record of each time step over this workgroup's rollouts (mppi.cpp:115-121)
   const double inf = __builtin_huge_val();
   const int rr = tid % R;
@@ -855,6 +869,7 @@ __global__ __launch_bounds__(kWave * R) void mppi_rollout_fused(RolloutArgs a, c
       rec[0] = mn; rec[1] = A; rec[2] = B; rec[3] = C; rec[4] = D; rec[5] = E; rec[6] = n; rec[7] = 0.0;
     }
   }
+  MTRACE(0, 6);
 }
 
 __device__ __forceinline__ double block_min(double v, double* scratch) {
@@ -973,6 +988,7 @@ __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, double 
   const int spw = kWave / tpr, sub = lane / tpr, l = lane - sub * tpr;
   const int i = (blockIdx.x * nw + wid) * spw + sub;
   const bool valid = i < T;
+  MTRACE(1, 0);
   // the warm-start controls do not depend on the records: fetch them first, under the record loads
   const double u_l = valid ? u.get(0, i, T) : 0.0, u_r = valid ? u.get(1, i, T) : 0.0;
   // Up to two records per lane stay in registers (R <= 2 * tpr: every configuration with at most 128 records per
@@ -990,6 +1006,7 @@ __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, double 
     for (int f = 0; f < 7; ++f) rk[q][f] = have ? rec[f] : 0.0;  // n == 0 marks "no record"
   }
   double M = __builtin_huge_val();
+  MTRACE(1, 1);
   if (keep) {
 #pragma unroll
     for (int q = 0; q < kKeep; ++q) if (rk[q][6] > 0.0) M = fmin(M, rk[q][0]);
@@ -1003,6 +1020,7 @@ __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, double 
   if (tpr == kWave) M = tbnav::wave_min_dpp(M);  // a whole wave per time step: reductions on the DPP network
   else for (int off = tpr >> 1; off > 0; off >>= 1) M = fmin(M, __shfl_xor(M, off, kWave));
   double W = 0, NL = 0, NR = 0, SD = 0, SE = 0, SN = 0;
+  MTRACE(1, 2);
   if (keep) {
 #pragma unroll
     for (int q = 0; q < kKeep; ++q)
@@ -1031,6 +1049,7 @@ __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, double 
       SD += __shfl_xor(SD, off, kWave); SE += __shfl_xor(SE, off, kWave); SN += __shfl_xor(SN, off, kWave);
     }
   }
+  MTRACE(1, 3);
   if (valid && l == 0) {
     W += 1e-8 * SN;  // the reference adds 1e-8 to every weight before normalising (mppi.cpp:117)
     double ul = u_l + (NL + 1e-8 * SD) / W;
@@ -1405,6 +1424,26 @@ int tbnav_mppi_create(const tbnav_mppi_params* params, tbnav_mppi** out) {
 }
 
 void tbnav_mppi_destroy(tbnav_mppi* h) {
+#ifdef TBNAV_PHASE_PROF
+  {
+    unsigned long long tr[2][8][8];
+    if (hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_mtrace), sizeof(tr)) == hipSuccess && tr[0][0][0]) {
+      const char* names[2] = {"mppi_rollout_fused, workgroup 5 (entry, noise + u requested, heading scan, x / y scans, J in LDS, barrier, records stored)",
+                              "mppi_combine, workgroup 5 (entry, records requested, min, sums)"};
+      for (int k = 0; k < 2; ++k) {
+        std::fprintf(stderr, "[%s; us]\n", names[k]);
+        unsigned long long t0 = ~0ull;
+        for (int w = 0; w < 8; ++w) if (tr[k][w][0] && tr[k][w][0] < t0) t0 = tr[k][w][0];
+        for (int w = 0; w < 8; ++w) {
+          if (!tr[k][w][0]) continue;
+          std::fprintf(stderr, "  wave %d:", w);
+          for (int i = 0; i < 7; ++i) std::fprintf(stderr, " %5.2f", tr[k][w][i] ? (double)(tr[k][w][i] - t0) * 0.01 : -1.0);
+          std::fprintf(stderr, "\n");
+        }
+      }
+    }
+  }
+#endif
   if (!h) return;
   DeviceGuard guard(h->device);
   (void)hipFree(h->d_u[0]); (void)hipFree(h->d_u[1]); (void)hipFree(h->d_J); (void)hipFree(h->d_duL); (void)hipFree(h->d_duR);
