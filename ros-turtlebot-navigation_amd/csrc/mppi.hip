@@ -1000,7 +1000,7 @@ __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, double 
   for (int q = 0; q < kKeep; ++q) {
     const int r = l + q * tpr;
     const bool have = valid && keep && r < R;
-    const int g = have ? r / S : 0, sl = have ? r - g * S : 0;
+    const int g = (have && G > 1) ? r / S : 0, sl = have ? r - g * S : 0;  // (one group — every single-GPU tick: no division)
     const double* rec = records + (((size_t)g * T + (valid ? i : 0)) * S + sl) * TBNAV_MPPI_REC;
 #pragma unroll
     for (int f = 0; f < 7; ++f) rk[q][f] = have ? rec[f] : 0.0;  // n == 0 marks "no record"
