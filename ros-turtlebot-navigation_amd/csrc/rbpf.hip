@@ -302,6 +302,9 @@ struct DistSrc {
   const unsigned long long* tbm;
   const int* tany;
   int R0, R1, W0, nW;
+  // optional, with the LDS tile: lut7[m] = least (c - 3)^2 over the set bits c of the 7-bit pattern m (100: none) — lets a
+  // lookup read the 7 x 7 cells round it as seven table look-ups instead of seven 64-column bit scans
+  const unsigned char* lut7;
 };
 // Walk rows i, i+-1, i+-2, ... of an occupancy bitmap (stride `words` u64 per row, rows row_lo..row_hi present,
 // cell columns [0, words*64) relative to the bitmap) and return the least squared distance found (INT_MAX: none
@@ -335,9 +338,28 @@ __device__ __forceinline__ uint16_t nearest_code_query(const GridC& g, const Dis
       if (d.R1 < g.xsize - 1) clear = min(clear, d.R1 - ci + 1);
       if (C0 > 0) clear = min(clear, cj - C0 + 1);
       if (C1 < g.ysize - 1) clear = min(clear, C1 - cj + 1);
+      bool looked7 = false;
       {
-        // A beam ends on or next to a wall: look at the 7 rows x 64 columns round the cell first, branch-free.
-        // Anything outside that window is >= 4 cells away, so a result <= 9 (and <= clear^2) is the map's answer.
+        // A beam ends on or next to a wall: the 7 x 7 cells round the looked-up cell first.  Every cell outside them is
+        // >= 4 cells away, so a result <= 9 (and <= clear^2) is the map's answer.  Row by row: the seven bits round the
+        // column (one v_alignbit on two adjacent dwords of the LDS tile) index a 128-entry table of least column offsets.
+        const int p0 = cj - C0 - 3, wi = p0 >> 5;
+        if (d.lut7 && ci - 3 >= d.R0 && ci + 3 <= d.R1 && p0 >= 0 && wi + 1 < 2 * d.nW) {
+          const unsigned int* t32 = reinterpret_cast<const unsigned int*>(d.tbm) + wi;
+          const int sh = p0 & 31, stride = 2 * d.nW;
+          int bw = 0x7fffffff;
+#pragma unroll
+          for (int dr = -3; dr <= 3; ++dr) {
+            const unsigned int* rp = t32 + (ci + dr - d.R0) * stride;
+            const unsigned int pat = __builtin_amdgcn_alignbit(rp[1], rp[0], sh) & 0x7Fu;
+            bw = min(bw, dr * dr + (int)d.lut7[pat]);
+          }
+          if (bw <= 9 && bw <= clear * clear) return (uint16_t)bw;
+          looked7 = true;
+        }
+      }
+      if (!looked7) {
+        // (no table, or the 7 x 7 window sticks out of the tile) the same 7 rows, 64 columns each, by bit scans, branch-free
         const int cjr = cj - C0, s0 = cjr - 32, w = s0 >> 6, sh = s0 & 63;
         int bw = 0x7fffffff;
 #pragma unroll
@@ -810,7 +832,14 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
           ta[r] = acc != 0ull;
         }
       }
-      ds.tany = ta; ds.R0 = R0; ds.R1 = R1; ds.W0 = W0; ds.nW = nW;
+      // the 128-entry table of nearest_code_query's 7 x 7 look (visible after the barrier below)
+      __shared__ unsigned char sh_lut7[128];
+      if (tid < 128) {
+        int best = 100;
+        for (int cbit = 0; cbit < 7; ++cbit) if ((tid >> cbit) & 1) { const int dc = cbit - 3; best = min(best, dc * dc); }
+        sh_lut7[tid] = (unsigned char)best;
+      }
+      ds.tany = ta; ds.R0 = R0; ds.R1 = R1; ds.W0 = W0; ds.nW = nW; ds.lut7 = sh_lut7;
     }
     TRACE_P(1);
     __syncthreads();
