@@ -629,7 +629,13 @@ __global__ __launch_bounds__(kMatchThreads) void rbpf_scanmatch(ScanC c, ScanMat
         }
         ta[r] = acc != 0ull;
       }
-      ds.tany = ta; ds.R0 = R0; ds.R1 = R1; ds.W0 = W0; ds.nW = nW;
+      __shared__ unsigned char sm_lut7[128];  // nearest_code_query's 7 x 7 look (visible after the barrier below)
+      if (tid < 128) {
+        int best = 100;
+        for (int cbit = 0; cbit < 7; ++cbit) if ((tid >> cbit) & 1) { const int dc = cbit - 3; best = min(best, dc * dc); }
+        sm_lut7[tid] = (unsigned char)best;
+      }
+      ds.tany = ta; ds.R0 = R0; ds.R1 = R1; ds.W0 = W0; ds.nW = nW; ds.lut7 = sm_lut7;
     }
   }
   if (tid == 0) { cur[0] = mu0[0]; cur[1] = mu0[1]; cur[2] = mu0[2]; steps[0] = sm.lstep; steps[1] = sm.astep; refinements = 0; done = 0; }
