@@ -206,6 +206,10 @@ def main():
         def tick():
             m.enqueueRng(X0, SEED, tk[0], stream)
             tk[0] += 1
+
+        def ticks(n):  # the same n ticks enqueued by ONE call through the C boundary (tbnav_mppi_enqueue_rng_batch): from
+            m.enqueueRngBatch(X0, SEED, tk[0], n, stream)  # Python an enqueue costs 8-10 us, as much as the tick itself
+            tk[0] += n
         barrier = lambda: None  # noqa: E731
     else:
         sm = ShardedMPPI(HipShardBackend(m, device))
@@ -218,7 +222,17 @@ def main():
             dist.barrier()
 
     sync = lambda: torch.cuda.synchronize(device)  # noqa: E731
-    el = time_ticks(tick, sync, args.steps, args.warmup, barrier)
+    if world == 1:
+        ticks(args.warmup)
+        sync(); barrier(); sync()
+        t0 = time.perf_counter()
+        ticks(args.steps)
+        sync(); barrier(); sync()
+        el = time.perf_counter() - t0
+        el_py = time_ticks(tick, sync, args.steps, args.warmup, barrier)  # one Python call per tick, for comparison
+    else:
+        el = time_ticks(tick, sync, args.steps, args.warmup, barrier)
+        el_py = None
     if world > 1:
         t = torch.tensor([el], dtype=torch.float64, device="cpu" if one_gpu_test else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -250,6 +264,8 @@ def main():
                        "parallelism": f"rollout-shard x{world}" + (", 1 all-gather of soft-min records/tick" if world > 1 else "")},
             "rollout_steps_per_s": round(value * T, 1),
             "sync_tick_ms": round(sync_ms, 6),
+            "entry_point": "tbnav_mppi_enqueue_rng_batch (the K ticks enqueued by one call through the C boundary)" if world == 1 else "tbnav_mppi_shard_* per tick",
+            "ms_per_step_one_python_call_per_tick": None if el_py is None else round(el_py / args.steps * 1e3, 6),
             "roofline": roofline_obj(K, T, ms_k, ms_step, m.rollout_kernel, "mppi_K1024_T50" if (K, T) == (1024, 50) else None),
             # the tick is two dependent launches: what the guide prices for that alone (MI355X_MICROARCH.md, "boundary" row)
             "latency_floor": {"dependent_launches_per_tick": 2, "boundary_us_each": [1.45, 1.9],

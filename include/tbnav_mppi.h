@@ -187,6 +187,12 @@ int tbnav_mppi_profile_tick(tbnav_mppi* h, const double x0[3], const double* d_d
 int tbnav_mppi_enqueue_rng(tbnav_mppi* h, const double x0[3], uint64_t seed, uint64_t tick, void* stream);
 int tbnav_mppi_new_controls_rng(tbnav_mppi* h, const double x0[3], uint64_t seed, uint64_t tick, void* stream,
                                 double u_out[2]);
+/* n_ticks production ticks in a row, enqueued from C: tick i starts from x0s + i * x0_stride (doubles; x0_stride = 0: the
+ * same state every tick — replay / throughput runs, the warm start is carried from tick to tick as always) with the
+ * perturbations of (seed, first_tick + i).  Exactly n_ticks tbnav_mppi_enqueue_rng calls, without a trip through the
+ * caller's language per tick (from Python one enqueue costs as much as the tick takes on the device). */
+int tbnav_mppi_enqueue_rng_batch(tbnav_mppi* h, const double* x0s, int32_t x0_stride, uint64_t seed, uint64_t first_tick,
+                                 int32_t n_ticks, void* stream);
 
 /* Per-kernel durations priced without the events' own cost: each kernel of the tick is launched `reps` (even, >= 2)
  * times back to back between one event pair; ms[i] = elapsed / reps (ms[1] = 0 when rollout and partials are one

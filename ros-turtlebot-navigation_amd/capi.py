@@ -128,6 +128,7 @@ def lib() -> C.CDLL:
         "tbnav_mppi_last_controls": (C.c_int, [vp, vp, dp]),
         "tbnav_mppi_sample_noise": (C.c_int, [vp, u64, u64, vp]),
         "tbnav_mppi_enqueue_rng": (C.c_int, [vp, dp, u64, u64, vp]),
+        "tbnav_mppi_enqueue_rng_batch": (C.c_int, [vp, dp, i32, u64, u64, i32, vp]),
         "tbnav_mppi_new_controls_rng": (C.c_int, [vp, dp, u64, u64, vp, dp]),
         "tbnav_mppi_get_noise": (C.c_int, [vp, vp, vp]),
         "tbnav_mppi_shard_partials": (C.c_int, [vp, dp, vp, vp, vp, vp]),

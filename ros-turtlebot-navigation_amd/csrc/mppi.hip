@@ -1749,6 +1749,16 @@ int tbnav_mppi_enqueue_rng(tbnav_mppi* h, const double x0[3], uint64_t seed, uin
   return rc != TBNAV_OK ? rc : launch_combine(h, h->d_records_f, 1, st, h->fused_S);
 }
 
+int tbnav_mppi_enqueue_rng_batch(tbnav_mppi* h, const double* x0s, int32_t x0_stride, uint64_t seed, uint64_t first_tick, int32_t n_ticks,
+                                 void* stream) {
+  if (!h || !x0s || n_ticks < 0 || (x0_stride != 0 && x0_stride < 3)) return TBNAV_ERR_INVALID_ARG;
+  for (int32_t i = 0; i < n_ticks; ++i) {
+    const int rc = tbnav_mppi_enqueue_rng(h, x0s + (size_t)i * x0_stride, seed, first_tick + (uint64_t)i, stream);
+    if (rc != TBNAV_OK) return rc;
+  }
+  return TBNAV_OK;
+}
+
 int tbnav_mppi_new_controls_rng(tbnav_mppi* h, const double x0[3], uint64_t seed, uint64_t tick, void* stream, double u_out[2]) {
   if (!h || !u_out) return TBNAV_ERR_INVALID_ARG;
   h->publish_next = true;

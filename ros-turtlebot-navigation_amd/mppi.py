@@ -144,6 +144,11 @@ class MPPI:
         """Production tick: perturbations of (seed, tick) drawn on the device, inside the fused kernel where there is one."""
         capi.check(self._L.tbnav_mppi_enqueue_rng(self._h, (C.c_double * 3)(*x0), seed, tick, stream or None), "enqueue_rng")
 
+    def enqueueRngBatch(self, x0, seed: int, first_tick: int, n_ticks: int, stream: int = 0):
+        """n_ticks production ticks in a row from the same state x0, enqueued from C (tbnav_mppi_enqueue_rng_batch)."""
+        capi.check(self._L.tbnav_mppi_enqueue_rng_batch(self._h, (C.c_double * 3)(*x0), 0, seed, first_tick, n_ticks, stream or None),
+                   "enqueue_rng_batch")
+
     def newControlsRng(self, x0, seed: int, tick: int, stream: int = 0):
         out = (C.c_double * 2)()
         capi.check(self._L.tbnav_mppi_new_controls_rng(self._h, (C.c_double * 3)(*x0), seed, tick, stream or None, out),

@@ -261,6 +261,25 @@ def test_device_rng_statistics_and_determinism(gpu_pkg):
     assert np.all(np.isfinite(out))
 
 
+def test_batched_production_ticks_equal_one_call_per_tick(gpu_pkg):
+    """tbnav_mppi_enqueue_rng_batch is n tbnav_mppi_enqueue_rng calls made from C: same seed, same ticks -> the same
+    control vector, bit for bit."""
+    import torch
+    d = mppi_cfg(1024, 0.5)
+    a_, b_ = make_mppi(gpu_pkg, d), make_mppi(gpu_pkg, d)
+    for m in (a_, b_):
+        m.setWaypoint(*WAYPOINTS[2])
+    x0 = (0.1, -0.2, 0.3)
+    for t in range(12):
+        a_.enqueueRng(x0, 99, 500 + t, 0)
+    b_.enqueueRngBatch(x0, 99, 500, 5, 0)
+    b_.enqueueRngBatch(x0, 99, 505, 7, 0)
+    torch.cuda.synchronize()
+    assert np.array_equal(a_.getControls(), b_.getControls())
+    assert a_.lastControls(0) == b_.lastControls(0)
+    a_.close(); b_.close()
+
+
 def test_full_size_properties_k65536_t100(gpu_pkg):
     """BASELINE configs[3] size on one GPU (K=65536, T=100): size-independent properties —
     (1) permuting the rollouts leaves the update unchanged (soft-min is a symmetric function),
