@@ -237,9 +237,11 @@ int tbnav_rbpf_particle_map(tbnav_rbpf* h, int32_t particle, int8_t* map);
  * TBNAV_RBPF_OPT_RAYCAST_THREADS 256 | 512 | 1024 threads per workgroup of the tile raycast (default 1024).
  * TBNAV_RBPF_OPT_COUNT_CELLS     1 = the tile raycast counts the cells it updates (tbnav_rbpf_scan_counts).
  * TBNAV_RBPF_OPT_RAYCAST_FORM    0 = box counters, rbpf_raycast_box (default); 1 = rbpf_raycast_tile, the first tile kernel
- *                                (kept for A-B runs).  All forms leave bit-identical maps. */
+ *                                (kept for A-B runs).  All forms leave bit-identical maps.
+ * TBNAV_RBPF_OPT_RAYCAST_BAND_ROWS n > 0 = rbpf_raycast_box keeps at most about n rows of a scan's bounding box in LDS at a
+ *                                time (0 = as many as fit): drives its band loop on small maps (tests). */
 enum { TBNAV_RBPF_OPT_DF_MODE = 1, TBNAV_RBPF_OPT_RAYCAST_ORDERED = 2, TBNAV_RBPF_OPT_RAYCAST_THREADS = 3, TBNAV_RBPF_OPT_COUNT_CELLS = 4,
-       TBNAV_RBPF_OPT_RAYCAST_FORM = 5 };
+       TBNAV_RBPF_OPT_RAYCAST_FORM = 5, TBNAV_RBPF_OPT_RAYCAST_BAND_ROWS = 6 };
 enum { TBNAV_RBPF_DF_FULL = 0, TBNAV_RBPF_DF_WINDOW = 1, TBNAV_RBPF_DF_QUERY = 2, TBNAV_RBPF_DF_REFERENCE = 3 };
 int tbnav_rbpf_set_option(tbnav_rbpf* h, int32_t option, int32_t value);
 /* Since the last reset, summed over particles and scans (TBNAV_RBPF_OPT_COUNT_CELLS on): cell_updates = log-odds

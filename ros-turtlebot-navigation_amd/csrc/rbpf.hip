@@ -2931,6 +2931,7 @@ struct tbnav_rbpf {
   int raycast_threads = 0;     // block size of the tile raycast: 0 = 1024 (TBNAV_RBPF_OPT_RAYCAST_THREADS)
   std::vector<double2> beam_cs;  // (cos, sin) of every beam's angle in the sensor frame, kept between scans
   std::vector<double2> beams_tmp;
+  int raycast_band_rows = 0;   // > 0: cap the LDS array of rbpf_raycast_box at about this many box rows (TBNAV_RBPF_OPT_RAYCAST_BAND_ROWS, tests)
   int raycast_form = 0;        // 0 = box counters (rbpf_raycast_box), 1 = event slots (rbpf_raycast_tile) (TBNAV_RBPF_OPT_RAYCAST_FORM)
   double* d_sens = nullptr;    // [N][4] sensor transform (X, Y, sin, cos) of each particle's new pose, left by the proposal kernel
   uint64_t seed = 0x5EEDull, scan_index = 0;  // device noise source (normals == NULL)
@@ -3279,6 +3280,8 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens)
     // at least one padded row must fit)
     const long cap_fit = ((78L * 1024 - (long)box_lds_bytes(0, (size_t)bvn) - 1536) / 4) & ~7L;
     if (cap_win > cap_fit) cap_win = std::max(cap_fit, (side + 9) & ~7L);
+    // (test hook: at most about this many rows of the box per band, to drive the band loop on small maps)
+    if (h->raycast_band_rows > 0) cap_win = std::min(cap_win, (h->raycast_band_rows * ((side + 2) & ~1L) + 7) & ~7L);
   }
   const size_t lds_win = box_lds_bytes((size_t)cap_win, (size_t)bvn);
   if (cap_win > 0 && !h->ref_field && c.Bv < 32768 && h->raycast_form == 0 && nt >= 512 && lds_win <= (size_t)kMaxLds - 2048) {
@@ -4326,6 +4329,10 @@ int tbnav_rbpf_set_option(tbnav_rbpf* h, int32_t option, int32_t value) {
     case TBNAV_RBPF_OPT_RAYCAST_THREADS:
       if (value != 0 && value != 256 && value != 512 && value != 1024) return TBNAV_ERR_INVALID_ARG;
       h->raycast_threads = value;
+      return TBNAV_OK;
+    case TBNAV_RBPF_OPT_RAYCAST_BAND_ROWS:
+      if (value < 0) return TBNAV_ERR_INVALID_ARG;
+      h->raycast_band_rows = value;
       return TBNAV_OK;
     case TBNAV_RBPF_OPT_RAYCAST_FORM:
       if (value != 0 && value != 1) return TBNAV_ERR_INVALID_ARG;

@@ -118,7 +118,7 @@ def test_configs4_shard_10000_particles_2000x2000_1080_beams(gpu_pkg):
     pf.close()
 
 
-@pytest.mark.parametrize("variant", ["box512", "slots256", "slots512_10bit", "slots1024", "beam_ordered"])
+@pytest.mark.parametrize("variant", ["box512", "box_bands12", "box_bands5", "slots256", "slots512_10bit", "slots1024", "beam_ordered"])
 def test_raycast_kernel_variants_are_bit_exact(gpu_pkg, variant):
     """Every form of the map update — the box-counter kernel with 512 threads (1024 is the default: every other
     test), the first tile kernel with 256 / 512 (10-bit tile fields, 8-event slots) / 1024 threads, and the
@@ -129,6 +129,8 @@ def test_raycast_kernel_variants_are_bit_exact(gpu_pkg, variant):
     pf = _dev(gpu_pkg, N=N, k=k, map_min=-10.0, map_max=10.0)
     if variant == "beam_ordered":
         pf.setOption(capi.RBPF_OPT_RAYCAST_ORDERED, 1)
+    elif variant.startswith("box_bands"):  # the box-counter kernel working the box through in bands of ~12 / ~5 rows
+        pf.setOption(capi.RBPF_OPT_RAYCAST_BAND_ROWS, int(variant[9:]))
     elif variant.startswith("slots"):
         pf.setOption(capi.RBPF_OPT_RAYCAST_FORM, 1)
         pf.setOption(capi.RBPF_OPT_RAYCAST_THREADS, int(variant[5:].split("_")[0]))

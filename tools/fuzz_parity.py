@@ -77,6 +77,11 @@ def rbpf_case(i):
     n_beams = int(round(360 / bd))
     pf_o = orc.PfAPI(orc.pf_params(N=N, k=k, map_min=-half, map_max=half, beam_delta_deg=bd, **extra))
     pf_d = ParticleFilter(default_params(N=N, k=k, map_min=-half, map_max=half, beam_delta_deg=bd, **extra), df_mode=mode)
+    band_rows = int(np.random.default_rng([seed, 3, i]).choice([0, 0, 3, 7, 20]))  # (its own stream: the other draws stay as they were)
+    if band_rows:
+        from rtn_amd import capi
+        pf_d.setOption(capi.RBPF_OPT_RAYCAST_BAND_ROWS, band_rows)
+    desc["band_rows"] = band_rows
     inc = (float(rng.uniform(-0.06, 0.06)), float(rng.uniform(0.01, 0.06)), float(rng.uniform(-0.04, 0.04)))
     steps, poses = rc.trajectory(4, inc=inc, start=(float(rng.uniform(-3.1, 3.1)), 0.0, 0.0))
     walls = (-1.2, 1.1, -1.0, 1.3)
