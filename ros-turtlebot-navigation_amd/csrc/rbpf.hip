@@ -1749,6 +1749,120 @@ __device__ __forceinline__ bool on_ray_packed(int x0, int y0, int x1, int y1, in
   return n >= 1 && n <= r.dmaj - 1 && side;
 }
 
+// ---- normalise / Neff / low-variance selection (sequential order = the reference's) ---------------
+struct NormOut { double sum_w, sq_sum; int neff, resampled; };
+// One workgroup.  The three reductions that decide integers (sum, sum of squares -> Neff, the comb's
+// running sum c) are done by ONE lane in index order — the reference's association — over an LDS copy of
+// the weights (the only serial part: 3N dependent fp64 adds).  Everything else is parallel: the
+// divisions, and the selection itself — with the sequential prefix c[] in hand, slot m's parent is the
+// first i with U_m <= c[i] (the reference's while-loop, particle_filter.cpp:485-493, advances to exactly
+// that i because U_m and c[] are both non-decreasing), found by binary search, clamped to N-1.
+// Any N: the weights pass through LDS in chunks of kNormChunk (parallel loads / divisions, the one lane carries its
+// running sums from chunk to chunk); the prefix c[] lives in LDS when one chunk holds it, else in a global scratch.
+constexpr int kNormChunk = 2048;
+// Left-to-right sum (of squares) of an LDS array by ONE thread, continuing from `acc` — the reference's order
+// (particle_filter.cpp:446-450, 458-461), which Neff and the resampling decision depend on.  The chain of adds is
+// inherent; the loads are not part of it: the next eight values are fetched while the current eight are added.
+template <bool SQ>
+__device__ __forceinline__ double seq_sum(double acc, const double* w, int N) {
+  // 32 values per trip: sixteen 16-byte LDS reads issued together, then the 32 dependent adds and nothing else — a lone wave
+  // issues an instruction every four to five cycles, so every instruction that is not an add stretches the chain (the
+  // first version's register shuffling made it 13 ns per add)
+  const double2* w2 = reinterpret_cast<const double2*>(w);  // (w is 16-byte aligned LDS)
+  int i = 0;
+  for (; i + 32 <= N; i += 32) {
+    double2 a[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) a[q] = w2[(i >> 1) + q];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { acc += SQ ? a[q].x * a[q].x : a[q].x; acc += SQ ? a[q].y * a[q].y : a[q].y; }
+  }
+  for (; i < N; ++i) acc += SQ ? w[i] * w[i] : w[i];
+  return acc;
+}
+// weight_out: where the normalised weights go ([N]; may alias weight).  cs: [N] scratch for the prefix (N > kNormChunk).
+// The body, for one workgroup of any size; w, cl: two LDS arrays of kNormChunk doubles (16-byte aligned).
+struct NormArgs { int N; const double* zp; const double* weight; double* weight_out; double* cs; int* parent; NormOut* out; };
+__device__ __forceinline__ void normalize_body(int N, const double* __restrict__ zp, const double* weight, double* weight_out,
+                                               double* __restrict__ cs, int* __restrict__ parent, NormOut* __restrict__ out,
+                                               double* w, double* cl) {
+  const double z = *zp;  // the one standard normal of lowVarianceResampling (particle_filter.cpp:474)
+  __shared__ double s_acc;
+  __shared__ int s_res;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  if (tid == 0) s_acc = 0.0;
+  for (int base = 0; base < N; base += kNormChunk) {
+    const int n = min(kNormChunk, N - base);
+    __syncthreads();
+    for (int i = tid; i < n; i += nthr) w[i] = weight[base + i];
+    __syncthreads();
+    if (tid == 0) s_acc = seq_sum<false>(s_acc, w, n);
+  }
+  __syncthreads();
+  const double sum = s_acc;
+  __syncthreads();
+  if (tid == 0) s_acc = 0.0;
+  for (int base = 0; base < N; base += kNormChunk) {
+    const int n = min(kNormChunk, N - base);
+    __syncthreads();
+    for (int i = tid; i < n; i += nthr) { const double v = weight[base + i] / sum; w[i] = v; weight_out[base + i] = v; }
+    __syncthreads();
+    if (tid == 0) s_acc = seq_sum<true>(s_acc, w, n);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const double sq = s_acc;
+    const int neff = (int)(1.0 / sq);
+    const int res = (neff < (N / 2)) ? 1 : 0;
+    out->sum_w = sum; out->sq_sum = sq; out->neff = neff; out->resampled = res;
+    s_res = res;
+    s_acc = 0.0;
+  }
+  __syncthreads();
+  if (!s_res) { for (int m = tid; m < N; m += nthr) parent[m] = m; return; }
+  const bool one_chunk = N <= kNormChunk;
+  for (int base = 0; base < N; base += kNormChunk) {
+    const int n = min(kNormChunk, N - base);
+    __syncthreads();
+    if (!one_chunk) for (int i = tid; i < n; i += nthr) w[i] = weight_out[base + i];  // (one chunk: w[] still holds them)
+    __syncthreads();
+    if (tid == 0) {
+      double c = s_acc;  // c = weight(0); c += weight(i), particle_filter.cpp:478,492
+      const double2* w2 = reinterpret_cast<const double2*>(w);
+      double2* c2 = reinterpret_cast<double2*>(cl);
+      int i = 0;
+      for (; i + 16 <= n; i += 16) {
+        double2 a[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] = w2[(i >> 1) + q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { double2 o; c += a[q].x; o.x = c; c += a[q].y; o.y = c; c2[(i >> 1) + q] = o; }
+      }
+      for (; i < n; ++i) { c += w[i]; cl[i] = c; }
+      s_acc = c;
+    }
+    __syncthreads();
+    if (!one_chunk) for (int i = tid; i < n; i += nthr) cs[base + i] = cl[i];
+  }
+  __syncthreads();
+  const double* csr = one_chunk ? cl : cs;
+  const double r = z / (double)N;
+  for (int m = tid; m < N; m += nthr) {
+    const double U = r + (double)(m * (1.0 / (N - 1)));
+    int lo = 0, hi = N - 1;  // first index with U <= cs[i]; N-1 if none (the reference clamps there)
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (U > csr[mid]) lo = mid + 1; else hi = mid;
+    }
+    parent[m] = lo;
+  }
+}
+__global__ __launch_bounds__(256) void rbpf_normalize(int N, const double* __restrict__ zp, const double* weight, double* weight_out,
+                                                      double* __restrict__ cs, int* __restrict__ parent, NormOut* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) double w[kNormChunk], cl[kNormChunk];
+  normalize_body(N, zp, weight, weight_out, cs, parent, out, w, cl);
+}
+
 // ---- the default map update: box counters ------------------------------------------------------------------------
 // Same contract as rbpf_raycast_tile (bit-identical maps) with fewer, cheaper phases:
 //  F. the beams' end-point cells — the only cells that see both l_free and l_occ in one scan, i.e. where the floating-
@@ -1801,8 +1915,16 @@ template <int NT>
 __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, MapT M, const double2* __restrict__ beams,
                                                           const double* __restrict__ pose, const double* __restrict__ sens,
                                                           int* __restrict__ trow_occ, int* __restrict__ n_occ, int* __restrict__ err,
-                                                          int tile_cap, unsigned long long* __restrict__ touched) {
+                                                          int tile_cap, unsigned long long* __restrict__ touched, NormArgs nz) {
   extern __shared__ __attribute__((aligned(16))) int lds_i[];
+  // nz.N > 0: workgroup 0 is not a particle's — it normalises the weights the proposal kernel left and selects the parents
+  // (one workgroup of dependent adds, independent of the maps: it rides in this launch, beside the map updates, instead of
+  // costing a second stream, an event and a dependent boundary); the particles' workgroups follow
+  if (nz.N > 0 && blockIdx.x == 0) {
+    double* w = reinterpret_cast<double*>(lds_i);
+    normalize_body(nz.N, nz.zp, nz.weight, nz.weight_out, nz.cs, nz.parent, nz.out, w, w + kNormChunk);
+    return;
+  }
   const int Bv = c.Bv;
   unsigned int* tile = reinterpret_cast<unsigned int*>(lds_i);         // (tile_cap is a multiple of 8)
   unsigned short* ev = reinterpret_cast<unsigned short*>(lds_i + tile_cap);  // [n_own][kBoxEv]  beam << 1 | occupied  (16 bytes a slot, 16-byte aligned)
@@ -1822,7 +1944,7 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
   __shared__ double robot_v0, robot_v;  // the robot's own cell: its log-odds before the scan / after the adds applied so far
   __shared__ int robot_cnt, robot_left; // beams with a free cell (each adds l_free to the robot's cell once) / adds still to apply
   constexpr int nthr = NT, nw = NT / kWave;
-  const int p = c.p0 + blockIdx.x, tid_k = threadIdx.x, tid = tid_k, lane = tid & (kWave - 1), wid = tid / kWave;
+  const int p = c.p0 + blockIdx.x - (nz.N > 0 ? 1 : 0), tid_k = threadIdx.x, tid = tid_k, lane = tid & (kWave - 1), wid = tid / kWave;
 #ifdef TBNAV_PHASE_PROF
   unsigned long long t_prev_ = wall_clock64();
 #endif
@@ -2578,113 +2700,6 @@ constexpr size_t edt_compact_lds(int smax) { return (size_t)smax * kWave * 4 + (
 constexpr int kEdtRowsA = 144;  // 38.9 KB -> 4 waves per CU
 constexpr int kEdtRowsB = 288;  // 77.8 KB -> 2 waves per CU
 
-// ---- normalise / Neff / low-variance selection (sequential order = the reference's) ---------------
-struct NormOut { double sum_w, sq_sum; int neff, resampled; };
-// One workgroup.  The three reductions that decide integers (sum, sum of squares -> Neff, the comb's
-// running sum c) are done by ONE lane in index order — the reference's association — over an LDS copy of
-// the weights (the only serial part: 3N dependent fp64 adds).  Everything else is parallel: the
-// divisions, and the selection itself — with the sequential prefix c[] in hand, slot m's parent is the
-// first i with U_m <= c[i] (the reference's while-loop, particle_filter.cpp:485-493, advances to exactly
-// that i because U_m and c[] are both non-decreasing), found by binary search, clamped to N-1.
-// Any N: the weights pass through LDS in chunks of kNormChunk (parallel loads / divisions, the one lane carries its
-// running sums from chunk to chunk); the prefix c[] lives in LDS when one chunk holds it, else in a global scratch.
-constexpr int kNormChunk = 2048;
-// Left-to-right sum (of squares) of an LDS array by ONE thread, continuing from `acc` — the reference's order
-// (particle_filter.cpp:446-450, 458-461), which Neff and the resampling decision depend on.  The chain of adds is
-// inherent; the loads are not part of it: the next eight values are fetched while the current eight are added.
-template <bool SQ>
-__device__ __forceinline__ double seq_sum(double acc, const double* w, int N) {
-  // 32 values per trip: sixteen 16-byte LDS reads issued together, then the 32 dependent adds and nothing else — a lone wave
-  // issues an instruction every four to five cycles, so every instruction that is not an add stretches the chain (the
-  // first version's register shuffling made it 13 ns per add)
-  const double2* w2 = reinterpret_cast<const double2*>(w);  // (w is 16-byte aligned LDS)
-  int i = 0;
-  for (; i + 32 <= N; i += 32) {
-    double2 a[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) a[q] = w2[(i >> 1) + q];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) { acc += SQ ? a[q].x * a[q].x : a[q].x; acc += SQ ? a[q].y * a[q].y : a[q].y; }
-  }
-  for (; i < N; ++i) acc += SQ ? w[i] * w[i] : w[i];
-  return acc;
-}
-// weight_out: where the normalised weights go ([N]; may alias weight).  cs: [N] scratch for the prefix (N > kNormChunk).
-__global__ __launch_bounds__(256) void rbpf_normalize(int N, const double* __restrict__ zp, const double* weight, double* weight_out,
-                                                      double* __restrict__ cs, int* __restrict__ parent, NormOut* __restrict__ out) {
-  const double z = *zp;  // the one standard normal of lowVarianceResampling (particle_filter.cpp:474)
-  __shared__ __attribute__((aligned(16))) double w[kNormChunk], cl[kNormChunk];
-  __shared__ double s_acc;
-  __shared__ int s_res;
-  const int tid = threadIdx.x, nthr = blockDim.x;
-  if (tid == 0) s_acc = 0.0;
-  for (int base = 0; base < N; base += kNormChunk) {
-    const int n = min(kNormChunk, N - base);
-    __syncthreads();
-    for (int i = tid; i < n; i += nthr) w[i] = weight[base + i];
-    __syncthreads();
-    if (tid == 0) s_acc = seq_sum<false>(s_acc, w, n);
-  }
-  __syncthreads();
-  const double sum = s_acc;
-  __syncthreads();
-  if (tid == 0) s_acc = 0.0;
-  for (int base = 0; base < N; base += kNormChunk) {
-    const int n = min(kNormChunk, N - base);
-    __syncthreads();
-    for (int i = tid; i < n; i += nthr) { const double v = weight[base + i] / sum; w[i] = v; weight_out[base + i] = v; }
-    __syncthreads();
-    if (tid == 0) s_acc = seq_sum<true>(s_acc, w, n);
-  }
-  __syncthreads();
-  if (tid == 0) {
-    const double sq = s_acc;
-    const int neff = (int)(1.0 / sq);
-    const int res = (neff < (N / 2)) ? 1 : 0;
-    out->sum_w = sum; out->sq_sum = sq; out->neff = neff; out->resampled = res;
-    s_res = res;
-    s_acc = 0.0;
-  }
-  __syncthreads();
-  if (!s_res) { for (int m = tid; m < N; m += nthr) parent[m] = m; return; }
-  const bool one_chunk = N <= kNormChunk;
-  for (int base = 0; base < N; base += kNormChunk) {
-    const int n = min(kNormChunk, N - base);
-    __syncthreads();
-    if (!one_chunk) for (int i = tid; i < n; i += nthr) w[i] = weight_out[base + i];  // (one chunk: w[] still holds them)
-    __syncthreads();
-    if (tid == 0) {
-      double c = s_acc;  // c = weight(0); c += weight(i), particle_filter.cpp:478,492
-      const double2* w2 = reinterpret_cast<const double2*>(w);
-      double2* c2 = reinterpret_cast<double2*>(cl);
-      int i = 0;
-      for (; i + 16 <= n; i += 16) {
-        double2 a[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) a[q] = w2[(i >> 1) + q];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { double2 o; c += a[q].x; o.x = c; c += a[q].y; o.y = c; c2[(i >> 1) + q] = o; }
-      }
-      for (; i < n; ++i) { c += w[i]; cl[i] = c; }
-      s_acc = c;
-    }
-    __syncthreads();
-    if (!one_chunk) for (int i = tid; i < n; i += nthr) cs[base + i] = cl[i];
-  }
-  __syncthreads();
-  const double* csr = one_chunk ? cl : cs;
-  const double r = z / (double)N;
-  for (int m = tid; m < N; m += nthr) {
-    const double U = r + (double)(m * (1.0 / (N - 1)));
-    int lo = 0, hi = N - 1;  // first index with U <= cs[i]; N-1 if none (the reference clamps there)
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (U > csr[mid]) lo = mid + 1; else hi = mid;
-    }
-    parent[m] = lo;
-  }
-}
-
 // free ring = every tile but tile 0 (the shared zero tile, pinned)
 __global__ void rbpf_pool_init(TilePool P) {
   for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i + 1 < P.cap; i += gridDim.x * blockDim.x) P.ring[i] = i + 1;
@@ -2959,8 +2974,6 @@ struct tbnav_rbpf {
   // fabric (a handful of bytes per scan) and the host reads them after the stream sync — no copy kernels, no memset
   int* h_err = nullptr;        // [4] host view; d_err is the device view of the same bytes
   NormOut* h_norm = nullptr;   // host view of d_norm
-  hipStream_t stream2 = nullptr;  // normalise/select runs here, beside the raycast (it only needs the weights)
-  hipEvent_t ev_w = nullptr, ev_n = nullptr;
   bool fstate_dirty = true;    // some d_fstate entry may be non-zero
   double* d_trace = nullptr;   // sampled, p_scan, p_pose, mu, sigma, eta, new_pose, weight_raw
   Trace tr{};
@@ -3244,7 +3257,9 @@ int ref_field_after_scan(tbnav_rbpf* h, bool resampled, int p_first = 0, int p_c
 
 // GridMapper::integrateScan's map update (grid_mapper.cpp:140-178) for particles [c.p0, c.p0 + count) at their poses.
 // sens: the sensor transforms the proposal kernel left for exactly these poses (NULL: the raycast derives them).
-int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens) {
+// nz (optional): the weights' normalise / select step to run with this update — inside the box-counter kernel's launch as
+// workgroup 0 (no second stream, no event), behind the other map-update kernels as a launch of its own.
+int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens, const NormArgs* nz = nullptr) {
   hipStream_t st = h->stream;
   StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
   const int bvn = c.Bv > 0 ? c.Bv : 1;
@@ -3287,12 +3302,15 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens)
   if (cap_win > 0 && !h->ref_field && c.Bv < 32768 && h->raycast_form == 0 && nt >= 512 && lds_win <= (size_t)kMaxLds - 2048) {
     // default: box counters (rbpf_raycast_box)
     unsigned long long* touched = h->count_touched ? h->d_touched : nullptr;
+    const NormArgs na = nz ? *nz : NormArgs{0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const int blocks = count + (nz ? 1 : 0);
+    const size_t lds_launch = nz ? std::max(lds_win, sizeof(double) * 2 * kNormChunk) : lds_win;  // (workgroup 0's two arrays)
     if (nt == 512)
-      hipLaunchKernelGGL((rbpf_raycast_box<512>), dim3(count), dim3(512), lds_win, st, c, h->pool, M, h->d_beams, sp.pose, sens,
-                         h->d_trow[h->cur], h->d_nocc[h->cur], h->d_err, (int)cap_win, touched);
+      hipLaunchKernelGGL((rbpf_raycast_box<512>), dim3(blocks), dim3(512), lds_launch, st, c, h->pool, M, h->d_beams, sp.pose, sens,
+                         h->d_trow[h->cur], h->d_nocc[h->cur], h->d_err, (int)cap_win, touched, na);
     else
-      hipLaunchKernelGGL((rbpf_raycast_box<1024>), dim3(count), dim3(1024), lds_win, st, c, h->pool, M, h->d_beams, sp.pose, sens,
-                         h->d_trow[h->cur], h->d_nocc[h->cur], h->d_err, (int)cap_win, touched);
+      hipLaunchKernelGGL((rbpf_raycast_box<1024>), dim3(blocks), dim3(1024), lds_launch, st, c, h->pool, M, h->d_beams, sp.pose, sens,
+                         h->d_trow[h->cur], h->d_nocc[h->cur], h->d_err, (int)cap_win, touched, na);
     TBNAV_HIP(hipGetLastError());
     return TBNAV_OK;
   }
@@ -3319,6 +3337,10 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens)
                        sp.pose, h->d_trow[h->cur], h->d_nocc[h->cur], h->d_err, log);
   }
   TBNAV_HIP(hipGetLastError());
+  if (nz) {
+    hipLaunchKernelGGL(rbpf_normalize, dim3(1), dim3(256), 0, st, nz->N, nz->zp, nz->weight, nz->weight_out, nz->cs, nz->parent, nz->out);
+    TBNAV_HIP(hipGetLastError());
+  }
   return TBNAV_OK;
 }
 
@@ -3434,24 +3456,19 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
                      h->d_nocc[h->cur], h->d_win, h->d_normals, center, sp.pose, sp.prev, sp.weight, h->tr, h->d_sens, h->d_err);
   TBNAV_HIP(hipGetLastError());
   if (h->timing) TBNAV_HIP(hipEventRecord(h->ev[2], st));
-  // normalise / select needs only the weights the proposal kernel left: it runs on the second stream, beside the
-  // raycast (one workgroup; the chain of adds it is made of would otherwise sit on the critical path).  With
-  // event timing on, everything stays on one stream so that the intervals mean what they say.
+  // normalise / select needs only the weights the proposal kernel left: it rides in the map update's launch as one extra
+  // workgroup (the chain of adds it is made of would otherwise sit on the critical path, and a second stream costs an
+  // event and a dependent boundary).  With event timing on it is a launch of its own, so that the intervals mean what
+  // they say.
+  const double* z_norm = h->d_normals + (size_t)h->N * c.stride_normals;
+  const NormArgs nz{h->N, z_norm, sp.weight, sp.weight, h->d_cs, h->d_parent, h->d_norm};
   auto launch_normalize = [&](hipStream_t s2) -> int {
-    const double* z = h->d_normals + (size_t)h->N * c.stride_normals;
-    hipLaunchKernelGGL(rbpf_normalize, dim3(1), dim3(256), 0, s2, h->N, z, sp.weight, sp.weight, h->d_cs, h->d_parent, h->d_norm);
+    hipLaunchKernelGGL(rbpf_normalize, dim3(1), dim3(256), 0, s2, h->N, z_norm, sp.weight, sp.weight, h->d_cs, h->d_parent, h->d_norm);
     TBNAV_HIP(hipGetLastError());
     return TBNAV_OK;
   };
   const bool overlap = !local_only && !h->timing;
-  if (overlap) {
-    TBNAV_HIP(hipEventRecord(h->ev_w, st));
-    TBNAV_HIP(hipStreamWaitEvent(h->stream2, h->ev_w, 0));
-    rc = launch_normalize(h->stream2);
-    if (rc != TBNAV_OK) return rc;
-    TBNAV_HIP(hipEventRecord(h->ev_n, h->stream2));
-  }
-  rc = launch_raycast(h, c, h->N, h->d_sens);
+  rc = launch_raycast(h, c, h->N, h->d_sens, overlap ? &nz : nullptr);
   if (rc != TBNAV_OK) return rc;
   if (h->timing) TBNAV_HIP(hipEventRecord(h->ev[3], st));
   if (h->full_edt) {
@@ -3476,7 +3493,6 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
     TBNAV_HIP(hipMemsetD32Async((hipDeviceptr_t)h->d_fstate, 0, h->N, st));
     h->fstate_dirty = h->df_mode != 2;
   }
-  if (overlap) TBNAV_HIP(hipStreamWaitEvent(st, h->ev_n, 0));
   TBNAV_HIP(hipStreamSynchronize(st));
   const int* err = h->h_err;
   const NormOut no = *h->h_norm;
@@ -3599,9 +3615,6 @@ int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf*
   if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_norm, sizeof(NormOut), hipHostMallocMapped);
   if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&h->d_err, h->h_err, 0);
   if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&h->d_norm, h->h_norm, 0);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_w, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_n, hipEventDisableTiming);
   const size_t kk = (size_t)h->k;
   const size_t trace_doubles = (size_t)N * (kk * 3 + kk + kk + 3 + 9 + 1 + 3 + 1);
   A((void**)&h->d_trace, sizeof(double) * trace_doubles);
@@ -3770,9 +3783,6 @@ void tbnav_rbpf_destroy(tbnav_rbpf* h) {
   (void)hipFree(h->d_beams); (void)hipFree(h->d_normals); (void)hipFree(h->d_parent); (void)hipFree(h->d_best); (void)hipFree(h->d_best_pose); (void)hipFree(h->d_export); (void)hipFree(h->d_tier); (void)hipFree(h->d_fstate); (void)hipFree(h->d_skip); (void)hipFree(h->d_win); (void)hipFree(h->d_center); (void)hipFree(h->d_score);
   (void)hipFree(h->d_trace);
   (void)hipHostFree(h->h_beams); (void)hipHostFree(h->h_err); (void)hipHostFree(h->h_norm);
-  if (h->ev_w) (void)hipEventDestroy(h->ev_w);
-  if (h->ev_n) (void)hipEventDestroy(h->ev_n);
-  if (h->stream2) (void)hipStreamDestroy(h->stream2);
   for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h->ref;
