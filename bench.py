@@ -224,10 +224,10 @@ def main():
     sync = lambda: torch.cuda.synchronize(device)  # noqa: E731
     if world == 1:
         ticks(args.warmup)
-        sync(); barrier(); sync()
+        sync()  # (one rank: the barrier of the bracket is empty)
         t0 = time.perf_counter()
         ticks(args.steps)
-        sync(); barrier(); sync()
+        sync()
         el = time.perf_counter() - t0
         el_py = time_ticks(tick, sync, args.steps, args.warmup, barrier)  # one Python call per tick, for comparison
     else:
