@@ -120,9 +120,13 @@ int tbnav_rbpf_slam(tbnav_rbpf* h, const float* scan, int32_t n_beams, const dou
                     const double T_icp[3], const double* normals, tbnav_rbpf_stats* out);
 /* Replay of a LOGGED run (what turtle_mapping_node.cpp:459-494 does per laser message, for n_scans messages in a row):
  * scans [n_scans][n_beams]; u [n_scans][3]; odom [n_scans + 1][3] with odom[s] = prev, odom[s + 1] = cur of scan s;
- * icp_ok [n_scans] or NULL (all 1); T_icp [n_scans][3]; noise drawn on the device; out [n_scans].  Exactly n_scans
- * tbnav_rbpf_slam calls (each synchronous), without a trip through the caller's language per scan.  Stops at the
- * first scan whose status is not TBNAV_OK and returns it. */
+ * icp_ok [n_scans] or NULL (all 1); T_icp [n_scans][3]; noise drawn on the device; out [n_scans].  The results of
+ * exactly n_scans tbnav_rbpf_slam calls, bit for bit, without a trip through the caller's language per scan — and, in the
+ * default configuration, without the device waiting for the host between scans: scan s + 1 is enqueued before the host
+ * has seen whether scan s resamples; its kernels check that decision on the device and do nothing if it does, the host
+ * then runs the copies and enqueues scan s + 1 again (TBNAV_RBPF_OPT_BATCH_PIPELINE 0 = one synchronous call per scan).
+ * Stops at the first scan whose status is not TBNAV_OK and returns it; the filter's state after an error is unspecified
+ * (the reference throws there and the node dies). */
 int tbnav_rbpf_slam_batch(tbnav_rbpf* h, const float* scans, int32_t n_beams, int32_t n_scans, const double* u,
                           const double* odom, const int32_t* icp_ok, const double* T_icp, tbnav_rbpf_stats* out);
 
@@ -239,9 +243,10 @@ int tbnav_rbpf_particle_map(tbnav_rbpf* h, int32_t particle, int8_t* map);
  * TBNAV_RBPF_OPT_RAYCAST_FORM    0 = box counters, rbpf_raycast_box (default); 1 = rbpf_raycast_tile, the first tile kernel
  *                                (kept for A-B runs).  All forms leave bit-identical maps.
  * TBNAV_RBPF_OPT_RAYCAST_BAND_ROWS n > 0 = rbpf_raycast_box keeps at most about n rows of a scan's bounding box in LDS at a
- *                                time (0 = as many as fit): drives its band loop on small maps (tests). */
+ *                                time (0 = as many as fit): drives its band loop on small maps (tests).
+ * TBNAV_RBPF_OPT_BATCH_PIPELINE  1 = tbnav_rbpf_slam_batch keeps two scans in the stream (default); 0 = n synchronous calls. */
 enum { TBNAV_RBPF_OPT_DF_MODE = 1, TBNAV_RBPF_OPT_RAYCAST_ORDERED = 2, TBNAV_RBPF_OPT_RAYCAST_THREADS = 3, TBNAV_RBPF_OPT_COUNT_CELLS = 4,
-       TBNAV_RBPF_OPT_RAYCAST_FORM = 5, TBNAV_RBPF_OPT_RAYCAST_BAND_ROWS = 6 };
+       TBNAV_RBPF_OPT_RAYCAST_FORM = 5, TBNAV_RBPF_OPT_RAYCAST_BAND_ROWS = 6, TBNAV_RBPF_OPT_BATCH_PIPELINE = 7 };
 enum { TBNAV_RBPF_DF_FULL = 0, TBNAV_RBPF_DF_WINDOW = 1, TBNAV_RBPF_DF_QUERY = 2, TBNAV_RBPF_DF_REFERENCE = 3 };
 int tbnav_rbpf_set_option(tbnav_rbpf* h, int32_t option, int32_t value);
 /* Since the last reset, summed over particles and scans (TBNAV_RBPF_OPT_COUNT_CELLS on): cell_updates = log-odds

@@ -31,6 +31,7 @@
 #include <cstring>
 #include <new>
 #include <type_traits>
+#include <atomic>
 #include <vector>
 
 #include "common.hpp"
@@ -585,8 +586,10 @@ __global__ __launch_bounds__(kMatchThreads) void rbpf_scanmatch(ScanC c, ScanMat
                                                                 int skip_eq, int df_mode, int radius, int occ_half,
                                                                 const int* __restrict__ n_occ, const int4* __restrict__ win,
                                                                 const double* __restrict__ pose, double* __restrict__ center,
-                                                                double* __restrict__ score, int* __restrict__ err) {
+                                                                double* __restrict__ score, int* __restrict__ err,
+                                                                const int* __restrict__ gate_prev = nullptr) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  if (gate_prev && *gate_prev) return;  // the scan before this one resamples: see rbpf_raycast_box
   const int p = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
   double2* lbeams = reinterpret_cast<double2*>(lds);                       // [Bv]
   double* lut = reinterpret_cast<double*>(lbeams + c.Bv);                 // [kMixLut] mixture term per distance code: the
@@ -712,8 +715,9 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
                                                                 const double* __restrict__ normals, const double* __restrict__ center,
                                                                 double* __restrict__ pose, double* __restrict__ prev_pose,
                                                                 double* __restrict__ weight, Trace tr, double* __restrict__ sens,
-                                                                int* __restrict__ err) {
+                                                                int* __restrict__ err, const int* __restrict__ gate_prev) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  if (gate_prev && *gate_prev) return;  // the scan before this one resamples: see rbpf_raycast_box
   const int p = blockIdx.x;
   const int k = c.k;
   double* smp = lds;               // [k][3]
@@ -1158,8 +1162,10 @@ struct OccLog { int* ev; int* count; int cap; };
 
 __global__ __launch_bounds__(kWave) void rbpf_raycast(ScanC c, TilePool P, MapT M, const double2* __restrict__ beams,
                                                      const double* __restrict__ pose, int* __restrict__ trow_occ,
-                                                     int* __restrict__ n_occ, int* __restrict__ err, OccLog log) {
+                                                     int* __restrict__ n_occ, int* __restrict__ err, OccLog log,
+                                                     const int* __restrict__ gate_prev = nullptr) {
   extern __shared__ __attribute__((aligned(16))) int lds_i[];
+  if (gate_prev && *gate_prev) return;  // the scan before this one resamples: see rbpf_raycast_box
   int* ex = lds_i;         // [Bv]
   int* ey = lds_i + c.Bv;  // [Bv]
   unsigned int* tbits = reinterpret_cast<unsigned int*>(lds_i + 2 * c.Bv);  // [(TT + 31) / 32] tiles this scan writes
@@ -1365,8 +1371,9 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : (NT == 512 ? 8 : 3)) void rbpf
                                                        const double* __restrict__ pose, const double* __restrict__ sens,
                                                        int* __restrict__ trow_occ,
                                                        int* __restrict__ n_occ, int* __restrict__ err, int tile_cap,
-                                                       unsigned long long* __restrict__ touched) {
+                                                       unsigned long long* __restrict__ touched, const int* __restrict__ gate_prev = nullptr) {
   extern __shared__ __attribute__((aligned(16))) int lds_i[];
+  if (gate_prev && *gate_prev) return;  // the scan before this one resamples: see rbpf_raycast_box
   const int Bv = c.Bv;
   int* exy = lds_i;      // [Bv] end-point cell, x | y << 16
   int* own = exy + Bv;   // [n_own] a beam ending in the slot's cell
@@ -1760,6 +1767,7 @@ struct NormOut { double sum_w, sq_sum; int neff, resampled; };
 // Any N: the weights pass through LDS in chunks of kNormChunk (parallel loads / divisions, the one lane carries its
 // running sums from chunk to chunk); the prefix c[] lives in LDS when one chunk holds it, else in a global scratch.
 constexpr int kNormChunk = 2048;
+constexpr int kScanSlots = 4;  // per-scan host-visible results (error flags, normalisation result, staged beams): a ring
 // Left-to-right sum (of squares) of an LDS array by ONE thread, continuing from `acc` — the reference's order
 // (particle_filter.cpp:446-450, 458-461), which Neff and the resampling decision depend on.  The chain of adds is
 // inherent; the loads are not part of it: the next eight values are fetched while the current eight are added.
@@ -1782,10 +1790,16 @@ __device__ __forceinline__ double seq_sum(double acc, const double* w, int N) {
 }
 // weight_out: where the normalised weights go ([N]; may alias weight).  cs: [N] scratch for the prefix (N > kNormChunk).
 // The body, for one workgroup of any size; w, cl: two LDS arrays of kNormChunk doubles (16-byte aligned).
-struct NormArgs { int N; const double* zp; const double* weight; double* weight_out; double* cs; int* parent; NormOut* out; };
+// gate (optional, device memory): 1 if this scan resamples, else 0 — what a scan enqueued BEHIND this one, before the host has
+// seen the decision, checks before it touches anything (gate_prev; see tbnav_rbpf_slam_batch).
+// seq (optional, mapped host memory): set to seq_val once `out` is written and visible to the host — what the host polls
+// instead of waiting for the whole launch.
+struct NormArgs { int N; const double* zp; const double* weight; double* weight_out; double* cs; int* parent; NormOut* out;
+                  int* gate; const int* gate_prev; unsigned int* seq; unsigned int seq_val; };
 __device__ __forceinline__ void normalize_body(int N, const double* __restrict__ zp, const double* weight, double* weight_out,
                                                double* __restrict__ cs, int* __restrict__ parent, NormOut* __restrict__ out,
-                                               double* w, double* cl) {
+                                               double* w, double* cl, int* __restrict__ gate = nullptr,
+                                               unsigned int* seq = nullptr, unsigned int seq_val = 0) {
   const double z = *zp;  // the one standard normal of lowVarianceResampling (particle_filter.cpp:474)
   __shared__ double s_acc;
   __shared__ int s_res;
@@ -1815,6 +1829,11 @@ __device__ __forceinline__ void normalize_body(int N, const double* __restrict__
     const int neff = (int)(1.0 / sq);
     const int res = (neff < (N / 2)) ? 1 : 0;
     out->sum_w = sum; out->sq_sum = sq; out->neff = neff; out->resampled = res;
+    if (gate) *gate = res;
+    if (seq) {
+      __threadfence_system();  // the four stores above reach the host before the flag does
+      __hip_atomic_store(seq, seq_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     s_res = res;
     s_acc = 0.0;
   }
@@ -1858,9 +1877,12 @@ __device__ __forceinline__ void normalize_body(int N, const double* __restrict__
   }
 }
 __global__ __launch_bounds__(256) void rbpf_normalize(int N, const double* __restrict__ zp, const double* weight, double* weight_out,
-                                                      double* __restrict__ cs, int* __restrict__ parent, NormOut* __restrict__ out) {
+                                                      double* __restrict__ cs, int* __restrict__ parent, NormOut* __restrict__ out,
+                                                      int* __restrict__ gate = nullptr, const int* __restrict__ gate_prev = nullptr,
+                                                      unsigned int* seq = nullptr, unsigned int seq_val = 0) {
   __shared__ __attribute__((aligned(16))) double w[kNormChunk], cl[kNormChunk];
-  normalize_body(N, zp, weight, weight_out, cs, parent, out, w, cl);
+  if (gate_prev && *gate_prev) return;
+  normalize_body(N, zp, weight, weight_out, cs, parent, out, w, cl, gate, seq, seq_val);
 }
 
 // ---- the default map update: box counters ------------------------------------------------------------------------
@@ -1917,12 +1939,15 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
                                                           int* __restrict__ trow_occ, int* __restrict__ n_occ, int* __restrict__ err,
                                                           int tile_cap, unsigned long long* __restrict__ touched, NormArgs nz) {
   extern __shared__ __attribute__((aligned(16))) int lds_i[];
+  // enqueued behind a scan whose resampling decision the host had not seen yet: if that scan resamples, this launch does
+  // nothing (the host runs the copies and enqueues this scan again)
+  if (nz.gate_prev && *nz.gate_prev) return;
   // nz.N > 0: workgroup 0 is not a particle's — it normalises the weights the proposal kernel left and selects the parents
   // (one workgroup of dependent adds, independent of the maps: it rides in this launch, beside the map updates, instead of
   // costing a second stream, an event and a dependent boundary); the particles' workgroups follow
   if (nz.N > 0 && blockIdx.x == 0) {
     double* w = reinterpret_cast<double*>(lds_i);
-    normalize_body(nz.N, nz.zp, nz.weight, nz.weight_out, nz.cs, nz.parent, nz.out, w, w + kNormChunk);
+    normalize_body(nz.N, nz.zp, nz.weight, nz.weight_out, nz.cs, nz.parent, nz.out, w, w + kNormChunk, nz.gate, nz.seq, nz.seq_val);
     return;
   }
   const int Bv = c.Bv;
@@ -2969,12 +2994,18 @@ struct tbnav_rbpf {
   NormOut* d_norm = nullptr;
   // pinned host staging: the scan going in, the error flags and the normalisation result coming out (pageable
   // buffers make every one of those small copies a blocking, staged transfer)
-  double2* h_beams = nullptr;  // capacity max_beams
+  double2* h_beams = nullptr;  // [kScanSlots] x capacity max_beams
   // error flags and normalisation result live in mapped pinned host memory: the kernels write them over the
   // fabric (a handful of bytes per scan) and the host reads them after the stream sync — no copy kernels, no memset
-  int* h_err = nullptr;        // [4] host view; d_err is the device view of the same bytes
-  NormOut* h_norm = nullptr;   // host view of d_norm
+  // kScanSlots of each: a scan in flight owns slot (scan number % kScanSlots) — tbnav_rbpf_slam_batch keeps two scans in the
+  // stream; every other entry point uses slot 0
+  int* h_err = nullptr;        // [kScanSlots][4] host view; d_err is the device view of the same bytes
+  NormOut* h_norm = nullptr;   // [kScanSlots] host view of d_norm
+  int* d_gate = nullptr;       // [kScanSlots] device memory: 1 = that scan resamples (NormArgs::gate)
+  unsigned int* h_seq = nullptr;  // [kScanSlots] mapped: the scan number whose normalisation result the slot holds (NormArgs::seq)
+  unsigned int* d_seq = nullptr;  // device view of h_seq
   bool fstate_dirty = true;    // some d_fstate entry may be non-zero
+  int batch_pipeline = 1;      // tbnav_rbpf_slam_batch keeps two scans in the stream (TBNAV_RBPF_OPT_BATCH_PIPELINE)
   double* d_trace = nullptr;   // sampled, p_scan, p_pose, mu, sigma, eta, new_pose, weight_raw
   Trace tr{};
   hipStream_t stream = nullptr;
@@ -3259,7 +3290,9 @@ int ref_field_after_scan(tbnav_rbpf* h, bool resampled, int p_first = 0, int p_c
 // sens: the sensor transforms the proposal kernel left for exactly these poses (NULL: the raycast derives them).
 // nz (optional): the weights' normalise / select step to run with this update — inside the box-counter kernel's launch as
 // workgroup 0 (no second stream, no event), behind the other map-update kernels as a launch of its own.
-int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens, const NormArgs* nz = nullptr) {
+int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens, const NormArgs* nz = nullptr, int* err = nullptr) {
+  if (!err) err = h->d_err;
+  const int* gp = nz ? nz->gate_prev : nullptr;
   hipStream_t st = h->stream;
   StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
   const int bvn = c.Bv > 0 ? c.Bv : 1;
@@ -3302,15 +3335,15 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens,
   if (cap_win > 0 && !h->ref_field && c.Bv < 32768 && h->raycast_form == 0 && nt >= 512 && lds_win <= (size_t)kMaxLds - 2048) {
     // default: box counters (rbpf_raycast_box)
     unsigned long long* touched = h->count_touched ? h->d_touched : nullptr;
-    const NormArgs na = nz ? *nz : NormArgs{0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const NormArgs na = nz ? *nz : NormArgs{0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
     const int blocks = count + (nz ? 1 : 0);
     const size_t lds_launch = nz ? std::max(lds_win, sizeof(double) * 2 * kNormChunk) : lds_win;  // (workgroup 0's two arrays)
     if (nt == 512)
       hipLaunchKernelGGL((rbpf_raycast_box<512>), dim3(blocks), dim3(512), lds_launch, st, c, h->pool, M, h->d_beams, sp.pose, sens,
-                         h->d_trow[h->cur], h->d_nocc[h->cur], h->d_err, (int)cap_win, touched, na);
+                         h->d_trow[h->cur], h->d_nocc[h->cur], err, (int)cap_win, touched, na);
     else
       hipLaunchKernelGGL((rbpf_raycast_box<1024>), dim3(blocks), dim3(1024), lds_launch, st, c, h->pool, M, h->d_beams, sp.pose, sens,
-                         h->d_trow[h->cur], h->d_nocc[h->cur], h->d_err, (int)cap_win, touched, na);
+                         h->d_trow[h->cur], h->d_nocc[h->cur], err, (int)cap_win, touched, na);
     TBNAV_HIP(hipGetLastError());
     return TBNAV_OK;
   }
@@ -3319,7 +3352,7 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens,
   if (cap > 0 && !h->ref_field && c.Bv < 32768 && tile_lds <= (size_t)kMaxLds - 2048) {
     unsigned long long* touched = h->count_touched ? h->d_touched : nullptr;
 #define TBNAV_RAYCAST(NT, FW, EC) hipLaunchKernelGGL((rbpf_raycast_tile<NT, FW, EC>), dim3(count), dim3(NT), tile_lds, st, c, h->pool, M, h->d_beams, sp.pose, sens, \
-                                                     h->d_trow[h->cur], h->d_nocc[h->cur], h->d_err, cap, touched)
+                                                     h->d_trow[h->cur], h->d_nocc[h->cur], err, cap, touched, gp)
     if (small) TBNAV_RAYCAST(512, 10, 8);
     else if (nt == 256) TBNAV_RAYCAST(256, 16, 16);
     else if (nt == 512) TBNAV_RAYCAST(512, 16, 16);
@@ -3334,40 +3367,47 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens,
       if (rc2 != TBNAV_OK) return rc2;
     }
     hipLaunchKernelGGL(rbpf_raycast, dim3(count), dim3(kWave), sizeof(int) * (2 * bvn + (h->TT + 31) / 32), st, c, h->pool, M, h->d_beams,
-                       sp.pose, h->d_trow[h->cur], h->d_nocc[h->cur], h->d_err, log);
+                       sp.pose, h->d_trow[h->cur], h->d_nocc[h->cur], err, log, gp);
   }
   TBNAV_HIP(hipGetLastError());
   if (nz) {
-    hipLaunchKernelGGL(rbpf_normalize, dim3(1), dim3(256), 0, st, nz->N, nz->zp, nz->weight, nz->weight_out, nz->cs, nz->parent, nz->out);
+    hipLaunchKernelGGL(rbpf_normalize, dim3(1), dim3(256), 0, st, nz->N, nz->zp, nz->weight, nz->weight_out, nz->cs, nz->parent, nz->out,
+                       nz->gate, nz->gate_prev, nz->seq, nz->seq_val);
     TBNAV_HIP(hipGetLastError());
   }
   return TBNAV_OK;
 }
 
 // the scan's valid beams into d_beams (shared by slam_impl and the one-particle entry points)
-int upload_beams(tbnav_rbpf* h, const std::vector<double2>& beams, int n_beams, int Bv, bool stage_only = false) {
+int upload_beams(tbnav_rbpf* h, const std::vector<double2>& beams, int n_beams, int Bv, bool stage_only = false, int slot = 0) {
   if (n_beams > h->max_beams) {
+    TBNAV_HIP(hipStreamSynchronize(h->stream));  // (a scan still in flight reads the buffers about to go)
     (void)hipFree(h->d_beams);
     (void)hipHostFree(h->h_beams);
     h->d_beams = nullptr; h->h_beams = nullptr; h->max_beams = 0;
     TBNAV_HIP(hipMalloc((void**)&h->d_beams, sizeof(double2) * n_beams));
-    TBNAV_HIP(hipHostMalloc((void**)&h->h_beams, sizeof(double2) * n_beams, hipHostMallocDefault));
+    TBNAV_HIP(hipHostMalloc((void**)&h->h_beams, sizeof(double2) * n_beams * kScanSlots, hipHostMallocDefault));
     h->max_beams = n_beams;
   }
   if (Bv) {
-    std::memcpy(h->h_beams, beams.data(), sizeof(double2) * Bv);
-    if (!stage_only) TBNAV_HIP(hipMemcpyAsync(h->d_beams, h->h_beams, sizeof(double2) * Bv, hipMemcpyHostToDevice, h->stream));
+    double2* hb = h->h_beams + (size_t)slot * h->max_beams;
+    std::memcpy(hb, beams.data(), sizeof(double2) * Bv);
+    if (!stage_only) TBNAV_HIP(hipMemcpyAsync(h->d_beams, hb, sizeof(double2) * Bv, hipMemcpyHostToDevice, h->stream));
   }
   return TBNAV_OK;
 }
 
-int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], const double cur_odom[3],
-              const double prev_odom[3], int icp_ok, const double T_icp[3], const double* normals,
-              tbnav_rbpf_stats* out, bool local_only) {
-  if (!h || !scan || n_beams <= 0 || !u || !cur_odom || !prev_odom || !T_icp || !out) return TBNAV_ERR_INVALID_ARG;
-  if (h->ref_field && local_only) return TBNAV_ERR_UNSUPPORTED;  // the reference-field mode is a single-handle mode
-  DeviceGuard guard(h->device);
+// One scan = scan_enqueue (everything up to and including the map update, on the handle's stream) + scan_finish (wait,
+// read the stats, run the resampling copies if the scan decided to resample).  `slot`: which of the kScanSlots result slots
+// the scan owns.  gate_prev (device pointer or NULL): the resampling decision of the scan enqueued before this one, when the
+// host has not seen it yet — the kernels of this scan do nothing if it is set (tbnav_rbpf_slam_batch).
+struct ScanTicket { int slot = 0; int n_valid = 0; bool local_only = false; bool poll = false; unsigned int seq = 0; };
+int scan_enqueue(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], const double cur_odom[3],
+                 const double prev_odom[3], int icp_ok, const double T_icp[3], const double* normals,
+                 tbnav_rbpf_stats* out, bool local_only, int slot, const int* gate_prev, ScanTicket& tk) {
   hipStream_t st = h->stream;
+  int* const d_err = h->d_err + 4 * slot;
+  int* const h_err = h->h_err + 4 * slot;
   ++h->scans_done;
   ScanC c;
   std::vector<double2>& beams = h->beams_tmp;  // (kept between calls: no allocation per scan)
@@ -3375,10 +3415,12 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
   std::memset(out, 0, sizeof *out);
   if (rc != TBNAV_OK) { out->status = rc; return rc; }
   out->n_valid_beams = c.Bv;
-  rc = upload_beams(h, beams, n_beams, c.Bv, /*stage_only=*/normals == nullptr);  // device noise: the noise kernel carries the beams over
+  tk.slot = slot; tk.n_valid = c.Bv; tk.local_only = local_only;
+  rc = upload_beams(h, beams, n_beams, c.Bv, /*stage_only=*/normals == nullptr, slot);  // device noise: the noise kernel carries the beams over
   if (rc != TBNAV_OK) return rc;
   const size_t n_norm = (size_t)h->N * c.stride_normals + 1;
   if (n_norm > h->normals_cap) {
+    TBNAV_HIP(hipStreamSynchronize(st));  // (a scan still in flight reads the old buffer)
     (void)hipFree(h->d_normals);
     h->d_normals = nullptr;
     TBNAV_HIP(hipMalloc((void**)&h->d_normals, sizeof(double) * n_norm));
@@ -3389,12 +3431,12 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
   } else {
     const int blocks = (int)std::min<size_t>((n_norm / 2 + 255) / 256, 4096);
     hipLaunchKernelGGL(rbpf_sample_normals, dim3(blocks), dim3(256), 0, st, n_norm, (unsigned long long)h->seed,
-                       (unsigned long long)h->scan_index, h->d_normals, (const double2*)h->h_beams, h->d_beams, c.Bv);
+                       (unsigned long long)h->scan_index, h->d_normals, (const double2*)(h->h_beams + (size_t)slot * h->max_beams), h->d_beams, c.Bv);
     TBNAV_HIP(hipGetLastError());
   }
   ++h->scan_index;
-  for (int q = 0; q < 4; ++q) h->h_err[q] = 0;  // mapped: the previous call has synchronised, nothing is in flight
-  *h->h_norm = NormOut{};
+  for (int q = 0; q < 4; ++q) h_err[q] = 0;  // mapped: the scan that last owned the slot has been waited for
+  h->h_norm[slot] = NormOut{};
   StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
 
   // ---- distance-field refresh for this call's lookups (windowed), then the particle update
@@ -3447,13 +3489,13 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
                           (propose_lds - propose_lds_base);
     hipLaunchKernelGGL(rbpf_scanmatch, dim3(h->N), dim3(kMatchThreads), sm_lds, st, c, h->sm, h->d_beams, h->d_code[h->cur],
                        h->pool, map_of(h), h->d_trow[h->cur], skip_arr, skip_eq, h->df_mode, h->radius, occ_half,
-                       h->d_nocc[h->cur], h->d_win, sp.pose, h->d_center, h->d_score, h->d_err);
+                       h->d_nocc[h->cur], h->d_win, sp.pose, h->d_center, h->d_score, d_err, gate_prev);
     TBNAV_HIP(hipGetLastError());
     center = h->d_center;
   }
   hipLaunchKernelGGL(rbpf_propose, dim3(h->N), dim3(kProposeThreads), propose_lds, st, c, h->d_beams,
                      h->d_code[h->cur], h->pool, map_of(h), h->d_trow[h->cur], skip_arr, skip_eq, h->df_mode, h->radius, occ_half,
-                     h->d_nocc[h->cur], h->d_win, h->d_normals, center, sp.pose, sp.prev, sp.weight, h->tr, h->d_sens, h->d_err);
+                     h->d_nocc[h->cur], h->d_win, h->d_normals, center, sp.pose, sp.prev, sp.weight, h->tr, h->d_sens, d_err, gate_prev);
   TBNAV_HIP(hipGetLastError());
   if (h->timing) TBNAV_HIP(hipEventRecord(h->ev[2], st));
   // normalise / select needs only the weights the proposal kernel left: it rides in the map update's launch as one extra
@@ -3461,14 +3503,17 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
   // event and a dependent boundary).  With event timing on it is a launch of its own, so that the intervals mean what
   // they say.
   const double* z_norm = h->d_normals + (size_t)h->N * c.stride_normals;
-  const NormArgs nz{h->N, z_norm, sp.weight, sp.weight, h->d_cs, h->d_parent, h->d_norm};
+  tk.seq = (unsigned int)h->scans_done;
+  const NormArgs nz{h->N, z_norm, sp.weight, sp.weight, h->d_cs, h->d_parent, h->d_norm + slot, h->d_gate + slot, gate_prev,
+                    tk.poll ? h->d_seq + slot : nullptr, tk.seq};
   auto launch_normalize = [&](hipStream_t s2) -> int {
-    hipLaunchKernelGGL(rbpf_normalize, dim3(1), dim3(256), 0, s2, h->N, z_norm, sp.weight, sp.weight, h->d_cs, h->d_parent, h->d_norm);
+    hipLaunchKernelGGL(rbpf_normalize, dim3(1), dim3(256), 0, s2, h->N, z_norm, sp.weight, sp.weight, h->d_cs, h->d_parent, h->d_norm + slot);
     TBNAV_HIP(hipGetLastError());
     return TBNAV_OK;
   };
   const bool overlap = !local_only && !h->timing;
-  rc = launch_raycast(h, c, h->N, h->d_sens, overlap ? &nz : nullptr);
+  if ((gate_prev || tk.poll) && !overlap) return TBNAV_ERR_INVALID_ARG;  // (a gated or polled scan is a batch scan: never local-only or timed)
+  rc = launch_raycast(h, c, h->N, h->d_sens, overlap ? &nz : nullptr, d_err);
   if (rc != TBNAV_OK) return rc;
   if (h->timing) TBNAV_HIP(hipEventRecord(h->ev[3], st));
   if (h->full_edt) {
@@ -3493,9 +3538,31 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
     TBNAV_HIP(hipMemsetD32Async((hipDeviceptr_t)h->d_fstate, 0, h->N, st));
     h->fstate_dirty = h->df_mode != 2;
   }
-  TBNAV_HIP(hipStreamSynchronize(st));
-  const int* err = h->h_err;
-  const NormOut no = *h->h_norm;
+  return TBNAV_OK;
+}
+
+int scan_finish(tbnav_rbpf* h, const ScanTicket& tk, tbnav_rbpf_stats* out) {
+  hipStream_t st = h->stream;
+  const bool local_only = tk.local_only;
+  int rc = TBNAV_OK;
+  if (tk.poll) {
+    // the normalise / select workgroup raises the slot's flag as soon as its result is in host memory — the host need not
+    // wait for the rest of the map update (error flags raised later in that launch: see tbnav_rbpf_slam_batch)
+    volatile unsigned int* flag = h->h_seq + tk.slot;
+    for (unsigned long spins = 1; *flag != tk.seq; ++spins) {
+      __builtin_ia32_pause();
+      if ((spins & 0xFFFF) == 0) {
+        const hipError_t q = hipStreamQuery(st);
+        if (q == hipSuccess && *flag != tk.seq) return TBNAV_ERR_HIP;  // the stream drained and the flag never came
+        if (q != hipSuccess && q != hipErrorNotReady) TBNAV_HIP(q);
+      }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  } else {
+    TBNAV_HIP(hipStreamSynchronize(st));
+  }
+  const int* err = h->h_err + 4 * tk.slot;
+  const NormOut no = h->h_norm[tk.slot];
   out->status = status_from_err(err);
   out->sum_w = no.sum_w; out->sq_sum = no.sq_sum; out->neff = no.neff; out->resampled = no.resampled;
   bool gathered = false;
@@ -3528,6 +3595,18 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
     if (rc != TBNAV_OK) return rc;
   }
   return out->status;
+}
+
+int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], const double cur_odom[3],
+              const double prev_odom[3], int icp_ok, const double T_icp[3], const double* normals,
+              tbnav_rbpf_stats* out, bool local_only) {
+  if (!h || !scan || n_beams <= 0 || !u || !cur_odom || !prev_odom || !T_icp || !out) return TBNAV_ERR_INVALID_ARG;
+  if (h->ref_field && local_only) return TBNAV_ERR_UNSUPPORTED;  // the reference-field mode is a single-handle mode
+  DeviceGuard guard(h->device);
+  ScanTicket tk;
+  const int rc = scan_enqueue(h, scan, n_beams, u, cur_odom, prev_odom, icp_ok, T_icp, normals, out, local_only, 0, nullptr, tk);
+  if (rc != TBNAV_OK) return rc;
+  return scan_finish(h, tk, out);
 }
 
 }  // namespace
@@ -3611,8 +3690,13 @@ int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf*
   A((void**)&h->d_skip, sizeof(int) * N);
   A((void**)&h->d_win, sizeof(int4) * N);
   A((void**)&h->d_tier, sizeof(int) * N);
-  if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_err, sizeof(int) * 4, hipHostMallocMapped);
-  if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_norm, sizeof(NormOut), hipHostMallocMapped);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_err, sizeof(int) * 4 * kScanSlots, hipHostMallocMapped);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_norm, sizeof(NormOut) * kScanSlots, hipHostMallocMapped);
+  if (e == hipSuccess) { std::memset(h->h_err, 0, sizeof(int) * 4 * kScanSlots); std::memset((void*)h->h_norm, 0, sizeof(NormOut) * kScanSlots); }
+  A((void**)&h->d_gate, sizeof(int) * kScanSlots);
+  if (e == hipSuccess) e = hipMemset(h->d_gate, 0, sizeof(int) * kScanSlots);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_seq, sizeof(unsigned int) * kScanSlots, hipHostMallocMapped);
+  if (e == hipSuccess) { std::memset(h->h_seq, 0, sizeof(unsigned int) * kScanSlots); e = hipHostGetDevicePointer((void**)&h->d_seq, h->h_seq, 0); }
   if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&h->d_err, h->h_err, 0);
   if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&h->d_norm, h->h_norm, 0);
   const size_t kk = (size_t)h->k;
@@ -3782,8 +3866,9 @@ void tbnav_rbpf_destroy(tbnav_rbpf* h) {
   (void)hipFree(h->d_gw); (void)hipFree(h->d_gcs); (void)hipFree(h->d_gparent); (void)hipFree(h->d_gz);
   (void)hipFree(h->d_beams); (void)hipFree(h->d_normals); (void)hipFree(h->d_parent); (void)hipFree(h->d_best); (void)hipFree(h->d_best_pose); (void)hipFree(h->d_export); (void)hipFree(h->d_tier); (void)hipFree(h->d_fstate); (void)hipFree(h->d_skip); (void)hipFree(h->d_win); (void)hipFree(h->d_center); (void)hipFree(h->d_score);
   (void)hipFree(h->d_trace);
-  (void)hipHostFree(h->h_beams); (void)hipHostFree(h->h_err); (void)hipHostFree(h->h_norm);
+  (void)hipHostFree(h->h_beams); (void)hipHostFree(h->h_err); (void)hipHostFree(h->h_norm); (void)hipFree(h->d_gate);
   for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
+  (void)hipHostFree(h->h_seq);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h->ref;
   delete h;
@@ -3824,12 +3909,60 @@ int tbnav_rbpf_slam(tbnav_rbpf* h, const float* scan, int32_t n_beams, const dou
 int tbnav_rbpf_slam_batch(tbnav_rbpf* h, const float* scans, int32_t n_beams, int32_t n_scans, const double* u, const double* odom,
                           const int32_t* icp_ok, const double* T_icp, tbnav_rbpf_stats* out) {
   if (!h || !scans || n_scans <= 0 || !u || !odom || !T_icp || !out) return TBNAV_ERR_INVALID_ARG;
-  for (int s = 0; s < n_scans; ++s) {
-    const int rc = slam_impl(h, scans + (size_t)s * n_beams, n_beams, u + 3 * s, odom + 3 * (s + 1), odom + 3 * s, icp_ok ? icp_ok[s] : 1,
-                             T_icp + 3 * s, nullptr, out + s, false);
-    if (rc != TBNAV_OK) return rc;
+  // Two scans in the stream at a time: scan s + 1 is enqueued BEFORE the host waits for scan s, on the assumption that scan
+  // s does not resample — its kernels check scan s's decision on the device (NormArgs::gate) and do nothing if it does; the
+  // host then runs the copies and enqueues scan s + 1 again.  Between scans the device waits for nothing, and the results
+  // are those of n_scans synchronous calls, bit for bit.  Only in the default configuration (distance look-ups by query: no
+  // per-scan field refresh on the stream; no event timing; not the reference-field mode).
+  const bool pipelined = n_scans > 1 && h->batch_pipeline && h->df_mode == 2 && !h->full_edt && !h->ref_field && !h->timing;
+  if (!pipelined) {
+    for (int s = 0; s < n_scans; ++s) {
+      const int rc = slam_impl(h, scans + (size_t)s * n_beams, n_beams, u + 3 * s, odom + 3 * (s + 1), odom + 3 * s, icp_ok ? icp_ok[s] : 1,
+                               T_icp + 3 * s, nullptr, out + s, false);
+      if (rc != TBNAV_OK) return rc;
+    }
+    return TBNAV_OK;
   }
-  return TBNAV_OK;
+  if (n_beams <= 0) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  ScanTicket tk[2];
+  auto enqueue = [&](int s, const int* gate_prev) {
+    ScanTicket& t = tk[s & 1];
+    t = ScanTicket{};
+    t.poll = true;
+    return scan_enqueue(h, scans + (size_t)s * n_beams, n_beams, u + 3 * s, odom + 3 * (s + 1), odom + 3 * s, icp_ok ? icp_ok[s] : 1,
+                        T_icp + 3 * s, nullptr, out + s, false, s % kScanSlots, gate_prev, t);
+  };
+  int rc = enqueue(0, nullptr);
+  if (rc != TBNAV_OK) return rc;
+  for (int s = 0; s < n_scans; ++s) {
+    const int rc_next = s + 1 < n_scans ? enqueue(s + 1, h->d_gate + s % kScanSlots) : TBNAV_OK;
+    rc = scan_finish(h, tk[s & 1], out + s);
+    if (rc == TBNAV_OK && s > 0) {
+      // scan s - 1 was finished when its weights were normalised, while its map update was still running; that launch is
+      // complete now (scan s ran behind it): anything it flagged after that?
+      const int late = status_from_err(h->h_err + 4 * ((s - 1) % kScanSlots));
+      if (late != TBNAV_OK) {
+        (void)hipStreamSynchronize(h->stream);
+        out[s - 1].status = late;
+        std::memset(out + s, 0, sizeof(tbnav_rbpf_stats) * (size_t)(n_scans - s));
+        return late;
+      }
+    }
+    if (rc != TBNAV_OK || rc_next != TBNAV_OK) {
+      (void)hipStreamSynchronize(h->stream);  // (whatever of scan s + 1 is in the stream: the filter's state after an error is unspecified)
+      return rc != TBNAV_OK ? rc : rc_next;
+    }
+    if (out[s].resampled && s + 1 < n_scans) {
+      // scan s + 1's launches did nothing: same scan number, same noise, again — on the resampled particles
+      --h->scan_index; --h->scans_done;
+      rc = enqueue(s + 1, nullptr);
+      if (rc != TBNAV_OK) { (void)hipStreamSynchronize(h->stream); return rc; }
+    }
+  }
+  TBNAV_HIP(hipStreamSynchronize(h->stream));  // the last scan's map update
+  out[n_scans - 1].status = status_from_err(h->h_err + 4 * ((n_scans - 1) % kScanSlots));
+  return out[n_scans - 1].status;
 }
 
 int tbnav_rbpf_slam_local(tbnav_rbpf* h, const float* scan, int32_t n_beams, const double u[3], const double cur_odom[3],
@@ -4343,6 +4476,10 @@ int tbnav_rbpf_set_option(tbnav_rbpf* h, int32_t option, int32_t value) {
     case TBNAV_RBPF_OPT_RAYCAST_BAND_ROWS:
       if (value < 0) return TBNAV_ERR_INVALID_ARG;
       h->raycast_band_rows = value;
+      return TBNAV_OK;
+    case TBNAV_RBPF_OPT_BATCH_PIPELINE:
+      if (value != 0 && value != 1) return TBNAV_ERR_INVALID_ARG;
+      h->batch_pipeline = value;
       return TBNAV_OK;
     case TBNAV_RBPF_OPT_RAYCAST_FORM:
       if (value != 0 && value != 1) return TBNAV_ERR_INVALID_ARG;

@@ -92,9 +92,10 @@ class ParticleFilter:
             capi.check(rc, "tbnav_rbpf_slam")
         return st
 
-    def SLAMBatch(self, scans, u, odom, T_icp, icp_ok=None):
+    def SLAMBatch(self, scans, u, odom, T_icp, icp_ok=None, check=True):
         """Replay of a logged run (tbnav_rbpf_slam_batch): scans [n][n_beams], u [n][3], odom [n + 1][3] (odom[s] = prev,
-        odom[s + 1] = cur), T_icp [n][3]; device noise.  Returns the list of per-scan stats."""
+        odom[s + 1] = cur), T_icp [n][3]; device noise.  Returns the list of per-scan stats (check=False: also when a
+        scan's status stopped the replay — the stats of the scans after it are zero)."""
         scans = np.ascontiguousarray(scans, dtype=np.float32)
         n, nb = scans.shape
         u = np.ascontiguousarray(u, dtype=np.float64).reshape(n, 3)
@@ -104,7 +105,8 @@ class ParticleFilter:
         out = (capi.RbpfStats * n)()
         rc = self._L.tbnav_rbpf_slam_batch(self._h, scans.ctypes.data, nb, n, u.ctypes.data, odom.ctypes.data,
                                            None if ok is None else ok.ctypes.data, T_icp.ctypes.data, C.cast(out, C.c_void_p))
-        capi.check(rc, "tbnav_rbpf_slam_batch")
+        if check:
+            capi.check(rc, "tbnav_rbpf_slam_batch")
         self.last_stats = out[n - 1]
         return list(out)
 

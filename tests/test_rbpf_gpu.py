@@ -505,3 +505,67 @@ def test_batch_replay_equals_one_call_per_scan(gpu_pkg):
     for m in (0, 17, N - 1):
         assert np.array_equal(a.logOdds(m), b.logOdds(m))
     a.close(); b.close()
+
+
+def _logged_run(n_scans, seed):
+    steps, poses = rc.trajectory(n_scans, inc=(0.05, 0.04, 0.03))
+    rng = np.random.default_rng(seed)
+    scans = np.stack([orc.room_scan(poses[s], walls=rc.ROOM_SMALL, rng=rng) for s in range(n_scans)])
+    odom = np.array([steps[0][0]] + [st[1] for st in steps], dtype=np.float64)
+    u = np.array([st[3] for st in steps], dtype=np.float64)
+    t_icp = np.array([st[2] for st in steps], dtype=np.float64)
+    return steps, scans, odom, u, t_icp
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("matcher", [False, True])
+def test_pipelined_batch_equals_synchronous_scans_across_resamples(gpu_pkg, matcher):
+    """tbnav_rbpf_slam_batch keeps two scans in the stream: scan s + 1 is enqueued before the host knows whether scan s
+    resamples, and does nothing on the device if it does.  A run that resamples in the middle must come out bit for bit
+    like one synchronous call per scan, and like the batch with the pipeline switched off."""
+    N, k, n_scans = 48, 10, 16
+    steps, scans_all, odom_all, u_all, t_all = _logged_run(n_scans + 2, 5)
+    scans, odom, u, t_icp = scans_all[:n_scans], odom_all[:n_scans + 1], u_all[:n_scans], t_all[:n_scans]
+    # wider sampling and a sharper sensor model than the shipped ones: the weights spread and the run resamples by itself
+    # (scans 8, 10, 11 and 14 without the matcher — twice in a row among them)
+    pfs = [_dev(gpu_pkg, N=N, k=k, sigma_hit=0.02, sample_range=[1e-5, 3e-4, 3e-4]) for _ in range(3)]
+    for pf in pfs:
+        pf.setSeed(1234)
+        if matcher:
+            pf.setScanMatching(True)
+    pfs[2].setOption(gpu_pkg.capi.RBPF_OPT_BATCH_PIPELINE, 0)
+    one = [pfs[0].SLAM(scans[s], steps[s][3], steps[s][1], steps[s][0], True, steps[s][2], None) for s in range(n_scans)]
+    piped = pfs[1].SLAMBatch(scans, u, odom, t_icp)
+    plain = pfs[2].SLAMBatch(scans, u, odom, t_icp)
+    fired = [s for s in range(n_scans) if one[s].resampled]
+    assert any(0 < s < n_scans - 1 for s in fired), "the run must resample in the middle for this test to mean anything"
+    for other in (piped, plain):
+        for x, y in zip(one, other):
+            assert (x.status, x.neff, x.resampled, x.n_valid_beams) == (y.status, y.neff, y.resampled, y.n_valid_beams)
+            assert x.sum_w == y.sum_w and x.sq_sum == y.sq_sum
+    ref = pfs[0].particles()
+    for pf in pfs[1:]:
+        got = pf.particles()
+        for q in range(3):
+            assert np.array_equal(ref[q], got[q])
+        for m in range(0, N, 5):
+            assert np.array_equal(pfs[0].logOdds(m), pf.logOdds(m))
+    # and the replay can go on from where the batch stopped
+    more = [pf.SLAMBatch(scans_all[n_scans:], u_all[n_scans:], odom_all[n_scans:], t_all[n_scans:]) for pf in pfs[1:]]
+    assert [(x.neff, x.sum_w) for x in more[0]] == [(x.neff, x.sum_w) for x in more[1]]
+    for pf in pfs:
+        pf.close()
+
+
+@pytest.mark.gpu
+def test_pipelined_batch_stops_at_the_first_failing_scan(gpu_pkg):
+    N, k, n_scans = 16, 5, 5
+    steps, scans, odom, u, t_icp = _logged_run(n_scans, 9)
+    scans[2, :] = 3.0  # end points outside the +-2 m world: the reference throws in scan 2
+    pf = _dev(gpu_pkg, N=N, k=k)
+    pf.setSeed(3)
+    out = pf.SLAMBatch(scans, u, odom, t_icp, check=False)
+    assert [o.status for o in out[:3]] == [0, 0, gpu_pkg.capi.ERR_OUT_OF_WORLD]
+    with pytest.raises(gpu_pkg.capi.TbnavError):
+        pf.SLAMBatch(scans, u, odom, t_icp)
+    pf.close()

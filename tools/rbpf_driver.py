@@ -11,6 +11,11 @@ n_scans = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 dev_noise = len(sys.argv) > 3 and sys.argv[3] == "dev"   # standard normals drawn on the device (bench mode)
 pf = ParticleFilter(default_params(N=N, k=50, map_min=-10.0, map_max=10.0))
 steps, scans = bench_rbpf.workload(n_scans)   # the bench's room: all 360 beams valid
+if len(sys.argv) > 3 and sys.argv[3] == "batch":   # the whole run as ONE tbnav_rbpf_slam_batch call (two scans in the stream)
+    odom = np.array([steps[0][0]] + [st[1] for st in steps]); u_all = np.array([st[3] for st in steps]); t_all = np.array([st[2] for st in steps])
+    out = pf.SLAMBatch(np.stack(scans[:n_scans]), u_all, odom, t_all)
+    print(out[-1].neff)
+    sys.exit(0)
 for s, (prev, cur, t_icp, u) in enumerate(steps):
     scan = scans[s]
     if s in bench_rbpf.RESAMPLE_AT:

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Device timeline of the kernels of the last scans of a cfg3 run (rocprofv3 --kernel-trace): start / end / gap to the previous
-# kernel, in us.  Run on the GPU box from the repo root: tools/rbpf_scan_timeline.sh [N]
-root=$(pwd); N=${1:-1000}
+# kernel, in us.  Run on the GPU box from the repo root: tools/rbpf_scan_timeline.sh [N] [dev|batch]
+root=$(pwd); N=${1:-1000}; mode=${2:-dev}   # mode: dev = one call per scan, batch = one tbnav_rbpf_slam_batch call
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/tl
-timeout -k 5 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -o run -- python "$root/tools/rbpf_driver.py" $N 10 dev > /tmp/tl.log 2>&1
+timeout -k 5 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -o run -- python "$root/tools/rbpf_driver.py" $N 10 $mode > /tmp/tl.log 2>&1
 f=$(find /tmp/tl -name "*kernel_trace.csv" | head -1)
 python - "$f" <<'PY'
 import csv, sys, re
