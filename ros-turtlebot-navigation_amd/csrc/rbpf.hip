@@ -16,7 +16,7 @@
 //                         the tiles' occupancy bits kept current         (grid_mapper.cpp:140-178, :549-807)
 //   rbpf_raycast          fallback when the tile cannot hold the scan: one wave per particle, beams in order
 //   rbpf_normalize(_seq)  sequential-order normalise / Neff / low-variance selection (particle_filter.cpp:442-500)
-//   rbpf_gather           copy parents into the alternate buffers after a resample (:495 deep copies)
+//   rbpf_resample_apply   tables, reference counts and parents' state into the alternate buffers after a resample (:495 deep copies)
 //   rbpf_argmax, rbpf_export_map   getRobotState / newMap on the device (:255-291, grid_mapper.cpp:185-226)
 //   rbpf_densify          dense bitmap rows of a range of particles from their tiles, for the exact-transform kernels
 //   rbpf_window, rbpf_edt_compact<R>, rbpf_edt<C>, rbpf_field_by_query
@@ -120,7 +120,7 @@ struct ScanC {  // everything constant during one SLAM call
 //   table[p][ti * TW + tj] = id of the tile holding cells (32*ti .. 32*ti+31, 32*tj .. 32*tj+31); id 0 = the shared
 //   all-zero tile (a cell nobody has touched has log-odds 0 = log_odds_prior_, grid_mapper.cpp:42-58);
 //   ref[id] = how many table (and shed) entries name the tile.
-// A resample copies tables and bumps counts (rbpf_resample_tables / rbpf_release_tables) instead of copying maps;
+// A resample copies tables and adjusts counts (rbpf_resample_apply) instead of copying maps;
 // the raycast makes a tile private on first write (tile_make_private): it takes a fresh tile from the free ring,
 // copies (or zero-fills) 8 KB, and notes the tile it left in shed[p][t].  Counts of shared tiles are NOT touched
 // while a scan runs (every sharer sees a stable count > 1 and copies); the shed notes are settled at the next
@@ -513,8 +513,12 @@ __device__ __forceinline__ void philox4x32_10(unsigned long long ctr, unsigned l
 }
 // (also carries the scan's beam table from pinned host memory to the device — n_copy entries, 0 = none: one launch and
 //  one dependent boundary fewer per scan than a separate copy)
+// blockIdx.y: scan within a chunk of consecutive scans (tbnav_rbpf_slam_batch draws a few scans ahead in one launch) — scan
+// number scan + y, normals at out + y * out_stride, beam tables at + y * beam_stride.
 __global__ void rbpf_sample_normals(size_t n, unsigned long long seed, unsigned long long scan, double* __restrict__ out,
-                                    const double2* __restrict__ host_beams, double2* __restrict__ dev_beams, int n_copy) {
+                                    const double2* __restrict__ host_beams, double2* __restrict__ dev_beams, int n_copy,
+                                    size_t out_stride = 0, size_t beam_stride = 0) {
+  scan += blockIdx.y; out += blockIdx.y * out_stride; host_beams += blockIdx.y * beam_stride; dev_beams += blockIdx.y * beam_stride;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_copy; i += gridDim.x * blockDim.x) dev_beams[i] = host_beams[i];
   const size_t pairs = (n + 1) / 2;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += (size_t)gridDim.x * blockDim.x) {
@@ -1795,11 +1799,11 @@ __device__ __forceinline__ double seq_sum(double acc, const double* w, int N) {
 // seq (optional, mapped host memory): set to seq_val once `out` is written and visible to the host — what the host polls
 // instead of waiting for the whole launch.
 struct NormArgs { int N; const double* zp; const double* weight; double* weight_out; double* cs; int* parent; NormOut* out;
-                  int* gate; const int* gate_prev; unsigned int* seq; unsigned int seq_val; };
+                  int* gate; const int* gate_prev; unsigned int* seq; unsigned int seq_val; int* children; };
 __device__ __forceinline__ void normalize_body(int N, const double* __restrict__ zp, const double* weight, double* weight_out,
                                                double* __restrict__ cs, int* __restrict__ parent, NormOut* __restrict__ out,
                                                double* w, double* cl, int* __restrict__ gate = nullptr,
-                                               unsigned int* seq = nullptr, unsigned int seq_val = 0) {
+                                               unsigned int* seq = nullptr, unsigned int seq_val = 0, int* __restrict__ children = nullptr) {
   const double z = *zp;  // the one standard normal of lowVarianceResampling (particle_filter.cpp:474)
   __shared__ double s_acc;
   __shared__ int s_res;
@@ -1875,14 +1879,39 @@ __device__ __forceinline__ void normalize_body(int N, const double* __restrict__
     }
     parent[m] = lo;
   }
+  if (!children) return;
+  // children[i] = how many slots chose parent i (optional): what the table / reference-count kernel needs per OLD particle.
+  // parent[] is non-decreasing, so a parent's children are one run: its first slot finds the run's end by bisection.
+  __threadfence_block();
+  __syncthreads();
+  const int* par = parent;
+  if (one_chunk) {  // (w[] is free by now: an LDS copy of parent[] for the bisections)
+    int* pl = reinterpret_cast<int*>(w);
+    for (int m = tid; m < N; m += nthr) pl[m] = parent[m];
+    par = pl;
+  }
+  for (int m = tid; m < N; m += nthr) children[m] = 0;
+  __threadfence_block();
+  __syncthreads();
+  for (int m = tid; m < N; m += nthr) {
+    const int me = par[m];
+    if (m > 0 && par[m - 1] == me) continue;
+    int lo = m, hi = N;  // first index > m whose parent is not `me`
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (par[mid] == me) lo = mid; else hi = mid;
+    }
+    children[me] = hi - m;
+  }
 }
 __global__ __launch_bounds__(256) void rbpf_normalize(int N, const double* __restrict__ zp, const double* weight, double* weight_out,
                                                       double* __restrict__ cs, int* __restrict__ parent, NormOut* __restrict__ out,
                                                       int* __restrict__ gate = nullptr, const int* __restrict__ gate_prev = nullptr,
-                                                      unsigned int* seq = nullptr, unsigned int seq_val = 0) {
+                                                      unsigned int* seq = nullptr, unsigned int seq_val = 0,
+                                                      int* __restrict__ children = nullptr) {
   __shared__ __attribute__((aligned(16))) double w[kNormChunk], cl[kNormChunk];
   if (gate_prev && *gate_prev) return;
-  normalize_body(N, zp, weight, weight_out, cs, parent, out, w, cl, gate, seq, seq_val);
+  normalize_body(N, zp, weight, weight_out, cs, parent, out, w, cl, gate, seq, seq_val, children);
 }
 
 // ---- the default map update: box counters ------------------------------------------------------------------------
@@ -1947,7 +1976,8 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
   // costing a second stream, an event and a dependent boundary); the particles' workgroups follow
   if (nz.N > 0 && blockIdx.x == 0) {
     double* w = reinterpret_cast<double*>(lds_i);
-    normalize_body(nz.N, nz.zp, nz.weight, nz.weight_out, nz.cs, nz.parent, nz.out, w, w + kNormChunk, nz.gate, nz.seq, nz.seq_val);
+    normalize_body(nz.N, nz.zp, nz.weight, nz.weight_out, nz.cs, nz.parent, nz.out, w, w + kNormChunk, nz.gate, nz.seq, nz.seq_val,
+                   nz.children);
     return;
   }
   const int Bv = c.Bv;
@@ -2736,37 +2766,75 @@ __global__ void rbpf_pool_init(TilePool P) {
 // old generation's references — table entries and the shed notes of tiles left since the last resample — are
 // dropped and tiles nobody names any more go back to the free ring (pass 2, a separate launch: no count may reach
 // zero before every new reference is in).  16 KB of table per particle at 2000 x 2000 instead of a 32 MB map.
-__global__ __launch_bounds__(256) void rbpf_resample_tables(int N, int TT, const int* __restrict__ parent, const unsigned int* __restrict__ tab_old,
-                                                            unsigned int* __restrict__ tab_new, int* __restrict__ ref) {
+// One pass over the [N][TT] table entries does both halves of a resample's bookkeeping (children[i] = how many slots chose
+// particle i; the new tables go to the alternate buffer, so the two halves do not see each other):
+//  A. slot m's new table is its parent's old one;
+//  B. old particle i held one reference on each tile its table named: its children hold children[i] now.  A tile nobody
+//     else referenced (count 1 — nobody else can be touching it) gets the new count with a plain store, or goes back to the
+//     pool when the particle died; a shared tile takes ONE atomic add of the difference.  While some holder has not been
+//     through yet the count stays above zero (every holder still counts 1), so the add that lands on zero is the last
+//     word on that tile.  Tiles a slot stopped using since the last resample (shed) are released likewise.
+// Freed tiles go back with one atomic on the ring's tail per WORKGROUP and round (lane-private pushes queue on that word:
+// ~90 atomics per microsecond on one address, and a resample that kills 900 of 1000 particles frees 13 000 tiles).  Instead of one atomic per child and tile plus one per old entry, in two launches.
+__device__ __forceinline__ void resample_tables_body(int N, int TT, const int* __restrict__ parent, const int* __restrict__ children,
+                                                     const unsigned int* __restrict__ tab_old, unsigned int* __restrict__ tab_new,
+                                                     unsigned int* __restrict__ shed, const TilePool& P, int block, int nblocks) {
   const size_t n = (size_t)N * TT;
-  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
-    const int m = (int)(e / TT), t = (int)(e - (size_t)m * TT);
-    const unsigned int id = tab_old[(size_t)parent[m] * TT + t];
-    tab_new[e] = id;
-    if (id) atomicAdd(&ref[id], 1);
-  }
-}
-__global__ __launch_bounds__(256) void rbpf_release_tables(int N, int TT, const unsigned int* __restrict__ tab_old, unsigned int* __restrict__ shed,
-                                                           TilePool P) {
-  const size_t n = (size_t)N * TT;
-  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
-    const unsigned int id = tab_old[e], sh = shed[e];
-    if (id && atomicSub(&P.ref[id], 1) == 1) tile_push(P, id);
-    if (sh) { if (atomicSub(&P.ref[sh], 1) == 1) tile_push(P, sh); shed[e] = 0u; }
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave, nw = blockDim.x / kWave;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  __shared__ int s_wave_total[16];
+  __shared__ unsigned long long s_base;
+  for (size_t e0 = (size_t)block * blockDim.x; e0 < n; e0 += (size_t)nblocks * blockDim.x) {
+    const size_t e = e0 + threadIdx.x;
+    unsigned int freed[2] = {0u, 0u};
+    if (e < n) {
+      const int m = (int)(e / TT), t = (int)(e - (size_t)m * TT);
+      tab_new[e] = tab_old[(size_t)parent[m] * TT + t];
+      const unsigned int id = tab_old[e], sh = shed[e];
+      const int c = children[m];
+      if (id && c != 1) {
+        if (P.ref[id] == 1) { P.ref[id] = c; if (c == 0) freed[0] = id; }
+        else if (atomicAdd(&P.ref[id], c - 1) + (c - 1) == 0) freed[0] = id;
+      }
+      if (sh) { if (atomicSub(&P.ref[sh], 1) == 1) freed[1] = sh; shed[e] = 0u; }
+    }
+    // (the trip count is the same for the whole workgroup: barriers inside the loop are safe)
+    const unsigned long long m0 = __ballot(freed[0] != 0u), m1 = __ballot(freed[1] != 0u);
+    const int total = __popcll(m0) + __popcll(m1);
+    if (lane == 0) s_wave_total[wid] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int sum = 0;
+      for (int q = 0; q < nw; ++q) { const int v = s_wave_total[q]; s_wave_total[q] = sum; sum += v; }  // -> exclusive prefix
+      s_base = sum ? atomicAdd(P.ctr + 1, (unsigned long long)sum) : 0ull;
+    }
+    __syncthreads();
+    unsigned long long at = s_base + s_wave_total[wid] + __popcll(m0 & below) + __popcll(m1 & below);
+    if (freed[0]) P.ring[at++ % P.cap] = freed[0];
+    if (freed[1]) P.ring[at % P.cap] = freed[1];
+    __syncthreads();  // (s_wave_total is rewritten by the next round)
   }
 }
 // Everything else a particle owns: pose / prev_pose / weight (weights are NOT reset, :495), its occupied counts (per tile
 // row and total; the occupancy BITS live in the tiles and follow the tables), the state of its stored distance field and — only where that field is authoritative (injected or
 // materialised, state 2; always in the stored-field modes) — the field itself.  grid (N, chunks).
-__global__ __launch_bounds__(256) void rbpf_gather(int N, size_t G, int TW, const int* __restrict__ parent,
-                                                   const double* __restrict__ st_src, double* __restrict__ st_dst,
-                                                   const int* __restrict__ rc_src, int* __restrict__ rc_dst,
-                                                   const int* __restrict__ nocc_src, int* __restrict__ nocc_dst,
-                                                   const int* __restrict__ fs_src, int* __restrict__ fs_dst,
-                                                   const uint16_t* __restrict__ cd_src, uint16_t* __restrict__ cd_dst, int copy_all_codes) {
-  const int m = blockIdx.x;
+struct GatherArgs {
+  size_t G; int TW;
+  const double* st_src; double* st_dst;
+  const int* rc_src; int* rc_dst;
+  const int* nocc_src; int* nocc_dst;
+  const int* fs_src; int* fs_dst;
+  const uint16_t* cd_src; uint16_t* cd_dst; int copy_all_codes;
+};
+__device__ __forceinline__ void gather_body(int N, const int* __restrict__ parent, const GatherArgs& a, int m, int chunk, int chunks) {
+  const size_t G = a.G; const int TW = a.TW;
+  const double* __restrict__ st_src = a.st_src; double* __restrict__ st_dst = a.st_dst;
+  const int* __restrict__ rc_src = a.rc_src; int* __restrict__ rc_dst = a.rc_dst;
+  const int* __restrict__ nocc_src = a.nocc_src; int* __restrict__ nocc_dst = a.nocc_dst;
+  const int* __restrict__ fs_src = a.fs_src; int* __restrict__ fs_dst = a.fs_dst;
+  const uint16_t* __restrict__ cd_src = a.cd_src; uint16_t* __restrict__ cd_dst = a.cd_dst; const int copy_all_codes = a.copy_all_codes;
   const int src = parent[m];
-  const size_t t0 = (size_t)blockIdx.y * blockDim.x + threadIdx.x, stride = (size_t)gridDim.y * blockDim.x;
+  const size_t t0 = (size_t)chunk * blockDim.x + threadIdx.x, stride = (size_t)chunks * blockDim.x;
   for (size_t t = t0; t < (size_t)TW; t += stride) rc_dst[(size_t)m * TW + t] = rc_src[(size_t)src * TW + t];
   const int fs = fs_src[src];
   if (cd_src && (copy_all_codes || fs == 2)) {
@@ -2783,6 +2851,18 @@ __global__ __launch_bounds__(256) void rbpf_gather(int N, size_t G, int TW, cons
     }
     st_dst[(size_t)6 * N + m] = st_src[(size_t)6 * N + src];
   }
+}
+// lowVarianceResampling's copies (particle_filter.cpp:495) in ONE launch: workgroups [0, table_blocks) do the tables and the
+// reference counts, the next N * chunks gather slot m's state from its parent.
+constexpr int kResampleThreads = 1024;
+__global__ __launch_bounds__(kResampleThreads) void rbpf_resample_apply(int N, int TT, const int* __restrict__ parent, const int* __restrict__ children,
+                                                           const unsigned int* __restrict__ tab_old, unsigned int* __restrict__ tab_new,
+                                                           unsigned int* __restrict__ shed, TilePool P, int table_blocks, int chunks,
+                                                           GatherArgs ga) {
+  const int b = blockIdx.x;
+  if (b < table_blocks) { resample_tables_body(N, TT, parent, children, tab_old, tab_new, shed, P, b, table_blocks); return; }
+  const int g = b - table_blocks;
+  gather_body(N, parent, ga, g / chunks, g % chunks, chunks);
 }
 
 // ---- dense views of one particle's tiled log-odds (tbnav_rbpf_get/set_log_odds, parity hooks) ------------------
@@ -2957,7 +3037,12 @@ struct tbnav_rbpf {
   int max_beams = 0;
   double* d_normals = nullptr;
   size_t normals_cap = 0;
-  int* d_parent = nullptr;
+  const double* last_normals = nullptr;  // the normals the last scan used (d_normals, or an entry of the batch ring)
+  // tbnav_rbpf_slam_batch draws the noise of a few scans ahead in one launch: normals and beam tables of ring_scans scans
+  double* d_norm_ring = nullptr; size_t norm_ring_stride = 0;
+  double2* d_beam_ring = nullptr; double2* h_beam_ring = nullptr; size_t beam_ring_stride = 0;
+  int ring_scans = 0;
+  int* d_parent = nullptr;     // [2][N]: the parent of every slot | how many slots chose each particle
   ExportCuts cuts{};           // host-derived (glibc) log-odds break points of the int8 map export
   int* d_best = nullptr;       // arg-max particle index
   double* d_best_pose = nullptr;
@@ -3214,23 +3299,20 @@ int ensure_full_field(tbnav_rbpf* h, int particle) {
   return TBNAV_OK;
 }
 
-// lowVarianceResampling's copies on the device: d_parent holds the parent of every slot.  Tables and counts first
-// (two launches, see rbpf_resample_tables), then state / counts / field state into the alternate buffers (the
-// occupancy bits travel with the tiles: nothing of map size is copied).
+// lowVarianceResampling's copies on the device: d_parent holds the parent of every slot and, behind them, how many slots
+// chose each particle.  One launch (rbpf_resample_apply): tables and reference counts, and state / counts / field state
+// into the alternate buffers (the occupancy bits travel with the tiles: nothing of map size is copied).
 int resample_on_device(tbnav_rbpf* h) {
   const int N = h->N, nxt = 1 - h->cur;
   hipStream_t st = h->stream;
   const size_t n = (size_t)N * h->TT;
-  const int blocks = (int)std::min<size_t>((n + 255) / 256, 16384);
-  hipLaunchKernelGGL(rbpf_resample_tables, dim3(blocks), dim3(256), 0, st, N, h->TT, h->d_parent, h->d_table[h->cur], h->d_table[nxt], h->pool.ref);
-  TBNAV_HIP(hipGetLastError());
-  hipLaunchKernelGGL(rbpf_release_tables, dim3(blocks), dim3(256), 0, st, N, h->TT, h->d_table[h->cur], h->d_shed, h->pool);
-  TBNAV_HIP(hipGetLastError());
+  const int blocks = (int)std::min<size_t>((n + kResampleThreads - 1) / kResampleThreads, 8192);
   const size_t work = h->d_code[0] ? h->G / 4 : (size_t)0;
   const int chunks = (int)std::min<size_t>(std::max<size_t>(work / 2048, 1), 64);
-  hipLaunchKernelGGL(rbpf_gather, dim3(N, chunks), dim3(256), 0, st, N, h->G, h->TW, h->d_parent, h->d_state[h->cur], h->d_state[nxt],
-                     h->d_trow[h->cur], h->d_trow[nxt], h->d_nocc[h->cur], h->d_nocc[nxt],
-                     h->d_fstate, h->d_fstate_alt, h->d_code[h->cur], h->d_code[nxt], h->df_mode != 2 ? 1 : 0);
+  const GatherArgs ga{h->G, h->TW, h->d_state[h->cur], h->d_state[nxt], h->d_trow[h->cur], h->d_trow[nxt], h->d_nocc[h->cur], h->d_nocc[nxt],
+                      h->d_fstate, h->d_fstate_alt, h->d_code[h->cur], h->d_code[nxt], h->df_mode != 2 ? 1 : 0};
+  hipLaunchKernelGGL(rbpf_resample_apply, dim3(blocks + N * chunks), dim3(kResampleThreads), 0, st, N, h->TT, h->d_parent, h->d_parent + N,
+                     h->d_table[h->cur], h->d_table[nxt], h->d_shed, h->pool, blocks, chunks, ga);
   TBNAV_HIP(hipGetLastError());
   std::swap(h->d_fstate, h->d_fstate_alt);
   h->cur = nxt;
@@ -3290,8 +3372,10 @@ int ref_field_after_scan(tbnav_rbpf* h, bool resampled, int p_first = 0, int p_c
 // sens: the sensor transforms the proposal kernel left for exactly these poses (NULL: the raycast derives them).
 // nz (optional): the weights' normalise / select step to run with this update — inside the box-counter kernel's launch as
 // workgroup 0 (no second stream, no event), behind the other map-update kernels as a launch of its own.
-int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens, const NormArgs* nz = nullptr, int* err = nullptr) {
+int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens, const NormArgs* nz = nullptr, int* err = nullptr,
+                   const double2* beams_dev = nullptr) {
   if (!err) err = h->d_err;
+  if (!beams_dev) beams_dev = h->d_beams;
   const int* gp = nz ? nz->gate_prev : nullptr;
   hipStream_t st = h->stream;
   StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
@@ -3335,14 +3419,14 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens,
   if (cap_win > 0 && !h->ref_field && c.Bv < 32768 && h->raycast_form == 0 && nt >= 512 && lds_win <= (size_t)kMaxLds - 2048) {
     // default: box counters (rbpf_raycast_box)
     unsigned long long* touched = h->count_touched ? h->d_touched : nullptr;
-    const NormArgs na = nz ? *nz : NormArgs{0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
+    const NormArgs na = nz ? *nz : NormArgs{0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, nullptr};
     const int blocks = count + (nz ? 1 : 0);
     const size_t lds_launch = nz ? std::max(lds_win, sizeof(double) * 2 * kNormChunk) : lds_win;  // (workgroup 0's two arrays)
     if (nt == 512)
-      hipLaunchKernelGGL((rbpf_raycast_box<512>), dim3(blocks), dim3(512), lds_launch, st, c, h->pool, M, h->d_beams, sp.pose, sens,
+      hipLaunchKernelGGL((rbpf_raycast_box<512>), dim3(blocks), dim3(512), lds_launch, st, c, h->pool, M, beams_dev, sp.pose, sens,
                          h->d_trow[h->cur], h->d_nocc[h->cur], err, (int)cap_win, touched, na);
     else
-      hipLaunchKernelGGL((rbpf_raycast_box<1024>), dim3(blocks), dim3(1024), lds_launch, st, c, h->pool, M, h->d_beams, sp.pose, sens,
+      hipLaunchKernelGGL((rbpf_raycast_box<1024>), dim3(blocks), dim3(1024), lds_launch, st, c, h->pool, M, beams_dev, sp.pose, sens,
                          h->d_trow[h->cur], h->d_nocc[h->cur], err, (int)cap_win, touched, na);
     TBNAV_HIP(hipGetLastError());
     return TBNAV_OK;
@@ -3351,7 +3435,7 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens,
   const size_t tile_lds = small ? lds10 : lds16;
   if (cap > 0 && !h->ref_field && c.Bv < 32768 && tile_lds <= (size_t)kMaxLds - 2048) {
     unsigned long long* touched = h->count_touched ? h->d_touched : nullptr;
-#define TBNAV_RAYCAST(NT, FW, EC) hipLaunchKernelGGL((rbpf_raycast_tile<NT, FW, EC>), dim3(count), dim3(NT), tile_lds, st, c, h->pool, M, h->d_beams, sp.pose, sens, \
+#define TBNAV_RAYCAST(NT, FW, EC) hipLaunchKernelGGL((rbpf_raycast_tile<NT, FW, EC>), dim3(count), dim3(NT), tile_lds, st, c, h->pool, M, beams_dev, sp.pose, sens, \
                                                      h->d_trow[h->cur], h->d_nocc[h->cur], err, cap, touched, gp)
     if (small) TBNAV_RAYCAST(512, 10, 8);
     else if (nt == 256) TBNAV_RAYCAST(256, 16, 16);
@@ -3366,13 +3450,13 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens,
       const int rc2 = ref_field_prepare_log(h, c.Bv, log);
       if (rc2 != TBNAV_OK) return rc2;
     }
-    hipLaunchKernelGGL(rbpf_raycast, dim3(count), dim3(kWave), sizeof(int) * (2 * bvn + (h->TT + 31) / 32), st, c, h->pool, M, h->d_beams,
+    hipLaunchKernelGGL(rbpf_raycast, dim3(count), dim3(kWave), sizeof(int) * (2 * bvn + (h->TT + 31) / 32), st, c, h->pool, M, beams_dev,
                        sp.pose, h->d_trow[h->cur], h->d_nocc[h->cur], err, log, gp);
   }
   TBNAV_HIP(hipGetLastError());
   if (nz) {
     hipLaunchKernelGGL(rbpf_normalize, dim3(1), dim3(256), 0, st, nz->N, nz->zp, nz->weight, nz->weight_out, nz->cs, nz->parent, nz->out,
-                       nz->gate, nz->gate_prev, nz->seq, nz->seq_val);
+                       nz->gate, nz->gate_prev, nz->seq, nz->seq_val, nz->children);
     TBNAV_HIP(hipGetLastError());
   }
   return TBNAV_OK;
@@ -3402,31 +3486,40 @@ int upload_beams(tbnav_rbpf* h, const std::vector<double2>& beams, int n_beams, 
 // the scan owns.  gate_prev (device pointer or NULL): the resampling decision of the scan enqueued before this one, when the
 // host has not seen it yet — the kernels of this scan do nothing if it is set (tbnav_rbpf_slam_batch).
 struct ScanTicket { int slot = 0; int n_valid = 0; bool local_only = false; bool poll = false; unsigned int seq = 0; };
+// A scan whose constants, beam table and noise are on the device already (tbnav_rbpf_slam_batch prepares a few scans at a time).
+struct Prefetched { ScanC c; int rc = TBNAV_OK; const double2* d_beams = nullptr; const double* d_normals = nullptr; };
 int scan_enqueue(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], const double cur_odom[3],
                  const double prev_odom[3], int icp_ok, const double T_icp[3], const double* normals,
-                 tbnav_rbpf_stats* out, bool local_only, int slot, const int* gate_prev, ScanTicket& tk) {
+                 tbnav_rbpf_stats* out, bool local_only, int slot, const int* gate_prev, ScanTicket& tk,
+                 const Prefetched* pre = nullptr) {
   hipStream_t st = h->stream;
   int* const d_err = h->d_err + 4 * slot;
   int* const h_err = h->h_err + 4 * slot;
   ++h->scans_done;
   ScanC c;
   std::vector<double2>& beams = h->beams_tmp;  // (kept between calls: no allocation per scan)
-  int rc = build_scan_consts(h, c, scan, n_beams, u, cur_odom, prev_odom, icp_ok, T_icp, beams);
+  int rc;
+  if (pre) { c = pre->c; rc = pre->rc; }
+  else rc = build_scan_consts(h, c, scan, n_beams, u, cur_odom, prev_odom, icp_ok, T_icp, beams);
   std::memset(out, 0, sizeof *out);
   if (rc != TBNAV_OK) { out->status = rc; return rc; }
   out->n_valid_beams = c.Bv;
   tk.slot = slot; tk.n_valid = c.Bv; tk.local_only = local_only;
-  rc = upload_beams(h, beams, n_beams, c.Bv, /*stage_only=*/normals == nullptr, slot);  // device noise: the noise kernel carries the beams over
-  if (rc != TBNAV_OK) return rc;
+  if (!pre) {
+    rc = upload_beams(h, beams, n_beams, c.Bv, /*stage_only=*/normals == nullptr, slot);  // device noise: the noise kernel carries the beams over
+    if (rc != TBNAV_OK) return rc;
+  }
   const size_t n_norm = (size_t)h->N * c.stride_normals + 1;
-  if (n_norm > h->normals_cap) {
+  if (!pre && n_norm > h->normals_cap) {
     TBNAV_HIP(hipStreamSynchronize(st));  // (a scan still in flight reads the old buffer)
     (void)hipFree(h->d_normals);
     h->d_normals = nullptr;
     TBNAV_HIP(hipMalloc((void**)&h->d_normals, sizeof(double) * n_norm));
     h->normals_cap = n_norm;
   }
-  if (normals) {
+  if (pre) {
+    // (drawn with the rest of its chunk)
+  } else if (normals) {
     TBNAV_HIP(hipMemcpyAsync(h->d_normals, normals, sizeof(double) * n_norm, hipMemcpyHostToDevice, st));
   } else {
     const int blocks = (int)std::min<size_t>((n_norm / 2 + 255) / 256, 4096);
@@ -3435,6 +3528,9 @@ int scan_enqueue(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3
     TBNAV_HIP(hipGetLastError());
   }
   ++h->scan_index;
+  const double2* const beams_dev = pre ? pre->d_beams : h->d_beams;
+  const double* const normals_dev = pre ? pre->d_normals : h->d_normals;
+  h->last_normals = normals_dev;
   for (int q = 0; q < 4; ++q) h_err[q] = 0;  // mapped: the scan that last owned the slot has been waited for
   h->h_norm[slot] = NormOut{};
   StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
@@ -3487,33 +3583,34 @@ int scan_enqueue(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3
     // N1 option: every particle refines T(pose) * T_icp against its own map first; the samples are drawn round that
     const size_t sm_lds = sizeof(double2) * (c.Bv > 0 ? c.Bv : 1) + sizeof(double) * kMixLut + sizeof(unsigned long long) * 4 * (c.Bv > 0 ? c.Bv : 1) +
                           (propose_lds - propose_lds_base);
-    hipLaunchKernelGGL(rbpf_scanmatch, dim3(h->N), dim3(kMatchThreads), sm_lds, st, c, h->sm, h->d_beams, h->d_code[h->cur],
+    hipLaunchKernelGGL(rbpf_scanmatch, dim3(h->N), dim3(kMatchThreads), sm_lds, st, c, h->sm, beams_dev, h->d_code[h->cur],
                        h->pool, map_of(h), h->d_trow[h->cur], skip_arr, skip_eq, h->df_mode, h->radius, occ_half,
                        h->d_nocc[h->cur], h->d_win, sp.pose, h->d_center, h->d_score, d_err, gate_prev);
     TBNAV_HIP(hipGetLastError());
     center = h->d_center;
   }
-  hipLaunchKernelGGL(rbpf_propose, dim3(h->N), dim3(kProposeThreads), propose_lds, st, c, h->d_beams,
+  hipLaunchKernelGGL(rbpf_propose, dim3(h->N), dim3(kProposeThreads), propose_lds, st, c, beams_dev,
                      h->d_code[h->cur], h->pool, map_of(h), h->d_trow[h->cur], skip_arr, skip_eq, h->df_mode, h->radius, occ_half,
-                     h->d_nocc[h->cur], h->d_win, h->d_normals, center, sp.pose, sp.prev, sp.weight, h->tr, h->d_sens, d_err, gate_prev);
+                     h->d_nocc[h->cur], h->d_win, normals_dev, center, sp.pose, sp.prev, sp.weight, h->tr, h->d_sens, d_err, gate_prev);
   TBNAV_HIP(hipGetLastError());
   if (h->timing) TBNAV_HIP(hipEventRecord(h->ev[2], st));
   // normalise / select needs only the weights the proposal kernel left: it rides in the map update's launch as one extra
   // workgroup (the chain of adds it is made of would otherwise sit on the critical path, and a second stream costs an
   // event and a dependent boundary).  With event timing on it is a launch of its own, so that the intervals mean what
   // they say.
-  const double* z_norm = h->d_normals + (size_t)h->N * c.stride_normals;
+  const double* z_norm = normals_dev + (size_t)h->N * c.stride_normals;
   tk.seq = (unsigned int)h->scans_done;
   const NormArgs nz{h->N, z_norm, sp.weight, sp.weight, h->d_cs, h->d_parent, h->d_norm + slot, h->d_gate + slot, gate_prev,
-                    tk.poll ? h->d_seq + slot : nullptr, tk.seq};
+                    tk.poll ? h->d_seq + slot : nullptr, tk.seq, h->d_parent + h->N};
   auto launch_normalize = [&](hipStream_t s2) -> int {
-    hipLaunchKernelGGL(rbpf_normalize, dim3(1), dim3(256), 0, s2, h->N, z_norm, sp.weight, sp.weight, h->d_cs, h->d_parent, h->d_norm + slot);
+    hipLaunchKernelGGL(rbpf_normalize, dim3(1), dim3(256), 0, s2, h->N, z_norm, sp.weight, sp.weight, h->d_cs, h->d_parent, h->d_norm + slot,
+                       nullptr, nullptr, nullptr, 0u, h->d_parent + h->N);
     TBNAV_HIP(hipGetLastError());
     return TBNAV_OK;
   };
   const bool overlap = !local_only && !h->timing;
   if ((gate_prev || tk.poll) && !overlap) return TBNAV_ERR_INVALID_ARG;  // (a gated or polled scan is a batch scan: never local-only or timed)
-  rc = launch_raycast(h, c, h->N, h->d_sens, overlap ? &nz : nullptr, d_err);
+  rc = launch_raycast(h, c, h->N, h->d_sens, overlap ? &nz : nullptr, d_err, beams_dev);
   if (rc != TBNAV_OK) return rc;
   if (h->timing) TBNAV_HIP(hipEventRecord(h->ev[3], st));
   if (h->full_edt) {
@@ -3574,7 +3671,7 @@ int scan_finish(tbnav_rbpf* h, const ScanTicket& tk, tbnav_rbpf_stats* out) {
     if (h->timing) TBNAV_HIP(hipEventRecord(h->ev[7], st));
     gathered = true;
   }
-  if (gathered) TBNAV_HIP(hipStreamSynchronize(st));
+  if (gathered && !tk.poll) TBNAV_HIP(hipStreamSynchronize(st));  // (a batch goes straight on: the next scan is behind the copies in the stream)
   for (float& v : h->last_ms) v = 0.f;
   if (h->timing) {
     float e01, e12, e23, e34, e45;
@@ -3679,7 +3776,7 @@ int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf*
   A((void**)&h->d_sens, sizeof(double) * 4 * N);
   A((void**)&h->d_tile_scratch, sizeof(unsigned int) * h->TT);
   A((void**)&h->d_touched, sizeof(unsigned long long) * 2);
-  A((void**)&h->d_parent, sizeof(int) * N);
+  A((void**)&h->d_parent, sizeof(int) * 2 * N);
   A((void**)&h->d_best, sizeof(int));
   A((void**)&h->d_best_pose, sizeof(double) * 3);
   A((void**)&h->d_export, h->G);
@@ -3868,7 +3965,7 @@ void tbnav_rbpf_destroy(tbnav_rbpf* h) {
   (void)hipFree(h->d_trace);
   (void)hipHostFree(h->h_beams); (void)hipHostFree(h->h_err); (void)hipHostFree(h->h_norm); (void)hipFree(h->d_gate);
   for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
-  (void)hipHostFree(h->h_seq);
+  (void)hipHostFree(h->h_seq); (void)hipHostFree(h->h_beam_ring); (void)hipFree(h->d_beam_ring); (void)hipFree(h->d_norm_ring);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h->ref;
   delete h;
@@ -3888,10 +3985,10 @@ int tbnav_rbpf_set_seed(tbnav_rbpf* h, uint64_t seed) {
 }
 
 int tbnav_rbpf_get_normals(tbnav_rbpf* h, double* out, int64_t n) {
-  if (!h || !out || n <= 0 || (size_t)n > h->normals_cap) return TBNAV_ERR_INVALID_ARG;
+  if (!h || !out || n <= 0 || (size_t)n > std::max(h->normals_cap, h->norm_ring_stride)) return TBNAV_ERR_INVALID_ARG;
   DeviceGuard guard(h->device);
   TBNAV_HIP(hipStreamSynchronize(h->stream));
-  TBNAV_HIP(hipMemcpy(out, h->d_normals, sizeof(double) * n, hipMemcpyDeviceToHost));
+  TBNAV_HIP(hipMemcpy(out, h->last_normals ? h->last_normals : h->d_normals, sizeof(double) * n, hipMemcpyDeviceToHost));
   return TBNAV_OK;
 }
 
@@ -3925,13 +4022,53 @@ int tbnav_rbpf_slam_batch(tbnav_rbpf* h, const float* scans, int32_t n_beams, in
   }
   if (n_beams <= 0) return TBNAV_ERR_INVALID_ARG;
   DeviceGuard guard(h->device);
+  // The noise and the beam tables of the next few scans are put on the device by ONE launch per chunk (same Philox counters
+  // as one launch per scan: same values), so that a scan is two launches — proposal, map update — back to back.
+  const size_t norm_stride = (((size_t)h->N * (3 * (size_t)h->k + 3) + 1) + 1) & ~(size_t)1;
+  int chunk = 8;
+  while (chunk > 2 && (size_t)chunk * norm_stride * sizeof(double) > ((size_t)512 << 20)) --chunk;
+  const bool ahead = chunk >= 3;  // (the host rewrites the pinned staging of chunk c + 1 once scan 0 of chunk c is through)
+  if (ahead && (h->ring_scans != chunk || h->norm_ring_stride != norm_stride || h->beam_ring_stride != (size_t)n_beams)) {
+    TBNAV_HIP(hipStreamSynchronize(h->stream));
+    (void)hipFree(h->d_norm_ring); (void)hipFree(h->d_beam_ring); (void)hipHostFree(h->h_beam_ring);
+    h->d_norm_ring = nullptr; h->d_beam_ring = nullptr; h->h_beam_ring = nullptr; h->ring_scans = 0;
+    TBNAV_HIP(hipMalloc((void**)&h->d_norm_ring, sizeof(double) * norm_stride * chunk));
+    TBNAV_HIP(hipMalloc((void**)&h->d_beam_ring, sizeof(double2) * (size_t)n_beams * chunk));
+    TBNAV_HIP(hipHostMalloc((void**)&h->h_beam_ring, sizeof(double2) * (size_t)n_beams * chunk, hipHostMallocDefault));
+    std::memset(h->h_beam_ring, 0, sizeof(double2) * (size_t)n_beams * chunk);
+    h->ring_scans = chunk; h->norm_ring_stride = norm_stride; h->beam_ring_stride = (size_t)n_beams;
+  }
+  const unsigned long long scan0 = h->scan_index;  // noise counter of the batch's first scan
+  std::vector<Prefetched> pre(ahead ? chunk : 0);
+  int prepared_to = 0;  // scans [0, prepared_to) have had their chunk prepared
+  auto prepare = [&](int first) -> int {
+    const int m = std::min(chunk, n_scans - first);
+    for (int j = 0; j < m; ++j) {
+      const int s = first + j;
+      Prefetched& q = pre[j];
+      q.rc = build_scan_consts(h, q.c, scans + (size_t)s * n_beams, n_beams, u + 3 * s, odom + 3 * (s + 1), odom + 3 * s,
+                               icp_ok ? icp_ok[s] : 1, T_icp + 3 * s, h->beams_tmp);
+      q.d_beams = h->d_beam_ring + (size_t)j * n_beams;
+      q.d_normals = h->d_norm_ring + (size_t)j * norm_stride;
+      if (q.rc == TBNAV_OK && q.c.Bv) std::memcpy(h->h_beam_ring + (size_t)j * n_beams, h->beams_tmp.data(), sizeof(double2) * q.c.Bv);
+    }
+    const int blocks = (int)std::min<size_t>((norm_stride / 2 + 255) / 256, 4096);
+    hipLaunchKernelGGL(rbpf_sample_normals, dim3(blocks, m), dim3(256), 0, h->stream, norm_stride, (unsigned long long)h->seed,
+                       scan0 + (unsigned long long)first, h->d_norm_ring, (const double2*)h->h_beam_ring, h->d_beam_ring, n_beams,
+                       norm_stride, (size_t)n_beams);
+    TBNAV_HIP(hipGetLastError());
+    prepared_to = first + m;
+    return TBNAV_OK;
+  };
   ScanTicket tk[2];
-  auto enqueue = [&](int s, const int* gate_prev) {
+  auto enqueue = [&](int s, const int* gate_prev) -> int {
+    if (ahead && s >= prepared_to) { const int rc = prepare(s); if (rc != TBNAV_OK) return rc; }
     ScanTicket& t = tk[s & 1];
     t = ScanTicket{};
     t.poll = true;
+    h->scan_index = scan0 + (unsigned long long)s;  // (scan_enqueue counts it)
     return scan_enqueue(h, scans + (size_t)s * n_beams, n_beams, u + 3 * s, odom + 3 * (s + 1), odom + 3 * s, icp_ok ? icp_ok[s] : 1,
-                        T_icp + 3 * s, nullptr, out + s, false, s % kScanSlots, gate_prev, t);
+                        T_icp + 3 * s, nullptr, out + s, false, s % kScanSlots, gate_prev, t, ahead ? &pre[s % chunk] : nullptr);
   };
   int rc = enqueue(0, nullptr);
   if (rc != TBNAV_OK) return rc;
@@ -3955,7 +4092,7 @@ int tbnav_rbpf_slam_batch(tbnav_rbpf* h, const float* scans, int32_t n_beams, in
     }
     if (out[s].resampled && s + 1 < n_scans) {
       // scan s + 1's launches did nothing: same scan number, same noise, again — on the resampled particles
-      --h->scan_index; --h->scans_done;
+      --h->scans_done;
       rc = enqueue(s + 1, nullptr);
       if (rc != TBNAV_OK) { (void)hipStreamSynchronize(h->stream); return rc; }
     }
@@ -4007,8 +4144,9 @@ int tbnav_rbpf_gather_local(tbnav_rbpf* h, const int32_t* local_parent) {
   const int N = h->N;
   // slots with parent -1 keep their own content: copy self
   std::vector<int> par(local_parent, local_parent + N);
-  for (int m = 0; m < N; ++m) { if (par[m] < 0) par[m] = m; if (par[m] >= N) return TBNAV_ERR_INVALID_ARG; }
-  TBNAV_HIP(hipMemcpyAsync(h->d_parent, par.data(), sizeof(int) * N, hipMemcpyHostToDevice, h->stream));
+  par.resize(2 * (size_t)N, 0);  // [N, 2N): how many slots chose each particle
+  for (int m = 0; m < N; ++m) { if (par[m] < 0) par[m] = m; if (par[m] >= N) return TBNAV_ERR_INVALID_ARG; ++par[N + par[m]]; }
+  TBNAV_HIP(hipMemcpyAsync(h->d_parent, par.data(), sizeof(int) * 2 * N, hipMemcpyHostToDevice, h->stream));
   TBNAV_HIP(hipStreamSynchronize(h->stream));  // par is a local
   const int rc = resample_on_device(h);
   if (rc != TBNAV_OK) return rc;
