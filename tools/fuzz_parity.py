@@ -1,6 +1,7 @@
 """Dev: randomized parity sweep of both hot paths against the oracle (run on the GPU box; not part of the suite).
 
-usage: python tools/fuzz_parity.py [n_mppi] [n_rbpf] [seed]
+usage: python tools/fuzz_parity.py [n_mppi] [n_rbpf] [seed] [only] [n_batch]
+(n_batch: cases of the pipelined replay, tbnav_rbpf_slam_batch, against one synchronous call per scan — bit for bit)
 Every case draws its own sizes, gains, start poses (incl. headings near +-pi), sensor offsets, sampling spreads,
 gated beams, dynamics model, scan-matching on/off ...; the assertions are the test suite's.  Prints one line per
 failing case with the parameters needed to reproduce it.
@@ -147,17 +148,80 @@ def rbpf_case(i):
     pf_d.close(); pf_o.close()
 
 
+def batch_case(i):
+    """tbnav_rbpf_slam_batch (two scans in the stream, gated speculation, noise drawn a chunk ahead) against one synchronous
+    tbnav_rbpf_slam per scan: same seed, same scans -> the same filter bit for bit, whatever resamples or fails on the way."""
+    from rtn_amd import capi
+    r = np.random.default_rng([seed, 4, i])
+    N = int(r.choice([1, 7, 48, 64, 200]))
+    k = int(r.choice([1, 5, 10, 30]))
+    n_scans = int(r.choice([2, 3, 9, 12, 17, 20]))
+    bd = float(r.choice([1.0, 1.0, 2.0]))
+    n_beams = int(round(360 / bd))
+    sharp = bool(r.random() < 0.6)  # a sharp sensor model and wide sampling: the run resamples by itself
+    kw = dict(sigma_hit=float(r.choice([0.02, 0.03])), sample_range=[1e-5, float(r.choice([1e-4, 3e-4])), float(r.choice([1e-4, 3e-4]))]) if sharp else {}
+    sm = bool(r.random() < 0.3)
+    band_rows = int(r.choice([0, 0, 5, 12]))
+    icp = (r.random(n_scans) < 0.85).astype(np.int32)
+    split = int(r.integers(1, n_scans))  # the replay arrives as two batches
+    desc = dict(N=N, k=k, n_scans=n_scans, bd=bd, sharp=sharp, sm=sm, band_rows=band_rows, icp=icp.tolist(), split=split)
+    inc = (float(r.uniform(-0.05, 0.05)), float(r.uniform(0.01, 0.04)), float(r.uniform(-0.03, 0.03)))
+    steps, poses = rc.trajectory(n_scans, inc=inc)
+    srng = np.random.default_rng(1000 + i)
+    scans = np.stack([orc.room_scan(poses[s], n_beams=n_beams, beam_delta_deg=bd, walls=rc.ROOM_SMALL, rng=srng) for s in range(n_scans)])
+    if r.random() < 0.15:
+        scans[int(r.integers(0, n_scans)), :] = 3.0  # a scan that leaves the +-2 m world: the replay stops there
+    odom = np.array([steps[0][0]] + [st[1] for st in steps], dtype=np.float64)
+    u = np.array([st[3] for st in steps], dtype=np.float64)
+    t_icp = np.array([st[2] for st in steps], dtype=np.float64)
+    pfs = [ParticleFilter(default_params(N=N, k=k, beam_delta_deg=bd, **kw)) for _ in range(2)]
+    for pf in pfs:
+        pf.setSeed(900 + i)
+        if sm: pf.setScanMatching(True)
+        if band_rows: pf.setOption(capi.RBPF_OPT_RAYCAST_BAND_ROWS, band_rows)
+    one = []
+    for s in range(n_scans):
+        st = pfs[0].SLAM(scans[s], steps[s][3], steps[s][1], steps[s][0], bool(icp[s]), steps[s][2], None, check=False)
+        one.append(st)
+        if st.status != 0:
+            break
+    many = list(pfs[1].SLAMBatch(scans[:split], u[:split], odom[:split + 1], t_icp[:split], icp_ok=icp[:split], check=False))
+    if all(o.status == 0 for o in many):
+        many += list(pfs[1].SLAMBatch(scans[split:], u[split:], odom[split:], t_icp[split:], icp_ok=icp[split:], check=False))
+    for s, x in enumerate(one):
+        y = many[s]
+        assert (x.status, x.n_valid_beams) == (y.status, y.n_valid_beams), ("status", s, x.status, y.status, desc)
+        if x.status == 0:
+            # (a sharp sensor model overflows the motion-model branch's product of 360 factors — inf / nan in both, as in the reference)
+            assert np.array_equal([x.neff, x.resampled, x.sum_w, x.sq_sum], [y.neff, y.resampled, y.sum_w, y.sq_sum], equal_nan=True), \
+                ("stats", s, (x.neff, x.resampled, x.sum_w, x.sq_sum), (y.neff, y.resampled, y.sum_w, y.sq_sum), desc)
+    if one[-1].status == 0:
+        a, b = pfs[0].particles(), pfs[1].particles()
+        for q in range(3):
+            assert np.array_equal(a[q], b[q], equal_nan=True), ("particles", q, desc)
+        for m in sorted(set([0, N // 2, N - 1])):
+            assert np.array_equal(pfs[0].logOdds(m), pfs[1].logOdds(m)), ("log-odds", m, desc)
+        assert pfs[0].poolStats() == pfs[1].poolStats(), ("pool", desc)
+    for pf in pfs:
+        pf.close()
+    return sum(o.resampled for o in one)
+
+
+n_batch = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 fails = 0
-for name, fn, n in (("mppi", mppi_case, n_mppi), ("rbpf", rbpf_case, n_rbpf)):
+events = 0
+for name, fn, n in (("mppi", mppi_case, n_mppi), ("rbpf", rbpf_case, n_rbpf), ("batch", batch_case, n_batch)):
     for i in range(n):
         if only and only != f"{name}:{i}":
             continue
         try:
-            fn(i)
+            ret = fn(i)
+            if isinstance(ret, (int, np.integer)):
+                events += int(ret)
         except Exception as e:  # noqa: BLE001
             fails += 1
             print(f"[FAIL] {name} case {i} (seed {seed}): {type(e).__name__}: {str(e)[:600]}")
             if fails <= 3:
                 traceback.print_exc(limit=2)
-    print(f"{name}: {n} cases done, failures so far {fails}", flush=True)
+    print(f"{name}: {n} cases done, failures so far {fails}" + (f" ({events} scans resampled on the way)" if name == "batch" and n else ""), flush=True)
 sys.exit(1 if fails else 0)
