@@ -142,6 +142,10 @@ class HipRbpfShardBackend:
         normalised weights lands in the handle.  Returns (stats, parents or None)."""
         import ctypes as C
         n = w_all.numel()
+        # the handle launches on its OWN stream: a collective that produced w_all is ordered before torch's current
+        # stream only (RCCL runs on the communicator's stream and does not block the host), so wait for it here
+        if w_all.is_cuda:
+            torch.cuda.current_stream(w_all.device).synchronize()
         parents = np.empty(n, dtype=np.int32)
         st = capi.RbpfStats()
         capi.check(self._L.tbnav_rbpf_resample_global_dev(self._h, w_all.data_ptr(), n, offset, float(z), parents.ctypes.data, C.byref(st)),
