@@ -32,10 +32,10 @@ def test_mppi_two_ranks_one_gpu(gpu_pkg):
     assert np.allclose(res[0]["u"], m.getControls(), rtol=1e-10, atol=1e-13)
 
 
-def _rbpf_sharded_vs_unsharded(n_local, k, skew_scan, heavy, backend):
+def _rbpf_sharded_vs_unsharded(n_local, k, skew_scan, heavy, backend, world=2):
     from rtn_amd.rbpf import ParticleFilter, default_params
-    N = 2 * n_local
-    res = run_spawn(rbpf_hip_worker, 2, n_local, k, skew_scan, heavy, backend=backend)
+    N = world * n_local
+    res = run_spawn(rbpf_hip_worker, world, n_local, k, skew_scan, heavy, backend=backend)
     pf = ParticleFilter(default_params(N=N, k=k))
     steps, scans = rbpf_scenario(4)
     stride = 3 * k + 3
@@ -49,16 +49,16 @@ def _rbpf_sharded_vs_unsharded(n_local, k, skew_scan, heavy, backend):
             w /= w.sum()
             pf.setParticles(w=w)
         st = pf.SLAM(scans[s], u, cur, prev, True, t_icp, normals)
-        for r in (0, 1):
+        for r in range(world):
             neff, resampled, parents = res[r]["hist"][s]
             assert (neff, resampled) == (st.neff, st.resampled)
             if st.resampled:
                 assert parents == pf.trace()["resample_idx"].tolist()
         resampled_any |= bool(st.resampled)
     assert resampled_any
-    assert res[0]["migrated"] + res[1]["migrated"] > 0      # a particle really crossed ranks ...
+    assert sum(res[r]["migrated"] for r in range(world)) > 0  # a particle really crossed ranks ...
     pose, prev_pose, w = pf.particles()
-    for r in (0, 1):
+    for r in range(world):
         sl = slice(r * n_local, (r + 1) * n_local)
         assert np.array_equal(res[r]["pose"], pose[sl]) and np.array_equal(res[r]["prev"], prev_pose[sl])
         assert np.array_equal(res[r]["w"], w[sl])
@@ -77,6 +77,16 @@ def test_rbpf_two_ranks_one_gpu_equals_unsharded_bit_exact(gpu_pkg, heavy):
     res = _rbpf_sharded_vs_unsharded(n_local, 8, 1, heavy, "gloo")
     # a travelling particle is its tiles, not its map: 80 x 80 cells = 9 tiles of 8 KB + 128 B at most + counts + state
     assert max(res[0]["migrated"], res[1]["migrated"]) < 8 * (9 * 8192 + 4096)
+
+
+def test_rbpf_four_ranks_one_gpu_children_span_three_ranks(gpu_pkg):
+    """Four ranks of 5 particles: particle 1 (rank 0) takes ~60 % of the global weight, so its children fill rank 0, rank 1
+    and part of rank 2 — one blob goes to two destinations — and particle 17 (rank 3) feeds ranks 2 and 3: a rank that
+    both sends and receives, ranks whose every slot is imported, parents shifted across more than one rank boundary."""
+    res = _rbpf_sharded_vs_unsharded(5, 8, 1, {1: 0.6, 17: 0.3}, "gloo", world=4)
+    parents = np.array(next(h[2] for h in res[0]["hist"] if h[1]))
+    assert len({m // 5 for m in np.nonzero(parents == 1)[0]}) >= 3   # particle 1's children live on three ranks
+    assert res[0]["migrated"] > 0
 
 
 def test_rbpf_two_ranks_two_gpus_rccl(gpu_pkg):
