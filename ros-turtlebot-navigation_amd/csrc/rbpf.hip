@@ -429,9 +429,24 @@ __device__ __forceinline__ void sensor_transform(const ScanC& c, double th, doub
 // ~1e-4 m of the centre, so nearly every (sample, beam) lands on the same cell (no lookup at all) or at least the
 // same code, and takes its term from the cache instead of re-evaluating sqrt + exp.  A beam that leaves the world
 // sets *oob (the reference throws from world2RowMajor) and contributes 1.
-constexpr int kMixLut = 1024;  // the scan matcher tabulates the mixture term of distance codes (squared cells) below this
+// The mixture term depends on the distance code and on constants fixed at create (z_hit, sigma_hit, z_rand / z_max,
+// resolution, max_occ_dist): the handle tabulates it ONCE for the codes below kMixLut (rbpf_mix_lut, same device code
+// as beam_mixture -> same bits) and the kernels read the table — its first kMixLds entries from LDS, the rest from
+// global memory — instead of a square root, a division and an exponential per beam.
+constexpr int kMixLut = 1024, kMixLds = 128;
+struct MixLut { const double* lds; const double* glob; };  // either may be NULL
+__device__ __forceinline__ double mix_term(const ScanC& c, const MixLut& L, int cd) {
+  if (L.lds && cd < kMixLds) return L.lds[cd];
+  if (L.glob && cd < kMixLut) return L.glob[cd];
+  return beam_mixture(c, (uint16_t)cd);
+}
+__global__ void rbpf_mix_lut(ScanC c, double* __restrict__ out) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < kMixLut) out[q] = beam_mixture(c, (uint16_t)q);
+}
 __device__ __forceinline__ double beam_factor(const ScanC& c, const DistSrc& ds, int radius, const double2 pt, double X, double Y,
-                                              double st, double ct, unsigned int cc, unsigned int tg, double pzc, int* oob) {
+                                              double st, double ct, unsigned int cc, unsigned int tg, double pzc, int* oob,
+                                              const MixLut& L = MixLut{nullptr, nullptr}) {
   const double ex = ct * pt.x - st * pt.y + X;
   const double ey = st * pt.x + ct * pt.y + Y;
   int ci, cj;
@@ -440,24 +455,26 @@ __device__ __forceinline__ double beam_factor(const ScanC& c, const DistSrc& ds,
   // (window mode: the window is sized so that a miss cannot happen — if it ever does it is reported, never read stale)
   const int cd = lookup_code(c.g, ds, radius, ci, cj);
   if (cd < 0) { *oob |= 2; return 1.0; }
-  return (tg == (unsigned int)cd) ? pzc : beam_mixture(c, (uint16_t)cd);
+  return (tg == (unsigned int)cd) ? pzc : mix_term(c, L, cd);
 }
 // GridMapper::likelihoodFieldModel for ONE pose, evaluated by one wave (lanes stride the valid beams).
 __device__ __forceinline__ double wave_scan_likelihood_t(const ScanC& c, const double2* __restrict__ beams,
                                                          const DistSrc& ds, int radius, int n_occ,
-                                                         double X, double Y, double st, double ct, int lane, int* oob) {
+                                                         double X, double Y, double st, double ct, int lane, int* oob,
+                                                         const MixLut& L = MixLut{nullptr, nullptr}) {
   if (n_occ == 0) return 1.0;  // grid_mapper.cpp:94-98
   double p = 1.0;
-  for (int b = lane; b < c.Bv; b += kWave) p *= beam_factor(c, ds, radius, beams[b], X, Y, st, ct, 0xFFFFFFFFu, 0xFFFFFFFFu, 0.0, oob);
+  for (int b = lane; b < c.Bv; b += kWave) p *= beam_factor(c, ds, radius, beams[b], X, Y, st, ct, 0xFFFFFFFFu, 0xFFFFFFFFu, 0.0, oob, L);
   return wave_prod(p);
 }
 __device__ __forceinline__ double wave_scan_likelihood(const ScanC& c, const double2* __restrict__ beams,
                                                        const DistSrc& ds, int radius, int n_occ,
-                                                       double th, double x, double y, int lane, int* oob) {
+                                                       double th, double x, double y, int lane, int* oob,
+                                                       const MixLut& L = MixLut{nullptr, nullptr}) {
   if (n_occ == 0) return 1.0;
   double T[4];
   sensor_transform(c, th, x, y, T);
-  return wave_scan_likelihood_t(c, beams, ds, radius, n_occ, T[0], T[1], T[2], T[3], lane, oob);
+  return wave_scan_likelihood_t(c, beams, ds, radius, n_occ, T[0], T[1], T[2], T[3], lane, oob, L);
 }
 
 // particle_filter.cpp:383-437 (odometry part precomputed on the host: rot1, trans, rot2)
@@ -560,12 +577,13 @@ __global__ __launch_bounds__(256) void rbpf_field_by_query(GridC g, int radius, 
 __global__ __launch_bounds__(kWave) void rbpf_likelihood_one(ScanC c, const double2* __restrict__ beams, const uint16_t* __restrict__ codes,
                                                             TilePool P, MapT M, const int* __restrict__ trow_occ,
                                                             const int* __restrict__ fstate, int radius, const int* __restrict__ n_occ,
-                                                            double th, double x, double y, double* __restrict__ out, int* __restrict__ err) {
+                                                            double th, double x, double y, double* __restrict__ out, int* __restrict__ err,
+                                                            const double* __restrict__ mixlut) {
   const int p = c.p0, lane = threadIdx.x;
   const DistSrc ds{codes ? codes + (size_t)p * c.g.xsize * c.g.ysize : nullptr, occ_of(P, M, trow_occ, p),
                    make_int4(0, c.g.xsize - 1, 0, c.g.ysize - 1), (codes && fstate[p] == 2) ? 0 : 2, nullptr, nullptr, 0, 0, 0, 0};
   int oob = 0;
-  const double v = wave_scan_likelihood(c, beams, ds, radius, n_occ[p], th, x, y, lane, &oob);
+  const double v = wave_scan_likelihood(c, beams, ds, radius, n_occ[p], th, x, y, lane, &oob, MixLut{nullptr, mixlut});
   if (oob & 1) atomicOr(&err[0], 1);
   if (lane == 0) *out = v;
 }
@@ -591,7 +609,7 @@ __global__ __launch_bounds__(kMatchThreads) void rbpf_scanmatch(ScanC c, ScanMat
                                                                 const int* __restrict__ n_occ, const int4* __restrict__ win,
                                                                 const double* __restrict__ pose, double* __restrict__ center,
                                                                 double* __restrict__ score, int* __restrict__ err,
-                                                                const int* __restrict__ gate_prev = nullptr) {
+                                                                const int* __restrict__ gate_prev, const double* __restrict__ mixlut) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   if (gate_prev && *gate_prev) return;  // the scan before this one resamples: see rbpf_raycast_box
   const int p = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
@@ -617,7 +635,7 @@ __global__ __launch_bounds__(kMatchThreads) void rbpf_scanmatch(ScanC c, ScanMat
   DistSrc ds{codes ? codes + (size_t)p * c.g.xsize * c.g.ysize : nullptr, occ_of(P, M, trow_occ, p),
              win[p], skip[p] == skip_eq ? 0 : df_mode, tile_bm, reinterpret_cast<const int*>(tile_bm), 0, 0, 0, 0};
   for (int b = tid; b < c.Bv; b += kMatchThreads) lbeams[b] = beams[b];
-  for (int q = tid; q < kMixLut; q += kMatchThreads) lut[q] = beam_mixture(c, (uint16_t)q);
+  for (int q = tid; q < kMixLut; q += kMatchThreads) lut[q] = mixlut[q];  // (the handle's table: same values, no sqrt / exp here)
   for (int q = tid; q < 4 * c.Bv; q += kMatchThreads) ccache[q] = 0ull;
   if (ds.mode == 2 && occ_half > 0) {  // the same LDS slice of the bitmap as the proposal kernel, round the first guess
     double Tc[4];
@@ -719,11 +737,14 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
                                                                 const double* __restrict__ normals, const double* __restrict__ center,
                                                                 double* __restrict__ pose, double* __restrict__ prev_pose,
                                                                 double* __restrict__ weight, Trace tr, double* __restrict__ sens,
-                                                                int* __restrict__ err, const int* __restrict__ gate_prev) {
+                                                                int* __restrict__ err, const int* __restrict__ gate_prev,
+                                                                const double* __restrict__ mixlut) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   if (gate_prev && *gate_prev) return;  // the scan before this one resamples: see rbpf_raycast_box
   const int p = blockIdx.x;
   const int k = c.k;
+  __shared__ double sh_mix[kMixLds];  // the head of the handle's mixture table (filled below, visible after the first barrier)
+  const MixLut mixL{sh_mix, mixlut};
   double* smp = lds;               // [k][3]
   double* pscan = lds + 3 * k;     // [k]
   double* ppose = lds + 4 * k;     // [k]
@@ -763,7 +784,7 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
         nx = x + ((-uvx / uw) * sin(nth) + (uvx / uw) * sin(nth + uw) + w1);
         ny = y + ((uvx / uw) * cos(nth) - (uvx / uw) * cos(nth + uw) + w2);
       }
-      const double sl = wave_scan_likelihood(c, beams, ds, radius, nocc, nth, nx, ny, lane, &oob);
+      const double sl = wave_scan_likelihood(c, beams, ds, radius, nocc, nth, nx, ny, lane, &oob, MixLut{nullptr, mixlut});
       if (lane == 0) {
         prev_pose[p * 3 + 0] = th; prev_pose[p * 3 + 1] = x; prev_pose[p * 3 + 2] = y;
         pose[p * 3 + 0] = nth; pose[p * 3 + 1] = nx; pose[p * 3 + 2] = ny;
@@ -796,6 +817,7 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
                          center ? center[p * 3 + 2] : s0 * c.Ticp[1] + c0 * c.Ticp[2] + y0};
   const double pv[3] = {prev_pose[p * 3 + 0], prev_pose[p * 3 + 1], prev_pose[p * 3 + 2]};
   for (int b = tid; b < c.Bv; b += kProposeThreads) lbeams[b] = beams[b];  // visible after the next barrier
+  for (int q = tid; q < kMixLds; q += kProposeThreads) sh_mix[q] = mixlut[q];
   double Tc[4];  // sensor transform at the centre of the samples
   sensor_transform(c, mu0[0], mu0[1], mu0[2], Tc);
   if (ds.mode == 2 && occ_half > 0 && nocc) {
@@ -911,8 +933,9 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
       if (cd >= 0) {
         tag = (unsigned int)cd;
         cell = (unsigned int)(ci * c.g.xsize + cj);
-        pz = beam_mixture(c, (uint16_t)cd);
-        const double delta = dxy + sqrt(pt.x * pt.x + pt.y * pt.y) * dth + 1e-9;
+        pz = mix_term(c, mixL, cd);
+        // (|beam| only has to be bounded from above: the fp32 root, rounded up by more than its error)
+        const double delta = dxy + (double)(sqrtf((float)(pt.x * pt.x + pt.y * pt.y)) * 1.000001f) * dth + 1e-9;
         const double x_lo = c.g.xmin + ci * c.g.res, x_hi = c.g.xmin + (ci + 1) * c.g.res;
         const double y_lo = c.g.ymin + cj * c.g.res, y_hi = c.g.ymin + (cj + 1) * c.g.res;
         stable = (ex - x_lo > delta) && (x_hi - ex > delta) && (ey - y_lo > delta) && (y_hi - ey > delta);
@@ -962,7 +985,7 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
         const int j = floor_div_small(pair, n_un), i = pair - j * n_un;
         const int b = ulist[i];
         fac[j * kUnCap + i] = beam_factor(c, ds, radius, lbeams[b], stf[4 * j + 0], stf[4 * j + 1], stf[4 * j + 2], stf[4 * j + 3],
-                                          ccell[b], ctag[b], cpz[b], &oob);
+                                          ccell[b], ctag[b], cpz[b], &oob, mixL);
       }
       __syncthreads();
       for (int j = tid; j < k; j += kProposeThreads) {
@@ -984,7 +1007,7 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
 #pragma unroll
         for (int u = 0; u < kSB; ++u) {
           const int j = j0 + u * kPW;
-          if (j < k) pr[u] *= beam_factor(c, ds, radius, pt, stf[4 * j + 0], stf[4 * j + 1], stf[4 * j + 2], stf[4 * j + 3], cc, tg, pzc, &oob);
+          if (j < k) pr[u] *= beam_factor(c, ds, radius, pt, stf[4 * j + 0], stf[4 * j + 1], stf[4 * j + 2], stf[4 * j + 3], cc, tg, pzc, &oob, mixL);
         }
       }
 #pragma unroll
@@ -3050,6 +3073,7 @@ struct tbnav_rbpf {
   bool sm_on = false;          // N1 option: per-particle scan matching before sampling (tbnav_rbpf_set_scan_matching)
   ScanMatchC sm{0.05, 0.05, 5, 64};
   double* d_center = nullptr;  // [N][3] matched poses of the last call
+  double* d_mixlut = nullptr;  // [kMixLut] mixture term per distance code (constants of the handle: tabulated once at create)
   double* d_score = nullptr;   // [N]
   bool timing = false;         // record HIP events round the kernels (tbnav_rbpf_set_timing): each costs device time, so off by default
   int tile_cap = 0;            // cells of the raycast LDS tile (0 = use the beam-ordered kernel)
@@ -3176,19 +3200,26 @@ ExportCuts derive_export_cuts(double cut_occ) {
 
 size_t edt_lds_bytes(int xs, int words, int C) { return (size_t)xs * words * 8 + (size_t)xs * C * 5; }
 
+// the part of ScanC the beam mixture term needs (also what the handle's table of it is built from at create)
+bool mixture_consts(const tbnav_rbpf* h, ScanC& c) {
+  const tbnav_rbpf_params& P = h->p;
+  c.g = GridC{P.xmin, P.xmax, P.ymin, P.ymax, P.resolution, h->xsize, h->ysize, h->words, h->max_occ_dist, 1.0 / P.resolution};
+  c.z_hit = P.z_hit;
+  c.var_hit = P.sigma_hit * P.sigma_hit;                       // grid_mapper.cpp:77
+  if (almost_equal(c.var_hit, 0.0)) return false;
+  c.sqrt_inv_hit = 1.0 / std::sqrt(2.0 * kPI * c.var_hit);    // pdfNormal, grid_mapper.cpp:25
+  c.rand_term = P.z_rand / P.z_max;                            // grid_mapper.cpp:121
+  return true;
+}
+
 int build_scan_consts(tbnav_rbpf* h, ScanC& c, const float* scan, int n_beams, const double u[3],
                       const double cur_odom[3], const double prev_odom[3], int icp_ok, const double T_icp[3],
                       std::vector<double2>& beams) {
   const tbnav_rbpf_params& P = h->p;
-  c.g = GridC{P.xmin, P.xmax, P.ymin, P.ymax, P.resolution, h->xsize, h->ysize, h->words, h->max_occ_dist, 1.0 / P.resolution};
   c.N = h->N; c.k = h->k; c.icp_ok = icp_ok ? 1 : 0;
   for (int q = 0; q < 3; ++q) { c.Trs[q] = P.Trs[q]; c.Ld[q] = std::sqrt(P.sample_range[q]); c.Lm[q] = std::sqrt(P.motion_noise[q]);
                                 c.Ticp[q] = T_icp[q]; c.u[q] = u[q]; }
-  c.z_hit = P.z_hit;
-  c.var_hit = P.sigma_hit * P.sigma_hit;                       // grid_mapper.cpp:77
-  if (almost_equal(c.var_hit, 0.0)) return TBNAV_ERR_PDF_VARIANCE;
-  c.sqrt_inv_hit = 1.0 / std::sqrt(2.0 * kPI * c.var_hit);    // pdfNormal, grid_mapper.cpp:25
-  c.rand_term = P.z_rand / P.z_max;                            // grid_mapper.cpp:121
+  if (!mixture_consts(h, c)) return TBNAV_ERR_PDF_VARIANCE;
   c.scan_min = P.scan_likelihood_min; c.scan_max = P.scan_likelihood_max;
   c.pose_min = P.pose_likelihood_min; c.pose_max = P.pose_likelihood_max;
   c.a1 = P.srr; c.a2 = P.srt; c.a3 = P.str_; c.a4 = P.stt;
@@ -3575,7 +3606,7 @@ int scan_enqueue(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3
       if (bytes <= 48 * 1024) { occ_half = half; propose_lds += bytes; break; }
     }
   }
-  if (propose_lds > (size_t)kMaxLds - 1024) return TBNAV_ERR_UNSUPPORTED;  // scan x samples too large for one workgroup's LDS
+  if (propose_lds > (size_t)kMaxLds - 2048) return TBNAV_ERR_UNSUPPORTED;  // scan x samples too large for one workgroup's LDS
   const int* skip_arr = h->df_mode == 2 ? h->d_fstate : h->d_skip;
   const int skip_eq = h->df_mode == 2 ? 2 : 1;
   const double* center = nullptr;
@@ -3585,13 +3616,13 @@ int scan_enqueue(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3
                           (propose_lds - propose_lds_base);
     hipLaunchKernelGGL(rbpf_scanmatch, dim3(h->N), dim3(kMatchThreads), sm_lds, st, c, h->sm, beams_dev, h->d_code[h->cur],
                        h->pool, map_of(h), h->d_trow[h->cur], skip_arr, skip_eq, h->df_mode, h->radius, occ_half,
-                       h->d_nocc[h->cur], h->d_win, sp.pose, h->d_center, h->d_score, d_err, gate_prev);
+                       h->d_nocc[h->cur], h->d_win, sp.pose, h->d_center, h->d_score, d_err, gate_prev, h->d_mixlut);
     TBNAV_HIP(hipGetLastError());
     center = h->d_center;
   }
   hipLaunchKernelGGL(rbpf_propose, dim3(h->N), dim3(kProposeThreads), propose_lds, st, c, beams_dev,
                      h->d_code[h->cur], h->pool, map_of(h), h->d_trow[h->cur], skip_arr, skip_eq, h->df_mode, h->radius, occ_half,
-                     h->d_nocc[h->cur], h->d_win, normals_dev, center, sp.pose, sp.prev, sp.weight, h->tr, h->d_sens, d_err, gate_prev);
+                     h->d_nocc[h->cur], h->d_win, normals_dev, center, sp.pose, sp.prev, sp.weight, h->tr, h->d_sens, d_err, gate_prev, h->d_mixlut);
   TBNAV_HIP(hipGetLastError());
   if (h->timing) TBNAV_HIP(hipEventRecord(h->ev[2], st));
   // normalise / select needs only the weights the proposal kernel left: it rides in the map update's launch as one extra
@@ -3877,12 +3908,20 @@ int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf*
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 1024);
   // the proposal / scan-match kernels carry the scan, the per-sample data and the bitmap slice: more than the 64 KB
   // default for long scans or many samples
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_propose), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_propose), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 2048);  // (1.8 KB static)
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_scanmatch), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_edt_compact<kEdtRowsA>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)edt_compact_lds(kEdtRowsA));
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_edt_compact<kEdtRowsB>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)edt_compact_lds(kEdtRowsB));
+  A((void**)&h->d_mixlut, sizeof(double) * kMixLut);
+  if (e == hipSuccess) {
+    ScanC cm{};
+    if (mixture_consts(h, cm)) {  // (a zero variance is reported by the first scan, as the reference throws there)
+      hipLaunchKernelGGL(rbpf_mix_lut, dim3(kMixLut / 256), dim3(256), 0, h->stream, cm, h->d_mixlut);
+      e = hipGetLastError();
+    }
+  }
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) {
     const int rc = tbnav::hip_fail(e, "tbnav_rbpf_create allocation", __FILE__, __LINE__);
@@ -3961,7 +4000,7 @@ void tbnav_rbpf_destroy(tbnav_rbpf* h) {
   (void)hipFree(h->d_sens); (void)hipFree(h->d_shed); (void)hipFree(h->d_dense); (void)hipFree(h->d_cs); (void)hipFree(h->d_touched); (void)hipFree(h->d_fstate_alt);
   (void)hipFree(h->d_log_ev); (void)hipFree(h->d_log_cnt); (void)hipFree(h->d_tile_scratch);
   (void)hipFree(h->d_gw); (void)hipFree(h->d_gcs); (void)hipFree(h->d_gparent); (void)hipFree(h->d_gz);
-  (void)hipFree(h->d_beams); (void)hipFree(h->d_normals); (void)hipFree(h->d_parent); (void)hipFree(h->d_best); (void)hipFree(h->d_best_pose); (void)hipFree(h->d_export); (void)hipFree(h->d_tier); (void)hipFree(h->d_fstate); (void)hipFree(h->d_skip); (void)hipFree(h->d_win); (void)hipFree(h->d_center); (void)hipFree(h->d_score);
+  (void)hipFree(h->d_beams); (void)hipFree(h->d_normals); (void)hipFree(h->d_parent); (void)hipFree(h->d_best); (void)hipFree(h->d_best_pose); (void)hipFree(h->d_export); (void)hipFree(h->d_tier); (void)hipFree(h->d_fstate); (void)hipFree(h->d_skip); (void)hipFree(h->d_win); (void)hipFree(h->d_center); (void)hipFree(h->d_mixlut); (void)hipFree(h->d_score);
   (void)hipFree(h->d_trace);
   (void)hipHostFree(h->h_beams); (void)hipHostFree(h->h_err); (void)hipHostFree(h->h_norm); (void)hipFree(h->d_gate);
   for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
@@ -4553,7 +4592,7 @@ int tbnav_rbpf_likelihood(tbnav_rbpf* h, int32_t particle, const float* scan, in
   if (rc != TBNAV_OK) return rc;
   for (int q = 0; q < 4; ++q) h->h_err[q] = 0;
   hipLaunchKernelGGL(rbpf_likelihood_one, dim3(1), dim3(kWave), 0, h->stream, c, h->d_beams, h->d_code[h->cur], h->pool, map_of(h),
-                     h->d_trow[h->cur], h->d_fstate, h->radius, h->d_nocc[h->cur], pose[0], pose[1], pose[2], h->d_score, h->d_err);
+                     h->d_trow[h->cur], h->d_fstate, h->radius, h->d_nocc[h->cur], pose[0], pose[1], pose[2], h->d_score, h->d_err, h->d_mixlut);
   TBNAV_HIP(hipGetLastError());
   TBNAV_HIP(hipMemcpyAsync(out, h->d_score, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   TBNAV_HIP(hipStreamSynchronize(h->stream));
