@@ -82,13 +82,14 @@ class ShardedMPPI:
         self.group = group
         self.world = _world(group)
         self._gathered = None
+        self._gloo = _backend_is_gloo(group)  # (looked up once: a tick is a few tens of microseconds)
 
     def tick(self, x0, noise):
         rec = self.b.partials(x0, noise)
         if self.world == 1:
             self.b.combine(rec, 1)
             return
-        if _backend_is_gloo(self.group) and rec.is_cuda:
+        if self._gloo and rec.is_cuda:
             # gloo moves host memory: stage the (tiny) record set through the CPU
             host = rec.cpu().reshape(-1)
             out = torch.empty(self.world * host.numel(), dtype=host.dtype)
