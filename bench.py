@@ -345,7 +345,7 @@ def multi_gpu_legs(world, rank, local_rank, device, one_gpu_test, stream, sync, 
     pf = ParticleFilter(default_params(N=n_local, k=k, map_min=-10.0, map_max=10.0, device=local_rank))
     pf.setSeed(2026 + rank)
     sr = ShardedRBPF(HipRbpfShardBackend(pf, device))
-    t_total, n_timed, resamples = 0.0, 0, 0
+    t_total, n_timed, resamples, t_res, t_plain = 0.0, 0, 0, [], []
     for s, (prev, cur, t_icp, u) in enumerate(steps):
         if s in (6, 10):  # skew the GLOBAL weights: heavy particles on the first and the last rank
             w = np.full(n_local, 0.2 / (n_local * world))
@@ -361,6 +361,7 @@ def multi_gpu_legs(world, rank, local_rank, device, one_gpu_test, stream, sync, 
         dt = time.perf_counter() - t0
         if s >= 2:
             t_total += dt; n_timed += 1
+            (t_res if st.resampled else t_plain).append(dt)
         resamples += st.resampled
     t = torch.tensor([t_total], dtype=torch.float64, device="cpu" if one_gpu_test else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -368,6 +369,8 @@ def multi_gpu_legs(world, rank, local_rank, device, one_gpu_test, stream, sync, 
                                        "global selection per scan, particle migration when resampling fires",
                            "particle_updates_per_s": round(n_local * world * n_timed / float(t.item()), 1),
                            "ms_per_scan": round(float(t.item()) / n_timed * 1e3, 4), "scans_timed": n_timed, "resamples": resamples,
+                           "ms_per_scan_rank0": {"without_resample": round(float(np.mean(t_plain)) * 1e3, 4) if t_plain else None,
+                                                 "resampling_with_migration": round(float(np.mean(t_res)) * 1e3, 4) if t_res else None},
                            "bytes_migrated_rank0": sr.bytes_migrated, "scaling": "weak"}
     pf.close()
     return out

@@ -185,6 +185,16 @@ int tbnav_rbpf_gather_local(tbnav_rbpf* h, const int32_t* local_parent /*[N], -1
 int tbnav_rbpf_export_size(tbnav_rbpf* h, int32_t slot, uint64_t* bytes);
 int tbnav_rbpf_export_particle_dev(tbnav_rbpf* h, int32_t slot, void* d_buf, uint64_t capacity, uint64_t* bytes);
 int tbnav_rbpf_import_particle_dev(tbnav_rbpf* h, int32_t slot, const void* d_buf, uint64_t bytes);
+/* The same for many particles per call (a cross-rank resample moves hundreds per rank; slots / sizes / offsets are host
+ * arrays).  export: the blobs of slots[0..n) back to back in d_buf (a slot may be listed more than once), offsets_out[i] =
+ * where blob i starts, offsets_out[n] = bytes written; sizes first (export_batch_sizes) to size the buffer and tell the
+ * receivers.  import: slot slots[i] (each at most once) takes the blob at d_buf + offsets[i] (several slots may name the
+ * same blob).  Two launches each, whatever n. */
+int tbnav_rbpf_export_batch_sizes(tbnav_rbpf* h, int32_t n, const int32_t* slots, uint64_t* sizes_out /*[n]*/);
+int tbnav_rbpf_export_batch_dev(tbnav_rbpf* h, int32_t n, const int32_t* slots, void* d_buf, uint64_t capacity,
+                                uint64_t* offsets_out /*[n + 1]*/);
+int tbnav_rbpf_import_batch_dev(tbnav_rbpf* h, int32_t n, const int32_t* slots, const void* d_buf, uint64_t bytes,
+                                const uint64_t* offsets /*[n]*/);
 /* Particle src_slot of `src` -> dst_slot of `dst` (same device, same grid, same distance-field mode): the deep copy
  * behind bmapping::GridMapper's value semantics.  In the REFERENCE mode the occupied set travels with its history. */
 int tbnav_rbpf_copy_particle(tbnav_rbpf* dst, int32_t dst_slot, tbnav_rbpf* src, int32_t src_slot);

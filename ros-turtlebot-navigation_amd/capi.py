@@ -165,6 +165,9 @@ def lib() -> C.CDLL:
         "tbnav_rbpf_export_size": (C.c_int, [vp, i32, C.POINTER(u64)]),
         "tbnav_rbpf_export_particle_dev": (C.c_int, [vp, i32, vp, u64, C.POINTER(u64)]),
         "tbnav_rbpf_import_particle_dev": (C.c_int, [vp, i32, vp, u64]),
+        "tbnav_rbpf_export_batch_sizes": (C.c_int, [vp, i32, vp, vp]),
+        "tbnav_rbpf_export_batch_dev": (C.c_int, [vp, i32, vp, vp, u64, vp]),
+        "tbnav_rbpf_import_batch_dev": (C.c_int, [vp, i32, vp, vp, u64, vp]),
         "tbnav_rbpf_copy_particle": (C.c_int, [vp, i32, vp, i32]),
         "tbnav_rbpf_best_state": (C.c_int, [vp, dp, C.POINTER(i32)]),
         "tbnav_rbpf_best_map": (C.c_int, [vp, vp]),

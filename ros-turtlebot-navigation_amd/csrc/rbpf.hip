@@ -2964,6 +2964,148 @@ __global__ __launch_bounds__(256) void rbpf_unpack_tiles(TilePool P, MapT M, int
   if (threadIdx.x < kTS) P.bm[(size_t)sid * kTS + threadIdx.x] = in_bm[(size_t)blockIdx.x * kTS + threadIdx.x];
 }
 
+// ---- the same, many particles per launch (a cross-rank resample moves hundreds of particles per rank: one call per particle
+//      is a host round trip each).  The buffer is the per-particle blobs of tbnav_rbpf_export_particle_dev back to back.
+struct BlobHeader { uint64_t magic; uint32_t n_tiles, has_codes; int32_t nocc, fstate; uint32_t xsize, TT; };
+constexpr uint64_t kBlobMagic = 0x54424e4156504631ull;  // "TBNAVPF1"
+struct BlobLayout { size_t state, tidx, tiles, tile_bm, trow, codes, total; };
+__host__ __device__ inline BlobLayout blob_layout_hd(int TW, size_t G, uint32_t n_tiles, bool has_codes) {
+  auto up8 = [](size_t v) { return (v + 7) & ~(size_t)7; };
+  BlobLayout L{};
+  size_t o = sizeof(BlobHeader);
+  L.state = o; o += sizeof(double) * 7;
+  L.tidx = o; o = up8(o + sizeof(uint32_t) * n_tiles);
+  L.tiles = o; o += sizeof(double) * kTileCells * n_tiles;
+  L.tile_bm = o; o = up8(o + sizeof(unsigned int) * kTS * n_tiles);
+  L.trow = o; o = up8(o + sizeof(int) * TW);
+  L.codes = o; if (has_codes) o = up8(o + sizeof(uint16_t) * G);
+  L.total = o;
+  return L;
+}
+struct BatchItem { int slot; unsigned int n_tiles; int has_codes; int pad; unsigned long long off; };
+// tiles named by each listed slot's table, and the slot's field state
+__global__ __launch_bounds__(256) void rbpf_count_tiles(MapT M, const int* __restrict__ slots, const int* __restrict__ fstate, int2* __restrict__ out) {
+  __shared__ int tot;
+  if (threadIdx.x == 0) tot = 0;
+  __syncthreads();
+  const int slot = slots[blockIdx.x];
+  const unsigned int* tab = M.table + (size_t)slot * M.TT;
+  int c = 0;
+  for (int t = threadIdx.x; t < M.TT; t += blockDim.x) c += tab[t] != 0u ? 1 : 0;
+  if (c) atomicAdd(&tot, c);
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = int2{tot, fstate[slot]};
+}
+// one workgroup per exported particle: header, state, tile indices (ascending), tile payloads, tile-row counts, stored field
+__global__ __launch_bounds__(256) void rbpf_pack_batch(TilePool P, MapT M, const double* __restrict__ pose, const double* __restrict__ prev,
+                                                       const double* __restrict__ weight, const int* __restrict__ trow, const int* __restrict__ nocc,
+                                                       const int* __restrict__ fstate, const uint16_t* __restrict__ codes, size_t G, int xsize,
+                                                       const BatchItem* __restrict__ items, char* __restrict__ buf) {
+  const BatchItem it = items[blockIdx.x];
+  const int slot = it.slot, tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+  const BlobLayout L = blob_layout_hd(M.TW, G, it.n_tiles, it.has_codes != 0);
+  char* b = buf + it.off;
+  const unsigned int* tab = M.table + (size_t)slot * M.TT;
+  unsigned int* tidx = reinterpret_cast<unsigned int*>(b + L.tidx);
+  if (tid == 0) {
+    *reinterpret_cast<BlobHeader*>(b) = BlobHeader{kBlobMagic, it.n_tiles, it.has_codes ? 1u : 0u, nocc[slot], fstate[slot], (uint32_t)xsize, (uint32_t)M.TT};
+    double* bs = reinterpret_cast<double*>(b + L.state);
+    for (int q = 0; q < 3; ++q) { bs[q] = pose[(size_t)slot * 3 + q]; bs[3 + q] = prev[(size_t)slot * 3 + q]; }
+    bs[6] = weight[slot];
+  }
+  __shared__ int base, wcnt[4];
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (int t0 = 0; t0 < M.TT; t0 += 256) {
+    const int t = t0 + tid;
+    const bool f = t < M.TT && tab[t] != 0u;
+    const unsigned long long m = __ballot(f);
+    if (lane == 0) wcnt[wv] = __popcll(m);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wv; ++w) off += wcnt[w];
+    if (f) tidx[off + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned int)t;
+    __syncthreads();
+    if (tid == 0) base += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    __syncthreads();
+  }
+  // (tidx was written by this workgroup: visible to it after the barrier)
+  double2* dst = reinterpret_cast<double2*>(b + L.tiles);
+  for (size_t i = tid; i < (size_t)it.n_tiles * (kTileCells / 2); i += 256) {
+    const unsigned int id = tab[tidx[i / (kTileCells / 2)]];
+    dst[i] = reinterpret_cast<const double2*>(P.lo + (size_t)id * kTileCells)[i % (kTileCells / 2)];
+  }
+  unsigned int* dbm = reinterpret_cast<unsigned int*>(b + L.tile_bm);
+  for (size_t i = tid; i < (size_t)it.n_tiles * kTS; i += 256) dbm[i] = P.bm[(size_t)tab[tidx[i / kTS]] * kTS + (i % kTS)];
+  int* dtr = reinterpret_cast<int*>(b + L.trow);
+  for (int r = tid; r < M.TW; r += 256) dtr[r] = trow[(size_t)slot * M.TW + r];
+  if (it.has_codes) {
+    uint16_t* dc = reinterpret_cast<uint16_t*>(b + L.codes);
+    const uint16_t* sc = codes + (size_t)slot * G;
+    for (size_t i = tid; i < G; i += 256) dc[i] = sc[i];
+  }
+}
+__global__ __launch_bounds__(256) void rbpf_blob_headers(const BatchItem* __restrict__ items, const char* __restrict__ buf, BlobHeader* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = *reinterpret_cast<const BlobHeader*>(buf + items[i].off);
+}
+__global__ __launch_bounds__(256) void rbpf_release_slots(TilePool P, MapT M, const BatchItem* __restrict__ items) {
+  const int p = items[blockIdx.x].slot;
+  unsigned int* tab = M.table + (size_t)p * M.TT;
+  unsigned int* shed = M.shed + (size_t)p * M.TT;
+  for (int t = threadIdx.x; t < M.TT; t += blockDim.x) {
+    const unsigned int id = tab[t], sh = shed[t];
+    if (id && atomicSub(&P.ref[id], 1) == 1) tile_push(P, id);
+    if (sh && atomicSub(&P.ref[sh], 1) == 1) tile_push(P, sh);
+    tab[t] = 0u; shed[t] = 0u;
+  }
+}
+// one workgroup per imported particle (its slot was released by the launch before): ONE pop for all its tiles
+__global__ __launch_bounds__(256) void rbpf_unpack_batch(TilePool P, MapT M, double* __restrict__ pose, double* __restrict__ prev,
+                                                         double* __restrict__ weight, int* __restrict__ trow, int* __restrict__ nocc,
+                                                         int* __restrict__ fstate, uint16_t* __restrict__ codes, size_t G,
+                                                         const BatchItem* __restrict__ items, const char* __restrict__ buf, int* __restrict__ err) {
+  const BatchItem it = items[blockIdx.x];
+  const int slot = it.slot, tid = threadIdx.x;
+  const char* b = buf + it.off;
+  const BlobHeader hd = *reinterpret_cast<const BlobHeader*>(b);
+  const BlobLayout L = blob_layout_hd(M.TW, G, hd.n_tiles, hd.has_codes != 0);
+  __shared__ unsigned long long sbase;
+  if (tid == 0) sbase = hd.n_tiles ? tile_pop_n(P, hd.n_tiles) : 0ull;
+  __syncthreads();
+  const unsigned long long pos = sbase;
+  if (pos == ~0ull) { if (tid == 0) atomicOr(&err[3], 8); return; }  // pool exhausted: the slot keeps the empty map
+  const unsigned int* tidx = reinterpret_cast<const unsigned int*>(b + L.tidx);
+  const double2* src = reinterpret_cast<const double2*>(b + L.tiles);
+  for (size_t i = tid; i < (size_t)hd.n_tiles * (kTileCells / 2); i += 256)
+    reinterpret_cast<double2*>(P.lo + (size_t)tile_at(P, pos + i / (kTileCells / 2)) * kTileCells)[i % (kTileCells / 2)] = src[i];
+  const unsigned int* sbm = reinterpret_cast<const unsigned int*>(b + L.tile_bm);
+  for (size_t i = tid; i < (size_t)hd.n_tiles * kTS; i += 256) P.bm[(size_t)tile_at(P, pos + i / kTS) * kTS + (i % kTS)] = sbm[i];
+  for (unsigned int j = tid; j < hd.n_tiles; j += 256) {
+    const unsigned int id = tile_at(P, pos + j);
+    P.ref[id] = 1;
+    M.table[(size_t)slot * M.TT + tidx[j]] = id;
+  }
+  const int* str = reinterpret_cast<const int*>(b + L.trow);
+  for (int r = tid; r < M.TW; r += 256) trow[(size_t)slot * M.TW + r] = str[r];
+  if (tid == 0) {
+    const double* bs = reinterpret_cast<const double*>(b + L.state);
+    for (int q = 0; q < 3; ++q) { pose[(size_t)slot * 3 + q] = bs[q]; prev[(size_t)slot * 3 + q] = bs[3 + q]; }
+    weight[slot] = bs[6];
+    nocc[slot] = hd.nocc;
+    fstate[slot] = hd.has_codes ? 2 : 0;
+  }
+  if (hd.has_codes) {
+    const uint16_t* sc = reinterpret_cast<const uint16_t*>(b + L.codes);
+    uint16_t* dc = codes + (size_t)slot * G;
+    for (size_t i = tid; i < G; i += 256) dc[i] = sc[i];
+  }
+}
+__global__ __launch_bounds__(256) void rbpf_gather_weights(int N, const double* __restrict__ gw, const int* __restrict__ parent, double* __restrict__ weight) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m < N) weight[m] = gw[parent[m]];
+}
+
 // ---- getRobotState / newMap on the device ------------------------------------------
 // arg-max weight with the reference's tie rule (strict '>', first wins, starting from 0.0:
 // particle_filter.cpp:260-267): the smallest index among the maxima, 0 if no weight is positive.
@@ -3073,6 +3215,9 @@ struct tbnav_rbpf {
   bool sm_on = false;          // N1 option: per-particle scan matching before sampling (tbnav_rbpf_set_scan_matching)
   ScanMatchC sm{0.05, 0.05, 5, 64};
   double* d_center = nullptr;  // [N][3] matched poses of the last call
+  // scratch of the batched export / import (tbnav_rbpf_export_batch_dev ...): grown on demand
+  int* d_bslots = nullptr; int2* d_bcount = nullptr; BatchItem* d_bitems = nullptr; BlobHeader* d_bhdr = nullptr; size_t batch_cap = 0;
+  std::vector<int> batch_slots; std::vector<int2> batch_counts;  // the slots last counted and what was found (sizes -> export)
   double* d_mixlut = nullptr;  // [kMixLut] mixture term per distance code (constants of the handle: tabulated once at create)
   double* d_score = nullptr;   // [N]
   bool timing = false;         // record HIP events round the kernels (tbnav_rbpf_set_timing): each costs device time, so off by default
@@ -4000,7 +4145,7 @@ void tbnav_rbpf_destroy(tbnav_rbpf* h) {
   (void)hipFree(h->d_sens); (void)hipFree(h->d_shed); (void)hipFree(h->d_dense); (void)hipFree(h->d_cs); (void)hipFree(h->d_touched); (void)hipFree(h->d_fstate_alt);
   (void)hipFree(h->d_log_ev); (void)hipFree(h->d_log_cnt); (void)hipFree(h->d_tile_scratch);
   (void)hipFree(h->d_gw); (void)hipFree(h->d_gcs); (void)hipFree(h->d_gparent); (void)hipFree(h->d_gz);
-  (void)hipFree(h->d_beams); (void)hipFree(h->d_normals); (void)hipFree(h->d_parent); (void)hipFree(h->d_best); (void)hipFree(h->d_best_pose); (void)hipFree(h->d_export); (void)hipFree(h->d_tier); (void)hipFree(h->d_fstate); (void)hipFree(h->d_skip); (void)hipFree(h->d_win); (void)hipFree(h->d_center); (void)hipFree(h->d_mixlut); (void)hipFree(h->d_score);
+  (void)hipFree(h->d_beams); (void)hipFree(h->d_normals); (void)hipFree(h->d_parent); (void)hipFree(h->d_best); (void)hipFree(h->d_best_pose); (void)hipFree(h->d_export); (void)hipFree(h->d_tier); (void)hipFree(h->d_fstate); (void)hipFree(h->d_skip); (void)hipFree(h->d_win); (void)hipFree(h->d_center); (void)hipFree(h->d_mixlut); (void)hipFree(h->d_bslots); (void)hipFree(h->d_bcount); (void)hipFree(h->d_bitems); (void)hipFree(h->d_bhdr); (void)hipFree(h->d_score);
   (void)hipFree(h->d_trace);
   (void)hipHostFree(h->h_beams); (void)hipHostFree(h->h_err); (void)hipHostFree(h->h_norm); (void)hipFree(h->d_gate);
   for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
@@ -4232,36 +4377,38 @@ int tbnav_rbpf_resample_global_dev(tbnav_rbpf* h, const double* d_weights_all, i
   return TBNAV_OK;
 }
 
+namespace {
+int batch_scratch(tbnav_rbpf* h, size_t n) {
+  if (n <= h->batch_cap) return TBNAV_OK;
+  (void)hipFree(h->d_bslots); (void)hipFree(h->d_bcount); (void)hipFree(h->d_bitems); (void)hipFree(h->d_bhdr);
+  h->d_bslots = nullptr; h->d_bcount = nullptr; h->d_bitems = nullptr; h->d_bhdr = nullptr; h->batch_cap = 0;
+  const size_t cap = n + n / 2 + 64;
+  TBNAV_HIP(hipMalloc((void**)&h->d_bslots, sizeof(int) * cap));
+  TBNAV_HIP(hipMalloc((void**)&h->d_bcount, sizeof(int2) * cap));
+  TBNAV_HIP(hipMalloc((void**)&h->d_bitems, sizeof(BatchItem) * cap));
+  TBNAV_HIP(hipMalloc((void**)&h->d_bhdr, sizeof(BlobHeader) * cap));
+  h->batch_cap = cap;
+  return TBNAV_OK;
+}
+}  // namespace
+
 int tbnav_rbpf_set_weights_from_global_dev(tbnav_rbpf* h, const int32_t* global_parent_of_slot /*[N]*/) {
   // after a resample every slot carries its parent's normalised weight (weights are NOT reset, particle_filter.cpp:495)
   if (!h || !global_parent_of_slot || !h->d_gw) return TBNAV_ERR_INVALID_ARG;
   DeviceGuard guard(h->device);
   StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
-  for (int m = 0; m < h->N; ++m) {
+  for (int m = 0; m < h->N; ++m)
     if (global_parent_of_slot[m] < 0 || (size_t)global_parent_of_slot[m] >= h->g_cap) return TBNAV_ERR_INVALID_ARG;
-    TBNAV_HIP(hipMemcpyAsync(sp.weight + m, h->d_gw + global_parent_of_slot[m], sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-  }
-  TBNAV_HIP(hipStreamSynchronize(h->stream));
+  { const int rc = batch_scratch(h, (size_t)h->N); if (rc != TBNAV_OK) return rc; }
+  TBNAV_HIP(hipMemcpyAsync(h->d_bslots, global_parent_of_slot, sizeof(int) * h->N, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(rbpf_gather_weights, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, h->N, h->d_gw, h->d_bslots, sp.weight);
+  TBNAV_HIP(hipGetLastError());
+  TBNAV_HIP(hipStreamSynchronize(h->stream));  // (the parent list is the caller's)
   return TBNAV_OK;
 }
 
 namespace {
-struct BlobHeader { uint64_t magic; uint32_t n_tiles, has_codes; int32_t nocc, fstate; uint32_t xsize, TT; };
-constexpr uint64_t kBlobMagic = 0x54424e4156504631ull;  // "TBNAVPF1"
-struct BlobLayout { size_t state, tidx, tiles, tile_bm, trow, codes, total; };
-BlobLayout blob_layout(const tbnav_rbpf* h, uint32_t n_tiles, bool has_codes) {
-  auto up8 = [](size_t v) { return (v + 7) & ~(size_t)7; };
-  BlobLayout L{};
-  size_t o = sizeof(BlobHeader);
-  L.state = o; o += sizeof(double) * 7;
-  L.tidx = o; o = up8(o + sizeof(uint32_t) * n_tiles);
-  L.tiles = o; o += sizeof(double) * kTileCells * n_tiles;
-  L.tile_bm = o; o = up8(o + sizeof(unsigned int) * kTS * n_tiles);
-  L.trow = o; o = up8(o + sizeof(int) * h->TW);
-  L.codes = o; if (has_codes) o = up8(o + sizeof(uint16_t) * h->G);
-  L.total = o;
-  return L;
-}
+BlobLayout blob_layout(const tbnav_rbpf* h, uint32_t n_tiles, bool has_codes) { return blob_layout_hd(h->TW, h->G, n_tiles, has_codes); }
 int slot_tiles(tbnav_rbpf* h, int slot, std::vector<uint32_t>& tidx, std::vector<uint32_t>& ids, int& fstate) {
   std::vector<uint32_t> row(h->TT);
   TBNAV_HIP(hipStreamSynchronize(h->stream));
@@ -4350,6 +4497,101 @@ int tbnav_rbpf_import_particle_dev(tbnav_rbpf* h, int32_t slot, const void* d_bu
   }
   TBNAV_HIP(hipMemcpyAsync(h->d_fstate + slot, &fs, sizeof(int), hipMemcpyHostToDevice, st));
   TBNAV_HIP(hipStreamSynchronize(st));  // hd / fs are locals
+  if (h->h_err[3] & 8) return TBNAV_ERR_POOL_EXHAUSTED;
+  return TBNAV_OK;
+}
+
+// ---- the same for many particles at once (what a cross-rank resample needs: hundreds of particles per rank) ------------
+namespace {
+int count_batch(tbnav_rbpf* h, int32_t n, const int32_t* slots) {
+  for (int i = 0; i < n; ++i) if (slots[i] < 0 || slots[i] >= h->N) return TBNAV_ERR_INVALID_ARG;
+  { const int rc = batch_scratch(h, (size_t)n); if (rc != TBNAV_OK) return rc; }
+  h->batch_slots.assign(slots, slots + n);
+  h->batch_counts.resize(n);
+  TBNAV_HIP(hipMemcpyAsync(h->d_bslots, slots, sizeof(int) * n, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(rbpf_count_tiles, dim3(n), dim3(256), 0, h->stream, map_of(h), h->d_bslots, h->d_fstate, h->d_bcount);
+  TBNAV_HIP(hipGetLastError());
+  TBNAV_HIP(hipMemcpyAsync(h->batch_counts.data(), h->d_bcount, sizeof(int2) * n, hipMemcpyDeviceToHost, h->stream));
+  TBNAV_HIP(hipStreamSynchronize(h->stream));
+  return TBNAV_OK;
+}
+}  // namespace
+
+int tbnav_rbpf_export_batch_sizes(tbnav_rbpf* h, int32_t n, const int32_t* slots, uint64_t* sizes_out) {
+  if (!h || n < 0 || (n && (!slots || !sizes_out))) return TBNAV_ERR_INVALID_ARG;
+  if (n == 0) return TBNAV_OK;
+  DeviceGuard guard(h->device);
+  { const int rc = count_batch(h, n, slots); if (rc != TBNAV_OK) return rc; }
+  for (int i = 0; i < n; ++i)
+    sizes_out[i] = blob_layout(h, (uint32_t)h->batch_counts[i].x, h->batch_counts[i].y == 2 && h->d_code[0]).total;
+  return TBNAV_OK;
+}
+
+int tbnav_rbpf_export_batch_dev(tbnav_rbpf* h, int32_t n, const int32_t* slots, void* d_buf, uint64_t capacity, uint64_t* offsets_out) {
+  if (!h || n < 0 || (n && (!slots || !d_buf || !offsets_out))) return TBNAV_ERR_INVALID_ARG;
+  if (n == 0) { if (offsets_out) offsets_out[0] = 0; return TBNAV_OK; }
+  DeviceGuard guard(h->device);
+  // (the counts of tbnav_rbpf_export_batch_sizes are reused when they are for this very list: nothing changes a map in between)
+  if ((int)h->batch_slots.size() != n || !std::equal(slots, slots + n, h->batch_slots.begin())) {
+    const int rc = count_batch(h, n, slots);
+    if (rc != TBNAV_OK) return rc;
+  }
+  std::vector<BatchItem> items(n);
+  uint64_t off = 0;
+  for (int i = 0; i < n; ++i) {
+    const bool has_codes = h->batch_counts[i].y == 2 && h->d_code[0];
+    items[i] = BatchItem{slots[i], (unsigned int)h->batch_counts[i].x, has_codes ? 1 : 0, 0, off};
+    offsets_out[i] = off;
+    off += blob_layout(h, items[i].n_tiles, has_codes).total;
+  }
+  offsets_out[n] = off;
+  h->batch_slots.clear();
+  if (off > capacity) return TBNAV_ERR_INVALID_ARG;
+  StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
+  TBNAV_HIP(hipMemcpyAsync(h->d_bitems, items.data(), sizeof(BatchItem) * n, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(rbpf_pack_batch, dim3(n), dim3(256), 0, h->stream, h->pool, map_of(h), sp.pose, sp.prev, sp.weight, h->d_trow[h->cur],
+                     h->d_nocc[h->cur], h->d_fstate, h->d_code[h->cur], h->G, h->xsize, h->d_bitems, static_cast<char*>(d_buf));
+  TBNAV_HIP(hipGetLastError());
+  TBNAV_HIP(hipStreamSynchronize(h->stream));  // (items is a local; the caller sends the buffer next)
+  return TBNAV_OK;
+}
+
+int tbnav_rbpf_import_batch_dev(tbnav_rbpf* h, int32_t n, const int32_t* slots, const void* d_buf, uint64_t bytes, const uint64_t* offsets) {
+  if (!h || n < 0 || (n && (!slots || !d_buf || !offsets))) return TBNAV_ERR_INVALID_ARG;
+  if (n == 0) return TBNAV_OK;
+  DeviceGuard guard(h->device);
+  std::vector<char> seen(h->N, 0);
+  std::vector<BatchItem> items(n);
+  for (int i = 0; i < n; ++i) {
+    if (slots[i] < 0 || slots[i] >= h->N || seen[slots[i]] || offsets[i] + sizeof(BlobHeader) > bytes || (offsets[i] & 7)) return TBNAV_ERR_INVALID_ARG;
+    seen[slots[i]] = 1;  // (a slot receives one particle; one particle may fill several slots)
+    items[i] = BatchItem{slots[i], 0u, 0, 0, offsets[i]};
+  }
+  { const int rc = batch_scratch(h, (size_t)n); if (rc != TBNAV_OK) return rc; }
+  hipStream_t st = h->stream;
+  const char* b = static_cast<const char*>(d_buf);
+  TBNAV_HIP(hipMemcpyAsync(h->d_bitems, items.data(), sizeof(BatchItem) * n, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(rbpf_blob_headers, dim3((n + 255) / 256), dim3(256), 0, st, h->d_bitems, b, h->d_bhdr, n);
+  TBNAV_HIP(hipGetLastError());
+  std::vector<BlobHeader> hd(n);
+  TBNAV_HIP(hipMemcpyAsync(hd.data(), h->d_bhdr, sizeof(BlobHeader) * n, hipMemcpyDeviceToHost, st));
+  TBNAV_HIP(hipStreamSynchronize(st));
+  bool any_codes = false;
+  for (int i = 0; i < n; ++i) {
+    if (hd[i].magic != kBlobMagic || hd[i].xsize != (uint32_t)h->xsize || hd[i].TT != (uint32_t)h->TT || hd[i].n_tiles > (uint32_t)h->TT) return TBNAV_ERR_INVALID_ARG;
+    if (offsets[i] + blob_layout(h, hd[i].n_tiles, hd[i].has_codes != 0).total > bytes) return TBNAV_ERR_INVALID_ARG;
+    any_codes |= hd[i].has_codes != 0;
+  }
+  if (any_codes) { const int rc = ensure_codes(h); if (rc != TBNAV_OK) return rc; h->fstate_dirty = true; }
+  for (int q = 0; q < 4; ++q) h->h_err[q] = 0;
+  const MapT M = map_of(h);
+  StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
+  hipLaunchKernelGGL(rbpf_release_slots, dim3(n), dim3(256), 0, st, h->pool, M, h->d_bitems);  // pushes: all before the first pop
+  TBNAV_HIP(hipGetLastError());
+  hipLaunchKernelGGL(rbpf_unpack_batch, dim3(n), dim3(256), 0, st, h->pool, M, sp.pose, sp.prev, sp.weight, h->d_trow[h->cur], h->d_nocc[h->cur],
+                     h->d_fstate, h->d_code[h->cur], h->G, h->d_bitems, b, h->d_err);
+  TBNAV_HIP(hipGetLastError());
+  TBNAV_HIP(hipStreamSynchronize(st));
   if (h->h_err[3] & 8) return TBNAV_ERR_POOL_EXHAUSTED;
   return TBNAV_OK;
 }

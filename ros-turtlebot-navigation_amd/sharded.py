@@ -157,26 +157,34 @@ class HipRbpfShardBackend:
         gp = np.ascontiguousarray(global_parents_of_my_slots, dtype=np.int32)
         capi.check(self._L.tbnav_rbpf_set_weights_from_global_dev(self._h, gp.ctypes.data), "set_weights_from_global_dev")
 
-    def export_size(self, slot: int) -> int:
-        import ctypes as C
-        n = C.c_uint64()
-        capi.check(self._L.tbnav_rbpf_export_size(self._h, slot, C.byref(n)), "export_size")
-        return n.value
-
-    def export_blob(self, slot: int) -> torch.Tensor:
-        import ctypes as C
-        buf = torch.empty(self.export_size(slot), dtype=torch.uint8, device=self.device)
-        n = C.c_uint64()
-        capi.check(self._L.tbnav_rbpf_export_particle_dev(self._h, slot, buf.data_ptr(), buf.numel(), C.byref(n)), "export_particle_dev")
-        assert n.value == buf.numel()
-        return buf
+    def export_batch(self, slots):
+        """The particles in `slots` (local indices; repeats allowed) as ONE device buffer, blobs back to back.
+        Returns (buffer, offsets[n + 1]).  Two launches whatever n."""
+        n = len(slots)
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        if n == 0:
+            return torch.empty(0, dtype=torch.uint8, device=self.device), offs.astype(np.int64)
+        a = np.ascontiguousarray(slots, dtype=np.int32)
+        sizes = np.zeros(n, dtype=np.uint64)
+        capi.check(self._L.tbnav_rbpf_export_batch_sizes(self._h, n, a.ctypes.data, sizes.ctypes.data), "export_batch_sizes")
+        total = int(sizes.sum())
+        buf = torch.empty(total, dtype=torch.uint8, device=self.device)
+        capi.check(self._L.tbnav_rbpf_export_batch_dev(self._h, n, a.ctypes.data, buf.data_ptr(), total, offs.ctypes.data), "export_batch_dev")
+        assert int(offs[n]) == total
+        return buf, offs.astype(np.int64)
 
     def new_blob(self, nbytes: int) -> torch.Tensor:
         return torch.empty(nbytes, dtype=torch.uint8, device=self.device)
 
-    def import_blob(self, slot: int, blob: torch.Tensor):
-        torch.cuda.synchronize(self.device)  # the receive ran on the communicator's stream
-        capi.check(self._L.tbnav_rbpf_import_particle_dev(self._h, slot, blob.data_ptr(), blob.numel()), "import_particle_dev")
+    def import_batch(self, slots, buf: torch.Tensor, offsets):
+        """Slot slots[i] takes the blob at buf + offsets[i] (several slots may name one blob)."""
+        n = len(slots)
+        if n == 0:
+            return
+        torch.cuda.synchronize(self.device)  # the receive ran on the communicator's stream, the handle has its own
+        a = np.ascontiguousarray(slots, dtype=np.int32)
+        o = np.ascontiguousarray(offsets, dtype=np.uint64)
+        capi.check(self._L.tbnav_rbpf_import_batch_dev(self._h, n, a.ctypes.data, buf.data_ptr(), buf.numel(), o.ctypes.data), "import_batch_dev")
 
     def gather_local(self, local_parent: np.ndarray):
         capi.check(self._L.tbnav_rbpf_gather_local(self._h, np.ascontiguousarray(local_parent, dtype=np.int32).ctypes.data),
@@ -187,7 +195,7 @@ class ShardedRBPF:
     """ParticleFilter::SLAM over `world_size` particle shards (equal shard sizes).
 
     Backend protocol (HipRbpfShardBackend above; the CPU tests plug in a numpy stand-in): slam_local, weights_tensor,
-    resample, set_weights_after_resample, export_size, export_blob, new_blob, import_blob, gather_local."""
+    resample, set_weights_after_resample, export_batch, new_blob, import_batch, gather_local."""
 
     def __init__(self, backend, group=None):
         self.b = backend
@@ -233,42 +241,53 @@ class ShardedRBPF:
 
     def _migrate(self, parents: np.ndarray):
         """Slot m (global) takes the state of particle parents[m].  Parents on this rank are gathered inside the
-        handle (tile tables + reference counts); a parent on another rank arrives as one device buffer: its state,
-        counts and the tiles it owns — point to point, only for the slots that need it."""
+        handle (tile tables + reference counts); parents on another rank arrive as device buffers — a particle is its
+        state, counts and the tiles it owns.  ONE export of everything this rank sends, one message per destination,
+        one receive buffer, one import: a handful of launches and host round trips per rank whatever the number of
+        particles that move (hundreds per rank in a resample of 1000 particles per rank)."""
         nl, me = self.n_local, self.rank
         lo = me * nl
-        sends = sorted({(m // nl, int(q)) for m, q in enumerate(parents) if q // nl == me and m // nl != me})
-        recvs = sorted({(int(parents[m]) // nl, int(parents[m])) for m in range(lo, lo + nl) if parents[m] // nl != me})
-        blobs = {key: self.b.export_blob(key[1] - lo) for key in sends}  # export BEFORE anything is overwritten
-        received = {}
+        sends = sorted({(m // nl, int(q)) for m, q in enumerate(parents) if q // nl == me and m // nl != me})   # (dst, q)
+        recvs = sorted({(int(parents[m]) // nl, int(parents[m])) for m in range(lo, lo + nl) if parents[m] // nl != me})  # (src, q)
+        buf, offs = self.b.export_batch([q - lo for _, q in sends])  # BEFORE anything is overwritten; blobs in (dst, q) order
+        rbuf, roffs = None, np.zeros(len(recvs) + 1, dtype=np.int64)
         if self.world > 1:
             # sizes first: one small all-gather (a particle's blob depends on how many tiles it owns)
             mine = torch.zeros(nl, dtype=torch.int64)
-            for (_, q), blob in blobs.items():
-                mine[q - lo] = blob.numel()
+            for i, (_, q) in enumerate(sends):
+                mine[q - lo] = int(offs[i + 1] - offs[i])
             stage_cpu = _backend_is_gloo(self.group)
             sizes = torch.empty(self.n_global, dtype=torch.int64, device=mine.device if stage_cpu else self.b.device)
             _all_gather_flat(sizes, mine if stage_cpu else mine.to(self.b.device), self.group)
             sizes = sizes.cpu().numpy()
+            roffs[1:] = np.cumsum([int(sizes[q]) for _, q in recvs])
+            rbuf = torch.empty(int(roffs[-1]), dtype=torch.uint8) if stage_cpu else self.b.new_blob(int(roffs[-1]))
             ops, keep = [], []
-            for (dst, q), blob in sorted(blobs.items()):
-                t = blob.cpu() if (stage_cpu and blob.is_cuda) else blob
+
+            def groups(pairs):  # runs of equal peer in a list sorted by (peer, particle)
+                i = 0
+                while i < len(pairs):
+                    j = i
+                    while j < len(pairs) and pairs[j][0] == pairs[i][0]:
+                        j += 1
+                    yield pairs[i][0], i, j
+                    i = j
+            for dst, i, j in groups(sends):
+                t = buf[int(offs[i]):int(offs[j])]
+                t = t.cpu() if (stage_cpu and t.is_cuda) else t
                 keep.append(t)
                 ops.append(dist.P2POp(dist.isend, t, dst, group=self.group))
-                self.bytes_migrated += blob.numel()
-            for (src, q) in recvs:
-                t = torch.empty(int(sizes[q]), dtype=torch.uint8) if stage_cpu else self.b.new_blob(int(sizes[q]))
-                received[q] = t
-                ops.append(dist.P2POp(dist.irecv, t, src, group=self.group))
+                self.bytes_migrated += t.numel()
+            for src, i, j in groups(recvs):
+                ops.append(dist.P2POp(dist.irecv, rbuf[int(roffs[i]):int(roffs[j])], src, group=self.group))
             if ops:
                 for r in dist.batch_isend_irecv(ops):
                     r.wait()
         # local parents first (inside the handle), then the imported ones
         local_parent = np.array([int(parents[m]) - lo if parents[m] // nl == me else -1 for m in range(lo, lo + nl)], dtype=np.int32)
         self.b.gather_local(local_parent)
-        for m in range(lo, lo + nl):
-            q = int(parents[m])
-            if q // nl != me:
-                t = received[q]
-                dev = getattr(self.b, "device", torch.device("cpu"))
-                self.b.import_blob(m - lo, t if t.device == dev else t.to(dev))
+        if recvs:
+            where = {q: int(roffs[i]) for i, (_, q) in enumerate(recvs)}
+            slots = [m - lo for m in range(lo, lo + nl) if parents[m] // nl != me]
+            dev = getattr(self.b, "device", torch.device("cpu"))
+            self.b.import_batch(slots, rbuf if rbuf.device == dev else rbuf.to(dev), [where[int(parents[lo + sl])] for sl in slots])

@@ -131,22 +131,27 @@ class FakeRbpfBackend:
     def set_weights_after_resample(self, gp):
         self.state[:, 6] = self._wn[gp]
 
-    def export_size(self, slot):
-        return 8 * (7 + 2 * self.map_len + 1 + int(self.pad[slot]))
+    def _blob(self, slot):
+        return np.concatenate([self.state[slot], self.maps[slot], self.dist_maps[slot], [float(self.pad[slot])], np.zeros(int(self.pad[slot]))])
 
-    def export_blob(self, slot):
-        v = np.concatenate([self.state[slot], self.maps[slot], self.dist_maps[slot], [float(self.pad[slot])], np.zeros(int(self.pad[slot]))])
-        return self.torch.from_numpy(v.copy()).view(self.torch.uint8)
+    def export_batch(self, slots):
+        blobs = [self._blob(sl) for sl in slots]
+        offs = np.zeros(len(slots) + 1, dtype=np.int64)
+        offs[1:] = np.cumsum([8 * b.size for b in blobs])
+        if not blobs:
+            return self.torch.empty(0, dtype=self.torch.uint8), offs
+        return self.torch.from_numpy(np.concatenate(blobs).copy()).view(self.torch.uint8), offs
 
     def new_blob(self, n):
         return self.torch.empty(n, dtype=self.torch.uint8)
 
-    def import_blob(self, slot, t):
-        v = t.view(self.torch.float64).numpy()
+    def import_batch(self, slots, buf, offsets):
+        v = buf.view(self.torch.float64).numpy()
         L = self.map_len
-        self.state[slot], self.maps[slot], self.dist_maps[slot] = v[:7], v[7:7 + L], v[7 + L:7 + 2 * L]
-        self.pad[slot] = int(v[7 + 2 * L])
-        assert v.size == 7 + 2 * L + 1 + self.pad[slot]
+        for slot, off in zip(slots, offsets):
+            w = v[off // 8:]
+            self.state[slot], self.maps[slot], self.dist_maps[slot] = w[:7], w[7:7 + L], w[7 + L:7 + 2 * L]
+            self.pad[slot] = int(w[7 + 2 * L])
 
     def gather_local(self, local_parent):
         src = np.where(local_parent < 0, np.arange(self.n_local), local_parent)
