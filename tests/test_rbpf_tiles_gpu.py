@@ -148,3 +148,56 @@ def test_raycast_kernel_variants_are_bit_exact(gpu_pkg, variant):
     for m in (0, 11, N - 1):
         assert np.array_equal(pf.logOdds(m), _oracle_map(grid, None, scans, [h[m] for h in hist])), (variant, m)
     pf.close()
+
+
+def test_batched_export_equals_single_exports_and_imports_rebuild_the_particles(gpu_pkg):
+    """tbnav_rbpf_export_batch_dev writes exactly the blobs tbnav_rbpf_export_particle_dev writes, back to back (a slot listed
+    twice included); tbnav_rbpf_import_batch_dev into ANOTHER handle rebuilds pose / weight / map / occupied counts of every
+    listed slot (one blob into two slots too), releases what the slots held before, and refuses a slot listed twice."""
+    import ctypes as C
+    import torch
+    N, k = 12, 6
+    src = _dev(gpu_pkg, N=N, k=k)
+    dst = _dev(gpu_pkg, N=N, k=k)
+    steps, poses = rc.trajectory(3)
+    rng = np.random.default_rng(3)
+    for s, (prev, cur, t_icp, u) in enumerate(steps):
+        scan = orc.room_scan(poses[s], walls=rc.ROOM_SMALL, rng=rng)
+        for pf, seed in ((src, 70), (dst, 90)):  # two different filters: dst's slots hold maps of their own before the import
+            st = pf.SLAM(scan, u, cur, prev, True, t_icp, orc.normal_stream(seed + s, N * (3 * k + 3) + 1, 0.0, 1.0))
+            assert st.status == 0
+    L = src._L
+    slots = np.array([5, 0, 11, 5, 7], dtype=np.int32)
+    sizes = np.zeros(len(slots), dtype=np.uint64)
+    assert L.tbnav_rbpf_export_batch_sizes(src._h, len(slots), slots.ctypes.data, sizes.ctypes.data) == 0
+    buf = torch.zeros(int(sizes.sum()), dtype=torch.uint8, device="cuda")
+    offs = np.zeros(len(slots) + 1, dtype=np.uint64)
+    assert L.tbnav_rbpf_export_batch_dev(src._h, len(slots), slots.ctypes.data, buf.data_ptr(), buf.numel(), offs.ctypes.data) == 0
+    assert int(offs[-1]) == buf.numel() and np.array_equal(np.diff(offs), sizes)
+    for i, sl in enumerate(slots):
+        n = C.c_uint64()
+        assert L.tbnav_rbpf_export_size(src._h, int(sl), C.byref(n)) == 0 and n.value == sizes[i]
+        one = torch.zeros(n.value, dtype=torch.uint8, device="cuda")
+        assert L.tbnav_rbpf_export_particle_dev(src._h, int(sl), one.data_ptr(), one.numel(), None) == 0
+        assert torch.equal(one, buf[int(offs[i]):int(offs[i + 1])]), sl
+    assert L.tbnav_rbpf_export_batch_dev(src._h, len(slots), slots.ctypes.data, buf.data_ptr(), buf.numel() - 8, offs.ctypes.data) != 0  # too small
+    # import: dst slots 1, 2 <- src 5 (one blob twice), 3 <- src 0, 9 <- src 7
+    into = np.array([1, 2, 3, 9], dtype=np.int32)
+    frm = np.array([offs[0], offs[0], offs[1], offs[4]], dtype=np.uint64)
+    cap0, free0, _ = dst.poolStats()
+    assert L.tbnav_rbpf_import_batch_dev(dst._h, len(into), into.ctypes.data, buf.data_ptr(), buf.numel(), frm.ctypes.data) == 0
+    sp, sv, sw = src.particles()
+    dp, dv, dw = dst.particles()
+    for d, s_ in zip(into, (5, 5, 0, 7)):
+        assert np.array_equal(dp[d], sp[s_]) and np.array_equal(dv[d], sv[s_]) and dw[d] == sw[s_]
+        assert np.array_equal(dst.logOdds(int(d)), src.logOdds(s_))
+        assert np.array_equal(dst.distCode(int(d)), src.distCode(s_))   # materialised from the imported occupancy bits / counts
+    untouched = dst.logOdds(0)
+    dup = np.array([4, 4], dtype=np.int32)
+    assert L.tbnav_rbpf_import_batch_dev(dst._h, 2, dup.ctypes.data, buf.data_ptr(), buf.numel(), frm.ctypes.data) != 0
+    assert np.array_equal(dst.logOdds(0), untouched)
+    # the next scan runs on the imported maps like on any other
+    scan = orc.room_scan(poses[2], walls=rc.ROOM_SMALL, rng=rng)
+    cur = steps[2][1]
+    assert dst.SLAM(scan, (0.0, 0.0, 0.0), cur, cur, True, (0.0, 0.0, 0.0), orc.normal_stream(5, N * (3 * k + 3) + 1, 0.0, 1.0)).status == 0
+    src.close(); dst.close()
