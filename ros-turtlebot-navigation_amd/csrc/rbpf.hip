@@ -3217,7 +3217,7 @@ struct tbnav_rbpf {
   double* d_center = nullptr;  // [N][3] matched poses of the last call
   // scratch of the batched export / import (tbnav_rbpf_export_batch_dev ...): grown on demand
   int* d_bslots = nullptr; int2* d_bcount = nullptr; BatchItem* d_bitems = nullptr; BlobHeader* d_bhdr = nullptr; size_t batch_cap = 0;
-  std::vector<int> batch_slots; std::vector<int2> batch_counts;  // the slots last counted and what was found (sizes -> export)
+  std::vector<int2> batch_counts;  // tiles / field state of the slots counted last
   double* d_mixlut = nullptr;  // [kMixLut] mixture term per distance code (constants of the handle: tabulated once at create)
   double* d_score = nullptr;   // [N]
   bool timing = false;         // record HIP events round the kernels (tbnav_rbpf_set_timing): each costs device time, so off by default
@@ -4506,7 +4506,6 @@ namespace {
 int count_batch(tbnav_rbpf* h, int32_t n, const int32_t* slots) {
   for (int i = 0; i < n; ++i) if (slots[i] < 0 || slots[i] >= h->N) return TBNAV_ERR_INVALID_ARG;
   { const int rc = batch_scratch(h, (size_t)n); if (rc != TBNAV_OK) return rc; }
-  h->batch_slots.assign(slots, slots + n);
   h->batch_counts.resize(n);
   TBNAV_HIP(hipMemcpyAsync(h->d_bslots, slots, sizeof(int) * n, hipMemcpyHostToDevice, h->stream));
   hipLaunchKernelGGL(rbpf_count_tiles, dim3(n), dim3(256), 0, h->stream, map_of(h), h->d_bslots, h->d_fstate, h->d_bcount);
@@ -4531,11 +4530,9 @@ int tbnav_rbpf_export_batch_dev(tbnav_rbpf* h, int32_t n, const int32_t* slots, 
   if (!h || n < 0 || (n && (!slots || !d_buf || !offsets_out))) return TBNAV_ERR_INVALID_ARG;
   if (n == 0) { if (offsets_out) offsets_out[0] = 0; return TBNAV_OK; }
   DeviceGuard guard(h->device);
-  // (the counts of tbnav_rbpf_export_batch_sizes are reused when they are for this very list: nothing changes a map in between)
-  if ((int)h->batch_slots.size() != n || !std::equal(slots, slots + n, h->batch_slots.begin())) {
-    const int rc = count_batch(h, n, slots);
-    if (rc != TBNAV_OK) return rc;
-  }
+  // (counted again rather than trusting what tbnav_rbpf_export_batch_sizes saw: a scan in between would change the tables;
+  //  a tiny launch and one 8-byte-per-particle copy)
+  { const int rc = count_batch(h, n, slots); if (rc != TBNAV_OK) return rc; }
   std::vector<BatchItem> items(n);
   uint64_t off = 0;
   for (int i = 0; i < n; ++i) {
@@ -4545,7 +4542,6 @@ int tbnav_rbpf_export_batch_dev(tbnav_rbpf* h, int32_t n, const int32_t* slots, 
     off += blob_layout(h, items[i].n_tiles, has_codes).total;
   }
   offsets_out[n] = off;
-  h->batch_slots.clear();
   if (off > capacity) return TBNAV_ERR_INVALID_ARG;
   StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
   TBNAV_HIP(hipMemcpyAsync(h->d_bitems, items.data(), sizeof(BatchItem) * n, hipMemcpyHostToDevice, h->stream));
