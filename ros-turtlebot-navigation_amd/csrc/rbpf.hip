@@ -3029,7 +3029,8 @@ __global__ __launch_bounds__(256) void rbpf_pack_batch(TilePool P, MapT M, const
     if (tid == 0) base += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
     __syncthreads();
   }
-  // (tidx was written by this workgroup: visible to it after the barrier)
+  __threadfence_block();  // tidx was written by this workgroup: visible to all of it after the fence + the barrier above
+  __syncthreads();
   double2* dst = reinterpret_cast<double2*>(b + L.tiles);
   for (size_t i = tid; i < (size_t)it.n_tiles * (kTileCells / 2); i += 256) {
     const unsigned int id = tab[tidx[i / (kTileCells / 2)]];
