@@ -89,6 +89,13 @@ def test_rbpf_four_ranks_one_gpu_children_span_three_ranks(gpu_pkg):
     assert res[0]["migrated"] > 0
 
 
+@pytest.mark.parametrize("world,n_local,heavy", [(3, 7, {0: 0.3, 9: 0.3, 20: 0.3}), (3, 4, {11: 0.9}), (4, 3, {5: 0.45, 6: 0.45})])
+def test_rbpf_more_rank_layouts_equal_unsharded_bit_exact(gpu_pkg, world, n_local, heavy):
+    """Other shapes of the exchange: three heavy particles one per rank (every rank sends and receives), one particle of the
+    LAST rank taking nearly everything (all ranks import from it, it keeps itself), two neighbours on one rank feeding four."""
+    _rbpf_sharded_vs_unsharded(n_local, 8, 1, heavy, "gloo", world=world)
+
+
 def test_rbpf_two_ranks_two_gpus_rccl(gpu_pkg):
     """The same exchange over RCCL (backend "nccl"), one GPU per rank: device tensors end to end."""
     import torch
