@@ -46,7 +46,10 @@ constexpr int kWave = 64;
 #define TBNAV_PROPOSE_THREADS 256
 #endif
 #ifndef TBNAV_PROPOSE_WAVES
-#define TBNAV_PROPOSE_WAVES 3
+#define TBNAV_PROPOSE_WAVES 4  // four workgroups of four waves per CU (what its LDS allows): 128 VGPRs
+#endif
+#ifndef TBNAV_PROPOSE_KSB
+#define TBNAV_PROPOSE_KSB 1
 #endif
 constexpr int kProposeThreads = TBNAV_PROPOSE_THREADS;
 constexpr int kUnCap = 16;  // unstable beams handled by the per-pair path of the proposal kernel
@@ -328,7 +331,41 @@ __device__ __forceinline__ int nearest_d2_rows(RowWord row_word, int words, int 
   }
   return best;
 }
+// The whole search.  Inlined by the scan matcher (~100 poses x Bv lookups per particle, many of them beyond the 7 x 7 look);
+// the proposal kernel inlines a lookup at four places, and with both row walks in each of them it was ~100 KB of code against
+// a 64 KB instruction cache shared by two CUs: there only the 7 x 7 look on the LDS tile is inline (it decides nearly
+// every lookup of a beam that ends on or next to a wall) and the rest is ONE out-of-line copy.
+__device__ __forceinline__ uint16_t nearest_code_query_body(const GridC& g, const DistSrc& d, int radius, int ci, int cj);
+__device__ __attribute__((noinline)) uint16_t nearest_code_query_full(const GridC g, const DistSrc d, int radius, int ci, int cj) {
+  return nearest_code_query_body(g, d, radius, ci, cj);
+}
+template <bool OUTLINE = true>
 __device__ __forceinline__ uint16_t nearest_code_query(const GridC& g, const DistSrc& d, int radius, int ci, int cj) {
+  if constexpr (!OUTLINE) return nearest_code_query_body(g, d, radius, ci, cj);
+  if (d.nW > 0 && d.lut7) {
+    const int C0 = d.W0 * 64, C1 = (d.W0 + d.nW) * 64 - 1;
+    const int p0 = cj - C0 - 3, wi = p0 >> 5;
+    if (ci - 3 >= d.R0 && ci + 3 <= d.R1 && p0 >= 0 && wi + 1 < 2 * d.nW && cj <= C1) {
+      int clear = radius + 1;
+      if (d.R0 > 0) clear = min(clear, ci - d.R0 + 1);
+      if (d.R1 < g.xsize - 1) clear = min(clear, d.R1 - ci + 1);
+      if (C0 > 0) clear = min(clear, cj - C0 + 1);
+      if (C1 < g.ysize - 1) clear = min(clear, C1 - cj + 1);
+      const unsigned int* t32 = reinterpret_cast<const unsigned int*>(d.tbm) + wi;
+      const int sh = p0 & 31, stride = 2 * d.nW;
+      int bw = 0x7fffffff;
+#pragma unroll
+      for (int dr = -3; dr <= 3; ++dr) {
+        const unsigned int* rp = t32 + (ci + dr - d.R0) * stride;
+        const unsigned int pat = __builtin_amdgcn_alignbit(rp[1], rp[0], sh) & 0x7Fu;
+        bw = min(bw, dr * dr + (int)d.lut7[pat]);
+      }
+      if (bw <= 9 && bw <= clear * clear) return (uint16_t)bw;
+    }
+  }
+  return nearest_code_query_full(g, d, radius, ci, cj);
+}
+__device__ __forceinline__ uint16_t nearest_code_query_body(const GridC& g, const DistSrc& d, int radius, int ci, int cj) {
   if (d.nW > 0) {
     // LDS tile first.  Its answer is the map's answer when no cell outside the tile can be nearer: a side of the
     // tile that is not the map's own border is (distance to that side + 1) cells away at least.
@@ -396,8 +433,9 @@ __device__ __forceinline__ uint16_t nearest_code_query(const GridC& g, const Dis
   return (best <= radius * radius) ? (uint16_t)best : (d.code ? d.code[(size_t)ci * g.xsize + cj] : kCodeUnreached);
 }
 // Distance code of cell (ci, cj), or -1 when a windowed lookup falls outside the refreshed window.
+template <bool OUTLINE = true>
 __device__ __forceinline__ int lookup_code(const GridC& g, const DistSrc& d, int radius, int ci, int cj) {
-  if (d.mode == 2) return nearest_code_query(g, d, radius, ci, cj);
+  if (d.mode == 2) return nearest_code_query<OUTLINE>(g, d, radius, ci, cj);
   if (d.mode == 1 && (ci < d.win.x || ci > d.win.y || cj < d.win.z || cj > d.win.w)) return -1;
   return d.code[(size_t)ci * g.xsize + cj];
 }
@@ -680,7 +718,7 @@ __global__ __launch_bounds__(kMatchThreads) void rbpf_scanmatch(ScanC c, ScanMat
       int cd;
       if ((e >> 16) == cell1) cd = (int)(e & 0xFFFFull);
       else {
-        cd = lookup_code(c.g, ds, radius, ci, cj);
+        cd = lookup_code<false>(c.g, ds, radius, ci, cj);
         if (cd < 0) { oob |= 2; continue; }
         *slot = (cell1 << 16) | (unsigned long long)cd;
       }
@@ -994,7 +1032,7 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
         pscan[j] = pr;
       }
     } else {
-    constexpr int kSB = 4;  // samples per wave in flight: their shuffle chains overlap
+    constexpr int kSB = TBNAV_PROPOSE_KSB;  // samples per wave in flight (their shuffle chains overlap; each is an inlined copy of the lookup)
     for (int j0 = wid; j0 < k; j0 += kPW * kSB) {
       double pr[kSB];
 #pragma unroll
