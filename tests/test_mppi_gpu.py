@@ -364,3 +364,29 @@ def test_streaming_rollout_kernel_against_the_oracle(gpu_pkg, K, horizon):
         ref = _check_tick(m, d, u, (0, 0), WAYPOINTS[2], x0, _noise(90 + tick, K, T))
         u = ref["u"]
         x0 = (x0[0] + 0.002, x0[1] - 0.001, x0[2] + 0.003)
+
+
+def test_hip_against_frozen_vectors_G_A1_G_A2(gpu_pkg):
+    """The HIP path held against the committed vectors of tests/golden/path_mppi.npz (three
+    warm-started cfg1 ticks with everything stored, one cfg2 tick by seed) — no oracle computation in the loop."""
+    import os
+    import zlib
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "path_mppi.npz"))
+    d = mppi_cfg(64, 0.25)
+    m = make_mppi(gpu_pkg, d)
+    m.setWaypoint(*g["a1_xd"])
+    for t in range(3):
+        assert np.allclose(m.getControls(), g[f"a1_u_before_{t}"], rtol=U_RTOL, atol=U_ATOL)
+        got = m.newControls(*g[f"a1_x0_{t}"], g[f"a1_noise_{t}"])
+        assert rel_err(m.costToGo(), g[f"a1_J_{t}"]) < J_RTOL
+        assert np.allclose(got, g[f"a1_out_{t}"], rtol=U_RTOL, atol=U_ATOL)
+        assert np.allclose(m.getControls(), g[f"a1_u_after_{t}"], rtol=U_RTOL, atol=U_ATOL)
+    d = mppi_cfg(1024, 0.5)
+    m2 = make_mppi(gpu_pkg, d)
+    m2.setWaypoint(*WAYPOINTS[1])
+    noise = _noise(int(g["a2_seed"]), 1024, 50)
+    assert np.uint32(zlib.crc32(np.ascontiguousarray(noise).tobytes())) == g["a2_noise_crc"]
+    got = m2.newControls(0.0, 0.0, 0.0, noise)
+    J = m2.costToGo()
+    assert rel_err(J[0], g["a2_J_row0"]) < J_RTOL and rel_err(J[-1], g["a2_J_last"]) < J_RTOL
+    assert np.allclose(got, g["a2_out"], rtol=U_RTOL, atol=U_ATOL) and np.allclose(m2.getControls(), g["a2_u_after"], rtol=U_RTOL, atol=U_ATOL)

@@ -175,3 +175,90 @@ def test_low_variance_resampling_quirks(z):
         exp.append(i)
     assert idx.tolist() == exp
     pf.close()
+
+
+# ---- frozen vectors of the two Eigen-dependent pieces (tests/golden/make_golden_paths.py:
+#      outputs of the restatement, NOT of the reference — they freeze the oracle and give the second restatement and the HIP
+#      path something to be held against that does not move) ------------------------------------------------------------------
+import zlib  # noqa: E402
+
+import second_restatement as sr  # noqa: E402
+from cases import WAYPOINTS, mppi_cfg  # noqa: E402
+
+
+def _crc(a):
+    return np.uint32(zlib.crc32(np.ascontiguousarray(a).tobytes()))
+
+
+@pytest.fixture(scope="module")
+def gp_mppi():
+    return np.load(os.path.join(GOLD, "path_mppi.npz"))
+
+
+@pytest.fixture(scope="module")
+def gp_rbpf():
+    return np.load(os.path.join(GOLD, "path_rbpf.npz"))
+
+
+def test_mppi_frozen_vectors_G_A1_G_A2(gp_mppi):
+    g = gp_mppi
+    d = mppi_cfg(64, 0.25)
+    for t in range(3):
+        args = (g[f"a1_u_before_{t}"], (0.0, 0.0), tuple(g["a1_xd"]), tuple(g[f"a1_x0_{t}"]), g[f"a1_noise_{t}"])
+        r = orc.mppi_new_controls(d, *args)
+        for key in ("loss", "J"):                                     # the oracle: bit for bit
+            assert np.array_equal(r[key], g[f"a1_{key}_{t}"]), (t, key)
+        assert np.array_equal(r["u"], g[f"a1_u_after_{t}"]) and np.array_equal(np.array(r["out"]), g[f"a1_out_{t}"])
+        r2 = sr.mppi_new_controls(d, *args)                           # the second restatement: to rounding, without the oracle
+        assert np.allclose(r2["loss"], g[f"a1_loss_{t}"], rtol=1e-12, atol=0) and np.allclose(r2["J"], g[f"a1_J_{t}"], rtol=1e-12, atol=0)
+        assert np.allclose(r2["u"], g[f"a1_u_after_{t}"], rtol=1e-11, atol=1e-13)
+        if t:
+            assert np.array_equal(g[f"a1_u_before_{t}"], g[f"a1_u_after_{t - 1}"])  # the warm start really is the shifted vector
+    d = mppi_cfg(1024, 0.5)
+    noise = orc.normal_stream(int(g["a2_seed"]), 1024 * 50 * 2, 0.0, np.sqrt(d["ul_var"])).reshape(1024, 50, 2)
+    assert _crc(noise) == g["a2_noise_crc"]
+    r = orc.mppi_new_controls(d, np.zeros((2, 50)), (0.0, 0.0), WAYPOINTS[1], (0.0, 0.0, 0.0), noise)
+    assert _crc(r["J"]) == g["a2_J_crc"] and np.array_equal(r["u"], g["a2_u_after"]) and np.array_equal(np.array(r["out"]), g["a2_out"])
+
+
+def test_particle_filter_frozen_trace_G_B4(gp_rbpf):
+    from golden.make_golden_paths import RBPF_SCENARIO as S
+    g = gp_rbpf
+    N, k = S["N"], S["k"]
+    pf = orc.PfAPI(orc.pf_params(N=N, k=k))
+    for s in range(S["n_scans"]):
+        prev, cur, t_icp, u = g[f"b4_odom_{s}"]
+        normals = orc.normal_stream(S["normals_seed"] + s, pf.normals_per_scan(True), 0.0, 1.0)
+        assert _crc(normals) == g[f"b4_normals_crc_{s}"]
+        if s == S["force_resample_at"]:
+            pf.set_particles(w=g["b4_forced_w"])
+        tr = pf.slam(g[f"b4_scan_{s}"], u, cur, prev, True, t_icp, normals)
+        assert tr["rc"] == 0
+        for key in ("sampled", "p_scan", "p_pose", "mu", "sigma", "eta", "new_pose", "weight_raw"):
+            assert np.array_equal(tr[key], g[f"b4_{key}_{s}"]), (s, key)
+        assert tr["neff"] == g[f"b4_neff_{s}"] and tr["resampled"] == g[f"b4_resampled_{s}"]
+        if tr["resampled"]:
+            assert np.array_equal(tr["resample_idx"], g[f"b4_parents_{s}"])
+        pose, _, w = pf.particles()
+        assert np.array_equal(pose, g[f"b4_pose_after_{s}"]) and np.array_equal(w, g[f"b4_weight_after_{s}"])
+    assert pf.best() == g["b4_best"] and np.array_equal(pf.grid(pf.best()).dump()["log_odds"], g["b4_log_odds_best"])
+    pf.close()
+
+
+def test_low_variance_resampling_frozen_lists_G_B5(gp_rbpf):
+    g = gp_rbpf
+    for i in range(5):
+        w = g[f"b5_w_{i}"]
+        wn, _, _, neff, resample = sr.normalize_and_neff(w.copy())
+        assert neff == g[f"b5_neff_{i}"]
+        for j, z in enumerate(g["b5_offsets"]):
+            want = g[f"b5_idx_{i}_{j}"]
+            assert np.array_equal(sr.low_variance_resampling(wn, float(z)), want)
+            assert np.all(np.diff(want) >= 0) and want.min() >= 0 and want.max() <= len(w) - 1  # non-decreasing, clamped
+            if resample:  # the oracle reaches the selection only when Neff triggers it
+                pfr = orc.PfAPI(orc.pf_params(N=len(w), k=4))
+                pfr.set_particles(w=w)
+                nz = np.zeros(pfr.normals_per_scan(False)); nz[-1] = z
+                tr = pfr.slam(np.zeros(360, dtype=np.float32), (0, 0, 0), (0, 0, 0), (0, 0, 0), False, (0, 0, 0), nz)
+                assert tr["resampled"] == 1 and np.array_equal(tr["resample_idx"], want)
+                pfr.close()

@@ -113,3 +113,40 @@ def test_default_mode_effect_of_the_exact_field_on_weights_is_bounded(gpu_pkg, c
     assert worst["best_xy"] <= 1e-6 and worst["best_th"] <= 1e-6
     assert neff_gap <= 1
     pf_d.close()
+
+
+def test_reference_mode_against_the_frozen_trace_G_B4(gpu_pkg):
+    """The reference's launch configuration replayed from tests/golden/path_rbpf.npz on the HIP path in
+    the reference distance-field mode, nothing injected and no oracle filter beside it: likelihoods / eta / weights within
+    1e-9 of the committed trace, Neff, the resampling decision, the parent list, the best particle and its map identical."""
+    import os
+    import zlib
+    from golden.make_golden_paths import RBPF_SCENARIO as S
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "path_rbpf.npz"))
+    N, k = S["N"], S["k"]
+    pf = _dev(gpu_pkg, df_mode="reference", N=N, k=k)
+    rel = lambda a, b: float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)))  # noqa: E731
+    resampled = 0
+    for s in range(S["n_scans"]):
+        prev, cur, t_icp, u = g[f"b4_odom_{s}"]
+        normals = orc.normal_stream(S["normals_seed"] + s, N * (3 * k + 3) + 1, 0.0, 1.0)
+        assert np.uint32(zlib.crc32(np.ascontiguousarray(normals).tobytes())) == g[f"b4_normals_crc_{s}"]
+        if s == S["force_resample_at"]:
+            pf.setParticles(w=g["b4_forced_w"])
+        st = pf.SLAM(g[f"b4_scan_{s}"], u, cur, prev, True, t_icp, normals)
+        assert st.status == 0
+        tr = pf.trace()
+        assert np.allclose(tr["sampled"], g[f"b4_sampled_{s}"], rtol=0, atol=1e-10)
+        assert rel(tr["p_scan"], g[f"b4_p_scan_{s}"]) <= 1e-9 and rel(tr["p_pose"], g[f"b4_p_pose_{s}"]) <= 1e-9
+        assert rel(tr["eta"], g[f"b4_eta_{s}"]) <= 1e-9 and rel(tr["weight_raw"], g[f"b4_weight_raw_{s}"]) <= 1e-9
+        assert np.allclose(tr["mu"], g[f"b4_mu_{s}"], rtol=0, atol=1e-10) and np.allclose(tr["new_pose"], g[f"b4_new_pose_{s}"], rtol=0, atol=1e-10)
+        assert st.neff == g[f"b4_neff_{s}"] and st.resampled == g[f"b4_resampled_{s}"]
+        if st.resampled:
+            resampled += 1
+            assert np.array_equal(tr["resample_idx"], g[f"b4_parents_{s}"])
+        pose, _, w = pf.particles()
+        assert np.allclose(pose, g[f"b4_pose_after_{s}"], rtol=0, atol=1e-10) and rel(w, g[f"b4_weight_after_{s}"]) <= 1e-9
+    assert resampled >= 1
+    (_, best) = pf.getRobotState()
+    assert best == g["b4_best"] and np.array_equal(pf.logOdds(int(best)), g["b4_log_odds_best"])
+    pf.close()
