@@ -8,7 +8,10 @@
 // vector or fixture for this path.  This file follows the reference line by
 // line, in IEEE double, with the evaluation order Eigen's expression templates produce for these
 // (tiny, coefficient-wise) expressions; the hand-checkable known answers of SURVEY.md's appendix
-// are asserted in tests/test_oracle_mppi.py.
+// are asserted in tests/test_oracle_mppi.py.  What stands in for a pin: a second, independent restatement in numpy
+// (tests/second_restatement.py) is held against this one (tests/test_second_restatement.py), and the outputs on which the
+// two agree are frozen in tests/golden/path_mppi.npz (an edit here that moves a bit fails tests/test_oracle_golden.py).
+// Neither is an output of the reference.
 //
 // All paths below are relative to /root/reference/.
 #include <algorithm>

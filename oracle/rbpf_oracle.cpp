@@ -14,6 +14,8 @@
 //    sampleMotionModel, normalizeWeights, lowVarianceResampling).  It is restated line by line; the
 //    only Eigen arithmetic involved is 3-vectors and a 3x3 LLT, written out below in the order
 //    Eigen 3.3's unblocked LLT / coefficient-wise evaluators use.
+//    A second, independent restatement (tests/second_restatement.py) is held against it and the agreed trace of the
+//    reference's launch configuration is frozen in tests/golden/path_rbpf.npz — neither is an output of the reference.
 //  * PCL ICP (cloud_alignment.cpp) is a third-party dependency, version unpinned (ROS Melodic
 //    ships PCL 1.8), absent here: its result (ok, T_icp) is an INPUT of orc_pf_slam.
 #include <algorithm>
