@@ -1132,6 +1132,9 @@ struct tbnav_mppi {
   int scan_tc = 0;            // steps per thread of the time-parallel rollout kernel (0 = sequential kernel)
   int fused_r = 0;            // rollouts per workgroup of the fused rollout+partials kernel (0 = off: three kernels)
   int fused_S = 0;            // its records per time step, ceil(K / fused_r)
+  // which ticks take the fused kernel: resident-noise ticks (tbnav_mppi_enqueue_dev, new_controls*) and device-noise ticks
+  // (tbnav_mppi_enqueue_rng ...: the perturbations are drawn inside it) cross over to the three-kernel tick at different K
+  bool fused_dev = false, fused_rng = false;
   double* d_records_f = nullptr;  // [T][fused_S][8]
   int trig = 1;               // sincos evaluations per RK4 step (1 = angle addition, 3 = the reference's three)
   int dyn = 0;                // rollout dynamics: 0 = the reference's RK4 cart, 1 = exact arcs (tbnav_mppi_set_dynamics)
@@ -1372,11 +1375,29 @@ int tbnav_mppi_create(const tbnav_mppi_params* params, tbnav_mppi** out) {
     hipDeviceProp_t prop;
     int cus = 256;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-    if ((params->rollouts + kWave - 1) / kWave >= 2 * cus) h->scan_tc = 0;
+    // Measured on MI355X (tools/mppi_size_sweep.py, T = 25 / 50 / 100, tick in us, resident noise):
+    //   K        fused<8>      time-parallel     sequential
+    //   2048     11.3          15.2              29.4            (T = 50)
+    //   4096     20.1          20.5              49.2            (T = 100)
+    //   8192     32.9          23.6              52.1
+    //   16384    54.6          29.3              56.1
+    //   32768    100           47.1              55.1
+    //   49152    -             66.2              62.1
+    //   65536    165 (T = 50)  86.6              76.1
+    // one wave per rollout (fused) costs 5x the instructions of one lane per rollout and only pays while the chip is
+    // otherwise empty; the time-parallel kernel carries the middle; the sequential one takes over once K/64 one-wave
+    // workgroups are ~2.5 per CU.  (Round 1 switched fused -> sequential at 2 per CU and never used the middle kernel
+    // below T = 129: K = 16384 ran at half speed.)
+    const long waves = (params->rollouts + kWave - 1) / kWave;
+    if (2 * waves > 5 * cus) h->scan_tc = 0;
+    // fused rollout + partials (lanes = time): T must fit two steps per lane.  With the perturbations drawn inside it the
+    // fused kernel saves the sample kernel's launch and 16 B per rollout-step, so device-noise ticks stay with it longer
+    // (K = 8192, T = 100: 33.1 us against 36.1 for sample + time-parallel; K = 12288, T = 50: 38.9 against 29.7).
+    const bool fused_ok = T <= 2 * kWave && h->scan_tc > 0;
+    h->fused_dev = fused_ok && 16 * waves <= 3 * cus;   // K <= 3072 at 256 CUs
+    h->fused_rng = fused_ok && 2 * waves <= cus;        // K <= 8192
+    h->fused_r = (h->fused_dev || h->fused_rng) ? 8 : 0;
   }
-  // fused rollout + partials (lanes = time): whenever the time-parallel kernel would be chosen and T fits two steps per lane
-  // (other kernel choices: tbnav_mppi_set_option)
-  h->fused_r = (h->scan_tc > 0 && T <= 2 * kWave) ? 8 : 0;
   h->fused_S = h->fused_r ? (h->K + h->fused_r - 1) / h->fused_r : 0;
   h->k_global = (uint64_t)h->K;
   const size_t tk = (size_t)T * h->K;
@@ -1490,6 +1511,8 @@ int tbnav_mppi_set_option(tbnav_mppi* h, int32_t option, int32_t value) {
       }
       h->scan_tc = tc;
       h->fused_r = fused;
+      h->fused_dev = fused > 0;          // a forced choice holds for both kinds of tick (in-kernel noise exists for 8 only:
+      h->fused_rng = fused == 8;         //  other fused forms sample first)
       h->fused_S = fused ? (h->K + fused - 1) / fused : 0;
       (void)hipFree(h->d_records_f);
       h->d_records_f = nullptr;
@@ -1507,7 +1530,7 @@ int tbnav_mppi_set_rng_shard(tbnav_mppi* h, uint64_t first_rollout, uint64_t rol
   return TBNAV_OK;
 }
 
-int tbnav_mppi_rollout_variant(const tbnav_mppi* h) { return h ? (h->fused_r > 0 ? -h->fused_r : h->scan_tc) : 0; }
+int tbnav_mppi_rollout_variant(const tbnav_mppi* h) { return h ? (h->fused_dev ? -h->fused_r : h->scan_tc) : 0; }
 int tbnav_mppi_rollouts(const tbnav_mppi* h) { return h ? h->K : -1; }
 int tbnav_mppi_records_per_step(const tbnav_mppi* h) { return h ? h->S : -1; }
 
@@ -1552,7 +1575,7 @@ int tbnav_mppi_shard_partials(tbnav_mppi* h, const double x0[3], const double* d
   if (!h || !x0 || !d_records_out || !pick_noise(h, d_duL, d_duR)) return TBNAV_ERR_INVALID_ARG;
   DeviceGuard guard(h->device);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (h->fused_r > 0 && kSlice % h->fused_r == 0) {
+  if (h->fused_dev && kSlice % h->fused_r == 0) {
     // small K: the fused rollout+partials kernel, then its fine records folded into the K-slice records that the
     // ranks exchange (two short launches instead of three)
     const int rcf = launch_fused(h, x0, d_duL, d_duR, st);
@@ -1571,7 +1594,7 @@ int tbnav_mppi_shard_partials(tbnav_mppi* h, const double x0[3], const double* d
 // the ensemble's counter space): inside the fused kernel when that is the handle's kernel, else sampled first.
 int tbnav_mppi_shard_partials_rng(tbnav_mppi* h, const double x0[3], uint64_t seed, uint64_t tick, void* stream, double* d_records_out) {
   if (!h || !x0 || !d_records_out) return TBNAV_ERR_INVALID_ARG;
-  if (!(h->fused_r == 8 && kSlice % h->fused_r == 0)) {
+  if (!(h->fused_rng && h->fused_r == 8 && kSlice % h->fused_r == 0)) {
     const int rc = tbnav_mppi_sample_noise(h, seed, tick, stream);
     return rc != TBNAV_OK ? rc : tbnav_mppi_shard_partials(h, x0, nullptr, nullptr, stream, d_records_out);
   }
@@ -1597,7 +1620,7 @@ int tbnav_mppi_enqueue_dev(tbnav_mppi* h, const double x0[3], const double* d_du
   if (!h || !x0 || !pick_noise(h, d_duL, d_duR)) return TBNAV_ERR_INVALID_ARG;
   DeviceGuard guard(h->device);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (h->fused_r > 0) {
+  if (h->fused_dev) {
     const int rcf = launch_fused(h, x0, d_duL, d_duR, st);
     if (rcf != TBNAV_OK) return rcf;
     return launch_combine(h, h->d_records_f, 1, st, h->fused_S);
@@ -1619,7 +1642,7 @@ int tbnav_mppi_profile_tick(tbnav_mppi* h, const double x0[3], const double* d_d
   for (auto& e : ev) TBNAV_HIP(hipEventCreate(&e));
   int rc = TBNAV_OK;
   TBNAV_HIP(hipEventRecord(ev[0], st));
-  if (h->fused_r > 0) {  // rollout and partials are one kernel: its time is reported under [0], [1] is the empty interval
+  if (h->fused_dev) {  // rollout and partials are one kernel: its time is reported under [0], [1] is the empty interval
     rc = launch_fused(h, x0, d_duL, d_duR, st);
     if (rc == TBNAV_OK) { TBNAV_HIP(hipEventRecord(ev[1], st)); TBNAV_HIP(hipEventRecord(ev[2], st)); rc = launch_combine(h, h->d_records_f, 1, st, h->fused_S); }
   } else {
@@ -1659,7 +1682,7 @@ int tbnav_mppi_profile_kernels(tbnav_mppi* h, const double x0[3], const double* 
     ms[which] = t / (float)reps;
   };
   for (int i = 0; i < TBNAV_MPPI_NKERNELS; ++i) ms[i] = 0.f;
-  if (h->fused_r > 0) {
+  if (h->fused_dev) {
     timed(0, [&] { return launch_fused(h, x0, d_duL, d_duR, st); });
     timed(2, [&] { return launch_combine(h, h->d_records_f, 1, st, h->fused_S); });
   } else {
@@ -1738,7 +1761,7 @@ int tbnav_mppi_sample_noise(tbnav_mppi* h, uint64_t seed, uint64_t tick, void* s
 // workgroup's LDS tile).  Other configurations sample into the handle's buffers first — same values, same result.
 int tbnav_mppi_enqueue_rng(tbnav_mppi* h, const double x0[3], uint64_t seed, uint64_t tick, void* stream) {
   if (!h || !x0) return TBNAV_ERR_INVALID_ARG;
-  if (h->fused_r != 8) {
+  if (!(h->fused_rng && h->fused_r == 8)) {
     const int rc = tbnav_mppi_sample_noise(h, seed, tick, stream);
     return rc != TBNAV_OK ? rc : tbnav_mppi_enqueue_dev(h, x0, nullptr, nullptr, stream);
   }

@@ -355,7 +355,7 @@ def test_streaming_rollout_kernel_against_the_oracle(gpu_pkg, K, horizon):
     (a whole number of rounds), 60, 12 (fewer groups than one round) and 32 (a partial last round), a ragged last wave,
     two ticks of warm start."""
     d = mppi_cfg(K, horizon)
-    m = make_mppi(gpu_pkg, d)
+    m = make_mppi(gpu_pkg, d, kernel=0)  # (at these sizes the handle's own choice is the time-parallel kernel: tested below)
     T = orc.mppi_steps(d)
     assert m.steps == T and T % 4 == 0 and m.rollout_kernel == "mppi_rollout_cost"
     m.setWaypoint(*WAYPOINTS[2])
@@ -390,3 +390,26 @@ def test_hip_against_frozen_vectors_G_A1_G_A2(gpu_pkg):
     J = m2.costToGo()
     assert rel_err(J[0], g["a2_J_row0"]) < J_RTOL and rel_err(J[-1], g["a2_J_last"]) < J_RTOL
     assert np.allclose(got, g["a2_out"], rtol=U_RTOL, atol=U_ATOL) and np.allclose(m2.getControls(), g["a2_u_after"], rtol=U_RTOL, atol=U_ATOL)
+
+
+@pytest.mark.parametrize("K,horizon,want", [(2048, 0.5, "fused"), (4096, 1.0, "scan"), (8192, 1.0, "scan"), (16384 + 5, 0.5, "scan"),
+                                            (40000, 0.25, "scan"), (45000, 0.12, "cost")])
+def test_default_kernel_choice_by_ensemble_size_against_the_oracle(gpu_pkg, K, horizon, want):
+    """What the handle picks by itself across ensemble sizes (fused one-wave-per-rollout kernel while the chip would be
+    empty otherwise, the time-parallel kernel in the middle, the sequential streaming kernel from ~2.5 one-wave workgroups
+    per CU), each against the oracle: a resident-noise tick, then a device-noise tick that must equal sample-then-tick."""
+    d = mppi_cfg(K, horizon)
+    m = make_mppi(gpu_pkg, d)
+    assert want in m.rollout_kernel, m.rollout_kernel
+    T = orc.mppi_steps(d)
+    m.setWaypoint(*WAYPOINTS[1])
+    ref = _check_tick(m, d, np.zeros((2, T)), (0, 0), WAYPOINTS[1], (0.01, 0.0, 0.05), _noise(7, K, T))
+    # production tick: in-kernel noise (K <= 8192) or sample + tick — either way the values tbnav_mppi_sample_noise writes
+    m2 = make_mppi(gpu_pkg, d); m2.setWaypoint(*WAYPOINTS[1]); m2.setControls(m.getControls())
+    m.sampleNoise(11, 3)
+    a = m.newControlsDev((0.02, 0.0, 0.06), 0, 0)
+    b = m2.newControlsRng((0.02, 0.0, 0.06), 11, 3)
+    if 3072 < K <= 8192:  # device-noise ticks stay with the fused kernel up to K = 8192, resident-noise ticks leave it at 3072:
+        assert np.allclose(a, b, rtol=U_RTOL, atol=U_ATOL) and np.allclose(m.getControls(), m2.getControls(), rtol=U_RTOL, atol=U_ATOL)
+    else:                 # same kernels on both sides: bit for bit
+        assert np.array_equal(np.array(a), np.array(b)) and np.array_equal(m.getControls(), m2.getControls())
