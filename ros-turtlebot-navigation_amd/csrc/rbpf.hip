@@ -806,41 +806,6 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
              tile_bm, reinterpret_cast<const int*>(tile_bm), 0, 0, 0, 0};
   int oob = 0;
 
-  if (!c.icp_ok) {
-    // ICP failed: odometry motion model sample + scan likelihood (particle_filter.cpp:161-176, :295-322)
-    if (wid == 0) {
-      double th = pose[p * 3 + 0], x = pose[p * 3 + 1], y = pose[p * 3 + 2];
-      const double w0 = c.Lm[0] * z[0], w1 = c.Lm[1] * z[1], w2 = c.Lm[2] * z[2];
-      const double uw = c.u[0], uvx = c.u[1];
-      double nth, nx, ny;
-      if (almost_equal(uw, 0.0)) {
-        nth = normalize_angle_PI(th + w0);
-        nx = x + (uvx * cos(nth) + w1);
-        ny = y + (uvx * sin(nth) + w2);
-      } else {
-        nth = normalize_angle_PI(th + uw + w0);
-        nx = x + ((-uvx / uw) * sin(nth) + (uvx / uw) * sin(nth + uw) + w1);
-        ny = y + ((uvx / uw) * cos(nth) - (uvx / uw) * cos(nth + uw) + w2);
-      }
-      const double sl = wave_scan_likelihood(c, beams, ds, radius, nocc, nth, nx, ny, lane, &oob, MixLut{nullptr, mixlut});
-      if (lane == 0) {
-        prev_pose[p * 3 + 0] = th; prev_pose[p * 3 + 1] = x; prev_pose[p * 3 + 2] = y;
-        pose[p * 3 + 0] = nth; pose[p * 3 + 1] = nx; pose[p * 3 + 2] = ny;
-        const double w = weight[p] * sl;
-        weight[p] = w;
-        tr.p_scan[(size_t)p * k] = sl;
-        tr.weight_raw[p] = w;
-        tr.new_pose[p * 3 + 0] = nth; tr.new_pose[p * 3 + 1] = nx; tr.new_pose[p * 3 + 2] = ny;
-        double Ts[4];  // the sensor transform of the new pose, for the raycast kernel
-        sensor_transform(c, nth, nx, ny, Ts);
-        for (int q = 0; q < 4; ++q) sens[p * 4 + q] = Ts[q];
-      }
-      if (oob & 1) atomicOr(&err[0], 1);
-      if (oob & 2) atomicOr(&err[3], 4);
-    }
-    return;
-  }
-
   // ---- sample k poses round T(pose) * T_icp (particle_filter.cpp:181-188, :504-519), score the odometry
   //      likelihood of each (:542) and derive its sensor transform: one thread per sample
 #ifdef TBNAV_PHASE_PROF
@@ -848,11 +813,29 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
 #endif
   const double th0 = pose[p * 3 + 0], x0 = pose[p * 3 + 1], y0 = pose[p * 3 + 2];
   TRACE_P(0);
-  double s0, c0;
-  sincos(th0, &s0, &c0);
-  // the mode the samples are drawn round: T(pose) * T_icp, or the particle's own scan-matched pose (N1 option)
-  const double mu0[3] = {center ? center[p * 3 + 0] : th0 + c.Ticp[0], center ? center[p * 3 + 1] : c0 * c.Ticp[1] - s0 * c.Ticp[2] + x0,
-                         center ? center[p * 3 + 2] : s0 * c.Ticp[1] + c0 * c.Ticp[2] + y0};
+  double mu0[3];
+  if (!c.icp_ok) {
+    // ICP failed: the pose moves by the odometry motion model (particle_filter.cpp:161-176, :295-322) — every thread works it
+    // out (three draws, two sincos), and the LDS slice of the bitmap is staged round THAT pose's sensor
+    const double w0 = c.Lm[0] * z[0], w1 = c.Lm[1] * z[1], w2 = c.Lm[2] * z[2];
+    const double uw = c.u[0], uvx = c.u[1];
+    if (almost_equal(uw, 0.0)) {
+      mu0[0] = normalize_angle_PI(th0 + w0);
+      mu0[1] = x0 + (uvx * cos(mu0[0]) + w1);
+      mu0[2] = y0 + (uvx * sin(mu0[0]) + w2);
+    } else {
+      mu0[0] = normalize_angle_PI(th0 + uw + w0);
+      mu0[1] = x0 + ((-uvx / uw) * sin(mu0[0]) + (uvx / uw) * sin(mu0[0] + uw) + w1);
+      mu0[2] = y0 + ((uvx / uw) * cos(mu0[0]) - (uvx / uw) * cos(mu0[0] + uw) + w2);
+    }
+  } else {
+    double s0, c0;
+    sincos(th0, &s0, &c0);
+    // the mode the samples are drawn round: T(pose) * T_icp, or the particle's own scan-matched pose (N1 option)
+    mu0[0] = center ? center[p * 3 + 0] : th0 + c.Ticp[0];
+    mu0[1] = center ? center[p * 3 + 1] : c0 * c.Ticp[1] - s0 * c.Ticp[2] + x0;
+    mu0[2] = center ? center[p * 3 + 2] : s0 * c.Ticp[1] + c0 * c.Ticp[2] + y0;
+  }
   const double pv[3] = {prev_pose[p * 3 + 0], prev_pose[p * 3 + 1], prev_pose[p * 3 + 2]};
   for (int b = tid; b < c.Bv; b += kProposeThreads) lbeams[b] = beams[b];  // visible after the next barrier
   for (int q = tid; q < kMixLds; q += kProposeThreads) sh_mix[q] = mixlut[q];
@@ -918,8 +901,34 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
     TRACE_P(1);
     __syncthreads();
   }
-  // ---- 1. wave 0: the k sampled poses and their sensor transforms; how far any of them is from the centre
   __shared__ double sh_spread[2], sh_pst[kProposeThreads / kWave];
+  if (!c.icp_ok) {
+    // weight *= likelihoodFieldModel(scan, T(new pose)) (:171-175): the beams over ALL the workgroup's lanes, lookups on
+    // the LDS slice; the product is taken per lane, per wave, then over the waves in wave order (a fixed order; the
+    // reference multiplies beam by beam: tolerance)
+    __syncthreads();  // lbeams / sh_mix (the staging block's barrier is conditional)
+    double pr = 1.0;
+    if (nocc) for (int b = tid; b < c.Bv; b += kProposeThreads) pr *= beam_factor(c, ds, radius, lbeams[b], Tc[0], Tc[1], Tc[2], Tc[3], 0xFFFFFFFFu, 0xFFFFFFFFu, 0.0, &oob, mixL);
+    pr = wave_prod(pr);
+    if (lane == 0) sh_pst[wid] = pr;
+    if (oob & 1) atomicOr(&err[0], 1);
+    if (oob & 2) atomicOr(&err[3], 4);
+    __syncthreads();
+    if (tid == 0) {
+      double sl = sh_pst[0];
+      for (int w = 1; w < kProposeThreads / kWave; ++w) sl *= sh_pst[w];
+      if (!nocc) sl = 1.0;  // grid_mapper.cpp:94-98
+      prev_pose[p * 3 + 0] = th0; prev_pose[p * 3 + 1] = x0; prev_pose[p * 3 + 2] = y0;
+      for (int q = 0; q < 3; ++q) { pose[p * 3 + q] = mu0[q]; tr.new_pose[p * 3 + q] = mu0[q]; }
+      const double w = weight[p] * sl;
+      weight[p] = w;
+      tr.p_scan[(size_t)p * k] = sl;
+      tr.weight_raw[p] = w;
+      for (int q = 0; q < 4; ++q) sens[p * 4 + q] = Tc[q];  // the sensor transform of the new pose, for the raycast kernel
+    }
+    return;
+  }
+  // ---- 1. wave 0: the k sampled poses and their sensor transforms; how far any of them is from the centre
   __shared__ int sh_nun;
   constexpr int kPW = kProposeThreads / kWave;
   if (wid == 0) {
