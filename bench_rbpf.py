@@ -163,6 +163,21 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
         if s >= 2:
             t_sm += time.perf_counter() - t0; n_sm += 1
     pf_m.close()
+    # ---- SURVEY.md 8-d's two other runs: the ICP-failed branch (motion-model sample + one likelihood per particle), and k = 10
+    def replay(pf_x, icp_ok):
+        pf_x.setSeed(2026)
+        icp = np.full(n_scans, 1 if icp_ok else 0, dtype=np.int32)
+        pf_x.SLAMBatch(np.stack(scans[:2]), u_all[:2], odom[:3], ticp_all[:2], icp_ok=icp[:2])
+        t0 = time.perf_counter()
+        pf_x.SLAMBatch(np.stack(scans[2:]), u_all[2:], odom[2:], ticp_all[2:], icp_ok=icp[2:])
+        return (time.perf_counter() - t0) / (n_scans - 2)
+    pf_f = mk()
+    t_fail = replay(pf_f, False)
+    pf_f.close()
+    from rtn_amd.rbpf import ParticleFilter, default_params
+    pf_k = ParticleFilter(default_params(N=N, k=10, map_min=-10.0, map_max=10.0, device=device.index or 0))
+    t_k10 = replay(pf_k, True)
+    pf_k.close()
     dev_ms = sum(kms.values())
     alg_dom = distinct_per * 16.0 * N             # bytes the raycast launch has to move: one RMW per distinct cell
     alg_ref = upd_per * 16.0 * N                  # one RMW per (beam, cell) touch
@@ -190,7 +205,11 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
                       "log_odds_bytes_in_use": (cap - free) * tile_bytes, "dense_equivalent_bytes": N * pf.G * 8},
         "dtype": "f64+u16",
         "options": {"scan_matching": {"value": round(N / (t_sm / n_sm), 1), "ms_per_scan": round(t_sm / n_sm * 1e3, 4),
-                                      "note": "per-particle hill climbing on the likelihood field before sampling (not the reference)"}},
+                                      "note": "per-particle hill climbing on the likelihood field before sampling (not the reference)"},
+                    "icp_failed_branch": {"value": round(N / t_fail, 1), "ms_per_scan": round(t_fail * 1e3, 4),
+                                          "note": "every scan with icp_ok = 0: sampleMotionModel + one likelihoodFieldModel per particle (particle_filter.cpp:157-176); whatever resampling the run triggers by itself is in the time"},
+                    "k10": {"value": round(N / t_k10, 1), "ms_per_scan": round(t_k10 * 1e3, 4),
+                            "note": "num_samples_mode = 10 instead of the shipped 50 (SURVEY.md 8-d: BASELINE names no k)"}},
         "distance_field_mode": "query",
         "roofline": {"bound": "hbm", "kernel": "rbpf_raycast_box (log-odds update)",
                      # SURVEY.md 8-d's algorithmic bytes of this kernel's share of a particle-update: (C_free + Bv) x 16 B, one
