@@ -1234,8 +1234,10 @@ int launch_fused(tbnav_mppi* h, const double x0[3], const double* d_duL, const d
   if (R == 8) { if (TL == 1) TBNAV_FUSED(TR, 8, 1, false); else TBNAV_FUSED(TR, 8, 2, false); }          \
   else if (R == 4) { if (TL == 1) TBNAV_FUSED(TR, 4, 1, false); else TBNAV_FUSED(TR, 4, 2, false); }     \
   else { if (TL == 1) TBNAV_FUSED(TR, 16, 1, false); else TBNAV_FUSED(TR, 16, 2, false); }
-#define TBNAV_FUSED_RNG(TR) if (TL == 1) TBNAV_FUSED(TR, 8, 1, true); else TBNAV_FUSED(TR, 8, 2, true)
-  if (rng) {  // in-kernel noise: instantiated for the default tile (8 rollouts per workgroup) only — the caller checks
+#define TBNAV_FUSED_RNG(TR)                                                                                  \
+  if (R == 16) { if (TL == 1) TBNAV_FUSED(TR, 16, 1, true); else TBNAV_FUSED(TR, 16, 2, true); }               \
+  else { if (TL == 1) TBNAV_FUSED(TR, 8, 1, true); else TBNAV_FUSED(TR, 8, 2, true); }
+  if (rng) {  // in-kernel noise: instantiated for 8 and 16 rollouts per workgroup (the handle's own choices) — the caller checks
     if (h->dyn == 1) { TBNAV_FUSED_RNG(4); } else if (h->trig == 3) { TBNAV_FUSED_RNG(3); } else { TBNAV_FUSED_RNG(2); }
   } else if (h->dyn == 1) { TBNAV_FUSED_R(4) } else if (h->trig == 3) { TBNAV_FUSED_R(3) } else { TBNAV_FUSED_R(2) }
 #undef TBNAV_FUSED_RNG
@@ -1394,9 +1396,12 @@ int tbnav_mppi_create(const tbnav_mppi_params* params, tbnav_mppi** out) {
     // fused kernel saves the sample kernel's launch and 16 B per rollout-step, so device-noise ticks stay with it longer
     // (K = 8192, T = 100: 33.1 us against 36.1 for sample + time-parallel; K = 12288, T = 50: 38.9 against 29.7).
     const bool fused_ok = T <= 2 * kWave && h->scan_tc > 0;
-    h->fused_dev = fused_ok && 16 * waves <= 3 * cus;   // K <= 3072 at 256 CUs
+    h->fused_dev = fused_ok && 4 * waves <= cus;        // K <= 4096 at 256 CUs
     h->fused_rng = fused_ok && 2 * waves <= cus;        // K <= 8192
-    h->fused_r = (h->fused_dev || h->fused_rng) ? 8 : 0;
+    // rollouts per workgroup: 8 spreads K = 1024 over 128 CUs (9.0 us against 10.0 with 16: latency-bound); from ~2048 up the
+    // chip is covered anyway and 16 halve the records the combine reads (K = 2048: 11.6 -> 10.7 us, 3072: 14.7 -> 12.1,
+    // 4096, T = 100: 20.1 -> 15.6)
+    h->fused_r = (h->fused_dev || h->fused_rng) ? (32 * waves <= 3 * cus ? 8 : 16) : 0;   // 8 up to K = 1536
   }
   h->fused_S = h->fused_r ? (h->K + h->fused_r - 1) / h->fused_r : 0;
   h->k_global = (uint64_t)h->K;
@@ -1511,8 +1516,8 @@ int tbnav_mppi_set_option(tbnav_mppi* h, int32_t option, int32_t value) {
       }
       h->scan_tc = tc;
       h->fused_r = fused;
-      h->fused_dev = fused > 0;          // a forced choice holds for both kinds of tick (in-kernel noise exists for 8 only:
-      h->fused_rng = fused == 8;         //  other fused forms sample first)
+      h->fused_dev = fused > 0;          // a forced choice holds for both kinds of tick (in-kernel noise exists for 8 and 16:
+      h->fused_rng = fused == 8 || fused == 16;  //  a 4-rollout workgroup samples first)
       h->fused_S = fused ? (h->K + fused - 1) / fused : 0;
       (void)hipFree(h->d_records_f);
       h->d_records_f = nullptr;
@@ -1594,7 +1599,7 @@ int tbnav_mppi_shard_partials(tbnav_mppi* h, const double x0[3], const double* d
 // the ensemble's counter space): inside the fused kernel when that is the handle's kernel, else sampled first.
 int tbnav_mppi_shard_partials_rng(tbnav_mppi* h, const double x0[3], uint64_t seed, uint64_t tick, void* stream, double* d_records_out) {
   if (!h || !x0 || !d_records_out) return TBNAV_ERR_INVALID_ARG;
-  if (!(h->fused_rng && h->fused_r == 8 && kSlice % h->fused_r == 0)) {
+  if (!(h->fused_rng && (h->fused_r == 8 || h->fused_r == 16) && kSlice % h->fused_r == 0)) {
     const int rc = tbnav_mppi_sample_noise(h, seed, tick, stream);
     return rc != TBNAV_OK ? rc : tbnav_mppi_shard_partials(h, x0, nullptr, nullptr, stream, d_records_out);
   }
@@ -1761,7 +1766,7 @@ int tbnav_mppi_sample_noise(tbnav_mppi* h, uint64_t seed, uint64_t tick, void* s
 // workgroup's LDS tile).  Other configurations sample into the handle's buffers first — same values, same result.
 int tbnav_mppi_enqueue_rng(tbnav_mppi* h, const double x0[3], uint64_t seed, uint64_t tick, void* stream) {
   if (!h || !x0) return TBNAV_ERR_INVALID_ARG;
-  if (!(h->fused_rng && h->fused_r == 8)) {
+  if (!(h->fused_rng && (h->fused_r == 8 || h->fused_r == 16))) {
     const int rc = tbnav_mppi_sample_noise(h, seed, tick, stream);
     return rc != TBNAV_OK ? rc : tbnav_mppi_enqueue_dev(h, x0, nullptr, nullptr, stream);
   }
