@@ -766,7 +766,8 @@ __global__ __launch_bounds__(kMatchThreads) void rbpf_scanmatch(ScanC c, ScanMat
 }
 
 // err[0] = out of world, err[1] = eta zero, err[2] = pdf variance zero, err[3] = bresenham
-__global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c, const double2* __restrict__ beams,
+template <int NT>
+__global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c, const double2* __restrict__ beams,
                                                                 const uint16_t* __restrict__ codes,
                                                                 TilePool P, MapT M,
                                                                 const int* __restrict__ trow_occ, const int* __restrict__ skip,
@@ -837,8 +838,8 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
     mu0[2] = center ? center[p * 3 + 2] : s0 * c.Ticp[1] + c0 * c.Ticp[2] + y0;
   }
   const double pv[3] = {prev_pose[p * 3 + 0], prev_pose[p * 3 + 1], prev_pose[p * 3 + 2]};
-  for (int b = tid; b < c.Bv; b += kProposeThreads) lbeams[b] = beams[b];  // visible after the next barrier
-  for (int q = tid; q < kMixLds; q += kProposeThreads) sh_mix[q] = mixlut[q];
+  for (int b = tid; b < c.Bv; b += NT) lbeams[b] = beams[b];  // visible after the next barrier
+  for (int q = tid; q < kMixLds; q += NT) sh_mix[q] = mixlut[q];
   double Tc[4];  // sensor transform at the centre of the samples
   sensor_transform(c, mu0[0], mu0[1], mu0[2], Tc);
   if (ds.mode == 2 && occ_half > 0 && nocc) {
@@ -856,12 +857,12 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
       __shared__ unsigned int st_ids[kStIds];
       const int tr0 = R0 >> kTSh, tc0 = 2 * W0, ntc = min(2 * nW, ds.occ.TW - tc0), n_ids = ((R1 >> kTSh) - tr0 + 1) * ntc;
       if (ntc <= kStC && n_ids <= kStIds) {
-        for (int q = tid; q < n_ids; q += kProposeThreads) {
+        for (int q = tid; q < n_ids; q += NT) {
           const int qi = floor_div_small(q, ntc);
           st_ids[q] = ds.occ.tab[(tr0 + qi) * ds.occ.TW + tc0 + (q - qi * ntc)];
         }
         __syncthreads();
-        for (int r = tid; r <= R1 - R0; r += kProposeThreads) {
+        for (int r = tid; r <= R1 - R0; r += NT) {
           const int row = R0 + r;
           const unsigned int* ids = st_ids + ((row >> kTSh) - tr0) * ntc;
           unsigned int v32[kStC];
@@ -879,7 +880,7 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
           ta[r] = acc != 0ull;
         }
       } else {
-        for (int r = tid; r <= R1 - R0; r += kProposeThreads) {
+        for (int r = tid; r <= R1 - R0; r += NT) {
           unsigned long long acc = 0ull;
           for (int w = 0; w < nW; ++w) {
             const unsigned long long v = ds.occ.word(R0 + r, W0 + w);
@@ -901,14 +902,14 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
     TRACE_P(1);
     __syncthreads();
   }
-  __shared__ double sh_spread[2], sh_pst[kProposeThreads / kWave];
+  __shared__ double sh_spread[2], sh_pst[NT / kWave];
   if (!c.icp_ok) {
     // weight *= likelihoodFieldModel(scan, T(new pose)) (:171-175): the beams over ALL the workgroup's lanes, lookups on
     // the LDS slice; the product is taken per lane, per wave, then over the waves in wave order (a fixed order; the
     // reference multiplies beam by beam: tolerance)
     __syncthreads();  // lbeams / sh_mix (the staging block's barrier is conditional)
     double pr = 1.0;
-    if (nocc) for (int b = tid; b < c.Bv; b += kProposeThreads) pr *= beam_factor(c, ds, radius, lbeams[b], Tc[0], Tc[1], Tc[2], Tc[3], 0xFFFFFFFFu, 0xFFFFFFFFu, 0.0, &oob, mixL);
+    if (nocc) for (int b = tid; b < c.Bv; b += NT) pr *= beam_factor(c, ds, radius, lbeams[b], Tc[0], Tc[1], Tc[2], Tc[3], 0xFFFFFFFFu, 0xFFFFFFFFu, 0.0, &oob, mixL);
     pr = wave_prod(pr);
     if (lane == 0) sh_pst[wid] = pr;
     if (oob & 1) atomicOr(&err[0], 1);
@@ -916,7 +917,7 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
     __syncthreads();
     if (tid == 0) {
       double sl = sh_pst[0];
-      for (int w = 1; w < kProposeThreads / kWave; ++w) sl *= sh_pst[w];
+      for (int w = 1; w < NT / kWave; ++w) sl *= sh_pst[w];
       if (!nocc) sl = 1.0;  // grid_mapper.cpp:94-98
       prev_pose[p * 3 + 0] = th0; prev_pose[p * 3 + 1] = x0; prev_pose[p * 3 + 2] = y0;
       for (int q = 0; q < 3; ++q) { pose[p * 3 + q] = mu0[q]; tr.new_pose[p * 3 + q] = mu0[q]; }
@@ -930,7 +931,7 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
   }
   // ---- 1. wave 0: the k sampled poses and their sensor transforms; how far any of them is from the centre
   __shared__ int sh_nun;
-  constexpr int kPW = kProposeThreads / kWave;
+  constexpr int kPW = NT / kWave;
   if (wid == 0) {
     double dxy = 0.0, dth = 0.0;
     for (int j = lane; j < k; j += kWave) {
@@ -968,7 +969,7 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
   } else if (nocc) {
     const double dxy = sh_spread[0], dth = sh_spread[1];
     double pst = 1.0;
-    for (int b = tid - kWave; b < c.Bv; b += kProposeThreads - kWave) {
+    for (int b = tid - kWave; b < c.Bv; b += NT - kWave) {
       const double2 pt = lbeams[b];
       const double ex = Tc[3] * pt.x - Tc[2] * pt.y + Tc[0], ey = Tc[2] * pt.x + Tc[3] * pt.y + Tc[1];
       int ci, cj;
@@ -1020,7 +1021,7 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
   // ---- 4. scan likelihood of every sample: (product over the stable beams) * (its own terms of the unstable ones);
   //      one wave per sample, lanes over the unstable beams
   if (nocc == 0) {
-    for (int j = tid; j < k; j += kProposeThreads) pscan[j] = 1.0;  // grid_mapper.cpp:94-98
+    for (int j = tid; j < k; j += NT) pscan[j] = 1.0;  // grid_mapper.cpp:94-98
   } else {
     double p_stable = sh_pst[1];
     for (int w = 2; w < kPW; ++w) p_stable *= sh_pst[w];
@@ -1028,14 +1029,14 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
     if (n_un <= kUnCap) {
       // the usual case, a handful of unstable beams: one THREAD per (sample, unstable beam), then each sample's
       // thread multiplies its few terms in beam order
-      for (int pair = tid; pair < k * n_un; pair += kProposeThreads) {
+      for (int pair = tid; pair < k * n_un; pair += NT) {
         const int j = floor_div_small(pair, n_un), i = pair - j * n_un;
         const int b = ulist[i];
         fac[j * kUnCap + i] = beam_factor(c, ds, radius, lbeams[b], stf[4 * j + 0], stf[4 * j + 1], stf[4 * j + 2], stf[4 * j + 3],
                                           ccell[b], ctag[b], cpz[b], &oob, mixL);
       }
       __syncthreads();
-      for (int j = tid; j < k; j += kProposeThreads) {
+      for (int j = tid; j < k; j += NT) {
         double pr = p_stable;
         for (int i = 0; i < n_un; ++i) pr *= fac[j * kUnCap + i];
         pscan[j] = pr;
@@ -1076,7 +1077,7 @@ __global__ __launch_bounds__(kProposeThreads, TBNAV_PROPOSE_WAVES) void rbpf_pro
   double* wj = stf;           // [k]    likelihoods.at(j)   (the sensor transforms are dead by now)
   __shared__ double sh_mu[3], sh_eta;
   __shared__ int sh_stop;
-  for (int j = tid; j < k; j += kProposeThreads) {
+  for (int j = tid; j < k; j += NT) {
     const double ps = fmin(fmax(pscan[j], c.scan_min), c.scan_max);  // std::clamp
     const double pp = fmin(fmax(ppose[j], c.pose_min), c.pose_max);
     tr.p_scan[(size_t)p * k + j] = pscan[j];
@@ -3813,7 +3814,15 @@ int scan_enqueue(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3
     TBNAV_HIP(hipGetLastError());
     center = h->d_center;
   }
-  hipLaunchKernelGGL(rbpf_propose, dim3(h->N), dim3(kProposeThreads), propose_lds, st, c, beams_dev,
+  // workgroup size: four waves when four workgroups fit a CU's LDS (the 360-beam scans: 38 KB each), eight when the scan's
+  // tables leave room for two or three only (1080 beams: 58 KB) — measured: 360 beams 32 us per 1000 particles with 256
+  // threads against 43 with 512; the configs[4] shard 0.80 ms with 256 against 0.61 with 512
+  if (propose_lds + 2048 > (size_t)kMaxLds / 4)
+    hipLaunchKernelGGL((rbpf_propose<2 * kProposeThreads>), dim3(h->N), dim3(2 * kProposeThreads), propose_lds, st, c, beams_dev,
+                     h->d_code[h->cur], h->pool, map_of(h), h->d_trow[h->cur], skip_arr, skip_eq, h->df_mode, h->radius, occ_half,
+                     h->d_nocc[h->cur], h->d_win, normals_dev, center, sp.pose, sp.prev, sp.weight, h->tr, h->d_sens, d_err, gate_prev, h->d_mixlut);
+    else
+    hipLaunchKernelGGL((rbpf_propose<kProposeThreads>), dim3(h->N), dim3(kProposeThreads), propose_lds, st, c, beams_dev,
                      h->d_code[h->cur], h->pool, map_of(h), h->d_trow[h->cur], skip_arr, skip_eq, h->df_mode, h->radius, occ_half,
                      h->d_nocc[h->cur], h->d_win, normals_dev, center, sp.pose, sp.prev, sp.weight, h->tr, h->d_sens, d_err, gate_prev, h->d_mixlut);
   TBNAV_HIP(hipGetLastError());
@@ -4101,7 +4110,8 @@ int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf*
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 1024);
   // the proposal / scan-match kernels carry the scan, the per-sample data and the bitmap slice: more than the 64 KB
   // default for long scans or many samples
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_propose), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 2048);  // (1.8 KB static)
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_propose<kProposeThreads>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 2048);  // (1.8 KB static)
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_propose<2 * kProposeThreads>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 2048);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_scanmatch), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_edt_compact<kEdtRowsA>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)edt_compact_lds(kEdtRowsA));
