@@ -50,6 +50,35 @@ def _skew(pf, N):
     pf.setParticles(w=w / w.sum())
 
 
+def configs4_shard(device, N=12500, k=50, n_scans=8):
+    """One GPU's shard of BASELINE configs[4] (100 000 particles / 8 GPUs, 2000 x 2000 cells @ 0.05 m, 1080-beam scans): the
+    per-rank work of that configuration measured on this GPU — replayed through tbnav_rbpf_slam_batch, device noise, the
+    first two scans (first-touch tile allocation) untimed.  Across ranks the per-scan exchange adds one all-gather of
+    100 000 weights and the global selection."""
+    from rtn_amd.rbpf import ParticleFilter, default_params
+    rc = _world()
+    bd = 1.0 / 3.0
+    pf = ParticleFilter(default_params(N=N, k=k, map_min=-50.0, map_max=50.0, beam_delta_deg=bd, device=device.index or 0), pool_bytes=16 << 30)
+    pf.setSeed(5)
+    steps, poses = rc.trajectory(n_scans, inc=(0.05, 0.04, 0.03))
+    rng = np.random.default_rng(8)
+    scans = np.stack([_room_scan(poses[s], rng, (-3.0, 3.0, -2.5, 2.5), n_beams=1080, beam_delta_deg=bd) for s in range(n_scans)])
+    odom = np.array([steps[0][0]] + [st_[1] for st_ in steps], dtype=np.float64)
+    u_all = np.array([st_[3] for st_ in steps], dtype=np.float64)
+    ticp_all = np.array([st_[2] for st_ in steps], dtype=np.float64)
+    pf.SLAMBatch(scans[:2], u_all[:2], odom[:3], ticp_all[:2])
+    t0 = time.perf_counter()
+    sts = pf.SLAMBatch(scans[2:], u_all[2:], odom[2:], ticp_all[2:])
+    dt = (time.perf_counter() - t0) / (n_scans - 2)
+    cap, free, tile_bytes = pf.poolStats()
+    out = {"workload": f"RBPF N={N} (= 100 000 / 8), k={k}, {int(sts[-1].n_valid_beams)} valid beams of 1080, {pf.xsize}x{pf.ysize} @0.05 m, one GPU",
+           "particle_updates_per_s": round(N / dt, 1), "ms_per_scan": round(dt * 1e3, 4), "scans_timed": n_scans - 2,
+           "resamples": int(sum(x.resampled for x in sts)), "log_odds_bytes_in_use": (cap - free) * tile_bytes,
+           "dense_equivalent_bytes": N * pf.G * 8}
+    pf.close()
+    return out
+
+
 def workload(n_scans=20):
     rc = _world()
     steps, poses = rc.trajectory(n_scans, inc=TRAJ_INC)
@@ -178,6 +207,7 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
     pf_k = ParticleFilter(default_params(N=N, k=10, map_min=-10.0, map_max=10.0, device=device.index or 0))
     t_k10 = replay(pf_k, True)
     pf_k.close()
+    shard4 = None if getattr(args, "no_large", False) else configs4_shard(device)
     dev_ms = sum(kms.values())
     alg_dom = distinct_per * 16.0 * N             # bytes the raycast launch has to move: one RMW per distinct cell
     alg_ref = upd_per * 16.0 * N                  # one RMW per (beam, cell) touch
@@ -210,6 +240,7 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
                                           "note": "every scan with icp_ok = 0: sampleMotionModel + one likelihoodFieldModel per particle (particle_filter.cpp:157-176); whatever resampling the run triggers by itself is in the time"},
                     "k10": {"value": round(N / t_k10, 1), "ms_per_scan": round(t_k10 * 1e3, 4),
                             "note": "num_samples_mode = 10 instead of the shipped 50 (SURVEY.md 8-d: BASELINE names no k)"}},
+        "configs4_shard_one_gpu": shard4,
         "distance_field_mode": "query",
         "roofline": {"bound": "hbm", "kernel": "rbpf_raycast_box (log-odds update)",
                      # SURVEY.md 8-d's algorithmic bytes of this kernel's share of a particle-update: (C_free + Bv) x 16 B, one
