@@ -285,6 +285,21 @@ def main():
             rl["rollouts_per_s"] = round(KL * 50 / el_l, 1)
             line["roofline_large"] = rl
             ml.close()
+            # one GPU's share of BASELINE configs[3] as written (K = 65536 over 8 GPUs = 8192 rollouts, T = 100): the per-rank
+            # compute of the strong-scaling leg, measured here (the exchange adds one all-gather of 100 x 4 records per tick)
+            ms8 = make_mppi(KL // 8, HL, local_rank)
+            a8, b8 = synth_noise(ms8.steps, KL // 8, device, 98)
+            el8 = time_ticks(lambda: ms8.enqueueDev(X0, a8.data_ptr(), b8.data_ptr(), stream), sync, 200, 20, lambda: None)
+            tk8 = [0]
+
+            def rng8():
+                ms8.enqueueRng(X0, SEED, tk8[0], stream)
+                tk8[0] += 1
+            el8r = time_ticks(rng8, sync, 200, 20, lambda: None)
+            line["configs3_shard_one_gpu"] = {"workload": f"MPPI K={KL // 8} (= 65536 / 8), T={ms8.steps}, one GPU", "kernel": ms8.rollout_kernel,
+                                              "ms_per_step_resident_noise": round(el8 / 200 * 1e3, 6), "ms_per_step_device_noise": round(el8r / 200 * 1e3, 6),
+                                              "rollouts_per_s_device_noise": round(KL // 8 * 200 / el8r, 1)}
+            ms8.close()
         if world == 1:
             n_a = min(args.steps, 1000)
             # the same tick with the perturbations already resident in HBM ([T][K] fp64 x2): the parity-mode data flow
