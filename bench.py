@@ -148,7 +148,7 @@ def _cpu_baseline(orc, K, T, horizon, budget_s, threads):
         r = orc.mppi_new_controls(d, u, (0, 0), WAYPOINT, X0, noise)
         u = r["u"]; n += 1
         el = time.perf_counter() - t0
-        if el > budget_s or n >= 2000:
+        if el > budget_s or n >= 6000:
             break
     import bench_rbpf
     return {"value": round(n * K / el, 1), "unit": "rollouts/s", "cores": int(threads), "kind": "port", "cpu": bench_rbpf._cpu_model(),

@@ -304,13 +304,13 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(k, scans, steps, threads=1, n_scans=5):
+def cpu_baseline(k, scans, steps, threads=1, n_scans=11):
     """oracle port (restated GridMapper + ParticleFilter incl. the reference's priority-queue brushfire; bit-exact vs
-    the reference's GridMapper), same world / parameters, a BOUNDED sample: 2 particles per thread (min 16) x 4 timed
+    the reference's GridMapper), same world / parameters, a BOUNDED sample (~5-10 s of CPU work): 2 particles per thread (min 32) x 10 timed
     scans.  threads > 1: the particle loop under OpenMP (the generous baseline)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_api as orc
-    n_particles = max(16, 2 * threads)
+    n_particles = max(32, 2 * threads)
     orc.lib().orc_set_threads(int(threads))
     try:
         pf = orc.PfAPI(orc.pf_params(N=n_particles, k=k, map_min=-10.0, map_max=10.0))
