@@ -14,6 +14,12 @@ bd = 1.0 / 3.0
 n_scans = 10
 pf = ParticleFilter(default_params(N=N, k=k, map_min=-50.0, map_max=50.0, beam_delta_deg=bd))
 pf.setSeed(5); pf.setTiming(True)
+if os.environ.get("RAYCAST_THREADS"):   # A-B runs: RAYCAST_THREADS=512, RAYCAST_FORM=1, RAYCAST_BAND_ROWS=n
+    from rtn_amd import capi
+    pf.setOption(capi.RBPF_OPT_RAYCAST_THREADS, int(os.environ["RAYCAST_THREADS"]))
+if os.environ.get("RAYCAST_FORM"):
+    from rtn_amd import capi
+    pf.setOption(capi.RBPF_OPT_RAYCAST_FORM, int(os.environ["RAYCAST_FORM"]))
 steps, poses = rc.trajectory(n_scans, inc=(0.05, 0.04, 0.03))
 rng = np.random.default_rng(8)
 scans = [orc.room_scan(poses[s], n_beams=1080, beam_delta_deg=bd, walls=rc.ROOM_SURVEY, rng=rng) for s in range(n_scans)]
