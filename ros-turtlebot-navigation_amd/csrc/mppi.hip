@@ -993,7 +993,7 @@ __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, double 
   // the warm-start controls do not depend on the records: fetch them first, under the record loads
   const double u_l = valid ? u.get(0, i, T) : 0.0, u_r = valid ? u.get(1, i, T) : 0.0;
   // Up to kKeep records per lane stay in registers (2: at most 128 records per step — the K = 1024 tick, whose critical
-  // path should not carry idle slots; 4: up to 256 — the fused kernel with 16 rollouts per workgroup up to K = 4096);
+  // path should not carry idle slots; 4 / 8: up to 256 / 512 — the fused kernel with 16 rollouts per workgroup up to K = 4096 / 8192);
   // beyond that the second pass re-reads them (L1/L2 hits).
   const bool keep = R <= kKeep * tpr;
   double rk[kKeep][7];
@@ -1263,7 +1263,10 @@ int launch_combine(tbnav_mppi* h, const double* d_records, int G, hipStream_t st
   const int steps_per_block = 4 * (kWave / tpr);  // 4 waves per workgroup
   const int blocks = (h->T + steps_per_block - 1) / steps_per_block;
   const USrc usrc{h->d_u[h->ucur], h->pending_shift ? 1 : 0, h->uinit[0], h->uinit[1]};
-  if (G * S > 2 * kWave && G * S <= 4 * kWave)
+  if (G * S > 4 * kWave && G * S <= 8 * kWave)
+    hipLaunchKernelGGL(mppi_combine<8>, dim3(blocks), dim3(256), 0, st, h->T, G, S, h->p.lambda, h->p.max_wheel_vel, usrc,
+                       d_records, h->d_u[1 - h->ucur], h->d_out, h->publish_next ? h->d_out_host : nullptr, (double)(h->seq + 1));
+  else if (G * S > 2 * kWave && G * S <= 4 * kWave)
     hipLaunchKernelGGL(mppi_combine<4>, dim3(blocks), dim3(256), 0, st, h->T, G, S, h->p.lambda, h->p.max_wheel_vel, usrc,
                        d_records, h->d_u[1 - h->ucur], h->d_out, h->publish_next ? h->d_out_host : nullptr, (double)(h->seq + 1));
   else
