@@ -978,6 +978,9 @@ __global__ __launch_bounds__(kWave) void mppi_merge_records(int T, int Sf, int p
 // most a wave): 64/tpr steps per wave, xor-shuffle reductions inside the group.  Any number of workgroups:
 // the updated controls are written UNSHIFTED to u_out and the shift is applied on read by the next tick
 // (USrc), u(:,0) goes to `out` (mppi.cpp:129-131).
+#ifndef TBNAV_COMBINE_WAVES
+#define TBNAV_COMBINE_WAVES 1  // one wave per workgroup: the groups spread over as many CUs as there are time steps (K = 1024 tick 8.9 -> 8.4 us against four waves)
+#endif
 template <int kKeep>
 __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, double lambda, double umax, USrc u,
                                                     const double* __restrict__ records, double* __restrict__ u_out,
@@ -1260,17 +1263,18 @@ int launch_combine(tbnav_mppi* h, const double* d_records, int G, hipStream_t st
   if (S < 0) S = h->S;
   int tpr = 1;
   while (tpr < G * S && tpr < kWave) tpr <<= 1;
-  const int steps_per_block = 4 * (kWave / tpr);  // 4 waves per workgroup
+  const int wpb = TBNAV_COMBINE_WAVES;  // waves per workgroup
+  const int steps_per_block = wpb * (kWave / tpr);
   const int blocks = (h->T + steps_per_block - 1) / steps_per_block;
   const USrc usrc{h->d_u[h->ucur], h->pending_shift ? 1 : 0, h->uinit[0], h->uinit[1]};
   if (G * S > 4 * kWave && G * S <= 8 * kWave)
-    hipLaunchKernelGGL(mppi_combine<8>, dim3(blocks), dim3(256), 0, st, h->T, G, S, h->p.lambda, h->p.max_wheel_vel, usrc,
+    hipLaunchKernelGGL(mppi_combine<8>, dim3(blocks), dim3(wpb * kWave), 0, st, h->T, G, S, h->p.lambda, h->p.max_wheel_vel, usrc,
                        d_records, h->d_u[1 - h->ucur], h->d_out, h->publish_next ? h->d_out_host : nullptr, (double)(h->seq + 1));
   else if (G * S > 2 * kWave && G * S <= 4 * kWave)
-    hipLaunchKernelGGL(mppi_combine<4>, dim3(blocks), dim3(256), 0, st, h->T, G, S, h->p.lambda, h->p.max_wheel_vel, usrc,
+    hipLaunchKernelGGL(mppi_combine<4>, dim3(blocks), dim3(wpb * kWave), 0, st, h->T, G, S, h->p.lambda, h->p.max_wheel_vel, usrc,
                        d_records, h->d_u[1 - h->ucur], h->d_out, h->publish_next ? h->d_out_host : nullptr, (double)(h->seq + 1));
   else
-    hipLaunchKernelGGL(mppi_combine<2>, dim3(blocks), dim3(256), 0, st, h->T, G, S, h->p.lambda, h->p.max_wheel_vel, usrc,
+    hipLaunchKernelGGL(mppi_combine<2>, dim3(blocks), dim3(wpb * kWave), 0, st, h->T, G, S, h->p.lambda, h->p.max_wheel_vel, usrc,
                        d_records, h->d_u[1 - h->ucur], h->d_out, h->publish_next ? h->d_out_host : nullptr, (double)(h->seq + 1));
   TBNAV_HIP(hipGetLastError());
   ++h->seq;
