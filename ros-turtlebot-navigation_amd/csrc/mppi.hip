@@ -1408,12 +1408,15 @@ int tbnav_mppi_create(const tbnav_mppi_params* params, tbnav_mppi** out) {
     // fused kernel saves the sample kernel's launch and 16 B per rollout-step, so device-noise ticks stay with it longer
     // (K = 8192, T = 100: 33.1 us against 36.1 for sample + time-parallel; K = 12288, T = 50: 38.9 against 29.7).
     const bool fused_ok = T <= 2 * kWave && h->scan_tc > 0;
-    h->fused_dev = fused_ok && 4 * waves <= cus;        // K <= 4096 at 256 CUs
-    h->fused_rng = fused_ok && 2 * waves <= cus;        // K <= 8192
+    // (re-measured after the combine learnt to keep a lane's records in registers and to spread over one-wave workgroups —
+    //  the fused kernel's many records were what made it lose earlier: K = 8192, T = 100: fused with 16 rollouts per workgroup
+    //  20.4 us, time-parallel 22.6; with device noise 21.3 against 35.5)
+    h->fused_dev = fused_ok && 2 * waves <= cus;        // K <= 8192 at 256 CUs
+    h->fused_rng = fused_ok && 2 * waves <= cus;
     // rollouts per workgroup: 8 spreads K = 1024 over 128 CUs (9.0 us against 10.0 with 16: latency-bound); from ~2048 up the
     // chip is covered anyway and 16 halve the records the combine reads (K = 2048: 11.6 -> 10.7 us, 3072: 14.7 -> 12.1,
     // 4096, T = 100: 20.1 -> 15.6)
-    h->fused_r = (h->fused_dev || h->fused_rng) ? (32 * waves <= 3 * cus ? 8 : 16) : 0;   // 8 up to K = 1536
+    h->fused_r = (h->fused_dev || h->fused_rng) ? (8 * waves <= cus ? 8 : 16) : 0;   // 8 up to K = 2048 (K = 2048, T = 50: 9.2 us against 10.0; 3072: 11.6 against 10.5)
   }
   h->fused_S = h->fused_r ? (h->K + h->fused_r - 1) / h->fused_r : 0;
   h->k_global = (uint64_t)h->K;
