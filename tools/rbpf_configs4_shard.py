@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import __graft_entry__ as g
 g.load_package()
-import oracle_api as orc, rbpf_cases as rc
+import bench_rbpf, rbpf_cases as rc
 from rtn_amd.rbpf import ParticleFilter, default_params
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 12500
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 50
@@ -22,7 +22,7 @@ if os.environ.get("RAYCAST_FORM"):
     pf.setOption(capi.RBPF_OPT_RAYCAST_FORM, int(os.environ["RAYCAST_FORM"]))
 steps, poses = rc.trajectory(n_scans, inc=(0.05, 0.04, 0.03))
 rng = np.random.default_rng(8)
-scans = [orc.room_scan(poses[s], n_beams=1080, beam_delta_deg=bd, walls=rc.ROOM_SURVEY, rng=rng) for s in range(n_scans)]
+scans = [bench_rbpf._room_scan(poses[s], rng, rc.ROOM_SURVEY, n_beams=1080, beam_delta_deg=bd) for s in range(n_scans)]
 for s, (prev, cur, t_icp, u) in enumerate(steps):
     if s == 6:
         w = np.full(N, 1e-6); w[[7, N // 3, N // 2, N - 1]] = [0.4, 0.3, 0.2, 0.1]; w /= w.sum()
