@@ -56,12 +56,14 @@ def test_resample_global_is_bit_exact_against_the_oracle_filter(pkg):
         pf.close()
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
-def test_rbpf_two_shards_weights_all_gather_and_migration(seed):
-    n_local = 8
-    res = run_spawn(rbpf_worker, 2, n_local, seed)
-    N = 2 * n_local
-    assert np.array_equal(res[0]["parents"], res[1]["parents"]) and res[0]["neff"] == res[1]["neff"]
+@pytest.mark.parametrize("seed,world", [(1, 2), (2, 2), (3, 2), (4, 3), (5, 4)])
+def test_rbpf_shards_weights_all_gather_and_migration(seed, world):
+    """world 3 / 4: a rank sends to several destinations (one message each) and receives from several sources into one buffer."""
+    n_local = 8 if world == 2 else 5
+    res = run_spawn(rbpf_worker, world, n_local, seed)
+    N = world * n_local
+    for r in range(1, world):
+        assert np.array_equal(res[0]["parents"], res[r]["parents"]) and res[0]["neff"] == res[r]["neff"]
     parents = res[0]["parents"]
     # unsharded expectation: the initial global state gathered by `parents`
     gid = np.arange(N)
@@ -71,9 +73,9 @@ def test_rbpf_two_shards_weights_all_gather_and_migration(seed):
     wn = raw / np.sum(raw)  # (summation order aside; compared loosely)
     maps0 = gid[:, None] * 1000.0 + np.arange(32)[None, :]
     state0 = np.stack([gid + 0.25, gid * 2.0, gid * 3.0, gid + 0.5, gid * 5.0, gid * 7.0], 1)
-    got_state = np.concatenate([res[0]["state"], res[1]["state"]])
-    got_maps = np.concatenate([res[0]["maps"], res[1]["maps"]])
-    got_dist = np.concatenate([res[0]["dist"], res[1]["dist"]])
+    got_state = np.concatenate([res[r]["state"] for r in range(world)])
+    got_maps = np.concatenate([res[r]["maps"] for r in range(world)])
+    got_dist = np.concatenate([res[r]["dist"] for r in range(world)])
     assert np.array_equal(got_state[:, :6], state0[parents])
     assert np.array_equal(got_maps, maps0[parents]) and np.array_equal(got_dist, -maps0[parents])
     assert np.allclose(got_state[:, 6], wn[parents], rtol=1e-12)
