@@ -195,6 +195,9 @@ def main():
     m.setRngShard(rank * K, world * K)
     T = m.steps
     a, b = synth_noise(T, K, device, 1234 + rank)
+    # a stream of its own (not the legacy default stream): tbnav_mppi_enqueue_rng_batch replays captured hipGraphs of ticks, and a
+    # capture cannot be taken on the null stream; every launch, event and synchronisation below is on / of this stream
+    torch.cuda.set_stream(torch.cuda.Stream(device))
     stream = torch.cuda.current_stream(device).cuda_stream
     SEED = 42
     tk = [0]
@@ -264,7 +267,7 @@ def main():
                        "parallelism": f"rollout-shard x{world}" + (", 1 all-gather of soft-min records/tick" if world > 1 else "")},
             "rollout_steps_per_s": round(value * T, 1),
             "sync_tick_ms": round(sync_ms, 6),
-            "entry_point": "tbnav_mppi_enqueue_rng_batch (the K ticks enqueued by one call through the C boundary)" if world == 1 else "tbnav_mppi_shard_* per tick",
+            "entry_point": "tbnav_mppi_enqueue_rng_batch (the K ticks enqueued by one call through the C boundary; chunks of 100 ticks replayed from a captured hipGraph)" if world == 1 else "tbnav_mppi_shard_* per tick",
             "ms_per_step_one_python_call_per_tick": None if el_py is None else round(el_py / args.steps * 1e3, 6),
             "roofline": roofline_obj(K, T, ms_k, ms_step, m.rollout_kernel, "mppi_K1024_T50" if (K, T) == (1024, 50) else None),
             # the tick is two dependent launches: what the guide prices for that alone (MI355X_MICROARCH.md, "boundary" row)

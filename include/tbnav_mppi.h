@@ -80,7 +80,8 @@ int tbnav_mppi_rollout_variant(const tbnav_mppi* h);
  *  TBNAV_MPPI_OPT_KEEP_J   1 = the fused kernel also stores the cost-to-go J[T][K] (410 KB at K=1024, T=50) so that
  *                          tbnav_mppi_get_cost_to_go can return it; off by default — the update needs only the records.
  *  TBNAV_MPPI_OPT_REG_TAIL 0 = do not use mppi_rollout_cost_reg (losses of the last steps in registers) even where it applies. */
-enum { TBNAV_MPPI_OPT_KERNEL = 1, TBNAV_MPPI_OPT_TRIG = 2, TBNAV_MPPI_OPT_NO_LDS_STAGING = 3, TBNAV_MPPI_OPT_KEEP_J = 4, TBNAV_MPPI_OPT_REG_TAIL = 5 };
+enum { TBNAV_MPPI_OPT_KERNEL = 1, TBNAV_MPPI_OPT_TRIG = 2, TBNAV_MPPI_OPT_NO_LDS_STAGING = 3, TBNAV_MPPI_OPT_KEEP_J = 4, TBNAV_MPPI_OPT_REG_TAIL = 5,
+       TBNAV_MPPI_OPT_BATCH_GRAPH = 6 /* 0: tbnav_mppi_enqueue_rng_batch launches every tick by itself instead of replaying a captured hipGraph of 100 */ };
 int tbnav_mppi_set_option(tbnav_mppi* h, int32_t option, int32_t value);
 
 /* Rollout dynamics.  TBNAV_MPPI_DYN_RK4 (default) is the reference MPPI: CartModel + RK4 (controller/include/
@@ -190,7 +191,9 @@ int tbnav_mppi_new_controls_rng(tbnav_mppi* h, const double x0[3], uint64_t seed
 /* n_ticks production ticks in a row, enqueued from C: tick i starts from x0s + i * x0_stride (doubles; x0_stride = 0: the
  * same state every tick — replay / throughput runs, the warm start is carried from tick to tick as always) with the
  * perturbations of (seed, first_tick + i).  Exactly n_ticks tbnav_mppi_enqueue_rng calls, without a trip through the
- * caller's language per tick (from Python one enqueue costs as much as the tick takes on the device). */
+ * caller's language per tick (from Python one enqueue costs as much as the tick takes on the device).  With one state for
+ * all ticks (x0_stride = 0) on a non-default stream and the fused kernel, whole chunks of 100 ticks are replayed from a captured
+ * hipGraph (same kernels, same arguments but for the tick number, which the kernel then reads from device memory): same result. */
 int tbnav_mppi_enqueue_rng_batch(tbnav_mppi* h, const double* x0s, int32_t x0_stride, uint64_t seed, uint64_t first_tick,
                                  int32_t n_ticks, void* stream);
 

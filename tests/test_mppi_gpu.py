@@ -410,3 +410,33 @@ def test_default_kernel_choice_by_ensemble_size_against_the_oracle(gpu_pkg, K, h
     a = m.newControlsDev((0.02, 0.0, 0.06), 0, 0)
     b = m2.newControlsRng((0.02, 0.0, 0.06), 11, 3)
     assert np.array_equal(np.array(a), np.array(b)) and np.array_equal(m.getControls(), m2.getControls())  # same kernels on both sides
+
+
+@pytest.mark.parametrize("K,horizon", [(1024, 0.5), (1500, 0.25), (4096, 1.0)])
+def test_batch_enqueue_by_graph_replay_equals_tick_by_tick(gpu_pkg, K, horizon):
+    """tbnav_mppi_enqueue_rng_batch replays whole chunks of 100 ticks from a captured hipGraph (the tick number comes from device
+    memory); the result must be the one of launching every tick by itself — bit for bit, over a run that is not a multiple of
+    the chunk, called twice (the second call reuses the graph), and after set_controls (first tick unshifted)."""
+    import torch
+    from rtn_amd import capi
+    d = mppi_cfg(K, horizon)
+    ma, mb = make_mppi(gpu_pkg, d), make_mppi(gpu_pkg, d)
+    mb.setOption(capi.MPPI_OPT_BATCH_GRAPH, 0)
+    side = torch.cuda.Stream()
+    st = side.cuda_stream
+    x0 = (0.05, -0.02, 0.3)
+    for m in (ma, mb):
+        m.setWaypoint(*WAYPOINTS[1])
+    for first, n in ((0, 250), (250, 330)):
+        ma.enqueueRngBatch(x0, 99, first, n, st)
+        for i in range(n):
+            mb.enqueueRng(x0, 99, first + i, st)
+        torch.cuda.synchronize()
+        assert ma.lastControls(st) == mb.lastControls(st)
+        assert np.array_equal(ma.getControls(), mb.getControls())
+    u = np.linspace(-1.0, 1.0, 2 * ma.steps).reshape(2, ma.steps)
+    ma.setControls(u); mb.setControls(u)
+    ma.enqueueRngBatch(x0, 7, 1000, 205, st)
+    mb.enqueueRngBatch(x0, 7, 1000, 205, st)
+    torch.cuda.synchronize()
+    assert np.array_equal(ma.getControls(), mb.getControls())
