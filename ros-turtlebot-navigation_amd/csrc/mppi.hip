@@ -1102,6 +1102,9 @@ __global__ void mppi_unpack_noise(int T, int K, const double* __restrict__ raw,
 }
 
 // ---- Philox4x32-10 (Salmon et al., SC'11) ------------------------------------------------------
+// last node of a captured chunk of ticks: the next replay's first tick
+__global__ void mppi_tick_advance(uint64_t* __restrict__ tick0, uint64_t n) { *tick0 += n; }
+
 __global__ void mppi_sample_noise(int T, int K, uint64_t seed, uint64_t base, double sig_l,
                                   double sig_r, double* __restrict__ duL, double* __restrict__ duR) {
   const size_t n = (size_t)T * K;
@@ -1143,6 +1146,7 @@ struct tbnav_mppi {
   hipGraph_t tg_graph = nullptr; hipGraphExec_t tg_exec = nullptr;
   uint64_t tg_seed = 0; double tg_x0[3] = {0, 0, 0}; hipStream_t tg_stream = nullptr; int tg_ucur = -1;
   uint64_t* d_tick0 = nullptr;
+  uint64_t tg_dev_tick = ~0ull;  // what *d_tick0 holds once everything enqueued so far has run (each replay's last node adds the chunk)
   int lds_from = 0;           // first time step whose loss is staged in LDS (0 = all of them)
   int reg_groups = 0;         // > 0: mppi_rollout_cost_reg keeps the losses of the last 4*reg_groups steps in registers
   int scan_tc = 0;            // steps per thread of the time-parallel rollout kernel (0 = sequential kernel)
@@ -1818,8 +1822,10 @@ int tbnav_mppi_enqueue_rng_batch(tbnav_mppi* h, const double* x0s, int32_t x0_st
   hipStream_t st = static_cast<hipStream_t>(stream);
   // (only where the tick is short enough for the launches themselves to matter: K = 1024: 8.25 -> 8.15 us per tick on a fast host, 8.9 -> 8.3
   //  on a slower one; from K = 2048 up the device is the bound and the replay is 1-3 % slower than plain launches)
-  if (h->graph_on && x0_stride == 0 && st != nullptr && h->fused_rng && h->fused_r == 8 && h->K <= 1536 && n_ticks >= 2 * kGraphTicks) {
+  if (h->graph_on && x0_stride == 0 && st != nullptr && h->fused_rng && h->fused_r == 8 && h->K <= 1536 && n_ticks >= 2) {
     DeviceGuard guard(h->device);
+    // (the graph is built by the first batch call that could use one, however short — a warm-up call, typically — so that a
+    //  later long call does not pay the ~1 ms of capture + instantiation)
     // the first tick after set_controls / set_initial_controls reads the vector unshifted: keep it out of the graph
     if (!h->pending_shift) { const int rc = tbnav_mppi_enqueue_rng(h, x0s, seed, first_tick, stream); if (rc != TBNAV_OK) return rc; ++i; }
     const bool same = h->tg_exec && h->tg_seed == seed && h->tg_stream == st && h->tg_ucur == h->ucur && std::memcmp(h->tg_x0, x0s, sizeof h->tg_x0) == 0;
@@ -1836,6 +1842,7 @@ int tbnav_mppi_enqueue_rng_batch(tbnav_mppi* h, const double* x0s, int32_t x0_st
           rc = launch_fused(h, x0s, h->d_duL, h->d_duR, st, &g);
           if (rc == TBNAV_OK) rc = launch_combine(h, h->d_records_f, 1, st, h->fused_S);
         }
+        if (rc == TBNAV_OK) { hipLaunchKernelGGL(mppi_tick_advance, dim3(1), dim3(1), 0, st, h->d_tick0, (uint64_t)kGraphTicks); if (hipGetLastError() != hipSuccess) rc = TBNAV_ERR_HIP; }
         hipGraph_t gr = nullptr;
         const hipError_t e_end = hipStreamEndCapture(st, &gr);
         h->ucur = ucur0; h->seq = seq0;  // nothing ran: the host-side state goes back
@@ -1849,8 +1856,10 @@ int tbnav_mppi_enqueue_rng_batch(tbnav_mppi* h, const double* x0s, int32_t x0_st
     }
     while (h->tg_exec && n_ticks - i >= kGraphTicks) {
       const uint64_t t0 = first_tick + (uint64_t)i;
-      TBNAV_HIP(hipMemcpyAsync(h->d_tick0, &t0, sizeof t0, hipMemcpyHostToDevice, st));  // (pageable source: staged before the call returns)
+      // (consecutive chunks need no copy: the replay's last node has advanced the device word)
+      if (t0 != h->tg_dev_tick) TBNAV_HIP(hipMemcpyAsync(h->d_tick0, &t0, sizeof t0, hipMemcpyHostToDevice, st));  // (pageable source: staged before the call returns)
       TBNAV_HIP(hipGraphLaunch(h->tg_exec, st));
+      h->tg_dev_tick = t0 + (uint64_t)kGraphTicks;
       h->seq += kGraphTicks;  // ucur: unchanged after an even number of ticks; the shift stays owed
       i += kGraphTicks;
     }
