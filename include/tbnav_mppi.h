@@ -69,6 +69,10 @@ int tbnav_mppi_rollouts(const tbnav_mppi* h); /* K of this handle           */
  * mppi_rollout_fused with -n rollouts per workgroup (one wave per rollout, lanes over time, partial records formed
  * in the same launch; tbnav_mppi_shard_partials then folds those fine records into the K-slice records). */
 int tbnav_mppi_rollout_variant(const tbnav_mppi* h);
+/* Which form of the sequential (one lane per rollout) kernel a variant-0 handle launches: 0 = mppi_rollout_cost (general),
+ * 1 = mppi_rollout_cost_reg (round 2: last losses in registers, the rest staged in LDS), 2 = mppi_rollout_prefix (round 3:
+ * exclusive prefixes written as the rollout goes, exact suffix sums for the horizon's last steps). */
+int tbnav_mppi_streaming_form(const tbnav_mppi* h);
 
 /* Options (explicit setters; nothing in the library reads the environment).
  *  TBNAV_MPPI_OPT_KERNEL   which rollout kernel the handle launches instead of the automatic choice: 0 = mppi_rollout_cost,
@@ -79,9 +83,13 @@ int tbnav_mppi_rollout_variant(const tbnav_mppi* h);
  *  TBNAV_MPPI_OPT_NO_LDS_STAGING  1 = mppi_rollout_cost stages every per-step loss through J (development).
  *  TBNAV_MPPI_OPT_KEEP_J   1 = the fused kernel also stores the cost-to-go J[T][K] (410 KB at K=1024, T=50) so that
  *                          tbnav_mppi_get_cost_to_go can return it; off by default — the update needs only the records.
- *  TBNAV_MPPI_OPT_REG_TAIL 0 = do not use mppi_rollout_cost_reg (losses of the last steps in registers) even where it applies. */
+ *  TBNAV_MPPI_OPT_REG_TAIL 0 = do not use mppi_rollout_cost_reg (losses of the last steps in registers) even where it applies.
+ *  TBNAV_MPPI_OPT_PREFIX_FORM 0 = do not use mppi_rollout_prefix (exclusive prefixes of the losses to J as the rollout goes, exact
+ *                          suffix sums only for the horizon's last steps, J = total - prefix formed by the consumers) even where
+ *                          it applies — the large-K default of round 3; the round-2 kernels stay for A-B runs. */
 enum { TBNAV_MPPI_OPT_KERNEL = 1, TBNAV_MPPI_OPT_TRIG = 2, TBNAV_MPPI_OPT_NO_LDS_STAGING = 3, TBNAV_MPPI_OPT_KEEP_J = 4, TBNAV_MPPI_OPT_REG_TAIL = 5,
-       TBNAV_MPPI_OPT_BATCH_GRAPH = 6 /* 0: tbnav_mppi_enqueue_rng_batch launches every tick by itself instead of replaying a captured hipGraph of 100 */ };
+       TBNAV_MPPI_OPT_BATCH_GRAPH = 6 /* 0: tbnav_mppi_enqueue_rng_batch launches every tick by itself instead of replaying a captured hipGraph of 100 */,
+       TBNAV_MPPI_OPT_PREFIX_FORM = 7 };
 int tbnav_mppi_set_option(tbnav_mppi* h, int32_t option, int32_t value);
 
 /* Rollout dynamics.  TBNAV_MPPI_DYN_RK4 (default) is the reference MPPI: CartModel + RK4 (controller/include/

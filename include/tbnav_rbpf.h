@@ -105,6 +105,13 @@ int tbnav_rbpf_grid_size(const tbnav_rbpf* h, int32_t* xsize, int32_t* ysize);
 int64_t tbnav_rbpf_num_normals(const tbnav_rbpf* h, int32_t icp_ok);
 /* Seed of the device noise source (resets its scan counter).  Default seed 0x5EED. */
 int tbnav_rbpf_set_seed(tbnav_rbpf* h, uint64_t seed);
+/* Sharded filters: this handle's particles are particles [first_particle, first_particle + N) of an ensemble of
+ * particles_global.  The device noise source then draws element first_particle * stride + j of the ENSEMBLE's stream for the
+ * handle's normal j (stride = 3k+3 or 3, tbnav_rbpf_num_normals) and the ensemble's resampling offset, so ranks that share a
+ * seed draw DISJOINT normals — exactly the ones the unsharded filter of particles_global particles draws from that seed.  Without
+ * this call every handle numbers its particles from 0 and ranks sharing a seed would all draw the same normals (their copies of a
+ * migrated particle would then evolve identically).  particles_global = 0 switches back to the unsharded numbering. */
+int tbnav_rbpf_set_rng_shard(tbnav_rbpf* h, uint64_t first_particle, uint64_t particles_global);
 /* The first n standard normals the LAST SLAM call consumed (host- or device-drawn) — for statistical tests. */
 int tbnav_rbpf_get_normals(tbnav_rbpf* h, double* out, int64_t n);
 
@@ -166,7 +173,8 @@ int tbnav_rbpf_slam_local(tbnav_rbpf* h, const float* scan, int32_t n_beams, con
 /* This handle's weights [N] -> device buffer (synchronous on the handle's stream). */
 int tbnav_rbpf_copy_weights_dev(tbnav_rbpf* h, double* d_dst);
 /* d_weights_all: n_global raw weights on the device (identical on every rank); offset: global index of this
- * handle's slot 0; z: the one standard normal of lowVarianceResampling (particle_filter.cpp:474).  parents_out
+ * handle's slot 0; z: the one standard normal of lowVarianceResampling (particle_filter.cpp:474) — NaN = the one the
+ * handle's last scan carries (device noise with tbnav_rbpf_set_rng_shard: the ensemble's offset, identical on every rank).  parents_out
  * (n_global int32, host, may be NULL) is filled only if out->resampled. */
 int tbnav_rbpf_resample_global_dev(tbnav_rbpf* h, const double* d_weights_all, int64_t n_global, int64_t offset, double z,
                                    int32_t* parents_out, tbnav_rbpf_stats* out);
@@ -189,7 +197,9 @@ int tbnav_rbpf_import_particle_dev(tbnav_rbpf* h, int32_t slot, const void* d_bu
  * arrays).  export: the blobs of slots[0..n) back to back in d_buf (a slot may be listed more than once), offsets_out[i] =
  * where blob i starts, offsets_out[n] = bytes written; sizes first (export_batch_sizes) to size the buffer and tell the
  * receivers.  import: slot slots[i] (each at most once) takes the blob at d_buf + offsets[i] (several slots may name the
- * same blob).  Two launches each, whatever n. */
+ * same blob).  Two launches each, whatever n.  import returns TBNAV_ERR_POOL_EXHAUSTED with NOTHING touched when the incoming
+ * tiles exceed the free tiles plus every tile the destination slots name; inside that bound the slots are released first and an
+ * exhaustion found while unpacking leaves those slots with empty maps (a sharded driver must then stop on every rank). */
 int tbnav_rbpf_export_batch_sizes(tbnav_rbpf* h, int32_t n, const int32_t* slots, uint64_t* sizes_out /*[n]*/);
 int tbnav_rbpf_export_batch_dev(tbnav_rbpf* h, int32_t n, const int32_t* slots, void* d_buf, uint64_t capacity,
                                 uint64_t* offsets_out /*[n + 1]*/);
@@ -254,9 +264,12 @@ int tbnav_rbpf_particle_map(tbnav_rbpf* h, int32_t particle, int8_t* map);
  *                                (kept for A-B runs).  All forms leave bit-identical maps.
  * TBNAV_RBPF_OPT_RAYCAST_BAND_ROWS n > 0 = rbpf_raycast_box keeps at most about n rows of a scan's bounding box in LDS at a
  *                                time (0 = as many as fit): drives its band loop on small maps (tests).
- * TBNAV_RBPF_OPT_BATCH_PIPELINE  1 = tbnav_rbpf_slam_batch keeps two scans in the stream (default); 0 = n synchronous calls. */
+ * TBNAV_RBPF_OPT_BATCH_PIPELINE  1 = tbnav_rbpf_slam_batch keeps two scans in the stream (default); 0 = n synchronous calls.
+ * TBNAV_RBPF_OPT_HOST_THREADS    host threads the REFERENCE distance-field mode spreads its per-particle brushfires over (particles are
+ *                                independent; the order of operations inside one particle is the reference's).  0 = the default: the
+ *                                cores in the process's affinity mask, at most 32. */
 enum { TBNAV_RBPF_OPT_DF_MODE = 1, TBNAV_RBPF_OPT_RAYCAST_ORDERED = 2, TBNAV_RBPF_OPT_RAYCAST_THREADS = 3, TBNAV_RBPF_OPT_COUNT_CELLS = 4,
-       TBNAV_RBPF_OPT_RAYCAST_FORM = 5, TBNAV_RBPF_OPT_RAYCAST_BAND_ROWS = 6, TBNAV_RBPF_OPT_BATCH_PIPELINE = 7 };
+       TBNAV_RBPF_OPT_RAYCAST_FORM = 5, TBNAV_RBPF_OPT_RAYCAST_BAND_ROWS = 6, TBNAV_RBPF_OPT_BATCH_PIPELINE = 7, TBNAV_RBPF_OPT_HOST_THREADS = 8 };
 enum { TBNAV_RBPF_DF_FULL = 0, TBNAV_RBPF_DF_WINDOW = 1, TBNAV_RBPF_DF_QUERY = 2, TBNAV_RBPF_DF_REFERENCE = 3 };
 int tbnav_rbpf_set_option(tbnav_rbpf* h, int32_t option, int32_t value);
 /* Since the last reset, summed over particles and scans (TBNAV_RBPF_OPT_COUNT_CELLS on): cell_updates = log-odds

@@ -21,12 +21,13 @@ OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OUT_OF_WORLD, ERR_ETA_ZERO, ERR
     ERR_BRESENHAM, ERR_UNSUPPORTED, ERR_POOL_EXHAUSTED = range(10)
 
 # tbnav_mppi.h options
-MPPI_OPT_KERNEL, MPPI_OPT_TRIG, MPPI_OPT_NO_LDS_STAGING, MPPI_OPT_KEEP_J, MPPI_OPT_REG_TAIL, MPPI_OPT_BATCH_GRAPH = 1, 2, 3, 4, 5, 6
+MPPI_OPT_KERNEL, MPPI_OPT_TRIG, MPPI_OPT_NO_LDS_STAGING, MPPI_OPT_KEEP_J, MPPI_OPT_REG_TAIL, MPPI_OPT_BATCH_GRAPH, MPPI_OPT_PREFIX_FORM = 1, 2, 3, 4, 5, 6, 7
 
 # tbnav_rbpf.h options
 RBPF_OPT_DF_MODE, RBPF_OPT_RAYCAST_ORDERED, RBPF_OPT_RAYCAST_THREADS, RBPF_OPT_COUNT_CELLS, RBPF_OPT_RAYCAST_FORM = 1, 2, 3, 4, 5
 RBPF_OPT_RAYCAST_BAND_ROWS = 6
 RBPF_OPT_BATCH_PIPELINE = 7
+RBPF_OPT_HOST_THREADS = 8
 RBPF_DF = {"full": 0, "window": 1, "query": 2, "reference": 3}
 
 
@@ -116,6 +117,7 @@ def lib() -> C.CDLL:
         "tbnav_mppi_steps": (C.c_int, [vp]),
         "tbnav_mppi_rollouts": (C.c_int, [vp]),
         "tbnav_mppi_rollout_variant": (C.c_int, [vp]),
+        "tbnav_mppi_streaming_form": (C.c_int, [vp]),
         "tbnav_mppi_set_dynamics": (C.c_int, [vp, i32]),
         "tbnav_mppi_set_option": (C.c_int, [vp, i32, i32]),
         "tbnav_mppi_set_rng_shard": (C.c_int, [vp, u64, u64]),
@@ -153,6 +155,7 @@ def lib() -> C.CDLL:
         "tbnav_rbpf_grid_size": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32)]),
         "tbnav_rbpf_num_normals": (C.c_int64, [vp, i32]),
         "tbnav_rbpf_set_seed": (C.c_int, [vp, u64]),
+        "tbnav_rbpf_set_rng_shard": (C.c_int, [vp, u64, u64]),
         "tbnav_rbpf_get_normals": (C.c_int, [vp, vp, C.c_int64]),
         "tbnav_rbpf_slam": (C.c_int, [vp, vp, i32, dp, dp, dp, i32, dp, vp, C.POINTER(RbpfStats)]),
         "tbnav_rbpf_slam_local": (C.c_int, [vp, vp, i32, dp, dp, dp, i32, dp, vp, C.POINTER(RbpfStats)]),

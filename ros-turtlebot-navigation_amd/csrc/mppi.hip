@@ -549,6 +549,181 @@ void mppi_rollout_cost_reg(RolloutArgs a_in, const double* __restrict__ duL, con
   }
 }
 
+// ---- streaming rollout, prefix form (round 3; the large-K default) --------------------------------------------------
+// What held mppi_rollout_cost_reg at 46 us (K = 65536, T = 100: ONE wave per SIMD — 1024 one-wave workgroups on 1024 SIMDs, so
+// all latency hiding has to come from inside the wave): (1) small_sincos's wave-uniform `if (__any(big))` sat in EVERY step and
+// cut the unrolled round into ~50 basic blocks of one step each — no scheduling region held more than one step's dependent
+// fp64 chain; (2) every loss made a round trip through LDS and the kernel ended with a backward pass that is pure memory.
+// Here:  * ONE branch per round of 12 steps: the round's controls are formed first, `any |d| > 2^-5` is decided once, and the
+//          straight-line Taylor round (no branch inside: one scheduling region, 12 independent small-angle chains + 3 fresh
+//          sincos chains) or the general round (the kernels above) runs;
+//        * the forward pass keeps the running sum and stores the EXCLUSIVE PREFIX E(i) = loss(0) + ... + loss(i-1) to J[i] as it
+//          goes (one coalesced 512-B store per step, under the trig); the last 4*RG steps keep their losses in registers and get
+//          their exact suffix sums J(i) as before, and the rollout's total S = E(T - 4 RG) + J(T - 4 RG) goes to total[k].  The
+//          consumers (mppi_partials, the parity getter) form J(i) = S - E(i) for the prefix rows: its rounding error is
+//          eps * S — what J(0) = S carries anyway — and the rows where S / J(i) would amplify it (the horizon's end) are the
+//          exact ones.  No LDS stage, no backward pass over LDS, J written once, nothing re-read.
+//        * the step itself in fewer instructions: heading += h * w (the reference's (h/6) * (((w + 2w) + 2w) + w) is the same
+//          number up to one rounding), stage headings by two successive rotations, x += (h/6 v) * ((c1 + 4 c2) + c4).  Differences
+//          from the reference's association are <= 2 ulp per step (J asserted within 1e-12 of the oracle as for every kernel).
+template <int G>
+__device__ __forceinline__ void lean_group(const RolloutArgs& a, double& x, double& y, double& th, const double (&ul)[G], const double (&ur)[G],
+                                           double (&thq)[G], double (&xq)[G], double (&yq)[G]) {
+  double g6[G], d[G], hth[G];
+  double t = th;
+#pragma unroll
+  for (int q = 0; q < G; ++q) {
+    const double w = a.r_over_b * (ur[q] - ul[q]);
+    g6[q] = a.h6 * (a.half_r * (ul[q] + ur[q]));
+    const double hw = a.h * w;
+    d[q] = 0.5 * hw;
+    hth[q] = t;
+    t = t + hw;
+    thq[q] = t;
+  }
+  th = t;
+  double s1, c1;
+  fast_sincos(hth[0], s1, c1);   // fresh at the group's first step; the later steps carry the stage-4 pair (<= 3 steps = 6 rotations)
+  double sd[G], cd[G];
+#pragma unroll
+  for (int q = 0; q < G; ++q) {   // straight-line Taylor pair, |d| <= 2^-5 (the caller checked the whole round)
+    const double d2 = d[q] * d[q];
+    double ps = fma(d2, -1.0 / 42.0, 1.0);
+    ps = fma(d2 * (-1.0 / 20.0), ps, 1.0);
+    ps = fma(d2 * (-1.0 / 6.0), ps, 1.0);
+    sd[q] = d[q] * ps;
+    double pc = fma(d2, -1.0 / 56.0, 1.0);
+    pc = fma(d2 * (-1.0 / 30.0), pc, 1.0);
+    pc = fma(d2 * (-1.0 / 12.0), pc, 1.0);
+    cd[q] = fma(d2 * -0.5, pc, 1.0);
+  }
+#pragma unroll
+  for (int q = 0; q < G; ++q) {
+    const double c2 = c1 * cd[q] - s1 * sd[q], s2 = s1 * cd[q] + c1 * sd[q];
+    const double c4 = c2 * cd[q] - s2 * sd[q], s4 = s2 * cd[q] + c2 * sd[q];
+    x = fma(g6[q], fma(4.0, c2, c1) + c4, x);
+    y = fma(g6[q], fma(4.0, s2, s1) + s4, y);
+    xq[q] = x; yq[q] = y;
+    s1 = s4; c1 = c4;
+  }
+}
+
+constexpr int kRoundGroups = 3;
+template <int RG>
+__global__ __launch_bounds__(kWave) void mppi_rollout_prefix(RolloutArgs a_in, const double* __restrict__ duL, const double* __restrict__ duR, USrc u,
+                                                             double* __restrict__ J, double* __restrict__ total) {
+  extern __shared__ __attribute__((aligned(16))) double lds_all[];
+  const int lane = threadIdx.x;
+  const int T = a_in.T, K = a_in.K;
+  double* u_lds = lds_all;                 // [2*T]
+  for (int t = lane; t < 2 * T; t += kWave) u_lds[t] = u.get(t >= T, t >= T ? t - T : t, T);
+  __shared__ double consts[20];            // (the rollout's constants through LDS into VECTOR registers: see mppi_rollout_cost_reg)
+  if (lane == 0) {
+    consts[0] = a_in.half_r; consts[1] = a_in.r_over_b; consts[2] = a_in.r_d; consts[3] = a_in.h; consts[4] = a_in.h6;
+    for (int q = 0; q < 3; ++q) { consts[5 + q] = a_in.x0[q]; consts[8 + q] = a_in.xd[q]; consts[11 + q] = a_in.Q[q]; consts[16 + q] = a_in.P1[q]; }
+    consts[14] = a_in.R[0]; consts[15] = a_in.R[1];
+  }
+  __syncthreads();
+  RolloutArgs a;
+  a.half_r = consts[0]; a.r_over_b = consts[1]; a.r_d = consts[2]; a.h = consts[3]; a.h6 = consts[4];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) { a.x0[q] = consts[5 + q]; a.xd[q] = consts[8 + q]; a.Q[q] = consts[11 + q]; a.P1[q] = consts[16 + q]; }
+  a.R[0] = consts[14]; a.R[1] = consts[15];
+  a.T = T; a.K = K; a.lds_from = 0;
+  const int k = blockIdx.x * kWave + lane;
+  if (k >= K) return;
+  double x = a.x0[0], y = a.x0[1], th = a.x0[2];
+  const int n_main = T / kGroup - RG;                  // groups whose exclusive prefix goes to J: a multiple of kRoundGroups
+  const size_t gstride = (size_t)kGroup * K;
+  const double* pl = duL + k;
+  const double* pr = duR + k;
+  double* Jk = J + k;
+  // |d| = |h/2 * r/b * (ur - ul)| <= 2^-5  <=>  |ur - ul| <= dmax
+  const double dmax = 0.0625 / fabs(a.h * a.r_over_b);
+  double nl[kRoundGroups][kGroup], nr[kRoundGroups][kGroup];
+#pragma unroll
+  for (int r = 0; r < kRoundGroups; ++r) {
+#pragma unroll
+    for (int q = 0; q < kGroup; ++q) {
+      const size_t off = (size_t)(r * kGroup + q) * K;
+      nl[r][q] = pl[off];
+      nr[r][q] = pr[off];
+    }
+  }
+  double acc = 0.0;  // E(i): losses of the steps before i, in step order
+  const double* nxl = pl + (size_t)kRoundGroups * gstride;
+  const double* nxr = pr + (size_t)kRoundGroups * gstride;
+  for (int g0 = 0; g0 < n_main; g0 += kRoundGroups) {
+    double ul[kRoundGroups][kGroup], ur[kRoundGroups][kGroup];
+    bool big = false;
+#pragma unroll
+    for (int r = 0; r < kRoundGroups; ++r) {
+#pragma unroll
+      for (int q = 0; q < kGroup; ++q) {
+        const int i = (g0 + r) * kGroup + q;
+        ul[r][q] = u_lds[i] + nl[r][q];        // mppi.cpp:93 — rollout controls are not clamped
+        ur[r][q] = u_lds[T + i] + nr[r][q];
+        big |= !(fabs(ur[r][q] - ul[r][q]) <= dmax);
+      }
+    }
+    // the noise of the next round (its last RG groups' worth past n_main is the late region's: same addresses, same ring)
+    if (g0 + kRoundGroups < T / kGroup) {
+#pragma unroll
+      for (int r = 0; r < kRoundGroups; ++r) {
+        if (g0 + kRoundGroups + r < T / kGroup) {
+#pragma unroll
+          for (int q = 0; q < kGroup; ++q) {
+            nl[r][q] = nxl[(size_t)r * gstride + (size_t)q * K];
+            nr[r][q] = nxr[(size_t)r * gstride + (size_t)q * K];
+          }
+        }
+      }
+      nxl += (size_t)kRoundGroups * gstride;
+      nxr += (size_t)kRoundGroups * gstride;
+    }
+    double thq[kRoundGroups][kGroup], xq[kRoundGroups][kGroup], yq[kRoundGroups][kGroup];
+    if (__any(big)) {
+#pragma unroll
+      for (int r = 0; r < kRoundGroups; ++r) rk4_steps<2, kGroup>(a, x, y, th, ul[r], ur[r], thq[r], xq[r], yq[r]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < kRoundGroups; ++r) lean_group<kGroup>(a, x, y, th, ul[r], ur[r], thq[r], xq[r], yq[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < kRoundGroups; ++r) {
+#pragma unroll
+      for (int q = 0; q < kGroup; ++q) {
+        const int i = (g0 + r) * kGroup + q;   // (never the terminal step: that one is in the late region)
+        Jk[(size_t)i * K] = acc;
+        acc = acc + lqr_loss(a, xq[r][q], yq[r][q], thq[r][q], ul[r][q], ur[r][q]);
+      }
+    }
+  }
+  // late region: the last RG groups, losses in registers, exact suffix sums (mppi.cpp:15-25 from the end)
+  static_assert(RG <= kRoundGroups, "the late region's noise is what the last round's prefetch left in the ring");
+  double lreg[RG][kGroup];
+#pragma unroll
+  for (int j = 0; j < RG; ++j) {
+    double dl[kGroup], dr[kGroup];
+#pragma unroll
+    for (int q = 0; q < kGroup; ++q) {
+      dl[q] = nl[j][q]; dr[q] = nr[j][q];
+    }
+    rollout_group<2, kGroup, true>(a, (n_main + j) * kGroup, lane, k, x, y, th, dl, dr, u_lds, nullptr, J, lreg[j]);
+  }
+  double suf = 0.0;
+#pragma unroll
+  for (int j = RG - 1; j >= 0; --j) {
+#pragma unroll
+    for (int q = kGroup - 1; q >= 0; --q) {
+      const int i = (n_main + j) * kGroup + q;
+      suf = (j == RG - 1 && q == kGroup - 1) ? lreg[j][q] : lreg[j][q] + suf;
+      Jk[(size_t)i * K] = suf;
+    }
+  }
+  total[k] = acc + suf;   // S = E(T - 4 RG) + J(T - 4 RG)
+}
+
 // ---- time-parallel rollout ---------------------------------------------------------------------------
 // The cart's increments do not depend on position: th_{i+1} = th_i + dth(u_i) and
 // x_{i+1} = x_i + incx(th_i, u_i), so a rollout is three scans (heading, position, cost-to-go) around
@@ -900,11 +1075,15 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
 }
 
 // grid = (S, T).  Block (s, i) reduces time step i over rollouts [s*kSlice, (s+1)*kSlice).
+// prefix_rows > 0 (mppi_rollout_prefix ran): rows i < prefix_rows of J hold the exclusive prefix E(i) and total[k] the
+// rollout's whole cost S: J(i, k) = S - E(i) is formed here (the 8 * K bytes of `total` are re-read by every time step's
+// workgroups: L2 hits).
 __global__ __launch_bounds__(kSliceThreads) void mppi_partials(int T, int K, int S, double lambda,
                                                                const double* __restrict__ J,
                                                                const double* __restrict__ duL,
                                                                const double* __restrict__ duR,
-                                                               double* __restrict__ records) {
+                                                               double* __restrict__ records, int prefix_rows,
+                                                               const double* __restrict__ total) {
   __shared__ double scratch[kSliceThreads / kWave];
   const int s = blockIdx.x, i = blockIdx.y;
   const int base = s * kSlice;
@@ -916,7 +1095,7 @@ __global__ __launch_bounds__(kSliceThreads) void mppi_partials(int T, int K, int
   for (int it = 0; it < kSliceItems; ++it) {
     const int k = base + it * kSliceThreads + threadIdx.x;  // coalesced across lanes
     const bool ok = k < K;
-    j[it] = ok ? J[(size_t)i * K + k] : inf;
+    j[it] = ok ? (i < prefix_rows ? total[k] - J[(size_t)i * K + k] : J[(size_t)i * K + k]) : inf;
     l[it] = ok ? duL[(size_t)i * K + k] : 0.0;
     r[it] = ok ? duR[(size_t)i * K + k] : 0.0;
     mn = fmin(mn, j[it]);
@@ -1104,6 +1283,9 @@ __global__ void mppi_unpack_noise(int T, int K, const double* __restrict__ raw,
 // ---- Philox4x32-10 (Salmon et al., SC'11) ------------------------------------------------------
 // last node of a captured chunk of ticks: the next replay's first tick
 __global__ void mppi_tick_advance(uint64_t* __restrict__ tick0, uint64_t n) { *tick0 += n; }
+// the first tick of a replay that does not continue the previous one (the value rides in the launch arguments: no host buffer
+// has to outlive the call)
+__global__ void mppi_tick_set(uint64_t* __restrict__ tick0, uint64_t v) { *tick0 = v; }
 
 __global__ void mppi_sample_noise(int T, int K, uint64_t seed, uint64_t base, double sig_l,
                                   double sig_r, double* __restrict__ duL, double* __restrict__ duR) {
@@ -1145,10 +1327,17 @@ struct tbnav_mppi {
   bool graph_on = true;         // TBNAV_MPPI_OPT_BATCH_GRAPH; cleared for good if a capture ever fails
   hipGraph_t tg_graph = nullptr; hipGraphExec_t tg_exec = nullptr;
   uint64_t tg_seed = 0; double tg_x0[3] = {0, 0, 0}; hipStream_t tg_stream = nullptr; int tg_ucur = -1;
+  // The graph's kernel nodes hold BY VALUE everything launch_fused / launch_combine read from the handle when it was captured
+  // (waypoint, uinit, lambda, dynamics, trig, keep_j + the J pointer, the rng shard, fused_S and the record buffer).  Every
+  // setter that changes one of those bumps cfg_epoch; a graph captured under another epoch is rebuilt, never replayed.
+  uint64_t cfg_epoch = 0, tg_epoch = ~0ull;
   uint64_t* d_tick0 = nullptr;
   uint64_t tg_dev_tick = ~0ull;  // what *d_tick0 holds once everything enqueued so far has run (each replay's last node adds the chunk)
   int lds_from = 0;           // first time step whose loss is staged in LDS (0 = all of them)
   int reg_groups = 0;         // > 0: mppi_rollout_cost_reg keeps the losses of the last 4*reg_groups steps in registers
+  int prefix_rg = 0;          // > 0: mppi_rollout_prefix (the large-K default): exact suffix sums for the last 4*prefix_rg steps, exclusive prefixes before
+  int prefix_rows = 0;        // rows of d_J that hold exclusive prefixes after the LAST rollout launch (0: every row is J)
+  double* d_total = nullptr;  // [K] whole cost of every rollout (mppi_rollout_prefix)
   int scan_tc = 0;            // steps per thread of the time-parallel rollout kernel (0 = sequential kernel)
   int fused_r = 0;            // rollouts per workgroup of the fused rollout+partials kernel (0 = off: three kernels)
   int fused_S = 0;            // its records per time step, ceil(K / fused_r)
@@ -1179,6 +1368,7 @@ int launch_rollout(tbnav_mppi* h, const double x0[3], const double* d_duL, const
   const dim3 grid((h->K + kWave - 1) / kWave), block(kWave);
   const USrc usrc{h->d_u[h->ucur], h->pending_shift ? 1 : 0, h->uinit[0], h->uinit[1]};
   if (h->scan_tc > 0 && h->dyn == 0) {  // (the arc dynamics live in the fused and the sequential kernels)
+    h->prefix_rows = 0;
     const int TCv = h->scan_tc, C = (h->T + TCv - 1) / TCv;
     const size_t lds = ((size_t)2 * h->T + (size_t)4 * C * kWave) * sizeof(double);
     const dim3 blk(kWave, C);
@@ -1196,6 +1386,20 @@ int launch_rollout(tbnav_mppi* h, const double x0[3], const double* d_duL, const
 #undef TBNAV_SCAN_TC
 #undef TBNAV_SCAN
   } else {
+    if (h->prefix_rg > 0 && h->dyn == 0 && h->trig == 1) {
+      const size_t ldsp = (size_t)2 * h->T * sizeof(double);
+      a.lds_from = 0;
+      switch (h->prefix_rg) {
+        case 1: hipLaunchKernelGGL((mppi_rollout_prefix<1>), grid, block, ldsp, st, a, d_duL, d_duR, usrc, h->d_J, h->d_total); break;
+        case 2: hipLaunchKernelGGL((mppi_rollout_prefix<2>), grid, block, ldsp, st, a, d_duL, d_duR, usrc, h->d_J, h->d_total); break;
+        default: hipLaunchKernelGGL((mppi_rollout_prefix<3>), grid, block, ldsp, st, a, d_duL, d_duR, usrc, h->d_J, h->d_total); break;
+      }
+      TBNAV_HIP(hipGetLastError());
+      h->j_valid = true;
+      h->prefix_rows = h->T - kGroup * h->prefix_rg;
+      return TBNAV_OK;
+    }
+    h->prefix_rows = 0;
     if (h->reg_groups > 0 && h->dyn == 0 && h->trig == 1) {
       const size_t ldsr = (size_t)2 * h->T * sizeof(double) + (size_t)(h->T - kGroup * h->reg_groups) * kWave * sizeof(double);
       a.lds_from = 0;
@@ -1265,12 +1469,13 @@ int launch_fused(tbnav_mppi* h, const double x0[3], const double* d_duL, const d
 #undef TBNAV_FUSED
   TBNAV_HIP(hipGetLastError());
   h->j_valid = h->keep_j;
+  h->prefix_rows = 0;
   return TBNAV_OK;
 }
 
 int launch_partials(tbnav_mppi* h, const double* d_duL, const double* d_duR, double* d_records, hipStream_t st) {
   const dim3 grid(h->S, h->T), block(kSliceThreads);
-  hipLaunchKernelGGL(mppi_partials, grid, block, 0, st, h->T, h->K, h->S, h->p.lambda, h->d_J, d_duL, d_duR, d_records);
+  hipLaunchKernelGGL(mppi_partials, grid, block, 0, st, h->T, h->K, h->S, h->p.lambda, h->d_J, d_duL, d_duR, d_records, h->prefix_rows, h->d_total);
   TBNAV_HIP(hipGetLastError());
   return TBNAV_OK;
 }
@@ -1392,6 +1597,10 @@ int tbnav_mppi_create(const tbnav_mppi_params* params, tbnav_mppi** out) {
       for (int rg : {2, 4, 6, 7, 8}) if (rg >= need && T / 4 - rg >= 1) { if (!pick) pick = rg; if ((T / 4 - rg) % kAheadR == 0) { pick = rg; break; } }
       h->reg_groups = pick;
     }
+    // round 3: the prefix-form kernel takes the streaming shape whenever a late region of 1, 2 or 3 groups leaves whole rounds
+    // of three groups (one of the three always does) and at least one round — whatever T: it stages nothing in LDS
+    if (T % 4 == 0 && blocks >= 2 * cus)
+      for (int rg : {1, 2, 3}) if ((T / 4 - rg) % kRoundGroups == 0 && T / 4 - rg >= kRoundGroups) { h->prefix_rg = rg; break; }
   }
   // time-parallel kernel: up to 16 chunks (waves) per workgroup
   h->scan_tc = 0;
@@ -1445,6 +1654,7 @@ int tbnav_mppi_create(const tbnav_mppi_params* params, tbnav_mppi** out) {
   alloc(&h->d_duL, tk);
   alloc(&h->d_duR, tk);
   alloc(&h->d_records, (size_t)T * h->S * TBNAV_MPPI_REC);
+  if (h->prefix_rg) alloc(&h->d_total, (size_t)h->K);
   if (h->fused_r) alloc(&h->d_records_f, (size_t)T * h->fused_S * TBNAV_MPPI_REC);
   alloc(&h->d_out, 2);
   if (e == hipSuccess) e = hipMemset(h->d_out, 0, 2 * sizeof(double));
@@ -1504,6 +1714,7 @@ void tbnav_mppi_destroy(tbnav_mppi* h) {
   if (!h) return;
   DeviceGuard guard(h->device);
   (void)hipFree(h->d_u[0]); (void)hipFree(h->d_u[1]); (void)hipFree(h->d_J); (void)hipFree(h->d_duL); (void)hipFree(h->d_duR);
+  (void)hipFree(h->d_total);
   (void)hipFree(h->d_raw); (void)hipFree(h->d_records); (void)hipFree(h->d_records_f); (void)hipFree(h->d_out);
   if (h->h_out) (void)hipHostFree(h->h_out);
   if (h->tg_exec) (void)hipGraphExecDestroy(h->tg_exec);
@@ -1516,6 +1727,7 @@ int tbnav_mppi_steps(const tbnav_mppi* h) { return h ? h->T : -1; }
 int tbnav_mppi_set_dynamics(tbnav_mppi* h, int32_t model) {
   if (!h || (model != TBNAV_MPPI_DYN_RK4 && model != TBNAV_MPPI_DYN_ARC)) return TBNAV_ERR_INVALID_ARG;
   h->dyn = model;
+  ++h->cfg_epoch;
   return TBNAV_OK;
 }
 
@@ -1523,6 +1735,7 @@ int tbnav_mppi_set_option(tbnav_mppi* h, int32_t option, int32_t value) {
   if (!h) return TBNAV_ERR_INVALID_ARG;
   DeviceGuard guard(h->device);
   const int T = h->T;
+  ++h->cfg_epoch;  // (any option may change what a captured graph of ticks has baked in)
   switch (option) {
     case TBNAV_MPPI_OPT_KEEP_J: h->keep_j = value != 0; return TBNAV_OK;
     case TBNAV_MPPI_OPT_TRIG:
@@ -1530,10 +1743,13 @@ int tbnav_mppi_set_option(tbnav_mppi* h, int32_t option, int32_t value) {
       h->trig = value;
       return TBNAV_OK;
     case TBNAV_MPPI_OPT_NO_LDS_STAGING:
-      if (value) { h->lds_from = T; h->reg_groups = 0; }
+      if (value) { h->lds_from = T; h->reg_groups = 0; h->prefix_rg = 0; }
       return TBNAV_OK;
     case TBNAV_MPPI_OPT_REG_TAIL:
       if (!value) h->reg_groups = 0;
+      return TBNAV_OK;
+    case TBNAV_MPPI_OPT_PREFIX_FORM:
+      if (!value) h->prefix_rg = 0;
       return TBNAV_OK;
     case TBNAV_MPPI_OPT_BATCH_GRAPH:
       h->graph_on = value != 0;
@@ -1569,10 +1785,15 @@ int tbnav_mppi_set_rng_shard(tbnav_mppi* h, uint64_t first_rollout, uint64_t rol
   if (!h || rollouts_global < first_rollout + (uint64_t)h->K) return TBNAV_ERR_INVALID_ARG;
   h->k0 = first_rollout;
   h->k_global = rollouts_global;
+  ++h->cfg_epoch;
   return TBNAV_OK;
 }
 
 int tbnav_mppi_rollout_variant(const tbnav_mppi* h) { return h ? (h->fused_dev ? -h->fused_r : h->scan_tc) : 0; }
+int tbnav_mppi_streaming_form(const tbnav_mppi* h) {
+  if (!h) return -1;
+  return (h->dyn == 0 && h->trig == 1) ? (h->prefix_rg > 0 ? 2 : (h->reg_groups > 0 ? 1 : 0)) : 0;
+}
 int tbnav_mppi_rollouts(const tbnav_mppi* h) { return h ? h->K : -1; }
 int tbnav_mppi_records_per_step(const tbnav_mppi* h) { return h ? h->S : -1; }
 
@@ -1580,6 +1801,7 @@ int tbnav_mppi_set_initial_controls(tbnav_mppi* h, double uL, double uR) {
   if (!h) return TBNAV_ERR_INVALID_ARG;
   DeviceGuard guard(h->device);
   h->uinit[0] = uL; h->uinit[1] = uR;
+  ++h->cfg_epoch;
   double* tmp = new (std::nothrow) double[2 * (size_t)h->T];
   if (!tmp) return TBNAV_ERR_INVALID_ARG;
   for (int i = 0; i < h->T; ++i) { tmp[i] = uL; tmp[h->T + i] = uR; }
@@ -1594,6 +1816,7 @@ int tbnav_mppi_set_initial_controls(tbnav_mppi* h, double uL, double uR) {
 int tbnav_mppi_set_waypoint(tbnav_mppi* h, double x, double y, double theta) {
   if (!h) return TBNAV_ERR_INVALID_ARG;
   h->xd[0] = x; h->xd[1] = y; h->xd[2] = theta;
+  ++h->cfg_epoch;
   return TBNAV_OK;
 }
 
@@ -1828,8 +2051,11 @@ int tbnav_mppi_enqueue_rng_batch(tbnav_mppi* h, const double* x0s, int32_t x0_st
     //  later long call does not pay the ~1 ms of capture + instantiation)
     // the first tick after set_controls / set_initial_controls reads the vector unshifted: keep it out of the graph
     if (!h->pending_shift) { const int rc = tbnav_mppi_enqueue_rng(h, x0s, seed, first_tick, stream); if (rc != TBNAV_OK) return rc; ++i; }
-    const bool same = h->tg_exec && h->tg_seed == seed && h->tg_stream == st && h->tg_ucur == h->ucur && std::memcmp(h->tg_x0, x0s, sizeof h->tg_x0) == 0;
+    const bool same = h->tg_exec && h->tg_epoch == h->cfg_epoch && h->tg_seed == seed && h->tg_stream == st && h->tg_ucur == h->ucur &&
+                      std::memcmp(h->tg_x0, x0s, sizeof h->tg_x0) == 0;
     if (!same) {
+      // (another stream may not have run the previous replay's tick-advance node yet: what the device word holds is unknown)
+      h->tg_dev_tick = ~0ull;
       if (h->tg_exec) { (void)hipGraphExecDestroy(h->tg_exec); h->tg_exec = nullptr; }
       if (h->tg_graph) { (void)hipGraphDestroy(h->tg_graph); h->tg_graph = nullptr; }
       if (!h->d_tick0 && hipMalloc((void**)&h->d_tick0, sizeof(uint64_t)) != hipSuccess) { h->d_tick0 = nullptr; h->graph_on = false; }
@@ -1847,7 +2073,7 @@ int tbnav_mppi_enqueue_rng_batch(tbnav_mppi* h, const double* x0s, int32_t x0_st
         const hipError_t e_end = hipStreamEndCapture(st, &gr);
         h->ucur = ucur0; h->seq = seq0;  // nothing ran: the host-side state goes back
         if (rc == TBNAV_OK && e_end == hipSuccess && gr && hipGraphInstantiate(&h->tg_exec, gr, nullptr, nullptr, 0) == hipSuccess) {
-          h->tg_graph = gr; h->tg_seed = seed; h->tg_stream = st; h->tg_ucur = h->ucur; std::memcpy(h->tg_x0, x0s, sizeof h->tg_x0);
+          h->tg_graph = gr; h->tg_seed = seed; h->tg_stream = st; h->tg_ucur = h->ucur; h->tg_epoch = h->cfg_epoch; std::memcpy(h->tg_x0, x0s, sizeof h->tg_x0);
         } else {
           if (gr) (void)hipGraphDestroy(gr);
           h->tg_exec = nullptr; h->graph_on = false; (void)hipGetLastError();  // plain launches from here on
@@ -1857,8 +2083,12 @@ int tbnav_mppi_enqueue_rng_batch(tbnav_mppi* h, const double* x0s, int32_t x0_st
     while (h->tg_exec && n_ticks - i >= kGraphTicks) {
       const uint64_t t0 = first_tick + (uint64_t)i;
       // (consecutive chunks need no copy: the replay's last node has advanced the device word)
-      if (t0 != h->tg_dev_tick) TBNAV_HIP(hipMemcpyAsync(h->d_tick0, &t0, sizeof t0, hipMemcpyHostToDevice, st));  // (pageable source: staged before the call returns)
-      TBNAV_HIP(hipGraphLaunch(h->tg_exec, st));
+      if (t0 != h->tg_dev_tick) {
+        h->tg_dev_tick = ~0ull;
+        hipLaunchKernelGGL(mppi_tick_set, dim3(1), dim3(1), 0, st, h->d_tick0, t0);
+        TBNAV_HIP(hipGetLastError());
+      }
+      { const hipError_t eg = hipGraphLaunch(h->tg_exec, st); if (eg != hipSuccess) { h->tg_dev_tick = ~0ull; TBNAV_HIP(eg); } }
       h->tg_dev_tick = t0 + (uint64_t)kGraphTicks;
       h->seq += kGraphTicks;  // ucur: unchanged after an even number of ticks; the shift stays owed
       i += kGraphTicks;
@@ -1910,6 +2140,12 @@ int tbnav_mppi_get_cost_to_go(tbnav_mppi* h, double* J_host) {
   DeviceGuard guard(h->device);
   TBNAV_HIP(hipDeviceSynchronize());
   TBNAV_HIP(hipMemcpy(J_host, h->d_J, (size_t)h->T * h->K * sizeof(double), hipMemcpyDeviceToHost));
+  if (h->prefix_rows > 0) {  // rows below prefix_rows hold exclusive prefixes: J(i) = S - E(i), as mppi_partials forms it
+    std::vector<double> tot((size_t)h->K);
+    TBNAV_HIP(hipMemcpy(tot.data(), h->d_total, tot.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int i = 0; i < h->prefix_rows; ++i)
+      for (int k = 0; k < h->K; ++k) J_host[(size_t)i * h->K + k] = tot[k] - J_host[(size_t)i * h->K + k];
+  }
   return TBNAV_OK;
 }
 

@@ -32,7 +32,9 @@
 #include <new>
 #include <type_traits>
 #include <atomic>
+#include <thread>
 #include <vector>
+#include <sched.h>
 
 #include "common.hpp"
 #include "ref_field.hpp"
@@ -570,22 +572,37 @@ __device__ __forceinline__ void philox4x32_10(unsigned long long ctr, unsigned l
 //  one dependent boundary fewer per scan than a separate copy)
 // blockIdx.y: scan within a chunk of consecutive scans (tbnav_rbpf_slam_batch draws a few scans ahead in one launch) — scan
 // number scan + y, normals at out + y * out_stride, beam tables at + y * beam_stride.
+// Sharded filters (tbnav_rbpf_set_rng_shard): the handle's local normal j is element base + j of the ENSEMBLE's stream and the
+// resampling offset (slot z_slot of `out`) is element z_index of it, so ranks that share a seed draw disjoint normals — the ones
+// the unsharded filter of all the particles would draw.  base = 0 / z_index = ~0: one contiguous stream of n values (unsharded).
 __global__ void rbpf_sample_normals(size_t n, unsigned long long seed, unsigned long long scan, double* __restrict__ out,
                                     const double2* __restrict__ host_beams, double2* __restrict__ dev_beams, int n_copy,
-                                    size_t out_stride = 0, size_t beam_stride = 0) {
+                                    size_t out_stride = 0, size_t beam_stride = 0, size_t base = 0, size_t z_index = ~(size_t)0,
+                                    size_t z_slot = 0) {
   scan += blockIdx.y; out += blockIdx.y * out_stride; host_beams += blockIdx.y * beam_stride; dev_beams += blockIdx.y * beam_stride;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_copy; i += gridDim.x * blockDim.x) dev_beams[i] = host_beams[i];
-  const size_t pairs = (n + 1) / 2;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += (size_t)gridDim.x * blockDim.x) {
+  auto pair = [&](size_t P, double& a_out, double& b_out) {
     unsigned int r[4];
-    philox4x32_10((scan << 40) + i, seed, r);
+    philox4x32_10((scan << 40) + P, seed, r);
     const unsigned long long a = ((unsigned long long)r[0] << 32) | r[1], b = ((unsigned long long)r[2] << 32) | r[3];
     const double u1 = ((double)(a >> 11) + 0.5) * 0x1.0p-53, u2 = ((double)(b >> 11) + 0.5) * 0x1.0p-53;
     const double rad = sqrt(-2.0 * log(u1));
     double sn, cs;
     sincospi(2.0 * u2, &sn, &cs);
-    out[2 * i] = rad * cs;
-    if (2 * i + 1 < n) out[2 * i + 1] = rad * sn;
+    a_out = rad * cs; b_out = rad * sn;
+  };
+  const size_t p0 = base >> 1, pairs = n ? ((base + n - 1) >> 1) - p0 + 1 : 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += (size_t)gridDim.x * blockDim.x) {
+    double va, vb;
+    pair(p0 + i, va, vb);
+    const size_t g0 = 2 * (p0 + i);
+    if (g0 >= base && g0 < base + n) out[g0 - base] = va;
+    if (g0 + 1 >= base && g0 + 1 < base + n) out[g0 + 1 - base] = vb;
+  }
+  if (z_index != ~(size_t)0 && blockIdx.x == 0 && threadIdx.x == 0) {
+    double va, vb;
+    pair(z_index >> 1, va, vb);
+    out[z_slot] = (z_index & 1) ? vb : va;
   }
 }
 
@@ -3252,6 +3269,7 @@ struct tbnav_rbpf {
   double* d_normals = nullptr;
   size_t normals_cap = 0;
   const double* last_normals = nullptr;  // the normals the last scan used (d_normals, or an entry of the batch ring)
+  size_t last_z_index = 0;               // where in them its resampling offset sits (N * stride)
   // tbnav_rbpf_slam_batch draws the noise of a few scans ahead in one launch: normals and beam tables of ring_scans scans
   double* d_norm_ring = nullptr; size_t norm_ring_stride = 0;
   double2* d_beam_ring = nullptr; double2* h_beam_ring = nullptr; size_t beam_ring_stride = 0;
@@ -3278,6 +3296,7 @@ struct tbnav_rbpf {
   int raycast_form = 0;        // 0 = box counters (rbpf_raycast_box), 1 = event slots (rbpf_raycast_tile) (TBNAV_RBPF_OPT_RAYCAST_FORM)
   double* d_sens = nullptr;    // [N][4] sensor transform (X, Y, sin, cos) of each particle's new pose, left by the proposal kernel
   uint64_t seed = 0x5EEDull, scan_index = 0;  // device noise source (normals == NULL)
+  uint64_t rng_first = 0, rng_n_global = 0;   // sharded filters: this handle's particles are [rng_first, rng_first + N) of rng_n_global (0 = unsharded)
   bool full_edt = false;       // distance-field mode 0 (TBNAV_RBPF_DF=full): whole-map transform after every map update
   int df_mode = 2;             // 0 full, 1 windowed refresh before the update (TBNAV_RBPF_DF=window), 2 exact query at lookup (default)
   int* d_fstate = nullptr;     // [N] distance-field state: 0 stale, 1 window fresh, 2 whole field fresh / injected
@@ -3286,6 +3305,7 @@ struct tbnav_rbpf {
   // device log of occupied-set changes it is fed from
   bool ref_field = false;
   tbnav::RefField* ref = nullptr;
+  int host_threads = 1;        // host threads of the reference-field mode's per-particle work (TBNAV_RBPF_OPT_HOST_THREADS; set at create)
   int* d_log_ev = nullptr;     // [N][log_cap]
   int* d_log_cnt = nullptr;    // [N]
   int log_cap = 0;
@@ -3572,14 +3592,19 @@ int ref_field_after_scan(tbnav_rbpf* h, bool resampled, int p_first = 0, int p_c
   TBNAV_HIP(hipStreamSynchronize(h->stream));
   std::vector<int> cnt(N);
   TBNAV_HIP(hipMemcpy(cnt.data(), h->d_log_cnt, sizeof(int) * N, hipMemcpyDeviceToHost));
-  std::vector<int> ev;
+  // the logs first (one copy per particle, a few thousand events each), then the particles' sets and brushfires side by side
+  // on the host's cores: particles are independent, and inside one particle the order of every set and heap operation is
+  // the reference's (round 3; serial before: 16 ms per particle at 400 x 400)
+  std::vector<std::vector<int>> evs((size_t)p_count);
   for (int p = p_first; p < p_first + p_count; ++p) {
     if (cnt[p] > h->log_cap) return TBNAV_ERR_UNSUPPORTED;  // cannot happen: the log holds every cell update
-    ev.resize(cnt[p]);
-    if (cnt[p]) TBNAV_HIP(hipMemcpy(ev.data(), h->d_log_ev + (size_t)p * h->log_cap, sizeof(int) * cnt[p], hipMemcpyDeviceToHost));
-    h->ref->apply(p, ev.data(), cnt[p]);
-    h->ref->brushfire(p);
+    evs[p - p_first].resize(cnt[p]);
+    if (cnt[p]) TBNAV_HIP(hipMemcpy(evs[p - p_first].data(), h->d_log_ev + (size_t)p * h->log_cap, sizeof(int) * cnt[p], hipMemcpyDeviceToHost));
   }
+  h->ref->for_each_particle(p_first, p_count, h->host_threads, [&](int p, tbnav::RefField::Scratch& sc) {
+    h->ref->apply(p, evs[p - p_first].data(), (int)evs[p - p_first].size());
+    h->ref->brushfire(p, sc);
+  });
   if (resampled) {
     h->h_parent.resize(N);
     TBNAV_HIP(hipMemcpy(h->h_parent.data(), h->d_parent, sizeof(int) * N, hipMemcpyDeviceToHost));
@@ -3748,6 +3773,11 @@ int scan_enqueue(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3
     TBNAV_HIP(hipMemcpyAsync(h->d_normals, normals, sizeof(double) * n_norm, hipMemcpyHostToDevice, st));
   } else {
     const int blocks = (int)std::min<size_t>((n_norm / 2 + 255) / 256, 4096);
+    if (h->rng_n_global)  // this shard's slice of the ensemble's stream + the ensemble's resampling offset (same on every rank)
+      hipLaunchKernelGGL(rbpf_sample_normals, dim3(blocks), dim3(256), 0, st, n_norm - 1, (unsigned long long)h->seed,
+                         (unsigned long long)h->scan_index, h->d_normals, (const double2*)(h->h_beams + (size_t)slot * h->max_beams), h->d_beams, c.Bv,
+                         (size_t)0, (size_t)0, (size_t)h->rng_first * c.stride_normals, (size_t)h->rng_n_global * c.stride_normals, n_norm - 1);
+    else
     hipLaunchKernelGGL(rbpf_sample_normals, dim3(blocks), dim3(256), 0, st, n_norm, (unsigned long long)h->seed,
                        (unsigned long long)h->scan_index, h->d_normals, (const double2*)(h->h_beams + (size_t)slot * h->max_beams), h->d_beams, c.Bv);
     TBNAV_HIP(hipGetLastError());
@@ -3756,6 +3786,7 @@ int scan_enqueue(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3
   const double2* const beams_dev = pre ? pre->d_beams : h->d_beams;
   const double* const normals_dev = pre ? pre->d_normals : h->d_normals;
   h->last_normals = normals_dev;
+  h->last_z_index = (size_t)h->N * c.stride_normals;
   for (int q = 0; q < 4; ++q) h_err[q] = 0;  // mapped: the scan that last owned the slot has been waited for
   h->h_norm[slot] = NormOut{};
   StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
@@ -3944,6 +3975,15 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
 extern "C" {
 
 namespace {
+// host threads for the reference-field mode: the cores this process may run on (its affinity mask; a container's CPU quota is
+// not visible here — TBNAV_RBPF_OPT_HOST_THREADS overrides), at most 32
+int default_host_threads() {
+  int n = 0;
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+  if (n <= 0) n = (int)std::thread::hardware_concurrency();
+  return n < 1 ? 1 : (n > 32 ? 32 : n);
+}
 int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf** out) {
   if (!P || !out) return TBNAV_ERR_INVALID_ARG;
   *out = nullptr;
@@ -3977,6 +4017,7 @@ int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf*
   tbnav_rbpf* h = new (std::nothrow) tbnav_rbpf();
   if (!h) return TBNAV_ERR_INVALID_ARG;
   h->p = *P; h->device = dev; h->N = P->num_particles; h->k = P->num_samples_mode;
+  h->host_threads = default_host_threads();
   h->xsize = xsize; h->ysize = ysize; h->words = words; h->radius = radius; h->edt_cols = C;
   h->G = (size_t)xsize * ysize;
   h->TW = (xsize + kTS - 1) / kTS; h->TT = h->TW * h->TW;
@@ -4226,6 +4267,13 @@ int tbnav_rbpf_set_seed(tbnav_rbpf* h, uint64_t seed) {
   return TBNAV_OK;
 }
 
+int tbnav_rbpf_set_rng_shard(tbnav_rbpf* h, uint64_t first_particle, uint64_t particles_global) {
+  if (!h || (particles_global && particles_global < first_particle + (uint64_t)h->N)) return TBNAV_ERR_INVALID_ARG;
+  h->rng_first = first_particle;
+  h->rng_n_global = particles_global;
+  return TBNAV_OK;
+}
+
 int tbnav_rbpf_get_normals(tbnav_rbpf* h, double* out, int64_t n) {
   if (!h || !out || n <= 0 || (size_t)n > std::max(h->normals_cap, h->norm_ring_stride)) return TBNAV_ERR_INVALID_ARG;
   DeviceGuard guard(h->device);
@@ -4253,7 +4301,7 @@ int tbnav_rbpf_slam_batch(tbnav_rbpf* h, const float* scans, int32_t n_beams, in
   // host then runs the copies and enqueues scan s + 1 again.  Between scans the device waits for nothing, and the results
   // are those of n_scans synchronous calls, bit for bit.  Only in the default configuration (distance look-ups by query: no
   // per-scan field refresh on the stream; no event timing; not the reference-field mode).
-  const bool pipelined = n_scans > 1 && h->batch_pipeline && h->df_mode == 2 && !h->full_edt && !h->ref_field && !h->timing;
+  const bool pipelined = n_scans > 1 && h->batch_pipeline && h->df_mode == 2 && !h->full_edt && !h->ref_field && !h->timing && !h->rng_n_global;
   if (!pipelined) {
     for (int s = 0; s < n_scans; ++s) {
       const int rc = slam_impl(h, scans + (size_t)s * n_beams, n_beams, u + 3 * s, odom + 3 * (s + 1), odom + 3 * s, icp_ok ? icp_ok[s] : 1,
@@ -4419,6 +4467,10 @@ int tbnav_rbpf_resample_global_dev(tbnav_rbpf* h, const double* d_weights_all, i
     h->g_cap = (size_t)n_global;
   }
   if (!h->d_gz) TBNAV_HIP(hipMalloc((void**)&h->d_gz, sizeof(double)));
+  if (z != z) {  // NaN: the offset the last scan's device noise carries (with tbnav_rbpf_set_rng_shard: the ENSEMBLE's, same on every rank)
+    if (!h->last_normals || !h->last_z_index) return TBNAV_ERR_INVALID_ARG;
+    TBNAV_HIP(hipMemcpyAsync(h->d_gz, h->last_normals + h->last_z_index, sizeof z, hipMemcpyDeviceToDevice, st));
+  } else
   TBNAV_HIP(hipMemcpyAsync(h->d_gz, &z, sizeof z, hipMemcpyHostToDevice, st));
   *h->h_norm = NormOut{};
   // the reference's sequential normalise / Neff / selection (particle_filter.cpp:442-500) over the GLOBAL vector:
@@ -4637,6 +4689,26 @@ int tbnav_rbpf_import_batch_dev(tbnav_rbpf* h, int32_t n, const int32_t* slots, 
     any_codes |= hd[i].has_codes != 0;
   }
   if (any_codes) { const int rc = ensure_codes(h); if (rc != TBNAV_OK) return rc; h->fstate_dirty = true; }
+  {
+    // Does the pool hold what is coming?  Checked BEFORE the destination slots give their tiles up: the incoming tiles against
+    // the free ones plus every tile the slots name now (an upper bound of what releasing them returns).  Beyond that the import
+    // cannot succeed and nothing is touched; inside the bound it goes ahead (tiles the slots share with particles that stay do
+    // not come back: the unpack kernel then reports the exhaustion, with the slots' maps already released — see the header).
+    uint64_t incoming = 0;
+    for (int i = 0; i < n; ++i) incoming += hd[i].n_tiles;
+    unsigned long long ctr[2] = {0, 0};
+    TBNAV_HIP(hipMemcpy(ctr, h->pool.ctr, sizeof ctr, hipMemcpyDeviceToHost));
+    const uint64_t free_now = ctr[1] - ctr[0];
+    if (incoming > free_now) {
+      std::vector<int> sl(n);
+      for (int i = 0; i < n; ++i) sl[i] = slots[i];
+      { const int rc = count_batch(h, n, sl.data()); if (rc != TBNAV_OK) return rc; }
+      uint64_t named = 0;
+      for (int i = 0; i < n; ++i) named += (uint64_t)h->batch_counts[i].x;
+      if (incoming > free_now + named) return TBNAV_ERR_POOL_EXHAUSTED;
+      TBNAV_HIP(hipMemcpyAsync(h->d_bitems, items.data(), sizeof(BatchItem) * n, hipMemcpyHostToDevice, st));  // (count_batch reused the scratch's slot list only)
+    }
+  }
   for (int q = 0; q < 4; ++q) h->h_err[q] = 0;
   const MapT M = map_of(h);
   StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
@@ -4953,6 +5025,10 @@ int tbnav_rbpf_set_option(tbnav_rbpf* h, int32_t option, int32_t value) {
     case TBNAV_RBPF_OPT_BATCH_PIPELINE:
       if (value != 0 && value != 1) return TBNAV_ERR_INVALID_ARG;
       h->batch_pipeline = value;
+      return TBNAV_OK;
+    case TBNAV_RBPF_OPT_HOST_THREADS:
+      if (value < 0 || value > 256) return TBNAV_ERR_INVALID_ARG;
+      h->host_threads = value ? value : default_host_threads();
       return TBNAV_OK;
     case TBNAV_RBPF_OPT_RAYCAST_FORM:
       if (value != 0 && value != 1) return TBNAV_ERR_INVALID_ARG;

@@ -68,12 +68,17 @@ class MPPI:
             self.setOption(capi.MPPI_OPT_KEEP_J, 1)
         self.rollouts = self._L.tbnav_mppi_rollouts(self._h)
         self.records_per_step = self._L.tbnav_mppi_records_per_step(self._h)
+        self._name_kernel()
+
+    def _name_kernel(self):
         v = self._L.tbnav_mppi_rollout_variant(self._h)
-        self.rollout_kernel = ("mppi_rollout_cost" if v == 0 else f"mppi_rollout_scan<{v} steps/thread>" if v > 0
+        seq = ("mppi_rollout_cost", "mppi_rollout_cost_reg", "mppi_rollout_prefix")[max(0, self._L.tbnav_mppi_streaming_form(self._h))]
+        self.rollout_kernel = (seq if v == 0 else f"mppi_rollout_scan<{v} steps/thread>" if v > 0
                                else f"mppi_rollout_fused<{-v} rollouts/workgroup> (rollout + partial records)")
 
     def setOption(self, option: int, value: int):
         capi.check(self._L.tbnav_mppi_set_option(self._h, option, value), "tbnav_mppi_set_option")
+        self._name_kernel()
 
     def setRngShard(self, first_rollout: int, rollouts_global: int):
         capi.check(self._L.tbnav_mppi_set_rng_shard(self._h, first_rollout, rollouts_global), "tbnav_mppi_set_rng_shard")

@@ -113,6 +113,11 @@ class ParticleFilter:
     def setSeed(self, seed: int):
         capi.check(self._L.tbnav_rbpf_set_seed(self._h, seed), "set_seed")
 
+    def setRngShard(self, first_particle: int, particles_global: int):
+        """This handle's particles are [first_particle, first_particle + N) of an ensemble of particles_global: the device noise
+        source draws the ensemble's normals for them (ranks sharing a seed draw disjoint normals, the unsharded filter's)."""
+        capi.check(self._L.tbnav_rbpf_set_rng_shard(self._h, first_particle, particles_global), "set_rng_shard")
+
     def lastNormals(self, n: int) -> np.ndarray:
         out = np.empty(n)
         capi.check(self._L.tbnav_rbpf_get_normals(self._h, out.ctypes.data, n), "get_normals")

@@ -133,6 +133,9 @@ class HipRbpfShardBackend:
     def slam_local(self, scan, u, cur_odom, prev_odom, icp_ok, T_icp, normals_local):
         return self.pf.SLAM(scan, u, cur_odom, prev_odom, icp_ok, T_icp, normals_local, local_only=True)
 
+    def set_rng_shard(self, first_particle: int, particles_global: int):
+        self.pf.setRngShard(first_particle, particles_global)
+
     def weights_tensor(self) -> torch.Tensor:
         w = torch.empty(self.n_local, dtype=torch.float64, device=self.device)
         capi.check(self._L.tbnav_rbpf_copy_weights_dev(self._h, w.data_ptr()), "copy_weights_dev")
@@ -204,6 +207,10 @@ class ShardedRBPF:
         self.n_local = backend.n_local
         self.n_global = self.n_local * self.world
         self.bytes_migrated = 0
+        # production mode (device-drawn normals): every rank draws ITS slice of the ensemble's stream — without this, ranks that
+        # share a seed draw identical normals and the copies of a migrated particle evolve identically (round-2 advisor finding)
+        if hasattr(backend, "set_rng_shard"):
+            backend.set_rng_shard(self.rank * self.n_local, self.n_global)
 
     def normals_slice(self, normals_global: np.ndarray, stride: int) -> np.ndarray:
         """This rank's part of the reference's draw stream (particle-major) + the resampling offset."""
@@ -220,7 +227,8 @@ class ShardedRBPF:
         else:
             w_all = w_local
         lo = self.rank * self.n_local
-        z = float(normals_global[-1]) if normals_global is not None else self.resample_offset()
+        # production mode: NaN = "the ensemble's offset the handle drew with its normals" (the same value on every rank)
+        z = float(normals_global[-1]) if normals_global is not None else (float("nan") if hasattr(self.b, "set_rng_shard") else self.resample_offset())
         st, parents = self.b.resample(w_all, lo, z)
         if parents is None:
             return st, st_local, np.arange(self.n_global, dtype=np.int32)
@@ -286,8 +294,22 @@ class ShardedRBPF:
         # local parents first (inside the handle), then the imported ones
         local_parent = np.array([int(parents[m]) - lo if parents[m] // nl == me else -1 for m in range(lo, lo + nl)], dtype=np.int32)
         self.b.gather_local(local_parent)
+        failed = None
         if recvs:
             where = {q: int(roffs[i]) for i, (_, q) in enumerate(recvs)}
             slots = [m - lo for m in range(lo, lo + nl) if parents[m] // nl != me]
             dev = getattr(self.b, "device", torch.device("cpu"))
-            self.b.import_batch(slots, rbuf if rbuf.device == dev else rbuf.to(dev), [where[int(parents[lo + sl])] for sl in slots])
+            try:
+                self.b.import_batch(slots, rbuf if rbuf.device == dev else rbuf.to(dev), [where[int(parents[lo + sl])] for sl in slots])
+            except capi.TbnavError as e:
+                failed = e
+        # a rank whose import failed (tile pool exhausted) must not leave its peers waiting in the next collective: agree on it
+        if self.world > 1:
+            flag = torch.tensor([1 if failed is not None else 0], dtype=torch.int32)
+            if not _backend_is_gloo(self.group):
+                flag = flag.to(self.b.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+            if int(flag.item()) and failed is None:
+                raise capi.TbnavError(capi.ERR_POOL_EXHAUSTED, "ShardedRBPF._migrate", "another rank could not import its particles")
+        if failed is not None:
+            raise failed

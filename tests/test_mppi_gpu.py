@@ -348,22 +348,43 @@ def test_device_sincos_accuracy(gpu_pkg):
     assert np.allclose(sb * sb + cb * cb, 1.0, atol=1e-12)
 
 
-@pytest.mark.parametrize("K,horizon", [(32768 + 37, 1.0), (32768, 0.6), (40000, 0.12), (33000, 0.32)])
-def test_streaming_rollout_kernel_against_the_oracle(gpu_pkg, K, horizon):
-    """The large-K rollout kernel (mppi_rollout_cost_reg: K/64 >= 2 waves per CU-SIMD pair, T a multiple of 4: losses of
-    the last steps in registers, the rest in LDS, branch-free rounds of three groups) against the oracle tick: T = 100
-    (a whole number of rounds), 60, 12 (fewer groups than one round) and 32 (a partial last round), a ragged last wave,
-    two ticks of warm start."""
+@pytest.mark.parametrize("form", ["prefix", "reg"])
+@pytest.mark.parametrize("K,horizon", [(32768 + 37, 1.0), (32768, 0.6), (40000, 0.12), (33000, 0.32), (32800, 4.0)])
+def test_streaming_rollout_kernel_against_the_oracle(gpu_pkg, K, horizon, form):
+    """The large-K rollout kernels (K/64 >= 2 waves per CU-SIMD pair, T a multiple of 4) against the oracle tick.
+    "prefix" = mppi_rollout_prefix (round 3: exclusive prefixes of the losses written as the rollout goes, exact suffix sums for
+    the last 4 / 8 / 12 steps, J = total - prefix formed by mppi_partials and the getter); "reg" = mppi_rollout_cost_reg (round 2).
+    T = 100 (late region of one group), 60 (three), 32 (two), 12 (too short for a round: the round-2 kernel either way), 400 (no
+    LDS stage could hold it: prefix form only); a ragged last wave; two ticks of warm start."""
+    from rtn_amd import capi
     d = mppi_cfg(K, horizon)
     m = make_mppi(gpu_pkg, d, kernel=0)  # (at these sizes the handle's own choice is the time-parallel kernel: tested below)
     T = orc.mppi_steps(d)
-    assert m.steps == T and T % 4 == 0 and m.rollout_kernel == "mppi_rollout_cost"
+    if form == "reg":
+        m.setOption(capi.MPPI_OPT_PREFIX_FORM, 0)
+    want = {"prefix": "mppi_rollout_prefix" if T >= 16 else "mppi_rollout_cost_reg", "reg": "mppi_rollout_cost_reg" if T <= 100 else "mppi_rollout_cost"}[form]
+    assert m.steps == T and T % 4 == 0 and m.rollout_kernel == want, m.rollout_kernel
     m.setWaypoint(*WAYPOINTS[2])
     u = np.zeros((2, T)); x0 = (0.3, -0.2, 0.7)
     for tick in range(2):
         ref = _check_tick(m, d, u, (0, 0), WAYPOINTS[2], x0, _noise(90 + tick, K, T))
         u = ref["u"]
         x0 = (x0[0] + 0.002, x0[1] - 0.001, x0[2] + 0.003)
+    m.close()
+
+
+def test_prefix_form_takes_the_general_round_for_large_wheel_speed_differences(gpu_pkg):
+    """mppi_rollout_prefix decides ONCE per round of 12 steps whether every |h/2 * r/b * (ur - ul)| <= 2^-5 (straight-line Taylor
+    round) or not (the general round with full sincos evaluations).  dt = 0.1 makes the general round the common case
+    (|ur - ul| > 3 rad/s is enough), and a sampling variance of 400 mixes both inside one wave."""
+    for dt, horizon, var in ((0.1, 4.0, 0.9), (0.01, 0.4, 400.0)):
+        d = mppi_cfg(32768 + 64, horizon, dt=dt, ul_var=var, ur_var=var)
+        m = make_mppi(gpu_pkg, d, kernel=0)
+        T = orc.mppi_steps(d)
+        assert m.rollout_kernel == "mppi_rollout_prefix" and T == 40
+        m.setWaypoint(*WAYPOINTS[1])
+        _check_tick(m, d, np.zeros((2, T)), (0, 0), WAYPOINTS[1], (0.1, 0.0, -0.4), _noise(7, d["rollouts"], T, var))
+        m.close()
 
 
 def test_hip_against_frozen_vectors_G_A1_G_A2(gpu_pkg):
@@ -393,7 +414,7 @@ def test_hip_against_frozen_vectors_G_A1_G_A2(gpu_pkg):
 
 
 @pytest.mark.parametrize("K,horizon,want", [(1024, 0.25, "fused<8"), (2048, 0.5, "fused<8"), (4096, 1.0, "fused<16"), (8192, 1.0, "fused<16"), (16384 + 5, 0.5, "scan"),
-                                            (40000, 0.25, "scan"), (45000, 0.12, "cost")])
+                                            (40000, 0.25, "scan"), (45000, 0.12, "cost"), (45000, 0.6, "prefix")])
 def test_default_kernel_choice_by_ensemble_size_against_the_oracle(gpu_pkg, K, horizon, want):
     """What the handle picks by itself across ensemble sizes (fused one-wave-per-rollout kernel while the chip would be
     empty otherwise, the time-parallel kernel in the middle, the sequential streaming kernel from ~2.5 one-wave workgroups
@@ -440,3 +461,101 @@ def test_batch_enqueue_by_graph_replay_equals_tick_by_tick(gpu_pkg, K, horizon):
     mb.enqueueRngBatch(x0, 7, 1000, 205, st)
     torch.cuda.synchronize()
     assert np.array_equal(ma.getControls(), mb.getControls())
+
+
+def test_graph_replay_is_rebuilt_when_a_baked_parameter_changes(gpu_pkg):
+    """The captured graph of ticks holds the waypoint, uinit, dynamics, trig, the rng shard and the record buffer BY VALUE
+    (round-2 advisor finding): every setter that changes one of them must invalidate it.  Batch, change one, batch again —
+    against a handle that launches every tick by itself."""
+    import torch
+    from rtn_amd import capi
+    d = mppi_cfg(1024, 0.5)
+    ma, mb = make_mppi(gpu_pkg, d), make_mppi(gpu_pkg, d)
+    mb.setOption(capi.MPPI_OPT_BATCH_GRAPH, 0)
+    side = torch.cuda.Stream()
+    st = side.cuda_stream
+    x0 = (0.05, -0.02, 0.3)
+    changes = [
+        lambda m: m.setWaypoint(*WAYPOINTS[1]),
+        lambda m: m.setWaypoint(*WAYPOINTS[2]),
+        lambda m: m.setOption(capi.MPPI_OPT_TRIG, 3),
+        lambda m: m.setRngShard(2048, 8192),
+        lambda m: m.setDynamics("arc"),
+        lambda m: m.setDynamics("rk4"),
+        lambda m: m.setOption(capi.MPPI_OPT_KERNEL, -8),   # frees and reallocates the record buffer the graph wrote to
+        lambda m: m.setOption(capi.MPPI_OPT_KEEP_J, 1),
+    ]
+    first = 0
+    for ch in changes:
+        ch(ma); ch(mb)
+        ma.enqueueRngBatch(x0, 5, first, 230, st)
+        for i in range(230):
+            mb.enqueueRng(x0, 5, first + i, st)
+        torch.cuda.synchronize()
+        assert ma.lastControls(st) == mb.lastControls(st)
+        assert np.array_equal(ma.getControls(), mb.getControls())
+        first += 230
+    # setInitialControls changes uinit (read by the shifted warm start of every later tick)
+    ma.setInitialControls(0.3, -0.2); mb.setInitialControls(0.3, -0.2)
+    ma.enqueueRngBatch(x0, 5, first, 230, st); mb.enqueueRngBatch(x0, 5, first, 230, st)
+    torch.cuda.synchronize()
+    assert np.array_equal(ma.getControls(), mb.getControls())
+    # the same graph on ANOTHER stream: the device tick word of the first stream's replay must not be trusted
+    other = torch.cuda.Stream()
+    ma.enqueueRngBatch(x0, 5, first + 230, 200, other.cuda_stream); mb.enqueueRngBatch(x0, 5, first + 230, 200, other.cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(ma.getControls(), mb.getControls())
+    ma.close(); mb.close()
+
+
+def test_configs3_as_written_k65536_t100_split_8_ways_against_the_full_cpu_oracle(gpu_pkg):
+    """BASELINE configs[3] AS WRITTEN: K = 65536, T = 100, the ensemble split 8 ways (8192 rollouts per shard: what each of
+    8 GPUs runs), every shard's partial records -> the combine of all 8 record sets (the all-gather's result) — against
+    (1) the unsharded K = 65536 tick on one handle (mppi_rollout_prefix + mppi_partials + mppi_combine) and
+    (2) the CPU oracle's tick over all 65536 rollouts (mppi.cpp:72-140 restated; OpenMP over rollouts).
+    Two ticks, warm start carried, every shard in its slice of the ensemble's noise."""
+    import torch
+    K, P, horizon = 65536, 8, 1.0
+    d = mppi_cfg(K, horizon)
+    T = orc.mppi_steps(d)
+    Ks = K // P
+    x0 = (0.02, -0.01, 0.05)
+    whole = make_mppi(gpu_pkg, d)
+    assert whole.rollout_kernel == "mppi_rollout_prefix"
+    shards = [make_mppi(gpu_pkg, mppi_cfg(Ks, horizon)) for _ in range(P)]
+    for m in [whole] + shards:
+        m.setWaypoint(*WAYPOINTS[1])
+    S = shards[0].records_per_step
+    rec_all = torch.zeros(P, T, S, 8, dtype=torch.float64, device="cuda")
+    orc.lib().orc_set_threads(8)
+    try:
+        u = np.zeros((2, T))
+        for tick in range(2):
+            noise = np.random.default_rng(500 + tick).standard_normal((K, T, 2)) * np.sqrt(0.9)
+            ref = orc.mppi_new_controls(d, u, (0, 0), WAYPOINTS[1], x0, noise)
+            got_whole = whole.newControls(*x0, noise)
+            assert rel_err(whole.costToGo(), ref["J"]) < J_RTOL
+            assert np.allclose(got_whole, ref["out"], rtol=U_RTOL, atol=U_ATOL)
+            assert np.allclose(whole.getControls(), ref["u"], rtol=U_RTOL, atol=U_ATOL)
+            dn = torch.from_numpy(noise).cuda()                    # [K][T][2] -> per shard [T][Ks] x 2
+            for g, m in enumerate(shards):
+                sl = dn[g * Ks:(g + 1) * Ks]
+                dl, dr = sl[:, :, 0].t().contiguous(), sl[:, :, 1].t().contiguous()
+                m.shardPartials(x0, dl.data_ptr(), dr.data_ptr(), rec_all[g].data_ptr())
+                torch.cuda.synchronize()
+                assert rel_err(m.costToGo(), ref["J"][:, g * Ks:(g + 1) * Ks]) < J_RTOL
+            for m in shards:
+                m.shardCombine(rec_all.data_ptr(), P)
+            torch.cuda.synchronize()
+            for m in shards:
+                assert np.allclose(m.lastControls(), ref["out"], rtol=U_RTOL, atol=U_ATOL)
+                assert np.allclose(m.getControls(), ref["u"], rtol=U_RTOL, atol=U_ATOL)
+                assert np.array_equal(m.getControls(), shards[0].getControls())   # every rank ends with the same warm start, bit for bit
+            u = ref["u"]
+            for m in [whole] + shards:   # carry the ORACLE's warm start on both sides (the comparison is per tick)
+                m.setControls(u)
+            x0 = (x0[0] + 0.002, x0[1] + 0.001, x0[2] + 0.004)
+    finally:
+        orc.lib().orc_set_threads(1)
+    for m in [whole] + shards:
+        m.close()

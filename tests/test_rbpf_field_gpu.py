@@ -150,3 +150,34 @@ def test_reference_mode_against_the_frozen_trace_G_B4(gpu_pkg):
     (_, best) = pf.getRobotState()
     assert best == g["b4_best"] and np.array_equal(pf.logOdds(int(best)), g["b4_log_odds_best"])
     pf.close()
+
+
+def test_cfg3_as_written_1000_particles_400x400_reference_mode_against_the_oracle(gpu_pkg):
+    """BASELINE configs[2] AS WRITTEN and nothing injected: 1000 particles, k = 50, 360 beams, 400 x 400 @ 0.05 m, three scans
+    with a forced resample at the second — the product in its reference-field mode (the per-particle brushfires spread over
+    the host's cores) against the oracle's ParticleFilter (OpenMP over particles): sampled poses, p_scan, p_pose, eta, mu, new
+    poses, raw and normalised weights <= 1e-9 (north star 1e-5), Neff / resampling decision / parent list / best particle
+    identical, log-odds and distance fields of spot particles bit for bit."""
+    import time
+    N, k = 1000, 50
+    orc.lib().orc_set_threads(8)
+    try:
+        t0 = time.perf_counter()
+        pf_o, pf_d, rows = _free_run(gpu_pkg, "reference", N=N, k=k, map_half=10.0, walls=rc.ROOM_SURVEY, n_scans=3,
+                                     inc=(0.07, 0.10, 0.05), seed=11, force_resample_at=1)
+        print(f"\n[cfg3 reference mode] 3 scans of {N} particles, oracle + device: {time.perf_counter() - t0:.1f} s")
+    finally:
+        orc.lib().orc_set_threads(1)
+    assert rows[1]["resampled"] == (1, 1)
+    for s, r in enumerate(rows):
+        assert r["p_scan"] <= 1e-9 and r["eta"] <= 1e-9 and r["w"] <= 1e-9, (s, r)
+        assert r["neff"][0] == r["neff"][1] and r["resampled"][0] == r["resampled"][1] and r["parents_equal"], (s, r)
+        assert r["best"][0] == r["best"][1] and r["best_xy"] <= 1e-9 and r["best_th"] <= 1e-9, (s, r)
+    po, pvo, wo = pf_o.particles()
+    pd, pvd, wd = pf_d.particles()
+    assert np.allclose(pd, po, rtol=1e-10, atol=1e-15) and np.allclose(pvd, pvo, rtol=1e-10, atol=1e-15)
+    for p in (0, 3, 499, 500, 998, 999):
+        g = pf_o.grid(p).dump()
+        assert np.array_equal(pf_d.logOdds(p), g["log_odds"]), p
+        assert np.array_equal(pf_d.occDist(p), g["occ_dist"]), p
+    pf_d.close()
