@@ -1085,21 +1085,29 @@ __global__ __launch_bounds__(kSliceThreads) void mppi_partials(int T, int K, int
                                                                double* __restrict__ records, int prefix_rows,
                                                                const double* __restrict__ total) {
   __shared__ double scratch[kSliceThreads / kWave];
-  const int s = blockIdx.x, i = blockIdx.y;
+  // which rows the rollout kernel touched LAST are the ones still in L2 / the Infinity Cache: the backward suffix pass of the
+  // round-2 kernels ends at row 0, the prefix-form kernel's forward pass at row T - 1 — start there (35.7 -> us at K = 65536)
+  const int s = blockIdx.x, i = prefix_rows > 0 ? T - 1 - (int)blockIdx.y : (int)blockIdx.y;
   const int base = s * kSlice;
   const double inf = __builtin_huge_val();
-  double j[kSliceItems], l[kSliceItems], r[kSliceItems];
+  double j[kSliceItems], l[kSliceItems], r[kSliceItems], tot[kSliceItems];
+  const bool pre = i < prefix_rows;
   double mn = inf;
   int cnt = 0;
 #pragma unroll
   for (int it = 0; it < kSliceItems; ++it) {
     const int k = base + it * kSliceThreads + threadIdx.x;  // coalesced across lanes
     const bool ok = k < K;
-    j[it] = ok ? (i < prefix_rows ? total[k] - J[(size_t)i * K + k] : J[(size_t)i * K + k]) : inf;
+    j[it] = ok ? J[(size_t)i * K + k] : inf;
+    tot[it] = (ok && pre) ? total[k] : inf;   // (requested with the other loads; subtracted below, once everything is on its way)
     l[it] = ok ? duL[(size_t)i * K + k] : 0.0;
     r[it] = ok ? duR[(size_t)i * K + k] : 0.0;
-    mn = fmin(mn, j[it]);
     cnt += ok ? 1 : 0;
+  }
+#pragma unroll
+  for (int it = 0; it < kSliceItems; ++it) {
+    if (pre && tot[it] != inf) j[it] = tot[it] - j[it];   // J(i) = S - E(i); a missing rollout (tot = +inf) stays +inf
+    mn = fmin(mn, j[it]);
   }
   mn = block_min(mn, scratch);
   double A = 0, B = 0, C = 0, D = 0, E = 0;

@@ -11,12 +11,12 @@ dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream(dev).cuda_stream
 sync = lambda: torch.cuda.synchronize(dev)
 for K, H in ((65536, 1.0), (32768, 1.0), (65536, 0.6)):
-    for name, opts in (("reg-tail", []), ("general", [(capi.MPPI_OPT_REG_TAIL, 0)]), ("no-lds", [(capi.MPPI_OPT_NO_LDS_STAGING, 1)])):
+    for name, opts in (("prefix", []), ("reg-tail", [(capi.MPPI_OPT_PREFIX_FORM, 0)]), ("general", [(capi.MPPI_OPT_PREFIX_FORM, 0), (capi.MPPI_OPT_REG_TAIL, 0)])):
         m = bench.make_mppi(K, H, 0)
         for o, v in opts:
             m.setOption(o, v)
         a, b = bench.synth_noise(m.steps, K, dev, 99)
         el = bench.time_ticks(lambda: m.enqueueDev(bench.X0, a.data_ptr(), b.data_ptr(), stream), sync, 50, 10, lambda: None)
         ms = bench.kernel_profile(m, a, b, stream, 50)
-        print(f"K={K} T={m.steps} {name}: tick {el / 50 * 1e3:.4f} ms, rollout {ms[0] * 1e3:.1f} us ({24.0 * K * m.steps / (ms[0] * 1e-3) / 8e12 * 100:.1f} % of HBM peak), partials {ms[1] * 1e3:.1f}, combine {ms[2] * 1e3:.1f}", flush=True)
+        print(f"K={K} T={m.steps} {name} [{m.rollout_kernel}]: tick {el / 50 * 1e3:.4f} ms, rollout {ms[0] * 1e3:.1f} us ({24.0 * K * m.steps / (ms[0] * 1e-3) / 8e12 * 100:.1f} % of HBM peak), partials {ms[1] * 1e3:.1f}, combine {ms[2] * 1e3:.1f}", flush=True)
         m.close()
