@@ -167,6 +167,44 @@ int tbnav_mppi_shard_partials_rng(tbnav_mppi* h, const double x0[3], uint64_t se
 int tbnav_mppi_shard_combine(tbnav_mppi* h, const double* d_records_all, int32_t n_shards,
                              void* stream);
 
+/* ---- the sharded tick behind the ordinary entry points (include/tbnav_comm.h) -------------------------------------
+ * One process per GPU: after tbnav_mppi_attach_comm(h, comm) — comm on the handle's device; params.rollouts is this
+ * rank's share, every rank the same — EVERY tick entry point of the handle (tbnav_mppi_new_controls*, _enqueue_dev,
+ * _enqueue_rng, _enqueue_rng_batch) runs rollouts + records of its shard -> ONE ncclAllGather of the records ->
+ * the combine of all shards' records, all enqueued on the tick's stream: no host round trip inside a tick, and every
+ * rank ends with the same warm start (mppi.cpp:112-137 over the whole ensemble).  The device noise counter space is
+ * set for rank * K ... of nranks * K (tbnav_mppi_set_rng_shard).  comm = NULL detaches.  The communicator must outlive
+ * the handle's last tick; the handle does not own it. */
+struct tbnav_comm;
+int tbnav_mppi_attach_comm(tbnav_mppi* h, struct tbnav_comm* comm);
+
+/* One process driving n_gpus devices (what controller::MPPI(..., n_gpus) holds: a ROS node is one process): the
+ * ensemble of params->rollouts rollouts (a multiple of n_gpus) split evenly over devices[0..n_gpus) (NULL: 0, 1, ...;
+ * a device may repeat — the members sharing it then exchange by copies instead of RCCL, see tbnav_comm.h).  Each member
+ * is a tbnav_mppi handle with its own stream; a tick enqueues every member's rollouts, ONE grouped all-gather, every
+ * member's combine.  Setters apply to every member; results are member 0's (all members hold the same controls). */
+typedef struct tbnav_mppi_group tbnav_mppi_group;
+int tbnav_mppi_group_create(const tbnav_mppi_params* params, int32_t n_gpus, const int32_t* devices, tbnav_mppi_group** out);
+void tbnav_mppi_group_destroy(tbnav_mppi_group* g);
+int tbnav_mppi_group_size(const tbnav_mppi_group* g);
+int tbnav_mppi_group_member(tbnav_mppi_group* g, int32_t rank, tbnav_mppi** out);  /* borrowed: parity hooks of one shard */
+int tbnav_mppi_group_set_waypoint(tbnav_mppi_group* g, double x, double y, double theta);
+int tbnav_mppi_group_set_initial_controls(tbnav_mppi_group* g, double uL, double uR);
+int tbnav_mppi_group_set_controls(tbnav_mppi_group* g, const double* u_host);
+int tbnav_mppi_group_get_controls(tbnav_mppi_group* g, double* u_host);
+int tbnav_mppi_group_set_dynamics(tbnav_mppi_group* g, int32_t model);
+int tbnav_mppi_group_set_option(tbnav_mppi_group* g, int32_t option, int32_t value);
+/* MPPI::newControls over the whole ensemble.  noise_host: the ENSEMBLE's perturbations in the reference's draw order,
+ * noise[(k*T + i)*2 + c] for k < params->rollouts (member r takes rollouts [r*K/n, (r+1)*K/n)). */
+int tbnav_mppi_group_new_controls(tbnav_mppi_group* g, const double x0[3], const double* noise_host, double u_out[2]);
+/* Production ticks, perturbations drawn on the devices (each member in its slice of the ensemble's counter space). */
+int tbnav_mppi_group_new_controls_rng(tbnav_mppi_group* g, const double x0[3], uint64_t seed, uint64_t tick, double u_out[2]);
+int tbnav_mppi_group_enqueue_rng(tbnav_mppi_group* g, const double x0[3], uint64_t seed, uint64_t tick);
+int tbnav_mppi_group_enqueue_rng_batch(tbnav_mppi_group* g, const double* x0s, int32_t x0_stride, uint64_t seed, uint64_t first_tick,
+                                       int32_t n_ticks);
+int tbnav_mppi_group_last_controls(tbnav_mppi_group* g, double u_out[2]);
+int tbnav_mppi_group_synchronize(tbnav_mppi_group* g);
+
 /* ---- parity / debug hooks --------------------------------------------------------------------- */
 
 /* Cost-to-go J of the last tick BEFORE the per-step min subtraction, host buffer [T][K]

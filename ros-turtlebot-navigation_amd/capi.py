@@ -142,6 +142,32 @@ def lib() -> C.CDLL:
         "tbnav_mppi_debug_sincos": (C.c_int, [vp, i32, vp, vp]),
         "tbnav_mppi_profile_tick": (C.c_int, [vp, dp, vp, vp, vp, C.POINTER(C.c_float)]),
         "tbnav_mppi_profile_kernels": (C.c_int, [vp, dp, vp, vp, vp, i32, C.POINTER(C.c_float)]),
+        # communicators (include/tbnav_comm.h) and the sharded MPPI tick
+        "tbnav_comm_unique_id": (C.c_int, [vp]),
+        "tbnav_comm_create": (C.c_int, [vp, i32, i32, i32, C.POINTER(vp)]),
+        "tbnav_comm_create_local": (C.c_int, [i32, vp, vp]),
+        "tbnav_comm_destroy": (None, [vp]),
+        "tbnav_comm_rank": (C.c_int, [vp]),
+        "tbnav_comm_size": (C.c_int, [vp]),
+        "tbnav_comm_device": (C.c_int, [vp]),
+        "tbnav_comm_uses_rccl": (C.c_int, [vp]),
+        "tbnav_mppi_attach_comm": (C.c_int, [vp, vp]),
+        "tbnav_mppi_group_create": (C.c_int, [C.POINTER(MppiParams), i32, vp, C.POINTER(vp)]),
+        "tbnav_mppi_group_destroy": (None, [vp]),
+        "tbnav_mppi_group_size": (C.c_int, [vp]),
+        "tbnav_mppi_group_member": (C.c_int, [vp, i32, C.POINTER(vp)]),
+        "tbnav_mppi_group_set_waypoint": (C.c_int, [vp, dbl, dbl, dbl]),
+        "tbnav_mppi_group_set_initial_controls": (C.c_int, [vp, dbl, dbl]),
+        "tbnav_mppi_group_set_controls": (C.c_int, [vp, vp]),
+        "tbnav_mppi_group_get_controls": (C.c_int, [vp, vp]),
+        "tbnav_mppi_group_set_dynamics": (C.c_int, [vp, i32]),
+        "tbnav_mppi_group_set_option": (C.c_int, [vp, i32, i32]),
+        "tbnav_mppi_group_new_controls": (C.c_int, [vp, dp, vp, dp]),
+        "tbnav_mppi_group_new_controls_rng": (C.c_int, [vp, dp, u64, u64, dp]),
+        "tbnav_mppi_group_enqueue_rng": (C.c_int, [vp, dp, u64, u64]),
+        "tbnav_mppi_group_enqueue_rng_batch": (C.c_int, [vp, vp, i32, u64, u64, i32]),
+        "tbnav_mppi_group_last_controls": (C.c_int, [vp, dp]),
+        "tbnav_mppi_group_synchronize": (C.c_int, [vp]),
         # RBPF
         "tbnav_rbpf_create": (C.c_int, [C.POINTER(RbpfParams), C.POINTER(vp)]),
         "tbnav_rbpf_create_pool": (C.c_int, [C.POINTER(RbpfParams), u64, C.POINTER(vp)]),

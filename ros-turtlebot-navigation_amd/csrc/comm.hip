@@ -1,0 +1,284 @@
+// comm.hip — include/tbnav_comm.h: communicators for the sharded MPPI tick and RBPF scan.
+// RCCL (librccl, loaded on first use) carries every exchange between distinct devices; ranks of a one-process group that
+// share a device (tests on a one-GPU box) exchange by event-ordered device-to-device copies with the same layout.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "comm.hpp"
+#include "common.hpp"
+
+namespace {
+
+// ---- librccl, resolved at run time ------------------------------------------------------------------------------------
+struct Rccl {
+  void* lib = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  bool ok = false;
+};
+Rccl& rccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    // a copy the process has mapped already (PyTorch ships its own librccl) is reused; otherwise the system's
+    for (const char* name : {"librccl.so", "librccl.so.1"}) { r.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD); if (r.lib) break; }
+    if (!r.lib) for (const char* name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) { r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (r.lib) break; }
+    if (!r.lib) return;
+#define TBNAV_SYM(f) r.f = reinterpret_cast<decltype(r.f)>(dlsym(r.lib, "nccl" #f))
+    TBNAV_SYM(GetUniqueId); TBNAV_SYM(CommInitRank); TBNAV_SYM(CommInitAll); TBNAV_SYM(CommDestroy); TBNAV_SYM(AllGather);
+    TBNAV_SYM(Send); TBNAV_SYM(Recv); TBNAV_SYM(GroupStart); TBNAV_SYM(GroupEnd); TBNAV_SYM(GetErrorString);
+#undef TBNAV_SYM
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommInitAll && r.CommDestroy && r.AllGather && r.Send && r.Recv && r.GroupStart && r.GroupEnd;
+  });
+  return r;
+}
+int rccl_fail(ncclResult_t e, const char* what) {
+  char buf[384];
+  const Rccl& r = rccl();
+  std::snprintf(buf, sizeof buf, "rccl: %s failed: %s", what, r.GetErrorString ? r.GetErrorString(e) : "?");
+  tbnav::last_hip_error_slot() = buf;
+  return TBNAV_ERR_HIP;
+}
+#define TBNAV_NCCL(call) do { ncclResult_t e_ = (call); if (e_ != ncclSuccess) return rccl_fail(e_, #call); } while (0)
+
+// shared state of the communicators one process made with tbnav_comm_create_local
+struct LocalGroup {
+  int n = 0, alive = 0;
+  bool use_rccl = false;                 // distinct devices: RCCL; repeated devices: in-process copies
+  std::vector<hipEvent_t> ready, done;   // copy transport: "my send buffer is written" / "I have read everybody's"
+  std::vector<int> device;
+};
+
+struct DevGuard {
+  int prev = -1;
+  explicit DevGuard(int d) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; (void)hipSetDevice(d); }
+  ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+}  // namespace
+
+struct tbnav_comm {
+  int rank = 0, nranks = 1, device = 0;
+  ncclComm_t nccl = nullptr;
+  LocalGroup* group = nullptr;  // non-null: member of a one-process group
+};
+
+namespace tbnav {
+
+int comm_rank(const tbnav_comm* c) { return c ? c->rank : 0; }
+int comm_size(const tbnav_comm* c) { return c ? c->nranks : 1; }
+
+namespace {
+// the members handed in are either one rank of a multi-process job, or every member of one local group in rank order
+int check_members(int n, tbnav_comm* const* comms) {
+  if (n <= 0 || !comms || !comms[0]) return TBNAV_ERR_INVALID_ARG;
+  if (n == 1) return (comms[0]->group && comms[0]->nranks != 1) ? TBNAV_ERR_INVALID_ARG : TBNAV_OK;
+  LocalGroup* g = comms[0]->group;
+  if (!g || g->n != n) return TBNAV_ERR_INVALID_ARG;
+  for (int r = 0; r < n; ++r) if (!comms[r] || comms[r]->group != g || comms[r]->rank != r) return TBNAV_ERR_INVALID_ARG;
+  return TBNAV_OK;
+}
+}  // namespace
+
+int comm_all_gather(int n, tbnav_comm* const* comms, const void* const* send, void* const* recv, size_t bytes, hipStream_t const* streams) {
+  { const int rc = check_members(n, comms); if (rc != TBNAV_OK) return rc; }
+  if (bytes == 0) return TBNAV_OK;
+  LocalGroup* g = comms[0]->group;
+  if (!g || g->use_rccl) {
+    Rccl& R = rccl();
+    if (!R.ok) return TBNAV_ERR_UNSUPPORTED;
+    if (n > 1) TBNAV_NCCL(R.GroupStart());
+    for (int r = 0; r < n; ++r) {
+      DevGuard dg(comms[r]->device);
+      const ncclResult_t e = R.AllGather(send[r], recv[r], bytes, ncclChar, comms[r]->nccl, streams[r]);
+      if (e != ncclSuccess) { if (n > 1) (void)R.GroupEnd(); return rccl_fail(e, "ncclAllGather"); }
+    }
+    if (n > 1) TBNAV_NCCL(R.GroupEnd());
+    return TBNAV_OK;
+  }
+  // copy transport: rank q's block goes to every rank's recv + q * bytes, on the RECEIVER's stream behind the sender's "ready"
+  for (int r = 0; r < n; ++r) { DevGuard dg(g->device[r]); TBNAV_HIP(hipEventRecord(g->ready[r], streams[r])); }
+  for (int d = 0; d < n; ++d) {
+    DevGuard dg(g->device[d]);
+    for (int q = 0; q < n; ++q) {
+      char* dst = static_cast<char*>(recv[d]) + (size_t)q * bytes;
+      if (dst == send[q]) continue;  // in place
+      if (q != d) TBNAV_HIP(hipStreamWaitEvent(streams[d], g->ready[q], 0));
+      TBNAV_HIP(hipMemcpyAsync(dst, send[q], bytes, hipMemcpyDeviceToDevice, streams[d]));
+    }
+    TBNAV_HIP(hipEventRecord(g->done[d], streams[d]));
+  }
+  // nobody rewrites its send buffer before every reader is through with it
+  for (int r = 0; r < n; ++r) {
+    DevGuard dg(g->device[r]);
+    for (int d = 0; d < n; ++d) if (d != r) TBNAV_HIP(hipStreamWaitEvent(streams[r], g->done[d], 0));
+  }
+  return TBNAV_OK;
+}
+
+int comm_exchange(int n, tbnav_comm* const* comms, const std::vector<P2P>* sends, const std::vector<P2P>* recvs, hipStream_t const* streams) {
+  { const int rc = check_members(n, comms); if (rc != TBNAV_OK) return rc; }
+  LocalGroup* g = comms[0]->group;
+  const int world = comms[0]->nranks;
+  for (int r = 0; r < n; ++r) {
+    for (const P2P& m : sends[r]) if (m.peer < 0 || m.peer >= world || (m.bytes && !m.ptr)) return TBNAV_ERR_INVALID_ARG;
+    for (const P2P& m : recvs[r]) if (m.peer < 0 || m.peer >= world || (m.bytes && !m.ptr)) return TBNAV_ERR_INVALID_ARG;
+  }
+  if (!g || g->use_rccl) {
+    Rccl& R = rccl();
+    if (!R.ok) return TBNAV_ERR_UNSUPPORTED;
+    bool any = false;
+    for (int r = 0; r < n; ++r) any |= !sends[r].empty() || !recvs[r].empty();
+    if (!any) return TBNAV_OK;
+    TBNAV_NCCL(R.GroupStart());
+    ncclResult_t e = ncclSuccess;
+    for (int r = 0; r < n && e == ncclSuccess; ++r) {
+      DevGuard dg(comms[r]->device);
+      for (const P2P& m : sends[r]) if (m.bytes && e == ncclSuccess) e = R.Send(m.ptr, m.bytes, ncclChar, m.peer, comms[r]->nccl, streams[r]);
+      for (const P2P& m : recvs[r]) if (m.bytes && e == ncclSuccess) e = R.Recv(m.ptr, m.bytes, ncclChar, m.peer, comms[r]->nccl, streams[r]);
+    }
+    const ncclResult_t e2 = R.GroupEnd();
+    if (e != ncclSuccess) return rccl_fail(e, "ncclSend / ncclRecv");
+    if (e2 != ncclSuccess) return rccl_fail(e2, "ncclGroupEnd");
+    return TBNAV_OK;
+  }
+  // copy transport: message i from q to d = the i-th send of q naming d and the i-th receive of d naming q
+  for (int r = 0; r < n; ++r) { DevGuard dg(g->device[r]); TBNAV_HIP(hipEventRecord(g->ready[r], streams[r])); }
+  for (int d = 0; d < n; ++d) {
+    DevGuard dg(g->device[d]);
+    for (int q = 0; q < n; ++q) {
+      size_t is = 0;
+      bool waited = q == d;
+      for (const P2P& rv : recvs[d]) {
+        if (rv.peer != q) continue;
+        while (is < sends[q].size() && sends[q][is].peer != d) ++is;
+        if (is == sends[q].size() || sends[q][is].bytes != rv.bytes) return TBNAV_ERR_INVALID_ARG;  // the two sides disagree
+        if (rv.bytes) {
+          if (!waited) { TBNAV_HIP(hipStreamWaitEvent(streams[d], g->ready[q], 0)); waited = true; }
+          TBNAV_HIP(hipMemcpyAsync(rv.ptr, sends[q][is].ptr, rv.bytes, hipMemcpyDeviceToDevice, streams[d]));
+        }
+        ++is;
+      }
+      for (; is < sends[q].size(); ++is) if (sends[q][is].peer == d) return TBNAV_ERR_INVALID_ARG;  // a send nobody receives
+    }
+    TBNAV_HIP(hipEventRecord(g->done[d], streams[d]));
+  }
+  for (int r = 0; r < n; ++r) {
+    DevGuard dg(g->device[r]);
+    for (int d = 0; d < n; ++d) if (d != r) TBNAV_HIP(hipStreamWaitEvent(streams[r], g->done[d], 0));
+  }
+  return TBNAV_OK;
+}
+
+}  // namespace tbnav
+
+extern "C" {
+
+int tbnav_comm_unique_id(uint8_t id[TBNAV_COMM_ID_BYTES]) {
+  if (!id) return TBNAV_ERR_INVALID_ARG;
+  Rccl& R = rccl();
+  if (!R.ok) { tbnav::last_hip_error_slot() = "librccl could not be loaded"; return TBNAV_ERR_UNSUPPORTED; }
+  static_assert(sizeof(ncclUniqueId) == TBNAV_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+  ncclUniqueId u;
+  TBNAV_NCCL(R.GetUniqueId(&u));
+  std::memcpy(id, &u, sizeof u);
+  return TBNAV_OK;
+}
+
+int tbnav_comm_create(const uint8_t id[TBNAV_COMM_ID_BYTES], int32_t nranks, int32_t rank, int32_t device, tbnav_comm** out) {
+  if (!id || !out || nranks <= 0 || rank < 0 || rank >= nranks) return TBNAV_ERR_INVALID_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  { const hipError_t e = hipGetDeviceCount(&ndev); if (e != hipSuccess || ndev <= 0) return tbnav::hip_fail(e == hipSuccess ? hipErrorNoDevice : e, "hipGetDeviceCount", __FILE__, __LINE__); }
+  if (device < 0) TBNAV_HIP(hipGetDevice(&device));
+  if (device >= ndev) return TBNAV_ERR_INVALID_ARG;
+  Rccl& R = rccl();
+  if (!R.ok) { tbnav::last_hip_error_slot() = "librccl could not be loaded"; return TBNAV_ERR_UNSUPPORTED; }
+  tbnav_comm* c = new (std::nothrow) tbnav_comm();
+  if (!c) return TBNAV_ERR_INVALID_ARG;
+  c->rank = rank; c->nranks = nranks; c->device = device;
+  DevGuard dg(device);
+  ncclUniqueId u;
+  std::memcpy(&u, id, sizeof u);
+  const ncclResult_t e = R.CommInitRank(&c->nccl, nranks, u, rank);
+  if (e != ncclSuccess) { delete c; return rccl_fail(e, "ncclCommInitRank"); }
+  *out = c;
+  return TBNAV_OK;
+}
+
+int tbnav_comm_create_local(int32_t n, const int32_t* devices, tbnav_comm** out) {
+  if (n <= 0 || !out) return TBNAV_ERR_INVALID_ARG;
+  for (int r = 0; r < n; ++r) out[r] = nullptr;
+  int ndev = 0;
+  { const hipError_t e = hipGetDeviceCount(&ndev); if (e != hipSuccess || ndev <= 0) return tbnav::hip_fail(e == hipSuccess ? hipErrorNoDevice : e, "hipGetDeviceCount", __FILE__, __LINE__); }
+  std::vector<int> dev(n);
+  std::set<int> distinct;
+  for (int r = 0; r < n; ++r) {
+    dev[r] = devices ? devices[r] : r;
+    if (dev[r] < 0 || dev[r] >= ndev) return TBNAV_ERR_INVALID_ARG;
+    distinct.insert(dev[r]);
+  }
+  LocalGroup* g = new (std::nothrow) LocalGroup();
+  if (!g) return TBNAV_ERR_INVALID_ARG;
+  g->n = n; g->alive = n; g->device = dev;
+  g->use_rccl = (int)distinct.size() == n;
+  std::vector<ncclComm_t> nc(n, nullptr);
+  if (g->use_rccl) {
+    Rccl& R = rccl();
+    if (!R.ok) { delete g; tbnav::last_hip_error_slot() = "librccl could not be loaded"; return TBNAV_ERR_UNSUPPORTED; }
+    const ncclResult_t e = R.CommInitAll(nc.data(), n, dev.data());
+    if (e != ncclSuccess) { delete g; return rccl_fail(e, "ncclCommInitAll"); }
+  } else {
+    g->ready.resize(n); g->done.resize(n);
+    for (int r = 0; r < n; ++r) {
+      DevGuard dg(dev[r]);
+      if (hipEventCreateWithFlags(&g->ready[r], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&g->done[r], hipEventDisableTiming) != hipSuccess) {
+        delete g;  // (events created so far leak with a failing runtime: nothing else can be done about them here)
+        return TBNAV_ERR_HIP;
+      }
+    }
+  }
+  for (int r = 0; r < n; ++r) {
+    tbnav_comm* c = new (std::nothrow) tbnav_comm();
+    if (!c) return TBNAV_ERR_INVALID_ARG;
+    c->rank = r; c->nranks = n; c->device = dev[r]; c->nccl = nc[r]; c->group = g;
+    out[r] = c;
+  }
+  return TBNAV_OK;
+}
+
+void tbnav_comm_destroy(tbnav_comm* c) {
+  if (!c) return;
+  if (c->nccl) { DevGuard dg(c->device); (void)rccl().CommDestroy(c->nccl); }
+  if (LocalGroup* g = c->group) {
+    if (--g->alive == 0) {
+      for (size_t r = 0; r < g->ready.size(); ++r) { DevGuard dg(g->device[r]); (void)hipEventDestroy(g->ready[r]); (void)hipEventDestroy(g->done[r]); }
+      delete g;
+    }
+  }
+  delete c;
+}
+
+int tbnav_comm_rank(const tbnav_comm* c) { return c ? c->rank : -1; }
+int tbnav_comm_size(const tbnav_comm* c) { return c ? c->nranks : -1; }
+int tbnav_comm_device(const tbnav_comm* c) { return c ? c->device : -1; }
+int tbnav_comm_uses_rccl(const tbnav_comm* c) { return c ? (c->nccl ? 1 : 0) : -1; }
+
+}  // extern "C"

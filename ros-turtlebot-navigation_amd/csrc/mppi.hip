@@ -32,6 +32,7 @@
 #include <type_traits>
 #include <vector>
 
+#include "comm.hpp"
 #include "common.hpp"
 #include "tbnav_mppi.h"
 
@@ -1358,6 +1359,10 @@ struct tbnav_mppi {
   bool keep_j = false;        // the fused kernel also writes J to HBM (parity hook tbnav_mppi_get_cost_to_go); other kernels always do
   bool j_valid = false;       // d_J holds the last tick's cost-to-go
   uint64_t k0 = 0, k_global = 0;  // device noise source: this handle's rollouts are [k0, k0 + K) of k_global (sharded ensembles)
+  // sharded ensemble (tbnav_mppi_attach_comm / tbnav_mppi_group_*): every tick is shard partials -> ONE all-gather of the
+  // records (RCCL) -> the combine of all shards' records, all enqueued on the tick's stream
+  tbnav_comm* comm = nullptr;
+  double* d_records_all = nullptr;  // [nranks][T][S][8]; this rank's records are written in place at [rank]
 };
 
 namespace {
@@ -1548,6 +1553,8 @@ bool pick_noise(tbnav_mppi* h, const double*& d_duL, const double*& d_duR) {
   return d_duL && d_duR;
 }
 
+int sharded_tick(tbnav_mppi* h, const double x0[3], const double* d_duL, const double* d_duR, const uint64_t* seed, uint64_t tick, void* stream);
+
 }  // namespace
 
 extern "C" {
@@ -1722,7 +1729,7 @@ void tbnav_mppi_destroy(tbnav_mppi* h) {
   if (!h) return;
   DeviceGuard guard(h->device);
   (void)hipFree(h->d_u[0]); (void)hipFree(h->d_u[1]); (void)hipFree(h->d_J); (void)hipFree(h->d_duL); (void)hipFree(h->d_duR);
-  (void)hipFree(h->d_total);
+  (void)hipFree(h->d_total); (void)hipFree(h->d_records_all);
   (void)hipFree(h->d_raw); (void)hipFree(h->d_records); (void)hipFree(h->d_records_f); (void)hipFree(h->d_out);
   if (h->h_out) (void)hipHostFree(h->h_out);
   if (h->tg_exec) (void)hipGraphExecDestroy(h->tg_exec);
@@ -1891,6 +1898,7 @@ int tbnav_mppi_shard_combine(tbnav_mppi* h, const double* d_records_all, int32_t
 int tbnav_mppi_enqueue_dev(tbnav_mppi* h, const double x0[3], const double* d_duL,
                            const double* d_duR, void* stream) {
   if (!h || !x0 || !pick_noise(h, d_duL, d_duR)) return TBNAV_ERR_INVALID_ARG;
+  if (h->comm) return sharded_tick(h, x0, d_duL, d_duR, nullptr, 0, stream);
   DeviceGuard guard(h->device);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (h->fused_dev) {
@@ -2034,6 +2042,7 @@ int tbnav_mppi_sample_noise(tbnav_mppi* h, uint64_t seed, uint64_t tick, void* s
 // workgroup's LDS tile).  Other configurations sample into the handle's buffers first — same values, same result.
 int tbnav_mppi_enqueue_rng(tbnav_mppi* h, const double x0[3], uint64_t seed, uint64_t tick, void* stream) {
   if (!h || !x0) return TBNAV_ERR_INVALID_ARG;
+  if (h->comm) return sharded_tick(h, x0, nullptr, nullptr, &seed, tick, stream);
   if (!(h->fused_rng && (h->fused_r == 8 || h->fused_r == 16))) {
     const int rc = tbnav_mppi_sample_noise(h, seed, tick, stream);
     return rc != TBNAV_OK ? rc : tbnav_mppi_enqueue_dev(h, x0, nullptr, nullptr, stream);
@@ -2053,7 +2062,7 @@ int tbnav_mppi_enqueue_rng_batch(tbnav_mppi* h, const double* x0s, int32_t x0_st
   hipStream_t st = static_cast<hipStream_t>(stream);
   // (only where the tick is short enough for the launches themselves to matter: K = 1024: 8.25 -> 8.15 us per tick on a fast host, 8.9 -> 8.3
   //  on a slower one; from K = 2048 up the device is the bound and the replay is 1-3 % slower than plain launches)
-  if (h->graph_on && x0_stride == 0 && st != nullptr && h->fused_rng && h->fused_r == 8 && h->K <= 1536 && n_ticks >= 2) {
+  if (h->graph_on && !h->comm && x0_stride == 0 && st != nullptr && h->fused_rng && h->fused_r == 8 && h->K <= 1536 && n_ticks >= 2) {
     DeviceGuard guard(h->device);
     // (the graph is built by the first batch call that could use one, however short — a warm-up call, typically — so that a
     //  later long call does not pay the ~1 ms of capture + instantiation)
@@ -2155,6 +2164,198 @@ int tbnav_mppi_get_cost_to_go(tbnav_mppi* h, double* J_host) {
       for (int k = 0; k < h->K; ++k) J_host[(size_t)i * h->K + k] = tot[k] - J_host[(size_t)i * h->K + k];
   }
   return TBNAV_OK;
+}
+
+
+// ---- sharded ensembles behind the same entry points ----------------------------------------------
+int tbnav_mppi_attach_comm(tbnav_mppi* h, tbnav_comm* comm) {
+  if (!h) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  TBNAV_HIP(hipDeviceSynchronize());
+  (void)hipFree(h->d_records_all);
+  h->d_records_all = nullptr;
+  h->comm = nullptr;
+  ++h->cfg_epoch;
+  if (!comm) { h->k0 = 0; h->k_global = (uint64_t)h->K; return TBNAV_OK; }
+  if (tbnav_comm_device(comm) != h->device) return TBNAV_ERR_INVALID_ARG;
+  const int P = tbnav::comm_size(comm), r = tbnav::comm_rank(comm);
+  TBNAV_HIP(hipMalloc((void**)&h->d_records_all, sizeof(double) * (size_t)P * h->T * h->S * TBNAV_MPPI_REC));
+  h->comm = comm;
+  // this shard's place in the ensemble's noise counter space (equal shards: every rank holds K rollouts)
+  h->k0 = (uint64_t)r * (uint64_t)h->K;
+  h->k_global = (uint64_t)P * (uint64_t)h->K;
+  return TBNAV_OK;
+}
+
+}  // extern "C"
+
+namespace {
+// one rank's tick: its rollouts and records (written in place into its slot of the gather buffer), the all-gather, the combine
+int sharded_partials(tbnav_mppi* h, const double x0[3], const double* d_duL, const double* d_duR, const uint64_t* seed, uint64_t tick, void* stream) {
+  double* mine = h->d_records_all + (size_t)tbnav::comm_rank(h->comm) * h->T * h->S * TBNAV_MPPI_REC;
+  return seed ? tbnav_mppi_shard_partials_rng(h, x0, *seed, tick, stream, mine) : tbnav_mppi_shard_partials(h, x0, d_duL, d_duR, stream, mine);
+}
+int sharded_tick(tbnav_mppi* h, const double x0[3], const double* d_duL, const double* d_duR, const uint64_t* seed, uint64_t tick, void* stream) {
+  int rc = sharded_partials(h, x0, d_duL, d_duR, seed, tick, stream);
+  if (rc != TBNAV_OK) return rc;
+  DeviceGuard guard(h->device);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t block = sizeof(double) * (size_t)h->T * h->S * TBNAV_MPPI_REC;
+  const void* send = reinterpret_cast<const char*>(h->d_records_all) + (size_t)tbnav::comm_rank(h->comm) * block;
+  void* recv = h->d_records_all;
+  rc = tbnav::comm_all_gather(1, &h->comm, &send, &recv, block, &st);
+  if (rc != TBNAV_OK) return rc;
+  return launch_combine(h, h->d_records_all, tbnav::comm_size(h->comm), st);
+}
+}  // namespace
+
+// One process driving several GPUs: the whole ensemble behind one object (what controller::MPPI built with n_gpus > 1 holds).
+struct tbnav_mppi_group {
+  int n = 0;
+  std::vector<tbnav_mppi*> m;
+  std::vector<tbnav_comm*> c;
+  std::vector<hipStream_t> st;
+  std::vector<double*> d_raw;  // per member: staging of its slice of host-order noise
+  int K_global = 0;
+};
+
+extern "C" {
+
+void tbnav_mppi_group_destroy(tbnav_mppi_group* g) {
+  if (!g) return;
+  for (int r = 0; r < g->n; ++r) {
+    if (r < (int)g->m.size() && g->m[r]) { DeviceGuard guard(g->m[r]->device); (void)hipDeviceSynchronize(); }
+    if (r < (int)g->m.size()) tbnav_mppi_destroy(g->m[r]);
+    if (r < (int)g->c.size()) tbnav_comm_destroy(g->c[r]);
+    if (r < (int)g->st.size() && g->st[r]) (void)hipStreamDestroy(g->st[r]);
+  }
+  delete g;
+}
+
+int tbnav_mppi_group_create(const tbnav_mppi_params* params, int32_t n_gpus, const int32_t* devices, tbnav_mppi_group** out) {
+  if (!params || !out || n_gpus <= 0 || params->rollouts <= 0 || params->rollouts % n_gpus != 0) return TBNAV_ERR_INVALID_ARG;
+  *out = nullptr;
+  tbnav_mppi_group* g = new (std::nothrow) tbnav_mppi_group();
+  if (!g) return TBNAV_ERR_INVALID_ARG;
+  g->n = n_gpus; g->K_global = params->rollouts;
+  g->m.assign(n_gpus, nullptr); g->c.assign(n_gpus, nullptr); g->st.assign(n_gpus, nullptr);
+  int rc = tbnav_comm_create_local(n_gpus, devices, g->c.data());
+  for (int r = 0; r < n_gpus && rc == TBNAV_OK; ++r) {
+    tbnav_mppi_params p = *params;
+    p.rollouts = params->rollouts / n_gpus;
+    p.device = tbnav_comm_device(g->c[r]);
+    rc = tbnav_mppi_create(&p, &g->m[r]);
+    if (rc == TBNAV_OK) rc = tbnav_mppi_attach_comm(g->m[r], g->c[r]);
+    if (rc == TBNAV_OK) { DeviceGuard guard(p.device); if (hipStreamCreateWithFlags(&g->st[r], hipStreamNonBlocking) != hipSuccess) rc = TBNAV_ERR_HIP; }
+  }
+  if (rc != TBNAV_OK) { tbnav_mppi_group_destroy(g); return rc; }
+  *out = g;
+  return TBNAV_OK;
+}
+
+int tbnav_mppi_group_size(const tbnav_mppi_group* g) { return g ? g->n : -1; }
+int tbnav_mppi_group_member(tbnav_mppi_group* g, int32_t rank, tbnav_mppi** out) {
+  if (!g || !out || rank < 0 || rank >= g->n) return TBNAV_ERR_INVALID_ARG;
+  *out = g->m[rank];
+  return TBNAV_OK;
+}
+int tbnav_mppi_group_set_waypoint(tbnav_mppi_group* g, double x, double y, double theta) {
+  if (!g) return TBNAV_ERR_INVALID_ARG;
+  for (tbnav_mppi* h : g->m) { const int rc = tbnav_mppi_set_waypoint(h, x, y, theta); if (rc != TBNAV_OK) return rc; }
+  return TBNAV_OK;
+}
+int tbnav_mppi_group_set_initial_controls(tbnav_mppi_group* g, double uL, double uR) {
+  if (!g) return TBNAV_ERR_INVALID_ARG;
+  for (tbnav_mppi* h : g->m) { const int rc = tbnav_mppi_set_initial_controls(h, uL, uR); if (rc != TBNAV_OK) return rc; }
+  return TBNAV_OK;
+}
+int tbnav_mppi_group_set_controls(tbnav_mppi_group* g, const double* u_host) {
+  if (!g) return TBNAV_ERR_INVALID_ARG;
+  for (tbnav_mppi* h : g->m) { const int rc = tbnav_mppi_set_controls(h, u_host); if (rc != TBNAV_OK) return rc; }
+  return TBNAV_OK;
+}
+int tbnav_mppi_group_get_controls(tbnav_mppi_group* g, double* u_host) { return g ? tbnav_mppi_get_controls(g->m[0], u_host) : TBNAV_ERR_INVALID_ARG; }
+int tbnav_mppi_group_set_dynamics(tbnav_mppi_group* g, int32_t model) {
+  if (!g) return TBNAV_ERR_INVALID_ARG;
+  for (tbnav_mppi* h : g->m) { const int rc = tbnav_mppi_set_dynamics(h, model); if (rc != TBNAV_OK) return rc; }
+  return TBNAV_OK;
+}
+int tbnav_mppi_group_set_option(tbnav_mppi_group* g, int32_t option, int32_t value) {
+  if (!g) return TBNAV_ERR_INVALID_ARG;
+  for (tbnav_mppi* h : g->m) { const int rc = tbnav_mppi_set_option(h, option, value); if (rc != TBNAV_OK) return rc; }
+  return TBNAV_OK;
+}
+
+}  // extern "C"
+
+namespace {
+// every member's partials, ONE grouped all-gather, every member's combine; member 0 publishes when asked to
+int group_tick(tbnav_mppi_group* g, const double x0[3], bool own_noise, const uint64_t* seed, uint64_t tick, bool publish) {
+  const int n = g->n;
+  for (int r = 0; r < n; ++r) {
+    const int rc = sharded_partials(g->m[r], x0, own_noise ? g->m[r]->d_duL : nullptr, own_noise ? g->m[r]->d_duR : nullptr, seed, tick, g->st[r]);
+    if (rc != TBNAV_OK) return rc;
+  }
+  std::vector<const void*> send(n);
+  std::vector<void*> recv(n);
+  const size_t block = sizeof(double) * (size_t)g->m[0]->T * g->m[0]->S * TBNAV_MPPI_REC;
+  for (int r = 0; r < n; ++r) { recv[r] = g->m[r]->d_records_all; send[r] = reinterpret_cast<const char*>(g->m[r]->d_records_all) + (size_t)r * block; }
+  { const int rc = tbnav::comm_all_gather(n, g->c.data(), send.data(), recv.data(), block, g->st.data()); if (rc != TBNAV_OK) return rc; }
+  for (int r = 0; r < n; ++r) {
+    DeviceGuard guard(g->m[r]->device);
+    g->m[r]->publish_next = publish && r == 0;
+    const int rc = launch_combine(g->m[r], g->m[r]->d_records_all, n, g->st[r]);
+    g->m[r]->publish_next = false;
+    if (rc != TBNAV_OK) return rc;
+  }
+  return TBNAV_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int tbnav_mppi_group_enqueue_rng(tbnav_mppi_group* g, const double x0[3], uint64_t seed, uint64_t tick) {
+  if (!g || !x0) return TBNAV_ERR_INVALID_ARG;
+  return group_tick(g, x0, false, &seed, tick, false);
+}
+int tbnav_mppi_group_enqueue_rng_batch(tbnav_mppi_group* g, const double* x0s, int32_t x0_stride, uint64_t seed, uint64_t first_tick, int32_t n_ticks) {
+  if (!g || !x0s || n_ticks < 0 || (x0_stride != 0 && x0_stride < 3)) return TBNAV_ERR_INVALID_ARG;
+  for (int32_t i = 0; i < n_ticks; ++i) {
+    const int rc = group_tick(g, x0s + (size_t)i * x0_stride, false, &seed, first_tick + (uint64_t)i, false);
+    if (rc != TBNAV_OK) return rc;
+  }
+  return TBNAV_OK;
+}
+int tbnav_mppi_group_last_controls(tbnav_mppi_group* g, double u_out[2]) {
+  if (!g || !u_out) return TBNAV_ERR_INVALID_ARG;
+  return tbnav_mppi_last_controls(g->m[0], g->st[0], u_out);
+}
+int tbnav_mppi_group_synchronize(tbnav_mppi_group* g) {
+  if (!g) return TBNAV_ERR_INVALID_ARG;
+  for (int r = 0; r < g->n; ++r) { DeviceGuard guard(g->m[r]->device); TBNAV_HIP(hipStreamSynchronize(g->st[r])); }
+  return TBNAV_OK;
+}
+int tbnav_mppi_group_new_controls_rng(tbnav_mppi_group* g, const double x0[3], uint64_t seed, uint64_t tick, double u_out[2]) {
+  if (!g || !x0 || !u_out) return TBNAV_ERR_INVALID_ARG;
+  const int rc = group_tick(g, x0, false, &seed, tick, true);
+  return rc != TBNAV_OK ? rc : tbnav_mppi_last_controls(g->m[0], g->st[0], u_out);
+}
+// parity mode: host noise in the reference's draw order for the WHOLE ensemble, noise[(k * T + i) * 2 + c]; member r takes
+// rollouts [r * K/n, (r + 1) * K/n)
+int tbnav_mppi_group_new_controls(tbnav_mppi_group* g, const double x0[3], const double* noise_host, double u_out[2]) {
+  if (!g || !x0 || !noise_host || !u_out) return TBNAV_ERR_INVALID_ARG;
+  for (int r = 0; r < g->n; ++r) {
+    tbnav_mppi* h = g->m[r];
+    DeviceGuard guard(h->device);
+    const size_t nk = (size_t)h->T * h->K;
+    if (!h->d_raw) TBNAV_HIP(hipMalloc((void**)&h->d_raw, 2 * nk * sizeof(double)));
+    TBNAV_HIP(hipMemcpyAsync(h->d_raw, noise_host + (size_t)r * 2 * nk, 2 * nk * sizeof(double), hipMemcpyHostToDevice, g->st[r]));
+    const int blocks = (int)((nk + 255) / 256 < 4096 ? (nk + 255) / 256 : 4096);
+    hipLaunchKernelGGL(mppi_unpack_noise, dim3(blocks), dim3(256), 0, g->st[r], h->T, h->K, h->d_raw, h->d_duL, h->d_duR);
+    TBNAV_HIP(hipGetLastError());
+  }
+  const int rc = group_tick(g, x0, true, nullptr, 0, true);
+  return rc != TBNAV_OK ? rc : tbnav_mppi_last_controls(g->m[0], g->st[0], u_out);
 }
 
 }  // extern "C"

@@ -15,7 +15,8 @@
 #include "rigid2d/diff_drive.hpp"
 #include "rigid2d/rigid2d.hpp"
 
-struct tbnav_mppi;  // C-ABI handle
+struct tbnav_mppi;        // C-ABI handle
+struct tbnav_mppi_group;  // the same over several GPUs (include/tbnav_mppi.h)
 
 namespace controller {
 
@@ -37,8 +38,12 @@ struct LossFunc {
 
 class MPPI {
  public:
+  /// The reference's nine arguments (mppi.hpp:133-141).  n_gpus (not in the reference): > 1 splits the
+  /// `rollouts` (a multiple of n_gpus) evenly over that many MI355X of this process — per tick every device rolls its share
+  /// out, ONE RCCL all-gather of the per-time-step soft-min records, the same combine on every device.  devices: HIP ordinals
+  /// (empty: 0 .. n_gpus-1).
   MPPI(const CartModel& cart_model, const LossFunc& loss_func, double lambda, double max_wheel_vel, double ul_var,
-       double ur_var, double horizon, double dt, int rollouts);
+       double ur_var, double horizon, double dt, int rollouts, int n_gpus = 1, const std::vector<int>& devices = {});
   ~MPPI();
   MPPI(const MPPI&) = delete;  // the handle owns device memory (the reference's copy is latently broken anyway: SURVEY.md section 5)
   MPPI& operator=(const MPPI&) = delete;
@@ -57,10 +62,12 @@ class MPPI {
   void useExactArcDynamics(bool on = true);
   int steps() const { return steps_; }
   int rollouts() const { return rollouts_; }
+  int gpus() const;
   std::vector<double> controls() const;      ///< warm-start matrix u, [2][T]
 
  private:
-  tbnav_mppi* h_ = nullptr;
+  tbnav_mppi* h_ = nullptr;         // n_gpus == 1
+  tbnav_mppi_group* g_ = nullptr;   // n_gpus > 1
   int steps_ = 0, rollouts_ = 0;
   double ul_sig_ = 0.0, ur_sig_ = 0.0;
   bool device_noise_ = false;

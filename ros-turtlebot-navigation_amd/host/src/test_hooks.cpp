@@ -146,13 +146,18 @@ int hst_mppi_closed_loop(const double* params, int rollouts, uint64_t seed, cons
   } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
 
+// next hst_mppi_tick: controller::MPPI built with n_gpus = n, every member on device 0 (a one-GPU box: the members then
+// exchange by copies instead of RCCL — same records, same layout, same stream order); 0 / 1 = the reference's nine arguments
+static int g_mppi_gpus = 1;
+void hst_mppi_gpus(int n) { g_mppi_gpus = n < 1 ? 1 : n; }
 // One MPPI tick through the class with the host twister seeded: returns (ul, ur) and u[2][T].
 int hst_mppi_tick(const double* params, int rollouts, uint64_t seed, const double wpt[3] /*x,y,theta*/, const double pose[3] /*theta,x,y*/,
                   int n_ticks, double* out_ul_ur, double* u_out) {
   try {
     controller::CartModel cart(params[0], params[1]);
     controller::LossFunc loss({params[8], params[9], params[10]}, {params[11], params[12]}, {params[13], params[14], params[15]});
-    controller::MPPI mppi(cart, loss, params[2], params[3], params[4], params[5], params[6], params[7], rollouts);
+    controller::MPPI mppi(cart, loss, params[2], params[3], params[4], params[5], params[6], params[7], rollouts, g_mppi_gpus,
+                          std::vector<int>(g_mppi_gpus > 1 ? g_mppi_gpus : 0, 0));
     rigid2d::getTwister().seed(seed);
     rigid2d::Pose w; w.x = wpt[0]; w.y = wpt[1]; w.theta = wpt[2];
     mppi.setWaypoint(w);

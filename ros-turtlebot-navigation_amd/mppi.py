@@ -83,10 +83,16 @@ class MPPI:
     def setRngShard(self, first_rollout: int, rollouts_global: int):
         capi.check(self._L.tbnav_mppi_set_rng_shard(self._h, first_rollout, rollouts_global), "tbnav_mppi_set_rng_shard")
 
+    def attachComm(self, comm):
+        """Every tick of this handle becomes the sharded tick (shard partials -> one RCCL all-gather of the records -> combine
+        of all shards) inside the library, on the tick's stream (rtn_amd.comm.Comm; None detaches)."""
+        capi.check(self._L.tbnav_mppi_attach_comm(self._h, comm._h if comm is not None else None), "tbnav_mppi_attach_comm")
+        self._comm = comm  # (the communicator must outlive the handle's ticks)
+
     def close(self):
-        if getattr(self, "_h", None) is not None and self._h.value:
+        if getattr(self, "_h", None) is not None and self._h.value and getattr(self, "_owned", True):
             self._L.tbnav_mppi_destroy(self._h)
-            self._h = C.c_void_p()
+        self._h = C.c_void_p()
 
     __del__ = close
 
@@ -196,3 +202,91 @@ class MPPI:
         J = np.empty((self.steps, self.rollouts))
         capi.check(self._L.tbnav_mppi_get_cost_to_go(self._h, J.ctypes.data), "get_cost_to_go")
         return J
+
+
+class MPPIGroup:
+    """tbnav_mppi_group: ONE process driving the ensemble over several devices (what controller::MPPI(..., n_gpus) holds).
+    rollouts is the ensemble's K; devices may repeat (members sharing a device exchange by copies instead of RCCL)."""
+
+    def __init__(self, cart_model: CartModel, loss_func: LossFunc, lam: float, max_wheel_vel: float, ul_var: float, ur_var: float,
+                 horizon: float, dt: float, rollouts: int, devices, keep_j: bool = True):
+        p = capi.MppiParams()
+        p.wheel_radius, p.wheel_base = cart_model.wheel_radius, cart_model.wheel_base
+        p.lam, p.max_wheel_vel, p.ul_var, p.ur_var = lam, max_wheel_vel, ul_var, ur_var
+        p.horizon, p.dt = horizon, dt
+        p.Q[:] = loss_func.Q[:3]; p.R[:] = loss_func.R[:2]; p.P1[:] = loss_func.P1[:3]
+        p.rollouts, p.device = rollouts, -1
+        self._L = capi.lib()
+        self._h = C.c_void_p()
+        d = np.ascontiguousarray(devices, dtype=np.int32)
+        capi.check(self._L.tbnav_mppi_group_create(C.byref(p), len(d), d.ctypes.data, C.byref(self._h)), "tbnav_mppi_group_create")
+        self.n = len(d)
+        self.rollouts = rollouts
+        self.steps = self._L.tbnav_mppi_steps(self._member_handle(0))
+        if keep_j:
+            self.setOption(capi.MPPI_OPT_KEEP_J, 1)
+
+    def _member_handle(self, r: int) -> C.c_void_p:
+        h = C.c_void_p()
+        capi.check(self._L.tbnav_mppi_group_member(self._h, r, C.byref(h)), "tbnav_mppi_group_member")
+        return h
+
+    def member(self, r: int) -> MPPI:
+        """A borrowed view of shard r (parity hooks: costToGo, getControls ...)."""
+        m = MPPI.__new__(MPPI)
+        m._L, m._h, m._owned = self._L, self._member_handle(r), False
+        m.steps = self.steps
+        m.rollouts = self._L.tbnav_mppi_rollouts(m._h)
+        m.records_per_step = self._L.tbnav_mppi_records_per_step(m._h)
+        m._name_kernel()
+        return m
+
+    def setOption(self, option: int, value: int):
+        capi.check(self._L.tbnav_mppi_group_set_option(self._h, option, value), "tbnav_mppi_group_set_option")
+
+    def setWaypoint(self, x, y, theta):
+        capi.check(self._L.tbnav_mppi_group_set_waypoint(self._h, x, y, theta), "group_set_waypoint")
+
+    def setInitialControls(self, uL, uR):
+        capi.check(self._L.tbnav_mppi_group_set_initial_controls(self._h, uL, uR), "group_set_initial_controls")
+
+    def setControls(self, u: np.ndarray):
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        capi.check(self._L.tbnav_mppi_group_set_controls(self._h, u.ctypes.data), "group_set_controls")
+
+    def getControls(self) -> np.ndarray:
+        u = np.empty((2, self.steps))
+        capi.check(self._L.tbnav_mppi_group_get_controls(self._h, u.ctypes.data), "group_get_controls")
+        return u
+
+    def newControls(self, x, y, theta, noise: np.ndarray):
+        """noise: the ENSEMBLE's perturbations [K][T][2] in the reference's draw order."""
+        noise = np.ascontiguousarray(noise, dtype=np.float64)
+        assert noise.shape == (self.rollouts, self.steps, 2)
+        x0 = (C.c_double * 3)(x, y, theta); out = (C.c_double * 2)()
+        capi.check(self._L.tbnav_mppi_group_new_controls(self._h, x0, noise.ctypes.data, out), "group_new_controls")
+        return (out[0], out[1])
+
+    def newControlsRng(self, x0, seed: int, tick: int):
+        x0c = (C.c_double * 3)(*x0); out = (C.c_double * 2)()
+        capi.check(self._L.tbnav_mppi_group_new_controls_rng(self._h, x0c, seed, tick, out), "group_new_controls_rng")
+        return (out[0], out[1])
+
+    def enqueueRngBatch(self, x0, seed: int, first_tick: int, n_ticks: int):
+        x0c = (C.c_double * 3)(*x0)
+        capi.check(self._L.tbnav_mppi_group_enqueue_rng_batch(self._h, C.cast(x0c, C.c_void_p), 0, seed, first_tick, n_ticks), "group_enqueue_rng_batch")
+
+    def lastControls(self):
+        out = (C.c_double * 2)()
+        capi.check(self._L.tbnav_mppi_group_last_controls(self._h, out), "group_last_controls")
+        return (out[0], out[1])
+
+    def synchronize(self):
+        capi.check(self._L.tbnav_mppi_group_synchronize(self._h), "group_synchronize")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.tbnav_mppi_group_destroy(self._h)
+        self._h = C.c_void_p()
+
+    __del__ = close

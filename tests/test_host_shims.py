@@ -104,6 +104,30 @@ def test_mppi_class_surface_matches_oracle_with_seeded_twister(host, gpu_pkg):
     assert np.allclose(u_dev, u, rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.gpu
+def test_mppi_class_with_n_gpus_matches_the_oracle(host, gpu_pkg):
+    """controller::MPPI(..., rollouts, n_gpus = 4) (SURVEY.md 8-b; not in the reference): the ensemble's 256 rollouts split over
+    four members — all on device 0 here, so the records travel by in-process copies; on four devices the same calls go through
+    one grouped ncclAllGather — host twister seeded: three ticks equal the oracle fed the same stream, as with one GPU."""
+    d = dict(MPPI_BASE, rollouts=256)
+    T, K, n_ticks = 25, 256, 3
+    out = np.empty(2 * n_ticks); u_dev = np.empty((2, T))
+    host.hst_mppi_gpus(4)
+    try:
+        got_T = host.hst_mppi_tick(_p(_mppi_params(d)), K, C.c_uint64(9), _p(_arr(WAYPOINTS[1])), _p(_arr([0.0, 0.0, 0.0])),
+                                   n_ticks, _p(out), _p(u_dev))
+    finally:
+        host.hst_mppi_gpus(1)
+    assert got_T == T, host.hst_last_error()
+    stream = orc.normal_stream(9, n_ticks * K * T * 2, 0.0, np.sqrt(0.9)).reshape(n_ticks, K, T, 2)
+    u = np.zeros((2, T))
+    for t in range(n_ticks):
+        ref = orc.mppi_new_controls(d, u, (0, 0), WAYPOINTS[1], (0, 0, 0), stream[t])
+        u = ref["u"]
+        assert np.allclose(out[2 * t:2 * t + 2], ref["out"], rtol=1e-9, atol=1e-12)
+    assert np.allclose(u_dev, u, rtol=1e-9, atol=1e-12)
+
+
 def _closed_loop(host, d, K, max_ticks, seed=3, odometry_mode=0):
     wp = _arr(WAYPOINTS).copy()
     traj = np.zeros((max_ticks, 5)); reached = C.c_int(); dev = C.c_double()

@@ -510,11 +510,13 @@ def test_graph_replay_is_rebuilt_when_a_baked_parameter_changes(gpu_pkg):
 
 def test_configs3_as_written_k65536_t100_split_8_ways_against_the_full_cpu_oracle(gpu_pkg):
     """BASELINE configs[3] AS WRITTEN: K = 65536, T = 100, the ensemble split 8 ways (8192 rollouts per shard: what each of
-    8 GPUs runs), every shard's partial records -> the combine of all 8 record sets (the all-gather's result) — against
+    8 GPUs runs) through the product's own sharded tick (tbnav_mppi_group: every member's rollouts + records, one all-gather,
+    the combine of all 8 record sets on every member; the 8 members share the one device of this box, so the all-gather is the
+    in-process copy transport — on 8 devices the same code issues one grouped ncclAllGather) — against
     (1) the unsharded K = 65536 tick on one handle (mppi_rollout_prefix + mppi_partials + mppi_combine) and
     (2) the CPU oracle's tick over all 65536 rollouts (mppi.cpp:72-140 restated; OpenMP over rollouts).
-    Two ticks, warm start carried, every shard in its slice of the ensemble's noise."""
-    import torch
+    Two ticks, warm start carried."""
+    from rtn_amd.mppi import MPPIGroup, CartModel, LossFunc
     K, P, horizon = 65536, 8, 1.0
     d = mppi_cfg(K, horizon)
     T = orc.mppi_steps(d)
@@ -522,11 +524,11 @@ def test_configs3_as_written_k65536_t100_split_8_ways_against_the_full_cpu_oracl
     x0 = (0.02, -0.01, 0.05)
     whole = make_mppi(gpu_pkg, d)
     assert whole.rollout_kernel == "mppi_rollout_prefix"
-    shards = [make_mppi(gpu_pkg, mppi_cfg(Ks, horizon)) for _ in range(P)]
-    for m in [whole] + shards:
-        m.setWaypoint(*WAYPOINTS[1])
-    S = shards[0].records_per_step
-    rec_all = torch.zeros(P, T, S, 8, dtype=torch.float64, device="cuda")
+    grp = MPPIGroup(CartModel(d["wheel_radius"], d["wheel_base"]), LossFunc(d["Q"], d["R"], d["P1"]), d["lam"], d["max_wheel_vel"],
+                    d["ul_var"], d["ur_var"], horizon, d["dt"], K, devices=[0] * P)
+    members = [grp.member(r) for r in range(P)]
+    assert all(m.rollouts == Ks for m in members)
+    whole.setWaypoint(*WAYPOINTS[1]); grp.setWaypoint(*WAYPOINTS[1])
     orc.lib().orc_set_threads(8)
     try:
         u = np.zeros((2, T))
@@ -537,25 +539,16 @@ def test_configs3_as_written_k65536_t100_split_8_ways_against_the_full_cpu_oracl
             assert rel_err(whole.costToGo(), ref["J"]) < J_RTOL
             assert np.allclose(got_whole, ref["out"], rtol=U_RTOL, atol=U_ATOL)
             assert np.allclose(whole.getControls(), ref["u"], rtol=U_RTOL, atol=U_ATOL)
-            dn = torch.from_numpy(noise).cuda()                    # [K][T][2] -> per shard [T][Ks] x 2
-            for g, m in enumerate(shards):
-                sl = dn[g * Ks:(g + 1) * Ks]
-                dl, dr = sl[:, :, 0].t().contiguous(), sl[:, :, 1].t().contiguous()
-                m.shardPartials(x0, dl.data_ptr(), dr.data_ptr(), rec_all[g].data_ptr())
-                torch.cuda.synchronize()
+            got = grp.newControls(*x0, noise)
+            assert np.allclose(got, ref["out"], rtol=U_RTOL, atol=U_ATOL)
+            u0 = members[0].getControls()
+            assert np.allclose(u0, ref["u"], rtol=U_RTOL, atol=U_ATOL)
+            for g, m in enumerate(members):
                 assert rel_err(m.costToGo(), ref["J"][:, g * Ks:(g + 1) * Ks]) < J_RTOL
-            for m in shards:
-                m.shardCombine(rec_all.data_ptr(), P)
-            torch.cuda.synchronize()
-            for m in shards:
-                assert np.allclose(m.lastControls(), ref["out"], rtol=U_RTOL, atol=U_ATOL)
-                assert np.allclose(m.getControls(), ref["u"], rtol=U_RTOL, atol=U_ATOL)
-                assert np.array_equal(m.getControls(), shards[0].getControls())   # every rank ends with the same warm start, bit for bit
+                assert np.array_equal(m.getControls(), u0)   # every rank ends with the same warm start, bit for bit
             u = ref["u"]
-            for m in [whole] + shards:   # carry the ORACLE's warm start on both sides (the comparison is per tick)
-                m.setControls(u)
+            whole.setControls(u); grp.setControls(u)   # carry the ORACLE's warm start on both sides (the comparison is per tick)
             x0 = (x0[0] + 0.002, x0[1] + 0.001, x0[2] + 0.004)
     finally:
         orc.lib().orc_set_threads(1)
-    for m in [whole] + shards:
-        m.close()
+    whole.close(); grp.close()
