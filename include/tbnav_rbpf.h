@@ -209,6 +209,46 @@ int tbnav_rbpf_import_batch_dev(tbnav_rbpf* h, int32_t n, const int32_t* slots, 
  * behind bmapping::GridMapper's value semantics.  In the REFERENCE mode the occupied set travels with its history. */
 int tbnav_rbpf_copy_particle(tbnav_rbpf* dst, int32_t dst_slot, tbnav_rbpf* src, int32_t src_slot);
 
+/* ---- the sharded filter behind the ordinary entry points (include/tbnav_comm.h) -----------------------------------
+ * One process per GPU: after tbnav_rbpf_attach_comm(h, comm) — comm on the handle's device, params.num_particles = this
+ * rank's share, every rank the same, weights initialised to 1 / (nranks * N) by the caller (tbnav_rbpf_set_particles) —
+ * tbnav_rbpf_slam (and _slam_batch, scan by scan) IS the sharded scan, issued by the library on the handle's own streams:
+ *   main stream    noise -> propose -> map update ............................... -> (when resampling fires: migration)
+ *   second stream           wait for the proposal kernel -> ONE ncclAllGather of the raw weights -> the reference's
+ *                           sequential normalise / Neff / low-variance selection over the GLOBAL vector
+ * i.e. the global normalise (a chain of dependent adds as long as the ENSEMBLE) runs beside the local map update; the host
+ * waits once per scan.  A resample that moves particles: one all-gather of blob sizes, one batched export, one ncclSend /
+ * ncclRecv per (source, destination) pair inside one group, one batched import, then an all-gather of the ranks' statuses
+ * (a rank whose tile pool is exhausted stops every rank with TBNAV_ERR_POOL_EXHAUSTED instead of leaving them in the next
+ * collective).  `normals` is this rank's slice of the ensemble's stream + the resampling offset (as for _slam_local), or
+ * NULL: device noise — the handle is given its place in the ensemble's counter space (tbnav_rbpf_set_rng_shard), so the
+ * sharded filter draws what the unsharded one would.  Not available in the REFERENCE distance-field mode.  comm = NULL
+ * detaches.  The communicator must outlive the handle's last scan; the handle does not own it. */
+struct tbnav_comm;
+int tbnav_rbpf_attach_comm(tbnav_rbpf* h, struct tbnav_comm* comm);
+
+/* One process driving n_gpus devices (what bmapping::ParticleFilter(..., n_gpus) holds): params->num_particles (a multiple
+ * of n_gpus) split evenly over devices[0..n_gpus) (NULL: 0, 1, ...; a device may repeat: those members exchange by copies
+ * instead of RCCL, see tbnav_comm.h); max_pool_bytes_per_member as in tbnav_rbpf_create_pool.  Results equal the unsharded
+ * filter's bit for bit (same weights -> same global selection; a particle is its state and its tiles wherever it lives). */
+typedef struct tbnav_rbpf_group tbnav_rbpf_group;
+int tbnav_rbpf_group_create(const tbnav_rbpf_params* params, int32_t n_gpus, const int32_t* devices, uint64_t max_pool_bytes_per_member,
+                            tbnav_rbpf_group** out);
+void tbnav_rbpf_group_destroy(tbnav_rbpf_group* g);
+int tbnav_rbpf_group_size(const tbnav_rbpf_group* g);
+int tbnav_rbpf_group_member(tbnav_rbpf_group* g, int32_t rank, tbnav_rbpf** out);  /* borrowed: parity hooks of one shard */
+int tbnav_rbpf_group_set_seed(tbnav_rbpf_group* g, uint64_t seed);
+int tbnav_rbpf_group_set_option(tbnav_rbpf_group* g, int32_t option, int32_t value);
+/* Standard normals one scan of the WHOLE filter consumes: N_global * (3k+3 | 3) + 1. */
+int64_t tbnav_rbpf_group_num_normals(const tbnav_rbpf_group* g, int32_t icp_ok);
+/* ParticleFilter::SLAM over the whole filter.  normals: the ensemble's draw stream in the reference's order, or NULL
+ * (device noise).  out: the ensemble's sum_w / sq_sum / neff / resampled. */
+int tbnav_rbpf_group_slam(tbnav_rbpf_group* g, const float* scan, int32_t n_beams, const double u[3], const double cur_odom[3],
+                          const double prev_odom[3], int32_t icp_ok, const double T_icp[3], const double* normals, tbnav_rbpf_stats* out);
+/* getRobotState / newMap over the ensemble (strict >, first wins; best_index is the GLOBAL slot). */
+int tbnav_rbpf_group_best_state(tbnav_rbpf_group* g, double pose[3], int32_t* best_index);
+int tbnav_rbpf_group_best_map(tbnav_rbpf_group* g, int8_t* map);
+
 /* ---- state access: parity hooks and particle migration --------------------------------------- */
 int tbnav_rbpf_get_particles(tbnav_rbpf* h, double* pose, double* prev_pose, double* weight);
 int tbnav_rbpf_set_particles(tbnav_rbpf* h, const double* pose, const double* prev_pose,

@@ -169,6 +169,17 @@ def lib() -> C.CDLL:
         "tbnav_mppi_group_last_controls": (C.c_int, [vp, dp]),
         "tbnav_mppi_group_synchronize": (C.c_int, [vp]),
         # RBPF
+        "tbnav_rbpf_attach_comm": (C.c_int, [vp, vp]),
+        "tbnav_rbpf_group_create": (C.c_int, [C.POINTER(RbpfParams), i32, vp, u64, C.POINTER(vp)]),
+        "tbnav_rbpf_group_destroy": (None, [vp]),
+        "tbnav_rbpf_group_size": (C.c_int, [vp]),
+        "tbnav_rbpf_group_member": (C.c_int, [vp, i32, C.POINTER(vp)]),
+        "tbnav_rbpf_group_set_seed": (C.c_int, [vp, u64]),
+        "tbnav_rbpf_group_set_option": (C.c_int, [vp, i32, i32]),
+        "tbnav_rbpf_group_num_normals": (C.c_int64, [vp, i32]),
+        "tbnav_rbpf_group_slam": (C.c_int, [vp, vp, i32, dp, dp, dp, i32, dp, vp, C.POINTER(RbpfStats)]),
+        "tbnav_rbpf_group_best_state": (C.c_int, [vp, dp, C.POINTER(i32)]),
+        "tbnav_rbpf_group_best_map": (C.c_int, [vp, vp]),
         "tbnav_rbpf_create": (C.c_int, [C.POINTER(RbpfParams), C.POINTER(vp)]),
         "tbnav_rbpf_create_pool": (C.c_int, [C.POINTER(RbpfParams), u64, C.POINTER(vp)]),
         "tbnav_rbpf_pool_stats": (C.c_int, [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]),

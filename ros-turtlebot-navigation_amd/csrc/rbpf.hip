@@ -36,6 +36,7 @@
 #include <vector>
 #include <sched.h>
 
+#include "comm.hpp"
 #include "common.hpp"
 #include "ref_field.hpp"
 #include "tbnav_rbpf.h"
@@ -3297,6 +3298,15 @@ struct tbnav_rbpf {
   double* d_sens = nullptr;    // [N][4] sensor transform (X, Y, sin, cos) of each particle's new pose, left by the proposal kernel
   uint64_t seed = 0x5EEDull, scan_index = 0;  // device noise source (normals == NULL)
   uint64_t rng_first = 0, rng_n_global = 0;   // sharded filters: this handle's particles are [rng_first, rng_first + N) of rng_n_global (0 = unsharded)
+  // sharded filter inside the library (tbnav_rbpf_attach_comm / tbnav_rbpf_group_*): the weights' all-gather and the global
+  // normalise / select run on a SECOND stream beside the local map update
+  tbnav_comm* comm = nullptr;
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_w = nullptr, ev_g = nullptr;   // "the proposal kernel has left the weights" / "the global normalise is through"
+  double* d_gw_raw = nullptr;                  // [n_global] all-gathered raw weights
+  char* d_sendbuf = nullptr; char* d_recvbuf = nullptr; size_t send_cap = 0, recv_cap = 0;   // particle blobs of a cross-rank resample
+  unsigned long long* d_sizes = nullptr;       // [n_local + n_global] blob size of every particle this rank sends | of every particle
+  int* d_status = nullptr;                     // [1 + nranks] this rank's status | everybody's
   bool full_edt = false;       // distance-field mode 0 (TBNAV_RBPF_DF=full): whole-map transform after every map update
   int df_mode = 2;             // 0 full, 1 windowed refresh before the update (TBNAV_RBPF_DF=window), 2 exact query at lookup (default)
   int* d_fstate = nullptr;     // [N] distance-field state: 0 stale, 1 window fresh, 2 whole field fresh / injected
@@ -3741,7 +3751,7 @@ struct Prefetched { ScanC c; int rc = TBNAV_OK; const double2* d_beams = nullptr
 int scan_enqueue(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], const double cur_odom[3],
                  const double prev_odom[3], int icp_ok, const double T_icp[3], const double* normals,
                  tbnav_rbpf_stats* out, bool local_only, int slot, const int* gate_prev, ScanTicket& tk,
-                 const Prefetched* pre = nullptr) {
+                 const Prefetched* pre = nullptr, hipEvent_t weights_ready = nullptr) {
   hipStream_t st = h->stream;
   int* const d_err = h->d_err + 4 * slot;
   int* const h_err = h->h_err + 4 * slot;
@@ -3857,6 +3867,7 @@ int scan_enqueue(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3
                      h->d_code[h->cur], h->pool, map_of(h), h->d_trow[h->cur], skip_arr, skip_eq, h->df_mode, h->radius, occ_half,
                      h->d_nocc[h->cur], h->d_win, normals_dev, center, sp.pose, sp.prev, sp.weight, h->tr, h->d_sens, d_err, gate_prev, h->d_mixlut);
   TBNAV_HIP(hipGetLastError());
+  if (weights_ready) TBNAV_HIP(hipEventRecord(weights_ready, st));  // (sharded filter: the exchange starts here, beside the map update)
   if (h->timing) TBNAV_HIP(hipEventRecord(h->ev[2], st));
   // normalise / select needs only the weights the proposal kernel left: it rides in the map update's launch as one extra
   // workgroup (the chain of adds it is made of would otherwise sit on the critical path, and a second stream costs an
@@ -3958,11 +3969,19 @@ int scan_finish(tbnav_rbpf* h, const ScanTicket& tk, tbnav_rbpf_stats* out) {
   return out->status;
 }
 
+int sharded_scan(int n, tbnav_rbpf* const* hs, const float* scan, int n_beams, const double u[3], const double cur_odom[3],
+                 const double prev_odom[3], int icp_ok, const double T_icp[3], const double* const* normals, tbnav_rbpf_stats* out,
+                 tbnav_rbpf_stats* local_out);
+
 int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], const double cur_odom[3],
               const double prev_odom[3], int icp_ok, const double T_icp[3], const double* normals,
               tbnav_rbpf_stats* out, bool local_only) {
   if (!h || !scan || n_beams <= 0 || !u || !cur_odom || !prev_odom || !T_icp || !out) return TBNAV_ERR_INVALID_ARG;
-  if (h->ref_field && local_only) return TBNAV_ERR_UNSUPPORTED;  // the reference-field mode is a single-handle mode
+  if (h->ref_field && (local_only || h->comm)) return TBNAV_ERR_UNSUPPORTED;  // the reference-field mode is a single-handle mode
+  if (h->comm && !local_only) {  // this process's rank of a sharded filter: the exchange is issued from here (sharded_scan)
+    const double* nr[1] = {normals};
+    return sharded_scan(1, &h, scan, n_beams, u, cur_odom, prev_odom, icp_ok, T_icp, nr, out, nullptr);
+  }
   DeviceGuard guard(h->device);
   ScanTicket tk;
   const int rc = scan_enqueue(h, scan, n_beams, u, cur_odom, prev_odom, icp_ok, T_icp, normals, out, local_only, 0, nullptr, tk);
@@ -4244,6 +4263,10 @@ void tbnav_rbpf_destroy(tbnav_rbpf* h) {
   (void)hipFree(h->d_sens); (void)hipFree(h->d_shed); (void)hipFree(h->d_dense); (void)hipFree(h->d_cs); (void)hipFree(h->d_touched); (void)hipFree(h->d_fstate_alt);
   (void)hipFree(h->d_log_ev); (void)hipFree(h->d_log_cnt); (void)hipFree(h->d_tile_scratch);
   (void)hipFree(h->d_gw); (void)hipFree(h->d_gcs); (void)hipFree(h->d_gparent); (void)hipFree(h->d_gz);
+  (void)hipFree(h->d_gw_raw); (void)hipFree(h->d_sendbuf); (void)hipFree(h->d_recvbuf); (void)hipFree(h->d_sizes); (void)hipFree(h->d_status);
+  if (h->ev_w) (void)hipEventDestroy(h->ev_w);
+  if (h->ev_g) (void)hipEventDestroy(h->ev_g);
+  if (h->stream2) (void)hipStreamDestroy(h->stream2);
   (void)hipFree(h->d_beams); (void)hipFree(h->d_normals); (void)hipFree(h->d_parent); (void)hipFree(h->d_best); (void)hipFree(h->d_best_pose); (void)hipFree(h->d_export); (void)hipFree(h->d_tier); (void)hipFree(h->d_fstate); (void)hipFree(h->d_skip); (void)hipFree(h->d_win); (void)hipFree(h->d_center); (void)hipFree(h->d_mixlut); (void)hipFree(h->d_bslots); (void)hipFree(h->d_bcount); (void)hipFree(h->d_bitems); (void)hipFree(h->d_bhdr); (void)hipFree(h->d_score);
   (void)hipFree(h->d_trace);
   (void)hipHostFree(h->h_beams); (void)hipHostFree(h->h_err); (void)hipHostFree(h->h_norm); (void)hipFree(h->d_gate);
@@ -4461,6 +4484,7 @@ int tbnav_rbpf_resample_global_dev(tbnav_rbpf* h, const double* d_weights_all, i
   hipStream_t st = h->stream;
   if ((size_t)n_global > h->g_cap) {
     (void)hipFree(h->d_gw); (void)hipFree(h->d_gcs); (void)hipFree(h->d_gparent); h->d_gw = h->d_gcs = nullptr; h->d_gparent = nullptr; h->g_cap = 0;
+    (void)hipFree(h->d_gw_raw); h->d_gw_raw = nullptr;  // (the in-library sharded scan sizes its buffers with the same capacity: it re-creates them)
     TBNAV_HIP(hipMalloc((void**)&h->d_gw, sizeof(double) * n_global));
     TBNAV_HIP(hipMalloc((void**)&h->d_gcs, sizeof(double) * n_global));
     TBNAV_HIP(hipMalloc((void**)&h->d_gparent, sizeof(int) * n_global));
@@ -4720,6 +4744,356 @@ int tbnav_rbpf_import_batch_dev(tbnav_rbpf* h, int32_t n, const int32_t* slots, 
   TBNAV_HIP(hipStreamSynchronize(st));
   if (h->h_err[3] & 8) return TBNAV_ERR_POOL_EXHAUSTED;
   return TBNAV_OK;
+}
+
+}  // extern "C"
+
+// =================================================================================================
+// The sharded filter inside the library (include/tbnav_comm.h)
+// =================================================================================================
+namespace {
+
+int ensure_shard_state(tbnav_rbpf* h) {
+  const int P = tbnav::comm_size(h->comm);
+  const size_t ng = (size_t)P * h->N;
+  if (!h->stream2) TBNAV_HIP(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+  if (!h->ev_w) TBNAV_HIP(hipEventCreateWithFlags(&h->ev_w, hipEventDisableTiming));
+  if (!h->ev_g) TBNAV_HIP(hipEventCreateWithFlags(&h->ev_g, hipEventDisableTiming));
+  if (ng > h->g_cap || !h->d_gw_raw) {
+    TBNAV_HIP(hipStreamSynchronize(h->stream));
+    TBNAV_HIP(hipStreamSynchronize(h->stream2));
+    (void)hipFree(h->d_gw); (void)hipFree(h->d_gcs); (void)hipFree(h->d_gparent); (void)hipFree(h->d_gw_raw); (void)hipFree(h->d_sizes); (void)hipFree(h->d_status);
+    h->d_gw = h->d_gcs = h->d_gw_raw = nullptr; h->d_gparent = nullptr; h->d_sizes = nullptr; h->d_status = nullptr; h->g_cap = 0;
+    TBNAV_HIP(hipMalloc((void**)&h->d_gw, sizeof(double) * ng));
+    TBNAV_HIP(hipMalloc((void**)&h->d_gcs, sizeof(double) * ng));
+    TBNAV_HIP(hipMalloc((void**)&h->d_gw_raw, sizeof(double) * ng));
+    TBNAV_HIP(hipMalloc((void**)&h->d_gparent, sizeof(int) * ng));
+    TBNAV_HIP(hipMalloc((void**)&h->d_sizes, sizeof(unsigned long long) * ((size_t)h->N + ng)));
+    TBNAV_HIP(hipMalloc((void**)&h->d_status, sizeof(int) * (1 + (size_t)P)));
+    h->g_cap = ng;
+  }
+  return TBNAV_OK;
+}
+
+int grow(char*& buf, size_t& cap, size_t need) {
+  if (need <= cap) return TBNAV_OK;
+  (void)hipFree(buf); buf = nullptr; cap = 0;
+  const size_t want = need + need / 4 + 4096;
+  TBNAV_HIP(hipMalloc((void**)&buf, want));
+  cap = want;
+  return TBNAV_OK;
+}
+
+// ParticleFilter::SLAM over the members' shards.  n == 1: this process's rank of a multi-process filter; n > 1: every member of a
+// one-process group, in rank order.  Per scan and member, on the device:
+//   main stream   noise -> propose -> [event: weights final] -> map update ........................ -> (resample: migration)
+//   second stream                      wait -> ONE all-gather of the raw weights -> the reference's sequential normalise /
+//                                      Neff / selection over the GLOBAL vector (identical on every rank) -> own slice back
+// so the chain of adds of the global normalise (which grows with the ensemble, not with the shard) runs BESIDE the local map
+// update, and the host waits once, for both streams.  Only when resampling fires do particles move: one all-gather of blob
+// sizes, one batched export per rank, one message per (source, destination) pair, one batched import (tbnav_rbpf_export_batch_*
+// / _import_batch_dev), and an all-gather of the ranks' statuses so that a rank whose pool is exhausted stops everybody.
+int sharded_scan(int n, tbnav_rbpf* const* hs, const float* scan, int n_beams, const double u[3], const double cur_odom[3],
+                 const double prev_odom[3], int icp_ok, const double T_icp[3], const double* const* normals, tbnav_rbpf_stats* out,
+                 tbnav_rbpf_stats* local_out) {
+  if (n <= 0 || !hs || !scan || n_beams <= 0 || !u || !cur_odom || !prev_odom || !T_icp || !out) return TBNAV_ERR_INVALID_ARG;
+  for (int r = 0; r < n; ++r) if (!hs[r] || !hs[r]->comm || hs[r]->N != hs[0]->N || hs[r]->ref_field) return TBNAV_ERR_INVALID_ARG;
+  const int P = tbnav::comm_size(hs[0]->comm), nl = hs[0]->N;
+  const size_t ng = (size_t)P * nl;
+  if (ng > ((size_t)1 << 24)) return TBNAV_ERR_UNSUPPORTED;
+  std::vector<tbnav_comm*> comms(n);
+  std::vector<hipStream_t> s1(n), s2(n);
+  std::vector<ScanTicket> tk(n);
+  std::vector<tbnav_rbpf_stats> lst(n);
+  std::memset(out, 0, sizeof *out);
+  // ---- A: every member's local scan (no normalise tail), its "weights are final" event recorded behind the proposal kernel
+  for (int r = 0; r < n; ++r) {
+    tbnav_rbpf* h = hs[r];
+    DeviceGuard guard(h->device);
+    { const int rc = ensure_shard_state(h); if (rc != TBNAV_OK) return rc; }
+    comms[r] = h->comm; s1[r] = h->stream; s2[r] = h->stream2;
+    const int rc = scan_enqueue(h, scan, n_beams, u, cur_odom, prev_odom, icp_ok, T_icp, normals ? normals[r] : nullptr, &lst[r], true, 0, nullptr, tk[r], nullptr, h->ev_w);
+    if (rc != TBNAV_OK) { out->status = rc; return rc; }
+    TBNAV_HIP(hipStreamWaitEvent(h->stream2, h->ev_w, 0));
+  }
+  // ---- B: the ONE collective of the update + the global normalise / selection, on the second streams
+  {
+    std::vector<const void*> send(n);
+    std::vector<void*> recv(n);
+    for (int r = 0; r < n; ++r) { send[r] = state_ptrs(hs[r]->d_state[hs[r]->cur], nl).weight; recv[r] = hs[r]->d_gw_raw; }
+    const int rc = tbnav::comm_all_gather(n, comms.data(), send.data(), recv.data(), sizeof(double) * nl, s2.data());
+    if (rc != TBNAV_OK) return rc;
+  }
+  for (int r = 0; r < n; ++r) {
+    tbnav_rbpf* h = hs[r];
+    DeviceGuard guard(h->device);
+    h->h_norm[1] = NormOut{};
+    // the resampling offset: the scan's last normal — with tbnav_rbpf_set_rng_shard (device noise) the ENSEMBLE's, identical on every rank
+    const double* zp = h->last_normals + h->last_z_index;
+    hipLaunchKernelGGL(rbpf_normalize, dim3(1), dim3(256), 0, h->stream2, (int)ng, zp, h->d_gw_raw, h->d_gw, h->d_gcs, h->d_gparent, h->d_norm + 1,
+                       nullptr, nullptr, nullptr, 0u);
+    TBNAV_HIP(hipGetLastError());
+    const size_t off = (size_t)tbnav::comm_rank(h->comm) * nl;
+    TBNAV_HIP(hipMemcpyAsync(state_ptrs(h->d_state[h->cur], nl).weight, h->d_gw + off, sizeof(double) * nl, hipMemcpyDeviceToDevice, h->stream2));
+    TBNAV_HIP(hipEventRecord(h->ev_g, h->stream2));
+    TBNAV_HIP(hipStreamWaitEvent(h->stream, h->ev_g, 0));  // whatever the main stream does next sees the normalised weights
+  }
+  // ---- C: the host waits once per member (the reference's SLAM() is synchronous)
+  int status = TBNAV_OK;
+  for (int r = 0; r < n; ++r) {
+    tbnav_rbpf* h = hs[r];
+    DeviceGuard guard(h->device);
+    TBNAV_HIP(hipStreamSynchronize(h->stream2));
+    const int rc = scan_finish(h, tk[r], &lst[r]);
+    if (rc != TBNAV_OK && status == TBNAV_OK) status = rc;
+    if (local_out) local_out[r] = lst[r];
+  }
+  const NormOut no = hs[0]->h_norm[1];
+  out->sum_w = no.sum_w; out->sq_sum = no.sq_sum; out->neff = no.neff; out->resampled = no.resampled;
+  out->n_valid_beams = lst[0].n_valid_beams;
+  out->status = status;
+  if (status != TBNAV_OK) return status;
+  if (!no.resampled) return TBNAV_OK;
+  // ---- D: lowVarianceResampling's copies across shards.  Slot m (global) takes particle parents[m].
+  std::vector<int> parents(ng);
+  { DeviceGuard guard(hs[0]->device); TBNAV_HIP(hipMemcpy(parents.data(), hs[0]->d_gparent, sizeof(int) * ng, hipMemcpyDeviceToHost)); }
+  struct Plan { std::vector<std::pair<int, int>> sends, recvs; std::vector<int32_t> send_slots; std::vector<uint64_t> send_sizes, send_offs; std::vector<unsigned long long> sizes_local; };
+  std::vector<Plan> plan(n);
+  for (int r = 0; r < n; ++r) {
+    tbnav_rbpf* h = hs[r];
+    DeviceGuard guard(h->device);
+    const int me = tbnav::comm_rank(h->comm), lo = me * nl;
+    Plan& pl = plan[r];
+    for (size_t m = 0; m < ng; ++m) {  // (dst, q): every particle of mine some other rank's slot chose — once per destination
+      const int q = parents[m], dst = (int)(m / nl);
+      if (q / nl == me && dst != me) pl.sends.emplace_back(dst, q);
+    }
+    std::sort(pl.sends.begin(), pl.sends.end());
+    pl.sends.erase(std::unique(pl.sends.begin(), pl.sends.end()), pl.sends.end());
+    for (int m = lo; m < lo + nl; ++m) { const int q = parents[m]; if (q / nl != me) pl.recvs.emplace_back(q / nl, q); }
+    std::sort(pl.recvs.begin(), pl.recvs.end());
+    pl.recvs.erase(std::unique(pl.recvs.begin(), pl.recvs.end()), pl.recvs.end());
+    pl.send_slots.resize(pl.sends.size());
+    for (size_t i = 0; i < pl.sends.size(); ++i) pl.send_slots[i] = pl.sends[i].second - lo;
+    pl.send_sizes.assign(pl.sends.size(), 0);
+    { const int rc = tbnav_rbpf_export_batch_sizes(h, (int32_t)pl.sends.size(), pl.send_slots.data(), pl.send_sizes.data()); if (rc != TBNAV_OK) return rc; }
+    // what a particle of mine weighs, for whoever receives it (a particle sent to several ranks weighs the same for each)
+    pl.sizes_local.assign(nl, 0ull);
+    for (size_t i = 0; i < pl.sends.size(); ++i) pl.sizes_local[pl.sends[i].second - lo] = pl.send_sizes[i];
+    TBNAV_HIP(hipMemcpyAsync(h->d_sizes, pl.sizes_local.data(), sizeof(unsigned long long) * nl, hipMemcpyHostToDevice, h->stream));
+  }
+  {
+    std::vector<const void*> send(n);
+    std::vector<void*> recv(n);
+    for (int r = 0; r < n; ++r) { send[r] = hs[r]->d_sizes; recv[r] = hs[r]->d_sizes + nl; }
+    const int rc = tbnav::comm_all_gather(n, comms.data(), send.data(), recv.data(), sizeof(unsigned long long) * nl, s1.data());
+    if (rc != TBNAV_OK) return rc;
+  }
+  std::vector<std::vector<tbnav::P2P>> p_send(n), p_recv(n);
+  std::vector<std::vector<uint64_t>> recv_offs(n);
+  std::vector<unsigned long long> sizes_all(ng);
+  for (int r = 0; r < n; ++r) {
+    tbnav_rbpf* h = hs[r];
+    DeviceGuard guard(h->device);
+    Plan& pl = plan[r];
+    TBNAV_HIP(hipMemcpyAsync(sizes_all.data(), h->d_sizes + nl, sizeof(unsigned long long) * ng, hipMemcpyDeviceToHost, h->stream));
+    TBNAV_HIP(hipStreamSynchronize(h->stream));
+    // everything this rank sends: ONE export, the blobs back to back in (destination, particle) order
+    uint64_t total = 0;
+    for (uint64_t b : pl.send_sizes) total += b;
+    { const int rc = grow(h->d_sendbuf, h->send_cap, (size_t)total); if (rc != TBNAV_OK) return rc; }
+    pl.send_offs.assign(pl.sends.size() + 1, 0);
+    { const int rc = tbnav_rbpf_export_batch_dev(h, (int32_t)pl.sends.size(), pl.send_slots.data(), h->d_sendbuf, total, pl.send_offs.data()); if (rc != TBNAV_OK) return rc; }
+    for (size_t i = 0; i < pl.sends.size();) {  // one message per destination
+      size_t j = i;
+      while (j < pl.sends.size() && pl.sends[j].first == pl.sends[i].first) ++j;
+      p_send[r].push_back(tbnav::P2P{pl.sends[i].first, h->d_sendbuf + pl.send_offs[i], (size_t)(pl.send_offs[j] - pl.send_offs[i])});
+      i = j;
+    }
+    // everything it receives: one buffer, the blobs in (source, particle) order
+    recv_offs[r].assign(pl.recvs.size() + 1, 0);
+    for (size_t i = 0; i < pl.recvs.size(); ++i) recv_offs[r][i + 1] = recv_offs[r][i] + sizes_all[pl.recvs[i].second];
+    { const int rc = grow(h->d_recvbuf, h->recv_cap, (size_t)recv_offs[r].back()); if (rc != TBNAV_OK) return rc; }
+    for (size_t i = 0; i < pl.recvs.size();) {
+      size_t j = i;
+      while (j < pl.recvs.size() && pl.recvs[j].first == pl.recvs[i].first) ++j;
+      p_recv[r].push_back(tbnav::P2P{pl.recvs[i].first, h->d_recvbuf + recv_offs[r][i], (size_t)(recv_offs[r][j] - recv_offs[r][i])});
+      i = j;
+    }
+  }
+  { const int rc = tbnav::comm_exchange(n, comms.data(), p_send.data(), p_recv.data(), s1.data()); if (rc != TBNAV_OK) return rc; }
+  // local parents inside the handle (tile tables + reference counts), then the imported ones; weights are NOT reset by the
+  // reference: every slot carries its parent's normalised weight
+  std::vector<int> mstat(n, TBNAV_OK);
+  for (int r = 0; r < n; ++r) {
+    tbnav_rbpf* h = hs[r];
+    DeviceGuard guard(h->device);
+    const int me = tbnav::comm_rank(h->comm), lo = me * nl;
+    Plan& pl = plan[r];
+    std::vector<int32_t> local_parent(nl), imp_slots;
+    std::vector<uint64_t> imp_offs;
+    for (int m = 0; m < nl; ++m) {
+      const int q = parents[lo + m];
+      if (q / nl == me) local_parent[m] = q - lo;
+      else {
+        local_parent[m] = -1;
+        const auto it = std::lower_bound(pl.recvs.begin(), pl.recvs.end(), std::make_pair(q / nl, q));
+        imp_slots.push_back(m);
+        imp_offs.push_back(recv_offs[r][(size_t)(it - pl.recvs.begin())]);
+      }
+    }
+    int rc = tbnav_rbpf_gather_local(h, local_parent.data());
+    if (rc == TBNAV_OK && !imp_slots.empty())
+      rc = tbnav_rbpf_import_batch_dev(h, (int32_t)imp_slots.size(), imp_slots.data(), h->d_recvbuf, recv_offs[r].back(), imp_offs.data());
+    if (rc == TBNAV_OK) rc = tbnav_rbpf_set_weights_from_global_dev(h, parents.data() + lo);
+    mstat[r] = rc;
+    TBNAV_HIP(hipMemcpyAsync(h->d_status, &mstat[r], sizeof(int), hipMemcpyHostToDevice, h->stream));
+  }
+  // a rank that failed (tile pool exhausted) must not leave the others waiting in the next scan's collective: agree on it
+  {
+    std::vector<const void*> send(n);
+    std::vector<void*> recv(n);
+    for (int r = 0; r < n; ++r) { send[r] = hs[r]->d_status; recv[r] = hs[r]->d_status + 1; }
+    const int rc = tbnav::comm_all_gather(n, comms.data(), send.data(), recv.data(), sizeof(int), s1.data());
+    if (rc != TBNAV_OK) return rc;
+  }
+  for (int r = 0; r < n; ++r) {
+    tbnav_rbpf* h = hs[r];
+    DeviceGuard guard(h->device);
+    std::vector<int> all(P);
+    TBNAV_HIP(hipMemcpyAsync(all.data(), h->d_status + 1, sizeof(int) * P, hipMemcpyDeviceToHost, h->stream));
+    TBNAV_HIP(hipStreamSynchronize(h->stream));
+    for (int q = 0; q < P; ++q) if (all[q] != TBNAV_OK && status == TBNAV_OK) status = all[q];
+  }
+  out->status = status;
+  return status;
+}
+
+}  // namespace
+
+// One process driving several GPUs: the whole filter behind one object (what bmapping::ParticleFilter built with n_gpus > 1 holds).
+struct tbnav_rbpf_group {
+  int n = 0, n_global = 0;
+  std::vector<tbnav_rbpf*> m;
+  std::vector<tbnav_comm*> c;
+  std::vector<std::vector<double>> normals;  // parity mode: each member's slice of the ensemble's draw stream + the offset
+};
+
+extern "C" {
+
+int tbnav_rbpf_attach_comm(tbnav_rbpf* h, tbnav_comm* comm) {
+  if (!h) return TBNAV_ERR_INVALID_ARG;
+  if (comm && (h->ref_field || tbnav_comm_device(comm) != h->device)) return TBNAV_ERR_INVALID_ARG;
+  DeviceGuard guard(h->device);
+  TBNAV_HIP(hipStreamSynchronize(h->stream));
+  h->comm = comm;
+  if (!comm) { h->rng_first = 0; h->rng_n_global = 0; return TBNAV_OK; }
+  // equal shards: this rank's particles are [rank * N, (rank + 1) * N) of nranks * N — also for the device noise source
+  h->rng_first = (uint64_t)tbnav::comm_rank(comm) * (uint64_t)h->N;
+  h->rng_n_global = (uint64_t)tbnav::comm_size(comm) * (uint64_t)h->N;
+  return ensure_shard_state(h);
+}
+
+void tbnav_rbpf_group_destroy(tbnav_rbpf_group* g) {
+  if (!g) return;
+  for (int r = 0; r < g->n; ++r) {
+    if (r < (int)g->m.size()) tbnav_rbpf_destroy(g->m[r]);
+    if (r < (int)g->c.size()) tbnav_comm_destroy(g->c[r]);
+  }
+  delete g;
+}
+
+int tbnav_rbpf_group_create(const tbnav_rbpf_params* params, int32_t n_gpus, const int32_t* devices, uint64_t max_pool_bytes_per_member,
+                            tbnav_rbpf_group** out) {
+  if (!params || !out || n_gpus <= 0 || params->num_particles <= 0 || params->num_particles % n_gpus != 0) return TBNAV_ERR_INVALID_ARG;
+  *out = nullptr;
+  tbnav_rbpf_group* g = new (std::nothrow) tbnav_rbpf_group();
+  if (!g) return TBNAV_ERR_INVALID_ARG;
+  g->n = n_gpus; g->n_global = params->num_particles;
+  g->m.assign(n_gpus, nullptr); g->c.assign(n_gpus, nullptr); g->normals.resize(n_gpus);
+  int rc = tbnav_comm_create_local(n_gpus, devices, g->c.data());
+  for (int r = 0; r < n_gpus && rc == TBNAV_OK; ++r) {
+    tbnav_rbpf_params p = *params;
+    p.num_particles = params->num_particles / n_gpus;
+    p.device = tbnav_comm_device(g->c[r]);
+    rc = create_impl(&p, max_pool_bytes_per_member, &g->m[r]);
+    if (rc == TBNAV_OK) {
+      // initParticleSet gives every particle weight 1 / N of the WHOLE filter (particle_filter.cpp:134)
+      std::vector<double> w((size_t)p.num_particles, 1.0 / params->num_particles);
+      rc = tbnav_rbpf_set_particles(g->m[r], nullptr, nullptr, w.data());
+    }
+    if (rc == TBNAV_OK) rc = tbnav_rbpf_attach_comm(g->m[r], g->c[r]);
+  }
+  if (rc != TBNAV_OK) { tbnav_rbpf_group_destroy(g); return rc; }
+  *out = g;
+  return TBNAV_OK;
+}
+
+int tbnav_rbpf_group_size(const tbnav_rbpf_group* g) { return g ? g->n : -1; }
+int tbnav_rbpf_group_member(tbnav_rbpf_group* g, int32_t rank, tbnav_rbpf** out) {
+  if (!g || !out || rank < 0 || rank >= g->n) return TBNAV_ERR_INVALID_ARG;
+  *out = g->m[rank];
+  return TBNAV_OK;
+}
+int tbnav_rbpf_group_set_seed(tbnav_rbpf_group* g, uint64_t seed) {
+  if (!g) return TBNAV_ERR_INVALID_ARG;
+  for (tbnav_rbpf* h : g->m) { const int rc = tbnav_rbpf_set_seed(h, seed); if (rc != TBNAV_OK) return rc; }  // one seed: the members draw disjoint slices of its stream
+  return TBNAV_OK;
+}
+int tbnav_rbpf_group_set_option(tbnav_rbpf_group* g, int32_t option, int32_t value) {
+  if (!g) return TBNAV_ERR_INVALID_ARG;
+  for (tbnav_rbpf* h : g->m) { const int rc = tbnav_rbpf_set_option(h, option, value); if (rc != TBNAV_OK) return rc; }
+  return TBNAV_OK;
+}
+int64_t tbnav_rbpf_group_num_normals(const tbnav_rbpf_group* g, int32_t icp_ok) {
+  if (!g) return -1;
+  return (int64_t)g->n_global * (icp_ok ? 3 * g->m[0]->k + 3 : 3) + 1;
+}
+
+// normals: the ENSEMBLE's draw stream in the reference's order (tbnav_rbpf_group_num_normals values: particle-major, the
+// resampling offset last) or NULL (device noise: every member draws its slice of one stream).
+int tbnav_rbpf_group_slam(tbnav_rbpf_group* g, const float* scan, int32_t n_beams, const double u[3], const double cur_odom[3],
+                          const double prev_odom[3], int32_t icp_ok, const double T_icp[3], const double* normals, tbnav_rbpf_stats* out) {
+  if (!g || !out) return TBNAV_ERR_INVALID_ARG;
+  std::vector<const double*> nr(g->n, nullptr);
+  if (normals) {
+    const size_t stride = icp_ok ? 3 * (size_t)g->m[0]->k + 3 : 3, nl = (size_t)g->m[0]->N;
+    for (int r = 0; r < g->n; ++r) {
+      std::vector<double>& v = g->normals[r];
+      v.resize(nl * stride + 1);
+      std::memcpy(v.data(), normals + (size_t)r * nl * stride, sizeof(double) * nl * stride);
+      v[nl * stride] = normals[(size_t)g->n_global * stride];
+      nr[r] = v.data();
+    }
+  }
+  return sharded_scan(g->n, g->m.data(), scan, n_beams, u, cur_odom, prev_odom, icp_ok, T_icp, normals ? nr.data() : nullptr, out, nullptr);
+}
+
+// ParticleFilter::getRobotState over the ensemble: strict >, first wins (particle_filter.cpp:255-274) — members in rank order
+int tbnav_rbpf_group_best_state(tbnav_rbpf_group* g, double pose[3], int32_t* best_index) {
+  if (!g || !pose) return TBNAV_ERR_INVALID_ARG;
+  double best_w = 0.0; int best_r = 0, best_i = 0; double best_pose[3] = {0, 0, 0};
+  bool have = false;
+  for (int r = 0; r < g->n; ++r) {
+    double p[3]; int32_t idx = 0;
+    int rc = tbnav_rbpf_best_state(g->m[r], p, &idx);
+    if (rc != TBNAV_OK) return rc;
+    double w = 0.0;
+    { DeviceGuard guard(g->m[r]->device); TBNAV_HIP(hipMemcpy(&w, state_ptrs(g->m[r]->d_state[g->m[r]->cur], g->m[r]->N).weight + idx, sizeof w, hipMemcpyDeviceToHost)); }
+    // (a member whose weights are all <= 0.0 reports its slot 0, as the reference's loop would keep index 0)
+    if (!have || w > best_w) { best_w = w; best_r = r; best_i = idx; std::memcpy(best_pose, p, sizeof p); have = true; }
+  }
+  std::memcpy(pose, best_pose, sizeof best_pose);
+  if (best_index) *best_index = best_r * g->m[0]->N + best_i;
+  return TBNAV_OK;
+}
+int tbnav_rbpf_group_best_map(tbnav_rbpf_group* g, int8_t* map) {
+  if (!g || !map) return TBNAV_ERR_INVALID_ARG;
+  double pose[3]; int32_t idx = 0;
+  const int rc = tbnav_rbpf_group_best_state(g, pose, &idx);
+  if (rc != TBNAV_OK) return rc;
+  const int nl = g->m[0]->N;
+  return tbnav_rbpf_particle_map(g->m[idx / nl], idx % nl, map);
 }
 
 int tbnav_rbpf_copy_particle(tbnav_rbpf* dst, int32_t dst_slot, tbnav_rbpf* src, int32_t src_slot) {

@@ -66,11 +66,17 @@ class ParticleFilter:
         self.last_stats = None
 
     def close(self):
-        if getattr(self, "_h", None) is not None and self._h.value:
+        if getattr(self, "_h", None) is not None and self._h.value and getattr(self, "_owned", True):
             self._L.tbnav_rbpf_destroy(self._h)
-            self._h = C.c_void_p()
+        self._h = C.c_void_p()
 
     __del__ = close
+
+    def attachComm(self, comm):
+        """SLAM() of this handle becomes this rank's part of the sharded scan, exchanged inside the library (rtn_amd.comm.Comm;
+        None detaches).  The caller sets the weights to 1 / N_global first (setParticles)."""
+        capi.check(self._L.tbnav_rbpf_attach_comm(self._h, comm._h if comm is not None else None), "tbnav_rbpf_attach_comm")
+        self._comm = comm
 
     def numNormals(self, icp_ok=True) -> int:
         return int(self._L.tbnav_rbpf_num_normals(self._h, 1 if icp_ok else 0))
@@ -214,6 +220,90 @@ class ParticleFilter:
         ms = (C.c_float * 6)()
         capi.check(self._L.tbnav_rbpf_last_kernel_ms(self._h, ms), "last_kernel_ms")
         return dict(zip(("propose", "raycast", "occupancy", "edt", "normalize", "gather"), [float(x) for x in ms]))
+
+
+class ParticleFilterGroup:
+    """tbnav_rbpf_group: ONE process driving the filter over several devices (what bmapping::ParticleFilter(..., n_gpus) holds).
+    params.num_particles is the ensemble's N; devices may repeat (members sharing a device exchange by copies, not RCCL)."""
+
+    def __init__(self, params: "capi.RbpfParams", devices, pool_bytes_per_member: int = 0):
+        self._L = capi.lib()
+        self.params = params
+        self._h = C.c_void_p()
+        d = np.ascontiguousarray(devices, dtype=np.int32)
+        capi.check(self._L.tbnav_rbpf_group_create(C.byref(params), len(d), d.ctypes.data, int(pool_bytes_per_member), C.byref(self._h)),
+                   "tbnav_rbpf_group_create")
+        self.n = len(d)
+        self.N, self.k = params.num_particles, params.num_samples_mode
+        self.n_local = self.N // self.n
+        m0 = self.member(0)
+        self.xsize, self.ysize, self.G = m0.xsize, m0.ysize, m0.G
+
+    def member(self, r: int) -> ParticleFilter:
+        """A borrowed view of shard r (parity hooks: particles(), logOdds(), trace() ...)."""
+        h = C.c_void_p()
+        capi.check(self._L.tbnav_rbpf_group_member(self._h, r, C.byref(h)), "tbnav_rbpf_group_member")
+        m = ParticleFilter.__new__(ParticleFilter)
+        m._L, m._h, m._owned, m.params = self._L, h, False, self.params
+        xs, ys = C.c_int32(), C.c_int32()
+        capi.check(self._L.tbnav_rbpf_grid_size(h, C.byref(xs), C.byref(ys)), "grid_size")
+        m.xsize, m.ysize = xs.value, ys.value
+        m.G = m.xsize * m.ysize
+        m.N, m.k, m.last_stats = self.N // self.n, self.k, None
+        return m
+
+    def numNormals(self, icp_ok=True) -> int:
+        return int(self._L.tbnav_rbpf_group_num_normals(self._h, 1 if icp_ok else 0))
+
+    def setSeed(self, seed: int):
+        capi.check(self._L.tbnav_rbpf_group_set_seed(self._h, seed), "group_set_seed")
+
+    def setOption(self, option: int, value: int):
+        capi.check(self._L.tbnav_rbpf_group_set_option(self._h, option, value), "group_set_option")
+
+    def SLAM(self, scan, u, cur_odom, prev_odom, icp_ok, T_icp, normals, check=True):
+        """normals: the ENSEMBLE's draw stream (numNormals values, the reference's order) or None (device noise)."""
+        scan = np.ascontiguousarray(scan, dtype=np.float32)
+        if normals is not None:
+            normals = np.ascontiguousarray(normals, dtype=np.float64)
+            assert normals.size >= self.numNormals(icp_ok)
+        st = capi.RbpfStats()
+        rc = self._L.tbnav_rbpf_group_slam(self._h, scan.ctypes.data, scan.size, _d3(u), _d3(cur_odom), _d3(prev_odom), 1 if icp_ok else 0,
+                                           _d3(T_icp), normals.ctypes.data if normals is not None else None, C.byref(st))
+        if check:
+            capi.check(rc, "tbnav_rbpf_group_slam")
+        return st
+
+    def particles(self):
+        parts = [self.member(r).particles() for r in range(self.n)]
+        return tuple(np.concatenate([p[i] for p in parts]) for i in range(3))
+
+    def setParticles(self, pose=None, prev=None, w=None):
+        nl = self.n_local
+        for r in range(self.n):
+            sl = slice(r * nl, (r + 1) * nl)
+            self.member(r).setParticles(None if pose is None else np.asarray(pose)[sl], None if prev is None else np.asarray(prev)[sl],
+                                        None if w is None else np.asarray(w)[sl])
+
+    def logOdds(self, p: int) -> np.ndarray:
+        return self.member(p // self.n_local).logOdds(p % self.n_local)
+
+    def getRobotState(self):
+        pose = (C.c_double * 3)(); idx = C.c_int32()
+        capi.check(self._L.tbnav_rbpf_group_best_state(self._h, pose, C.byref(idx)), "group_best_state")
+        return (pose[0], pose[1], pose[2]), idx.value
+
+    def newMap(self) -> np.ndarray:
+        m = np.empty(self.G, dtype=np.int8)
+        capi.check(self._L.tbnav_rbpf_group_best_map(self._h, m.ctypes.data), "group_best_map")
+        return m
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.tbnav_rbpf_group_destroy(self._h)
+        self._h = C.c_void_p()
+
+    __del__ = close
 
 
 def resample_global(weights_all: np.ndarray, z: float):
