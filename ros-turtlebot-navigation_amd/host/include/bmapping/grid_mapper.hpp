@@ -40,9 +40,11 @@ class GridMapper : public LaserScanner {
   void gridMap(std::vector<int8_t>& map) const;
 
   // ---- additions (not in the reference) ----
-  /// true: the reference's own priority-queue brushfire (bit for bit; serial host work per scan); false (default):
-  /// the exact nearest-obstacle distance, computed at lookup (include/tbnav_rbpf.h "DISTANCE FIELD").  Before the first scan.
+  /// true (the default: a GridMapper used on its own behaves as the reference's): the reference's own priority-queue
+  /// brushfire, bit for bit (host work per scan); false: the exact nearest-obstacle distance, computed at lookup
+  /// (include/tbnav_rbpf.h "DISTANCE FIELD").  Before the first scan.
   void useReferenceDistanceField(bool on = true);
+  void useExactDistanceField() { useReferenceDistanceField(false); }
   double resolution() const { return resolution_; }
   double xmin() const { return xmin_; }
   double xmax() const { return xmax_; }
@@ -53,7 +55,7 @@ class GridMapper : public LaserScanner {
  private:
   tbnav_rbpf* handle() const;  // opens the one-particle handle on first use
   double resolution_, xmin_, xmax_, ymin_, ymax_;
-  bool reference_field_ = false;
+  bool reference_field_ = true;
   mutable tbnav_rbpf* h_ = nullptr;
 };
 

@@ -4,11 +4,13 @@
 // (:404-410, :474, :479, :494) compiles unchanged against it.  All particle state lives on the GPU
 // behind include/tbnav_rbpf.h.
 //
-// ONE DEVIATION to know about: by default the likelihood-field lookups use the exact nearest-obstacle distance,
-// not the reference's priority-queue brushfire (grid_mapper.cpp:333-435), whose result depends on the occupied
-// set's hash order and keeps stale cells (include/tbnav_rbpf.h, "DISTANCE FIELD"; measured effect on the weights:
-// DESIGN.md section 5).  useReferenceDistanceField() switches to a bit-for-bit reproduction of the brushfire
-// (serial host work per particle: meant for the reference's 40-particle launch configuration).
+// DISTANCE FIELD.  The reference's likelihood field is a priority-queue brushfire (grid_mapper.cpp:333-435) whose result
+// depends on the occupied set's hash order and keeps stale cells.  This class reproduces it bit for bit BY DEFAULT for the
+// ensembles the reference can run (num_particles <= 4096, one GPU): the device logs every change of the occupied set in the
+// reference's order and the per-particle brushfires run on the host's cores with the same libstdc++ containers — never slower
+// than the reference's own loop.  useExactDistanceField() switches to the fast mode (exact nearest-obstacle distance computed
+// at lookup, no transform at all: include/tbnav_rbpf.h "DISTANCE FIELD"; measured effect on the weights: DESIGN.md section 4),
+// which is also what larger ensembles and n_gpus > 1 always use.
 #ifndef TBNAV_BMAPPING_PARTICLE_FILTER_HPP
 #define TBNAV_BMAPPING_PARTICLE_FILTER_HPP
 
@@ -22,7 +24,8 @@
 #include "rigid2d/diff_drive.hpp"
 #include "rigid2d/rigid2d.hpp"
 
-struct tbnav_rbpf;  // C-ABI handle
+struct tbnav_rbpf;        // C-ABI handle
+struct tbnav_rbpf_group;  // the same over several GPUs (include/tbnav_rbpf.h)
 
 namespace bmapping {
 
@@ -39,7 +42,10 @@ class ParticleFilter {
                  double motion_noise_x, double motion_noise_y, double sample_range_theta, double sample_range_x,
                  double sample_range_y, double scan_likelihood_min, double scan_likelihood_max,
                  double pose_likelihood_min, double pose_likelihood_max, ScanAlignment& scan_matcher,
-                 const Transform2D& pose, const GridMapper& mapper);
+                 const Transform2D& pose, const GridMapper& mapper, int n_gpus = 1, const std::vector<int>& devices = {});
+  // (the reference's 19 arguments, particle_filter.hpp:112-130.  n_gpus — not in the reference, SURVEY.md section 8-b — > 1
+  //  splits num_particles, a multiple of n_gpus, evenly over that many MI355X of this process: per scan ONE RCCL all-gather of
+  //  the weights, the same global selection on every device, particles migrate as tile blobs when resampling fires.)
   ~ParticleFilter();
   ParticleFilter(const ParticleFilter&) = delete;
   ParticleFilter& operator=(const ParticleFilter&) = delete;
@@ -56,14 +62,20 @@ class ParticleFilter {
   /// Not in the reference: every particle refines T(pose) * T_icp against its own map (hill climbing on the
   /// likelihood field) before sampling, so T_icp may be a rough guess such as the odometry increment.
   void useScanMatching(bool on = true, double lstep = 0.05, double astep = 0.05, int iterations = 5);
-  /// Reproduce the reference's brushfire distance field bit for bit instead of the exact one (see the header note).
+  /// The reference's brushfire distance field, bit for bit (the default up to 4096 particles on one GPU; see the header note).
   /// Call before the first SLAM(): the brushfire's result depends on the whole history of the occupied set.
   void useReferenceDistanceField(bool on = true);
+  /// The fast mode: exact nearest-obstacle distances computed at lookup (not the reference's field).  Before the first SLAM().
+  void useExactDistanceField() { useReferenceDistanceField(false); }
+  bool referenceDistanceField() const { return reference_field_; }
+  int gpus() const;
   int effectiveParticles() const { return last_neff_; }
   bool resampledLastScan() const { return last_resampled_; }
 
  private:
-  tbnav_rbpf* h_ = nullptr;
+  tbnav_rbpf* h_ = nullptr;         // n_gpus == 1
+  tbnav_rbpf_group* g_ = nullptr;   // n_gpus > 1
+  bool reference_field_ = false;
   ScanAlignment scan_matcher_;  // copied, as the reference does (particle_filter.hpp:222)
   int num_particles_ = 0, k_ = 0, last_neff_ = 0;
   bool last_resampled_ = false, device_noise_ = false;

@@ -41,7 +41,7 @@ ParticleFilter::ParticleFilter(int num_particles, int k, double srr, double srt,
                                double sample_range_theta, double sample_range_x, double sample_range_y,
                                double scan_likelihood_min, double scan_likelihood_max, double pose_likelihood_min,
                                double pose_likelihood_max, ScanAlignment& scan_matcher, const Transform2D& pose,
-                               const GridMapper& mapper)
+                               const GridMapper& mapper, int n_gpus, const std::vector<int>& devices)
     : scan_matcher_(scan_matcher), num_particles_(num_particles), k_(k) {
   tbnav_rbpf_params p{};
   p.num_particles = num_particles; p.num_samples_mode = k;
@@ -59,22 +59,43 @@ ParticleFilter::ParticleFilter(int num_particles, int k, double srr, double srt,
   p.resolution = mapper.resolution(); p.xmin = mapper.xmin(); p.xmax = mapper.xmax(); p.ymin = mapper.ymin(); p.ymax = mapper.ymax();
   const auto p0 = pose.displacement();  // initParticleSet, particle_filter.cpp:132-133
   p.pose0[0] = p0.theta; p.pose0[1] = p0.x; p.pose0[2] = p0.y;
-  check(tbnav_rbpf_create(&p, &h_), "bmapping::ParticleFilter");
+  if (n_gpus > 1) {
+    if (!devices.empty() && (int)devices.size() != n_gpus) throw std::invalid_argument("bmapping::ParticleFilter: devices.size() != n_gpus");
+    check(tbnav_rbpf_group_create(&p, n_gpus, devices.empty() ? nullptr : devices.data(), 0, &g_), "bmapping::ParticleFilter (n_gpus)");
+  } else {
+    check(tbnav_rbpf_create(&p, &h_), "bmapping::ParticleFilter");
+    // the reference's own distance field is the default wherever it can run (header note)
+    if (num_particles <= 4096) useReferenceDistanceField(true);
+  }
 }
 
-ParticleFilter::~ParticleFilter() { tbnav_rbpf_destroy(h_); }
+ParticleFilter::~ParticleFilter() { tbnav_rbpf_destroy(h_); tbnav_rbpf_group_destroy(g_); }
+int ParticleFilter::gpus() const { return g_ ? tbnav_rbpf_group_size(g_) : 1; }
 
 void ParticleFilter::useScanMatching(bool on, double lstep, double astep, int iterations) {
+  if (g_) {
+    for (int r = 0; r < tbnav_rbpf_group_size(g_); ++r) {
+      tbnav_rbpf* m = nullptr;
+      check(tbnav_rbpf_group_member(g_, r, &m), "useScanMatching");
+      check(tbnav_rbpf_set_scan_matching(m, on ? 1 : 0, lstep, astep, iterations), "useScanMatching");
+    }
+    return;
+  }
   check(tbnav_rbpf_set_scan_matching(h_, on ? 1 : 0, lstep, astep, iterations), "useScanMatching");
 }
 
 void ParticleFilter::useReferenceDistanceField(bool on) {
+  if (g_) {  // the brushfire reproduction is host work of ONE handle: not available across GPUs
+    if (on) throw std::invalid_argument("useReferenceDistanceField: not available with n_gpus > 1");
+    return;
+  }
   check(tbnav_rbpf_set_option(h_, TBNAV_RBPF_OPT_DF_MODE, on ? TBNAV_RBPF_DF_REFERENCE : TBNAV_RBPF_DF_QUERY), "useReferenceDistanceField");
+  reference_field_ = on;
 }
 
 void ParticleFilter::useDeviceNoise(std::uint64_t seed) {
   device_noise_ = true;
-  check(tbnav_rbpf_set_seed(h_, seed), "useDeviceNoise");
+  check(g_ ? tbnav_rbpf_group_set_seed(g_, seed) : tbnav_rbpf_set_seed(h_, seed), "useDeviceNoise");
 }
 
 void ParticleFilter::SLAM(const std::vector<float>& scan, const Twist2D& u, const Pose& cur_odom, const Pose& prev_odom) {
@@ -88,7 +109,7 @@ void ParticleFilter::SLAM(const std::vector<float>& scan, const Twist2D& u, cons
   // the standard normals this call consumes, drawn in the reference's order from the filter's own
   // engine: per particle 3k (sampleMode) + 3 (new pose), or 3 (motion model); the resampling offset
   // is drawn only if resampling fires, so the engine is rewound when it does not.
-  const int64_t n = tbnav_rbpf_num_normals(h_, ok ? 1 : 0);
+  const int64_t n = g_ ? tbnav_rbpf_group_num_normals(g_, ok ? 1 : 0) : tbnav_rbpf_num_normals(h_, ok ? 1 : 0);
   std::mt19937_64& gen = getTwister();
   std::mt19937_64 before_resample_draw = gen;
   if (!device_noise_) {
@@ -106,7 +127,9 @@ void ParticleFilter::SLAM(const std::vector<float>& scan, const Twist2D& u, cons
   const double prev[3] = {prev_odom.theta, prev_odom.x, prev_odom.y};
   const double ticp[3] = {t.theta, t.x, t.y};
   tbnav_rbpf_stats st{};
-  const int rc = tbnav_rbpf_slam(h_, scan.data(), (int32_t)scan.size(), uu, cur, prev, ok ? 1 : 0, ticp, device_noise_ ? nullptr : normals_.data(), &st);
+  const double* nz = device_noise_ ? nullptr : normals_.data();
+  const int rc = g_ ? tbnav_rbpf_group_slam(g_, scan.data(), (int32_t)scan.size(), uu, cur, prev, ok ? 1 : 0, ticp, nz, &st)
+                    : tbnav_rbpf_slam(h_, scan.data(), (int32_t)scan.size(), uu, cur, prev, ok ? 1 : 0, ticp, nz, &st);
   if (rc != TBNAV_OK || !st.resampled) gen = before_resample_draw;
   check(rc, "ParticleFilter::SLAM");
   last_neff_ = st.neff;
@@ -117,15 +140,17 @@ void ParticleFilter::SLAM(const std::vector<float>& scan, const Twist2D& u, cons
 
 Transform2D ParticleFilter::getRobotState() {
   double pose[3];
-  check(tbnav_rbpf_best_state(h_, pose, nullptr), "getRobotState");
+  check(g_ ? tbnav_rbpf_group_best_state(g_, pose, nullptr) : tbnav_rbpf_best_state(h_, pose, nullptr), "getRobotState");
   return Transform2D(rigid2d::Vector2D(pose[1], pose[2]), pose[0]);
 }
 
 void ParticleFilter::newMap(std::vector<int8_t>& map) {
   int32_t xs = 0, ys = 0;
-  check(tbnav_rbpf_grid_size(h_, &xs, &ys), "newMap");
+  tbnav_rbpf* any = h_;
+  if (g_) check(tbnav_rbpf_group_member(g_, 0, &any), "newMap");
+  check(tbnav_rbpf_grid_size(any, &xs, &ys), "newMap");
   map.resize((size_t)xs * ys, 0);
-  check(tbnav_rbpf_best_map(h_, map.data()), "newMap");
+  check(g_ ? tbnav_rbpf_group_best_map(g_, map.data()) : tbnav_rbpf_best_map(h_, map.data()), "newMap");
 }
 
 }  // namespace bmapping

@@ -176,8 +176,9 @@ int hst_mppi_tick(const double* params, int rollouts, uint64_t seed, const doubl
 // Shipped parameters (slam.launch) with N, k, map half-size given; runs n_scans of SLAM() on the given
 // scans/odometry with the filter's twister seeded; out_pose [n_scans][3] = getRobotState per scan,
 // out_neff [n_scans]; map_out = newMap() after the last scan.  Returns xsize or -1 (message in hst_last_error).
-static int g_pf_reference_field = 0;
-void hst_pf_reference_field(int on) { g_pf_reference_field = on; }  // next hst_pf_run: ParticleFilter::useReferenceDistanceField()
+static int g_pf_reference_field = 1, g_pf_gpus = 1;
+void hst_pf_reference_field(int on) { g_pf_reference_field = on; }  // next hst_pf_run: 1 = the class's default (the reference's field), 0 = useExactDistanceField()
+void hst_pf_gpus(int n) { g_pf_gpus = n < 1 ? 1 : n; }              // next hst_pf_run: ParticleFilter(..., n_gpus = n), every member on device 0
 
 int hst_pf_run(int N, int k, double map_half, uint64_t seed, const float* scans, int n_beams, int n_scans,
                const double* odom /*[n_scans+1][3] theta,x,y: odom[s] = prev, odom[s+1] = cur*/, double* out_pose,
@@ -192,8 +193,10 @@ int hst_pf_run(int N, int k, double map_half, uint64_t seed, const float* scans,
     Transform2D icp_result;
     aligner.setMatcher([&](Transform2D& T, const Transform2D&, const std::vector<float>&, const std::vector<float>&) { T = icp_result; return true; });
     Transform2D start(Vector2D(odom[1], odom[2]), odom[0]);
-    bmapping::ParticleFilter pf(N, k, 0.1, 0.2, 0.1, 0.2, 1e-10, 1e-10, 1e-10, 1e-10, 1e-8, 1e-8, 1.0, 20.0, 1.0, 10.0, aligner, start, grid);
-    if (g_pf_reference_field) pf.useReferenceDistanceField(true);
+    bmapping::ParticleFilter pf(N, k, 0.1, 0.2, 0.1, 0.2, 1e-10, 1e-10, 1e-10, 1e-10, 1e-8, 1e-8, 1.0, 20.0, 1.0, 10.0, aligner, start, grid,
+                                g_pf_gpus, std::vector<int>(g_pf_gpus > 1 ? g_pf_gpus : 0, 0));
+    if (g_pf_gpus == 1 && pf.referenceDistanceField() != true) throw std::runtime_error("the class's default is the reference's distance field");
+    if (!g_pf_reference_field) pf.useExactDistanceField();
     bmapping::getTwister().seed(seed);
     for (int s = 0; s < n_scans; ++s) {
       std::vector<float> scan(scans + (size_t)s * n_beams, scans + (size_t)(s + 1) * n_beams);
@@ -223,7 +226,7 @@ void* hst_gm_create(const double grid[5], const float laser[5], const double mix
   try {
     bmapping::LaserProperties props(laser[0], laser[1], laser[2], laser[3], laser[4], mix[0], mix[1], mix[2], mix[3], mix[4]);
     auto* g = new bmapping::GridMapper(grid[0], grid[1], grid[2], grid[3], grid[4], props, make_T(trs));
-    if (reference_field) g->useReferenceDistanceField(true);
+    g->useReferenceDistanceField(reference_field != 0);  // (the class's default is true)
     return g;
   } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
 }

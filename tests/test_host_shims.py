@@ -193,18 +193,18 @@ def test_closed_loop_with_exact_arc_rollouts(host, gpu_pkg):
 @pytest.mark.parametrize("reference_field", [0, 1])
 def test_particle_filter_class_surface_end_to_end(host, gpu_pkg, reference_field):
     """bmapping::ParticleFilter driven like turtle_mapping_node.cpp:459-494 (SLAM, getRobotState,
-    newMap).  No distance-field injection.  Default (exact field): best pose within 1 mm, exported maps agree on
-    >= 99 % of cells.  With ParticleFilter::useReferenceDistanceField() the class IS the reference filter: best pose
-    to 1e-9, Neff and the exported map identical."""
+    newMap).  No distance-field injection.  By DEFAULT (round 3: the reference's own distance field up to 4096 particles)
+    the class IS the reference filter: best pose to 1e-9, Neff and the exported map identical.  After
+    ParticleFilter::useExactDistanceField() (the fast mode): best pose within 1 mm, exported maps agree on >= 99 % of cells."""
     N, k, n_scans = 40, 50, 5
-    host.hst_pf_reference_field(reference_field)
+    host.hst_pf_reference_field(reference_field)   # 1: the class's DEFAULT (the reference's field); 0: useExactDistanceField()
     steps, poses = rc.trajectory(n_scans, inc=(0.04, 0.03, 0.02))
     rng = np.random.default_rng(3)
     scans = np.stack([orc.room_scan(poses[s], walls=rc.ROOM_SMALL, rng=rng) for s in range(n_scans)])
     odom = np.stack([steps[0][0]] + [st[1] for st in steps])
     out_pose = np.empty((n_scans, 3)); out_neff = np.empty(n_scans, dtype=np.int32); m = np.empty(80 * 80, dtype=np.int8)
     xs = host.hst_pf_run(N, k, C.c_double(2.0), C.c_uint64(11), _p(scans), 360, n_scans, _p(odom), _p(out_pose), _p(out_neff), _p(m))
-    host.hst_pf_reference_field(0)
+    host.hst_pf_reference_field(1)
     assert xs == 80, host.hst_last_error()
     # the same run through the oracle filter: same twister stream, same ICP convention
     pf = orc.PfAPI(orc.pf_params(N=N, k=k, pose0=tuple(odom[0])))
@@ -224,6 +224,30 @@ def test_particle_filter_class_surface_end_to_end(host, gpu_pkg, reference_field
     agree = np.mean(m == pf.grid(pf.best()).grid_map())
     print(f"\n[pf class surface, reference_field={reference_field}] Neff {out_neff.tolist()}, exported map agreement {agree*100:.2f} %")
     assert agree == 1.0 if reference_field else agree >= 0.99
+
+
+@pytest.mark.gpu
+def test_particle_filter_class_with_n_gpus_equals_one_gpu(host, gpu_pkg):
+    """bmapping::ParticleFilter(..., n_gpus = 4) (SURVEY.md 8-b; not in the reference): the 40 particles of the launch
+    configuration over four members (device 0 four times on this box: copy transport; on four devices RCCL), the filter's
+    twister seeded — best pose per scan, Neff and the exported map identical to the same class on one GPU in the same
+    (exact) distance-field mode: sharding changes nothing but where a particle lives."""
+    N, k, n_scans = 40, 50, 6
+    steps, poses = rc.trajectory(n_scans, inc=(0.04, 0.03, 0.02))
+    rng = np.random.default_rng(3)
+    scans = np.stack([orc.room_scan(poses[s], walls=rc.ROOM_SMALL, rng=rng) for s in range(n_scans)])
+    odom = np.stack([steps[0][0]] + [st[1] for st in steps])
+    res = []
+    for gpus in (1, 4):
+        out_pose = np.empty((n_scans, 3)); out_neff = np.empty(n_scans, dtype=np.int32); m = np.empty(80 * 80, dtype=np.int8)
+        host.hst_pf_reference_field(0); host.hst_pf_gpus(gpus)
+        try:
+            xs = host.hst_pf_run(N, k, C.c_double(2.0), C.c_uint64(11), _p(scans), 360, n_scans, _p(odom), _p(out_pose), _p(out_neff), _p(m))
+        finally:
+            host.hst_pf_reference_field(1); host.hst_pf_gpus(1)
+        assert xs == 80, host.hst_last_error()
+        res.append((out_pose, out_neff, m))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
 
 
 def test_node_call_sites_compile_against_these_headers():
