@@ -8,7 +8,9 @@ A "step" is one MPPI control tick (controller::MPPI::newControls, mppi.cpp:72-14
 sampling (mppi.cpp:173-184), which is part of the path: the perturbations of every tick are drawn on the device inside
 the rollout kernel.  Only the 2*T warm-start controls are resident when the timed region starts.
 Workload at every N: BASELINE.json configs[1] per GPU — K=1024 rollouts, T=50 steps, shipped controller parameters — so
-N>1 is weak scaling (global K = N*1024) with ONE all-gather of the per-time-step soft-min records per tick (RCCL).
+N>1 is weak scaling (global K = N*1024) with ONE all-gather of the per-time-step soft-min records per tick, issued by
+libtbnav_hip.so itself (tbnav_mppi_attach_comm: shard partials -> ncclAllGather -> combine on the tick's stream; the ticks of
+the timed region are enqueued by one C call per rank, no Python and no host synchronisation between them).
 value = rollouts/s = N*K*steps / max-over-ranks time.  Extra objects on the same JSON line:
   roofline        dominant kernel of the timed workload vs the HBM roofline (per-kernel times: HIP events on the launch stream)
   latency_floor   what two dependent launches cost by themselves (the K=1024 tick is latency-bound, not HBM-bound)
@@ -37,7 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
-PMC_FILE = "r02_traffic_pmc.json"  # rocprofv3 --pmc passes of this round's final build (tools/collect_pmc.sh)
+PMC_FILE = "r03_traffic_pmc.json"  # rocprofv3 --pmc passes of this round's final build (tools/collect_pmc.sh)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_ROLLOUT_STEP = 48.0          # rollout pass 16 B noise + 8 B J; weighting 8 B J + 16 B noise
 BYTES_ROLLOUT_KERNEL = 24.0            # of which the rollout/cost kernel: reads duL,duR (16 B), writes J (8 B)
@@ -105,7 +107,7 @@ def pmc_traffic(workload_key, kernel_prefix):
                 return v["hbm_bytes"]
     except (OSError, KeyError, ValueError):
         pass
-    return None
+    return None  # (no PMC pass of this kernel committed for this round: null, never a number from another kernel)
 
 
 def roofline_obj(K, T, ms_kernels, ms_tick, kernel_name, traffic_key=None):
@@ -189,6 +191,12 @@ def main():
 
     graft.load_package()
     from rtn_amd.sharded import HipShardBackend, ShardedMPPI
+    comm = None
+    if world > 1 and not one_gpu_test:
+        # the communicator the LIBRARY exchanges through (include/tbnav_comm.h): rank 0's RCCL unique id travels over the job's own
+        # process group; torch.distributed is left with the barriers and the max-over-ranks of the timing
+        from rtn_amd.comm import Comm
+        comm = Comm.from_torch_distributed(local_rank)
 
     K, horizon = 1024, 0.5  # BASELINE configs[1] per GPU
     m = make_mppi(K, horizon, local_rank)
@@ -214,7 +222,20 @@ def main():
             m.enqueueRngBatch(X0, SEED, tk[0], n, stream)  # Python an enqueue costs 8-10 us, as much as the tick itself
             tk[0] += n
         barrier = lambda: None  # noqa: E731
-    else:
+    elif comm is not None:
+        m.attachComm(comm)   # every tick entry point of the handle is now the sharded tick, inside the library
+
+        def tick():
+            m.enqueueRng(X0, SEED, tk[0], stream)
+            tk[0] += 1
+
+        def ticks(n):
+            m.enqueueRngBatch(X0, SEED, tk[0], n, stream)
+            tk[0] += n
+
+        def barrier():
+            dist.barrier()
+    else:  # dev switch: all ranks on one GPU over gloo (RCCL refuses two ranks on one device): the Python exchange path
         sm = ShardedMPPI(HipShardBackend(m, device))
 
         def tick():
@@ -225,14 +246,25 @@ def main():
             dist.barrier()
 
     sync = lambda: torch.cuda.synchronize(device)  # noqa: E731
+    graph_ticks_timed = 0
     if world == 1:
         ticks(args.warmup)
         sync()  # (one rank: the barrier of the bracket is empty)
+        g0 = m.graphReplayedTicks()
         t0 = time.perf_counter()
         ticks(args.steps)
         sync()
         el = time.perf_counter() - t0
+        graph_ticks_timed = m.graphReplayedTicks() - g0
         el_py = time_ticks(tick, sync, args.steps, args.warmup, barrier)  # one Python call per tick, for comparison
+    elif comm is not None:
+        ticks(args.warmup)
+        sync(); barrier(); sync()
+        t0 = time.perf_counter()
+        ticks(args.steps)
+        sync(); barrier(); sync()
+        el = time.perf_counter() - t0
+        el_py = None
     else:
         el = time_ticks(tick, sync, args.steps, args.warmup, barrier)
         el_py = None
@@ -245,7 +277,7 @@ def main():
 
     extra = {}
     if world > 1:
-        extra = multi_gpu_legs(world, rank, local_rank, device, one_gpu_test, stream, sync, barrier)
+        extra = multi_gpu_legs(world, rank, local_rank, device, one_gpu_test, stream, sync, barrier, comm)
 
     if rank == 0:
         ms_step = el / args.steps * 1e3
@@ -267,7 +299,13 @@ def main():
                        "parallelism": f"rollout-shard x{world}" + (", 1 all-gather of soft-min records/tick" if world > 1 else "")},
             "rollout_steps_per_s": round(value * T, 1),
             "sync_tick_ms": round(sync_ms, 6),
-            "entry_point": "tbnav_mppi_enqueue_rng_batch (the K ticks enqueued by one call through the C boundary; chunks of 100 ticks replayed from a captured hipGraph)" if world == 1 else "tbnav_mppi_shard_* per tick",
+            "entry_point": ("tbnav_mppi_enqueue_rng_batch (the timed ticks enqueued by ONE call through the C boundary)" if (world == 1 or comm is not None)
+                            else "tbnav_mppi_shard_* per tick from Python (one-GPU gloo dev switch)"),
+            # what actually ran in the timed region: whole chunks of 100 ticks are replayed from a captured hipGraph, the rest (all of
+            # them when --steps < 100, as with the driver's --steps 20) are plain launches
+            "graph_replayed_ticks": graph_ticks_timed,
+            "exchange": None if world == 1 else ("ncclAllGather of the soft-min records issued by libtbnav_hip.so on the tick's stream (tbnav_mppi_attach_comm)"
+                                                 if comm is not None else "torch.distributed gloo all-gather from Python (dev switch)"),
             "ms_per_step_one_python_call_per_tick": None if el_py is None else round(el_py / args.steps * 1e3, 6),
             "roofline": roofline_obj(K, T, ms_k, ms_step, m.rollout_kernel, "mppi_K1024_T50" if (K, T) == (1024, 50) else None),
             # the tick is two dependent launches: what the guide prices for that alone (MI355X_MICROARCH.md, "boundary" row)
@@ -334,7 +372,7 @@ def main():
         dist.destroy_process_group()
 
 
-def multi_gpu_legs(world, rank, local_rank, device, one_gpu_test, stream, sync, barrier):
+def multi_gpu_legs(world, rank, local_rank, device, one_gpu_test, stream, sync, barrier, comm=None):
     """Two more measurements when N > 1 (same processes, after the headline):
       strong_scaling_configs3  BASELINE configs[3]: K = 65536, T = 100 split N ways (K/N rollouts per rank, resident
                                noise — the streaming regime), one all-gather of records per tick;
@@ -347,8 +385,12 @@ def multi_gpu_legs(world, rank, local_rank, device, one_gpu_test, stream, sync, 
     KL, HL = 65536, 1.0
     ml = make_mppi(KL // world, HL, local_rank)
     al, bl = synth_noise(ml.steps, KL // world, device, 99 + rank)
-    sml = ShardedMPPI(HipShardBackend(ml, device))
-    el = time_ticks(lambda: sml.tick(X0, (al.data_ptr(), bl.data_ptr())), sync, 50, 10, barrier)
+    if comm is not None:
+        ml.attachComm(comm)
+        el = time_ticks(lambda: ml.enqueueDev(X0, al.data_ptr(), bl.data_ptr(), stream), sync, 50, 10, barrier)
+    else:
+        sml = ShardedMPPI(HipShardBackend(ml, device))
+        el = time_ticks(lambda: sml.tick(X0, (al.data_ptr(), bl.data_ptr())), sync, 50, 10, barrier)
     t = torch.tensor([el], dtype=torch.float64, device="cpu" if one_gpu_test else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     out["strong_scaling_configs3"] = {"workload": f"MPPI K={KL} total, T={ml.steps}, K/N = {KL // world} per rank, resident noise",
@@ -361,8 +403,13 @@ def multi_gpu_legs(world, rank, local_rank, device, one_gpu_test, stream, sync, 
     n_local, k = 1000, 50
     steps, scans = bench_rbpf.workload(14)
     pf = ParticleFilter(default_params(N=n_local, k=k, map_min=-10.0, map_max=10.0, device=local_rank))
-    pf.setSeed(2026 + rank)
-    sr = ShardedRBPF(HipRbpfShardBackend(pf, device))
+    pf.setSeed(2026)   # one seed: every rank draws its slice of the ensemble's stream (tbnav_rbpf_set_rng_shard)
+    if comm is not None:
+        pf.setParticles(w=np.full(n_local, 1.0 / (n_local * world)))
+        pf.attachComm(comm)   # pf.SLAM is now this rank's part of the sharded scan, exchanged inside the library
+        sr = None
+    else:
+        sr = ShardedRBPF(HipRbpfShardBackend(pf, device))
     t_total, n_timed, resamples, t_res, t_plain = 0.0, 0, 0, [], []
     for s, (prev, cur, t_icp, u) in enumerate(steps):
         if s in (6, 10):  # skew the GLOBAL weights: heavy particles on the first and the last rank
@@ -374,7 +421,10 @@ def multi_gpu_legs(world, rank, local_rank, device, one_gpu_test, stream, sync, 
             pf.setParticles(w=w)
         sync(); barrier(); sync()
         t0 = time.perf_counter()
-        st, _, _ = sr.tick(scans[s], u, cur, prev, True, t_icp, None, 3 * k + 3)
+        if sr is None:
+            st = pf.SLAM(scans[s], u, cur, prev, True, t_icp, None)
+        else:
+            st, _, _ = sr.tick(scans[s], u, cur, prev, True, t_icp, None, 3 * k + 3)
         sync(); barrier(); sync()
         dt = time.perf_counter() - t0
         if s >= 2:
@@ -389,7 +439,9 @@ def multi_gpu_legs(world, rank, local_rank, device, one_gpu_test, stream, sync, 
                            "ms_per_scan": round(float(t.item()) / n_timed * 1e3, 4), "scans_timed": n_timed, "resamples": resamples,
                            "ms_per_scan_rank0": {"without_resample": round(float(np.mean(t_plain)) * 1e3, 4) if t_plain else None,
                                                  "resampling_with_migration": round(float(np.mean(t_res)) * 1e3, 4) if t_res else None},
-                           "bytes_migrated_rank0": sr.bytes_migrated, "scaling": "weak"}
+                           "bytes_migrated_rank0": None if sr is None else sr.bytes_migrated, "scaling": "weak",
+                           "exchange": ("inside libtbnav_hip.so (tbnav_rbpf_attach_comm): ncclAllGather of the weights + the global normalise on a second "
+                                        "stream beside the map update; ncclSend / ncclRecv of tile blobs when resampling fires") if sr is None else "torch.distributed (gloo dev switch)"}
     pf.close()
     return out
 

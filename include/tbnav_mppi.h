@@ -243,6 +243,10 @@ int tbnav_mppi_new_controls_rng(tbnav_mppi* h, const double x0[3], uint64_t seed
 int tbnav_mppi_enqueue_rng_batch(tbnav_mppi* h, const double* x0s, int32_t x0_stride, uint64_t seed, uint64_t first_tick,
                                  int32_t n_ticks, void* stream);
 
+/* How many of the ticks enqueued through tbnav_mppi_enqueue_rng_batch so far went out as replays of the captured 100-tick
+ * graph (the rest were plain launches): lets a benchmark line say what actually ran. */
+int64_t tbnav_mppi_graph_replayed_ticks(const tbnav_mppi* h);
+
 /* Per-kernel durations priced without the events' own cost: each kernel of the tick is launched `reps` (even, >= 2)
  * times back to back between one event pair; ms[i] = elapsed / reps (ms[1] = 0 when rollout and partials are one
  * kernel).  The controller state advances as if `reps` ticks had run on the same inputs. */

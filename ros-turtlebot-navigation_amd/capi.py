@@ -118,6 +118,7 @@ def lib() -> C.CDLL:
         "tbnav_mppi_rollouts": (C.c_int, [vp]),
         "tbnav_mppi_rollout_variant": (C.c_int, [vp]),
         "tbnav_mppi_streaming_form": (C.c_int, [vp]),
+        "tbnav_mppi_graph_replayed_ticks": (C.c_int64, [vp]),
         "tbnav_mppi_set_dynamics": (C.c_int, [vp, i32]),
         "tbnav_mppi_set_option": (C.c_int, [vp, i32, i32]),
         "tbnav_mppi_set_rng_shard": (C.c_int, [vp, u64, u64]),

@@ -1340,6 +1340,7 @@ struct tbnav_mppi {
   // (waypoint, uinit, lambda, dynamics, trig, keep_j + the J pointer, the rng shard, fused_S and the record buffer).  Every
   // setter that changes one of those bumps cfg_epoch; a graph captured under another epoch is rebuilt, never replayed.
   uint64_t cfg_epoch = 0, tg_epoch = ~0ull;
+  uint64_t graph_ticks = 0;  // ticks enqueued through graph replays so far (tbnav_mppi_graph_replayed_ticks: what a bench line should say ran)
   uint64_t* d_tick0 = nullptr;
   uint64_t tg_dev_tick = ~0ull;  // what *d_tick0 holds once everything enqueued so far has run (each replay's last node adds the chunk)
   int lds_from = 0;           // first time step whose loss is staged in LDS (0 = all of them)
@@ -1809,6 +1810,7 @@ int tbnav_mppi_streaming_form(const tbnav_mppi* h) {
   if (!h) return -1;
   return (h->dyn == 0 && h->trig == 1) ? (h->prefix_rg > 0 ? 2 : (h->reg_groups > 0 ? 1 : 0)) : 0;
 }
+int64_t tbnav_mppi_graph_replayed_ticks(const tbnav_mppi* h) { return h ? (int64_t)h->graph_ticks : -1; }
 int tbnav_mppi_rollouts(const tbnav_mppi* h) { return h ? h->K : -1; }
 int tbnav_mppi_records_per_step(const tbnav_mppi* h) { return h ? h->S : -1; }
 
@@ -2108,6 +2110,7 @@ int tbnav_mppi_enqueue_rng_batch(tbnav_mppi* h, const double* x0s, int32_t x0_st
       { const hipError_t eg = hipGraphLaunch(h->tg_exec, st); if (eg != hipSuccess) { h->tg_dev_tick = ~0ull; TBNAV_HIP(eg); } }
       h->tg_dev_tick = t0 + (uint64_t)kGraphTicks;
       h->seq += kGraphTicks;  // ucur: unchanged after an even number of ticks; the shift stays owed
+      h->graph_ticks += kGraphTicks;
       i += kGraphTicks;
     }
   }

@@ -83,6 +83,9 @@ class MPPI:
     def setRngShard(self, first_rollout: int, rollouts_global: int):
         capi.check(self._L.tbnav_mppi_set_rng_shard(self._h, first_rollout, rollouts_global), "tbnav_mppi_set_rng_shard")
 
+    def graphReplayedTicks(self) -> int:
+        return int(self._L.tbnav_mppi_graph_replayed_ticks(self._h))
+
     def attachComm(self, comm):
         """Every tick of this handle becomes the sharded tick (shard partials -> one RCCL all-gather of the records -> combine
         of all shards) inside the library, on the tick's stream (rtn_amd.comm.Comm; None detaches)."""
