@@ -196,7 +196,15 @@ def main():
         # the communicator the LIBRARY exchanges through (include/tbnav_comm.h): rank 0's RCCL unique id travels over the job's own
         # process group; torch.distributed is left with the barriers and the max-over-ranks of the timing
         from rtn_amd.comm import Comm
-        comm = Comm.from_torch_distributed(local_rank)
+        try:
+            comm = Comm.from_torch_distributed(local_rank)
+            ok = torch.ones(1, device=device)
+        except Exception as e:  # noqa: BLE001 — the line says which exchange ran ("exchange"); the Python path is the round-2 one
+            print(f"[bench rank {rank}] in-library communicator unavailable ({e}); using the torch.distributed exchange", file=sys.stderr, flush=True)
+            comm, ok = None, torch.zeros(1, device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # all ranks take the same path
+        if float(ok.item()) == 0.0:
+            comm = None
 
     K, horizon = 1024, 0.5  # BASELINE configs[1] per GPU
     m = make_mppi(K, horizon, local_rank)
