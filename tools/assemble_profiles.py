@@ -1,13 +1,15 @@
-"""Builds profiles/r02_traffic_pmc.json, r02_sq_counters.json and r02_kernel_stats.md from what tools/profile_round.sh left in
-gpurun_out/ (run here after the GPU call has merged its files back)."""
-import json, os, shutil
+"""Builds profiles/<round>_traffic_pmc.json, <round>_sq_counters.json and <round>_kernel_stats.md from what tools/profile_round.sh
+left in gpurun_out/ (run here after the GPU call has merged its files back).  usage: python tools/assemble_profiles.py [r03]"""
+import json, os, shutil, sys
+R = sys.argv[1] if len(sys.argv) > 1 else "r03"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = lambda f: os.path.join(ROOT, "gpurun_out", f)  # noqa: E731
 P = lambda f: os.path.join(ROOT, "profiles", f)    # noqa: E731
 
 old = json.load(open(P("r02_traffic_pmc.json")))
+old["_about"] = old["_about"].replace("round 2", "round " + R[1:].lstrip("0")).replace("mppi_rollout_cost_reg reads", "the large-K rollout kernel (mppi_rollout_prefix from round 3) reads")
 tags = {"mppi_K1024_T50": "mppi_small_rng", "mppi_K1024_T50_resident_noise": "mppi_small", "mppi_K65536_T100": "mppi_large",
-        "rbpf_N1000_k50_400x400": "rbpf"}
+        "rbpf_N1000_k50_400x400": "rbpf", "rbpf_N1000_k50_400x400_plain_scans_only": "rbpf_plain"}
 out = {"_about": old["_about"], "commands": old["commands"] + ["python tools/assemble_profiles.py"], "workloads": {}}
 out["commands"] = sorted(set(out["commands"]), key=out["commands"].index)
 for key, tag in tags.items():
@@ -22,13 +24,18 @@ for key, tag in tags.items():
                          "+123 MB written, +123 MB read in that launch); 16-byte accesses, whole cache lines per wave: the x2 read "
                          "correction and the 1:1 write reading are uncalibrated for this pattern (MI355X_MICROARCH.md, HBM)")
     out["workloads"][key] = wl
-json.dump(out, open(P("r02_traffic_pmc.json"), "w"), indent=1)
+    if key.endswith("plain_scans_only"):
+        for name, v in wl.items():
+            if name.startswith("rbpf_raycast"):
+                v["note"] = ("the same run WITHOUT the forced resamples: every launch is a plain scan (no tile clones) — the difference to "
+                             "rbpf_N1000_k50_400x400 is what the post-resample scans' clones cost")
+json.dump(out, open(P(f"{R}_traffic_pmc.json"), "w"), indent=1)
 
 olds = json.load(open(P("r02_sq_counters.json")))
 sq = {"_about": olds["_about"]}
 for key, tag in {"rbpf_N1000_k50_400x400": "rbpf", "mppi_K65536_T100": "mppi_large", "mppi_K1024_T50_device_noise": "mppi_small_rng"}.items():
     sq[key] = json.load(open(G(f"sq_summary_{tag}.json")))
-json.dump(sq, open(P("r02_sq_counters.json"), "w"), indent=1)
-shutil.copy(G("r02_kernel_stats.md"), P("r02_kernel_stats.md"))
-shutil.copy(G("r02_bench_under_rocprof.json"), P("r02_bench_under_rocprof.json"))
+json.dump(sq, open(P(f"{R}_sq_counters.json"), "w"), indent=1)
+shutil.copy(G(f"{R}_kernel_stats.md"), P(f"{R}_kernel_stats.md"))
+shutil.copy(G(f"{R}_bench_under_rocprof.json"), P(f"{R}_bench_under_rocprof.json"))
 print("profiles/ refreshed")
