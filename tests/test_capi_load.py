@@ -67,3 +67,30 @@ def test_create_rejects_bad_arguments(pkg):
     p = pkg.capi.MppiParams()
     p.rollouts = 0
     assert L.tbnav_mppi_create(C.byref(p), C.byref(h)) == pkg.capi.ERR_INVALID_ARG
+
+
+def test_comm_and_group_entry_points_fail_loudly_without_gpu_and_reject_bad_arguments(pkg):
+    """include/tbnav_comm.h + the group constructors: bad arguments are TBNAV_ERR_INVALID_ARG before any device or RCCL call;
+    without a GPU a communicator / group cannot be made (no CPU path, no silent single-rank stand-in)."""
+    c = pkg.capi
+    L = c.lib()
+    out = (C.c_void_p * 4)()
+    assert L.tbnav_comm_create_local(0, None, C.cast(out, C.c_void_p)) == c.ERR_INVALID_ARG
+    assert L.tbnav_comm_create(None, 2, 0, 0, C.byref(C.c_void_p())) == c.ERR_INVALID_ARG
+    uid = (C.c_uint8 * 128)()
+    assert L.tbnav_comm_create(C.cast(uid, C.c_void_p), 2, 2, 0, C.byref(C.c_void_p())) == c.ERR_INVALID_ARG   # rank >= nranks
+    assert L.tbnav_comm_rank(None) == -1 and L.tbnav_comm_size(None) == -1
+    g = C.c_void_p()
+    p = c.MppiParams()
+    p.rollouts = 1000
+    assert L.tbnav_mppi_group_create(C.byref(p), 3, None, C.byref(g)) == c.ERR_INVALID_ARG      # 1000 rollouts do not split 3 ways
+    assert L.tbnav_mppi_attach_comm(None, None) == c.ERR_INVALID_ARG and L.tbnav_rbpf_attach_comm(None, None) == c.ERR_INVALID_ARG
+    if L.tbnav_device_count() == 0:
+        devs = (C.c_int32 * 2)(0, 0)
+        assert L.tbnav_comm_create_local(2, C.cast(devs, C.c_void_p), C.cast(out, C.c_void_p)) in (c.ERR_NO_DEVICE, c.ERR_HIP)
+        from cases import MPPI_BASE
+        from rtn_amd.mppi import CartModel, LossFunc, MPPIGroup
+        d = dict(MPPI_BASE)
+        with pytest.raises(c.TbnavError):
+            MPPIGroup(CartModel(d["wheel_radius"], d["wheel_base"]), LossFunc(d["Q"], d["R"], d["P1"]), d["lam"], d["max_wheel_vel"], d["ul_var"],
+                      d["ur_var"], d["horizon"], d["dt"], 64, devices=[0, 0])
