@@ -1864,19 +1864,21 @@ constexpr int kScanSlots = 4;  // per-scan host-visible results (error flags, no
 // Left-to-right sum (of squares) of an LDS array by ONE thread, continuing from `acc` — the reference's order
 // (particle_filter.cpp:446-450, 458-461), which Neff and the resampling decision depend on.  The chain of adds is
 // inherent; the loads are not part of it: the next eight values are fetched while the current eight are added.
-template <bool SQ>
+template <bool SQ, int BLK = 32>
 __device__ __forceinline__ double seq_sum(double acc, const double* w, int N) {
   // 32 values per trip: sixteen 16-byte LDS reads issued together, then the 32 dependent adds and nothing else — a lone wave
   // issues an instruction every four to five cycles, so every instruction that is not an add stretches the chain (the
   // first version's register shuffling made it 13 ns per add)
   const double2* w2 = reinterpret_cast<const double2*>(w);  // (w is 16-byte aligned LDS)
   int i = 0;
-  for (; i + 32 <= N; i += 32) {
-    double2 a[16];
+  // (BLK values per trip: 32 in the kernel of its own; 16 where the body rides in rbpf_raycast_box, whose 64-register budget made
+  //  a block of 32 spill three values per trip INTO the chain of adds — scratch loads with a full wait each)
+  for (; i + BLK <= N; i += BLK) {
+    double2 a[BLK / 2];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) a[q] = w2[(i >> 1) + q];
+    for (int q = 0; q < BLK / 2; ++q) a[q] = w2[(i >> 1) + q];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) { acc += SQ ? a[q].x * a[q].x : a[q].x; acc += SQ ? a[q].y * a[q].y : a[q].y; }
+    for (int q = 0; q < BLK / 2; ++q) { acc += SQ ? a[q].x * a[q].x : a[q].x; acc += SQ ? a[q].y * a[q].y : a[q].y; }
   }
   for (; i < N; ++i) acc += SQ ? w[i] * w[i] : w[i];
   return acc;
@@ -1889,6 +1891,7 @@ __device__ __forceinline__ double seq_sum(double acc, const double* w, int N) {
 // instead of waiting for the whole launch.
 struct NormArgs { int N; const double* zp; const double* weight; double* weight_out; double* cs; int* parent; NormOut* out;
                   int* gate; const int* gate_prev; unsigned int* seq; unsigned int seq_val; int* children; };
+template <int BLK = 32>
 __device__ __forceinline__ void normalize_body(int N, const double* __restrict__ zp, const double* weight, double* weight_out,
                                                double* __restrict__ cs, int* __restrict__ parent, NormOut* __restrict__ out,
                                                double* w, double* cl, int* __restrict__ gate = nullptr,
@@ -1903,7 +1906,7 @@ __device__ __forceinline__ void normalize_body(int N, const double* __restrict__
     __syncthreads();
     for (int i = tid; i < n; i += nthr) w[i] = weight[base + i];
     __syncthreads();
-    if (tid == 0) s_acc = seq_sum<false>(s_acc, w, n);
+    if (tid == 0) s_acc = seq_sum<false, BLK>(s_acc, w, n);
   }
   __syncthreads();
   const double sum = s_acc;
@@ -1914,7 +1917,7 @@ __device__ __forceinline__ void normalize_body(int N, const double* __restrict__
     __syncthreads();
     for (int i = tid; i < n; i += nthr) { const double v = weight[base + i] / sum; w[i] = v; weight_out[base + i] = v; }
     __syncthreads();
-    if (tid == 0) s_acc = seq_sum<true>(s_acc, w, n);
+    if (tid == 0) s_acc = seq_sum<true, BLK>(s_acc, w, n);
   }
   __syncthreads();
   if (tid == 0) {
@@ -2065,7 +2068,7 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
   // costing a second stream, an event and a dependent boundary); the particles' workgroups follow
   if (nz.N > 0 && blockIdx.x == 0) {
     double* w = reinterpret_cast<double*>(lds_i);
-    normalize_body(nz.N, nz.zp, nz.weight, nz.weight_out, nz.cs, nz.parent, nz.out, w, w + kNormChunk, nz.gate, nz.seq, nz.seq_val,
+    normalize_body<16>(nz.N, nz.zp, nz.weight, nz.weight_out, nz.cs, nz.parent, nz.out, w, w + kNormChunk, nz.gate, nz.seq, nz.seq_val,
                    nz.children);
     return;
   }
