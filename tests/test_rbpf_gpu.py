@@ -569,3 +569,44 @@ def test_pipelined_batch_stops_at_the_first_failing_scan(gpu_pkg):
     with pytest.raises(gpu_pkg.capi.TbnavError):
         pf.SLAMBatch(scans, u, odom, t_icp)
     pf.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 37, 1000, 2047, 2048, 2049, 5000, 100_000])
+def test_parallel_exact_chains_equal_the_sequential_sums_bit_for_bit(gpu_pkg, n):
+    """rbpf_normalize's three left-to-right sums (sum of weights, sum of squares of the normalised weights -> Neff, the comb's
+    running sum -> parent list: particle_filter.cpp:442-500) are evaluated WITHOUT a chain of dependent adds (chain_exact: integer
+    prefix sums per binade, ties and binade crossings by single plain adds).  Against the plain sequential loops on the host
+    (tbnav_rbpf_resample_global) — sums bit for bit, Neff, decision, every parent — on weight vectors built to hit what breaks the
+    pattern: uniform weights (every add a tie candidate: dyadic values), one dominant weight (crossings up and long runs in one
+    binade), 20 orders of magnitude of spread, zeros, weights that are exact multiples of the running sum's half-ulp."""
+    import ctypes as C
+    import torch
+    from rtn_amd import capi
+    from rtn_amd.rbpf import resample_global
+    pf = _dev(gpu_pkg, N=1, k=2)
+    rng = np.random.default_rng(n)
+    cases = {
+        "uniform": np.full(n, 1.0 / max(n, 1)),
+        "dyadic": np.ldexp(rng.integers(1, 1 << 12, n).astype(np.float64), -int(np.ceil(np.log2(max(n, 2))) + 20)),
+        "random": rng.random(n),
+        "lognormal": np.exp(rng.normal(0.0, 8.0, n)),
+        "dominant": np.where(np.arange(n) == n // 3, 1.0, rng.random(n) * 1e-9),
+        "zeros": np.where(rng.random(n) < 0.5, 0.0, rng.random(n)),
+        "half_ulps": np.ldexp(2.0 * rng.integers(1, 1 << 20, n).astype(np.float64) + 1.0, -53 - 8),   # odd multiples of 2^-61: ties once the sum passes 2^-8
+        "skewed_resample": np.where(np.arange(n) % 97 == 5, 1.0, 1e-6 * rng.random(n)),
+    }
+    for name, w in cases.items():
+        if n == 1:
+            w = np.array([0.37])
+        if w.sum() == 0.0:
+            w[0] = 1.0
+        z = float(rng.standard_normal())
+        parents_h, wn_h, st_h = resample_global(w, z)
+        dw = torch.from_numpy(w).cuda()
+        parents_d = np.empty(n, dtype=np.int32)
+        st = capi.RbpfStats()
+        capi.check(pf._L.tbnav_rbpf_resample_global_dev(pf._h, dw.data_ptr(), n, 0, C.c_double(z), parents_d.ctypes.data, C.byref(st)), "resample_global_dev")
+        assert (st.sum_w, st.sq_sum, st.neff, st.resampled) == (st_h.sum_w, st_h.sq_sum, st_h.neff, st_h.resampled), (name, n, st.sum_w - st_h.sum_w, st.sq_sum - st_h.sq_sum)
+        if st.resampled:
+            assert np.array_equal(parents_d, parents_h), (name, n)
+    pf.close()
