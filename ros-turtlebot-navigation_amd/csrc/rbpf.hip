@@ -2026,7 +2026,7 @@ __device__ __forceinline__ double chain_exact(double s, const double* w, double*
 // instead of waiting for the whole launch.
 struct NormArgs { int N; const double* zp; const double* weight; double* weight_out; double* cs; int* parent; NormOut* out;
                   int* gate; const int* gate_prev; unsigned int* seq; unsigned int seq_val; int* children; };
-template <int NTHR>
+template <int NTHR, bool PAR>
 __device__ __forceinline__ void normalize_body(int N, const double* __restrict__ zp, const double* weight, double* weight_out,
                                                double* __restrict__ cs, int* __restrict__ parent, NormOut* __restrict__ out,
                                                double* w, double* cl, int* __restrict__ gate = nullptr,
@@ -2039,7 +2039,10 @@ __device__ __forceinline__ void normalize_body(int N, const double* __restrict__
   // One chunk (N <= 2048: BASELINE configs[2], the reference's launch file): the plain chain on one lane — 10 ns an add, 20 us at
   // N = 1000, hidden beside the map update; the parallel form's ~2 us per binade crossing (log2 N of them) would cost more.
   // More than one chunk (the sharded filter's global vector, 100 000 for configs[4]): chain_exact.
+  // PAR = false (the copy that rides in rbpf_raycast_box's launch as workgroup 0): always the plain chain — it runs beside that
+  // launch's other workgroups anyway, and the parallel form inlined there cost the map update 3 % (registers, code size).
   const bool one_chunk = N <= kNormChunk;
+  const bool plain = one_chunk || !PAR;
   constexpr int kSeqBlk = NTHR == 256 ? 32 : 16;  // (register block of the plain chain: 16 under rbpf_raycast_box's 64-register budget)
   constexpr int kHead = 128;
   __shared__ double s_acc;
@@ -2049,8 +2052,8 @@ __device__ __forceinline__ void normalize_body(int N, const double* __restrict__
     __syncthreads();
     for (int i = tid; i < n; i += nthr) w[i] = weight[base + i];
     __syncthreads();
-    if (one_chunk) { if (tid == 0) s_acc = seq_sum<false, kSeqBlk>(0.0, w, n); __syncthreads(); run = s_acc; }
-    else run = chain_exact<false, false, kIpt>(run, w, nullptr, n, base == 0 ? kHead : 0);   // sum += weight(i), particle_filter.cpp:446-450
+    if (plain) { if (tid == 0) s_acc = seq_sum<false, kSeqBlk>(run, w, n); __syncthreads(); run = s_acc; }
+    else if constexpr (PAR) run = chain_exact<false, false, kIpt>(run, w, nullptr, n, base == 0 ? kHead : 0);   // sum += weight(i), particle_filter.cpp:446-450
   }
   __syncthreads();
   const double sum = run;
@@ -2060,8 +2063,8 @@ __device__ __forceinline__ void normalize_body(int N, const double* __restrict__
     __syncthreads();
     for (int i = tid; i < n; i += nthr) { const double v = weight[base + i] / sum; w[i] = v; weight_out[base + i] = v; }
     __syncthreads();
-    if (one_chunk) { if (tid == 0) s_acc = seq_sum<true, kSeqBlk>(0.0, w, n); __syncthreads(); run = s_acc; }
-    else run = chain_exact<true, false, kIpt>(run, w, nullptr, n, base == 0 ? kHead : 0);    // normal_sqrd_sum_ += w * w, :458-461
+    if (plain) { if (tid == 0) s_acc = seq_sum<true, kSeqBlk>(run, w, n); __syncthreads(); run = s_acc; }
+    else if constexpr (PAR) run = chain_exact<true, false, kIpt>(run, w, nullptr, n, base == 0 ? kHead : 0);    // normal_sqrd_sum_ += w * w, :458-461
   }
   __syncthreads();
   if (tid == 0) {
@@ -2085,9 +2088,9 @@ __device__ __forceinline__ void normalize_body(int N, const double* __restrict__
     if (!one_chunk) for (int i = tid; i < n; i += nthr) w[i] = weight_out[base + i];  // (one chunk: w[] still holds them)
     __syncthreads();
     // c = weight(0); c += weight(i), particle_filter.cpp:478,492 — every c[i] kept
-    if (one_chunk) {
+    if (plain) {
       if (tid == 0) {
-        double c = 0.0;
+        double c = run;
         const double2* w2 = reinterpret_cast<const double2*>(w);
         double2* c2 = reinterpret_cast<double2*>(cl);
         int i = 0;
@@ -2099,8 +2102,11 @@ __device__ __forceinline__ void normalize_body(int N, const double* __restrict__
           for (int q = 0; q < 8; ++q) { double2 o; c += a[q].x; o.x = c; c += a[q].y; o.y = c; c2[(i >> 1) + q] = o; }
         }
         for (; i < n; ++i) { c += w[i]; cl[i] = c; }
+        s_acc = c;
       }
-    } else run = chain_exact<false, true, kIpt>(run, w, cl, n, base == 0 ? kHead : 0);
+      __syncthreads();
+      run = s_acc;
+    } else if constexpr (PAR) run = chain_exact<false, true, kIpt>(run, w, cl, n, base == 0 ? kHead : 0);
     __syncthreads();
     if (!one_chunk) for (int i = tid; i < n; i += nthr) cs[base + i] = cl[i];
   }
@@ -2148,7 +2154,7 @@ __global__ __launch_bounds__(256) void rbpf_normalize(int N, const double* __res
                                                       int* __restrict__ children = nullptr) {
   __shared__ __attribute__((aligned(16))) double w[kNormChunk], cl[kNormChunk];
   if (gate_prev && *gate_prev) return;
-  normalize_body<256>(N, zp, weight, weight_out, cs, parent, out, w, cl, gate, seq, seq_val, children);
+  normalize_body<256, true>(N, zp, weight, weight_out, cs, parent, out, w, cl, gate, seq, seq_val, children);
 }
 
 // ---- the default map update: box counters ------------------------------------------------------------------------
@@ -2213,7 +2219,7 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
   // costing a second stream, an event and a dependent boundary); the particles' workgroups follow
   if (nz.N > 0 && blockIdx.x == 0) {
     double* w = reinterpret_cast<double*>(lds_i);
-    normalize_body<NT>(nz.N, nz.zp, nz.weight, nz.weight_out, nz.cs, nz.parent, nz.out, w, w + kNormChunk, nz.gate, nz.seq, nz.seq_val,
+    normalize_body<NT, false>(nz.N, nz.zp, nz.weight, nz.weight_out, nz.cs, nz.parent, nz.out, w, w + kNormChunk, nz.gate, nz.seq, nz.seq_val,
                    nz.children);
     return;
   }
