@@ -198,6 +198,7 @@ def main():
         from rtn_amd.comm import Comm
         try:
             comm = Comm.from_torch_distributed(local_rank)
+            comm.selftest(1 << 16)   # one all-gather + one ring of sends through the library's transport, checked, before anything is timed
             ok = torch.ones(1, device=device)
         except Exception as e:  # noqa: BLE001 — the line says which exchange ran ("exchange"); the Python path is the round-2 one
             print(f"[bench rank {rank}] in-library communicator unavailable ({e}); using the torch.distributed exchange", file=sys.stderr, flush=True)

@@ -45,6 +45,10 @@ int tbnav_comm_create(const uint8_t id[TBNAV_COMM_ID_BYTES], int32_t nranks, int
 int tbnav_comm_create_local(int32_t n, const int32_t* devices, tbnav_comm** out);
 /* Destroys one communicator (a local group's shared state goes with its last member). */
 void tbnav_comm_destroy(tbnav_comm* c);
+/* Runs every transport call the library makes — one all-gather, one ring of point-to-point messages (a message to itself when
+ * there is one rank: ncclSend / ncclRecv execute) — on `bytes` of pattern data and checks the result on the host.  Collective over
+ * the communicator's ranks; communicators made by tbnav_comm_create (and local groups of one). */
+int tbnav_comm_selftest(tbnav_comm* c, uint64_t bytes);
 int tbnav_comm_rank(const tbnav_comm* c);
 int tbnav_comm_size(const tbnav_comm* c);
 int tbnav_comm_device(const tbnav_comm* c);

@@ -148,6 +148,7 @@ def lib() -> C.CDLL:
         "tbnav_comm_create": (C.c_int, [vp, i32, i32, i32, C.POINTER(vp)]),
         "tbnav_comm_create_local": (C.c_int, [i32, vp, vp]),
         "tbnav_comm_destroy": (None, [vp]),
+        "tbnav_comm_selftest": (C.c_int, [vp, u64]),
         "tbnav_comm_rank": (C.c_int, [vp]),
         "tbnav_comm_size": (C.c_int, [vp]),
         "tbnav_comm_device": (C.c_int, [vp]),

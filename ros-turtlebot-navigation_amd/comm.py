@@ -61,6 +61,10 @@ class Comm:
     device = property(lambda self: self._L.tbnav_comm_device(self._h))
     uses_rccl = property(lambda self: bool(self._L.tbnav_comm_uses_rccl(self._h)))
 
+    def selftest(self, nbytes: int = 1 << 20):
+        """One all-gather and one ring of point-to-point messages through this communicator's transport, checked (collective)."""
+        capi.check(self._L.tbnav_comm_selftest(self._h, nbytes), "tbnav_comm_selftest")
+
     def close(self):
         if self._owns and getattr(self, "_h", None) is not None and self._h.value:
             self._L.tbnav_comm_destroy(self._h)

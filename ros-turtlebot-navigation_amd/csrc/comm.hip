@@ -276,6 +276,38 @@ void tbnav_comm_destroy(tbnav_comm* c) {
   delete c;
 }
 
+// Every transport call this library makes, once, on `bytes` of pattern data, checked on the host: an all-gather (each rank's
+// block is its rank number repeated) and a ring of point-to-point messages (rank r sends to r + 1, receives from r - 1; with one
+// rank that is a message to itself — RCCL supports it — so ncclSend / ncclRecv execute even on a one-GPU box).  Collective:
+// every rank of the communicator calls it (a one-process group: pass member 0, the group's members are walked here).
+int tbnav_comm_selftest(tbnav_comm* c, uint64_t bytes) {
+  if (!c || bytes == 0 || bytes > (1ull << 28)) return TBNAV_ERR_INVALID_ARG;
+  const int P = c->nranks;
+  // a one-process group is driven as a whole from its member 0 — which this library never keeps a list of: only the multi-process
+  // form and groups of one are tested here (the groups' exchanges are exercised through tbnav_mppi_group_* / tbnav_rbpf_group_*)
+  if (c->group && P != 1) return TBNAV_ERR_UNSUPPORTED;
+  DevGuard dg(c->device);
+  hipStream_t st = nullptr;
+  TBNAV_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  unsigned char *d_send = nullptr, *d_all = nullptr, *d_recv = nullptr;
+  int rc = TBNAV_OK;
+  std::vector<unsigned char> h((size_t)bytes * P);
+  auto done = [&](int code) { (void)hipStreamDestroy(st); (void)hipFree(d_send); (void)hipFree(d_all); (void)hipFree(d_recv); return code; };
+  if (hipMalloc((void**)&d_send, bytes) != hipSuccess || hipMalloc((void**)&d_all, bytes * P) != hipSuccess || hipMalloc((void**)&d_recv, bytes) != hipSuccess) return done(TBNAV_ERR_HIP);
+  if (hipMemsetAsync(d_send, 0x40 + c->rank, bytes, st) != hipSuccess || hipMemsetAsync(d_all, 0, bytes * P, st) != hipSuccess || hipMemsetAsync(d_recv, 0, bytes, st) != hipSuccess) return done(TBNAV_ERR_HIP);
+  const void* sp = d_send; void* rp = d_all;
+  rc = tbnav::comm_all_gather(1, &c, &sp, &rp, (size_t)bytes, &st);
+  if (rc != TBNAV_OK) return done(rc);
+  std::vector<tbnav::P2P> sends{tbnav::P2P{(c->rank + 1) % P, d_send, (size_t)bytes}}, recvs{tbnav::P2P{(c->rank + P - 1) % P, d_recv, (size_t)bytes}};
+  rc = tbnav::comm_exchange(1, &c, &sends, &recvs, &st);
+  if (rc != TBNAV_OK) return done(rc);
+  if (hipMemcpyAsync(h.data(), d_all, bytes * P, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return done(TBNAV_ERR_HIP);
+  for (int q = 0; q < P; ++q) for (uint64_t i = 0; i < bytes; ++i) if (h[(size_t)q * bytes + i] != (unsigned char)(0x40 + q)) return done(TBNAV_ERR_HIP);
+  if (hipMemcpy(h.data(), d_recv, bytes, hipMemcpyDeviceToHost) != hipSuccess) return done(TBNAV_ERR_HIP);
+  for (uint64_t i = 0; i < bytes; ++i) if (h[i] != (unsigned char)(0x40 + (c->rank + P - 1) % P)) return done(TBNAV_ERR_HIP);
+  return done(TBNAV_OK);
+}
+
 int tbnav_comm_rank(const tbnav_comm* c) { return c ? c->rank : -1; }
 int tbnav_comm_size(const tbnav_comm* c) { return c ? c->nranks : -1; }
 int tbnav_comm_device(const tbnav_comm* c) { return c ? c->device : -1; }

@@ -27,6 +27,7 @@ def test_rccl_communicator_of_one_rank_carries_the_mppi_tick(gpu_pkg):
     from rtn_amd.comm import Comm
     comm = Comm.create(Comm.unique_id(), 1, 0, 0)
     assert (comm.rank, comm.size, comm.device, comm.uses_rccl) == (0, 1, 0, True)
+    comm.selftest(1 << 20)   # ncclAllGather + ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd (a message to itself) really execute
     for K, horizon in ((1024, 0.5), (40000, 0.24)):
         d = mppi_cfg(K, horizon)
         T = orc.mppi_steps(d)
