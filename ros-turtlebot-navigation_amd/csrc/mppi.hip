@@ -2070,9 +2070,18 @@ int tbnav_mppi_enqueue_rng_batch(tbnav_mppi* h, const double* x0s, int32_t x0_st
     //  later long call does not pay the ~1 ms of capture + instantiation)
     // the first tick after set_controls / set_initial_controls reads the vector unshifted: keep it out of the graph
     if (!h->pending_shift) { const int rc = tbnav_mppi_enqueue_rng(h, x0s, seed, first_tick, stream); if (rc != TBNAV_OK) return rc; ++i; }
-    const bool same = h->tg_exec && h->tg_epoch == h->cfg_epoch && h->tg_seed == seed && h->tg_stream == st && h->tg_ucur == h->ucur &&
-                      std::memcmp(h->tg_x0, x0s, sizeof h->tg_x0) == 0;
-    if (!same) {
+    const bool usable = h->tg_exec && h->tg_epoch == h->cfg_epoch && h->tg_seed == seed && h->tg_stream == st &&
+                        std::memcmp(h->tg_x0, x0s, sizeof h->tg_x0) == 0;
+    // (the graph has the controls' double buffer baked in as it stood at capture: on the other parity ONE plain tick brings it
+    //  back — a rebuild would cost ~0.5 ms inside the caller's batch.  Shorter chunks were measured and dropped: a 10-tick graph
+    //  replays at 9.9-10.2 us per tick against 8.9 for plain launches — a replay's fixed cost needs ~100 ticks to amortise)
+    if (usable && h->tg_ucur != h->ucur && n_ticks - i > kGraphTicks) {
+      const int rc = tbnav_mppi_enqueue_rng(h, x0s, seed, first_tick + (uint64_t)i, stream);
+      if (rc != TBNAV_OK) return rc;
+      ++i;
+    }
+    const bool same = usable && h->tg_ucur == h->ucur;
+    if (!same && (!usable || n_ticks - i >= kGraphTicks)) {
       // (another stream may not have run the previous replay's tick-advance node yet: what the device word holds is unknown)
       h->tg_dev_tick = ~0ull;
       if (h->tg_exec) { (void)hipGraphExecDestroy(h->tg_exec); h->tg_exec = nullptr; }

@@ -448,7 +448,7 @@ def test_batch_enqueue_by_graph_replay_equals_tick_by_tick(gpu_pkg, K, horizon):
     x0 = (0.05, -0.02, 0.3)
     for m in (ma, mb):
         m.setWaypoint(*WAYPOINTS[1])
-    for first, n in ((0, 250), (250, 330)):
+    for first, n in ((0, 250), (250, 330), (580, 4), (584, 23), (607, 10), (617, 11), (628, 1), (629, 20)):   # long chunks, short chunks, both parities of the double buffer
         ma.enqueueRngBatch(x0, 99, first, n, st)
         for i in range(n):
             mb.enqueueRng(x0, 99, first + i, st)
