@@ -220,7 +220,8 @@ int tbnav_rbpf_copy_particle(tbnav_rbpf* dst, int32_t dst_slot, tbnav_rbpf* src,
  * waits once per scan.  A resample that moves particles: one all-gather of blob sizes, one batched export, one ncclSend /
  * ncclRecv per (source, destination) pair inside one group, one batched import, then an all-gather of the ranks' statuses
  * (a rank whose tile pool is exhausted stops every rank with TBNAV_ERR_POOL_EXHAUSTED instead of leaving them in the next
- * collective).  `normals` is this rank's slice of the ensemble's stream + the resampling offset (as for _slam_local), or
+ * collective).  Every scan also ends with an all-gather of the ranks' statuses (4 bytes each): what the reference reports by
+ * throwing — a particle out of the world, eta is 0 — is returned by EVERY rank at the same scan (the lowest failing rank's code).  `normals` is this rank's slice of the ensemble's stream + the resampling offset (as for _slam_local), or
  * NULL: device noise — the handle is given its place in the ensemble's counter space (tbnav_rbpf_set_rng_shard), so the
  * sharded filter draws what the unsharded one would.  Not available in the REFERENCE distance-field mode.  comm = NULL
  * detaches.  The communicator must outlive the handle's last scan; the handle does not own it. */

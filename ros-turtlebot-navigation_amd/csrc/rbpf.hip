@@ -4995,13 +4995,33 @@ int sharded_scan(int n, tbnav_rbpf* const* hs, const float* scan, int n_beams, c
   }
   // ---- C: the host waits once per member (the reference's SLAM() is synchronous)
   int status = TBNAV_OK;
+  std::vector<int> lstat(n, TBNAV_OK);
   for (int r = 0; r < n; ++r) {
     tbnav_rbpf* h = hs[r];
     DeviceGuard guard(h->device);
     TBNAV_HIP(hipStreamSynchronize(h->stream2));
-    const int rc = scan_finish(h, tk[r], &lst[r]);
-    if (rc != TBNAV_OK && status == TBNAV_OK) status = rc;
+    lstat[r] = scan_finish(h, tk[r], &lst[r]);
+    if (lstat[r] != TBNAV_OK && status == TBNAV_OK) status = lstat[r];
     if (local_out) local_out[r] = lst[r];
+  }
+  if (n < P) {
+    // Ranks outside this process: what the reference reports by throwing (a particle left the world, eta is 0 ...) happens to the
+    // rank that holds the particle.  Every rank must stop at the SAME scan with the same status — a rank that went on alone would
+    // sit in the next scan's all-gather for ever: one all-gather of the ranks' statuses per scan (4 bytes each; ~1 % of a scan).
+    std::vector<const void*> send(n);
+    std::vector<void*> recv(n);
+    for (int r = 0; r < n; ++r) {
+      DeviceGuard guard(hs[r]->device);
+      TBNAV_HIP(hipMemcpyAsync(hs[r]->d_status, &lstat[r], sizeof(int), hipMemcpyHostToDevice, hs[r]->stream));
+      send[r] = hs[r]->d_status; recv[r] = hs[r]->d_status + 1;
+    }
+    { const int rc = tbnav::comm_all_gather(n, comms.data(), send.data(), recv.data(), sizeof(int), s1.data()); if (rc != TBNAV_OK) return rc; }
+    std::vector<int> all(P);
+    { DeviceGuard guard(hs[0]->device);
+      TBNAV_HIP(hipMemcpyAsync(all.data(), hs[0]->d_status + 1, sizeof(int) * P, hipMemcpyDeviceToHost, hs[0]->stream));
+      TBNAV_HIP(hipStreamSynchronize(hs[0]->stream)); }
+    status = TBNAV_OK;
+    for (int q = 0; q < P; ++q) if (all[q] != TBNAV_OK) { status = all[q]; break; }   // (the lowest rank's, on every rank)
   }
   const NormOut no = hs[0]->h_norm[1];
   out->sum_w = no.sum_w; out->sq_sum = no.sq_sum; out->neff = no.neff; out->resampled = no.resampled;
