@@ -32,6 +32,7 @@
 #include <new>
 #include <type_traits>
 #include <atomic>
+#include <map>
 #include <thread>
 #include <vector>
 #include <sched.h>
@@ -2193,9 +2194,15 @@ __device__ unsigned long long g_phase_w[16];
 #define PHASE_STAMP_W(i)
 #endif
 #ifdef TBNAV_PHASE_PROF
-__device__ unsigned long long g_trace[16][16];  // [wave][stamp] of ONE workgroup (blockIdx.x == 100): 10 ns ticks since its first stamp
-#define TRACE_W(i) do { if (blockIdx.x == 100 && (threadIdx.x & 63) == 0) g_trace[threadIdx.x >> 6][i] = wall_clock64(); } while (0)
+__device__ unsigned long long g_trace[2][16][16];  // [which][wave][stamp] of TWO workgroups (blockIdx.x == 100: first round of residents; 900: second): 10 ns ticks
+#define TRACE_W(i) do { if ((blockIdx.x == 100 || blockIdx.x == 900) && (threadIdx.x & 63) == 0) g_trace[blockIdx.x == 900][threadIdx.x >> 6][i] = wall_clock64(); } while (0)
+__device__ unsigned long long g_wg[4096][3];    // [workgroup] entry, exit (10 ns ticks), XCC_ID << 32 | HW_ID — of the LAST launch
+#define WG_IN() do { if (threadIdx.x == 0 && blockIdx.x < 4096) { g_wg[blockIdx.x][0] = wall_clock64(); \
+  g_wg[blockIdx.x][2] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned int)__builtin_amdgcn_s_getreg(63492); } } while (0)
+#define WG_OUT() do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_wg[blockIdx.x][1] = wall_clock64(); } while (0)
 #else
+#define WG_IN()
+#define WG_OUT()
 #define TRACE_W(i)
 #endif
 #ifndef TBNAV_EXP
@@ -2249,6 +2256,7 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
   unsigned int* tab = M.table + (size_t)p * M.TT;
   unsigned int* shed = M.shed + (size_t)p * M.TT;
   TRACE_W(0);
+  WG_IN();
   if (wid == 0) {
     const double x = pose[p * 3 + 1], y = pose[p * 3 + 2];
     int rx0 = 0, ry0 = 0;
@@ -2277,6 +2285,9 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
   }
   __syncthreads();
   TRACE_W(1);
+#if defined(TBNAV_STOP) && TBNAV_STOP == 1
+  return;  // (development: instruction counts / kernel time up to this phase — tools/README.md)
+#endif
   // (workgroup-uniform values read from LDS are moved to scalar registers: the kernel has 64 VGPRs to live in)
   auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
   const int rx = uni(srx), ry = uni(sry);
@@ -2308,6 +2319,9 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
   }
   __syncthreads();
   TRACE_W(2);
+#if defined(TBNAV_STOP) && TBNAV_STOP == 2
+  return;  // (development: instruction counts / kernel time up to this phase — tools/README.md)
+#endif
   if (bad) { if (tid == 0) atomicOr(&err[0], 1); return; }
   auto robot_chain = [&](int most) {  // (lane 0 of the last wave) up to `most` more adds of the robot cell's chain
     int left = robot_left;
@@ -2396,6 +2410,9 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
     __syncthreads();
     PHASE_STAMP_W(0);
     TRACE_W(4);
+#if defined(TBNAV_STOP) && TBNAV_STOP == 3
+  return;  // (development: instruction counts / kernel time up to this phase — tools/README.md)
+#endif
     // 1. events and counters
     for (int b = tid; b < Bv; b += nthr) { const int e = exy[b]; if (in_band(e)) record(tile[cell_t(e)], (b << 1) | 1); }
     TRACE_W(5);
@@ -2464,6 +2481,9 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
     TRACE_W(6);
     __syncthreads();  // every event is recorded
     TRACE_W(7);
+#if defined(TBNAV_STOP) && TBNAV_STOP == 4
+  return;  // (development: instruction counts / kernel time up to this phase — tools/README.md)
+#endif
     PHASE_STAMP_W(1);
     // 2. requests and marks in one pass.  The band as PAIRS of cells (16 bytes of a map tile's row, two tile words): pair
     //    tid + i * nthr for i < 4 — consecutive lanes take consecutive pairs, so a wave's request is whole cache lines.  A
@@ -2493,7 +2513,11 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
       if (w.x | w.y) {
         const int mt = map_tile(cx, cy);
         mt_touch[mt] = 1;
+#if !(TBNAV_EXP & 64)
         v[i] = *reinterpret_cast<const double2*>(P.lo + (size_t)mt_id[mt] * kTileCells + in_tile(cx, cy));
+#else
+        v[i] = double2{(double)((size_t)mt_id[mt] * kTileCells + in_tile(cx, cy)) * 1e-300, 0.0};  // (development: no loads)
+#endif
       }
     });
     for (int first = kSl * nthr; first < np; first += kSl * nthr)  // (bands of more than 8 * nthr cells: marks only, their loads follow)
@@ -2510,6 +2534,9 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
     __syncthreads();
     PHASE_STAMP_W(2);
     TRACE_W(9);
+#if defined(TBNAV_STOP) && TBNAV_STOP == 5
+  return;  // (development: instruction counts / kernel time up to this phase — tools/README.md)
+#endif
     // C. make the written tiles private to the particle (first write after a resample, or first touch of the area): ONE pop
     //    of the free ring for all of them, then one wave per tile copies 8 KB.  Usually there is nothing to do.
     if (tq >= 0 && tq < mtn && mt_touch[tq]) {
@@ -2655,6 +2682,9 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
     TRACE_W(12);
     __syncthreads();  // val_e is complete
     TRACE_W(13);
+#if defined(TBNAV_STOP) && TBNAV_STOP == 6
+  return;  // (development: instruction counts / kernel time up to this phase — tools/README.md)
+#endif
     PHASE_STAMP_W(4);
     // 3c. the pairs: a plain cell adds its count, an end-point or hot cell takes the value worked out for it, an untouched one
     //     keeps its own; the pair goes back as one 16-byte store (the tile is private to the particle and nobody else writes
@@ -2721,6 +2751,7 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
 #ifdef TBNAV_PHASE_PROF
   if (tid == 0) { atomicAdd(&g_phase_w[15], 1ull); }
 #endif
+  WG_OUT();
 }
 
 // The exact-transform kernels below (stored-field modes, on-demand fields) work on dense bitmap rows and per-row
@@ -4391,14 +4422,55 @@ void tbnav_rbpf_destroy(tbnav_rbpf* h) {
         std::fprintf(stderr, "\n");
       }
     }
-    unsigned long long tr[16][16];
-    if (hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_trace), sizeof(tr)) == hipSuccess && tr[0][0]) {
-      std::fprintf(stderr, "[raycast_box trace of workgroup 100, us since its first stamp; columns: entry, pose barrier, end-point barrier, flags, flag barrier, own events, walk, walk barrier, requests, barrier, tiles private, replay, overflow+hot, barrier, stores]\n");
-      unsigned long long t0 = ~0ull;
-      for (int w = 0; w < 16; ++w) if (tr[w][0] && tr[w][0] < t0) t0 = tr[w][0];
-      for (int w = 0; w < 16; ++w) {
-        std::fprintf(stderr, "  wave %2d:", w);
-        for (int i = 0; i < 15; ++i) std::fprintf(stderr, " %5.2f", tr[w][i] ? (double)(tr[w][i] - t0) * 0.01 : -1.0);
+    unsigned long long tr[2][16][16];
+    if (hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_trace), sizeof(tr)) == hipSuccess && tr[0][0][0]) {
+      for (int g = 0; g < 2; ++g) {
+        std::fprintf(stderr, "[raycast_box trace of workgroup %d, us since its first stamp; columns: entry, pose barrier, end-point barrier, flags, flag barrier, own events, walk, walk barrier, requests, barrier, tiles private, replay, overflow+hot, barrier, stores]\n", g ? 900 : 100);
+        unsigned long long t0 = ~0ull;
+        for (int w = 0; w < 16; ++w) if (tr[g][w][0] && tr[g][w][0] < t0) t0 = tr[g][w][0];
+        for (int w = 0; w < 16; ++w) {
+          std::fprintf(stderr, "  wave %2d:", w);
+          for (int i = 0; i < 15; ++i) std::fprintf(stderr, " %5.2f", tr[g][w][i] ? (double)(tr[g][w][i] - t0) * 0.01 : -1.0);
+          std::fprintf(stderr, "\n");
+        }
+      }
+    }
+    {
+      static unsigned long long wg[4096][3];
+      if (hipMemcpyFromSymbol(wg, HIP_SYMBOL(g_wg), sizeof(wg)) == hipSuccess && wg[1][0]) {
+        int n = 0;
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (int i = 0; i < 4096; ++i) if (wg[i][0] && wg[i][1]) { ++n; t0 = std::min(t0, wg[i][0]); t1 = std::max(t1, wg[i][1]); }
+        std::fprintf(stderr, "[raycast_box workgroups of the last launch] %d recorded, first entry to last exit %.2f us\n", n, (double)(t1 - t0) * 0.01);
+        const int nb = 16;
+        const double span = (double)(t1 - t0);
+        int active[nb] = {0}, starts[nb] = {0};
+        double dur_by_start[nb] = {0};
+        for (int i = 0; i < 4096; ++i) if (wg[i][0] && wg[i][1]) {
+          const int bs = std::min(nb - 1, (int)((double)(wg[i][0] - t0) / span * nb));
+          ++starts[bs]; dur_by_start[bs] += (double)(wg[i][1] - wg[i][0]) * 0.01;
+          for (int b = 0; b < nb; ++b) { const double tm = t0 + (b + 0.5) * span / nb; if ((double)wg[i][0] <= tm && tm < (double)wg[i][1]) ++active[b]; }
+        }
+        std::fprintf(stderr, "  time bin (%.2f us each):", span * 0.01 / nb);
+        for (int b = 0; b < nb; ++b) std::fprintf(stderr, " %5d", b);
+        std::fprintf(stderr, "\n  resident at mid-bin:    ");
+        for (int b = 0; b < nb; ++b) std::fprintf(stderr, " %5d", active[b]);
+        std::fprintf(stderr, "\n  entered in bin:         ");
+        for (int b = 0; b < nb; ++b) std::fprintf(stderr, " %5d", starts[b]);
+        std::fprintf(stderr, "\n  mean residence (us):    ");
+        for (int b = 0; b < nb; ++b) std::fprintf(stderr, " %5.1f", starts[b] ? dur_by_start[b] / starts[b] : 0.0);
+        std::map<unsigned long long, int> per_cu, per_xcc;
+        for (int i = 0; i < 4096; ++i) if (wg[i][0] && wg[i][1]) {
+          const unsigned int hw = (unsigned int)wg[i][2], xcc = (unsigned int)(wg[i][2] >> 32) & 0xF;
+          ++per_cu[((unsigned long long)xcc << 16) | (hw & 0xFF00u)];   // cu_id [11:8], sh_id [12], se_id [15:13]
+          ++per_xcc[xcc];
+        }
+        int hist[16] = {0};
+        for (auto& kv : per_cu) ++hist[std::min(15, kv.second)];
+        std::fprintf(stderr, "\n  CUs that ran workgroups: %zu; CUs by number of workgroups run:", per_cu.size());
+        for (int k = 1; k < 16; ++k) if (hist[k]) std::fprintf(stderr, " %d:%d", k, hist[k]);
+        std::fprintf(stderr, "\n  workgroups per XCC:");
+        for (auto& kv : per_xcc) std::fprintf(stderr, " %d", kv.second);
         std::fprintf(stderr, "\n");
       }
     }

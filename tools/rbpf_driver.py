@@ -6,6 +6,9 @@ import __graft_entry__ as g
 g.load_package()
 import bench_rbpf, rbpf_cases as rc
 from rtn_amd.rbpf import ParticleFilter, default_params
+if os.environ.get("TBNAV_DEV_LIB"):   # (A/B runs of two builds of the library in one gpurun call)
+    from rtn_amd import capi
+    capi.LIB_PATH = os.path.abspath(os.environ["TBNAV_DEV_LIB"])
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 n_scans = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 dev_noise = len(sys.argv) > 3 and sys.argv[3] in ("dev", "plain")   # standard normals drawn on the device (bench mode)

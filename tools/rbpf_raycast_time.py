@@ -1,4 +1,5 @@
-"""Kernel time of the map update on the bench workload (BASELINE configs[2]) from HIP events: python tools/rbpf_raycast_time.py [N ...]"""
+"""Kernel time of the map update on the bench workload (BASELINE configs[2]) from HIP events: python tools/rbpf_raycast_time.py [N ...]
+(TBNAV_DEV_LIB=<path to another build of libtbnav_hip.so> for A/B runs of two builds in one gpurun call — read here, not by the package)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -8,6 +9,8 @@ import torch
 import bench_rbpf
 from rtn_amd import capi
 from rtn_amd.rbpf import ParticleFilter, default_params
+if os.environ.get("TBNAV_DEV_LIB"):
+    capi.LIB_PATH = os.path.abspath(os.environ["TBNAV_DEV_LIB"])
 steps, scans = bench_rbpf.workload(14)
 for N in [int(a) for a in sys.argv[1:]] or [1000, 4000]:
     pf = ParticleFilter(default_params(N=N, k=50, map_min=-10.0, map_max=10.0))
