@@ -185,6 +185,10 @@ int tbnav_rbpf_set_weights_from_global_dev(tbnav_rbpf* h, const int32_t* global_
  * resampling fires); weights_out (n_global, host) the normalised weights. */
 int tbnav_rbpf_resample_global(const double* weights_all, int64_t n_global, double z,
                                int32_t* parents_out, double* weights_out, tbnav_rbpf_stats* out);
+/* Parity-test hook: out[i] = x[i] after n[i] times x = fl(x + d[i]) as the map update evaluates a cell that n beams cross
+ * (grid_mapper.cpp:438-477 adds the same log-odds once per beam) — on the device, WITHOUT the chain of dependent adds (integer steps
+ * inside a binade, plain adds across its ends); must equal the plain loop bit for bit.  Host buffers; uses the current device. */
+int tbnav_rbpf_add_repeated(const double* x, const double* d, const int32_t* n, double* out, int64_t count);
 /* Re-populate this rank's slots from LOCAL parents (tables and state move on the device); -1 = keep. */
 int tbnav_rbpf_gather_local(tbnav_rbpf* h, const int32_t* local_parent /*[N], -1 = leave*/);
 /* A particle as one device buffer: header, state (pose, prev_pose, weight), the indices and 8 KB payloads of the

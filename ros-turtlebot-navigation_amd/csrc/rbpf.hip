@@ -1826,6 +1826,46 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : (NT == 512 ? 8 : 3)) void rbpf
 // its LOW end (xa, ya) — the robot's cell or, for a reversed ray, the end point — takes dmaj steps and moves c_t =
 // max(0, ceil((2 dmin t - dmaj) / (2 dmaj))) cells sideways (negated if neg); its free cells are the robot's cell and
 // the cells strictly between the ends.
+// n times  x = fl(x + d)  — the updates one cell takes from n beams (grid_mapper.cpp:438-477 adds the same log-odds once per beam) —
+// bit for bit WITHOUT the chain of n dependent adds (13 ns each for one lane: the robot's own cell takes one per beam).  While x
+// stays in one binade it is m * u (u = ulp(x), m a 53-bit integer) and d = kd * ud with ud = u / 2^sh: x + d = (m + q) u + rem ud
+// (q = kd >> sh, rem = the bits shifted out), which rounds to (m + q) u or (m + q + 1) u by rem against half a u — the SAME integer
+// step s every time, so j steps are m + j s (exact in 64-bit integers) as long as m + j s < 2^53.  What does not fit the pattern is
+// done with a plain add: a step that leaves the binade (the sum is then rounded to the coarser grid), a tie (rem == u / 2: round to
+// even alternates), opposite signs, x within a factor 4 of d, zeros, subnormals, infinities and NaNs.  (chain_exact is the same idea
+// for a sum of different addends.)
+__device__ __forceinline__ double add_repeated(double x, const double d, int n) {
+  constexpr unsigned long long kMant = (1ull << 52) - 1ull;
+  const unsigned long long bd = (unsigned long long)__double_as_longlong(d);
+  const int ed = (int)((bd >> 52) & 0x7FFull);
+  const unsigned long long kd = (bd & kMant) | (1ull << 52);
+  while (n > 0) {
+    const unsigned long long bx = (unsigned long long)__double_as_longlong(x);
+    const int ex = (int)((bx >> 52) & 0x7FFull), sh = ex - ed;
+    if (n < 4 || ((bx ^ bd) >> 63) != 0ull || sh < 2 || ex == 0x7FF || ed == 0 || ed == 0x7FF) { x += d; --n; continue; }
+    if (sh > 54) return x;  // |d| < ulp(x) / 4: no add changes x
+    const unsigned long long rem = kd & ((1ull << sh) - 1ull), half = 1ull << (sh - 1);
+    if (rem == half) { x += d; --n; continue; }
+    const unsigned long long s = (kd >> sh) + (rem > half ? 1ull : 0ull);
+    if (s == 0ull) return x;  // d is less than half an ulp of x: no add changes it
+    const unsigned long long m = (bx & kMant) | (1ull << 52);
+    const unsigned long long room = (1ull << 53) - 1ull - m;  // the steps that stay in the binade: m + j s <= 2^53 - 1
+    unsigned long long j = (unsigned long long)n;
+    if (__umul64hi(j, s) != 0ull || j * s > room) {
+      j = (unsigned long long)((double)room / (double)s);     // both exact in fp64 and the division is correctly rounded: floor or floor + 1
+      if (j * s > room) --j;
+    }
+    const unsigned long long mj = m + j * s;
+    x = __longlong_as_double((long long)((bx & (1ull << 63)) | ((unsigned long long)ex << 52) | (mj & kMant)));
+    n -= (int)j;
+    if (n > 0) { x += d; --n; }  // the step across the binade's end
+  }
+  return x;
+}
+__global__ void rbpf_add_repeated_test(const double* __restrict__ x, const double* __restrict__ d, const int* __restrict__ n, double* __restrict__ out, int count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) out[i] = add_repeated(x[i], d[i], n[i]);
+}
 struct RayP { int xa, ya, dmaj, dmin; bool ymajor, neg; };
 __device__ __forceinline__ RayP ray_packed(int x0, int y0, int x1, int y1) {
   const int dx = x1 - x0, dy = y1 - y0, adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
@@ -2211,7 +2251,8 @@ __device__ unsigned long long g_wg[4096][3];    // [workgroup] entry, exit (10 n
 constexpr int kBoxEv = 8;     // events a slot holds before it is replayed exhaustively
 constexpr int kHotSide = 7;   // the kHotSide x kHotSide cells round the robot are candidates for a lane of their own ...
 constexpr int kHotMin = 16;   // ... when they collect at least this many free adds
-__host__ __device__ constexpr size_t box_lds_bytes(size_t cap, size_t bv) { return 4 * cap + 8 * (bv + 64) + 4 * 3 * bv + 2 * kBoxEv * bv; }
+constexpr int kVeryHot = 80;  // ... and from this many on they are worked out without the chain of adds (add_repeated)
+__host__ __device__ constexpr size_t box_lds_bytes(size_t cap, size_t bv) { return 4 * cap + 8 * (bv + 64) + 4 * 2 * bv + 2 * kBoxEv * bv; }
 template <int NT>
 __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, MapT M, const double2* __restrict__ beams,
                                                           const double* __restrict__ pose, const double* __restrict__ sens,
@@ -2232,14 +2273,14 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
   }
   const int Bv = c.Bv;
   unsigned int* tile = reinterpret_cast<unsigned int*>(lds_i);         // (tile_cap is a multiple of 8)
-  unsigned short* ev = reinterpret_cast<unsigned short*>(lds_i + tile_cap);  // [n_own][kBoxEv]  beam << 1 | occupied  (16 bytes a slot, 16-byte aligned)
+  unsigned short* ev = reinterpret_cast<unsigned short*>(lds_i + tile_cap);  // [Bv][kBoxEv]  beam << 1 | occupied  (16 bytes a slot, 16-byte aligned)
   double* val_e = reinterpret_cast<double*>(lds_i + tile_cap + 4 * Bv);      // [Bv + 64] the value replayed for an end-point cell / a hot cell
   int* exy = lds_i + tile_cap + 4 * Bv + 2 * (Bv + 64);  // [Bv] end-point cell, x | y << 16
-  int* own = exy + Bv;                                   // [n_own] the first beam that ended in each distinct end-point cell of the band
-  int* ecnt = own + Bv;                                  // [n_own] events recorded (may exceed kBoxEv: overflow)
+  int* ecnt = exy + Bv;                                  // [Bv] events recorded in the slot of beam b — the FIRST beam that ended in its cell (0: b opened
+                                                         //      no slot; may exceed kBoxEv: overflow)
   constexpr unsigned int kFlag = 0x80000000u;
   constexpr int kEv = kBoxEv;
-  __shared__ int bad, bx0, bx1, by0, by1, n_own, srx, sry, n_need, nocc_delta, n_ovf;
+  __shared__ int bad, bx0, bx1, by0, by1, srx, sry, n_need, nocc_delta, n_ovf;
   __shared__ unsigned long long need_base;
   __shared__ unsigned int mt_id[kMapTilesMax];  // map tiles under the box: the tile the particle's table names (once written: its private tile)
   __shared__ int mt_touch[kMapTilesMax], mt_slot[kMapTilesMax], mt_priv[kMapTilesMax];
@@ -2247,7 +2288,7 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
   __shared__ int ovf[kWave];                    // slots whose event list overflowed (more than these: found by scanning)
   __shared__ double sh_pose[4];
   __shared__ double robot_v0, robot_v;  // the robot's own cell: its log-odds before the scan / after the adds applied so far
-  __shared__ int robot_cnt, robot_left; // beams with a free cell (each adds l_free to the robot's cell once) / adds still to apply
+  __shared__ int robot_cnt;             // beams with a free cell (each adds l_free to the robot's cell once)
   constexpr int nthr = NT, nw = NT / kWave;
   const int p = c.p0 + blockIdx.x - (nz.N > 0 ? 1 : 0), tid_k = threadIdx.x, tid = tid_k, lane = tid & (kWave - 1), wid = tid / kWave;
 #ifdef TBNAV_PHASE_PROF
@@ -2273,7 +2314,7 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
     }
     if (lane == 0) {
       sh_pose[0] = X; sh_pose[1] = Y; sh_pose[2] = st0; sh_pose[3] = ct0;
-      bad = robot_ok ? 0 : 1; bx0 = bx1 = rx0; by0 = by1 = ry0; n_own = 0; srx = rx0; sry = ry0;
+      bad = robot_ok ? 0 : 1; bx0 = bx1 = rx0; by0 = by1 = ry0; srx = rx0; sry = ry0;
       n_need = 0; nocc_delta = 0; n_ovf = 0; robot_cnt = 0;
     }
   } else {
@@ -2291,7 +2332,6 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
   // (workgroup-uniform values read from LDS are moved to scalar registers: the kernel has 64 VGPRs to live in)
   auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
   const int rx = uni(srx), ry = uni(sry);
-  double robot_old = 0.0;
   {
     const double X = sh_pose[0], Y = sh_pose[1], st = sh_pose[2], ct = sh_pose[3];
     for (int b0 = wid * kWave; b0 < Bv; b0 += nthr) {
@@ -2309,13 +2349,9 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
         if (has_free) atomicAdd(&robot_cnt, __popcll(has_free));
       }
     }
-    // The robot's own cell takes one add per beam — hundreds of DEPENDENT adds, microseconds for one lane.  Its count is
-    // known as soon as the end points are, so lane 0 of the last wave (which walks no ray) fetches the cell now and works
-    // the chain off in pieces between the barriers that follow, out of everybody's way.
-    if (tid == nthr - kWave) {
-      const unsigned int rt = tab[(rx >> kTSh) * M.TW + (ry >> kTSh)];
-      robot_old = P.lo[(size_t)rt * kTileCells + in_tile(rx, ry)];  // (used after the barrier: nothing waits for it here)
-    }
+    // (The robot's own cell takes one add per beam: lane 0 of the last wave, which walks no ray, fetches it and works the adds
+    //  out beside the walk — add_repeated: no chain of dependent adds.  Fetched HERE and looked at in front of the flag barrier, its
+    //  two dependent loads held the whole workgroup up: 1-3 us per particle once the chip is loaded.)
   }
   __syncthreads();
   TRACE_W(2);
@@ -2323,17 +2359,6 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
   return;  // (development: instruction counts / kernel time up to this phase — tools/README.md)
 #endif
   if (bad) { if (tid == 0) atomicOr(&err[0], 1); return; }
-  auto robot_chain = [&](int most) {  // (lane 0 of the last wave) up to `most` more adds of the robot cell's chain
-    int left = robot_left;
-    if (left <= 0) return;
-    const int k = left < most ? left : most;
-    double vv = robot_v;
-    int a = 0;
-    for (; a + 4 <= k; a += 4) { vv += c.d_free; vv += c.d_free; vv += c.d_free; vv += c.d_free; }
-    for (; a < k; ++a) vv += c.d_free;
-    robot_v = vv; robot_left = left - k;
-  };
-  if (tid == nthr - kWave) { robot_v0 = robot_old; robot_v = robot_old; robot_left = robot_cnt; }
   const int minx = uni(bx0), maxx = uni(bx1), maxy = uni(by1);
   const int miny = uni(by0) & ~1;                                   // the box starts on an even column and is an even number of
   const int bw = ((maxy | 1) + 1) - miny;                           // columns wide: a PAIR of cells never straddles a row or a map tile
@@ -2345,14 +2370,12 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
   // (the table work sits on the last threads of the LAST BUT ONE wave, which walks no ray — the last wave, which walks none
   //  either, has the robot cell's chain to work on)
   const int tq = nthr - kWave - 1 - tid;
-  unsigned int my_tab = 0u;
-  int my_ref = 0;
+  //  — the entry goes to LDS as it arrives (these threads have nothing else to do in the flag phase); the reference count of the
+  //  tile it names is fetched beside the walk: nothing needs it before phase C)
   if (tq >= 0 && tq < mtn) {
     const int qi = floor_div_small(tq, mty), qj = tq - qi * mty;
-    my_tab = tab[(tx0 + qi) * M.TW + (ty0 + qj)];
-    my_ref = my_tab ? P.ref[my_tab] : 0;
+    mt_id[tq] = tab[(tx0 + qi) * M.TW + (ty0 + qj)];
   }
-  if (tid == nthr - kWave) robot_chain(100);
   auto map_tile = [&](int cx, int cy) { return __mul24((cx >> kTSh) - tx0, mty) + ((cy >> kTSh) - ty0); };
   auto cell_ptr = [&](int cx, int cy) -> double* { return P.lo + (size_t)mt_id[map_tile(cx, cy)] * kTileCells + in_tile(cx, cy); };
   auto toggled = [&](int cx, int cy, bool now) {  // the cell crossed the occupied cut-off: its bit in the (private) tile, tile-row count, total
@@ -2382,29 +2405,21 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
       for (int t = tid; t < tile_cap / 4; t += nthr) t4[t] = uint4{0u, 0u, 0u, 0u};
       for (int b = tid; b < Bv; b += nthr) ecnt[b] = 0;
       for (int t = tid; t < kMapTilesMax; t += nthr) mt_touch[t] = 0;
-      if (tid == 0) { n_own = 0; n_need = 0; n_ovf = 0; }
+      if (tid == 0) { n_need = 0; n_ovf = 0; }
       __syncthreads();
     }
     auto cell_t = [&](int e) { return __mul24((e & 0xFFFF) - x0, bw) + ((e >> 16) - miny); };
     auto in_band = [&](int e) { return (unsigned int)((e & 0xFFFF) - x0) < (unsigned int)nr; };
-    // F. flag the end-point cells; the beam that finds the flag clear opens the cell's slot
+    // F. flag the end-point cells.  The first beam to reach a cell leaves its own index there as the cell's slot — one
+    //    compare-and-swap against the cleared word: winner and losers alike know the slot at once — and every beam records its
+    //    end-point event straight away (three dependent LDS operations; a flag, a slot counter, the slot number and then the
+    //    event in a phase of its own were six).
     for (int b = tid; b < Bv; b += nthr) {
       const int e = exy[b];
       if (!in_band(e)) continue;
-      const int t = cell_t(e);
-      const bool first = !(atomicOr(&tile[t], kFlag) & kFlag);
-      const unsigned long long fm = __ballot(first);  // (the lanes that open a slot take consecutive ones: one add per wave on the counter)
-      if (fm) {
-        const int leader = __ffsll((long long)fm) - 1;
-        int base = 0;
-        if (lane == leader) base = atomicAdd(&n_own, __popcll(fm));
-        base = __builtin_amdgcn_readlane(base, leader);
-        if (first) {
-          const int o = base + __popcll(fm & ((1ull << lane) - 1ull));
-          own[o] = b;
-          atomicOr(&tile[t], (unsigned int)o << 16);
-        }
-      }
+      const unsigned int mine = kFlag | ((unsigned int)b << 16);
+      const unsigned int old = atomicCAS(&tile[cell_t(e)], 0u, mine);
+      record(old ? old : mine, (b << 1) | 1);
     }
     TRACE_W(3);
     __syncthreads();
@@ -2413,11 +2428,18 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
 #if defined(TBNAV_STOP) && TBNAV_STOP == 3
   return;  // (development: instruction counts / kernel time up to this phase — tools/README.md)
 #endif
-    // 1. events and counters
-    for (int b = tid; b < Bv; b += nthr) { const int e = exy[b]; if (in_band(e)) record(tile[cell_t(e)], (b << 1) | 1); }
+    // 1. the walk
     TRACE_W(5);
-    if (x0 == minx && tq >= 0 && tq < mtn) { mt_id[tq] = my_tab; mt_priv[tq] = (my_tab != 0u && my_ref == 1) ? 1 : 0; }
-    if (tid == nthr - kWave) robot_chain(clip ? 64 : 220);  // (the last wave walks no ray; the walk of a clipped band is shorter)
+    if (x0 == minx && tq >= 0 && tq < mtn) {
+      const unsigned int id = mt_id[tq];
+      const int rf = id ? P.ref[id] : 0;
+      mt_priv[tq] = (id != 0u && rf == 1) ? 1 : 0;
+    }
+    if (x0 == minx && tid == nthr - kWave) {  // the robot's own cell (the last wave walks no ray)
+      const unsigned int rt = tab[(rx >> kTSh) * M.TW + (ry >> kTSh)];
+      const double old = P.lo[(size_t)rt * kTileCells + in_tile(rx, ry)];
+      robot_v0 = old; robot_v = add_repeated(old, c.d_free, robot_cnt);
+    }
     {
       int S = Bv > 0 ? nthr / Bv : 1;  // segments per ray: as many as give every thread at most one task
       S = S < 1 ? 1 : (S > 4 ? 4 : S);
@@ -2523,9 +2545,9 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
     for (int first = kSl * nthr; first < np; first += kSl * nthr)  // (bands of more than 8 * nthr cells: marks only, their loads follow)
       pairs(first, [&](int, uint2 w, int cx, int cy) { if (w.x | w.y) mt_touch[map_tile(cx, cy)] = 1; });
 #endif
-    const int n_cells = uni(n_own);
-    for (int o = tid; o < n_cells; o += nthr) {
-      const int e = exy[own[o]];
+    for (int o = tid; o < Bv; o += nthr) {
+      if (ecnt[o] == 0) continue;
+      const int e = exy[o];
       const bool robot_cell = (e & 0xFFFF) == rx && (e >> 16) == ry;  // an end point too: no events from the walk, replayed against every beam
       if (robot_cell) ecnt[o] = kEv + 1;
       if (robot_cell || ecnt[o] > kEv) { const int i = atomicAdd(&n_ovf, 1); if (i < kWave) ovf[i] = o; }
@@ -2567,10 +2589,10 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
 #if !(TBNAV_EXP & 16)
     // 3a. end-point cells whose slot holds every event: one lane each, the events sorted by beam in registers (a
     //     19-comparator network on the 8 sixteen-bit entries; an empty entry sorts last) and applied in that order
-    for (int o = tid; o < n_cells; o += nthr) {
+    for (int o = tid; o < Bv; o += nthr) {
       const int ne = ecnt[o];
-      if (ne > kEv) continue;
-      const int e = exy[own[o]], cx = e & 0xFFFF, cy = e >> 16;
+      if (ne == 0 || ne > kEv) continue;
+      const int e = exy[o], cx = e & 0xFFFF, cy = e >> 16;
       const double v0o = *cell_ptr(cx, cy);
       // the events in beam order without sorting: every beam that reaches the cell lies within a few beams of the slot's
       // own beam b0, so bit (beam - b0 + 32) of a 64-bit mask per kind orders them (checked per event; a stray one sends
@@ -2578,7 +2600,7 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
       // lowest ABSOLUTE beam index.
       const uint4 raw = *reinterpret_cast<const uint4*>(ev + o * kEv);
       const unsigned int w4[4] = {raw.x, raw.y, raw.z, raw.w};
-      const int base = own[o] - 32;
+      const int base = o - 32;
       unsigned long long m_free = 0ull, m_occ = 0ull;
       bool stray = false;
 #pragma unroll
@@ -2627,10 +2649,10 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
     {
       const int n_over = uni(n_ovf);
       const int trips = (Bv + kWave - 1) / kWave;
-      for (int i0 = wid; i0 < (n_over <= kWave ? n_over : n_cells); i0 += nw) {
+      for (int i0 = wid; i0 < (n_over <= kWave ? n_over : Bv); i0 += nw) {
         const int o = n_over <= kWave ? ovf[i0] : i0;  // (more overflowed slots than the list holds: scan them all)
         if (ecnt[o] <= kEv) continue;
-        const int eo = exy[own[o]], cx = eo & 0xFFFF, cy = eo >> 16;
+        const int eo = exy[o], cx = eo & 0xFFFF, cy = eo >> 16;
         const double v0o = *cell_ptr(cx, cy);
         double vv = v0o;
         const int ux = cx - rx, uy = cy - ry;
@@ -2657,21 +2679,28 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
     }
     // 3h. the cells round the robot: every ray starts there, so they collect tens to hundreds of adds — one long dependent
     //     chain each.  They get a lane of their own in the last wave (which has no end-point cell to replay), are then
-    //     flagged like end-point cells, and their group's owner takes the value from val_e.
-    if (wid == nw - 1 && lane < kHotSide * kHotSide) {
+    //     flagged like end-point cells, and their group's owner takes the value from val_e.  The few that take kVeryHot adds or
+    //     more (the robot's neighbours: up to half the beams each) go to the last wave but one instead, which works them out
+    //     without the chain (add_repeated: a few hundred integer instructions per binade, worth it from about a hundred adds);
+    //     the two waves run side by side, so the phase lasts as long as a chain of kVeryHot adds, not of the longest.
+    if ((wid == nw - 1 || wid == nw - 2) && lane < kHotSide * kHotSide) {
       const int hi = floor_div_small(lane, kHotSide), hx = rx - kHotSide / 2 + hi, hy = ry - kHotSide / 2 + (lane - hi * kHotSide);
       if ((unsigned int)(hx - x0) < (unsigned int)nr && hy >= miny && hy < miny + bw) {
         const int t = __mul24(hx - x0, bw) + (hy - miny);
         const unsigned int f = tile[t];
-        const bool robot_cell = hx == rx && hy == ry;  // its chain is under way: what is left of it runs here, beside the others
-        if (!(f & kFlag) && (robot_cell ? f != 0u : (int)(f & 0xFFFFu) >= kHotMin)) {
+        const int cnq = (int)(f & 0xFFFFu);
+        const bool robot_cell = hx == rx && hy == ry;  // (worked out beside the walk)
+        const bool very = !robot_cell && cnq >= kVeryHot;
+        if (!(f & kFlag) && (robot_cell ? f != 0u : cnq >= kHotMin) && very == (wid == nw - 2)) {
           double v0o, vv;
-          int cnq;
-          if (robot_cell) { v0o = robot_v0; vv = robot_v; cnq = robot_left; }
-          else { v0o = *cell_ptr(hx, hy); vv = v0o; cnq = (int)(f & 0xFFFFu); }
-          int a = 0;
-          for (; a + 4 <= cnq; a += 4) { vv += c.d_free; vv += c.d_free; vv += c.d_free; vv += c.d_free; }
-          for (; a < cnq; ++a) vv += c.d_free;
+          if (robot_cell) { v0o = robot_v0; vv = robot_v; }
+          else if (very) { v0o = *cell_ptr(hx, hy); vv = add_repeated(v0o, c.d_free, cnq); }
+          else {
+            v0o = *cell_ptr(hx, hy); vv = v0o;
+            int a = 0;
+            for (; a + 4 <= cnq; a += 4) { vv += c.d_free; vv += c.d_free; vv += c.d_free; vv += c.d_free; }
+            for (; a < cnq; ++a) vv += c.d_free;
+          }
           tile[t] = kFlag | ((unsigned int)(Bv + lane) << 16);
           ++n_distinct;
           finish_end(Bv + lane, hx, hy, v0o, vv);
@@ -3861,7 +3890,7 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens,
     if (h->raycast_band_rows > 0) cap_win = std::min(cap_win, (h->raycast_band_rows * ((side + 2) & ~1L) + 7) & ~7L);
   }
   const size_t lds_win = box_lds_bytes((size_t)cap_win, (size_t)bvn);
-  if (cap_win > 0 && !h->ref_field && c.Bv < 32768 && h->raycast_form == 0 && nt >= 512 && lds_win <= (size_t)kMaxLds - 4096) {
+  if (cap_win > 0 && !h->ref_field && c.Bv < 32768 - kWave && h->raycast_form == 0 && nt >= 512 && lds_win <= (size_t)kMaxLds - 4096) {
     // default: box counters (rbpf_raycast_box)
     unsigned long long* touched = h->count_touched ? h->d_touched : nullptr;
     const NormArgs na = nz ? *nz : NormArgs{0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, nullptr};
@@ -4675,6 +4704,26 @@ int tbnav_rbpf_resample_global(const double* w, int64_t n, double z, int32_t* pa
     parents[m] = i;
   }
   return TBNAV_OK;
+}
+
+int tbnav_rbpf_add_repeated(const double* x, const double* d, const int32_t* n, double* out, int64_t count) {
+  if (!x || !d || !n || !out || count <= 0 || count > (1 << 26)) return TBNAV_ERR_INVALID_ARG;
+  double *dx = nullptr, *dd = nullptr, *dout = nullptr;
+  int* dn = nullptr;
+  int rc = TBNAV_OK;
+  auto body = [&]() -> int {
+    TBNAV_HIP(hipMalloc((void**)&dx, sizeof(double) * count)); TBNAV_HIP(hipMalloc((void**)&dd, sizeof(double) * count));
+    TBNAV_HIP(hipMalloc((void**)&dout, sizeof(double) * count)); TBNAV_HIP(hipMalloc((void**)&dn, sizeof(int) * count));
+    TBNAV_HIP(hipMemcpy(dx, x, sizeof(double) * count, hipMemcpyHostToDevice)); TBNAV_HIP(hipMemcpy(dd, d, sizeof(double) * count, hipMemcpyHostToDevice));
+    TBNAV_HIP(hipMemcpy(dn, n, sizeof(int) * count, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(rbpf_add_repeated_test, dim3((unsigned int)((count + 255) / 256)), dim3(256), 0, 0, dx, dd, dn, dout, (int)count);
+    TBNAV_HIP(hipGetLastError());
+    TBNAV_HIP(hipMemcpy(out, dout, sizeof(double) * count, hipMemcpyDeviceToHost));
+    return TBNAV_OK;
+  };
+  rc = body();
+  (void)hipFree(dx); (void)hipFree(dd); (void)hipFree(dout); (void)hipFree(dn);
+  return rc;
 }
 
 int tbnav_rbpf_gather_local(tbnav_rbpf* h, const int32_t* local_parent) {

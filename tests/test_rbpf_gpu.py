@@ -610,3 +610,45 @@ def test_parallel_exact_chains_equal_the_sequential_sums_bit_for_bit(gpu_pkg, n)
         if st.resampled:
             assert np.array_equal(parents_d, parents_h), (name, n)
     pf.close()
+
+
+def test_repeated_adds_without_the_chain_equal_the_plain_loop_bit_for_bit(gpu_pkg):
+    """A cell that n beams cross takes n times  x = fl(x + l)  (grid_mapper.cpp:438-477: one add per beam) — for the robot's own cell
+    n is the number of beams.  add_repeated (rbpf.hip) evaluates that without the chain of dependent adds: integer steps while x
+    stays in one binade, plain adds across its ends, at ties and where the signs differ.  Against the plain loop in numpy, bit for
+    bit: the shipped log-odds, random addends, powers of two (every add a tie candidate), addends far below / above x, zeros,
+    infinities, sign changes, and counts from 0 to 65535."""
+    import ctypes as C
+    from rtn_amd import capi
+    lib = capi.lib()
+    rng = np.random.default_rng(5)
+    l_free, l_occ = np.log(0.35 / 0.65), np.log(0.9 / 0.1)
+    xs, ds, ns = [], [], []
+    def add(x, d, n):
+        x, d, n = np.broadcast_arrays(np.asarray(x, np.float64), np.asarray(d, np.float64), np.asarray(n, np.int64))
+        xs.append(x.ravel().copy()); ds.append(d.ravel().copy()); ns.append(n.ravel().copy())
+    m = 3000
+    for l in (l_free, l_occ, -l_occ):
+        add(-np.abs(rng.normal(0, 300, m)), l, rng.integers(0, 400, m))           # what the maps hold
+        add(rng.normal(0, 5, m), l, rng.integers(0, 40, m))                       # round zero: sign changes, small binades
+        add(np.ldexp(rng.random(m) + 1.0, rng.integers(-30, 60, m)) * np.sign(l), l, rng.integers(0, 65536, m))
+        add(0.0, l, np.arange(0, 600))                                            # a fresh cell: every binade from zero up
+    add(rng.normal(0, 100, m), rng.normal(0, 2, m), rng.integers(0, 3000, m))     # any addend
+    add(np.ldexp(rng.integers(1, 1 << 20, m).astype(np.float64), -10), np.ldexp(1.0, rng.integers(-14, 3, m)), rng.integers(0, 5000, m))   # ties
+    add(np.ldexp(2.0 * rng.integers(1 << 51, 1 << 52, m).astype(np.float64) + 1.0, -40), np.ldexp(1.0, -41), rng.integers(0, 200, m))      # x odd, d = ulp/2
+    add(rng.normal(0, 1, m) * 1e15, l_free, rng.integers(0, 65536, m))            # addend near / below half an ulp
+    add(rng.normal(0, 1, m) * 1e17, l_free, rng.integers(0, 65536, m))
+    add([np.inf, -np.inf, np.nan, 1.0, 0.0, -0.0, 5e-324, -1e-310], [l_free, l_free, l_free, np.inf, 0.0, -0.0, l_free, -1e-310], 1000)
+    add(-np.ldexp(1.0, np.arange(1, 40)) + 0.25, l_free, 50)                      # just inside a binade's end
+    x = np.concatenate(xs); d = np.concatenate(ds); n = np.concatenate(ns).astype(np.int32)
+    out = np.empty_like(x)
+    rc = lib.tbnav_rbpf_add_repeated(x.ctypes.data, d.ctypes.data, n.ctypes.data, out.ctypes.data, C.c_int64(len(x)))
+    assert rc == 0
+    want = x.copy()
+    with np.errstate(all="ignore"):
+        for step in range(int(n.max())):
+            live = n > step
+            want[live] = want[live] + d[live]
+    same = (out.view(np.uint64) == want.view(np.uint64)) | (np.isnan(out) & np.isnan(want))
+    bad = np.flatnonzero(~same)
+    assert bad.size == 0, (bad[:5], x[bad[:5]], d[bad[:5]], n[bad[:5]], out[bad[:5]], want[bad[:5]])
