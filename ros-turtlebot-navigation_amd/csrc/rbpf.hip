@@ -2280,7 +2280,7 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
                                                          //      no slot; may exceed kBoxEv: overflow)
   constexpr unsigned int kFlag = 0x80000000u;
   constexpr int kEv = kBoxEv;
-  __shared__ int bad, bx0, bx1, by0, by1, srx, sry, n_need, nocc_delta, n_ovf;
+  __shared__ int bad, bx0, bx1, by0, by1, srx, sry, nocc_delta, n_ovf;
   __shared__ unsigned long long need_base;
   __shared__ unsigned int mt_id[kMapTilesMax];  // map tiles under the box: the tile the particle's table names (once written: its private tile)
   __shared__ int mt_touch[kMapTilesMax], mt_slot[kMapTilesMax], mt_priv[kMapTilesMax];
@@ -2315,7 +2315,7 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
     if (lane == 0) {
       sh_pose[0] = X; sh_pose[1] = Y; sh_pose[2] = st0; sh_pose[3] = ct0;
       bad = robot_ok ? 0 : 1; bx0 = bx1 = rx0; by0 = by1 = ry0; srx = rx0; sry = ry0;
-      n_need = 0; nocc_delta = 0; n_ovf = 0; robot_cnt = 0;
+      nocc_delta = 0; n_ovf = 0; robot_cnt = 0;
     }
   } else {
     uint4* t4 = reinterpret_cast<uint4*>(tile);
@@ -2405,7 +2405,7 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
       for (int t = tid; t < tile_cap / 4; t += nthr) t4[t] = uint4{0u, 0u, 0u, 0u};
       for (int b = tid; b < Bv; b += nthr) ecnt[b] = 0;
       for (int t = tid; t < kMapTilesMax; t += nthr) mt_touch[t] = 0;
-      if (tid == 0) { n_need = 0; n_ovf = 0; }
+      if (tid == 0) n_ovf = 0;
       __syncthreads();
     }
     auto cell_t = [&](int e) { return __mul24((e & 0xFFFF) - x0, bw) + ((e >> 16) - miny); };
@@ -2560,14 +2560,12 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
   return;  // (development: instruction counts / kernel time up to this phase — tools/README.md)
 #endif
     // C. make the written tiles private to the particle (first write after a resample, or first touch of the area): ONE pop
-    //    of the free ring for all of them, then one wave per tile copies 8 KB.  Usually there is nothing to do.
-    if (tq >= 0 && tq < mtn && mt_touch[tq]) {
-      if (mt_priv[tq]) mt_slot[tq] = -1;
-      else mt_slot[tq] = atomicAdd(&n_need, 1);
-    }
-    __syncthreads();
-    if (n_need) {  // workgroup-uniform
-      if (tid == 0) { need_base = tile_pop_n(P, (unsigned int)n_need); if (need_base == ~0ull) bad = 1; }
+    //    of the free ring for all of them, then one wave per tile copies 8 KB.  Usually there is nothing to do — and every wave
+    //    sees that for itself (one ballot over the at most 64 tiles under the box), without a barrier to agree on it.
+    const unsigned long long need_m = __ballot(lane < mtn && mt_touch[lane < mtn ? lane : 0] && !mt_priv[lane < mtn ? lane : 0]);
+    if (need_m) {  // workgroup-uniform
+      if (wid == 0 && lane < mtn) mt_slot[lane] = ((need_m >> lane) & 1ull) ? __popcll(need_m & ((1ull << lane) - 1ull)) : -1;
+      if (tid == 0) { need_base = tile_pop_n(P, (unsigned int)__popcll(need_m)); if (need_base == ~0ull) bad = 1; }
       __syncthreads();
       if (bad) { if (tid == 0) atomicOr(&err[3], 8); return; }  // tile pool exhausted (nothing has been written if this is the first band)
       for (int q = wid; q < mtn; q += nw) {
