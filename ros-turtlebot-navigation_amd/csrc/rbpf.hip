@@ -76,10 +76,16 @@ __device__ __forceinline__ int floor_div_small(int num, int den);  // exact floo
 // over workgroups and printed by tbnav_rbpf_destroy.  The stamps add barriers and global atomics — the kernels
 // run measurably slower with them; the numbers are for comparing phases, not for the bench.
 #ifdef TBNAV_PHASE_PROF
-__device__ unsigned long long g_trace_p[4][16];  // [wave][stamp] of ONE proposal workgroup (blockIdx.x == 100)
-#define TRACE_P(i) do { if (blockIdx.x == 100 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 4) g_trace_p[threadIdx.x >> 6][i] = wall_clock64(); } while (0)
+__device__ unsigned long long g_trace_p[2][4][16];  // [which][wave][stamp] of TWO proposal workgroups (blockIdx.x == 96, 100: XCCs 0 and 4)
+#define TRACE_P(i) do { if ((blockIdx.x == 96 || blockIdx.x == 100) && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 4) g_trace_p[blockIdx.x == 100][threadIdx.x >> 6][i] = wall_clock64(); } while (0)
+__device__ unsigned long long g_wgp[4096][3];   // [workgroup] entry, exit (10 ns ticks), XCC_ID << 32 | HW_ID of the LAST proposal launch
+#define WGP_IN() do { if (threadIdx.x == 0 && blockIdx.x < 4096) { g_wgp[blockIdx.x][0] = wall_clock64(); \
+  g_wgp[blockIdx.x][2] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned int)__builtin_amdgcn_s_getreg(63492); } } while (0)
+#define WGP_OUT() do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_wgp[blockIdx.x][1] = wall_clock64(); } while (0)
 #else
 #define TRACE_P(i)
+#define WGP_IN()
+#define WGP_OUT()
 #endif
 #ifdef TBNAV_PHASE_PROF
 __device__ unsigned long long g_phase[8];
@@ -831,7 +837,14 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
 #ifdef TBNAV_PHASE_PROF
   unsigned long long t_prev_ = wall_clock64();
 #endif
+  WGP_IN();
   const double th0 = pose[p * 3 + 0], x0 = pose[p * 3 + 1], y0 = pose[p * 3 + 2];
+  // (a table of at most NT entries — maps up to 512 x 512 cells at 256 threads — is requested WHOLE here, with the pose: which
+  //  entries the window needs depends on the pose, and waiting for it made the staging below three dependent round trips)
+  const int tt_all = ds.occ.TW * ds.occ.TW;
+  const bool whole_table = ds.mode == 2 && occ_half > 0 && nocc && tt_all <= NT && tt_all <= 256;
+  unsigned int my_id = 0u;
+  if (whole_table && tid < tt_all) my_id = ds.occ.tab[tid];
   TRACE_P(0);
   double mu0[3];
   if (!c.icp_ok) {
@@ -872,18 +885,20 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
       int* ta = reinterpret_cast<int*>(tile_bm + (size_t)(R1 - R0 + 1) * nW);
       // Two round trips instead of a chain of dependent ones per word: the ids of the tiles under the window go to LDS
       // first, then every row requests its (up to kStC) 32-bit pieces at once.
-      constexpr int kStC = 12, kStIds = 128;
+      constexpr int kStC = 12, kStIds = 256;
       __shared__ unsigned int st_ids[kStIds];
       const int tr0 = R0 >> kTSh, tc0 = 2 * W0, ntc = min(2 * nW, ds.occ.TW - tc0), n_ids = ((R1 >> kTSh) - tr0 + 1) * ntc;
-      if (ntc <= kStC && n_ids <= kStIds) {
-        for (int q = tid; q < n_ids; q += NT) {
-          const int qi = floor_div_small(q, ntc);
-          st_ids[q] = ds.occ.tab[(tr0 + qi) * ds.occ.TW + tc0 + (q - qi * ntc)];
-        }
+      if (ntc <= kStC && (whole_table || n_ids <= kStIds)) {
+        if (whole_table) { if (tid < tt_all) st_ids[tid] = my_id; }
+        else
+          for (int q = tid; q < n_ids; q += NT) {
+            const int qi = floor_div_small(q, ntc);
+            st_ids[q] = ds.occ.tab[(tr0 + qi) * ds.occ.TW + tc0 + (q - qi * ntc)];
+          }
         __syncthreads();
         for (int r = tid; r <= R1 - R0; r += NT) {
           const int row = R0 + r;
-          const unsigned int* ids = st_ids + ((row >> kTSh) - tr0) * ntc;
+          const unsigned int* ids = whole_table ? st_ids + (row >> kTSh) * ds.occ.TW + tc0 : st_ids + ((row >> kTSh) - tr0) * ntc;
           unsigned int v32[kStC];
 #pragma unroll
           for (int q = 0; q < kStC; ++q) v32[q] = q < ntc ? ds.occ.bm[(size_t)ids[q] * kTS + (row & (kTS - 1))] : 0u;
@@ -969,7 +984,7 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
   }
   __syncthreads();
   TRACE_P(2);
-#ifdef TBNAV_PHASE_PROF
+#if defined(TBNAV_PHASE_PROF) && !defined(TBNAV_TRACE_ONLY)  // (the sums are contended atomics on ONE address: they distort the very timeline TRACE_ONLY records)
   if (tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_phase_p[5], now_ - t_prev_); }
 #endif
   // ---- 2. wave 0: odometry likelihood of every sample (:542).  Other waves: one lookup per beam at the centre of
@@ -1031,7 +1046,7 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
       n += __popcll(m);
     }
     if (lane == 0) sh_nun = n;
-#ifdef TBNAV_PHASE_PROF
+#if defined(TBNAV_PHASE_PROF) && !defined(TBNAV_TRACE_ONLY)  // (the sums are contended atomics on ONE address: they distort the very timeline TRACE_ONLY records)
     if (lane == 0) atomicAdd(&g_phase_p[6], (unsigned long long)n);
 #endif
   }
@@ -1170,9 +1185,10 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
   }
   TRACE_P(10);
   PHASE_STAMP_P(2);
-#ifdef TBNAV_PHASE_PROF
+#if defined(TBNAV_PHASE_PROF) && !defined(TBNAV_TRACE_ONLY)  // (the sums are contended atomics on ONE address: they distort the very timeline TRACE_ONLY records)
   if (tid == 0) atomicAdd(&g_phase_p[7], 1ull);
 #endif
+  WGP_OUT();
 }
 
 // ---- raycast ---------------------------------------------------------------------------------------
@@ -2775,7 +2791,7 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
     __syncthreads();
     if (tid == 0) { atomicAdd(&touched[0], (unsigned long long)cnt_upd); atomicAdd(&touched[1], (unsigned long long)cnt_dis); }
   }
-#ifdef TBNAV_PHASE_PROF
+#if defined(TBNAV_PHASE_PROF) && !defined(TBNAV_TRACE_ONLY)  // (the sums are contended atomics on ONE address: they distort the very timeline TRACE_ONLY records)
   if (tid == 0) { atomicAdd(&g_phase_w[15], 1ull); }
 #endif
   WG_OUT();
@@ -4053,7 +4069,7 @@ int scan_enqueue(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3
       if (bytes <= 48 * 1024) { occ_half = half; propose_lds += bytes; break; }
     }
   }
-  if (propose_lds > (size_t)kMaxLds - 2048) return TBNAV_ERR_UNSUPPORTED;  // scan x samples too large for one workgroup's LDS
+  if (propose_lds > (size_t)kMaxLds - 3072) return TBNAV_ERR_UNSUPPORTED;  // scan x samples too large for one workgroup's LDS
   const int* skip_arr = h->df_mode == 2 ? h->d_fstate : h->d_skip;
   const int skip_eq = h->df_mode == 2 ? 2 : 1;
   const double* center = nullptr;
@@ -4070,7 +4086,7 @@ int scan_enqueue(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3
   // workgroup size: four waves when four workgroups fit a CU's LDS (the 360-beam scans: 38 KB each), eight when the scan's
   // tables leave room for two or three only (1080 beams: 58 KB) — measured: 360 beams 32 us per 1000 particles with 256
   // threads against 43 with 512; the configs[4] shard 0.80 ms with 256 against 0.61 with 512
-  if (propose_lds + 2048 > (size_t)kMaxLds / 4)
+  if (propose_lds + 3072 > (size_t)kMaxLds / 4)
     hipLaunchKernelGGL((rbpf_propose<2 * kProposeThreads>), dim3(h->N), dim3(2 * kProposeThreads), propose_lds, st, c, beams_dev,
                      h->d_code[h->cur], h->pool, map_of(h), h->d_trow[h->cur], skip_arr, skip_eq, h->df_mode, h->radius, occ_half,
                      h->d_nocc[h->cur], h->d_win, normals_dev, center, sp.pose, sp.prev, sp.weight, h->tr, h->d_sens, d_err, gate_prev, h->d_mixlut);
@@ -4383,8 +4399,8 @@ int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf*
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 1024);
   // the proposal / scan-match kernels carry the scan, the per-sample data and the bitmap slice: more than the 64 KB
   // default for long scans or many samples
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_propose<kProposeThreads>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 2048);  // (1.8 KB static)
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_propose<2 * kProposeThreads>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 2048);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_propose<kProposeThreads>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 3072);  // (2.3 KB static)
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_propose<2 * kProposeThreads>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 3072);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_scanmatch), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_edt_compact<kEdtRowsA>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)edt_compact_lds(kEdtRowsA));
@@ -4437,16 +4453,18 @@ void tbnav_rbpf_destroy(tbnav_rbpf* h) {
                            "other cells %.1f | overflowed slots %.2f | end-point cells %.1f\n",
                    (double)ph[0] / ph[7], (double)ph[1] / ph[7], (double)ph[2] / ph[7], (double)ph[3] / ph[7], (double)ph[4] / ph[7],
                    (double)ph[5] / ph[7], (double)ph[6] / ph[7]);
-    unsigned long long tp[4][16];
-    if (hipMemcpyFromSymbol(tp, HIP_SYMBOL(g_trace_p), sizeof(tp)) == hipSuccess && tp[0][0]) {
-      std::fprintf(stderr, "[rbpf_propose trace of workgroup 100, us; columns: entry, bitmap slice staged, samples drawn (barrier), lookups done, barrier, "
-                           "unstable list (barrier), -, products (barrier), weights (barrier), mean (barrier), end]\n");
-      unsigned long long t0 = ~0ull;
-      for (int w = 0; w < 4; ++w) if (tp[w][0] && tp[w][0] < t0) t0 = tp[w][0];
-      for (int w = 0; w < 4; ++w) {
-        std::fprintf(stderr, "  wave %d:", w);
-        for (int i = 0; i < 11; ++i) std::fprintf(stderr, " %6.2f", tp[w][i] ? (double)(tp[w][i] - t0) * 0.01 : -1.0);
-        std::fprintf(stderr, "\n");
+    unsigned long long tp[2][4][16];
+    if (hipMemcpyFromSymbol(tp, HIP_SYMBOL(g_trace_p), sizeof(tp)) == hipSuccess && tp[0][0][0]) {
+      for (int g = 0; g < 2; ++g) {
+        std::fprintf(stderr, "[rbpf_propose trace of workgroup %d, us; columns: entry, bitmap slice staged, samples drawn (barrier), lookups done, barrier, "
+                             "unstable list (barrier), -, products (barrier), weights (barrier), mean (barrier), end]\n", g ? 100 : 96);
+        unsigned long long t0 = ~0ull;
+        for (int w = 0; w < 4; ++w) if (tp[g][w][0] && tp[g][w][0] < t0) t0 = tp[g][w][0];
+        for (int w = 0; w < 4; ++w) {
+          std::fprintf(stderr, "  wave %d:", w);
+          for (int i = 0; i < 11; ++i) std::fprintf(stderr, " %6.2f", tp[g][w][i] ? (double)(tp[g][w][i] - t0) * 0.01 : -1.0);
+          std::fprintf(stderr, "\n");
+        }
       }
     }
     unsigned long long tr[2][16][16];
@@ -4460,6 +4478,51 @@ void tbnav_rbpf_destroy(tbnav_rbpf* h) {
           for (int i = 0; i < 15; ++i) std::fprintf(stderr, " %5.2f", tr[g][w][i] ? (double)(tr[g][w][i] - t0) * 0.01 : -1.0);
           std::fprintf(stderr, "\n");
         }
+      }
+    }
+    {
+      static unsigned long long wgp[4096][3];
+      if (hipMemcpyFromSymbol(wgp, HIP_SYMBOL(g_wgp), sizeof(wgp)) == hipSuccess && wgp[1][0]) {
+        int n = 0;
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (int i = 0; i < 4096; ++i) if (wgp[i][0] && wgp[i][1]) { ++n; t0 = std::min(t0, wgp[i][0]); t1 = std::max(t1, wgp[i][1]); }
+        const int nb = 16;
+        const double span = (double)(t1 - t0);
+        int active[nb] = {0}, starts[nb] = {0};
+        double dur[nb] = {0};
+        for (int i = 0; i < 4096; ++i) if (wgp[i][0] && wgp[i][1]) {
+          const int bs = std::min(nb - 1, (int)((double)(wgp[i][0] - t0) / span * nb));
+          ++starts[bs]; dur[bs] += (double)(wgp[i][1] - wgp[i][0]) * 0.01;
+          for (int b = 0; b < nb; ++b) { const double tm = t0 + (b + 0.5) * span / nb; if ((double)wgp[i][0] <= tm && tm < (double)wgp[i][1]) ++active[b]; }
+        }
+        std::fprintf(stderr, "[rbpf_propose workgroups of the last launch] %d recorded, first entry to last exit %.2f us; bins of %.2f us\n  resident at mid-bin:", n, span * 0.01, span * 0.01 / nb);
+        for (int b = 0; b < nb; ++b) std::fprintf(stderr, " %5d", active[b]);
+        std::fprintf(stderr, "\n  entered in bin:     ");
+        for (int b = 0; b < nb; ++b) std::fprintf(stderr, " %5d", starts[b]);
+        std::fprintf(stderr, "\n  mean residence (us):");
+        for (int b = 0; b < nb; ++b) std::fprintf(stderr, " %5.1f", starts[b] ? dur[b] / starts[b] : 0.0);
+        // by XCC and by CU: is a slow workgroup's CU slow as a whole?
+        std::map<unsigned long long, std::vector<double>> by_cu;
+        double xs[16] = {0}; int xn[16] = {0};
+        for (int i = 0; i < 4096; ++i) if (wgp[i][0] && wgp[i][1]) {
+          const unsigned int hw = (unsigned int)wgp[i][2], xcc = (unsigned int)(wgp[i][2] >> 32) & 0xF;
+          const double d = (double)(wgp[i][1] - wgp[i][0]) * 0.01;
+          by_cu[((unsigned long long)xcc << 16) | (hw & 0xFF00u)].push_back(d);
+          xs[xcc] += d; ++xn[xcc];
+        }
+        std::fprintf(stderr, "\n  mean residence by XCC:");
+        for (int x = 0; x < 16; ++x) if (xn[x]) std::fprintf(stderr, " %.1f", xs[x] / xn[x]);
+        double spread_in = 0.0; int ncu = 0; double cu_min = 1e9, cu_max = 0; int n3 = 0, n4 = 0; double d3 = 0, d4 = 0;
+        for (auto& kv : by_cu) {
+          double lo = 1e9, hi = 0, sum = 0;
+          for (double d : kv.second) { lo = std::min(lo, d); hi = std::max(hi, d); sum += d; }
+          spread_in += hi - lo; ++ncu;
+          const double mean = sum / kv.second.size();
+          cu_min = std::min(cu_min, mean); cu_max = std::max(cu_max, mean);
+          if (kv.second.size() <= 3) { ++n3; d3 += mean; } else { ++n4; d4 += mean; }
+        }
+        std::fprintf(stderr, "\n  %d CUs; mean (max - min) inside a CU %.1f us; CU means from %.1f to %.1f us; CUs with <= 3 workgroups: %d, mean %.1f us; with 4+: %d, mean %.1f us\n",
+                     ncu, spread_in / std::max(1, ncu), cu_min, cu_max, n3, n3 ? d3 / n3 : 0.0, n4, n4 ? d4 / n4 : 0.0);
       }
     }
     {
@@ -4498,6 +4561,10 @@ void tbnav_rbpf_destroy(tbnav_rbpf* h) {
         for (int k = 1; k < 16; ++k) if (hist[k]) std::fprintf(stderr, " %d:%d", k, hist[k]);
         std::fprintf(stderr, "\n  workgroups per XCC:");
         for (auto& kv : per_xcc) std::fprintf(stderr, " %d", kv.second);
+        double xs[16] = {0}; int xn[16] = {0};
+        for (int i = 0; i < 4096; ++i) if (wg[i][0] && wg[i][1]) { const unsigned int xcc = (unsigned int)(wg[i][2] >> 32) & 0xF; xs[xcc] += (double)(wg[i][1] - wg[i][0]) * 0.01; ++xn[xcc]; }
+        std::fprintf(stderr, "\n  mean residence by XCC (us):");
+        for (int x = 0; x < 16; ++x) if (xn[x]) std::fprintf(stderr, " %.1f", xs[x] / xn[x]);
         std::fprintf(stderr, "\n");
       }
     }
