@@ -874,6 +874,7 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
   for (int q = tid; q < kMixLds; q += NT) sh_mix[q] = mixlut[q];
   double Tc[4];  // sensor transform at the centre of the samples
   sensor_transform(c, mu0[0], mu0[1], mu0[2], Tc);
+  TRACE_P(11);
   if (ds.mode == 2 && occ_half > 0 && nocc) {
     // query mode: stage the bitmap rows/columns within occ_half cells of the sensor in LDS — every lookup of this
     // block ends within range_max of it, and its nearest obstacle is usually a few cells further at most
@@ -896,6 +897,7 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
             st_ids[q] = ds.occ.tab[(tr0 + qi) * ds.occ.TW + tc0 + (q - qi * ntc)];
           }
         __syncthreads();
+        TRACE_P(12);
         for (int r = tid; r <= R1 - R0; r += NT) {
           const int row = R0 + r;
           const unsigned int* ids = whole_table ? st_ids + (row >> kTSh) * ds.occ.TW + tc0 : st_ids + ((row >> kTSh) - tr0) * ntc;
@@ -4457,12 +4459,12 @@ void tbnav_rbpf_destroy(tbnav_rbpf* h) {
     if (hipMemcpyFromSymbol(tp, HIP_SYMBOL(g_trace_p), sizeof(tp)) == hipSuccess && tp[0][0][0]) {
       for (int g = 0; g < 2; ++g) {
         std::fprintf(stderr, "[rbpf_propose trace of workgroup %d, us; columns: entry, bitmap slice staged, samples drawn (barrier), lookups done, barrier, "
-                             "unstable list (barrier), -, products (barrier), weights (barrier), mean (barrier), end]\n", g ? 100 : 96);
+                             "unstable list (barrier), -, products (barrier), weights (barrier), mean (barrier), end | centre's sensor transform known, table ids in LDS (barrier)]\n", g ? 100 : 96);
         unsigned long long t0 = ~0ull;
         for (int w = 0; w < 4; ++w) if (tp[g][w][0] && tp[g][w][0] < t0) t0 = tp[g][w][0];
         for (int w = 0; w < 4; ++w) {
           std::fprintf(stderr, "  wave %d:", w);
-          for (int i = 0; i < 11; ++i) std::fprintf(stderr, " %6.2f", tp[g][w][i] ? (double)(tp[g][w][i] - t0) * 0.01 : -1.0);
+          for (int i = 0; i < 13; ++i) std::fprintf(stderr, " %6.2f", tp[g][w][i] ? (double)(tp[g][w][i] - t0) * 0.01 : -1.0);
           std::fprintf(stderr, "\n");
         }
       }
