@@ -79,14 +79,18 @@ def configs4_shard(device, N=12500, k=50, n_scans=8):
     return out
 
 
-def reference_field_mode(device, N, k, map_half, walls, n_scans, host_threads=0):
+def reference_field_mode(device, N, k, map_half, walls, n_scans, host_threads=0, spread=None):
     """The product in the mode that reproduces the reference's distance field bit for bit (TBNAV_RBPF_DF_REFERENCE: what
-    bmapping::ParticleFilter defaults to up to 4096 particles): the per-particle priority-queue brushfires run on the host's
-    cores, everything else on the device.  Synchronous calls, device noise, first scan untimed."""
+    bmapping::ParticleFilter defaults to up to 4096 particles): the priority-queue brushfires run on the host's cores — ONE per
+    distinct (particle state, the scan's insert / erase sequence), shared by the particles that are copies of one another and saw
+    the same cells change (csrc/ref_field.hpp) — everything else on the device.  Synchronous calls, device noise, first scan
+    untimed.  spread: a sampling spread (theta, x, y) instead of the shipped 1e-10 / 1e-8 / 1e-8 (slam.launch:24-26) — wide enough
+    and every particle's beams end in other cells: nothing is shared, every particle pays for its own brushfire."""
     from rtn_amd import capi
     from rtn_amd.rbpf import ParticleFilter, default_params
     rc = _world()
-    pf = ParticleFilter(default_params(N=N, k=k, map_min=-map_half, map_max=map_half, device=device.index or 0), df_mode="reference")
+    kw = {} if spread is None else {"sample_range": list(spread)}
+    pf = ParticleFilter(default_params(N=N, k=k, map_min=-map_half, map_max=map_half, device=device.index or 0, **kw), df_mode="reference")
     pf.setOption(capi.RBPF_OPT_HOST_THREADS, host_threads)
     pf.setSeed(2026)
     steps, poses = rc.trajectory(n_scans, inc=TRAJ_INC if map_half > 5 else (0.03, 0.02, 0.01))
@@ -96,11 +100,16 @@ def reference_field_mode(device, N, k, map_half, walls, n_scans, host_threads=0)
         scan = _room_scan(poses[s], rng, walls)
         t0 = time.perf_counter()
         st = pf.SLAM(scan, u, cur, prev, True, t_icp, None)
+        if s == 0:
+            fires0 = pf.referenceFieldCounts()[2]
         if s >= 1:
             t += time.perf_counter() - t0; n += 1
+    distinct, _, fires = pf.referenceFieldCounts()
     pf.close()
-    return {"workload": f"RBPF N={N}, k={k}, {int(st.n_valid_beams)} valid beams of 360, {int(2 * map_half / 0.05)}^2 @0.05 m, distance field = the reference's brushfire (bit-exact mode)",
+    return {"workload": f"RBPF N={N}, k={k}, {int(st.n_valid_beams)} valid beams of 360, {int(2 * map_half / 0.05)}^2 @0.05 m, distance field = the reference's brushfire (bit-exact mode)"
+                        + ("" if spread is None else f", sampling spread {tuple(spread)} instead of the shipped 1e-10 / 1e-8 / 1e-8"),
             "particle_updates_per_s": round(N * n / t, 1), "ms_per_scan": round(t / n * 1e3, 3), "scans_timed": n,
+            "brushfires_per_scan": round((fires - fires0) / n, 1), "distinct_particle_states_at_the_end": distinct,
             "host_threads": host_threads or "all cores of the affinity mask (<= 32)"}
 
 
@@ -271,7 +280,8 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
     cfg4 = None if getattr(args, "no_large", False) else configs4_as_written(device)
     rc_ = _world()
     ref_mode = {"launch_configuration_40_particles_80x80": reference_field_mode(device, 40, 50, 2.0, rc_.ROOM_SMALL, 12),
-                "configs2_1000_particles_400x400": None if getattr(args, "no_large", False) else reference_field_mode(device, N, k, 10.0, ROOM_BENCH, 5),
+                "configs2_1000_particles_400x400": None if getattr(args, "no_large", False) else reference_field_mode(device, N, k, 10.0, ROOM_BENCH, 8),
+                "configs2_every_particle_distinct": None if getattr(args, "no_large", False) else reference_field_mode(device, N, k, 10.0, ROOM_BENCH, 3, spread=(0.02, 0.05, 0.05)),
                 "note": "every figure outside this object is for the default exact-distance (query) mode, whose likelihoods differ from the "
                         "reference's by up to 7.5e-3 at 400x400 (tests/test_rbpf_field_gpu.py); this mode meets the 1e-5 bar un-injected"}
     if True:

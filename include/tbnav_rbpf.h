@@ -321,6 +321,11 @@ int tbnav_rbpf_set_option(tbnav_rbpf* h, int32_t option, int32_t value);
  * adds the reference performs (free cells of every ray + end points, grid_mapper.cpp:153-177), distinct_cells =
  * cells actually read-modified-written (a cell touched by several beams of one scan counts once per scan). */
 int tbnav_rbpf_scan_counts(tbnav_rbpf* h, uint64_t* cell_updates, uint64_t* distinct_cells, int32_t reset);
+/* Reference-field mode (TBNAV_RBPF_DF_REFERENCE) only: how many DISTINCT (occupied set with its history, field) states the particles
+ * hold now, how many brushfires the last scan ran and how many all scans so far — one per distinct (state, insert / erase sequence)
+ * of the scan, not one per particle: particles that are copies of one another and saw the same cells change share the result
+ * (csrc/ref_field.hpp).  Any pointer may be NULL. */
+int tbnav_rbpf_reference_field_counts(tbnav_rbpf* h, int32_t* distinct_states, int32_t* last_brushfires, int64_t* total_brushfires);
 
 /* ---- measurement hook --------------------------------------------------------------------------
  * Durations (ms, HIP events on the handle's stream) of the kernels of the LAST slam call:

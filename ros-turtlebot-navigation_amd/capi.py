@@ -190,6 +190,7 @@ def lib() -> C.CDLL:
         "tbnav_rbpf_likelihood": (C.c_int, [vp, i32, vp, i32, dp, dp]),
         "tbnav_rbpf_particle_map": (C.c_int, [vp, i32, vp]),
         "tbnav_rbpf_scan_counts": (C.c_int, [vp, C.POINTER(u64), C.POINTER(u64), i32]),
+        "tbnav_rbpf_reference_field_counts": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_int64)]),
         "tbnav_rbpf_destroy": (None, [vp]),
         "tbnav_rbpf_grid_size": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32)]),
         "tbnav_rbpf_num_normals": (C.c_int64, [vp, i32]),

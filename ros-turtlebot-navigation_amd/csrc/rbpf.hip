@@ -3545,6 +3545,10 @@ struct tbnav_rbpf {
   // device log of occupied-set changes it is fed from
   bool ref_field = false;
   tbnav::RefField* ref = nullptr;
+  std::vector<tbnav::RefField::StatePtr> ref_on_dev;  // [N] the reference-field state whose field slot p of d_code holds (empty: unknown); holding the
+                                                      //     pointer keeps the state alive, so an address is never re-used while it is compared
+  int* d_log_pack = nullptr; unsigned long long* d_log_off = nullptr; size_t log_pack_cap = 0, log_off_cap = 0;  // the scan's logs, packed
+  int* d_code_src = nullptr;              // [N] slot to copy the field from (rbpf_copy_codes)
   int host_threads = 1;        // host threads of the reference-field mode's per-particle work (TBNAV_RBPF_OPT_HOST_THREADS; set at create)
   int* d_log_ev = nullptr;     // [N][log_cap]
   int* d_log_cnt = nullptr;    // [N]
@@ -3825,35 +3829,93 @@ int ref_field_prepare_log(tbnav_rbpf* h, int Bv, OccLog& log) {
 // After the scan (and its resample, if one fired): replay the logged set changes, run the reference's brushfire for
 // every particle as it was BEFORE the resample (the reference integrates the scan in the particle loop and resamples
 // afterwards, particle_filter.cpp:158-249), copy like the resample did, and make the result the authoritative field.
+// the particles' logged sequences packed back to back (one copy to the host instead of one per particle)
+__global__ __launch_bounds__(256) void rbpf_pack_logs(const int* __restrict__ ev, int log_cap, int p_first, const unsigned long long* __restrict__ off,
+                                                      int* __restrict__ out) {
+  const int i = blockIdx.x;
+  const unsigned long long o = off[i], n = off[i + 1] - o;
+  const int* src = ev + (size_t)(p_first + i) * log_cap;
+  for (unsigned long long q = threadIdx.x; q < n; q += blockDim.x) out[o + q] = src[q];
+}
+// slot p takes the field slot src[p] holds (src[p] == p: keep) — the particles that share a state with one already on the device
+__global__ __launch_bounds__(256) void rbpf_copy_codes(uint16_t* __restrict__ code, size_t G, const int* __restrict__ src) {
+  const int p = blockIdx.y, q = src[p];
+  if (q == p) return;
+  const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+  if ((G & 7) == 0) {  // (every slot starts on a 16-byte boundary)
+    const uint4* s = reinterpret_cast<const uint4*>(code + (size_t)q * G);
+    uint4* d = reinterpret_cast<uint4*>(code + (size_t)p * G);
+    for (size_t i = i0; i < G / 8; i += step) d[i] = s[i];
+  } else {
+    for (size_t i = i0; i < G; i += step) code[(size_t)p * G + i] = code[(size_t)q * G + i];
+  }
+}
 int ref_field_after_scan(tbnav_rbpf* h, bool resampled, int p_first = 0, int p_count = -1) {
   const int N = h->N;
   if (p_count < 0) p_count = N;
   { const int rc = ensure_codes(h); if (rc != TBNAV_OK) return rc; }
-  TBNAV_HIP(hipStreamSynchronize(h->stream));
+  hipStream_t st = h->stream;
+  TBNAV_HIP(hipStreamSynchronize(st));
   std::vector<int> cnt(N);
   TBNAV_HIP(hipMemcpy(cnt.data(), h->d_log_cnt, sizeof(int) * N, hipMemcpyDeviceToHost));
-  // the logs first (one copy per particle, a few thousand events each), then the particles' sets and brushfires side by side
-  // on the host's cores: particles are independent, and inside one particle the order of every set and heap operation is
-  // the reference's (round 3; serial before: 16 ms per particle at 400 x 400)
-  std::vector<std::vector<int>> evs((size_t)p_count);
-  for (int p = p_first; p < p_first + p_count; ++p) {
-    if (cnt[p] > h->log_cap) return TBNAV_ERR_UNSUPPORTED;  // cannot happen: the log holds every cell update
-    evs[p - p_first].resize(cnt[p]);
-    if (cnt[p]) TBNAV_HIP(hipMemcpy(evs[p - p_first].data(), h->d_log_ev + (size_t)p * h->log_cap, sizeof(int) * cnt[p], hipMemcpyDeviceToHost));
+  // the logs: packed on the device, ONE copy (a few thousand events per particle; one small copy each was 10-20 ms per 1000)
+  std::vector<size_t> off((size_t)p_count + 1, 0);
+  for (int i = 0; i < p_count; ++i) {
+    if (cnt[p_first + i] > h->log_cap) return TBNAV_ERR_UNSUPPORTED;  // cannot happen: the log holds every cell update
+    off[i + 1] = off[i] + (size_t)cnt[p_first + i];
   }
-  h->ref->for_each_particle(p_first, p_count, h->host_threads, [&](int p, tbnav::RefField::Scratch& sc) {
-    h->ref->apply(p, evs[p - p_first].data(), (int)evs[p - p_first].size());
-    h->ref->brushfire(p, sc);
-  });
+  const size_t total = off[p_count];
+  std::vector<int> all(total ? total : 1);
+  if (total) {
+    if (total > h->log_pack_cap || (size_t)p_count + 1 > h->log_off_cap) {
+      (void)hipFree(h->d_log_pack); (void)hipFree(h->d_log_off); h->d_log_pack = nullptr; h->d_log_off = nullptr; h->log_pack_cap = h->log_off_cap = 0;
+      const size_t cap = total + total / 2, ocap = (size_t)N + 1;
+      TBNAV_HIP(hipMalloc((void**)&h->d_log_pack, sizeof(int) * cap));
+      TBNAV_HIP(hipMalloc((void**)&h->d_log_off, sizeof(unsigned long long) * ocap));
+      h->log_pack_cap = cap; h->log_off_cap = ocap;
+    }
+    std::vector<unsigned long long> off64(off.begin(), off.end());
+    TBNAV_HIP(hipMemcpy(h->d_log_off, off64.data(), sizeof(unsigned long long) * off64.size(), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(rbpf_pack_logs, dim3(p_count), dim3(256), 0, st, h->d_log_ev, h->log_cap, p_first, h->d_log_off, h->d_log_pack);
+    TBNAV_HIP(hipGetLastError());
+    TBNAV_HIP(hipMemcpyAsync(all.data(), h->d_log_pack, sizeof(int) * total, hipMemcpyDeviceToHost, st));
+    TBNAV_HIP(hipStreamSynchronize(st));
+  }
+  // one replay + brushfire per distinct (state, sequence) — ref_field.hpp — side by side on the host's cores: inside one state the
+  // order of every set and heap operation is the reference's
+  h->ref->step(p_first, p_count, h->host_threads, all.data(), off.data());
   if (resampled) {
     h->h_parent.resize(N);
     TBNAV_HIP(hipMemcpy(h->h_parent.data(), h->d_parent, sizeof(int) * N, hipMemcpyDeviceToHost));
     h->ref->resample(h->h_parent.data());
   }
-  if (resampled) { p_first = 0; p_count = N; }
-  for (int p = p_first; p < p_first + p_count; ++p)
-    TBNAV_HIP(hipMemcpy(h->d_code[h->cur] + (size_t)p * h->G, h->ref->codes(p), sizeof(uint16_t) * h->G, hipMemcpyHostToDevice));
-  TBNAV_HIP(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(h->d_fstate + p_first), 2, p_count));
+  h->ref_on_dev.resize(N);
+  if (resampled) { p_first = 0; p_count = N; for (auto& q : h->ref_on_dev) q.reset(); }  // (the device's own gather moved the slots)
+  // to the device: a state no slot holds yet is uploaded once; the other particles that share it copy it on the device
+  std::unordered_map<const void*, int> holder;  // state -> a slot whose device field is that state's
+  for (int p = 0; p < N; ++p) if (h->ref_on_dev[p] && h->ref_on_dev[p].get() == h->ref->state(p)) holder.emplace(h->ref_on_dev[p].get(), p);
+  std::vector<int> src(N);
+  bool any_copy = false;
+  for (int p = 0; p < N; ++p) {
+    src[p] = p;
+    if (p < p_first || p >= p_first + p_count) continue;
+    const void* s = (const void*)h->ref->state(p);
+    if (h->ref_on_dev[p].get() == s) continue;
+    auto it = holder.find(s);
+    if (it == holder.end()) {
+      TBNAV_HIP(hipMemcpyAsync(h->d_code[h->cur] + (size_t)p * h->G, h->ref->codes(p), sizeof(uint16_t) * h->G, hipMemcpyHostToDevice, st));
+      holder.emplace(s, p);
+    } else { src[p] = it->second; any_copy = true; }
+    h->ref_on_dev[p] = h->ref->state_ptr(p);
+  }
+  if (any_copy) {
+    if (!h->d_code_src) TBNAV_HIP(hipMalloc((void**)&h->d_code_src, sizeof(int) * N));
+    TBNAV_HIP(hipMemcpyAsync(h->d_code_src, src.data(), sizeof(int) * N, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(rbpf_copy_codes, dim3(64, N), dim3(256), 0, st, h->d_code[h->cur], h->G, h->d_code_src);
+    TBNAV_HIP(hipGetLastError());
+  }
+  TBNAV_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->d_fstate + p_first), 2, p_count, st));
+  TBNAV_HIP(hipStreamSynchronize(st));  // (src and the states' host buffers are read by the copies)
   h->fstate_dirty = true;
   return TBNAV_OK;
 }
@@ -4584,7 +4646,7 @@ void tbnav_rbpf_destroy(tbnav_rbpf* h) {
   (void)hipFree(h->d_bm_dense); (void)hipFree(h->d_rc_dense);
   (void)hipFree(h->pool.lo); (void)hipFree(h->pool.bm); (void)hipFree(h->pool.ref); (void)hipFree(h->pool.ring); (void)hipFree(h->pool.ctr);
   (void)hipFree(h->d_sens); (void)hipFree(h->d_shed); (void)hipFree(h->d_dense); (void)hipFree(h->d_cs); (void)hipFree(h->d_touched); (void)hipFree(h->d_fstate_alt);
-  (void)hipFree(h->d_log_ev); (void)hipFree(h->d_log_cnt); (void)hipFree(h->d_tile_scratch);
+  (void)hipFree(h->d_log_ev); (void)hipFree(h->d_log_cnt); (void)hipFree(h->d_tile_scratch); (void)hipFree(h->d_log_pack); (void)hipFree(h->d_log_off); (void)hipFree(h->d_code_src);
   (void)hipFree(h->d_gw); (void)hipFree(h->d_gcs); (void)hipFree(h->d_gparent); (void)hipFree(h->d_gz);
   (void)hipFree(h->d_gw_raw); (void)hipFree(h->d_sendbuf); (void)hipFree(h->d_recvbuf); (void)hipFree(h->d_sizes); (void)hipFree(h->d_status);
   if (h->ev_w) (void)hipEventDestroy(h->ev_w);
@@ -5471,7 +5533,10 @@ int tbnav_rbpf_copy_particle(tbnav_rbpf* dst, int32_t dst_slot, tbnav_rbpf* src,
   rc = tbnav_rbpf_export_particle_dev(src, src_slot, buf, bytes, nullptr);
   if (rc == TBNAV_OK) rc = tbnav_rbpf_import_particle_dev(dst, dst_slot, buf, bytes);
   (void)hipFree(buf);
-  if (rc == TBNAV_OK && src->ref_field) dst->ref->copy_slot(dst_slot, *src->ref, src_slot);  // the set with its history, the field with its stale cells
+  if (rc == TBNAV_OK && src->ref_field) {  // the set with its history, the field with its stale cells
+    dst->ref->copy_slot(dst_slot, *src->ref, src_slot);
+    if ((size_t)dst_slot < dst->ref_on_dev.size()) dst->ref_on_dev[dst_slot].reset();
+  }
   return rc;
 }
 
@@ -5532,6 +5597,7 @@ int tbnav_rbpf_set_log_odds(tbnav_rbpf* h, int32_t particle, const double* in) {
     std::vector<int> cells;
     for (size_t c = 0; c < h->G; ++c) if (in[c] >= h->cut_occ) cells.push_back((int)c);
     h->ref->reset(particle, cells);
+    if ((size_t)particle < h->ref_on_dev.size()) h->ref_on_dev[particle].reset();
   }
   return TBNAV_OK;
 }
@@ -5570,7 +5636,7 @@ int tbnav_rbpf_set_occ_dist(tbnav_rbpf* h, int32_t particle, const double* in) {
   DeviceGuard guard(h->device);
   { const int rc = ensure_codes(h); if (rc != TBNAV_OK) return rc; }
   TBNAV_HIP(hipStreamSynchronize(h->stream));
-  if (h->ref_field) h->ref->set_codes(particle, code.data());
+  if (h->ref_field) { h->ref->set_codes(particle, code.data()); if ((size_t)particle < h->ref_on_dev.size()) h->ref_on_dev[particle].reset(); }
   TBNAV_HIP(hipMemcpy(h->d_code[h->cur] + (size_t)particle * h->G, code.data(), sizeof(uint16_t) * h->G, hipMemcpyHostToDevice));
   const int two = 2;  // an injected field is authoritative: the next call does not refresh it
   TBNAV_HIP(hipMemcpy(h->d_fstate + particle, &two, sizeof two, hipMemcpyHostToDevice));
@@ -5728,6 +5794,7 @@ int tbnav_rbpf_set_option(tbnav_rbpf* h, int32_t option, int32_t value) {
         if (h->N > 4096) return TBNAV_ERR_UNSUPPORTED;  // serial host brushfire per particle: small ensembles only
         { const int rc = ensure_codes(h); if (rc != TBNAV_OK) return rc; }
         delete h->ref;
+        h->ref_on_dev.clear();
         h->ref = new (std::nothrow) tbnav::RefField(h->N, h->xsize, h->radius);
         if (!h->ref) return TBNAV_ERR_INVALID_ARG;
         h->ref_field = true; h->df_mode = 2; h->full_edt = false;
@@ -5787,6 +5854,14 @@ int tbnav_rbpf_scan_counts(tbnav_rbpf* h, uint64_t* cell_updates, uint64_t* dist
   if (cell_updates) *cell_updates = v[0];
   if (distinct_cells) *distinct_cells = v[1];
   if (reset) TBNAV_HIP(hipMemset(h->d_touched, 0, sizeof v));
+  return TBNAV_OK;
+}
+
+int tbnav_rbpf_reference_field_counts(tbnav_rbpf* h, int32_t* distinct_states, int32_t* last_brushfires, int64_t* total_brushfires) {
+  if (!h || !h->ref_field || !h->ref) return TBNAV_ERR_INVALID_ARG;
+  if (distinct_states) *distinct_states = h->ref->distinct_states();
+  if (last_brushfires) *last_brushfires = h->ref->last_step_brushfires();
+  if (total_brushfires) *total_brushfires = h->ref->total_brushfires();
   return TBNAV_OK;
 }
 

@@ -1,4 +1,4 @@
-// ref_field.hpp — the reference's distance field, reproduced on the host for small ensembles.
+// ref_field.hpp — the reference's distance field, reproduced on the host.
 //
 // bmapping::GridMapper::euclideanSignedDistanceField (bmapping/src/bmapping/grid_mapper.cpp:333-435, enqueueCell
 // :272-329) is a multi-source brushfire over a std::priority_queue, seeded by iterating the std::unordered_set<int>
@@ -11,9 +11,16 @@
 // is the third leg of SURVEY's contract: a mode in which the product reproduces the reference's field bit for bit
 // — same libstdc++ containers, fed the same insert / erase sequence (the beam-ordered raycast kernel logs it),
 // copied the way ParticleFilter::lowVarianceResampling copies particles (particle_filter.cpp:468-500) — so that
-// an un-injected run matches the reference end to end.  It is serial host work per particle (~0.5 ms at 80 x 80,
-// ~16 ms at 400 x 400) — particles are independent, so the handle spreads them over host threads (for_each_particle;
-// round 3): the order of operations inside one particle's set and heap, which is what the result depends on, is untouched.
+// an un-injected run matches the reference end to end.  One brushfire is serial host work (~0.5 ms at 80 x 80,
+// ~16 ms at 400 x 400).  Two things keep that affordable (round 3):
+//   * particles are independent: distinct work is spread over host threads (the order of operations inside one set and
+//     heap, which is what the result depends on, is untouched);
+//   * the result is a FUNCTION of (set with its history, stale field, the scan's insert / erase sequence), and particles share
+//     those far more often than not: every particle starts from the same empty map, the shipped sampling spread is
+//     1e-8 m (slam.launch:24-26) — the same beams end in the same cells — and a resample makes copies.  A particle's state is
+//     therefore an immutable, shared object; a scan groups the particles by (state, event sequence — compared in full, not
+//     by hash) and runs ONE copy + replay + brushfire per group, exactly what each member's own would have been.  Particles
+//     that have diverged (another cell somewhere) are their own group and pay for themselves as before.
 //
 // Distances are kept as u16 codes = squared distance in cells (0xFFFF = never reached = max_occ_dist_):
 // sqrt((double)code) * resolution is the reference's distances_[di][dj] * resolution_ bit for bit
@@ -22,9 +29,12 @@
 #pragma once
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
 #include <atomic>
+#include <memory>
 #include <queue>
 #include <thread>
+#include <unordered_map>
 #include <unordered_set>
 #include <vector>
 
@@ -32,40 +42,117 @@ namespace tbnav {
 
 class RefField {
  public:
-  RefField(int n_particles, int xsize, int radius)
-      : xs_(xsize), radius_(radius), sets_(n_particles), codes_(n_particles, std::vector<uint16_t>((size_t)xsize * xsize, 0xFFFF)) {}
+  // One particle's occupied set (with its iteration order: its whole history) and field (with its stale cells).  Never
+  // modified once a particle points at it.
+  struct State {
+    std::unordered_set<int> occ;
+    std::vector<uint16_t> code;
+    bool fresh = false;  // code is what the brushfire left for exactly this set (false once either was written from outside)
+  };
+  using StatePtr = std::shared_ptr<const State>;
 
-  // fn(p, scratch) for p in [first, first + count) on up to `threads` host threads (particles are independent; each thread has
-  // its own brushfire scratch).  threads <= 1: in the calling thread.
-  struct Scratch { std::vector<uint8_t> marked; };
-  template <class Fn>
-  void for_each_particle(int first, int count, int threads, Fn fn) {
-    const size_t G = (size_t)xs_ * xs_;
-    if (threads > count) threads = count;
-    if (threads <= 1) {
-      Scratch sc; sc.marked.resize(G);
-      for (int p = first; p < first + count; ++p) fn(p, sc);
-      return;
-    }
-    std::atomic<int> next{first};
-    auto work = [&] {
-      Scratch sc; sc.marked.resize(G);
-      for (int p = next.fetch_add(1); p < first + count; p = next.fetch_add(1)) fn(p, sc);
-    };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < threads; ++t) pool.emplace_back(work);
-    work();
-    for (auto& t : pool) t.join();
+  RefField(int n_particles, int xsize, int radius) : xs_(xsize), radius_(radius) {
+    auto s = std::make_shared<State>();
+    s->code.assign((size_t)xsize * xsize, 0xFFFF);
+    st_.assign((size_t)n_particles, s);  // "N deep copies of the prototype" (particle_filter.cpp:125-138): equal, hence shared
   }
 
-  int particles() const { return (int)sets_.size(); }
-  const uint16_t* codes(int p) const { return codes_[p].data(); }
-  size_t occupied(int p) const { return sets_[p].size(); }
+  int particles() const { return (int)st_.size(); }
+  const uint16_t* codes(int p) const { return st_[p]->code.data(); }
+  size_t occupied(int p) const { return st_[p]->occ.size(); }
+  const State* state(int p) const { return st_[p].get(); }
+  StatePtr state_ptr(int p) const { return st_[p]; }
+  // distinct states among the particles / brushfires run by the last step() (what the sharing saved: tests, bench)
+  int distinct_states() const { std::unordered_set<const State*> u; for (auto& s : st_) u.insert(s.get()); return (int)u.size(); }
+  int last_step_brushfires() const { return last_brushfires_; }
+  long long total_brushfires() const { return total_brushfires_; }
 
-  // updateCellHash (grid_mapper.cpp:480-546) for the logged changes of one scan, in the reference's call order.
-  // ev: cell index, bit 31 set = the cell left the occupied state.
-  void apply(int p, const int* ev, int n) {
-    std::unordered_set<int>& occ = sets_[p];
+  // One scan for particles [first, first + count): evs[i] = the logged set changes of particle first + i in the reference's
+  // call order (cell index, bit 31 set = the cell left the occupied state) -> updateCellHash (grid_mapper.cpp:480-546) for each,
+  // then euclideanSignedDistanceField.  One replay + brushfire per distinct (state, sequence), on up to `threads` host threads.
+  // (all / off: the particles' sequences back to back, particle first + i's at all[off[i]] .. all[off[i + 1]])
+  void step(int first, int count, int threads, const int* all, const size_t* off) {
+    struct Group { StatePtr from; const int* ev; size_t n; std::vector<int> members; StatePtr to; };
+    std::vector<Group> groups;
+    std::unordered_map<uint64_t, std::vector<int>> by_hash;  // hash -> indices into groups
+    for (int i = 0; i < count; ++i) {
+      const int p = first + i;
+      const int* ev = all + off[i];
+      const size_t n = off[i + 1] - off[i];
+      uint64_t hsh = 1469598103934665603ull ^ (uint64_t)(uintptr_t)st_[p].get();
+      for (size_t q = 0; q < n; ++q) { hsh ^= (uint32_t)ev[q]; hsh *= 1099511628211ull; }
+      std::vector<int>& cand = by_hash[hsh];
+      int g = -1;
+      for (int c : cand)
+        if (groups[c].from.get() == st_[p].get() && groups[c].n == n && (n == 0 || std::memcmp(groups[c].ev, ev, sizeof(int) * n) == 0)) { g = c; break; }
+      if (g < 0) { g = (int)groups.size(); groups.push_back(Group{st_[p], ev, n, {}, nullptr}); cand.push_back(g); }
+      groups[g].members.push_back(p);
+    }
+    std::atomic<int> next{0}, fires{0};
+    const size_t G = (size_t)xs_ * xs_;
+    auto work = [&] {
+      std::vector<uint8_t> marked(G);
+      for (int g = next.fetch_add(1); g < (int)groups.size(); g = next.fetch_add(1)) {
+        Group& gr = groups[g];
+        // no set operation at all: nothing occupied (the reference returns at :338), or the same set in the same order whose
+        // brushfire the field already is — every reached cell would get the value it has, every other keeps it
+        if (gr.n == 0 && (gr.from->occ.empty() || gr.from->fresh)) { gr.to = gr.from; continue; }
+        // (copy-construct, as GridMapper's copy does: std::unordered_set's copy keeps the iteration order, the bucket layout and
+        //  the rehash policy's state, so the copy behaves like the original from here on)
+        auto s = std::make_shared<State>(*gr.from);
+        apply(s->occ, gr.ev, (int)gr.n);
+        brushfire(*s, marked);
+        s->fresh = true;
+        fires.fetch_add(1);
+        gr.to = s;
+      }
+    };
+    int nt = threads < 1 ? 1 : threads;
+    if (nt > (int)groups.size()) nt = (int)groups.size();
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+    for (Group& gr : groups) for (int p : gr.members) st_[p] = gr.to;
+    last_brushfires_ = fires.load();
+    total_brushfires_ += last_brushfires_;
+  }
+
+  // The occupied set of a particle whose map was written from outside (tbnav_rbpf_set_log_odds): the history is
+  // unknown, the cells go in in ascending order.
+  void reset(int p, const std::vector<int>& cells_ascending) {
+    auto s = std::make_shared<State>();
+    for (int c : cells_ascending) s->occ.insert(c);
+    s->code = st_[p]->code;
+    s->fresh = false;
+    st_[p] = s;
+  }
+  // One particle of another filter, copied the way a GridMapper is copied: the set with its history, the field with its stale cells.
+  void copy_slot(int p, const RefField& from, int q) { st_[p] = from.st_[q]; }
+  void set_codes(int p, const uint16_t* codes) {
+    auto s = std::make_shared<State>(*st_[p]);
+    s->code.assign(codes, codes + s->code.size());
+    s->fresh = false;
+    st_[p] = s;
+  }
+
+  // lowVarianceResampling's copies (particle_filter.cpp:495-499): every slot becomes a copy of its parent.
+  void resample(const int* parent) {
+    const int n = particles();
+    std::vector<StatePtr> tmp((size_t)n);
+    for (int m = 0; m < n; ++m) tmp[m] = st_[parent[m]];
+    st_.swap(tmp);
+  }
+
+ private:
+  // (12 bytes instead of the reference's 48-byte Cell: the heap is std::priority_queue — the same std::push_heap / std::pop_heap
+  //  sequence over the same comparison results, hence the same order among equal distances — it just moves a quarter of the bytes)
+  struct Node { uint32_t d2; uint16_t i, j, si, sj; };
+  struct Farther { bool operator()(const Node& a, const Node& b) const { return a.d2 > b.d2; } };  // CompareDistance, grid_mapper.hpp:104-110
+  using Heap = std::priority_queue<Node, std::vector<Node>, Farther>;
+
+  // updateCellHash (grid_mapper.cpp:480-546) for the logged changes of one scan, in the reference's call order
+  static void apply(std::unordered_set<int>& occ, const int* ev, int n) {
     for (int q = 0; q < n; ++q) {
       const int idx = ev[q] & 0x7FFFFFFF;
       if (ev[q] < 0) { if (occ.find(idx) != occ.end()) occ.erase(idx); }
@@ -73,30 +160,15 @@ class RefField {
     }
   }
 
-  // The occupied set of a particle whose map was written from outside (tbnav_rbpf_set_log_odds): the history is
-  // unknown, the cells go in in ascending order.
-  void reset(int p, const std::vector<int>& cells_ascending) {
-    sets_[p] = std::unordered_set<int>();
-    for (int c : cells_ascending) sets_[p].insert(c);
-  }
-  // One particle of another filter, copied the way a GridMapper is copied (std::unordered_set's copy constructor keeps
-  // the iteration order and bucket layout, so the copy behaves like the original from here on).
-  void copy_slot(int p, const RefField& from, int q) {
-    sets_[p] = std::unordered_set<int>(from.sets_[q]);  // copy-construct (as GridMapper's copy does), then move in
-    codes_[p] = from.codes_[q];
-  }
-  void set_codes(int p, const uint16_t* codes) { codes_[p].assign(codes, codes + codes_[p].size()); }
-
   // euclideanSignedDistanceField, grid_mapper.cpp:333-435
-  void brushfire(int p, Scratch& sc) {
-    const std::unordered_set<int>& occ = sets_[p];
+  void brushfire(State& st, std::vector<uint8_t>& marked) const {
+    const std::unordered_set<int>& occ = st.occ;
     if (occ.empty()) return;
-    std::vector<uint16_t>& code = codes_[p];
-    std::vector<uint8_t>& marked = sc.marked;
+    std::vector<uint16_t>& code = st.code;
     std::fill(marked.begin(), marked.end(), 0);  // "std::vector<int> marked(xsize_ * ysize_)", :342
     std::vector<Node> store;
     store.reserve((size_t)xs_ * 8);
-    std::priority_queue<Node, std::vector<Node>, Farther> Q(Farther(), std::move(store));
+    Heap Q(Farther(), std::move(store));
     for (int key : occ) {  // :348-362
       code[key] = 0;
       marked[key] = 1;
@@ -112,29 +184,9 @@ class RefField {
       Q.pop();
     }
   }
-  void brushfire(int p) { Scratch sc; sc.marked.resize((size_t)xs_ * xs_); brushfire(p, sc); }
-
-  // lowVarianceResampling's copies (particle_filter.cpp:495-499): push_back(copy) per slot, clear, copy-assign.
-  void resample(const int* parent) {
-    const int n = particles();
-    std::vector<std::unordered_set<int>> tmp_sets;
-    std::vector<std::vector<uint16_t>> tmp_codes;
-    for (int m = 0; m < n; ++m) { tmp_sets.push_back(sets_[parent[m]]); tmp_codes.push_back(codes_[parent[m]]); }
-    sets_.clear();
-    sets_ = tmp_sets;
-    codes_.clear();
-    codes_ = tmp_codes;
-  }
-
- private:
-  // (12 bytes instead of the reference's 48-byte Cell: the heap is std::priority_queue — the same std::push_heap / std::pop_heap
-  //  sequence over the same comparison results, hence the same order among equal distances — it just moves a quarter of the bytes)
-  struct Node { uint32_t d2; uint16_t i, j, si, sj; };
-  struct Farther { bool operator()(const Node& a, const Node& b) const { return a.d2 > b.d2; } };  // CompareDistance, grid_mapper.hpp:104-110
 
   // enqueueCell, grid_mapper.cpp:272-329
-  void enqueue(int i, int j, int si, int sj, std::priority_queue<Node, std::vector<Node>, Farther>& Q, std::vector<uint16_t>& code,
-               std::vector<uint8_t>& marked) {
+  void enqueue(int i, int j, int si, int sj, Heap& Q, std::vector<uint16_t>& code, std::vector<uint8_t>& marked) const {
     const int idx = i * xs_ + j;
     if (marked[idx]) return;
     const int di = std::abs(i - si), dj = std::abs(j - sj);
@@ -147,8 +199,9 @@ class RefField {
   }
 
   int xs_, radius_;
-  std::vector<std::unordered_set<int>> sets_;
-  std::vector<std::vector<uint16_t>> codes_;
+  int last_brushfires_ = 0;
+  long long total_brushfires_ = 0;
+  std::vector<StatePtr> st_;
 };
 
 }  // namespace tbnav

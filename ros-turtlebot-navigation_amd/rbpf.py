@@ -211,6 +211,13 @@ class ParticleFilter:
         capi.check(self._L.tbnav_rbpf_scan_counts(self._h, C.byref(a), C.byref(b), 1 if reset else 0), "scan_counts")
         return a.value, b.value
 
+    def referenceFieldCounts(self):
+        """Reference-field mode: (distinct states the particles hold, brushfires run by the last scan, by all scans) —
+        tbnav_rbpf_reference_field_counts."""
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int64()
+        capi.check(self._L.tbnav_rbpf_reference_field_counts(self._h, C.byref(a), C.byref(b), C.byref(c)), "reference_field_counts")
+        return a.value, b.value, c.value
+
     def setTiming(self, on: bool = True):
         """Record HIP events round the kernels of the following SLAM calls (they cost device time: off by default)."""
         capi.check(self._L.tbnav_rbpf_set_timing(self._h, 1 if on else 0), "set_timing")

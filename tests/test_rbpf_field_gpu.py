@@ -23,10 +23,10 @@ def _dev(gpu_pkg, df_mode=None, **kw):
     return ParticleFilter(default_params(**kw), df_mode=df_mode)
 
 
-def _free_run(gpu_pkg, df_mode, N, k, map_half, walls, n_scans, inc, seed, force_resample_at=None, **extra):
-    pf_o = orc.PfAPI(orc.pf_params(N=N, k=k, map_min=-map_half, map_max=map_half, **extra))
-    pf_d = _dev(gpu_pkg, df_mode=df_mode, N=N, k=k, map_min=-map_half, map_max=map_half, **extra)
-    steps, poses = rc.trajectory(n_scans, inc=inc)
+def _free_run(gpu_pkg, df_mode, N, k, map_half, walls, n_scans, inc, seed, force_resample_at=None, start=(0.0, 0.0, 0.0), **extra):
+    pf_o = orc.PfAPI(orc.pf_params(N=N, k=k, map_min=-map_half, map_max=map_half, pose0=start, **extra))
+    pf_d = _dev(gpu_pkg, df_mode=df_mode, N=N, k=k, map_min=-map_half, map_max=map_half, pose0=start, **extra)
+    steps, poses = rc.trajectory(n_scans, inc=inc, start=start)
     rng = np.random.default_rng(seed)
     rows = []
     for s, (prev, cur, t_icp, u) in enumerate(steps):
@@ -73,6 +73,29 @@ def test_reference_mode_shipped_config_is_the_reference_end_to_end(gpu_pkg):
         exact = orc.exact_edt_codes(occ.reshape(pf_d.xsize, pf_d.xsize), 200, np.full((pf_d.xsize, pf_d.xsize), 0xFFFF, np.uint16))
         n_nonexact += int((pf_d.distCode(p).reshape(pf_d.xsize, pf_d.xsize) != exact).sum())
     assert n_nonexact > 0  # ... i.e. this really is the brushfire, not the exact transform
+    pf_d.close()
+
+
+def test_reference_mode_shares_one_brushfire_among_particles_in_the_same_state(gpu_pkg):
+    """The reference's field is a function of (occupied set with its history, stale field, the scan's insert / erase sequence), and
+    the product runs ONE brushfire per distinct such triple instead of one per particle (csrc/ref_field.hpp).  With the shipped
+    sampling spread (1e-8 m) and a robot that does not sit on a cell corner, most particles see the same cells change — fewer
+    brushfires than particle-scans — and a resample makes copies; every particle's field must still be the oracle's own
+    per-particle brushfire bit for bit, stale cells and all."""
+    N, n_scans = 48, 6
+    pf_o, pf_d, rows = _free_run(gpu_pkg, "reference", N=N, k=50, map_half=2.0, walls=rc.ROOM_SMALL, n_scans=n_scans,
+                                 inc=(0.04, 0.03, 0.02), seed=11, force_resample_at=3, start=(0.3, 0.0137, 0.0211))
+    assert rows[3]["resampled"] == (1, 1)
+    for s, r in enumerate(rows):
+        assert r["p_scan"] <= 1e-9 and r["eta"] <= 1e-9 and r["w"] <= 1e-9, (s, r)
+        assert r["neff"][0] == r["neff"][1] and r["parents_equal"] and r["best"][0] == r["best"][1], (s, r)
+    for p in range(N):
+        g = pf_o.grid(p).dump()
+        assert np.array_equal(pf_d.occDist(p), g["occ_dist"]), p
+        assert np.array_equal(pf_d.logOdds(p), g["log_odds"]), p
+    distinct, last, total = pf_d.referenceFieldCounts()
+    assert 1 <= distinct <= N and last <= N
+    assert total < N * n_scans // 2, (distinct, last, total)   # (every particle on its own would be N * n_scans = 288)
     pf_d.close()
 
 
