@@ -158,6 +158,37 @@ def _cpu_baseline(orc, K, T, horizon, budget_s, threads):
             "ms_per_tick": round(el / n * 1e3, 4)}
 
 
+LEGS_BUDGET_S = 240.0  # the N > 1 legs take seconds (60 ticks, 14 scans, RCCL's first point-to-point connections)
+
+
+class LegWatchdog:
+    """Bounds the optional multi-GPU legs: if they are not through after `seconds`, rank 0 prints the headline line it already
+    has (with the reason) and every rank leaves with os._exit — a hung collective cannot be interrupted any other way."""
+
+    def __init__(self, rank, line, seconds):
+        import threading
+        self.rank, self.line = rank, line
+        self.timer = threading.Timer(seconds, self._fire, args=(f"not finished after {seconds:.0f} s",))
+        self.timer.daemon = True
+        self.timer.start()
+
+    def _fire(self, why):
+        if self.rank == 0 and self.line is not None:
+            out = dict(self.line)
+            out["multi_gpu_legs"] = f"skipped: {why}"
+            print(json.dumps(out), flush=True)
+        else:
+            time.sleep(3.0)  # (rank 0's line first)
+        os._exit(0)
+
+    def expire_now(self, why):
+        self.timer.cancel()
+        self._fire(why)
+
+    def cancel(self):
+        self.timer.cancel()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -284,19 +315,25 @@ def main():
     out_controls = m.lastControls(stream)
     assert all(np.isfinite(out_controls)), out_controls
 
-    extra = {}
+    # one synchronous tick (launch + wait + 16-byte D2H), the latency a control loop sees.  With a communicator attached the
+    # tick contains the all-gather, so EVERY rank takes part (on rank 0 alone it would wait for peers that never call)
+    n_sync = 200
     if world > 1:
-        extra = multi_gpu_legs(world, rank, local_rank, device, one_gpu_test, stream, sync, barrier, comm)
+        sync(); barrier(); sync()
+    t0 = time.perf_counter()
+    for i in range(n_sync):
+        if world == 1 or comm is not None:
+            m.newControlsRng(X0, SEED, 10_000_000 + i, stream)
+        else:
+            tick(); sync()
+    sync_ms = (time.perf_counter() - t0) / n_sync * 1e3
 
+    line = None
     if rank == 0:
         ms_step = el / args.steps * 1e3
         value = world * K * args.steps / el
+        # (local launches of this rank's kernels — no exchange — also on a handle with a communicator attached)
         ms_k = kernel_profile(m, a, b, stream, min(args.steps, 500))
-        # one synchronous tick (launch + wait + 16-byte D2H), the latency a control loop sees
-        t0 = time.perf_counter()
-        for i in range(200):
-            m.newControlsRng(X0, SEED, 10_000_000 + i, stream)
-        sync_ms = (time.perf_counter() - t0) / 200 * 1e3
         line = {
             "metric": "MPPI rollouts/s", "value": round(value, 1), "unit": "rollouts/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 6),
@@ -309,12 +346,12 @@ def main():
             "rollout_steps_per_s": round(value * T, 1),
             "sync_tick_ms": round(sync_ms, 6),
             "entry_point": ("tbnav_mppi_enqueue_rng_batch (the timed ticks enqueued by ONE call through the C boundary)" if (world == 1 or comm is not None)
-                            else "tbnav_mppi_shard_* per tick from Python (one-GPU gloo dev switch)"),
+                            else "tbnav_mppi_shard_* per tick from Python (rtn_amd.sharded)"),
             # what actually ran in the timed region: whole chunks of 100 ticks are replayed from a captured hipGraph, the rest (all of
             # them when --steps < 100, as with the driver's --steps 20) are plain launches
             "graph_replayed_ticks": graph_ticks_timed,
             "exchange": None if world == 1 else ("ncclAllGather of the soft-min records issued by libtbnav_hip.so on the tick's stream (tbnav_mppi_attach_comm)"
-                                                 if comm is not None else "torch.distributed gloo all-gather from Python (dev switch)"),
+                                                 if comm is not None else f"torch.distributed {dist.get_backend()} all-gather from Python (rtn_amd.sharded; the in-library communicator was unavailable or the one-GPU dev switch is on)"),
             "ms_per_step_one_python_call_per_tick": None if el_py is None else round(el_py / args.steps * 1e3, 6),
             "roofline": roofline_obj(K, T, ms_k, ms_step, m.rollout_kernel, "mppi_K1024_T50" if (K, T) == (1024, 50) else None),
             # the tick is two dependent launches: what the guide prices for that alone (MI355X_MICROARCH.md, "boundary" row)
@@ -322,7 +359,23 @@ def main():
                               "note": "K*T*48 B = 2.46 MB lives in L2: the tick is launch / dependent-latency bound, not HBM bound; "
                                       "kernel_ms are back-to-back launch averages and already contain one boundary each"},
         }
-        line.update(extra)
+
+    # ---- N > 1: two more measurements with the same processes.  They run under a watchdog: the headline above is complete, and a
+    #      leg that does not come back (an exchange that hangs on this node) must not take it along — on expiry rank 0 prints the
+    #      line without them (`multi_gpu_legs` says so) and every rank leaves.
+    if world > 1:
+        extra = {}
+        wd = LegWatchdog(rank, line, LEGS_BUDGET_S)
+        try:
+            extra = multi_gpu_legs(world, rank, local_rank, device, one_gpu_test, stream, sync, barrier, comm)
+        except Exception as e:  # noqa: BLE001 — the peers may be inside a collective this rank never reaches: leave through the watchdog
+            print(f"[bench rank {rank}] multi-GPU legs failed: {e!r}", file=sys.stderr, flush=True)
+            wd.expire_now(f"failed on rank {rank}: {e!r}")
+        wd.cancel()
+        if rank == 0:
+            line.update(extra)
+
+    if rank == 0:
         if world == 1 and not args.no_large:
             KL, HL = 65536, 1.0  # BASELINE configs[3] per-call size, on one GPU
             ml = make_mppi(KL, HL, local_rank)
@@ -377,6 +430,10 @@ def main():
             line["rbpf"] = bench_rbpf.run(device, args, with_cpu=not args.no_cpu_baseline)
         print(json.dumps(line), flush=True)
     if world > 1:
+        # handles before the communicator they exchange through, the communicator before the job's own process group
+        m.close()
+        if comm is not None:
+            comm.close()
         dist.barrier()
         dist.destroy_process_group()
 

@@ -48,13 +48,23 @@ class Comm:
         import torch
         import torch.distributed as dist
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        t = torch.zeros(ID_BYTES, dtype=torch.uint8)
+        # the id and one more byte: 1 = rank 0 has an id.  A rank 0 that cannot draw one (librccl missing) still takes part in
+        # the broadcast, so that EVERY rank raises here instead of rank 0 alone leaving its peers inside the collective
+        t = torch.zeros(ID_BYTES + 1, dtype=torch.uint8)
+        err = None
         if rank == 0:
-            t = torch.frombuffer(bytearray(cls.unique_id()), dtype=torch.uint8).clone()
+            try:
+                t[:ID_BYTES] = torch.frombuffer(bytearray(cls.unique_id()), dtype=torch.uint8)
+                t[ID_BYTES] = 1
+            except Exception as e:  # noqa: BLE001
+                err = e
         if dist.get_backend(group) != "gloo":
             t = t.to(torch.device("cuda", device))
         dist.broadcast(t, 0, group=group)
-        return cls.create(bytes(t.cpu().numpy().tobytes()), world, rank, device)
+        raw = bytes(t.cpu().numpy().tobytes())
+        if raw[ID_BYTES] != 1:
+            raise RuntimeError(f"rank 0 could not draw an RCCL unique id ({err})" if rank == 0 else "rank 0 could not draw an RCCL unique id")
+        return cls.create(raw[:ID_BYTES], world, rank, device)
 
     rank = property(lambda self: self._L.tbnav_comm_rank(self._h))
     size = property(lambda self: self._L.tbnav_comm_size(self._h))
