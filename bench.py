@@ -223,17 +223,21 @@ def main():
     graft.load_package()
     from rtn_amd.sharded import HipShardBackend, ShardedMPPI
     comm = None
-    if world > 1 and not one_gpu_test:
-        # the communicator the LIBRARY exchanges through (include/tbnav_comm.h): rank 0's RCCL unique id travels over the job's own
+    # dev switch: the round-2 exchange driven from Python (rtn_amd.sharded) instead of the library's own
+    py_exchange = os.environ.get("TBNAV_BENCH_PY_EXCHANGE") == "1"
+    transport = "ipc" if one_gpu_test else "rccl"   # ranks sharing one device: RCCL refuses them, the library's IPC transport does not
+    if world > 1 and not py_exchange:
+        # the communicator the LIBRARY exchanges through (include/tbnav_comm.h): rank 0's id travels over the job's own
         # process group; torch.distributed is left with the barriers and the max-over-ranks of the timing
         from rtn_amd.comm import Comm
+        red_dev = "cpu" if one_gpu_test else device
         try:
-            comm = Comm.from_torch_distributed(local_rank)
+            comm = Comm.from_torch_distributed(local_rank, transport=transport)
             comm.selftest(1 << 16)   # one all-gather + one ring of sends through the library's transport, checked, before anything is timed
-            ok = torch.ones(1, device=device)
+            ok = torch.ones(1, device=red_dev)
         except Exception as e:  # noqa: BLE001 — the line says which exchange ran ("exchange"); the Python path is the round-2 one
             print(f"[bench rank {rank}] in-library communicator unavailable ({e}); using the torch.distributed exchange", file=sys.stderr, flush=True)
-            comm, ok = None, torch.zeros(1, device=device)
+            comm, ok = None, torch.zeros(1, device=red_dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # all ranks take the same path
         if float(ok.item()) == 0.0:
             comm = None
@@ -350,7 +354,8 @@ def main():
             # what actually ran in the timed region: whole chunks of 100 ticks are replayed from a captured hipGraph, the rest (all of
             # them when --steps < 100, as with the driver's --steps 20) are plain launches
             "graph_replayed_ticks": graph_ticks_timed,
-            "exchange": None if world == 1 else ("ncclAllGather of the soft-min records issued by libtbnav_hip.so on the tick's stream (tbnav_mppi_attach_comm)"
+            "exchange": None if world == 1 else ((("ncclAllGather" if transport == "rccl" else "all-gather (IPC transport: ranks share one device)")
+                                                  + " of the soft-min records issued by libtbnav_hip.so on the tick's stream (tbnav_mppi_attach_comm)")
                                                  if comm is not None else f"torch.distributed {dist.get_backend()} all-gather from Python (rtn_amd.sharded; the in-library communicator was unavailable or the one-GPU dev switch is on)"),
             "ms_per_step_one_python_call_per_tick": None if el_py is None else round(el_py / args.steps * 1e3, 6),
             "roofline": roofline_obj(K, T, ms_k, ms_step, m.rollout_kernel, "mppi_K1024_T50" if (K, T) == (1024, 50) else None),
@@ -506,8 +511,9 @@ def multi_gpu_legs(world, rank, local_rank, device, one_gpu_test, stream, sync, 
                            "ms_per_scan_rank0": {"without_resample": round(float(np.mean(t_plain)) * 1e3, 4) if t_plain else None,
                                                  "resampling_with_migration": round(float(np.mean(t_res)) * 1e3, 4) if t_res else None},
                            "bytes_migrated_rank0": None if sr is None else sr.bytes_migrated, "scaling": "weak",
-                           "exchange": ("inside libtbnav_hip.so (tbnav_rbpf_attach_comm): ncclAllGather of the weights + the global normalise on a second "
-                                        "stream beside the map update; ncclSend / ncclRecv of tile blobs when resampling fires") if sr is None else "torch.distributed (gloo dev switch)"}
+                           "exchange": ("inside libtbnav_hip.so (tbnav_rbpf_attach_comm): all-gather of the weights + the global normalise on a second "
+                                        "stream beside the map update; point-to-point sends of tile blobs when resampling fires; transport: "
+                                        + ("RCCL" if comm.uses_rccl else "IPC (ranks share one device)")) if sr is None else f"torch.distributed {dist.get_backend()} (rtn_amd.sharded)"}
     pf.close()
     return out
 

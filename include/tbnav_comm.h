@@ -38,6 +38,13 @@ typedef struct tbnav_comm tbnav_comm; /* opaque */
 
 /* A fresh job-wide identifier (ncclGetUniqueId); call on one rank and hand the bytes to the others. */
 int tbnav_comm_unique_id(uint8_t id[TBNAV_COMM_ID_BYTES]);
+/* The same for the IPC transport: the ranks are processes of ONE node and may share a device, which RCCL refuses.  They meet in
+ * a POSIX shared-memory segment named by the id and copy device to device out of each other's allocations (hipIpcMemHandle).
+ * Host-synchronous (every exchange drains the stream it is given and returns when the data has arrived) and every exchange is
+ * collective over all ranks; a peer that does not show up within two minutes is an error, not a hang.  What it is for: running
+ * the multi-process code paths — one rank per process, exactly as under RCCL — on a one-GPU box (tests, bench.py's dev
+ * switch).  tbnav_comm_create recognises such an id. */
+int tbnav_comm_unique_id_ipc(uint8_t id[TBNAV_COMM_ID_BYTES]);
 /* This process's rank of an nranks-rank job; device = HIP ordinal (-1: current).  Collective: returns when every
  * rank has called it. */
 int tbnav_comm_create(const uint8_t id[TBNAV_COMM_ID_BYTES], int32_t nranks, int32_t rank, int32_t device, tbnav_comm** out);

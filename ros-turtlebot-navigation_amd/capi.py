@@ -145,6 +145,7 @@ def lib() -> C.CDLL:
         "tbnav_mppi_profile_kernels": (C.c_int, [vp, dp, vp, vp, vp, i32, C.POINTER(C.c_float)]),
         # communicators (include/tbnav_comm.h) and the sharded MPPI tick
         "tbnav_comm_unique_id": (C.c_int, [vp]),
+        "tbnav_comm_unique_id_ipc": (C.c_int, [vp]),
         "tbnav_comm_create": (C.c_int, [vp, i32, i32, i32, C.POINTER(vp)]),
         "tbnav_comm_create_local": (C.c_int, [i32, vp, vp]),
         "tbnav_comm_destroy": (None, [vp]),

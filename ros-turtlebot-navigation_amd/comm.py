@@ -21,9 +21,15 @@ class Comm:
         self._owns = owns
 
     @staticmethod
-    def unique_id() -> bytes:
+    def unique_id(transport: str = "rccl") -> bytes:
+        """transport "rccl": ncclGetUniqueId; "ipc": an id of the IPC transport (ranks = processes of one node that may share a
+        device; tbnav_comm_unique_id_ipc) — tbnav_comm_create tells them apart."""
         buf = (C.c_uint8 * ID_BYTES)()
-        capi.check(capi.lib().tbnav_comm_unique_id(C.cast(buf, C.c_void_p)), "tbnav_comm_unique_id")
+        if transport == "ipc":
+            capi.check(capi.lib().tbnav_comm_unique_id_ipc(C.cast(buf, C.c_void_p)), "tbnav_comm_unique_id_ipc")
+        else:
+            assert transport == "rccl", transport
+            capi.check(capi.lib().tbnav_comm_unique_id(C.cast(buf, C.c_void_p)), "tbnav_comm_unique_id")
         return bytes(buf)
 
     @classmethod
@@ -43,7 +49,7 @@ class Comm:
         return [cls(C.c_void_p(out[i])) for i in range(n)]
 
     @classmethod
-    def from_torch_distributed(cls, device: int, group=None) -> "Comm":
+    def from_torch_distributed(cls, device: int, group=None, transport: str = "rccl") -> "Comm":
         """This process's rank of the initialised torch.distributed job (any backend: the id travels as a byte tensor)."""
         import torch
         import torch.distributed as dist
@@ -54,7 +60,7 @@ class Comm:
         err = None
         if rank == 0:
             try:
-                t[:ID_BYTES] = torch.frombuffer(bytearray(cls.unique_id()), dtype=torch.uint8)
+                t[:ID_BYTES] = torch.frombuffer(bytearray(cls.unique_id(transport)), dtype=torch.uint8)
                 t[ID_BYTES] = 1
             except Exception as e:  # noqa: BLE001
                 err = e
@@ -63,7 +69,7 @@ class Comm:
         dist.broadcast(t, 0, group=group)
         raw = bytes(t.cpu().numpy().tobytes())
         if raw[ID_BYTES] != 1:
-            raise RuntimeError(f"rank 0 could not draw an RCCL unique id ({err})" if rank == 0 else "rank 0 could not draw an RCCL unique id")
+            raise RuntimeError(f"rank 0 could not draw a communicator id ({err})" if rank == 0 else "rank 0 could not draw a communicator id")
         return cls.create(raw[:ID_BYTES], world, rank, device)
 
     rank = property(lambda self: self._L.tbnav_comm_rank(self._h))

@@ -4,7 +4,12 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
 
+#include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -72,13 +77,168 @@ struct DevGuard {
   ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
+// ---- the IPC transport: processes of one node whose ranks may SHARE a device (RCCL refuses two ranks on one device) ----------
+// A POSIX shared-memory segment carries a barrier and, per rank, the table of what it sends this round (destination, bytes);
+// every rank owns one device MAILBOX, exported once (hipIpcMemHandle) and mapped once by every peer when the communicator is
+// made.  An exchange: the sender copies its messages, back to back, into its own mailbox; the ranks meet; every receiver
+// copies what is addressed to it out of the sender's mailbox (device to device); they meet again.  More than a mailbox holds
+// goes in several such rounds.  Host-synchronous — every call drains the caller's stream and returns when the data has
+// arrived — which is more than the stream order the callers rely on.  What it is for: running the multi-PROCESS code paths (one
+// rank per process, exactly as under RCCL) on a one-GPU box — tests/test_comm_processes_gpu.py, bench.py's one-GPU dev switch.
+// An all-zero segment is the initial state.
+constexpr unsigned char kIpcMagic[8] = {'T', 'B', 'N', 'A', 'V', 'I', 'P', 'C'};
+constexpr int kIpcMaxRanks = 16, kIpcMaxMsgs = kIpcMaxRanks + 1;
+constexpr size_t kIpcMailbox = (size_t)16 << 20;
+constexpr double kIpcTimeoutS = 120.0;   // a peer that never arrives (it failed) is an error here, not a hang
+struct IpcMsg { unsigned long long bytes; int dst, pad; };   // dst -1: every other rank reads it (an all-gather's block)
+struct IpcSlot { hipIpcMemHandle_t mailbox; unsigned int n_msgs, pad; IpcMsg msg[kIpcMaxMsgs]; };
+struct IpcShared {
+  std::atomic<unsigned int> arrived, generation, failed;
+  unsigned int pad;
+  IpcSlot slot[kIpcMaxRanks];
+};
+struct IpcState {
+  IpcShared* sh = nullptr;
+  char* mailbox = nullptr;            // mine
+  char* peer[kIpcMaxRanks] = {};      // the others', mapped
+  bool i_failed = false;
+  // a failure is final for the whole communicator: the flag in the segment stops every rank at its next barrier
+  int fail(const char* what) {
+    if (sh) sh->failed.store(1u);
+    if (!i_failed) tbnav::last_hip_error_slot() = std::string("ipc transport: ") + what;   // (the first cause stays)
+    i_failed = true;
+    return TBNAV_ERR_HIP;
+  }
+  int peer_failed() {
+    if (!i_failed) tbnav::last_hip_error_slot() = "ipc transport: another rank reported a failure";
+    return TBNAV_ERR_HIP;
+  }
+  // every rank arrives; TBNAV_ERR_HIP if some rank has failed or a peer does not arrive within kIpcTimeoutS
+  int barrier(int nranks) {
+    if (sh->failed.load()) return peer_failed();
+    const unsigned int gen = sh->generation.load();
+    if (sh->arrived.fetch_add(1u) + 1u == (unsigned int)nranks) { sh->arrived.store(0u); sh->generation.fetch_add(1u); }
+    else {
+      const auto t0 = std::chrono::steady_clock::now();
+      for (unsigned int spins = 0; sh->generation.load() == gen; ++spins) {
+        if (spins > 2000) usleep(50);
+        if ((spins & 255u) == 255u) {
+          if (sh->failed.load()) return peer_failed();
+          if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > kIpcTimeoutS) return fail("a rank did not arrive at the barrier");
+        }
+      }
+    }
+    return sh->failed.load() ? peer_failed() : TBNAV_OK;
+  }
+};
+
 }  // namespace
 
 struct tbnav_comm {
   int rank = 0, nranks = 1, device = 0;
   ncclComm_t nccl = nullptr;
   LocalGroup* group = nullptr;  // non-null: member of a one-process group
+  IpcState* ipc = nullptr;      // non-null: rank of a multi-process job on the IPC transport
 };
+
+namespace {
+// One exchange on the IPC transport (collective over ALL ranks).  sends: (peer, pointer, bytes), peer -1 = every other rank reads
+// it; recvs: (peer, pointer, bytes); message i from q to me = the i-th entry of q's table naming me (or everybody) and my i-th
+// receive naming q.  A rank's messages form one byte stream in table order; round i moves the stream's window
+// [i * kIpcMailbox, (i + 1) * kIpcMailbox) through the mailbox.
+int ipc_round(tbnav_comm* c, const std::vector<tbnav::P2P>& sends, const std::vector<tbnav::P2P>& recvs, hipStream_t st) {
+  IpcState& I = *c->ipc;
+  DevGuard dg(c->device);
+  const int P = c->nranks, me = c->rank;
+  int rc = TBNAV_OK;
+  auto note = [&](bool ok, const char* what) { if (!ok && rc == TBNAV_OK) rc = I.fail(what); return ok; };
+  note(hipStreamSynchronize(st) == hipSuccess, "hipStreamSynchronize");   // what I send is written
+  IpcSlot& mine = I.sh->slot[me];
+  if (note(sends.size() <= (size_t)kIpcMaxMsgs, "too many messages in one exchange")) {
+    mine.n_msgs = (unsigned int)sends.size();
+    for (size_t i = 0; i < sends.size(); ++i) { mine.msg[i].bytes = sends[i].bytes; mine.msg[i].dst = sends[i].peer; mine.msg[i].pad = 0; }
+  } else mine.n_msgs = 0;
+  if (I.barrier(P) != TBNAV_OK || rc != TBNAV_OK) return TBNAV_ERR_HIP;   // tables are up
+  // where each of my receives sits in its sender's stream
+  struct Piece { const char* src_base; unsigned long long off, bytes; char* dst; };
+  std::vector<Piece> in;
+  unsigned long long longest = 0;
+  for (int q = 0; q < P; ++q) {
+    const IpcSlot& sl = I.sh->slot[q];
+    unsigned long long total = 0;
+    unsigned int is = 0;
+    std::vector<unsigned long long> off(sl.n_msgs + 1, 0);
+    for (unsigned int i = 0; i < sl.n_msgs; ++i) off[i + 1] = off[i] + sl.msg[i].bytes;
+    total = off[sl.n_msgs];
+    longest = total > longest ? total : longest;
+    if (q == me) continue;
+    for (const tbnav::P2P& rv : recvs) {
+      if (rv.peer != q) continue;
+      while (is < sl.n_msgs && sl.msg[is].dst != me && sl.msg[is].dst != -1) ++is;
+      if (!note(is < sl.n_msgs && sl.msg[is].bytes == rv.bytes, "the two sides of an exchange disagree")) break;
+      if (rv.bytes) in.push_back(Piece{I.peer[q], off[is], rv.bytes, static_cast<char*>(rv.ptr)});
+      ++is;
+    }
+  }
+  // a message to myself (the self-test of a one-rank communicator) never touches the mailbox
+  for (const tbnav::P2P& rv : recvs) {
+    if (rv.peer != me || !rv.bytes) continue;
+    const tbnav::P2P* sv = nullptr;
+    for (const tbnav::P2P& x : sends) if (x.peer == me && x.bytes == rv.bytes) { sv = &x; break; }
+    if (note(sv != nullptr, "a message to itself without its send")) note(hipMemcpyAsync(rv.ptr, sv->ptr, rv.bytes, hipMemcpyDeviceToDevice, st) == hipSuccess, "local copy");
+  }
+  std::vector<unsigned long long> my_off(sends.size() + 1, 0);
+  for (size_t i = 0; i < sends.size(); ++i) my_off[i + 1] = my_off[i] + sends[i].bytes;
+  const unsigned long long rounds = (longest + kIpcMailbox - 1) / kIpcMailbox;
+  for (unsigned long long r = 0; r < rounds; ++r) {
+    const unsigned long long w0 = r * kIpcMailbox, w1 = w0 + kIpcMailbox;
+    for (size_t i = 0; i < sends.size() && rc == TBNAV_OK; ++i) {     // my stream's window into my mailbox
+      if (sends[i].peer == me) continue;
+      const unsigned long long a0 = my_off[i] > w0 ? my_off[i] : w0, a1 = my_off[i + 1] < w1 ? my_off[i + 1] : w1;
+      if (a0 < a1) note(hipMemcpyAsync(I.mailbox + (a0 - w0), static_cast<const char*>(sends[i].ptr) + (a0 - my_off[i]), (size_t)(a1 - a0), hipMemcpyDeviceToDevice, st) == hipSuccess, "copy into the mailbox");
+    }
+    note(hipStreamSynchronize(st) == hipSuccess, "hipStreamSynchronize");
+    if (I.barrier(P) != TBNAV_OK || rc != TBNAV_OK) return TBNAV_ERR_HIP;   // mailboxes are full
+    for (const Piece& pc : in) {
+      const unsigned long long a0 = pc.off > w0 ? pc.off : w0, a1 = pc.off + pc.bytes < w1 ? pc.off + pc.bytes : w1;
+      if (a0 < a1 && rc == TBNAV_OK) note(hipMemcpyAsync(pc.dst + (a0 - pc.off), pc.src_base + (a0 - w0), (size_t)(a1 - a0), hipMemcpyDeviceToDevice, st) == hipSuccess, "copy out of a peer's mailbox");
+    }
+    note(hipStreamSynchronize(st) == hipSuccess, "hipStreamSynchronize");
+    if (I.barrier(P) != TBNAV_OK || rc != TBNAV_OK) return TBNAV_ERR_HIP;   // mailboxes are free again
+  }
+  if (rounds == 0) note(hipStreamSynchronize(st) == hipSuccess, "hipStreamSynchronize");
+  return rc;
+}
+
+// the mailboxes: allocate and export mine, map everybody else's (called once, by tbnav_comm_create)
+int ipc_open_mailboxes(tbnav_comm* c) {
+  IpcState& I = *c->ipc;
+  DevGuard dg(c->device);
+  int rc = TBNAV_OK;
+  if (hipMalloc((void**)&I.mailbox, kIpcMailbox) != hipSuccess) rc = I.fail("hipMalloc of the mailbox");
+  if (rc == TBNAV_OK && hipIpcGetMemHandle(&I.sh->slot[c->rank].mailbox, I.mailbox) != hipSuccess) rc = I.fail("hipIpcGetMemHandle");
+  if (I.barrier(c->nranks) != TBNAV_OK || rc != TBNAV_OK) return TBNAV_ERR_HIP;
+  for (int q = 0; q < c->nranks && rc == TBNAV_OK; ++q) {
+    if (q == c->rank) { I.peer[q] = I.mailbox; continue; }
+    void* base = nullptr;
+    if (hipIpcOpenMemHandle(&base, I.sh->slot[q].mailbox, hipIpcMemLazyEnablePeerAccess) != hipSuccess) rc = I.fail("hipIpcOpenMemHandle");
+    I.peer[q] = static_cast<char*>(base);
+  }
+  if (I.barrier(c->nranks) != TBNAV_OK || rc != TBNAV_OK) return TBNAV_ERR_HIP;
+  return TBNAV_OK;
+}
+void ipc_close(tbnav_comm* c) {
+  IpcState* I = c->ipc;
+  if (!I) return;
+  DevGuard dg(c->device);
+  (void)hipDeviceSynchronize();
+  for (int q = 0; q < c->nranks; ++q) if (q != c->rank && I->peer[q]) (void)hipIpcCloseMemHandle(I->peer[q]);
+  if (I->mailbox) (void)hipFree(I->mailbox);
+  if (I->sh) munmap(I->sh, sizeof(IpcShared));
+  delete I;
+  c->ipc = nullptr;
+}
+}  // namespace
 
 namespace tbnav {
 
@@ -101,6 +261,14 @@ int comm_all_gather(int n, tbnav_comm* const* comms, const void* const* send, vo
   { const int rc = check_members(n, comms); if (rc != TBNAV_OK) return rc; }
   if (bytes == 0) return TBNAV_OK;
   LocalGroup* g = comms[0]->group;
+  if (comms[0]->ipc) {  // (n == 1: check_members) my block is ONE entry every other rank reads; the own block is a local copy
+    tbnav_comm* c = comms[0];
+    std::vector<P2P> sends{P2P{-1, const_cast<void*>(send[0]), bytes}}, recvs;
+    for (int q = 0; q < c->nranks; ++q) if (q != c->rank) recvs.push_back(P2P{q, static_cast<char*>(recv[0]) + (size_t)q * bytes, bytes});
+    char* own = static_cast<char*>(recv[0]) + (size_t)c->rank * bytes;
+    if (own != send[0]) { DevGuard dg(c->device); TBNAV_HIP(hipMemcpyAsync(own, send[0], bytes, hipMemcpyDeviceToDevice, streams[0])); }
+    return ipc_round(c, sends, recvs, streams[0]);
+  }
   if (!g || g->use_rccl) {
     Rccl& R = rccl();
     if (!R.ok) return TBNAV_ERR_UNSUPPORTED;
@@ -141,6 +309,7 @@ int comm_exchange(int n, tbnav_comm* const* comms, const std::vector<P2P>* sends
     for (const P2P& m : sends[r]) if (m.peer < 0 || m.peer >= world || (m.bytes && !m.ptr)) return TBNAV_ERR_INVALID_ARG;
     for (const P2P& m : recvs[r]) if (m.peer < 0 || m.peer >= world || (m.bytes && !m.ptr)) return TBNAV_ERR_INVALID_ARG;
   }
+  if (comms[0]->ipc) return ipc_round(comms[0], sends[0], recvs[0], streams[0]);  // (collective on this transport: every rank calls, also with nothing to send)
   if (!g || g->use_rccl) {
     Rccl& R = rccl();
     if (!R.ok) return TBNAV_ERR_UNSUPPORTED;
@@ -202,6 +371,17 @@ int tbnav_comm_unique_id(uint8_t id[TBNAV_COMM_ID_BYTES]) {
   return TBNAV_OK;
 }
 
+int tbnav_comm_unique_id_ipc(uint8_t id[TBNAV_COMM_ID_BYTES]) {
+  if (!id) return TBNAV_ERR_INVALID_ARG;
+  std::memset(id, 0, TBNAV_COMM_ID_BYTES);
+  std::memcpy(id, kIpcMagic, sizeof kIpcMagic);
+  const int fd = open("/dev/urandom", O_RDONLY);
+  const bool ok = fd >= 0 && read(fd, id + 8, 16) == 16;
+  if (fd >= 0) close(fd);
+  if (!ok) { tbnav::last_hip_error_slot() = "ipc transport: /dev/urandom"; return TBNAV_ERR_HIP; }
+  return TBNAV_OK;
+}
+
 int tbnav_comm_create(const uint8_t id[TBNAV_COMM_ID_BYTES], int32_t nranks, int32_t rank, int32_t device, tbnav_comm** out) {
   if (!id || !out || nranks <= 0 || rank < 0 || rank >= nranks) return TBNAV_ERR_INVALID_ARG;
   *out = nullptr;
@@ -209,6 +389,28 @@ int tbnav_comm_create(const uint8_t id[TBNAV_COMM_ID_BYTES], int32_t nranks, int
   { const hipError_t e = hipGetDeviceCount(&ndev); if (e != hipSuccess || ndev <= 0) return tbnav::hip_fail(e == hipSuccess ? hipErrorNoDevice : e, "hipGetDeviceCount", __FILE__, __LINE__); }
   if (device < 0) TBNAV_HIP(hipGetDevice(&device));
   if (device >= ndev) return TBNAV_ERR_INVALID_ARG;
+  if (std::memcmp(id, kIpcMagic, sizeof kIpcMagic) == 0) {  // an id drawn by tbnav_comm_unique_id_ipc: the IPC transport
+    if (nranks > kIpcMaxRanks) return TBNAV_ERR_INVALID_ARG;
+    char name[48] = "/tbnav_";
+    for (int i = 0; i < 16; ++i) std::snprintf(name + 7 + 2 * i, 3, "%02x", id[8 + i]);
+    const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
+    if (fd < 0) { tbnav::last_hip_error_slot() = "ipc transport: shm_open"; return TBNAV_ERR_HIP; }
+    void* mem = MAP_FAILED;
+    if (ftruncate(fd, (off_t)sizeof(IpcShared)) == 0) mem = mmap(nullptr, sizeof(IpcShared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (mem == MAP_FAILED) { tbnav::last_hip_error_slot() = "ipc transport: mmap"; return TBNAV_ERR_HIP; }
+    tbnav_comm* c = new (std::nothrow) tbnav_comm();
+    IpcState* st = new (std::nothrow) IpcState();
+    if (!c || !st) { delete c; delete st; munmap(mem, sizeof(IpcShared)); return TBNAV_ERR_INVALID_ARG; }
+    st->sh = static_cast<IpcShared*>(mem);
+    c->rank = rank; c->nranks = nranks; c->device = device; c->ipc = st;
+    int rc = st->barrier(nranks);   // collective, as ncclCommInitRank is
+    if (rank == 0) (void)shm_unlink(name);  // every rank has it mapped (or has given up): the name can go
+    if (rc == TBNAV_OK) rc = ipc_open_mailboxes(c);
+    if (rc != TBNAV_OK) { ipc_close(c); delete c; return rc; }
+    *out = c;
+    return TBNAV_OK;
+  }
   Rccl& R = rccl();
   if (!R.ok) { tbnav::last_hip_error_slot() = "librccl could not be loaded"; return TBNAV_ERR_UNSUPPORTED; }
   tbnav_comm* c = new (std::nothrow) tbnav_comm();
@@ -267,6 +469,7 @@ int tbnav_comm_create_local(int32_t n, const int32_t* devices, tbnav_comm** out)
 void tbnav_comm_destroy(tbnav_comm* c) {
   if (!c) return;
   if (c->nccl) { DevGuard dg(c->device); (void)rccl().CommDestroy(c->nccl); }
+  ipc_close(c);
   if (LocalGroup* g = c->group) {
     if (--g->alive == 0) {
       for (size_t r = 0; r < g->ready.size(); ++r) { DevGuard dg(g->device[r]); (void)hipEventDestroy(g->ready[r]); (void)hipEventDestroy(g->done[r]); }

@@ -1,6 +1,7 @@
 // comm.hpp — internal face of include/tbnav_comm.h for the kernel files: the two exchanges the sharded paths need, over
 // whichever transport the communicator has (RCCL, or in-process copies for local-group ranks that share a device).
-// Every call only ENQUEUES on the given streams; nothing here waits on the host.
+// Every call only ENQUEUES on the given streams; nothing here waits on the host — except on the IPC transport (ranks in separate
+// processes that may share a device: tbnav_comm_unique_id_ipc), which drains the stream and returns when the data has arrived.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstddef>

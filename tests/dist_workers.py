@@ -234,3 +234,115 @@ def rbpf_hip_worker(rank, world, n_local, k, skew_scan, heavy=None, df_inject=Fa
     pose, prev_pose, w = pf.particles()
     return dict(pose=pose, prev=prev_pose, w=w, hist=hist, lo=[pf.logOdds(p) for p in range(n_local)],
                 codes=[pf.distCode(p) for p in range(n_local)], migrated=sr.bytes_migrated)
+
+
+# ---- the in-library sharded paths with one PROCESS per rank (include/tbnav_comm.h) ------------------------------------------
+# On a one-GPU box every rank sits on device 0, which RCCL refuses: the communicator is made on the IPC transport
+# (tbnav_comm_unique_id_ipc; rank 0's id travels over this job's gloo group).  Everything above the transport — attach, the
+# rank's offsets into the gather buffers and the noise counter space, the status agreement, the migration plan — is the code
+# the RCCL job runs.
+def _ipc_comm():
+    import __graft_entry__ as g
+    g.load_package()
+    import torch
+    torch.cuda.set_device(0)
+    from rtn_amd.comm import Comm
+    comm = Comm.from_torch_distributed(0, transport="ipc")
+    assert comm.uses_rccl is False
+    return comm
+
+
+def comm_selftest_worker(rank, world, nbytes):
+    comm = _ipc_comm()
+    assert (comm.rank, comm.size, comm.device) == (rank, world, 0)
+    comm.selftest(nbytes)   # one all-gather and one ring of point-to-point messages, checked on every rank
+    comm.close()
+    return True
+
+
+def mppi_comm_worker(rank, world, K_local, horizon, n_ticks):
+    """This rank's shard of a K_local * world ensemble behind an attached handle: host-noise ticks (its slice of the ensemble's
+    perturbations), production ticks one by one and as one batch; returns what the parent compares across ranks and against
+    the oracle / an unsharded handle."""
+    import torch
+    comm = _ipc_comm()
+    import oracle_api as orc
+    from cases import WAYPOINTS, make_mppi, mppi_cfg
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    K = K_local * world
+    d, dl = mppi_cfg(K, horizon), mppi_cfg(K_local, horizon)
+    T = orc.mppi_steps(d)
+    m = make_mppi(pkg, dl)
+    m.setWaypoint(*WAYPOINTS[2])
+    m.attachComm(comm)
+    x0 = (0.1, -0.05, 0.3)
+    out = {"host": [], "rng": []}
+    u = np.zeros((2, T))
+    for tick in range(2):
+        noise = np.random.default_rng(70 + tick).standard_normal((K, T, 2)) * np.sqrt(0.9)
+        got = m.newControls(*x0, np.ascontiguousarray(noise[rank * K_local:(rank + 1) * K_local]))
+        out["host"].append((np.array(got), m.getControls().copy()))
+        if rank == 0:
+            ref = orc.mppi_new_controls(d, u, (0, 0), WAYPOINTS[2], x0, noise)
+            assert np.allclose(got, ref["out"], rtol=1e-9, atol=1e-12) and np.allclose(m.getControls(), ref["u"], rtol=1e-9, atol=1e-12)
+        u = m.getControls().copy()
+    for tick in range(n_ticks):
+        out["rng"].append(np.array(m.newControlsRng(x0, 77, tick)))
+    st = torch.cuda.Stream()
+    m.enqueueRngBatch(x0, 77, 100, 6, st.cuda_stream)
+    torch.cuda.synchronize()
+    out["batch_u"] = m.getControls().copy()
+    out["batch_last"] = np.array(m.lastControls(st.cuda_stream))
+    m.close()
+    if rank == 0:  # the same production ticks on ONE handle holding the whole ensemble (same counter space: same perturbations)
+        one = make_mppi(pkg, d)
+        one.setWaypoint(*WAYPOINTS[2]); one.setControls(u)
+        for tick in range(n_ticks):
+            assert np.allclose(one.newControlsRng(x0, 77, tick), out["rng"][tick], rtol=1e-9, atol=1e-12), tick
+        for i in range(6):
+            one.newControlsRng(x0, 77, 100 + i)
+        assert np.allclose(one.getControls(), out["batch_u"], rtol=1e-9, atol=1e-12)
+        one.close()
+    comm.close()
+    return out
+
+
+def rbpf_comm_worker(rank, world, n_local, k, heavy, device_noise):
+    """This rank's shard of an n_local * world filter behind an attached handle, four scans with a forced cross-rank resample
+    before the second; the unsharded filter runs beside it in the same process and every local particle is compared with its
+    global twin bit for bit (poses, weights, maps), as are Neff / the decision."""
+    comm = _ipc_comm()
+    import oracle_api as orc
+    from rtn_amd.rbpf import ParticleFilter, default_params
+    N = n_local * world
+    lo = rank * n_local
+    a = ParticleFilter(default_params(N=n_local, k=k))
+    b = ParticleFilter(default_params(N=N, k=k))
+    a.setParticles(w=np.full(n_local, 1.0 / N))
+    if device_noise:
+        a.setSeed(99); b.setSeed(99)
+    a.attachComm(comm)
+    steps, scans = rbpf_scenario(4)
+    stride = 3 * k + 3
+    resampled, stats = 0, []
+    for s, (prev, cur, t_icp, u) in enumerate(steps):
+        full = None if device_noise else orc.normal_stream(50 + s, N * stride + 1, 0.0, 1.0)
+        mine = None if device_noise else np.concatenate([full[lo * stride:(lo + n_local) * stride], full[-1:]])
+        if s == 1:
+            w = np.full(N, 0.01)
+            for i, v in heavy.items():
+                w[i] = v
+            w /= w.sum()
+            a.setParticles(w=w[lo:lo + n_local]); b.setParticles(w=w)
+        sa = a.SLAM(scans[s], u, cur, prev, True, t_icp, mine)
+        sb = b.SLAM(scans[s], u, cur, prev, True, t_icp, full)
+        assert (sa.neff, sa.resampled, sa.sum_w, sa.sq_sum, sa.n_valid_beams) == (sb.neff, sb.resampled, sb.sum_w, sb.sq_sum, sb.n_valid_beams), s
+        resampled += sa.resampled
+        for x, y in zip(a.particles(), b.particles()):
+            assert np.array_equal(x, y[lo:lo + n_local]), s
+        for p in range(n_local):
+            assert np.array_equal(a.logOdds(p), b.logOdds(lo + p)), (s, p)
+        stats.append((sa.neff, sa.resampled))
+    a.close(); b.close(); comm.close()
+    return {"resampled": resampled, "stats": stats}

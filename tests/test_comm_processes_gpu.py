@@ -1,0 +1,70 @@
+"""The in-library sharded paths with one PROCESS per rank — the shape of the real multi-GPU job (bench.py under
+torch.distributed.run, one rank per GPU over RCCL) — on this one-GPU box: every rank on device 0 through the IPC transport of
+include/tbnav_comm.h (RCCL refuses two ranks on one device).  What differs from the RCCL job is the transport alone; attach,
+the rank's offsets, the status agreement, the migration plan and bench.py's own N > 1 flow are the same code."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ipc_transport_selftest_across_processes(gpu_pkg, world):
+    from dist_workers import comm_selftest_worker, run_spawn
+    out = run_spawn(comm_selftest_worker, world, 1 << 18)
+    assert all(out[r] is True for r in range(world))
+
+
+@pytest.mark.parametrize("world,K_local,horizon", [(2, 512, 0.5), (4, 1024, 0.25), (2, 40000, 0.24)])
+def test_mppi_ranks_in_separate_processes(gpu_pkg, world, K_local, horizon):
+    """Host-noise ticks against the oracle over the whole ensemble and production ticks against ONE handle holding it (asserted
+    inside rank 0); here: every rank ends every tick with bit-identical controls (the combine runs on identical gathered records)."""
+    from dist_workers import mppi_comm_worker, run_spawn
+    out = run_spawn(mppi_comm_worker, world, K_local, horizon, 3)
+    for r in range(1, world):
+        for (g0, u0), (g1, u1) in zip(out[0]["host"], out[r]["host"]):
+            assert np.array_equal(g0, g1) and np.array_equal(u0, u1)
+        for x, y in zip(out[0]["rng"], out[r]["rng"]):
+            assert np.array_equal(x, y)
+        assert np.array_equal(out[0]["batch_u"], out[r]["batch_u"]) and np.array_equal(out[0]["batch_last"], out[r]["batch_last"])
+
+
+@pytest.mark.parametrize("world,n_local,heavy,device_noise", [(2, 6, {3: 0.6, 10: 0.25}, False), (3, 7, {0: 0.3, 9: 0.3, 20: 0.3}, False),
+                                                              (4, 5, {1: 0.6, 17: 0.3}, True), (3, 4, {11: 0.9}, True)])
+def test_rbpf_ranks_in_separate_processes_equal_the_unsharded_filter(gpu_pkg, world, n_local, heavy, device_noise):
+    """Each rank asserts its shard equal to its slice of an unsharded filter bit for bit after every scan (dist_workers); the
+    layouts are tests/test_comm_gpu.py's: a forced resample that sends one particle's children to several ranks, ranks whose
+    every slot is imported."""
+    from dist_workers import rbpf_comm_worker, run_spawn
+    out = run_spawn(rbpf_comm_worker, world, n_local, 8, heavy, device_noise)
+    assert out[0]["resampled"] >= 1
+    for r in range(1, world):
+        assert out[r]["stats"] == out[0]["stats"]
+
+
+def test_bench_two_ranks_on_one_gpu_through_the_library_communicator(gpu_pkg):
+    """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, --steps 20 --warmup 5), with its one-GPU dev
+    switch: the timed ticks, the synchronous-tick measurement and both multi-GPU legs go through tbnav_mppi_attach_comm /
+    tbnav_rbpf_attach_comm in two processes.  (Round 3: the synchronous-tick loop ran on rank 0 alone — with a communicator
+    attached that is a collective the other rank never joins.)"""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, TBNAV_BENCH_ONE_GPU_GLOO="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and "tbnav_mppi_attach_comm" in line["exchange"]
+    assert "multi_gpu_legs" not in line, line.get("multi_gpu_legs")
+    assert line["strong_scaling_configs3"]["rollouts_per_s"] > 0
+    assert line["rbpf_sharded"]["resamples"] >= 2 and "tbnav_rbpf_attach_comm" in line["rbpf_sharded"]["exchange"]
