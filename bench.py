@@ -354,7 +354,9 @@ def main():
             # what actually ran in the timed region: whole chunks of 100 ticks are replayed from a captured hipGraph, the rest (all of
             # them when --steps < 100, as with the driver's --steps 20) are plain launches
             "graph_replayed_ticks": graph_ticks_timed,
-            "exchange": None if world == 1 else ((("ncclAllGather" if transport == "rccl" else "all-gather (IPC transport: ranks share one device)")
+            "exchange": None if world == 1 else (("DIRECT: every rank stores its soft-min records into every peer's gather buffer (IPC-mapped fine-grained memory over xGMI, tagged 8-byte words; "
+                                                  "tbnav_mppi_exchange_kind 2), issued by libtbnav_hip.so on the tick's stream (tbnav_mppi_attach_comm)" if m.exchangeKind() == 2 else
+                                                  ("ncclAllGather" if transport == "rccl" else "all-gather (IPC transport: ranks share one device)")
                                                   + " of the soft-min records issued by libtbnav_hip.so on the tick's stream (tbnav_mppi_attach_comm)")
                                                  if comm is not None else f"torch.distributed {dist.get_backend()} all-gather from Python (rtn_amd.sharded; the in-library communicator was unavailable or the one-GPU dev switch is on)"),
             "ms_per_step_one_python_call_per_tick": None if el_py is None else round(el_py / args.steps * 1e3, 6),
@@ -452,6 +454,24 @@ def multi_gpu_legs(world, rank, local_rank, device, one_gpu_test, stream, sync, 
                                forced to resample, so the cross-rank particle migration (tile blobs over RCCL) is timed."""
     from rtn_amd.sharded import HipRbpfShardBackend, HipShardBackend, ShardedMPPI, ShardedRBPF
     out = {}
+    red_dev = "cpu" if one_gpu_test else device
+    if comm is not None:
+        # ---- the headline's tick once more with the records carried by the communicator's all-gather (RCCL) instead of the direct
+        #      stores into the peers' buffers: what the exchange costs either way, same processes, same K per rank
+        mb = make_mppi(1024, 0.5, local_rank)
+        mb.setDirectExchange(False)
+        mb.attachComm(comm)
+        mb.enqueueRngBatch(X0, 42, 0, 10, stream)
+        sync(); barrier(); sync()
+        t0 = time.perf_counter()
+        mb.enqueueRngBatch(X0, 42, 10, 100, stream)
+        sync(); barrier(); sync()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        out["weak_tick_via_comm_all_gather"] = {"workload": "the headline's tick (K=1024 per rank, T=50, device noise), 100 ticks, exchange kind 1",
+                                                "exchange_kind": mb.exchangeKind(), "ms_per_step": round(float(t.item()) / 100 * 1e3, 6),
+                                                "rollouts_per_s": round(world * 1024 * 100 / float(t.item()), 1)}
+        mb.close()
     # ---- MPPI strong scaling
     KL, HL = 65536, 1.0
     ml = make_mppi(KL // world, HL, local_rank)
@@ -466,6 +486,7 @@ def multi_gpu_legs(world, rank, local_rank, device, one_gpu_test, stream, sync, 
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     out["strong_scaling_configs3"] = {"workload": f"MPPI K={KL} total, T={ml.steps}, K/N = {KL // world} per rank, resident noise",
                                       "rollouts_per_s": round(KL * 50 / float(t.item()), 1), "ms_per_step": round(float(t.item()) / 50 * 1e3, 6),
+                                      "exchange_kind": ml.exchangeKind() if comm is not None else None,
                                       "scaling": "strong"}
     ml.close()
     # ---- RBPF weak scaling with migration

@@ -89,7 +89,9 @@ int tbnav_mppi_streaming_form(const tbnav_mppi* h);
  *                          it applies — the large-K default of round 3; the round-2 kernels stay for A-B runs. */
 enum { TBNAV_MPPI_OPT_KERNEL = 1, TBNAV_MPPI_OPT_TRIG = 2, TBNAV_MPPI_OPT_NO_LDS_STAGING = 3, TBNAV_MPPI_OPT_KEEP_J = 4, TBNAV_MPPI_OPT_REG_TAIL = 5,
        TBNAV_MPPI_OPT_BATCH_GRAPH = 6 /* 0: tbnav_mppi_enqueue_rng_batch launches every tick by itself instead of replaying a captured hipGraph of 100 */,
-       TBNAV_MPPI_OPT_PREFIX_FORM = 7 };
+       TBNAV_MPPI_OPT_PREFIX_FORM = 7,
+       TBNAV_MPPI_OPT_DIRECT_EXCHANGE = 8 /* 0: a handle attached to a multi-process communicator always exchanges through the communicator's
+                                             all-gather (default 1: directly into the peers' buffers when every rank can; takes effect at the next attach) */ };
 int tbnav_mppi_set_option(tbnav_mppi* h, int32_t option, int32_t value);
 
 /* Rollout dynamics.  TBNAV_MPPI_DYN_RK4 (default) is the reference MPPI: CartModel + RK4 (controller/include/
@@ -177,6 +179,12 @@ int tbnav_mppi_shard_combine(tbnav_mppi* h, const double* d_records_all, int32_t
  * the handle's last tick; the handle does not own it. */
 struct tbnav_comm;
 int tbnav_mppi_attach_comm(tbnav_mppi* h, struct tbnav_comm* comm);
+/* How an attached handle's ticks exchange their records: 0 = no communicator attached; 1 = the communicator's all-gather (RCCL; copies
+ * inside a one-process group); 2 = DIRECT: ranks in separate processes of one node store their records straight into every peer's
+ * gather buffer (hipIpcMemHandle mappings of fine-grained memory over xGMI; self-validating 8-byte words, the receiver polls its own
+ * buffer with a bound) — an RCCL all-gather of a few KB costs several 9 us ticks.  Chosen at attach, collectively: every rank maps
+ * every rank's buffer and runs a self-test through the tick's own kernels; if any rank cannot, all ranks use 1. */
+int tbnav_mppi_exchange_kind(const tbnav_mppi* h);
 
 /* One process driving n_gpus devices (what controller::MPPI(..., n_gpus) holds: a ROS node is one process): the
  * ensemble of params->rollouts rollouts (a multiple of n_gpus) split evenly over devices[0..n_gpus) (NULL: 0, 1, ...;

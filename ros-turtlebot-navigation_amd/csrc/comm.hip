@@ -356,6 +356,24 @@ int comm_exchange(int n, tbnav_comm* const* comms, const std::vector<P2P>* sends
   return TBNAV_OK;
 }
 
+bool comm_is_multiprocess(const tbnav_comm* c) { return c && !c->group && c->nranks > 1; }
+
+int comm_all_gather_host(tbnav_comm* c, const void* send_host, void* recv_host, size_t bytes) {
+  if (!c || !send_host || !recv_host || bytes == 0 || (c->group && c->nranks != 1)) return TBNAV_ERR_INVALID_ARG;
+  DevGuard dg(c->device);
+  hipStream_t st = nullptr;
+  char *d_send = nullptr, *d_recv = nullptr;
+  auto done = [&](int code) { if (st) (void)hipStreamDestroy(st); (void)hipFree(d_send); (void)hipFree(d_recv); return code; };
+  if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&d_send, bytes) != hipSuccess ||
+      hipMalloc((void**)&d_recv, bytes * (size_t)c->nranks) != hipSuccess) return done(TBNAV_ERR_HIP);
+  if (hipMemcpyAsync(d_send, send_host, bytes, hipMemcpyHostToDevice, st) != hipSuccess) return done(TBNAV_ERR_HIP);
+  const void* sp = d_send; void* rp = d_recv;
+  const int rc = comm_all_gather(1, &c, &sp, &rp, bytes, &st);
+  if (rc != TBNAV_OK) return done(rc);
+  if (hipMemcpyAsync(recv_host, d_recv, bytes * (size_t)c->nranks, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return done(TBNAV_ERR_HIP);
+  return done(TBNAV_OK);
+}
+
 }  // namespace tbnav
 
 extern "C" {

@@ -21,6 +21,12 @@ int comm_all_gather(int n, tbnav_comm* const* comms, const void* const* send, vo
 struct P2P { int peer; void* ptr; size_t bytes; };
 int comm_exchange(int n, tbnav_comm* const* comms, const std::vector<P2P>* sends, const std::vector<P2P>* recvs, hipStream_t const* streams);
 
+// A small HOST blob from every rank (IPC handles, status words): recv_host receives size(comm) * bytes, rank q's at q * bytes.
+// Collective and host-synchronous; communicators of multi-process jobs (and groups of one).
+int comm_all_gather_host(tbnav_comm* c, const void* send_host, void* recv_host, size_t bytes);
+// a rank of a multi-process job of more than one rank (not a member of a one-process group)
+bool comm_is_multiprocess(const tbnav_comm* c);
+
 int comm_rank(const tbnav_comm* c);
 int comm_size(const tbnav_comm* c);
 

@@ -1296,6 +1296,46 @@ __global__ void mppi_tick_advance(uint64_t* __restrict__ tick0, uint64_t n) { *t
 // has to outlive the call)
 __global__ void mppi_tick_set(uint64_t* __restrict__ tick0, uint64_t v) { *tick0 = v; }
 
+// ---- direct exchange of the sharded tick's records between the ranks of ONE node (multi-process communicators) ---------------
+// An RCCL all-gather of a few KB costs tens of microseconds per call on eight GPUs — several 9 us ticks.  Here every rank
+// stores its records straight into every peer's gather buffer (mapped through hipIpcMemHandle, fine-grained memory, xGMI) as
+// self-validating 8-byte words — (sequence number << 32) | 32 bits of payload, two words a double: a naturally aligned
+// 8-byte store is atomic, so a word is either the old tick's or the new one's and no flag, fence or ordering between stores
+// is needed — and the receiver polls its OWN buffer's words until they carry the tick's number (system-scope loads; bounded:
+// a peer that never delivers raises an error word instead of hanging the device).  Two buffers take turns by the tick's
+// parity: a rank can be at most one tick ahead of a peer still reading (it needs that peer's records to get further).
+__global__ __launch_bounds__(256) void mppi_direct_publish(const double* __restrict__ mine, int n, unsigned long long* const* __restrict__ peers,
+                                                            int me, int P, int parity, unsigned int seq) {
+  unsigned long long* dst = peers[blockIdx.y] + (size_t)(parity * P + me) * 2 * n;
+  const unsigned long long tag = (unsigned long long)seq << 32;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(mine[i]);
+    __hip_atomic_store(dst + 2 * i, tag | (b & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(dst + 2 * i + 1, tag | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+__global__ __launch_bounds__(256) void mppi_direct_collect(unsigned long long* __restrict__ words, int n, int P, int parity, unsigned int seq,
+                                                            double* __restrict__ out, int* __restrict__ err, unsigned long long budget_ticks) {
+  const size_t total = (size_t)P * n;
+  unsigned long long* w0 = words + (size_t)parity * P * 2 * n;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned long long lo = 0ull, hi = 0ull;
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+      lo = __hip_atomic_load(w0 + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      hi = __hip_atomic_load(w0 + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if ((unsigned int)(lo >> 32) == seq && (unsigned int)(hi >> 32) == seq) break;
+      if (wall_clock64() - t0 > budget_ticks) {  // (100 MHz ticks) the records never came: report, deliver zeros
+        __hip_atomic_fetch_or(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        lo = hi = 0ull;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(4);
+    }
+    out[i] = __longlong_as_double((long long)((hi << 32) | (lo & 0xFFFFFFFFull)));
+  }
+}
+
 __global__ void mppi_sample_noise(int T, int K, uint64_t seed, uint64_t base, double sig_l,
                                   double sig_r, double* __restrict__ duL, double* __restrict__ duR) {
   const size_t n = (size_t)T * K;
@@ -1364,6 +1404,14 @@ struct tbnav_mppi {
   // records (RCCL) -> the combine of all shards' records, all enqueued on the tick's stream
   tbnav_comm* comm = nullptr;
   double* d_records_all = nullptr;  // [nranks][T][S][8]; this rank's records are written in place at [rank]
+  // direct exchange (mppi_direct_publish / _collect): set up at attach for multi-process communicators when every rank can
+  // (fine-grained memory, IPC mapping, a self-test); otherwise the communicator's all-gather carries the records
+  bool direct_want = true, direct_on = false;   // TBNAV_MPPI_OPT_DIRECT_EXCHANGE
+  unsigned long long* d_dx = nullptr;           // [2 parities][nranks][2 * n] tagged words (n = T * S * 8), fine-grained
+  unsigned long long** d_dx_peers = nullptr;    // [nranks] every rank's d_dx as mapped into this process
+  std::vector<void*> dx_opened;                 // the mappings of the peers' buffers (closed at detach)
+  int* h_dx_err = nullptr; int* d_dx_err = nullptr;  // mapped pinned: raised by a collect that ran out of time
+  unsigned int dx_seq = 0;
 };
 
 namespace {
@@ -1706,6 +1754,10 @@ int tbnav_mppi_create(const tbnav_mppi_params* params, tbnav_mppi** out) {
   return TBNAV_OK;
 }
 
+}  // extern "C"
+namespace { void direct_teardown(tbnav_mppi* h); }
+extern "C" {
+
 void tbnav_mppi_destroy(tbnav_mppi* h) {
 #ifdef TBNAV_PHASE_PROF
   {
@@ -1731,6 +1783,7 @@ void tbnav_mppi_destroy(tbnav_mppi* h) {
   DeviceGuard guard(h->device);
   (void)hipFree(h->d_u[0]); (void)hipFree(h->d_u[1]); (void)hipFree(h->d_J); (void)hipFree(h->d_duL); (void)hipFree(h->d_duR);
   (void)hipFree(h->d_total); (void)hipFree(h->d_records_all);
+  direct_teardown(h);
   (void)hipFree(h->d_raw); (void)hipFree(h->d_records); (void)hipFree(h->d_records_f); (void)hipFree(h->d_out);
   if (h->h_out) (void)hipHostFree(h->h_out);
   if (h->tg_exec) (void)hipGraphExecDestroy(h->tg_exec);
@@ -1769,6 +1822,9 @@ int tbnav_mppi_set_option(tbnav_mppi* h, int32_t option, int32_t value) {
       return TBNAV_OK;
     case TBNAV_MPPI_OPT_BATCH_GRAPH:
       h->graph_on = value != 0;
+      return TBNAV_OK;
+    case TBNAV_MPPI_OPT_DIRECT_EXCHANGE:  // (takes effect at the next tbnav_mppi_attach_comm)
+      h->direct_want = value != 0;
       return TBNAV_OK;
     case TBNAV_MPPI_OPT_KERNEL: {
       // 0: mppi_rollout_cost (sequential); n > 0: mppi_rollout_scan with n steps per thread; -4 / -8 / -16: fused, that many rollouts per workgroup
@@ -1981,12 +2037,17 @@ int tbnav_mppi_last_controls(tbnav_mppi* h, void* stream, double u_out[2]) {
   if (!h || !u_out) return TBNAV_ERR_INVALID_ARG;
   DeviceGuard guard(h->device);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  auto exchange_ok = [&]() -> int {  // (the stream has been waited for) a direct exchange that ran out of time left its mark in host memory
+    if (!h->direct_on || !h->h_dx_err || !*h->h_dx_err) return TBNAV_OK;
+    tbnav::last_hip_error_slot() = "direct exchange: a peer's records did not arrive in time";
+    return TBNAV_ERR_HIP;
+  };
   if (h->published != h->seq) {  // the last tick was enqueue-only: fetch the device copy
     TBNAV_HIP(hipMemcpyAsync(h->h_out, h->d_out, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
     TBNAV_HIP(hipStreamSynchronize(st));
     u_out[0] = h->h_out[0];
     u_out[1] = h->h_out[1];
-    return TBNAV_OK;
+    return exchange_ok();
   }
   // The last combine published (ul, ur, tick number) in mapped host memory.  Poll for its number for a short while (a
   // control loop calls this right behind the enqueue: the answer is microseconds away and a stream synchronisation
@@ -2000,7 +2061,7 @@ int tbnav_mppi_last_controls(tbnav_mppi* h, void* stream, double u_out[2]) {
   std::atomic_thread_fence(std::memory_order_acquire);
   u_out[0] = vo[0];
   u_out[1] = vo[1];
-  return TBNAV_OK;
+  return exchange_ok();
 }
 
 int tbnav_mppi_new_controls_dev(tbnav_mppi* h, const double x0[3], const double* d_duL,
@@ -2180,10 +2241,14 @@ int tbnav_mppi_get_cost_to_go(tbnav_mppi* h, double* J_host) {
 
 
 // ---- sharded ensembles behind the same entry points ----------------------------------------------
+}  // extern "C"
+namespace { int direct_setup(tbnav_mppi* h); }
+extern "C" {
 int tbnav_mppi_attach_comm(tbnav_mppi* h, tbnav_comm* comm) {
   if (!h) return TBNAV_ERR_INVALID_ARG;
   DeviceGuard guard(h->device);
   TBNAV_HIP(hipDeviceSynchronize());
+  direct_teardown(h);
   (void)hipFree(h->d_records_all);
   h->d_records_all = nullptr;
   h->comm = nullptr;
@@ -2196,8 +2261,13 @@ int tbnav_mppi_attach_comm(tbnav_mppi* h, tbnav_comm* comm) {
   // this shard's place in the ensemble's noise counter space (equal shards: every rank holds K rollouts)
   h->k0 = (uint64_t)r * (uint64_t)h->K;
   h->k_global = (uint64_t)P * (uint64_t)h->K;
+  // ranks in separate processes of one node: the records can go straight into the peers' buffers (collective: every rank
+  // of the communicator attaches, with the same option)
+  if (tbnav::comm_is_multiprocess(comm) && h->direct_want) return direct_setup(h);
   return TBNAV_OK;
 }
+
+int tbnav_mppi_exchange_kind(const tbnav_mppi* h) { return !h ? -1 : (!h->comm ? 0 : (h->direct_on ? 2 : 1)); }
 
 }  // extern "C"
 
@@ -2207,11 +2277,108 @@ int sharded_partials(tbnav_mppi* h, const double x0[3], const double* d_duL, con
   double* mine = h->d_records_all + (size_t)tbnav::comm_rank(h->comm) * h->T * h->S * TBNAV_MPPI_REC;
   return seed ? tbnav_mppi_shard_partials_rng(h, x0, *seed, tick, stream, mine) : tbnav_mppi_shard_partials(h, x0, d_duL, d_duR, stream, mine);
 }
+constexpr unsigned long long kDirectBudgetTicks = 200000000ull;   // 2 s of the 100 MHz clock: a peer that takes longer has failed
+// this rank's freshly written records -> every rank's buffer; then wait for everybody's and unpack them into d_records_all
+int direct_exchange(tbnav_mppi* h, hipStream_t st, unsigned long long budget = kDirectBudgetTicks) {
+  const int P = tbnav::comm_size(h->comm), me = tbnav::comm_rank(h->comm), n = h->T * h->S * TBNAV_MPPI_REC;
+  const unsigned int seq = ++h->dx_seq;
+  const int parity = (int)(seq & 1u);
+  const double* mine = h->d_records_all + (size_t)me * n;
+  const int bx = std::min(8, (n + 255) / 256);
+  hipLaunchKernelGGL(mppi_direct_publish, dim3(bx, P), dim3(256), 0, st, mine, n, h->d_dx_peers, me, P, parity, seq);
+  const int bc = (int)std::min<size_t>(64, ((size_t)P * n + 255) / 256);
+  hipLaunchKernelGGL(mppi_direct_collect, dim3(bc), dim3(256), 0, st, h->d_dx, n, P, parity, seq, h->d_records_all, h->d_dx_err, budget);
+  TBNAV_HIP(hipGetLastError());
+  return TBNAV_OK;
+}
+
+void direct_teardown(tbnav_mppi* h) {
+  if (!h) return;
+  h->direct_on = false;
+  for (void* p : h->dx_opened) (void)hipIpcCloseMemHandle(p);
+  h->dx_opened.clear();
+  (void)hipFree(h->d_dx); h->d_dx = nullptr;
+  (void)hipFree(h->d_dx_peers); h->d_dx_peers = nullptr;
+  if (h->h_dx_err) (void)hipHostFree(h->h_dx_err);
+  h->h_dx_err = nullptr; h->d_dx_err = nullptr;
+}
+
+// Called by tbnav_mppi_attach_comm on every rank of a multi-process communicator.  Every step that can fail on one rank is
+// followed by an agreement (an all-gather of status words through the communicator), so that all ranks end in the same
+// state: direct exchange on, or off (the communicator's all-gather carries the records) — never a mixture.
+int direct_setup(tbnav_mppi* h) {
+  const int P = tbnav::comm_size(h->comm), me = tbnav::comm_rank(h->comm), n = h->T * h->S * TBNAV_MPPI_REC;
+  const size_t words = (size_t)2 * P * 2 * n;
+  struct Hello { int ok; int pad; hipIpcMemHandle_t handle; };
+  auto agree = [&](int mine_ok, bool& all_ok) {   // collective
+    std::vector<int> all(P, 0);
+    const int rc = tbnav::comm_all_gather_host(h->comm, &mine_ok, all.data(), sizeof(int));
+    all_ok = rc == TBNAV_OK;
+    for (int q = 0; q < P; ++q) all_ok = all_ok && all[q] == 1;
+    return rc;
+  };
+  // 1. the buffer (fine-grained: written by other devices while kernels of this one poll it), its IPC handle
+  Hello hello{};
+  hello.ok = hipExtMallocWithFlags((void**)&h->d_dx, sizeof(unsigned long long) * words, hipDeviceMallocFinegrained) == hipSuccess &&
+             hipMemset(h->d_dx, 0, sizeof(unsigned long long) * words) == hipSuccess &&
+             hipIpcGetMemHandle(&hello.handle, h->d_dx) == hipSuccess &&
+             hipHostMalloc((void**)&h->h_dx_err, sizeof(int), hipHostMallocMapped) == hipSuccess &&
+             hipHostGetDevicePointer((void**)&h->d_dx_err, h->h_dx_err, 0) == hipSuccess &&
+             hipMalloc((void**)&h->d_dx_peers, sizeof(unsigned long long*) * P) == hipSuccess;
+  if (h->h_dx_err) *h->h_dx_err = 0;
+  std::vector<Hello> all(P);
+  { const int rc = tbnav::comm_all_gather_host(h->comm, &hello, all.data(), sizeof(Hello)); if (rc != TBNAV_OK) { direct_teardown(h); return rc; } }
+  bool everybody = true;
+  for (int q = 0; q < P; ++q) everybody = everybody && all[q].ok == 1;
+  if (!everybody) { direct_teardown(h); return TBNAV_OK; }
+  // 2. map every peer's buffer
+  std::vector<unsigned long long*> peers(P, nullptr);
+  int ok = 1;
+  for (int q = 0; q < P && ok; ++q) {
+    if (q == me) { peers[q] = h->d_dx; continue; }
+    void* base = nullptr;
+    if (hipIpcOpenMemHandle(&base, all[q].handle, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { ok = 0; break; }
+    h->dx_opened.push_back(base);
+    peers[q] = static_cast<unsigned long long*>(base);
+  }
+  if (ok && hipMemcpy(h->d_dx_peers, peers.data(), sizeof(unsigned long long*) * P, hipMemcpyHostToDevice) != hipSuccess) ok = 0;
+  { const int rc = agree(ok, everybody); if (rc != TBNAV_OK) { direct_teardown(h); return rc; } }
+  if (!everybody) { direct_teardown(h); return TBNAV_OK; }
+  // 3. self-test: rounds of pattern records through the very kernels the tick uses, every rank checking every rank's block
+  //    (a stale cache line, a store that never becomes visible to the peer, a torn word would show here, not in a tick)
+  hipStream_t st = nullptr;
+  ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess ? 1 : 0;
+  std::vector<double> pat((size_t)P * n), got((size_t)P * n);
+  auto pattern = [](int q, int it, int j) {
+    unsigned long long z = 0x9E3779B97F4A7C15ull * (unsigned long long)(q * 1000003 + it * 7919 + j + 1);
+    z ^= z >> 31; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 29;
+    double d; std::memcpy(&d, &z, sizeof d); return d;
+  };
+  for (int it = 0; it < 24 && ok; ++it) {
+    for (int q = 0; q < P; ++q) for (int j = 0; j < n; ++j) pat[(size_t)q * n + j] = pattern(q, it, j);
+    if (hipMemcpyAsync(h->d_records_all + (size_t)me * n, pat.data() + (size_t)me * n, sizeof(double) * n, hipMemcpyHostToDevice, st) != hipSuccess) { ok = 0; break; }
+    if (direct_exchange(h, st, 25000000ull /* 0.25 s */) != TBNAV_OK) { ok = 0; break; }
+    if (hipMemcpyAsync(got.data(), h->d_records_all, sizeof(double) * P * n, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { ok = 0; break; }
+    if (*h->h_dx_err || std::memcmp(got.data(), pat.data(), sizeof(double) * P * n) != 0) ok = 0;
+  }
+  if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+  { const int rc = agree(ok, everybody); if (rc != TBNAV_OK) { direct_teardown(h); return rc; } }
+  if (!everybody) { direct_teardown(h); return TBNAV_OK; }
+  *h->h_dx_err = 0;
+  h->direct_on = true;
+  return TBNAV_OK;
+}
+
 int sharded_tick(tbnav_mppi* h, const double x0[3], const double* d_duL, const double* d_duR, const uint64_t* seed, uint64_t tick, void* stream) {
   int rc = sharded_partials(h, x0, d_duL, d_duR, seed, tick, stream);
   if (rc != TBNAV_OK) return rc;
   DeviceGuard guard(h->device);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (h->direct_on) {
+    rc = direct_exchange(h, st);
+    if (rc != TBNAV_OK) return rc;
+    return launch_combine(h, h->d_records_all, tbnav::comm_size(h->comm), st);
+  }
   const size_t block = sizeof(double) * (size_t)h->T * h->S * TBNAV_MPPI_REC;
   const void* send = reinterpret_cast<const char*>(h->d_records_all) + (size_t)tbnav::comm_rank(h->comm) * block;
   void* recv = h->d_records_all;

@@ -92,6 +92,14 @@ class MPPI:
         capi.check(self._L.tbnav_mppi_attach_comm(self._h, comm._h if comm is not None else None), "tbnav_mppi_attach_comm")
         self._comm = comm  # (the communicator must outlive the handle's ticks)
 
+    def exchangeKind(self) -> int:
+        """0: no communicator; 1: the communicator's all-gather; 2: direct stores into the peers' buffers (tbnav_mppi_exchange_kind)."""
+        return int(self._L.tbnav_mppi_exchange_kind(self._h))
+
+    def setDirectExchange(self, on: bool):
+        """TBNAV_MPPI_OPT_DIRECT_EXCHANGE; before attachComm."""
+        capi.check(self._L.tbnav_mppi_set_option(self._h, 8, 1 if on else 0), "set_option(direct exchange)")
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value and getattr(self, "_owned", True):
             self._L.tbnav_mppi_destroy(self._h)

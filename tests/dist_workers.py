@@ -260,7 +260,7 @@ def comm_selftest_worker(rank, world, nbytes):
     return True
 
 
-def mppi_comm_worker(rank, world, K_local, horizon, n_ticks):
+def mppi_comm_worker(rank, world, K_local, horizon, n_ticks, direct=True):
     """This rank's shard of a K_local * world ensemble behind an attached handle: host-noise ticks (its slice of the ensemble's
     perturbations), production ticks one by one and as one batch; returns what the parent compares across ranks and against
     the oracle / an unsharded handle."""
@@ -275,9 +275,10 @@ def mppi_comm_worker(rank, world, K_local, horizon, n_ticks):
     T = orc.mppi_steps(d)
     m = make_mppi(pkg, dl)
     m.setWaypoint(*WAYPOINTS[2])
+    m.setDirectExchange(direct)
     m.attachComm(comm)
     x0 = (0.1, -0.05, 0.3)
-    out = {"host": [], "rng": []}
+    out = {"host": [], "rng": [], "kind": m.exchangeKind()}
     u = np.zeros((2, T))
     for tick in range(2):
         noise = np.random.default_rng(70 + tick).standard_normal((K, T, 2)) * np.sqrt(0.9)

@@ -28,6 +28,13 @@ def test_mppi_ranks_in_separate_processes(gpu_pkg, world, K_local, horizon):
     inside rank 0); here: every rank ends every tick with bit-identical controls (the combine runs on identical gathered records)."""
     from dist_workers import mppi_comm_worker, run_spawn
     out = run_spawn(mppi_comm_worker, world, K_local, horizon, 3)
+    # the records went straight into the peers' buffers (tbnav_mppi_exchange_kind 2: IPC-mapped fine-grained memory, tagged words);
+    # the same run through the communicator's all-gather (kind 1) ends in the same bits: the combine sees identical records
+    via = run_spawn(mppi_comm_worker, world, K_local, horizon, 3, False)
+    assert all(out[r]["kind"] == 2 for r in range(world)) and all(via[r]["kind"] == 1 for r in range(world))
+    for (g0, u0), (g1, u1) in zip(out[0]["host"], via[0]["host"]):
+        assert np.array_equal(g0, g1) and np.array_equal(u0, u1)
+    assert all(np.array_equal(x, y) for x, y in zip(out[0]["rng"], via[0]["rng"])) and np.array_equal(out[0]["batch_u"], via[0]["batch_u"])
     for r in range(1, world):
         for (g0, u0), (g1, u1) in zip(out[0]["host"], out[r]["host"]):
             assert np.array_equal(g0, g1) and np.array_equal(u0, u1)
