@@ -1175,10 +1175,34 @@ __global__ __launch_bounds__(kWave) void mppi_merge_records(int T, int Sf, int p
 #ifndef TBNAV_COMBINE_WAVES
 #define TBNAV_COMBINE_WAVES 1  // one wave per workgroup: the groups spread over as many CUs as there are time steps (K = 1024 tick 8.9 -> 8.4 us against four waves)
 #endif
-template <int kKeep>
+// The direct exchange's receiving side (see mppi_direct_publish): a record field is two tagged 8-byte words in this rank's own
+// fine-grained buffer; poll them until both carry the tick's sequence number (bounded: an error word and zeros after `budget`
+// ticks of the 100 MHz clock).
+struct DirectSrc { const unsigned long long* w0; unsigned long long budget; int* err; unsigned int seq; };
+__device__ __forceinline__ double direct_load(const DirectSrc& d, size_t idx) {
+  unsigned long long* w = const_cast<unsigned long long*>(d.w0) + 2 * idx;
+  unsigned long long lo = 0ull, hi = 0ull;
+  const unsigned long long t0 = wall_clock64();
+  for (;;) {
+    lo = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    hi = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((unsigned int)(lo >> 32) == d.seq && (unsigned int)(hi >> 32) == d.seq) break;
+    if (wall_clock64() - t0 > d.budget) {
+      __hip_atomic_fetch_or(d.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      lo = hi = 0ull;
+      break;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return __longlong_as_double((long long)((hi << 32) | (lo & 0xFFFFFFFFull)));
+}
+
+template <int kKeep, bool DIRECT = false>
 __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, double lambda, double umax, USrc u,
                                                     const double* __restrict__ records, double* __restrict__ u_out,
-                                                    double* __restrict__ out, double* __restrict__ out_host, double seq) {
+                                                    double* __restrict__ out, double* __restrict__ out_host, double seq, DirectSrc ds) {
+  // (DIRECT: `records` is not read — field f of record (g, i, sl) is polled for in the exchange buffer, same index)
+  auto field = [&](const double* rec, int f) { return DIRECT ? direct_load(ds, (size_t)(rec - records) + f) : rec[f]; };
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave, nw = blockDim.x / kWave;
   const int R = G * S;
   int tpr = 1;
@@ -1201,7 +1225,7 @@ __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, double 
     const int g = (have && G > 1) ? r / S : 0, sl = have ? r - g * S : 0;  // (one group — every single-GPU tick: no division)
     const double* rec = records + (((size_t)g * T + (valid ? i : 0)) * S + sl) * TBNAV_MPPI_REC;
 #pragma unroll
-    for (int f = 0; f < 7; ++f) rk[q][f] = have ? rec[f] : 0.0;  // n == 0 marks "no record"
+    for (int f = 0; f < 7; ++f) rk[q][f] = have ? field(rec, f) : 0.0;  // n == 0 marks "no record"
   }
   double M = __builtin_huge_val();
   MTRACE(1, 1);
@@ -1212,7 +1236,7 @@ __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, double 
     for (int r = l; r < R; r += tpr) {
       const int g = r / S, sl = r - g * S;
       const double* rec = records + (((size_t)g * T + i) * S + sl) * TBNAV_MPPI_REC;
-      if (rec[6] > 0.0) M = fmin(M, rec[0]);
+      if (field(rec, 6) > 0.0) M = fmin(M, field(rec, 0));
     }
   }
   if (tpr == kWave) M = tbnav::wave_min_dpp(M);  // a whole wave per time step: reductions on the DPP network
@@ -1231,10 +1255,11 @@ __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, double 
     for (int r = l; r < R; r += tpr) {
       const int g = r / S, sl = r - g * S;
       const double* rec = records + (((size_t)g * T + i) * S + sl) * TBNAV_MPPI_REC;
-      if (rec[6] > 0.0) {
-        const double sc = exp(((rec[0] - M) * -1.0) / lambda);
-        W += sc * rec[1]; NL += sc * rec[2]; NR += sc * rec[3];
-        SD += rec[4]; SE += rec[5]; SN += rec[6];
+      const double rn = field(rec, 6);
+      if (rn > 0.0) {
+        const double sc = exp(((field(rec, 0) - M) * -1.0) / lambda);
+        W += sc * field(rec, 1); NL += sc * field(rec, 2); NR += sc * field(rec, 3);
+        SD += field(rec, 4); SE += field(rec, 5); SN += rn;
       }
     }
   }
@@ -1542,7 +1567,7 @@ int launch_partials(tbnav_mppi* h, const double* d_duL, const double* d_duR, dou
   return TBNAV_OK;
 }
 
-int launch_combine(tbnav_mppi* h, const double* d_records, int G, hipStream_t st, int S = -1) {
+int launch_combine(tbnav_mppi* h, const double* d_records, int G, hipStream_t st, int S = -1, const DirectSrc* direct = nullptr) {
   if (S < 0) S = h->S;
   int tpr = 1;
   while (tpr < G * S && tpr < kWave) tpr <<= 1;
@@ -1550,15 +1575,19 @@ int launch_combine(tbnav_mppi* h, const double* d_records, int G, hipStream_t st
   const int steps_per_block = wpb * (kWave / tpr);
   const int blocks = (h->T + steps_per_block - 1) / steps_per_block;
   const USrc usrc{h->d_u[h->ucur], h->pending_shift ? 1 : 0, h->uinit[0], h->uinit[1]};
-  if (G * S > 4 * kWave && G * S <= 8 * kWave)
-    hipLaunchKernelGGL(mppi_combine<8>, dim3(blocks), dim3(wpb * kWave), 0, st, h->T, G, S, h->p.lambda, h->p.max_wheel_vel, usrc,
-                       d_records, h->d_u[1 - h->ucur], h->d_out, h->publish_next ? h->d_out_host : nullptr, (double)(h->seq + 1));
-  else if (G * S > 2 * kWave && G * S <= 4 * kWave)
-    hipLaunchKernelGGL(mppi_combine<4>, dim3(blocks), dim3(wpb * kWave), 0, st, h->T, G, S, h->p.lambda, h->p.max_wheel_vel, usrc,
-                       d_records, h->d_u[1 - h->ucur], h->d_out, h->publish_next ? h->d_out_host : nullptr, (double)(h->seq + 1));
-  else
-    hipLaunchKernelGGL(mppi_combine<2>, dim3(blocks), dim3(wpb * kWave), 0, st, h->T, G, S, h->p.lambda, h->p.max_wheel_vel, usrc,
-                       d_records, h->d_u[1 - h->ucur], h->d_out, h->publish_next ? h->d_out_host : nullptr, (double)(h->seq + 1));
+  const DirectSrc ds = direct ? *direct : DirectSrc{nullptr, 0ull, nullptr, 0u};
+#define TBNAV_COMBINE(KEEP, DIR) hipLaunchKernelGGL((mppi_combine<KEEP, DIR>), dim3(blocks), dim3(wpb * kWave), 0, st, h->T, G, S, h->p.lambda, h->p.max_wheel_vel, usrc, \
+                                                    d_records, h->d_u[1 - h->ucur], h->d_out, h->publish_next ? h->d_out_host : nullptr, (double)(h->seq + 1), ds)
+  if (direct) {
+    if (G * S > 4 * kWave && G * S <= 8 * kWave) TBNAV_COMBINE(8, true);
+    else if (G * S > 2 * kWave && G * S <= 4 * kWave) TBNAV_COMBINE(4, true);
+    else TBNAV_COMBINE(2, true);
+  } else {
+    if (G * S > 4 * kWave && G * S <= 8 * kWave) TBNAV_COMBINE(8, false);
+    else if (G * S > 2 * kWave && G * S <= 4 * kWave) TBNAV_COMBINE(4, false);
+    else TBNAV_COMBINE(2, false);
+  }
+#undef TBNAV_COMBINE
   TBNAV_HIP(hipGetLastError());
   ++h->seq;
   if (h->publish_next) h->published = h->seq;
@@ -2277,15 +2306,17 @@ int sharded_partials(tbnav_mppi* h, const double x0[3], const double* d_duL, con
   double* mine = h->d_records_all + (size_t)tbnav::comm_rank(h->comm) * h->T * h->S * TBNAV_MPPI_REC;
   return seed ? tbnav_mppi_shard_partials_rng(h, x0, *seed, tick, stream, mine) : tbnav_mppi_shard_partials(h, x0, d_duL, d_duR, stream, mine);
 }
-constexpr unsigned long long kDirectBudgetTicks = 200000000ull;   // 2 s of the 100 MHz clock: a peer that takes longer has failed
+constexpr unsigned long long kDirectBudgetTicks = 2000000000ull;  // 20 s of the 100 MHz clock (host-side skew between ranks is legitimate; a peer that takes longer has failed)
 // this rank's freshly written records -> every rank's buffer; then wait for everybody's and unpack them into d_records_all
-int direct_exchange(tbnav_mppi* h, hipStream_t st, unsigned long long budget = kDirectBudgetTicks) {
+// (collect = false: only the stores; the tick's combine polls for the words itself — one launch fewer)
+int direct_exchange(tbnav_mppi* h, hipStream_t st, unsigned long long budget = kDirectBudgetTicks, bool collect = true) {
   const int P = tbnav::comm_size(h->comm), me = tbnav::comm_rank(h->comm), n = h->T * h->S * TBNAV_MPPI_REC;
   const unsigned int seq = ++h->dx_seq;
   const int parity = (int)(seq & 1u);
   const double* mine = h->d_records_all + (size_t)me * n;
   const int bx = std::min(8, (n + 255) / 256);
   hipLaunchKernelGGL(mppi_direct_publish, dim3(bx, P), dim3(256), 0, st, mine, n, h->d_dx_peers, me, P, parity, seq);
+  if (!collect) { TBNAV_HIP(hipGetLastError()); return TBNAV_OK; }
   const int bc = (int)std::min<size_t>(64, ((size_t)P * n + 255) / 256);
   hipLaunchKernelGGL(mppi_direct_collect, dim3(bc), dim3(256), 0, st, h->d_dx, n, P, parity, seq, h->d_records_all, h->d_dx_err, budget);
   TBNAV_HIP(hipGetLastError());
@@ -2375,9 +2406,11 @@ int sharded_tick(tbnav_mppi* h, const double x0[3], const double* d_duL, const d
   DeviceGuard guard(h->device);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (h->direct_on) {
-    rc = direct_exchange(h, st);
+    rc = direct_exchange(h, st, kDirectBudgetTicks, false);
     if (rc != TBNAV_OK) return rc;
-    return launch_combine(h, h->d_records_all, tbnav::comm_size(h->comm), st);
+    const int P = tbnav::comm_size(h->comm);
+    const DirectSrc ds{h->d_dx + (size_t)(h->dx_seq & 1u) * P * 2 * ((size_t)h->T * h->S * TBNAV_MPPI_REC), kDirectBudgetTicks, h->d_dx_err, h->dx_seq};
+    return launch_combine(h, h->d_records_all, P, st, -1, &ds);
   }
   const size_t block = sizeof(double) * (size_t)h->T * h->S * TBNAV_MPPI_REC;
   const void* send = reinterpret_cast<const char*>(h->d_records_all) + (size_t)tbnav::comm_rank(h->comm) * block;
