@@ -91,7 +91,8 @@ enum { TBNAV_MPPI_OPT_KERNEL = 1, TBNAV_MPPI_OPT_TRIG = 2, TBNAV_MPPI_OPT_NO_LDS
        TBNAV_MPPI_OPT_BATCH_GRAPH = 6 /* 0: tbnav_mppi_enqueue_rng_batch launches every tick by itself instead of replaying a captured hipGraph of 100 */,
        TBNAV_MPPI_OPT_PREFIX_FORM = 7,
        TBNAV_MPPI_OPT_DIRECT_EXCHANGE = 8 /* 0: a handle attached to a multi-process communicator always exchanges through the communicator's
-                                             all-gather (default 1: directly into the peers' buffers when every rank can; takes effect at the next attach) */ };
+                                             all-gather (default 1: directly into the peers' buffers when every rank can; takes effect at the next attach; 2: as 1 with a fault injected for the tests of the
+                                             bound — after the self-test this rank's records never reach its peers, and the bound is 0.3 s instead of 20 s) */ };
 int tbnav_mppi_set_option(tbnav_mppi* h, int32_t option, int32_t value);
 
 /* Rollout dynamics.  TBNAV_MPPI_DYN_RK4 (default) is the reference MPPI: CartModel + RK4 (controller/include/

@@ -1178,7 +1178,7 @@ __global__ __launch_bounds__(kWave) void mppi_merge_records(int T, int Sf, int p
 // The direct exchange's receiving side (see mppi_direct_publish): a record field is two tagged 8-byte words in this rank's own
 // fine-grained buffer; poll them until both carry the tick's sequence number (bounded: an error word and zeros after `budget`
 // ticks of the 100 MHz clock).
-struct DirectSrc { const unsigned long long* w0; unsigned long long budget; int* err; unsigned int seq; };
+struct DirectSrc { const unsigned long long* w0; unsigned long long budget; int* err; int* err_dev; unsigned int seq; };  // err: mapped host word; err_dev: its device twin (what later ticks look at)
 __device__ __forceinline__ double direct_load(const DirectSrc& d, size_t idx) {
   unsigned long long* w = const_cast<unsigned long long*>(d.w0) + 2 * idx;
   unsigned long long lo = 0ull, hi = 0ull;
@@ -1189,6 +1189,7 @@ __device__ __forceinline__ double direct_load(const DirectSrc& d, size_t idx) {
     if ((unsigned int)(lo >> 32) == d.seq && (unsigned int)(hi >> 32) == d.seq) break;
     if (wall_clock64() - t0 > d.budget) {
       __hip_atomic_fetch_or(d.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_fetch_or(d.err_dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       lo = hi = 0ull;
       break;
     }
@@ -1202,7 +1203,9 @@ __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, double 
                                                     const double* __restrict__ records, double* __restrict__ u_out,
                                                     double* __restrict__ out, double* __restrict__ out_host, double seq, DirectSrc ds) {
   // (DIRECT: `records` is not read — field f of record (g, i, sl) is polled for in the exchange buffer, same index)
-  auto field = [&](const double* rec, int f) { return DIRECT ? direct_load(ds, (size_t)(rec - records) + f) : rec[f]; };
+  // (an exchange that has timed out once stays dead: the ticks queued behind it must not each wait the whole bound again)
+  const bool dead = DIRECT && __hip_atomic_load(ds.err_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+  auto field = [&](const double* rec, int f) { return DIRECT ? (dead ? 0.0 : direct_load(ds, (size_t)(rec - records) + f)) : rec[f]; };
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave, nw = blockDim.x / kWave;
   const int R = G * S;
   int tpr = 1;
@@ -1330,7 +1333,8 @@ __global__ void mppi_tick_set(uint64_t* __restrict__ tick0, uint64_t v) { *tick0
 // a peer that never delivers raises an error word instead of hanging the device).  Two buffers take turns by the tick's
 // parity: a rank can be at most one tick ahead of a peer still reading (it needs that peer's records to get further).
 __global__ __launch_bounds__(256) void mppi_direct_publish(const double* __restrict__ mine, int n, unsigned long long* const* __restrict__ peers,
-                                                            int me, int P, int parity, unsigned int seq) {
+                                                            int me, int P, int parity, unsigned int seq, int only_self) {
+  if (only_self && (int)blockIdx.y != me) return;  // (fault injection for the tests of the bound: the peers never see this tick's records)
   unsigned long long* dst = peers[blockIdx.y] + (size_t)(parity * P + me) * 2 * n;
   const unsigned long long tag = (unsigned long long)seq << 32;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -1435,7 +1439,10 @@ struct tbnav_mppi {
   unsigned long long* d_dx = nullptr;           // [2 parities][nranks][2 * n] tagged words (n = T * S * 8), fine-grained
   unsigned long long** d_dx_peers = nullptr;    // [nranks] every rank's d_dx as mapped into this process
   std::vector<void*> dx_opened;                 // the mappings of the peers' buffers (closed at detach)
-  int* h_dx_err = nullptr; int* d_dx_err = nullptr;  // mapped pinned: raised by a collect that ran out of time
+  int* h_dx_err = nullptr; int* d_dx_err = nullptr;  // mapped pinned: raised by a combine that ran out of time waiting for a peer's words
+  int* d_dx_dead = nullptr;                          // its device twin: later ticks see it without a trip over PCIe
+  unsigned long long dx_budget = 2000000000ull;      // 20 s of the 100 MHz clock (host-side skew between ranks is legitimate; longer: the peer has failed)
+  bool dx_withhold = false;                          // fault injection (TBNAV_MPPI_OPT_DIRECT_EXCHANGE = 2, tests): this rank's records never reach its peers
   unsigned int dx_seq = 0;
 };
 
@@ -1575,7 +1582,7 @@ int launch_combine(tbnav_mppi* h, const double* d_records, int G, hipStream_t st
   const int steps_per_block = wpb * (kWave / tpr);
   const int blocks = (h->T + steps_per_block - 1) / steps_per_block;
   const USrc usrc{h->d_u[h->ucur], h->pending_shift ? 1 : 0, h->uinit[0], h->uinit[1]};
-  const DirectSrc ds = direct ? *direct : DirectSrc{nullptr, 0ull, nullptr, 0u};
+  const DirectSrc ds = direct ? *direct : DirectSrc{nullptr, 0ull, nullptr, nullptr, 0u};
 #define TBNAV_COMBINE(KEEP, DIR) hipLaunchKernelGGL((mppi_combine<KEEP, DIR>), dim3(blocks), dim3(wpb * kWave), 0, st, h->T, G, S, h->p.lambda, h->p.max_wheel_vel, usrc, \
                                                     d_records, h->d_u[1 - h->ucur], h->d_out, h->publish_next ? h->d_out_host : nullptr, (double)(h->seq + 1), ds)
   if (direct) {
@@ -1854,6 +1861,8 @@ int tbnav_mppi_set_option(tbnav_mppi* h, int32_t option, int32_t value) {
       return TBNAV_OK;
     case TBNAV_MPPI_OPT_DIRECT_EXCHANGE:  // (takes effect at the next tbnav_mppi_attach_comm)
       h->direct_want = value != 0;
+      h->dx_withhold = value == 2;                       // (tests of the bound: see dx_withhold)
+      h->dx_budget = value == 2 ? 30000000ull : 2000000000ull;  // 0.3 s there
       return TBNAV_OK;
     case TBNAV_MPPI_OPT_KERNEL: {
       // 0: mppi_rollout_cost (sequential); n > 0: mppi_rollout_scan with n steps per thread; -4 / -8 / -16: fused, that many rollouts per workgroup
@@ -2306,16 +2315,15 @@ int sharded_partials(tbnav_mppi* h, const double x0[3], const double* d_duL, con
   double* mine = h->d_records_all + (size_t)tbnav::comm_rank(h->comm) * h->T * h->S * TBNAV_MPPI_REC;
   return seed ? tbnav_mppi_shard_partials_rng(h, x0, *seed, tick, stream, mine) : tbnav_mppi_shard_partials(h, x0, d_duL, d_duR, stream, mine);
 }
-constexpr unsigned long long kDirectBudgetTicks = 2000000000ull;  // 20 s of the 100 MHz clock (host-side skew between ranks is legitimate; a peer that takes longer has failed)
 // this rank's freshly written records -> every rank's buffer; then wait for everybody's and unpack them into d_records_all
 // (collect = false: only the stores; the tick's combine polls for the words itself — one launch fewer)
-int direct_exchange(tbnav_mppi* h, hipStream_t st, unsigned long long budget = kDirectBudgetTicks, bool collect = true) {
+int direct_exchange(tbnav_mppi* h, hipStream_t st, unsigned long long budget, bool collect) {
   const int P = tbnav::comm_size(h->comm), me = tbnav::comm_rank(h->comm), n = h->T * h->S * TBNAV_MPPI_REC;
   const unsigned int seq = ++h->dx_seq;
   const int parity = (int)(seq & 1u);
   const double* mine = h->d_records_all + (size_t)me * n;
   const int bx = std::min(8, (n + 255) / 256);
-  hipLaunchKernelGGL(mppi_direct_publish, dim3(bx, P), dim3(256), 0, st, mine, n, h->d_dx_peers, me, P, parity, seq);
+  hipLaunchKernelGGL(mppi_direct_publish, dim3(bx, P), dim3(256), 0, st, mine, n, h->d_dx_peers, me, P, parity, seq, (h->dx_withhold && !collect) ? 1 : 0);
   if (!collect) { TBNAV_HIP(hipGetLastError()); return TBNAV_OK; }
   const int bc = (int)std::min<size_t>(64, ((size_t)P * n + 255) / 256);
   hipLaunchKernelGGL(mppi_direct_collect, dim3(bc), dim3(256), 0, st, h->d_dx, n, P, parity, seq, h->d_records_all, h->d_dx_err, budget);
@@ -2330,6 +2338,7 @@ void direct_teardown(tbnav_mppi* h) {
   h->dx_opened.clear();
   (void)hipFree(h->d_dx); h->d_dx = nullptr;
   (void)hipFree(h->d_dx_peers); h->d_dx_peers = nullptr;
+  (void)hipFree(h->d_dx_dead); h->d_dx_dead = nullptr;
   if (h->h_dx_err) (void)hipHostFree(h->h_dx_err);
   h->h_dx_err = nullptr; h->d_dx_err = nullptr;
 }
@@ -2355,7 +2364,8 @@ int direct_setup(tbnav_mppi* h) {
              hipIpcGetMemHandle(&hello.handle, h->d_dx) == hipSuccess &&
              hipHostMalloc((void**)&h->h_dx_err, sizeof(int), hipHostMallocMapped) == hipSuccess &&
              hipHostGetDevicePointer((void**)&h->d_dx_err, h->h_dx_err, 0) == hipSuccess &&
-             hipMalloc((void**)&h->d_dx_peers, sizeof(unsigned long long*) * P) == hipSuccess;
+             hipMalloc((void**)&h->d_dx_peers, sizeof(unsigned long long*) * P) == hipSuccess &&
+             hipMalloc((void**)&h->d_dx_dead, sizeof(int)) == hipSuccess && hipMemset(h->d_dx_dead, 0, sizeof(int)) == hipSuccess;
   if (h->h_dx_err) *h->h_dx_err = 0;
   std::vector<Hello> all(P);
   { const int rc = tbnav::comm_all_gather_host(h->comm, &hello, all.data(), sizeof(Hello)); if (rc != TBNAV_OK) { direct_teardown(h); return rc; } }
@@ -2388,7 +2398,7 @@ int direct_setup(tbnav_mppi* h) {
   for (int it = 0; it < 24 && ok; ++it) {
     for (int q = 0; q < P; ++q) for (int j = 0; j < n; ++j) pat[(size_t)q * n + j] = pattern(q, it, j);
     if (hipMemcpyAsync(h->d_records_all + (size_t)me * n, pat.data() + (size_t)me * n, sizeof(double) * n, hipMemcpyHostToDevice, st) != hipSuccess) { ok = 0; break; }
-    if (direct_exchange(h, st, 25000000ull /* 0.25 s */) != TBNAV_OK) { ok = 0; break; }
+    if (direct_exchange(h, st, 25000000ull /* 0.25 s */, true) != TBNAV_OK) { ok = 0; break; }
     if (hipMemcpyAsync(got.data(), h->d_records_all, sizeof(double) * P * n, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { ok = 0; break; }
     if (*h->h_dx_err || std::memcmp(got.data(), pat.data(), sizeof(double) * P * n) != 0) ok = 0;
   }
@@ -2406,10 +2416,10 @@ int sharded_tick(tbnav_mppi* h, const double x0[3], const double* d_duL, const d
   DeviceGuard guard(h->device);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (h->direct_on) {
-    rc = direct_exchange(h, st, kDirectBudgetTicks, false);
+    rc = direct_exchange(h, st, h->dx_budget, false);
     if (rc != TBNAV_OK) return rc;
     const int P = tbnav::comm_size(h->comm);
-    const DirectSrc ds{h->d_dx + (size_t)(h->dx_seq & 1u) * P * 2 * ((size_t)h->T * h->S * TBNAV_MPPI_REC), kDirectBudgetTicks, h->d_dx_err, h->dx_seq};
+    const DirectSrc ds{h->d_dx + (size_t)(h->dx_seq & 1u) * P * 2 * ((size_t)h->T * h->S * TBNAV_MPPI_REC), h->dx_budget, h->d_dx_err, h->d_dx_dead, h->dx_seq};
     return launch_combine(h, h->d_records_all, P, st, -1, &ds);
   }
   const size_t block = sizeof(double) * (size_t)h->T * h->S * TBNAV_MPPI_REC;

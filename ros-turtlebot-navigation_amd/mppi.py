@@ -98,7 +98,7 @@ class MPPI:
 
     def setDirectExchange(self, on: bool):
         """TBNAV_MPPI_OPT_DIRECT_EXCHANGE; before attachComm."""
-        capi.check(self._L.tbnav_mppi_set_option(self._h, 8, 1 if on else 0), "set_option(direct exchange)")
+        capi.check(self._L.tbnav_mppi_set_option(self._h, 8, int(on)), "set_option(direct exchange)")  # (2: fault injection, tests)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value and getattr(self, "_owned", True):

@@ -347,3 +347,38 @@ def rbpf_comm_worker(rank, world, n_local, k, heavy, device_noise):
         stats.append((sa.neff, sa.resampled))
     a.close(); b.close(); comm.close()
     return {"resampled": resampled, "stats": stats}
+
+
+def mppi_direct_fault_worker(rank, world, K_local, horizon):
+    """The direct exchange with a fault injected on every rank (records never reach the peers; bound 0.3 s): a batch of ticks must
+    come back with an error status in about one bound — not one bound per tick, not a hang — and the handle must work again, through
+    the communicator's all-gather, after a detach / re-attach (what bench.py does when its headline fails that way)."""
+    import time
+    import torch
+    comm = _ipc_comm()
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    from cases import WAYPOINTS, make_mppi, mppi_cfg
+    from rtn_amd import capi
+    m = make_mppi(pkg, mppi_cfg(K_local, horizon))
+    m.setWaypoint(*WAYPOINTS[1])
+    m.setDirectExchange(2)
+    m.attachComm(comm)
+    assert m.exchangeKind() == 2   # (the self-test runs before the fault is switched on)
+    st = torch.cuda.Stream()
+    t0 = time.perf_counter()
+    m.enqueueRngBatch((0.0, 0.0, 0.0), 5, 0, 6, st.cuda_stream)
+    msg = None
+    try:
+        m.lastControls(st.cuda_stream)
+    except capi.TbnavError as e:
+        msg = str(e)
+    waited = time.perf_counter() - t0
+    m.attachComm(None)
+    m.setDirectExchange(0)
+    m.setInitialControls(0.0, 0.0)
+    m.attachComm(comm)
+    kind = m.exchangeKind()
+    out = [np.array(m.newControlsRng((0.0, 0.0, 0.0), 5, i)) for i in range(3)]
+    m.close(); comm.close()
+    return {"msg": msg, "waited": waited, "kind": kind, "out": out}

@@ -43,6 +43,16 @@ def test_mppi_ranks_in_separate_processes(gpu_pkg, world, K_local, horizon):
         assert np.array_equal(out[0]["batch_u"], out[r]["batch_u"]) and np.array_equal(out[0]["batch_last"], out[r]["batch_last"])
 
 
+def test_direct_exchange_that_never_delivers_is_an_error_not_a_hang(gpu_pkg):
+    from dist_workers import mppi_direct_fault_worker, run_spawn
+    out = run_spawn(mppi_direct_fault_worker, 2, 1024, 0.5)
+    for r in range(2):
+        assert out[r]["msg"] is not None and "direct exchange" in out[r]["msg"], out[r]["msg"]
+        assert out[r]["waited"] < 5.0, out[r]["waited"]   # one 0.3 s bound for the first tick; the five behind it see the dead mark
+        assert out[r]["kind"] == 1 and all(np.all(np.isfinite(x)) for x in out[r]["out"])
+    assert all(np.array_equal(a, b) for a, b in zip(out[0]["out"], out[1]["out"]))
+
+
 @pytest.mark.parametrize("world,n_local,heavy,device_noise", [(2, 6, {3: 0.6, 10: 0.25}, False), (3, 7, {0: 0.3, 9: 0.3, 20: 0.3}, False),
                                                               (4, 5, {1: 0.6, 17: 0.3}, True), (3, 4, {11: 0.9}, True)])
 def test_rbpf_ranks_in_separate_processes_equal_the_unsharded_filter(gpu_pkg, world, n_local, heavy, device_noise):
