@@ -1139,8 +1139,10 @@ __global__ __launch_bounds__(kSliceThreads) void mppi_partials(int T, int K, int
 // interface exchanges ([T][S][8], one per kSlice = 2048 rollouts): grid (S, T), one wave each.  Same algebra as the
 // combine's first half — re-base every partial sum to the common minimum — so the result equals the partials
 // kernel's record for that slice up to the association of the sums.
+// (the direct exchange's sending side, when the records are produced here: see mppi_direct_publish further down)
+struct DirectPub { unsigned long long* const* peers; int me, P, parity; unsigned int seq; int only_self; };
 __global__ __launch_bounds__(kWave) void mppi_merge_records(int T, int Sf, int per_slice, int S, double lambda,
-                                                            const double* __restrict__ fine, double* __restrict__ records) {
+                                                            const double* __restrict__ fine, double* __restrict__ records, DirectPub pub) {
   const int s = blockIdx.x, i = blockIdx.y, lane = threadIdx.x;
   const int r0 = s * per_slice, r1 = min(Sf, r0 + per_slice);
   const double inf = __builtin_huge_val();
@@ -1164,6 +1166,22 @@ __global__ __launch_bounds__(kWave) void mppi_merge_records(int T, int Sf, int p
   if (lane == 0) {
     double* out = records + ((size_t)i * S + s) * TBNAV_MPPI_REC;
     out[0] = M; out[1] = A; out[2] = B; out[3] = C; out[4] = D; out[5] = E; out[6] = n; out[7] = 0.0;
+  }
+  if (pub.peers) {
+    // direct exchange: this record goes straight into every rank's buffer as tagged words (mppi_direct_publish's layout) — the
+    // fold and the publish are one launch
+    __shared__ double rec8[TBNAV_MPPI_REC];
+    if (lane == 0) { rec8[0] = M; rec8[1] = A; rec8[2] = B; rec8[3] = C; rec8[4] = D; rec8[5] = E; rec8[6] = n; rec8[7] = 0.0; }
+    __syncthreads();
+    const size_t nrec = (size_t)T * S * TBNAV_MPPI_REC, base = ((size_t)i * S + s) * TBNAV_MPPI_REC;
+    const unsigned long long tag = (unsigned long long)pub.seq << 32;
+    for (int j = lane; j < pub.P * 2 * TBNAV_MPPI_REC; j += kWave) {
+      const int q = j / (2 * TBNAV_MPPI_REC), w = j - q * 2 * TBNAV_MPPI_REC, f = w >> 1;
+      if (pub.only_self && q != pub.me) continue;
+      const unsigned long long b = (unsigned long long)__double_as_longlong(rec8[f]);
+      unsigned long long* dst = pub.peers[q] + ((size_t)(pub.parity * pub.P + pub.me) * nrec + base + f) * 2 + (w & 1);
+      __hip_atomic_store(dst, tag | ((w & 1) ? (b >> 32) : (b & 0xFFFFFFFFull)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -1444,9 +1462,20 @@ struct tbnav_mppi {
   unsigned long long dx_budget = 2000000000ull;      // 20 s of the 100 MHz clock (host-side skew between ranks is legitimate; longer: the peer has failed)
   bool dx_withhold = false;                          // fault injection (TBNAV_MPPI_OPT_DIRECT_EXCHANGE = 2, tests): this rank's records never reach its peers
   unsigned int dx_seq = 0;
+  // set by the sharded tick round its call of the shard-partials entry point: if that ends in mppi_merge_records, the kernel
+  // publishes the records itself (and clears this); otherwise the tick launches mppi_direct_publish
+  bool pub_pending = false;
+  DirectPub pub_next{nullptr, 0, 0, 0, 0u, 0};
 };
 
 namespace {
+
+// the publication the sharded tick has asked for, taken over by the launch that can carry it out (see pub_pending)
+DirectPub take_pub(tbnav_mppi* h) {
+  if (!h->pub_pending) return DirectPub{nullptr, 0, 0, 0, 0u, 0};
+  h->pub_pending = false;
+  return h->pub_next;
+}
 
 int launch_rollout(tbnav_mppi* h, const double x0[3], const double* d_duL, const double* d_duR,
                    hipStream_t st) {
@@ -1957,7 +1986,7 @@ int tbnav_mppi_shard_partials(tbnav_mppi* h, const double x0[3], const double* d
     const int rcf = launch_fused(h, x0, d_duL, d_duR, st);
     if (rcf != TBNAV_OK) return rcf;
     hipLaunchKernelGGL(mppi_merge_records, dim3(h->S, h->T), dim3(kWave), 0, st, h->T, h->fused_S, kSlice / h->fused_r, h->S,
-                       h->p.lambda, h->d_records_f, d_records_out);
+                       h->p.lambda, h->d_records_f, d_records_out, take_pub(h));
     TBNAV_HIP(hipGetLastError());
     return TBNAV_OK;
   }
@@ -1980,7 +2009,7 @@ int tbnav_mppi_shard_partials_rng(tbnav_mppi* h, const double x0[3], uint64_t se
   const int rcf = launch_fused(h, x0, h->d_duL, h->d_duR, st, &g);
   if (rcf != TBNAV_OK) return rcf;
   hipLaunchKernelGGL(mppi_merge_records, dim3(h->S, h->T), dim3(kWave), 0, st, h->T, h->fused_S, kSlice / h->fused_r, h->S,
-                     h->p.lambda, h->d_records_f, d_records_out);
+                     h->p.lambda, h->d_records_f, d_records_out, take_pub(h));
   TBNAV_HIP(hipGetLastError());
   return TBNAV_OK;
 }
@@ -2411,12 +2440,20 @@ int direct_setup(tbnav_mppi* h) {
 }
 
 int sharded_tick(tbnav_mppi* h, const double x0[3], const double* d_duL, const double* d_duR, const uint64_t* seed, uint64_t tick, void* stream) {
+  if (h->direct_on) {  // (the sequence number is drawn here: the kernel that produces the records may publish them itself)
+    const unsigned int seq = h->dx_seq + 1u;
+    h->pub_next = DirectPub{h->d_dx_peers, tbnav::comm_rank(h->comm), tbnav::comm_size(h->comm), (int)(seq & 1u), seq, h->dx_withhold ? 1 : 0};
+    h->pub_pending = true;
+  }
   int rc = sharded_partials(h, x0, d_duL, d_duR, seed, tick, stream);
+  const bool published = h->direct_on && !h->pub_pending;
+  h->pub_pending = false;
   if (rc != TBNAV_OK) return rc;
   DeviceGuard guard(h->device);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (h->direct_on) {
-    rc = direct_exchange(h, st, h->dx_budget, false);
+    if (published) ++h->dx_seq;
+    else rc = direct_exchange(h, st, h->dx_budget, false);
     if (rc != TBNAV_OK) return rc;
     const int P = tbnav::comm_size(h->comm);
     const DirectSrc ds{h->d_dx + (size_t)(h->dx_seq & 1u) * P * 2 * ((size_t)h->T * h->S * TBNAV_MPPI_REC), h->dx_budget, h->d_dx_err, h->d_dx_dead, h->dx_seq};
