@@ -2427,7 +2427,7 @@ int direct_setup(tbnav_mppi* h) {
   for (int it = 0; it < 24 && ok; ++it) {
     for (int q = 0; q < P; ++q) for (int j = 0; j < n; ++j) pat[(size_t)q * n + j] = pattern(q, it, j);
     if (hipMemcpyAsync(h->d_records_all + (size_t)me * n, pat.data() + (size_t)me * n, sizeof(double) * n, hipMemcpyHostToDevice, st) != hipSuccess) { ok = 0; break; }
-    if (direct_exchange(h, st, 25000000ull /* 0.25 s */, true) != TBNAV_OK) { ok = 0; break; }
+    if (direct_exchange(h, st, 200000000ull /* 2 s: the first touch of a fresh peer mapping may take its time; the loop ends at the first failure */, true) != TBNAV_OK) { ok = 0; break; }
     if (hipMemcpyAsync(got.data(), h->d_records_all, sizeof(double) * P * n, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { ok = 0; break; }
     if (*h->h_dx_err || std::memcmp(got.data(), pat.data(), sizeof(double) * P * n) != 0) ok = 0;
   }
