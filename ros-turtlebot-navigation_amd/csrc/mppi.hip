@@ -2345,19 +2345,49 @@ int sharded_partials(tbnav_mppi* h, const double x0[3], const double* d_duL, con
   return seed ? tbnav_mppi_shard_partials_rng(h, x0, *seed, tick, stream, mine) : tbnav_mppi_shard_partials(h, x0, d_duL, d_duR, stream, mine);
 }
 // this rank's freshly written records -> every rank's buffer; then wait for everybody's and unpack them into d_records_all
-// (collect = false: only the stores; the tick's combine polls for the words itself — one launch fewer)
-int direct_exchange(tbnav_mppi* h, hipStream_t st, unsigned long long budget, bool collect) {
+// this rank's freshly written records (its slot of d_records_all) -> every rank's buffer, under the next sequence number
+int direct_publish(tbnav_mppi* h, hipStream_t st, bool withhold) {
   const int P = tbnav::comm_size(h->comm), me = tbnav::comm_rank(h->comm), n = h->T * h->S * TBNAV_MPPI_REC;
   const unsigned int seq = ++h->dx_seq;
-  const int parity = (int)(seq & 1u);
   const double* mine = h->d_records_all + (size_t)me * n;
   const int bx = std::min(8, (n + 255) / 256);
-  hipLaunchKernelGGL(mppi_direct_publish, dim3(bx, P), dim3(256), 0, st, mine, n, h->d_dx_peers, me, P, parity, seq, (h->dx_withhold && !collect) ? 1 : 0);
-  if (!collect) { TBNAV_HIP(hipGetLastError()); return TBNAV_OK; }
-  const int bc = (int)std::min<size_t>(64, ((size_t)P * n + 255) / 256);
-  hipLaunchKernelGGL(mppi_direct_collect, dim3(bc), dim3(256), 0, st, h->d_dx, n, P, parity, seq, h->d_records_all, h->d_dx_err, budget);
+  hipLaunchKernelGGL(mppi_direct_publish, dim3(bx, P), dim3(256), 0, st, mine, n, h->d_dx_peers, me, P, (int)(seq & 1u), seq, withhold ? 1 : 0);
   TBNAV_HIP(hipGetLastError());
   return TBNAV_OK;
+}
+// wait for everybody's records of the current sequence number and unpack them into d_records_all (the self-tests; the tick's
+// combine polls for the words itself — one launch fewer)
+int direct_collect(tbnav_mppi* h, hipStream_t st, unsigned long long budget) {
+  const int P = tbnav::comm_size(h->comm), n = h->T * h->S * TBNAV_MPPI_REC;
+  const int bc = (int)std::min<size_t>(64, ((size_t)P * n + 255) / 256);
+  hipLaunchKernelGGL(mppi_direct_collect, dim3(bc), dim3(256), 0, st, h->d_dx, n, P, (int)(h->dx_seq & 1u), h->dx_seq, h->d_records_all, h->d_dx_err, budget);
+  TBNAV_HIP(hipGetLastError());
+  return TBNAV_OK;
+}
+// the tick's two halves on one member: rollouts + records + their publication; the combine that polls for everybody's
+int direct_partials_and_publish(tbnav_mppi* h, const double x0[3], const double* d_duL, const double* d_duR, const uint64_t* seed, uint64_t tick, void* stream);
+int direct_combine(tbnav_mppi* h, hipStream_t st) {
+  const int P = tbnav::comm_size(h->comm);
+  const DirectSrc ds{h->d_dx + (size_t)(h->dx_seq & 1u) * P * 2 * ((size_t)h->T * h->S * TBNAV_MPPI_REC), h->dx_budget, h->d_dx_err, h->d_dx_dead, h->dx_seq};
+  return launch_combine(h, h->d_records_all, P, st, -1, &ds);
+}
+// the buffer, the error words and the table of peers of one member (host side of both set-ups)
+bool direct_alloc(tbnav_mppi* h) {
+  const int P = tbnav::comm_size(h->comm), n = h->T * h->S * TBNAV_MPPI_REC;
+  const size_t words = (size_t)2 * P * 2 * n;
+  const bool ok = hipExtMallocWithFlags((void**)&h->d_dx, sizeof(unsigned long long) * words, hipDeviceMallocFinegrained) == hipSuccess &&
+                  hipMemset(h->d_dx, 0, sizeof(unsigned long long) * words) == hipSuccess &&
+                  hipHostMalloc((void**)&h->h_dx_err, sizeof(int), hipHostMallocMapped) == hipSuccess &&
+                  hipHostGetDevicePointer((void**)&h->d_dx_err, h->h_dx_err, 0) == hipSuccess &&
+                  hipMalloc((void**)&h->d_dx_peers, sizeof(unsigned long long*) * P) == hipSuccess &&
+                  hipMalloc((void**)&h->d_dx_dead, sizeof(int)) == hipSuccess && hipMemset(h->d_dx_dead, 0, sizeof(int)) == hipSuccess;
+  if (h->h_dx_err) *h->h_dx_err = 0;
+  return ok;
+}
+double direct_pattern(int q, int it, int j) {  // the self-tests' records: every bit in play
+  unsigned long long z = 0x9E3779B97F4A7C15ull * (unsigned long long)(q * 1000003 + it * 7919 + j + 1);
+  z ^= z >> 31; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 29;
+  double d; std::memcpy(&d, &z, sizeof d); return d;
 }
 
 void direct_teardown(tbnav_mppi* h) {
@@ -2377,7 +2407,6 @@ void direct_teardown(tbnav_mppi* h) {
 // state: direct exchange on, or off (the communicator's all-gather carries the records) — never a mixture.
 int direct_setup(tbnav_mppi* h) {
   const int P = tbnav::comm_size(h->comm), me = tbnav::comm_rank(h->comm), n = h->T * h->S * TBNAV_MPPI_REC;
-  const size_t words = (size_t)2 * P * 2 * n;
   struct Hello { int ok; int pad; hipIpcMemHandle_t handle; };
   auto agree = [&](int mine_ok, bool& all_ok) {   // collective
     std::vector<int> all(P, 0);
@@ -2388,14 +2417,7 @@ int direct_setup(tbnav_mppi* h) {
   };
   // 1. the buffer (fine-grained: written by other devices while kernels of this one poll it), its IPC handle
   Hello hello{};
-  hello.ok = hipExtMallocWithFlags((void**)&h->d_dx, sizeof(unsigned long long) * words, hipDeviceMallocFinegrained) == hipSuccess &&
-             hipMemset(h->d_dx, 0, sizeof(unsigned long long) * words) == hipSuccess &&
-             hipIpcGetMemHandle(&hello.handle, h->d_dx) == hipSuccess &&
-             hipHostMalloc((void**)&h->h_dx_err, sizeof(int), hipHostMallocMapped) == hipSuccess &&
-             hipHostGetDevicePointer((void**)&h->d_dx_err, h->h_dx_err, 0) == hipSuccess &&
-             hipMalloc((void**)&h->d_dx_peers, sizeof(unsigned long long*) * P) == hipSuccess &&
-             hipMalloc((void**)&h->d_dx_dead, sizeof(int)) == hipSuccess && hipMemset(h->d_dx_dead, 0, sizeof(int)) == hipSuccess;
-  if (h->h_dx_err) *h->h_dx_err = 0;
+  hello.ok = direct_alloc(h) && hipIpcGetMemHandle(&hello.handle, h->d_dx) == hipSuccess;
   std::vector<Hello> all(P);
   { const int rc = tbnav::comm_all_gather_host(h->comm, &hello, all.data(), sizeof(Hello)); if (rc != TBNAV_OK) { direct_teardown(h); return rc; } }
   bool everybody = true;
@@ -2419,15 +2441,11 @@ int direct_setup(tbnav_mppi* h) {
   hipStream_t st = nullptr;
   ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess ? 1 : 0;
   std::vector<double> pat((size_t)P * n), got((size_t)P * n);
-  auto pattern = [](int q, int it, int j) {
-    unsigned long long z = 0x9E3779B97F4A7C15ull * (unsigned long long)(q * 1000003 + it * 7919 + j + 1);
-    z ^= z >> 31; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 29;
-    double d; std::memcpy(&d, &z, sizeof d); return d;
-  };
   for (int it = 0; it < 24 && ok; ++it) {
-    for (int q = 0; q < P; ++q) for (int j = 0; j < n; ++j) pat[(size_t)q * n + j] = pattern(q, it, j);
+    for (int q = 0; q < P; ++q) for (int j = 0; j < n; ++j) pat[(size_t)q * n + j] = direct_pattern(q, it, j);
     if (hipMemcpyAsync(h->d_records_all + (size_t)me * n, pat.data() + (size_t)me * n, sizeof(double) * n, hipMemcpyHostToDevice, st) != hipSuccess) { ok = 0; break; }
-    if (direct_exchange(h, st, 200000000ull /* 2 s: the first touch of a fresh peer mapping may take its time; the loop ends at the first failure */, true) != TBNAV_OK) { ok = 0; break; }
+    // (2 s: the first touch of a fresh peer mapping may take its time; the loop ends at the first failure)
+    if (direct_publish(h, st, false) != TBNAV_OK || direct_collect(h, st, 200000000ull) != TBNAV_OK) { ok = 0; break; }
     if (hipMemcpyAsync(got.data(), h->d_records_all, sizeof(double) * P * n, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { ok = 0; break; }
     if (*h->h_dx_err || std::memcmp(got.data(), pat.data(), sizeof(double) * P * n) != 0) ok = 0;
   }
@@ -2439,26 +2457,31 @@ int direct_setup(tbnav_mppi* h) {
   return TBNAV_OK;
 }
 
+int direct_partials_and_publish(tbnav_mppi* h, const double x0[3], const double* d_duL, const double* d_duR, const uint64_t* seed, uint64_t tick, void* stream) {
+  // (the sequence number is drawn here: the kernel that produces the records may publish them itself — mppi_merge_records)
+  const unsigned int seq = h->dx_seq + 1u;
+  h->pub_next = DirectPub{h->d_dx_peers, tbnav::comm_rank(h->comm), tbnav::comm_size(h->comm), (int)(seq & 1u), seq, h->dx_withhold ? 1 : 0};
+  h->pub_pending = true;
+  const int rc = sharded_partials(h, x0, d_duL, d_duR, seed, tick, stream);
+  const bool published = !h->pub_pending;
+  h->pub_pending = false;
+  if (rc != TBNAV_OK) return rc;
+  if (published) { ++h->dx_seq; return TBNAV_OK; }
+  DeviceGuard guard(h->device);
+  return direct_publish(h, static_cast<hipStream_t>(stream), h->dx_withhold);
+}
+
 int sharded_tick(tbnav_mppi* h, const double x0[3], const double* d_duL, const double* d_duR, const uint64_t* seed, uint64_t tick, void* stream) {
-  if (h->direct_on) {  // (the sequence number is drawn here: the kernel that produces the records may publish them itself)
-    const unsigned int seq = h->dx_seq + 1u;
-    h->pub_next = DirectPub{h->d_dx_peers, tbnav::comm_rank(h->comm), tbnav::comm_size(h->comm), (int)(seq & 1u), seq, h->dx_withhold ? 1 : 0};
-    h->pub_pending = true;
+  if (h->direct_on) {
+    const int rc = direct_partials_and_publish(h, x0, d_duL, d_duR, seed, tick, stream);
+    if (rc != TBNAV_OK) return rc;
+    DeviceGuard guard(h->device);
+    return direct_combine(h, static_cast<hipStream_t>(stream));
   }
   int rc = sharded_partials(h, x0, d_duL, d_duR, seed, tick, stream);
-  const bool published = h->direct_on && !h->pub_pending;
-  h->pub_pending = false;
   if (rc != TBNAV_OK) return rc;
   DeviceGuard guard(h->device);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (h->direct_on) {
-    if (published) ++h->dx_seq;
-    else rc = direct_exchange(h, st, h->dx_budget, false);
-    if (rc != TBNAV_OK) return rc;
-    const int P = tbnav::comm_size(h->comm);
-    const DirectSrc ds{h->d_dx + (size_t)(h->dx_seq & 1u) * P * 2 * ((size_t)h->T * h->S * TBNAV_MPPI_REC), h->dx_budget, h->d_dx_err, h->d_dx_dead, h->dx_seq};
-    return launch_combine(h, h->d_records_all, P, st, -1, &ds);
-  }
   const size_t block = sizeof(double) * (size_t)h->T * h->S * TBNAV_MPPI_REC;
   const void* send = reinterpret_cast<const char*>(h->d_records_all) + (size_t)tbnav::comm_rank(h->comm) * block;
   void* recv = h->d_records_all;
@@ -2477,6 +2500,56 @@ struct tbnav_mppi_group {
   std::vector<double*> d_raw;  // per member: staging of its slice of host-order noise
   int K_global = 0;
 };
+
+namespace {
+// The direct exchange for the members of one process (a ROS node driving several GPUs): the members' buffers are plain device
+// pointers of this process — peer access between distinct devices, nothing to map — and one host thread enqueues, per tick,
+// every member's rollouts + publication and then every member's polling combine (what a kernel polls for was enqueued before
+// it, on every stream).  Same kernels, same words, same self-test as between processes.
+int group_direct_setup(tbnav_mppi_group* g) {
+  const int P = g->n;
+  for (tbnav_mppi* h : g->m) { DeviceGuard guard(h->device); (void)hipDeviceSynchronize(); direct_teardown(h); }
+  bool want = P > 1;
+  for (tbnav_mppi* h : g->m) want = want && h->direct_want && h->comm;
+  if (!want) return TBNAV_OK;
+  auto give_up = [&]() { for (tbnav_mppi* h : g->m) { DeviceGuard guard(h->device); (void)hipDeviceSynchronize(); direct_teardown(h); } return (int)TBNAV_OK; };
+  for (int r = 0; r < P; ++r)
+    for (int q = 0; q < P; ++q) {
+      if (g->m[r]->device == g->m[q]->device) continue;
+      DeviceGuard guard(g->m[r]->device);
+      const hipError_t e = hipDeviceEnablePeerAccess(g->m[q]->device, 0);
+      (void)hipGetLastError();
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return give_up();
+    }
+  for (tbnav_mppi* h : g->m) { DeviceGuard guard(h->device); if (!direct_alloc(h)) return give_up(); }
+  std::vector<unsigned long long*> peers(P);
+  for (int q = 0; q < P; ++q) peers[q] = g->m[q]->d_dx;
+  for (tbnav_mppi* h : g->m) {
+    DeviceGuard guard(h->device);
+    if (hipMemcpy(h->d_dx_peers, peers.data(), sizeof(unsigned long long*) * P, hipMemcpyHostToDevice) != hipSuccess) return give_up();
+  }
+  const int n = g->m[0]->T * g->m[0]->S * TBNAV_MPPI_REC;
+  std::vector<double> pat((size_t)P * n), got((size_t)P * n);
+  for (int it = 0; it < 12; ++it) {
+    for (int q = 0; q < P; ++q) for (int j = 0; j < n; ++j) pat[(size_t)q * n + j] = direct_pattern(q, it, j);
+    for (int r = 0; r < P; ++r) {
+      tbnav_mppi* h = g->m[r];
+      DeviceGuard guard(h->device);
+      if (hipMemcpyAsync(h->d_records_all + (size_t)r * n, pat.data() + (size_t)r * n, sizeof(double) * n, hipMemcpyHostToDevice, g->st[r]) != hipSuccess ||
+          direct_publish(h, g->st[r], false) != TBNAV_OK) return give_up();
+    }
+    for (int r = 0; r < P; ++r) { DeviceGuard guard(g->m[r]->device); if (direct_collect(g->m[r], g->st[r], 200000000ull) != TBNAV_OK) return give_up(); }
+    for (int r = 0; r < P; ++r) {
+      tbnav_mppi* h = g->m[r];
+      DeviceGuard guard(h->device);
+      if (hipMemcpyAsync(got.data(), h->d_records_all, sizeof(double) * P * n, hipMemcpyDeviceToHost, g->st[r]) != hipSuccess || hipStreamSynchronize(g->st[r]) != hipSuccess ||
+          *h->h_dx_err || std::memcmp(got.data(), pat.data(), sizeof(double) * P * n) != 0) return give_up();
+    }
+  }
+  for (tbnav_mppi* h : g->m) { *h->h_dx_err = 0; h->direct_on = true; }
+  return TBNAV_OK;
+}
+}  // namespace
 
 extern "C" {
 
@@ -2507,6 +2580,7 @@ int tbnav_mppi_group_create(const tbnav_mppi_params* params, int32_t n_gpus, con
     if (rc == TBNAV_OK) rc = tbnav_mppi_attach_comm(g->m[r], g->c[r]);
     if (rc == TBNAV_OK) { DeviceGuard guard(p.device); if (hipStreamCreateWithFlags(&g->st[r], hipStreamNonBlocking) != hipSuccess) rc = TBNAV_ERR_HIP; }
   }
+  if (rc == TBNAV_OK) rc = group_direct_setup(g);
   if (rc != TBNAV_OK) { tbnav_mppi_group_destroy(g); return rc; }
   *out = g;
   return TBNAV_OK;
@@ -2542,6 +2616,7 @@ int tbnav_mppi_group_set_dynamics(tbnav_mppi_group* g, int32_t model) {
 int tbnav_mppi_group_set_option(tbnav_mppi_group* g, int32_t option, int32_t value) {
   if (!g) return TBNAV_ERR_INVALID_ARG;
   for (tbnav_mppi* h : g->m) { const int rc = tbnav_mppi_set_option(h, option, value); if (rc != TBNAV_OK) return rc; }
+  if (option == TBNAV_MPPI_OPT_DIRECT_EXCHANGE) return group_direct_setup(g);   // (a group is attached already: the choice is made here)
   return TBNAV_OK;
 }
 
@@ -2551,6 +2626,20 @@ namespace {
 // every member's partials, ONE grouped all-gather, every member's combine; member 0 publishes when asked to
 int group_tick(tbnav_mppi_group* g, const double x0[3], bool own_noise, const uint64_t* seed, uint64_t tick, bool publish) {
   const int n = g->n;
+  if (g->m[0]->direct_on) {
+    for (int r = 0; r < n; ++r) {
+      const int rc = direct_partials_and_publish(g->m[r], x0, own_noise ? g->m[r]->d_duL : nullptr, own_noise ? g->m[r]->d_duR : nullptr, seed, tick, g->st[r]);
+      if (rc != TBNAV_OK) return rc;
+    }
+    for (int r = 0; r < n; ++r) {
+      DeviceGuard guard(g->m[r]->device);
+      g->m[r]->publish_next = publish && r == 0;
+      const int rc = direct_combine(g->m[r], g->st[r]);
+      g->m[r]->publish_next = false;
+      if (rc != TBNAV_OK) return rc;
+    }
+    return TBNAV_OK;
+  }
   for (int r = 0; r < n; ++r) {
     const int rc = sharded_partials(g->m[r], x0, own_noise ? g->m[r]->d_duL : nullptr, own_noise ? g->m[r]->d_duR : nullptr, seed, tick, g->st[r]);
     if (rc != TBNAV_OK) return rc;

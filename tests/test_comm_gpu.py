@@ -98,6 +98,34 @@ def test_mppi_group_of_members_on_one_device_equals_the_oracle_and_the_unsharded
     grp.close(); g2.close(); one.close()
 
 
+@pytest.mark.parametrize("K,horizon,P", [(2048, 0.5, 2), (8 * 1024, 0.5, 8), (3 * 40000, 0.2, 3)])
+def test_mppi_group_direct_exchange_equals_the_all_gather_bit_for_bit(gpu_pkg, K, horizon, P):
+    """The members of a one-process group exchange their records DIRECTLY by default (tbnav_mppi_exchange_kind 2: every member stores
+    tagged words into every member's buffer, the combine polls its own) — the same kernels as between processes; with
+    TBNAV_MPPI_OPT_DIRECT_EXCHANGE 0 the group's all-gather carries them (kind 1).  Same records either way: identical controls,
+    tick by tick and through a batch, with the fused small-K kernels (the fold publishes) and the streaming ones (a publish launch)."""
+    d = mppi_cfg(K, horizon)
+    a, b = _group(d, [0] * P), _group(d, [0] * P)
+    b.setOption(8, 0)
+    assert all(a.member(r).exchangeKind() == 2 for r in range(P)) and all(b.member(r).exchangeKind() == 1 for r in range(P))
+    x0 = (0.05, 0.02, -0.2)
+    for g in (a, b):
+        g.setWaypoint(*WAYPOINTS[3])
+    for tick in range(3):
+        assert a.newControlsRng(x0, 31, tick) == b.newControlsRng(x0, 31, tick)
+    a.enqueueRngBatch(x0, 31, 10, 9); b.enqueueRngBatch(x0, 31, 10, 9)
+    a.synchronize(); b.synchronize()
+    assert np.array_equal(a.getControls(), b.getControls()) and a.lastControls() == b.lastControls()
+    for r in range(P):
+        assert np.array_equal(a.member(r).getControls(), a.getControls())
+    noise = np.random.default_rng(3).standard_normal((K, orc.mppi_steps(d), 2)) * np.sqrt(0.9)
+    assert a.newControls(*x0, noise) == b.newControls(*x0, noise)
+    b.setOption(8, 1)   # and back
+    assert all(b.member(r).exchangeKind() == 2 for r in range(P))
+    assert a.newControlsRng(x0, 31, 40) == b.newControlsRng(x0, 31, 40)
+    a.close(); b.close()
+
+
 def test_group_rejects_an_ensemble_that_does_not_split_evenly(gpu_pkg):
     from rtn_amd import capi
     with pytest.raises(capi.TbnavError) as ei:
