@@ -2681,6 +2681,8 @@ int tbnav_mppi_group_last_controls(tbnav_mppi_group* g, double u_out[2]) {
 int tbnav_mppi_group_synchronize(tbnav_mppi_group* g) {
   if (!g) return TBNAV_ERR_INVALID_ARG;
   for (int r = 0; r < g->n; ++r) { DeviceGuard guard(g->m[r]->device); TBNAV_HIP(hipStreamSynchronize(g->st[r])); }
+  for (const tbnav_mppi* h : g->m)  // (any member's combine that ran out of time waiting for a peer's records)
+    if (h->direct_on && h->h_dx_err && *h->h_dx_err) { tbnav::last_hip_error_slot() = "direct exchange: a member's records did not arrive in time"; return TBNAV_ERR_HIP; }
   return TBNAV_OK;
 }
 int tbnav_mppi_group_new_controls_rng(tbnav_mppi_group* g, const double x0[3], uint64_t seed, uint64_t tick, double u_out[2]) {
