@@ -209,6 +209,9 @@ def main():
     one_gpu_test = os.environ.get("TBNAV_BENCH_ONE_GPU_GLOO") == "1"
     if one_gpu_test:
         local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        # a launcher that gives every rank ONE visible device (HIP_VISIBLE_DEVICES per process): that device is ordinal 0
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
