@@ -8,9 +8,12 @@ A "step" is one MPPI control tick (controller::MPPI::newControls, mppi.cpp:72-14
 sampling (mppi.cpp:173-184), which is part of the path: the perturbations of every tick are drawn on the device inside
 the rollout kernel.  Only the 2*T warm-start controls are resident when the timed region starts.
 Workload at every N: BASELINE.json configs[1] per GPU — K=1024 rollouts, T=50 steps, shipped controller parameters — so
-N>1 is weak scaling (global K = N*1024) with ONE all-gather of the per-time-step soft-min records per tick, issued by
-libtbnav_hip.so itself (tbnav_mppi_attach_comm: shard partials -> ncclAllGather -> combine on the tick's stream; the ticks of
-the timed region are enqueued by one C call per rank, no Python and no host synchronisation between them).
+N>1 is weak scaling (global K = N*1024) with ONE exchange of the per-time-step soft-min records per tick, issued by
+libtbnav_hip.so itself (tbnav_mppi_attach_comm: shard partials -> exchange -> combine on the tick's stream; the ticks of the
+timed region are enqueued by one C call per rank, no Python and no host synchronisation between them).  Between the GPUs of one
+node the exchange is DIRECT when every rank can (tbnav_mppi_exchange_kind 2: each rank stores its records into every peer's
+buffer over xGMI, the combine polls its own); otherwise an ncclAllGather.  `exchange` says which ran, and
+`weak_tick_via_comm_all_gather` times the same tick through the all-gather beside it.
 value = rollouts/s = N*K*steps / max-over-ranks time.  Extra objects on the same JSON line:
   roofline        dominant kernel of the timed workload vs the HBM roofline (per-kernel times: HIP events on the launch stream)
   latency_floor   what two dependent launches cost by themselves (the K=1024 tick is latency-bound, not HBM-bound)
@@ -19,8 +22,9 @@ value = rollouts/s = N*K*steps / max-over-ranks time.  Extra objects on the same
   options         the same tick with resident noise; the exact-arc dynamics option
   cpu_baseline / cpu_baseline_all_cores   the oracle port (oracle/mppi_oracle.cpp) on 1 core / all host cores (OpenMP)
   rbpf            secondary headline: RBPF particle-updates/s (BASELINE configs[2]), bench_rbpf.py
-  N > 1 only:     strong_scaling_configs3 (K=65536 split N ways), rbpf_sharded (1000 particles per rank with
-                  cross-rank particle migration in the timed region)
+  N > 1 only:     weak_tick_via_comm_all_gather, strong_scaling_configs3 (K=65536 split N ways), rbpf_sharded (1000 particles
+                  per rank with cross-rank particle migration in the timed region) — under a watchdog: if one of them does not
+                  come back, the line is printed without them (`multi_gpu_legs` says why)
 Only the cpu_baseline legs touch oracle/.
 """
 from __future__ import annotations
