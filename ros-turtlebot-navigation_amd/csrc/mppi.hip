@@ -1216,6 +1216,51 @@ __device__ __forceinline__ double direct_load(const DirectSrc& d, size_t idx) {
   return __longlong_as_double((long long)((hi << 32) | (lo & 0xFFFFFFFFull)));
 }
 
+// NR whole records (7 fields = 14 consecutive words each) at once: every word is requested before any is looked at — the
+// buffer is fine-grained memory, every load a trip to the fabric, and one field after the other would be fourteen of them
+// in a row per record; only records whose words do not all carry the tick's number yet are asked for again.
+template <int NR>
+__device__ __forceinline__ void direct_load_records(const DirectSrc& d, const size_t (&idx)[NR], const bool (&have)[NR], double (&out)[NR][7]) {
+  unsigned long long w[NR][14];
+  bool done[NR];
+#pragma unroll
+  for (int q = 0; q < NR; ++q) {
+    done[q] = !have[q];
+#pragma unroll
+    for (int f = 0; f < 7; ++f) out[q][f] = 0.0;
+  }
+  const unsigned long long t0 = wall_clock64();
+  for (;;) {
+#pragma unroll
+    for (int q = 0; q < NR; ++q)
+      if (!done[q]) {
+        unsigned long long* p = const_cast<unsigned long long*>(d.w0) + 2 * idx[q];
+#pragma unroll
+        for (int k = 0; k < 14; ++k) w[q][k] = __hip_atomic_load(p + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    bool all = true;
+#pragma unroll
+    for (int q = 0; q < NR; ++q)
+      if (!done[q]) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < 14; ++k) ok = ok && (unsigned int)(w[q][k] >> 32) == d.seq;
+        if (ok) {
+          done[q] = true;
+#pragma unroll
+          for (int f = 0; f < 7; ++f) out[q][f] = __longlong_as_double((long long)((w[q][2 * f + 1] << 32) | (w[q][2 * f] & 0xFFFFFFFFull)));
+        } else all = false;
+      }
+    if (all) break;
+    if (wall_clock64() - t0 > d.budget) {
+      __hip_atomic_fetch_or(d.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_fetch_or(d.err_dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;  // (the records that never came stay zero: n == 0 marks "no record")
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
 template <int kKeep, bool DIRECT = false>
 __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, double lambda, double umax, USrc u,
                                                     const double* __restrict__ records, double* __restrict__ u_out,
@@ -1239,14 +1284,38 @@ __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, double 
   // beyond that the second pass re-reads them (L1/L2 hits).
   const bool keep = R <= kKeep * tpr;
   double rk[kKeep][7];
+  if constexpr (DIRECT) {
+    size_t idx[kKeep];
+    bool hv[kKeep];
 #pragma unroll
-  for (int q = 0; q < kKeep; ++q) {
-    const int r = l + q * tpr;
-    const bool have = valid && keep && r < R;
-    const int g = (have && G > 1) ? r / S : 0, sl = have ? r - g * S : 0;  // (one group — every single-GPU tick: no division)
-    const double* rec = records + (((size_t)g * T + (valid ? i : 0)) * S + sl) * TBNAV_MPPI_REC;
+    for (int q = 0; q < kKeep; ++q) {
+      const int r = l + q * tpr;
+      hv[q] = valid && keep && r < R && !dead;
+      const int g = (hv[q] && G > 1) ? r / S : 0, sl = hv[q] ? r - g * S : 0;
+      idx[q] = (((size_t)g * T + (valid ? i : 0)) * S + sl) * TBNAV_MPPI_REC;
+    }
+    if constexpr (kKeep <= 2) direct_load_records<kKeep>(ds, idx, hv, rk);   // (the K = 1024 tick: both records' words in flight together)
+    else {
 #pragma unroll
-    for (int f = 0; f < 7; ++f) rk[q][f] = have ? field(rec, f) : 0.0;  // n == 0 marks "no record"
+      for (int q = 0; q < kKeep; ++q) {
+        const size_t i1[1] = {idx[q]};
+        const bool h1[1] = {hv[q]};
+        double o1[1][7];
+        direct_load_records<1>(ds, i1, h1, o1);
+#pragma unroll
+        for (int f = 0; f < 7; ++f) rk[q][f] = o1[0][f];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < kKeep; ++q) {
+      const int r = l + q * tpr;
+      const bool have = valid && keep && r < R;
+      const int g = (have && G > 1) ? r / S : 0, sl = have ? r - g * S : 0;  // (one group — every single-GPU tick: no division)
+      const double* rec = records + (((size_t)g * T + (valid ? i : 0)) * S + sl) * TBNAV_MPPI_REC;
+#pragma unroll
+      for (int f = 0; f < 7; ++f) rk[q][f] = have ? rec[f] : 0.0;  // n == 0 marks "no record"
+    }
   }
   double M = __builtin_huge_val();
   MTRACE(1, 1);

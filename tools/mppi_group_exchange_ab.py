@@ -12,6 +12,9 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import __graft_entry__ as g  # noqa: E402
 
 g.load_package()
+if os.environ.get("TBNAV_DEV_LIB"):   # (A/B runs of two builds of the library in one gpurun call)
+    from rtn_amd import capi
+    capi.LIB_PATH = os.path.abspath(os.environ["TBNAV_DEV_LIB"])
 from cases import WAYPOINTS, mppi_cfg  # noqa: E402
 from rtn_amd.mppi import MPPIGroup, CartModel, LossFunc  # noqa: E402
 
