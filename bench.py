@@ -491,10 +491,19 @@ def multi_gpu_legs(world, rank, local_rank, device, one_gpu_test, stream, sync, 
         sync(); barrier(); sync()
         t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        # the two exchanges by themselves (no rollouts): 200 rounds of the 3.2 KB-per-rank record block each way
+        probe = {"all_gather_us": round(mb.exchangeProbe(200, stream), 3), "all_gather_kind": mb.exchangeKind()}
         out["weak_tick_via_comm_all_gather"] = {"workload": "the headline's tick (K=1024 per rank, T=50, device noise), 100 ticks, exchange kind 1",
                                                 "exchange_kind": mb.exchangeKind(), "ms_per_step": round(float(t.item()) / 100 * 1e3, 6),
                                                 "rollouts_per_s": round(world * 1024 * 100 / float(t.item()), 1)}
         mb.close()
+        mp = make_mppi(1024, 0.5, local_rank)
+        mp.attachComm(comm)
+        if mp.exchangeKind() == 2:
+            probe["direct_us"] = round(mp.exchangeProbe(200, stream), 3)
+        mp.close()
+        out["exchange_probe"] = dict(probe, note="microseconds per exchange of the K=1024 tick's record block (T*8 doubles per rank) alone, HIP events on rank 0's stream; "
+                                                 "direct = publish + collect kernels (the tick's combine polls instead of the collect launch)")
     # ---- MPPI strong scaling
     KL, HL = 65536, 1.0
     ml = make_mppi(KL // world, HL, local_rank)

@@ -186,6 +186,10 @@ int tbnav_mppi_attach_comm(tbnav_mppi* h, struct tbnav_comm* comm);
  * buffer with a bound) — an RCCL all-gather of a few KB costs several 9 us ticks.  Chosen at attach, collectively: every rank maps
  * every rank's buffer and runs a self-test through the tick's own kernels; if any rank cannot, all ranks use 1. */
 int tbnav_mppi_exchange_kind(const tbnav_mppi* h);
+/* `rounds` exchanges of the handle's record block ([T][S][8] doubles per rank) and nothing else — through the direct path if that is on,
+ * else the communicator's all-gather — timed with HIP events on `stream`: microseconds per exchange on the node at hand.  Collective:
+ * every rank of the (multi-process) communicator calls it with the same count.  Between ticks only (it overwrites the gather buffer). */
+int tbnav_mppi_exchange_probe(tbnav_mppi* h, int32_t rounds, void* stream, double* us_per_round);
 
 /* One process driving n_gpus devices (what controller::MPPI(..., n_gpus) holds: a ROS node is one process): the
  * ensemble of params->rollouts rollouts (a multiple of n_gpus) split evenly over devices[0..n_gpus) (NULL: 0, 1, ...;

@@ -156,6 +156,7 @@ def lib() -> C.CDLL:
         "tbnav_comm_uses_rccl": (C.c_int, [vp]),
         "tbnav_mppi_attach_comm": (C.c_int, [vp, vp]),
         "tbnav_mppi_exchange_kind": (C.c_int, [vp]),
+        "tbnav_mppi_exchange_probe": (C.c_int, [vp, i32, vp, C.POINTER(C.c_double)]),
         "tbnav_mppi_group_create": (C.c_int, [C.POINTER(MppiParams), i32, vp, C.POINTER(vp)]),
         "tbnav_mppi_group_destroy": (None, [vp]),
         "tbnav_mppi_group_size": (C.c_int, [vp]),

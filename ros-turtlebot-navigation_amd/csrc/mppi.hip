@@ -2560,6 +2560,35 @@ int sharded_tick(tbnav_mppi* h, const double x0[3], const double* d_duL, const d
 }
 }  // namespace
 
+extern "C" {
+// `rounds` exchanges of this handle's record block and nothing else, timed with HIP events on `stream` (collective: every rank of
+// the communicator calls it with the same count) — what the exchange costs by itself on the node at hand
+int tbnav_mppi_exchange_probe(tbnav_mppi* h, int32_t rounds, void* stream, double* us_per_round) {
+  if (!h || !h->comm || rounds <= 0 || !us_per_round || h->comm == nullptr) return TBNAV_ERR_INVALID_ARG;
+  if (!tbnav::comm_is_multiprocess(h->comm) && tbnav::comm_size(h->comm) != 1) return TBNAV_ERR_UNSUPPORTED;  // (a group's members are driven together)
+  DeviceGuard guard(h->device);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipEvent_t ev[2];
+  for (auto& e : ev) TBNAV_HIP(hipEventCreate(&e));
+  const size_t block = sizeof(double) * (size_t)h->T * h->S * TBNAV_MPPI_REC;
+  const void* send = reinterpret_cast<const char*>(h->d_records_all) + (size_t)tbnav::comm_rank(h->comm) * block;
+  void* recv = h->d_records_all;
+  int rc = TBNAV_OK;
+  if (hipEventRecord(ev[0], st) != hipSuccess) rc = TBNAV_ERR_HIP;
+  for (int r = 0; r < rounds && rc == TBNAV_OK; ++r) {
+    if (h->direct_on) { rc = direct_publish(h, st, false); if (rc == TBNAV_OK) rc = direct_collect(h, st, h->dx_budget); }
+    else rc = tbnav::comm_all_gather(1, &h->comm, &send, &recv, block, &st);
+  }
+  float ms = 0.f;
+  if (rc == TBNAV_OK && (hipEventRecord(ev[1], st) != hipSuccess || hipEventSynchronize(ev[1]) != hipSuccess || hipEventElapsedTime(&ms, ev[0], ev[1]) != hipSuccess)) rc = TBNAV_ERR_HIP;
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  if (rc == TBNAV_OK && h->direct_on && *h->h_dx_err) { tbnav::last_hip_error_slot() = "direct exchange: a peer's records did not arrive in time"; rc = TBNAV_ERR_HIP; }
+  *us_per_round = rc == TBNAV_OK ? (double)ms * 1e3 / rounds : 0.0;
+  return rc;
+}
+
+}  // extern "C"
+
 // One process driving several GPUs: the whole ensemble behind one object (what controller::MPPI built with n_gpus > 1 holds).
 struct tbnav_mppi_group {
   int n = 0;

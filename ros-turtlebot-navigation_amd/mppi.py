@@ -96,6 +96,12 @@ class MPPI:
         """0: no communicator; 1: the communicator's all-gather; 2: direct stores into the peers' buffers (tbnav_mppi_exchange_kind)."""
         return int(self._L.tbnav_mppi_exchange_kind(self._h))
 
+    def exchangeProbe(self, rounds: int, stream: int = 0) -> float:
+        """Microseconds per exchange of the record block alone (collective over the communicator's ranks; tbnav_mppi_exchange_probe)."""
+        us = C.c_double()
+        capi.check(self._L.tbnav_mppi_exchange_probe(self._h, rounds, stream or None, C.byref(us)), "exchange_probe")
+        return us.value
+
     def setDirectExchange(self, on: bool):
         """TBNAV_MPPI_OPT_DIRECT_EXCHANGE; before attachComm."""
         capi.check(self._L.tbnav_mppi_set_option(self._h, 8, int(on)), "set_option(direct exchange)")  # (2: fault injection, tests)
