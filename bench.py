@@ -342,19 +342,6 @@ def main():
     out_controls = m.lastControls(stream)
     assert all(np.isfinite(out_controls)), out_controls
 
-    # one synchronous tick (launch + wait + 16-byte D2H), the latency a control loop sees.  With a communicator attached the
-    # tick contains the all-gather, so EVERY rank takes part (on rank 0 alone it would wait for peers that never call)
-    n_sync = 200
-    if world > 1:
-        sync(); barrier(); sync()
-    t0 = time.perf_counter()
-    for i in range(n_sync):
-        if world == 1 or comm is not None:
-            m.newControlsRng(X0, SEED, 10_000_000 + i, stream)
-        else:
-            tick(); sync()
-    sync_ms = (time.perf_counter() - t0) / n_sync * 1e3
-
     line = None
     if rank == 0:
         ms_step = el / args.steps * 1e3
@@ -371,7 +358,7 @@ def main():
                        "state_carried": True,
                        "parallelism": f"rollout-shard x{world}" + (", 1 all-gather of soft-min records/tick" if world > 1 else "")},
             "rollout_steps_per_s": round(value * T, 1),
-            "sync_tick_ms": round(sync_ms, 6),
+            "sync_tick_ms": None,   # (measured below, under the watchdog when N > 1)
             "entry_point": ("tbnav_mppi_enqueue_rng_batch (the timed ticks enqueued by ONE call through the C boundary)" if (world == 1 or comm is not None)
                             else "tbnav_mppi_shard_* per tick from Python (rtn_amd.sharded)"),
             # what actually ran in the timed region: whole chunks of 100 ticks are replayed from a captured hipGraph, the rest (all of
@@ -390,12 +377,28 @@ def main():
                                       "kernel_ms are back-to-back launch averages and already contain one boundary each"},
         }
 
-    # ---- N > 1: two more measurements with the same processes.  They run under a watchdog: the headline above is complete, and a
-    #      leg that does not come back (an exchange that hangs on this node) must not take it along — on expiry rank 0 prints the
-    #      line without them (`multi_gpu_legs` says so) and every rank leaves.
+    # ---- N > 1: everything after the headline runs under a watchdog: the headline above is complete, and a collective that does
+    #      not come back (an exchange that hangs on this node) must not take it along — on expiry rank 0 prints the line without
+    #      what is missing (`multi_gpu_legs` says so) and every rank leaves.
+    wd = LegWatchdog(rank, line, LEGS_BUDGET_S) if world > 1 else None
+    # one synchronous tick (launch + wait + 16-byte D2H), the latency a control loop sees.  With a communicator attached the
+    # tick contains the all-gather, so EVERY rank takes part (on rank 0 alone it would wait for peers that never call)
+    n_sync = 200
+    if world > 1:
+        m.setInitialControls(0.0, 0.0)   # (rank 0's local kernel profile advanced ITS warm start: every rank starts from the same controls again)
+        sync(); barrier(); sync()
+    t0 = time.perf_counter()
+    for i in range(n_sync):
+        if world == 1 or comm is not None:
+            m.newControlsRng(X0, SEED, 10_000_000 + i, stream)
+        else:
+            tick(); sync()
+    sync_ms = (time.perf_counter() - t0) / n_sync * 1e3
+
+    if rank == 0:
+        line["sync_tick_ms"] = round(sync_ms, 6)
     if world > 1:
         extra = {}
-        wd = LegWatchdog(rank, line, LEGS_BUDGET_S)
         try:
             extra = multi_gpu_legs(world, rank, local_rank, device, one_gpu_test, stream, sync, barrier, comm)
         except Exception as e:  # noqa: BLE001 — the peers may be inside a collective this rank never reaches: leave through the watchdog
