@@ -19,7 +19,7 @@ wd = bench.LegWatchdog({rank}, line if {rank} == 0 else None, 0.3)
 
 def run(rank, body):
     code = SCRIPT.format(root=ROOT, rank=rank, body=body)
-    return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
 
 
 def test_a_leg_that_hangs_leaves_the_headline_line():
