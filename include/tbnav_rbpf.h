@@ -303,18 +303,22 @@ int tbnav_rbpf_particle_map(tbnav_rbpf* h, int32_t particle, int8_t* map);
  *                           own launch configuration.  After tbnav_rbpf_set_log_odds the set of that particle is
  *                           rebuilt in ascending cell order (its history is unknown).
  * TBNAV_RBPF_OPT_RAYCAST_ORDERED 1 = always use the beam-ordered raycast kernel (development / A-B runs).
- * TBNAV_RBPF_OPT_RAYCAST_THREADS 256 | 512 | 1024 threads per workgroup of the tile raycast (default 1024).
+ * TBNAV_RBPF_OPT_RAYCAST_THREADS 256 | 512 | 1024 threads per workgroup of the tile raycast (default 0: chosen per launch, see _RAYCAST_ADAPT).
  * TBNAV_RBPF_OPT_COUNT_CELLS     1 = the tile raycast counts the cells it updates (tbnav_rbpf_scan_counts).
  * TBNAV_RBPF_OPT_RAYCAST_FORM    0 = box counters, rbpf_raycast_box (default); 1 = rbpf_raycast_tile, the first tile kernel
  *                                (kept for A-B runs).  All forms leave bit-identical maps.
  * TBNAV_RBPF_OPT_RAYCAST_BAND_ROWS n > 0 = rbpf_raycast_box keeps at most about n rows of a scan's bounding box in LDS at a
  *                                time (0 = as many as fit): drives its band loop on small maps (tests).
+ * TBNAV_RBPF_OPT_RAYCAST_ADAPT   1 = rbpf_raycast_box's LDS array is sized by what the particles' boxes needed in the last scans (default;
+ *                                the kernel reports it through mapped memory: less LDS per workgroup = three workgroups per CU instead of
+ *                                two; a box that outgrows the guess takes a second band); 0 = by the scan's longest beam in every direction.
+ *                                TBNAV_RBPF_OPT_RAYCAST_THREADS 0 = 512 threads when three workgroups fit a CU's LDS, else 1024 (default).
  * TBNAV_RBPF_OPT_BATCH_PIPELINE  1 = tbnav_rbpf_slam_batch keeps two scans in the stream (default); 0 = n synchronous calls.
  * TBNAV_RBPF_OPT_HOST_THREADS    host threads the REFERENCE distance-field mode spreads its per-particle brushfires over (particles are
  *                                independent; the order of operations inside one particle is the reference's).  0 = the default: the
  *                                cores in the process's affinity mask, at most 32. */
 enum { TBNAV_RBPF_OPT_DF_MODE = 1, TBNAV_RBPF_OPT_RAYCAST_ORDERED = 2, TBNAV_RBPF_OPT_RAYCAST_THREADS = 3, TBNAV_RBPF_OPT_COUNT_CELLS = 4,
-       TBNAV_RBPF_OPT_RAYCAST_FORM = 5, TBNAV_RBPF_OPT_RAYCAST_BAND_ROWS = 6, TBNAV_RBPF_OPT_BATCH_PIPELINE = 7, TBNAV_RBPF_OPT_HOST_THREADS = 8 };
+       TBNAV_RBPF_OPT_RAYCAST_FORM = 5, TBNAV_RBPF_OPT_RAYCAST_BAND_ROWS = 6, TBNAV_RBPF_OPT_BATCH_PIPELINE = 7, TBNAV_RBPF_OPT_HOST_THREADS = 8, TBNAV_RBPF_OPT_RAYCAST_ADAPT = 9 };
 enum { TBNAV_RBPF_DF_FULL = 0, TBNAV_RBPF_DF_WINDOW = 1, TBNAV_RBPF_DF_QUERY = 2, TBNAV_RBPF_DF_REFERENCE = 3 };
 int tbnav_rbpf_set_option(tbnav_rbpf* h, int32_t option, int32_t value);
 /* Since the last reset, summed over particles and scans (TBNAV_RBPF_OPT_COUNT_CELLS on): cell_updates = log-odds

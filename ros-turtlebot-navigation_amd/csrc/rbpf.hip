@@ -2271,11 +2271,17 @@ constexpr int kHotSide = 7;   // the kHotSide x kHotSide cells round the robot a
 constexpr int kHotMin = 16;   // ... when they collect at least this many free adds
 constexpr int kVeryHot = 80;  // ... and from this many on they are worked out without the chain of adds (add_repeated)
 __host__ __device__ constexpr size_t box_lds_bytes(size_t cap, size_t bv) { return 4 * cap + 8 * (bv + 64) + 4 * 2 * bv + 2 * kBoxEv * bv; }
+// (512 threads: three workgroups = 24 waves per CU when the LDS array is sized by what the boxes need, see launch_raycast —
+//  6 waves per SIMD leave 80 registers a lane: the kernel needs 77 and spills nothing; 1024 threads: two workgroups = 32 waves, 64)
+#ifndef TBNAV_RC512_WAVES
+#define TBNAV_RC512_WAVES 6
+#endif
 template <int NT>
-__global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, MapT M, const double2* __restrict__ beams,
+__global__ __launch_bounds__(NT, NT == 512 ? TBNAV_RC512_WAVES : 8) void rbpf_raycast_box(ScanC c, TilePool P, MapT M, const double2* __restrict__ beams,
                                                           const double* __restrict__ pose, const double* __restrict__ sens,
                                                           int* __restrict__ trow_occ, int* __restrict__ n_occ, int* __restrict__ err,
-                                                          int tile_cap, unsigned long long* __restrict__ touched, NormArgs nz) {
+                                                          int tile_cap, unsigned long long* __restrict__ touched, NormArgs nz,
+                                                          int* __restrict__ box_need, int* __restrict__ box_need_host, int need_slot) {
   extern __shared__ __attribute__((aligned(16))) int lds_i[];
   // enqueued behind a scan whose resampling decision the host had not seen yet: if that scan resamples, this launch does
   // nothing (the host runs the copies and enqueues this scan again)
@@ -2384,6 +2390,19 @@ __global__ __launch_bounds__(NT, 8) void rbpf_raycast_box(ScanC c, TilePool P, M
   const int tx0 = minx >> kTSh, ty0 = miny >> kTSh, mty = (maxy >> kTSh) - ty0 + 1, mtn = ((maxx >> kTSh) - tx0 + 1) * mty;
   const int rows_fit = uni(floor_div_small(tile_cap, bw));          // rows of the box the LDS array holds at a time
   if (rows_fit < 1 || mtn > kMapTilesMax || bh > kBoxSideMax) { if (tid == 0) atomicOr(&err[3], 2); return; }  // cannot happen: see launch_raycast
+  // What the LDS array would have to hold for this particle's box to be ONE band: the host sizes the array of the scans to
+  // come from it (launch_raycast: less LDS per workgroup = three workgroups per CU instead of two).  Three slots take turns:
+  // this launch accumulates into need_slot; one workgroup hands the PREVIOUS launch's maximum (complete: stream order) to the
+  // host through mapped memory and clears the slot of the next launch.  Nothing waits for any of it.
+  // (one particle in sixteen reports: the particles' boxes are a cell or two apart, and a thousand atomics on one word drain at
+  //  ~12 ns each while every later load of the wave waits behind its own — 5 us on the first residents' critical path)
+  if (box_need && tid == 0 && (blockIdx.x & 15u) == 1u) {
+    atomicMax(&box_need[need_slot], bh * bw);
+    if ((int)blockIdx.x == 1) {
+      *box_need_host = box_need[(need_slot + 2) % 3];
+      box_need[(need_slot + 1) % 3] = 0;
+    }
+  }
   // the particle's table entries under the box, and the reference counts of the tiles they name (needed in phase C)
   // (the table work sits on the last threads of the LAST BUT ONE wave, which walks no ray — the last wave, which walks none
   //  either, has the robot cell's chain to work on)
@@ -3486,6 +3505,12 @@ struct tbnav_rbpf {
   // sharded filter: normalise / select over the all-gathered weights (tbnav_rbpf_resample_global_dev)
   double* d_gw = nullptr; double* d_gcs = nullptr; int* d_gparent = nullptr; double* d_gz = nullptr; size_t g_cap = 0;
   unsigned long long* d_touched = nullptr;  // [2] measurement hook: cell updates / distinct cells written (tbnav_rbpf_scan_counts)
+  // rbpf_raycast_box's LDS array sized by what the particles' boxes needed in the last scans (device feedback, see the kernel)
+  int* d_box_need = nullptr;      // [3] words of LDS array the largest box of a launch needed; the slots take turns
+  int* h_box_need = nullptr;      // mapped pinned: the last complete launch's maximum
+  int* d_box_need_host = nullptr; // device view of h_box_need
+  unsigned int rc_launches = 0;   // box-counter launches so far (which slot accumulates)
+  int raycast_adapt = 1;          // TBNAV_RBPF_OPT_RAYCAST_ADAPT: 0 = size the array for the worst case of the scan's longest beam
   bool count_touched = false;
   // stored distance field, u16 [N][G] x 2: allocated on first need (injection, materialisation, the stored-field
   // modes); the default query mode never touches it.  NULL until then.
@@ -3951,6 +3976,7 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens,
   const bool small_ok = c.Bv <= 511 && lds10 + 2048 <= 40 * 1024;
   // measured at cfg3 (N = 1000 / 4000): 1024 threads x 2 per CU 69.5 / 266 us; 512 threads x 4 per CU (10-bit form, 37 KB of
   // LDS) 81 / 355 us; 256 threads 113 / 391 us — with 32 waves resident either way, fewer and larger workgroups win
+  const bool nt_auto = nt == 0;
   if (nt == 0) nt = 1024;
   // rbpf_raycast_box: one u32 per cell of the box, the box padded to whole groups of 8 cells along y
   long cap_win = 0;
@@ -3966,20 +3992,33 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens,
     if (cap_win > cap_fit) cap_win = std::max(cap_fit, (side + 9) & ~7L);
     // (test hook: at most about this many rows of the box per band, to drive the band loop on small maps)
     if (h->raycast_band_rows > 0) cap_win = std::min(cap_win, (h->raycast_band_rows * ((side + 2) & ~1L) + 7) & ~7L);
+    // ... and no more than the particles' boxes needed lately (+ 1/8 + 512 words for what a scan's motion changes): the bound
+    // above is the scan's longest beam in every direction from every pose, a room's box is a fraction of that — the array is
+    // what keeps a CU at two workgroups.  A box that outgrows the guess costs its particle a second band, not correctness.
+    const int need = (h->raycast_adapt && h->h_box_need) ? *reinterpret_cast<volatile int*>(h->h_box_need) : 0;
+    if (need > 0) {
+      const long want = ((long)need + need / 8 + 512 + 7) & ~7L;
+      cap_win = std::min(cap_win, std::max(want, (side + 9) & ~7L));
+    }
   }
   const size_t lds_win = box_lds_bytes((size_t)cap_win, (size_t)bvn);
+  // workgroup size: 512 threads when THREE workgroups fit a CU's LDS (24 waves, 80 registers a lane), else 1024 (two, 32 waves).
+  // Measured at cfg3, N = 1000 / 4000 (56 KB of LDS saved by the adaptive array): 1024 x 2: 55.8 / 191 us; 512 x 2: 54.4 / 199;
+  // 512 x 3: 49.1 / 163
+  if (nt_auto && cap_win > 0 && 3 * (lds_win + 1536) <= (size_t)kMaxLds) nt = 512;
   if (cap_win > 0 && !h->ref_field && c.Bv < 32768 - kWave && h->raycast_form == 0 && nt >= 512 && lds_win <= (size_t)kMaxLds - 4096) {
     // default: box counters (rbpf_raycast_box)
     unsigned long long* touched = h->count_touched ? h->d_touched : nullptr;
     const NormArgs na = nz ? *nz : NormArgs{0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, nullptr};
     const int blocks = count + (nz ? 1 : 0);
     const size_t lds_launch = nz ? std::max(lds_win, sizeof(double) * 2 * kNormChunk) : lds_win;  // (workgroup 0's two arrays)
+    const int need_slot = (int)(h->rc_launches++ % 3u);
     if (nt == 512)
       hipLaunchKernelGGL((rbpf_raycast_box<512>), dim3(blocks), dim3(512), lds_launch, st, c, h->pool, M, beams_dev, sp.pose, sens,
-                         h->d_trow[h->cur], h->d_nocc[h->cur], err, (int)cap_win, touched, na);
+                         h->d_trow[h->cur], h->d_nocc[h->cur], err, (int)cap_win, touched, na, h->d_box_need, h->d_box_need_host, need_slot);
     else
       hipLaunchKernelGGL((rbpf_raycast_box<1024>), dim3(blocks), dim3(1024), lds_launch, st, c, h->pool, M, beams_dev, sp.pose, sens,
-                         h->d_trow[h->cur], h->d_nocc[h->cur], err, (int)cap_win, touched, na);
+                         h->d_trow[h->cur], h->d_nocc[h->cur], err, (int)cap_win, touched, na, h->d_box_need, h->d_box_need_host, need_slot);
     TBNAV_HIP(hipGetLastError());
     return TBNAV_OK;
   }
@@ -4361,6 +4400,7 @@ int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf*
   A((void**)&h->d_sens, sizeof(double) * 4 * N);
   A((void**)&h->d_tile_scratch, sizeof(unsigned int) * h->TT);
   A((void**)&h->d_touched, sizeof(unsigned long long) * 2);
+  A((void**)&h->d_box_need, sizeof(int) * 3);
   A((void**)&h->d_parent, sizeof(int) * 2 * N);
   A((void**)&h->d_best, sizeof(int));
   A((void**)&h->d_best_pose, sizeof(double) * 3);
@@ -4435,6 +4475,9 @@ int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf*
       e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemset(h->d_touched, 0, sizeof(unsigned long long) * 2);
+    if (e == hipSuccess) e = hipMemset(h->d_box_need, 0, sizeof(int) * 3);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_box_need, sizeof(int), hipHostMallocMapped);
+    if (e == hipSuccess) { *h->h_box_need = 0; e = hipHostGetDevicePointer((void**)&h->d_box_need_host, h->h_box_need, 0); }
     if (e == hipSuccess) e = hipMemset(h->d_nocc[0], 0, sizeof(int) * N);
     if (e == hipSuccess) e = hipMemset(h->d_skip, 0, sizeof(int) * N);
     // empty maps: the field "everything unreached" is what any lookup computes, no stored field needed (state 0)
@@ -4645,7 +4688,7 @@ void tbnav_rbpf_destroy(tbnav_rbpf* h) {
   for (int b = 0; b < 2; ++b) { (void)hipFree(h->d_state[b]); (void)hipFree(h->d_table[b]); (void)hipFree(h->d_code[b]); (void)hipFree(h->d_nocc[b]); (void)hipFree(h->d_trow[b]); }
   (void)hipFree(h->d_bm_dense); (void)hipFree(h->d_rc_dense);
   (void)hipFree(h->pool.lo); (void)hipFree(h->pool.bm); (void)hipFree(h->pool.ref); (void)hipFree(h->pool.ring); (void)hipFree(h->pool.ctr);
-  (void)hipFree(h->d_sens); (void)hipFree(h->d_shed); (void)hipFree(h->d_dense); (void)hipFree(h->d_cs); (void)hipFree(h->d_touched); (void)hipFree(h->d_fstate_alt);
+  (void)hipFree(h->d_sens); (void)hipFree(h->d_shed); (void)hipFree(h->d_dense); (void)hipFree(h->d_cs); (void)hipFree(h->d_touched); (void)hipFree(h->d_box_need); if (h->h_box_need) (void)hipHostFree(h->h_box_need); (void)hipFree(h->d_fstate_alt);
   (void)hipFree(h->d_log_ev); (void)hipFree(h->d_log_cnt); (void)hipFree(h->d_tile_scratch); (void)hipFree(h->d_log_pack); (void)hipFree(h->d_log_off); (void)hipFree(h->d_code_src);
   (void)hipFree(h->d_gw); (void)hipFree(h->d_gcs); (void)hipFree(h->d_gparent); (void)hipFree(h->d_gz);
   (void)hipFree(h->d_gw_raw); (void)hipFree(h->d_sendbuf); (void)hipFree(h->d_recvbuf); (void)hipFree(h->d_sizes); (void)hipFree(h->d_status);
@@ -5825,6 +5868,10 @@ int tbnav_rbpf_set_option(tbnav_rbpf* h, int32_t option, int32_t value) {
     case TBNAV_RBPF_OPT_RAYCAST_BAND_ROWS:
       if (value < 0) return TBNAV_ERR_INVALID_ARG;
       h->raycast_band_rows = value;
+      return TBNAV_OK;
+    case TBNAV_RBPF_OPT_RAYCAST_ADAPT:
+      if (value != 0 && value != 1) return TBNAV_ERR_INVALID_ARG;
+      h->raycast_adapt = value;
       return TBNAV_OK;
     case TBNAV_RBPF_OPT_BATCH_PIPELINE:
       if (value != 0 && value != 1) return TBNAV_ERR_INVALID_ARG;

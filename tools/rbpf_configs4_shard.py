@@ -17,6 +17,9 @@ pf.setSeed(5); pf.setTiming(True)
 if os.environ.get("RAYCAST_THREADS"):   # A-B runs: RAYCAST_THREADS=512, RAYCAST_FORM=1, RAYCAST_BAND_ROWS=n
     from rtn_amd import capi
     pf.setOption(capi.RBPF_OPT_RAYCAST_THREADS, int(os.environ["RAYCAST_THREADS"]))
+if os.environ.get("RAYCAST_ADAPT"):     # RAYCAST_ADAPT=0: the LDS array sized for the scan's longest beam (round 3 before its last change)
+    from rtn_amd import capi
+    pf.setOption(capi.RBPF_OPT_RAYCAST_ADAPT, int(os.environ["RAYCAST_ADAPT"]))
 if os.environ.get("RAYCAST_FORM"):
     from rtn_amd import capi
     pf.setOption(capi.RBPF_OPT_RAYCAST_FORM, int(os.environ["RAYCAST_FORM"]))
