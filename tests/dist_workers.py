@@ -382,3 +382,27 @@ def mppi_direct_fault_worker(rank, world, K_local, horizon):
     out = [np.array(m.newControlsRng((0.0, 0.0, 0.0), 5, i)) for i in range(3)]
     m.close(); comm.close()
     return {"msg": msg, "waited": waited, "kind": kind, "out": out}
+
+
+def mppi_soak_worker(rank, world, K_local, horizon, n_ticks, direct):
+    """Many production ticks in batches through the attached handle (sequence numbers, buffer parity, the dead mark never raised);
+    returns the final controls."""
+    import torch
+    comm = _ipc_comm()
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    from cases import WAYPOINTS, make_mppi, mppi_cfg
+    m = make_mppi(pkg, mppi_cfg(K_local, horizon))
+    m.setWaypoint(*WAYPOINTS[1])
+    m.setDirectExchange(direct)
+    m.attachComm(comm)
+    st = torch.cuda.Stream()
+    done = 0
+    while done < n_ticks:
+        n = min(5000, n_ticks - done)
+        m.enqueueRngBatch((0.0, 0.0, 0.0), 9, done, n, st.cuda_stream)
+        m.lastControls(st.cuda_stream)   # (raises if an exchange ran out of time)
+        done += n
+    out = {"u": m.getControls().copy(), "kind": m.exchangeKind()}
+    m.close(); comm.close()
+    return out
