@@ -463,12 +463,19 @@ def main():
             line["rbpf"] = bench_rbpf.run(device, args, with_cpu=not args.no_cpu_baseline)
         print(json.dumps(line), flush=True)
     if world > 1:
+        # (the line is out: a teardown that does not come back — a peer already gone, a communicator that waits — must not keep the
+        #  job alive: after a minute every rank leaves)
+        import threading
+        bye = threading.Timer(60.0, lambda: os._exit(0))
+        bye.daemon = True
+        bye.start()
         # handles before the communicator they exchange through, the communicator before the job's own process group
         m.close()
         if comm is not None:
             comm.close()
         dist.barrier()
         dist.destroy_process_group()
+        bye.cancel()
 
 
 def multi_gpu_legs(world, rank, local_rank, device, one_gpu_test, stream, sync, barrier, comm=None):
