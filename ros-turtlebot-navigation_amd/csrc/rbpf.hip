@@ -2551,7 +2551,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? TBNAV_RC512_WAVES : 8) void rbpf_ra
     //    private).  Slots that overflowed are listed on the way.
     const int np = band_cells >> 1;
     const uint2* tile2 = reinterpret_cast<const uint2*>(tile);
-    constexpr int kSl = 4;
+    constexpr int kSl = NT == 512 ? 6 : 4;  // pairs a thread holds across the passes (512 threads: 6 fill the 80 registers exactly — 48.6 vs 50.1 us per 1000 particles; 8 spill)
     double2 v[kSl];
     auto pairs = [&](int first, auto&& fn) {  // fn(i, the pair's two tile words, cx, cy of its first cell), i < kSl
       const int pi0 = first + tid;
