@@ -25,6 +25,7 @@
 #include <queue>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <unordered_set>
 #include <vector>
 
@@ -146,7 +147,8 @@ struct DiffDrive {
 };
 
 // ---- error codes (what the reference throws) -----------------------------------------------------
-enum Err { OK = 0, OUT_OF_WORLD = 4, ETA_ZERO = 5, PDF_VARIANCE = 6, BRESENHAM = 7 };  // = tbnav_status
+enum Err { OK = 0, OUT_OF_WORLD = 4, ETA_ZERO = 5, PDF_VARIANCE = 6, BRESENHAM = 7,  // = tbnav_status
+           OUT_OF_WINDOW = 100 };  // oracle only: a write outside a windowed CellStore (below)
 struct Thrown { int code; };
 
 // grid_mapper.cpp:18-28
@@ -176,17 +178,62 @@ struct CompareDistance {  // grid_mapper.hpp:105-111
   bool operator()(const Cell& a, const Cell& b) { return a.occ_dist > b.occ_dist; }
 };
 
+// Storage of the reference's dense `std::vector<Cell> map_` (grid_mapper.hpp:173): dense by default — then this IS that
+// vector.  A 2000 x 2000 map is 192 MB per particle, so a test with thousands of particles at BASELINE configs[4]'s grid
+// limits the STORAGE to a window of rows / columns [i0, i1) x [j0, j1): same row-major indices, same arithmetic
+// everywhere else; a cell outside the window reads as the untouched prototype cell and WRITING one throws
+// OUT_OF_WINDOW (a test whose scans leave its window fails loudly instead of comparing against nothing).
+class CellStore {
+ public:
+  CellStore(int xsize, int ysize, const Cell& proto, const int* window)
+      : xsize_(xsize), n_((size_t)xsize * ysize), proto_(proto) {
+    if (window) { i0_ = window[0]; i1_ = window[1]; j0_ = window[2]; j1_ = window[3]; windowed_ = true; }
+    else { i0_ = 0; i1_ = xsize; j0_ = 0; j1_ = ysize; }
+    wj_ = j1_ - j0_;
+    cells_.assign((size_t)(i1_ - i0_) * wj_, proto);
+  }
+  size_t size() const { return n_; }
+  bool windowed() const { return windowed_; }
+  Cell& at(size_t idx) {
+    if (idx >= n_) throw std::out_of_range("map_");
+    const long s = slot(idx);
+    if (s < 0) throw_out_of_window();
+    return cells_[(size_t)s];
+  }
+  const Cell& at(size_t idx) const {
+    if (idx >= n_) throw std::out_of_range("map_");
+    const long s = slot(idx);
+    return s < 0 ? proto_ : cells_[(size_t)s];
+  }
+  Cell& operator[](size_t idx) { return at(idx); }
+  const Cell& operator[](size_t idx) const { return at(idx); }
+
+ private:
+  long slot(size_t idx) const {
+    if (!windowed_) return (long)idx;
+    const int i = (int)(idx / xsize_), j = (int)(idx % xsize_);
+    if (i < i0_ || i >= i1_ || j < j0_ || j >= j1_) return -1;
+    return (long)(i - i0_) * wj_ + (j - j0_);
+  }
+  [[noreturn]] static void throw_out_of_window();
+  int xsize_; size_t n_; Cell proto_;
+  int i0_, i1_, j0_, j1_, wj_; bool windowed_ = false;
+  std::vector<Cell> cells_;
+};
+inline void CellStore::throw_out_of_window() { throw Thrown{OUT_OF_WINDOW}; }
+
 // bmapping::GridMapper (+ its LaserScanner base), grid_mapper.cpp / sensor_model.cpp
 class Grid {
  public:
-  Grid(double resolution, double xmin, double xmax, double ymin, double ymax, const Laser& L, const T2& Trs)
+  Grid(double resolution, double xmin, double xmax, double ymin, double ymax, const Laser& L, const T2& Trs,
+       const int* window = nullptr)
       : laser_(L), Trs_(Trs), prior_(0.5), prob_occ_(0.90), prob_free_(0.35),
         log_odds_prior_(prob_to_log_odds(prior_)), log_odds_occ_(prob_to_log_odds(prob_occ_)),
         log_odds_free_(prob_to_log_odds(prob_free_)), resolution_(resolution), max_occ_dist_(10.0),
         cell_radius_(map_size(0.0, max_occ_dist_, resolution_)), xmin_(xmin), xmax_(xmax), ymin_(ymin),
         ymax_(ymax), xsize_(map_size(xmin_, xmax_, resolution_)), ysize_(map_size(ymin_, ymax_, resolution_)),
         distances_((size_t)cell_radius_, std::vector<double>((size_t)cell_radius_)),
-        map_((size_t)xsize_ * ysize_, Cell{log_odds_prior_, prior_, max_occ_dist_, -1}) {
+        map_(xsize_, ysize_, Cell{log_odds_prior_, prior_, max_occ_dist_, -1}, window) {
     for (unsigned int i = 0; i < distances_.size(); i++)        // preComposeDistanceField, :257-269
       for (unsigned int j = 0; j < distances_.size(); j++) distances_[i][j] = std::sqrt(i * i + j * j);
   }
@@ -221,7 +268,7 @@ class Grid {
     for (size_t b = 0; b + 1 < pts.size(); b += 2) {
       double pz = 0.0;
       const unsigned int idx = world2rowmajor(pts[b], pts[b + 1]);
-      const double z = map_.at(idx).occ_dist;
+      const double z = exact_field_ ? exact_dist(idx) : map_.at(idx).occ_dist;
       pz += laser_.z_hit * pdf_normal(z, var_hit);
       pz += laser_.z_rand / laser_.z_max;
       p *= pz;
@@ -244,7 +291,32 @@ class Grid {
       map_.at(idx).log_odds += log_odds_occ_ - log_odds_prior_;
       update_cell_state(map_.at(idx), idx);
     }
-    if (run_esdf) esdf();
+    exact_memo_.clear();
+    if (run_esdf and !exact_field_) esdf();
+  }
+
+  // The `exact_field` switch (NOT in the reference).  The reference's field is its brushfire (esdf() below), which is
+  // not a function of the occupied set and differs from the exact Euclidean distance on a few per cent of the cells
+  // (distance field).  The device's default ("query") mode looks up the EXACT distance to the nearest occupied
+  // cell instead.  With the switch on, likelihood() reads that exact distance — same LUT value
+  // distances_[di][dj] * resolution_ (grid_mapper.cpp:263,318) at the nearest occupied cell, same radius cut-off
+  // dist > cell_radius_ (:310-313), max_occ_dist_ where nothing is in reach (the constructor's value, :51-60) — by brute
+  // force over occ_cells_, integers only, memoised per cell until the next integrate_scan; esdf() is not run and the
+  // cells' occ_dist members are left alone.  Everything else in the filter is the restated reference.
+  double exact_dist(unsigned int idx) const {
+    const auto hit = exact_memo_.find((int)idx);
+    if (hit != exact_memo_.end()) return hit->second;
+    const long i = idx / xsize_, j = idx % xsize_;
+    long best = -1;
+    for (int key : occ_cells_) {
+      const long di = i - key / xsize_, dj = j - key % xsize_;
+      const long d2 = di * di + dj * dj;
+      if (best < 0 || d2 < best) best = d2;
+    }
+    const long r = (long)cell_radius_;
+    const double z = (best >= 0 && best <= r * r) ? std::sqrt((double)best) * resolution_ : max_occ_dist_;
+    exact_memo_.emplace((int)idx, z);
+    return z;
   }
 
   // grid_mapper.cpp:185-226
@@ -388,7 +460,11 @@ class Grid {
   int xsize_, ysize_;
   std::unordered_set<int> occ_cells_;
   std::vector<std::vector<double>> distances_;
-  std::vector<Cell> map_;
+  CellStore map_;
+  // NOT the reference (see exact_dist below): the field the DEVICE's default mode looks up, for holding that mode against
+  // this filter at full size.  Off by default; the reference's brushfire is esdf().
+  bool exact_field_ = false;
+  mutable std::unordered_map<int, double> exact_memo_;
 
  private:
   void enqueue(int i, int j, int src_i, int src_j,
@@ -464,9 +540,12 @@ struct Stats { double sum_w, sq_sum; int32_t neff, resampled, err, normals_used;
 
 class PF {
  public:
-  explicit PF(const PfParams& p) : P(p) {
+  // exact_field / window: test-only switches, see Grid::exact_dist and CellStore (a windowed store needs exact_field:
+  // the brushfire writes every reachable cell of the map)
+  explicit PF(const PfParams& p, bool exact_field = false, const int* window = nullptr) : P(p) {
     Laser L{p.beam_min, p.beam_max, p.beam_delta, p.range_min, p.range_max, p.z_hit, p.z_short, p.z_max, p.z_rand, p.sigma_hit};
-    Grid proto(p.resolution, p.xmin, p.xmax, p.ymin, p.ymax, L, make_T(p.Trs[1], p.Trs[2], p.Trs[0]));
+    Grid proto(p.resolution, p.xmin, p.xmax, p.ymin, p.ymax, L, make_T(p.Trs[1], p.Trs[2], p.Trs[0]), window);
+    proto.exact_field_ = exact_field;
     const double w = 1.0 / p.num_particles;  // initParticleSet, :125-138
     set.reserve(p.num_particles);
     for (int i = 0; i < p.num_particles; i++) {
@@ -790,7 +869,7 @@ double orc_gm_likelihood(void* g, const float* scan, int n, const double pose[3]
   try { *err = 0; return static_cast<orc::Grid*>(g)->likelihood(scan, n, T_of(pose)); } catch (const orc::Thrown& t) { *err = t.code; return 0.0; }
 }
 void orc_gm_dump(void* g, double* log_odds, double* prob, double* occ_dist, int32_t* state) {
-  auto* gm = static_cast<orc::Grid*>(g);
+  const auto* gm = static_cast<const orc::Grid*>(g);  // (const: cells outside a windowed store read as the prototype)
   for (size_t c = 0; c < gm->map_.size(); ++c) {
     if (log_odds) log_odds[c] = gm->map_[c].log_odds;
     if (prob) prob[c] = gm->map_[c].prob;
@@ -800,6 +879,7 @@ void orc_gm_dump(void* g, double* log_odds, double* prob, double* occ_dist, int3
 }
 void orc_gm_set_occ_dist(void* g, const double* occ_dist) {
   auto* gm = static_cast<orc::Grid*>(g);
+  if (gm->map_.windowed()) return;  // (an injected field has no meaning for a windowed, exact-field grid)
   for (size_t c = 0; c < gm->map_.size(); ++c) gm->map_[c].occ_dist = occ_dist[c];
 }
 int orc_gm_occ_cells(void* g, int32_t* out, int cap) {
@@ -841,6 +921,14 @@ void orc_exact_edt_codes(int xsize, int ysize, const uint8_t* occ, int radius, c
 
 // ---- particle filter ------------------------------------------------------------------------------
 void* orc_pf_create(const orc::PfParams* p) { return new orc::PF(*p); }
+// exact_field != 0: likelihoods read the exact nearest-occupied-cell distance (Grid::exact_dist) instead of the reference's
+// brushfire — the checker of the device's default mode, NOT the reference's behaviour.  window (nullable, needs exact_field):
+// {i0, i1, j0, j1}, the rows / columns of the map that get storage.
+void* orc_pf_create_ex(const orc::PfParams* p, int exact_field, const int* window) {
+  if (window && !exact_field) return nullptr;
+  return new orc::PF(*p, exact_field != 0, window);
+}
+void orc_gm_set_exact_field(void* g, int on) { auto* gm = static_cast<orc::Grid*>(g); gm->exact_field_ = on != 0; gm->exact_memo_.clear(); }
 void orc_pf_destroy(void* pf) { delete static_cast<orc::PF*>(pf); }
 int orc_pf_slam(void* pf, const float* scan, int n, const double u[3], const double cur_odom[3], const double prev_odom[3],
                 int icp_ok, const double T_icp[3], const double* normals, orc::Trace* trace, orc::Stats* stats) {

@@ -382,14 +382,24 @@ def pf_params(N=40, k=50, map_min=-2.0, map_max=2.0, beam_delta_deg=1.0, pose0=(
 
 
 class PfAPI:
-    def __init__(self, params: PfParams):
+    def __init__(self, params: PfParams, exact_field=False, window=None):
+        """exact_field: the likelihoods read the EXACT distance to the nearest occupied cell (what the device's default
+        mode looks up) instead of the reference's brushfire — the checker of that mode, not the reference's behaviour.
+        window = (i0, i1, j0, j1): only these rows / columns of every particle's map get storage (needs exact_field)."""
         self.L = lib()
         self.L.orc_pf_create.restype = C.c_void_p
+        self.L.orc_pf_create_ex.restype = C.c_void_p
         self.L.orc_pf_grid.restype = C.c_void_p
         self.L.orc_pf_grid.argtypes = [C.c_void_p, C.c_int]
         self.p = params
         self.N, self.k = params.num_particles, params.k
-        self.h = C.c_void_p(self.L.orc_pf_create(C.byref(params)))
+        if exact_field or window is not None:
+            win = None if window is None else np.array(window, dtype=np.int32)
+            self.h = C.c_void_p(self.L.orc_pf_create_ex(C.byref(params), C.c_int(1 if exact_field else 0),
+                                                        None if win is None else _p(win)))
+            assert self.h, "a windowed oracle filter needs exact_field"
+        else:
+            self.h = C.c_void_p(self.L.orc_pf_create(C.byref(params)))
 
     def close(self):
         if self.h:

@@ -18,19 +18,28 @@ import rbpf_cases as rc
 pytestmark = pytest.mark.gpu
 
 
-def _dev(gpu_pkg, df_mode=None, **kw):
+def _dev(gpu_pkg, df_mode=None, pool_bytes=0, **kw):
     from rtn_amd.rbpf import ParticleFilter, default_params
-    return ParticleFilter(default_params(**kw), df_mode=df_mode)
+    return ParticleFilter(default_params(**kw), pool_bytes=pool_bytes, df_mode=df_mode)
 
 
-def _free_run(gpu_pkg, df_mode, N, k, map_half, walls, n_scans, inc, seed, force_resample_at=None, start=(0.0, 0.0, 0.0), **extra):
-    pf_o = orc.PfAPI(orc.pf_params(N=N, k=k, map_min=-map_half, map_max=map_half, pose0=start, **extra))
-    pf_d = _dev(gpu_pkg, df_mode=df_mode, N=N, k=k, map_min=-map_half, map_max=map_half, pose0=start, **extra)
+def _rel(a, b):
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)))
+
+
+def _free_run(gpu_pkg, df_mode, N, k, map_half, walls, n_scans, inc, seed, force_resample_at=None, start=(0.0, 0.0, 0.0),
+              oracle_exact_field=False, oracle_window=None, pool_bytes=0, n_beams=360, **extra):
+    """Oracle filter and device filter side by side, same scans, same draws, nothing injected.  oracle_exact_field: the
+    oracle's likelihoods read the exact nearest-obstacle distance (the checker of the device's default mode) instead of
+    the reference's brushfire."""
+    pf_o = orc.PfAPI(orc.pf_params(N=N, k=k, map_min=-map_half, map_max=map_half, pose0=start, **extra),
+                     exact_field=oracle_exact_field, window=oracle_window)
+    pf_d = _dev(gpu_pkg, df_mode=df_mode, pool_bytes=pool_bytes, N=N, k=k, map_min=-map_half, map_max=map_half, pose0=start, **extra)
     steps, poses = rc.trajectory(n_scans, inc=inc, start=start)
     rng = np.random.default_rng(seed)
     rows = []
     for s, (prev, cur, t_icp, u) in enumerate(steps):
-        scan = orc.room_scan(poses[s], walls=walls, rng=rng)
+        scan = orc.room_scan(poses[s], n_beams=n_beams, beam_delta_deg=extra.get("beam_delta_deg", 1.0), walls=walls, rng=rng)
         normals = orc.normal_stream(900 + s, pf_o.normals_per_scan(True), 0.0, 1.0)
         if force_resample_at == s:
             w = np.full(N, 0.2 / N); w[3] += 0.5; w[N // 2] += 0.3; w /= w.sum()
@@ -49,8 +58,19 @@ def _free_run(gpu_pkg, df_mode, N, k, map_half, walls, n_scans, inc, seed, force
             neff=(st.neff, tr_o["neff"]), resampled=(st.resampled, tr_o["resampled"]),
             parents_equal=(not st.resampled) or np.array_equal(tr_d["resample_idx"], tr_o["resample_idx"]),
             best=(idx_d, pf_o.best()), best_xy=float(np.hypot(pose_d[1] - pose_o[1], pose_d[2] - pose_o[2])),
-            best_th=float(abs(pose_d[0] - pose_o[0]))))
+            best_th=float(abs(pose_d[0] - pose_o[0])),
+            sampled=float(np.max(np.abs(tr_d["sampled"] - tr_o["sampled"]))), p_pose=_rel(tr_d["p_pose"], tr_o["p_pose"]),
+            mu=float(np.max(np.abs(tr_d["mu"] - tr_o["mu"]))), new_pose=float(np.max(np.abs(tr_d["new_pose"] - tr_o["new_pose"]))),
+            w_raw=_rel(tr_d["weight_raw"], tr_o["weight_raw"])))
     return pf_o, pf_d, rows
+
+
+def _assert_every_stage(rows, tol=1e-9):
+    for s, r in enumerate(rows):
+        assert r["sampled"] <= 1e-10 and r["mu"] <= 1e-10 and r["new_pose"] <= 1e-10, (s, r)
+        assert max(r["p_scan"], r["p_pose"], r["eta"], r["w_raw"], r["w"]) <= tol, (s, r)                  # north star: 1e-5
+        assert r["neff"][0] == r["neff"][1] and r["resampled"][0] == r["resampled"][1] and r["parents_equal"], (s, r)
+        assert r["best"][0] == r["best"][1] and r["best_xy"] <= 1e-9 and r["best_th"] <= 1e-9, (s, r)
 
 
 def test_reference_mode_shipped_config_is_the_reference_end_to_end(gpu_pkg):
@@ -204,3 +224,56 @@ def test_cfg3_as_written_1000_particles_400x400_reference_mode_against_the_oracl
         assert np.array_equal(pf_d.logOdds(p), g["log_odds"]), p
         assert np.array_equal(pf_d.occDist(p), g["occ_dist"]), p
     pf_d.close()
+
+
+def test_cfg3_as_written_1000_particles_400x400_default_query_mode_against_the_exact_field_oracle(gpu_pkg):
+    """The mode bench_rbpf.py's headline number is measured in, held against an oracle AT FULL SIZE (round-3 review, weak 3):
+    BASELINE configs[2] as written — 1000 particles, k = 50, 360 beams, 400 x 400 @ 0.05 m, three scans with a forced
+    resample at the second — the product in its DEFAULT distance mode (exact nearest-obstacle query, nothing stored, nothing
+    injected) against the restated filter with its `exact_field` switch on (oracle/rbpf_oracle.cpp Grid::exact_dist: the
+    same filter, likelihoods over the exact distance instead of the brushfire; tests/test_oracle_exact_field.py pins the
+    switch).  Sampled poses / mu / new poses 1e-10, p_scan, p_pose, eta, raw and normalised weights <= 1e-9, Neff /
+    resampling decision / parent list / best particle identical, six spot particles' log-odds bit for bit.
+    The mirror image of ..._reference_mode_against_the_oracle above: that one says the reference-field mode IS the reference
+    (brushfire and all); this one says the fast mode is exactly "the reference's filter over the exact field"."""
+    import time
+    N, k = 1000, 50
+    orc.lib().orc_set_threads(8)
+    try:
+        t0 = time.perf_counter()
+        pf_o, pf_d, rows = _free_run(gpu_pkg, None, N=N, k=k, map_half=10.0, walls=rc.ROOM_SURVEY, n_scans=3,
+                                     inc=(0.07, 0.10, 0.05), seed=11, force_resample_at=1, oracle_exact_field=True)
+        print(f"\n[cfg3 query mode] 3 scans of {N} particles, exact-field oracle + device: {time.perf_counter() - t0:.1f} s")
+    finally:
+        orc.lib().orc_set_threads(1)
+    assert rows[1]["resampled"] == (1, 1)
+    _assert_every_stage(rows)
+    po, pvo, wo = pf_o.particles()
+    pd, pvd, wd = pf_d.particles()
+    assert np.allclose(pd, po, rtol=1e-10, atol=1e-15) and np.allclose(pvd, pvo, rtol=1e-10, atol=1e-15)
+    for p in (0, 3, 499, 500, 998, 999):
+        assert np.array_equal(pf_d.logOdds(p), pf_o.grid(p).dump()["log_odds"]), p
+    pf_d.close()
+    pf_o.close()
+
+
+def test_configs4_shard_shape_2000_particles_2000x2000_1080_beams_query_mode_against_the_exact_field_oracle(gpu_pkg):
+    """The same comparison at the SHAPE of BASELINE configs[4]'s per-GPU shard: 2000 x 2000 cells @ 0.05 m, 1080-beam scans,
+    k = 50, N = 2000 particles (the shard is 12 500; the oracle's particles are dense reference maps — 192 MB each at this
+    grid — so its cell store is limited to the 240 x 240-cell window round the room, tests/test_oracle_exact_field.py: a
+    write outside it fails the run).  Three scans, forced resample at the second; every stage as above."""
+    N, k, bd = 2000, 50, 1.0 / 3.0
+    orc.lib().orc_set_threads(8)
+    try:
+        pf_o, pf_d, rows = _free_run(gpu_pkg, None, N=N, k=k, map_half=50.0, walls=rc.ROOM_SURVEY, n_scans=3,
+                                     inc=(0.05, 0.04, 0.03), seed=8, force_resample_at=1, oracle_exact_field=True,
+                                     oracle_window=(880, 1120, 880, 1120), pool_bytes=8 << 30, n_beams=1080, beam_delta_deg=bd)
+    finally:
+        orc.lib().orc_set_threads(1)
+    assert (pf_d.xsize, pf_d.ysize) == (2000, 2000)
+    assert rows[1]["resampled"] == (1, 1)
+    _assert_every_stage(rows)
+    for p in (0, 1, 999, 1000, 1998, 1999):
+        assert np.array_equal(pf_d.logOdds(p), pf_o.grid(p).dump()["log_odds"]), p
+    pf_d.close()
+    pf_o.close()
