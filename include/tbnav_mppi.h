@@ -92,7 +92,7 @@ enum { TBNAV_MPPI_OPT_KERNEL = 1, TBNAV_MPPI_OPT_TRIG = 2, TBNAV_MPPI_OPT_NO_LDS
        TBNAV_MPPI_OPT_PREFIX_FORM = 7,
        TBNAV_MPPI_OPT_DIRECT_EXCHANGE = 8 /* 0: a handle attached to a multi-process communicator always exchanges through the communicator's
                                              all-gather (default 1: directly into the peers' buffers when every rank can; takes effect at the next attach; 2: as 1 with a fault injected for the tests of the
-                                             bound — after the self-test this rank's records never reach its peers, and the bound is 0.3 s instead of 20 s) */ };
+                                             bound — after the self-test this rank's records never reach its peers, and the bound is 0.3 s instead of 2 s) */ };
 int tbnav_mppi_set_option(tbnav_mppi* h, int32_t option, int32_t value);
 
 /* Rollout dynamics.  TBNAV_MPPI_DYN_RK4 (default) is the reference MPPI: CartModel + RK4 (controller/include/
@@ -265,6 +265,18 @@ int64_t tbnav_mppi_graph_replayed_ticks(const tbnav_mppi* h);
  * kernel).  The controller state advances as if `reps` ticks had run on the same inputs. */
 int tbnav_mppi_profile_kernels(tbnav_mppi* h, const double x0[3], const double* d_duL, const double* d_duR, void* stream,
                                int32_t reps, float ms[TBNAV_MPPI_NKERNELS]);
+
+/* The same for the PRODUCTION tick (tbnav_mppi_enqueue_rng): where that tick draws its perturbations inside the fused kernel,
+ * the kernel launched here is that very instantiation (in-kernel Philox, nothing read from the noise buffers), with the
+ * perturbations of (seed, tick + r) in repetition r.  Other configurations: sample once into the handle's buffers, then
+ * tbnav_mppi_profile_kernels on them (what their production tick runs). */
+int tbnav_mppi_profile_kernels_rng(tbnav_mppi* h, const double x0[3], uint64_t seed, uint64_t tick, void* stream, int32_t reps,
+                                   float ms[TBNAV_MPPI_NKERNELS]);
+
+/* Names of the kernel instantiations the handle's LAST rollout and combine launches were, spelled as a profiler prints
+ * them ("mppi_rollout_fused<2, 8, 1, true>", "mppi_combine<2, false>"): lets a benchmark line point at one row of a
+ * rocprofv3 --kernel-trace --stats summary.  Empty strings before the first launch. */
+int tbnav_mppi_last_kernel_names(const tbnav_mppi* h, char* rollout, int32_t rollout_cap, char* combine, int32_t combine_cap);
 
 #ifdef __cplusplus
 }

@@ -144,6 +144,8 @@ def lib() -> C.CDLL:
         "tbnav_mppi_debug_sincos": (C.c_int, [vp, i32, vp, vp]),
         "tbnav_mppi_profile_tick": (C.c_int, [vp, dp, vp, vp, vp, C.POINTER(C.c_float)]),
         "tbnav_mppi_profile_kernels": (C.c_int, [vp, dp, vp, vp, vp, i32, C.POINTER(C.c_float)]),
+        "tbnav_mppi_profile_kernels_rng": (C.c_int, [vp, dp, C.c_uint64, C.c_uint64, vp, i32, C.POINTER(C.c_float)]),
+        "tbnav_mppi_last_kernel_names": (C.c_int, [vp, C.c_char_p, i32, C.c_char_p, i32]),
         # communicators (include/tbnav_comm.h) and the sharded MPPI tick
         "tbnav_comm_unique_id": (C.c_int, [vp]),
         "tbnav_comm_unique_id_ipc": (C.c_int, [vp]),

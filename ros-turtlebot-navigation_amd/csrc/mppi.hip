@@ -1107,7 +1107,10 @@ __global__ __launch_bounds__(kSliceThreads) void mppi_partials(int T, int K, int
   }
 #pragma unroll
   for (int it = 0; it < kSliceItems; ++it) {
-    if (pre && tot[it] != inf) j[it] = tot[it] - j[it];   // J(i) = S - E(i); a missing rollout (tot = +inf) stays +inf
+    // J(i) = S - E(i).  A missing rollout (tot = +inf by construction) and a rollout whose total OVERFLOWED to +inf both end as
+    // J = +inf, weight 0 — what the suffix-sum kernels give the latter (its prefix row alone would be a FINITE E(i) and look like
+    // the cheapest rollout of the step; round-3 advisor finding)
+    if (pre) j[it] = (tot[it] == inf) ? inf : tot[it] - j[it];
     mn = fmin(mn, j[it]);
   }
   mn = block_min(mn, scratch);
@@ -1197,7 +1200,7 @@ __global__ __launch_bounds__(kWave) void mppi_merge_records(int T, int Sf, int p
 // fine-grained buffer; poll them until both carry the tick's sequence number (bounded: an error word and zeros after `budget`
 // ticks of the 100 MHz clock).
 struct DirectSrc { const unsigned long long* w0; unsigned long long budget; int* err; int* err_dev; unsigned int seq; };  // err: mapped host word; err_dev: its device twin (what later ticks look at)
-__device__ __forceinline__ double direct_load(const DirectSrc& d, size_t idx) {
+__device__ __forceinline__ double direct_load(const DirectSrc& d, size_t idx, bool& failed) {
   unsigned long long* w = const_cast<unsigned long long*>(d.w0) + 2 * idx;
   unsigned long long lo = 0ull, hi = 0ull;
   const unsigned long long t0 = wall_clock64();
@@ -1209,6 +1212,7 @@ __device__ __forceinline__ double direct_load(const DirectSrc& d, size_t idx) {
       __hip_atomic_fetch_or(d.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __hip_atomic_fetch_or(d.err_dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       lo = hi = 0ull;
+      failed = true;
       break;
     }
     __builtin_amdgcn_s_sleep(1);
@@ -1220,7 +1224,7 @@ __device__ __forceinline__ double direct_load(const DirectSrc& d, size_t idx) {
 // buffer is fine-grained memory, every load a trip to the fabric, and one field after the other would be fourteen of them
 // in a row per record; only records whose words do not all carry the tick's number yet are asked for again.
 template <int NR>
-__device__ __forceinline__ void direct_load_records(const DirectSrc& d, const size_t (&idx)[NR], const bool (&have)[NR], double (&out)[NR][7]) {
+__device__ __forceinline__ bool direct_load_records(const DirectSrc& d, const size_t (&idx)[NR], const bool (&have)[NR], double (&out)[NR][7]) {
   unsigned long long w[NR][14];
   bool done[NR];
 #pragma unroll
@@ -1255,10 +1259,11 @@ __device__ __forceinline__ void direct_load_records(const DirectSrc& d, const si
     if (wall_clock64() - t0 > d.budget) {
       __hip_atomic_fetch_or(d.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __hip_atomic_fetch_or(d.err_dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      break;  // (the records that never came stay zero: n == 0 marks "no record")
+      return false;  // (the records that never came stay zero; the caller leaves its time step's controls as they were)
     }
     __builtin_amdgcn_s_sleep(1);
   }
+  return true;
 }
 
 template <int kKeep, bool DIRECT = false>
@@ -1268,7 +1273,10 @@ __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, double 
   // (DIRECT: `records` is not read — field f of record (g, i, sl) is polled for in the exchange buffer, same index)
   // (an exchange that has timed out once stays dead: the ticks queued behind it must not each wait the whole bound again)
   const bool dead = DIRECT && __hip_atomic_load(ds.err_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-  auto field = [&](const double* rec, int f) { return DIRECT ? (dead ? 0.0 : direct_load(ds, (size_t)(rec - records) + f)) : rec[f]; };
+  // (a time step whose peers' records did not all arrive — now or in an earlier tick — is NOT updated: its controls go out as they
+  //  came in, never a soft-min over this rank's shard alone; the error word reaches the host with the next enqueue / last_controls)
+  bool failed = dead;
+  auto field = [&](const double* rec, int f) { return DIRECT ? (dead ? 0.0 : direct_load(ds, (size_t)(rec - records) + f, failed)) : rec[f]; };
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave, nw = blockDim.x / kWave;
   const int R = G * S;
   int tpr = 1;
@@ -1294,14 +1302,14 @@ __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, double 
       const int g = (hv[q] && G > 1) ? r / S : 0, sl = hv[q] ? r - g * S : 0;
       idx[q] = (((size_t)g * T + (valid ? i : 0)) * S + sl) * TBNAV_MPPI_REC;
     }
-    if constexpr (kKeep <= 2) direct_load_records<kKeep>(ds, idx, hv, rk);   // (the K = 1024 tick: both records' words in flight together)
+    if constexpr (kKeep <= 2) failed = !direct_load_records<kKeep>(ds, idx, hv, rk) || failed;   // (the K = 1024 tick: both records' words in flight together)
     else {
 #pragma unroll
       for (int q = 0; q < kKeep; ++q) {
         const size_t i1[1] = {idx[q]};
         const bool h1[1] = {hv[q]};
         double o1[1][7];
-        direct_load_records<1>(ds, i1, h1, o1);
+        failed = !direct_load_records<1>(ds, i1, h1, o1) || failed;
 #pragma unroll
         for (int f = 0; f < 7; ++f) rk[q][f] = o1[0][f];
       }
@@ -1362,6 +1370,11 @@ __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, double 
       SD += __shfl_xor(SD, off, kWave); SE += __shfl_xor(SE, off, kWave); SN += __shfl_xor(SN, off, kWave);
     }
   }
+  if constexpr (DIRECT) {  // any lane of the time step's group
+    int fl = failed ? 1 : 0;
+    for (int off = tpr >> 1; off > 0; off >>= 1) fl |= __shfl_xor(fl, off, kWave);
+    failed = fl != 0;
+  }
   MTRACE(1, 3);
   if (valid && l == 0) {
     W += 1e-8 * SN;  // the reference adds 1e-8 to every weight before normalising (mppi.cpp:117)
@@ -1369,6 +1382,7 @@ __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, double 
     double ur = u_r + (NR + 1e-8 * SE) / W;
     ul = fmin(fmax(ul, -umax), umax);  // std::clamp(u, -max, max), mppi.cpp:124-125
     ur = fmin(fmax(ur, -umax), umax);
+    if (DIRECT && failed) { ul = u_l; ur = u_r; }
     u_out[i] = ul;
     u_out[T + i] = ur;
     if (i == 0) {
@@ -1471,6 +1485,8 @@ __global__ void mppi_sample_noise(int T, int K, uint64_t seed, uint64_t base, do
 struct tbnav_mppi {
   tbnav_mppi_params p;
   int T = 0, K = 0, S = 0, device = 0;
+  int lk_rollout[5] = {0, 0, 0, 0, 0};  // the instantiation the last rollout launch picked: kind (1 fused, 2 scan, 3 prefix, 4 cost), template arguments
+  int lk_combine[2] = {0, 0};           // ... and the last combine: KEEP, DIRECT  (tbnav_mppi_last_kernel_names)
   double xd[3] = {0, 0, 0};
   double uinit[2] = {0, 0};
   double* d_u[2] = {nullptr, nullptr};  // [2][T] each; d_u[ucur] holds the controls, d_u[1-ucur] receives the next update
@@ -1528,7 +1544,7 @@ struct tbnav_mppi {
   std::vector<void*> dx_opened;                 // the mappings of the peers' buffers (closed at detach)
   int* h_dx_err = nullptr; int* d_dx_err = nullptr;  // mapped pinned: raised by a combine that ran out of time waiting for a peer's words
   int* d_dx_dead = nullptr;                          // its device twin: later ticks see it without a trip over PCIe
-  unsigned long long dx_budget = 2000000000ull;      // 20 s of the 100 MHz clock (host-side skew between ranks is legitimate; longer: the peer has failed)
+  unsigned long long dx_budget = 200000000ull;       // 2 s of the 100 MHz clock (host-side skew between ranks is legitimate — a control loop's is milliseconds; longer: the peer has failed)
   bool dx_withhold = false;                          // fault injection (TBNAV_MPPI_OPT_DIRECT_EXCHANGE = 2, tests): this rank's records never reach its peers
   unsigned int dx_seq = 0;
   // set by the sharded tick round its call of the shard-partials entry point: if that ends in mppi_merge_records, the kernel
@@ -1564,7 +1580,8 @@ int launch_rollout(tbnav_mppi* h, const double x0[3], const double* d_duL, const
     const int TCv = h->scan_tc, C = (h->T + TCv - 1) / TCv;
     const size_t lds = ((size_t)2 * h->T + (size_t)4 * C * kWave) * sizeof(double);
     const dim3 blk(kWave, C);
-#define TBNAV_SCAN(TR, TCC, MW) hipLaunchKernelGGL((mppi_rollout_scan<TR, TCC, MW>), grid, blk, lds, st, a, d_duL, d_duR, usrc, h->d_J)
+#define TBNAV_SCAN(TR, TCC, MW) do { h->lk_rollout[0] = 2; h->lk_rollout[1] = TR; h->lk_rollout[2] = TCC; h->lk_rollout[3] = MW; \
+                                 hipLaunchKernelGGL((mppi_rollout_scan<TR, TCC, MW>), grid, blk, lds, st, a, d_duL, d_duR, usrc, h->d_J); } while (0)
 #define TBNAV_SCAN_TC(TR)                                                                                          \
   switch (TCv) {                                                                                                   \
     case 4: if (C > 12) TBNAV_SCAN(TR, 4, 16); else TBNAV_SCAN(TR, 4, 12); break;                                  \
@@ -1581,6 +1598,7 @@ int launch_rollout(tbnav_mppi* h, const double x0[3], const double* d_duL, const
     if (h->prefix_rg > 0 && h->dyn == 0 && h->trig == 1) {
       const size_t ldsp = (size_t)2 * h->T * sizeof(double);
       a.lds_from = 0;
+      h->lk_rollout[0] = 3; h->lk_rollout[1] = h->prefix_rg < 3 ? h->prefix_rg : 3;
       switch (h->prefix_rg) {
         case 1: hipLaunchKernelGGL((mppi_rollout_prefix<1>), grid, block, ldsp, st, a, d_duL, d_duR, usrc, h->d_J, h->d_total); break;
         case 2: hipLaunchKernelGGL((mppi_rollout_prefix<2>), grid, block, ldsp, st, a, d_duL, d_duR, usrc, h->d_J, h->d_total); break;
@@ -1595,6 +1613,7 @@ int launch_rollout(tbnav_mppi* h, const double x0[3], const double* d_duL, const
     if (h->reg_groups > 0 && h->dyn == 0 && h->trig == 1) {
       const size_t ldsr = (size_t)2 * h->T * sizeof(double) + (size_t)(h->T - kGroup * h->reg_groups) * kWave * sizeof(double);
       a.lds_from = 0;
+      h->lk_rollout[0] = 5; h->lk_rollout[1] = 1; h->lk_rollout[2] = (h->reg_groups == 2 || h->reg_groups == 4 || h->reg_groups == 6 || h->reg_groups == 7) ? h->reg_groups : 8;
       switch (h->reg_groups) {
         case 2: hipLaunchKernelGGL((mppi_rollout_cost_reg<1, 2>), grid, block, ldsr, st, a, d_duL, d_duR, usrc, h->d_J); break;
         case 4: hipLaunchKernelGGL((mppi_rollout_cost_reg<1, 4>), grid, block, ldsr, st, a, d_duL, d_duR, usrc, h->d_J); break;
@@ -1608,6 +1627,7 @@ int launch_rollout(tbnav_mppi* h, const double x0[3], const double* d_duL, const
     }
     const size_t lds = (size_t)2 * h->T * sizeof(double) + (size_t)(h->T - h->lds_from) * kWave * sizeof(double);
     a.lds_from = h->lds_from;
+    h->lk_rollout[0] = 4; h->lk_rollout[1] = h->dyn == 1 ? 4 : (h->trig >= 1 && h->trig <= 2 ? h->trig : 3);
     if (h->dyn == 1) hipLaunchKernelGGL((mppi_rollout_cost<4>), grid, block, lds, st, a, d_duL, d_duR, usrc, h->d_J);
     else if (h->trig == 1) hipLaunchKernelGGL((mppi_rollout_cost<1>), grid, block, lds, st, a, d_duL, d_duR, usrc, h->d_J);
     else if (h->trig == 2) hipLaunchKernelGGL((mppi_rollout_cost<2>), grid, block, lds, st, a, d_duL, d_duR, usrc, h->d_J);
@@ -1644,8 +1664,9 @@ int launch_fused(tbnav_mppi* h, const double x0[3], const double* d_duL, const d
   const dim3 grid(h->fused_S), block(kWave * R);
   const size_t lds = fused_lds_bytes(h->T, R);
   const RngArgs g = rng ? *rng : RngArgs{0, 0, 0.0, 0.0};
-#define TBNAV_FUSED(TR, RR, TLL, RG) hipLaunchKernelGGL((mppi_rollout_fused<TR, RR, TLL, RG>), grid, block, lds, st, a, d_duL, d_duR, usrc, \
-                                                        h->p.lambda, h->keep_j ? h->d_J : nullptr, h->d_records_f, h->fused_S, g)
+#define TBNAV_FUSED(TR, RR, TLL, RG) do { h->lk_rollout[0] = 1; h->lk_rollout[1] = TR; h->lk_rollout[2] = RR; h->lk_rollout[3] = TLL; h->lk_rollout[4] = RG;     \
+                                     hipLaunchKernelGGL((mppi_rollout_fused<TR, RR, TLL, RG>), grid, block, lds, st, a, d_duL, d_duR, usrc, \
+                                                        h->p.lambda, h->keep_j ? h->d_J : nullptr, h->d_records_f, h->fused_S, g); } while (0)
 #define TBNAV_FUSED_R(TR)                                                                                \
   if (R == 8) { if (TL == 1) TBNAV_FUSED(TR, 8, 1, false); else TBNAV_FUSED(TR, 8, 2, false); }          \
   else if (R == 4) { if (TL == 1) TBNAV_FUSED(TR, 4, 1, false); else TBNAV_FUSED(TR, 4, 2, false); }     \
@@ -1681,8 +1702,8 @@ int launch_combine(tbnav_mppi* h, const double* d_records, int G, hipStream_t st
   const int blocks = (h->T + steps_per_block - 1) / steps_per_block;
   const USrc usrc{h->d_u[h->ucur], h->pending_shift ? 1 : 0, h->uinit[0], h->uinit[1]};
   const DirectSrc ds = direct ? *direct : DirectSrc{nullptr, 0ull, nullptr, nullptr, 0u};
-#define TBNAV_COMBINE(KEEP, DIR) hipLaunchKernelGGL((mppi_combine<KEEP, DIR>), dim3(blocks), dim3(wpb * kWave), 0, st, h->T, G, S, h->p.lambda, h->p.max_wheel_vel, usrc, \
-                                                    d_records, h->d_u[1 - h->ucur], h->d_out, h->publish_next ? h->d_out_host : nullptr, (double)(h->seq + 1), ds)
+#define TBNAV_COMBINE(KEEP, DIR) do { h->lk_combine[0] = KEEP; h->lk_combine[1] = DIR; hipLaunchKernelGGL((mppi_combine<KEEP, DIR>), dim3(blocks), dim3(wpb * kWave), 0, st, h->T, G, S, h->p.lambda, h->p.max_wheel_vel, usrc, \
+                                                    d_records, h->d_u[1 - h->ucur], h->d_out, h->publish_next ? h->d_out_host : nullptr, (double)(h->seq + 1), ds); } while (0)
   if (direct) {
     if (G * S > 4 * kWave && G * S <= 8 * kWave) TBNAV_COMBINE(8, true);
     else if (G * S > 2 * kWave && G * S <= 4 * kWave) TBNAV_COMBINE(4, true);
@@ -1960,7 +1981,7 @@ int tbnav_mppi_set_option(tbnav_mppi* h, int32_t option, int32_t value) {
     case TBNAV_MPPI_OPT_DIRECT_EXCHANGE:  // (takes effect at the next tbnav_mppi_attach_comm)
       h->direct_want = value != 0;
       h->dx_withhold = value == 2;                       // (tests of the bound: see dx_withhold)
-      h->dx_budget = value == 2 ? 30000000ull : 2000000000ull;  // 0.3 s there
+      h->dx_budget = value == 2 ? 30000000ull : 200000000ull;  // 0.3 s there
       return TBNAV_OK;
     case TBNAV_MPPI_OPT_KERNEL: {
       // 0: mppi_rollout_cost (sequential); n > 0: mppi_rollout_scan with n steps per thread; -4 / -8 / -16: fused, that many rollouts per workgroup
@@ -2167,6 +2188,60 @@ int tbnav_mppi_profile_kernels(tbnav_mppi* h, const double x0[3], const double* 
   }
   for (auto& e : ev) (void)hipEventDestroy(e);
   return rc;
+}
+
+int tbnav_mppi_profile_kernels_rng(tbnav_mppi* h, const double x0[3], uint64_t seed, uint64_t tick, void* stream, int32_t reps,
+                                   float ms[TBNAV_MPPI_NKERNELS]) {
+  if (!h || !x0 || !ms || reps < 2 || (reps & 1)) return TBNAV_ERR_INVALID_ARG;
+  if (!(h->fused_dev && h->fused_rng && (h->fused_r == 8 || h->fused_r == 16))) {
+    // no in-kernel noise for this configuration: the production tick samples into the handle's buffers and runs the plain kernels
+    const int rc = tbnav_mppi_sample_noise(h, seed, tick, stream);
+    return rc != TBNAV_OK ? rc : tbnav_mppi_profile_kernels(h, x0, nullptr, nullptr, stream, reps, ms);
+  }
+  DeviceGuard guard(h->device);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipEvent_t ev[2];
+  for (auto& e : ev) TBNAV_HIP(hipEventCreate(&e));
+  int rc = TBNAV_OK;
+  auto timed = [&](int which, auto&& launch) {
+    if (rc != TBNAV_OK) return;
+    if (hipEventRecord(ev[0], st) != hipSuccess) { rc = TBNAV_ERR_HIP; return; }
+    for (int r = 0; r < reps && rc == TBNAV_OK; ++r) rc = launch(r);
+    if (rc != TBNAV_OK) return;
+    float t = 0.f;
+    if (hipEventRecord(ev[1], st) != hipSuccess || hipEventSynchronize(ev[1]) != hipSuccess ||
+        hipEventElapsedTime(&t, ev[0], ev[1]) != hipSuccess) { rc = TBNAV_ERR_HIP; return; }
+    ms[which] = t / (float)reps;
+  };
+  for (int i = 0; i < TBNAV_MPPI_NKERNELS; ++i) ms[i] = 0.f;
+  // the launches of tbnav_mppi_enqueue_rng, kernel by kernel: the RNG = true instantiation of the fused kernel
+  timed(0, [&](int r) {
+    const RngArgs g{seed, rng_base(h, tick + (uint64_t)r), std::sqrt(h->p.ul_var), std::sqrt(h->p.ur_var)};
+    return launch_fused(h, x0, h->d_duL, h->d_duR, st, &g);
+  });
+  timed(2, [&](int) { return launch_combine(h, h->d_records_f, 1, st, h->fused_S); });
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  return rc;
+}
+
+int tbnav_mppi_last_kernel_names(const tbnav_mppi* h, char* rollout, int32_t rollout_cap, char* combine, int32_t combine_cap) {
+  if (!h) return TBNAV_ERR_INVALID_ARG;
+  const int* k = h->lk_rollout;
+  if (rollout && rollout_cap > 0) {
+    switch (k[0]) {
+      case 1: snprintf(rollout, (size_t)rollout_cap, "mppi_rollout_fused<%d, %d, %d, %s>", k[1], k[2], k[3], k[4] ? "true" : "false"); break;
+      case 2: snprintf(rollout, (size_t)rollout_cap, "mppi_rollout_scan<%d, %d, %d>", k[1], k[2], k[3]); break;
+      case 3: snprintf(rollout, (size_t)rollout_cap, "mppi_rollout_prefix<%d>", k[1]); break;
+      case 4: snprintf(rollout, (size_t)rollout_cap, "mppi_rollout_cost<%d>", k[1]); break;
+      case 5: snprintf(rollout, (size_t)rollout_cap, "mppi_rollout_cost_reg<%d, %d>", k[1], k[2]); break;
+      default: rollout[0] = 0;
+    }
+  }
+  if (combine && combine_cap > 0) {
+    if (h->lk_combine[0]) snprintf(combine, (size_t)combine_cap, "mppi_combine<%d, %s>", h->lk_combine[0], h->lk_combine[1] ? "true" : "false");
+    else combine[0] = 0;
+  }
+  return TBNAV_OK;
 }
 
 int tbnav_mppi_last_controls(tbnav_mppi* h, void* stream, double u_out[2]) {
@@ -2384,6 +2459,14 @@ int tbnav_mppi_attach_comm(tbnav_mppi* h, tbnav_comm* comm) {
   if (!h) return TBNAV_ERR_INVALID_ARG;
   DeviceGuard guard(h->device);
   TBNAV_HIP(hipDeviceSynchronize());
+  if (h->comm && h->direct_on && tbnav::comm_is_multiprocess(h->comm)) {
+    // detaching from a direct exchange is COLLECTIVE, like attaching: a peer's publish kernel may still be storing into this
+    // rank's buffer (it can be one tick ahead) — every rank synchronises its device (above), then all meet here, and only then
+    // are the peers' mappings closed and the buffer freed.  A communicator that fails here is reported; the teardown still runs.
+    int mine = 1;
+    std::vector<int> all((size_t)tbnav::comm_size(h->comm), 0);
+    (void)tbnav::comm_all_gather_host(h->comm, &mine, all.data(), sizeof(int));
+  }
   direct_teardown(h);
   (void)hipFree(h->d_records_all);
   h->d_records_all = nullptr;
@@ -2462,6 +2545,10 @@ double direct_pattern(int q, int it, int j) {  // the self-tests' records: every
 void direct_teardown(tbnav_mppi* h) {
   if (!h) return;
   h->direct_on = false;
+  // a fresh attachment starts from a zeroed buffer and tag 1 on every rank: the self-tests end at the first local failure, so
+  // ranks may leave a set-up with different counts (round-3 advisor finding)
+  h->dx_seq = 0;
+  h->pub_pending = false;
   for (void* p : h->dx_opened) (void)hipIpcCloseMemHandle(p);
   h->dx_opened.clear();
   (void)hipFree(h->d_dx); h->d_dx = nullptr;
@@ -2542,19 +2629,35 @@ int direct_partials_and_publish(tbnav_mppi* h, const double x0[3], const double*
 
 int sharded_tick(tbnav_mppi* h, const double x0[3], const double* d_duL, const double* d_duR, const uint64_t* seed, uint64_t tick, void* stream) {
   if (h->direct_on) {
+    if (h->h_dx_err && *h->h_dx_err) {  // an earlier tick's bound expired: say so now, not only at the next last_controls
+      tbnav::last_hip_error_slot() = "direct exchange: a peer's records did not arrive in time (latched; re-attach the communicator)";
+      return TBNAV_ERR_HIP;
+    }
     const int rc = direct_partials_and_publish(h, x0, d_duL, d_duR, seed, tick, stream);
     if (rc != TBNAV_OK) return rc;
     DeviceGuard guard(h->device);
     return direct_combine(h, static_cast<hipStream_t>(stream));
   }
-  int rc = sharded_partials(h, x0, d_duL, d_duR, seed, tick, stream);
-  if (rc != TBNAV_OK) return rc;
+  const int rc_local = sharded_partials(h, x0, d_duL, d_duR, seed, tick, stream);
   DeviceGuard guard(h->device);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t block = sizeof(double) * (size_t)h->T * h->S * TBNAV_MPPI_REC;
-  const void* send = reinterpret_cast<const char*>(h->d_records_all) + (size_t)tbnav::comm_rank(h->comm) * block;
+  void* mine = reinterpret_cast<char*>(h->d_records_all) + (size_t)tbnav::comm_rank(h->comm) * block;
+  if (rc_local != TBNAV_OK) {
+    // This rank's rollouts failed.  Its peers are about to enter (or sit in) an all-gather that has no timeout: JOIN it — with
+    // records that poison every rank's combine (cost NaN, count 1: the soft-min and with it the controls come out NaN on every
+    // rank, which every caller checks) instead of leaving the others hanging or, worse, quietly combining without this shard —
+    // and report the failure here.  (Round-3 advisor finding: the early return left the peers in ncclAllGather for good.)
+    std::vector<double> bad((size_t)h->T * h->S * TBNAV_MPPI_REC, std::numeric_limits<double>::quiet_NaN());
+    for (size_t q = 6; q < bad.size(); q += TBNAV_MPPI_REC) bad[q] = 1.0;
+    (void)hipMemcpyAsync(mine, bad.data(), block, hipMemcpyHostToDevice, st);
+    (void)hipStreamSynchronize(st);   // (`bad` is pageable host memory: do not let it go out of scope under the copy)
+    (void)hipGetLastError();
+  }
+  const void* send = mine;
   void* recv = h->d_records_all;
-  rc = tbnav::comm_all_gather(1, &h->comm, &send, &recv, block, &st);
+  const int rc = tbnav::comm_all_gather(1, &h->comm, &send, &recv, block, &st);
+  if (rc_local != TBNAV_OK) return rc_local;
   if (rc != TBNAV_OK) return rc;
   return launch_combine(h, h->d_records_all, tbnav::comm_size(h->comm), st);
 }
@@ -2606,11 +2709,15 @@ namespace {
 // it, on every stream).  Same kernels, same words, same self-test as between processes.
 int group_direct_setup(tbnav_mppi_group* g) {
   const int P = g->n;
-  for (tbnav_mppi* h : g->m) { DeviceGuard guard(h->device); (void)hipDeviceSynchronize(); direct_teardown(h); }
+  // every member's device idle BEFORE any member's buffer is freed: a member's publish kernel, still in flight on its own device,
+  // stores into every other member's buffer (round-3 advisor finding: one member at a time freed a buffer under such stores)
+  auto quiesce_all = [&]() { for (tbnav_mppi* h : g->m) if (h) { DeviceGuard guard(h->device); (void)hipDeviceSynchronize(); } };
+  auto teardown_all = [&]() { quiesce_all(); for (tbnav_mppi* h : g->m) if (h) { DeviceGuard guard(h->device); direct_teardown(h); } };
+  teardown_all();
   bool want = P > 1;
   for (tbnav_mppi* h : g->m) want = want && h->direct_want && h->comm;
   if (!want) return TBNAV_OK;
-  auto give_up = [&]() { for (tbnav_mppi* h : g->m) { DeviceGuard guard(h->device); (void)hipDeviceSynchronize(); direct_teardown(h); } return (int)TBNAV_OK; };
+  auto give_up = [&]() { teardown_all(); return (int)TBNAV_OK; };
   for (int r = 0; r < P; ++r)
     for (int q = 0; q < P; ++q) {
       if (g->m[r]->device == g->m[q]->device) continue;
@@ -2653,8 +2760,9 @@ extern "C" {
 
 void tbnav_mppi_group_destroy(tbnav_mppi_group* g) {
   if (!g) return;
+  // (all members idle before the first one's buffers go: their kernels store into each other's exchange buffers)
+  for (tbnav_mppi* h : g->m) if (h) { DeviceGuard guard(h->device); (void)hipDeviceSynchronize(); }
   for (int r = 0; r < g->n; ++r) {
-    if (r < (int)g->m.size() && g->m[r]) { DeviceGuard guard(g->m[r]->device); (void)hipDeviceSynchronize(); }
     if (r < (int)g->m.size()) tbnav_mppi_destroy(g->m[r]);
     if (r < (int)g->c.size()) tbnav_comm_destroy(g->c[r]);
     if (r < (int)g->st.size() && g->st[r]) (void)hipStreamDestroy(g->st[r]);

@@ -5249,63 +5249,27 @@ int sharded_scan(int n, tbnav_rbpf* const* hs, const float* scan, int n_beams, c
   const int P = tbnav::comm_size(hs[0]->comm), nl = hs[0]->N;
   const size_t ng = (size_t)P * nl;
   if (ng > ((size_t)1 << 24)) return TBNAV_ERR_UNSUPPORTED;
+  // (everything above is a function of arguments every rank shares: all ranks return together.  From here on a failure that
+  //  only THIS rank sees — a launch that fails, an allocation, a pool that runs dry — must not make it leave while its peers
+  //  wait in a collective that has no timeout: the rank notes the code in lerr[], skips its own work, KEEPS JOINING the
+  //  collectives, and the ranks agree on a status before anyone acts on data that may be missing.  Round-3 advisor finding.)
   std::vector<tbnav_comm*> comms(n);
   std::vector<hipStream_t> s1(n), s2(n);
   std::vector<ScanTicket> tk(n);
   std::vector<tbnav_rbpf_stats> lst(n);
-  std::memset(out, 0, sizeof *out);
-  // ---- A: every member's local scan (no normalise tail), its "weights are final" event recorded behind the proposal kernel
-  for (int r = 0; r < n; ++r) {
-    tbnav_rbpf* h = hs[r];
-    DeviceGuard guard(h->device);
-    { const int rc = ensure_shard_state(h); if (rc != TBNAV_OK) return rc; }
-    comms[r] = h->comm; s1[r] = h->stream; s2[r] = h->stream2;
-    const int rc = scan_enqueue(h, scan, n_beams, u, cur_odom, prev_odom, icp_ok, T_icp, normals ? normals[r] : nullptr, &lst[r], true, 0, nullptr, tk[r], nullptr, h->ev_w);
-    if (rc != TBNAV_OK) { out->status = rc; return rc; }
-    TBNAV_HIP(hipStreamWaitEvent(h->stream2, h->ev_w, 0));
-  }
-  // ---- B: the ONE collective of the update + the global normalise / selection, on the second streams
-  {
-    std::vector<const void*> send(n);
-    std::vector<void*> recv(n);
-    for (int r = 0; r < n; ++r) { send[r] = state_ptrs(hs[r]->d_state[hs[r]->cur], nl).weight; recv[r] = hs[r]->d_gw_raw; }
-    const int rc = tbnav::comm_all_gather(n, comms.data(), send.data(), recv.data(), sizeof(double) * nl, s2.data());
-    if (rc != TBNAV_OK) return rc;
-  }
-  for (int r = 0; r < n; ++r) {
-    tbnav_rbpf* h = hs[r];
-    DeviceGuard guard(h->device);
-    h->h_norm[1] = NormOut{};
-    // the resampling offset: the scan's last normal — with tbnav_rbpf_set_rng_shard (device noise) the ENSEMBLE's, identical on every rank
-    const double* zp = h->last_normals + h->last_z_index;
-    hipLaunchKernelGGL(rbpf_normalize, dim3(1), dim3(256), 0, h->stream2, (int)ng, zp, h->d_gw_raw, h->d_gw, h->d_gcs, h->d_gparent, h->d_norm + 1,
-                       nullptr, nullptr, nullptr, 0u);
-    TBNAV_HIP(hipGetLastError());
-    const size_t off = (size_t)tbnav::comm_rank(h->comm) * nl;
-    TBNAV_HIP(hipMemcpyAsync(state_ptrs(h->d_state[h->cur], nl).weight, h->d_gw + off, sizeof(double) * nl, hipMemcpyDeviceToDevice, h->stream2));
-    TBNAV_HIP(hipEventRecord(h->ev_g, h->stream2));
-    TBNAV_HIP(hipStreamWaitEvent(h->stream, h->ev_g, 0));  // whatever the main stream does next sees the normalised weights
-  }
-  // ---- C: the host waits once per member (the reference's SLAM() is synchronous)
-  int status = TBNAV_OK;
-  std::vector<int> lstat(n, TBNAV_OK);
-  for (int r = 0; r < n; ++r) {
-    tbnav_rbpf* h = hs[r];
-    DeviceGuard guard(h->device);
-    TBNAV_HIP(hipStreamSynchronize(h->stream2));
-    lstat[r] = scan_finish(h, tk[r], &lst[r]);
-    if (lstat[r] != TBNAV_OK && status == TBNAV_OK) status = lstat[r];
-    if (local_out) local_out[r] = lst[r];
-  }
-  if (n < P) {
-    // Ranks outside this process: what the reference reports by throwing (a particle left the world, eta is 0 ...) happens to the
-    // rank that holds the particle.  Every rank must stop at the SAME scan with the same status — a rank that went on alone would
-    // sit in the next scan's all-gather for ever: one all-gather of the ranks' statuses per scan (4 bytes each; ~1 % of a scan).
+  std::vector<int> lerr(n, TBNAV_OK);
+  auto note = [&](int r, int rc) { if (rc != TBNAV_OK && lerr[r] == TBNAV_OK) lerr[r] = rc; };
+  auto hipok = [&](int r, hipError_t e, const char* what, int line) { if (e != hipSuccess) note(r, tbnav::hip_fail(e, what, __FILE__, line)); return e == hipSuccess; };
+#define TBNAV_L(r, call) hipok(r, (call), #call, __LINE__)
+  // the ranks' codes -> one status, the same on every rank (the lowest rank's failure); collective when ranks live elsewhere
+  auto agree = [&](const std::vector<int>& codes, int& status) -> int {
+    status = TBNAV_OK;
+    if (n == P) { for (int r = 0; r < n; ++r) if (codes[r] != TBNAV_OK && status == TBNAV_OK) status = codes[r]; return TBNAV_OK; }
     std::vector<const void*> send(n);
     std::vector<void*> recv(n);
     for (int r = 0; r < n; ++r) {
       DeviceGuard guard(hs[r]->device);
-      TBNAV_HIP(hipMemcpyAsync(hs[r]->d_status, &lstat[r], sizeof(int), hipMemcpyHostToDevice, hs[r]->stream));
+      TBNAV_HIP(hipMemcpyAsync(hs[r]->d_status, &codes[r], sizeof(int), hipMemcpyHostToDevice, hs[r]->stream));
       send[r] = hs[r]->d_status; recv[r] = hs[r]->d_status + 1;
     }
     { const int rc = tbnav::comm_all_gather(n, comms.data(), send.data(), recv.data(), sizeof(int), s1.data()); if (rc != TBNAV_OK) return rc; }
@@ -5313,9 +5277,60 @@ int sharded_scan(int n, tbnav_rbpf* const* hs, const float* scan, int n_beams, c
     { DeviceGuard guard(hs[0]->device);
       TBNAV_HIP(hipMemcpyAsync(all.data(), hs[0]->d_status + 1, sizeof(int) * P, hipMemcpyDeviceToHost, hs[0]->stream));
       TBNAV_HIP(hipStreamSynchronize(hs[0]->stream)); }
-    status = TBNAV_OK;
-    for (int q = 0; q < P; ++q) if (all[q] != TBNAV_OK) { status = all[q]; break; }   // (the lowest rank's, on every rank)
+    for (int q = 0; q < P; ++q) if (all[q] != TBNAV_OK) { status = all[q]; break; }
+    return TBNAV_OK;
+  };
+  std::memset(out, 0, sizeof *out);
+  // ---- A: every member's local scan (no normalise tail), its "weights are final" event recorded behind the proposal kernel
+  for (int r = 0; r < n; ++r) {
+    tbnav_rbpf* h = hs[r];
+    DeviceGuard guard(h->device);
+    comms[r] = h->comm; s1[r] = h->stream; s2[r] = h->stream2;
+    note(r, ensure_shard_state(h));   // (sized at attach: a no-op here unless the handle was resized since)
+    if (!h->d_gw_raw || !h->d_status) { out->status = lerr[r]; return lerr[r]; }   // nothing to join a collective WITH: only before the first scan, at attach
+    comms[r] = h->comm; s1[r] = h->stream; s2[r] = h->stream2;
+    if (lerr[r] == TBNAV_OK)
+      note(r, scan_enqueue(h, scan, n_beams, u, cur_odom, prev_odom, icp_ok, T_icp, normals ? normals[r] : nullptr, &lst[r], true, 0, nullptr, tk[r], nullptr, h->ev_w));
+    if (lerr[r] == TBNAV_OK) TBNAV_L(r, hipStreamWaitEvent(h->stream2, h->ev_w, 0));
   }
+  // ---- B: the ONE collective of the update + the global normalise / selection, on the second streams
+  //         (a member that failed above still takes part — with whatever its weight buffer holds: nobody will use the result)
+  {
+    std::vector<const void*> send(n);
+    std::vector<void*> recv(n);
+    for (int r = 0; r < n; ++r) { send[r] = state_ptrs(hs[r]->d_state[hs[r]->cur], nl).weight; recv[r] = hs[r]->d_gw_raw; }
+    const int rc = tbnav::comm_all_gather(n, comms.data(), send.data(), recv.data(), sizeof(double) * nl, s2.data());
+    if (rc != TBNAV_OK) return rc;   // (the communicator itself failed: it reports on every rank)
+  }
+  for (int r = 0; r < n; ++r) {
+    tbnav_rbpf* h = hs[r];
+    if (lerr[r] != TBNAV_OK) continue;
+    DeviceGuard guard(h->device);
+    h->h_norm[1] = NormOut{};
+    // the resampling offset: the scan's last normal — with tbnav_rbpf_set_rng_shard (device noise) the ENSEMBLE's, identical on every rank
+    const double* zp = h->last_normals + h->last_z_index;
+    hipLaunchKernelGGL(rbpf_normalize, dim3(1), dim3(256), 0, h->stream2, (int)ng, zp, h->d_gw_raw, h->d_gw, h->d_gcs, h->d_gparent, h->d_norm + 1,
+                       nullptr, nullptr, nullptr, 0u);
+    const size_t off = (size_t)tbnav::comm_rank(h->comm) * nl;
+    (void)(TBNAV_L(r, hipGetLastError()) &&
+           TBNAV_L(r, hipMemcpyAsync(state_ptrs(h->d_state[h->cur], nl).weight, h->d_gw + off, sizeof(double) * nl, hipMemcpyDeviceToDevice, h->stream2)) &&
+           TBNAV_L(r, hipEventRecord(h->ev_g, h->stream2)) &&
+           TBNAV_L(r, hipStreamWaitEvent(h->stream, h->ev_g, 0)));  // whatever the main stream does next sees the normalised weights
+  }
+  // ---- C: the host waits once per member (the reference's SLAM() is synchronous)
+  std::vector<int> lstat(n, TBNAV_OK);
+  for (int r = 0; r < n; ++r) {
+    tbnav_rbpf* h = hs[r];
+    DeviceGuard guard(h->device);
+    TBNAV_L(r, hipStreamSynchronize(h->stream2));
+    // what the reference reports by throwing (a particle left the world, eta is 0 ...) happens to the rank that holds the particle
+    lstat[r] = lerr[r] != TBNAV_OK ? lerr[r] : scan_finish(h, tk[r], &lst[r]);
+    if (local_out) local_out[r] = lst[r];
+  }
+  // Every rank must stop at the SAME scan with the same status — a rank that went on alone would sit in the next scan's
+  // all-gather for ever: one all-gather of the ranks' statuses per scan (4 bytes each; ~1 % of a scan) when ranks live elsewhere.
+  int status = TBNAV_OK;
+  { const int rc = agree(lstat, status); if (rc != TBNAV_OK) return rc; }
   const NormOut no = hs[0]->h_norm[1];
   out->sum_w = no.sum_w; out->sq_sum = no.sq_sum; out->neff = no.neff; out->resampled = no.resampled;
   out->n_valid_beams = lst[0].n_valid_beams;
@@ -5324,7 +5339,7 @@ int sharded_scan(int n, tbnav_rbpf* const* hs, const float* scan, int n_beams, c
   if (!no.resampled) return TBNAV_OK;
   // ---- D: lowVarianceResampling's copies across shards.  Slot m (global) takes particle parents[m].
   std::vector<int> parents(ng);
-  { DeviceGuard guard(hs[0]->device); TBNAV_HIP(hipMemcpy(parents.data(), hs[0]->d_gparent, sizeof(int) * ng, hipMemcpyDeviceToHost)); }
+  { DeviceGuard guard(hs[0]->device); if (!TBNAV_L(0, hipMemcpy(parents.data(), hs[0]->d_gparent, sizeof(int) * ng, hipMemcpyDeviceToHost))) std::fill(parents.begin(), parents.end(), 0); }
   struct Plan { std::vector<std::pair<int, int>> sends, recvs; std::vector<int32_t> send_slots; std::vector<uint64_t> send_sizes, send_offs; std::vector<unsigned long long> sizes_local; };
   std::vector<Plan> plan(n);
   for (int r = 0; r < n; ++r) {
@@ -5344,11 +5359,12 @@ int sharded_scan(int n, tbnav_rbpf* const* hs, const float* scan, int n_beams, c
     pl.send_slots.resize(pl.sends.size());
     for (size_t i = 0; i < pl.sends.size(); ++i) pl.send_slots[i] = pl.sends[i].second - lo;
     pl.send_sizes.assign(pl.sends.size(), 0);
-    { const int rc = tbnav_rbpf_export_batch_sizes(h, (int32_t)pl.sends.size(), pl.send_slots.data(), pl.send_sizes.data()); if (rc != TBNAV_OK) return rc; }
+    if (lerr[r] == TBNAV_OK) note(r, tbnav_rbpf_export_batch_sizes(h, (int32_t)pl.sends.size(), pl.send_slots.data(), pl.send_sizes.data()));
+    if (lerr[r] != TBNAV_OK) std::fill(pl.send_sizes.begin(), pl.send_sizes.end(), 0);
     // what a particle of mine weighs, for whoever receives it (a particle sent to several ranks weighs the same for each)
     pl.sizes_local.assign(nl, 0ull);
     for (size_t i = 0; i < pl.sends.size(); ++i) pl.sizes_local[pl.sends[i].second - lo] = pl.send_sizes[i];
-    TBNAV_HIP(hipMemcpyAsync(h->d_sizes, pl.sizes_local.data(), sizeof(unsigned long long) * nl, hipMemcpyHostToDevice, h->stream));
+    TBNAV_L(r, hipMemcpyAsync(h->d_sizes, pl.sizes_local.data(), sizeof(unsigned long long) * nl, hipMemcpyHostToDevice, h->stream));
   }
   {
     std::vector<const void*> send(n);
@@ -5364,14 +5380,14 @@ int sharded_scan(int n, tbnav_rbpf* const* hs, const float* scan, int n_beams, c
     tbnav_rbpf* h = hs[r];
     DeviceGuard guard(h->device);
     Plan& pl = plan[r];
-    TBNAV_HIP(hipMemcpyAsync(sizes_all.data(), h->d_sizes + nl, sizeof(unsigned long long) * ng, hipMemcpyDeviceToHost, h->stream));
-    TBNAV_HIP(hipStreamSynchronize(h->stream));
+    if (!(TBNAV_L(r, hipMemcpyAsync(sizes_all.data(), h->d_sizes + nl, sizeof(unsigned long long) * ng, hipMemcpyDeviceToHost, h->stream)) &&
+          TBNAV_L(r, hipStreamSynchronize(h->stream)))) std::fill(sizes_all.begin(), sizes_all.end(), 0ull);
     // everything this rank sends: ONE export, the blobs back to back in (destination, particle) order
     uint64_t total = 0;
     for (uint64_t b : pl.send_sizes) total += b;
-    { const int rc = grow(h->d_sendbuf, h->send_cap, (size_t)total); if (rc != TBNAV_OK) return rc; }
     pl.send_offs.assign(pl.sends.size() + 1, 0);
-    { const int rc = tbnav_rbpf_export_batch_dev(h, (int32_t)pl.sends.size(), pl.send_slots.data(), h->d_sendbuf, total, pl.send_offs.data()); if (rc != TBNAV_OK) return rc; }
+    if (lerr[r] == TBNAV_OK) note(r, grow(h->d_sendbuf, h->send_cap, (size_t)total));
+    if (lerr[r] == TBNAV_OK) note(r, tbnav_rbpf_export_batch_dev(h, (int32_t)pl.sends.size(), pl.send_slots.data(), h->d_sendbuf, total, pl.send_offs.data()));
     for (size_t i = 0; i < pl.sends.size();) {  // one message per destination
       size_t j = i;
       while (j < pl.sends.size() && pl.sends[j].first == pl.sends[i].first) ++j;
@@ -5381,7 +5397,7 @@ int sharded_scan(int n, tbnav_rbpf* const* hs, const float* scan, int n_beams, c
     // everything it receives: one buffer, the blobs in (source, particle) order
     recv_offs[r].assign(pl.recvs.size() + 1, 0);
     for (size_t i = 0; i < pl.recvs.size(); ++i) recv_offs[r][i + 1] = recv_offs[r][i] + sizes_all[pl.recvs[i].second];
-    { const int rc = grow(h->d_recvbuf, h->recv_cap, (size_t)recv_offs[r].back()); if (rc != TBNAV_OK) return rc; }
+    if (lerr[r] == TBNAV_OK) note(r, grow(h->d_recvbuf, h->recv_cap, (size_t)recv_offs[r].back()));
     for (size_t i = 0; i < pl.recvs.size();) {
       size_t j = i;
       while (j < pl.recvs.size() && pl.recvs[j].first == pl.recvs[i].first) ++j;
@@ -5389,6 +5405,10 @@ int sharded_scan(int n, tbnav_rbpf* const* hs, const float* scan, int n_beams, c
       i = j;
     }
   }
+  // is every rank ready to send what the sizes promised and to receive it?  A rank whose export or allocation failed cannot
+  // honour its messages (its peers would wait for bytes that never come): agree BEFORE the exchange; nobody has touched a slot yet
+  { const int rc = agree(lerr, status); if (rc != TBNAV_OK) return rc; }
+  if (status != TBNAV_OK) { out->status = status; return status; }
   { const int rc = tbnav::comm_exchange(n, comms.data(), p_send.data(), p_recv.data(), s1.data()); if (rc != TBNAV_OK) return rc; }
   // local parents inside the handle (tile tables + reference counts), then the imported ones; weights are NOT reset by the
   // reference: every slot carries its parent's normalised weight
@@ -5415,24 +5435,10 @@ int sharded_scan(int n, tbnav_rbpf* const* hs, const float* scan, int n_beams, c
       rc = tbnav_rbpf_import_batch_dev(h, (int32_t)imp_slots.size(), imp_slots.data(), h->d_recvbuf, recv_offs[r].back(), imp_offs.data());
     if (rc == TBNAV_OK) rc = tbnav_rbpf_set_weights_from_global_dev(h, parents.data() + lo);
     mstat[r] = rc;
-    TBNAV_HIP(hipMemcpyAsync(h->d_status, &mstat[r], sizeof(int), hipMemcpyHostToDevice, h->stream));
   }
   // a rank that failed (tile pool exhausted) must not leave the others waiting in the next scan's collective: agree on it
-  {
-    std::vector<const void*> send(n);
-    std::vector<void*> recv(n);
-    for (int r = 0; r < n; ++r) { send[r] = hs[r]->d_status; recv[r] = hs[r]->d_status + 1; }
-    const int rc = tbnav::comm_all_gather(n, comms.data(), send.data(), recv.data(), sizeof(int), s1.data());
-    if (rc != TBNAV_OK) return rc;
-  }
-  for (int r = 0; r < n; ++r) {
-    tbnav_rbpf* h = hs[r];
-    DeviceGuard guard(h->device);
-    std::vector<int> all(P);
-    TBNAV_HIP(hipMemcpyAsync(all.data(), h->d_status + 1, sizeof(int) * P, hipMemcpyDeviceToHost, h->stream));
-    TBNAV_HIP(hipStreamSynchronize(h->stream));
-    for (int q = 0; q < P; ++q) if (all[q] != TBNAV_OK && status == TBNAV_OK) status = all[q];
-  }
+  { const int rc = agree(mstat, status); if (rc != TBNAV_OK) return rc; }
+#undef TBNAV_L
   out->status = status;
   return status;
 }

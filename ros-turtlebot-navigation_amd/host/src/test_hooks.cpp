@@ -150,6 +150,15 @@ int hst_mppi_closed_loop(const double* params, int rollouts, uint64_t seed, cons
 // exchange by copies instead of RCCL — same records, same layout, same stream order); 0 / 1 = the reference's nine arguments
 static int g_mppi_gpus = 1;
 void hst_mppi_gpus(int n) { g_mppi_gpus = n < 1 ? 1 : n; }
+// on: the members of the next n_gpus > 1 object go on devices 0, 1, ... n-1 (a multi-GPU box: RCCL / peer stores between them)
+// instead of device 0 n times
+static int g_distinct_devices = 0;
+void hst_distinct_devices(int on) { g_distinct_devices = on ? 1 : 0; }
+static std::vector<int> member_devices(int n) {
+  std::vector<int> d(n > 1 ? n : 0, 0);
+  if (g_distinct_devices) for (int i = 0; i < (int)d.size(); ++i) d[i] = i;
+  return d;
+}
 // One MPPI tick through the class with the host twister seeded: returns (ul, ur) and u[2][T].
 int hst_mppi_tick(const double* params, int rollouts, uint64_t seed, const double wpt[3] /*x,y,theta*/, const double pose[3] /*theta,x,y*/,
                   int n_ticks, double* out_ul_ur, double* u_out) {
@@ -157,7 +166,7 @@ int hst_mppi_tick(const double* params, int rollouts, uint64_t seed, const doubl
     controller::CartModel cart(params[0], params[1]);
     controller::LossFunc loss({params[8], params[9], params[10]}, {params[11], params[12]}, {params[13], params[14], params[15]});
     controller::MPPI mppi(cart, loss, params[2], params[3], params[4], params[5], params[6], params[7], rollouts, g_mppi_gpus,
-                          std::vector<int>(g_mppi_gpus > 1 ? g_mppi_gpus : 0, 0));
+                          member_devices(g_mppi_gpus));
     rigid2d::getTwister().seed(seed);
     rigid2d::Pose w; w.x = wpt[0]; w.y = wpt[1]; w.theta = wpt[2];
     mppi.setWaypoint(w);
@@ -194,7 +203,7 @@ int hst_pf_run(int N, int k, double map_half, uint64_t seed, const float* scans,
     aligner.setMatcher([&](Transform2D& T, const Transform2D&, const std::vector<float>&, const std::vector<float>&) { T = icp_result; return true; });
     Transform2D start(Vector2D(odom[1], odom[2]), odom[0]);
     bmapping::ParticleFilter pf(N, k, 0.1, 0.2, 0.1, 0.2, 1e-10, 1e-10, 1e-10, 1e-10, 1e-8, 1e-8, 1.0, 20.0, 1.0, 10.0, aligner, start, grid,
-                                g_pf_gpus, std::vector<int>(g_pf_gpus > 1 ? g_pf_gpus : 0, 0));
+                                g_pf_gpus, member_devices(g_pf_gpus));
     if (g_pf_gpus == 1 && pf.referenceDistanceField() != true) throw std::runtime_error("the class's default is the reference's distance field");
     if (!g_pf_reference_field) pf.useExactDistanceField();
     bmapping::getTwister().seed(seed);

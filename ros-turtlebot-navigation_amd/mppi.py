@@ -163,6 +163,19 @@ class MPPI:
                    "profile_kernels")
         return ms[0], ms[1], ms[2]
 
+    def profileKernelsRng(self, x0, seed: int, tick: int, stream: int = 0, reps: int = 100):
+        """The same for the production tick: the fused kernel's in-kernel-noise instantiation where that is what the tick runs."""
+        ms = (C.c_float * 3)()
+        capi.check(self._L.tbnav_mppi_profile_kernels_rng(self._h, (C.c_double * 3)(*x0), seed, tick, stream or None, reps, ms),
+                   "profile_kernels_rng")
+        return ms[0], ms[1], ms[2]
+
+    def lastKernelNames(self):
+        """(rollout, combine): the instantiations the last launches were, as rocprofv3 prints them."""
+        a, b = C.create_string_buffer(96), C.create_string_buffer(96)
+        capi.check(self._L.tbnav_mppi_last_kernel_names(self._h, a, 96, b, 96), "last_kernel_names")
+        return a.value.decode(), b.value.decode()
+
     def lastControls(self, stream: int = 0):
         out = (C.c_double * 2)()
         capi.check(self._L.tbnav_mppi_last_controls(self._h, stream or None, out), "last_controls")

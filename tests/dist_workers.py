@@ -23,15 +23,16 @@ def _init(rank, world, port, backend="gloo"):
     return dist
 
 
-def run_spawn(fn, world, *args, backend="gloo"):
-    """Spawn `world` processes running fn(rank, world, *args) under a `backend` process group; returns {rank: result}."""
+def run_spawn(fn, world, *args, backend="gloo", transport="ipc"):
+    """Spawn `world` processes running fn(rank, world, *args) under a `backend` process group; returns {rank: result}.
+    transport: what _ipc_comm() builds in the workers ("ipc": all ranks on device 0; "rccl": rank r on device r)."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     mgr = ctx.Manager()
     res = mgr.dict()
-    procs = [ctx.Process(target=_guard, args=(fn, r, world, port, res, backend) + args) for r in range(world)]
+    procs = [ctx.Process(target=_guard, args=(fn, r, world, port, res, backend, transport) + args) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -46,7 +47,9 @@ def run_spawn(fn, world, *args, backend="gloo"):
     return out
 
 
-def _guard(fn, rank, world, port, res, backend, *args):
+def _guard(fn, rank, world, port, res, backend, transport, *args):
+    global _TRANSPORT
+    _TRANSPORT = transport
     try:
         dist = _init(rank, world, port, backend)
         res[rank] = fn(rank, world, *args)
@@ -241,12 +244,24 @@ def rbpf_hip_worker(rank, world, n_local, k, skew_scan, heavy=None, df_inject=Fa
 # (tbnav_comm_unique_id_ipc; rank 0's id travels over this job's gloo group).  Everything above the transport — attach, the
 # rank's offsets into the gather buffers and the noise counter space, the status agreement, the migration plan — is the code
 # the RCCL job runs.
+_TRANSPORT = "ipc"   # "rccl": one DEVICE per rank (rank r on device r) over the library's RCCL communicator — tests/test_multi_device_gpu.py
+
+
 def _ipc_comm():
+    """This rank's communicator: the IPC transport with every rank on device 0 (the one-GPU box), or — when the spawning test
+    set transport="rccl" — RCCL with rank r on device r."""
     import __graft_entry__ as g
     g.load_package()
     import torch
-    torch.cuda.set_device(0)
+    import torch.distributed as dist
     from rtn_amd.comm import Comm
+    if _TRANSPORT == "rccl":
+        dev = dist.get_rank()
+        torch.cuda.set_device(dev)
+        comm = Comm.from_torch_distributed(dev, transport="rccl")
+        assert comm.uses_rccl is True and comm.device == dev
+        return comm
+    torch.cuda.set_device(0)
     comm = Comm.from_torch_distributed(0, transport="ipc")
     assert comm.uses_rccl is False
     return comm
@@ -254,7 +269,7 @@ def _ipc_comm():
 
 def comm_selftest_worker(rank, world, nbytes):
     comm = _ipc_comm()
-    assert (comm.rank, comm.size, comm.device) == (rank, world, 0)
+    assert (comm.rank, comm.size, comm.device) == (rank, world, rank if _TRANSPORT == "rccl" else 0)
     comm.selftest(nbytes)   # one all-gather and one ring of point-to-point messages, checked on every rank
     comm.close()
     return True
