@@ -69,9 +69,9 @@ int tbnav_mppi_rollouts(const tbnav_mppi* h); /* K of this handle           */
  * mppi_rollout_fused with -n rollouts per workgroup (one wave per rollout, lanes over time, partial records formed
  * in the same launch; tbnav_mppi_shard_partials then folds those fine records into the K-slice records). */
 int tbnav_mppi_rollout_variant(const tbnav_mppi* h);
-/* Which form of the sequential (one lane per rollout) kernel a variant-0 handle launches: 0 = mppi_rollout_cost (general),
- * 1 = mppi_rollout_cost_reg (round 2: last losses in registers, the rest staged in LDS), 2 = mppi_rollout_prefix (round 3:
- * exclusive prefixes written as the rollout goes, exact suffix sums for the horizon's last steps). */
+/* Which form of the sequential (one lane per rollout) kernel a variant-0 handle launches: 0 = mppi_rollout_cost (general: any T,
+ * either dynamics), 2 = mppi_rollout_prefix (the streaming shape: exclusive prefixes written as the rollout goes, exact suffix
+ * sums for the horizon's last steps).  (1 was round 2's mppi_rollout_cost_reg, removed in round 4: superseded by the prefix form.) */
 int tbnav_mppi_streaming_form(const tbnav_mppi* h);
 
 /* Options (explicit setters; nothing in the library reads the environment).
@@ -83,10 +83,10 @@ int tbnav_mppi_streaming_form(const tbnav_mppi* h);
  *  TBNAV_MPPI_OPT_NO_LDS_STAGING  1 = mppi_rollout_cost stages every per-step loss through J (development).
  *  TBNAV_MPPI_OPT_KEEP_J   1 = the fused kernel also stores the cost-to-go J[T][K] (410 KB at K=1024, T=50) so that
  *                          tbnav_mppi_get_cost_to_go can return it; off by default — the update needs only the records.
- *  TBNAV_MPPI_OPT_REG_TAIL 0 = do not use mppi_rollout_cost_reg (losses of the last steps in registers) even where it applies.
+ *  TBNAV_MPPI_OPT_REG_TAIL (retired: the kernel it switched was removed in round 4; accepted and ignored.)
  *  TBNAV_MPPI_OPT_PREFIX_FORM 0 = do not use mppi_rollout_prefix (exclusive prefixes of the losses to J as the rollout goes, exact
  *                          suffix sums only for the horizon's last steps, J = total - prefix formed by the consumers) even where
- *                          it applies — the large-K default of round 3; the round-2 kernels stay for A-B runs. */
+ *                          it applies — the large-K default; mppi_rollout_cost is the general fallback. */
 enum { TBNAV_MPPI_OPT_KERNEL = 1, TBNAV_MPPI_OPT_TRIG = 2, TBNAV_MPPI_OPT_NO_LDS_STAGING = 3, TBNAV_MPPI_OPT_KEEP_J = 4, TBNAV_MPPI_OPT_REG_TAIL = 5,
        TBNAV_MPPI_OPT_BATCH_GRAPH = 6 /* 0: tbnav_mppi_enqueue_rng_batch launches every tick by itself instead of replaying a captured hipGraph of 100 */,
        TBNAV_MPPI_OPT_PREFIX_FORM = 7,

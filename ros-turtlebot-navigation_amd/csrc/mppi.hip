@@ -394,162 +394,6 @@ __global__ __launch_bounds__(kWave) void mppi_rollout_cost(RolloutArgs a,
   }
 }
 
-// Same rollout, for the shape that streams from HBM (K/64 >= 2 waves per CU-SIMD pair, T a multiple of 4): the losses
-// of the LAST 4*RG steps never leave the registers — they are the first ones the backward suffix sum consumes — and
-// the first T - 4*RG steps stage theirs in LDS, so that J is written exactly once and never re-read (the general
-// kernel above parks the steps that do not fit LDS in J itself: 1.19x the algorithmic traffic at K = 65536, T = 100).
-// With one wave per SIMD the register file is not a constraint (512 VGPRs): the noise of those last RG groups is
-// requested at kernel start and simply waits in registers, and the ring of the main loop runs kAheadR groups ahead.
-constexpr int kAheadR = 3;  // groups of noise in flight ahead of the one being integrated (12 steps ~ 6 us of rollout)
-template <int TRIG, int RG>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2)))
-void mppi_rollout_cost_reg(RolloutArgs a_in, const double* __restrict__ duL, const double* __restrict__ duR, USrc u, double* __restrict__ J) {
-  extern __shared__ __attribute__((aligned(16))) double lds_all[];
-  const int lane = threadIdx.x;
-  const int T = a_in.T, K = a_in.K;
-  double* u_lds = lds_all;                 // [2*T]
-  double* lds_loss = lds_all + 2 * T;      // [T - 4*RG][64]   (lds_from == 0)
-  for (int t = lane; t < 2 * T; t += kWave) u_lds[t] = u.get(t >= T, t >= T ? t - T : t, T);
-  // The rollout's constants live in VECTOR registers here: as kernel arguments they are ~40 scalar registers, and with
-  // the address arithmetic of the prefetch ring on top the scalar file spills (each spill is a v_readlane/v_writelane
-  // in the step loop).  A round trip through LDS makes them look lane-varying to the compiler; the vector file is
-  // nearly empty at one wave per SIMD.
-  __shared__ double consts[20];
-  if (lane == 0) {
-    consts[0] = a_in.half_r; consts[1] = a_in.r_over_b; consts[2] = a_in.r_d; consts[3] = a_in.h; consts[4] = a_in.h6;
-    for (int q = 0; q < 3; ++q) { consts[5 + q] = a_in.x0[q]; consts[8 + q] = a_in.xd[q]; consts[11 + q] = a_in.Q[q]; consts[16 + q] = a_in.P1[q]; }
-    consts[14] = a_in.R[0]; consts[15] = a_in.R[1];
-  }
-  __syncthreads();
-  RolloutArgs a;
-  a.half_r = consts[0]; a.r_over_b = consts[1]; a.r_d = consts[2]; a.h = consts[3]; a.h6 = consts[4];
-#pragma unroll
-  for (int q = 0; q < 3; ++q) { a.x0[q] = consts[5 + q]; a.xd[q] = consts[8 + q]; a.Q[q] = consts[11 + q]; a.P1[q] = consts[16 + q]; }
-  a.R[0] = consts[14]; a.R[1] = consts[15];
-  a.T = T; a.K = K; a.lds_from = 0;
-  const int k = blockIdx.x * kWave + lane;
-  if (k >= K) return;
-  double x = a.x0[0], y = a.x0[1], th = a.x0[2];
-  const int n_main = T / kGroup - RG;      // groups staged through LDS
-  const size_t gstride = (size_t)kGroup * K;  // elements between the same step of consecutive groups
-  const double* pl = duL + k;
-  const double* pr = duR + k;
-  double el[RG][kGroup], er[RG][kGroup];   // noise of the last RG groups: requested now, used at the end
-#pragma unroll
-  for (int j = 0; j < RG; ++j) {
-#pragma unroll
-    for (int q = 0; q < kGroup; ++q) {
-      const size_t off = (size_t)((n_main + j) * kGroup + q) * K;
-      el[j][q] = pl[off];
-      er[j][q] = pr[off];
-    }
-  }
-  double nl[kAheadR][kGroup], nr[kAheadR][kGroup];
-#pragma unroll
-  for (int r = 0; r < kAheadR; ++r) {
-    if (r < n_main) {
-#pragma unroll
-      for (int q = 0; q < kGroup; ++q) {
-        const size_t off = (size_t)(r * kGroup + q) * K;
-        nl[r][q] = pl[off];
-        nr[r][q] = pr[off];
-      }
-    }
-  }
-  // One round = kAheadR groups with NO branch between them (one scheduling region: the trig of a group overlaps the
-  // losses of the one before); PF: also request the noise of the round after next.
-  const double* nxl = pl + (size_t)kAheadR * gstride;  // noise of group g0 + kAheadR
-  const double* nxr = pr + (size_t)kAheadR * gstride;
-  int g0 = 0;
-  auto round = [&](auto pf) {
-#pragma unroll
-    for (int r = 0; r < kAheadR; ++r) {
-      double dl[kGroup], dr[kGroup];
-#pragma unroll
-      for (int q = 0; q < kGroup; ++q) { dl[q] = nl[r][q]; dr[q] = nr[r][q]; }
-      if constexpr (decltype(pf)::value) {
-#pragma unroll
-        for (int q = 0; q < kGroup; ++q) {
-          nl[r][q] = nxl[(size_t)r * gstride + (size_t)q * K];
-          nr[r][q] = nxr[(size_t)r * gstride + (size_t)q * K];
-        }
-      }
-      rollout_group<TRIG, kGroup, true>(a, (g0 + r) * kGroup, lane, k, x, y, th, dl, dr, u_lds, lds_loss, J);
-    }
-    nxl += (size_t)kAheadR * gstride;
-    nxr += (size_t)kAheadR * gstride;
-    g0 += kAheadR;
-  };
-  while (g0 + 2 * kAheadR <= n_main) round(std::integral_constant<bool, true>{});
-  if (g0 + kAheadR <= n_main && g0 + 2 * kAheadR > n_main) {
-    // the ring holds this round; of the next one only the first (n_main - g0 - kAheadR) groups exist: request those
-    const int rem = n_main - g0 - kAheadR;
-    double tl[kAheadR][kGroup], tr_[kAheadR][kGroup];
-#pragma unroll
-    for (int r = 0; r < kAheadR; ++r) {
-      if (r < rem) {
-#pragma unroll
-        for (int q = 0; q < kGroup; ++q) { tl[r][q] = nxl[(size_t)r * gstride + (size_t)q * K]; tr_[r][q] = nxr[(size_t)r * gstride + (size_t)q * K]; }
-      }
-    }
-    round(std::integral_constant<bool, false>{});
-#pragma unroll
-    for (int r = 0; r < kAheadR; ++r) {
-      if (r < rem) {
-#pragma unroll
-        for (int q = 0; q < kGroup; ++q) { nl[r][q] = tl[r][q]; nr[r][q] = tr_[r][q]; }
-      }
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < kAheadR; ++r) {   // fewer than kAheadR groups left (their noise is in the ring)
-    if (g0 + r < n_main) rollout_group<TRIG, kGroup, true>(a, (g0 + r) * kGroup, lane, k, x, y, th, nl[r], nr[r], u_lds, lds_loss, J);
-  }
-  double lreg[RG][kGroup];
-#pragma unroll
-  for (int j = 0; j < RG; ++j)
-    rollout_group<TRIG, kGroup, true>(a, (n_main + j) * kGroup, lane, k, x, y, th, el[j], er[j], u_lds, lds_loss, J, lreg[j]);
-  // cumSumCost (mppi.cpp:15-25): J(i) = loss(i) + J(i+1), from the end: registers first, then LDS eight at a time
-  double* Jk = J + k;
-  double acc = 0.0;
-#pragma unroll
-  for (int j = RG - 1; j >= 0; --j) {
-#pragma unroll
-    for (int q = kGroup - 1; q >= 0; --q) {
-      const int i = (n_main + j) * kGroup + q;
-      acc = (j == RG - 1 && q == kGroup - 1) ? lreg[j][q] : lreg[j][q] + acc;   // the last step starts the sum
-      Jk[(size_t)i * K] = acc;
-    }
-  }
-  constexpr int kB = 8;
-  int i = n_main * kGroup - 1;
-  double cur[kB], nxt[kB];
-  if (i >= kB - 1) {
-#pragma unroll
-    for (int q = 0; q < kB; ++q) cur[q] = lds_loss[(i - q) * kWave + lane];
-  }
-  for (; i >= kB - 1; i -= kB) {
-    const bool more = (i - kB) >= kB - 1;
-    if (more) {
-#pragma unroll
-      for (int q = 0; q < kB; ++q) nxt[q] = lds_loss[(i - kB - q) * kWave + lane];
-    }
-#pragma unroll
-    for (int q = 0; q < kB; ++q) {
-      acc = cur[q] + acc;
-      Jk[(size_t)(i - q) * K] = acc;
-    }
-    if (more) {
-#pragma unroll
-      for (int q = 0; q < kB; ++q) cur[q] = nxt[q];
-    }
-  }
-  for (; i >= 0; --i) {
-    acc = lds_loss[i * kWave + lane] + acc;
-    Jk[(size_t)i * K] = acc;
-  }
-}
-
 // ---- streaming rollout, prefix form (round 3; the large-K default) --------------------------------------------------
 // What held mppi_rollout_cost_reg at 46 us (K = 65536, T = 100: ONE wave per SIMD — 1024 one-wave workgroups on 1024 SIMDs, so
 // all latency hiding has to come from inside the wave): (1) small_sincos's wave-uniform `if (__any(big))` sat in EVERY step and
@@ -1516,7 +1360,6 @@ struct tbnav_mppi {
   uint64_t* d_tick0 = nullptr;
   uint64_t tg_dev_tick = ~0ull;  // what *d_tick0 holds once everything enqueued so far has run (each replay's last node adds the chunk)
   int lds_from = 0;           // first time step whose loss is staged in LDS (0 = all of them)
-  int reg_groups = 0;         // > 0: mppi_rollout_cost_reg keeps the losses of the last 4*reg_groups steps in registers
   int prefix_rg = 0;          // > 0: mppi_rollout_prefix (the large-K default): exact suffix sums for the last 4*prefix_rg steps, exclusive prefixes before
   int prefix_rows = 0;        // rows of d_J that hold exclusive prefixes after the LAST rollout launch (0: every row is J)
   double* d_total = nullptr;  // [K] whole cost of every rollout (mppi_rollout_prefix)
@@ -1610,21 +1453,6 @@ int launch_rollout(tbnav_mppi* h, const double x0[3], const double* d_duL, const
       return TBNAV_OK;
     }
     h->prefix_rows = 0;
-    if (h->reg_groups > 0 && h->dyn == 0 && h->trig == 1) {
-      const size_t ldsr = (size_t)2 * h->T * sizeof(double) + (size_t)(h->T - kGroup * h->reg_groups) * kWave * sizeof(double);
-      a.lds_from = 0;
-      h->lk_rollout[0] = 5; h->lk_rollout[1] = 1; h->lk_rollout[2] = (h->reg_groups == 2 || h->reg_groups == 4 || h->reg_groups == 6 || h->reg_groups == 7) ? h->reg_groups : 8;
-      switch (h->reg_groups) {
-        case 2: hipLaunchKernelGGL((mppi_rollout_cost_reg<1, 2>), grid, block, ldsr, st, a, d_duL, d_duR, usrc, h->d_J); break;
-        case 4: hipLaunchKernelGGL((mppi_rollout_cost_reg<1, 4>), grid, block, ldsr, st, a, d_duL, d_duR, usrc, h->d_J); break;
-        case 6: hipLaunchKernelGGL((mppi_rollout_cost_reg<1, 6>), grid, block, ldsr, st, a, d_duL, d_duR, usrc, h->d_J); break;
-        case 7: hipLaunchKernelGGL((mppi_rollout_cost_reg<1, 7>), grid, block, ldsr, st, a, d_duL, d_duR, usrc, h->d_J); break;
-        default: hipLaunchKernelGGL((mppi_rollout_cost_reg<1, 8>), grid, block, ldsr, st, a, d_duL, d_duR, usrc, h->d_J); break;
-      }
-      TBNAV_HIP(hipGetLastError());
-      h->j_valid = true;
-      return TBNAV_OK;
-    }
     const size_t lds = (size_t)2 * h->T * sizeof(double) + (size_t)(h->T - h->lds_from) * kWave * sizeof(double);
     a.lds_from = h->lds_from;
     h->lk_rollout[0] = 4; h->lk_rollout[1] = h->dyn == 1 ? 4 : (h->trig >= 1 && h->trig <= 2 ? h->trig : 3);
@@ -1805,17 +1633,6 @@ int tbnav_mppi_create(const tbnav_mppi_params* params, tbnav_mppi** out) {
     h->lds_from = T - (int)steps_in_lds;
     h->lds_from = ((h->lds_from + 3) / 4) * 4;  // whole groups of 4 steps switch staging together
     if (h->lds_from > T) h->lds_from = T;
-    // the steps that do not fit LDS: in registers instead of through J, when they are few enough (<= 32) and the grid is
-    // the one-wave-per-SIMD shape that kernel is written for (also when everything fits LDS: its branch-free rounds are
-    // the faster loop either way)
-    if (h->lds_from <= 32 && T % 4 == 0 && T >= 12 && blocks >= 2 * cus) {
-      // the smallest instantiated count that covers them, preferring one that leaves a whole number of rounds of
-      // kAheadR groups for the branch-free main loop
-      const int need = h->lds_from / 4;
-      int pick = 0;
-      for (int rg : {2, 4, 6, 7, 8}) if (rg >= need && T / 4 - rg >= 1) { if (!pick) pick = rg; if ((T / 4 - rg) % kAheadR == 0) { pick = rg; break; } }
-      h->reg_groups = pick;
-    }
     // round 3: the prefix-form kernel takes the streaming shape whenever a late region of 1, 2 or 3 groups leaves whole rounds
     // of three groups (one of the three always does) and at least one round — whatever T: it stages nothing in LDS
     if (T % 4 == 0 && blocks >= 2 * cus)
@@ -1893,11 +1710,6 @@ int tbnav_mppi_create(const tbnav_mppi_params* params, tbnav_mppi** out) {
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mppi_rollout_cost<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     if (e == hipSuccess)
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mppi_rollout_cost<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mppi_rollout_cost_reg<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mppi_rollout_cost_reg<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mppi_rollout_cost_reg<1, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mppi_rollout_cost_reg<1, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mppi_rollout_cost_reg<1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
   }
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) {
@@ -1967,10 +1779,9 @@ int tbnav_mppi_set_option(tbnav_mppi* h, int32_t option, int32_t value) {
       h->trig = value;
       return TBNAV_OK;
     case TBNAV_MPPI_OPT_NO_LDS_STAGING:
-      if (value) { h->lds_from = T; h->reg_groups = 0; h->prefix_rg = 0; }
+      if (value) { h->lds_from = T; h->prefix_rg = 0; }
       return TBNAV_OK;
-    case TBNAV_MPPI_OPT_REG_TAIL:
-      if (!value) h->reg_groups = 0;
+    case TBNAV_MPPI_OPT_REG_TAIL:   // (the round-2 kernel this switched is gone — mppi_rollout_prefix superseded it; accepted and ignored)
       return TBNAV_OK;
     case TBNAV_MPPI_OPT_PREFIX_FORM:
       if (!value) h->prefix_rg = 0;
@@ -2021,7 +1832,7 @@ int tbnav_mppi_set_rng_shard(tbnav_mppi* h, uint64_t first_rollout, uint64_t rol
 int tbnav_mppi_rollout_variant(const tbnav_mppi* h) { return h ? (h->fused_dev ? -h->fused_r : h->scan_tc) : 0; }
 int tbnav_mppi_streaming_form(const tbnav_mppi* h) {
   if (!h) return -1;
-  return (h->dyn == 0 && h->trig == 1) ? (h->prefix_rg > 0 ? 2 : (h->reg_groups > 0 ? 1 : 0)) : 0;
+  return (h->dyn == 0 && h->trig == 1 && h->prefix_rg > 0) ? 2 : 0;
 }
 int64_t tbnav_mppi_graph_replayed_ticks(const tbnav_mppi* h) { return h ? (int64_t)h->graph_ticks : -1; }
 int tbnav_mppi_rollouts(const tbnav_mppi* h) { return h ? h->K : -1; }
@@ -2233,7 +2044,6 @@ int tbnav_mppi_last_kernel_names(const tbnav_mppi* h, char* rollout, int32_t rol
       case 2: snprintf(rollout, (size_t)rollout_cap, "mppi_rollout_scan<%d, %d, %d>", k[1], k[2], k[3]); break;
       case 3: snprintf(rollout, (size_t)rollout_cap, "mppi_rollout_prefix<%d>", k[1]); break;
       case 4: snprintf(rollout, (size_t)rollout_cap, "mppi_rollout_cost<%d>", k[1]); break;
-      case 5: snprintf(rollout, (size_t)rollout_cap, "mppi_rollout_cost_reg<%d, %d>", k[1], k[2]); break;
       default: rollout[0] = 0;
     }
   }
@@ -2445,7 +2255,8 @@ int tbnav_mppi_get_cost_to_go(tbnav_mppi* h, double* J_host) {
     std::vector<double> tot((size_t)h->K);
     TBNAV_HIP(hipMemcpy(tot.data(), h->d_total, tot.size() * sizeof(double), hipMemcpyDeviceToHost));
     for (int i = 0; i < h->prefix_rows; ++i)
-      for (int k = 0; k < h->K; ++k) J_host[(size_t)i * h->K + k] = tot[k] - J_host[(size_t)i * h->K + k];
+      for (int k = 0; k < h->K; ++k)   // (a total that overflowed: +inf on every row, as mppi_partials reads it)
+        J_host[(size_t)i * h->K + k] = std::isinf(tot[k]) ? tot[k] : tot[k] - J_host[(size_t)i * h->K + k];
   }
   return TBNAV_OK;
 }

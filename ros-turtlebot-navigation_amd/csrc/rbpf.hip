@@ -290,6 +290,11 @@ template <class Op> __device__ __forceinline__ double wave_reduce_dpp_d(double v
 __device__ __forceinline__ double wave_max_d(double v) { return wave_reduce_dpp_d(v, -1.0e300, [](double a, double b) { return fmax(a, b); }); }
 __device__ __forceinline__ double wave_sum_d(double v) { return wave_reduce_dpp_d(v, 0.0, [](double a, double b) { return a + b; }); }
 __device__ __forceinline__ double wave_prod(double v) { return wave_reduce_dpp_d(v, 1.0, [](double a, double b) { return a * b; }); }
+// A value every lane of the workgroup holds alike (the particle's pose, what is derived from it): into scalar registers — the
+// proposal kernel lives at its 128-VGPR ceiling, and these are a dozen doubles that stay live across its phases.
+__device__ __forceinline__ double uniform_d(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
 
 // GridMapper::likelihoodFieldModel for ONE pose, evaluated by one wave (lanes stride the valid beams).
 // beams[b] = (r*cos a_b, r*sin a_b) in the sensor frame, built on the host exactly as
@@ -526,7 +531,8 @@ __device__ __forceinline__ double wave_scan_likelihood(const ScanC& c, const dou
 }
 
 // particle_filter.cpp:383-437 (odometry part precomputed on the host: rot1, trans, rot2)
-__device__ __forceinline__ double pose_likelihood_odom(const ScanC& c, const double* cur, const double* prev, int* var_err) {
+// nrot1 / nrot2: normalize_angle_PI(c.rot1) / (c.rot2), particle- and sample-independent (the caller keeps them in scalar registers)
+__device__ __forceinline__ double pose_likelihood_odom(const ScanC& c, const double* cur, const double* prev, int* var_err, double nrot1, double nrot2) {
   const double rot1_hat = atan2(cur[2] - prev[2], cur[1] - prev[1]) - prev[0];
   const double dx = cur[1] - prev[1], dy = cur[2] - prev[2];
   const double trans_hat = sqrt(dx * dx + dy * dy);
@@ -535,9 +541,9 @@ __device__ __forceinline__ double pose_likelihood_odom(const ScanC& c, const dou
   const double temp2 = c.a3 * trans_hat * trans_hat + c.a4 * rot1_hat * rot1_hat + c.a4 * rot2_hat * rot2_hat;
   const double temp3 = c.a1 * rot2_hat * rot2_hat + c.a2 * trans_hat * trans_hat;
   if (almost_equal(temp1, 0.0) || almost_equal(temp2, 0.0) || almost_equal(temp3, 0.0)) { *var_err = 1; return 0.0; }
-  const double p1 = pdf_normal(normalize_angle_PI(normalize_angle_PI(c.rot1) - normalize_angle_PI(rot1_hat)), temp1);
+  const double p1 = pdf_normal(normalize_angle_PI(nrot1 - normalize_angle_PI(rot1_hat)), temp1);
   const double p2 = pdf_normal(c.trans - trans_hat, temp2);
-  const double p3 = pdf_normal(normalize_angle_PI(normalize_angle_PI(c.rot2) - normalize_angle_PI(rot2_hat)), temp3);
+  const double p3 = pdf_normal(normalize_angle_PI(nrot2 - normalize_angle_PI(rot2_hat)), temp3);
   return p1 * p2 * p3;
 }
 
@@ -790,7 +796,62 @@ __global__ __launch_bounds__(kMatchThreads) void rbpf_scanmatch(ScanC c, ScanMat
   if (tid == 0) { center[p * 3 + 0] = cur[0]; center[p * 3 + 1] = cur[1]; center[p * 3 + 2] = cur[2]; score[p] = best; }
 }
 
+// The 7 x 7 look of the query mode (or a read of the stored field) and nothing else: the code (>= 0), -1 = a windowed lookup
+// outside the refreshed window, kNeedSearch = the query mode's answer needs the row walks (nearest_code_query_body).  The
+// proposal kernel defers those to a phase of their own — ONE inlined copy of the search per phase, run by all threads over the
+// marked entries — instead of calling an out-of-line copy from inside its lookup loops (round 3: seven call sites, 224 B of
+// scratch per lane for the saves and restores round them).
+constexpr int kNeedSearch = -2;
+__device__ __forceinline__ int lookup_code_fast(const GridC& g, const DistSrc& d, int radius, int ci, int cj) {
+  if (d.mode == 2) {
+    if (d.nW > 0 && d.lut7) {
+      const int C0 = d.W0 * 64, C1 = (d.W0 + d.nW) * 64 - 1;
+      const int p0 = cj - C0 - 3, wi = p0 >> 5;
+      if (ci - 3 >= d.R0 && ci + 3 <= d.R1 && p0 >= 0 && wi + 1 < 2 * d.nW && cj <= C1) {
+        int clear = radius + 1;
+        if (d.R0 > 0) clear = min(clear, ci - d.R0 + 1);
+        if (d.R1 < g.xsize - 1) clear = min(clear, d.R1 - ci + 1);
+        if (C0 > 0) clear = min(clear, cj - C0 + 1);
+        if (C1 < g.ysize - 1) clear = min(clear, C1 - cj + 1);
+        const unsigned int* t32 = reinterpret_cast<const unsigned int*>(d.tbm) + wi;
+        const int sh = p0 & 31, stride = 2 * d.nW;
+        int bw = 0x7fffffff;
+#pragma unroll
+        for (int dr = -3; dr <= 3; ++dr) {
+          const unsigned int* rp = t32 + (ci + dr - d.R0) * stride;
+          const unsigned int pat = __builtin_amdgcn_alignbit(rp[1], rp[0], sh) & 0x7Fu;
+          bw = min(bw, dr * dr + (int)d.lut7[pat]);
+        }
+        if (bw <= 9 && bw <= clear * clear) return bw;
+      }
+    }
+    return kNeedSearch;
+  }
+  if (d.mode == 1 && (ci < d.win.x || ci > d.win.y || cj < d.win.z || cj > d.win.w)) return -1;
+  return d.code[(size_t)ci * g.xsize + cj];
+}
+
 // err[0] = out of world, err[1] = eta zero, err[2] = pdf variance zero, err[3] = bresenham
+//
+// One workgroup per particle (particle_filter.cpp:158-231).  Round 4's schedule — six barriers on the usual path, nine before:
+//   0. every thread: pose / table / beams requested together; the sensor transform at the centre of the samples, T(pose) * T_icp;
+//      the slice of the occupancy bitmap within reach of the sensor staged in LDS (two round trips: table entries, then rows)
+//   1. wave 0: the k samples, their sensor transforms, how far any of them is from the centre, and — same lanes, no barrier in
+//      between — the odometry likelihood of every sample (:542);
+//      the OTHER waves, beside it: ONE lookup per beam at the centre (cell, code, mixture term) and the distance of the centre's
+//      end point from the nearest border of its cell.  (Round 3 ran the samples first, a barrier, then the two side by side.)
+//   2. [only if a lookup could not be settled by the 7 x 7 look] every thread: the full nearest-obstacle search for those beams
+//   3. wave 0: a beam is STABLE if that distance exceeds what the samples' spread can move an end point
+//          |e_j - e_c|_inf <= max_j |T_j - T_c|_inf + |beam| * max_j |theta_j - theta_c|   (chord <= arc)  + 1e-9 m:
+//      every sample then sees the beam in the centre's cell, i.e. with the centre's term — the k x Bv evaluations of the
+//      reference (grid_mapper.cpp:100-121 from particle_filter.cpp:541) collapse to Bv + (k x the few unstable beams); the
+//      product over the stable beams and the list of the unstable ones, in beam order
+//   4. every thread: one (sample, unstable beam) pair each, kUnCap unstable beams at a time (any number of them: chunks);
+//      [rarely: the full search for pairs that need it]; each sample's thread multiplies its terms in beam order, clamps,
+//      forms likelihoods.at(j) and writes the trace
+//   5. wave 0 alone: the weighted sums, the 3 x 3 LLT, the new pose, weight *= eta (:545-599, :214-231)
+// The ICP-failed branch (:161-176) is steps 0, 1 (every wave looks beams up, at the moved pose), 2 and a product.
+// Same cells, same terms as the reference's brute force; only the ORDER of the products / sums differs (asserted <= 1e-9).
 template <int NT>
 __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c, const double2* __restrict__ beams,
                                                                 const uint16_t* __restrict__ codes,
@@ -812,14 +873,18 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
   double* smp = lds;               // [k][3]
   double* pscan = lds + 3 * k;     // [k]
   double* ppose = lds + 4 * k;     // [k]
-  double* stf = lds + 5 * k;       // [k][4] sensor transform of sample j; later reused as wj[k] | op[k][6]
-  double* fac = lds + 12 * k;      // [k][kUnCap] per-(sample, unstable beam) terms
+  double* stf = lds + 5 * k;       // [k][4] sensor transform of sample j; later reused as wj[k]
+  double* fac = lds + 12 * k;      // [k][kUnCap] per-(sample, unstable beam) terms of one chunk of unstable beams
   double2* lbeams = reinterpret_cast<double2*>(lds + (12 + kUnCap) * k);  // [Bv] the scan, staged: every later read is an LDS read
   double* cpz = lds + (12 + kUnCap) * k + 2 * c.Bv;  // [Bv] mixture term of beam b at the samples' centre
-  unsigned int* ctag = reinterpret_cast<unsigned int*>(cpz + c.Bv);  // [Bv] the code it was computed for (0xFFFFFFFF = none)
-  unsigned int* ccell = ctag + c.Bv;                                 // [Bv] the cell that code was looked up at
-  int* unst = reinterpret_cast<int*>(ccell + c.Bv);                  // [Bv] 1 = some sample may see the beam in another cell
-  int* ulist = unst + c.Bv;                                          // [<= Bv] those beams, ascending
+  unsigned int* ctag = reinterpret_cast<unsigned int*>(cpz + c.Bv);  // [Bv] the code it was computed for, or one of kTag*
+  unsigned int* ccell = ctag + c.Bv;                                 // [Bv] the cell that code was looked up at (0xFFFFFFFF: none)
+  float* marg = reinterpret_cast<float*>(ccell + c.Bv);              // [Bv] distance of the centre's end point from its cell's nearest border, rounded DOWN (-1: no code)
+  int* ulist = reinterpret_cast<int*>(marg + c.Bv);                  // [<= Bv] the unstable beams, ascending
+  constexpr unsigned int kTagNone = 0xFFFFFFFFu;    // a windowed lookup outside the window
+  constexpr unsigned int kTagSearch = 0xFFFFFFFEu;  // query mode: the 7 x 7 look did not settle it — step 2
+  constexpr unsigned int kTagOut = 0xFFFFFFFDu;     // the end point is outside the world
+  constexpr unsigned int kBoxHi = 0x7FF8C0DEu;      // high word of a NaN that carries a cell index: a pair term waiting for step 4's search
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
   const uint16_t* code = codes ? codes + (size_t)p * c.g.xsize * c.g.ysize : nullptr;  // NULL: no stored field (query mode)
   const double* z = normals + (size_t)p * c.stride_normals;
@@ -831,14 +896,19 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
   DistSrc ds{code, occ_of(P, M, trow_occ, p), win[p], skip[p] == skip_eq ? 0 : df_mode,
              tile_bm, reinterpret_cast<const int*>(tile_bm), 0, 0, 0, 0};
   int oob = 0;
+  __shared__ int sh_def[2];  // [0] beams, [1] pairs whose lookup needs the full search (counts that only grow)
+  if (tid == 0) { sh_def[0] = 0; sh_def[1] = 0; }
 
-  // ---- sample k poses round T(pose) * T_icp (particle_filter.cpp:181-188, :504-519), score the odometry
-  //      likelihood of each (:542) and derive its sensor transform: one thread per sample
-#ifdef TBNAV_PHASE_PROF
-  unsigned long long t_prev_ = wall_clock64();
-#endif
+  // ---- 0. loads, the centre of the samples, the LDS slice of the occupancy bitmap
   WGP_IN();
-  const double th0 = pose[p * 3 + 0], x0 = pose[p * 3 + 1], y0 = pose[p * 3 + 2];
+  const double th0v = pose[p * 3 + 0], x0v = pose[p * 3 + 1], y0v = pose[p * 3 + 2];
+  const double pv0 = prev_pose[p * 3 + 0], pv1 = prev_pose[p * 3 + 1], pv2 = prev_pose[p * 3 + 2];
+  // (requested WITH the pose, used much later: the first 64 samples' normals by wave 0, the new pose's three normals and the
+  //  particle's weight by the last step — each was a dependent round trip on the workgroup's critical path)
+  double zj0 = 0.0, zj1 = 0.0, zj2 = 0.0;   // sample tid's normals (samples beyond the workgroup's size load theirs in step 1)
+  if (c.icp_ok && tid < k) { zj0 = z[3 * tid + 0]; zj1 = z[3 * tid + 1]; zj2 = z[3 * tid + 2]; }
+  double zz0 = 0.0, zz1 = 0.0, zz2 = 0.0, w_old = 0.0;
+  if (c.icp_ok && wid == 0) { zz0 = z[3 * k + 0]; zz1 = z[3 * k + 1]; zz2 = z[3 * k + 2]; w_old = weight[p]; }
   // (a table of at most NT entries — maps up to 512 x 512 cells at 256 threads — is requested WHOLE here, with the pose: which
   //  entries the window needs depends on the pose, and waiting for it made the staging below three dependent round trips)
   const int tt_all = ds.occ.TW * ds.occ.TW;
@@ -846,6 +916,7 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
   unsigned int my_id = 0u;
   if (whole_table && tid < tt_all) my_id = ds.occ.tab[tid];
   TRACE_P(0);
+  const double th0 = uniform_d(th0v), x0 = uniform_d(x0v), y0 = uniform_d(y0v);
   double mu0[3];
   if (!c.icp_ok) {
     // ICP failed: the pose moves by the odometry motion model (particle_filter.cpp:161-176, :295-322) — every thread works it
@@ -869,12 +940,18 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
     mu0[1] = center ? center[p * 3 + 1] : c0 * c.Ticp[1] - s0 * c.Ticp[2] + x0;
     mu0[2] = center ? center[p * 3 + 2] : s0 * c.Ticp[1] + c0 * c.Ticp[2] + y0;
   }
-  const double pv[3] = {prev_pose[p * 3 + 0], prev_pose[p * 3 + 1], prev_pose[p * 3 + 2]};
+  mu0[0] = uniform_d(mu0[0]); mu0[1] = uniform_d(mu0[1]); mu0[2] = uniform_d(mu0[2]);
+  const double pv[3] = {uniform_d(pv0), uniform_d(pv1), uniform_d(pv2)};
   for (int b = tid; b < c.Bv; b += NT) lbeams[b] = beams[b];  // visible after the next barrier
   for (int q = tid; q < kMixLds; q += NT) sh_mix[q] = mixlut[q];
   double Tc[4];  // sensor transform at the centre of the samples
   sensor_transform(c, mu0[0], mu0[1], mu0[2], Tc);
-  TRACE_P(11);
+  Tc[0] = uniform_d(Tc[0]); Tc[1] = uniform_d(Tc[1]); Tc[2] = uniform_d(Tc[2]); Tc[3] = uniform_d(Tc[3]);
+  // (the normals have arrived with the pose: parked in the samples' own LDS slots until wave 0 turns them into samples, so that
+  //  they do not hold six registers through the staging)
+  if (c.icp_ok && tid < k) { smp[3 * tid + 0] = zj0; smp[3 * tid + 1] = zj1; smp[3 * tid + 2] = zj2; }
+  TRACE_P(1);
+  bool staged = false;
   if (ds.mode == 2 && occ_half > 0 && nocc) {
     // query mode: stage the bitmap rows/columns within occ_half cells of the sensor in LDS — every lookup of this
     // block ends within range_max of it, and its nearest obstacle is usually a few cells further at most
@@ -897,7 +974,7 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
             st_ids[q] = ds.occ.tab[(tr0 + qi) * ds.occ.TW + tc0 + (q - qi * ntc)];
           }
         __syncthreads();
-        TRACE_P(12);
+        TRACE_P(2);
         for (int r = tid; r <= R1 - R0; r += NT) {
           const int row = R0 + r;
           const unsigned int* ids = whole_table ? st_ids + (row >> kTSh) * ds.occ.TW + tc0 : st_ids + ((row >> kTSh) - tr0) * ntc;
@@ -926,7 +1003,7 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
           ta[r] = acc != 0ull;
         }
       }
-      // the 128-entry table of nearest_code_query's 7 x 7 look (visible after the barrier below)
+      // the 128-entry table of the 7 x 7 look (visible after the barrier below)
       __shared__ unsigned char sh_lut7[128];
       if (tid < 128) {
         int best = 100;
@@ -935,17 +1012,95 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
       }
       ds.tany = ta; ds.R0 = R0; ds.R1 = R1; ds.W0 = W0; ds.nW = nW; ds.lut7 = sh_lut7;
     }
-    TRACE_P(1);
+    __syncthreads();
+    staged = true;
+  }
+  if (!staged) __syncthreads();  // lbeams / sh_mix / sh_def
+  TRACE_P(3);
+  zz0 = uniform_d(zz0); zz1 = uniform_d(zz1); zz2 = uniform_d(zz2); w_old = uniform_d(w_old);  // (arrived long ago; wave-uniform: scalar registers from here on)
+
+  // ---- 1. wave 0 (ICP ok): samples, their sensor transforms, their odometry likelihoods.  The other waves (ICP failed: every
+  //      wave): one lookup per beam at the centre.
+  constexpr int kPW = NT / kWave;
+  __shared__ double sh_spread[2];
+  double dxy = 0.0, dth = 0.0;  // wave 0: how far any sample's sensor is from the centre's
+  if (c.icp_ok && wid == 0) {
+    int var_err = 0;
+    const double nrot1 = uniform_d(normalize_angle_PI(c.rot1)), nrot2 = uniform_d(normalize_angle_PI(c.rot2));
+    for (int j = lane; j < k; j += kWave) {
+      double sj[3];
+      const bool parked = j < NT;
+      const double n0 = parked ? smp[3 * j + 0] : z[3 * j + 0], n1 = parked ? smp[3 * j + 1] : z[3 * j + 1], n2 = parked ? smp[3 * j + 2] : z[3 * j + 2];
+      sj[0] = mu0[0] + c.Ld[0] * n0; sj[1] = mu0[1] + c.Ld[1] * n1; sj[2] = mu0[2] + c.Ld[2] * n2;
+      dth = fmax(dth, fabs(c.Ld[0] * n0));
+      sj[0] = normalize_angle_PI(sj[0]);
+      smp[3 * j + 0] = sj[0]; smp[3 * j + 1] = sj[1]; smp[3 * j + 2] = sj[2];
+      {
+        double T[4];
+        sensor_transform(c, sj[0], sj[1], sj[2], T);
+        stf[4 * j + 0] = T[0]; stf[4 * j + 1] = T[1]; stf[4 * j + 2] = T[2]; stf[4 * j + 3] = T[3];
+        dxy = fmax(dxy, fmax(fabs(T[0] - Tc[0]), fabs(T[1] - Tc[1])));
+      }
+      // (the samples' spread first: the other waves' step 3 needs it, nothing needs the odometry likelihoods before step 4)
+      ppose[j] = pose_likelihood_odom(c, &smp[3 * j], pv, &var_err, nrot1, nrot2);   // (:542: against prev_pose as it stands — updated only after this call)
+    }
+    dxy = wave_max_d(dxy); dth = wave_max_d(dth);
+    if (lane == 0) { sh_spread[0] = dxy; sh_spread[1] = dth; }
+    if (var_err) atomicOr(&err[2], 1);
+  } else if (nocc) {
+    const int b_first = c.icp_ok ? tid - kWave : tid, b_step = c.icp_ok ? NT - kWave : NT;
+    bool deferred = false;
+    for (int b = b_first; b < c.Bv; b += b_step) {
+      const double2 pt = lbeams[b];
+      const double ex = Tc[3] * pt.x - Tc[2] * pt.y + Tc[0], ey = Tc[2] * pt.x + Tc[3] * pt.y + Tc[1];
+      int ci, cj;
+      unsigned int tag = kTagOut, cell = 0xFFFFFFFFu;
+      double pz = 0.0;
+      float mg = -1.0f;
+      if (world2cell(c.g, ex, ey, ci, cj)) {
+        const int cd = lookup_code_fast(c.g, ds, radius, ci, cj);
+        tag = kTagNone;
+        if (cd != -1) {
+          cell = (unsigned int)(ci * c.g.xsize + cj);
+          if (cd == kNeedSearch) { tag = kTagSearch; deferred = true; }
+          else { tag = (unsigned int)cd; pz = mix_term(c, mixL, cd); }
+          const double x_lo = c.g.xmin + ci * c.g.res, x_hi = c.g.xmin + (ci + 1) * c.g.res;
+          const double y_lo = c.g.ymin + cj * c.g.res, y_hi = c.g.ymin + (cj + 1) * c.g.res;
+          // (kept as a float rounded DOWN: a beam can only become unstable by it, never wrongly stable)
+          mg = __double2float_rd(fmin(fmin(ex - x_lo, x_hi - ex), fmin(ey - y_lo, y_hi - ey)));
+        }
+      }
+      ctag[b] = tag; ccell[b] = cell; cpz[b] = pz; marg[b] = mg;
+    }
+    if (deferred) atomicAdd(&sh_def[0], 1);
+  }
+  TRACE_P(4);
+  __syncthreads();
+  // ---- 2. the lookups the 7 x 7 look did not settle (a beam that ends more than three cells from every obstacle the slice
+  //      shows: the first scans of a map, a doorway): the full search, all threads, one inlined copy
+  if (sh_def[0]) {  // workgroup-uniform
+    for (int b = tid; b < c.Bv; b += NT) {
+      if (ctag[b] != kTagSearch) continue;
+      const int cell = (int)ccell[b], ci = cell / c.g.xsize, cj = cell - ci * c.g.xsize;
+      const int cd = nearest_code_query_body(c.g, ds, radius, ci, cj);
+      ctag[b] = (unsigned int)cd;
+      cpz[b] = mix_term(c, mixL, cd);
+    }
     __syncthreads();
   }
-  __shared__ double sh_spread[2], sh_pst[NT / kWave];
+  TRACE_P(5);
+  __shared__ double sh_pst[kPW];
   if (!c.icp_ok) {
-    // weight *= likelihoodFieldModel(scan, T(new pose)) (:171-175): the beams over ALL the workgroup's lanes, lookups on
-    // the LDS slice; the product is taken per lane, per wave, then over the waves in wave order (a fixed order; the
-    // reference multiplies beam by beam: tolerance)
-    __syncthreads();  // lbeams / sh_mix (the staging block's barrier is conditional)
+    // weight *= likelihoodFieldModel(scan, T(new pose)) (:171-175): the product per lane, per wave, then over the waves in wave
+    // order (a fixed order; the reference multiplies beam by beam: tolerance)
     double pr = 1.0;
-    if (nocc) for (int b = tid; b < c.Bv; b += NT) pr *= beam_factor(c, ds, radius, lbeams[b], Tc[0], Tc[1], Tc[2], Tc[3], 0xFFFFFFFFu, 0xFFFFFFFFu, 0.0, &oob, mixL);
+    if (nocc)
+      for (int b = tid; b < c.Bv; b += NT) {
+        const unsigned int tg = ctag[b];
+        if (tg == kTagOut) oob |= 1;          // the reference throws from world2RowMajor
+        else if (tg == kTagNone) oob |= 2;    // (window mode: sized so that this cannot happen — reported, never read stale)
+        else pr *= cpz[b];
+      }
     pr = wave_prod(pr);
     if (lane == 0) sh_pst[wid] = pr;
     if (oob & 1) atomicOr(&err[0], 1);
@@ -953,243 +1108,188 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
     __syncthreads();
     if (tid == 0) {
       double sl = sh_pst[0];
-      for (int w = 1; w < NT / kWave; ++w) sl *= sh_pst[w];
+      for (int w = 1; w < kPW; ++w) sl *= sh_pst[w];
       if (!nocc) sl = 1.0;  // grid_mapper.cpp:94-98
       prev_pose[p * 3 + 0] = th0; prev_pose[p * 3 + 1] = x0; prev_pose[p * 3 + 2] = y0;
-      for (int q = 0; q < 3; ++q) { pose[p * 3 + q] = mu0[q]; tr.new_pose[p * 3 + q] = mu0[q]; }
+      pose[p * 3 + 0] = mu0[0]; pose[p * 3 + 1] = mu0[1]; pose[p * 3 + 2] = mu0[2];
+      tr.new_pose[p * 3 + 0] = mu0[0]; tr.new_pose[p * 3 + 1] = mu0[1]; tr.new_pose[p * 3 + 2] = mu0[2];
       const double w = weight[p] * sl;
       weight[p] = w;
       tr.p_scan[(size_t)p * k] = sl;
       tr.weight_raw[p] = w;
-      for (int q = 0; q < 4; ++q) sens[p * 4 + q] = Tc[q];  // the sensor transform of the new pose, for the raycast kernel
+      sens[p * 4 + 0] = Tc[0]; sens[p * 4 + 1] = Tc[1]; sens[p * 4 + 2] = Tc[2]; sens[p * 4 + 3] = Tc[3];  // the sensor transform of the new pose, for the raycast kernel
     }
+    WGP_OUT();
     return;
   }
-  // ---- 1. wave 0: the k sampled poses and their sensor transforms; how far any of them is from the centre
-  __shared__ int sh_nun;
-  constexpr int kPW = NT / kWave;
-  if (wid == 0) {
-    double dxy = 0.0, dth = 0.0;
-    for (int j = lane; j < k; j += kWave) {
-      double sj[3];
-      for (int q = 0; q < 3; ++q) sj[q] = mu0[q] + c.Ld[q] * z[3 * j + q];
-      dth = fmax(dth, fabs(c.Ld[0] * z[3 * j]));
-      sj[0] = normalize_angle_PI(sj[0]);
-      smp[3 * j + 0] = sj[0]; smp[3 * j + 1] = sj[1]; smp[3 * j + 2] = sj[2];
-      double T[4];
-      sensor_transform(c, sj[0], sj[1], sj[2], T);
-      for (int q = 0; q < 4; ++q) stf[4 * j + q] = T[q];
-      dxy = fmax(dxy, fmax(fabs(T[0] - Tc[0]), fabs(T[1] - Tc[1])));
-    }
-    dxy = wave_max_d(dxy); dth = wave_max_d(dth);
-    if (lane == 0) { sh_spread[0] = dxy; sh_spread[1] = dth; }
-  }
-  __syncthreads();
-  TRACE_P(2);
-#if defined(TBNAV_PHASE_PROF) && !defined(TBNAV_TRACE_ONLY)  // (the sums are contended atomics on ONE address: they distort the very timeline TRACE_ONLY records)
-  if (tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_phase_p[5], now_ - t_prev_); }
-#endif
-  // ---- 2. wave 0: odometry likelihood of every sample (:542).  Other waves: one lookup per beam at the centre of
-  //      the samples, and the beam's verdict: STABLE if the centre's end point is further from every border of
-  //      its cell than any sample's end point can be from it,
-  //          |e_j - e_c|_inf <= max_j |T_j - T_c|_inf + |beam| * max_j |theta_j - theta_c|      (chord <= arc),
-  //      plus 1e-9 m for the rounding of the end points themselves.  Every sample then sees that beam in the
-  //      centre's cell, i.e. with the centre's mixture term: the k * Bv evaluations of the reference
-  //      (grid_mapper.cpp:100-121 called from particle_filter.cpp:541) collapse to Bv, and only the few beams
-  //      near a cell border are evaluated per sample (step 4).  Same cells, same terms — only the order of the
-  //      product differs from the reference's (tolerance).
-  int var_err = 0;
-  if (wid == 0) {
-    for (int j = lane; j < k; j += kWave) ppose[j] = pose_likelihood_odom(c, &smp[3 * j], pv, &var_err);
-    if (var_err) atomicOr(&err[2], 1);
-  } else if (nocc) {
-    const double dxy = sh_spread[0], dth = sh_spread[1];
+  // ---- 3. which beams are stable, the product of their terms, the others listed: every wave over ITS contiguous range of
+  //      beams [w C, (w + 1) C), its unstable ones compacted (in beam order) into its own segment of ulist — no wave waits for
+  //      another's count; the pairs below walk the segments in wave order, i.e. the unstable beams in beam order
+  __shared__ int sh_cnt[kPW];
+  const int seg = (c.Bv + kPW - 1) / kPW;  // beams per wave's range
+  {
+    const double sdxy = sh_spread[0], sdth = sh_spread[1];
+    int n = 0;
     double pst = 1.0;
-    for (int b = tid - kWave; b < c.Bv; b += NT - kWave) {
-      const double2 pt = lbeams[b];
-      const double ex = Tc[3] * pt.x - Tc[2] * pt.y + Tc[0], ey = Tc[2] * pt.x + Tc[3] * pt.y + Tc[1];
-      int ci, cj;
-      unsigned int tag = 0xFFFFFFFFu, cell = 0xFFFFFFFFu;
-      double pz = 0.0;
-      int cd = -1;
-      if (world2cell(c.g, ex, ey, ci, cj)) cd = lookup_code(c.g, ds, radius, ci, cj);
-      bool stable = false;
-      if (cd >= 0) {
-        tag = (unsigned int)cd;
-        cell = (unsigned int)(ci * c.g.xsize + cj);
-        pz = mix_term(c, mixL, cd);
-        // (|beam| only has to be bounded from above: the fp32 root, rounded up by more than its error)
-        const double delta = dxy + (double)(sqrtf((float)(pt.x * pt.x + pt.y * pt.y)) * 1.000001f) * dth + 1e-9;
-        const double x_lo = c.g.xmin + ci * c.g.res, x_hi = c.g.xmin + (ci + 1) * c.g.res;
-        const double y_lo = c.g.ymin + cj * c.g.res, y_hi = c.g.ymin + (cj + 1) * c.g.res;
-        stable = (ex - x_lo > delta) && (x_hi - ex > delta) && (ey - y_lo > delta) && (y_hi - ey > delta);
+    if (nocc) {
+      const int b_lo = wid * seg, b_hi = min(c.Bv, b_lo + seg);
+      for (int b0 = b_lo; b0 < b_hi; b0 += kWave) {
+        const int b = b0 + lane;
+        bool unstable = false;
+        if (b < b_hi) {
+          const double2 pt = lbeams[b];
+          // (|beam| only has to be bounded from above: the fp32 root, rounded up by more than its error)
+          const double delta = sdxy + (double)(sqrtf((float)(pt.x * pt.x + pt.y * pt.y)) * 1.000001f) * sdth + 1e-9;
+          const bool stable = ctag[b] < 0x10000u && (double)marg[b] > delta;
+          if (stable) pst *= cpz[b];
+          unstable = !stable;
+        }
+        const unsigned long long m = __ballot(unstable);
+        if (unstable) ulist[b_lo + n + __popcll(m & ((1ull << lane) - 1ull))] = b;
+        n += __popcll(m);
       }
-      if (stable) pst *= pz;
-      unst[b] = stable ? 0 : 1;
-      ctag[b] = tag;
-      ccell[b] = cell;
-      cpz[b] = pz;
     }
     pst = wave_prod(pst);
-    if (lane == 0) sh_pst[wid] = pst;
-  }
-  TRACE_P(3);
-  __syncthreads();
-  PHASE_STAMP_P(0);
-  TRACE_P(4);
-  // ---- 3. the unstable beams, listed in beam order (so that the products below have one fixed order)
-  if (wid == 0 && nocc) {
-    int n = 0;
-    for (int b0 = 0; b0 < c.Bv; b0 += kWave) {
-      const int b = b0 + lane;
-      const bool f = b < c.Bv && unst[b];
-      const unsigned long long m = __ballot(f);
-      if (f) ulist[n + __popcll(m & ((1ull << lane) - 1ull))] = b;
-      n += __popcll(m);
-    }
-    if (lane == 0) sh_nun = n;
-#if defined(TBNAV_PHASE_PROF) && !defined(TBNAV_TRACE_ONLY)  // (the sums are contended atomics on ONE address: they distort the very timeline TRACE_ONLY records)
-    if (lane == 0) atomicAdd(&g_phase_p[6], (unsigned long long)n);
-#endif
+    if (lane == 0) { sh_cnt[wid] = n; sh_pst[wid] = pst; }
   }
   __syncthreads();
-  TRACE_P(5);
-  // ---- 4. scan likelihood of every sample: (product over the stable beams) * (its own terms of the unstable ones);
-  //      one wave per sample, lanes over the unstable beams
-  if (nocc == 0) {
-    for (int j = tid; j < k; j += NT) pscan[j] = 1.0;  // grid_mapper.cpp:94-98
-  } else {
-    double p_stable = sh_pst[1];
-    for (int w = 2; w < kPW; ++w) p_stable *= sh_pst[w];
-    const int n_un = sh_nun;
-    if (n_un <= kUnCap) {
-      // the usual case, a handful of unstable beams: one THREAD per (sample, unstable beam), then each sample's
-      // thread multiplies its few terms in beam order
-      for (int pair = tid; pair < k * n_un; pair += NT) {
-        const int j = floor_div_small(pair, n_un), i = pair - j * n_un;
-        const int b = ulist[i];
-        fac[j * kUnCap + i] = beam_factor(c, ds, radius, lbeams[b], stf[4 * j + 0], stf[4 * j + 1], stf[4 * j + 2], stf[4 * j + 3],
-                                          ccell[b], ctag[b], cpz[b], &oob, mixL);
+  TRACE_P(6);
+  // ---- 4. scan likelihood of every sample: (product over the stable beams) * (its own terms of the unstable ones)
+  double* wj = stf;  // [k] likelihoods.at(j) (the sensor transforms are dead once the pairs are through)
+  {
+    int n_un = 0;
+    double p_stable = 1.0;  // grid_mapper.cpp:94-98: 1.0 until the map has an occupied cell
+    if (nocc)
+      for (int w = 0; w < kPW; ++w) { n_un += sh_cnt[w]; p_stable *= sh_pst[w]; }
+    // the i-th unstable beam of the scan: segment by segment
+    auto unstable_beam = [&](int i) {
+      int w = 0;
+#pragma unroll
+      for (int q = 0; q < kPW - 1; ++q) { const int cq = sh_cnt[q]; if (w == q && i >= cq) { i -= cq; ++w; } }
+      return ulist[w * seg + i];
+    };
+    for (int j = tid; j < k; j += NT) pscan[j] = p_stable;
+    int seen = 0;
+    for (int u0 = 0; u0 < n_un; u0 += kUnCap) {
+      const int nu = min(kUnCap, n_un - u0);
+      // one THREAD per (sample, unstable beam) of this chunk (grid_mapper.cpp:100-121 for that sample's pose and that beam)
+      bool deferred = false;
+      for (int pair = tid; pair < k * nu; pair += NT) {
+        const int j = floor_div_small(pair, nu), i = pair - j * nu;
+        const int b = unstable_beam(u0 + i);
+        const double2 pt = lbeams[b];
+        const double X = stf[4 * j + 0], Y = stf[4 * j + 1], st = stf[4 * j + 2], ct = stf[4 * j + 3];
+        const double ex = ct * pt.x - st * pt.y + X, ey = st * pt.x + ct * pt.y + Y;
+        int ci, cj;
+        double term = 1.0;
+        if (!world2cell(c.g, ex, ey, ci, cj)) oob |= 1;  // (the reference throws from world2RowMajor)
+        else {
+          const unsigned int cell = (unsigned int)(ci * c.g.xsize + cj);
+          if (cell == ccell[b]) term = cpz[b];  // the centre's cell -> its code -> its term
+          else {
+            const int cd = lookup_code_fast(c.g, ds, radius, ci, cj);
+            if (cd == kNeedSearch) { term = __hiloint2double((int)kBoxHi, (int)cell); deferred = true; }
+            else if (cd < 0) oob |= 2;
+            else term = ((unsigned int)cd == ctag[b]) ? cpz[b] : mix_term(c, mixL, cd);
+          }
+        }
+        fac[j * kUnCap + i] = term;
       }
+      if (deferred) atomicAdd(&sh_def[1], 1);
       __syncthreads();
+      const int def_now = sh_def[1];
+      if (def_now != seen) {  // workgroup-uniform: some pair of this chunk waits for the full search
+        seen = def_now;
+        for (int pair = tid; pair < k * nu; pair += NT) {
+          const int j = floor_div_small(pair, nu), i = pair - j * nu;
+          const double v = fac[j * kUnCap + i];
+          if ((unsigned int)__double2hiint(v) != kBoxHi) continue;
+          const int cell = __double2loint(v), ci = cell / c.g.xsize, cj = cell - ci * c.g.xsize;
+          const int cd = nearest_code_query_body(c.g, ds, radius, ci, cj);
+          const int b = unstable_beam(u0 + i);
+          fac[j * kUnCap + i] = ((unsigned int)cd == ctag[b]) ? cpz[b] : mix_term(c, mixL, cd);
+        }
+        __syncthreads();
+      }
       for (int j = tid; j < k; j += NT) {
-        double pr = p_stable;
-        for (int i = 0; i < n_un; ++i) pr *= fac[j * kUnCap + i];
+        double pr = pscan[j];
+        for (int i = 0; i < nu; ++i) pr *= fac[j * kUnCap + i];
         pscan[j] = pr;
       }
-    } else {
-    constexpr int kSB = TBNAV_PROPOSE_KSB;  // samples per wave in flight (their shuffle chains overlap; each is an inlined copy of the lookup)
-    for (int j0 = wid; j0 < k; j0 += kPW * kSB) {
-      double pr[kSB];
-#pragma unroll
-      for (int u = 0; u < kSB; ++u) pr[u] = 1.0;
-      for (int i = lane; i < n_un; i += kWave) {
-        const int b = ulist[i];
-        const double2 pt = lbeams[b];
-        const unsigned int cc = ccell[b], tg = ctag[b];
-        const double pzc = cpz[b];
-#pragma unroll
-        for (int u = 0; u < kSB; ++u) {
-          const int j = j0 + u * kPW;
-          if (j < k) pr[u] *= beam_factor(c, ds, radius, pt, stf[4 * j + 0], stf[4 * j + 1], stf[4 * j + 2], stf[4 * j + 3], cc, tg, pzc, &oob, mixL);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < kSB; ++u) pr[u] = wave_prod(pr[u]);
-#pragma unroll
-      for (int u = 0; u < kSB; ++u) if (lane == 0 && j0 + u * kPW < k) pscan[j0 + u * kPW] = p_stable * pr[u];
+      if (u0 + kUnCap < n_un) __syncthreads();  // (the next chunk rewrites fac)
     }
+    if (oob & 1) atomicOr(&err[0], 1);
+    if (oob & 2) atomicOr(&err[3], 4);
+    if (n_un > 0) __syncthreads();  // (stf -> wj: every pair has read its sample's transform)
+    // the sample's own thread: clamps, likelihoods.at(j), the trace (:541-556)
+    for (int j = tid; j < k; j += NT) {
+      const double psj = pscan[j], ppj = ppose[j];
+      const double ps = fmin(fmax(psj, c.scan_min), c.scan_max);  // std::clamp
+      const double pp = fmin(fmax(ppj, c.pose_min), c.pose_max);
+      tr.p_scan[(size_t)p * k + j] = psj;
+      tr.p_pose[(size_t)p * k + j] = ppj;
+      tr.sampled[((size_t)p * k + j) * 3 + 0] = smp[3 * j + 0];
+      tr.sampled[((size_t)p * k + j) * 3 + 1] = smp[3 * j + 1];
+      tr.sampled[((size_t)p * k + j) * 3 + 2] = smp[3 * j + 2];
+      wj[j] = ps * pp;
     }
   }
-  if (oob & 1) atomicOr(&err[0], 1);
-  if (oob & 2) atomicOr(&err[3], 4);
   __syncthreads();
   TRACE_P(7);
-
-  // ---- Gaussian proposal (:522-599), new pose (:214-231).  The sums run in the reference's sequential order on
-  //      one thread; everything that is per-sample (clamps, products, outer products, trace) is done by the
-  //      sample's own thread so that the serial part is only the chains of adds.
-  PHASE_STAMP_P(1);
-  double* wj = stf;           // [k]    likelihoods.at(j)   (the sensor transforms are dead by now)
-  __shared__ double sh_mu[3], sh_eta;
-  __shared__ int sh_stop;
-  for (int j = tid; j < k; j += NT) {
-    const double ps = fmin(fmax(pscan[j], c.scan_min), c.scan_max);  // std::clamp
-    const double pp = fmin(fmax(ppose[j], c.pose_min), c.pose_max);
-    tr.p_scan[(size_t)p * k + j] = pscan[j];
-    tr.p_pose[(size_t)p * k + j] = ppose[j];
-    tr.sampled[((size_t)p * k + j) * 3 + 0] = smp[3 * j + 0];
-    tr.sampled[((size_t)p * k + j) * 3 + 1] = smp[3 * j + 1];
-    tr.sampled[((size_t)p * k + j) * 3 + 2] = smp[3 * j + 2];
-    wj[j] = ps * pp;
+  // ---- 5. Gaussian proposal (:522-599), new pose (:214-231): wave 0 alone.  The weighted sums are lane-strided partial sums
+  //      closed with a butterfly — a fixed order, not the reference's left-to-right one: the results agree to rounding
+  //      (asserted at 1e-10 against the oracle) — and every lane of the wave holds them, so nothing goes through LDS again.
+  if (wid != 0) return;
+  double a[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int j = lane; j < k; j += kWave) {
+    const double pj = wj[j];
+    for (int q = 0; q < 3; ++q) a[q] += smp[3 * j + q] * pj;
+    a[3] += pj;
   }
-  __syncthreads();
-  TRACE_P(8);
-  // The weighted sums (:545-585) are taken by wave 0 as lane-strided partial sums closed with a butterfly: a fixed
-  // order, not the reference's left-to-right one — the results agree to rounding (asserted at 1e-10 against the
-  // oracle), and the serial chain of 4 + 6 adds per sample leaves the block's critical path.
-  if (wid == 0) {
-    double a[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int j = lane; j < k; j += kWave) {
-      const double pj = wj[j];
-      for (int q = 0; q < 3; ++q) a[q] += smp[3 * j + q] * pj;
-      a[3] += pj;
-    }
-    for (int q = 0; q < 4; ++q) a[q] = wave_sum_d(a[q]);
+  for (int q = 0; q < 4; ++q) a[q] = wave_sum_d(a[q]);
+  const double eta = a[3];
+  if (almost_equal(eta, 0.0)) {  // "eta is 0" (:563, reported): the pose stays, and so does its sensor transform
     if (lane == 0) {
-      const int stop = almost_equal(a[3], 0.0) ? 1 : 0;
-      if (stop) atomicOr(&err[1], 1);
-      else {
-        for (int q = 0; q < 3; ++q) a[q] /= a[3];
-        a[0] = normalize_angle_PI(a[0]);
-      }
-      sh_mu[0] = a[0]; sh_mu[1] = a[1]; sh_mu[2] = a[2]; sh_eta = a[3]; sh_stop = stop;
-    }
-  }
-  __syncthreads();
-  TRACE_P(9);
-  if (sh_stop) {  // eta is 0 (reported): the pose stays, and so does its sensor transform
-    if (tid == 0) { double Ts[4]; sensor_transform(c, th0, x0, y0, Ts); for (int q = 0; q < 4; ++q) sens[p * 4 + q] = Ts[q]; }
-    return;
-  }
-  if (wid == 0) {
-    const double mu[3] = {sh_mu[0], sh_mu[1], sh_mu[2]}, eta = sh_eta;
-    double su[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    for (int j = lane; j < k; j += kWave) {
-      const double d[3] = {smp[3 * j + 0] - mu[0], smp[3 * j + 1] - mu[1], smp[3 * j + 2] - mu[2]};
-      const double w = wj[j];
-      int o = 0;
-      for (int r = 0; r < 3; ++r) for (int q = r; q < 3; ++q) su[o++] += (d[r] * d[q]) * w;
-    }
-    for (int o = 0; o < 6; ++o) su[o] = wave_sum_d(su[o]);
-    if (lane == 0) {
-      double sigma[3][3];
-      {
-        int o = 0;
-        for (int r = 0; r < 3; ++r) for (int q = r; q < 3; ++q) { sigma[r][q] = su[o] / eta; sigma[q][r] = sigma[r][q]; ++o; }
-      }
-      double L[3][3];
-      llt3(sigma, L);
-      const double* zz = z + 3 * k;
-      double np[3];
-      for (int r = 0; r < 3; ++r) np[r] = mu[r] + ((L[r][0] * zz[0] + L[r][1] * zz[1]) + L[r][2] * zz[2]);
-      prev_pose[p * 3 + 0] = th0; prev_pose[p * 3 + 1] = x0; prev_pose[p * 3 + 2] = y0;
-      for (int q = 0; q < 3; ++q) { pose[p * 3 + q] = np[q]; tr.new_pose[p * 3 + q] = np[q]; tr.mu[p * 3 + q] = mu[q]; }
-      for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) tr.sigma[p * 9 + r * 3 + q] = sigma[r][q];
-      tr.eta[p] = eta;
-      const double w = weight[p] * eta;
-      weight[p] = w;
-      tr.weight_raw[p] = w;
-      double Ts[4];  // the sensor transform of the new pose, for the raycast kernel (saves it two sincos on its critical path)
-      sensor_transform(c, np[0], np[1], np[2], Ts);
+      atomicOr(&err[1], 1);
+      double Ts[4];
+      sensor_transform(c, th0, x0, y0, Ts);
       for (int q = 0; q < 4; ++q) sens[p * 4 + q] = Ts[q];
     }
+    return;
   }
-  TRACE_P(10);
-  PHASE_STAMP_P(2);
-#if defined(TBNAV_PHASE_PROF) && !defined(TBNAV_TRACE_ONLY)  // (the sums are contended atomics on ONE address: they distort the very timeline TRACE_ONLY records)
-  if (tid == 0) atomicAdd(&g_phase_p[7], 1ull);
-#endif
+  double mu[3] = {a[0] / eta, a[1] / eta, a[2] / eta};
+  mu[0] = normalize_angle_PI(mu[0]);
+  double su[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int j = lane; j < k; j += kWave) {
+    const double d[3] = {smp[3 * j + 0] - mu[0], smp[3 * j + 1] - mu[1], smp[3 * j + 2] - mu[2]};
+    const double w = wj[j];
+    int o = 0;
+    for (int r = 0; r < 3; ++r) for (int q = r; q < 3; ++q) su[o++] += (d[r] * d[q]) * w;
+  }
+  for (int o = 0; o < 6; ++o) su[o] = wave_sum_d(su[o]);
+  TRACE_P(8);
+  if (lane == 0) {
+    double sigma[3][3];
+    {
+      int o = 0;
+      for (int r = 0; r < 3; ++r) for (int q = r; q < 3; ++q) { sigma[r][q] = su[o] / eta; sigma[q][r] = sigma[r][q]; ++o; }
+    }
+    double L[3][3];
+    llt3(sigma, L);
+    double np[3];
+    for (int r = 0; r < 3; ++r) np[r] = mu[r] + ((L[r][0] * zz0 + L[r][1] * zz1) + L[r][2] * zz2);
+    prev_pose[p * 3 + 0] = th0; prev_pose[p * 3 + 1] = x0; prev_pose[p * 3 + 2] = y0;
+    for (int q = 0; q < 3; ++q) { pose[p * 3 + q] = np[q]; tr.new_pose[p * 3 + q] = np[q]; tr.mu[p * 3 + q] = mu[q]; }
+    for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) tr.sigma[p * 9 + r * 3 + q] = sigma[r][q];
+    tr.eta[p] = eta;
+    const double w = w_old * eta;
+    weight[p] = w;
+    tr.weight_raw[p] = w;
+    double Ts[4];  // the sensor transform of the new pose, for the raycast kernel (saves it two sincos on its critical path)
+    sensor_transform(c, np[0], np[1], np[2], Ts);
+    for (int q = 0; q < 4; ++q) sens[p * 4 + q] = Ts[q];
+  }
+  TRACE_P(9);
   WGP_OUT();
 }
 
@@ -1416,23 +1516,6 @@ __device__ __forceinline__ bool on_ray(const Ray& r, int cx, int cy) {
 // LDS (ints): ex ey own rk rxy rdd ecnt [Bv each] | ev u16[Bv][kEvCap] | tile u32[(cap+1)/2] (two 16-bit
 // halves per word: bit 15 = end-point flag, low 15 bits = free-add count, or the slot index when flagged).
 constexpr int kMapTilesMax = 64;  // map tiles a scan's bounding box can span: (ceil(175 / 32) + 1)^2 = 49 for tile_cap 30000
-// Packed ray for the counting pass.  Every ray is written in the form of the reference's plotLineLow / plotLineHigh
-// cases: a major axis, a start (xa, ya) at the low end of that axis, dmaj steps along it, and the minor offset
-// c_t of ray_cell.  The vertical / horizontal / diagonal cases fit the same form with dmin = 0 / 0 / dmaj
-// (a = 2*dmin*t - dmaj gives c_t = 0 and c_t = t), and the SET of free cells is the same: the robot cell plus the
-// cells strictly between the two ends (the counting pass is order-free; ordered work uses Ray/on_ray).
-//   k  = ymajor | (sgn < 0) << 1 | count << 8        xy = xa | ya << 16        dd = dmaj | dmin << 16
-struct PackedRay { int k, xy, dd; };
-__device__ __forceinline__ PackedRay pack_ray(const Ray& r, int x1, int y1) {
-  int ymajor = (r.kind == 3), xa = r.xa, ya = r.ya, dmaj = r.dmaj, dmin = r.dmin, sgn = r.sgn;
-  if (r.kind == 0) { ymajor = 1; xa = r.x0; ya = r.y0 < y1 ? r.y0 : y1; dmaj = r.count; dmin = 0; sgn = 1; }
-  if (r.kind == 1) { ymajor = 0; ya = r.y0; xa = r.x0 < x1 ? r.x0 : x1; dmaj = r.count; dmin = 0; sgn = 1; }
-  if (r.kind == 4) {
-    ymajor = 0; dmaj = r.count; dmin = r.count;
-    if (r.x0 < x1) { xa = r.x0; ya = r.y0; sgn = (y1 < r.y0) ? -1 : 1; } else { xa = x1; ya = y1; sgn = (r.y0 < y1) ? -1 : 1; }
-  }
-  return PackedRay{ymajor | (sgn < 0 ? 2 : 0) | (r.count << 8), xa | (ya << 16), dmaj | (dmin << 16)};
-}
 __device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off, 64); v = o < v ? o : v; }
@@ -1463,381 +1546,7 @@ template <class Op> __device__ __forceinline__ int wave_reduce_dpp(int v, int id
 __device__ __forceinline__ int wave_min_dpp(int v) { return wave_reduce_dpp(v, 0x7FFFFFFF, [](int a, int b) { return a < b ? a : b; }); }
 __device__ __forceinline__ int wave_max_dpp(int v) { return wave_reduce_dpp(v, (int)0x80000000, [](int a, int b) { return a > b ? a : b; }); }
 __device__ __forceinline__ int wave_sum_dpp(int v) { return wave_reduce_dpp(v, 0, [](int a, int b) { return a + b; }); }
-// LDS of the tile kernel (ints): exy own ecnt [Bv each] | ev u16[Bv][kEvCap] | tile u32[(cap+1)/2].  A ray is rebuilt
-// from (robot cell, end point) where it is walked instead of being stored.
 constexpr int kBoxSideMax = 176;  // rows a scan's bounding box can have (tile_cap <= 30000 -> side <= 173)
-// Residency the register allocation is held to: 1024 threads -> 2 workgroups per CU (8 waves per SIMD, 64 VGPRs),
-// 512 -> 3 (6 per SIMD, 80 VGPRs), 256 -> 3 (LDS-bound anyway).
-// FW = bits per cell of the LDS tile: 16 (flag + 15 bits of count / slot index; any scan), or 10 (flag + 9 bits, three
-// cells per word: 2/3 of the LDS — scans of at most 511 valid beams, where neither a count nor a slot index can reach
-// 512).  EC = events a slot holds before it is replayed exhaustively.  The 10-bit / 8-event form is what lets four
-// 512-thread workgroups share a CU instead of two 1024-thread ones.
-template <int FW> struct TileF {
-  static constexpr unsigned int kFlag = 1u << (FW - 1), kMask = (1u << FW) - 1u, kLow = kFlag - 1u;
-  static __device__ __forceinline__ int word(int t) { return FW == 16 ? (t >> 1) : (int)(((unsigned int)t * 43691u) >> 17); }  // t / 3, t < 2^15
-  static __device__ __forceinline__ int shift(int t) { return FW == 16 ? (t & 1) * 16 : (t - 3 * word(t)) * 10; }
-  static __host__ __device__ constexpr size_t words(size_t cap) { return FW == 16 ? (cap + 1) / 2 : (cap + 2) / 3; }
-};
-template <int NT, int FW, int EC>
-__global__ __launch_bounds__(NT, NT == 1024 ? 8 : (NT == 512 ? 8 : 3)) void rbpf_raycast_tile(ScanC c, TilePool P, MapT M, const double2* __restrict__ beams,
-                                                       const double* __restrict__ pose, const double* __restrict__ sens,
-                                                       int* __restrict__ trow_occ,
-                                                       int* __restrict__ n_occ, int* __restrict__ err, int tile_cap,
-                                                       unsigned long long* __restrict__ touched, const int* __restrict__ gate_prev = nullptr) {
-  extern __shared__ __attribute__((aligned(16))) int lds_i[];
-  if (gate_prev && *gate_prev) return;  // the scan before this one resamples: see rbpf_raycast_box
-  const int Bv = c.Bv;
-  int* exy = lds_i;      // [Bv] end-point cell, x | y << 16
-  int* own = exy + Bv;   // [n_own] a beam ending in the slot's cell
-  int* ecnt = own + Bv;  // [n_own] events recorded (may exceed kEvCap: overflow)
-  unsigned short* ev = reinterpret_cast<unsigned short*>(ecnt + Bv);  // [n_own][EC]  beam | 0x8000 if occupied
-  unsigned int* tile = reinterpret_cast<unsigned int*>(lds_i + (3 + EC / 2) * Bv);
-  using TF = TileF<FW>;
-  constexpr int kEvCap = EC;
-  __shared__ int bad, bx0, bx1, by0, by1, n_own, srx, sry, n_need, robot_cnt, nocc_delta;
-  __shared__ unsigned long long need_base;
-  __shared__ unsigned int mt_id[kMapTilesMax];  // map tiles under the bounding box: 0 = not written by this scan, else the
-  //                                               particle's private tile id (phase C)
-  __shared__ int mt_ref[kMapTilesMax], mt_slot[kMapTilesMax];
-  __shared__ int rc_delta[kBoxSideMax / kTS + 2];  // change of the occupied count of each tile row under the box
-  __shared__ double sh_pose[4];                 // X, Y, sin, cos of Tms = T(pose) * Trs
-  constexpr int nthr = NT, nw = NT / kWave;
-  const int p = c.p0 + blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
-#ifdef TBNAV_PHASE_PROF
-  unsigned long long t_prev_ = wall_clock64();
-#endif
-  int* rc = trow_occ + (size_t)p * M.TW;
-  unsigned int* tab = M.table + (size_t)p * M.TT;
-  unsigned int* shed = M.shed + (size_t)p * M.TT;
-  // wave 0 derives everything that depends only on the particle's pose while the other waves clear the tile; the
-  // sensor transform comes from the proposal kernel when it ran for this particle (`sens`), else two sincos here
-  if (wid == 0) {
-    const double x = pose[p * 3 + 1], y = pose[p * 3 + 2];
-    int rx0 = 0, ry0 = 0;
-    const bool robot_ok = world2cell(c.g, x, y, rx0, ry0);  // freeGridIndex: world2Grid of the ROBOT pose (:558)
-    double X, Y, st0, ct0;
-    if (sens) { X = sens[p * 4 + 0]; Y = sens[p * 4 + 1]; st0 = sens[p * 4 + 2]; ct0 = sens[p * 4 + 3]; }
-    else {
-      const double th = pose[p * 3 + 0];
-      double s0, c0;
-      sincos(th, &s0, &c0);
-      if (c.Trs[0] == 0.0) { st0 = s0; ct0 = c0; } else sincos(th + c.Trs[0], &st0, &ct0);
-      X = c0 * c.Trs[1] - s0 * c.Trs[2] + x;
-      Y = s0 * c.Trs[1] + c0 * c.Trs[2] + y;
-    }
-    if (lane == 0) {
-      sh_pose[0] = X; sh_pose[1] = Y; sh_pose[2] = st0; sh_pose[3] = ct0;
-      bad = robot_ok ? 0 : 1; bx0 = bx1 = rx0; by0 = by1 = ry0; n_own = 0; srx = rx0; sry = ry0;
-      n_need = 0; robot_cnt = 0; nocc_delta = 0;
-    }
-  } else {
-    for (int t = tid - kWave; t < (int)TF::words(tile_cap); t += nthr - kWave) tile[t] = 0u;
-    for (int b = tid - kWave; b < Bv; b += nthr - kWave) ecnt[b] = 0;
-    for (int t = tid - kWave; t < kMapTilesMax; t += nthr - kWave) mt_id[t] = 0u;
-    for (int t = tid - kWave; t < kBoxSideMax / kTS + 2; t += nthr - kWave) rc_delta[t] = 0;
-  }
-  __syncthreads();
-  const int rx = srx, ry = sry;
-  {
-    const double X = sh_pose[0], Y = sh_pose[1], st = sh_pose[2], ct = sh_pose[3];
-    for (int b0 = wid * kWave; b0 < Bv; b0 += nthr) {
-      const int b = b0 + lane;
-      int ci = rx, cj = ry;
-      if (b < Bv) {
-        const double2 pt = beams[b];
-        if (!world2cell(c.g, ct * pt.x - st * pt.y + X, st * pt.x + ct * pt.y + Y, ci, cj)) { bad = 1; ci = rx; cj = ry; }
-        exy[b] = ci | (cj << 16);
-      }
-      const int lo_x = wave_min_i(ci), hi_x = wave_max_i(ci), lo_y = wave_min_i(cj), hi_y = wave_max_i(cj);
-      if (lane == 0) { atomicMin(&bx0, lo_x); atomicMax(&bx1, hi_x); atomicMin(&by0, lo_y); atomicMax(&by1, hi_y); }
-    }
-  }
-  __syncthreads();
-  if (bad) { if (tid == 0) atomicOr(&err[0], 1); return; }
-  const int minx = bx0, miny = by0, bw = by1 - by0 + 1, bh = bx1 - bx0 + 1, ncell = bw * bh;
-  const int tx0 = minx >> kTSh, ty0 = miny >> kTSh, mty = (by1 >> kTSh) - ty0 + 1, mtn = ((bx1 >> kTSh) - tx0 + 1) * mty;
-  if (ncell > tile_cap || mtn > kMapTilesMax || bh > kBoxSideMax) { if (tid == 0) atomicOr(&err[3], 2); return; }  // cannot happen: see launch_raycast
-  // the particle's table entries under the box and the reference counts of the tiles they name: requested now, needed
-  // only after the ray walk (phase C) — the two dependent round trips fly under the flag and walk phases
-  unsigned int my_tab = 0u;
-  int my_ref = 0;
-  if (tid < mtn) {
-    const int qi = floor_div_small(tid, mty), qj = tid - qi * mty;
-    my_tab = tab[(tx0 + qi) * M.TW + (ty0 + qj)];
-  }
-  PHASE_STAMP(0);
-  // F. flag the end-point cells; the beam that finds the flag clear opens the cell's slot
-  for (int b = tid; b < Bv; b += nthr) {
-    const int e = exy[b], t = ((e & 0xFFFF) - minx) * bw + ((e >> 16) - miny), sh = TF::shift(t), tw = TF::word(t);
-    if (!((atomicOr(&tile[tw], TF::kFlag << sh) >> sh) & TF::kFlag)) {
-      const int o = atomicAdd(&n_own, 1);
-      own[o] = b;
-      atomicOr(&tile[tw], (unsigned int)o << sh);
-    }
-  }
-  if (tid < mtn) my_ref = my_tab ? P.ref[my_tab] : 0;
-  __syncthreads();
-  for (int b = tid; b < Bv; b += nthr) {
-    const int e = exy[b], t = ((e & 0xFFFF) - minx) * bw + ((e >> 16) - miny);
-    const int o = (int)((tile[TF::word(t)] >> TF::shift(t)) & TF::kLow);
-    const int en = atomicAdd(&ecnt[o], 1);
-    if (en < kEvCap) ev[o * kEvCap + en] = (unsigned short)(b | 0x8000);
-  }
-  const int t_robot = (rx - minx) * bw + (ry - miny);
-  PHASE_STAMP(1);
-  // 1. counters / events: one LANE per ray segment.  A lane finds its first cell in closed form (one division)
-  //    and then walks the ray with the integer error recurrence that the closed form solves:
-  //      rem_t = a_t - 2*dmaj*(c_t - 1) in (0, 2*dmaj];   rem += 2*dmin;  if (rem > 2*dmaj) { ++c; rem -= 2*dmaj; }
-  //    — a handful of integer instructions per cell instead of a division per cell.  Lanes of one wave take rays
-  //    spread round the scan (b = lane * G + ...), so that they rarely meet in the same LDS word near the robot.
-  //    The ROBOT's own cell is the first free cell of every ray: it is not visited (Bv atomics on one LDS word), its
-  //    count is the number of rays that have a free cell at all, added once below.
-  {
-    int S = Bv > 0 ? nthr / Bv : 1;  // segments per ray: as many as give every thread at most one task
-    S = S < 1 ? 1 : (S > 4 ? 4 : S);
-    const int G = (Bv + kWave - 1) / kWave;
-    auto visit = [&](int t, int b) {
-      const int sh = TF::shift(t), tw = TF::word(t);
-      const unsigned int hlf = tile[tw] >> sh;  // the flag and slot bits are final since the barrier above
-      if (hlf & TF::kFlag) {
-        const int o = (int)(hlf & TF::kLow);
-        const int e = atomicAdd(&ecnt[o], 1);
-        if (e < kEvCap) ev[o * kEvCap + e] = (unsigned short)b;
-      } else {
-        atomicAdd(&tile[tw], 1u << sh);
-      }
-    };
-    int n_first = 0;
-    for (int task = tid; task < kWave * G * S; task += nthr) {
-      const int tb = floor_div_small(task, S), sgm = task - tb * S;
-      const int b = (tb & (kWave - 1)) * G + (tb >> 6);
-      if (b >= Bv) continue;
-      const int e = exy[b], ex = e & 0xFFFF, ey = e >> 16;
-      const PackedRay pr = pack_ray(make_ray(rx, ry, ex, ey), ex, ey);
-      const int k = pr.k, xy = pr.xy, dd = pr.dd;
-      const int count = k >> 8, L = floor_div_small(count + S - 1, S);
-      int n = sgm * L;
-      const int n1 = (n + L < count) ? n + L : count;
-      if (n >= n1) continue;
-      const int xa = xy & 0xFFFF, ya = xy >> 16, dmaj = dd & 0xFFFF, dmin = dd >> 16;
-      const bool ymajor = k & 1, neg = k & 2;
-      const int a0 = 2 * dmin * n - dmaj;
-      const int c0 = a0 > 0 ? floor_div_small(a0 + 2 * dmaj - 1, 2 * dmaj) : 0;  // operands < 2^24
-      int rem = a0 - 2 * dmaj * (c0 - 1);
-      const int sc = neg ? -c0 : c0;
-      int t = ((ymajor ? xa + sc : xa + n) - minx) * bw + ((ymajor ? ya + n : ya + sc) - miny);
-      const int d_major = ymajor ? 1 : bw, d_minor = (ymajor ? bw : 1) * (neg ? -1 : 1);
-      const int two_dmin = 2 * dmin, two_dmaj = 2 * dmaj;
-      if (n == 0) {  // the first free cell is the robot's own cell (for a reversed ray, step 0 is the end point)
-        ++n_first;
-        rem += two_dmin; t += d_major;
-        if (rem > two_dmaj) { rem -= two_dmaj; t += d_minor; }
-        ++n;
-      }
-      for (; n < n1; ++n) {
-        visit(t, b);
-        rem += two_dmin; t += d_major;
-        if (rem > two_dmaj) { rem -= two_dmaj; t += d_minor; }
-      }
-    }
-    n_first = wave_sum_i(n_first);
-    if (lane == 0 && n_first) atomicAdd(&robot_cnt, n_first);
-  }
-  __syncthreads();  // every event is recorded
-  if (tid == 0 && robot_cnt) {
-    const int sh = TF::shift(t_robot), tw = TF::word(t_robot);
-    const unsigned int hlf = tile[tw] >> sh;
-    if (hlf & TF::kFlag) ecnt[hlf & TF::kLow] = kEvCap + 1;  // the robot's cell is an end point too: replayed against every beam (2b)
-    else tile[tw] += (unsigned int)robot_cnt << sh;
-  }
-  if (tid < mtn) mt_ref[tid] = my_ref;
-  __syncthreads();
-  PHASE_STAMP(2);
-  // M. which map tiles does this scan write?  Every cell with a counter or a flag marks its tile (kTS x kTS cells of
-  //    the particle's tile table; the bounding box spans mtx x mty of them).
-  const int step_r = floor_div_small(nthr, bw), step_c = nthr - step_r * bw;  // cell t + nthr in (row, col) terms
-  {
-    int trow = floor_div_small(tid < ncell ? tid : 0, bw), tcol = (tid < ncell ? tid : 0) - trow * bw;
-    for (int t = tid; t < ncell; t += nthr) {
-      if ((tile[TF::word(t)] >> TF::shift(t)) & TF::kMask) mt_id[(((minx + trow) >> kTSh) - tx0) * mty + (((miny + tcol) >> kTSh) - ty0)] = 1u;
-      trow += step_r; tcol += step_c;
-      if (tcol >= bw) { tcol -= bw; ++trow; }
-    }
-  }
-  __syncthreads();
-  // C. make those tiles private to the particle (first write after a resample, or first touch of the area): ONE pop of
-  //    the free ring for all of them, then one wave per tile copies 8 KB
-  if (tid < mtn && mt_id[tid] != 0u) {
-    if (my_tab != 0u && mt_ref[tid] == 1) { mt_slot[tid] = -1; mt_id[tid] = my_tab; }
-    else mt_slot[tid] = atomicAdd(&n_need, 1);
-  }
-  __syncthreads();
-  if (n_need) {  // workgroup-uniform
-    if (tid == 0) { need_base = tile_pop_n(P, (unsigned int)n_need); if (need_base == ~0ull) bad = 1; }
-    __syncthreads();
-    if (bad) { if (tid == 0) atomicOr(&err[3], 8); return; }  // tile pool exhausted: nothing has been written
-    for (int q = wid; q < mtn; q += nw) {
-      if (mt_id[q] == 0u || mt_slot[q] < 0) continue;
-      const int qi = floor_div_small(q, mty), qj = q - qi * mty;
-      const unsigned int nid = tile_at(P, need_base + (unsigned long long)mt_slot[q]);
-      tile_clone_into(P, tab, shed, (tx0 + qi) * M.TW + (ty0 + qj), nid, lane);
-      if (lane == 0) mt_id[q] = nid;
-    }
-    __syncthreads();
-  }
-  auto cell_ptr = [&](int cx, int cy) -> double* {
-    return P.lo + (size_t)mt_id[((cx >> kTSh) - tx0) * mty + ((cy >> kTSh) - ty0)] * kTileCells + in_tile(cx, cy);
-  };
-  auto toggled = [&](int cx, int cy, bool now) {  // the cell crossed the occupied cut-off: its bit in the (private) tile, tile-row count, total
-    atomicXor(&P.bm[(size_t)mt_id[((cx >> kTSh) - tx0) * mty + ((cy >> kTSh) - ty0)] * kTS + (cx & (kTS - 1))], 1u << (cy & (kTS - 1)));
-    atomicAdd(&rc_delta[(cx >> kTSh) - tx0], now ? 1 : -1);
-    atomicAdd(&nocc_delta, now ? 1 : -1);
-  };
-  // The two read-modify-write passes share their memory round trip: the end-point cell of this thread (2a) and the
-  // first eight plain cells (3) are requested together, then the end point is replayed while the rest is in flight.
-  const int n_cells = n_own;
-  constexpr int kPer = NT == 1024 ? 4 : 8;  // plain cells per thread in flight (1024 threads: 64 VGPRs to live in)
-  double v0[kPer];         // (only the loaded values stay live across the end-point replay: counts and addresses are re-derived)
-  int n_distinct = 0;
-  // cell t0 + q * nthr of the box, q = 0 .. kPer-1: its count of free adds (0: untouched or an end point) and its address
-  auto plain_cells = [&](int base, auto&& fn) {
-    const int t0 = base + tid;
-    int trow = floor_div_small(t0 < ncell ? t0 : 0, bw), tcol = (t0 < ncell ? t0 : 0) - trow * bw;  // t < 2^15, bw < 2^8
-#pragma unroll
-    for (int q = 0; q < kPer; ++q) {
-      const int t = t0 + q * nthr;
-      int cnq = 0;
-      if (t < ncell) {
-        const unsigned int hlf = (tile[TF::word(t)] >> TF::shift(t)) & TF::kMask;
-        if (!(hlf & TF::kFlag)) cnq = (int)hlf;
-      }
-      fn(q, cnq, minx + trow, miny + tcol);
-      trow += step_r; tcol += step_c;
-      if (tcol >= bw) { tcol -= bw; ++trow; }
-    }
-  };
-  auto fetch_plain = [&](int base) {
-    plain_cells(base, [&](int q, int cnq, int cx, int cy) { v0[q] = cnq ? *cell_ptr(cx, cy) : 0.0; });
-  };
-  auto finish_plain = [&](int base) {
-    plain_cells(base, [&](int q, int cnq, int cx, int cy) {
-      if (!cnq) return;
-      ++n_distinct;
-      double v = v0[q];
-      int a = 0;
-      for (; a + 4 <= cnq; a += 4) { v += c.d_free; v += c.d_free; v += c.d_free; v += c.d_free; }
-      for (; a < cnq; ++a) v += c.d_free;
-      *cell_ptr(cx, cy) = v;
-      const bool was = v0[q] >= c.cut_occ, now = v >= c.cut_occ;
-      if (was != now) toggled(cx, cy, now);
-    });
-  };
-  // 2a. end-point cells whose slot holds every event: one lane each, events applied in beam order
-  auto replay_slot = [&](int o, double* cellp, double v0e) {
-    const int ne = ecnt[o];
-    double v = v0e;
-    int last = -1;
-    for (int i = 0; i < ne; ++i) {  // selection by ascending beam (ne is a handful)
-      int best_key = 0x8000, best_ev = 0;
-      for (int j = 0; j < ne; ++j) {
-        const int e = ev[o * kEvCap + j], key = e & 0x7FFF;
-        if (key > last && key < best_key) { best_key = key; best_ev = e; }
-      }
-      v += (best_ev & 0x8000) ? c.d_occ : c.d_free;
-      last = best_key;
-    }
-    *cellp = v;
-    const bool was = v0e >= c.cut_occ, now = v >= c.cut_occ;
-    if (was != now) { const int e = exy[own[o]]; toggled(e & 0xFFFF, e >> 16, now); }
-  };
-  {
-    const bool mine = tid < n_cells && ecnt[tid] <= kEvCap;
-    double* cellp = nullptr;
-    double v0e = 0.0;
-    if (mine) { const int e = exy[own[tid]]; cellp = cell_ptr(e & 0xFFFF, e >> 16); v0e = *cellp; }
-    fetch_plain(0);
-    if (mine) replay_slot(tid, cellp, v0e);
-    for (int o = tid + nthr; o < n_cells; o += nthr) {  // (more end-point cells than threads: long scans)
-      if (ecnt[o] > kEvCap) continue;
-      const int e = exy[own[o]];
-      double* cp = cell_ptr(e & 0xFFFF, e >> 16);
-      replay_slot(o, cp, *cp);
-    }
-  }
-  // 2b. overflowed slots: one wave per cell.  Lanes test beams q = 64*i + lane against the cell (is it q's end
-  //     point / one of q's free cells); the two ballots are the cell's update sequence for those 64 beams,
-  //     replayed in bit (= beam) order.  Pre-filter: Bresenham cells lie within half a cell of the line
-  //     robot -> end point, so a cell whose perpendicular distance to that line exceeds ONE cell
-  //     (cross^2 > |d|^2, exact in f64) cannot be on the ray.
-  const int trips = (Bv + kWave - 1) / kWave;
-  for (int o = wid; o < n_cells; o += nw) {
-    if (ecnt[o] <= kEvCap) continue;
-    const int eo = exy[own[o]], cx = eo & 0xFFFF, cy = eo >> 16;
-    double* const cellp = cell_ptr(cx, cy);
-    const double v0o = *cellp;
-    double v = v0o;
-    const int ux = cx - rx, uy = cy - ry;
-    for (int i = 0; i < trips; ++i) {
-      const int q = i * kWave + lane;
-      bool is_end = false, hit = false;
-      if (q < Bv) {
-        const int eq = exy[q], qx = eq & 0xFFFF, qy = eq >> 16;
-        is_end = (qx == cx) && (qy == cy);  // the end point is never one of its own ray's free cells
-        const int dx = qx - rx, dy = qy - ry;
-        const double cr = (double)(ux * dy - uy * dx), l2 = (double)(dx * dx + dy * dy);
-        // a ray only visits cells inside the box spanned by the robot cell and its end point
-        const bool outside = (cx < rx && cx < qx) || (cx > rx && cx > qx) || (cy < ry && cy < qy) || (cy > ry && cy > qy);
-        if (!is_end && !outside && cr * cr <= l2) hit = on_ray(make_ray(rx, ry, qx, qy), cx, cy);
-      }
-      const unsigned long long occm = __ballot(is_end), freem = __ballot(hit);
-      unsigned long long m = occm | freem;
-      while (m) {
-        const int bit = __ffsll((long long)m) - 1;
-        v += ((occm >> bit) & 1ull) ? c.d_occ : c.d_free;
-        m &= m - 1;
-      }
-    }
-    if (lane == 0) {
-      *cellp = v;
-      const bool was = v0o >= c.cut_occ, now = v >= c.cut_occ;
-      if (was != now) toggled(cx, cy, now);
-    }
-  }
-  PHASE_STAMP(3);
-  // 3. every other touched cell: its count of free adds (the first eight per thread are already here)
-  finish_plain(0);
-  for (int base = nthr * kPer; base < ncell; base += nthr * kPer) {
-    fetch_plain(base);
-    finish_plain(base);
-  }
-  __syncthreads();
-  // the row counts / occupied count of the particle: one plain update per changed row (this workgroup owns them)
-  for (int r = tid; r <= (bx1 >> kTSh) - tx0; r += nthr) if (rc_delta[r]) rc[tx0 + r] += rc_delta[r];
-  if (tid == 0 && nocc_delta) n_occ[p] += nocc_delta;
-  if (touched) {  // measurement hook (tbnav_rbpf_scan_counts): [0] += cell updates (free adds + end points), [1] += distinct cells written
-    __shared__ int cnt_upd, cnt_dis;
-    if (tid == 0) { cnt_upd = 0; cnt_dis = n_cells; }
-    __syncthreads();
-    int n_upd = 0;
-    for (int b = tid; b < Bv; b += nthr) {
-      const int e = exy[b], dx = (e & 0xFFFF) - rx, dy = (e >> 16) - ry;
-      n_upd += max(dx < 0 ? -dx : dx, dy < 0 ? -dy : dy) + 1;  // free cells of the ray (its Chebyshev length) + the end point
-    }
-    n_upd = wave_sum_i(n_upd); n_distinct = wave_sum_i(n_distinct);
-    if (lane == 0) { atomicAdd(&cnt_upd, n_upd); atomicAdd(&cnt_dis, n_distinct); }
-    __syncthreads();
-    if (tid == 0) { atomicAdd(&touched[0], (unsigned long long)cnt_upd); atomicAdd(&touched[1], (unsigned long long)cnt_dis); }
-  }
-  PHASE_STAMP(4);
-#ifdef TBNAV_PHASE_PROF
-  if (tid == 0) {
-    int novf = 0;
-    for (int o = 0; o < n_cells; ++o) novf += ecnt[o] > kEvCap;
-    atomicAdd(&g_phase[5], (unsigned long long)novf); atomicAdd(&g_phase[6], (unsigned long long)n_cells); atomicAdd(&g_phase[7], 1ull);
-  }
-#endif
-}
-
 // ---- dense view of the occupancy bits -----------------------------------------------------------------------
 // The packed form of a ray straight from its two ends, selects only (what pack_ray(make_ray(..)) returns; the Ray struct's
 // case analysis turns into a private array the compiler indexes at run time).  Along the major axis the ray starts at
@@ -3549,7 +3258,7 @@ struct tbnav_rbpf {
   std::vector<double2> beam_cs;  // (cos, sin) of every beam's angle in the sensor frame, kept between scans
   std::vector<double2> beams_tmp;
   int raycast_band_rows = 0;   // > 0: cap the LDS array of rbpf_raycast_box at about this many box rows (TBNAV_RBPF_OPT_RAYCAST_BAND_ROWS, tests)
-  int raycast_form = 0;        // 0 = box counters (rbpf_raycast_box), 1 = event slots (rbpf_raycast_tile) (TBNAV_RBPF_OPT_RAYCAST_FORM)
+  int raycast_form = 0;        // 0 = box counters (rbpf_raycast_box), 1 = the beam-ordered kernel (rbpf_raycast) (TBNAV_RBPF_OPT_RAYCAST_FORM)
   double* d_sens = nullptr;    // [N][4] sensor transform (X, Y, sin, cos) of each particle's new pose, left by the proposal kernel
   uint64_t seed = 0x5EEDull, scan_index = 0;  // device noise source (normals == NULL)
   uint64_t rng_first = 0, rng_n_global = 0;   // sharded filters: this handle's particles are [rng_first, rng_first + N) of rng_n_global (0 = unsharded)
@@ -3957,25 +3666,8 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens,
   hipStream_t st = h->stream;
   StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
   const int bvn = c.Bv > 0 ? c.Bv : 1;
-  // The LDS counter tile covers the scan's bounding box: every end point lies within (longest valid beam of THIS scan
-  // + the laser's offset) of the robot cell, +2 cells for rounding — usually well below the worst case the handle
-  // was sized for (range_max), which is what lets more than two workgroups share a CU.
-  int cap = 0;
-  if (h->tile_cap > 0) {
-    const double reach = c.rmax + std::hypot(h->p.Trs[1], h->p.Trs[2]);
-    const long side = 2 * ((long)std::ceil(reach / h->p.resolution) + 2) + 1;
-    cap = (int)std::min<long>(side * side, h->tile_cap);
-  }
-  // two forms of the kernel: 16-bit tile fields / 16 events per slot / 1024 threads (any scan), and 10-bit fields /
-  // 8 events / 512 threads for scans of at most 511 valid beams when that brings a workgroup under 40 KB of LDS
-  // (four workgroups = 32 waves per CU instead of two)
-  const size_t lds16 = sizeof(int) * (3 + 16 / 2) * bvn + sizeof(unsigned int) * TileF<16>::words((size_t)cap);
-  const size_t lds10 = sizeof(int) * (3 + 8 / 2) * bvn + sizeof(unsigned int) * TileF<10>::words((size_t)cap);
   const MapT M = map_of(h);
   int nt = h->raycast_threads;
-  const bool small_ok = c.Bv <= 511 && lds10 + 2048 <= 40 * 1024;
-  // measured at cfg3 (N = 1000 / 4000): 1024 threads x 2 per CU 69.5 / 266 us; 512 threads x 4 per CU (10-bit form, 37 KB of
-  // LDS) 81 / 355 us; 256 threads 113 / 391 us — with 32 waves resident either way, fewer and larger workgroups win
   const bool nt_auto = nt == 0;
   if (nt == 0) nt = 1024;
   // rbpf_raycast_box: one u32 per cell of the box, the box padded to whole groups of 8 cells along y
@@ -4022,18 +3714,7 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens,
     TBNAV_HIP(hipGetLastError());
     return TBNAV_OK;
   }
-  const bool small = nt == 512 && small_ok;
-  const size_t tile_lds = small ? lds10 : lds16;
-  if (cap > 0 && !h->ref_field && c.Bv < 32768 && tile_lds <= (size_t)kMaxLds - 2048) {
-    unsigned long long* touched = h->count_touched ? h->d_touched : nullptr;
-#define TBNAV_RAYCAST(NT, FW, EC) hipLaunchKernelGGL((rbpf_raycast_tile<NT, FW, EC>), dim3(count), dim3(NT), tile_lds, st, c, h->pool, M, beams_dev, sp.pose, sens, \
-                                                     h->d_trow[h->cur], h->d_nocc[h->cur], err, cap, touched, gp)
-    if (small) TBNAV_RAYCAST(512, 10, 8);
-    else if (nt == 256) TBNAV_RAYCAST(256, 16, 16);
-    else if (nt == 512) TBNAV_RAYCAST(512, 16, 16);
-    else TBNAV_RAYCAST(1024, 16, 16);
-#undef TBNAV_RAYCAST
-  } else {
+  {
     // beam-ordered kernel: scans the LDS tile cannot hold, and the reference distance-field mode (it logs the
     // occupied-set changes in the reference's order)
     OccLog log{nullptr, nullptr, 0};
@@ -4496,10 +4177,6 @@ int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf*
     e = (C == 64) ? hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_edt<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)
                   : hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_edt<32>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_tile<256, 16, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 2048);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_tile<512, 16, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 2048);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_tile<512, 10, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 2048);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_tile<1024, 16, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 2048);
   // (2.3 KB of static LDS: the embedded normalise's scan scratch)
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_box<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 4096);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_box<512>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 4096);
@@ -4563,13 +4240,14 @@ void tbnav_rbpf_destroy(tbnav_rbpf* h) {
     unsigned long long tp[2][4][16];
     if (hipMemcpyFromSymbol(tp, HIP_SYMBOL(g_trace_p), sizeof(tp)) == hipSuccess && tp[0][0][0]) {
       for (int g = 0; g < 2; ++g) {
-        std::fprintf(stderr, "[rbpf_propose trace of workgroup %d, us; columns: entry, bitmap slice staged, samples drawn (barrier), lookups done, barrier, "
-                             "unstable list (barrier), -, products (barrier), weights (barrier), mean (barrier), end | centre's sensor transform known, table ids in LDS (barrier)]\n", g ? 100 : 96);
+        std::fprintf(stderr, "[rbpf_propose trace of workgroup %d, us; columns: loads requested, centre's sensor transform known, table ids in LDS (barrier), "
+                             "slice staged (barrier), step 1 done (wave 0: samples + odometry likelihoods; others: centre lookups), barrier (+ deferred searches), "
+                             "stable product + unstable list (barrier), pairs / products / weights (barrier), sums, end]\n", g ? 100 : 96);
         unsigned long long t0 = ~0ull;
         for (int w = 0; w < 4; ++w) if (tp[g][w][0] && tp[g][w][0] < t0) t0 = tp[g][w][0];
         for (int w = 0; w < 4; ++w) {
           std::fprintf(stderr, "  wave %d:", w);
-          for (int i = 0; i < 13; ++i) std::fprintf(stderr, " %6.2f", tp[g][w][i] ? (double)(tp[g][w][i] - t0) * 0.01 : -1.0);
+          for (int i = 0; i < 10; ++i) std::fprintf(stderr, " %6.2f", tp[g][w][i] ? (double)(tp[g][w][i] - t0) * 0.01 : -1.0);
           std::fprintf(stderr, "\n");
         }
       }

@@ -12,6 +12,7 @@
 #define TBNAV_BMAPPING_CLOUD_ALIGNMENT_HPP
 
 #include <functional>
+#include <iostream>
 #include <vector>
 
 #include "bmapping/sensor_model.hpp"
@@ -40,7 +41,15 @@ class ScanAlignment {
     }
     bool ok = true;
     if (matcher_) ok = matcher_(T, T_init, prev_scan_, scan);
-    else T = T_init;
+    else {
+      // No scan matcher plugged in: the initial guess goes back unchanged (what a PCL ICP that converges onto its guess returns).
+      // A node linked against this header WITHOUT setMatcher() therefore runs on odometry alone — say so, once.
+      if (!warned_) {
+        std::cerr << "bmapping::ScanAlignment: no scan matcher set (setMatcher); pclICPWrapper returns its initial guess" << std::endl;
+        warned_ = true;
+      }
+      T = T_init;
+    }
     if (ok) prev_scan_ = scan;
     return ok;
   }
@@ -51,6 +60,7 @@ class ScanAlignment {
   Matcher matcher_;
   std::vector<float> prev_scan_;
   bool have_prev_ = false;
+  bool warned_ = false;
 };
 
 }  // namespace bmapping

@@ -72,7 +72,7 @@ class MPPI:
 
     def _name_kernel(self):
         v = self._L.tbnav_mppi_rollout_variant(self._h)
-        seq = ("mppi_rollout_cost", "mppi_rollout_cost_reg", "mppi_rollout_prefix")[max(0, self._L.tbnav_mppi_streaming_form(self._h))]
+        seq = ("mppi_rollout_cost", "mppi_rollout_cost", "mppi_rollout_prefix")[max(0, self._L.tbnav_mppi_streaming_form(self._h))]
         self.rollout_kernel = (seq if v == 0 else f"mppi_rollout_scan<{v} steps/thread>" if v > 0
                                else f"mppi_rollout_fused<{-v} rollouts/workgroup> (rollout + partial records)")
 

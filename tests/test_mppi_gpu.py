@@ -348,21 +348,22 @@ def test_device_sincos_accuracy(gpu_pkg):
     assert np.allclose(sb * sb + cb * cb, 1.0, atol=1e-12)
 
 
-@pytest.mark.parametrize("form", ["prefix", "reg"])
+@pytest.mark.parametrize("form", ["prefix", "general"])
 @pytest.mark.parametrize("K,horizon", [(32768 + 37, 1.0), (32768, 0.6), (40000, 0.12), (33000, 0.32), (32800, 4.0)])
 def test_streaming_rollout_kernel_against_the_oracle(gpu_pkg, K, horizon, form):
     """The large-K rollout kernels (K/64 >= 2 waves per CU-SIMD pair, T a multiple of 4) against the oracle tick.
-    "prefix" = mppi_rollout_prefix (round 3: exclusive prefixes of the losses written as the rollout goes, exact suffix sums for
-    the last 4 / 8 / 12 steps, J = total - prefix formed by mppi_partials and the getter); "reg" = mppi_rollout_cost_reg (round 2).
-    T = 100 (late region of one group), 60 (three), 32 (two), 12 (too short for a round: the round-2 kernel either way), 400 (no
-    LDS stage could hold it: prefix form only); a ragged last wave; two ticks of warm start."""
+    "prefix" = mppi_rollout_prefix (exclusive prefixes of the losses written as the rollout goes, exact suffix sums for the last
+    4 / 8 / 12 steps, J = total - prefix formed by mppi_partials and the getter); "general" = mppi_rollout_cost, the one fallback
+    (any T, either dynamics; round 2's mppi_rollout_cost_reg between the two was removed in round 4).
+    T = 100 (late region of one group), 60 (three), 32 (two), 12 (too short for a round: the general kernel either way), 400 (no
+    LDS stage could hold it); a ragged last wave; two ticks of warm start."""
     from rtn_amd import capi
     d = mppi_cfg(K, horizon)
     m = make_mppi(gpu_pkg, d, kernel=0)  # (at these sizes the handle's own choice is the time-parallel kernel: tested below)
     T = orc.mppi_steps(d)
-    if form == "reg":
+    if form == "general":
         m.setOption(capi.MPPI_OPT_PREFIX_FORM, 0)
-    want = {"prefix": "mppi_rollout_prefix" if T >= 16 else "mppi_rollout_cost_reg", "reg": "mppi_rollout_cost_reg" if T <= 100 else "mppi_rollout_cost"}[form]
+    want = {"prefix": "mppi_rollout_prefix" if T >= 16 else "mppi_rollout_cost", "general": "mppi_rollout_cost"}[form]
     assert m.steps == T and T % 4 == 0 and m.rollout_kernel == want, m.rollout_kernel
     m.setWaypoint(*WAYPOINTS[2])
     u = np.zeros((2, T)); x0 = (0.3, -0.2, 0.7)
@@ -370,6 +371,42 @@ def test_streaming_rollout_kernel_against_the_oracle(gpu_pkg, K, horizon, form):
         ref = _check_tick(m, d, u, (0, 0), WAYPOINTS[2], x0, _noise(90 + tick, K, T))
         u = ref["u"]
         x0 = (x0[0] + 0.002, x0[1] - 0.001, x0[2] + 0.003)
+    assert m.lastKernelNames()[0].startswith(want + "<")
+    m.close()
+
+
+@pytest.mark.parametrize("lam", [1e-3, 1.0])
+def test_prefix_form_across_lambda_and_an_overflowing_rollout(gpu_pkg, lam):
+    """Round-3 advisor findings on the prefix form.  (1) Its prefix rows carry an absolute error of eps * S (S = the rollout's
+    whole cost) where the suffix sums carried eps * J(i); the soft-min divides by lambda, so the bound moves with lambda: held
+    here at a tenth of the shipped lambda (and at lambda = 1) — J within 1e-12 relative as everywhere, controls within 1e-6
+    relative (north star: 1e-5; at the shipped 0.01 every test asserts 1e-9).  (2) A rollout whose total overflows to +inf must
+    weigh NOTHING (J = +inf on every row, as the suffix-sum kernels give it) — its prefix rows alone are finite and would make
+    it the cheapest rollout of the step: the tick with one such rollout equals the tick with that rollout's noise zeroed out
+    of the sums, i.e. finite controls close to the ensemble's."""
+    K, horizon = 32768 + 64, 1.0
+    d = mppi_cfg(K, horizon, lam=lam)
+    T = orc.mppi_steps(d)
+    m = make_mppi(gpu_pkg, d, kernel=0)
+    assert m.rollout_kernel == "mppi_rollout_prefix"
+    m.setWaypoint(*WAYPOINTS[2])
+    noise = _noise(5, K, T)
+    x0 = (0.3, -0.2, 0.7)
+    ref = orc.mppi_new_controls(d, np.zeros((2, T)), (0, 0), WAYPOINTS[2], x0, noise)
+    got = m.newControls(*x0, noise)
+    assert rel_err(m.costToGo(), ref["J"]) < J_RTOL
+    assert np.allclose(got, ref["out"], rtol=1e-6, atol=1e-9) and np.allclose(m.getControls(), ref["u"], rtol=1e-6, atol=1e-9)
+    # (2) one rollout with absurd late controls: its loss overflows in the horizon's second half (finite prefixes before that)
+    m.setInitialControls(0.0, 0.0)
+    bad = noise.copy()
+    bad[17, T // 2:, :] = 1e160
+    got_bad = m.newControls(*x0, bad)
+    J = m.costToGo()
+    assert np.all(np.isinf(J[:, 17])) and np.all(np.isfinite(np.delete(J, 17, axis=1)))
+    assert np.all(np.isfinite(got_bad)) and np.all(np.isfinite(m.getControls()))
+    ref_bad = orc.mppi_new_controls(d, np.zeros((2, T)), (0, 0), WAYPOINTS[2], x0, bad)
+    if np.all(np.isfinite(ref_bad["u"])):   # (the reference's own arithmetic on such a rollout: weight exp(-inf) = 0 as well)
+        assert np.allclose(m.getControls(), ref_bad["u"], rtol=1e-6, atol=1e-9)
     m.close()
 
 

@@ -11,7 +11,7 @@ dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream(dev).cuda_stream
 sync = lambda: torch.cuda.synchronize(dev)
 for K, H in ((65536, 1.0), (32768, 1.0), (65536, 0.6)):
-    for name, opts in (("prefix", []), ("reg-tail", [(capi.MPPI_OPT_PREFIX_FORM, 0)]), ("general", [(capi.MPPI_OPT_PREFIX_FORM, 0), (capi.MPPI_OPT_REG_TAIL, 0)])):
+    for name, opts in (("prefix", []), ("general", [(capi.MPPI_OPT_PREFIX_FORM, 0)])):
         m = bench.make_mppi(K, H, 0)
         for o, v in opts:
             m.setOption(o, v)

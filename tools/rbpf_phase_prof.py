@@ -10,6 +10,8 @@ import bench_rbpf
 from rtn_amd import capi
 from rtn_amd.rbpf import ParticleFilter, default_params
 steps, scans = bench_rbpf.workload(12)
+if os.environ.get("TBNAV_DEV_LIB"):
+    capi.LIB_PATH = os.path.abspath(os.environ["TBNAV_DEV_LIB"])
 nt = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 pf = ParticleFilter(default_params(N=N, k=50, map_min=-10.0, map_max=10.0))

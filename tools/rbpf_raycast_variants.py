@@ -1,4 +1,4 @@
-"""A/B of the tile raycast's form (0 = box counters, 1 = the first tile kernel) and workgroup size on the bench
+"""A/B of the map update's form (0 = box counters, 1 = the beam-ordered kernel) and workgroup size on the bench
 workload (BASELINE configs[2]): kernel time from HIP events."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,7 +11,7 @@ from rtn_amd import capi
 from rtn_amd.rbpf import ParticleFilter, default_params
 steps, scans = bench_rbpf.workload(14)
 for N in (1000, 4000):
-    for form, nt in ((0, 0), (0, 512), (1, 1024), (1, 512), (1, 256)):
+    for form, nt in ((0, 0), (0, 512), (0, 1024), (1, 0)):
         pf = ParticleFilter(default_params(N=N, k=50, map_min=-10.0, map_max=10.0))
         pf.setSeed(1); pf.setTiming(True); pf.setOption(capi.RBPF_OPT_RAYCAST_FORM, form); pf.setOption(capi.RBPF_OPT_RAYCAST_THREADS, nt)
         acc, n = {}, 0
