@@ -43,7 +43,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
-PMC_FILE = "r03_traffic_pmc.json"  # rocprofv3 --pmc passes of this round's final build (tools/collect_pmc.sh)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_ROLLOUT_STEP = 48.0          # rollout pass 16 B noise + 8 B J; weighting 8 B J + 16 B noise
 BYTES_ROLLOUT_KERNEL = 24.0            # of which the rollout/cost kernel: reads duL,duR (16 B), writes J (8 B)
@@ -81,48 +80,49 @@ def time_ticks(tick_fn, sync_fn, steps, warmup, barrier):
     return time.perf_counter() - t0
 
 
-def kernel_profile(m, a, b, stream, n):
+def kernel_profile(m, a, b, stream, n, rng=None):
     """Average per-kernel duration (ms), HIP events on the launch stream: each kernel of the tick launched back to back
-    between one event pair (tbnav_mppi_profile_kernels) — a single launch of a 5 us kernel between two events measures
-    the events as much as the kernel, and the rocprofv3 trace in profiles/ would not agree with it."""
-    acc = np.zeros(3)
-    n_tick = min(n, 50)
-    for _ in range(n_tick):  # in tick order, one event pair per launch: right for kernels much longer than an event
-        acc += np.array(m.profileTick(X0, a.data_ptr(), b.data_ptr(), stream))
-    acc /= n_tick
-    if acc[0] >= 0.02:
-        return acc
+    between one event pair (tbnav_mppi_profile_kernels[_rng]) — a single launch of a 5 us kernel between two events measures
+    the events as much as the kernel.  rng = (seed, tick): the PRODUCTION tick's kernels, i.e. the fused kernel's in-kernel-noise
+    instantiation where that is what the timed region ran (round-3 review: the profile launched the resident-noise one)."""
+    if rng is None:
+        acc = np.zeros(3)
+        n_tick = min(n, 50)
+        for _ in range(n_tick):  # in tick order, one event pair per launch: right for kernels much longer than an event
+            acc += np.array(m.profileTick(X0, a.data_ptr(), b.data_ptr(), stream))
+        acc /= n_tick
+        if acc[0] >= 0.02:
+            return acc
     reps = max(2, (min(n, 200) // 2) * 2)
     acc = np.zeros(3)
     rounds = max(1, n // reps)
-    for _ in range(rounds):
-        acc += np.array(m.profileKernels(X0, a.data_ptr(), b.data_ptr(), stream, reps))
+    for r in range(rounds):
+        if rng is None:
+            acc += np.array(m.profileKernels(X0, a.data_ptr(), b.data_ptr(), stream, reps))
+        else:
+            acc += np.array(m.profileKernelsRng(X0, rng[0], rng[1] + r * reps, stream, reps))
     return acc / rounds
 
 
-def pmc_traffic(workload_key, kernel_prefix):
-    """HBM bytes per launch of a kernel from the committed PMC passes (profiles/r01_traffic_pmc.json:
-    separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 read correction calibrated on a known byte count)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
-            wl = json.load(f)["workloads"][workload_key]
-        for name, v in wl.items():
-            if name.startswith(kernel_prefix):
-                return v["hbm_bytes"]
-    except (OSError, KeyError, ValueError):
-        pass
-    return None  # (no PMC pass of this kernel committed for this round: null, never a number from another kernel)
-
-
-def roofline_obj(K, T, ms_kernels, ms_tick, kernel_name, traffic_key=None):
+def roofline_obj(K, T, ms_kernels, ms_tick, kernel_name, grid_threads=None, traffic_key=None):
+    """The dominant kernel against the HBM roofline.  `achieved` / `frac` (= frac_events): SURVEY 8-d's algorithmic bytes of the
+    kernel / its live HIP-event duration in THIS run; `frac_rocprof`: the same bytes / the rocprofv3 average of the row named in
+    `rocprof` (profiles/, committed) — every figure recomputable from one named row.  The two clocks differ for the 5 us kernels
+    (events: launch-to-launch interval of back-to-back launches; rocprofv3: begin-to-end of each dispatch while the tracer
+    spaces the launches out — cold caches, idle clocks), within a few per cent for the long ones."""
+    import bench_profiles as bp
     alg = BYTES_ROLLOUT_KERNEL * K * T
     achieved = alg / (ms_kernels[0] * 1e-3) / 1e9
     tick_gbs = BYTES_PER_ROLLOUT_STEP * K * T / (ms_tick * 1e-3) / 1e9
+    row = bp.rocprof_row(kernel_name, grid_threads)
+    pmc = bp.pmc_row(traffic_key, kernel_name) if traffic_key else None
+    frac_rp = None if row is None else round(alg / (row["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 6)
     return {
         "bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-        "traffic": pmc_traffic(traffic_key, kernel_name.split("<")[0]) if traffic_key else None,
-        "traffic_source": f"profiles/{PMC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" if traffic_key else None,
+        "frac_events": round(achieved / HBM_PEAK_GBS, 6), "frac_rocprof": frac_rp, "rocprof": row,
+        "traffic": None if pmc is None else pmc["hbm_bytes"],
+        "traffic_source": None if pmc is None else pmc["source"] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
         "algorithmic_bytes_per_launch": alg,
         "kernel_ms": {"rollout": round(float(ms_kernels[0]), 6), "partials": round(float(ms_kernels[1]), 6),
                       "combine": round(float(ms_kernels[2]), 6)},
@@ -347,7 +347,9 @@ def main():
         ms_step = el / args.steps * 1e3
         value = world * K * args.steps / el
         # (local launches of this rank's kernels — no exchange — also on a handle with a communicator attached)
-        ms_k = kernel_profile(m, a, b, stream, min(args.steps, 500))
+        # the production tick's own kernels: the in-kernel-noise instantiation the timed region ran
+        ms_k = kernel_profile(m, a, b, stream, min(args.steps, 500), rng=(SEED, 20_000_000))
+        k_rollout, k_combine = m.lastKernelNames()
         line = {
             "metric": "MPPI rollouts/s", "value": round(value, 1), "unit": "rollouts/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 6),
@@ -370,7 +372,8 @@ def main():
                                                   + " of the soft-min records issued by libtbnav_hip.so on the tick's stream (tbnav_mppi_attach_comm)")
                                                  if comm is not None else f"torch.distributed {dist.get_backend()} all-gather from Python (rtn_amd.sharded; the in-library communicator was unavailable or the one-GPU dev switch is on)"),
             "ms_per_step_one_python_call_per_tick": None if el_py is None else round(el_py / args.steps * 1e3, 6),
-            "roofline": roofline_obj(K, T, ms_k, ms_step, m.rollout_kernel, "mppi_K1024_T50" if (K, T) == (1024, 50) else None),
+            "roofline": dict(roofline_obj(K, T, ms_k, ms_step, k_rollout, None, "mppi_K1024_T50" if (K, T) == (1024, 50) else None),
+                             combine_kernel=k_combine),
             # the tick is two dependent launches: what the guide prices for that alone (MI355X_MICROARCH.md, "boundary" row)
             "latency_floor": {"dependent_launches_per_tick": 2, "boundary_us_each": [1.45, 1.9],
                               "note": "K*T*48 B = 2.46 MB lives in L2: the tick is launch / dependent-latency bound, not HBM bound; "
@@ -416,7 +419,7 @@ def main():
             tl = lambda: ml.enqueueDev(X0, al.data_ptr(), bl.data_ptr(), stream)  # noqa: E731
             el_l = time_ticks(tl, sync, 50, 10, lambda: None)
             ms_l = kernel_profile(ml, al, bl, stream, 50)
-            rl = roofline_obj(KL, ml.steps, ms_l, el_l / 50 * 1e3, ml.rollout_kernel, "mppi_K65536_T100")
+            rl = roofline_obj(KL, ml.steps, ms_l, el_l / 50 * 1e3, ml.lastKernelNames()[0], KL, "mppi_K65536_T100")
             rl["workload"] = f"MPPI newControls K={KL}, T={ml.steps} on 1 GPU, noise resident in HBM (the streaming regime)"
             rl["rollouts_per_s"] = round(KL * 50 / el_l, 1)
             line["roofline_large"] = rl

@@ -1972,9 +1972,6 @@ __device__ unsigned long long g_wg[4096][3];    // [workgroup] entry, exit (10 n
 #define WG_OUT()
 #define TRACE_W(i)
 #endif
-#ifndef TBNAV_EXP
-#define TBNAV_EXP 0  // development: -DTBNAV_EXP=<mask> removes parts of the kernel to time the rest (results are then wrong)
-#endif
 constexpr int kBoxEv = 8;     // events a slot holds before it is replayed exhaustively
 constexpr int kHotSide = 7;   // the kHotSide x kHotSide cells round the robot are candidates for a lane of their own ...
 constexpr int kHotMin = 16;   // ... when they collect at least this many free adds
@@ -2059,9 +2056,6 @@ __global__ __launch_bounds__(NT, NT == 512 ? TBNAV_RC512_WAVES : 8) void rbpf_ra
   }
   __syncthreads();
   TRACE_W(1);
-#if defined(TBNAV_STOP) && TBNAV_STOP == 1
-  return;  // (development: instruction counts / kernel time up to this phase — tools/README.md)
-#endif
   // (workgroup-uniform values read from LDS are moved to scalar registers: the kernel has 64 VGPRs to live in)
   auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
   const int rx = uni(srx), ry = uni(sry);
@@ -2088,9 +2082,6 @@ __global__ __launch_bounds__(NT, NT == 512 ? TBNAV_RC512_WAVES : 8) void rbpf_ra
   }
   __syncthreads();
   TRACE_W(2);
-#if defined(TBNAV_STOP) && TBNAV_STOP == 2
-  return;  // (development: instruction counts / kernel time up to this phase — tools/README.md)
-#endif
   if (bad) { if (tid == 0) atomicOr(&err[0], 1); return; }
   const int minx = uni(bx0), maxx = uni(bx1), maxy = uni(by1);
   const int miny = uni(by0) & ~1;                                   // the box starts on an even column and is an even number of
@@ -2171,9 +2162,6 @@ __global__ __launch_bounds__(NT, NT == 512 ? TBNAV_RC512_WAVES : 8) void rbpf_ra
     __syncthreads();
     PHASE_STAMP_W(0);
     TRACE_W(4);
-#if defined(TBNAV_STOP) && TBNAV_STOP == 3
-  return;  // (development: instruction counts / kernel time up to this phase — tools/README.md)
-#endif
     // 1. the walk
     TRACE_W(5);
     if (x0 == minx && tq >= 0 && tq < mtn) {
@@ -2225,11 +2213,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? TBNAV_RC512_WAVES : 8) void rbpf_ra
         unsigned int r0 = 0u, r1 = 0u, r2 = 0u;
         auto look = [&](unsigned int& old) { if (old & kFlag) record(old, b << 1); old = 0u; };
         auto step = [&](auto clipped, unsigned int& fresh, unsigned int& old) {
-#if TBNAV_EXP & 4
-          fresh = 0u;
-#else
           if (!decltype(clipped)::value || (unsigned int)at < band_bytes) fresh = atomicAdd(reinterpret_cast<unsigned int*>(tile_b + at), 1u);  // (clipped: the cells of the ray in this band of rows)
-#endif
           advance();
           look(old);
         };
@@ -2249,9 +2233,6 @@ __global__ __launch_bounds__(NT, NT == 512 ? TBNAV_RC512_WAVES : 8) void rbpf_ra
     TRACE_W(6);
     __syncthreads();  // every event is recorded
     TRACE_W(7);
-#if defined(TBNAV_STOP) && TBNAV_STOP == 4
-  return;  // (development: instruction counts / kernel time up to this phase — tools/README.md)
-#endif
     PHASE_STAMP_W(1);
     // 2. requests and marks in one pass.  The band as PAIRS of cells (16 bytes of a map tile's row, two tile words): pair
     //    tid + i * nthr for i < 4 — consecutive lanes take consecutive pairs, so a wave's request is whole cache lines.  A
@@ -2275,22 +2256,16 @@ __global__ __launch_bounds__(NT, NT == 512 ? TBNAV_RC512_WAVES : 8) void rbpf_ra
         if (col >= bw) { col -= bw; ++row; }
       }
     };
-#if !(TBNAV_EXP & 8)
     pairs(0, [&](int i, uint2 w, int cx, int cy) {
       v[i] = double2{0.0, 0.0};
       if (w.x | w.y) {
         const int mt = map_tile(cx, cy);
         mt_touch[mt] = 1;
-#if !(TBNAV_EXP & 64)
         v[i] = *reinterpret_cast<const double2*>(P.lo + (size_t)mt_id[mt] * kTileCells + in_tile(cx, cy));
-#else
-        v[i] = double2{(double)((size_t)mt_id[mt] * kTileCells + in_tile(cx, cy)) * 1e-300, 0.0};  // (development: no loads)
-#endif
       }
     });
     for (int first = kSl * nthr; first < np; first += kSl * nthr)  // (bands of more than 8 * nthr cells: marks only, their loads follow)
       pairs(first, [&](int, uint2 w, int cx, int cy) { if (w.x | w.y) mt_touch[map_tile(cx, cy)] = 1; });
-#endif
     for (int o = tid; o < Bv; o += nthr) {
       if (ecnt[o] == 0) continue;
       const int e = exy[o];
@@ -2302,9 +2277,6 @@ __global__ __launch_bounds__(NT, NT == 512 ? TBNAV_RC512_WAVES : 8) void rbpf_ra
     __syncthreads();
     PHASE_STAMP_W(2);
     TRACE_W(9);
-#if defined(TBNAV_STOP) && TBNAV_STOP == 5
-  return;  // (development: instruction counts / kernel time up to this phase — tools/README.md)
-#endif
     // C. make the written tiles private to the particle (first write after a resample, or first touch of the area): ONE pop
     //    of the free ring for all of them, then one wave per tile copies 8 KB.  Usually there is nothing to do — and every wave
     //    sees that for itself (one ballot over the at most 64 tiles under the box), without a barrier to agree on it.
@@ -2330,7 +2302,6 @@ __global__ __launch_bounds__(NT, NT == 512 ? TBNAV_RC512_WAVES : 8) void rbpf_ra
       const bool was = v0o >= c.cut_occ, now = vv >= c.cut_occ;
       if (was != now) toggled(cx, cy, now);
     };
-#if !(TBNAV_EXP & 16)
     // 3a. end-point cells whose slot holds every event: one lane each, the events sorted by beam in registers (a
     //     19-comparator network on the 8 sixteen-bit entries; an empty entry sorts last) and applied in that order
     for (int o = tid; o < Bv; o += nthr) {
@@ -2451,18 +2422,13 @@ __global__ __launch_bounds__(NT, NT == 512 ? TBNAV_RC512_WAVES : 8) void rbpf_ra
         }
       }
     }
-#endif
     TRACE_W(12);
     __syncthreads();  // val_e is complete
     TRACE_W(13);
-#if defined(TBNAV_STOP) && TBNAV_STOP == 6
-  return;  // (development: instruction counts / kernel time up to this phase — tools/README.md)
-#endif
     PHASE_STAMP_W(4);
     // 3c. the pairs: a plain cell adds its count, an end-point or hot cell takes the value worked out for it, an untouched one
     //     keeps its own; the pair goes back as one 16-byte store (the tile is private to the particle and nobody else writes
     //     these cells)
-#if !(TBNAV_EXP & 8)
     for (int first = 0; first < np; first += kSl * nthr) {
       if (first) pairs(first, [&](int i, uint2 w, int cx, int cy) { v[i] = (w.x | w.y) ? *reinterpret_cast<const double2*>(cell_ptr(cx, cy)) : double2{0.0, 0.0}; });
       pairs(first, [&](int i, uint2 w, int cx, int cy) {
@@ -2470,11 +2436,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? TBNAV_RC512_WAVES : 8) void rbpf_ra
         // both cells of the pair in ONE loop (two independent chains of adds, predicated on each cell's count): a few
         // straight-line instructions instead of a nest of divergent branches and loops per cell
         const bool plain0 = w.x != 0u && !(w.x & kFlag), plain1 = w.y != 0u && !(w.y & kFlag);
-#if TBNAV_EXP & 1
-        const int c0 = plain0 ? 1 : 0, c1 = plain1 ? 1 : 0;
-#else
         const int c0 = plain0 ? (int)(w.x & 0xFFFFu) : 0, c1 = plain1 ? (int)(w.y & 0xFFFFu) : 0;
-#endif
         const double o0 = v[i].x, o1 = v[i].y;
         double n0 = o0, n1 = o1;
         const int cm = c0 > c1 ? c0 : c1;
@@ -2488,9 +2450,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? TBNAV_RC512_WAVES : 8) void rbpf_ra
           if (w.y & kFlag) n1 = val_e[(w.y >> 16) & 0x7FFFu];
         }
         n_distinct += (plain0 ? 1 : 0) + (plain1 ? 1 : 0);
-#if !(TBNAV_EXP & 32)
         *reinterpret_cast<double2*>(cell_ptr(cx, cy)) = double2{n0, n1};
-#endif
         const bool tog0 = plain0 && ((o0 >= c.cut_occ) != (n0 >= c.cut_occ)), tog1 = plain1 && ((o1 >= c.cut_occ) != (n1 >= c.cut_occ));
         if (tog0 | tog1) {
           if (tog0) toggled(cx, cy, n0 >= c.cut_occ);
@@ -2498,7 +2458,6 @@ __global__ __launch_bounds__(NT, NT == 512 ? TBNAV_RC512_WAVES : 8) void rbpf_ra
         }
       });
     }
-#endif
     PHASE_STAMP_W(5);
   }
   TRACE_W(14);
@@ -3258,6 +3217,7 @@ struct tbnav_rbpf {
   std::vector<double2> beam_cs;  // (cos, sin) of every beam's angle in the sensor frame, kept between scans
   std::vector<double2> beams_tmp;
   int raycast_band_rows = 0;   // > 0: cap the LDS array of rbpf_raycast_box at about this many box rows (TBNAV_RBPF_OPT_RAYCAST_BAND_ROWS, tests)
+  int lk_raycast = -1, lk_raycast_grid = 0, lk_propose = 0;  // the instantiations the last launches were (tbnav_rbpf_last_kernel_names): raycast threads (0 = beam-ordered), its workgroups, propose threads
   int raycast_form = 0;        // 0 = box counters (rbpf_raycast_box), 1 = the beam-ordered kernel (rbpf_raycast) (TBNAV_RBPF_OPT_RAYCAST_FORM)
   double* d_sens = nullptr;    // [N][4] sensor transform (X, Y, sin, cos) of each particle's new pose, left by the proposal kernel
   uint64_t seed = 0x5EEDull, scan_index = 0;  // device noise source (normals == NULL)
@@ -3705,6 +3665,7 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens,
     const int blocks = count + (nz ? 1 : 0);
     const size_t lds_launch = nz ? std::max(lds_win, sizeof(double) * 2 * kNormChunk) : lds_win;  // (workgroup 0's two arrays)
     const int need_slot = (int)(h->rc_launches++ % 3u);
+    h->lk_raycast = nt == 512 ? 512 : 1024; h->lk_raycast_grid = blocks;
     if (nt == 512)
       hipLaunchKernelGGL((rbpf_raycast_box<512>), dim3(blocks), dim3(512), lds_launch, st, c, h->pool, M, beams_dev, sp.pose, sens,
                          h->d_trow[h->cur], h->d_nocc[h->cur], err, (int)cap_win, touched, na, h->d_box_need, h->d_box_need_host, need_slot);
@@ -3722,6 +3683,7 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens,
       const int rc2 = ref_field_prepare_log(h, c.Bv, log);
       if (rc2 != TBNAV_OK) return rc2;
     }
+    h->lk_raycast = 0; h->lk_raycast_grid = count;
     hipLaunchKernelGGL(rbpf_raycast, dim3(count), dim3(kWave), sizeof(int) * (2 * bvn + (h->TT + 31) / 32), st, c, h->pool, M, beams_dev,
                        sp.pose, h->d_trow[h->cur], h->d_nocc[h->cur], err, log, gp);
   }
@@ -3870,6 +3832,7 @@ int scan_enqueue(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3
   // workgroup size: four waves when four workgroups fit a CU's LDS (the 360-beam scans: 38 KB each), eight when the scan's
   // tables leave room for two or three only (1080 beams: 58 KB) — measured: 360 beams 32 us per 1000 particles with 256
   // threads against 43 with 512; the configs[4] shard 0.80 ms with 256 against 0.61 with 512
+  h->lk_propose = (propose_lds + 3072 > (size_t)kMaxLds / 4) ? 2 * kProposeThreads : kProposeThreads;
   if (propose_lds + 3072 > (size_t)kMaxLds / 4)
     hipLaunchKernelGGL((rbpf_propose<2 * kProposeThreads>), dim3(h->N), dim3(2 * kProposeThreads), propose_lds, st, c, beams_dev,
                      h->d_code[h->cur], h->pool, map_of(h), h->d_trow[h->cur], skip_arr, skip_eq, h->df_mode, h->radius, occ_half,
@@ -5599,6 +5562,18 @@ int tbnav_rbpf_reference_field_counts(tbnav_rbpf* h, int32_t* distinct_states, i
 int tbnav_rbpf_set_timing(tbnav_rbpf* h, int32_t enable) {
   if (!h) return TBNAV_ERR_INVALID_ARG;
   h->timing = enable != 0;
+  return TBNAV_OK;
+}
+
+int tbnav_rbpf_last_kernel_names(const tbnav_rbpf* h, char* propose, int32_t propose_cap, char* raycast, int32_t raycast_cap, int32_t* raycast_workgroups) {
+  if (!h) return TBNAV_ERR_INVALID_ARG;
+  if (propose && propose_cap > 0) { if (h->lk_propose) snprintf(propose, (size_t)propose_cap, "rbpf_propose<%d>", h->lk_propose); else propose[0] = 0; }
+  if (raycast && raycast_cap > 0) {
+    if (h->lk_raycast > 0) snprintf(raycast, (size_t)raycast_cap, "rbpf_raycast_box<%d>", h->lk_raycast);
+    else if (h->lk_raycast == 0) snprintf(raycast, (size_t)raycast_cap, "rbpf_raycast");
+    else raycast[0] = 0;
+  }
+  if (raycast_workgroups) *raycast_workgroups = h->lk_raycast_grid;
   return TBNAV_OK;
 }
 

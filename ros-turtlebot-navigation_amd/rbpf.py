@@ -229,6 +229,13 @@ class ParticleFilter:
         return dict(zip(("propose", "raycast", "occupancy", "edt", "normalize", "gather"), [float(x) for x in ms]))
 
 
+    def lastKernelNames(self):
+        """(propose, raycast, raycast workgroups): the instantiations the last launches were, as rocprofv3 prints them."""
+        a, b, n = C.create_string_buffer(64), C.create_string_buffer(64), C.c_int32()
+        capi.check(self._L.tbnav_rbpf_last_kernel_names(self._h, a, 64, b, 64, C.byref(n)), "last_kernel_names")
+        return a.value.decode(), b.value.decode(), int(n.value)
+
+
 class ParticleFilterGroup:
     """tbnav_rbpf_group: ONE process driving the filter over several devices (what bmapping::ParticleFilter(..., n_gpus) holds).
     params.num_particles is the ensemble's N; devices may repeat (members sharing a device exchange by copies, not RCCL)."""

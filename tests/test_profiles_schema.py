@@ -1,0 +1,66 @@
+"""The measurement contract's plumbing, on the CPU: what bench.py / bench_rbpf.py read from profiles/ (bench_profiles.py) is
+what tools/profile_round.sh's summarisers write (profiles/summarize_rocpd.py, tools/pmc_summary.py -> tools/assemble_profiles.py),
+and the committed files of the newest round carry a row for every kernel a bench line points at (round-3 review, weak 12)."""
+import csv
+import json
+import os
+import sqlite3
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench_profiles as bp  # noqa: E402
+
+
+def test_kernel_stats_table_written_by_the_summariser_is_what_the_bench_parses(tmp_path):
+    db = tmp_path / "run_results.db"
+    c = sqlite3.connect(db)
+    c.execute("create table kernels (name text, grid_x int, grid_y int, grid_z int, workgroup_x int, duration int, vgpr_count int, "
+              "sgpr_count int, lds_size int, scratch_size int)")
+    rows = [("void (anonymous namespace)::mppi_rollout_fused<2, 8, 1, true>((anonymous namespace)::RolloutArgs, double const*)", 65536, 1, 1, 512, 5000),
+            ("void (anonymous namespace)::mppi_rollout_fused<2, 8, 1, true>((anonymous namespace)::RolloutArgs, double const*)", 65536, 1, 1, 512, 6000),
+            ("void (anonymous namespace)::rbpf_raycast_box<512>((anonymous namespace)::ScanC)", 512512, 1, 1, 512, 48000),
+            ("void (anonymous namespace)::rbpf_raycast_box<512>((anonymous namespace)::ScanC)", 512000, 1, 1, 512, 50000),
+            ("mppi_partials(int, int)", 8192, 100, 1, 256, 26000)]
+    c.executemany("insert into kernels values (?,?,?,?,?,?,28,80,0,0)", rows)
+    c.commit(); c.close()
+    md = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "summarize_rocpd.py"), str(db)], capture_output=True, text=True, check=True).stdout
+    path = tmp_path / "r99_kernel_stats.md"
+    path.write_text(md)
+    parsed, _ = bp.kernel_stats_rows(str(path))
+    by = {(r["kernel"], r["grid_threads"]): r for r in parsed}
+    assert by[("mppi_rollout_fused<2, 8, 1, true>", 65536)]["calls"] == 2 and abs(by[("mppi_rollout_fused<2, 8, 1, true>", 65536)]["avg_us"] - 5.5) < 1e-9
+    assert by[("rbpf_raycast_box<512>", 512512)]["avg_us"] == 48.0 and by[("rbpf_raycast_box<512>", 512000)]["avg_us"] == 50.0
+    assert by[("mppi_partials", 819200)]["wg"] == 256   # a two-dimensional grid: threads multiply
+
+
+def test_pmc_summary_output_is_what_the_bench_parses(tmp_path):
+    g = tmp_path / "gpurun_out"
+    g.mkdir()
+    for counter, kb in (("FETCH_SIZE", 100.0), ("WRITE_SIZE", 40.0)):
+        with open(g / f"pmc_t_{counter}.csv", "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Kernel_Name", "Counter_Name", "Counter_Value"])
+            for _ in range(4):
+                w.writerow(["void (anonymous namespace)::mppi_rollout_prefix<1>((anonymous namespace)::RolloutArgs)", counter, kb])
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), "t", "1"], capture_output=True, text=True, check=True, cwd=tmp_path).stdout
+    row = json.loads(out)["mppi_rollout_prefix<1>"]
+    assert {"launches", "read_bytes", "write_bytes", "hbm_bytes"} <= set(row)
+    assert row["hbm_bytes"] == int(100.0 * 1024 * 2 + 40.0 * 1024)   # gfx950: FETCH_SIZE counts a 128-B request as 64 B
+
+
+def test_committed_profiles_have_a_row_for_every_kernel_the_bench_lines_point_at():
+    rows, src = bp.kernel_stats_rows()
+    assert src and rows, "profiles/<round>_kernel_stats.md is missing"
+    for kernel, grid in (("mppi_rollout_fused<2, 8, 1, true>", None), ("mppi_rollout_prefix<1>", 65536), ("mppi_partials", None), ("rbpf_propose<256>", 256000)):
+        r = bp.rocprof_row(kernel, grid)
+        assert r is not None and r["avg_us"] > 0 and r["source"].startswith("profiles/"), kernel
+    assert bp.rocprof_row("rbpf_raycast_box<512>", 512 * 1001) or bp.rocprof_row("rbpf_raycast_box<512>", 512 * 1000)
+    assert bp.rocprof_row("mppi_rollout_fused<2, 8, 1, false>") != bp.rocprof_row("mppi_rollout_fused<2, 8, 1, true>")   # never another instantiation's row
+    assert bp.rocprof_row("no_such_kernel<1>") is None
+    for wl, kernel in (("mppi_K1024_T50", "mppi_rollout_fused<2, 8, 1, true>"), ("mppi_K65536_T100", "mppi_rollout_prefix<1>"),
+                       ("rbpf_N1000_k50_400x400_plain_scans_only", "rbpf_raycast_box<512>")):
+        p = bp.pmc_row(wl, kernel)
+        assert p is not None and p["hbm_bytes"] > 0 and wl in p["source"], (wl, kernel)
+    assert bp.pmc_row("mppi_K1024_T50", "mppi_rollout_fused<2, 8, 1, false>") is None
