@@ -1,0 +1,739 @@
+// rbpf_propose.hip — the proposal side of ParticleFilter::SLAM (particle_filter.cpp:158-231, :383-437, :504-599;
+// grid_mapper.cpp:69-133; sensor_model.cpp:43-112): the handle's mixture table, the production noise source, the
+// one-pose likelihood (bmapping::GridMapper::likelihoodFieldModel), the per-particle scan matcher (option N1) and
+// rbpf_propose itself — one workgroup per particle: k samples, one lookup per beam at their centre, stable-beam collapse,
+// Gaussian proposal, new pose, weight *= eta.
+#include "rbpf_device.hpp"
+
+namespace tbnav_rk {
+
+__global__ void rbpf_mix_lut(ScanC c, double* __restrict__ out) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < kMixLut) out[q] = beam_mixture(c, (uint16_t)q);
+}
+// (also carries the scan's beam table from pinned host memory to the device — n_copy entries, 0 = none: one launch and
+//  one dependent boundary fewer per scan than a separate copy)
+// blockIdx.y: scan within a chunk of consecutive scans (tbnav_rbpf_slam_batch draws a few scans ahead in one launch) — scan
+// number scan + y, normals at out + y * out_stride, beam tables at + y * beam_stride.
+// Sharded filters (tbnav_rbpf_set_rng_shard): the handle's local normal j is element base + j of the ENSEMBLE's stream and the
+// resampling offset (slot z_slot of `out`) is element z_index of it, so ranks that share a seed draw disjoint normals — the ones
+// the unsharded filter of all the particles would draw.  base = 0 / z_index = ~0: one contiguous stream of n values (unsharded).
+__global__ void rbpf_sample_normals(size_t n, unsigned long long seed, unsigned long long scan, double* __restrict__ out,
+                                    const double2* __restrict__ host_beams, double2* __restrict__ dev_beams, int n_copy,
+                                    size_t out_stride, size_t beam_stride, size_t base, size_t z_index,
+                                    size_t z_slot) {
+  scan += blockIdx.y; out += blockIdx.y * out_stride; host_beams += blockIdx.y * beam_stride; dev_beams += blockIdx.y * beam_stride;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_copy; i += gridDim.x * blockDim.x) dev_beams[i] = host_beams[i];
+  auto pair = [&](size_t P, double& a_out, double& b_out) {
+    unsigned int r[4];
+    philox4x32_10((scan << 40) + P, seed, r);
+    const unsigned long long a = ((unsigned long long)r[0] << 32) | r[1], b = ((unsigned long long)r[2] << 32) | r[3];
+    const double u1 = ((double)(a >> 11) + 0.5) * 0x1.0p-53, u2 = ((double)(b >> 11) + 0.5) * 0x1.0p-53;
+    const double rad = sqrt(-2.0 * log(u1));
+    double sn, cs;
+    sincospi(2.0 * u2, &sn, &cs);
+    a_out = rad * cs; b_out = rad * sn;
+  };
+  const size_t p0 = base >> 1, pairs = n ? ((base + n - 1) >> 1) - p0 + 1 : 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += (size_t)gridDim.x * blockDim.x) {
+    double va, vb;
+    pair(p0 + i, va, vb);
+    const size_t g0 = 2 * (p0 + i);
+    if (g0 >= base && g0 < base + n) out[g0 - base] = va;
+    if (g0 + 1 >= base && g0 + 1 < base + n) out[g0 + 1 - base] = vb;
+  }
+  if (z_index != ~(size_t)0 && blockIdx.x == 0 && threadIdx.x == 0) {
+    double va, vb;
+    pair(z_index >> 1, va, vb);
+    out[z_slot] = (z_index & 1) ? vb : va;
+  }
+}
+// Whole field of ONE particle for maps whose column envelope does not fit a workgroup's LDS (xsize > ~640): every
+// cell asks the same exact query the likelihood uses (rows i, i+-1, ... on the global bitmap).  On-demand path only
+// (get_occ_dist / get_dist_code / export) — the SLAM path of such maps runs in query mode and never needs it.
+__global__ __launch_bounds__(256) void rbpf_field_by_query(GridC g, int radius, int particle, TilePool P, MapT M,
+                                                           const int* __restrict__ trow_occ, uint16_t* __restrict__ codes) {
+  const size_t G = (size_t)g.xsize * g.ysize;
+  const size_t cell = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell >= G) return;
+  const int ci = (int)(cell / g.xsize), cj = (int)(cell - (size_t)ci * g.xsize);
+  uint16_t* code = codes + (size_t)particle * G;
+  const DistSrc ds{code, occ_of(P, M, trow_occ, particle), make_int4(0, 0, 0, 0), 2, nullptr, nullptr, 0, 0, 0, 0};
+  code[cell] = nearest_code_query(g, ds, radius, ci, cj);  // a cell out of reach keeps its stored code, like the transform
+}
+// GridMapper::likelihoodFieldModel (grid_mapper.cpp:69-133) of ONE particle's map at an arbitrary pose — the host
+// class bmapping::GridMapper's method of that name (tbnav_rbpf_likelihood).  One wave; product in beam order per lane,
+// closed by the wave's butterfly.
+__global__ __launch_bounds__(kWave) void rbpf_likelihood_one(ScanC c, const double2* __restrict__ beams, const uint16_t* __restrict__ codes,
+                                                            TilePool P, MapT M, const int* __restrict__ trow_occ,
+                                                            const int* __restrict__ fstate, int radius, const int* __restrict__ n_occ,
+                                                            double th, double x, double y, double* __restrict__ out, int* __restrict__ err,
+                                                            const double* __restrict__ mixlut) {
+  const int p = c.p0, lane = threadIdx.x;
+  const DistSrc ds{codes ? codes + (size_t)p * c.g.xsize * c.g.ysize : nullptr, occ_of(P, M, trow_occ, p),
+                   make_int4(0, c.g.xsize - 1, 0, c.g.ysize - 1), (codes && fstate[p] == 2) ? 0 : 2, nullptr, nullptr, 0, 0, 0, 0};
+  int oob = 0;
+  const double v = wave_scan_likelihood(c, beams, ds, radius, n_occ[p], th, x, y, lane, &oob, MixLut{nullptr, mixlut});
+  if (oob & 1) atomicOr(&err[0], 1);
+  if (lane == 0) *out = v;
+}
+__global__ __launch_bounds__(kMatchThreads) void rbpf_scanmatch(ScanC c, ScanMatchC sm, const double2* __restrict__ beams,
+                                                                const uint16_t* __restrict__ codes,
+                                                                TilePool P, MapT M,
+                                                                const int* __restrict__ trow_occ, const int* __restrict__ skip,
+                                                                int skip_eq, int df_mode, int radius, int occ_half,
+                                                                const int* __restrict__ n_occ, const int4* __restrict__ win,
+                                                                const double* __restrict__ pose, double* __restrict__ center,
+                                                                double* __restrict__ score, int* __restrict__ err,
+                                                                const int* __restrict__ gate_prev, const double* __restrict__ mixlut) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  if (gate_prev && *gate_prev) return;  // the scan before this one resamples: see rbpf_raycast_box
+  const int p = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
+  double2* lbeams = reinterpret_cast<double2*>(lds);                       // [Bv]
+  double* lut = reinterpret_cast<double*>(lbeams + c.Bv);                 // [kMixLut] mixture term per distance code: the
+  //   matcher scores ~100 poses x Bv beams, nearly all of them a few cells from a wall (sqrt + exp each otherwise)
+  // per-beam cache of looked-up cells, shared by the six waves: [Bv][4] words, slot = parity of (ci, cj) — the four
+  // cells of any 2 x 2 neighbourhood never collide, and the matcher's poses move a beam's end point by a cell or two.
+  // One u64 per entry ((cell + 1) << 16 | code) so that concurrent writers leave a consistent entry either way.
+  unsigned long long* ccache = reinterpret_cast<unsigned long long*>(lut + kMixLut);
+  unsigned long long* const tile_bm = ccache + (size_t)4 * c.Bv;
+  __shared__ double cur[3], best, steps[2], cand[6];
+  __shared__ int refinements, done;
+  const double th0 = pose[p * 3 + 0], x0 = pose[p * 3 + 1], y0 = pose[p * 3 + 2];
+  double s0, c0;
+  sincos(th0, &s0, &c0);
+  const double mu0[3] = {th0 + c.Ticp[0], c0 * c.Ticp[1] - s0 * c.Ticp[2] + x0, s0 * c.Ticp[1] + c0 * c.Ticp[2] + y0};
+  const int nocc = n_occ[p];
+  if (nocc == 0) {  // empty map: the likelihood is 1 everywhere (grid_mapper.cpp:94-98), nothing can improve
+    if (tid == 0) { center[p * 3 + 0] = mu0[0]; center[p * 3 + 1] = mu0[1]; center[p * 3 + 2] = mu0[2]; score[p] = 1.0; }
+    return;
+  }
+  DistSrc ds{codes ? codes + (size_t)p * c.g.xsize * c.g.ysize : nullptr, occ_of(P, M, trow_occ, p),
+             win[p], skip[p] == skip_eq ? 0 : df_mode, tile_bm, reinterpret_cast<const int*>(tile_bm), 0, 0, 0, 0};
+  for (int b = tid; b < c.Bv; b += kMatchThreads) lbeams[b] = beams[b];
+  for (int q = tid; q < kMixLut; q += kMatchThreads) lut[q] = mixlut[q];  // (the handle's table: same values, no sqrt / exp here)
+  for (int q = tid; q < 4 * c.Bv; q += kMatchThreads) ccache[q] = 0ull;
+  if (ds.mode == 2 && occ_half > 0) {  // the same LDS slice of the bitmap as the proposal kernel, round the first guess
+    double Tc[4];
+    sensor_transform(c, mu0[0], mu0[1], mu0[2], Tc);
+    int sci, scj;
+    if (world2cell(c.g, Tc[0], Tc[1], sci, scj)) {
+      const int R0 = max(0, sci - occ_half), R1 = min(c.g.xsize - 1, sci + occ_half);
+      const int W0 = max(0, scj - occ_half) >> 6, W1 = min(c.g.ysize - 1, scj + occ_half) >> 6, nW = W1 - W0 + 1;
+      int* ta = reinterpret_cast<int*>(tile_bm + (size_t)(R1 - R0 + 1) * nW);
+      for (int r = tid; r <= R1 - R0; r += kMatchThreads) {
+        unsigned long long acc = 0ull;
+        for (int w = 0; w < nW; ++w) {
+          const unsigned long long v = ds.occ.word(R0 + r, W0 + w);
+          tile_bm[r * nW + w] = v;
+          acc |= v;
+        }
+        ta[r] = acc != 0ull;
+      }
+      __shared__ unsigned char sm_lut7[128];  // nearest_code_query's 7 x 7 look (visible after the barrier below)
+      if (tid < 128) {
+        int best = 100;
+        for (int cbit = 0; cbit < 7; ++cbit) if ((tid >> cbit) & 1) { const int dc = cbit - 3; best = min(best, dc * dc); }
+        sm_lut7[tid] = (unsigned char)best;
+      }
+      ds.tany = ta; ds.R0 = R0; ds.R1 = R1; ds.W0 = W0; ds.nW = nW; ds.lut7 = sm_lut7;
+    }
+  }
+  if (tid == 0) { cur[0] = mu0[0]; cur[1] = mu0[1]; cur[2] = mu0[2]; steps[0] = sm.lstep; steps[1] = sm.astep; refinements = 0; done = 0; }
+  __syncthreads();
+  int oob = 0;
+  auto likelihood = [&](double th, double x, double y) {
+    double T[4];
+    sensor_transform(c, th, x, y, T);
+    double pr = 1.0;
+    for (int b = lane; b < c.Bv; b += kWave) {
+      const double2 pt = lbeams[b];
+      int ci, cj;
+      if (!world2cell(c.g, T[3] * pt.x - T[2] * pt.y + T[0], T[2] * pt.x + T[3] * pt.y + T[1], ci, cj)) { oob |= 1; continue; }
+      const unsigned long long cell1 = (unsigned long long)(ci * c.g.xsize + cj) + 1ull;
+      unsigned long long* slot = ccache + 4 * b + ((ci & 1) | ((cj & 1) << 1));
+      const unsigned long long e = *slot;
+      int cd;
+      if ((e >> 16) == cell1) cd = (int)(e & 0xFFFFull);
+      else {
+        cd = lookup_code<false>(c.g, ds, radius, ci, cj);
+        if (cd < 0) { oob |= 2; continue; }
+        *slot = (cell1 << 16) | (unsigned long long)cd;
+      }
+      pr *= cd < kMixLut ? lut[cd] : beam_mixture(c, (uint16_t)cd);
+    }
+    return wave_prod(pr);
+  };
+  if (wid == 0) {
+    const double l0 = likelihood(cur[0], cur[1], cur[2]);
+    if (lane == 0) best = l0;
+  }
+  __syncthreads();
+  for (int round = 0; round < sm.max_moves; ++round) {
+    {
+      const double sgn = (wid & 1) ? -1.0 : 1.0;
+      double q[3] = {cur[0], cur[1], cur[2]};
+      if (wid < 2) q[1] = cur[1] + sgn * steps[0];
+      else if (wid < 4) q[2] = cur[2] + sgn * steps[0];
+      else q[0] = normalize_angle_PI(cur[0] + sgn * steps[1]);
+      const double sc = likelihood(q[0], q[1], q[2]);
+      if (lane == 0) cand[wid] = sc;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double cb = best;
+      int arg = -1;
+      for (int m = 0; m < 6; ++m) if (cand[m] > cb * (1.0 + 1e-9)) { cb = cand[m]; arg = m; }
+      if (arg >= 0) {
+        const double sgn = (arg & 1) ? -1.0 : 1.0;
+        if (arg < 2) cur[1] = cur[1] + sgn * steps[0];
+        else if (arg < 4) cur[2] = cur[2] + sgn * steps[0];
+        else cur[0] = normalize_angle_PI(cur[0] + sgn * steps[1]);
+        best = cb;
+      } else {
+        steps[0] *= 0.5; steps[1] *= 0.5;
+        if (++refinements >= sm.iters) done = 1;
+      }
+    }
+    __syncthreads();
+    if (done) break;
+  }
+  if (oob & 1) atomicOr(&err[0], 1);
+  if (oob & 2) atomicOr(&err[3], 4);
+  if (tid == 0) { center[p * 3 + 0] = cur[0]; center[p * 3 + 1] = cur[1]; center[p * 3 + 2] = cur[2]; score[p] = best; }
+}
+// err[0] = out of world, err[1] = eta zero, err[2] = pdf variance zero, err[3] = bresenham
+//
+// One workgroup per particle (particle_filter.cpp:158-231).  Round 4's schedule — six barriers on the usual path, nine before:
+//   0. every thread: pose / table / beams requested together; the sensor transform at the centre of the samples, T(pose) * T_icp;
+//      the slice of the occupancy bitmap within reach of the sensor staged in LDS (two round trips: table entries, then rows)
+//   1. wave 0: the k samples, their sensor transforms, how far any of them is from the centre, and — same lanes, no barrier in
+//      between — the odometry likelihood of every sample (:542);
+//      the OTHER waves, beside it: ONE lookup per beam at the centre (cell, code, mixture term) and the distance of the centre's
+//      end point from the nearest border of its cell.  (Round 3 ran the samples first, a barrier, then the two side by side.)
+//   2. [only if a lookup could not be settled by the 7 x 7 look] every thread: the full nearest-obstacle search for those beams
+//   3. wave 0: a beam is STABLE if that distance exceeds what the samples' spread can move an end point
+//          |e_j - e_c|_inf <= max_j |T_j - T_c|_inf + |beam| * max_j |theta_j - theta_c|   (chord <= arc)  + 1e-9 m:
+//      every sample then sees the beam in the centre's cell, i.e. with the centre's term — the k x Bv evaluations of the
+//      reference (grid_mapper.cpp:100-121 from particle_filter.cpp:541) collapse to Bv + (k x the few unstable beams); the
+//      product over the stable beams and the list of the unstable ones, in beam order
+//   4. every thread: one (sample, unstable beam) pair each, kUnCap unstable beams at a time (any number of them: chunks);
+//      [rarely: the full search for pairs that need it]; each sample's thread multiplies its terms in beam order, clamps,
+//      forms likelihoods.at(j) and writes the trace
+//   5. wave 0 alone: the weighted sums, the 3 x 3 LLT, the new pose, weight *= eta (:545-599, :214-231)
+// The ICP-failed branch (:161-176) is steps 0, 1 (every wave looks beams up, at the moved pose), 2 and a product.
+// Same cells, same terms as the reference's brute force; only the ORDER of the products / sums differs (asserted <= 1e-9).
+template <int NT>
+__global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c, const double2* __restrict__ beams,
+                                                                const uint16_t* __restrict__ codes,
+                                                                TilePool P, MapT M,
+                                                                const int* __restrict__ trow_occ, const int* __restrict__ skip,
+                                                                int skip_eq, int df_mode, int radius, int occ_half,
+                                                                const int* __restrict__ n_occ, const int4* __restrict__ win,
+                                                                const double* __restrict__ normals, const double* __restrict__ center,
+                                                                double* __restrict__ pose, double* __restrict__ prev_pose,
+                                                                double* __restrict__ weight, Trace tr, double* __restrict__ sens,
+                                                                int* __restrict__ err, const int* __restrict__ gate_prev,
+                                                                const double* __restrict__ mixlut) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  if (gate_prev && *gate_prev) return;  // the scan before this one resamples: see rbpf_raycast_box
+  const int p = blockIdx.x;
+  const int k = c.k;
+  __shared__ double sh_mix[kMixLds];  // the head of the handle's mixture table (filled below, visible after the first barrier)
+  const MixLut mixL{sh_mix, mixlut};
+  double* smp = lds;               // [k][3]
+  double* pscan = lds + 3 * k;     // [k]
+  double* ppose = lds + 4 * k;     // [k]
+  double* stf = lds + 5 * k;       // [k][4] sensor transform of sample j; later reused as wj[k]
+  double* fac = lds + 12 * k;      // [k][kUnCap] per-(sample, unstable beam) terms of one chunk of unstable beams
+  double2* lbeams = reinterpret_cast<double2*>(lds + (12 + kUnCap) * k);  // [Bv] the scan, staged: every later read is an LDS read
+  double* cpz = lds + (12 + kUnCap) * k + 2 * c.Bv;  // [Bv] mixture term of beam b at the samples' centre
+  unsigned int* ctag = reinterpret_cast<unsigned int*>(cpz + c.Bv);  // [Bv] the code it was computed for, or one of kTag*
+  unsigned int* ccell = ctag + c.Bv;                                 // [Bv] the cell that code was looked up at (0xFFFFFFFF: none)
+  float* marg = reinterpret_cast<float*>(ccell + c.Bv);              // [Bv] distance of the centre's end point from its cell's nearest border, rounded DOWN (-1: no code)
+  int* ulist = reinterpret_cast<int*>(marg + c.Bv);                  // [<= Bv] the unstable beams, ascending
+  constexpr unsigned int kTagNone = 0xFFFFFFFFu;    // a windowed lookup outside the window
+  constexpr unsigned int kTagSearch = 0xFFFFFFFEu;  // query mode: the 7 x 7 look did not settle it — step 2
+  constexpr unsigned int kTagOut = 0xFFFFFFFDu;     // the end point is outside the world
+  constexpr unsigned int kBoxHi = 0x7FF8C0DEu;      // high word of a NaN that carries a cell index: a pair term waiting for step 4's search
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
+  const uint16_t* code = codes ? codes + (size_t)p * c.g.xsize * c.g.ysize : nullptr;  // NULL: no stored field (query mode)
+  const double* z = normals + (size_t)p * c.stride_normals;
+  const int nocc = n_occ[p];
+  // a particle whose field is authoritative (injected / whole-field fresh) always reads it
+  // (the tile pointers are set unconditionally — nW == 0 means "no tile" — so that the compiler can see they are LDS
+  //  addresses and use ds_read instead of flat loads in the lookups)
+  unsigned long long* const tile_bm = reinterpret_cast<unsigned long long*>(ulist + c.Bv);
+  DistSrc ds{code, occ_of(P, M, trow_occ, p), win[p], skip[p] == skip_eq ? 0 : df_mode,
+             tile_bm, reinterpret_cast<const int*>(tile_bm), 0, 0, 0, 0};
+  int oob = 0;
+  __shared__ int sh_def[2];  // [0] beams, [1] pairs whose lookup needs the full search (counts that only grow)
+  if (tid == 0) { sh_def[0] = 0; sh_def[1] = 0; }
+
+  // ---- 0. loads, the centre of the samples, the LDS slice of the occupancy bitmap
+  WGP_IN();
+  const double th0v = pose[p * 3 + 0], x0v = pose[p * 3 + 1], y0v = pose[p * 3 + 2];
+  const double pv0 = prev_pose[p * 3 + 0], pv1 = prev_pose[p * 3 + 1], pv2 = prev_pose[p * 3 + 2];
+  // (requested WITH the pose, used much later: the first 64 samples' normals by wave 0, the new pose's three normals and the
+  //  particle's weight by the last step — each was a dependent round trip on the workgroup's critical path)
+  double zj0 = 0.0, zj1 = 0.0, zj2 = 0.0;   // sample tid's normals (samples beyond the workgroup's size load theirs in step 1)
+  if (c.icp_ok && tid < k) { zj0 = z[3 * tid + 0]; zj1 = z[3 * tid + 1]; zj2 = z[3 * tid + 2]; }
+  double zz0 = 0.0, zz1 = 0.0, zz2 = 0.0, w_old = 0.0;
+  if (c.icp_ok && wid == 0) { zz0 = z[3 * k + 0]; zz1 = z[3 * k + 1]; zz2 = z[3 * k + 2]; w_old = weight[p]; }
+  // (a table of at most NT entries — maps up to 512 x 512 cells at 256 threads — is requested WHOLE here, with the pose: which
+  //  entries the window needs depends on the pose, and waiting for it made the staging below three dependent round trips)
+  const int tt_all = ds.occ.TW * ds.occ.TW;
+  const bool whole_table = ds.mode == 2 && occ_half > 0 && nocc && tt_all <= NT && tt_all <= 256;
+  unsigned int my_id = 0u;
+  if (whole_table && tid < tt_all) my_id = ds.occ.tab[tid];
+  TRACE_P(0);
+  const double th0 = uniform_d(th0v), x0 = uniform_d(x0v), y0 = uniform_d(y0v);
+  double mu0[3];
+  if (!c.icp_ok) {
+    // ICP failed: the pose moves by the odometry motion model (particle_filter.cpp:161-176, :295-322) — every thread works it
+    // out (three draws, two sincos), and the LDS slice of the bitmap is staged round THAT pose's sensor
+    const double w0 = c.Lm[0] * z[0], w1 = c.Lm[1] * z[1], w2 = c.Lm[2] * z[2];
+    const double uw = c.u[0], uvx = c.u[1];
+    if (almost_equal(uw, 0.0)) {
+      mu0[0] = normalize_angle_PI(th0 + w0);
+      mu0[1] = x0 + (uvx * cos(mu0[0]) + w1);
+      mu0[2] = y0 + (uvx * sin(mu0[0]) + w2);
+    } else {
+      mu0[0] = normalize_angle_PI(th0 + uw + w0);
+      mu0[1] = x0 + ((-uvx / uw) * sin(mu0[0]) + (uvx / uw) * sin(mu0[0] + uw) + w1);
+      mu0[2] = y0 + ((uvx / uw) * cos(mu0[0]) - (uvx / uw) * cos(mu0[0] + uw) + w2);
+    }
+  } else {
+    double s0, c0;
+    sincos(th0, &s0, &c0);
+    // the mode the samples are drawn round: T(pose) * T_icp, or the particle's own scan-matched pose (N1 option)
+    mu0[0] = center ? center[p * 3 + 0] : th0 + c.Ticp[0];
+    mu0[1] = center ? center[p * 3 + 1] : c0 * c.Ticp[1] - s0 * c.Ticp[2] + x0;
+    mu0[2] = center ? center[p * 3 + 2] : s0 * c.Ticp[1] + c0 * c.Ticp[2] + y0;
+  }
+  mu0[0] = uniform_d(mu0[0]); mu0[1] = uniform_d(mu0[1]); mu0[2] = uniform_d(mu0[2]);
+  const double pv[3] = {uniform_d(pv0), uniform_d(pv1), uniform_d(pv2)};
+  for (int b = tid; b < c.Bv; b += NT) lbeams[b] = beams[b];  // visible after the next barrier
+  for (int q = tid; q < kMixLds; q += NT) sh_mix[q] = mixlut[q];
+  double Tc[4];  // sensor transform at the centre of the samples
+  sensor_transform(c, mu0[0], mu0[1], mu0[2], Tc);
+  Tc[0] = uniform_d(Tc[0]); Tc[1] = uniform_d(Tc[1]); Tc[2] = uniform_d(Tc[2]); Tc[3] = uniform_d(Tc[3]);
+  // (the normals have arrived with the pose: parked in the samples' own LDS slots until wave 0 turns them into samples, so that
+  //  they do not hold six registers through the staging)
+  if (c.icp_ok && tid < k) { smp[3 * tid + 0] = zj0; smp[3 * tid + 1] = zj1; smp[3 * tid + 2] = zj2; }
+  TRACE_P(1);
+  bool staged = false;
+  if (ds.mode == 2 && occ_half > 0 && nocc) {
+    // query mode: stage the bitmap rows/columns within occ_half cells of the sensor in LDS — every lookup of this
+    // block ends within range_max of it, and its nearest obstacle is usually a few cells further at most
+    int sci, scj;
+    if (world2cell(c.g, Tc[0], Tc[1], sci, scj)) {
+      const int R0 = max(0, sci - occ_half), R1 = min(c.g.xsize - 1, sci + occ_half);
+      const int W0 = max(0, scj - occ_half) >> 6, W1 = min(c.g.ysize - 1, scj + occ_half) >> 6, nW = W1 - W0 + 1;
+      unsigned long long* tb = tile_bm;
+      int* ta = reinterpret_cast<int*>(tile_bm + (size_t)(R1 - R0 + 1) * nW);
+      // Two round trips instead of a chain of dependent ones per word: the ids of the tiles under the window go to LDS
+      // first, then every row requests its (up to kStC) 32-bit pieces at once.
+      constexpr int kStC = 12, kStIds = 256;
+      __shared__ unsigned int st_ids[kStIds];
+      const int tr0 = R0 >> kTSh, tc0 = 2 * W0, ntc = min(2 * nW, ds.occ.TW - tc0), n_ids = ((R1 >> kTSh) - tr0 + 1) * ntc;
+      if (ntc <= kStC && (whole_table || n_ids <= kStIds)) {
+        if (whole_table) { if (tid < tt_all) st_ids[tid] = my_id; }
+        else
+          for (int q = tid; q < n_ids; q += NT) {
+            const int qi = floor_div_small(q, ntc);
+            st_ids[q] = ds.occ.tab[(tr0 + qi) * ds.occ.TW + tc0 + (q - qi * ntc)];
+          }
+        __syncthreads();
+        TRACE_P(2);
+        for (int r = tid; r <= R1 - R0; r += NT) {
+          const int row = R0 + r;
+          const unsigned int* ids = whole_table ? st_ids + (row >> kTSh) * ds.occ.TW + tc0 : st_ids + ((row >> kTSh) - tr0) * ntc;
+          unsigned int v32[kStC];
+#pragma unroll
+          for (int q = 0; q < kStC; ++q) v32[q] = q < ntc ? ds.occ.bm[(size_t)ids[q] * kTS + (row & (kTS - 1))] : 0u;
+          unsigned long long acc = 0ull;
+#pragma unroll
+          for (int w = 0; w < kStC / 2; ++w) {
+            if (w < nW) {
+              const unsigned long long v = (unsigned long long)v32[2 * w] | ((unsigned long long)v32[2 * w + 1] << 32);
+              tb[r * nW + w] = v;
+              acc |= v;
+            }
+          }
+          ta[r] = acc != 0ull;
+        }
+      } else {
+        for (int r = tid; r <= R1 - R0; r += NT) {
+          unsigned long long acc = 0ull;
+          for (int w = 0; w < nW; ++w) {
+            const unsigned long long v = ds.occ.word(R0 + r, W0 + w);
+            tb[r * nW + w] = v;
+            acc |= v;
+          }
+          ta[r] = acc != 0ull;
+        }
+      }
+      // the 128-entry table of the 7 x 7 look (visible after the barrier below)
+      __shared__ unsigned char sh_lut7[128];
+      if (tid < 128) {
+        int best = 100;
+        for (int cbit = 0; cbit < 7; ++cbit) if ((tid >> cbit) & 1) { const int dc = cbit - 3; best = min(best, dc * dc); }
+        sh_lut7[tid] = (unsigned char)best;
+      }
+      ds.tany = ta; ds.R0 = R0; ds.R1 = R1; ds.W0 = W0; ds.nW = nW; ds.lut7 = sh_lut7;
+    }
+    __syncthreads();
+    staged = true;
+  }
+  if (!staged) __syncthreads();  // lbeams / sh_mix / sh_def
+  TRACE_P(3);
+  zz0 = uniform_d(zz0); zz1 = uniform_d(zz1); zz2 = uniform_d(zz2); w_old = uniform_d(w_old);  // (arrived long ago; wave-uniform: scalar registers from here on)
+
+  // ---- 1. wave 0 (ICP ok): samples, their sensor transforms, their odometry likelihoods.  The other waves (ICP failed: every
+  //      wave): one lookup per beam at the centre.
+  constexpr int kPW = NT / kWave;
+  __shared__ double sh_spread[2];
+  double dxy = 0.0, dth = 0.0;  // wave 0: how far any sample's sensor is from the centre's
+  if (c.icp_ok && wid == 0) {
+    int var_err = 0;
+    const double nrot1 = uniform_d(normalize_angle_PI(c.rot1)), nrot2 = uniform_d(normalize_angle_PI(c.rot2));
+    for (int j = lane; j < k; j += kWave) {
+      double sj[3];
+      const bool parked = j < NT;
+      const double n0 = parked ? smp[3 * j + 0] : z[3 * j + 0], n1 = parked ? smp[3 * j + 1] : z[3 * j + 1], n2 = parked ? smp[3 * j + 2] : z[3 * j + 2];
+      sj[0] = mu0[0] + c.Ld[0] * n0; sj[1] = mu0[1] + c.Ld[1] * n1; sj[2] = mu0[2] + c.Ld[2] * n2;
+      dth = fmax(dth, fabs(c.Ld[0] * n0));
+      sj[0] = normalize_angle_PI(sj[0]);
+      smp[3 * j + 0] = sj[0]; smp[3 * j + 1] = sj[1]; smp[3 * j + 2] = sj[2];
+      {
+        double T[4];
+        sensor_transform(c, sj[0], sj[1], sj[2], T);
+        stf[4 * j + 0] = T[0]; stf[4 * j + 1] = T[1]; stf[4 * j + 2] = T[2]; stf[4 * j + 3] = T[3];
+        dxy = fmax(dxy, fmax(fabs(T[0] - Tc[0]), fabs(T[1] - Tc[1])));
+      }
+      // (the samples' spread first: the other waves' step 3 needs it, nothing needs the odometry likelihoods before step 4)
+      ppose[j] = pose_likelihood_odom(c, &smp[3 * j], pv, &var_err, nrot1, nrot2);   // (:542: against prev_pose as it stands — updated only after this call)
+    }
+    dxy = wave_max_d(dxy); dth = wave_max_d(dth);
+    if (lane == 0) { sh_spread[0] = dxy; sh_spread[1] = dth; }
+    if (var_err) atomicOr(&err[2], 1);
+  } else if (nocc) {
+    const int b_first = c.icp_ok ? tid - kWave : tid, b_step = c.icp_ok ? NT - kWave : NT;
+    bool deferred = false;
+    for (int b = b_first; b < c.Bv; b += b_step) {
+      const double2 pt = lbeams[b];
+      const double ex = Tc[3] * pt.x - Tc[2] * pt.y + Tc[0], ey = Tc[2] * pt.x + Tc[3] * pt.y + Tc[1];
+      int ci, cj;
+      unsigned int tag = kTagOut, cell = 0xFFFFFFFFu;
+      double pz = 0.0;
+      float mg = -1.0f;
+      if (world2cell(c.g, ex, ey, ci, cj)) {
+        const int cd = lookup_code_fast(c.g, ds, radius, ci, cj);
+        tag = kTagNone;
+        if (cd != -1) {
+          cell = (unsigned int)(ci * c.g.xsize + cj);
+          if (cd == kNeedSearch) { tag = kTagSearch; deferred = true; }
+          else { tag = (unsigned int)cd; pz = mix_term(c, mixL, cd); }
+          const double x_lo = c.g.xmin + ci * c.g.res, x_hi = c.g.xmin + (ci + 1) * c.g.res;
+          const double y_lo = c.g.ymin + cj * c.g.res, y_hi = c.g.ymin + (cj + 1) * c.g.res;
+          // (kept as a float rounded DOWN: a beam can only become unstable by it, never wrongly stable)
+          mg = __double2float_rd(fmin(fmin(ex - x_lo, x_hi - ex), fmin(ey - y_lo, y_hi - ey)));
+        }
+      }
+      ctag[b] = tag; ccell[b] = cell; cpz[b] = pz; marg[b] = mg;
+    }
+    if (deferred) atomicAdd(&sh_def[0], 1);
+  }
+  TRACE_P(4);
+  __syncthreads();
+  // ---- 2. the lookups the 7 x 7 look did not settle (a beam that ends more than three cells from every obstacle the slice
+  //      shows: the first scans of a map, a doorway): the full search, all threads, one inlined copy
+  if (sh_def[0]) {  // workgroup-uniform
+    for (int b = tid; b < c.Bv; b += NT) {
+      if (ctag[b] != kTagSearch) continue;
+      const int cell = (int)ccell[b], ci = cell / c.g.xsize, cj = cell - ci * c.g.xsize;
+      const int cd = nearest_code_query_body(c.g, ds, radius, ci, cj);
+      ctag[b] = (unsigned int)cd;
+      cpz[b] = mix_term(c, mixL, cd);
+    }
+    __syncthreads();
+  }
+  TRACE_P(5);
+  __shared__ double sh_pst[kPW];
+  if (!c.icp_ok) {
+    // weight *= likelihoodFieldModel(scan, T(new pose)) (:171-175): the product per lane, per wave, then over the waves in wave
+    // order (a fixed order; the reference multiplies beam by beam: tolerance)
+    double pr = 1.0;
+    if (nocc)
+      for (int b = tid; b < c.Bv; b += NT) {
+        const unsigned int tg = ctag[b];
+        if (tg == kTagOut) oob |= 1;          // the reference throws from world2RowMajor
+        else if (tg == kTagNone) oob |= 2;    // (window mode: sized so that this cannot happen — reported, never read stale)
+        else pr *= cpz[b];
+      }
+    pr = wave_prod(pr);
+    if (lane == 0) sh_pst[wid] = pr;
+    if (oob & 1) atomicOr(&err[0], 1);
+    if (oob & 2) atomicOr(&err[3], 4);
+    __syncthreads();
+    if (tid == 0) {
+      double sl = sh_pst[0];
+      for (int w = 1; w < kPW; ++w) sl *= sh_pst[w];
+      if (!nocc) sl = 1.0;  // grid_mapper.cpp:94-98
+      prev_pose[p * 3 + 0] = th0; prev_pose[p * 3 + 1] = x0; prev_pose[p * 3 + 2] = y0;
+      pose[p * 3 + 0] = mu0[0]; pose[p * 3 + 1] = mu0[1]; pose[p * 3 + 2] = mu0[2];
+      tr.new_pose[p * 3 + 0] = mu0[0]; tr.new_pose[p * 3 + 1] = mu0[1]; tr.new_pose[p * 3 + 2] = mu0[2];
+      const double w = weight[p] * sl;
+      weight[p] = w;
+      tr.p_scan[(size_t)p * k] = sl;
+      tr.weight_raw[p] = w;
+      sens[p * 4 + 0] = Tc[0]; sens[p * 4 + 1] = Tc[1]; sens[p * 4 + 2] = Tc[2]; sens[p * 4 + 3] = Tc[3];  // the sensor transform of the new pose, for the raycast kernel
+    }
+    WGP_OUT();
+    return;
+  }
+  // ---- 3. which beams are stable, the product of their terms, the others listed: every wave over ITS contiguous range of
+  //      beams [w C, (w + 1) C), its unstable ones compacted (in beam order) into its own segment of ulist — no wave waits for
+  //      another's count; the pairs below walk the segments in wave order, i.e. the unstable beams in beam order
+  __shared__ int sh_cnt[kPW];
+  const int seg = (c.Bv + kPW - 1) / kPW;  // beams per wave's range
+  {
+    const double sdxy = sh_spread[0], sdth = sh_spread[1];
+    int n = 0;
+    double pst = 1.0;
+    if (nocc) {
+      const int b_lo = wid * seg, b_hi = min(c.Bv, b_lo + seg);
+      for (int b0 = b_lo; b0 < b_hi; b0 += kWave) {
+        const int b = b0 + lane;
+        bool unstable = false;
+        if (b < b_hi) {
+          const double2 pt = lbeams[b];
+          // (|beam| only has to be bounded from above: the fp32 root, rounded up by more than its error)
+          const double delta = sdxy + (double)(sqrtf((float)(pt.x * pt.x + pt.y * pt.y)) * 1.000001f) * sdth + 1e-9;
+          const bool stable = ctag[b] < 0x10000u && (double)marg[b] > delta;
+          if (stable) pst *= cpz[b];
+          unstable = !stable;
+        }
+        const unsigned long long m = __ballot(unstable);
+        if (unstable) ulist[b_lo + n + __popcll(m & ((1ull << lane) - 1ull))] = b;
+        n += __popcll(m);
+      }
+    }
+    pst = wave_prod(pst);
+    if (lane == 0) { sh_cnt[wid] = n; sh_pst[wid] = pst; }
+  }
+  __syncthreads();
+  TRACE_P(6);
+  // ---- 4. scan likelihood of every sample: (product over the stable beams) * (its own terms of the unstable ones)
+  double* wj = stf;  // [k] likelihoods.at(j) (the sensor transforms are dead once the pairs are through)
+  {
+    int n_un = 0;
+    double p_stable = 1.0;  // grid_mapper.cpp:94-98: 1.0 until the map has an occupied cell
+    if (nocc)
+      for (int w = 0; w < kPW; ++w) { n_un += sh_cnt[w]; p_stable *= sh_pst[w]; }
+    // the i-th unstable beam of the scan: segment by segment
+    auto unstable_beam = [&](int i) {
+      int w = 0;
+#pragma unroll
+      for (int q = 0; q < kPW - 1; ++q) { const int cq = sh_cnt[q]; if (w == q && i >= cq) { i -= cq; ++w; } }
+      return ulist[w * seg + i];
+    };
+    for (int j = tid; j < k; j += NT) pscan[j] = p_stable;
+    int seen = 0;
+    for (int u0 = 0; u0 < n_un; u0 += kUnCap) {
+      const int nu = min(kUnCap, n_un - u0);
+      // one THREAD per (sample, unstable beam) of this chunk (grid_mapper.cpp:100-121 for that sample's pose and that beam)
+      bool deferred = false;
+      for (int pair = tid; pair < k * nu; pair += NT) {
+        const int j = floor_div_small(pair, nu), i = pair - j * nu;
+        const int b = unstable_beam(u0 + i);
+        const double2 pt = lbeams[b];
+        const double X = stf[4 * j + 0], Y = stf[4 * j + 1], st = stf[4 * j + 2], ct = stf[4 * j + 3];
+        const double ex = ct * pt.x - st * pt.y + X, ey = st * pt.x + ct * pt.y + Y;
+        int ci, cj;
+        double term = 1.0;
+        if (!world2cell(c.g, ex, ey, ci, cj)) oob |= 1;  // (the reference throws from world2RowMajor)
+        else {
+          const unsigned int cell = (unsigned int)(ci * c.g.xsize + cj);
+          if (cell == ccell[b]) term = cpz[b];  // the centre's cell -> its code -> its term
+          else {
+            const int cd = lookup_code_fast(c.g, ds, radius, ci, cj);
+            if (cd == kNeedSearch) { term = __hiloint2double((int)kBoxHi, (int)cell); deferred = true; }
+            else if (cd < 0) oob |= 2;
+            else term = ((unsigned int)cd == ctag[b]) ? cpz[b] : mix_term(c, mixL, cd);
+          }
+        }
+        fac[j * kUnCap + i] = term;
+      }
+      if (deferred) atomicAdd(&sh_def[1], 1);
+      __syncthreads();
+      const int def_now = sh_def[1];
+      if (def_now != seen) {  // workgroup-uniform: some pair of this chunk waits for the full search
+        seen = def_now;
+        for (int pair = tid; pair < k * nu; pair += NT) {
+          const int j = floor_div_small(pair, nu), i = pair - j * nu;
+          const double v = fac[j * kUnCap + i];
+          if ((unsigned int)__double2hiint(v) != kBoxHi) continue;
+          const int cell = __double2loint(v), ci = cell / c.g.xsize, cj = cell - ci * c.g.xsize;
+          const int cd = nearest_code_query_body(c.g, ds, radius, ci, cj);
+          const int b = unstable_beam(u0 + i);
+          fac[j * kUnCap + i] = ((unsigned int)cd == ctag[b]) ? cpz[b] : mix_term(c, mixL, cd);
+        }
+        __syncthreads();
+      }
+      for (int j = tid; j < k; j += NT) {
+        double pr = pscan[j];
+        for (int i = 0; i < nu; ++i) pr *= fac[j * kUnCap + i];
+        pscan[j] = pr;
+      }
+      if (u0 + kUnCap < n_un) __syncthreads();  // (the next chunk rewrites fac)
+    }
+    if (oob & 1) atomicOr(&err[0], 1);
+    if (oob & 2) atomicOr(&err[3], 4);
+    if (n_un > 0) __syncthreads();  // (stf -> wj: every pair has read its sample's transform)
+    // the sample's own thread: clamps, likelihoods.at(j), the trace (:541-556)
+    for (int j = tid; j < k; j += NT) {
+      const double psj = pscan[j], ppj = ppose[j];
+      const double ps = fmin(fmax(psj, c.scan_min), c.scan_max);  // std::clamp
+      const double pp = fmin(fmax(ppj, c.pose_min), c.pose_max);
+      tr.p_scan[(size_t)p * k + j] = psj;
+      tr.p_pose[(size_t)p * k + j] = ppj;
+      tr.sampled[((size_t)p * k + j) * 3 + 0] = smp[3 * j + 0];
+      tr.sampled[((size_t)p * k + j) * 3 + 1] = smp[3 * j + 1];
+      tr.sampled[((size_t)p * k + j) * 3 + 2] = smp[3 * j + 2];
+      wj[j] = ps * pp;
+    }
+  }
+  __syncthreads();
+  TRACE_P(7);
+  // ---- 5. Gaussian proposal (:522-599), new pose (:214-231): wave 0 alone.  The weighted sums are lane-strided partial sums
+  //      closed with a butterfly — a fixed order, not the reference's left-to-right one: the results agree to rounding
+  //      (asserted at 1e-10 against the oracle) — and every lane of the wave holds them, so nothing goes through LDS again.
+  if (wid != 0) return;
+  double a[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int j = lane; j < k; j += kWave) {
+    const double pj = wj[j];
+    for (int q = 0; q < 3; ++q) a[q] += smp[3 * j + q] * pj;
+    a[3] += pj;
+  }
+  for (int q = 0; q < 4; ++q) a[q] = wave_sum_d(a[q]);
+  const double eta = a[3];
+  if (almost_equal(eta, 0.0)) {  // "eta is 0" (:563, reported): the pose stays, and so does its sensor transform
+    if (lane == 0) {
+      atomicOr(&err[1], 1);
+      double Ts[4];
+      sensor_transform(c, th0, x0, y0, Ts);
+      for (int q = 0; q < 4; ++q) sens[p * 4 + q] = Ts[q];
+    }
+    return;
+  }
+  double mu[3] = {a[0] / eta, a[1] / eta, a[2] / eta};
+  mu[0] = normalize_angle_PI(mu[0]);
+  double su[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int j = lane; j < k; j += kWave) {
+    const double d[3] = {smp[3 * j + 0] - mu[0], smp[3 * j + 1] - mu[1], smp[3 * j + 2] - mu[2]};
+    const double w = wj[j];
+    int o = 0;
+    for (int r = 0; r < 3; ++r) for (int q = r; q < 3; ++q) su[o++] += (d[r] * d[q]) * w;
+  }
+  for (int o = 0; o < 6; ++o) su[o] = wave_sum_d(su[o]);
+  TRACE_P(8);
+  if (lane == 0) {
+    double sigma[3][3];
+    {
+      int o = 0;
+      for (int r = 0; r < 3; ++r) for (int q = r; q < 3; ++q) { sigma[r][q] = su[o] / eta; sigma[q][r] = sigma[r][q]; ++o; }
+    }
+    double L[3][3];
+    llt3(sigma, L);
+    double np[3];
+    for (int r = 0; r < 3; ++r) np[r] = mu[r] + ((L[r][0] * zz0 + L[r][1] * zz1) + L[r][2] * zz2);
+    prev_pose[p * 3 + 0] = th0; prev_pose[p * 3 + 1] = x0; prev_pose[p * 3 + 2] = y0;
+    for (int q = 0; q < 3; ++q) { pose[p * 3 + q] = np[q]; tr.new_pose[p * 3 + q] = np[q]; tr.mu[p * 3 + q] = mu[q]; }
+    for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) tr.sigma[p * 9 + r * 3 + q] = sigma[r][q];
+    tr.eta[p] = eta;
+    const double w = w_old * eta;
+    weight[p] = w;
+    tr.weight_raw[p] = w;
+    double Ts[4];  // the sensor transform of the new pose, for the raycast kernel (saves it two sincos on its critical path)
+    sensor_transform(c, np[0], np[1], np[2], Ts);
+    for (int q = 0; q < 4; ++q) sens[p * 4 + q] = Ts[q];
+  }
+  TRACE_P(9);
+  WGP_OUT();
+}
+template __global__ void rbpf_propose<kProposeThreads>(ScanC, const double2* __restrict__, const uint16_t* __restrict__, TilePool, MapT, const int* __restrict__, const int* __restrict__, int, int, int, int, const int* __restrict__, const int4* __restrict__, const double* __restrict__, const double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, Trace, double* __restrict__, int* __restrict__, const int* __restrict__, const double* __restrict__);
+template __global__ void rbpf_propose<2 * kProposeThreads>(ScanC, const double2* __restrict__, const uint16_t* __restrict__, TilePool, MapT, const int* __restrict__, const int* __restrict__, int, int, int, int, const int* __restrict__, const int4* __restrict__, const double* __restrict__, const double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, Trace, double* __restrict__, int* __restrict__, const int* __restrict__, const double* __restrict__);
+
+}  // namespace tbnav_rk
+
+#ifdef TBNAV_PHASE_PROF
+#include <cstdio>
+#include <map>
+#include <vector>
+namespace tbnav_rk {
+void rbpf_prof_print_propose() {
+    unsigned long long tp[2][4][16];
+    if (hipMemcpyFromSymbol(tp, HIP_SYMBOL(g_trace_p), sizeof(tp)) == hipSuccess && tp[0][0][0]) {
+      for (int g = 0; g < 2; ++g) {
+        std::fprintf(stderr, "[rbpf_propose trace of workgroup %d, us; columns: loads requested, centre's sensor transform known, table ids in LDS (barrier), "
+                             "slice staged (barrier), step 1 done (wave 0: samples + odometry likelihoods; others: centre lookups), barrier (+ deferred searches), "
+                             "stable product + unstable list (barrier), pairs / products / weights (barrier), sums, end]\n", g ? 100 : 96);
+        unsigned long long t0 = ~0ull;
+        for (int w = 0; w < 4; ++w) if (tp[g][w][0] && tp[g][w][0] < t0) t0 = tp[g][w][0];
+        for (int w = 0; w < 4; ++w) {
+          std::fprintf(stderr, "  wave %d:", w);
+          for (int i = 0; i < 10; ++i) std::fprintf(stderr, " %6.2f", tp[g][w][i] ? (double)(tp[g][w][i] - t0) * 0.01 : -1.0);
+          std::fprintf(stderr, "\n");
+        }
+      }
+    }
+    {
+      static unsigned long long wgp[4096][3];
+      if (hipMemcpyFromSymbol(wgp, HIP_SYMBOL(g_wgp), sizeof(wgp)) == hipSuccess && wgp[1][0]) {
+        int n = 0;
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (int i = 0; i < 4096; ++i) if (wgp[i][0] && wgp[i][1]) { ++n; t0 = std::min(t0, wgp[i][0]); t1 = std::max(t1, wgp[i][1]); }
+        const int nb = 16;
+        const double span = (double)(t1 - t0);
+        int active[nb] = {0}, starts[nb] = {0};
+        double dur[nb] = {0};
+        for (int i = 0; i < 4096; ++i) if (wgp[i][0] && wgp[i][1]) {
+          const int bs = std::min(nb - 1, (int)((double)(wgp[i][0] - t0) / span * nb));
+          ++starts[bs]; dur[bs] += (double)(wgp[i][1] - wgp[i][0]) * 0.01;
+          for (int b = 0; b < nb; ++b) { const double tm = t0 + (b + 0.5) * span / nb; if ((double)wgp[i][0] <= tm && tm < (double)wgp[i][1]) ++active[b]; }
+        }
+        std::fprintf(stderr, "[rbpf_propose workgroups of the last launch] %d recorded, first entry to last exit %.2f us; bins of %.2f us\n  resident at mid-bin:", n, span * 0.01, span * 0.01 / nb);
+        for (int b = 0; b < nb; ++b) std::fprintf(stderr, " %5d", active[b]);
+        std::fprintf(stderr, "\n  entered in bin:     ");
+        for (int b = 0; b < nb; ++b) std::fprintf(stderr, " %5d", starts[b]);
+        std::fprintf(stderr, "\n  mean residence (us):");
+        for (int b = 0; b < nb; ++b) std::fprintf(stderr, " %5.1f", starts[b] ? dur[b] / starts[b] : 0.0);
+        // by XCC and by CU: is a slow workgroup's CU slow as a whole?
+        std::map<unsigned long long, std::vector<double>> by_cu;
+        double xs[16] = {0}; int xn[16] = {0};
+        for (int i = 0; i < 4096; ++i) if (wgp[i][0] && wgp[i][1]) {
+          const unsigned int hw = (unsigned int)wgp[i][2], xcc = (unsigned int)(wgp[i][2] >> 32) & 0xF;
+          const double d = (double)(wgp[i][1] - wgp[i][0]) * 0.01;
+          by_cu[((unsigned long long)xcc << 16) | (hw & 0xFF00u)].push_back(d);
+          xs[xcc] += d; ++xn[xcc];
+        }
+        std::fprintf(stderr, "\n  mean residence by XCC:");
+        for (int x = 0; x < 16; ++x) if (xn[x]) std::fprintf(stderr, " %.1f", xs[x] / xn[x]);
+        double spread_in = 0.0; int ncu = 0; double cu_min = 1e9, cu_max = 0; int n3 = 0, n4 = 0; double d3 = 0, d4 = 0;
+        for (auto& kv : by_cu) {
+          double lo = 1e9, hi = 0, sum = 0;
+          for (double d : kv.second) { lo = std::min(lo, d); hi = std::max(hi, d); sum += d; }
+          spread_in += hi - lo; ++ncu;
+          const double mean = sum / kv.second.size();
+          cu_min = std::min(cu_min, mean); cu_max = std::max(cu_max, mean);
+          if (kv.second.size() <= 3) { ++n3; d3 += mean; } else { ++n4; d4 += mean; }
+        }
+        std::fprintf(stderr, "\n  %d CUs; mean (max - min) inside a CU %.1f us; CU means from %.1f to %.1f us; CUs with <= 3 workgroups: %d, mean %.1f us; with 4+: %d, mean %.1f us\n",
+                     ncu, spread_in / std::max(1, ncu), cu_min, cu_max, n3, n3 ? d3 / n3 : 0.0, n4, n4 ? d4 / n4 : 0.0);
+      }
+    }
+}
+}  // namespace tbnav_rk
+#endif

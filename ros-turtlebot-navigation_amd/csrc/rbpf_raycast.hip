@@ -1,0 +1,701 @@
+// rbpf_raycast.hip — GridMapper::integrateScan's map update (grid_mapper.cpp:140-182, :549-807, :438-546): the box-counter
+// kernel rbpf_raycast_box (default: LDS counters over the scan's bounding box, end-point cells replayed in beam order, the
+// weights' normalise / selection riding along as workgroup 0) and the beam-ordered rbpf_raycast (scans the box kernel cannot
+// hold; the reference-field mode, whose occupied-set log it writes).  Bit-identical maps.
+#include "rbpf_device.hpp"
+
+namespace tbnav_rk {
+
+__global__ __launch_bounds__(kWave) void rbpf_raycast(ScanC c, TilePool P, MapT M, const double2* __restrict__ beams,
+                                                     const double* __restrict__ pose, int* __restrict__ trow_occ,
+                                                     int* __restrict__ n_occ, int* __restrict__ err, OccLog log,
+                                                     const int* __restrict__ gate_prev) {
+  extern __shared__ __attribute__((aligned(16))) int lds_i[];
+  if (gate_prev && *gate_prev) return;  // the scan before this one resamples: see rbpf_raycast_box
+  int* ex = lds_i;         // [Bv]
+  int* ey = lds_i + c.Bv;  // [Bv]
+  unsigned int* tbits = reinterpret_cast<unsigned int*>(lds_i + 2 * c.Bv);  // [(TT + 31) / 32] tiles this scan writes
+  __shared__ int bad;
+  const int p = c.p0 + blockIdx.x, lane = threadIdx.x;
+  unsigned int* tab = M.table + (size_t)p * M.TT;
+  unsigned int* shed = M.shed + (size_t)p * M.TT;
+  int* rc = trow_occ + (size_t)p * M.TW;
+  int* nocc = n_occ + p;
+  const double th = pose[p * 3 + 0], x = pose[p * 3 + 1], y = pose[p * 3 + 2];
+  if (lane == 0) bad = 0;
+  const int tword = (M.TT + 31) / 32;
+  for (int w = lane; w < tword; w += kWave) tbits[w] = 0u;
+  __syncthreads();
+  double s0, c0;
+  sincos(th, &s0, &c0);
+  const double X = c0 * c.Trs[1] - s0 * c.Trs[2] + x;
+  const double Y = s0 * c.Trs[1] + c0 * c.Trs[2] + y;
+  double st, ct;
+  sincos(th + c.Trs[0], &st, &ct);
+  for (int b = lane; b < c.Bv; b += kWave) {
+    const double2 pt = beams[b];
+    int ci = 0, cj = 0;
+    if (!world2cell(c.g, ct * pt.x - st * pt.y + X, st * pt.x + ct * pt.y + Y, ci, cj)) bad = 1;
+    ex[b] = ci; ey[b] = cj;
+  }
+  int rx = 0, ry = 0;
+  if (!world2cell(c.g, x, y, rx, ry)) bad = 1;  // freeGridIndex: world2Grid of the ROBOT pose (:558)
+  __syncthreads();
+  if (bad) { if (lane == 0) atomicOr(&err[0], 1); return; }
+  // which tiles does this scan write?  (one extra walk of the rays; this kernel is the fallback / reference-mode path)
+  for (int b = 0; b < c.Bv; ++b) {
+    const int x1 = ex[b], y1 = ey[b];
+    const Ray r = make_ray(rx, ry, x1, y1);
+    for (int n = lane; n < r.count; n += kWave) {
+      int cx, cy;
+      ray_cell(r, n, cx, cy);
+      const int t = tile_of(M, cx, cy);
+      atomicOr(&tbits[t >> 5], 1u << (t & 31));
+    }
+    if (lane == 0) { const int t = tile_of(M, x1, y1); atomicOr(&tbits[t >> 5], 1u << (t & 31)); }
+  }
+  __syncthreads();
+  {
+    int need = 0;  // tiles to clone: one pop of the ring for all of them
+    for (int w = 0; w < tword; ++w) {
+      unsigned int m = tbits[w];
+      while (m) {
+        const int t = w * 32 + __ffs((int)m) - 1;
+        m &= m - 1;
+        if (!tile_is_private(P, tab, t)) ++need;
+      }
+    }
+    if (need) {
+      unsigned long long base = 0ull;
+      if (lane == 0) base = tile_pop_n(P, (unsigned int)need);
+      base = ((unsigned long long)__shfl((int)(base >> 32), 0, kWave) << 32) | (unsigned int)__shfl((int)base, 0, kWave);
+      if (base == ~0ull) { if (lane == 0) atomicOr(&err[3], 8); return; }  // tile pool exhausted: nothing has been written
+      for (int w = 0; w < tword; ++w) {
+        unsigned int m = tbits[w];
+        while (m) {
+          const int t = w * 32 + __ffs((int)m) - 1;
+          m &= m - 1;
+          if (!tile_is_private(P, tab, t)) { tile_clone_into(P, tab, shed, t, tile_at(P, base), lane); ++base; }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  int n_log = 0;
+  int* ev = log.ev ? log.ev + (size_t)p * log.cap : nullptr;
+  for (int b = 0; b < c.Bv; ++b) {
+    const int x1 = ex[b], y1 = ey[b];
+    const Ray r = make_ray(rx, ry, x1, y1);
+    for (int n0 = 0; n0 < r.count; n0 += kWave) {
+      const int n = n0 + lane;
+      bool flip = false;
+      int cell = 0;
+      if (n < r.count) {
+        int cx, cy;
+        ray_cell(r, n, cx, cy);
+        cell = cx * c.g.xsize + cy;
+        flip = add_log_odds(P, tab[tile_of(M, cx, cy)], c.d_free, c.cut_occ, cx, cy, rc, nocc);
+      }
+      if (ev) {  // a free add can only take a cell OUT of the occupied set
+        const unsigned long long m = __ballot(flip);
+        if (flip) { const int at = n_log + __popcll(m & ((1ull << lane) - 1ull)); if (at < log.cap) ev[at] = cell | (int)0x80000000; }
+        n_log += __popcll(m);
+      }
+    }
+    __syncthreads();  // free-cell adds of this beam land before the endpoint / next beam touch the cells
+    int eflip = 0;
+    if (lane == 0) {
+      const unsigned int eid = tab[tile_of(M, x1, y1)];
+      const double before = P.lo[(size_t)eid * kTileCells + in_tile(x1, y1)];
+      const bool flip = add_log_odds(P, eid, c.d_occ, c.cut_occ, x1, y1, rc, nocc);
+      if (ev && flip && n_log < log.cap) ev[n_log] = (x1 * c.g.xsize + y1) | (before >= c.cut_occ ? (int)0x80000000 : 0);
+      eflip = flip ? 1 : 0;
+    }
+    if (ev) n_log += __shfl(eflip, 0, kWave);
+    __syncthreads();
+  }
+  if (ev && lane == 0) log.count[p] = n_log;
+}
+__global__ void rbpf_add_repeated_test(const double* __restrict__ x, const double* __restrict__ d, const int* __restrict__ n, double* __restrict__ out, int count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) out[i] = add_repeated(x[i], d[i], n[i]);
+}
+template <int NT>
+__global__ __launch_bounds__(NT, NT == 512 ? TBNAV_RC512_WAVES : 8) void rbpf_raycast_box(ScanC c, TilePool P, MapT M, const double2* __restrict__ beams,
+                                                          const double* __restrict__ pose, const double* __restrict__ sens,
+                                                          int* __restrict__ trow_occ, int* __restrict__ n_occ, int* __restrict__ err,
+                                                          int tile_cap, unsigned long long* __restrict__ touched, NormArgs nz,
+                                                          int* __restrict__ box_need, int* __restrict__ box_need_host, int need_slot) {
+  extern __shared__ __attribute__((aligned(16))) int lds_i[];
+  // enqueued behind a scan whose resampling decision the host had not seen yet: if that scan resamples, this launch does
+  // nothing (the host runs the copies and enqueues this scan again)
+  if (nz.gate_prev && *nz.gate_prev) return;
+  // nz.N > 0: workgroup 0 is not a particle's — it normalises the weights the proposal kernel left and selects the parents
+  // (one workgroup of dependent adds, independent of the maps: it rides in this launch, beside the map updates, instead of
+  // costing a second stream, an event and a dependent boundary); the particles' workgroups follow
+  if (nz.N > 0 && blockIdx.x == 0) {
+    double* w = reinterpret_cast<double*>(lds_i);
+    normalize_body<NT, false>(nz.N, nz.zp, nz.weight, nz.weight_out, nz.cs, nz.parent, nz.out, w, w + kNormChunk, nz.gate, nz.seq, nz.seq_val,
+                   nz.children);
+    return;
+  }
+  const int Bv = c.Bv;
+  unsigned int* tile = reinterpret_cast<unsigned int*>(lds_i);         // (tile_cap is a multiple of 8)
+  unsigned short* ev = reinterpret_cast<unsigned short*>(lds_i + tile_cap);  // [Bv][kBoxEv]  beam << 1 | occupied  (16 bytes a slot, 16-byte aligned)
+  double* val_e = reinterpret_cast<double*>(lds_i + tile_cap + 4 * Bv);      // [Bv + 64] the value replayed for an end-point cell / a hot cell
+  int* exy = lds_i + tile_cap + 4 * Bv + 2 * (Bv + 64);  // [Bv] end-point cell, x | y << 16
+  int* ecnt = exy + Bv;                                  // [Bv] events recorded in the slot of beam b — the FIRST beam that ended in its cell (0: b opened
+                                                         //      no slot; may exceed kBoxEv: overflow)
+  constexpr unsigned int kFlag = 0x80000000u;
+  constexpr int kEv = kBoxEv;
+  __shared__ int bad, bx0, bx1, by0, by1, srx, sry, nocc_delta, n_ovf;
+  __shared__ unsigned long long need_base;
+  __shared__ unsigned int mt_id[kMapTilesMax];  // map tiles under the box: the tile the particle's table names (once written: its private tile)
+  __shared__ int mt_touch[kMapTilesMax], mt_slot[kMapTilesMax], mt_priv[kMapTilesMax];
+  __shared__ int rc_delta[kBoxSideMax / kTS + 2];
+  __shared__ int ovf[kWave];                    // slots whose event list overflowed (more than these: found by scanning)
+  __shared__ double sh_pose[4];
+  __shared__ double robot_v0, robot_v;  // the robot's own cell: its log-odds before the scan / after the adds applied so far
+  __shared__ int robot_cnt;             // beams with a free cell (each adds l_free to the robot's cell once)
+  constexpr int nthr = NT, nw = NT / kWave;
+  const int p = c.p0 + blockIdx.x - (nz.N > 0 ? 1 : 0), tid_k = threadIdx.x, tid = tid_k, lane = tid & (kWave - 1), wid = tid / kWave;
+#ifdef TBNAV_PHASE_PROF
+  unsigned long long t_prev_ = wall_clock64();
+#endif
+  unsigned int* tab = M.table + (size_t)p * M.TT;
+  unsigned int* shed = M.shed + (size_t)p * M.TT;
+  TRACE_W(0);
+  WG_IN();
+  if (wid == 0) {
+    const double x = pose[p * 3 + 1], y = pose[p * 3 + 2];
+    int rx0 = 0, ry0 = 0;
+    const bool robot_ok = world2cell(c.g, x, y, rx0, ry0);  // freeGridIndex: world2Grid of the ROBOT pose (:558)
+    double X, Y, st0, ct0;
+    if (sens) { X = sens[p * 4 + 0]; Y = sens[p * 4 + 1]; st0 = sens[p * 4 + 2]; ct0 = sens[p * 4 + 3]; }
+    else {
+      const double th = pose[p * 3 + 0];
+      double s0, c0;
+      sincos(th, &s0, &c0);
+      if (c.Trs[0] == 0.0) { st0 = s0; ct0 = c0; } else sincos(th + c.Trs[0], &st0, &ct0);
+      X = c0 * c.Trs[1] - s0 * c.Trs[2] + x;
+      Y = s0 * c.Trs[1] + c0 * c.Trs[2] + y;
+    }
+    if (lane == 0) {
+      sh_pose[0] = X; sh_pose[1] = Y; sh_pose[2] = st0; sh_pose[3] = ct0;
+      bad = robot_ok ? 0 : 1; bx0 = bx1 = rx0; by0 = by1 = ry0; srx = rx0; sry = ry0;
+      nocc_delta = 0; n_ovf = 0; robot_cnt = 0;
+    }
+  } else {
+    uint4* t4 = reinterpret_cast<uint4*>(tile);
+    for (int t = tid - kWave; t < tile_cap / 4; t += nthr - kWave) t4[t] = uint4{0u, 0u, 0u, 0u};
+    for (int b = tid - kWave; b < Bv; b += nthr - kWave) ecnt[b] = 0;
+    for (int t = tid - kWave; t < kMapTilesMax; t += nthr - kWave) mt_touch[t] = 0;
+    for (int t = tid - kWave; t < kBoxSideMax / kTS + 2; t += nthr - kWave) rc_delta[t] = 0;
+  }
+  __syncthreads();
+  TRACE_W(1);
+  // (workgroup-uniform values read from LDS are moved to scalar registers: the kernel has 64 VGPRs to live in)
+  auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+  const int rx = uni(srx), ry = uni(sry);
+  {
+    const double X = sh_pose[0], Y = sh_pose[1], st = sh_pose[2], ct = sh_pose[3];
+    for (int b0 = wid * kWave; b0 < Bv; b0 += nthr) {
+      const int b = b0 + lane;
+      int ci = rx, cj = ry;
+      if (b < Bv) {
+        const double2 pt = beams[b];
+        if (!world2cell(c.g, ct * pt.x - st * pt.y + X, st * pt.x + ct * pt.y + Y, ci, cj)) { bad = 1; ci = rx; cj = ry; }
+        exy[b] = ci | (cj << 16);
+      }
+      const int lo_x = wave_min_dpp(ci), hi_x = wave_max_dpp(ci), lo_y = wave_min_dpp(cj), hi_y = wave_max_dpp(cj);
+      const unsigned long long has_free = __ballot(b < Bv && (ci != rx || cj != ry));  // the ray has a free cell: its first is the robot's
+      if (lane == 0) {
+        atomicMin(&bx0, lo_x); atomicMax(&bx1, hi_x); atomicMin(&by0, lo_y); atomicMax(&by1, hi_y);
+        if (has_free) atomicAdd(&robot_cnt, __popcll(has_free));
+      }
+    }
+    // (The robot's own cell takes one add per beam: lane 0 of the last wave, which walks no ray, fetches it and works the adds
+    //  out beside the walk — add_repeated: no chain of dependent adds.  Fetched HERE and looked at in front of the flag barrier, its
+    //  two dependent loads held the whole workgroup up: 1-3 us per particle once the chip is loaded.)
+  }
+  __syncthreads();
+  TRACE_W(2);
+  if (bad) { if (tid == 0) atomicOr(&err[0], 1); return; }
+  const int minx = uni(bx0), maxx = uni(bx1), maxy = uni(by1);
+  const int miny = uni(by0) & ~1;                                   // the box starts on an even column and is an even number of
+  const int bw = ((maxy | 1) + 1) - miny;                           // columns wide: a PAIR of cells never straddles a row or a map tile
+  const int bh = maxx - minx + 1;
+  const int tx0 = minx >> kTSh, ty0 = miny >> kTSh, mty = (maxy >> kTSh) - ty0 + 1, mtn = ((maxx >> kTSh) - tx0 + 1) * mty;
+  const int rows_fit = uni(floor_div_small(tile_cap, bw));          // rows of the box the LDS array holds at a time
+  if (rows_fit < 1 || mtn > kMapTilesMax || bh > kBoxSideMax) { if (tid == 0) atomicOr(&err[3], 2); return; }  // cannot happen: see launch_raycast
+  // What the LDS array would have to hold for this particle's box to be ONE band: the host sizes the array of the scans to
+  // come from it (launch_raycast: less LDS per workgroup = three workgroups per CU instead of two).  Three slots take turns:
+  // this launch accumulates into need_slot; one workgroup hands the PREVIOUS launch's maximum (complete: stream order) to the
+  // host through mapped memory and clears the slot of the next launch.  Nothing waits for any of it.
+  // (one particle in sixteen reports: the particles' boxes are a cell or two apart, and a thousand atomics on one word drain at
+  //  ~12 ns each while every later load of the wave waits behind its own — 5 us on the first residents' critical path)
+  if (box_need && tid == 0 && (blockIdx.x & 15u) == 1u) {
+    atomicMax(&box_need[need_slot], bh * bw);
+    if ((int)blockIdx.x == 1) {
+      *box_need_host = box_need[(need_slot + 2) % 3];
+      box_need[(need_slot + 1) % 3] = 0;
+    }
+  }
+  // the particle's table entries under the box, and the reference counts of the tiles they name (needed in phase C)
+  // (the table work sits on the last threads of the LAST BUT ONE wave, which walks no ray — the last wave, which walks none
+  //  either, has the robot cell's chain to work on)
+  const int tq = nthr - kWave - 1 - tid;
+  //  — the entry goes to LDS as it arrives (these threads have nothing else to do in the flag phase); the reference count of the
+  //  tile it names is fetched beside the walk: nothing needs it before phase C)
+  if (tq >= 0 && tq < mtn) {
+    const int qi = floor_div_small(tq, mty), qj = tq - qi * mty;
+    mt_id[tq] = tab[(tx0 + qi) * M.TW + (ty0 + qj)];
+  }
+  auto map_tile = [&](int cx, int cy) { return __mul24((cx >> kTSh) - tx0, mty) + ((cy >> kTSh) - ty0); };
+  auto cell_ptr = [&](int cx, int cy) -> double* { return P.lo + (size_t)mt_id[map_tile(cx, cy)] * kTileCells + in_tile(cx, cy); };
+  auto toggled = [&](int cx, int cy, bool now) {  // the cell crossed the occupied cut-off: its bit in the (private) tile, tile-row count, total
+    atomicXor(&P.bm[(size_t)mt_id[map_tile(cx, cy)] * kTS + (cx & (kTS - 1))], 1u << (cy & (kTS - 1)));
+    atomicAdd(&rc_delta[(cx >> kTSh) - tx0], now ? 1 : -1);
+    atomicAdd(&nocc_delta, now ? 1 : -1);
+  };
+  auto record = [&](unsigned int word, int what) {  // an event for the flagged cell whose tile word this is
+    const int o = (int)((word >> 16) & 0x7FFFu);
+    const int en = atomicAdd(&ecnt[o], 1);
+    if (en < kEv) ev[o * kEv + en] = (unsigned short)what;
+  };
+  const int step_r = uni(floor_div_small(2 * nthr, bw)), step_c = 2 * nthr - step_r * bw;  // pair pi + nthr in (row, column) terms
+  int n_distinct = 0, n_ends = 0;
+  for (int x0 = minx; x0 <= maxx; x0 += rows_fit) {  // one band of rows at a time (one trip unless the box is larger than the LDS array)
+    // (per-thread values are re-derived from an opaque copy of the thread index in every trip: hoisted out of this loop they
+    //  would be spilled — the kernel has 64 VGPRs — and a spill reload between memory requests serialises them)
+    int tid = tid_k;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & (kWave - 1), wid = tid / kWave, tq = nthr - kWave - 1 - tid;
+    const int nr = (maxx - x0 + 1 < rows_fit) ? maxx - x0 + 1 : rows_fit;
+    const int band_cells = __mul24(nr, bw);
+    const bool clip = nr != bh;
+    if (x0 != minx) {  // (a further band: the LDS state of the previous one is cleared)
+      __syncthreads();
+      uint4* t4 = reinterpret_cast<uint4*>(tile);
+      for (int t = tid; t < tile_cap / 4; t += nthr) t4[t] = uint4{0u, 0u, 0u, 0u};
+      for (int b = tid; b < Bv; b += nthr) ecnt[b] = 0;
+      for (int t = tid; t < kMapTilesMax; t += nthr) mt_touch[t] = 0;
+      if (tid == 0) n_ovf = 0;
+      __syncthreads();
+    }
+    auto cell_t = [&](int e) { return __mul24((e & 0xFFFF) - x0, bw) + ((e >> 16) - miny); };
+    auto in_band = [&](int e) { return (unsigned int)((e & 0xFFFF) - x0) < (unsigned int)nr; };
+    // F. flag the end-point cells.  The first beam to reach a cell leaves its own index there as the cell's slot — one
+    //    compare-and-swap against the cleared word: winner and losers alike know the slot at once — and every beam records its
+    //    end-point event straight away (three dependent LDS operations; a flag, a slot counter, the slot number and then the
+    //    event in a phase of its own were six).
+    for (int b = tid; b < Bv; b += nthr) {
+      const int e = exy[b];
+      if (!in_band(e)) continue;
+      const unsigned int mine = kFlag | ((unsigned int)b << 16);
+      const unsigned int old = atomicCAS(&tile[cell_t(e)], 0u, mine);
+      record(old ? old : mine, (b << 1) | 1);
+    }
+    TRACE_W(3);
+    __syncthreads();
+    PHASE_STAMP_W(0);
+    TRACE_W(4);
+    // 1. the walk
+    TRACE_W(5);
+    if (x0 == minx && tq >= 0 && tq < mtn) {
+      const unsigned int id = mt_id[tq];
+      const int rf = id ? P.ref[id] : 0;
+      mt_priv[tq] = (id != 0u && rf == 1) ? 1 : 0;
+    }
+    if (x0 == minx && tid == nthr - kWave) {  // the robot's own cell (the last wave walks no ray)
+      const unsigned int rt = tab[(rx >> kTSh) * M.TW + (ry >> kTSh)];
+      const double old = P.lo[(size_t)rt * kTileCells + in_tile(rx, ry)];
+      robot_v0 = old; robot_v = add_repeated(old, c.d_free, robot_cnt);
+    }
+    {
+      int S = Bv > 0 ? nthr / Bv : 1;  // segments per ray: as many as give every thread at most one task
+      S = S < 1 ? 1 : (S > 4 ? 4 : S);
+      const int G = (Bv + kWave - 1) / kWave;
+      const unsigned int band_bytes = 4u * (unsigned int)band_cells;
+      int n_first = 0;
+      for (int task = tid; task < kWave * G * S; task += nthr) {
+        const int tb = floor_div_small(task, S), sgm = task - tb * S;
+        const int b = __mul24(tb & (kWave - 1), G) + (tb >> 6);  // lanes of a wave take rays spread round the scan
+        if (b >= Bv) continue;
+        const int e = exy[b];
+        const RayP pr = ray_packed(rx, ry, e & 0xFFFF, e >> 16);
+        const int count = pr.dmaj, L = floor_div_small(count + S - 1, S);
+        int n = __mul24(sgm, L);
+        const int n1 = (n + L < count) ? n + L : count;
+        if (n >= n1) continue;
+        const int two_dmin = 2 * pr.dmin, two_dmaj = 2 * pr.dmaj;
+        const int a0 = __mul24(two_dmin, n) - pr.dmaj;
+        const int c0 = a0 > 0 ? floor_div_small(a0 + two_dmaj - 1, two_dmaj) : 0;  // operands < 2^24
+        int rem = a0 - __mul24(two_dmaj, c0 - 1);
+        const int sc = pr.neg ? -c0 : c0;
+        // byte offset of the segment's first cell in the band's array, and the byte steps along / across the ray
+        int at = 4 * (__mul24((pr.ymajor ? pr.xa + sc : pr.xa + n) - x0, bw) + ((pr.ymajor ? pr.ya + n : pr.ya + sc) - miny));
+        const int d_major = 4 * (pr.ymajor ? 1 : bw);
+        const int d_both = d_major + 4 * (pr.ymajor ? bw : 1) * (pr.neg ? -1 : 1);
+        auto advance = [&]() {
+          const int r2 = rem + two_dmin;
+          const bool side = r2 > two_dmaj;
+          rem = side ? r2 - two_dmaj : r2;
+          at += side ? d_both : d_major;
+        };
+        if (n == 0) { ++n_first; advance(); ++n; }  // position 0 is the robot's cell (or, for a reversed ray, the end point): counted below
+        char* const tile_b = reinterpret_cast<char*>(tile);
+        // What an add returns is looked at TWO steps later, while the next two adds are in flight: three registers take turns
+        // (no register is copied at the top of the loop, which would wait for the add just issued), so the walk never waits
+        // for LDS unless it has an event to record.
+        unsigned int r0 = 0u, r1 = 0u, r2 = 0u;
+        auto look = [&](unsigned int& old) { if (old & kFlag) record(old, b << 1); old = 0u; };
+        auto step = [&](auto clipped, unsigned int& fresh, unsigned int& old) {
+          if (!decltype(clipped)::value || (unsigned int)at < band_bytes) fresh = atomicAdd(reinterpret_cast<unsigned int*>(tile_b + at), 1u);  // (clipped: the cells of the ray in this band of rows)
+          advance();
+          look(old);
+        };
+        auto walk = [&](auto clipped) {
+          int m = n1 - n;
+          for (; m >= 3; m -= 3) { step(clipped, r0, r1); step(clipped, r1, r2); step(clipped, r2, r0); }
+          if (m >= 1) step(clipped, r0, r1);
+          if (m >= 2) step(clipped, r1, r2);
+        };
+        if (clip) walk(std::true_type{}); else walk(std::false_type{});
+        look(r0); look(r1); look(r2);
+      }
+      // the robot's own cell is the first free cell of every ray that has a free cell at all
+      n_first = wave_sum_dpp(n_first);
+      if (lane == 0 && n_first && (unsigned int)(rx - x0) < (unsigned int)nr) atomicAdd(&tile[__mul24(rx - x0, bw) + (ry - miny)], (unsigned int)n_first);
+    }
+    TRACE_W(6);
+    __syncthreads();  // every event is recorded
+    TRACE_W(7);
+    PHASE_STAMP_W(1);
+    // 2. requests and marks in one pass.  The band as PAIRS of cells (16 bytes of a map tile's row, two tile words): pair
+    //    tid + i * nthr for i < 4 — consecutive lanes take consecutive pairs, so a wave's request is whole cache lines.  A
+    //    counted or flagged pair marks its map tile as written and asks for its log-odds from whichever tile the particle's
+    //    table names NOW (shared, private or the zero tile hold the same values: the loads fly while the tiles are made
+    //    private).  Slots that overflowed are listed on the way.
+    const int np = band_cells >> 1;
+    const uint2* tile2 = reinterpret_cast<const uint2*>(tile);
+    constexpr int kSl = NT == 512 ? 6 : 4;  // pairs a thread holds across the passes (512 threads: 6 fill the 80 registers exactly — 48.6 vs 50.1 us per 1000 particles; 8 spill)
+    double2 v[kSl];
+    auto pairs = [&](int first, auto&& fn) {  // fn(i, the pair's two tile words, cx, cy of its first cell), i < kSl
+      const int pi0 = first + tid;
+      int row = floor_div_small(2 * (pi0 < np ? pi0 : 0), bw), col = 2 * (pi0 < np ? pi0 : 0) - __mul24(row, bw);  // cell index < 2^16, bw < 2^8
+#pragma unroll
+      for (int i = 0; i < kSl; ++i) {
+        const int pi = pi0 + i * nthr;
+        uint2 w = uint2{0u, 0u};
+        if (pi < np) w = tile2[pi];
+        fn(i, w, x0 + row, miny + col);
+        row += step_r; col += step_c;
+        if (col >= bw) { col -= bw; ++row; }
+      }
+    };
+    pairs(0, [&](int i, uint2 w, int cx, int cy) {
+      v[i] = double2{0.0, 0.0};
+      if (w.x | w.y) {
+        const int mt = map_tile(cx, cy);
+        mt_touch[mt] = 1;
+        v[i] = *reinterpret_cast<const double2*>(P.lo + (size_t)mt_id[mt] * kTileCells + in_tile(cx, cy));
+      }
+    });
+    for (int first = kSl * nthr; first < np; first += kSl * nthr)  // (bands of more than 8 * nthr cells: marks only, their loads follow)
+      pairs(first, [&](int, uint2 w, int cx, int cy) { if (w.x | w.y) mt_touch[map_tile(cx, cy)] = 1; });
+    for (int o = tid; o < Bv; o += nthr) {
+      if (ecnt[o] == 0) continue;
+      const int e = exy[o];
+      const bool robot_cell = (e & 0xFFFF) == rx && (e >> 16) == ry;  // an end point too: no events from the walk, replayed against every beam
+      if (robot_cell) ecnt[o] = kEv + 1;
+      if (robot_cell || ecnt[o] > kEv) { const int i = atomicAdd(&n_ovf, 1); if (i < kWave) ovf[i] = o; }
+    }
+    TRACE_W(8);
+    __syncthreads();
+    PHASE_STAMP_W(2);
+    TRACE_W(9);
+    // C. make the written tiles private to the particle (first write after a resample, or first touch of the area): ONE pop
+    //    of the free ring for all of them, then one wave per tile copies 8 KB.  Usually there is nothing to do — and every wave
+    //    sees that for itself (one ballot over the at most 64 tiles under the box), without a barrier to agree on it.
+    const unsigned long long need_m = __ballot(lane < mtn && mt_touch[lane < mtn ? lane : 0] && !mt_priv[lane < mtn ? lane : 0]);
+    if (need_m) {  // workgroup-uniform
+      if (wid == 0 && lane < mtn) mt_slot[lane] = ((need_m >> lane) & 1ull) ? __popcll(need_m & ((1ull << lane) - 1ull)) : -1;
+      if (tid == 0) { need_base = tile_pop_n(P, (unsigned int)__popcll(need_m)); if (need_base == ~0ull) bad = 1; }
+      __syncthreads();
+      if (bad) { if (tid == 0) atomicOr(&err[3], 8); return; }  // tile pool exhausted (nothing has been written if this is the first band)
+      for (int q = wid; q < mtn; q += nw) {
+        if (!mt_touch[q] || mt_slot[q] < 0) continue;
+        const int qi = floor_div_small(q, mty), qj = q - qi * mty;
+        const unsigned int nid = tile_at(P, need_base + (unsigned long long)mt_slot[q]);
+        tile_clone_into(P, tab, shed, (tx0 + qi) * M.TW + (ty0 + qj), nid, lane);
+        if (lane == 0) { mt_id[q] = nid; mt_priv[q] = 1; }
+      }
+      __syncthreads();
+    }
+    PHASE_STAMP_W(3);
+    TRACE_W(10);
+    auto finish_end = [&](int slot, int cx, int cy, double v0o, double vv) {
+      val_e[slot] = vv;
+      const bool was = v0o >= c.cut_occ, now = vv >= c.cut_occ;
+      if (was != now) toggled(cx, cy, now);
+    };
+    // 3a. end-point cells whose slot holds every event: one lane each, the events sorted by beam in registers (a
+    //     19-comparator network on the 8 sixteen-bit entries; an empty entry sorts last) and applied in that order
+    for (int o = tid; o < Bv; o += nthr) {
+      const int ne = ecnt[o];
+      if (ne == 0 || ne > kEv) continue;
+      const int e = exy[o], cx = e & 0xFFFF, cy = e >> 16;
+      const double v0o = *cell_ptr(cx, cy);
+      // the events in beam order without sorting: every beam that reaches the cell lies within a few beams of the slot's
+      // own beam b0, so bit (beam - b0 + 32) of a 64-bit mask per kind orders them (checked per event; a stray one sends
+      // the slot to the exhaustive path).  Beam indices are circular: the bits are walked from the one that stands for the
+      // lowest ABSOLUTE beam index.
+      const uint4 raw = *reinterpret_cast<const uint4*>(ev + o * kEv);
+      const unsigned int w4[4] = {raw.x, raw.y, raw.z, raw.w};
+      const int base = o - 32;
+      unsigned long long m_free = 0ull, m_occ = 0ull;
+      bool stray = false;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const unsigned int k = (q & 1) ? (w4[q >> 1] >> 16) : (w4[q >> 1] & 0xFFFFu);
+        int d = (int)(k >> 1) - base;
+        d += d < 0 ? Bv : 0; d -= d >= Bv ? Bv : 0;  // circular distance from base, in [0, Bv)
+        const bool valid = q < ne;
+        stray |= valid && d > 63;
+        const unsigned long long bit = valid ? 1ull << (d & 63) : 0ull;
+        if (k & 1u) m_occ |= bit; else m_free |= bit;
+      }
+      // absolute beam of bit d is base + d (mod Bv): bits from d0 = (base < 0 ? -base : (base + 63 >= Bv ? Bv - base : 0)) up are
+      // the low absolute indices when the window wraps
+      int d0 = 0;
+      if (base < 0) d0 = -base; else if (base + 63 >= Bv) d0 = Bv - base;
+      d0 = d0 > 63 ? 0 : d0;
+      double vv = v0o;
+      if (!stray) {
+#pragma unroll 1
+        for (int part = 0; part < 2; ++part) {
+          const unsigned long long keep = part == 0 ? ~0ull << d0 : ~(~0ull << d0);
+          unsigned long long m = (m_free | m_occ) & keep;
+          while (m) {
+            const int bit = __ffsll((long long)m) - 1;
+            vv += ((m_occ >> bit) & 1ull) ? c.d_occ : c.d_free;
+            m &= m - 1;
+          }
+        }
+      } else {  // (never seen: an event more than 31 beams from the slot's own) selection by ascending beam from LDS
+        int last = -1;
+        for (int i = 0; i < ne; ++i) {
+          int best = 0x10000;
+          for (int j = 0; j < ne; ++j) { const int k = ev[o * kEv + j]; if (k > last && k < best) best = k; }
+          vv += (best & 1) ? c.d_occ : c.d_free;
+          last = best;
+        }
+      }
+      ++n_ends;
+      finish_end(o, cx, cy, v0o, vv);
+    }
+    TRACE_W(11);
+    // 3b. overflowed slots: one wave per cell.  Lanes test beams q = 64*i + lane against the cell (is it q's end point /
+    //     one of q's free cells); the two ballots are the cell's update sequence for those 64 beams, replayed in bit (=
+    //     beam) order.  Pre-filter: a Bresenham cell lies within one cell of the line robot -> end point.
+    {
+      const int n_over = uni(n_ovf);
+      const int trips = (Bv + kWave - 1) / kWave;
+      for (int i0 = wid; i0 < (n_over <= kWave ? n_over : Bv); i0 += nw) {
+        const int o = n_over <= kWave ? ovf[i0] : i0;  // (more overflowed slots than the list holds: scan them all)
+        if (ecnt[o] <= kEv) continue;
+        const int eo = exy[o], cx = eo & 0xFFFF, cy = eo >> 16;
+        const double v0o = *cell_ptr(cx, cy);
+        double vv = v0o;
+        const int ux = cx - rx, uy = cy - ry;
+        for (int i = 0; i < trips; ++i) {
+          const int q = i * kWave + lane;
+          bool is_end = false, hit = false;
+          if (q < Bv) {
+            const int eq = exy[q], qx = eq & 0xFFFF, qy = eq >> 16;
+            is_end = eq == eo;  // the end point is never one of its own ray's free cells
+            const int dx = qx - rx, dy = qy - ry;
+            const double cr = (double)(ux * dy - uy * dx), l2 = (double)(dx * dx + dy * dy);
+            if (!is_end && cr * cr <= l2) hit = on_ray_packed(rx, ry, qx, qy, cx, cy);
+          }
+          const unsigned long long occm = __ballot(is_end), freem = __ballot(hit);
+          unsigned long long m = occm | freem;
+          while (m) {
+            const int bit = __ffsll((long long)m) - 1;
+            vv += ((occm >> bit) & 1ull) ? c.d_occ : c.d_free;
+            m &= m - 1;
+          }
+        }
+        if (lane == 0) { ++n_ends; finish_end(o, cx, cy, v0o, vv); }
+      }
+    }
+    // 3h. the cells round the robot: every ray starts there, so they collect tens to hundreds of adds — one long dependent
+    //     chain each.  They get a lane of their own in the last wave (which has no end-point cell to replay), are then
+    //     flagged like end-point cells, and their group's owner takes the value from val_e.  The few that take kVeryHot adds or
+    //     more (the robot's neighbours: up to half the beams each) go to the last wave but one instead, which works them out
+    //     without the chain (add_repeated: a few hundred integer instructions per binade, worth it from about a hundred adds);
+    //     the two waves run side by side, so the phase lasts as long as a chain of kVeryHot adds, not of the longest.
+    if ((wid == nw - 1 || wid == nw - 2) && lane < kHotSide * kHotSide) {
+      const int hi = floor_div_small(lane, kHotSide), hx = rx - kHotSide / 2 + hi, hy = ry - kHotSide / 2 + (lane - hi * kHotSide);
+      if ((unsigned int)(hx - x0) < (unsigned int)nr && hy >= miny && hy < miny + bw) {
+        const int t = __mul24(hx - x0, bw) + (hy - miny);
+        const unsigned int f = tile[t];
+        const int cnq = (int)(f & 0xFFFFu);
+        const bool robot_cell = hx == rx && hy == ry;  // (worked out beside the walk)
+        const bool very = !robot_cell && cnq >= kVeryHot;
+        if (!(f & kFlag) && (robot_cell ? f != 0u : cnq >= kHotMin) && very == (wid == nw - 2)) {
+          double v0o, vv;
+          if (robot_cell) { v0o = robot_v0; vv = robot_v; }
+          else if (very) { v0o = *cell_ptr(hx, hy); vv = add_repeated(v0o, c.d_free, cnq); }
+          else {
+            v0o = *cell_ptr(hx, hy); vv = v0o;
+            int a = 0;
+            for (; a + 4 <= cnq; a += 4) { vv += c.d_free; vv += c.d_free; vv += c.d_free; vv += c.d_free; }
+            for (; a < cnq; ++a) vv += c.d_free;
+          }
+          tile[t] = kFlag | ((unsigned int)(Bv + lane) << 16);
+          ++n_distinct;
+          finish_end(Bv + lane, hx, hy, v0o, vv);
+        }
+      }
+    }
+    TRACE_W(12);
+    __syncthreads();  // val_e is complete
+    TRACE_W(13);
+    PHASE_STAMP_W(4);
+    // 3c. the pairs: a plain cell adds its count, an end-point or hot cell takes the value worked out for it, an untouched one
+    //     keeps its own; the pair goes back as one 16-byte store (the tile is private to the particle and nobody else writes
+    //     these cells)
+    for (int first = 0; first < np; first += kSl * nthr) {
+      if (first) pairs(first, [&](int i, uint2 w, int cx, int cy) { v[i] = (w.x | w.y) ? *reinterpret_cast<const double2*>(cell_ptr(cx, cy)) : double2{0.0, 0.0}; });
+      pairs(first, [&](int i, uint2 w, int cx, int cy) {
+        if (!(w.x | w.y)) return;
+        // both cells of the pair in ONE loop (two independent chains of adds, predicated on each cell's count): a few
+        // straight-line instructions instead of a nest of divergent branches and loops per cell
+        const bool plain0 = w.x != 0u && !(w.x & kFlag), plain1 = w.y != 0u && !(w.y & kFlag);
+        const int c0 = plain0 ? (int)(w.x & 0xFFFFu) : 0, c1 = plain1 ? (int)(w.y & 0xFFFFu) : 0;
+        const double o0 = v[i].x, o1 = v[i].y;
+        double n0 = o0, n1 = o1;
+        const int cm = c0 > c1 ? c0 : c1;
+        for (int a = 0; a < cm; ++a) {
+          const double t0 = n0 + c.d_free, t1 = n1 + c.d_free;
+          n0 = a < c0 ? t0 : n0;
+          n1 = a < c1 ? t1 : n1;
+        }
+        if ((w.x | w.y) & kFlag) {  // an end-point or hot cell takes the value worked out for it
+          if (w.x & kFlag) n0 = val_e[(w.x >> 16) & 0x7FFFu];
+          if (w.y & kFlag) n1 = val_e[(w.y >> 16) & 0x7FFFu];
+        }
+        n_distinct += (plain0 ? 1 : 0) + (plain1 ? 1 : 0);
+        *reinterpret_cast<double2*>(cell_ptr(cx, cy)) = double2{n0, n1};
+        const bool tog0 = plain0 && ((o0 >= c.cut_occ) != (n0 >= c.cut_occ)), tog1 = plain1 && ((o1 >= c.cut_occ) != (n1 >= c.cut_occ));
+        if (tog0 | tog1) {
+          if (tog0) toggled(cx, cy, n0 >= c.cut_occ);
+          if (tog1) toggled(cx, cy + 1, n1 >= c.cut_occ);
+        }
+      });
+    }
+    PHASE_STAMP_W(5);
+  }
+  TRACE_W(14);
+  __syncthreads();
+  // the tile-row counts / occupied count of the particle (this workgroup owns them; nothing waits for the adds)
+  int* rc = trow_occ + (size_t)p * M.TW;
+  for (int r = tid; r <= (maxx >> kTSh) - tx0; r += nthr) if (rc_delta[r]) atomicAdd(&rc[tx0 + r], rc_delta[r]);
+  if (tid == 0 && nocc_delta) atomicAdd(&n_occ[p], nocc_delta);
+  if (touched) {  // measurement hook (tbnav_rbpf_scan_counts): [0] += cell updates (free adds + end points), [1] += distinct cells written
+    __shared__ int cnt_upd, cnt_dis;
+    if (tid == 0) { cnt_upd = 0; cnt_dis = 0; }
+    __syncthreads();
+    int n_upd = 0;
+    for (int b = tid; b < Bv; b += nthr) {
+      const int e = exy[b], dx = (e & 0xFFFF) - rx, dy = (e >> 16) - ry;
+      n_upd += max(dx < 0 ? -dx : dx, dy < 0 ? -dy : dy) + 1;  // free cells of the ray (its Chebyshev length) + the end point
+    }
+    n_upd = wave_sum_i(n_upd); n_distinct = wave_sum_i(n_distinct + n_ends);
+    if (lane == 0) { atomicAdd(&cnt_upd, n_upd); atomicAdd(&cnt_dis, n_distinct); }
+    __syncthreads();
+    if (tid == 0) { atomicAdd(&touched[0], (unsigned long long)cnt_upd); atomicAdd(&touched[1], (unsigned long long)cnt_dis); }
+  }
+#if defined(TBNAV_PHASE_PROF) && !defined(TBNAV_TRACE_ONLY)  // (the sums are contended atomics on ONE address: they distort the very timeline TRACE_ONLY records)
+  if (tid == 0) { atomicAdd(&g_phase_w[15], 1ull); }
+#endif
+  WG_OUT();
+}
+template __global__ void rbpf_raycast_box<512>(ScanC, TilePool, MapT, const double2* __restrict__, const double* __restrict__, const double* __restrict__, int* __restrict__, int* __restrict__, int* __restrict__, int, unsigned long long* __restrict__, NormArgs, int* __restrict__, int* __restrict__, int);
+template __global__ void rbpf_raycast_box<1024>(ScanC, TilePool, MapT, const double2* __restrict__, const double* __restrict__, const double* __restrict__, int* __restrict__, int* __restrict__, int* __restrict__, int, unsigned long long* __restrict__, NormArgs, int* __restrict__, int* __restrict__, int);
+
+}  // namespace tbnav_rk
+
+#ifdef TBNAV_PHASE_PROF
+#include <cstdio>
+#include <map>
+#include <vector>
+namespace tbnav_rk {
+void rbpf_prof_print_raycast() {
+    unsigned long long tr[2][16][16];
+    if (hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_trace), sizeof(tr)) == hipSuccess && tr[0][0][0]) {
+      for (int g = 0; g < 2; ++g) {
+        std::fprintf(stderr, "[raycast_box trace of workgroup %d, us since its first stamp; columns: entry, pose barrier, end-point barrier, flags, flag barrier, own events, walk, walk barrier, requests, barrier, tiles private, replay, overflow+hot, barrier, stores]\n", g ? 900 : 100);
+        unsigned long long t0 = ~0ull;
+        for (int w = 0; w < 16; ++w) if (tr[g][w][0] && tr[g][w][0] < t0) t0 = tr[g][w][0];
+        for (int w = 0; w < 16; ++w) {
+          std::fprintf(stderr, "  wave %2d:", w);
+          for (int i = 0; i < 15; ++i) std::fprintf(stderr, " %5.2f", tr[g][w][i] ? (double)(tr[g][w][i] - t0) * 0.01 : -1.0);
+          std::fprintf(stderr, "\n");
+        }
+      }
+    }
+    {
+      static unsigned long long wg[4096][3];
+      if (hipMemcpyFromSymbol(wg, HIP_SYMBOL(g_wg), sizeof(wg)) == hipSuccess && wg[1][0]) {
+        int n = 0;
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (int i = 0; i < 4096; ++i) if (wg[i][0] && wg[i][1]) { ++n; t0 = std::min(t0, wg[i][0]); t1 = std::max(t1, wg[i][1]); }
+        std::fprintf(stderr, "[raycast_box workgroups of the last launch] %d recorded, first entry to last exit %.2f us\n", n, (double)(t1 - t0) * 0.01);
+        const int nb = 16;
+        const double span = (double)(t1 - t0);
+        int active[nb] = {0}, starts[nb] = {0};
+        double dur_by_start[nb] = {0};
+        for (int i = 0; i < 4096; ++i) if (wg[i][0] && wg[i][1]) {
+          const int bs = std::min(nb - 1, (int)((double)(wg[i][0] - t0) / span * nb));
+          ++starts[bs]; dur_by_start[bs] += (double)(wg[i][1] - wg[i][0]) * 0.01;
+          for (int b = 0; b < nb; ++b) { const double tm = t0 + (b + 0.5) * span / nb; if ((double)wg[i][0] <= tm && tm < (double)wg[i][1]) ++active[b]; }
+        }
+        std::fprintf(stderr, "  time bin (%.2f us each):", span * 0.01 / nb);
+        for (int b = 0; b < nb; ++b) std::fprintf(stderr, " %5d", b);
+        std::fprintf(stderr, "\n  resident at mid-bin:    ");
+        for (int b = 0; b < nb; ++b) std::fprintf(stderr, " %5d", active[b]);
+        std::fprintf(stderr, "\n  entered in bin:         ");
+        for (int b = 0; b < nb; ++b) std::fprintf(stderr, " %5d", starts[b]);
+        std::fprintf(stderr, "\n  mean residence (us):    ");
+        for (int b = 0; b < nb; ++b) std::fprintf(stderr, " %5.1f", starts[b] ? dur_by_start[b] / starts[b] : 0.0);
+        std::map<unsigned long long, int> per_cu, per_xcc;
+        for (int i = 0; i < 4096; ++i) if (wg[i][0] && wg[i][1]) {
+          const unsigned int hw = (unsigned int)wg[i][2], xcc = (unsigned int)(wg[i][2] >> 32) & 0xF;
+          ++per_cu[((unsigned long long)xcc << 16) | (hw & 0xFF00u)];   // cu_id [11:8], sh_id [12], se_id [15:13]
+          ++per_xcc[xcc];
+        }
+        int hist[16] = {0};
+        for (auto& kv : per_cu) ++hist[std::min(15, kv.second)];
+        std::fprintf(stderr, "\n  CUs that ran workgroups: %zu; CUs by number of workgroups run:", per_cu.size());
+        for (int k = 1; k < 16; ++k) if (hist[k]) std::fprintf(stderr, " %d:%d", k, hist[k]);
+        std::fprintf(stderr, "\n  workgroups per XCC:");
+        for (auto& kv : per_xcc) std::fprintf(stderr, " %d", kv.second);
+        double xs[16] = {0}; int xn[16] = {0};
+        for (int i = 0; i < 4096; ++i) if (wg[i][0] && wg[i][1]) { const unsigned int xcc = (unsigned int)(wg[i][2] >> 32) & 0xF; xs[xcc] += (double)(wg[i][1] - wg[i][0]) * 0.01; ++xn[xcc]; }
+        std::fprintf(stderr, "\n  mean residence by XCC (us):");
+        for (int x = 0; x < 16; ++x) if (xn[x]) std::fprintf(stderr, " %.1f", xs[x] / xn[x]);
+        std::fprintf(stderr, "\n");
+      }
+    }
+    unsigned long long pw[16];
+    if (hipMemcpyFromSymbol(pw, HIP_SYMBOL(g_phase_w), sizeof(pw)) == hipSuccess && pw[15])
+      std::fprintf(stderr, "[raycast_box phases, 10 ns ticks per workgroup] set-up + flags %.1f | events + walk %.1f | requests + marks %.1f | "
+                           "private tiles %.1f | end-point replay + hot cells %.1f | pairs %.1f | (unused) %.1f\n",
+                   (double)pw[0] / pw[15], (double)pw[1] / pw[15], (double)pw[2] / pw[15], (double)pw[3] / pw[15], (double)pw[4] / pw[15],
+                   (double)pw[5] / pw[15], (double)pw[14] / pw[15]);
+}
+}  // namespace tbnav_rk
+#endif

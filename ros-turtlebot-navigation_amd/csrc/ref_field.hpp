@@ -7,7 +7,7 @@
 // element when a neighbour pushed during an expansion is nearer than the current top (:401-431 read top, push,
 // THEN pop), and cells that are no longer reached keep their old value (hard part 1).
 //
-// The device's default lookups compute the exact nearest-obstacle distance instead (rbpf.hip, DistSrc).  This class
+// The device's default lookups compute the exact nearest-obstacle distance instead (rbpf_device.hpp, DistSrc).  This class
 // is the third leg of SURVEY's contract: a mode in which the product reproduces the reference's field bit for bit
 // — same libstdc++ containers, fed the same insert / erase sequence (the beam-ordered raycast kernel logs it),
 // copied the way ParticleFilter::lowVarianceResampling copies particles (particle_filter.cpp:468-500) — so that

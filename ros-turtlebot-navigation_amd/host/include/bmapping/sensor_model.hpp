@@ -1,7 +1,7 @@
 // bmapping/sensor_model.hpp — LaserProperties and LaserScanner with the reference's surface
 // (reference bmapping/include/bmapping/sensor_model.hpp:20-117, bmapping/src/bmapping/sensor_model.cpp:9-131).
 // LaserScanner's two public methods are small host loops and stay on the host (src/grid_mapper_shim.cpp): the device
-// kernels transform beams themselves (csrc/rbpf.hip), from a per-scan table built exactly like laserEndPoints does.
+// kernels transform beams themselves (csrc/rbpf_propose.hip, rbpf_raycast.hip), from a per-scan table built exactly like laserEndPoints does.
 #ifndef TBNAV_BMAPPING_SENSOR_MODEL_HPP
 #define TBNAV_BMAPPING_SENSOR_MODEL_HPP
 

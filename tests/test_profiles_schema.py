@@ -20,7 +20,7 @@ def test_kernel_stats_table_written_by_the_summariser_is_what_the_bench_parses(t
               "sgpr_count int, lds_size int, scratch_size int)")
     rows = [("void (anonymous namespace)::mppi_rollout_fused<2, 8, 1, true>((anonymous namespace)::RolloutArgs, double const*)", 65536, 1, 1, 512, 5000),
             ("void (anonymous namespace)::mppi_rollout_fused<2, 8, 1, true>((anonymous namespace)::RolloutArgs, double const*)", 65536, 1, 1, 512, 6000),
-            ("void (anonymous namespace)::rbpf_raycast_box<512>((anonymous namespace)::ScanC)", 512512, 1, 1, 512, 48000),
+            ("void tbnav_rk::rbpf_raycast_box<512>(tbnav_rk::ScanC)", 512512, 1, 1, 512, 48000),
             ("void (anonymous namespace)::rbpf_raycast_box<512>((anonymous namespace)::ScanC)", 512000, 1, 1, 512, 50000),
             ("mppi_partials(int, int)", 8192, 100, 1, 256, 26000)]
     c.executemany("insert into kernels values (?,?,?,?,?,?,28,80,0,0)", rows)

@@ -614,7 +614,7 @@ def test_parallel_exact_chains_equal_the_sequential_sums_bit_for_bit(gpu_pkg, n)
 
 def test_repeated_adds_without_the_chain_equal_the_plain_loop_bit_for_bit(gpu_pkg):
     """A cell that n beams cross takes n times  x = fl(x + l)  (grid_mapper.cpp:438-477: one add per beam) — for the robot's own cell
-    n is the number of beams.  add_repeated (rbpf.hip) evaluates that without the chain of dependent adds: integer steps while x
+    n is the number of beams.  add_repeated (rbpf_device.hpp) evaluates that without the chain of dependent adds: integer steps while x
     stays in one binade, plain adds across its ends, at ties and where the signs differ.  Against the plain loop in numpy, bit for
     bit: the shipped log-odds, random addends, powers of two (every add a tie candidate), addends far below / above x, zeros,
     infinities, sign changes, and counts from 0 to 65535."""

@@ -25,7 +25,7 @@ for line in demangle.splitlines():
         continue
     k, v = m.group(1).strip(), m.group(2).strip()
     if k == "Function Name":
-        cur = re.sub(r"\(anonymous namespace\)::", "", v)
+        cur = re.sub(r"(\(anonymous namespace\)|tbnav_rk)::", "", v)
         cur = re.sub(r"^void ", "", cur).split("(")[0]
         rows[cur] = {}
     elif cur:
