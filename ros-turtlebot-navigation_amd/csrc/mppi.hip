@@ -1434,7 +1434,9 @@ int launch_rollout(tbnav_mppi* h, const double x0[3], const double* d_duL, const
     case 10: TBNAV_SCAN(TR, 10, 12); break; case 12: TBNAV_SCAN(TR, 12, 12); break;                                \
     case 16: TBNAV_SCAN(TR, 16, 12); break; default: TBNAV_SCAN(TR, 20, 12); break;                                \
   }
-    if (h->trig == 1) { TBNAV_SCAN_TC(1) } else if (h->trig == 2) { TBNAV_SCAN_TC(2) } else { TBNAV_SCAN_TC(3) }
+    // (TRIG 2 — a fresh sincos every step — is an A-B setting of the sequential / fused kernels; here it takes the three-evaluation form:
+    //  its eleven instantiations spilled up to 1.2 KB per lane and nothing selected them)
+    if (h->trig == 1) { TBNAV_SCAN_TC(1) } else { TBNAV_SCAN_TC(3) }
 #undef TBNAV_SCAN_TC
 #undef TBNAV_SCAN
   } else {

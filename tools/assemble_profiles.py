@@ -1,13 +1,14 @@
 """Builds profiles/<round>_traffic_pmc.json, <round>_sq_counters.json and <round>_kernel_stats.md from what tools/profile_round.sh
 left in gpurun_out/ (run here after the GPU call has merged its files back).  usage: python tools/assemble_profiles.py [r03]"""
 import json, os, shutil, sys
-R = sys.argv[1] if len(sys.argv) > 1 else "r03"
+R = sys.argv[1] if len(sys.argv) > 1 else "r04"
+PREV = "r%02d" % (int(R[1:]) - 1)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = lambda f: os.path.join(ROOT, "gpurun_out", f)  # noqa: E731
 P = lambda f: os.path.join(ROOT, "profiles", f)    # noqa: E731
 
-old = json.load(open(P("r02_traffic_pmc.json")))
-old["_about"] = old["_about"].replace("round 2", "round " + R[1:].lstrip("0")).replace("mppi_rollout_cost_reg reads", "the large-K rollout kernel (mppi_rollout_prefix from round 3) reads")
+old = json.load(open(P(f"{PREV}_traffic_pmc.json")))
+old["_about"] = old["_about"].replace("round " + PREV[1:].lstrip("0"), "round " + R[1:].lstrip("0"))
 tags = {"mppi_K1024_T50": "mppi_small_rng", "mppi_K1024_T50_resident_noise": "mppi_small", "mppi_K65536_T100": "mppi_large",
         "rbpf_N1000_k50_400x400": "rbpf", "rbpf_N1000_k50_400x400_plain_scans_only": "rbpf_plain"}
 out = {"_about": old["_about"], "commands": old["commands"] + ["python tools/assemble_profiles.py"], "workloads": {}}
@@ -31,7 +32,7 @@ for key, tag in tags.items():
                              "rbpf_N1000_k50_400x400 is what the post-resample scans' clones cost")
 json.dump(out, open(P(f"{R}_traffic_pmc.json"), "w"), indent=1)
 
-olds = json.load(open(P("r02_sq_counters.json")))
+olds = json.load(open(P(f"{PREV}_sq_counters.json")))
 sq = {"_about": olds["_about"]}
 for key, tag in {"rbpf_N1000_k50_400x400": "rbpf", "mppi_K65536_T100": "mppi_large", "mppi_K1024_T50_device_noise": "mppi_small_rng"}.items():
     sq[key] = json.load(open(G(f"sq_summary_{tag}.json")))

@@ -4,7 +4,7 @@
 #   2. PMC passes (FETCH_SIZE, WRITE_SIZE separately; no other tracing) of the three workloads        -> gpurun_out/pmc_*.csv
 #   3. SQ counter pass of the RBPF scan and the large MPPI tick                                       -> gpurun_out/sq_*.csv
 set -u
-R=${R:-r03}
+R=${R:-r04}
 root=$(pwd)
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp
