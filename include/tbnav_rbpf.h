@@ -311,8 +311,9 @@ int tbnav_rbpf_particle_map(tbnav_rbpf* h, int32_t particle, int8_t* map);
  * TBNAV_RBPF_OPT_RAYCAST_BAND_ROWS n > 0 = rbpf_raycast_box keeps at most about n rows of a scan's bounding box in LDS at a
  *                                time (0 = as many as fit): drives its band loop on small maps (tests).
  * TBNAV_RBPF_OPT_RAYCAST_ADAPT   1 = rbpf_raycast_box's LDS array is sized by what the particles' boxes needed in the last scans (default;
- *                                the kernel reports it through mapped memory: less LDS per workgroup = three workgroups per CU instead of
- *                                two; a box that outgrows the guess takes a second band); 0 = by the scan's longest beam in every direction.
+ *                                the kernel reports it through mapped memory: less LDS per workgroup = three — or, when need + 256 words fits a
+ *                                quarter of a CU's LDS, FOUR — workgroups per CU instead of two; a box that outgrows the guess takes a second
+ *                                band); 2 = as 1 but never the four-per-CU form (A-B runs); 0 = by the scan's longest beam in every direction.
  *                                TBNAV_RBPF_OPT_RAYCAST_THREADS 0 = 512 threads when three workgroups fit a CU's LDS, else 1024 (default).
  * TBNAV_RBPF_OPT_BATCH_PIPELINE  1 = tbnav_rbpf_slam_batch keeps two scans in the stream (default); 0 = n synchronous calls.
  * TBNAV_RBPF_OPT_HOST_THREADS    host threads the REFERENCE distance-field mode spreads its per-particle brushfires over (particles are
@@ -345,6 +346,9 @@ int tbnav_rbpf_set_timing(tbnav_rbpf* h, int32_t enable);
 /* Names of the instantiations the handle's LAST proposal and map-update launches were, as a profiler prints them
  * ("rbpf_propose<256>", "rbpf_raycast_box<512>", "rbpf_raycast"), and the map update's workgroup count (particles + 1 when the
  * normalise / select workgroup rode in its launch): lets a benchmark line point at one row of a rocprofv3 --stats summary. */
+/* rbpf_raycast_box's LDS array at the last map update: the cells the particles' bounding boxes needed lately (0: not known yet or
+ * TBNAV_RBPF_OPT_RAYCAST_ADAPT 0) and the cells the launch's array held (what decides two / three / four workgroups per CU). */
+int tbnav_rbpf_raycast_box_cells(const tbnav_rbpf* h, int32_t* need_cells, int32_t* array_cells);
 int tbnav_rbpf_last_kernel_names(const tbnav_rbpf* h, char* propose, int32_t propose_cap, char* raycast, int32_t raycast_cap,
                                  int32_t* raycast_workgroups);
 

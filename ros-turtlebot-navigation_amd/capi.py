@@ -231,6 +231,7 @@ def lib() -> C.CDLL:
         "tbnav_rbpf_get_occupied_count": (C.c_int, [vp, vp]),
         "tbnav_rbpf_get_trace": (C.c_int, [vp] + [vp] * 9),
         "tbnav_rbpf_last_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
+        "tbnav_rbpf_raycast_box_cells": (C.c_int, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "tbnav_rbpf_last_kernel_names": (C.c_int, [vp, C.c_char_p, i32, C.c_char_p, i32, C.POINTER(C.c_int32)]),
         "tbnav_rbpf_set_timing": (C.c_int, [vp, i32]),
         "tbnav_rbpf_set_scan_matching": (C.c_int, [vp, i32, C.c_double, C.c_double, i32]),

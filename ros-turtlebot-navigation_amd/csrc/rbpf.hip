@@ -101,7 +101,7 @@ struct tbnav_rbpf {
   std::vector<double2> beam_cs;  // (cos, sin) of every beam's angle in the sensor frame, kept between scans
   std::vector<double2> beams_tmp;
   int raycast_band_rows = 0;   // > 0: cap the LDS array of rbpf_raycast_box at about this many box rows (TBNAV_RBPF_OPT_RAYCAST_BAND_ROWS, tests)
-  int lk_raycast = -1, lk_raycast_grid = 0, lk_propose = 0;  // the instantiations the last launches were (tbnav_rbpf_last_kernel_names): raycast threads (0 = beam-ordered), its workgroups, propose threads
+  int lk_raycast = -1, lk_raycast_wps = 0, lk_raycast_grid = 0, lk_propose = 0, lk_box_need = 0, lk_box_cap = 0;  // the instantiations the last launches were (tbnav_rbpf_last_kernel_names): raycast threads (0 = beam-ordered), its workgroups, propose threads
   int raycast_form = 0;        // 0 = box counters (rbpf_raycast_box), 1 = the beam-ordered kernel (rbpf_raycast) (TBNAV_RBPF_OPT_RAYCAST_FORM)
   double* d_sens = nullptr;    // [N][4] sensor transform (X, Y, sin, cos) of each particle's new pose, left by the proposal kernel
   uint64_t seed = 0x5EEDull, scan_index = 0;  // device noise source (normals == NULL)
@@ -515,7 +515,7 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens,
   const bool nt_auto = nt == 0;
   if (nt == 0) nt = 1024;
   // rbpf_raycast_box: one u32 per cell of the box, the box padded to whole groups of 8 cells along y
-  long cap_win = 0;
+  long cap_win = 0, cap_four = 0;
   if (h->tile_cap > 0) {
     // every end point lies within `reach` of the robot's position: at most floor(2 reach / res) + 2 rows or columns (+1 spare);
     // along y the box is padded to whole pairs of cells
@@ -524,7 +524,7 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens,
     cap_win = (side * ((side + 2) & ~1L) + 7) & ~7L;
     // ... but no more than lets TWO workgroups share a CU's 160 KB (the kernel works a larger box through in bands of rows;
     // at least one padded row must fit)
-    const long cap_fit = ((78L * 1024 - (long)box_lds_bytes(0, (size_t)bvn) - 1536) / 4) & ~7L;
+    const long cap_fit = ((78L * 1024 - (long)box_lds_bytes(0, (size_t)bvn) - (long)kBoxStaticLds) / 4) & ~7L;
     if (cap_win > cap_fit) cap_win = std::max(cap_fit, (side + 9) & ~7L);
     // (test hook: at most about this many rows of the box per band, to drive the band loop on small maps)
     if (h->raycast_band_rows > 0) cap_win = std::min(cap_win, (h->raycast_band_rows * ((side + 2) & ~1L) + 7) & ~7L);
@@ -535,13 +535,25 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens,
     if (need > 0) {
       const long want = ((long)need + need / 8 + 512 + 7) & ~7L;
       cap_win = std::min(cap_win, std::max(want, (side + 9) & ~7L));
+      // FOUR 512-thread workgroups per CU — every one of 1000 particles resident at once instead of 768 and a second, partial
+      // round (round 4; measured 24.6 / 30.8 / 37.1 us with 1 / 2 / 3 workgroups per CU, 48.3 for 1000 particles on 768 slots) —
+      // when the boxes' need plus a margin of three rows or so fits a quarter of the CU's LDS.  The margin is tighter than the
+      // three-per-CU form's 1/8 + 512: a box that outgrows it costs its particle a second band, never correctness.
+      const long cap4 = std::max(((long)need + 256 + 7) & ~7L, (side + 9) & ~7L);
+      const size_t lds4 = std::max(box_lds_bytes((size_t)cap4, (size_t)bvn), nz ? sizeof(double) * 2 * kNormChunk : (size_t)0);
+      if (h->raycast_adapt != 2 && cap4 <= cap_win && 4 * (lds4 + kBoxStaticLds) <= (size_t)kMaxLds) cap_four = cap4;
     }
   }
+  // workgroup size and residency the register allocation is held to: 512 threads x 4 per CU (64 registers a lane) when cap_four says
+  // the LDS allows it, x 3 (80 registers) when three fit, else 1024 x 2 (64).  Measured at cfg3, N = 1000 / 4000: 1024 x 2: 55.8 /
+  // 191 us; 512 x 2: 54.4 / 199; 512 x 3: 49.1 / 163
+  int wps = 8;
+  if ((nt_auto || nt == 512) && cap_four > 0) { nt = 512; cap_win = cap_four; }
   const size_t lds_win = box_lds_bytes((size_t)cap_win, (size_t)bvn);
-  // workgroup size: 512 threads when THREE workgroups fit a CU's LDS (24 waves, 80 registers a lane), else 1024 (two, 32 waves).
-  // Measured at cfg3, N = 1000 / 4000 (56 KB of LDS saved by the adaptive array): 1024 x 2: 55.8 / 191 us; 512 x 2: 54.4 / 199;
-  // 512 x 3: 49.1 / 163
-  if (nt_auto && cap_win > 0 && 3 * (lds_win + 1536) <= (size_t)kMaxLds) nt = 512;
+  if (cap_four == 0) {
+    if (nt_auto && cap_win > 0 && 3 * (lds_win + kBoxStaticLds) <= (size_t)kMaxLds) nt = 512;
+    if (nt == 512) wps = 6;
+  }
   if (cap_win > 0 && !h->ref_field && c.Bv < 32768 - kWave && h->raycast_form == 0 && nt >= 512 && lds_win <= (size_t)kMaxLds - 4096) {
     // default: box counters (rbpf_raycast_box)
     unsigned long long* touched = h->count_touched ? h->d_touched : nullptr;
@@ -549,13 +561,14 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens,
     const int blocks = count + (nz ? 1 : 0);
     const size_t lds_launch = nz ? std::max(lds_win, sizeof(double) * 2 * kNormChunk) : lds_win;  // (workgroup 0's two arrays)
     const int need_slot = (int)(h->rc_launches++ % 3u);
-    h->lk_raycast = nt == 512 ? 512 : 1024; h->lk_raycast_grid = blocks;
-    if (nt == 512)
-      hipLaunchKernelGGL((rbpf_raycast_box<512>), dim3(blocks), dim3(512), lds_launch, st, c, h->pool, M, beams_dev, sp.pose, sens,
-                         h->d_trow[h->cur], h->d_nocc[h->cur], err, (int)cap_win, touched, na, h->d_box_need, h->d_box_need_host, need_slot);
-    else
-      hipLaunchKernelGGL((rbpf_raycast_box<1024>), dim3(blocks), dim3(1024), lds_launch, st, c, h->pool, M, beams_dev, sp.pose, sens,
-                         h->d_trow[h->cur], h->d_nocc[h->cur], err, (int)cap_win, touched, na, h->d_box_need, h->d_box_need_host, need_slot);
+    h->lk_raycast = nt == 512 ? 512 : 1024; h->lk_raycast_wps = wps; h->lk_raycast_grid = blocks;
+    h->lk_box_cap = (int)cap_win; h->lk_box_need = (h->raycast_adapt && h->h_box_need) ? *reinterpret_cast<volatile int*>(h->h_box_need) : 0;
+#define TBNAV_BOX(NT_, WPS_) hipLaunchKernelGGL((rbpf_raycast_box<NT_, WPS_>), dim3(blocks), dim3(NT_), lds_launch, st, c, h->pool, M, beams_dev, sp.pose, sens, \
+                                                h->d_trow[h->cur], h->d_nocc[h->cur], err, (int)cap_win, touched, na, h->d_box_need, h->d_box_need_host, need_slot)
+    if (nt == 512 && wps == 8) TBNAV_BOX(512, 8);
+    else if (nt == 512) TBNAV_BOX(512, 6);
+    else TBNAV_BOX(1024, 8);
+#undef TBNAV_BOX
     TBNAV_HIP(hipGetLastError());
     return TBNAV_OK;
   }
@@ -1025,8 +1038,9 @@ int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf*
                   : hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_edt<32>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
   // (2.3 KB of static LDS: the embedded normalise's scan scratch)
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_box<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 4096);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_box<512>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 4096);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_box<1024, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 4096);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_box<512, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 4096);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_box<512, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 4096);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 1024);
   // the proposal / scan-match kernels carry the scan, the per-sample data and the bitmap slice: more than the 64 KB
   // default for long scans or many samples
@@ -2269,7 +2283,7 @@ int tbnav_rbpf_set_option(tbnav_rbpf* h, int32_t option, int32_t value) {
       h->raycast_band_rows = value;
       return TBNAV_OK;
     case TBNAV_RBPF_OPT_RAYCAST_ADAPT:
-      if (value != 0 && value != 1) return TBNAV_ERR_INVALID_ARG;
+      if (value < 0 || value > 2) return TBNAV_ERR_INVALID_ARG;
       h->raycast_adapt = value;
       return TBNAV_OK;
     case TBNAV_RBPF_OPT_BATCH_PIPELINE:
@@ -2321,11 +2335,18 @@ int tbnav_rbpf_last_kernel_names(const tbnav_rbpf* h, char* propose, int32_t pro
   if (!h) return TBNAV_ERR_INVALID_ARG;
   if (propose && propose_cap > 0) { if (h->lk_propose) snprintf(propose, (size_t)propose_cap, "rbpf_propose<%d>", h->lk_propose); else propose[0] = 0; }
   if (raycast && raycast_cap > 0) {
-    if (h->lk_raycast > 0) snprintf(raycast, (size_t)raycast_cap, "rbpf_raycast_box<%d>", h->lk_raycast);
+    if (h->lk_raycast > 0) snprintf(raycast, (size_t)raycast_cap, "rbpf_raycast_box<%d, %d>", h->lk_raycast, h->lk_raycast_wps);
     else if (h->lk_raycast == 0) snprintf(raycast, (size_t)raycast_cap, "rbpf_raycast");
     else raycast[0] = 0;
   }
   if (raycast_workgroups) *raycast_workgroups = h->lk_raycast_grid;
+  return TBNAV_OK;
+}
+
+int tbnav_rbpf_raycast_box_cells(const tbnav_rbpf* h, int32_t* need_cells, int32_t* array_cells) {
+  if (!h) return TBNAV_ERR_INVALID_ARG;
+  if (need_cells) *need_cells = h->lk_box_need;
+  if (array_cells) *array_cells = h->lk_box_cap;
   return TBNAV_OK;
 }
 

@@ -1134,7 +1134,7 @@ __device__ __forceinline__ void normalize_body(int N, const double* __restrict__
 // What bounds it (per-wave trace): instruction issue — ~28 k wave-instructions per particle through
 // 16 waves on 4 SIMDs between 9 barriers; memory traffic is the distinct cells once each way.
 // LDS: tile u32[tile_cap] (rows padded to an even number of columns: pair i = words 2i, 2i+1) |
-// ev u16[Bv][kBoxEv] | val_e f64[Bv + 64] | exy own ecnt i32[Bv]
+// ev u16[Bv][kBoxEv] (slot o's first 8 bytes double as its replayed value) | hot-cell values f64[64] | exy i32[Bv] | ecnt u16[Bv]
 #ifdef TBNAV_PHASE_PROF
 static __device__ unsigned long long g_phase_w[16];
 #endif
@@ -1159,12 +1159,11 @@ constexpr int kBoxEv = 8;     // events a slot holds before it is replayed exhau
 constexpr int kHotSide = 7;   // the kHotSide x kHotSide cells round the robot are candidates for a lane of their own ...
 constexpr int kHotMin = 16;   // ... when they collect at least this many free adds
 constexpr int kVeryHot = 80;  // ... and from this many on they are worked out without the chain of adds (add_repeated)
-__host__ __device__ constexpr size_t box_lds_bytes(size_t cap, size_t bv) { return 4 * cap + 8 * (bv + 64) + 4 * 2 * bv + 2 * kBoxEv * bv; }
+// tile u32[cap] | ev u16[bv][kBoxEv] (a slot's first 8 bytes become its replayed value once its events are read) | hot values f64[64] | exy, ecnt i32[bv]
+__host__ __device__ constexpr size_t box_lds_bytes(size_t cap, size_t bv) { return 4 * cap + 2 * kBoxEv * bv + 8 * 64 + 4 * bv + 2 * ((bv + 1) & ~(size_t)1); }
+constexpr size_t kBoxStaticLds = 768;  // the kernel's __shared__ variables (tools/kernel_resources.py rbpf_raycast: 7xx B), rounded up
 // (512 threads: three workgroups = 24 waves per CU when the LDS array is sized by what the boxes need, see launch_raycast —
 //  6 waves per SIMD leave 80 registers a lane: the kernel needs 77 and spills nothing; 1024 threads: two workgroups = 32 waves, 64)
-#ifndef TBNAV_RC512_WAVES
-#define TBNAV_RC512_WAVES 6
-#endif
 
 
 
@@ -1414,8 +1413,8 @@ __global__ __launch_bounds__(256) void rbpf_normalize(int N, const double* __res
                                                       unsigned int* seq = nullptr, unsigned int seq_val = 0,
                                                       int* __restrict__ children = nullptr);
 // rbpf_raycast.hip
-template <int NT>
-__global__ __launch_bounds__(NT, NT == 512 ? TBNAV_RC512_WAVES : 8) void rbpf_raycast_box(ScanC c, TilePool P, MapT M, const double2* __restrict__ beams,
+template <int NT, int WPS>
+__global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P, MapT M, const double2* __restrict__ beams,
                                                           const double* __restrict__ pose, const double* __restrict__ sens,
                                                           int* __restrict__ trow_occ, int* __restrict__ n_occ, int* __restrict__ err,
                                                           int tile_cap, unsigned long long* __restrict__ touched, NormArgs nz,

@@ -120,8 +120,8 @@ __global__ void rbpf_add_repeated_test(const double* __restrict__ x, const doubl
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < count) out[i] = add_repeated(x[i], d[i], n[i]);
 }
-template <int NT>
-__global__ __launch_bounds__(NT, NT == 512 ? TBNAV_RC512_WAVES : 8) void rbpf_raycast_box(ScanC c, TilePool P, MapT M, const double2* __restrict__ beams,
+template <int NT, int WPS>
+__global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P, MapT M, const double2* __restrict__ beams,
                                                           const double* __restrict__ pose, const double* __restrict__ sens,
                                                           int* __restrict__ trow_occ, int* __restrict__ n_occ, int* __restrict__ err,
                                                           int tile_cap, unsigned long long* __restrict__ touched, NormArgs nz,
@@ -142,18 +142,24 @@ __global__ __launch_bounds__(NT, NT == 512 ? TBNAV_RC512_WAVES : 8) void rbpf_ra
   const int Bv = c.Bv;
   unsigned int* tile = reinterpret_cast<unsigned int*>(lds_i);         // (tile_cap is a multiple of 8)
   unsigned short* ev = reinterpret_cast<unsigned short*>(lds_i + tile_cap);  // [Bv][kBoxEv]  beam << 1 | occupied  (16 bytes a slot, 16-byte aligned)
-  double* val_e = reinterpret_cast<double*>(lds_i + tile_cap + 4 * Bv);      // [Bv + 64] the value replayed for an end-point cell / a hot cell
-  int* exy = lds_i + tile_cap + 4 * Bv + 2 * (Bv + 64);  // [Bv] end-point cell, x | y << 16
-  int* ecnt = exy + Bv;                                  // [Bv] events recorded in the slot of beam b — the FIRST beam that ended in its cell (0: b opened
-                                                         //      no slot; may exceed kBoxEv: overflow)
+  double* val_hot = reinterpret_cast<double*>(lds_i + tile_cap + 4 * Bv);    // [64] the value worked out for a hot cell (slot Bv + lane)
+  int* exy = lds_i + tile_cap + 4 * Bv + 2 * 64;         // [Bv] end-point cell, x | y << 16
+  unsigned short* ecnt = reinterpret_cast<unsigned short*>(exy + Bv);  // [Bv] events recorded in the slot of beam b — the FIRST beam that ended in its
+                                                                       //      cell (0: b opened no slot; may exceed kBoxEv: overflow).  Two counts a dword:
+                                                                       //      LDS atomics are 32-bit, a count never reaches 2^16 (one event per beam at most)
   constexpr unsigned int kFlag = 0x80000000u;
   constexpr int kEv = kBoxEv;
+  // the value replayed for end-point slot o (< Bv) lives in the first 8 bytes of the slot's own 16-byte event list — the lane
+  // that replays it has the events in registers by then, nobody else reads them — and a hot cell's (slot Bv + lane) in val_hot:
+  // 8 bytes per beam less LDS than an array of its own, which is what lets FOUR workgroups share a CU when the box is small
+  auto val_at = [&](int slot) -> double* { return slot < Bv ? reinterpret_cast<double*>(ev + slot * kEv) : val_hot + (slot - Bv); };
   __shared__ int bad, bx0, bx1, by0, by1, srx, sry, nocc_delta, n_ovf;
   __shared__ unsigned long long need_base;
   __shared__ unsigned int mt_id[kMapTilesMax];  // map tiles under the box: the tile the particle's table names (once written: its private tile)
-  __shared__ int mt_touch[kMapTilesMax], mt_slot[kMapTilesMax], mt_priv[kMapTilesMax];
+  __shared__ unsigned char mt_touch[kMapTilesMax], mt_priv[kMapTilesMax];  // (bytes: every byte of LDS counts towards a fourth resident workgroup)
+  __shared__ signed char mt_slot[kMapTilesMax];
   __shared__ int rc_delta[kBoxSideMax / kTS + 2];
-  __shared__ int ovf[kWave];                    // slots whose event list overflowed (more than these: found by scanning)
+  __shared__ unsigned short ovf[kWave];                 // slots whose event list overflowed (more than these: found by scanning)
   __shared__ double sh_pose[4];
   __shared__ double robot_v0, robot_v;  // the robot's own cell: its log-odds before the scan / after the adds applied so far
   __shared__ int robot_cnt;             // beams with a free cell (each adds l_free to the robot's cell once)
@@ -260,7 +266,8 @@ __global__ __launch_bounds__(NT, NT == 512 ? TBNAV_RC512_WAVES : 8) void rbpf_ra
   };
   auto record = [&](unsigned int word, int what) {  // an event for the flagged cell whose tile word this is
     const int o = (int)((word >> 16) & 0x7FFFu);
-    const int en = atomicAdd(&ecnt[o], 1);
+    const unsigned int was = atomicAdd(reinterpret_cast<unsigned int*>(ecnt) + (o >> 1), (o & 1) ? 0x10000u : 1u);
+    const int en = (int)((o & 1) ? was >> 16 : was & 0xFFFFu);
     if (en < kEv) ev[o * kEv + en] = (unsigned short)what;
   };
   const int step_r = uni(floor_div_small(2 * nthr, bw)), step_c = 2 * nthr - step_r * bw;  // pair pi + nthr in (row, column) terms
@@ -379,7 +386,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? TBNAV_RC512_WAVES : 8) void rbpf_ra
     //    private).  Slots that overflowed are listed on the way.
     const int np = band_cells >> 1;
     const uint2* tile2 = reinterpret_cast<const uint2*>(tile);
-    constexpr int kSl = NT == 512 ? 6 : 4;  // pairs a thread holds across the passes (512 threads: 6 fill the 80 registers exactly — 48.6 vs 50.1 us per 1000 particles; 8 spill)
+    constexpr int kSl = (NT == 512 && WPS <= 6) ? 6 : 4;  // pairs a thread holds across the passes (512 threads at 6 waves per SIMD: 6 fill the 80 registers exactly — 48.6 vs 50.1 us per 1000 particles; 8 spill; 64 registers: 4)
     double2 v[kSl];
     auto pairs = [&](int first, auto&& fn) {  // fn(i, the pair's two tile words, cx, cy of its first cell), i < kSl
       const int pi0 = first + tid;
@@ -408,8 +415,8 @@ __global__ __launch_bounds__(NT, NT == 512 ? TBNAV_RC512_WAVES : 8) void rbpf_ra
       if (ecnt[o] == 0) continue;
       const int e = exy[o];
       const bool robot_cell = (e & 0xFFFF) == rx && (e >> 16) == ry;  // an end point too: no events from the walk, replayed against every beam
-      if (robot_cell) ecnt[o] = kEv + 1;
-      if (robot_cell || ecnt[o] > kEv) { const int i = atomicAdd(&n_ovf, 1); if (i < kWave) ovf[i] = o; }
+      if (robot_cell) ecnt[o] = (unsigned short)(kEv + 1);
+      if (robot_cell || ecnt[o] > kEv) { const int i = atomicAdd(&n_ovf, 1); if (i < kWave) ovf[i] = (unsigned short)o; }
     }
     TRACE_W(8);
     __syncthreads();
@@ -420,7 +427,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? TBNAV_RC512_WAVES : 8) void rbpf_ra
     //    sees that for itself (one ballot over the at most 64 tiles under the box), without a barrier to agree on it.
     const unsigned long long need_m = __ballot(lane < mtn && mt_touch[lane < mtn ? lane : 0] && !mt_priv[lane < mtn ? lane : 0]);
     if (need_m) {  // workgroup-uniform
-      if (wid == 0 && lane < mtn) mt_slot[lane] = ((need_m >> lane) & 1ull) ? __popcll(need_m & ((1ull << lane) - 1ull)) : -1;
+      if (wid == 0 && lane < mtn) mt_slot[lane] = (signed char)(((need_m >> lane) & 1ull) ? __popcll(need_m & ((1ull << lane) - 1ull)) : -1);
       if (tid == 0) { need_base = tile_pop_n(P, (unsigned int)__popcll(need_m)); if (need_base == ~0ull) bad = 1; }
       __syncthreads();
       if (bad) { if (tid == 0) atomicOr(&err[3], 8); return; }  // tile pool exhausted (nothing has been written if this is the first band)
@@ -436,7 +443,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? TBNAV_RC512_WAVES : 8) void rbpf_ra
     PHASE_STAMP_W(3);
     TRACE_W(10);
     auto finish_end = [&](int slot, int cx, int cy, double v0o, double vv) {
-      val_e[slot] = vv;
+      *val_at(slot) = vv;
       const bool was = v0o >= c.cut_occ, now = vv >= c.cut_occ;
       if (was != now) toggled(cx, cy, now);
     };
@@ -532,7 +539,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? TBNAV_RC512_WAVES : 8) void rbpf_ra
     }
     // 3h. the cells round the robot: every ray starts there, so they collect tens to hundreds of adds — one long dependent
     //     chain each.  They get a lane of their own in the last wave (which has no end-point cell to replay), are then
-    //     flagged like end-point cells, and their group's owner takes the value from val_e.  The few that take kVeryHot adds or
+    //     flagged like end-point cells, and their group's owner takes the value from val_hot.  The few that take kVeryHot adds or
     //     more (the robot's neighbours: up to half the beams each) go to the last wave but one instead, which works them out
     //     without the chain (add_repeated: a few hundred integer instructions per binade, worth it from about a hundred adds);
     //     the two waves run side by side, so the phase lasts as long as a chain of kVeryHot adds, not of the longest.
@@ -561,7 +568,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? TBNAV_RC512_WAVES : 8) void rbpf_ra
       }
     }
     TRACE_W(12);
-    __syncthreads();  // val_e is complete
+    __syncthreads();  // every replayed / hot value is in its slot
     TRACE_W(13);
     PHASE_STAMP_W(4);
     // 3c. the pairs: a plain cell adds its count, an end-point or hot cell takes the value worked out for it, an untouched one
@@ -584,8 +591,8 @@ __global__ __launch_bounds__(NT, NT == 512 ? TBNAV_RC512_WAVES : 8) void rbpf_ra
           n1 = a < c1 ? t1 : n1;
         }
         if ((w.x | w.y) & kFlag) {  // an end-point or hot cell takes the value worked out for it
-          if (w.x & kFlag) n0 = val_e[(w.x >> 16) & 0x7FFFu];
-          if (w.y & kFlag) n1 = val_e[(w.y >> 16) & 0x7FFFu];
+          if (w.x & kFlag) n0 = *val_at((int)((w.x >> 16) & 0x7FFFu));
+          if (w.y & kFlag) n1 = *val_at((int)((w.y >> 16) & 0x7FFFu));
         }
         n_distinct += (plain0 ? 1 : 0) + (plain1 ? 1 : 0);
         *reinterpret_cast<double2*>(cell_ptr(cx, cy)) = double2{n0, n1};
@@ -623,8 +630,9 @@ __global__ __launch_bounds__(NT, NT == 512 ? TBNAV_RC512_WAVES : 8) void rbpf_ra
 #endif
   WG_OUT();
 }
-template __global__ void rbpf_raycast_box<512>(ScanC, TilePool, MapT, const double2* __restrict__, const double* __restrict__, const double* __restrict__, int* __restrict__, int* __restrict__, int* __restrict__, int, unsigned long long* __restrict__, NormArgs, int* __restrict__, int* __restrict__, int);
-template __global__ void rbpf_raycast_box<1024>(ScanC, TilePool, MapT, const double2* __restrict__, const double* __restrict__, const double* __restrict__, int* __restrict__, int* __restrict__, int* __restrict__, int, unsigned long long* __restrict__, NormArgs, int* __restrict__, int* __restrict__, int);
+template __global__ void rbpf_raycast_box<512, 6>(ScanC, TilePool, MapT, const double2* __restrict__, const double* __restrict__, const double* __restrict__, int* __restrict__, int* __restrict__, int* __restrict__, int, unsigned long long* __restrict__, NormArgs, int* __restrict__, int* __restrict__, int);
+template __global__ void rbpf_raycast_box<512, 8>(ScanC, TilePool, MapT, const double2* __restrict__, const double* __restrict__, const double* __restrict__, int* __restrict__, int* __restrict__, int* __restrict__, int, unsigned long long* __restrict__, NormArgs, int* __restrict__, int* __restrict__, int);
+template __global__ void rbpf_raycast_box<1024, 8>(ScanC, TilePool, MapT, const double2* __restrict__, const double* __restrict__, const double* __restrict__, int* __restrict__, int* __restrict__, int* __restrict__, int, unsigned long long* __restrict__, NormArgs, int* __restrict__, int* __restrict__, int);
 
 }  // namespace tbnav_rk
 

@@ -236,6 +236,13 @@ class ParticleFilter:
         return a.value.decode(), b.value.decode(), int(n.value)
 
 
+    def raycastBoxCells(self):
+        """(cells the particles' boxes needed lately, cells of the last launch's LDS array) of rbpf_raycast_box."""
+        a, b = C.c_int32(), C.c_int32()
+        capi.check(self._L.tbnav_rbpf_raycast_box_cells(self._h, C.byref(a), C.byref(b)), "raycast_box_cells")
+        return int(a.value), int(b.value)
+
+
 class ParticleFilterGroup:
     """tbnav_rbpf_group: ONE process driving the filter over several devices (what bmapping::ParticleFilter(..., n_gpus) holds).
     params.num_particles is the ensemble's N; devices may repeat (members sharing a device exchange by copies, not RCCL)."""

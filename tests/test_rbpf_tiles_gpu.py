@@ -149,6 +149,35 @@ def test_raycast_kernel_variants_are_bit_exact(gpu_pkg, variant):
     pf.close()
 
 
+def test_box_kernel_residency_forms_are_bit_exact_and_chosen_by_the_boxes_need(gpu_pkg):
+    """rbpf_raycast_box sizes its LDS array by what the particles' boxes needed two scans ago and picks the residency that
+    fits: <1024, 8> or <512, 6> (two / three per CU, by the scan's longest beam) before any need is known, then <512, 8> (FOUR per CU, round 4) for a room whose box + 256 words
+    fits a quarter of a CU's LDS, <512, 6> (three) when TBNAV_RBPF_OPT_RAYCAST_ADAPT = 2 forbids four.  Every form leaves the
+    oracle's GridMapper bits."""
+    from rtn_amd import capi
+    N, k, n_scans = 24, 6, 6
+    steps, poses = rc.trajectory(n_scans, inc=(0.05, 0.04, 0.03))
+    rng = np.random.default_rng(12)
+    scans = [orc.room_scan(poses[s], walls=rc.ROOM_SMALL, rng=rng) for s in range(n_scans)]
+    grid = (0.05, -10.0, 10.0, -10.0, 10.0)
+    seen = {}
+    for adapt in (1, 2):
+        pf = _dev(gpu_pkg, N=N, k=k, map_min=-10.0, map_max=10.0)
+        pf.setOption(capi.RBPF_OPT_RAYCAST_ADAPT, adapt)
+        hist, names = [], []
+        for s, (prev, cur, t_icp, u) in enumerate(steps):
+            st = pf.SLAM(scans[s], u, cur, prev, True, t_icp, orc.normal_stream(60 + s, pf.numNormals(True), 0.0, 1.0))
+            assert st.status == 0
+            hist.append(pf.trace()["new_pose"].copy())
+            names.append(pf.lastKernelNames()[1])
+        seen[adapt] = names
+        for m in (0, 11, N - 1):
+            assert np.array_equal(pf.logOdds(m), _oracle_map(grid, None, scans, [h[m] for h in hist])), (adapt, m)
+        pf.close()
+    assert seen[1][0] != "rbpf_raycast_box<512, 8>" and seen[1][-1] == "rbpf_raycast_box<512, 8>", seen[1]   # (no need known at the first launch)
+    assert seen[2][-1] == "rbpf_raycast_box<512, 6>", seen[2]
+
+
 def test_batched_export_equals_single_exports_and_imports_rebuild_the_particles(gpu_pkg):
     """tbnav_rbpf_export_batch_dev writes exactly the blobs tbnav_rbpf_export_particle_dev writes, back to back (a slot listed
     twice included); tbnav_rbpf_import_batch_dev into ANOTHER handle rebuilds pose / weight / map / occupied counts of every
