@@ -291,11 +291,13 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
     import bench_profiles as bp
     t_rc = kms["raycast"] * 1e-3   # s per launch, live HIP events
     # the committed profiler rows of exactly this instantiation and grid (N particles' workgroups + the normalise workgroup)
-    rp_row = bp.rocprof_row(k_raycast, int(k_raycast.split("<")[1].rstrip(">")) * (N + 1)) if "<" in k_raycast and N == 1000 else None
-    if rp_row is None and "<" in k_raycast and N == 1000:
-        rp_row = bp.rocprof_row(k_raycast, int(k_raycast.split("<")[1].rstrip(">")) * N)
+    def _threads(name):   # "rbpf_raycast_box<512, 6>" -> 512
+        return int(name.split("<")[1].rstrip(">").split(",")[0])
+    rp_row = None
+    if "<" in k_raycast and N == 1000:   # the grid of THIS workload: N particles' workgroups (+ the normalise workgroup when it rode along)
+        rp_row = bp.rocprof_row(k_raycast, _threads(k_raycast) * (N + 1)) or bp.rocprof_row(k_raycast, _threads(k_raycast) * N)
     pmc = bp.pmc_row("rbpf_N1000_k50_400x400_plain_scans_only", k_raycast) if N == 1000 else None
-    rp_propose = bp.rocprof_row(k_propose, int(k_propose.split("<")[1].rstrip(">")) * N) if "<" in k_propose and N == 1000 else None
+    rp_propose = bp.rocprof_row(k_propose, _threads(k_propose) * N) if "<" in k_propose and N == 1000 else None
     rm = ref_mode.get("configs2_1000_particles_400x400") or {}
     rm_off = ref_mode.get("configs2_off_the_cell_corners") or {}
     # the two modes side by side, with equal weight (round-3 review): the one that reproduces the reference's results, and the

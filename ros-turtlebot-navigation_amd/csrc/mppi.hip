@@ -57,6 +57,17 @@ struct USrc {
   }
 };
 
+// lambda and fl(1 / lambda) (formed on the host by the correctly rounded division; 0: use the division).  x / lambda is needed
+// once per soft-min weight and sits on the K = 1024 tick's latency chain; the quotient below is the correctly rounded one — the
+// SAME bits as x / lambda (Markstein: with y = RN(1/b), q = RN(a y), e = a - b q exactly by FMA, RN(q + e y) = RN(a/b) unless b's
+// significand is all ones, which the host excludes) — in three dependent instructions instead of the division's ~25.
+struct Lam { double lambda, inv; };
+__device__ __forceinline__ double div_lambda(double x, const Lam& l) {
+  if (l.inv == 0.0) return x / l.lambda;   // (launch-uniform)
+  const double q = x * l.inv;
+  const double e = fma(-q, l.lambda, x);
+  return (fabs(q) < __builtin_huge_val()) ? fma(e, l.inv, q) : q;   // (an infinite cost: the quotient is the infinity itself, not inf - inf)
+}
 struct RolloutArgs {
   double half_r;    // wheel_radius / 2.0            (mppi.hpp:45)
   double r_over_b;  // wheel_radius / wheel_base     (mppi.hpp:47)
@@ -756,7 +767,7 @@ __device__ unsigned long long g_mtrace[2][8][8];
 // instead of sequential chains (a few 1e-16 relative on x, y, theta, J — inside the 1e-11 J assertion).
 template <int TRIG, int R, int TL, bool RNG>
 __global__ __launch_bounds__(kWave * R) void mppi_rollout_fused(RolloutArgs a, const double* __restrict__ duL,
-                                                                const double* __restrict__ duR, USrc u, double lambda,
+                                                                const double* __restrict__ duR, USrc u, Lam lam,
                                                                 double* __restrict__ J /* NULL: not kept */, double* __restrict__ records, int S,
                                                                 RngArgs rng) {
   extern __shared__ __attribute__((aligned(16))) double lds_all[];
@@ -887,7 +898,7 @@ __global__ __launch_bounds__(kWave * R) void mppi_rollout_fused(RolloutArgs a, c
     auto gsum = [](double x, double y) { return x + y; };
     const double mn = tbnav::group_reduce_dpp<R>(j, gmin);
     // exp(-(J - min)/lambda) with the reference's association: (J - min) * -1.0 / lambda (mppi.cpp:117)
-    const double e = ok ? exp(((j - mn) * -1.0) / lambda) : 0.0;
+    const double e = ok ? exp(div_lambda((j - mn) * -1.0, lam)) : 0.0;
     const double A = tbnav::group_reduce_dpp<R>(e, gsum), B = tbnav::group_reduce_dpp<R>(e * l, gsum), C = tbnav::group_reduce_dpp<R>(e * rg, gsum);
     const double D = tbnav::group_reduce_dpp<R>(l, gsum), E = tbnav::group_reduce_dpp<R>(rg, gsum), n = tbnav::group_reduce_dpp<R>(ok ? 1.0 : 0.0, gsum);
     if (rr == 0) {
@@ -923,7 +934,7 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
 // prefix_rows > 0 (mppi_rollout_prefix ran): rows i < prefix_rows of J hold the exclusive prefix E(i) and total[k] the
 // rollout's whole cost S: J(i, k) = S - E(i) is formed here (the 8 * K bytes of `total` are re-read by every time step's
 // workgroups: L2 hits).
-__global__ __launch_bounds__(kSliceThreads) void mppi_partials(int T, int K, int S, double lambda,
+__global__ __launch_bounds__(kSliceThreads) void mppi_partials(int T, int K, int S, Lam lam,
                                                                const double* __restrict__ J,
                                                                const double* __restrict__ duL,
                                                                const double* __restrict__ duR,
@@ -962,7 +973,7 @@ __global__ __launch_bounds__(kSliceThreads) void mppi_partials(int T, int K, int
 #pragma unroll
   for (int it = 0; it < kSliceItems; ++it) {
     // exp(-(J - min)/lambda) with the reference's association: (J - min) * -1.0 / lambda (mppi.cpp:117)
-    const double e = (j[it] == inf) ? 0.0 : exp(((j[it] - mn) * -1.0) / lambda);
+    const double e = (j[it] == inf) ? 0.0 : exp(div_lambda((j[it] - mn) * -1.0, lam));
     A += e;
     B += e * l[it];
     C += e * r[it];
@@ -988,7 +999,7 @@ __global__ __launch_bounds__(kSliceThreads) void mppi_partials(int T, int K, int
 // kernel's record for that slice up to the association of the sums.
 // (the direct exchange's sending side, when the records are produced here: see mppi_direct_publish further down)
 struct DirectPub { unsigned long long* const* peers; int me, P, parity; unsigned int seq; int only_self; };
-__global__ __launch_bounds__(kWave) void mppi_merge_records(int T, int Sf, int per_slice, int S, double lambda,
+__global__ __launch_bounds__(kWave) void mppi_merge_records(int T, int Sf, int per_slice, int S, Lam lam,
                                                             const double* __restrict__ fine, double* __restrict__ records, DirectPub pub) {
   const int s = blockIdx.x, i = blockIdx.y, lane = threadIdx.x;
   const int r0 = s * per_slice, r1 = min(Sf, r0 + per_slice);
@@ -1003,7 +1014,7 @@ __global__ __launch_bounds__(kWave) void mppi_merge_records(int T, int Sf, int p
   for (int r = r0 + lane; r < r1; r += kWave) {
     const double* rec = fine + ((size_t)i * Sf + r) * TBNAV_MPPI_REC;
     if (rec[6] > 0.0) {
-      const double sc = exp(((rec[0] - M) * -1.0) / lambda);
+      const double sc = exp(div_lambda((rec[0] - M) * -1.0, lam));
       A += sc * rec[1]; B += sc * rec[2]; C += sc * rec[3];
       D += rec[4]; E += rec[5]; n += rec[6];
     }
@@ -1111,7 +1122,7 @@ __device__ __forceinline__ bool direct_load_records(const DirectSrc& d, const si
 }
 
 template <int kKeep, bool DIRECT = false>
-__global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, double lambda, double umax, USrc u,
+__global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, Lam lam, double umax, USrc u,
                                                     const double* __restrict__ records, double* __restrict__ u_out,
                                                     double* __restrict__ out, double* __restrict__ out_host, double seq, DirectSrc ds) {
   // (DIRECT: `records` is not read — field f of record (g, i, sl) is polled for in the exchange buffer, same index)
@@ -1189,7 +1200,7 @@ __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, double 
 #pragma unroll
     for (int q = 0; q < kKeep; ++q)
       if (rk[q][6] > 0.0) {
-        const double sc = exp(((rk[q][0] - M) * -1.0) / lambda);
+        const double sc = exp(div_lambda((rk[q][0] - M) * -1.0, lam));
         W += sc * rk[q][1]; NL += sc * rk[q][2]; NR += sc * rk[q][3];
         SD += rk[q][4]; SE += rk[q][5]; SN += rk[q][6];
       }
@@ -1199,7 +1210,7 @@ __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, double 
       const double* rec = records + (((size_t)g * T + i) * S + sl) * TBNAV_MPPI_REC;
       const double rn = field(rec, 6);
       if (rn > 0.0) {
-        const double sc = exp(((field(rec, 0) - M) * -1.0) / lambda);
+        const double sc = exp(div_lambda((field(rec, 0) - M) * -1.0, lam));
         W += sc * field(rec, 1); NL += sc * field(rec, 2); NR += sc * field(rec, 3);
         SD += field(rec, 4); SE += field(rec, 5); SN += rn;
       }
@@ -1405,6 +1416,13 @@ DirectPub take_pub(tbnav_mppi* h) {
   return h->pub_next;
 }
 
+Lam lam_of(const tbnav_mppi* h) {
+  const double lambda = h->p.lambda, inv = 1.0 / lambda;
+  unsigned long long bits; std::memcpy(&bits, &lambda, sizeof bits);
+  const bool all_ones = (bits & 0xFFFFFFFFFFFFFull) == 0xFFFFFFFFFFFFFull;   // the one significand Markstein's theorem excludes
+  return Lam{lambda, (std::isnormal(inv) && std::isnormal(lambda) && !all_ones) ? inv : 0.0};
+}
+
 int launch_rollout(tbnav_mppi* h, const double x0[3], const double* d_duL, const double* d_duR,
                    hipStream_t st) {
   RolloutArgs a;
@@ -1496,7 +1514,7 @@ int launch_fused(tbnav_mppi* h, const double x0[3], const double* d_duL, const d
   const RngArgs g = rng ? *rng : RngArgs{0, 0, 0.0, 0.0};
 #define TBNAV_FUSED(TR, RR, TLL, RG) do { h->lk_rollout[0] = 1; h->lk_rollout[1] = TR; h->lk_rollout[2] = RR; h->lk_rollout[3] = TLL; h->lk_rollout[4] = RG;     \
                                      hipLaunchKernelGGL((mppi_rollout_fused<TR, RR, TLL, RG>), grid, block, lds, st, a, d_duL, d_duR, usrc, \
-                                                        h->p.lambda, h->keep_j ? h->d_J : nullptr, h->d_records_f, h->fused_S, g); } while (0)
+                                                        lam_of(h), h->keep_j ? h->d_J : nullptr, h->d_records_f, h->fused_S, g); } while (0)
 #define TBNAV_FUSED_R(TR)                                                                                \
   if (R == 8) { if (TL == 1) TBNAV_FUSED(TR, 8, 1, false); else TBNAV_FUSED(TR, 8, 2, false); }          \
   else if (R == 4) { if (TL == 1) TBNAV_FUSED(TR, 4, 1, false); else TBNAV_FUSED(TR, 4, 2, false); }     \
@@ -1518,7 +1536,7 @@ int launch_fused(tbnav_mppi* h, const double x0[3], const double* d_duL, const d
 
 int launch_partials(tbnav_mppi* h, const double* d_duL, const double* d_duR, double* d_records, hipStream_t st) {
   const dim3 grid(h->S, h->T), block(kSliceThreads);
-  hipLaunchKernelGGL(mppi_partials, grid, block, 0, st, h->T, h->K, h->S, h->p.lambda, h->d_J, d_duL, d_duR, d_records, h->prefix_rows, h->d_total);
+  hipLaunchKernelGGL(mppi_partials, grid, block, 0, st, h->T, h->K, h->S, lam_of(h), h->d_J, d_duL, d_duR, d_records, h->prefix_rows, h->d_total);
   TBNAV_HIP(hipGetLastError());
   return TBNAV_OK;
 }
@@ -1532,7 +1550,7 @@ int launch_combine(tbnav_mppi* h, const double* d_records, int G, hipStream_t st
   const int blocks = (h->T + steps_per_block - 1) / steps_per_block;
   const USrc usrc{h->d_u[h->ucur], h->pending_shift ? 1 : 0, h->uinit[0], h->uinit[1]};
   const DirectSrc ds = direct ? *direct : DirectSrc{nullptr, 0ull, nullptr, nullptr, 0u};
-#define TBNAV_COMBINE(KEEP, DIR) do { h->lk_combine[0] = KEEP; h->lk_combine[1] = DIR; hipLaunchKernelGGL((mppi_combine<KEEP, DIR>), dim3(blocks), dim3(wpb * kWave), 0, st, h->T, G, S, h->p.lambda, h->p.max_wheel_vel, usrc, \
+#define TBNAV_COMBINE(KEEP, DIR) do { h->lk_combine[0] = KEEP; h->lk_combine[1] = DIR; hipLaunchKernelGGL((mppi_combine<KEEP, DIR>), dim3(blocks), dim3(wpb * kWave), 0, st, h->T, G, S, lam_of(h), h->p.max_wheel_vel, usrc, \
                                                     d_records, h->d_u[1 - h->ucur], h->d_out, h->publish_next ? h->d_out_host : nullptr, (double)(h->seq + 1), ds); } while (0)
   if (direct) {
     if (G * S > 4 * kWave && G * S <= 8 * kWave) TBNAV_COMBINE(8, true);
@@ -1889,7 +1907,7 @@ int tbnav_mppi_shard_partials(tbnav_mppi* h, const double x0[3], const double* d
     const int rcf = launch_fused(h, x0, d_duL, d_duR, st);
     if (rcf != TBNAV_OK) return rcf;
     hipLaunchKernelGGL(mppi_merge_records, dim3(h->S, h->T), dim3(kWave), 0, st, h->T, h->fused_S, kSlice / h->fused_r, h->S,
-                       h->p.lambda, h->d_records_f, d_records_out, take_pub(h));
+                       lam_of(h), h->d_records_f, d_records_out, take_pub(h));
     TBNAV_HIP(hipGetLastError());
     return TBNAV_OK;
   }
@@ -1912,7 +1930,7 @@ int tbnav_mppi_shard_partials_rng(tbnav_mppi* h, const double x0[3], uint64_t se
   const int rcf = launch_fused(h, x0, h->d_duL, h->d_duR, st, &g);
   if (rcf != TBNAV_OK) return rcf;
   hipLaunchKernelGGL(mppi_merge_records, dim3(h->S, h->T), dim3(kWave), 0, st, h->T, h->fused_S, kSlice / h->fused_r, h->S,
-                     h->p.lambda, h->d_records_f, d_records_out, take_pub(h));
+                     lam_of(h), h->d_records_f, d_records_out, take_pub(h));
   TBNAV_HIP(hipGetLastError());
   return TBNAV_OK;
 }
