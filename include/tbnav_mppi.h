@@ -228,6 +228,11 @@ int tbnav_mppi_get_cost_to_go(tbnav_mppi* h, double* J_host);
  * beyond |x| = 1e5) evaluated on n host values — lets the tests bound its error against libm. */
 int tbnav_mppi_debug_sincos(const double* x_host, int32_t n, double* sin_host, double* cos_host);
 
+/* The soft-min kernels' x / lambda (three dependent instructions from lambda's correctly rounded reciprocal instead of the
+ * division's own iterations) evaluated on n host values — lets the tests hold it against the IEEE division bit for bit.
+ * *used_reciprocal = 0 when this lambda takes the plain division (reciprocal not normal, or lambda's significand all ones). */
+int tbnav_mppi_debug_div_lambda(const double* x_host, int32_t n, double lambda, double* out_host, int32_t* used_reciprocal);
+
 /* ---- measurement hook -------------------------------------------------------------------------- */
 
 /* One tick with a hipEvent pair around each kernel, recorded on `stream` (the stream the kernels

@@ -142,6 +142,7 @@ def lib() -> C.CDLL:
         "tbnav_mppi_shard_partials_rng": (C.c_int, [vp, dp, u64, u64, vp, vp]),
         "tbnav_mppi_get_cost_to_go": (C.c_int, [vp, vp]),
         "tbnav_mppi_debug_sincos": (C.c_int, [vp, i32, vp, vp]),
+        "tbnav_mppi_debug_div_lambda": (C.c_int, [vp, i32, dbl, vp, C.POINTER(C.c_int32)]),
         "tbnav_mppi_profile_tick": (C.c_int, [vp, dp, vp, vp, vp, C.POINTER(C.c_float)]),
         "tbnav_mppi_profile_kernels": (C.c_int, [vp, dp, vp, vp, vp, i32, C.POINTER(C.c_float)]),
         "tbnav_mppi_profile_kernels_rng": (C.c_int, [vp, dp, C.c_uint64, C.c_uint64, vp, i32, C.POINTER(C.c_float)]),

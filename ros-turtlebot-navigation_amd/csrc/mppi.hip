@@ -1254,6 +1254,10 @@ __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, Lam lam
   }
 }
 
+__global__ void mppi_debug_div_lambda(int n, const double* __restrict__ x, Lam lam, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = div_lambda(x[i], lam);
+}
 // raw[(k*T + i)*2 + c]  ->  duL[i*K + k], duR[i*K + k]
 __global__ void mppi_debug_sincos(int n, const double* __restrict__ x, double* __restrict__ sn, double* __restrict__ cs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2261,6 +2265,23 @@ int tbnav_mppi_debug_sincos(const double* x_host, int32_t n, double* sin_host, d
   if (e == hipSuccess) e = hipMemcpy(sin_host, ds, sizeof(double) * n, hipMemcpyDeviceToHost);
   if (e == hipSuccess) e = hipMemcpy(cos_host, dc, sizeof(double) * n, hipMemcpyDeviceToHost);
   (void)hipFree(dx); (void)hipFree(ds); (void)hipFree(dc);
+  TBNAV_HIP(e);
+  return TBNAV_OK;
+}
+
+int tbnav_mppi_debug_div_lambda(const double* x_host, int32_t n, double lambda, double* out_host, int32_t* used_reciprocal) {
+  if (!x_host || !out_host || n <= 0) return TBNAV_ERR_INVALID_ARG;
+  tbnav_mppi tmp;
+  tmp.p.lambda = lambda;
+  const Lam lam = lam_of(&tmp);
+  if (used_reciprocal) *used_reciprocal = lam.inv != 0.0;
+  double *dx = nullptr, *dy = nullptr;
+  TBNAV_HIP(hipMalloc((void**)&dx, sizeof(double) * n));
+  TBNAV_HIP(hipMalloc((void**)&dy, sizeof(double) * n));
+  hipError_t e = hipMemcpy(dx, x_host, sizeof(double) * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess) { hipLaunchKernelGGL(mppi_debug_div_lambda, dim3((n + 255) / 256), dim3(256), 0, nullptr, n, dx, lam, dy); e = hipGetLastError(); }
+  if (e == hipSuccess) e = hipMemcpy(out_host, dy, sizeof(double) * n, hipMemcpyDeviceToHost);
+  (void)hipFree(dx); (void)hipFree(dy);
   TBNAV_HIP(e);
   return TBNAV_OK;
 }

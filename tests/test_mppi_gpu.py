@@ -348,6 +348,32 @@ def test_device_sincos_accuracy(gpu_pkg):
     assert np.allclose(sb * sb + cb * cb, 1.0, atol=1e-12)
 
 
+def test_division_by_lambda_from_its_reciprocal_is_the_ieee_quotient_bit_for_bit(gpu_pkg):
+    """The soft-min weights need (J - min) * -1.0 / lambda with the reference's association (mppi.cpp:117).  The kernels form the
+    quotient from lambda's correctly rounded reciprocal — q = x r, e = fma(-q, lambda, x), fma(e, r, q): three dependent
+    instructions instead of the division's ~25, and by Markstein's theorem the correctly rounded quotient, i.e. the SAME bits as
+    x / lambda.  Held here against numpy's IEEE division on 2 x 10^5 values per lambda (cost differences from 1e-300 to 1e300,
+    zeros, infinities), for the shipped lambda and awkward ones; a lambda whose significand is all ones takes the plain division."""
+    import ctypes as C
+    L = gpu_pkg.capi.lib()
+    rng = np.random.default_rng(17)
+    x = -np.abs(np.concatenate([rng.standard_normal(100000) * 10.0 ** rng.uniform(-300, 300, 100000), rng.uniform(0, 1e6, 99990),
+                                [0.0, np.inf, 1e-320, 5e-324, 1.7976931348623157e308, 1.0, 3.0, 1e-8, 0.01, 2.0 ** -1022]]))
+    used_any = False
+    for lam in (0.01, 1e-3, 1.0, 3.0, 0.1, 7.3e-5, 1.9999999999999998, 2.0 ** -40, 123456.789, float(np.nextafter(1.0, 0.0))):
+        out = np.empty_like(x); used = C.c_int32()
+        assert L.tbnav_mppi_debug_div_lambda(x.ctypes.data, x.size, C.c_double(lam), out.ctypes.data, C.byref(used)) == 0
+        with np.errstate(over="ignore", under="ignore"):
+            want = x / lam
+        sub = np.abs(want) < 2.3e-308   # (a subnormal quotient: outside the theorem — and outside anything exp() distinguishes)
+        assert np.array_equal(out[~sub], want[~sub]), lam
+        assert np.allclose(out[sub], want[sub], rtol=0, atol=1e-307)
+        used_any |= bool(used.value)
+        if lam in (1.9999999999999998, float(np.nextafter(1.0, 0.0))):
+            assert used.value == 0   # significand all ones: the theorem's exception
+    assert used_any
+
+
 @pytest.mark.parametrize("form", ["prefix", "general"])
 @pytest.mark.parametrize("K,horizon", [(32768 + 37, 1.0), (32768, 0.6), (40000, 0.12), (33000, 0.32), (32800, 4.0)])
 def test_streaming_rollout_kernel_against_the_oracle(gpu_pkg, K, horizon, form):
