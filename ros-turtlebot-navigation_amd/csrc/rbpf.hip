@@ -11,7 +11,8 @@
 //   rbpf_field.hip     rbpf_densify, rbpf_window, rbpf_edt<C>, rbpf_edt_compact<R> (stored-field modes, on-demand fields)
 //   rbpf_resample.hip  rbpf_normalize, rbpf_resample_apply, rbpf_pool_init, dense <-> tiles, rbpf_argmax, rbpf_export_map
 //   rbpf_migrate.hip   particle blobs for the sharded filter's cross-rank resample
-//   rbpf_device.hpp    what they share: launch-argument structs, map accessors, lookups, reductions, kernel declarations
+//   rbpf_device.hpp    what they share: launch-argument structs, map accessors, reductions, kernel declarations
+//   rbpf_normalize.hpp the normalise / selection body (a kernel of its own and workgroup 0 of the map update)
 // (two small kernels of the reference-field mode's plumbing, rbpf_pack_logs / rbpf_copy_codes, stay here beside their only caller)
 #include <hip/hip_runtime.h>
 

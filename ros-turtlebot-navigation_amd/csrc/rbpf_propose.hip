@@ -7,6 +7,356 @@
 
 namespace tbnav_rk {
 
+// Development build (-DTBNAV_PHASE_PROF): per-phase wall-clock stamps inside the proposal and raycast kernels, summed
+// over workgroups and printed by tbnav_rbpf_destroy.  The stamps add barriers and global atomics — the kernels
+// run measurably slower with them; the numbers are for comparing phases, not for the bench.
+#ifdef TBNAV_PHASE_PROF
+static __device__ unsigned long long g_trace_p[2][4][16];  // [which][wave][stamp] of TWO proposal workgroups (blockIdx.x == 96, 100: XCCs 0 and 4)
+#define TRACE_P(i) do { if ((blockIdx.x == 96 || blockIdx.x == 100) && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 4) g_trace_p[blockIdx.x == 100][threadIdx.x >> 6][i] = wall_clock64(); } while (0)
+static __device__ unsigned long long g_wgp[4096][3];   // [workgroup] entry, exit (10 ns ticks), XCC_ID << 32 | HW_ID of the LAST proposal launch
+#define WGP_IN() do { if (threadIdx.x == 0 && blockIdx.x < 4096) { g_wgp[blockIdx.x][0] = wall_clock64(); \
+  g_wgp[blockIdx.x][2] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned int)__builtin_amdgcn_s_getreg(63492); } } while (0)
+#define WGP_OUT() do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_wgp[blockIdx.x][1] = wall_clock64(); } while (0)
+#else
+#define TRACE_P(i)
+#define WGP_IN()
+#define WGP_OUT()
+#endif
+// GridMapper::likelihoodFieldModel for ONE pose, evaluated by one wave (lanes stride the valid beams).
+// beams[b] = (r*cos a_b, r*sin a_b) in the sensor frame, built on the host exactly as
+// sensor_model.cpp:73-108 does.  Returns the product in every lane; *oob is set if a beam leaves
+// the world (the reference throws from world2RowMajor).
+template <class Word> __device__ __forceinline__ int row_nearest_f(Word word, int words, int j, int cap);
+__device__ __forceinline__ int row_nearest(const unsigned long long* row, int words, int j, int cap);
+
+// Where a lookup gets its distance code from.
+//  field  : the particle's u16 field is authoritative (injected, or whole-field fresh) -> read it
+//  window : the field was refreshed inside `win` for this call -> read it, report a lookup outside the window
+//  query  : no field refresh at all — the squared distance to the nearest occupied cell is computed from the
+//           occupancy bitmap at the looked-up cell: rows i, i+-1, i+-2, ... each contribute (dr^2 + nearest set
+//           bit in that row)^2 and the walk stops once dr^2 >= best.  A beam ends on or next to a wall, so this
+//           is a handful of rows; the result is the exact transform's value (same integer arithmetic), and a
+//           cell with no obstacle within cell_radius keeps its stored code, like the transform.
+struct DistSrc {
+  const uint16_t* code;             // [G] of the particle; NULL when the handle keeps no stored field (query mode only)
+  OccT occ;                         // the particle's occupancy bits (tiled)
+  int4 win;
+  int mode;                         // 0 field, 1 window, 2 query
+  // query mode, optional: the part of the bitmap round the particle held in LDS (rows R0..R1, 64-cell word
+  // columns W0..W0+nW-1; any[r] = row r has a set bit inside those columns).  nW == 0: no tile.
+  const unsigned long long* tbm;
+  const int* tany;
+  int R0, R1, W0, nW;
+  // optional, with the LDS tile: lut7[m] = least (c - 3)^2 over the set bits c of the 7-bit pattern m (100: none) — lets a
+  // lookup read the 7 x 7 cells round it as seven table look-ups instead of seven 64-column bit scans
+  const unsigned char* lut7;
+};
+// Walk rows i, i+-1, i+-2, ... of an occupancy bitmap (stride `words` u64 per row, rows row_lo..row_hi present,
+// cell columns [0, words*64) relative to the bitmap) and return the least squared distance found (INT_MAX: none
+// within `radius`).  row_any(r) says whether row r can hold a set bit.
+template <class RowWord, class RowAny>
+__device__ __forceinline__ int nearest_d2_rows(RowWord row_word, int words, int row_lo, int row_hi, int radius,
+                                               int ci, int cj, RowAny row_any) {
+  int best = 0x7fffffff;
+  for (int dr = 0; dr <= radius; ++dr) {
+    if (dr * dr >= best) break;
+    if (ci + dr > row_hi && ci - dr < row_lo) break;
+    for (int sg = 0; sg < (dr ? 2 : 1); ++sg) {
+      const int r = sg ? ci - dr : ci + dr;
+      if (r < row_lo || r > row_hi || !row_any(r)) continue;
+      int cap = radius;
+      if (best != 0x7fffffff) { cap = (int)sqrtf((float)(best - dr * dr)) + 1; cap = cap < radius ? cap : radius; }
+      const int f = row_nearest_f([&](int w) { return row_word(r, w); }, words, cj, cap);
+      if (f != 255) { const int cand = dr * dr + f * f; best = cand < best ? cand : best; }
+    }
+  }
+  return best;
+}
+// The whole search.  Inlined by the scan matcher (~100 poses x Bv lookups per particle, many of them beyond the 7 x 7 look);
+// the proposal kernel inlines a lookup at four places, and with both row walks in each of them it was ~100 KB of code against
+// a 64 KB instruction cache shared by two CUs: there only the 7 x 7 look on the LDS tile is inline (it decides nearly
+// every lookup of a beam that ends on or next to a wall) and the rest is ONE out-of-line copy.
+__device__ __forceinline__ uint16_t nearest_code_query_body(const GridC& g, const DistSrc& d, int radius, int ci, int cj);
+__device__ __attribute__((noinline)) uint16_t nearest_code_query_full(const GridC g, const DistSrc d, int radius, int ci, int cj) {
+  return nearest_code_query_body(g, d, radius, ci, cj);
+}
+template <bool OUTLINE = true>
+__device__ __forceinline__ uint16_t nearest_code_query(const GridC& g, const DistSrc& d, int radius, int ci, int cj) {
+  if constexpr (!OUTLINE) return nearest_code_query_body(g, d, radius, ci, cj);
+  if (d.nW > 0 && d.lut7) {
+    const int C0 = d.W0 * 64, C1 = (d.W0 + d.nW) * 64 - 1;
+    const int p0 = cj - C0 - 3, wi = p0 >> 5;
+    if (ci - 3 >= d.R0 && ci + 3 <= d.R1 && p0 >= 0 && wi + 1 < 2 * d.nW && cj <= C1) {
+      int clear = radius + 1;
+      if (d.R0 > 0) clear = min(clear, ci - d.R0 + 1);
+      if (d.R1 < g.xsize - 1) clear = min(clear, d.R1 - ci + 1);
+      if (C0 > 0) clear = min(clear, cj - C0 + 1);
+      if (C1 < g.ysize - 1) clear = min(clear, C1 - cj + 1);
+      const unsigned int* t32 = reinterpret_cast<const unsigned int*>(d.tbm) + wi;
+      const int sh = p0 & 31, stride = 2 * d.nW;
+      int bw = 0x7fffffff;
+#pragma unroll
+      for (int dr = -3; dr <= 3; ++dr) {
+        const unsigned int* rp = t32 + (ci + dr - d.R0) * stride;
+        const unsigned int pat = __builtin_amdgcn_alignbit(rp[1], rp[0], sh) & 0x7Fu;
+        bw = min(bw, dr * dr + (int)d.lut7[pat]);
+      }
+      if (bw <= 9 && bw <= clear * clear) return (uint16_t)bw;
+    }
+  }
+  return nearest_code_query_full(g, d, radius, ci, cj);
+}
+__device__ __forceinline__ uint16_t nearest_code_query_body(const GridC& g, const DistSrc& d, int radius, int ci, int cj) {
+  if (d.nW > 0) {
+    // LDS tile first.  Its answer is the map's answer when no cell outside the tile can be nearer: a side of the
+    // tile that is not the map's own border is (distance to that side + 1) cells away at least.
+    const int C0 = d.W0 * 64, C1 = (d.W0 + d.nW) * 64 - 1;
+    if (ci >= d.R0 && ci <= d.R1 && cj >= C0 && cj <= C1) {
+      int clear = radius + 1;  // nothing beyond the radius matters
+      if (d.R0 > 0) clear = min(clear, ci - d.R0 + 1);
+      if (d.R1 < g.xsize - 1) clear = min(clear, d.R1 - ci + 1);
+      if (C0 > 0) clear = min(clear, cj - C0 + 1);
+      if (C1 < g.ysize - 1) clear = min(clear, C1 - cj + 1);
+      bool looked7 = false;
+      {
+        // A beam ends on or next to a wall: the 7 x 7 cells round the looked-up cell first.  Every cell outside them is
+        // >= 4 cells away, so a result <= 9 (and <= clear^2) is the map's answer.  Row by row: the seven bits round the
+        // column (one v_alignbit on two adjacent dwords of the LDS tile) index a 128-entry table of least column offsets.
+        const int p0 = cj - C0 - 3, wi = p0 >> 5;
+        if (d.lut7 && ci - 3 >= d.R0 && ci + 3 <= d.R1 && p0 >= 0 && wi + 1 < 2 * d.nW) {
+          const unsigned int* t32 = reinterpret_cast<const unsigned int*>(d.tbm) + wi;
+          const int sh = p0 & 31, stride = 2 * d.nW;
+          int bw = 0x7fffffff;
+#pragma unroll
+          for (int dr = -3; dr <= 3; ++dr) {
+            const unsigned int* rp = t32 + (ci + dr - d.R0) * stride;
+            const unsigned int pat = __builtin_amdgcn_alignbit(rp[1], rp[0], sh) & 0x7Fu;
+            bw = min(bw, dr * dr + (int)d.lut7[pat]);
+          }
+          if (bw <= 9 && bw <= clear * clear) return (uint16_t)bw;
+          looked7 = true;
+        }
+      }
+      if (!looked7) {
+        // (no table, or the 7 x 7 window sticks out of the tile) the same 7 rows, 64 columns each, by bit scans, branch-free
+        const int cjr = cj - C0, s0 = cjr - 32, w = s0 >> 6, sh = s0 & 63;
+        int bw = 0x7fffffff;
+#pragma unroll
+        for (int dr = -3; dr <= 3; ++dr) {
+          const int r = ci + dr;
+          if (r < d.R0 || r > d.R1) continue;
+          const unsigned long long* row = d.tbm + (size_t)(r - d.R0) * d.nW;
+          const unsigned long long lo64 = (w >= 0 && w < d.nW) ? row[w] : 0ull, hi64 = (w + 1 >= 0 && w + 1 < d.nW) ? row[w + 1] : 0ull;
+          const unsigned long long W = sh ? ((lo64 >> sh) | (hi64 << (64 - sh))) : lo64;  // bit i = column s0 + i, the cell at bit 32
+          const unsigned long long L = W & 0x1FFFFFFFFull, Rr = W >> 33;
+          int f = 1 << 12;
+          if (L) f = __clzll((long long)L) - 31;
+          if (Rr) f = min(f, __ffsll((long long)Rr));
+          bw = min(bw, dr * dr + f * f);
+        }
+        if (bw <= 9 && bw <= clear * clear) return (uint16_t)bw;
+      }
+      const int* any = d.tany;
+      const int R0 = d.R0;
+      const unsigned long long* tbm = d.tbm;
+      const int nW = d.nW;
+      const int best = nearest_d2_rows([tbm, nW, R0](int r, int w) { return tbm[(size_t)(r - R0) * nW + w]; }, d.nW, d.R0, d.R1, radius, ci, cj - C0,
+                                       [any, R0](int r) { return any[r - R0] != 0; });
+      if (best != 0x7fffffff && best <= clear * clear && best <= radius * radius) return (uint16_t)best;
+      if (best == 0x7fffffff && clear > radius) return d.code ? d.code[(size_t)ci * g.xsize + cj] : kCodeUnreached;
+    }
+  }
+  const OccT occ = d.occ;
+  const int best = nearest_d2_rows([&occ](int r, int w) { return occ.word(r, w); }, g.words, 0, g.xsize - 1, radius, ci, cj,
+                                   [&occ](int r) { return occ.row_any(r); });
+  // nothing within cell_radius_: the stored code if the handle keeps a stored field (injected / materialised), else
+  // "never reached" (the reference keeps whatever an earlier brushfire left there, grid_mapper.cpp:310-313)
+  return (best <= radius * radius) ? (uint16_t)best : (d.code ? d.code[(size_t)ci * g.xsize + cj] : kCodeUnreached);
+}
+// Distance code of cell (ci, cj), or -1 when a windowed lookup falls outside the refreshed window.
+template <bool OUTLINE = true>
+__device__ __forceinline__ int lookup_code(const GridC& g, const DistSrc& d, int radius, int ci, int cj) {
+  if (d.mode == 2) return nearest_code_query<OUTLINE>(g, d, radius, ci, cj);
+  if (d.mode == 1 && (ci < d.win.x || ci > d.win.y || cj < d.win.z || cj > d.win.w)) return -1;
+  return d.code[(size_t)ci * g.xsize + cj];
+}
+
+// Mixture term of one beam as a function of the distance code it lands on (grid_mapper.cpp:119-121).
+__device__ __forceinline__ double beam_mixture(const ScanC& c, uint16_t code) {
+  const double z = code_to_dist(c.g, code);
+  double pz = 0.0;
+  pz += c.z_hit * (c.sqrt_inv_hit * exp(-0.5 * (z * z) / c.var_hit));
+  pz += c.rand_term;
+  return pz;
+}
+
+// ctag/ccell/cpz (nullable): per-beam cache filled once per particle for the centre of its k samples — the
+// samples lie within ~1e-4 m of it, so nearly every (sample, beam) lands on the same cell (no lookup at all) or at
+// least the same code, and takes its mixture term from LDS instead of re-evaluating sqrt + exp.  Read-only here;
+// a miss computes the term afresh.
+// Tms = T(pose) * Trs  (rigid2d.cpp:214-224) as (X, Y, sin, cos); Trs.theta == 0 (the shipped robot) needs one sincos
+__device__ __forceinline__ void sensor_transform(const ScanC& c, double th, double x, double y, double out[4]) {
+  double s0, c0;
+  sincos(th, &s0, &c0);
+  out[0] = c0 * c.Trs[1] - s0 * c.Trs[2] + x;
+  out[1] = s0 * c.Trs[1] + c0 * c.Trs[2] + y;
+  if (c.Trs[0] == 0.0) { out[2] = s0; out[3] = c0; }  // th + 0.0 == th: same bits
+  else sincos(th + c.Trs[0], &out[2], &out[3]);
+}
+// Mixture term of one beam seen from one sensor pose (grid_mapper.cpp:100-121).  (cc, tg, pzc) is the beam's cache
+// entry — cell / code / term at the centre of the particle's samples (0xFFFFFFFF: none): the samples lie within
+// ~1e-4 m of the centre, so nearly every (sample, beam) lands on the same cell (no lookup at all) or at least the
+// same code, and takes its term from the cache instead of re-evaluating sqrt + exp.  A beam that leaves the world
+// sets *oob (the reference throws from world2RowMajor) and contributes 1.
+// The mixture term depends on the distance code and on constants fixed at create (z_hit, sigma_hit, z_rand / z_max,
+// resolution, max_occ_dist): the handle tabulates it ONCE for the codes below kMixLut (rbpf_mix_lut, same device code
+// as beam_mixture -> same bits) and the kernels read the table — its first kMixLds entries from LDS, the rest from
+// global memory — instead of a square root, a division and an exponential per beam.
+struct MixLut { const double* lds; const double* glob; };  // either may be NULL
+__device__ __forceinline__ double mix_term(const ScanC& c, const MixLut& L, int cd) {
+  if (L.lds && cd < kMixLds) return L.lds[cd];
+  if (L.glob && cd < kMixLut) return L.glob[cd];
+  return beam_mixture(c, (uint16_t)cd);
+}
+__device__ __forceinline__ double beam_factor(const ScanC& c, const DistSrc& ds, int radius, const double2 pt, double X, double Y,
+                                              double st, double ct, unsigned int cc, unsigned int tg, double pzc, int* oob,
+                                              const MixLut& L = MixLut{nullptr, nullptr}) {
+  const double ex = ct * pt.x - st * pt.y + X;
+  const double ey = st * pt.x + ct * pt.y + Y;
+  int ci, cj;
+  if (!world2cell(c.g, ex, ey, ci, cj)) { *oob |= 1; return 1.0; }
+  if (cc == (unsigned int)(ci * c.g.xsize + cj)) return pzc;  // same cell -> same code -> same term
+  // (window mode: the window is sized so that a miss cannot happen — if it ever does it is reported, never read stale)
+  const int cd = lookup_code(c.g, ds, radius, ci, cj);
+  if (cd < 0) { *oob |= 2; return 1.0; }
+  return (tg == (unsigned int)cd) ? pzc : mix_term(c, L, cd);
+}
+// GridMapper::likelihoodFieldModel for ONE pose, evaluated by one wave (lanes stride the valid beams).
+__device__ __forceinline__ double wave_scan_likelihood_t(const ScanC& c, const double2* __restrict__ beams,
+                                                         const DistSrc& ds, int radius, int n_occ,
+                                                         double X, double Y, double st, double ct, int lane, int* oob,
+                                                         const MixLut& L = MixLut{nullptr, nullptr}) {
+  if (n_occ == 0) return 1.0;  // grid_mapper.cpp:94-98
+  double p = 1.0;
+  for (int b = lane; b < c.Bv; b += kWave) p *= beam_factor(c, ds, radius, beams[b], X, Y, st, ct, 0xFFFFFFFFu, 0xFFFFFFFFu, 0.0, oob, L);
+  return wave_prod(p);
+}
+__device__ __forceinline__ double wave_scan_likelihood(const ScanC& c, const double2* __restrict__ beams,
+                                                       const DistSrc& ds, int radius, int n_occ,
+                                                       double th, double x, double y, int lane, int* oob,
+                                                       const MixLut& L = MixLut{nullptr, nullptr}) {
+  if (n_occ == 0) return 1.0;
+  double T[4];
+  sensor_transform(c, th, x, y, T);
+  return wave_scan_likelihood_t(c, beams, ds, radius, n_occ, T[0], T[1], T[2], T[3], lane, oob, L);
+}
+
+// particle_filter.cpp:383-437 (odometry part precomputed on the host: rot1, trans, rot2)
+// nrot1 / nrot2: normalize_angle_PI(c.rot1) / (c.rot2), particle- and sample-independent (the caller keeps them in scalar registers)
+__device__ __forceinline__ double pose_likelihood_odom(const ScanC& c, const double* cur, const double* prev, int* var_err, double nrot1, double nrot2) {
+  const double rot1_hat = atan2(cur[2] - prev[2], cur[1] - prev[1]) - prev[0];
+  const double dx = cur[1] - prev[1], dy = cur[2] - prev[2];
+  const double trans_hat = sqrt(dx * dx + dy * dy);
+  const double rot2_hat = normalize_angle_PI(normalize_angle_PI(cur[0]) - normalize_angle_PI(prev[0]) - rot1_hat);
+  const double temp1 = c.a1 * rot1_hat * rot1_hat + c.a2 * trans_hat * trans_hat;
+  const double temp2 = c.a3 * trans_hat * trans_hat + c.a4 * rot1_hat * rot1_hat + c.a4 * rot2_hat * rot2_hat;
+  const double temp3 = c.a1 * rot2_hat * rot2_hat + c.a2 * trans_hat * trans_hat;
+  if (almost_equal(temp1, 0.0) || almost_equal(temp2, 0.0) || almost_equal(temp3, 0.0)) { *var_err = 1; return 0.0; }
+  const double p1 = pdf_normal(normalize_angle_PI(nrot1 - normalize_angle_PI(rot1_hat)), temp1);
+  const double p2 = pdf_normal(c.trans - trans_hat, temp2);
+  const double p3 = pdf_normal(normalize_angle_PI(nrot2 - normalize_angle_PI(rot2_hat)), temp3);
+  return p1 * p2 * p3;
+}
+
+// Eigen 3.3 unblocked lower LLT of a 3x3 (stops at a non-positive pivot, like llt_inplace)
+__device__ inline void llt3(const double A[3][3], double L[3][3]) {
+  double M[3][3];
+  for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) M[r][q] = A[r][q];
+  for (int kk = 0; kk < 3; ++kk) {
+    double x = M[kk][kk];
+    if (kk > 0) { double sq = 0.0; for (int q = 0; q < kk; ++q) sq += M[kk][q] * M[kk][q]; x -= sq; }
+    if (x <= 0.0) break;
+    x = sqrt(x);
+    M[kk][kk] = x;
+    for (int r = kk + 1; r < 3; ++r) {
+      if (kk > 0) { double dot = 0.0; for (int q = 0; q < kk; ++q) dot += M[r][q] * M[kk][q]; M[r][kk] -= dot; }
+      M[r][kk] /= x;
+    }
+  }
+  for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) L[r][q] = (q <= r) ? M[r][q] : 0.0;
+}
+
+// ---- production noise source: standard normals drawn on the device (normals == NULL) --------------------
+// Philox4x32-10 keyed by the handle's seed, counter = scan_index * 2^40 + pair index; each counter value
+// yields one Box-Muller pair.  Replaces the host's mt19937_64 draws (particle_filter.cpp:25-34) when
+// reproducibility against the CPU path is not needed; same layout as the host stream.
+__device__ __forceinline__ void philox4x32_10(unsigned long long ctr, unsigned long long key, unsigned int (&out)[4]) {
+  unsigned int c0 = (unsigned int)ctr, c1 = (unsigned int)(ctr >> 32), c2 = 0u, c3 = 0u;
+  unsigned int k0 = (unsigned int)key, k1 = (unsigned int)(key >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned int)p1;
+    const unsigned int n2 = (unsigned int)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned int)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+
+
+
+
+
+// ---- per-particle scan matcher (SURVEY.md 8-f N1 — an OPTION, not the reference) -----------------------------
+// The reference matches scan to scan ONCE per call with PCL ICP (cloud_alignment.cpp:37-223) and every particle
+// samples round T(pose) * T_icp (particle_filter.cpp:146-153,181-188).  With scan matching on, each particle
+// refines that pose against ITS OWN map before sampling, gmapping-style: hill climbing on the likelihood field
+// (GridMapper::likelihoodFieldModel, grid_mapper.cpp:69-133 — the reference's own scoring function).  From the
+// current pose evaluate the six neighbours +x, -x, +y, -y, +theta, -theta (world frame); move to the best of them if it
+// is better by a factor > 1 + 1e-9 (the likelihood only sees cells, so neighbouring poses often carry the same
+// factors on different beams: a bare > would follow rounding noise); otherwise halve both steps; stop after
+// `iters` halvings (or max_moves rounds).
+// Workgroup = particle, 6 waves: wave m scores neighbour m (lanes over the beams, lookups on the LDS slice of the
+// bitmap), thread 0 applies the rule.  Same rule, same order of comparisons as oracle/rbpf_oracle.cpp::scan_match.
+
+// The 7 x 7 look of the query mode (or a read of the stored field) and nothing else: the code (>= 0), -1 = a windowed lookup
+// outside the refreshed window, kNeedSearch = the query mode's answer needs the row walks (nearest_code_query_body).  The
+// proposal kernel defers those to a phase of their own — ONE inlined copy of the search per phase, run by all threads over the
+// marked entries — instead of calling an out-of-line copy from inside its lookup loops (round 3: seven call sites, 224 B of
+// scratch per lane for the saves and restores round them).
+constexpr int kNeedSearch = -2;
+__device__ __forceinline__ int lookup_code_fast(const GridC& g, const DistSrc& d, int radius, int ci, int cj) {
+  if (d.mode == 2) {
+    if (d.nW > 0 && d.lut7) {
+      const int C0 = d.W0 * 64, C1 = (d.W0 + d.nW) * 64 - 1;
+      const int p0 = cj - C0 - 3, wi = p0 >> 5;
+      if (ci - 3 >= d.R0 && ci + 3 <= d.R1 && p0 >= 0 && wi + 1 < 2 * d.nW && cj <= C1) {
+        int clear = radius + 1;
+        if (d.R0 > 0) clear = min(clear, ci - d.R0 + 1);
+        if (d.R1 < g.xsize - 1) clear = min(clear, d.R1 - ci + 1);
+        if (C0 > 0) clear = min(clear, cj - C0 + 1);
+        if (C1 < g.ysize - 1) clear = min(clear, C1 - cj + 1);
+        const unsigned int* t32 = reinterpret_cast<const unsigned int*>(d.tbm) + wi;
+        const int sh = p0 & 31, stride = 2 * d.nW;
+        int bw = 0x7fffffff;
+#pragma unroll
+        for (int dr = -3; dr <= 3; ++dr) {
+          const unsigned int* rp = t32 + (ci + dr - d.R0) * stride;
+          const unsigned int pat = __builtin_amdgcn_alignbit(rp[1], rp[0], sh) & 0x7Fu;
+          bw = min(bw, dr * dr + (int)d.lut7[pat]);
+        }
+        if (bw <= 9 && bw <= clear * clear) return bw;
+      }
+    }
+    return kNeedSearch;
+  }
+  if (d.mode == 1 && (ci < d.win.x || ci > d.win.y || cj < d.win.z || cj > d.win.w)) return -1;
+  return d.code[(size_t)ci * g.xsize + cj];
+}
+
+
 __global__ void rbpf_mix_lut(ScanC c, double* __restrict__ out) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q < kMixLut) out[q] = beam_mixture(c, (uint16_t)q);

@@ -3,9 +3,249 @@
 // weights' normalise / selection riding along as workgroup 0) and the beam-ordered rbpf_raycast (scans the box kernel cannot
 // hold; the reference-field mode, whose occupied-set log it writes).  Bit-identical maps.
 #include "rbpf_device.hpp"
+#include "rbpf_normalize.hpp"
 
 namespace tbnav_rk {
 
+// ---- raycast ---------------------------------------------------------------------------------------
+// n-th free cell of the ray robot(x0,y0) -> endpoint(x1,y1), grid_mapper.cpp:549-807, in closed form:
+// Bresenham's error recurrence D > 0 <=> c_t < (2*dmin*t - dmaj)/(2*dmaj) gives the minor-axis offset
+// after t major steps  c_t = max(0, ceil((2*dmin*t - dmaj) / (2*dmaj)))  (checked against the
+// reference's loops for every octant in tests).  Reversed octants start from the endpoint side.
+struct Ray {
+  int kind, count;   // 0 vertical, 1 horizontal, 2 low, 3 high, 4 diagonal
+  int x0, y0, xa, ya, dmaj, dmin, sgn, sx, sy;
+};
+__device__ __forceinline__ Ray make_ray(int x0, int y0, int x1, int y1) {
+  Ray r;
+  r.x0 = x0; r.y0 = y0; r.xa = x0; r.ya = y0; r.dmaj = 0; r.dmin = 0; r.sgn = 1; r.sx = 1; r.sy = 1;
+  const int dx = x1 - x0, dy = y1 - y0;
+  const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
+  if (dx == 0) { r.kind = 0; r.count = ady; r.sy = dy < 0 ? -1 : 1; }
+  else if (dy == 0) { r.kind = 1; r.count = adx; r.sx = dx < 0 ? -1 : 1; }
+  else if (ady < adx) {
+    r.kind = 2; r.count = adx;
+    int xb, yb;
+    if (x0 > x1) { r.xa = x1; r.ya = y1; xb = x0; yb = y0; } else { xb = x1; yb = y1; }
+    r.dmaj = xb - r.xa;
+    const int d = yb - r.ya;
+    r.sgn = d < 0 ? -1 : 1;
+    r.dmin = d < 0 ? -d : d;
+  } else if (ady > adx) {
+    r.kind = 3; r.count = ady;
+    int xb, yb;
+    if (y0 > y1) { r.xa = x1; r.ya = y1; xb = x0; yb = y0; } else { xb = x1; yb = y1; }
+    r.dmaj = yb - r.ya;
+    const int d = xb - r.xa;
+    r.sgn = d < 0 ? -1 : 1;
+    r.dmin = d < 0 ? -d : d;
+  } else { r.kind = 4; r.count = adx; r.sx = dx < 0 ? -1 : 1; r.sy = dy < 0 ? -1 : 1; }
+  return r;
+}
+__device__ __forceinline__ void ray_cell(const Ray& r, int n, int& cx, int& cy) {
+  switch (r.kind) {
+    case 0: cx = r.x0; cy = r.y0 + r.sy * n; break;
+    case 1: cx = r.x0 + r.sx * n; cy = r.y0; break;
+    case 4: cx = r.x0 + r.sx * n; cy = r.y0 + r.sy * n; break;
+    default: {
+      if (n == 0) { cx = r.x0; cy = r.y0; break; }
+      const int a = 2 * r.dmin * n - r.dmaj;
+      const int ct = a > 0 ? floor_div_small(a + 2 * r.dmaj - 1, 2 * r.dmaj) : 0;  // operands < 2^24
+      if (r.kind == 2) { cx = r.xa + n; cy = r.ya + r.sgn * ct; }
+      else { cx = r.xa + r.sgn * ct; cy = r.ya + n; }
+    }
+  }
+}
+
+// One wave per particle.  Beams are applied IN ORDER (the per-cell floating-point add order is the
+// reference's); the cells of one ray are distinct, so the lanes of the wave update them in parallel
+// without atomics.  Endpoints are staged in LDS first.
+// The occupancy bits (one u32 per tile row, copy-on-write with the tile) / per-tile-row counts / occupied count of
+// the particle are kept up to date here: a log-odds add that crosses the occupied cut-off toggles the cell's bit
+// (rare: a few hundred cells per scan), so no pass over the whole map is needed to find the nearest-obstacle
+// query's rows.
+__device__ __forceinline__ bool add_log_odds(const TilePool& P, unsigned int id, double d, double cut, int cx, int cy,
+                                             int* __restrict__ trow, int* __restrict__ nocc) {
+  double* cell = P.lo + (size_t)id * kTileCells + in_tile(cx, cy);
+  const double old = *cell;
+  const double nw = old + d;
+  *cell = nw;
+  const bool was = old >= cut, now = nw >= cut;
+  if (was != now) {
+    atomicXor(&P.bm[(size_t)id * kTS + (cx & (kTS - 1))], 1u << (cy & (kTS - 1)));
+    const int delta = now ? 1 : -1;
+    atomicAdd(&trow[cx >> kTSh], delta);
+    atomicAdd(nocc, delta);
+  }
+  return was != now;
+}
+
+// Ordered log of the occupied-set changes of one scan, per particle (reference distance-field mode only): entry =
+// cell index, bit 31 set = the cell LEFT the set.  Same order as the reference's occ_cells_ insert / erase calls
+// (grid_mapper.cpp:153-177 -> updateCellState/updateCellHash :438-546): beam by beam, the ray's free cells in
+// free_index order, then the end point.  ev == NULL: no log.
+
+
+// Is map cell (cx, cy) one of the FREE cells of ray r (i.e. some n in [0, count) has ray_cell(r, n) == it)?
+__device__ __forceinline__ bool on_ray(const Ray& r, int cx, int cy) {
+  switch (r.kind) {
+    case 0: { const int n = (cy - r.y0) * r.sy; return cx == r.x0 && n >= 0 && n < r.count; }
+    case 1: { const int n = (cx - r.x0) * r.sx; return cy == r.y0 && n >= 0 && n < r.count; }
+    case 4: { const int n = (cx - r.x0) * r.sx; return n >= 0 && n < r.count && cy == r.y0 + r.sy * n; }
+    default: {
+      if (cx == r.x0 && cy == r.y0) return r.count > 0;
+      const int n = (r.kind == 2) ? cx - r.xa : cy - r.ya;      // steps along the major axis
+      if (n < 1 || n > r.dmaj - 1) return false;
+      const int t = ((r.kind == 2) ? cy - r.ya : cx - r.xa) * r.sgn;  // offset along the minor axis
+      // ray_cell gives offset c = max(0, ceil(a / (2*dmaj))) with a = 2*dmin*n - dmaj; test t == c without dividing
+      const int a = 2 * r.dmin * n - r.dmaj, d2 = 2 * r.dmaj;
+      return (a <= 0) ? (t == 0) : (t >= 1 && d2 * (t - 1) < a && a <= d2 * t);
+    }
+  }
+}
+
+// Tile version of the raycast (the default): no per-beam barrier.
+//  F. every distinct END-POINT cell (<= Bv of them; the only cells that see both kinds of update in one scan,
+//     and there the floating-point add order matters) is flagged in an LDS tile covering the scan's bounding
+//     box (<= (2*range_max/res + 3)^2 cells) and gets a slot: a short list of (beam, kind) events;
+//  1. every (beam, step) pair looks at its cell in the tile: a plain cell bumps its 15-bit counter (order-free
+//     LDS atomic), a flagged cell records the event "beam b, free" in the cell's slot; every beam also records
+//     "beam b, occupied" in its own end point's slot;
+//  2. one LANE per end-point cell replays its slot in beam order ("+= l_free" / "+= l_occ": exactly the
+//     reference's sequence of adds for that cell).  A slot that overflowed (kEvCap events; e.g. the robot's
+//     own cell) is replayed by a whole wave instead, which tests the cell against every beam;
+//  3. every other touched cell gets its count of "+= l_free" (same addend each time, so the order among
+//     them is immaterial) — bit-identical to the beam-ordered loop, checked against it and the oracle.
+// LDS (ints): ex ey own rk rxy rdd ecnt [Bv each] | ev u16[Bv][kEvCap] | tile u32[(cap+1)/2] (two 16-bit
+// halves per word: bit 15 = end-point flag, low 15 bits = free-add count, or the slot index when flagged).
+// The same reductions without LDS round trips: an inclusive scan inside each row of 16 lanes by DPP shifts, then the row
+// totals broadcast down the rows (row_bcast:15 / :31); lane 63 holds the result.  (__shfl_xor is ds_bpermute: six
+// dependent LDS-latency steps per reduction.)
+template <class Op> __device__ __forceinline__ int wave_reduce_dpp(int v, int ident, Op op) {
+  v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x111, 0xf, 0xf, false));  // row_shr:1
+  v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x112, 0xf, 0xf, false));  // row_shr:2
+  v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x114, 0xf, 0xf, false));  // row_shr:4
+  v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x118, 0xf, 0xf, false));  // row_shr:8
+  v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x142, 0xa, 0xf, false));  // row_bcast:15 into rows 1, 3
+  v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x143, 0xc, 0xf, false));  // row_bcast:31 into rows 2, 3
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_min_dpp(int v) { return wave_reduce_dpp(v, 0x7FFFFFFF, [](int a, int b) { return a < b ? a : b; }); }
+__device__ __forceinline__ int wave_max_dpp(int v) { return wave_reduce_dpp(v, (int)0x80000000, [](int a, int b) { return a > b ? a : b; }); }
+__device__ __forceinline__ int wave_sum_dpp(int v) { return wave_reduce_dpp(v, 0, [](int a, int b) { return a + b; }); }
+// ---- dense view of the occupancy bits -----------------------------------------------------------------------
+// The packed form of a ray straight from its two ends, selects only (what pack_ray(make_ray(..)) returns; the Ray struct's
+// case analysis turns into a private array the compiler indexes at run time).  Along the major axis the ray starts at
+// its LOW end (xa, ya) — the robot's cell or, for a reversed ray, the end point — takes dmaj steps and moves c_t =
+// max(0, ceil((2 dmin t - dmaj) / (2 dmaj))) cells sideways (negated if neg); its free cells are the robot's cell and
+// the cells strictly between the ends.
+// n times  x = fl(x + d)  — the updates one cell takes from n beams (grid_mapper.cpp:438-477 adds the same log-odds once per beam) —
+// bit for bit WITHOUT the chain of n dependent adds (13 ns each for one lane: the robot's own cell takes one per beam).  While x
+// stays in one binade it is m * u (u = ulp(x), m a 53-bit integer) and d = kd * ud with ud = u / 2^sh: x + d = (m + q) u + rem ud
+// (q = kd >> sh, rem = the bits shifted out), which rounds to (m + q) u or (m + q + 1) u by rem against half a u — the SAME integer
+// step s every time, so j steps are m + j s (exact in 64-bit integers) as long as m + j s < 2^53.  What does not fit the pattern is
+// done with a plain add: a step that leaves the binade (the sum is then rounded to the coarser grid), a tie (rem == u / 2: round to
+// even alternates), opposite signs, x within a factor 4 of d, zeros, subnormals, infinities and NaNs.  (chain_exact is the same idea
+// for a sum of different addends.)
+__device__ __forceinline__ double add_repeated(double x, const double d, int n) {
+  constexpr unsigned long long kMant = (1ull << 52) - 1ull;
+  const unsigned long long bd = (unsigned long long)__double_as_longlong(d);
+  const int ed = (int)((bd >> 52) & 0x7FFull);
+  const unsigned long long kd = (bd & kMant) | (1ull << 52);
+  while (n > 0) {
+    const unsigned long long bx = (unsigned long long)__double_as_longlong(x);
+    const int ex = (int)((bx >> 52) & 0x7FFull), sh = ex - ed;
+    if (n < 4 || ((bx ^ bd) >> 63) != 0ull || sh < 2 || ex == 0x7FF || ed == 0 || ed == 0x7FF) { x += d; --n; continue; }
+    if (sh > 54) return x;  // |d| < ulp(x) / 4: no add changes x
+    const unsigned long long rem = kd & ((1ull << sh) - 1ull), half = 1ull << (sh - 1);
+    if (rem == half) { x += d; --n; continue; }
+    const unsigned long long s = (kd >> sh) + (rem > half ? 1ull : 0ull);
+    if (s == 0ull) return x;  // d is less than half an ulp of x: no add changes it
+    const unsigned long long m = (bx & kMant) | (1ull << 52);
+    const unsigned long long room = (1ull << 53) - 1ull - m;  // the steps that stay in the binade: m + j s <= 2^53 - 1
+    unsigned long long j = (unsigned long long)n;
+    if (__umul64hi(j, s) != 0ull || j * s > room) {
+      j = (unsigned long long)((double)room / (double)s);     // both exact in fp64 and the division is correctly rounded: floor or floor + 1
+      if (j * s > room) --j;
+    }
+    const unsigned long long mj = m + j * s;
+    x = __longlong_as_double((long long)((bx & (1ull << 63)) | ((unsigned long long)ex << 52) | (mj & kMant)));
+    n -= (int)j;
+    if (n > 0) { x += d; --n; }  // the step across the binade's end
+  }
+  return x;
+}
+struct RayP { int xa, ya, dmaj, dmin; bool ymajor, neg; };
+__device__ __forceinline__ RayP ray_packed(int x0, int y0, int x1, int y1) {
+  const int dx = x1 - x0, dy = y1 - y0, adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
+  RayP r;
+  r.ymajor = ady > adx;
+  const bool rev = r.ymajor ? (y0 > y1) : (x0 > x1);
+  r.xa = rev ? x1 : x0; r.ya = rev ? y1 : y0;
+  const int d = r.ymajor ? (rev ? x0 : x1) - r.xa : (rev ? y0 : y1) - r.ya;
+  r.neg = d < 0;
+  r.dmaj = r.ymajor ? ady : adx; r.dmin = r.ymajor ? adx : ady;
+  return r;
+}
+// Is (cx, cy) a free cell of the ray (x0, y0) -> (x1, y1)?  Same set as on_ray(make_ray(..)).
+__device__ __forceinline__ bool on_ray_packed(int x0, int y0, int x1, int y1, int cx, int cy) {
+  const RayP r = ray_packed(x0, y0, x1, y1);
+  if (r.dmaj == 0) return false;  // the beam ends in the robot's cell: no free cell
+  if (cx == x0 && cy == y0) return true;
+  const int n = r.ymajor ? cy - r.ya : cx - r.xa;  // steps along the major axis
+  const int tm = r.ymajor ? cx - r.xa : cy - r.ya, t = r.neg ? -tm : tm;  // offset along the minor axis, in the ray's sense
+  const int a = 2 * r.dmin * n - r.dmaj, d2 = 2 * r.dmaj;
+  const bool side = (a <= 0) ? (t == 0) : (t >= 1 && d2 * (t - 1) < a && a <= d2 * t);
+  return n >= 1 && n <= r.dmaj - 1 && side;
+}
+
+// ---- the default map update: box counters ------------------------------------------------------------------------
+// Same contract as rbpf_raycast_tile (bit-identical maps) with fewer, cheaper phases:
+//  F. the beams' end-point cells — the only cells that see both l_free and l_occ in one scan, i.e. where the floating-
+//     point add order matters — are flagged in an LDS array with one 32-bit word per cell of the scan's bounding box
+//     (bit 31; bits 16-30 = the cell's slot in the list of distinct end-point cells);
+//  1. every ray segment walks its cells with ONE returning LDS add per cell (low 16 bits = free adds) and never waits
+//     for it: the value that comes back is looked at one step later, and only if it carries the flag does the lane
+//     record "beam b, free" in that cell's slot (a few percent of the steps); every beam records "beam b, occupied" in
+//     its own end point's slot;
+//  2. one pass over the box, a PAIR of cells (16 bytes of a map tile's row) per lane and consecutive pairs in consecutive
+//     lanes — whole cache lines per wave: a counted or flagged pair marks its map tile as written and requests its log-odds
+//     from whichever tile the particle's table names now (shared, private or the zero tile hold the same values); the
+//     written tiles are then made private to the particle (usually they already are) while the loads are in flight;
+//  3. one lane per end-point cell replays its slot in beam order — bit (beam - own beam + 32) of a 64-bit mask per kind
+//     orders the events without sorting; an overflowed slot: a whole wave tests the cell against every beam — and the
+//     cells round the robot, tens to hundreds of DEPENDENT adds each because every ray starts there, get a lane of their
+//     own in the last wave, which walks no ray (the robot's own cell, one add per beam, is started right after the end
+//     points are known and worked off in pieces between the barriers); both hand their result over through LDS;
+//  4. the pairs: a plain cell adds its count of l_free (same addend each time, so the order among the adds is
+//     immaterial), an end-point or hot cell takes the value worked out for it; the pair goes back as one 16-byte store.
+// The LDS array holds as many rows of the box as fit (tile_cap words: the host keeps a workgroup under half of the CU's
+// 160 KB so that two are resident); a box with more rows (a long-range scan seen from a rotated pose) is worked through in
+// bands of rows, every phase once per band with the rays clipped to the band.
+// What bounds it (per-wave trace): instruction issue — ~28 k wave-instructions per particle through
+// 16 waves on 4 SIMDs between 9 barriers; memory traffic is the distinct cells once each way.
+// LDS: tile u32[tile_cap] (rows padded to an even number of columns: pair i = words 2i, 2i+1) |
+// ev u16[Bv][kBoxEv] (slot o's first 8 bytes double as its replayed value) | hot-cell values f64[64] | exy i32[Bv] | ecnt u16[Bv]
+#ifdef TBNAV_PHASE_PROF
+static __device__ unsigned long long g_phase_w[16];
+#endif
+#if defined(TBNAV_PHASE_PROF) && !defined(TBNAV_TRACE_ONLY)
+#define PHASE_STAMP_W(i) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_phase_w[i], now_ - t_prev_); t_prev_ = now_; } } while (0)
+#else
+#define PHASE_STAMP_W(i)
+#endif
+#ifdef TBNAV_PHASE_PROF
+static __device__ unsigned long long g_trace[2][16][16];  // [which][wave][stamp] of TWO workgroups (blockIdx.x == 100: first round of residents; 900: second): 10 ns ticks
+#define TRACE_W(i) do { if ((blockIdx.x == 100 || blockIdx.x == 900) && (threadIdx.x & 63) == 0) g_trace[blockIdx.x == 900][threadIdx.x >> 6][i] = wall_clock64(); } while (0)
+static __device__ unsigned long long g_wg[4096][3];    // [workgroup] entry, exit (10 ns ticks), XCC_ID << 32 | HW_ID — of the LAST launch
+#define WG_IN() do { if (threadIdx.x == 0 && blockIdx.x < 4096) { g_wg[blockIdx.x][0] = wall_clock64(); \
+  g_wg[blockIdx.x][2] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned int)__builtin_amdgcn_s_getreg(63492); } } while (0)
+#define WG_OUT() do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_wg[blockIdx.x][1] = wall_clock64(); } while (0)
+#else
+#define WG_IN()
+#define WG_OUT()
+#define TRACE_W(i)
+#endif
 __global__ __launch_bounds__(kWave) void rbpf_raycast(ScanC c, TilePool P, MapT M, const double2* __restrict__ beams,
                                                      const double* __restrict__ pose, int* __restrict__ trow_occ,
                                                      int* __restrict__ n_occ, int* __restrict__ err, OccLog log,

@@ -2,6 +2,7 @@
 // kernel of its own, the resampling copies as tile-table copies + reference counts (:495), the tile pool, dense views of one
 // particle's map, and getRobotState / newMap on the device (:255-291, grid_mapper.cpp:185-226).
 #include "rbpf_device.hpp"
+#include "rbpf_normalize.hpp"
 
 namespace tbnav_rk {
 
