@@ -364,6 +364,32 @@ def rbpf_comm_worker(rank, world, n_local, k, heavy, device_noise):
     return {"resampled": resampled, "stats": stats}
 
 
+def rbpf_rank_failure_worker(rank, world, n_local, failing_rank):
+    """A failure only ONE rank sees — its tile pool runs dry in the map update of the second scan — must stop EVERY rank at that
+    scan with that status (the ranks agree on a status word per scan; round-3 advisor finding: a rank that left alone had its
+    peers wait in the next collective for ever).  Returns the status of every scan as this rank saw it, and how long it took."""
+    import time
+    comm = _ipc_comm()
+    from rtn_amd.rbpf import ParticleFilter, default_params
+    # the failing rank: room for the first scan's tiles of its particles (an 80 x 80 map is 3 x 3 tiles) but not for the second
+    # scan's clones after its tables were shared by a forced resample ... simpler and deterministic: a pool of ONE particle's tiles
+    pool = 8320 * 12 if rank == failing_rank else 0
+    a = ParticleFilter(default_params(N=n_local, k=6), pool_bytes=pool)
+    a.setParticles(w=np.full(n_local, 1.0 / (n_local * world)))
+    a.setSeed(7)
+    a.attachComm(comm)
+    steps, scans = rbpf_scenario(3)
+    out, t0 = [], time.perf_counter()
+    for s, (prev, cur, t_icp, u) in enumerate(steps):
+        st = a.SLAM(scans[s], u, cur, prev, True, t_icp, None, check=False)
+        out.append(int(st.status))
+        if st.status != 0:
+            break
+    waited = time.perf_counter() - t0
+    a.close(); comm.close()
+    return {"status": out, "waited": waited}
+
+
 def mppi_direct_fault_worker(rank, world, K_local, horizon):
     """The direct exchange with a fault injected on every rank (records never reach the peers; bound 0.3 s): a batch of ticks must
     come back with an error status in about one bound — not one bound per tick, not a hang — and the handle must work again, through

@@ -66,6 +66,20 @@ def test_rbpf_ranks_in_separate_processes_equal_the_unsharded_filter(gpu_pkg, wo
         assert out[r]["stats"] == out[0]["stats"]
 
 
+@pytest.mark.parametrize("world,failing_rank", [(2, 1), (3, 0)])
+def test_a_failure_on_one_rank_stops_every_rank_at_the_same_scan(gpu_pkg, world, failing_rank):
+    """One rank's tile pool is too small for its particles (TBNAV_ERR_POOL_EXHAUSTED in its map update); the others are fine.
+    Every rank must come back from THAT scan with THAT status — not hang in a collective, not run on alone (round-3 advisor
+    finding; tbnav_rbpf_attach_comm's per-scan status agreement)."""
+    from dist_workers import rbpf_rank_failure_worker, run_spawn
+    from rtn_amd import capi
+    out = run_spawn(rbpf_rank_failure_worker, world, 8, failing_rank)
+    seen = [tuple(out[r]["status"]) for r in range(world)]
+    assert all(s == seen[0] for s in seen), seen
+    assert seen[0][-1] == capi.ERR_POOL_EXHAUSTED and all(v == 0 for v in seen[0][:-1]), seen
+    assert all(out[r]["waited"] < 60.0 for r in range(world))
+
+
 def test_bench_two_ranks_on_one_gpu_through_the_library_communicator(gpu_pkg):
     """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, --steps 20 --warmup 5), with its one-GPU dev
     switch: the timed ticks, the synchronous-tick measurement and both multi-GPU legs go through tbnav_mppi_attach_comm /
