@@ -315,12 +315,15 @@ int tbnav_rbpf_particle_map(tbnav_rbpf* h, int32_t particle, int8_t* map);
  *                                quarter of a CU's LDS, FOUR — workgroups per CU instead of two; a box that outgrows the guess takes a second
  *                                band); 2 = as 1 but never the four-per-CU form (A-B runs); 0 = by the scan's longest beam in every direction.
  *                                TBNAV_RBPF_OPT_RAYCAST_THREADS 0 = 512 threads when three workgroups fit a CU's LDS, else 1024 (default).
+ * TBNAV_RBPF_OPT_RAYCAST_CELL16  rbpf_raycast_box's 16-bit cell form (half the LDS per cell of the box, slots by table look-up): 1 = where it lets
+ *                                more workgroups share a CU than the 32-bit form (default), 0 = never, 2 = wherever it can run (tests, A-B).
+ *                                Bit-identical maps in either form.
  * TBNAV_RBPF_OPT_BATCH_PIPELINE  1 = tbnav_rbpf_slam_batch keeps two scans in the stream (default); 0 = n synchronous calls.
  * TBNAV_RBPF_OPT_HOST_THREADS    host threads the REFERENCE distance-field mode spreads its per-particle brushfires over (particles are
  *                                independent; the order of operations inside one particle is the reference's).  0 = the default: the
  *                                cores in the process's affinity mask, at most 32. */
 enum { TBNAV_RBPF_OPT_DF_MODE = 1, TBNAV_RBPF_OPT_RAYCAST_ORDERED = 2, TBNAV_RBPF_OPT_RAYCAST_THREADS = 3, TBNAV_RBPF_OPT_COUNT_CELLS = 4,
-       TBNAV_RBPF_OPT_RAYCAST_FORM = 5, TBNAV_RBPF_OPT_RAYCAST_BAND_ROWS = 6, TBNAV_RBPF_OPT_BATCH_PIPELINE = 7, TBNAV_RBPF_OPT_HOST_THREADS = 8, TBNAV_RBPF_OPT_RAYCAST_ADAPT = 9 };
+       TBNAV_RBPF_OPT_RAYCAST_FORM = 5, TBNAV_RBPF_OPT_RAYCAST_BAND_ROWS = 6, TBNAV_RBPF_OPT_BATCH_PIPELINE = 7, TBNAV_RBPF_OPT_HOST_THREADS = 8, TBNAV_RBPF_OPT_RAYCAST_ADAPT = 9, TBNAV_RBPF_OPT_RAYCAST_CELL16 = 10 };
 enum { TBNAV_RBPF_DF_FULL = 0, TBNAV_RBPF_DF_WINDOW = 1, TBNAV_RBPF_DF_QUERY = 2, TBNAV_RBPF_DF_REFERENCE = 3 };
 int tbnav_rbpf_set_option(tbnav_rbpf* h, int32_t option, int32_t value);
 /* Since the last reset, summed over particles and scans (TBNAV_RBPF_OPT_COUNT_CELLS on): cell_updates = log-odds

@@ -27,6 +27,7 @@ MPPI_OPT_KERNEL, MPPI_OPT_TRIG, MPPI_OPT_NO_LDS_STAGING, MPPI_OPT_KEEP_J, MPPI_O
 RBPF_OPT_DF_MODE, RBPF_OPT_RAYCAST_ORDERED, RBPF_OPT_RAYCAST_THREADS, RBPF_OPT_COUNT_CELLS, RBPF_OPT_RAYCAST_FORM = 1, 2, 3, 4, 5
 RBPF_OPT_RAYCAST_BAND_ROWS = 6
 RBPF_OPT_RAYCAST_ADAPT = 9
+RBPF_OPT_RAYCAST_CELL16 = 10
 RBPF_OPT_BATCH_PIPELINE = 7
 RBPF_OPT_HOST_THREADS = 8
 RBPF_DF = {"full": 0, "window": 1, "query": 2, "reference": 3}

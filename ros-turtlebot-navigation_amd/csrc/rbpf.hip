@@ -102,7 +102,8 @@ struct tbnav_rbpf {
   std::vector<double2> beam_cs;  // (cos, sin) of every beam's angle in the sensor frame, kept between scans
   std::vector<double2> beams_tmp;
   int raycast_band_rows = 0;   // > 0: cap the LDS array of rbpf_raycast_box at about this many box rows (TBNAV_RBPF_OPT_RAYCAST_BAND_ROWS, tests)
-  int lk_raycast = -1, lk_raycast_wps = 0, lk_raycast_grid = 0, lk_propose = 0, lk_box_need = 0, lk_box_cap = 0;  // the instantiations the last launches were (tbnav_rbpf_last_kernel_names): raycast threads (0 = beam-ordered), its workgroups, propose threads
+  int raycast_cell16 = 1;      // 0: never the 16-bit cell form; 1: where it buys a higher residency (default); 2: wherever it can run (TBNAV_RBPF_OPT_RAYCAST_CELL16)
+  int lk_raycast = -1, lk_raycast_wps = 0, lk_raycast_c16 = 0, lk_raycast_grid = 0, lk_propose = 0, lk_box_need = 0, lk_box_cap = 0;  // the instantiations the last launches were (tbnav_rbpf_last_kernel_names): raycast threads (0 = beam-ordered), its workgroups, propose threads
   int raycast_form = 0;        // 0 = box counters (rbpf_raycast_box), 1 = the beam-ordered kernel (rbpf_raycast) (TBNAV_RBPF_OPT_RAYCAST_FORM)
   double* d_sens = nullptr;    // [N][4] sensor transform (X, Y, sin, cos) of each particle's new pose, left by the proposal kernel
   uint64_t seed = 0x5EEDull, scan_index = 0;  // device noise source (normals == NULL)
@@ -516,7 +517,7 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens,
   const bool nt_auto = nt == 0;
   if (nt == 0) nt = 1024;
   // rbpf_raycast_box: one u32 per cell of the box, the box padded to whole groups of 8 cells along y
-  long cap_win = 0, cap_four = 0;
+  long cap_win = 0, cap4 = 0;
   if (h->tile_cap > 0) {
     // every end point lies within `reach` of the robot's position: at most floor(2 reach / res) + 2 rows or columns (+1 spare);
     // along y the box is padded to whole pairs of cells
@@ -540,21 +541,32 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens,
       // round (round 4; measured 24.6 / 30.8 / 37.1 us with 1 / 2 / 3 workgroups per CU, 48.3 for 1000 particles on 768 slots) —
       // when the boxes' need plus a margin of three rows or so fits a quarter of the CU's LDS.  The margin is tighter than the
       // three-per-CU form's 1/8 + 512: a box that outgrows it costs its particle a second band, never correctness.
-      const long cap4 = std::max(((long)need + 256 + 7) & ~7L, (side + 9) & ~7L);
-      const size_t lds4 = std::max(box_lds_bytes((size_t)cap4, (size_t)bvn), nz ? sizeof(double) * 2 * kNormChunk : (size_t)0);
-      if (h->raycast_adapt != 2 && cap4 <= cap_win && 4 * (lds4 + kBoxStaticLds) <= (size_t)kMaxLds) cap_four = cap4;
+      cap4 = std::max(((long)need + 256 + 7) & ~7L, (side + 9) & ~7L);
     }
   }
-  // workgroup size and residency the register allocation is held to: 512 threads x 4 per CU (64 registers a lane) when cap_four says
-  // the LDS allows it, x 3 (80 registers) when three fit, else 1024 x 2 (64).  Measured at cfg3, N = 1000 / 4000: 1024 x 2: 55.8 /
-  // 191 us; 512 x 2: 54.4 / 199; 512 x 3: 49.1 / 163
+  // Residency the launch gets: R workgroups per CU need R x (dynamic + static LDS) <= 160 KB; 4 and 3 per CU are 512-thread
+  // workgroups (64 / 80 registers a lane), 2 per CU 1024 threads (64).  Two cell formats: 32-bit words (slot in the word) and,
+  // when that buys a higher residency, 16-bit words + a slot table (C16: a few more instructions per walk step).  Measured at
+  // cfg3, N = 1000 / 4000, 32-bit words: 1024 x 2: 55.8 / 191 us; 512 x 2: 54.4 / 199; 512 x 3: 49.1 / 163; in a smaller room
+  // 512 x 3 -> 512 x 4: 46.4 -> 39.7 / 144 -> 130.
+  const size_t nz_lds = nz ? sizeof(double) * 2 * kNormChunk : (size_t)0;
+  auto fits = [&](int R, size_t bytes) { return (size_t)R * (std::max(bytes, nz_lds) + kBoxStaticLds) <= (size_t)kMaxLds; };
+  const bool may4 = h->raycast_adapt != 2 && cap4 > 0 && cap4 <= cap_win;
   int wps = 8;
-  if ((nt_auto || nt == 512) && cap_four > 0) { nt = 512; cap_win = cap_four; }
-  const size_t lds_win = box_lds_bytes((size_t)cap_win, (size_t)bvn);
-  if (cap_four == 0) {
-    if (nt_auto && cap_win > 0 && 3 * (lds_win + kBoxStaticLds) <= (size_t)kMaxLds) nt = 512;
-    if (nt == 512) wps = 6;
-  }
+  bool c16 = false;
+  const bool pick = nt_auto || nt == 512;
+  const bool c16_ok = h->raycast_cell16 != 0 && cap_win > 0 && cap_win < 65528 && c.Bv + 64 < 32768;
+  // (measured, N = 1000: the 16-bit form costs ~15 % at EQUAL residency — 57.2 against 49.8 us at three per CU: twice the
+  //  same-dword collisions of the LDS adds where rays converge, the sub-word arithmetic of every step — so going from three to
+  //  four per CU with it loses, 51.5 against 49.8 us, and it is used only where the 32-bit form is stuck at TWO per CU: the
+  //  SURVEY room's 13 860-cell boxes, 63.7 -> 60.7 us)
+  if (pick && may4 && fits(4, box_lds_bytes((size_t)cap4, (size_t)bvn))) { nt = 512; cap_win = cap4; }
+  else if (pick && cap_win > 0 && fits(3, box_lds_bytes((size_t)cap_win, (size_t)bvn))) { nt = 512; wps = 6; }
+  else if (pick && may4 && c16_ok && fits(4, box16_lds_bytes((size_t)cap4, (size_t)bvn))) { nt = 512; cap_win = cap4; c16 = true; }
+  else if (pick && c16_ok && fits(3, box16_lds_bytes((size_t)cap_win, (size_t)bvn))) { nt = 512; wps = 6; c16 = true; }
+  else if (nt == 512) wps = 6;
+  if (h->raycast_cell16 == 2 && c16_ok && nt == 512) c16 = true;   // (tests / A-B: the 16-bit form wherever it can run)
+  const size_t lds_win = c16 ? box16_lds_bytes((size_t)cap_win, (size_t)bvn) : box_lds_bytes((size_t)cap_win, (size_t)bvn);
   if (cap_win > 0 && !h->ref_field && c.Bv < 32768 - kWave && h->raycast_form == 0 && nt >= 512 && lds_win <= (size_t)kMaxLds - 4096) {
     // default: box counters (rbpf_raycast_box)
     unsigned long long* touched = h->count_touched ? h->d_touched : nullptr;
@@ -562,13 +574,16 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens,
     const int blocks = count + (nz ? 1 : 0);
     const size_t lds_launch = nz ? std::max(lds_win, sizeof(double) * 2 * kNormChunk) : lds_win;  // (workgroup 0's two arrays)
     const int need_slot = (int)(h->rc_launches++ % 3u);
-    h->lk_raycast = nt == 512 ? 512 : 1024; h->lk_raycast_wps = wps; h->lk_raycast_grid = blocks;
+    h->lk_raycast = nt == 512 ? 512 : 1024; h->lk_raycast_wps = wps; h->lk_raycast_c16 = c16 ? 1 : 0; h->lk_raycast_grid = blocks;
     h->lk_box_cap = (int)cap_win; h->lk_box_need = (h->raycast_adapt && h->h_box_need) ? *reinterpret_cast<volatile int*>(h->h_box_need) : 0;
-#define TBNAV_BOX(NT_, WPS_) hipLaunchKernelGGL((rbpf_raycast_box<NT_, WPS_>), dim3(blocks), dim3(NT_), lds_launch, st, c, h->pool, M, beams_dev, sp.pose, sens, \
-                                                h->d_trow[h->cur], h->d_nocc[h->cur], err, (int)cap_win, touched, na, h->d_box_need, h->d_box_need_host, need_slot)
-    if (nt == 512 && wps == 8) TBNAV_BOX(512, 8);
-    else if (nt == 512) TBNAV_BOX(512, 6);
-    else TBNAV_BOX(1024, 8);
+    const int hash_words = c16 ? (int)box16_hash_words((size_t)bvn) : 0;
+#define TBNAV_BOX(NT_, WPS_, C16_) hipLaunchKernelGGL((rbpf_raycast_box<NT_, WPS_, C16_>), dim3(blocks), dim3(NT_), lds_launch, st, c, h->pool, M, beams_dev, sp.pose, sens, \
+                                                h->d_trow[h->cur], h->d_nocc[h->cur], err, (int)cap_win, touched, na, h->d_box_need, h->d_box_need_host, need_slot, hash_words)
+    if (nt == 512 && wps == 8 && c16) TBNAV_BOX(512, 8, true);
+    else if (nt == 512 && wps == 8) TBNAV_BOX(512, 8, false);
+    else if (nt == 512 && c16) TBNAV_BOX(512, 6, true);
+    else if (nt == 512) TBNAV_BOX(512, 6, false);
+    else TBNAV_BOX(1024, 8, false);
 #undef TBNAV_BOX
     TBNAV_HIP(hipGetLastError());
     return TBNAV_OK;
@@ -1039,9 +1054,11 @@ int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf*
                   : hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_edt<32>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
   // (2.3 KB of static LDS: the embedded normalise's scan scratch)
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_box<1024, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 4096);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_box<512, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 4096);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_box<512, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 4096);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_box<1024, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 4096);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_box<512, 6, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 4096);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_box<512, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 4096);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_box<512, 6, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 4096);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_box<512, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 4096);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 1024);
   // the proposal / scan-match kernels carry the scan, the per-sample data and the bitmap slice: more than the 64 KB
   // default for long scans or many samples
@@ -2283,6 +2300,10 @@ int tbnav_rbpf_set_option(tbnav_rbpf* h, int32_t option, int32_t value) {
       if (value < 0) return TBNAV_ERR_INVALID_ARG;
       h->raycast_band_rows = value;
       return TBNAV_OK;
+    case TBNAV_RBPF_OPT_RAYCAST_CELL16:
+      if (value < 0 || value > 2) return TBNAV_ERR_INVALID_ARG;
+      h->raycast_cell16 = value;
+      return TBNAV_OK;
     case TBNAV_RBPF_OPT_RAYCAST_ADAPT:
       if (value < 0 || value > 2) return TBNAV_ERR_INVALID_ARG;
       h->raycast_adapt = value;
@@ -2336,7 +2357,7 @@ int tbnav_rbpf_last_kernel_names(const tbnav_rbpf* h, char* propose, int32_t pro
   if (!h) return TBNAV_ERR_INVALID_ARG;
   if (propose && propose_cap > 0) { if (h->lk_propose) snprintf(propose, (size_t)propose_cap, "rbpf_propose<%d>", h->lk_propose); else propose[0] = 0; }
   if (raycast && raycast_cap > 0) {
-    if (h->lk_raycast > 0) snprintf(raycast, (size_t)raycast_cap, "rbpf_raycast_box<%d, %d>", h->lk_raycast, h->lk_raycast_wps);
+    if (h->lk_raycast > 0) snprintf(raycast, (size_t)raycast_cap, "rbpf_raycast_box<%d, %d, %s>", h->lk_raycast, h->lk_raycast_wps, h->lk_raycast_c16 ? "true" : "false");
     else if (h->lk_raycast == 0) snprintf(raycast, (size_t)raycast_cap, "rbpf_raycast");
     else raycast[0] = 0;
   }

@@ -287,8 +287,11 @@ constexpr int kBoxEv = 8;     // events a slot holds before it is replayed exhau
 constexpr int kHotSide = 7;   // the kHotSide x kHotSide cells round the robot are candidates for a lane of their own ...
 constexpr int kHotMin = 16;   // ... when they collect at least this many free adds
 constexpr int kVeryHot = 80;  // ... and from this many on they are worked out without the chain of adds (add_repeated)
-// tile u32[cap] | ev u16[bv][kBoxEv] (a slot's first 8 bytes become its replayed value once its events are read) | hot values f64[64] | exy, ecnt i32[bv]
+// tile u32[cap] | ev u16[bv][kBoxEv] (a slot's first 8 bytes become its replayed value once its events are read) | hot values f64[64] | exy i32[bv] | ecnt u16[bv]
 __host__ __device__ constexpr size_t box_lds_bytes(size_t cap, size_t bv) { return 4 * cap + 2 * kBoxEv * bv + 8 * 64 + 4 * bv + 2 * ((bv + 1) & ~(size_t)1); }
+// the 16-bit cell form: half the cell array + the slot table (hash_words u32, a power of two >= 2 x (bv + 64) slots)
+__host__ __device__ constexpr size_t box16_hash_words(size_t bv) { size_t h = 256; while (h < 2 * (bv + 64)) h *= 2; return h; }
+__host__ __device__ constexpr size_t box16_lds_bytes(size_t cap, size_t bv) { return box_lds_bytes(cap, bv) - 2 * cap + 4 * box16_hash_words(bv); }
 constexpr size_t kBoxStaticLds = 768;  // the kernel's __shared__ variables (tools/kernel_resources.py rbpf_raycast: 7xx B), rounded up
 // (512 threads: three workgroups = 24 waves per CU when the LDS array is sized by what the boxes need, see launch_raycast —
 //  6 waves per SIMD leave 80 registers a lane: the kernel needs 77 and spills nothing; 1024 threads: two workgroups = 32 waves, 64)
@@ -541,12 +544,12 @@ __global__ __launch_bounds__(256) void rbpf_normalize(int N, const double* __res
                                                       unsigned int* seq = nullptr, unsigned int seq_val = 0,
                                                       int* __restrict__ children = nullptr);
 // rbpf_raycast.hip
-template <int NT, int WPS>
+template <int NT, int WPS, bool C16>
 __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P, MapT M, const double2* __restrict__ beams,
                                                           const double* __restrict__ pose, const double* __restrict__ sens,
                                                           int* __restrict__ trow_occ, int* __restrict__ n_occ, int* __restrict__ err,
                                                           int tile_cap, unsigned long long* __restrict__ touched, NormArgs nz,
-                                                          int* __restrict__ box_need, int* __restrict__ box_need_host, int need_slot);
+                                                          int* __restrict__ box_need, int* __restrict__ box_need_host, int need_slot, int hash_words);
 // rbpf_field.hip
 __global__ __launch_bounds__(256) void rbpf_densify(GridC g, int p0, TilePool P, MapT M, const int* __restrict__ trow_occ,
                                                     unsigned long long* __restrict__ bitmap, int* __restrict__ row_count);

@@ -360,12 +360,12 @@ __global__ void rbpf_add_repeated_test(const double* __restrict__ x, const doubl
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < count) out[i] = add_repeated(x[i], d[i], n[i]);
 }
-template <int NT, int WPS>
+template <int NT, int WPS, bool C16>
 __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P, MapT M, const double2* __restrict__ beams,
                                                           const double* __restrict__ pose, const double* __restrict__ sens,
                                                           int* __restrict__ trow_occ, int* __restrict__ n_occ, int* __restrict__ err,
                                                           int tile_cap, unsigned long long* __restrict__ touched, NormArgs nz,
-                                                          int* __restrict__ box_need, int* __restrict__ box_need_host, int need_slot) {
+                                                          int* __restrict__ box_need, int* __restrict__ box_need_host, int need_slot, int hash_words) {
   extern __shared__ __attribute__((aligned(16))) int lds_i[];
   // enqueued behind a scan whose resampling decision the host had not seen yet: if that scan resamples, this launch does
   // nothing (the host runs the copies and enqueues this scan again)
@@ -380,15 +380,47 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
     return;
   }
   const int Bv = c.Bv;
+  // C16 (round 4): a cell is a 16-BIT word — bit 15: end-point (or hot) cell, low 15 bits: free adds — and the slot of a flagged
+  // cell is found by look-up in a small open-addressing table keyed by the cell (hash_words entries, a power of two >= 2 x the
+  // slots; entry = (cell + 1) << 16 | slot).  Half the LDS per cell of the box: what makes room for a fourth workgroup per CU
+  // (or a third / fourth where the 32-bit form fits two) at the price of a few instructions per walk step (LDS atomics are
+  // 32-bit: the add goes to the containing dword, shifted) and a probe per event.  The 32-bit form (!C16) keeps the slot in
+  // bits 16-30 of the cell's own word.
+  const int tile_words = C16 ? tile_cap / 2 + hash_words : tile_cap;   // ints the cell array (+ the table) take
   unsigned int* tile = reinterpret_cast<unsigned int*>(lds_i);         // (tile_cap is a multiple of 8)
-  unsigned short* ev = reinterpret_cast<unsigned short*>(lds_i + tile_cap);  // [Bv][kBoxEv]  beam << 1 | occupied  (16 bytes a slot, 16-byte aligned)
-  double* val_hot = reinterpret_cast<double*>(lds_i + tile_cap + 4 * Bv);    // [64] the value worked out for a hot cell (slot Bv + lane)
-  int* exy = lds_i + tile_cap + 4 * Bv + 2 * 64;         // [Bv] end-point cell, x | y << 16
+  unsigned short* tile16 = reinterpret_cast<unsigned short*>(lds_i);
+  unsigned int* htab = reinterpret_cast<unsigned int*>(lds_i + tile_cap / 2);
+  const unsigned int hmask = (unsigned int)hash_words - 1u;
+  unsigned short* ev = reinterpret_cast<unsigned short*>(lds_i + tile_words);  // [Bv][kBoxEv]  beam << 1 | occupied  (16 bytes a slot, 16-byte aligned)
+  double* val_hot = reinterpret_cast<double*>(lds_i + tile_words + 4 * Bv);    // [64] the value worked out for a hot cell (slot Bv + lane)
+  int* exy = lds_i + tile_words + 4 * Bv + 2 * 64;         // [Bv] end-point cell, x | y << 16
   unsigned short* ecnt = reinterpret_cast<unsigned short*>(exy + Bv);  // [Bv] events recorded in the slot of beam b — the FIRST beam that ended in its
                                                                        //      cell (0: b opened no slot; may exceed kBoxEv: overflow).  Two counts a dword:
                                                                        //      LDS atomics are 32-bit, a count never reaches 2^16 (one event per beam at most)
-  constexpr unsigned int kFlag = 0x80000000u;
+  constexpr unsigned int kFlag = 0x80000000u;   // (the flag as the passes below see a cell: C16 cells are widened to this form when read)
   constexpr int kEv = kBoxEv;
+  // C16: the slot of flagged cell t.  claim: the first caller's slot wins and is returned to everybody (one compare-and-swap per
+  // probe); find: the cell IS in the table (its flag is set only after its claim).
+  auto h_of = [&](int t) { return ((unsigned int)t * 0x9E3779B1u >> 12) & hmask; };
+  auto slot_claim = [&](int t, int slot) {
+    const unsigned int key = (unsigned int)(t + 1) << 16;
+    unsigned int h = h_of(t);
+    for (;;) {
+      const unsigned int old = atomicCAS(&htab[h], 0u, key | (unsigned int)slot);
+      if (old == 0u) return slot;
+      if ((old & 0xFFFF0000u) == key) return (int)(old & 0xFFFFu);
+      h = (h + 1u) & hmask;
+    }
+  };
+  auto slot_find = [&](int t) {
+    const unsigned int key = (unsigned int)(t + 1) << 16;
+    unsigned int h = h_of(t);
+    for (;;) {
+      const unsigned int e = htab[h];
+      if ((e & 0xFFFF0000u) == key) return (int)(e & 0xFFFFu);
+      h = (h + 1u) & hmask;
+    }
+  };
   // the value replayed for end-point slot o (< Bv) lives in the first 8 bytes of the slot's own 16-byte event list — the lane
   // that replays it has the events in registers by then, nobody else reads them — and a hot cell's (slot Bv + lane) in val_hot:
   // 8 bytes per beam less LDS than an array of its own, which is what lets FOUR workgroups share a CU when the box is small
@@ -433,7 +465,7 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
     }
   } else {
     uint4* t4 = reinterpret_cast<uint4*>(tile);
-    for (int t = tid - kWave; t < tile_cap / 4; t += nthr - kWave) t4[t] = uint4{0u, 0u, 0u, 0u};
+    for (int t = tid - kWave; t < tile_words / 4; t += nthr - kWave) t4[t] = uint4{0u, 0u, 0u, 0u};
     for (int b = tid - kWave; b < Bv; b += nthr - kWave) ecnt[b] = 0;
     for (int t = tid - kWave; t < kMapTilesMax; t += nthr - kWave) mt_touch[t] = 0;
     for (int t = tid - kWave; t < kBoxSideMax / kTS + 2; t += nthr - kWave) rc_delta[t] = 0;
@@ -504,8 +536,7 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
     atomicAdd(&rc_delta[(cx >> kTSh) - tx0], now ? 1 : -1);
     atomicAdd(&nocc_delta, now ? 1 : -1);
   };
-  auto record = [&](unsigned int word, int what) {  // an event for the flagged cell whose tile word this is
-    const int o = (int)((word >> 16) & 0x7FFFu);
+  auto record = [&](int o, int what) {  // an event for the flagged cell whose slot is o
     const unsigned int was = atomicAdd(reinterpret_cast<unsigned int*>(ecnt) + (o >> 1), (o & 1) ? 0x10000u : 1u);
     const int en = (int)((o & 1) ? was >> 16 : was & 0xFFFFu);
     if (en < kEv) ev[o * kEv + en] = (unsigned short)what;
@@ -524,7 +555,7 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
     if (x0 != minx) {  // (a further band: the LDS state of the previous one is cleared)
       __syncthreads();
       uint4* t4 = reinterpret_cast<uint4*>(tile);
-      for (int t = tid; t < tile_cap / 4; t += nthr) t4[t] = uint4{0u, 0u, 0u, 0u};
+      for (int t = tid; t < tile_words / 4; t += nthr) t4[t] = uint4{0u, 0u, 0u, 0u};
       for (int b = tid; b < Bv; b += nthr) ecnt[b] = 0;
       for (int t = tid; t < kMapTilesMax; t += nthr) mt_touch[t] = 0;
       if (tid == 0) n_ovf = 0;
@@ -539,9 +570,16 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
     for (int b = tid; b < Bv; b += nthr) {
       const int e = exy[b];
       if (!in_band(e)) continue;
-      const unsigned int mine = kFlag | ((unsigned int)b << 16);
-      const unsigned int old = atomicCAS(&tile[cell_t(e)], 0u, mine);
-      record(old ? old : mine, (b << 1) | 1);
+      if constexpr (C16) {
+        const int t = cell_t(e);
+        const int o = slot_claim(t, b);
+        atomicOr(&tile[t >> 1], (t & 1) ? 0x80000000u : 0x8000u);   // (after the claim: whoever sees the flag finds the slot)
+        record(o, (b << 1) | 1);
+      } else {
+        const unsigned int mine = kFlag | ((unsigned int)b << 16);
+        const unsigned int old = atomicCAS(&tile[cell_t(e)], 0u, mine);
+        record((int)(((old ? old : mine) >> 16) & 0x7FFFu), (b << 1) | 1);
+      }
     }
     TRACE_W(3);
     __syncthreads();
@@ -563,7 +601,8 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
       int S = Bv > 0 ? nthr / Bv : 1;  // segments per ray: as many as give every thread at most one task
       S = S < 1 ? 1 : (S > 4 ? 4 : S);
       const int G = (Bv + kWave - 1) / kWave;
-      const unsigned int band_bytes = 4u * (unsigned int)band_cells;
+      constexpr int kCellBytes = C16 ? 2 : 4;
+      const unsigned int band_bytes = (unsigned int)kCellBytes * (unsigned int)band_cells;
       int n_first = 0;
       for (int task = tid; task < kWave * G * S; task += nthr) {
         const int tb = floor_div_small(task, S), sgm = task - tb * S;
@@ -581,9 +620,9 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
         int rem = a0 - __mul24(two_dmaj, c0 - 1);
         const int sc = pr.neg ? -c0 : c0;
         // byte offset of the segment's first cell in the band's array, and the byte steps along / across the ray
-        int at = 4 * (__mul24((pr.ymajor ? pr.xa + sc : pr.xa + n) - x0, bw) + ((pr.ymajor ? pr.ya + n : pr.ya + sc) - miny));
-        const int d_major = 4 * (pr.ymajor ? 1 : bw);
-        const int d_both = d_major + 4 * (pr.ymajor ? bw : 1) * (pr.neg ? -1 : 1);
+        int at = kCellBytes * (__mul24((pr.ymajor ? pr.xa + sc : pr.xa + n) - x0, bw) + ((pr.ymajor ? pr.ya + n : pr.ya + sc) - miny));
+        const int d_major = kCellBytes * (pr.ymajor ? 1 : bw);
+        const int d_both = d_major + kCellBytes * (pr.ymajor ? bw : 1) * (pr.neg ? -1 : 1);
         auto advance = [&]() {
           const int r2 = rem + two_dmin;
           const bool side = r2 > two_dmaj;
@@ -596,24 +635,41 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
         // (no register is copied at the top of the loop, which would wait for the add just issued), so the walk never waits
         // for LDS unless it has an event to record.
         unsigned int r0 = 0u, r1 = 0u, r2 = 0u;
-        auto look = [&](unsigned int& old) { if (old & kFlag) record(old, b << 1); old = 0u; };
-        auto step = [&](auto clipped, unsigned int& fresh, unsigned int& old) {
-          if (!decltype(clipped)::value || (unsigned int)at < band_bytes) fresh = atomicAdd(reinterpret_cast<unsigned int*>(tile_b + at), 1u);  // (clipped: the cells of the ray in this band of rows)
+        // (C16: what comes back is the cell's DWORD — this cell's half is picked when it is looked at — and the byte offset the add
+        //  went to rides along, so that a flagged cell's slot can be looked up: a0..a2 take turns like r0..r2)
+        int a0r = 0, a1r = 0, a2r = 0;
+        auto look = [&](unsigned int& old, int where) {
+          if constexpr (C16) {
+            if ((old >> ((where & 2) << 3)) & 0x8000u) record(slot_find(where >> 1), b << 1);
+          } else {
+            if (old & kFlag) record((int)((old >> 16) & 0x7FFFu), b << 1);
+          }
+          old = 0u;
+        };
+        auto step = [&](auto clipped, unsigned int& fresh, int& fresh_at, unsigned int& old, int old_at) {
+          if (!decltype(clipped)::value || (unsigned int)at < band_bytes) {  // (clipped: the cells of the ray in this band of rows)
+            if constexpr (C16) { fresh = atomicAdd(reinterpret_cast<unsigned int*>(tile_b + (at & ~3)), (at & 2) ? 0x10000u : 1u); fresh_at = at; }
+            else fresh = atomicAdd(reinterpret_cast<unsigned int*>(tile_b + at), 1u);
+          }
           advance();
-          look(old);
+          look(old, old_at);
         };
         auto walk = [&](auto clipped) {
           int m = n1 - n;
-          for (; m >= 3; m -= 3) { step(clipped, r0, r1); step(clipped, r1, r2); step(clipped, r2, r0); }
-          if (m >= 1) step(clipped, r0, r1);
-          if (m >= 2) step(clipped, r1, r2);
+          for (; m >= 3; m -= 3) { step(clipped, r0, a0r, r1, a1r); step(clipped, r1, a1r, r2, a2r); step(clipped, r2, a2r, r0, a0r); }
+          if (m >= 1) step(clipped, r0, a0r, r1, a1r);
+          if (m >= 2) step(clipped, r1, a1r, r2, a2r);
         };
         if (clip) walk(std::true_type{}); else walk(std::false_type{});
-        look(r0); look(r1); look(r2);
+        look(r0, a0r); look(r1, a1r); look(r2, a2r);
       }
       // the robot's own cell is the first free cell of every ray that has a free cell at all
       n_first = wave_sum_dpp(n_first);
-      if (lane == 0 && n_first && (unsigned int)(rx - x0) < (unsigned int)nr) atomicAdd(&tile[__mul24(rx - x0, bw) + (ry - miny)], (unsigned int)n_first);
+      if (lane == 0 && n_first && (unsigned int)(rx - x0) < (unsigned int)nr) {
+        const int t = __mul24(rx - x0, bw) + (ry - miny);
+        if constexpr (C16) atomicAdd(&tile[t >> 1], (unsigned int)n_first << ((t & 1) << 4));
+        else atomicAdd(&tile[t], (unsigned int)n_first);
+      }
     }
     TRACE_W(6);
     __syncthreads();  // every event is recorded
@@ -635,7 +691,13 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
       for (int i = 0; i < kSl; ++i) {
         const int pi = pi0 + i * nthr;
         uint2 w = uint2{0u, 0u};
-        if (pi < np) w = tile2[pi];
+        if (pi < np) {
+          if constexpr (C16) {  // the pair is ONE dword; widened to the 32-bit form's words (flag -> bit 31; the slot is looked up where needed)
+            const unsigned int d = tile[pi];
+            w.x = (d & 0x7FFFu) | ((d & 0x8000u) << 16);
+            w.y = ((d >> 16) & 0x7FFFu) | (d & 0x80000000u);
+          } else w = tile2[pi];
+        }
         fn(i, w, x0 + row, miny + col);
         row += step_r; col += step_c;
         if (col >= bw) { col -= bw; ++row; }
@@ -787,7 +849,8 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
       const int hi = floor_div_small(lane, kHotSide), hx = rx - kHotSide / 2 + hi, hy = ry - kHotSide / 2 + (lane - hi * kHotSide);
       if ((unsigned int)(hx - x0) < (unsigned int)nr && hy >= miny && hy < miny + bw) {
         const int t = __mul24(hx - x0, bw) + (hy - miny);
-        const unsigned int f = tile[t];
+        unsigned int f;
+        if constexpr (C16) { const unsigned int hh = tile16[t]; f = (hh & 0x7FFFu) | ((hh & 0x8000u) << 16); } else f = tile[t];
         const int cnq = (int)(f & 0xFFFFu);
         const bool robot_cell = hx == rx && hy == ry;  // (worked out beside the walk)
         const bool very = !robot_cell && cnq >= kVeryHot;
@@ -801,7 +864,8 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
             for (; a + 4 <= cnq; a += 4) { vv += c.d_free; vv += c.d_free; vv += c.d_free; vv += c.d_free; }
             for (; a < cnq; ++a) vv += c.d_free;
           }
-          tile[t] = kFlag | ((unsigned int)(Bv + lane) << 16);
+          if constexpr (C16) { slot_claim(t, Bv + lane); tile16[t] = (unsigned short)(0x8000u | (unsigned int)cnq); }   // (nobody else touches this cell in this phase)
+          else tile[t] = kFlag | ((unsigned int)(Bv + lane) << 16);
           ++n_distinct;
           finish_end(Bv + lane, hx, hy, v0o, vv);
         }
@@ -831,8 +895,9 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
           n1 = a < c1 ? t1 : n1;
         }
         if ((w.x | w.y) & kFlag) {  // an end-point or hot cell takes the value worked out for it
-          if (w.x & kFlag) n0 = *val_at((int)((w.x >> 16) & 0x7FFFu));
-          if (w.y & kFlag) n1 = *val_at((int)((w.y >> 16) & 0x7FFFu));
+          const int t0c = __mul24(cx - x0, bw) + (cy - miny);   // the pair's first cell in the band's array
+          if (w.x & kFlag) n0 = *val_at(C16 ? slot_find(t0c) : (int)((w.x >> 16) & 0x7FFFu));
+          if (w.y & kFlag) n1 = *val_at(C16 ? slot_find(t0c + 1) : (int)((w.y >> 16) & 0x7FFFu));
         }
         n_distinct += (plain0 ? 1 : 0) + (plain1 ? 1 : 0);
         *reinterpret_cast<double2*>(cell_ptr(cx, cy)) = double2{n0, n1};
@@ -870,9 +935,11 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
 #endif
   WG_OUT();
 }
-template __global__ void rbpf_raycast_box<512, 6>(ScanC, TilePool, MapT, const double2* __restrict__, const double* __restrict__, const double* __restrict__, int* __restrict__, int* __restrict__, int* __restrict__, int, unsigned long long* __restrict__, NormArgs, int* __restrict__, int* __restrict__, int);
-template __global__ void rbpf_raycast_box<512, 8>(ScanC, TilePool, MapT, const double2* __restrict__, const double* __restrict__, const double* __restrict__, int* __restrict__, int* __restrict__, int* __restrict__, int, unsigned long long* __restrict__, NormArgs, int* __restrict__, int* __restrict__, int);
-template __global__ void rbpf_raycast_box<1024, 8>(ScanC, TilePool, MapT, const double2* __restrict__, const double* __restrict__, const double* __restrict__, int* __restrict__, int* __restrict__, int* __restrict__, int, unsigned long long* __restrict__, NormArgs, int* __restrict__, int* __restrict__, int);
+template __global__ void rbpf_raycast_box<512, 6, false>(ScanC, TilePool, MapT, const double2* __restrict__, const double* __restrict__, const double* __restrict__, int* __restrict__, int* __restrict__, int* __restrict__, int, unsigned long long* __restrict__, NormArgs, int* __restrict__, int* __restrict__, int, int);
+template __global__ void rbpf_raycast_box<512, 6, true>(ScanC, TilePool, MapT, const double2* __restrict__, const double* __restrict__, const double* __restrict__, int* __restrict__, int* __restrict__, int* __restrict__, int, unsigned long long* __restrict__, NormArgs, int* __restrict__, int* __restrict__, int, int);
+template __global__ void rbpf_raycast_box<512, 8, false>(ScanC, TilePool, MapT, const double2* __restrict__, const double* __restrict__, const double* __restrict__, int* __restrict__, int* __restrict__, int* __restrict__, int, unsigned long long* __restrict__, NormArgs, int* __restrict__, int* __restrict__, int, int);
+template __global__ void rbpf_raycast_box<512, 8, true>(ScanC, TilePool, MapT, const double2* __restrict__, const double* __restrict__, const double* __restrict__, int* __restrict__, int* __restrict__, int* __restrict__, int, unsigned long long* __restrict__, NormArgs, int* __restrict__, int* __restrict__, int, int);
+template __global__ void rbpf_raycast_box<1024, 8, false>(ScanC, TilePool, MapT, const double2* __restrict__, const double* __restrict__, const double* __restrict__, int* __restrict__, int* __restrict__, int* __restrict__, int, unsigned long long* __restrict__, NormArgs, int* __restrict__, int* __restrict__, int, int);
 
 }  // namespace tbnav_rk
 

@@ -118,7 +118,7 @@ def test_configs4_shard_10000_particles_2000x2000_1080_beams(gpu_pkg):
     pf.close()
 
 
-@pytest.mark.parametrize("variant", ["box512", "box1024", "box_bands12", "box_bands5", "beam_ordered", "form1"])
+@pytest.mark.parametrize("variant", ["box512", "box1024", "box_bands12", "box_bands5", "box512_cell16", "box_bands5_cell16", "beam_ordered", "form1"])
 def test_raycast_kernel_variants_are_bit_exact(gpu_pkg, variant):
     """Every form of the map update the library ships — the box-counter kernel with 512 and 1024 threads, the same working its
     box through in bands of rows, and the beam-ordered kernel (by either option) — must leave the oracle's GridMapper bits.
@@ -127,6 +127,11 @@ def test_raycast_kernel_variants_are_bit_exact(gpu_pkg, variant):
     from rtn_amd import capi
     N, k, n_scans = 24, 6, 4
     pf = _dev(gpu_pkg, N=N, k=k, map_min=-10.0, map_max=10.0)
+    cell16 = variant.endswith("_cell16")   # the 16-bit cell form (slots by table look-up), forced wherever it can run
+    if cell16:
+        variant = variant[:-len("_cell16")]
+        pf.setOption(capi.RBPF_OPT_RAYCAST_CELL16, 2)
+        pf.setOption(capi.RBPF_OPT_RAYCAST_THREADS, 512)
     if variant == "beam_ordered":
         pf.setOption(capi.RBPF_OPT_RAYCAST_ORDERED, 1)
     elif variant.startswith("box_bands"):  # the box-counter kernel working the box through in bands of ~12 / ~5 rows
@@ -146,6 +151,8 @@ def test_raycast_kernel_variants_are_bit_exact(gpu_pkg, variant):
     grid = (0.05, -10.0, 10.0, -10.0, 10.0)
     for m in (0, 11, N - 1):
         assert np.array_equal(pf.logOdds(m), _oracle_map(grid, None, scans, [h[m] for h in hist])), (variant, m)
+    if cell16:
+        assert pf.lastKernelNames()[1].endswith("true>"), pf.lastKernelNames()
     pf.close()
 
 
@@ -174,8 +181,23 @@ def test_box_kernel_residency_forms_are_bit_exact_and_chosen_by_the_boxes_need(g
         for m in (0, 11, N - 1):
             assert np.array_equal(pf.logOdds(m), _oracle_map(grid, None, scans, [h[m] for h in hist])), (adapt, m)
         pf.close()
-    assert seen[1][0] != "rbpf_raycast_box<512, 8>" and seen[1][-1] == "rbpf_raycast_box<512, 8>", seen[1]   # (no need known at the first launch)
-    assert seen[2][-1] == "rbpf_raycast_box<512, 6>", seen[2]
+    assert not seen[1][0].startswith("rbpf_raycast_box<512, 8") and seen[1][-1] == "rbpf_raycast_box<512, 8, false>", seen[1]   # (no need known at the first launch)
+    assert seen[2][-1] == "rbpf_raycast_box<512, 6, false>", seen[2]
+    # a room whose boxes (13 860 cells) leave the 32-bit cell form at TWO workgroups per CU: the 16-bit cell form (slots by table
+    # look-up) takes over with four — unless TBNAV_RBPF_OPT_RAYCAST_CELL16 0 forbids it
+    steps, poses = rc.trajectory(n_scans, inc=(0.07, 0.02, 0.01))
+    scans = [orc.room_scan(poses[s], walls=rc.ROOM_SURVEY, rng=rng) for s in range(n_scans)]
+    for cell16, want in ((1, "rbpf_raycast_box<512, 8, true>"), (0, "rbpf_raycast_box<1024, 8, false>")):
+        pf = _dev(gpu_pkg, N=N, k=k, map_min=-10.0, map_max=10.0)
+        pf.setOption(capi.RBPF_OPT_RAYCAST_CELL16, cell16)
+        hist = []
+        for s, (prev, cur, t_icp, u) in enumerate(steps):
+            assert pf.SLAM(scans[s], u, cur, prev, True, t_icp, orc.normal_stream(80 + s, pf.numNormals(True), 0.0, 1.0)).status == 0
+            hist.append(pf.trace()["new_pose"].copy())
+        assert pf.lastKernelNames()[1] == want, (cell16, pf.lastKernelNames(), pf.raycastBoxCells())
+        for m in (0, 11, N - 1):
+            assert np.array_equal(pf.logOdds(m), _oracle_map(grid, None, scans, [h[m] for h in hist])), (cell16, m)
+        pf.close()
 
 
 def test_batched_export_equals_single_exports_and_imports_rebuild_the_particles(gpu_pkg):

@@ -18,13 +18,13 @@ if os.environ.get("WALLS"):   # e.g. WALLS=-2.0,2.0,-1.8,1.8: a room whose box f
     rng = np.random.default_rng(7)
     scans = [bench_rbpf._room_scan(poses[s], rng, walls) for s in range(16)]
 for N in [int(a) for a in sys.argv[1:]] or [1000, 2000, 4000]:
-    for adapt in (2, 1, 2, 1):
+    for adapt, cell16 in ((2, 0), (1, 0), (1, 1), (2, 0), (1, 0), (1, 1), (2, 2)):
         pf = ParticleFilter(default_params(N=N, k=50, map_min=-10.0, map_max=10.0))
-        pf.setSeed(1); pf.setTiming(True); pf.setOption(capi.RBPF_OPT_RAYCAST_ADAPT if hasattr(capi, "RBPF_OPT_RAYCAST_ADAPT") else 9, adapt)
+        pf.setSeed(1); pf.setTiming(True); pf.setOption(capi.RBPF_OPT_RAYCAST_ADAPT, adapt); pf.setOption(capi.RBPF_OPT_RAYCAST_CELL16, cell16)
         acc, n = 0.0, 0
         for s, (prev, cur, t_icp, u) in enumerate(steps):
             pf.SLAM(scans[s], u, cur, prev, True, t_icp, None)
             if s >= 5:
                 acc += pf.kernelMs()["raycast"]; n += 1
-        print(f"N={N} adapt={adapt}: raycast {acc / n * 1e3:.1f} us  ({pf.lastKernelNames()[1]}; box need / array cells {pf.raycastBoxCells()})", flush=True)
+        print(f"N={N} adapt={adapt} cell16={cell16}: raycast {acc / n * 1e3:.1f} us  ({pf.lastKernelNames()[1]}; box need / array cells {pf.raycastBoxCells()})", flush=True)
         pf.close()
