@@ -2,7 +2,7 @@
 recomputed from the committed profiler output.
 
   profiles/<round>_kernel_stats.md   rocprofv3 --kernel-trace --stats of `python bench.py ...` (tools/profile_round.sh,
-                                     profiles/summarize_rocpd.py): | kernel | grid (threads) | wg | calls | avg us | min | max | ...
+                                     profiles/summarize_rocpd.py): | kernel | grid (threads) | wg | calls | avg us | min | max | ... | median us
   profiles/<round>_traffic_pmc.json  separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/collect_pmc.sh,
                                      tools/pmc_summary.py, tools/assemble_profiles.py): workloads.<key>.<kernel>.hbm_bytes
 
@@ -46,7 +46,8 @@ def kernel_stats_rows(path=None):
                 continue
             try:
                 rows.append(dict(kernel=cells[0], grid=cells[1], grid_threads=_grid_threads(cells[1]), wg=int(cells[2]), calls=int(cells[3]),
-                                 avg_us=float(cells[4]), min_us=float(cells[5]), max_us=float(cells[6])))
+                                 avg_us=float(cells[4]), min_us=float(cells[5]), max_us=float(cells[6]),
+                                 median_us=float(cells[13]) if len(cells) > 13 else None))
             except ValueError:
                 continue
     return rows, os.path.relpath(path, ROOT)
@@ -60,7 +61,7 @@ def rocprof_row(kernel: str, grid_threads: int | None = None):
     if not hits:
         return None
     r = max(hits, key=lambda q: q["calls"])
-    return dict(source=src, row=f"{r['kernel']} | {r['grid']}", avg_us=r["avg_us"], min_us=r["min_us"], calls=r["calls"])
+    return dict(source=src, row=f"{r['kernel']} | {r['grid']}", avg_us=r["avg_us"], median_us=r["median_us"], min_us=r["min_us"], calls=r["calls"])
 
 
 def pmc_row(workload: str, kernel: str, prefix_ok: bool = False):

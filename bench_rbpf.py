@@ -187,25 +187,33 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
     # ---- per-kernel durations: their own pass (each HIP event costs device time)
     pf_k = mk()
     pf_k.setSeed(2026); pf_k.setTiming(True)
-    kms, kms_res, n_k, n_kr = {}, {}, 0, 0
+    # three kinds of scan: plain; the one that resamples (its own gather launch); and the FIRST scan after a resampling, whose map
+    # update makes every written tile of a shared map private (8 KB copies: ~70 KB per particle on top of the cells it writes) —
+    # the roofline's algorithmic bytes are the plain scan's, so its kernel time is the plain scans' too
+    kms, kms_res, kms_cow, n_k, n_kr, n_kc = {}, {}, {}, 0, 0, 0
+    after_resample = False
     for s, (prev, cur, t_icp, u) in enumerate(steps):
         if s in RESAMPLE_AT:
             _skew(pf_k, N)
         st = pf_k.SLAM(scans[s], u, cur, prev, True, t_icp, None)
         k_propose, k_raycast, k_raycast_wgs = pf_k.lastKernelNames()
         if s >= 4:  # (the map update's LDS array has adapted to the boxes' need by then: the steady state's kernels; the headline pass times from scan 2 on)
-            tgt, = ((kms_res,) if st.resampled else (kms,))
+            tgt = kms_res if st.resampled else (kms_cow if after_resample else kms)
             for key, v in pf_k.kernelMs().items():
                 tgt[key] = tgt.get(key, 0.0) + v
             if st.resampled:
                 n_kr += 1
+            elif after_resample:
+                n_kc += 1
             else:
                 n_k += 1
+        after_resample = bool(st.resampled)
     n_counted = (n_scans - 2) * N
     upd_per, distinct_per = upd / n_counted, distinct / n_counted
     pf_k.close()
     kms = {key: v / max(n_k, 1) for key, v in kms.items()}
     kms_res = {key: v / max(n_kr, 1) for key, v in kms_res.items()}
+    kms_cow = {key: v / max(n_kc, 1) for key, v in kms_cow.items()}
     # ---- single-call pass: one tbnav_rbpf_slam call per scan from this (Python) harness — what round 1 and the first half
     #      of round 2 reported; kept beside the headline to show what the harness costs
     pf_s = mk()
@@ -333,6 +341,8 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
         "device_only_updates_per_s": round(N / (dev_ms * 1e-3), 1),
         "kernel_ms": {key: round(v, 4) for key, v in kms.items()},
         "kernel_ms_resampling_scan": {key: round(v, 4) for key, v in kms_res.items()},
+        "kernel_ms_first_scan_after_a_resampling": {key: round(v, 4) for key, v in kms_cow.items()},
+        "kernel_ms_note": f"HIP events, averages over {n_k} plain scans / {n_kr} resampling scans / {n_kc} scans that follow one (the map update then copies every written tile of a shared map: copy-on-write)",
         "tile_pool": {"tiles": cap, "in_use": cap - free, "tile_bytes": tile_bytes,
                       "log_odds_bytes_in_use": (cap - free) * tile_bytes, "dense_equivalent_bytes": N * pf.G * 8},
         "dtype": "f64+u16",
@@ -356,7 +366,10 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
                      "achieved": round(alg_dom / t_rc / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(alg_dom / t_rc / 1e9 / HBM_PEAK_GBS, 6),
                      "frac_events": round(alg_dom / t_rc / 1e9 / HBM_PEAK_GBS, 6),
-                     "frac_rocprof": None if rp_row is None else round(alg_dom / (rp_row["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 6),
+                     # (the row's MEDIAN where the table has one: the plain scan's launch, like kernel_ms — the average also holds the scans
+                     #  after a resampling, which copy tiles as well)
+                     "frac_rocprof": None if rp_row is None else round(alg_dom / ((rp_row.get("median_us") or rp_row["avg_us"]) * 1e-6) / 1e9 / HBM_PEAK_GBS, 6),
+                     "frac_rocprof_of": None if rp_row is None else ("median_us" if rp_row.get("median_us") else "avg_us"),
                      "rocprof": rp_row,
                      "algorithmic_bytes_per_launch": round(alg_dom, 1),
                      "algorithmic_bytes_note": f"{distinct_per:.1f} distinct cells written per particle and scan (counted on the device, TBNAV_RBPF_OPT_COUNT_CELLS) x 16 B x N",

@@ -26,13 +26,20 @@ def main():
         "sum(duration), max(vgpr_count), max(sgpr_count), max(lds_size), max(scratch_size) from kernels "
         "group by name, grid_x, grid_y, grid_z, workgroup_x order by sum(duration) desc").fetchall()
     total = sum(r[9] for r in rows) or 1
-    print("| kernel | grid (threads) | wg | calls | avg µs | min µs | max µs | total ms | % | vgpr | sgpr | lds B | scratch |")
-    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+    # the median beside the average: a kernel launched on two kinds of step (rbpf_raycast_box on a plain scan and on the scan after a
+    # resampling, which also copies tiles) has an average that describes neither
+    durs = {}
+    for name, gx, gy, gz, wx, d in c.execute("select name, grid_x, grid_y, grid_z, workgroup_x, duration from kernels"):
+        durs.setdefault((name, gx, gy, gz, wx), []).append(d)
+    print("| kernel | grid (threads) | wg | calls | avg µs | min µs | max µs | total ms | % | vgpr | sgpr | lds B | scratch | median µs |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     for r in rows:
         if match and match not in r[0]:
             continue
+        dd = sorted(durs[(r[0], r[1], r[2], r[3], r[4])])
+        med = dd[len(dd) // 2] if len(dd) % 2 else 0.5 * (dd[len(dd) // 2 - 1] + dd[len(dd) // 2])
         print(f"| {short(r[0])} | {r[1]}x{r[2]}x{r[3]} | {r[4]} | {r[5]} | {r[6]/1e3:.3f} | {r[7]/1e3:.3f} | {r[8]/1e3:.3f} | "
-              f"{r[9]/1e6:.3f} | {100*r[9]/total:.1f} | {r[10]} | {r[11]} | {r[12]} | {r[13]} |")
+              f"{r[9]/1e6:.3f} | {100*r[9]/total:.1f} | {r[10]} | {r[11]} | {r[12]} | {r[13]} | {med/1e3:.3f} |")
 
 
 if __name__ == "__main__":

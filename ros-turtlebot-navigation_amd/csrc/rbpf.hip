@@ -560,13 +560,14 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens,
   //  same-dword collisions of the LDS adds where rays converge, the sub-word arithmetic of every step — so going from three to
   //  four per CU with it loses, 51.5 against 49.8 us, and it is used only where the 32-bit form is stuck at TWO per CU: the
   //  SURVEY room's 13 860-cell boxes, 63.7 -> 60.7 us)
-  if (pick && may4 && fits(4, box_lds_bytes((size_t)cap4, (size_t)bvn))) { nt = 512; cap_win = cap4; }
+  if (pick && may4 && fits(4, box_lds_bytes((size_t)cap4, (size_t)bvn, kBoxEvFour))) { nt = 512; cap_win = cap4; }
   else if (pick && cap_win > 0 && fits(3, box_lds_bytes((size_t)cap_win, (size_t)bvn))) { nt = 512; wps = 6; }
-  else if (pick && may4 && c16_ok && fits(4, box16_lds_bytes((size_t)cap4, (size_t)bvn))) { nt = 512; cap_win = cap4; c16 = true; }
+  else if (pick && may4 && c16_ok && fits(4, box16_lds_bytes((size_t)cap4, (size_t)bvn, kBoxEvFour))) { nt = 512; cap_win = cap4; c16 = true; }
   else if (pick && c16_ok && fits(3, box16_lds_bytes((size_t)cap_win, (size_t)bvn))) { nt = 512; wps = 6; c16 = true; }
   else if (nt == 512) wps = 6;
   if (h->raycast_cell16 == 2 && c16_ok && nt == 512) c16 = true;   // (tests / A-B: the 16-bit form wherever it can run)
-  const size_t lds_win = c16 ? box16_lds_bytes((size_t)cap_win, (size_t)bvn) : box_lds_bytes((size_t)cap_win, (size_t)bvn);
+  const size_t ev_slot = (nt == 512 && wps == 8) ? kBoxEvFour : kBoxEv;  // (what the instantiation launched below holds per slot)
+  const size_t lds_win = c16 ? box16_lds_bytes((size_t)cap_win, (size_t)bvn, ev_slot) : box_lds_bytes((size_t)cap_win, (size_t)bvn, ev_slot);
   if (cap_win > 0 && !h->ref_field && c.Bv < 32768 - kWave && h->raycast_form == 0 && nt >= 512 && lds_win <= (size_t)kMaxLds - 4096) {
     // default: box counters (rbpf_raycast_box)
     unsigned long long* touched = h->count_touched ? h->d_touched : nullptr;
@@ -1032,6 +1033,10 @@ int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf*
       e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemset(h->d_touched, 0, sizeof(unsigned long long) * 2);
+    if (e == hipSuccess) {  // the queue's scratch memory, before the first map update that needs it (see the kernel)
+      hipLaunchKernelGGL(rbpf_warm_scratch, dim3(1024), dim3(512), 0, h->stream, reinterpret_cast<int*>(h->d_touched), 0);
+      e = hipGetLastError();
+    }
     if (e == hipSuccess) e = hipMemset(h->d_box_need, 0, sizeof(int) * 3);
     if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_box_need, sizeof(int), hipHostMallocMapped);
     if (e == hipSuccess) { *h->h_box_need = 0; e = hipHostGetDevicePointer((void**)&h->d_box_need_host, h->h_box_need, 0); }

@@ -288,10 +288,11 @@ constexpr int kHotSide = 7;   // the kHotSide x kHotSide cells round the robot a
 constexpr int kHotMin = 16;   // ... when they collect at least this many free adds
 constexpr int kVeryHot = 80;  // ... and from this many on they are worked out without the chain of adds (add_repeated)
 // tile u32[cap] | ev u16[bv][kBoxEv] (a slot's first 8 bytes become its replayed value once its events are read) | hot values f64[64] | exy i32[bv] | ecnt u16[bv]
-__host__ __device__ constexpr size_t box_lds_bytes(size_t cap, size_t bv) { return 4 * cap + 2 * kBoxEv * bv + 8 * 64 + 4 * bv + 2 * ((bv + 1) & ~(size_t)1); }
+constexpr int kBoxEvFour = 4; // ... in the four-workgroups-per-CU form (8 bytes a slot: exactly the replayed value; the bench room's box fits with them)
+__host__ __device__ constexpr size_t box_lds_bytes(size_t cap, size_t bv, size_t ev = kBoxEv) { return 4 * cap + 2 * ev * bv + 8 * 64 + 4 * bv + 2 * ((bv + 1) & ~(size_t)1); }
 // the 16-bit cell form: half the cell array + the slot table (hash_words u32, a power of two >= 2 x (bv + 64) slots)
 __host__ __device__ constexpr size_t box16_hash_words(size_t bv) { size_t h = 256; while (h < 2 * (bv + 64)) h *= 2; return h; }
-__host__ __device__ constexpr size_t box16_lds_bytes(size_t cap, size_t bv) { return box_lds_bytes(cap, bv) - 2 * cap + 4 * box16_hash_words(bv); }
+__host__ __device__ constexpr size_t box16_lds_bytes(size_t cap, size_t bv, size_t ev = kBoxEv) { return box_lds_bytes(cap, bv, ev) - 2 * cap + 4 * box16_hash_words(bv); }
 constexpr size_t kBoxStaticLds = 768;  // the kernel's __shared__ variables (tools/kernel_resources.py rbpf_raycast: 7xx B), rounded up
 // (512 threads: three workgroups = 24 waves per CU when the LDS array is sized by what the boxes need, see launch_raycast —
 //  6 waves per SIMD leave 80 registers a lane: the kernel needs 77 and spills nothing; 1024 threads: two workgroups = 32 waves, 64)
@@ -564,6 +565,8 @@ __global__ __launch_bounds__(kWave) void rbpf_edt_compact(GridC g, int radius, c
                                                           uint16_t* __restrict__ codes, int* __restrict__ tier, int my_tier, EdtJob job);
 // rbpf_resample.hip
 __global__ void rbpf_pool_init(TilePool P);
+__global__ void rbpf_warm_scratch(int* sink, int n);  // (rbpf_raycast.hip)
+constexpr int kWarmScratchInts = 40;  // 160 bytes a lane: more than any map-update instantiation spills (tools/kernel_resources.py: <= 136)
 __global__ __launch_bounds__(kResampleThreads) void rbpf_resample_apply(int N, int TT, const int* __restrict__ parent, const int* __restrict__ children,
                                                            const unsigned int* __restrict__ tab_old, unsigned int* __restrict__ tab_new,
                                                            unsigned int* __restrict__ shed, TilePool P, int table_blocks, int chunks,

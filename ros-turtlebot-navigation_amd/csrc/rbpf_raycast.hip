@@ -360,6 +360,14 @@ __global__ void rbpf_add_repeated_test(const double* __restrict__ x, const doubl
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < count) out[i] = add_repeated(x[i], d[i], n[i]);
 }
+// Launched once when a handle is created: a kernel with a private array per lane, over a grid that fills the device, so that the
+// stream's queue has its scratch memory BEFORE the first map update whose instantiation spills (the four-per-CU form: ~100 bytes
+// a lane).  Without it that launch pays the allocation: 171 us instead of 44 — a whole scan's worth, inside somebody's timed call.
+__global__ __launch_bounds__(512) void rbpf_warm_scratch(int* sink, int n) {
+  volatile int a[kWarmScratchInts];
+  for (int i = 0; i < kWarmScratchInts; ++i) a[i] = i + n;
+  if (n == 0x7ead) sink[0] = a[(threadIdx.x + n) % kWarmScratchInts];  // (never: keeps the array alive and dynamically indexed)
+}
 template <int NT, int WPS, bool C16>
 __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P, MapT M, const double2* __restrict__ beams,
                                                           const double* __restrict__ pose, const double* __restrict__ sens,
@@ -391,14 +399,16 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
   unsigned short* tile16 = reinterpret_cast<unsigned short*>(lds_i);
   unsigned int* htab = reinterpret_cast<unsigned int*>(lds_i + tile_cap / 2);
   const unsigned int hmask = (unsigned int)hash_words - 1u;
-  unsigned short* ev = reinterpret_cast<unsigned short*>(lds_i + tile_words);  // [Bv][kBoxEv]  beam << 1 | occupied  (16 bytes a slot, 16-byte aligned)
-  double* val_hot = reinterpret_cast<double*>(lds_i + tile_words + 4 * Bv);    // [64] the value worked out for a hot cell (slot Bv + lane)
-  int* exy = lds_i + tile_words + 4 * Bv + 2 * 64;         // [Bv] end-point cell, x | y << 16
+  // events a slot holds before its cell is replayed exhaustively: 8, and 4 in the four-per-CU form (2 x 360 x 4 bytes less —
+  // what the bench room's 94 x 88 box lacked for a fourth resident workgroup; its cells take 1-3 events each)
+  constexpr int kEv = (NT == 512 && WPS == 8) ? kBoxEvFour : kBoxEv;
+  unsigned short* ev = reinterpret_cast<unsigned short*>(lds_i + tile_words);  // [Bv][kEv]  beam << 1 | occupied  (16 or 8 bytes a slot, aligned)
+  double* val_hot = reinterpret_cast<double*>(lds_i + tile_words + (kEv / 2) * Bv);    // [64] the value worked out for a hot cell (slot Bv + lane)
+  int* exy = lds_i + tile_words + (kEv / 2) * Bv + 2 * 64;         // [Bv] end-point cell, x | y << 16
   unsigned short* ecnt = reinterpret_cast<unsigned short*>(exy + Bv);  // [Bv] events recorded in the slot of beam b — the FIRST beam that ended in its
                                                                        //      cell (0: b opened no slot; may exceed kBoxEv: overflow).  Two counts a dword:
                                                                        //      LDS atomics are 32-bit, a count never reaches 2^16 (one event per beam at most)
   constexpr unsigned int kFlag = 0x80000000u;   // (the flag as the passes below see a cell: C16 cells are widened to this form when read)
-  constexpr int kEv = kBoxEv;
   // C16: the slot of flagged cell t.  claim: the first caller's slot wins and is returned to everybody (one compare-and-swap per
   // probe); find: the cell IS in the table (its flag is set only after its claim).
   auto h_of = [&](int t) { return ((unsigned int)t * 0x9E3779B1u >> 12) & hmask; };
@@ -682,7 +692,7 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
     //    private).  Slots that overflowed are listed on the way.
     const int np = band_cells >> 1;
     const uint2* tile2 = reinterpret_cast<const uint2*>(tile);
-    constexpr int kSl = (NT == 512 && WPS <= 6) ? 6 : 4;  // pairs a thread holds across the passes (512 threads at 6 waves per SIMD: 6 fill the 80 registers exactly — 48.6 vs 50.1 us per 1000 particles; 8 spill; 64 registers: 4)
+    constexpr int kSl = (NT == 512 && WPS <= 6) ? 6 : (NT == 512 ? 5 : 4);  // pairs a thread holds across the passes (512 threads at 6 waves per SIMD: 6 fill the 80 registers exactly — 48.6 vs 50.1 us per 1000 particles; 8 spill; 64 registers: 4)
     double2 v[kSl];
     auto pairs = [&](int first, auto&& fn) {  // fn(i, the pair's two tile words, cx, cy of its first cell), i < kSl
       const int pi0 = first + tid;
@@ -760,13 +770,14 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
       // own beam b0, so bit (beam - b0 + 32) of a 64-bit mask per kind orders them (checked per event; a stray one sends
       // the slot to the exhaustive path).  Beam indices are circular: the bits are walked from the one that stands for the
       // lowest ABSOLUTE beam index.
-      const uint4 raw = *reinterpret_cast<const uint4*>(ev + o * kEv);
-      const unsigned int w4[4] = {raw.x, raw.y, raw.z, raw.w};
+      unsigned int w4[kEv / 2];
+      if constexpr (kEv == 8) { const uint4 raw = *reinterpret_cast<const uint4*>(ev + o * kEv); w4[0] = raw.x; w4[1] = raw.y; w4[2] = raw.z; w4[3] = raw.w; }
+      else { const uint2 raw = *reinterpret_cast<const uint2*>(ev + o * kEv); w4[0] = raw.x; w4[1] = raw.y; }
       const int base = o - 32;
       unsigned long long m_free = 0ull, m_occ = 0ull;
       bool stray = false;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < kEv; ++q) {
         const unsigned int k = (q & 1) ? (w4[q >> 1] >> 16) : (w4[q >> 1] & 0xFFFFu);
         int d = (int)(k >> 1) - base;
         d += d < 0 ? Bv : 0; d -= d >= Bv ? Bv : 0;  // circular distance from base, in [0, Bv)
