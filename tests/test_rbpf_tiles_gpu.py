@@ -183,6 +183,21 @@ def test_box_kernel_residency_forms_are_bit_exact_and_chosen_by_the_boxes_need(g
         pf.close()
     assert not seen[1][0].startswith("rbpf_raycast_box<512, 8") and seen[1][-1] == "rbpf_raycast_box<512, 8, false>", seen[1]   # (no need known at the first launch)
     assert seen[2][-1] == "rbpf_raycast_box<512, 6, false>", seen[2]
+    # the four-per-CU form keeps FOUR events per end-point slot (8 in the others): a corridor whose near walls are 0.3 m away puts
+    # 5-10 beams into one cell, so most slots overflow (more than the 64 the list holds: every slot is scanned) and are replayed
+    # exhaustively — same bits
+    steps, poses = rc.trajectory(n_scans, inc=(0.01, 0.01, 0.05))
+    corridor = (-0.3, 0.35, -1.6, 1.9)
+    scans = [orc.room_scan(poses[s], walls=corridor, rng=rng) for s in range(n_scans)]
+    pf = _dev(gpu_pkg, N=N, k=k, map_min=-10.0, map_max=10.0)
+    hist = []
+    for s, (prev, cur, t_icp, u) in enumerate(steps):
+        assert pf.SLAM(scans[s], u, cur, prev, True, t_icp, orc.normal_stream(70 + s, pf.numNormals(True), 0.0, 1.0)).status == 0
+        hist.append(pf.trace()["new_pose"].copy())
+    assert pf.lastKernelNames()[1] == "rbpf_raycast_box<512, 8, false>", (pf.lastKernelNames(), pf.raycastBoxCells())
+    for m in (0, 11, N - 1):
+        assert np.array_equal(pf.logOdds(m), _oracle_map(grid, None, scans, [h[m] for h in hist])), ("corridor", m)
+    pf.close()
     # a room whose boxes (13 860 cells) leave the 32-bit cell form at TWO workgroups per CU: the 16-bit cell form (slots by table
     # look-up) takes over with four — unless TBNAV_RBPF_OPT_RAYCAST_CELL16 0 forbids it
     steps, poses = rc.trajectory(n_scans, inc=(0.07, 0.02, 0.01))
