@@ -893,18 +893,16 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
       if (first) pairs(first, [&](int i, uint2 w, int cx, int cy) { v[i] = (w.x | w.y) ? *reinterpret_cast<const double2*>(cell_ptr(cx, cy)) : double2{0.0, 0.0}; });
       pairs(first, [&](int i, uint2 w, int cx, int cy) {
         if (!(w.x | w.y)) return;
-        // both cells of the pair in ONE loop (two independent chains of adds, predicated on each cell's count): a few
-        // straight-line instructions instead of a nest of divergent branches and loops per cell
         const bool plain0 = w.x != 0u && !(w.x & kFlag), plain1 = w.y != 0u && !(w.y & kFlag);
         const int c0 = plain0 ? (int)(w.x & 0xFFFFu) : 0, c1 = plain1 ? (int)(w.y & 0xFFFFu) : 0;
         const double o0 = v[i].x, o1 = v[i].y;
         double n0 = o0, n1 = o1;
-        const int cm = c0 > c1 ? c0 : c1;
-        for (int a = 0; a < cm; ++a) {
-          const double t0 = n0 + c.d_free, t1 = n1 + c.d_free;
-          n0 = a < c0 ? t0 : n0;
-          n1 = a < c1 ? t1 : n1;
-        }
+        // (one lean loop per cell — an add, a count, a compare — rather than one predicated loop for both: with four workgroups
+        //  per CU the kernel is bound by VALU issue, not by the latency of a chain of adds: 43.8 -> 41.8 us per 1000 particles)
+#pragma unroll 1
+        for (int a = 0; a < c0; ++a) n0 += c.d_free;
+#pragma unroll 1
+        for (int a = 0; a < c1; ++a) n1 += c.d_free;
         if ((w.x | w.y) & kFlag) {  // an end-point or hot cell takes the value worked out for it
           const int t0c = __mul24(cx - x0, bw) + (cy - miny);   // the pair's first cell in the band's array
           if (w.x & kFlag) n0 = *val_at(C16 ? slot_find(t0c) : (int)((w.x >> 16) & 0x7FFFu));
