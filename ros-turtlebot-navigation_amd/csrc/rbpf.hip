@@ -547,8 +547,8 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens,
   // Residency the launch gets: R workgroups per CU need R x (dynamic + static LDS) <= 160 KB; 4 and 3 per CU are 512-thread
   // workgroups (64 / 80 registers a lane), 2 per CU 1024 threads (64).  Two cell formats: 32-bit words (slot in the word) and,
   // when that buys a higher residency, 16-bit words + a slot table (C16: a few more instructions per walk step).  Measured at
-  // cfg3, N = 1000 / 4000, 32-bit words: 1024 x 2: 55.8 / 191 us; 512 x 2: 54.4 / 199; 512 x 3: 49.1 / 163; in a smaller room
-  // 512 x 3 -> 512 x 4: 46.4 -> 39.7 / 144 -> 130.
+  // cfg3, N = 1000 / 4000, 32-bit words: 1024 x 2: 55.8 / 191 us; 512 x 2: 54.4 / 199; 512 x 3: 47.9 / 163; 512 x 4 (four
+  // events a slot instead of eight: what lets the bench room's 8272-cell boxes in): 41.7 / 143.
   const size_t nz_lds = nz ? sizeof(double) * 2 * kNormChunk : (size_t)0;
   auto fits = [&](int R, size_t bytes) { return (size_t)R * (std::max(bytes, nz_lds) + kBoxStaticLds) <= (size_t)kMaxLds; };
   const bool may4 = h->raycast_adapt != 2 && cap4 > 0 && cap4 <= cap_win;

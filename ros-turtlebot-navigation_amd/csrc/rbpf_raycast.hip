@@ -222,10 +222,10 @@ __device__ __forceinline__ bool on_ray_packed(int x0, int y0, int x1, int y1, in
 // The LDS array holds as many rows of the box as fit (tile_cap words: the host keeps a workgroup under half of the CU's
 // 160 KB so that two are resident); a box with more rows (a long-range scan seen from a rotated pose) is worked through in
 // bands of rows, every phase once per band with the rays clipped to the band.
-// What bounds it (per-wave trace): instruction issue — ~28 k wave-instructions per particle through
-// 16 waves on 4 SIMDs between 9 barriers; memory traffic is the distinct cells once each way.
+// What bounds it: VALU issue — ~18 k VALU wave-instructions per particle; with four workgroups per CU the
+// vector units are busy 29 us of a 42 us launch (SQ_ACTIVE_INST_VALU); memory traffic is the distinct cells once each way.
 // LDS: tile u32[tile_cap] (rows padded to an even number of columns: pair i = words 2i, 2i+1) |
-// ev u16[Bv][kBoxEv] (slot o's first 8 bytes double as its replayed value) | hot-cell values f64[64] | exy i32[Bv] | ecnt u16[Bv]
+// ev u16[Bv][8, or 4 in the four-per-CU form] (slot o's first 8 bytes double as its replayed value) | hot-cell values f64[64] | exy i32[Bv] | ecnt u16[Bv]
 #ifdef TBNAV_PHASE_PROF
 static __device__ unsigned long long g_phase_w[16];
 #endif
