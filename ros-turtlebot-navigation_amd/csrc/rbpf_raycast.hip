@@ -551,7 +551,6 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
     const int en = (int)((o & 1) ? was >> 16 : was & 0xFFFFu);
     if (en < kEv) ev[o * kEv + en] = (unsigned short)what;
   };
-  const int step_r = uni(floor_div_small(2 * nthr, bw)), step_c = 2 * nthr - step_r * bw;  // pair pi + nthr in (row, column) terms
   int n_distinct = 0, n_ends = 0;
   for (int x0 = minx; x0 <= maxx; x0 += rows_fit) {  // one band of rows at a time (one trip unless the box is larger than the LDS array)
     // (per-thread values are re-derived from an opaque copy of the thread index in every trip: hoisted out of this loop they
@@ -703,44 +702,55 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
     __syncthreads();  // every event is recorded
     TRACE_W(7);
     PHASE_STAMP_W(1);
-    // 2. requests and marks in one pass.  The band as PAIRS of cells (16 bytes of a map tile's row, two tile words): pair
-    //    tid + i * nthr for i < 4 — consecutive lanes take consecutive pairs, so a wave's request is whole cache lines.  A
-    //    counted or flagged pair marks its map tile as written and asks for its log-odds from whichever tile the particle's
-    //    table names NOW (shared, private or the zero tile hold the same values: the loads fly while the tiles are made
-    //    private).  Slots that overflowed are listed on the way.
-    const int np = band_cells >> 1;
+    // 2. requests and marks in one pass.  The band as PAIRS of cells (16 bytes of a map tile's row, two tile words), a thread's
+    //    work ITEM a column of kSl pairs: rows j * kSl .. + kSl - 1 of the band, pair column pc — consecutive lanes take consecutive
+    //    pair columns, so a wave's request is whole cache lines, and down the column the address moves by one tile row (256 bytes):
+    //    the map tile is looked up once per item (twice when the column crosses into the next tile row), not once per pair.
+    //    (Pair tid + i * nthr, what this was until round 4, cost 38 of a pair's ~50 vector instructions in row / column
+    //    bookkeeping and address arithmetic — twice per pair, here and in the last pass: 46 % of the kernel's VALU work was
+    //    that pass.)  A counted or flagged pair marks its map tile as written and asks for its log-odds from whichever tile the
+    //    particle's table names NOW (shared, private or the zero tile hold the same values: the loads fly while the tiles are
+    //    made private).  Slots that overflowed are listed on the way.
+    const int PW = bw >> 1;                                                   // pairs in a row of the box
+    // (the columns are cut at ABSOLUTE rows that are multiples of kSl, which divides the tile side: a column never crosses into
+    //  the next tile row; its first and last may stick out of the band)
+    constexpr int kSl = 4;  // pairs a thread holds across the passes
+    const int A0 = x0 & ~(kSl - 1);
+    const int n_items = __mul24(uni(((x0 + nr - 1) >> 2) - (x0 >> 2) + 1), PW);
     const uint2* tile2 = reinterpret_cast<const uint2*>(tile);
-    constexpr int kSl = (NT == 512 && WPS <= 6) ? 6 : (NT == 512 ? 5 : 4);  // pairs a thread holds across the passes (512 threads at 6 waves per SIMD: 6 fill the 80 registers exactly — 48.6 vs 50.1 us per 1000 particles; 8 spill; 64 registers: 4)
     double2 v[kSl];
-    auto pairs = [&](int first, auto&& fn) {  // fn(i, the pair's two tile words, cx, cy of its first cell), i < kSl
-      const int pi0 = first + tid;
-      int row = floor_div_small(2 * (pi0 < np ? pi0 : 0), bw), col = 2 * (pi0 < np ? pi0 : 0) - __mul24(row, bw);  // cell index < 2^16, bw < 2^8
+#pragma unroll
+    for (int i = 0; i < kSl; ++i) v[i] = double2{0.0, 0.0};
+    auto pairs = [&](int first, auto&& fn) {  // fn(i, the pair's two tile words, cx, cy of its first cell, where its log-odds are, its map tile), i < kSl
+      const int q = first + tid;
+      if (q >= n_items) return;
+      const int j = floor_div_small(q, PW), pc = q - __mul24(j, PW);           // items < 2^16, PW < 2^8
+      const int cxb = A0 + kSl * j, cy = miny + 2 * pc;
+      const int mt = map_tile(cxb, cy);
+      double* const ptr = P.lo + (size_t)mt_id[mt] * kTileCells + in_tile(cxb, cy);
+      const int pib = __mul24(cxb - x0, PW) + pc;
 #pragma unroll
       for (int i = 0; i < kSl; ++i) {
-        const int pi = pi0 + i * nthr;
         uint2 w = uint2{0u, 0u};
-        if (pi < np) {
+        if ((unsigned int)(cxb + i - x0) < (unsigned int)nr) {
+          const int pi = pib + i * PW;
           if constexpr (C16) {  // the pair is ONE dword; widened to the 32-bit form's words (flag -> bit 31; the slot is looked up where needed)
             const unsigned int d = tile[pi];
             w.x = (d & 0x7FFFu) | ((d & 0x8000u) << 16);
             w.y = ((d >> 16) & 0x7FFFu) | (d & 0x80000000u);
           } else w = tile2[pi];
         }
-        fn(i, w, x0 + row, miny + col);
-        row += step_r; col += step_c;
-        if (col >= bw) { col -= bw; ++row; }
+        fn(i, w, cxb + i, cy, ptr + i * kTS, mt);
       }
     };
-    pairs(0, [&](int i, uint2 w, int cx, int cy) {
-      v[i] = double2{0.0, 0.0};
+    pairs(0, [&](int i, uint2 w, int, int, double* ptr, int mt) {
       if (w.x | w.y) {
-        const int mt = map_tile(cx, cy);
         mt_touch[mt] = 1;
-        v[i] = *reinterpret_cast<const double2*>(P.lo + (size_t)mt_id[mt] * kTileCells + in_tile(cx, cy));
+        v[i] = *reinterpret_cast<const double2*>(ptr);
       }
     });
-    for (int first = kSl * nthr; first < np; first += kSl * nthr)  // (bands of more than 8 * nthr cells: marks only, their loads follow)
-      pairs(first, [&](int, uint2 w, int cx, int cy) { if (w.x | w.y) mt_touch[map_tile(cx, cy)] = 1; });
+    for (int first = nthr; first < n_items; first += nthr)  // (bands of more than kSl * nthr pairs: marks only, their loads follow)
+      pairs(first, [&](int, uint2 w, int, int, double*, int mt) { if (w.x | w.y) mt_touch[mt] = 1; });
     for (int o = tid; o < Bv; o += nthr) {
       if (ecnt[o] == 0) continue;
       const int e = exy[o];
@@ -907,32 +917,51 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
     // 3c. the pairs: a plain cell adds its count, an end-point or hot cell takes the value worked out for it, an untouched one
     //     keeps its own; the pair goes back as one 16-byte store (the tile is private to the particle and nobody else writes
     //     these cells)
-    for (int first = 0; first < np; first += kSl * nthr) {
-      if (first) pairs(first, [&](int i, uint2 w, int cx, int cy) { v[i] = (w.x | w.y) ? *reinterpret_cast<const double2*>(cell_ptr(cx, cy)) : double2{0.0, 0.0}; });
-      pairs(first, [&](int i, uint2 w, int cx, int cy) {
-        if (!(w.x | w.y)) return;
-        const bool plain0 = w.x != 0u && !(w.x & kFlag), plain1 = w.y != 0u && !(w.y & kFlag);
-        const int c0 = plain0 ? (int)(w.x & 0xFFFFu) : 0, c1 = plain1 ? (int)(w.y & 0xFFFFu) : 0;
-        const double o0 = v[i].x, o1 = v[i].y;
-        double n0 = o0, n1 = o1;
-        // (one lean loop per cell — an add, a count, a compare — rather than one predicated loop for both: with four workgroups
-        //  per CU the kernel is bound by VALU issue, not by the latency of a chain of adds: 43.8 -> 41.8 us per 1000 particles)
-#pragma unroll 1
-        for (int a = 0; a < c0; ++a) n0 += c.d_free;
-#pragma unroll 1
-        for (int a = 0; a < c1; ++a) n1 += c.d_free;
-        if ((w.x | w.y) & kFlag) {  // an end-point or hot cell takes the value worked out for it
-          const int t0c = __mul24(cx - x0, bw) + (cy - miny);   // the pair's first cell in the band's array
-          if (w.x & kFlag) n0 = *val_at(C16 ? slot_find(t0c) : (int)((w.x >> 16) & 0x7FFFu));
-          if (w.y & kFlag) n1 = *val_at(C16 ? slot_find(t0c + 1) : (int)((w.y >> 16) & 0x7FFFu));
+    for (int first = 0; first < n_items; first += nthr) {
+      // v holds this trip's log-odds: asked for in phase 2 (first trip) or, slot by slot, while the PREVIOUS trip's pairs were
+      // worked on — as soon as a pair is stored its register takes the request for the same slot of the thread's next item, so
+      // no trip waits for memory with nothing to do
+      const int qn = first + nthr + tid;
+      const bool next_live = qn < n_items;
+      const int jn = floor_div_small(next_live ? qn : 0, PW), pcn = (next_live ? qn : 0) - __mul24(jn, PW);
+      const int cxbn = A0 + kSl * jn, cyn = miny + 2 * pcn;
+      const double* const ptrn = P.lo + (size_t)mt_id[map_tile(cxbn, cyn)] * kTileCells + in_tile(cxbn, cyn);
+      const int pibn = __mul24(cxbn - x0, PW) + pcn;
+      auto request_next = [&](int i) {
+        double2 nv = double2{0.0, 0.0};
+        if (next_live && (unsigned int)(cxbn + i - x0) < (unsigned int)nr) {
+          bool any;
+          if constexpr (C16) any = tile[pibn + i * PW] != 0u; else { const uint2 wn = tile2[pibn + i * PW]; any = (wn.x | wn.y) != 0u; }
+          if (any) nv = *reinterpret_cast<const double2*>(ptrn + i * kTS);
         }
-        n_distinct += (plain0 ? 1 : 0) + (plain1 ? 1 : 0);
-        *reinterpret_cast<double2*>(cell_ptr(cx, cy)) = double2{n0, n1};
-        const bool tog0 = plain0 && ((o0 >= c.cut_occ) != (n0 >= c.cut_occ)), tog1 = plain1 && ((o1 >= c.cut_occ) != (n1 >= c.cut_occ));
-        if (tog0 | tog1) {
-          if (tog0) toggled(cx, cy, n0 >= c.cut_occ);
-          if (tog1) toggled(cx, cy + 1, n1 >= c.cut_occ);
+        v[i] = nv;
+      };
+      pairs(first, [&](int i, uint2 w, int cx, int cy, double* ptr, int) {
+        if (w.x | w.y) {
+          const bool plain0 = w.x != 0u && !(w.x & kFlag), plain1 = w.y != 0u && !(w.y & kFlag);
+          const int c0 = plain0 ? (int)(w.x & 0xFFFFu) : 0, c1 = plain1 ? (int)(w.y & 0xFFFFu) : 0;
+          const double o0 = v[i].x, o1 = v[i].y;
+          double n0 = o0, n1 = o1;
+          // (one lean loop per cell — an add, a count, a compare — rather than one predicated loop for both: with four workgroups
+          //  per CU the kernel is bound by VALU issue, not by the latency of a chain of adds: 43.8 -> 41.8 us per 1000 particles)
+#pragma unroll 1
+          for (int a = 0; a < c0; ++a) n0 += c.d_free;
+#pragma unroll 1
+          for (int a = 0; a < c1; ++a) n1 += c.d_free;
+          if ((w.x | w.y) & kFlag) {  // an end-point or hot cell takes the value worked out for it
+            const int t0c = __mul24(cx - x0, bw) + (cy - miny);   // the pair's first cell in the band's array
+            if (w.x & kFlag) n0 = *val_at(C16 ? slot_find(t0c) : (int)((w.x >> 16) & 0x7FFFu));
+            if (w.y & kFlag) n1 = *val_at(C16 ? slot_find(t0c + 1) : (int)((w.y >> 16) & 0x7FFFu));
+          }
+          n_distinct += (plain0 ? 1 : 0) + (plain1 ? 1 : 0);
+          *reinterpret_cast<double2*>(ptr) = double2{n0, n1};
+          const bool tog0 = plain0 && ((o0 >= c.cut_occ) != (n0 >= c.cut_occ)), tog1 = plain1 && ((o1 >= c.cut_occ) != (n1 >= c.cut_occ));
+          if (tog0 | tog1) {
+            if (tog0) toggled(cx, cy, n0 >= c.cut_occ);
+            if (tog1) toggled(cx, cy + 1, n1 >= c.cut_occ);
+          }
         }
+        request_next(i);
       });
     }
     PHASE_STAMP_W(5);
