@@ -299,7 +299,7 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
     import bench_profiles as bp
     t_rc = kms["raycast"] * 1e-3   # s per launch, live HIP events
     # the committed profiler rows of exactly this instantiation and grid (N particles' workgroups + the normalise workgroup)
-    def _threads(name):   # "rbpf_raycast_box<512, 6, false>" -> 512
+    def _threads(name):   # "rbpf_raycast_box<512, 6, false, 8>" -> 512
         return int(name.split("<")[1].rstrip(">").split(",")[0])
     rp_row = None
     if "<" in k_raycast and N == 1000:   # the grid of THIS workload: N particles' workgroups (+ the normalise workgroup when it rode along)

@@ -314,7 +314,8 @@ int tbnav_rbpf_particle_map(tbnav_rbpf* h, int32_t particle, int8_t* map);
  *                                the kernel reports it through mapped memory: less LDS per workgroup = three — or, when need + 256 words fits a
  *                                quarter of a CU's LDS, FOUR — workgroups per CU instead of two; a box that outgrows the guess takes a second
  *                                band; the four-per-CU form lists 4 events per end-point cell instead of 8 before it replays the cell against
- *                                every beam); 2 = as 1 but never the four-per-CU form (A-B runs); 0 = by the scan's longest beam in every direction.
+ *                                every beam — and only where a box does not fit four per CU with 8); 2 = as 1 but never the four-per-CU form (A-B
+ *                                runs); 3 = as 1 with the 4-event lists wherever four fit (tests); 0 = by the scan's longest beam in every direction.
  *                                TBNAV_RBPF_OPT_RAYCAST_THREADS 0 = 512 threads when three workgroups fit a CU's LDS, else 1024 (default).
  * TBNAV_RBPF_OPT_RAYCAST_CELL16  rbpf_raycast_box's 16-bit cell form (half the LDS per cell of the box, slots by table look-up): 1 = where it lets
  *                                more workgroups share a CU than the 32-bit form (default), 0 = never, 2 = wherever it can run (tests, A-B).

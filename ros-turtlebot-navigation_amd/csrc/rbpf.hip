@@ -103,7 +103,7 @@ struct tbnav_rbpf {
   std::vector<double2> beams_tmp;
   int raycast_band_rows = 0;   // > 0: cap the LDS array of rbpf_raycast_box at about this many box rows (TBNAV_RBPF_OPT_RAYCAST_BAND_ROWS, tests)
   int raycast_cell16 = 1;      // 0: never the 16-bit cell form; 1: where it buys a higher residency (default); 2: wherever it can run (TBNAV_RBPF_OPT_RAYCAST_CELL16)
-  int lk_raycast = -1, lk_raycast_wps = 0, lk_raycast_c16 = 0, lk_raycast_grid = 0, lk_propose = 0, lk_box_need = 0, lk_box_cap = 0;  // the instantiations the last launches were (tbnav_rbpf_last_kernel_names): raycast threads (0 = beam-ordered), its workgroups, propose threads
+  int lk_raycast = -1, lk_raycast_wps = 0, lk_raycast_c16 = 0, lk_raycast_ev = 8, lk_raycast_grid = 0, lk_propose = 0, lk_box_need = 0, lk_box_cap = 0;  // the instantiations the last launches were (tbnav_rbpf_last_kernel_names): raycast threads (0 = beam-ordered), its workgroups, propose threads
   int raycast_form = 0;        // 0 = box counters (rbpf_raycast_box), 1 = the beam-ordered kernel (rbpf_raycast) (TBNAV_RBPF_OPT_RAYCAST_FORM)
   double* d_sens = nullptr;    // [N][4] sensor transform (X, Y, sin, cos) of each particle's new pose, left by the proposal kernel
   uint64_t seed = 0x5EEDull, scan_index = 0;  // device noise source (normals == NULL)
@@ -560,13 +560,18 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens,
   //  same-dword collisions of the LDS adds where rays converge, the sub-word arithmetic of every step — so going from three to
   //  four per CU with it loses, 51.5 against 49.8 us, and it is used only where the 32-bit form is stuck at TWO per CU: the
   //  SURVEY room's 13 860-cell boxes, 63.7 -> 60.7 us)
-  if (pick && may4 && fits(4, box_lds_bytes((size_t)cap4, (size_t)bvn, kBoxEvFour))) { nt = 512; cap_win = cap4; }
+  // (four per CU: with eight events a slot where they fit, with four where only they do — measured in a 3 x 1.9 m room whose cells take
+  //  5-10 events: 39.4 us with four-event slots against 37.7 with three workgroups per CU and eight)
+  size_t ev_slot = kBoxEv;  // (what the instantiation launched below holds per slot)
+  const bool force4 = h->raycast_adapt == 3;  // (tests: four-event slots wherever four workgroups fit)
+  if (pick && may4 && !force4 && fits(4, box_lds_bytes((size_t)cap4, (size_t)bvn, kBoxEv))) { nt = 512; cap_win = cap4; }
+  else if (pick && may4 && fits(4, box_lds_bytes((size_t)cap4, (size_t)bvn, kBoxEvFour))) { nt = 512; cap_win = cap4; ev_slot = kBoxEvFour; }
   else if (pick && cap_win > 0 && fits(3, box_lds_bytes((size_t)cap_win, (size_t)bvn))) { nt = 512; wps = 6; }
-  else if (pick && may4 && c16_ok && fits(4, box16_lds_bytes((size_t)cap4, (size_t)bvn, kBoxEvFour))) { nt = 512; cap_win = cap4; c16 = true; }
+  else if (pick && may4 && c16_ok && fits(4, box16_lds_bytes((size_t)cap4, (size_t)bvn, kBoxEv))) { nt = 512; cap_win = cap4; c16 = true; }
+  else if (pick && may4 && c16_ok && fits(4, box16_lds_bytes((size_t)cap4, (size_t)bvn, kBoxEvFour))) { nt = 512; cap_win = cap4; c16 = true; ev_slot = kBoxEvFour; }
   else if (pick && c16_ok && fits(3, box16_lds_bytes((size_t)cap_win, (size_t)bvn))) { nt = 512; wps = 6; c16 = true; }
   else if (nt == 512) wps = 6;
   if (h->raycast_cell16 == 2 && c16_ok && nt == 512) c16 = true;   // (tests / A-B: the 16-bit form wherever it can run)
-  const size_t ev_slot = (nt == 512 && wps == 8) ? kBoxEvFour : kBoxEv;  // (what the instantiation launched below holds per slot)
   const size_t lds_win = c16 ? box16_lds_bytes((size_t)cap_win, (size_t)bvn, ev_slot) : box_lds_bytes((size_t)cap_win, (size_t)bvn, ev_slot);
   if (cap_win > 0 && !h->ref_field && c.Bv < 32768 - kWave && h->raycast_form == 0 && nt >= 512 && lds_win <= (size_t)kMaxLds - 4096) {
     // default: box counters (rbpf_raycast_box)
@@ -575,16 +580,19 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens,
     const int blocks = count + (nz ? 1 : 0);
     const size_t lds_launch = nz ? std::max(lds_win, sizeof(double) * 2 * kNormChunk) : lds_win;  // (workgroup 0's two arrays)
     const int need_slot = (int)(h->rc_launches++ % 3u);
-    h->lk_raycast = nt == 512 ? 512 : 1024; h->lk_raycast_wps = wps; h->lk_raycast_c16 = c16 ? 1 : 0; h->lk_raycast_grid = blocks;
+    h->lk_raycast = nt == 512 ? 512 : 1024; h->lk_raycast_wps = wps; h->lk_raycast_c16 = c16 ? 1 : 0; h->lk_raycast_ev = (int)ev_slot; h->lk_raycast_grid = blocks;
     h->lk_box_cap = (int)cap_win; h->lk_box_need = (h->raycast_adapt && h->h_box_need) ? *reinterpret_cast<volatile int*>(h->h_box_need) : 0;
     const int hash_words = c16 ? (int)box16_hash_words((size_t)bvn) : 0;
-#define TBNAV_BOX(NT_, WPS_, C16_) hipLaunchKernelGGL((rbpf_raycast_box<NT_, WPS_, C16_>), dim3(blocks), dim3(NT_), lds_launch, st, c, h->pool, M, beams_dev, sp.pose, sens, \
+#define TBNAV_BOX(NT_, WPS_, C16_, EV_) hipLaunchKernelGGL((rbpf_raycast_box<NT_, WPS_, C16_, EV_>), dim3(blocks), dim3(NT_), lds_launch, st, c, h->pool, M, beams_dev, sp.pose, sens, \
                                                 h->d_trow[h->cur], h->d_nocc[h->cur], err, (int)cap_win, touched, na, h->d_box_need, h->d_box_need_host, need_slot, hash_words)
-    if (nt == 512 && wps == 8 && c16) TBNAV_BOX(512, 8, true);
-    else if (nt == 512 && wps == 8) TBNAV_BOX(512, 8, false);
-    else if (nt == 512 && c16) TBNAV_BOX(512, 6, true);
-    else if (nt == 512) TBNAV_BOX(512, 6, false);
-    else TBNAV_BOX(1024, 8, false);
+    const bool ev4 = ev_slot == (size_t)kBoxEvFour;
+    if (nt == 512 && wps == 8 && c16 && ev4) TBNAV_BOX(512, 8, true, 4);
+    else if (nt == 512 && wps == 8 && c16) TBNAV_BOX(512, 8, true, 8);
+    else if (nt == 512 && wps == 8 && ev4) TBNAV_BOX(512, 8, false, 4);
+    else if (nt == 512 && wps == 8) TBNAV_BOX(512, 8, false, 8);
+    else if (nt == 512 && c16) TBNAV_BOX(512, 6, true, 8);
+    else if (nt == 512) TBNAV_BOX(512, 6, false, 8);
+    else TBNAV_BOX(1024, 8, false, 8);
 #undef TBNAV_BOX
     TBNAV_HIP(hipGetLastError());
     return TBNAV_OK;
@@ -1059,11 +1067,13 @@ int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf*
                   : hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_edt<32>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
   // (2.3 KB of static LDS: the embedded normalise's scan scratch)
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_box<1024, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 4096);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_box<512, 6, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 4096);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_box<512, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 4096);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_box<512, 6, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 4096);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_box<512, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 4096);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_box<512, 6, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 4096);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_box<512, 6, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 4096);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_box<512, 8, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 4096);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_box<512, 8, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 4096);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_box<512, 8, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 4096);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_box<512, 8, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 4096);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_box<1024, 8, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 4096);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 1024);
   // the proposal / scan-match kernels carry the scan, the per-sample data and the bitmap slice: more than the 64 KB
   // default for long scans or many samples
@@ -2310,7 +2320,7 @@ int tbnav_rbpf_set_option(tbnav_rbpf* h, int32_t option, int32_t value) {
       h->raycast_cell16 = value;
       return TBNAV_OK;
     case TBNAV_RBPF_OPT_RAYCAST_ADAPT:
-      if (value < 0 || value > 2) return TBNAV_ERR_INVALID_ARG;
+      if (value < 0 || value > 3) return TBNAV_ERR_INVALID_ARG;
       h->raycast_adapt = value;
       return TBNAV_OK;
     case TBNAV_RBPF_OPT_BATCH_PIPELINE:
@@ -2362,7 +2372,7 @@ int tbnav_rbpf_last_kernel_names(const tbnav_rbpf* h, char* propose, int32_t pro
   if (!h) return TBNAV_ERR_INVALID_ARG;
   if (propose && propose_cap > 0) { if (h->lk_propose) snprintf(propose, (size_t)propose_cap, "rbpf_propose<%d>", h->lk_propose); else propose[0] = 0; }
   if (raycast && raycast_cap > 0) {
-    if (h->lk_raycast > 0) snprintf(raycast, (size_t)raycast_cap, "rbpf_raycast_box<%d, %d, %s>", h->lk_raycast, h->lk_raycast_wps, h->lk_raycast_c16 ? "true" : "false");
+    if (h->lk_raycast > 0) snprintf(raycast, (size_t)raycast_cap, "rbpf_raycast_box<%d, %d, %s, %d>", h->lk_raycast, h->lk_raycast_wps, h->lk_raycast_c16 ? "true" : "false", h->lk_raycast_ev);
     else if (h->lk_raycast == 0) snprintf(raycast, (size_t)raycast_cap, "rbpf_raycast");
     else raycast[0] = 0;
   }

@@ -545,7 +545,7 @@ __global__ __launch_bounds__(256) void rbpf_normalize(int N, const double* __res
                                                       unsigned int* seq = nullptr, unsigned int seq_val = 0,
                                                       int* __restrict__ children = nullptr);
 // rbpf_raycast.hip
-template <int NT, int WPS, bool C16>
+template <int NT, int WPS, bool C16, int EV>
 __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P, MapT M, const double2* __restrict__ beams,
                                                           const double* __restrict__ pose, const double* __restrict__ sens,
                                                           int* __restrict__ trow_occ, int* __restrict__ n_occ, int* __restrict__ err,

@@ -368,7 +368,7 @@ __global__ __launch_bounds__(512) void rbpf_warm_scratch(int* sink, int n) {
   for (int i = 0; i < kWarmScratchInts; ++i) a[i] = i + n;
   if (n == 0x7ead) sink[0] = a[(threadIdx.x + n) % kWarmScratchInts];  // (never: keeps the array alive and dynamically indexed)
 }
-template <int NT, int WPS, bool C16>
+template <int NT, int WPS, bool C16, int EV>
 __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P, MapT M, const double2* __restrict__ beams,
                                                           const double* __restrict__ pose, const double* __restrict__ sens,
                                                           int* __restrict__ trow_occ, int* __restrict__ n_occ, int* __restrict__ err,
@@ -399,9 +399,11 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
   unsigned short* tile16 = reinterpret_cast<unsigned short*>(lds_i);
   unsigned int* htab = reinterpret_cast<unsigned int*>(lds_i + tile_cap / 2);
   const unsigned int hmask = (unsigned int)hash_words - 1u;
-  // events a slot holds before its cell is replayed exhaustively: 8, and 4 in the four-per-CU form (2 x 360 x 4 bytes less —
-  // what the bench room's 94 x 88 box lacked for a fourth resident workgroup; its cells take 1-3 events each)
-  constexpr int kEv = (NT == 512 && WPS == 8) ? kBoxEvFour : kBoxEv;
+  // events a slot holds before its cell is replayed exhaustively: 8 — or 4 where that is what lets a FOURTH workgroup share
+  // the CU (2 x 360 x 4 bytes less: what the bench room's 94 x 88 box lacked; its cells take 1-3 events each.  Not where 8 fit as
+  // well: a corridor's cells take 5-10 events, and replaying most slots exhaustively costs more than the residency buys)
+  static_assert(EV == kBoxEv || EV == kBoxEvFour, "8 or 4 events a slot");
+  constexpr int kEv = EV;
   unsigned short* ev = reinterpret_cast<unsigned short*>(lds_i + tile_words);  // [Bv][kEv]  beam << 1 | occupied  (16 or 8 bytes a slot, aligned)
   double* val_hot = reinterpret_cast<double*>(lds_i + tile_words + (kEv / 2) * Bv);    // [64] the value worked out for a hot cell (slot Bv + lane)
   int* exy = lds_i + tile_words + (kEv / 2) * Bv + 2 * 64;         // [Bv] end-point cell, x | y << 16
@@ -991,11 +993,13 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
 #endif
   WG_OUT();
 }
-template __global__ void rbpf_raycast_box<512, 6, false>(ScanC, TilePool, MapT, const double2* __restrict__, const double* __restrict__, const double* __restrict__, int* __restrict__, int* __restrict__, int* __restrict__, int, unsigned long long* __restrict__, NormArgs, int* __restrict__, int* __restrict__, int, int);
-template __global__ void rbpf_raycast_box<512, 6, true>(ScanC, TilePool, MapT, const double2* __restrict__, const double* __restrict__, const double* __restrict__, int* __restrict__, int* __restrict__, int* __restrict__, int, unsigned long long* __restrict__, NormArgs, int* __restrict__, int* __restrict__, int, int);
-template __global__ void rbpf_raycast_box<512, 8, false>(ScanC, TilePool, MapT, const double2* __restrict__, const double* __restrict__, const double* __restrict__, int* __restrict__, int* __restrict__, int* __restrict__, int, unsigned long long* __restrict__, NormArgs, int* __restrict__, int* __restrict__, int, int);
-template __global__ void rbpf_raycast_box<512, 8, true>(ScanC, TilePool, MapT, const double2* __restrict__, const double* __restrict__, const double* __restrict__, int* __restrict__, int* __restrict__, int* __restrict__, int, unsigned long long* __restrict__, NormArgs, int* __restrict__, int* __restrict__, int, int);
-template __global__ void rbpf_raycast_box<1024, 8, false>(ScanC, TilePool, MapT, const double2* __restrict__, const double* __restrict__, const double* __restrict__, int* __restrict__, int* __restrict__, int* __restrict__, int, unsigned long long* __restrict__, NormArgs, int* __restrict__, int* __restrict__, int, int);
+template __global__ void rbpf_raycast_box<512, 6, false, 8>(ScanC, TilePool, MapT, const double2* __restrict__, const double* __restrict__, const double* __restrict__, int* __restrict__, int* __restrict__, int* __restrict__, int, unsigned long long* __restrict__, NormArgs, int* __restrict__, int* __restrict__, int, int);
+template __global__ void rbpf_raycast_box<512, 6, true, 8>(ScanC, TilePool, MapT, const double2* __restrict__, const double* __restrict__, const double* __restrict__, int* __restrict__, int* __restrict__, int* __restrict__, int, unsigned long long* __restrict__, NormArgs, int* __restrict__, int* __restrict__, int, int);
+template __global__ void rbpf_raycast_box<512, 8, false, 8>(ScanC, TilePool, MapT, const double2* __restrict__, const double* __restrict__, const double* __restrict__, int* __restrict__, int* __restrict__, int* __restrict__, int, unsigned long long* __restrict__, NormArgs, int* __restrict__, int* __restrict__, int, int);
+template __global__ void rbpf_raycast_box<512, 8, false, 4>(ScanC, TilePool, MapT, const double2* __restrict__, const double* __restrict__, const double* __restrict__, int* __restrict__, int* __restrict__, int* __restrict__, int, unsigned long long* __restrict__, NormArgs, int* __restrict__, int* __restrict__, int, int);
+template __global__ void rbpf_raycast_box<512, 8, true, 8>(ScanC, TilePool, MapT, const double2* __restrict__, const double* __restrict__, const double* __restrict__, int* __restrict__, int* __restrict__, int* __restrict__, int, unsigned long long* __restrict__, NormArgs, int* __restrict__, int* __restrict__, int, int);
+template __global__ void rbpf_raycast_box<512, 8, true, 4>(ScanC, TilePool, MapT, const double2* __restrict__, const double* __restrict__, const double* __restrict__, int* __restrict__, int* __restrict__, int* __restrict__, int, unsigned long long* __restrict__, NormArgs, int* __restrict__, int* __restrict__, int, int);
+template __global__ void rbpf_raycast_box<1024, 8, false, 8>(ScanC, TilePool, MapT, const double2* __restrict__, const double* __restrict__, const double* __restrict__, int* __restrict__, int* __restrict__, int* __restrict__, int, unsigned long long* __restrict__, NormArgs, int* __restrict__, int* __restrict__, int, int);
 
 }  // namespace tbnav_rk
 

@@ -1,5 +1,5 @@
 """A-B of rbpf_raycast_box's residency on the bench workload: TBNAV_RBPF_OPT_RAYCAST_ADAPT 1 (four 512-thread workgroups per CU when the
-boxes fit) against 2 (at most three) — kernel time from HIP events and which instantiation ran."""
+boxes fit) against 2 (at most three) and 3 (four-event slots wherever four fit) — kernel time from HIP events and which instantiation ran."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -18,7 +18,7 @@ if os.environ.get("WALLS"):   # e.g. WALLS=-2.0,2.0,-1.8,1.8: a room whose box f
     rng = np.random.default_rng(7)
     scans = [bench_rbpf._room_scan(poses[s], rng, walls) for s in range(16)]
 for N in [int(a) for a in sys.argv[1:]] or [1000, 2000, 4000]:
-    for adapt, cell16 in ((2, 0), (1, 0), (1, 1), (2, 0), (1, 0), (1, 1), (2, 2)):
+    for adapt, cell16 in ((2, 0), (1, 0), (3, 0), (2, 0), (1, 0), (3, 0), (1, 1), (2, 2)):
         pf = ParticleFilter(default_params(N=N, k=50, map_min=-10.0, map_max=10.0))
         pf.setSeed(1); pf.setTiming(True); pf.setOption(capi.RBPF_OPT_RAYCAST_ADAPT, adapt); pf.setOption(capi.RBPF_OPT_RAYCAST_CELL16, cell16)
         acc, n = 0.0, 0
