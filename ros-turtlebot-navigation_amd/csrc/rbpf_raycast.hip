@@ -634,7 +634,6 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
         int at = kCellBytes * (__mul24((pr.ymajor ? pr.xa + sc : pr.xa + n) - x0, bw) + ((pr.ymajor ? pr.ya + n : pr.ya + sc) - miny));
         const int d_major = kCellBytes * (pr.ymajor ? 1 : bw);
         const int d_both = d_major + kCellBytes * (pr.ymajor ? bw : 1) * (pr.neg ? -1 : 1);
-#ifndef TBNAV_WALK_INT
         // The error term in fixed point: x = rem / two_dmaj in (0, 1] is kept as acc = x * 2^32 - 1 - slack, a step adds
         // F = dmin / dmaj * 2^32 - slack', and the add's CARRY is the step across the ray (rem + two_dmin > two_dmaj) — an add, a select
         // and an add per cell instead of six instructions; with four workgroups per CU the kernel is bound by VALU issue.  Exact:
@@ -650,14 +649,6 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
           acc = nxt;
           at += side ? d_both : d_major;
         };
-#else
-        auto advance = [&]() {
-          const int r2 = rem + two_dmin;
-          const bool side = r2 > two_dmaj;
-          rem = side ? r2 - two_dmaj : r2;
-          at += side ? d_both : d_major;
-        };
-#endif
         if (n == 0) { ++n_first; advance(); ++n; }  // position 0 is the robot's cell (or, for a reversed ray, the end point): counted below
         char* const tile_b = reinterpret_cast<char*>(tile);
         // What an add returns is looked at TWO steps later, while the next two adds are in flight: three registers take turns
