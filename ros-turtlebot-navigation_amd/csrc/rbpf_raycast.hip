@@ -780,57 +780,70 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
       const bool was = v0o >= c.cut_occ, now = vv >= c.cut_occ;
       if (was != now) toggled(cx, cy, now);
     };
-    // 3a. end-point cells whose slot holds every event: one lane each, the events sorted by beam in registers (a
-    //     19-comparator network on the 8 sixteen-bit entries; an empty entry sorts last) and applied in that order
+    // 3a. end-point cells whose slot holds every event: one lane each, the events applied in beam order
     for (int o = tid; o < Bv; o += nthr) {
       const int ne = ecnt[o];
       if (ne == 0 || ne > kEv) continue;
       const int e = exy[o], cx = e & 0xFFFF, cy = e >> 16;
       const double v0o = *cell_ptr(cx, cy);
-      // the events in beam order without sorting: every beam that reaches the cell lies within a few beams of the slot's
-      // own beam b0, so bit (beam - b0 + 32) of a 64-bit mask per kind orders them (checked per event; a stray one sends
-      // the slot to the exhaustive path).  Beam indices are circular: the bits are walked from the one that stands for the
-      // lowest ABSOLUTE beam index.
-      unsigned int w4[kEv / 2];
-      if constexpr (kEv == 8) { const uint4 raw = *reinterpret_cast<const uint4*>(ev + o * kEv); w4[0] = raw.x; w4[1] = raw.y; w4[2] = raw.z; w4[3] = raw.w; }
-      else { const uint2 raw = *reinterpret_cast<const uint2*>(ev + o * kEv); w4[0] = raw.x; w4[1] = raw.y; }
-      const int base = o - 32;
-      unsigned long long m_free = 0ull, m_occ = 0ull;
-      bool stray = false;
-#pragma unroll
-      for (int q = 0; q < kEv; ++q) {
-        const unsigned int k = (q & 1) ? (w4[q >> 1] >> 16) : (w4[q >> 1] & 0xFFFFu);
-        int d = (int)(k >> 1) - base;
-        d += d < 0 ? Bv : 0; d -= d >= Bv ? Bv : 0;  // circular distance from base, in [0, Bv)
-        const bool valid = q < ne;
-        stray |= valid && d > 63;
-        const unsigned long long bit = valid ? 1ull << (d & 63) : 0ull;
-        if (k & 1u) m_occ |= bit; else m_free |= bit;
-      }
-      // absolute beam of bit d is base + d (mod Bv): bits from d0 = (base < 0 ? -base : (base + 63 >= Bv ? Bv - base : 0)) up are
-      // the low absolute indices when the window wraps
-      int d0 = 0;
-      if (base < 0) d0 = -base; else if (base + 63 >= Bv) d0 = Bv - base;
-      d0 = d0 > 63 ? 0 : d0;
       double vv = v0o;
-      if (!stray) {
-#pragma unroll 1
-        for (int part = 0; part < 2; ++part) {
-          const unsigned long long keep = part == 0 ? ~0ull << d0 : ~(~0ull << d0);
-          unsigned long long m = (m_free | m_occ) & keep;
-          while (m) {
-            const int bit = __ffsll((long long)m) - 1;
-            vv += ((m_occ >> bit) & 1ull) ? c.d_occ : c.d_free;
-            m &= m - 1;
-          }
+      if constexpr (kEv == 4) {
+        // four events: sorted by (beam, kind) in registers — five compare-exchanges on the 16-bit entries, an empty entry last — and
+        // applied in that order (the reference's: ascending beam)
+        const uint2 raw = *reinterpret_cast<const uint2*>(ev + o * kEv);
+        unsigned int k0 = raw.x & 0xFFFFu, k1 = raw.x >> 16, k2 = raw.y & 0xFFFFu, k3 = raw.y >> 16;
+        k1 = ne > 1 ? k1 : 0xFFFFu; k2 = ne > 2 ? k2 : 0xFFFFu; k3 = ne > 3 ? k3 : 0xFFFFu;
+        auto cx2 = [](unsigned int& a, unsigned int& b) { const unsigned int lo = a < b ? a : b, hi = a < b ? b : a; a = lo; b = hi; };
+        cx2(k0, k1); cx2(k2, k3); cx2(k0, k2); cx2(k1, k3); cx2(k1, k2);
+        vv += (k0 & 1u) ? c.d_occ : c.d_free;
+        if (k1 != 0xFFFFu) vv += (k1 & 1u) ? c.d_occ : c.d_free;
+        if (k2 != 0xFFFFu) vv += (k2 & 1u) ? c.d_occ : c.d_free;
+        if (k3 != 0xFFFFu) vv += (k3 & 1u) ? c.d_occ : c.d_free;
+      } else {
+        // the events in beam order without sorting: every beam that reaches the cell lies within a few beams of the slot's
+        // own beam b0, so bit (beam - b0 + 32) of a 64-bit mask per kind orders them (checked per event; a stray one sends
+        // the slot to the exhaustive path).  Beam indices are circular: the bits are walked from the one that stands for the
+        // lowest ABSOLUTE beam index.
+        unsigned int w4[kEv / 2];
+        if constexpr (kEv == 8) { const uint4 raw = *reinterpret_cast<const uint4*>(ev + o * kEv); w4[0] = raw.x; w4[1] = raw.y; w4[2] = raw.z; w4[3] = raw.w; }
+        else { const uint2 raw = *reinterpret_cast<const uint2*>(ev + o * kEv); w4[0] = raw.x; w4[1] = raw.y; }
+        const int base = o - 32;
+        unsigned long long m_free = 0ull, m_occ = 0ull;
+        bool stray = false;
+#pragma unroll
+        for (int q = 0; q < kEv; ++q) {
+          const unsigned int k = (q & 1) ? (w4[q >> 1] >> 16) : (w4[q >> 1] & 0xFFFFu);
+          int d = (int)(k >> 1) - base;
+          d += d < 0 ? Bv : 0; d -= d >= Bv ? Bv : 0;  // circular distance from base, in [0, Bv)
+          const bool valid = q < ne;
+          stray |= valid && d > 63;
+          const unsigned long long bit = valid ? 1ull << (d & 63) : 0ull;
+          if (k & 1u) m_occ |= bit; else m_free |= bit;
         }
-      } else {  // (never seen: an event more than 31 beams from the slot's own) selection by ascending beam from LDS
-        int last = -1;
-        for (int i = 0; i < ne; ++i) {
-          int best = 0x10000;
-          for (int j = 0; j < ne; ++j) { const int k = ev[o * kEv + j]; if (k > last && k < best) best = k; }
-          vv += (best & 1) ? c.d_occ : c.d_free;
-          last = best;
+        // absolute beam of bit d is base + d (mod Bv): bits from d0 = (base < 0 ? -base : (base + 63 >= Bv ? Bv - base : 0)) up are
+        // the low absolute indices when the window wraps
+        int d0 = 0;
+        if (base < 0) d0 = -base; else if (base + 63 >= Bv) d0 = Bv - base;
+        d0 = d0 > 63 ? 0 : d0;
+        if (!stray) {
+#pragma unroll 1
+          for (int part = 0; part < 2; ++part) {
+            const unsigned long long keep = part == 0 ? ~0ull << d0 : ~(~0ull << d0);
+            unsigned long long m = (m_free | m_occ) & keep;
+            while (m) {
+              const int bit = __ffsll((long long)m) - 1;
+              vv += ((m_occ >> bit) & 1ull) ? c.d_occ : c.d_free;
+              m &= m - 1;
+            }
+          }
+        } else {  // (never seen: an event more than 31 beams from the slot's own) selection by ascending beam from LDS
+          int last = -1;
+          for (int i = 0; i < ne; ++i) {
+            int best = 0x10000;
+            for (int j = 0; j < ne; ++j) { const int k = ev[o * kEv + j]; if (k > last && k < best) best = k; }
+            vv += (best & 1) ? c.d_occ : c.d_free;
+            last = best;
+          }
         }
       }
       ++n_ends;
