@@ -707,9 +707,10 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
     const int PW = bw >> 1;                                                   // pairs in a row of the box
     // (the columns are cut at ABSOLUTE rows that are multiples of kSl, which divides the tile side: a column never crosses into
     //  the next tile row; its first and last may stick out of the band)
-    constexpr int kSl = 4;  // pairs a thread holds across the passes
+    constexpr int kSl = 4, kSlSh = 2;  // pairs a thread holds across the passes
+    static_assert((1 << kSlSh) == kSl && kTS % kSl == 0, "a column of pairs never crosses a tile row");
     const int A0 = x0 & ~(kSl - 1);
-    const int n_items = __mul24(uni(((x0 + nr - 1) >> 2) - (x0 >> 2) + 1), PW);
+    const int n_items = __mul24(uni(((x0 + nr - 1) >> kSlSh) - (x0 >> kSlSh) + 1), PW);
     const uint2* tile2 = reinterpret_cast<const uint2*>(tile);
     double2 v[kSl];
 #pragma unroll
