@@ -216,6 +216,31 @@ def test_box_kernel_residency_forms_are_bit_exact_and_chosen_by_the_boxes_need(g
         pf.close()
 
 
+def test_a_box_that_outgrows_the_four_per_cu_array_is_worked_through_in_bands(gpu_pkg):
+    """The four-per-CU form sizes its LDS array by what the boxes needed in the last scans plus three rows or so.  When the next
+    scan's boxes are much larger (the robot leaves a small room for a hall), the launch still runs with the small array: every
+    particle's box goes through in bands of rows, rays clipped per band — same bits as the oracle's GridMapper — and the array
+    follows the need from the next launch on."""
+    from rtn_amd import capi
+    N, k, n_scans = 24, 6, 7
+    steps, poses = rc.trajectory(n_scans, inc=(0.05, 0.04, 0.03))
+    rng = np.random.default_rng(21)
+    scans = [orc.room_scan(poses[s], walls=rc.ROOM_SMALL if s < 4 else rc.ROOM_SURVEY, rng=rng) for s in range(n_scans)]
+    pf = _dev(gpu_pkg, N=N, k=k, map_min=-10.0, map_max=10.0)
+    hist, names, cells = [], [], []
+    for s, (prev, cur, t_icp, u) in enumerate(steps):
+        assert pf.SLAM(scans[s], u, cur, prev, True, t_icp, orc.normal_stream(40 + s, pf.numNormals(True), 0.0, 1.0)).status == 0
+        hist.append(pf.trace()["new_pose"].copy())
+        names.append(pf.lastKernelNames()[1]); cells.append(pf.raycastBoxCells())
+    # scan 4: the hall's boxes (several times the small room's cells) met the array sized for the small room
+    assert names[4].startswith("rbpf_raycast_box<512, 8, false"), names
+    assert cells[4][1] < 0.6 * max(c[0] for c in cells[5:]), cells
+    grid = (0.05, -10.0, 10.0, -10.0, 10.0)
+    for m in (0, 11, N - 1):
+        assert np.array_equal(pf.logOdds(m), _oracle_map(grid, None, scans, [h[m] for h in hist])), m
+    pf.close()
+
+
 def test_batched_export_equals_single_exports_and_imports_rebuild_the_particles(gpu_pkg):
     """tbnav_rbpf_export_batch_dev writes exactly the blobs tbnav_rbpf_export_particle_dev writes, back to back (a slot listed
     twice included); tbnav_rbpf_import_batch_dev into ANOTHER handle rebuilds pose / weight / map / occupied counts of every
