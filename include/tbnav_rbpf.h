@@ -348,12 +348,13 @@ int tbnav_rbpf_last_kernel_ms(tbnav_rbpf* h, float ms[TBNAV_RBPF_NKERNELS]);
  * not small next to the kernels), so they are recorded only after tbnav_rbpf_set_timing(h, 1); off by default,
  * in which case last_kernel_ms reports zeros. */
 int tbnav_rbpf_set_timing(tbnav_rbpf* h, int32_t enable);
-/* Names of the instantiations the handle's LAST proposal and map-update launches were, as a profiler prints them
- * ("rbpf_propose<256>", "rbpf_raycast_box<512>", "rbpf_raycast"), and the map update's workgroup count (particles + 1 when the
- * normalise / select workgroup rode in its launch): lets a benchmark line point at one row of a rocprofv3 --stats summary. */
 /* rbpf_raycast_box's LDS array at the last map update: the cells the particles' bounding boxes needed lately (0: not known yet or
  * TBNAV_RBPF_OPT_RAYCAST_ADAPT 0) and the cells the launch's array held (what decides two / three / four workgroups per CU). */
 int tbnav_rbpf_raycast_box_cells(const tbnav_rbpf* h, int32_t* need_cells, int32_t* array_cells);
+/* Names of the instantiations the handle's LAST proposal and map-update launches were, as a profiler prints them
+ * ("rbpf_propose<256>"; "rbpf_raycast_box<512, 8, false, 4>" = threads, waves per SIMD, 16-bit cells, events per end-point slot; "rbpf_raycast"),
+ * and the map update's workgroup count (particles + 1 when the normalise / select workgroup rode in its launch): lets a benchmark
+ * line point at one row of a rocprofv3 --stats summary. */
 int tbnav_rbpf_last_kernel_names(const tbnav_rbpf* h, char* propose, int32_t propose_cap, char* raycast, int32_t raycast_cap,
                                  int32_t* raycast_workgroups);
 
