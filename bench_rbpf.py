@@ -24,8 +24,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 HBM_PEAK_GBS = 8000.0
-ROOM_BENCH = (-2.2, 2.2, -2.0, 2.0)   # every corner < 3.4 m from every pose of the trajectory below: 360 valid beams
-TRAJ_INC = (0.07, 0.02, 0.01)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from rbpf_cases import ROOM_BENCH, ROOM_SURVEY, TRAJ_BENCH as TRAJ_INC, TRAJ_SURVEY  # noqa: E402  (pure constants; the rooms the full-size parity tests use)
 RESAMPLE_AT = (8, 14)                 # timed scans forced to resample
 
 

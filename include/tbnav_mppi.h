@@ -60,6 +60,9 @@ typedef struct tbnav_mppi tbnav_mppi; /* opaque */
 
 /* MPPI::MPPI + initController (mppi.cpp:28-51,157-170): u = 0, uinit = 0, xd = 0, J/duL/duR = 0. */
 int tbnav_mppi_create(const tbnav_mppi_params* params, tbnav_mppi** out);
+/* Waits for the handle's device.  A handle that is still attached to a communicator detaches first (tbnav_mppi_attach_comm(h, NULL)):
+ * destroy handles BEFORE their communicators; where the attachment is a multi-process direct exchange the detach — hence this call —
+ * is collective (every rank of the communicator destroys or detaches). */
 void tbnav_mppi_destroy(tbnav_mppi* h);
 
 int tbnav_mppi_steps(const tbnav_mppi* h);    /* T = (int)(horizon / dt)   */
@@ -92,7 +95,12 @@ enum { TBNAV_MPPI_OPT_KERNEL = 1, TBNAV_MPPI_OPT_TRIG = 2, TBNAV_MPPI_OPT_NO_LDS
        TBNAV_MPPI_OPT_PREFIX_FORM = 7,
        TBNAV_MPPI_OPT_DIRECT_EXCHANGE = 8 /* 0: a handle attached to a multi-process communicator always exchanges through the communicator's
                                              all-gather (default 1: directly into the peers' buffers when every rank can; takes effect at the next attach; 2: as 1 with a fault injected for the tests of the
-                                             bound — after the self-test this rank's records never reach its peers, and the bound is 0.3 s instead of 2 s) */ };
+                                             bound — after the self-test this rank's records never reach its peers, and the bound is 0.3 s instead of 2 s) */,
+       TBNAV_MPPI_OPT_SAMPLER = 9 /* the device noise source's width (replacement of utilities.cpp:20-24 / mppi.cpp:173-184; the Philox counters are the same either way):
+                                     0 (default): fp32 Box-Muller on 24-bit uniforms — normals on a 2^-24 grid out to 5.9 sigma;
+                                     1: fp64 Box-Muller on 52-bit uniforms — what std::normal_distribution<double> is in width, out to 8.57 sigma (in the fused
+                                        kernel for the default dynamics, sampled first for the others: same values) */,
+       TBNAV_MPPI_OPT_FAULT_INJECT = 10 /* tests: 1 = the local half of this handle's next sharded tick reports a failure (its rollouts are not launched) */ };
 int tbnav_mppi_set_option(tbnav_mppi* h, int32_t option, int32_t value);
 
 /* Rollout dynamics.  TBNAV_MPPI_DYN_RK4 (default) is the reference MPPI: CartModel + RK4 (controller/include/

@@ -305,9 +305,8 @@ int tbnav_rbpf_particle_map(tbnav_rbpf* h, int32_t particle, int8_t* map);
  * TBNAV_RBPF_OPT_RAYCAST_ORDERED 1 = always use the beam-ordered raycast kernel (development / A-B runs).
  * TBNAV_RBPF_OPT_RAYCAST_THREADS 256 | 512 | 1024 threads per workgroup of the tile raycast (default 0: chosen per launch, see _RAYCAST_ADAPT).
  * TBNAV_RBPF_OPT_COUNT_CELLS     1 = the tile raycast counts the cells it updates (tbnav_rbpf_scan_counts).
- * TBNAV_RBPF_OPT_RAYCAST_FORM    0 = box counters, rbpf_raycast_box (default); 1 = the beam-ordered kernel rbpf_raycast (what scans the box
- *                                kernel cannot hold and the reference-field mode use anyway).  Bit-identical maps either way.
- *                                (Round 2's first tile kernel, which 1 used to select, was removed in round 4.)
+ * TBNAV_RBPF_OPT_RAYCAST_FORM    retired.  0 is accepted (the box-counter kernel rbpf_raycast_box, the only form); 1 — round 2's first tile kernel,
+ *                                removed in round 4 — is TBNAV_ERR_INVALID_ARG: the beam-ordered kernel is selected by _RAYCAST_ORDERED.
  * TBNAV_RBPF_OPT_RAYCAST_BAND_ROWS n > 0 = rbpf_raycast_box keeps at most about n rows of a scan's bounding box in LDS at a
  *                                time (0 = as many as fit): drives its band loop on small maps (tests).
  * TBNAV_RBPF_OPT_RAYCAST_ADAPT   1 = rbpf_raycast_box's LDS array is sized by what the particles' boxes needed in the last scans (default;

@@ -12,7 +12,7 @@ import sys
 
 
 def short(name: str) -> str:
-    name = re.sub(r"(\(anonymous namespace\)|tbnav_rk)::", "", name)
+    name = re.sub(r"(\(anonymous namespace\)|tbnav_rk|tbnav_mk)::", "", name)
     name = re.sub(r"^void ", "", name)
     return name.split("(")[0][:70]
 

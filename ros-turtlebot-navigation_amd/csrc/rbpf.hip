@@ -104,7 +104,6 @@ struct tbnav_rbpf {
   int raycast_band_rows = 0;   // > 0: cap the LDS array of rbpf_raycast_box at about this many box rows (TBNAV_RBPF_OPT_RAYCAST_BAND_ROWS, tests)
   int raycast_cell16 = 1;      // 0: never the 16-bit cell form; 1: where it buys a higher residency (default); 2: wherever it can run (TBNAV_RBPF_OPT_RAYCAST_CELL16)
   int lk_raycast = -1, lk_raycast_wps = 0, lk_raycast_c16 = 0, lk_raycast_ev = 8, lk_raycast_grid = 0, lk_propose = 0, lk_box_need = 0, lk_box_cap = 0;  // the instantiations the last launches were (tbnav_rbpf_last_kernel_names): raycast threads (0 = beam-ordered), its workgroups, propose threads
-  int raycast_form = 0;        // 0 = box counters (rbpf_raycast_box), 1 = the beam-ordered kernel (rbpf_raycast) (TBNAV_RBPF_OPT_RAYCAST_FORM)
   double* d_sens = nullptr;    // [N][4] sensor transform (X, Y, sin, cos) of each particle's new pose, left by the proposal kernel
   uint64_t seed = 0x5EEDull, scan_index = 0;  // device noise source (normals == NULL)
   uint64_t rng_first = 0, rng_n_global = 0;   // sharded filters: this handle's particles are [rng_first, rng_first + N) of rng_n_global (0 = unsharded)
@@ -112,7 +111,8 @@ struct tbnav_rbpf {
   // normalise / select run on a SECOND stream beside the local map update
   tbnav_comm* comm = nullptr;
   hipStream_t stream2 = nullptr;
-  hipEvent_t ev_w = nullptr, ev_g = nullptr;   // "the proposal kernel has left the weights" / "the global normalise is through"
+  hipEvent_t ev_w = nullptr, ev_g = nullptr;   // "the proposal kernel has left the weights" / (ev_g: unused since round 5 — the weights come back on the main stream)
+  int shard_latched = TBNAV_OK;                // a rank-local failure after a scan's last agreement: carried into the next scan's, where every rank stops with it
   double* d_gw_raw = nullptr;                  // [n_global] all-gathered raw weights
   char* d_sendbuf = nullptr; char* d_recvbuf = nullptr; size_t send_cap = 0, recv_cap = 0;   // particle blobs of a cross-rank resample
   unsigned long long* d_sizes = nullptr;       // [n_local + n_global] blob size of every particle this rank sends | of every particle
@@ -573,7 +573,7 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens,
   else if (nt == 512) wps = 6;
   if (h->raycast_cell16 == 2 && c16_ok && nt == 512) c16 = true;   // (tests / A-B: the 16-bit form wherever it can run)
   const size_t lds_win = c16 ? box16_lds_bytes((size_t)cap_win, (size_t)bvn, ev_slot) : box_lds_bytes((size_t)cap_win, (size_t)bvn, ev_slot);
-  if (cap_win > 0 && !h->ref_field && c.Bv < 32768 - kWave && h->raycast_form == 0 && nt >= 512 && lds_win <= (size_t)kMaxLds - 4096) {
+  if (cap_win > 0 && !h->ref_field && c.Bv < 32768 - kWave && nt >= 512 && lds_win <= (size_t)kMaxLds - 4096) {
     // default: box counters (rbpf_raycast_box)
     unsigned long long* touched = h->count_touched ? h->d_touched : nullptr;
     const NormArgs na = nz ? *nz : NormArgs{0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, nullptr};
@@ -1686,6 +1686,8 @@ int sharded_scan(int n, tbnav_rbpf* const* hs, const float* scan, int n_beams, c
                  tbnav_rbpf_stats* local_out) {
   if (n <= 0 || !hs || !scan || n_beams <= 0 || !u || !cur_odom || !prev_odom || !T_icp || !out) return TBNAV_ERR_INVALID_ARG;
   for (int r = 0; r < n; ++r) if (!hs[r] || !hs[r]->comm || hs[r]->N != hs[0]->N || hs[r]->ref_field) return TBNAV_ERR_INVALID_ARG;
+  // (made at attach and never resized while attached — tbnav_rbpf_attach_comm; a handle without them was never attached)
+  for (int r = 0; r < n; ++r) if (!hs[r]->d_gw_raw || !hs[r]->d_status || !hs[r]->stream2 || (size_t)tbnav::comm_size(hs[r]->comm) * hs[r]->N > hs[r]->g_cap) return TBNAV_ERR_INVALID_ARG;
   const int P = tbnav::comm_size(hs[0]->comm), nl = hs[0]->N;
   const size_t ng = (size_t)P * nl;
   if (ng > ((size_t)1 << 24)) return TBNAV_ERR_UNSUPPORTED;
@@ -1705,19 +1707,26 @@ int sharded_scan(int n, tbnav_rbpf* const* hs, const float* scan, int n_beams, c
   auto agree = [&](const std::vector<int>& codes, int& status) -> int {
     status = TBNAV_OK;
     if (n == P) { for (int r = 0; r < n; ++r) if (codes[r] != TBNAV_OK && status == TBNAV_OK) status = codes[r]; return TBNAV_OK; }
+    // (the same rule inside the agreement itself: a copy that fails on this rank is a code this rank contributes — if its word
+    //  cannot even be uploaded, the word it holds is whatever the last agreement left, and the rank still reports its own
+    //  failure below — never a return before the all-gather its peers are entering)
     std::vector<const void*> send(n);
     std::vector<void*> recv(n);
+    int local_fail = TBNAV_OK;
     for (int r = 0; r < n; ++r) {
       DeviceGuard guard(hs[r]->device);
-      TBNAV_HIP(hipMemcpyAsync(hs[r]->d_status, &codes[r], sizeof(int), hipMemcpyHostToDevice, hs[r]->stream));
+      const hipError_t e = hipMemcpyAsync(hs[r]->d_status, &codes[r], sizeof(int), hipMemcpyHostToDevice, hs[r]->stream);
+      if (e != hipSuccess && local_fail == TBNAV_OK) local_fail = tbnav::hip_fail(e, "agree: status upload", __FILE__, __LINE__);
       send[r] = hs[r]->d_status; recv[r] = hs[r]->d_status + 1;
     }
     { const int rc = tbnav::comm_all_gather(n, comms.data(), send.data(), recv.data(), sizeof(int), s1.data()); if (rc != TBNAV_OK) return rc; }
-    std::vector<int> all(P);
+    std::vector<int> all(P, TBNAV_OK);
     { DeviceGuard guard(hs[0]->device);
-      TBNAV_HIP(hipMemcpyAsync(all.data(), hs[0]->d_status + 1, sizeof(int) * P, hipMemcpyDeviceToHost, hs[0]->stream));
-      TBNAV_HIP(hipStreamSynchronize(hs[0]->stream)); }
+      hipError_t e = hipMemcpyAsync(all.data(), hs[0]->d_status + 1, sizeof(int) * P, hipMemcpyDeviceToHost, hs[0]->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(hs[0]->stream);
+      if (e != hipSuccess && local_fail == TBNAV_OK) local_fail = tbnav::hip_fail(e, "agree: status download", __FILE__, __LINE__); }
     for (int q = 0; q < P; ++q) if (all[q] != TBNAV_OK) { status = all[q]; break; }
+    if (local_fail != TBNAV_OK && status == TBNAV_OK) status = local_fail;   // (this rank stops; its peers learn of it at the next agreement, which it still joins)
     return TBNAV_OK;
   };
   std::memset(out, 0, sizeof *out);
@@ -1726,9 +1735,7 @@ int sharded_scan(int n, tbnav_rbpf* const* hs, const float* scan, int n_beams, c
     tbnav_rbpf* h = hs[r];
     DeviceGuard guard(h->device);
     comms[r] = h->comm; s1[r] = h->stream; s2[r] = h->stream2;
-    note(r, ensure_shard_state(h));   // (sized at attach: a no-op here unless the handle was resized since)
-    if (!h->d_gw_raw || !h->d_status) { out->status = lerr[r]; return lerr[r]; }   // nothing to join a collective WITH: only before the first scan, at attach
-    comms[r] = h->comm; s1[r] = h->stream; s2[r] = h->stream2;
+    note(r, h->shard_latched);
     if (lerr[r] == TBNAV_OK)
       note(r, scan_enqueue(h, scan, n_beams, u, cur_odom, prev_odom, icp_ok, T_icp, normals ? normals[r] : nullptr, &lst[r], true, 0, nullptr, tk[r], nullptr, h->ev_w));
     if (lerr[r] == TBNAV_OK) TBNAV_L(r, hipStreamWaitEvent(h->stream2, h->ev_w, 0));
@@ -1751,11 +1758,9 @@ int sharded_scan(int n, tbnav_rbpf* const* hs, const float* scan, int n_beams, c
     const double* zp = h->last_normals + h->last_z_index;
     hipLaunchKernelGGL(rbpf_normalize, dim3(1), dim3(256), 0, h->stream2, (int)ng, zp, h->d_gw_raw, h->d_gw, h->d_gcs, h->d_gparent, h->d_norm + 1,
                        nullptr, nullptr, nullptr, 0u);
-    const size_t off = (size_t)tbnav::comm_rank(h->comm) * nl;
-    (void)(TBNAV_L(r, hipGetLastError()) &&
-           TBNAV_L(r, hipMemcpyAsync(state_ptrs(h->d_state[h->cur], nl).weight, h->d_gw + off, sizeof(double) * nl, hipMemcpyDeviceToDevice, h->stream2)) &&
-           TBNAV_L(r, hipEventRecord(h->ev_g, h->stream2)) &&
-           TBNAV_L(r, hipStreamWaitEvent(h->stream, h->ev_g, 0)));  // whatever the main stream does next sees the normalised weights
+    (void)TBNAV_L(r, hipGetLastError());
+    // (the normalised weights go back into the shard only once the ranks have AGREED that this scan succeeded everywhere — below:
+    //  a failed rank's slice of the gathered vector is whatever its buffer held)
   }
   // ---- C: the host waits once per member (the reference's SLAM() is synchronous)
   std::vector<int> lstat(n, TBNAV_OK);
@@ -1776,6 +1781,17 @@ int sharded_scan(int n, tbnav_rbpf* const* hs, const float* scan, int n_beams, c
   out->n_valid_beams = lst[0].n_valid_beams;
   out->status = status;
   if (status != TBNAV_OK) return status;
+  // the scan stands on every rank: each shard takes its slice of the globally normalised weights (on its main stream — the host
+  // has waited for the second one above; whatever the main stream does next sees them)
+  for (int r = 0; r < n; ++r) {
+    tbnav_rbpf* h = hs[r];
+    DeviceGuard guard(h->device);
+    const size_t off = (size_t)tbnav::comm_rank(h->comm) * nl;
+    TBNAV_L(r, hipMemcpyAsync(state_ptrs(h->d_state[h->cur], nl).weight, h->d_gw + off, sizeof(double) * nl, hipMemcpyDeviceToDevice, h->stream));
+  }
+  // (a copy that could not even be enqueued: the ranks have already agreed on this scan — the code is latched and stops every rank
+  //  at the next scan's agreement, or at this one's if a resampling follows)
+  for (int r = 0; r < n; ++r) if (lerr[r] != TBNAV_OK) hs[r]->shard_latched = lerr[r];
   if (!no.resampled) return TBNAV_OK;
   // ---- D: lowVarianceResampling's copies across shards.  Slot m (global) takes particle parents[m].
   std::vector<int> parents(ng);
@@ -1901,11 +1917,17 @@ int tbnav_rbpf_attach_comm(tbnav_rbpf* h, tbnav_comm* comm) {
   DeviceGuard guard(h->device);
   TBNAV_HIP(hipStreamSynchronize(h->stream));
   h->comm = comm;
+  h->shard_latched = TBNAV_OK;
   if (!comm) { h->rng_first = 0; h->rng_n_global = 0; return TBNAV_OK; }
   // equal shards: this rank's particles are [rank * N, (rank + 1) * N) of nranks * N — also for the device noise source
   h->rng_first = (uint64_t)tbnav::comm_rank(comm) * (uint64_t)h->N;
   h->rng_n_global = (uint64_t)tbnav::comm_size(comm) * (uint64_t)h->N;
-  return ensure_shard_state(h);
+  // the buffers every collective of a scan works on exist from here on (nranks * N is fixed for the attachment): a handle
+  // whose shard state cannot be made is NOT attached — sharded_scan's precondition, so that no rank finds itself without
+  // something to join a collective with in the middle of a scan (round-4 advisor finding)
+  const int rc = ensure_shard_state(h);
+  if (rc != TBNAV_OK) { h->comm = nullptr; h->rng_first = 0; h->rng_n_global = 0; }
+  return rc;
 }
 
 void tbnav_rbpf_group_destroy(tbnav_rbpf_group* g) {
@@ -2332,9 +2354,9 @@ int tbnav_rbpf_set_option(tbnav_rbpf* h, int32_t option, int32_t value) {
       h->host_threads = value ? value : default_host_threads();
       return TBNAV_OK;
     case TBNAV_RBPF_OPT_RAYCAST_FORM:
-      if (value != 0 && value != 1) return TBNAV_ERR_INVALID_ARG;
-      h->raycast_form = value;
-      return TBNAV_OK;
+      // retired: 1 named round 2's tile kernel (removed in round 4) and for a while silently meant the much slower beam-ordered
+      // kernel instead — that one has its own switch, _RAYCAST_ORDERED (round-4 advisor finding)
+      return value == 0 ? TBNAV_OK : TBNAV_ERR_INVALID_ARG;
     case TBNAV_RBPF_OPT_COUNT_CELLS:
       h->count_touched = value != 0;
       return TBNAV_OK;

@@ -566,7 +566,11 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
     if (x0 != minx) {  // (a further band: the LDS state of the previous one is cleared)
       __syncthreads();
       uint4* t4 = reinterpret_cast<uint4*>(tile);
-      for (int t = tid; t < tile_words / 4; t += nthr) t4[t] = uint4{0u, 0u, 0u, 0u};
+      // (the zeros are made HERE, from an opaque register: as a loop invariant they were hoisted above the band loop and — the kernel
+      //  has 64 VGPRs — spilled there, a 16-byte scratch store per lane in EVERY launch for a path one-band scans never take)
+      unsigned int z = 0u;
+      asm volatile("" : "+v"(z));
+      for (int t = tid; t < tile_words / 4; t += nthr) t4[t] = uint4{z, z, z, z};
       for (int b = tid; b < Bv; b += nthr) ecnt[b] = 0;
       for (int t = tid; t < kMapTilesMax; t += nthr) mt_touch[t] = 0;
       if (tid == 0) n_ovf = 0;
@@ -768,8 +772,13 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
       for (int q = wid; q < mtn; q += nw) {
         if (!mt_touch[q] || mt_slot[q] < 0) continue;
         const int qi = floor_div_small(q, mty), qj = q - qi * mty;
-        const unsigned int nid = tile_at(P, need_base + (unsigned long long)mt_slot[q]);
-        tile_clone_into(P, tab, shed, (tx0 + qi) * M.TW + (ty0 + qj), nid, lane);
+        // (the ring position and the lane are taken afresh in every trip — an LDS read, an opaque copy: as loop invariants the position
+        //  and the lane's bitmap address were kept live across the 8 KB copy and spilled, 2 x 8 bytes of scratch per lane)
+        const unsigned long long nb = *reinterpret_cast<volatile unsigned long long*>(&need_base);
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const unsigned int nid = tile_at(P, nb + (unsigned long long)mt_slot[q]);
+        tile_clone_into(P, tab, shed, (tx0 + qi) * M.TW + (ty0 + qj), nid, ln);
         if (lane == 0) { mt_id[q] = nid; mt_priv[q] = 1; }
       }
       __syncthreads();

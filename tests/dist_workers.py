@@ -425,6 +425,54 @@ def mppi_direct_fault_worker(rank, world, K_local, horizon):
     return {"msg": msg, "waited": waited, "kind": kind, "out": out}
 
 
+def mppi_rank_failure_worker(rank, world, K_local, horizon, failing_rank):
+    """The all-gather exchange with ONE rank's own rollouts failing in the third tick (TBNAV_MPPI_OPT_FAULT_INJECT): that rank gets
+    the error from its enqueue; every other rank's enqueue succeeds (the rank cannot know yet) and its last_controls / next enqueue
+    report the failure; NO rank's controls are updated by that tick — they are the previous controls, shifted — and all ranks'
+    warm starts stay identical and finite (round 4 poisoned the combine with NaN records, which the clamp turned into
+    u = -max_wheel_vel on the healthy ranks: advisor finding); after a detach / re-attach the ensemble works again."""
+    import time
+    import torch
+    comm = _ipc_comm()
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    from cases import WAYPOINTS, make_mppi, mppi_cfg
+    from rtn_amd import capi
+    m = make_mppi(pkg, mppi_cfg(K_local, horizon))
+    m.setWaypoint(*WAYPOINTS[1])
+    m.setDirectExchange(0)
+    m.attachComm(comm)
+    assert m.exchangeKind() == 1
+    st = torch.cuda.Stream()
+    for i in range(2):
+        m.newControlsRng((0.0, 0.0, 0.0), 5, i, st.cuda_stream)
+    before = m.getControls()   # (materialises the owed shift: what tick 2 reads)
+    if rank == failing_rank:
+        m.setOption(capi.MPPI_OPT_FAULT_INJECT, 1)
+    t0 = time.perf_counter()
+    enq_msg = last_msg = again_msg = None
+    try:
+        m.enqueueRng((0.0, 0.0, 0.0), 5, 2, st.cuda_stream)
+    except capi.TbnavError as e:
+        enq_msg = str(e)
+    try:
+        m.lastControls(st.cuda_stream)
+    except capi.TbnavError as e:
+        last_msg = str(e)
+    try:   # latched on every rank: nobody enters the all-gather again
+        m.enqueueRng((0.0, 0.0, 0.0), 5, 3, st.cuda_stream)
+    except capi.TbnavError as e:
+        again_msg = str(e)
+    waited = time.perf_counter() - t0
+    after = m.getControls()
+    m.attachComm(None)
+    m.setControls(before)
+    m.attachComm(comm)
+    good = [np.array(m.newControlsRng((0.0, 0.0, 0.0), 5, 2 + i, st.cuda_stream)) for i in range(2)]
+    m.close(); comm.close()
+    return {"enq": enq_msg, "last": last_msg, "again": again_msg, "waited": waited, "before": before, "after": after, "good": good}
+
+
 def mppi_soak_worker(rank, world, K_local, horizon, n_ticks, direct):
     """Many production ticks in batches through the attached handle (sequence numbers, buffer parity, the dead mark never raised);
     returns the final controls."""

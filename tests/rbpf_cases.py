@@ -31,4 +31,10 @@ def trajectory(n_scans, inc=(0.07, 0.10, 0.05), start=(0.0, 0.0, 0.0)):
 
 
 ROOM_SMALL = (-1.6, 1.5, -1.3, 1.7)   # fits the shipped 80x80 map (+-2 m)
-ROOM_SURVEY = (-3.0, 3.0, -2.5, 2.5)  # SURVEY.md 8-d, for the 400x400 map (+-10 m)
+ROOM_SURVEY = (-3.0, 3.0, -2.5, 2.5)  # SURVEY.md 8-d, for the 400x400 map (+-10 m): 246 of 360 beams return inside range_max
+# bench_rbpf.py's headline room and trajectory (it imports them from here, so that what is benched is what is tested): every corner
+# is < 3.4 m from every pose of the trajectory — all 360 beams valid — and the scans' bounding boxes (94 x 88 cells) let the map
+# update run four workgroups per CU (rbpf_raycast_box<512, 8, false, 4>)
+ROOM_BENCH = (-2.2, 2.2, -2.0, 2.0)
+TRAJ_BENCH = (0.07, 0.02, 0.01)
+TRAJ_SURVEY = (0.07, 0.10, 0.05)

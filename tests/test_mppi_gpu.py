@@ -153,6 +153,73 @@ def test_in_kernel_noise_equals_sampled_noise(gpu_pkg, K, horizon):
         x0 = (x0[0] + 0.002, x0[1], x0[2] + 0.001)
 
 
+@pytest.mark.parametrize("K,horizon,dyn", [(1024, 0.5, "rk4"), (4096, 1.0, "rk4"), (100, 1.28, "rk4"), (1024, 0.5, "arc"), (200, 2.0, "rk4")])
+def test_fp64_sampler_in_kernel_equals_sampled_noise(gpu_pkg, K, horizon, dyn):
+    """TBNAV_MPPI_OPT_SAMPLER = 1 (fp64 Box-Muller on 52-bit uniforms, the width of the reference's std::normal_distribution<double>,
+    utilities.cpp:20-24): same contract as the default sampler — drawn inside the fused kernel (default dynamics) or sampled first
+    (arc dynamics, T = 200: no in-kernel form), the tick equals "sample, then tick on the sampled arrays" bit for bit, and the oracle
+    fed those arrays agrees."""
+    from rtn_amd import capi
+    d = mppi_cfg(K, horizon)
+    m_rng, m_ref = make_mppi(gpu_pkg, d), make_mppi(gpu_pkg, d)
+    T = m_rng.steps
+    for m in (m_rng, m_ref):
+        m.setWaypoint(*WAYPOINTS[1]); m.setDynamics(dyn); m.setOption(capi.MPPI_OPT_SAMPLER, 1)
+    x0 = (0.1, -0.2, 0.3)
+    u = np.zeros((2, T))
+    for tick in range(3):
+        got = m_rng.newControlsRng(x0, 77, tick)
+        if dyn == "rk4" and T <= 128:
+            assert m_rng.lastKernelNames()[0].endswith(", 2>"), m_rng.lastKernelNames()   # mppi_rollout_fused<2, R, TL, 2>
+        m_ref.sampleNoise(77, tick)
+        want = m_ref.newControlsDev(x0, 0, 0)
+        assert got == want and np.array_equal(m_rng.getControls(), m_ref.getControls())
+        a, b = m_ref.getNoise()
+        ref = orc.mppi_new_controls(d, u, (0, 0), WAYPOINTS[1], x0, np.stack([a.T, b.T], axis=2), dyn=1 if dyn == "arc" else 0)
+        assert np.allclose(got, ref["out"], rtol=U_RTOL, atol=U_ATOL)
+        u = ref["u"]
+        x0 = (x0[0] + 0.002, x0[1], x0[2] + 0.001)
+    # the two samplers share the Philox counters but not the bits they use: different perturbations
+    m_ref.setOption(capi.MPPI_OPT_SAMPLER, 0); m_ref.sampleNoise(77, 0); a0, _ = m_ref.getNoise()
+    m_ref.setOption(capi.MPPI_OPT_SAMPLER, 1); m_ref.sampleNoise(77, 0); a1, _ = m_ref.getNoise()
+    assert not np.array_equal(a0, a1)
+    m_rng.close(); m_ref.close()
+
+
+def test_fp64_sampler_statistics_and_tails_to_six_sigma(gpu_pkg):
+    """6.5 M pairs per draw x 8 draws = 1.05e8 normals: moments, and the tail counts beyond 3, 4, 5 and 6 sigma against the normal
+    law (expected beyond 6 sigma: 0.21 of 1.05e8 — the default fp32 sampler's grid ENDS at 5.9; here a value out there is
+    possible and the counts at 5 sigma (60 expected) must be right); values fill the fp64 grid (no 2^-24 lattice)."""
+    from math import erfc, sqrt
+    from rtn_amd import capi
+    d = mppi_cfg(65536, 1.0, ul_var=1.0, ur_var=1.0)
+    m = make_mppi(gpu_pkg, d)
+    m.setOption(capi.MPPI_OPT_SAMPLER, 1)
+    n = 0
+    cnt = {3.0: 0, 4.0: 0, 5.0: 0, 6.0: 0}
+    s1 = s2 = s4 = 0.0
+    mx = 0.0
+    for tick in range(8):
+        m.sampleNoise(2024, tick)
+        a, b = m.getNoise()
+        z = np.concatenate([a.ravel(), b.ravel()])
+        n += z.size; s1 += z.sum(); s2 += (z ** 2).sum(); s4 += (z ** 4).sum(); mx = max(mx, np.abs(z).max())
+        for t in cnt:
+            cnt[t] += int((np.abs(z) > t).sum())
+        if tick == 0:
+            assert abs(np.corrcoef(a.ravel(), b.ravel())[0, 1]) < 1e-3
+            frac = np.mod(np.abs(z[:100000]) * 2.0 ** 24, 1.0)
+            assert (frac != 0).mean() > 0.99   # not on the fp32 sampler's lattice
+    mean, var = s1 / n, s2 / n
+    assert abs(mean) < 5 / sqrt(n) and abs(var - 1.0) < 5 * sqrt(2.0 / n) and abs(s4 / n / var ** 2 - 3.0) < 5 * sqrt(96.0 / n)
+    for t, c in cnt.items():
+        exp = n * erfc(t / sqrt(2.0))
+        print(f"[fp64 sampler] |z| > {t}: {c} (expected {exp:.2f})")
+        assert abs(c - exp) <= 5 * sqrt(exp) + 3, (t, c, exp)
+    assert 5.0 < mx < 8.6
+    m.close()
+
+
 def test_long_horizon_uses_global_scratch_path(gpu_pkg):
     """T = 400 > 320: per-step losses no longer fit LDS ([T][64] doubles), J is the scratch."""
     d = mppi_cfg(96, 4.0)
@@ -352,26 +419,45 @@ def test_division_by_lambda_from_its_reciprocal_is_the_ieee_quotient_bit_for_bit
     """The soft-min weights need (J - min) * -1.0 / lambda with the reference's association (mppi.cpp:117).  The kernels form the
     quotient from lambda's correctly rounded reciprocal — q = x r, e = fma(-q, lambda, x), fma(e, r, q): three dependent
     instructions instead of the division's ~25, and by Markstein's theorem the correctly rounded quotient, i.e. the SAME bits as
-    x / lambda.  Held here against numpy's IEEE division on 2 x 10^5 values per lambda (cost differences from 1e-300 to 1e300,
-    zeros, infinities), for the shipped lambda and awkward ones; a lambda whose significand is all ones takes the plain division."""
+    x / lambda — provided nothing under- or overflows on the way, so a wave takes the short form only when all its values are 0 or
+    within 2^-900 ... 2^900 and divides otherwise (round-4 advisor finding).  Held here against numpy's IEEE division, EVERY value
+    bit for bit: 2 x 10^5 values per lambda (cost differences from 1e-300 to 1e300 — waves that divide — and from 0 to 1e6 — waves
+    that do not), zeros, infinities, subnormal and near-overflow arguments, subnormal quotients, and arguments one ulp either side of
+    exact products q * lambda (the nearest a quotient of doubles gets to a rounding boundary); for the shipped lambda and awkward
+    ones; a lambda whose significand is all ones takes the plain division."""
     import ctypes as C
     L = gpu_pkg.capi.lib()
     rng = np.random.default_rng(17)
-    x = -np.abs(np.concatenate([rng.standard_normal(100000) * 10.0 ** rng.uniform(-300, 300, 100000), rng.uniform(0, 1e6, 99990),
-                                [0.0, np.inf, 1e-320, 5e-324, 1.7976931348623157e308, 1.0, 3.0, 1e-8, 0.01, 2.0 ** -1022]]))
+    edge = np.array([0.0, np.inf, 1e-320, 5e-324, 1.7976931348623157e308, 1.0, 3.0, 1e-8, 0.01, 2.0 ** -1022, 2.0 ** -1074, 2.0 ** -1023,
+                     2.0 ** -900, float(np.nextafter(2.0 ** -900, 0.0)), 2.0 ** 900, float(np.nextafter(2.0 ** 900, np.inf)), 1e308, 8.9e307,
+                     2.0 ** 1023, 2.0 ** -1000, 3.0 * 2.0 ** -1060, 1.5e-310])
     used_any = False
-    for lam in (0.01, 1e-3, 1.0, 3.0, 0.1, 7.3e-5, 1.9999999999999998, 2.0 ** -40, 123456.789, float(np.nextafter(1.0, 0.0))):
+    for lam in (0.01, 1e-3, 1.0, 3.0, 0.1, 7.3e-5, 1.9999999999999998, 2.0 ** -40, 123456.789, float(np.nextafter(1.0, 0.0)), 2.0 ** 40, 1e-30, 1e30):
+        q0 = rng.uniform(0.5, 2.0, 20000) * 2.0 ** rng.integers(-30, 30, 20000)
+        prod = q0 * lam
+        near = np.concatenate([prod, np.nextafter(prod, np.inf), np.nextafter(prod, 0.0)])   # in-range: waves of the short form
+        x = -np.abs(np.concatenate([rng.standard_normal(100000) * 10.0 ** rng.uniform(-300, 300, 100000), rng.uniform(0, 1e6, 99968), near, edge]))
         out = np.empty_like(x); used = C.c_int32()
         assert L.tbnav_mppi_debug_div_lambda(x.ctypes.data, x.size, C.c_double(lam), out.ctypes.data, C.byref(used)) == 0
         with np.errstate(over="ignore", under="ignore"):
             want = x / lam
-        sub = np.abs(want) < 2.3e-308   # (a subnormal quotient: outside the theorem — and outside anything exp() distinguishes)
-        assert np.array_equal(out[~sub], want[~sub]), lam
-        assert np.allclose(out[sub], want[sub], rtol=0, atol=1e-307)
+        bad = ~((out == want) | (np.isnan(out) & np.isnan(want)))
+        assert not bad.any(), (lam, x[bad][:5], out[bad][:5], want[bad][:5])
+        assert np.array_equal(np.signbit(out), np.signbit(want))
         used_any |= bool(used.value)
         if lam in (1.9999999999999998, float(np.nextafter(1.0, 0.0))):
             assert used.value == 0   # significand all ones: the theorem's exception
     assert used_any
+
+
+def test_nan_state_gives_nan_controls_like_std_clamp(gpu_pkg):
+    """mppi.cpp:124-125 clamps with std::clamp, which passes a NaN through (both comparisons are false).  fmin / fmax return the
+    OTHER operand: round 4's clamp turned NaN controls into -max_wheel_vel — full reverse — silently (advisor finding)."""
+    m = make_mppi(gpu_pkg, mppi_cfg(256, 0.25))
+    m.setWaypoint(*WAYPOINTS[1])
+    out = m.newControls(float("nan"), 0.0, 0.0, _noise(3, 256, m.steps))
+    assert np.all(np.isnan(out)) and np.all(np.isnan(m.getControls()[:, :-1]))
+    m.close()
 
 
 @pytest.mark.parametrize("form", ["prefix", "general"])

@@ -20,6 +20,7 @@ def test_kernel_stats_table_written_by_the_summariser_is_what_the_bench_parses(t
               "sgpr_count int, lds_size int, scratch_size int)")
     rows = [("void (anonymous namespace)::mppi_rollout_fused<2, 8, 1, true>((anonymous namespace)::RolloutArgs, double const*)", 65536, 1, 1, 512, 5000),
             ("void (anonymous namespace)::mppi_rollout_fused<2, 8, 1, true>((anonymous namespace)::RolloutArgs, double const*)", 65536, 1, 1, 512, 6000),
+            ("void tbnav_mk::mppi_rollout_fused<2, 8, 1, 1>(tbnav_mk::RolloutArgs, double const*)", 65536, 1, 1, 512, 7000),
             ("void tbnav_rk::rbpf_raycast_box<512>(tbnav_rk::ScanC)", 512512, 1, 1, 512, 48000),
             ("void (anonymous namespace)::rbpf_raycast_box<512>((anonymous namespace)::ScanC)", 512000, 1, 1, 512, 50000),
             ("mppi_partials(int, int)", 8192, 100, 1, 256, 26000)]
@@ -30,6 +31,7 @@ def test_kernel_stats_table_written_by_the_summariser_is_what_the_bench_parses(t
     path.write_text(md)
     parsed, _ = bp.kernel_stats_rows(str(path))
     by = {(r["kernel"], r["grid_threads"]): r for r in parsed}
+    assert by[("mppi_rollout_fused<2, 8, 1, 1>", 65536)]["calls"] == 1   # (round 5: the MPPI kernels live in namespace tbnav_mk)
     assert by[("mppi_rollout_fused<2, 8, 1, true>", 65536)]["calls"] == 2 and abs(by[("mppi_rollout_fused<2, 8, 1, true>", 65536)]["avg_us"] - 5.5) < 1e-9
     assert by[("rbpf_raycast_box<512>", 512512)]["avg_us"] == 48.0 and by[("rbpf_raycast_box<512>", 512000)]["avg_us"] == 50.0
     assert by[("mppi_partials", 819200)]["wg"] == 256   # a two-dimensional grid: threads multiply

@@ -207,7 +207,7 @@ def test_cfg3_as_written_1000_particles_400x400_reference_mode_against_the_oracl
     try:
         t0 = time.perf_counter()
         pf_o, pf_d, rows = _free_run(gpu_pkg, "reference", N=N, k=k, map_half=10.0, walls=rc.ROOM_SURVEY, n_scans=3,
-                                     inc=(0.07, 0.10, 0.05), seed=11, force_resample_at=1)
+                                     inc=rc.TRAJ_SURVEY, seed=11, force_resample_at=1)
         print(f"\n[cfg3 reference mode] 3 scans of {N} particles, oracle + device: {time.perf_counter() - t0:.1f} s")
     finally:
         orc.lib().orc_set_threads(1)
@@ -226,7 +226,8 @@ def test_cfg3_as_written_1000_particles_400x400_reference_mode_against_the_oracl
     pf_d.close()
 
 
-def test_cfg3_as_written_1000_particles_400x400_default_query_mode_against_the_exact_field_oracle(gpu_pkg):
+@pytest.mark.parametrize("room", ["survey", "bench"])
+def test_cfg3_as_written_1000_particles_400x400_default_query_mode_against_the_exact_field_oracle(gpu_pkg, room):
     """The mode bench_rbpf.py's headline number is measured in, held against an oracle AT FULL SIZE (round-3 review, weak 3):
     BASELINE configs[2] as written — 1000 particles, k = 50, 360 beams, 400 x 400 @ 0.05 m, three scans with a forced
     resample at the second — the product in its DEFAULT distance mode (exact nearest-obstacle query, nothing stored, nothing
@@ -235,17 +236,29 @@ def test_cfg3_as_written_1000_particles_400x400_default_query_mode_against_the_e
     switch).  Sampled poses / mu / new poses 1e-10, p_scan, p_pose, eta, raw and normalised weights <= 1e-9, Neff /
     resampling decision / parent list / best particle identical, six spot particles' log-odds bit for bit.
     The mirror image of ..._reference_mode_against_the_oracle above: that one says the reference-field mode IS the reference
-    (brushfire and all); this one says the fast mode is exactly "the reference's filter over the exact field"."""
+    (brushfire and all); this one says the fast mode is exactly "the reference's filter over the exact field".
+    Both rooms the bench has a leg for (round-4 review, weak 3: what is benched must be what is tested): SURVEY 8-d's 6 x 5 m room
+    (246 valid beams; the map update picks its two-per-CU / 16-bit-cell form) and the bench's headline room and trajectory
+    (rbpf_cases.ROOM_BENCH / TRAJ_BENCH: 360 valid beams) — there the benched instantiation itself, rbpf_raycast_box<512, 8, false,
+    4>, is what meets the oracle, at N = 1000."""
     import time
     N, k = 1000, 50
+    walls, inc = (rc.ROOM_SURVEY, rc.TRAJ_SURVEY) if room == "survey" else (rc.ROOM_BENCH, rc.TRAJ_BENCH)
     orc.lib().orc_set_threads(8)
     try:
         t0 = time.perf_counter()
-        pf_o, pf_d, rows = _free_run(gpu_pkg, None, N=N, k=k, map_half=10.0, walls=rc.ROOM_SURVEY, n_scans=3,
-                                     inc=(0.07, 0.10, 0.05), seed=11, force_resample_at=1, oracle_exact_field=True)
-        print(f"\n[cfg3 query mode] 3 scans of {N} particles, exact-field oracle + device: {time.perf_counter() - t0:.1f} s")
+        pf_o, pf_d, rows = _free_run(gpu_pkg, None, N=N, k=k, map_half=10.0, walls=walls, n_scans=3,
+                                     inc=inc, seed=11, force_resample_at=1, oracle_exact_field=True)
+        print(f"\n[cfg3 query mode, {room} room] 3 scans of {N} particles, exact-field oracle + device: {time.perf_counter() - t0:.1f} s; "
+              f"kernels {pf_d.lastKernelNames()}")
     finally:
         orc.lib().orc_set_threads(1)
+    k_propose, k_raycast, _ = pf_d.lastKernelNames()
+    assert k_propose == "rbpf_propose<256>", k_propose
+    if room == "bench":
+        assert k_raycast == "rbpf_raycast_box<512, 8, false, 4>", (k_raycast, pf_d.raycastBoxCells())
+    else:
+        assert k_raycast.startswith("rbpf_raycast_box<512, "), k_raycast
     assert rows[1]["resampled"] == (1, 1)
     _assert_every_stage(rows)
     po, pvo, wo = pf_o.particles()

@@ -136,8 +136,10 @@ def test_raycast_kernel_variants_are_bit_exact(gpu_pkg, variant):
         pf.setOption(capi.RBPF_OPT_RAYCAST_ORDERED, 1)
     elif variant.startswith("box_bands"):  # the box-counter kernel working the box through in bands of ~12 / ~5 rows
         pf.setOption(capi.RBPF_OPT_RAYCAST_BAND_ROWS, int(variant[9:]))
-    elif variant == "form1":
-        pf.setOption(capi.RBPF_OPT_RAYCAST_FORM, 1)
+    elif variant == "form1":   # the retired switch: 1 is refused loudly (it used to fall through to the beam-ordered kernel), 0 is the box kernel
+        with pytest.raises(Exception):
+            pf.setOption(capi.RBPF_OPT_RAYCAST_FORM, 1)
+        pf.setOption(capi.RBPF_OPT_RAYCAST_FORM, 0)
     else:
         pf.setOption(capi.RBPF_OPT_RAYCAST_THREADS, int(variant[3:]))
     steps, poses = rc.trajectory(n_scans, inc=(0.05, 0.04, 0.03))

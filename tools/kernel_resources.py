@@ -12,7 +12,7 @@ CSRC = os.path.join(ROOT, "ros-turtlebot-navigation_amd", "csrc")
 which = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 extra = sys.argv[3:]
-contract = {"mppi": "-ffp-contract=fast-honor-pragmas"}.get(which, "-ffp-contract=off")
+contract = "-ffp-contract=fast-honor-pragmas" if which.startswith("mppi") else "-ffp-contract=off"
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", f"-I{ROOT}/include", f"-I{CSRC}",
        contract, "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, which + ".hip"), "-o", "/tmp/_kr.o"] + extra
 err = subprocess.run(cmd, stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True).stderr

@@ -12,7 +12,7 @@ skip = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 
 
 def short(name):
-    name = re.sub(r"(\(anonymous namespace\)|tbnav_rk)::", "", name)
+    name = re.sub(r"(\(anonymous namespace\)|tbnav_rk|tbnav_mk)::", "", name)
     return re.sub(r"^void ", "", name).split("(")[0]
 
 

@@ -14,15 +14,15 @@ bd = 1.0 / 3.0
 n_scans = 10
 pf = ParticleFilter(default_params(N=N, k=k, map_min=-50.0, map_max=50.0, beam_delta_deg=bd))
 pf.setSeed(5); pf.setTiming(True)
-if os.environ.get("RAYCAST_THREADS"):   # A-B runs: RAYCAST_THREADS=512, RAYCAST_FORM=1, RAYCAST_BAND_ROWS=n
+if os.environ.get("RAYCAST_THREADS"):   # A-B runs: RAYCAST_THREADS=512, RAYCAST_ORDERED=1
     from rtn_amd import capi
     pf.setOption(capi.RBPF_OPT_RAYCAST_THREADS, int(os.environ["RAYCAST_THREADS"]))
 if os.environ.get("RAYCAST_ADAPT"):     # RAYCAST_ADAPT=0: the LDS array sized for the scan's longest beam (round 3 before its last change)
     from rtn_amd import capi
     pf.setOption(capi.RBPF_OPT_RAYCAST_ADAPT, int(os.environ["RAYCAST_ADAPT"]))
-if os.environ.get("RAYCAST_FORM"):
+if os.environ.get("RAYCAST_ORDERED"):
     from rtn_amd import capi
-    pf.setOption(capi.RBPF_OPT_RAYCAST_FORM, int(os.environ["RAYCAST_FORM"]))
+    pf.setOption(capi.RBPF_OPT_RAYCAST_ORDERED, int(os.environ["RAYCAST_ORDERED"]))
 steps, poses = rc.trajectory(n_scans, inc=(0.05, 0.04, 0.03))
 rng = np.random.default_rng(8)
 scans = [bench_rbpf._room_scan(poses[s], rng, rc.ROOM_SURVEY, n_beams=1080, beam_delta_deg=bd) for s in range(n_scans)]

@@ -13,7 +13,7 @@ steps, scans = bench_rbpf.workload(14)
 for N in (1000, 4000):
     for form, nt in ((0, 0), (0, 512), (0, 1024), (1, 0)):
         pf = ParticleFilter(default_params(N=N, k=50, map_min=-10.0, map_max=10.0))
-        pf.setSeed(1); pf.setTiming(True); pf.setOption(capi.RBPF_OPT_RAYCAST_FORM, form); pf.setOption(capi.RBPF_OPT_RAYCAST_THREADS, nt)
+        pf.setSeed(1); pf.setTiming(True); pf.setOption(capi.RBPF_OPT_RAYCAST_ORDERED, form); pf.setOption(capi.RBPF_OPT_RAYCAST_THREADS, nt)
         acc, n = {}, 0
         for s, (prev, cur, t_icp, u) in enumerate(steps):
             pf.SLAM(scans[s], u, cur, prev, True, t_icp, None)

@@ -13,7 +13,7 @@ rows = rows[-16:]
 t0 = int(rows[0]["Start_Timestamp"]); prev = None
 for r in rows:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"]).split("(")[0][:40]
+    name = re.sub(r"(\(anonymous namespace\)|tbnav_rk|tbnav_mk)::", "", r["Kernel_Name"]).split("(")[0][:40]
     print(f"{(s - t0) / 1e3:9.2f} {(e - t0) / 1e3:9.2f}  dur {(e - s) / 1e3:7.2f}  gap {((s - prev) / 1e3) if prev else 0:7.2f}  {name}")
     prev = e
 PY

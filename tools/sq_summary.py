@@ -6,7 +6,7 @@ skip = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 vals = defaultdict(lambda: defaultdict(list))
 with open(f"gpurun_out/sq_{tag}.csv") as f:
     for row in csv.DictReader(f):
-        name = re.sub(r"(\(anonymous namespace\)|tbnav_rk)::", "", row["Kernel_Name"])
+        name = re.sub(r"(\(anonymous namespace\)|tbnav_rk|tbnav_mk)::", "", row["Kernel_Name"])
         name = re.sub(r"^void ", "", name).split("(")[0]
         vals[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {}
