@@ -307,6 +307,10 @@ int tbnav_rbpf_particle_map(tbnav_rbpf* h, int32_t particle, int8_t* map);
  * TBNAV_RBPF_OPT_COUNT_CELLS     1 = the tile raycast counts the cells it updates (tbnav_rbpf_scan_counts).
  * TBNAV_RBPF_OPT_RAYCAST_FORM    retired.  0 is accepted (the box-counter kernel rbpf_raycast_box, the only form); 1 — round 2's first tile kernel,
  *                                removed in round 4 — is TBNAV_ERR_INVALID_ARG: the beam-ordered kernel is selected by _RAYCAST_ORDERED.
+ * TBNAV_RBPF_OPT_NOISE_IN_KERNEL 1 (default) = with device noise (normals == NULL) the standard normals are drawn INSIDE rbpf_propose and never
+ *                                stored, and the scan's beam table reaches the device through that launch's leading workgroup: a scan
+ *                                is two launches; 0 = rbpf_sample_normals stores them first (up to round 4).  Same Philox counters,
+ *                                same values either way (particle_filter.cpp:25-34, :504-519 are what both replace).
  * TBNAV_RBPF_OPT_RAYCAST_BAND_ROWS n > 0 = rbpf_raycast_box keeps at most about n rows of a scan's bounding box in LDS at a
  *                                time (0 = as many as fit): drives its band loop on small maps (tests).
  * TBNAV_RBPF_OPT_RAYCAST_ADAPT   1 = rbpf_raycast_box's LDS array is sized by what the particles' boxes needed in the last scans (default;
@@ -324,7 +328,8 @@ int tbnav_rbpf_particle_map(tbnav_rbpf* h, int32_t particle, int8_t* map);
  *                                independent; the order of operations inside one particle is the reference's).  0 = the default: the
  *                                cores in the process's affinity mask, at most 32. */
 enum { TBNAV_RBPF_OPT_DF_MODE = 1, TBNAV_RBPF_OPT_RAYCAST_ORDERED = 2, TBNAV_RBPF_OPT_RAYCAST_THREADS = 3, TBNAV_RBPF_OPT_COUNT_CELLS = 4,
-       TBNAV_RBPF_OPT_RAYCAST_FORM = 5, TBNAV_RBPF_OPT_RAYCAST_BAND_ROWS = 6, TBNAV_RBPF_OPT_BATCH_PIPELINE = 7, TBNAV_RBPF_OPT_HOST_THREADS = 8, TBNAV_RBPF_OPT_RAYCAST_ADAPT = 9, TBNAV_RBPF_OPT_RAYCAST_CELL16 = 10 };
+       TBNAV_RBPF_OPT_RAYCAST_FORM = 5, TBNAV_RBPF_OPT_RAYCAST_BAND_ROWS = 6, TBNAV_RBPF_OPT_BATCH_PIPELINE = 7, TBNAV_RBPF_OPT_HOST_THREADS = 8, TBNAV_RBPF_OPT_RAYCAST_ADAPT = 9, TBNAV_RBPF_OPT_RAYCAST_CELL16 = 10,
+       TBNAV_RBPF_OPT_NOISE_IN_KERNEL = 11 };
 enum { TBNAV_RBPF_DF_FULL = 0, TBNAV_RBPF_DF_WINDOW = 1, TBNAV_RBPF_DF_QUERY = 2, TBNAV_RBPF_DF_REFERENCE = 3 };
 int tbnav_rbpf_set_option(tbnav_rbpf* h, int32_t option, int32_t value);
 /* Since the last reset, summed over particles and scans (TBNAV_RBPF_OPT_COUNT_CELLS on): cell_updates = log-odds

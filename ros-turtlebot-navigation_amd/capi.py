@@ -29,6 +29,7 @@ RBPF_OPT_DF_MODE, RBPF_OPT_RAYCAST_ORDERED, RBPF_OPT_RAYCAST_THREADS, RBPF_OPT_C
 RBPF_OPT_RAYCAST_BAND_ROWS = 6
 RBPF_OPT_RAYCAST_ADAPT = 9
 RBPF_OPT_RAYCAST_CELL16 = 10
+RBPF_OPT_NOISE_IN_KERNEL = 11
 RBPF_OPT_BATCH_PIPELINE = 7
 RBPF_OPT_HOST_THREADS = 8
 RBPF_DF = {"full": 0, "window": 1, "query": 2, "reference": 3}

@@ -77,8 +77,17 @@ struct tbnav_rbpf {
   int max_beams = 0;
   double* d_normals = nullptr;
   size_t normals_cap = 0;
-  const double* last_normals = nullptr;  // the normals the last scan used (d_normals, or an entry of the batch ring)
+  const double* last_normals = nullptr;  // the normals the last scan used (d_normals, or an entry of the batch ring); NULL: drawn inside rbpf_propose
   size_t last_z_index = 0;               // where in them its resampling offset sits (N * stride)
+  const double* last_z_ptr = nullptr;    // the resampling offset's normal of the last scan, wherever it is (last_normals + last_z_index, or d_zslot)
+  // device noise drawn inside rbpf_propose (round 5; TBNAV_RBPF_OPT_NOISE_IN_KERNEL, default on): nothing is stored but the
+  // resampling offset's normal; workgroup 0 of the proposal launch carries the beam table over and publishes beam_seq (NoiseSrc)
+  int noise_in_kernel = 1;   // 1: normals drawn in the kernel, beams through its leading workgroup; 2: normals in the kernel, beams by a copy launch; 3 (development): stored normals, beams through the leading workgroup
+  double* d_zslot = nullptr;
+  unsigned int* d_beam_ready = nullptr;   // fine-grained
+  double2* d_beams_fg = nullptr; int fg_beams_cap = 0;   // fine-grained copy of the beam table (NoiseSrc::fg_beams)
+  unsigned int beam_seq = 0;
+  struct { unsigned long long seed = 0, scan = 0; size_t base = 0, z_index = 0, n = 0; bool valid = false; } last_drawn;  // what tbnav_rbpf_get_normals regenerates from
   // tbnav_rbpf_slam_batch draws the noise of a few scans ahead in one launch: normals and beam tables of ring_scans scans
   double* d_norm_ring = nullptr; size_t norm_ring_stride = 0;
   double2* d_beam_ring = nullptr; double2* h_beam_ring = nullptr; size_t beam_ring_stride = 0;
@@ -301,6 +310,7 @@ int status_from_err(const int err[4]) {
   if (err[0]) return TBNAV_ERR_OUT_OF_WORLD;
   if (err[2]) return TBNAV_ERR_PDF_VARIANCE;
   if (err[1]) return TBNAV_ERR_ETA_ZERO;
+  if (err[3] & 16) { tbnav::last_hip_error_slot() = "rbpf_propose: the scan's beam table never reached the device (the launch's leading workgroup never published it)"; return TBNAV_ERR_HIP; }
   if (err[3] & 8) return TBNAV_ERR_POOL_EXHAUSTED;  // no free log-odds tile left (the scan of that particle was not applied)
   if (err[3] & 4) return TBNAV_ERR_UNSUPPORTED;  // a likelihood lookup left the particle's refreshed window (cannot happen: see rbpf_window)
   if (err[3]) return TBNAV_ERR_BRESENHAM;
@@ -666,6 +676,40 @@ int scan_enqueue(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3
     if (rc != TBNAV_OK) return rc;
   }
   const size_t n_norm = (size_t)h->N * c.stride_normals + 1;
+  // device noise: drawn inside the proposal kernel, whose leading workgroup also carries the beam table over (NoiseSrc) — unless a
+  // kernel in front of it needs the table on the device (the per-particle scan matcher), the scan comes prepared with its chunk
+  // (tbnav_rbpf_slam_batch), or the option is off: then rbpf_sample_normals stores the same values first, as up to round 4
+  const bool dev_ok = !pre && !normals && !(h->sm_on && c.icp_ok);
+  const bool dn = dev_ok && (h->noise_in_kernel == 1 || h->noise_in_kernel == 2);        // normals drawn in the kernel
+  const bool stage = dev_ok && (h->noise_in_kernel == 1 || h->noise_in_kernel == 3);     // beam table through the leading workgroup
+  NoiseSrc ns{};
+  if (dn || stage) {
+    if (!h->d_zslot) {
+      TBNAV_HIP(hipMalloc((void**)&h->d_zslot, sizeof(double)));
+      TBNAV_HIP(hipExtMallocWithFlags((void**)&h->d_beam_ready, sizeof(unsigned int) * kReadyCopies * kReadyStride, hipDeviceMallocFinegrained));
+      TBNAV_HIP(hipMemsetAsync(h->d_beam_ready, 0, sizeof(unsigned int) * kReadyCopies * kReadyStride, st));
+      h->beam_seq = 0;
+    }
+    if (++h->beam_seq == 0u) ++h->beam_seq;   // (0 is the cleared word)
+    ns.seed = h->seed; ns.scan = h->scan_index;
+    ns.base = h->rng_n_global ? (size_t)h->rng_first * c.stride_normals : 0;
+    ns.z_index = h->rng_n_global ? (size_t)h->rng_n_global * c.stride_normals : (size_t)h->N * c.stride_normals;
+    ns.z_out = h->d_zslot;
+    if (stage && h->fg_beams_cap < h->max_beams) {
+      TBNAV_HIP(hipStreamSynchronize(st));
+      (void)hipFree(h->d_beams_fg); h->d_beams_fg = nullptr; h->fg_beams_cap = 0;
+      TBNAV_HIP(hipExtMallocWithFlags((void**)&h->d_beams_fg, sizeof(double2) * h->max_beams, hipDeviceMallocFinegrained));
+      h->fg_beams_cap = h->max_beams;
+    }
+    ns.host_beams = (const double2*)(h->h_beams + (size_t)slot * h->max_beams); ns.dev_beams = h->d_beams; ns.fg_beams = h->d_beams_fg;
+    ns.ready = stage ? h->d_beam_ready : nullptr; ns.seq = h->beam_seq; ns.on = dn ? 1 : 0;
+    if (!stage) TBNAV_HIP(hipMemcpyAsync(h->d_beams, ns.host_beams, sizeof(double2) * c.Bv, hipMemcpyHostToDevice, st));
+  }
+  h->last_drawn.valid = false;
+  if (dn) {
+    h->last_drawn.seed = ns.seed; h->last_drawn.scan = ns.scan; h->last_drawn.base = ns.base; h->last_drawn.z_index = ns.z_index;
+    h->last_drawn.n = n_norm; h->last_drawn.valid = true;
+  } else {
   if (!pre && n_norm > h->normals_cap) {
     TBNAV_HIP(hipStreamSynchronize(st));  // (a scan still in flight reads the old buffer)
     (void)hipFree(h->d_normals);
@@ -688,11 +732,13 @@ int scan_enqueue(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3
                        (unsigned long long)h->scan_index, h->d_normals, (const double2*)(h->h_beams + (size_t)slot * h->max_beams), h->d_beams, c.Bv);
     TBNAV_HIP(hipGetLastError());
   }
+  }
   ++h->scan_index;
   const double2* const beams_dev = pre ? pre->d_beams : h->d_beams;
-  const double* const normals_dev = pre ? pre->d_normals : h->d_normals;
+  const double* const normals_dev = dn ? nullptr : (pre ? pre->d_normals : h->d_normals);
   h->last_normals = normals_dev;
   h->last_z_index = (size_t)h->N * c.stride_normals;
+  h->last_z_ptr = dn ? h->d_zslot : normals_dev + h->last_z_index;
   for (int q = 0; q < 4; ++q) h_err[q] = 0;  // mapped: the scan that last owned the slot has been waited for
   h->h_norm[slot] = NormOut{};
   StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
@@ -756,13 +802,13 @@ int scan_enqueue(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3
   // threads against 43 with 512; the configs[4] shard 0.80 ms with 256 against 0.61 with 512
   h->lk_propose = (propose_lds + 3072 > (size_t)kMaxLds / 4) ? 2 * kProposeThreads : kProposeThreads;
   if (propose_lds + 3072 > (size_t)kMaxLds / 4)
-    hipLaunchKernelGGL((rbpf_propose<2 * kProposeThreads>), dim3(h->N), dim3(2 * kProposeThreads), propose_lds, st, c, beams_dev,
+    hipLaunchKernelGGL((rbpf_propose<2 * kProposeThreads>), dim3(h->N + (stage ? 1 : 0)), dim3(2 * kProposeThreads), propose_lds, st, c, beams_dev,
                      h->d_code[h->cur], h->pool, map_of(h), h->d_trow[h->cur], skip_arr, skip_eq, h->df_mode, h->radius, occ_half,
-                     h->d_nocc[h->cur], h->d_win, normals_dev, center, sp.pose, sp.prev, sp.weight, h->tr, h->d_sens, d_err, gate_prev, h->d_mixlut);
+                     h->d_nocc[h->cur], h->d_win, normals_dev, center, sp.pose, sp.prev, sp.weight, h->tr, h->d_sens, d_err, gate_prev, h->d_mixlut, ns);
     else
-    hipLaunchKernelGGL((rbpf_propose<kProposeThreads>), dim3(h->N), dim3(kProposeThreads), propose_lds, st, c, beams_dev,
+    hipLaunchKernelGGL((rbpf_propose<kProposeThreads>), dim3(h->N + (stage ? 1 : 0)), dim3(kProposeThreads), propose_lds, st, c, beams_dev,
                      h->d_code[h->cur], h->pool, map_of(h), h->d_trow[h->cur], skip_arr, skip_eq, h->df_mode, h->radius, occ_half,
-                     h->d_nocc[h->cur], h->d_win, normals_dev, center, sp.pose, sp.prev, sp.weight, h->tr, h->d_sens, d_err, gate_prev, h->d_mixlut);
+                     h->d_nocc[h->cur], h->d_win, normals_dev, center, sp.pose, sp.prev, sp.weight, h->tr, h->d_sens, d_err, gate_prev, h->d_mixlut, ns);
   TBNAV_HIP(hipGetLastError());
   if (weights_ready) TBNAV_HIP(hipEventRecord(weights_ready, st));  // (sharded filter: the exchange starts here, beside the map update)
   if (h->timing) TBNAV_HIP(hipEventRecord(h->ev[2], st));
@@ -770,7 +816,7 @@ int scan_enqueue(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3
   // workgroup (the chain of adds it is made of would otherwise sit on the critical path, and a second stream costs an
   // event and a dependent boundary).  With event timing on it is a launch of its own, so that the intervals mean what
   // they say.
-  const double* z_norm = normals_dev + (size_t)h->N * c.stride_normals;
+  const double* z_norm = h->last_z_ptr;
   tk.seq = (unsigned int)h->scans_done;
   const NormArgs nz{h->N, z_norm, sp.weight, sp.weight, h->d_cs, h->d_parent, h->d_norm + slot, h->d_gate + slot, gate_prev,
                     tk.poll ? h->d_seq + slot : nullptr, tk.seq, h->d_parent + h->N};
@@ -891,14 +937,23 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
 extern "C" {
 
 namespace {
-// host threads for the reference-field mode: the cores this process may run on (its affinity mask; a container's CPU quota is
-// not visible here — TBNAV_RBPF_OPT_HOST_THREADS overrides), at most 32
+// host threads for the reference-field mode: the cores this process may run on — its affinity mask, and under a cgroup CPU quota
+// (cpu.max: a container that sees 128 CPUs but may use 32 of them) no more than that — at most 128; TBNAV_RBPF_OPT_HOST_THREADS
+// overrides.  (Round 4 capped this at 32: the bench box has more.)
 int default_host_threads() {
   int n = 0;
   cpu_set_t set;
   if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
   if (n <= 0) n = (int)std::thread::hardware_concurrency();
-  return n < 1 ? 1 : (n > 32 ? 32 : n);
+  if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2: "<quota> <period>" or "max <period>"
+    long long quota = 0, period = 0;
+    if (std::fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) {
+      const int q = (int)((quota + period - 1) / period);
+      if (q >= 1 && q < n) n = q;
+    }
+    std::fclose(f);
+  }
+  return n < 1 ? 1 : (n > 128 ? 128 : n);
 }
 int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf** out) {
   if (!P || !out) return TBNAV_ERR_INVALID_ARG;
@@ -1135,6 +1190,7 @@ void tbnav_rbpf_destroy(tbnav_rbpf* h) {
   if (h->ev_w) (void)hipEventDestroy(h->ev_w);
   if (h->ev_g) (void)hipEventDestroy(h->ev_g);
   if (h->stream2) (void)hipStreamDestroy(h->stream2);
+  (void)hipFree(h->d_zslot); (void)hipFree(h->d_beam_ready); (void)hipFree(h->d_beams_fg);
   (void)hipFree(h->d_beams); (void)hipFree(h->d_normals); (void)hipFree(h->d_parent); (void)hipFree(h->d_best); (void)hipFree(h->d_best_pose); (void)hipFree(h->d_export); (void)hipFree(h->d_tier); (void)hipFree(h->d_fstate); (void)hipFree(h->d_skip); (void)hipFree(h->d_win); (void)hipFree(h->d_center); (void)hipFree(h->d_mixlut); (void)hipFree(h->d_bslots); (void)hipFree(h->d_bcount); (void)hipFree(h->d_bitems); (void)hipFree(h->d_bhdr); (void)hipFree(h->d_score);
   (void)hipFree(h->d_trace);
   (void)hipHostFree(h->h_beams); (void)hipHostFree(h->h_err); (void)hipHostFree(h->h_norm); (void)hipFree(h->d_gate);
@@ -1166,9 +1222,33 @@ int tbnav_rbpf_set_rng_shard(tbnav_rbpf* h, uint64_t first_particle, uint64_t pa
 }
 
 int tbnav_rbpf_get_normals(tbnav_rbpf* h, double* out, int64_t n) {
-  if (!h || !out || n <= 0 || (size_t)n > std::max(h->normals_cap, h->norm_ring_stride)) return TBNAV_ERR_INVALID_ARG;
+  if (!h || !out || n <= 0) return TBNAV_ERR_INVALID_ARG;
   DeviceGuard guard(h->device);
   TBNAV_HIP(hipStreamSynchronize(h->stream));
+  if (h->last_drawn.valid) {
+    // the last scan drew its noise inside the proposal kernel and stored none of it: the same counters through rbpf_sample_normals
+    // give the same values (one definition: normal_pair) — what the kernel used, regenerated for whoever asks
+    if ((size_t)n > h->last_drawn.n) return TBNAV_ERR_INVALID_ARG;
+    const size_t nn = h->last_drawn.n;
+    if (nn > h->normals_cap) {
+      (void)hipFree(h->d_normals); h->d_normals = nullptr; h->normals_cap = 0;
+      TBNAV_HIP(hipMalloc((void**)&h->d_normals, sizeof(double) * nn));
+      h->normals_cap = nn;
+    }
+    const int blocks = (int)std::min<size_t>((nn / 2 + 255) / 256, 4096);
+    const bool sharded = h->last_drawn.z_index != nn - 1 || h->last_drawn.base != 0;
+    if (sharded)
+      hipLaunchKernelGGL(rbpf_sample_normals, dim3(blocks), dim3(256), 0, h->stream, nn - 1, h->last_drawn.seed, h->last_drawn.scan, h->d_normals,
+                         (const double2*)nullptr, (double2*)nullptr, 0, (size_t)0, (size_t)0, h->last_drawn.base, h->last_drawn.z_index, nn - 1);
+    else
+      hipLaunchKernelGGL(rbpf_sample_normals, dim3(blocks), dim3(256), 0, h->stream, nn, h->last_drawn.seed, h->last_drawn.scan, h->d_normals,
+                         (const double2*)nullptr, (double2*)nullptr, 0, (size_t)0, (size_t)0, (size_t)0, ~(size_t)0, (size_t)0);
+    TBNAV_HIP(hipGetLastError());
+    TBNAV_HIP(hipStreamSynchronize(h->stream));
+    TBNAV_HIP(hipMemcpy(out, h->d_normals, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return TBNAV_OK;
+  }
+  if ((size_t)n > std::max(h->normals_cap, h->norm_ring_stride)) return TBNAV_ERR_INVALID_ARG;
   TBNAV_HIP(hipMemcpy(out, h->last_normals ? h->last_normals : h->d_normals, sizeof(double) * n, hipMemcpyDeviceToHost));
   return TBNAV_OK;
 }
@@ -1380,8 +1460,8 @@ int tbnav_rbpf_resample_global_dev(tbnav_rbpf* h, const double* d_weights_all, i
   }
   if (!h->d_gz) TBNAV_HIP(hipMalloc((void**)&h->d_gz, sizeof(double)));
   if (z != z) {  // NaN: the offset the last scan's device noise carries (with tbnav_rbpf_set_rng_shard: the ENSEMBLE's, same on every rank)
-    if (!h->last_normals || !h->last_z_index) return TBNAV_ERR_INVALID_ARG;
-    TBNAV_HIP(hipMemcpyAsync(h->d_gz, h->last_normals + h->last_z_index, sizeof z, hipMemcpyDeviceToDevice, st));
+    if (!h->last_z_ptr) return TBNAV_ERR_INVALID_ARG;
+    TBNAV_HIP(hipMemcpyAsync(h->d_gz, h->last_z_ptr, sizeof z, hipMemcpyDeviceToDevice, st));
   } else
   TBNAV_HIP(hipMemcpyAsync(h->d_gz, &z, sizeof z, hipMemcpyHostToDevice, st));
   *h->h_norm = NormOut{};
@@ -1755,7 +1835,7 @@ int sharded_scan(int n, tbnav_rbpf* const* hs, const float* scan, int n_beams, c
     DeviceGuard guard(h->device);
     h->h_norm[1] = NormOut{};
     // the resampling offset: the scan's last normal — with tbnav_rbpf_set_rng_shard (device noise) the ENSEMBLE's, identical on every rank
-    const double* zp = h->last_normals + h->last_z_index;
+    const double* zp = h->last_z_ptr;
     hipLaunchKernelGGL(rbpf_normalize, dim3(1), dim3(256), 0, h->stream2, (int)ng, zp, h->d_gw_raw, h->d_gw, h->d_gcs, h->d_gparent, h->d_norm + 1,
                        nullptr, nullptr, nullptr, 0u);
     (void)TBNAV_L(r, hipGetLastError());
@@ -2359,6 +2439,10 @@ int tbnav_rbpf_set_option(tbnav_rbpf* h, int32_t option, int32_t value) {
       return value == 0 ? TBNAV_OK : TBNAV_ERR_INVALID_ARG;
     case TBNAV_RBPF_OPT_COUNT_CELLS:
       h->count_touched = value != 0;
+      return TBNAV_OK;
+    case TBNAV_RBPF_OPT_NOISE_IN_KERNEL:
+      if (value < 0 || value > 3) return TBNAV_ERR_INVALID_ARG;
+      h->noise_in_kernel = value;
       return TBNAV_OK;
     default: return TBNAV_ERR_INVALID_ARG;
   }

@@ -500,6 +500,26 @@ struct ExportCuts {
 // ---- the kernels (defined in rbpf_<family>.hip) ----------------------------------------------------------------------
 // rbpf_propose.hip
 __global__ void rbpf_mix_lut(ScanC c, double* __restrict__ out);
+// Device noise drawn INSIDE rbpf_propose (round 5; normals == NULL and on != 0): the values rbpf_sample_normals would have stored —
+// same Philox counters, same Box-Muller — for the particle's own 3k + 3 (or 3) normals, and the scan's beam table carried over by
+// an extra leading workgroup instead of a launch of its own: workgroup 0 copies the table from pinned host memory to dev_beams,
+// leaves the resampling offset's normal in *z_out (read by the normalise, a later launch) and publishes `seq` in *ready; the
+// particles' workgroups (blockIdx.x - 1) look for it once without waiting when they start — those dispatched later find it —
+// and otherwise wait for it, bounded, just before they first need the table (by then it has long arrived: the copy takes one
+// PCIe round trip, their own first loads two dependent trips to HBM).
+constexpr int kReadyCopies = 64, kReadyStride = 32;   // copies of the "beam table is there" word (NoiseSrc::ready), 128 bytes apart
+struct NoiseSrc {
+  unsigned long long seed, scan;   // key and counter prefix (scan << 40) of the scan's stream
+  size_t base;                     // index of this handle's first normal in the ENSEMBLE's stream (sharded filters; 0 otherwise)
+  size_t z_index;                  // index of the resampling offset in it
+  double* z_out;
+  const double2* host_beams;       // pinned host memory, device-visible
+  double2* dev_beams;              // for the launches behind this one
+  double2* fg_beams;               // FINE-GRAINED device memory (uncached): for the other workgroups of this one
+  unsigned int* ready;             // fine-grained too: kReadyCopies copies, kReadyStride words apart
+  unsigned int seq;
+  int on;
+};
 __global__ void rbpf_sample_normals(size_t n, unsigned long long seed, unsigned long long scan, double* __restrict__ out,
                                     const double2* __restrict__ host_beams, double2* __restrict__ dev_beams, int n_copy,
                                     size_t out_stride = 0, size_t beam_stride = 0, size_t base = 0, size_t z_index = ~(size_t)0,
@@ -531,7 +551,7 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
                                                                 double* __restrict__ pose, double* __restrict__ prev_pose,
                                                                 double* __restrict__ weight, Trace tr, double* __restrict__ sens,
                                                                 int* __restrict__ err, const int* __restrict__ gate_prev,
-                                                                const double* __restrict__ mixlut);
+                                                                const double* __restrict__ mixlut, NoiseSrc ns);
 // rbpf_raycast.hip
 __global__ __launch_bounds__(kWave) void rbpf_raycast(ScanC c, TilePool P, MapT M, const double2* __restrict__ beams,
                                                      const double* __restrict__ pose, int* __restrict__ trow_occ,

@@ -303,6 +303,26 @@ __device__ __forceinline__ void philox4x32_10(unsigned long long ctr, unsigned l
   }
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
+// Box-Muller pair number P of scan `scan` under `seed`: normals 2P and 2P + 1 of the scan's stream (fp64: 53-bit uniforms, log, sqrt,
+// sincospi).  What rbpf_sample_normals stores and what rbpf_propose draws in place: one definition.
+__device__ __forceinline__ void normal_pair(unsigned long long seed, unsigned long long scan, size_t P, double& a_out, double& b_out) {
+  unsigned int r[4];
+  philox4x32_10((scan << 40) + P, seed, r);
+  const unsigned long long a = ((unsigned long long)r[0] << 32) | r[1], b = ((unsigned long long)r[2] << 32) | r[3];
+  const double u1 = ((double)(a >> 11) + 0.5) * 0x1.0p-53, u2 = ((double)(b >> 11) + 0.5) * 0x1.0p-53;
+  const double rad = sqrt(-2.0 * log(u1));
+  double sn, cs;
+  sincospi(2.0 * u2, &sn, &cs);
+  a_out = rad * cs; b_out = rad * sn;
+}
+// normals g, g + 1, g + 2 of the stream: two pairs whatever g's parity
+__device__ __forceinline__ void normal3(const NoiseSrc& ns, size_t g, double& n0, double& n1, double& n2) {
+  double a0, b0, a1, b1;
+  normal_pair(ns.seed, ns.scan, g >> 1, a0, b0);
+  normal_pair(ns.seed, ns.scan, (g >> 1) + 1, a1, b1);
+  const bool odd = (g & 1) != 0;
+  n0 = odd ? b0 : a0; n1 = odd ? a1 : b0; n2 = odd ? b1 : a1;
+}
 
 
 
@@ -374,16 +394,7 @@ __global__ void rbpf_sample_normals(size_t n, unsigned long long seed, unsigned 
                                     size_t z_slot) {
   scan += blockIdx.y; out += blockIdx.y * out_stride; host_beams += blockIdx.y * beam_stride; dev_beams += blockIdx.y * beam_stride;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_copy; i += gridDim.x * blockDim.x) dev_beams[i] = host_beams[i];
-  auto pair = [&](size_t P, double& a_out, double& b_out) {
-    unsigned int r[4];
-    philox4x32_10((scan << 40) + P, seed, r);
-    const unsigned long long a = ((unsigned long long)r[0] << 32) | r[1], b = ((unsigned long long)r[2] << 32) | r[3];
-    const double u1 = ((double)(a >> 11) + 0.5) * 0x1.0p-53, u2 = ((double)(b >> 11) + 0.5) * 0x1.0p-53;
-    const double rad = sqrt(-2.0 * log(u1));
-    double sn, cs;
-    sincospi(2.0 * u2, &sn, &cs);
-    a_out = rad * cs; b_out = rad * sn;
-  };
+  auto pair = [&](size_t P, double& a_out, double& b_out) { normal_pair(seed, scan, P, a_out, b_out); };
   const size_t p0 = base >> 1, pairs = n ? ((base + n - 1) >> 1) - p0 + 1 : 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += (size_t)gridDim.x * blockDim.x) {
     double va, vb;
@@ -584,10 +595,42 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
                                                                 double* __restrict__ pose, double* __restrict__ prev_pose,
                                                                 double* __restrict__ weight, Trace tr, double* __restrict__ sens,
                                                                 int* __restrict__ err, const int* __restrict__ gate_prev,
-                                                                const double* __restrict__ mixlut) {
+                                                                const double* __restrict__ mixlut, NoiseSrc ns) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   if (gate_prev && *gate_prev) return;  // the scan before this one resamples: see rbpf_raycast_box
-  const int p = blockIdx.x;
+  const bool dn = ns.on != 0;            // (launch-uniform) the noise is drawn here: see NoiseSrc
+  const bool stage = ns.ready != nullptr;  // (launch-uniform) ... and workgroup 0 carries the beam table over
+  if (stage && blockIdx.x == 0) {
+    // (two copies: the fine-grained one — uncached, so what the other workgroups of THIS launch read is what was stored, on whichever
+    //  XCD they run, without a cache invalidate per wave (four thousand of those emptied the L2s and cost 50 us a scan) — and the
+    //  ordinary one the map update, a later launch, reads through the caches)
+    //  (system-scope stores and loads, word by word: a plain access to fine-grained memory may still be served by the XCD's L2)
+    for (int b = threadIdx.x; b < c.Bv; b += NT) {
+      const double2 v = ns.host_beams[b];
+      __hip_atomic_store(&ns.fg_beams[b].x, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&ns.fg_beams[b].y, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      ns.dev_beams[b] = v;
+    }
+    if (dn && threadIdx.x == 0) {
+      double va, vb;
+      normal_pair(ns.seed, ns.scan, ns.z_index >> 1, va, vb);
+      *ns.z_out = (ns.z_index & 1) ? vb : va;
+    }
+    __builtin_amdgcn_s_waitcnt(0);   // this thread's stores have been acknowledged (vmcnt counts stores) ...
+    __syncthreads();                 // ... and so have every other thread's, before the sequence number says so
+    // kReadyCopies copies of the sequence number, a cache line apart: a thousand workgroups looking at ONE word queue at the memory
+    // side (a single address retires ~90 requests per microsecond: the first form of this cost every scan 80 us); workgroup b looks
+    // at copy b mod kReadyCopies
+    if (threadIdx.x < kReadyCopies) __hip_atomic_store(ns.ready + threadIdx.x * kReadyStride, ns.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
+  const unsigned int* const my_ready = ns.ready + (blockIdx.x & (kReadyCopies - 1)) * kReadyStride;
+  const int p = blockIdx.x - (stage ? 1 : 0);
+  if (!stage && dn && blockIdx.x == 0 && threadIdx.x == 0) {   // (no leading workgroup: particle 0's leaves the resampling offset's normal)
+    double va, vb;
+    normal_pair(ns.seed, ns.scan, ns.z_index >> 1, va, vb);
+    *ns.z_out = (ns.z_index & 1) ? vb : va;
+  }
   const int k = c.k;
   __shared__ double sh_mix[kMixLds];  // the head of the handle's mixture table (filled below, visible after the first barrier)
   const MixLut mixL{sh_mix, mixlut};
@@ -608,7 +651,9 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
   constexpr unsigned int kBoxHi = 0x7FF8C0DEu;      // high word of a NaN that carries a cell index: a pair term waiting for step 4's search
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
   const uint16_t* code = codes ? codes + (size_t)p * c.g.xsize * c.g.ysize : nullptr;  // NULL: no stored field (query mode)
-  const double* z = normals + (size_t)p * c.stride_normals;
+  const double* z = normals + (size_t)p * c.stride_normals;   // (dn: never dereferenced)
+  const size_t zg = ns.base + (size_t)p * c.stride_normals;   // dn: the same place in the ensemble's stream
+  __shared__ double sh_zz[3];   // dn: the new pose's three normals, drawn by the thread that would be sample k
   const int nocc = n_occ[p];
   // a particle whose field is authoritative (injected / whole-field fresh) always reads it
   // (the tile pointers are set unconditionally — nW == 0 means "no tile" — so that the compiler can see they are LDS
@@ -627,22 +672,48 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
   // (requested WITH the pose, used much later: the first 64 samples' normals by wave 0, the new pose's three normals and the
   //  particle's weight by the last step — each was a dependent round trip on the workgroup's critical path)
   double zj0 = 0.0, zj1 = 0.0, zj2 = 0.0;   // sample tid's normals (samples beyond the workgroup's size load theirs in step 1)
-  if (c.icp_ok && tid < k) { zj0 = z[3 * tid + 0]; zj1 = z[3 * tid + 1]; zj2 = z[3 * tid + 2]; }
+  if (!dn && c.icp_ok && tid < k) { zj0 = z[3 * tid + 0]; zj1 = z[3 * tid + 1]; zj2 = z[3 * tid + 2]; }
   double zz0 = 0.0, zz1 = 0.0, zz2 = 0.0, w_old = 0.0;
-  if (c.icp_ok && wid == 0) { zz0 = z[3 * k + 0]; zz1 = z[3 * k + 1]; zz2 = z[3 * k + 2]; w_old = weight[p]; }
+  if (c.icp_ok && wid == 0) { if (!dn) { zz0 = z[3 * k + 0]; zz1 = z[3 * k + 1]; zz2 = z[3 * k + 2]; } w_old = weight[p]; }
+  // (the beam table: has workgroup 0 published it already?  One look, no waiting — the workgroups dispatched after the first few
+  //  microseconds find it and request their beams here, under everything else, as before; the others come back to it below)
+  bool have_beams = true;
+  if (stage) have_beams = __hip_atomic_load(my_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == ns.seq;   // (fine-grained memory: no cache holds it)
+  auto beam_in = [&](int b) -> double2 {
+    if (!stage) return beams[b];
+    return double2{__hip_atomic_load(&ns.fg_beams[b].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __hip_atomic_load(&ns.fg_beams[b].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)};
+  };
   // (a table of at most NT entries — maps up to 512 x 512 cells at 256 threads — is requested WHOLE here, with the pose: which
   //  entries the window needs depends on the pose, and waiting for it made the staging below three dependent round trips)
   const int tt_all = ds.occ.TW * ds.occ.TW;
   const bool whole_table = ds.mode == 2 && occ_half > 0 && nocc && tt_all <= NT && tt_all <= 256;
   unsigned int my_id = 0u;
   if (whole_table && tid < tt_all) my_id = ds.occ.tab[tid];
+  if (dn && c.icp_ok) {
+    // drawn while the loads above are in flight (nothing here depends on them): the particle's 3k + 3 normals are (3k + 3) / 2 (+ 1)
+    // Box-Muller PAIRS of the stream — one pair per thread, the first threads of the workgroup (k = 50: 77 or 78 threads, two waves
+    // side by side; one thread per sample drew two pairs each and took twice as long on the workgroup's critical path) — straight
+    // into the samples' LDS slots (smp[3j + q] is local normal 3j + q) and, the last three, the new pose's
+    const int n_loc = 3 * k + 3;
+    const size_t P0 = zg >> 1;
+    const int npairs = (int)(((zg + (size_t)n_loc - 1) >> 1) - P0) + 1;
+    for (int t = tid; t < npairs; t += NT) {
+      double a, b;
+      normal_pair(ns.seed, ns.scan, P0 + (size_t)t, a, b);
+      const int l0 = (int)(2 * (P0 + (size_t)t) - zg + 1) - 1;   // local index of the pair's first normal: -1 .. n_loc - 1
+      if (l0 >= 0) { if (l0 < 3 * k) smp[l0] = a; else sh_zz[l0 - 3 * k] = a; }
+      if (l0 + 1 < n_loc) { if (l0 + 1 < 3 * k) smp[l0 + 1] = b; else sh_zz[l0 + 1 - 3 * k] = b; }
+    }
+  }
   TRACE_P(0);
   const double th0 = uniform_d(th0v), x0 = uniform_d(x0v), y0 = uniform_d(y0v);
   double mu0[3];
   if (!c.icp_ok) {
     // ICP failed: the pose moves by the odometry motion model (particle_filter.cpp:161-176, :295-322) — every thread works it
     // out (three draws, two sincos), and the LDS slice of the bitmap is staged round THAT pose's sensor
-    const double w0 = c.Lm[0] * z[0], w1 = c.Lm[1] * z[1], w2 = c.Lm[2] * z[2];
+    double z0n, z1n, z2n;
+    if (dn) normal3(ns, zg, z0n, z1n, z2n); else { z0n = z[0]; z1n = z[1]; z2n = z[2]; }
+    const double w0 = c.Lm[0] * z0n, w1 = c.Lm[1] * z1n, w2 = c.Lm[2] * z2n;
     const double uw = c.u[0], uvx = c.u[1];
     if (almost_equal(uw, 0.0)) {
       mu0[0] = normalize_angle_PI(th0 + w0);
@@ -663,14 +734,31 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
   }
   mu0[0] = uniform_d(mu0[0]); mu0[1] = uniform_d(mu0[1]); mu0[2] = uniform_d(mu0[2]);
   const double pv[3] = {uniform_d(pv0), uniform_d(pv1), uniform_d(pv2)};
-  for (int b = tid; b < c.Bv; b += NT) lbeams[b] = beams[b];  // visible after the next barrier
+  if (have_beams) for (int b = tid; b < c.Bv; b += NT) lbeams[b] = beam_in(b);  // visible after the next barrier
+  // (not published yet when this wave looked: wait for it just before the barrier in front of step 1 — bounded: a table that never
+  //  arrives raises err[3] bit 4 instead of hanging the device)
+  auto late_beams = [&]() {
+    if (have_beams) return;
+    if (lane == 0) {
+      // (bounded by a count of looks, not by the clock: wall_clock64 is a message to a unit every wave of the chip shares — four
+      //  thousand waves asking it once per look serialised there and cost every scan 50 us; a look is a trip to the memory side,
+      //  ~1 us with the sleep: the bound is a few tenths of a second)
+      int looks = 0;
+      while (__hip_atomic_load(my_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != ns.seq) {
+        if (++looks > 200000) { atomicOr(&err[3], 16); break; }
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int b = tid; b < c.Bv; b += NT) lbeams[b] = beam_in(b);   // (issued after lane 0 has SEEN the number; uncached: what was stored before it)
+  };
   for (int q = tid; q < kMixLds; q += NT) sh_mix[q] = mixlut[q];
   double Tc[4];  // sensor transform at the centre of the samples
   sensor_transform(c, mu0[0], mu0[1], mu0[2], Tc);
   Tc[0] = uniform_d(Tc[0]); Tc[1] = uniform_d(Tc[1]); Tc[2] = uniform_d(Tc[2]); Tc[3] = uniform_d(Tc[3]);
   // (the normals have arrived with the pose: parked in the samples' own LDS slots until wave 0 turns them into samples, so that
   //  they do not hold six registers through the staging)
-  if (c.icp_ok && tid < k) { smp[3 * tid + 0] = zj0; smp[3 * tid + 1] = zj1; smp[3 * tid + 2] = zj2; }
+  if (!dn && c.icp_ok && tid < k) { smp[3 * tid + 0] = zj0; smp[3 * tid + 1] = zj1; smp[3 * tid + 2] = zj2; }
   TRACE_P(1);
   bool staged = false;
   if (ds.mode == 2 && occ_half > 0 && nocc) {
@@ -733,11 +821,13 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
       }
       ds.tany = ta; ds.R0 = R0; ds.R1 = R1; ds.W0 = W0; ds.nW = nW; ds.lut7 = sh_lut7;
     }
+    late_beams();
     __syncthreads();
     staged = true;
   }
-  if (!staged) __syncthreads();  // lbeams / sh_mix / sh_def
+  if (!staged) { late_beams(); __syncthreads(); }  // lbeams / sh_mix / sh_def / sh_zz
   TRACE_P(3);
+  if (dn && c.icp_ok) { zz0 = sh_zz[0]; zz1 = sh_zz[1]; zz2 = sh_zz[2]; }
   zz0 = uniform_d(zz0); zz1 = uniform_d(zz1); zz2 = uniform_d(zz2); w_old = uniform_d(w_old);  // (arrived long ago; wave-uniform: scalar registers from here on)
 
   // ---- 1. wave 0 (ICP ok): samples, their sensor transforms, their odometry likelihoods.  The other waves (ICP failed: every
@@ -750,7 +840,7 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
     const double nrot1 = uniform_d(normalize_angle_PI(c.rot1)), nrot2 = uniform_d(normalize_angle_PI(c.rot2));
     for (int j = lane; j < k; j += kWave) {
       double sj[3];
-      const bool parked = j < NT;
+      const bool parked = dn || j < NT;   // (dn: every sample's normals are in its slot)
       const double n0 = parked ? smp[3 * j + 0] : z[3 * j + 0], n1 = parked ? smp[3 * j + 1] : z[3 * j + 1], n2 = parked ? smp[3 * j + 2] : z[3 * j + 2];
       sj[0] = mu0[0] + c.Ld[0] * n0; sj[1] = mu0[1] + c.Ld[1] * n1; sj[2] = mu0[2] + c.Ld[2] * n2;
       dth = fmax(dth, fabs(c.Ld[0] * n0));
@@ -1013,8 +1103,8 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
   TRACE_P(9);
   WGP_OUT();
 }
-template __global__ void rbpf_propose<kProposeThreads>(ScanC, const double2* __restrict__, const uint16_t* __restrict__, TilePool, MapT, const int* __restrict__, const int* __restrict__, int, int, int, int, const int* __restrict__, const int4* __restrict__, const double* __restrict__, const double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, Trace, double* __restrict__, int* __restrict__, const int* __restrict__, const double* __restrict__);
-template __global__ void rbpf_propose<2 * kProposeThreads>(ScanC, const double2* __restrict__, const uint16_t* __restrict__, TilePool, MapT, const int* __restrict__, const int* __restrict__, int, int, int, int, const int* __restrict__, const int4* __restrict__, const double* __restrict__, const double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, Trace, double* __restrict__, int* __restrict__, const int* __restrict__, const double* __restrict__);
+template __global__ void rbpf_propose<kProposeThreads>(ScanC, const double2* __restrict__, const uint16_t* __restrict__, TilePool, MapT, const int* __restrict__, const int* __restrict__, int, int, int, int, const int* __restrict__, const int4* __restrict__, const double* __restrict__, const double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, Trace, double* __restrict__, int* __restrict__, const int* __restrict__, const double* __restrict__, NoiseSrc);
+template __global__ void rbpf_propose<2 * kProposeThreads>(ScanC, const double2* __restrict__, const uint16_t* __restrict__, TilePool, MapT, const int* __restrict__, const int* __restrict__, int, int, int, int, const int* __restrict__, const int4* __restrict__, const double* __restrict__, const double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, Trace, double* __restrict__, int* __restrict__, const int* __restrict__, const double* __restrict__, NoiseSrc);
 
 }  // namespace tbnav_rk
 

@@ -92,6 +92,7 @@ class RefField {
     const size_t G = (size_t)xs_ * xs_;
     auto work = [&] {
       std::vector<uint8_t> marked(G);
+      std::vector<Node> store;   // the heap's storage, kept from one brushfire of this thread to the next
       for (int g = next.fetch_add(1); g < (int)groups.size(); g = next.fetch_add(1)) {
         Group& gr = groups[g];
         // no set operation at all: nothing occupied (the reference returns at :338), or the same set in the same order whose
@@ -101,7 +102,7 @@ class RefField {
         //  the rehash policy's state, so the copy behaves like the original from here on)
         auto s = std::make_shared<State>(*gr.from);
         apply(s->occ, gr.ev, (int)gr.n);
-        brushfire(*s, marked);
+        brushfire(*s, marked, store);
         s->fresh = true;
         fires.fetch_add(1);
         gr.to = s;
@@ -144,13 +145,68 @@ class RefField {
     st_.swap(tmp);
   }
 
- private:
-  // (12 bytes instead of the reference's 48-byte Cell: the heap is std::priority_queue — the same std::push_heap / std::pop_heap
-  //  sequence over the same comparison results, hence the same order among equal distances — it just moves a quarter of the bytes)
-  struct Node { uint32_t d2; uint16_t i, j, si, sj; };
-  struct Farther { bool operator()(const Node& a, const Node& b) const { return a.d2 > b.d2; } };  // CompareDistance, grid_mapper.hpp:104-110
-  using Heap = std::priority_queue<Node, std::vector<Node>, Farther>;
+  // (public: tests/ref_field_check.cpp drives Heap against std::priority_queue)
+  // The reference's queue is std::priority_queue<Cell, std::vector<Cell>, CompareDistance> (grid_mapper.hpp:104-110, 48-byte cells).
+  // What its result depends on is the ORDER in which equal distances leave the heap, i.e. libstdc++'s std::push_heap / std::pop_heap
+  // (bits/stl_heap.h: __push_heap, __adjust_heap) applied to the same comparison results.  Heap below is those two algorithms written
+  // out over 16-byte nodes — the hole walks down to a leaf taking, at every level, the child the library takes (the right one unless
+  // it is FARTHER than the left), then the displaced last element is pushed up from there — with the child chosen by arithmetic
+  // instead of a data-dependent branch (a 400 x 400 brushfire is 157 k pops through a heap of ~800 nodes, ten levels each: 8.0 -> 7.1 ms
+  // on one core; the state's copy, 0.05 ms, and the cleared marks, 0.005 ms, are not where the time is).  tests/test_ref_field_heap.py holds it against std::priority_queue itself (pop order of equal
+  // keys, whole fields) on random sequences; the GPU suite holds the fields against the oracle's, which is pinned to the compiled reference.
+  struct Node { uint32_t d2; uint16_t i, j, si, sj; uint32_t pad; };
+  static_assert(sizeof(Node) == 16, "one 16-byte move per level");
+  class Heap {
+   public:
+    explicit Heap(std::vector<Node>& store) : v_(store) { v_.clear(); }
+    bool empty() const { return v_.empty(); }
+    const Node& top() const { return v_.front(); }
+    // priority_queue::push = push_back + std::push_heap: __push_heap(first, len - 1, 0, value) with comp(parent, value) = parent.d2 > value.d2
+    void push(const Node& value) {
+      v_.push_back(value);
+      Node* const a = v_.data();
+      size_t hole = v_.size() - 1;
+      while (hole > 0) {
+        const size_t parent = (hole - 1) / 2;
+        if (!(a[parent].d2 > value.d2)) break;
+        a[hole] = a[parent];
+        hole = parent;
+      }
+      a[hole] = value;
+    }
+    // priority_queue::pop = std::pop_heap + pop_back: value = last; last = first; __adjust_heap(first, 0, len - 1, value)
+    void pop() {
+      Node* const a = v_.data();
+      const size_t len = v_.size() - 1;   // the heap that remains
+      if (len == 0) { v_.pop_back(); return; }
+      const Node value = a[len];
+      size_t hole = 0, child = 0;
+      const size_t inner = (len - 1) / 2;
+      while (child < inner) {
+        child = 2 * (child + 1);
+        child -= (size_t)(a[child].d2 > a[child - 1].d2);   // comp(first + secondChild, first + (secondChild - 1)): --secondChild
+        a[hole] = a[child];
+        hole = child;
+      }
+      if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        a[hole] = a[child - 1];
+        hole = child - 1;
+      }
+      while (hole > 0) {   // __push_heap(first, hole, 0, value)
+        const size_t parent = (hole - 1) / 2;
+        if (!(a[parent].d2 > value.d2)) break;
+        a[hole] = a[parent];
+        hole = parent;
+      }
+      a[hole] = value;
+      v_.pop_back();
+    }
+   private:
+    std::vector<Node>& v_;
+  };
 
+ private:
   // updateCellHash (grid_mapper.cpp:480-546) for the logged changes of one scan, in the reference's call order
   static void apply(std::unordered_set<int>& occ, const int* ev, int n) {
     for (int q = 0; q < n; ++q) {
@@ -161,41 +217,41 @@ class RefField {
   }
 
   // euclideanSignedDistanceField, grid_mapper.cpp:333-435
-  void brushfire(State& st, std::vector<uint8_t>& marked) const {
+  void brushfire(State& st, std::vector<uint8_t>& marked, std::vector<Node>& store) const {
     const std::unordered_set<int>& occ = st.occ;
     if (occ.empty()) return;
-    std::vector<uint16_t>& code = st.code;
+    uint16_t* const code = st.code.data();
     std::fill(marked.begin(), marked.end(), 0);  // "std::vector<int> marked(xsize_ * ysize_)", :342
-    std::vector<Node> store;
-    store.reserve((size_t)xs_ * 8);
-    Heap Q(Farther(), std::move(store));
+    uint8_t* const mk = marked.data();
+    if (store.capacity() < (size_t)xs_ * 8) store.reserve((size_t)xs_ * 8);
+    Heap Q(store);   // (the thread's storage: its capacity is kept from one brushfire to the next)
     for (int key : occ) {  // :348-362
       code[key] = 0;
-      marked[key] = 1;
+      mk[key] = 1;
       const uint16_t ki = (uint16_t)(key / xs_), kj = (uint16_t)(key % xs_);
-      Q.push(Node{0, ki, kj, ki, kj});
+      Q.push(Node{0, ki, kj, ki, kj, 0});
     }
+    const int xs = xs_, r = radius_, r2 = radius_ * radius_;
+    // enqueueCell, grid_mapper.cpp:272-329
+    auto enqueue = [&](int i, int j, int si, int sj) {
+      const int idx = i * xs + j;
+      if (mk[idx]) return;
+      const int di = std::abs(i - si), dj = std::abs(j - sj);
+      if (di >= r || dj >= r) return;  // distances_ is cell_radius_ x cell_radius_: .at() throws, caught, return (:300-308)
+      const int d2 = di * di + dj * dj;
+      if (d2 > r2) return;             // dist > cell_radius_ (:311-314); sqrt(d2) > r <=> d2 > r^2 exactly
+      code[idx] = (uint16_t)d2;
+      Q.push(Node{(uint32_t)d2, (uint16_t)i, (uint16_t)j, (uint16_t)si, (uint16_t)sj, 0});
+      mk[idx] = 1;
+    };
     while (!Q.empty()) {  // :399-433: top, push the four neighbours, THEN pop
       const Node c = Q.top();
-      if (c.i > 0) enqueue(c.i - 1, c.j, c.si, c.sj, Q, code, marked);
-      if (c.j > 0) enqueue(c.i, c.j - 1, c.si, c.sj, Q, code, marked);
-      if (c.i < xs_ - 1) enqueue(c.i + 1, c.j, c.si, c.sj, Q, code, marked);
-      if (c.j < xs_ - 1) enqueue(c.i, c.j + 1, c.si, c.sj, Q, code, marked);
+      if (c.i > 0) enqueue(c.i - 1, c.j, c.si, c.sj);
+      if (c.j > 0) enqueue(c.i, c.j - 1, c.si, c.sj);
+      if (c.i < xs - 1) enqueue(c.i + 1, c.j, c.si, c.sj);
+      if (c.j < xs - 1) enqueue(c.i, c.j + 1, c.si, c.sj);
       Q.pop();
     }
-  }
-
-  // enqueueCell, grid_mapper.cpp:272-329
-  void enqueue(int i, int j, int si, int sj, Heap& Q, std::vector<uint16_t>& code, std::vector<uint8_t>& marked) const {
-    const int idx = i * xs_ + j;
-    if (marked[idx]) return;
-    const int di = std::abs(i - si), dj = std::abs(j - sj);
-    if (di >= radius_ || dj >= radius_) return;  // distances_ is cell_radius_ x cell_radius_: .at() throws, caught, return (:300-308)
-    const int d2 = di * di + dj * dj;
-    if (d2 > radius_ * radius_) return;          // dist > cell_radius_ (:311-314); sqrt(d2) > r <=> d2 > r^2 exactly
-    code[idx] = (uint16_t)d2;
-    Q.push(Node{(uint32_t)d2, (uint16_t)i, (uint16_t)j, (uint16_t)si, (uint16_t)sj});
-    marked[idx] = 1;
   }
 
   int xs_, radius_;

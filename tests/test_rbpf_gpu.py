@@ -437,6 +437,49 @@ def test_device_noise_source_statistics_and_filter_health(gpu_pkg):
     assert np.array_equal(pf2.lastNormals(pf2.numNormals(True)), streams[0])
 
 
+@pytest.mark.parametrize("N,k,icp", [(64, 50, "ok"), (40, 300, "ok"), (33, 7, "alternating"), (1000, 50, "ok")])
+def test_noise_drawn_inside_the_proposal_kernel_equals_sampled_noise(gpu_pkg, N, k, icp):
+    """Round 5: with device noise the standard normals are drawn INSIDE rbpf_propose (nothing stored; the beam table rides in
+    through the launch's leading workgroup).  Same contract as MPPI's in-kernel sampler: the filter equals, bit for bit, (a) the
+    filter with TBNAV_RBPF_OPT_NOISE_IN_KERNEL = 0 (rbpf_sample_normals stores the stream first, as up to round 4) and (b) a
+    filter fed the regenerated stream (tbnav_rbpf_get_normals) as HOST normals — the path the oracle tests drive.  k = 300: more
+    samples than threads; alternating: ICP-failed scans (three normals per particle); a forced resampling on the way (the
+    resampling offset's normal is the one value the kernel does store)."""
+    from rtn_amd import capi
+    a, b, h = _dev(gpu_pkg, N=N, k=k), _dev(gpu_pkg, N=N, k=k), _dev(gpu_pkg, N=N, k=k)
+    b.setOption(capi.RBPF_OPT_NOISE_IN_KERNEL, 0)
+    for pf in (a, b, h):
+        pf.setSeed(4242)
+    n_scans = 5
+    steps, poses = rc.trajectory(n_scans, inc=(0.04, 0.03, 0.02))
+    rng = np.random.default_rng(3)
+    scans = [orc.room_scan(poses[s], walls=rc.ROOM_SMALL, rng=rng) for s in range(n_scans)]
+    resampled = 0
+    for s, (prev, cur, t_icp, u) in enumerate(steps):
+        ok = True if icp == "ok" else (s % 2 == 0)
+        if s == 2:
+            w = np.full(N, 0.2 / N); w[1] += 0.5; w[N - 2] += 0.3; w /= w.sum()
+            for pf in (a, b, h):
+                pf.setParticles(w=w)
+        sa = a.SLAM(scans[s], u, cur, prev, ok, t_icp, None)
+        sb = b.SLAM(scans[s], u, cur, prev, ok, t_icp, None)
+        assert sa.status == 0 and sb.status == 0
+        za, zb = a.lastNormals(a.numNormals(ok)), b.lastNormals(b.numNormals(ok))
+        assert np.array_equal(za, zb)                                   # regenerated from the counters == stored by the sample kernel
+        sh = h.SLAM(scans[s], u, cur, prev, ok, t_icp, za)             # ... and fed back as host normals
+        assert (sa.neff, sa.resampled) == (sb.neff, sb.resampled) == (sh.neff, sh.resampled)
+        resampled += int(sa.resampled)
+        for x, y in ((a, b), (a, h)):
+            (px, vx, wx), (py, vy, wy) = x.particles(), y.particles()
+            assert np.array_equal(px, py) and np.array_equal(vx, vy) and np.array_equal(wx, wy), s
+    assert resampled >= 1
+    for p in (0, N // 2, N - 1):
+        assert np.array_equal(a.logOdds(p), b.logOdds(p)) and np.array_equal(a.logOdds(p), h.logOdds(p))
+    assert a.lastKernelNames()[0] == b.lastKernelNames()[0]
+    for pf in (a, b, h):
+        pf.close()
+
+
 def test_device_map_export_matches_glibc_evaluation(gpu_pkg):
     """newMap on the device: int8 {-1, 0, 100, (int8)(prob*100)}, transposed
     (grid_mapper.cpp:185-226).  The device never evaluates prob; it uses log-odds break points found with glibc
