@@ -106,7 +106,7 @@ def kernel_profile(m, a, b, stream, n, rng=None):
     return acc / rounds
 
 
-def roofline_obj(K, T, ms_kernels, ms_tick, kernel_name, grid_threads=None, traffic_key=None):
+def roofline_obj(K, T, ms_kernels, ms_tick, kernel_name, grid_threads=None, traffic_key=None, stats_workload=None, sq_key=None):
     """The dominant kernel against the HBM roofline.  `achieved` / `frac` (= frac_events): SURVEY 8-d's algorithmic bytes of the
     kernel / its live HIP-event duration in THIS run; `frac_rocprof`: the same bytes / the rocprofv3 average of the row named in
     `rocprof` (profiles/, committed) — every figure recomputable from one named row.  The two clocks differ for the 5 us kernels
@@ -116,8 +116,9 @@ def roofline_obj(K, T, ms_kernels, ms_tick, kernel_name, grid_threads=None, traf
     alg = BYTES_ROLLOUT_KERNEL * K * T
     achieved = alg / (ms_kernels[0] * 1e-3) / 1e9
     tick_gbs = BYTES_PER_ROLLOUT_STEP * K * T / (ms_tick * 1e-3) / 1e9
-    row = bp.rocprof_row(kernel_name, grid_threads)
+    row = bp.rocprof_row(kernel_name, grid_threads, stats_workload)
     pmc = bp.pmc_row(traffic_key, kernel_name) if traffic_key else None
+    sq = bp.sq_row(sq_key, kernel_name) if sq_key else None
     frac_rp = None if row is None else round(alg / (row["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 6)
     return {
         "bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
@@ -126,6 +127,8 @@ def roofline_obj(K, T, ms_kernels, ms_tick, kernel_name, grid_threads=None, traf
         "traffic": None if pmc is None else pmc["hbm_bytes"],
         "traffic_source": None if pmc is None else pmc["source"] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
         "algorithmic_bytes_per_launch": alg,
+        "frac_rocprof_of": "avg_us",   # (every frac_rocprof of this line divides by the named row's AVERAGE; its median rides in `rocprof`)
+        "sq_counters": sq,
         "kernel_ms": {"rollout": round(float(ms_kernels[0]), 6), "partials": round(float(ms_kernels[1]), 6),
                       "combine": round(float(ms_kernels[2]), 6)},
         "whole_tick": {"algorithmic_bytes": BYTES_PER_ROLLOUT_STEP * K * T, "ms": round(ms_tick, 6),
@@ -358,7 +361,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"MPPI newControls K={K} per GPU, T={T} (BASELINE configs[1]); global K={world * K}",
-                       "noise": "drawn on the device inside the timed tick (Philox4x32-10 + Box-Muller, in the rollout kernel)",
+                       "noise": "drawn on the device inside the timed tick, in the rollout kernel: Philox4x32-10 + Box-Muller in fp32 on 24-bit uniforms (normals on a 2^-24 grid "
+                                "out to 5.9 sigma; the path's arithmetic is fp64).  The reference draws std::normal_distribution<double> (utilities.cpp:20-24): "
+                                "options.mppi_tick_fp64_sampler is the same tick with that width (52-bit uniforms, fp64 log / sqrt / sincospi in the kernel)",
                        "state_carried": True,
                        "parallelism": f"rollout-shard x{world}" + (", 1 all-gather of soft-min records/tick" if world > 1 else "")},
             "rollout_steps_per_s": round(value * T, 1),
@@ -374,7 +379,7 @@ def main():
                                                   + " of the soft-min records issued by libtbnav_hip.so on the tick's stream (tbnav_mppi_attach_comm)")
                                                  if comm is not None else f"torch.distributed {dist.get_backend()} all-gather from Python (rtn_amd.sharded; the in-library communicator was unavailable or the one-GPU dev switch is on)"),
             "ms_per_step_one_python_call_per_tick": None if el_py is None else round(el_py / args.steps * 1e3, 6),
-            "roofline": dict(roofline_obj(K, T, ms_k, ms_step, k_rollout, None, "mppi_K1024_T50" if (K, T) == (1024, 50) else None),
+            "roofline": dict(roofline_obj(K, T, ms_k, ms_step, k_rollout, None, "mppi_K1024_T50" if (K, T) == (1024, 50) else None, None, "mppi_K1024_T50_device_noise"),
                              combine_kernel=k_combine),
             # the tick is two dependent launches: what the guide prices for that alone (MI355X_MICROARCH.md, "boundary" row)
             "latency_floor": {"dependent_launches_per_tick": 2, "boundary_us_each": [1.45, 1.9],
@@ -421,7 +426,7 @@ def main():
             tl = lambda: ml.enqueueDev(X0, al.data_ptr(), bl.data_ptr(), stream)  # noqa: E731
             el_l = time_ticks(tl, sync, 50, 10, lambda: None)
             ms_l = kernel_profile(ml, al, bl, stream, 50)
-            rl = roofline_obj(KL, ml.steps, ms_l, el_l / 50 * 1e3, ml.lastKernelNames()[0], KL, "mppi_K65536_T100")
+            rl = roofline_obj(KL, ml.steps, ms_l, el_l / 50 * 1e3, ml.lastKernelNames()[0], KL, "mppi_K65536_T100", None, "mppi_K65536_T100")
             rl["workload"] = f"MPPI newControls K={KL}, T={ml.steps} on 1 GPU, noise resident in HBM (the streaming regime)"
             rl["rollouts_per_s"] = round(KL * 50 / el_l, 1)
             line["roofline_large"] = rl
@@ -437,9 +442,15 @@ def main():
                 ms8.enqueueRng(X0, SEED, tk8[0], stream)
                 tk8[0] += 1
             el8r = time_ticks(rng8, sync, 200, 20, lambda: None)
+            # its own roofline object (round-4 review): the production tick's kernels at this shape, HIP events; the committed rows are
+            # those of this workload's own profiler passes (tools/profile_round.sh: mppi_K8192_T100)
+            ms_k8 = kernel_profile(ms8, a8, b8, stream, 200, rng=(SEED, 30_000_000))
+            rl8 = roofline_obj(KL // 8, ms8.steps, ms_k8, el8r / 200 * 1e3, ms8.lastKernelNames()[0], None, "mppi_K8192_T100", "mppi_K8192_T100", "mppi_K8192_T100")
+            rl8["combine_kernel"] = ms8.lastKernelNames()[1]
+            rl8["fp64_flops_note"] = "the rollout is ~200 fp64 operations per rollout-step: 8192 x 100 x 200 / kernel time against the 78.6 TFLOP/s vector peak is the other roof (DESIGN.md section 4)"
             line["configs3_shard_one_gpu"] = {"workload": f"MPPI K={KL // 8} (= 65536 / 8), T={ms8.steps}, one GPU", "kernel": ms8.rollout_kernel,
                                               "ms_per_step_resident_noise": round(el8 / 200 * 1e3, 6), "ms_per_step_device_noise": round(el8r / 200 * 1e3, 6),
-                                              "rollouts_per_s_device_noise": round(KL // 8 * 200 / el8r, 1)}
+                                              "rollouts_per_s_device_noise": round(KL // 8 * 200 / el8r, 1), "roofline": rl8}
             ms8.close()
         if world == 1:
             n_a = min(args.steps, 1000)
@@ -459,6 +470,24 @@ def main():
             line["options"]["mppi_exact_arc_dynamics"] = {"rollouts_per_s": round(K * n_a / el_a, 1),
                                                           "ms_per_step": round(el_a / n_a * 1e3, 6)}
             ma.close()
+            # the same production tick with the fp64 sampler (TBNAV_MPPI_OPT_SAMPLER = 1): what the narrower default sampler is worth
+            from rtn_amd import capi as _capi
+            mw = make_mppi(K, horizon, local_rank)
+            mw.setOption(_capi.MPPI_OPT_SAMPLER, 1)
+            tkw = [0]
+
+            def wide_ticks(n):
+                mw.enqueueRngBatch(X0, SEED, tkw[0], n, stream)
+                tkw[0] += n
+            wide_ticks(min(args.warmup, 100)); sync()
+            t0w = time.perf_counter()
+            wide_ticks(n_a); sync()
+            el_w = time.perf_counter() - t0w
+            line["options"]["mppi_tick_fp64_sampler"] = {"rollouts_per_s": round(K * n_a / el_w, 1), "ms_per_step": round(el_w / n_a * 1e3, 6),
+                                                          "kernel": mw.lastKernelNames()[0],
+                                                          "note": "Philox -> two 52-bit uniforms -> fp64 Box-Muller (log, sqrt, sincospi) inside the rollout kernel: normals out to 8.57 sigma "
+                                                                  "(tests/test_mppi_gpu.py: tail counts to 6 sigma); the headline's sampler is fp32 on 24-bit uniforms"}
+            mw.close()
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(K, T, horizon, threads=1)
             import bench_rbpf

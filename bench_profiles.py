@@ -3,6 +3,9 @@ recomputed from the committed profiler output.
 
   profiles/<round>_kernel_stats.md   rocprofv3 --kernel-trace --stats of `python bench.py ...` (tools/profile_round.sh,
                                      profiles/summarize_rocpd.py): | kernel | grid (threads) | wg | calls | avg us | min | max | ... | median us
+  profiles/<round>_kernel_stats_<workload>.md   (round 5) the same table from a --kernel-trace --stats pass of ONE workload's driver
+                                     (tools/profile_round.sh): the per-GPU shard shapes and the SURVEY room, whose launches the bench run
+                                     mixes with other legs' — looked up first when a workload is named
   profiles/<round>_traffic_pmc.json  separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/collect_pmc.sh,
                                      tools/pmc_summary.py, tools/assemble_profiles.py): workloads.<key>.<kernel>.hbm_bytes
 
@@ -15,7 +18,7 @@ import os
 import re
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-ROUNDS = ("r04", "r03")
+ROUNDS = ("r05", "r04", "r03")
 
 
 def _first_existing(suffix):
@@ -53,15 +56,36 @@ def kernel_stats_rows(path=None):
     return rows, os.path.relpath(path, ROOT)
 
 
-def rocprof_row(kernel: str, grid_threads: int | None = None):
+def rocprof_row(kernel: str, grid_threads: int | None = None, workload: str | None = None):
     """The row of exactly this kernel instantiation (as the profiler spells it) — with this many threads in the grid when the
-    kernel was launched in several shapes; None when there is no such row."""
-    rows, src = kernel_stats_rows()
+    kernel was launched in several shapes; None when there is no such row.  workload: look in that workload's own table
+    (profiles/<round>_kernel_stats_<workload>.md) first; its AVERAGE is over that workload's launches only."""
+    rows, src = (None, None)
+    if workload:
+        path = _first_existing(f"kernel_stats_{workload}.md")
+        if path:
+            rows, src = kernel_stats_rows(path)
+    if not rows:
+        rows, src = kernel_stats_rows()
     hits = [r for r in rows if r["kernel"] == kernel and (grid_threads is None or r["grid_threads"] == grid_threads)]
     if not hits:
         return None
     r = max(hits, key=lambda q: q["calls"])
     return dict(source=src, row=f"{r['kernel']} | {r['grid']}", avg_us=r["avg_us"], median_us=r["median_us"], min_us=r["min_us"], calls=r["calls"])
+
+
+def sq_row(workload: str, kernel: str):
+    """The SQ counter entry (instruction mix, busy cycles) of `kernel` in workload `workload` of the committed SQ pass; None if absent."""
+    path = _first_existing("sq_counters.json")
+    if not path:
+        return None
+    try:
+        with open(path) as f:
+            wl = json.load(f)[workload]
+    except (OSError, KeyError, ValueError):
+        return None
+    v = wl.get(kernel)
+    return None if v is None else dict(source=f"{os.path.relpath(path, ROOT)}: {workload}.{kernel}", **v)
 
 
 def pmc_row(workload: str, kernel: str, prefix_ok: bool = False):

@@ -79,6 +79,74 @@ def configs4_shard(device, N=12500, k=50, n_scans=8):
     return out
 
 
+def _kernel_threads(name):   # "rbpf_raycast_box<512, 6, false, 8>" -> 512
+    return int(name.split("<")[1].rstrip(">").split(",")[0])
+
+
+def map_update_leg(device, label, N, k, map_half, walls, inc, n_scans=12, n_beams=360, beam_delta_deg=1.0, pool_bytes=0,
+                   traffic_key=None, stats_workload=None, sq_key=None):
+    """A first-class leg for ONE workload of the scan update (round-4 review: every BASELINE shape carries its own roofline): the
+    kernels that ran (names as the profiler spells them), their HIP-event times over the plain scans, the distinct cells counted on
+    the device (TBNAV_RBPF_OPT_COUNT_CELLS) -> algorithmic bytes of the map update, its fraction of the HBM roofline by events and
+    by the AVERAGE of this workload's own committed profiler row, and the PMC traffic of this workload's own passes."""
+    from rtn_amd import capi
+    from rtn_amd.rbpf import ParticleFilter, default_params
+    import bench_profiles as bp
+    rc = _world()
+    mk = lambda: ParticleFilter(default_params(N=N, k=k, map_min=-map_half, map_max=map_half, beam_delta_deg=beam_delta_deg,  # noqa: E731
+                                               device=device.index or 0), pool_bytes=pool_bytes)
+    steps, poses = rc.trajectory(n_scans, inc=inc)
+    rng = np.random.default_rng(7)
+    scans = [_room_scan(poses[s], rng, walls, n_beams=n_beams, beam_delta_deg=beam_delta_deg) for s in range(n_scans)]
+    pf_c = mk()
+    pf_c.setSeed(2026); pf_c.setOption(capi.RBPF_OPT_COUNT_CELLS, 1)
+    for s, (prev, cur, t_icp, u) in enumerate(steps):
+        if s == 2:
+            pf_c.scanCounts(reset=True)
+        st = pf_c.SLAM(scans[s], u, cur, prev, True, t_icp, None)
+    upd, distinct = pf_c.scanCounts()
+    pf_c.close()
+    distinct_per, upd_per = distinct / ((n_scans - 2) * N), upd / ((n_scans - 2) * N)
+    pf_k = mk()
+    pf_k.setSeed(2026); pf_k.setTiming(True)
+    kms, n_k, wall = {}, 0, 0.0
+    for s, (prev, cur, t_icp, u) in enumerate(steps):
+        t0 = time.perf_counter()
+        st = pf_k.SLAM(scans[s], u, cur, prev, True, t_icp, None)
+        if s >= 4:   # (the LDS array has adapted to the boxes' need by then)
+            wall += time.perf_counter() - t0
+            for key, v in pf_k.kernelMs().items():
+                kms[key] = kms.get(key, 0.0) + v
+            n_k += 1
+    k_propose, k_raycast, _ = pf_k.lastKernelNames()
+    cap, free, tile_bytes = pf_k.poolStats()
+    pf_k.close()
+    kms = {key: v / n_k for key, v in kms.items() if key not in ("edt", "occupancy")}
+    alg = distinct_per * 16.0 * N
+    t_rc = kms["raycast"] * 1e-3
+    grid = _kernel_threads(k_raycast) * (N + 1) if "<" in k_raycast else None
+    row = None if grid is None else (bp.rocprof_row(k_raycast, grid, stats_workload) or bp.rocprof_row(k_raycast, _kernel_threads(k_raycast) * N, stats_workload))
+    pmc = bp.pmc_row(traffic_key, k_raycast) if traffic_key else None
+    return {"workload": f"RBPF {label}: N={N}, k={k}, {int(st.n_valid_beams)} valid beams of {n_beams}, {int(2 * map_half / 0.05)}^2 @0.05 m, walls {list(walls)}, trajectory step {list(inc)}; "
+                        f"synchronous scans with event timing, device noise",
+            "kernels": {"propose": k_propose, "raycast": k_raycast},
+            "kernel_ms": {key: round(v, 4) for key, v in kms.items()}, "scans_timed": n_k,
+            "log_odds_bytes_in_use": (cap - free) * tile_bytes,
+            "roofline": {"bound": "hbm", "kernel": k_raycast, "kernel_ms": round(kms["raycast"], 6),
+                         "algorithmic_bytes_per_launch": round(alg, 1),
+                         "algorithmic_bytes_note": f"{distinct_per:.1f} distinct cells written per particle and scan (counted on the device) x 16 B x N; per-touch count {upd_per:.1f}",
+                         "achieved": round(alg / t_rc / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg / t_rc / 1e9 / HBM_PEAK_GBS, 6), "frac_events": round(alg / t_rc / 1e9 / HBM_PEAK_GBS, 6),
+                         "frac_rocprof": None if row is None else round(alg / (row["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 6),
+                         "frac_rocprof_of": "avg_us", "rocprof": row,
+                         "traffic": None if pmc is None else pmc["hbm_bytes"],
+                         "traffic_source": None if pmc is None else pmc["source"] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; plain scans)",
+                         "traffic_over_algorithmic": None if pmc is None else round(pmc["hbm_bytes"] / alg, 3),
+                         "sq_counters": bp.sq_row(sq_key, k_raycast) if sq_key else None,
+                         "second_kernel": {"kernel": k_propose, "kernel_ms": round(kms["propose"], 6),
+                                           "rocprof": bp.rocprof_row(k_propose, _kernel_threads(k_propose) * (N + 1), stats_workload) if "<" in k_propose else None}}}
+
+
 def reference_field_mode(device, N, k, map_half, walls, n_scans, host_threads=0, spread=None, start=(0.0, 0.0, 0.0), inc=None):
     """The product in the mode that reproduces the reference's distance field bit for bit (TBNAV_RBPF_DF_REFERENCE: what
     bmapping::ParticleFilter defaults to up to 4096 particles): the priority-queue brushfires run on the host's cores — ONE per
@@ -274,6 +342,11 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
     t_k10 = replay(pf_k, True)
     pf_k.close()
     shard4 = None if getattr(args, "no_large", False) else configs4_shard(device)
+    if shard4 is not None:
+        # ... and its roofline object: the per-GPU shard shape of BASELINE configs[4] (12 500 x 2000^2 x 1080 beams), synchronous scans
+        shard4["roofline_leg"] = map_update_leg(device, "configs[4] / 8", 12500, k, 50.0, ROOM_SURVEY, (0.05, 0.04, 0.03), n_scans=8, n_beams=1080,
+                                                beam_delta_deg=1.0 / 3.0, pool_bytes=16 << 30, traffic_key="rbpf_N12500_2000x2000_1080beams",
+                                                stats_workload="rbpf_N12500_2000x2000_1080beams", sq_key="rbpf_N12500_2000x2000_1080beams")
     cfg4 = None if getattr(args, "no_large", False) else configs4_as_written(device)
     rc_ = _world()
     ref_mode = {"launch_configuration_40_particles_80x80": reference_field_mode(device, 40, 50, 2.0, rc_.ROOM_SMALL, 12),
@@ -299,13 +372,16 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
     import bench_profiles as bp
     t_rc = kms["raycast"] * 1e-3   # s per launch, live HIP events
     # the committed profiler rows of exactly this instantiation and grid (N particles' workgroups + the normalise workgroup)
-    def _threads(name):   # "rbpf_raycast_box<512, 6, false, 8>" -> 512
-        return int(name.split("<")[1].rstrip(">").split(",")[0])
+    _threads = _kernel_threads
     rp_row = None
     if "<" in k_raycast and N == 1000:   # the grid of THIS workload: N particles' workgroups (+ the normalise workgroup when it rode along)
-        rp_row = bp.rocprof_row(k_raycast, _threads(k_raycast) * (N + 1)) or bp.rocprof_row(k_raycast, _threads(k_raycast) * N)
+        rp_row = (bp.rocprof_row(k_raycast, _threads(k_raycast) * (N + 1), "rbpf_N1000_k50_400x400_plain_scans_only") or
+                  bp.rocprof_row(k_raycast, _threads(k_raycast) * (N + 1)) or bp.rocprof_row(k_raycast, _threads(k_raycast) * N))
     pmc = bp.pmc_row("rbpf_N1000_k50_400x400_plain_scans_only", k_raycast) if N == 1000 else None
-    rp_propose = bp.rocprof_row(k_propose, _threads(k_propose) * N) if "<" in k_propose and N == 1000 else None
+    rp_propose = None
+    if "<" in k_propose and N == 1000:   # (round 5: the proposal launch has a leading workgroup that carries the beam table over)
+        rp_propose = (bp.rocprof_row(k_propose, _threads(k_propose) * (N + 1), "rbpf_N1000_k50_400x400_plain_scans_only") or
+                      bp.rocprof_row(k_propose, _threads(k_propose) * (N + 1)) or bp.rocprof_row(k_propose, _threads(k_propose) * N))
     rm = ref_mode.get("configs2_1000_particles_400x400") or {}
     rm_off = ref_mode.get("configs2_off_the_cell_corners") or {}
     # the two modes side by side, with equal weight (round-3 review): the one that reproduces the reference's results, and the
@@ -352,6 +428,11 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
                                           "note": "every scan with icp_ok = 0: sampleMotionModel + one likelihoodFieldModel per particle (particle_filter.cpp:157-176); whatever resampling the run triggers by itself is in the time"},
                     "k10": {"value": round(N / t_k10, 1), "ms_per_scan": round(t_k10 * 1e3, 4),
                             "note": "num_samples_mode = 10 instead of the shipped 50 (SURVEY.md 8-d: BASELINE names no k)"}},
+        # SURVEY 8-d's own room (+-3.0 / +-2.5 m, 246 valid beams): its boxes do not fit four workgroups per CU, the map update runs another
+        # instantiation — a first-class leg with its own kernel name, bytes, profiler row and PMC row (round-4 review)
+        "survey_room": None if getattr(args, "no_large", False) else map_update_leg(
+            device, "SURVEY 8-d room", N, k, 10.0, ROOM_SURVEY, TRAJ_SURVEY, traffic_key="rbpf_N1000_k50_400x400_survey_room",
+            stats_workload="rbpf_N1000_k50_400x400_survey_room", sq_key="rbpf_N1000_k50_400x400_survey_room"),
         "configs4_shard_one_gpu": shard4,
         "configs4_as_written_one_gpu": cfg4,
         "distance_field_mode": "query",
@@ -366,10 +447,11 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
                      "achieved": round(alg_dom / t_rc / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(alg_dom / t_rc / 1e9 / HBM_PEAK_GBS, 6),
                      "frac_events": round(alg_dom / t_rc / 1e9 / HBM_PEAK_GBS, 6),
-                     # (the row's MEDIAN where the table has one: the plain scan's launch, like kernel_ms — the average also holds the scans
-                     #  after a resampling, which copy tiles as well)
-                     "frac_rocprof": None if rp_row is None else round(alg_dom / ((rp_row.get("median_us") or rp_row["avg_us"]) * 1e-6) / 1e9 / HBM_PEAK_GBS, 6),
-                     "frac_rocprof_of": None if rp_row is None else ("median_us" if rp_row.get("median_us") else "avg_us"),
+                     # (ONE convention for every frac_rocprof of the line, round-4 review: the named row's AVERAGE — here the row of this
+                     #  workload's own plain-scan pass; the median beside it)
+                     "frac_rocprof": None if rp_row is None else round(alg_dom / (rp_row["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 6),
+                     "frac_rocprof_of": "avg_us",
+                     "frac_rocprof_median": None if rp_row is None or not rp_row.get("median_us") else round(alg_dom / (rp_row["median_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 6),
                      "rocprof": rp_row,
                      "algorithmic_bytes_per_launch": round(alg_dom, 1),
                      "algorithmic_bytes_note": f"{distinct_per:.1f} distinct cells written per particle and scan (counted on the device, TBNAV_RBPF_OPT_COUNT_CELLS) x 16 B x N",

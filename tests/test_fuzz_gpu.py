@@ -1,0 +1,36 @@
+"""One bounded randomized sweep inside the suite (round-4 review: the fuzz tools were only ever run by hand, their logs in untracked
+scratch): tools/fuzz_parity.py — random sizes, gains, poses near +-pi, sensor models that make the run resample by itself, scan
+matcher, ICP failures, band loop — 20 MPPI ticks-pairs + 40 RBPF runs + 10 pipelined replays from a FIXED seed, each against the
+oracle with the suite's own assertions.  About 40 s.  The summary goes to profiles/r05_fuzz_in_suite.txt when the run happens in the
+repo (the committed copy is the GPU box's)."""
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bounded_fuzz_sweep_of_both_paths_against_the_oracle(gpu_pkg):
+    t0 = time.perf_counter()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "20", "40", "2025", "", "10"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    dt = time.perf_counter() - t0
+    lines = [l for l in r.stdout.splitlines() if l.startswith(("mppi:", "rbpf:", "batch:", "[FAIL]"))]
+    summary = "\n".join([f"python tools/fuzz_parity.py 20 40 2025 '' 10   ({dt:.1f} s, exit code {r.returncode})"] + lines) + "\n"
+    print("\n" + summary)
+    for d in ("profiles", "gpurun_out"):   # (gpurun_out/ is what a gpurun call carries back; profiles/ holds the committed copy)
+        try:
+            os.makedirs(os.path.join(ROOT, d), exist_ok=True)
+            with open(os.path.join(ROOT, d, "r05_fuzz_in_suite.txt"), "w") as f:
+                f.write(summary)
+        except OSError:
+            pass
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert any(l.startswith("mppi: 20 cases done, failures so far 0") for l in lines)
+    assert any(l.startswith("rbpf: 40 cases done, failures so far 0") for l in lines)
+    assert any(l.startswith("batch: 10 cases done, failures so far 0") for l in lines)
