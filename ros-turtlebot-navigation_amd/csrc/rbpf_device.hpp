@@ -293,7 +293,7 @@ __host__ __device__ constexpr size_t box_lds_bytes(size_t cap, size_t bv, size_t
 // the 16-bit cell form: half the cell array + the slot table (hash_words u32, a power of two >= 2 x (bv + 64) slots)
 __host__ __device__ constexpr size_t box16_hash_words(size_t bv) { size_t h = 256; while (h < 2 * (bv + 64)) h *= 2; return h; }
 __host__ __device__ constexpr size_t box16_lds_bytes(size_t cap, size_t bv, size_t ev = kBoxEv) { return box_lds_bytes(cap, bv, ev) - 2 * cap + 4 * box16_hash_words(bv); }
-constexpr size_t kBoxStaticLds = 768;  // the kernel's __shared__ variables (tools/kernel_resources.py rbpf_raycast: 7xx B), rounded up
+constexpr size_t kBoxStaticLds = 896;  // the kernel's __shared__ variables (tools/kernel_resources.py rbpf_raycast: 856 B since mt_src, round 5), rounded up
 // (512 threads: three workgroups = 24 waves per CU when the LDS array is sized by what the boxes need, see launch_raycast —
 //  6 waves per SIMD leave 80 registers a lane: the kernel needs 77 and spills nothing; 1024 threads: two workgroups = 32 waves, 64)
 

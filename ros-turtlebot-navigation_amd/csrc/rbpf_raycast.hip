@@ -439,9 +439,11 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
   auto val_at = [&](int slot) -> double* { return slot < Bv ? reinterpret_cast<double*>(ev + slot * kEv) : val_hot + (slot - Bv); };
   __shared__ int bad, bx0, bx1, by0, by1, srx, sry, nocc_delta, n_ovf;
   __shared__ unsigned long long need_base;
-  __shared__ unsigned int mt_id[kMapTilesMax];  // map tiles under the box: the tile the particle's table names (once written: its private tile)
-  __shared__ unsigned char mt_touch[kMapTilesMax], mt_priv[kMapTilesMax];  // (bytes: every byte of LDS counts towards a fourth resident workgroup)
-  __shared__ signed char mt_slot[kMapTilesMax];
+  __shared__ unsigned int mt_id[kMapTilesMax];  // map tiles under the box: the tile the particle's table names (once written: its private tile) — where the update WRITES
+  __shared__ unsigned int mt_src[kMapTilesMax]; // ... and the tile it named when the band began — where the update READS (round 5: a tile made private in this
+                                                //     launch is not copied whole first; the cells the update writes go from the shared tile straight into the new one)
+  __shared__ unsigned char mt_touch[kMapTilesMax];  // (bytes: every byte of LDS counts towards a fourth resident workgroup ...
+  __shared__ unsigned int mt_priv_bits[2];          //  ... and bits: tile q of the box is private to the particle already)
   __shared__ int rc_delta[kBoxSideMax / kTS + 2];
   __shared__ unsigned short ovf[kWave];                 // slots whose event list overflowed (more than these: found by scanning)
   __shared__ double sh_pose[4];
@@ -473,7 +475,7 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
     if (lane == 0) {
       sh_pose[0] = X; sh_pose[1] = Y; sh_pose[2] = st0; sh_pose[3] = ct0;
       bad = robot_ok ? 0 : 1; bx0 = bx1 = rx0; by0 = by1 = ry0; srx = rx0; sry = ry0;
-      nocc_delta = 0; n_ovf = 0; robot_cnt = 0;
+      nocc_delta = 0; n_ovf = 0; robot_cnt = 0; mt_priv_bits[0] = 0u; mt_priv_bits[1] = 0u;
     }
   } else {
     uint4* t4 = reinterpret_cast<uint4*>(tile);
@@ -539,10 +541,11 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
   //  tile it names is fetched beside the walk: nothing needs it before phase C)
   if (tq >= 0 && tq < mtn) {
     const int qi = floor_div_small(tq, mty), qj = tq - qi * mty;
-    mt_id[tq] = tab[(tx0 + qi) * M.TW + (ty0 + qj)];
+    const unsigned int id0 = tab[(tx0 + qi) * M.TW + (ty0 + qj)];
+    mt_id[tq] = id0; mt_src[tq] = id0;
   }
   auto map_tile = [&](int cx, int cy) { return __mul24((cx >> kTSh) - tx0, mty) + ((cy >> kTSh) - ty0); };
-  auto cell_ptr = [&](int cx, int cy) -> double* { return P.lo + (size_t)mt_id[map_tile(cx, cy)] * kTileCells + in_tile(cx, cy); };
+  auto cell_ptr = [&](int cx, int cy) -> const double* { return P.lo + (size_t)mt_src[map_tile(cx, cy)] * kTileCells + in_tile(cx, cy); };   // (reads: see mt_src)
   auto toggled = [&](int cx, int cy, bool now) {  // the cell crossed the occupied cut-off: its bit in the (private) tile, tile-row count, total
     atomicXor(&P.bm[(size_t)mt_id[map_tile(cx, cy)] * kTS + (cx & (kTS - 1))], 1u << (cy & (kTS - 1)));
     atomicAdd(&rc_delta[(cx >> kTSh) - tx0], now ? 1 : -1);
@@ -572,7 +575,7 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
       asm volatile("" : "+v"(z));
       for (int t = tid; t < tile_words / 4; t += nthr) t4[t] = uint4{z, z, z, z};
       for (int b = tid; b < Bv; b += nthr) ecnt[b] = 0;
-      for (int t = tid; t < kMapTilesMax; t += nthr) mt_touch[t] = 0;
+      for (int t = tid; t < kMapTilesMax; t += nthr) { mt_touch[t] = 0; mt_src[t] = mt_id[t]; }   // (what an earlier band made private is the tile to read now)
       if (tid == 0) n_ovf = 0;
       __syncthreads();
     }
@@ -605,7 +608,7 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
     if (x0 == minx && tq >= 0 && tq < mtn) {
       const unsigned int id = mt_id[tq];
       const int rf = id ? P.ref[id] : 0;
-      mt_priv[tq] = (id != 0u && rf == 1) ? 1 : 0;
+      if (id != 0u && rf == 1) atomicOr(&mt_priv_bits[tq >> 5], 1u << (tq & 31));
     }
     if (x0 == minx && tid == nthr - kWave) {  // the robot's own cell (the last wave walks no ray)
       const unsigned int rt = tab[(rx >> kTSh) * M.TW + (ry >> kTSh)];
@@ -763,23 +766,50 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
     // C. make the written tiles private to the particle (first write after a resample, or first touch of the area): ONE pop
     //    of the free ring for all of them, then one wave per tile copies 8 KB.  Usually there is nothing to do — and every wave
     //    sees that for itself (one ballot over the at most 64 tiles under the box), without a barrier to agree on it.
-    const unsigned long long need_m = __ballot(lane < mtn && mt_touch[lane < mtn ? lane : 0] && !mt_priv[lane < mtn ? lane : 0]);
+    const unsigned long long need_m = __ballot(lane < mtn && mt_touch[lane < mtn ? lane : 0]) &
+                                      ~((unsigned long long)mt_priv_bits[0] | ((unsigned long long)mt_priv_bits[1] << 32));
     if (need_m) {  // workgroup-uniform
-      if (wid == 0 && lane < mtn) mt_slot[lane] = (signed char)(((need_m >> lane) & 1ull) ? __popcll(need_m & ((1ull << lane) - 1ull)) : -1);
       if (tid == 0) { need_base = tile_pop_n(P, (unsigned int)__popcll(need_m)); if (need_base == ~0ull) bad = 1; }
       __syncthreads();
       if (bad) { if (tid == 0) atomicOr(&err[3], 8); return; }  // tile pool exhausted (nothing has been written if this is the first band)
       for (int q = wid; q < mtn; q += nw) {
-        if (!mt_touch[q] || mt_slot[q] < 0) continue;
+        if (!((need_m >> q) & 1ull)) continue;
         const int qi = floor_div_small(q, mty), qj = q - qi * mty;
         // (the ring position and the lane are taken afresh in every trip — an LDS read, an opaque copy: as loop invariants the position
-        //  and the lane's bitmap address were kept live across the 8 KB copy and spilled, 2 x 8 bytes of scratch per lane)
+        //  and the lane's bitmap address were kept live across the copy and spilled, 2 x 8 bytes of scratch per lane)
         const unsigned long long nb = *reinterpret_cast<volatile unsigned long long*>(&need_base);
         int ln = lane;
         asm volatile("" : "+v"(ln));
-        const unsigned int nid = tile_at(P, nb + (unsigned long long)mt_slot[q]);
-        tile_clone_into(P, tab, shed, (tx0 + qi) * M.TW + (ty0 + qj), nid, ln);
-        if (lane == 0) { mt_id[q] = nid; mt_priv[q] = 1; }
+        const int slot_q = __popcll(need_m & ((1ull << q) - 1ull));   // (every wave holds the same ballot: no table of slots in LDS)
+        const unsigned int nid = tile_at(P, nb + (unsigned long long)slot_q);
+        // The fresh tile takes from the shared one ONLY what this band's update will not write: the pairs of the tile outside the
+        // band and the band's untouched pairs (and the occupancy bits).  A touched pair is read from the shared tile (mt_src) and
+        // written to the new one by the passes below anyway — copying it first moved every byte of the tile twice: the scan that
+        // follows a resampling spent 45 of its 85 us there (~16 tiles x 8 KB per particle, read and written).
+        const int t_map = (tx0 + qi) * M.TW + (ty0 + qj);
+        const unsigned int id = tab[t_map];
+        double2* const dst = reinterpret_cast<double2*>(P.lo + (size_t)nid * kTileCells);
+        const double2* const src = reinterpret_cast<const double2*>(P.lo + (size_t)id * kTileCells);  // id 0 = the zero tile
+        const int gx0 = (tx0 + qi) << kTSh, gy0 = (ty0 + qj) << kTSh;   // the tile's first cell
+#pragma unroll
+        for (int i = 0; i < kTileCells / 2 / kWave; ++i) {
+          const int pi = i * kWave + ln;                                   // pair pi of the tile: row pi / 16, cells 2 (pi % 16), + 1
+          const int cx = gx0 + (pi >> (kTSh - 1)), cy = gy0 + 2 * (pi & (kTS / 2 - 1));
+          bool written = false;
+          if ((unsigned int)(cx - x0) < (unsigned int)nr && cy >= miny && cy < miny + bw) {
+            const int bp = __mul24(cx - x0, bw >> 1) + ((cy - miny) >> 1);  // the pair's index in the band's array
+            if constexpr (C16) written = tile[bp] != 0u;
+            else { const uint2 wv = reinterpret_cast<const uint2*>(tile)[bp]; written = (wv.x | wv.y) != 0u; }
+          }
+          if (!written) dst[pi] = src[pi];
+        }
+        if (ln < kTS) P.bm[(size_t)nid * kTS + ln] = P.bm[(size_t)id * kTS + ln];
+        if (ln == 0) {
+          P.ref[nid] = 1;
+          tab[t_map] = nid;
+          if (id != 0u) shed[t_map] = id;  // a (p, t) entry leaves a shared tile at most once between two resamples
+          mt_id[q] = nid; atomicOr(&mt_priv_bits[q >> 5], 1u << (q & 31));  // (mt_src keeps the shared tile: what the passes below read)
+        }
       }
       __syncthreads();
     }
@@ -941,7 +971,7 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
       const bool next_live = qn < n_items;
       const int jn = floor_div_small(next_live ? qn : 0, PW), pcn = (next_live ? qn : 0) - __mul24(jn, PW);
       const int cxbn = A0 + kSl * jn, cyn = miny + 2 * pcn;
-      const double* const ptrn = P.lo + (size_t)mt_id[map_tile(cxbn, cyn)] * kTileCells + in_tile(cxbn, cyn);
+      const double* const ptrn = P.lo + (size_t)mt_src[map_tile(cxbn, cyn)] * kTileCells + in_tile(cxbn, cyn);   // (reads: the tile named when the band began)
       const int pibn = __mul24(cxbn - x0, PW) + pcn;
       auto request_next = [&](int i) {
         double2 nv = double2{0.0, 0.0};
