@@ -147,6 +147,39 @@ def map_update_leg(device, label, N, k, map_half, walls, inc, n_scans=12, n_beam
                                            "rocprof": bp.rocprof_row(k_propose, _kernel_threads(k_propose) * (N + 1), stats_workload) if "<" in k_propose else None}}}
 
 
+def noise_forms(device, N, k, n_scans=30):
+    """Where the device noise is drawn (TBNAV_RBPF_OPT_NOISE_IN_KERNEL), side by side on the bench workload: 1 (default) — inside
+    rbpf_propose, the beam table through its leading workgroup, two launches per scan; 0 — rbpf_sample_normals stores the stream first
+    (up to round 4), three launches.  Wall time of synchronous calls without event timing, and the proposal kernel by HIP events."""
+    from rtn_amd import capi
+    from rtn_amd.rbpf import ParticleFilter, default_params
+    steps, scans = workload(n_scans)
+    out = {}
+    for name, val in (("in_kernel", 1), ("stored_first", 0)):
+        res = {}
+        for timing in (False, True):
+            pf = ParticleFilter(default_params(N=N, k=k, map_min=-10.0, map_max=10.0, device=device.index or 0))
+            pf.setSeed(2026); pf.setTiming(timing); pf.setOption(capi.RBPF_OPT_NOISE_IN_KERNEL, val)
+            wall, n, prop = 0.0, 0, 0.0
+            for s, (prev, cur, t_icp, u) in enumerate(steps):
+                t0 = time.perf_counter()
+                pf.SLAM(scans[s], u, cur, prev, True, t_icp, None)
+                if s >= 6:
+                    wall += time.perf_counter() - t0; n += 1
+                    if timing:
+                        prop += pf.kernelMs()["propose"]
+            if timing:
+                res["propose_kernel_ms"] = round(prop / n, 5); res["propose_kernel"] = pf.lastKernelNames()[0]
+            else:
+                res["ms_per_synchronous_scan"] = round(wall / n * 1e3, 5)
+            pf.close()
+        out[name] = res
+    out["note"] = ("drawing inside the kernel removes the 4.7 us rbpf_sample_normals launch and 2.4 MB of traffic per scan and adds ~4 us to the proposal kernel's own chain "
+                   "(78 threads draw one fp64 Box-Muller pair each in front of the first barrier): the wall time of a synchronous scan is the same within 1-2 us — the "
+                   "sample launch used to run under the host's enqueue of the proposal launch.  The headline's tbnav_rbpf_slam_batch draws a chunk of scans ahead in one launch either way")
+    return out
+
+
 def reference_field_mode(device, N, k, map_half, walls, n_scans, host_threads=0, spread=None, start=(0.0, 0.0, 0.0), inc=None):
     """The product in the mode that reproduces the reference's distance field bit for bit (TBNAV_RBPF_DF_REFERENCE: what
     bmapping::ParticleFilter defaults to up to 4096 particles): the priority-queue brushfires run on the host's cores — ONE per
@@ -433,6 +466,7 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
         "survey_room": None if getattr(args, "no_large", False) else map_update_leg(
             device, "SURVEY 8-d room", N, k, 10.0, ROOM_SURVEY, TRAJ_SURVEY, traffic_key="rbpf_N1000_k50_400x400_survey_room",
             stats_workload="rbpf_N1000_k50_400x400_survey_room", sq_key="rbpf_N1000_k50_400x400_survey_room"),
+        "noise_forms": noise_forms(device, N, k),
         "configs4_shard_one_gpu": shard4,
         "configs4_as_written_one_gpu": cfg4,
         "distance_field_mode": "query",

@@ -82,7 +82,7 @@ struct tbnav_rbpf {
   const double* last_z_ptr = nullptr;    // the resampling offset's normal of the last scan, wherever it is (last_normals + last_z_index, or d_zslot)
   // device noise drawn inside rbpf_propose (round 5; TBNAV_RBPF_OPT_NOISE_IN_KERNEL, default on): nothing is stored but the
   // resampling offset's normal; workgroup 0 of the proposal launch carries the beam table over and publishes beam_seq (NoiseSrc)
-  int noise_in_kernel = 1;   // 1: normals drawn in the kernel, beams through its leading workgroup; 2: normals in the kernel, beams by a copy launch; 3 (development): stored normals, beams through the leading workgroup
+  int noise_in_kernel = 1;   // TBNAV_RBPF_OPT_NOISE_IN_KERNEL
   double* d_zslot = nullptr;
   unsigned int* d_beam_ready = nullptr;   // fine-grained
   double2* d_beams_fg = nullptr; int fg_beams_cap = 0;   // fine-grained copy of the beam table (NoiseSrc::fg_beams)
@@ -112,7 +112,7 @@ struct tbnav_rbpf {
   std::vector<double2> beams_tmp;
   int raycast_band_rows = 0;   // > 0: cap the LDS array of rbpf_raycast_box at about this many box rows (TBNAV_RBPF_OPT_RAYCAST_BAND_ROWS, tests)
   int raycast_cell16 = 1;      // 0: never the 16-bit cell form; 1: where it buys a higher residency (default); 2: wherever it can run (TBNAV_RBPF_OPT_RAYCAST_CELL16)
-  int lk_raycast = -1, lk_raycast_wps = 0, lk_raycast_c16 = 0, lk_raycast_ev = 8, lk_raycast_grid = 0, lk_propose = 0, lk_box_need = 0, lk_box_cap = 0;  // the instantiations the last launches were (tbnav_rbpf_last_kernel_names): raycast threads (0 = beam-ordered), its workgroups, propose threads
+  int lk_raycast = -1, lk_raycast_wps = 0, lk_raycast_c16 = 0, lk_raycast_ev = 8, lk_raycast_grid = 0, lk_propose = 0, lk_propose_dn = 0, lk_box_need = 0, lk_box_cap = 0;  // the instantiations the last launches were (tbnav_rbpf_last_kernel_names): raycast threads (0 = beam-ordered), its workgroups, propose threads
   double* d_sens = nullptr;    // [N][4] sensor transform (X, Y, sin, cos) of each particle's new pose, left by the proposal kernel
   uint64_t seed = 0x5EEDull, scan_index = 0;  // device noise source (normals == NULL)
   uint64_t rng_first = 0, rng_n_global = 0;   // sharded filters: this handle's particles are [rng_first, rng_first + N) of rng_n_global (0 = unsharded)
@@ -680,8 +680,8 @@ int scan_enqueue(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3
   // kernel in front of it needs the table on the device (the per-particle scan matcher), the scan comes prepared with its chunk
   // (tbnav_rbpf_slam_batch), or the option is off: then rbpf_sample_normals stores the same values first, as up to round 4
   const bool dev_ok = !pre && !normals && !(h->sm_on && c.icp_ok);
-  const bool dn = dev_ok && (h->noise_in_kernel == 1 || h->noise_in_kernel == 2);        // normals drawn in the kernel
-  const bool stage = dev_ok && (h->noise_in_kernel == 1 || h->noise_in_kernel == 3);     // beam table through the leading workgroup
+  const bool dn = dev_ok && h->noise_in_kernel == 1;   // normals drawn in the kernel AND the beam table through its leading workgroup
+  const bool stage = dn;
   NoiseSrc ns{};
   if (dn || stage) {
     if (!h->d_zslot) {
@@ -801,14 +801,13 @@ int scan_enqueue(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3
   // tables leave room for two or three only (1080 beams: 58 KB) — measured: 360 beams 32 us per 1000 particles with 256
   // threads against 43 with 512; the configs[4] shard 0.80 ms with 256 against 0.61 with 512
   h->lk_propose = (propose_lds + 3072 > (size_t)kMaxLds / 4) ? 2 * kProposeThreads : kProposeThreads;
-  if (propose_lds + 3072 > (size_t)kMaxLds / 4)
-    hipLaunchKernelGGL((rbpf_propose<2 * kProposeThreads>), dim3(h->N + (stage ? 1 : 0)), dim3(2 * kProposeThreads), propose_lds, st, c, beams_dev,
-                     h->d_code[h->cur], h->pool, map_of(h), h->d_trow[h->cur], skip_arr, skip_eq, h->df_mode, h->radius, occ_half,
-                     h->d_nocc[h->cur], h->d_win, normals_dev, center, sp.pose, sp.prev, sp.weight, h->tr, h->d_sens, d_err, gate_prev, h->d_mixlut, ns);
-    else
-    hipLaunchKernelGGL((rbpf_propose<kProposeThreads>), dim3(h->N + (stage ? 1 : 0)), dim3(kProposeThreads), propose_lds, st, c, beams_dev,
-                     h->d_code[h->cur], h->pool, map_of(h), h->d_trow[h->cur], skip_arr, skip_eq, h->df_mode, h->radius, occ_half,
-                     h->d_nocc[h->cur], h->d_win, normals_dev, center, sp.pose, sp.prev, sp.weight, h->tr, h->d_sens, d_err, gate_prev, h->d_mixlut, ns);
+  h->lk_propose_dn = dn ? 1 : 0;
+#define TBNAV_PROPOSE(NT_, DN_) hipLaunchKernelGGL((rbpf_propose<NT_, DN_>), dim3(h->N + (DN_ ? 1 : 0)), dim3(NT_), propose_lds, st, c, beams_dev,                    \
+                     h->d_code[h->cur], h->pool, map_of(h), h->d_trow[h->cur], skip_arr, skip_eq, h->df_mode, h->radius, occ_half,                       \
+                     h->d_nocc[h->cur], h->d_win, normals_dev, center, sp.pose, sp.prev, sp.weight, h->tr, h->d_sens, d_err, gate_prev, h->d_mixlut, ns)
+  if (propose_lds + 3072 > (size_t)kMaxLds / 4) { if (dn) TBNAV_PROPOSE(2 * kProposeThreads, true); else TBNAV_PROPOSE(2 * kProposeThreads, false); }
+  else { if (dn) TBNAV_PROPOSE(kProposeThreads, true); else TBNAV_PROPOSE(kProposeThreads, false); }
+#undef TBNAV_PROPOSE
   TBNAV_HIP(hipGetLastError());
   if (weights_ready) TBNAV_HIP(hipEventRecord(weights_ready, st));  // (sharded filter: the exchange starts here, beside the map update)
   if (h->timing) TBNAV_HIP(hipEventRecord(h->ev[2], st));
@@ -1132,8 +1131,10 @@ int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf*
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 1024);
   // the proposal / scan-match kernels carry the scan, the per-sample data and the bitmap slice: more than the 64 KB
   // default for long scans or many samples
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_propose<kProposeThreads>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 3072);  // (2.3 KB static)
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_propose<2 * kProposeThreads>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 3072);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_propose<kProposeThreads, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 3072);  // (2.3 KB static)
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_propose<2 * kProposeThreads, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 3072);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_propose<kProposeThreads, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 3072);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_propose<2 * kProposeThreads, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 3072);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_scanmatch), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_edt_compact<kEdtRowsA>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)edt_compact_lds(kEdtRowsA));
@@ -2441,7 +2442,7 @@ int tbnav_rbpf_set_option(tbnav_rbpf* h, int32_t option, int32_t value) {
       h->count_touched = value != 0;
       return TBNAV_OK;
     case TBNAV_RBPF_OPT_NOISE_IN_KERNEL:
-      if (value < 0 || value > 3) return TBNAV_ERR_INVALID_ARG;
+      if (value != 0 && value != 1) return TBNAV_ERR_INVALID_ARG;
       h->noise_in_kernel = value;
       return TBNAV_OK;
     default: return TBNAV_ERR_INVALID_ARG;
@@ -2476,7 +2477,7 @@ int tbnav_rbpf_set_timing(tbnav_rbpf* h, int32_t enable) {
 
 int tbnav_rbpf_last_kernel_names(const tbnav_rbpf* h, char* propose, int32_t propose_cap, char* raycast, int32_t raycast_cap, int32_t* raycast_workgroups) {
   if (!h) return TBNAV_ERR_INVALID_ARG;
-  if (propose && propose_cap > 0) { if (h->lk_propose) snprintf(propose, (size_t)propose_cap, "rbpf_propose<%d>", h->lk_propose); else propose[0] = 0; }
+  if (propose && propose_cap > 0) { if (h->lk_propose) snprintf(propose, (size_t)propose_cap, "rbpf_propose<%d, %s>", h->lk_propose, h->lk_propose_dn ? "true" : "false"); else propose[0] = 0; }
   if (raycast && raycast_cap > 0) {
     if (h->lk_raycast > 0) snprintf(raycast, (size_t)raycast_cap, "rbpf_raycast_box<%d, %d, %s, %d>", h->lk_raycast, h->lk_raycast_wps, h->lk_raycast_c16 ? "true" : "false", h->lk_raycast_ev);
     else if (h->lk_raycast == 0) snprintf(raycast, (size_t)raycast_cap, "rbpf_raycast");

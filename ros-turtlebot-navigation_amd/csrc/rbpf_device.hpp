@@ -540,7 +540,7 @@ __global__ __launch_bounds__(kMatchThreads) void rbpf_scanmatch(ScanC c, ScanMat
                                                                 const double* __restrict__ pose, double* __restrict__ center,
                                                                 double* __restrict__ score, int* __restrict__ err,
                                                                 const int* __restrict__ gate_prev, const double* __restrict__ mixlut);
-template <int NT>
+template <int NT, bool DN>
 __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c, const double2* __restrict__ beams,
                                                                 const uint16_t* __restrict__ codes,
                                                                 TilePool P, MapT M,

@@ -584,7 +584,7 @@ __global__ __launch_bounds__(kMatchThreads) void rbpf_scanmatch(ScanC c, ScanMat
 //   5. wave 0 alone: the weighted sums, the 3 x 3 LLT, the new pose, weight *= eta (:545-599, :214-231)
 // The ICP-failed branch (:161-176) is steps 0, 1 (every wave looks beams up, at the moved pose), 2 and a product.
 // Same cells, same terms as the reference's brute force; only the ORDER of the products / sums differs (asserted <= 1e-9).
-template <int NT>
+template <int NT, bool DN>
 __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c, const double2* __restrict__ beams,
                                                                 const uint16_t* __restrict__ codes,
                                                                 TilePool P, MapT M,
@@ -598,8 +598,10 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
                                                                 const double* __restrict__ mixlut, NoiseSrc ns) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   if (gate_prev && *gate_prev) return;  // the scan before this one resamples: see rbpf_raycast_box
-  const bool dn = ns.on != 0;            // (launch-uniform) the noise is drawn here: see NoiseSrc
-  const bool stage = ns.ready != nullptr;  // (launch-uniform) ... and workgroup 0 carries the beam table over
+  // DN: the noise is drawn here and workgroup 0 carries the beam table over (NoiseSrc).  A template argument, not a launch-time
+  // switch: with both forms in one body the stored-normals form — same source as round 4's — ran 3.3 us slower (30.7 -> 34.0 us per
+  // 1000 particles by events: registers and scheduling of code it never executes)
+  constexpr bool dn = DN, stage = DN;
   if (stage && blockIdx.x == 0) {
     // (two copies: the fine-grained one — uncached, so what the other workgroups of THIS launch read is what was stored, on whichever
     //  XCD they run, without a cache invalidate per wave (four thousand of those emptied the L2s and cost 50 us a scan) — and the
@@ -1103,8 +1105,10 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
   TRACE_P(9);
   WGP_OUT();
 }
-template __global__ void rbpf_propose<kProposeThreads>(ScanC, const double2* __restrict__, const uint16_t* __restrict__, TilePool, MapT, const int* __restrict__, const int* __restrict__, int, int, int, int, const int* __restrict__, const int4* __restrict__, const double* __restrict__, const double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, Trace, double* __restrict__, int* __restrict__, const int* __restrict__, const double* __restrict__, NoiseSrc);
-template __global__ void rbpf_propose<2 * kProposeThreads>(ScanC, const double2* __restrict__, const uint16_t* __restrict__, TilePool, MapT, const int* __restrict__, const int* __restrict__, int, int, int, int, const int* __restrict__, const int4* __restrict__, const double* __restrict__, const double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, Trace, double* __restrict__, int* __restrict__, const int* __restrict__, const double* __restrict__, NoiseSrc);
+template __global__ void rbpf_propose<kProposeThreads, false>(ScanC, const double2* __restrict__, const uint16_t* __restrict__, TilePool, MapT, const int* __restrict__, const int* __restrict__, int, int, int, int, const int* __restrict__, const int4* __restrict__, const double* __restrict__, const double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, Trace, double* __restrict__, int* __restrict__, const int* __restrict__, const double* __restrict__, NoiseSrc);
+template __global__ void rbpf_propose<kProposeThreads, true>(ScanC, const double2* __restrict__, const uint16_t* __restrict__, TilePool, MapT, const int* __restrict__, const int* __restrict__, int, int, int, int, const int* __restrict__, const int4* __restrict__, const double* __restrict__, const double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, Trace, double* __restrict__, int* __restrict__, const int* __restrict__, const double* __restrict__, NoiseSrc);
+template __global__ void rbpf_propose<2 * kProposeThreads, false>(ScanC, const double2* __restrict__, const uint16_t* __restrict__, TilePool, MapT, const int* __restrict__, const int* __restrict__, int, int, int, int, const int* __restrict__, const int4* __restrict__, const double* __restrict__, const double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, Trace, double* __restrict__, int* __restrict__, const int* __restrict__, const double* __restrict__, NoiseSrc);
+template __global__ void rbpf_propose<2 * kProposeThreads, true>(ScanC, const double2* __restrict__, const uint16_t* __restrict__, TilePool, MapT, const int* __restrict__, const int* __restrict__, int, int, int, int, const int* __restrict__, const int4* __restrict__, const double* __restrict__, const double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, Trace, double* __restrict__, int* __restrict__, const int* __restrict__, const double* __restrict__, NoiseSrc);
 
 }  // namespace tbnav_rk
 

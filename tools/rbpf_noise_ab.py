@@ -12,7 +12,7 @@ from rtn_amd.rbpf import ParticleFilter, default_params
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 steps, scans = bench_rbpf.workload(40)
 for rep in range(2):
-    for in_kernel in (1, 2, 3, 0):
+    for in_kernel in (1, 0):
         for timing in (False, True):
             pf = ParticleFilter(default_params(N=N, k=50, map_min=-10.0, map_max=10.0))
             pf.setSeed(1); pf.setTiming(timing); pf.setOption(capi.RBPF_OPT_NOISE_IN_KERNEL, in_kernel)
