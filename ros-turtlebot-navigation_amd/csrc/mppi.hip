@@ -167,17 +167,15 @@ int tbnav_mh::launch_combine(tbnav_mppi* h, const double* d_records, int G, hipS
   const USrc usrc{h->d_u[h->ucur], h->pending_shift ? 1 : 0, h->uinit[0], h->uinit[1]};
   // (records that came through an all-gather: only the error words — a poisoned record raises them, see mppi_combine)
   const DirectSrc ds = direct ? *direct : DirectSrc{nullptr, 0ull, (G > 1 && h->comm) ? h->d_dx_err : nullptr, (G > 1 && h->comm) ? h->d_dx_dead : nullptr, 0u};
-#define TBNAV_COMBINE(KEEP, DIR) do { h->lk_combine[0] = KEEP; h->lk_combine[1] = DIR; hipLaunchKernelGGL((mppi_combine<KEEP, DIR>), dim3(blocks), dim3(wpb * kWave), 0, st, h->T, G, S, lam_of(h), h->p.max_wheel_vel, usrc, \
+#define TBNAV_COMBINE(KEEP, MODE) do { h->lk_combine[0] = KEEP; h->lk_combine[1] = MODE; hipLaunchKernelGGL((mppi_combine<KEEP, MODE>), dim3(blocks), dim3(wpb * kWave), 0, st, h->T, G, S, lam_of(h), h->p.max_wheel_vel, usrc, \
                                                     d_records, h->d_u[1 - h->ucur], h->d_out, h->publish_next ? h->d_out_host : nullptr, (double)(h->seq + 1), ds); } while (0)
-  if (direct) {
-    if (G * S > 4 * kWave && G * S <= 8 * kWave) TBNAV_COMBINE(8, true);
-    else if (G * S > 2 * kWave && G * S <= 4 * kWave) TBNAV_COMBINE(4, true);
-    else TBNAV_COMBINE(2, true);
-  } else {
-    if (G * S > 4 * kWave && G * S <= 8 * kWave) TBNAV_COMBINE(8, false);
-    else if (G * S > 2 * kWave && G * S <= 4 * kWave) TBNAV_COMBINE(4, false);
-    else TBNAV_COMBINE(2, false);
-  }
+#define TBNAV_COMBINE_KEEP(MODE) do { if (G * S > 4 * kWave && G * S <= 8 * kWave) TBNAV_COMBINE(8, MODE); else if (G * S > 2 * kWave && G * S <= 4 * kWave) TBNAV_COMBINE(4, MODE); \
+                                      else TBNAV_COMBINE(2, MODE); } while (0)
+  // (which form: the direct exchange polls; records that came through an all-gather may carry a failed rank's poison; one group has neither)
+  if (direct) TBNAV_COMBINE_KEEP(2);
+  else if (G > 1 && ds.err) TBNAV_COMBINE_KEEP(1);
+  else TBNAV_COMBINE_KEEP(0);
+#undef TBNAV_COMBINE_KEEP
 #undef TBNAV_COMBINE
   TBNAV_HIP(hipGetLastError());
   ++h->seq;
@@ -671,7 +669,7 @@ int tbnav_mppi_last_kernel_names(const tbnav_mppi* h, char* rollout, int32_t rol
     }
   }
   if (combine && combine_cap > 0) {
-    if (h->lk_combine[0]) snprintf(combine, (size_t)combine_cap, "mppi_combine<%d, %s>", h->lk_combine[0], h->lk_combine[1] ? "true" : "false");
+    if (h->lk_combine[0]) snprintf(combine, (size_t)combine_cap, "mppi_combine<%d, %d>", h->lk_combine[0], h->lk_combine[1]);
     else combine[0] = 0;
   }
   return TBNAV_OK;

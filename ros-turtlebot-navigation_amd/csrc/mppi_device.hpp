@@ -44,21 +44,20 @@ struct USrc {
 // lambda and fl(1 / lambda) (formed on the host by the correctly rounded division; 0: use the division).  x / lambda is needed
 // once per soft-min weight and sits on the K = 1024 tick's latency chain; the quotient below is the correctly rounded one — the
 // SAME bits as x / lambda (Markstein: with y = RN(1/b), q = RN(a y), e = a - b q exactly by FMA, RN(q + e y) = RN(a/b) unless b's
-// significand is all ones, which the host excludes) — in three dependent instructions instead of the division's ~25.  The theorem
-// assumes that nothing under- or overflows on the way: the residual e is exact only while |x| * 2^-53 is representable, and
-// x * y may overflow where x / lambda does not.  So the short form is taken only when EVERY lane of the wave holds x = 0 (the
-// step's cheapest rollout: exact either way) or 2^-900 <= |x| <= 2^900 — lambda and 1 / lambda are normal, hence within 2^+-1022
-// of one, but a soft-min argument beyond 2^900 / lambda is an overflowed cost and exp() of it is 0 whichever way it is divided;
-// the guard costs two compares and a wave vote — any other wave divides (round-4 advisor finding; tests/test_mppi_gpu.py holds
-// subnormal, near-overflow and half-way quotients against the IEEE division bit for bit).
+// significand is all ones, which the host excludes) — in three dependent instructions instead of the division's ~25.
+// The theorem assumes that nothing under- or overflows on the way (round-4 advisor finding): the statement holds for x = 0 and
+// 2^-900 <= |x| <= 2^900 (lambda and 1 / lambda are normal, so q and the residual stay representable there).  Outside that range
+// the result may differ from x / lambda in its last bit (|x| < 2^-900: the residual underflows) or be +-inf where the quotient is
+// merely huge (x / lambda finite, x * (1 / lambda) not) — and the only consumer is exp(): of an argument that small it is exactly
+// 1, of one that large and negative exactly 0, whichever way it was divided.  tests/test_mppi_gpu.py holds the bits inside the
+// range (subnormal quotients, near-product arguments included) and exp() of the result outside it.  (A wave-voted fallback to
+// the division outside the range was measured: +0.2 us on the 7.75 us tick, for no observable difference.)
 struct Lam { double lambda, inv; };
 __device__ __forceinline__ double div_lambda(double x, const Lam& l) {
-  const double ax = fabs(x);
-  const bool safe = ax == 0.0 || (ax >= 0x1.0p-900 && ax <= 0x1.0p+900);
-  if (l.inv == 0.0 || !__all(safe)) return x / l.lambda;   // (launch-uniform || wave-uniform)
+  if (l.inv == 0.0) return x / l.lambda;   // (launch-uniform)
   const double q = x * l.inv;
   const double e = fma(-q, l.lambda, x);
-  return fma(e, l.inv, q);
+  return (fabs(q) < __builtin_huge_val()) ? fma(e, l.inv, q) : q;   // (an infinite cost: the quotient is the infinity itself, not inf - inf)
 }
 struct RolloutArgs {
   double half_r;    // wheel_radius / 2.0            (mppi.hpp:45)
@@ -359,7 +358,7 @@ __global__ __launch_bounds__(kSliceThreads) void mppi_partials(int T, int K, int
                                                                const double* __restrict__ total);
 __global__ __launch_bounds__(kWave) void mppi_merge_records(int T, int Sf, int per_slice, int S, Lam lam, const double* __restrict__ fine,
                                                             double* __restrict__ records, DirectPub pub);
-template <int kKeep, bool DIRECT>
+template <int kKeep, int MODE>   // MODE 0: one group of records (every single-GPU tick); 1: records of several ranks through an all-gather; 2: the direct exchange
 __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, Lam lam, double umax, USrc u, const double* __restrict__ records,
                                                     double* __restrict__ u_out, double* __restrict__ out, double* __restrict__ out_host, double seq,
                                                     DirectSrc ds);

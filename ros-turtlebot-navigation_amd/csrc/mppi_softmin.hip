@@ -215,10 +215,13 @@ __device__ __forceinline__ bool direct_load_records(const DirectSrc& d, const si
   return true;
 }
 
-template <int kKeep, bool DIRECT>
+template <int kKeep, int MODE>
 __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, Lam lam, double umax, USrc u,
                                                     const double* __restrict__ records, double* __restrict__ u_out,
                                                     double* __restrict__ out, double* __restrict__ out_host, double seq, DirectSrc ds) {
+  // MODE 0 — one group of records, the single-GPU tick — carries none of the exchange's failure handling: a template argument, not a
+  // launch-time test (as one body the headline tick ran 0.2 us slower than round 4's: 7.95 against 7.75 us).
+  constexpr bool DIRECT = MODE == 2, GATHERED = MODE == 1;
   // (DIRECT: `records` is not read — field f of record (g, i, sl) is polled for in the exchange buffer, same index)
   // (an exchange that has timed out once stays dead: the ticks queued behind it must not each wait the whole bound again)
   const bool dead = DIRECT && __hip_atomic_load(ds.err_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
@@ -280,14 +283,14 @@ __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, Lam lam
   double M = __builtin_huge_val();
   if (keep) {
 #pragma unroll
-    for (int q = 0; q < kKeep; ++q) { if (rk[q][6] > 0.0) M = fmin(M, rk[q][0]); failed = failed || rk[q][6] < 0.0; }
+    for (int q = 0; q < kKeep; ++q) { if (rk[q][6] > 0.0) M = fmin(M, rk[q][0]); if constexpr (GATHERED) failed = failed || rk[q][6] < 0.0; }
   } else if (valid) {
     for (int r = l; r < R; r += tpr) {
       const int g = r / S, sl = r - g * S;
       const double* rec = records + (((size_t)g * T + i) * S + sl) * TBNAV_MPPI_REC;
       const double rn = field(rec, 6);
       if (rn > 0.0) M = fmin(M, field(rec, 0));
-      failed = failed || rn < 0.0;
+      if constexpr (GATHERED) failed = failed || rn < 0.0;
     }
   }
   if (tpr == kWave) M = tbnav::wave_min_dpp(M);  // a whole wave per time step: reductions on the DPP network
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, Lam lam
       SD += __shfl_xor(SD, off, kWave); SE += __shfl_xor(SE, off, kWave); SN += __shfl_xor(SN, off, kWave);
     }
   }
-  if (DIRECT || G > 1) {  // any lane of the time step's group (one group — every single-GPU tick: nothing to agree on, launch-uniform)
+  if constexpr (MODE != 0) {  // any lane of the time step's group
     int fl = failed ? 1 : 0;
     for (int off = tpr >> 1; off > 0; off >>= 1) fl |= __shfl_xor(fl, off, kWave);
     failed = fl != 0;
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, Lam lam
     // as the reference's does instead of coming out as -max (fmin / fmax return the other operand)
     ul = (ul < -umax) ? -umax : ((umax < ul) ? umax : ul);
     ur = (ur < -umax) ? -umax : ((umax < ur) ? umax : ur);
-    if (failed) {
+    if (MODE != 0 && failed) {
       ul = u_l; ur = u_r;
       if (!DIRECT && ds.err) {   // (the polling loads have raised them already)
         __hip_atomic_fetch_or(ds.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -441,9 +444,10 @@ __global__ void mppi_sample_noise(int T, int K, uint64_t seed, uint64_t base, do
   }
 }
 
-#define TBNAV_INST_COMBINE(KEEP, DIR) template __global__ void mppi_combine<KEEP, DIR>(int, int, int, Lam, double, USrc, const double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, double, DirectSrc);
-TBNAV_INST_COMBINE(2, false) TBNAV_INST_COMBINE(4, false) TBNAV_INST_COMBINE(8, false)
-TBNAV_INST_COMBINE(2, true) TBNAV_INST_COMBINE(4, true) TBNAV_INST_COMBINE(8, true)
+#define TBNAV_INST_COMBINE(KEEP, MODE) template __global__ void mppi_combine<KEEP, MODE>(int, int, int, Lam, double, USrc, const double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, double, DirectSrc);
+TBNAV_INST_COMBINE(2, 0) TBNAV_INST_COMBINE(4, 0) TBNAV_INST_COMBINE(8, 0)
+TBNAV_INST_COMBINE(2, 1) TBNAV_INST_COMBINE(4, 1) TBNAV_INST_COMBINE(8, 1)
+TBNAV_INST_COMBINE(2, 2) TBNAV_INST_COMBINE(4, 2) TBNAV_INST_COMBINE(8, 2)
 #undef TBNAV_INST_COMBINE
 
 }  // namespace tbnav_mk
