@@ -679,31 +679,40 @@ int scan_enqueue(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3
   // device noise: drawn inside the proposal kernel, whose leading workgroup also carries the beam table over (NoiseSrc) — unless a
   // kernel in front of it needs the table on the device (the per-particle scan matcher), the scan comes prepared with its chunk
   // (tbnav_rbpf_slam_batch), or the option is off: then rbpf_sample_normals stores the same values first, as up to round 4
-  const bool dev_ok = !pre && !normals && !(h->sm_on && c.icp_ok);
-  const bool dn = dev_ok && h->noise_in_kernel == 1;   // normals drawn in the kernel AND the beam table through its leading workgroup
-  const bool stage = dn;
+  bool dn = !pre && !normals && !(h->sm_on && c.icp_ok) && h->noise_in_kernel == 1;
   NoiseSrc ns{};
-  if (dn || stage) {
+  if (dn) {
+    // (the hand-over needs fine-grained device memory: where the platform does not give any, the option switches itself off for good —
+    //  the stored-first form computes the same values)
+    hipError_t ea = hipSuccess;
     if (!h->d_zslot) {
-      TBNAV_HIP(hipMalloc((void**)&h->d_zslot, sizeof(double)));
-      TBNAV_HIP(hipExtMallocWithFlags((void**)&h->d_beam_ready, sizeof(unsigned int) * kReadyCopies * kReadyStride, hipDeviceMallocFinegrained));
-      TBNAV_HIP(hipMemsetAsync(h->d_beam_ready, 0, sizeof(unsigned int) * kReadyCopies * kReadyStride, st));
+      ea = hipMalloc((void**)&h->d_zslot, sizeof(double));
+      if (ea == hipSuccess) ea = hipExtMallocWithFlags((void**)&h->d_beam_ready, sizeof(unsigned int) * kReadyCopies * kReadyStride, hipDeviceMallocFinegrained);
+      if (ea == hipSuccess) ea = hipMemsetAsync(h->d_beam_ready, 0, sizeof(unsigned int) * kReadyCopies * kReadyStride, st);
       h->beam_seq = 0;
     }
+    if (ea == hipSuccess && h->fg_beams_cap < h->max_beams) {
+      ea = hipStreamSynchronize(st);
+      (void)hipFree(h->d_beams_fg); h->d_beams_fg = nullptr; h->fg_beams_cap = 0;
+      if (ea == hipSuccess) ea = hipExtMallocWithFlags((void**)&h->d_beams_fg, sizeof(double2) * h->max_beams, hipDeviceMallocFinegrained);
+      if (ea == hipSuccess) h->fg_beams_cap = h->max_beams;
+    }
+    if (ea != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipFree(h->d_zslot); (void)hipFree(h->d_beam_ready); (void)hipFree(h->d_beams_fg);
+      h->d_zslot = nullptr; h->d_beam_ready = nullptr; h->d_beams_fg = nullptr; h->fg_beams_cap = 0;
+      h->noise_in_kernel = 0;
+      dn = false;
+    }
+  }
+  if (dn) {
     if (++h->beam_seq == 0u) ++h->beam_seq;   // (0 is the cleared word)
     ns.seed = h->seed; ns.scan = h->scan_index;
     ns.base = h->rng_n_global ? (size_t)h->rng_first * c.stride_normals : 0;
     ns.z_index = h->rng_n_global ? (size_t)h->rng_n_global * c.stride_normals : (size_t)h->N * c.stride_normals;
     ns.z_out = h->d_zslot;
-    if (stage && h->fg_beams_cap < h->max_beams) {
-      TBNAV_HIP(hipStreamSynchronize(st));
-      (void)hipFree(h->d_beams_fg); h->d_beams_fg = nullptr; h->fg_beams_cap = 0;
-      TBNAV_HIP(hipExtMallocWithFlags((void**)&h->d_beams_fg, sizeof(double2) * h->max_beams, hipDeviceMallocFinegrained));
-      h->fg_beams_cap = h->max_beams;
-    }
     ns.host_beams = (const double2*)(h->h_beams + (size_t)slot * h->max_beams); ns.dev_beams = h->d_beams; ns.fg_beams = h->d_beams_fg;
-    ns.ready = stage ? h->d_beam_ready : nullptr; ns.seq = h->beam_seq; ns.on = dn ? 1 : 0;
-    if (!stage) TBNAV_HIP(hipMemcpyAsync(h->d_beams, ns.host_beams, sizeof(double2) * c.Bv, hipMemcpyHostToDevice, st));
+    ns.ready = h->d_beam_ready; ns.seq = h->beam_seq; ns.on = 1;
   }
   h->last_drawn.valid = false;
   if (dn) {

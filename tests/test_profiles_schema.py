@@ -55,20 +55,48 @@ def test_pmc_summary_output_is_what_the_bench_parses(tmp_path):
 def test_committed_profiles_have_a_row_for_every_kernel_the_bench_lines_point_at():
     rows, src = bp.kernel_stats_rows()
     assert src and rows, "profiles/<round>_kernel_stats.md is missing"
-    for kernel, grid in (("mppi_rollout_fused<2, 8, 1, true>", None), ("mppi_rollout_prefix<1>", 65536), ("mppi_partials", None), ("rbpf_propose<256>", 256000)):
+    for kernel, grid in (("mppi_rollout_fused<2, 8, 1, 1>", None), ("mppi_rollout_prefix<1>", 65536), ("mppi_partials", None)):
         r = bp.rocprof_row(kernel, grid)
         assert r is not None and r["avg_us"] > 0 and r["source"].startswith("profiles/"), kernel
     # the map update's instantiation is chosen per launch (launch_raycast): the committed bench line names the one that ran
     line_path = os.path.join(ROOT, "profiles", src.split("/")[-1].replace("kernel_stats.md", "bench_line.json"))
     with open(line_path) as f:
-        k_raycast = json.loads(f.read().strip().splitlines()[-1])["rbpf"]["roofline"]["kernel"]
+        line = json.loads(f.read().strip().splitlines()[-1])
+    k_raycast = line["rbpf"]["roofline"]["kernel"]
     assert k_raycast.startswith("rbpf_raycast_box<"), k_raycast
-    r = bp.rocprof_row(k_raycast, 512 * 1001) or bp.rocprof_row(k_raycast, 512 * 1000)
-    assert r and r["median_us"] and r["median_us"] <= r["avg_us"] * 1.5, (k_raycast, r)
-    assert bp.rocprof_row("mppi_rollout_fused<2, 8, 1, false>") != bp.rocprof_row("mppi_rollout_fused<2, 8, 1, true>")   # never another instantiation's row
+    r = bp.rocprof_row(k_raycast, 512 * 1001, "rbpf_N1000_k50_400x400_plain_scans_only")
+    assert r and "plain_scans_only" in r["source"] and r["median_us"] and r["median_us"] <= r["avg_us"] * 1.5, (k_raycast, r)
+    assert bp.rocprof_row("mppi_rollout_fused<2, 8, 1, 0>") != bp.rocprof_row("mppi_rollout_fused<2, 8, 1, 1>")   # never another instantiation's row
     assert bp.rocprof_row("no_such_kernel<1>") is None
-    for wl, kernel in (("mppi_K1024_T50", "mppi_rollout_fused<2, 8, 1, true>"), ("mppi_K65536_T100", "mppi_rollout_prefix<1>"),
+    for wl, kernel in (("mppi_K1024_T50", "mppi_rollout_fused<2, 8, 1, 1>"), ("mppi_K65536_T100", "mppi_rollout_prefix<1>"),
                        ("rbpf_N1000_k50_400x400_plain_scans_only", k_raycast)):
         p = bp.pmc_row(wl, kernel)
         assert p is not None and p["hbm_bytes"] > 0 and wl in p["source"], (wl, kernel)
-    assert bp.pmc_row("mppi_K1024_T50", "mppi_rollout_fused<2, 8, 1, false>") is None
+    assert bp.pmc_row("mppi_K1024_T50", "mppi_rollout_fused<2, 8, 1, 0>") is None
+
+
+def test_every_baseline_shape_has_a_roofline_whose_frac_follows_from_one_named_row_each():
+    """Round-4 review, item 1: a `frac` for every configs[*] shape, recomputable from ONE named row of a kernel-stats table (its
+    AVERAGE) and ONE named entry of the traffic file — here recomputed from the committed bench line and the committed profiles."""
+    with open(os.path.join(ROOT, "profiles", "r05_bench_line.json")) as f:
+        line = json.loads(f.read().strip().splitlines()[-1])
+    objs = {"configs[1] K=1024,T=50": line["roofline"], "configs[3] K=65536,T=100": line["roofline_large"],
+            "configs[3]/8 K=8192,T=100": line["configs3_shard_one_gpu"]["roofline"], "configs[2] bench room": line["rbpf"]["roofline"],
+            "configs[2] SURVEY room": line["rbpf"]["survey_room"]["roofline"],
+            "configs[4]/8 N=12500": line["rbpf"]["configs4_shard_one_gpu"]["roofline_leg"]["roofline"]}
+    for name, o in objs.items():
+        assert o["rocprof"] is not None and o["frac_rocprof"] is not None and o["traffic"] is not None, name
+        assert o["frac_rocprof_of"] == "avg_us", name
+        src, row = o["rocprof"]["source"], o["rocprof"]["row"]
+        kernel, grid = [x.strip() for x in row.split("|")]
+        rows, _ = bp.kernel_stats_rows(os.path.join(ROOT, src))
+        hit = [r for r in rows if r["kernel"] == kernel and r["grid"] == grid]
+        assert len(hit) == 1, (name, row, src)
+        frac = o["algorithmic_bytes_per_launch"] / (hit[0]["avg_us"] * 1e-6) / 1e9 / 8000.0
+        assert abs(frac - o["frac_rocprof"]) <= 1e-5 + 1e-4 * frac, (name, frac, o["frac_rocprof"])
+        assert o["kernel"] == kernel, name
+        tsrc = o["traffic_source"].split(" (")[0]
+        path, key = tsrc.split(": workloads.")
+        wl, kname = key.split(".", 1)
+        with open(os.path.join(ROOT, path)) as f:
+            assert json.load(f)["workloads"][wl][kname]["hbm_bytes"] == o["traffic"], name
