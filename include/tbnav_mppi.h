@@ -100,6 +100,8 @@ enum { TBNAV_MPPI_OPT_KERNEL = 1, TBNAV_MPPI_OPT_TRIG = 2, TBNAV_MPPI_OPT_NO_LDS
                                      0 (default): fp32 Box-Muller on 24-bit uniforms — normals on a 2^-24 grid out to 5.9 sigma;
                                      1: fp64 Box-Muller on 52-bit uniforms — what std::normal_distribution<double> is in width, out to 8.57 sigma (in the fused
                                         kernel for the default dynamics, sampled first for the others: same values) */,
+       TBNAV_MPPI_OPT_WIDE_COMBINE = 11 /* 1 (default): a single-GPU tick whose time steps have more than 256 soft-min records (the fused kernel at K = 4097 ... 8192) combines
+                                            them with four waves per step (mppi_combine_wide); 0: always one wave per step (A-B measurements) */,
        TBNAV_MPPI_OPT_FAULT_INJECT = 10 /* tests: 1 = the local half of this handle's next sharded tick reports a failure (its rollouts are not launched) */ };
 int tbnav_mppi_set_option(tbnav_mppi* h, int32_t option, int32_t value);
 

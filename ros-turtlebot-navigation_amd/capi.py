@@ -22,7 +22,7 @@ OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OUT_OF_WORLD, ERR_ETA_ZERO, ERR
 
 # tbnav_mppi.h options
 MPPI_OPT_KERNEL, MPPI_OPT_TRIG, MPPI_OPT_NO_LDS_STAGING, MPPI_OPT_KEEP_J, MPPI_OPT_REG_TAIL, MPPI_OPT_BATCH_GRAPH, MPPI_OPT_PREFIX_FORM = 1, 2, 3, 4, 5, 6, 7
-MPPI_OPT_DIRECT_EXCHANGE, MPPI_OPT_SAMPLER, MPPI_OPT_FAULT_INJECT = 8, 9, 10
+MPPI_OPT_DIRECT_EXCHANGE, MPPI_OPT_SAMPLER, MPPI_OPT_FAULT_INJECT, MPPI_OPT_WIDE_COMBINE = 8, 9, 10, 11
 
 # tbnav_rbpf.h options
 RBPF_OPT_DF_MODE, RBPF_OPT_RAYCAST_ORDERED, RBPF_OPT_RAYCAST_THREADS, RBPF_OPT_COUNT_CELLS, RBPF_OPT_RAYCAST_FORM = 1, 2, 3, 4, 5

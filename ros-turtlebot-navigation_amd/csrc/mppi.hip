@@ -171,9 +171,15 @@ int tbnav_mh::launch_combine(tbnav_mppi* h, const double* d_records, int G, hipS
                                                     d_records, h->d_u[1 - h->ucur], h->d_out, h->publish_next ? h->d_out_host : nullptr, (double)(h->seq + 1), ds); } while (0)
 #define TBNAV_COMBINE_KEEP(MODE) do { if (G * S > 4 * kWave && G * S <= 8 * kWave) TBNAV_COMBINE(8, MODE); else if (G * S > 2 * kWave && G * S <= 4 * kWave) TBNAV_COMBINE(4, MODE); \
                                       else TBNAV_COMBINE(2, MODE); } while (0)
-  // (which form: the direct exchange polls; records that came through an all-gather may carry a failed rank's poison; one group has neither)
+  // (which form: the direct exchange polls; records that came through an all-gather may carry a failed rank's poison; one group has neither —
+  //  and with more than 256 records per step, the fused kernel's at K = 4097 ... 8192, it gets four waves per time step)
   if (direct) TBNAV_COMBINE_KEEP(2);
   else if (G > 1 && ds.err) TBNAV_COMBINE_KEEP(1);
+  else if (G == 1 && S > 4 * kWave && S <= 16 * kWave && h->wide_combine) {
+    h->lk_combine[0] = -4; h->lk_combine[1] = 0;
+    hipLaunchKernelGGL(mppi_combine_wide, dim3(h->T), dim3(4 * kWave), 0, st, h->T, S, lam_of(h), h->p.max_wheel_vel, usrc, d_records, h->d_u[1 - h->ucur], h->d_out,
+                       h->publish_next ? h->d_out_host : nullptr, (double)(h->seq + 1));
+  }
   else TBNAV_COMBINE_KEEP(0);
 #undef TBNAV_COMBINE_KEEP
 #undef TBNAV_COMBINE
@@ -410,6 +416,9 @@ int tbnav_mppi_set_option(tbnav_mppi* h, int32_t option, int32_t value) {
       return TBNAV_OK;
     case TBNAV_MPPI_OPT_FAULT_INJECT:   // (tests) the next sharded tick's local half reports a failure; 0 takes it back
       h->fail_next = value != 0;
+      return TBNAV_OK;
+    case TBNAV_MPPI_OPT_WIDE_COMBINE:   // 0: always the one-wave-per-step combine (A-B); default 1
+      h->wide_combine = value != 0;
       return TBNAV_OK;
     case TBNAV_MPPI_OPT_SAMPLER:        // 0: fp32 Box-Muller on 24-bit uniforms (default); 1: fp64 on 52-bit uniforms (utilities.cpp:20-24's width)
       if (value != 0 && value != 1) return TBNAV_ERR_INVALID_ARG;
@@ -669,7 +678,8 @@ int tbnav_mppi_last_kernel_names(const tbnav_mppi* h, char* rollout, int32_t rol
     }
   }
   if (combine && combine_cap > 0) {
-    if (h->lk_combine[0]) snprintf(combine, (size_t)combine_cap, "mppi_combine<%d, %d>", h->lk_combine[0], h->lk_combine[1]);
+    if (h->lk_combine[0] == -4) snprintf(combine, (size_t)combine_cap, "mppi_combine_wide");
+    else if (h->lk_combine[0]) snprintf(combine, (size_t)combine_cap, "mppi_combine<%d, %d>", h->lk_combine[0], h->lk_combine[1]);
     else combine[0] = 0;
   }
   return TBNAV_OK;

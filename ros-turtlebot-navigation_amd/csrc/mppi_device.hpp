@@ -362,6 +362,8 @@ template <int kKeep, int MODE>   // MODE 0: one group of records (every single-G
 __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, Lam lam, double umax, USrc u, const double* __restrict__ records,
                                                     double* __restrict__ u_out, double* __restrict__ out, double* __restrict__ out_host, double seq,
                                                     DirectSrc ds);
+__global__ __launch_bounds__(256) void mppi_combine_wide(int T, int R, Lam lam, double umax, USrc u, const double* __restrict__ records, double* __restrict__ u_out,
+                                                         double* __restrict__ out, double* __restrict__ out_host, double seq);
 __global__ __launch_bounds__(256) void mppi_direct_publish(const double* __restrict__ mine, int n, unsigned long long* const* __restrict__ peers, int me, int P,
                                                            int parity, unsigned int seq, int only_self);
 __global__ __launch_bounds__(256) void mppi_direct_collect(unsigned long long* __restrict__ words, int n, int P, int parity, unsigned int seq,

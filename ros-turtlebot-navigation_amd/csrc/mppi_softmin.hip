@@ -361,6 +361,67 @@ __global__ __launch_bounds__(256) void mppi_combine(int T, int G, int S, Lam lam
   }
 }
 
+// The single-GPU combine for MANY records per time step (256 < records <= 1024: the fused kernel's 16-rollout records at K = 4097 ...
+// 8192, round 5): a workgroup of FOUR waves per time step, at most four records a lane.  mppi_combine gives such a step ONE wave holding
+// eight records of seven doubles per lane (198 registers, 56 loads in a chain of latency): 5.7-6.1 us at K = 8192, a quarter of that
+// tick; here the step's loads are spread over four times the lanes and the two reductions (min, then the six sums) meet in LDS.
+// Same algebra, same epilogue (mppi.cpp:117-137); the sums associate differently (per-wave trees, then four partials in wave order):
+// the controls agree with the one-wave form to rounding (asserted at 1e-9 against the oracle like every kernel).
+constexpr int kWideWaves = 4;
+__global__ __launch_bounds__(kWave * kWideWaves) void mppi_combine_wide(int T, int R, Lam lam, double umax, USrc u, const double* __restrict__ records,
+                                                                       double* __restrict__ u_out, double* __restrict__ out, double* __restrict__ out_host, double seq) {
+  __shared__ double s_min[kWideWaves], s_sum[kWideWaves][6];
+  const int i = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
+  constexpr int kPer = 4, nthr = kWave * kWideWaves;
+  const double u_l = u.get(0, i, T), u_r = u.get(1, i, T);   // (do not depend on the records: requested first)
+  double rk[kPer][7];
+#pragma unroll
+  for (int q = 0; q < kPer; ++q) {
+    const int r = tid + q * nthr;
+    const double* rec = records + ((size_t)i * R + (r < R ? r : 0)) * TBNAV_MPPI_REC;
+#pragma unroll
+    for (int f = 0; f < 7; ++f) rk[q][f] = r < R ? rec[f] : 0.0;   // n == 0 marks "no record"
+  }
+  double M = __builtin_huge_val();
+#pragma unroll
+  for (int q = 0; q < kPer; ++q) if (rk[q][6] > 0.0) M = fmin(M, rk[q][0]);
+  M = tbnav::wave_min_dpp(M);
+  if (lane == 0) s_min[wid] = M;
+  __syncthreads();
+  M = fmin(fmin(s_min[0], s_min[1]), fmin(s_min[2], s_min[3]));
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int q = 0; q < kPer; ++q)
+    if (rk[q][6] > 0.0) {
+      const double sc = exp(div_lambda((rk[q][0] - M) * -1.0, lam));
+      acc[0] += sc * rk[q][1]; acc[1] += sc * rk[q][2]; acc[2] += sc * rk[q][3];
+      acc[3] += rk[q][4]; acc[4] += rk[q][5]; acc[5] += rk[q][6];
+    }
+#pragma unroll
+  for (int f = 0; f < 6; ++f) { acc[f] = tbnav::wave_sum_dpp(acc[f]); if (lane == 0) s_sum[wid][f] = acc[f]; }
+  __syncthreads();
+  if (tid == 0) {
+    double W = ((s_sum[0][0] + s_sum[1][0]) + s_sum[2][0]) + s_sum[3][0], NL = ((s_sum[0][1] + s_sum[1][1]) + s_sum[2][1]) + s_sum[3][1];
+    const double NR = ((s_sum[0][2] + s_sum[1][2]) + s_sum[2][2]) + s_sum[3][2], SD = ((s_sum[0][3] + s_sum[1][3]) + s_sum[2][3]) + s_sum[3][3];
+    const double SE = ((s_sum[0][4] + s_sum[1][4]) + s_sum[2][4]) + s_sum[3][4], SN = ((s_sum[0][5] + s_sum[1][5]) + s_sum[2][5]) + s_sum[3][5];
+    W += 1e-8 * SN;  // the reference adds 1e-8 to every weight before normalising (mppi.cpp:117)
+    double ul = u_l + (NL + 1e-8 * SD) / W;
+    double ur = u_r + (NR + 1e-8 * SE) / W;
+    ul = (ul < -umax) ? -umax : ((umax < ul) ? umax : ul);   // std::clamp (mppi.cpp:124-125): a NaN stays a NaN
+    ur = (ur < -umax) ? -umax : ((umax < ur) ? umax : ur);
+    u_out[i] = ul;
+    u_out[T + i] = ur;
+    if (i == 0) {
+      out[0] = ul; out[1] = ur;
+      if (out_host) {   // (synchronous ticks: see mppi_combine)
+        out_host[0] = ul; out_host[1] = ur;
+        __threadfence_system();
+        out_host[2] = seq;
+      }
+    }
+  }
+}
+
 __global__ void mppi_debug_div_lambda(int n, const double* __restrict__ x, Lam lam, double* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = div_lambda(x[i], lam);

@@ -220,6 +220,30 @@ def test_fp64_sampler_statistics_and_tails_to_six_sigma(gpu_pkg):
     m.close()
 
 
+@pytest.mark.parametrize("K,horizon", [(8192, 1.0), (6000, 0.5), (5000, 1.28)])
+def test_mid_k_tick_with_four_waves_per_time_step_in_the_combine(gpu_pkg, K, horizon):
+    """K = 4097 ... 8192 (what each of 8 GPUs runs for BASELINE configs[3]): the fused kernel leaves more than 256 soft-min records per time
+    step and the combine takes four waves per step (mppi_combine_wide, round 5).  Against the oracle tick over three warm-started ticks,
+    and against the one-wave-per-step combine (TBNAV_MPPI_OPT_WIDE_COMBINE = 0): same controls to rounding."""
+    from rtn_amd import capi
+    d = mppi_cfg(K, horizon)
+    m, m1 = make_mppi(gpu_pkg, d), make_mppi(gpu_pkg, d)
+    m1.setOption(capi.MPPI_OPT_WIDE_COMBINE, 0)
+    T = m.steps
+    for x in (m, m1):
+        x.setWaypoint(*WAYPOINTS[1])
+    u = np.zeros((2, T)); x0 = (0.05, -0.02, 0.1)
+    for tick in range(3):
+        nz = _noise(300 + tick, K, T)
+        ref = _check_tick(m, d, u, (0.0, 0.0), WAYPOINTS[1], x0, nz)
+        got1 = m1.newControls(*x0, nz)
+        assert m.lastKernelNames()[1] == "mppi_combine_wide" and m1.lastKernelNames()[1].startswith("mppi_combine<"), (m.lastKernelNames(), m1.lastKernelNames())
+        assert np.allclose(got1, ref["out"], rtol=U_RTOL, atol=U_ATOL) and np.allclose(m1.getControls(), m.getControls(), rtol=1e-12, atol=1e-14)
+        u = ref["u"]
+        x0 = (x0[0] + 0.002, x0[1], x0[2] + 0.001)
+    m.close(); m1.close()
+
+
 def test_long_horizon_uses_global_scratch_path(gpu_pkg):
     """T = 400 > 320: per-step losses no longer fit LDS ([T][64] doubles), J is the scratch."""
     d = mppi_cfg(96, 4.0)
