@@ -712,7 +712,7 @@ int scan_enqueue(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3
     ns.z_index = h->rng_n_global ? (size_t)h->rng_n_global * c.stride_normals : (size_t)h->N * c.stride_normals;
     ns.z_out = h->d_zslot;
     ns.host_beams = (const double2*)(h->h_beams + (size_t)slot * h->max_beams); ns.dev_beams = h->d_beams; ns.fg_beams = h->d_beams_fg;
-    ns.ready = h->d_beam_ready; ns.seq = h->beam_seq; ns.on = 1;
+    ns.ready = h->d_beam_ready; ns.seq = h->beam_seq;
   }
   h->last_drawn.valid = false;
   if (dn) {

@@ -500,7 +500,7 @@ struct ExportCuts {
 // ---- the kernels (defined in rbpf_<family>.hip) ----------------------------------------------------------------------
 // rbpf_propose.hip
 __global__ void rbpf_mix_lut(ScanC c, double* __restrict__ out);
-// Device noise drawn INSIDE rbpf_propose (round 5; normals == NULL and on != 0): the values rbpf_sample_normals would have stored —
+// Device noise drawn INSIDE rbpf_propose (round 5; the kernel's DN = true instantiation): the values rbpf_sample_normals would have stored —
 // same Philox counters, same Box-Muller — for the particle's own 3k + 3 (or 3) normals, and the scan's beam table carried over by
 // an extra leading workgroup instead of a launch of its own: workgroup 0 copies the table from pinned host memory to dev_beams,
 // leaves the resampling offset's normal in *z_out (read by the normalise, a later launch) and publishes `seq` in *ready; the
@@ -518,7 +518,6 @@ struct NoiseSrc {
   double2* fg_beams;               // FINE-GRAINED device memory (uncached): for the other workgroups of this one
   unsigned int* ready;             // fine-grained too: kReadyCopies copies, kReadyStride words apart
   unsigned int seq;
-  int on;
 };
 __global__ void rbpf_sample_normals(size_t n, unsigned long long seed, unsigned long long scan, double* __restrict__ out,
                                     const double2* __restrict__ host_beams, double2* __restrict__ dev_beams, int n_copy,

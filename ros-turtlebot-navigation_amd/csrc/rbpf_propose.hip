@@ -601,8 +601,8 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
   // DN: the noise is drawn here and workgroup 0 carries the beam table over (NoiseSrc).  A template argument, not a launch-time
   // switch: with both forms in one body the stored-normals form — same source as round 4's — ran 3.3 us slower (30.7 -> 34.0 us per
   // 1000 particles by events: registers and scheduling of code it never executes)
-  constexpr bool dn = DN, stage = DN;
-  if (stage && blockIdx.x == 0) {
+  constexpr bool dn = DN;
+  if (dn && blockIdx.x == 0) {
     // (two copies: the fine-grained one — uncached, so what the other workgroups of THIS launch read is what was stored, on whichever
     //  XCD they run, without a cache invalidate per wave (four thousand of those emptied the L2s and cost 50 us a scan) — and the
     //  ordinary one the map update, a later launch, reads through the caches)
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
       __hip_atomic_store(&ns.fg_beams[b].y, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       ns.dev_beams[b] = v;
     }
-    if (dn && threadIdx.x == 0) {
+    if (threadIdx.x == 0) {
       double va, vb;
       normal_pair(ns.seed, ns.scan, ns.z_index >> 1, va, vb);
       *ns.z_out = (ns.z_index & 1) ? vb : va;
@@ -626,13 +626,8 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
     if (threadIdx.x < kReadyCopies) __hip_atomic_store(ns.ready + threadIdx.x * kReadyStride, ns.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return;
   }
-  const unsigned int* const my_ready = ns.ready + (blockIdx.x & (kReadyCopies - 1)) * kReadyStride;
-  const int p = blockIdx.x - (stage ? 1 : 0);
-  if (!stage && dn && blockIdx.x == 0 && threadIdx.x == 0) {   // (no leading workgroup: particle 0's leaves the resampling offset's normal)
-    double va, vb;
-    normal_pair(ns.seed, ns.scan, ns.z_index >> 1, va, vb);
-    *ns.z_out = (ns.z_index & 1) ? vb : va;
-  }
+  const unsigned int* const my_ready = dn ? ns.ready + (blockIdx.x & (kReadyCopies - 1)) * kReadyStride : nullptr;
+  const int p = blockIdx.x - (dn ? 1 : 0);
   const int k = c.k;
   __shared__ double sh_mix[kMixLds];  // the head of the handle's mixture table (filled below, visible after the first barrier)
   const MixLut mixL{sh_mix, mixlut};
@@ -680,9 +675,9 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
   // (the beam table: has workgroup 0 published it already?  One look, no waiting — the workgroups dispatched after the first few
   //  microseconds find it and request their beams here, under everything else, as before; the others come back to it below)
   bool have_beams = true;
-  if (stage) have_beams = __hip_atomic_load(my_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == ns.seq;   // (fine-grained memory: no cache holds it)
+  if (dn) have_beams = __hip_atomic_load(my_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == ns.seq;   // (fine-grained memory: no cache holds it)
   auto beam_in = [&](int b) -> double2 {
-    if (!stage) return beams[b];
+    if (!dn) return beams[b];
     return double2{__hip_atomic_load(&ns.fg_beams[b].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __hip_atomic_load(&ns.fg_beams[b].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)};
   };
   // (a table of at most NT entries — maps up to 512 x 512 cells at 256 threads — is requested WHOLE here, with the pose: which
