@@ -578,10 +578,12 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens,
   else if (pick && may4 && fits(4, box_lds_bytes((size_t)cap4, (size_t)bvn, kBoxEvFour))) { nt = 512; cap_win = cap4; ev_slot = kBoxEvFour; }
   else if (pick && cap_win > 0 && fits(3, box_lds_bytes((size_t)cap_win, (size_t)bvn))) { nt = 512; wps = 6; }
   else if (pick && may4 && c16_ok && fits(4, box16_lds_bytes((size_t)cap4, (size_t)bvn, kBoxEv))) { nt = 512; cap_win = cap4; c16 = true; }
-  else if (pick && may4 && c16_ok && fits(4, box16_lds_bytes((size_t)cap4, (size_t)bvn, kBoxEvFour))) { nt = 512; cap_win = cap4; c16 = true; ev_slot = kBoxEvFour; }
+  // (no 16-bit form with four-event slots: its niche — boxes that fit four per CU only with BOTH economies — is a few hundred cells wide, and
+  //  the instantiation was the one map-update kernel left with a spill; such boxes run three per CU in <512, 6, true, 8>)
   else if (pick && c16_ok && fits(3, box16_lds_bytes((size_t)cap_win, (size_t)bvn))) { nt = 512; wps = 6; c16 = true; }
   else if (nt == 512) wps = 6;
   if (h->raycast_cell16 == 2 && c16_ok && nt == 512) c16 = true;   // (tests / A-B: the 16-bit form wherever it can run)
+  if (c16) ev_slot = kBoxEv;   // (the 16-bit form has eight-event slots only)
   const size_t lds_win = c16 ? box16_lds_bytes((size_t)cap_win, (size_t)bvn, ev_slot) : box_lds_bytes((size_t)cap_win, (size_t)bvn, ev_slot);
   if (cap_win > 0 && !h->ref_field && c.Bv < 32768 - kWave && nt >= 512 && lds_win <= (size_t)kMaxLds - 4096) {
     // default: box counters (rbpf_raycast_box)
@@ -596,8 +598,7 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens,
 #define TBNAV_BOX(NT_, WPS_, C16_, EV_) hipLaunchKernelGGL((rbpf_raycast_box<NT_, WPS_, C16_, EV_>), dim3(blocks), dim3(NT_), lds_launch, st, c, h->pool, M, beams_dev, sp.pose, sens, \
                                                 h->d_trow[h->cur], h->d_nocc[h->cur], err, (int)cap_win, touched, na, h->d_box_need, h->d_box_need_host, need_slot, hash_words)
     const bool ev4 = ev_slot == (size_t)kBoxEvFour;
-    if (nt == 512 && wps == 8 && c16 && ev4) TBNAV_BOX(512, 8, true, 4);
-    else if (nt == 512 && wps == 8 && c16) TBNAV_BOX(512, 8, true, 8);
+    if (nt == 512 && wps == 8 && c16) TBNAV_BOX(512, 8, true, 8);
     else if (nt == 512 && wps == 8 && ev4) TBNAV_BOX(512, 8, false, 4);
     else if (nt == 512 && wps == 8) TBNAV_BOX(512, 8, false, 8);
     else if (nt == 512 && c16) TBNAV_BOX(512, 6, true, 8);
@@ -1135,7 +1136,6 @@ int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf*
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_box<512, 8, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 4096);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_box<512, 8, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 4096);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_box<512, 8, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 4096);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_box<512, 8, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 4096);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast_box<1024, 8, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 4096);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rbpf_raycast), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 1024);
   // the proposal / scan-match kernels carry the scan, the per-sample data and the bitmap slice: more than the 64 KB

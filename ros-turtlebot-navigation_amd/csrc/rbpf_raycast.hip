@@ -162,11 +162,21 @@ __device__ __forceinline__ double add_repeated(double x, const double d, int n) 
     const unsigned long long s = (kd >> sh) + (rem > half ? 1ull : 0ull);
     if (s == 0ull) return x;  // d is less than half an ulp of x: no add changes it
     const unsigned long long m = (bx & kMant) | (1ull << 52);
-    const unsigned long long room = (1ull << 53) - 1ull - m;  // the steps that stay in the binade: m + j s <= 2^53 - 1
+    // j steps at once: all n if they stay in the binade (m + j s <= 2^53 - 1), else floor(room / s) of them and a plain add across the
+    // binade's end.  The quotient is below n there, so a single-precision estimate (both operands to 24 bits, the hardware reciprocal:
+    // ~2^-21 relative) is within one or two of it for the counts a cell can take, and the two loops on the remainder make it exact for any count.  (An fp64
+    // division stood here: its u64 -> f64 conversions were the last spill of the 16-bit-cell instantiations.  A cell that starts at zero
+    // crosses nine binades in its first scans, so this branch is not rare enough for a search over j either — tried: the map update 40.4 -> 42.3 us at N = 1000 / 360 beams,
+    // 0.85 -> 1.14 ms at N = 12 500 / 1080 beams.)
     unsigned long long j = (unsigned long long)n;
-    if (__umul64hi(j, s) != 0ull || j * s > room) {
-      j = (unsigned long long)((double)room / (double)s);     // both exact in fp64 and the division is correctly rounded: floor or floor + 1
-      if (j * s > room) --j;
+    if (__umul64hi(j, s) != 0ull || ((j * s) >> 53) != 0ull || ((m + j * s) >> 53) != 0ull) {
+      const unsigned long long room = (1ull << 53) - 1ull - m;
+      const float rf = (float)(unsigned int)(room >> 32) * 4294967296.0f + (float)(unsigned int)room;
+      const float sf = (float)(unsigned int)(s >> 32) * 4294967296.0f + (float)(unsigned int)s;
+      j = (unsigned long long)(unsigned int)(rf * __builtin_amdgcn_rcpf(sf));
+      long long r = (long long)(room - j * s);   // (j s <= room (1 + 2^-20) < 2^54: no wrap) the remainder, made to lie in [0, s)
+      while (r < 0ll) { --j; r += (long long)s; }
+      while (r >= (long long)s) { ++j; r -= (long long)s; }
     }
     const unsigned long long mj = m + j * s;
     x = __longlong_as_double((long long)((bx & (1ull << 63)) | ((unsigned long long)ex << 52) | (mj & kMant)));
@@ -933,7 +943,8 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
     if ((wid == nw - 1 || wid == nw - 2) && lane < kHotSide * kHotSide) {
       const int hi = floor_div_small(lane, kHotSide), hx = rx - kHotSide / 2 + hi, hy = ry - kHotSide / 2 + (lane - hi * kHotSide);
       if ((unsigned int)(hx - x0) < (unsigned int)nr && hy >= miny && hy < miny + bw) {
-        const int t = __mul24(hx - x0, bw) + (hy - miny);
+        int t = __mul24(hx - x0, bw) + (hy - miny);
+        asm volatile("" : "+v"(t));   // held as ONE register across add_repeated (else hx - x0 and hy - miny both are: a 4-byte spill in the 16-bit form)
         unsigned int f;
         if constexpr (C16) { const unsigned int hh = tile16[t]; f = (hh & 0x7FFFu) | ((hh & 0x8000u) << 16); } else f = tile[t];
         const int cnq = (int)(f & 0xFFFFu);
@@ -1042,7 +1053,6 @@ template __global__ void rbpf_raycast_box<512, 6, true, 8>(ScanC, TilePool, MapT
 template __global__ void rbpf_raycast_box<512, 8, false, 8>(ScanC, TilePool, MapT, const double2* __restrict__, const double* __restrict__, const double* __restrict__, int* __restrict__, int* __restrict__, int* __restrict__, int, unsigned long long* __restrict__, NormArgs, int* __restrict__, int* __restrict__, int, int);
 template __global__ void rbpf_raycast_box<512, 8, false, 4>(ScanC, TilePool, MapT, const double2* __restrict__, const double* __restrict__, const double* __restrict__, int* __restrict__, int* __restrict__, int* __restrict__, int, unsigned long long* __restrict__, NormArgs, int* __restrict__, int* __restrict__, int, int);
 template __global__ void rbpf_raycast_box<512, 8, true, 8>(ScanC, TilePool, MapT, const double2* __restrict__, const double* __restrict__, const double* __restrict__, int* __restrict__, int* __restrict__, int* __restrict__, int, unsigned long long* __restrict__, NormArgs, int* __restrict__, int* __restrict__, int, int);
-template __global__ void rbpf_raycast_box<512, 8, true, 4>(ScanC, TilePool, MapT, const double2* __restrict__, const double* __restrict__, const double* __restrict__, int* __restrict__, int* __restrict__, int* __restrict__, int, unsigned long long* __restrict__, NormArgs, int* __restrict__, int* __restrict__, int, int);
 template __global__ void rbpf_raycast_box<1024, 8, false, 8>(ScanC, TilePool, MapT, const double2* __restrict__, const double* __restrict__, const double* __restrict__, int* __restrict__, int* __restrict__, int* __restrict__, int, unsigned long long* __restrict__, NormArgs, int* __restrict__, int* __restrict__, int, int);
 
 }  // namespace tbnav_rk
