@@ -1312,8 +1312,15 @@ int tbnav_rbpf_slam_batch(tbnav_rbpf* h, const float* scans, int32_t n_beams, in
   const unsigned long long scan0 = h->scan_index;  // noise counter of the batch's first scan
   std::vector<Prefetched> pre(ahead ? chunk : 0);
   int prepared_to = 0;  // scans [0, prepared_to) have had their chunk prepared
+  int chunk_first = 0;  // the first scan of the chunk prepared last: scan s of it uses slot s - chunk_first of the rings
   auto prepare = [&](int first) -> int {
-    const int m = std::min(chunk, n_scans - first);
+    // The call's FIRST chunk is two scans: the host's share of a chunk (the scans' beam tables, ~5 us each) sits in front of the
+    // call's first launch, where nothing hides it — a call of 6 scans cost 40 us on top of its scans, one of 3 cost 21.  Later chunks
+    // are prepared while two scans are in the stream.  (Two, not one: the pinned staging of a chunk is rewritten when the next is
+    // prepared, during the iteration of its last scan — by then the scan before that has been waited for, and with it the launch
+    // that read the staging, only if the chunk had two scans at least.)
+    const int m = std::min(first == 0 ? 2 : chunk, n_scans - first);
+    chunk_first = first;
     for (int j = 0; j < m; ++j) {
       const int s = first + j;
       Prefetched& q = pre[j];
@@ -1339,7 +1346,7 @@ int tbnav_rbpf_slam_batch(tbnav_rbpf* h, const float* scans, int32_t n_beams, in
     t.poll = true;
     h->scan_index = scan0 + (unsigned long long)s;  // (scan_enqueue counts it)
     return scan_enqueue(h, scans + (size_t)s * n_beams, n_beams, u + 3 * s, odom + 3 * (s + 1), odom + 3 * s, icp_ok ? icp_ok[s] : 1,
-                        T_icp + 3 * s, nullptr, out + s, false, s % kScanSlots, gate_prev, t, ahead ? &pre[s % chunk] : nullptr);
+                        T_icp + 3 * s, nullptr, out + s, false, s % kScanSlots, gate_prev, t, ahead ? &pre[s - chunk_first] : nullptr);
   };
   int rc = enqueue(0, nullptr);
   if (rc != TBNAV_OK) return rc;
