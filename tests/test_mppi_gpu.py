@@ -55,11 +55,12 @@ def test_cfg2_k1024_t50(gpu_pkg):
     _check_tick(m, d, u, (0.5, 0.6), WAYPOINTS[1], (0.02, -0.01, 0.1), _noise(42, 1024, 50))
 
 
-@pytest.mark.parametrize("K,horizon", [(1, 0.05), (5, 1.0), (63, 0.1), (65, 0.1), (100, 0.29),
+@pytest.mark.parametrize("K,horizon", [(1, 0.05), (1, 0.01), (3, 0.01), (2, 0.02), (5, 1.0), (63, 0.1), (65, 0.1), (100, 0.29),
                                         (2047, 0.05), (2049, 0.05), (4100, 0.02)])
 def test_ragged_sizes(gpu_pkg, K, horizon):
     """K not a multiple of the wave (64) or of the K-slice (2048); the shipped rollouts=5, T=100;
-    the int(horizon/dt) truncation case 0.29/0.01 -> 28 (mppi.cpp:47)."""
+    the int(horizon/dt) truncation case 0.29/0.01 -> 28 (mppi.cpp:47); a horizon of ONE step (the terminal loss is all there is,
+    mppi.cpp:105) and of two, with one to three rollouts."""
     d = mppi_cfg(K, horizon)
     m = make_mppi(gpu_pkg, d)
     T = orc.mppi_steps(d)

@@ -206,6 +206,43 @@ def test_gated_beams_and_ragged_scan(gpu_pkg):
         _compare_scan(pf_o, pf_d, tr_o, st, True)
 
 
+@pytest.mark.parametrize("icp_ok", [True, False])
+@pytest.mark.parametrize("kind", ["no_valid_beam", "one_valid_beam", "first_scan_empty"])
+def test_scans_with_no_or_one_valid_beam(gpu_pkg, kind, icp_ok):
+    """The edge of a ragged scan: every range gated out (laserEndPoints returns nothing: the likelihood is an empty product, the map is
+    not touched — sensor_model.cpp:77-108, grid_mapper.cpp:100-121, 140-182), a single surviving beam, and an empty scan as the very
+    first one (empty maps, no tile allocated yet) — then ordinary scans on top, against the oracle as every other case."""
+    N, k = 6, 9
+    pf_o = orc.PfAPI(orc.pf_params(N=N, k=k)); pf_d = _dev(gpu_pkg, N=N, k=k)
+    steps, poses = rc.trajectory(4, inc=(0.03, 0.02, 0.02))
+    rng = np.random.default_rng(2)
+    for s, (prev, cur, t_icp, u) in enumerate(steps):
+        scan = orc.room_scan(poses[s], walls=rc.ROOM_SMALL, rng=rng)
+        want_valid = None
+        if (kind == "first_scan_empty" and s == 0) or (kind != "first_scan_empty" and s == 2):
+            keep = scan[77]
+            scan[:] = np.where(np.arange(scan.size) % 2 == 0, 0.01, 9.0)   # below range_min / beyond range_max
+            want_valid = 0
+            if kind == "one_valid_beam":
+                scan[77] = keep; want_valid = 1
+        normals = orc.normal_stream(40 + s, pf_o.normals_per_scan(icp_ok), 0.0, 1.0)
+        _inject(pf_o, pf_d)
+        tr_o = pf_o.slam(scan, u, cur, prev, icp_ok, t_icp, normals)
+        st = pf_d.SLAM(scan, u, cur, prev, icp_ok, t_icp, normals)
+        if want_valid is not None:
+            assert st.n_valid_beams == want_valid
+        _compare_scan(pf_o, pf_d, tr_o, st, icp_ok)
+    # ... and with device noise through the batch entry point the empty scan is just another scan
+    scans = np.stack([orc.room_scan(poses[s], walls=rc.ROOM_SMALL, rng=rng) for s in range(4)])
+    scans[1, :] = 0.01
+    odom = np.array([steps[0][0]] + [st_[1] for st_ in steps], dtype=np.float64)
+    pf_b = _dev(gpu_pkg, N=N, k=k)
+    pf_b.setSeed(9)
+    out = pf_b.SLAMBatch(scans, np.array([st_[3] for st_ in steps]), odom, np.array([st_[2] for st_ in steps]), icp_ok=np.full(4, int(icp_ok), dtype=np.int32))
+    assert [x.status for x in out] == [0, 0, 0, 0] and out[1].n_valid_beams == 0
+    pf_o.close(); pf_d.close(); pf_b.close()
+
+
 def test_forced_resampling_parents_and_map_copies(gpu_pkg):
     """Skewed weights make Neff < N/2: the parent list is bit-exact (negative Gaussian offset,
     1/(N-1) spacing, clamp at N-1 — particle_filter.cpp:468-500), maps follow their parents and the
