@@ -28,7 +28,7 @@ def _rel(a, b):
 
 
 def _free_run(gpu_pkg, df_mode, N, k, map_half, walls, n_scans, inc, seed, force_resample_at=None, start=(0.0, 0.0, 0.0),
-              oracle_exact_field=False, oracle_window=None, pool_bytes=0, n_beams=360, **extra):
+              oracle_exact_field=False, oracle_window=None, pool_bytes=0, n_beams=360, empty_at=(), **extra):
     """Oracle filter and device filter side by side, same scans, same draws, nothing injected.  oracle_exact_field: the
     oracle's likelihoods read the exact nearest-obstacle distance (the checker of the device's default mode) instead of
     the reference's brushfire."""
@@ -40,6 +40,8 @@ def _free_run(gpu_pkg, df_mode, N, k, map_half, walls, n_scans, inc, seed, force
     rows = []
     for s, (prev, cur, t_icp, u) in enumerate(steps):
         scan = orc.room_scan(poses[s], n_beams=n_beams, beam_delta_deg=extra.get("beam_delta_deg", 1.0), walls=walls, rng=rng)
+        if s in empty_at:
+            scan[:] = 0.01   # every range below range_min: no valid beam
         normals = orc.normal_stream(900 + s, pf_o.normals_per_scan(True), 0.0, 1.0)
         if force_resample_at == s:
             w = np.full(N, 0.2 / N); w[3] += 0.5; w[N // 2] += 0.3; w /= w.sum()
@@ -93,6 +95,24 @@ def test_reference_mode_shipped_config_is_the_reference_end_to_end(gpu_pkg):
         exact = orc.exact_edt_codes(occ.reshape(pf_d.xsize, pf_d.xsize), 200, np.full((pf_d.xsize, pf_d.xsize), 0xFFFF, np.uint16))
         n_nonexact += int((pf_d.distCode(p).reshape(pf_d.xsize, pf_d.xsize) != exact).sum())
     assert n_nonexact > 0  # ... i.e. this really is the brushfire, not the exact transform
+    pf_d.close()
+
+
+@pytest.mark.parametrize("mode", ["reference", "query"])
+def test_un_injected_run_with_empty_scans(gpu_pkg, mode):
+    """A scan without a valid beam as the first scan (empty maps, nothing occupied: the reference's brushfire returns at once,
+    grid_mapper.cpp:338) and in the middle of a run, right after a forced resampling (no set operation on freshly copied states) —
+    nothing injected, both distance-field modes against their oracle."""
+    N = 24
+    pf_o, pf_d, rows = _free_run(gpu_pkg, mode, N=N, k=20, map_half=2.0, walls=rc.ROOM_SMALL, n_scans=7, inc=(0.04, 0.03, 0.02), seed=5,
+                                 force_resample_at=3, empty_at=(0, 4), oracle_exact_field=(mode == "query"))
+    assert rows[3]["resampled"] == (1, 1)
+    _assert_every_stage(rows)
+    for p in range(N):
+        g = pf_o.grid(p).dump()
+        assert np.array_equal(pf_d.logOdds(p), g["log_odds"]), p
+        if mode == "reference":
+            assert np.array_equal(pf_d.occDist(p), g["occ_dist"]), p
     pf_d.close()
 
 
