@@ -278,7 +278,7 @@ def test_cfg3_as_written_1000_particles_400x400_default_query_mode_against_the_e
     if room == "bench":
         assert k_raycast == "rbpf_raycast_box<512, 8, false, 4>", (k_raycast, pf_d.raycastBoxCells())
     else:
-        assert k_raycast.startswith("rbpf_raycast_box<512, "), k_raycast
+        assert k_raycast == "rbpf_raycast_box<512, 8, true, 8>", (k_raycast, pf_d.raycastBoxCells())   # (the instantiation of bench_rbpf.py's survey_room leg)
     assert rows[1]["resampled"] == (1, 1)
     _assert_every_stage(rows)
     po, pvo, wo = pf_o.particles()
