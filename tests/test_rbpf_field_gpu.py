@@ -304,6 +304,8 @@ def test_configs4_shard_shape_2000_particles_2000x2000_1080_beams_query_mode_aga
     finally:
         orc.lib().orc_set_threads(1)
     assert (pf_d.xsize, pf_d.ysize) == (2000, 2000)
+    # the instantiations bench_rbpf.py's configs4_shard_one_gpu leg times (there with device noise: rbpf_propose<512, true>)
+    assert pf_d.lastKernelNames()[:2] == ("rbpf_propose<512, false>", "rbpf_raycast_box<1024, 8, false, 8>"), pf_d.lastKernelNames()
     assert rows[1]["resampled"] == (1, 1)
     _assert_every_stage(rows)
     for p in (0, 1, 999, 1000, 1998, 1999):
