@@ -128,7 +128,7 @@ def test_arc_and_rk4_dynamics_agree_to_truncation_order(gpu_pkg):
     assert 0 < rel.max() < 1e-6
 
 
-@pytest.mark.parametrize("K,horizon", [(1024, 0.5), (100, 1.0), (37, 1.28), (200, 2.0)])
+@pytest.mark.parametrize("K,horizon", [(1024, 0.5), (8192, 1.0), (100, 1.0), (37, 1.28), (200, 2.0)])
 def test_in_kernel_noise_equals_sampled_noise(gpu_pkg, K, horizon):
     """Production tick (tbnav_mppi_new_controls_rng): the fused small-K kernel generates the perturbations of
     (seed, tick) itself instead of loading them.  They must be the values tbnav_mppi_sample_noise writes, so the tick
@@ -152,6 +152,10 @@ def test_in_kernel_noise_equals_sampled_noise(gpu_pkg, K, horizon):
         assert rel_err(m_rng.costToGo(), ref["J"]) < J_RTOL
         u = ref["u"]
         x0 = (x0[0] + 0.002, x0[1], x0[2] + 0.001)
+    if (K, horizon) == (1024, 0.5):   # BASELINE configs[1]: the kernels of bench.py's headline line, by name
+        assert m_rng.lastKernelNames()[:2] == ("mppi_rollout_fused<2, 8, 1, 1>", "mppi_combine<2, 0>"), m_rng.lastKernelNames()
+    if (K, horizon) == (8192, 1.0):   # one GPU's share of configs[3] on 8: bench.py's configs3_shard_one_gpu leg
+        assert m_rng.lastKernelNames()[:2] == ("mppi_rollout_fused<2, 16, 2, 1>", "mppi_combine_wide"), m_rng.lastKernelNames()
 
 
 @pytest.mark.parametrize("K,horizon,dyn", [(1024, 0.5, "rk4"), (4096, 1.0, "rk4"), (100, 1.28, "rk4"), (1024, 0.5, "arc"), (200, 2.0, "rk4")])
