@@ -16,6 +16,7 @@ nt = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 pf = ParticleFilter(default_params(N=N, k=50, map_min=-10.0, map_max=10.0))
 pf.setSeed(1); pf.setOption(capi.RBPF_OPT_RAYCAST_THREADS, nt)
+if len(sys.argv) > 3: pf.setOption(capi.RBPF_OPT_NOISE_IN_KERNEL, int(sys.argv[3]))   # 0: rbpf_propose<., false> (stored normals)
 for s, (prev, cur, t_icp, u) in enumerate(steps):
     pf.SLAM(scans[s], u, cur, prev, True, t_icp, None)
 pf.close()
