@@ -174,10 +174,36 @@ def noise_forms(device, N, k, n_scans=30):
                 res["ms_per_synchronous_scan"] = round(wall / n * 1e3, 5)
             pf.close()
         out[name] = res
-    out["note"] = ("drawing inside the kernel removes the 4.7 us rbpf_sample_normals launch and 2.4 MB of traffic per scan and adds ~4 us to the proposal kernel's own chain "
-                   "(78 threads draw one fp64 Box-Muller pair each in front of the first barrier): the wall time of a synchronous scan is the same within 1-2 us — the "
-                   "sample launch used to run under the host's enqueue of the proposal launch.  The headline's tbnav_rbpf_slam_batch draws a chunk of scans ahead in one launch either way")
+    out["note"] = ("drawing inside the kernel removes the 4.7 us rbpf_sample_normals launch and 2.4 MB of traffic per scan; the proposal launch's interval grows by ~4 us, of which "
+                   "under 1 us is inside its workgroups (78 threads draw one fp64 Box-Muller pair each, the wait for the beam table; per-wave timelines: profiles/r05_phase_timelines.txt, "
+                   "docs/lab_notebook.md) — the rest is the scan's first dispatch after the host's wait, which used to be the sample launch's: the wall time of a synchronous scan is the "
+                   "same within 1-2 us.  The headline's tbnav_rbpf_slam_batch draws a chunk of scans ahead in one launch either way")
     return out
+
+
+def long_replay(device, N, k, n_scans=56, warm=8):
+    """The bench workload replayed by ONE tbnav_rbpf_slam_batch call, as it comes (no weights skewed: the filter does not resample on it):
+    what a scan costs when nothing sits between the launches — the headline cuts its replay into calls of 6 scans and forces a resampling
+    at two of the cuts, which is where its ms_per_scan exceeds the kernels' sum."""
+    from rtn_amd.rbpf import ParticleFilter, default_params
+    steps, scans = workload(n_scans)
+    odom = np.array([steps[0][0]] + [st_[1] for st_ in steps], dtype=np.float64)
+    u_all = np.array([st_[3] for st_ in steps], dtype=np.float64)
+    ticp_all = np.array([st_[2] for st_ in steps], dtype=np.float64)
+    sc = np.stack(scans)
+    pf = ParticleFilter(default_params(N=N, k=k, map_min=-10.0, map_max=10.0, device=device.index or 0))
+    pf.setSeed(2026)
+    pf.SLAMBatch(sc[:warm], u_all[:warm], odom[:warm + 1], ticp_all[:warm])
+    t0 = time.perf_counter()
+    sts = pf.SLAMBatch(sc[warm:], u_all[warm:], odom[warm:], ticp_all[warm:])
+    dt = time.perf_counter() - t0
+    k_propose, k_raycast, _ = pf.lastKernelNames()
+    pf.close()
+    n = n_scans - warm
+    return {"ms_per_scan": round(dt / n * 1e3, 4), "particle_updates_per_s": round(N * n / dt, 1), "scans_timed": n, "calls": 1,
+            "resamples": int(sum(x.resampled for x in sts)), "kernels": {"propose": k_propose, "raycast": k_raycast},
+            "note": "two launches per scan back to back (the noise of eight scans at a time by a third); the two kernels by rocprofv3: "
+                    "profiles/r05_kernel_stats_rbpf_N1000_k50_400x400*.md (rbpf_propose<256, false> 27.0 us median, rbpf_raycast_box<512, 8, false, 4> 37.3)"}
 
 
 def reference_field_mode(device, N, k, map_half, walls, n_scans, host_threads=0, spread=None, start=(0.0, 0.0, 0.0), inc=None):
@@ -467,6 +493,7 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
             device, "SURVEY 8-d room", N, k, 10.0, ROOM_SURVEY, TRAJ_SURVEY, traffic_key="rbpf_N1000_k50_400x400_survey_room",
             stats_workload="rbpf_N1000_k50_400x400_survey_room", sq_key="rbpf_N1000_k50_400x400_survey_room"),
         "noise_forms": noise_forms(device, N, k),
+        "long_replay_one_call_no_resampling": long_replay(device, N, k),
         "configs4_shard_one_gpu": shard4,
         "configs4_as_written_one_gpu": cfg4,
         "distance_field_mode": "query",
