@@ -181,6 +181,47 @@ def noise_forms(device, N, k, n_scans=30):
     return out
 
 
+def layout_floor(walls, inc, n_scans=14, first=2, seed=7):
+    """The HBM bytes per particle and scan the map update cannot go below WITH THIS MAP LAYOUT (no GPU needed): every 128-byte line that
+    holds a touched cell is fetched whole, every 32-byte sector that holds one is written whole (profiles/r05_fetch_write_calibration.txt:
+    what FETCH_SIZE / WRITE_SIZE count on gfx950 for partial-line 16-byte accesses), tiles of 32 x 32 cells whose rows are 256 contiguous
+    bytes.  The cells of the scan's Bresenham rays from the robot's cell at the trajectory's poses (the particles are micrometres from
+    them), as distinct cells, sectors and lines; mean over scans [first, n_scans)."""
+    rc = _world()
+    res, map_min, rmin, rmax = 0.05, -10.0, 0.12, 3.5
+    _, poses = rc.trajectory(n_scans, inc=inc)
+    rng = np.random.default_rng(seed)
+    rows = []
+    for s in range(n_scans):
+        th, x, y = poses[s]
+        scan = _room_scan(poses[s], rng, walls).astype(np.float64)
+        ang = th + np.deg2rad(1.0) * np.arange(scan.size)
+        ok = (scan >= rmin) & (scan < rmax)
+        ex, ey = x + scan * np.cos(ang), y + scan * np.sin(ang)
+        cx, cy = int(np.floor((x - map_min) / res)), int(np.floor((y - map_min) / res))
+        cells = set()
+        for b in np.flatnonzero(ok):
+            x1, y1 = int(np.floor((ex[b] - map_min) / res)), int(np.floor((ey[b] - map_min) / res))
+            x0, y0 = cx, cy
+            dx, dy = abs(x1 - x0), abs(y1 - y0)
+            sx, sy = (1 if x1 > x0 else -1), (1 if y1 > y0 else -1)
+            err = dx - dy
+            while True:   # (a textbook Bresenham: the counts move by a fraction of a percent between variants; the kernel's is grid_mapper.cpp:229-270's)
+                cells.add((x0, y0))
+                if x0 == x1 and y0 == y1:
+                    break
+                e2 = 2 * err
+                if e2 > -dy:
+                    err -= dy; x0 += sx
+                if e2 < dx:
+                    err += dx; y0 += sy
+        if s >= first:
+            rows.append((len(cells), len({(i, j >> 2) for i, j in cells}), len({(i, j >> 4) for i, j in cells}), int(ok.sum())))
+    r = np.array(rows, dtype=np.float64).mean(axis=0)
+    return {"distinct_cells": round(float(r[0]), 1), "sectors_32B": round(float(r[1]), 1), "lines_128B": round(float(r[2]), 1), "valid_beams": round(float(r[3]), 1),
+            "algorithmic_bytes": float(r[0]) * 16.0, "read_floor_bytes": float(r[2]) * 128.0, "write_floor_bytes": float(r[1]) * 32.0}
+
+
 def long_replay(device, N, k, n_scans=56, warm=8):
     """The bench workload replayed by ONE tbnav_rbpf_slam_batch call, as it comes (no weights skewed: the filter does not resample on it):
     what a scan costs when nothing sits between the launches — the headline cuts its replay into calls of 6 scans and forces a resampling
@@ -458,6 +499,16 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
                                     "(4e-14 on the shipped 80 x 80 launch configuration) — OUTSIDE north_star's 1e-5 on this grid",
                           "vs_target_1e5": round(N / (ms_scan * 1e-3) / 1e5, 2)},
     }
+    # what this map layout lets the traffic go down to (layout_floor above: whole lines read, whole sectors written), beside what was measured
+    fl = layout_floor(ROOM_BENCH, TRAJ_INC)
+    fl_bytes = (fl["read_floor_bytes"] + fl["write_floor_bytes"]) * N
+    floor_obj = {"bytes_per_launch": round(fl_bytes, 1), "over_algorithmic": round((fl["read_floor_bytes"] + fl["write_floor_bytes"]) / fl["algorithmic_bytes"], 3),
+                 "reads": round(fl["read_floor_bytes"] * N, 1), "writes": round(fl["write_floor_bytes"] * N, 1),
+                 "measured_reads": None if pmc is None else pmc.get("read_bytes"), "measured_writes": None if pmc is None else pmc.get("write_bytes"),
+                 "traffic_over_floor": None if pmc is None else round(pmc["hbm_bytes"] / fl_bytes, 3),
+                 "note": f"{fl['lines_128B']:.0f} 128-byte lines and {fl['sectors_32B']:.0f} 32-byte sectors hold the {fl['distinct_cells']:.0f} cells one scan touches (modelled on the host from the "
+                         "trajectory's poses; tiles of 32 x 32 cells, rows of 256 bytes): a touched line is FETCHED whole, a touched sector WRITTEN whole "
+                         "(profiles/r05_fetch_write_calibration.txt, tools/fetch_calibrate.hip) — the floor of any kernel over this layout"}
     out = {
         "metric": "RBPF particle-updates/s", "value": round(N / (ms_scan * 1e-3), 1), "unit": "particle-updates/s",
         "value_is_for_mode": "query_default", "modes": modes,
@@ -520,6 +571,7 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
                      "traffic_source": None if pmc is None else pmc["source"] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; plain scans, no tile clones)",
                      "traffic_rate": None if pmc is None else {"achieved": round(pmc["hbm_bytes"] / t_rc / 1e9, 3), "frac": round(pmc["hbm_bytes"] / t_rc / 1e9 / HBM_PEAK_GBS, 6),
                                                                 "traffic_over_algorithmic": round(pmc["hbm_bytes"] / alg_dom, 3)},
+                     "layout_floor": floor_obj,
                      "kernel_ms": round(kms["raycast"], 6),
                      "per_touch_note": {"bytes_per_launch": round(alg_ref, 1), "frac": round(alg_ref / t_rc / 1e9 / HBM_PEAK_GBS, 6),
                                         "note": f"SURVEY.md 8-d's (C_free + Bv) x 16 B — one RMW per (beam, cell) touch as the reference's loop performs them: {upd_per:.1f} "
