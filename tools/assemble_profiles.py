@@ -31,9 +31,11 @@ for key, tag in TAGS.items():
             v["note"] = "reads are 64- / 128-byte row segments (8 or 16 rollouts x 8 B per time step): FETCH_SIZE at face value, no x2"
         if name.startswith("rbpf_raycast") and key == "rbpf_N1000_k50_400x400":
             v["note"] = ("average over 11 launches of which two follow a forced resample (tiles of a shared map are made private in that launch); 16-byte accesses, "
-                         "whole cache lines per wave: the x2 read correction and the 1:1 write reading are uncalibrated for this pattern (MI355X_MICROARCH.md, HBM)")
+                         "whole cache lines per wave: the x2 read correction and the 1:1 write reading hold for this pattern (calibrated: profiles/r05_fetch_write_calibration.txt — "
+                         "whole 128-byte lines fetched, whole 32-byte sectors written)")
         elif name.startswith("rbpf_raycast"):
-            v["note"] = "no forced resample in this run: every launch is a plain scan (no tile clones)"
+            v["note"] = ("no forced resample in this run: every launch is a plain scan (no tile clones); partial-line 16-byte accesses: FETCH_SIZE x 2 = whole 128-byte "
+                         "lines fetched, WRITE_SIZE = whole 32-byte sectors written (calibrated: profiles/r05_fetch_write_calibration.txt)")
     out["workloads"][key] = wl
     if os.path.exists(G(f"kstats_{tag}.md")):
         shutil.copy(G(f"kstats_{tag}.md"), P(f"{R}_kernel_stats_{key}.md"))
