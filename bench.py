@@ -167,6 +167,92 @@ def _cpu_baseline(orc, K, T, horizon, budget_s, threads):
             "ms_per_tick": round(el / n * 1e3, 4)}
 
 
+LINE_LIMIT = 6144   # bytes: the driver parses the LAST stdout line and keeps an 8 KB tail (round 5's 22 KB line came back unparsed)
+DETAIL_PATH = os.environ.get("TBNAV_BENCH_DETAIL") or os.path.join(ROOT, "bench_detail.json")
+
+
+def _pick(d, keys):
+    return None if d is None else {k: d.get(k) for k in keys if k in d}
+
+
+def _short(text, n=120):
+    return text if text is None or len(text) <= n else text[:n - 1] + "\u2026"
+
+
+def _cpu_obj(c):
+    if c is None:
+        return None
+    o = _pick(c, ("value", "unit", "cores", "kind"))
+    o["sample"] = _short(c.get("sample"), 140)
+    return o
+
+
+def _roof_obj(r):
+    """The contract's roofline object, numbers and names only: bound, kernel, achieved / peak / frac (live HIP events), frac_rocprof
+    with the row it divides by, traffic with its source, the algorithmic bytes."""
+    if r is None:
+        return None
+    o = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_rocprof", "traffic", "algorithmic_bytes_per_launch", "traffic_over_algorithmic"))
+    o["rocprof"] = _pick(r.get("rocprof"), ("source", "row", "avg_us"))
+    o["traffic_source"] = None if not r.get("traffic_source") else r["traffic_source"].split(" (")[0]
+    if isinstance(r.get("kernel_ms"), dict):
+        o["kernel_us"] = {k: round(v * 1e3, 3) for k, v in r["kernel_ms"].items()}
+    elif r.get("kernel_ms") is not None:
+        o["kernel_us"] = round(r["kernel_ms"] * 1e3, 3)
+    if r.get("traffic") and r.get("algorithmic_bytes_per_launch") and "traffic_over_algorithmic" not in o:
+        o["traffic_over_algorithmic"] = round(r["traffic"] / r["algorithmic_bytes_per_launch"], 3)
+    return o
+
+
+def compact_line(full):
+    """The record the driver parses: the contract's keys, one roofline and one cpu_baseline object, a small RBPF summary — numbers and
+    names, no prose.  Everything else the run measured is in bench_detail.json (`detail`)."""
+    keys = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_min", "ms_per_step_max", "repeats",
+            "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    out = {k: full.get(k) for k in keys}
+    cfg = full.get("config") or {}
+    out["config"] = {"workload": _short(cfg.get("workload")), "noise": _short(cfg.get("noise")), "parallelism": _short(cfg.get("parallelism"))}
+    out["roofline"] = _roof_obj(full.get("roofline"))
+    out["cpu_baseline"] = _cpu_obj(full.get("cpu_baseline"))
+    out["cpu_baseline_all_cores"] = _cpu_obj(full.get("cpu_baseline_all_cores"))
+    for k in ("sync_tick_ms", "graph_replayed_ticks", "exchange", "multi_gpu_legs"):
+        if full.get(k) is not None:
+            out[k] = _short(full[k]) if isinstance(full[k], str) else full[k]
+    rb = full.get("rbpf")
+    if rb is not None:
+        modes = rb.get("modes") or {}
+        out["rbpf"] = {
+            "metric": rb.get("metric"), "unit": rb.get("unit"), "value": rb.get("value"), "value_is_for_mode": rb.get("value_is_for_mode"),
+            "ms_per_scan": rb.get("ms_per_scan"), "dtype": rb.get("dtype"),
+            "config": {"workload": _short((rb.get("config") or {}).get("workload"), 160)},
+            "modes": {name: _pick(mo, ("particle_updates_per_s", "ms_per_scan", "vs_target_1e5", "max_rel_err_vs_reference")) for name, mo in modes.items()},
+            "roofline": _roof_obj(rb.get("roofline")),
+            "cpu_baseline": _cpu_obj(rb.get("cpu_baseline")), "cpu_baseline_all_cores": _cpu_obj(rb.get("cpu_baseline_all_cores")),
+        }
+    for k in ("strong_scaling_configs3", "rbpf_sharded", "weak_tick_via_comm_all_gather"):   # N > 1 legs: the figures only
+        if full.get(k) is not None:
+            out[k] = _pick(full[k], ("rollouts_per_s", "particle_updates_per_s", "ms_per_step", "ms_per_scan", "exchange_kind", "exchange", "resamples", "scaling"))
+    out["detail"] = os.path.basename(DETAIL_PATH)
+    return out
+
+
+def emit(full):
+    """bench_detail.json <- everything measured; stdout's LAST line <- the compact record (asserted under LINE_LIMIT bytes)."""
+    try:
+        with open(DETAIL_PATH, "w") as f:
+            json.dump(full, f, indent=1)
+            f.write("\n")
+    except OSError as e:   # (a read-only checkout: the line still goes out)
+        print(f"[bench] could not write {DETAIL_PATH}: {e}", file=sys.stderr, flush=True)
+    text = json.dumps(compact_line(full), separators=(",", ":"))
+    if len(text) >= LINE_LIMIT:   # never print a line the driver cannot read: drop the secondary object first
+        c = compact_line(full)
+        c.pop("rbpf", None)
+        text = json.dumps(c, separators=(",", ":"))
+    sys.stdout.flush()
+    print(text, flush=True)
+
+
 LEGS_BUDGET_S = 240.0  # the N > 1 legs take seconds (60 ticks, 14 scans, RCCL's first point-to-point connections)
 
 
@@ -185,7 +271,7 @@ class LegWatchdog:
         if self.rank == 0 and self.line is not None:
             out = dict(self.line)
             out["multi_gpu_legs"] = f"skipped: {why}"
-            print(json.dumps(out), flush=True)
+            emit(out)
         else:
             time.sleep(3.0)  # (rank 0's line first)
         os._exit(0)
@@ -206,6 +292,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large", action="store_true")
     ap.add_argument("--no-rbpf", action="store_true", help="skip the secondary RBPF object (development)")
+    ap.add_argument("--detail", action="store_true", help="every optional leg as well (per-shape roofline objects, options, noise forms, "
+                    "reference-field variants, configs[4] as written); all of it goes to bench_detail.json, never into the last line")
+    ap.add_argument("--repeats", type=int, default=31, help="the --steps block is timed this many times; ms_per_step is the median")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -303,24 +392,39 @@ def main():
 
     sync = lambda: torch.cuda.synchronize(device)  # noqa: E731
     graph_ticks_timed = 0
+    els = None
     if world == 1:
         ticks(args.warmup)
         sync()  # (one rank: the barrier of the bracket is empty)
         g0 = m.graphReplayedTicks()
-        t0 = time.perf_counter()
-        ticks(args.steps)
-        sync()
-        el = time.perf_counter() - t0
-        graph_ticks_timed = m.graphReplayedTicks() - g0
-        el_py = time_ticks(tick, sync, args.steps, args.warmup, barrier)  # one Python call per tick, for comparison
-    elif comm is not None:
-        def headline():
-            ticks(args.warmup)
-            sync(); barrier(); sync()
+        # the block of EXACTLY --steps ticks, timed --repeats times back to back (state carried): 20 ticks are 0.2 ms of work, one
+        # sample of that is inside the noise of a wake-up — the line reports the MEDIAN block (min / max beside it)
+        els = []
+        for _ in range(max(1, args.repeats)):
             t0 = time.perf_counter()
             ticks(args.steps)
-            sync(); barrier(); sync()
-            el = time.perf_counter() - t0
+            sync()
+            els.append(time.perf_counter() - t0)
+        el = float(np.median(els))
+        graph_ticks_timed = (m.graphReplayedTicks() - g0) // max(1, args.repeats)
+        el_py = time_ticks(tick, sync, args.steps, args.warmup, barrier) if args.detail else None  # one Python call per tick, for comparison
+    elif comm is not None:
+        els_box = []
+
+        def headline():
+            ticks(args.warmup)
+            blocks = []
+            for _ in range(max(1, args.repeats)):   # every block bracketed as the contract says; max over ranks per block, median of those
+                sync(); barrier(); sync()
+                t0 = time.perf_counter()
+                ticks(args.steps)
+                sync(); barrier(); sync()
+                blocks.append(time.perf_counter() - t0)
+            tb = torch.tensor(blocks, dtype=torch.float64, device="cpu" if one_gpu_test else device)
+            dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+            blocks = [float(x) for x in tb.cpu()]
+            el = float(np.median(blocks))
+            els_box[:] = blocks
             try:
                 good = bool(np.all(np.isfinite(m.lastControls(stream))))
             except Exception as e:  # noqa: BLE001 — a direct exchange whose bound expired reports here
@@ -337,6 +441,7 @@ def main():
             el, good = headline()
         assert good, "the sharded ticks did not come through"
         el_py = None
+        els = list(els_box)
     else:
         el = time_ticks(tick, sync, args.steps, args.warmup, barrier)
         el_py = None
@@ -355,36 +460,34 @@ def main():
         # the production tick's own kernels: the in-kernel-noise instantiation the timed region ran
         ms_k = kernel_profile(m, a, b, stream, min(args.steps, 500), rng=(SEED, 20_000_000))
         k_rollout, k_combine = m.lastKernelNames()
+        sampler = "fp64 Box-Muller on 52-bit uniforms (std::normal_distribution<double>'s width)" if k_rollout.endswith(", 2>") else "fp32 Box-Muller on 24-bit uniforms"
         line = {
             "metric": "MPPI rollouts/s", "value": round(value, 1), "unit": "rollouts/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 6),
+            "ms_per_step_min": None if not els else round(min(els) / args.steps * 1e3, 6),
+            "ms_per_step_max": None if not els else round(max(els) / args.steps * 1e3, 6),
+            "repeats": None if not els else len(els), "ms_per_step_is": "median over `repeats` timed blocks of `steps` ticks",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"MPPI newControls K={K} per GPU, T={T} (BASELINE configs[1]); global K={world * K}",
-                       "noise": "drawn on the device inside the timed tick, in the rollout kernel: Philox4x32-10 + Box-Muller in fp32 on 24-bit uniforms (normals on a 2^-24 grid "
-                                "out to 5.9 sigma; the path's arithmetic is fp64).  The reference draws std::normal_distribution<double> (utilities.cpp:20-24): "
-                                "options.mppi_tick_fp64_sampler is the same tick with that width (52-bit uniforms, fp64 log / sqrt / sincospi in the kernel)",
+                       "noise": f"drawn in the rollout kernel inside the timed tick: Philox4x32-10 + {sampler}",
                        "state_carried": True,
-                       "parallelism": f"rollout-shard x{world}" + (", 1 all-gather of soft-min records/tick" if world > 1 else "")},
+                       "parallelism": f"rollout-shard x{world}" + (", 1 exchange of soft-min records/tick" if world > 1 else "")},
             "rollout_steps_per_s": round(value * T, 1),
             "sync_tick_ms": None,   # (measured below, under the watchdog when N > 1)
-            "entry_point": ("tbnav_mppi_enqueue_rng_batch (the timed ticks enqueued by ONE call through the C boundary)" if (world == 1 or comm is not None)
-                            else "tbnav_mppi_shard_* per tick from Python (rtn_amd.sharded)"),
-            # what actually ran in the timed region: whole chunks of 100 ticks are replayed from a captured hipGraph, the rest (all of
+            "entry_point": ("tbnav_mppi_enqueue_rng_batch" if (world == 1 or comm is not None) else "tbnav_mppi_shard_* per tick from Python (rtn_amd.sharded)"),
+            # what actually ran in a timed block: whole chunks of 100 ticks are replayed from a captured hipGraph, the rest (all of
             # them when --steps < 100, as with the driver's --steps 20) are plain launches
             "graph_replayed_ticks": graph_ticks_timed,
-            "exchange": None if world == 1 else (("DIRECT: every rank stores its soft-min records into every peer's gather buffer (IPC-mapped fine-grained memory over xGMI, tagged 8-byte words; "
-                                                  "tbnav_mppi_exchange_kind 2), issued by libtbnav_hip.so on the tick's stream (tbnav_mppi_attach_comm)" if m.exchangeKind() == 2 else
-                                                  ("ncclAllGather" if transport == "rccl" else "all-gather (IPC transport: ranks share one device)")
-                                                  + " of the soft-min records issued by libtbnav_hip.so on the tick's stream (tbnav_mppi_attach_comm)")
-                                                 if comm is not None else f"torch.distributed {dist.get_backend()} all-gather from Python (rtn_amd.sharded; the in-library communicator was unavailable or the one-GPU dev switch is on)"),
+            "exchange": None if world == 1 else (("direct peer stores (tbnav_mppi_exchange_kind 2)" if m.exchangeKind() == 2 else
+                                                  ("ncclAllGather" if transport == "rccl" else "all-gather (IPC transport: ranks share one device)"))
+                                                 + ", issued by libtbnav_hip.so on the tick's stream (tbnav_mppi_attach_comm)"
+                                                 if comm is not None else f"torch.distributed {dist.get_backend()} all-gather from Python (rtn_amd.sharded)"),
             "ms_per_step_one_python_call_per_tick": None if el_py is None else round(el_py / args.steps * 1e3, 6),
-            "roofline": dict(roofline_obj(K, T, ms_k, ms_step, k_rollout, None, "mppi_K1024_T50" if (K, T) == (1024, 50) else None, None, "mppi_K1024_T50_device_noise"),
+            "roofline": dict(roofline_obj(K, T, ms_k, ms_step, k_rollout, None, "mppi_K1024_T50" if (K, T) == (1024, 50) else None, "mppi_K1024_T50", "mppi_K1024_T50_device_noise"),
                              combine_kernel=k_combine),
             # the tick is two dependent launches: what the guide prices for that alone (MI355X_MICROARCH.md, "boundary" row)
-            "latency_floor": {"dependent_launches_per_tick": 2, "boundary_us_each": [1.45, 1.9],
-                              "note": "K*T*48 B = 2.46 MB lives in L2: the tick is launch / dependent-latency bound, not HBM bound; "
-                                      "kernel_ms are back-to-back launch averages and already contain one boundary each"},
+            "latency_floor": {"dependent_launches_per_tick": 2, "boundary_us_each": [1.45, 1.9]},
         }
 
     # ---- N > 1: everything after the headline runs under a watchdog: the headline above is complete, and a collective that does
@@ -419,7 +522,7 @@ def main():
             line.update(extra)
 
     if rank == 0:
-        if world == 1 and not args.no_large:
+        if world == 1 and args.detail and not args.no_large:
             KL, HL = 65536, 1.0  # BASELINE configs[3] per-call size, on one GPU
             ml = make_mppi(KL, HL, local_rank)
             al, bl = synth_noise(ml.steps, KL, device, 99)
@@ -452,7 +555,7 @@ def main():
                                               "ms_per_step_resident_noise": round(el8 / 200 * 1e3, 6), "ms_per_step_device_noise": round(el8r / 200 * 1e3, 6),
                                               "rollouts_per_s_device_noise": round(KL // 8 * 200 / el8r, 1), "roofline": rl8}
             ms8.close()
-        if world == 1:
+        if world == 1 and args.detail:
             n_a = min(args.steps, 1000)
             # the same tick with the perturbations already resident in HBM ([T][K] fp64 x2): the parity-mode data flow
             el_r = time_ticks(lambda: m.enqueueDev(X0, a.data_ptr(), b.data_ptr(), stream), sync, n_a, min(args.warmup, 100), lambda: None)
@@ -470,23 +573,21 @@ def main():
             line["options"]["mppi_exact_arc_dynamics"] = {"rollouts_per_s": round(K * n_a / el_a, 1),
                                                           "ms_per_step": round(el_a / n_a * 1e3, 6)}
             ma.close()
-            # the same production tick with the fp64 sampler (TBNAV_MPPI_OPT_SAMPLER = 1): what the narrower default sampler is worth
+            # the same production tick with the fp32 sampler (TBNAV_MPPI_OPT_SAMPLER = 0, the default up to round 5): what the narrower sampler buys
             from rtn_amd import capi as _capi
             mw = make_mppi(K, horizon, local_rank)
-            mw.setOption(_capi.MPPI_OPT_SAMPLER, 1)
+            mw.setOption(_capi.MPPI_OPT_SAMPLER, 0)
             tkw = [0]
 
-            def wide_ticks(n):
+            def narrow_ticks(n):
                 mw.enqueueRngBatch(X0, SEED, tkw[0], n, stream)
                 tkw[0] += n
-            wide_ticks(min(args.warmup, 100)); sync()
+            narrow_ticks(min(args.warmup, 100)); sync()
             t0w = time.perf_counter()
-            wide_ticks(n_a); sync()
+            narrow_ticks(n_a); sync()
             el_w = time.perf_counter() - t0w
-            line["options"]["mppi_tick_fp64_sampler"] = {"rollouts_per_s": round(K * n_a / el_w, 1), "ms_per_step": round(el_w / n_a * 1e3, 6),
-                                                          "kernel": mw.lastKernelNames()[0],
-                                                          "note": "Philox -> two 52-bit uniforms -> fp64 Box-Muller (log, sqrt, sincospi) inside the rollout kernel: normals out to 8.57 sigma "
-                                                                  "(tests/test_mppi_gpu.py: tail counts to 6 sigma); the headline's sampler is fp32 on 24-bit uniforms"}
+            line["options"]["mppi_tick_fp32_sampler"] = {"rollouts_per_s": round(K * n_a / el_w, 1), "ms_per_step": round(el_w / n_a * 1e3, 6),
+                                                          "kernel": mw.lastKernelNames()[0]}
             mw.close()
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(K, T, horizon, threads=1)
@@ -494,8 +595,8 @@ def main():
             line["cpu_baseline_all_cores"] = cpu_baseline(K, T, horizon, threads=bench_rbpf.effective_cores(), budget_s=8.0)
         if world == 1 and not args.no_rbpf:
             import bench_rbpf
-            line["rbpf"] = bench_rbpf.run(device, args, with_cpu=not args.no_cpu_baseline)
-        print(json.dumps(line), flush=True)
+            line["rbpf"] = bench_rbpf.run(device, args, with_cpu=not args.no_cpu_baseline, detail=args.detail)
+        emit(line)
     if world > 1:
         # (the line is out: a teardown that does not come back — a peer already gone, a communicator that waits — must not keep the
         #  job alive: after a minute every rank leaves)
@@ -608,9 +709,8 @@ def multi_gpu_legs(world, rank, local_rank, device, one_gpu_test, stream, sync, 
                            "ms_per_scan_rank0": {"without_resample": round(float(np.mean(t_plain)) * 1e3, 4) if t_plain else None,
                                                  "resampling_with_migration": round(float(np.mean(t_res)) * 1e3, 4) if t_res else None},
                            "bytes_migrated_rank0": None if sr is None else sr.bytes_migrated, "scaling": "weak",
-                           "exchange": ("inside libtbnav_hip.so (tbnav_rbpf_attach_comm): all-gather of the weights + the global normalise on a second "
-                                        "stream beside the map update; point-to-point sends of tile blobs when resampling fires; transport: "
-                                        + ("RCCL" if comm.uses_rccl else "IPC (ranks share one device)")) if sr is None else f"torch.distributed {dist.get_backend()} (rtn_amd.sharded)"}
+                           "exchange": (f"libtbnav_hip.so (tbnav_rbpf_attach_comm), transport {'RCCL' if comm.uses_rccl else 'IPC (ranks share one device)'}"
+                                        if sr is None else f"torch.distributed {dist.get_backend()} (rtn_amd.sharded)")}
     pf.close()
     return out
 

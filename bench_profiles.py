@@ -18,7 +18,7 @@ import os
 import re
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-ROUNDS = ("r05", "r04", "r03")
+ROUNDS = ("r06", "r05", "r04", "r03")
 
 
 def _first_existing(suffix):

@@ -325,7 +325,9 @@ def workload(n_scans=20):
     return steps, scans
 
 
-def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
+def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True, detail=False):
+    """detail=False (what the driver's command runs): the headline replay, the counted-cells and event-timing passes its roofline needs,
+    the reference-equal mode at configs[2], the two CPU baselines.  detail=True adds every other leg (bench.py --detail)."""
     from rtn_amd import capi
     from rtn_amd.rbpf import ParticleFilter, default_params
     mk = lambda: ParticleFilter(default_params(N=N, k=k, map_min=-10.0, map_max=10.0, device=device.index or 0))  # noqa: E731
@@ -333,16 +335,17 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
     pf = mk()
     nn = pf.numNormals(True)
     # ---- parity-mode pass (host normals, PCIe-inclusive), its own filter
-    normals = [np.random.default_rng(100 + s).standard_normal(nn) for s in range(n_scans)]
-    pf_h = mk()
     t_host, n_host = 0.0, 0
-    for s, (prev, cur, t_icp, u) in enumerate(steps):
-        t0 = time.perf_counter()
-        pf_h.SLAM(scans[s], u, cur, prev, True, t_icp, normals[s])
-        if s >= 2:
-            t_host += time.perf_counter() - t0; n_host += 1
-    pf_h.close()
-    del normals
+    if detail:
+        normals = [np.random.default_rng(100 + s).standard_normal(nn) for s in range(n_scans)]
+        pf_h = mk()
+        for s, (prev, cur, t_icp, u) in enumerate(steps):
+            t0 = time.perf_counter()
+            pf_h.SLAM(scans[s], u, cur, prev, True, t_icp, normals[s])
+            if s >= 2:
+                t_host += time.perf_counter() - t0; n_host += 1
+        pf_h.close()
+        del normals
     # ---- counted cells: their own pass (the counters cost device time)
     pf_c = mk()
     pf_c.setSeed(2026); pf_c.setOption(capi.RBPF_OPT_COUNT_CELLS, 1)
@@ -384,17 +387,18 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
     kms_cow = {key: v / max(n_kc, 1) for key, v in kms_cow.items()}
     # ---- single-call pass: one tbnav_rbpf_slam call per scan from this (Python) harness — what round 1 and the first half
     #      of round 2 reported; kept beside the headline to show what the harness costs
-    pf_s = mk()
-    pf_s.setSeed(2026)
     t_single, n_single = 0.0, 0
-    for s, (prev, cur, t_icp, u) in enumerate(steps):
-        if s in RESAMPLE_AT:
-            _skew(pf_s, N)
-        t0 = time.perf_counter()
-        pf_s.SLAM(scans[s], u, cur, prev, True, t_icp, None)
-        if s >= 2:
-            t_single += time.perf_counter() - t0; n_single += 1
-    pf_s.close()
+    if detail:
+        pf_s = mk()
+        pf_s.setSeed(2026)
+        for s, (prev, cur, t_icp, u) in enumerate(steps):
+            if s in RESAMPLE_AT:
+                _skew(pf_s, N)
+            t0 = time.perf_counter()
+            pf_s.SLAM(scans[s], u, cur, prev, True, t_icp, None)
+            if s >= 2:
+                t_single += time.perf_counter() - t0; n_single += 1
+        pf_s.close()
     # ---- headline pass: the logged run replayed through tbnav_rbpf_slam_batch (the same synchronous per-scan calls, made
     #      from C), in stretches between the points where the weights are skewed (untimed) to force a resample
     t_total, n_timed, resamples, scan_ms = 0.0, 0, 0, []
@@ -417,15 +421,16 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
     cap, free, tile_bytes = pf.poolStats()
     Bv = int(st.n_valid_beams)
     # ---- the per-particle scan-matching option on the same scans, its own filter
-    pf_m = mk()
-    pf_m.setSeed(2026); pf_m.setScanMatching(True)
     t_sm, n_sm = 0.0, 0
-    for s, (prev, cur, t_icp, u) in enumerate(steps[:12]):
-        t0 = time.perf_counter()
-        pf_m.SLAM(scans[s], u, cur, prev, True, t_icp, None)
-        if s >= 2:
-            t_sm += time.perf_counter() - t0; n_sm += 1
-    pf_m.close()
+    if detail:
+        pf_m = mk()
+        pf_m.setSeed(2026); pf_m.setScanMatching(True)
+        for s, (prev, cur, t_icp, u) in enumerate(steps[:12]):
+            t0 = time.perf_counter()
+            pf_m.SLAM(scans[s], u, cur, prev, True, t_icp, None)
+            if s >= 2:
+                t_sm += time.perf_counter() - t0; n_sm += 1
+        pf_m.close()
     # ---- SURVEY.md 8-d's two other runs: the ICP-failed branch (motion-model sample + one likelihood per particle), and k = 10
     def replay(pf_x, icp_ok):
         pf_x.setSeed(2026)
@@ -434,28 +439,30 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
         t0 = time.perf_counter()
         pf_x.SLAMBatch(np.stack(scans[2:]), u_all[2:], odom[2:], ticp_all[2:], icp_ok=icp[2:])
         return (time.perf_counter() - t0) / (n_scans - 2)
-    pf_f = mk()
-    t_fail = replay(pf_f, False)
-    pf_f.close()
-    from rtn_amd.rbpf import ParticleFilter, default_params
-    pf_k = ParticleFilter(default_params(N=N, k=10, map_min=-10.0, map_max=10.0, device=device.index or 0))
-    t_k10 = replay(pf_k, True)
-    pf_k.close()
-    shard4 = None if getattr(args, "no_large", False) else configs4_shard(device)
+    t_fail = t_k10 = None
+    if detail:
+        pf_f = mk()
+        t_fail = replay(pf_f, False)
+        pf_f.close()
+        pf_k = ParticleFilter(default_params(N=N, k=10, map_min=-10.0, map_max=10.0, device=device.index or 0))
+        t_k10 = replay(pf_k, True)
+        pf_k.close()
+    big = detail and not getattr(args, "no_large", False)
+    shard4 = configs4_shard(device) if big else None
     if shard4 is not None:
         # ... and its roofline object: the per-GPU shard shape of BASELINE configs[4] (12 500 x 2000^2 x 1080 beams), synchronous scans
         shard4["roofline_leg"] = map_update_leg(device, "configs[4] / 8", 12500, k, 50.0, ROOM_SURVEY, (0.05, 0.04, 0.03), n_scans=8, n_beams=1080,
                                                 beam_delta_deg=1.0 / 3.0, pool_bytes=16 << 30, traffic_key="rbpf_N12500_2000x2000_1080beams",
                                                 stats_workload="rbpf_N12500_2000x2000_1080beams", sq_key="rbpf_N12500_2000x2000_1080beams")
-    cfg4 = None if getattr(args, "no_large", False) else configs4_as_written(device)
+    cfg4 = configs4_as_written(device) if big else None
     rc_ = _world()
-    ref_mode = {"launch_configuration_40_particles_80x80": reference_field_mode(device, 40, 50, 2.0, rc_.ROOM_SMALL, 12),
-                "configs2_1000_particles_400x400": None if getattr(args, "no_large", False) else reference_field_mode(device, N, k, 10.0, ROOM_BENCH, 8),
+    ref_mode = {"launch_configuration_40_particles_80x80": reference_field_mode(device, 40, 50, 2.0, rc_.ROOM_SMALL, 12) if detail else None,
+                "configs2_1000_particles_400x400": reference_field_mode(device, N, k, 10.0, ROOM_BENCH, n_scans),
                 # SURVEY 8-d's trajectory starts on a corner of four cells and moves by whole cells: the 1e-8 m sampling spread then
                 # DOES put beams in different cells and little is shared.  Off the corners (start and step not multiples of the cell
                 # size) most particles see the same cells change: what the state sharing buys where it works
-                "configs2_off_the_cell_corners": None if getattr(args, "no_large", False) else reference_field_mode(device, N, k, 10.0, ROOM_BENCH, 8, start=(0.013, 0.0137, 0.0211), inc=(0.07, 0.0213, 0.0117)),
-                "configs2_every_particle_distinct": None if getattr(args, "no_large", False) else reference_field_mode(device, N, k, 10.0, ROOM_BENCH, 3, spread=(0.02, 0.05, 0.05)),
+                "configs2_off_the_cell_corners": None if not big else reference_field_mode(device, N, k, 10.0, ROOM_BENCH, 8, start=(0.013, 0.0137, 0.0211), inc=(0.07, 0.0213, 0.0117)),
+                "configs2_every_particle_distinct": None if not big else reference_field_mode(device, N, k, 10.0, ROOM_BENCH, 3, spread=(0.02, 0.05, 0.05)),
                 "note": "every figure outside this object is for the default exact-distance (query) mode, whose likelihoods differ from the "
                         "reference's by up to 7.5e-3 at 400x400 (tests/test_rbpf_field_gpu.py); this mode meets the 1e-5 bar un-injected"}
     if True:
@@ -518,11 +525,11 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
                    "room": list(ROOM_BENCH),
                    "room_note": "walls at x = +-2.2, y = +-2.0 m instead of SURVEY 8-d's +-3.0 / +-2.5: chosen so that all 360 beams are inside "
                                 "[range_min, range_max) at every pose (47 % more lookups and ray cells per scan than the SURVEY room's 246 valid beams)"},
-        "host_normals": {"value": round(N / (t_host / n_host), 1), "ms_per_scan": round(t_host / n_host * 1e3, 4),
-                         "note": "parity mode: 1.2 MB/scan of reference-order normals copied H2D inside the call (PCIe-inclusive)"},
+        "host_normals": None if not n_host else {"value": round(N / (t_host / n_host), 1), "ms_per_scan": round(t_host / n_host * 1e3, 4),
+                                                 "note": "parity mode: 1.2 MB/scan of reference-order normals copied H2D inside the call (PCIe-inclusive)"},
         "ms_per_scan": round(ms_scan, 4), "scan_ms_by_stretch": scan_ms,
-        "single_calls_from_python": {"value": round(N / (t_single / n_single), 1), "ms_per_scan": round(t_single / n_single * 1e3, 4),
-                                     "note": "the same scans, one tbnav_rbpf_slam call each from this harness"},
+        "single_calls_from_python": None if not n_single else {"value": round(N / (t_single / n_single), 1), "ms_per_scan": round(t_single / n_single * 1e3, 4),
+                                                               "note": "the same scans, one tbnav_rbpf_slam call each from this harness"},
         "device_ms_per_scan": round(dev_ms, 4),
         "device_only_updates_per_s": round(N / (dev_ms * 1e-3), 1),
         "kernel_ms": {key: round(v, 4) for key, v in kms.items()},
@@ -532,7 +539,7 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
         "tile_pool": {"tiles": cap, "in_use": cap - free, "tile_bytes": tile_bytes,
                       "log_odds_bytes_in_use": (cap - free) * tile_bytes, "dense_equivalent_bytes": N * pf.G * 8},
         "dtype": "f64+u16",
-        "options": {"scan_matching": {"value": round(N / (t_sm / n_sm), 1), "ms_per_scan": round(t_sm / n_sm * 1e3, 4),
+        "options": None if not detail else {"scan_matching": {"value": round(N / (t_sm / n_sm), 1), "ms_per_scan": round(t_sm / n_sm * 1e3, 4),
                                       "note": "per-particle hill climbing on the likelihood field before sampling (not the reference)"},
                     "icp_failed_branch": {"value": round(N / t_fail, 1), "ms_per_scan": round(t_fail * 1e3, 4),
                                           "note": "every scan with icp_ok = 0: sampleMotionModel + one likelihoodFieldModel per particle (particle_filter.cpp:157-176); whatever resampling the run triggers by itself is in the time"},
@@ -540,11 +547,11 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
                             "note": "num_samples_mode = 10 instead of the shipped 50 (SURVEY.md 8-d: BASELINE names no k)"}},
         # SURVEY 8-d's own room (+-3.0 / +-2.5 m, 246 valid beams): its boxes do not fit four workgroups per CU, the map update runs another
         # instantiation — a first-class leg with its own kernel name, bytes, profiler row and PMC row (round-4 review)
-        "survey_room": None if getattr(args, "no_large", False) else map_update_leg(
+        "survey_room": None if not big else map_update_leg(
             device, "SURVEY 8-d room", N, k, 10.0, ROOM_SURVEY, TRAJ_SURVEY, traffic_key="rbpf_N1000_k50_400x400_survey_room",
             stats_workload="rbpf_N1000_k50_400x400_survey_room", sq_key="rbpf_N1000_k50_400x400_survey_room"),
-        "noise_forms": noise_forms(device, N, k),
-        "long_replay_one_call_no_resampling": long_replay(device, N, k),
+        "noise_forms": noise_forms(device, N, k) if detail else None,
+        "long_replay_one_call_no_resampling": long_replay(device, N, k) if detail else None,
         "configs4_shard_one_gpu": shard4,
         "configs4_as_written_one_gpu": cfg4,
         "distance_field_mode": "query",
@@ -587,7 +594,7 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True):
     }
     pf.close()
     if with_cpu:
-        out["cpu_baseline"] = cpu_baseline(k, scans, steps, threads=1)
+        out["cpu_baseline"] = cpu_baseline(k, scans, steps, threads=1, n_scans=11 if detail else 7)
         out["cpu_baseline_all_cores"] = cpu_baseline(k, scans, steps, threads=effective_cores())
     return out
 

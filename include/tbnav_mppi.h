@@ -97,9 +97,9 @@ enum { TBNAV_MPPI_OPT_KERNEL = 1, TBNAV_MPPI_OPT_TRIG = 2, TBNAV_MPPI_OPT_NO_LDS
                                              all-gather (default 1: directly into the peers' buffers when every rank can; takes effect at the next attach; 2: as 1 with a fault injected for the tests of the
                                              bound — after the self-test this rank's records never reach its peers, and the bound is 0.3 s instead of 2 s) */,
        TBNAV_MPPI_OPT_SAMPLER = 9 /* the device noise source's width (replacement of utilities.cpp:20-24 / mppi.cpp:173-184; the Philox counters are the same either way):
-                                     0 (default): fp32 Box-Muller on 24-bit uniforms — normals on a 2^-24 grid out to 5.9 sigma;
-                                     1: fp64 Box-Muller on 52-bit uniforms — what std::normal_distribution<double> is in width, out to 8.57 sigma (in the fused
-                                        kernel for the default dynamics, sampled first for the others: same values) */,
+                                     1 (default since round 6): fp64 Box-Muller on 52-bit uniforms — what std::normal_distribution<double> is in width, out to
+                                        8.57 sigma (drawn inside the fused kernel wherever the fp32 one is);
+                                     0: fp32 Box-Muller on 24-bit uniforms — normals on a 2^-24 grid out to 5.9 sigma (about 2 % faster at K = 1024) */,
        TBNAV_MPPI_OPT_WIDE_COMBINE = 11 /* 1 (default): a single-GPU tick whose time steps have more than 256 soft-min records (the fused kernel at K = 4097 ... 8192) combines
                                             them with four waves per step (mppi_combine_wide); 0: always one wave per step (A-B measurements) */,
        TBNAV_MPPI_OPT_FAULT_INJECT = 10 /* tests: 1 = the local half of this handle's next sharded tick reports a failure (its rollouts are not launched) */ };

@@ -137,8 +137,10 @@ int launch_fused(tbnav_mppi* h, const double x0[3], const double* d_duL, const d
   if (R == 16) { if (TL == 1) TBNAV_FUSED(TR, 16, 1, RG); else TBNAV_FUSED(TR, 16, 2, RG); }                   \
   else { if (TL == 1) TBNAV_FUSED(TR, 8, 1, RG); else TBNAV_FUSED(TR, 8, 2, RG); }
   if (rng) {  // in-kernel noise: instantiated for 8 and 16 rollouts per workgroup (the handle's own choices) — the caller checks
-    // (RNG 2, the fp64 sampler, exists for the default dynamics only: rng_in_kernel says no otherwise and the caller samples first)
-    if (h->dyn == 1) { TBNAV_FUSED_RNG(4, 1); } else if (h->trig == 3) { TBNAV_FUSED_RNG(3, 1); } else if (h->sampler == 1) { TBNAV_FUSED_RNG(2, 2); } else { TBNAV_FUSED_RNG(2, 1); }
+    // (RNG 2 = the fp64 sampler, the handle's default; RNG 1 = the fp32 one, TBNAV_MPPI_OPT_SAMPLER = 0)
+    if (h->sampler == 1) {
+      if (h->dyn == 1) { TBNAV_FUSED_RNG(4, 2); } else if (h->trig == 3) { TBNAV_FUSED_RNG(3, 2); } else { TBNAV_FUSED_RNG(2, 2); }
+    } else if (h->dyn == 1) { TBNAV_FUSED_RNG(4, 1); } else if (h->trig == 3) { TBNAV_FUSED_RNG(3, 1); } else { TBNAV_FUSED_RNG(2, 1); }
   } else if (h->dyn == 1) { TBNAV_FUSED_R(4) } else if (h->trig == 3) { TBNAV_FUSED_R(3) } else { TBNAV_FUSED_R(2) }
 #undef TBNAV_FUSED_RNG
 #undef TBNAV_FUSED_R
@@ -218,10 +220,9 @@ bool pick_noise(tbnav_mppi* h, const double*& d_duL, const double*& d_duR) {
   return d_duL && d_duR;
 }
 
-// the perturbations can be drawn inside the fused kernel: its in-kernel form exists for 8 and 16 rollouts per workgroup, and with
-// the fp64 sampler for the default dynamics only
+// the perturbations can be drawn inside the fused kernel: its in-kernel form exists for 8 and 16 rollouts per workgroup (either sampler)
 bool rng_in_kernel(const tbnav_mppi* h) {
-  return h->fused_rng && (h->fused_r == 8 || h->fused_r == 16) && (h->sampler == 0 || (h->dyn == 0 && h->trig != 3));
+  return h->fused_rng && (h->fused_r == 8 || h->fused_r == 16);
 }
 
 }  // namespace
@@ -420,7 +421,7 @@ int tbnav_mppi_set_option(tbnav_mppi* h, int32_t option, int32_t value) {
     case TBNAV_MPPI_OPT_WIDE_COMBINE:   // 0: always the one-wave-per-step combine (A-B); default 1
       h->wide_combine = value != 0;
       return TBNAV_OK;
-    case TBNAV_MPPI_OPT_SAMPLER:        // 0: fp32 Box-Muller on 24-bit uniforms (default); 1: fp64 on 52-bit uniforms (utilities.cpp:20-24's width)
+    case TBNAV_MPPI_OPT_SAMPLER:        // 1 (default): fp64 Box-Muller on 52-bit uniforms (utilities.cpp:20-24's width); 0: fp32 on 24-bit uniforms
       if (value != 0 && value != 1) return TBNAV_ERR_INVALID_ARG;
       h->sampler = value;
       return TBNAV_OK;

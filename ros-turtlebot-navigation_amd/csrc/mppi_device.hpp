@@ -297,12 +297,12 @@ struct RngArgs {  // base = tick * T * K_global + k0 * T
   // first tick is read from device memory, times the counters one tick uses
   const uint64_t* tick0 = nullptr; uint64_t per_tick = 0;
 };
-// WIDE = false (the default sampler, TBNAV_MPPI_OPT_SAMPLER = 0): Box-Muller on the fp32 transcendental units (v_log_f32,
+// WIDE = false (the narrow sampler, TBNAV_MPPI_OPT_SAMPLER = 0; the default up to round 5): Box-Muller on the fp32 transcendental units (v_log_f32,
 // v_sin_f32 / v_cos_f32 take their argument in turns): a handful of instructions instead of ~130 fp64 ones for log +
 // sincospi + sqrt.  The perturbations are random numbers, not parity quantities: 24-bit uniforms give normals on a 2^-24 grid
 // out to 5.9 sigma, which is all a sampling controller can use (the reference's own sampler is not reproducible run to run
 // either, utilities.cpp:14).
-// WIDE = true (TBNAV_MPPI_OPT_SAMPLER = 1): what the reference's std::normal_distribution<double> is in width
+// WIDE = true (TBNAV_MPPI_OPT_SAMPLER = 1, the default): what the reference's std::normal_distribution<double> is in width
 // (utilities.cpp:20-24): the same Philox counter, all 128 bits of it — two uniforms of 52 random bits + the half-ulp centring
 // ((n + 0.5) * 2^-52 is exact in a double: 53 significant bits, never 0 or 1), fp64 log / sqrt / sincospi: normals out to
 // sqrt(2 * 53 * ln 2) = 8.57 sigma on a grid finer than 2^-52.

@@ -82,7 +82,7 @@ struct tbnav_mppi {
   int* d_dx_dead = nullptr;                          // its device twin: later ticks see it without a trip over PCIe
   bool fail_next = false;                            // fault injection (TBNAV_MPPI_OPT_FAULT_INJECT, tests): the next sharded tick's local half fails
   bool wide_combine = true;                          // TBNAV_MPPI_OPT_WIDE_COMBINE: four waves per time step when a step has more than 256 records
-  int sampler = 0;                                   // TBNAV_MPPI_OPT_SAMPLER: 0 = fp32 Box-Muller on 24-bit uniforms, 1 = fp64 on 52-bit uniforms
+  int sampler = 1;                                   // TBNAV_MPPI_OPT_SAMPLER: 1 (default) = fp64 Box-Muller on 52-bit uniforms, 0 = fp32 on 24-bit uniforms
   unsigned long long dx_budget = 200000000ull;       // 2 s of the 100 MHz clock (host-side skew between ranks is legitimate — a control loop's is milliseconds; longer: the peer has failed)
   bool dx_withhold = false;                          // fault injection (TBNAV_MPPI_OPT_DIRECT_EXCHANGE = 2, tests): this rank's records never reach its peers
   unsigned int dx_seq = 0;

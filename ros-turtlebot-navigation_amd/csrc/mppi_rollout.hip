@@ -614,8 +614,8 @@ TBNAV_INST_SCAN(3)
 TBNAV_INST_FUSED_TR(2)
 TBNAV_INST_FUSED_TR(3)
 TBNAV_INST_FUSED_TR(4)
-// (the fp64 sampler rides in the default dynamics' kernel only; any other setting samples first, same values)
-TBNAV_INST_FUSED(2, 8, 2) TBNAV_INST_FUSED(2, 16, 2)
+// the fp64 sampler (round 6: the handle's default, TBNAV_MPPI_OPT_SAMPLER = 1) in every dynamics' kernel
+TBNAV_INST_FUSED(2, 8, 2) TBNAV_INST_FUSED(2, 16, 2) TBNAV_INST_FUSED(3, 8, 2) TBNAV_INST_FUSED(3, 16, 2) TBNAV_INST_FUSED(4, 8, 2) TBNAV_INST_FUSED(4, 16, 2)
 #undef TBNAV_INST_FUSED_TR
 #undef TBNAV_INST_FUSED
 #undef TBNAV_ARGS_FUSED

@@ -19,7 +19,12 @@ wd = bench.LegWatchdog({rank}, line if {rank} == 0 else None, 0.3)
 
 def run(rank, body):
     code = SCRIPT.format(root=ROOT, rank=rank, body=body)
-    return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    env = dict(os.environ, TBNAV_BENCH_DETAIL=os.path.join(os.environ.get("TMPDIR", "/tmp"), f"tbnav_bench_detail_{os.getpid()}.json"))
+    try:
+        return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+    finally:
+        if os.path.exists(env["TBNAV_BENCH_DETAIL"]):
+            os.remove(env["TBNAV_BENCH_DETAIL"])
 
 
 def test_a_leg_that_hangs_leaves_the_headline_line():

@@ -128,17 +128,24 @@ def test_arc_and_rk4_dynamics_agree_to_truncation_order(gpu_pkg):
     assert 0 < rel.max() < 1e-6
 
 
+@pytest.mark.parametrize("sampler", [None, 0])
 @pytest.mark.parametrize("K,horizon", [(1024, 0.5), (8192, 1.0), (100, 1.0), (37, 1.28), (200, 2.0)])
-def test_in_kernel_noise_equals_sampled_noise(gpu_pkg, K, horizon):
+def test_in_kernel_noise_equals_sampled_noise(gpu_pkg, K, horizon, sampler):
     """Production tick (tbnav_mppi_new_controls_rng): the fused small-K kernel generates the perturbations of
     (seed, tick) itself instead of loading them.  They must be the values tbnav_mppi_sample_noise writes, so the tick
     equals "sample, then tick on the sampled arrays" bit for bit — and those arrays are what the oracle is fed.
-    T = 200 has no fused kernel: the entry point then samples first, same contract."""
+    T = 200 has no fused kernel: the entry point then samples first, same contract.
+    sampler None: the handle's default — since round 6 the fp64 sampler (the reference's std::normal_distribution<double> width,
+    utilities.cpp:20-24), which is what bench.py's headline tick runs; 0: the fp32 sampler, now the option."""
+    from rtn_amd import capi
     d = mppi_cfg(K, horizon)
     m_rng, m_ref = make_mppi(gpu_pkg, d), make_mppi(gpu_pkg, d)
     T = m_rng.steps
+    rg = 2 if sampler is None else 1
     for m in (m_rng, m_ref):
         m.setWaypoint(*WAYPOINTS[1])
+        if sampler is not None:
+            m.setOption(capi.MPPI_OPT_SAMPLER, sampler)
     x0 = (0.1, -0.2, 0.3)
     u = np.zeros((2, T))
     for tick in range(3):
@@ -153,16 +160,16 @@ def test_in_kernel_noise_equals_sampled_noise(gpu_pkg, K, horizon):
         u = ref["u"]
         x0 = (x0[0] + 0.002, x0[1], x0[2] + 0.001)
     if (K, horizon) == (1024, 0.5):   # BASELINE configs[1]: the kernels of bench.py's headline line, by name
-        assert m_rng.lastKernelNames()[:2] == ("mppi_rollout_fused<2, 8, 1, 1>", "mppi_combine<2, 0>"), m_rng.lastKernelNames()
+        assert m_rng.lastKernelNames()[:2] == (f"mppi_rollout_fused<2, 8, 1, {rg}>", "mppi_combine<2, 0>"), m_rng.lastKernelNames()
     if (K, horizon) == (8192, 1.0):   # one GPU's share of configs[3] on 8: bench.py's configs3_shard_one_gpu leg
-        assert m_rng.lastKernelNames()[:2] == ("mppi_rollout_fused<2, 16, 2, 1>", "mppi_combine_wide"), m_rng.lastKernelNames()
+        assert m_rng.lastKernelNames()[:2] == (f"mppi_rollout_fused<2, 16, 2, {rg}>", "mppi_combine_wide"), m_rng.lastKernelNames()
 
 
 @pytest.mark.parametrize("K,horizon,dyn", [(1024, 0.5, "rk4"), (4096, 1.0, "rk4"), (100, 1.28, "rk4"), (1024, 0.5, "arc"), (200, 2.0, "rk4")])
 def test_fp64_sampler_in_kernel_equals_sampled_noise(gpu_pkg, K, horizon, dyn):
     """TBNAV_MPPI_OPT_SAMPLER = 1 (fp64 Box-Muller on 52-bit uniforms, the width of the reference's std::normal_distribution<double>,
     utilities.cpp:20-24): same contract as the default sampler — drawn inside the fused kernel (default dynamics) or sampled first
-    (arc dynamics, T = 200: no in-kernel form), the tick equals "sample, then tick on the sampled arrays" bit for bit, and the oracle
+    (T = 200: no in-kernel form), the tick equals "sample, then tick on the sampled arrays" bit for bit, and the oracle
     fed those arrays agrees."""
     from rtn_amd import capi
     d = mppi_cfg(K, horizon)
@@ -174,8 +181,8 @@ def test_fp64_sampler_in_kernel_equals_sampled_noise(gpu_pkg, K, horizon, dyn):
     u = np.zeros((2, T))
     for tick in range(3):
         got = m_rng.newControlsRng(x0, 77, tick)
-        if dyn == "rk4" and T <= 128:
-            assert m_rng.lastKernelNames()[0].endswith(", 2>"), m_rng.lastKernelNames()   # mppi_rollout_fused<2, R, TL, 2>
+        if T <= 128:
+            assert m_rng.lastKernelNames()[0].endswith(", 2>"), m_rng.lastKernelNames()   # mppi_rollout_fused<TRIG, R, TL, 2> (round 6: every dynamics)
         m_ref.sampleNoise(77, tick)
         want = m_ref.newControlsDev(x0, 0, 0)
         assert got == want and np.array_equal(m_rng.getControls(), m_ref.getControls())

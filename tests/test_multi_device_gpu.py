@@ -254,7 +254,7 @@ def test_bench_two_gpus_as_the_driver_launches_it(gpu_pkg, devices):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
     assert "tbnav_mppi_attach_comm" in line["exchange"], line["exchange"]
-    assert line["exchange"].startswith("DIRECT") or "ncclAllGather" in line["exchange"] or "all-gather" in line["exchange"]
+    assert line["exchange"].startswith("direct") or "ncclAllGather" in line["exchange"] or "all-gather" in line["exchange"]
     assert "multi_gpu_legs" not in line, line.get("multi_gpu_legs")
     assert line["weak_tick_via_comm_all_gather"]["exchange_kind"] == 1 and line["weak_tick_via_comm_all_gather"]["rollouts_per_s"] > 0
     assert line["strong_scaling_configs3"]["rollouts_per_s"] > 0
