@@ -326,10 +326,17 @@ int tbnav_rbpf_particle_map(tbnav_rbpf* h, int32_t particle, int8_t* map);
  * TBNAV_RBPF_OPT_BATCH_PIPELINE  1 = tbnav_rbpf_slam_batch keeps two scans in the stream (default); 0 = n synchronous calls.
  * TBNAV_RBPF_OPT_HOST_THREADS    host threads the REFERENCE distance-field mode spreads its per-particle brushfires over (particles are
  *                                independent; the order of operations inside one particle is the reference's).  0 = the default: the
- *                                cores in the process's affinity mask, at most 32. */
+ *                                cores in the process's affinity mask, capped by the cgroup's CPU quota, at most 128.
+ * TBNAV_RBPF_OPT_REF_REACH       REFERENCE mode: how many cells out from the occupied cells a scan's brushfire runs before it stops
+ *                                (default 6; 0 = to the end, the round-3..5 behaviour).  The pass writes every cell once, in a
+ *                                deterministic order, so a stopped pass equals the finished one on every cell it has written and can be
+ *                                resumed; the proposal kernel reports a lookup that lands on an unwritten cell, exactly that state's pass
+ *                                is resumed and the proposal run again (tbnav_rbpf_reference_field_stats counts both).  Results are
+ *                                bit-identical for every value; whole-field exports finish the pass (and replay the lineage where a
+ *                                stale cell's value depends on the unfinished part of an earlier pass). */
 enum { TBNAV_RBPF_OPT_DF_MODE = 1, TBNAV_RBPF_OPT_RAYCAST_ORDERED = 2, TBNAV_RBPF_OPT_RAYCAST_THREADS = 3, TBNAV_RBPF_OPT_COUNT_CELLS = 4,
        TBNAV_RBPF_OPT_RAYCAST_FORM = 5, TBNAV_RBPF_OPT_RAYCAST_BAND_ROWS = 6, TBNAV_RBPF_OPT_BATCH_PIPELINE = 7, TBNAV_RBPF_OPT_HOST_THREADS = 8, TBNAV_RBPF_OPT_RAYCAST_ADAPT = 9, TBNAV_RBPF_OPT_RAYCAST_CELL16 = 10,
-       TBNAV_RBPF_OPT_NOISE_IN_KERNEL = 11 };
+       TBNAV_RBPF_OPT_NOISE_IN_KERNEL = 11, TBNAV_RBPF_OPT_REF_REACH = 12 };
 enum { TBNAV_RBPF_DF_FULL = 0, TBNAV_RBPF_DF_WINDOW = 1, TBNAV_RBPF_DF_QUERY = 2, TBNAV_RBPF_DF_REFERENCE = 3 };
 int tbnav_rbpf_set_option(tbnav_rbpf* h, int32_t option, int32_t value);
 /* Since the last reset, summed over particles and scans (TBNAV_RBPF_OPT_COUNT_CELLS on): cell_updates = log-odds
@@ -341,6 +348,18 @@ int tbnav_rbpf_scan_counts(tbnav_rbpf* h, uint64_t* cell_updates, uint64_t* dist
  * of the scan, not one per particle: particles that are copies of one another and saw the same cells change share the result
  * (csrc/ref_field.hpp).  Any pointer may be NULL. */
 int tbnav_rbpf_reference_field_counts(tbnav_rbpf* h, int32_t* distinct_states, int32_t* last_brushfires, int64_t* total_brushfires);
+/* Reference-field mode only, since the mode was chosen — the lazy brushfire's bookkeeping (csrc/ref_field.hpp; round 6):
+ *   out[0] passes started (one per distinct (state, insert / erase sequence) of a scan)
+ *   out[1] iterations of grid_mapper.cpp:399-433 run, all passes (a whole 400 x 400 pass is about 157 000)
+ *   out[2] states whose pass was RESUMED because a likelihood lookup landed on a cell it had not written yet
+ *   out[3] passes that ran to their end          out[4] lineages REPLAYED from their last exact ancestor (stale cells wanted)
+ *   out[5] generations re-run by those replays   out[6] bytes of history (event lists) alive
+ *   out[7] proposals run a second time (tbnav_rbpf_slam: the scans in which out[2] grew)
+ *   out[8..13] host microseconds spent, summed over the scans: fetching the scans' insert / erase logs | the grouped brushfires
+ *              (RefField::step) | a resampling's copies | bringing the device's field slots up to date | before the proposal
+ *              (kept particle state, flags) | looking for pending lookups after it;  out[14], out[15]: of out[9], the part spent grouping the
+ *              particles by (state, event sequence) | releasing the scan's old states */
+int tbnav_rbpf_reference_field_stats(tbnav_rbpf* h, int64_t out[16]);
 
 /* ---- measurement hook --------------------------------------------------------------------------
  * Durations (ms, HIP events on the handle's stream) of the kernels of the LAST slam call:

@@ -32,6 +32,7 @@ RBPF_OPT_RAYCAST_CELL16 = 10
 RBPF_OPT_NOISE_IN_KERNEL = 11
 RBPF_OPT_BATCH_PIPELINE = 7
 RBPF_OPT_HOST_THREADS = 8
+RBPF_OPT_REF_REACH = 12
 RBPF_DF = {"full": 0, "window": 1, "query": 2, "reference": 3}
 
 
@@ -201,6 +202,7 @@ def lib() -> C.CDLL:
         "tbnav_rbpf_particle_map": (C.c_int, [vp, i32, vp]),
         "tbnav_rbpf_scan_counts": (C.c_int, [vp, C.POINTER(u64), C.POINTER(u64), i32]),
         "tbnav_rbpf_reference_field_counts": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_int64)]),
+        "tbnav_rbpf_reference_field_stats": (C.c_int, [vp, C.POINTER(C.c_int64)]),
         "tbnav_rbpf_destroy": (None, [vp]),
         "tbnav_rbpf_grid_size": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32)]),
         "tbnav_rbpf_num_normals": (C.c_int64, [vp, i32]),

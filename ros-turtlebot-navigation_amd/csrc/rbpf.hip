@@ -30,6 +30,7 @@
 
 #include "comm.hpp"
 #include "common.hpp"
+#include <chrono>
 #include "ref_field.hpp"
 #include "tbnav_rbpf.h"
 #include "rbpf_device.hpp"
@@ -134,8 +135,16 @@ struct tbnav_rbpf {
   // device log of occupied-set changes it is fed from
   bool ref_field = false;
   tbnav::RefField* ref = nullptr;
-  std::vector<tbnav::RefField::StatePtr> ref_on_dev;  // [N] the reference-field state whose field slot p of d_code holds (empty: unknown); holding the
-                                                      //     pointer keeps the state alive, so an address is never re-used while it is compared
+  // (which state — and how much of its journal — every field slot of d_code holds is the RefField's own bookkeeping: plan_flush)
+  tbnav::RefField::Flush ref_flush;       // the last flush's plan (buffers kept between scans)
+  int* d_pend = nullptr;                  // [N] cell + 1 of a lookup that landed on a cell the particle's pass has not written yet (kCodePending), else 0
+  int* h_pend = nullptr;                  // [N] pinned copy
+  double* d_state_snap = nullptr;         // [7 N] pose / prev_pose / weight before the proposal: a proposal that met pending cells is run again from here
+  uint2* d_jentries = nullptr; size_t jentries_cap = 0;   // the flush's packed (cell, code) pairs
+  uint3* d_jjobs = nullptr;               // [N] (offset, count, reset) per slot
+  int ref_reach = 6;                      // TBNAV_RBPF_OPT_REF_REACH: how far (cells) a scan's brushfire runs before it stops (0: to the end)
+  long long ref_reruns = 0;               // proposals run again because a lookup met a pending cell
+  long long ref_us[6] = {0, 0, 0, 0, 0, 0}; // host microseconds spent: fetching the logs | RefField::step | resample copies | flushes | before the proposal | the settle look
   int* d_log_pack = nullptr; unsigned long long* d_log_off = nullptr; size_t log_pack_cap = 0, log_off_cap = 0;  // the scan's logs, packed
   int* d_code_src = nullptr;              // [N] slot to copy the field from (rbpf_copy_codes)
   int host_threads = 1;        // host threads of the reference-field mode's per-particle work (TBNAV_RBPF_OPT_HOST_THREADS; set at create)
@@ -389,7 +398,7 @@ int resample_on_device(tbnav_rbpf* h) {
   const size_t work = h->d_code[0] ? h->G / 4 : (size_t)0;
   const int chunks = (int)std::min<size_t>(std::max<size_t>(work / 2048, 1), 64);
   const GatherArgs ga{h->G, h->TW, h->d_state[h->cur], h->d_state[nxt], h->d_trow[h->cur], h->d_trow[nxt], h->d_nocc[h->cur], h->d_nocc[nxt],
-                      h->d_fstate, h->d_fstate_alt, h->d_code[h->cur], h->d_code[nxt], h->df_mode != 2 ? 1 : 0};
+                      h->d_fstate, h->d_fstate_alt, h->d_code[h->cur], h->d_code[nxt], (h->df_mode != 2 || h->ref_field) ? 1 : 0};
   hipLaunchKernelGGL(rbpf_resample_apply, dim3(blocks + N * chunks), dim3(kResampleThreads), 0, st, N, h->TT, h->d_parent, h->d_parent + N,
                      h->d_table[h->cur], h->d_table[nxt], h->d_shed, h->pool, blocks, chunks, ga);
   TBNAV_HIP(hipGetLastError());
@@ -427,7 +436,7 @@ __global__ __launch_bounds__(256) void rbpf_pack_logs(const int* __restrict__ ev
   const int* src = ev + (size_t)(p_first + i) * log_cap;
   for (unsigned long long q = threadIdx.x; q < n; q += blockDim.x) out[o + q] = src[q];
 }
-// slot p takes the field slot src[p] holds (src[p] == p: keep) — the particles that share a state with one already on the device
+// slot p takes the field slot src[p] holds (src[p] == p: keep) — the particles that share a state with one whose whole image was uploaded
 __global__ __launch_bounds__(256) void rbpf_copy_codes(uint16_t* __restrict__ code, size_t G, const int* __restrict__ src) {
   const int p = blockIdx.y, q = src[p];
   if (q == p) return;
@@ -440,12 +449,153 @@ __global__ __launch_bounds__(256) void rbpf_copy_codes(uint16_t* __restrict__ co
     for (size_t i = i0; i < G; i += step) code[(size_t)p * G + i] = code[(size_t)q * G + i];
   }
 }
+// The journal of field slot p (ref_field.hpp, plan_flush): optionally "everything pending" first, then `count` (cell, code) pairs —
+// every cell at most once per launch.  One workgroup per slot.
+__global__ __launch_bounds__(256) void rbpf_field_journal(uint16_t* __restrict__ code, size_t G, const uint3* __restrict__ jobs, const uint2* __restrict__ entries) {
+  const int p = blockIdx.x;
+  const uint3 j = jobs[p];
+  if (!j.y && !j.z) return;
+  uint16_t* const slot = code + (size_t)p * G;
+  if (j.z) {
+    const unsigned int fill = (unsigned int)kCodePending * 0x10001u;
+    if ((G & 7) == 0) {
+      uint4* d = reinterpret_cast<uint4*>(slot);
+      for (size_t i = threadIdx.x; i < G / 8; i += blockDim.x) d[i] = make_uint4(fill, fill, fill, fill);
+    } else {
+      for (size_t i = threadIdx.x; i < G; i += blockDim.x) slot[i] = kCodePending;
+    }
+    __threadfence();
+    __syncthreads();
+  }
+  for (unsigned int e = threadIdx.x; e < j.y; e += blockDim.x) {
+    const uint2 v = entries[j.x + e];
+    slot[v.x] = (uint16_t)v.y;
+  }
+}
+// Bring the device's field slots to where the host's states are: whole images for slots whose content is unknown (or whose state
+// has become exact and complete), journal ranges for the others.  Synchronises the stream (the plan's host buffers are read).
+struct UsTimer {   // adds the enclosing scope's wall time to a counter
+  long long& acc; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  explicit UsTimer(long long& a) : acc(a) {}
+  ~UsTimer() { acc += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(); }
+};
+int ref_field_flush(tbnav_rbpf* h) {
+  UsTimer ut(h->ref_us[3]);
+  const int N = h->N;
+  hipStream_t st = h->stream;
+  tbnav::RefField::Flush& f = h->ref_flush;
+  h->ref->plan_flush(f);
+  if (f.dense_slot.empty() && !f.any_job) return TBNAV_OK;
+  bool any_copy = false;
+  std::vector<int> src;
+  for (size_t q = 0; q < f.dense_slot.size(); ++q) {
+    if (f.dense_img[q] >= 0)
+      TBNAV_HIP(hipMemcpyAsync(h->d_code[h->cur] + (size_t)f.dense_slot[q] * h->G, f.images[f.dense_img[q]].data(), sizeof(uint16_t) * h->G, hipMemcpyHostToDevice, st));
+    else {
+      if (src.empty()) { src.resize(N); for (int p = 0; p < N; ++p) src[p] = p; }
+      src[f.dense_slot[q]] = f.dense_src[q];
+      any_copy = true;
+    }
+  }
+  if (any_copy) {
+    if (!h->d_code_src) TBNAV_HIP(hipMalloc((void**)&h->d_code_src, sizeof(int) * N));
+    TBNAV_HIP(hipMemcpyAsync(h->d_code_src, src.data(), sizeof(int) * N, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(rbpf_copy_codes, dim3(64, N), dim3(256), 0, st, h->d_code[h->cur], h->G, h->d_code_src);
+    TBNAV_HIP(hipGetLastError());
+  }
+  if (f.any_job) {
+    static_assert(sizeof(tbnav::RefField::JEntry) == sizeof(uint2) && sizeof(tbnav::RefField::Flush::Job) == sizeof(uint3), "the plan's records are what the kernel reads");
+    if (f.entries.size() > h->jentries_cap) {
+      TBNAV_HIP(hipStreamSynchronize(st));
+      (void)hipFree(h->d_jentries); h->d_jentries = nullptr; h->jentries_cap = 0;
+      const size_t cap = f.entries.size() + f.entries.size() / 2 + 4096;
+      TBNAV_HIP(hipMalloc((void**)&h->d_jentries, sizeof(uint2) * cap));
+      h->jentries_cap = cap;
+    }
+    if (!h->d_jjobs) TBNAV_HIP(hipMalloc((void**)&h->d_jjobs, sizeof(uint3) * N));
+    if (!f.entries.empty()) TBNAV_HIP(hipMemcpyAsync(h->d_jentries, f.entries.data(), sizeof(uint2) * f.entries.size(), hipMemcpyHostToDevice, st));
+    TBNAV_HIP(hipMemcpyAsync(h->d_jjobs, f.jobs.data(), sizeof(uint3) * N, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(rbpf_field_journal, dim3(N), dim3(256), 0, st, h->d_code[h->cur], h->G, h->d_jjobs, h->d_jentries);
+    TBNAV_HIP(hipGetLastError());
+  }
+  TBNAV_HIP(hipStreamSynchronize(st));
+  return TBNAV_OK;
+}
+// The whole field of one particle as the reference holds it, on the device (exports, the one-particle entry points): the pass is run
+// to the end, stale cells are recovered by replaying the lineage where they are not known (ref_field.hpp).
+int ref_field_materialize(tbnav_rbpf* h, int particle) {
+  if (!h->ref->codes(particle)) {
+    tbnav::last_hip_error_slot() = "reference-field mode: a whole field was asked for whose stale cells need history beyond the history budget";
+    return TBNAV_ERR_UNSUPPORTED;
+  }
+  const int rc = ref_field_flush(h);
+  if (rc != TBNAV_OK) return rc;
+  const int two = 2;
+  TBNAV_HIP(hipMemcpy(h->d_fstate + particle, &two, sizeof two, hipMemcpyHostToDevice));
+  h->fstate_dirty = true;
+  return TBNAV_OK;
+}
+// Before the proposal of a scan: the slots in step with the states (imports and exports since the last scan), the particle state
+// kept for a second run, the pending flags cleared.
+int ref_field_before_propose(tbnav_rbpf* h) {
+  UsTimer ut(h->ref_us[4]);
+  const int N = h->N;
+  { const int rc = ensure_codes(h); if (rc != TBNAV_OK) return rc; }
+  if (!h->d_pend) {
+    TBNAV_HIP(hipMalloc((void**)&h->d_pend, sizeof(int) * N));
+    TBNAV_HIP(hipHostMalloc((void**)&h->h_pend, sizeof(int) * N, hipHostMallocDefault));
+    TBNAV_HIP(hipMalloc((void**)&h->d_state_snap, sizeof(double) * 7 * N));
+  }
+  if (h->sm_on) {   // the per-particle scan matcher reads whole fields: every pass to the end (the option is not the reference's filter)
+    for (int p = 0; p < N; ++p) if (!h->ref->codes(p)) return TBNAV_ERR_UNSUPPORTED;
+  }
+  { const int rc = ref_field_flush(h); if (rc != TBNAV_OK) return rc; }
+  TBNAV_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->d_fstate), 2, N, h->stream));
+  h->fstate_dirty = true;
+  TBNAV_HIP(hipMemcpyAsync(h->d_state_snap, h->d_state[h->cur], sizeof(double) * 7 * N, hipMemcpyDeviceToDevice, h->stream));
+  TBNAV_HIP(hipMemsetAsync(h->d_pend, 0, sizeof(int) * N, h->stream));
+  return TBNAV_OK;
+}
+// After the proposal: did a lookup land on a cell its particle's pass has not written?  Then exactly those states are resumed on the
+// host (RefField::ensure), the new cells go to the device, and the proposal runs again from the kept particle state — until none
+// does.  (A closed room never gets here: its beams end within a cell or two of the obstacles the last scans integrated.)
+template <class Relaunch>
+int ref_field_settle(tbnav_rbpf* h, int* h_err, Relaunch relaunch) {
+  const int N = h->N;
+  hipStream_t st = h->stream;
+  std::vector<int> ps, cs;
+  for (int round = 0; round < 4096; ++round) {
+    {
+      UsTimer ut(h->ref_us[5]);
+      TBNAV_HIP(hipMemcpyAsync(h->h_pend, h->d_pend, sizeof(int) * N, hipMemcpyDeviceToHost, st));
+      TBNAV_HIP(hipStreamSynchronize(st));
+    }
+    ps.clear(); cs.clear();
+    for (int p = 0; p < N; ++p) if (h->h_pend[p]) { ps.push_back(p); cs.push_back(h->h_pend[p] - 1); }
+    if (ps.empty()) return TBNAV_OK;
+    const int rc = h->ref->ensure(ps.data(), cs.data(), (int)ps.size(), h->host_threads);
+    if (rc == -1) {
+      tbnav::last_hip_error_slot() = "reference-field mode: a lookup needs a stale cell whose history is beyond the history budget";
+      return TBNAV_ERR_UNSUPPORTED;
+    }
+    if (rc != 0) { tbnav::last_hip_error_slot() = "reference-field mode: a replayed pass differs from the pass it re-ran (internal error)"; return TBNAV_ERR_HIP; }
+    { const int rf = ref_field_flush(h); if (rf != TBNAV_OK) return rf; }
+    TBNAV_HIP(hipMemcpyAsync(h->d_state[h->cur], h->d_state_snap, sizeof(double) * 7 * N, hipMemcpyDeviceToDevice, st));
+    TBNAV_HIP(hipMemsetAsync(h->d_pend, 0, sizeof(int) * N, st));
+    for (int q = 0; q < 4; ++q) h_err[q] = 0;   // (mapped; the stream is idle)
+    ++h->ref_reruns;
+    const int rl = relaunch();
+    if (rl != TBNAV_OK) return rl;
+  }
+  return TBNAV_ERR_UNSUPPORTED;
+}
 int ref_field_after_scan(tbnav_rbpf* h, bool resampled, int p_first = 0, int p_count = -1) {
   const int N = h->N;
   if (p_count < 0) p_count = N;
   { const int rc = ensure_codes(h); if (rc != TBNAV_OK) return rc; }
   hipStream_t st = h->stream;
   TBNAV_HIP(hipStreamSynchronize(st));
+  auto t_log0 = std::chrono::steady_clock::now();
   std::vector<int> cnt(N);
   TBNAV_HIP(hipMemcpy(cnt.data(), h->d_log_cnt, sizeof(int) * N, hipMemcpyDeviceToHost));
   // the logs: packed on the device, ONE copy (a few thousand events per particle; one small copy each was 10-20 ms per 1000)
@@ -473,39 +623,19 @@ int ref_field_after_scan(tbnav_rbpf* h, bool resampled, int p_first = 0, int p_c
   }
   // one replay + brushfire per distinct (state, sequence) — ref_field.hpp — side by side on the host's cores: inside one state the
   // order of every set and heap operation is the reference's
-  h->ref->step(p_first, p_count, h->host_threads, all.data(), off.data());
+  h->ref_us[0] += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_log0).count();
+  h->ref->set_reach(h->ref_reach);
+  { UsTimer ut(h->ref_us[1]); h->ref->step(p_first, p_count, h->host_threads, all.data(), off.data()); }
   if (resampled) {
+    UsTimer ut(h->ref_us[2]);
     h->h_parent.resize(N);
     TBNAV_HIP(hipMemcpy(h->h_parent.data(), h->d_parent, sizeof(int) * N, hipMemcpyDeviceToHost));
-    h->ref->resample(h->h_parent.data());
+    h->ref->resample(h->h_parent.data());   // (the device's gather has moved the field slots the same way: resample_on_device)
   }
-  h->ref_on_dev.resize(N);
-  if (resampled) { p_first = 0; p_count = N; for (auto& q : h->ref_on_dev) q.reset(); }  // (the device's own gather moved the slots)
-  // to the device: a state no slot holds yet is uploaded once; the other particles that share it copy it on the device
-  std::unordered_map<const void*, int> holder;  // state -> a slot whose device field is that state's
-  for (int p = 0; p < N; ++p) if (h->ref_on_dev[p] && h->ref_on_dev[p].get() == h->ref->state(p)) holder.emplace(h->ref_on_dev[p].get(), p);
-  std::vector<int> src(N);
-  bool any_copy = false;
-  for (int p = 0; p < N; ++p) {
-    src[p] = p;
-    if (p < p_first || p >= p_first + p_count) continue;
-    const void* s = (const void*)h->ref->state(p);
-    if (h->ref_on_dev[p].get() == s) continue;
-    auto it = holder.find(s);
-    if (it == holder.end()) {
-      TBNAV_HIP(hipMemcpyAsync(h->d_code[h->cur] + (size_t)p * h->G, h->ref->codes(p), sizeof(uint16_t) * h->G, hipMemcpyHostToDevice, st));
-      holder.emplace(s, p);
-    } else { src[p] = it->second; any_copy = true; }
-    h->ref_on_dev[p] = h->ref->state_ptr(p);
-  }
-  if (any_copy) {
-    if (!h->d_code_src) TBNAV_HIP(hipMalloc((void**)&h->d_code_src, sizeof(int) * N));
-    TBNAV_HIP(hipMemcpyAsync(h->d_code_src, src.data(), sizeof(int) * N, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(rbpf_copy_codes, dim3(64, N), dim3(256), 0, st, h->d_code[h->cur], h->G, h->d_code_src);
-    TBNAV_HIP(hipGetLastError());
-  }
-  TBNAV_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->d_fstate + p_first), 2, p_count, st));
-  TBNAV_HIP(hipStreamSynchronize(st));  // (src and the states' host buffers are read by the copies)
+  // to the device: what each pass wrote, as a journal on top of the parent's image the slot holds
+  { const int rc = ref_field_flush(h); if (rc != TBNAV_OK) return rc; }
+  TBNAV_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->d_fstate), 2, N, st));
+  TBNAV_HIP(hipStreamSynchronize(st));
   h->fstate_dirty = true;
   return TBNAV_OK;
 }
@@ -680,7 +810,8 @@ int scan_enqueue(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3
   // device noise: drawn inside the proposal kernel, whose leading workgroup also carries the beam table over (NoiseSrc) — unless a
   // kernel in front of it needs the table on the device (the per-particle scan matcher), the scan comes prepared with its chunk
   // (tbnav_rbpf_slam_batch), or the option is off: then rbpf_sample_normals stores the same values first, as up to round 4
-  bool dn = !pre && !normals && !(h->sm_on && c.icp_ok) && h->noise_in_kernel == 1;
+  // (... or the reference-field mode may have to run the proposal twice: the stored stream is there for the second run)
+  bool dn = !pre && !normals && !(h->sm_on && c.icp_ok) && h->noise_in_kernel == 1 && !h->ref_field;
   NoiseSrc ns{};
   if (dn) {
     // (the hand-over needs fine-grained device memory: where the platform does not give any, the option switches itself off for good —
@@ -754,6 +885,7 @@ int scan_enqueue(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3
   StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
 
   // ---- distance-field refresh for this call's lookups (windowed), then the particle update
+  if (h->ref_field) { rc = ref_field_before_propose(h); if (rc != TBNAV_OK) { out->status = rc; return rc; } }
   if (h->timing) TBNAV_HIP(hipEventRecord(h->ev[0], st));
   {
     // every lookup of this call lies within `half` metres of the particle's CURRENT position: the sampled poses
@@ -812,13 +944,23 @@ int scan_enqueue(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3
   // threads against 43 with 512; the configs[4] shard 0.80 ms with 256 against 0.61 with 512
   h->lk_propose = (propose_lds + 3072 > (size_t)kMaxLds / 4) ? 2 * kProposeThreads : kProposeThreads;
   h->lk_propose_dn = dn ? 1 : 0;
+  int* const pend = h->ref_field ? h->d_pend : nullptr;
 #define TBNAV_PROPOSE(NT_, DN_) hipLaunchKernelGGL((rbpf_propose<NT_, DN_>), dim3(h->N + (DN_ ? 1 : 0)), dim3(NT_), propose_lds, st, c, beams_dev,                    \
                      h->d_code[h->cur], h->pool, map_of(h), h->d_trow[h->cur], skip_arr, skip_eq, h->df_mode, h->radius, occ_half,                       \
-                     h->d_nocc[h->cur], h->d_win, normals_dev, center, sp.pose, sp.prev, sp.weight, h->tr, h->d_sens, d_err, gate_prev, h->d_mixlut, ns)
-  if (propose_lds + 3072 > (size_t)kMaxLds / 4) { if (dn) TBNAV_PROPOSE(2 * kProposeThreads, true); else TBNAV_PROPOSE(2 * kProposeThreads, false); }
-  else { if (dn) TBNAV_PROPOSE(kProposeThreads, true); else TBNAV_PROPOSE(kProposeThreads, false); }
+                     h->d_nocc[h->cur], h->d_win, normals_dev, center, sp.pose, sp.prev, sp.weight, h->tr, h->d_sens, d_err, gate_prev, h->d_mixlut, ns, pend)
+  auto launch_propose = [&]() -> int {
+    if (propose_lds + 3072 > (size_t)kMaxLds / 4) { if (dn) TBNAV_PROPOSE(2 * kProposeThreads, true); else TBNAV_PROPOSE(2 * kProposeThreads, false); }
+    else { if (dn) TBNAV_PROPOSE(kProposeThreads, true); else TBNAV_PROPOSE(kProposeThreads, false); }
+    TBNAV_HIP(hipGetLastError());
+    return TBNAV_OK;
+  };
 #undef TBNAV_PROPOSE
-  TBNAV_HIP(hipGetLastError());
+  rc = launch_propose();
+  if (rc != TBNAV_OK) return rc;
+  if (h->ref_field) {  // lookups that met cells the lazy brushfire has not written: resume those states, run the proposal again
+    rc = ref_field_settle(h, h_err, launch_propose);
+    if (rc != TBNAV_OK) { out->status = rc; return rc; }
+  }
   if (weights_ready) TBNAV_HIP(hipEventRecord(weights_ready, st));  // (sharded filter: the exchange starts here, beside the map update)
   if (h->timing) TBNAV_HIP(hipEventRecord(h->ev[2], st));
   // normalise / select needs only the weights the proposal kernel left: it rides in the map update's launch as one extra
@@ -1195,6 +1337,7 @@ void tbnav_rbpf_destroy(tbnav_rbpf* h) {
   (void)hipFree(h->pool.lo); (void)hipFree(h->pool.bm); (void)hipFree(h->pool.ref); (void)hipFree(h->pool.ring); (void)hipFree(h->pool.ctr);
   (void)hipFree(h->d_sens); (void)hipFree(h->d_shed); (void)hipFree(h->d_dense); (void)hipFree(h->d_cs); (void)hipFree(h->d_touched); (void)hipFree(h->d_box_need); if (h->h_box_need) (void)hipHostFree(h->h_box_need); (void)hipFree(h->d_fstate_alt);
   (void)hipFree(h->d_log_ev); (void)hipFree(h->d_log_cnt); (void)hipFree(h->d_tile_scratch); (void)hipFree(h->d_log_pack); (void)hipFree(h->d_log_off); (void)hipFree(h->d_code_src);
+  (void)hipFree(h->d_pend); (void)hipHostFree(h->h_pend); (void)hipFree(h->d_state_snap); (void)hipFree(h->d_jentries); (void)hipFree(h->d_jjobs);
   (void)hipFree(h->d_gw); (void)hipFree(h->d_gcs); (void)hipFree(h->d_gparent); (void)hipFree(h->d_gz);
   (void)hipFree(h->d_gw_raw); (void)hipFree(h->d_sendbuf); (void)hipFree(h->d_recvbuf); (void)hipFree(h->d_sizes); (void)hipFree(h->d_status);
   if (h->ev_w) (void)hipEventDestroy(h->ev_w);
@@ -2142,8 +2285,7 @@ int tbnav_rbpf_copy_particle(tbnav_rbpf* dst, int32_t dst_slot, tbnav_rbpf* src,
   if (rc == TBNAV_OK) rc = tbnav_rbpf_import_particle_dev(dst, dst_slot, buf, bytes);
   (void)hipFree(buf);
   if (rc == TBNAV_OK && src->ref_field) {  // the set with its history, the field with its stale cells
-    dst->ref->copy_slot(dst_slot, *src->ref, src_slot);
-    if ((size_t)dst_slot < dst->ref_on_dev.size()) dst->ref_on_dev[dst_slot].reset();
+    dst->ref->copy_slot(dst_slot, *src->ref, src_slot);   // (the slot's device content counts as unknown: the next flush uploads the state's image)
   }
   return rc;
 }
@@ -2205,7 +2347,7 @@ int tbnav_rbpf_set_log_odds(tbnav_rbpf* h, int32_t particle, const double* in) {
     std::vector<int> cells;
     for (size_t c = 0; c < h->G; ++c) if (in[c] >= h->cut_occ) cells.push_back((int)c);
     h->ref->reset(particle, cells);
-    if ((size_t)particle < h->ref_on_dev.size()) h->ref_on_dev[particle].reset();
+    h->ref->forget_slot(particle);
   }
   return TBNAV_OK;
 }
@@ -2213,7 +2355,8 @@ int tbnav_rbpf_set_log_odds(tbnav_rbpf* h, int32_t particle, const double* in) {
 int tbnav_rbpf_get_dist_code(tbnav_rbpf* h, int32_t particle, uint16_t* out) {
   if (!h || !out || particle < 0 || particle >= h->N) return TBNAV_ERR_INVALID_ARG;
   DeviceGuard guard(h->device);
-  { const int rc = ensure_full_field(h, particle); if (rc != TBNAV_OK) return rc; }  // whole field on demand
+  if (h->ref_field) { const int rc = ref_field_materialize(h, particle); if (rc != TBNAV_OK) return rc; }  // the pass to its end, stale cells by replay
+  else { const int rc = ensure_full_field(h, particle); if (rc != TBNAV_OK) return rc; }  // whole field on demand
   TBNAV_HIP(hipStreamSynchronize(h->stream));
   TBNAV_HIP(hipMemcpy(out, h->d_code[h->cur] + (size_t)particle * h->G, sizeof(uint16_t) * h->G, hipMemcpyDeviceToHost));
   return TBNAV_OK;
@@ -2244,7 +2387,7 @@ int tbnav_rbpf_set_occ_dist(tbnav_rbpf* h, int32_t particle, const double* in) {
   DeviceGuard guard(h->device);
   { const int rc = ensure_codes(h); if (rc != TBNAV_OK) return rc; }
   TBNAV_HIP(hipStreamSynchronize(h->stream));
-  if (h->ref_field) { h->ref->set_codes(particle, code.data()); if ((size_t)particle < h->ref_on_dev.size()) h->ref_on_dev[particle].reset(); }
+  if (h->ref_field) { h->ref->set_codes(particle, code.data()); h->ref->forget_slot(particle); }
   TBNAV_HIP(hipMemcpy(h->d_code[h->cur] + (size_t)particle * h->G, code.data(), sizeof(uint16_t) * h->G, hipMemcpyHostToDevice));
   const int two = 2;  // an injected field is authoritative: the next call does not refresh it
   TBNAV_HIP(hipMemcpy(h->d_fstate + particle, &two, sizeof two, hipMemcpyHostToDevice));
@@ -2369,6 +2512,7 @@ int tbnav_rbpf_likelihood(tbnav_rbpf* h, int32_t particle, const float* scan, in
   ScanC c;
   int rc = one_particle_consts(h, particle, scan, n_beams, c);
   if (rc != TBNAV_OK) return rc;
+  if (h->ref_field) { rc = ref_field_materialize(h, particle); if (rc != TBNAV_OK) return rc; }  // (a lookup anywhere: the whole field)
   for (int q = 0; q < 4; ++q) h->h_err[q] = 0;
   hipLaunchKernelGGL(rbpf_likelihood_one, dim3(1), dim3(kWave), 0, h->stream, c, h->d_beams, h->d_code[h->cur], h->pool, map_of(h),
                      h->d_trow[h->cur], h->d_fstate, h->radius, h->d_nocc[h->cur], pose[0], pose[1], pose[2], h->d_score, h->d_err, h->d_mixlut);
@@ -2402,9 +2546,13 @@ int tbnav_rbpf_set_option(tbnav_rbpf* h, int32_t option, int32_t value) {
         if (h->N > 4096) return TBNAV_ERR_UNSUPPORTED;  // serial host brushfire per particle: small ensembles only
         { const int rc = ensure_codes(h); if (rc != TBNAV_OK) return rc; }
         delete h->ref;
-        h->ref_on_dev.clear();
         h->ref = new (std::nothrow) tbnav::RefField(h->N, h->xsize, h->radius);
         if (!h->ref) return TBNAV_ERR_INVALID_ARG;
+        h->ref->set_reach(h->ref_reach);
+        // (no scan yet: the maps are empty, and the slots were allocated holding "unreached" everywhere — the initial state's image)
+        TBNAV_HIP(hipStreamSynchronize(h->stream));
+        TBNAV_HIP(hipMemset(h->d_code[h->cur], 0xFF, sizeof(uint16_t) * h->G * (size_t)h->N));
+        h->ref->slots_hold_initial_image();
         h->ref_field = true; h->df_mode = 2; h->full_edt = false;
         return TBNAV_OK;
       }
@@ -2418,6 +2566,11 @@ int tbnav_rbpf_set_option(tbnav_rbpf* h, int32_t option, int32_t value) {
       h->ref_field = false; h->df_mode = value; h->full_edt = value == TBNAV_RBPF_DF_FULL;
       return TBNAV_OK;
     }
+    case TBNAV_RBPF_OPT_REF_REACH:   // reference-field mode: cells a scan's brushfire runs out to before it stops (0: to the end, as up to round 5)
+      if (value < 0 || value > 65535) return TBNAV_ERR_INVALID_ARG;
+      h->ref_reach = value;
+      if (h->ref) h->ref->set_reach(value);
+      return TBNAV_OK;
     case TBNAV_RBPF_OPT_RAYCAST_ORDERED:
       if (value) h->tile_cap = 0;
       else {
@@ -2482,6 +2635,16 @@ int tbnav_rbpf_reference_field_counts(tbnav_rbpf* h, int32_t* distinct_states, i
   if (distinct_states) *distinct_states = h->ref->distinct_states();
   if (last_brushfires) *last_brushfires = h->ref->last_step_brushfires();
   if (total_brushfires) *total_brushfires = h->ref->total_brushfires();
+  return TBNAV_OK;
+}
+
+int tbnav_rbpf_reference_field_stats(tbnav_rbpf* h, int64_t out[16]) {
+  if (!h || !out || !h->ref_field || !h->ref) return TBNAV_ERR_INVALID_ARG;
+  const tbnav::RefField::Counters& k = h->ref->counters();
+  out[0] = k.passes; out[1] = k.pops; out[2] = k.resumes; out[3] = k.completions; out[4] = k.replays; out[5] = k.replay_generations;
+  out[6] = h->ref->history_bytes(); out[7] = h->ref_reruns;
+  for (int q = 0; q < 6; ++q) out[8 + q] = h->ref_us[q];
+  out[14] = k.us_group; out[15] = k.us_bury;
   return TBNAV_OK;
 }
 

@@ -36,6 +36,10 @@ constexpr int kProposeThreads = TBNAV_PROPOSE_THREADS;
 constexpr int kUnCap = 16;  // unstable beams handled by the per-pair path of the proposal kernel
 static_assert(kProposeThreads >= 128 && kProposeThreads % 64 == 0, "wave 0 samples, the other waves look the beams up");
 constexpr uint16_t kCodeUnreached = 0xFFFF;
+// reference-field mode only (ref_field.hpp): the particle's brushfire has not written this cell yet — a lookup that reads it is
+// reported to the host (DistSrc::pend), which resumes that brushfire and has the proposal run again.  The largest real code is
+// cell_radius^2 = 40 000.
+constexpr uint16_t kCodePending = 0xFFFE;
 constexpr int kMaxLds = 160 * 1024;
 
 // ---- small math shared by host and device ----------------------------------------------------------
@@ -445,9 +449,13 @@ __device__ __forceinline__ void gather_body(int N, const int* __restrict__ paren
   for (size_t t = t0; t < (size_t)TW; t += stride) rc_dst[(size_t)m * TW + t] = rc_src[(size_t)src * TW + t];
   const int fs = fs_src[src];
   if (cd_src && (copy_all_codes || fs == 2)) {
-    const uint2* ca = reinterpret_cast<const uint2*>(cd_src + (size_t)src * G);
-    uint2* cb = reinterpret_cast<uint2*>(cd_dst + (size_t)m * G);
-    for (size_t t = t0; t < G / 4; t += stride) cb[t] = ca[t];
+    if ((G & 3) == 0) {   // (every slot starts on an 8-byte boundary)
+      const uint2* ca = reinterpret_cast<const uint2*>(cd_src + (size_t)src * G);
+      uint2* cb = reinterpret_cast<uint2*>(cd_dst + (size_t)m * G);
+      for (size_t t = t0; t < G / 4; t += stride) cb[t] = ca[t];
+    } else {
+      for (size_t t = t0; t < G; t += stride) cd_dst[(size_t)m * G + t] = cd_src[(size_t)src * G + t];
+    }
   }
   if (t0 == 0) {
     nocc_dst[m] = nocc_src[src];
@@ -550,7 +558,7 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
                                                                 double* __restrict__ pose, double* __restrict__ prev_pose,
                                                                 double* __restrict__ weight, Trace tr, double* __restrict__ sens,
                                                                 int* __restrict__ err, const int* __restrict__ gate_prev,
-                                                                const double* __restrict__ mixlut, NoiseSrc ns);
+                                                                const double* __restrict__ mixlut, NoiseSrc ns, int* __restrict__ pend = nullptr);
 // rbpf_raycast.hip
 __global__ __launch_bounds__(kWave) void rbpf_raycast(ScanC c, TilePool P, MapT M, const double2* __restrict__ beams,
                                                      const double* __restrict__ pose, int* __restrict__ trow_occ,

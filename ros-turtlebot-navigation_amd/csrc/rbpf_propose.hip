@@ -50,7 +50,15 @@ struct DistSrc {
   // optional, with the LDS tile: lut7[m] = least (c - 3)^2 over the set bits c of the 7-bit pattern m (100: none) — lets a
   // lookup read the 7 x 7 cells round it as seven table look-ups instead of seven 64-column bit scans
   const unsigned char* lut7;
+  // reference-field mode: where a stored-field lookup that reads kCodePending leaves cell + 1 (NULL: nobody asks)
+  int* pend;
 };
+// a stored code as the lookups read it: a pending cell (the reference-field mode's lazy brushfire has not written it) is reported
+__device__ __forceinline__ uint16_t stored_code(const GridC& g, const DistSrc& d, int ci, int cj) {
+  const uint16_t v = d.code[(size_t)ci * g.xsize + cj];
+  if (v == kCodePending && d.pend) *d.pend = ci * g.xsize + cj + 1;
+  return v;
+}
 // Walk rows i, i+-1, i+-2, ... of an occupancy bitmap (stride `words` u64 per row, rows row_lo..row_hi present,
 // cell columns [0, words*64) relative to the bitmap) and return the least squared distance found (INT_MAX: none
 // within `radius`).  row_any(r) says whether row r can hold a set bit.
@@ -178,7 +186,7 @@ template <bool OUTLINE = true>
 __device__ __forceinline__ int lookup_code(const GridC& g, const DistSrc& d, int radius, int ci, int cj) {
   if (d.mode == 2) return nearest_code_query<OUTLINE>(g, d, radius, ci, cj);
   if (d.mode == 1 && (ci < d.win.x || ci > d.win.y || cj < d.win.z || cj > d.win.w)) return -1;
-  return d.code[(size_t)ci * g.xsize + cj];
+  return stored_code(g, d, ci, cj);
 }
 
 // Mixture term of one beam as a function of the distance code it lands on (grid_mapper.cpp:119-121).
@@ -373,7 +381,7 @@ __device__ __forceinline__ int lookup_code_fast(const GridC& g, const DistSrc& d
     return kNeedSearch;
   }
   if (d.mode == 1 && (ci < d.win.x || ci > d.win.y || cj < d.win.z || cj > d.win.w)) return -1;
-  return d.code[(size_t)ci * g.xsize + cj];
+  return stored_code(g, d, ci, cj);
 }
 
 
@@ -595,7 +603,7 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
                                                                 double* __restrict__ pose, double* __restrict__ prev_pose,
                                                                 double* __restrict__ weight, Trace tr, double* __restrict__ sens,
                                                                 int* __restrict__ err, const int* __restrict__ gate_prev,
-                                                                const double* __restrict__ mixlut, NoiseSrc ns) {
+                                                                const double* __restrict__ mixlut, NoiseSrc ns, int* __restrict__ pend) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   if (gate_prev && *gate_prev) return;  // the scan before this one resamples: see rbpf_raycast_box
   // DN: the noise is drawn here and workgroup 0 carries the beam table over (NoiseSrc).  A template argument, not a launch-time
@@ -657,7 +665,7 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
   //  addresses and use ds_read instead of flat loads in the lookups)
   unsigned long long* const tile_bm = reinterpret_cast<unsigned long long*>(ulist + c.Bv);
   DistSrc ds{code, occ_of(P, M, trow_occ, p), win[p], skip[p] == skip_eq ? 0 : df_mode,
-             tile_bm, reinterpret_cast<const int*>(tile_bm), 0, 0, 0, 0};
+             tile_bm, reinterpret_cast<const int*>(tile_bm), 0, 0, 0, 0, nullptr, pend ? pend + p : nullptr};
   int oob = 0;
   __shared__ int sh_def[2];  // [0] beams, [1] pairs whose lookup needs the full search (counts that only grow)
   if (tid == 0) { sh_def[0] = 0; sh_def[1] = 0; }
@@ -1100,10 +1108,10 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
   TRACE_P(9);
   WGP_OUT();
 }
-template __global__ void rbpf_propose<kProposeThreads, false>(ScanC, const double2* __restrict__, const uint16_t* __restrict__, TilePool, MapT, const int* __restrict__, const int* __restrict__, int, int, int, int, const int* __restrict__, const int4* __restrict__, const double* __restrict__, const double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, Trace, double* __restrict__, int* __restrict__, const int* __restrict__, const double* __restrict__, NoiseSrc);
-template __global__ void rbpf_propose<kProposeThreads, true>(ScanC, const double2* __restrict__, const uint16_t* __restrict__, TilePool, MapT, const int* __restrict__, const int* __restrict__, int, int, int, int, const int* __restrict__, const int4* __restrict__, const double* __restrict__, const double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, Trace, double* __restrict__, int* __restrict__, const int* __restrict__, const double* __restrict__, NoiseSrc);
-template __global__ void rbpf_propose<2 * kProposeThreads, false>(ScanC, const double2* __restrict__, const uint16_t* __restrict__, TilePool, MapT, const int* __restrict__, const int* __restrict__, int, int, int, int, const int* __restrict__, const int4* __restrict__, const double* __restrict__, const double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, Trace, double* __restrict__, int* __restrict__, const int* __restrict__, const double* __restrict__, NoiseSrc);
-template __global__ void rbpf_propose<2 * kProposeThreads, true>(ScanC, const double2* __restrict__, const uint16_t* __restrict__, TilePool, MapT, const int* __restrict__, const int* __restrict__, int, int, int, int, const int* __restrict__, const int4* __restrict__, const double* __restrict__, const double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, Trace, double* __restrict__, int* __restrict__, const int* __restrict__, const double* __restrict__, NoiseSrc);
+template __global__ void rbpf_propose<kProposeThreads, false>(ScanC, const double2* __restrict__, const uint16_t* __restrict__, TilePool, MapT, const int* __restrict__, const int* __restrict__, int, int, int, int, const int* __restrict__, const int4* __restrict__, const double* __restrict__, const double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, Trace, double* __restrict__, int* __restrict__, const int* __restrict__, const double* __restrict__, NoiseSrc, int* __restrict__);
+template __global__ void rbpf_propose<kProposeThreads, true>(ScanC, const double2* __restrict__, const uint16_t* __restrict__, TilePool, MapT, const int* __restrict__, const int* __restrict__, int, int, int, int, const int* __restrict__, const int4* __restrict__, const double* __restrict__, const double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, Trace, double* __restrict__, int* __restrict__, const int* __restrict__, const double* __restrict__, NoiseSrc, int* __restrict__);
+template __global__ void rbpf_propose<2 * kProposeThreads, false>(ScanC, const double2* __restrict__, const uint16_t* __restrict__, TilePool, MapT, const int* __restrict__, const int* __restrict__, int, int, int, int, const int* __restrict__, const int4* __restrict__, const double* __restrict__, const double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, Trace, double* __restrict__, int* __restrict__, const int* __restrict__, const double* __restrict__, NoiseSrc, int* __restrict__);
+template __global__ void rbpf_propose<2 * kProposeThreads, true>(ScanC, const double2* __restrict__, const uint16_t* __restrict__, TilePool, MapT, const int* __restrict__, const int* __restrict__, int, int, int, int, const int* __restrict__, const int4* __restrict__, const double* __restrict__, const double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, Trace, double* __restrict__, int* __restrict__, const int* __restrict__, const double* __restrict__, NoiseSrc, int* __restrict__);
 
 }  // namespace tbnav_rk
 

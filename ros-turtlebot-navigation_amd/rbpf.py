@@ -218,6 +218,14 @@ class ParticleFilter:
         capi.check(self._L.tbnav_rbpf_reference_field_counts(self._h, C.byref(a), C.byref(b), C.byref(c)), "reference_field_counts")
         return a.value, b.value, c.value
 
+    def referenceFieldStats(self):
+        """Reference-field mode: the lazy brushfire's counters (tbnav_rbpf_reference_field_stats) as a dict."""
+        out = (C.c_int64 * 16)()
+        capi.check(self._L.tbnav_rbpf_reference_field_stats(self._h, out), "reference_field_stats")
+        keys = ("passes", "iterations", "states_resumed", "passes_completed", "lineages_replayed", "generations_replayed", "history_bytes", "proposals_rerun",
+                "us_logs", "us_step", "us_resample", "us_flush", "us_before_propose", "us_settle_look", "us_step_grouping", "us_step_release")
+        return dict(zip(keys, (int(v) for v in out)))
+
     def setTiming(self, on: bool = True):
         """Record HIP events round the kernels of the following SLAM calls (they cost device time: off by default)."""
         capi.check(self._L.tbnav_rbpf_set_timing(self._h, 1 if on else 0), "set_timing")
