@@ -47,7 +47,9 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -56,6 +58,55 @@
 #include <vector>
 
 namespace tbnav {
+
+// Host threads that stay: a scan hands them its groups (std::thread creation is ~25 us apiece, in sequence — 16 of them twice per scan
+// was a tenth of a 10 ms scan).  run(n, f) runs f on n - 1 of them and on the caller, and returns when all are through.
+class Workers {
+ public:
+  ~Workers() {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  template <class F>
+  void run(int n, F& f) {
+    if (n <= 1) { f(); return; }
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      while ((int)th_.size() < n - 1) th_.emplace_back([this, idx = (int)th_.size()] { loop(idx); });
+      job_ = [&f] { f(); };
+      want_ = n - 1; left_ = n - 1; ++gen_;
+    }
+    cv_.notify_all();
+    f();
+    std::unique_lock<std::mutex> lk(mu_);
+    done_.wait(lk, [this] { return left_ == 0; });
+  }
+ private:
+  void loop(int idx) {
+    unsigned long seen = 0;
+    for (;;) {
+      std::function<void()> job;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return stop_ || (gen_ != seen && idx < want_); });
+        if (stop_) return;
+        seen = gen_;
+        job = job_;
+      }
+      job();
+      std::lock_guard<std::mutex> lk(mu_);
+      if (--left_ == 0) done_.notify_all();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_, done_;
+  std::vector<std::thread> th_;
+  std::function<void()> job_;
+  int want_ = 0, left_ = 0;
+  unsigned long gen_ = 0;
+  bool stop_ = false;
+};
 
 class RefField {
  public:
@@ -71,8 +122,22 @@ class RefField {
   // it is FARTHER than the left), then the displaced last element is pushed up from there — with the child chosen by arithmetic
   // instead of a data-dependent branch.  tests/test_ref_field_heap.py holds it against std::priority_queue itself (pop order of equal
   // keys, whole fields) on random sequences; the GPU suite holds the fields against the oracle's, which is pinned to the compiled reference.
-  struct Node { uint32_t d2; uint16_t i, j, si, sj; uint32_t pad; };
-  static_assert(sizeof(Node) == 16, "one 16-byte move per level");
+  // One 8-byte word per node (round 6; 16 bytes before): squared distance in the top 16 bits — the ONLY part the heap compares, so
+  // equal distances stay "not farther" as in CompareDistance — then the cell and its source, 12 bits each (grids up to 4096 x 4096;
+  // the codes are u16, so a squared distance fits).
+  struct Node {
+    uint64_t v;
+    static Node make(uint32_t d2, int i, int j, int si, int sj) {
+      return Node{((uint64_t)d2 << 48) | ((uint64_t)(i & 0xFFF) << 36) | ((uint64_t)(j & 0xFFF) << 24) | ((uint64_t)(si & 0xFFF) << 12) | (uint64_t)(sj & 0xFFF)};
+    }
+    uint32_t d2() const { return (uint32_t)(v >> 48); }
+    int i() const { return (int)((v >> 36) & 0xFFF); }
+    int j() const { return (int)((v >> 24) & 0xFFF); }
+    int si() const { return (int)((v >> 12) & 0xFFF); }
+    int sj() const { return (int)(v & 0xFFF); }
+  };
+  static_assert(sizeof(Node) == 8, "one 8-byte move per level");
+  static constexpr int kMaxSide = 4096;
   class Heap {
    public:
     // keep = false: a new queue in `store` (its capacity is reused); keep = true: the queue `store` already holds (a resumed pass)
@@ -87,7 +152,7 @@ class RefField {
       size_t hole = v_.size() - 1;
       while (hole > 0) {
         const size_t parent = (hole - 1) / 2;
-        if (!(a[parent].d2 > value.d2)) break;
+        if (!(a[parent].d2() > value.d2())) break;
         a[hole] = a[parent];
         hole = parent;
       }
@@ -103,7 +168,7 @@ class RefField {
       const size_t inner = (len - 1) / 2;
       while (child < inner) {
         child = 2 * (child + 1);
-        child -= (size_t)(a[child].d2 > a[child - 1].d2);   // comp(first + secondChild, first + (secondChild - 1)): --secondChild
+        child -= (size_t)(a[child].d2() > a[child - 1].d2());   // comp(first + secondChild, first + (secondChild - 1)): --secondChild
         a[hole] = a[child];
         hole = child;
       }
@@ -114,7 +179,7 @@ class RefField {
       }
       while (hole > 0) {   // __push_heap(first, hole, 0, value)
         const size_t parent = (hole - 1) / 2;
-        if (!(a[parent].d2 > value.d2)) break;
+        if (!(a[parent].d2() > value.d2())) break;
         a[hole] = a[parent];
         hole = parent;
       }
@@ -123,6 +188,53 @@ class RefField {
     }
    private:
     std::vector<Node>& v_;
+  };
+
+  // A field of u16 codes that is cheap to copy from one generation to the next: a private WINDOW (the bounding box of everything the
+  // lineage's passes have written since the background was made, a few thousand cells round a room's walls) over a shared, immutable
+  // dense BACKGROUND.  A pass that writes outside the window grows it (values come over from the background); copying a field copies
+  // the window and a pointer.  (A 400 x 400 field is 320 KB; 1000 new states per scan copied 320 MB of it — the host's memory
+  // bandwidth, shared by the threads — to change a few hundred cells each.)
+  class Codes {
+   public:
+    void assign_fill(int xs, uint16_t v) { xs_ = xs; bg_ = std::make_shared<std::vector<uint16_t>>((size_t)xs * xs, v); drop_window(); }
+    void assign_dense(int xs, const uint16_t* src) { xs_ = xs; bg_ = std::make_shared<std::vector<uint16_t>>(src, src + (size_t)xs * xs); drop_window(); }
+    void copy_from(const Codes& o) { xs_ = o.xs_; bg_ = o.bg_; i0_ = o.i0_; i1_ = o.i1_; j0_ = o.j0_; j1_ = o.j1_; w_ = o.w_; win_.assign(o.win_.begin(), o.win_.end()); }
+    void swap(Codes& o) { std::swap(xs_, o.xs_); bg_.swap(o.bg_); std::swap(i0_, o.i0_); std::swap(i1_, o.i1_); std::swap(j0_, o.j0_); std::swap(j1_, o.j1_); std::swap(w_, o.w_); win_.swap(o.win_); }
+    bool inside(int i, int j) const { return i >= i0_ && i <= i1_ && j >= j0_ && j <= j1_; }
+    uint16_t get(int i, int j) const { return inside(i, j) ? win_[(size_t)(i - i0_) * w_ + (j - j0_)] : (*bg_)[(size_t)i * xs_ + j]; }
+    uint16_t at(int cell) const { return get(cell / xs_, cell % xs_); }
+    // the cell's slot in the window (grown to hold it if need be): read the old value, write the new one
+    uint16_t* slot(int i, int j) {
+      if (!inside(i, j)) grow(i, j);
+      return &win_[(size_t)(i - i0_) * w_ + (j - j0_)];
+    }
+    void to_dense(std::vector<uint16_t>& out) const {
+      out = *bg_;
+      for (int i = i0_; i <= i1_; ++i) std::memcpy(&out[(size_t)i * xs_ + j0_], &win_[(size_t)(i - i0_) * w_], sizeof(uint16_t) * (size_t)w_);
+    }
+    size_t window_cells() const { return win_.size(); }
+    void keep_capacity_only() { bg_.reset(); drop_window(); }
+   private:
+    void drop_window() { i0_ = j0_ = 0; i1_ = j1_ = -1; w_ = 0; win_.clear(); }
+    void grow(int i, int j) {
+      const int m = 16;   // (a pass spreads ring by ring: room for the next rings too)
+      int a0 = std::max(0, i - m), a1 = std::min(xs_ - 1, i + m), b0 = std::max(0, j - m), b1 = std::min(xs_ - 1, j + m);
+      if (i1_ >= i0_) { a0 = std::min(a0, i0_); a1 = std::max(a1, i1_); b0 = std::min(b0, j0_); b1 = std::max(b1, j1_); }
+      const int nw = b1 - b0 + 1;
+      std::vector<uint16_t> nwin((size_t)(a1 - a0 + 1) * nw);
+      for (int r = a0; r <= a1; ++r) {
+        uint16_t* dst = &nwin[(size_t)(r - a0) * nw];
+        std::memcpy(dst, &(*bg_)[(size_t)r * xs_ + b0], sizeof(uint16_t) * (size_t)nw);
+        if (r >= i0_ && r <= i1_) std::memcpy(dst + (j0_ - b0), &win_[(size_t)(r - i0_) * w_], sizeof(uint16_t) * (size_t)w_);
+      }
+      win_.swap(nwin);
+      i0_ = a0; i1_ = a1; j0_ = b0; j1_ = b1; w_ = nw;
+    }
+    int xs_ = 0;
+    std::shared_ptr<const std::vector<uint16_t>> bg_;
+    int i0_ = 0, i1_ = -1, j0_ = 0, j1_ = -1, w_ = 0;
+    std::vector<uint16_t> win_;
   };
 
   struct State;
@@ -176,7 +288,8 @@ class RefField {
   struct State {
     uint64_t id = 0;
     std::unordered_set<int> occ;
-    std::vector<uint16_t> code;     // [G] the newest value any pass of the lineage has written (the reference's value in every cell of `mark`)
+    Codes code;                     // [G] the newest value any pass of the lineage has written (the reference's value in every cell of `mark`)
+    std::vector<uint16_t> dense;    // the same as one array, made when somebody asks for the whole field (codes())
     bool fresh = false;             // code is what the brushfire leaves for exactly this set (false once either was written from outside)
     // the pass (euclideanSignedDistanceField for exactly this set)
     std::vector<uint64_t> mark;     // [G / 64] cell written by this pass (empty: no pass ran for this state)
@@ -200,7 +313,7 @@ class RefField {
     void recycle() {
       id = 0; fresh = false; complete = true; exact = true; from_dense = true; hist_lost = false; hist.reset();
       from_id = 0; from_len = 0; j_reset = false;
-      mark.clear(); band.clear(); heap.clear(); journal.clear();
+      mark.clear(); band.clear(); heap.clear(); journal.clear(); dense.clear(); code.keep_capacity_only();
     }
   };
 
@@ -220,7 +333,7 @@ class RefField {
     pool_->keep = (size_t)n_particles + 64;
     auto s = new_state();
     initial_id_ = s->id;
-    s->code.assign((size_t)xsize * xsize, kUnreached);
+    s->code.assign_fill(xsize, kUnreached);
     st_.assign((size_t)n_particles, s);  // "N deep copies of the prototype" (particle_filter.cpp:125-138): equal, hence shared
     dev_.assign((size_t)n_particles, Slot{});
   }
@@ -245,7 +358,8 @@ class RefField {
     State& s = *st_[p];
     if (!s.complete) { advance(s, ~0u, -1); }
     if (!s.exact && make_exact(s) != 0) return nullptr;
-    return s.code.data();
+    s.code.to_dense(s.dense);
+    return s.dense.data();
   }
 
   // One scan for particles [first, first + count): evs[i] = the logged set changes of particle first + i in the reference's
@@ -287,7 +401,7 @@ class RefField {
         // (copy-construct, as GridMapper's copy does: std::unordered_set's copy keeps the iteration order, the bucket layout and
         //  the rehash policy's state, so the copy behaves like the original from here on)
         s.occ = P.occ;
-        s.code.assign(P.code.begin(), P.code.end());
+        s.code.copy_from(P.code);
         apply(s.occ, gr.ev, (int)gr.n);
         s.fresh = true;
         s.from_dense = P.dense_image();
@@ -325,13 +439,11 @@ class RefField {
     const auto t_b = std::chrono::steady_clock::now();
     run_threads(threads, (int)groups.size(), work);
     const auto t_c = std::chrono::steady_clock::now();
-    // the particles move to their new states; the old ones die here — side by side too (an occupied set is a thousand list nodes)
+    // the particles move to their new states; the old ones go back to the pool
     std::vector<StatePtr> grave;
     grave.reserve((size_t)count);
     for (Group& gr : groups) { for (int p : gr.members) { grave.push_back(std::move(st_[p])); st_[p] = gr.to; } gr.from.reset(); gr.to.reset(); }
-    std::atomic<size_t> gnext{0};
-    auto bury = [&] { for (size_t g = gnext.fetch_add(16); g < grave.size(); g = gnext.fetch_add(16)) for (size_t q = g; q < std::min(grave.size(), g + 16); ++q) grave[q].reset(); };
-    run_threads(threads, (int)((grave.size() + 15) / 16), bury);
+    grave.clear();   // (recycled, not destroyed: see Pool)
     const auto t_d = std::chrono::steady_clock::now();
     auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return (long long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
     cnt_.us_group += us(t_a, t_b); cnt_.us_work += us(t_b, t_c); cnt_.us_bury += us(t_c, t_d);
@@ -359,7 +471,7 @@ class RefField {
           if (!s.complete) {
             pops.fetch_add(advance(s, ~0u, c));
             if (s.marked(c) && !s.complete) {   // one more ring: (sqrt(d2) + 1)^2
-              const uint32_t d2 = s.code[c];
+              const uint32_t d2 = s.code.at(c);
               const uint32_t r1 = (uint32_t)std::ceil(std::sqrt((double)d2)) + 1u;
               pops.fetch_add(advance(s, r1 * r1, -1));
             }
@@ -443,7 +555,7 @@ class RefField {
     auto s = new_state();
     s->occ = std::unordered_set<int>();   // (a NEW set — one bucket, growing as the cells go in — not a cleared one that keeps its bucket count)
     for (int c : cells_ascending) s->occ.insert(c);
-    if (old) s->code.assign(old, old + G()); else s->code.assign(G(), kUnreached);
+    if (old) s->code.assign_dense(xs_, old); else s->code.assign_fill(xs_, kUnreached);
     s->fresh = false;
     st_[p] = s;
   }
@@ -455,9 +567,9 @@ class RefField {
     auto s = new_state();
     s->occ = o.occ;
     s->fresh = o.fresh;
-    if (c) s->code.assign(c, c + G());
+    if (c) s->code.assign_dense(xs_, c);
     else {   // the source's history is gone: the copy inherits what is known, and the hole
-      s->code = o.code; s->mark = o.mark; s->band = o.band; s->heap = o.heap; s->complete = o.complete; s->exact = false; s->from_dense = false; s->hist_lost = true;
+      s->code.copy_from(o.code); s->mark = o.mark; s->band = o.band; s->heap = o.heap; s->complete = o.complete; s->exact = false; s->from_dense = false; s->hist_lost = true;
     }
     st_[p] = s;
     dev_[p] = Slot{};
@@ -465,7 +577,7 @@ class RefField {
   void set_codes(int p, const uint16_t* codes_in) {
     auto s = new_state();
     s->occ = st_[p]->occ;
-    s->code.assign(codes_in, codes_in + G());
+    s->code.assign_dense(xs_, codes_in);
     s->fresh = false;
     st_[p] = s;
   }
@@ -488,9 +600,10 @@ class RefField {
   size_t G() const { return (size_t)xs_ * xs_; }
 
   static void image_of(const State& s, std::vector<uint16_t>& out) {
-    if (s.dense_image()) { out = s.code; return; }
-    out.assign(s.code.size(), kPending);
-    for (int c : s.band) out[c] = s.code[c];
+    if (s.dense_image()) { s.code.to_dense(out); return; }
+    s.code.to_dense(out);   // (for its size)
+    std::fill(out.begin(), out.end(), kPending);
+    for (int c : s.band) out[c] = s.code.at(c);
   }
   void need_dense(Flush& f, std::unordered_map<uint64_t, int>& first, int p, const State& T) {
     auto it = first.find(T.id);
@@ -505,13 +618,11 @@ class RefField {
   }
 
   template <class Work>
-  static void run_threads(int threads, int jobs, Work& work) {
+  void run_threads(int threads, int jobs, Work& work) {
     int nt = threads < 1 ? 1 : threads;
     if (nt > jobs) nt = jobs;
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
-    work();
-    for (auto& t : pool) t.join();
+    if (nt <= 1) { if (jobs > 0) work(); return; }
+    workers_.run(nt, work);
   }
 
   // updateCellHash (grid_mapper.cpp:480-546) for the logged changes of one scan, in the reference's call order
@@ -525,21 +636,21 @@ class RefField {
 
   // A cell's code goes to the device unless the slot is known to hold it already: the parent's image has the cell written with
   // this very code (the child's `code` starts as the parent's).
-  static bool parent_has(const State* P, int idx, uint16_t d2, const uint16_t* code) { return P && P->marked(idx) && code[idx] == d2; }
+  static bool parent_has(const State* P, int idx, uint16_t d2, uint16_t old) { return P && old == d2 && P->marked(idx); }
 
   // euclideanSignedDistanceField, grid_mapper.cpp:348-362: the sources, in the set's iteration order
   void seed(State& st, const State* P) const {
-    uint16_t* const code = st.code.data();
     uint64_t* const mk = st.mark.data();
     if (st.heap.capacity() < (size_t)xs_ * 8) st.heap.reserve((size_t)xs_ * 8);
     Heap Q(st.heap);
     for (int key : st.occ) {
-      if (!parent_has(P, key, 0, code)) st.journal.push_back(JEntry{(uint32_t)key, 0u});
-      code[key] = 0;
+      const uint16_t ki = (uint16_t)(key / xs_), kj = (uint16_t)(key % xs_);
+      uint16_t* const cs = st.code.slot(ki, kj);
+      if (!parent_has(P, key, 0, *cs)) st.journal.push_back(JEntry{(uint32_t)key, 0u});
+      *cs = 0;
       mk[(size_t)key >> 6] |= 1ull << (key & 63);
       st.band.push_back(key);
-      const uint16_t ki = (uint16_t)(key / xs_), kj = (uint16_t)(key % xs_);
-      Q.push(Node{0, ki, kj, ki, kj, 0});
+      Q.push(Node::make(0, ki, kj, ki, kj));
     }
   }
 
@@ -547,7 +658,7 @@ class RefField {
   // (complete), its top is farther than limit2, or cell `until` (>= 0) has been written.  Returns the iterations run.
   long long advance(State& st, uint32_t limit2, int until, const State* P = nullptr) const {
     if (st.complete) return 0;
-    uint16_t* const code = st.code.data();
+    Codes& code = st.code;
     uint64_t* const mk = st.mark.data();
     Heap Q(st.heap, true);
     const int xs = xs_, r = radius_, r2 = radius_ * radius_;
@@ -563,9 +674,10 @@ class RefField {
       if (di >= r || dj >= r) return;  // distances_ is cell_radius_ x cell_radius_: .at() throws, caught, return (:300-308)
       const int d2 = di * di + dj * dj;
       if (d2 > r2) return;             // dist > cell_radius_ (:311-314); sqrt(d2) > r <=> d2 > r^2 exactly
-      if (!parent_has(P, idx, (uint16_t)d2, code)) jr.push_back(JEntry{(uint32_t)idx, (uint32_t)d2});
-      code[idx] = (uint16_t)d2;
-      Q.push(Node{(uint32_t)d2, (uint16_t)i, (uint16_t)j, (uint16_t)si, (uint16_t)sj, 0});
+      uint16_t* const cs = code.slot(i, j);
+      if (!parent_has(P, idx, (uint16_t)d2, *cs)) jr.push_back(JEntry{(uint32_t)idx, (uint32_t)d2});
+      *cs = (uint16_t)d2;
+      Q.push(Node::make((uint32_t)d2, i, j, si, sj));
       w |= bit;
       band.push_back(idx);
     };
@@ -574,12 +686,13 @@ class RefField {
     const uint64_t ubit = until >= 0 ? 1ull << (until & 63) : 0ull;
     while (!Q.empty()) {
       const Node c = Q.top();
-      if (c.d2 > limit2) return it;
+      if (c.d2() > limit2) return it;
       if (uw && (*uw & ubit)) return it;
-      if (c.i > 0) enqueue(c.i - 1, c.j, c.si, c.sj);
-      if (c.j > 0) enqueue(c.i, c.j - 1, c.si, c.sj);
-      if (c.i < xs - 1) enqueue(c.i + 1, c.j, c.si, c.sj);
-      if (c.j < xs - 1) enqueue(c.i, c.j + 1, c.si, c.sj);
+      const int ci = c.i(), cj = c.j(), si = c.si(), sj = c.sj();
+      if (ci > 0) enqueue(ci - 1, cj, si, sj);
+      if (cj > 0) enqueue(ci, cj - 1, si, sj);
+      if (ci < xs - 1) enqueue(ci + 1, cj, si, sj);
+      if (cj < xs - 1) enqueue(ci, cj + 1, si, sj);
       Q.pop();
       ++it;
     }
@@ -601,7 +714,7 @@ class RefField {
     if (!base) return -1;
     State cur;
     cur.occ = base->occ;
-    cur.code = base->code;
+    cur.code.copy_from(base->code);
     long long pops = 0;
     for (size_t g = chain.size(); g-- > 0;) {
       apply(cur.occ, chain[g]->events.data(), (int)chain[g]->events.size());
@@ -615,7 +728,7 @@ class RefField {
     }
     // the last generation's pass IS this state's pass: same set, same order — it must have written the same cells the same way
     if (cur.occ.size() != s.occ.size() || cur.band.size() != s.band.size()) return -2;
-    for (int c : s.band) if (cur.code[c] != s.code[c]) return -2;
+    for (int c : s.band) if (cur.code.at(c) != s.code.at(c)) return -2;
     s.code.swap(cur.code);
     s.exact = true;
     s.hist.reset();
@@ -625,7 +738,7 @@ class RefField {
   }
 
   int xs_, radius_;
-  int reach_ = 6;
+  int reach_ = 3;
   long long hist_budget_ = (long long)1 << 30;
   int last_brushfires_ = 0;
   long long total_brushfires_ = 0;
@@ -635,6 +748,7 @@ class RefField {
   uint64_t initial_id_ = 0;
   std::shared_ptr<std::atomic<long long>> hist_bytes_;
   std::shared_ptr<Pool> pool_;
+  Workers workers_;
   std::vector<StatePtr> st_;
   std::vector<Slot> dev_;
 };

@@ -26,7 +26,7 @@ struct StdNode { uint32_t d2; uint16_t i, j, si, sj; };
 struct StdFarther { bool operator()(const StdNode& a, const StdNode& b) const { return a.d2 > b.d2; } };
 using StdHeap = std::priority_queue<StdNode, std::vector<StdNode>, StdFarther>;
 
-bool same(const RefField::Node& a, const StdNode& b) { return a.d2 == b.d2 && a.i == b.i && a.j == b.j && a.si == b.si && a.sj == b.sj; }
+bool same(const RefField::Node& a, const StdNode& b) { return a.d2() == b.d2 && a.i() == b.i && a.j() == b.j && a.si() == b.si && a.sj() == b.sj; }
 
 int heap_order(unsigned seed, int ops, int key_range) {
   std::mt19937 rng(seed);
@@ -36,9 +36,9 @@ int heap_order(unsigned seed, int ops, int key_range) {
   uint32_t serial = 0;
   auto push = [&](uint32_t d2) {
     ++serial;
-    const uint16_t a = (uint16_t)(serial & 0xFFFF), b = (uint16_t)(serial >> 16);
-    H.push(RefField::Node{d2, a, b, (uint16_t)(a ^ 0x5555), (uint16_t)(b + 1), 0});
-    S.push(StdNode{d2, a, b, (uint16_t)(a ^ 0x5555), (uint16_t)(b + 1)});
+    const uint16_t a = (uint16_t)(serial & 0xFFF), b = (uint16_t)((serial >> 12) & 0xFFF);   // (a node carries 12 bits per coordinate)
+    H.push(RefField::Node::make(d2, a, b, (a ^ 0x555) & 0xFFF, (b + 1) & 0xFFF));
+    S.push(StdNode{d2, a, b, (uint16_t)((a ^ 0x555) & 0xFFF), (uint16_t)((b + 1) & 0xFFF)});
   };
   for (int q = 0; q < ops; ++q) {
     const unsigned what = rng() % 8;
@@ -47,7 +47,7 @@ int heap_order(unsigned seed, int ops, int key_range) {
     else if (what < 5) { if (!same(H.top(), S.top())) return 2; H.pop(); S.pop(); }
     else {  // the brushfire's step: read the top, push up to four (some nearer than the top), THEN pop
       if (!same(H.top(), S.top())) return 3;
-      const uint32_t base = H.top().d2;
+      const uint32_t base = H.top().d2();
       const int n = rng() % 5;
       for (int t = 0; t < n; ++t) push(base + (rng() % 7) - (rng() % 3 == 0 ? 2 : 0) < 0x7FFFFFFFu ? base + (rng() % 7) : 0);
       H.pop(); S.pop();

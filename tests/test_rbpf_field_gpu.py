@@ -28,18 +28,21 @@ def _rel(a, b):
 
 
 def _free_run(gpu_pkg, df_mode, N, k, map_half, walls, n_scans, inc, seed, force_resample_at=None, start=(0.0, 0.0, 0.0),
-              oracle_exact_field=False, oracle_window=None, pool_bytes=0, n_beams=360, empty_at=(), **extra):
+              oracle_exact_field=False, oracle_window=None, pool_bytes=0, n_beams=360, empty_at=(), walls_at=None, ref_reach=None, **extra):
     """Oracle filter and device filter side by side, same scans, same draws, nothing injected.  oracle_exact_field: the
     oracle's likelihoods read the exact nearest-obstacle distance (the checker of the device's default mode) instead of
     the reference's brushfire."""
     pf_o = orc.PfAPI(orc.pf_params(N=N, k=k, map_min=-map_half, map_max=map_half, pose0=start, **extra),
                      exact_field=oracle_exact_field, window=oracle_window)
     pf_d = _dev(gpu_pkg, df_mode=df_mode, pool_bytes=pool_bytes, N=N, k=k, map_min=-map_half, map_max=map_half, pose0=start, **extra)
+    if ref_reach is not None:
+        from rtn_amd import capi
+        pf_d.setOption(capi.RBPF_OPT_REF_REACH, ref_reach)
     steps, poses = rc.trajectory(n_scans, inc=inc, start=start)
     rng = np.random.default_rng(seed)
     rows = []
     for s, (prev, cur, t_icp, u) in enumerate(steps):
-        scan = orc.room_scan(poses[s], n_beams=n_beams, beam_delta_deg=extra.get("beam_delta_deg", 1.0), walls=walls, rng=rng)
+        scan = orc.room_scan(poses[s], n_beams=n_beams, beam_delta_deg=extra.get("beam_delta_deg", 1.0), walls=walls_at(s) if walls_at else walls, rng=rng)
         if s in empty_at:
             scan[:] = 0.01   # every range below range_min: no valid beam
         normals = orc.normal_stream(900 + s, pf_o.normals_per_scan(True), 0.0, 1.0)
@@ -136,6 +139,66 @@ def test_reference_mode_shares_one_brushfire_among_particles_in_the_same_state(g
     distinct, last, total = pf_d.referenceFieldCounts()
     assert 1 <= distinct <= N and last <= N
     assert total < N * n_scans // 2, (distinct, last, total)   # (every particle on its own would be N * n_scans = 288)
+    pf_d.close()
+
+
+@pytest.mark.parametrize("reach", [0, 1, 3, 6])
+def test_reference_mode_lazy_brushfire_is_the_eager_one_for_every_reach(gpu_pkg, reach):
+    """Round 6: the reference-mode brushfire stops `reach` cells out (TBNAV_RBPF_OPT_REF_REACH; 0 = to the end, as before) and is
+    resumed when a likelihood lookup lands on a cell it has not written (csrc/ref_field.hpp).  Whatever the reach, every stage of
+    every scan equals the oracle (whose brushfire always runs to the end), a forced resampling included, and the whole fields —
+    whose export finishes the passes — are the oracle's bit for bit."""
+    N = 32
+    pf_o, pf_d, rows = _free_run(gpu_pkg, "reference", N=N, k=50, map_half=2.0, walls=rc.ROOM_SMALL, n_scans=7,
+                                 inc=(0.04, 0.03, 0.02), seed=17, force_resample_at=3, ref_reach=reach)
+    assert rows[3]["resampled"] == (1, 1)
+    _assert_every_stage(rows)
+    st = pf_d.referenceFieldStats()
+    assert st["passes"] > 0 and (st["passes_completed"] == st["passes"]) == (reach == 0), st
+    for p in range(N):
+        g = pf_o.grid(p).dump()
+        assert np.array_equal(pf_d.occDist(p), g["occ_dist"]), p
+        assert np.array_equal(pf_d.logOdds(p), g["log_odds"]), p
+    pf_d.close()
+
+
+@pytest.mark.parametrize("grid", ["120x120", "400x400"])
+def test_reference_mode_walls_that_appear_far_from_the_map_resume_the_passes(gpu_pkg, grid, record_property):
+    """The lazy brushfire's hard case: after three scans in a small room the scans come from a room with walls 20-30 cells beyond
+    everything mapped so far — their end points land on cells no pass has written (kCodePending on the device).  The proposal kernel
+    reports them, exactly those states' passes are resumed until the cells are written (tbnav_rbpf_reference_field_stats:
+    states_resumed, proposals_rerun), and every stage still equals the oracle, nothing injected.  On the 400 x 400 grid cells farther
+    than cell_radius_ from every obstacle keep STALE values (grid_mapper.cpp:311-314): the whole-field export at the end replays the
+    lineages whose passes were cut short (lineages_replayed) and equals the oracle's field bit for bit."""
+    big = grid == "400x400"
+    N, half = (10, 10.0) if big else (24, 3.0)
+    small, large = (-1.0, 1.0, -0.8, 0.9), (-2.4, 2.5, -2.2, 2.3)
+    pf_o, pf_d, rows = _free_run(gpu_pkg, "reference", N=N, k=20, map_half=half, walls=small, n_scans=7, inc=(0.05, 0.03, 0.02), seed=23,
+                                 force_resample_at=5, walls_at=lambda s: small if s < 3 else large, ref_reach=2)
+    _assert_every_stage(rows)
+    st = pf_d.referenceFieldStats()
+    record_property("reference_field_stats", st)
+    print(f"\n[lazy brushfire, {grid}] {st}")
+    assert st["states_resumed"] > 0 and st["proposals_rerun"] > 0 and st["passes_completed"] < st["passes"], st
+    for p in range(N):
+        g = pf_o.grid(p).dump()
+        assert np.array_equal(pf_d.occDist(p), g["occ_dist"]), p
+        assert np.array_equal(pf_d.logOdds(p), g["log_odds"]), p
+    st2 = pf_d.referenceFieldStats()
+    if big:
+        assert st2["lineages_replayed"] > 0, st2   # (cells out of every obstacle's reach: their values come from the replay)
+    # ... and the filter goes on from the finished, exact states as if nothing had happened
+    steps, poses = rc.trajectory(9, inc=(0.05, 0.03, 0.02))
+    rng = np.random.default_rng(99)
+    for s in (7, 8):
+        prev, cur, t_icp, u = steps[s]
+        scan = orc.room_scan(poses[s], walls=large, rng=rng)
+        normals = orc.normal_stream(1900 + s, pf_o.normals_per_scan(True), 0.0, 1.0)
+        tr_o = pf_o.slam(scan, u, cur, prev, True, t_icp, normals)
+        stt = pf_d.SLAM(scan, u, cur, prev, True, t_icp, normals)
+        assert stt.status == 0 and tr_o["rc"] == 0
+        wo, wd = pf_o.particles()[2], pf_d.particles()[2]
+        assert float(np.max(np.abs(wd - wo) / np.abs(wo))) <= 1e-9 and stt.neff == tr_o["neff"]
     pf_d.close()
 
 
