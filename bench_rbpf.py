@@ -148,9 +148,9 @@ def map_update_leg(device, label, N, k, map_half, walls, inc, n_scans=12, n_beam
 
 
 def noise_forms(device, N, k, n_scans=30):
-    """Where the device noise is drawn (TBNAV_RBPF_OPT_NOISE_IN_KERNEL), side by side on the bench workload: 1 (default) — inside
-    rbpf_propose, the beam table through its leading workgroup, two launches per scan; 0 — rbpf_sample_normals stores the stream first
-    (up to round 4), three launches.  Wall time of synchronous calls without event timing, and the proposal kernel by HIP events."""
+    """Where the device noise is drawn (TBNAV_RBPF_OPT_NOISE_IN_KERNEL), side by side on the bench workload: 1 — inside
+    rbpf_propose, the beam table through its leading workgroup, two launches per scan; 0 (default since round 6) — rbpf_sample_normals
+    stores the stream first, three launches.  Wall time of synchronous calls without event timing, and the proposal kernel by HIP events."""
     from rtn_amd import capi
     from rtn_amd.rbpf import ParticleFilter, default_params
     steps, scans = workload(n_scans)

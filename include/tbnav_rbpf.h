@@ -307,10 +307,14 @@ int tbnav_rbpf_particle_map(tbnav_rbpf* h, int32_t particle, int8_t* map);
  * TBNAV_RBPF_OPT_COUNT_CELLS     1 = the tile raycast counts the cells it updates (tbnav_rbpf_scan_counts).
  * TBNAV_RBPF_OPT_RAYCAST_FORM    retired.  0 is accepted (the box-counter kernel rbpf_raycast_box, the only form); 1 — round 2's first tile kernel,
  *                                removed in round 4 — is TBNAV_ERR_INVALID_ARG: the beam-ordered kernel is selected by _RAYCAST_ORDERED.
- * TBNAV_RBPF_OPT_NOISE_IN_KERNEL 1 (default) = with device noise (normals == NULL) the standard normals are drawn INSIDE rbpf_propose and never
- *                                stored, and the scan's beam table reaches the device through that launch's leading workgroup: a scan
- *                                is two launches; 0 = rbpf_sample_normals stores them first (up to round 4).  Same Philox counters,
- *                                same values either way (particle_filter.cpp:25-34, :504-519 are what both replace).
+ * TBNAV_RBPF_OPT_NOISE_IN_KERNEL 0 (default since round 6) = with device noise (normals == NULL) rbpf_sample_normals stores the standard normals first
+ *                                and carries the scan's beam table over: three launches per scan, no hand-over inside a launch;
+ *                                1 = they are drawn INSIDE rbpf_propose and never stored, and the beam table reaches the device through
+ *                                that launch's leading workgroup (two launches; the proposal kernel is ~5 us slower per 1000 particles
+ *                                and a synchronous scan takes the same wall time either way, which is why it is not the default; the
+ *                                other workgroups wait for the table with a bound — a table that never arrives is TBNAV_ERR_HIP and
+ *                                nothing of the scan is applied).  Same Philox counters, same values either way
+ *                                (particle_filter.cpp:25-34, :504-519 are what both replace).
  * TBNAV_RBPF_OPT_RAYCAST_BAND_ROWS n > 0 = rbpf_raycast_box keeps at most about n rows of a scan's bounding box in LDS at a
  *                                time (0 = as many as fit): drives its band loop on small maps (tests).
  * TBNAV_RBPF_OPT_RAYCAST_ADAPT   1 = rbpf_raycast_box's LDS array is sized by what the particles' boxes needed in the last scans (default;

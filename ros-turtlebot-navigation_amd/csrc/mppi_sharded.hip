@@ -214,16 +214,31 @@ int direct_partials_and_publish(tbnav_mppi* h, const double x0[3], const double*
 }  // namespace
 int tbnav_mh::sharded_tick(tbnav_mppi* h, const double x0[3], const double* d_duL, const double* d_duR, const uint64_t* seed, uint64_t tick, void* stream) {
   // an earlier tick's exchange failed (a bound expired, a rank's rollouts failed): say so now, not only at the next last_controls
-  { const int rc = exchange_error(h); if (rc != TBNAV_OK) return rc; }
+  const int rc_latched = exchange_error(h);
   if (h->direct_on) {
+    // (the direct exchange has a bound: no peer waits for ever for a rank that has stopped)
+    if (rc_latched != TBNAV_OK) return rc_latched;
     const int rc = direct_partials_and_publish(h, x0, d_duL, d_duR, seed, tick, stream);
-    // (a local failure here publishes nothing: the peers' combines run into the bound, leave their controls as they were and latch
-    //  the same error — the direct exchange needs no poison)
-    if (rc != TBNAV_OK) return rc;
+    if (rc != TBNAV_OK) {
+      // A local failure publishes nothing: the peers' combines run into the bound, leave their controls as they were and latch the
+      // error.  THIS rank latches too (round-5 advisor finding: it did not, and its next tick — same sequence number, the peers'
+      // records of the tick it never ran already in its buffer under that number — combined two different ticks and returned OK):
+      // bit 1 of its error words, as the all-gather path raises on every rank, and the sequence number moves on so that a stale
+      // tag can never match.
+      DeviceGuard guard(h->device);
+      if (h->h_dx_err) *h->h_dx_err |= 2;
+      if (h->d_dx_dead) { const int dead = 2; (void)hipMemcpy(h->d_dx_dead, &dead, sizeof dead, hipMemcpyHostToDevice); (void)hipGetLastError(); }
+      ++h->dx_seq;
+      return rc;
+    }
     DeviceGuard guard(h->device);
     return direct_combine(h, static_cast<hipStream_t>(stream));
   }
-  const int rc_local = sharded_partials(h, x0, d_duL, d_duR, seed, tick, stream);
+  // Through the communicator's all-gather, which has NO bound: a rank that knows of a failure — its own rollouts' now, or the latch an
+  // earlier tick's combine raised (a mapped host word: every rank sees it at its own time, round-5 advisor finding) — must not stay
+  // away from a collective its peers may already be in.  It JOINS, with records that say so, every tick, for as long as it is
+  // attached; the error is what it returns.
+  const int rc_local = rc_latched != TBNAV_OK ? rc_latched : sharded_partials(h, x0, d_duL, d_duR, seed, tick, stream);
   DeviceGuard guard(h->device);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t block = sizeof(double) * (size_t)h->T * h->S * TBNAV_MPPI_REC;

@@ -83,7 +83,7 @@ struct tbnav_rbpf {
   const double* last_z_ptr = nullptr;    // the resampling offset's normal of the last scan, wherever it is (last_normals + last_z_index, or d_zslot)
   // device noise drawn inside rbpf_propose (round 5; TBNAV_RBPF_OPT_NOISE_IN_KERNEL, default on): nothing is stored but the
   // resampling offset's normal; workgroup 0 of the proposal launch carries the beam table over and publishes beam_seq (NoiseSrc)
-  int noise_in_kernel = 1;   // TBNAV_RBPF_OPT_NOISE_IN_KERNEL
+  int noise_in_kernel = 0;   // TBNAV_RBPF_OPT_NOISE_IN_KERNEL (round 6: off by default — the stored-first form is the faster kernel and has no hand-over inside a launch)
   double* d_zslot = nullptr;
   unsigned int* d_beam_ready = nullptr;   // fine-grained
   double2* d_beams_fg = nullptr; int fg_beams_cap = 0;   // fine-grained copy of the beam table (NoiseSrc::fg_beams)
@@ -316,10 +316,11 @@ int build_scan_consts(tbnav_rbpf* h, ScanC& c, const float* scan, int n_beams, c
 }
 
 int status_from_err(const int err[4]) {
+  // (first: a scan whose beam table never arrived has computed nothing — whatever else is raised would be an artefact of that)
+  if (err[3] & 16) { tbnav::last_hip_error_slot() = "rbpf_propose: the scan's beam table never reached the device (the launch's leading workgroup never published it)"; return TBNAV_ERR_HIP; }
   if (err[0]) return TBNAV_ERR_OUT_OF_WORLD;
   if (err[2]) return TBNAV_ERR_PDF_VARIANCE;
   if (err[1]) return TBNAV_ERR_ETA_ZERO;
-  if (err[3] & 16) { tbnav::last_hip_error_slot() = "rbpf_propose: the scan's beam table never reached the device (the launch's leading workgroup never published it)"; return TBNAV_ERR_HIP; }
   if (err[3] & 8) return TBNAV_ERR_POOL_EXHAUSTED;  // no free log-odds tile left (the scan of that particle was not applied)
   if (err[3] & 4) return TBNAV_ERR_UNSUPPORTED;  // a likelihood lookup left the particle's refreshed window (cannot happen: see rbpf_window)
   if (err[3]) return TBNAV_ERR_BRESENHAM;
@@ -1966,7 +1967,11 @@ int sharded_scan(int n, tbnav_rbpf* const* hs, const float* scan, int n_beams, c
       if (e == hipSuccess) e = hipStreamSynchronize(hs[0]->stream);
       if (e != hipSuccess && local_fail == TBNAV_OK) local_fail = tbnav::hip_fail(e, "agree: status download", __FILE__, __LINE__); }
     for (int q = 0; q < P; ++q) if (all[q] != TBNAV_OK) { status = all[q]; break; }
-    if (local_fail != TBNAV_OK && status == TBNAV_OK) status = local_fail;   // (this rank stops; its peers learn of it at the next agreement, which it still joins)
+    // A failure of the agreement's own copies on THIS rank is not this scan's status (round-5 advisor finding: the rank returned
+    // while its peers, who agreed on OK, went on into the scan's next collectives and waited for it).  It is latched: the rank goes
+    // on with the agreed status, keeps joining this scan's collectives, and contributes the failure to the NEXT scan's first
+    // agreement, where every rank stops with it.
+    if (local_fail != TBNAV_OK) for (int r = 0; r < n; ++r) if (hs[r]->shard_latched == TBNAV_OK) hs[r]->shard_latched = local_fail;
     return TBNAV_OK;
   };
   std::memset(out, 0, sizeof *out);

@@ -631,7 +631,9 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
     // kReadyCopies copies of the sequence number, a cache line apart: a thousand workgroups looking at ONE word queue at the memory
     // side (a single address retires ~90 requests per microsecond: the first form of this cost every scan 80 us); workgroup b looks
     // at copy b mod kReadyCopies
-    if (threadIdx.x < kReadyCopies) __hip_atomic_store(ns.ready + threadIdx.x * kReadyStride, ns.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // (a RELEASE store, round 6: the table's stores above are ordered before the number by the language's rules too, not only by the
+    //  s_waitcnt + barrier — eight threads of one workgroup pay for it, once per scan)
+    if (threadIdx.x < kReadyCopies) __hip_atomic_store(ns.ready + threadIdx.x * kReadyStride, ns.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     return;
   }
   const unsigned int* const my_ready = dn ? ns.ready + (blockIdx.x & (kReadyCopies - 1)) * kReadyStride : nullptr;
@@ -742,20 +744,35 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
   if (have_beams) for (int b = tid; b < c.Bv; b += NT) lbeams[b] = beam_in(b);  // visible after the next barrier
   // (not published yet when this wave looked: wait for it just before the barrier in front of step 1 — bounded: a table that never
   //  arrives raises err[3] bit 4 instead of hanging the device)
-  auto late_beams = [&]() {
-    if (have_beams) return;
+  // Returns true (wave-uniform) when the table never came: the workgroup then leaves WITHOUT writing a pose or a weight (the callers
+  // turn the barrier that follows into a vote, round 6) — up to round 5 such a wave went on with whatever fg_beams held.
+  // On the consumer side the loads stay relaxed: every one of them is a system-scope access to fine-grained memory, served by the
+  // memory side and not by a cache, and a wave issues them in order after its lane 0 has SEEN the number — an acquire here is a cache
+  // invalidate per wave, four thousand per scan, which is what this form was built to avoid (gfx950 only, like the rest of the library;
+  // the default form — TBNAV_RBPF_OPT_NOISE_IN_KERNEL 0 — has no hand-over inside a launch at all).
+  auto late_beams = [&]() -> bool {
+    if (have_beams) return false;
+    int dead = 0;
     if (lane == 0) {
       // (bounded by a count of looks, not by the clock: wall_clock64 is a message to a unit every wave of the chip shares — four
       //  thousand waves asking it once per look serialised there and cost every scan 50 us; a look is a trip to the memory side,
       //  ~1 us with the sleep: the bound is a few tenths of a second)
       int looks = 0;
       while (__hip_atomic_load(my_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != ns.seq) {
-        if (++looks > 200000) { atomicOr(&err[3], 16); break; }
+        if (++looks > 200000) { atomicOr(&err[3], 16); dead = 1; break; }
         __builtin_amdgcn_s_sleep(8);
       }
     }
+    dead = __builtin_amdgcn_readfirstlane(dead);
     __builtin_amdgcn_wave_barrier();
+    if (dead) return true;
     for (int b = tid; b < c.Bv; b += NT) lbeams[b] = beam_in(b);   // (issued after lane 0 has SEEN the number; uncached: what was stored before it)
+    return false;
+  };
+  // the barrier behind late_beams(): with in-kernel noise it also carries the waves' "the table never came" to everybody
+  auto barrier_or_leave = [&](bool dead_wave) -> bool {
+    if (!dn) { __syncthreads(); return false; }
+    return __syncthreads_or(dead_wave ? 1 : 0) != 0;
   };
   for (int q = tid; q < kMixLds; q += NT) sh_mix[q] = mixlut[q];
   double Tc[4];  // sensor transform at the centre of the samples
@@ -826,11 +843,10 @@ __global__ __launch_bounds__(NT, TBNAV_PROPOSE_WAVES) void rbpf_propose(ScanC c,
       }
       ds.tany = ta; ds.R0 = R0; ds.R1 = R1; ds.W0 = W0; ds.nW = nW; ds.lut7 = sh_lut7;
     }
-    late_beams();
-    __syncthreads();
+    if (barrier_or_leave(late_beams())) return;   // (workgroup-uniform: nothing written yet)
     staged = true;
   }
-  if (!staged) { late_beams(); __syncthreads(); }  // lbeams / sh_mix / sh_def / sh_zz
+  if (!staged) { if (barrier_or_leave(late_beams())) return; }  // lbeams / sh_mix / sh_def / sh_zz
   TRACE_P(3);
   if (dn && c.icp_ok) { zz0 = sh_zz[0]; zz1 = sh_zz[1]; zz2 = sh_zz[2]; }
   zz0 = uniform_d(zz0); zz1 = uniform_d(zz1); zz2 = uniform_d(zz2); w_old = uniform_d(w_old);  // (arrived long ago; wave-uniform: scalar registers from here on)

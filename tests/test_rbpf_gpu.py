@@ -476,15 +476,16 @@ def test_device_noise_source_statistics_and_filter_health(gpu_pkg):
 
 @pytest.mark.parametrize("N,k,icp", [(64, 50, "ok"), (40, 300, "ok"), (33, 7, "alternating"), (1000, 50, "ok")])
 def test_noise_drawn_inside_the_proposal_kernel_equals_sampled_noise(gpu_pkg, N, k, icp):
-    """Round 5: with device noise the standard normals are drawn INSIDE rbpf_propose (nothing stored; the beam table rides in
-    through the launch's leading workgroup).  Same contract as MPPI's in-kernel sampler: the filter equals, bit for bit, (a) the
-    filter with TBNAV_RBPF_OPT_NOISE_IN_KERNEL = 0 (rbpf_sample_normals stores the stream first, as up to round 4) and (b) a
+    """Round 5: with device noise the standard normals can be drawn INSIDE rbpf_propose (TBNAV_RBPF_OPT_NOISE_IN_KERNEL = 1: nothing
+    stored; the beam table rides in through the launch's leading workgroup; since round 6 the option, not the default — the stored-first
+    kernel is the faster one).  Same contract as MPPI's in-kernel sampler: the filter equals, bit for bit, (a) the
+    filter with TBNAV_RBPF_OPT_NOISE_IN_KERNEL = 0 (rbpf_sample_normals stores the stream first, the default) and (b) a
     filter fed the regenerated stream (tbnav_rbpf_get_normals) as HOST normals — the path the oracle tests drive.  k = 300: more
     samples than threads; alternating: ICP-failed scans (three normals per particle); a forced resampling on the way (the
     resampling offset's normal is the one value the kernel does store)."""
     from rtn_amd import capi
     a, b, h = _dev(gpu_pkg, N=N, k=k), _dev(gpu_pkg, N=N, k=k), _dev(gpu_pkg, N=N, k=k)
-    b.setOption(capi.RBPF_OPT_NOISE_IN_KERNEL, 0)
+    a.setOption(capi.RBPF_OPT_NOISE_IN_KERNEL, 1)
     for pf in (a, b, h):
         pf.setSeed(4242)
     n_scans = 5
