@@ -187,7 +187,14 @@ int tbnav_mppi_shard_combine(tbnav_mppi* h, const double* d_records_all, int32_t
  * the combine of all shards' records, all enqueued on the tick's stream: no host round trip inside a tick, and every
  * rank ends with the same warm start (mppi.cpp:112-137 over the whole ensemble).  The device noise counter space is
  * set for rank * K ... of nranks * K (tbnav_mppi_set_rng_shard).  comm = NULL detaches.  The communicator must outlive
- * the handle's last tick; the handle does not own it. */
+ * the handle's last tick; the handle does not own it.
+ * Failures.  A rank whose own rollouts fail still JOINS the tick's all-gather, with records that say so; a combine that meets
+ * such a record leaves that time step's controls as they were (shifted, not updated) and latches the error on its rank — so every
+ * rank returns it from its next enqueue / last_controls / synchronize, and all warm starts stay identical.  A latched rank keeps
+ * joining the all-gather on every further tick (round 6: the latch is a word each rank sees at its own time, so no rank may stay
+ * away from a collective its peers could already be in) and keeps returning the error; detach and re-attach to go on.  The direct
+ * exchange (kind 2) has a bound instead: a rank that fails publishes nothing and latches itself, its peers latch when the bound
+ * expires. */
 struct tbnav_comm;
 int tbnav_mppi_attach_comm(tbnav_mppi* h, struct tbnav_comm* comm);
 /* How an attached handle's ticks exchange their records: 0 = no communicator attached; 1 = the communicator's all-gather (RCCL; copies

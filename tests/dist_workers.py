@@ -459,7 +459,7 @@ def mppi_rank_failure_worker(rank, world, K_local, horizon, failing_rank):
         m.lastControls(st.cuda_stream)
     except capi.TbnavError as e:
         last_msg = str(e)
-    try:   # latched on every rank: nobody enters the all-gather again
+    try:   # latched on every rank: each goes on JOINING the all-gather (round 6), with records that say so, and returns the error
         m.enqueueRng((0.0, 0.0, 0.0), 5, 3, st.cuda_stream)
     except capi.TbnavError as e:
         again_msg = str(e)

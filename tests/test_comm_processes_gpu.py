@@ -65,7 +65,10 @@ def test_a_rank_whose_rollouts_fail_stops_every_rank_with_controls_unchanged(gpu
         assert o["again"] is not None and "rollouts failed" in o["again"], (r, o["again"])
         assert o["waited"] < 30.0
         T = o["before"].shape[1]
-        expect = np.concatenate([o["before"][:, 1:], np.zeros((2, 1))], axis=1)   # the failed tick: shifted (mppi.cpp:134-137), NOT updated
+        # the failed tick AND the one after it: shifted (mppi.cpp:134-137), NOT updated.  (Round 6: a latched rank keeps JOINING the
+        # all-gather — with records that say "failed" — instead of staying away from a collective its peers may already be in: the
+        # latch is a mapped host word every rank sees at its own time.  Every rank's combine meets such a record in both ticks.)
+        expect = np.concatenate([o["before"][:, 2:], np.zeros((2, 2))], axis=1)
         assert o["after"].shape == (2, T) and np.array_equal(o["after"], expect), (r, np.abs(o["after"] - expect).max())
         assert np.all(np.isfinite(o["after"])) and np.all(np.isfinite(np.array(o["good"])))
     for r in range(1, world):
