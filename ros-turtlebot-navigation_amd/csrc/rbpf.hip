@@ -1,7 +1,6 @@
-// rbpf.hip — bmapping::ParticleFilter::SLAM on MI355X (gfx950) behind the C-ABI of include/tbnav_rbpf.h: the handle (device
-// state, tile pool, pinned result slots), the launch sequence of one scan, the reference-field mode's host side, the sharded
-// scan (tbnav_rbpf_attach_comm / tbnav_rbpf_group_*) and every extern "C" entry point.  Reference (paths relative to the
-// reference tree):
+// rbpf.hip — bmapping::ParticleFilter::SLAM on MI355X (gfx950) behind the C-ABI of include/tbnav_rbpf.h: the launch sequence of
+// one scan, create / destroy and tbnav_rbpf_slam.  The handle itself and the other host files (batch pipeline, sharded scan, blobs,
+// queries / options, reference-field plumbing): rbpf_host.hpp.  Reference (paths relative to the reference tree):
 //   bmapping/src/bmapping/particle_filter.cpp:141-251 (SLAM), :295-322, :383-437, :442-500, :504-599
 //   bmapping/src/bmapping/grid_mapper.cpp:69-182 (likelihood field, integrateScan), :549-898
 //   bmapping/src/bmapping/sensor_model.cpp:43-112 (laserEndPoints)
@@ -13,184 +12,10 @@
 //   rbpf_migrate.hip   particle blobs for the sharded filter's cross-rank resample
 //   rbpf_device.hpp    what they share: launch-argument structs, map accessors, reductions, kernel declarations
 //   rbpf_normalize.hpp the normalise / selection body (a kernel of its own and workgroup 0 of the map update)
-// (two small kernels of the reference-field mode's plumbing, rbpf_pack_logs / rbpf_copy_codes, stay here beside their only caller)
-#include <hip/hip_runtime.h>
+#include "rbpf_host.hpp"
 
-#include <algorithm>
-#include <cmath>
-#include <cstdlib>
-#include <cstring>
-#include <new>
-#include <type_traits>
-#include <atomic>
-#include <map>
-#include <thread>
-#include <vector>
-#include <sched.h>
+namespace tbnav_rh {
 
-#include "comm.hpp"
-#include "common.hpp"
-#include <chrono>
-#include "ref_field.hpp"
-#include "tbnav_rbpf.h"
-#include "rbpf_device.hpp"
-
-using namespace tbnav_rk;  // the launch-argument structs and the kernels (rbpf_device.hpp)
-
-
-// =================================================================================================
-// Handle + C-ABI
-// =================================================================================================
-struct tbnav_rbpf {
-  tbnav_rbpf_params p;
-  int device = 0, N = 0, k = 0, xsize = 0, ysize = 0, words = 0, radius = 0, edt_cols = 64;
-  size_t G = 0;
-  double l_prior = 0, l_occ = 0, l_free = 0, cut_occ = 0, max_occ_dist = 10.0;
-  // particle state: [N][7] = pose(3), prev_pose(3), weight — double-buffered with the maps
-  double* d_state[2] = {nullptr, nullptr};
-  // log-odds: tiled, copy-on-write (see TilePool).  The tables are double-buffered with the rest of the particle state.
-  TilePool pool{};
-  unsigned int* d_table[2] = {nullptr, nullptr};  // [N][TT]
-  unsigned int* d_shed = nullptr;                 // [N][TT]
-  int TW = 0, TT = 0;
-  double* d_dense = nullptr;   // [G] staging of one particle's dense log-odds (get/set_log_odds), allocated on first use
-  double* d_cs = nullptr;      // [N] prefix scratch of the normalise kernel (N > kNormChunk)
-  unsigned int* d_tile_scratch = nullptr;  // [TT] tile ids of a particle being exported
-  // sharded filter: normalise / select over the all-gathered weights (tbnav_rbpf_resample_global_dev)
-  double* d_gw = nullptr; double* d_gcs = nullptr; int* d_gparent = nullptr; double* d_gz = nullptr; size_t g_cap = 0;
-  unsigned long long* d_touched = nullptr;  // [2] measurement hook: cell updates / distinct cells written (tbnav_rbpf_scan_counts)
-  // rbpf_raycast_box's LDS array sized by what the particles' boxes needed in the last scans (device feedback, see the kernel)
-  int* d_box_need = nullptr;      // [3] words of LDS array the largest box of a launch needed; the slots take turns
-  int* h_box_need = nullptr;      // mapped pinned: the last complete launch's maximum
-  int* d_box_need_host = nullptr; // device view of h_box_need
-  unsigned int rc_launches = 0;   // box-counter launches so far (which slot accumulates)
-  int raycast_adapt = 1;          // TBNAV_RBPF_OPT_RAYCAST_ADAPT: 0 = size the array for the worst case of the scan's longest beam
-  bool count_touched = false;
-  // stored distance field, u16 [N][G] x 2: allocated on first need (injection, materialisation, the stored-field
-  // modes); the default query mode never touches it.  NULL until then.
-  uint16_t* d_code[2] = {nullptr, nullptr};
-  int* d_nocc[2] = {nullptr, nullptr};
-  int cur = 0;
-  int* d_trow[2] = {nullptr, nullptr};                   // [N][TW] occupied cells per tile row, kept current by the raycast kernel (the bits themselves live in the tiles)
-  unsigned long long* d_bm_dense = nullptr;              // [N][xsize][words] dense rows for the exact-transform kernels, rebuilt from the tiles on demand
-  int* d_rc_dense = nullptr;                             // [N][xsize]        (allocated with the stored field)
-  double2* d_beams = nullptr;  // capacity max_beams
-  int max_beams = 0;
-  double* d_normals = nullptr;
-  size_t normals_cap = 0;
-  const double* last_normals = nullptr;  // the normals the last scan used (d_normals, or an entry of the batch ring); NULL: drawn inside rbpf_propose
-  size_t last_z_index = 0;               // where in them its resampling offset sits (N * stride)
-  const double* last_z_ptr = nullptr;    // the resampling offset's normal of the last scan, wherever it is (last_normals + last_z_index, or d_zslot)
-  // device noise drawn inside rbpf_propose (round 5; TBNAV_RBPF_OPT_NOISE_IN_KERNEL, default on): nothing is stored but the
-  // resampling offset's normal; workgroup 0 of the proposal launch carries the beam table over and publishes beam_seq (NoiseSrc)
-  int noise_in_kernel = 0;   // TBNAV_RBPF_OPT_NOISE_IN_KERNEL (round 6: off by default — the stored-first form is the faster kernel and has no hand-over inside a launch)
-  double* d_zslot = nullptr;
-  unsigned int* d_beam_ready = nullptr;   // fine-grained
-  double2* d_beams_fg = nullptr; int fg_beams_cap = 0;   // fine-grained copy of the beam table (NoiseSrc::fg_beams)
-  unsigned int beam_seq = 0;
-  struct { unsigned long long seed = 0, scan = 0; size_t base = 0, z_index = 0, n = 0; bool valid = false; } last_drawn;  // what tbnav_rbpf_get_normals regenerates from
-  // tbnav_rbpf_slam_batch draws the noise of a few scans ahead in one launch: normals and beam tables of ring_scans scans
-  double* d_norm_ring = nullptr; size_t norm_ring_stride = 0;
-  double2* d_beam_ring = nullptr; double2* h_beam_ring = nullptr; size_t beam_ring_stride = 0;
-  int ring_scans = 0;
-  int* d_parent = nullptr;     // [2][N]: the parent of every slot | how many slots chose each particle
-  ExportCuts cuts{};           // host-derived (glibc) log-odds break points of the int8 map export
-  int* d_best = nullptr;       // arg-max particle index
-  double* d_best_pose = nullptr;
-  int8_t* d_export = nullptr;  // [G]
-  bool sm_on = false;          // N1 option: per-particle scan matching before sampling (tbnav_rbpf_set_scan_matching)
-  ScanMatchC sm{0.05, 0.05, 5, 64};
-  double* d_center = nullptr;  // [N][3] matched poses of the last call
-  // scratch of the batched export / import (tbnav_rbpf_export_batch_dev ...): grown on demand
-  int* d_bslots = nullptr; int2* d_bcount = nullptr; BatchItem* d_bitems = nullptr; BlobHeader* d_bhdr = nullptr; size_t batch_cap = 0;
-  std::vector<int2> batch_counts;  // tiles / field state of the slots counted last
-  double* d_mixlut = nullptr;  // [kMixLut] mixture term per distance code (constants of the handle: tabulated once at create)
-  double* d_score = nullptr;   // [N]
-  bool timing = false;         // record HIP events round the kernels (tbnav_rbpf_set_timing): each costs device time, so off by default
-  int tile_cap = 0;            // cells of the raycast LDS tile (0 = use the beam-ordered kernel)
-  int raycast_threads = 0;     // block size of the tile raycast: 0 = 1024 (TBNAV_RBPF_OPT_RAYCAST_THREADS)
-  std::vector<double2> beam_cs;  // (cos, sin) of every beam's angle in the sensor frame, kept between scans
-  std::vector<double2> beams_tmp;
-  int raycast_band_rows = 0;   // > 0: cap the LDS array of rbpf_raycast_box at about this many box rows (TBNAV_RBPF_OPT_RAYCAST_BAND_ROWS, tests)
-  int raycast_cell16 = 1;      // 0: never the 16-bit cell form; 1: where it buys a higher residency (default); 2: wherever it can run (TBNAV_RBPF_OPT_RAYCAST_CELL16)
-  int lk_raycast = -1, lk_raycast_wps = 0, lk_raycast_c16 = 0, lk_raycast_ev = 8, lk_raycast_grid = 0, lk_propose = 0, lk_propose_dn = 0, lk_box_need = 0, lk_box_cap = 0;  // the instantiations the last launches were (tbnav_rbpf_last_kernel_names): raycast threads (0 = beam-ordered), its workgroups, propose threads
-  double* d_sens = nullptr;    // [N][4] sensor transform (X, Y, sin, cos) of each particle's new pose, left by the proposal kernel
-  uint64_t seed = 0x5EEDull, scan_index = 0;  // device noise source (normals == NULL)
-  uint64_t rng_first = 0, rng_n_global = 0;   // sharded filters: this handle's particles are [rng_first, rng_first + N) of rng_n_global (0 = unsharded)
-  // sharded filter inside the library (tbnav_rbpf_attach_comm / tbnav_rbpf_group_*): the weights' all-gather and the global
-  // normalise / select run on a SECOND stream beside the local map update
-  tbnav_comm* comm = nullptr;
-  hipStream_t stream2 = nullptr;
-  hipEvent_t ev_w = nullptr, ev_g = nullptr;   // "the proposal kernel has left the weights" / (ev_g: unused since round 5 — the weights come back on the main stream)
-  int shard_latched = TBNAV_OK;                // a rank-local failure after a scan's last agreement: carried into the next scan's, where every rank stops with it
-  double* d_gw_raw = nullptr;                  // [n_global] all-gathered raw weights
-  char* d_sendbuf = nullptr; char* d_recvbuf = nullptr; size_t send_cap = 0, recv_cap = 0;   // particle blobs of a cross-rank resample
-  unsigned long long* d_sizes = nullptr;       // [n_local + n_global] blob size of every particle this rank sends | of every particle
-  int* d_status = nullptr;                     // [1 + nranks] this rank's status | everybody's
-  bool full_edt = false;       // distance-field mode 0 (TBNAV_RBPF_DF=full): whole-map transform after every map update
-  int df_mode = 2;             // 0 full, 1 windowed refresh before the update (TBNAV_RBPF_DF=window), 2 exact query at lookup (default)
-  int* d_fstate = nullptr;     // [N] distance-field state: 0 stale, 1 window fresh, 2 whole field fresh / injected
-  int* d_fstate_alt = nullptr; // [N] the other buffer of the resample gather
-  // reference distance-field mode (tbnav_rbpf_set_option DF_MODE = REFERENCE): host-side brushfire state + the
-  // device log of occupied-set changes it is fed from
-  bool ref_field = false;
-  tbnav::RefField* ref = nullptr;
-  // (which state — and how much of its journal — every field slot of d_code holds is the RefField's own bookkeeping: plan_flush)
-  tbnav::RefField::Flush ref_flush;       // the last flush's plan (buffers kept between scans)
-  int* d_pend = nullptr;                  // [N] cell + 1 of a lookup that landed on a cell the particle's pass has not written yet (kCodePending), else 0
-  int* h_pend = nullptr;                  // [N] pinned copy
-  double* d_state_snap = nullptr;         // [7 N] pose / prev_pose / weight before the proposal: a proposal that met pending cells is run again from here
-  uint2* d_jentries = nullptr; size_t jentries_cap = 0;   // the flush's packed (cell, code) pairs
-  uint3* d_jjobs = nullptr;               // [N] (offset, count, reset) per slot
-  int ref_reach = 3;                      // TBNAV_RBPF_OPT_REF_REACH: how far (cells) a scan's brushfire runs before it stops (0: to the end)
-  long long ref_reruns = 0;               // proposals run again because a lookup met a pending cell
-  long long ref_us[6] = {0, 0, 0, 0, 0, 0}; // host microseconds spent: fetching the logs | RefField::step | resample copies | flushes | before the proposal | the settle look
-  int* d_log_pack = nullptr; unsigned long long* d_log_off = nullptr; size_t log_pack_cap = 0, log_off_cap = 0;  // the scan's logs, packed
-  int* d_code_src = nullptr;              // [N] slot to copy the field from (rbpf_copy_codes)
-  int host_threads = 1;        // host threads of the reference-field mode's per-particle work (TBNAV_RBPF_OPT_HOST_THREADS; set at create)
-  int* d_log_ev = nullptr;     // [N][log_cap]
-  int* d_log_cnt = nullptr;    // [N]
-  int log_cap = 0;
-  uint64_t scans_done = 0;
-  int* d_skip = nullptr;       // [N] scratch: 1 = no refresh needed this call
-  int4* d_win = nullptr;       // [N] refreshed window (i0, i1, j0, j1), inclusive
-  int* d_tier = nullptr;       // [N] which distance-field kernel handles the particle this scan
-  int* d_err = nullptr;
-  NormOut* d_norm = nullptr;
-  // pinned host staging: the scan going in, the error flags and the normalisation result coming out (pageable
-  // buffers make every one of those small copies a blocking, staged transfer)
-  double2* h_beams = nullptr;  // [kScanSlots] x capacity max_beams
-  // error flags and normalisation result live in mapped pinned host memory: the kernels write them over the
-  // fabric (a handful of bytes per scan) and the host reads them after the stream sync — no copy kernels, no memset
-  // kScanSlots of each: a scan in flight owns slot (scan number % kScanSlots) — tbnav_rbpf_slam_batch keeps two scans in the
-  // stream; every other entry point uses slot 0
-  int* h_err = nullptr;        // [kScanSlots][4] host view; d_err is the device view of the same bytes
-  NormOut* h_norm = nullptr;   // [kScanSlots] host view of d_norm
-  int* d_gate = nullptr;       // [kScanSlots] device memory: 1 = that scan resamples (NormArgs::gate)
-  unsigned int* h_seq = nullptr;  // [kScanSlots] mapped: the scan number whose normalisation result the slot holds (NormArgs::seq)
-  unsigned int* d_seq = nullptr;  // device view of h_seq
-  bool fstate_dirty = true;    // some d_fstate entry may be non-zero
-  int batch_pipeline = 1;      // tbnav_rbpf_slam_batch keeps two scans in the stream (TBNAV_RBPF_OPT_BATCH_PIPELINE)
-  double* d_trace = nullptr;   // sampled, p_scan, p_pose, mu, sigma, eta, new_pose, weight_raw
-  Trace tr{};
-  hipStream_t stream = nullptr;
-  hipEvent_t ev[TBNAV_RBPF_NKERNELS + 2] = {};  // 0..5 bracket kernels 0..4; 6,7 bracket the gather
-  float last_ms[TBNAV_RBPF_NKERNELS] = {0};
-  std::vector<int> h_parent;
-};
-
-namespace {
-
-struct DeviceGuard {
-  int prev = -1;
-  bool ok = false;
-  explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(dev) == hipSuccess) ok = true; }
-  ~DeviceGuard() { if (ok && prev >= 0) (void)hipSetDevice(prev); }
-};
-
-// state layout helpers: the kernels take pose / prev_pose / weight pointers with [N][3] / [N] strides,
-// so the 7-double record is split into three arrays inside one allocation.
-struct StatePtrs { double *pose, *prev, *weight; };
 StatePtrs state_ptrs(double* base, int N) { return {base, base + (size_t)3 * N, base + (size_t)6 * N}; }
 MapT map_of(const tbnav_rbpf* h) { return MapT{h->d_table[h->cur], h->d_shed, h->TW, h->TT}; }
 
@@ -408,245 +233,12 @@ int resample_on_device(tbnav_rbpf* h) {
   return TBNAV_OK;
 }
 
-// ---- reference distance-field mode (ref_field.hpp) ------------------------------------------------------------
-// Before the raycast: a log big enough for every cell update of the scan (a cell can enter and leave the occupied set
-// more than once in one scan).
-int ref_field_prepare_log(tbnav_rbpf* h, int Bv, OccLog& log) {
-  const double reach = (double)h->p.range_max + std::hypot(h->p.Trs[1], h->p.Trs[2]);
-  const long per_ray = (long)std::ceil(reach / h->p.resolution) + 4;
-  const long cap = (long)std::max(Bv, 1) * per_ray;
-  if ((size_t)cap * h->N * sizeof(int) > ((size_t)1 << 30)) return TBNAV_ERR_UNSUPPORTED;
-  if (cap > h->log_cap) {
-    (void)hipFree(h->d_log_ev); h->d_log_ev = nullptr; h->log_cap = 0;
-    TBNAV_HIP(hipMalloc((void**)&h->d_log_ev, sizeof(int) * (size_t)cap * h->N));
-    h->log_cap = (int)cap;
-  }
-  if (!h->d_log_cnt) TBNAV_HIP(hipMalloc((void**)&h->d_log_cnt, sizeof(int) * h->N));
-  TBNAV_HIP(hipMemsetAsync(h->d_log_cnt, 0, sizeof(int) * h->N, h->stream));
-  log = OccLog{h->d_log_ev, h->d_log_cnt, h->log_cap};
-  return TBNAV_OK;
-}
-// After the scan (and its resample, if one fired): replay the logged set changes, run the reference's brushfire for
-// every particle as it was BEFORE the resample (the reference integrates the scan in the particle loop and resamples
-// afterwards, particle_filter.cpp:158-249), copy like the resample did, and make the result the authoritative field.
-// the particles' logged sequences packed back to back (one copy to the host instead of one per particle)
-__global__ __launch_bounds__(256) void rbpf_pack_logs(const int* __restrict__ ev, int log_cap, int p_first, const unsigned long long* __restrict__ off,
-                                                      int* __restrict__ out) {
-  const int i = blockIdx.x;
-  const unsigned long long o = off[i], n = off[i + 1] - o;
-  const int* src = ev + (size_t)(p_first + i) * log_cap;
-  for (unsigned long long q = threadIdx.x; q < n; q += blockDim.x) out[o + q] = src[q];
-}
-// slot p takes the field slot src[p] holds (src[p] == p: keep) — the particles that share a state with one whose whole image was uploaded
-__global__ __launch_bounds__(256) void rbpf_copy_codes(uint16_t* __restrict__ code, size_t G, const int* __restrict__ src) {
-  const int p = blockIdx.y, q = src[p];
-  if (q == p) return;
-  const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
-  if ((G & 7) == 0) {  // (every slot starts on a 16-byte boundary)
-    const uint4* s = reinterpret_cast<const uint4*>(code + (size_t)q * G);
-    uint4* d = reinterpret_cast<uint4*>(code + (size_t)p * G);
-    for (size_t i = i0; i < G / 8; i += step) d[i] = s[i];
-  } else {
-    for (size_t i = i0; i < G; i += step) code[(size_t)p * G + i] = code[(size_t)q * G + i];
-  }
-}
-// The journal of field slot p (ref_field.hpp, plan_flush): optionally "everything pending" first, then `count` (cell, code) pairs —
-// every cell at most once per launch.  One workgroup per slot.
-__global__ __launch_bounds__(256) void rbpf_field_journal(uint16_t* __restrict__ code, size_t G, const uint3* __restrict__ jobs, const uint2* __restrict__ entries) {
-  const int p = blockIdx.x;
-  const uint3 j = jobs[p];
-  if (!j.y && !j.z) return;
-  uint16_t* const slot = code + (size_t)p * G;
-  if (j.z) {
-    const unsigned int fill = (unsigned int)kCodePending * 0x10001u;
-    if ((G & 7) == 0) {
-      uint4* d = reinterpret_cast<uint4*>(slot);
-      for (size_t i = threadIdx.x; i < G / 8; i += blockDim.x) d[i] = make_uint4(fill, fill, fill, fill);
-    } else {
-      for (size_t i = threadIdx.x; i < G; i += blockDim.x) slot[i] = kCodePending;
-    }
-    __threadfence();
-    __syncthreads();
-  }
-  for (unsigned int e = threadIdx.x; e < j.y; e += blockDim.x) {
-    const uint2 v = entries[j.x + e];
-    slot[v.x] = (uint16_t)v.y;
-  }
-}
-// Bring the device's field slots to where the host's states are: whole images for slots whose content is unknown (or whose state
-// has become exact and complete), journal ranges for the others.  Synchronises the stream (the plan's host buffers are read).
-struct UsTimer {   // adds the enclosing scope's wall time to a counter
-  long long& acc; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-  explicit UsTimer(long long& a) : acc(a) {}
-  ~UsTimer() { acc += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(); }
-};
-int ref_field_flush(tbnav_rbpf* h) {
-  UsTimer ut(h->ref_us[3]);
-  const int N = h->N;
-  hipStream_t st = h->stream;
-  tbnav::RefField::Flush& f = h->ref_flush;
-  h->ref->plan_flush(f);
-  if (f.dense_slot.empty() && !f.any_job) return TBNAV_OK;
-  bool any_copy = false;
-  std::vector<int> src;
-  for (size_t q = 0; q < f.dense_slot.size(); ++q) {
-    if (f.dense_img[q] >= 0)
-      TBNAV_HIP(hipMemcpyAsync(h->d_code[h->cur] + (size_t)f.dense_slot[q] * h->G, f.images[f.dense_img[q]].data(), sizeof(uint16_t) * h->G, hipMemcpyHostToDevice, st));
-    else {
-      if (src.empty()) { src.resize(N); for (int p = 0; p < N; ++p) src[p] = p; }
-      src[f.dense_slot[q]] = f.dense_src[q];
-      any_copy = true;
-    }
-  }
-  if (any_copy) {
-    if (!h->d_code_src) TBNAV_HIP(hipMalloc((void**)&h->d_code_src, sizeof(int) * N));
-    TBNAV_HIP(hipMemcpyAsync(h->d_code_src, src.data(), sizeof(int) * N, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(rbpf_copy_codes, dim3(64, N), dim3(256), 0, st, h->d_code[h->cur], h->G, h->d_code_src);
-    TBNAV_HIP(hipGetLastError());
-  }
-  if (f.any_job) {
-    static_assert(sizeof(tbnav::RefField::JEntry) == sizeof(uint2) && sizeof(tbnav::RefField::Flush::Job) == sizeof(uint3), "the plan's records are what the kernel reads");
-    if (f.entries.size() > h->jentries_cap) {
-      TBNAV_HIP(hipStreamSynchronize(st));
-      (void)hipFree(h->d_jentries); h->d_jentries = nullptr; h->jentries_cap = 0;
-      const size_t cap = f.entries.size() + f.entries.size() / 2 + 4096;
-      TBNAV_HIP(hipMalloc((void**)&h->d_jentries, sizeof(uint2) * cap));
-      h->jentries_cap = cap;
-    }
-    if (!h->d_jjobs) TBNAV_HIP(hipMalloc((void**)&h->d_jjobs, sizeof(uint3) * N));
-    if (!f.entries.empty()) TBNAV_HIP(hipMemcpyAsync(h->d_jentries, f.entries.data(), sizeof(uint2) * f.entries.size(), hipMemcpyHostToDevice, st));
-    TBNAV_HIP(hipMemcpyAsync(h->d_jjobs, f.jobs.data(), sizeof(uint3) * N, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(rbpf_field_journal, dim3(N), dim3(256), 0, st, h->d_code[h->cur], h->G, h->d_jjobs, h->d_jentries);
-    TBNAV_HIP(hipGetLastError());
-  }
-  TBNAV_HIP(hipStreamSynchronize(st));
-  return TBNAV_OK;
-}
-// The whole field of one particle as the reference holds it, on the device (exports, the one-particle entry points): the pass is run
-// to the end, stale cells are recovered by replaying the lineage where they are not known (ref_field.hpp).
-int ref_field_materialize(tbnav_rbpf* h, int particle) {
-  if (!h->ref->codes(particle)) {
-    tbnav::last_hip_error_slot() = "reference-field mode: a whole field was asked for whose stale cells need history beyond the history budget";
-    return TBNAV_ERR_UNSUPPORTED;
-  }
-  const int rc = ref_field_flush(h);
-  if (rc != TBNAV_OK) return rc;
-  const int two = 2;
-  TBNAV_HIP(hipMemcpy(h->d_fstate + particle, &two, sizeof two, hipMemcpyHostToDevice));
-  h->fstate_dirty = true;
-  return TBNAV_OK;
-}
-// Before the proposal of a scan: the slots in step with the states (imports and exports since the last scan), the particle state
-// kept for a second run, the pending flags cleared.
-int ref_field_before_propose(tbnav_rbpf* h) {
-  UsTimer ut(h->ref_us[4]);
-  const int N = h->N;
-  { const int rc = ensure_codes(h); if (rc != TBNAV_OK) return rc; }
-  if (!h->d_pend) {
-    TBNAV_HIP(hipMalloc((void**)&h->d_pend, sizeof(int) * N));
-    TBNAV_HIP(hipHostMalloc((void**)&h->h_pend, sizeof(int) * N, hipHostMallocDefault));
-    TBNAV_HIP(hipMalloc((void**)&h->d_state_snap, sizeof(double) * 7 * N));
-  }
-  if (h->sm_on) {   // the per-particle scan matcher reads whole fields: every pass to the end (the option is not the reference's filter)
-    for (int p = 0; p < N; ++p) if (!h->ref->codes(p)) return TBNAV_ERR_UNSUPPORTED;
-  }
-  { const int rc = ref_field_flush(h); if (rc != TBNAV_OK) return rc; }
-  TBNAV_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->d_fstate), 2, N, h->stream));
-  h->fstate_dirty = true;
-  TBNAV_HIP(hipMemcpyAsync(h->d_state_snap, h->d_state[h->cur], sizeof(double) * 7 * N, hipMemcpyDeviceToDevice, h->stream));
-  TBNAV_HIP(hipMemsetAsync(h->d_pend, 0, sizeof(int) * N, h->stream));
-  return TBNAV_OK;
-}
-// After the proposal: did a lookup land on a cell its particle's pass has not written?  Then exactly those states are resumed on the
-// host (RefField::ensure), the new cells go to the device, and the proposal runs again from the kept particle state — until none
-// does.  (A closed room never gets here: its beams end within a cell or two of the obstacles the last scans integrated.)
-template <class Relaunch>
-int ref_field_settle(tbnav_rbpf* h, int* h_err, Relaunch relaunch) {
-  const int N = h->N;
-  hipStream_t st = h->stream;
-  std::vector<int> ps, cs;
-  for (int round = 0; round < 4096; ++round) {
-    {
-      UsTimer ut(h->ref_us[5]);
-      TBNAV_HIP(hipMemcpyAsync(h->h_pend, h->d_pend, sizeof(int) * N, hipMemcpyDeviceToHost, st));
-      TBNAV_HIP(hipStreamSynchronize(st));
-    }
-    ps.clear(); cs.clear();
-    for (int p = 0; p < N; ++p) if (h->h_pend[p]) { ps.push_back(p); cs.push_back(h->h_pend[p] - 1); }
-    if (ps.empty()) return TBNAV_OK;
-    const int rc = h->ref->ensure(ps.data(), cs.data(), (int)ps.size(), h->host_threads);
-    if (rc == -1) {
-      tbnav::last_hip_error_slot() = "reference-field mode: a lookup needs a stale cell whose history is beyond the history budget";
-      return TBNAV_ERR_UNSUPPORTED;
-    }
-    if (rc != 0) { tbnav::last_hip_error_slot() = "reference-field mode: a replayed pass differs from the pass it re-ran (internal error)"; return TBNAV_ERR_HIP; }
-    { const int rf = ref_field_flush(h); if (rf != TBNAV_OK) return rf; }
-    TBNAV_HIP(hipMemcpyAsync(h->d_state[h->cur], h->d_state_snap, sizeof(double) * 7 * N, hipMemcpyDeviceToDevice, st));
-    TBNAV_HIP(hipMemsetAsync(h->d_pend, 0, sizeof(int) * N, st));
-    for (int q = 0; q < 4; ++q) h_err[q] = 0;   // (mapped; the stream is idle)
-    ++h->ref_reruns;
-    const int rl = relaunch();
-    if (rl != TBNAV_OK) return rl;
-  }
-  return TBNAV_ERR_UNSUPPORTED;
-}
-int ref_field_after_scan(tbnav_rbpf* h, bool resampled, int p_first = 0, int p_count = -1) {
-  const int N = h->N;
-  if (p_count < 0) p_count = N;
-  { const int rc = ensure_codes(h); if (rc != TBNAV_OK) return rc; }
-  hipStream_t st = h->stream;
-  TBNAV_HIP(hipStreamSynchronize(st));
-  auto t_log0 = std::chrono::steady_clock::now();
-  std::vector<int> cnt(N);
-  TBNAV_HIP(hipMemcpy(cnt.data(), h->d_log_cnt, sizeof(int) * N, hipMemcpyDeviceToHost));
-  // the logs: packed on the device, ONE copy (a few thousand events per particle; one small copy each was 10-20 ms per 1000)
-  std::vector<size_t> off((size_t)p_count + 1, 0);
-  for (int i = 0; i < p_count; ++i) {
-    if (cnt[p_first + i] > h->log_cap) return TBNAV_ERR_UNSUPPORTED;  // cannot happen: the log holds every cell update
-    off[i + 1] = off[i] + (size_t)cnt[p_first + i];
-  }
-  const size_t total = off[p_count];
-  std::vector<int> all(total ? total : 1);
-  if (total) {
-    if (total > h->log_pack_cap || (size_t)p_count + 1 > h->log_off_cap) {
-      (void)hipFree(h->d_log_pack); (void)hipFree(h->d_log_off); h->d_log_pack = nullptr; h->d_log_off = nullptr; h->log_pack_cap = h->log_off_cap = 0;
-      const size_t cap = total + total / 2, ocap = (size_t)N + 1;
-      TBNAV_HIP(hipMalloc((void**)&h->d_log_pack, sizeof(int) * cap));
-      TBNAV_HIP(hipMalloc((void**)&h->d_log_off, sizeof(unsigned long long) * ocap));
-      h->log_pack_cap = cap; h->log_off_cap = ocap;
-    }
-    std::vector<unsigned long long> off64(off.begin(), off.end());
-    TBNAV_HIP(hipMemcpy(h->d_log_off, off64.data(), sizeof(unsigned long long) * off64.size(), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(rbpf_pack_logs, dim3(p_count), dim3(256), 0, st, h->d_log_ev, h->log_cap, p_first, h->d_log_off, h->d_log_pack);
-    TBNAV_HIP(hipGetLastError());
-    TBNAV_HIP(hipMemcpyAsync(all.data(), h->d_log_pack, sizeof(int) * total, hipMemcpyDeviceToHost, st));
-    TBNAV_HIP(hipStreamSynchronize(st));
-  }
-  // one replay + brushfire per distinct (state, sequence) — ref_field.hpp — side by side on the host's cores: inside one state the
-  // order of every set and heap operation is the reference's
-  h->ref_us[0] += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_log0).count();
-  h->ref->set_reach(h->ref_reach);
-  { UsTimer ut(h->ref_us[1]); h->ref->step(p_first, p_count, h->host_threads, all.data(), off.data()); }
-  if (resampled) {
-    UsTimer ut(h->ref_us[2]);
-    h->h_parent.resize(N);
-    TBNAV_HIP(hipMemcpy(h->h_parent.data(), h->d_parent, sizeof(int) * N, hipMemcpyDeviceToHost));
-    h->ref->resample(h->h_parent.data());   // (the device's gather has moved the field slots the same way: resample_on_device)
-  }
-  // to the device: what each pass wrote, as a journal on top of the parent's image the slot holds
-  { const int rc = ref_field_flush(h); if (rc != TBNAV_OK) return rc; }
-  TBNAV_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->d_fstate), 2, N, st));
-  TBNAV_HIP(hipStreamSynchronize(st));
-  h->fstate_dirty = true;
-  return TBNAV_OK;
-}
-
 // GridMapper::integrateScan's map update (grid_mapper.cpp:140-178) for particles [c.p0, c.p0 + count) at their poses.
 // sens: the sensor transforms the proposal kernel left for exactly these poses (NULL: the raycast derives them).
 // nz (optional): the weights' normalise / select step to run with this update — inside the box-counter kernel's launch as
 // workgroup 0 (no second stream, no event), behind the other map-update kernels as a launch of its own.
-int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens, const NormArgs* nz = nullptr, int* err = nullptr,
-                   const double2* beams_dev = nullptr) {
+int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens, const NormArgs* nz, int* err,
+                   const double2* beams_dev) {
   if (!err) err = h->d_err;
   if (!beams_dev) beams_dev = h->d_beams;
   const int* gp = nz ? nz->gate_prev : nullptr;
@@ -761,7 +353,7 @@ int launch_raycast(tbnav_rbpf* h, const ScanC& c, int count, const double* sens,
 }
 
 // the scan's valid beams into d_beams (shared by slam_impl and the one-particle entry points)
-int upload_beams(tbnav_rbpf* h, const std::vector<double2>& beams, int n_beams, int Bv, bool stage_only = false, int slot = 0) {
+int upload_beams(tbnav_rbpf* h, const std::vector<double2>& beams, int n_beams, int Bv, bool stage_only, int slot) {
   if (n_beams > h->max_beams) {
     TBNAV_HIP(hipStreamSynchronize(h->stream));  // (a scan still in flight reads the buffers about to go)
     (void)hipFree(h->d_beams);
@@ -779,17 +371,10 @@ int upload_beams(tbnav_rbpf* h, const std::vector<double2>& beams, int n_beams, 
   return TBNAV_OK;
 }
 
-// One scan = scan_enqueue (everything up to and including the map update, on the handle's stream) + scan_finish (wait,
-// read the stats, run the resampling copies if the scan decided to resample).  `slot`: which of the kScanSlots result slots
-// the scan owns.  gate_prev (device pointer or NULL): the resampling decision of the scan enqueued before this one, when the
-// host has not seen it yet — the kernels of this scan do nothing if it is set (tbnav_rbpf_slam_batch).
-struct ScanTicket { int slot = 0; int n_valid = 0; bool local_only = false; bool poll = false; unsigned int seq = 0; };
-// A scan whose constants, beam table and noise are on the device already (tbnav_rbpf_slam_batch prepares a few scans at a time).
-struct Prefetched { ScanC c; int rc = TBNAV_OK; const double2* d_beams = nullptr; const double* d_normals = nullptr; };
 int scan_enqueue(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], const double cur_odom[3],
                  const double prev_odom[3], int icp_ok, const double T_icp[3], const double* normals,
                  tbnav_rbpf_stats* out, bool local_only, int slot, const int* gate_prev, ScanTicket& tk,
-                 const Prefetched* pre = nullptr, hipEvent_t weights_ready = nullptr) {
+                 const Prefetched* pre, hipEvent_t weights_ready) {
   hipStream_t st = h->stream;
   int* const d_err = h->d_err + 4 * slot;
   int* const h_err = h->h_err + 4 * slot;
@@ -1064,10 +649,6 @@ int scan_finish(tbnav_rbpf* h, const ScanTicket& tk, tbnav_rbpf_stats* out) {
   return out->status;
 }
 
-int sharded_scan(int n, tbnav_rbpf* const* hs, const float* scan, int n_beams, const double u[3], const double cur_odom[3],
-                 const double prev_odom[3], int icp_ok, const double T_icp[3], const double* const* normals, tbnav_rbpf_stats* out,
-                 tbnav_rbpf_stats* local_out);
-
 int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], const double cur_odom[3],
               const double prev_odom[3], int icp_ok, const double T_icp[3], const double* normals,
               tbnav_rbpf_stats* out, bool local_only) {
@@ -1084,11 +665,6 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
   return scan_finish(h, tk, out);
 }
 
-}  // namespace
-
-extern "C" {
-
-namespace {
 // host threads for the reference-field mode: the cores this process may run on — its affinity mask, and under a cgroup CPU quota
 // (cpu.max: a container that sees 128 CPUs but may use 32 of them) no more than that — at most 128; TBNAV_RBPF_OPT_HOST_THREADS
 // overrides.  (Round 4 capped this at 32: the bench box has more.)
@@ -1309,7 +885,10 @@ int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf*
   *out = h;
   return TBNAV_OK;
 }
-}  // namespace
+
+}  // namespace tbnav_rh
+
+extern "C" {
 
 int tbnav_rbpf_create(const tbnav_rbpf_params* P, tbnav_rbpf** out) { return create_impl(P, 0, out); }
 int tbnav_rbpf_create_pool(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf** out) { return create_impl(P, max_pool_bytes, out); }
@@ -1416,1273 +995,6 @@ int tbnav_rbpf_slam(tbnav_rbpf* h, const float* scan, int32_t n_beams, const dou
                     const double prev_odom[3], int32_t icp_ok, const double T_icp[3], const double* normals,
                     tbnav_rbpf_stats* out) {
   return slam_impl(h, scan, n_beams, u, cur_odom, prev_odom, icp_ok, T_icp, normals, out, false);
-}
-
-int tbnav_rbpf_slam_batch(tbnav_rbpf* h, const float* scans, int32_t n_beams, int32_t n_scans, const double* u, const double* odom,
-                          const int32_t* icp_ok, const double* T_icp, tbnav_rbpf_stats* out) {
-  if (!h || !scans || n_scans <= 0 || !u || !odom || !T_icp || !out) return TBNAV_ERR_INVALID_ARG;
-  // Two scans in the stream at a time: scan s + 1 is enqueued BEFORE the host waits for scan s, on the assumption that scan
-  // s does not resample — its kernels check scan s's decision on the device (NormArgs::gate) and do nothing if it does; the
-  // host then runs the copies and enqueues scan s + 1 again.  Between scans the device waits for nothing, and the results
-  // are those of n_scans synchronous calls, bit for bit.  Only in the default configuration (distance look-ups by query: no
-  // per-scan field refresh on the stream; no event timing; not the reference-field mode).
-  const bool pipelined = n_scans > 1 && h->batch_pipeline && h->df_mode == 2 && !h->full_edt && !h->ref_field && !h->timing && !h->rng_n_global;
-  if (!pipelined) {
-    for (int s = 0; s < n_scans; ++s) {
-      const int rc = slam_impl(h, scans + (size_t)s * n_beams, n_beams, u + 3 * s, odom + 3 * (s + 1), odom + 3 * s, icp_ok ? icp_ok[s] : 1,
-                               T_icp + 3 * s, nullptr, out + s, false);
-      if (rc != TBNAV_OK) return rc;
-    }
-    return TBNAV_OK;
-  }
-  if (n_beams <= 0) return TBNAV_ERR_INVALID_ARG;
-  DeviceGuard guard(h->device);
-  // The noise and the beam tables of the next few scans are put on the device by ONE launch per chunk (same Philox counters
-  // as one launch per scan: same values), so that a scan is two launches — proposal, map update — back to back.
-  const size_t norm_stride = (((size_t)h->N * (3 * (size_t)h->k + 3) + 1) + 1) & ~(size_t)1;
-  int chunk = 8;
-  while (chunk > 2 && (size_t)chunk * norm_stride * sizeof(double) > ((size_t)512 << 20)) --chunk;
-  const bool ahead = chunk >= 3;  // (the host rewrites the pinned staging of chunk c + 1 once scan 0 of chunk c is through)
-  if (ahead && (h->ring_scans != chunk || h->norm_ring_stride != norm_stride || h->beam_ring_stride != (size_t)n_beams)) {
-    TBNAV_HIP(hipStreamSynchronize(h->stream));
-    (void)hipFree(h->d_norm_ring); (void)hipFree(h->d_beam_ring); (void)hipHostFree(h->h_beam_ring);
-    h->d_norm_ring = nullptr; h->d_beam_ring = nullptr; h->h_beam_ring = nullptr; h->ring_scans = 0;
-    TBNAV_HIP(hipMalloc((void**)&h->d_norm_ring, sizeof(double) * norm_stride * chunk));
-    TBNAV_HIP(hipMalloc((void**)&h->d_beam_ring, sizeof(double2) * (size_t)n_beams * chunk));
-    TBNAV_HIP(hipHostMalloc((void**)&h->h_beam_ring, sizeof(double2) * (size_t)n_beams * chunk, hipHostMallocDefault));
-    std::memset(h->h_beam_ring, 0, sizeof(double2) * (size_t)n_beams * chunk);
-    h->ring_scans = chunk; h->norm_ring_stride = norm_stride; h->beam_ring_stride = (size_t)n_beams;
-  }
-  const unsigned long long scan0 = h->scan_index;  // noise counter of the batch's first scan
-  std::vector<Prefetched> pre(ahead ? chunk : 0);
-  int prepared_to = 0;  // scans [0, prepared_to) have had their chunk prepared
-  int chunk_first = 0;  // the first scan of the chunk prepared last: scan s of it uses slot s - chunk_first of the rings
-  auto prepare = [&](int first) -> int {
-    // The call's FIRST chunk is two scans: the host's share of a chunk (the scans' beam tables, ~5 us each) sits in front of the
-    // call's first launch, where nothing hides it — a call of 6 scans cost 40 us on top of its scans, one of 3 cost 21.  Later chunks
-    // are prepared while two scans are in the stream.  (Two, not one: the pinned staging of a chunk is rewritten when the next is
-    // prepared, during the iteration of its last scan — by then the scan before that has been waited for, and with it the launch
-    // that read the staging, only if the chunk had two scans at least.)
-    const int m = std::min(first == 0 ? 2 : chunk, n_scans - first);
-    chunk_first = first;
-    for (int j = 0; j < m; ++j) {
-      const int s = first + j;
-      Prefetched& q = pre[j];
-      q.rc = build_scan_consts(h, q.c, scans + (size_t)s * n_beams, n_beams, u + 3 * s, odom + 3 * (s + 1), odom + 3 * s,
-                               icp_ok ? icp_ok[s] : 1, T_icp + 3 * s, h->beams_tmp);
-      q.d_beams = h->d_beam_ring + (size_t)j * n_beams;
-      q.d_normals = h->d_norm_ring + (size_t)j * norm_stride;
-      if (q.rc == TBNAV_OK && q.c.Bv) std::memcpy(h->h_beam_ring + (size_t)j * n_beams, h->beams_tmp.data(), sizeof(double2) * q.c.Bv);
-    }
-    const int blocks = (int)std::min<size_t>((norm_stride / 2 + 255) / 256, 4096);
-    hipLaunchKernelGGL(rbpf_sample_normals, dim3(blocks, m), dim3(256), 0, h->stream, norm_stride, (unsigned long long)h->seed,
-                       scan0 + (unsigned long long)first, h->d_norm_ring, (const double2*)h->h_beam_ring, h->d_beam_ring, n_beams,
-                       norm_stride, (size_t)n_beams);
-    TBNAV_HIP(hipGetLastError());
-    prepared_to = first + m;
-    return TBNAV_OK;
-  };
-  ScanTicket tk[2];
-  auto enqueue = [&](int s, const int* gate_prev) -> int {
-    if (ahead && s >= prepared_to) { const int rc = prepare(s); if (rc != TBNAV_OK) return rc; }
-    ScanTicket& t = tk[s & 1];
-    t = ScanTicket{};
-    t.poll = true;
-    h->scan_index = scan0 + (unsigned long long)s;  // (scan_enqueue counts it)
-    return scan_enqueue(h, scans + (size_t)s * n_beams, n_beams, u + 3 * s, odom + 3 * (s + 1), odom + 3 * s, icp_ok ? icp_ok[s] : 1,
-                        T_icp + 3 * s, nullptr, out + s, false, s % kScanSlots, gate_prev, t, ahead ? &pre[s - chunk_first] : nullptr);
-  };
-  int rc = enqueue(0, nullptr);
-  if (rc != TBNAV_OK) return rc;
-  for (int s = 0; s < n_scans; ++s) {
-    const int rc_next = s + 1 < n_scans ? enqueue(s + 1, h->d_gate + s % kScanSlots) : TBNAV_OK;
-    rc = scan_finish(h, tk[s & 1], out + s);
-    if (rc == TBNAV_OK && s > 0) {
-      // scan s - 1 was finished when its weights were normalised, while its map update was still running; that launch is
-      // complete now (scan s ran behind it): anything it flagged after that?
-      const int late = status_from_err(h->h_err + 4 * ((s - 1) % kScanSlots));
-      if (late != TBNAV_OK) {
-        (void)hipStreamSynchronize(h->stream);
-        out[s - 1].status = late;
-        std::memset(out + s, 0, sizeof(tbnav_rbpf_stats) * (size_t)(n_scans - s));
-        return late;
-      }
-    }
-    if (rc != TBNAV_OK || rc_next != TBNAV_OK) {
-      (void)hipStreamSynchronize(h->stream);  // (whatever of scan s + 1 is in the stream: the filter's state after an error is unspecified)
-      return rc != TBNAV_OK ? rc : rc_next;
-    }
-    if (out[s].resampled && s + 1 < n_scans) {
-      // scan s + 1's launches did nothing: same scan number, same noise, again — on the resampled particles
-      --h->scans_done;
-      rc = enqueue(s + 1, nullptr);
-      if (rc != TBNAV_OK) { (void)hipStreamSynchronize(h->stream); return rc; }
-    }
-  }
-  TBNAV_HIP(hipStreamSynchronize(h->stream));  // the last scan's map update
-  out[n_scans - 1].status = status_from_err(h->h_err + 4 * ((n_scans - 1) % kScanSlots));
-  return out[n_scans - 1].status;
-}
-
-int tbnav_rbpf_slam_local(tbnav_rbpf* h, const float* scan, int32_t n_beams, const double u[3], const double cur_odom[3],
-                          const double prev_odom[3], int32_t icp_ok, const double T_icp[3], const double* normals,
-                          tbnav_rbpf_stats* out) {
-  return slam_impl(h, scan, n_beams, u, cur_odom, prev_odom, icp_ok, T_icp, normals, out, true);
-}
-
-// Host-side, sequential, bit-faithful: O(n_global) double adds — the exchange step of the sharded
-// filter; every rank runs it on the same all-gathered weights.
-int tbnav_rbpf_resample_global(const double* w, int64_t n, double z, int32_t* parents, double* wn, tbnav_rbpf_stats* out) {
-  if (!w || n <= 0 || !parents || !wn || !out) return TBNAV_ERR_INVALID_ARG;
-  std::memset(out, 0, sizeof *out);
-  double sum = 0.0;
-  for (int64_t i = 0; i < n; ++i) sum += w[i];
-  double sq = 0.0;
-  for (int64_t i = 0; i < n; ++i) { wn[i] = w[i] / sum; sq += wn[i] * wn[i]; }
-  out->sum_w = sum; out->sq_sum = sq;
-  out->neff = static_cast<int>(1.0 / sq);
-  const int N = (int)n;
-  out->resampled = (out->neff < (N / 2)) ? 1 : 0;
-  if (!out->resampled) { for (int m = 0; m < N; ++m) parents[m] = m; return TBNAV_OK; }
-  const double r = z / static_cast<double>(N);
-  double c = wn[0];
-  int i = 0;
-  for (int m = 0; m < N; ++m) {
-    const double U = r + static_cast<double>(m * (1.0 / (N - 1)));
-    while (U > c) {
-      i++;
-      if (i > N - 1) { i = N - 1; break; }
-      c += wn[i];
-    }
-    parents[m] = i;
-  }
-  return TBNAV_OK;
-}
-
-int tbnav_rbpf_add_repeated(const double* x, const double* d, const int32_t* n, double* out, int64_t count) {
-  if (!x || !d || !n || !out || count <= 0 || count > (1 << 26)) return TBNAV_ERR_INVALID_ARG;
-  double *dx = nullptr, *dd = nullptr, *dout = nullptr;
-  int* dn = nullptr;
-  int rc = TBNAV_OK;
-  auto body = [&]() -> int {
-    TBNAV_HIP(hipMalloc((void**)&dx, sizeof(double) * count)); TBNAV_HIP(hipMalloc((void**)&dd, sizeof(double) * count));
-    TBNAV_HIP(hipMalloc((void**)&dout, sizeof(double) * count)); TBNAV_HIP(hipMalloc((void**)&dn, sizeof(int) * count));
-    TBNAV_HIP(hipMemcpy(dx, x, sizeof(double) * count, hipMemcpyHostToDevice)); TBNAV_HIP(hipMemcpy(dd, d, sizeof(double) * count, hipMemcpyHostToDevice));
-    TBNAV_HIP(hipMemcpy(dn, n, sizeof(int) * count, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(rbpf_add_repeated_test, dim3((unsigned int)((count + 255) / 256)), dim3(256), 0, 0, dx, dd, dn, dout, (int)count);
-    TBNAV_HIP(hipGetLastError());
-    TBNAV_HIP(hipMemcpy(out, dout, sizeof(double) * count, hipMemcpyDeviceToHost));
-    return TBNAV_OK;
-  };
-  rc = body();
-  (void)hipFree(dx); (void)hipFree(dd); (void)hipFree(dout); (void)hipFree(dn);
-  return rc;
-}
-
-int tbnav_rbpf_gather_local(tbnav_rbpf* h, const int32_t* local_parent) {
-  if (!h || !local_parent) return TBNAV_ERR_INVALID_ARG;
-  if (h->ref_field) return TBNAV_ERR_UNSUPPORTED;  // the reference-field mode is a single-handle mode
-  DeviceGuard guard(h->device);
-  const int N = h->N;
-  // slots with parent -1 keep their own content: copy self
-  std::vector<int> par(local_parent, local_parent + N);
-  par.resize(2 * (size_t)N, 0);  // [N, 2N): how many slots chose each particle
-  for (int m = 0; m < N; ++m) { if (par[m] < 0) par[m] = m; if (par[m] >= N) return TBNAV_ERR_INVALID_ARG; ++par[N + par[m]]; }
-  TBNAV_HIP(hipMemcpyAsync(h->d_parent, par.data(), sizeof(int) * 2 * N, hipMemcpyHostToDevice, h->stream));
-  TBNAV_HIP(hipStreamSynchronize(h->stream));  // par is a local
-  const int rc = resample_on_device(h);
-  if (rc != TBNAV_OK) return rc;
-  TBNAV_HIP(hipStreamSynchronize(h->stream));
-  return TBNAV_OK;
-}
-
-// ---- device-side exchange for the sharded filter -------------------------------------------------------------
-int tbnav_rbpf_copy_weights_dev(tbnav_rbpf* h, double* d_dst) {
-  if (!h || !d_dst) return TBNAV_ERR_INVALID_ARG;
-  DeviceGuard guard(h->device);
-  StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
-  TBNAV_HIP(hipMemcpyAsync(d_dst, sp.weight, sizeof(double) * h->N, hipMemcpyDeviceToDevice, h->stream));
-  TBNAV_HIP(hipStreamSynchronize(h->stream));
-  return TBNAV_OK;
-}
-
-int tbnav_rbpf_resample_global_dev(tbnav_rbpf* h, const double* d_weights_all, int64_t n_global, int64_t offset, double z,
-                                   int32_t* parents_out, tbnav_rbpf_stats* out) {
-  if (!h || !d_weights_all || n_global <= 0 || offset < 0 || offset + h->N > n_global || !out || n_global > (1 << 24)) return TBNAV_ERR_INVALID_ARG;
-  DeviceGuard guard(h->device);
-  hipStream_t st = h->stream;
-  if ((size_t)n_global > h->g_cap) {
-    (void)hipFree(h->d_gw); (void)hipFree(h->d_gcs); (void)hipFree(h->d_gparent); h->d_gw = h->d_gcs = nullptr; h->d_gparent = nullptr; h->g_cap = 0;
-    (void)hipFree(h->d_gw_raw); h->d_gw_raw = nullptr;  // (the in-library sharded scan sizes its buffers with the same capacity: it re-creates them)
-    TBNAV_HIP(hipMalloc((void**)&h->d_gw, sizeof(double) * n_global));
-    TBNAV_HIP(hipMalloc((void**)&h->d_gcs, sizeof(double) * n_global));
-    TBNAV_HIP(hipMalloc((void**)&h->d_gparent, sizeof(int) * n_global));
-    h->g_cap = (size_t)n_global;
-  }
-  if (!h->d_gz) TBNAV_HIP(hipMalloc((void**)&h->d_gz, sizeof(double)));
-  if (z != z) {  // NaN: the offset the last scan's device noise carries (with tbnav_rbpf_set_rng_shard: the ENSEMBLE's, same on every rank)
-    if (!h->last_z_ptr) return TBNAV_ERR_INVALID_ARG;
-    TBNAV_HIP(hipMemcpyAsync(h->d_gz, h->last_z_ptr, sizeof z, hipMemcpyDeviceToDevice, st));
-  } else
-  TBNAV_HIP(hipMemcpyAsync(h->d_gz, &z, sizeof z, hipMemcpyHostToDevice, st));
-  *h->h_norm = NormOut{};
-  // the reference's sequential normalise / Neff / selection (particle_filter.cpp:442-500) over the GLOBAL vector:
-  // every rank runs the same kernel on the same values, so all ranks agree bit for bit
-  hipLaunchKernelGGL(rbpf_normalize, dim3(1), dim3(256), 0, st, (int)n_global, h->d_gz, d_weights_all, h->d_gw, h->d_gcs, h->d_gparent, h->d_norm);
-  TBNAV_HIP(hipGetLastError());
-  StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
-  TBNAV_HIP(hipMemcpyAsync(sp.weight, h->d_gw + offset, sizeof(double) * h->N, hipMemcpyDeviceToDevice, st));
-  TBNAV_HIP(hipStreamSynchronize(st));
-  const NormOut no = *h->h_norm;
-  std::memset(out, 0, sizeof *out);
-  out->sum_w = no.sum_w; out->sq_sum = no.sq_sum; out->neff = no.neff; out->resampled = no.resampled;
-  if (no.resampled && parents_out) TBNAV_HIP(hipMemcpy(parents_out, h->d_gparent, sizeof(int) * n_global, hipMemcpyDeviceToHost));
-  return TBNAV_OK;
-}
-
-namespace {
-int batch_scratch(tbnav_rbpf* h, size_t n) {
-  if (n <= h->batch_cap) return TBNAV_OK;
-  (void)hipFree(h->d_bslots); (void)hipFree(h->d_bcount); (void)hipFree(h->d_bitems); (void)hipFree(h->d_bhdr);
-  h->d_bslots = nullptr; h->d_bcount = nullptr; h->d_bitems = nullptr; h->d_bhdr = nullptr; h->batch_cap = 0;
-  const size_t cap = n + n / 2 + 64;
-  TBNAV_HIP(hipMalloc((void**)&h->d_bslots, sizeof(int) * cap));
-  TBNAV_HIP(hipMalloc((void**)&h->d_bcount, sizeof(int2) * cap));
-  TBNAV_HIP(hipMalloc((void**)&h->d_bitems, sizeof(BatchItem) * cap));
-  TBNAV_HIP(hipMalloc((void**)&h->d_bhdr, sizeof(BlobHeader) * cap));
-  h->batch_cap = cap;
-  return TBNAV_OK;
-}
-}  // namespace
-
-int tbnav_rbpf_set_weights_from_global_dev(tbnav_rbpf* h, const int32_t* global_parent_of_slot /*[N]*/) {
-  // after a resample every slot carries its parent's normalised weight (weights are NOT reset, particle_filter.cpp:495)
-  if (!h || !global_parent_of_slot || !h->d_gw) return TBNAV_ERR_INVALID_ARG;
-  DeviceGuard guard(h->device);
-  StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
-  for (int m = 0; m < h->N; ++m)
-    if (global_parent_of_slot[m] < 0 || (size_t)global_parent_of_slot[m] >= h->g_cap) return TBNAV_ERR_INVALID_ARG;
-  { const int rc = batch_scratch(h, (size_t)h->N); if (rc != TBNAV_OK) return rc; }
-  TBNAV_HIP(hipMemcpyAsync(h->d_bslots, global_parent_of_slot, sizeof(int) * h->N, hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(rbpf_gather_weights, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, h->N, h->d_gw, h->d_bslots, sp.weight);
-  TBNAV_HIP(hipGetLastError());
-  TBNAV_HIP(hipStreamSynchronize(h->stream));  // (the parent list is the caller's)
-  return TBNAV_OK;
-}
-
-namespace {
-BlobLayout blob_layout(const tbnav_rbpf* h, uint32_t n_tiles, bool has_codes) { return blob_layout_hd(h->TW, h->G, n_tiles, has_codes); }
-int slot_tiles(tbnav_rbpf* h, int slot, std::vector<uint32_t>& tidx, std::vector<uint32_t>& ids, int& fstate) {
-  std::vector<uint32_t> row(h->TT);
-  TBNAV_HIP(hipStreamSynchronize(h->stream));
-  TBNAV_HIP(hipMemcpy(row.data(), h->d_table[h->cur] + (size_t)slot * h->TT, sizeof(uint32_t) * h->TT, hipMemcpyDeviceToHost));
-  TBNAV_HIP(hipMemcpy(&fstate, h->d_fstate + slot, sizeof(int), hipMemcpyDeviceToHost));
-  tidx.clear(); ids.clear();
-  for (int t = 0; t < h->TT; ++t) if (row[t]) { tidx.push_back((uint32_t)t); ids.push_back(row[t]); }
-  return TBNAV_OK;
-}
-}  // namespace
-
-int tbnav_rbpf_export_size(tbnav_rbpf* h, int32_t slot, uint64_t* bytes) {
-  if (!h || !bytes || slot < 0 || slot >= h->N) return TBNAV_ERR_INVALID_ARG;
-  DeviceGuard guard(h->device);
-  std::vector<uint32_t> tidx, ids; int fs = 0;
-  { const int rc = slot_tiles(h, slot, tidx, ids, fs); if (rc != TBNAV_OK) return rc; }
-  *bytes = blob_layout(h, (uint32_t)tidx.size(), fs == 2 && h->d_code[0]).total;
-  return TBNAV_OK;
-}
-
-int tbnav_rbpf_export_particle_dev(tbnav_rbpf* h, int32_t slot, void* d_buf, uint64_t capacity, uint64_t* bytes) {
-  if (!h || !d_buf || slot < 0 || slot >= h->N) return TBNAV_ERR_INVALID_ARG;
-  DeviceGuard guard(h->device);
-  hipStream_t st = h->stream;
-  std::vector<uint32_t> tidx, ids; int fs = 0;
-  { const int rc = slot_tiles(h, slot, tidx, ids, fs); if (rc != TBNAV_OK) return rc; }
-  const bool has_codes = fs == 2 && h->d_code[0];
-  const uint32_t n = (uint32_t)tidx.size();
-  const BlobLayout L = blob_layout(h, n, has_codes);
-  if (bytes) *bytes = L.total;
-  if (L.total > capacity) return TBNAV_ERR_INVALID_ARG;
-  char* b = static_cast<char*>(d_buf);
-  BlobHeader hd{kBlobMagic, n, has_codes ? 1u : 0u, 0, fs, (uint32_t)h->xsize, (uint32_t)h->TT};
-  TBNAV_HIP(hipMemcpy(&hd.nocc, h->d_nocc[h->cur] + slot, sizeof(int), hipMemcpyDeviceToHost));
-  TBNAV_HIP(hipMemcpy(b, &hd, sizeof hd, hipMemcpyHostToDevice));
-  StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
-  double* bs = reinterpret_cast<double*>(b + L.state);
-  TBNAV_HIP(hipMemcpyAsync(bs, sp.pose + (size_t)slot * 3, sizeof(double) * 3, hipMemcpyDeviceToDevice, st));
-  TBNAV_HIP(hipMemcpyAsync(bs + 3, sp.prev + (size_t)slot * 3, sizeof(double) * 3, hipMemcpyDeviceToDevice, st));
-  TBNAV_HIP(hipMemcpyAsync(bs + 6, sp.weight + slot, sizeof(double), hipMemcpyDeviceToDevice, st));
-  if (n) {
-    TBNAV_HIP(hipMemcpy(b + L.tidx, tidx.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
-    TBNAV_HIP(hipMemcpy(h->d_tile_scratch, ids.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(rbpf_pack_tiles, dim3(n), dim3(256), 0, st, h->pool, h->d_tile_scratch, reinterpret_cast<double*>(b + L.tiles),
-                       reinterpret_cast<unsigned int*>(b + L.tile_bm));
-    TBNAV_HIP(hipGetLastError());
-  }
-  TBNAV_HIP(hipMemcpyAsync(b + L.trow, h->d_trow[h->cur] + (size_t)slot * h->TW, sizeof(int) * h->TW, hipMemcpyDeviceToDevice, st));
-  if (has_codes) TBNAV_HIP(hipMemcpyAsync(b + L.codes, h->d_code[h->cur] + (size_t)slot * h->G, sizeof(uint16_t) * h->G, hipMemcpyDeviceToDevice, st));
-  TBNAV_HIP(hipStreamSynchronize(st));
-  return TBNAV_OK;
-}
-
-int tbnav_rbpf_import_particle_dev(tbnav_rbpf* h, int32_t slot, const void* d_buf, uint64_t bytes) {
-  if (!h || !d_buf || slot < 0 || slot >= h->N || bytes < sizeof(BlobHeader)) return TBNAV_ERR_INVALID_ARG;
-  DeviceGuard guard(h->device);
-  hipStream_t st = h->stream;
-  const char* b = static_cast<const char*>(d_buf);
-  BlobHeader hd{};
-  TBNAV_HIP(hipStreamSynchronize(st));
-  TBNAV_HIP(hipMemcpy(&hd, b, sizeof hd, hipMemcpyDeviceToHost));
-  if (hd.magic != kBlobMagic || hd.xsize != (uint32_t)h->xsize || hd.TT != (uint32_t)h->TT || hd.n_tiles > (uint32_t)h->TT) return TBNAV_ERR_INVALID_ARG;
-  const BlobLayout L = blob_layout(h, hd.n_tiles, hd.has_codes != 0);
-  if (L.total > bytes) return TBNAV_ERR_INVALID_ARG;
-  if (hd.has_codes) { const int rc = ensure_codes(h); if (rc != TBNAV_OK) return rc; }
-  const MapT M = map_of(h);
-  for (int q = 0; q < 4; ++q) h->h_err[q] = 0;
-  hipLaunchKernelGGL(rbpf_release_slot, dim3((h->TT + 255) / 256), dim3(256), 0, st, h->pool, M, slot);
-  TBNAV_HIP(hipGetLastError());
-  if (hd.n_tiles) {
-    hipLaunchKernelGGL(rbpf_unpack_tiles, dim3(hd.n_tiles), dim3(256), 0, st, h->pool, M, slot, reinterpret_cast<const unsigned int*>(b + L.tidx),
-                       reinterpret_cast<const double*>(b + L.tiles), reinterpret_cast<const unsigned int*>(b + L.tile_bm), h->d_err);
-    TBNAV_HIP(hipGetLastError());
-  }
-  StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
-  const double* bs = reinterpret_cast<const double*>(b + L.state);
-  TBNAV_HIP(hipMemcpyAsync(sp.pose + (size_t)slot * 3, bs, sizeof(double) * 3, hipMemcpyDeviceToDevice, st));
-  TBNAV_HIP(hipMemcpyAsync(sp.prev + (size_t)slot * 3, bs + 3, sizeof(double) * 3, hipMemcpyDeviceToDevice, st));
-  TBNAV_HIP(hipMemcpyAsync(sp.weight + slot, bs + 6, sizeof(double), hipMemcpyDeviceToDevice, st));
-  TBNAV_HIP(hipMemcpyAsync(h->d_trow[h->cur] + (size_t)slot * h->TW, b + L.trow, sizeof(int) * h->TW, hipMemcpyDeviceToDevice, st));
-  TBNAV_HIP(hipMemcpyAsync(h->d_nocc[h->cur] + slot, &hd.nocc, sizeof(int), hipMemcpyHostToDevice, st));
-  const int fs = hd.has_codes ? 2 : 0;
-  if (hd.has_codes) {
-    TBNAV_HIP(hipMemcpyAsync(h->d_code[h->cur] + (size_t)slot * h->G, b + L.codes, sizeof(uint16_t) * h->G, hipMemcpyDeviceToDevice, st));
-    h->fstate_dirty = true;
-  }
-  TBNAV_HIP(hipMemcpyAsync(h->d_fstate + slot, &fs, sizeof(int), hipMemcpyHostToDevice, st));
-  TBNAV_HIP(hipStreamSynchronize(st));  // hd / fs are locals
-  if (h->h_err[3] & 8) return TBNAV_ERR_POOL_EXHAUSTED;
-  return TBNAV_OK;
-}
-
-// ---- the same for many particles at once (what a cross-rank resample needs: hundreds of particles per rank) ------------
-namespace {
-int count_batch(tbnav_rbpf* h, int32_t n, const int32_t* slots) {
-  for (int i = 0; i < n; ++i) if (slots[i] < 0 || slots[i] >= h->N) return TBNAV_ERR_INVALID_ARG;
-  { const int rc = batch_scratch(h, (size_t)n); if (rc != TBNAV_OK) return rc; }
-  h->batch_counts.resize(n);
-  TBNAV_HIP(hipMemcpyAsync(h->d_bslots, slots, sizeof(int) * n, hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(rbpf_count_tiles, dim3(n), dim3(256), 0, h->stream, map_of(h), h->d_bslots, h->d_fstate, h->d_bcount);
-  TBNAV_HIP(hipGetLastError());
-  TBNAV_HIP(hipMemcpyAsync(h->batch_counts.data(), h->d_bcount, sizeof(int2) * n, hipMemcpyDeviceToHost, h->stream));
-  TBNAV_HIP(hipStreamSynchronize(h->stream));
-  return TBNAV_OK;
-}
-}  // namespace
-
-int tbnav_rbpf_export_batch_sizes(tbnav_rbpf* h, int32_t n, const int32_t* slots, uint64_t* sizes_out) {
-  if (!h || n < 0 || (n && (!slots || !sizes_out))) return TBNAV_ERR_INVALID_ARG;
-  if (n == 0) return TBNAV_OK;
-  DeviceGuard guard(h->device);
-  { const int rc = count_batch(h, n, slots); if (rc != TBNAV_OK) return rc; }
-  for (int i = 0; i < n; ++i)
-    sizes_out[i] = blob_layout(h, (uint32_t)h->batch_counts[i].x, h->batch_counts[i].y == 2 && h->d_code[0]).total;
-  return TBNAV_OK;
-}
-
-int tbnav_rbpf_export_batch_dev(tbnav_rbpf* h, int32_t n, const int32_t* slots, void* d_buf, uint64_t capacity, uint64_t* offsets_out) {
-  if (!h || n < 0 || (n && (!slots || !d_buf || !offsets_out))) return TBNAV_ERR_INVALID_ARG;
-  if (n == 0) { if (offsets_out) offsets_out[0] = 0; return TBNAV_OK; }
-  DeviceGuard guard(h->device);
-  // (counted again rather than trusting what tbnav_rbpf_export_batch_sizes saw: a scan in between would change the tables;
-  //  a tiny launch and one 8-byte-per-particle copy)
-  { const int rc = count_batch(h, n, slots); if (rc != TBNAV_OK) return rc; }
-  std::vector<BatchItem> items(n);
-  uint64_t off = 0;
-  for (int i = 0; i < n; ++i) {
-    const bool has_codes = h->batch_counts[i].y == 2 && h->d_code[0];
-    items[i] = BatchItem{slots[i], (unsigned int)h->batch_counts[i].x, has_codes ? 1 : 0, 0, off};
-    offsets_out[i] = off;
-    off += blob_layout(h, items[i].n_tiles, has_codes).total;
-  }
-  offsets_out[n] = off;
-  if (off > capacity) return TBNAV_ERR_INVALID_ARG;
-  StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
-  TBNAV_HIP(hipMemcpyAsync(h->d_bitems, items.data(), sizeof(BatchItem) * n, hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(rbpf_pack_batch, dim3(n), dim3(256), 0, h->stream, h->pool, map_of(h), sp.pose, sp.prev, sp.weight, h->d_trow[h->cur],
-                     h->d_nocc[h->cur], h->d_fstate, h->d_code[h->cur], h->G, h->xsize, h->d_bitems, static_cast<char*>(d_buf));
-  TBNAV_HIP(hipGetLastError());
-  TBNAV_HIP(hipStreamSynchronize(h->stream));  // (items is a local; the caller sends the buffer next)
-  return TBNAV_OK;
-}
-
-int tbnav_rbpf_import_batch_dev(tbnav_rbpf* h, int32_t n, const int32_t* slots, const void* d_buf, uint64_t bytes, const uint64_t* offsets) {
-  if (!h || n < 0 || (n && (!slots || !d_buf || !offsets))) return TBNAV_ERR_INVALID_ARG;
-  if (n == 0) return TBNAV_OK;
-  DeviceGuard guard(h->device);
-  std::vector<char> seen(h->N, 0);
-  std::vector<BatchItem> items(n);
-  for (int i = 0; i < n; ++i) {
-    if (slots[i] < 0 || slots[i] >= h->N || seen[slots[i]] || offsets[i] + sizeof(BlobHeader) > bytes || (offsets[i] & 7)) return TBNAV_ERR_INVALID_ARG;
-    seen[slots[i]] = 1;  // (a slot receives one particle; one particle may fill several slots)
-    items[i] = BatchItem{slots[i], 0u, 0, 0, offsets[i]};
-  }
-  { const int rc = batch_scratch(h, (size_t)n); if (rc != TBNAV_OK) return rc; }
-  hipStream_t st = h->stream;
-  const char* b = static_cast<const char*>(d_buf);
-  TBNAV_HIP(hipMemcpyAsync(h->d_bitems, items.data(), sizeof(BatchItem) * n, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(rbpf_blob_headers, dim3((n + 255) / 256), dim3(256), 0, st, h->d_bitems, b, h->d_bhdr, n);
-  TBNAV_HIP(hipGetLastError());
-  std::vector<BlobHeader> hd(n);
-  TBNAV_HIP(hipMemcpyAsync(hd.data(), h->d_bhdr, sizeof(BlobHeader) * n, hipMemcpyDeviceToHost, st));
-  TBNAV_HIP(hipStreamSynchronize(st));
-  bool any_codes = false;
-  for (int i = 0; i < n; ++i) {
-    if (hd[i].magic != kBlobMagic || hd[i].xsize != (uint32_t)h->xsize || hd[i].TT != (uint32_t)h->TT || hd[i].n_tiles > (uint32_t)h->TT) return TBNAV_ERR_INVALID_ARG;
-    if (offsets[i] + blob_layout(h, hd[i].n_tiles, hd[i].has_codes != 0).total > bytes) return TBNAV_ERR_INVALID_ARG;
-    any_codes |= hd[i].has_codes != 0;
-  }
-  if (any_codes) { const int rc = ensure_codes(h); if (rc != TBNAV_OK) return rc; h->fstate_dirty = true; }
-  {
-    // Does the pool hold what is coming?  Checked BEFORE the destination slots give their tiles up: the incoming tiles against
-    // the free ones plus every tile the slots name now (an upper bound of what releasing them returns).  Beyond that the import
-    // cannot succeed and nothing is touched; inside the bound it goes ahead (tiles the slots share with particles that stay do
-    // not come back: the unpack kernel then reports the exhaustion, with the slots' maps already released — see the header).
-    uint64_t incoming = 0;
-    for (int i = 0; i < n; ++i) incoming += hd[i].n_tiles;
-    unsigned long long ctr[2] = {0, 0};
-    TBNAV_HIP(hipMemcpy(ctr, h->pool.ctr, sizeof ctr, hipMemcpyDeviceToHost));
-    const uint64_t free_now = ctr[1] - ctr[0];
-    if (incoming > free_now) {
-      std::vector<int> sl(n);
-      for (int i = 0; i < n; ++i) sl[i] = slots[i];
-      { const int rc = count_batch(h, n, sl.data()); if (rc != TBNAV_OK) return rc; }
-      uint64_t named = 0;
-      for (int i = 0; i < n; ++i) named += (uint64_t)h->batch_counts[i].x;
-      if (incoming > free_now + named) return TBNAV_ERR_POOL_EXHAUSTED;
-      TBNAV_HIP(hipMemcpyAsync(h->d_bitems, items.data(), sizeof(BatchItem) * n, hipMemcpyHostToDevice, st));  // (count_batch reused the scratch's slot list only)
-    }
-  }
-  for (int q = 0; q < 4; ++q) h->h_err[q] = 0;
-  const MapT M = map_of(h);
-  StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
-  hipLaunchKernelGGL(rbpf_release_slots, dim3(n), dim3(256), 0, st, h->pool, M, h->d_bitems);  // pushes: all before the first pop
-  TBNAV_HIP(hipGetLastError());
-  hipLaunchKernelGGL(rbpf_unpack_batch, dim3(n), dim3(256), 0, st, h->pool, M, sp.pose, sp.prev, sp.weight, h->d_trow[h->cur], h->d_nocc[h->cur],
-                     h->d_fstate, h->d_code[h->cur], h->G, h->d_bitems, b, h->d_err);
-  TBNAV_HIP(hipGetLastError());
-  TBNAV_HIP(hipStreamSynchronize(st));
-  if (h->h_err[3] & 8) return TBNAV_ERR_POOL_EXHAUSTED;
-  return TBNAV_OK;
-}
-
-}  // extern "C"
-
-// =================================================================================================
-// The sharded filter inside the library (include/tbnav_comm.h)
-// =================================================================================================
-namespace {
-
-int ensure_shard_state(tbnav_rbpf* h) {
-  const int P = tbnav::comm_size(h->comm);
-  const size_t ng = (size_t)P * h->N;
-  if (!h->stream2) TBNAV_HIP(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
-  if (!h->ev_w) TBNAV_HIP(hipEventCreateWithFlags(&h->ev_w, hipEventDisableTiming));
-  if (!h->ev_g) TBNAV_HIP(hipEventCreateWithFlags(&h->ev_g, hipEventDisableTiming));
-  if (ng > h->g_cap || !h->d_gw_raw) {
-    TBNAV_HIP(hipStreamSynchronize(h->stream));
-    TBNAV_HIP(hipStreamSynchronize(h->stream2));
-    (void)hipFree(h->d_gw); (void)hipFree(h->d_gcs); (void)hipFree(h->d_gparent); (void)hipFree(h->d_gw_raw); (void)hipFree(h->d_sizes); (void)hipFree(h->d_status);
-    h->d_gw = h->d_gcs = h->d_gw_raw = nullptr; h->d_gparent = nullptr; h->d_sizes = nullptr; h->d_status = nullptr; h->g_cap = 0;
-    TBNAV_HIP(hipMalloc((void**)&h->d_gw, sizeof(double) * ng));
-    TBNAV_HIP(hipMalloc((void**)&h->d_gcs, sizeof(double) * ng));
-    TBNAV_HIP(hipMalloc((void**)&h->d_gw_raw, sizeof(double) * ng));
-    TBNAV_HIP(hipMalloc((void**)&h->d_gparent, sizeof(int) * ng));
-    TBNAV_HIP(hipMalloc((void**)&h->d_sizes, sizeof(unsigned long long) * ((size_t)h->N + ng)));
-    TBNAV_HIP(hipMalloc((void**)&h->d_status, sizeof(int) * (1 + (size_t)P)));
-    h->g_cap = ng;
-  }
-  return TBNAV_OK;
-}
-
-int grow(char*& buf, size_t& cap, size_t need) {
-  if (need <= cap) return TBNAV_OK;
-  (void)hipFree(buf); buf = nullptr; cap = 0;
-  const size_t want = need + need / 4 + 4096;
-  TBNAV_HIP(hipMalloc((void**)&buf, want));
-  cap = want;
-  return TBNAV_OK;
-}
-
-// ParticleFilter::SLAM over the members' shards.  n == 1: this process's rank of a multi-process filter; n > 1: every member of a
-// one-process group, in rank order.  Per scan and member, on the device:
-//   main stream   noise -> propose -> [event: weights final] -> map update ........................ -> (resample: migration)
-//   second stream                      wait -> ONE all-gather of the raw weights -> the reference's sequential normalise /
-//                                      Neff / selection over the GLOBAL vector (identical on every rank) -> own slice back
-// so the chain of adds of the global normalise (which grows with the ensemble, not with the shard) runs BESIDE the local map
-// update, and the host waits once, for both streams.  Only when resampling fires do particles move: one all-gather of blob
-// sizes, one batched export per rank, one message per (source, destination) pair, one batched import (tbnav_rbpf_export_batch_*
-// / _import_batch_dev), and an all-gather of the ranks' statuses so that a rank whose pool is exhausted stops everybody.
-int sharded_scan(int n, tbnav_rbpf* const* hs, const float* scan, int n_beams, const double u[3], const double cur_odom[3],
-                 const double prev_odom[3], int icp_ok, const double T_icp[3], const double* const* normals, tbnav_rbpf_stats* out,
-                 tbnav_rbpf_stats* local_out) {
-  if (n <= 0 || !hs || !scan || n_beams <= 0 || !u || !cur_odom || !prev_odom || !T_icp || !out) return TBNAV_ERR_INVALID_ARG;
-  for (int r = 0; r < n; ++r) if (!hs[r] || !hs[r]->comm || hs[r]->N != hs[0]->N || hs[r]->ref_field) return TBNAV_ERR_INVALID_ARG;
-  // (made at attach and never resized while attached — tbnav_rbpf_attach_comm; a handle without them was never attached)
-  for (int r = 0; r < n; ++r) if (!hs[r]->d_gw_raw || !hs[r]->d_status || !hs[r]->stream2 || (size_t)tbnav::comm_size(hs[r]->comm) * hs[r]->N > hs[r]->g_cap) return TBNAV_ERR_INVALID_ARG;
-  const int P = tbnav::comm_size(hs[0]->comm), nl = hs[0]->N;
-  const size_t ng = (size_t)P * nl;
-  if (ng > ((size_t)1 << 24)) return TBNAV_ERR_UNSUPPORTED;
-  // (everything above is a function of arguments every rank shares: all ranks return together.  From here on a failure that
-  //  only THIS rank sees — a launch that fails, an allocation, a pool that runs dry — must not make it leave while its peers
-  //  wait in a collective that has no timeout: the rank notes the code in lerr[], skips its own work, KEEPS JOINING the
-  //  collectives, and the ranks agree on a status before anyone acts on data that may be missing.  Round-3 advisor finding.)
-  std::vector<tbnav_comm*> comms(n);
-  std::vector<hipStream_t> s1(n), s2(n);
-  std::vector<ScanTicket> tk(n);
-  std::vector<tbnav_rbpf_stats> lst(n);
-  std::vector<int> lerr(n, TBNAV_OK);
-  auto note = [&](int r, int rc) { if (rc != TBNAV_OK && lerr[r] == TBNAV_OK) lerr[r] = rc; };
-  auto hipok = [&](int r, hipError_t e, const char* what, int line) { if (e != hipSuccess) note(r, tbnav::hip_fail(e, what, __FILE__, line)); return e == hipSuccess; };
-#define TBNAV_L(r, call) hipok(r, (call), #call, __LINE__)
-  // the ranks' codes -> one status, the same on every rank (the lowest rank's failure); collective when ranks live elsewhere
-  auto agree = [&](const std::vector<int>& codes, int& status) -> int {
-    status = TBNAV_OK;
-    if (n == P) { for (int r = 0; r < n; ++r) if (codes[r] != TBNAV_OK && status == TBNAV_OK) status = codes[r]; return TBNAV_OK; }
-    // (the same rule inside the agreement itself: a copy that fails on this rank is a code this rank contributes — if its word
-    //  cannot even be uploaded, the word it holds is whatever the last agreement left, and the rank still reports its own
-    //  failure below — never a return before the all-gather its peers are entering)
-    std::vector<const void*> send(n);
-    std::vector<void*> recv(n);
-    int local_fail = TBNAV_OK;
-    for (int r = 0; r < n; ++r) {
-      DeviceGuard guard(hs[r]->device);
-      const hipError_t e = hipMemcpyAsync(hs[r]->d_status, &codes[r], sizeof(int), hipMemcpyHostToDevice, hs[r]->stream);
-      if (e != hipSuccess && local_fail == TBNAV_OK) local_fail = tbnav::hip_fail(e, "agree: status upload", __FILE__, __LINE__);
-      send[r] = hs[r]->d_status; recv[r] = hs[r]->d_status + 1;
-    }
-    { const int rc = tbnav::comm_all_gather(n, comms.data(), send.data(), recv.data(), sizeof(int), s1.data()); if (rc != TBNAV_OK) return rc; }
-    std::vector<int> all(P, TBNAV_OK);
-    { DeviceGuard guard(hs[0]->device);
-      hipError_t e = hipMemcpyAsync(all.data(), hs[0]->d_status + 1, sizeof(int) * P, hipMemcpyDeviceToHost, hs[0]->stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(hs[0]->stream);
-      if (e != hipSuccess && local_fail == TBNAV_OK) local_fail = tbnav::hip_fail(e, "agree: status download", __FILE__, __LINE__); }
-    for (int q = 0; q < P; ++q) if (all[q] != TBNAV_OK) { status = all[q]; break; }
-    // A failure of the agreement's own copies on THIS rank is not this scan's status (round-5 advisor finding: the rank returned
-    // while its peers, who agreed on OK, went on into the scan's next collectives and waited for it).  It is latched: the rank goes
-    // on with the agreed status, keeps joining this scan's collectives, and contributes the failure to the NEXT scan's first
-    // agreement, where every rank stops with it.
-    if (local_fail != TBNAV_OK) for (int r = 0; r < n; ++r) if (hs[r]->shard_latched == TBNAV_OK) hs[r]->shard_latched = local_fail;
-    return TBNAV_OK;
-  };
-  std::memset(out, 0, sizeof *out);
-  // ---- A: every member's local scan (no normalise tail), its "weights are final" event recorded behind the proposal kernel
-  for (int r = 0; r < n; ++r) {
-    tbnav_rbpf* h = hs[r];
-    DeviceGuard guard(h->device);
-    comms[r] = h->comm; s1[r] = h->stream; s2[r] = h->stream2;
-    note(r, h->shard_latched);
-    if (lerr[r] == TBNAV_OK)
-      note(r, scan_enqueue(h, scan, n_beams, u, cur_odom, prev_odom, icp_ok, T_icp, normals ? normals[r] : nullptr, &lst[r], true, 0, nullptr, tk[r], nullptr, h->ev_w));
-    if (lerr[r] == TBNAV_OK) TBNAV_L(r, hipStreamWaitEvent(h->stream2, h->ev_w, 0));
-  }
-  // ---- B: the ONE collective of the update + the global normalise / selection, on the second streams
-  //         (a member that failed above still takes part — with whatever its weight buffer holds: nobody will use the result)
-  {
-    std::vector<const void*> send(n);
-    std::vector<void*> recv(n);
-    for (int r = 0; r < n; ++r) { send[r] = state_ptrs(hs[r]->d_state[hs[r]->cur], nl).weight; recv[r] = hs[r]->d_gw_raw; }
-    const int rc = tbnav::comm_all_gather(n, comms.data(), send.data(), recv.data(), sizeof(double) * nl, s2.data());
-    if (rc != TBNAV_OK) return rc;   // (the communicator itself failed: it reports on every rank)
-  }
-  for (int r = 0; r < n; ++r) {
-    tbnav_rbpf* h = hs[r];
-    if (lerr[r] != TBNAV_OK) continue;
-    DeviceGuard guard(h->device);
-    h->h_norm[1] = NormOut{};
-    // the resampling offset: the scan's last normal — with tbnav_rbpf_set_rng_shard (device noise) the ENSEMBLE's, identical on every rank
-    const double* zp = h->last_z_ptr;
-    hipLaunchKernelGGL(rbpf_normalize, dim3(1), dim3(256), 0, h->stream2, (int)ng, zp, h->d_gw_raw, h->d_gw, h->d_gcs, h->d_gparent, h->d_norm + 1,
-                       nullptr, nullptr, nullptr, 0u);
-    (void)TBNAV_L(r, hipGetLastError());
-    // (the normalised weights go back into the shard only once the ranks have AGREED that this scan succeeded everywhere — below:
-    //  a failed rank's slice of the gathered vector is whatever its buffer held)
-  }
-  // ---- C: the host waits once per member (the reference's SLAM() is synchronous)
-  std::vector<int> lstat(n, TBNAV_OK);
-  for (int r = 0; r < n; ++r) {
-    tbnav_rbpf* h = hs[r];
-    DeviceGuard guard(h->device);
-    TBNAV_L(r, hipStreamSynchronize(h->stream2));
-    // what the reference reports by throwing (a particle left the world, eta is 0 ...) happens to the rank that holds the particle
-    lstat[r] = lerr[r] != TBNAV_OK ? lerr[r] : scan_finish(h, tk[r], &lst[r]);
-    if (local_out) local_out[r] = lst[r];
-  }
-  // Every rank must stop at the SAME scan with the same status — a rank that went on alone would sit in the next scan's
-  // all-gather for ever: one all-gather of the ranks' statuses per scan (4 bytes each; ~1 % of a scan) when ranks live elsewhere.
-  int status = TBNAV_OK;
-  { const int rc = agree(lstat, status); if (rc != TBNAV_OK) return rc; }
-  const NormOut no = hs[0]->h_norm[1];
-  out->sum_w = no.sum_w; out->sq_sum = no.sq_sum; out->neff = no.neff; out->resampled = no.resampled;
-  out->n_valid_beams = lst[0].n_valid_beams;
-  out->status = status;
-  if (status != TBNAV_OK) return status;
-  // the scan stands on every rank: each shard takes its slice of the globally normalised weights (on its main stream — the host
-  // has waited for the second one above; whatever the main stream does next sees them)
-  for (int r = 0; r < n; ++r) {
-    tbnav_rbpf* h = hs[r];
-    DeviceGuard guard(h->device);
-    const size_t off = (size_t)tbnav::comm_rank(h->comm) * nl;
-    TBNAV_L(r, hipMemcpyAsync(state_ptrs(h->d_state[h->cur], nl).weight, h->d_gw + off, sizeof(double) * nl, hipMemcpyDeviceToDevice, h->stream));
-  }
-  // (a copy that could not even be enqueued: the ranks have already agreed on this scan — the code is latched and stops every rank
-  //  at the next scan's agreement, or at this one's if a resampling follows)
-  for (int r = 0; r < n; ++r) if (lerr[r] != TBNAV_OK) hs[r]->shard_latched = lerr[r];
-  if (!no.resampled) return TBNAV_OK;
-  // ---- D: lowVarianceResampling's copies across shards.  Slot m (global) takes particle parents[m].
-  std::vector<int> parents(ng);
-  { DeviceGuard guard(hs[0]->device); if (!TBNAV_L(0, hipMemcpy(parents.data(), hs[0]->d_gparent, sizeof(int) * ng, hipMemcpyDeviceToHost))) std::fill(parents.begin(), parents.end(), 0); }
-  struct Plan { std::vector<std::pair<int, int>> sends, recvs; std::vector<int32_t> send_slots; std::vector<uint64_t> send_sizes, send_offs; std::vector<unsigned long long> sizes_local; };
-  std::vector<Plan> plan(n);
-  for (int r = 0; r < n; ++r) {
-    tbnav_rbpf* h = hs[r];
-    DeviceGuard guard(h->device);
-    const int me = tbnav::comm_rank(h->comm), lo = me * nl;
-    Plan& pl = plan[r];
-    for (size_t m = 0; m < ng; ++m) {  // (dst, q): every particle of mine some other rank's slot chose — once per destination
-      const int q = parents[m], dst = (int)(m / nl);
-      if (q / nl == me && dst != me) pl.sends.emplace_back(dst, q);
-    }
-    std::sort(pl.sends.begin(), pl.sends.end());
-    pl.sends.erase(std::unique(pl.sends.begin(), pl.sends.end()), pl.sends.end());
-    for (int m = lo; m < lo + nl; ++m) { const int q = parents[m]; if (q / nl != me) pl.recvs.emplace_back(q / nl, q); }
-    std::sort(pl.recvs.begin(), pl.recvs.end());
-    pl.recvs.erase(std::unique(pl.recvs.begin(), pl.recvs.end()), pl.recvs.end());
-    pl.send_slots.resize(pl.sends.size());
-    for (size_t i = 0; i < pl.sends.size(); ++i) pl.send_slots[i] = pl.sends[i].second - lo;
-    pl.send_sizes.assign(pl.sends.size(), 0);
-    if (lerr[r] == TBNAV_OK) note(r, tbnav_rbpf_export_batch_sizes(h, (int32_t)pl.sends.size(), pl.send_slots.data(), pl.send_sizes.data()));
-    if (lerr[r] != TBNAV_OK) std::fill(pl.send_sizes.begin(), pl.send_sizes.end(), 0);
-    // what a particle of mine weighs, for whoever receives it (a particle sent to several ranks weighs the same for each)
-    pl.sizes_local.assign(nl, 0ull);
-    for (size_t i = 0; i < pl.sends.size(); ++i) pl.sizes_local[pl.sends[i].second - lo] = pl.send_sizes[i];
-    TBNAV_L(r, hipMemcpyAsync(h->d_sizes, pl.sizes_local.data(), sizeof(unsigned long long) * nl, hipMemcpyHostToDevice, h->stream));
-  }
-  {
-    std::vector<const void*> send(n);
-    std::vector<void*> recv(n);
-    for (int r = 0; r < n; ++r) { send[r] = hs[r]->d_sizes; recv[r] = hs[r]->d_sizes + nl; }
-    const int rc = tbnav::comm_all_gather(n, comms.data(), send.data(), recv.data(), sizeof(unsigned long long) * nl, s1.data());
-    if (rc != TBNAV_OK) return rc;
-  }
-  std::vector<std::vector<tbnav::P2P>> p_send(n), p_recv(n);
-  std::vector<std::vector<uint64_t>> recv_offs(n);
-  std::vector<unsigned long long> sizes_all(ng);
-  for (int r = 0; r < n; ++r) {
-    tbnav_rbpf* h = hs[r];
-    DeviceGuard guard(h->device);
-    Plan& pl = plan[r];
-    if (!(TBNAV_L(r, hipMemcpyAsync(sizes_all.data(), h->d_sizes + nl, sizeof(unsigned long long) * ng, hipMemcpyDeviceToHost, h->stream)) &&
-          TBNAV_L(r, hipStreamSynchronize(h->stream)))) std::fill(sizes_all.begin(), sizes_all.end(), 0ull);
-    // everything this rank sends: ONE export, the blobs back to back in (destination, particle) order
-    uint64_t total = 0;
-    for (uint64_t b : pl.send_sizes) total += b;
-    pl.send_offs.assign(pl.sends.size() + 1, 0);
-    if (lerr[r] == TBNAV_OK) note(r, grow(h->d_sendbuf, h->send_cap, (size_t)total));
-    if (lerr[r] == TBNAV_OK) note(r, tbnav_rbpf_export_batch_dev(h, (int32_t)pl.sends.size(), pl.send_slots.data(), h->d_sendbuf, total, pl.send_offs.data()));
-    for (size_t i = 0; i < pl.sends.size();) {  // one message per destination
-      size_t j = i;
-      while (j < pl.sends.size() && pl.sends[j].first == pl.sends[i].first) ++j;
-      p_send[r].push_back(tbnav::P2P{pl.sends[i].first, h->d_sendbuf + pl.send_offs[i], (size_t)(pl.send_offs[j] - pl.send_offs[i])});
-      i = j;
-    }
-    // everything it receives: one buffer, the blobs in (source, particle) order
-    recv_offs[r].assign(pl.recvs.size() + 1, 0);
-    for (size_t i = 0; i < pl.recvs.size(); ++i) recv_offs[r][i + 1] = recv_offs[r][i] + sizes_all[pl.recvs[i].second];
-    if (lerr[r] == TBNAV_OK) note(r, grow(h->d_recvbuf, h->recv_cap, (size_t)recv_offs[r].back()));
-    for (size_t i = 0; i < pl.recvs.size();) {
-      size_t j = i;
-      while (j < pl.recvs.size() && pl.recvs[j].first == pl.recvs[i].first) ++j;
-      p_recv[r].push_back(tbnav::P2P{pl.recvs[i].first, h->d_recvbuf + recv_offs[r][i], (size_t)(recv_offs[r][j] - recv_offs[r][i])});
-      i = j;
-    }
-  }
-  // is every rank ready to send what the sizes promised and to receive it?  A rank whose export or allocation failed cannot
-  // honour its messages (its peers would wait for bytes that never come): agree BEFORE the exchange; nobody has touched a slot yet
-  { const int rc = agree(lerr, status); if (rc != TBNAV_OK) return rc; }
-  if (status != TBNAV_OK) { out->status = status; return status; }
-  { const int rc = tbnav::comm_exchange(n, comms.data(), p_send.data(), p_recv.data(), s1.data()); if (rc != TBNAV_OK) return rc; }
-  // local parents inside the handle (tile tables + reference counts), then the imported ones; weights are NOT reset by the
-  // reference: every slot carries its parent's normalised weight
-  std::vector<int> mstat(n, TBNAV_OK);
-  for (int r = 0; r < n; ++r) {
-    tbnav_rbpf* h = hs[r];
-    DeviceGuard guard(h->device);
-    const int me = tbnav::comm_rank(h->comm), lo = me * nl;
-    Plan& pl = plan[r];
-    std::vector<int32_t> local_parent(nl), imp_slots;
-    std::vector<uint64_t> imp_offs;
-    for (int m = 0; m < nl; ++m) {
-      const int q = parents[lo + m];
-      if (q / nl == me) local_parent[m] = q - lo;
-      else {
-        local_parent[m] = -1;
-        const auto it = std::lower_bound(pl.recvs.begin(), pl.recvs.end(), std::make_pair(q / nl, q));
-        imp_slots.push_back(m);
-        imp_offs.push_back(recv_offs[r][(size_t)(it - pl.recvs.begin())]);
-      }
-    }
-    int rc = tbnav_rbpf_gather_local(h, local_parent.data());
-    if (rc == TBNAV_OK && !imp_slots.empty())
-      rc = tbnav_rbpf_import_batch_dev(h, (int32_t)imp_slots.size(), imp_slots.data(), h->d_recvbuf, recv_offs[r].back(), imp_offs.data());
-    if (rc == TBNAV_OK) rc = tbnav_rbpf_set_weights_from_global_dev(h, parents.data() + lo);
-    mstat[r] = rc;
-  }
-  // a rank that failed (tile pool exhausted) must not leave the others waiting in the next scan's collective: agree on it
-  { const int rc = agree(mstat, status); if (rc != TBNAV_OK) return rc; }
-#undef TBNAV_L
-  out->status = status;
-  return status;
-}
-
-}  // namespace
-
-// One process driving several GPUs: the whole filter behind one object (what bmapping::ParticleFilter built with n_gpus > 1 holds).
-struct tbnav_rbpf_group {
-  int n = 0, n_global = 0;
-  std::vector<tbnav_rbpf*> m;
-  std::vector<tbnav_comm*> c;
-  std::vector<std::vector<double>> normals;  // parity mode: each member's slice of the ensemble's draw stream + the offset
-};
-
-extern "C" {
-
-int tbnav_rbpf_attach_comm(tbnav_rbpf* h, tbnav_comm* comm) {
-  if (!h) return TBNAV_ERR_INVALID_ARG;
-  if (comm && (h->ref_field || tbnav_comm_device(comm) != h->device)) return TBNAV_ERR_INVALID_ARG;
-  DeviceGuard guard(h->device);
-  TBNAV_HIP(hipStreamSynchronize(h->stream));
-  h->comm = comm;
-  h->shard_latched = TBNAV_OK;
-  if (!comm) { h->rng_first = 0; h->rng_n_global = 0; return TBNAV_OK; }
-  // equal shards: this rank's particles are [rank * N, (rank + 1) * N) of nranks * N — also for the device noise source
-  h->rng_first = (uint64_t)tbnav::comm_rank(comm) * (uint64_t)h->N;
-  h->rng_n_global = (uint64_t)tbnav::comm_size(comm) * (uint64_t)h->N;
-  // the buffers every collective of a scan works on exist from here on (nranks * N is fixed for the attachment): a handle
-  // whose shard state cannot be made is NOT attached — sharded_scan's precondition, so that no rank finds itself without
-  // something to join a collective with in the middle of a scan (round-4 advisor finding)
-  const int rc = ensure_shard_state(h);
-  if (rc != TBNAV_OK) { h->comm = nullptr; h->rng_first = 0; h->rng_n_global = 0; }
-  return rc;
-}
-
-void tbnav_rbpf_group_destroy(tbnav_rbpf_group* g) {
-  if (!g) return;
-  for (int r = 0; r < g->n; ++r) {
-    if (r < (int)g->m.size()) tbnav_rbpf_destroy(g->m[r]);
-    if (r < (int)g->c.size()) tbnav_comm_destroy(g->c[r]);
-  }
-  delete g;
-}
-
-int tbnav_rbpf_group_create(const tbnav_rbpf_params* params, int32_t n_gpus, const int32_t* devices, uint64_t max_pool_bytes_per_member,
-                            tbnav_rbpf_group** out) {
-  if (!params || !out || n_gpus <= 0 || params->num_particles <= 0 || params->num_particles % n_gpus != 0) return TBNAV_ERR_INVALID_ARG;
-  *out = nullptr;
-  tbnav_rbpf_group* g = new (std::nothrow) tbnav_rbpf_group();
-  if (!g) return TBNAV_ERR_INVALID_ARG;
-  g->n = n_gpus; g->n_global = params->num_particles;
-  g->m.assign(n_gpus, nullptr); g->c.assign(n_gpus, nullptr); g->normals.resize(n_gpus);
-  int rc = tbnav_comm_create_local(n_gpus, devices, g->c.data());
-  for (int r = 0; r < n_gpus && rc == TBNAV_OK; ++r) {
-    tbnav_rbpf_params p = *params;
-    p.num_particles = params->num_particles / n_gpus;
-    p.device = tbnav_comm_device(g->c[r]);
-    rc = create_impl(&p, max_pool_bytes_per_member, &g->m[r]);
-    if (rc == TBNAV_OK) {
-      // initParticleSet gives every particle weight 1 / N of the WHOLE filter (particle_filter.cpp:134)
-      std::vector<double> w((size_t)p.num_particles, 1.0 / params->num_particles);
-      rc = tbnav_rbpf_set_particles(g->m[r], nullptr, nullptr, w.data());
-    }
-    if (rc == TBNAV_OK) rc = tbnav_rbpf_attach_comm(g->m[r], g->c[r]);
-  }
-  if (rc != TBNAV_OK) { tbnav_rbpf_group_destroy(g); return rc; }
-  *out = g;
-  return TBNAV_OK;
-}
-
-int tbnav_rbpf_group_size(const tbnav_rbpf_group* g) { return g ? g->n : -1; }
-int tbnav_rbpf_group_member(tbnav_rbpf_group* g, int32_t rank, tbnav_rbpf** out) {
-  if (!g || !out || rank < 0 || rank >= g->n) return TBNAV_ERR_INVALID_ARG;
-  *out = g->m[rank];
-  return TBNAV_OK;
-}
-int tbnav_rbpf_group_set_seed(tbnav_rbpf_group* g, uint64_t seed) {
-  if (!g) return TBNAV_ERR_INVALID_ARG;
-  for (tbnav_rbpf* h : g->m) { const int rc = tbnav_rbpf_set_seed(h, seed); if (rc != TBNAV_OK) return rc; }  // one seed: the members draw disjoint slices of its stream
-  return TBNAV_OK;
-}
-int tbnav_rbpf_group_set_option(tbnav_rbpf_group* g, int32_t option, int32_t value) {
-  if (!g) return TBNAV_ERR_INVALID_ARG;
-  for (tbnav_rbpf* h : g->m) { const int rc = tbnav_rbpf_set_option(h, option, value); if (rc != TBNAV_OK) return rc; }
-  return TBNAV_OK;
-}
-int64_t tbnav_rbpf_group_num_normals(const tbnav_rbpf_group* g, int32_t icp_ok) {
-  if (!g) return -1;
-  return (int64_t)g->n_global * (icp_ok ? 3 * g->m[0]->k + 3 : 3) + 1;
-}
-
-// normals: the ENSEMBLE's draw stream in the reference's order (tbnav_rbpf_group_num_normals values: particle-major, the
-// resampling offset last) or NULL (device noise: every member draws its slice of one stream).
-int tbnav_rbpf_group_slam(tbnav_rbpf_group* g, const float* scan, int32_t n_beams, const double u[3], const double cur_odom[3],
-                          const double prev_odom[3], int32_t icp_ok, const double T_icp[3], const double* normals, tbnav_rbpf_stats* out) {
-  if (!g || !out) return TBNAV_ERR_INVALID_ARG;
-  std::vector<const double*> nr(g->n, nullptr);
-  if (normals) {
-    const size_t stride = icp_ok ? 3 * (size_t)g->m[0]->k + 3 : 3, nl = (size_t)g->m[0]->N;
-    for (int r = 0; r < g->n; ++r) {
-      std::vector<double>& v = g->normals[r];
-      v.resize(nl * stride + 1);
-      std::memcpy(v.data(), normals + (size_t)r * nl * stride, sizeof(double) * nl * stride);
-      v[nl * stride] = normals[(size_t)g->n_global * stride];
-      nr[r] = v.data();
-    }
-  }
-  return sharded_scan(g->n, g->m.data(), scan, n_beams, u, cur_odom, prev_odom, icp_ok, T_icp, normals ? nr.data() : nullptr, out, nullptr);
-}
-
-// ParticleFilter::getRobotState over the ensemble: strict >, first wins (particle_filter.cpp:255-274) — members in rank order
-int tbnav_rbpf_group_best_state(tbnav_rbpf_group* g, double pose[3], int32_t* best_index) {
-  if (!g || !pose) return TBNAV_ERR_INVALID_ARG;
-  double best_w = 0.0; int best_r = 0, best_i = 0; double best_pose[3] = {0, 0, 0};
-  bool have = false;
-  for (int r = 0; r < g->n; ++r) {
-    double p[3]; int32_t idx = 0;
-    int rc = tbnav_rbpf_best_state(g->m[r], p, &idx);
-    if (rc != TBNAV_OK) return rc;
-    double w = 0.0;
-    { DeviceGuard guard(g->m[r]->device); TBNAV_HIP(hipMemcpy(&w, state_ptrs(g->m[r]->d_state[g->m[r]->cur], g->m[r]->N).weight + idx, sizeof w, hipMemcpyDeviceToHost)); }
-    // (a member whose weights are all <= 0.0 reports its slot 0, as the reference's loop would keep index 0)
-    if (!have || w > best_w) { best_w = w; best_r = r; best_i = idx; std::memcpy(best_pose, p, sizeof p); have = true; }
-  }
-  std::memcpy(pose, best_pose, sizeof best_pose);
-  if (best_index) *best_index = best_r * g->m[0]->N + best_i;
-  return TBNAV_OK;
-}
-int tbnav_rbpf_group_best_map(tbnav_rbpf_group* g, int8_t* map) {
-  if (!g || !map) return TBNAV_ERR_INVALID_ARG;
-  double pose[3]; int32_t idx = 0;
-  const int rc = tbnav_rbpf_group_best_state(g, pose, &idx);
-  if (rc != TBNAV_OK) return rc;
-  const int nl = g->m[0]->N;
-  return tbnav_rbpf_particle_map(g->m[idx / nl], idx % nl, map);
-}
-
-int tbnav_rbpf_copy_particle(tbnav_rbpf* dst, int32_t dst_slot, tbnav_rbpf* src, int32_t src_slot) {
-  if (!dst || !src || dst_slot < 0 || dst_slot >= dst->N || src_slot < 0 || src_slot >= src->N) return TBNAV_ERR_INVALID_ARG;
-  if (dst->xsize != src->xsize || dst->ref_field != src->ref_field || dst->device != src->device) return TBNAV_ERR_INVALID_ARG;
-  DeviceGuard guard(src->device);
-  uint64_t bytes = 0;
-  int rc = tbnav_rbpf_export_size(src, src_slot, &bytes);
-  if (rc != TBNAV_OK) return rc;
-  void* buf = nullptr;
-  TBNAV_HIP(hipMalloc(&buf, bytes));
-  rc = tbnav_rbpf_export_particle_dev(src, src_slot, buf, bytes, nullptr);
-  if (rc == TBNAV_OK) rc = tbnav_rbpf_import_particle_dev(dst, dst_slot, buf, bytes);
-  (void)hipFree(buf);
-  if (rc == TBNAV_OK && src->ref_field) {  // the set with its history, the field with its stale cells
-    dst->ref->copy_slot(dst_slot, *src->ref, src_slot);   // (the slot's device content counts as unknown: the next flush uploads the state's image)
-  }
-  return rc;
-}
-
-int tbnav_rbpf_get_particles(tbnav_rbpf* h, double* pose, double* prev_pose, double* weight) {
-  if (!h) return TBNAV_ERR_INVALID_ARG;
-  DeviceGuard guard(h->device);
-  const int N = h->N;
-  StatePtrs sp = state_ptrs(h->d_state[h->cur], N);
-  TBNAV_HIP(hipStreamSynchronize(h->stream));
-  if (pose) TBNAV_HIP(hipMemcpy(pose, sp.pose, sizeof(double) * 3 * N, hipMemcpyDeviceToHost));
-  if (prev_pose) TBNAV_HIP(hipMemcpy(prev_pose, sp.prev, sizeof(double) * 3 * N, hipMemcpyDeviceToHost));
-  if (weight) TBNAV_HIP(hipMemcpy(weight, sp.weight, sizeof(double) * N, hipMemcpyDeviceToHost));
-  return TBNAV_OK;
-}
-
-int tbnav_rbpf_set_particles(tbnav_rbpf* h, const double* pose, const double* prev_pose, const double* weight) {
-  if (!h) return TBNAV_ERR_INVALID_ARG;
-  DeviceGuard guard(h->device);
-  const int N = h->N;
-  StatePtrs sp = state_ptrs(h->d_state[h->cur], N);
-  TBNAV_HIP(hipStreamSynchronize(h->stream));
-  if (pose) TBNAV_HIP(hipMemcpy(sp.pose, pose, sizeof(double) * 3 * N, hipMemcpyHostToDevice));
-  if (prev_pose) TBNAV_HIP(hipMemcpy(sp.prev, prev_pose, sizeof(double) * 3 * N, hipMemcpyHostToDevice));
-  if (weight) TBNAV_HIP(hipMemcpy(sp.weight, weight, sizeof(double) * N, hipMemcpyHostToDevice));
-  return TBNAV_OK;
-}
-
-int tbnav_rbpf_get_log_odds(tbnav_rbpf* h, int32_t particle, double* out) {
-  if (!h || !out || particle < 0 || particle >= h->N) return TBNAV_ERR_INVALID_ARG;
-  DeviceGuard guard(h->device);
-  if (!h->d_dense) TBNAV_HIP(hipMalloc((void**)&h->d_dense, sizeof(double) * h->G));
-  const int blocks = (int)std::min<size_t>((h->G + 255) / 256, 4096);
-  hipLaunchKernelGGL(rbpf_tiles_to_dense, dim3(blocks), dim3(256), 0, h->stream, h->xsize, h->G, h->pool, map_of(h), particle, h->d_dense);
-  TBNAV_HIP(hipGetLastError());
-  TBNAV_HIP(hipMemcpyAsync(out, h->d_dense, sizeof(double) * h->G, hipMemcpyDeviceToHost, h->stream));
-  TBNAV_HIP(hipStreamSynchronize(h->stream));
-  return TBNAV_OK;
-}
-
-int tbnav_rbpf_set_log_odds(tbnav_rbpf* h, int32_t particle, const double* in) {
-  if (!h || !in || particle < 0 || particle >= h->N) return TBNAV_ERR_INVALID_ARG;
-  DeviceGuard guard(h->device);
-  if (!h->d_dense) TBNAV_HIP(hipMalloc((void**)&h->d_dense, sizeof(double) * h->G));
-  TBNAV_HIP(hipStreamSynchronize(h->stream));
-  TBNAV_HIP(hipMemcpy(h->d_dense, in, sizeof(double) * h->G, hipMemcpyHostToDevice));
-  for (int q = 0; q < 4; ++q) h->h_err[q] = 0;
-  // the tiles take the new log-odds and the occupancy bits they imply; the particle's occupied counts are rebuilt
-  TBNAV_HIP(hipMemsetAsync(h->d_nocc[h->cur] + particle, 0, sizeof(int), h->stream));
-  TBNAV_HIP(hipMemsetAsync(h->d_trow[h->cur] + (size_t)particle * h->TW, 0, sizeof(int) * h->TW, h->stream));
-  hipLaunchKernelGGL(rbpf_dense_to_tiles, dim3(h->TT), dim3(kWave), 0, h->stream, h->xsize, h->cut_occ, h->pool, map_of(h), particle, h->d_dense,
-                     h->d_trow[h->cur], h->d_nocc[h->cur], h->d_err);
-  TBNAV_HIP(hipGetLastError());
-  TBNAV_HIP(hipStreamSynchronize(h->stream));
-  if (h->h_err[3] & 8) return TBNAV_ERR_POOL_EXHAUSTED;
-  const int zero = 0;  // the distance field no longer matches the map
-  TBNAV_HIP(hipMemcpy(h->d_fstate + particle, &zero, sizeof zero, hipMemcpyHostToDevice));
-  if (h->ref_field) {  // the occupied set's history is unknown from here on: ascending order (documented in tbnav_rbpf.h)
-    std::vector<int> cells;
-    for (size_t c = 0; c < h->G; ++c) if (in[c] >= h->cut_occ) cells.push_back((int)c);
-    h->ref->reset(particle, cells);
-    h->ref->forget_slot(particle);
-  }
-  return TBNAV_OK;
-}
-
-int tbnav_rbpf_get_dist_code(tbnav_rbpf* h, int32_t particle, uint16_t* out) {
-  if (!h || !out || particle < 0 || particle >= h->N) return TBNAV_ERR_INVALID_ARG;
-  DeviceGuard guard(h->device);
-  if (h->ref_field) { const int rc = ref_field_materialize(h, particle); if (rc != TBNAV_OK) return rc; }  // the pass to its end, stale cells by replay
-  else { const int rc = ensure_full_field(h, particle); if (rc != TBNAV_OK) return rc; }  // whole field on demand
-  TBNAV_HIP(hipStreamSynchronize(h->stream));
-  TBNAV_HIP(hipMemcpy(out, h->d_code[h->cur] + (size_t)particle * h->G, sizeof(uint16_t) * h->G, hipMemcpyDeviceToHost));
-  return TBNAV_OK;
-}
-
-int tbnav_rbpf_get_occ_dist(tbnav_rbpf* h, int32_t particle, double* out) {
-  if (!h || !out || particle < 0 || particle >= h->N) return TBNAV_ERR_INVALID_ARG;
-  std::vector<uint16_t> code(h->G);
-  int rc = tbnav_rbpf_get_dist_code(h, particle, code.data());
-  if (rc != TBNAV_OK) return rc;
-  for (size_t c = 0; c < h->G; ++c)
-    out[c] = code[c] == kCodeUnreached ? h->max_occ_dist : std::sqrt((double)code[c]) * h->p.resolution;
-  return TBNAV_OK;
-}
-
-int tbnav_rbpf_set_occ_dist(tbnav_rbpf* h, int32_t particle, const double* in) {
-  if (!h || !in || particle < 0 || particle >= h->N) return TBNAV_ERR_INVALID_ARG;
-  std::vector<uint16_t> code(h->G);
-  const double res = h->p.resolution;
-  for (size_t c = 0; c < h->G; ++c) {
-    const double v = in[c];
-    const double cells = v / res;
-    const long d2 = std::lround(cells * cells);
-    if (d2 >= 0 && d2 < 65535 && std::sqrt((double)d2) * res == v) { code[c] = (uint16_t)d2; continue; }
-    if (v == h->max_occ_dist) { code[c] = kCodeUnreached; continue; }
-    return TBNAV_ERR_INVALID_ARG;
-  }
-  DeviceGuard guard(h->device);
-  { const int rc = ensure_codes(h); if (rc != TBNAV_OK) return rc; }
-  TBNAV_HIP(hipStreamSynchronize(h->stream));
-  if (h->ref_field) { h->ref->set_codes(particle, code.data()); h->ref->forget_slot(particle); }
-  TBNAV_HIP(hipMemcpy(h->d_code[h->cur] + (size_t)particle * h->G, code.data(), sizeof(uint16_t) * h->G, hipMemcpyHostToDevice));
-  const int two = 2;  // an injected field is authoritative: the next call does not refresh it
-  TBNAV_HIP(hipMemcpy(h->d_fstate + particle, &two, sizeof two, hipMemcpyHostToDevice));
-  h->fstate_dirty = true;
-  return TBNAV_OK;
-}
-
-int tbnav_rbpf_get_occupied_count(tbnav_rbpf* h, int32_t* counts) {
-  if (!h || !counts) return TBNAV_ERR_INVALID_ARG;
-  DeviceGuard guard(h->device);
-  TBNAV_HIP(hipStreamSynchronize(h->stream));
-  TBNAV_HIP(hipMemcpy(counts, h->d_nocc[h->cur], sizeof(int) * h->N, hipMemcpyDeviceToHost));
-  return TBNAV_OK;
-}
-
-int tbnav_rbpf_get_trace(tbnav_rbpf* h, double* sampled, double* p_scan, double* p_pose, double* mu, double* sigma,
-                         double* eta, double* new_pose, double* weight_raw, int32_t* resample_parent) {
-  if (!h) return TBNAV_ERR_INVALID_ARG;
-  DeviceGuard guard(h->device);
-  const size_t N = h->N, k = h->k;
-  TBNAV_HIP(hipStreamSynchronize(h->stream));
-  auto get = [&](double* dst, const double* src, size_t n) -> hipError_t {
-    return dst ? hipMemcpy(dst, src, sizeof(double) * n, hipMemcpyDeviceToHost) : hipSuccess;
-  };
-  TBNAV_HIP(get(sampled, h->tr.sampled, N * k * 3));
-  TBNAV_HIP(get(p_scan, h->tr.p_scan, N * k));
-  TBNAV_HIP(get(p_pose, h->tr.p_pose, N * k));
-  TBNAV_HIP(get(mu, h->tr.mu, N * 3));
-  TBNAV_HIP(get(sigma, h->tr.sigma, N * 9));
-  TBNAV_HIP(get(eta, h->tr.eta, N));
-  TBNAV_HIP(get(new_pose, h->tr.new_pose, N * 3));
-  TBNAV_HIP(get(weight_raw, h->tr.weight_raw, N));
-  if (resample_parent) TBNAV_HIP(hipMemcpy(resample_parent, h->d_parent, sizeof(int) * N, hipMemcpyDeviceToHost));
-  return TBNAV_OK;
-}
-
-int tbnav_rbpf_best_state(tbnav_rbpf* h, double pose[3], int32_t* best_index) {
-  if (!h || !pose) return TBNAV_ERR_INVALID_ARG;
-  DeviceGuard guard(h->device);
-  hipStream_t st = h->stream;
-  StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
-  hipLaunchKernelGGL(rbpf_argmax, dim3(1), dim3(256), 0, st, h->N, sp.weight, sp.pose, h->d_best, h->d_best_pose);
-  TBNAV_HIP(hipGetLastError());
-  int idx = 0;
-  TBNAV_HIP(hipMemcpyAsync(pose, h->d_best_pose, sizeof(double) * 3, hipMemcpyDeviceToHost, st));
-  TBNAV_HIP(hipMemcpyAsync(&idx, h->d_best, sizeof(int), hipMemcpyDeviceToHost, st));
-  TBNAV_HIP(hipStreamSynchronize(st));
-  if (best_index) *best_index = idx;
-  return TBNAV_OK;
-}
-
-int tbnav_rbpf_best_map(tbnav_rbpf* h, int8_t* map) {
-  if (!h || !map) return TBNAV_ERR_INVALID_ARG;
-  DeviceGuard guard(h->device);
-  hipStream_t st = h->stream;
-  StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
-  hipLaunchKernelGGL(rbpf_argmax, dim3(1), dim3(256), 0, st, h->N, sp.weight, sp.pose, h->d_best, h->d_best_pose);
-  TBNAV_HIP(hipGetLastError());
-  const int blocks = (int)std::min<size_t>((h->G + 255) / 256, 2048);
-  hipLaunchKernelGGL(rbpf_export_map, dim3(blocks), dim3(256), 0, st, h->xsize, h->G, h->cuts, h->d_best, h->pool, map_of(h),
-                     h->d_export);
-  TBNAV_HIP(hipGetLastError());
-  TBNAV_HIP(hipMemcpyAsync(map, h->d_export, h->G, hipMemcpyDeviceToHost, st));
-  TBNAV_HIP(hipStreamSynchronize(st));
-  return TBNAV_OK;
-}
-
-int tbnav_rbpf_set_scan_matching(tbnav_rbpf* h, int32_t enable, double lstep, double astep, int32_t iterations) {
-  if (!h || (enable && (!(lstep > 0.0) || !(astep > 0.0) || iterations < 1 || iterations > 32))) return TBNAV_ERR_INVALID_ARG;
-  h->sm_on = enable != 0;
-  if (enable) { h->sm.lstep = lstep; h->sm.astep = astep; h->sm.iters = iterations; h->sm.max_moves = 64; }
-  return TBNAV_OK;
-}
-
-int tbnav_rbpf_get_scan_match(tbnav_rbpf* h, double* centers, double* scores) {
-  if (!h) return TBNAV_ERR_INVALID_ARG;
-  DeviceGuard guard(h->device);
-  TBNAV_HIP(hipStreamSynchronize(h->stream));
-  if (centers) TBNAV_HIP(hipMemcpy(centers, h->d_center, sizeof(double) * 3 * h->N, hipMemcpyDeviceToHost));
-  if (scores) TBNAV_HIP(hipMemcpy(scores, h->d_score, sizeof(double) * h->N, hipMemcpyDeviceToHost));
-  return TBNAV_OK;
-}
-
-// ---- one particle's GridMapper, for the host class bmapping::GridMapper (grid_mapper.hpp:128-140) ---------------
-namespace {
-int one_particle_consts(tbnav_rbpf* h, int32_t particle, const float* scan, int32_t n_beams, ScanC& c) {
-  const double zero[3] = {0.0, 0.0, 0.0};
-  std::vector<double2> beams;
-  int rc = build_scan_consts(h, c, scan, n_beams, zero, zero, zero, 1, zero, beams);
-  if (rc != TBNAV_OK) return rc;
-  c.p0 = particle;
-  return upload_beams(h, beams, n_beams, c.Bv);
-}
-}  // namespace
-
-int tbnav_rbpf_integrate_scan(tbnav_rbpf* h, int32_t particle, const float* scan, int32_t n_beams, const double pose[3]) {
-  if (!h || !scan || n_beams <= 0 || !pose || particle < 0 || particle >= h->N) return TBNAV_ERR_INVALID_ARG;
-  DeviceGuard guard(h->device);
-  ++h->scans_done;
-  ScanC c;
-  int rc = one_particle_consts(h, particle, scan, n_beams, c);
-  if (rc != TBNAV_OK) return rc;
-  StatePtrs sp = state_ptrs(h->d_state[h->cur], h->N);
-  TBNAV_HIP(hipStreamSynchronize(h->stream));
-  TBNAV_HIP(hipMemcpy(sp.pose + (size_t)particle * 3, pose, sizeof(double) * 3, hipMemcpyHostToDevice));
-  for (int q = 0; q < 4; ++q) h->h_err[q] = 0;
-  rc = launch_raycast(h, c, 1, nullptr);
-  if (rc != TBNAV_OK) return rc;
-  const int zero = 0;  // the map changed: a stored field of this particle is stale
-  TBNAV_HIP(hipMemcpyAsync(h->d_fstate + particle, &zero, sizeof zero, hipMemcpyHostToDevice, h->stream));
-  TBNAV_HIP(hipStreamSynchronize(h->stream));
-  rc = status_from_err(h->h_err);
-  if (rc != TBNAV_OK) return rc;
-  if (h->ref_field) return ref_field_after_scan(h, false, particle, 1);
-  if (h->df_mode != 2) return ensure_full_field(h, particle);  // stored-field modes: the whole field after the update
-  return TBNAV_OK;
-}
-
-int tbnav_rbpf_likelihood(tbnav_rbpf* h, int32_t particle, const float* scan, int32_t n_beams, const double pose[3], double* out) {
-  if (!h || !scan || n_beams <= 0 || !pose || !out || particle < 0 || particle >= h->N) return TBNAV_ERR_INVALID_ARG;
-  DeviceGuard guard(h->device);
-  ScanC c;
-  int rc = one_particle_consts(h, particle, scan, n_beams, c);
-  if (rc != TBNAV_OK) return rc;
-  if (h->ref_field) { rc = ref_field_materialize(h, particle); if (rc != TBNAV_OK) return rc; }  // (a lookup anywhere: the whole field)
-  for (int q = 0; q < 4; ++q) h->h_err[q] = 0;
-  hipLaunchKernelGGL(rbpf_likelihood_one, dim3(1), dim3(kWave), 0, h->stream, c, h->d_beams, h->d_code[h->cur], h->pool, map_of(h),
-                     h->d_trow[h->cur], h->d_fstate, h->radius, h->d_nocc[h->cur], pose[0], pose[1], pose[2], h->d_score, h->d_err, h->d_mixlut);
-  TBNAV_HIP(hipGetLastError());
-  TBNAV_HIP(hipMemcpyAsync(out, h->d_score, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  TBNAV_HIP(hipStreamSynchronize(h->stream));
-  return status_from_err(h->h_err);
-}
-
-int tbnav_rbpf_particle_map(tbnav_rbpf* h, int32_t particle, int8_t* map) {
-  if (!h || !map || particle < 0 || particle >= h->N) return TBNAV_ERR_INVALID_ARG;
-  DeviceGuard guard(h->device);
-  hipStream_t st = h->stream;
-  TBNAV_HIP(hipMemcpyAsync(h->d_best, &particle, sizeof(int), hipMemcpyHostToDevice, st));
-  const int blocks = (int)std::min<size_t>((h->G + 255) / 256, 2048);
-  hipLaunchKernelGGL(rbpf_export_map, dim3(blocks), dim3(256), 0, st, h->xsize, h->G, h->cuts, h->d_best, h->pool, map_of(h), h->d_export);
-  TBNAV_HIP(hipGetLastError());
-  TBNAV_HIP(hipMemcpyAsync(map, h->d_export, h->G, hipMemcpyDeviceToHost, st));
-  TBNAV_HIP(hipStreamSynchronize(st));
-  return TBNAV_OK;
-}
-
-int tbnav_rbpf_set_option(tbnav_rbpf* h, int32_t option, int32_t value) {
-  if (!h) return TBNAV_ERR_INVALID_ARG;
-  DeviceGuard guard(h->device);
-  switch (option) {
-    case TBNAV_RBPF_OPT_DF_MODE: {
-      if (value < TBNAV_RBPF_DF_FULL || value > TBNAV_RBPF_DF_REFERENCE) return TBNAV_ERR_INVALID_ARG;
-      if (h->scans_done) return TBNAV_ERR_INVALID_ARG;  // the mode belongs to the filter's whole life
-      if (value == TBNAV_RBPF_DF_REFERENCE) {
-        if (h->N > 4096) return TBNAV_ERR_UNSUPPORTED;  // serial host brushfire per particle: small ensembles only
-        if (h->xsize > tbnav::RefField::kMaxSide || (long)h->radius * h->radius >= 65534) return TBNAV_ERR_UNSUPPORTED;  // (the host queue's nodes: 12-bit coordinates, 16-bit squared distances)
-        { const int rc = ensure_codes(h); if (rc != TBNAV_OK) return rc; }
-        delete h->ref;
-        h->ref = new (std::nothrow) tbnav::RefField(h->N, h->xsize, h->radius);
-        if (!h->ref) return TBNAV_ERR_INVALID_ARG;
-        h->ref->set_reach(h->ref_reach);
-        // (no scan yet: the maps are empty, and the slots were allocated holding "unreached" everywhere — the initial state's image)
-        TBNAV_HIP(hipStreamSynchronize(h->stream));
-        TBNAV_HIP(hipMemset(h->d_code[h->cur], 0xFF, sizeof(uint16_t) * h->G * (size_t)h->N));
-        h->ref->slots_hold_initial_image();
-        h->ref_field = true; h->df_mode = 2; h->full_edt = false;
-        return TBNAV_OK;
-      }
-      if (value != TBNAV_RBPF_DF_QUERY) {
-        if (h->edt_cols == 0) return TBNAV_ERR_UNSUPPORTED;  // no LDS transform for this map size
-        { const int rc = ensure_codes(h); if (rc != TBNAV_OK) return rc; }
-        // empty maps: the stored field "everything unreached" IS the whole, fresh field
-        TBNAV_HIP(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(h->d_fstate), 2, h->N));
-        h->fstate_dirty = true;
-      }
-      h->ref_field = false; h->df_mode = value; h->full_edt = value == TBNAV_RBPF_DF_FULL;
-      return TBNAV_OK;
-    }
-    case TBNAV_RBPF_OPT_REF_REACH:   // reference-field mode: cells a scan's brushfire runs out to before it stops (0: to the end, as up to round 5)
-      if (value < 0 || value > 65535) return TBNAV_ERR_INVALID_ARG;
-      h->ref_reach = value;
-      if (h->ref) h->ref->set_reach(value);
-      return TBNAV_OK;
-    case TBNAV_RBPF_OPT_RAYCAST_ORDERED:
-      if (value) h->tile_cap = 0;
-      else {
-        const double reach = (double)h->p.range_max + std::hypot(h->p.Trs[1], h->p.Trs[2]);
-        const long side = 2 * ((long)std::ceil(reach / h->p.resolution) + 2) + 1;
-        h->tile_cap = (side * side <= 30000) ? (int)(side * side) : 0;
-      }
-      return TBNAV_OK;
-    case TBNAV_RBPF_OPT_RAYCAST_THREADS:
-      if (value != 0 && value != 256 && value != 512 && value != 1024) return TBNAV_ERR_INVALID_ARG;
-      h->raycast_threads = value;
-      return TBNAV_OK;
-    case TBNAV_RBPF_OPT_RAYCAST_BAND_ROWS:
-      if (value < 0) return TBNAV_ERR_INVALID_ARG;
-      h->raycast_band_rows = value;
-      return TBNAV_OK;
-    case TBNAV_RBPF_OPT_RAYCAST_CELL16:
-      if (value < 0 || value > 2) return TBNAV_ERR_INVALID_ARG;
-      h->raycast_cell16 = value;
-      return TBNAV_OK;
-    case TBNAV_RBPF_OPT_RAYCAST_ADAPT:
-      if (value < 0 || value > 3) return TBNAV_ERR_INVALID_ARG;
-      h->raycast_adapt = value;
-      return TBNAV_OK;
-    case TBNAV_RBPF_OPT_BATCH_PIPELINE:
-      if (value != 0 && value != 1) return TBNAV_ERR_INVALID_ARG;
-      h->batch_pipeline = value;
-      return TBNAV_OK;
-    case TBNAV_RBPF_OPT_HOST_THREADS:
-      if (value < 0 || value > 256) return TBNAV_ERR_INVALID_ARG;
-      h->host_threads = value ? value : default_host_threads();
-      return TBNAV_OK;
-    case TBNAV_RBPF_OPT_RAYCAST_FORM:
-      // retired: 1 named round 2's tile kernel (removed in round 4) and for a while silently meant the much slower beam-ordered
-      // kernel instead — that one has its own switch, _RAYCAST_ORDERED (round-4 advisor finding)
-      return value == 0 ? TBNAV_OK : TBNAV_ERR_INVALID_ARG;
-    case TBNAV_RBPF_OPT_COUNT_CELLS:
-      h->count_touched = value != 0;
-      return TBNAV_OK;
-    case TBNAV_RBPF_OPT_NOISE_IN_KERNEL:
-      if (value != 0 && value != 1) return TBNAV_ERR_INVALID_ARG;
-      h->noise_in_kernel = value;
-      return TBNAV_OK;
-    default: return TBNAV_ERR_INVALID_ARG;
-  }
-}
-
-int tbnav_rbpf_scan_counts(tbnav_rbpf* h, uint64_t* cell_updates, uint64_t* distinct_cells, int32_t reset) {
-  if (!h) return TBNAV_ERR_INVALID_ARG;
-  DeviceGuard guard(h->device);
-  TBNAV_HIP(hipStreamSynchronize(h->stream));
-  unsigned long long v[2] = {0, 0};
-  TBNAV_HIP(hipMemcpy(v, h->d_touched, sizeof v, hipMemcpyDeviceToHost));
-  if (cell_updates) *cell_updates = v[0];
-  if (distinct_cells) *distinct_cells = v[1];
-  if (reset) TBNAV_HIP(hipMemset(h->d_touched, 0, sizeof v));
-  return TBNAV_OK;
-}
-
-int tbnav_rbpf_reference_field_counts(tbnav_rbpf* h, int32_t* distinct_states, int32_t* last_brushfires, int64_t* total_brushfires) {
-  if (!h || !h->ref_field || !h->ref) return TBNAV_ERR_INVALID_ARG;
-  if (distinct_states) *distinct_states = h->ref->distinct_states();
-  if (last_brushfires) *last_brushfires = h->ref->last_step_brushfires();
-  if (total_brushfires) *total_brushfires = h->ref->total_brushfires();
-  return TBNAV_OK;
-}
-
-int tbnav_rbpf_reference_field_stats(tbnav_rbpf* h, int64_t out[16]) {
-  if (!h || !out || !h->ref_field || !h->ref) return TBNAV_ERR_INVALID_ARG;
-  const tbnav::RefField::Counters& k = h->ref->counters();
-  out[0] = k.passes; out[1] = k.pops; out[2] = k.resumes; out[3] = k.completions; out[4] = k.replays; out[5] = k.replay_generations;
-  out[6] = h->ref->history_bytes(); out[7] = h->ref_reruns;
-  for (int q = 0; q < 6; ++q) out[8 + q] = h->ref_us[q];
-  out[14] = k.us_group; out[15] = k.us_bury;
-  return TBNAV_OK;
-}
-
-int tbnav_rbpf_set_timing(tbnav_rbpf* h, int32_t enable) {
-  if (!h) return TBNAV_ERR_INVALID_ARG;
-  h->timing = enable != 0;
-  return TBNAV_OK;
-}
-
-int tbnav_rbpf_last_kernel_names(const tbnav_rbpf* h, char* propose, int32_t propose_cap, char* raycast, int32_t raycast_cap, int32_t* raycast_workgroups) {
-  if (!h) return TBNAV_ERR_INVALID_ARG;
-  if (propose && propose_cap > 0) { if (h->lk_propose) snprintf(propose, (size_t)propose_cap, "rbpf_propose<%d, %s>", h->lk_propose, h->lk_propose_dn ? "true" : "false"); else propose[0] = 0; }
-  if (raycast && raycast_cap > 0) {
-    if (h->lk_raycast > 0) snprintf(raycast, (size_t)raycast_cap, "rbpf_raycast_box<%d, %d, %s, %d>", h->lk_raycast, h->lk_raycast_wps, h->lk_raycast_c16 ? "true" : "false", h->lk_raycast_ev);
-    else if (h->lk_raycast == 0) snprintf(raycast, (size_t)raycast_cap, "rbpf_raycast");
-    else raycast[0] = 0;
-  }
-  if (raycast_workgroups) *raycast_workgroups = h->lk_raycast_grid;
-  return TBNAV_OK;
-}
-
-int tbnav_rbpf_raycast_box_cells(const tbnav_rbpf* h, int32_t* need_cells, int32_t* array_cells) {
-  if (!h) return TBNAV_ERR_INVALID_ARG;
-  if (need_cells) *need_cells = h->lk_box_need;
-  if (array_cells) *array_cells = h->lk_box_cap;
-  return TBNAV_OK;
-}
-
-int tbnav_rbpf_last_kernel_ms(tbnav_rbpf* h, float ms[TBNAV_RBPF_NKERNELS]) {
-  if (!h || !ms) return TBNAV_ERR_INVALID_ARG;
-  for (int i = 0; i < TBNAV_RBPF_NKERNELS; ++i) ms[i] = h->last_ms[i];
-  return TBNAV_OK;
 }
 
 }  // extern "C"

@@ -1,9 +1,9 @@
-// rbpf_device.hpp — what the RBPF kernel files and the host side (rbpf.hip: handle, launches, C-ABI) share: the launch-argument
+// rbpf_device.hpp — what the RBPF kernel files and the host side (rbpf_host.hpp + rbpf*.hip: handle, launches, C-ABI) share: the launch-argument
 // structs, the tiled copy-on-write map's accessors, world -> cell, wave reductions, the exact-transform / resampling / migration
 // helpers and the declarations of every kernel.  What only one family needs lives in that family's file: the distance lookups
 // and likelihoods in rbpf_propose.hip, rays and add_repeated in rbpf_raycast.hip; the normalise / selection body, which runs in
 // a kernel of its own AND as workgroup 0 of the map update, in rbpf_normalize.hpp.  Kernels are defined in their family's file
-// and launched from rbpf.hip; the template kernels are explicitly instantiated where they are defined.  Everything is compiled
+// and launched from the host files; the template kernels are explicitly instantiated where they are defined.  Everything is compiled
 // -ffp-contract=off (csrc/Makefile): grid indices, log-odds, Neff and parent lists are bit-exact targets.
 #ifndef TBNAV_RBPF_DEVICE_HPP
 #define TBNAV_RBPF_DEVICE_HPP
