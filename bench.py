@@ -529,7 +529,7 @@ def main():
             tl = lambda: ml.enqueueDev(X0, al.data_ptr(), bl.data_ptr(), stream)  # noqa: E731
             el_l = time_ticks(tl, sync, 50, 10, lambda: None)
             ms_l = kernel_profile(ml, al, bl, stream, 50)
-            rl = roofline_obj(KL, ml.steps, ms_l, el_l / 50 * 1e3, ml.lastKernelNames()[0], KL, "mppi_K65536_T100", None, "mppi_K65536_T100")
+            rl = roofline_obj(KL, ml.steps, ms_l, el_l / 50 * 1e3, ml.lastKernelNames()[0], KL, "mppi_K65536_T100", "mppi_K65536_T100", "mppi_K65536_T100")
             rl["workload"] = f"MPPI newControls K={KL}, T={ml.steps} on 1 GPU, noise resident in HBM (the streaming regime)"
             rl["rollouts_per_s"] = round(KL * 50 / el_l, 1)
             line["roofline_large"] = rl

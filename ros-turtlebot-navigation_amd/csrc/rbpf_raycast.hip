@@ -668,9 +668,7 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
         };
         if (n == 0) { ++n_first; advance(); ++n; }  // position 0 is the robot's cell (or, for a reversed ray, the end point): counted below
         char* const tile_b = reinterpret_cast<char*>(tile);
-        // What an add returns is looked at TWO steps later, while the next two adds are in flight: three registers take turns
-        // (no register is copied at the top of the loop, which would wait for the add just issued), so the walk never waits
-        // for LDS unless it has an event to record.
+        // Three adds are issued back to back and what they return is looked at together (below): three registers, no copies.
         unsigned int r0 = 0u, r1 = 0u, r2 = 0u;
         // (C16: what comes back is the cell's DWORD — this cell's half is picked when it is looked at — and the byte offset the add
         //  went to rides along, so that a flagged cell's slot can be looked up: a0..a2 take turns like r0..r2)
@@ -683,22 +681,31 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
           }
           old = 0u;
         };
-        auto step = [&](auto clipped, unsigned int& fresh, int& fresh_at, unsigned int& old, int old_at) {
-          if (!decltype(clipped)::value || (unsigned int)at < band_bytes) {  // (clipped: the cells of the ray in this band of rows)
+        // (round 6) Three steps, THEN one look at what the three adds returned: a cell with an event is a few percent of the steps,
+        // and the test per step was a compare, a saveexec, a branch and an exec restore each — with eight waves per SIMD a wave that
+        // waits for its third add costs nothing, the scalar and vector issue slots it no longer takes are what the kernel is short of.
+        auto flagged = [&](unsigned int old, int where) -> unsigned int {
+          if constexpr (C16) return (old >> ((where & 2) << 3)) & 0x8000u; else return old & kFlag;
+        };
+        auto add_at = [&](auto clipped, unsigned int& fresh, int& fresh_at) {
+          if (!decltype(clipped)::value || (unsigned int)at < band_bytes) {
             if constexpr (C16) { fresh = atomicAdd(reinterpret_cast<unsigned int*>(tile_b + (at & ~3)), (at & 2) ? 0x10000u : 1u); fresh_at = at; }
             else fresh = atomicAdd(reinterpret_cast<unsigned int*>(tile_b + at), 1u);
-          }
+          } else fresh = 0u;
           advance();
-          look(old, old_at);
         };
         auto walk = [&](auto clipped) {
           int m = n1 - n;
-          for (; m >= 3; m -= 3) { step(clipped, r0, a0r, r1, a1r); step(clipped, r1, a1r, r2, a2r); step(clipped, r2, a2r, r0, a0r); }
-          if (m >= 1) step(clipped, r0, a0r, r1, a1r);
-          if (m >= 2) step(clipped, r1, a1r, r2, a2r);
+          for (; m >= 3; m -= 3) {
+            add_at(clipped, r0, a0r); add_at(clipped, r1, a1r); add_at(clipped, r2, a2r);
+            if (flagged(r0, a0r) | flagged(r1, a1r) | flagged(r2, a2r)) { look(r0, a0r); look(r1, a1r); look(r2, a2r); }
+          }
+          r0 = 0u; r1 = 0u; r2 = 0u;
+          if (m >= 1) add_at(clipped, r0, a0r);
+          if (m >= 2) add_at(clipped, r1, a1r);
         };
         if (clip) walk(std::true_type{}); else walk(std::false_type{});
-        look(r0, a0r); look(r1, a1r); look(r2, a2r);
+        look(r0, a0r); look(r1, a1r);
       }
       // the robot's own cell is the first free cell of every ray that has a free cell at all
       n_first = wave_sum_dpp(n_first);

@@ -55,20 +55,27 @@ def test_pmc_summary_output_is_what_the_bench_parses(tmp_path):
 def test_committed_profiles_have_a_row_for_every_kernel_the_bench_lines_point_at():
     rows, src = bp.kernel_stats_rows()
     assert src and rows, "profiles/<round>_kernel_stats.md is missing"
-    for kernel, grid in (("mppi_rollout_fused<2, 8, 1, 1>", None), ("mppi_rollout_prefix<1>", 65536), ("mppi_partials", None)):
-        r = bp.rocprof_row(kernel, grid)
+    # (round 6: the driver's command no longer runs the large-K leg, so its kernels are in their workload's own table only)
+    for kernel, grid, wl in (("mppi_rollout_fused<2, 8, 1, 2>", None, None), ("mppi_rollout_prefix<1>", 65536, "mppi_K65536_T100"), ("mppi_partials", None, "mppi_K65536_T100")):
+        r = bp.rocprof_row(kernel, grid, wl)
         assert r is not None and r["avg_us"] > 0 and r["source"].startswith("profiles/"), kernel
     # the map update's instantiation is chosen per launch (launch_raycast): the committed bench line names the one that ran
+    # (round 6: the line is the compact record the driver parses — bench.compact_line — and carries the same names)
     line_path = os.path.join(ROOT, "profiles", src.split("/")[-1].replace("kernel_stats.md", "bench_line.json"))
     with open(line_path) as f:
-        line = json.loads(f.read().strip().splitlines()[-1])
+        text = f.read().strip().splitlines()[-1]
+    assert len(text) < 6144, len(text)
+    line = json.loads(text)
+    assert line["roofline"]["kernel"] == "mppi_rollout_fused<2, 8, 1, 2>"   # the headline tick draws with the fp64 sampler (the reference's width)
+    assert line["roofline"]["frac_rocprof"] is not None and line["roofline"]["traffic"] is not None and line["cpu_baseline"]["value"] > 0
+    assert line["rbpf"]["modes"]["reference_equal"]["particle_updates_per_s"] >= 1e5   # bars (1) and (2) in the same mode, on the committed run
     k_raycast = line["rbpf"]["roofline"]["kernel"]
     assert k_raycast.startswith("rbpf_raycast_box<"), k_raycast
     r = bp.rocprof_row(k_raycast, 512 * 1001, "rbpf_N1000_k50_400x400_plain_scans_only")
     assert r and "plain_scans_only" in r["source"] and r["median_us"] and r["median_us"] <= r["avg_us"] * 1.5, (k_raycast, r)
-    assert bp.rocprof_row("mppi_rollout_fused<2, 8, 1, 0>") != bp.rocprof_row("mppi_rollout_fused<2, 8, 1, 1>")   # never another instantiation's row
+    assert bp.rocprof_row("mppi_rollout_fused<2, 8, 1, 0>") != bp.rocprof_row("mppi_rollout_fused<2, 8, 1, 2>")   # never another instantiation's row
     assert bp.rocprof_row("no_such_kernel<1>") is None
-    for wl, kernel in (("mppi_K1024_T50", "mppi_rollout_fused<2, 8, 1, 1>"), ("mppi_K65536_T100", "mppi_rollout_prefix<1>"),
+    for wl, kernel in (("mppi_K1024_T50", "mppi_rollout_fused<2, 8, 1, 2>"), ("mppi_K65536_T100", "mppi_rollout_prefix<1>"),
                        ("rbpf_N1000_k50_400x400_plain_scans_only", k_raycast)):
         p = bp.pmc_row(wl, kernel)
         assert p is not None and p["hbm_bytes"] > 0 and wl in p["source"], (wl, kernel)
@@ -77,9 +84,10 @@ def test_committed_profiles_have_a_row_for_every_kernel_the_bench_lines_point_at
 
 def test_every_baseline_shape_has_a_roofline_whose_frac_follows_from_one_named_row_each():
     """Round-4 review, item 1: a `frac` for every configs[*] shape, recomputable from ONE named row of a kernel-stats table (its
-    AVERAGE) and ONE named entry of the traffic file — here recomputed from the committed bench line and the committed profiles."""
-    with open(os.path.join(ROOT, "profiles", "r05_bench_line.json")) as f:
-        line = json.loads(f.read().strip().splitlines()[-1])
+    AVERAGE) and ONE named entry of the traffic file — here recomputed from the committed run's full record (round 6: bench.py --detail
+    writes everything it measured to bench_detail.json; the last stdout line is the compact record) and the committed profiles."""
+    with open(os.path.join(ROOT, "profiles", "r06_bench_detail.json")) as f:
+        line = json.load(f)
     objs = {"configs[1] K=1024,T=50": line["roofline"], "configs[3] K=65536,T=100": line["roofline_large"],
             "configs[3]/8 K=8192,T=100": line["configs3_shard_one_gpu"]["roofline"], "configs[2] bench room": line["rbpf"]["roofline"],
             "configs[2] SURVEY room": line["rbpf"]["survey_room"]["roofline"],

@@ -7,7 +7,7 @@
 #   mppi_small[_rng]  K=1024,T=50 (configs[1])            mppi_mid_rng  K=8192,T=100 (configs[3] / 8)     mppi_large  K=65536,T=100
 #   rbpf / rbpf_plain N=1000 x 400^2 bench room (configs[2])   rbpf_survey  the same on SURVEY 8-d's room   rbpf_cfg4  N=12500 x 2000^2 x 1080 beams (configs[4] / 8)
 set -u
-R=${R:-r05}
+R=${R:-r06}
 root=$(pwd)
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp
