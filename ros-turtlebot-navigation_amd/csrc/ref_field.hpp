@@ -290,6 +290,7 @@ class RefField {
     std::unordered_set<int> occ;
     Codes code;                     // [G] the newest value any pass of the lineage has written (the reference's value in every cell of `mark`)
     std::vector<uint16_t> dense;    // the same as one array, made when somebody asks for the whole field (codes())
+    bool dense_valid = false;       // ... and still what `code` holds
     bool fresh = false;             // code is what the brushfire leaves for exactly this set (false once either was written from outside)
     // the pass (euclideanSignedDistanceField for exactly this set)
     std::vector<uint64_t> mark;     // [G / 64] cell written by this pass (empty: no pass ran for this state)
@@ -313,7 +314,7 @@ class RefField {
     void recycle() {
       id = 0; fresh = false; complete = true; exact = true; from_dense = true; hist_lost = false; hist.reset();
       from_id = 0; from_len = 0; j_reset = false;
-      mark.clear(); band.clear(); heap.clear(); journal.clear(); dense.clear(); code.keep_capacity_only();
+      mark.clear(); band.clear(); heap.clear(); journal.clear(); dense.clear(); dense_valid = false; code.keep_capacity_only();
     }
   };
 
@@ -358,7 +359,7 @@ class RefField {
     State& s = *st_[p];
     if (!s.complete) { advance(s, ~0u, -1); }
     if (!s.exact && make_exact(s) != 0) return nullptr;
-    s.code.to_dense(s.dense);
+    if (!s.dense_valid) { s.code.to_dense(s.dense); s.dense_valid = true; }
     return s.dense.data();
   }
 
@@ -658,6 +659,7 @@ class RefField {
   // (complete), its top is farther than limit2, or cell `until` (>= 0) has been written.  Returns the iterations run.
   long long advance(State& st, uint32_t limit2, int until, const State* P = nullptr) const {
     if (st.complete) return 0;
+    st.dense_valid = false;
     Codes& code = st.code;
     uint64_t* const mk = st.mark.data();
     Heap Q(st.heap, true);
@@ -730,6 +732,7 @@ class RefField {
     if (cur.occ.size() != s.occ.size() || cur.band.size() != s.band.size()) return -2;
     for (int c : s.band) if (cur.code.at(c) != s.code.at(c)) return -2;
     s.code.swap(cur.code);
+    s.dense_valid = false;
     s.exact = true;
     s.hist.reset();
     std::lock_guard<std::mutex> lk(cnt_mu_);
