@@ -332,7 +332,7 @@ int tbnav_rbpf_particle_map(tbnav_rbpf* h, int32_t particle, int8_t* map);
  *                                independent; the order of operations inside one particle is the reference's).  0 = the default: the
  *                                cores in the process's affinity mask, capped by the cgroup's CPU quota, at most 128.
  * TBNAV_RBPF_OPT_REF_REACH       REFERENCE mode: how many cells out from the occupied cells a scan's brushfire runs before it stops
- *                                (default 3; 0 = to the end, the round-3..5 behaviour).  The pass writes every cell once, in a
+ *                                (default 1: the occupied cells and their neighbours' neighbours; 0 = to the end, the round-3..5 behaviour).  The pass writes every cell once, in a
  *                                deterministic order, so a stopped pass equals the finished one on every cell it has written and can be
  *                                resumed; the proposal kernel reports a lookup that lands on an unwritten cell, exactly that state's pass
  *                                is resumed and the proposal run again (tbnav_rbpf_reference_field_stats counts both).  Results are

@@ -138,7 +138,7 @@ struct tbnav_rbpf {
   double* d_state_snap = nullptr;         // [7 N] pose / prev_pose / weight before the proposal: a proposal that met pending cells is run again from here
   uint2* d_jentries = nullptr; size_t jentries_cap = 0;   // the flush's packed (cell, code) pairs
   uint3* d_jjobs = nullptr;               // [N] (offset, count, reset) per slot
-  int ref_reach = 3;                      // TBNAV_RBPF_OPT_REF_REACH: how far (cells) a scan's brushfire runs before it stops (0: to the end)
+  int ref_reach = 1;                      // TBNAV_RBPF_OPT_REF_REACH: how far (cells) a scan's brushfire runs before it stops (0: to the end)
   long long ref_reruns = 0;               // proposals run again because a lookup met a pending cell
   long long ref_us[6] = {0, 0, 0, 0, 0, 0}; // host microseconds spent: fetching the logs | RefField::step | resample copies | flushes | before the proposal | the settle look
   int* d_log_pack = nullptr; unsigned long long* d_log_off = nullptr; size_t log_pack_cap = 0, log_off_cap = 0;  // the scan's logs, packed

@@ -368,7 +368,7 @@ class RefField {
   // then euclideanSignedDistanceField — up to `reach` cells.  One replay + brushfire per distinct (state, sequence), on up to
   // `threads` host threads.  (all / off: the particles' sequences back to back, particle first + i's at all[off[i]] .. all[off[i + 1]])
   void step(int first, int count, int threads, const int* all, const size_t* off) {
-    struct Group { StatePtr from; const int* ev; size_t n; std::vector<int> members; StatePtr to; };
+    struct Group { StatePtr from; const int* ev; size_t n; std::vector<int> members; StatePtr to; bool steal = false; };
     const auto t_a = std::chrono::steady_clock::now();
     std::vector<Group> groups;
     std::unordered_map<uint64_t, std::vector<int>> by_hash;  // hash -> indices into groups
@@ -382,10 +382,14 @@ class RefField {
       int g = -1;
       for (int c : cand)
         if (groups[c].from.get() == st_[p].get() && groups[c].n == n && (n == 0 || std::memcmp(groups[c].ev, ev, sizeof(int) * n) == 0)) { g = c; break; }
-      if (g < 0) { g = (int)groups.size(); groups.push_back(Group{st_[p], ev, n, {}, nullptr}); cand.push_back(g); }
+      if (g < 0) { g = (int)groups.size(); groups.push_back(Group{st_[p], ev, n, {}, nullptr, false}); cand.push_back(g); }
       groups[g].members.push_back(p);
     }
-    for (Group& gr : groups) if (!(gr.n == 0 && (gr.from->occ.empty() || gr.from->fresh))) gr.to = new_state();
+    for (Group& gr : groups) if (!(gr.n == 0 && (gr.from->occ.empty() || gr.from->fresh))) {
+      gr.to = new_state();
+      // every reference to the parent is one of this group's members' (or the group's own): it dies when they move on
+      gr.steal = !gr.from->dense_image() && (size_t)gr.from.use_count() == gr.members.size() + 1;
+    }
     std::atomic<int> next{0}, fires{0};
     std::atomic<long long> pops{0}, done{0};
     const uint32_t limit2 = reach_ > 0 ? (uint32_t)reach_ * (uint32_t)reach_ : ~0u;
@@ -400,8 +404,11 @@ class RefField {
         const State& P = *gr.from;
         State& s = *gr.to;
         // (copy-construct, as GridMapper's copy does: std::unordered_set's copy keeps the iteration order, the bucket layout and
-        //  the rehash policy's state, so the copy behaves like the original from here on)
-        s.occ = P.occ;
+        //  the rehash policy's state, so the copy behaves like the original from here on.  Where the parent dies with this step —
+        //  nobody but this group's members holds it, and it is not an exact state a lineage's history may start from — its set is
+        //  MOVED instead: the very object the reference would have gone on using, and a thousand list nodes not walked)
+        if (gr.steal) s.occ = std::move(const_cast<State&>(P).occ);
+        else s.occ = P.occ;
         s.code.copy_from(P.code);
         apply(s.occ, gr.ev, (int)gr.n);
         s.fresh = true;
@@ -741,7 +748,7 @@ class RefField {
   }
 
   int xs_, radius_;
-  int reach_ = 3;
+  int reach_ = 1;
   long long hist_budget_ = (long long)1 << 30;
   int last_brushfires_ = 0;
   long long total_brushfires_ = 0;

@@ -1,5 +1,6 @@
 """Reference-field mode on the bench workload (configs[2]): ms per scan for a few TBNAV_RBPF_OPT_REF_REACH values, with the lazy
-brushfire's counters (tbnav_rbpf_reference_field_stats).  python tools/ref_mode_probe.py [n_scans] [reach ...]"""
+brushfire's counters (tbnav_rbpf_reference_field_stats).  python tools/ref_mode_probe.py [n_scans] [reach ...]
+TBNAV_PROBE_ROOM=survey: SURVEY 8-d's room and trajectory instead of the bench's."""
 import json
 import os
 import sys
@@ -18,7 +19,13 @@ from rtn_amd.rbpf import ParticleFilter, default_params  # noqa: E402
 
 n_scans = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 reaches = [int(x) for x in sys.argv[2:]] or [6, 3, 0]
-steps, scans = br.workload(n_scans)
+if os.environ.get("TBNAV_PROBE_ROOM") == "survey":
+    import rbpf_cases as rc
+    steps, poses = rc.trajectory(n_scans, inc=rc.TRAJ_SURVEY)
+    rng = np.random.default_rng(7)
+    scans = [br._room_scan(poses[s], rng, rc.ROOM_SURVEY) for s in range(n_scans)]
+else:
+    steps, scans = br.workload(n_scans)
 for reach in reaches:
     pf = ParticleFilter(default_params(N=1000, k=50, map_min=-10.0, map_max=10.0, device=0), df_mode="reference")
     pf.setOption(capi.RBPF_OPT_REF_REACH, reach)
