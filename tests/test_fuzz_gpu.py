@@ -33,3 +33,18 @@ def test_bounded_fuzz_sweep_of_both_paths_against_the_oracle(gpu_pkg):
     assert any(l.startswith("mppi: 20 cases done, failures so far 0") for l in lines)
     assert any(l.startswith("rbpf: 40 cases done, failures so far 0") for l in lines)
     assert any(l.startswith("batch: 10 cases done, failures so far 0") for l in lines)
+
+
+def test_bounded_fuzz_sweep_of_the_reference_field_mode_against_the_oracle(gpu_pkg):
+    """Round 6: the lazy brushfire under random reach, sharing, rooms that change in mid-run (passes resumed, proposals rerun),
+    forced resamplings, ICP failures, empty scans and whole-field exports (lineages replayed): tools/fuzz_reffield.py, 24 cases from a
+    fixed seed, every stage of every scan and every particle's field and log-odds against the oracle's filter, nothing injected."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_reffield.py"), "24", "2026"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith(("reffield:", "[FAIL]"))]
+    print("\n" + "\n".join(lines[-3:]))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    last = lines[-1]
+    assert last.startswith("reffield: 24 cases done, failures so far 0"), last
+    import ast
+    tot = ast.literal_eval(last.split("; ", 1)[1])
+    assert tot["states_resumed"] > 0 and tot["proposals_rerun"] > 0 and tot["lineages_replayed"] > 0, tot   # the sweep really goes down those paths
