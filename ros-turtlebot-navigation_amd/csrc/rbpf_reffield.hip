@@ -78,8 +78,10 @@ int ref_field_flush(tbnav_rbpf* h) {
   const int N = h->N;
   hipStream_t st = h->stream;
   tbnav::RefField::Flush& f = h->ref_flush;
-  h->ref->plan_flush(f);
+  h->ref->plan_flush(f);   // (the plan already counts the slots as brought up to date ...)
   if (f.dense_slot.empty() && !f.any_job) return TBNAV_OK;
+  // ... so a copy or launch that fails below leaves them unknown: the next flush sends whole images
+  struct Guard { tbnav::RefField* r; bool done = false; ~Guard() { if (!done) r->forget_all_slots(); } } guard{h->ref};
   bool any_copy = false;
   std::vector<int> src;
   for (size_t q = 0; q < f.dense_slot.size(); ++q) {
@@ -113,6 +115,7 @@ int ref_field_flush(tbnav_rbpf* h) {
     TBNAV_HIP(hipGetLastError());
   }
   TBNAV_HIP(hipStreamSynchronize(st));
+  guard.done = true;
   return TBNAV_OK;
 }
 // The whole field of one particle as the reference holds it, on the device (exports, the one-particle entry points): the pass is run

@@ -202,6 +202,47 @@ def test_reference_mode_walls_that_appear_far_from_the_map_resume_the_passes(gpu
     pf_d.close()
 
 
+def test_reference_mode_replay_in_one_call_with_device_noise_equals_scan_by_scan(gpu_pkg):
+    """tbnav_rbpf_slam_batch in the reference-field mode (never pipelined there: every scan's field comes from the host) with the
+    standard normals drawn on the device, against one tbnav_rbpf_slam call per scan on a second filter with the same seed and against a
+    third with the brushfire run to the end every scan (reach 0): poses, weights, Neff, the resampling and every field bit for bit —
+    the rooms change in mid-run so that passes are resumed inside the replay."""
+    from rtn_amd import capi
+    N, n_scans = 24, 8
+    small, large = (-1.0, 1.0, -0.8, 0.9), (-2.4, 2.5, -2.2, 2.3)
+    steps, poses = rc.trajectory(n_scans, inc=(0.05, 0.03, 0.02))
+    rng = np.random.default_rng(41)
+    scans = np.stack([orc.room_scan(poses[s], walls=small if s < 3 else large, rng=rng) for s in range(n_scans)])
+    odom = np.array([steps[0][0]] + [st_[1] for st_ in steps]); u_all = np.array([st_[3] for st_ in steps]); ticp = np.array([st_[2] for st_ in steps])
+    a, b, e = (_dev(gpu_pkg, df_mode="reference", N=N, k=20, map_min=-3.0, map_max=3.0) for _ in range(3))
+    e.setOption(capi.RBPF_OPT_REF_REACH, 0)
+    for pf in (a, b, e):
+        pf.setSeed(99)
+    sts_a = a.SLAMBatch(scans[:5], u_all[:5], odom[:6], ticp[:5])
+    w = np.full(N, 0.2 / N); w[2] += 0.5; w[N - 3] += 0.3; w /= w.sum()
+    for pf in (a, b, e):
+        if pf is not a:
+            for s in range(5):
+                prev, cur, t_icp, u = steps[s]
+                pf.SLAM(scans[s], u, cur, prev, True, t_icp, None)
+        pf.setParticles(w=w)   # (the sixth scan resamples)
+    sts_a += a.SLAMBatch(scans[5:], u_all[5:], odom[5:], ticp[5:])
+    sts_b = []
+    for s in range(5, n_scans):
+        prev, cur, t_icp, u = steps[s]
+        sts_b.append(b.SLAM(scans[s], u, cur, prev, True, t_icp, None)); e.SLAM(scans[s], u, cur, prev, True, t_icp, None)
+    assert sts_a[5].resampled == 1 and [(x.neff, x.resampled) for x in sts_a[5:]] == [(x.neff, x.resampled) for x in sts_b]
+    for x, y in ((a, b), (a, e)):
+        (px, vx, wx), (py, vy, wy) = x.particles(), y.particles()
+        assert np.array_equal(px, py) and np.array_equal(vx, vy) and np.array_equal(wx, wy)
+    assert a.referenceFieldStats()["states_resumed"] > 0 and e.referenceFieldStats()["states_resumed"] == 0
+    for p in range(N):
+        assert np.array_equal(a.occDist(p), e.occDist(p)) and np.array_equal(b.occDist(p), e.occDist(p)), p
+        assert np.array_equal(a.logOdds(p), e.logOdds(p)), p
+    for pf in (a, b, e):
+        pf.close()
+
+
 def test_reference_mode_400x400(gpu_pkg):
     """The 400 x 400 map of BASELINE configs[2] with a small ensemble (the brushfire is 16 ms per particle and scan)."""
     pf_o, pf_d, rows = _free_run(gpu_pkg, "reference", N=12, k=20, map_half=10.0, walls=rc.ROOM_SURVEY, n_scans=4,
