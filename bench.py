@@ -21,7 +21,7 @@ value = rollouts/s = N*K*steps / max-over-ranks time.  Extra objects on the same
                   where the path actually streams from HBM (315 MB algorithmic per tick)
   options         the same tick with resident noise; the exact-arc dynamics option
   cpu_baseline / cpu_baseline_all_cores   the oracle port (oracle/mppi_oracle.cpp) on 1 core / all host cores (OpenMP)
-  rbpf            secondary headline: RBPF particle-updates/s (BASELINE configs[2]), bench_rbpf.py
+  rbpf            secondary headline: RBPF particle-updates/s (BASELINE configs[2]) per distance-field mode, bench_rbpf.py (+ bench_rbpf_detail.py with --detail)
   N > 1 only:     weak_tick_via_comm_all_gather, strong_scaling_configs3 (K=65536 split N ways), rbpf_sharded (1000 particles
                   per rank with cross-rank particle migration in the timed region) — under a watchdog: if one of them does not
                   come back, the line is printed without them (`multi_gpu_legs` says why)

@@ -2,20 +2,20 @@
 k = 50 samples round the mode (shipped slam.launch), ICP-ok branch, a 20-scan trajectory in a room small enough
 that EVERY one of the 360 beams returns inside [range_min, range_max) at every pose.
 
-particle-updates/s = N * SLAM calls / wall time of the synchronous tbnav_rbpf_slam calls with the standard normals
-drawn ON the device (normals == NULL: nothing but the 1.4 KB scan crosses PCIe).  Two of the timed scans are forced
-to RESAMPLE (skewed weights set beforehand, untimed): their table copy / reference counting, the state gather and
-the tile clones of the scan that follows are all inside the timed region (`resamples`, `scan_ms`).
-`host_normals` is the parity-mode figure (1.2 MB/scan of reference-order normals copied inside the call;
-PCIe-inclusive, never the headline); `device_ms_per_scan` is the sum of the kernels' HIP-event durations.
-
-roofline (dominant kernel = the raycast / log-odds update): algorithmic bytes are COUNTED on the device
-(TBNAV_RBPF_OPT_COUNT_CELLS): every distinct cell a scan writes is one f64 read + one f64 write = 16 B; SURVEY.md
-8-d's (C_free + Bv) * 16 — one RMW per (beam, cell) touch, what the reference's loop does — is reported beside it.
+Two modes, side by side (`modes`):
+  reference_equal  TBNAV_RBPF_DF_REFERENCE — the reference's own brushfire field bit for bit (lazy, host cores; csrc/ref_field.hpp):
+                   synchronous tbnav_rbpf_slam calls, device noise, first scan untimed;
+  query_default    the C-ABI's default (exact nearest-obstacle distance per lookup): particle-updates/s = N * SLAM calls / wall time
+                   of the logged run replayed through tbnav_rbpf_slam_batch with the standard normals drawn ON the device (nothing
+                   but the 1.4 KB scan crosses PCIe).  Two of the timed scans are forced to RESAMPLE (skewed weights set beforehand,
+                   untimed): their table copies, the state gather and the tile clones of the scan that follows are in the time.
+roofline (dominant kernel = the raycast / log-odds update of the query mode): algorithmic bytes are COUNTED on the device
+(TBNAV_RBPF_OPT_COUNT_CELLS): every distinct cell a scan writes is one f64 read + one f64 write = 16 B; the kernel's time by live HIP
+events (`frac`) and by the committed rocprofv3 row of exactly this instantiation (`frac_rocprof`); `traffic` from the committed PMC passes.
+Everything else (options, other rooms and shapes, noise forms, reference-field variants): bench_rbpf_detail.py, with bench.py --detail.
 """
 from __future__ import annotations
 
-import json
 import os
 import sys
 import time
@@ -25,7 +25,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 HBM_PEAK_GBS = 8000.0
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from rbpf_cases import ROOM_BENCH, ROOM_SURVEY, TRAJ_BENCH as TRAJ_INC, TRAJ_SURVEY  # noqa: E402  (pure constants; the rooms the full-size parity tests use)
+from rbpf_cases import ROOM_BENCH, ROOM_SURVEY, TRAJ_BENCH as TRAJ_INC, TRAJ_SURVEY  # noqa: E402,F401  (pure constants; the rooms the full-size parity tests use)
 RESAMPLE_AT = (8, 14)                 # timed scans forced to resample
 
 
@@ -50,201 +50,8 @@ def _skew(pf, N):
     pf.setParticles(w=w / w.sum())
 
 
-def configs4_shard(device, N=12500, k=50, n_scans=8):
-    """One GPU's shard of BASELINE configs[4] (100 000 particles / 8 GPUs, 2000 x 2000 cells @ 0.05 m, 1080-beam scans): the
-    per-rank work of that configuration measured on this GPU — replayed through tbnav_rbpf_slam_batch, device noise, the
-    first two scans (first-touch tile allocation) untimed.  Across ranks the per-scan exchange adds one all-gather of
-    100 000 weights and the global selection."""
-    from rtn_amd.rbpf import ParticleFilter, default_params
-    rc = _world()
-    bd = 1.0 / 3.0
-    pf = ParticleFilter(default_params(N=N, k=k, map_min=-50.0, map_max=50.0, beam_delta_deg=bd, device=device.index or 0), pool_bytes=16 << 30)
-    pf.setSeed(5)
-    steps, poses = rc.trajectory(n_scans, inc=(0.05, 0.04, 0.03))
-    rng = np.random.default_rng(8)
-    scans = np.stack([_room_scan(poses[s], rng, (-3.0, 3.0, -2.5, 2.5), n_beams=1080, beam_delta_deg=bd) for s in range(n_scans)])
-    odom = np.array([steps[0][0]] + [st_[1] for st_ in steps], dtype=np.float64)
-    u_all = np.array([st_[3] for st_ in steps], dtype=np.float64)
-    ticp_all = np.array([st_[2] for st_ in steps], dtype=np.float64)
-    pf.SLAMBatch(scans[:2], u_all[:2], odom[:3], ticp_all[:2])
-    t0 = time.perf_counter()
-    sts = pf.SLAMBatch(scans[2:], u_all[2:], odom[2:], ticp_all[2:])
-    dt = (time.perf_counter() - t0) / (n_scans - 2)
-    cap, free, tile_bytes = pf.poolStats()
-    out = {"workload": f"RBPF N={N} (= 100 000 / 8), k={k}, {int(sts[-1].n_valid_beams)} valid beams of 1080, {pf.xsize}x{pf.ysize} @0.05 m, one GPU",
-           "particle_updates_per_s": round(N / dt, 1), "ms_per_scan": round(dt * 1e3, 4), "scans_timed": n_scans - 2,
-           "resamples": int(sum(x.resampled for x in sts)), "log_odds_bytes_in_use": (cap - free) * tile_bytes,
-           "dense_equivalent_bytes": N * pf.G * 8}
-    pf.close()
-    return out
-
-
 def _kernel_threads(name):   # "rbpf_raycast_box<512, 6, false, 8>" -> 512
     return int(name.split("<")[1].rstrip(">").split(",")[0])
-
-
-def map_update_leg(device, label, N, k, map_half, walls, inc, n_scans=12, n_beams=360, beam_delta_deg=1.0, pool_bytes=0,
-                   traffic_key=None, stats_workload=None, sq_key=None):
-    """A first-class leg for ONE workload of the scan update (round-4 review: every BASELINE shape carries its own roofline): the
-    kernels that ran (names as the profiler spells them), their HIP-event times over the plain scans, the distinct cells counted on
-    the device (TBNAV_RBPF_OPT_COUNT_CELLS) -> algorithmic bytes of the map update, its fraction of the HBM roofline by events and
-    by the AVERAGE of this workload's own committed profiler row, and the PMC traffic of this workload's own passes."""
-    from rtn_amd import capi
-    from rtn_amd.rbpf import ParticleFilter, default_params
-    import bench_profiles as bp
-    rc = _world()
-    mk = lambda: ParticleFilter(default_params(N=N, k=k, map_min=-map_half, map_max=map_half, beam_delta_deg=beam_delta_deg,  # noqa: E731
-                                               device=device.index or 0), pool_bytes=pool_bytes)
-    steps, poses = rc.trajectory(n_scans, inc=inc)
-    rng = np.random.default_rng(7)
-    scans = [_room_scan(poses[s], rng, walls, n_beams=n_beams, beam_delta_deg=beam_delta_deg) for s in range(n_scans)]
-    pf_c = mk()
-    pf_c.setSeed(2026); pf_c.setOption(capi.RBPF_OPT_COUNT_CELLS, 1)
-    for s, (prev, cur, t_icp, u) in enumerate(steps):
-        if s == 2:
-            pf_c.scanCounts(reset=True)
-        st = pf_c.SLAM(scans[s], u, cur, prev, True, t_icp, None)
-    upd, distinct = pf_c.scanCounts()
-    pf_c.close()
-    distinct_per, upd_per = distinct / ((n_scans - 2) * N), upd / ((n_scans - 2) * N)
-    pf_k = mk()
-    pf_k.setSeed(2026); pf_k.setTiming(True)
-    kms, n_k, wall = {}, 0, 0.0
-    for s, (prev, cur, t_icp, u) in enumerate(steps):
-        t0 = time.perf_counter()
-        st = pf_k.SLAM(scans[s], u, cur, prev, True, t_icp, None)
-        if s >= 4:   # (the LDS array has adapted to the boxes' need by then)
-            wall += time.perf_counter() - t0
-            for key, v in pf_k.kernelMs().items():
-                kms[key] = kms.get(key, 0.0) + v
-            n_k += 1
-    k_propose, k_raycast, _ = pf_k.lastKernelNames()
-    cap, free, tile_bytes = pf_k.poolStats()
-    pf_k.close()
-    kms = {key: v / n_k for key, v in kms.items() if key not in ("edt", "occupancy")}
-    alg = distinct_per * 16.0 * N
-    t_rc = kms["raycast"] * 1e-3
-    grid = _kernel_threads(k_raycast) * (N + 1) if "<" in k_raycast else None
-    row = None if grid is None else (bp.rocprof_row(k_raycast, grid, stats_workload) or bp.rocprof_row(k_raycast, _kernel_threads(k_raycast) * N, stats_workload))
-    pmc = bp.pmc_row(traffic_key, k_raycast) if traffic_key else None
-    return {"workload": f"RBPF {label}: N={N}, k={k}, {int(st.n_valid_beams)} valid beams of {n_beams}, {int(2 * map_half / 0.05)}^2 @0.05 m, walls {list(walls)}, trajectory step {list(inc)}; "
-                        f"synchronous scans with event timing, device noise",
-            "kernels": {"propose": k_propose, "raycast": k_raycast},
-            "kernel_ms": {key: round(v, 4) for key, v in kms.items()}, "scans_timed": n_k,
-            "log_odds_bytes_in_use": (cap - free) * tile_bytes,
-            "roofline": {"bound": "hbm", "kernel": k_raycast, "kernel_ms": round(kms["raycast"], 6),
-                         "algorithmic_bytes_per_launch": round(alg, 1),
-                         "algorithmic_bytes_note": f"{distinct_per:.1f} distinct cells written per particle and scan (counted on the device) x 16 B x N; per-touch count {upd_per:.1f}",
-                         "achieved": round(alg / t_rc / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(alg / t_rc / 1e9 / HBM_PEAK_GBS, 6), "frac_events": round(alg / t_rc / 1e9 / HBM_PEAK_GBS, 6),
-                         "frac_rocprof": None if row is None else round(alg / (row["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 6),
-                         "frac_rocprof_of": "avg_us", "rocprof": row,
-                         "traffic": None if pmc is None else pmc["hbm_bytes"],
-                         "traffic_source": None if pmc is None else pmc["source"] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; plain scans)",
-                         "traffic_over_algorithmic": None if pmc is None else round(pmc["hbm_bytes"] / alg, 3),
-                         "sq_counters": bp.sq_row(sq_key, k_raycast) if sq_key else None,
-                         "second_kernel": {"kernel": k_propose, "kernel_ms": round(kms["propose"], 6),
-                                           "rocprof": bp.rocprof_row(k_propose, _kernel_threads(k_propose) * (N + 1), stats_workload) if "<" in k_propose else None}}}
-
-
-def noise_forms(device, N, k, n_scans=30):
-    """Where the device noise is drawn (TBNAV_RBPF_OPT_NOISE_IN_KERNEL), side by side on the bench workload: 1 — inside
-    rbpf_propose, the beam table through its leading workgroup, two launches per scan; 0 (default since round 6) — rbpf_sample_normals
-    stores the stream first, three launches.  Wall time of synchronous calls without event timing, and the proposal kernel by HIP events."""
-    from rtn_amd import capi
-    from rtn_amd.rbpf import ParticleFilter, default_params
-    steps, scans = workload(n_scans)
-    out = {}
-    for name, val in (("in_kernel", 1), ("stored_first", 0)):
-        res = {}
-        for timing in (False, True):
-            pf = ParticleFilter(default_params(N=N, k=k, map_min=-10.0, map_max=10.0, device=device.index or 0))
-            pf.setSeed(2026); pf.setTiming(timing); pf.setOption(capi.RBPF_OPT_NOISE_IN_KERNEL, val)
-            wall, n, prop = 0.0, 0, 0.0
-            for s, (prev, cur, t_icp, u) in enumerate(steps):
-                t0 = time.perf_counter()
-                pf.SLAM(scans[s], u, cur, prev, True, t_icp, None)
-                if s >= 6:
-                    wall += time.perf_counter() - t0; n += 1
-                    if timing:
-                        prop += pf.kernelMs()["propose"]
-            if timing:
-                res["propose_kernel_ms"] = round(prop / n, 5); res["propose_kernel"] = pf.lastKernelNames()[0]
-            else:
-                res["ms_per_synchronous_scan"] = round(wall / n * 1e3, 5)
-            pf.close()
-        out[name] = res
-    out["note"] = ("drawing inside the kernel removes the 4.7 us rbpf_sample_normals launch and 2.4 MB of traffic per scan; the proposal launch's interval grows by ~4 us, of which "
-                   "under 1 us is inside its workgroups (78 threads draw one fp64 Box-Muller pair each, the wait for the beam table; per-wave timelines: profiles/r05_phase_timelines.txt, "
-                   "docs/lab_notebook.md) — the rest is the scan's first dispatch after the host's wait, which used to be the sample launch's: the wall time of a synchronous scan is the "
-                   "same within 1-2 us.  The headline's tbnav_rbpf_slam_batch draws a chunk of scans ahead in one launch either way")
-    return out
-
-
-def layout_floor(walls, inc, n_scans=14, first=2, seed=7):
-    """The HBM bytes per particle and scan the map update cannot go below WITH THIS MAP LAYOUT (no GPU needed): every 128-byte line that
-    holds a touched cell is fetched whole, every 32-byte sector that holds one is written whole (profiles/r05_fetch_write_calibration.txt:
-    what FETCH_SIZE / WRITE_SIZE count on gfx950 for partial-line 16-byte accesses), tiles of 32 x 32 cells whose rows are 256 contiguous
-    bytes.  The cells of the scan's Bresenham rays from the robot's cell at the trajectory's poses (the particles are micrometres from
-    them), as distinct cells, sectors and lines; mean over scans [first, n_scans)."""
-    rc = _world()
-    res, map_min, rmin, rmax = 0.05, -10.0, 0.12, 3.5
-    _, poses = rc.trajectory(n_scans, inc=inc)
-    rng = np.random.default_rng(seed)
-    rows = []
-    for s in range(n_scans):
-        th, x, y = poses[s]
-        scan = _room_scan(poses[s], rng, walls).astype(np.float64)
-        ang = th + np.deg2rad(1.0) * np.arange(scan.size)
-        ok = (scan >= rmin) & (scan < rmax)
-        ex, ey = x + scan * np.cos(ang), y + scan * np.sin(ang)
-        cx, cy = int(np.floor((x - map_min) / res)), int(np.floor((y - map_min) / res))
-        cells = set()
-        for b in np.flatnonzero(ok):
-            x1, y1 = int(np.floor((ex[b] - map_min) / res)), int(np.floor((ey[b] - map_min) / res))
-            x0, y0 = cx, cy
-            dx, dy = abs(x1 - x0), abs(y1 - y0)
-            sx, sy = (1 if x1 > x0 else -1), (1 if y1 > y0 else -1)
-            err = dx - dy
-            while True:   # (a textbook Bresenham: the counts move by a fraction of a percent between variants; the kernel's is grid_mapper.cpp:229-270's)
-                cells.add((x0, y0))
-                if x0 == x1 and y0 == y1:
-                    break
-                e2 = 2 * err
-                if e2 > -dy:
-                    err -= dy; x0 += sx
-                if e2 < dx:
-                    err += dx; y0 += sy
-        if s >= first:
-            rows.append((len(cells), len({(i, j >> 2) for i, j in cells}), len({(i, j >> 4) for i, j in cells}), int(ok.sum())))
-    r = np.array(rows, dtype=np.float64).mean(axis=0)
-    return {"distinct_cells": round(float(r[0]), 1), "sectors_32B": round(float(r[1]), 1), "lines_128B": round(float(r[2]), 1), "valid_beams": round(float(r[3]), 1),
-            "algorithmic_bytes": float(r[0]) * 16.0, "read_floor_bytes": float(r[2]) * 128.0, "write_floor_bytes": float(r[1]) * 32.0}
-
-
-def long_replay(device, N, k, n_scans=56, warm=8):
-    """The bench workload replayed by ONE tbnav_rbpf_slam_batch call, as it comes (no weights skewed: the filter does not resample on it):
-    what a scan costs when nothing sits between the launches — the headline cuts its replay into calls of 6 scans and forces a resampling
-    at two of the cuts, which is where its ms_per_scan exceeds the kernels' sum."""
-    from rtn_amd.rbpf import ParticleFilter, default_params
-    steps, scans = workload(n_scans)
-    odom = np.array([steps[0][0]] + [st_[1] for st_ in steps], dtype=np.float64)
-    u_all = np.array([st_[3] for st_ in steps], dtype=np.float64)
-    ticp_all = np.array([st_[2] for st_ in steps], dtype=np.float64)
-    sc = np.stack(scans)
-    pf = ParticleFilter(default_params(N=N, k=k, map_min=-10.0, map_max=10.0, device=device.index or 0))
-    pf.setSeed(2026)
-    pf.SLAMBatch(sc[:warm], u_all[:warm], odom[:warm + 1], ticp_all[:warm])
-    t0 = time.perf_counter()
-    sts = pf.SLAMBatch(sc[warm:], u_all[warm:], odom[warm:], ticp_all[warm:])
-    dt = time.perf_counter() - t0
-    k_propose, k_raycast, _ = pf.lastKernelNames()
-    pf.close()
-    n = n_scans - warm
-    return {"ms_per_scan": round(dt / n * 1e3, 4), "particle_updates_per_s": round(N * n / dt, 1), "scans_timed": n, "calls": 1,
-            "resamples": int(sum(x.resampled for x in sts)), "kernels": {"propose": k_propose, "raycast": k_raycast},
-            "note": "two launches per scan back to back (the noise of eight scans at a time by a third); the two kernels by rocprofv3: "
-                    "profiles/r05_kernel_stats_rbpf_N1000_k50_400x400*.md (rbpf_propose<256, false> 27.0 us median, rbpf_raycast_box<512, 8, false, 4> 37.3)"}
 
 
 def reference_field_mode(device, N, k, map_half, walls, n_scans, host_threads=0, spread=None, start=(0.0, 0.0, 0.0), inc=None):
@@ -284,41 +91,6 @@ def reference_field_mode(device, N, k, map_half, walls, n_scans, host_threads=0,
             "host_threads": host_threads or effective_cores()}
 
 
-def configs4_as_written(device, N=100_000, P=8, k=50, n_scans=7):
-    """BASELINE configs[4] as written on ONE GPU: 100 000 particles in 8 shards of 12 500 (tbnav_rbpf_group, every member on this
-    device: the library's own sharded scan — weights all-gather, global normalise beside the map update, migration when
-    resampling fires — with its in-process copy transport; on 8 devices the same calls go through RCCL), 1080-beam scans,
-    2000 x 2000 cells, device noise; one of the timed scans is forced to resample across members.  Beside it: ONE handle holding
-    all 100 000 particles.  (8 members on one device run one after another: this prices the sharded code path, not a speed-up.)"""
-    from rtn_amd.rbpf import ParticleFilter, ParticleFilterGroup, default_params
-    rc = _world()
-    bd = 1.0 / 3.0
-    kw = dict(map_min=-50.0, map_max=50.0, beam_delta_deg=bd)
-    steps, poses = rc.trajectory(n_scans, inc=(0.05, 0.04, 0.03))
-    rng = np.random.default_rng(8)
-    scans = [_room_scan(poses[s], rng, (-3.0, 3.0, -2.5, 2.5), n_beams=1080, beam_delta_deg=bd) for s in range(n_scans)]
-    out = {}
-    for name, mk in (("eight_shards", lambda: ParticleFilterGroup(default_params(N=N, k=k, **kw), [device.index or 0] * P, pool_bytes_per_member=10 << 30)),
-                     ("one_handle", lambda: ParticleFilter(default_params(N=N, k=k, device=device.index or 0, **kw), pool_bytes=80 << 30))):
-        pf = mk()
-        pf.setSeed(5)
-        plain, res = [], []
-        for s, (prev, cur, t_icp, u) in enumerate(steps):
-            if s == 4:
-                w = np.full(N, 0.3 / N); w[7] += 0.3; w[60_000] += 0.3; w[N - 1] += 0.1
-                pf.setParticles(w=w)
-            t0 = time.perf_counter()
-            st = pf.SLAM(scans[s], u, cur, prev, True, t_icp, None)
-            dt = time.perf_counter() - t0
-            if s >= 2:
-                (res if st.resampled else plain).append(dt)
-        out[name] = {"ms_per_scan_without_resample": round(float(np.mean(plain)) * 1e3, 3), "ms_per_resampling_scan": round(float(np.mean(res)) * 1e3, 3) if res else None,
-                     "particle_updates_per_s": round(N / float(np.mean(plain)), 1)}
-        pf.close()
-    out["workload"] = f"RBPF N={N}, k={k}, 1080-beam scans, 2000x2000 @0.05 m (BASELINE configs[4]) on one GPU"
-    return out
-
-
 def workload(n_scans=20):
     rc = _world()
     steps, poses = rc.trajectory(n_scans, inc=TRAJ_INC)
@@ -328,26 +100,13 @@ def workload(n_scans=20):
 
 
 def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True, detail=False):
-    """detail=False (what the driver's command runs): the headline replay, the counted-cells and event-timing passes its roofline needs,
-    the reference-equal mode at configs[2], the two CPU baselines.  detail=True adds every other leg (bench.py --detail)."""
+    """What the driver's command runs: the headline replay, the counted-cells and event-timing passes its roofline needs, the
+    reference-equal mode at configs[2], the two CPU baselines.  detail=True adds every other leg (bench_rbpf_detail.add_legs)."""
+    import bench_profiles as bp
     from rtn_amd import capi
     from rtn_amd.rbpf import ParticleFilter, default_params
     mk = lambda: ParticleFilter(default_params(N=N, k=k, map_min=-10.0, map_max=10.0, device=device.index or 0))  # noqa: E731
     steps, scans = workload(n_scans)
-    pf = mk()
-    nn = pf.numNormals(True)
-    # ---- parity-mode pass (host normals, PCIe-inclusive), its own filter
-    t_host, n_host = 0.0, 0
-    if detail:
-        normals = [np.random.default_rng(100 + s).standard_normal(nn) for s in range(n_scans)]
-        pf_h = mk()
-        for s, (prev, cur, t_icp, u) in enumerate(steps):
-            t0 = time.perf_counter()
-            pf_h.SLAM(scans[s], u, cur, prev, True, t_icp, normals[s])
-            if s >= 2:
-                t_host += time.perf_counter() - t0; n_host += 1
-        pf_h.close()
-        del normals
     # ---- counted cells: their own pass (the counters cost device time)
     pf_c = mk()
     pf_c.setSeed(2026); pf_c.setOption(capi.RBPF_OPT_COUNT_CELLS, 1)
@@ -357,57 +116,38 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True, detail=False):
         pf_c.SLAM(scans[s], u, cur, prev, True, t_icp, None)
     upd, distinct = pf_c.scanCounts()
     pf_c.close()
-    # ---- per-kernel durations: their own pass (each HIP event costs device time)
+    n_counted = (n_scans - 2) * N
+    upd_per, distinct_per = upd / n_counted, distinct / n_counted
+    # ---- per-kernel durations: their own pass (each HIP event costs device time).  Three kinds of scan: plain; the one that
+    #      resamples (its own gather launch); the FIRST scan after a resampling, whose map update makes every written tile of a shared
+    #      map private — the roofline's algorithmic bytes are the plain scan's, so its kernel time is the plain scans' too
     pf_k = mk()
     pf_k.setSeed(2026); pf_k.setTiming(True)
-    # three kinds of scan: plain; the one that resamples (its own gather launch); and the FIRST scan after a resampling, whose map
-    # update makes every written tile of a shared map private (8 KB copies: ~70 KB per particle on top of the cells it writes) —
-    # the roofline's algorithmic bytes are the plain scan's, so its kernel time is the plain scans' too
     kms, kms_res, kms_cow, n_k, n_kr, n_kc = {}, {}, {}, 0, 0, 0
     after_resample = False
     for s, (prev, cur, t_icp, u) in enumerate(steps):
         if s in RESAMPLE_AT:
             _skew(pf_k, N)
         st = pf_k.SLAM(scans[s], u, cur, prev, True, t_icp, None)
-        k_propose, k_raycast, k_raycast_wgs = pf_k.lastKernelNames()
-        if s >= 4:  # (the map update's LDS array has adapted to the boxes' need by then: the steady state's kernels; the headline pass times from scan 2 on)
+        k_propose, k_raycast, _ = pf_k.lastKernelNames()
+        if s >= 4:  # (the map update's LDS array has adapted to the boxes' need by then: the steady state's kernels)
             tgt = kms_res if st.resampled else (kms_cow if after_resample else kms)
             for key, v in pf_k.kernelMs().items():
                 tgt[key] = tgt.get(key, 0.0) + v
-            if st.resampled:
-                n_kr += 1
-            elif after_resample:
-                n_kc += 1
-            else:
-                n_k += 1
+            n_kr += int(bool(st.resampled)); n_kc += int(after_resample and not st.resampled); n_k += int(not st.resampled and not after_resample)
         after_resample = bool(st.resampled)
-    n_counted = (n_scans - 2) * N
-    upd_per, distinct_per = upd / n_counted, distinct / n_counted
     pf_k.close()
-    kms = {key: v / max(n_k, 1) for key, v in kms.items()}
-    kms_res = {key: v / max(n_kr, 1) for key, v in kms_res.items()}
+    kms = {key: v / max(n_k, 1) for key, v in kms.items() if key not in ("edt", "occupancy")}   # (query mode has no distance-field pass)
+    kms_res = {key: v / max(n_kr, 1) for key, v in kms_res.items() if key not in ("edt", "occupancy")}
     kms_cow = {key: v / max(n_kc, 1) for key, v in kms_cow.items()}
-    # ---- single-call pass: one tbnav_rbpf_slam call per scan from this (Python) harness — what round 1 and the first half
-    #      of round 2 reported; kept beside the headline to show what the harness costs
-    t_single, n_single = 0.0, 0
-    if detail:
-        pf_s = mk()
-        pf_s.setSeed(2026)
-        for s, (prev, cur, t_icp, u) in enumerate(steps):
-            if s in RESAMPLE_AT:
-                _skew(pf_s, N)
-            t0 = time.perf_counter()
-            pf_s.SLAM(scans[s], u, cur, prev, True, t_icp, None)
-            if s >= 2:
-                t_single += time.perf_counter() - t0; n_single += 1
-        pf_s.close()
-    # ---- headline pass: the logged run replayed through tbnav_rbpf_slam_batch (the same synchronous per-scan calls, made
-    #      from C), in stretches between the points where the weights are skewed (untimed) to force a resample
-    t_total, n_timed, resamples, scan_ms = 0.0, 0, 0, []
+    # ---- headline pass: the logged run replayed through tbnav_rbpf_slam_batch (the same synchronous per-scan calls, made from C),
+    #      in stretches between the points where the weights are skewed (untimed) to force a resample
+    pf = mk()
     pf.setSeed(2026)
     odom = np.array([steps[0][0]] + [st_[1] for st_ in steps], dtype=np.float64)
     u_all = np.array([st_[3] for st_ in steps], dtype=np.float64)
     ticp_all = np.array([st_[2] for st_ in steps], dtype=np.float64)
+    t_total, n_timed, resamples, scan_ms = 0.0, 0, 0, []
     cuts = sorted(set([0, 2, n_scans] + [r for r in RESAMPLE_AT if r < n_scans]))
     for lo, hi in zip(cuts[:-1], cuts[1:]):
         if lo in RESAMPLE_AT:
@@ -418,183 +158,74 @@ def run(device, args, N=1000, k=50, n_scans=20, with_cpu=True, detail=False):
         if lo >= 2:  # first two scans: empty maps / first-touch tile allocation
             t_total += dt; n_timed += hi - lo; scan_ms.append(round(dt / (hi - lo) * 1e3, 4))
         resamples += sum(x.resampled for x in sts)
-        st = sts[-1]
     ms_scan = t_total / n_timed * 1e3
     cap, free, tile_bytes = pf.poolStats()
-    Bv = int(st.n_valid_beams)
-    # ---- the per-particle scan-matching option on the same scans, its own filter
-    t_sm, n_sm = 0.0, 0
-    if detail:
-        pf_m = mk()
-        pf_m.setSeed(2026); pf_m.setScanMatching(True)
-        for s, (prev, cur, t_icp, u) in enumerate(steps[:12]):
-            t0 = time.perf_counter()
-            pf_m.SLAM(scans[s], u, cur, prev, True, t_icp, None)
-            if s >= 2:
-                t_sm += time.perf_counter() - t0; n_sm += 1
-        pf_m.close()
-    # ---- SURVEY.md 8-d's two other runs: the ICP-failed branch (motion-model sample + one likelihood per particle), and k = 10
-    def replay(pf_x, icp_ok):
-        pf_x.setSeed(2026)
-        icp = np.full(n_scans, 1 if icp_ok else 0, dtype=np.int32)
-        pf_x.SLAMBatch(np.stack(scans[:2]), u_all[:2], odom[:3], ticp_all[:2], icp_ok=icp[:2])
-        t0 = time.perf_counter()
-        pf_x.SLAMBatch(np.stack(scans[2:]), u_all[2:], odom[2:], ticp_all[2:], icp_ok=icp[2:])
-        return (time.perf_counter() - t0) / (n_scans - 2)
-    t_fail = t_k10 = None
-    if detail:
-        pf_f = mk()
-        t_fail = replay(pf_f, False)
-        pf_f.close()
-        pf_k = ParticleFilter(default_params(N=N, k=10, map_min=-10.0, map_max=10.0, device=device.index or 0))
-        t_k10 = replay(pf_k, True)
-        pf_k.close()
-    big = detail and not getattr(args, "no_large", False)
-    shard4 = configs4_shard(device) if big else None
-    if shard4 is not None:
-        # ... and its roofline object: the per-GPU shard shape of BASELINE configs[4] (12 500 x 2000^2 x 1080 beams), synchronous scans
-        shard4["roofline_leg"] = map_update_leg(device, "configs[4] / 8", 12500, k, 50.0, ROOM_SURVEY, (0.05, 0.04, 0.03), n_scans=8, n_beams=1080,
-                                                beam_delta_deg=1.0 / 3.0, pool_bytes=16 << 30, traffic_key="rbpf_N12500_2000x2000_1080beams",
-                                                stats_workload="rbpf_N12500_2000x2000_1080beams", sq_key="rbpf_N12500_2000x2000_1080beams")
-    cfg4 = configs4_as_written(device) if big else None
-    rc_ = _world()
-    ref_mode = {"launch_configuration_40_particles_80x80": reference_field_mode(device, 40, 50, 2.0, rc_.ROOM_SMALL, 12) if detail else None,
-                "configs2_1000_particles_400x400": reference_field_mode(device, N, k, 10.0, ROOM_BENCH, n_scans),
-                # SURVEY 8-d's trajectory starts on a corner of four cells and moves by whole cells: the 1e-8 m sampling spread then
-                # DOES put beams in different cells and little is shared.  Off the corners (start and step not multiples of the cell
-                # size) most particles see the same cells change: what the state sharing buys where it works
-                "configs2_off_the_cell_corners": None if not big else reference_field_mode(device, N, k, 10.0, ROOM_BENCH, 8, start=(0.013, 0.0137, 0.0211), inc=(0.07, 0.0213, 0.0117)),
-                "configs2_every_particle_distinct": None if not big else reference_field_mode(device, N, k, 10.0, ROOM_BENCH, 3, spread=(0.02, 0.05, 0.05)),
-                "note": "every figure outside this object is for the default exact-distance (query) mode, whose likelihoods differ from the "
-                        "reference's by up to 7.5e-3 at 400x400 (tests/test_rbpf_field_gpu.py); this mode meets the 1e-5 bar un-injected"}
-    if True:
-        # (query mode has no distance-field pass: the 'edt' / 'occupancy' intervals bracket nothing but two event records)
-        for d_ in (kms, kms_res):
-            d_.pop("edt", None); d_.pop("occupancy", None)
+    Bv, xsize, ysize, G = int(sts[-1].n_valid_beams), pf.xsize, pf.ysize, pf.G
+    pf.close()
+    # ---- the mode that reproduces the reference's field
+    rm = reference_field_mode(device, N, k, 10.0, ROOM_BENCH, n_scans)
+    # ---- the roofline of the dominant kernel: the committed profiler rows of exactly this instantiation and grid (N particles'
+    #      workgroups + the normalise workgroup)
     dev_ms = sum(kms.values())
     alg_dom = distinct_per * 16.0 * N             # bytes the raycast launch has to move: one RMW per distinct cell
-    alg_ref = upd_per * 16.0 * N                  # one RMW per (beam, cell) touch
-    # what one particle-update has to move on the device: the log-odds RMW, the slice of its occupancy bitmap the
-    # lookups read, its normals, and the per-stage outputs the C-ABI keeps (trace)
-    slice_bytes = min(pf.xsize, 2 * (int(np.ceil(3.5 / 0.05)) + 2 + 48) + 1) * 4 * 8
-    dev_alg_per = distinct_per * 16.0 + slice_bytes + (3 * k + 3) * 8 + (k * 5 + 17) * 8
-    import bench_profiles as bp
-    t_rc = kms["raycast"] * 1e-3   # s per launch, live HIP events
-    # the committed profiler rows of exactly this instantiation and grid (N particles' workgroups + the normalise workgroup)
-    _threads = _kernel_threads
-    rp_row = None
-    if "<" in k_raycast and N == 1000:   # the grid of THIS workload: N particles' workgroups (+ the normalise workgroup when it rode along)
-        rp_row = (bp.rocprof_row(k_raycast, _threads(k_raycast) * (N + 1), "rbpf_N1000_k50_400x400_plain_scans_only") or
-                  bp.rocprof_row(k_raycast, _threads(k_raycast) * (N + 1)) or bp.rocprof_row(k_raycast, _threads(k_raycast) * N))
-    pmc = bp.pmc_row("rbpf_N1000_k50_400x400_plain_scans_only", k_raycast) if N == 1000 else None
-    rp_propose = None
-    if "<" in k_propose and N == 1000:   # (round 5: the proposal launch has a leading workgroup that carries the beam table over)
-        rp_propose = (bp.rocprof_row(k_propose, _threads(k_propose) * (N + 1), "rbpf_N1000_k50_400x400_plain_scans_only") or
-                      bp.rocprof_row(k_propose, _threads(k_propose) * (N + 1)) or bp.rocprof_row(k_propose, _threads(k_propose) * N))
-    rm = ref_mode.get("configs2_1000_particles_400x400") or {}
-    rm_off = ref_mode.get("configs2_off_the_cell_corners") or {}
-    # the two modes side by side, with equal weight (round-3 review): the one that reproduces the reference's results, and the
-    # one the headline `value` is measured in
-    modes = {
-        "reference_equal": {"distance_field": "the reference's own priority-queue brushfire, reproduced bit for bit, run lazily (host cores, one resumable pass per distinct particle state; csrc/ref_field.hpp)",
-                            "particle_updates_per_s": rm.get("particle_updates_per_s"), "ms_per_scan": rm.get("ms_per_scan"),
-                            "particle_updates_per_s_off_the_cell_corners": rm_off.get("particle_updates_per_s"),
-                            "parity": "likelihoods / eta / weights <= 1e-9, Neff / parents / best particle identical to the oracle, nothing injected, N = 1000 x 400^2 (tests/test_rbpf_field_gpu.py); meets north_star's 1e-5",
-                            "vs_target_1e5": None if not rm.get("particle_updates_per_s") else round(rm["particle_updates_per_s"] / 1e5, 4)},
-        "query_default": {"distance_field": "exact squared distance to the nearest occupied cell, computed per lookup from the occupancy bits (no field refresh)",
-                          "particle_updates_per_s": round(N / (ms_scan * 1e-3), 1), "ms_per_scan": round(ms_scan, 4),
-                          "parity": "equal (<= 1e-9; integers identical) to the restated filter reading the EXACT distance (oracle exact_field switch) at N = 1000 x 400^2 and at "
-                                    "configs[4]'s shard shape; against the reference's brushfire field its likelihoods / weights differ by up to 7.5e-3 at 400 x 400 "
-                                    "(4e-14 on the shipped 80 x 80 launch configuration) — OUTSIDE north_star's 1e-5 on this grid",
-                          "vs_target_1e5": round(N / (ms_scan * 1e-3) / 1e5, 2)},
-    }
-    # what this map layout lets the traffic go down to (layout_floor above: whole lines read, whole sectors written), beside what was measured
-    fl = layout_floor(ROOM_BENCH, TRAJ_INC)
-    fl_bytes = (fl["read_floor_bytes"] + fl["write_floor_bytes"]) * N
-    floor_obj = {"bytes_per_launch": round(fl_bytes, 1), "over_algorithmic": round((fl["read_floor_bytes"] + fl["write_floor_bytes"]) / fl["algorithmic_bytes"], 3),
-                 "reads": round(fl["read_floor_bytes"] * N, 1), "writes": round(fl["write_floor_bytes"] * N, 1),
-                 "measured_reads": None if pmc is None else pmc.get("read_bytes"), "measured_writes": None if pmc is None else pmc.get("write_bytes"),
-                 "traffic_over_floor": None if pmc is None else round(pmc["hbm_bytes"] / fl_bytes, 3),
-                 "note": f"{fl['lines_128B']:.0f} 128-byte lines and {fl['sectors_32B']:.0f} 32-byte sectors hold the {fl['distinct_cells']:.0f} cells one scan touches (modelled on the host from the "
-                         "trajectory's poses; tiles of 32 x 32 cells, rows of 256 bytes): a touched line is FETCHED whole, a touched sector WRITTEN whole "
-                         "(profiles/r05_fetch_write_calibration.txt, tools/fetch_calibrate.hip) — the floor of any kernel over this layout"}
+    t_rc = kms["raycast"] * 1e-3                  # s per launch, live HIP events
+    wl = "rbpf_N1000_k50_400x400_plain_scans_only"
+    rows = lambda name: None if "<" not in name or N != 1000 else (   # noqa: E731
+        bp.rocprof_row(name, _kernel_threads(name) * (N + 1), wl) or bp.rocprof_row(name, _kernel_threads(name) * (N + 1)) or bp.rocprof_row(name, _kernel_threads(name) * N))
+    rp_row, rp_propose = rows(k_raycast), rows(k_propose)
+    pmc = bp.pmc_row(wl, k_raycast) if N == 1000 else None
+    frac = lambda us: round(alg_dom / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 6)   # noqa: E731
     out = {
         "metric": "RBPF particle-updates/s", "value": round(N / (ms_scan * 1e-3), 1), "unit": "particle-updates/s",
-        "value_is_for_mode": "query_default", "modes": modes,
-        "config": {"workload": f"RBPF SLAM N={N}, k={k}, {Bv} valid beams of 360, {pf.xsize}x{pf.ysize} @0.05 m, ICP-ok branch "
-                               "(BASELINE configs[2])", "scans_timed": n_timed, "resamples": resamples, "entry_point": "tbnav_rbpf_slam_batch (synchronous per scan)",
-                   "inputs": "standard normals drawn on the device (Philox); only the 1.4 KB scan is a host buffer",
-                   "room": list(ROOM_BENCH),
-                   "room_note": "walls at x = +-2.2, y = +-2.0 m instead of SURVEY 8-d's +-3.0 / +-2.5: chosen so that all 360 beams are inside "
-                                "[range_min, range_max) at every pose (47 % more lookups and ray cells per scan than the SURVEY room's 246 valid beams)"},
-        "host_normals": None if not n_host else {"value": round(N / (t_host / n_host), 1), "ms_per_scan": round(t_host / n_host * 1e3, 4),
-                                                 "note": "parity mode: 1.2 MB/scan of reference-order normals copied H2D inside the call (PCIe-inclusive)"},
+        "value_is_for_mode": "query_default",
+        # the two modes side by side, with equal weight (round-3 review): the one that reproduces the reference's results, and the
+        # one `value` is measured in
+        "modes": {
+            "reference_equal": {"distance_field": "the reference's brushfire, bit for bit, run lazily on the host's cores (csrc/ref_field.hpp)",
+                                "particle_updates_per_s": rm["particle_updates_per_s"], "ms_per_scan": rm["ms_per_scan"],
+                                "parity": "<= 1e-9 / integers identical to the oracle, nothing injected (tests/test_rbpf_field_gpu.py): meets north_star's 1e-5",
+                                "vs_target_1e5": round(rm["particle_updates_per_s"] / 1e5, 4)},
+            "query_default": {"distance_field": "exact squared distance to the nearest occupied cell, per lookup, from the occupancy bits",
+                              "particle_updates_per_s": round(N / (ms_scan * 1e-3), 1), "ms_per_scan": round(ms_scan, 4),
+                              "parity": "<= 1e-9 to the restated filter over the EXACT distance; 7.5e-3 from the reference's field at 400x400: outside 1e-5",
+                              "vs_target_1e5": round(N / (ms_scan * 1e-3) / 1e5, 2)}},
+        "config": {"workload": f"RBPF SLAM N={N}, k={k}, {Bv} valid beams of 360, {xsize}x{ysize} @0.05 m, ICP-ok branch (BASELINE configs[2])",
+                   "scans_timed": n_timed, "resamples": resamples, "entry_point": "tbnav_rbpf_slam_batch (synchronous per scan)",
+                   "inputs": "standard normals drawn on the device (Philox); only the 1.4 KB scan is a host buffer", "room": list(ROOM_BENCH)},
         "ms_per_scan": round(ms_scan, 4), "scan_ms_by_stretch": scan_ms,
-        "single_calls_from_python": None if not n_single else {"value": round(N / (t_single / n_single), 1), "ms_per_scan": round(t_single / n_single * 1e3, 4),
-                                                               "note": "the same scans, one tbnav_rbpf_slam call each from this harness"},
-        "device_ms_per_scan": round(dev_ms, 4),
-        "device_only_updates_per_s": round(N / (dev_ms * 1e-3), 1),
+        "device_ms_per_scan": round(dev_ms, 4), "device_only_updates_per_s": round(N / (dev_ms * 1e-3), 1),
         "kernel_ms": {key: round(v, 4) for key, v in kms.items()},
         "kernel_ms_resampling_scan": {key: round(v, 4) for key, v in kms_res.items()},
         "kernel_ms_first_scan_after_a_resampling": {key: round(v, 4) for key, v in kms_cow.items()},
-        "kernel_ms_note": f"HIP events, averages over {n_k} plain scans / {n_kr} resampling scans / {n_kc} scans that follow one (the map update then copies every written tile of a shared map: copy-on-write)",
+        "kernel_ms_scans": {"plain": n_k, "resampling": n_kr, "after_a_resampling": n_kc},
         "tile_pool": {"tiles": cap, "in_use": cap - free, "tile_bytes": tile_bytes,
-                      "log_odds_bytes_in_use": (cap - free) * tile_bytes, "dense_equivalent_bytes": N * pf.G * 8},
+                      "log_odds_bytes_in_use": (cap - free) * tile_bytes, "dense_equivalent_bytes": N * G * 8},
         "dtype": "f64+u16",
-        "options": None if not detail else {"scan_matching": {"value": round(N / (t_sm / n_sm), 1), "ms_per_scan": round(t_sm / n_sm * 1e3, 4),
-                                      "note": "per-particle hill climbing on the likelihood field before sampling (not the reference)"},
-                    "icp_failed_branch": {"value": round(N / t_fail, 1), "ms_per_scan": round(t_fail * 1e3, 4),
-                                          "note": "every scan with icp_ok = 0: sampleMotionModel + one likelihoodFieldModel per particle (particle_filter.cpp:157-176); whatever resampling the run triggers by itself is in the time"},
-                    "k10": {"value": round(N / t_k10, 1), "ms_per_scan": round(t_k10 * 1e3, 4),
-                            "note": "num_samples_mode = 10 instead of the shipped 50 (SURVEY.md 8-d: BASELINE names no k)"}},
-        # SURVEY 8-d's own room (+-3.0 / +-2.5 m, 246 valid beams): its boxes do not fit four workgroups per CU, the map update runs another
-        # instantiation — a first-class leg with its own kernel name, bytes, profiler row and PMC row (round-4 review)
-        "survey_room": None if not big else map_update_leg(
-            device, "SURVEY 8-d room", N, k, 10.0, ROOM_SURVEY, TRAJ_SURVEY, traffic_key="rbpf_N1000_k50_400x400_survey_room",
-            stats_workload="rbpf_N1000_k50_400x400_survey_room", sq_key="rbpf_N1000_k50_400x400_survey_room"),
-        "noise_forms": noise_forms(device, N, k) if detail else None,
-        "long_replay_one_call_no_resampling": long_replay(device, N, k) if detail else None,
-        "configs4_shard_one_gpu": shard4,
-        "configs4_as_written_one_gpu": cfg4,
         "distance_field_mode": "query",
-        "distance_field_mode_note": "the timed path computes exact nearest-obstacle distances at lookup and does NOT perform the reference's whole-map "
-                                    "distance-field refresh (SURVEY 8-d's G_reach x 16 B term): see reference_field_mode for the mode that reproduces it",
-        "reference_field_mode": ref_mode,
+        "reference_field_mode": {"configs2_1000_particles_400x400": rm},
         # Dominant kernel = the map update.  What has to MOVE is one read-modify-write per DISTINCT cell of a scan (the kernel merges
         # the touches of one scan in LDS): `achieved` / `frac` are those bytes over the kernel's live HIP-event time; `traffic` is what
-        # the PMC passes measured moving per launch (plain scans), `traffic_rate` that over the same time.  SURVEY 8-d's per-touch
-        # formula — bytes the kernel by design does NOT move — is kept as a note only (round-3 review).
+        # the PMC passes measured moving per launch (plain scans).
         "roofline": {"bound": "hbm", "kernel": k_raycast,
                      "achieved": round(alg_dom / t_rc / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(alg_dom / t_rc / 1e9 / HBM_PEAK_GBS, 6),
-                     "frac_events": round(alg_dom / t_rc / 1e9 / HBM_PEAK_GBS, 6),
-                     # (ONE convention for every frac_rocprof of the line, round-4 review: the named row's AVERAGE — here the row of this
-                     #  workload's own plain-scan pass; the median beside it)
-                     "frac_rocprof": None if rp_row is None else round(alg_dom / (rp_row["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 6),
-                     "frac_rocprof_of": "avg_us",
-                     "frac_rocprof_median": None if rp_row is None or not rp_row.get("median_us") else round(alg_dom / (rp_row["median_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 6),
+                     "frac": frac(kms["raycast"] * 1e3), "frac_events": frac(kms["raycast"] * 1e3),
+                     # (ONE convention for every frac_rocprof: the named row's AVERAGE — the row of this workload's own plain-scan pass)
+                     "frac_rocprof": None if rp_row is None else frac(rp_row["avg_us"]), "frac_rocprof_of": "avg_us",
+                     "frac_rocprof_median": None if rp_row is None or not rp_row.get("median_us") else frac(rp_row["median_us"]),
                      "rocprof": rp_row,
-                     "algorithmic_bytes_per_launch": round(alg_dom, 1),
-                     "algorithmic_bytes_note": f"{distinct_per:.1f} distinct cells written per particle and scan (counted on the device, TBNAV_RBPF_OPT_COUNT_CELLS) x 16 B x N",
+                     "algorithmic_bytes_per_launch": round(alg_dom, 1), "distinct_cells_per_particle_and_scan": round(distinct_per, 1),
+                     "touches_per_particle_and_scan": round(upd_per, 1),
                      "traffic": None if pmc is None else pmc["hbm_bytes"],
                      "traffic_source": None if pmc is None else pmc["source"] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; plain scans, no tile clones)",
-                     "traffic_rate": None if pmc is None else {"achieved": round(pmc["hbm_bytes"] / t_rc / 1e9, 3), "frac": round(pmc["hbm_bytes"] / t_rc / 1e9 / HBM_PEAK_GBS, 6),
-                                                                "traffic_over_algorithmic": round(pmc["hbm_bytes"] / alg_dom, 3)},
-                     "layout_floor": floor_obj,
+                     "traffic_over_algorithmic": None if pmc is None else round(pmc["hbm_bytes"] / alg_dom, 3),
+                     "traffic_reads_writes": None if pmc is None else [pmc.get("read_bytes"), pmc.get("write_bytes")],
                      "kernel_ms": round(kms["raycast"], 6),
-                     "per_touch_note": {"bytes_per_launch": round(alg_ref, 1), "frac": round(alg_ref / t_rc / 1e9 / HBM_PEAK_GBS, 6),
-                                        "note": f"SURVEY.md 8-d's (C_free + Bv) x 16 B — one RMW per (beam, cell) touch as the reference's loop performs them: {upd_per:.1f} "
-                                                "touches per particle and scan, counted; the kernel coalesces repeated touches in LDS and does not move these bytes"},
-                     "second_kernel": {"kernel": k_propose, "kernel_ms": round(kms["propose"], 6), "rocprof": rp_propose,
-                                       "note": "latency-bound (one workgroup per particle, six barrier-separated steps); scratch 0 B since round 4"},
-                     "whole_update": {"algorithmic_bytes_per_particle_update": round(dev_alg_per, 1),
-                                      "achieved": round(dev_alg_per * N / (dev_ms * 1e-3) / 1e9, 3),
-                                      "frac": round(dev_alg_per * N / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
-                                      "note": "bytes the DEVICE data flow has to move per particle-update (log-odds RMW of the distinct "
-                                              "cells + bitmap slice + normals + per-stage outputs) over the kernels' time; the reference's "
-                                              "k*Bv*8 lookup gathers and G*16 distance transform are not part of it (DESIGN.md section 4)"}},
+                     "second_kernel": {"kernel": k_propose, "kernel_ms": round(kms["propose"], 6), "rocprof": rp_propose}},
     }
-    pf.close()
+    if detail:
+        import bench_rbpf_detail
+        bench_rbpf_detail.add_legs(out, device, args, N, k, n_scans, dict(steps=steps, scans=scans, odom=odom, u_all=u_all, ticp_all=ticp_all, upd_per=upd_per,
+                                                                            distinct_per=distinct_per, kms=kms, dev_ms=dev_ms, t_rc=t_rc, pmc=pmc, xsize=xsize))
     if with_cpu:
         out["cpu_baseline"] = cpu_baseline(k, scans, steps, threads=1, n_scans=11 if detail else 7)
         out["cpu_baseline_all_cores"] = cpu_baseline(k, scans, steps, threads=effective_cores())

@@ -5,7 +5,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import rbpf_cases as rc
-import bench_rbpf
+import bench_rbpf_detail as bench_rbpf
 room = sys.argv[1] if len(sys.argv) > 1 else "bench"
 n_scans = int(sys.argv[2]) if len(sys.argv) > 2 else 14
 walls, inc = (rc.ROOM_BENCH, rc.TRAJ_BENCH) if room == "bench" else (rc.ROOM_SURVEY, rc.TRAJ_SURVEY)
