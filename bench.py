@@ -460,7 +460,7 @@ def main():
         # the production tick's own kernels: the in-kernel-noise instantiation the timed region ran
         ms_k = kernel_profile(m, a, b, stream, min(args.steps, 500), rng=(SEED, 20_000_000))
         k_rollout, k_combine = m.lastKernelNames()
-        sampler = "fp64 Box-Muller on 52-bit uniforms (std::normal_distribution<double>'s width)" if k_rollout.endswith(", 2>") else "fp32 Box-Muller on 24-bit uniforms"
+        sampler = "fp64 Box-Muller on 52-bit uniforms" if k_rollout.endswith(", 2>") else "fp32 Box-Muller on 24-bit uniforms"
         line = {
             "metric": "MPPI rollouts/s", "value": round(value, 1), "unit": "rollouts/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 6),
@@ -470,7 +470,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"MPPI newControls K={K} per GPU, T={T} (BASELINE configs[1]); global K={world * K}",
-                       "noise": f"drawn in the rollout kernel inside the timed tick: Philox4x32-10 + {sampler}",
+                       "noise": f"drawn in the rollout kernel, inside the timed tick: Philox4x32-10 + {sampler}",
                        "state_carried": True,
                        "parallelism": f"rollout-shard x{world}" + (", 1 exchange of soft-min records/tick" if world > 1 else "")},
             "rollout_steps_per_s": round(value * T, 1),

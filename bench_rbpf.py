@@ -290,6 +290,5 @@ def cpu_baseline(k, scans, steps, threads=1, n_scans=11):
         orc.lib().orc_set_threads(1)
     return {"value": round(n_particles * n / t_total, 2), "unit": "particle-updates/s", "cores": int(threads), "kind": "port",
             "cpu": _cpu_model(),
-            "sample": f"{n_particles} particles x {n} scans, k={k}, 360 beams, 400x400 (oracle/rbpf_oracle.cpp incl. the "
-                      f"reference's priority-queue brushfire, g++ -O2, {threads} thread(s))",
+            "sample": f"{n_particles} particles x {n} scans, k={k}, 360 beams, 400x400 (oracle/rbpf_oracle.cpp, eager brushfire, g++ -O2, {threads} thread(s))",
             "ms_per_particle_update": round(t_total / (n_particles * n) * 1e3, 3)}
