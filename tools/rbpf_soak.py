@@ -8,6 +8,7 @@ import __graft_entry__ as g
 g.load_package()
 import numpy as np
 import bench_rbpf
+from rtn_amd import capi
 from rtn_amd.rbpf import ParticleFilter, default_params
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
 steps, scans = bench_rbpf.workload(40)
@@ -15,6 +16,7 @@ for N in (1, 37, 1000, 1025, 4000):
     pfs = [ParticleFilter(default_params(N=N, k=50, map_min=-10.0, map_max=10.0)) for _ in range(2)]
     for i, pf in enumerate(pfs):
         pf.setSeed(11 + i)
+        pf.setOption(capi.RBPF_OPT_NOISE_IN_KERNEL, 1)   # (round 6: the option, no longer the default)
     t0 = time.perf_counter()
     m = n if N <= 1025 else n // 8
     for q in range(m):
@@ -28,7 +30,7 @@ for N in (1, 37, 1000, 1025, 4000):
     dt = time.perf_counter() - t0
     a, b = pfs[0].particles(), pfs[1].particles()
     assert np.all(np.isfinite(a[0])) and np.all(np.isfinite(b[0]))
-    print(f"N={N}: {2 * m} scans ok, {dt / (2 * m) * 1e6:.1f} us per scan", flush=True)
+    print(f"N={N}: {2 * m} scans ok, {dt / (2 * m) * 1e6:.1f} us per scan ({pfs[0].lastKernelNames()[0]})", flush=True)
     for pf in pfs:
         pf.close()
 print("soak ok")
