@@ -17,6 +17,7 @@ import bench_rbpf as br  # noqa: E402
 from rtn_amd import capi  # noqa: E402
 from rtn_amd.rbpf import ParticleFilter, default_params  # noqa: E402
 
+N = int(os.environ.get("TBNAV_PROBE_N", "1000"))
 n_scans = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 reaches = [int(x) for x in sys.argv[2:]] or [6, 3, 0]
 if os.environ.get("TBNAV_PROBE_ROOM") == "survey":
@@ -27,7 +28,7 @@ if os.environ.get("TBNAV_PROBE_ROOM") == "survey":
 else:
     steps, scans = br.workload(n_scans)
 for reach in reaches:
-    pf = ParticleFilter(default_params(N=1000, k=50, map_min=-10.0, map_max=10.0, device=0), df_mode="reference")
+    pf = ParticleFilter(default_params(N=N, k=50, map_min=-10.0, map_max=10.0, device=0), df_mode="reference")
     pf.setOption(capi.RBPF_OPT_REF_REACH, reach)
     pf.setSeed(2026)
     t, per = 0.0, []
@@ -38,7 +39,7 @@ for reach in reaches:
         per.append(round(dt * 1e3, 3))
         if s >= 1:
             t += dt
-    out = {"reach": reach, "ms_per_scan": round(t / (n_scans - 1) * 1e3, 3), "updates_per_s": round(1000 * (n_scans - 1) / t, 1),
+    out = {"reach": reach, "ms_per_scan": round(t / (n_scans - 1) * 1e3, 3), "N": N, "updates_per_s": round(N * (n_scans - 1) / t, 1),
            "stats": pf.referenceFieldStats(), "counts": pf.referenceFieldCounts(), "per_scan_ms": per}
     print(json.dumps(out), flush=True)
     pf.close()
