@@ -344,6 +344,12 @@ __device__ __forceinline__ int floor_div(int num, int den) {  // den > 0
 // one, and an integer remainder check fixes it — ~12 instructions instead of the ~40 of an int division.
 // (the quotient comes from v_rcp_f32 — one instruction, 1 ulp — not from a float division, which without fast-math is a
 //  twelve-instruction sequence: the estimate may then be off by two, hence two correction steps each way)
+// Exact n / d for 0 <= n < 2^16 by a divisor 1 <= d <= 2^8 that is the SAME for the whole workgroup (pairs in a row of the box, map tiles
+// under it, segments per ray): with m = ceil(2^24 / d), worked out once, the quotient is the high word of (n << 8) * m — two
+// instructions where floor_div_small is about twenty.  (m d - 2^24 < d, so n m / 2^24 exceeds n / d by less than n / 2^24 < 2^-8 <= 1 / d:
+// the floor is the same.  tests/test_raycast_step_arithmetic.py holds the formula against // for every such n and d.)
+__device__ __forceinline__ unsigned int udiv16_magic(int d) { return ((1u << 24) + (unsigned int)d - 1u) / (unsigned int)d; }
+__device__ __forceinline__ int udiv16(int n, unsigned int m) { return (int)__umulhi((unsigned int)n << 8, m); }
 __device__ __forceinline__ int floor_div_small(int num, int den) {
   int q = (int)floorf((float)num * __builtin_amdgcn_rcpf((float)den));
   int r = num - q * den;

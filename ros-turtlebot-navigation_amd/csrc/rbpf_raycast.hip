@@ -528,6 +528,7 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
   const int bw = ((maxy | 1) + 1) - miny;                           // columns wide: a PAIR of cells never straddles a row or a map tile
   const int bh = maxx - minx + 1;
   const int tx0 = minx >> kTSh, ty0 = miny >> kTSh, mty = (maxy >> kTSh) - ty0 + 1, mtn = ((maxx >> kTSh) - tx0 + 1) * mty;
+  const unsigned int mty_m = (unsigned int)uni((int)udiv16_magic(mty));   // (uniform divisors: udiv16, rbpf_device.hpp)
   const int rows_fit = uni(floor_div_small(tile_cap, bw));          // rows of the box the LDS array holds at a time
   if (rows_fit < 1 || mtn > kMapTilesMax || bh > kBoxSideMax) { if (tid == 0) atomicOr(&err[3], 2); return; }  // cannot happen: see launch_raycast
   // What the LDS array would have to hold for this particle's box to be ONE band: the host sizes the array of the scans to
@@ -550,7 +551,7 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
   //  — the entry goes to LDS as it arrives (these threads have nothing else to do in the flag phase); the reference count of the
   //  tile it names is fetched beside the walk: nothing needs it before phase C)
   if (tq >= 0 && tq < mtn) {
-    const int qi = floor_div_small(tq, mty), qj = tq - qi * mty;
+    const int qi = udiv16(tq, mty_m), qj = tq - qi * mty;
     const unsigned int id0 = tab[(tx0 + qi) * M.TW + (ty0 + qj)];
     mt_id[tq] = id0; mt_src[tq] = id0;
   }
@@ -629,16 +630,17 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
       int S = Bv > 0 ? nthr / Bv : 1;  // segments per ray: as many as give every thread at most one task
       S = S < 1 ? 1 : (S > 4 ? 4 : S);
       const int G = (Bv + kWave - 1) / kWave;
+      const unsigned int S_m = (unsigned int)uni((int)udiv16_magic(S));
       constexpr int kCellBytes = C16 ? 2 : 4;
       const unsigned int band_bytes = (unsigned int)kCellBytes * (unsigned int)band_cells;
       int n_first = 0;
       for (int task = tid; task < kWave * G * S; task += nthr) {
-        const int tb = floor_div_small(task, S), sgm = task - tb * S;
+        const int tb = udiv16(task, S_m), sgm = task - tb * S;
         const int b = __mul24(tb & (kWave - 1), G) + (tb >> 6);  // lanes of a wave take rays spread round the scan
         if (b >= Bv) continue;
         const int e = exy[b];
         const RayP pr = ray_packed(rx, ry, e & 0xFFFF, e >> 16);
-        const int count = pr.dmaj, L = floor_div_small(count + S - 1, S);
+        const int count = pr.dmaj, L = udiv16(count + S - 1, S_m);
         int n = __mul24(sgm, L);
         const int n1 = (n + L < count) ? n + L : count;
         if (n >= n1) continue;
@@ -729,6 +731,7 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
     //    particle's table names NOW (shared, private or the zero tile hold the same values: the loads fly while the tiles are
     //    made private).  Slots that overflowed are listed on the way.
     const int PW = bw >> 1;                                                   // pairs in a row of the box
+    const unsigned int PW_m = (unsigned int)uni((int)udiv16_magic(PW));
     // (the columns are cut at ABSOLUTE rows that are multiples of kSl, which divides the tile side: a column never crosses into
     //  the next tile row; its first and last may stick out of the band)
     constexpr int kSl = 4, kSlSh = 2;  // pairs a thread holds across the passes
@@ -742,7 +745,7 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
     auto pairs = [&](int first, auto&& fn) {  // fn(i, the pair's two tile words, cx, cy of its first cell, where its log-odds are, its map tile), i < kSl
       const int q = first + tid;
       if (q >= n_items) return;
-      const int j = floor_div_small(q, PW), pc = q - __mul24(j, PW);           // items < 2^16, PW < 2^8
+      const int j = udiv16(q, PW_m), pc = q - __mul24(j, PW);                  // items < 2^16, PW <= 88
       const int cxb = A0 + kSl * j, cy = miny + 2 * pc;
       const int mt = map_tile(cxb, cy);
       double* const ptr = P.lo + (size_t)mt_id[mt] * kTileCells + in_tile(cxb, cy);
@@ -791,7 +794,7 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
       if (bad) { if (tid == 0) atomicOr(&err[3], 8); return; }  // tile pool exhausted (nothing has been written if this is the first band)
       for (int q = wid; q < mtn; q += nw) {
         if (!((need_m >> q) & 1ull)) continue;
-        const int qi = floor_div_small(q, mty), qj = q - qi * mty;
+        const int qi = udiv16(q, mty_m), qj = q - qi * mty;
         // (the ring position and the lane are taken afresh in every trip — an LDS read, an opaque copy: as loop invariants the position
         //  and the lane's bitmap address were kept live across the copy and spilled, 2 x 8 bytes of scratch per lane)
         const unsigned long long nb = *reinterpret_cast<volatile unsigned long long*>(&need_base);
@@ -948,7 +951,7 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
     //     without the chain (add_repeated: a few hundred integer instructions per binade, worth it from about a hundred adds);
     //     the two waves run side by side, so the phase lasts as long as a chain of kVeryHot adds, not of the longest.
     if ((wid == nw - 1 || wid == nw - 2) && lane < kHotSide * kHotSide) {
-      const int hi = floor_div_small(lane, kHotSide), hx = rx - kHotSide / 2 + hi, hy = ry - kHotSide / 2 + (lane - hi * kHotSide);
+      const int hi = lane / kHotSide, hx = rx - kHotSide / 2 + hi, hy = ry - kHotSide / 2 + (lane - hi * kHotSide);
       if ((unsigned int)(hx - x0) < (unsigned int)nr && hy >= miny && hy < miny + bw) {
         int t = __mul24(hx - x0, bw) + (hy - miny);
         asm volatile("" : "+v"(t));   // held as ONE register across add_repeated (else hx - x0 and hy - miny both are: a 4-byte spill in the 16-bit form)
@@ -987,7 +990,7 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
       // no trip waits for memory with nothing to do
       const int qn = first + nthr + tid;
       const bool next_live = qn < n_items;
-      const int jn = floor_div_small(next_live ? qn : 0, PW), pcn = (next_live ? qn : 0) - __mul24(jn, PW);
+      const int jn = udiv16(next_live ? qn : 0, PW_m), pcn = (next_live ? qn : 0) - __mul24(jn, PW);
       const int cxbn = A0 + kSl * jn, cyn = miny + 2 * pcn;
       const double* const ptrn = P.lo + (size_t)mt_src[map_tile(cxbn, cyn)] * kTileCells + in_tile(cxbn, cyn);   // (reads: the tile named when the band began)
       const int pibn = __mul24(cxbn - x0, PW) + pcn;

@@ -50,3 +50,15 @@ def test_fixed_point_carry_is_the_integer_step_for_every_ray_shape():
                     assert np.array_equal(got, want), (dmaj, dmin, n0, ulp)
                     checked += 1
     assert checked > 100000
+
+
+def test_uniform_divisor_magic_is_the_integer_quotient_for_every_operand():
+    """udiv16 (csrc/rbpf_device.hpp, round 6): n // d as the high word of (n << 8) * ceil(2^24 / d) — for every 0 <= n < 2^16 and every
+    workgroup-uniform divisor the map update has (1 <= d <= 2^8: pairs in a row of the box <= 88, map tiles under it <= 8, segments per
+    ray <= 4)."""
+    n = np.arange(1 << 16, dtype=np.uint64)
+    for d in range(1, 257):
+        m = np.uint64(((1 << 24) + d - 1) // d)
+        assert m < (1 << 32)
+        q = ((n << np.uint64(8)) * m) >> np.uint64(32)
+        assert np.array_equal(q, n // np.uint64(d)), d
