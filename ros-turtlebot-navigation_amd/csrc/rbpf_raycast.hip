@@ -994,14 +994,14 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
       const int cxbn = A0 + kSl * jn, cyn = miny + 2 * pcn;
       const double* const ptrn = P.lo + (size_t)mt_src[map_tile(cxbn, cyn)] * kTileCells + in_tile(cxbn, cyn);   // (reads: the tile named when the band began)
       const int pibn = __mul24(cxbn - x0, PW) + pcn;
+      // (a slot whose next pair is untouched — or outside the band, or beyond the last item — keeps whatever it holds: the next trip
+      //  looks at v[i] only under the same test of the same tile words.  Zeroing it cost ten moves per pair, round 6)
       auto request_next = [&](int i) {
-        double2 nv = double2{0.0, 0.0};
         if (next_live && (unsigned int)(cxbn + i - x0) < (unsigned int)nr) {
           bool any;
           if constexpr (C16) any = tile[pibn + i * PW] != 0u; else { const uint2 wn = tile2[pibn + i * PW]; any = (wn.x | wn.y) != 0u; }
-          if (any) nv = *reinterpret_cast<const double2*>(ptrn + i * kTS);
+          if (any) v[i] = *reinterpret_cast<const double2*>(ptrn + i * kTS);
         }
-        v[i] = nv;
       };
       pairs(first, [&](int i, uint2 w, int cx, int cy, double* ptr, int) {
         if (w.x | w.y) {
