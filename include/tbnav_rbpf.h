@@ -329,8 +329,12 @@ int tbnav_rbpf_particle_map(tbnav_rbpf* h, int32_t particle, int8_t* map);
  *                                Bit-identical maps in either form.
  * TBNAV_RBPF_OPT_BATCH_PIPELINE  1 = tbnav_rbpf_slam_batch keeps two scans in the stream (default); 0 = n synchronous calls.
  * TBNAV_RBPF_OPT_HOST_THREADS    host threads the REFERENCE distance-field mode spreads its per-particle brushfires over (particles are
- *                                independent; the order of operations inside one particle is the reference's).  0 = the default: the
- *                                cores in the process's affinity mask, capped by the cgroup's CPU quota, at most 128.
+ *                                independent; the order of operations inside one particle is the reference's).  0 = the default,
+ *                                automatic: a scan's passes are a burst of CPU time (60 ms of it in 4 ms at configs[2], then nothing
+ *                                until the next scan), so the count follows the CPU TIME the process is granted — the cgroup's
+ *                                cpu.max quota, or the affinity mask without one: as many threads as keep the average over a scan
+ *                                period under 85 % of the quota, at least the quota's own count, at most four times it (and the
+ *                                affinity mask, and 128).  n > 0: exactly n.
  * TBNAV_RBPF_OPT_REF_REACH       REFERENCE mode: how many cells out from the occupied cells a scan's brushfire runs before it stops
  *                                (default 1: the occupied cells and their neighbours' neighbours; 0 = to the end, the round-3..5 behaviour).  The pass writes every cell once, in a
  *                                deterministic order, so a stopped pass equals the finished one on every cell it has written and can be
@@ -362,8 +366,10 @@ int tbnav_rbpf_reference_field_counts(tbnav_rbpf* h, int32_t* distinct_states, i
  *   out[8..13] host microseconds spent, summed over the scans: fetching the scans' insert / erase logs | the grouped brushfires
  *              (RefField::step) | a resampling's copies | bringing the device's field slots up to date | before the proposal
  *              (kept particle state, flags) | looking for pending lookups after it;  out[14], out[15]: of out[9], the part spent grouping the
- *              particles by (state, event sequence) | releasing the scan's old states */
-int tbnav_rbpf_reference_field_stats(tbnav_rbpf* h, int64_t out[16]);
+ *              particles by (state, event sequence) | releasing the scan's old states
+ *   out[16] microseconds the host threads spent in the passes, summed over the threads (the CPU time the fields cost)
+ *   out[17] host threads the last scan's passes ran on (TBNAV_RBPF_OPT_HOST_THREADS 0: chosen per scan, see there) */
+int tbnav_rbpf_reference_field_stats(tbnav_rbpf* h, int64_t out[18]);
 
 /* ---- measurement hook --------------------------------------------------------------------------
  * Durations (ms, HIP events on the handle's stream) of the kernels of the LAST slam call:

@@ -668,20 +668,25 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
 // host threads for the reference-field mode: the cores this process may run on — its affinity mask, and under a cgroup CPU quota
 // (cpu.max: a container that sees 128 CPUs but may use 32 of them) no more than that — at most 128; TBNAV_RBPF_OPT_HOST_THREADS
 // overrides.  (Round 4 capped this at 32: the bench box has more.)
-int default_host_threads() {
+int host_cpu_budget(double& quota_cpus) {
   int n = 0;
   cpu_set_t set;
   if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
   if (n <= 0) n = (int)std::thread::hardware_concurrency();
+  if (n < 1) n = 1;
+  quota_cpus = (double)n;
   if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2: "<quota> <period>" or "max <period>"
     long long quota = 0, period = 0;
-    if (std::fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) {
-      const int q = (int)((quota + period - 1) / period);
-      if (q >= 1 && q < n) n = q;
-    }
+    if (std::fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) quota_cpus = std::min((double)n, (double)quota / (double)period);
     std::fclose(f);
   }
-  return n < 1 ? 1 : (n > 128 ? 128 : n);
+  return n;
+}
+int default_host_threads() {
+  double q = 1.0;
+  const int n = host_cpu_budget(q);
+  const int t = std::min(n, (int)std::ceil(q));
+  return t < 1 ? 1 : (t > 128 ? 128 : t);
 }
 int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf** out) {
   if (!P || !out) return TBNAV_ERR_INVALID_ARG;
@@ -717,6 +722,7 @@ int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf*
   if (!h) return TBNAV_ERR_INVALID_ARG;
   h->p = *P; h->device = dev; h->N = P->num_particles; h->k = P->num_samples_mode;
   h->host_threads = default_host_threads();
+  h->host_affinity = host_cpu_budget(h->host_quota_cpus);
   h->xsize = xsize; h->ysize = ysize; h->words = words; h->radius = radius; h->edt_cols = C;
   h->G = (size_t)xsize * ysize;
   h->TW = (xsize + kTS - 1) / kTS; h->TT = h->TW * h->TW;

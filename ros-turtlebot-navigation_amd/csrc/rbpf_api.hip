@@ -208,6 +208,7 @@ int tbnav_rbpf_set_option(tbnav_rbpf* h, int32_t option, int32_t value) {
     case TBNAV_RBPF_OPT_HOST_THREADS:
       if (value < 0 || value > 256) return TBNAV_ERR_INVALID_ARG;
       h->host_threads = value ? value : default_host_threads();
+      h->host_threads_auto = value == 0;
       return TBNAV_OK;
     case TBNAV_RBPF_OPT_RAYCAST_FORM:
       // retired: 1 named round 2's tile kernel (removed in round 4) and for a while silently meant the much slower beam-ordered

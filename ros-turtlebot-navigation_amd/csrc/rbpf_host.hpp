@@ -143,6 +143,13 @@ struct tbnav_rbpf {
   long long ref_us[6] = {0, 0, 0, 0, 0, 0}; // host microseconds spent: fetching the logs | RefField::step | resample copies | flushes | before the proposal | the settle look
   int* d_log_pack = nullptr; unsigned long long* d_log_off = nullptr; size_t log_pack_cap = 0, log_off_cap = 0;  // the scan's logs, packed
   int* d_code_src = nullptr;              // [N] slot to copy the field from (rbpf_copy_codes)
+  // Reference-field mode, TBNAV_RBPF_OPT_HOST_THREADS 0 (automatic): the passes of a scan are a BURST — 60 ms of CPU time in 4 ms, then
+  // nothing until the next scan's — so the number of threads follows the CPU TIME the container is granted (its cgroup quota), not
+  // the number of CPUs that quota would keep busy all the time: as many threads as keep the average over a scan period under
+  // kRefCpuShare of the quota, between the quota's own count and four times it (ref_field_after_scan).
+  bool host_threads_auto = true;
+  int host_affinity = 1; double host_quota_cpus = 1.0;   // CPUs this process may run on | CPU time per wall time it may use (= affinity without a quota)
+  int ref_threads_used = 0; double ref_prev_step_start_s = -1.0, ref_last_step_wall_s = 0.0;
   int host_threads = 1;        // host threads of the reference-field mode's per-particle work (TBNAV_RBPF_OPT_HOST_THREADS; set at create)
   int* d_log_ev = nullptr;     // [N][log_cap]
   int* d_log_cnt = nullptr;    // [N]
@@ -246,6 +253,7 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
               const double prev_odom[3], int icp_ok, const double T_icp[3], const double* normals,
               tbnav_rbpf_stats* out, bool local_only);
 int default_host_threads();
+int host_cpu_budget(double& quota_cpus);   // the affinity mask's CPUs; quota_cpus: the cgroup's CPU-time quota in CPUs (the same number without one)
 int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf** out);
 int batch_scratch(tbnav_rbpf* h, size_t n);
 BlobLayout blob_layout(const tbnav_rbpf* h, uint32_t n_tiles, bool has_codes);

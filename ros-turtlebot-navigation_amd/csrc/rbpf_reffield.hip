@@ -169,7 +169,7 @@ int ref_field_settle(tbnav_rbpf* h, int* h_err, const std::function<int()>& rela
     ps.clear(); cs.clear();
     for (int p = 0; p < N; ++p) if (h->h_pend[p]) { ps.push_back(p); cs.push_back(h->h_pend[p] - 1); }
     if (ps.empty()) return TBNAV_OK;
-    const int rc = h->ref->ensure(ps.data(), cs.data(), (int)ps.size(), h->host_threads);
+    const int rc = h->ref->ensure(ps.data(), cs.data(), (int)ps.size(), std::max(h->host_threads, h->ref_threads_used));
     if (rc == -1) {
       tbnav::last_hip_error_slot() = "reference-field mode: a lookup needs a stale cell whose history is beyond the history budget";
       return TBNAV_ERR_UNSUPPORTED;
@@ -221,7 +221,28 @@ int ref_field_after_scan(tbnav_rbpf* h, bool resampled, int p_first, int p_count
   // order of every set and heap operation is the reference's
   h->ref_us[0] += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_log0).count();
   h->ref->set_reach(h->ref_reach);
-  { UsTimer ut(h->ref_us[1]); h->ref->step(p_first, p_count, h->host_threads, all.data(), off.data()); }
+  // how many threads: the quota's own count, or — automatic mode — as many as keep the CPU time per scan period under kRefCpuShare of
+  // the quota (rbpf_host.hpp): with W thread-seconds of passes per scan and t_other seconds of everything else, T threads use
+  // W / (t_other + W / T) CPUs on average
+  int threads = h->host_threads;
+  const double now_s = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  if (h->host_threads_auto && h->ref_prev_step_start_s >= 0.0 && h->ref_threads_used > 0 && p_count == N) {
+    constexpr double kRefCpuShare = 0.85;
+    const double W = (double)h->ref->last_step_busy_us() * 1e-6, period = now_s - h->ref_prev_step_start_s;
+    const double t_other = std::max(period - h->ref_last_step_wall_s, 0.0), budget = kRefCpuShare * h->host_quota_cpus;
+    const int cap = std::min(std::min(h->host_affinity, 4 * h->host_threads), 128);
+    const double denom = W / budget - t_other;
+    const double t_max = denom <= 0.0 ? (double)cap : W / denom;
+    threads = std::max(h->host_threads, std::min(cap, (int)t_max));
+  }
+  h->ref_prev_step_start_s = now_s;
+  {
+    UsTimer ut(h->ref_us[1]);
+    const auto t0 = std::chrono::steady_clock::now();
+    h->ref->step(p_first, p_count, threads, all.data(), off.data());
+    h->ref_last_step_wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    h->ref_threads_used = threads;
+  }
   if (resampled) {
     UsTimer ut(h->ref_us[2]);
     h->h_parent.resize(N);
@@ -248,13 +269,14 @@ int tbnav_rbpf_reference_field_counts(tbnav_rbpf* h, int32_t* distinct_states, i
   return TBNAV_OK;
 }
 
-int tbnav_rbpf_reference_field_stats(tbnav_rbpf* h, int64_t out[16]) {
+int tbnav_rbpf_reference_field_stats(tbnav_rbpf* h, int64_t out[18]) {
   if (!h || !out || !h->ref_field || !h->ref) return TBNAV_ERR_INVALID_ARG;
   const tbnav::RefField::Counters& k = h->ref->counters();
   out[0] = k.passes; out[1] = k.pops; out[2] = k.resumes; out[3] = k.completions; out[4] = k.replays; out[5] = k.replay_generations;
   out[6] = h->ref->history_bytes(); out[7] = h->ref_reruns;
   for (int q = 0; q < 6; ++q) out[8 + q] = h->ref_us[q];
   out[14] = k.us_group; out[15] = k.us_bury;
+  out[16] = k.us_busy; out[17] = h->ref_threads_used;
   return TBNAV_OK;
 }
 

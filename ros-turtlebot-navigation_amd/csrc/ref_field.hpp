@@ -327,6 +327,7 @@ class RefField {
     long long replays = 0;      // lineages replayed from their base (stale cells wanted)
     long long replay_generations = 0;
     long long us_group = 0, us_work = 0, us_bury = 0;   // step(): wall microseconds grouping the particles | in the passes | releasing the old states
+    long long us_busy = 0;      // step(): microseconds the threads spent in the passes, summed over the threads (the CPU time a scan's fields cost)
   };
 
   RefField(int n_particles, int xsize, int radius) : xs_(xsize), radius_(radius), hist_bytes_(std::make_shared<std::atomic<long long>>(0)),
@@ -345,6 +346,7 @@ class RefField {
   // distinct states among the particles / brushfires run by the last step() (what the sharing saved: tests, bench)
   int distinct_states() const { std::unordered_set<const State*> u; for (auto& s : st_) u.insert(s.get()); return (int)u.size(); }
   int last_step_brushfires() const { return last_brushfires_; }
+  long long last_step_busy_us() const { return last_busy_us_; }
   long long total_brushfires() const { return total_brushfires_; }
   const Counters& counters() const { return cnt_; }
   long long history_bytes() const { return hist_bytes_->load(); }
@@ -394,8 +396,12 @@ class RefField {
     std::atomic<long long> pops{0}, done{0};
     const uint32_t limit2 = reach_ > 0 ? (uint32_t)reach_ * (uint32_t)reach_ : ~0u;
     const bool keep_history = hist_bytes_->load() <= hist_budget_;
+    std::atomic<long long> busy{0};
     auto work = [&] {
       long long my_pops = 0, my_done = 0;
+      const auto t_in = std::chrono::steady_clock::now();
+      struct Busy { std::atomic<long long>& acc; std::chrono::steady_clock::time_point t0;
+                    ~Busy() { acc.fetch_add((long long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count()); } } busy_guard{busy, t_in};
       for (int g = next.fetch_add(1); g < (int)groups.size(); g = next.fetch_add(1)) {
         Group& gr = groups[g];
         // no set operation at all: nothing occupied (the reference returns at :338), or the same set in the same order whose
@@ -455,6 +461,7 @@ class RefField {
     const auto t_d = std::chrono::steady_clock::now();
     auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return (long long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
     cnt_.us_group += us(t_a, t_b); cnt_.us_work += us(t_b, t_c); cnt_.us_bury += us(t_c, t_d);
+    cnt_.us_busy += busy.load(); last_busy_us_ = busy.load();
     last_brushfires_ = fires.load();
     total_brushfires_ += last_brushfires_;
     cnt_.passes += last_brushfires_; cnt_.pops += pops.load(); cnt_.completions += done.load();
@@ -751,6 +758,7 @@ class RefField {
   int reach_ = 1;
   long long hist_budget_ = (long long)1 << 30;
   int last_brushfires_ = 0;
+  long long last_busy_us_ = 0;
   long long total_brushfires_ = 0;
   Counters cnt_;
   std::mutex cnt_mu_;

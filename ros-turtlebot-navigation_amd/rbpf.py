@@ -220,10 +220,11 @@ class ParticleFilter:
 
     def referenceFieldStats(self):
         """Reference-field mode: the lazy brushfire's counters (tbnav_rbpf_reference_field_stats) as a dict."""
-        out = (C.c_int64 * 16)()
+        out = (C.c_int64 * 18)()
         capi.check(self._L.tbnav_rbpf_reference_field_stats(self._h, out), "reference_field_stats")
         keys = ("passes", "iterations", "states_resumed", "passes_completed", "lineages_replayed", "generations_replayed", "history_bytes", "proposals_rerun",
-                "us_logs", "us_step", "us_resample", "us_flush", "us_before_propose", "us_settle_look", "us_step_grouping", "us_step_release")
+                "us_logs", "us_step", "us_resample", "us_flush", "us_before_propose", "us_settle_look", "us_step_grouping", "us_step_release",
+                "us_threads_busy", "host_threads_last_scan")
         return dict(zip(keys, (int(v) for v in out)))
 
     def setTiming(self, on: bool = True):

@@ -30,6 +30,8 @@ else:
 for reach in reaches:
     pf = ParticleFilter(default_params(N=N, k=50, map_min=-10.0, map_max=10.0, device=0), df_mode="reference")
     pf.setOption(capi.RBPF_OPT_REF_REACH, reach)
+    if os.environ.get("TBNAV_PROBE_THREADS"):
+        pf.setOption(capi.RBPF_OPT_HOST_THREADS, int(os.environ["TBNAV_PROBE_THREADS"]))
     pf.setSeed(2026)
     t, per = 0.0, []
     for s, (prev, cur, t_icp, u) in enumerate(steps):
@@ -39,7 +41,7 @@ for reach in reaches:
         per.append(round(dt * 1e3, 3))
         if s >= 1:
             t += dt
-    out = {"reach": reach, "ms_per_scan": round(t / (n_scans - 1) * 1e3, 3), "N": N, "updates_per_s": round(N * (n_scans - 1) / t, 1),
+    out = {"threads": os.environ.get("TBNAV_PROBE_THREADS"), "reach": reach, "ms_per_scan": round(t / (n_scans - 1) * 1e3, 3), "N": N, "updates_per_s": round(N * (n_scans - 1) / t, 1),
            "stats": pf.referenceFieldStats(), "counts": pf.referenceFieldCounts(), "per_scan_ms": per}
     print(json.dumps(out), flush=True)
     pf.close()
