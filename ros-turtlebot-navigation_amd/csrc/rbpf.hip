@@ -688,6 +688,14 @@ int default_host_threads() {
   const int t = std::min(n, (int)std::ceil(q));
   return t < 1 ? 1 : (t > 128 ? 128 : t);
 }
+int pool_free_tiles(tbnav_rbpf* h, uint64_t* free_tiles) {
+  unsigned long long ctr[kPoolCtrStride * kPoolShards];
+  TBNAV_HIP(hipMemcpy(ctr, h->pool.ctr, sizeof ctr, hipMemcpyDeviceToHost));
+  uint64_t f = 0;
+  for (unsigned int s = 0; s < h->pool.shards; ++s) f += ctr[s * kPoolCtrStride + 1] - ctr[s * kPoolCtrStride];
+  *free_tiles = f;
+  return TBNAV_OK;
+}
 int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf** out) {
   if (!P || !out) return TBNAV_ERR_INVALID_ARG;
   *out = nullptr;
@@ -795,11 +803,13 @@ int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf*
     if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
     if (cap < (size_t)N + 2 && e == hipSuccess) e = hipErrorOutOfMemory;  // not even one tile per particle
     h->pool.cap = (unsigned int)cap;
+    h->pool.shards = cap >= (size_t)kPoolShardMin ? (unsigned int)kPoolShards : 1u;   // free lists: rbpf_device.hpp
+    h->pool.shard_cap = (unsigned int)((cap + h->pool.shards - 1) / h->pool.shards);
     A((void**)&h->pool.lo, sizeof(double) * kTileCells * cap);
     A((void**)&h->pool.bm, sizeof(unsigned int) * kTS * cap);
     A((void**)&h->pool.ref, sizeof(int) * cap);
-    A((void**)&h->pool.ring, sizeof(unsigned int) * cap);
-    A((void**)&h->pool.ctr, sizeof(unsigned long long) * 2);
+    A((void**)&h->pool.ring, sizeof(unsigned int) * (size_t)h->pool.shard_cap * h->pool.shards);
+    A((void**)&h->pool.ctr, sizeof(unsigned long long) * kPoolCtrStride * kPoolShards);
   }
   if (e == hipSuccess) {
     double* t = h->d_trace;
@@ -903,10 +913,10 @@ int tbnav_rbpf_pool_stats(tbnav_rbpf* h, uint64_t* capacity_tiles, uint64_t* fre
   if (!h) return TBNAV_ERR_INVALID_ARG;
   DeviceGuard guard(h->device);
   TBNAV_HIP(hipStreamSynchronize(h->stream));
-  unsigned long long ctr[2] = {0, 0};
-  TBNAV_HIP(hipMemcpy(ctr, h->pool.ctr, sizeof ctr, hipMemcpyDeviceToHost));
+  uint64_t free_now = 0;
+  { const int rc = tbnav_rh::pool_free_tiles(h, &free_now); if (rc != TBNAV_OK) return rc; }
   if (capacity_tiles) *capacity_tiles = h->pool.cap - 1;  // tile 0 is the shared zero tile
-  if (free_tiles) *free_tiles = ctr[1] - ctr[0];
+  if (free_tiles) *free_tiles = free_now;
   if (tile_bytes) *tile_bytes = sizeof(double) * kTileCells;
   return TBNAV_OK;
 }

@@ -91,13 +91,27 @@ struct ScanC {  // everything constant during one SLAM call
 // resample, which is also the only time tiles return to the ring.  Pops (scan) and pushes (resample) therefore
 // never run concurrently and the ring needs no ABA protection.
 constexpr int kTS = 32, kTSh = 5, kTileCells = kTS * kTS;
+// The free tiles are kept in kPoolShards lists (rings), list s holding the ids = s (mod kPoolShards), each with its head and tail on
+// a 128-byte line of its own: the map update that follows a resampling pops once per particle, all within a few microseconds, and
+// one word retires ~80 returning atomics per microsecond — a thousand co-resident workgroups waited up to 17 us for their ring
+// position, sixteen words 1.3 us (tools/atomic_queue_probe.hip).  A caller pops from the list its hint names and moves on to the
+// next when that one cannot supply the request; a tile goes back to the list of its id, so no list ever holds more than its share.
+// Pools below kPoolShardMin tiles keep ONE list (a request for a particle's 15-60 tiles would find no list of a small pool long
+// enough): "exhausted" then means what it says to the tile; with sixteen lists it is reported when no list holds the n tiles
+// asked for at once — at most 16 x (n - 1) tiles short of empty, n <= 64.
+constexpr int kPoolShards = 16, kPoolShardsLog2 = 4;
+constexpr unsigned int kPoolShardMin = 16384u;   // tiles (128 MB of log-odds)
+constexpr int kPoolCtrStride = 16;               // 64-bit words between two lists' counters
+constexpr int kPoolPosShift = 40;                // a ring position as the callers hold it: list << 40 | tiles popped from it so far
 struct TilePool {
   double* lo;               // [cap][kTileCells], in-tile index = (i & 31) * 32 + (j & 31)
   unsigned int* bm;         // [cap][kTS] occupancy bits of the tile's cells (prob >= 0.90): row i & 31, bit j & 31
   int* ref;                 // [cap]
-  unsigned int* ring;       // [cap] free tile ids
-  unsigned long long* ctr;  // [0] head: tiles popped, [1] tail: tiles pushed (free = tail - head)
+  unsigned int* ring;       // [shards][shard_cap] free tile ids
+  unsigned long long* ctr;  // [shards][kPoolCtrStride]: [0] head: tiles popped, [1] tail: tiles pushed (free = tail - head)
   unsigned int cap;
+  unsigned int shards;      // 1 or kPoolShards
+  unsigned int shard_cap;   // ceil(cap / shards)
 };
 struct MapT {
   unsigned int* table;  // [N][TT] of the current buffer
@@ -106,24 +120,34 @@ struct MapT {
 };
 __device__ __forceinline__ int tile_of(const MapT& M, int ci, int cj) { return (ci >> kTSh) * M.TW + (cj >> kTSh); }
 __device__ __forceinline__ int in_tile(int ci, int cj) { return ((ci & (kTS - 1)) << kTSh) | (cj & (kTS - 1)); }
-__device__ __forceinline__ unsigned int tile_pop(const TilePool& P) {  // 0 = pool exhausted
-  const unsigned long long pos = atomicAdd(P.ctr, 1ull);
-  if (pos >= P.ctr[1]) { atomicAdd(P.ctr, ~0ull); return 0u; }  // (no push can be in flight: see above)
-  return P.ring[pos % P.cap];
+__device__ __forceinline__ unsigned int* ring_slot(const TilePool& P, unsigned int s, unsigned long long pos) {
+  return P.ring + (size_t)s * P.shard_cap + (size_t)(pos % P.shard_cap);
 }
 __device__ __forceinline__ void tile_push(const TilePool& P, unsigned int id) {
-  const unsigned long long pos = atomicAdd(P.ctr + 1, 1ull);
-  P.ring[pos % P.cap] = id;
+  const unsigned int s = id & (P.shards - 1u);
+  const unsigned long long pos = atomicAdd(P.ctr + (size_t)s * kPoolCtrStride + 1, 1ull);
+  *ring_slot(P, s, pos) = id;
 }
-// n tiles at once: ONE atomic on the ring's head per caller (a workgroup that clones 15 tiles after a resample would
-// otherwise queue 15 times on a word every other workgroup is queueing on — a single address retires ~90 atomics
-// per microsecond).  Returns the position of the first tile in the ring, ~0 if fewer than n are free.
-__device__ __forceinline__ unsigned long long tile_pop_n(const TilePool& P, unsigned int n) {
-  const unsigned long long pos = atomicAdd(P.ctr, (unsigned long long)n);
-  if (pos + n > P.ctr[1]) { atomicAdd(P.ctr, ~(unsigned long long)n + 1ull); return ~0ull; }
-  return pos;
+// n tiles at once: ONE atomic on a list's head per caller (a workgroup that clones 15 tiles after a resample would otherwise
+// queue 15 times).  hint: which list to try first (callers that pop together pass consecutive numbers).  Returns the position of
+// the first tile (tile_at(P, pos + i) is the i-th), ~0 if no list holds n free tiles.
+__device__ __forceinline__ unsigned long long tile_pop_n(const TilePool& P, unsigned int n, unsigned int hint) {
+  for (unsigned int k = 0; k < P.shards; ++k) {
+    const unsigned int s = (hint + k) & (P.shards - 1u);
+    unsigned long long* const c = P.ctr + (size_t)s * kPoolCtrStride;
+    const unsigned long long pos = atomicAdd(c, (unsigned long long)n);
+    if (pos + n <= c[1]) return ((unsigned long long)s << kPoolPosShift) | pos;   // (no push can be in flight: see above)
+    atomicAdd(c, ~(unsigned long long)n + 1ull);
+  }
+  return ~0ull;
 }
-__device__ __forceinline__ unsigned int tile_at(const TilePool& P, unsigned long long pos) { return P.ring[pos % P.cap]; }
+__device__ __forceinline__ unsigned int tile_at(const TilePool& P, unsigned long long pos) {
+  return *ring_slot(P, (unsigned int)(pos >> kPoolPosShift), pos & ((1ull << kPoolPosShift) - 1ull));
+}
+__device__ __forceinline__ unsigned int tile_pop(const TilePool& P, unsigned int hint) {  // 0 = pool exhausted
+  const unsigned long long pos = tile_pop_n(P, 1u, hint);
+  return pos == ~0ull ? 0u : tile_at(P, pos);
+}
 __device__ __forceinline__ bool tile_is_private(const TilePool& P, const unsigned int* __restrict__ table_p, int t) {
   const unsigned int id = table_p[t];
   return id != 0u && P.ref[id] == 1;
@@ -150,7 +174,7 @@ __device__ __forceinline__ unsigned int tile_make_private(const TilePool& P, uns
   const unsigned int id = table_p[t];
   if (id != 0u && P.ref[id] == 1) return id;
   unsigned int nid = 0u;
-  if (lane == 0) nid = tile_pop(P);
+  if (lane == 0) nid = tile_pop(P, blockIdx.x);
   nid = __shfl(nid, 0, kWave);
   if (nid == 0u) return 0u;
   double2* dst = reinterpret_cast<double2*>(P.lo + (size_t)nid * kTileCells);
@@ -391,19 +415,19 @@ constexpr int kEdtRowsB = 288;  // 77.8 KB -> 2 waves per CU
 //     pool when the particle died; a shared tile takes ONE atomic add of the difference.  While some holder has not been
 //     through yet the count stays above zero (every holder still counts 1), so the add that lands on zero is the last
 //     word on that tile.  Tiles a slot stopped using since the last resample (shed) are released likewise.
-// Freed tiles go back with one atomic on the ring's tail per WORKGROUP and round (lane-private pushes queue on that word:
+// Freed tiles go back with one atomic per free list, WORKGROUP and round (lane-private pushes queue on the lists' tails:
 // ~90 atomics per microsecond on one address, and a resample that kills 900 of 1000 particles frees 13 000 tiles).  Instead of one atomic per child and tile plus one per old entry, in two launches.
 __device__ __forceinline__ void resample_tables_body(int N, int TT, const int* __restrict__ parent, const int* __restrict__ children,
                                                      const unsigned int* __restrict__ tab_old, unsigned int* __restrict__ tab_new,
                                                      unsigned int* __restrict__ shed, const TilePool& P, int block, int nblocks) {
   const size_t n = (size_t)N * TT;
-  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave, nw = blockDim.x / kWave;
-  const unsigned long long below = (1ull << lane) - 1ull;
-  __shared__ int s_wave_total[16];
-  __shared__ unsigned long long s_base;
+  __shared__ int s_cnt[kPoolShards];
+  __shared__ unsigned long long s_base[kPoolShards];
+  const unsigned int smask = P.shards - 1u;
   for (size_t e0 = (size_t)block * blockDim.x; e0 < n; e0 += (size_t)nblocks * blockDim.x) {
     const size_t e = e0 + threadIdx.x;
     unsigned int freed[2] = {0u, 0u};
+    if (threadIdx.x < kPoolShards) s_cnt[threadIdx.x] = 0;
     if (e < n) {
       const int m = (int)(e / TT), t = (int)(e - (size_t)m * TT);
       tab_new[e] = tab_old[(size_t)parent[m] * TT + t];
@@ -416,20 +440,18 @@ __device__ __forceinline__ void resample_tables_body(int N, int TT, const int* _
       if (sh) { if (atomicSub(&P.ref[sh], 1) == 1) freed[1] = sh; shed[e] = 0u; }
     }
     // (the trip count is the same for the whole workgroup: barriers inside the loop are safe)
-    const unsigned long long m0 = __ballot(freed[0] != 0u), m1 = __ballot(freed[1] != 0u);
-    const int total = __popcll(m0) + __popcll(m1);
-    if (lane == 0) s_wave_total[wid] = total;
+    // a freed tile goes to the list of its id: counted per list in LDS, then ONE atomic per list and round for the workgroup
     __syncthreads();
-    if (threadIdx.x == 0) {
-      int sum = 0;
-      for (int q = 0; q < nw; ++q) { const int v = s_wave_total[q]; s_wave_total[q] = sum; sum += v; }  // -> exclusive prefix
-      s_base = sum ? atomicAdd(P.ctr + 1, (unsigned long long)sum) : 0ull;
-    }
+    int off0 = 0, off1 = 0;
+    if (freed[0]) off0 = atomicAdd(&s_cnt[freed[0] & smask], 1);
+    if (freed[1]) off1 = atomicAdd(&s_cnt[freed[1] & smask], 1);
     __syncthreads();
-    unsigned long long at = s_base + s_wave_total[wid] + __popcll(m0 & below) + __popcll(m1 & below);
-    if (freed[0]) P.ring[at++ % P.cap] = freed[0];
-    if (freed[1]) P.ring[at % P.cap] = freed[1];
-    __syncthreads();  // (s_wave_total is rewritten by the next round)
+    if (threadIdx.x < P.shards && s_cnt[threadIdx.x])
+      s_base[threadIdx.x] = atomicAdd(P.ctr + (size_t)threadIdx.x * kPoolCtrStride + 1, (unsigned long long)s_cnt[threadIdx.x]);
+    __syncthreads();
+    if (freed[0]) *ring_slot(P, freed[0] & smask, s_base[freed[0] & smask] + (unsigned long long)off0) = freed[0];
+    if (freed[1]) *ring_slot(P, freed[1] & smask, s_base[freed[1] & smask] + (unsigned long long)off1) = freed[1];
+    __syncthreads();  // (s_cnt is cleared by the next round)
   }
 }
 // Everything else a particle owns: pose / prev_pose / weight (weights are NOT reset, :495), its occupied counts (per tile

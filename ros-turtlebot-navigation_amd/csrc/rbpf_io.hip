@@ -184,9 +184,8 @@ int tbnav_rbpf_import_batch_dev(tbnav_rbpf* h, int32_t n, const int32_t* slots, 
     // not come back: the unpack kernel then reports the exhaustion, with the slots' maps already released — see the header).
     uint64_t incoming = 0;
     for (int i = 0; i < n; ++i) incoming += hd[i].n_tiles;
-    unsigned long long ctr[2] = {0, 0};
-    TBNAV_HIP(hipMemcpy(ctr, h->pool.ctr, sizeof ctr, hipMemcpyDeviceToHost));
-    const uint64_t free_now = ctr[1] - ctr[0];
+    uint64_t free_now = 0;
+    { const int rc = tbnav_rh::pool_free_tiles(h, &free_now); if (rc != TBNAV_OK) return rc; }
     if (incoming > free_now) {
       std::vector<int> sl(n);
       for (int i = 0; i < n; ++i) sl[i] = slots[i];

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void rbpf_unpack_tiles(TilePool P, MapT M, int
                                                          int* __restrict__ err) {
   __shared__ unsigned int sid;
   if (threadIdx.x == 0) {
-    const unsigned int id = tile_pop(P);
+    const unsigned int id = tile_pop(P, blockIdx.x);
     if (id) { P.ref[id] = 1; M.table[(size_t)p * M.TT + tidx[blockIdx.x]] = id; } else atomicOr(&err[3], 8);
     sid = id;
   }
@@ -109,7 +109,11 @@ __global__ __launch_bounds__(256) void rbpf_release_slots(TilePool P, MapT M, co
     tab[t] = 0u; shed[t] = 0u;
   }
 }
-// one workgroup per imported particle (its slot was released by the launch before): ONE pop for all its tiles
+// one workgroup per imported particle (its slot was released by the launch before).  Its tiles are popped in runs of 64 (more for
+// maps of more than 16 384 tiles: at most 256 runs), one thread a run, each from the free list its number names first
+// (rbpf_device.hpp: a list supplies a run or passes; 64 is what the map update asks of one at most).  If a run finds no list
+// long enough the particle is not installed: the tiles the other runs took are noted as SHED by the slot — the next resample, or
+// the slot's release, hands them back (pops and pushes never share a launch) — and the slot keeps the empty map.
 __global__ __launch_bounds__(256) void rbpf_unpack_batch(TilePool P, MapT M, double* __restrict__ pose, double* __restrict__ prev,
                                                          double* __restrict__ weight, int* __restrict__ trow, int* __restrict__ nocc,
                                                          int* __restrict__ fstate, uint16_t* __restrict__ codes, size_t G,
@@ -119,19 +123,35 @@ __global__ __launch_bounds__(256) void rbpf_unpack_batch(TilePool P, MapT M, dou
   const char* b = buf + it.off;
   const BlobHeader hd = *reinterpret_cast<const BlobHeader*>(b);
   const BlobLayout L = blob_layout_hd(M.TW, G, hd.n_tiles, hd.has_codes != 0);
-  __shared__ unsigned long long sbase;
-  if (tid == 0) sbase = hd.n_tiles ? tile_pop_n(P, hd.n_tiles) : 0ull;
+  __shared__ unsigned long long sbase[256];
+  __shared__ int s_fail;
+  int rsh = 6;                                                   // log2 of a run's length
+  while (((hd.n_tiles + (1u << rsh) - 1u) >> rsh) > 256u) ++rsh;
+  const unsigned int run = 1u << rsh, n_runs = (hd.n_tiles + run - 1u) >> rsh;
+  if (tid == 0) s_fail = 0;
   __syncthreads();
-  const unsigned long long pos = sbase;
-  if (pos == ~0ull) { if (tid == 0) atomicOr(&err[3], 8); return; }  // pool exhausted: the slot keeps the empty map
+  if ((unsigned int)tid < n_runs) {
+    const unsigned int first = (unsigned int)tid << rsh, n = hd.n_tiles - first < run ? hd.n_tiles - first : run;
+    const unsigned long long pos = tile_pop_n(P, n, blockIdx.x * 5u + (unsigned int)tid);
+    sbase[tid] = pos;
+    if (pos == ~0ull) s_fail = 1;
+  }
+  __syncthreads();
   const unsigned int* tidx = reinterpret_cast<const unsigned int*>(b + L.tidx);
+  auto nth = [&](size_t j) { return tile_at(P, sbase[j >> rsh] + (j & (run - 1u))); };
+  if (s_fail) {  // pool exhausted
+    for (unsigned int j = tid; j < hd.n_tiles; j += 256)
+      if (sbase[j >> rsh] != ~0ull) { const unsigned int id = nth(j); P.ref[id] = 1; M.shed[(size_t)slot * M.TT + tidx[j]] = id; }
+    if (tid == 0) atomicOr(&err[3], 8);
+    return;
+  }
   const double2* src = reinterpret_cast<const double2*>(b + L.tiles);
   for (size_t i = tid; i < (size_t)hd.n_tiles * (kTileCells / 2); i += 256)
-    reinterpret_cast<double2*>(P.lo + (size_t)tile_at(P, pos + i / (kTileCells / 2)) * kTileCells)[i % (kTileCells / 2)] = src[i];
+    reinterpret_cast<double2*>(P.lo + (size_t)nth(i / (kTileCells / 2)) * kTileCells)[i % (kTileCells / 2)] = src[i];
   const unsigned int* sbm = reinterpret_cast<const unsigned int*>(b + L.tile_bm);
-  for (size_t i = tid; i < (size_t)hd.n_tiles * kTS; i += 256) P.bm[(size_t)tile_at(P, pos + i / kTS) * kTS + (i % kTS)] = sbm[i];
+  for (size_t i = tid; i < (size_t)hd.n_tiles * kTS; i += 256) P.bm[(size_t)nth(i / kTS) * kTS + (i % kTS)] = sbm[i];
   for (unsigned int j = tid; j < hd.n_tiles; j += 256) {
-    const unsigned int id = tile_at(P, pos + j);
+    const unsigned int id = nth(j);
     P.ref[id] = 1;
     M.table[(size_t)slot * M.TT + tidx[j]] = id;
   }

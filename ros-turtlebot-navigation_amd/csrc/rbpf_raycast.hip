@@ -317,7 +317,7 @@ __global__ __launch_bounds__(kWave) void rbpf_raycast(ScanC c, TilePool P, MapT 
     }
     if (need) {
       unsigned long long base = 0ull;
-      if (lane == 0) base = tile_pop_n(P, (unsigned int)need);
+      if (lane == 0) base = tile_pop_n(P, (unsigned int)need, blockIdx.x);
       base = ((unsigned long long)__shfl((int)(base >> 32), 0, kWave) << 32) | (unsigned int)__shfl((int)base, 0, kWave);
       if (base == ~0ull) { if (lane == 0) atomicOr(&err[3], 8); return; }  // tile pool exhausted: nothing has been written
       for (int w = 0; w < tword; ++w) {
@@ -784,14 +784,17 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
     PHASE_STAMP_W(2);
     TRACE_W(9);
     // C. make the written tiles private to the particle (first write after a resample, or first touch of the area): ONE pop
-    //    of the free ring for all of them, then one wave per tile copies 8 KB.  Usually there is nothing to do — and every wave
+    //    of a free list for all of them (rbpf_device.hpp: sixteen lists, the workgroup's number names the first to try), then one wave per tile copies 8 KB.  Usually there is nothing to do — and every wave
     //    sees that for itself (one ballot over the at most 64 tiles under the box), without a barrier to agree on it.
     const unsigned long long need_m = __ballot(lane < mtn && mt_touch[lane < mtn ? lane : 0]) &
                                       ~((unsigned long long)mt_priv_bits[0] | ((unsigned long long)mt_priv_bits[1] << 32));
     if (need_m) {  // workgroup-uniform
-      if (tid == 0) { need_base = tile_pop_n(P, (unsigned int)__popcll(need_m)); if (need_base == ~0ull) bad = 1; }
+      if (tid == 0) { need_base = tile_pop_n(P, (unsigned int)__popcll(need_m), blockIdx.x); if (need_base == ~0ull) bad = 1; }
       __syncthreads();
+      TRACE_W(15);
       if (bad) { if (tid == 0) atomicOr(&err[3], 8); return; }  // tile pool exhausted (nothing has been written if this is the first band)
+      // (tried: every workgroup starting at another tile and another eighth of it — after a resampling hundreds of particles copy
+      //  from the same few parents' tiles.  No change: the parents' lines are served by the L2s, tools/rbpf_cow_trace.py)
       for (int q = wid; q < mtn; q += nw) {
         if (!((need_m >> q) & 1ull)) continue;
         const int qi = udiv16(q, mty_m), qj = q - qi * mty;
@@ -1076,12 +1079,12 @@ void rbpf_prof_print_raycast() {
     unsigned long long tr[2][16][16];
     if (hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_trace), sizeof(tr)) == hipSuccess && tr[0][0][0]) {
       for (int g = 0; g < 2; ++g) {
-        std::fprintf(stderr, "[raycast_box trace of workgroup %d, us since its first stamp; columns: entry, pose barrier, end-point barrier, flags, flag barrier, own events, walk, walk barrier, requests, barrier, tiles private, replay, overflow+hot, barrier, stores]\n", g ? 900 : 100);
+        std::fprintf(stderr, "[raycast_box trace of workgroup %d, us since its first stamp; columns: entry, pose barrier, end-point barrier, flags, flag barrier, own events, walk, walk barrier, requests, barrier, tiles private, replay, overflow+hot, barrier, stores, (ring position known: only when tiles are made private)]\n", g ? 900 : 100);
         unsigned long long t0 = ~0ull;
         for (int w = 0; w < 16; ++w) if (tr[g][w][0] && tr[g][w][0] < t0) t0 = tr[g][w][0];
         for (int w = 0; w < 16; ++w) {
           std::fprintf(stderr, "  wave %2d:", w);
-          for (int i = 0; i < 15; ++i) std::fprintf(stderr, " %5.2f", tr[g][w][i] ? (double)(tr[g][w][i] - t0) * 0.01 : -1.0);
+          for (int i = 0; i < 16; ++i) std::fprintf(stderr, " %5.2f", tr[g][w][i] ? (double)(tr[g][w][i] - t0) * 0.01 : -1.0);
           std::fprintf(stderr, "\n");
         }
       }

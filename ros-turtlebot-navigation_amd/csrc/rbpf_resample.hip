@@ -15,10 +15,18 @@ __global__ __launch_bounds__(256) void rbpf_normalize(int N, const double* __res
   if (gate_prev && *gate_prev) return;
   normalize_body<256, true>(N, zp, weight, weight_out, cs, parent, out, w, cl, gate, seq, seq_val, children);
 }
-// free ring = every tile but tile 0 (the shared zero tile, pinned)
+// free lists = every tile but tile 0 (the shared zero tile, pinned): tile id sits in slot id / shards of list id % shards
+// (list 0's first slot holds tile 0 and is skipped: its head starts at 1)
 __global__ void rbpf_pool_init(TilePool P) {
-  for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i + 1 < P.cap; i += gridDim.x * blockDim.x) P.ring[i] = i + 1;
-  if (blockIdx.x == 0 && threadIdx.x == 0) { P.ctr[0] = 0ull; P.ctr[1] = (unsigned long long)P.cap - 1ull; P.ref[0] = 1 << 30; }
+  const unsigned int sh = P.shards == 1u ? 0u : (unsigned int)kPoolShardsLog2;
+  for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.cap; i += gridDim.x * blockDim.x)
+    P.ring[(size_t)(i & (P.shards - 1u)) * P.shard_cap + (i >> sh)] = i;
+  if (blockIdx.x == 0 && threadIdx.x < P.shards) {
+    const unsigned int s = threadIdx.x;
+    P.ctr[(size_t)s * kPoolCtrStride] = s == 0u ? 1ull : 0ull;
+    P.ctr[(size_t)s * kPoolCtrStride + 1] = P.cap > s ? (unsigned long long)((P.cap - s + P.shards - 1u) >> sh) : 0ull;
+    if (s == 0u) P.ref[0] = 1 << 30;
+  }
 }
 __global__ __launch_bounds__(kResampleThreads) void rbpf_resample_apply(int N, int TT, const int* __restrict__ parent, const int* __restrict__ children,
                                                            const unsigned int* __restrict__ tab_old, unsigned int* __restrict__ tab_new,
