@@ -192,6 +192,13 @@ int tbnav_rbpf_resample_global(const double* weights_all, int64_t n_global, doub
  * (grid_mapper.cpp:438-477 adds the same log-odds once per beam) — on the device, WITHOUT the chain of dependent adds (integer steps
  * inside a binade, plain adds across its ends); must equal the plain loop bit for bit.  Host buffers; uses the current device. */
 int tbnav_rbpf_add_repeated(const double* x, const double* d, const int32_t* n, double* out, int64_t count);
+/* Test hook for the tile pool's free lists, on a pool of cap_tiles tiles that belongs to no handle (see tbnav_rbpf_create_pool:
+ * sixteen lists from 16 384 tiles, one below): `rounds` times, `callers` callers pop tiles_each (<= 64) tiles at once — every
+ * caller starting at the list its number names, or all at list 0 (same_hint != 0) — and the tiles are pushed back.  ids_out
+ * [callers * tiles_each]: the ids the LAST round's callers got (zeros where no list could supply a caller); the free counts after
+ * that round's pops and pushes.  Host buffers; uses the current device. */
+int tbnav_rbpf_pool_selftest(uint32_t cap_tiles, int32_t rounds, int32_t callers, int32_t tiles_each, int32_t same_hint,
+                             uint32_t* ids_out, uint64_t* free_after_pop, uint64_t* free_after_push);
 /* Re-populate this rank's slots from LOCAL parents (tables and state move on the device); -1 = keep. */
 int tbnav_rbpf_gather_local(tbnav_rbpf* h, const int32_t* local_parent /*[N], -1 = leave*/);
 /* A particle as one device buffer: header, state (pose, prev_pose, weight), the indices and 8 KB payloads of the

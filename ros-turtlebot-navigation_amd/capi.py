@@ -214,6 +214,7 @@ def lib() -> C.CDLL:
         "tbnav_rbpf_slam_batch": (C.c_int, [vp, vp, i32, i32, vp, vp, vp, vp, vp]),
         "tbnav_rbpf_resample_global": (C.c_int, [vp, C.c_int64, dbl, vp, vp, C.POINTER(RbpfStats)]),
         "tbnav_rbpf_add_repeated": (C.c_int, [vp, vp, vp, vp, C.c_int64]),
+        "tbnav_rbpf_pool_selftest": (C.c_int, [C.c_uint32, i32, i32, i32, i32, vp, vp, vp]),
         "tbnav_rbpf_gather_local": (C.c_int, [vp, vp]),
         "tbnav_rbpf_copy_weights_dev": (C.c_int, [vp, vp]),
         "tbnav_rbpf_resample_global_dev": (C.c_int, [vp, vp, C.c_int64, C.c_int64, dbl, vp, C.POINTER(RbpfStats)]),

@@ -1,0 +1,58 @@
+// rbpf_pool.hip — the tile pool's free lists on their own (rbpf_device.hpp: tile_pop_n / tile_at / tile_push): a self-test the
+// GPU tests drive through the C-ABI, on a pool that belongs to no handle (rings and counters only, no tiles behind them).
+#include "rbpf_host.hpp"
+
+namespace tbnav_rk {
+// caller c pops `each` tiles at once (hint: its own number, or 0 for everybody) and writes their ids, or zeros if no list could
+// supply them
+__global__ __launch_bounds__(64) void rbpf_pool_test_pop(TilePool P, int callers, int each, int same_hint, unsigned int* __restrict__ ids) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= callers) return;
+  const unsigned long long pos = tile_pop_n(P, (unsigned int)each, same_hint ? 0u : (unsigned int)c);
+  for (int i = 0; i < each; ++i) ids[(size_t)c * each + i] = pos == ~0ull ? 0u : tile_at(P, pos + (unsigned long long)i);
+}
+__global__ __launch_bounds__(256) void rbpf_pool_test_push(TilePool P, size_t n, const unsigned int* __restrict__ ids) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && ids[i]) tile_push(P, ids[i]);
+}
+}  // namespace tbnav_rk
+
+int tbnav_rbpf_pool_selftest(uint32_t cap_tiles, int32_t rounds, int32_t callers, int32_t tiles_each, int32_t same_hint,
+                             uint32_t* ids_out, uint64_t* free_after_pop, uint64_t* free_after_push) {
+  using namespace tbnav_rk;
+  if (cap_tiles < 2 || rounds < 1 || callers < 1 || tiles_each < 1 || tiles_each > 64 || !ids_out || !free_after_pop || !free_after_push)
+    return TBNAV_ERR_INVALID_ARG;
+  TilePool P{};
+  P.cap = cap_tiles;
+  P.shards = cap_tiles >= kPoolShardMin ? (unsigned int)kPoolShards : 1u;
+  P.shard_cap = (cap_tiles + P.shards - 1) / P.shards;
+  unsigned int* d_ids = nullptr;
+  const size_t n = (size_t)callers * tiles_each;
+  auto free_tiles = [&](uint64_t* out) -> int {
+    unsigned long long ctr[kPoolCtrStride * kPoolShards];
+    TBNAV_HIP(hipMemcpy(ctr, P.ctr, sizeof ctr, hipMemcpyDeviceToHost));
+    *out = 0;
+    for (unsigned int s = 0; s < P.shards; ++s) *out += ctr[s * kPoolCtrStride + 1] - ctr[s * kPoolCtrStride];
+    return TBNAV_OK;
+  };
+  auto body = [&]() -> int {
+    TBNAV_HIP(hipMalloc((void**)&P.ring, sizeof(unsigned int) * (size_t)P.shard_cap * P.shards));
+    TBNAV_HIP(hipMalloc((void**)&P.ctr, sizeof(unsigned long long) * kPoolCtrStride * kPoolShards));
+    TBNAV_HIP(hipMalloc((void**)&P.ref, sizeof(int)));   // (the init kernel pins tile 0's count)
+    TBNAV_HIP(hipMalloc((void**)&d_ids, sizeof(unsigned int) * n));
+    hipLaunchKernelGGL(rbpf_pool_init, dim3(256), dim3(256), 0, 0, P);
+    for (int r = 0; r < rounds; ++r) {
+      hipLaunchKernelGGL(rbpf_pool_test_pop, dim3((unsigned int)((callers + 63) / 64)), dim3(64), 0, 0, P, callers, tiles_each, same_hint, d_ids);
+      TBNAV_HIP(hipDeviceSynchronize());
+      { const int rc = free_tiles(free_after_pop); if (rc != TBNAV_OK) return rc; }
+      TBNAV_HIP(hipMemcpy(ids_out, d_ids, sizeof(unsigned int) * n, hipMemcpyDeviceToHost));
+      hipLaunchKernelGGL(rbpf_pool_test_push, dim3((unsigned int)((n + 255) / 256)), dim3(256), 0, 0, P, n, d_ids);
+      TBNAV_HIP(hipDeviceSynchronize());
+      { const int rc = free_tiles(free_after_push); if (rc != TBNAV_OK) return rc; }
+    }
+    return TBNAV_OK;
+  };
+  const int rc = body();
+  (void)hipFree(P.ring); (void)hipFree(P.ctr); (void)hipFree(P.ref); (void)hipFree(d_ids);
+  return rc;
+}

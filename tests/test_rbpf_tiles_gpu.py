@@ -294,3 +294,81 @@ def test_batched_export_equals_single_exports_and_imports_rebuild_the_particles(
     cur = steps[2][1]
     assert dst.SLAM(scan, (0.0, 0.0, 0.0), cur, cur, True, (0.0, 0.0, 0.0), orc.normal_stream(5, N * (3 * k + 3) + 1, 0.0, 1.0)).status == 0
     src.close(); dst.close()
+
+
+def test_sixteen_free_lists_run_nearly_dry_then_report_exhaustion(gpu_pkg):
+    """A pool of 16 384 tiles or more keeps its free tiles in sixteen lists (csrc/rbpf_device.hpp); a particle pops the tiles one map
+    update makes private from ONE list and moves to the next when that one is short.  Here the particles need 96-98 % of the
+    pool: the last workgroups find their own list too short and are served by another — every map still the oracle's bits, the
+    counters add up — and with a few particles more than the pool holds the scan reports the exhaustion."""
+    from rtn_amd import capi
+    k, per_tile, cap_tiles = 4, 8192 + 128 + 4 + 4, 16400
+    steps, poses = rc.trajectory(2, inc=(0.05, 0.04, 0.03))
+    rng = np.random.default_rng(5)
+    scans = [orc.room_scan(poses[s], walls=rc.ROOM_SURVEY, rng=rng) for s in range(2)]
+
+    def run(N, n_scans=2):
+        pf = _dev(gpu_pkg, pool_bytes=cap_tiles * per_tile, N=N, k=k, map_min=-10.0, map_max=10.0)
+        cap, free0, _ = pf.poolStats()
+        assert free0 == cap and (cap == cap_tiles - 1 or N < 48)   # (tile 0 is the shared zero tile; a few particles' maps could never need the budget)
+        hist, sts = [], []
+        for s, (prev, cur, t_icp, u) in enumerate(steps[:n_scans]):
+            st = pf.SLAM(scans[s], u, cur, prev, True, t_icp, orc.normal_stream(70 + s, pf.numNormals(True), 0.0, 1.0), check=False)
+            sts.append(st.status)
+            hist.append(pf.trace()["new_pose"].copy())
+        return pf, cap, hist, sts
+
+    pf, cap, _, sts = run(16, 1)                                # pilot: tiles one particle's first scan takes
+    assert sts == [0]
+    per_particle = (cap - pf.poolStats()[1]) / 16
+    pf.close()
+    assert 10 < per_particle < 40
+    N_fit = int(0.97 * (cap_tiles - 1) / per_particle)
+    pf, cap, hist, sts = run(N_fit)
+    assert sts == [0, 0]
+    used = cap - pf.poolStats()[1]
+    assert 0.94 * cap < used <= cap, (used, cap)                 # nearly dry: most lists have fewer tiles left than one particle takes
+    grid = (0.05, -10.0, 10.0, -10.0, 10.0)
+    for m in (0, N_fit // 2, N_fit - 3, N_fit - 2, N_fit - 1):   # (the last workgroups are the ones that found their list short)
+        assert np.array_equal(pf.logOdds(m), _oracle_map(grid, None, scans, [hist[0][m], hist[1][m]])), m
+    pf.close()
+    pf, cap, _, sts = run(int(1.05 * (cap_tiles - 1) / per_particle), 1)
+    assert sts == [capi.ERR_POOL_EXHAUSTED]
+    pf.close()
+
+
+@pytest.mark.parametrize("cap,callers,each,same_hint", [
+    (20000, 1000, 14, 0),    # sixteen lists, every caller served by the list of its number
+    (20000, 1000, 14, 1),    # everybody starts at list 0 (1250 tiles): it runs dry after 89 callers, the rest move on
+    (20000, 1500, 14, 0),    # 21 000 tiles asked of 19 999: some callers find no list long enough
+    (20000, 400, 64, 1),     # the longest request a map update makes
+    (16384, 2000, 9, 0),     # the smallest pool with sixteen lists, asked for more than it holds
+    (5000, 300, 14, 0),      # one list
+    (5000, 400, 14, 0),      # one list, exhausted: exactly floor(4999 / 14) callers are served
+])
+def test_free_lists_hand_every_tile_out_once_and_take_it_back(gpu_pkg, cap, callers, each, same_hint):
+    """tile_pop_n / tile_at / tile_push on their own (csrc/rbpf_pool.hip): no tile is handed to two callers, a caller gets all its
+    tiles or none, the counts add up, and three rounds of pops and pushes leave the lists whole."""
+    import ctypes as C
+    from rtn_amd import capi
+    lib = capi.lib()
+    ids = np.zeros(callers * each, dtype=np.uint32)
+    f_pop, f_push = C.c_uint64(0), C.c_uint64(0)
+    rc = lib.tbnav_rbpf_pool_selftest(cap, 3, callers, each, same_hint, ids.ctypes.data, C.addressof(f_pop), C.addressof(f_push))
+    assert rc == 0
+    per = ids.reshape(callers, each)
+    served = (per != 0).all(axis=1)
+    assert ((per != 0).any(axis=1) == served).all()                 # all of a caller's tiles or none
+    got = per[served].ravel()
+    assert got.size == np.unique(got).size and got.min() >= 1 and got.max() < cap
+    assert f_pop.value == cap - 1 - got.size and f_push.value == cap - 1
+    sharded = cap >= 16384
+    if sharded:
+        assert (per[served] % 16 == (per[served][:, :1] % 16)).all()   # one list per request: the ids of a request share a residue
+    n_served = int(served.sum())
+    if callers * each <= cap - 1 - (16 * (each - 1) if sharded else 0):
+        assert n_served == callers
+    else:   # short of empty by at most (each - 1) tiles per list
+        assert (cap - 1 - (16 if sharded else 1) * (each - 1)) // each <= n_served <= (cap - 1) // each
+    if not sharded and callers * each > cap - 1:
+        assert n_served == (cap - 1) // each
