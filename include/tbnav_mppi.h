@@ -91,7 +91,7 @@ int tbnav_mppi_streaming_form(const tbnav_mppi* h);
  *                          suffix sums only for the horizon's last steps, J = total - prefix formed by the consumers) even where
  *                          it applies — the large-K default; mppi_rollout_cost is the general fallback. */
 enum { TBNAV_MPPI_OPT_KERNEL = 1, TBNAV_MPPI_OPT_TRIG = 2, TBNAV_MPPI_OPT_NO_LDS_STAGING = 3, TBNAV_MPPI_OPT_KEEP_J = 4, TBNAV_MPPI_OPT_REG_TAIL = 5,
-       TBNAV_MPPI_OPT_BATCH_GRAPH = 6 /* 0: tbnav_mppi_enqueue_rng_batch launches every tick by itself instead of replaying a captured hipGraph of 100 */,
+       TBNAV_MPPI_OPT_BATCH_GRAPH = 6 /* 0: tbnav_mppi_enqueue_rng_batch launches every tick by itself instead of replaying captured hipGraphs (chunks of 100 ticks; one of the batch's own length for 8-99) */,
        TBNAV_MPPI_OPT_PREFIX_FORM = 7,
        TBNAV_MPPI_OPT_DIRECT_EXCHANGE = 8 /* 0: a handle attached to a multi-process communicator always exchanges through the communicator's
                                              all-gather (default 1: directly into the peers' buffers when every rank can; takes effect at the next attach; 2: as 1 with a fault injected for the tests of the
@@ -274,12 +274,14 @@ int tbnav_mppi_new_controls_rng(tbnav_mppi* h, const double x0[3], uint64_t seed
  * perturbations of (seed, first_tick + i).  Exactly n_ticks tbnav_mppi_enqueue_rng calls, without a trip through the
  * caller's language per tick (from Python one enqueue costs as much as the tick takes on the device).  With one state for
  * all ticks (x0_stride = 0) on a non-default stream and the fused kernel, whole chunks of 100 ticks are replayed from a captured
- * hipGraph (same kernels, same arguments but for the tick number, which the kernel then reads from device memory): same result. */
+ * hipGraph (same kernels, same arguments but for the tick number, which the kernel then reads from device memory): same result.
+ * What is left of a batch, or a batch of 8 to 99 ticks, is replayed from ONE graph of its own length (less one tick if odd) once
+ * a second batch in a row asks for the same length: a caller that synchronises every 20 ticks submits one graph per block. */
 int tbnav_mppi_enqueue_rng_batch(tbnav_mppi* h, const double* x0s, int32_t x0_stride, uint64_t seed, uint64_t first_tick,
                                  int32_t n_ticks, void* stream);
 
-/* How many of the ticks enqueued through tbnav_mppi_enqueue_rng_batch so far went out as replays of the captured 100-tick
- * graph (the rest were plain launches): lets a benchmark line say what actually ran. */
+/* How many of the ticks enqueued through tbnav_mppi_enqueue_rng_batch so far went out as replays of a captured graph (the rest
+ * were plain launches): lets a benchmark line say what actually ran. */
 int64_t tbnav_mppi_graph_replayed_ticks(const tbnav_mppi* h);
 
 /* Per-kernel durations priced without the events' own cost: each kernel of the tick is launched `reps` (even, >= 2)

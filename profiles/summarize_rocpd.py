@@ -40,6 +40,19 @@ def main():
         med = dd[len(dd) // 2] if len(dd) % 2 else 0.5 * (dd[len(dd) // 2 - 1] + dd[len(dd) // 2])
         print(f"| {short(r[0])} | {r[1]}x{r[2]}x{r[3]} | {r[4]} | {r[5]} | {r[6]/1e3:.3f} | {r[7]/1e3:.3f} | {r[8]/1e3:.3f} | "
               f"{r[9]/1e6:.3f} | {100*r[9]/total:.1f} | {r[10]} | {r[11]} | {r[12]} | {r[13]} | {med/1e3:.3f} |")
+    # the map update's launches one by one, in launch order (a run of a dozen scans): the first two (empty maps: every tile a first
+    # touch), the plain ones and the one that follows a resampling (tiles of a shared map made private) are three different launches
+    seq = {}
+    cols = [r[1] for r in c.execute("pragma table_info('kernels')")]
+    order = next((k for k in ("start", "start_time", "dispatch_id", "id") if k in cols), None)
+    for name, d in c.execute("select name, duration from kernels" + (f" order by {order}" if order else "")):
+        if "rbpf_raycast_box" in name:
+            seq.setdefault(short(name), []).append(d)
+    if seq and sum(len(v) for v in seq.values()) <= 40:
+        print()
+        print("Map-update launches in launch order, µs (a kernel's own launches; tools/rbpf_driver.py says which scans resample):")
+        for k, v in seq.items():
+            print(f"- `{k}`: " + " ".join(f"{d/1e3:.1f}" for d in v))
 
 
 if __name__ == "__main__":

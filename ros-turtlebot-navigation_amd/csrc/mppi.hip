@@ -374,8 +374,7 @@ void tbnav_mppi_destroy(tbnav_mppi* h) {
   exchange_words_free(h);
   (void)hipFree(h->d_raw); (void)hipFree(h->d_records); (void)hipFree(h->d_records_f); (void)hipFree(h->d_out);
   if (h->h_out) (void)hipHostFree(h->h_out);
-  if (h->tg_exec) (void)hipGraphExecDestroy(h->tg_exec);
-  if (h->tg_graph) (void)hipGraphDestroy(h->tg_graph);
+  for (auto* g : {&h->tg, &h->tgs}) { if (g->exec) (void)hipGraphExecDestroy(g->exec); if (g->graph) (void)hipGraphDestroy(g->graph); }
   (void)hipFree(h->d_tick0);
   delete h;
 }
@@ -766,71 +765,111 @@ int tbnav_mppi_enqueue_rng(tbnav_mppi* h, const double x0[3], uint64_t seed, uin
   return rc != TBNAV_OK ? rc : launch_combine(h, h->d_records_f, 1, st, h->fused_S);
 }
 
+namespace {
+using TickGraph = tbnav_mppi::TickGraph;
+void drop_graph(TickGraph& g) {
+  if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+  if (g.graph) { (void)hipGraphDestroy(g.graph); g.graph = nullptr; }
+}
+bool graph_usable(const tbnav_mppi* h, const TickGraph& g, const double* x0, uint64_t seed, hipStream_t st) {
+  return g.exec && g.epoch == h->cfg_epoch && g.seed == seed && g.stream == st && std::memcmp(g.x0, x0, sizeof g.x0) == 0;
+}
+// Capture `len` ticks (len even: the controls' double buffer is back where it was after a replay) and a last node that advances
+// the device's tick word by len.  A capture that fails turns the replays off for good (plain launches from there on).
+void build_graph(tbnav_mppi* h, TickGraph& g, int len, const double* x0, uint64_t seed, hipStream_t st) {
+  // (another stream may not have run the previous replay's tick-advance node yet: what the device word holds is unknown)
+  h->tg_dev_tick = ~0ull;
+  drop_graph(g);
+  if (!h->d_tick0 && hipMalloc((void**)&h->d_tick0, sizeof(uint64_t)) != hipSuccess) { h->d_tick0 = nullptr; h->graph_on = false; }
+  if (!h->graph_on) return;
+  if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) != hipSuccess) { h->graph_on = false; (void)hipGetLastError(); return; }
+  const int ucur0 = h->ucur; const uint64_t seq0 = h->seq;
+  int rc = TBNAV_OK;
+  for (int t = 0; t < len && rc == TBNAV_OK; ++t) {
+    RngArgs ra{seed, rng_base(h, (uint64_t)t), std::sqrt(h->p.ul_var), std::sqrt(h->p.ur_var)};
+    ra.tick0 = h->d_tick0; ra.per_tick = (uint64_t)h->T * h->k_global;
+    rc = launch_fused(h, x0, h->d_duL, h->d_duR, st, &ra);
+    if (rc == TBNAV_OK) rc = launch_combine(h, h->d_records_f, 1, st, h->fused_S);
+  }
+  if (rc == TBNAV_OK) { hipLaunchKernelGGL(mppi_tick_advance, dim3(1), dim3(1), 0, st, h->d_tick0, (uint64_t)len); if (hipGetLastError() != hipSuccess) rc = TBNAV_ERR_HIP; }
+  hipGraph_t gr = nullptr;
+  const hipError_t e_end = hipStreamEndCapture(st, &gr);
+  h->ucur = ucur0; h->seq = seq0;  // nothing ran: the host-side state goes back
+  if (rc == TBNAV_OK && e_end == hipSuccess && gr && hipGraphInstantiate(&g.exec, gr, nullptr, nullptr, 0) == hipSuccess) {
+    g.graph = gr; g.len = len; g.seed = seed; g.stream = st; g.ucur = h->ucur; g.epoch = h->cfg_epoch; std::memcpy(g.x0, x0, sizeof g.x0);
+  } else {
+    if (gr) (void)hipGraphDestroy(gr);
+    g.exec = nullptr; h->graph_on = false; (void)hipGetLastError();
+  }
+}
+int replay_graph(tbnav_mppi* h, const TickGraph& g, uint64_t t0, hipStream_t st) {
+  // (consecutive replays need no copy: the last node of the one before has advanced the device word)
+  if (t0 != h->tg_dev_tick) {
+    h->tg_dev_tick = ~0ull;
+    hipLaunchKernelGGL(mppi_tick_set, dim3(1), dim3(1), 0, st, h->d_tick0, t0);
+    TBNAV_HIP(hipGetLastError());
+  }
+  { const hipError_t eg = hipGraphLaunch(g.exec, st); if (eg != hipSuccess) { h->tg_dev_tick = ~0ull; TBNAV_HIP(eg); } }
+  h->tg_dev_tick = t0 + (uint64_t)g.len;
+  h->seq += (uint64_t)g.len;  // ucur: unchanged after an even number of ticks; the shift stays owed
+  h->graph_ticks += (uint64_t)g.len;
+  return TBNAV_OK;
+}
+}  // namespace
+
 int tbnav_mppi_enqueue_rng_batch(tbnav_mppi* h, const double* x0s, int32_t x0_stride, uint64_t seed, uint64_t first_tick, int32_t n_ticks,
                                  void* stream) {
   if (!h || !x0s || n_ticks < 0 || (x0_stride != 0 && x0_stride < 3)) return TBNAV_ERR_INVALID_ARG;
   int32_t i = 0;
   constexpr int kGraphTicks = 100;  // (even: the controls' double buffer is back where it was after a chunk)
+  constexpr int kShortMin = 8;      // the shortest batch worth a graph of its own
   hipStream_t st = static_cast<hipStream_t>(stream);
   // (only where the tick is short enough for the launches themselves to matter: K = 1024: 8.25 -> 8.15 us per tick on a fast host, 8.9 -> 8.3
   //  on a slower one; from K = 2048 up the device is the bound and the replay is 1-3 % slower than plain launches)
   if (h->graph_on && !h->comm && x0_stride == 0 && st != nullptr && rng_in_kernel(h) && h->fused_r == 8 && h->K <= 1536 && n_ticks >= 2) {
     DeviceGuard guard(h->device);
-    // (the graph is built by the first batch call that could use one, however short — a warm-up call, typically — so that a
+    // (the chunk graph is built by the first batch call that could use one, however short — a warm-up call, typically — so that a
     //  later long call does not pay the ~1 ms of capture + instantiation)
-    // the first tick after set_controls / set_initial_controls reads the vector unshifted: keep it out of the graph
+    // the first tick after set_controls / set_initial_controls reads the vector unshifted: keep it out of the graphs
     if (!h->pending_shift) { const int rc = tbnav_mppi_enqueue_rng(h, x0s, seed, first_tick, stream); if (rc != TBNAV_OK) return rc; ++i; }
-    const bool usable = h->tg_exec && h->tg_epoch == h->cfg_epoch && h->tg_seed == seed && h->tg_stream == st &&
-                        std::memcmp(h->tg_x0, x0s, sizeof h->tg_x0) == 0;
-    // (the graph has the controls' double buffer baked in as it stood at capture: on the other parity ONE plain tick brings it
-    //  back — a rebuild would cost ~0.5 ms inside the caller's batch.  Shorter chunks were measured and dropped: a 10-tick graph
-    //  replays at 9.9-10.2 us per tick against 8.9 for plain launches — a replay's fixed cost needs ~100 ticks to amortise)
-    if (usable && h->tg_ucur != h->ucur && n_ticks - i > kGraphTicks) {
+    const bool usable = graph_usable(h, h->tg, x0s, seed, st);
+    // (a graph has the controls' double buffer baked in as it stood at capture: on the other parity ONE plain tick brings it
+    //  back — a rebuild would cost ~0.5 ms inside the caller's batch)
+    if (usable && h->tg.ucur != h->ucur && n_ticks - i > kGraphTicks) {
       const int rc = tbnav_mppi_enqueue_rng(h, x0s, seed, first_tick + (uint64_t)i, stream);
       if (rc != TBNAV_OK) return rc;
       ++i;
     }
-    const bool same = usable && h->tg_ucur == h->ucur;
-    if (!same && (!usable || n_ticks - i >= kGraphTicks)) {
-      // (another stream may not have run the previous replay's tick-advance node yet: what the device word holds is unknown)
-      h->tg_dev_tick = ~0ull;
-      if (h->tg_exec) { (void)hipGraphExecDestroy(h->tg_exec); h->tg_exec = nullptr; }
-      if (h->tg_graph) { (void)hipGraphDestroy(h->tg_graph); h->tg_graph = nullptr; }
-      if (!h->d_tick0 && hipMalloc((void**)&h->d_tick0, sizeof(uint64_t)) != hipSuccess) { h->d_tick0 = nullptr; h->graph_on = false; }
-      if (h->graph_on && hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess) {
-        const int ucur0 = h->ucur; const uint64_t seq0 = h->seq;
-        int rc = TBNAV_OK;
-        for (int t = 0; t < kGraphTicks && rc == TBNAV_OK; ++t) {
-          RngArgs g{seed, rng_base(h, (uint64_t)t), std::sqrt(h->p.ul_var), std::sqrt(h->p.ur_var)};
-          g.tick0 = h->d_tick0; g.per_tick = (uint64_t)h->T * h->k_global;
-          rc = launch_fused(h, x0s, h->d_duL, h->d_duR, st, &g);
-          if (rc == TBNAV_OK) rc = launch_combine(h, h->d_records_f, 1, st, h->fused_S);
-        }
-        if (rc == TBNAV_OK) { hipLaunchKernelGGL(mppi_tick_advance, dim3(1), dim3(1), 0, st, h->d_tick0, (uint64_t)kGraphTicks); if (hipGetLastError() != hipSuccess) rc = TBNAV_ERR_HIP; }
-        hipGraph_t gr = nullptr;
-        const hipError_t e_end = hipStreamEndCapture(st, &gr);
-        h->ucur = ucur0; h->seq = seq0;  // nothing ran: the host-side state goes back
-        if (rc == TBNAV_OK && e_end == hipSuccess && gr && hipGraphInstantiate(&h->tg_exec, gr, nullptr, nullptr, 0) == hipSuccess) {
-          h->tg_graph = gr; h->tg_seed = seed; h->tg_stream = st; h->tg_ucur = h->ucur; h->tg_epoch = h->cfg_epoch; std::memcpy(h->tg_x0, x0s, sizeof h->tg_x0);
-        } else {
-          if (gr) (void)hipGraphDestroy(gr);
-          h->tg_exec = nullptr; h->graph_on = false; (void)hipGetLastError();  // plain launches from here on
-        }
-      } else h->graph_on = false;
-    }
-    while (h->tg_exec && n_ticks - i >= kGraphTicks) {
-      const uint64_t t0 = first_tick + (uint64_t)i;
-      // (consecutive chunks need no copy: the replay's last node has advanced the device word)
-      if (t0 != h->tg_dev_tick) {
-        h->tg_dev_tick = ~0ull;
-        hipLaunchKernelGGL(mppi_tick_set, dim3(1), dim3(1), 0, st, h->d_tick0, t0);
-        TBNAV_HIP(hipGetLastError());
-      }
-      { const hipError_t eg = hipGraphLaunch(h->tg_exec, st); if (eg != hipSuccess) { h->tg_dev_tick = ~0ull; TBNAV_HIP(eg); } }
-      h->tg_dev_tick = t0 + (uint64_t)kGraphTicks;
-      h->seq += kGraphTicks;  // ucur: unchanged after an even number of ticks; the shift stays owed
-      h->graph_ticks += kGraphTicks;
+    const bool same = usable && h->tg.ucur == h->ucur;
+    if (!same && (!usable || n_ticks - i >= kGraphTicks)) build_graph(h, h->tg, kGraphTicks, x0s, seed, st);
+    while (h->tg.exec && n_ticks - i >= kGraphTicks) {
+      const int rc = replay_graph(h, h->tg, first_tick + (uint64_t)i, st);
+      if (rc != TBNAV_OK) return rc;
       i += kGraphTicks;
+    }
+    // What is left (or a batch shorter than a chunk): one graph of exactly that many ticks, less one if odd.  Built by the second
+    // batch in a row that asks for the same length on the same parity of the double buffer — a caller that times blocks of 20
+    // ticks gets it in its second block; one with batches of ever-changing length never pays for a graph it would not reuse.
+    // (Measured at K = 1024, T = 50, blocks of 20 between synchronisations: 9.3 us per tick replayed, 9.8-12.1 launched one by
+    //  one — the spread is the host's launch rate, which the replay does not depend on.  An earlier note here gave a 10-tick
+    //  replay 9.9-10.2 us against 8.9: that was a chunk graph plus plain ticks plus the tick-set launch in one batch.)
+    // (an odd batch leaves the double buffer on the other parity: ONE plain tick in front brings the next batch back to the parity
+    //  the graph was captured on, if what is left then still is the graph's length)
+    if (h->graph_on && graph_usable(h, h->tgs, x0s, seed, st) && h->tgs.ucur != h->ucur && ((n_ticks - i - 1) & ~1) == h->tgs.len) {
+      const int rc = tbnav_mppi_enqueue_rng(h, x0s, seed, first_tick + (uint64_t)i, stream);
+      if (rc != TBNAV_OK) return rc;
+      ++i;
+    }
+    const int L = (n_ticks - i) & ~1;
+    if (h->graph_on && h->tg.exec && L >= kShortMin) {
+      const bool fits = graph_usable(h, h->tgs, x0s, seed, st) && h->tgs.len == L && h->tgs.ucur == h->ucur;
+      if (!fits && h->tgs_wish_len == L && h->tgs_wish_ucur == h->ucur) build_graph(h, h->tgs, L, x0s, seed, st);
+      h->tgs_wish_len = L; h->tgs_wish_ucur = h->ucur;
+      if (h->tgs.exec && graph_usable(h, h->tgs, x0s, seed, st) && h->tgs.len == L && h->tgs.ucur == h->ucur) {
+        const int rc = replay_graph(h, h->tgs, first_tick + (uint64_t)i, st);
+        if (rc != TBNAV_OK) return rc;
+        i += L;
+      }
     }
   }
   for (; i < n_ticks; ++i) {

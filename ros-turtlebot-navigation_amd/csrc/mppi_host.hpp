@@ -38,15 +38,21 @@ struct tbnav_mppi {
   uint64_t seq = 0;             // combines enqueued so far
   uint64_t published = 0;       // tick number of the last combine that was asked to publish to h_out
   bool publish_next = false;    // set by the synchronous entry points round their enqueue
-  // tbnav_mppi_enqueue_rng_batch replays a captured hipGraph of kGraphTicks ticks (two launches each) instead of launching
-  // them one by one: ~0.5 us less per tick of a 8-9 us tick
+  // tbnav_mppi_enqueue_rng_batch replays captured hipGraphs of ticks (two launches each) instead of launching them one by one:
+  // chunks of kGraphTicks (~0.5 us less per tick of a 8-9 us tick) and, for what is left — or a batch shorter than a chunk —,
+  // ONE graph of the batch's own length (tgs): a batch of 20 ticks is one submission instead of forty, 9.3 us per tick whatever
+  // the host's launch rate is doing (9.8-12.1 launched one by one)
   bool graph_on = true;         // TBNAV_MPPI_OPT_BATCH_GRAPH; cleared for good if a capture ever fails
-  hipGraph_t tg_graph = nullptr; hipGraphExec_t tg_exec = nullptr;
-  uint64_t tg_seed = 0; double tg_x0[3] = {0, 0, 0}; hipStream_t tg_stream = nullptr; int tg_ucur = -1;
+  struct TickGraph {
+    hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+    int len = 0; uint64_t seed = 0; double x0[3] = {0, 0, 0}; hipStream_t stream = nullptr; int ucur = -1; uint64_t epoch = ~0ull;
+  };
+  TickGraph tg, tgs;
+  int tgs_wish_len = 0, tgs_wish_ucur = -1;   // the short graph is built by the SECOND batch in a row that could use the same one
   // The graph's kernel nodes hold BY VALUE everything launch_fused / launch_combine read from the handle when it was captured
   // (waypoint, uinit, lambda, dynamics, trig, keep_j + the J pointer, the rng shard, fused_S and the record buffer).  Every
   // setter that changes one of those bumps cfg_epoch; a graph captured under another epoch is rebuilt, never replayed.
-  uint64_t cfg_epoch = 0, tg_epoch = ~0ull;
+  uint64_t cfg_epoch = 0;
   uint64_t graph_ticks = 0;  // ticks enqueued through graph replays so far (tbnav_mppi_graph_replayed_ticks: what a bench line should say ran)
   uint64_t* d_tick0 = nullptr;
   uint64_t tg_dev_tick = ~0ull;  // what *d_tick0 holds once everything enqueued so far has run (each replay's last node adds the chunk)

@@ -653,6 +653,53 @@ def test_batch_enqueue_by_graph_replay_equals_tick_by_tick(gpu_pkg, K, horizon):
     assert np.array_equal(ma.getControls(), mb.getControls())
 
 
+def test_short_batches_replay_a_graph_of_their_own_length(gpu_pkg):
+    """A batch shorter than a chunk of 100 — what is left of a long one, or the 20 ticks a harness times between two
+    synchronisations — is replayed from ONE graph of its own length once a second batch in a row asks for the same length on the
+    same parity of the controls' double buffer (csrc/mppi.hip: tgs).  Bit for bit the ticks launched one by one: repeated lengths
+    (the graph is built by the second and replayed from then on), odd lengths (one plain tick behind the replay flips the parity,
+    one in front of the next brings it back), a length change, a long batch with a short rest, a parameter change in between."""
+    import torch
+    from rtn_amd import capi
+    d = mppi_cfg(1024, 0.5)
+    ma, mb = make_mppi(gpu_pkg, d), make_mppi(gpu_pkg, d)
+    mb.setOption(capi.MPPI_OPT_BATCH_GRAPH, 0)
+    side = torch.cuda.Stream()
+    st = side.cuda_stream
+    x0 = (0.05, -0.02, 0.3)
+    for m in (ma, mb):
+        m.setWaypoint(*WAYPOINTS[1])
+    first = 0
+    replayed = [ma.graphReplayedTicks()]
+    plan = [5] + [20] * 5 + [21] * 4 + [8] * 3 + [7] * 2 + [130] * 3 + [20] * 3
+    for j, n in enumerate(plan):
+        if j == 8:
+            ma.setWaypoint(*WAYPOINTS[2]); mb.setWaypoint(*WAYPOINTS[2])   # (baked into the graphs: both are rebuilt)
+        ma.enqueueRngBatch(x0, 31, first, n, st)
+        for i in range(n):
+            mb.enqueueRng(x0, 31, first + i, st)
+        torch.cuda.synchronize()
+        assert ma.lastControls(st) == mb.lastControls(st), (j, n)   # (the state carries: one wrong tick shows in every later one)
+        first += n
+        replayed.append(ma.graphReplayedTicks())
+    assert np.array_equal(ma.getControls(), mb.getControls())
+    # (getControls applies the owed shift for real: the next batch starts with one plain tick, its graph is one of 18 — same results)
+    for n in (20, 20, 20):
+        ma.enqueueRngBatch(x0, 31, first, n, st)
+        for i in range(n):
+            mb.enqueueRng(x0, 31, first + i, st)
+        torch.cuda.synchronize()
+        assert np.array_equal(ma.getControls(), mb.getControls())
+        first += n
+    per_call = np.diff(replayed)
+    assert list(per_call[1:6]) == [0, 20, 20, 20, 20]          # the first batch of 20 asks, the second builds, all replay from then on
+    assert list(per_call[6:10]) == [20, 20, 20, 20]            # 21 ticks: the graph of 20 + one plain tick, behind or in front (rebuilt at once after the waypoint change: the wish stands)
+    assert list(per_call[10:13]) == [0, 8, 8] and list(per_call[13:15]) == [0, 0]   # 7 ticks: below the shortest graph
+    assert list(per_call[15:18]) == [100, 130, 130]            # 100 by the chunk graph, the rest of 30 by its own from the second call
+    assert mb.graphReplayedTicks() == 0
+    ma.close(); mb.close()
+
+
 def test_graph_replay_is_rebuilt_when_a_baked_parameter_changes(gpu_pkg):
     """The captured graph of ticks holds the waypoint, uinit, dynamics, trig, the rng shard and the record buffer BY VALUE
     (round-2 advisor finding): every setter that changes one of them must invalidate it.  Batch, change one, batch again —

@@ -30,9 +30,10 @@ for key, tag in TAGS.items():
             v["hbm_bytes"] = v["read_bytes"] + v["write_bytes"]
             v["note"] = "reads are 64- / 128-byte row segments (8 or 16 rollouts x 8 B per time step): FETCH_SIZE at face value, no x2"
         if name.startswith("rbpf_raycast") and key == "rbpf_N1000_k50_400x400":
-            v["note"] = ("average over 11 launches of which two follow a forced resample (tiles of a shared map are made private in that launch); 16-byte accesses, "
-                         "whole cache lines per wave: the x2 read correction and the 1:1 write reading hold for this pattern (calibrated: profiles/r05_fetch_write_calibration.txt — "
-                         "whole 128-byte lines fetched, whole 32-byte sectors written)")
+            v["note"] = ("the run's 14 scans: <512, 6, true, 8> = the FIRST TWO (the LDS array not yet sized to the boxes' need, every tile a first touch of the zero tile); "
+                         "<512, 8, false, 4> = the other twelve, of which the eighth (scan 9) follows the forced resampling of scan 8 and makes the written tiles of the shared maps "
+                         "private — its own counters: _map_update_launches_in_order.  16-byte accesses, whole cache lines per wave: the x2 read correction and the 1:1 write reading "
+                         "hold for this pattern (calibrated: profiles/r05_fetch_write_calibration.txt — whole 128-byte lines fetched, whole 32-byte sectors written)")
         elif name.startswith("rbpf_raycast"):
             v["note"] = ("no forced resample in this run: every launch is a plain scan (no tile clones); partial-line 16-byte accesses: FETCH_SIZE x 2 = whole 128-byte "
                          "lines fetched, WRITE_SIZE = whole 32-byte sectors written (calibrated: profiles/r05_fetch_write_calibration.txt)")

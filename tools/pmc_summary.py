@@ -35,4 +35,15 @@ for k in sorted(set(rd) | set(wr)):
     r, n = rd.get(k, (0.0, 0)); w, _ = wr.get(k, (0.0, 0))
     out[k] = {"launches": n, "fetch_size_kb_raw": round(r, 1), "write_size_kb_raw": round(w, 1),
               "read_bytes": int(r * 1024 * 2), "write_bytes": int(w * 1024), "hbm_bytes": int(r * 1024 * 2 + w * 1024)}
+# the map update's launches one by one (launch order): the first scans, the plain ones and the one after a resampling differ
+seq = {}
+for path, counter in ((f"gpurun_out/pmc_{tag}_FETCH_SIZE.csv", "FETCH_SIZE"), (f"gpurun_out/pmc_{tag}_WRITE_SIZE.csv", "WRITE_SIZE")):
+    with open(path) as f:
+        rows = [r for r in csv.DictReader(f) if r.get("Counter_Name") == counter and "rbpf_raycast_box" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    for r in rows:
+        seq.setdefault(short(r["Kernel_Name"]), {}).setdefault(counter, []).append(float(r["Counter_Value"]))
+if seq and sum(len(v.get("FETCH_SIZE", [])) for v in seq.values()) <= 40:
+    out["_map_update_launches_in_order"] = {k: {"read_bytes": " ".join(str(int(x * 2048)) for x in v.get("FETCH_SIZE", [])),
+                                                 "write_bytes": " ".join(str(int(x * 1024)) for x in v.get("WRITE_SIZE", []))} for k, v in seq.items()}
 print(json.dumps(out, indent=1))
