@@ -95,9 +95,9 @@ int tbnav_rbpf_create(const tbnav_rbpf_params* params, tbnav_rbpf** out);
 /* Same, with an explicit budget for the log-odds tile pool (bytes; 0 = the default: what every particle's map could
  * ever need if that fits in half of the device memory free at create time, else that half).  A scan that needs a
  * tile when none is free returns TBNAV_ERR_POOL_EXHAUSTED and leaves the maps of the particles concerned unchanged.
- * (Pools of 16 384 tiles — 128 MB — or more keep their free tiles in sixteen lists, and a particle takes the tiles one map
- * update makes private, at most 64, from ONE of them: there the error means that no list held that many at once, which can
- * happen with up to 16 x 63 tiles, 8 MB, still free.  Smaller pools keep one list and run to the last tile.) */
+ * (Pools of 16 384 tiles — 128 MB — or more keep their free tiles in sixteen lists; a particle takes the tiles one map update
+ * makes private from one of them, and gathers them from all lists when none holds that many: the pool runs to its last tile
+ * either way.) */
 int tbnav_rbpf_create_pool(const tbnav_rbpf_params* params, uint64_t max_pool_bytes, tbnav_rbpf** out);
 void tbnav_rbpf_destroy(tbnav_rbpf* h);
 /* Tile pool occupancy: tiles the pool holds, tiles free now, bytes of log-odds per tile (any pointer may be NULL). */

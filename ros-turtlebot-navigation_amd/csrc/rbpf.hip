@@ -688,11 +688,18 @@ int default_host_threads() {
   const int t = std::min(n, (int)std::ceil(q));
   return t < 1 ? 1 : (t > 128 ? 128 : t);
 }
+// free lists: rbpf_device.hpp.  (TBNAV_POOL_SHARD_MIN: a test hook — the GPU suite is run once with every pool of 32 tiles or
+//  more on sixteen lists, so that the small parity cases pop from lists a few tiles long, move on and gather all the time)
+unsigned int pool_lists_for(size_t cap_tiles) {
+  size_t shard_min = kPoolShardMin;
+  if (const char* ev = std::getenv("TBNAV_POOL_SHARD_MIN")) { const long v = std::atol(ev); if (v >= kPoolShards) shard_min = (size_t)v; }
+  return cap_tiles >= shard_min ? (unsigned int)kPoolShards : 1u;
+}
 int pool_free_tiles(tbnav_rbpf* h, uint64_t* free_tiles) {
-  unsigned long long ctr[kPoolCtrStride * kPoolShards];
+  unsigned long long ctr[kPoolCtrWords];
   TBNAV_HIP(hipMemcpy(ctr, h->pool.ctr, sizeof ctr, hipMemcpyDeviceToHost));
   uint64_t f = 0;
-  for (unsigned int s = 0; s < h->pool.shards; ++s) f += ctr[s * kPoolCtrStride + 1] - ctr[s * kPoolCtrStride];
+  for (unsigned int s = 0; s < h->pool.shards + (h->pool.shards > 1u ? 1u : 0u); ++s) f += ctr[s * kPoolCtrStride + 1] - ctr[s * kPoolCtrStride];   // (+ the spill list)
   *free_tiles = f;
   return TBNAV_OK;
 }
@@ -803,13 +810,13 @@ int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf*
     if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
     if (cap < (size_t)N + 2 && e == hipSuccess) e = hipErrorOutOfMemory;  // not even one tile per particle
     h->pool.cap = (unsigned int)cap;
-    h->pool.shards = cap >= (size_t)kPoolShardMin ? (unsigned int)kPoolShards : 1u;   // free lists: rbpf_device.hpp
+    h->pool.shards = pool_lists_for(cap);
     h->pool.shard_cap = (unsigned int)((cap + h->pool.shards - 1) / h->pool.shards);
     A((void**)&h->pool.lo, sizeof(double) * kTileCells * cap);
     A((void**)&h->pool.bm, sizeof(unsigned int) * kTS * cap);
     A((void**)&h->pool.ref, sizeof(int) * cap);
-    A((void**)&h->pool.ring, sizeof(unsigned int) * (size_t)h->pool.shard_cap * h->pool.shards);
-    A((void**)&h->pool.ctr, sizeof(unsigned long long) * kPoolCtrStride * kPoolShards);
+    A((void**)&h->pool.ring, sizeof(unsigned int) * (size_t)h->pool.shard_cap * h->pool.shards * (h->pool.shards > 1u ? 2 : 1));   // (+ the spill list)
+    A((void**)&h->pool.ctr, sizeof(unsigned long long) * kPoolCtrWords);
   }
   if (e == hipSuccess) {
     double* t = h->d_trace;

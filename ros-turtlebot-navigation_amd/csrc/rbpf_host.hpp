@@ -255,6 +255,7 @@ int slam_impl(tbnav_rbpf* h, const float* scan, int n_beams, const double u[3], 
 int default_host_threads();
 int host_cpu_budget(double& quota_cpus);   // the affinity mask's CPUs; quota_cpus: the cgroup's CPU-time quota in CPUs (the same number without one)
 int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf** out);
+unsigned int pool_lists_for(size_t cap_tiles);   // 1 or kPoolShards (TBNAV_POOL_SHARD_MIN: a test hook, see rbpf.hip)
 int pool_free_tiles(tbnav_rbpf* h, uint64_t* free_tiles);   // summed over the pool's free lists (the caller has synchronised the stream)
 int batch_scratch(tbnav_rbpf* h, size_t n);
 BlobLayout blob_layout(const tbnav_rbpf* h, uint32_t n_tiles, bool has_codes);

@@ -24,20 +24,20 @@ int tbnav_rbpf_pool_selftest(uint32_t cap_tiles, int32_t rounds, int32_t callers
     return TBNAV_ERR_INVALID_ARG;
   TilePool P{};
   P.cap = cap_tiles;
-  P.shards = cap_tiles >= kPoolShardMin ? (unsigned int)kPoolShards : 1u;
+  P.shards = tbnav_rh::pool_lists_for(cap_tiles);
   P.shard_cap = (cap_tiles + P.shards - 1) / P.shards;
   unsigned int* d_ids = nullptr;
   const size_t n = (size_t)callers * tiles_each;
   auto free_tiles = [&](uint64_t* out) -> int {
-    unsigned long long ctr[kPoolCtrStride * kPoolShards];
+    unsigned long long ctr[kPoolCtrWords];
     TBNAV_HIP(hipMemcpy(ctr, P.ctr, sizeof ctr, hipMemcpyDeviceToHost));
     *out = 0;
-    for (unsigned int s = 0; s < P.shards; ++s) *out += ctr[s * kPoolCtrStride + 1] - ctr[s * kPoolCtrStride];
+    for (unsigned int s = 0; s < P.shards + (P.shards > 1u ? 1u : 0u); ++s) *out += ctr[s * kPoolCtrStride + 1] - ctr[s * kPoolCtrStride];
     return TBNAV_OK;
   };
   auto body = [&]() -> int {
-    TBNAV_HIP(hipMalloc((void**)&P.ring, sizeof(unsigned int) * (size_t)P.shard_cap * P.shards));
-    TBNAV_HIP(hipMalloc((void**)&P.ctr, sizeof(unsigned long long) * kPoolCtrStride * kPoolShards));
+    TBNAV_HIP(hipMalloc((void**)&P.ring, sizeof(unsigned int) * (size_t)P.shard_cap * P.shards * (P.shards > 1u ? 2 : 1)));
+    TBNAV_HIP(hipMalloc((void**)&P.ctr, sizeof(unsigned long long) * kPoolCtrWords));
     TBNAV_HIP(hipMalloc((void**)&P.ref, sizeof(int)));   // (the init kernel pins tile 0's count)
     TBNAV_HIP(hipMalloc((void**)&d_ids, sizeof(unsigned int) * n));
     hipLaunchKernelGGL(rbpf_pool_init, dim3(256), dim3(256), 0, 0, P);

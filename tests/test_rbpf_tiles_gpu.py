@@ -362,13 +362,24 @@ def test_free_lists_hand_every_tile_out_once_and_take_it_back(gpu_pkg, cap, call
     got = per[served].ravel()
     assert got.size == np.unique(got).size and got.min() >= 1 and got.max() < cap
     assert f_pop.value == cap - 1 - got.size and f_push.value == cap - 1
-    sharded = cap >= 16384
-    if sharded:
-        assert (per[served] % 16 == (per[served][:, :1] % 16)).all()   # one list per request: the ids of a request share a residue
-    n_served = int(served.sum())
-    if callers * each <= cap - 1 - (16 * (each - 1) if sharded else 0):
-        assert n_served == callers
-    else:   # short of empty by at most (each - 1) tiles per list
-        assert (cap - 1 - (16 if sharded else 1) * (each - 1)) // each <= n_served <= (cap - 1) // each
-    if not sharded and callers * each > cap - 1:
-        assert n_served == (cap - 1) // each
+    assert int(served.sum()) == min(callers, (cap - 1) // each)    # to the tile: a request no list can fill is gathered from all of them
+
+
+def test_free_lists_on_a_small_pool_gather_across_lists(gpu_pkg, monkeypatch):
+    """TBNAV_POOL_SHARD_MIN (a test hook) puts a pool of 200 tiles on sixteen lists of 12-13: no list ever holds a request of 14,
+    every caller takes the pool's lock and gathers its tiles through the spill list — same guarantees."""
+    import ctypes as C
+    from rtn_amd import capi
+    monkeypatch.setenv("TBNAV_POOL_SHARD_MIN", "32")
+    lib = capi.lib()
+    for cap, callers, each in ((200, 20, 14), (200, 10, 14), (1000, 40, 30), (1000, 90, 7)):
+        ids = np.zeros(callers * each, dtype=np.uint32)
+        f_pop, f_push = C.c_uint64(0), C.c_uint64(0)
+        assert lib.tbnav_rbpf_pool_selftest(cap, 3, callers, each, 0, ids.ctypes.data, C.addressof(f_pop), C.addressof(f_push)) == 0
+        per = ids.reshape(callers, each)
+        served = (per != 0).all(axis=1)
+        assert ((per != 0).any(axis=1) == served).all()
+        got = per[served].ravel()
+        assert got.size == np.unique(got).size and got.min() >= 1 and got.max() < cap
+        assert int(served.sum()) == min(callers, (cap - 1) // each), (cap, callers, each, int(served.sum()))
+        assert f_pop.value == cap - 1 - got.size and f_push.value == cap - 1
