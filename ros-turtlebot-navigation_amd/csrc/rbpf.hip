@@ -699,7 +699,7 @@ int pool_free_tiles(tbnav_rbpf* h, uint64_t* free_tiles) {
   unsigned long long ctr[kPoolCtrWords];
   TBNAV_HIP(hipMemcpy(ctr, h->pool.ctr, sizeof ctr, hipMemcpyDeviceToHost));
   uint64_t f = 0;
-  for (unsigned int s = 0; s < h->pool.shards + (h->pool.shards > 1u ? 1u : 0u); ++s) f += ctr[s * kPoolCtrStride + 1] - ctr[s * kPoolCtrStride];   // (+ the spill list)
+  for (unsigned int s = 0; s < h->pool.shards; ++s) f += ctr[s * kPoolCtrStride + 1] - ctr[s * kPoolCtrStride];
   *free_tiles = f;
   return TBNAV_OK;
 }
@@ -815,7 +815,7 @@ int create_impl(const tbnav_rbpf_params* P, uint64_t max_pool_bytes, tbnav_rbpf*
     A((void**)&h->pool.lo, sizeof(double) * kTileCells * cap);
     A((void**)&h->pool.bm, sizeof(unsigned int) * kTS * cap);
     A((void**)&h->pool.ref, sizeof(int) * cap);
-    A((void**)&h->pool.ring, sizeof(unsigned int) * (size_t)h->pool.shard_cap * h->pool.shards * (h->pool.shards > 1u ? 2 : 1));   // (+ the spill list)
+    A((void**)&h->pool.ring, sizeof(unsigned int) * (size_t)h->pool.shard_cap * h->pool.shards);
     A((void**)&h->pool.ctr, sizeof(unsigned long long) * kPoolCtrWords);
   }
   if (e == hipSuccess) {

@@ -96,21 +96,25 @@ constexpr int kTS = 32, kTSh = 5, kTileCells = kTS * kTS;
 // one word retires ~80 returning atomics per microsecond — a thousand co-resident workgroups waited up to 17 us for their ring
 // position, sixteen words 1.3 us (tools/atomic_queue_probe.hip).  A caller pops from the list its hint names and moves on to the
 // next when that one cannot supply the request; a tile goes back to the list of its id, so no list ever holds more than its share.
-// When NO list holds the n tiles of a request at once, the caller takes the pool's lock and moves free tiles one by one from the
-// lists into a seventeenth, the spill list, until that holds n (or the lists are empty: "exhausted" means what it says, to the
-// tile) — a path for pools run to their last few tiles, one caller at a time.  Pools below kPoolShardMin tiles keep ONE list.
+// A request is ONE fetch-add on a list's head: it is granted what lies between the position it got and the list's tail — all it
+// asked for, usually; a part, or nothing, when the list is short — and takes the rest from the next lists the same way, keeping
+// the ids where it has room for them (the map update in its LDS table of the box's tiles, an import in the slot's tile table).  A
+// head that was pushed past its tail is brought back TO the tail by the caller that did it (atomicMin: never below a position
+// that was granted — the add-then-subtract this replaces could hand a position out twice once failing on one list had become a
+// normal event).  So a launch whose requests fit the pool's free tiles never sees "exhausted", whatever the lists' lengths; one
+// that asks for more fails, possibly for several of its callers racing for the last tiles: the scan is an error as a whole.
+// Pools below kPoolShardMin tiles keep ONE list.
 constexpr int kPoolShards = 16, kPoolShardsLog2 = 4;
 constexpr unsigned int kPoolShardMin = 16384u;   // tiles (128 MB of log-odds)
 constexpr int kPoolCtrStride = 16;               // 64-bit words between two lists' counters
-constexpr int kPoolCtrWords = kPoolCtrStride * (kPoolShards + 2);   // the lists', the spill list's, the lock's line
+constexpr int kPoolCtrWords = kPoolCtrStride * kPoolShards;
 constexpr int kPoolPosShift = 40;                // a ring position as the callers hold it: list << 40 | tiles popped from it so far
 struct TilePool {
   double* lo;               // [cap][kTileCells], in-tile index = (i & 31) * 32 + (j & 31)
   unsigned int* bm;         // [cap][kTS] occupancy bits of the tile's cells (prob >= 0.90): row i & 31, bit j & 31
   int* ref;                 // [cap]
-  unsigned int* ring;       // [shards][shard_cap] free tile ids; sixteen lists: + the spill list's [shards * shard_cap]
-  unsigned long long* ctr;  // [list][kPoolCtrStride]: [0] head: tiles popped, [1] tail: tiles pushed (free = tail - head); list `shards` = the
-                            // spill list; [(kPoolShards + 1) * kPoolCtrStride] = the lock
+  unsigned int* ring;       // [shards][shard_cap] free tile ids
+  unsigned long long* ctr;  // [list][kPoolCtrStride]: [0] head: tiles popped, [1] tail: tiles pushed (free = tail - head)
   unsigned int cap;
   unsigned int shards;      // 1 or kPoolShards
   unsigned int shard_cap;   // ceil(cap / shards)
@@ -130,66 +134,39 @@ __device__ __forceinline__ void tile_push(const TilePool& P, unsigned int id) {
   const unsigned long long pos = atomicAdd(P.ctr + (size_t)s * kPoolCtrStride + 1, 1ull);
   *ring_slot(P, s, pos) = id;
 }
-// n tiles at once: ONE atomic on a list's head per caller (a workgroup that clones 15 tiles after a resample would otherwise
-// queue 15 times).  hint: which list to try first (callers that pop together pass consecutive numbers).  Returns the position of
-// the first tile (tile_at(P, pos + i) is the i-th), ~0 if the pool holds fewer than n free tiles.
-__device__ __noinline__ unsigned long long tile_pop_n_gather(const TilePool& P, unsigned int n) {
-  // no list holds n at once: under the pool's lock, free tiles move one by one into the spill list until it holds n.  Only lock
-  // holders touch the spill list's counters and entries; they are read and written past the (per-XCD) L2 — holders and the
-  // callers that read the entries afterwards run on any XCD.  Other callers keep popping from the lists meanwhile: a list that
-  // runs dry under the holder's hands is simply left.
-  unsigned int* const lock = reinterpret_cast<unsigned int*>(P.ctr + (size_t)(kPoolShards + 1) * kPoolCtrStride);
-  unsigned long long* const sc = P.ctr + (size_t)P.shards * kPoolCtrStride;
-  unsigned int* const spill = P.ring + (size_t)P.shards * P.shard_cap;
-  const unsigned long long spill_cap = (unsigned long long)P.shards * P.shard_cap;
-  unsigned long long got = ~0ull;
-  // (several lanes of one wave may be here — an import pops a run per lane: the holder's work sits INSIDE the loop that takes the
-  //  lock, so the lanes still spinning do not keep the wave from getting to the holder's unlock)
-  for (bool done = false; !done;) {
-    if (atomicCAS(lock, 0u, 1u) == 0u) {
-      __threadfence();
-      unsigned long long head = __hip_atomic_load(sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      unsigned long long tail = __hip_atomic_load(sc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      for (unsigned int s = 0; s < P.shards && tail - head < n; ++s) {
-        unsigned long long* const c = P.ctr + (size_t)s * kPoolCtrStride;
-        while (tail - head < n) {
-          const unsigned long long pos = atomicAdd(c, 1ull);
-          if (pos + 1ull > c[1]) { atomicAdd(c, ~0ull); break; }
-          __hip_atomic_store(spill + tail % spill_cap, *ring_slot(P, s, pos), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ++tail;
-        }
-      }
-      if (tail - head >= n) { got = ((unsigned long long)P.shards << kPoolPosShift) | head; head += n; }
-      __hip_atomic_store(sc, head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(sc + 1, tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __threadfence();
-      atomicExch(lock, 0u);
-      done = true;
-    } else __builtin_amdgcn_s_sleep(16);
-  }
-  return got;
-}
-__device__ __forceinline__ unsigned long long tile_pop_n(const TilePool& P, unsigned int n, unsigned int hint) {
-  for (unsigned int k = 0; k < P.shards; ++k) {
-    const unsigned int s = (hint + k) & (P.shards - 1u);
-    unsigned long long* const c = P.ctr + (size_t)s * kPoolCtrStride;
-    const unsigned long long pos = atomicAdd(c, (unsigned long long)n);
-    if (pos + n <= c[1]) return ((unsigned long long)s << kPoolPosShift) | pos;   // (no push can be in flight: see above)
-    atomicAdd(c, ~(unsigned long long)n + 1ull);
-  }
-  return P.shards == 1u ? ~0ull : tile_pop_n_gather(P, n);
-}
 __device__ __forceinline__ unsigned int tile_at(const TilePool& P, unsigned long long pos) {
-  const unsigned int s = (unsigned int)(pos >> kPoolPosShift);
-  const unsigned long long at = pos & ((1ull << kPoolPosShift) - 1ull);
-  if (s == P.shards && P.shards > 1u)   // the spill list
-    return __hip_atomic_load(P.ring + (size_t)P.shards * P.shard_cap + at % ((unsigned long long)P.shards * P.shard_cap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return *ring_slot(P, s, at);
+  return *ring_slot(P, (unsigned int)(pos >> kPoolPosShift), pos & ((1ull << kPoolPosShift) - 1ull));
 }
-__device__ __forceinline__ unsigned int tile_pop(const TilePool& P, unsigned int hint) {  // 0 = pool exhausted
-  const unsigned long long pos = tile_pop_n(P, 1u, hint);
-  return pos == ~0ull ? 0u : tile_at(P, pos);
+// `want` tiles from list `list`: ONE atomic on its head (a workgroup that clones 15 tiles after a resample would otherwise queue 15
+// times).  Granted: tile_at(P, pos + i), i < n — n == want unless the list is short (then n < want, possibly 0).
+struct TileGrant { unsigned long long pos; unsigned int n; };
+__device__ __forceinline__ TileGrant tile_grab(const TilePool& P, unsigned int want, unsigned int list) {
+  unsigned long long* const c = P.ctr + (size_t)list * kPoolCtrStride;
+  const unsigned long long pos = atomicAdd(c, (unsigned long long)want), tail = c[1];   // (no push can be in flight: see above)
+  const unsigned long long at = ((unsigned long long)list << kPoolPosShift) | pos;
+  if (pos + want <= tail) return TileGrant{at, want};
+  atomicMin(c, tail);   // the head went past the tail: back to it (nobody waits for this one)
+  return TileGrant{at, pos < tail ? (unsigned int)(tail - pos) : 0u};
 }
+// Tile by tile for a caller whose first grant was short: the grant in hand, then the next lists'.  want = how many the caller
+// still needs, this one included.  0 = the pool is exhausted.
+struct TileTaker { unsigned long long pos; unsigned int left, list, tried; };
+__device__ __forceinline__ TileTaker tile_taker(unsigned int hint) { return TileTaker{0ull, 0u, hint, 0u}; }
+__device__ __forceinline__ unsigned int tile_take(const TilePool& P, TileTaker& t, unsigned int want) {
+  while (t.left == 0u) {
+    if (t.tried >= P.shards) return 0u;
+    const TileGrant g = tile_grab(P, want, (t.list + t.tried) & (P.shards - 1u));
+    ++t.tried;
+    t.pos = g.pos; t.left = g.n;
+  }
+  --t.left;
+  return tile_at(P, t.pos++);
+}
+__device__ __forceinline__ unsigned int tile_pop(const TilePool& P, unsigned int hint) {  // one tile, from whichever list has one; 0 = pool exhausted
+  TileTaker t = tile_taker(hint);
+  return tile_take(P, t, 1u);
+}
+constexpr unsigned long long kPoolScattered = ~1ull;   // what a caller keeps in place of a position when its tiles came from several grants
 __device__ __forceinline__ bool tile_is_private(const TilePool& P, const unsigned int* __restrict__ table_p, int t) {
   const unsigned int id = table_p[t];
   return id != 0u && P.ref[id] == 1;

@@ -111,9 +111,10 @@ __global__ __launch_bounds__(256) void rbpf_release_slots(TilePool P, MapT M, co
 }
 // one workgroup per imported particle (its slot was released by the launch before).  Its tiles are popped in runs of 64 (more for
 // maps of more than 16 384 tiles: at most 256 runs), one thread a run, each from the free list its number names first
-// (rbpf_device.hpp: a list supplies a run or passes; 64 is what the map update asks of one at most).  If a run finds no list
-// long enough the particle is not installed: the tiles the other runs took are noted as SHED by the slot — the next resample, or
-// the slot's release, hands them back (pops and pushes never share a launch) — and the slot keeps the empty map.
+// (rbpf_device.hpp: a list supplies a run or passes).  A run no list can supply is popped tile by tile from whichever list has
+// any, the ids going straight into the slot's table.  If the pool runs out the particle is not installed: the tiles taken so far
+// are noted as SHED by the slot — the next resample, or the slot's release, hands them back (pops and pushes never share a
+// launch) — and the slot keeps the empty map.
 __global__ __launch_bounds__(256) void rbpf_unpack_batch(TilePool P, MapT M, double* __restrict__ pose, double* __restrict__ prev,
                                                          double* __restrict__ weight, int* __restrict__ trow, int* __restrict__ nocc,
                                                          int* __restrict__ fstate, uint16_t* __restrict__ codes, size_t G,
@@ -128,20 +129,35 @@ __global__ __launch_bounds__(256) void rbpf_unpack_batch(TilePool P, MapT M, dou
   int rsh = 6;                                                   // log2 of a run's length
   while (((hd.n_tiles + (1u << rsh) - 1u) >> rsh) > 256u) ++rsh;
   const unsigned int run = 1u << rsh, n_runs = (hd.n_tiles + run - 1u) >> rsh;
+  const unsigned int* tidx = reinterpret_cast<const unsigned int*>(b + L.tidx);
+  unsigned int* const tab = M.table + (size_t)slot * M.TT;
   if (tid == 0) s_fail = 0;
   __syncthreads();
   if ((unsigned int)tid < n_runs) {
     const unsigned int first = (unsigned int)tid << rsh, n = hd.n_tiles - first < run ? hd.n_tiles - first : run;
-    const unsigned long long pos = tile_pop_n(P, n, blockIdx.x * 5u + (unsigned int)tid);
+    const unsigned int list = (blockIdx.x * 5u + (unsigned int)tid) & (P.shards - 1u);
+    const TileGrant g = tile_grab(P, n, list);
+    unsigned long long pos = g.pos;
+    if (g.n != n) {   // the list was short: its grant and the next lists', tile by tile; the ids wait in the table (the entries are zero: the slot was released)
+      pos = kPoolScattered;
+      TileTaker tk{g.pos, g.n, list, 1u};
+      for (unsigned int j = first; j < first + n; ++j) {
+        const unsigned int id = tile_take(P, tk, first + n - j);
+        if (!id) { s_fail = 1; break; }
+        tab[tidx[j]] = id;
+      }
+    }
     sbase[tid] = pos;
-    if (pos == ~0ull) s_fail = 1;
   }
   __syncthreads();
-  const unsigned int* tidx = reinterpret_cast<const unsigned int*>(b + L.tidx);
-  auto nth = [&](size_t j) { return tile_at(P, sbase[j >> rsh] + (j & (run - 1u))); };
+  auto nth = [&](size_t j) { const unsigned long long sb = sbase[j >> rsh]; return sb == kPoolScattered ? tab[tidx[j]] : tile_at(P, sb + (j & (run - 1u))); };
   if (s_fail) {  // pool exhausted
-    for (unsigned int j = tid; j < hd.n_tiles; j += 256)
-      if (sbase[j >> rsh] != ~0ull) { const unsigned int id = nth(j); P.ref[id] = 1; M.shed[(size_t)slot * M.TT + tidx[j]] = id; }
+    for (unsigned int j = tid; j < hd.n_tiles; j += 256) {
+      const unsigned long long sb = sbase[j >> rsh];
+      const unsigned int id = nth(j);     // (a scattered run that stopped half way: zero from there on)
+      if (sb == kPoolScattered) tab[tidx[j]] = 0u;
+      if (id) { P.ref[id] = 1; M.shed[(size_t)slot * M.TT + tidx[j]] = id; }
+    }
     if (tid == 0) atomicOr(&err[3], 8);
     return;
   }
@@ -150,10 +166,11 @@ __global__ __launch_bounds__(256) void rbpf_unpack_batch(TilePool P, MapT M, dou
     reinterpret_cast<double2*>(P.lo + (size_t)nth(i / (kTileCells / 2)) * kTileCells)[i % (kTileCells / 2)] = src[i];
   const unsigned int* sbm = reinterpret_cast<const unsigned int*>(b + L.tile_bm);
   for (size_t i = tid; i < (size_t)hd.n_tiles * kTS; i += 256) P.bm[(size_t)nth(i / kTS) * kTS + (i % kTS)] = sbm[i];
+  __syncthreads();   // (a scattered run's ids are read from the table above: every reader is through before the entries are rewritten)
   for (unsigned int j = tid; j < hd.n_tiles; j += 256) {
     const unsigned int id = nth(j);
     P.ref[id] = 1;
-    M.table[(size_t)slot * M.TT + tidx[j]] = id;
+    tab[tidx[j]] = id;
   }
   const int* str = reinterpret_cast<const int*>(b + L.trow);
   for (int r = tid; r < M.TW; r += 256) trow[(size_t)slot * M.TW + r] = str[r];

@@ -316,16 +316,23 @@ __global__ __launch_bounds__(kWave) void rbpf_raycast(ScanC c, TilePool P, MapT 
       }
     }
     if (need) {
-      unsigned long long base = 0ull;
-      if (lane == 0) base = tile_pop_n(P, (unsigned int)need, blockIdx.x);
-      base = ((unsigned long long)__shfl((int)(base >> 32), 0, kWave) << 32) | (unsigned int)__shfl((int)base, 0, kWave);
-      if (base == ~0ull) { if (lane == 0) atomicOr(&err[3], 8); return; }  // tile pool exhausted: nothing has been written
+      // one request for all of them; a list that is short grants what it has and the next lists supply the rest (lane 0 holds the
+      // grants).  A tile cloned before the pool runs out stays the particle's (same values as the tile it left): no log-odds has
+      // been written either way
+      TileTaker tk = tile_taker(blockIdx.x);
+      int left = need;
       for (int w = 0; w < tword; ++w) {
         unsigned int m = tbits[w];
         while (m) {
           const int t = w * 32 + __ffs((int)m) - 1;
           m &= m - 1;
-          if (!tile_is_private(P, tab, t)) { tile_clone_into(P, tab, shed, t, tile_at(P, base), lane); ++base; }
+          if (tile_is_private(P, tab, t)) continue;
+          unsigned int nid = 0u;
+          if (lane == 0) nid = tile_take(P, tk, (unsigned int)left);
+          nid = (unsigned int)__shfl((int)nid, 0, kWave);
+          if (nid == 0u) { if (lane == 0) atomicOr(&err[3], 8); return; }  // tile pool exhausted
+          tile_clone_into(P, tab, shed, t, nid, lane);
+          --left;
         }
       }
     }
@@ -789,7 +796,36 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
     const unsigned long long need_m = __ballot(lane < mtn && mt_touch[lane < mtn ? lane : 0]) &
                                       ~((unsigned long long)mt_priv_bits[0] | ((unsigned long long)mt_priv_bits[1] << 32));
     if (need_m) {  // workgroup-uniform
-      if (tid == 0) { need_base = tile_pop_n(P, (unsigned int)__popcll(need_m), blockIdx.x); if (need_base == ~0ull) bad = 1; }
+      if (tid == 0) {
+        const unsigned int cnt = (unsigned int)__popcll(need_m);
+        const TileGrant g = tile_grab(P, cnt, blockIdx.x & (P.shards - 1u));
+        unsigned long long nb = g.pos;
+        if (g.n != cnt) {
+          // the list was short: what it granted and the next lists' grants, tile by tile, the ids parked in mt_id (the clones below put
+          // them there anyway; what they read — the tile's old id — is in mt_src and in the table).  If the pool runs out half way the
+          // tiles taken are noted as shed by their entries (an entry that is not private has shed nothing since the last resample):
+          // the next resample hands them back, nothing has been written.
+          nb = kPoolScattered;
+          TileTaker tk{g.pos, g.n, blockIdx.x, 1u};
+          unsigned long long m = need_m, taken = 0ull;
+          unsigned int left = cnt;
+          while (m) {
+            const int q = __ffsll((long long)m) - 1;
+            m &= m - 1ull;
+            const unsigned int nid = tile_take(P, tk, left);
+            if (nid == 0u) { nb = ~0ull; break; }
+            mt_id[q] = nid; taken |= 1ull << q; --left;
+          }
+          if (nb == ~0ull) while (taken) {
+            const int q = __ffsll((long long)taken) - 1;
+            taken &= taken - 1ull;
+            const int qi = udiv16(q, mty_m), qj = q - qi * mty;
+            P.ref[mt_id[q]] = 1; shed[(tx0 + qi) * M.TW + (ty0 + qj)] = mt_id[q];
+          }
+        }
+        need_base = nb;
+        if (nb == ~0ull) bad = 1;
+      }
       __syncthreads();
       TRACE_W(15);
       if (bad) { if (tid == 0) atomicOr(&err[3], 8); return; }  // tile pool exhausted (nothing has been written if this is the first band)
@@ -804,7 +840,7 @@ __global__ __launch_bounds__(NT, WPS) void rbpf_raycast_box(ScanC c, TilePool P,
         int ln = lane;
         asm volatile("" : "+v"(ln));
         const int slot_q = __popcll(need_m & ((1ull << q) - 1ull));   // (every wave holds the same ballot: no table of slots in LDS)
-        const unsigned int nid = tile_at(P, nb + (unsigned long long)slot_q);
+        const unsigned int nid = nb == kPoolScattered ? mt_id[q] : tile_at(P, nb + (unsigned long long)slot_q);
         // The fresh tile takes from the shared one ONLY what this band's update will not write: the pairs of the tile outside the
         // band and the band's untouched pairs (and the occupancy bits).  A touched pair is read from the shared tile (mt_src) and
         // written to the new one by the passes below anyway — copying it first moved every byte of the tile twice: the scan that

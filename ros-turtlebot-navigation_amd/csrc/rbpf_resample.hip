@@ -21,7 +21,7 @@ __global__ void rbpf_pool_init(TilePool P) {
   const unsigned int sh = P.shards == 1u ? 0u : (unsigned int)kPoolShardsLog2;
   for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.cap; i += gridDim.x * blockDim.x)
     P.ring[(size_t)(i & (P.shards - 1u)) * P.shard_cap + (i >> sh)] = i;
-  if (blockIdx.x == 0 && threadIdx.x < kPoolShards + 2) {   // every line of the counters: the lists', the (empty) spill list's, the lock's
+  if (blockIdx.x == 0 && threadIdx.x < kPoolShards) {   // every line of the counters (an unused list: empty)
     const unsigned int s = threadIdx.x;
     const bool list = s < P.shards;
     P.ctr[(size_t)s * kPoolCtrStride] = list && s == 0u ? 1ull : 0ull;

@@ -1,6 +1,8 @@
 """GPU tests of the tiled copy-on-write maps: a resample copies tile tables, the next scan
 clones only the tiles it writes, tiles nobody names return to the pool — and the log-odds stay the reference's bits
 (particle_filter.cpp:468-500 deep copies, grid_mapper.cpp:140-178 updates)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -360,14 +362,19 @@ def test_free_lists_hand_every_tile_out_once_and_take_it_back(gpu_pkg, cap, call
     served = (per != 0).all(axis=1)
     assert ((per != 0).any(axis=1) == served).all()                 # all of a caller's tiles or none
     got = per[served].ravel()
-    assert got.size == np.unique(got).size and got.min() >= 1 and got.max() < cap
+    assert got.size == np.unique(got).size and (got.size == 0 or (got.min() >= 1 and got.max() < cap))
     assert f_pop.value == cap - 1 - got.size and f_push.value == cap - 1
-    assert int(served.sum()) == min(callers, (cap - 1) // each)    # to the tile: a request no list can fill is gathered from all of them
+    n_served, fits = int(served.sum()), callers * each <= cap - 1
+    # a request no list can fill at once is popped tile by tile from all of them: whatever fits is served; beyond that the callers
+    # that run dry half way hold tiles while they fail (the hook pushes them back before it counts), so the count is a bound
+    assert n_served == callers if fits else n_served <= (cap - 1) // each
+    if cap < 16384 and not fits and not os.environ.get("TBNAV_POOL_SHARD_MIN"):
+        assert n_served == (cap - 1) // each                        # one list: to the tile
 
 
-def test_free_lists_on_a_small_pool_gather_across_lists(gpu_pkg, monkeypatch):
+def test_free_lists_on_a_small_pool_pop_tile_by_tile(gpu_pkg, monkeypatch):
     """TBNAV_POOL_SHARD_MIN (a test hook) puts a pool of 200 tiles on sixteen lists of 12-13: no list ever holds a request of 14,
-    every caller takes the pool's lock and gathers its tiles through the spill list — same guarantees."""
+    every caller is granted what its list has and takes the rest from the next lists — same guarantees."""
     import ctypes as C
     from rtn_amd import capi
     monkeypatch.setenv("TBNAV_POOL_SHARD_MIN", "32")
@@ -380,6 +387,9 @@ def test_free_lists_on_a_small_pool_gather_across_lists(gpu_pkg, monkeypatch):
         served = (per != 0).all(axis=1)
         assert ((per != 0).any(axis=1) == served).all()
         got = per[served].ravel()
-        assert got.size == np.unique(got).size and got.min() >= 1 and got.max() < cap
-        assert int(served.sum()) == min(callers, (cap - 1) // each), (cap, callers, each, int(served.sum()))
+        assert got.size == np.unique(got).size and (got.size == 0 or (got.min() >= 1 and got.max() < cap))
+        n_served = int(served.sum())
+        # (asked for more than the pool holds, the callers race for the last tiles one by one and may ALL run dry half way: the scan
+        #  that does this fails as a whole anyway; asked for no more than it holds, nobody fails)
+        assert n_served == callers if callers * each <= cap - 1 else n_served <= (cap - 1) // each, (cap, callers, each, n_served)
         assert f_pop.value == cap - 1 - got.size and f_push.value == cap - 1
