@@ -96,8 +96,8 @@ int tbnav_rbpf_create(const tbnav_rbpf_params* params, tbnav_rbpf** out);
  * ever need if that fits in half of the device memory free at create time, else that half).  A scan that needs a
  * tile when none is free returns TBNAV_ERR_POOL_EXHAUSTED and leaves the maps of the particles concerned unchanged.
  * (Pools of 16 384 tiles — 128 MB — or more keep their free tiles in sixteen lists; a particle takes the tiles one map update
- * makes private from one of them, or one by one from all of them when none holds that many: a scan whose particles need no
- * more tiles than are free never fails, whatever the lists' lengths.) */
+ * makes private from one of them, and what that list lacks from the next ones: a scan whose particles need no more tiles
+ * than are free never fails, whatever the lists' lengths.) */
 int tbnav_rbpf_create_pool(const tbnav_rbpf_params* params, uint64_t max_pool_bytes, tbnav_rbpf** out);
 void tbnav_rbpf_destroy(tbnav_rbpf* h);
 /* Tile pool occupancy: tiles the pool holds, tiles free now, bytes of log-odds per tile (any pointer may be NULL). */
