@@ -393,3 +393,43 @@ def test_free_lists_on_a_small_pool_pop_tile_by_tile(gpu_pkg, monkeypatch):
         #  that does this fails as a whole anyway; asked for no more than it holds, nobody fails)
         assert n_served == callers if callers * each <= cap - 1 else n_served <= (cap - 1) // each, (cap, callers, each, n_served)
         assert f_pop.value == cap - 1 - got.size and f_push.value == cap - 1
+
+
+@pytest.mark.parametrize("N", [48, 300])
+def test_no_tile_leaks_or_is_freed_twice_over_a_long_run(gpu_pkg, N):
+    """The pool's whole life cycle, counted: 36 scans of a moving robot, a resampling with random weights every third scan (tables
+    copied, counts adjusted, dead particles' tiles and shed notes pushed back to the free lists, the next scan's clones popped from
+    them) — then every particle is made a copy of ONE, and the tiles in use must be exactly the tiles of that particle's map that
+    hold a non-zero cell (a tile is taken only when a cell of it is written, and no sum of l_occ's and l_free's is zero).  A tile
+    leaked anywhere leaves the count too high, one freed twice (or handed to two owners) too low or the maps wrong.
+    N = 300: sixteen free lists (the pool holds 101 401 tiles); N = 48: one."""
+    k, n_scans = 4, 36
+    pf = _dev(gpu_pkg, N=N, k=k, map_min=-10.0, map_max=10.0)
+    cap, free0, _ = pf.poolStats()
+    assert free0 == cap
+    steps, poses = rc.trajectory(n_scans, inc=(0.06, 0.05, 0.04))
+    rng = np.random.default_rng(17)
+    scans = [orc.room_scan(poses[s], walls=rc.ROOM_SURVEY, rng=rng) for s in range(n_scans)]
+    resamples = 0
+    for s, (prev, cur, t_icp, u) in enumerate(steps):
+        if s % 3 == 2:
+            w = rng.dirichlet(np.full(N, 0.05)) + 1e-9            # a few heavy particles, most of the rest die
+            pf.setParticles(w=w / w.sum())
+        st = pf.SLAM(scans[s], u, cur, prev, True, t_icp, orc.normal_stream(900 + s, pf.numNormals(True), 0.0, 1.0))
+        assert st.status == 0
+        resamples += int(st.resampled)
+        used = cap - pf.poolStats()[1]
+        assert 0 < used <= cap
+    assert resamples >= 8
+    w = np.full(N, 1e-12); w[N - 1] = 1.0      # (the LAST particle: the selection's walk past the end is clamped to it, particle_filter.cpp:483-491)
+    pf.setParticles(w=w / w.sum())
+    prev, cur, t_icp, u = steps[-1]
+    st = pf.SLAM(scans[-1], u, cur, prev, True, t_icp, orc.normal_stream(999, pf.numNormals(True), 0.0, 1.0))
+    assert st.resampled == 1 and set(pf.trace()["resample_idx"].tolist()) == {N - 1}
+    lo = pf.logOdds(0)
+    assert np.array_equal(lo, pf.logOdds(N - 1))
+    G = pf.xsize
+    pad = (-G) % 32
+    tiles = np.pad(np.asarray(lo).reshape(G, G) != 0.0, ((0, pad), (0, pad))).reshape((G + pad) // 32, 32, (G + pad) // 32, 32).any(axis=(1, 3))
+    assert cap - pf.poolStats()[1] == int(tiles.sum())
+    pf.close()
